@@ -1,0 +1,51 @@
+"""Loads libexon_gpu.so (in-tree build) and binds the C-ABI.  Fails loudly when it is missing."""
+import ctypes as C
+import os
+
+from . import abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libexon_gpu.so")
+
+
+class ExgError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"libexon_gpu error {code}: {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen the HIP library; raises ExgError if it has not been built (no fallback exists)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise ExgError(abi.EXG_E_NO_DEVICE, f"{p} not found: run `python __graft_entry__.py build` "
+                       "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    l = C.CDLL(p)
+    for name, (res, args) in abi.SIGNATURES.items():
+        fn = getattr(l, name)
+        fn.restype = res
+        fn.argtypes = args
+    if l.exg_abi_version() != abi.EXG_ABI_VERSION:
+        raise ExgError(abi.EXG_E_INVALID_ARG, "ABI version mismatch between abi.py and libexon_gpu.so")
+    if path is None:
+        _lib = l
+    return l
+
+
+class _LazyLib:
+    def __getattr__(self, name):
+        return getattr(load_library(), name)
+
+
+lib = _LazyLib()
+
+
+def check(rc):
+    if rc != 0:
+        raise ExgError(rc, load_library().exg_last_error_message().decode("utf-8", "replace"))

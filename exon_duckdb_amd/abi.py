@@ -1,0 +1,82 @@
+"""ctypes mirror of include/exon_gpu.h (keep in sync with the header; tests check sizes)."""
+import ctypes as C
+
+EXG_ABI_VERSION = 1
+EXG_VECTOR_SIZE = 2048
+
+EXG_OK = 0
+EXG_E_INVALID_ARG, EXG_E_NO_DEVICE, EXG_E_HIP, EXG_E_IO = -1, -2, -3, -4
+EXG_E_UNSUPPORTED, EXG_E_PARSE, EXG_E_CAPACITY, EXG_E_NOMEM = -5, -6, -7, -8
+
+EXG_PE_NONE = 0
+EXG_PE_FASTQ_NAME_PREFIX = 1
+EXG_PE_FASTQ_PLUS_PREFIX = 2
+EXG_PE_UNEXPECTED_EOF = 3
+EXG_PE_INVALID_UTF8 = 4
+EXG_PE_FASTA_MISSING_PREFIX = 5
+EXG_PE_FASTA_MISSING_NAME = 6
+EXG_PE_FASTA_EMPTY_DEF = 7
+EXG_PE_VCF_MISSING_FIELD = 8
+EXG_PE_VCF_BAD_POS = 9
+EXG_PE_VCF_BAD_QUAL = 10
+EXG_PE_VCF_NO_HEADER = 11
+EXG_PE_FIELD_TOO_LONG = 12
+
+EXG_FMT_FASTA, EXG_FMT_FASTQ, EXG_FMT_VCF = 1, 2, 3
+EXG_F_BOF, EXG_F_EOF = 1, 2
+EXG_RF_NON_ASCII, EXG_RF_HEAD_UNRESOLVED, EXG_RF_FALLBACK, EXG_RF_CAPACITY, EXG_RF_INDEX_OVERFLOW = 1, 2, 4, 8, 16
+EXG_ALGO_AUTO, EXG_ALGO_MULTIPASS, EXG_ALGO_FUSED = 0, 1, 2
+
+EXG_SYNTH_FASTQ_SEED = 0xE0A5EED0001
+EXG_SYNTH_VCF_SEED = 0xE0A5EED0002
+EXG_SYNTH_FASTQ_RECORD_BYTES = 332
+
+
+class ScanResult(C.Structure):
+    _fields_ = [
+        ("n_records", C.c_uint64),
+        ("n_lines", C.c_uint64),
+        ("consumed_bytes", C.c_uint64),
+        ("error_offset", C.c_uint64),
+        ("error_record", C.c_uint64),
+        ("error_code", C.c_uint32),
+        ("flags", C.c_uint32),
+        ("payload_bytes", C.c_uint64),
+        ("reserved", C.c_uint64),
+    ]
+
+
+class FastqScanArgs(C.Structure):
+    _fields_ = [
+        ("d_input", C.c_void_p),
+        ("n_bytes", C.c_uint64),
+        ("lead", C.c_uint64),
+        ("first_line_index", C.c_uint64),
+        ("payload_base", C.c_uint64),
+        ("flags", C.c_uint32),
+        ("algo", C.c_uint32),
+        ("d_name", C.c_void_p),
+        ("d_description", C.c_void_p),
+        ("d_sequence", C.c_void_p),
+        ("d_quality", C.c_void_p),
+        ("d_description_validity", C.c_void_p),
+        ("capacity_records", C.c_uint64),
+        ("d_workspace", C.c_void_p),
+        ("workspace_bytes", C.c_uint64),
+        ("d_result", C.c_void_p),
+        ("stream", C.c_void_p),
+    ]
+
+
+# every symbol include/exon_gpu.h declares -> (restype, argtypes); None = not yet bound by name only
+SIGNATURES = {
+    "exg_abi_version": (C.c_int, []),
+    "exg_device_count": (C.c_int, []),
+    "exg_last_error_message": (C.c_char_p, []),
+    "exg_parse_error_string": (C.c_char_p, [C.c_uint32]),
+    "exg_scan_workspace_bytes": (C.c_uint64, [C.c_int, C.c_uint64]),
+    "exg_fastq_scan": (C.c_int, [C.POINTER(FastqScanArgs)]),
+    "exg_fetch_result": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(ScanResult)]),
+    "exg_count_newlines": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "exg_synth_fastq": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
+}

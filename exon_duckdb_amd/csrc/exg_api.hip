@@ -1,0 +1,123 @@
+// exg_api.hip — C-ABI entry points of the device level (include/exon_gpu.h, layer 1) and the
+// library plumbing (errors, device probe, result fetch).
+#include <stdarg.h>
+#include <string.h>
+
+#include "exg_fastq.hpp"
+
+namespace exg {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+}  // namespace exg
+
+using namespace exg;
+
+extern "C" int exg_abi_version(void) { return EXG_ABI_VERSION; }
+
+extern "C" const char *exg_last_error_message(void) { return g_err; }
+
+extern "C" int exg_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device visible (%s): libexon_gpu has no CPU fallback", hipGetErrorString(e));
+        return EXG_E_NO_DEVICE;
+    }
+    return n;
+}
+
+extern "C" const char *exg_parse_error_string(uint32_t code) {
+    switch (code) {
+        case EXG_PE_NONE: return "ok";
+        case EXG_PE_FASTQ_NAME_PREFIX: return "invalid name prefix";           // noodles-fastq InvalidData
+        case EXG_PE_FASTQ_PLUS_PREFIX: return "invalid description prefix";    // noodles-fastq InvalidData
+        case EXG_PE_UNEXPECTED_EOF: return "unexpected end of file";
+        case EXG_PE_INVALID_UTF8: return "invalid utf-8";
+        case EXG_PE_FASTA_MISSING_PREFIX: return "missing prefix ('>')";
+        case EXG_PE_FASTA_MISSING_NAME: return "missing name";
+        case EXG_PE_FASTA_EMPTY_DEF: return "empty input";
+        case EXG_PE_VCF_MISSING_FIELD: return "missing field";
+        case EXG_PE_VCF_BAD_POS: return "invalid position";
+        case EXG_PE_VCF_BAD_QUAL: return "invalid quality score";
+        case EXG_PE_VCF_NO_HEADER: return "missing header";
+        case EXG_PE_FIELD_TOO_LONG: return "field longer than 4 GiB";
+        default: return "unknown parse error";
+    }
+}
+
+extern "C" uint64_t exg_scan_workspace_bytes(int format, uint64_t n_bytes) {
+    (void)format;  // one layout serves the three formats
+    return fastq_ws_layout(n_bytes, 0).total_bytes;
+}
+
+extern "C" int exg_fetch_result(const exg_scan_result *d_result, void *stream, exg_scan_result *out) {
+    if (!d_result || !out) {
+        set_error("exg_fetch_result: null pointer");
+        return EXG_E_INVALID_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    EXG_HIP_CHECK(hipMemcpyAsync(out, d_result, sizeof(*out), hipMemcpyDeviceToHost, s));
+    EXG_HIP_CHECK(hipStreamSynchronize(s));
+    return EXG_OK;
+}
+
+extern "C" int exg_fastq_scan(const exg_fastq_scan_args *a) {
+    if (!a || !a->d_result || !a->d_workspace || (a->n_bytes && !a->d_input) || ((uintptr_t)a->d_input & 15) ||
+        a->lead > a->n_bytes) {
+        set_error("exg_fastq_scan: bad arguments (null pointer, unaligned input or lead > n_bytes)");
+        return EXG_E_INVALID_ARG;
+    }
+    if (a->capacity_records &&
+        (!a->d_name || !a->d_description || !a->d_sequence || !a->d_quality || !a->d_description_validity)) {
+        set_error("exg_fastq_scan: null output column");
+        return EXG_E_INVALID_ARG;
+    }
+    FastqWsLayout l = fastq_ws_layout(a->n_bytes, a->workspace_bytes);
+    if (a->workspace_bytes < fastq_ws_layout(a->n_bytes, 0).off_nl_pos + 64) {
+        set_error("exg_fastq_scan: workspace too small (%llu bytes, need %llu)",
+                  (unsigned long long)a->workspace_bytes,
+                  (unsigned long long)exg_scan_workspace_bytes(EXG_FMT_FASTQ, a->n_bytes));
+        return EXG_E_INVALID_ARG;
+    }
+    FastqDev dev;
+    dev.d_in = (const uint8_t *)a->d_input;
+    dev.n_bytes = a->n_bytes;
+    dev.lead = a->lead;
+    dev.first_line_index = a->first_line_index;
+    dev.payload_base = a->payload_base;
+    dev.flags = a->flags;
+    dev.pad = 0;
+    dev.d_name = a->d_name;
+    dev.d_desc = a->d_description;
+    dev.d_seq = a->d_sequence;
+    dev.d_qual = a->d_quality;
+    dev.d_desc_valid = a->d_description_validity;
+    dev.capacity = a->capacity_records;
+    hipStream_t stream = (hipStream_t)a->stream;
+    uint8_t *ws = (uint8_t *)a->d_workspace;
+    if (a->capacity_records)
+        EXG_HIP_CHECK(hipMemsetAsync(a->d_description_validity, 0, (size_t)((a->capacity_records + 63) / 64) * 8, stream));
+    switch (a->algo) {
+        case EXG_ALGO_MULTIPASS:
+            return run_fastq_multipass(a, dev, ws, l, stream, false);
+        case EXG_ALGO_FUSED:
+            return run_fastq_fused(a, dev, ws, l, stream);
+        case EXG_ALGO_AUTO: {
+            int rc = run_fastq_fused(a, dev, ws, l, stream);
+            if (rc) return rc;
+            // general kernels, gated on the device by the fused kernel's overflow word
+            return run_fastq_multipass(a, dev, ws, l, stream, true);
+        }
+        default:
+            set_error("exg_fastq_scan: unknown algo %u", a->algo);
+            return EXG_E_INVALID_ARG;
+    }
+}

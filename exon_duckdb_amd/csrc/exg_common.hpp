@@ -1,0 +1,86 @@
+// exg_common.hpp — shared host/device helpers of libexon_gpu.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/exon_gpu.h"
+
+namespace exg {
+
+// thread-local error text returned by exg_last_error_message()
+void set_error(const char *fmt, ...);
+
+#define EXG_HIP_CHECK(expr)                                                                   \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            ::exg::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                             __LINE__);                                                       \
+            return EXG_E_HIP;                                                                 \
+        }                                                                                     \
+    } while (0)
+
+static_assert(sizeof(exg_string_t) == 16, "duckdb::string_t is 16 bytes");
+static_assert(sizeof(exg_scan_result) == 64, "exg_scan_result is 64 bytes");
+
+// ---- device helpers -----------------------------------------------------------
+#if defined(__HIPCC__)
+
+// SWAR byte match: 0x80 in every byte of w equal to the byte replicated in pat4. Exact (no
+// borrow false positives): y keeps bit 7 clear only where all of x's low 7 bits are 0.
+__device__ __forceinline__ uint32_t match4(uint32_t w, uint32_t pat4) {
+    uint32_t x = w ^ pat4;
+    uint32_t y = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    return ~(y | x | 0x7F7F7F7Fu);
+}
+
+// bits 7,15,23,31 -> 4-bit nibble (multiply gathers them at 28..31, no carries collide)
+__device__ __forceinline__ uint32_t nib4(uint32_t m) { return (m * 0x00204081u) >> 28; }
+
+// 16-bit match mask of one 16-byte chunk
+__device__ __forceinline__ uint32_t match16(uint4 v, uint32_t pat4) {
+    return nib4(match4(v.x, pat4)) | (nib4(match4(v.y, pat4)) << 4) | (nib4(match4(v.z, pat4)) << 8) |
+           (nib4(match4(v.w, pat4)) << 12);
+}
+
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+
+// inclusive wave64 prefix sum
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(v, d, 64);
+        if ((int)lane_id() >= d) v += o;
+    }
+    return v;
+}
+
+// Build a duckdb::string_t for the field d_in[s, s+len) reading bytes from global memory.
+__device__ __forceinline__ uint4 make_string_global(const uint8_t *d_in, uint64_t s, uint64_t len,
+                                                     uint64_t payload_base) {
+    uint4 r;
+    r.x = (uint32_t)len;
+    r.y = r.z = r.w = 0;
+    if (len <= EXG_INLINE_LENGTH) {
+        uint32_t w[3] = {0, 0, 0};
+        for (uint32_t i = 0; i < (uint32_t)len; i++) w[i >> 2] |= (uint32_t)d_in[s + i] << (8 * (i & 3));
+        r.y = w[0];
+        r.z = w[1];
+        r.w = w[2];
+    } else {
+        r.y = (uint32_t)d_in[s] | ((uint32_t)d_in[s + 1] << 8) | ((uint32_t)d_in[s + 2] << 16) |
+              ((uint32_t)d_in[s + 3] << 24);
+        uint64_t p = payload_base + s;
+        r.z = (uint32_t)p;
+        r.w = (uint32_t)(p >> 32);
+    }
+    return r;
+}
+
+#endif  // __HIPCC__
+
+// error word packing: (record index << 8) | code, atomicMin picks the first failing record.
+static constexpr uint64_t kNoError = ~0ull;
+
+}  // namespace exg

@@ -1,0 +1,76 @@
+// exg_fastq_ws.hpp — device workspace layout shared by the FASTQ kernels.
+#pragma once
+#include "exg_common.hpp"
+
+namespace exg {
+
+// Multipass tiles: 256 threads x 16 B x 4 iterations.
+static constexpr uint32_t kMpThreads = 256;
+static constexpr uint32_t kMpIterBytes = kMpThreads * 16;  // 4 KiB
+static constexpr uint32_t kMpIters = 4;
+static constexpr uint32_t kMpTileBytes = kMpIterBytes * kMpIters;  // 16 KiB
+
+// Fused kernel tile (see exg_fastq_fused.hip)
+static constexpr uint32_t kFusedTileBytes = 16384;
+static constexpr uint32_t kFusedWindow = 1024;  // bytes before the tile staged in LDS for straddling records
+
+struct alignas(256) ScanWsHeader {
+    unsigned long long total_nl;     // real '\n' in [0, n_bytes)
+    unsigned long long total_lines;  // + virtual lines appended at EOF
+    unsigned long long halo_nl;      // '\n' at offsets < lead
+    unsigned long long err_word;     // (output record index << 8) | EXG_PE_*, atomicMin; ~0 = none
+    unsigned long long n_unresolved; // owned records whose first line starts before d_input[0]
+    unsigned int flags;              // EXG_RF_*
+    unsigned int ticket;             // fused kernel: dynamic tile counter
+    unsigned int epoch;              // fused kernel: tag of the current launch in the tile descriptors
+    unsigned int overflow;           // fused kernel: a record did not fit the LDS window
+    unsigned long long lines_cap;    // capacity of nl_pos
+    unsigned long long err_off;      // atomicMin: start offset of a failing record; ~0 = none
+    unsigned long long consumed;     // atomicMax: offset just past the last owned quality line
+    unsigned long long pad[22];
+};
+static_assert(sizeof(ScanWsHeader) == 256, "header is 256 bytes");
+
+struct FastqWsLayout {
+    uint64_t n_tiles_mp;
+    uint64_t n_tiles_fused;
+    uint64_t off_tile_counts;   // u32[n_tiles_mp]
+    uint64_t off_tile_offsets;  // u64[n_tiles_mp]
+    uint64_t off_tile_desc;     // u64[n_tiles_fused]  (fused look-back descriptors)
+    uint64_t off_nl_pos;        // u64[lines_cap]
+    uint64_t lines_cap;
+    uint64_t total_bytes;
+};
+
+static inline uint64_t round_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+// nl_pos capacity: the general kernels index every line.  Worst case is one line per byte; the
+// default provisions one line per 8 bytes (FASTQ/VCF lines are far longer) but never less than
+// min(n, 1 Mi) + 8 so small inputs are always safe.  Overflow is reported, never silent.
+static inline FastqWsLayout fastq_ws_layout(uint64_t n_bytes, uint64_t ws_bytes_or_0) {
+    FastqWsLayout l;
+    l.n_tiles_mp = (n_bytes + kMpTileBytes - 1) / kMpTileBytes + 1;
+    l.n_tiles_fused = (n_bytes + kFusedTileBytes - 1) / kFusedTileBytes + 1;
+    uint64_t at = sizeof(ScanWsHeader);
+    l.off_tile_counts = at;
+    at = round_up(at + l.n_tiles_mp * 4, 256);
+    l.off_tile_offsets = at;
+    at = round_up(at + l.n_tiles_mp * 8, 256);
+    l.off_tile_desc = at;
+    at = round_up(at + l.n_tiles_fused * 8, 256);
+    l.off_nl_pos = at;
+    uint64_t want = n_bytes / 8;
+    uint64_t small = n_bytes < (1ull << 20) ? n_bytes : (1ull << 20);
+    if (want < small) want = small;
+    want += 8;
+    if (ws_bytes_or_0) {
+        uint64_t avail = ws_bytes_or_0 > at ? (ws_bytes_or_0 - at) / 8 : 0;
+        l.lines_cap = avail;
+    } else {
+        l.lines_cap = want;
+    }
+    l.total_bytes = at + l.lines_cap * 8;
+    return l;
+}
+
+}  // namespace exg

@@ -1,0 +1,221 @@
+// exg_lines.hip — general line index (multipass): count '\n' per tile, scan the tile counts,
+// emit every newline offset.  Used by the general (any line length) paths of all three formats
+// and as the differential partner of the fused single-pass kernels.
+//
+// Reference behaviour being replaced: the `memchr(b'\n')` line splitting inside the noodles
+// readers that exon drives per record (external crates; call sites rust/src/arrow_reader.rs:116-153).
+#include "exg_fastq_ws.hpp"
+#include "exg_lines.hpp"
+
+namespace exg {
+
+// Pass 1: per 16 KiB tile newline count; also counts newlines inside the halo [0, lead) and ORs
+// a non-ASCII flag.  Reads each input byte once, coalesced 16 B per lane.
+__global__ __launch_bounds__(kMpThreads) void k_count_nl(const uint8_t *__restrict__ d_in, uint64_t n_bytes,
+                                                         uint64_t lead, uint32_t *__restrict__ tile_counts,
+                                                         ScanWsHeader *hdr, const unsigned int *gate) {
+    __shared__ uint32_t s_cnt[4], s_halo[4], s_hi[4];
+    if (gate && *gate == 0) return;
+    for (uint64_t tile = blockIdx.x; tile * kMpTileBytes < n_bytes || (tile == 0 && n_bytes == 0);
+         tile += gridDim.x) {
+        uint32_t cnt = 0, halo = 0, hi = 0;
+        uint64_t tile_off = tile * (uint64_t)kMpTileBytes;
+#pragma unroll
+        for (uint32_t j = 0; j < kMpIters; j++) {
+            uint64_t off = tile_off + (uint64_t)j * kMpIterBytes + (uint64_t)threadIdx.x * 16;
+            if (off < n_bytes) {
+                uint4 v = *reinterpret_cast<const uint4 *>(d_in + off);
+                uint32_t m = match16(v, 0x0A0A0A0Au);
+                uint32_t h = nib4(v.x & 0x80808080u) | (nib4(v.y & 0x80808080u) << 4) |
+                             (nib4(v.z & 0x80808080u) << 8) | (nib4(v.w & 0x80808080u) << 12);
+                if (off + 16 > n_bytes) {
+                    uint32_t keep = (1u << (uint32_t)(n_bytes - off)) - 1u;
+                    m &= keep;
+                    h &= keep;
+                }
+                cnt += __popc(m);
+                hi |= h;
+                if (off < lead) {
+                    uint32_t hm = m;
+                    if (off + 16 > lead) hm &= (1u << (uint32_t)(lead - off)) - 1u;
+                    halo += __popc(hm);
+                }
+            }
+        }
+        // block reduce
+        for (int d = 32; d > 0; d >>= 1) {
+            cnt += __shfl_down(cnt, d, 64);
+            halo += __shfl_down(halo, d, 64);
+            hi |= __shfl_down(hi, d, 64);
+        }
+        uint32_t w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) {
+            s_cnt[w] = cnt;
+            s_halo[w] = halo;
+            s_hi[w] = hi;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t c = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+            uint32_t h = s_halo[0] + s_halo[1] + s_halo[2] + s_halo[3];
+            tile_counts[tile] = c;
+            if (h) atomicAdd(&hdr->halo_nl, (unsigned long long)h);
+            if (s_hi[0] | s_hi[1] | s_hi[2] | s_hi[3]) atomicOr(&hdr->flags, EXG_RF_NON_ASCII);
+        }
+        __syncthreads();
+        if (n_bytes == 0) break;
+    }
+}
+
+// Pass 2: single-block exclusive scan of the tile counts; appends the virtual line ends that the
+// readers' EOF rules imply (format specific, selected by eof_mode).
+//   eof_mode 0: none (not at EOF)
+//   eof_mode 1: an unterminated last line counts as a line (all formats)
+//   eof_mode 2: FASTQ — additionally, a record that has its '+' line but no quality line gets an
+//               empty quality line (noodles read_line returns 0 bytes at EOF without error)
+__global__ __launch_bounds__(1024) void k_scan_tiles(const uint8_t *__restrict__ d_in, uint64_t n_bytes,
+                                                     uint64_t n_tiles, const uint32_t *__restrict__ tile_counts,
+                                                     uint64_t *__restrict__ tile_offsets, uint64_t *nl_pos,
+                                                     ScanWsHeader *hdr, int eof_mode, uint64_t first_line_index,
+                                                     const unsigned int *gate) {
+    __shared__ unsigned long long s_wave[16];
+    if (gate && *gate == 0) return;
+    __shared__ unsigned long long s_running;
+    if (threadIdx.x == 0) s_running = 0;
+    __syncthreads();
+    for (uint64_t base = 0; base < n_tiles; base += 1024) {
+        uint64_t t = base + threadIdx.x;
+        unsigned long long c = t < n_tiles ? tile_counts[t] : 0;
+        unsigned long long incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            unsigned long long o = __shfl_up(incl, d, 64);
+            if ((int)(threadIdx.x & 63) >= d) incl += o;
+        }
+        uint32_t w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 63) s_wave[w] = incl;
+        __syncthreads();
+        unsigned long long wave_off = 0;
+        for (uint32_t k = 0; k < w; k++) wave_off += s_wave[k];
+        unsigned long long run = s_running;
+        if (t < n_tiles) tile_offsets[t] = run + wave_off + incl - c;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_running = run + wave_off + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        unsigned long long total = s_running;
+        hdr->total_nl = total;
+        unsigned long long lines = total;
+        if (eof_mode >= 1 && n_bytes > 0 && d_in[n_bytes - 1] != '\n') {
+            if (lines < hdr->lines_cap) nl_pos[lines] = n_bytes;
+            lines++;
+        }
+        if (eof_mode == 2) {
+            unsigned long long p0 = first_line_index - hdr->halo_nl;
+            if (((p0 + lines) & 3) == 3) {
+                if (lines < hdr->lines_cap) nl_pos[lines] = n_bytes;
+                lines++;
+            }
+        }
+        hdr->total_lines = lines;
+    }
+}
+
+// Pass 3: write the offset of every '\n' in order.  Re-reads the input once.
+__global__ __launch_bounds__(kMpThreads) void k_emit_nl(const uint8_t *__restrict__ d_in, uint64_t n_bytes,
+                                                        const uint64_t *__restrict__ tile_offsets,
+                                                        uint64_t *__restrict__ nl_pos, uint64_t lines_cap,
+                                                        const unsigned int *gate) {
+    __shared__ uint32_t s_wave[4];
+    if (gate && *gate == 0) return;
+    for (uint64_t tile = blockIdx.x; tile * kMpTileBytes < n_bytes; tile += gridDim.x) {
+        uint64_t tile_off = tile * (uint64_t)kMpTileBytes;
+        uint64_t rank_base = tile_offsets[tile];
+        for (uint32_t j = 0; j < kMpIters; j++) {
+            uint64_t off = tile_off + (uint64_t)j * kMpIterBytes + (uint64_t)threadIdx.x * 16;
+            uint32_t m = 0;
+            if (off < n_bytes) {
+                uint4 v = *reinterpret_cast<const uint4 *>(d_in + off);
+                m = match16(v, 0x0A0A0A0Au);
+                if (off + 16 > n_bytes) m &= (1u << (uint32_t)(n_bytes - off)) - 1u;
+            }
+            uint32_t c = __popc(m);
+            uint32_t incl = wave_incl_sum(c);
+            uint32_t w = threadIdx.x >> 6;
+            if ((threadIdx.x & 63) == 63) s_wave[w] = incl;
+            __syncthreads();
+            uint32_t wave_off = 0, iter_total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+            for (uint32_t k = 0; k < w; k++) wave_off += s_wave[k];
+            uint64_t r = rank_base + wave_off + incl - c;
+            while (m) {
+                uint32_t b = __ffs(m) - 1;
+                m &= m - 1;
+                if (r < lines_cap) nl_pos[r] = off + b;
+                r++;
+            }
+            rank_base += iter_total;
+            __syncthreads();
+        }
+    }
+}
+
+int launch_line_index(const uint8_t *d_in, uint64_t n_bytes, uint64_t lead, uint8_t *ws, const FastqWsLayout &l,
+                      int eof_mode, uint64_t first_line_index, hipStream_t stream, const unsigned int *gate) {
+    ScanWsHeader *hdr = reinterpret_cast<ScanWsHeader *>(ws);
+    uint32_t *tile_counts = reinterpret_cast<uint32_t *>(ws + l.off_tile_counts);
+    uint64_t *tile_offsets = reinterpret_cast<uint64_t *>(ws + l.off_tile_offsets);
+    uint64_t *nl_pos = reinterpret_cast<uint64_t *>(ws + l.off_nl_pos);
+    uint64_t n_tiles = (n_bytes + kMpTileBytes - 1) / kMpTileBytes;
+    uint32_t grid = (uint32_t)(n_tiles < 8192 ? (n_tiles ? n_tiles : 1) : 8192);
+    hipLaunchKernelGGL(k_count_nl, dim3(grid), dim3(kMpThreads), 0, stream, d_in, n_bytes, lead, tile_counts, hdr, gate);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, stream, d_in, n_bytes, n_tiles, tile_counts,
+                       tile_offsets, nl_pos, hdr, eof_mode, first_line_index, gate);
+    if (n_tiles)
+        hipLaunchKernelGGL(k_emit_nl, dim3(grid), dim3(kMpThreads), 0, stream, d_in, n_bytes, tile_offsets, nl_pos,
+                           l.lines_cap, gate);
+    EXG_HIP_CHECK(hipGetLastError());
+    return EXG_OK;
+}
+
+// ---- exg_count_newlines ------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_count_range(const uint8_t *__restrict__ d_in, uint64_t begin, uint64_t end,
+                                                     unsigned long long *d_count) {
+    // 16-byte aligned chunks covering [begin, end); lanes mask bytes outside the range
+    uint64_t a0 = begin & ~15ull;
+    uint64_t n_chunks = (end > a0) ? (end - a0 + 15) / 16 : 0;
+    unsigned long long cnt = 0;
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks;
+         c += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t off = a0 + c * 16;
+        uint4 v = *reinterpret_cast<const uint4 *>(d_in + off);
+        uint32_t m = match16(v, 0x0A0A0A0Au);
+        if (off < begin) m &= ~((1u << (uint32_t)(begin - off)) - 1u);
+        if (off + 16 > end) m &= (1u << (uint32_t)(end - off)) - 1u;
+        cnt += __popc(m);
+    }
+    for (int d = 32; d > 0; d >>= 1) cnt += __shfl_down(cnt, d, 64);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(d_count, cnt);
+}
+
+}  // namespace exg
+
+extern "C" int exg_count_newlines(const void *d_input, uint64_t begin, uint64_t end, uint64_t *d_count,
+                                  void *stream) {
+    if (!d_count || (end > begin && !d_input) || ((uintptr_t)d_input & 15)) {
+        exg::set_error("exg_count_newlines: bad arguments");
+        return EXG_E_INVALID_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    EXG_HIP_CHECK(hipMemsetAsync(d_count, 0, 8, s));
+    if (end > begin) {
+        uint64_t n_chunks = (end - (begin & ~15ull) + 15) / 16;
+        uint64_t blocks = (n_chunks + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(exg::k_count_range, dim3((uint32_t)blocks), dim3(256), 0, s,
+                           (const uint8_t *)d_input, begin, end, (unsigned long long *)d_count);
+        EXG_HIP_CHECK(hipGetLastError());
+    }
+    return EXG_OK;
+}

@@ -1,0 +1,88 @@
+"""Device-level scans on torch-owned HBM buffers (torch = allocator + streams only)."""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from ._lib import ExgError, check, load_library
+
+
+def _torch():
+    import torch
+
+    if not torch.cuda.is_available():
+        raise ExgError(abi.EXG_E_NO_DEVICE, "no GPU visible to torch: the record scan has no CPU fallback")
+    return torch
+
+
+def stream_ptr():
+    torch = _torch()
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def upload(data: bytes, device="cuda", pad=64):
+    """Host bytes -> 16-byte-aligned device uint8 tensor, zero padded (API contract: readable to
+    round_up(n,16))."""
+    torch = _torch()
+    n = len(data)
+    t = torch.zeros(n + pad + 16, dtype=torch.uint8, device=device)
+    if n:
+        t[:n].copy_(torch.frombuffer(bytearray(data), dtype=torch.uint8))
+    assert t.data_ptr() % 16 == 0
+    return t
+
+
+def synth_fastq(n_bytes, file_offset=0, seed=abi.EXG_SYNTH_FASTQ_SEED, device="cuda"):
+    torch = _torch()
+    lib = load_library()
+    t = torch.empty(((n_bytes + 15) // 16) * 16 + 64, dtype=torch.uint8, device=device)
+    t[n_bytes:].zero_()
+    check(lib.exg_synth_fastq(C.c_void_p(t.data_ptr()), file_offset, n_bytes, seed, stream_ptr()))
+    return t
+
+
+class FastqScan:
+    """Reusable output + workspace buffers for exg_fastq_scan on one device buffer size."""
+
+    def __init__(self, n_bytes, capacity_records=None, device="cuda"):
+        torch = _torch()
+        self.lib = load_library()
+        self.n_bytes = n_bytes
+        self.capacity = int(capacity_records if capacity_records is not None else n_bytes // 8 + 16)
+        cap = max(self.capacity, 1)
+        self.cols = [torch.empty((cap, 2), dtype=torch.int64, device=device) for _ in range(4)]
+        self.validity = torch.empty(((cap + 63) // 64,), dtype=torch.int64, device=device)
+        self.ws_bytes = int(self.lib.exg_scan_workspace_bytes(abi.EXG_FMT_FASTQ, n_bytes))
+        self.ws = torch.empty((self.ws_bytes + 255) // 8, dtype=torch.int64, device=device)
+        self.result = torch.zeros(8, dtype=torch.int64, device=device)
+        self.args = abi.FastqScanArgs()
+
+    def launch(self, d_input, n_bytes=None, lead=0, first_line_index=0, payload_base=0,
+               flags=abi.EXG_F_BOF | abi.EXG_F_EOF, algo=abi.EXG_ALGO_AUTO):
+        a = self.args
+        a.d_input = d_input.data_ptr()
+        a.n_bytes = self.n_bytes if n_bytes is None else n_bytes
+        a.lead = lead
+        a.first_line_index = first_line_index
+        a.payload_base = payload_base
+        a.flags = flags
+        a.algo = algo
+        a.d_name, a.d_description, a.d_sequence, a.d_quality = (c.data_ptr() for c in self.cols)
+        a.d_description_validity = self.validity.data_ptr()
+        a.capacity_records = self.capacity
+        a.d_workspace = self.ws.data_ptr()
+        a.workspace_bytes = self.ws_bytes
+        a.d_result = self.result.data_ptr()
+        a.stream = stream_ptr().value
+        check(self.lib.exg_fastq_scan(C.byref(a)))
+
+    def fetch(self):
+        r = abi.ScanResult()
+        check(self.lib.exg_fetch_result(C.c_void_p(self.result.data_ptr()), stream_ptr(), C.byref(r)))
+        return r
+
+    def columns_host(self, n):
+        """(4 x [n,16] uint8 string_t arrays, validity words) on the host."""
+        cols = [c[:n].cpu().numpy().view(np.uint8).reshape(n, 16) for c in self.cols]
+        words = self.validity[: (n + 63) // 64].cpu().numpy().view(np.uint64)
+        return cols, words

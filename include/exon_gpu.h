@@ -1,0 +1,266 @@
+/*
+ * exon_gpu.h — C-ABI of the MI355X-native record-scan engine (libexon_gpu.so).
+ *
+ * Drop-in boundary for ONE path of wheretrue/exon-duckdb: the read_fasta /
+ * read_fastq / read_vcf_file_records table functions that tokenise raw file
+ * bytes into DuckDB DataChunks.  Plain C, plain pointers and sizes; no torch,
+ * no HIP and no DuckDB types appear in any signature.
+ *
+ * Three layers, lowest first:
+ *
+ *   (1) exg_*_scan  — device level.  Input bytes are already resident in HBM;
+ *       output column vectors (arrays of 16-byte duckdb::string_t + validity
+ *       words) are written to HBM.  This is the hot path bench.py measures.
+ *       Replaces the per-batch work of the reference's Rust side:
+ *       exon `BatchReader::read_batch` + noodles line readers + Arrow builders
+ *       (external crates, reached through rust/src/arrow_reader.rs:116-153)
+ *       and the Arrow->DataChunk conversion at
+ *       exon/src/exon/arrow_table_function/module.cpp:257-294 (Scan).
+ *
+ *   (2) exg_open / exg_next_chunk — reader level.  File on the host ->
+ *       pinned staging -> HBM -> kernels -> DataChunk-shaped host buffers.
+ *       Replaces `new_reader` + the ArrowArrayStream it returns
+ *       (exon/include/rust.hpp:41-46, rust/src/arrow_reader.rs:38-166).
+ *
+ *   (3) new_reader / replacement_scan compatible entry points are declared in
+ *       exon_gpu_compat.h (same names and argument meaning as rust.hpp).
+ *
+ * Error convention: every function returns 0 on success or a negative
+ * EXG_E_* code; nothing throws across this boundary.  Parse errors found by a
+ * kernel are reported through exg_scan_result (error_code > 0 = EXG_PE_*).
+ */
+#ifndef EXON_GPU_H
+#define EXON_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EXG_ABI_VERSION 1
+
+/* DuckDB v0.8.1 STANDARD_VECTOR_SIZE; the reference asks the Rust side for
+ * batches of exactly this many rows (module.cpp:83, :233). */
+#define EXG_VECTOR_SIZE 2048
+
+/* ---- API status codes (negative) ---------------------------------------- */
+#define EXG_OK 0
+#define EXG_E_INVALID_ARG (-1)
+#define EXG_E_NO_DEVICE (-2)   /* HIP runtime / GPU missing: the product path fails loudly */
+#define EXG_E_HIP (-3)         /* a HIP call failed; see exg_last_error_message() */
+#define EXG_E_IO (-4)
+#define EXG_E_UNSUPPORTED (-5) /* e.g. zstd: no device decoder yet */
+#define EXG_E_PARSE (-6)       /* reader level: a record failed to parse */
+#define EXG_E_CAPACITY (-7)    /* output arrays too small */
+#define EXG_E_NOMEM (-8)
+
+/* ---- parse error codes (positive; exg_scan_result.error_code) ----------- */
+/* Mirrors the io::Error cases of the noodles readers at the pinned versions
+ * (rust/Cargo.lock:1991-2194); each is a named oracle test. */
+#define EXG_PE_NONE 0
+#define EXG_PE_FASTQ_NAME_PREFIX 1    /* line 1 of a record does not start with '@' */
+#define EXG_PE_FASTQ_PLUS_PREFIX 2    /* line 3 of a record does not start with '+' */
+#define EXG_PE_UNEXPECTED_EOF 3       /* file ends inside a record (before line 3) */
+#define EXG_PE_INVALID_UTF8 4         /* a field is not valid UTF-8 */
+#define EXG_PE_FASTA_MISSING_PREFIX 5 /* definition line does not start with '>' */
+#define EXG_PE_FASTA_MISSING_NAME 6   /* '>' followed by whitespace / nothing */
+#define EXG_PE_FASTA_EMPTY_DEF 7      /* empty definition line */
+#define EXG_PE_VCF_MISSING_FIELD 8    /* data line with fewer than 8 tab-separated fields */
+#define EXG_PE_VCF_BAD_POS 9          /* POS is not a decimal integer */
+#define EXG_PE_VCF_BAD_QUAL 10        /* QUAL is neither '.' nor a float */
+#define EXG_PE_VCF_NO_HEADER 11       /* no '#CHROM' header line */
+#define EXG_PE_FIELD_TOO_LONG 12      /* a field exceeds 2^32-1 bytes (string_t length is u32) */
+
+/* ---- duckdb::string_t, bit-for-bit (v0.8.1 duckdb/common/types/string_type.hpp)
+ * length <= 12: bytes inlined, zero padded.  Otherwise 4-byte prefix + pointer.
+ * Rows that are NULL hold 16 zero bytes. */
+typedef union exg_string_t {
+    struct {
+        uint32_t length;
+        char prefix[4];
+        uint64_t ptr; /* payload_base + byte offset of the field in the input */
+    } pointer;
+    struct {
+        uint32_t length;
+        char inlined[12];
+    } inlined;
+} exg_string_t;
+
+#define EXG_INLINE_LENGTH 12
+
+/* ---- formats ------------------------------------------------------------- */
+#define EXG_FMT_FASTA 1
+#define EXG_FMT_FASTQ 2
+#define EXG_FMT_VCF 3
+
+/* ---- scan flags ------------------------------------------------------------ */
+#define EXG_F_BOF 1u /* a line starts at d_input[0] (start of file, or a record-aligned batch) */
+#define EXG_F_EOF 2u /* d_input[n_bytes-1] is the last byte of the file */
+
+/* result flags */
+#define EXG_RF_NON_ASCII 1u /* a byte >= 0x80 was seen; UTF-8 was validated by the slow kernel */
+#define EXG_RF_HEAD_UNRESOLVED 2u /* first owned record starts before d_input[0]: host must stitch */
+#define EXG_RF_FALLBACK 4u  /* the fused kernel met a record larger than its LDS window and the general kernel ran */
+#define EXG_RF_CAPACITY 8u  /* more records than capacity_records: the surplus was not written */
+#define EXG_RF_INDEX_OVERFLOW 16u /* general path: more lines than the workspace can index (enlarge d_workspace) */
+
+/* algorithm selector (exg_*_scan_args.algo) */
+#define EXG_ALGO_AUTO 0
+#define EXG_ALGO_MULTIPASS 1 /* count -> scan -> index -> fields: 4 launches, reads the input ~3x */
+#define EXG_ALGO_FUSED 2     /* single pass, decoupled look-back: reads the input once */
+
+/* Written by the device (64 bytes, 8-byte aligned), copied back by exg_fetch_result. */
+typedef struct exg_scan_result {
+    uint64_t n_records;      /* records owned by this buffer (end at offset >= lead) */
+    uint64_t n_lines;        /* '\n' count in [lead, n_bytes) (+1 for an unterminated last line at EOF) */
+    uint64_t consumed_bytes; /* offset just past the last complete owned record */
+    uint64_t error_offset;   /* byte offset (in d_input) of the first failing line; ~0 if none */
+    uint64_t error_record;   /* index (within this buffer's output) of the first failing record */
+    uint32_t error_code;     /* EXG_PE_* */
+    uint32_t flags;          /* EXG_RF_* */
+    uint64_t payload_bytes;  /* FASTA: bytes written to the compacted sequence payload */
+    uint64_t reserved;
+} exg_scan_result;
+
+/* FASTQ: 4 VARCHAR columns name, description, sequence, quality_scores
+ * (order pinned by test/sql/exondb-release-with-deb-info/test_fastq_scan.test:35-41). */
+typedef struct exg_fastq_scan_args {
+    const void *d_input;       /* device pointer, 16-byte aligned, readable up to round_up(n_bytes,16) */
+    uint64_t n_bytes;          /* halo + shard */
+    uint64_t lead;             /* halo: records whose last line ends before this offset belong to the previous shard */
+    uint64_t first_line_index; /* number of '\n' in the file before d_input[lead] (gives the 4-line phase) */
+    uint64_t payload_base;     /* string_t.ptr = payload_base + offset in d_input */
+    uint32_t flags;            /* EXG_F_* */
+    uint32_t algo;             /* EXG_ALGO_* */
+    exg_string_t *d_name;      /* device, capacity_records entries each */
+    exg_string_t *d_description;
+    exg_string_t *d_sequence;
+    exg_string_t *d_quality;
+    uint64_t *d_description_validity; /* device, ceil(capacity/64) words, bit r = row r valid */
+    uint64_t capacity_records;
+    void *d_workspace; /* device, exg_scan_workspace_bytes(EXG_FMT_FASTQ, n_bytes) */
+    uint64_t workspace_bytes;
+    exg_scan_result *d_result; /* device, 64 bytes */
+    void *stream;              /* hipStream_t (NULL = default stream) */
+} exg_fastq_scan_args;
+
+/* VCF: one row per data line; the 8 fixed columns (+ the FORMAT/samples rest)
+ * as raw field slices, POS parsed to int64, QUAL to float32. */
+typedef struct exg_vcf_scan_args {
+    const void *d_input;
+    uint64_t n_bytes;
+    uint64_t lead;
+    uint64_t payload_base;
+    uint32_t flags;
+    uint32_t algo;
+    exg_string_t *d_fields[9]; /* chrom,pos,id,ref,alt,qual,filter,info,formats(rest) — any may be NULL (projection) */
+    int64_t *d_pos;            /* parsed POS, may be NULL */
+    float *d_qual;             /* parsed QUAL, may be NULL */
+    uint64_t *d_qual_validity; /* '.' => NULL */
+    uint64_t *d_formats_validity;
+    uint64_t capacity_records;
+    void *d_workspace;
+    uint64_t workspace_bytes;
+    exg_scan_result *d_result;
+    void *stream;
+} exg_vcf_scan_args;
+
+/* FASTA: id, description, sequence.  The sequence is the concatenation of the
+ * record's lines with terminators removed, so it is materialised in a
+ * compacted payload buffer (d_seq_payload); id/description point into d_input. */
+typedef struct exg_fasta_scan_args {
+    const void *d_input;
+    uint64_t n_bytes;
+    uint64_t lead;
+    uint64_t payload_base;     /* for id/description */
+    uint64_t seq_payload_base; /* string_t.ptr of sequences = seq_payload_base + offset in d_seq_payload */
+    uint32_t flags;
+    uint32_t algo;
+    exg_string_t *d_id;
+    exg_string_t *d_description;
+    exg_string_t *d_sequence;
+    uint64_t *d_description_validity;
+    uint8_t *d_seq_payload; /* device, >= n_bytes */
+    uint64_t capacity_records;
+    void *d_workspace;
+    uint64_t workspace_bytes;
+    exg_scan_result *d_result;
+    void *stream;
+} exg_fasta_scan_args;
+
+/* ---- library / device ------------------------------------------------------ */
+int exg_abi_version(void);
+/* Number of visible HIP devices, or EXG_E_NO_DEVICE. Does not initialise a context. */
+int exg_device_count(void);
+/* Thread-local message for the last failing call on this thread. */
+const char *exg_last_error_message(void);
+const char *exg_parse_error_string(uint32_t pe_code);
+
+/* ---- (1) device level -------------------------------------------------------- */
+uint64_t exg_scan_workspace_bytes(int format, uint64_t n_bytes);
+/* Enqueue on args->stream; asynchronous. */
+int exg_fastq_scan(const exg_fastq_scan_args *args);
+int exg_vcf_scan(const exg_vcf_scan_args *args);
+int exg_fasta_scan(const exg_fasta_scan_args *args);
+/* Synchronising copy of the 64-byte result to the host. */
+int exg_fetch_result(const exg_scan_result *d_result, void *stream, exg_scan_result *out);
+/* '\n' count of d_input[begin,end) into *d_count (device u64); used for the shard phase exchange. */
+int exg_count_newlines(const void *d_input, uint64_t begin, uint64_t end, uint64_t *d_count, void *stream);
+/* FASTQ 4-line phase of the first line that starts at or after `lead`, decided from local
+ * structure ('@' on line 0, '+' on line 2 for 8 consecutive records).  *d_phase (device u32)
+ * receives 0..3, or 0xFFFFFFFF when no or several phases fit (caller falls back to counting). */
+int exg_fastq_guess_phase(const void *d_input, uint64_t n_bytes, uint64_t lead, uint32_t *d_phase, void *stream);
+
+/* Deterministic synthetic inputs, generated on the device so the bench
+ * needs no PCIe traffic: writes file bytes [file_offset, file_offset+n_bytes) to d_out. */
+#define EXG_SYNTH_FASTQ_SEED 0xE0A5EED0001ull
+#define EXG_SYNTH_VCF_SEED 0xE0A5EED0002ull
+#define EXG_SYNTH_FASTQ_RECORD_BYTES 332
+int exg_synth_fastq(void *d_out, uint64_t file_offset, uint64_t n_bytes, uint64_t seed, void *stream);
+
+/* ---- (2) reader level ----------------------------------------------------------- */
+typedef struct exg_reader exg_reader;
+
+typedef struct exg_open_args {
+    const char *path;        /* local file or directory (the reference lists directories: test_fasta_scan.test:55-59) */
+    const char *file_format; /* "fasta" | "fastq" | "vcf" (the reference's file_type strings, exon_extension.cpp:50,51,55) */
+    const char *compression; /* NULL = infer from extension like arrow_reader.rs:60-75; "gzip","zstd","uncompressed",... */
+    uint64_t batch_rows;     /* rows per chunk; 0 => EXG_VECTOR_SIZE */
+    int device;              /* HIP device ordinal */
+    uint64_t device_batch_bytes; /* bytes shipped to HBM per launch; 0 => default */
+} exg_open_args;
+
+#define EXG_TYPE_VARCHAR 1
+#define EXG_TYPE_BIGINT 2
+#define EXG_TYPE_FLOAT 3
+
+typedef struct exg_schema {
+    int n_columns;
+    const char *names[16]; /* owned by the reader */
+    int types[16];
+    int nullable[16];
+} exg_schema;
+
+typedef struct exg_chunk {
+    uint64_t n_rows;           /* 0 => end of stream */
+    int n_columns;
+    void *data[16];            /* host pointers: exg_string_t[n_rows] / int64_t[] / float[] */
+    uint64_t *validity[16];    /* NULL => all valid; else ceil(n_rows/64) words */
+    void *keepalive;           /* opaque; payload + vectors stay valid until exg_release_chunk */
+} exg_chunk;
+
+int exg_open(const exg_open_args *args, exg_reader **out);
+int exg_schema_of(exg_reader *r, exg_schema *out);
+int exg_next_chunk(exg_reader *r, exg_chunk *out);
+void exg_release_chunk(exg_reader *r, exg_chunk *chunk);
+/* COUNT(*) fast path: no column is materialised. */
+int exg_count_only(exg_reader *r, uint64_t *n_rows);
+const char *exg_reader_error(exg_reader *r);
+void exg_close(exg_reader *r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EXON_GPU_H */

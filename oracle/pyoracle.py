@@ -1,0 +1,245 @@
+"""ctypes front-end of oracle/libexon_oracle.so — TEST INFRASTRUCTURE ONLY.
+
+Imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libexon_oracle.so")
+
+
+class Utf8Col(C.Structure):
+    _fields_ = [
+        ("n_rows", C.c_int64),
+        ("offsets", C.POINTER(C.c_int64)),
+        ("values", C.POINTER(C.c_uint8)),
+        ("valid", C.POINTER(C.c_uint8)),
+        ("src_off", C.POINTER(C.c_int64)),
+        ("cap_rows", C.c_int64),
+        ("cap_values", C.c_int64),
+    ]
+
+
+class I64Col(C.Structure):
+    _fields_ = [("n_rows", C.c_int64), ("data", C.POINTER(C.c_int64)), ("valid", C.POINTER(C.c_uint8)),
+                ("cap_rows", C.c_int64)]
+
+
+class F32Col(C.Structure):
+    _fields_ = [("n_rows", C.c_int64), ("data", C.POINTER(C.c_float)), ("valid", C.POINTER(C.c_uint8)),
+                ("cap_rows", C.c_int64)]
+
+
+class Error(C.Structure):
+    _fields_ = [("code", C.c_uint32), ("record", C.c_uint64), ("offset", C.c_uint64), ("message", C.c_char * 128)]
+
+
+class FastqTable(C.Structure):
+    _fields_ = [("name", Utf8Col), ("description", Utf8Col), ("sequence", Utf8Col), ("quality_scores", Utf8Col),
+                ("err", Error)]
+
+
+class FastaTable(C.Structure):
+    _fields_ = [("id", Utf8Col), ("description", Utf8Col), ("sequence", Utf8Col), ("err", Error)]
+
+
+class VcfTable(C.Structure):
+    _fields_ = [("fields", Utf8Col * 9), ("pos", I64Col), ("qual", F32Col), ("header_bytes", C.c_int64),
+                ("n_header_lines", C.c_int64), ("err", Error)]
+
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", HERE])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        l = C.CDLL(LIB_PATH)
+        l.orc_fastq_parse.restype = C.c_int64
+        l.orc_fastq_parse.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(FastqTable)]
+        l.orc_fasta_parse.restype = C.c_int64
+        l.orc_fasta_parse.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(FastaTable)]
+        l.orc_vcf_parse.restype = C.c_int64
+        l.orc_vcf_parse.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(VcfTable)]
+        l.orc_fastq_free.argtypes = [C.POINTER(FastqTable)]
+        l.orc_fasta_free.argtypes = [C.POINTER(FastaTable)]
+        l.orc_vcf_free.argtypes = [C.POINTER(VcfTable)]
+        l.orc_utf8_to_string_t.argtypes = [C.POINTER(Utf8Col), C.c_int64, C.c_int64, C.c_int, C.c_uint64,
+                                           C.c_void_p, C.c_void_p]
+        l.orc_is_valid_utf8.restype = C.c_int
+        l.orc_is_valid_utf8.argtypes = [C.c_void_p, C.c_uint64]
+        l.orc_synth_fastq.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
+        for f in ("orc_synth_fastq_ragged", "orc_synth_vcf", "orc_synth_fasta"):
+            getattr(l, f).restype = C.c_uint64
+            getattr(l, f).argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
+        l.orc_fastq_scan_baseline.restype = C.c_int64
+        l.orc_fastq_scan_baseline.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        l.orc_infer_compression.restype = C.c_char_p
+        l.orc_infer_compression.argtypes = [C.c_char_p, C.c_char_p]
+        l.orc_replacement_scan.restype = C.c_char_p
+        l.orc_replacement_scan.argtypes = [C.c_char_p]
+        _lib = l
+    return _lib
+
+
+SYNTH_FASTQ_SEED = 0xE0A5EED0001
+SYNTH_VCF_SEED = 0xE0A5EED0002
+SYNTH_FASTA_SEED = 0xE0A5EED0003
+
+
+class Column:
+    """Host copy of an Arrow-style Utf8 column: offsets / values / valid / src_off."""
+
+    def __init__(self, c: Utf8Col, n_rows=None):
+        n = int(c.n_rows if n_rows is None else min(n_rows, c.n_rows))
+        self.n = n
+        if n:
+            self.offsets = np.ctypeslib.as_array(c.offsets, shape=(n + 1,)).copy()
+            nb = int(self.offsets[n])
+            self.values = np.ctypeslib.as_array(c.values, shape=(max(nb, 1),))[:nb].copy() if nb else np.zeros(0, np.uint8)
+            self.valid = np.ctypeslib.as_array(c.valid, shape=(n,)).copy()
+            self.src_off = np.ctypeslib.as_array(c.src_off, shape=(n,)).copy()
+        else:
+            self.offsets = np.zeros(1, np.int64)
+            self.values = np.zeros(0, np.uint8)
+            self.valid = np.zeros(0, np.uint8)
+            self.src_off = np.zeros(0, np.int64)
+
+    def row(self, i):
+        if not self.valid[i]:
+            return None
+        return self.values[self.offsets[i]:self.offsets[i + 1]].tobytes()
+
+    def lengths(self):
+        return np.diff(self.offsets)
+
+    def to_list(self):
+        return [self.row(i) for i in range(self.n)]
+
+
+def _string_t(c: Utf8Col, n, mode, payload_base):
+    out = np.zeros((max(n, 1), 16), np.uint8)
+    words = np.zeros(((max(n, 1) + 63) // 64,), np.uint64)
+    if n:
+        lib().orc_utf8_to_string_t(C.byref(c), 0, n, mode, payload_base, out.ctypes.data, words.ctypes.data)
+    return out[:n], words[: (n + 63) // 64]
+
+
+class ParseResult:
+    def __init__(self, n_rows, columns, err, string_t=None, extra=None):
+        self.n_rows = n_rows
+        self.columns = columns      # dict name -> Column
+        self.error_code = int(err.code)
+        self.error_record = int(err.record)
+        self.error_offset = int(err.offset)
+        self.error_message = err.message.decode()
+        self.string_t = string_t or {}   # dict name -> ([n,16] u8, validity words)  (canonical zero-copy view)
+        self.extra = extra or {}
+
+
+def _as_buf(data):
+    if isinstance(data, np.ndarray):
+        arr = np.ascontiguousarray(data, dtype=np.uint8)
+    else:
+        arr = np.frombuffer(bytes(data), dtype=np.uint8)
+    return arr, arr.ctypes.data if arr.size else None
+
+
+def fastq_parse(data, payload_base=0, want_string_t=True):
+    arr, ptr = _as_buf(data)
+    t = FastqTable()
+    n = int(lib().orc_fastq_parse(ptr, arr.size, C.byref(t)))
+    names = ["name", "description", "sequence", "quality_scores"]
+    cols = {k: Column(getattr(t, k), n) for k in names}
+    st = {k: _string_t(getattr(t, k), n, 1, payload_base) for k in names} if want_string_t else {}
+    res = ParseResult(n, cols, t.err, st)
+    lib().orc_fastq_free(C.byref(t))
+    return res
+
+
+def fasta_parse(data):
+    arr, ptr = _as_buf(data)
+    t = FastaTable()
+    n = int(lib().orc_fasta_parse(ptr, arr.size, C.byref(t)))
+    names = ["id", "description", "sequence"]
+    cols = {k: Column(getattr(t, k), n) for k in names}
+    res = ParseResult(n, cols, t.err)
+    lib().orc_fasta_free(C.byref(t))
+    return res
+
+
+VCF_FIELDS = ["chrom", "pos", "id", "ref", "alt", "qual", "filter", "info", "formats"]
+
+
+def vcf_parse(data, payload_base=0, want_string_t=True):
+    arr, ptr = _as_buf(data)
+    t = VcfTable()
+    n = int(lib().orc_vcf_parse(ptr, arr.size, C.byref(t)))
+    cols = {VCF_FIELDS[k]: Column(t.fields[k], n) for k in range(9)}
+    st = {VCF_FIELDS[k]: _string_t(t.fields[k], n, 1, payload_base) for k in range(9)} if want_string_t else {}
+    extra = {
+        "pos": np.ctypeslib.as_array(t.pos.data, shape=(max(n, 1),))[:n].copy() if n else np.zeros(0, np.int64),
+        "qual": np.ctypeslib.as_array(t.qual.data, shape=(max(n, 1),))[:n].copy() if n else np.zeros(0, np.float32),
+        "qual_valid": np.ctypeslib.as_array(t.qual.valid, shape=(max(n, 1),))[:n].copy() if n else np.zeros(0, np.uint8),
+        "header_bytes": int(t.header_bytes),
+        "n_header_lines": int(t.n_header_lines),
+    }
+    res = ParseResult(n, cols, t.err, st, extra)
+    lib().orc_vcf_free(C.byref(t))
+    return res
+
+
+def is_valid_utf8(b: bytes) -> bool:
+    arr, ptr = _as_buf(b)
+    return bool(lib().orc_is_valid_utf8(ptr, arr.size))
+
+
+def synth_fastq(n_bytes, file_offset=0, seed=SYNTH_FASTQ_SEED):
+    out = np.empty(n_bytes, np.uint8)
+    if n_bytes:
+        lib().orc_synth_fastq(out.ctypes.data, file_offset, n_bytes, seed)
+    return out
+
+
+def _synth_var(fn, n, seed, cap):
+    out = np.empty(cap, np.uint8)
+    got = int(fn(out.ctypes.data, cap, n, seed))
+    return out[:got].copy()
+
+
+def synth_fastq_ragged(n_records, seed=SYNTH_FASTQ_SEED + 1):
+    return _synth_var(lib().orc_synth_fastq_ragged, n_records, seed, n_records * 720 + 4096)
+
+
+def synth_vcf(n_lines, seed=SYNTH_VCF_SEED):
+    return _synth_var(lib().orc_synth_vcf, n_lines, seed, n_lines * 160 + 8192)
+
+
+def synth_fasta(n_records, seed=SYNTH_FASTA_SEED):
+    return _synth_var(lib().orc_synth_fasta, n_records, seed, n_records * 3300 + 4096)
+
+
+def fastq_scan_baseline(data):
+    arr, ptr = _as_buf(data)
+    chk = C.c_uint64(0)
+    n = int(lib().orc_fastq_scan_baseline(ptr, arr.size, C.byref(chk)))
+    return n, int(chk.value)
+
+
+def infer_compression(uri, compression=None):
+    return lib().orc_infer_compression(uri.encode(), compression.encode() if compression is not None else None).decode()
+
+
+def replacement_scan(uri):
+    r = lib().orc_replacement_scan(uri.encode())
+    return r.decode() if r else None

@@ -1,0 +1,195 @@
+"""Named tests for the [RECALLED] noodles / exon rules the oracle restates beyond what the
+reference's sqllogictests pin (parity UNPINNED): a run against a real exon build can falsify each."""
+import pytest
+
+PE = dict(NAME=1, PLUS=2, EOF=3, UTF8=4, FA_PREFIX=5, FA_NAME=6, FA_EMPTY=7, VCF_FIELD=8, VCF_POS=9, VCF_QUAL=10,
+          VCF_HDR=11)
+
+
+def rows(r):
+    return [[r.columns[k].row(i) for k in r.columns] for i in range(r.n_rows)]
+
+
+# ---- FASTQ (noodles-fastq 0.8.0 read_record; exon FASTQArrayBuilder) -------------------------------
+
+def test_fastq_empty_input_is_zero_rows(oracle):
+    r = oracle.fastq_parse(b"")
+    assert r.n_rows == 0 and r.error_code == 0
+
+
+def test_fastq_split_at_first_space_only(oracle):
+    r = oracle.fastq_parse(b"@id a b  c\nAC\n+\n!!\n")
+    assert rows(r) == [[b"id", b"a b  c", b"AC", b"!!"]]
+
+
+def test_fastq_tab_is_not_a_delimiter(oracle):
+    r = oracle.fastq_parse(b"@id\tx\nAC\n+\n!!\n")
+    assert rows(r) == [[b"id\tx", None, b"AC", b"!!"]]
+
+
+def test_fastq_trailing_space_gives_null_description(oracle):
+    r = oracle.fastq_parse(b"@id \nAC\n+\n!!\n")
+    assert rows(r) == [[b"id", None, b"AC", b"!!"]]
+
+
+def test_fastq_empty_name_is_allowed(oracle):
+    r = oracle.fastq_parse(b"@\nAC\n+\n!!\n@ d\nAC\n+\n!!\n")
+    assert rows(r) == [[b"", None, b"AC", b"!!"], [b"", b"d", b"AC", b"!!"]]
+
+
+def test_fastq_crlf_is_stripped(oracle):
+    r = oracle.fastq_parse(b"@id d\r\nAC\r\n+\r\n!!\r\n")
+    assert rows(r) == [[b"id", b"d", b"AC", b"!!"]]
+
+
+def test_fastq_plus_line_content_is_discarded(oracle):
+    r = oracle.fastq_parse(b"@id\nAC\n+id again\n!!\n")
+    assert rows(r) == [[b"id", None, b"AC", b"!!"]]
+
+
+def test_fastq_quality_may_start_with_at(oracle):
+    r = oracle.fastq_parse(b"@a\nAC\n+\n@!\n@b\nGT\n+\n@@\n")
+    assert rows(r) == [[b"a", None, b"AC", b"@!"], [b"b", None, b"GT", b"@@"]]
+
+
+def test_fastq_no_trailing_newline(oracle):
+    r = oracle.fastq_parse(b"@a\nAC\n+\n!!")
+    assert rows(r) == [[b"a", None, b"AC", b"!!"]] and r.error_code == 0
+
+
+def test_fastq_cr_before_eof_without_lf_is_kept(oracle):
+    r = oracle.fastq_parse(b"@a\nAC\n+\n!!\r")
+    assert rows(r) == [[b"a", None, b"AC", b"!!\r"]]
+
+
+def test_fastq_missing_quality_line_is_empty_quality(oracle):
+    # read_line returns 0 bytes at EOF without error
+    r = oracle.fastq_parse(b"@a\nAC\n+\n")
+    assert rows(r) == [[b"a", None, b"AC", b""]] and r.error_code == 0
+    r = oracle.fastq_parse(b"@a\nAC\n+")
+    assert rows(r) == [[b"a", None, b"AC", b""]] and r.error_code == 0
+
+
+def test_fastq_truncated_before_plus_is_unexpected_eof(oracle):
+    for data in (b"@a\n", b"@a", b"@a\nAC\n", b"@a\nAC"):
+        r = oracle.fastq_parse(b"@x\nAC\n+\n!!\n" + data)
+        assert r.n_rows == 1 and r.error_code == PE["EOF"] and r.error_record == 1 and r.error_offset == 11
+
+
+def test_fastq_bad_name_prefix(oracle):
+    r = oracle.fastq_parse(b"@x\nAC\n+\n!!\nx\nAC\n+\n!!\n")
+    assert r.n_rows == 1 and r.error_code == PE["NAME"] and r.error_record == 1 and r.error_offset == 11
+
+
+def test_fastq_blank_line_between_records_is_an_error(oracle):
+    r = oracle.fastq_parse(b"@x\nAC\n+\n!!\n\n@y\nAC\n+\n!!\n")
+    assert r.n_rows == 1 and r.error_code == PE["NAME"]
+
+
+def test_fastq_trailing_blank_line_is_an_error(oracle):
+    r = oracle.fastq_parse(b"@x\nAC\n+\n!!\n\n")
+    assert r.n_rows == 1 and r.error_code == PE["NAME"] and r.error_record == 1
+
+
+def test_fastq_bad_plus_prefix(oracle):
+    r = oracle.fastq_parse(b"@x\nAC\n-\n!!\n")
+    assert r.n_rows == 0 and r.error_code == PE["PLUS"] and r.error_record == 0 and r.error_offset == 0
+    r = oracle.fastq_parse(b"@x\nAC\n\n!!\n")
+    assert r.error_code == PE["PLUS"]
+
+
+def test_fastq_invalid_utf8_is_an_error(oracle):
+    r = oracle.fastq_parse(b"@x\nAC\n+\n!!\n@y \xff\nAC\n+\n!!\n")
+    assert r.n_rows == 1 and r.error_code == PE["UTF8"] and r.error_record == 1
+    r = oracle.fastq_parse("@é ü\nAC\n+\n!!\n".encode())
+    assert r.error_code == 0 and rows(r) == [["é".encode(), "ü".encode(), b"AC", b"!!"]]
+
+
+def test_fastq_structural_error_wins_over_utf8_in_the_same_record(oracle):
+    r = oracle.fastq_parse(b"@y \xff\nAC\n-\n!!\n")
+    assert r.error_code == PE["PLUS"]
+
+
+# ---- FASTA (noodles-fasta 0.27.0 read_definition / read_sequence; Definition::from_str) ---------------
+
+def test_fasta_multiline_sequence_is_concatenated(oracle):
+    r = oracle.fasta_parse(b">a d\nAC\nGT\n\nTT\n>b\nA\n")
+    assert rows(r) == [[b"a", b"d", b"ACGTTT"], [b"b", None, b"A"]]
+
+
+def test_fasta_description_is_trimmed_and_split_on_ascii_whitespace(oracle):
+    r = oracle.fasta_parse(b">a\t  two words \nAC\n")
+    assert rows(r) == [[b"a", b"two words", b"AC"]]
+
+
+def test_fasta_trailing_space_gives_empty_not_null_description(oracle):
+    r = oracle.fasta_parse(b">a \nAC\n")
+    assert rows(r) == [[b"a", b"", b"AC"]]
+
+
+def test_fasta_crlf(oracle):
+    r = oracle.fasta_parse(b">a d\r\nAC\r\nGT\r\n")
+    assert rows(r) == [[b"a", b"d", b"ACGT"]]
+
+
+def test_fasta_empty_sequence_is_allowed(oracle):
+    r = oracle.fasta_parse(b">a\n>b\nAC\n")
+    assert rows(r) == [[b"a", None, b""], [b"b", None, b"AC"]]
+
+
+def test_fasta_errors(oracle):
+    assert oracle.fasta_parse(b"ACGT\n>a\nAC\n").error_code == PE["FA_PREFIX"]
+    assert oracle.fasta_parse(b"\n>a\nAC\n").error_code == PE["FA_EMPTY"]
+    r = oracle.fasta_parse(b">a\nAC\n> desc only\nAC\n")
+    assert r.n_rows == 1 and r.error_code == PE["FA_NAME"] and r.error_record == 1
+    assert oracle.fasta_parse(b">a \xff\nAC\n").error_code == PE["UTF8"]
+    assert oracle.fasta_parse(b"").n_rows == 0
+
+
+def test_fasta_gt_inside_a_sequence_line_is_data(oracle):
+    r = oracle.fasta_parse(b">a\nAC>GT\n")
+    assert rows(r) == [[b"a", None, b"AC>GT"]]
+
+
+# ---- VCF (noodles-vcf 0.34.0, tokenising level) ------------------------------------------------------
+
+HDR = b"##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n"
+
+
+def test_vcf_eight_columns_and_rest(oracle):
+    r = oracle.vcf_parse(HDR + b"1\t5\t.\tA\tC\t.\tPASS\tDP=1\n2\t6\trs1\tA\tC,G\t1e2\tq10\t.\tGT\t0/1\t1/1\n")
+    assert r.error_code == 0 and r.n_rows == 2
+    assert rows(r)[0] == [b"1", b"5", b".", b"A", b"C", b".", b"PASS", b"DP=1", None]
+    assert rows(r)[1][-1] == b"GT\t0/1\t1/1"
+    assert list(r.extra["pos"]) == [5, 6]
+    assert list(r.extra["qual_valid"]) == [0, 1] and float(r.extra["qual"][1]) == 100.0
+
+
+def test_vcf_errors(oracle):
+    assert oracle.vcf_parse(b"1\t5\t.\tA\tC\t.\tPASS\tDP=1\n").error_code == PE["VCF_HDR"]
+    assert oracle.vcf_parse(HDR + b"1\t5\t.\tA\tC\t.\tPASS\n").error_code == PE["VCF_FIELD"]
+    assert oracle.vcf_parse(HDR + b"1\tx5\t.\tA\tC\t.\tPASS\t.\n").error_code == PE["VCF_POS"]
+    assert oracle.vcf_parse(HDR + b"1\t5\t.\tA\tC\tabc\tPASS\t.\n").error_code == PE["VCF_QUAL"]
+    r = oracle.vcf_parse(HDR + b"1\t5\t.\tA\tC\t.\tPASS\t.\n\n")
+    assert r.n_rows == 1 and r.error_code == PE["VCF_FIELD"]   # blank data line
+
+
+def test_vcf_last_line_without_newline_and_crlf(oracle):
+    r = oracle.vcf_parse(HDR + b"1\t5\t.\tA\tC\t3.5\tPASS\tX\r\n1\t7\t.\tA\tC\t.\t.\tY")
+    assert r.n_rows == 2 and rows(r)[0][7] == b"X" and rows(r)[1][7] == b"Y"
+
+
+# ---- from_utf8 ---------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("b,ok", [
+    (b"plain", True), ("é€😀".encode(), True), (b"\xc0\xaf", False), (b"\xed\xa0\x80", False),
+    (b"\xf4\x90\x80\x80", False), (b"\xe2\x82", False), (b"\x80", False), (b"\xf0\x9f\x98\x80", True),
+])
+def test_utf8_acceptance(oracle, b, ok):
+    assert oracle.is_valid_utf8(b) == ok
+    try:
+        b.decode("utf-8")
+        py_ok = True
+    except UnicodeDecodeError:
+        py_ok = False
+    assert py_ok == ok
