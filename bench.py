@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py — FASTQ records/s into DataChunk column vectors on MI355X (BASELINE.json metric).
+
+A step = one pass of the hot path (exg_fastq_scan through the C-ABI) over one device-resident
+batch of synthetic 150 bp FASTQ (332 B/record, generated in HBM by exg_synth_fastq).  N=1 runs
+BASELINE configs[1] (10 GB on one MI355X).  N>1: one process per GPU (torch.distributed, RCCL),
+the file is byte-range sharded — each rank scans its own 10 GB shard of an N x 10 GB file whose
+cut points are NOT record aligned (1 KiB halo, global line phase from the shard-local structure,
+verified by an all_gather of the newline counts) — weak scaling, no collective on the data path;
+one all_reduce of the record counts per step (the COUNT(*) of config 5).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+REC = 332
+
+
+def cpu_baseline(seconds_target=12.0):
+    """Oracle ("port") timed on one host core, like the reference (one core per file)."""
+    import numpy as np
+    from oracle import pyoracle
+
+    n_rec = 1_000_000  # 332 MB sample of the same workload
+    data = pyoracle.synth_fastq(REC * n_rec)
+    t0 = time.perf_counter()
+    total = 0
+    reps = 0
+    while True:
+        n, _ = pyoracle.fastq_scan_baseline(data)
+        assert n == n_rec
+        total += n
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds_target or reps >= 64:
+            break
+    return {
+        "value": total / dt,
+        "unit": "records/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{reps} x {n_rec} records ({REC * n_rec / 1e6:.0f} MB synthetic FASTQ-150, in memory), "
+                  f"oracle read_batch(2048)+ArrowToDuckDB loop, {dt:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--gb", type=float, default=10.0, help="shard size per GPU in GB (1e9 bytes)")
+    ap.add_argument("--algo", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from exon_duckdb_amd import abi, device, load_library
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the record scan has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    lib = load_library()
+
+    shard = int(args.gb * 1e9) // 16 * 16          # 16-byte aligned cut points, not record aligned
+    halo = 1024 if rank > 0 else 0
+    start = rank * shard
+    end = start + shard
+    file_bytes = world * shard
+    is_last = rank == world - 1
+    if is_last:
+        end = file_bytes = (file_bytes // REC) * REC   # the file ends on a record boundary
+    n_bytes = end - (start - halo)
+    d_in = device.synth_fastq(n_bytes, file_offset=start - halo)
+    cap = n_bytes // REC + 16
+    scan = device.FastqScan(n_bytes, capacity_records=cap)
+
+    # global line phase of the shard start: the generator makes it analytic, the product derives it
+    # from the bytes (count of '\n' before the shard = all_gather of per-shard counts, verified below)
+    import ctypes as C
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    device.check(lib.exg_count_newlines(C.c_void_p(d_in.data_ptr()), halo, n_bytes, C.c_void_p(cnt.data_ptr()),
+                                        device.stream_ptr()))
+    if world > 1:
+        counts = [torch.zeros_like(cnt) for _ in range(world)]
+        dist.all_gather(counts, cnt)                 # 8 bytes per rank over RCCL
+        first_line_index = int(sum(int(c.item()) for c in counts[:rank]))
+    else:
+        first_line_index = 0
+    flags = (abi.EXG_F_BOF if rank == 0 else 0) | (abi.EXG_F_EOF if is_last else 0)
+
+    def step():
+        scan.launch(d_in, n_bytes=n_bytes, lead=halo, first_line_index=first_line_index,
+                    payload_base=0x100000000000 + start - halo, flags=flags, algo=args.algo)
+
+    total = torch.zeros(1, dtype=torch.int64, device="cuda")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    res = scan.fetch()
+    assert res.error_code == 0 and not (res.flags & abi.EXG_RF_FALLBACK), (res.error_code, res.flags)
+    n_rec_local = int(res.n_records)
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        step()
+        ev[i][1].record()
+        if world > 1:
+            # COUNT(*) of the whole file: one 8-byte all_reduce per step
+            total.copy_(scan.result[:1])
+            dist.all_reduce(total)
+    barrier()
+    dt = time.perf_counter() - t0
+    res = scan.fetch()
+    assert res.error_code == 0 and int(res.n_records) == n_rec_local
+
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    nrec = torch.tensor([n_rec_local], dtype=torch.int64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(nrec)
+        assert int(total.item()) == int(nrec.item()), "COUNT(*) all_reduce disagrees"
+    dt = float(t.item())
+    total_records = int(nrec.item())
+    assert total_records == file_bytes // REC, (total_records, file_bytes // REC)
+
+    if rank == 0:
+        # per-launch device time of the scan (all kernels of one exg_fastq_scan call) from HIP events
+        # on the launch stream; the dominant kernel is k_fastq_fused (see profiles/)
+        ms = sorted(a.elapsed_time(b) for a, b in ev)
+        avg_ms = sum(ms) / len(ms)
+        achieved = n_bytes / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_fastq_fused.json")
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch_10GB")
+        out = {
+            "metric": "FASTQ records/sec into DataChunks",
+            "value": total_records * args.steps / dt,
+            "unit": "records/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": f"read_fastq on {shard * world / 1e9:.0f} GB synthetic 150 bp FASTQ "
+                            f"({REC} B/record, {total_records} records), {world}x MI355X, byte-range shards",
+                "bytes_per_gpu": n_bytes,
+                "algo": {0: "auto(fused+gated general path)", 1: "multipass", 2: "fused"}[args.algo],
+                "columns": "name,description,sequence,quality_scores as duckdb::string_t + validity",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": traffic,
+                "kernel": "exg_fastq_scan launch (k_fastq_fused dominant)",
+                "algorithmic_bytes_per_launch": n_bytes,
+                "avg_launch_ms": avg_ms,
+                "min_launch_ms": ms[0],
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

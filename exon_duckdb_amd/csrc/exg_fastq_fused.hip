@@ -7,9 +7,11 @@
 // construction called at exon/src/exon/arrow_table_function/module.cpp:289.
 //
 // Design (MI355X / gfx950, wave64, HBM-bound byte work, no MFMA):
-//   * one 256-thread workgroup per 16 KiB tile, tile ids handed out by an atomic ticket so that
-//     every lower-numbered tile has started (forward progress of the look-back, whatever the
-//     dispatch order or XCD placement);
+//   * one 256-thread workgroup per 16 KiB tile, tile = blockIdx.x.  No ticket counter: a single
+//     hot atomic word caps the chip at ~90 tiles/us (measured: 3 such words held the first version
+//     at 0.3 TB/s).  Forward progress does not depend on dispatch order either: a look-back that
+//     waits longer than ~40 us for a predecessor's descriptor counts that tile's newlines itself
+//     ("helping"), so a block never blocks on an undispatched block;
 //   * coalesced 16 B/lane global loads -> LDS (each input byte leaves HBM once); the 1 KiB that
 //     precedes the tile is staged too, so the record straddling the tile's left edge is resolved
 //     from LDS (a record larger than that window raises `overflow` and the general multipass
@@ -124,16 +126,32 @@ __device__ bool utf8_valid_lds(const FusedLds &s, int b, int e) {
     return true;
 }
 
+// '\n' count of tile t, by one wave, straight from global memory (look-back helping path)
+__device__ unsigned long long help_count_tile(const uint8_t *__restrict__ d_in, uint64_t n_bytes, uint32_t t,
+                                              uint32_t lane) {
+    uint64_t tile_off = (uint64_t)t * kTile;
+    uint32_t cnt = 0;
+    for (int j = 0; j < kTile / 1024; j++) {
+        uint64_t off = tile_off + (uint64_t)(j * 64 + lane) * 16;
+        if (off < n_bytes) {
+            uint4 q = *reinterpret_cast<const uint4 *>(d_in + off);
+            uint32_t mm = match16(q, 0x0A0A0A0Au);
+            if (off + 16 > n_bytes) mm &= (1u << (uint32_t)(n_bytes - off)) - 1u;
+            cnt += __popc(mm);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+    return (unsigned long long)__shfl(cnt, 0, 64);
+}
+
 __global__ __launch_bounds__(kThreads) void k_fastq_fused(FastqDev a, unsigned long long *__restrict__ desc,
+                                                          unsigned long long *__restrict__ tile_qend,
                                                           ScanWsHeader *hdr, uint32_t n_tiles) {
     __shared__ __attribute__((aligned(16))) FusedLds s;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63, wave = tid >> 6;
 
-    if (tid == 0) s.tile = atomicAdd(&hdr->ticket, 1u);
-    __syncthreads();
-    const uint32_t tile = s.tile;
-    if (tile >= n_tiles) return;
+    const uint32_t tile = blockIdx.x;
     const uint64_t tile_off = (uint64_t)tile * kTile;
     const uint8_t *__restrict__ d_in = a.d_in;
     const uint64_t n_pad = (a.n_bytes + 15) & ~15ull;
@@ -219,10 +237,24 @@ __global__ __launch_bounds__(kThreads) void k_fastq_fused(FastqDev a, unsigned l
             for (;;) {
                 int64_t idx = base - lane;
                 unsigned long long d;
+                unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
                 for (;;) {
                     d = idx >= 0 ? __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kStatusP;
-                    if (!__any((d >> 62) == 0)) break;
-                    __builtin_amdgcn_s_sleep(1);
+                    unsigned long long missing = __ballot((d >> 62) == 0);
+                    if (!missing) break;
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 4000) {
+                        // ~40 us without a descriptor: that block may not have been dispatched.
+                        // Count its tile ourselves (any dispatch order makes progress).
+                        while (missing) {
+                            int l = __ffsll((long long)missing) - 1;
+                            missing &= missing - 1;
+                            uint32_t ht = (uint32_t)(base - l);
+                            unsigned long long c = help_count_tile(d_in, a.n_bytes, ht, lane);
+                            if ((int)lane == l) d = kStatusA | c;
+                        }
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
                 }
                 unsigned long long pm = __ballot((d >> 62) == 2);
                 unsigned long long val = d & kValueMask;
@@ -292,6 +324,14 @@ __global__ __launch_bounds__(kThreads) void k_fastq_fused(FastqDev a, unsigned l
     const uint32_t n_rec = n_lines > i_first ? (n_lines - i_first + 3) / 4 : 0;
     const uint64_t ptr_of_p0 = a.payload_base + tile_off;
 
+    if (tid == 0) {  // offset just past the last quality line that ends in this tile (0: none)
+        long long e = 0;
+        if (n_rec) {
+            e = (long long)tile_off + s.nlist[4 + i_first + 4 * (n_rec - 1)] + 1;
+            if ((unsigned long long)e > a.n_bytes) e = (long long)a.n_bytes;
+        }
+        tile_qend[tile] = (unsigned long long)e;
+    }
     for (uint32_t jb = 0; jb < n_rec; jb += kThreads) {  // one pass unless > 256 records end here
         uint32_t j = jb + tid;
         bool desc_valid = false;
@@ -387,20 +427,34 @@ __global__ __launch_bounds__(kThreads) void k_fastq_fused(FastqDev a, unsigned l
                 if (hi2) atomicOr((unsigned long long *)&a.d_desc_valid[(out_base >> 6) + 1], hi2);
             }
         }
-        // offset just past the last owned record of the tile
-        unsigned long long am = __ballot(act);
-        if (am && lane == 63 - __clzll((long long)am)) {
-            int i = (int)(i_first + 4 * j);
-            long long e = (long long)tile_off + s.nlist[4 + i] + 1;
-            if ((unsigned long long)e > a.n_bytes) e = (long long)a.n_bytes;
-            atomicMax(&hdr->consumed, (unsigned long long)e);
-        }
     }
 }
 
 // Runs after k_fastq_fused on the same stream: folds the header into the 64-byte result.
-__global__ void k_fastq_finalize_fused(FastqDev a, ScanWsHeader *hdr, exg_scan_result *res) {
-    if (threadIdx.x || blockIdx.x) return;
+__global__ __launch_bounds__(256) void k_fastq_finalize_fused(FastqDev a, ScanWsHeader *hdr,
+                                                                const unsigned long long *__restrict__ tile_qend,
+                                                                uint32_t n_tiles, exg_scan_result *res) {
+    // last tile (searching backwards) in which a quality line ends
+    __shared__ unsigned long long s_qend;
+    __shared__ int s_found;
+    if (threadIdx.x == 0) {
+        s_qend = 0;
+        s_found = 0;
+    }
+    __syncthreads();
+    if (!hdr->overflow) {
+        for (int64_t base = (int64_t)n_tiles - 1; base >= 0; base -= 256) {
+            int64_t t = base - threadIdx.x;
+            unsigned long long q = t >= 0 ? tile_qend[t] : 0;
+            if (q) atomicMax(&s_qend, q);
+            if (q) s_found = 1;
+            __syncthreads();
+            if (s_found) break;
+        }
+    }
+    __syncthreads();
+    const unsigned long long last_qend = s_qend;
+    if (threadIdx.x) return;
     if (hdr->overflow) {  // the general kernels that follow on the stream overwrite this
         exg_scan_result r = {};
         r.flags = EXG_RF_FALLBACK;
@@ -416,12 +470,16 @@ __global__ void k_fastq_finalize_fused(FastqDev a, ScanWsHeader *hdr, exg_scan_r
     uint64_t n_hc = halo_nl > i0 ? (halo_nl - i0 + 3) / 4 : 0;
     uint64_t n_owned = n_cand - (n_hc < n_cand ? n_hc : n_cand);
     unsigned long long err = hdr->err_word, err_off = hdr->err_off;
-    uint64_t consumed = hdr->consumed > a.lead ? hdr->consumed : a.lead;
+    uint64_t consumed = last_qend > a.lead ? last_qend : a.lead;
     if ((a.flags & EXG_F_EOF) && ((p0 + T) & 3) != 0 && T > halo_nl) {
-        unsigned long long w = ((unsigned long long)n_owned << 8) | EXG_PE_UNEXPECTED_EOF;
+        // the truncated record starts where the last complete one ended; the reader checks its '@'
+        // before it can run out of lines
+        uint64_t start = last_qend;
+        uint32_t code = (start < a.n_bytes && a.d_in[start] == '@') ? EXG_PE_UNEXPECTED_EOF : EXG_PE_FASTQ_NAME_PREFIX;
+        unsigned long long w = ((unsigned long long)n_owned << 8) | code;
         if (w < err) {
             err = w;
-            err_off = consumed;  // the truncated record starts where the last complete one ended
+            err_off = start;
         }
     }
     exg_scan_result r;
@@ -465,8 +523,10 @@ int run_fastq_fused(const exg_fastq_scan_args *args, const FastqDev &dev, uint8_
         int rc = exg_count_newlines(dev.d_in, 0, dev.lead, (uint64_t *)&hdr->halo_nl, stream);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_fastq_fused, dim3(n_tiles), dim3(kThreads), 0, stream, dev, desc, hdr, n_tiles);
-    hipLaunchKernelGGL(k_fastq_finalize_fused, dim3(1), dim3(1), 0, stream, dev, hdr, args->d_result);
+    unsigned long long *tile_qend = desc + l.n_tiles_fused;
+    hipLaunchKernelGGL(k_fastq_fused, dim3(n_tiles), dim3(kThreads), 0, stream, dev, desc, tile_qend, hdr, n_tiles);
+    hipLaunchKernelGGL(k_fastq_finalize_fused, dim3(1), dim3(256), 0, stream, dev, hdr, tile_qend, n_tiles,
+                       args->d_result);
     EXG_HIP_CHECK(hipGetLastError());
     return EXG_OK;
 }

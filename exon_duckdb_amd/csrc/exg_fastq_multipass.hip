@@ -199,7 +199,11 @@ __global__ void k_fastq_finalize_mp(FastqDev a, const uint64_t *__restrict__ nl_
     unsigned long long err = hdr->err_word;
     uint64_t p0 = a.first_line_index - hdr->halo_nl;
     if ((a.flags & EXG_F_EOF) && ((p0 + T) & 3) != 0 && T > hdr->halo_nl) {
-        unsigned long long w = ((unsigned long long)n_owned << 8) | EXG_PE_UNEXPECTED_EOF;
+        // the reader checks '@' before it can run out of lines
+        int64_t name_li = (int64_t)(c.i0 + 4 * c.n_cand) - 3;
+        uint64_t start = name_li - 1 >= 0 ? nl_pos[name_li - 1] + 1 : 0;
+        uint32_t code = (start < a.n_bytes && a.d_in[start] == '@') ? EXG_PE_UNEXPECTED_EOF : EXG_PE_FASTQ_NAME_PREFIX;
+        unsigned long long w = ((unsigned long long)n_owned << 8) | code;
         if (w < err) err = w;
     }
     exg_scan_result r;
@@ -242,7 +246,8 @@ __global__ void k_init_hdr(ScanWsHeader *hdr, uint64_t lines_cap, uint32_t mode)
     unsigned int overflow = hdr->overflow;
     if (mode == 1 && overflow == 0) return;
     ScanWsHeader h;
-    for (int i = 0; i < 22; i++) h.pad[i] = 0;
+    for (int i = 0; i < 21; i++) h.pad[i] = 0;
+    h.last_qend = 0;
     h.total_nl = h.total_lines = h.halo_nl = h.n_unresolved = 0;
     h.err_word = kNoError;
     h.err_off = ~0ull;

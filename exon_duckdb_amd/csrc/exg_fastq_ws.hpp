@@ -27,7 +27,8 @@ struct alignas(256) ScanWsHeader {
     unsigned long long lines_cap;    // capacity of nl_pos
     unsigned long long err_off;      // atomicMin: start offset of a failing record; ~0 = none
     unsigned long long consumed;     // atomicMax: offset just past the last owned quality line
-    unsigned long long pad[22];
+    unsigned long long last_qend;    // atomicMax: offset just past the last quality line, owned or not
+    unsigned long long pad[21];
 };
 static_assert(sizeof(ScanWsHeader) == 256, "header is 256 bytes");
 
@@ -36,7 +37,7 @@ struct FastqWsLayout {
     uint64_t n_tiles_fused;
     uint64_t off_tile_counts;   // u32[n_tiles_mp]
     uint64_t off_tile_offsets;  // u64[n_tiles_mp]
-    uint64_t off_tile_desc;     // u64[n_tiles_fused]  (fused look-back descriptors)
+    uint64_t off_tile_desc;     // u64[n_tiles_fused] look-back descriptors + u64[n_tiles_fused] tile_qend
     uint64_t off_nl_pos;        // u64[lines_cap]
     uint64_t lines_cap;
     uint64_t total_bytes;
@@ -57,7 +58,7 @@ static inline FastqWsLayout fastq_ws_layout(uint64_t n_bytes, uint64_t ws_bytes_
     l.off_tile_offsets = at;
     at = round_up(at + l.n_tiles_mp * 8, 256);
     l.off_tile_desc = at;
-    at = round_up(at + l.n_tiles_fused * 8, 256);
+    at = round_up(at + l.n_tiles_fused * 16, 256);  // descriptors, then per-tile last-quality-line ends
     l.off_nl_pos = at;
     uint64_t want = n_bytes / 8;
     uint64_t small = n_bytes < (1ull << 20) ? n_bytes : (1ull << 20);

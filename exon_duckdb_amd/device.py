@@ -48,7 +48,7 @@ class FastqScan:
         torch = _torch()
         self.lib = load_library()
         self.n_bytes = n_bytes
-        self.capacity = int(capacity_records if capacity_records is not None else n_bytes // 8 + 16)
+        self.capacity = int(capacity_records if capacity_records is not None else n_bytes // 4 + 16)
         cap = max(self.capacity, 1)
         self.cols = [torch.empty((cap, 2), dtype=torch.int64, device=device) for _ in range(4)]
         self.validity = torch.empty(((cap + 63) // 64,), dtype=torch.int64, device=device)
