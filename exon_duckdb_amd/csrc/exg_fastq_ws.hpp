@@ -51,14 +51,14 @@ static inline uint64_t round_up(uint64_t v, uint64_t a) { return (v + a - 1) / a
 static inline FastqWsLayout fastq_ws_layout(uint64_t n_bytes, uint64_t ws_bytes_or_0) {
     FastqWsLayout l;
     l.n_tiles_mp = (n_bytes + kMpTileBytes - 1) / kMpTileBytes + 1;
-    l.n_tiles_fused = (n_bytes + kFusedTileBytes - 1) / kFusedTileBytes + 1;
+    l.n_tiles_fused = (n_bytes + kFusedTileBytes - 1) / kFusedTileBytes + 2;
     uint64_t at = sizeof(ScanWsHeader);
     l.off_tile_counts = at;
     at = round_up(at + l.n_tiles_mp * 4, 256);
     l.off_tile_offsets = at;
     at = round_up(at + l.n_tiles_mp * 8, 256);
     l.off_tile_desc = at;
-    at = round_up(at + l.n_tiles_fused * 16, 256);  // descriptors, then per-tile last-quality-line ends
+    at = round_up(at + l.n_tiles_fused * 24, 256);  // tileA, tileP, tile_qend
     l.off_nl_pos = at;
     uint64_t want = n_bytes / 8;
     uint64_t small = n_bytes < (1ull << 20) ? n_bytes : (1ull << 20);

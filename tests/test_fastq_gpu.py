@@ -36,9 +36,12 @@ def check_against_oracle(oracle, data, algo, expect_fallback=None):
     data = bytes(data)
     exp = oracle.fastq_parse(data, payload_base=BASE)
     res, cols, words = run_gpu(data, algo)
+    non_ascii = any(b >= 0x80 for b in data)   # UTF-8 validation is left to the general path
     if algo == abi.EXG_ALGO_FUSED and (res.flags & abi.EXG_RF_FALLBACK):
-        assert expect_fallback, "fused kernel unexpectedly asked for the general path"
+        assert expect_fallback or non_ascii, "fused kernel unexpectedly asked for the general path"
         return res
+    if non_ascii and algo == abi.EXG_ALGO_AUTO:
+        assert res.flags & abi.EXG_RF_FALLBACK
     if expect_fallback is True and algo == abi.EXG_ALGO_AUTO:
         assert res.flags & abi.EXG_RF_FALLBACK
     assert res.error_code == exp.error_code, (res.error_code, exp.error_code, exp.error_message)
