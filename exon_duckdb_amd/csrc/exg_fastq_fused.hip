@@ -172,12 +172,10 @@ __device__ void scanner_wave(const uint8_t *__restrict__ d_in, uint64_t n_bytes,
     }
 }
 
-// Workgroup side (wave 0): publish the count, wait for the exclusive prefix.
-__device__ unsigned long long publish_and_wait(const uint8_t *__restrict__ d_in, uint64_t n_bytes,
-                                               unsigned long long *__restrict__ tileA,
-                                               unsigned long long *__restrict__ tileP, uint32_t st, uint32_t n_nl,
-                                               uint32_t lane) {
-    if (lane == 0) st_desc(&tileA[st], kFlag | n_nl);
+// Workgroup side (wave 0): wait for the exclusive prefix of super-tile st (its count is published).
+__device__ unsigned long long wait_prefix(const uint8_t *__restrict__ d_in, uint64_t n_bytes,
+                                          unsigned long long *__restrict__ tileA,
+                                          unsigned long long *__restrict__ tileP, uint32_t st, uint32_t lane) {
     if (st == 0) return 0;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
@@ -424,17 +422,9 @@ __global__ __launch_bounds__(kThreads, 7) void k_fastq_fused(FastqDev a, unsigne
     const uint32_t n_nl[kHalves] = {both & 0xFFFFu, both >> 16};
     const bool non_ascii = (s.hi_or[0] | s.hi_or[1] | s.hi_or[2] | s.hi_or[3]) != 0;
 
-    // ---- wave 0: publish the super-tile count and wait for its prefix; meanwhile stage half 0 --------
-    if (wave == 0) {
-        unsigned long long pre;
-        if (dev_mode >= 1 && dev_mode <= 3) {
-            uint64_t k = super_off / 332, w = super_off % 332;
-            pre = 4 * k + (w > 27) + (w > 178) + (w > 180);
-        } else {
-            pre = publish_and_wait(d_in, a.n_bytes, tileA, tileP, st, n_nl[0] + n_nl[1], lane);
-        }
-        if (lane == 0) s.prefix = pre;
-    }
+    // ---- publish the super-tile count; its prefix is awaited after half 0 has been staged ---------------
+    const bool analytic = dev_mode >= 1 && dev_mode <= 3;
+    if (tid == 0 && !analytic) st_desc(&tileA[st], kFlag | (unsigned long long)(n_nl[0] + n_nl[1]));
     const unsigned long long halo_nl = rfl64(hdr->halo_nl);
     // Bytes >= 0x80 need UTF-8 validation of every field (the reference builds Arrow Utf8 columns).
     // That is rare in FASTQ and is left to the general path: raise `overflow`, which gates it in.
@@ -510,6 +500,19 @@ __global__ __launch_bounds__(kThreads, 7) void k_fastq_fused(FastqDev a, unsigne
                 mask &= mask - 1;
                 if (r < (uint32_t)kNlCap) s.nlist[4 + r] = (uint16_t)(e0 + b);
                 r++;
+            }
+        }
+        if (h == 0) {
+            // the half is staged while the scanner turns the published count into our prefix
+            if (wave == 0) {
+                unsigned long long pre;
+                if (analytic) {
+                    uint64_t k = super_off / 332, w = super_off % 332;
+                    pre = 4 * k + (w > 27) + (w > 178) + (w > 180);
+                } else {
+                    pre = wait_prefix(d_in, a.n_bytes, tileA, tileP, st, lane);
+                }
+                if (lane == 0) s.prefix = pre;
             }
         }
         __syncthreads();  // staged (and, for h == 0, the prefix has arrived)
