@@ -23,7 +23,7 @@ EXG_PE_VCF_NO_HEADER = 11
 EXG_PE_FIELD_TOO_LONG = 12
 
 EXG_FMT_FASTA, EXG_FMT_FASTQ, EXG_FMT_VCF = 1, 2, 3
-EXG_F_BOF, EXG_F_EOF = 1, 2
+EXG_F_BOF, EXG_F_EOF, EXG_F_NO_STORE = 1, 2, 4
 EXG_RF_NON_ASCII, EXG_RF_HEAD_UNRESOLVED, EXG_RF_FALLBACK, EXG_RF_CAPACITY, EXG_RF_INDEX_OVERFLOW = 1, 2, 4, 8, 16
 EXG_ALGO_AUTO, EXG_ALGO_MULTIPASS, EXG_ALGO_FUSED = 0, 1, 2
 

@@ -1,0 +1,123 @@
+// duck_mini.hpp — the slice of DuckDB v0.8.1's table-function API that the record-scan path
+// touches, restated so the host side can be built and tested without DuckDB (its submodule is
+// empty in the reference tree and no DuckDB headers exist on the build box).
+//
+// Layout-bearing types are bit-compatible with DuckDB v0.8.1:
+//   string_t            == exg_string_t (16 bytes, duckdb/common/types/string_type.hpp)
+//   ValidityMask words  == uint64_t[STANDARD_VECTOR_SIZE / 64], bit set = valid, nullptr = all valid
+//   STANDARD_VECTOR_SIZE == 2048
+// The classes below keep DuckDB's names and member meaning (duckdb/function/table_function.hpp) so
+// that duckdb_shim/exon_extension.cpp — the real binding, compiled where DuckDB headers exist — is
+// a mechanical mapping.
+#pragma once
+#include <stdint.h>
+
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/exon_gpu.h"
+
+namespace exon_amd {
+
+using idx_t = uint64_t;
+static constexpr idx_t STANDARD_VECTOR_SIZE = EXG_VECTOR_SIZE;
+static constexpr idx_t COLUMN_IDENTIFIER_ROW_ID = (idx_t)-1;
+
+enum class LogicalTypeId { VARCHAR = EXG_TYPE_VARCHAR, BIGINT = EXG_TYPE_BIGINT, FLOAT = EXG_TYPE_FLOAT };
+
+struct LogicalType {
+    LogicalTypeId id;
+    bool operator==(const LogicalType &o) const { return id == o.id; }
+};
+
+using string_t = exg_string_t;
+
+// A flat vector that references memory owned by `buffer` (DuckDB: Vector + VectorBuffer).
+struct Vector {
+    LogicalType type{LogicalTypeId::VARCHAR};
+    void *data = nullptr;
+    uint64_t *validity = nullptr;  // nullptr = all rows valid
+    std::shared_ptr<void> buffer;  // keeps data + string payload alive
+};
+
+struct DataChunk {
+    std::vector<Vector> data;
+    idx_t count = 0;
+    idx_t size() const { return count; }
+    void SetCardinality(idx_t n) { count = n; }
+    void Reset() {
+        data.clear();
+        count = 0;
+    }
+};
+
+struct TableFunctionInfo {
+    virtual ~TableFunctionInfo() = default;
+};
+struct FunctionData {
+    virtual ~FunctionData() = default;
+};
+struct GlobalTableFunctionState {
+    virtual ~GlobalTableFunctionState() = default;
+    virtual idx_t MaxThreads() const { return 1; }
+};
+struct LocalTableFunctionState {
+    virtual ~LocalTableFunctionState() = default;
+};
+
+struct TableFunctionBindInput {
+    std::vector<std::string> inputs;                        // positional VARCHAR arguments
+    std::map<std::string, std::string> named_parameters;    // e.g. compression
+    const TableFunctionInfo *info = nullptr;
+};
+struct TableFunctionInitInput {
+    const FunctionData *bind_data = nullptr;
+    std::vector<idx_t> column_ids;  // projection pushdown
+};
+struct TableFunctionInput {
+    const FunctionData *bind_data = nullptr;
+    LocalTableFunctionState *local_state = nullptr;
+    GlobalTableFunctionState *global_state = nullptr;
+};
+
+struct TableFunction {
+    using bind_t = std::function<std::unique_ptr<FunctionData>(TableFunctionBindInput &, std::vector<LogicalType> &,
+                                                               std::vector<std::string> &)>;
+    using init_global_t = std::function<std::unique_ptr<GlobalTableFunctionState>(TableFunctionInitInput &)>;
+    using init_local_t =
+        std::function<std::unique_ptr<LocalTableFunctionState>(TableFunctionInitInput &, GlobalTableFunctionState *)>;
+    using function_t = std::function<void(TableFunctionInput &, DataChunk &)>;
+
+    std::string name;
+    std::vector<LogicalType> arguments;
+    function_t function;
+    bind_t bind;
+    init_global_t init_global;
+    init_local_t init_local;
+    std::map<std::string, LogicalType> named_parameters;
+    std::shared_ptr<TableFunctionInfo> function_info;
+    bool projection_pushdown = false;
+    bool filter_pushdown = false;
+};
+
+class Catalog {
+public:
+    void CreateTableFunction(const TableFunction &f) { functions_[f.name] = f; }
+    const TableFunction *GetTableFunction(const std::string &name) const {
+        auto it = functions_.find(name);
+        return it == functions_.end() ? nullptr : &it->second;
+    }
+    std::vector<std::string> Names() const {
+        std::vector<std::string> n;
+        for (auto &kv : functions_) n.push_back(kv.first);
+        return n;
+    }
+
+private:
+    std::map<std::string, TableFunction> functions_;
+};
+
+}  // namespace exon_amd

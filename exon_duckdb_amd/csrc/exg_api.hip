@@ -75,7 +75,7 @@ extern "C" int exg_fastq_scan(const exg_fastq_scan_args *a) {
         set_error("exg_fastq_scan: bad arguments (null pointer, unaligned input or lead > n_bytes)");
         return EXG_E_INVALID_ARG;
     }
-    if (a->capacity_records &&
+    if (a->capacity_records && !(a->flags & EXG_F_NO_STORE) &&
         (!a->d_name || !a->d_description || !a->d_sequence || !a->d_quality || !a->d_description_validity)) {
         set_error("exg_fastq_scan: null output column");
         return EXG_E_INVALID_ARG;
@@ -103,7 +103,7 @@ extern "C" int exg_fastq_scan(const exg_fastq_scan_args *a) {
     dev.capacity = a->capacity_records;
     hipStream_t stream = (hipStream_t)a->stream;
     uint8_t *ws = (uint8_t *)a->d_workspace;
-    if (a->capacity_records)
+    if (a->capacity_records && !(a->flags & EXG_F_NO_STORE))
         EXG_HIP_CHECK(hipMemsetAsync(a->d_description_validity, 0, (size_t)((a->capacity_records + 63) / 64) * 8, stream));
     switch (a->algo) {
         case EXG_ALGO_MULTIPASS:

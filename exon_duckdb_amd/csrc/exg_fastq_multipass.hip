@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void k_fastq_records(FastqDev a, const uint64_
         uint64_t j = it * 64 + lane_id();
         bool owned = j < c.n_cand && j >= c.n_hc;
         int64_t out = (int64_t)j - (int64_t)c.n_hc;
-        bool in_cap = owned && (uint64_t)out < a.capacity;
+        const bool no_store = (a.flags & EXG_F_NO_STORE) != 0;
+        bool in_cap = owned && (no_store || (uint64_t)out < a.capacity);
         if (owned && !in_cap) atomicOr(&hdr->flags, EXG_RF_CAPACITY);
         bool desc_valid = false;
         if (in_cap) {
@@ -94,10 +95,12 @@ __global__ __launch_bounds__(256) void k_fastq_records(FastqDev a, const uint64_
                 atomicAdd(&hdr->n_unresolved, 1ull);
                 atomicOr(&hdr->flags, EXG_RF_HEAD_UNRESOLVED);
                 uint4 z = {0, 0, 0, 0};
-                reinterpret_cast<uint4 *>(a.d_name)[out] = z;
-                reinterpret_cast<uint4 *>(a.d_desc)[out] = z;
-                reinterpret_cast<uint4 *>(a.d_seq)[out] = z;
-                reinterpret_cast<uint4 *>(a.d_qual)[out] = z;
+                if (!no_store) {
+                    reinterpret_cast<uint4 *>(a.d_name)[out] = z;
+                    reinterpret_cast<uint4 *>(a.d_desc)[out] = z;
+                    reinterpret_cast<uint4 *>(a.d_seq)[out] = z;
+                    reinterpret_cast<uint4 *>(a.d_qual)[out] = z;
+                }
             } else {
                 uint32_t code = 0;
                 if (!g.name_ok)
@@ -109,13 +112,15 @@ __global__ __launch_bounds__(256) void k_fastq_records(FastqDev a, const uint64_
                               lens[3] > 0xFFFFFFFFull))
                     code = EXG_PE_FIELD_TOO_LONG;
                 if (code) atomicMin(&hdr->err_word, ((unsigned long long)out << 8) | code);
-                desc_valid = lens[1] != 0;
+                desc_valid = lens[1] != 0 && !no_store;
                 uint4 z = {0, 0, 0, 0};
-                reinterpret_cast<uint4 *>(a.d_name)[out] = make_string_global(d_in, g.s[0], lens[0], a.payload_base);
-                reinterpret_cast<uint4 *>(a.d_desc)[out] =
-                    desc_valid ? make_string_global(d_in, g.desc_s, lens[1], a.payload_base) : z;
-                reinterpret_cast<uint4 *>(a.d_seq)[out] = make_string_global(d_in, g.s[1], lens[2], a.payload_base);
-                reinterpret_cast<uint4 *>(a.d_qual)[out] = make_string_global(d_in, g.s[3], lens[3], a.payload_base);
+                if (!no_store) {
+                    reinterpret_cast<uint4 *>(a.d_name)[out] = make_string_global(d_in, g.s[0], lens[0], a.payload_base);
+                    reinterpret_cast<uint4 *>(a.d_desc)[out] =
+                        desc_valid ? make_string_global(d_in, g.desc_s, lens[1], a.payload_base) : z;
+                    reinterpret_cast<uint4 *>(a.d_seq)[out] = make_string_global(d_in, g.s[1], lens[2], a.payload_base);
+                    reinterpret_cast<uint4 *>(a.d_qual)[out] = make_string_global(d_in, g.s[3], lens[3], a.payload_base);
+                }
             }
         }
         // description validity: one ballot per wave, at most two word updates
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(256) void k_fastq_utf8(FastqDev a, const uint64_t *
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + c.n_hc; j < c.n_cand;
          j += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t out = j - c.n_hc;
-        if (out >= a.capacity) break;
+        if (out >= a.capacity && !(a.flags & EXG_F_NO_STORE)) break;
         FastqGeom g = fastq_geometry(a.d_in, a.n_bytes, nl_pos, (int64_t)(c.i0 + 4 * j), a.flags & EXG_F_BOF);
         if (!g.resolved) continue;
         bool ok = utf8_valid_global(a.d_in, g.s[0], g.name_e) && utf8_valid_global(a.d_in, g.desc_s, g.e[0]) &&
@@ -214,7 +219,7 @@ __global__ void k_fastq_finalize_mp(FastqDev a, const uint64_t *__restrict__ nl_
     r.error_code = 0;
     r.error_offset = ~0ull;
     r.error_record = ~0ull;
-    uint64_t n_rec = n_owned < a.capacity ? n_owned : a.capacity;
+    uint64_t n_rec = (n_owned < a.capacity || (a.flags & EXG_F_NO_STORE)) ? n_owned : a.capacity;
     if (err != kNoError) {
         uint64_t rec = err >> 8;
         r.error_code = (uint32_t)(err & 0xFF);
@@ -277,7 +282,7 @@ int run_fastq_multipass(const exg_fastq_scan_args *args, const FastqDev &dev, ui
         // only in that case (no host round trip on the stream)
         uint64_t words = (dev.capacity + 63) / 64;
         uint32_t g = (uint32_t)((words + 255) / 256 < 1024 ? (words + 255) / 256 : 1024);
-        if (words) hipLaunchKernelGGL(k_clear_words_gated, dim3(g), dim3(256), 0, stream, dev.d_desc_valid, words, gate);
+        if (words && !(dev.flags & EXG_F_NO_STORE)) hipLaunchKernelGGL(k_clear_words_gated, dim3(g), dim3(256), 0, stream, dev.d_desc_valid, words, gate);
     }
     int rc = launch_line_index(dev.d_in, dev.n_bytes, dev.lead, ws, l, (dev.flags & EXG_F_EOF) ? 2 : 0,
                                dev.first_line_index, stream, gate);

@@ -1,0 +1,409 @@
+// exg_fused_core.hpp — the single-pass skeleton shared by the fused record-scan kernels.
+//
+// (see exg_fastq_fused.hip for the design rationale and the measurements behind it)
+//   * 256-thread workgroup per 32 KiB super-tile held in registers, processed as two 16 KiB halves
+//     through one LDS buffer (+ the 1 KiB window that precedes the half);
+//   * newline count published per super-tile, exclusive prefix from the central scanner wave
+//     (block 0), awaited only after half 0 has been staged;
+//   * per half: bytes -> LDS, contiguous 64 B per thread re-classified from LDS (conflict-free
+//     read order), one wave scan -> u16 newline list; format policy F emits the records.
+// A format policy F provides:
+//   typename F::Dev                       by-value kernel argument (d_in, n_bytes, lead, flags,
+//                                         first_line_index, payload_base, capacity + outputs)
+//   F::eof_extra_lines(line_index_total)  extra virtual (empty) lines at EOF besides the unterminated one
+//   F::emit_half(...)                     records ending in the staged half
+//   F::analytic_prefix(offset)            dev-only ablation hook
+#pragma once
+#include "exg_fastq_ws.hpp"
+
+namespace exg {
+
+
+static constexpr int kTile = kFusedTileBytes;  // 16384: one half, the unit of LDS staging and of tile_qend
+static constexpr int kHalves = 2;
+static constexpr int kSuper = kTile * kHalves;  // 32768 bytes per workgroup
+static constexpr int kWin = kFusedWindow;       // 1024
+static constexpr int kThreads = 256;
+static constexpr int kRows = kTile / (kThreads * 16);  // 4 chunk rows (4 KiB each) per half
+static constexpr int kLdsBytes = kWin + kTile + 96;
+static constexpr int kNlCap = 1024;  // newline positions kept per half
+static constexpr uint32_t kNoneE = 0xFFFFu;
+
+static constexpr unsigned long long kFlag = 1ull << 63;  // descriptor word is published
+static constexpr unsigned long long kVal = (1ull << 48) - 1;
+
+struct FusedLds {
+    uint8_t bytes[kLdsBytes];        // [0,kWin) window, then the half; e = p + kWin
+    uint16_t nlist[4 + kNlCap + 4];  // e-offsets of newlines: [0..3] the 4 before the half (oldest first)
+    uint32_t wtot[4];   // per-wave newline counts of the staged half
+    uint32_t wcnt[4];   // per-wave packed (half 0 | half 1 << 16) newline counts
+    unsigned long long prefix;            // '\n' in the buffer before this super-tile
+    uint32_t hi_or[4];
+    uint16_t carry[4];  // the 4 newlines before the second half, relative to it
+};
+
+__device__ __forceinline__ uint32_t ldw(const FusedLds &s, uint32_t e_aligned) {
+    return *reinterpret_cast<const uint32_t *>(s.bytes + e_aligned);
+}
+__device__ __forceinline__ uint32_t ldb(const FusedLds &s, int e) { return s.bytes[e]; }
+// 4 bytes at extended offset e (any alignment)
+__device__ __forceinline__ uint32_t ldu32(const FusedLds &s, int e) {
+    uint32_t a = (uint32_t)e & ~3u;
+    uint32_t lo = ldw(s, a), hi = ldw(s, a + 4);
+    return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)e & 3u);
+}
+
+// duckdb::string_t of the field [e, e+len); ptr_of_e0 = payload pointer of extended offset 0
+__device__ __forceinline__ uint4 make_string_lds(const FusedLds &s, int e, uint32_t len, uint64_t ptr_of_e0) {
+    uint4 r;
+    r.x = len;
+    uint32_t w0 = ldu32(s, e);
+    if (len <= EXG_INLINE_LENGTH) {
+        uint32_t w1 = ldu32(s, e + 4), w2 = ldu32(s, e + 8);
+        uint32_t m0 = len >= 4 ? 0xFFFFFFFFu : ((1u << (8 * len)) - 1u);
+        uint32_t l1 = len > 4 ? len - 4 : 0, l2 = len > 8 ? len - 8 : 0;
+        uint32_t m1 = l1 >= 4 ? 0xFFFFFFFFu : ((1u << (8 * l1)) - 1u);
+        uint32_t m2 = l2 >= 4 ? 0xFFFFFFFFu : ((1u << (8 * l2)) - 1u);
+        r.y = w0 & m0;
+        r.z = w1 & m1;
+        r.w = w2 & m2;
+    } else {
+        uint64_t ptr = ptr_of_e0 + (uint64_t)e;
+        r.y = w0;
+        r.z = (uint32_t)ptr;
+        r.w = (uint32_t)(ptr >> 32);
+    }
+    return r;
+}
+
+// '\n' count of bytes [b, e), by one wave, straight from global memory (helping path)
+__device__ unsigned long long help_count_bytes(const uint8_t *__restrict__ d_in, uint64_t n_bytes, uint64_t b,
+                                               uint64_t e, uint32_t lane) {
+    unsigned long long cnt = 0;
+    if (e > n_bytes) e = n_bytes;
+    for (uint64_t off = b + (uint64_t)lane * 16; off < e; off += 1024) {
+        uint4 q = *reinterpret_cast<const uint4 *>(d_in + off);
+        uint32_t mm = match16(q, 0x0A0A0A0Au);
+        if (off + 16 > e) mm &= (1u << (uint32_t)(e - off)) - 1u;
+        cnt += __popc(mm);
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+    return __shfl(cnt, 0, 64);
+}
+
+__device__ __forceinline__ unsigned long long rfl64(unsigned long long x) {  // wave-uniform value -> SGPRs
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long ld_desc(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_desc(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- ordered prefix: central scanner --------------------------------------------------------------
+static constexpr int kScanBatches = 8;  // 512 descriptors per scanner probe
+
+__device__ void scanner_wave(const uint8_t *__restrict__ d_in, uint64_t n_bytes,
+                             const unsigned long long *__restrict__ tileA, unsigned long long *__restrict__ tileP,
+                             uint32_t n_super, uint32_t lane) {
+    __builtin_amdgcn_s_setprio(3);
+    uint64_t next = 0;
+    unsigned long long running = 0;
+    unsigned long long t_last = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+    while (next < n_super) {
+        unsigned long long d[kScanBatches];
+#pragma unroll
+        for (int k = 0; k < kScanBatches; k++) {
+            uint64_t idx = next + (uint64_t)k * 64 + lane;
+            d[k] = idx < n_super ? ld_desc(&tileA[idx]) : 0ull;
+        }
+        bool progressed = false;
+#pragma unroll
+        for (int k = 0; k < kScanBatches; k++) {
+            unsigned long long rdy = __ballot((d[k] & kFlag) != 0);
+            int r = rdy == ~0ull ? 64 : __ffsll((long long)~rdy) - 1;  // leading run of published counts
+            if (r > 0) {
+                uint32_t c = (int)lane < r ? (uint32_t)(d[k] & kVal) : 0u;
+                uint32_t inc = wave_incl_sum(c);
+                if ((int)lane < r) st_desc(&tileP[next + lane], kFlag | (running + inc - c));
+                running += __shfl(inc, 63, 64);
+                next += (uint64_t)r;
+                progressed = true;
+            }
+            if (r < 64) break;
+        }
+        if (progressed) {
+            t_last = __builtin_amdgcn_s_memrealtime();
+        } else if (__builtin_amdgcn_s_memrealtime() - t_last > 4000) {
+            // ~40 us without the next count: that block may not have been dispatched; count its bytes
+            // ourselves so that progress never depends on the dispatch order.
+            unsigned long long c = help_count_bytes(d_in, n_bytes, next * kSuper, (next + 1) * kSuper, lane);
+            if (lane == 0) st_desc(&tileP[next], kFlag | running);
+            running += c;
+            next++;
+            t_last = __builtin_amdgcn_s_memrealtime();
+        } else {
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+}
+
+// Workgroup side (wave 0): wait for the exclusive prefix of super-tile st (its count is published).
+__device__ unsigned long long wait_prefix(const uint8_t *__restrict__ d_in, uint64_t n_bytes,
+                                          unsigned long long *__restrict__ tileA,
+                                          unsigned long long *__restrict__ tileP, uint32_t st, uint32_t lane) {
+    if (st == 0) return 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        unsigned long long x = lane == 0 ? ld_desc(&tileP[st]) : 0ull;
+        x = (unsigned long long)__shfl((long long)x, 0, 64);
+        if (x & kFlag) return x & kVal;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000) break;  // 2 ms: the scanner is not running
+        __builtin_amdgcn_s_sleep(2);
+    }
+    // Last resort (never seen with in-order dispatch): sum every predecessor ourselves.
+    unsigned long long sum = 0;
+    for (uint64_t b = 0; b < st; b += 64) {
+        uint64_t idx = b + lane;
+        unsigned long long x = idx < st ? ld_desc(&tileA[idx]) : kFlag;
+        unsigned long long miss = __ballot((x & kFlag) == 0);
+        while (miss) {
+            int l = __ffsll((long long)miss) - 1;
+            miss &= miss - 1;
+            unsigned long long c = help_count_bytes(d_in, n_bytes, (b + l) * kSuper, (b + l + 1) * kSuper, lane);
+            if ((int)lane == l) x = kFlag | c;
+        }
+        unsigned long long v = idx < st ? (x & kVal) : 0;
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        sum += __shfl(v, 0, 64);
+    }
+    return sum;
+}
+
+struct TileCtx {  // what emission needs besides the LDS contents (all workgroup-uniform)
+    uint64_t tile_off;          // offset of the half in d_input
+    unsigned long long P;       // '\n' in the buffer before the half
+    uint32_t n_lines;           // newline entries of the half (incl. virtual EOF lines)
+    int lim_e;                  // extended offset of the end of input inside this half (kWin + min(lim, kTile))
+    bool is_eof_tile;           // the input ends in this half and EXG_F_EOF
+    bool first_of_buffer;       // half 0 of super-tile 0: what precedes is before d_input[0]
+};
+
+template <class F>
+__global__ __launch_bounds__(kThreads, 7) void k_fused(typename F::Dev a, unsigned long long *__restrict__ tileA,
+                                                             unsigned long long *__restrict__ tileP,
+                                                             unsigned long long *__restrict__ tile_qend,
+                                                             ScanWsHeader *hdr, uint32_t n_super) {
+    __shared__ __attribute__((aligned(16))) FusedLds s;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    // DEV ONLY (tools/dev_probe.py): flags bits 8..11 select ablations on the synthetic FASTQ-150 file
+    //   1: analytic prefix instead of the scanner   2: 1 + no output stores
+    //   3: 1 + no emission at all                    4: scanner, no emission
+    const uint32_t dev_mode = (a.flags >> 8) & 15u;
+    if (blockIdx.x == 0) {  // the scanner: one wave, no tile
+        if (wave == 0 && !(dev_mode >= 1 && dev_mode <= 3)) scanner_wave(a.d_in, a.n_bytes, tileA, tileP, n_super, lane);
+        return;
+    }
+    const uint32_t st = blockIdx.x - 1;
+    const uint64_t super_off = (uint64_t)st * kSuper;
+    const uint8_t *__restrict__ d_in = a.d_in;
+    const uint64_t n_pad = (a.n_bytes + 15) & ~15ull;
+    const int64_t lim64 = (int64_t)a.n_bytes - (int64_t)super_off;
+    const int lim_s = lim64 < kSuper ? (int)lim64 : kSuper;  // super-tile-relative end of input (> 0)
+    const bool last_super = st + 1 == n_super;
+
+    // ---- loads: 8 strided 16 B chunks per thread, all in flight at once (+ window by wave 3) ------
+    uint4 v[kHalves * kRows];
+#pragma unroll
+    for (int j = 0; j < kHalves * kRows; j++) {
+        uint64_t off = super_off + (uint64_t)(j * kThreads + tid) * 16;
+        v[j] = off < n_pad ? *reinterpret_cast<const uint4 *>(d_in + off) : make_uint4(0, 0, 0, 0);
+    }
+    uint4 wv = make_uint4(0, 0, 0, 0);
+    const int64_t woff = (int64_t)super_off - kWin + (int64_t)lane * 16;  // wave 3 only
+    if (wave == 3 && woff >= 0) wv = *reinterpret_cast<const uint4 *>(d_in + woff);
+
+    // ---- count in registers (all that is needed to publish) ----------------------------------------
+    // zero-byte SWAR without compaction: z has bit 7 of a byte clear iff the byte matched, every
+    // other bit set, so matches in a dword = 32 - popcount(z): 5 VALU ops per dword.
+    uint32_t hi = 0, cnt = 0;
+    if (lim_s == kSuper) {
+        uint32_t z0 = 0, z1 = 0;  // popcount accumulators (half 0, half 1)
+#pragma unroll
+        for (int j = 0; j < kHalves * kRows; j++) {
+            const uint32_t w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+            hi |= (w[0] | w[1] | w[2] | w[3]);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t x = w[q] ^ 0x0A0A0A0Au;
+                uint32_t y = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+                uint32_t z = y | x | 0x7F7F7F7Fu;
+                if (j < kRows)
+                    z0 += __popc(z);
+                else
+                    z1 += __popc(z);
+            }
+        }
+        hi &= 0x80808080u;
+        cnt = (kRows * 4 * 32 - z0) | ((kRows * 4 * 32 - z1) << 16);  // half 0 low 16 bits, half 1 high
+    } else {
+        // the input ends inside this super-tile: mask the bytes past the end
+#pragma unroll
+        for (int j = 0; j < kHalves * kRows; j++) {
+            uint32_t mj = match16(v[j], 0x0A0A0A0Au);
+            hi |= (v[j].x | v[j].y | v[j].z | v[j].w) & 0x80808080u;
+            int rem = lim_s - (int)(j * kThreads + tid) * 16;  // bytes of this chunk inside the input
+            if (rem < 16) mj &= rem <= 0 ? 0u : ((1u << rem) - 1u);
+            cnt += __popc(mj) << (j < kRows ? 0 : 16);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+    if (wave == 3) hi |= (wv.x | wv.y | wv.z | wv.w) & 0x80808080u;
+    uint32_t any_hi = __any(hi != 0);
+    if (lane == 0) {
+        s.hi_or[wave] = any_hi;
+        s.wcnt[wave] = cnt;
+    }
+    __syncthreads();  // #1
+    const uint32_t both = __builtin_amdgcn_readfirstlane(s.wcnt[0] + s.wcnt[1] + s.wcnt[2] + s.wcnt[3]);
+    const uint32_t n_nl[kHalves] = {both & 0xFFFFu, both >> 16};
+    const bool non_ascii = (s.hi_or[0] | s.hi_or[1] | s.hi_or[2] | s.hi_or[3]) != 0;
+
+    // ---- publish the super-tile count; its prefix is awaited after half 0 has been staged ---------------
+    const bool analytic = dev_mode >= 1 && dev_mode <= 3;
+    if (tid == 0 && !analytic) st_desc(&tileA[st], kFlag | (unsigned long long)(n_nl[0] + n_nl[1]));
+    const unsigned long long halo_nl = rfl64(hdr->halo_nl);
+    // Bytes >= 0x80 need UTF-8 validation of every field (the reference builds Arrow Utf8 columns).
+    // That is rare in FASTQ and is left to the general path: raise `overflow`, which gates it in.
+    if (non_ascii && tid == 0) {
+        atomicOr(&hdr->flags, EXG_RF_NON_ASCII);
+        atomicOr(&hdr->overflow, 1u);
+    }
+
+#pragma unroll
+    for (int h = 0; h < kHalves; h++) {
+        const int lim_h = lim_s - h * kTile;  // half-relative end of input
+        if (h > 0 && lim_h <= 0) {
+            // no input in this half: nothing ends here
+            if (tid == 0) tile_qend[(uint64_t)st * kHalves + h] = 0;
+            break;
+        }
+        // ---- stage the half: window, bytes, newline list ------------------------------------------
+        if (h == 0) {
+            if (wave == 3) {
+                *reinterpret_cast<uint4 *>(s.bytes + lane * 16) = wv;
+                if (lane < 4) s.nlist[lane] = (uint16_t)kNoneE;
+                uint32_t wm = woff >= 0 ? match16(wv, 0x0A0A0A0Au) : 0u;
+                uint32_t wc = __popc(wm);
+                uint32_t wincl = wave_incl_sum(wc);
+                uint32_t W = __shfl(wincl, 63, 64);
+                uint32_t r = wincl - wc;  // rank, oldest first; goes to slot 4 - (W - r) when >= 0
+                while (wm) {
+                    uint32_t b = __ffs(wm) - 1;
+                    wm &= wm - 1;
+                    int slot = 4 - (int)(W - r);
+                    if (slot >= 0) s.nlist[slot] = (uint16_t)(lane * 16 + b);
+                    r++;
+                }
+                // a line starts at d_input[0] when EXG_F_BOF: model it as a newline at offset -1 (W == 0 here)
+                if (st == 0 && (a.flags & EXG_F_BOF) && lane == 0) s.nlist[3] = (uint16_t)(kWin - 1);
+            }
+        } else {
+            // window = last 1 KiB of the previous half (still in LDS); its last 4 newlines were saved
+            uint4 t = make_uint4(0, 0, 0, 0);
+            if (wave == 3) t = *reinterpret_cast<const uint4 *>(s.bytes + kTile + lane * 16);
+            __syncthreads();
+            if (wave == 3) {
+                *reinterpret_cast<uint4 *>(s.bytes + lane * 16) = t;
+                if (lane < 4) s.nlist[lane] = s.carry[lane];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kRows; j++)
+            *reinterpret_cast<uint4 *>(s.bytes + kWin + (j * kThreads + tid) * 16) = v[h * kRows + j];
+        __syncthreads();  // bytes staged
+        {
+            // Each thread now owns 64 CONTIGUOUS bytes of the half, so newline ranks follow from one
+            // 32-bit wave scan.  The four 16 B chunks are read in the order (t>>2)+k mod 4: any 16 lanes
+            // of a ds_read_b128 group then touch 16 different bank slots (lane stride alone is 4-way).
+            const uint8_t *mine = s.bytes + kWin + tid * 64;
+            unsigned long long mask = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint32_t cidx = ((tid >> 2) + k) & 3u;
+                uint4 q = *reinterpret_cast<const uint4 *>(mine + cidx * 16);
+                mask |= (unsigned long long)match16(q, 0x0A0A0A0Au) << (16 * cidx);
+            }
+            int rem = lim_h - (int)tid * 64;  // bytes of my 64 inside the input
+            if (rem < 64) mask &= rem <= 0 ? 0ull : ((1ull << rem) - 1ull);
+            uint32_t c = (uint32_t)__popcll(mask);
+            uint32_t inc = wave_incl_sum(c);
+            if (lane == 63) s.wtot[wave] = inc;
+            __syncthreads();
+            uint32_t r = inc - c + (wave > 0 ? s.wtot[0] : 0) + (wave > 1 ? s.wtot[1] : 0) + (wave > 2 ? s.wtot[2] : 0);
+            const uint32_t e0 = kWin + tid * 64;
+            while (mask) {
+                uint32_t b = (uint32_t)__ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                if (r < (uint32_t)kNlCap) s.nlist[4 + r] = (uint16_t)(e0 + b);
+                r++;
+            }
+        }
+        if (h == 0) {
+            // the half is staged while the scanner turns the published count into our prefix
+            if (wave == 0) {
+                unsigned long long pre;
+                if (analytic) {
+                    pre = F::analytic_prefix(super_off);
+                } else {
+                    pre = wait_prefix(d_in, a.n_bytes, tileA, tileP, st, lane);
+                }
+                if (lane == 0) s.prefix = pre;
+            }
+        }
+        __syncthreads();  // staged (and, for h == 0, the prefix has arrived)
+
+        TileCtx c;
+        c.tile_off = super_off + (uint64_t)h * kTile;
+        c.P = rfl64(s.prefix) + (h ? n_nl[0] : 0);
+        c.first_of_buffer = st == 0 && h == 0;
+        const bool ends_here = last_super && lim_h <= kTile;  // the input ends inside (or at the end of) this half
+        c.is_eof_tile = ends_here && (a.flags & EXG_F_EOF);
+        c.lim_e = (lim_h < kTile ? lim_h : kTile) + kWin;
+        uint32_t n_lines = n_nl[h];
+        if (c.is_eof_tile) {
+            // noodles EOF rules: an unterminated last line is a line; a record with its '+' line but no
+            // quality line gets an empty one (read_line returns 0 bytes at EOF without error).
+            const unsigned long long P0 = a.first_line_index - halo_nl;
+            bool unterminated = a.n_bytes > 0 && ldb(s, c.lim_e - 1) != '\n';
+            uint32_t n0 = n_lines;
+            if (unterminated) n_lines++;
+            n_lines += F::eof_extra_lines(P0 + c.P + n_lines);
+            if (tid == 0 && n_lines <= (uint32_t)kNlCap)
+                for (uint32_t q = n0; q < n_lines; q++) s.nlist[4 + q] = (uint16_t)c.lim_e;
+            __syncthreads();
+        }
+        c.n_lines = n_lines;
+        if (ends_here && tid == 0) {
+            hdr->total_nl = c.P + n_nl[h];
+            hdr->total_lines = c.P + n_lines;
+        }
+        if (n_lines > (uint32_t)kNlCap) {  // more lines than the list holds: general path
+            if (tid == 0) atomicOr(&hdr->overflow, 1u);
+            return;
+        }
+        if (h + 1 < kHalves && tid < 4) {
+            // the 4 newlines before the next half, relative to it (entries 4+n-4 .. 4+n-1 of this list)
+            uint32_t e = s.nlist[n_lines + tid];
+            s.carry[tid] = (e != kNoneE && e >= (uint32_t)kTile) ? (uint16_t)(e - kTile) : (uint16_t)kNoneE;
+        }
+        F::emit_half(s, a, hdr, c, halo_nl, dev_mode, lane, wave, tile_qend, (uint64_t)st * kHalves + h);
+        if (h + 1 < kHalves) __syncthreads();  // everyone is done reading this half
+    }
+}
+
+
+}  // namespace exg

@@ -1,0 +1,422 @@
+// exg_reader.cpp — reader level of the C-ABI (include/exon_gpu.h, layer 2):
+//   file on the host -> pinned host memory -> HBM -> scan kernels -> DataChunk-shaped host vectors.
+//
+// Replaces `new_reader` + the ArrowArrayStream it hands back (exon/include/rust.hpp:41-46,
+// rust/src/arrow_reader.rs:38-166) and the per-batch pull in WTArrowTableFunction::Scan
+// (exon/src/exon/arrow_table_function/module.cpp:257-294).  One reader per scan, one thread at a
+// time, like the reference (MaxThreads() == 1).
+//
+// Data layout: the whole file is read into ONE pinned host block.  Device batches are record
+// aligned (each starts on the first byte after the last complete record of the previous one, so
+// EXG_F_BOF always holds); the kernels emit string_t whose pointers address the pinned block
+// (payload_base = host address of the batch start), i.e. the DataChunk payload is zero-copy and only
+// 64 B/record of string_t + validity cross PCIe on the way back.  Chunks are 2048-row slices of the
+// batch's host vectors; buffers are reference counted until exg_release_chunk.
+#include <dirent.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "exg_common.hpp"
+
+namespace {
+
+struct PinnedBlock {
+    void *p = nullptr;
+    size_t n = 0;
+    ~PinnedBlock() {
+        if (p) (void)hipHostFree(p);
+    }
+};
+
+struct Batch {  // host vectors of one device batch, shared by its chunks
+    std::shared_ptr<PinnedBlock> file;
+    PinnedBlock cols[4];
+    PinnedBlock validity;
+    uint64_t n_rows = 0;
+};
+
+struct ChunkKeep {
+    std::shared_ptr<Batch> batch;
+};
+
+enum Compression { kNone, kGzip, kZstd, kBzip2, kXz };
+
+// DataFusion 28 FileCompressionType::from_str as used at rust/src/arrow_reader.rs:87-88
+bool parse_compression(const std::string &s, Compression *out) {
+    std::string u;
+    for (char ch : s) u.push_back((char)toupper((unsigned char)ch));
+    if (u == "GZIP" || u == "GZ") return *out = kGzip, true;
+    if (u == "ZSTD" || u == "ZST") return *out = kZstd, true;
+    if (u == "BZIP2" || u == "BZ2") return *out = kBzip2, true;
+    if (u == "XZ") return *out = kXz, true;
+    if (u.empty()) return *out = kNone, true;
+    return false;
+}
+
+}  // namespace
+
+struct exg_reader {
+    int format = 0;
+    Compression compression = kNone;
+    std::vector<std::string> files;
+    size_t file_idx = 0;
+    uint64_t batch_rows = EXG_VECTOR_SIZE;
+    uint64_t device_batch_bytes = 256ull << 20;
+    int device = 0;
+    std::string error;
+    hipStream_t stream = nullptr;
+
+    // current file
+    std::shared_ptr<PinnedBlock> file;
+    uint64_t file_pos = 0;  // first byte not yet consumed by a complete record
+    bool file_done = true;
+
+    // device buffers (sized for device_batch_bytes)
+    void *d_in = nullptr, *d_ws = nullptr, *d_res = nullptr, *d_valid = nullptr;
+    void *d_cols[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t d_in_cap = 0, ws_bytes = 0, cap_records = 0;
+
+    // current batch
+    std::shared_ptr<Batch> batch;
+    uint64_t batch_row = 0;
+    uint32_t pending_error = 0;  // parse error to raise once the rows before it have been handed out
+    uint64_t pending_error_offset = 0;
+
+    ~exg_reader() {
+        if (d_in) (void)hipFree(d_in);
+        if (d_ws) (void)hipFree(d_ws);
+        if (d_res) (void)hipFree(d_res);
+        if (d_valid) (void)hipFree(d_valid);
+        for (void *p : d_cols)
+            if (p) (void)hipFree(p);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+int fail(exg_reader *r, int code, const std::string &msg) {
+    r->error = msg;
+    exg::set_error("%s", msg.c_str());
+    return code;
+}
+
+#define RD_HIP(r, expr)                                                                            \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(r, EXG_E_HIP, std::string(#expr " failed: ") + hipGetErrorString(_e));     \
+    } while (0)
+
+int list_files(exg_reader *r, const std::string &path) {
+    struct stat st;
+    if (path.empty() || stat(path.c_str(), &st) != 0)
+        return fail(r, EXG_E_IO, "could not register table: cannot open '" + path + "': " + strerror(errno));
+    if (S_ISDIR(st.st_mode)) {
+        // the reference lists a directory (test_fasta_scan.test:55-59, test_fastq_scan.test:65-68)
+        DIR *d = opendir(path.c_str());
+        if (!d) return fail(r, EXG_E_IO, "cannot list '" + path + "'");
+        while (dirent *e = readdir(d)) {
+            if (e->d_name[0] == '.') continue;
+            std::string p = path + (path.back() == '/' ? "" : "/") + e->d_name;
+            struct stat s2;
+            if (stat(p.c_str(), &s2) == 0 && S_ISREG(s2.st_mode)) r->files.push_back(p);
+        }
+        closedir(d);
+        std::sort(r->files.begin(), r->files.end());
+    } else {
+        r->files.push_back(path);
+    }
+    return EXG_OK;
+}
+
+int open_next_file(exg_reader *r) {
+    const std::string &p = r->files[r->file_idx++];
+    int fd = open(p.c_str(), O_RDONLY);
+    if (fd < 0) return fail(r, EXG_E_IO, "cannot open '" + p + "': " + strerror(errno));
+    struct stat st;
+    fstat(fd, &st);
+    auto blk = std::make_shared<PinnedBlock>();
+    blk->n = (size_t)st.st_size;
+    hipError_t he = hipHostMalloc(&blk->p, blk->n + 64, hipHostMallocDefault);
+    if (he != hipSuccess) {
+        close(fd);
+        return fail(r, EXG_E_HIP, std::string("hipHostMalloc failed: ") + hipGetErrorString(he));
+    }
+    size_t got = 0;
+    while (got < blk->n) {
+        ssize_t k = read(fd, (char *)blk->p + got, blk->n - got);
+        if (k <= 0) break;
+        got += (size_t)k;
+    }
+    close(fd);
+    if (got != blk->n) return fail(r, EXG_E_IO, "short read on '" + p + "'");
+    memset((char *)blk->p + blk->n, 0, 64);
+    r->file = blk;
+    r->file_pos = 0;
+    r->file_done = false;
+    return EXG_OK;
+}
+
+int ensure_device(exg_reader *r, uint64_t need_bytes) {
+    if (r->d_in && need_bytes <= r->d_in_cap) return EXG_OK;
+    if (r->d_in) {
+        RD_HIP(r, hipStreamSynchronize(r->stream));
+        (void)hipFree(r->d_in), (void)hipFree(r->d_ws), (void)hipFree(r->d_valid);
+        for (void *&p : r->d_cols) (void)hipFree(p), p = nullptr;
+        r->d_in = r->d_ws = r->d_valid = nullptr;
+    }
+    uint64_t cap = std::max<uint64_t>(need_bytes, 1 << 16);
+    r->d_in_cap = cap;
+    r->cap_records = cap / 6 + 16;  // a FASTQ record is at least 6 bytes ("@\n\n+\n\n" minus the last LF at EOF)
+    r->ws_bytes = exg_scan_workspace_bytes(r->format, cap);
+    RD_HIP(r, hipMalloc(&r->d_in, cap + 64));
+    RD_HIP(r, hipMalloc(&r->d_ws, r->ws_bytes));
+    RD_HIP(r, hipMalloc(&r->d_valid, (r->cap_records + 63) / 64 * 8));
+    for (void *&p : r->d_cols) RD_HIP(r, hipMalloc(&p, r->cap_records * 16));
+    if (!r->d_res) RD_HIP(r, hipMalloc(&r->d_res, sizeof(exg_scan_result)));
+    return EXG_OK;
+}
+
+// Scan the next device batch of the current file.  On return r->batch holds its host vectors
+// (n_rows may be 0 when the file is exhausted).  count_only: no column leaves the device.
+int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
+    *n_records_out = 0;
+    r->batch.reset();
+    r->batch_row = 0;
+    uint64_t want = r->device_batch_bytes;
+    for (;;) {
+        const uint64_t remaining = r->file->n - r->file_pos;
+        if (remaining == 0) {
+            r->file_done = true;
+            return EXG_OK;
+        }
+        uint64_t n = std::min<uint64_t>(want, remaining);
+        const bool eof = n == remaining;
+        int rc = ensure_device(r, n);
+        if (rc) return rc;
+        const uint8_t *h = (const uint8_t *)r->file->p + r->file_pos;
+        RD_HIP(r, hipMemcpyAsync(r->d_in, h, (n + 15) / 16 * 16, hipMemcpyHostToDevice, r->stream));
+        exg_scan_result res;
+        if (r->format == EXG_FMT_FASTQ) {
+            exg_fastq_scan_args a;
+            memset(&a, 0, sizeof a);
+            a.d_input = r->d_in;
+            a.n_bytes = n;
+            a.payload_base = (uint64_t)(uintptr_t)h;
+            a.flags = EXG_F_BOF | (eof ? EXG_F_EOF : 0u) | (count_only ? EXG_F_NO_STORE : 0u);
+            a.algo = EXG_ALGO_AUTO;
+            a.d_name = (exg_string_t *)r->d_cols[0];
+            a.d_description = (exg_string_t *)r->d_cols[1];
+            a.d_sequence = (exg_string_t *)r->d_cols[2];
+            a.d_quality = (exg_string_t *)r->d_cols[3];
+            a.d_description_validity = (uint64_t *)r->d_valid;
+            a.capacity_records = r->cap_records;
+            a.d_workspace = r->d_ws;
+            a.workspace_bytes = r->ws_bytes;
+            a.d_result = (exg_scan_result *)r->d_res;
+            a.stream = r->stream;
+            rc = exg_fastq_scan(&a);
+            if (rc) return fail(r, rc, exg_last_error_message());
+        } else {
+            return fail(r, EXG_E_UNSUPPORTED, "reader: this format has no device scan yet");
+        }
+        rc = exg_fetch_result((const exg_scan_result *)r->d_res, r->stream, &res);
+        if (rc) return fail(r, rc, exg_last_error_message());
+        if (res.flags & EXG_RF_INDEX_OVERFLOW)
+            return fail(r, EXG_E_CAPACITY, "line index overflow in the general path (pathological line density)");
+        if (res.n_records == 0 && !res.error_code && !eof) {
+            want *= 2;  // not even one complete record in the batch: widen it
+            continue;
+        }
+        if (res.error_code) {
+            r->pending_error = res.error_code;
+            r->pending_error_offset = r->file_pos + res.error_offset;
+        }
+        const uint64_t k = res.n_records;
+        *n_records_out = k;
+        if (k && !count_only) {
+            auto b = std::make_shared<Batch>();
+            b->file = r->file;
+            b->n_rows = k;
+            for (int c = 0; c < 4; c++) {
+                b->cols[c].n = k * 16;
+                RD_HIP(r, hipHostMalloc(&b->cols[c].p, k * 16, hipHostMallocDefault));
+                RD_HIP(r, hipMemcpyAsync(b->cols[c].p, r->d_cols[c], k * 16, hipMemcpyDeviceToHost, r->stream));
+            }
+            size_t vw = (size_t)((k + 63) / 64) * 8;
+            b->validity.n = vw;
+            RD_HIP(r, hipHostMalloc(&b->validity.p, vw, hipHostMallocDefault));
+            RD_HIP(r, hipMemcpyAsync(b->validity.p, r->d_valid, vw, hipMemcpyDeviceToHost, r->stream));
+            RD_HIP(r, hipStreamSynchronize(r->stream));
+            r->batch = b;
+        }
+        if (res.error_code || eof)
+            r->file_done = true;
+        else
+            r->file_pos += res.consumed_bytes;
+        return EXG_OK;
+    }
+}
+
+}  // namespace
+
+extern "C" int exg_open(const exg_open_args *args, exg_reader **out) {
+    if (!args || !out || !args->path || !args->file_format) {
+        exg::set_error("exg_open: null argument");
+        return EXG_E_INVALID_ARG;
+    }
+    *out = nullptr;
+    std::unique_ptr<exg_reader> r(new exg_reader());
+    std::string fmt = args->file_format;
+    for (char &ch : fmt) ch = (char)tolower((unsigned char)ch);
+    if (fmt == "fasta")
+        r->format = EXG_FMT_FASTA;
+    else if (fmt == "fastq")
+        r->format = EXG_FMT_FASTQ;
+    else if (fmt == "vcf")
+        r->format = EXG_FMT_VCF;
+    else {
+        // rust/src/arrow_reader.rs:93-102
+        exg::set_error("could not parse file_format %s", args->file_format);
+        return EXG_E_INVALID_ARG;
+    }
+    std::string path = args->path;
+    // compression: NULL => extension sniffing (arrow_reader.rs:60-75); unknown string => uncompressed (:87-88)
+    if (!args->compression) {
+        size_t dot = path.rfind('.');
+        std::string ext = dot == std::string::npos ? path : path.substr(dot + 1);
+        r->compression = ext == "gz" ? kGzip : ext == "zst" ? kZstd : kNone;
+    } else if (!parse_compression(args->compression, &r->compression)) {
+        r->compression = kNone;
+    }
+    if (args->batch_rows) r->batch_rows = args->batch_rows;
+    if (r->batch_rows % 64) {
+        exg::set_error("exg_open: batch_rows must be a multiple of 64 (validity words)");
+        return EXG_E_INVALID_ARG;
+    }
+    if (args->device_batch_bytes) r->device_batch_bytes = (args->device_batch_bytes + 15) / 16 * 16;
+    r->device = args->device;
+    int rc = list_files(r.get(), path);
+    if (rc) return rc;
+    if (r->compression != kNone) {
+        exg::set_error("compressed input is not supported yet: there is no device inflate and no CPU fallback");
+        return EXG_E_UNSUPPORTED;
+    }
+    if (exg_device_count() < 1) return EXG_E_NO_DEVICE;
+    hipError_t he = hipSetDevice(r->device);
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
+    if (he != hipSuccess) {
+        exg::set_error("cannot initialise device %d: %s", r->device, hipGetErrorString(he));
+        return EXG_E_HIP;
+    }
+    *out = r.release();
+    return EXG_OK;
+}
+
+extern "C" int exg_schema_of(exg_reader *r, exg_schema *out) {
+    if (!r || !out) return EXG_E_INVALID_ARG;
+    memset(out, 0, sizeof *out);
+    if (r->format == EXG_FMT_FASTQ) {
+        // order pinned by test_fastq_scan.test:35-41; names as exon 0.2.6 registers them
+        static const char *n[] = {"name", "description", "sequence", "quality_scores"};
+        out->n_columns = 4;
+        for (int i = 0; i < 4; i++) out->names[i] = n[i], out->types[i] = EXG_TYPE_VARCHAR;
+        out->nullable[1] = 1;
+    } else if (r->format == EXG_FMT_FASTA) {
+        // `id` pinned by test_fasta_scan.test:34-37, order + NULL description by test_fasta_copy.test:75-80
+        static const char *n[] = {"id", "description", "sequence"};
+        out->n_columns = 3;
+        for (int i = 0; i < 3; i++) out->names[i] = n[i], out->types[i] = EXG_TYPE_VARCHAR;
+        out->nullable[1] = 1;
+    } else {
+        static const char *n[] = {"chrom", "pos", "id", "ref", "alt", "qual", "filter", "info", "formats"};
+        out->n_columns = 9;
+        for (int i = 0; i < 9; i++) out->names[i] = n[i], out->types[i] = EXG_TYPE_VARCHAR;
+        out->types[1] = EXG_TYPE_BIGINT;
+        out->types[5] = EXG_TYPE_FLOAT;
+        out->nullable[5] = out->nullable[8] = 1;
+    }
+    return EXG_OK;
+}
+
+extern "C" int exg_next_chunk(exg_reader *r, exg_chunk *out) {
+    if (!r || !out) return EXG_E_INVALID_ARG;
+    memset(out, 0, sizeof *out);
+    for (;;) {
+        if (r->batch && r->batch_row < r->batch->n_rows) {
+            uint64_t row0 = r->batch_row;
+            uint64_t n = std::min<uint64_t>(r->batch_rows, r->batch->n_rows - row0);
+            out->n_rows = n;
+            out->n_columns = 4;
+            for (int c = 0; c < 4; c++) out->data[c] = (char *)r->batch->cols[c].p + row0 * 16;
+            out->validity[1] = (uint64_t *)r->batch->validity.p + row0 / 64;
+            out->keepalive = new ChunkKeep{r->batch};
+            r->batch_row += n;
+            return EXG_OK;
+        }
+        if (r->pending_error) {
+            // rows before the failing record have been handed out; now surface the error
+            std::string msg = std::string(exg_parse_error_string(r->pending_error)) + " at byte " +
+                              std::to_string(r->pending_error_offset) + " of " + r->files[r->file_idx - 1];
+            r->pending_error = 0;
+            r->batch.reset();
+            return fail(r, EXG_E_PARSE, msg);
+        }
+        if (r->file_done) {
+            if (r->file_idx >= r->files.size()) {
+                r->batch.reset();
+                return EXG_OK;  // n_rows == 0: end of stream
+            }
+            int rc = open_next_file(r);
+            if (rc) return rc;
+        }
+        uint64_t k;
+        int rc = next_batch(r, false, &k);
+        if (rc) return rc;
+    }
+}
+
+extern "C" void exg_release_chunk(exg_reader *, exg_chunk *chunk) {
+    if (chunk && chunk->keepalive) {
+        delete (ChunkKeep *)chunk->keepalive;
+        chunk->keepalive = nullptr;
+    }
+}
+
+extern "C" int exg_count_only(exg_reader *r, uint64_t *n_rows) {
+    if (!r || !n_rows) return EXG_E_INVALID_ARG;
+    uint64_t total = 0;
+    for (;;) {
+        if (r->pending_error) {
+            std::string msg = std::string(exg_parse_error_string(r->pending_error)) + " at byte " +
+                              std::to_string(r->pending_error_offset) + " of " + r->files[r->file_idx - 1];
+            r->pending_error = 0;
+            return fail(r, EXG_E_PARSE, msg);
+        }
+        if (r->file_done) {
+            if (r->file_idx >= r->files.size()) break;
+            int rc = open_next_file(r);
+            if (rc) return rc;
+        }
+        uint64_t k;
+        int rc = next_batch(r, true, &k);
+        if (rc) return rc;
+        total += k;
+    }
+    *n_rows = total;
+    return EXG_OK;
+}
+
+extern "C" const char *exg_reader_error(exg_reader *r) { return r ? r->error.c_str() : ""; }
+
+extern "C" void exg_close(exg_reader *r) { delete r; }

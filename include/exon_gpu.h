@@ -98,6 +98,7 @@ typedef union exg_string_t {
 /* ---- scan flags ------------------------------------------------------------ */
 #define EXG_F_BOF 1u /* a line starts at d_input[0] (start of file, or a record-aligned batch) */
 #define EXG_F_EOF 2u /* d_input[n_bytes-1] is the last byte of the file */
+#define EXG_F_NO_STORE 4u /* COUNT(*) path: parse and validate every record, write no column (capacity ignored) */
 
 /* result flags */
 #define EXG_RF_NON_ASCII 1u /* a byte >= 0x80 was seen; UTF-8 was validated by the slow kernel */
