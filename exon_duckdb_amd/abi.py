@@ -25,6 +25,7 @@ EXG_PE_FIELD_TOO_LONG = 12
 EXG_FMT_FASTA, EXG_FMT_FASTQ, EXG_FMT_VCF = 1, 2, 3
 EXG_F_BOF, EXG_F_EOF, EXG_F_NO_STORE = 1, 2, 4
 EXG_RF_NON_ASCII, EXG_RF_HEAD_UNRESOLVED, EXG_RF_FALLBACK, EXG_RF_CAPACITY, EXG_RF_INDEX_OVERFLOW = 1, 2, 4, 8, 16
+EXG_RF_QUAL_RANGE = 32
 EXG_ALGO_AUTO, EXG_ALGO_MULTIPASS, EXG_ALGO_FUSED = 0, 1, 2
 
 EXG_SYNTH_FASTQ_SEED = 0xE0A5EED0001
@@ -68,6 +69,27 @@ class FastqScanArgs(C.Structure):
     ]
 
 
+class VcfScanArgs(C.Structure):
+    _fields_ = [
+        ("d_input", C.c_void_p),
+        ("n_bytes", C.c_uint64),
+        ("lead", C.c_uint64),
+        ("payload_base", C.c_uint64),
+        ("flags", C.c_uint32),
+        ("algo", C.c_uint32),
+        ("d_fields", C.c_void_p * 9),
+        ("d_pos", C.c_void_p),
+        ("d_qual", C.c_void_p),
+        ("d_qual_validity", C.c_void_p),
+        ("d_formats_validity", C.c_void_p),
+        ("capacity_records", C.c_uint64),
+        ("d_workspace", C.c_void_p),
+        ("workspace_bytes", C.c_uint64),
+        ("d_result", C.c_void_p),
+        ("stream", C.c_void_p),
+    ]
+
+
 # every symbol include/exon_gpu.h declares -> (restype, argtypes); None = not yet bound by name only
 SIGNATURES = {
     "exg_abi_version": (C.c_int, []),
@@ -76,6 +98,7 @@ SIGNATURES = {
     "exg_parse_error_string": (C.c_char_p, [C.c_uint32]),
     "exg_scan_workspace_bytes": (C.c_uint64, [C.c_int, C.c_uint64]),
     "exg_fastq_scan": (C.c_int, [C.POINTER(FastqScanArgs)]),
+    "exg_vcf_scan": (C.c_int, [C.POINTER(VcfScanArgs)]),
     "exg_fetch_result": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(ScanResult)]),
     "exg_count_newlines": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
     "exg_synth_fastq": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),

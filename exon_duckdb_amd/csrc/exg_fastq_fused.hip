@@ -178,6 +178,7 @@ __device__ __forceinline__ void fastq_emit_half(const FusedLds &s, const FastqDe
 
 struct FastqFormat {
     using Dev = FastqDev;
+    static constexpr int kMinWavesPerSimd = 7;  // 71 VGPRs, no scratch: 7 x 32 KiB in flight per CU
     // noodles-fastq at EOF: a record that has its '+' line but no quality line gets an empty one
     __device__ static __forceinline__ uint32_t eof_extra_lines(unsigned long long total_lines) {
         return (total_lines & 3) == 3 ? 1u : 0u;

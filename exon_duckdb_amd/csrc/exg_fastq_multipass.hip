@@ -141,37 +141,6 @@ __global__ __launch_bounds__(256) void k_fastq_records(FastqDev a, const uint64_
     }
 }
 
-// core::str::from_utf8 acceptance over d_in[s, e)
-__device__ bool utf8_valid_global(const uint8_t *__restrict__ p, uint64_t s, uint64_t e) {
-    uint64_t i = s;
-    while (i < e) {
-        uint32_t b = p[i];
-        if (b < 0x80) {
-            i++;
-            continue;
-        }
-        if (b >= 0xC2 && b <= 0xDF) {
-            if (i + 1 >= e || (p[i + 1] & 0xC0) != 0x80) return false;
-            i += 2;
-        } else if (b >= 0xE0 && b <= 0xEF) {
-            if (i + 2 >= e) return false;
-            uint32_t c1 = p[i + 1], c2 = p[i + 2];
-            uint32_t lo = b == 0xE0 ? 0xA0 : 0x80, hi = b == 0xED ? 0x9F : 0xBF;
-            if (c1 < lo || c1 > hi || (c2 & 0xC0) != 0x80) return false;
-            i += 3;
-        } else if (b >= 0xF0 && b <= 0xF4) {
-            if (i + 3 >= e) return false;
-            uint32_t c1 = p[i + 1], c2 = p[i + 2], c3 = p[i + 3];
-            uint32_t lo = b == 0xF0 ? 0x90 : 0x80, hi = b == 0xF4 ? 0x8F : 0xBF;
-            if (c1 < lo || c1 > hi || (c2 & 0xC0) != 0x80 || (c3 & 0xC0) != 0x80) return false;
-            i += 4;
-        } else {
-            return false;
-        }
-    }
-    return true;
-}
-
 // Slow kernel, only does work when pass 1 saw a byte >= 0x80.
 __global__ __launch_bounds__(256) void k_fastq_utf8(FastqDev a, const uint64_t *__restrict__ nl_pos,
                                                     ScanWsHeader *hdr, const unsigned int *gate) {

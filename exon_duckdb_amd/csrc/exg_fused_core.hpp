@@ -13,6 +13,7 @@
 //   F::eof_extra_lines(line_index_total)  extra virtual (empty) lines at EOF besides the unterminated one
 //   F::emit_half(...)                     records ending in the staged half
 //   F::analytic_prefix(offset)            dev-only ablation hook
+//   F::kMinWavesPerSimd                   occupancy the register allocator must respect (7 = 7 workgroups/CU)
 #pragma once
 #include "exg_fastq_ws.hpp"
 
@@ -192,7 +193,7 @@ struct TileCtx {  // what emission needs besides the LDS contents (all workgroup
 };
 
 template <class F>
-__global__ __launch_bounds__(kThreads, 7) void k_fused(typename F::Dev a, unsigned long long *__restrict__ tileA,
+__global__ __launch_bounds__(kThreads, F::kMinWavesPerSimd) void k_fused(typename F::Dev a, unsigned long long *__restrict__ tileA,
                                                              unsigned long long *__restrict__ tileP,
                                                              unsigned long long *__restrict__ tile_qend,
                                                              ScanWsHeader *hdr, uint32_t n_super) {

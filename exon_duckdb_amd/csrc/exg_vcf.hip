@@ -1,0 +1,572 @@
+// exg_vcf.hip — VCF record scan (read_vcf_file_records / read_vcf): one row per data line, the 8
+// fixed tab-separated columns CHROM POS ID REF ALT QUAL FILTER INFO (+ the FORMAT/sample remainder)
+// as duckdb::string_t slices of the input, POS parsed to int64, QUAL to float32.
+//
+// Replaces the tokenising the reference gets from noodles-vcf 0.34.0 through exon 0.2.6
+// (rust/src/arrow_reader.rs:116-153; registered at exon/src/exon_extension.cpp:55).  The
+// reference's LIST / STRUCT typing of id/alt/filter/info/formats is the next row of the scope
+// table and is not done here.
+//
+// Two implementations behind exg_vcf_scan:
+//   * fused (exg_fused_core.hpp skeleton): thread = line, fields cut out of LDS;
+//   * general: line index (exg_lines.hip) + thread = line reading global memory — any line length
+//     (multi-sample VCF lines exceed the fused kernel's 1 KiB straddle window), non-ASCII bytes.
+// Header lines (leading '#') are found by the host and passed as `lead`: lines that end before
+// `lead` are not rows.
+#include "exg_fused_core.hpp"
+#include "exg_lines.hpp"
+
+namespace exg {
+
+struct VcfDev {
+    const uint8_t *d_in;
+    uint64_t n_bytes;
+    uint64_t lead;
+    uint64_t first_line_index;  // unused (kept for the core's EOF arithmetic): 0
+    uint64_t payload_base;
+    uint32_t flags;
+    uint32_t pad;
+    exg_string_t *d_fields[9];
+    int64_t *d_pos;
+    float *d_qual;
+    uint64_t *d_qual_valid;
+    uint64_t *d_formats_valid;
+    uint64_t capacity;
+};
+
+// ---- exact decimal -> float32 ---------------------------------------------------------------------
+// f32::from_str is correctly rounded.  Device domain: <= 15 significant digits (mantissa < 2^53),
+// |decimal exponent| <= 22, result 0 or a normal float.  One correctly rounded f64 operation
+// (Clinger) + an FMA-exact residual decides the single case a double-rounded conversion could get
+// wrong (the f64 result sitting exactly on a float rounding boundary).  Literals outside the
+// domain are reported (EXG_PE_VCF_BAD_QUAL + EXG_RF_QUAL_RANGE), never mis-rounded.
+__device__ __constant__ double kPow10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                                             1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+
+__device__ __forceinline__ float round_exact(double q, double resid) {
+    // true value = q + (something with the sign of resid, magnitude < 1/2 ulp(q))
+    float f = (float)q;  // round to nearest even of q itself
+    unsigned long long b = (unsigned long long)__double_as_longlong(q);
+    if ((b & 0x1FFFFFFFull) == 0x10000000ull && resid != 0.0) {
+        float t = (float)__longlong_as_double((long long)(b & ~0x1FFFFFFFull));  // q truncated to 24 bits
+        f = resid > 0.0 ? __uint_as_float(__float_as_uint(t) + 1u) : t;
+    }
+    return f;
+}
+
+// status: 0 ok, 1 syntax error, 2 outside the exact device domain
+template <class Src>
+__device__ int parse_f32(const Src &src, int s, int e, float *out) {
+    int i = s;
+    if (i >= e) return 1;
+    bool neg = false;
+    uint32_t c = src.b(i);
+    if (c == '+' || c == '-') {
+        neg = c == '-';
+        i++;
+    }
+    int n = e - i;
+    if (n == 3 || n == 8) {
+        uint32_t l0 = src.b(i) | 0x20, l1 = src.b(i + 1) | 0x20, l2 = src.b(i + 2) | 0x20;
+        if (n == 3 && l0 == 'n' && l1 == 'a' && l2 == 'n') {
+            *out = __uint_as_float(0x7FC00000u);
+            return 0;
+        }
+        bool inf = l0 == 'i' && l1 == 'n' && l2 == 'f';
+        if (inf && n == 8) {
+            const char *rest = "inity";
+            for (int k = 0; k < 5; k++) inf = inf && (src.b(i + 3 + k) | 0x20) == (uint32_t)rest[k];
+        }
+        if (inf) {
+            *out = __uint_as_float(neg ? 0xFF800000u : 0x7F800000u);
+            return 0;
+        }
+    }
+    unsigned long long m = 0;
+    int nd = 0, sig = 0, e10 = 0;
+    bool inexact = false, seen_dot = false;
+    for (; i < e; i++) {
+        c = src.b(i);
+        if (c == '.') {
+            if (seen_dot) return 1;
+            seen_dot = true;
+            continue;
+        }
+        if (c < '0' || c > '9') break;
+        nd++;
+        if (sig < 19) {
+            if (m || c != '0') {
+                m = m * 10 + (c - '0');
+                sig++;
+            }
+            if (seen_dot) e10--;
+        } else {
+            if (c != '0') inexact = true;
+            if (!seen_dot) e10++;
+        }
+    }
+    if (nd == 0) return 1;
+    if (i < e) {
+        c = src.b(i);
+        if (c != 'e' && c != 'E') return 1;
+        i++;
+        bool eneg = false;
+        if (i < e && (src.b(i) == '+' || src.b(i) == '-')) eneg = src.b(i++) == '-';
+        if (i >= e) return 1;
+        int ev = 0;
+        for (; i < e; i++) {
+            c = src.b(i);
+            if (c < '0' || c > '9') return 1;
+            if (ev < 100000) ev = ev * 10 + (int)(c - '0');
+        }
+        e10 += eneg ? -ev : ev;
+    }
+    if (m == 0) {
+        *out = neg ? -0.0f : 0.0f;
+        return 0;
+    }
+    if (inexact || m >= (1ull << 53) || e10 < -22 || e10 > 22) return 2;
+    double dm = (double)m, q, resid;
+    if (e10 < 0) {
+        double p = kPow10[-e10];
+        q = dm / p;
+        resid = __fma_rn(-q, p, dm);  // m - q p, exact
+    } else {
+        double p = kPow10[e10];
+        q = dm * p;
+        resid = __fma_rn(dm, p, -q);  // m p - q, exact
+    }
+    if (!(q >= 1.1754943508222875e-38 && q <= 3.4028234663852886e38)) return 2;
+    float f = round_exact(q, resid);
+    *out = neg ? -f : f;
+    return 0;
+}
+
+// usize::from_str: optional '+', one or more digits, no overflow (63 bits kept)
+template <class Src>
+__device__ bool parse_pos(const Src &src, int s, int e, long long *out) {
+    int i = s;
+    if (i < e && src.b(i) == '+') i++;
+    if (i >= e) return false;
+    unsigned long long v = 0;
+    for (; i < e; i++) {
+        uint32_t c = src.b(i);
+        if (c < '0' || c > '9') return false;
+        if (v > (0x7FFFFFFFFFFFFFFFull - (c - '0')) / 10) return false;
+        v = v * 10 + (c - '0');
+    }
+    *out = (long long)v;
+    return true;
+}
+
+struct VcfRowInfo {
+    bool qual_valid, rest_valid;
+    uint32_t code;
+};
+
+// One data line [s, e) (CR already stripped), stored straight to row `out` (store == false: validate
+// only).  Src: b(i) byte, u32(i) 4 bytes at any alignment, str(i, len) -> string_t.
+// Everything is statically indexed (runtime-indexed arrays would live in scratch memory).
+template <class Src>
+__device__ __forceinline__ VcfRowInfo vcf_line(const Src &src, int s, int e, const VcfDev &a, unsigned long long out,
+                                               bool store) {
+    VcfRowInfo r;
+    r.code = 0;
+    r.qual_valid = false;
+    r.rest_valid = false;
+    // positions of the first 8 tabs (e when there are fewer); found 64 bytes at a time
+    int t[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) t[k] = e;
+    int found = 0;
+    for (int base = s; base < e && found < 8; base += 64) {
+        unsigned long long bits = 0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) bits |= (unsigned long long)nib4(match4(src.u32(base + 4 * q), 0x09090909u)) << (4 * q);
+        int rem = e - base;
+        if (rem < 64) bits &= (1ull << rem) - 1ull;
+        while (bits && found < 8) {
+            int pos = base + __ffsll((long long)bits) - 1;
+            bits &= bits - 1;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (k == found) t[k] = pos;
+            found++;
+        }
+    }
+    // field k = [fs_k, t[k]); fs_0 = s, fs_k = t[k-1] + 1; it exists iff fs_k <= e
+    if (found < 7) {
+        r.code = EXG_PE_VCF_MISSING_FIELD;
+        return r;
+    }
+    long long pos_v = 0;
+    if (!parse_pos(src, t[0] + 1, t[1], &pos_v)) {
+        r.code = EXG_PE_VCF_BAD_POS;
+        return r;
+    }
+    float qual_v = 0.f;
+    if (!(t[5] - (t[4] + 1) == 1 && src.b(t[4] + 1) == '.')) {
+        int st = parse_f32(src, t[4] + 1, t[5], &qual_v);
+        if (st) {
+            r.code = EXG_PE_VCF_BAD_QUAL | (st == 2 ? 0x80u : 0u);
+            return r;
+        }
+        r.qual_valid = true;
+    }
+    r.rest_valid = found == 8;
+    if (store) {
+        if (a.d_pos) a.d_pos[out] = pos_v;
+        if (a.d_qual) a.d_qual[out] = qual_v;
+        int fs = s;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (a.d_fields[k]) reinterpret_cast<uint4 *>(a.d_fields[k])[out] = src.str(fs, (uint32_t)(t[k] - fs));
+            fs = t[k] + 1;
+        }
+        if (a.d_fields[8]) {
+            uint4 z = {0, 0, 0, 0};
+            reinterpret_cast<uint4 *>(a.d_fields[8])[out] = r.rest_valid ? src.str(fs, (uint32_t)(e - fs)) : z;
+        }
+    }
+    return r;
+}
+
+// validity bits of 64 consecutive rows starting at out_base (may be negative for unowned lanes)
+__device__ __forceinline__ void store_validity64(uint64_t *words, unsigned long long bits, long long out_base,
+                                                 uint32_t lane) {
+    if (!words || !bits) return;
+    if (out_base < 0) {
+        bits >>= (unsigned long long)(-out_base);
+        out_base = 0;
+    }
+    if (lane == 0 && bits) {
+        uint32_t sh = (uint32_t)(out_base & 63);
+        unsigned long long lo = bits << sh, hi = sh ? bits >> (64 - sh) : 0;
+        if (lo) atomicOr((unsigned long long *)&words[out_base >> 6], lo);
+        if (hi) atomicOr((unsigned long long *)&words[(out_base >> 6) + 1], hi);
+    }
+}
+
+__device__ __forceinline__ void vcf_report(ScanWsHeader *hdr, uint32_t code, unsigned long long out, uint64_t line_off) {
+    if (code & 0x80u) atomicOr(&hdr->flags, EXG_RF_QUAL_RANGE);
+    atomicMin(&hdr->err_word, (out << 8) | (code & 0x7Fu));
+    atomicMin(&hdr->err_off, (unsigned long long)line_off);
+}
+
+// ---- fused ------------------------------------------------------------------------------------------
+struct LdsSrc {
+    const FusedLds &s;
+    uint64_t ptr_of_e0;
+    __device__ __forceinline__ uint32_t b(int e) const { return ldb(s, e); }
+    __device__ __forceinline__ uint32_t u32(int e) const { return ldu32(s, e); }  // reads stay inside the LDS slack
+    __device__ __forceinline__ uint4 str(int e, uint32_t len) const { return make_string_lds(s, e, len, ptr_of_e0); }
+};
+
+struct VcfFormat {
+    using Dev = VcfDev;
+    static constexpr int kMinWavesPerSimd = 5;
+    __device__ static __forceinline__ uint32_t eof_extra_lines(unsigned long long) { return 0; }
+    __device__ static __forceinline__ unsigned long long analytic_prefix(uint64_t) { return 0; }
+
+    __device__ static __forceinline__ void emit_half(const FusedLds &s, const VcfDev &a, ScanWsHeader *hdr,
+                                                     const TileCtx &c, unsigned long long halo_nl, uint32_t dev_mode,
+                                                     uint32_t lane, uint32_t wave,
+                                                     unsigned long long *__restrict__ tile_qend, uint64_t tile_index) {
+        if (threadIdx.x == 0) {  // offset just past the last line that ends in this half (0: none)
+            long long e = 0;
+            if (c.n_lines) {
+                e = (long long)c.tile_off + (int)s.nlist[4 + c.n_lines - 1] - kWin + 1;
+                if ((unsigned long long)e > a.n_bytes) e = (long long)a.n_bytes;
+            }
+            tile_qend[tile_index] = (unsigned long long)e;
+        }
+        if (dev_mode >= 3) return;
+        const bool no_store = (a.flags & EXG_F_NO_STORE) != 0;
+        const LdsSrc src{s, a.payload_base + c.tile_off - kWin};
+        for (uint32_t jb = 0; jb < c.n_lines; jb += kThreads) {
+            const uint32_t j = jb + threadIdx.x;
+            const long long out = (long long)(c.P + j) - (long long)halo_nl;
+            bool act = j < c.n_lines;
+            int e1 = 0;
+            if (act) {
+                e1 = s.nlist[4 + j];
+                act = (uint64_t)((int64_t)c.tile_off + e1 - kWin) >= a.lead && out >= 0;
+                if (act && !no_store && (unsigned long long)out >= a.capacity) {
+                    atomicOr(&hdr->flags, EXG_RF_CAPACITY);
+                    act = false;
+                }
+            }
+            bool qv = false, rv = false;
+            if (act) {
+                const uint32_t q0 = s.nlist[3 + j];  // newline before the line
+                if (q0 == kNoneE) {
+                    if (c.first_of_buffer) {
+                        atomicAdd(&hdr->n_unresolved, 1ull);
+                        atomicOr(&hdr->flags, EXG_RF_HEAD_UNRESOLVED);
+                    } else {
+                        atomicOr(&hdr->overflow, 1u);  // line longer than the window: general path
+                    }
+                } else {
+                    int s0 = (int)q0 + 1;
+                    if (e1 > s0 && !(c.is_eof_tile && e1 == c.lim_e) && ldb(s, e1 - 1) == '\r') e1--;
+                    VcfRowInfo r = vcf_line(src, s0, e1, a, (unsigned long long)out, !no_store && dev_mode != 2);
+                    if (r.code) vcf_report(hdr, r.code, (unsigned long long)out, c.tile_off + s0 - kWin);
+                    qv = r.qual_valid;
+                    rv = r.rest_valid;
+                }
+            }
+            if (!no_store) {
+                long long out_base = (long long)(c.P + jb + wave * 64) - (long long)halo_nl;
+                unsigned long long qb = __ballot(qv), rb = __ballot(rv);
+                store_validity64(a.d_qual_valid, qb, out_base, lane);
+                store_validity64(a.d_formats_valid, rb, out_base, lane);
+            }
+        }
+    }
+};
+
+// ---- general path: thread = line, bytes from global memory -----------------------------------------------
+struct GlobalSrc {
+    const uint8_t *p;  // d_in
+    uint64_t base;     // offset added to the (int) positions
+    uint64_t payload_base;
+    uint64_t limit;  // n_bytes rounded up to 16: reads past it are not allowed
+    __device__ __forceinline__ uint32_t b(int i) const { return p[base + (uint64_t)(int64_t)i]; }
+    __device__ __forceinline__ uint32_t u32(int i) const {
+        uint64_t o = base + (uint64_t)(int64_t)i;
+        uint32_t w = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (o + k < limit) w |= (uint32_t)p[o + k] << (8 * k);
+        return w;
+    }
+    __device__ __forceinline__ uint4 str(int i, uint32_t len) const {
+        return make_string_global(p, base + (uint64_t)(int64_t)i, len, payload_base);
+    }
+};
+
+__global__ __launch_bounds__(256) void k_vcf_lines(VcfDev a, const uint64_t *__restrict__ nl_pos, ScanWsHeader *hdr,
+                                                   const unsigned int *gate) {
+    if (gate && *gate == 0) return;
+    const uint64_t T = hdr->total_lines < hdr->lines_cap ? hdr->total_lines : hdr->lines_cap;
+    const uint64_t halo = hdr->halo_nl;
+    const bool no_store = (a.flags & EXG_F_NO_STORE) != 0;
+    const uint64_t n_iter = (T + 63) / 64;
+    const uint64_t wave_id = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t it = wave_id; it < n_iter; it += n_waves) {
+        const uint64_t j = it * 64 + lane_id();
+        bool act = j < T && j >= halo;
+        const uint64_t out = j - halo;
+        if (act && !no_store && out >= a.capacity) {
+            atomicOr(&hdr->flags, EXG_RF_CAPACITY);
+            act = false;
+        }
+        bool qv = false, rv = false;
+        if (act) {
+            uint64_t e1 = nl_pos[j];
+            bool resolved = j > 0 || (a.flags & EXG_F_BOF);
+            uint64_t s0 = j > 0 ? nl_pos[j - 1] + 1 : 0;
+            if (!resolved) {
+                atomicAdd(&hdr->n_unresolved, 1ull);
+                atomicOr(&hdr->flags, EXG_RF_HEAD_UNRESOLVED);
+            } else if (e1 - s0 > 0x7FFFFFF0ull) {
+                vcf_report(hdr, EXG_PE_FIELD_TOO_LONG, out, s0);
+            } else {
+                if (s0 > e1) s0 = e1;
+                bool virt = e1 >= a.n_bytes;
+                if (!virt && e1 > s0 && a.d_in[e1 - 1] == '\r') e1--;
+                const GlobalSrc src{a.d_in, s0, a.payload_base, (a.n_bytes + 15) & ~15ull};
+                VcfRowInfo r = vcf_line(src, 0, (int)(e1 - s0), a, out, !no_store);
+                if (!r.code && (hdr->flags & EXG_RF_NON_ASCII)) {
+                    // noodles builds str fields: the line must be UTF-8
+                    if (!utf8_valid_global(a.d_in, s0, e1)) r.code = EXG_PE_INVALID_UTF8;
+                }
+                if (r.code) vcf_report(hdr, r.code, out, s0);
+                qv = r.qual_valid;
+                rv = r.rest_valid;
+            }
+        }
+        if (!no_store) {
+            long long out_base = (long long)(it * 64) - (long long)halo;
+            unsigned long long qb = __ballot(qv), rb = __ballot(rv);
+            store_validity64(a.d_qual_valid, qb, out_base, lane_id());
+            store_validity64(a.d_formats_valid, rb, out_base, lane_id());
+        }
+    }
+}
+
+// Result block.  fused != 0: positions come from tile_qend; else from nl_pos.
+__global__ __launch_bounds__(256) void k_vcf_finalize(VcfDev a, ScanWsHeader *hdr,
+                                                      const unsigned long long *__restrict__ tile_qend, uint32_t n_tiles,
+                                                      const uint64_t *__restrict__ nl_pos, int fused, exg_scan_result *res,
+                                                      const unsigned int *gate) {
+    if (gate && *gate == 0) return;
+    __shared__ unsigned long long s_qend;
+    __shared__ int s_found;
+    if (threadIdx.x == 0) {
+        s_qend = 0;
+        s_found = 0;
+    }
+    __syncthreads();
+    if (fused && !hdr->overflow) {
+        for (int64_t base = (int64_t)n_tiles - 1; base >= 0; base -= 256) {
+            int64_t t = base - threadIdx.x;
+            unsigned long long q = t >= 0 ? tile_qend[t] : 0;
+            if (q) atomicMax(&s_qend, q);
+            if (q) s_found = 1;
+            __syncthreads();
+            if (s_found) break;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x) return;
+    if (fused && hdr->overflow) {
+        exg_scan_result r = {};
+        r.flags = EXG_RF_FALLBACK;
+        r.error_offset = ~0ull;
+        r.error_record = ~0ull;
+        *res = r;
+        return;
+    }
+    const uint64_t T = hdr->total_lines, halo = hdr->halo_nl;
+    uint64_t n_owned = T > halo ? T - halo : 0;
+    uint64_t last_end = s_qend;
+    if (!fused) {
+        uint64_t Tc = T < hdr->lines_cap ? T : hdr->lines_cap;
+        last_end = Tc ? nl_pos[Tc - 1] + 1 : 0;
+        if (last_end > a.n_bytes) last_end = a.n_bytes;
+    }
+    exg_scan_result r;
+    r.n_lines = n_owned;
+    r.flags = hdr->flags | (gate ? EXG_RF_FALLBACK : 0u);
+    if (!fused && T > hdr->lines_cap) r.flags |= EXG_RF_INDEX_OVERFLOW;
+    r.payload_bytes = 0;
+    r.reserved = 0;
+    r.error_code = 0;
+    r.error_offset = ~0ull;
+    r.error_record = ~0ull;
+    uint64_t n_rec = (n_owned < a.capacity || (a.flags & EXG_F_NO_STORE)) ? n_owned : a.capacity;
+    uint64_t consumed = last_end > a.lead ? last_end : a.lead;
+    unsigned long long err = hdr->err_word;
+    if (err != kNoError) {
+        uint64_t rec = err >> 8;
+        r.error_code = (uint32_t)(err & 0xFF);
+        r.error_record = rec;
+        r.error_offset = hdr->err_off;
+        if (rec < n_rec) {
+            n_rec = rec;
+            consumed = hdr->err_off > a.lead ? hdr->err_off : a.lead;
+        }
+    }
+    r.n_records = n_rec;
+    r.consumed_bytes = n_rec ? consumed : a.lead;
+    *res = r;
+}
+
+__global__ void k_init_hdr(ScanWsHeader *hdr, uint64_t lines_cap, uint32_t mode);
+__global__ void k_clear_words_gated(uint64_t *w, uint64_t n, const unsigned int *gate);
+
+static int run_vcf_general(const VcfDev &dev, uint8_t *ws, const FastqWsLayout &l, exg_scan_result *d_result,
+                           hipStream_t stream, bool after_fused) {
+    ScanWsHeader *hdr = reinterpret_cast<ScanWsHeader *>(ws);
+    const uint64_t *nl_pos = reinterpret_cast<const uint64_t *>(ws + l.off_nl_pos);
+    const unsigned int *gate = after_fused ? &hdr->overflow : nullptr;
+    hipLaunchKernelGGL(k_init_hdr, dim3(1), dim3(1), 0, stream, hdr, l.lines_cap, after_fused ? 1u : 0u);
+    if (after_fused && !(dev.flags & EXG_F_NO_STORE)) {
+        uint64_t words = (dev.capacity + 63) / 64;
+        uint32_t g = (uint32_t)((words + 255) / 256 < 1024 ? (words + 255) / 256 : 1024);
+        if (words && dev.d_qual_valid)
+            hipLaunchKernelGGL(k_clear_words_gated, dim3(g), dim3(256), 0, stream, dev.d_qual_valid, words, gate);
+        if (words && dev.d_formats_valid)
+            hipLaunchKernelGGL(k_clear_words_gated, dim3(g), dim3(256), 0, stream, dev.d_formats_valid, words, gate);
+    }
+    int rc = launch_line_index(dev.d_in, dev.n_bytes, dev.lead, ws, l, (dev.flags & EXG_F_EOF) ? 1 : 0, 0, stream, gate);
+    if (rc) return rc;
+    uint64_t est = dev.n_bytes / 32 + 256;
+    uint32_t grid = (uint32_t)((est + 255) / 256 < 2048 ? (est + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_vcf_lines, dim3(grid), dim3(256), 0, stream, dev, nl_pos, hdr, gate);
+    hipLaunchKernelGGL(k_vcf_finalize, dim3(1), dim3(256), 0, stream, dev, hdr, (const unsigned long long *)nullptr, 0u,
+                       nl_pos, 0, d_result, gate);
+    EXG_HIP_CHECK(hipGetLastError());
+    return EXG_OK;
+}
+
+static int run_vcf_fused(const VcfDev &dev, uint8_t *ws, const FastqWsLayout &l, exg_scan_result *d_result,
+                         hipStream_t stream) {
+    ScanWsHeader *hdr = reinterpret_cast<ScanWsHeader *>(ws);
+    uint64_t n_super64 = (dev.n_bytes + kSuper - 1) / kSuper;
+    if (n_super64 == 0) n_super64 = 1;
+    if (n_super64 > 0x7FFFFFF0ull) {
+        set_error("exg_vcf_scan: buffer too large for one launch");
+        return EXG_E_INVALID_ARG;
+    }
+    uint32_t n_super = (uint32_t)n_super64;
+    unsigned long long *tileA = reinterpret_cast<unsigned long long *>(ws + l.off_tile_desc);
+    unsigned long long *tileP = tileA + l.n_tiles_fused;
+    unsigned long long *tile_qend = tileP + l.n_tiles_fused;
+    hipLaunchKernelGGL(k_init_hdr, dim3(1), dim3(1), 0, stream, hdr, l.lines_cap, 0u);
+    EXG_HIP_CHECK(hipMemsetAsync(tileA, 0, (size_t)l.n_tiles_fused * 16, stream));
+    if (dev.lead) {
+        int rc = exg_count_newlines(dev.d_in, 0, dev.lead, (uint64_t *)&hdr->halo_nl, stream);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_fused<VcfFormat>, dim3(n_super + 1), dim3(kThreads), 0, stream, dev, tileA, tileP, tile_qend, hdr,
+                       n_super);
+    hipLaunchKernelGGL(k_vcf_finalize, dim3(1), dim3(256), 0, stream, dev, hdr, tile_qend, n_super * kHalves,
+                       (const uint64_t *)nullptr, 1, d_result, (const unsigned int *)nullptr);
+    EXG_HIP_CHECK(hipGetLastError());
+    return EXG_OK;
+}
+
+}  // namespace exg
+
+using namespace exg;
+
+extern "C" int exg_vcf_scan(const exg_vcf_scan_args *a) {
+    if (!a || !a->d_result || !a->d_workspace || (a->n_bytes && !a->d_input) || ((uintptr_t)a->d_input & 15) ||
+        a->lead > a->n_bytes) {
+        set_error("exg_vcf_scan: bad arguments (null pointer, unaligned input or lead > n_bytes)");
+        return EXG_E_INVALID_ARG;
+    }
+    FastqWsLayout l = fastq_ws_layout(a->n_bytes, a->workspace_bytes);
+    if (a->workspace_bytes < fastq_ws_layout(a->n_bytes, 0).off_nl_pos + 64) {
+        set_error("exg_vcf_scan: workspace too small");
+        return EXG_E_INVALID_ARG;
+    }
+    VcfDev dev;
+    dev.d_in = (const uint8_t *)a->d_input;
+    dev.n_bytes = a->n_bytes;
+    dev.lead = a->lead;
+    dev.first_line_index = 0;
+    dev.payload_base = a->payload_base;
+    dev.flags = a->flags;
+    dev.pad = 0;
+    for (int k = 0; k < 9; k++) dev.d_fields[k] = a->d_fields[k];
+    dev.d_pos = a->d_pos;
+    dev.d_qual = a->d_qual;
+    dev.d_qual_valid = a->d_qual_validity;
+    dev.d_formats_valid = a->d_formats_validity;
+    dev.capacity = a->capacity_records;
+    hipStream_t stream = (hipStream_t)a->stream;
+    uint8_t *ws = (uint8_t *)a->d_workspace;
+    if (a->capacity_records && !(a->flags & EXG_F_NO_STORE)) {
+        size_t vb = (size_t)((a->capacity_records + 63) / 64) * 8;
+        if (dev.d_qual_valid) EXG_HIP_CHECK(hipMemsetAsync(dev.d_qual_valid, 0, vb, stream));
+        if (dev.d_formats_valid) EXG_HIP_CHECK(hipMemsetAsync(dev.d_formats_valid, 0, vb, stream));
+    }
+    switch (a->algo) {
+        case EXG_ALGO_MULTIPASS:
+            return run_vcf_general(dev, ws, l, a->d_result, stream, false);
+        case EXG_ALGO_FUSED:
+            return run_vcf_fused(dev, ws, l, a->d_result, stream);
+        case EXG_ALGO_AUTO: {
+            int rc = run_vcf_fused(dev, ws, l, a->d_result, stream);
+            if (rc) return rc;
+            return run_vcf_general(dev, ws, l, a->d_result, stream, true);
+        }
+        default:
+            set_error("exg_vcf_scan: unknown algo %u", a->algo);
+            return EXG_E_INVALID_ARG;
+    }
+}

@@ -86,3 +86,59 @@ class FastqScan:
         cols = [c[:n].cpu().numpy().view(np.uint8).reshape(n, 16) for c in self.cols]
         words = self.validity[: (n + 63) // 64].cpu().numpy().view(np.uint64)
         return cols, words
+
+
+class VcfScan:
+    """Reusable output + workspace buffers for exg_vcf_scan."""
+
+    FIELDS = ["chrom", "pos", "id", "ref", "alt", "qual", "filter", "info", "formats"]
+
+    def __init__(self, n_bytes, capacity_records=None, device="cuda"):
+        torch = _torch()
+        self.lib = load_library()
+        self.n_bytes = n_bytes
+        self.capacity = int(capacity_records if capacity_records is not None else n_bytes // 8 + 16)
+        cap = max(self.capacity, 1)
+        self.cols = [torch.empty((cap, 2), dtype=torch.int64, device=device) for _ in range(9)]
+        self.pos = torch.empty((cap,), dtype=torch.int64, device=device)
+        self.qual = torch.empty((cap,), dtype=torch.float32, device=device)
+        self.qual_valid = torch.empty(((cap + 63) // 64,), dtype=torch.int64, device=device)
+        self.formats_valid = torch.empty(((cap + 63) // 64,), dtype=torch.int64, device=device)
+        self.ws_bytes = int(self.lib.exg_scan_workspace_bytes(abi.EXG_FMT_VCF, n_bytes))
+        self.ws = torch.empty((self.ws_bytes + 255) // 8, dtype=torch.int64, device=device)
+        self.result = torch.zeros(8, dtype=torch.int64, device=device)
+        self.args = abi.VcfScanArgs()
+
+    def launch(self, d_input, n_bytes=None, lead=0, payload_base=0, flags=abi.EXG_F_BOF | abi.EXG_F_EOF,
+               algo=abi.EXG_ALGO_AUTO, project=None):
+        a = self.args
+        a.d_input = d_input.data_ptr()
+        a.n_bytes = self.n_bytes if n_bytes is None else n_bytes
+        a.lead = lead
+        a.payload_base = payload_base
+        a.flags = flags
+        a.algo = algo
+        for k in range(9):
+            a.d_fields[k] = self.cols[k].data_ptr() if (project is None or k in project) else None
+        a.d_pos = self.pos.data_ptr()
+        a.d_qual = self.qual.data_ptr()
+        a.d_qual_validity = self.qual_valid.data_ptr()
+        a.d_formats_validity = self.formats_valid.data_ptr()
+        a.capacity_records = self.capacity
+        a.d_workspace = self.ws.data_ptr()
+        a.workspace_bytes = self.ws_bytes
+        a.d_result = self.result.data_ptr()
+        a.stream = stream_ptr().value
+        check(self.lib.exg_vcf_scan(C.byref(a)))
+
+    def fetch(self):
+        r = abi.ScanResult()
+        check(self.lib.exg_fetch_result(C.c_void_p(self.result.data_ptr()), stream_ptr(), C.byref(r)))
+        return r
+
+    def host(self, n):
+        cols = [c[:n].cpu().numpy().view(np.uint8).reshape(n, 16) for c in self.cols]
+        nw = (n + 63) // 64
+        return dict(cols=cols, pos=self.pos[:n].cpu().numpy(), qual=self.qual[:n].cpu().numpy(),
+                    qual_valid=self.qual_valid[:nw].cpu().numpy().view(np.uint64),
+                    formats_valid=self.formats_valid[:nw].cpu().numpy().view(np.uint64))

@@ -1,0 +1,191 @@
+"""Parity of the HIP VCF scan (C-ABI exg_vcf_scan) against the oracle: nine string_t column vectors,
+parsed POS (int64) and QUAL (float32, exact), QUAL / formats validity words, result block."""
+import os
+
+import numpy as np
+import pytest
+
+from exon_duckdb_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+BASE = 0x7E0000000000
+ALGOS = [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS, abi.EXG_ALGO_AUTO]
+HDR = b"##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n"
+
+
+def header_bytes(data: bytes) -> int:
+    """Host side of the boundary: leading '#' lines (what the reader does before calling the kernel)."""
+    pos = 0
+    while pos < len(data) and data[pos:pos + 1] == b"#":
+        nl = data.find(b"\n", pos)
+        pos = len(data) if nl < 0 else nl + 1
+    return pos
+
+
+def run_gpu(data, algo, capacity=None, flags=abi.EXG_F_BOF | abi.EXG_F_EOF):
+    from exon_duckdb_amd import device
+
+    data = bytes(data)
+    d_in = device.upload(data)
+    scan = device.VcfScan(len(data), capacity_records=capacity)
+    scan.launch(d_in, lead=header_bytes(data), payload_base=BASE, flags=flags, algo=algo)
+    res = scan.fetch()
+    return res, scan.host(int(res.n_records))
+
+
+def bits(words, n):
+    return np.unpackbits(words.view(np.uint8), bitorder="little")[:n]
+
+
+def check(oracle, data, algo, expect_fallback=False):
+    data = bytes(data)
+    exp = oracle.vcf_parse(data, payload_base=BASE)
+    res, got = run_gpu(data, algo)
+    non_ascii = any(b >= 0x80 for b in data)
+    if algo == abi.EXG_ALGO_FUSED and (res.flags & abi.EXG_RF_FALLBACK):
+        assert expect_fallback or non_ascii
+        return res
+    assert res.error_code == exp.error_code, (res.error_code, exp.error_code, exp.error_message)
+    assert res.n_records == exp.n_rows
+    n = exp.n_rows
+    if exp.error_code:
+        assert res.error_record == exp.error_record and res.error_offset == exp.error_offset
+    for k, name in enumerate(oracle.VCF_FIELDS):
+        assert np.array_equal(got["cols"][k], exp.string_t[name][0]), name
+    assert np.array_equal(got["pos"], exp.extra["pos"])
+    qv = bits(got["qual_valid"], n)
+    assert np.array_equal(qv, exp.extra["qual_valid"])
+    assert np.array_equal(got["qual"].view(np.uint32)[qv == 1], exp.extra["qual"].view(np.uint32)[qv == 1])  # bit exact
+    assert np.array_equal(bits(got["formats_valid"], n), exp.columns["formats"].valid)
+    if not exp.error_code:
+        assert res.consumed_bytes == len(data) and res.n_lines == n
+    return res
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("name", ["vcf/index.vcf", "vcf/vcf_file.vcf", "vcf/vcf_meta_meta.vcf"])
+def test_reference_fixtures(gpu, oracle, golden_dir, name, algo):
+    with open(os.path.join(golden_dir, name), "rb") as f:
+        data = f.read()
+    res = check(oracle, data, algo)
+    if name == "vcf/index.vcf":
+        assert res.n_records == 621        # test_vcf_record_scan.test:4-7
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_reference_row0(gpu, golden_dir, algo):
+    # test_vcf_record_scan.test:10-19, straight from the device output
+    with open(os.path.join(golden_dir, "vcf/index.vcf"), "rb") as f:
+        data = f.read()
+    res, got = run_gpu(data, algo)
+
+    def text(k):
+        st = got["cols"][k][0]
+        ln = int(st[:4].view(np.uint32)[0])
+        if ln <= 12:
+            return st[4:4 + ln].tobytes().decode()
+        off = int(st[8:16].view(np.uint64)[0]) - BASE
+        return data[off:off + ln].decode()
+    assert text(0) == "1" and int(got["pos"][0]) == 9999919 and text(3) == "G" and text(4) == "<*>"
+    assert float(got["qual"][0]) == 0.0 and (int(got["qual_valid"][0]) & 1) == 1
+    info = text(7)
+    assert "INDEL" not in info.split(";") and "DP=1" in info.split(";")
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("n_lines", [1, 2, 63, 64, 65, 1000, 30011])
+def test_synth_vcf(gpu, oracle, n_lines, algo):
+    data = oracle.synth_vcf(n_lines)
+    res = check(oracle, data, algo)
+    assert res.n_records == n_lines
+
+
+EDGE = {
+    "header_only": HDR,
+    "one_line": HDR + b"1\t5\t.\tA\tC\t.\tPASS\tDP=1\n",
+    "no_trailing_newline": HDR + b"1\t5\t.\tA\tC\t3.5\tPASS\tX\n1\t7\t.\tA\tC\t.\t.\tY",
+    "crlf": HDR + b"1\t5\t.\tA\tC\t3.5\tPASS\tX\r\n1\t7\trs1\tA\tC,G\t1e2\tq10\t.\tGT\t0/1\t1/1\r\n",
+    "with_samples": HDR + b"2\t6\trs1\tA\tC,G\t1e2\tq10\t.\tGT\t0/1\t1/1\n",
+    "empty_fields": HDR + b"\t5\t\t\t\t.\t\t\n",
+    "missing_field": HDR + b"1\t5\t.\tA\tC\t.\tPASS\tOK\n1\t5\t.\tA\tC\t.\tPASS\n",
+    "blank_line": HDR + b"1\t5\t.\tA\tC\t.\tPASS\t.\n\n",
+    "bad_pos": HDR + b"1\tx5\t.\tA\tC\t.\tPASS\t.\n",
+    "bad_pos_empty": HDR + b"1\t\t.\tA\tC\t.\tPASS\t.\n",
+    "pos_plus_sign": HDR + b"1\t+42\t.\tA\tC\t.\tPASS\t.\n",
+    "pos_big": HDR + b"1\t9223372036854775807\t.\tA\tC\t.\tPASS\t.\n",
+    "pos_overflow": HDR + b"1\t9223372036854775808\t.\tA\tC\t.\tPASS\t.\n",
+    "bad_qual": HDR + b"1\t5\t.\tA\tC\tabc\tPASS\t.\n",
+    "qual_forms": HDR + b"".join(b"1\t5\t.\tA\tC\t" + q + b"\tPASS\t.\n" for q in
+                                 [b"0", b"0.0", b"59.2", b"12.9", b"1e2", b"1E+2", b"2.5e-3", b".5", b"5.", b"+7.25",
+                                  b"-0", b"inf", b"-Infinity", b"NaN", b"3000", b"16777217", b"0.1", b"0.3",
+                                  b"123456.789", b"1.17549435e-38"[:0] + b"9.999999e9", b"000012.50"]),
+    "qual_bad_forms": HDR + b"1\t5\t.\tA\tC\t1e\tPASS\t.\n",
+    "qual_dot_only": HDR + b"1\t5\t.\tA\tC\t..\tPASS\t.\n",
+    "long_info": HDR + b"1\t5\t.\tA\tC\t1\tPASS\t" + b"K=" + b"v" * 700 + b"\tGT\t0/1\n" + b"1\t6\t.\tA\tC\t1\tPASS\tS\n",
+    "first_error_wins": HDR + b"1\t5\t.\tA\tC\t.\tPASS\t.\n1\tzz\t.\tA\tC\t.\tPASS\t.\n1\t5\t.\tA\n",
+    "hash_line_after_header_is_data": HDR + b"1\t5\t.\tA\tC\t.\tPASS\t.\n#oops\n",
+}
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("case", sorted(EDGE))
+def test_edge_cases(gpu, oracle, case, algo):
+    check(oracle, EDGE[case], algo)
+
+
+def test_no_header_is_reported_by_the_oracle_only(oracle):
+    # header detection is host work (the reader finds the '#' prefix): documented split of labour
+    assert oracle.vcf_parse(b"1\t5\t.\tA\tC\t.\tPASS\tDP=1\n").error_code == abi.EXG_PE_VCF_NO_HEADER
+
+
+@pytest.mark.parametrize("algo", [abi.EXG_ALGO_MULTIPASS, abi.EXG_ALGO_AUTO, abi.EXG_ALGO_FUSED])
+def test_long_lines_fall_back(gpu, oracle, algo):
+    # multi-sample lines longer than the fused kernel's straddle window
+    rng = np.random.default_rng(3)
+    lines = []
+    for k in range(200):
+        ns = int(rng.integers(1, 4000)) if k % 2 else 2
+        lines.append(b"%d\t%d\t.\tA\tC\t%d.5\tPASS\tDP=%d\tGT" % (k % 22 + 1, 100 + k, k, k) + b"\t0/1" * ns + b"\n")
+    data = HDR + b"".join(lines)
+    res = check(oracle, data, algo, expect_fallback=True)
+    if algo != abi.EXG_ALGO_FUSED:
+        assert res.n_records == 200 and (algo == abi.EXG_ALGO_MULTIPASS or res.flags & abi.EXG_RF_FALLBACK)
+
+
+@pytest.mark.parametrize("algo", [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS])
+def test_qual_parse_is_correctly_rounded(gpu, oracle, algo):
+    rng = np.random.default_rng(11)
+    quals = []
+    for _ in range(4000):
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            quals.append(b"%d.%0*d" % (rng.integers(0, 100000), int(rng.integers(1, 7)), rng.integers(0, 10 ** 6) % 10 ** int(rng.integers(1, 7))))
+        elif kind == 1:
+            quals.append(b"%d" % rng.integers(0, 2 ** 40))
+        elif kind == 2:
+            quals.append(b"%.9g" % float(np.float32(rng.random() * 10.0 ** int(rng.integers(-6, 9)))))
+        else:
+            quals.append(b"%de%d" % (rng.integers(1, 10 ** 9), rng.integers(-20, 15)))
+    data = HDR + b"".join(b"1\t5\t.\tA\tC\t" + q + b"\tPASS\t.\n" for q in quals)
+    check(oracle, data, algo)
+
+
+@pytest.mark.parametrize("algo", [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS])
+def test_projection_and_capacity(gpu, oracle, algo):
+    from exon_duckdb_amd import device
+
+    data = bytes(oracle.synth_vcf(500))
+    exp = oracle.vcf_parse(data, payload_base=BASE)
+    d_in = device.upload(data)
+    scan = device.VcfScan(len(data), capacity_records=100)
+    for c in scan.cols:
+        c.fill_(-1)
+    scan.launch(d_in, lead=header_bytes(data), payload_base=BASE, algo=algo, project={0, 7})
+    res = scan.fetch()
+    assert res.flags & abi.EXG_RF_CAPACITY and res.n_records == 100
+    got = scan.host(100)
+    assert np.array_equal(got["cols"][0], exp.string_t["chrom"][0][:100])
+    assert np.array_equal(got["cols"][7], exp.string_t["info"][0][:100])
+    assert (got["cols"][3] == 0xFF).all()       # unprojected column untouched
+    assert np.array_equal(got["pos"], exp.extra["pos"][:100])
