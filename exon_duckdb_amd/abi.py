@@ -90,6 +90,28 @@ class VcfScanArgs(C.Structure):
     ]
 
 
+class FastaScanArgs(C.Structure):
+    _fields_ = [
+        ("d_input", C.c_void_p),
+        ("n_bytes", C.c_uint64),
+        ("lead", C.c_uint64),
+        ("payload_base", C.c_uint64),
+        ("seq_payload_base", C.c_uint64),
+        ("flags", C.c_uint32),
+        ("algo", C.c_uint32),
+        ("d_id", C.c_void_p),
+        ("d_description", C.c_void_p),
+        ("d_sequence", C.c_void_p),
+        ("d_description_validity", C.c_void_p),
+        ("d_seq_payload", C.c_void_p),
+        ("capacity_records", C.c_uint64),
+        ("d_workspace", C.c_void_p),
+        ("workspace_bytes", C.c_uint64),
+        ("d_result", C.c_void_p),
+        ("stream", C.c_void_p),
+    ]
+
+
 # every symbol include/exon_gpu.h declares -> (restype, argtypes); None = not yet bound by name only
 SIGNATURES = {
     "exg_abi_version": (C.c_int, []),
@@ -99,6 +121,7 @@ SIGNATURES = {
     "exg_scan_workspace_bytes": (C.c_uint64, [C.c_int, C.c_uint64]),
     "exg_fastq_scan": (C.c_int, [C.POINTER(FastqScanArgs)]),
     "exg_vcf_scan": (C.c_int, [C.POINTER(VcfScanArgs)]),
+    "exg_fasta_scan": (C.c_int, [C.POINTER(FastaScanArgs)]),
     "exg_fetch_result": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(ScanResult)]),
     "exg_count_newlines": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
     "exg_synth_fastq": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),

@@ -54,8 +54,7 @@ extern "C" const char *exg_parse_error_string(uint32_t code) {
 }
 
 extern "C" uint64_t exg_scan_workspace_bytes(int format, uint64_t n_bytes) {
-    (void)format;  // one layout serves the three formats
-    return fastq_ws_layout(n_bytes, 0).total_bytes;
+    return fastq_ws_layout(n_bytes, 0, format == EXG_FMT_FASTA ? 4 : 1).total_bytes;
 }
 
 extern "C" int exg_fetch_result(const exg_scan_result *d_result, void *stream, exg_scan_result *out) {

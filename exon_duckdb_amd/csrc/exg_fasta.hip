@@ -1,0 +1,392 @@
+// exg_fasta.hip — FASTA record scan (read_fasta): id, description (NULL when absent), sequence.
+//
+// Semantics restated (not the code): noodles-fasta 0.27.0 Reader::read_definition / read_sequence and
+// record::Definition::from_str as driven by exon 0.2.6 datasources::fasta (reached from
+// rust/src/arrow_reader.rs:116-153; registered at exon/src/exon_extension.cpp:50):
+//   definition line = any line whose first byte is '>' (the first line must be one); after '>' the
+//   id runs to the first ASCII whitespace, the rest, trimmed, is the description; the sequence is
+//   every following line up to the next definition line, LF (and a CR before it) removed and the
+//   lines CONCATENATED — so it is materialised in a compacted payload buffer, it is not a slice of
+//   the input.
+//
+// Round-1 implementation: the general multipass shape (line index -> per-line classification ->
+// device-wide scans of record count and payload bytes -> definitions -> payload copy -> sequence
+// string_t).  Whole-file buffers only (EXG_F_BOF | EXG_F_EOF): a FASTA record can span the whole
+// input, so byte-range shards would split sequences.  The single-pass form is the
+// next step for this format.
+#include "exg_fastq_ws.hpp"
+#include "exg_lines.hpp"
+
+namespace exg {
+
+struct FastaDev {
+    const uint8_t *d_in;
+    uint64_t n_bytes;
+    uint64_t payload_base;
+    uint64_t seq_payload_base;
+    uint32_t flags;
+    uint32_t pad;
+    exg_string_t *d_id, *d_desc, *d_seq;
+    uint64_t *d_desc_valid;
+    uint8_t *d_payload;
+    uint64_t capacity;
+};
+
+struct FastaArrays {
+    const uint64_t *nl_pos;
+    uint64_t *rec_pre;    // [i] = definition lines before line i   (T + 1 entries after the scan)
+    uint64_t *pay_pre;    // [i] = sequence bytes before line i      (T + 1 entries)
+    uint64_t *rec_start;  // [r] = payload offset of record r's sequence (n_rec + 1 entries)
+};
+
+__device__ __forceinline__ void line_bounds(const FastaDev &a, const uint64_t *nl_pos, uint64_t i, uint64_t *s,
+                                            uint64_t *e) {
+    uint64_t raw_end = nl_pos[i];
+    uint64_t start = i ? nl_pos[i - 1] + 1 : 0;
+    if (start > raw_end) start = raw_end;
+    uint64_t end = raw_end;
+    if (raw_end < a.n_bytes && end > start && a.d_in[end - 1] == '\r') end--;  // CR only in front of a real LF
+    *s = start;
+    *e = end;
+}
+
+// per line: is it a definition line, how many sequence bytes does it contribute
+__global__ __launch_bounds__(256) void k_fa_classify(FastaDev a, FastaArrays w, ScanWsHeader *hdr) {
+    const uint64_t T = hdr->total_lines < hdr->lines_cap ? hdr->total_lines : hdr->lines_cap;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= T; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t def = 0, len = 0;
+        if (i < T) {
+            uint64_t s, e;
+            line_bounds(a, w.nl_pos, i, &s, &e);
+            uint64_t raw_end = w.nl_pos[i];
+            def = (s < raw_end && a.d_in[s] == '>') ? 1 : 0;
+            len = def ? 0 : e - s;
+            if (i == 0 && !def)  // the reader wants a definition first
+                atomicMin(&hdr->err_word, (0ull << 8) | (s == e ? EXG_PE_FASTA_EMPTY_DEF : EXG_PE_FASTA_MISSING_PREFIX));
+        }
+        w.rec_pre[i] = def;
+        w.pay_pre[i] = len;
+    }
+}
+
+// ---- in-place exclusive scan of a u64 array whose length lives on the device -------------------------
+static constexpr uint32_t kScanChunk = 4096;  // 1024 threads x 4
+
+__global__ __launch_bounds__(1024) void k_scan_local(uint64_t *data, const ScanWsHeader *hdr, uint64_t *block_sums) {
+    __shared__ unsigned long long s_w[16];
+    const uint64_t n = (hdr->total_lines < hdr->lines_cap ? hdr->total_lines : hdr->lines_cap) + 1;
+    const uint64_t base = (uint64_t)blockIdx.x * kScanChunk;
+    if (base >= n) return;
+    uint64_t v[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint64_t idx = base + (uint64_t)threadIdx.x * 4 + k;
+        v[k] = idx < n ? data[idx] : 0;
+        sum += v[k];
+    }
+    unsigned long long incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        unsigned long long o = __shfl_up(incl, d, 64);
+        if ((int)(threadIdx.x & 63) >= d) incl += o;
+    }
+    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    unsigned long long off = 0, tot = 0;
+    for (uint32_t k = 0; k < 16; k++) {
+        if (k < (threadIdx.x >> 6)) off += s_w[k];
+        tot += s_w[k];
+    }
+    uint64_t run = off + incl - sum;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint64_t idx = base + (uint64_t)threadIdx.x * 4 + k;
+        if (idx < n) data[idx] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_blocks(uint64_t *block_sums, const ScanWsHeader *hdr) {
+    __shared__ unsigned long long s_w[16];
+    __shared__ unsigned long long s_run;
+    const uint64_t n = (hdr->total_lines < hdr->lines_cap ? hdr->total_lines : hdr->lines_cap) + 1;
+    const uint64_t nb = (n + kScanChunk - 1) / kScanChunk;
+    if (threadIdx.x == 0) s_run = 0;
+    __syncthreads();
+    for (uint64_t base = 0; base < nb; base += 1024) {
+        uint64_t idx = base + threadIdx.x;
+        unsigned long long c = idx < nb ? block_sums[idx] : 0, incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            unsigned long long o = __shfl_up(incl, d, 64);
+            if ((int)(threadIdx.x & 63) >= d) incl += o;
+        }
+        if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        unsigned long long off = 0;
+        for (uint32_t k = 0; k < (threadIdx.x >> 6); k++) off += s_w[k];
+        unsigned long long run = s_run;
+        if (idx < nb) block_sums[idx] = run + off + incl - c;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_run = run + off + incl;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_scan_add(uint64_t *data, const ScanWsHeader *hdr, const uint64_t *block_sums) {
+    const uint64_t n = (hdr->total_lines < hdr->lines_cap ? hdr->total_lines : hdr->lines_cap) + 1;
+    const uint64_t base = (uint64_t)blockIdx.x * kScanChunk;
+    if (base >= n) return;
+    const uint64_t add = block_sums[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint64_t idx = base + (uint64_t)threadIdx.x * 4 + k;
+        if (idx < n) data[idx] += add;
+    }
+}
+
+// ---- definitions ----------------------------------------------------------------------------------------
+__device__ __forceinline__ bool is_ascii_ws(uint32_t b) { return b == ' ' || b == '\t' || b == '\n' || b == '\f' || b == '\r'; }
+
+// length of a Unicode White_Space scalar starting at p[i] (str::trim), 0 if none
+__device__ int ws_len_fwd(const uint8_t *p, uint64_t i, uint64_t e) {
+    if (i >= e) return 0;
+    uint32_t b = p[i];
+    if ((b >= 0x09 && b <= 0x0D) || b == 0x20) return 1;
+    if (i + 1 < e && b == 0xC2 && (p[i + 1] == 0x85 || p[i + 1] == 0xA0)) return 2;
+    if (i + 2 < e) {
+        uint32_t c1 = p[i + 1], c2 = p[i + 2];
+        if (b == 0xE1 && c1 == 0x9A && c2 == 0x80) return 3;
+        if (b == 0xE2 && c1 == 0x80 && ((c2 >= 0x80 && c2 <= 0x8A) || c2 == 0xA8 || c2 == 0xA9 || c2 == 0xAF)) return 3;
+        if (b == 0xE2 && c1 == 0x81 && c2 == 0x9F) return 3;
+        if (b == 0xE3 && c1 == 0x80 && c2 == 0x80) return 3;
+    }
+    return 0;
+}
+__device__ int ws_len_bwd(const uint8_t *p, uint64_t s, uint64_t e) {
+    for (int l = 1; l <= 3; l++)
+        if (e - s >= (uint64_t)l && ws_len_fwd(p, e - l, e) == l) return l;
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void k_fa_defs(FastaDev a, FastaArrays w, ScanWsHeader *hdr) {
+    const uint64_t T = hdr->total_lines < hdr->lines_cap ? hdr->total_lines : hdr->lines_cap;
+    const uint64_t n_iter = (T + 63) / 64;
+    const uint64_t wave_id = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const bool no_store = (a.flags & EXG_F_NO_STORE) != 0;
+    for (uint64_t it = wave_id; it < n_iter; it += n_waves) {
+        const uint64_t i = it * 64 + lane_id();
+        if (i >= T) continue;
+        const uint64_t r = w.rec_pre[i];
+        if (w.rec_pre[i + 1] == r) continue;  // not a definition line
+        w.rec_start[r] = w.pay_pre[i];        // its sequence starts where the payload stands
+        if (!no_store && r >= a.capacity) {
+            atomicOr(&hdr->flags, EXG_RF_CAPACITY);
+            continue;
+        }
+        uint64_t s, e;
+        line_bounds(a, w.nl_pos, i, &s, &e);
+        uint32_t code = 0;
+        if ((hdr->flags & EXG_RF_NON_ASCII) && !utf8_valid_global(a.d_in, s, e)) code = EXG_PE_INVALID_UTF8;
+        uint64_t id_s = s + 1, id_e = id_s;
+        while (id_e < e && !is_ascii_ws(a.d_in[id_e])) id_e++;
+        if (!code && id_e == id_s) code = EXG_PE_FASTA_MISSING_NAME;
+        bool has_desc = id_e < e;
+        uint64_t d_s = has_desc ? id_e + 1 : e, d_e = e;
+        if (has_desc) {
+            int l;
+            while (d_s < d_e && (l = ws_len_fwd(a.d_in, d_s, d_e)) > 0) d_s += (uint64_t)l;
+            while (d_e > d_s && (l = ws_len_bwd(a.d_in, d_s, d_e)) > 0) d_e -= (uint64_t)l;
+        }
+        if (!code && (id_e - id_s > 0xFFFFFFFFull || d_e - d_s > 0xFFFFFFFFull)) code = EXG_PE_FIELD_TOO_LONG;
+        if (code) {
+            atomicMin(&hdr->err_word, (r << 8) | code);
+            atomicMin(&hdr->err_off, (unsigned long long)s);
+        }
+        if (!no_store) {
+            uint4 z = {0, 0, 0, 0};
+            reinterpret_cast<uint4 *>(a.d_id)[r] = make_string_global(a.d_in, id_s, id_e - id_s, a.payload_base);
+            reinterpret_cast<uint4 *>(a.d_desc)[r] =
+                has_desc ? make_string_global(a.d_in, d_s, d_e - d_s, a.payload_base) : z;
+            if (has_desc) atomicOr((unsigned long long *)&a.d_desc_valid[r >> 6], 1ull << (r & 63));
+        }
+    }
+    // sentinel: rec_start[n_rec] = total payload
+    if (blockIdx.x == 0 && threadIdx.x == 0) w.rec_start[w.rec_pre[T]] = w.pay_pre[T];
+}
+
+// ---- payload: copy every sequence byte to its compacted position ---------------------------------------
+// thread = 16 input bytes; the line of the first byte by binary search in the line index
+__global__ __launch_bounds__(256) void k_fa_copy(FastaDev a, FastaArrays w, ScanWsHeader *hdr) {
+    if (a.flags & EXG_F_NO_STORE) return;
+    const uint64_t T = hdr->total_lines < hdr->lines_cap ? hdr->total_lines : hdr->lines_cap;
+    const uint64_t n_chunks = (a.n_bytes + 15) / 16;
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t pos = c * 16, end = pos + 16 < a.n_bytes ? pos + 16 : a.n_bytes;
+        // first line whose terminator is >= pos
+        uint64_t lo = 0, hi = T;
+        while (lo < hi) {
+            uint64_t mid = (lo + hi) >> 1;
+            if (w.nl_pos[mid] < pos)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        uint64_t li = lo;
+        while (pos < end && li < T) {
+            uint64_t s, e;
+            line_bounds(a, w.nl_pos, li, &s, &e);
+            bool def = w.rec_pre[li + 1] != w.rec_pre[li];
+            uint64_t stop = e < end ? e : end;  // sequence bytes of this line inside the chunk
+            if (!def) {
+                uint64_t dst = w.pay_pre[li] + (pos - s);
+                for (uint64_t p = pos; p < stop; p++) a.d_payload[dst++] = a.d_in[p];
+            }
+            uint64_t raw_end = w.nl_pos[li];
+            if (raw_end + 1 > end) break;  // the line continues in the next chunk
+            pos = raw_end + 1;
+            li++;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fa_seq_strings(FastaDev a, FastaArrays w, ScanWsHeader *hdr) {
+    if (a.flags & EXG_F_NO_STORE) return;
+    const uint64_t T = hdr->total_lines < hdr->lines_cap ? hdr->total_lines : hdr->lines_cap;
+    const uint64_t n_rec = w.rec_pre[T];
+    const uint64_t n = n_rec < a.capacity ? n_rec : a.capacity;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t s = w.rec_start[r], len = w.rec_start[r + 1] - s;
+        if (len > 0xFFFFFFFFull) {
+            atomicMin(&hdr->err_word, (r << 8) | EXG_PE_FIELD_TOO_LONG);
+            len = 0;
+        }
+        // sequences are validated after their definition (exon FASTAArrayBuilder::append order)
+        if ((hdr->flags & EXG_RF_NON_ASCII) && reinterpret_cast<const uint32_t *>(a.d_id)[r * 4] != 0 &&
+            !utf8_valid_global(a.d_payload, s, s + len)) {
+            atomicMin(&hdr->err_word, (r << 8) | EXG_PE_INVALID_UTF8);
+            // offset of the record = start of its definition line: first line i with rec_pre[i + 1] > r
+            uint64_t lo = 0, hi = T;
+            while (lo < hi) {
+                uint64_t mid = (lo + hi) >> 1;
+                if (w.rec_pre[mid + 1] > r)
+                    hi = mid;
+                else
+                    lo = mid + 1;
+            }
+            atomicMin(&hdr->err_off, (unsigned long long)(lo ? w.nl_pos[lo - 1] + 1 : 0));
+        }
+        reinterpret_cast<uint4 *>(a.d_seq)[r] = make_string_global(a.d_payload, s, len, a.seq_payload_base);
+    }
+}
+
+__global__ void k_fa_finalize(FastaDev a, FastaArrays w, ScanWsHeader *hdr, exg_scan_result *res) {
+    if (threadIdx.x || blockIdx.x) return;
+    const uint64_t T = hdr->total_lines, Tc = T < hdr->lines_cap ? T : hdr->lines_cap;
+    const uint64_t n_owned = w.rec_pre[Tc];
+    exg_scan_result r;
+    r.n_lines = T;
+    r.flags = hdr->flags;
+    if (T > hdr->lines_cap) r.flags |= EXG_RF_INDEX_OVERFLOW;
+    r.payload_bytes = w.pay_pre[Tc];
+    r.reserved = 0;
+    r.error_code = 0;
+    r.error_offset = ~0ull;
+    r.error_record = ~0ull;
+    uint64_t n_rec = (n_owned < a.capacity || (a.flags & EXG_F_NO_STORE)) ? n_owned : a.capacity;
+    uint64_t consumed = a.n_bytes;
+    unsigned long long err = hdr->err_word;
+    if (err != kNoError) {
+        uint64_t rec = err >> 8;
+        r.error_code = (uint32_t)(err & 0xFF);
+        r.error_record = rec;
+        // offset of the failing record's definition line (errors on the sequence report it too)
+        r.error_offset = hdr->err_off != ~0ull ? hdr->err_off : 0;
+        if (r.error_code == EXG_PE_FASTA_EMPTY_DEF || r.error_code == EXG_PE_FASTA_MISSING_PREFIX) r.error_offset = 0;
+        if (rec < n_rec) n_rec = rec;
+        consumed = r.error_offset;
+    }
+    r.n_records = n_rec;
+    r.consumed_bytes = consumed;
+    *res = r;
+}
+
+__global__ void k_init_hdr(ScanWsHeader *hdr, uint64_t lines_cap, uint32_t mode);
+
+}  // namespace exg
+
+using namespace exg;
+
+extern "C" int exg_fasta_scan(const exg_fasta_scan_args *a) {
+    if (!a || !a->d_result || !a->d_workspace || (a->n_bytes && !a->d_input) || ((uintptr_t)a->d_input & 15)) {
+        set_error("exg_fasta_scan: bad arguments (null pointer or unaligned input)");
+        return EXG_E_INVALID_ARG;
+    }
+    if (a->lead != 0 || (a->flags & (EXG_F_BOF | EXG_F_EOF)) != (EXG_F_BOF | EXG_F_EOF)) {
+        set_error("exg_fasta_scan: whole-file buffers only (lead = 0, EXG_F_BOF | EXG_F_EOF): a FASTA record can "
+                  "span the whole input");
+        return EXG_E_UNSUPPORTED;
+    }
+    const bool no_store = a->flags & EXG_F_NO_STORE;
+    if (!no_store && a->capacity_records &&
+        (!a->d_id || !a->d_description || !a->d_sequence || !a->d_description_validity || !a->d_seq_payload)) {
+        set_error("exg_fasta_scan: null output");
+        return EXG_E_INVALID_ARG;
+    }
+    FastqWsLayout l = fastq_ws_layout(a->n_bytes, a->workspace_bytes, 4);
+    if (a->workspace_bytes < fastq_ws_layout(a->n_bytes, 0, 4).off_nl_pos + 64 * 4 || l.lines_cap < 2) {
+        set_error("exg_fasta_scan: workspace too small");
+        return EXG_E_INVALID_ARG;
+    }
+    FastaDev dev;
+    dev.d_in = (const uint8_t *)a->d_input;
+    dev.n_bytes = a->n_bytes;
+    dev.payload_base = a->payload_base;
+    dev.seq_payload_base = a->seq_payload_base;
+    dev.flags = a->flags;
+    dev.pad = 0;
+    dev.d_id = a->d_id;
+    dev.d_desc = a->d_description;
+    dev.d_seq = a->d_sequence;
+    dev.d_desc_valid = a->d_description_validity;
+    dev.d_payload = a->d_seq_payload;
+    dev.capacity = a->capacity_records;
+    hipStream_t stream = (hipStream_t)a->stream;
+    uint8_t *ws = (uint8_t *)a->d_workspace;
+    ScanWsHeader *hdr = reinterpret_cast<ScanWsHeader *>(ws);
+    FastaArrays w;
+    uint64_t *base = reinterpret_cast<uint64_t *>(ws + l.off_nl_pos);
+    w.nl_pos = base;
+    w.rec_pre = base + (l.lines_cap + 2);
+    w.pay_pre = base + 2 * (l.lines_cap + 2);
+    w.rec_start = base + 3 * (l.lines_cap + 2);
+    uint64_t *block_sums = reinterpret_cast<uint64_t *>(ws + l.off_block_sums);
+    if (a->capacity_records && !no_store)
+        EXG_HIP_CHECK(hipMemsetAsync(a->d_description_validity, 0, (size_t)((a->capacity_records + 63) / 64) * 8, stream));
+    hipLaunchKernelGGL(k_init_hdr, dim3(1), dim3(1), 0, stream, hdr, l.lines_cap, 0u);
+    int rc = launch_line_index(dev.d_in, dev.n_bytes, 0, ws, l, 1, 0, stream, nullptr);
+    if (rc) return rc;
+    uint64_t est_lines = dev.n_bytes / 16 + 256;
+    uint32_t grid = (uint32_t)((est_lines + 255) / 256 < 4096 ? (est_lines + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_fa_classify, dim3(grid), dim3(256), 0, stream, dev, w, hdr);
+    // scans: the grid covers the index capacity, blocks past the real line count return at once
+    uint64_t cover = dev.n_bytes + 2 < l.lines_cap + 1 ? dev.n_bytes + 2 : l.lines_cap + 1;  // lines <= bytes + 1
+    uint32_t sgrid = (uint32_t)((cover + kScanChunk - 1) / kScanChunk);
+    if (sgrid == 0) sgrid = 1;
+    for (uint64_t *arr : {w.rec_pre, w.pay_pre}) {
+        hipLaunchKernelGGL(k_scan_local, dim3(sgrid), dim3(1024), 0, stream, arr, hdr, block_sums);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, block_sums, hdr);
+        hipLaunchKernelGGL(k_scan_add, dim3(sgrid), dim3(1024), 0, stream, arr, hdr, block_sums);
+    }
+    hipLaunchKernelGGL(k_fa_defs, dim3(grid), dim3(256), 0, stream, dev, w, hdr);
+    uint64_t n_chunks = (dev.n_bytes + 15) / 16;
+    uint32_t cgrid = (uint32_t)((n_chunks + 255) / 256 < 16384 ? (n_chunks + 255) / 256 : 16384);
+    if (cgrid == 0) cgrid = 1;
+    hipLaunchKernelGGL(k_fa_copy, dim3(cgrid), dim3(256), 0, stream, dev, w, hdr);
+    hipLaunchKernelGGL(k_fa_seq_strings, dim3(grid), dim3(256), 0, stream, dev, w, hdr);
+    hipLaunchKernelGGL(k_fa_finalize, dim3(1), dim3(1), 0, stream, dev, w, hdr, a->d_result);
+    EXG_HIP_CHECK(hipGetLastError());
+    return EXG_OK;
+}

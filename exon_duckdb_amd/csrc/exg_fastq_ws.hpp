@@ -38,6 +38,7 @@ struct FastqWsLayout {
     uint64_t off_tile_counts;   // u32[n_tiles_mp]
     uint64_t off_tile_offsets;  // u64[n_tiles_mp]
     uint64_t off_tile_desc;     // u64[n_tiles_fused] look-back descriptors + u64[n_tiles_fused] tile_qend
+    uint64_t off_block_sums;    // u64[lines_cap / 4096 + 2] (FASTA device-wide scans)
     uint64_t off_nl_pos;        // u64[lines_cap]
     uint64_t lines_cap;
     uint64_t total_bytes;
@@ -45,10 +46,11 @@ struct FastqWsLayout {
 
 static inline uint64_t round_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
+// n_line_arrays: FASTA keeps 4 u64 arrays per line (offsets, record prefix, payload prefix, record starts).
 // nl_pos capacity: the general kernels index every line.  Worst case is one line per byte; the
 // default provisions one line per 8 bytes (FASTQ/VCF lines are far longer) but never less than
 // min(n, 1 Mi) + 8 so small inputs are always safe.  Overflow is reported, never silent.
-static inline FastqWsLayout fastq_ws_layout(uint64_t n_bytes, uint64_t ws_bytes_or_0) {
+static inline FastqWsLayout fastq_ws_layout(uint64_t n_bytes, uint64_t ws_bytes_or_0, uint64_t n_line_arrays = 1) {
     FastqWsLayout l;
     l.n_tiles_mp = (n_bytes + kMpTileBytes - 1) / kMpTileBytes + 1;
     l.n_tiles_fused = (n_bytes + kFusedTileBytes - 1) / kFusedTileBytes + 2;
@@ -59,18 +61,20 @@ static inline FastqWsLayout fastq_ws_layout(uint64_t n_bytes, uint64_t ws_bytes_
     at = round_up(at + l.n_tiles_mp * 8, 256);
     l.off_tile_desc = at;
     at = round_up(at + l.n_tiles_fused * 24, 256);  // tileA, tileP, tile_qend
-    l.off_nl_pos = at;
     uint64_t want = n_bytes / 8;
     uint64_t small = n_bytes < (1ull << 20) ? n_bytes : (1ull << 20);
     if (want < small) want = small;
     want += 8;
+    l.off_block_sums = at;
+    at = round_up(at + ((n_bytes + 16) / 4096 + 4) * 8, 256);  // lines <= bytes + 1, whatever the workspace size
+    l.off_nl_pos = at;
     if (ws_bytes_or_0) {
-        uint64_t avail = ws_bytes_or_0 > at ? (ws_bytes_or_0 - at) / 8 : 0;
-        l.lines_cap = avail;
+        uint64_t avail = ws_bytes_or_0 > at ? (ws_bytes_or_0 - at) / (8 * n_line_arrays) : 0;
+        l.lines_cap = avail > 2 ? avail - 2 : 0;  // each per-line array holds lines_cap + 2 entries
     } else {
         l.lines_cap = want;
     }
-    l.total_bytes = at + l.lines_cap * 8;
+    l.total_bytes = at + (l.lines_cap + 2) * 8 * n_line_arrays;
     return l;
 }
 

@@ -142,3 +142,50 @@ class VcfScan:
         return dict(cols=cols, pos=self.pos[:n].cpu().numpy(), qual=self.qual[:n].cpu().numpy(),
                     qual_valid=self.qual_valid[:nw].cpu().numpy().view(np.uint64),
                     formats_valid=self.formats_valid[:nw].cpu().numpy().view(np.uint64))
+
+
+class FastaScan:
+    """Reusable output + workspace buffers for exg_fasta_scan (whole-file buffers)."""
+
+    def __init__(self, n_bytes, capacity_records=None, device="cuda"):
+        torch = _torch()
+        self.lib = load_library()
+        self.n_bytes = n_bytes
+        self.capacity = int(capacity_records if capacity_records is not None else n_bytes // 2 + 16)
+        cap = max(self.capacity, 1)
+        self.cols = [torch.empty((cap, 2), dtype=torch.int64, device=device) for _ in range(3)]
+        self.validity = torch.empty(((cap + 63) // 64,), dtype=torch.int64, device=device)
+        self.payload = torch.empty((n_bytes + 64,), dtype=torch.uint8, device=device)
+        self.ws_bytes = int(self.lib.exg_scan_workspace_bytes(abi.EXG_FMT_FASTA, n_bytes))
+        self.ws = torch.empty((self.ws_bytes + 255) // 8, dtype=torch.int64, device=device)
+        self.result = torch.zeros(8, dtype=torch.int64, device=device)
+        self.args = abi.FastaScanArgs()
+
+    def launch(self, d_input, payload_base=0, seq_payload_base=0, flags=abi.EXG_F_BOF | abi.EXG_F_EOF, lead=0):
+        a = self.args
+        a.d_input = d_input.data_ptr()
+        a.n_bytes = self.n_bytes
+        a.lead = lead
+        a.payload_base = payload_base
+        a.seq_payload_base = seq_payload_base
+        a.flags = flags
+        a.algo = abi.EXG_ALGO_AUTO
+        a.d_id, a.d_description, a.d_sequence = (c.data_ptr() for c in self.cols)
+        a.d_description_validity = self.validity.data_ptr()
+        a.d_seq_payload = self.payload.data_ptr()
+        a.capacity_records = self.capacity
+        a.d_workspace = self.ws.data_ptr()
+        a.workspace_bytes = self.ws_bytes
+        a.d_result = self.result.data_ptr()
+        a.stream = stream_ptr().value
+        check(self.lib.exg_fasta_scan(C.byref(a)))
+
+    def fetch(self):
+        r = abi.ScanResult()
+        check(self.lib.exg_fetch_result(C.c_void_p(self.result.data_ptr()), stream_ptr(), C.byref(r)))
+        return r
+
+    def host(self, n, payload_bytes):
+        cols = [c[:n].cpu().numpy().view(np.uint8).reshape(n, 16) for c in self.cols]
+        words = self.validity[: (n + 63) // 64].cpu().numpy().view(np.uint64)
+        return cols, words, self.payload[:payload_bytes].cpu().numpy()

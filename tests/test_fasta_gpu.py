@@ -1,0 +1,157 @@
+"""Parity of the HIP FASTA scan (C-ABI exg_fasta_scan) against the oracle.
+
+id / description are slices of the input (ptr = BASE + offset); the sequence is the record's lines
+concatenated in a compacted payload buffer (ptr = SEQ_BASE + payload offset).  The oracle's Arrow-style
+columns give lengths + bytes + validity; string_t values are resolved and compared field by field, and
+the whole payload buffer must equal the concatenation of the oracle's sequence values."""
+import os
+
+import numpy as np
+import pytest
+
+from exon_duckdb_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+BASE = 0x7D0000000000
+SEQ_BASE = 0x7C0000000000
+
+
+def run_gpu(data, capacity=None, flags=abi.EXG_F_BOF | abi.EXG_F_EOF):
+    from exon_duckdb_amd import device
+
+    data = bytes(data)
+    d_in = device.upload(data)
+    scan = device.FastaScan(len(data), capacity_records=capacity)
+    scan.launch(d_in, payload_base=BASE, seq_payload_base=SEQ_BASE, flags=flags)
+    res = scan.fetch()
+    cols, words, payload = scan.host(int(res.n_records), int(res.payload_bytes))
+    return res, cols, words, payload
+
+
+def resolve(st, data, payload):
+    ln = int(st[:4].view(np.uint32)[0])
+    if ln <= 12:
+        assert not st[4 + ln:].any(), "inlined string_t must be zero padded"
+        return st[4:4 + ln].tobytes()
+    ptr = int(st[8:16].view(np.uint64)[0])
+    if ptr >= BASE:
+        off, buf = ptr - BASE, data
+    else:
+        off, buf = ptr - SEQ_BASE, payload
+    got = bytes(buf[off:off + ln])
+    assert st[4:8].tobytes() == got[:4], "prefix must be the first 4 bytes"
+    return got
+
+
+def check(oracle, data):
+    data = bytes(data)
+    exp = oracle.fasta_parse(data)
+    res, cols, words, payload = run_gpu(data)
+    assert res.error_code == exp.error_code, (res.error_code, exp.error_code, exp.error_message)
+    assert res.n_records == exp.n_rows
+    if exp.error_code:
+        assert res.error_record == exp.error_record and res.error_offset == exp.error_offset
+    n = exp.n_rows
+    valid = np.unpackbits(words.view(np.uint8), bitorder="little")[:n]
+    assert np.array_equal(valid, exp.columns["description"].valid)
+    pl = payload.tobytes()
+    for k, name in enumerate(["id", "description", "sequence"]):
+        col = exp.columns[name]
+        for i in range(n):
+            want = col.row(i)
+            if want is None:
+                assert not cols[k][i].any()          # NULL rows are 16 zero bytes
+            else:
+                assert resolve(cols[k][i], data, pl) == want, (name, i)
+    if not exp.error_code:
+        assert pl == exp.columns["sequence"].values.tobytes()
+        assert res.consumed_bytes == len(data)
+    return res
+
+
+@pytest.mark.parametrize("name", ["test.fasta", "test.mixed-desc.fasta"])
+def test_reference_fixtures(gpu, oracle, golden_dir, name):
+    with open(os.path.join(golden_dir, name), "rb") as f:
+        data = f.read()
+    res = check(oracle, data)
+    assert res.n_records == 2      # test_fasta_scan.test:5-8
+
+
+def test_reference_null_description_row(gpu, golden_dir):
+    # test_fasta_copy.test:75-80: (b, NULL, ATCG), straight from the device output
+    with open(os.path.join(golden_dir, "test.mixed-desc.fasta"), "rb") as f:
+        data = f.read()
+    res, cols, words, payload = run_gpu(data)
+    assert int(words[0]) & 3 == 1
+    assert resolve(cols[0][1], data, payload.tobytes()) == b"b"
+    assert not cols[1][1].any()
+    assert resolve(cols[2][1], data, payload.tobytes()) == b"ATCG"
+
+
+@pytest.mark.parametrize("n_records", [1, 2, 50, 700])
+def test_synth_fasta(gpu, oracle, n_records):
+    res = check(oracle, oracle.synth_fasta(n_records))
+    assert res.n_records == n_records
+
+
+def test_config1_one_megabyte(gpu, oracle):
+    # BASELINE config 1 shape: SELECT COUNT(*) FROM read_fasta() on a 1 MB FASTA
+    data = bytes(oracle.synth_fasta(620))
+    assert 0.9e6 < len(data) < 1.3e6
+    res = check(oracle, data)
+    from exon_duckdb_amd import device
+    d_in = device.upload(data)
+    scan = device.FastaScan(len(data))
+    scan.launch(d_in, flags=abi.EXG_F_BOF | abi.EXG_F_EOF | abi.EXG_F_NO_STORE)
+    assert scan.fetch().n_records == res.n_records == 620
+
+
+EDGE = {
+    "empty": b"",
+    "multiline": b">a d\nAC\nGT\n\nTT\n>b\nA\n",
+    "desc_trim_and_tab": b">a\t  two words \nAC\n",
+    "trailing_space_empty_desc": b">a \nAC\n",
+    "crlf": b">a d\r\nAC\r\nGT\r\n>b\r\nA\r\n",
+    "empty_sequence": b">a\n>b\nAC\n>c\n",
+    "no_trailing_newline": b">a d\nACGT",
+    "cr_before_eof_kept": b">a\nAC\r",
+    "gt_inside_sequence": b">a\nAC>GT\n",
+    "missing_prefix": b"ACGT\n>a\nAC\n",
+    "empty_first_line": b"\n>a\nAC\n",
+    "empty_first_line_crlf": b"\r\n>a\nAC\n",
+    "missing_name": b">a\nAC\n> desc only\nAC\n",
+    "missing_name_bare": b">a\nAC\n>\nAC\n",
+    "bad_utf8_definition": b">a \xff\nAC\n",
+    "bad_utf8_sequence": b">a\nAC\n>b\nA\xc3\n",
+    "utf8_ok": ">é ü \nAC\n".encode(),
+    "unicode_trim": ">a 　x y \nAC\n".encode(),
+    "inline_lengths": b"".join(b">" + b"n" * k + b" " + b"d" * (13 - k) + b"\n" + b"A" * k + b"\n" for k in range(1, 14)),
+    "long_single_line": b">chr1 one line\n" + b"ACGT" * 50000 + b"\n>chr2\n" + b"TTGCA" * 3000 + b"\n",
+    "many_short_lines": b">x\n" + b"A\n" * 5000,
+    "cr_mid_line_splits_definition": b">a\rb\nAC\n",
+}
+
+
+@pytest.mark.parametrize("case", sorted(EDGE))
+def test_edge_cases(gpu, oracle, case):
+    check(oracle, EDGE[case])
+
+
+def test_capacity(gpu, oracle):
+    data = bytes(oracle.synth_fasta(100))
+    exp = oracle.fasta_parse(data)
+    res, cols, words, payload = run_gpu(data, capacity=10)
+    assert res.flags & abi.EXG_RF_CAPACITY and res.n_records == 10
+    for i in range(10):
+        assert resolve(cols[0][i], data, payload.tobytes()) == exp.columns["id"].row(i)
+
+
+def test_shards_are_refused(gpu, oracle):
+    from exon_duckdb_amd import device, ExgError
+
+    data = bytes(oracle.synth_fasta(10))
+    d_in = device.upload(data)
+    scan = device.FastaScan(len(data))
+    with pytest.raises(ExgError):
+        scan.launch(d_in, flags=abi.EXG_F_BOF)          # not at EOF: a record could be cut
