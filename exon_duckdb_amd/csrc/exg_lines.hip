@@ -219,3 +219,49 @@ extern "C" int exg_count_newlines(const void *d_input, uint64_t begin, uint64_t 
     }
     return EXG_OK;
 }
+
+// ---- exg_fastq_guess_phase -------------------------------------------------------------------------
+// Shard-local 4-line phase of FASTQ (multi-GPU byte-range shards start anywhere): the phase p of the
+// first line that starts at or after `lead` must put '@' on every line k with (p + k) % 4 == 0 and
+// '+' on every line with (p + k) % 4 == 2, over up to 32 lines.  Well-formed FASTQ leaves exactly one
+// candidate ('@' can also open a quality line, which is why one line is not enough); the caller still
+// VERIFIES it against the exchanged newline counts, so a wrong guess can cost a re-scan, never a result.
+namespace exg {
+__global__ void k_fastq_guess_phase(const uint8_t *__restrict__ d_in, uint64_t n_bytes, uint64_t lead, uint32_t *d_phase) {
+    if (threadIdx.x || blockIdx.x) return;
+    uint64_t pos = 0;
+    if (lead > 0) {
+        pos = lead - 1;
+        while (pos < n_bytes && d_in[pos] != '\n') pos++;
+        pos++;  // first line start at or after lead
+    }
+    uint32_t ok = 0xF;  // candidate phases still standing
+    int lines = 0;
+    const uint64_t limit = pos + 65536 < n_bytes ? pos + 65536 : n_bytes;
+    while (lines < 32 && pos < limit) {
+        uint32_t c = d_in[pos];
+        for (uint32_t p = 0; p < 4; p++) {
+            uint32_t ph = (p + (uint32_t)lines) & 3;
+            if ((ph == 0 && c != '@') || (ph == 2 && c != '+')) ok &= ~(1u << p);
+        }
+        lines++;
+        while (pos < limit && d_in[pos] != '\n') pos++;
+        pos++;
+    }
+    uint32_t res = 0xFFFFFFFFu;
+    if (lines >= 8 && ok && (ok & (ok - 1)) == 0) res = (uint32_t)__ffs(ok) - 1;
+    *d_phase = res;
+}
+}  // namespace exg
+
+extern "C" int exg_fastq_guess_phase(const void *d_input, uint64_t n_bytes, uint64_t lead, uint32_t *d_phase,
+                                     void *stream) {
+    if (!d_phase || (n_bytes && !d_input) || lead > n_bytes) {
+        exg::set_error("exg_fastq_guess_phase: bad arguments");
+        return EXG_E_INVALID_ARG;
+    }
+    hipLaunchKernelGGL(exg::k_fastq_guess_phase, dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint8_t *)d_input,
+                       n_bytes, lead, d_phase);
+    EXG_HIP_CHECK(hipGetLastError());
+    return EXG_OK;
+}

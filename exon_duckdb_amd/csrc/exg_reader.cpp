@@ -39,8 +39,11 @@ struct PinnedBlock {
 
 struct Batch {  // host vectors of one device batch, shared by its chunks
     std::shared_ptr<PinnedBlock> file;
-    PinnedBlock cols[4];
-    PinnedBlock validity;
+    int n_cols = 0;
+    PinnedBlock cols[9];
+    uint32_t elem[9] = {16, 16, 16, 16, 16, 16, 16, 16, 16};  // bytes per row
+    PinnedBlock validity[9];                                     // empty => all rows valid
+    PinnedBlock payload;                                         // FASTA: compacted sequences
     uint64_t n_rows = 0;
 };
 
@@ -81,9 +84,12 @@ struct exg_reader {
     bool file_done = true;
 
     // device buffers (sized for device_batch_bytes)
-    void *d_in = nullptr, *d_ws = nullptr, *d_res = nullptr, *d_valid = nullptr;
-    void *d_cols[4] = {nullptr, nullptr, nullptr, nullptr};
+    void *d_in = nullptr, *d_ws = nullptr, *d_res = nullptr;
+    void *d_valid[2] = {nullptr, nullptr};
+    void *d_cols[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    void *d_pos = nullptr, *d_qual = nullptr, *d_payload = nullptr;
     uint64_t d_in_cap = 0, ws_bytes = 0, cap_records = 0;
+    uint64_t vcf_header_bytes = 0;
 
     // current batch
     std::shared_ptr<Batch> batch;
@@ -91,13 +97,15 @@ struct exg_reader {
     uint32_t pending_error = 0;  // parse error to raise once the rows before it have been handed out
     uint64_t pending_error_offset = 0;
 
+    void free_device() {
+        for (void **p : {&d_in, &d_ws, &d_valid[0], &d_valid[1], &d_pos, &d_qual, &d_payload})
+            if (*p) (void)hipFree(*p), *p = nullptr;
+        for (void *&p : d_cols)
+            if (p) (void)hipFree(p), p = nullptr;
+    }
     ~exg_reader() {
-        if (d_in) (void)hipFree(d_in);
-        if (d_ws) (void)hipFree(d_ws);
+        free_device();
         if (d_res) (void)hipFree(d_res);
-        if (d_valid) (void)hipFree(d_valid);
-        for (void *p : d_cols)
-            if (p) (void)hipFree(p);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -164,25 +172,45 @@ int open_next_file(exg_reader *r) {
     r->file = blk;
     r->file_pos = 0;
     r->file_done = false;
+    if (r->format == EXG_FMT_VCF) {
+        // header = the leading '#' lines (noodles-vcf read_header); it must hold the #CHROM line
+        const char *d = (const char *)blk->p;
+        size_t pos = 0;
+        bool chrom = false;
+        while (pos < blk->n && d[pos] == '#') {
+            if (blk->n - pos >= 6 && memcmp(d + pos, "#CHROM", 6) == 0) chrom = true;
+            const void *nl = memchr(d + pos, '\n', blk->n - pos);
+            pos = nl ? (size_t)((const char *)nl - d) + 1 : blk->n;
+        }
+        if (!chrom) return fail(r, EXG_E_PARSE, std::string(exg_parse_error_string(EXG_PE_VCF_NO_HEADER)) + " in '" + p + "'");
+        r->vcf_header_bytes = pos;
+        r->file_pos = pos;
+    }
     return EXG_OK;
 }
+
+int n_string_cols(int format) { return format == EXG_FMT_FASTQ ? 4 : format == EXG_FMT_FASTA ? 3 : 9; }
 
 int ensure_device(exg_reader *r, uint64_t need_bytes) {
     if (r->d_in && need_bytes <= r->d_in_cap) return EXG_OK;
     if (r->d_in) {
         RD_HIP(r, hipStreamSynchronize(r->stream));
-        (void)hipFree(r->d_in), (void)hipFree(r->d_ws), (void)hipFree(r->d_valid);
-        for (void *&p : r->d_cols) (void)hipFree(p), p = nullptr;
-        r->d_in = r->d_ws = r->d_valid = nullptr;
+        r->free_device();
     }
     uint64_t cap = std::max<uint64_t>(need_bytes, 1 << 16);
     r->d_in_cap = cap;
-    r->cap_records = cap / 6 + 16;  // a FASTQ record is at least 6 bytes ("@\n\n+\n\n" minus the last LF at EOF)
+    // smallest possible record: FASTQ "@\n\n+\n" (5 bytes at EOF), FASTA ">a\n" minus LF, VCF a blank line
+    r->cap_records = cap / (r->format == EXG_FMT_FASTQ ? 5 : r->format == EXG_FMT_FASTA ? 2 : 1) + 16;
     r->ws_bytes = exg_scan_workspace_bytes(r->format, cap);
     RD_HIP(r, hipMalloc(&r->d_in, cap + 64));
     RD_HIP(r, hipMalloc(&r->d_ws, r->ws_bytes));
-    RD_HIP(r, hipMalloc(&r->d_valid, (r->cap_records + 63) / 64 * 8));
-    for (void *&p : r->d_cols) RD_HIP(r, hipMalloc(&p, r->cap_records * 16));
+    for (int k = 0; k < 2; k++) RD_HIP(r, hipMalloc(&r->d_valid[k], (r->cap_records + 63) / 64 * 8));
+    for (int c = 0; c < n_string_cols(r->format); c++) RD_HIP(r, hipMalloc(&r->d_cols[c], r->cap_records * 16));
+    if (r->format == EXG_FMT_VCF) {
+        RD_HIP(r, hipMalloc(&r->d_pos, r->cap_records * 8));
+        RD_HIP(r, hipMalloc(&r->d_qual, r->cap_records * 4));
+    }
+    if (r->format == EXG_FMT_FASTA) RD_HIP(r, hipMalloc(&r->d_payload, cap + 64));
     if (!r->d_res) RD_HIP(r, hipMalloc(&r->d_res, sizeof(exg_scan_result)));
     return EXG_OK;
 }
@@ -207,29 +235,76 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         const uint8_t *h = (const uint8_t *)r->file->p + r->file_pos;
         RD_HIP(r, hipMemcpyAsync(r->d_in, h, (n + 15) / 16 * 16, hipMemcpyHostToDevice, r->stream));
         exg_scan_result res;
+        const uint32_t fl = EXG_F_BOF | (eof ? EXG_F_EOF : 0u) | (count_only ? EXG_F_NO_STORE : 0u);
+        std::shared_ptr<Batch> b;
         if (r->format == EXG_FMT_FASTQ) {
             exg_fastq_scan_args a;
             memset(&a, 0, sizeof a);
             a.d_input = r->d_in;
             a.n_bytes = n;
             a.payload_base = (uint64_t)(uintptr_t)h;
-            a.flags = EXG_F_BOF | (eof ? EXG_F_EOF : 0u) | (count_only ? EXG_F_NO_STORE : 0u);
+            a.flags = fl;
             a.algo = EXG_ALGO_AUTO;
             a.d_name = (exg_string_t *)r->d_cols[0];
             a.d_description = (exg_string_t *)r->d_cols[1];
             a.d_sequence = (exg_string_t *)r->d_cols[2];
             a.d_quality = (exg_string_t *)r->d_cols[3];
-            a.d_description_validity = (uint64_t *)r->d_valid;
+            a.d_description_validity = (uint64_t *)r->d_valid[0];
             a.capacity_records = r->cap_records;
             a.d_workspace = r->d_ws;
             a.workspace_bytes = r->ws_bytes;
             a.d_result = (exg_scan_result *)r->d_res;
             a.stream = r->stream;
             rc = exg_fastq_scan(&a);
-            if (rc) return fail(r, rc, exg_last_error_message());
+        } else if (r->format == EXG_FMT_VCF) {
+            exg_vcf_scan_args a;
+            memset(&a, 0, sizeof a);
+            a.d_input = r->d_in;
+            a.n_bytes = n;
+            a.payload_base = (uint64_t)(uintptr_t)h;
+            a.flags = fl;
+            a.algo = EXG_ALGO_AUTO;
+            for (int c = 0; c < 9; c++) a.d_fields[c] = (exg_string_t *)r->d_cols[c];
+            a.d_pos = (int64_t *)r->d_pos;
+            a.d_qual = (float *)r->d_qual;
+            a.d_qual_validity = (uint64_t *)r->d_valid[0];
+            a.d_formats_validity = (uint64_t *)r->d_valid[1];
+            a.capacity_records = r->cap_records;
+            a.d_workspace = r->d_ws;
+            a.workspace_bytes = r->ws_bytes;
+            a.d_result = (exg_scan_result *)r->d_res;
+            a.stream = r->stream;
+            rc = exg_vcf_scan(&a);
         } else {
-            return fail(r, EXG_E_UNSUPPORTED, "reader: this format has no device scan yet");
+            if (!eof) {  // a FASTA record can span the whole file: one batch
+                want = remaining;
+                continue;
+            }
+            b = std::make_shared<Batch>();
+            if (!count_only) {
+                b->payload.n = n;
+                RD_HIP(r, hipHostMalloc(&b->payload.p, n + 64, hipHostMallocDefault));
+            }
+            exg_fasta_scan_args a;
+            memset(&a, 0, sizeof a);
+            a.d_input = r->d_in;
+            a.n_bytes = n;
+            a.payload_base = (uint64_t)(uintptr_t)h;
+            a.seq_payload_base = (uint64_t)(uintptr_t)b->payload.p;
+            a.flags = fl;
+            a.d_id = (exg_string_t *)r->d_cols[0];
+            a.d_description = (exg_string_t *)r->d_cols[1];
+            a.d_sequence = (exg_string_t *)r->d_cols[2];
+            a.d_description_validity = (uint64_t *)r->d_valid[0];
+            a.d_seq_payload = (uint8_t *)r->d_payload;
+            a.capacity_records = r->cap_records;
+            a.d_workspace = r->d_ws;
+            a.workspace_bytes = r->ws_bytes;
+            a.d_result = (exg_scan_result *)r->d_res;
+            a.stream = r->stream;
+            rc = exg_fasta_scan(&a);
         }
+        if (rc) return fail(r, rc, exg_last_error_message());
         rc = exg_fetch_result((const exg_scan_result *)r->d_res, r->stream, &res);
         if (rc) return fail(r, rc, exg_last_error_message());
         if (res.flags & EXG_RF_INDEX_OVERFLOW)
@@ -245,18 +320,36 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         const uint64_t k = res.n_records;
         *n_records_out = k;
         if (k && !count_only) {
-            auto b = std::make_shared<Batch>();
+            if (!b) b = std::make_shared<Batch>();
             b->file = r->file;
             b->n_rows = k;
-            for (int c = 0; c < 4; c++) {
-                b->cols[c].n = k * 16;
-                RD_HIP(r, hipHostMalloc(&b->cols[c].p, k * 16, hipHostMallocDefault));
-                RD_HIP(r, hipMemcpyAsync(b->cols[c].p, r->d_cols[c], k * 16, hipMemcpyDeviceToHost, r->stream));
+            const int ns = n_string_cols(r->format);
+            // schema order (exg_schema_of): VCF exposes parsed POS / QUAL in place of their raw text
+            b->n_cols = ns;
+            const size_t vw = (size_t)((k + 63) / 64) * 8;
+            for (int c = 0; c < ns; c++) {
+                const void *src = r->d_cols[c];
+                uint32_t es = 16;
+                if (r->format == EXG_FMT_VCF && c == 1) src = r->d_pos, es = 8;
+                if (r->format == EXG_FMT_VCF && c == 5) src = r->d_qual, es = 4;
+                b->elem[c] = es;
+                b->cols[c].n = k * es;
+                RD_HIP(r, hipHostMalloc(&b->cols[c].p, k * es, hipHostMallocDefault));
+                RD_HIP(r, hipMemcpyAsync(b->cols[c].p, src, k * es, hipMemcpyDeviceToHost, r->stream));
             }
-            size_t vw = (size_t)((k + 63) / 64) * 8;
-            b->validity.n = vw;
-            RD_HIP(r, hipHostMalloc(&b->validity.p, vw, hipHostMallocDefault));
-            RD_HIP(r, hipMemcpyAsync(b->validity.p, r->d_valid, vw, hipMemcpyDeviceToHost, r->stream));
+            auto copy_validity = [&](int col, const void *d) -> int {
+                b->validity[col].n = vw;
+                RD_HIP(r, hipHostMalloc(&b->validity[col].p, vw, hipHostMallocDefault));
+                RD_HIP(r, hipMemcpyAsync(b->validity[col].p, d, vw, hipMemcpyDeviceToHost, r->stream));
+                return EXG_OK;
+            };
+            if (r->format == EXG_FMT_VCF) {
+                if ((rc = copy_validity(5, r->d_valid[0])) || (rc = copy_validity(8, r->d_valid[1]))) return rc;
+            } else {
+                if ((rc = copy_validity(1, r->d_valid[0]))) return rc;
+            }
+            if (r->format == EXG_FMT_FASTA && res.payload_bytes)
+                RD_HIP(r, hipMemcpyAsync(b->payload.p, r->d_payload, res.payload_bytes, hipMemcpyDeviceToHost, r->stream));
             RD_HIP(r, hipStreamSynchronize(r->stream));
             r->batch = b;
         }
@@ -357,9 +450,11 @@ extern "C" int exg_next_chunk(exg_reader *r, exg_chunk *out) {
             uint64_t row0 = r->batch_row;
             uint64_t n = std::min<uint64_t>(r->batch_rows, r->batch->n_rows - row0);
             out->n_rows = n;
-            out->n_columns = 4;
-            for (int c = 0; c < 4; c++) out->data[c] = (char *)r->batch->cols[c].p + row0 * 16;
-            out->validity[1] = (uint64_t *)r->batch->validity.p + row0 / 64;
+            out->n_columns = r->batch->n_cols;
+            for (int c = 0; c < r->batch->n_cols; c++) {
+                out->data[c] = (char *)r->batch->cols[c].p + row0 * r->batch->elem[c];
+                out->validity[c] = r->batch->validity[c].p ? (uint64_t *)r->batch->validity[c].p + row0 / 64 : nullptr;
+            }
             out->keepalive = new ChunkKeep{r->batch};
             r->batch_row += n;
             return EXG_OK;

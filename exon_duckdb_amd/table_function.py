@@ -1,0 +1,179 @@
+"""Python front-end of the host-side table functions (csrc/exon_table_function.cpp).
+
+It plays the role DuckDB plays for the reference: look a table function up in the catalog, bind it,
+init the scan with a projection, pull DataChunks until an empty one comes back.  Used by the parity
+tests, which read like the reference's sqllogictests:
+
+    con.table_function("read_fastq", path).count()
+    con.table_function("read_fasta", path, compression="gzip").fetchall()
+    con.from_path("x/test.fasta")                     # replacement scan
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from ._lib import ExgError, load_library
+
+ROW_ID = (1 << 64) - 1
+
+
+class Schema(C.Structure):
+    _fields_ = [("n_columns", C.c_int), ("names", C.c_char_p * 16), ("types", C.c_int * 16), ("nullable", C.c_int * 16)]
+
+
+class Chunk(C.Structure):
+    _fields_ = [("n_rows", C.c_uint64), ("n_columns", C.c_int), ("data", C.c_void_p * 16),
+                ("validity", C.c_void_p * 16), ("keepalive", C.c_void_p)]
+
+
+_bound = False
+
+
+def _lib():
+    global _bound
+    l = load_library()
+    if not _bound:
+        l.exon_tf_catalog_has.restype = C.c_int
+        l.exon_tf_catalog_has.argtypes = [C.c_char_p]
+        l.exon_tf_bind.restype = C.c_int
+        l.exon_tf_bind.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
+        l.exon_tf_schema.argtypes = [C.c_void_p, C.POINTER(Schema)]
+        l.exon_tf_init.restype = C.c_int
+        l.exon_tf_init.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
+        l.exon_tf_scan.restype = C.c_int
+        l.exon_tf_scan.argtypes = [C.c_void_p, C.POINTER(Chunk)]
+        l.exon_tf_close.argtypes = [C.c_void_p]
+        l.exon_replacement_scan.restype = C.c_int
+        l.exon_replacement_scan.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+        _bound = True
+    return l
+
+
+def _err(l):
+    return l.exg_last_error_message().decode("utf-8", "replace")
+
+
+def _decode_strings(ptr, validity_ptr, n):
+    """n duckdb::string_t at host address ptr -> list of bytes / None."""
+    raw = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n * 16,)).reshape(n, 16)
+    lens = raw[:, :4].copy().view(np.uint32).reshape(n)
+    ptrs = raw[:, 8:16].copy().view(np.uint64).reshape(n)
+    valid = None
+    if validity_ptr:
+        words = np.ctypeslib.as_array(C.cast(validity_ptr, C.POINTER(C.c_uint64)), shape=((n + 63) // 64,))
+        valid = np.unpackbits(words.view(np.uint8), bitorder="little")[:n]
+    out = []
+    for i in range(n):
+        if valid is not None and not valid[i]:
+            out.append(None)
+        elif lens[i] <= 12:
+            out.append(raw[i, 4:4 + lens[i]].tobytes())
+        else:
+            out.append(C.string_at(int(ptrs[i]), int(lens[i])))   # zero-copy payload in pinned host memory
+    return out
+
+
+class Relation:
+    def __init__(self, fn_name, path, compression=None):
+        self._l = _lib()
+        self.fn_name, self.path, self.compression = fn_name, path, compression
+        h = C.c_void_p()
+        rc = self._l.exon_tf_bind(fn_name.encode(), path.encode(), compression.encode() if compression else None, C.byref(h))
+        if rc != 0:
+            raise ExgError(rc, _err(self._l))          # bind-time error, e.g. read_fastq('')
+        sch = Schema()
+        self._l.exon_tf_schema(h, C.byref(sch))
+        self.names = [sch.names[i].decode() for i in range(sch.n_columns)]
+        self.types = [sch.types[i] for i in range(sch.n_columns)]
+        self._l.exon_tf_close(h)
+
+    def _scan(self, column_ids):
+        h = C.c_void_p()
+        rc = self._l.exon_tf_bind(self.fn_name.encode(), self.path.encode(),
+                                  self.compression.encode() if self.compression else None, C.byref(h))
+        if rc != 0:
+            raise ExgError(rc, _err(self._l))
+        try:
+            ids = (C.c_uint64 * len(column_ids))(*column_ids)
+            if self._l.exon_tf_init(h, ids, len(column_ids)) != 0:
+                raise ExgError(abi.EXG_E_IO, _err(self._l))
+            while True:
+                ch = Chunk()
+                if self._l.exon_tf_scan(h, C.byref(ch)) != 0:
+                    raise ExgError(abi.EXG_E_PARSE, _err(self._l))
+                if ch.n_rows == 0:
+                    return
+                yield ch
+        finally:
+            self._l.exon_tf_close(h)
+
+    def count(self):
+        """SELECT count(*): only the row id is projected, no column is materialised."""
+        return sum(int(ch.n_rows) for ch in self._scan([ROW_ID]))
+
+    def chunk_sizes(self, columns=None):
+        cols = self.names if columns is None else columns
+        return [int(ch.n_rows) for ch in self._scan([self.names.index(c) for c in cols])]
+
+    def fetchall(self, columns=None, limit=None, where=None):
+        """SELECT columns ... [WHERE where(row_dict)] [LIMIT limit] -> list of tuples (bytes/None/int/float)."""
+        cols = self.names if columns is None else columns
+        ids = [self.names.index(c) for c in cols]
+        rows = []
+        for ch in self._scan(ids):
+            n = int(ch.n_rows)
+            decoded = []
+            for k, cid in enumerate(ids):
+                t = self.types[cid]
+                if t == abi_type("VARCHAR"):
+                    decoded.append(_decode_strings(ch.data[k], ch.validity[k], n))
+                else:
+                    dt = np.int64 if t == abi_type("BIGINT") else np.float32
+                    arr = np.ctypeslib.as_array(C.cast(ch.data[k], C.POINTER(C.c_uint8)), shape=(n * np.dtype(dt).itemsize,)).view(dt).copy()
+                    vals = arr.tolist()
+                    if ch.validity[k]:
+                        words = np.ctypeslib.as_array(C.cast(ch.validity[k], C.POINTER(C.c_uint64)), shape=((n + 63) // 64,))
+                        v = np.unpackbits(words.view(np.uint8), bitorder="little")[:n]
+                        vals = [x if ok else None for x, ok in zip(vals, v)]
+                    decoded.append(vals)
+            for i in range(n):
+                row = tuple(d[i] for d in decoded)
+                if where is None or where(dict(zip(cols, row))):
+                    rows.append(row)
+                    if limit is not None and len(rows) >= limit:
+                        return rows
+        return rows
+
+
+def abi_type(name):
+    return {"VARCHAR": 1, "BIGINT": 2, "FLOAT": 3}[name]
+
+
+class Connection:
+    """LOAD exon; then call table functions by name."""
+
+    def has_table_function(self, name):
+        return bool(_lib().exon_tf_catalog_has(name.encode()))
+
+    def table_function(self, name, path, compression=None):
+        if not self.has_table_function(name):
+            raise ExgError(abi.EXG_E_INVALID_ARG, f"Catalog Error: Table Function with name {name} does not exist!")
+        return Relation(name, path, compression)
+
+    def replacement_scan(self, table_name):
+        buf = C.create_string_buffer(64)
+        if _lib().exon_replacement_scan(table_name.encode(), buf, 64):
+            return buf.value.decode()
+        return None
+
+    def from_path(self, path):
+        """SELECT ... FROM 'path'  (WTArrowTableFunction::ReplacementScan, module.cpp:320-382)."""
+        fn = self.replacement_scan(path)
+        if fn is None:
+            raise ExgError(abi.EXG_E_INVALID_ARG, f"Catalog Error: Table with name {path} does not exist!")
+        return Relation(fn, path)
+
+
+def connect():
+    return Connection()

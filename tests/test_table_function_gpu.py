@@ -1,0 +1,163 @@
+"""The reference's sqllogictests for the path, statement by statement, against the host-side table
+functions (bind / init_global / init_local / scan over the reader-level C-ABI and the HIP kernels).
+
+test/sql/exondb-release-with-deb-info/test_fastq_scan.test, test_fasta_scan.test,
+test_vcf_record_scan.test — same fixtures (tests/golden/), same expected values.  Statements on
+.gz / .zst inputs are expected to fail LOUDLY for now (no device inflate yet, and no CPU fallback)."""
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def con(gpu):
+    from exon_duckdb_amd import table_function
+    return table_function.connect()
+
+
+def G(golden_dir, name):
+    return os.path.join(golden_dir, name)
+
+
+# ---- test_fastq_scan.test ---------------------------------------------------------------------------
+
+def test_fastq_count(con, golden_dir):
+    # SELECT count(*) FROM read_fastq('…/test.fastq');   -> 2          (:5-8)
+    assert con.table_function("read_fastq", G(golden_dir, "test.fastq")).count() == 2
+
+
+def test_fastq_table_structure(con, golden_dir):
+    # SELECT * FROM read_fastq('…/test.fastq') LIMIT 1;                (:35-41)
+    rel = con.table_function("read_fastq", G(golden_dir, "test.fastq"))
+    assert rel.names == ["name", "description", "sequence", "quality_scores"]
+    assert rel.fetchall(limit=1) == [(
+        b"SEQ_ID", b"This is a description",
+        b"GATTTGGGGTTCAAAGCAGTATCGATCAAATAGTAAATCCATTTGTTCAACTCACAGTTT",
+        b"!''*((((***+))%%%++)(%%%%).1***-+*''))**55CCF>>>>>>CCCCCCC65")]
+    assert rel.fetchall(columns=["description"]) == [(b"This is a description",), (None,)]
+
+
+def test_fastq_replacement_scan(con, golden_dir):
+    # SELECT count(*) FROM '…/test.fastq';                             (:44-47)
+    assert con.from_path(G(golden_dir, "test.fastq")).count() == 2
+    assert con.replacement_scan("x/test.fastq.gz") == "read_fastq"     # (:50-53)
+    assert con.replacement_scan("x/test.fastq.zst") == "read_fastq"    # (:56-59)
+
+
+def test_fastq_empty_path_is_an_error(con):
+    # statement error: SELECT count(*) FROM read_fastq('');            (:61-62)
+    from exon_duckdb_amd import ExgError
+    with pytest.raises(ExgError):
+        con.table_function("read_fastq", "")
+
+
+def test_fastq_directory(con, golden_dir):
+    # SELECT COUNT(*) FROM read_fastq('…/fastq/') LIMIT 1;  -> 4       (:65-68)
+    assert con.table_function("read_fastq", G(golden_dir, "fastq") + "/").count() == 4
+    names = con.table_function("read_fastq", G(golden_dir, "fastq")).fetchall(columns=["name"])
+    assert names == [(b"SEQ_ID",), (b"SEQ_ID2",)] * 2
+
+
+@pytest.mark.parametrize("name,compression", [("test.fastq.gz", None), ("test.fastq.gzip", "gzip"),
+                                              ("test.fastq.zst", None), ("test.fastq.zstd", "zstd")])
+def test_fastq_compressed_fails_loudly(con, golden_dir, name, compression):
+    # (:11-32) need a device inflate; until it exists the statement must error, never fall back to a CPU
+    from exon_duckdb_amd import ExgError
+    with pytest.raises(ExgError, match="not supported"):
+        con.table_function("read_fastq", G(golden_dir, name), compression=compression).count()
+
+
+# ---- test_fasta_scan.test / test_fasta_copy.test -------------------------------------------------------
+
+def test_fasta_count(con, golden_dir):
+    assert con.table_function("read_fasta", G(golden_dir, "test.fasta")).count() == 2        # (:5-8)
+    assert con.from_path(G(golden_dir, "test.fasta")).count() == 2                            # (:29-32)
+
+
+def test_fasta_where_id(con, golden_dir):
+    # SELECT count(*) FROM '…/test.fasta' WHERE id = 'a';   -> 1       (:34-37)
+    rel = con.from_path(G(golden_dir, "test.fasta"))
+    assert rel.names == ["id", "description", "sequence"]
+    assert len(rel.fetchall(where=lambda r: r["id"] == b"a")) == 1
+    assert rel.fetchall() == [(b"a", b"description", b"ATCG"), (b"b", b"description2", b"ATCG")]
+
+
+def test_fasta_null_description(con, golden_dir):
+    # FROM read_fasta(…mixed-desc…) WHERE description IS NULL -> b, NULL, ATCG   (test_fasta_copy.test:75-80)
+    rel = con.table_function("read_fasta", G(golden_dir, "test.mixed-desc.fasta"))
+    assert rel.fetchall(where=lambda r: r["description"] is None) == [(b"b", None, b"ATCG")]
+
+
+def test_fasta_empty_path_is_an_error(con):
+    from exon_duckdb_amd import ExgError
+    with pytest.raises(ExgError):
+        con.table_function("read_fasta", "")                                                  # (:51-53)
+
+
+def test_fasta_compressed_fails_loudly(con, golden_dir):
+    from exon_duckdb_amd import ExgError
+    with pytest.raises(ExgError, match="not supported"):
+        con.table_function("read_fasta", G(golden_dir, "test.fasta.gz")).count()              # (:17-20)
+    with pytest.raises(ExgError, match="not supported"):
+        con.table_function("read_fasta", G(golden_dir, "fasta") + "/", compression="gzip").count()   # (:55-59)
+
+
+# ---- test_vcf_record_scan.test ---------------------------------------------------------------------------
+
+def test_vcf_count(con, golden_dir):
+    # SELECT COUNT(*) FROM read_vcf_file_records('…/vcf/index.vcf');  -> 621     (:4-7)
+    assert con.table_function("read_vcf_file_records", G(golden_dir, "vcf/index.vcf")).count() == 621
+    assert con.table_function("read_vcf", G(golden_dir, "vcf/index.vcf")).count() == 621     # the north star's name
+    assert con.from_path(G(golden_dir, "vcf/index.vcf")).count() == 621
+
+
+def test_vcf_row0(con, golden_dir):
+    # SELECT chrom, pos, ref, alt, qual, info.indel, info.dp … LIMIT 1            (:10-19)
+    rel = con.table_function("read_vcf_file_records", G(golden_dir, "vcf/index.vcf"))
+    assert rel.names == ["chrom", "pos", "id", "ref", "alt", "qual", "filter", "info", "formats"]
+    chrom, pos, ref, alt, qual, info = rel.fetchall(columns=["chrom", "pos", "ref", "alt", "qual", "info"], limit=1)[0]
+    assert (chrom, pos, ref, alt.split(b","), qual) == (b"1", 9999919, b"G", [b"<*>"], 0.0)
+    kv = dict(x.split(b"=", 1) if b"=" in x else (x, None) for x in info.split(b";"))
+    assert b"INDEL" not in kv and int(kv[b"DP"]) == 1       # info.indel IS NULL, info.dp = 1
+
+
+def test_vcf_nulls(con, golden_dir):
+    rows = con.table_function("read_vcf_file_records", G(golden_dir, "vcf/vcf_meta_meta.vcf")).fetchall()
+    assert rows == [(b"1", 123, b"test", b"TC", b"T", None, b".", b".", None)]
+
+
+# ---- chunking: the reference asks for STANDARD_VECTOR_SIZE rows per batch (module.cpp:83) ----------------------
+
+def test_chunks_are_2048_rows(con, oracle, tmp_path):
+    p = tmp_path / "many.fastq"
+    p.write_bytes(oracle.synth_fastq(332 * 5000).tobytes())
+    rel = con.table_function("read_fastq", str(p))
+    assert rel.chunk_sizes() == [2048, 2048, 904]
+    assert rel.count() == 5000
+    rows = rel.fetchall(columns=["name", "description"])
+    assert rows[4999] == (b"SYN000000004999", b"3:N:0:ACGT")
+
+
+def test_parse_error_surfaces_after_the_good_rows(con, tmp_path):
+    from exon_duckdb_amd import ExgError
+    p = tmp_path / "bad.fastq"
+    p.write_bytes(b"@x\nAC\n+\n!!\n" * 3000 + b"oops\nAC\n+\n!!\n")
+    rel = con.table_function("read_fastq", str(p))
+    with pytest.raises(ExgError, match="invalid name prefix"):
+        rel.count()
+    with pytest.raises(ExgError, match="invalid name prefix"):
+        rel.fetchall()
+
+
+def test_streaming_batches_match_one_batch(con, oracle, tmp_path, monkeypatch):
+    # several record-aligned device batches must give the same rows as one
+    data = bytes(oracle.synth_fastq_ragged(3000))
+    p = tmp_path / "ragged.fastq"
+    p.write_bytes(data)
+    exp = oracle.fastq_parse(data)
+    rows = con.table_function("read_fastq", str(p)).fetchall()
+    assert len(rows) == 3000
+    for i in (0, 1, 2999):
+        assert rows[i] == tuple(exp.columns[k].row(i) for k in exp.columns)
