@@ -298,3 +298,15 @@ extern "C" int exon_replacement_scan(const char *table_name, char *out_fn, size_
     memcpy(out_fn, f.c_str(), f.size() + 1);
     return 1;
 }
+
+// exon/include/rust.hpp:48 — same symbol, same result struct (file type upper-cased, NULL when unknown)
+extern "C" ReplacementScanResult replacement_scan(const char *uri) {
+    ReplacementScanResult r;
+    r.file_type = nullptr;
+    if (!uri) return r;
+    std::string f = WTArrowTableFunction::ReplacementScan(uri);
+    if (f == "read_fasta") r.file_type = "FASTA";
+    if (f == "read_fastq") r.file_type = "FASTQ";
+    if (f == "read_vcf_file_records") r.file_type = "VCF";
+    return r;
+}

@@ -22,8 +22,11 @@
  *       Replaces `new_reader` + the ArrowArrayStream it returns
  *       (exon/include/rust.hpp:41-46, rust/src/arrow_reader.rs:38-166).
  *
- *   (3) new_reader / replacement_scan compatible entry points are declared in
- *       exon_gpu_compat.h (same names and argument meaning as rust.hpp).
+ *   (3) replacement_scan — same name, argument and result struct as the reference's FFI
+ *       (exon/include/rust.hpp:11-13, :48), so the reference's ReplacementScan glue
+ *       (module.cpp:320-382) binds to it unchanged.  `new_reader` is NOT re-exported: it returns
+ *       an Arrow stream the DataChunk path no longer needs (INTEGRATION.md shows the binding that
+ *       replaces its two call sites, module.cpp:98-102 and :239-243, with exg_open).
  *
  * Error convention: every function returns 0 on success or a negative
  * EXG_E_* code; nothing throws across this boundary.  Parse errors found by a
@@ -261,6 +264,15 @@ void exg_release_chunk(exg_reader *r, exg_chunk *chunk);
 int exg_count_only(exg_reader *r, uint64_t *n_rows);
 const char *exg_reader_error(exg_reader *r);
 void exg_close(exg_reader *r);
+
+/* ---- (3) reference-FFI compatible ------------------------------------------------------ */
+/* exon/include/rust.hpp:11-13 */
+typedef struct ReplacementScanResult {
+    const char *file_type; /* "FASTA" | "FASTQ" | "VCF" (static storage) or NULL */
+} ReplacementScanResult;
+/* exon/include/rust.hpp:48, rust/src/arrow_reader.rs:173-197: last extension, skipping one
+ * compression extension (gz, gzip, zst, zstd, bz2, bzip2, xz). */
+ReplacementScanResult replacement_scan(const char *uri);
 
 #ifdef __cplusplus
 }
