@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--gb", type=float, default=10.0, help="shard size per GPU in GB (1e9 bytes)")
     ap.add_argument("--algo", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; default) | gloo (functional test of the N>1 path)")
+    ap.add_argument("--single-device", action="store_true", help="test only: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -70,44 +72,49 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the record scan has no CPU fallback")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    coll_dev = "cuda" if args.backend == "nccl" else "cpu"   # where the 8-byte collectives live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     lib = load_library()
 
-    shard = int(args.gb * 1e9) // 16 * 16          # 16-byte aligned cut points, not record aligned
-    halo = 1024 if rank > 0 else 0
-    start = rank * shard
-    end = start + shard
-    file_bytes = world * shard
-    is_last = rank == world - 1
-    if is_last:
-        end = file_bytes = (file_bytes // REC) * REC   # the file ends on a record boundary
-    n_bytes = end - (start - halo)
-    d_in = device.synth_fastq(n_bytes, file_offset=start - halo)
+    from exon_duckdb_amd import sharding
+
+    # file = world x args.gb GB of FASTQ-150, cut at 16-byte boundaries (NOT record boundaries)
+    file_bytes = (world * int(args.gb * 1e9)) // REC * REC     # the file ends on a record boundary
+    sh = sharding.plan_shards(file_bytes, world, halo=1024)[rank]
+    halo, start, n_bytes = sh.halo, sh.start, sh.n_bytes
+    d_in = device.synth_fastq(n_bytes, file_offset=sh.load_offset)
     cap = n_bytes // REC + 16
     scan = device.FastqScan(n_bytes, capacity_records=cap)
 
-    # global line phase of the shard start: the generator makes it analytic, the product derives it
-    # from the bytes (count of '\n' before the shard = all_gather of per-shard counts, verified below)
+    # 4-line phase of the shard start, guessed from the shard's own bytes (one tiny kernel, once);
+    # every step re-verifies it against the exact newline counts the scans return (all_gather).
     import ctypes as C
-    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
-    device.check(lib.exg_count_newlines(C.c_void_p(d_in.data_ptr()), halo, n_bytes, C.c_void_p(cnt.data_ptr()),
-                                        device.stream_ptr()))
-    if world > 1:
-        counts = [torch.zeros_like(cnt) for _ in range(world)]
-        dist.all_gather(counts, cnt)                 # 8 bytes per rank over RCCL
-        first_line_index = int(sum(int(c.item()) for c in counts[:rank]))
-    else:
-        first_line_index = 0
-    flags = (abi.EXG_F_BOF if rank == 0 else 0) | (abi.EXG_F_EOF if is_last else 0)
+    ph = torch.zeros(1, dtype=torch.int32, device="cuda")
+    device.check(lib.exg_fastq_guess_phase(C.c_void_p(d_in.data_ptr()), n_bytes, halo, C.c_void_p(ph.data_ptr()),
+                                           device.stream_ptr()))
+    guess = int(ph.item()) & 0xFFFFFFFF
+    assert guess < 4, "phase guess failed on well-formed FASTQ"
+    # the guess is the phase of the first line STARTING at or after the shard start; the line that
+    # contains the shard's first byte is one earlier unless the shard starts exactly on a line start
+    prev_is_nl = True if sh.start == 0 else bool(int(d_in[halo - 1].item()) == 10)
+    first_line_index = guess if prev_is_nl else (guess - 1) % 4
+    flags = (abi.EXG_F_BOF if sh.is_first else 0) | (abi.EXG_F_EOF if sh.is_last else 0)
 
     def step():
         scan.launch(d_in, n_bytes=n_bytes, lead=halo, first_line_index=first_line_index,
-                    payload_base=0x100000000000 + start - halo, flags=flags, algo=args.algo)
+                    payload_base=0x100000000000 + sh.load_offset, flags=flags, algo=args.algo)
 
-    total = torch.zeros(1, dtype=torch.int64, device="cuda")
+    total = torch.zeros(1, dtype=torch.int64, device=coll_dev)
+    lines = torch.zeros(1, dtype=torch.int64, device=coll_dev)
+    line_counts = [torch.zeros(1, dtype=torch.int64, device=coll_dev) for _ in range(world)]
 
     def barrier():
         if world > 1:
@@ -129,16 +136,22 @@ def main():
         step()
         ev[i][1].record()
         if world > 1:
-            # COUNT(*) of the whole file: one 8-byte all_reduce per step
+            # per step: all_gather of the exact newline counts (verifies the phase guess) and the
+            # COUNT(*) all_reduce — 8 bytes per rank each, no byte of the file crosses xGMI
+            lines.copy_(scan.result[1:2])
+            dist.all_gather(line_counts, lines)
             total.copy_(scan.result[:1])
             dist.all_reduce(total)
     barrier()
     dt = time.perf_counter() - t0
     res = scan.fetch()
     assert res.error_code == 0 and int(res.n_records) == n_rec_local
+    if world > 1:
+        exact = sharding.first_line_index_from_counts([int(c.item()) for c in line_counts], rank)
+        assert sharding.phase_is_consistent(first_line_index % 4, exact), "phase guess contradicted by the exact counts"
 
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    nrec = torch.tensor([n_rec_local], dtype=torch.int64, device="cuda")
+    t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+    nrec = torch.tensor([n_rec_local], dtype=torch.int64, device=coll_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(nrec)
@@ -172,8 +185,9 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": f"read_fastq on {shard * world / 1e9:.0f} GB synthetic 150 bp FASTQ "
+                "workload": f"read_fastq on {file_bytes / 1e9:.0f} GB synthetic 150 bp FASTQ "
                             f"({REC} B/record, {total_records} records), {world}x MI355X, byte-range shards",
+                "file_bytes": file_bytes,
                 "bytes_per_gpu": n_bytes,
                 "algo": {0: "auto(fused+gated general path)", 1: "multipass", 2: "fused"}[args.algo],
                 "columns": "name,description,sequence,quality_scores as duckdb::string_t + validity",
