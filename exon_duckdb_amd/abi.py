@@ -112,6 +112,14 @@ class FastaScanArgs(C.Structure):
     ]
 
 
+class InflateMember(C.Structure):
+    _fields_ = [("comp_off", C.c_uint64), ("comp_size", C.c_uint64), ("out_off", C.c_uint64), ("out_cap", C.c_uint64)]
+
+
+class InflateStatus(C.Structure):
+    _fields_ = [("code", C.c_uint32), ("pad", C.c_uint32), ("produced", C.c_uint64), ("consumed", C.c_uint64)]
+
+
 # every symbol include/exon_gpu.h declares -> (restype, argtypes); None = not yet bound by name only
 SIGNATURES = {
     "exg_abi_version": (C.c_int, []),
@@ -122,6 +130,9 @@ SIGNATURES = {
     "exg_fastq_scan": (C.c_int, [C.POINTER(FastqScanArgs)]),
     "exg_vcf_scan": (C.c_int, [C.POINTER(VcfScanArgs)]),
     "exg_fasta_scan": (C.c_int, [C.POINTER(FastaScanArgs)]),
+    "exg_gzip_index": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                 C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    "exg_inflate_members": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "exg_fetch_result": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(ScanResult)]),
     "exg_count_newlines": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
     "exg_synth_fastq": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),

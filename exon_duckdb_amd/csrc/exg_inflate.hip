@@ -1,0 +1,423 @@
+// exg_inflate.hip — DEFLATE (RFC 1951) on the device, one wavefront per gzip member.
+//
+// Replaces the decompression the reference gets from DataFusion 28 `FileCompressionType::convert_stream`
+// -> async-compression 0.4.0 -> flate2 1.0.26 (and noodles-bgzf for .vcf.gz), selected at
+// rust/src/arrow_reader.rs:60-91.  The host parses the gzip member framing (RFC 1952; BGZF members
+// carry their compressed size in the 'BC' extra subfield, so they are found without decoding and are
+// inflated in parallel); the inflated bytes stay in HBM and feed the scan kernels directly.
+//
+// Kernel shape: block = 1 wave (64 lanes).  Every lane runs the same (uniform) decoder — bit buffer
+// and positions live in SGPRs — so no broadcast is needed; the lanes split the work that is parallel:
+//   * compressed bytes are staged through a 2 KiB LDS ring with coalesced 16 B/lane loads;
+//   * Huffman tables (10-bit / 9-bit primary LUTs in LDS + canonical count/offset arrays for the
+//     rare longer codes) are built cooperatively: canonical codes by wave ballots, LUT fill per symbol;
+//   * the 32 KiB sliding window is an LDS ring: literals are single LDS byte writes, LZ77 matches are
+//     copied by all lanes (source index folded modulo the distance, so overlapping copies are exact);
+//   * every completed 1 KiB of the ring is flushed to HBM with 16 B/lane stores.
+// LDS: 32 KiB window + 2 KiB input + ~4.5 KiB tables => 4 waves per CU, 1024 members in flight.
+#include "exg_common.hpp"
+
+namespace exg {
+
+struct InflateMember {
+    unsigned long long comp_off;   // offset of the DEFLATE stream in d_comp
+    unsigned long long comp_size;  // bytes available from comp_off (deflate data + trailer)
+    unsigned long long out_off;    // where the member's output starts in d_out
+    unsigned long long out_cap;    // bytes it may produce (ISIZE when known)
+};
+
+struct InflateStatus {
+    unsigned int code;             // 0 ok; 1 bad block type / stored len; 2 bad code lengths; 3 bad symbol or distance;
+                                   // 4 output overflow; 5 input exhausted
+    unsigned int pad;
+    unsigned long long produced;   // bytes written
+    unsigned long long consumed;   // compressed bytes consumed (from comp_off, byte aligned after the final block)
+};
+
+static constexpr int kWinBytes = 32768;
+static constexpr int kInRing = 2048;
+static constexpr int kLitBits = 10, kDistBits = 9;
+
+struct InflateLds {
+    uint8_t win[kWinBytes];
+    uint8_t in[kInRing];
+    uint16_t lit_lut[1 << kLitBits];    // (symbol << 4) | length, 0 = code longer than kLitBits (or unused)
+    uint16_t dist_lut[1 << kDistBits];
+    uint16_t lit_sorted[288], dist_sorted[32];   // symbols ordered by (length, symbol) — canonical decode
+    uint16_t lit_count[16], dist_count[16];
+    uint8_t lens[384];  // [0,288) literal/length, [288,320) distance; [32,348) scratch while a dynamic header is read
+};
+
+__device__ __constant__ unsigned short kLenBase[29] = {3,  4,  5,  6,  7,  8,  9,  10, 11,  13,  15,  17,  19,  23, 27,
+                                                      31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__device__ __constant__ unsigned char kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__device__ __constant__ unsigned short kDistBase[30] = {1,   2,   3,   4,   5,   7,    9,    13,   17,   25,
+                                                       33,  49,  65,  97,  129, 193,  257,  385,  513,  769,
+                                                       1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__device__ __constant__ unsigned char kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__device__ __constant__ unsigned char kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+__device__ __forceinline__ uint32_t sgpr(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+
+struct BitReader {
+    unsigned long long bb;  // bit buffer, LSB first
+    uint32_t bc;            // valid bits
+    uint32_t ip;            // next byte to fetch, relative to g0 (multiple of 4)
+    uint32_t loaded;        // input chunks [0, loaded) (1 KiB each) have been staged
+    uint32_t limit;         // bytes available relative to g0
+    const uint8_t *g0;      // 16-byte aligned global address of chunk 0
+};
+
+// stage 1 KiB chunk c of the compressed input (coalesced, 16 B per lane)
+__device__ __forceinline__ void stage_chunk(InflateLds &s, const BitReader &br, uint32_t c, uint32_t lane) {
+    uint32_t off = c * 1024 + lane * 16;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (off < ((br.limit + 15) & ~15u)) v = *reinterpret_cast<const uint4 *>(br.g0 + off);
+    *reinterpret_cast<uint4 *>(s.in + ((c & 1) * 1024 + lane * 16)) = v;
+}
+
+// make at least n (<= 32) bits available
+__device__ __forceinline__ void need(InflateLds &s, BitReader &br, uint32_t n, uint32_t lane) {
+    while (br.bc < n) {
+        uint32_t c = br.ip >> 10;
+        if (c + 1 >= br.loaded) {  // keep chunk c and c + 1 staged
+            stage_chunk(s, br, br.loaded, lane);
+            br.loaded++;
+            continue;
+        }
+        uint32_t w = sgpr(*reinterpret_cast<const uint32_t *>(s.in + (br.ip & (kInRing - 1))));
+        br.bb |= (unsigned long long)w << br.bc;
+        br.bc += 32;
+        br.ip += 4;
+    }
+}
+__device__ __forceinline__ uint32_t getbits(InflateLds &s, BitReader &br, uint32_t n, uint32_t lane) {
+    need(s, br, n, lane);
+    uint32_t v = (uint32_t)br.bb & ((1u << n) - 1u);
+    br.bb >>= n;
+    br.bc -= n;
+    return v;
+}
+
+// Build one decode table from code lengths lens[0..n): LUT (primary `bits`), sorted symbols, counts.
+// Returns false when the lengths are over-subscribed or incomplete (except the single-code cases zlib allows).
+__device__ bool build_table(const uint8_t *lens, uint32_t n, uint16_t *lut, uint32_t bits, uint16_t *sorted,
+                            uint16_t *count, uint32_t lane) {
+    for (uint32_t e = lane; e < (1u << bits); e += 64) lut[e] = 0;
+    // counts per length
+    uint32_t cnt[16];
+#pragma unroll
+    for (int L = 0; L < 16; L++) cnt[L] = 0;
+    for (uint32_t base = 0; base < n; base += 64) {
+        uint32_t sym = base + lane;
+        uint32_t l = sym < n ? lens[sym] : 0;
+#pragma unroll
+        for (int L = 1; L < 16; L++) cnt[L] += __popcll(__ballot(l == (uint32_t)L));
+    }
+    // canonical first codes and offsets into `sorted`
+    uint32_t first[16], offs[16];
+    uint32_t code = 0, off = 0;
+    int left = 1;
+    bool bad = false;
+#pragma unroll
+    for (int L = 1; L < 16; L++) {
+        left = (left << 1) - (int)cnt[L];
+        if (left < 0) bad = true;
+        code = (code + cnt[L - 1]) << 1;
+        first[L] = code;
+        offs[L] = off;
+        off += cnt[L];
+    }
+    first[0] = 0;
+    offs[0] = 0;
+#pragma unroll
+    for (int L = 0; L < 16; L++)
+        if (lane == (uint32_t)L) count[L] = (uint16_t)(L ? cnt[L] : 0);
+    if (bad) return false;
+    // incomplete codes are only legal with a single code of length 1 (zlib / puff behaviour)
+    if (left > 0 && !(off == 1 && cnt[1] == 1) && off != 0) return false;
+    // per symbol: canonical code = first[len] + rank among equal lengths, in symbol order
+    uint32_t run[16];
+#pragma unroll
+    for (int L = 0; L < 16; L++) run[L] = 0;
+    for (uint32_t base = 0; base < n; base += 64) {
+        uint32_t sym = base + lane;
+        uint32_t l = sym < n ? lens[sym] : 0;
+        uint32_t rank = 0, f = 0, o = 0;
+#pragma unroll
+        for (int L = 1; L < 16; L++) {
+            unsigned long long m = __ballot(l == (uint32_t)L);
+            if (l == (uint32_t)L) {
+                rank = run[L] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                f = first[L];
+                o = offs[L];
+            }
+            run[L] += (uint32_t)__popcll(m);
+        }
+        if (l) {
+            sorted[o + rank] = (uint16_t)sym;
+            if (l <= bits) {
+                uint32_t c = f + rank;
+                uint32_t r = __brev(c) >> (32 - l);  // codes are sent MSB first
+                for (uint32_t e = r; e < (1u << bits); e += 1u << l) lut[e] = (uint16_t)((sym << 4) | l);
+            }
+        }
+    }
+    return true;
+}
+
+// decode one symbol; returns 0xFFFFFFFF on an invalid code
+__device__ __forceinline__ uint32_t decode_sym(InflateLds &s, BitReader &br, const uint16_t *lut, uint32_t bits,
+                                               const uint16_t *sorted, const uint16_t *count, uint32_t lane) {
+    need(s, br, 15, lane);
+    uint32_t e = sgpr(lut[(uint32_t)br.bb & ((1u << bits) - 1u)]);
+    if (e) {
+        uint32_t l = e & 15;
+        br.bb >>= l;
+        br.bc -= l;
+        return e >> 4;
+    }
+    // canonical decode, bit by bit (codes longer than the primary table; rare)
+    uint32_t code = 0, first = 0, index = 0;
+    unsigned long long bits64 = br.bb;
+    for (uint32_t len = 1; len <= 15; len++) {
+        code |= (uint32_t)bits64 & 1u;
+        bits64 >>= 1;
+        uint32_t c = sgpr(count[len]);
+        if (code < first + c) {
+            br.bb >>= len;
+            br.bc -= len;
+            return sgpr(sorted[index + (code - first)]);
+        }
+        index += c;
+        first += c;
+        first <<= 1;
+        code <<= 1;
+    }
+    return 0xFFFFFFFFu;
+}
+
+// flush every completed 1 KiB segment of the window ring to HBM
+__device__ __forceinline__ void flush_segments(InflateLds &s, uint8_t *out, unsigned long long out_off, uint32_t &flushed,
+                                               uint32_t pos, uint32_t lane) {
+    while (flushed + 1024 <= pos) {
+        uint4 v = *reinterpret_cast<const uint4 *>(s.win + ((flushed & (kWinBytes - 1)) + lane * 16));
+        // the member's out_off is arbitrary: fall back to byte stores when the destination is not 16-byte aligned
+        uint8_t *dst = out + out_off + flushed + lane * 16;
+        if ((((uintptr_t)dst) & 15) == 0) {
+            *reinterpret_cast<uint4 *>(dst) = v;
+        } else {
+            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 16; k++) dst[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+        }
+        flushed += 1024;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ d_comp, uint8_t *__restrict__ d_out,
+                                                const InflateMember *__restrict__ members, InflateStatus *status,
+                                                uint32_t n_members) {
+    __shared__ __attribute__((aligned(16))) InflateLds s;
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t m = blockIdx.x; m < n_members; m += gridDim.x) {
+        const InflateMember mb = members[m];
+        BitReader br;
+        const unsigned long long a0 = mb.comp_off & ~15ull;
+        br.g0 = d_comp + a0;
+        const uint32_t skip = (uint32_t)(mb.comp_off - a0);
+        unsigned long long lim = mb.comp_size + skip;
+        br.limit = lim > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)lim;
+        br.bb = 0;
+        br.bc = 0;
+        br.ip = skip & ~3u;
+        br.loaded = 0;
+        __syncthreads();
+        stage_chunk(s, br, 0, lane);
+        stage_chunk(s, br, 1, lane);
+        br.loaded = 2;
+        if (skip & 3) (void)getbits(s, br, 8 * (skip & 3), lane);
+
+        uint32_t pos = 0, flushed = 0, err = 0;
+        const unsigned long long cap = mb.out_cap;
+        bool last = false;
+        while (!last && !err) {
+            last = getbits(s, br, 1, lane) != 0;
+            uint32_t type = getbits(s, br, 2, lane);
+            if (type == 0) {
+                // stored: skip to a byte boundary, LEN / NLEN, raw bytes
+                (void)getbits(s, br, br.bc & 7, lane);
+                uint32_t len = getbits(s, br, 16, lane), nlen = getbits(s, br, 16, lane);
+                if ((len ^ 0xFFFFu) != nlen) {
+                    err = 1;
+                    break;
+                }
+                if ((unsigned long long)pos + len > cap) {
+                    err = 4;
+                    break;
+                }
+                for (uint32_t i = 0; i < len; i++) {  // byte at a time through the bit reader: stored blocks are rare
+                    uint32_t b = getbits(s, br, 8, lane);
+                    if (lane == 0) s.win[(pos + i) & (kWinBytes - 1)] = (uint8_t)b;
+                    if (((pos + i + 1) & 1023) == 0) flush_segments(s, d_out, mb.out_off, flushed, pos + i + 1, lane);
+                }
+                pos += len;
+                continue;
+            }
+            if (type == 3) {
+                err = 1;
+                break;
+            }
+            uint32_t nlit, ndist;
+            if (type == 1) {
+                for (uint32_t i = lane; i < 288; i += 64) s.lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
+                if (lane < 32) s.lens[288 + lane] = 5;  // 32 codes make the fixed distance code complete; 30, 31 are invalid
+                nlit = 288;
+                ndist = 32;
+            } else {
+                nlit = getbits(s, br, 5, lane) + 257;
+                ndist = getbits(s, br, 5, lane) + 1;
+                uint32_t ncode = getbits(s, br, 4, lane) + 4;
+                if (nlit > 286 || ndist > 30) {
+                    err = 2;
+                    break;
+                }
+                if (lane < 19) s.lens[lane] = 0;
+                for (uint32_t i = 0; i < ncode; i++) {
+                    uint32_t v = getbits(s, br, 3, lane);
+                    if (lane == 0) s.lens[kClOrder[i]] = (uint8_t)v;
+                }
+                // the code-length code reuses the distance table storage (7-bit codes, 19 symbols)
+                if (!build_table(s.lens, 19, s.dist_lut, 7, s.dist_sorted, s.dist_count, lane)) {
+                    err = 2;
+                    break;
+                }
+                // the lengths themselves: staged in registers-free fashion straight into s.lens (after the 19)
+                uint32_t idx = 0, prev = 0;
+                while (idx < nlit + ndist) {
+                    uint32_t sym = decode_sym(s, br, s.dist_lut, 7, s.dist_sorted, s.dist_count, lane);
+                    if (sym == 0xFFFFFFFFu) {
+                        err = 2;
+                        break;
+                    }
+                    uint32_t rep = 1, val = sym;
+                    if (sym == 16) {
+                        if (idx == 0) {
+                            err = 2;
+                            break;
+                        }
+                        val = prev;
+                        rep = 3 + getbits(s, br, 2, lane);
+                    } else if (sym == 17) {
+                        val = 0;
+                        rep = 3 + getbits(s, br, 3, lane);
+                    } else if (sym == 18) {
+                        val = 0;
+                        rep = 11 + getbits(s, br, 7, lane);
+                    }
+                    if (idx + rep > nlit + ndist) {
+                        err = 2;
+                        break;
+                    }
+                    for (uint32_t k = lane; k < rep; k += 64) s.lens[32 + idx + k] = (uint8_t)val;
+                    idx += rep;
+                    prev = val;
+                }
+                if (err) break;
+                // move to their final places: literal/length lengths at [0, nlit), distance at [288, 288+ndist)
+                uint8_t lv[5];
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    uint32_t i = k * 64 + lane;
+                    lv[k] = i < nlit + ndist ? s.lens[32 + i] : 0;
+                }
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    uint32_t i = k * 64 + lane;
+                    if (i < nlit)
+                        s.lens[i] = lv[k];
+                    else if (i < nlit + ndist)
+                        s.lens[288 + (i - nlit)] = lv[k];
+                }
+            }
+            if (!build_table(s.lens, nlit, s.lit_lut, kLitBits, s.lit_sorted, s.lit_count, lane) ||
+                !build_table(s.lens + 288, ndist, s.dist_lut, kDistBits, s.dist_sorted, s.dist_count, lane)) {
+                err = 2;
+                break;
+            }
+            // ---- symbols of the block ----------------------------------------------------------
+            for (;;) {
+                uint32_t sym = decode_sym(s, br, s.lit_lut, kLitBits, s.lit_sorted, s.lit_count, lane);
+                if (sym < 256) {
+                    if (pos >= cap) {
+                        err = 4;
+                        break;
+                    }
+                    if (lane == 0) s.win[pos & (kWinBytes - 1)] = (uint8_t)sym;
+                    pos++;
+                    if ((pos & 1023) == 0) flush_segments(s, d_out, mb.out_off, flushed, pos, lane);
+                    continue;
+                }
+                if (sym == 256) break;
+                if (sym > 285) {
+                    err = 3;
+                    break;
+                }
+                sym -= 257;
+                uint32_t len = kLenBase[sym] + getbits(s, br, kLenExtra[sym], lane);
+                uint32_t ds = decode_sym(s, br, s.dist_lut, kDistBits, s.dist_sorted, s.dist_count, lane);
+                if (ds > 29) {
+                    err = 3;
+                    break;
+                }
+                uint32_t dist = kDistBase[ds] + getbits(s, br, kDistExtra[ds], lane);
+                if (dist > pos || (unsigned long long)pos + len > cap) {
+                    err = dist > pos ? 3 : 4;
+                    break;
+                }
+                // all lanes copy; the source index is folded into [pos - dist, pos) so overlaps are exact
+                for (uint32_t i = lane; i < len; i += 64) {
+                    uint32_t src = pos - dist + (dist >= len ? i : i % dist);
+                    s.win[(pos + i) & (kWinBytes - 1)] = s.win[src & (kWinBytes - 1)];
+                }
+                uint32_t np = pos + len;
+                if ((np >> 10) != (pos >> 10)) flush_segments(s, d_out, mb.out_off, flushed, np, lane);
+                pos = np;
+            }
+        }
+        // tail: the bytes after the last full segment
+        if (!err) {
+            for (uint32_t i = flushed + lane; i < pos; i += 64) d_out[mb.out_off + i] = s.win[i & (kWinBytes - 1)];
+        }
+        if (lane == 0) {
+            InflateStatus st;
+            st.code = err;
+            st.pad = 0;
+            st.produced = pos;
+            // consumed: bytes fetched minus whole bytes still in the bit buffer, relative to comp_off
+            st.consumed = (unsigned long long)br.ip - (br.bc >> 3) - skip;
+            status[m] = st;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace exg
+
+// ---- C-ABI ----------------------------------------------------------------------------------------------
+// members / status are device arrays of exg_inflate_member / exg_inflate_status (same layout as above).
+extern "C" int exg_inflate_members(const void *d_comp, void *d_out, const exg_inflate_member *d_members,
+                                   exg_inflate_status *d_status, uint32_t n_members, void *stream) {
+    static_assert(sizeof(exg_inflate_member) == sizeof(exg::InflateMember), "layout");
+    static_assert(sizeof(exg_inflate_status) == sizeof(exg::InflateStatus), "layout");
+    if (!n_members) return EXG_OK;
+    if (!d_comp || !d_out || !d_members || !d_status || ((uintptr_t)d_comp & 15)) {
+        exg::set_error("exg_inflate_members: bad arguments (null or unaligned compressed buffer)");
+        return EXG_E_INVALID_ARG;
+    }
+    uint32_t grid = n_members < 4096 ? n_members : 4096;
+    hipLaunchKernelGGL(exg::k_inflate, dim3(grid), dim3(64), 0, (hipStream_t)stream, (const uint8_t *)d_comp,
+                       (uint8_t *)d_out, (const exg::InflateMember *)d_members, (exg::InflateStatus *)d_status, n_members);
+    EXG_HIP_CHECK(hipGetLastError());
+    return EXG_OK;
+}

@@ -218,6 +218,28 @@ int exg_count_newlines(const void *d_input, uint64_t begin, uint64_t end, uint64
  * receives 0..3, or 0xFFFFFFFF when no or several phases fit (caller falls back to counting). */
 int exg_fastq_guess_phase(const void *d_input, uint64_t n_bytes, uint64_t lead, uint32_t *d_phase, void *stream);
 
+/* ---- device inflate (gzip / BGZF members; replaces flate2 behind rust/src/arrow_reader.rs:60-91) ---- */
+typedef struct exg_inflate_member {
+    uint64_t comp_off;  /* offset of the member's DEFLATE stream (after the gzip header) in d_comp */
+    uint64_t comp_size; /* bytes available from comp_off */
+    uint64_t out_off;   /* where its output starts in d_out */
+    uint64_t out_cap;   /* bytes it may produce (ISIZE when known) */
+} exg_inflate_member;
+typedef struct exg_inflate_status {
+    uint32_t code; /* 0 ok, 1 bad block, 2 bad code lengths, 3 bad symbol/distance, 4 output overflow */
+    uint32_t pad;
+    uint64_t produced; /* bytes written at out_off */
+    uint64_t consumed; /* compressed bytes consumed from comp_off (byte aligned after the final block) */
+} exg_inflate_status;
+/* Host: index the gzip members of data[start, n) (RFC 1952 framing).  Members that carry their size (BGZF 'BC'
+ * subfield) are all returned; a member of unknown size is returned last with *open_ended = 1 (inflate it, then
+ * index again from comp_off + consumed + 8).  *total_out is in/out: running sum of the output offsets. */
+int exg_gzip_index(const uint8_t *data, uint64_t n, uint64_t start, exg_inflate_member *members, uint64_t cap,
+                   uint64_t *n_members, uint64_t *total_out, int *open_ended);
+/* One wavefront per member; d_members / d_status are device arrays; d_comp 16-byte aligned. Asynchronous. */
+int exg_inflate_members(const void *d_comp, void *d_out, const exg_inflate_member *d_members,
+                        exg_inflate_status *d_status, uint32_t n_members, void *stream);
+
 /* Deterministic synthetic inputs, generated on the device so the bench
  * needs no PCIe traffic: writes file bytes [file_offset, file_offset+n_bytes) to d_out. */
 #define EXG_SYNTH_FASTQ_SEED 0xE0A5EED0001ull
