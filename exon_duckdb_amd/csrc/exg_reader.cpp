@@ -15,6 +15,7 @@
 #include <dirent.h>
 #include <errno.h>
 #include <fcntl.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -90,6 +91,8 @@ struct exg_reader {
     void *d_pos = nullptr, *d_qual = nullptr, *d_payload = nullptr;
     uint64_t d_in_cap = 0, ws_bytes = 0, cap_records = 0;
     uint64_t vcf_header_bytes = 0;
+    void *d_file = nullptr;  // gzip input: the inflated bytes live here and are scanned in place
+    uint64_t d_file_bytes = 0;
 
     // current batch
     std::shared_ptr<Batch> batch;
@@ -106,6 +109,7 @@ struct exg_reader {
     ~exg_reader() {
         free_device();
         if (d_res) (void)hipFree(d_res);
+        if (d_file) (void)hipFree(d_file);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -147,6 +151,87 @@ int list_files(exg_reader *r, const std::string &path) {
     return EXG_OK;
 }
 
+// gzip input: H2D the compressed bytes, inflate every member on the device (exg_inflate.hip), keep the
+// inflated bytes in HBM for the scan and bring one copy back for the DataChunk payload.
+int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::string &path) {
+    const uint8_t *comp = (const uint8_t *)blk->p;
+    const uint64_t n = blk->n;
+    if (n == 0) return fail(r, EXG_E_PARSE, "empty gzip file '" + path + "'");
+    void *d_comp = nullptr;
+    RD_HIP(r, hipMalloc(&d_comp, n + 64));
+    struct Free {
+        void *p;
+        ~Free() { if (p) (void)hipFree(p); }
+    } free_comp{d_comp};
+    RD_HIP(r, hipMemcpyAsync(d_comp, comp, n, hipMemcpyHostToDevice, r->stream));
+    std::vector<exg_inflate_member> members(std::max<uint64_t>(16, n / 18 + 4));
+    uint64_t out_cap_total = 0, produced_total = 0;
+    void *d_out = nullptr;
+    uint64_t d_out_cap = 0;
+    uint64_t start = 0;
+    while (start < n) {
+        uint64_t k = 0, total = produced_total;
+        int open_ended = 0;
+        int rc = exg_gzip_index(comp, n, start, members.data(), members.size(), &k, &total, &open_ended);
+        if (rc) return fail(r, rc, std::string(exg_last_error_message()) + " in '" + path + "'");
+        if (k == 0) break;
+        out_cap_total = total;
+        if (out_cap_total + 64 > d_out_cap) {  // grow the output (members of earlier rounds are kept)
+            void *nd = nullptr;
+            uint64_t ncap = out_cap_total + 64;
+            RD_HIP(r, hipMalloc(&nd, ncap));
+            if (d_out) {
+                RD_HIP(r, hipMemcpyAsync(nd, d_out, produced_total, hipMemcpyDeviceToDevice, r->stream));
+                RD_HIP(r, hipStreamSynchronize(r->stream));
+                (void)hipFree(d_out);
+            }
+            d_out = nd;
+            d_out_cap = ncap;
+        }
+        void *d_members = nullptr, *d_status = nullptr;
+        RD_HIP(r, hipMalloc(&d_members, k * sizeof(exg_inflate_member)));
+        RD_HIP(r, hipMalloc(&d_status, k * sizeof(exg_inflate_status)));
+        Free fm{d_members}, fs{d_status};
+        RD_HIP(r, hipMemcpyAsync(d_members, members.data(), k * sizeof(exg_inflate_member), hipMemcpyHostToDevice, r->stream));
+        rc = exg_inflate_members(d_comp, d_out, (const exg_inflate_member *)d_members, (exg_inflate_status *)d_status,
+                                 (uint32_t)k, r->stream);
+        if (rc) return fail(r, rc, exg_last_error_message());
+        std::vector<exg_inflate_status> st(k);
+        RD_HIP(r, hipMemcpyAsync(st.data(), d_status, k * sizeof(exg_inflate_status), hipMemcpyDeviceToHost, r->stream));
+        RD_HIP(r, hipStreamSynchronize(r->stream));
+        for (uint64_t i = 0; i < k; i++) {
+            const bool sized = !(open_ended && i + 1 == k);
+            if (st[i].code || (sized && st[i].produced != members[i].out_cap)) {
+                if (d_out) (void)hipFree(d_out);
+                return fail(r, EXG_E_PARSE, "corrupt deflate stream (member " + std::to_string(i) + ", code " +
+                                                std::to_string(st[i].code) + ") in '" + path + "'");
+            }
+        }
+        if (open_ended) {
+            // the last member ran to its own end: compact its output, continue after its 8-byte trailer
+            const exg_inflate_member &m = members[k - 1];
+            produced_total = m.out_off + st[k - 1].produced;
+            start = m.comp_off + st[k - 1].consumed + 8;
+        } else {
+            produced_total = out_cap_total;
+            start = n;
+        }
+    }
+    // host copy of the inflated bytes: this is what the string_t payload pointers address
+    auto out_blk = std::make_shared<PinnedBlock>();
+    out_blk->n = produced_total;
+    hipError_t he = hipHostMalloc(&out_blk->p, produced_total + 64, hipHostMallocDefault);
+    if (he != hipSuccess) return fail(r, EXG_E_HIP, std::string("hipHostMalloc failed: ") + hipGetErrorString(he));
+    if (produced_total) RD_HIP(r, hipMemcpyAsync(out_blk->p, d_out, produced_total, hipMemcpyDeviceToHost, r->stream));
+    if (d_out) RD_HIP(r, hipMemsetAsync((char *)d_out + produced_total, 0, 64, r->stream));
+    RD_HIP(r, hipStreamSynchronize(r->stream));
+    memset((char *)out_blk->p + produced_total, 0, 64);
+    blk = out_blk;
+    r->d_file = d_out;
+    r->d_file_bytes = produced_total;
+    return EXG_OK;
+}
+
 int open_next_file(exg_reader *r) {
     const std::string &p = r->files[r->file_idx++];
     int fd = open(p.c_str(), O_RDONLY);
@@ -169,6 +254,11 @@ int open_next_file(exg_reader *r) {
     close(fd);
     if (got != blk->n) return fail(r, EXG_E_IO, "short read on '" + p + "'");
     memset((char *)blk->p + blk->n, 0, 64);
+    if (r->d_file) (void)hipFree(r->d_file), r->d_file = nullptr;
+    if (r->compression == kGzip) {
+        int rc = inflate_file(r, blk, p);  // replaces blk by the inflated bytes (host copy) and sets d_file
+        if (rc) return rc;
+    }
     r->file = blk;
     r->file_pos = 0;
     r->file_done = false;
@@ -230,18 +320,31 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         }
         uint64_t n = std::min<uint64_t>(want, remaining);
         const bool eof = n == remaining;
-        int rc = ensure_device(r, n);
+        int rc = ensure_device(r, n + 16);
         if (rc) return rc;
+        // Input of the scan: an H2D copy of the batch, or — gzip — the inflated bytes already in HBM.
+        // In place the batch start is only byte aligned: the buffer starts at the 16-byte boundary below
+        // it and `lead` skips the tail of the previous record (whose last '\n' is then inside the buffer).
         const uint8_t *h = (const uint8_t *)r->file->p + r->file_pos;
-        RD_HIP(r, hipMemcpyAsync(r->d_in, h, (n + 15) / 16 * 16, hipMemcpyHostToDevice, r->stream));
+        const void *d_input = r->d_in;
+        uint64_t lead = 0;
+        if (r->d_file) {
+            lead = r->file_pos & 15;
+            d_input = (const uint8_t *)r->d_file + (r->file_pos - lead);
+            h -= lead;
+            n += lead;
+        } else {
+            RD_HIP(r, hipMemcpyAsync(r->d_in, h, (n + 15) / 16 * 16, hipMemcpyHostToDevice, r->stream));
+        }
         exg_scan_result res;
-        const uint32_t fl = EXG_F_BOF | (eof ? EXG_F_EOF : 0u) | (count_only ? EXG_F_NO_STORE : 0u);
+        const uint32_t fl = (lead ? 0u : EXG_F_BOF) | (eof ? EXG_F_EOF : 0u) | (count_only ? EXG_F_NO_STORE : 0u);
         std::shared_ptr<Batch> b;
         if (r->format == EXG_FMT_FASTQ) {
             exg_fastq_scan_args a;
             memset(&a, 0, sizeof a);
-            a.d_input = r->d_in;
+            a.d_input = d_input;
             a.n_bytes = n;
+            a.lead = lead;
             a.payload_base = (uint64_t)(uintptr_t)h;
             a.flags = fl;
             a.algo = EXG_ALGO_AUTO;
@@ -259,8 +362,9 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         } else if (r->format == EXG_FMT_VCF) {
             exg_vcf_scan_args a;
             memset(&a, 0, sizeof a);
-            a.d_input = r->d_in;
+            a.d_input = d_input;
             a.n_bytes = n;
+            a.lead = lead;
             a.payload_base = (uint64_t)(uintptr_t)h;
             a.flags = fl;
             a.algo = EXG_ALGO_AUTO;
@@ -287,7 +391,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             }
             exg_fasta_scan_args a;
             memset(&a, 0, sizeof a);
-            a.d_input = r->d_in;
+            a.d_input = d_input;
             a.n_bytes = n;
             a.payload_base = (uint64_t)(uintptr_t)h;
             a.seq_payload_base = (uint64_t)(uintptr_t)b->payload.p;
@@ -315,7 +419,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         }
         if (res.error_code) {
             r->pending_error = res.error_code;
-            r->pending_error_offset = r->file_pos + res.error_offset;
+            r->pending_error_offset = r->file_pos - lead + res.error_offset;
         }
         const uint64_t k = res.n_records;
         *n_records_out = k;
@@ -356,7 +460,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         if (res.error_code || eof)
             r->file_done = true;
         else
-            r->file_pos += res.consumed_bytes;
+            r->file_pos += res.consumed_bytes - lead;
         return EXG_OK;
     }
 }
@@ -398,11 +502,13 @@ extern "C" int exg_open(const exg_open_args *args, exg_reader **out) {
         return EXG_E_INVALID_ARG;
     }
     if (args->device_batch_bytes) r->device_batch_bytes = (args->device_batch_bytes + 15) / 16 * 16;
+    else if (const char *e = getenv("EXG_DEVICE_BATCH_BYTES"))  // tuning / test knob
+        r->device_batch_bytes = std::max<uint64_t>(4096, (strtoull(e, nullptr, 10) + 15) / 16 * 16);
     r->device = args->device;
     int rc = list_files(r.get(), path);
     if (rc) return rc;
-    if (r->compression != kNone) {
-        exg::set_error("compressed input is not supported yet: there is no device inflate and no CPU fallback");
+    if (r->compression != kNone && r->compression != kGzip) {
+        exg::set_error("compression is not supported: only gzip has a device decoder, and there is no CPU fallback");
         return EXG_E_UNSUPPORTED;
     }
     if (exg_device_count() < 1) return EXG_E_NO_DEVICE;

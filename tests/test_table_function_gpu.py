@@ -60,10 +60,20 @@ def test_fastq_directory(con, golden_dir):
     assert names == [(b"SEQ_ID",), (b"SEQ_ID2",)] * 2
 
 
-@pytest.mark.parametrize("name,compression", [("test.fastq.gz", None), ("test.fastq.gzip", "gzip"),
-                                              ("test.fastq.zst", None), ("test.fastq.zstd", "zstd")])
-def test_fastq_compressed_fails_loudly(con, golden_dir, name, compression):
-    # (:11-32) need a device inflate; until it exists the statement must error, never fall back to a CPU
+@pytest.mark.parametrize("name,compression", [("test.fastq.gz", None), ("test.fastq.gzip", "gzip")])
+def test_fastq_gzip(con, golden_dir, name, compression):
+    # SELECT count(*) FROM read_fastq('…/test.fastq.gz'); / ('…/test.fastq.gzip', compression='gzip')  -> 2   (:11-20)
+    rel = con.table_function("read_fastq", G(golden_dir, name), compression=compression)
+    assert rel.count() == 2
+    # this fixture inflates to a different file than test.fastq: record 1 has no description
+    assert rel.fetchall(columns=["name", "description"]) == [(b"SEQ_ID", None), (b"SEQ_ID2", None)]
+    if compression is None:
+        assert con.from_path(G(golden_dir, name)).count() == 2                                           # (:50-53)
+
+
+@pytest.mark.parametrize("name,compression", [("test.fastq.zst", None), ("test.fastq.zstd", "zstd")])
+def test_fastq_zstd_fails_loudly(con, golden_dir, name, compression):
+    # (:23-32) zstd has no device decoder: the statement must error, never fall back to a CPU
     from exon_duckdb_amd import ExgError
     with pytest.raises(ExgError, match="not supported"):
         con.table_function("read_fastq", G(golden_dir, name), compression=compression).count()
@@ -96,12 +106,22 @@ def test_fasta_empty_path_is_an_error(con):
         con.table_function("read_fasta", "")                                                  # (:51-53)
 
 
-def test_fasta_compressed_fails_loudly(con, golden_dir):
+def test_fasta_gzip(con, golden_dir):
+    assert con.table_function("read_fasta", G(golden_dir, "test.fasta.gzip"), compression="gzip").count() == 2   # (:11-14)
+    assert con.table_function("read_fasta", G(golden_dir, "test.fasta.gz")).count() == 2                          # (:17-20)
+    assert con.from_path(G(golden_dir, "test.fasta.gz")).count() == 2                                             # (:40-43)
+    # SELECT COUNT(*) FROM read_fasta('…/fasta/', compression='gzip');  -> 4                                      (:55-59)
+    rel = con.table_function("read_fasta", G(golden_dir, "fasta") + "/", compression="gzip")
+    assert rel.count() == 4
+    assert rel.fetchall() == [(b"a", b"description", b"ATCG"), (b"b", b"description2", b"ATCG")] * 2
+
+
+def test_fasta_zstd_fails_loudly(con, golden_dir):
     from exon_duckdb_amd import ExgError
     with pytest.raises(ExgError, match="not supported"):
-        con.table_function("read_fasta", G(golden_dir, "test.fasta.gz")).count()              # (:17-20)
+        con.table_function("read_fasta", G(golden_dir, "test.fasta.zst")).count()              # (:46-49)
     with pytest.raises(ExgError, match="not supported"):
-        con.table_function("read_fasta", G(golden_dir, "fasta") + "/", compression="gzip").count()   # (:55-59)
+        con.table_function("read_fasta", G(golden_dir, "test.fasta.zstd"), compression="zstd").count()   # (:22-26)
 
 
 # ---- test_vcf_record_scan.test ---------------------------------------------------------------------------
@@ -121,6 +141,16 @@ def test_vcf_row0(con, golden_dir):
     assert (chrom, pos, ref, alt.split(b","), qual) == (b"1", 9999919, b"G", [b"<*>"], 0.0)
     kv = dict(x.split(b"=", 1) if b"=" in x else (x, None) for x in info.split(b";"))
     assert b"INDEL" not in kv and int(kv[b"DP"]) == 1       # info.indel IS NULL, info.dp = 1
+
+
+def test_vcf_bgzf(con, golden_dir):
+    # same statements on '…/vcf/index.vcf.gz' (BGZF = multi-member gzip)                         (:32-41)
+    rel = con.table_function("read_vcf_file_records", G(golden_dir, "vcf/index.vcf.gz"))
+    assert rel.count() == 621
+    chrom, pos, ref, alt, qual = rel.fetchall(columns=["chrom", "pos", "ref", "alt", "qual"], limit=1)[0]
+    assert (chrom, pos, ref, alt, qual) == (b"1", 9999919, b"G", b"<*>", 0.0)
+    plain = con.table_function("read_vcf_file_records", G(golden_dir, "vcf/index.vcf")).fetchall()
+    assert rel.fetchall() == plain
 
 
 def test_vcf_nulls(con, golden_dir):
@@ -161,3 +191,52 @@ def test_streaming_batches_match_one_batch(con, oracle, tmp_path, monkeypatch):
     assert len(rows) == 3000
     for i in (0, 1, 2999):
         assert rows[i] == tuple(exp.columns[k].row(i) for k in exp.columns)
+
+
+def test_gzip_streams_through_several_batches(con, oracle, tmp_path, monkeypatch):
+    # BGZF-framed and plain single-member gzip of the same FASTQ, scanned in place on the device in
+    # record-aligned batches (batch starts are only byte aligned there)
+    import gzip
+    import struct
+    import zlib
+
+    data = bytes(oracle.synth_fastq_ragged(6000))
+    exp = oracle.fastq_parse(data)
+    blocks = []
+    for i in range(0, len(data), 65280):
+        chunk = data[i:i + 65280]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        raw = co.compress(chunk) + co.flush()
+        blocks.append(b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\0\xff" + struct.pack("<H", 6) + b"BC" +
+                      struct.pack("<HH", 2, 12 + 6 + len(raw) + 8 - 1) + raw + struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+    (tmp_path / "bgzf.fastq.gz").write_bytes(b"".join(blocks))
+    (tmp_path / "plain.fastq.gz").write_bytes(gzip.compress(data, mtime=0))
+    (tmp_path / "two_members.fastq.gz").write_bytes(gzip.compress(data[:len(data) // 2 + 7], mtime=0) +
+                                                    gzip.compress(data[len(data) // 2 + 7:], mtime=0))
+    (tmp_path / "plain.fastq").write_bytes(data)
+    want = [tuple(exp.columns[k].row(i) for k in exp.columns) for i in range(exp.n_rows)]
+    for batch in (None, "65536", "4096"):
+        if batch:
+            monkeypatch.setenv("EXG_DEVICE_BATCH_BYTES", batch)
+        for name in ["bgzf.fastq.gz", "plain.fastq.gz", "two_members.fastq.gz", "plain.fastq"]:
+            rel = con.table_function("read_fastq", str(tmp_path / name))
+            assert rel.count() == 6000, (name, batch)
+            assert rel.fetchall() == want, (name, batch)
+
+
+def test_vcf_streams_through_several_batches(con, oracle, tmp_path, monkeypatch):
+    import gzip
+    data = bytes(oracle.synth_vcf(5000))
+    exp = oracle.vcf_parse(data)
+    (tmp_path / "v.vcf").write_bytes(data)
+    (tmp_path / "v.vcf.gz").write_bytes(gzip.compress(data, mtime=0))
+    want_pos = exp.extra["pos"].tolist()
+    for batch in (None, "32768"):
+        if batch:
+            monkeypatch.setenv("EXG_DEVICE_BATCH_BYTES", batch)
+        for name in ["v.vcf", "v.vcf.gz"]:
+            rel = con.table_function("read_vcf", str(tmp_path / name))
+            assert rel.count() == 5000
+            rows = rel.fetchall(columns=["chrom", "pos", "info"])
+            assert [r[1] for r in rows] == want_pos
+            assert rows[4999][2] == exp.columns["info"].row(4999)
