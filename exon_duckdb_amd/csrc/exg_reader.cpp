@@ -17,24 +17,32 @@
 #include <fcntl.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "exg_common.hpp"
 
 namespace {
 
-struct PinnedBlock {
+struct PinnedBlock {  // host memory: pinned (hipHostMalloc) or a read-only file mapping
     void *p = nullptr;
     size_t n = 0;
+    size_t mapped = 0;  // != 0: p is an mmap of that many bytes
     ~PinnedBlock() {
-        if (p) (void)hipHostFree(p);
+        if (!p) return;
+        if (mapped)
+            munmap(p, mapped);
+        else
+            (void)hipHostFree(p);
     }
 };
 
@@ -91,6 +99,12 @@ struct exg_reader {
     void *d_pos = nullptr, *d_qual = nullptr, *d_payload = nullptr;
     uint64_t d_in_cap = 0, ws_bytes = 0, cap_records = 0;
     uint64_t vcf_header_bytes = 0;
+    struct FdCloser {
+        int fd;
+        ~FdCloser() { if (fd >= 0) close(fd); }
+    };
+    std::unique_ptr<FdCloser> fd_keep;  // current file (pread source of the bounce buffer)
+    PinnedBlock staging;     // pinned bounce buffer for H2D (the file itself is only mapped)
     void *d_file = nullptr;  // gzip input: the inflated bytes live here and are scanned in place
     uint64_t d_file_bytes = 0;
 
@@ -232,28 +246,51 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
     return EXG_OK;
 }
 
+static double now_s() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+static bool trace_on() {
+    static int on = getenv("EXG_TRACE") ? 1 : 0;
+    return on;
+}
+#define TRACE(label, t0)                                                            \
+    do {                                                                            \
+        if (trace_on()) fprintf(stderr, "[exg] %-22s %.1f ms\n", label, (now_s() - (t0)) * 1e3); \
+    } while (0)
+
 int open_next_file(exg_reader *r) {
     const std::string &p = r->files[r->file_idx++];
+    double t_all = now_s();
     int fd = open(p.c_str(), O_RDONLY);
     if (fd < 0) return fail(r, EXG_E_IO, "cannot open '" + p + "': " + strerror(errno));
     struct stat st;
     fstat(fd, &st);
+    // The file is mapped, not copied: DataChunk strings point straight into the page cache mapping
+    // (kept alive by the chunks); bytes travel to the device through a pinned bounce buffer.
     auto blk = std::make_shared<PinnedBlock>();
     blk->n = (size_t)st.st_size;
-    hipError_t he = hipHostMalloc(&blk->p, blk->n + 64, hipHostMallocDefault);
-    if (he != hipSuccess) {
-        close(fd);
-        return fail(r, EXG_E_HIP, std::string("hipHostMalloc failed: ") + hipGetErrorString(he));
+    double t0 = now_s();
+    if (blk->n) {
+        void *m = mmap(nullptr, blk->n, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) {
+            close(fd);
+            return fail(r, EXG_E_IO, "cannot map '" + p + "': " + strerror(errno));
+        }
+        blk->p = m;
+        blk->mapped = blk->n;
+    } else {
+        hipError_t he = hipHostMalloc(&blk->p, 64, hipHostMallocDefault);
+        if (he != hipSuccess) {
+            close(fd);
+            return fail(r, EXG_E_HIP, std::string("hipHostMalloc failed: ") + hipGetErrorString(he));
+        }
+        memset(blk->p, 0, 64);
     }
-    size_t got = 0;
-    while (got < blk->n) {
-        ssize_t k = read(fd, (char *)blk->p + got, blk->n - got);
-        if (k <= 0) break;
-        got += (size_t)k;
-    }
-    close(fd);
-    if (got != blk->n) return fail(r, EXG_E_IO, "short read on '" + p + "'");
-    memset((char *)blk->p + blk->n, 0, 64);
+    r->fd_keep.reset(new exg_reader::FdCloser{fd});
+    TRACE("mmap(file)", t0);
+    (void)t_all;
     if (r->d_file) (void)hipFree(r->d_file), r->d_file = nullptr;
     if (r->compression == kGzip) {
         int rc = inflate_file(r, blk, p);  // replaces blk by the inflated bytes (host copy) and sets d_file
@@ -305,6 +342,50 @@ int ensure_device(exg_reader *r, uint64_t need_bytes) {
     return EXG_OK;
 }
 
+// file bytes [off, off + n) -> pinned bounce buffer (parallel pread) -> d_in
+int stage_and_upload(exg_reader *r, uint64_t off, uint64_t n) {
+    const uint64_t padded = (n + 15) / 16 * 16;
+    if (r->staging.n < padded) {
+        RD_HIP(r, hipStreamSynchronize(r->stream));
+        if (r->staging.p) (void)hipHostFree(r->staging.p), r->staging.p = nullptr;
+        double t0 = now_s();
+        RD_HIP(r, hipHostMalloc(&r->staging.p, padded + 64, hipHostMallocDefault));
+        r->staging.n = padded;
+        TRACE("hipHostMalloc(staging)", t0);
+    }
+    RD_HIP(r, hipStreamSynchronize(r->stream));  // the previous H2D out of this buffer is done
+    double t0 = now_s();
+    const size_t slice = 16u << 20;
+    const size_t n_slices = (n + slice - 1) / slice;
+    unsigned nt = (unsigned)std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), std::min<size_t>(n_slices, 16));
+    std::atomic<size_t> next{0};
+    std::atomic<bool> ok{true};
+    const int fd = r->fd_keep->fd;
+    char *dst = (char *)r->staging.p;
+    auto work = [&]() {
+        for (size_t i = next.fetch_add(1); i < n_slices; i = next.fetch_add(1)) {
+            size_t o = i * slice, len = std::min<size_t>(slice, n - o), got = 0;
+            while (got < len) {
+                ssize_t k = pread(fd, dst + o + got, len - got, (off_t)(off + o + got));
+                if (k <= 0) {
+                    ok = false;
+                    return;
+                }
+                got += (size_t)k;
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    if (!ok) return fail(r, EXG_E_IO, "short read");
+    memset(dst + n, 0, padded - n);
+    TRACE("pread(batch)", t0);
+    RD_HIP(r, hipMemcpyAsync(r->d_in, dst, padded, hipMemcpyHostToDevice, r->stream));
+    return EXG_OK;
+}
+
 // Scan the next device batch of the current file.  On return r->batch holds its host vectors
 // (n_rows may be 0 when the file is exhausted).  count_only: no column leaves the device.
 int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
@@ -312,6 +393,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
     r->batch.reset();
     r->batch_row = 0;
     uint64_t want = r->device_batch_bytes;
+    double t_batch = now_s();
     for (;;) {
         const uint64_t remaining = r->file->n - r->file_pos;
         if (remaining == 0) {
@@ -334,7 +416,8 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             h -= lead;
             n += lead;
         } else {
-            RD_HIP(r, hipMemcpyAsync(r->d_in, h, (n + 15) / 16 * 16, hipMemcpyHostToDevice, r->stream));
+            int rc2 = stage_and_upload(r, r->file_pos, n);
+            if (rc2) return rc2;
         }
         exg_scan_result res;
         const uint32_t fl = (lead ? 0u : EXG_F_BOF) | (eof ? EXG_F_EOF : 0u) | (count_only ? EXG_F_NO_STORE : 0u);
@@ -461,6 +544,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             r->file_done = true;
         else
             r->file_pos += res.consumed_bytes - lead;
+        TRACE("batch (h2d+scan+d2h)", t_batch);
         return EXG_OK;
     }
 }
