@@ -46,7 +46,8 @@ struct FastqFormat;
 
 
 // Records that END in the half staged in LDS: wave = column, lane = record.
-__device__ __forceinline__ void fastq_emit_half(const FusedLds &s, const FastqDev &a, ScanWsHeader *hdr, const TileCtx &c,
+template <class L>
+__device__ __forceinline__ void fastq_emit_half(const L &s, const FastqDev &a, ScanWsHeader *hdr, const TileCtx &c,
                                           unsigned long long halo_nl, uint32_t dev_mode, uint32_t lane,
                                           uint32_t wave, unsigned long long *__restrict__ tile_qend,
                                           uint64_t tile_index) {
@@ -178,12 +179,14 @@ __device__ __forceinline__ void fastq_emit_half(const FusedLds &s, const FastqDe
 
 struct FastqFormat {
     using Dev = FastqDev;
+    static constexpr int kNlCap = 512;          // 197 lines per half for 150 bp reads; LDS 22.7 KB -> 7 per CU
     static constexpr int kMinWavesPerSimd = 7;  // 71 VGPRs, no scratch: 7 x 32 KiB in flight per CU
     // noodles-fastq at EOF: a record that has its '+' line but no quality line gets an empty one
     __device__ static __forceinline__ uint32_t eof_extra_lines(unsigned long long total_lines) {
         return (total_lines & 3) == 3 ? 1u : 0u;
     }
-    __device__ static __forceinline__ void emit_half(const FusedLds &s, const FastqDev &a, ScanWsHeader *hdr,
+    template <class L>
+    __device__ static __forceinline__ void emit_half(const L &s, const FastqDev &a, ScanWsHeader *hdr,
                                                      const TileCtx &c, unsigned long long halo_nl, uint32_t dev_mode,
                                                      uint32_t lane, uint32_t wave,
                                                      unsigned long long *__restrict__ tile_qend, uint64_t tile_index) {
@@ -282,8 +285,9 @@ int run_fastq_fused(const exg_fastq_scan_args *args, const FastqDev &dev, uint8_
     }
     uint32_t n_super = (uint32_t)n_super64;
     // descriptor block: tileA[n_tiles_fused], tileP[n_tiles_fused], tile_qend[n_tiles_fused]
-    unsigned long long *tileA = reinterpret_cast<unsigned long long *>(ws + l.off_tile_desc);
-    unsigned long long *tileP = tileA + l.n_tiles_fused;
+    // descriptor block: u32 tileA[n] (padded to n u64), u64 tileP[n], u64 tile_qend[n]
+    unsigned int *tileA = reinterpret_cast<unsigned int *>(ws + l.off_tile_desc);
+    unsigned long long *tileP = reinterpret_cast<unsigned long long *>(ws + l.off_tile_desc) + l.n_tiles_fused;
     unsigned long long *tile_qend = tileP + l.n_tiles_fused;
     hipLaunchKernelGGL(k_init_hdr, dim3(1), dim3(1), 0, stream, hdr, l.lines_cap, 0u);
     EXG_HIP_CHECK(hipMemsetAsync(tileA, 0, (size_t)l.n_tiles_fused * 16, stream));

@@ -13,6 +13,7 @@
 //   F::eof_extra_lines(line_index_total)  extra virtual (empty) lines at EOF besides the unterminated one
 //   F::emit_half(...)                     records ending in the staged half
 //   F::analytic_prefix(offset)            dev-only ablation hook
+//   F::kNlCap                             newline positions kept per half (LDS)
 //   F::kMinWavesPerSimd                   occupancy the register allocator must respect (7 = 7 workgroups/CU)
 #pragma once
 #include "exg_fastq_ws.hpp"
@@ -27,15 +28,18 @@ static constexpr int kWin = kFusedWindow;       // 1024
 static constexpr int kThreads = 256;
 static constexpr int kRows = kTile / (kThreads * 16);  // 4 chunk rows (4 KiB each) per half
 static constexpr int kLdsBytes = kWin + kTile + 96;
-static constexpr int kNlCap = 1024;  // newline positions kept per half
 static constexpr uint32_t kNoneE = 0xFFFFu;
 
 static constexpr unsigned long long kFlag = 1ull << 63;  // descriptor word is published
 static constexpr unsigned long long kVal = (1ull << 48) - 1;
 
-struct FusedLds {
+// NL = newline positions kept per half (a half with more lines goes to the general path)
+template <int NL>
+struct FusedLdsT {
+    static constexpr int kNlCap = NL;
     uint8_t bytes[kLdsBytes];        // [0,kWin) window, then the half; e = p + kWin
-    uint16_t nlist[4 + kNlCap + 4];  // e-offsets of newlines: [0..3] the 4 before the half (oldest first)
+    uint16_t nlist[4 + NL + 4];  // e-offsets of newlines: [0..3] the 4 before the half (oldest first)
+    uint16_t bitmap[kHalves][kTile / 16];  // '\n' mask of every 16-byte chunk, written by the first pass
     uint32_t wtot[4];   // per-wave newline counts of the staged half
     uint32_t wcnt[4];   // per-wave packed (half 0 | half 1 << 16) newline counts
     unsigned long long prefix;            // '\n' in the buffer before this super-tile
@@ -43,19 +47,23 @@ struct FusedLds {
     uint16_t carry[4];  // the 4 newlines before the second half, relative to it
 };
 
-__device__ __forceinline__ uint32_t ldw(const FusedLds &s, uint32_t e_aligned) {
+template <class L>
+__device__ __forceinline__ uint32_t ldw(const L &s, uint32_t e_aligned) {
     return *reinterpret_cast<const uint32_t *>(s.bytes + e_aligned);
 }
-__device__ __forceinline__ uint32_t ldb(const FusedLds &s, int e) { return s.bytes[e]; }
+template <class L>
+__device__ __forceinline__ uint32_t ldb(const L &s, int e) { return s.bytes[e]; }
 // 4 bytes at extended offset e (any alignment)
-__device__ __forceinline__ uint32_t ldu32(const FusedLds &s, int e) {
+template <class L>
+__device__ __forceinline__ uint32_t ldu32(const L &s, int e) {
     uint32_t a = (uint32_t)e & ~3u;
     uint32_t lo = ldw(s, a), hi = ldw(s, a + 4);
     return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)e & 3u);
 }
 
 // duckdb::string_t of the field [e, e+len); ptr_of_e0 = payload pointer of extended offset 0
-__device__ __forceinline__ uint4 make_string_lds(const FusedLds &s, int e, uint32_t len, uint64_t ptr_of_e0) {
+template <class L>
+__device__ __forceinline__ uint4 make_string_lds(const L &s, int e, uint32_t len, uint64_t ptr_of_e0) {
     uint4 r;
     r.x = len;
     uint32_t w0 = ldu32(s, e);
@@ -104,29 +112,30 @@ __device__ __forceinline__ void st_desc(unsigned long long *p, unsigned long lon
 }
 
 // ---- ordered prefix: central scanner --------------------------------------------------------------
-static constexpr int kScanBatches = 8;  // 512 descriptors per scanner probe
+static constexpr int kScanBatches = 8;  // 1024 descriptors per scanner probe (32-bit count words keep this in registers)
+static constexpr uint32_t kFlagA = 1u << 31;
 
 __device__ void scanner_wave(const uint8_t *__restrict__ d_in, uint64_t n_bytes,
-                             const unsigned long long *__restrict__ tileA, unsigned long long *__restrict__ tileP,
+                             const unsigned int *__restrict__ tileA, unsigned long long *__restrict__ tileP,
                              uint32_t n_super, uint32_t lane) {
     __builtin_amdgcn_s_setprio(3);
     uint64_t next = 0;
     unsigned long long running = 0;
     unsigned long long t_last = __builtin_amdgcn_s_memrealtime();  // 100 MHz
     while (next < n_super) {
-        unsigned long long d[kScanBatches];
+        unsigned int d[kScanBatches];
 #pragma unroll
         for (int k = 0; k < kScanBatches; k++) {
             uint64_t idx = next + (uint64_t)k * 64 + lane;
-            d[k] = idx < n_super ? ld_desc(&tileA[idx]) : 0ull;
+            d[k] = idx < n_super ? __hip_atomic_load(&tileA[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         }
         bool progressed = false;
 #pragma unroll
         for (int k = 0; k < kScanBatches; k++) {
-            unsigned long long rdy = __ballot((d[k] & kFlag) != 0);
+            unsigned long long rdy = __ballot((d[k] & kFlagA) != 0);
             int r = rdy == ~0ull ? 64 : __ffsll((long long)~rdy) - 1;  // leading run of published counts
             if (r > 0) {
-                uint32_t c = (int)lane < r ? (uint32_t)(d[k] & kVal) : 0u;
+                uint32_t c = (int)lane < r ? (d[k] & ~kFlagA) : 0u;
                 uint32_t inc = wave_incl_sum(c);
                 if ((int)lane < r) st_desc(&tileP[next + lane], kFlag | (running + inc - c));
                 running += __shfl(inc, 63, 64);
@@ -153,7 +162,7 @@ __device__ void scanner_wave(const uint8_t *__restrict__ d_in, uint64_t n_bytes,
 
 // Workgroup side (wave 0): wait for the exclusive prefix of super-tile st (its count is published).
 __device__ unsigned long long wait_prefix(const uint8_t *__restrict__ d_in, uint64_t n_bytes,
-                                          unsigned long long *__restrict__ tileA,
+                                          unsigned int *__restrict__ tileA,
                                           unsigned long long *__restrict__ tileP, uint32_t st, uint32_t lane) {
     if (st == 0) return 0;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -168,7 +177,11 @@ __device__ unsigned long long wait_prefix(const uint8_t *__restrict__ d_in, uint
     unsigned long long sum = 0;
     for (uint64_t b = 0; b < st; b += 64) {
         uint64_t idx = b + lane;
-        unsigned long long x = idx < st ? ld_desc(&tileA[idx]) : kFlag;
+        unsigned long long x = kFlag;
+        if (idx < st) {
+            unsigned int a32 = __hip_atomic_load(&tileA[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            x = (a32 & kFlagA) ? (kFlag | (a32 & ~kFlagA)) : 0ull;
+        }
         unsigned long long miss = __ballot((x & kFlag) == 0);
         while (miss) {
             int l = __ffsll((long long)miss) - 1;
@@ -193,10 +206,12 @@ struct TileCtx {  // what emission needs besides the LDS contents (all workgroup
 };
 
 template <class F>
-__global__ __launch_bounds__(kThreads, F::kMinWavesPerSimd) void k_fused(typename F::Dev a, unsigned long long *__restrict__ tileA,
+__global__ __launch_bounds__(kThreads, F::kMinWavesPerSimd) void k_fused(typename F::Dev a, unsigned int *__restrict__ tileA,
                                                              unsigned long long *__restrict__ tileP,
                                                              unsigned long long *__restrict__ tile_qend,
                                                              ScanWsHeader *hdr, uint32_t n_super) {
+    using FusedLds = FusedLdsT<F::kNlCap>;
+    constexpr int kNlCap = F::kNlCap;
     __shared__ __attribute__((aligned(16))) FusedLds s;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63, wave = tid >> 6;
@@ -218,49 +233,36 @@ __global__ __launch_bounds__(kThreads, F::kMinWavesPerSimd) void k_fused(typenam
 
     // ---- loads: 8 strided 16 B chunks per thread, all in flight at once (+ window by wave 3) ------
     uint4 v[kHalves * kRows];
+    if (lim_s == kSuper) {
+        const uint8_t *mine = d_in + super_off + (uint64_t)tid * 16;
 #pragma unroll
-    for (int j = 0; j < kHalves * kRows; j++) {
-        uint64_t off = super_off + (uint64_t)(j * kThreads + tid) * 16;
-        v[j] = off < n_pad ? *reinterpret_cast<const uint4 *>(d_in + off) : make_uint4(0, 0, 0, 0);
+        for (int j = 0; j < kHalves * kRows; j++) v[j] = *reinterpret_cast<const uint4 *>(mine + j * (kThreads * 16));
+    } else {
+#pragma unroll
+        for (int j = 0; j < kHalves * kRows; j++) {
+            uint64_t off = super_off + (uint64_t)(j * kThreads + tid) * 16;
+            v[j] = off < n_pad ? *reinterpret_cast<const uint4 *>(d_in + off) : make_uint4(0, 0, 0, 0);
+        }
     }
     uint4 wv = make_uint4(0, 0, 0, 0);
     const int64_t woff = (int64_t)super_off - kWin + (int64_t)lane * 16;  // wave 3 only
     if (wave == 3 && woff >= 0) wv = *reinterpret_cast<const uint4 *>(d_in + woff);
 
-    // ---- count in registers (all that is needed to publish) ----------------------------------------
-    // zero-byte SWAR without compaction: z has bit 7 of a byte clear iff the byte matched, every
-    // other bit set, so matches in a dword = 32 - popcount(z): 5 VALU ops per dword.
+    // ---- classify ONCE, in registers: 16-bit '\n' mask per chunk -> LDS bitmap; count for the publish ----
+    // (the kernel is instruction-issue bound: classifying again when a half is staged cost 20 % more VALU)
     uint32_t hi = 0, cnt = 0;
-    if (lim_s == kSuper) {
-        uint32_t z0 = 0, z1 = 0;  // popcount accumulators (half 0, half 1)
 #pragma unroll
-        for (int j = 0; j < kHalves * kRows; j++) {
-            const uint32_t w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
-            hi |= (w[0] | w[1] | w[2] | w[3]);
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                uint32_t x = w[q] ^ 0x0A0A0A0Au;
-                uint32_t y = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
-                uint32_t z = y | x | 0x7F7F7F7Fu;
-                if (j < kRows)
-                    z0 += __popc(z);
-                else
-                    z1 += __popc(z);
-            }
-        }
-        hi &= 0x80808080u;
-        cnt = (kRows * 4 * 32 - z0) | ((kRows * 4 * 32 - z1) << 16);  // half 0 low 16 bits, half 1 high
-    } else {
-        // the input ends inside this super-tile: mask the bytes past the end
-#pragma unroll
-        for (int j = 0; j < kHalves * kRows; j++) {
-            uint32_t mj = match16(v[j], 0x0A0A0A0Au);
-            hi |= (v[j].x | v[j].y | v[j].z | v[j].w) & 0x80808080u;
-            int rem = lim_s - (int)(j * kThreads + tid) * 16;  // bytes of this chunk inside the input
+    for (int j = 0; j < kHalves * kRows; j++) {
+        uint32_t mj = match16(v[j], 0x0A0A0A0Au);
+        hi |= v[j].x | v[j].y | v[j].z | v[j].w;
+        if (lim_s != kSuper) {  // the input ends inside this super-tile: mask the bytes past the end
+            int rem = lim_s - (int)(j * kThreads + tid) * 16;
             if (rem < 16) mj &= rem <= 0 ? 0u : ((1u << rem) - 1u);
-            cnt += __popc(mj) << (j < kRows ? 0 : 16);
         }
+        s.bitmap[j / kRows][(j % kRows) * kThreads + tid] = (uint16_t)mj;
+        cnt += __popc(mj) << (j < kRows ? 0 : 16);  // half 0 in the low 16 bits, half 1 in the high
     }
+    hi &= 0x80808080u;
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
     if (wave == 3) hi |= (wv.x | wv.y | wv.z | wv.w) & 0x80808080u;
     uint32_t any_hi = __any(hi != 0);
@@ -275,7 +277,8 @@ __global__ __launch_bounds__(kThreads, F::kMinWavesPerSimd) void k_fused(typenam
 
     // ---- publish the super-tile count; its prefix is awaited after half 0 has been staged ---------------
     const bool analytic = dev_mode >= 1 && dev_mode <= 3;
-    if (tid == 0 && !analytic) st_desc(&tileA[st], kFlag | (unsigned long long)(n_nl[0] + n_nl[1]));
+    if (tid == 0 && !analytic)
+        __hip_atomic_store(&tileA[st], kFlagA | (n_nl[0] + n_nl[1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long halo_nl = rfl64(hdr->halo_nl);
     // Bytes >= 0x80 need UTF-8 validation of every field (the reference builds Arrow Utf8 columns).
     // That is rare in FASTQ and is left to the general path: raise `overflow`, which gates it in.
@@ -325,21 +328,10 @@ __global__ __launch_bounds__(kThreads, F::kMinWavesPerSimd) void k_fused(typenam
 #pragma unroll
         for (int j = 0; j < kRows; j++)
             *reinterpret_cast<uint4 *>(s.bytes + kWin + (j * kThreads + tid) * 16) = v[h * kRows + j];
-        __syncthreads();  // bytes staged
         {
-            // Each thread now owns 64 CONTIGUOUS bytes of the half, so newline ranks follow from one
-            // 32-bit wave scan.  The four 16 B chunks are read in the order (t>>2)+k mod 4: any 16 lanes
-            // of a ds_read_b128 group then touch 16 different bank slots (lane stride alone is 4-way).
-            const uint8_t *mine = s.bytes + kWin + tid * 64;
-            unsigned long long mask = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                uint32_t cidx = ((tid >> 2) + k) & 3u;
-                uint4 q = *reinterpret_cast<const uint4 *>(mine + cidx * 16);
-                mask |= (unsigned long long)match16(q, 0x0A0A0A0Au) << (16 * cidx);
-            }
-            int rem = lim_h - (int)tid * 64;  // bytes of my 64 inside the input
-            if (rem < 64) mask &= rem <= 0 ? 0ull : ((1ull << rem) - 1ull);
+            // Each thread now owns 64 CONTIGUOUS bytes of the half (4 chunks): their masks are one 8-byte
+            // read of the bitmap, so newline ranks follow from one 32-bit wave scan.
+            unsigned long long mask = *reinterpret_cast<const unsigned long long *>(&s.bitmap[h][tid * 4]);
             uint32_t c = (uint32_t)__popcll(mask);
             uint32_t inc = wave_incl_sum(c);
             if (lane == 63) s.wtot[wave] = inc;

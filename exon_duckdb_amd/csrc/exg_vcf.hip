@@ -254,8 +254,9 @@ __device__ __forceinline__ void vcf_report(ScanWsHeader *hdr, uint32_t code, uns
 }
 
 // ---- fused ------------------------------------------------------------------------------------------
+template <class L>
 struct LdsSrc {
-    const FusedLds &s;
+    const L &s;
     uint64_t ptr_of_e0;
     __device__ __forceinline__ uint32_t b(int e) const { return ldb(s, e); }
     __device__ __forceinline__ uint32_t u32(int e) const { return ldu32(s, e); }  // reads stay inside the LDS slack
@@ -264,11 +265,13 @@ struct LdsSrc {
 
 struct VcfFormat {
     using Dev = VcfDev;
+    static constexpr int kNlCap = 1024;  // short data lines are common
     static constexpr int kMinWavesPerSimd = 5;
     __device__ static __forceinline__ uint32_t eof_extra_lines(unsigned long long) { return 0; }
     __device__ static __forceinline__ unsigned long long analytic_prefix(uint64_t) { return 0; }
 
-    __device__ static __forceinline__ void emit_half(const FusedLds &s, const VcfDev &a, ScanWsHeader *hdr,
+    template <class L>
+    __device__ static __forceinline__ void emit_half(const L &s, const VcfDev &a, ScanWsHeader *hdr,
                                                      const TileCtx &c, unsigned long long halo_nl, uint32_t dev_mode,
                                                      uint32_t lane, uint32_t wave,
                                                      unsigned long long *__restrict__ tile_qend, uint64_t tile_index) {
@@ -282,7 +285,7 @@ struct VcfFormat {
         }
         if (dev_mode >= 3) return;
         const bool no_store = (a.flags & EXG_F_NO_STORE) != 0;
-        const LdsSrc src{s, a.payload_base + c.tile_off - kWin};
+        const LdsSrc<L> src{s, a.payload_base + c.tile_off - kWin};
         for (uint32_t jb = 0; jb < c.n_lines; jb += kThreads) {
             const uint32_t j = jb + threadIdx.x;
             const long long out = (long long)(c.P + j) - (long long)halo_nl;
@@ -502,8 +505,9 @@ static int run_vcf_fused(const VcfDev &dev, uint8_t *ws, const FastqWsLayout &l,
         return EXG_E_INVALID_ARG;
     }
     uint32_t n_super = (uint32_t)n_super64;
-    unsigned long long *tileA = reinterpret_cast<unsigned long long *>(ws + l.off_tile_desc);
-    unsigned long long *tileP = tileA + l.n_tiles_fused;
+    // descriptor block: u32 tileA[n] (padded to n u64), u64 tileP[n], u64 tile_qend[n]
+    unsigned int *tileA = reinterpret_cast<unsigned int *>(ws + l.off_tile_desc);
+    unsigned long long *tileP = reinterpret_cast<unsigned long long *>(ws + l.off_tile_desc) + l.n_tiles_fused;
     unsigned long long *tile_qend = tileP + l.n_tiles_fused;
     hipLaunchKernelGGL(k_init_hdr, dim3(1), dim3(1), 0, stream, hdr, l.lines_cap, 0u);
     EXG_HIP_CHECK(hipMemsetAsync(tileA, 0, (size_t)l.n_tiles_fused * 16, stream));
