@@ -18,6 +18,13 @@
 #pragma once
 #include "exg_fastq_ws.hpp"
 
+#ifndef EXG_FIRST_POLL_SLEEP
+#define EXG_FIRST_POLL_SLEEP 0
+#endif
+#ifndef EXG_POLL_SLEEP
+#define EXG_POLL_SLEEP 2
+#endif
+
 namespace exg {
 
 
@@ -166,12 +173,13 @@ __device__ unsigned long long wait_prefix(const uint8_t *__restrict__ d_in, uint
                                           unsigned long long *__restrict__ tileP, uint32_t st, uint32_t lane) {
     if (st == 0) return 0;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_sleep(EXG_FIRST_POLL_SLEEP);
     for (;;) {
         unsigned long long x = lane == 0 ? ld_desc(&tileP[st]) : 0ull;
         x = (unsigned long long)__shfl((long long)x, 0, 64);
         if (x & kFlag) return x & kVal;
         if (__builtin_amdgcn_s_memrealtime() - t0 > 200000) break;  // 2 ms: the scanner is not running
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(EXG_POLL_SLEEP);
     }
     // Last resort (never seen with in-order dispatch): sum every predecessor ourselves.
     unsigned long long sum = 0;
