@@ -23,6 +23,14 @@ def load_library(path=None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    if not os.path.exists(p) and path is None:
+        # in-tree build on first use (hipcc cross-compiles gfx950 without a GPU); never a CPU fallback
+        try:
+            from . import build as _build
+
+            _build.build(verbose=False)
+        except Exception as e:  # noqa: BLE001
+            raise ExgError(abi.EXG_E_NO_DEVICE, f"{p} is missing and could not be built with hipcc: {e}") from e
     if not os.path.exists(p):
         raise ExgError(abi.EXG_E_NO_DEVICE, f"{p} not found: run `python __graft_entry__.py build` "
                        "(hipcc --offload-arch=gfx950); there is no CPU fallback")
