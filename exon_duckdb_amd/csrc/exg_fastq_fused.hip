@@ -180,7 +180,8 @@ __device__ __forceinline__ void fastq_emit_half(const L &s, const FastqDev &a, S
 struct FastqFormat {
     using Dev = FastqDev;
     static constexpr int kNlCap = 512;          // 197 lines per half for 150 bp reads; LDS 22.7 KB -> 7 per CU
-    static constexpr int kMinWavesPerSimd = 7;  // 71 VGPRs, no scratch: 7 x 32 KiB in flight per CU
+    static constexpr int kHalves = 3;   // 48 KiB per workgroup: A/B on one box 2 -> 3 halves +3 %, 4 halves -7 %
+    static constexpr int kMinWavesPerSimd = 6;  // 80 VGPRs, no scratch: 6 x 48 KiB in flight per CU
     // noodles-fastq at EOF: a record that has its '+' line but no quality line gets an empty one
     __device__ static __forceinline__ uint32_t eof_extra_lines(unsigned long long total_lines) {
         return (total_lines & 3) == 3 ? 1u : 0u;
@@ -277,7 +278,9 @@ __global__ __launch_bounds__(256) void k_fastq_finalize_fused(FastqDev a, ScanWs
 int run_fastq_fused(const exg_fastq_scan_args *args, const FastqDev &dev, uint8_t *ws, const FastqWsLayout &l,
                     hipStream_t stream) {
     ScanWsHeader *hdr = reinterpret_cast<ScanWsHeader *>(ws);
-    uint64_t n_super64 = (dev.n_bytes + kSuper - 1) / kSuper;
+    constexpr uint64_t kSuperBytes = (uint64_t)FastqFormat::kHalves * kTile;
+    constexpr uint32_t kHalvesHost = FastqFormat::kHalves;
+    uint64_t n_super64 = (dev.n_bytes + kSuperBytes - 1) / kSuperBytes;
     if (n_super64 == 0) n_super64 = 1;
     if (n_super64 > 0x7FFFFFF0ull) {
         set_error("exg_fastq_scan: buffer too large for one launch (%llu super-tiles)", (unsigned long long)n_super64);
@@ -297,7 +300,7 @@ int run_fastq_fused(const exg_fastq_scan_args *args, const FastqDev &dev, uint8_
     }
     hipLaunchKernelGGL(k_fused<FastqFormat>, dim3(n_super + 1), dim3(kThreads), 0, stream, dev, tileA, tileP, tile_qend, hdr,
                        n_super);
-    hipLaunchKernelGGL(k_fastq_finalize_fused, dim3(1), dim3(256), 0, stream, dev, hdr, tile_qend, n_super * kHalves,
+    hipLaunchKernelGGL(k_fastq_finalize_fused, dim3(1), dim3(256), 0, stream, dev, hdr, tile_qend, n_super * kHalvesHost,
                        args->d_result);
     EXG_HIP_CHECK(hipGetLastError());
     return EXG_OK;

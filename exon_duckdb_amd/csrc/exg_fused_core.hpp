@@ -14,6 +14,7 @@
 //   F::emit_half(...)                     records ending in the staged half
 //   F::analytic_prefix(offset)            dev-only ablation hook
 //   F::kNlCap                             newline positions kept per half (LDS)
+//   F::kHalves                            16 KiB halves per workgroup (bytes waiting in registers: 16 VGPRs each)
 //   F::kMinWavesPerSimd                   occupancy the register allocator must respect (7 = 7 workgroups/CU)
 #pragma once
 #include "exg_fastq_ws.hpp"
@@ -29,8 +30,7 @@ namespace exg {
 
 
 static constexpr int kTile = kFusedTileBytes;  // 16384: one half, the unit of LDS staging and of tile_qend
-static constexpr int kHalves = 2;
-static constexpr int kSuper = kTile * kHalves;  // 32768 bytes per workgroup
+static constexpr int kMaxHalves = 4;  // a format picks F::kHalves 16 KiB halves per workgroup (its bytes wait in registers)
 static constexpr int kWin = kFusedWindow;       // 1024
 static constexpr int kThreads = 256;
 static constexpr int kRows = kTile / (kThreads * 16);  // 4 chunk rows (4 KiB each) per half
@@ -41,12 +41,12 @@ static constexpr unsigned long long kFlag = 1ull << 63;  // descriptor word is p
 static constexpr unsigned long long kVal = (1ull << 48) - 1;
 
 // NL = newline positions kept per half (a half with more lines goes to the general path)
-template <int NL>
+template <int NL, int H>
 struct FusedLdsT {
     static constexpr int kNlCap = NL;
     uint8_t bytes[kLdsBytes];        // [0,kWin) window, then the half; e = p + kWin
     uint16_t nlist[4 + NL + 4];  // e-offsets of newlines: [0..3] the 4 before the half (oldest first)
-    uint16_t bitmap[kHalves][kTile / 16];  // '\n' mask of every 16-byte chunk, written by the first pass
+    uint16_t bitmap[H][kTile / 16];  // '\n' mask of every 16-byte chunk, written by the first pass
     uint32_t wtot[4];   // per-wave newline counts of the staged half
     uint32_t wcnt[4];   // per-wave packed (half 0 | half 1 << 16) newline counts
     unsigned long long prefix;            // '\n' in the buffer before this super-tile
@@ -122,6 +122,7 @@ __device__ __forceinline__ void st_desc(unsigned long long *p, unsigned long lon
 static constexpr int kScanBatches = 8;  // 1024 descriptors per scanner probe (32-bit count words keep this in registers)
 static constexpr uint32_t kFlagA = 1u << 31;
 
+template <int kSuper>
 __device__ void scanner_wave(const uint8_t *__restrict__ d_in, uint64_t n_bytes,
                              const unsigned int *__restrict__ tileA, unsigned long long *__restrict__ tileP,
                              uint32_t n_super, uint32_t lane) {
@@ -168,6 +169,7 @@ __device__ void scanner_wave(const uint8_t *__restrict__ d_in, uint64_t n_bytes,
 }
 
 // Workgroup side (wave 0): wait for the exclusive prefix of super-tile st (its count is published).
+template <int kSuper>
 __device__ unsigned long long wait_prefix(const uint8_t *__restrict__ d_in, uint64_t n_bytes,
                                           unsigned int *__restrict__ tileA,
                                           unsigned long long *__restrict__ tileP, uint32_t st, uint32_t lane) {
@@ -218,8 +220,10 @@ __global__ __launch_bounds__(kThreads, F::kMinWavesPerSimd) void k_fused(typenam
                                                              unsigned long long *__restrict__ tileP,
                                                              unsigned long long *__restrict__ tile_qend,
                                                              ScanWsHeader *hdr, uint32_t n_super) {
-    using FusedLds = FusedLdsT<F::kNlCap>;
+    using FusedLds = FusedLdsT<F::kNlCap, F::kHalves>;
     constexpr int kNlCap = F::kNlCap;
+    constexpr int kHalves = F::kHalves;
+    constexpr int kSuper = kTile * kHalves;
     __shared__ __attribute__((aligned(16))) FusedLds s;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63, wave = tid >> 6;
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(kThreads, F::kMinWavesPerSimd) void k_fused(typenam
     //   3: 1 + no emission at all                    4: scanner, no emission
     const uint32_t dev_mode = (a.flags >> 8) & 15u;
     if (blockIdx.x == 0) {  // the scanner: one wave, no tile
-        if (wave == 0 && !(dev_mode >= 1 && dev_mode <= 3)) scanner_wave(a.d_in, a.n_bytes, tileA, tileP, n_super, lane);
+        if (wave == 0 && !(dev_mode >= 1 && dev_mode <= 3)) scanner_wave<F::kHalves * kTile>(a.d_in, a.n_bytes, tileA, tileP, n_super, lane);
         return;
     }
     const uint32_t st = blockIdx.x - 1;
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(kThreads, F::kMinWavesPerSimd) void k_fused(typenam
             if (rem < 16) mj &= rem <= 0 ? 0u : ((1u << rem) - 1u);
         }
         s.bitmap[j / kRows][(j % kRows) * kThreads + tid] = (uint16_t)mj;
-        cnt += __popc(mj) << (j < kRows ? 0 : 16);  // half 0 in the low 16 bits, half 1 in the high
+        cnt += __popc(mj);
     }
     hi &= 0x80808080u;
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
@@ -279,14 +283,14 @@ __global__ __launch_bounds__(kThreads, F::kMinWavesPerSimd) void k_fused(typenam
         s.wcnt[wave] = cnt;
     }
     __syncthreads();  // #1
-    const uint32_t both = __builtin_amdgcn_readfirstlane(s.wcnt[0] + s.wcnt[1] + s.wcnt[2] + s.wcnt[3]);
-    const uint32_t n_nl[kHalves] = {both & 0xFFFFu, both >> 16};
+    const uint32_t n_nl_super = __builtin_amdgcn_readfirstlane(s.wcnt[0] + s.wcnt[1] + s.wcnt[2] + s.wcnt[3]);
+    unsigned long long nl_before_half = 0;  // '\n' in the halves of this super-tile already processed
     const bool non_ascii = (s.hi_or[0] | s.hi_or[1] | s.hi_or[2] | s.hi_or[3]) != 0;
 
     // ---- publish the super-tile count; its prefix is awaited after half 0 has been staged ---------------
     const bool analytic = dev_mode >= 1 && dev_mode <= 3;
     if (tid == 0 && !analytic)
-        __hip_atomic_store(&tileA[st], kFlagA | (n_nl[0] + n_nl[1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&tileA[st], kFlagA | n_nl_super, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long halo_nl = rfl64(hdr->halo_nl);
     // Bytes >= 0x80 need UTF-8 validation of every field (the reference builds Arrow Utf8 columns).
     // That is rare in FASTQ and is left to the general path: raise `overflow`, which gates it in.
@@ -300,7 +304,8 @@ __global__ __launch_bounds__(kThreads, F::kMinWavesPerSimd) void k_fused(typenam
         const int lim_h = lim_s - h * kTile;  // half-relative end of input
         if (h > 0 && lim_h <= 0) {
             // no input in this half: nothing ends here
-            if (tid == 0) tile_qend[(uint64_t)st * kHalves + h] = 0;
+            if (tid == 0)
+                for (int hh = h; hh < kHalves; hh++) tile_qend[(uint64_t)st * kHalves + hh] = 0;
             break;
         }
         // ---- stage the half: window, bytes, newline list ------------------------------------------
@@ -336,6 +341,7 @@ __global__ __launch_bounds__(kThreads, F::kMinWavesPerSimd) void k_fused(typenam
 #pragma unroll
         for (int j = 0; j < kRows; j++)
             *reinterpret_cast<uint4 *>(s.bytes + kWin + (j * kThreads + tid) * 16) = v[h * kRows + j];
+        uint32_t n_nl_h = 0;  // '\n' in this half
         {
             // Each thread now owns 64 CONTIGUOUS bytes of the half (4 chunks): their masks are one 8-byte
             // read of the bitmap, so newline ranks follow from one 32-bit wave scan.
@@ -345,6 +351,7 @@ __global__ __launch_bounds__(kThreads, F::kMinWavesPerSimd) void k_fused(typenam
             if (lane == 63) s.wtot[wave] = inc;
             __syncthreads();
             uint32_t r = inc - c + (wave > 0 ? s.wtot[0] : 0) + (wave > 1 ? s.wtot[1] : 0) + (wave > 2 ? s.wtot[2] : 0);
+            n_nl_h = __builtin_amdgcn_readfirstlane(s.wtot[0] + s.wtot[1] + s.wtot[2] + s.wtot[3]);
             const uint32_t e0 = kWin + tid * 64;
             while (mask) {
                 uint32_t b = (uint32_t)__ffsll((long long)mask) - 1;
@@ -360,7 +367,7 @@ __global__ __launch_bounds__(kThreads, F::kMinWavesPerSimd) void k_fused(typenam
                 if (analytic) {
                     pre = F::analytic_prefix(super_off);
                 } else {
-                    pre = wait_prefix(d_in, a.n_bytes, tileA, tileP, st, lane);
+                    pre = wait_prefix<kSuper>(d_in, a.n_bytes, tileA, tileP, st, lane);
                 }
                 if (lane == 0) s.prefix = pre;
             }
@@ -369,12 +376,13 @@ __global__ __launch_bounds__(kThreads, F::kMinWavesPerSimd) void k_fused(typenam
 
         TileCtx c;
         c.tile_off = super_off + (uint64_t)h * kTile;
-        c.P = rfl64(s.prefix) + (h ? n_nl[0] : 0);
+        c.P = rfl64(s.prefix) + nl_before_half;
+        nl_before_half += n_nl_h;
         c.first_of_buffer = st == 0 && h == 0;
         const bool ends_here = last_super && lim_h <= kTile;  // the input ends inside (or at the end of) this half
         c.is_eof_tile = ends_here && (a.flags & EXG_F_EOF);
         c.lim_e = (lim_h < kTile ? lim_h : kTile) + kWin;
-        uint32_t n_lines = n_nl[h];
+        uint32_t n_lines = n_nl_h;
         if (c.is_eof_tile) {
             // noodles EOF rules: an unterminated last line is a line; a record with its '+' line but no
             // quality line gets an empty one (read_line returns 0 bytes at EOF without error).
@@ -389,7 +397,7 @@ __global__ __launch_bounds__(kThreads, F::kMinWavesPerSimd) void k_fused(typenam
         }
         c.n_lines = n_lines;
         if (ends_here && tid == 0) {
-            hdr->total_nl = c.P + n_nl[h];
+            hdr->total_nl = c.P + n_nl_h;
             hdr->total_lines = c.P + n_lines;
         }
         if (n_lines > (uint32_t)kNlCap) {  // more lines than the list holds: general path

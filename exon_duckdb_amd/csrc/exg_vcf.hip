@@ -266,6 +266,7 @@ struct LdsSrc {
 struct VcfFormat {
     using Dev = VcfDev;
     static constexpr int kNlCap = 1024;  // short data lines are common
+    static constexpr int kHalves = 2;
     static constexpr int kMinWavesPerSimd = 5;
     __device__ static __forceinline__ uint32_t eof_extra_lines(unsigned long long) { return 0; }
     __device__ static __forceinline__ unsigned long long analytic_prefix(uint64_t) { return 0; }
@@ -498,7 +499,9 @@ static int run_vcf_general(const VcfDev &dev, uint8_t *ws, const FastqWsLayout &
 static int run_vcf_fused(const VcfDev &dev, uint8_t *ws, const FastqWsLayout &l, exg_scan_result *d_result,
                          hipStream_t stream) {
     ScanWsHeader *hdr = reinterpret_cast<ScanWsHeader *>(ws);
-    uint64_t n_super64 = (dev.n_bytes + kSuper - 1) / kSuper;
+    constexpr uint64_t kSuperBytes = (uint64_t)VcfFormat::kHalves * kTile;
+    constexpr uint32_t kHalvesHost = VcfFormat::kHalves;
+    uint64_t n_super64 = (dev.n_bytes + kSuperBytes - 1) / kSuperBytes;
     if (n_super64 == 0) n_super64 = 1;
     if (n_super64 > 0x7FFFFFF0ull) {
         set_error("exg_vcf_scan: buffer too large for one launch");
@@ -517,7 +520,7 @@ static int run_vcf_fused(const VcfDev &dev, uint8_t *ws, const FastqWsLayout &l,
     }
     hipLaunchKernelGGL(k_fused<VcfFormat>, dim3(n_super + 1), dim3(kThreads), 0, stream, dev, tileA, tileP, tile_qend, hdr,
                        n_super);
-    hipLaunchKernelGGL(k_vcf_finalize, dim3(1), dim3(256), 0, stream, dev, hdr, tile_qend, n_super * kHalves,
+    hipLaunchKernelGGL(k_vcf_finalize, dim3(1), dim3(256), 0, stream, dev, hdr, tile_qend, n_super * kHalvesHost,
                        (const uint64_t *)nullptr, 1, d_result, (const unsigned int *)nullptr);
     EXG_HIP_CHECK(hipGetLastError());
     return EXG_OK;
