@@ -45,6 +45,8 @@ struct InflateLds {
     uint16_t dist_lut[1 << kDistBits];
     uint16_t lit_sorted[288], dist_sorted[32];   // symbols ordered by (length, symbol) — canonical decode
     uint16_t lit_count[16], dist_count[16];
+    uint16_t len_base[32], dist_base[32];
+    uint8_t len_extra[32], dist_extra[32];
     uint8_t lens[384];  // [0,288) literal/length, [288,320) distance; [32,348) scratch while a dynamic header is read
 };
 
@@ -59,44 +61,54 @@ __device__ __constant__ unsigned char kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6,
 
 __device__ __forceinline__ uint32_t sgpr(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
 
-struct BitReader {
-    unsigned long long bb;  // bit buffer, LSB first
-    uint32_t bc;            // valid bits
-    uint32_t ip;            // next byte to fetch, relative to g0 (multiple of 4)
-    uint32_t loaded;        // input chunks [0, loaded) (1 KiB each) have been staged
-    uint32_t limit;         // bytes available relative to g0
-    const uint8_t *g0;      // 16-byte aligned global address of chunk 0
+// ---- bit input: absolute bit position + a 2 KiB LDS ring of the compressed bytes --------------------------
+struct BitIn {
+    unsigned long long bitpos;  // next bit, relative to g0 (wave uniform)
+    uint32_t loaded;            // input chunks [0, loaded) (1 KiB each) have been staged
+    uint32_t limit;             // bytes available relative to g0
+    const uint8_t *g0;          // 16-byte aligned global address of chunk 0
 };
 
 // stage 1 KiB chunk c of the compressed input (coalesced, 16 B per lane)
-__device__ __forceinline__ void stage_chunk(InflateLds &s, const BitReader &br, uint32_t c, uint32_t lane) {
+__device__ __forceinline__ void stage_chunk(InflateLds &s, const BitIn &br, uint32_t c, uint32_t lane) {
     uint32_t off = c * 1024 + lane * 16;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (off < ((br.limit + 15) & ~15u)) v = *reinterpret_cast<const uint4 *>(br.g0 + off);
     *reinterpret_cast<uint4 *>(s.in + ((c & 1) * 1024 + lane * 16)) = v;
 }
 
-// make at least n (<= 32) bits available
-__device__ __forceinline__ void need(InflateLds &s, BitReader &br, uint32_t n, uint32_t lane) {
-    while (br.bc < n) {
-        uint32_t c = br.ip >> 10;
-        if (c + 1 >= br.loaded) {  // keep chunk c and c + 1 staged
-            stage_chunk(s, br, br.loaded, lane);
-            br.loaded++;
-            continue;
-        }
-        uint32_t w = sgpr(*reinterpret_cast<const uint32_t *>(s.in + (br.ip & (kInRing - 1))));
-        br.bb |= (unsigned long long)w << br.bc;
-        br.bc += 32;
-        br.ip += 4;
+// keep the chunk that holds the current byte and the next one staged (reads go up to ~20 bytes ahead)
+__device__ __forceinline__ void ensure(InflateLds &s, BitIn &br, uint32_t lane) {
+    uint32_t c = (uint32_t)(br.bitpos >> 13);  // 8192 bits per chunk
+    while (c + 1 >= br.loaded) {
+        stage_chunk(s, br, br.loaded, lane);
+        br.loaded++;
     }
 }
-__device__ __forceinline__ uint32_t getbits(InflateLds &s, BitReader &br, uint32_t n, uint32_t lane) {
-    need(s, br, n, lane);
-    uint32_t v = (uint32_t)br.bb & ((1u << n) - 1u);
-    br.bb >>= n;
-    br.bc -= n;
+
+// 64 bits starting at absolute bit `o` (per lane), >= 57 of them valid
+__device__ __forceinline__ unsigned long long peek_at(const InflateLds &s, unsigned long long o) {
+    uint32_t byte = (uint32_t)(o >> 3);
+    uint32_t a = byte & ~3u;
+    uint32_t w0 = *reinterpret_cast<const uint32_t *>(s.in + (a & (kInRing - 1)));
+    uint32_t w1 = *reinterpret_cast<const uint32_t *>(s.in + ((a + 4) & (kInRing - 1)));
+    uint32_t w2 = *reinterpret_cast<const uint32_t *>(s.in + ((a + 8) & (kInRing - 1)));
+    uint32_t sh = 8 * (byte & 3u) + (uint32_t)(o & 7);  // 0..31
+    unsigned long long lo = ((unsigned long long)w1 << 32) | w0;
+    unsigned long long v = lo >> sh;
+    if (sh) v |= (unsigned long long)w2 << (64 - sh);
     return v;
+}
+__device__ __forceinline__ unsigned long long peek(InflateLds &s, BitIn &br, uint32_t lane) {
+    ensure(s, br, lane);
+    unsigned long long v = peek_at(s, br.bitpos);
+    uint32_t lo = sgpr((uint32_t)v), hi = sgpr((uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t getbits(InflateLds &s, BitIn &br, uint32_t n, uint32_t lane) {
+    unsigned long long v = peek(s, br, lane);
+    br.bitpos += n;
+    return (uint32_t)v & (n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u));
 }
 
 // Build one decode table from code lengths lens[0..n): LUT (primary `bits`), sorted symbols, counts.
@@ -166,35 +178,40 @@ __device__ bool build_table(const uint8_t *lens, uint32_t n, uint16_t *lut, uint
     return true;
 }
 
-// decode one symbol; returns 0xFFFFFFFF on an invalid code
-__device__ __forceinline__ uint32_t decode_sym(InflateLds &s, BitReader &br, const uint16_t *lut, uint32_t bits,
-                                               const uint16_t *sorted, const uint16_t *count, uint32_t lane) {
-    need(s, br, 15, lane);
-    uint32_t e = sgpr(lut[(uint32_t)br.bb & ((1u << bits) - 1u)]);
-    if (e) {
-        uint32_t l = e & 15;
-        br.bb >>= l;
-        br.bc -= l;
-        return e >> 4;
-    }
-    // canonical decode, bit by bit (codes longer than the primary table; rare)
+// canonical decode, bit by bit, of the code at the front of `bits` (codes longer than the primary table; rare)
+__device__ __forceinline__ uint32_t decode_slow(unsigned long long bits, const uint16_t *sorted, const uint16_t *count,
+                                                uint32_t *len_out) {
     uint32_t code = 0, first = 0, index = 0;
-    unsigned long long bits64 = br.bb;
     for (uint32_t len = 1; len <= 15; len++) {
-        code |= (uint32_t)bits64 & 1u;
-        bits64 >>= 1;
-        uint32_t c = sgpr(count[len]);
+        code |= (uint32_t)bits & 1u;
+        bits >>= 1;
+        uint32_t c = count[len];
         if (code < first + c) {
-            br.bb >>= len;
-            br.bc -= len;
-            return sgpr(sorted[index + (code - first)]);
+            *len_out = len;
+            return sorted[index + (code - first)];
         }
         index += c;
         first += c;
         first <<= 1;
         code <<= 1;
     }
+    *len_out = 0;
     return 0xFFFFFFFFu;
+}
+
+// decode one symbol serially (block headers); returns 0xFFFFFFFF on an invalid code
+__device__ __forceinline__ uint32_t decode_sym(InflateLds &s, BitIn &br, const uint16_t *lut, uint32_t bits,
+                                               const uint16_t *sorted, const uint16_t *count, uint32_t lane) {
+    unsigned long long v = peek(s, br, lane);
+    uint32_t e = sgpr(lut[(uint32_t)v & ((1u << bits) - 1u)]);
+    if (e) {
+        br.bitpos += e & 15;
+        return e >> 4;
+    }
+    uint32_t l = 0;
+    uint32_t sym = sgpr(decode_slow(v, sorted, count, &l));
+    br.bitpos += sgpr(l);
+    return sym;
 }
 
 // flush every completed 1 KiB segment of the window ring to HBM
@@ -215,39 +232,48 @@ __device__ __forceinline__ void flush_segments(InflateLds &s, uint8_t *out, unsi
     }
 }
 
+// token kinds of the speculative decode
+static constexpr uint32_t kLit = 0, kMatch = 1, kEob = 2, kSlow = 3, kBad = 4;
+
 __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ d_comp, uint8_t *__restrict__ d_out,
                                                 const InflateMember *__restrict__ members, InflateStatus *status,
                                                 uint32_t n_members) {
     __shared__ __attribute__((aligned(16))) InflateLds s;
     const uint32_t lane = threadIdx.x;
+    // length / distance tables -> LDS (per-lane indexed lookups; constant memory would serialise them)
+    if (lane < 29) {
+        s.len_base[lane] = kLenBase[lane];
+        s.len_extra[lane] = kLenExtra[lane];
+    }
+    if (lane < 30) {
+        s.dist_base[lane] = kDistBase[lane];
+        s.dist_extra[lane] = kDistExtra[lane];
+    }
     for (uint32_t m = blockIdx.x; m < n_members; m += gridDim.x) {
         const InflateMember mb = members[m];
-        BitReader br;
+        BitIn br;
         const unsigned long long a0 = mb.comp_off & ~15ull;
         br.g0 = d_comp + a0;
         const uint32_t skip = (uint32_t)(mb.comp_off - a0);
         unsigned long long lim = mb.comp_size + skip;
         br.limit = lim > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)lim;
-        br.bb = 0;
-        br.bc = 0;
-        br.ip = skip & ~3u;
+        br.bitpos = (unsigned long long)skip * 8;
         br.loaded = 0;
         __syncthreads();
-        stage_chunk(s, br, 0, lane);
-        stage_chunk(s, br, 1, lane);
-        br.loaded = 2;
-        if (skip & 3) (void)getbits(s, br, 8 * (skip & 3), lane);
+        ensure(s, br, lane);
 
         uint32_t pos = 0, flushed = 0, err = 0;
         const unsigned long long cap = mb.out_cap;
         bool last = false;
         while (!last && !err) {
-            last = getbits(s, br, 1, lane) != 0;
-            uint32_t type = getbits(s, br, 2, lane);
+            uint32_t hdr3 = getbits(s, br, 3, lane);
+            last = (hdr3 & 1) != 0;
+            uint32_t type = hdr3 >> 1;
             if (type == 0) {
                 // stored: skip to a byte boundary, LEN / NLEN, raw bytes
-                (void)getbits(s, br, br.bc & 7, lane);
-                uint32_t len = getbits(s, br, 16, lane), nlen = getbits(s, br, 16, lane);
+                br.bitpos = (br.bitpos + 7) & ~7ull;
+                uint32_t ln = getbits(s, br, 32, lane);
+                uint32_t len = ln & 0xFFFFu, nlen = ln >> 16;
                 if ((len ^ 0xFFFFu) != nlen) {
                     err = 1;
                     break;
@@ -256,10 +282,13 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ d_co
                     err = 4;
                     break;
                 }
-                for (uint32_t i = 0; i < len; i++) {  // byte at a time through the bit reader: stored blocks are rare
-                    uint32_t b = getbits(s, br, 8, lane);
-                    if (lane == 0) s.win[(pos + i) & (kWinBytes - 1)] = (uint8_t)b;
-                    if (((pos + i + 1) & 1023) == 0) flush_segments(s, d_out, mb.out_off, flushed, pos + i + 1, lane);
+                // 64 bytes per step, lane = byte
+                for (uint32_t i = 0; i < len; i += 64) {
+                    ensure(s, br, lane);
+                    uint32_t n = len - i < 64 ? len - i : 64;
+                    if (lane < n) s.win[(pos + i + lane) & (kWinBytes - 1)] = s.in[((uint32_t)(br.bitpos >> 3) + lane) & (kInRing - 1)];
+                    br.bitpos += 8ull * n;
+                    flush_segments(s, d_out, mb.out_off, flushed, pos + i + n, lane);
                 }
                 pos += len;
                 continue;
@@ -275,24 +304,26 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ d_co
                 nlit = 288;
                 ndist = 32;
             } else {
-                nlit = getbits(s, br, 5, lane) + 257;
-                ndist = getbits(s, br, 5, lane) + 1;
-                uint32_t ncode = getbits(s, br, 4, lane) + 4;
+                uint32_t h14 = getbits(s, br, 14, lane);
+                nlit = (h14 & 31) + 257;
+                ndist = ((h14 >> 5) & 31) + 1;
+                uint32_t ncode = (h14 >> 10) + 4;
                 if (nlit > 286 || ndist > 30) {
                     err = 2;
                     break;
                 }
                 if (lane < 19) s.lens[lane] = 0;
-                for (uint32_t i = 0; i < ncode; i++) {
-                    uint32_t v = getbits(s, br, 3, lane);
-                    if (lane == 0) s.lens[kClOrder[i]] = (uint8_t)v;
+                {
+                    // 19 x 3 bits = 57 bits: one peek
+                    unsigned long long v = peek(s, br, lane);
+                    if (lane < ncode) s.lens[kClOrder[lane]] = (uint8_t)((v >> (3 * lane)) & 7);
+                    br.bitpos += 3ull * ncode;
                 }
                 // the code-length code reuses the distance table storage (7-bit codes, 19 symbols)
                 if (!build_table(s.lens, 19, s.dist_lut, 7, s.dist_sorted, s.dist_count, lane)) {
                     err = 2;
                     break;
                 }
-                // the lengths themselves: staged in registers-free fashion straight into s.lens (after the 19)
                 uint32_t idx = 0, prev = 0;
                 while (idx < nlit + ndist) {
                     uint32_t sym = decode_sym(s, br, s.dist_lut, 7, s.dist_sorted, s.dist_count, lane);
@@ -345,44 +376,156 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ d_co
                 err = 2;
                 break;
             }
-            // ---- symbols of the block ----------------------------------------------------------
-            for (;;) {
-                uint32_t sym = decode_sym(s, br, s.lit_lut, kLitBits, s.lit_sorted, s.lit_count, lane);
-                if (sym < 256) {
-                    if (pos >= cap) {
-                        err = 4;
+            // ---- tokens of the block: 64 speculative decodes per step, then the true chain ----------------
+            bool eob = false;
+            while (!eob && !err) {
+                ensure(s, br, lane);
+                // lane l decodes the token that would start at bit bitpos + l
+                unsigned long long v = peek_at(s, br.bitpos + lane);
+                uint32_t kind, tl, val = 0;
+                {
+                    uint32_t e = s.lit_lut[(uint32_t)v & ((1u << kLitBits) - 1u)];
+                    uint32_t l1 = e & 15, sym = e >> 4;
+                    if (e == 0) {  // longer than the primary table: decoded serially IF it is a real token start
+                        kind = kSlow;
+                        tl = 0;
+                    } else if (sym > 285) {
+                        kind = kBad;
+                        tl = 1;
+                    } else if (sym < 256) {
+                        kind = kLit;
+                        tl = l1;
+                        val = sym;
+                    } else if (sym == 256) {
+                        kind = kEob;
+                        tl = l1;
+                    } else {
+                        uint32_t si = sym - 257;
+                        uint32_t lx = s.len_extra[si];
+                        uint32_t len = s.len_base[si] + ((uint32_t)(v >> l1) & ((1u << lx) - 1u));
+                        uint32_t t = l1 + lx;
+                        unsigned long long v2 = v >> t;
+                        uint32_t de = s.dist_lut[(uint32_t)v2 & ((1u << kDistBits) - 1u)];
+                        uint32_t l2 = de & 15, ds = de >> 4;
+                        if (de == 0) {
+                            kind = kSlow;
+                            tl = 0;
+                        } else if (ds > 29) {
+                            kind = kBad;
+                            tl = 1;
+                        } else {
+                            uint32_t dx = s.dist_extra[ds];
+                            uint32_t dist = s.dist_base[ds] + ((uint32_t)(v2 >> l2) & ((1u << dx) - 1u));
+                            kind = kMatch;
+                            tl = t + l2 + dx;  // <= 15 + 5 + 15 + 13 = 48 bits
+                            val = len | (dist << 16);
+                        }
+                    }
+                }
+                // the real chain from offset 0: one readlane per token marks the token starts ...
+                unsigned long long marks = 0;
+                uint32_t cur = 0;
+                bool slow_token = false;
+                while (cur < 64) {
+                    uint32_t t = __builtin_amdgcn_readlane(tl, cur);
+                    if (t == 0) {  // kSlow: the window ends in front of it
+                        slow_token = true;
                         break;
                     }
-                    if (lane == 0) s.win[pos & (kWinBytes - 1)] = (uint8_t)sym;
-                    pos++;
-                    if ((pos & 1023) == 0) flush_segments(s, d_out, mb.out_off, flushed, pos, lane);
-                    continue;
+                    marks |= 1ull << cur;
+                    cur += t;
                 }
-                if (sym == 256) break;
-                if (sym > 285) {
-                    err = 3;
-                    break;
+                // ... then runs of literals go out in ONE step (rank = popcount of the marks below the lane);
+                // only matches / end-of-block / bad codes are handled one at a time, in order
+                const unsigned long long m_lit = __ballot(kind == kLit) & marks;
+                unsigned long long m_other = marks & ~m_lit;
+                uint32_t from = 0, advance = cur;
+                for (;;) {
+                    const uint32_t upto = m_other ? (uint32_t)__ffsll((long long)m_other) - 1 : 64u;
+                    unsigned long long seg = m_lit;
+                    if (upto < 64) seg &= (1ull << upto) - 1ull;
+                    if (from >= 64)
+                        seg = 0;
+                    else if (from)
+                        seg &= ~((1ull << from) - 1ull);
+                    const uint32_t n = (uint32_t)__popcll(seg);
+                    if (n) {
+                        if ((unsigned long long)pos + n > cap) {
+                            err = 4;
+                            break;
+                        }
+                        uint32_t rank = (uint32_t)__popcll(seg & ((1ull << lane) - 1ull));
+                        if ((seg >> lane) & 1ull) s.win[(pos + rank) & (kWinBytes - 1)] = (uint8_t)val;
+                        uint32_t np = pos + n;
+                        if ((np >> 10) != (pos >> 10)) flush_segments(s, d_out, mb.out_off, flushed, np, lane);
+                        pos = np;
+                    }
+                    if (upto == 64) break;
+                    const uint32_t k = __builtin_amdgcn_readlane(kind, upto);
+                    const uint32_t x = __builtin_amdgcn_readlane(val, upto);
+                    if (k == kMatch) {
+                        uint32_t len = x & 0xFFFFu, dist = x >> 16;
+                        if (dist > pos || (unsigned long long)pos + len > cap) {
+                            err = dist > pos ? 3 : 4;
+                            break;
+                        }
+                        // all lanes copy; the source index is folded into [pos - dist, pos) so overlaps are exact
+                        for (uint32_t i = lane; i < len; i += 64) {
+                            uint32_t src = pos - dist + (dist >= len ? i : i % dist);
+                            s.win[(pos + i) & (kWinBytes - 1)] = s.win[src & (kWinBytes - 1)];
+                        }
+                        uint32_t np = pos + len;
+                        if ((np >> 10) != (pos >> 10)) flush_segments(s, d_out, mb.out_off, flushed, np, lane);
+                        pos = np;
+                    } else if (k == kEob) {
+                        advance = upto + __builtin_amdgcn_readlane(tl, upto);
+                        eob = true;
+                        break;
+                    } else {
+                        err = 3;
+                        break;
+                    }
+                    m_other &= m_other - 1;
+                    from = upto + 1;
                 }
-                sym -= 257;
-                uint32_t len = kLenBase[sym] + getbits(s, br, kLenExtra[sym], lane);
-                uint32_t ds = decode_sym(s, br, s.dist_lut, kDistBits, s.dist_sorted, s.dist_count, lane);
-                if (ds > 29) {
-                    err = 3;
-                    break;
+                br.bitpos += advance;
+                if (slow_token && !eob && !err) {
+                    // one token with a code longer than the primary tables, decoded by every lane uniformly
+                    uint32_t sym = decode_sym(s, br, s.lit_lut, kLitBits, s.lit_sorted, s.lit_count, lane);
+                    if (sym < 256) {
+                        if (pos >= cap) {
+                            err = 4;
+                        } else {
+                            if (lane == 0) s.win[pos & (kWinBytes - 1)] = (uint8_t)sym;
+                            pos++;
+                            if ((pos & 1023) == 0) flush_segments(s, d_out, mb.out_off, flushed, pos, lane);
+                        }
+                    } else if (sym == 256) {
+                        eob = true;
+                    } else if (sym > 285) {
+                        err = 3;
+                    } else {
+                        sym -= 257;
+                        uint32_t len = kLenBase[sym] + getbits(s, br, kLenExtra[sym], lane);
+                        uint32_t ds = decode_sym(s, br, s.dist_lut, kDistBits, s.dist_sorted, s.dist_count, lane);
+                        if (ds > 29) {
+                            err = 3;
+                        } else {
+                            uint32_t dist = kDistBase[ds] + getbits(s, br, kDistExtra[ds], lane);
+                            if (dist > pos || (unsigned long long)pos + len > cap) {
+                                err = dist > pos ? 3 : 4;
+                            } else {
+                                for (uint32_t i = lane; i < len; i += 64) {
+                                    uint32_t src = pos - dist + (dist >= len ? i : i % dist);
+                                    s.win[(pos + i) & (kWinBytes - 1)] = s.win[src & (kWinBytes - 1)];
+                                }
+                                uint32_t np = pos + len;
+                                if ((np >> 10) != (pos >> 10)) flush_segments(s, d_out, mb.out_off, flushed, np, lane);
+                                pos = np;
+                            }
+                        }
+                    }
                 }
-                uint32_t dist = kDistBase[ds] + getbits(s, br, kDistExtra[ds], lane);
-                if (dist > pos || (unsigned long long)pos + len > cap) {
-                    err = dist > pos ? 3 : 4;
-                    break;
-                }
-                // all lanes copy; the source index is folded into [pos - dist, pos) so overlaps are exact
-                for (uint32_t i = lane; i < len; i += 64) {
-                    uint32_t src = pos - dist + (dist >= len ? i : i % dist);
-                    s.win[(pos + i) & (kWinBytes - 1)] = s.win[src & (kWinBytes - 1)];
-                }
-                uint32_t np = pos + len;
-                if ((np >> 10) != (pos >> 10)) flush_segments(s, d_out, mb.out_off, flushed, np, lane);
-                pos = np;
             }
         }
         // tail: the bytes after the last full segment
@@ -394,8 +537,8 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ d_co
             st.code = err;
             st.pad = 0;
             st.produced = pos;
-            // consumed: bytes fetched minus whole bytes still in the bit buffer, relative to comp_off
-            st.consumed = (unsigned long long)br.ip - (br.bc >> 3) - skip;
+            // consumed: bytes up to the byte boundary after the final block, relative to comp_off
+            st.consumed = ((br.bitpos + 7) >> 3) - skip;
             status[m] = st;
         }
         __syncthreads();
