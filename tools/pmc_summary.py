@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/<tag>_* (tools/collect_profiles.sh) into profiles/.
+
+  python tools/pmc_summary.py r01_d
+
+Copies the kernel-stats CSV and the per-dispatch counter rows of the dominant kernel, and rewrites
+profiles/pmc_fastq_fused.json (read by bench.py for roofline.traffic).  rocprofv3 reports
+FETCH_SIZE/WRITE_SIZE in kilobytes (x1024 -> bytes); on gfx950 FETCH_SIZE under-reports wide
+streaming reads by 2x (MI355X_MICROARCH.md, HBM section), so reads are doubled.
+"""
+import csv, glob, json, os, shutil, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01_d"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = os.path.join(root, "gpurun_out")
+prof = os.path.join(root, "profiles")
+KERNEL = "k_fused<exg::FastqFormat>"
+
+
+def find(pattern):
+    g = glob.glob(os.path.join(out, pattern), recursive=True)
+    return g[0] if g else None
+
+
+def counter_rows(path):
+    rows = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if KERNEL in r["Kernel_Name"]:
+                rows.append(r)
+    return rows
+
+
+res = {}
+stats = find(f"{tag}_kt/**/*kernel_stats.csv")
+if stats:
+    shutil.copy(stats, os.path.join(prof, f"{tag}_kernel_stats.csv"))
+    with open(stats) as f:
+        for r in csv.DictReader(f):
+            if KERNEL in r["Name"]:
+                res["kernel_avg_ns"] = float(r["AverageNs"])
+                res["kernel_calls"] = int(r["Calls"])
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    p = find(f"{tag}_pmc_{c}/**/*counter_collection.csv")
+    if not p:
+        continue
+    rows = counter_rows(p)
+    with open(os.path.join(prof, f"{tag}_pmc_{c.lower()}_k_fused.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows(rows)
+    vals = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == c]
+    res[c] = sum(vals) / len(vals)
+b = os.path.join(out, f"{tag}_bench.json")
+if os.path.exists(b):
+    shutil.copy(b, os.path.join(prof, f"{tag}_bench.json"))
+if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
+    old = json.load(open(os.path.join(prof, "pmc_fastq_fused.json")))
+    rd = res["FETCH_SIZE"] * 1024 * 2
+    wr = res["WRITE_SIZE"] * 1024
+    old.update({
+        "tag": tag,
+        "FETCH_SIZE_bytes_raw": res["FETCH_SIZE"] * 1024,
+        "read_bytes_per_launch": rd,
+        "write_bytes_per_launch": wr,
+        "hbm_bytes_per_launch_10GB": rd + wr,
+        "kernel_avg_ns_rocprofv3": res.get("kernel_avg_ns"),
+    })
+    old.pop("sq_counters_per_launch", None)
+    json.dump(old, open(os.path.join(prof, "pmc_fastq_fused.json"), "w"), indent=1)
+print(json.dumps(res, indent=1))
