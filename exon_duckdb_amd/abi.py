@@ -21,6 +21,8 @@ EXG_PE_VCF_BAD_POS = 9
 EXG_PE_VCF_BAD_QUAL = 10
 EXG_PE_VCF_NO_HEADER = 11
 EXG_PE_FIELD_TOO_LONG = 12
+EXG_PE_VCF_INFO = 13
+EXG_PE_VCF_FORMAT = 14
 
 EXG_FMT_FASTA, EXG_FMT_FASTQ, EXG_FMT_VCF = 1, 2, 3
 EXG_F_BOF, EXG_F_EOF, EXG_F_NO_STORE = 1, 2, 4

@@ -49,6 +49,8 @@ extern "C" const char *exg_parse_error_string(uint32_t code) {
         case EXG_PE_VCF_BAD_QUAL: return "invalid quality score";
         case EXG_PE_VCF_NO_HEADER: return "missing header";
         case EXG_PE_FIELD_TOO_LONG: return "field longer than 4 GiB";
+        case EXG_PE_VCF_INFO: return "invalid info field value";
+        case EXG_PE_VCF_FORMAT: return "invalid genotype field value";
         default: return "unknown parse error";
     }
 }

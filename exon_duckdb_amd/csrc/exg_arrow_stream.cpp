@@ -1,0 +1,1008 @@
+// exg_arrow_stream.cpp — `new_reader`, the reference's own FFI entry point (exon/include/rust.hpp:41-46,
+// rust/src/arrow_reader.rs:38-166), on top of the device reader: an ArrowArrayStream whose record batches
+// (<= batch_size rows) carry the reference's schema
+//     FASTA  id, description, sequence                       (Utf8)
+//     FASTQ  name, description, sequence, quality_scores     (Utf8)
+//     VCF    chrom Utf8, pos Int64, id List<Utf8>, ref Utf8, alt List<Utf8>, qual Float32,
+//            filter List<Utf8>, info Struct<##INFO keys>, formats List<Struct<##FORMAT keys>>
+// so the unchanged C++ glue of the reference (WTArrowTableFunction::FileTypeBind / InitGlobal / Scan,
+// module.cpp:75-294) can sit on top of it.  Every Arrow buffer is produced on the device (exg_arrow.hip,
+// exg_vcf_typed.hip); this file parses the VCF header and the `filters` text, sizes the buffers, copies
+// them back and wires the ArrowArray / ArrowSchema structs.
+#include <errno.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "exg_arrow.hpp"
+#include "exg_reader.hpp"
+
+using namespace exg_rd;
+namespace ea = exg::arrow;
+
+namespace {
+
+// ---- schema -------------------------------------------------------------------------------------------------------------
+struct Field {
+    std::string name, format;
+    bool nullable = true;
+    std::vector<Field> children;
+};
+
+struct KeyDef {
+    std::string id;
+    uint8_t type = ea::kVtString;
+    bool is_list = false;
+};
+
+// `##INFO=<ID=DP,Number=1,Type=Integer,...>` / `##FORMAT=<...>` in header order (noodles-vcf Header::infos /
+// ::formats are insertion-ordered maps)
+void parse_vcf_header(const char *d, size_t n, std::vector<KeyDef> *info, std::vector<KeyDef> *format) {
+    size_t pos = 0;
+    while (pos < n && d[pos] == '#') {
+        const char *nl = (const char *)memchr(d + pos, '\n', n - pos);
+        size_t end = nl ? (size_t)(nl - d) : n;
+        std::string line(d + pos, end - pos);
+        pos = nl ? end + 1 : n;
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        std::vector<KeyDef> *dst = nullptr;
+        size_t lt = 0;
+        if (line.compare(0, 8, "##INFO=<") == 0) dst = info, lt = 8;
+        if (line.compare(0, 10, "##FORMAT=<") == 0) dst = format, lt = 10;
+        if (!dst) continue;
+        // key=value pairs separated by ',' outside double quotes
+        KeyDef k;
+        std::string number = "1", type = "String";
+        size_t i = lt;
+        while (i < line.size() && line[i] != '>') {
+            size_t eq = line.find('=', i);
+            if (eq == std::string::npos) break;
+            std::string key = line.substr(i, eq - i), val;
+            size_t j = eq + 1;
+            if (j < line.size() && line[j] == '"') {
+                j++;
+                while (j < line.size() && line[j] != '"') {
+                    if (line[j] == '\\' && j + 1 < line.size()) j++;
+                    val.push_back(line[j++]);
+                }
+                j++;
+            } else {
+                while (j < line.size() && line[j] != ',' && line[j] != '>') val.push_back(line[j++]);
+            }
+            if (key == "ID") k.id = val;
+            if (key == "Number") number = val;
+            if (key == "Type") type = val;
+            i = j < line.size() && line[j] == ',' ? j + 1 : j;
+        }
+        if (k.id.empty()) continue;
+        k.type = type == "Integer" ? ea::kVtInt : type == "Float" ? ea::kVtFloat : type == "Flag" ? ea::kVtFlag : ea::kVtString;
+        k.is_list = k.type != ea::kVtFlag && number != "1";
+        bool dup = false;
+        for (auto &o : *dst) dup = dup || o.id == k.id;
+        if (!dup) dst->push_back(k);
+    }
+}
+
+Field key_field(const KeyDef &k) {
+    Field f;
+    f.name = k.id;
+    const char *fmt = k.type == ea::kVtInt ? "i" : k.type == ea::kVtFloat ? "f" : k.type == ea::kVtFlag ? "b" : "u";
+    if (k.is_list) {
+        f.format = "+l";
+        Field item;
+        item.name = "item";
+        item.format = fmt;
+        f.children.push_back(item);
+    } else {
+        f.format = fmt;
+    }
+    return f;
+}
+
+// ---- filters: the text FilterToString renders (module.cpp:158-214) ------------------------------------------------------
+struct FilterParser {
+    const std::string &s;
+    size_t i = 0;
+    const std::vector<Field> &cols;
+    ea::FilterProgram prog;
+    std::string consts;
+    std::string err;
+
+    FilterParser(const std::string &text, const std::vector<Field> &c) : s(text), cols(c) { prog.n_ops = 0; }
+    void ws() {
+        while (i < s.size() && isspace((unsigned char)s[i])) i++;
+    }
+    bool kw(const char *k) {
+        ws();
+        size_t n = strlen(k);
+        if (i + n > s.size() || strncasecmp(s.c_str() + i, k, n) != 0) return false;
+        if (i + n < s.size() && (isalnum((unsigned char)s[i + n]) || s[i + n] == '_')) return false;
+        i += n;
+        return true;
+    }
+    bool push(const ea::FilterOp &op) {
+        if (prog.n_ops >= (uint32_t)ea::kMaxFilterOps) return err = "filter too long", false;
+        prog.ops[prog.n_ops++] = op;
+        return true;
+    }
+    bool primary() {
+        ws();
+        if (i < s.size() && s[i] == '(') {
+            i++;
+            if (!or_expr()) return false;
+            ws();
+            if (i >= s.size() || s[i] != ')') return err = "expected )", false;
+            i++;
+            return true;
+        }
+        std::string name;
+        if (i < s.size() && s[i] == '"') {
+            i++;
+            while (i < s.size() && s[i] != '"') name.push_back(s[i++]);
+            i++;
+        } else {
+            while (i < s.size() && (isalnum((unsigned char)s[i]) || s[i] == '_')) name.push_back(s[i++]);
+        }
+        if (name.empty()) return err = "expected a column name at '" + s.substr(i) + "'", false;
+        int col = -1;
+        for (size_t c = 0; c < cols.size(); c++)
+            if (strcasecmp(cols[c].name.c_str(), name.c_str()) == 0) col = (int)c;
+        if (col < 0) return err = "No field named " + name, false;
+        const std::string &fmt = cols[col].format;
+        if (fmt != "u" && fmt != "l" && fmt != "f") return err = "filters on nested column " + name + " are not supported", false;
+        ea::FilterOp op;
+        memset(&op, 0, sizeof op);
+        op.col = (uint8_t)col;
+        if (kw("IS")) {
+            bool neg = kw("NOT");
+            if (!kw("NULL")) return err = "expected NULL", false;
+            op.op = neg ? ea::kOpIsNotNull : ea::kOpIsNull;
+            return push(op);
+        }
+        ws();
+        op.op = ea::kOpCmp;
+        if (s.compare(i, 2, "!=") == 0 || s.compare(i, 2, "<>") == 0) op.cmp = ea::kNe, i += 2;
+        else if (s.compare(i, 2, "<=") == 0) op.cmp = ea::kLe, i += 2;
+        else if (s.compare(i, 2, ">=") == 0) op.cmp = ea::kGe, i += 2;
+        else if (s.compare(i, 1, "=") == 0) op.cmp = ea::kEq, i += 1;
+        else if (s.compare(i, 1, "<") == 0) op.cmp = ea::kLt, i += 1;
+        else if (s.compare(i, 1, ">") == 0) op.cmp = ea::kGt, i += 1;
+        else return err = "expected a comparison at '" + s.substr(i) + "'", false;
+        ws();
+        if (i < s.size() && s[i] == '\'') {
+            i++;
+            std::string lit;
+            for (;;) {
+                if (i >= s.size()) return err = "unterminated string literal", false;
+                if (s[i] == '\'') {
+                    if (i + 1 < s.size() && s[i + 1] == '\'') {
+                        lit.push_back('\'');
+                        i += 2;
+                        continue;
+                    }
+                    i++;
+                    break;
+                }
+                lit.push_back(s[i++]);
+            }
+            if (fmt != "u") return err = "cannot compare " + name + " with a string", false;
+            op.lit = ea::kLitStr;
+            op.str_off = (uint32_t)consts.size();
+            op.str_len = (uint32_t)lit.size();
+            consts += lit;
+        } else {
+            size_t j = i;
+            if (j < s.size() && (s[j] == '-' || s[j] == '+')) j++;
+            bool is_float = false;
+            while (j < s.size() && (isdigit((unsigned char)s[j]) || s[j] == '.' || s[j] == 'e' || s[j] == 'E' ||
+                                    ((s[j] == '-' || s[j] == '+') && (s[j - 1] == 'e' || s[j - 1] == 'E')))) {
+                if (!isdigit((unsigned char)s[j])) is_float = true;
+                j++;
+            }
+            if (j == i) return err = "expected a literal at '" + s.substr(i) + "'", false;
+            std::string num = s.substr(i, j - i);
+            i = j;
+            if (fmt == "u") return err = "cannot compare " + name + " with a number", false;
+            if (is_float) {
+                op.lit = ea::kLitFloat;
+                op.f = strtod(num.c_str(), nullptr);
+            } else {
+                op.lit = ea::kLitInt;
+                op.i = strtoll(num.c_str(), nullptr, 10);
+                op.f = (double)op.i;
+            }
+        }
+        return push(op);
+    }
+    bool and_expr() {
+        if (!primary()) return false;
+        while (kw("AND")) {
+            if (!primary()) return false;
+            ea::FilterOp op;
+            memset(&op, 0, sizeof op);
+            op.op = ea::kOpAnd;
+            if (!push(op)) return false;
+        }
+        return true;
+    }
+    bool or_expr() {
+        if (!and_expr()) return false;
+        while (kw("OR")) {
+            if (!and_expr()) return false;
+            ea::FilterOp op;
+            memset(&op, 0, sizeof op);
+            op.op = ea::kOpOr;
+            if (!push(op)) return false;
+        }
+        return true;
+    }
+    bool parse() {
+        if (!or_expr()) return false;
+        ws();
+        if (i != s.size()) return err = "unexpected '" + s.substr(i) + "'", false;
+        return true;
+    }
+};
+
+// ---- memory ------------------------------------------------------------------------------------------------------------------
+struct DevArena {  // bump allocator, reset per batch; overflow goes to hipMalloc'd extras
+    char *base = nullptr;
+    size_t cap = 0, used = 0;
+    std::vector<void *> extra;
+    void *alloc(size_t n) {
+        n = (n + 255) & ~(size_t)255;
+        if (n == 0) n = 256;
+        if (used + n <= cap) {
+            void *p = base + used;
+            used += n;
+            return p;
+        }
+        void *p = nullptr;
+        if (hipMalloc(&p, n) != hipSuccess) return nullptr;
+        extra.push_back(p);
+        return p;
+    }
+    void reset() {
+        for (void *p : extra) (void)hipFree(p);
+        extra.clear();
+        used = 0;
+    }
+    ~DevArena() {
+        reset();
+        if (base) (void)hipFree(base);
+    }
+};
+
+struct HostArena {  // pinned blocks that live as long as the Arrow batch they back
+    std::vector<std::pair<char *, size_t>> blocks;
+    size_t used = 0;
+    void *alloc(size_t n) {
+        n = (n + 63) & ~(size_t)63;
+        if (n == 0) n = 64;
+        if (blocks.empty() || used + n > blocks.back().second) {
+            size_t sz = std::max<size_t>(n, 32u << 20);
+            void *p = nullptr;
+            if (hipHostMalloc(&p, sz, hipHostMallocDefault) != hipSuccess) return nullptr;
+            blocks.emplace_back((char *)p, sz);
+            used = 0;
+        }
+        void *p = blocks.back().first + used;
+        used += n;
+        return p;
+    }
+    ~HostArena() {
+        for (auto &b : blocks) (void)hipHostFree(b.first);
+    }
+};
+
+// ---- one emitted column (host buffers of a whole device batch) ------------------------------------------------------
+struct AColumn {
+    enum Kind { kUtf8Top, kUtf8Abs, kPrim, kBool, kList, kStruct } kind = kPrim;
+    int elem_size = 0;
+    int64_t length = 0;                // elements of the batch-wide array
+    const uint8_t *validity = nullptr;  // NULL: no nulls
+    const uint8_t *offsets = nullptr;
+    const uint8_t *data = nullptr;
+    std::vector<uint64_t> chunk_base;  // kUtf8Top
+    std::vector<AColumn> children;
+};
+
+struct ABatch {
+    HostArena host;
+    std::vector<AColumn> cols;
+    uint64_t n_rows = 0;
+};
+
+struct StreamState {
+    exg_reader *r = nullptr;
+    std::vector<Field> schema;
+    std::vector<KeyDef> info_keys, format_keys;
+    bool has_filter = false;
+    ea::FilterProgram prog;
+    std::string consts;
+    void *d_consts = nullptr, *d_prog = nullptr;
+    void *d_info_names = nullptr, *d_format_names = nullptr;
+    ea::VtKeys info_vt, format_vt;
+    DevArena arena;
+    std::shared_ptr<ABatch> batch;
+    uint64_t batch_row = 0;
+    std::string last_error;
+    ~StreamState() {
+        for (void *p : {d_consts, d_prog, d_info_names, d_format_names})
+            if (p) (void)hipFree(p);
+        arena.reset();
+        delete r;
+    }
+};
+
+#define EM_HIP(expr)                                                                                     \
+    do {                                                                                                 \
+        hipError_t _e = (expr);                                                                          \
+        if (_e != hipSuccess) return fail(r, EXG_E_HIP, std::string(#expr " failed: ") + hipGetErrorString(_e)); \
+    } while (0)
+
+struct Emit {
+    exg_reader *r;
+    StreamState *st;
+    ABatch *out;
+    hipStream_t s;
+    uint64_t n;                 // output rows
+    const uint32_t *d_row_map;  // NULL: identity
+    unsigned long long *d_err;
+    int rc = 0;
+
+    void *dalloc(size_t bytes) {
+        void *p = st->arena.alloc(bytes);
+        if (!p && !rc) rc = fail(r, EXG_E_HIP, "out of device memory in the Arrow emitter");
+        return p;
+    }
+    void *halloc(size_t bytes) {
+        void *p = out->host.alloc(bytes);
+        if (!p && !rc) rc = fail(r, EXG_E_HIP, "out of pinned host memory in the Arrow emitter");
+        return p;
+    }
+    uint64_t fetch_u64(const uint64_t *d) {
+        uint64_t v = 0;
+        if (hipMemcpyAsync(&v, d, 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+            if (!rc) rc = fail(r, EXG_E_HIP, "device read failed in the Arrow emitter");
+        }
+        return v;
+    }
+    const uint8_t *to_host(const void *d, size_t bytes) {
+        void *h = halloc(bytes);
+        if (h && bytes && hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s) != hipSuccess && !rc)
+            rc = fail(r, EXG_E_HIP, "D2H copy failed in the Arrow emitter");
+        return (const uint8_t *)h;
+    }
+    static size_t bitmap_bytes(uint64_t m) { return (size_t)((m + 63) / 64) * 8; }
+
+    // validity of a row-space column whose source bitmap is indexed by scan rows
+    const uint8_t *row_validity(const uint64_t *d_src) {
+        if (!d_src) return nullptr;
+        if (!d_row_map) return to_host(d_src, bitmap_bytes(n));
+        uint64_t *d = (uint64_t *)dalloc(bitmap_bytes(n));
+        if (!d) return nullptr;
+        ea::gather_bits(d_src, d_row_map, n, d, s);
+        return to_host(d, bitmap_bytes(n));
+    }
+
+    AColumn utf8_top(const ea::StrCol &c, const uint64_t *d_valid_src) {
+        AColumn col;
+        col.kind = AColumn::kUtf8Top;
+        col.length = (int64_t)n;
+        const uint64_t B = r->batch_rows, n_chunks = (n + B - 1) / B;
+        uint64_t *d_goff = (uint64_t *)dalloc((n + 1) * 8);
+        uint64_t *d_tmp = (uint64_t *)dalloc(ea::scan_tmp_entries(n) * 8);
+        if (rc) return col;
+        ea::utf8_goff_from_col(c, d_row_map, n, d_goff, d_tmp, s);
+        const uint64_t total = fetch_u64(d_goff + n);
+        const uint32_t big_cap = (uint32_t)(total / 8192 + 1);
+        uint8_t *d_values = (uint8_t *)dalloc(total + 16);
+        uint32_t *d_big = (uint32_t *)dalloc(4 * ((size_t)big_cap + 1));
+        int32_t *d_off32 = (int32_t *)dalloc(n_chunks * (B + 1) * 4);
+        uint64_t *d_cbase = (uint64_t *)dalloc(n_chunks * 8 + 8);
+        if (rc) return col;
+        ea::utf8_copy_from_col(c, d_row_map, n, d_goff, d_values, d_big, big_cap, s);
+        ea::rebase_offsets(d_goff, n, B, d_off32, d_cbase, s);
+        col.offsets = to_host(d_off32, n_chunks * (B + 1) * 4);
+        col.data = to_host(d_values, total);
+        col.chunk_base.resize(n_chunks + 1);
+        if (n_chunks && hipMemcpyAsync(col.chunk_base.data(), d_cbase, n_chunks * 8, hipMemcpyDeviceToHost, s) != hipSuccess && !rc)
+            rc = fail(r, EXG_E_HIP, "D2H copy failed in the Arrow emitter");
+        col.chunk_base[n_chunks] = total;
+        col.validity = row_validity(d_valid_src);
+        return col;
+    }
+
+    // strings given as views; m elements; absolute int32 offsets
+    AColumn utf8_abs(const ea::View *d_views, uint64_t m, const uint8_t *h_validity) {
+        AColumn col;
+        col.kind = AColumn::kUtf8Abs;
+        col.length = (int64_t)m;
+        col.validity = h_validity;
+        uint64_t *d_goff = (uint64_t *)dalloc((m + 1) * 8);
+        uint64_t *d_tmp = (uint64_t *)dalloc(ea::scan_tmp_entries(m) * 8);
+        if (rc) return col;
+        ea::utf8_goff_from_views(d_views, m, d_goff, d_tmp, s);
+        const uint64_t total = fetch_u64(d_goff + m);
+        if (total >= (1ull << 31)) {
+            if (!rc) rc = fail(r, EXG_E_CAPACITY, "a nested string column exceeds Arrow's int32 offsets in one device batch");
+            return col;
+        }
+        const uint32_t big_cap = (uint32_t)(total / 8192 + 1);
+        uint8_t *d_values = (uint8_t *)dalloc(total + 16);
+        uint32_t *d_big = (uint32_t *)dalloc(4 * ((size_t)big_cap + 1));
+        int32_t *d_off32 = (int32_t *)dalloc((m + 1) * 4);
+        if (rc) return col;
+        ea::utf8_copy_from_views(d_views, m, d_goff, d_values, d_big, big_cap, s);
+        ea::narrow_offsets(d_goff, m, d_off32, s);
+        col.offsets = to_host(d_off32, (m + 1) * 4);
+        col.data = to_host(d_values, total);
+        return col;
+    }
+
+    // List<Utf8> out of a raw column split on `sep`
+    AColumn list_of_strings(const ea::StrCol &c, uint8_t sep) {
+        AColumn col;
+        col.kind = AColumn::kList;
+        col.length = (int64_t)n;
+        uint64_t *d_goff = (uint64_t *)dalloc((n + 1) * 8);
+        uint64_t *d_tmp = (uint64_t *)dalloc(ea::scan_tmp_entries(n) * 8);
+        if (rc) return col;
+        ea::list_counts(c, d_row_map, n, sep, d_goff, d_tmp, s);
+        const uint64_t total = fetch_u64(d_goff + n);
+        if (total >= (1ull << 31)) {
+            if (!rc) rc = fail(r, EXG_E_CAPACITY, "a list column exceeds Arrow's int32 offsets in one device batch");
+            return col;
+        }
+        ea::View *d_views = (ea::View *)dalloc(total * sizeof(ea::View));
+        int32_t *d_off32 = (int32_t *)dalloc((n + 1) * 4);
+        if (rc) return col;
+        ea::list_views(c, d_row_map, n, sep, d_goff, d_views, s);
+        ea::narrow_offsets(d_goff, n, d_off32, s);
+        col.offsets = to_host(d_off32, (n + 1) * 4);
+        col.children.push_back(utf8_abs(d_views, total, nullptr));
+        return col;
+    }
+
+    // the typed children of INFO (elements = output rows) or FORMAT (elements = samples)
+    std::vector<AColumn> cell_children(const std::vector<KeyDef> &keys, ea::CellSrc src, uint64_t m, uint32_t err_code) {
+        std::vector<AColumn> kids;
+        for (size_t k = 0; k < keys.size() && !rc; k++) {
+            src.key = (uint32_t)k;
+            const KeyDef &kd = keys[k];
+            AColumn col;
+            col.length = (int64_t)m;
+            uint64_t *d_valid = (uint64_t *)dalloc(bitmap_bytes(m));
+            if (rc) break;
+            if (!kd.is_list) {
+                if (kd.type == ea::kVtInt || kd.type == ea::kVtFloat) {
+                    void *d_vals = dalloc(m * 4);
+                    if (rc) break;
+                    if (kd.type == ea::kVtInt)
+                        ea::cells_to_i32(src, m, (int32_t *)d_vals, d_valid, d_err, err_code, s);
+                    else
+                        ea::cells_to_f32(src, m, (float *)d_vals, d_valid, d_err, err_code, s);
+                    col.kind = AColumn::kPrim;
+                    col.elem_size = 4;
+                    col.data = to_host(d_vals, m * 4);
+                    col.validity = to_host(d_valid, bitmap_bytes(m));
+                } else if (kd.type == ea::kVtFlag) {
+                    uint64_t *d_bits = (uint64_t *)dalloc(bitmap_bytes(m));
+                    if (rc) break;
+                    ea::cells_to_flag(src, m, d_bits, d_valid, s);
+                    col.kind = AColumn::kBool;
+                    col.data = to_host(d_bits, bitmap_bytes(m));
+                    col.validity = to_host(d_valid, bitmap_bytes(m));
+                } else {
+                    ea::View *d_views = (ea::View *)dalloc(m * sizeof(ea::View));
+                    if (rc) break;
+                    ea::cells_to_views(src, m, d_views, d_valid, s);
+                    col = utf8_abs(d_views, m, to_host(d_valid, bitmap_bytes(m)));
+                }
+            } else {
+                uint64_t *d_goff = (uint64_t *)dalloc((m + 1) * 8);
+                uint64_t *d_tmp = (uint64_t *)dalloc(ea::scan_tmp_entries(m) * 8);
+                if (rc) break;
+                ea::cells_list_counts(src, m, d_goff, d_tmp, d_valid, s);
+                const uint64_t total = fetch_u64(d_goff + m);
+                if (total >= (1ull << 31)) {
+                    rc = fail(r, EXG_E_CAPACITY, "a list column exceeds Arrow's int32 offsets in one device batch");
+                    break;
+                }
+                col.kind = AColumn::kList;
+                int32_t *d_off32 = (int32_t *)dalloc((m + 1) * 4);
+                uint32_t *d_cv = (uint32_t *)dalloc(bitmap_bytes(total));
+                if (rc) break;
+                ea::narrow_offsets(d_goff, m, d_off32, s);
+                (void)hipMemsetAsync(d_cv, 0, bitmap_bytes(total), s);
+                col.offsets = to_host(d_off32, (m + 1) * 4);
+                col.validity = to_host(d_valid, bitmap_bytes(m));
+                AColumn child;
+                child.length = (int64_t)total;
+                if (kd.type == ea::kVtInt || kd.type == ea::kVtFloat) {
+                    void *d_vals = dalloc(total * 4);
+                    if (rc) break;
+                    if (kd.type == ea::kVtInt)
+                        ea::cells_list_i32(src, m, d_goff, (int32_t *)d_vals, d_cv, d_err, err_code, s);
+                    else
+                        ea::cells_list_f32(src, m, d_goff, (float *)d_vals, d_cv, d_err, err_code, s);
+                    child.kind = AColumn::kPrim;
+                    child.elem_size = 4;
+                    child.data = to_host(d_vals, total * 4);
+                    child.validity = to_host(d_cv, bitmap_bytes(total));
+                } else {
+                    ea::View *d_views = (ea::View *)dalloc(total * sizeof(ea::View));
+                    if (rc) break;
+                    ea::cells_list_views(src, m, d_goff, d_views, d_cv, s);
+                    child = utf8_abs(d_views, total, to_host(d_cv, bitmap_bytes(total)));
+                }
+                col.children.push_back(std::move(child));
+            }
+            kids.push_back(std::move(col));
+        }
+        return kids;
+    }
+};
+
+int upload_keys(exg_reader *r, const std::vector<KeyDef> &keys, ea::VtKeys *vt, void **d_names) {
+    if (keys.size() > (size_t)ea::kMaxVtKeys)
+        return fail(r, EXG_E_UNSUPPORTED, "VCF header declares more than " + std::to_string(ea::kMaxVtKeys) + " INFO or FORMAT keys");
+    std::string names;
+    vt->n = (uint32_t)keys.size();
+    for (size_t k = 0; k < keys.size(); k++) {
+        vt->k[k].name_off = (uint32_t)names.size();
+        vt->k[k].name_len = (uint32_t)keys[k].id.size();
+        vt->k[k].type = keys[k].type;
+        vt->k[k].is_list = keys[k].is_list;
+        names += keys[k].id;
+    }
+    EM_HIP(hipMalloc(d_names, names.size() + 16));
+    if (!names.empty()) EM_HIP(hipMemcpy(*d_names, names.data(), names.size(), hipMemcpyHostToDevice));
+    vt->d_names = (const uint8_t *)*d_names;
+    return EXG_OK;
+}
+
+// Called by next_batch with the scan's columns still in HBM.
+int arrow_emit(exg_reader *r, const ScanCtx &ctx) {
+    StreamState *st = (StreamState *)r->arrow_state.get();
+    st->arena.reset();
+    if (!st->arena.base) {
+        // sized for the typical batch: offsets + values + views of every column; anything beyond goes to hipMalloc
+        size_t cap = (size_t)std::min<uint64_t>(r->d_in_cap * 3 + (64u << 20), 6ull << 30);
+        if (hipMalloc((void **)&st->arena.base, cap) == hipSuccess) st->arena.cap = cap;
+    }
+    auto batch = std::make_shared<ABatch>();
+    Emit em;
+    em.r = r;
+    em.st = st;
+    em.out = batch.get();
+    em.s = r->stream;
+    em.n = ctx.n_records;
+    em.d_row_map = nullptr;
+    const uint8_t *d_base = (const uint8_t *)ctx.d_input;
+    const uint64_t pb = (uint64_t)(uintptr_t)ctx.h;
+    auto str_col = [&](int c) {
+        ea::StrCol sc{(const exg_string_t *)r->d_cols[c], d_base, pb};
+        if (r->format == EXG_FMT_FASTA && c == 2) {
+            sc.d_base = (const uint8_t *)r->d_payload;
+            sc.payload_base = (uint64_t)(uintptr_t)ctx.h_seq_payload;
+        }
+        return sc;
+    };
+    em.d_err = (unsigned long long *)em.dalloc(8);
+    if (em.rc) return em.rc;
+    EM_HIP(hipMemsetAsync(em.d_err, 0xFF, 8, r->stream));
+
+    if (st->has_filter) {
+        ea::FilterCols fc;
+        memset(&fc, 0, sizeof fc);
+        for (size_t c = 0; c < st->schema.size() && c < (size_t)ea::kMaxFilterCols; c++) {
+            const std::string &f = st->schema[c].format;
+            ea::StrCol sc = str_col((int)c);
+            fc.kind[c] = f == "l" ? ea::kColI64 : f == "f" ? ea::kColF32 : ea::kColStr;
+            fc.data[c] = f == "l" ? r->d_pos : f == "f" ? r->d_qual : (const void *)sc.d_col;
+            fc.d_base[c] = sc.d_base;
+            fc.payload_base[c] = sc.payload_base;
+            fc.validity[c] = nullptr;
+        }
+        if (r->format == EXG_FMT_VCF)
+            fc.validity[5] = (const uint64_t *)r->d_valid[0];
+        else
+            fc.validity[1] = (const uint64_t *)r->d_valid[0];
+        uint64_t *d_goff = (uint64_t *)em.dalloc((em.n + 1) * 8);
+        uint64_t *d_tmp = (uint64_t *)em.dalloc(ea::scan_tmp_entries(em.n) * 8);
+        uint32_t *d_map = (uint32_t *)em.dalloc(em.n * 4 + 4);
+        if (em.rc) return em.rc;
+        ea::FilterCols *d_fc = (ea::FilterCols *)em.dalloc(sizeof fc);
+        if (em.rc) return em.rc;
+        EM_HIP(hipMemcpyAsync(d_fc, &fc, sizeof fc, hipMemcpyHostToDevice, r->stream));
+        EM_HIP(hipStreamSynchronize(r->stream));  // fc is a stack object
+        ea::filter_rows((const ea::FilterProgram *)st->d_prog, d_fc, (const uint8_t *)st->d_consts, em.n, d_goff, d_tmp, d_map,
+                        r->stream);
+        em.n = em.fetch_u64(d_goff + ctx.n_records);
+        em.d_row_map = d_map;
+        if (em.rc) return em.rc;
+    }
+    const uint64_t n = em.n;
+    if (n == 0) {
+        st->batch.reset();
+        st->batch_row = 0;
+        return EXG_OK;
+    }
+    std::vector<AColumn> &cols = batch->cols;
+    if (r->format == EXG_FMT_FASTQ || r->format == EXG_FMT_FASTA) {
+        const int nc = r->format == EXG_FMT_FASTQ ? 4 : 3;
+        for (int c = 0; c < nc && !em.rc; c++)
+            cols.push_back(em.utf8_top(str_col(c), c == 1 ? (const uint64_t *)r->d_valid[0] : nullptr));
+    } else {
+        auto prim = [&](const void *d_src, int es, const uint64_t *d_valid_src) {
+            AColumn col;
+            col.kind = AColumn::kPrim;
+            col.elem_size = es;
+            col.length = (int64_t)n;
+            const void *d = d_src;
+            if (em.d_row_map) {
+                void *g = em.dalloc(n * es);
+                if (em.rc) return col;
+                if (es == 8)
+                    ea::gather_u64((const uint64_t *)d_src, em.d_row_map, n, (uint64_t *)g, r->stream);
+                else
+                    ea::gather_u32((const uint32_t *)d_src, em.d_row_map, n, (uint32_t *)g, r->stream);
+                d = g;
+            }
+            col.data = em.to_host(d, n * es);
+            col.validity = em.row_validity(d_valid_src);
+            return col;
+        };
+        cols.push_back(em.utf8_top(str_col(0), nullptr));                              // chrom
+        cols.push_back(prim(r->d_pos, 8, nullptr));                                     // pos
+        cols.push_back(em.list_of_strings(str_col(2), ';'));                            // id
+        cols.push_back(em.utf8_top(str_col(3), nullptr));                              // ref
+        cols.push_back(em.list_of_strings(str_col(4), ','));                            // alt
+        cols.push_back(prim(r->d_qual, 4, (const uint64_t *)r->d_valid[0]));            // qual
+        cols.push_back(em.list_of_strings(str_col(6), ';'));                            // filter
+        if (em.rc) return em.rc;
+        {  // info
+            AColumn info;
+            info.kind = AColumn::kStruct;
+            info.length = (int64_t)n;
+            const uint32_t K = st->info_vt.n;
+            if (K) {
+                ea::VtCell *d_cells = (ea::VtCell *)em.dalloc((size_t)n * K * sizeof(ea::VtCell));
+                if (em.rc) return em.rc;
+                ea::info_cells(str_col(7), em.d_row_map, n, st->info_vt, d_cells, r->stream);
+                ea::CellSrc src{d_cells, K, 0, str_col(7), em.d_row_map, nullptr, nullptr};
+                info.children = em.cell_children(st->info_keys, src, n, EXG_PE_VCF_INFO);
+            }
+            cols.push_back(std::move(info));
+        }
+        if (em.rc) return em.rc;
+        {  // formats
+            AColumn fl;
+            fl.kind = AColumn::kList;
+            fl.length = (int64_t)n;
+            uint64_t *d_goff = (uint64_t *)em.dalloc((n + 1) * 8);
+            uint64_t *d_tmp = (uint64_t *)em.dalloc(ea::scan_tmp_entries(n) * 8);
+            if (em.rc) return em.rc;
+            ea::sample_counts(str_col(8), (const uint64_t *)r->d_valid[1], em.d_row_map, n, d_goff, d_tmp, r->stream);
+            const uint64_t S = em.fetch_u64(d_goff + n);
+            if (S >= (1ull << 31)) return fail(r, EXG_E_CAPACITY, "formats exceeds Arrow's int32 offsets in one device batch");
+            int32_t *d_off32 = (int32_t *)em.dalloc((n + 1) * 4);
+            if (em.rc) return em.rc;
+            ea::narrow_offsets(d_goff, n, d_off32, r->stream);
+            fl.offsets = em.to_host(d_off32, (n + 1) * 4);
+            AColumn item;
+            item.kind = AColumn::kStruct;
+            item.length = (int64_t)S;
+            const uint32_t K = st->format_vt.n;
+            if (K) {
+                ea::VtCell *d_cells = (ea::VtCell *)em.dalloc((size_t)S * K * sizeof(ea::VtCell));
+                ea::View *d_fields = (ea::View *)em.dalloc((size_t)S * sizeof(ea::View));
+                uint32_t *d_srow = (uint32_t *)em.dalloc((size_t)S * 4);
+                if (em.rc) return em.rc;
+                ea::sample_cells(str_col(8), em.d_row_map, n, d_goff, st->format_vt, d_cells, d_fields, d_srow, r->stream);
+                ea::CellSrc src{d_cells, K, 0, ea::StrCol{nullptr, nullptr, 0}, nullptr, d_fields, d_srow};
+                item.children = em.cell_children(st->format_keys, src, S, EXG_PE_VCF_FORMAT);
+            }
+            fl.children.push_back(std::move(item));
+            cols.push_back(std::move(fl));
+        }
+    }
+    if (em.rc) return em.rc;
+    const uint64_t err = em.fetch_u64((const uint64_t *)em.d_err);  // also drains the D2H copies
+    if (em.rc) return em.rc;
+    EM_HIP(hipStreamSynchronize(r->stream));
+    uint64_t n_rows = n;
+    if (err != ~0ull) {
+        // a typed value did not parse: rows before it are delivered, then the error (like the scan's own errors)
+        n_rows = err >> 8;
+        if (!r->pending_error) {
+            r->pending_error = (uint32_t)(err & 0xFF);
+            r->pending_error_offset = 0;
+        }
+    }
+    for (AColumn &c : cols)
+        if (c.kind == AColumn::kUtf8Top) {
+            const uint64_t B = r->batch_rows;
+            for (size_t k = 0; k + 1 < c.chunk_base.size(); k++)
+                if (c.chunk_base[k + 1] - c.chunk_base[k] >= (1ull << 31) && k * B < n_rows)
+                    return fail(r, EXG_E_CAPACITY, "a record batch holds more than 2 GiB of one string column (Arrow Utf8 offsets are int32)");
+        }
+    batch->n_rows = n_rows;
+    st->batch = n_rows ? batch : nullptr;
+    st->batch_row = 0;
+    return EXG_OK;
+}
+
+// ---- ArrowSchema / ArrowArray export -------------------------------------------------------------------------------------
+struct SchemaPriv {
+    std::string name, format;
+    std::vector<ArrowSchema> kids;
+    std::vector<ArrowSchema *> kid_ptrs;
+};
+void release_schema(ArrowSchema *s) {
+    if (!s || !s->release) return;
+    for (int64_t i = 0; i < s->n_children; i++)
+        if (s->children[i]->release) s->children[i]->release(s->children[i]);
+    delete (SchemaPriv *)s->private_data;
+    s->release = nullptr;
+}
+void export_field(const Field &f, ArrowSchema *out) {
+    auto *p = new SchemaPriv();
+    p->name = f.name;
+    p->format = f.format;
+    p->kids.resize(f.children.size());
+    p->kid_ptrs.resize(f.children.size());
+    for (size_t i = 0; i < f.children.size(); i++) {
+        export_field(f.children[i], &p->kids[i]);
+        p->kid_ptrs[i] = &p->kids[i];
+    }
+    memset(out, 0, sizeof *out);
+    out->format = p->format.c_str();
+    out->name = p->name.c_str();
+    out->flags = f.nullable ? ARROW_FLAG_NULLABLE : 0;
+    out->n_children = (int64_t)f.children.size();
+    out->children = p->kid_ptrs.empty() ? nullptr : p->kid_ptrs.data();
+    out->release = release_schema;
+    out->private_data = p;
+}
+
+struct ArrayPriv {
+    std::shared_ptr<ABatch> keep;
+    const void *buffers[3] = {nullptr, nullptr, nullptr};
+    std::vector<ArrowArray> kids;
+    std::vector<ArrowArray *> kid_ptrs;
+};
+void release_array(ArrowArray *a) {
+    if (!a || !a->release) return;
+    for (int64_t i = 0; i < a->n_children; i++)
+        if (a->children[i]->release) a->children[i]->release(a->children[i]);
+    delete (ArrayPriv *)a->private_data;
+    a->release = nullptr;
+}
+// rows [row0, row0 + len) of a row-space column (chunk = row0 / batch_rows), or the whole array of a child
+void export_column(const AColumn &c, bool row_space, uint64_t row0, uint64_t len, uint64_t chunk, uint64_t batch_rows,
+                   const std::shared_ptr<ABatch> &keep, ArrowArray *out) {
+    auto *p = new ArrayPriv();
+    p->keep = keep;
+    memset(out, 0, sizeof *out);
+    const uint64_t r0 = row_space ? row0 : 0;
+    out->length = (int64_t)(row_space ? len : (uint64_t)c.length);
+    out->null_count = c.validity ? -1 : 0;
+    out->offset = 0;
+    p->buffers[0] = c.validity ? c.validity + r0 / 8 : nullptr;
+    switch (c.kind) {
+        case AColumn::kUtf8Top:
+            out->n_buffers = 3;
+            p->buffers[1] = c.offsets + chunk * (batch_rows + 1) * 4;
+            p->buffers[2] = c.data + c.chunk_base[chunk];
+            break;
+        case AColumn::kUtf8Abs:
+            out->n_buffers = 3;
+            p->buffers[1] = c.offsets + r0 * 4;
+            p->buffers[2] = c.data;
+            break;
+        case AColumn::kPrim:
+            out->n_buffers = 2;
+            p->buffers[1] = c.data + r0 * c.elem_size;
+            break;
+        case AColumn::kBool:
+            out->n_buffers = 2;
+            p->buffers[1] = c.data + r0 / 8;
+            break;
+        case AColumn::kList:
+            out->n_buffers = 2;
+            p->buffers[1] = c.offsets + r0 * 4;
+            break;
+        case AColumn::kStruct:
+            out->n_buffers = 1;
+            break;
+    }
+    const bool kids_row_space = row_space && c.kind == AColumn::kStruct;
+    p->kids.resize(c.children.size());
+    p->kid_ptrs.resize(c.children.size());
+    for (size_t i = 0; i < c.children.size(); i++) {
+        export_column(c.children[i], kids_row_space, row0, len, chunk, batch_rows, keep, &p->kids[i]);
+        p->kid_ptrs[i] = &p->kids[i];
+    }
+    out->n_children = (int64_t)c.children.size();
+    out->children = p->kid_ptrs.empty() ? nullptr : p->kid_ptrs.data();
+    out->buffers = p->buffers;
+    out->release = release_array;
+    out->private_data = p;
+}
+
+// ---- the stream -----------------------------------------------------------------------------------------------------------
+int stream_get_schema(ArrowArrayStream *s, ArrowSchema *out) {
+    StreamState *st = (StreamState *)s->private_data;
+    Field root;
+    root.format = "+s";
+    root.nullable = false;
+    root.children = st->schema;
+    export_field(root, out);
+    return 0;
+}
+
+int stream_get_next(ArrowArrayStream *s, ArrowArray *out) {
+    StreamState *st = (StreamState *)s->private_data;
+    exg_reader *r = st->r;
+    memset(out, 0, sizeof *out);
+    for (;;) {
+        if (st->batch && st->batch_row < st->batch->n_rows) {
+            const uint64_t row0 = st->batch_row, B = r->batch_rows;
+            const uint64_t len = std::min<uint64_t>(B, st->batch->n_rows - row0);
+            auto *p = new ArrayPriv();
+            p->keep = st->batch;
+            const size_t nc = st->batch->cols.size();
+            p->kids.resize(nc);
+            p->kid_ptrs.resize(nc);
+            for (size_t c = 0; c < nc; c++) {
+                export_column(st->batch->cols[c], true, row0, len, row0 / B, B, st->batch, &p->kids[c]);
+                p->kid_ptrs[c] = &p->kids[c];
+            }
+            out->length = (int64_t)len;
+            out->null_count = 0;
+            out->n_buffers = 1;
+            out->buffers = p->buffers;
+            out->n_children = (int64_t)nc;
+            out->children = p->kid_ptrs.data();
+            out->release = release_array;
+            out->private_data = p;
+            st->batch_row += len;
+            return 0;
+        }
+        st->batch.reset();
+        if (r->pending_error) {
+            st->last_error = std::string(exg_parse_error_string(r->pending_error)) + " in " + r->files[r->file_idx - 1];
+            r->pending_error = 0;
+            r->file_done = true;
+            r->file_idx = r->files.size();
+            return EIO;
+        }
+        if (r->file_done) {
+            if (r->file_idx >= r->files.size()) return 0;  // out->release == NULL: end of stream
+            if (open_next_file(r)) {
+                st->last_error = r->error;
+                return EIO;
+            }
+        }
+        uint64_t k;
+        if (next_batch(r, false, &k)) {
+            st->last_error = r->error;
+            return EIO;
+        }
+    }
+}
+
+const char *stream_last_error(ArrowArrayStream *s) {
+    StreamState *st = (StreamState *)s->private_data;
+    return st->last_error.empty() ? nullptr : st->last_error.c_str();
+}
+
+void stream_release(ArrowArrayStream *s) {
+    if (!s || !s->release) return;
+    StreamState *st = (StreamState *)s->private_data;
+    st->batch.reset();
+    std::shared_ptr<void> last = std::move(st->r->arrow_state);
+    last.reset();  // deletes st, and the reader with it
+    s->release = nullptr;
+}
+
+ReaderResult result_error(const std::string &msg) {
+    ReaderResult rr;
+    rr.error = strdup(msg.c_str());
+    return rr;
+}
+
+}  // namespace
+
+extern "C" ReaderResult new_reader(ArrowArrayStream *stream_ptr, const char *uri, uintptr_t batch_size, const char *compression,
+                                   const char *file_format, const char *filters) {
+    if (!stream_ptr || !uri || !file_format) return result_error("new_reader: null argument");
+    exg_open_args oa;
+    memset(&oa, 0, sizeof oa);
+    oa.path = uri;
+    oa.file_format = file_format;
+    oa.compression = compression;
+    oa.batch_rows = batch_size;
+    exg_reader *r = nullptr;
+    int rc = exg_open(&oa, &r);
+    if (rc) {
+        std::string m = exg_last_error_message();
+        // arrow_reader.rs:93-102 / :118-123
+        if (m.rfind("could not", 0) != 0) m = "could not register table: " + m;
+        return result_error(m);
+    }
+    auto st = std::make_shared<StreamState>();
+    st->r = r;
+    // the schema needs the first file (VCF: its header), like register_exon_table (arrow_reader.rs:118-123)
+    if (open_next_file(r)) return result_error("could not register table: " + r->error);
+    auto utf8 = [](const char *name, bool nullable) {
+        Field f;
+        f.name = name;
+        f.format = "u";
+        f.nullable = nullable;
+        return f;
+    };
+    if (r->format == EXG_FMT_FASTQ) {
+        st->schema = {utf8("name", false), utf8("description", true), utf8("sequence", false), utf8("quality_scores", false)};
+    } else if (r->format == EXG_FMT_FASTA) {
+        st->schema = {utf8("id", false), utf8("description", true), utf8("sequence", false)};
+    } else {
+        parse_vcf_header((const char *)r->file->p, (size_t)r->vcf_header_bytes, &st->info_keys, &st->format_keys);
+        auto list_utf8 = [&](const char *name) {
+            Field f;
+            f.name = name;
+            f.format = "+l";
+            Field item = utf8("item", true);
+            f.children.push_back(item);
+            return f;
+        };
+        Field pos, qual, info, formats, item;
+        pos.name = "pos", pos.format = "l", pos.nullable = false;
+        qual.name = "qual", qual.format = "f";
+        info.name = "info", info.format = "+s";
+        for (auto &k : st->info_keys) info.children.push_back(key_field(k));
+        item.name = "item", item.format = "+s";
+        for (auto &k : st->format_keys) item.children.push_back(key_field(k));
+        formats.name = "formats", formats.format = "+l";
+        formats.children.push_back(item);
+        st->schema = {utf8("chrom", false), pos, list_utf8("id"), utf8("ref", false), list_utf8("alt"), qual,
+                      list_utf8("filter"), info, formats};
+        if ((rc = upload_keys(r, st->info_keys, &st->info_vt, &st->d_info_names)) ||
+            (rc = upload_keys(r, st->format_keys, &st->format_vt, &st->d_format_names)))
+            return result_error("could not register table: " + r->error);
+    }
+    if (filters && *filters) {
+        // `SELECT * FROM exon_table WHERE <filters>` (arrow_reader.rs:125-141)
+        std::string text = filters;
+        FilterParser fp(text, st->schema);
+        if (!fp.parse()) return result_error("could not execute sql: " + fp.err);
+        st->has_filter = true;
+        st->prog = fp.prog;
+        st->consts = fp.consts;
+        if (hipMalloc(&st->d_consts, st->consts.size() + 16) != hipSuccess ||
+            hipMalloc(&st->d_prog, sizeof(ea::FilterProgram)) != hipSuccess ||
+            hipMemcpy(st->d_prog, &st->prog, sizeof(ea::FilterProgram), hipMemcpyHostToDevice) != hipSuccess ||
+            (!st->consts.empty() &&
+             hipMemcpy(st->d_consts, st->consts.data(), st->consts.size(), hipMemcpyHostToDevice) != hipSuccess))
+            return result_error("could not execute sql: device allocation failed");
+    }
+    r->arrow_emit = arrow_emit;
+    // the reader is owned by the stream state from here on
+    std::shared_ptr<StreamState> owned = st;
+    r->arrow_state = std::shared_ptr<void>(owned, owned.get());
+    stream_ptr->get_schema = stream_get_schema;
+    stream_ptr->get_next = stream_get_next;
+    stream_ptr->get_last_error = stream_last_error;
+    stream_ptr->release = stream_release;
+    stream_ptr->private_data = owned.get();
+    ReaderResult ok;
+    ok.error = nullptr;
+    return ok;
+}

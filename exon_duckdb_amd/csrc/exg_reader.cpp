@@ -29,41 +29,20 @@
 #include <thread>
 #include <vector>
 
-#include "exg_common.hpp"
+#include "exg_reader.hpp"
 
-namespace {
+namespace exg_rd {
 
-struct PinnedBlock {  // host memory: pinned (hipHostMalloc) or a read-only file mapping
-    void *p = nullptr;
-    size_t n = 0;
-    size_t mapped = 0;  // != 0: p is an mmap of that many bytes
-    ~PinnedBlock() {
-        if (!p) return;
-        if (mapped)
-            munmap(p, mapped);
-        else
-            (void)hipHostFree(p);
-    }
-};
-
-struct Batch {  // host vectors of one device batch, shared by its chunks
-    std::shared_ptr<PinnedBlock> file;
-    int n_cols = 0;
-    PinnedBlock cols[9];
-    uint32_t elem[9] = {16, 16, 16, 16, 16, 16, 16, 16, 16};  // bytes per row
-    PinnedBlock validity[9];                                     // empty => all rows valid
-    PinnedBlock payload;                                         // FASTA: compacted sequences
-    uint64_t n_rows = 0;
-};
-
-struct ChunkKeep {
-    std::shared_ptr<Batch> batch;
-};
-
-enum Compression { kNone, kGzip, kZstd, kBzip2, kXz };
+PinnedBlock::~PinnedBlock() {
+    if (!p) return;
+    if (mapped)
+        munmap(p, mapped);
+    else
+        (void)hipHostFree(p);
+}
 
 // DataFusion 28 FileCompressionType::from_str as used at rust/src/arrow_reader.rs:87-88
-bool parse_compression(const std::string &s, Compression *out) {
+static bool parse_compression(const std::string &s, Compression *out) {
     std::string u;
     for (char ch : s) u.push_back((char)toupper((unsigned char)ch));
     if (u == "GZIP" || u == "GZ") return *out = kGzip, true;
@@ -74,61 +53,25 @@ bool parse_compression(const std::string &s, Compression *out) {
     return false;
 }
 
-}  // namespace
+}  // namespace exg_rd
 
-struct exg_reader {
-    int format = 0;
-    Compression compression = kNone;
-    std::vector<std::string> files;
-    size_t file_idx = 0;
-    uint64_t batch_rows = EXG_VECTOR_SIZE;
-    uint64_t device_batch_bytes = 256ull << 20;
-    int device = 0;
-    std::string error;
-    hipStream_t stream = nullptr;
+exg_reader::FdCloser::~FdCloser() {
+    if (fd >= 0) close(fd);
+}
+void exg_reader::free_device() {
+    for (void **p : {&d_in, &d_ws, &d_valid[0], &d_valid[1], &d_pos, &d_qual, &d_payload})
+        if (*p) (void)hipFree(*p), *p = nullptr;
+    for (void *&p : d_cols)
+        if (p) (void)hipFree(p), p = nullptr;
+}
+exg_reader::~exg_reader() {
+    free_device();
+    if (d_res) (void)hipFree(d_res);
+    if (d_file) (void)hipFree(d_file);
+    if (stream) (void)hipStreamDestroy(stream);
+}
 
-    // current file
-    std::shared_ptr<PinnedBlock> file;
-    uint64_t file_pos = 0;  // first byte not yet consumed by a complete record
-    bool file_done = true;
-
-    // device buffers (sized for device_batch_bytes)
-    void *d_in = nullptr, *d_ws = nullptr, *d_res = nullptr;
-    void *d_valid[2] = {nullptr, nullptr};
-    void *d_cols[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    void *d_pos = nullptr, *d_qual = nullptr, *d_payload = nullptr;
-    uint64_t d_in_cap = 0, ws_bytes = 0, cap_records = 0;
-    uint64_t vcf_header_bytes = 0;
-    struct FdCloser {
-        int fd;
-        ~FdCloser() { if (fd >= 0) close(fd); }
-    };
-    std::unique_ptr<FdCloser> fd_keep;  // current file (pread source of the bounce buffer)
-    PinnedBlock staging;     // pinned bounce buffer for H2D (the file itself is only mapped)
-    void *d_file = nullptr;  // gzip input: the inflated bytes live here and are scanned in place
-    uint64_t d_file_bytes = 0;
-
-    // current batch
-    std::shared_ptr<Batch> batch;
-    uint64_t batch_row = 0;
-    uint32_t pending_error = 0;  // parse error to raise once the rows before it have been handed out
-    uint64_t pending_error_offset = 0;
-
-    void free_device() {
-        for (void **p : {&d_in, &d_ws, &d_valid[0], &d_valid[1], &d_pos, &d_qual, &d_payload})
-            if (*p) (void)hipFree(*p), *p = nullptr;
-        for (void *&p : d_cols)
-            if (p) (void)hipFree(p), p = nullptr;
-    }
-    ~exg_reader() {
-        free_device();
-        if (d_res) (void)hipFree(d_res);
-        if (d_file) (void)hipFree(d_file);
-        if (stream) (void)hipStreamDestroy(stream);
-    }
-};
-
-namespace {
+namespace exg_rd {
 
 int fail(exg_reader *r, int code, const std::string &msg) {
     r->error = msg;
@@ -506,7 +449,16 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         }
         const uint64_t k = res.n_records;
         *n_records_out = k;
-        if (k && !count_only) {
+        if (r->arrow_emit && !count_only) {
+            // new_reader: the columns stay in HBM and become Arrow buffers there (exg_arrow_stream.cpp)
+            ScanCtx ctx;
+            ctx.d_input = d_input;
+            ctx.h = h;
+            ctx.n_records = k;
+            ctx.res = res;
+            ctx.h_seq_payload = b ? (const uint8_t *)b->payload.p : nullptr;
+            if (k && (rc = r->arrow_emit(r, ctx))) return rc;
+        } else if (k && !count_only) {
             if (!b) b = std::make_shared<Batch>();
             b->file = r->file;
             b->n_rows = k;
@@ -549,7 +501,9 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
     }
 }
 
-}  // namespace
+}  // namespace exg_rd
+
+using namespace exg_rd;
 
 extern "C" int exg_open(const exg_open_args *args, exg_reader **out) {
     if (!args || !out || !args->path || !args->file_format) {

@@ -75,6 +75,8 @@ extern "C" {
 #define EXG_PE_VCF_BAD_QUAL 10        /* QUAL is neither '.' nor a float */
 #define EXG_PE_VCF_NO_HEADER 11       /* no '#CHROM' header line */
 #define EXG_PE_FIELD_TOO_LONG 12      /* a field exceeds 2^32-1 bytes (string_t length is u32) */
+#define EXG_PE_VCF_INFO 13            /* an INFO value does not parse as the type its ##INFO line declares */
+#define EXG_PE_VCF_FORMAT 14          /* a sample value does not parse as the type its ##FORMAT line declares */
 
 /* ---- duckdb::string_t, bit-for-bit (v0.8.1 duckdb/common/types/string_type.hpp)
  * length <= 12: bytes inlined, zero padded.  Otherwise 4-byte prefix + pointer.
@@ -295,6 +297,66 @@ typedef struct ReplacementScanResult {
 /* exon/include/rust.hpp:48, rust/src/arrow_reader.rs:173-197: last extension, skipping one
  * compression extension (gz, gzip, zst, zstd, bz2, bzip2, xz). */
 ReplacementScanResult replacement_scan(const char *uri);
+
+/* The Arrow C data / stream interface (the published ABI the reference exchanges batches through:
+ * `struct ArrowArrayStream stream;` at exon/src/exon/arrow_table_function/module.cpp:82, 228). */
+#ifndef ARROW_C_DATA_INTERFACE
+#define ARROW_C_DATA_INTERFACE
+#define ARROW_FLAG_DICTIONARY_ORDERED 1
+#define ARROW_FLAG_NULLABLE 2
+#define ARROW_FLAG_MAP_KEYS_SORTED 4
+struct ArrowSchema {
+    const char *format;
+    const char *name;
+    const char *metadata;
+    int64_t flags;
+    int64_t n_children;
+    struct ArrowSchema **children;
+    struct ArrowSchema *dictionary;
+    void (*release)(struct ArrowSchema *);
+    void *private_data;
+};
+struct ArrowArray {
+    int64_t length;
+    int64_t null_count;
+    int64_t offset;
+    int64_t n_buffers;
+    int64_t n_children;
+    const void **buffers;
+    struct ArrowArray **children;
+    struct ArrowArray *dictionary;
+    void (*release)(struct ArrowArray *);
+    void *private_data;
+};
+#endif
+#ifndef ARROW_C_STREAM_INTERFACE
+#define ARROW_C_STREAM_INTERFACE
+struct ArrowArrayStream {
+    int (*get_schema)(struct ArrowArrayStream *, struct ArrowSchema *out);
+    int (*get_next)(struct ArrowArrayStream *, struct ArrowArray *out);
+    const char *(*get_last_error)(struct ArrowArrayStream *);
+    void (*release)(struct ArrowArrayStream *);
+    void *private_data;
+};
+#endif
+
+/* exon/include/rust.hpp:7-9 */
+typedef struct ReaderResult {
+    const char *error; /* NULL on success; else a heap C string the caller may free() (the reference leaks it) */
+} ReaderResult;
+
+/* exon/include/rust.hpp:41-46, rust/src/arrow_reader.rs:38-166 — the reference's own entry point,
+ * same name, same arguments, same results: fills *stream_ptr with a stream of record batches of at
+ * most batch_size rows (a multiple of 64).  The tokenising, the typed VCF columns (LIST / STRUCT),
+ * the `filters` predicate and the Arrow buffers themselves (offsets, values, validity) are produced
+ * on the device; the host only copies them back and wires the ArrowArray structs.
+ *   compression: NULL = by extension (:60-75), else DataFusion's FileCompressionType names (:77-91)
+ *   file_format: "fasta" | "fastq" | "vcf"
+ *   filters:     NULL / "" or the predicate text FilterToString renders (module.cpp:158-214):
+ *                <column> (= | != | <> | < | <= | > | >=) <literal>, <column> IS [NOT] NULL, AND, OR
+ *                with SQL precedence; it is applied as `SELECT * FROM exon_table WHERE <filters>` (:125-141). */
+ReaderResult new_reader(struct ArrowArrayStream *stream_ptr, const char *uri, uintptr_t batch_size,
+                        const char *compression, const char *file_format, const char *filters);
 
 #ifdef __cplusplus
 }

@@ -468,6 +468,30 @@ static int parse_f32(const uint8_t *p, uint64_t n, float *out) {
     return 1;
 }
 
+/* i32::from_str / f32::from_str on a text slice: the typed INFO / FORMAT values of the nested VCF
+ * columns (oracle/pyoracle.py vcf_typed_rows) go through the same two parsers as POS and QUAL. */
+int orc_parse_f32_text(const uint8_t *p, uint64_t n, float *out) { return parse_f32(p, n, out); }
+
+int orc_parse_i32_text(const uint8_t *p, uint64_t n, int32_t *out) {
+    uint64_t i = 0;
+    int neg = 0;
+    if (n && (p[0] == '+' || p[0] == '-')) {
+        neg = p[0] == '-';
+        i = 1;
+    }
+    if (i >= n) return 0;
+    int64_t v = 0;
+    for (; i < n; i++) {
+        if (p[i] < '0' || p[i] > '9') return 0;
+        v = v * 10 + (p[i] - '0');
+        if (v > INT64_C(2147483648)) return 0;
+    }
+    if (neg) v = -v;
+    if (v > INT64_C(2147483647)) return 0;
+    *out = (int32_t)v;
+    return 1;
+}
+
 /*
  * noodles-vcf 0.34.0 header + record reader as driven by exon 0.2.6
  * datasources::vcf.  Restated at the tokenising level the north star names:

@@ -97,6 +97,10 @@ void orc_vcf_free(orc_vcf_table *t);
 void orc_utf8_to_string_t(const orc_utf8_col *col, int64_t row0, int64_t n, int mode, uint64_t payload_base,
                           orc_string_t *out, uint64_t *validity_words);
 
+/* f32::from_str / i32::from_str acceptance + value (1 = parsed). */
+int orc_parse_f32_text(const uint8_t *p, uint64_t n, float *out);
+int orc_parse_i32_text(const uint8_t *p, uint64_t n, int32_t *out);
+
 /* Rust core::str::from_utf8 acceptance test. */
 int orc_is_valid_utf8(const uint8_t *p, uint64_t n);
 

@@ -76,6 +76,10 @@ def lib():
         l.orc_vcf_free.argtypes = [C.POINTER(VcfTable)]
         l.orc_utf8_to_string_t.argtypes = [C.POINTER(Utf8Col), C.c_int64, C.c_int64, C.c_int, C.c_uint64,
                                            C.c_void_p, C.c_void_p]
+        l.orc_parse_f32_text.restype = C.c_int
+        l.orc_parse_f32_text.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(C.c_float)]
+        l.orc_parse_i32_text.restype = C.c_int
+        l.orc_parse_i32_text.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(C.c_int32)]
         l.orc_is_valid_utf8.restype = C.c_int
         l.orc_is_valid_utf8.argtypes = [C.c_void_p, C.c_uint64]
         l.orc_synth_fastq.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
@@ -197,6 +201,146 @@ def vcf_parse(data, payload_base=0, want_string_t=True):
     res = ParseResult(n, cols, t.err, st, extra)
     lib().orc_vcf_free(C.byref(t))
     return res
+
+
+# ---- nested VCF columns -----------------------------------------------------------------
+# Restates exon 0.2.6 datasources::vcf::{VCFSchemaBuilder, VCFArrayBuilder} over noodles-vcf 0.34.0 at the
+# level the reference's Arrow schema shows it (parity unpinned beyond test_vcf_record_scan.test:10-19):
+#   id / alt / filter: List<Utf8> ("." => []), info: Struct of the header's ##INFO keys, formats:
+#   List<Struct of the ##FORMAT keys>, one entry per sample.  Rows come out as pyarrow's to_pylist() would
+#   print them.  Pure Python over the C tokeniser above: small inputs only.
+def parse_f32_text(b: bytes):
+    v = C.c_float(0)
+    return float(v.value) if lib().orc_parse_f32_text(b, len(b), C.byref(v)) else None
+
+
+def parse_i32_text(b: bytes):
+    v = C.c_int32(0)
+    return int(v.value) if lib().orc_parse_i32_text(b, len(b), C.byref(v)) else None
+
+
+def vcf_header_keys(data: bytes):
+    """([(id, type, is_list)] for ##INFO, same for ##FORMAT), header order, first definition of an ID wins."""
+    out = {"INFO": [], "FORMAT": []}
+    for raw in bytes(data).split(b"\n"):
+        if not raw.startswith(b"#"):
+            break
+        line = raw.rstrip(b"\r").decode("utf-8", "replace")
+        for kind in ("INFO", "FORMAT"):
+            pre = "##" + kind + "=<"
+            if not line.startswith(pre):
+                continue
+            body, fields, i = line[len(pre):], {}, 0
+            while i < len(body) and body[i] != ">":
+                eq = body.find("=", i)
+                if eq < 0:
+                    break
+                key, j, val = body[i:eq], eq + 1, ""
+                if j < len(body) and body[j] == '"':
+                    j += 1
+                    while j < len(body) and body[j] != '"':
+                        if body[j] == "\\" and j + 1 < len(body):
+                            j += 1
+                        val += body[j]
+                        j += 1
+                    j += 1
+                else:
+                    while j < len(body) and body[j] not in ",>":
+                        val += body[j]
+                        j += 1
+                fields.setdefault(key, val)
+                i = j + 1 if j < len(body) and body[j] == "," else j
+            if "ID" in fields and fields["ID"] and all(k[0] != fields["ID"] for k in out[kind]):
+                ty = fields.get("Type", "String")
+                ty = ty if ty in ("Integer", "Float", "Flag") else "String"
+                out[kind].append((fields["ID"], ty, ty != "Flag" and fields.get("Number", "1") != "1"))
+    return out["INFO"], out["FORMAT"]
+
+
+class TypedValueError(ValueError):
+    pass
+
+
+def _typed(text: bytes, ty, is_list):
+    """value text (after '=') -> python value; None for the missing value '.'"""
+    def one(t):
+        if ty == "Integer":
+            v = parse_i32_text(t)
+        elif ty == "Float":
+            v = parse_f32_text(t)
+        else:
+            return t.decode("utf-8")
+        if v is None:
+            raise TypedValueError(t)
+        return v
+
+    if text == b".":
+        return None
+    if not is_list:
+        return one(text)
+    return [None if t == b"." else one(t) for t in text.split(b",")]
+
+
+def vcf_typed_rows(data):
+    """-> (rows, error_row): rows as dicts in the reference's schema; error_row = index of the first row whose
+    INFO / FORMAT values do not parse (rows stop there), else None."""
+    data = bytes(data)
+    base = vcf_parse(data, want_string_t=False)
+    info_keys, format_keys = vcf_header_keys(data)
+    cols = {k: base.columns[k].to_list() for k in VCF_FIELDS}
+    rows = []
+    for r in range(base.n_rows):
+        def split(field, sep):
+            t = cols[field][r]
+            return [] if t in (b".", b"") else [x.decode("utf-8") for x in t.split(sep)]
+
+        try:
+            info = {k: None for k, _, _ in info_keys}
+            raw = cols["info"][r]
+            if raw not in (b".", b""):
+                seen = set()
+                for ent in raw.split(b";"):
+                    key, eq, val = ent.partition(b"=")
+                    name = key.decode("utf-8", "replace")
+                    if not key or name in seen:
+                        continue
+                    seen.add(name)
+                    for k, ty, is_list in info_keys:
+                        if k == name:
+                            if ty == "Flag":
+                                info[k] = True
+                            elif eq:
+                                info[k] = _typed(val, ty, is_list)
+            formats = []
+            rest = cols["formats"][r]
+            if rest is not None:
+                parts = rest.split(b"\t")
+                fkeys = [p.decode("utf-8", "replace") for p in parts[0].split(b":")]
+                for sample in parts[1:]:
+                    d = {k: None for k, _, _ in format_keys}
+                    vals, done = sample.split(b":"), set()
+                    for p, name in enumerate(fkeys):
+                        if p >= len(vals) or name in done:
+                            continue
+                        for k, ty, is_list in format_keys:
+                            if k == name:
+                                done.add(name)
+                                d[k] = _typed(vals[p], ty, is_list)
+                    formats.append(d)
+        except TypedValueError:
+            return rows, r
+        rows.append({
+            "chrom": cols["chrom"][r].decode("utf-8"),
+            "pos": int(base.extra["pos"][r]),
+            "id": split("id", b";"),
+            "ref": cols["ref"][r].decode("utf-8"),
+            "alt": split("alt", b","),
+            "qual": float(base.extra["qual"][r]) if base.extra["qual_valid"][r] else None,
+            "filter": split("filter", b";"),
+            "info": info,
+            "formats": formats,
+        })
+    return rows, None
 
 
 def is_valid_utf8(b: bytes) -> bool:

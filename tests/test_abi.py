@@ -16,13 +16,13 @@ def declared_functions():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = re.findall(r"\b([a-z_][a-z0-9_]*)\s*\([^;{}]*\)\s*;", src)
-    return sorted(set(n for n in names if n.startswith("exg_") or n == "replacement_scan"))
+    return sorted(set(n for n in names if n.startswith("exg_") or n in ("replacement_scan", "new_reader")))
 
 
 def test_header_declares_the_expected_surface():
     fns = declared_functions()
     for must in ["exg_fastq_scan", "exg_vcf_scan", "exg_fasta_scan", "exg_open", "exg_next_chunk", "exg_count_only",
-                 "exg_close", "exg_count_newlines", "exg_fastq_guess_phase", "replacement_scan"]:
+                 "exg_close", "exg_count_newlines", "exg_fastq_guess_phase", "replacement_scan", "new_reader"]:
         assert must in fns
 
 

@@ -193,3 +193,70 @@ def test_utf8_acceptance(oracle, b, ok):
     except UnicodeDecodeError:
         py_ok = False
     assert py_ok == ok
+
+
+# ---- nested VCF columns: every [RECALLED] rule of oracle.vcf_typed_rows by name -----------------
+
+VCF_HDR = (b"##fileformat=VCFv4.2\n"
+           b"##INFO=<ID=DP,Number=1,Type=Integer,Description=\"d\">\n"
+           b"##INFO=<ID=AF,Number=A,Type=Float,Description=\"a, with a comma and \\\"quotes\\\"\">\n"
+           b"##INFO=<ID=DB,Number=0,Type=Flag,Description=\"f\">\n"
+           b"##INFO=<ID=ANN,Number=.,Type=String,Description=\"s\">\n"
+           b"##INFO=<ID=DP,Number=1,Type=Float,Description=\"a second definition of DP is ignored\">\n"
+           b"##FORMAT=<ID=GT,Number=1,Type=String,Description=\"g\">\n"
+           b"##FORMAT=<ID=AD,Number=R,Type=Integer,Description=\"r\">\n"
+           b"#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\tS2\n")
+
+
+def _typed(oracle, *lines):
+    return oracle.vcf_typed_rows(VCF_HDR + b"\n".join(lines) + b"\n")
+
+
+def test_vcf_typed_pinned_row(oracle, golden_dir):
+    # test_vcf_record_scan.test:10-19 — chrom 1, pos 9999919, ref G, alt [<*>], qual 0.0, info.indel NULL, info.dp 1
+    import os
+    rows, err = oracle.vcf_typed_rows(open(os.path.join(golden_dir, "vcf/index.vcf"), "rb").read())
+    assert err is None and len(rows) == 621
+    r = rows[0]
+    assert (r["chrom"], r["pos"], r["ref"], r["alt"], r["qual"], r["info"]["INDEL"], r["info"]["DP"]) == \
+           ("1", 9999919, "G", ["<*>"], 0.0, None, 1)
+
+
+def test_vcf_typed_header_keys_in_header_order_first_definition_wins(oracle):
+    info, fmt = oracle.vcf_header_keys(VCF_HDR)
+    assert info == [("DP", "Integer", False), ("AF", "Float", True), ("DB", "Flag", False), ("ANN", "String", True)]
+    assert fmt == [("GT", "String", False), ("AD", "Integer", True)]
+
+
+def test_vcf_typed_lists_split_and_missing_is_empty(oracle):
+    rows, _ = _typed(oracle, b"1\t5\ta;b\tA\tC,<DEL>\t1\tq10;s50\t.", b"1\t6\t.\tA\t.\t1\t.\t.", b"1\t7\tx\tA\tT\t1\tPASS\t.")
+    assert rows[0]["id"] == ["a", "b"] and rows[0]["alt"] == ["C", "<DEL>"] and rows[0]["filter"] == ["q10", "s50"]
+    assert rows[1]["id"] == [] and rows[1]["alt"] == [] and rows[1]["filter"] == []
+    assert rows[2]["filter"] == ["PASS"]
+
+
+def test_vcf_typed_info_rules(oracle):
+    rows, err = _typed(oracle, b"1\t5\t.\tA\tC\t1\t.\tDP=7;AF=0.5,.;DB;ANN=x,y;ZZ=1;DP=9", b"1\t6\t.\tA\tC\t1\t.\tDP=.;AF=.;ANN=",
+                       b"1\t7\t.\tA\tC\t1\t.\t.")
+    assert err is None
+    assert rows[0]["info"] == {"DP": 7, "AF": [0.5, None], "DB": True, "ANN": ["x", "y"]}   # undeclared ZZ, repeated DP dropped
+    assert rows[1]["info"] == {"DP": None, "AF": None, "DB": None, "ANN": [""]}
+    assert rows[2]["info"] == {"DP": None, "AF": None, "DB": None, "ANN": None}
+
+
+def test_vcf_typed_formats_rules(oracle):
+    rows, err = _typed(oracle, b"1\t5\t.\tA\tC\t1\t.\t.\tGT:AD:XX\t0/1:3,.:q\t.", b"1\t6\t.\tA\tC\t1\t.\t.\tAD\t1,2\t3",
+                       b"1\t7\t.\tA\tC\t1\t.\t.")
+    assert err is None
+    assert rows[0]["formats"] == [{"GT": "0/1", "AD": [3, None]}, {"GT": None, "AD": None}]
+    assert rows[1]["formats"] == [{"GT": None, "AD": [1, 2]}, {"GT": None, "AD": [3]}]
+    assert rows[2]["formats"] == []
+
+
+def test_vcf_typed_bad_number_is_a_record_error(oracle):
+    rows, err = _typed(oracle, b"1\t5\t.\tA\tC\t1\t.\tDP=3", b"1\t6\t.\tA\tC\t1\t.\tDP=3.5")
+    assert err == 1 and len(rows) == 1
+    rows, err = _typed(oracle, b"1\t5\t.\tA\tC\t1\t.\t.\tAD\tx")
+    assert err == 0 and rows == []
+    assert oracle.parse_i32_text(b"2147483647") == 2147483647 and oracle.parse_i32_text(b"2147483648") is None
+    assert oracle.parse_i32_text(b"-2147483648") == -2147483648 and oracle.parse_i32_text(b"+") is None
