@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -277,17 +278,66 @@ struct DevArena {  // bump allocator, reset per batch; overflow goes to hipMallo
     }
 };
 
+// Pinned host blocks are expensive to create (hipHostMalloc is ~ms per 10 MiB), so they are recycled: a
+// batch returns its blocks to the pool when the consumer releases its last record batch.
+struct BlockPool {
+    std::mutex mu;
+    std::vector<std::pair<char *, size_t>> free_blocks;
+    size_t pooled_bytes = 0;
+    static constexpr size_t kMaxPooled = 4ull << 30;
+    char *take(size_t *sz) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            size_t best = free_blocks.size();
+            for (size_t i = 0; i < free_blocks.size(); i++)
+                if (free_blocks[i].second >= *sz && (best == free_blocks.size() || free_blocks[i].second < free_blocks[best].second))
+                    best = i;
+            if (best != free_blocks.size()) {
+                char *p = free_blocks[best].first;
+                *sz = free_blocks[best].second;
+                pooled_bytes -= *sz;
+                free_blocks.erase(free_blocks.begin() + (long)best);
+                return p;
+            }
+        }
+        void *p = nullptr;
+        if (hipHostMalloc(&p, *sz, hipHostMallocDefault) != hipSuccess) return nullptr;
+        return (char *)p;
+    }
+    void give(char *p, size_t sz) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (pooled_bytes + sz <= kMaxPooled) {
+                free_blocks.emplace_back(p, sz);
+                pooled_bytes += sz;
+                return;
+            }
+        }
+        (void)hipHostFree(p);
+    }
+    ~BlockPool() {
+        for (auto &b : free_blocks) (void)hipHostFree(b.first);
+    }
+};
+
+// one pool per process: streams come and go (the reference opens one at bind and one per scan)
+std::shared_ptr<BlockPool> global_pool() {
+    static std::shared_ptr<BlockPool> pool = std::make_shared<BlockPool>();
+    return pool;
+}
+
 struct HostArena {  // pinned blocks that live as long as the Arrow batch they back
+    std::shared_ptr<BlockPool> pool;
     std::vector<std::pair<char *, size_t>> blocks;
     size_t used = 0;
     void *alloc(size_t n) {
         n = (n + 63) & ~(size_t)63;
         if (n == 0) n = 64;
         if (blocks.empty() || used + n > blocks.back().second) {
-            size_t sz = std::max<size_t>(n, 32u << 20);
-            void *p = nullptr;
-            if (hipHostMalloc(&p, sz, hipHostMallocDefault) != hipSuccess) return nullptr;
-            blocks.emplace_back((char *)p, sz);
+            size_t sz = (std::max<size_t>(n, 32u << 20) + (8u << 20) - 1) & ~(size_t)((8u << 20) - 1);
+            char *p = pool->take(&sz);
+            if (!p) return nullptr;
+            blocks.emplace_back(p, sz);
             used = 0;
         }
         void *p = blocks.back().first + used;
@@ -295,7 +345,7 @@ struct HostArena {  // pinned blocks that live as long as the Arrow batch they b
         return p;
     }
     ~HostArena() {
-        for (auto &b : blocks) (void)hipHostFree(b.first);
+        for (auto &b : blocks) pool->give(b.first, b.second);
     }
 };
 
@@ -328,6 +378,7 @@ struct StreamState {
     void *d_info_names = nullptr, *d_format_names = nullptr;
     ea::VtKeys info_vt, format_vt;
     DevArena arena;
+    std::shared_ptr<BlockPool> pool = global_pool();
     std::shared_ptr<ABatch> batch;
     uint64_t batch_row = 0;
     std::string last_error;
@@ -577,6 +628,7 @@ int arrow_emit(exg_reader *r, const ScanCtx &ctx) {
         if (hipMalloc((void **)&st->arena.base, cap) == hipSuccess) st->arena.cap = cap;
     }
     auto batch = std::make_shared<ABatch>();
+    batch->host.pool = st->pool;
     Emit em;
     em.r = r;
     em.st = st;
@@ -940,8 +992,10 @@ extern "C" ReaderResult new_reader(ArrowArrayStream *stream_ptr, const char *uri
     }
     auto st = std::make_shared<StreamState>();
     st->r = r;
-    // the schema needs the first file (VCF: its header), like register_exon_table (arrow_reader.rs:118-123)
-    if (open_next_file(r)) return result_error("could not register table: " + r->error);
+    // The VCF schema needs the first file's header, like register_exon_table (arrow_reader.rs:118-123).  The file
+    // is let go again right after: the reference's bind opens a stream only for its schema and never releases
+    // it (module.cpp:82-155), so a stream that was not read must not pin a mapping or inflated bytes in HBM.
+    if (r->format == EXG_FMT_VCF && open_next_file(r)) return result_error("could not register table: " + r->error);
     auto utf8 = [](const char *name, bool nullable) {
         Field f;
         f.name = name;
@@ -977,6 +1031,12 @@ extern "C" ReaderResult new_reader(ArrowArrayStream *stream_ptr, const char *uri
         if ((rc = upload_keys(r, st->info_keys, &st->info_vt, &st->d_info_names)) ||
             (rc = upload_keys(r, st->format_keys, &st->format_vt, &st->d_format_names)))
             return result_error("could not register table: " + r->error);
+        r->file.reset();
+        r->fd_keep.reset();
+        if (r->d_file) (void)hipFree(r->d_file), r->d_file = nullptr;
+        r->file_idx = 0;
+        r->file_pos = 0;
+        r->file_done = true;
     }
     if (filters && *filters) {
         // `SELECT * FROM exon_table WHERE <filters>` (arrow_reader.rs:125-141)
