@@ -38,7 +38,7 @@ struct FastqWsLayout {
     uint64_t off_tile_counts;   // u32[n_tiles_mp]
     uint64_t off_tile_offsets;  // u64[n_tiles_mp]
     uint64_t off_tile_desc;     // u64[n_tiles_fused] look-back descriptors + u64[n_tiles_fused] tile_qend
-    uint64_t off_block_sums;    // u64[lines_cap / 4096 + 2] (FASTA device-wide scans)
+    uint64_t off_block_sums;    // 2 x u64[lines / 4096 + 2] (FASTA device-wide scans: records, payload)
     uint64_t off_nl_pos;        // u64[lines_cap]
     uint64_t lines_cap;
     uint64_t total_bytes;
@@ -66,7 +66,7 @@ static inline FastqWsLayout fastq_ws_layout(uint64_t n_bytes, uint64_t ws_bytes_
     if (want < small) want = small;
     want += 8;
     l.off_block_sums = at;
-    at = round_up(at + ((n_bytes + 16) / 4096 + 4) * 8, 256);  // lines <= bytes + 1, whatever the workspace size
+    at = round_up(at + ((n_bytes + 16) / 4096 + 4) * 16, 256);  // 2 sums per block; lines <= bytes + 1, whatever the workspace size
     l.off_nl_pos = at;
     if (ws_bytes_or_0) {
         uint64_t avail = ws_bytes_or_0 > at ? (ws_bytes_or_0 - at) / (8 * n_line_arrays) : 0;

@@ -123,10 +123,13 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const uint8_t *__restrict__
 }
 
 // Pass 3: write the offset of every '\n' in order.  Re-reads the input once.
+// line_flags (optional, FASTA): per newline, bit 0 = the byte after it is '>' (the NEXT line is a definition
+// line), bit 1 = the byte before it is '\r' — both are in the registers of the thread that finds it, except
+// at the edges of its 16-byte chunk.
 __global__ __launch_bounds__(kMpThreads) void k_emit_nl(const uint8_t *__restrict__ d_in, uint64_t n_bytes,
                                                         const uint64_t *__restrict__ tile_offsets,
                                                         uint64_t *__restrict__ nl_pos, uint64_t lines_cap,
-                                                        const unsigned int *gate) {
+                                                        const unsigned int *gate, uint8_t *__restrict__ line_flags) {
     __shared__ uint32_t s_wave[4];
     if (gate && *gate == 0) return;
     for (uint64_t tile = blockIdx.x; tile * kMpTileBytes < n_bytes; tile += gridDim.x) {
@@ -134,11 +137,17 @@ __global__ __launch_bounds__(kMpThreads) void k_emit_nl(const uint8_t *__restric
         uint64_t rank_base = tile_offsets[tile];
         for (uint32_t j = 0; j < kMpIters; j++) {
             uint64_t off = tile_off + (uint64_t)j * kMpIterBytes + (uint64_t)threadIdx.x * 16;
-            uint32_t m = 0;
+            uint32_t m = 0, gt = 0, cr = 0;
             if (off < n_bytes) {
                 uint4 v = *reinterpret_cast<const uint4 *>(d_in + off);
                 m = match16(v, 0x0A0A0A0Au);
                 if (off + 16 > n_bytes) m &= (1u << (uint32_t)(n_bytes - off)) - 1u;
+                if (line_flags && m) {
+                    gt = match16(v, 0x3E3E3E3Eu) >> 1;  // bit b: byte b + 1 is '>'
+                    cr = match16(v, 0x0D0D0D0Du) << 1;  // bit b: byte b - 1 is '\r'
+                    if ((m & 0x8000u) && off + 16 < n_bytes && d_in[off + 16] == '>') gt |= 0x8000u;
+                    if ((m & 1u) && off > 0 && d_in[off - 1] == '\r') cr |= 1u;
+                }
             }
             uint32_t c = __popc(m);
             uint32_t incl = wave_incl_sum(c);
@@ -151,7 +160,10 @@ __global__ __launch_bounds__(kMpThreads) void k_emit_nl(const uint8_t *__restric
             while (m) {
                 uint32_t b = __ffs(m) - 1;
                 m &= m - 1;
-                if (r < lines_cap) nl_pos[r] = off + b;
+                if (r < lines_cap) {
+                    nl_pos[r] = off + b;
+                    if (line_flags) line_flags[r] = (uint8_t)(((gt >> b) & 1u) | (((cr >> b) & 1u) << 1));
+                }
                 r++;
             }
             rank_base += iter_total;
@@ -161,7 +173,8 @@ __global__ __launch_bounds__(kMpThreads) void k_emit_nl(const uint8_t *__restric
 }
 
 int launch_line_index(const uint8_t *d_in, uint64_t n_bytes, uint64_t lead, uint8_t *ws, const FastqWsLayout &l,
-                      int eof_mode, uint64_t first_line_index, hipStream_t stream, const unsigned int *gate) {
+                      int eof_mode, uint64_t first_line_index, hipStream_t stream, const unsigned int *gate,
+                      uint8_t *line_flags) {
     ScanWsHeader *hdr = reinterpret_cast<ScanWsHeader *>(ws);
     uint32_t *tile_counts = reinterpret_cast<uint32_t *>(ws + l.off_tile_counts);
     uint64_t *tile_offsets = reinterpret_cast<uint64_t *>(ws + l.off_tile_offsets);
@@ -173,7 +186,7 @@ int launch_line_index(const uint8_t *d_in, uint64_t n_bytes, uint64_t lead, uint
                        tile_offsets, nl_pos, hdr, eof_mode, first_line_index, gate);
     if (n_tiles)
         hipLaunchKernelGGL(k_emit_nl, dim3(grid), dim3(kMpThreads), 0, stream, d_in, n_bytes, tile_offsets, nl_pos,
-                           l.lines_cap, gate);
+                           l.lines_cap, gate, line_flags);
     EXG_HIP_CHECK(hipGetLastError());
     return EXG_OK;
 }
