@@ -12,6 +12,7 @@
 #include <errno.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
 #include <memory>
@@ -252,7 +253,7 @@ struct FilterParser {
 // ---- memory ------------------------------------------------------------------------------------------------------------------
 struct DevArena {  // bump allocator, reset per batch; overflow goes to hipMalloc'd extras
     char *base = nullptr;
-    size_t cap = 0, used = 0;
+    size_t cap = 0, used = 0, extra_bytes = 0;
     std::vector<void *> extra;
     void *alloc(size_t n) {
         n = (n + 255) & ~(size_t)255;
@@ -265,87 +266,18 @@ struct DevArena {  // bump allocator, reset per batch; overflow goes to hipMallo
         void *p = nullptr;
         if (hipMalloc(&p, n) != hipSuccess) return nullptr;
         extra.push_back(p);
+        extra_bytes += n;
         return p;
     }
     void reset() {
         for (void *p : extra) (void)hipFree(p);
         extra.clear();
         used = 0;
+        extra_bytes = 0;
     }
     ~DevArena() {
         reset();
         if (base) (void)hipFree(base);
-    }
-};
-
-// Pinned host blocks are expensive to create (hipHostMalloc is ~ms per 10 MiB), so they are recycled: a
-// batch returns its blocks to the pool when the consumer releases its last record batch.
-struct BlockPool {
-    std::mutex mu;
-    std::vector<std::pair<char *, size_t>> free_blocks;
-    size_t pooled_bytes = 0;
-    static constexpr size_t kMaxPooled = 4ull << 30;
-    char *take(size_t *sz) {
-        {
-            std::lock_guard<std::mutex> g(mu);
-            size_t best = free_blocks.size();
-            for (size_t i = 0; i < free_blocks.size(); i++)
-                if (free_blocks[i].second >= *sz && (best == free_blocks.size() || free_blocks[i].second < free_blocks[best].second))
-                    best = i;
-            if (best != free_blocks.size()) {
-                char *p = free_blocks[best].first;
-                *sz = free_blocks[best].second;
-                pooled_bytes -= *sz;
-                free_blocks.erase(free_blocks.begin() + (long)best);
-                return p;
-            }
-        }
-        void *p = nullptr;
-        if (hipHostMalloc(&p, *sz, hipHostMallocDefault) != hipSuccess) return nullptr;
-        return (char *)p;
-    }
-    void give(char *p, size_t sz) {
-        {
-            std::lock_guard<std::mutex> g(mu);
-            if (pooled_bytes + sz <= kMaxPooled) {
-                free_blocks.emplace_back(p, sz);
-                pooled_bytes += sz;
-                return;
-            }
-        }
-        (void)hipHostFree(p);
-    }
-    ~BlockPool() {
-        for (auto &b : free_blocks) (void)hipHostFree(b.first);
-    }
-};
-
-// one pool per process: streams come and go (the reference opens one at bind and one per scan)
-std::shared_ptr<BlockPool> global_pool() {
-    static std::shared_ptr<BlockPool> pool = std::make_shared<BlockPool>();
-    return pool;
-}
-
-struct HostArena {  // pinned blocks that live as long as the Arrow batch they back
-    std::shared_ptr<BlockPool> pool;
-    std::vector<std::pair<char *, size_t>> blocks;
-    size_t used = 0;
-    void *alloc(size_t n) {
-        n = (n + 63) & ~(size_t)63;
-        if (n == 0) n = 64;
-        if (blocks.empty() || used + n > blocks.back().second) {
-            size_t sz = (std::max<size_t>(n, 32u << 20) + (8u << 20) - 1) & ~(size_t)((8u << 20) - 1);
-            char *p = pool->take(&sz);
-            if (!p) return nullptr;
-            blocks.emplace_back(p, sz);
-            used = 0;
-        }
-        void *p = blocks.back().first + used;
-        used += n;
-        return p;
-    }
-    ~HostArena() {
-        for (auto &b : blocks) pool->give(b.first, b.second);
     }
 };
 
@@ -378,10 +310,10 @@ struct StreamState {
     void *d_info_names = nullptr, *d_format_names = nullptr;
     ea::VtKeys info_vt, format_vt;
     DevArena arena;
-    std::shared_ptr<BlockPool> pool = global_pool();
     std::shared_ptr<ABatch> batch;
     uint64_t batch_row = 0;
     std::string last_error;
+    size_t host_hint = 0;  // pinned bytes the previous batch needed
     ~StreamState() {
         for (void *p : {d_consts, d_prog, d_info_names, d_format_names})
             if (p) (void)hipFree(p);
@@ -619,16 +551,33 @@ int upload_keys(exg_reader *r, const std::vector<KeyDef> &keys, ea::VtKeys *vt, 
 }
 
 // Called by next_batch with the scan's columns still in HBM.
+static double em_now() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+#define EM_TRACE(label)                                                                          \
+    do {                                                                                         \
+        if (getenv("EXG_TRACE")) {                                                               \
+            (void)hipStreamSynchronize(r->stream);                                               \
+            double _t = em_now();                                                                \
+            fprintf(stderr, "[exg]   emit %-18s %.1f ms\n", label, (_t - em_t0) * 1e3);          \
+            em_t0 = _t;                                                                          \
+        }                                                                                        \
+    } while (0)
+
 int arrow_emit(exg_reader *r, const ScanCtx &ctx) {
     StreamState *st = (StreamState *)r->arrow_state.get();
+    double em_t0 = em_now();
     st->arena.reset();
     if (!st->arena.base) {
         // sized for the typical batch: offsets + values + views of every column; anything beyond goes to hipMalloc
         size_t cap = (size_t)std::min<uint64_t>(r->d_in_cap * 3 + (64u << 20), 6ull << 30);
         if (hipMalloc((void **)&st->arena.base, cap) == hipSuccess) st->arena.cap = cap;
     }
+    EM_TRACE("arena");
     auto batch = std::make_shared<ABatch>();
-    batch->host.pool = st->pool;
+    batch->host.reserve(st->host_hint);
     Emit em;
     em.r = r;
     em.st = st;
@@ -719,6 +668,7 @@ int arrow_emit(exg_reader *r, const ScanCtx &ctx) {
         cols.push_back(prim(r->d_qual, 4, (const uint64_t *)r->d_valid[0]));            // qual
         cols.push_back(em.list_of_strings(str_col(6), ';'));                            // filter
         if (em.rc) return em.rc;
+        EM_TRACE("flat + lists");
         {  // info
             AColumn info;
             info.kind = AColumn::kStruct;
@@ -734,6 +684,7 @@ int arrow_emit(exg_reader *r, const ScanCtx &ctx) {
             cols.push_back(std::move(info));
         }
         if (em.rc) return em.rc;
+        EM_TRACE("info");
         {  // formats
             AColumn fl;
             fl.kind = AColumn::kList;
@@ -766,6 +717,7 @@ int arrow_emit(exg_reader *r, const ScanCtx &ctx) {
         }
     }
     if (em.rc) return em.rc;
+    EM_TRACE("formats / columns");
     const uint64_t err = em.fetch_u64((const uint64_t *)em.d_err);  // also drains the D2H copies
     if (em.rc) return em.rc;
     EM_HIP(hipStreamSynchronize(r->stream));
@@ -785,6 +737,11 @@ int arrow_emit(exg_reader *r, const ScanCtx &ctx) {
                 if (c.chunk_base[k + 1] - c.chunk_base[k] >= (1ull << 31) && k * B < n_rows)
                     return fail(r, EXG_E_CAPACITY, "a record batch holds more than 2 GiB of one string column (Arrow Utf8 offsets are int32)");
         }
+    if (getenv("EXG_TRACE"))
+        fprintf(stderr, "[exg] arrow emit: arena %zu of %zu MiB, %zu extra allocations (%zu MiB), %zu pinned blocks\n",
+                st->arena.used >> 20, st->arena.cap >> 20, st->arena.extra.size(), st->arena.extra_bytes >> 20,
+                batch->host.blocks.size());
+    st->host_hint = batch->host.total + batch->host.total / 8 + (1u << 20);
     batch->n_rows = n_rows;
     st->batch = n_rows ? batch : nullptr;
     st->batch_row = 0;

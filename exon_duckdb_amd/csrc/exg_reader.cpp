@@ -37,6 +37,8 @@ PinnedBlock::~PinnedBlock() {
     if (!p) return;
     if (mapped)
         munmap(p, mapped);
+    else if (pooled)
+        global_pool()->give((char *)p, n);
     else
         (void)hipHostFree(p);
 }
@@ -59,7 +61,10 @@ exg_reader::FdCloser::~FdCloser() {
     if (fd >= 0) close(fd);
 }
 void exg_reader::free_device() {
-    for (void **p : {&d_in, &d_ws, &d_valid[0], &d_valid[1], &d_pos, &d_qual, &d_payload})
+    if (up_stream) (void)hipStreamSynchronize(up_stream);
+    pf.valid = false;
+    d_in = nullptr;
+    for (void **p : {&d_in_slot[0], &d_in_slot[1], &d_ws, &d_valid[0], &d_valid[1], &d_pos, &d_qual, &d_payload})
         if (*p) (void)hipFree(*p), *p = nullptr;
     for (void *&p : d_cols)
         if (p) (void)hipFree(p), p = nullptr;
@@ -68,6 +73,8 @@ exg_reader::~exg_reader() {
     free_device();
     if (d_res) (void)hipFree(d_res);
     if (d_file) (void)hipFree(d_file);
+    if (up_done) (void)hipEventDestroy(up_done);
+    if (up_stream) (void)hipStreamDestroy(up_stream);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -259,6 +266,11 @@ int open_next_file(exg_reader *r) {
     return EXG_OK;
 }
 
+// The next batch starts where this one's last complete record ends - known only after the scan - so the
+// prefetch starts this many bytes before the end of the current batch; a batch whose unconsumed tail is
+// longer (one giant record) falls back to the synchronous upload.
+static constexpr uint64_t kPrefetchSlack = 1u << 20;
+
 int n_string_cols(int format) { return format == EXG_FMT_FASTQ ? 4 : format == EXG_FMT_FASTA ? 3 : 9; }
 
 int ensure_device(exg_reader *r, uint64_t need_bytes) {
@@ -267,12 +279,21 @@ int ensure_device(exg_reader *r, uint64_t need_bytes) {
         RD_HIP(r, hipStreamSynchronize(r->stream));
         r->free_device();
     }
+    if (r->format != EXG_FMT_FASTA && r->file)  // room for a prefetched batch (its slack included), small files stay small
+        need_bytes = std::max<uint64_t>(need_bytes, std::min<uint64_t>(r->device_batch_bytes, r->file->n) + kPrefetchSlack + 64);
     uint64_t cap = std::max<uint64_t>(need_bytes, 1 << 16);
     r->d_in_cap = cap;
     // smallest possible record: FASTQ "@\n\n+\n" (5 bytes at EOF), FASTA ">a\n" minus LF, VCF a blank line
     r->cap_records = cap / (r->format == EXG_FMT_FASTQ ? 5 : r->format == EXG_FMT_FASTA ? 2 : 1) + 16;
     r->ws_bytes = exg_scan_workspace_bytes(r->format, cap);
-    RD_HIP(r, hipMalloc(&r->d_in, cap + 64));
+    // FASTA scans the whole file as one batch: one slot
+    for (int k = 0; k < (r->format == EXG_FMT_FASTA ? 1 : 2); k++) RD_HIP(r, hipMalloc(&r->d_in_slot[k], cap + 64));
+    r->d_in = r->d_in_slot[0];
+    r->cur_slot = 0;
+    if (!r->up_stream) {
+        RD_HIP(r, hipStreamCreateWithFlags(&r->up_stream, hipStreamNonBlocking));
+        RD_HIP(r, hipEventCreateWithFlags(&r->up_done, hipEventDisableTiming));
+    }
     RD_HIP(r, hipMalloc(&r->d_ws, r->ws_bytes));
     for (int k = 0; k < 2; k++) RD_HIP(r, hipMalloc(&r->d_valid[k], (r->cap_records + 63) / 64 * 8));
     for (int c = 0; c < n_string_cols(r->format); c++) RD_HIP(r, hipMalloc(&r->d_cols[c], r->cap_records * 16));
@@ -285,47 +306,58 @@ int ensure_device(exg_reader *r, uint64_t need_bytes) {
     return EXG_OK;
 }
 
-// file bytes [off, off + n) -> pinned bounce buffer (parallel pread) -> d_in
-int stage_and_upload(exg_reader *r, uint64_t off, uint64_t n) {
+// file bytes [off, off + n) -> the slot's pinned bounce buffer (parallel pread) -> d_in_slot[slot], on `st`.
+// pread and H2D are pipelined slice by slice: a slice travels while the next ones are still being read.
+int upload_range(exg_reader *r, uint64_t off, uint64_t n, int slot, hipStream_t st) {
     const uint64_t padded = (n + 15) / 16 * 16;
-    if (r->staging.n < padded) {
+    PinnedBlock &stg = r->staging[slot];
+    if (stg.n < padded) {
         RD_HIP(r, hipStreamSynchronize(r->stream));
-        if (r->staging.p) (void)hipHostFree(r->staging.p), r->staging.p = nullptr;
+        RD_HIP(r, hipStreamSynchronize(r->up_stream));
+        if (stg.p) global_pool()->give((char *)stg.p, stg.n), stg.p = nullptr, stg.n = 0;
         double t0 = now_s();
-        RD_HIP(r, hipHostMalloc(&r->staging.p, padded + 64, hipHostMallocDefault));
-        r->staging.n = padded;
-        TRACE("hipHostMalloc(staging)", t0);
+        size_t want = (size_t)std::max<uint64_t>(padded, std::min<uint64_t>(r->d_in_cap, r->file->n + 16)) + 64;
+        stg.p = global_pool()->take(&want);
+        if (!stg.p) return fail(r, EXG_E_HIP, "out of pinned host memory");
+        stg.n = want;
+        stg.pooled = true;
+        TRACE("pinned staging", t0);
     }
-    RD_HIP(r, hipStreamSynchronize(r->stream));  // the previous H2D out of this buffer is done
     double t0 = now_s();
-    const size_t slice = 16u << 20;
+    const size_t slice = 8u << 20;
     const size_t n_slices = (n + slice - 1) / slice;
-    unsigned nt = (unsigned)std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), std::min<size_t>(n_slices, 16));
+    unsigned nt = (unsigned)std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), std::min<size_t>(n_slices, 8));
     std::atomic<size_t> next{0};
-    std::atomic<bool> ok{true};
+    std::atomic<int> bad{0};
     const int fd = r->fd_keep->fd;
-    char *dst = (char *)r->staging.p;
+    char *dst = (char *)stg.p;
+    char *d_dst = (char *)r->d_in_slot[slot];
     auto work = [&]() {
         for (size_t i = next.fetch_add(1); i < n_slices; i = next.fetch_add(1)) {
             size_t o = i * slice, len = std::min<size_t>(slice, n - o), got = 0;
             while (got < len) {
                 ssize_t k = pread(fd, dst + o + got, len - got, (off_t)(off + o + got));
                 if (k <= 0) {
-                    ok = false;
+                    bad = 1;
                     return;
                 }
                 got += (size_t)k;
             }
+            size_t len16 = len;
+            if (i + 1 == n_slices) {
+                memset(dst + n, 0, padded - n);
+                len16 = padded - o;
+            }
+            if (hipMemcpyAsync(d_dst + o, dst + o, len16, hipMemcpyHostToDevice, st) != hipSuccess) bad = 2;
         }
     };
     std::vector<std::thread> th;
     for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
     work();
     for (auto &t : th) t.join();
-    if (!ok) return fail(r, EXG_E_IO, "short read");
-    memset(dst + n, 0, padded - n);
-    TRACE("pread(batch)", t0);
-    RD_HIP(r, hipMemcpyAsync(r->d_in, dst, padded, hipMemcpyHostToDevice, r->stream));
+    if (bad == 1) return fail(r, EXG_E_IO, "short read");
+    if (bad == 2) return fail(r, EXG_E_HIP, "hipMemcpyAsync failed");
+    TRACE("pread + h2d enqueue", t0);
     return EXG_OK;
 }
 
@@ -343,24 +375,44 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             r->file_done = true;
             return EXG_OK;
         }
+        if (r->format == EXG_FMT_FASTA) want = remaining;  // a FASTA record can span the whole file: one batch
         uint64_t n = std::min<uint64_t>(want, remaining);
-        const bool eof = n == remaining;
+        bool eof = n == remaining;
         int rc = ensure_device(r, n + 16);
         if (rc) return rc;
-        // Input of the scan: an H2D copy of the batch, or — gzip — the inflated bytes already in HBM.
-        // In place the batch start is only byte aligned: the buffer starts at the 16-byte boundary below
-        // it and `lead` skips the tail of the previous record (whose last '\n' is then inside the buffer).
+        // Input of the scan: the inflated bytes already in HBM (gzip), the prefetched slot, or a synchronous
+        // H2D copy.  In the first two cases the batch start is only byte aligned: the buffer starts at the
+        // 16-byte boundary below it and `lead` skips the tail of the previous record (whose last '\n' is
+        // then inside the buffer).
         const uint8_t *h = (const uint8_t *)r->file->p + r->file_pos;
-        const void *d_input = r->d_in;
+        const void *d_input = nullptr;
         uint64_t lead = 0;
+        uint64_t batch_end = r->file_pos + n;  // file offset one past the bytes of this batch
         if (r->d_file) {
             lead = r->file_pos & 15;
             d_input = (const uint8_t *)r->d_file + (r->file_pos - lead);
             h -= lead;
             n += lead;
+        } else if (r->pf.valid && want == r->device_batch_bytes && r->file_pos >= r->pf.file_start &&
+                   r->file_pos < r->pf.file_start + r->pf.len) {
+            const uint64_t off = r->file_pos - r->pf.file_start;
+            lead = off & 15;
+            r->cur_slot = r->pf.slot;
+            r->d_in = r->d_in_slot[r->cur_slot];
+            d_input = (const uint8_t *)r->d_in + (off - lead);
+            batch_end = r->pf.file_start + r->pf.len;
+            n = batch_end - r->file_pos + lead;
+            eof = batch_end == r->file->n;
+            h -= lead;
+            r->pf.valid = false;
+            RD_HIP(r, hipStreamWaitEvent(r->stream, r->up_done, 0));
         } else {
-            int rc2 = stage_and_upload(r, r->file_pos, n);
+            if (r->pf.valid) RD_HIP(r, hipStreamSynchronize(r->up_stream));  // a prefetch that missed: let it land first
+            r->pf.valid = false;
+            r->d_in = r->d_in_slot[r->cur_slot];
+            int rc2 = upload_range(r, r->file_pos, n, r->cur_slot, r->stream);
             if (rc2) return rc2;
+            d_input = r->d_in;
         }
         exg_scan_result res;
         const uint32_t fl = (lead ? 0u : EXG_F_BOF) | (eof ? EXG_F_EOF : 0u) | (count_only ? EXG_F_NO_STORE : 0u);
@@ -406,21 +458,17 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             a.stream = r->stream;
             rc = exg_vcf_scan(&a);
         } else {
-            if (!eof) {  // a FASTA record can span the whole file: one batch
-                want = remaining;
-                continue;
-            }
             b = std::make_shared<Batch>();
             if (!count_only) {
-                b->payload.n = n;
-                RD_HIP(r, hipHostMalloc(&b->payload.p, n + 64, hipHostMallocDefault));
+                b->payload = b->host.alloc(n + 64);
+                if (!b->payload) return fail(r, EXG_E_HIP, "out of pinned host memory");
             }
             exg_fasta_scan_args a;
             memset(&a, 0, sizeof a);
             a.d_input = d_input;
             a.n_bytes = n;
             a.payload_base = (uint64_t)(uintptr_t)h;
-            a.seq_payload_base = (uint64_t)(uintptr_t)b->payload.p;
+            a.seq_payload_base = (uint64_t)(uintptr_t)b->payload;
             a.flags = fl;
             a.d_id = (exg_string_t *)r->d_cols[0];
             a.d_description = (exg_string_t *)r->d_cols[1];
@@ -435,8 +483,10 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             rc = exg_fasta_scan(&a);
         }
         if (rc) return fail(r, rc, exg_last_error_message());
+        double t_scan = now_s();
         rc = exg_fetch_result((const exg_scan_result *)r->d_res, r->stream, &res);
         if (rc) return fail(r, rc, exg_last_error_message());
+        TRACE("wait(h2d) + scan", t_scan);
         if (res.flags & EXG_RF_INDEX_OVERFLOW)
             return fail(r, EXG_E_CAPACITY, "line index overflow in the general path (pathological line density)");
         if (res.n_records == 0 && !res.error_code && !eof) {
@@ -447,6 +497,24 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             r->pending_error = res.error_code;
             r->pending_error_offset = r->file_pos - lead + res.error_offset;
         }
+        // While the columns travel back (and the consumer works through the chunks): start moving the bytes
+        // the next batch will need into the other slot.
+        if (!eof && !res.error_code && !r->d_file && r->format != EXG_FMT_FASTA && want == r->device_batch_bytes &&
+            !getenv("EXG_NO_PREFETCH")) {
+            const uint64_t slack = std::min<uint64_t>(kPrefetchSlack, (batch_end - r->file_pos) / 2);
+            const uint64_t start = (batch_end - slack) & ~15ull;
+            const uint64_t len = std::min<uint64_t>(r->file->n - start, r->device_batch_bytes + slack);
+            const int other = r->cur_slot ^ 1;
+            if (len + 16 <= r->d_in_cap && r->d_in_slot[other]) {
+                int rc3 = upload_range(r, start, len, other, r->up_stream);
+                if (rc3) return rc3;
+                RD_HIP(r, hipEventRecord(r->up_done, r->up_stream));
+                r->pf.valid = true;
+                r->pf.file_start = start;
+                r->pf.len = len;
+                r->pf.slot = other;
+            }
+        }
         const uint64_t k = res.n_records;
         *n_records_out = k;
         if (r->arrow_emit && !count_only) {
@@ -456,10 +524,11 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             ctx.h = h;
             ctx.n_records = k;
             ctx.res = res;
-            ctx.h_seq_payload = b ? (const uint8_t *)b->payload.p : nullptr;
+            ctx.h_seq_payload = b ? (const uint8_t *)b->payload : nullptr;
             if (k && (rc = r->arrow_emit(r, ctx))) return rc;
         } else if (k && !count_only) {
             if (!b) b = std::make_shared<Batch>();
+            b->host.reserve(r->host_hint);
             b->file = r->file;
             b->n_rows = k;
             const int ns = n_string_cols(r->format);
@@ -472,14 +541,12 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
                 if (r->format == EXG_FMT_VCF && c == 1) src = r->d_pos, es = 8;
                 if (r->format == EXG_FMT_VCF && c == 5) src = r->d_qual, es = 4;
                 b->elem[c] = es;
-                b->cols[c].n = k * es;
-                RD_HIP(r, hipHostMalloc(&b->cols[c].p, k * es, hipHostMallocDefault));
-                RD_HIP(r, hipMemcpyAsync(b->cols[c].p, src, k * es, hipMemcpyDeviceToHost, r->stream));
+                if (!(b->cols[c] = b->host.alloc(k * es))) return fail(r, EXG_E_HIP, "out of pinned host memory");
+                RD_HIP(r, hipMemcpyAsync(b->cols[c], src, k * es, hipMemcpyDeviceToHost, r->stream));
             }
             auto copy_validity = [&](int col, const void *d) -> int {
-                b->validity[col].n = vw;
-                RD_HIP(r, hipHostMalloc(&b->validity[col].p, vw, hipHostMallocDefault));
-                RD_HIP(r, hipMemcpyAsync(b->validity[col].p, d, vw, hipMemcpyDeviceToHost, r->stream));
+                if (!(b->validity[col] = b->host.alloc(vw))) return fail(r, EXG_E_HIP, "out of pinned host memory");
+                RD_HIP(r, hipMemcpyAsync(b->validity[col], d, vw, hipMemcpyDeviceToHost, r->stream));
                 return EXG_OK;
             };
             if (r->format == EXG_FMT_VCF) {
@@ -488,8 +555,9 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
                 if ((rc = copy_validity(1, r->d_valid[0]))) return rc;
             }
             if (r->format == EXG_FMT_FASTA && res.payload_bytes)
-                RD_HIP(r, hipMemcpyAsync(b->payload.p, r->d_payload, res.payload_bytes, hipMemcpyDeviceToHost, r->stream));
+                RD_HIP(r, hipMemcpyAsync(b->payload, r->d_payload, res.payload_bytes, hipMemcpyDeviceToHost, r->stream));
             RD_HIP(r, hipStreamSynchronize(r->stream));
+            r->host_hint = b->host.total + b->host.total / 8 + (1u << 20);
             r->batch = b;
         }
         if (res.error_code || eof)
@@ -596,8 +664,8 @@ extern "C" int exg_next_chunk(exg_reader *r, exg_chunk *out) {
             out->n_rows = n;
             out->n_columns = r->batch->n_cols;
             for (int c = 0; c < r->batch->n_cols; c++) {
-                out->data[c] = (char *)r->batch->cols[c].p + row0 * r->batch->elem[c];
-                out->validity[c] = r->batch->validity[c].p ? (uint64_t *)r->batch->validity[c].p + row0 / 64 : nullptr;
+                out->data[c] = (char *)r->batch->cols[c] + row0 * r->batch->elem[c];
+                out->validity[c] = r->batch->validity[c] ? (uint64_t *)r->batch->validity[c] + row0 / 64 : nullptr;
             }
             out->keepalive = new ChunkKeep{r->batch};
             r->batch_row += n;

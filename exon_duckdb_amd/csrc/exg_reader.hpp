@@ -1,7 +1,9 @@
 // exg_reader.hpp — internals of the reader level shared by exg_reader.cpp (DuckDB-shaped chunks) and
 // exg_arrow_stream.cpp (the reference's new_reader: Arrow record batches).
 #pragma once
+#include <algorithm>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -13,16 +15,102 @@ struct PinnedBlock {  // host memory: pinned (hipHostMalloc) or a read-only file
     void *p = nullptr;
     size_t n = 0;
     size_t mapped = 0;  // != 0: p is an mmap of that many bytes
+    bool pooled = false;  // p came from the BlockPool and goes back to it
     ~PinnedBlock();
+};
+
+// Pinned host blocks are expensive to create (hipHostMalloc is ~ms per 10 MiB), so they are recycled: a
+// batch returns its blocks to the pool when the consumer releases its last record batch.
+struct BlockPool {
+    std::mutex mu;
+    std::vector<std::pair<char *, size_t>> free_blocks;
+    size_t pooled_bytes = 0;
+    static constexpr size_t kMaxPooled = 6ull << 30;
+    // sizes are multiples of 32 MiB; a free block is reused for a request it fits without wasting more than
+    // half of it (batches of one scan are alike, so in the steady state the same few blocks go round)
+    static size_t size_class(size_t n) { return (std::max<size_t>(n, 1) + (32u << 20) - 1) & ~(size_t)((32u << 20) - 1); }
+    char *take(size_t *sz) {
+        *sz = size_class(*sz);
+        {
+            std::lock_guard<std::mutex> g(mu);
+            size_t best = free_blocks.size();
+            for (size_t i = 0; i < free_blocks.size(); i++)
+                if (free_blocks[i].second >= *sz && free_blocks[i].second <= 2 * *sz + (64u << 20) &&
+                    (best == free_blocks.size() || free_blocks[i].second < free_blocks[best].second))
+                    best = i;
+            if (best != free_blocks.size()) {
+                char *p = free_blocks[best].first;
+                *sz = free_blocks[best].second;
+                pooled_bytes -= *sz;
+                free_blocks.erase(free_blocks.begin() + (long)best);
+                return p;
+            }
+        }
+        void *p = nullptr;
+        if (hipHostMalloc(&p, *sz, hipHostMallocDefault) != hipSuccess) return nullptr;
+        return (char *)p;
+    }
+    void give(char *p, size_t sz) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (pooled_bytes + sz <= kMaxPooled) {
+                free_blocks.emplace_back(p, sz);
+                pooled_bytes += sz;
+                return;
+            }
+        }
+        (void)hipHostFree(p);
+    }
+    ~BlockPool() {
+        for (auto &b : free_blocks) (void)hipHostFree(b.first);
+    }
+};
+
+// one pool per process: streams come and go (the reference opens one at bind and one per scan)
+inline std::shared_ptr<BlockPool> global_pool() {
+    static std::shared_ptr<BlockPool> pool = std::make_shared<BlockPool>();
+    return pool;
+}
+
+struct HostArena {  // pinned blocks that live as long as the batch they back
+    std::shared_ptr<BlockPool> pool = global_pool();
+    std::vector<std::pair<char *, size_t>> blocks;
+    size_t used = 0, total = 0;
+    // first block sized for the whole batch (hint = what the previous batch of this scan needed)
+    void reserve(size_t hint) {
+        if (!blocks.empty() || hint == 0) return;
+        size_t sz = hint;
+        char *p = pool->take(&sz);
+        if (p) blocks.emplace_back(p, sz), used = 0;
+    }
+    void *alloc(size_t n) {
+        n = (n + 63) & ~(size_t)63;
+        if (n == 0) n = 64;
+        if (blocks.empty() || used + n > blocks.back().second) {
+            size_t sz = n;
+            char *p = pool->take(&sz);
+            if (!p) return nullptr;
+            blocks.emplace_back(p, sz);
+            used = 0;
+        }
+        void *p = blocks.back().first + used;
+        used += n;
+        total += n;
+        return p;
+    }
+    ~HostArena() {
+        for (auto &b : blocks) pool->give(b.first, b.second);
+    }
 };
 
 struct Batch {  // host vectors of one device batch, shared by its chunks
     std::shared_ptr<PinnedBlock> file;
+    HostArena host;
     int n_cols = 0;
-    PinnedBlock cols[9];
+    void *cols[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t elem[9] = {16, 16, 16, 16, 16, 16, 16, 16, 16};  // bytes per row
-    PinnedBlock validity[9];                                     // empty => all rows valid
-    PinnedBlock payload;                                         // FASTA: compacted sequences
+    void *validity[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // NULL => all valid
+    void *payload = nullptr;  // FASTA: compacted sequences
     uint64_t n_rows = 0;
 };
 
@@ -59,8 +147,19 @@ struct exg_reader {
     uint64_t file_pos = 0;  // first byte not yet consumed by a complete record
     bool file_done = true;
 
-    // device buffers (sized for device_batch_bytes)
-    void *d_in = nullptr, *d_ws = nullptr, *d_res = nullptr;
+    // device buffers (sized for device_batch_bytes).  Two input slots: while slot A is scanned, the bytes the
+    // next batch is expected to need are already travelling into slot B on `up_stream` (see next_batch).
+    void *d_in = nullptr, *d_ws = nullptr, *d_res = nullptr;  // d_in = the slot the current batch sits in
+    void *d_in_slot[2] = {nullptr, nullptr};
+    hipStream_t up_stream = nullptr;
+    hipEvent_t up_done = nullptr;
+    struct Prefetch {
+        bool valid = false;
+        uint64_t file_start = 0, len = 0;  // file bytes [file_start, file_start + len) are (being) uploaded
+        int slot = 0;
+    } pf;
+    int cur_slot = 0;
+    size_t host_hint = 0;  // pinned bytes the previous batch's host vectors needed
     void *d_valid[2] = {nullptr, nullptr};
     void *d_cols[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     void *d_pos = nullptr, *d_qual = nullptr, *d_payload = nullptr;
@@ -71,7 +170,7 @@ struct exg_reader {
         ~FdCloser();
     };
     std::unique_ptr<FdCloser> fd_keep;  // current file (pread source of the bounce buffer)
-    exg_rd::PinnedBlock staging;     // pinned bounce buffer for H2D (the file itself is only mapped)
+    exg_rd::PinnedBlock staging[2];  // pinned bounce buffers for H2D, one per slot (the file itself is only mapped)
     void *d_file = nullptr;  // gzip input: the inflated bytes live here and are scanned in place
     uint64_t d_file_bytes = 0;
 
