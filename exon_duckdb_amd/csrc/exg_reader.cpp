@@ -246,6 +246,8 @@ int open_next_file(exg_reader *r) {
         int rc = inflate_file(r, blk, p);  // replaces blk by the inflated bytes (host copy) and sets d_file
         if (rc) return rc;
     }
+    if (r->pf.valid && r->up_stream) (void)hipStreamSynchronize(r->up_stream);  // a prefetch of the previous file
+    r->pf.valid = false;
     r->file = blk;
     r->file_pos = 0;
     r->file_done = false;

@@ -240,3 +240,27 @@ def test_vcf_streams_through_several_batches(con, oracle, tmp_path, monkeypatch)
             rows = rel.fetchall(columns=["chrom", "pos", "info"])
             assert [r[1] for r in rows] == want_pos
             assert rows[4999][2] == exp.columns["info"].row(4999)
+
+
+def test_prefetch_miss_and_batch_growth(con, oracle, tmp_path, monkeypatch):
+    """Records far longer than the prefetch slack and than the device batch itself: the reader has to fall
+    back to synchronous uploads and to double the batch until a whole record fits; rows must not change."""
+    import random
+    rnd = random.Random(5)
+    recs = []
+    for i in range(40):
+        ln = rnd.choice([10, 150, 30_000, 90_000, 200_000])
+        seq = "".join(rnd.choice("ACGT") for _ in range(64)) * (ln // 64 + 1)
+        recs.append(f"@r{i} d{i}\n{seq[:ln]}\n+\n{'I' * ln}\n")
+    data = "".join(recs).encode()
+    (tmp_path / "long.fastq").write_bytes(data)
+    exp = oracle.fastq_parse(data, want_string_t=False)
+    want = list(zip(*[exp.columns[k].to_list() for k in ("name", "description", "sequence", "quality_scores")]))
+    for batch in ("65536", "262144", None):
+        if batch:
+            monkeypatch.setenv("EXG_DEVICE_BATCH_BYTES", batch)
+        else:
+            monkeypatch.delenv("EXG_DEVICE_BATCH_BYTES")
+        rel = con.table_function("read_fastq", str(tmp_path / "long.fastq"))
+        assert rel.count() == 40
+        assert rel.fetchall() == want
