@@ -893,6 +893,41 @@ int64_t orc_fastq_scan_baseline(const uint8_t *buf, uint64_t n, uint64_t *checks
 
 /* ------------------------------------------------------------------ plumbing restated */
 
+/* the same loop on `n_threads` host threads, each scanning the whole buffer `reps` times: an upper bound
+ * for what byte-range sharding over all host cores could reach (SURVEY.md §8 D5 ii).  Returns the records
+ * scanned by all threads together. */
+#include <pthread.h>
+typedef struct mt_arg {
+    const uint8_t *buf;
+    uint64_t n;
+    int reps;
+    int64_t records;
+} mt_arg;
+static void *mt_worker(void *p) {
+    mt_arg *a = (mt_arg *)p;
+    for (int k = 0; k < a->reps; k++) a->records += orc_fastq_scan_baseline(a->buf, a->n, NULL);
+    return NULL;
+}
+int64_t orc_fastq_scan_baseline_mt(const uint8_t *buf, uint64_t n, int n_threads, int reps) {
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 256) n_threads = 256;
+    pthread_t th[256];
+    mt_arg args[256];
+    for (int t = 0; t < n_threads; t++) {
+        args[t].buf = buf;
+        args[t].n = n;
+        args[t].reps = reps;
+        args[t].records = 0;
+        pthread_create(&th[t], NULL, mt_worker, &args[t]);
+    }
+    int64_t total = 0;
+    for (int t = 0; t < n_threads; t++) {
+        pthread_join(th[t], NULL);
+        total += args[t].records;
+    }
+    return total;
+}
+
 static int ext_eq(const char *s, size_t n, const char *lit) { return strlen(lit) == n && strncmp(s, lit, n) == 0; }
 
 /* DataFusion 28 FileCompressionType::from_str (upper-cased match) */

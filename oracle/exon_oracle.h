@@ -117,6 +117,7 @@ uint64_t orc_synth_fasta(uint8_t *out, uint64_t cap, uint64_t n_records, uint64_
  * Returns records parsed; *checksum folds every emitted string_t length so the
  * work cannot be optimised away. */
 int64_t orc_fastq_scan_baseline(const uint8_t *buf, uint64_t n, uint64_t *checksum);
+int64_t orc_fastq_scan_baseline_mt(const uint8_t *buf, uint64_t n, int n_threads, int reps);
 
 /* replacement-scan / compression inference restated from rust/src/arrow_reader.rs:60-91,173-197 */
 const char *orc_infer_compression(const char *uri, const char *compression_or_null);

@@ -88,6 +88,8 @@ def lib():
             getattr(l, f).argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
         l.orc_fastq_scan_baseline.restype = C.c_int64
         l.orc_fastq_scan_baseline.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        l.orc_fastq_scan_baseline_mt.restype = C.c_int64
+        l.orc_fastq_scan_baseline_mt.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int]
         l.orc_infer_compression.restype = C.c_char_p
         l.orc_infer_compression.argtypes = [C.c_char_p, C.c_char_p]
         l.orc_replacement_scan.restype = C.c_char_p
@@ -378,6 +380,11 @@ def fastq_scan_baseline(data):
     chk = C.c_uint64(0)
     n = int(lib().orc_fastq_scan_baseline(ptr, arr.size, C.byref(chk)))
     return n, int(chk.value)
+
+
+def fastq_scan_baseline_mt(data, n_threads, reps):
+    arr, ptr = _as_buf(data)
+    return int(lib().orc_fastq_scan_baseline_mt(ptr, arr.size, n_threads, reps))
 
 
 def infer_compression(uri, compression=None):
