@@ -741,10 +741,12 @@ int arrow_emit(exg_reader *r, const ScanCtx &ctx) {
         fprintf(stderr, "[exg] arrow emit: arena %zu of %zu MiB, %zu extra allocations (%zu MiB), %zu pinned blocks\n",
                 st->arena.used >> 20, st->arena.cap >> 20, st->arena.extra.size(), st->arena.extra_bytes >> 20,
                 batch->host.blocks.size());
+    EM_TRACE("drain");
     st->host_hint = batch->host.total + batch->host.total / 8 + (1u << 20);
     batch->n_rows = n_rows;
     st->batch = n_rows ? batch : nullptr;
     st->batch_row = 0;
+    EM_TRACE("swap batch");
     return EXG_OK;
 }
 

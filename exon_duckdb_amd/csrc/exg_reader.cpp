@@ -285,8 +285,13 @@ int ensure_device(exg_reader *r, uint64_t need_bytes) {
         need_bytes = std::max<uint64_t>(need_bytes, std::min<uint64_t>(r->device_batch_bytes, r->file->n) + kPrefetchSlack + 64);
     uint64_t cap = std::max<uint64_t>(need_bytes, 1 << 16);
     r->d_in_cap = cap;
-    // smallest possible record: FASTQ "@\n\n+\n" (5 bytes at EOF), FASTA ">a\n" minus LF, VCF a blank line
-    r->cap_records = cap / (r->format == EXG_FMT_FASTQ ? 5 : r->format == EXG_FMT_FASTA ? 2 : 1) + 16;
+    // Rows the output vectors can hold.  Realistic density first (a FASTQ record under 32 bytes, a FASTA record
+    // or a VCF line under 16 would be unusual) — the worst case (FASTQ "@\n\n+\n" = 5 bytes, FASTA ">a\n" minus
+    // LF, a blank VCF line) would pin 16 B x 9 columns per input BYTE of device memory; a batch that does
+    // overflow is reported by the kernels (EXG_RF_CAPACITY) and rescanned with worst-case vectors.
+    const uint64_t div = r->worst_case_rows ? (r->format == EXG_FMT_FASTQ ? 5 : r->format == EXG_FMT_FASTA ? 2 : 1)
+                                            : (r->format == EXG_FMT_FASTQ ? 32 : 16);
+    r->cap_records = cap / div + 4096;
     r->ws_bytes = exg_scan_workspace_bytes(r->format, cap);
     // FASTA scans the whole file as one batch: one slot
     for (int k = 0; k < (r->format == EXG_FMT_FASTA ? 1 : 2); k++) RD_HIP(r, hipMalloc(&r->d_in_slot[k], cap + 64));
@@ -491,6 +496,13 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         TRACE("wait(h2d) + scan", t_scan);
         if (res.flags & EXG_RF_INDEX_OVERFLOW)
             return fail(r, EXG_E_CAPACITY, "line index overflow in the general path (pathological line density)");
+        if ((res.flags & EXG_RF_CAPACITY) && !count_only) {
+            if (r->worst_case_rows) return fail(r, EXG_E_CAPACITY, "more rows than bytes allow: internal error");
+            RD_HIP(r, hipStreamSynchronize(r->stream));  // denser rows than provisioned: worst-case vectors, same batch again
+            r->free_device();
+            r->worst_case_rows = true;
+            continue;
+        }
         if (res.n_records == 0 && !res.error_code && !eof) {
             want *= 2;  // not even one complete record in the batch: widen it
             continue;
@@ -499,6 +511,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             r->pending_error = res.error_code;
             r->pending_error_offset = r->file_pos - lead + res.error_offset;
         }
+        double t_pf = now_s();
         // While the columns travel back (and the consumer works through the chunks): start moving the bytes
         // the next batch will need into the other slot.
         if (!eof && !res.error_code && !r->d_file && r->format != EXG_FMT_FASTA && want == r->device_batch_bytes &&
@@ -517,6 +530,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
                 r->pf.slot = other;
             }
         }
+        TRACE("prefetch issue", t_pf);
         const uint64_t k = res.n_records;
         *n_records_out = k;
         if (r->arrow_emit && !count_only) {
@@ -527,7 +541,9 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             ctx.n_records = k;
             ctx.res = res;
             ctx.h_seq_payload = b ? (const uint8_t *)b->payload : nullptr;
+            double t_emit = now_s();
             if (k && (rc = r->arrow_emit(r, ctx))) return rc;
+            TRACE("arrow emit", t_emit);
         } else if (k && !count_only) {
             if (!b) b = std::make_shared<Batch>();
             b->host.reserve(r->host_hint);

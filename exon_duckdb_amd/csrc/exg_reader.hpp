@@ -160,6 +160,7 @@ struct exg_reader {
     } pf;
     int cur_slot = 0;
     size_t host_hint = 0;  // pinned bytes the previous batch's host vectors needed
+    bool worst_case_rows = false;  // output vectors sized for the densest possible input (after an overflow)
     void *d_valid[2] = {nullptr, nullptr};
     void *d_cols[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     void *d_pos = nullptr, *d_qual = nullptr, *d_payload = nullptr;

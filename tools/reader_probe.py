@@ -22,7 +22,40 @@ def arrow_filtered():
     return sum(b.num_rows for b in new_reader(path, "fastq", filters="description='3:N:0:ACGT' AND sequence<'C'"))
 
 
-for label, fn in (("count", rel.count), ("chunks", lambda: sum(rel.chunk_sizes())), ("arrow", arrow_all),
+import ctypes as C  # noqa: E402
+
+
+class _ArrowArray(C.Structure):
+    _fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("offset", C.c_int64), ("n_buffers", C.c_int64),
+                ("n_children", C.c_int64), ("buffers", C.c_void_p), ("children", C.c_void_p), ("dictionary", C.c_void_p),
+                ("release", C.CFUNCTYPE(None, C.c_void_p)), ("private_data", C.c_void_p)]
+
+
+class _ArrowStream(C.Structure):
+    _fields_ = [("get_schema", C.c_void_p), ("get_next", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)),
+                ("get_last_error", C.c_void_p), ("release", C.CFUNCTYPE(None, C.c_void_p)), ("private_data", C.c_void_p)]
+
+
+def arrow_raw(filters=None):
+    """the stream pulled through its C callbacks only (no pyarrow objects): the library's own rate"""
+    from exon_duckdb_amd import arrow as A
+    l = A._lib()
+    st = _ArrowStream()
+    res = l.new_reader(C.addressof(st), path.encode(), 2048, None, b"fastq", filters.encode() if filters else None)
+    assert not res.error
+    n = 0
+    while True:
+        arr = _ArrowArray()
+        assert st.get_next(C.addressof(st), C.addressof(arr)) == 0
+        if not arr.release:
+            break
+        n += arr.length
+        arr.release(C.addressof(arr))
+    st.release(C.addressof(st))
+    return n
+
+
+for label, fn in (("count", rel.count), ("arrow (C callbacks only)", arrow_raw), ("chunks", lambda: sum(rel.chunk_sizes())), ("arrow", arrow_all),
                   ("arrow+filter", arrow_filtered)):
     fn()
     for _ in range(2):
