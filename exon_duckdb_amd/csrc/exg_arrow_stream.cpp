@@ -275,9 +275,10 @@ struct DevArena {  // bump allocator, reset per batch; overflow goes to hipMallo
         used = 0;
         extra_bytes = 0;
     }
+    int dev = 0;
     ~DevArena() {
         reset();
-        if (base) (void)hipFree(base);
+        if (base) dev_pool()->give(dev, base, cap);
     }
 };
 
@@ -573,7 +574,9 @@ int arrow_emit(exg_reader *r, const ScanCtx &ctx) {
     if (!st->arena.base) {
         // sized for the typical batch: offsets + values + views of every column; anything beyond goes to hipMalloc
         size_t cap = (size_t)std::min<uint64_t>(r->d_in_cap * 3 + (64u << 20), 6ull << 30);
-        if (hipMalloc((void **)&st->arena.base, cap) == hipSuccess) st->arena.cap = cap;
+        cap = (cap + 4095) & ~(size_t)4095;
+        st->arena.dev = r->device;
+        if ((st->arena.base = (char *)dev_pool()->take(r->device, cap))) st->arena.cap = cap;
     }
     EM_TRACE("arena");
     auto batch = std::make_shared<ABatch>();

@@ -64,10 +64,18 @@ void exg_reader::free_device() {
     if (up_stream) (void)hipStreamSynchronize(up_stream);
     pf.valid = false;
     d_in = nullptr;
-    for (void **p : {&d_in_slot[0], &d_in_slot[1], &d_ws, &d_valid[0], &d_valid[1], &d_pos, &d_qual, &d_payload})
-        if (*p) (void)hipFree(*p), *p = nullptr;
-    for (void *&p : d_cols)
-        if (p) (void)hipFree(p), p = nullptr;
+    for (auto &a : dev_allocs) {
+        exg_rd::dev_pool()->give(device, *a.first, a.second);
+        *a.first = nullptr;
+    }
+    dev_allocs.clear();
+}
+int exg_reader::dev_alloc(void **slot, size_t bytes) {
+    bytes = (bytes + 4095) & ~(size_t)4095;
+    *slot = exg_rd::dev_pool()->take(device, bytes);
+    if (!*slot) return exg_rd::fail(this, EXG_E_HIP, "out of device memory (" + std::to_string(bytes >> 20) + " MiB)");
+    dev_allocs.emplace_back(slot, bytes);
+    return EXG_OK;
 }
 exg_reader::~exg_reader() {
     free_device();
@@ -294,21 +302,25 @@ int ensure_device(exg_reader *r, uint64_t need_bytes) {
     r->cap_records = cap / div + 4096;
     r->ws_bytes = exg_scan_workspace_bytes(r->format, cap);
     // FASTA scans the whole file as one batch: one slot
-    for (int k = 0; k < (r->format == EXG_FMT_FASTA ? 1 : 2); k++) RD_HIP(r, hipMalloc(&r->d_in_slot[k], cap + 64));
+    int arc = 0;
+    for (int k = 0; k < (r->format == EXG_FMT_FASTA ? 1 : 2); k++)
+        if ((arc = r->dev_alloc(&r->d_in_slot[k], cap + 64))) return arc;
     r->d_in = r->d_in_slot[0];
     r->cur_slot = 0;
     if (!r->up_stream) {
         RD_HIP(r, hipStreamCreateWithFlags(&r->up_stream, hipStreamNonBlocking));
         RD_HIP(r, hipEventCreateWithFlags(&r->up_done, hipEventDisableTiming));
     }
-    RD_HIP(r, hipMalloc(&r->d_ws, r->ws_bytes));
-    for (int k = 0; k < 2; k++) RD_HIP(r, hipMalloc(&r->d_valid[k], (r->cap_records + 63) / 64 * 8));
-    for (int c = 0; c < n_string_cols(r->format); c++) RD_HIP(r, hipMalloc(&r->d_cols[c], r->cap_records * 16));
+    if ((arc = r->dev_alloc(&r->d_ws, r->ws_bytes))) return arc;
+    for (int k = 0; k < 2; k++)
+        if ((arc = r->dev_alloc(&r->d_valid[k], (r->cap_records + 63) / 64 * 8))) return arc;
+    for (int c = 0; c < n_string_cols(r->format); c++)
+        if ((arc = r->dev_alloc(&r->d_cols[c], r->cap_records * 16))) return arc;
     if (r->format == EXG_FMT_VCF) {
-        RD_HIP(r, hipMalloc(&r->d_pos, r->cap_records * 8));
-        RD_HIP(r, hipMalloc(&r->d_qual, r->cap_records * 4));
+        if ((arc = r->dev_alloc(&r->d_pos, r->cap_records * 8))) return arc;
+        if ((arc = r->dev_alloc(&r->d_qual, r->cap_records * 4))) return arc;
     }
-    if (r->format == EXG_FMT_FASTA) RD_HIP(r, hipMalloc(&r->d_payload, cap + 64));
+    if (r->format == EXG_FMT_FASTA && (arc = r->dev_alloc(&r->d_payload, cap + 64))) return arc;
     if (!r->d_res) RD_HIP(r, hipMalloc(&r->d_res, sizeof(exg_scan_result)));
     return EXG_OK;
 }

@@ -68,7 +68,65 @@ struct BlockPool {
 
 // one pool per process: streams come and go (the reference opens one at bind and one per scan)
 inline std::shared_ptr<BlockPool> global_pool() {
-    static std::shared_ptr<BlockPool> pool = std::make_shared<BlockPool>();
+    // never destroyed: hipHostFree after the HIP runtime has shut down is not safe
+    static auto *pool = new std::shared_ptr<BlockPool>(std::make_shared<BlockPool>());
+    return *pool;
+}
+
+// Device buffers of a reader (input slots, workspace, column vectors, the Arrow emitter's arena) are the same
+// sizes scan after scan; mapping and unmapping gigabytes of HBM per open costs tens of ms and was seen to
+// stall later GPU work for far longer.  They go round through this pool instead (exact size match).
+struct DevPool {
+    struct Blk {
+        int dev;
+        void *p;
+        size_t sz;
+    };
+    std::mutex mu;
+    std::vector<Blk> free_blocks;
+    size_t pooled_bytes = 0;
+    static constexpr size_t kMaxPooled = 16ull << 30;
+    void *take(int dev, size_t sz) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            for (size_t i = 0; i < free_blocks.size(); i++)
+                if (free_blocks[i].dev == dev && free_blocks[i].sz == sz) {
+                    void *p = free_blocks[i].p;
+                    pooled_bytes -= sz;
+                    free_blocks.erase(free_blocks.begin() + (long)i);
+                    return p;
+                }
+        }
+        void *p = nullptr;
+        if (hipMalloc(&p, sz) != hipSuccess) {
+            trim(0);  // give the cached blocks back and try once more
+            if (hipMalloc(&p, sz) != hipSuccess) return nullptr;
+        }
+        return p;
+    }
+    void give(int dev, void *p, size_t sz) {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (sz >= (1u << 20) && pooled_bytes + sz <= kMaxPooled) {
+                free_blocks.push_back(Blk{dev, p, sz});
+                pooled_bytes += sz;
+                return;
+            }
+        }
+        (void)hipFree(p);
+    }
+    void trim(size_t keep_bytes) {
+        std::lock_guard<std::mutex> g(mu);
+        while (!free_blocks.empty() && pooled_bytes > keep_bytes) {
+            (void)hipFree(free_blocks.back().p);
+            pooled_bytes -= free_blocks.back().sz;
+            free_blocks.pop_back();
+        }
+    }
+};
+inline DevPool *dev_pool() {
+    static DevPool *pool = new DevPool();  // intentionally never destroyed: the HIP runtime may be gone by then
     return pool;
 }
 
@@ -160,6 +218,8 @@ struct exg_reader {
     } pf;
     int cur_slot = 0;
     size_t host_hint = 0;  // pinned bytes the previous batch's host vectors needed
+    std::vector<std::pair<void **, size_t>> dev_allocs;  // pooled device buffers of this reader (slot, bytes)
+    int dev_alloc(void **slot, size_t bytes);
     bool worst_case_rows = false;  // output vectors sized for the densest possible input (after an overflow)
     void *d_valid[2] = {nullptr, nullptr};
     void *d_cols[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
