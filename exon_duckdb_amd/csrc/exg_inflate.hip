@@ -41,12 +41,16 @@ static constexpr int kLitBits = 10, kDistBits = 9;
 struct InflateLds {
     uint8_t win[kWinBytes];
     uint8_t in[kInRing];
-    uint16_t lit_lut[1 << kLitBits];    // (symbol << 4) | length, 0 = code longer than kLitBits (or unused)
-    uint16_t dist_lut[1 << kDistBits];
+    // Primary tables, 0 = code longer than the table (or unused).  The entries carry what the token needs, so a
+    // decode is peek -> lit_lut -> dist_lut, three dependent LDS levels instead of five:
+    //   lit_lut  literal: bits 0-3 code length, 4-11 byte, 12 end-of-block, 13 invalid symbol
+    //            length : bit 15, bits 0-3 code length, 4-6 extra bit count, 7-14 base length - 3
+    //   dist_lut bits 0-3 code length, 4-7 extra bit count, 8 invalid symbol, 16-30 base distance
+    //            (the code-length alphabet of a dynamic header borrows it as a plain u16 table)
+    uint16_t lit_lut[1 << kLitBits];
+    uint32_t dist_lut[1 << kDistBits];
     uint16_t lit_sorted[288], dist_sorted[32];   // symbols ordered by (length, symbol) — canonical decode
     uint16_t lit_count[16], dist_count[16];
-    uint16_t len_base[32], dist_base[32];
-    uint8_t len_extra[32], dist_extra[32];
     uint8_t lens[384];  // [0,288) literal/length, [288,320) distance; [32,348) scratch while a dynamic header is read
 };
 
@@ -113,8 +117,28 @@ __device__ __forceinline__ uint32_t getbits(InflateLds &s, BitIn &br, uint32_t n
 
 // Build one decode table from code lengths lens[0..n): LUT (primary `bits`), sorted symbols, counts.
 // Returns false when the lengths are over-subscribed or incomplete (except the single-code cases zlib allows).
-__device__ bool build_table(const uint8_t *lens, uint32_t n, uint16_t *lut, uint32_t bits, uint16_t *sorted,
-                            uint16_t *count, uint32_t lane) {
+struct EncPlain {  // (symbol << 4) | length
+    __device__ __forceinline__ uint16_t operator()(uint32_t sym, uint32_t l) const { return (uint16_t)((sym << 4) | l); }
+};
+struct EncLit {
+    __device__ __forceinline__ uint16_t operator()(uint32_t sym, uint32_t l) const {
+        if (sym < 256) return (uint16_t)((sym << 4) | l);
+        if (sym == 256) return (uint16_t)((1u << 12) | l);
+        if (sym > 285) return (uint16_t)((1u << 13) | l);
+        const uint32_t si = sym - 257;
+        return (uint16_t)(0x8000u | ((uint32_t)(kLenBase[si] - 3) << 7) | ((uint32_t)kLenExtra[si] << 4) | l);
+    }
+};
+struct EncDist {
+    __device__ __forceinline__ uint32_t operator()(uint32_t sym, uint32_t l) const {
+        if (sym > 29) return (1u << 8) | l;
+        return ((uint32_t)kDistBase[sym] << 16) | ((uint32_t)kDistExtra[sym] << 4) | l;
+    }
+};
+
+template <class Lut, class Enc>
+__device__ bool build_table(const uint8_t *lens, uint32_t n, Lut *lut, uint32_t bits, uint16_t *sorted, uint16_t *count,
+                            uint32_t lane, Enc enc) {
     for (uint32_t e = lane; e < (1u << bits); e += 64) lut[e] = 0;
     // counts per length
     uint32_t cnt[16];
@@ -171,7 +195,8 @@ __device__ bool build_table(const uint8_t *lens, uint32_t n, uint16_t *lut, uint
             if (l <= bits) {
                 uint32_t c = f + rank;
                 uint32_t r = __brev(c) >> (32 - l);  // codes are sent MSB first
-                for (uint32_t e = r; e < (1u << bits); e += 1u << l) lut[e] = (uint16_t)((sym << 4) | l);
+                const Lut entry = enc(sym, l);
+                for (uint32_t e = r; e < (1u << bits); e += 1u << l) lut[e] = entry;
             }
         }
     }
@@ -214,6 +239,16 @@ __device__ __forceinline__ uint32_t decode_sym(InflateLds &s, BitIn &br, const u
     return sym;
 }
 
+// one symbol decoded bit by bit by every lane uniformly (tokens the primary tables cannot resolve)
+__device__ __forceinline__ uint32_t decode_serial(InflateLds &s, BitIn &br, const uint16_t *sorted, const uint16_t *count,
+                                                  uint32_t lane) {
+    unsigned long long v = peek(s, br, lane);
+    uint32_t l = 0;
+    uint32_t sym = sgpr(decode_slow(v, sorted, count, &l));
+    br.bitpos += sgpr(l);
+    return sym;
+}
+
 // flush every completed 1 KiB segment of the window ring to HBM
 __device__ __forceinline__ void flush_segments(InflateLds &s, uint8_t *out, unsigned long long out_off, uint32_t &flushed,
                                                uint32_t pos, uint32_t lane) {
@@ -240,15 +275,6 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ d_co
                                                 uint32_t n_members) {
     __shared__ __attribute__((aligned(16))) InflateLds s;
     const uint32_t lane = threadIdx.x;
-    // length / distance tables -> LDS (per-lane indexed lookups; constant memory would serialise them)
-    if (lane < 29) {
-        s.len_base[lane] = kLenBase[lane];
-        s.len_extra[lane] = kLenExtra[lane];
-    }
-    if (lane < 30) {
-        s.dist_base[lane] = kDistBase[lane];
-        s.dist_extra[lane] = kDistExtra[lane];
-    }
     for (uint32_t m = blockIdx.x; m < n_members; m += gridDim.x) {
         const InflateMember mb = members[m];
         BitIn br;
@@ -320,13 +346,14 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ d_co
                     br.bitpos += 3ull * ncode;
                 }
                 // the code-length code reuses the distance table storage (7-bit codes, 19 symbols)
-                if (!build_table(s.lens, 19, s.dist_lut, 7, s.dist_sorted, s.dist_count, lane)) {
+                uint16_t *cl_lut = reinterpret_cast<uint16_t *>(s.dist_lut);  // borrowed until the real tables are built
+                if (!build_table(s.lens, 19, cl_lut, 7, s.dist_sorted, s.dist_count, lane, EncPlain())) {
                     err = 2;
                     break;
                 }
                 uint32_t idx = 0, prev = 0;
                 while (idx < nlit + ndist) {
-                    uint32_t sym = decode_sym(s, br, s.dist_lut, 7, s.dist_sorted, s.dist_count, lane);
+                    uint32_t sym = decode_sym(s, br, cl_lut, 7, s.dist_sorted, s.dist_count, lane);
                     if (sym == 0xFFFFFFFFu) {
                         err = 2;
                         break;
@@ -371,8 +398,8 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ d_co
                         s.lens[288 + (i - nlit)] = lv[k];
                 }
             }
-            if (!build_table(s.lens, nlit, s.lit_lut, kLitBits, s.lit_sorted, s.lit_count, lane) ||
-                !build_table(s.lens + 288, ndist, s.dist_lut, kDistBits, s.dist_sorted, s.dist_count, lane)) {
+            if (!build_table(s.lens, nlit, s.lit_lut, kLitBits, s.lit_sorted, s.lit_count, lane, EncLit()) ||
+                !build_table(s.lens + 288, ndist, s.dist_lut, kDistBits, s.dist_sorted, s.dist_count, lane, EncDist())) {
                 err = 2;
                 break;
             }
@@ -384,38 +411,30 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ d_co
                 unsigned long long v = peek_at(s, br.bitpos + lane);
                 uint32_t kind, tl, val = 0;
                 {
-                    uint32_t e = s.lit_lut[(uint32_t)v & ((1u << kLitBits) - 1u)];
-                    uint32_t l1 = e & 15, sym = e >> 4;
+                    const uint32_t e = s.lit_lut[(uint32_t)v & ((1u << kLitBits) - 1u)];
+                    const uint32_t l1 = e & 15;
                     if (e == 0) {  // longer than the primary table: decoded serially IF it is a real token start
                         kind = kSlow;
                         tl = 0;
-                    } else if (sym > 285) {
-                        kind = kBad;
-                        tl = 1;
-                    } else if (sym < 256) {
-                        kind = kLit;
-                        tl = l1;
-                        val = sym;
-                    } else if (sym == 256) {
-                        kind = kEob;
-                        tl = l1;
+                    } else if (!(e & 0x8000u)) {
+                        kind = (e & (1u << 13)) ? kBad : (e & (1u << 12)) ? kEob : kLit;
+                        tl = kind == kBad ? 1 : l1;
+                        val = (e >> 4) & 0xFFu;
                     } else {
-                        uint32_t si = sym - 257;
-                        uint32_t lx = s.len_extra[si];
-                        uint32_t len = s.len_base[si] + ((uint32_t)(v >> l1) & ((1u << lx) - 1u));
-                        uint32_t t = l1 + lx;
-                        unsigned long long v2 = v >> t;
-                        uint32_t de = s.dist_lut[(uint32_t)v2 & ((1u << kDistBits) - 1u)];
-                        uint32_t l2 = de & 15, ds = de >> 4;
+                        const uint32_t lx = (e >> 4) & 7u;
+                        const uint32_t len = ((e >> 7) & 0xFFu) + 3u + ((uint32_t)(v >> l1) & ((1u << lx) - 1u));
+                        const uint32_t t = l1 + lx;
+                        const unsigned long long v2 = v >> t;
+                        const uint32_t de = s.dist_lut[(uint32_t)v2 & ((1u << kDistBits) - 1u)];
+                        const uint32_t l2 = de & 15, dx = (de >> 4) & 15u;
                         if (de == 0) {
                             kind = kSlow;
                             tl = 0;
-                        } else if (ds > 29) {
+                        } else if (de & (1u << 8)) {
                             kind = kBad;
                             tl = 1;
                         } else {
-                            uint32_t dx = s.dist_extra[ds];
-                            uint32_t dist = s.dist_base[ds] + ((uint32_t)(v2 >> l2) & ((1u << dx) - 1u));
+                            const uint32_t dist = (de >> 16) + ((uint32_t)(v2 >> l2) & ((1u << dx) - 1u));
                             kind = kMatch;
                             tl = t + l2 + dx;  // <= 15 + 5 + 15 + 13 = 48 bits
                             val = len | (dist << 16);
@@ -491,7 +510,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ d_co
                 br.bitpos += advance;
                 if (slow_token && !eob && !err) {
                     // one token with a code longer than the primary tables, decoded by every lane uniformly
-                    uint32_t sym = decode_sym(s, br, s.lit_lut, kLitBits, s.lit_sorted, s.lit_count, lane);
+                    uint32_t sym = decode_serial(s, br, s.lit_sorted, s.lit_count, lane);
                     if (sym < 256) {
                         if (pos >= cap) {
                             err = 4;
@@ -507,7 +526,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ d_co
                     } else {
                         sym -= 257;
                         uint32_t len = kLenBase[sym] + getbits(s, br, kLenExtra[sym], lane);
-                        uint32_t ds = decode_sym(s, br, s.dist_lut, kDistBits, s.dist_sorted, s.dist_count, lane);
+                        uint32_t ds = decode_serial(s, br, s.dist_sorted, s.dist_count, lane);
                         if (ds > 29) {
                             err = 3;
                         } else {
