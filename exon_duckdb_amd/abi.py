@@ -1,7 +1,7 @@
 """ctypes mirror of include/exon_gpu.h (keep in sync with the header; tests check sizes)."""
 import ctypes as C
 
-EXG_ABI_VERSION = 1
+EXG_ABI_VERSION = 2
 EXG_VECTOR_SIZE = 2048
 
 EXG_OK = 0

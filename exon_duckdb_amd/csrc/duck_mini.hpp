@@ -11,6 +11,7 @@
 // a mechanical mapping.
 #pragma once
 #include <stdint.h>
+#include <stdio.h>
 
 #include <functional>
 #include <map>
@@ -73,9 +74,68 @@ struct TableFunctionBindInput {
     std::map<std::string, std::string> named_parameters;    // e.g. compression
     const TableFunctionInfo *info = nullptr;
 };
+// duckdb/planner/table_filter.hpp + filter/{constant,conjunction,null}_filter.hpp, the part FilterToString reads
+enum class TableFilterType : uint8_t { CONSTANT_COMPARISON = 0, IS_NULL = 1, IS_NOT_NULL = 2, CONJUNCTION_OR = 3, CONJUNCTION_AND = 4 };
+enum class ExpressionType : uint8_t {
+    COMPARE_EQUAL = 25,
+    COMPARE_NOTEQUAL = 26,
+    COMPARE_LESSTHAN = 27,
+    COMPARE_GREATERTHAN = 28,
+    COMPARE_LESSTHANOREQUALTO = 29,
+    COMPARE_GREATERTHANOREQUALTO = 30
+};
+// duckdb::Value, reduced to what a pushed-down constant of these columns can be
+struct Value {
+    LogicalTypeId type = LogicalTypeId::VARCHAR;
+    std::string str;
+    int64_t i = 0;
+    double f = 0;
+    // Value::ToSQLString: strings quoted with '' escaping, numbers bare
+    std::string ToSQLString() const {
+        if (type == LogicalTypeId::VARCHAR) {
+            std::string out = "'";
+            for (char c : str) {
+                if (c == '\'') out += "'";
+                out += c;
+            }
+            return out + "'";
+        }
+        if (type == LogicalTypeId::BIGINT) return std::to_string(i);
+        char buf[64];
+        snprintf(buf, sizeof buf, "%.9g", f);
+        std::string t = buf;
+        if (t.find_first_of(".eEn") == std::string::npos) t += ".0";
+        return t;
+    }
+};
+struct TableFilter {
+    TableFilterType filter_type;
+    explicit TableFilter(TableFilterType t) : filter_type(t) {}
+    virtual ~TableFilter() = default;
+};
+struct ConstantFilter : TableFilter {
+    ExpressionType comparison_type;
+    Value constant;
+    ConstantFilter(ExpressionType c, Value v) : TableFilter(TableFilterType::CONSTANT_COMPARISON), comparison_type(c), constant(std::move(v)) {}
+};
+struct IsNullFilter : TableFilter {
+    IsNullFilter() : TableFilter(TableFilterType::IS_NULL) {}
+};
+struct IsNotNullFilter : TableFilter {
+    IsNotNullFilter() : TableFilter(TableFilterType::IS_NOT_NULL) {}
+};
+struct ConjunctionFilter : TableFilter {
+    std::vector<std::unique_ptr<TableFilter>> child_filters;
+    explicit ConjunctionFilter(TableFilterType t) : TableFilter(t) {}
+};
+struct TableFilterSet {
+    std::map<idx_t, std::unique_ptr<TableFilter>> filters;  // key: index into column_ids
+};
+
 struct TableFunctionInitInput {
     const FunctionData *bind_data = nullptr;
     std::vector<idx_t> column_ids;  // projection pushdown
+    const TableFilterSet *filters = nullptr;  // filter pushdown
 };
 struct TableFunctionInput {
     const FunctionData *bind_data = nullptr;

@@ -340,6 +340,11 @@ void gather_u64(const uint64_t *d_in, const uint32_t *d_row_map, uint64_t n_out,
     uint32_t grid = (uint32_t)((n_out + 255) / 256 < 8192 ? (n_out + 255) / 256 : 8192);
     hipLaunchKernelGGL(k_gather<uint64_t>, dim3(grid), dim3(256), 0, stream, d_in, d_row_map, n_out, d_out);
 }
+void gather_u128(const void *d_in, const uint32_t *d_row_map, uint64_t n_out, void *d_out, hipStream_t stream) {
+    if (!n_out) return;
+    uint32_t grid = (uint32_t)((n_out + 255) / 256 < 8192 ? (n_out + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_gather<uint4>, dim3(grid), dim3(256), 0, stream, (const uint4 *)d_in, d_row_map, n_out, (uint4 *)d_out);
+}
 void gather_u32(const uint32_t *d_in, const uint32_t *d_row_map, uint64_t n_out, uint32_t *d_out, hipStream_t stream) {
     if (!n_out) return;
     uint32_t grid = (uint32_t)((n_out + 255) / 256 < 8192 ? (n_out + 255) / 256 : 8192);

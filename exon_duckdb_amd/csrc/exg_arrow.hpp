@@ -84,6 +84,7 @@ void filter_rows(const FilterProgram *d_prog, const FilterCols *d_cols, const ui
 void gather_bits(const uint64_t *d_in, const uint32_t *d_row_map, uint64_t n_out, uint64_t *d_out, hipStream_t stream);
 void gather_u64(const uint64_t *d_in, const uint32_t *d_row_map, uint64_t n_out, uint64_t *d_out, hipStream_t stream);
 void gather_u32(const uint32_t *d_in, const uint32_t *d_row_map, uint64_t n_out, uint32_t *d_out, hipStream_t stream);
+void gather_u128(const void *d_in, const uint32_t *d_row_map, uint64_t n_out, void *d_out, hipStream_t stream);  // string_t
 
 // ---- VCF typed columns (exg_vcf_typed.hip) ------------------------------------------------------------------
 enum : uint8_t { kVtFlag = 0, kVtInt = 1, kVtFloat = 2, kVtString = 3 };

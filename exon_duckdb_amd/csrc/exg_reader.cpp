@@ -29,6 +29,7 @@
 #include <thread>
 #include <vector>
 
+#include "exg_filter.hpp"
 #include "exg_reader.hpp"
 
 namespace exg_rd {
@@ -80,6 +81,8 @@ int exg_reader::dev_alloc(void **slot, size_t bytes) {
 exg_reader::~exg_reader() {
     free_device();
     if (d_res) (void)hipFree(d_res);
+    if (d_filter_prog) (void)hipFree(d_filter_prog);
+    if (d_filter_consts) (void)hipFree(d_filter_consts);
     if (d_file) (void)hipFree(d_file);
     if (up_done) (void)hipEventDestroy(up_done);
     if (up_stream) (void)hipStreamDestroy(up_stream);
@@ -321,6 +324,11 @@ int ensure_device(exg_reader *r, uint64_t need_bytes) {
         if ((arc = r->dev_alloc(&r->d_qual, r->cap_records * 4))) return arc;
     }
     if (r->format == EXG_FMT_FASTA && (arc = r->dev_alloc(&r->d_payload, cap + 64))) return arc;
+    if (r->has_filter) {
+        if ((arc = r->dev_alloc(&r->d_row_map, r->cap_records * 4 + 64))) return arc;
+        if ((arc = r->dev_alloc(&r->d_gather, r->cap_records * 16))) return arc;
+        if ((arc = r->dev_alloc(&r->d_filter_tmp, (r->cap_records + 1 + exg::arrow::scan_tmp_entries(r->cap_records)) * 8))) return arc;
+    }
     if (!r->d_res) RD_HIP(r, hipMalloc(&r->d_res, sizeof(exg_scan_result)));
     return EXG_OK;
 }
@@ -434,7 +442,8 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             d_input = r->d_in;
         }
         exg_scan_result res;
-        const uint32_t fl = (lead ? 0u : EXG_F_BOF) | (eof ? EXG_F_EOF : 0u) | (count_only ? EXG_F_NO_STORE : 0u);
+        const bool no_store = count_only && !r->has_filter;  // a predicate needs the columns even for COUNT(*)
+        const uint32_t fl = (lead ? 0u : EXG_F_BOF) | (eof ? EXG_F_EOF : 0u) | (no_store ? EXG_F_NO_STORE : 0u);
         std::shared_ptr<Batch> b;
         if (r->format == EXG_FMT_FASTQ) {
             exg_fastq_scan_args a;
@@ -508,7 +517,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         TRACE("wait(h2d) + scan", t_scan);
         if (res.flags & EXG_RF_INDEX_OVERFLOW)
             return fail(r, EXG_E_CAPACITY, "line index overflow in the general path (pathological line density)");
-        if ((res.flags & EXG_RF_CAPACITY) && !count_only) {
+        if ((res.flags & EXG_RF_CAPACITY) && !no_store) {
             if (r->worst_case_rows) return fail(r, EXG_E_CAPACITY, "more rows than bytes allow: internal error");
             RD_HIP(r, hipStreamSynchronize(r->stream));  // denser rows than provisioned: worst-case vectors, same batch again
             r->free_device();
@@ -543,7 +552,42 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             }
         }
         TRACE("prefetch issue", t_pf);
-        const uint64_t k = res.n_records;
+        uint64_t k = res.n_records;
+        const uint32_t *row_map = nullptr;
+        if (r->has_filter && k && !r->arrow_emit) {
+            // rows where the predicate is TRUE -> row map; the columns are gathered through it on their way out
+            namespace ea = exg::arrow;
+            ea::FilterCols fc;
+            memset(&fc, 0, sizeof fc);
+            const int nsc = n_string_cols(r->format);
+            for (int c = 0; c < nsc; c++) {
+                fc.kind[c] = ea::kColStr;
+                fc.data[c] = r->d_cols[c];
+                fc.d_base[c] = (const uint8_t *)d_input;
+                fc.payload_base[c] = (uint64_t)(uintptr_t)h;
+            }
+            if (r->format == EXG_FMT_VCF) {
+                fc.kind[1] = ea::kColI64, fc.data[1] = r->d_pos;
+                fc.kind[5] = ea::kColF32, fc.data[5] = r->d_qual, fc.validity[5] = (const uint64_t *)r->d_valid[0];
+                fc.validity[8] = (const uint64_t *)r->d_valid[1];
+            } else {
+                fc.validity[1] = (const uint64_t *)r->d_valid[0];
+                if (r->format == EXG_FMT_FASTA) {
+                    fc.d_base[2] = (const uint8_t *)r->d_payload;
+                    fc.payload_base[2] = (uint64_t)(uintptr_t)(b ? b->payload : nullptr);
+                }
+            }
+            uint64_t *d_goff = (uint64_t *)r->d_filter_tmp, *d_tmp = d_goff + r->cap_records + 1;
+            ea::FilterCols *d_fc = (ea::FilterCols *)r->d_gather;  // the scratch column is free until the gathers
+            RD_HIP(r, hipMemcpyAsync(d_fc, &fc, sizeof fc, hipMemcpyHostToDevice, r->stream));
+            ea::filter_rows((const ea::FilterProgram *)r->d_filter_prog, d_fc, (const uint8_t *)r->d_filter_consts, k, d_goff,
+                            d_tmp, (uint32_t *)r->d_row_map, r->stream);
+            uint64_t n_sel = 0;
+            RD_HIP(r, hipMemcpyAsync(&n_sel, d_goff + k, 8, hipMemcpyDeviceToHost, r->stream));
+            RD_HIP(r, hipStreamSynchronize(r->stream));
+            k = n_sel;
+            row_map = (const uint32_t *)r->d_row_map;
+        }
         *n_records_out = k;
         if (r->arrow_emit && !count_only) {
             // new_reader: the columns stay in HBM and become Arrow buffers there (exg_arrow_stream.cpp)
@@ -572,10 +616,23 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
                 if (r->format == EXG_FMT_VCF && c == 5) src = r->d_qual, es = 4;
                 b->elem[c] = es;
                 if (!(b->cols[c] = b->host.alloc(k * es))) return fail(r, EXG_E_HIP, "out of pinned host memory");
+                if (row_map) {
+                    if (es == 16)
+                        exg::arrow::gather_u128(src, row_map, k, r->d_gather, r->stream);
+                    else if (es == 8)
+                        exg::arrow::gather_u64((const uint64_t *)src, row_map, k, (uint64_t *)r->d_gather, r->stream);
+                    else
+                        exg::arrow::gather_u32((const uint32_t *)src, row_map, k, (uint32_t *)r->d_gather, r->stream);
+                    src = r->d_gather;
+                }
                 RD_HIP(r, hipMemcpyAsync(b->cols[c], src, k * es, hipMemcpyDeviceToHost, r->stream));
             }
             auto copy_validity = [&](int col, const void *d) -> int {
                 if (!(b->validity[col] = b->host.alloc(vw))) return fail(r, EXG_E_HIP, "out of pinned host memory");
+                if (row_map) {
+                    exg::arrow::gather_bits((const uint64_t *)d, row_map, k, (uint64_t *)r->d_gather, r->stream);
+                    d = r->d_gather;
+                }
                 RD_HIP(r, hipMemcpyAsync(b->validity[col], d, vw, hipMemcpyDeviceToHost, r->stream));
                 return EXG_OK;
             };
@@ -653,6 +710,29 @@ extern "C" int exg_open(const exg_open_args *args, exg_reader **out) {
     if (he != hipSuccess) {
         exg::set_error("cannot initialise device %d: %s", r->device, hipGetErrorString(he));
         return EXG_E_HIP;
+    }
+    if (args->filters && *args->filters) {
+        // `SELECT * FROM exon_table WHERE <filters>` (arrow_reader.rs:125-141), evaluated on the device
+        exg_schema sch;
+        exg_schema_of(r.get(), &sch);
+        std::vector<FilterColumn> fcols;
+        for (int c = 0; c < sch.n_columns; c++)
+            fcols.push_back({sch.names[c], sch.types[c] == EXG_TYPE_BIGINT ? 'l' : sch.types[c] == EXG_TYPE_FLOAT ? 'f' : 'u'});
+        const std::string text = args->filters;
+        FilterParser fp(text, fcols);
+        if (!fp.parse()) {
+            exg::set_error("could not execute sql: %s", fp.err.c_str());
+            return EXG_E_INVALID_ARG;
+        }
+        if (hipMalloc(&r->d_filter_prog, sizeof fp.prog) != hipSuccess ||
+            hipMalloc(&r->d_filter_consts, fp.consts.size() + 16) != hipSuccess ||
+            hipMemcpy(r->d_filter_prog, &fp.prog, sizeof fp.prog, hipMemcpyHostToDevice) != hipSuccess ||
+            (!fp.consts.empty() &&
+             hipMemcpy(r->d_filter_consts, fp.consts.data(), fp.consts.size(), hipMemcpyHostToDevice) != hipSuccess)) {
+            exg::set_error("could not execute sql: device allocation failed");
+            return EXG_E_HIP;
+        }
+        r->has_filter = true;
     }
     *out = r.release();
     return EXG_OK;

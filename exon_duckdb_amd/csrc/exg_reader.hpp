@@ -220,7 +220,11 @@ struct exg_reader {
     size_t host_hint = 0;  // pinned bytes the previous batch's host vectors needed
     std::vector<std::pair<void **, size_t>> dev_allocs;  // pooled device buffers of this reader (slot, bytes)
     int dev_alloc(void **slot, size_t bytes);
-    bool worst_case_rows = false;  // output vectors sized for the densest possible input (after an overflow)
+    bool worst_case_rows = false;
+    // exg_open_args.filters: postfix program + constants in device memory, a row map and one column of scratch
+    bool has_filter = false;
+    void *d_filter_prog = nullptr, *d_filter_consts = nullptr;
+    void *d_row_map = nullptr, *d_gather = nullptr, *d_filter_tmp = nullptr;  // output vectors sized for the densest possible input (after an overflow)
     void *d_valid[2] = {nullptr, nullptr};
     void *d_cols[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     void *d_pos = nullptr, *d_qual = nullptr, *d_payload = nullptr;

@@ -7,9 +7,10 @@
 //
 // Deliberate differences from the reference, all listed in SURVEY.md Appendix B / §7.2:
 //   * bind does not open a second full reader and leak it (module.cpp:82-155);
-//   * filter_pushdown is false: DuckDB applies filters above the scan, results are identical
-//     (the reference renders them to SQL for DataFusion, module.cpp:158-214);
+//   * filters are pushed down like the reference's (rendered by FilterToString, module.cpp:158-214) but
+//     evaluated on the device: rejected rows never cross PCIe;
 //   * COUNT(*) (only COLUMN_IDENTIFIER_ROW_ID projected) never materialises a column.
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -54,9 +55,10 @@ struct ChunkBuffer {  // VectorBuffer: releases the engine chunk when the last V
     ~ChunkBuffer() { exg_release_chunk(reader, &chunk); }
 };
 
-static exg_reader *open_reader(const ExonScanFunctionData &d) {
+static exg_reader *open_reader(const ExonScanFunctionData &d, const std::string &filter_clause = "") {
     exg_open_args a;
     memset(&a, 0, sizeof a);
+    a.filters = filter_clause.empty() ? nullptr : filter_clause.c_str();                // module.cpp:239-243
     a.path = d.file_name.c_str();
     a.file_format = d.file_type.c_str();
     a.compression = d.compression == "auto_detect" ? nullptr : d.compression.c_str();  // module.cpp:95-103
@@ -64,6 +66,52 @@ static exg_reader *open_reader(const ExonScanFunctionData &d) {
     exg_reader *r = nullptr;
     if (exg_open(&a, &r) != EXG_OK) throw std::runtime_error(exg_last_error_message());  // module.cpp:105-108
     return r;
+}
+
+// ExpressionTypeToOperator (duckdb/common/enums/expression_type.cpp) for the comparison types a filter carries
+static std::string ExpressionTypeToOperator(ExpressionType t) {
+    switch (t) {
+        case ExpressionType::COMPARE_EQUAL: return "=";
+        case ExpressionType::COMPARE_NOTEQUAL: return "!=";
+        case ExpressionType::COMPARE_LESSTHAN: return "<";
+        case ExpressionType::COMPARE_GREATERTHAN: return ">";
+        case ExpressionType::COMPARE_LESSTHANOREQUALTO: return "<=";
+        default: return ">=";
+    }
+}
+
+static std::string Join(const std::vector<std::string> &v, const std::string &sep) {
+    std::string out;
+    for (size_t i = 0; i < v.size(); i++) out += (i ? sep : "") + v[i];
+    return out;
+}
+
+// module.cpp:158-199, same output text (note: no parentheses, like the reference)
+static std::string FilterToString(const TableFilter &filter, const std::string &column_name) {
+    switch (filter.filter_type) {
+        case TableFilterType::CONSTANT_COMPARISON: {
+            auto &cf = static_cast<const ConstantFilter &>(filter);
+            return column_name + ExpressionTypeToOperator(cf.comparison_type) + cf.constant.ToSQLString();
+        }
+        case TableFilterType::CONJUNCTION_AND:
+        case TableFilterType::CONJUNCTION_OR: {
+            auto &cj = static_cast<const ConjunctionFilter &>(filter);
+            std::vector<std::string> parts;
+            for (auto &c : cj.child_filters) parts.push_back(FilterToString(*c, column_name));
+            return Join(parts, filter.filter_type == TableFilterType::CONJUNCTION_AND ? " AND " : " OR ");
+        }
+        case TableFilterType::IS_NOT_NULL: return column_name + " IS NOT NULL";
+        case TableFilterType::IS_NULL: return column_name + " IS NULL";
+    }
+    throw std::runtime_error("FilterToString: filter type not implemented");
+}
+
+// module.cpp:201-214
+static std::string FilterToString(const TableFilterSet &set, const std::vector<idx_t> &column_ids,
+                                  const std::vector<std::string> &column_names) {
+    std::vector<std::string> parts;
+    for (auto &f : set.filters) parts.push_back(FilterToString(*f.second, column_names.at(column_ids.at(f.first))));
+    return Join(parts, " AND ");
 }
 
 struct WTArrowTableFunction {
@@ -99,7 +147,9 @@ struct WTArrowTableFunction {
         gs->column_ids = input.column_ids;
         gs->count_only = std::all_of(input.column_ids.begin(), input.column_ids.end(),
                                      [](idx_t c) { return c == COLUMN_IDENTIFIER_ROW_ID; });
-        gs->reader = open_reader(data);
+        std::string filter_clause;
+        if (input.filters) filter_clause = FilterToString(*input.filters, input.column_ids, data.all_names);  // module.cpp:222-226
+        gs->reader = open_reader(data, filter_clause);
         return gs;
     }
 
@@ -154,7 +204,7 @@ struct WTArrowTableFunction {
         scan.function_info = std::make_shared<WTArrowTableScanInfo>(file_type);
         scan.named_parameters["compression"] = LogicalType{LogicalTypeId::VARCHAR};
         scan.projection_pushdown = true;
-        scan.filter_pushdown = false;
+        scan.filter_pushdown = true;
         catalog.CreateTableFunction(scan);
     }
 
@@ -259,6 +309,58 @@ extern "C" int exon_tf_init(exon_tf_handle *h, const uint64_t *column_ids, int n
     in.bind_data = h->bind_data.get();
     in.column_ids.assign(column_ids, column_ids + n);
     try {
+        h->global = h->fn->init_global(in);
+        h->local = h->fn->init_local(in, h->global.get());
+    } catch (const std::exception &e) {
+        exg::set_error("%s", e.what());
+        return EXG_E_IO;
+    }
+    return EXG_OK;
+}
+
+// The same with a TableFilterSet, described as a flat pre-order list of nodes:
+//   kind 0 constant comparison (cmp = ExpressionType value, constant text, const_type = column type id),
+//   1 IS NULL, 2 IS NOT NULL, 3 OR / 4 AND with n_children following nodes; `column` = key of the set
+//   (index into column_ids) on top-level nodes.
+struct exon_tf_filter_node {
+    int kind, column, cmp, const_type, n_children;
+    const char *constant;
+};
+static std::unique_ptr<TableFilter> build_filter(const exon_tf_filter_node *nodes, int n, int *pos) {
+    if (*pos >= n) throw std::runtime_error("malformed filter description");
+    const exon_tf_filter_node &nd = nodes[(*pos)++];
+    switch (nd.kind) {
+        case 0: {
+            Value v;
+            v.type = (LogicalTypeId)nd.const_type;
+            v.str = nd.constant ? nd.constant : "";
+            if (v.type == LogicalTypeId::BIGINT) v.i = strtoll(v.str.c_str(), nullptr, 10);
+            if (v.type == LogicalTypeId::FLOAT) v.f = strtod(v.str.c_str(), nullptr);
+            return std::make_unique<ConstantFilter>((ExpressionType)nd.cmp, v);
+        }
+        case 1: return std::make_unique<IsNullFilter>();
+        case 2: return std::make_unique<IsNotNullFilter>();
+        default: {
+            auto cj = std::make_unique<ConjunctionFilter>(nd.kind == 4 ? TableFilterType::CONJUNCTION_AND : TableFilterType::CONJUNCTION_OR);
+            for (int k = 0; k < nd.n_children; k++) cj->child_filters.push_back(build_filter(nodes, n, pos));
+            return cj;
+        }
+    }
+}
+extern "C" int exon_tf_init_filtered(exon_tf_handle *h, const uint64_t *column_ids, int n, const exon_tf_filter_node *nodes,
+                                     int n_nodes) {
+    TableFunctionInitInput in;
+    in.bind_data = h->bind_data.get();
+    in.column_ids.assign(column_ids, column_ids + n);
+    TableFilterSet set;
+    try {
+        if (!h->fn->filter_pushdown && n_nodes) throw std::runtime_error("filter pushdown is off for this function");
+        int pos = 0;
+        while (pos < n_nodes) {
+            const idx_t key = (idx_t)nodes[pos].column;
+            set.filters[key] = build_filter(nodes, n_nodes, &pos);
+        }
+        in.filters = n_nodes ? &set : nullptr;
         h->global = h->fn->init_global(in);
         h->local = h->fn->init_local(in, h->global.get());
     } catch (const std::exception &e) {

@@ -27,6 +27,52 @@ class Chunk(C.Structure):
                 ("validity", C.c_void_p * 16), ("keepalive", C.c_void_p)]
 
 
+class FilterNode(C.Structure):
+    _fields_ = [("kind", C.c_int), ("column", C.c_int), ("cmp", C.c_int), ("const_type", C.c_int), ("n_children", C.c_int),
+                ("constant", C.c_char_p)]
+
+
+class F:
+    """Builders of DuckDB TableFilters (what the optimizer hands a scan with filter_pushdown = true):
+    F.cmp('>=', 'r5'), F.isnull(), F.notnull(), F.and_(...), F.or_(...)."""
+    OPS = {"=": 25, "!=": 26, "<": 27, ">": 28, "<=": 29, ">=": 30}
+
+    @staticmethod
+    def cmp(op, value):
+        return ("cmp", F.OPS[op], value)
+
+    @staticmethod
+    def isnull():
+        return ("isnull",)
+
+    @staticmethod
+    def notnull():
+        return ("notnull",)
+
+    @staticmethod
+    def and_(*children):
+        return ("and", children)
+
+    @staticmethod
+    def or_(*children):
+        return ("or", children)
+
+
+def _flatten(node, column, const_type, out):
+    if node[0] == "cmp":
+        v = node[2]
+        text = v if isinstance(v, bytes) else str(v).encode()
+        out.append(FilterNode(0, column, node[1], const_type, 0, text))
+    elif node[0] == "isnull":
+        out.append(FilterNode(1, column, 0, 0, 0, None))
+    elif node[0] == "notnull":
+        out.append(FilterNode(2, column, 0, 0, 0, None))
+    else:
+        out.append(FilterNode(4 if node[0] == "and" else 3, column, 0, 0, len(node[1]), None))
+        for ch in node[1]:
+            _flatten(ch, column, const_type, out)
+
+
 _bound = False
 
 
@@ -41,6 +87,8 @@ def _lib():
         l.exon_tf_schema.argtypes = [C.c_void_p, C.POINTER(Schema)]
         l.exon_tf_init.restype = C.c_int
         l.exon_tf_init.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
+        l.exon_tf_init_filtered.restype = C.c_int
+        l.exon_tf_init_filtered.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int, C.POINTER(FilterNode), C.c_int]
         l.exon_tf_scan.restype = C.c_int
         l.exon_tf_scan.argtypes = [C.c_void_p, C.POINTER(Chunk)]
         l.exon_tf_close.argtypes = [C.c_void_p]
@@ -88,7 +136,7 @@ class Relation:
         self.types = [sch.types[i] for i in range(sch.n_columns)]
         self._l.exon_tf_close(h)
 
-    def _scan(self, column_ids):
+    def _scan(self, column_ids, filters=None):
         h = C.c_void_p()
         rc = self._l.exon_tf_bind(self.fn_name.encode(), self.path.encode(),
                                   self.compression.encode() if self.compression else None, C.byref(h))
@@ -96,7 +144,17 @@ class Relation:
             raise ExgError(rc, _err(self._l))
         try:
             ids = (C.c_uint64 * len(column_ids))(*column_ids)
-            if self._l.exon_tf_init(h, ids, len(column_ids)) != 0:
+            if filters:
+                # TableFilterSet: keyed by the position of the column in column_ids (module.cpp:201-214)
+                nodes = []
+                for name, node in filters.items():
+                    cid = self.names.index(name)
+                    _flatten(node, list(column_ids).index(cid), self.types[cid], nodes)
+                arr = (FilterNode * len(nodes))(*nodes)
+                rc = self._l.exon_tf_init_filtered(h, ids, len(column_ids), arr, len(nodes))
+            else:
+                rc = self._l.exon_tf_init(h, ids, len(column_ids))
+            if rc != 0:
                 raise ExgError(abi.EXG_E_IO, _err(self._l))
             while True:
                 ch = Chunk()
@@ -108,23 +166,31 @@ class Relation:
         finally:
             self._l.exon_tf_close(h)
 
-    def count(self):
-        """SELECT count(*): only the row id is projected, no column is materialised."""
-        return sum(int(ch.n_rows) for ch in self._scan([ROW_ID]))
+    def count(self, filters=None):
+        """SELECT count(*) [WHERE filters]: only the row id (and the filter columns) are projected."""
+        ids = [ROW_ID]
+        if filters:
+            ids += [self.names.index(c) for c in filters]
+        return sum(int(ch.n_rows) for ch in self._scan(ids, filters))
 
     def chunk_sizes(self, columns=None):
         cols = self.names if columns is None else columns
         return [int(ch.n_rows) for ch in self._scan([self.names.index(c) for c in cols])]
 
-    def fetchall(self, columns=None, limit=None, where=None):
-        """SELECT columns ... [WHERE where(row_dict)] [LIMIT limit] -> list of tuples (bytes/None/int/float)."""
+    def fetchall(self, columns=None, limit=None, where=None, filters=None):
+        """SELECT columns ... [WHERE where(row_dict)] [LIMIT limit] -> list of tuples (bytes/None/int/float).
+        `filters` = {column: F....}: pushed down into the scan like DuckDB's TableFilterSet; `where` = a Python
+        predicate applied above the scan."""
         cols = self.names if columns is None else columns
         ids = [self.names.index(c) for c in cols]
+        for c in (filters or {}):                     # DuckDB keeps filter columns in column_ids
+            if self.names.index(c) not in ids:
+                ids.append(self.names.index(c))
         rows = []
-        for ch in self._scan(ids):
+        for ch in self._scan(ids, filters):
             n = int(ch.n_rows)
             decoded = []
-            for k, cid in enumerate(ids):
+            for k, cid in enumerate(ids[:len(cols)]):
                 t = self.types[cid]
                 if t == abi_type("VARCHAR"):
                     decoded.append(_decode_strings(ch.data[k], ch.validity[k], n))

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define EXG_ABI_VERSION 1
+#define EXG_ABI_VERSION 2
 
 /* DuckDB v0.8.1 STANDARD_VECTOR_SIZE; the reference asks the Rust side for
  * batches of exactly this many rows (module.cpp:83, :233). */
@@ -259,6 +259,9 @@ typedef struct exg_open_args {
     uint64_t batch_rows;     /* rows per chunk; 0 => EXG_VECTOR_SIZE */
     int device;              /* HIP device ordinal */
     uint64_t device_batch_bytes; /* bytes shipped to HBM per launch; 0 => default */
+    const char *filters;     /* NULL / "" or the predicate FilterToString renders (module.cpp:158-214), same grammar as
+                              * new_reader's: evaluated on the device, only the rows where it is TRUE are copied back.
+                              * VCF id / alt / filter / info / formats are VARCHAR at this boundary and may be compared. */
 } exg_open_args;
 
 #define EXG_TYPE_VARCHAR 1

@@ -264,3 +264,74 @@ def test_prefetch_miss_and_batch_growth(con, oracle, tmp_path, monkeypatch):
         rel = con.table_function("read_fastq", str(tmp_path / "long.fastq"))
         assert rel.count() == 40
         assert rel.fetchall() == want
+
+
+# ---- filter pushdown (scan.filter_pushdown = true, module.cpp:311): TableFilterSet -> FilterToString -> device ------
+
+def test_filter_pushdown_reference_statement(con, golden_dir):
+    # SELECT * FROM read_fasta('…/test.fasta') WHERE id = 'a'                      (test_fasta_scan.test:34-37)
+    from exon_duckdb_amd.table_function import F
+    rel = con.table_function("read_fasta", G(golden_dir, "test.fasta"))
+    rows = rel.fetchall(filters={"id": F.cmp("=", "a")})
+    assert [r[0] for r in rows] == [b"a"]
+    assert rel.count(filters={"id": F.cmp("=", "a")}) == 1
+    assert rel.count(filters={"id": F.cmp("!=", "a")}) == 1
+
+
+def _fq_cases():
+    from exon_duckdb_amd.table_function import F
+    return [
+        ({"description": F.isnull()}, lambda r: r["description"] is None),
+        ({"description": F.notnull(), "name": F.cmp(">", b"r5")}, lambda r: r["description"] is not None and r["name"] > b"r5"),
+        ({"name": F.or_(F.cmp("=", b"SYNTH_RAGGED_17"), F.cmp("=", b"r4242"), F.and_(F.cmp(">=", b"r10"), F.cmp("<", b"r11")))},
+         lambda r: r["name"] in (b"SYNTH_RAGGED_17", b"r4242") or b"r10" <= r["name"] < b"r11"),
+        ({"sequence": F.cmp("<", b"AC"), "quality_scores": F.cmp(">=", b"5")}, lambda r: r["sequence"] < b"AC" and r["quality_scores"] >= b"5"),
+        ({"name": F.cmp("=", b"it's")}, lambda r: False),
+    ]
+
+
+@pytest.mark.parametrize("case", range(5))
+def test_filter_pushdown_fastq(con, oracle, tmp_path, monkeypatch, case):
+    filters, pred = _fq_cases()[case]
+    data = bytes(oracle.synth_fastq_ragged(6000))
+    (tmp_path / "r.fastq").write_bytes(data)
+    monkeypatch.setenv("EXG_DEVICE_BATCH_BYTES", str(300 << 10))
+    rel = con.table_function("read_fastq", str(tmp_path / "r.fastq"))
+    want = rel.fetchall(where=pred)                      # the same predicate applied above an unfiltered scan
+    assert rel.fetchall(filters=filters) == want
+    assert rel.count(filters=filters) == len(want)
+    assert rel.fetchall(columns=["sequence"], filters=filters) == [(r[2],) for r in want]
+
+
+def test_filter_pushdown_vcf(con, oracle, tmp_path, monkeypatch):
+    from exon_duckdb_amd.table_function import F
+    data = bytes(oracle.synth_vcf(8000))
+    (tmp_path / "s.vcf").write_bytes(data)
+    monkeypatch.setenv("EXG_DEVICE_BATCH_BYTES", str(100 << 10))
+    rel = con.table_function("read_vcf", str(tmp_path / "s.vcf"))
+    cases = [
+        ({"chrom": F.cmp("=", b"7"), "pos": F.and_(F.cmp(">=", 3000), F.cmp("<", 9000))},
+         lambda r: r["chrom"] == b"7" and 3000 <= r["pos"] < 9000),
+        ({"qual": F.or_(F.isnull(), F.cmp(">", 900.5))}, lambda r: r["qual"] is None or r["qual"] > 900.5),
+        ({"info": F.cmp(">=", b"DP=5"), "filter": F.cmp("!=", b"PASS")}, lambda r: r["info"] >= b"DP=5" and r["filter"] != b"PASS"),
+    ]
+    for filters, pred in cases:
+        want = rel.fetchall(where=pred)
+        assert len(want) > 0
+        assert rel.fetchall(filters=filters) == want
+        assert rel.count(filters=filters) == len(want)
+
+
+def test_filter_on_unknown_column_is_a_bind_time_error(gpu, golden_dir):
+    import ctypes as C
+    from exon_duckdb_amd.table_function import _lib  # noqa: F401  (binds the library)
+    from exon_duckdb_amd import load_library
+
+    class OpenArgs(C.Structure):
+        _fields_ = [("path", C.c_char_p), ("file_format", C.c_char_p), ("compression", C.c_char_p), ("batch_rows", C.c_uint64),
+                    ("device", C.c_int), ("device_batch_bytes", C.c_uint64), ("filters", C.c_char_p)]
+    lib = load_library()
+    a = OpenArgs(G(golden_dir, "test.fastq").encode(), b"fastq", None, 2048, 0, 0, b"nope='x'")
+    r = C.c_void_p()
+    assert lib.exg_open(C.byref(a), C.byref(r)) != 0
+    assert b"could not execute sql" in lib.exg_last_error_message()
