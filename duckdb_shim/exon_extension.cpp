@@ -18,6 +18,9 @@
 #include "duckdb/parser/expression/function_expression.hpp"
 #include "duckdb/parser/parsed_data/create_table_function_info.hpp"
 #include "duckdb/parser/tableref/table_function_ref.hpp"
+#include "duckdb/planner/filter/conjunction_filter.hpp"
+#include "duckdb/planner/filter/constant_filter.hpp"
+#include "duckdb/planner/table_filter.hpp"
 
 #include "exon_gpu.h"
 
@@ -36,6 +39,7 @@ struct WTArrowTableScanInfo : public TableFunctionInfo {
 struct ExonScanFunctionData : public TableFunctionData {
 	string file_type, compression, file_name;
 	vector<LogicalType> all_types;
+	vector<string> all_names;
 };
 
 struct ExonScanGlobalState : public GlobalTableFunctionState {
@@ -64,8 +68,39 @@ struct ExonChunkBuffer : public VectorBuffer {
 	exg_chunk chunk;
 };
 
-static exg_reader *OpenReader(const ExonScanFunctionData &d) {
+// the reference's FilterToString (module.cpp:158-214), unchanged in what it renders
+static string FilterToString(const TableFilter &filter, const string &column_name) {
+	switch (filter.filter_type) {
+	case TableFilterType::CONSTANT_COMPARISON: {
+		auto &cf = (const ConstantFilter &)filter;
+		return column_name + ExpressionTypeToOperator(cf.comparison_type) + cf.constant.ToSQLString();
+	}
+	case TableFilterType::CONJUNCTION_AND: {
+		vector<string> parts;
+		for (auto &c : ((const ConjunctionAndFilter &)filter).child_filters) {
+			parts.push_back(FilterToString(*c, column_name));
+		}
+		return StringUtil::Join(parts, " AND ");
+	}
+	case TableFilterType::CONJUNCTION_OR: {
+		vector<string> parts;
+		for (auto &c : ((const ConjunctionOrFilter &)filter).child_filters) {
+			parts.push_back(FilterToString(*c, column_name));
+		}
+		return StringUtil::Join(parts, " OR ");
+	}
+	case TableFilterType::IS_NOT_NULL:
+		return column_name + " IS NOT NULL";
+	case TableFilterType::IS_NULL:
+		return column_name + " IS NULL";
+	default:
+		throw NotImplementedException("FilterToString: filter type not implemented");
+	}
+}
+
+static exg_reader *OpenReader(const ExonScanFunctionData &d, const string &filter_clause = "") {
 	exg_open_args a {};
+	a.filters = filter_clause.empty() ? nullptr : filter_clause.c_str(); // evaluated on the device
 	a.path = d.file_name.c_str();
 	a.file_format = d.file_type.c_str();
 	a.compression = d.compression == "auto_detect" ? nullptr : d.compression.c_str();
@@ -105,6 +140,7 @@ static unique_ptr<FunctionData> FileTypeBind(ClientContext &, TableFunctionBindI
 		names.emplace_back(sch.names[i]);
 	}
 	result->all_types = return_types;
+	result->all_names = names;
 	return std::move(result);
 }
 
@@ -116,7 +152,15 @@ static unique_ptr<GlobalTableFunctionState> InitGlobal(ClientContext &, TableFun
 	for (auto c : input.column_ids) {
 		gs->count_only = gs->count_only && c == COLUMN_IDENTIFIER_ROW_ID;
 	}
-	gs->reader = OpenReader(data);
+	string filter_clause;
+	if (input.filters) { // module.cpp:222-226
+		vector<string> parts;
+		for (auto &f : input.filters->filters) {
+			parts.push_back(FilterToString(*f.second, data.all_names[input.column_ids[f.first]]));
+		}
+		filter_clause = StringUtil::Join(parts, " AND ");
+	}
+	gs->reader = OpenReader(data, filter_clause);
 	return std::move(gs);
 }
 
@@ -162,7 +206,7 @@ static void Register(const string &name, const string &file_type, DatabaseInstan
 	scan.function_info = make_shared<WTArrowTableScanInfo>(file_type);
 	scan.named_parameters["compression"] = LogicalType::VARCHAR;
 	scan.projection_pushdown = true;
-	scan.filter_pushdown = false; // DuckDB filters above the scan: identical results
+	scan.filter_pushdown = true; // like the reference (module.cpp:311); the predicate runs on the device
 	ExtensionUtil::RegisterFunction(db, scan);
 }
 
