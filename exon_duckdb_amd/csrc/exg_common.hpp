@@ -56,6 +56,17 @@ __device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v) {
     return v;
 }
 
+// inclusive wave64 prefix sum on the VALU (DPP row shifts + row broadcasts: no LDS traffic, unlike __shfl_up)
+__device__ __forceinline__ uint32_t wave_incl_sum_dpp(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 // Build a duckdb::string_t for the field d_in[s, s+len) reading bytes from global memory.
 __device__ __forceinline__ uint4 make_string_global(const uint8_t *d_in, uint64_t s, uint64_t len,
                                                      uint64_t payload_base) {

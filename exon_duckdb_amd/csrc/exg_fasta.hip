@@ -14,23 +14,10 @@
 // string_t).  Whole-file buffers only (EXG_F_BOF | EXG_F_EOF): a FASTA record can span the whole
 // input, so byte-range shards would split sequences.  The single-pass form is the
 // next step for this format.
-#include "exg_fastq_ws.hpp"
+#include "exg_fasta.hpp"
 #include "exg_lines.hpp"
 
 namespace exg {
-
-struct FastaDev {
-    const uint8_t *d_in;
-    uint64_t n_bytes;
-    uint64_t payload_base;
-    uint64_t seq_payload_base;
-    uint32_t flags;
-    uint32_t pad;
-    exg_string_t *d_id, *d_desc, *d_seq;
-    uint64_t *d_desc_valid;
-    uint8_t *d_payload;
-    uint64_t capacity;
-};
 
 struct FastaArrays {
     const uint64_t *nl_pos;
@@ -153,29 +140,6 @@ __global__ __launch_bounds__(1024) void k_fa_scan_add(FastaArrays w, const ScanW
 }
 
 // ---- definitions ----------------------------------------------------------------------------------------
-__device__ __forceinline__ bool is_ascii_ws(uint32_t b) { return b == ' ' || b == '\t' || b == '\n' || b == '\f' || b == '\r'; }
-
-// length of a Unicode White_Space scalar starting at p[i] (str::trim), 0 if none
-__device__ int ws_len_fwd(const uint8_t *p, uint64_t i, uint64_t e) {
-    if (i >= e) return 0;
-    uint32_t b = p[i];
-    if ((b >= 0x09 && b <= 0x0D) || b == 0x20) return 1;
-    if (i + 1 < e && b == 0xC2 && (p[i + 1] == 0x85 || p[i + 1] == 0xA0)) return 2;
-    if (i + 2 < e) {
-        uint32_t c1 = p[i + 1], c2 = p[i + 2];
-        if (b == 0xE1 && c1 == 0x9A && c2 == 0x80) return 3;
-        if (b == 0xE2 && c1 == 0x80 && ((c2 >= 0x80 && c2 <= 0x8A) || c2 == 0xA8 || c2 == 0xA9 || c2 == 0xAF)) return 3;
-        if (b == 0xE2 && c1 == 0x81 && c2 == 0x9F) return 3;
-        if (b == 0xE3 && c1 == 0x80 && c2 == 0x80) return 3;
-    }
-    return 0;
-}
-__device__ int ws_len_bwd(const uint8_t *p, uint64_t s, uint64_t e) {
-    for (int l = 1; l <= 3; l++)
-        if (e - s >= (uint64_t)l && ws_len_fwd(p, e - l, e) == l) return l;
-    return 0;
-}
-
 // pass 1, thread = line: remember which line defines record r (kept in rec_start[r] until pass 2)
 __global__ __launch_bounds__(256) void k_fa_def_lines(FastaDev a, FastaArrays w, ScanWsHeader *hdr) {
     const uint64_t T = hdr->total_lines < hdr->lines_cap ? hdr->total_lines : hdr->lines_cap;
@@ -514,6 +478,7 @@ extern "C" int exg_fasta_scan(const exg_fasta_scan_args *a) {
     uint64_t *block_sums = reinterpret_cast<uint64_t *>(ws + l.off_block_sums);
     if (a->capacity_records && !no_store)
         EXG_HIP_CHECK(hipMemsetAsync(a->d_description_validity, 0, (size_t)((a->capacity_records + 63) / 64) * 8, stream));
+    if (a->algo != EXG_ALGO_MULTIPASS) return run_fasta_tiled(dev, ws, l, a->d_result, stream);
     hipLaunchKernelGGL(k_init_hdr, dim3(1), dim3(1), 0, stream, hdr, l.lines_cap, 0u);
     uint8_t *line_flags = reinterpret_cast<uint8_t *>(w.rec_start);  // dead before k_fa_def_lines fills rec_start
     int rc = launch_line_index(dev.d_in, dev.n_bytes, 0, ws, l, 1, 0, stream, nullptr, line_flags);

@@ -1,0 +1,554 @@
+// exg_fasta_tiled.hip — FASTA record scan in two passes over 16 KiB tiles.
+//
+// Same semantics as exg_fasta.hip (noodles-fasta 0.27.0 read_definition / read_sequence as driven by
+// exon 0.2.6; reached from rust/src/arrow_reader.rs:116-153): a line whose first byte is '>' defines a
+// record (id to the first ASCII whitespace, the rest trimmed = description); the sequence is every
+// following line with LF (and a CR before it) removed, concatenated in a compacted payload buffer.
+//
+// What a tile needs from the bytes in front of it is tiny — records before it, sequence bytes before it
+// and one bit (does it begin inside a definition line) — so no line index is built:
+//   pass 1  k_fa_tile_count   a workgroup per tile, 64 contiguous bytes per thread held in registers:
+//                             newline / '>' / CR masks, line starts, definition-line extents ->
+//                             descriptor {definitions, sequence bytes after the first line start,
+//                             sequence bytes before it (they count only if the tile begins outside a
+//                             definition line), has a line start, last line is a definition}
+//           k_fa_tile_scan    one workgroup: resolves the begin-inside-a-definition bit tile by tile
+//                             (64 tiles per step with ballots), then a two-quantity prefix sum
+//   pass 2  k_fa_tile_emit    re-reads the tile (second and last read of the input), compacts the
+//                             sequence bytes through LDS and writes them with 16-byte stores at the
+//                             tile's payload offset; the threads that own a '>' at a line start write the
+//                             record's id / description string_t and its payload offset
+//           k_fa_tile_strings sequence string_t (length = next record's payload offset - own)
+// Traffic: 2 reads + 1 write of the file (the multipass form: ~5 reads + 3 writes of it plus 40 B per
+// line of index).  Algorithmic bytes: file read once + sequence bytes written once.
+#include "exg_fasta.hpp"
+
+namespace exg {
+
+namespace {
+
+static constexpr uint32_t kTile = 16384;
+static constexpr uint32_t kThreads = 256;  // x 64 bytes
+
+// tile descriptor (one u64):  [0,14) definitions  [14,29) bytes_after  [29,44) bytes_head  44 has a newline
+// 45 the line after its last newline is a definition
+// [47,62) newlines (a per-tile atomicAdd on one counter would cost more than the whole pass: ~88 atomics/us)
+static constexpr int kDAfter = 14, kDHead = 29, kDHas = 44, kDTail = 45, kDNl = 47;
+__device__ __forceinline__ unsigned long long pack_desc(uint32_t defs, uint32_t after, uint32_t head, bool has_nl,
+                                                        bool tail_def, uint32_t nls) {
+    return (unsigned long long)defs | ((unsigned long long)after << kDAfter) | ((unsigned long long)head << kDHead) |
+           ((unsigned long long)has_nl << kDHas) | ((unsigned long long)tail_def << kDTail) | ((unsigned long long)nls << kDNl);
+}
+
+struct TileArrays {
+    unsigned long long *desc;  // [n_tiles]
+    uint64_t *rec_before;      // [n_tiles + 1]
+    uint64_t *pay_before;      // [n_tiles + 1]  bit 63: the tile begins inside a definition line
+    uint64_t *rec_start;       // [n_rec + 1] payload offset of every record's sequence
+    uint64_t *rec_def_off;     // [n_rec] input offset of every record's '>'
+    uint64_t rec_cap;          // records the two arrays can hold (more is reported as EXG_RF_INDEX_OVERFLOW)
+};
+
+// ---- the 16 bytes of one lane (a wave instruction = 1 KiB, coalesced) -----------------------------------------------
+// Everything hangs off the NEWLINES of the chunk (one in four chunks has any): the line after a newline is a
+// definition line iff the byte after it is '>', a CR counts only right in front of a newline.  Only the
+// newline mask is a full SWAR match; the rest looks at single bytes next to the (rare) newline bits.
+struct Chunk {
+    uint32_t nl;           // newline bits
+    uint32_t def_after;    // newline bits whose next line is a definition line
+    uint32_t pay_known;    // sequence bytes after the first newline (their line's kind is known)
+    uint32_t pay_head;     // sequence bytes before the first newline (kind comes from the left)
+    bool has_nl, last_is_def, hi;
+};
+
+__device__ __forceinline__ uint32_t below(uint32_t b) { return b >= 32 ? ~0u : (1u << b) - 1u; }
+__device__ __forceinline__ unsigned long long mask_below(uint32_t b) { return b >= 64 ? ~0ull : (1ull << b) - 1ull; }
+
+__device__ __forceinline__ uint32_t byte_of(const uint4 v, uint32_t b) {  // b < 16
+    const uint32_t w = b < 8 ? (b < 4 ? v.x : v.y) : (b < 12 ? v.z : v.w);
+    return (w >> (8 * (b & 3))) & 0xFFu;
+}
+
+__device__ __forceinline__ Chunk classify16(const uint4 v, const uint8_t *__restrict__ d_in, uint64_t o, uint64_t n_bytes) {
+    Chunk c;
+    const uint32_t valid = o >= n_bytes ? 0u : below((uint32_t)(n_bytes - o < 16 ? n_bytes - o : 16));
+    const uint32_t nl = match16(v, 0x0A0A0A0Au) & valid;
+    c.hi = ((v.x | v.y | v.z | v.w) & 0x80808080u) != 0;  // bytes past the end are zero
+    c.nl = nl;
+    c.has_nl = nl != 0;
+    uint32_t def_after = 0, strip = 0, def_region = 0;
+    uint32_t m = nl;
+    while (m) {
+        const uint32_t b = (uint32_t)__ffs((int)m) - 1;
+        m &= m - 1;
+        // CR only in front of a real LF (a CR at byte 15 is looked at below, by its own chunk)
+        if (b > 0 && byte_of(v, b - 1) == '\r') strip |= 1u << (b - 1);
+        // the line that starts after this newline
+        const uint32_t next = b < 15 ? ((valid >> (b + 1)) & 1u ? byte_of(v, b + 1) : 0u)
+                                     : (o + 16 < n_bytes ? (uint32_t)d_in[o + 16] : 0u);
+        if (next == '>') {
+            def_after |= 1u << b;
+            const uint32_t e = m ? (uint32_t)__ffs((int)m) - 1 : 16u;  // up to the next newline
+            def_region |= below(e) & ~below(b + 1);
+        }
+    }
+    if ((v.w >> 24) == '\r' && (valid >> 15) && o + 16 < n_bytes && d_in[o + 16] == '\n') strip |= 1u << 15;
+    c.def_after = def_after;
+    c.last_is_def = c.has_nl && ((def_after >> (31 - __clz((int)nl))) & 1u);
+    const uint32_t first = c.has_nl ? (uint32_t)__ffs((int)nl) - 1 : 16u;
+    const uint32_t seq = valid & ~nl & ~strip;
+    c.pay_known = seq & ~def_region & ~below(first);
+    c.pay_head = seq & below(first);
+    return c;
+}
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// A wavefront owns a tile and walks it in sixteen 1 KiB rows (64 lanes x 16 bytes, four rows loaded at a time),
+// carrying the line state from row to row: no workgroup barrier anywhere.  `Carry` = is there a newline to the
+// left inside the tile (or the start of the input) and, if so, is the line after the nearest one a definition.
+struct Carry {
+    bool resolved, in_def;
+};
+// state entering this lane's chunk, then the carry after the row
+__device__ __forceinline__ Carry lane_state(const Chunk &c, Carry &carry) {
+    const uint32_t lane = threadIdx.x & 63;
+    const unsigned long long bs = __ballot(c.has_nl), bd = __ballot(c.last_is_def);
+    const unsigned long long left = bs & mask_below(lane);
+    Carry st = carry;
+    if (left) {
+        st.resolved = true;
+        st.in_def = (bd >> (63 - __clzll((long long)left))) & 1ull;
+    }
+    if (bs) {
+        carry.resolved = true;
+        carry.in_def = (bd >> (63 - __clzll((long long)bs))) & 1ull;
+    }
+    return st;
+}
+
+__device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
+    return __shfl(v, 0, 64);
+}
+
+// The input begins at a line start: tile 0 enters with a known state (and, if its first byte is '>', with a
+// definition that no newline announces).
+__device__ __forceinline__ Carry tile_carry(const FastaDev &a, uint64_t tile, bool *def_at_zero) {
+    *def_at_zero = tile == 0 && a.n_bytes > 0 && a.d_in[0] == '>';
+    Carry c = {tile == 0, *def_at_zero};
+    return c;
+}
+
+// ---- pass 1 --------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_fa_tile_count(FastaDev a, TileArrays t, ScanWsHeader *hdr, uint64_t n_tiles) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = (uint64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * (kThreads / 64);
+    for (uint64_t tile = wave; tile < n_tiles; tile += n_waves) {
+        bool def0;
+        Carry carry = tile_carry(a, tile, &def0);
+        // packed per-lane sums: [0,16) bytes after a known state, [16,32) head bytes, [32,48) definitions, [48,63) newlines
+        unsigned long long acc = (def0 && lane == 0) ? 1ull << 32 : 0ull;
+        bool any_hi = false;
+#pragma unroll 1
+        for (int g = 0; g < 4; g++) {
+            const uint64_t gbase = tile * kTile + (uint64_t)g * 4096;
+            if (gbase >= a.n_bytes) break;
+            uint4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint64_t off = gbase + (uint64_t)k * 1024 + (uint64_t)lane * 16;
+                v[k] = off < a.n_bytes ? *reinterpret_cast<const uint4 *>(a.d_in + off) : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint64_t o = gbase + (uint64_t)k * 1024 + (uint64_t)lane * 16;
+                const Chunk c = classify16(v[k], a.d_in, o, a.n_bytes);
+                const Carry st = lane_state(c, carry);
+                const unsigned long long known = (unsigned long long)__popc(c.pay_known), head = (unsigned long long)__popc(c.pay_head);
+                // a lane whose state is known counts its head bytes itself; otherwise they are the tile's head
+                acc += known + ((st.resolved && !st.in_def) ? head : 0ull);
+                acc += (st.resolved ? 0ull : head) << 16;
+                acc += (unsigned long long)__popc(c.def_after) << 32;
+                acc += (unsigned long long)__popc(c.nl) << 48;
+                any_hi = any_hi || c.hi;
+            }
+        }
+        const unsigned long long tot = wave_sum64(acc);
+        const bool hi = __ballot(any_hi) != 0;
+        if (lane == 0) {
+            t.desc[tile] = pack_desc((uint32_t)((tot >> 32) & 0xFFFFu), (uint32_t)(tot & 0xFFFFu), (uint32_t)((tot >> 16) & 0xFFFFu),
+                                     carry.resolved, carry.in_def, (uint32_t)(tot >> 48));
+            if (hi) atomicOr(&hdr->flags, EXG_RF_NON_ASCII);
+        }
+    }
+}
+
+// ---- tile scan ---------------------------------------------------------------------------------------------------------------
+// One workgroup, 4096 tiles per step (four consecutive tiles per thread): the begin-inside-a-definition bit of
+// every tile (nearest newline to the left: inside the thread, then ballots inside the wave, 16 wave summaries in
+// LDS, a carry across steps), then the two prefix sums (32-bit DPP scans per step, 64-bit running totals).
+__global__ __launch_bounds__(1024) void k_fa_tile_scan(FastaDev a, TileArrays t, ScanWsHeader *hdr, uint64_t n_tiles) {
+    __shared__ unsigned long long s_a[16], s_b[16];
+    __shared__ uint32_t s_has[16], s_def[16];
+    __shared__ unsigned long long s_ra, s_rb;
+    __shared__ uint32_t s_carry;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_ra = s_rb = 0, s_carry = 0;
+    __syncthreads();
+    unsigned long long nl_sum = 0;
+    for (uint64_t base = 0; base < n_tiles; base += 4096) {
+        const uint64_t i0 = base + (uint64_t)threadIdx.x * 4;
+        unsigned long long d[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) d[j] = i0 + j < n_tiles ? t.desc[i0 + j] : 0ull;
+        // the thread's own four tiles: does any have a newline, and what follows the last one
+        bool has = false, tail = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if ((d[j] >> kDHas) & 1ull) has = true, tail = (d[j] >> kDTail) & 1ull;
+            nl_sum += (d[j] >> kDNl) & 0x7FFFull;
+        }
+        const unsigned long long bs = __ballot(has), bd = __ballot(tail);
+        if (lane == 0) {
+            s_has[w] = bs != 0;
+            s_def[w] = bs ? (uint32_t)((bd >> (63 - __clzll((long long)bs))) & 1ull) : 0u;
+        }
+        __syncthreads();
+        bool in_def = s_carry != 0;  // state entering the thread's first tile
+        for (uint32_t k = 0; k < w; k++)
+            if (s_has[k]) in_def = s_def[k] != 0;
+        const unsigned long long left = bs & mask_below(lane);
+        if (left) in_def = (bd >> (63 - __clzll((long long)left))) & 1ull;
+        bool st[4];
+        uint32_t ca[4], cb[4], sa = 0, sb = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            st[j] = in_def;
+            ca[j] = (uint32_t)(d[j] & 0x3FFFull);
+            cb[j] = (uint32_t)((d[j] >> kDAfter) & 0x7FFFull) + (in_def ? 0u : (uint32_t)((d[j] >> kDHead) & 0x7FFFull));
+            sa += ca[j];
+            sb += cb[j];
+            if ((d[j] >> kDHas) & 1ull) in_def = (d[j] >> kDTail) & 1ull;
+        }
+        const unsigned long long ia = wave_incl_sum_dpp(sa), ib = wave_incl_sum_dpp(sb);
+        if (lane == 63) s_a[w] = ia, s_b[w] = ib;
+        __syncthreads();
+        unsigned long long fa = 0, fb = 0, za = 0, zb = 0;
+        for (uint32_t k = 0; k < 16; k++) {
+            if (k < w) fa += s_a[k], fb += s_b[k];
+            za += s_a[k], zb += s_b[k];
+        }
+        unsigned long long ra = s_ra + fa + ia - sa, rb = s_rb + fb + ib - sb;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (i0 + j < n_tiles) {
+                t.rec_before[i0 + j] = ra;
+                t.pay_before[i0 + j] = rb | ((unsigned long long)st[j] << 63);
+            }
+            ra += ca[j];
+            rb += cb[j];
+        }
+        bool carry = s_carry != 0;
+        for (uint32_t k = 0; k < 16; k++)
+            if (s_has[k]) carry = s_def[k] != 0;
+        __syncthreads();
+        if (threadIdx.x == 0) s_ra += za, s_rb += zb, s_carry = carry;
+        __syncthreads();
+    }
+    // newlines of the whole input
+    nl_sum = wave_sum64(nl_sum);
+    if (lane == 0) s_a[w] = nl_sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long total_nl = 0;
+        for (uint32_t k = 0; k < 16; k++) total_nl += s_a[k];
+        t.rec_before[n_tiles] = s_ra;
+        t.pay_before[n_tiles] = s_rb;
+        if (s_ra <= t.rec_cap) t.rec_start[s_ra] = s_rb;  // sentinel: end of the last record's sequence
+        hdr->total_nl = total_nl;
+        hdr->total_lines = total_nl + ((a.n_bytes && a.d_in[a.n_bytes - 1] != '\n') ? 1 : 0);
+    }
+}
+
+// ---- pass 2 --------------------------------------------------------------------------------------------------------------
+// one definition line: id / description string_t of record r (the line may run past the tile: read from HBM)
+// bytes of the input through one cached, aligned 8-byte word: a walk along a line costs one dependent load per 8
+// bytes instead of one per byte (the buffer is readable to round_up(n_bytes, 16))
+struct ByteReader {
+    const uint8_t *p;
+    uint64_t base = ~0ull;
+    unsigned long long w = 0;
+    __device__ __forceinline__ uint32_t get(uint64_t i) {
+        const uint64_t al = i & ~7ull;
+        if (al != base) {
+            w = *reinterpret_cast<const unsigned long long *>(p + al);
+            base = al;
+        }
+        return (uint32_t)(w >> (8 * (i & 7))) & 0xFFu;
+    }
+};
+
+__device__ void emit_definition(const FastaDev &a, ScanWsHeader *hdr, uint64_t r, uint64_t s) {
+    const bool no_store = (a.flags & EXG_F_NO_STORE) != 0;
+    if (!no_store && r >= a.capacity) {
+        atomicOr(&hdr->flags, EXG_RF_CAPACITY);
+        return;
+    }
+    ByteReader rd;
+    rd.p = a.d_in;
+    // one walk: the end of the id (first ASCII whitespace) and the end of the line
+    uint64_t raw_end = s, id_e = ~0ull;
+    for (; raw_end < a.n_bytes; raw_end++) {
+        const uint32_t ch = rd.get(raw_end);
+        if (ch == '\n') break;
+        if (id_e == ~0ull && raw_end > s && is_ascii_ws(ch)) id_e = raw_end;
+    }
+    uint64_t e = raw_end;
+    if (raw_end < a.n_bytes && e > s && a.d_in[e - 1] == '\r') e--;  // CR only in front of a real LF
+    uint32_t code = 0;
+    if ((hdr->flags & EXG_RF_NON_ASCII) && !utf8_valid_global(a.d_in, s, e)) code = EXG_PE_INVALID_UTF8;
+    const uint64_t id_s = s + 1;
+    if (id_e == ~0ull || id_e > e) id_e = e;
+    if (id_e < id_s) id_e = id_s;
+    if (!code && id_e == id_s) code = EXG_PE_FASTA_MISSING_NAME;
+    const bool has_desc = id_e < e;
+    uint64_t d_s = has_desc ? id_e + 1 : e, d_e = e;
+    if (has_desc) {
+        int l;
+        while (d_s < d_e && (l = ws_len_fwd(a.d_in, d_s, d_e)) > 0) d_s += (uint64_t)l;
+        while (d_e > d_s && (l = ws_len_bwd(a.d_in, d_s, d_e)) > 0) d_e -= (uint64_t)l;
+    }
+    if (!code && (id_e - id_s > 0xFFFFFFFFull || d_e - d_s > 0xFFFFFFFFull)) code = EXG_PE_FIELD_TOO_LONG;
+    if (code) {
+        atomicMin(&hdr->err_word, (r << 8) | code);
+        atomicMin(&hdr->err_off, (unsigned long long)s);
+    }
+    if (!no_store) {
+        const uint4 z = {0, 0, 0, 0};
+        reinterpret_cast<uint4 *>(a.d_id)[r] = make_string_global(a.d_in, id_s, id_e - id_s, a.payload_base);
+        reinterpret_cast<uint4 *>(a.d_desc)[r] = has_desc ? make_string_global(a.d_in, d_s, d_e - d_s, a.payload_base) : z;
+        if (has_desc) atomicOr((unsigned long long *)&a.d_desc_valid[r >> 6], 1ull << (r & 63));
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_fa_tile_emit(FastaDev a, TileArrays t, ScanWsHeader *hdr, uint64_t n_tiles) {
+    // per wave: the sequence bytes of four rows (4 KiB of input), compacted, on their way to the payload
+    __shared__ __attribute__((aligned(16))) uint32_t s_out_all[kThreads / 64][4096 / 4 + 8];
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t *s_out = s_out_all[threadIdx.x >> 6];
+    uint8_t *out8 = reinterpret_cast<uint8_t *>(s_out);
+    const bool no_store = (a.flags & EXG_F_NO_STORE) != 0;
+    const uint64_t wave = (uint64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * (kThreads / 64);
+    for (uint64_t tile = wave; tile < n_tiles; tile += n_waves) {
+        const unsigned long long pb = t.pay_before[tile];
+        bool def0;
+        Carry carry = tile_carry(a, tile, &def0);
+        const bool tile_in_def = pb >> 63;
+        uint64_t pay_at = pb & ~(1ull << 63);  // payload offset of the current group of rows
+        uint64_t rec_at = t.rec_before[tile];
+        if (def0) {  // the definition at offset 0: no newline announces it
+            if (lane == 0 && rec_at < t.rec_cap) {
+                t.rec_start[rec_at] = 0;
+                t.rec_def_off[rec_at] = 0;
+            }
+            rec_at++;
+        }
+        uint32_t g_out = 0;  // sequence bytes compacted in LDS and not yet written (wave uniform)
+        uint4 v_next = make_uint4(0, 0, 0, 0);
+        {
+            const uint64_t off = tile * kTile + (uint64_t)lane * 16;
+            if (off < a.n_bytes) v_next = *reinterpret_cast<const uint4 *>(a.d_in + off);
+        }
+#pragma unroll 1
+        for (int row = 0; row < 16; row++) {
+            const uint64_t rbase = tile * kTile + (uint64_t)row * 1024;
+            if (rbase >= a.n_bytes) break;
+            const uint64_t o = rbase + (uint64_t)lane * 16;
+            const uint4 v = v_next;
+            if (row < 15 && o + 1024 < a.n_bytes) v_next = *reinterpret_cast<const uint4 *>(a.d_in + o + 1024);  // next row in flight
+            else v_next = make_uint4(0, 0, 0, 0);
+            const Chunk c = classify16(v, a.d_in, o, a.n_bytes);
+            const Carry st = lane_state(c, carry);
+            const bool in_def = st.resolved ? st.in_def : tile_in_def;
+            const uint32_t pay = c.pay_known | (in_def ? 0u : c.pay_head);
+            // one scan for both counts: sequence bytes (<= 1024 per row) and definitions (<= 512)
+            const uint32_t cnt = (uint32_t)__popc(pay) | ((uint32_t)__popc(c.def_after) << 16);
+            const uint32_t incl = wave_incl_sum_dpp(cnt);
+            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            const uint32_t excl = incl - cnt;
+            const uint32_t my_off = g_out + (excl & 0xFFFFu);
+            // definitions announced by my newlines
+            uint32_t d = c.def_after;
+            uint64_t r = rec_at + (excl >> 16);
+            while (d) {
+                const uint32_t b = (uint32_t)__ffs((int)d) - 1;
+                if (r < t.rec_cap && o + b + 1 < a.n_bytes) {
+                    t.rec_start[r] = pay_at + my_off + (uint32_t)__popc(pay & below(b));
+                    t.rec_def_off[r] = o + b + 1;
+                }
+                r++;
+                d &= d - 1;
+            }
+            if (!no_store && pay) {
+                // my sequence bytes -> their place in the compacted group (every register index is static)
+                const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+                uint32_t w = my_off;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t nib = (pay >> (4 * q)) & 0xFu;
+                    if (nib == 0xFu) {
+                        __builtin_memcpy(out8 + w, &words[q], 4);
+                        w += 4;
+                    } else if (nib) {
+#pragma unroll
+                        for (int bb = 0; bb < 4; bb++)
+                            if (nib & (1u << bb)) out8[w++] = (uint8_t)(words[q] >> (8 * bb));
+                    }
+                }
+            }
+            g_out += tot & 0xFFFFu;
+            rec_at += tot >> 16;
+            const bool last_row = row == 15 || rbase + 1024 >= a.n_bytes;
+            if (!no_store && g_out && ((row & 3) == 3 || last_row)) {  // (uniform per wave)
+                wave_sync();
+                // compacted rows -> payload, 16 bytes per store on the destination's grid
+                uint8_t *dst0 = a.d_payload + pay_at;
+                const uint32_t mis = (uint32_t)((uintptr_t)dst0 & 15);
+                const uint32_t n_groups = (g_out + mis + 15) / 16;
+                for (uint32_t q = lane; q < n_groups; q += 64) {
+                    const int32_t so = (int32_t)(q * 16) - (int32_t)mis;  // offset in s_out of the group's first byte
+                    if (so >= 0 && (uint32_t)so + 16 <= g_out) {
+                        const uint32_t base = (uint32_t)so >> 2, sh = (uint32_t)so & 3;
+                        const uint32_t w0 = s_out[base], w1 = s_out[base + 1], w2 = s_out[base + 2], w3 = s_out[base + 3],
+                                       w4 = s_out[base + 4];
+                        uint4 ov;
+                        ov.x = __builtin_amdgcn_alignbyte(w1, w0, sh);
+                        ov.y = __builtin_amdgcn_alignbyte(w2, w1, sh);
+                        ov.z = __builtin_amdgcn_alignbyte(w3, w2, sh);
+                        ov.w = __builtin_amdgcn_alignbyte(w4, w3, sh);
+                        *reinterpret_cast<uint4 *>(dst0 + so) = ov;
+                    } else {
+                        for (int bb = 0; bb < 16; bb++) {
+                            const int32_t pp = so + bb;
+                            if (pp >= 0 && (uint32_t)pp < g_out) dst0[pp] = out8[pp];
+                        }
+                    }
+                }
+                wave_sync();
+                pay_at += g_out;
+                g_out = 0;
+            }
+            if (no_store) {
+                pay_at += g_out;
+                g_out = 0;
+            }
+        }
+    }
+}
+
+// id / description of every record, a thread per record: the walk over a definition line is a chain of dependent
+// byte loads from HBM (~15 us) — inside the emit pass it stalled a whole wavefront for the one lane that owned a '>'
+__global__ __launch_bounds__(256) void k_fa_tile_defs(FastaDev a, TileArrays t, ScanWsHeader *hdr, uint64_t n_tiles) {
+    uint64_t n_rec = t.rec_before[n_tiles];
+    if (n_rec > t.rec_cap) n_rec = t.rec_cap;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rec; r += (uint64_t)gridDim.x * blockDim.x)
+        emit_definition(a, hdr, r, t.rec_def_off[r]);
+}
+
+__global__ __launch_bounds__(256) void k_fa_tile_strings(FastaDev a, TileArrays t, ScanWsHeader *hdr, uint64_t n_tiles) {
+    if (a.flags & EXG_F_NO_STORE) return;
+    uint64_t n_rec = t.rec_before[n_tiles];
+    if (n_rec > t.rec_cap) n_rec = t.rec_cap;
+    const uint64_t n = n_rec < a.capacity ? n_rec : a.capacity;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t s = t.rec_start[r], len = t.rec_start[r + 1] - s;
+        if (len > 0xFFFFFFFFull) {
+            atomicMin(&hdr->err_word, (r << 8) | EXG_PE_FIELD_TOO_LONG);
+            len = 0;
+        }
+        // sequences are validated after their definition (exon FASTAArrayBuilder::append order)
+        if ((hdr->flags & EXG_RF_NON_ASCII) && reinterpret_cast<const uint32_t *>(a.d_id)[r * 4] != 0 &&
+            !utf8_valid_global(a.d_payload, s, s + len)) {
+            atomicMin(&hdr->err_word, (r << 8) | EXG_PE_INVALID_UTF8);
+            atomicMin(&hdr->err_off, (unsigned long long)t.rec_def_off[r]);
+        }
+        reinterpret_cast<uint4 *>(a.d_seq)[r] = make_string_global(a.d_payload, s, len, a.seq_payload_base);
+    }
+}
+
+__global__ void k_fa_tile_finalize(FastaDev a, TileArrays t, ScanWsHeader *hdr, uint64_t n_tiles, exg_scan_result *res) {
+    if (threadIdx.x || blockIdx.x) return;
+    const uint64_t n_owned = t.rec_before[n_tiles];
+    exg_scan_result r;
+    r.n_lines = hdr->total_lines;
+    r.flags = hdr->flags;
+    if (n_owned > t.rec_cap) r.flags |= EXG_RF_INDEX_OVERFLOW;
+    r.payload_bytes = t.pay_before[n_tiles];
+    r.reserved = 0;
+    r.error_code = 0;
+    r.error_offset = ~0ull;
+    r.error_record = ~0ull;
+    // the reader wants a definition first
+    if (a.n_bytes && a.d_in[0] != '>') {
+        uint64_t e = 0;
+        while (e < a.n_bytes && a.d_in[e] != '\n') e++;
+        if (e < a.n_bytes && e > 0 && a.d_in[e - 1] == '\r') e--;
+        atomicMin(&hdr->err_word, (0ull << 8) | (e == 0 ? EXG_PE_FASTA_EMPTY_DEF : EXG_PE_FASTA_MISSING_PREFIX));
+    }
+    uint64_t n_rec = (n_owned < a.capacity || (a.flags & EXG_F_NO_STORE)) ? n_owned : a.capacity;
+    uint64_t consumed = a.n_bytes;
+    const unsigned long long err = hdr->err_word;
+    if (err != kNoError) {
+        const uint64_t rec = err >> 8;
+        r.error_code = (uint32_t)(err & 0xFF);
+        r.error_record = rec;
+        r.error_offset = hdr->err_off != ~0ull ? hdr->err_off : 0;
+        if (r.error_code == EXG_PE_FASTA_EMPTY_DEF || r.error_code == EXG_PE_FASTA_MISSING_PREFIX) r.error_offset = 0;
+        if (rec < n_rec) n_rec = rec;
+        consumed = r.error_offset;
+    }
+    r.n_records = n_rec;
+    r.consumed_bytes = consumed;
+    *res = r;
+}
+
+}  // namespace
+
+__global__ void k_init_hdr(ScanWsHeader *hdr, uint64_t lines_cap, uint32_t mode);
+
+int run_fasta_tiled(const FastaDev &dev, uint8_t *ws, const FastqWsLayout &l, exg_scan_result *d_result, hipStream_t stream) {
+    ScanWsHeader *hdr = reinterpret_cast<ScanWsHeader *>(ws);
+    const uint64_t n_tiles = (dev.n_bytes + kTile - 1) / kTile;
+    TileArrays t;
+    // 24 B per 16 KiB tile live in the fused kernels' descriptor region; the per-record arrays in the line arrays
+    unsigned long long *region = reinterpret_cast<unsigned long long *>(ws + l.off_tile_desc);
+    t.desc = region;
+    t.rec_before = reinterpret_cast<uint64_t *>(region + (n_tiles + 1));
+    t.pay_before = reinterpret_cast<uint64_t *>(region + 2 * (n_tiles + 1));
+    uint64_t *base = reinterpret_cast<uint64_t *>(ws + l.off_nl_pos);
+    t.rec_start = base;
+    t.rec_def_off = base + (l.lines_cap + 2);
+    t.rec_cap = l.lines_cap;
+    // records <= lines: the per-record arrays hold lines_cap + 2 entries each (a file with more definition
+    // lines than that is reported like a line-index overflow)
+    hipLaunchKernelGGL(k_init_hdr, dim3(1), dim3(1), 0, stream, hdr, l.lines_cap, 0u);
+    const uint32_t grid = (uint32_t)(n_tiles < 16384 ? (n_tiles ? n_tiles : 1) : 16384);
+    if (n_tiles) hipLaunchKernelGGL(k_fa_tile_count, dim3(grid), dim3(kThreads), 0, stream, dev, t, hdr, n_tiles);
+    hipLaunchKernelGGL(k_fa_tile_scan, dim3(1), dim3(1024), 0, stream, dev, t, hdr, n_tiles);
+    if (n_tiles) hipLaunchKernelGGL(k_fa_tile_emit, dim3(grid), dim3(kThreads), 0, stream, dev, t, hdr, n_tiles);
+    const uint64_t est_rec = dev.n_bytes / 64 + 256;
+    const uint32_t sgrid = (uint32_t)((est_rec + 255) / 256 < 4096 ? (est_rec + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_fa_tile_defs, dim3(sgrid), dim3(256), 0, stream, dev, t, hdr, n_tiles);
+    hipLaunchKernelGGL(k_fa_tile_strings, dim3(sgrid), dim3(256), 0, stream, dev, t, hdr, n_tiles);
+    hipLaunchKernelGGL(k_fa_tile_finalize, dim3(1), dim3(1), 0, stream, dev, t, hdr, n_tiles, d_result);
+    EXG_HIP_CHECK(hipGetLastError());
+    return EXG_OK;
+}
+
+}  // namespace exg

@@ -161,7 +161,8 @@ class FastaScan:
         self.result = torch.zeros(8, dtype=torch.int64, device=device)
         self.args = abi.FastaScanArgs()
 
-    def launch(self, d_input, payload_base=0, seq_payload_base=0, flags=abi.EXG_F_BOF | abi.EXG_F_EOF, lead=0):
+    def launch(self, d_input, payload_base=0, seq_payload_base=0, flags=abi.EXG_F_BOF | abi.EXG_F_EOF, lead=0,
+               algo=abi.EXG_ALGO_AUTO):
         a = self.args
         a.d_input = d_input.data_ptr()
         a.n_bytes = self.n_bytes
@@ -169,7 +170,7 @@ class FastaScan:
         a.payload_base = payload_base
         a.seq_payload_base = seq_payload_base
         a.flags = flags
-        a.algo = abi.EXG_ALGO_AUTO
+        a.algo = algo
         a.d_id, a.d_description, a.d_sequence = (c.data_ptr() for c in self.cols)
         a.d_description_validity = self.validity.data_ptr()
         a.d_seq_payload = self.payload.data_ptr()

@@ -17,13 +17,17 @@ BASE = 0x7D0000000000
 SEQ_BASE = 0x7C0000000000
 
 
-def run_gpu(data, capacity=None, flags=abi.EXG_F_BOF | abi.EXG_F_EOF):
+# both device implementations: EXG_ALGO_AUTO = two passes over tiles, EXG_ALGO_MULTIPASS = line index
+ALGOS = [abi.EXG_ALGO_AUTO, abi.EXG_ALGO_MULTIPASS]
+
+
+def run_gpu(data, capacity=None, flags=abi.EXG_F_BOF | abi.EXG_F_EOF, algo=abi.EXG_ALGO_AUTO):
     from exon_duckdb_amd import device
 
     data = bytes(data)
     d_in = device.upload(data)
     scan = device.FastaScan(len(data), capacity_records=capacity)
-    scan.launch(d_in, payload_base=BASE, seq_payload_base=SEQ_BASE, flags=flags)
+    scan.launch(d_in, payload_base=BASE, seq_payload_base=SEQ_BASE, flags=flags, algo=algo)
     res = scan.fetch()
     cols, words, payload = scan.host(int(res.n_records), int(res.payload_bytes))
     return res, cols, words, payload
@@ -44,10 +48,16 @@ def resolve(st, data, payload):
     return got
 
 
-def check(oracle, data):
+def check(oracle, data, algos=None):
+    for algo in (algos or ALGOS):
+        res = check_one(oracle, data, algo)
+    return res
+
+
+def check_one(oracle, data, algo):
     data = bytes(data)
     exp = oracle.fasta_parse(data)
-    res, cols, words, payload = run_gpu(data)
+    res, cols, words, payload = run_gpu(data, algo=algo)
     assert res.error_code == exp.error_code, (res.error_code, exp.error_code, exp.error_message)
     assert res.n_records == exp.n_rows
     if exp.error_code:
