@@ -56,7 +56,9 @@ __device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v) {
     return v;
 }
 
-// inclusive wave64 prefix sum on the VALU (DPP row shifts + row broadcasts: no LDS traffic, unlike __shfl_up)
+// inclusive wave64 prefix sum on the VALU (DPP row shifts + row broadcasts: no LDS traffic, unlike __shfl_up).
+// Not a free win: in the fused FASTQ kernel, which is VALU-bound with an idle LDS pipeline, it measured 4 % SLOWER
+// than the ds_bpermute form above (A/B on one box); it pays where the LDS pipeline is the busy one (FASTA tiles).
 __device__ __forceinline__ uint32_t wave_incl_sum_dpp(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
