@@ -180,6 +180,7 @@ __device__ __forceinline__ void fastq_emit_half(const L &s, const FastqDev &a, S
 struct FastqFormat {
     using Dev = FastqDev;
     static constexpr int kNlCap = 512;          // 197 lines per half for 150 bp reads; LDS 22.7 KB -> 7 per CU
+    static constexpr bool kTabMap = false;
     static constexpr int kHalves = 3;   // 48 KiB per workgroup: A/B on one box 2 -> 3 halves +3 %, 4 halves -7 %
     static constexpr int kMinWavesPerSimd = 6;  // 80 VGPRs, no scratch: 6 x 48 KiB in flight per CU
     // noodles-fastq at EOF: a record that has its '+' line but no quality line gets an empty one

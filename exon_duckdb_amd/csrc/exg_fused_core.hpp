@@ -14,6 +14,7 @@
 //   F::emit_half(...)                     records ending in the staged half
 //   F::analytic_prefix(offset)            dev-only ablation hook
 //   F::kNlCap                             newline positions kept per half (LDS)
+//   F::kTabMap                            also keep a '\t' bitmap of every half (VCF)
 //   F::kHalves                            16 KiB halves per workgroup (bytes waiting in registers: 16 VGPRs each)
 //   F::kMinWavesPerSimd                   occupancy the register allocator must respect (7 = 7 workgroups/CU)
 #pragma once
@@ -41,9 +42,14 @@ static constexpr unsigned long long kFlag = 1ull << 63;  // descriptor word is p
 static constexpr unsigned long long kVal = (1ull << 48) - 1;
 
 // NL = newline positions kept per half (a half with more lines goes to the general path)
-template <int NL, int H>
+template <int NL, int H, bool TABS = false>
 struct FusedLdsT {
     static constexpr int kNlCap = NL;
+    // TABS (VCF): '\t' mask of every 16-byte chunk next to the '\n' one; a line's first eight tabs are then eight
+    // bit pops out of one funnel-shifted 64-bit word instead of a SWAR search over the line's bytes.  Rows carry
+    // 8 bytes of slack so that the word after a line's last one can always be read.
+    static constexpr int kTabRow = TABS ? kTile / 16 + 4 : 4;
+    __attribute__((aligned(8))) uint16_t tabmap[TABS ? H : 1][kTabRow];
     uint8_t bytes[kLdsBytes];        // [0,kWin) window, then the half; e = p + kWin
     uint16_t nlist[4 + NL + 4];  // e-offsets of newlines: [0..3] the 4 before the half (oldest first)
     uint16_t bitmap[H][kTile / 16];  // '\n' mask of every 16-byte chunk, written by the first pass
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(kThreads, F::kMinWavesPerSimd) void k_fused(typenam
                                                              unsigned long long *__restrict__ tileP,
                                                              unsigned long long *__restrict__ tile_qend,
                                                              ScanWsHeader *hdr, uint32_t n_super) {
-    using FusedLds = FusedLdsT<F::kNlCap, F::kHalves>;
+    using FusedLds = FusedLdsT<F::kNlCap, F::kHalves, F::kTabMap>;
     constexpr int kNlCap = F::kNlCap;
     constexpr int kHalves = F::kHalves;
     constexpr int kSuper = kTile * kHalves;
@@ -272,6 +278,7 @@ __global__ __launch_bounds__(kThreads, F::kMinWavesPerSimd) void k_fused(typenam
             if (rem < 16) mj &= rem <= 0 ? 0u : ((1u << rem) - 1u);
         }
         s.bitmap[j / kRows][(j % kRows) * kThreads + tid] = (uint16_t)mj;
+        if constexpr (F::kTabMap) s.tabmap[j / kRows][(j % kRows) * kThreads + tid] = (uint16_t)match16(v[j], 0x09090909u);
         cnt += __popc(mj);
     }
     hi &= 0x80808080u;

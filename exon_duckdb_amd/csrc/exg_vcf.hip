@@ -51,12 +51,33 @@ __device__ __forceinline__ VcfRowInfo vcf_line(const Src &src, int s, int e, con
     r.code = 0;
     r.qual_valid = false;
     r.rest_valid = false;
-    // positions of the first 8 tabs (e when there are fewer); found 64 bytes at a time
+    // positions of the first 8 tabs (e when there are fewer)
     int t[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) t[k] = e;
     int found = 0;
-    for (int base = s; base < e && found < 8; base += 64) {
+    bool have_tabs = false;
+    {
+        // fused path: the tab bits of the 64 bytes from s on come out of the half's bitmap; eight pops
+        unsigned long long tb;
+        if (src.tab_bits(s, &tb)) {
+            const int len = e - s;
+            if (len < 64) tb &= len <= 0 ? 0ull : ((1ull << len) - 1ull);
+            if (len <= 64 || __popcll(tb) >= 8) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    if (tb) {
+                        t[k] = s + __ffsll((long long)tb) - 1;
+                        tb &= tb - 1;
+                        found++;
+                    }
+                }
+                have_tabs = true;
+            }
+        }
+    }
+    // otherwise (line starting in the window, or long with few tabs in front; general path): 64 bytes at a time
+    for (int base = s; !have_tabs && base < e && found < 8; base += 64) {
         unsigned long long bits = 0;
 #pragma unroll
         for (int q = 0; q < 16; q++) bits |= (unsigned long long)nib4(match4(src.u32(base + 4 * q), 0x09090909u)) << (4 * q);
@@ -135,8 +156,19 @@ template <class L>
 struct LdsSrc {
     const L &s;
     uint64_t ptr_of_e0;
+    const uint16_t *tabs;  // '\t' bitmap of the staged half (bit p = byte kWin + p)
     __device__ __forceinline__ uint32_t b(int e) const { return ldb(s, e); }
     __device__ __forceinline__ uint32_t u32(int e) const { return ldu32(s, e); }  // reads stay inside the LDS slack
+    // tab bits of the 64 bytes starting at extended offset e (only for lines that start inside the half)
+    __device__ __forceinline__ bool tab_bits(int e, unsigned long long *out) const {
+        const int p = e - kWin;
+        if (p < 0) return false;
+        const unsigned long long *w = reinterpret_cast<const unsigned long long *>(tabs) + (p >> 6);
+        const uint32_t sh = (uint32_t)p & 63u;
+        const unsigned long long lo = w[0], hi = w[1];
+        *out = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+        return true;
+    }
     __device__ __forceinline__ uint4 str(int e, uint32_t len) const { return make_string_lds(s, e, len, ptr_of_e0); }
 };
 
@@ -144,6 +176,7 @@ struct VcfFormat {
     using Dev = VcfDev;
     static constexpr int kNlCap = 1024;  // short data lines are common
     static constexpr int kHalves = 2;
+    static constexpr bool kTabMap = true;
     static constexpr int kMinWavesPerSimd = 5;
     __device__ static __forceinline__ uint32_t eof_extra_lines(unsigned long long) { return 0; }
     __device__ static __forceinline__ unsigned long long analytic_prefix(uint64_t) { return 0; }
@@ -163,7 +196,7 @@ struct VcfFormat {
         }
         if (dev_mode >= 3) return;
         const bool no_store = (a.flags & EXG_F_NO_STORE) != 0;
-        const LdsSrc<L> src{s, a.payload_base + c.tile_off - kWin};
+        const LdsSrc<L> src{s, a.payload_base + c.tile_off - kWin, s.tabmap[tile_index % kHalves]};
         for (uint32_t jb = 0; jb < c.n_lines; jb += kThreads) {
             const uint32_t j = jb + threadIdx.x;
             const long long out = (long long)(c.P + j) - (long long)halo_nl;
@@ -224,6 +257,7 @@ struct GlobalSrc {
     __device__ __forceinline__ uint4 str(int i, uint32_t len) const {
         return make_string_global(p, base + (uint64_t)(int64_t)i, len, payload_base);
     }
+    __device__ __forceinline__ bool tab_bits(int, unsigned long long *) const { return false; }
 };
 
 __global__ __launch_bounds__(256) void k_vcf_lines(VcfDev a, const uint64_t *__restrict__ nl_pos, ScanWsHeader *hdr,
