@@ -15,6 +15,8 @@
 //     copied by all lanes (source index folded modulo the distance, so overlapping copies are exact);
 //   * every completed 1 KiB of the ring is flushed to HBM with 16 B/lane stores.
 // LDS: 32 KiB window + 2 KiB input + ~4.5 KiB tables => 4 waves per CU, 1024 members in flight.
+#include <type_traits>
+
 #include "exg_common.hpp"
 
 namespace exg {
@@ -38,8 +40,13 @@ static constexpr int kWinBytes = 32768;
 static constexpr int kInRing = 2048;
 static constexpr int kLitBits = 10, kDistBits = 9;
 
-struct InflateLds {
-    uint8_t win[kWinBytes];
+// SYM = false: the window holds bytes (a gzip member decoded from its first bit).
+// SYM = true:  the window holds 16-bit symbols — a byte, or 0x8000 | i for "byte i of the 32 KiB in front of where
+//              this decode started", which are not known yet (exg_inflate_stream: one big member decoded in chunks).
+template <bool SYM>
+struct InflateLdsT {
+    using Elem = typename std::conditional<SYM, uint16_t, uint8_t>::type;
+    Elem win[kWinBytes];
     uint8_t in[kInRing];
     // Primary tables, 0 = code longer than the table (or unused).  The entries carry what the token needs, so a
     // decode is peek -> lit_lut -> dist_lut, three dependent LDS levels instead of five:
@@ -74,7 +81,8 @@ struct BitIn {
 };
 
 // stage 1 KiB chunk c of the compressed input (coalesced, 16 B per lane)
-__device__ __forceinline__ void stage_chunk(InflateLds &s, const BitIn &br, uint32_t c, uint32_t lane) {
+template <class L>
+__device__ __forceinline__ void stage_chunk(L &s, const BitIn &br, uint32_t c, uint32_t lane) {
     uint32_t off = c * 1024 + lane * 16;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (off < ((br.limit + 15) & ~15u)) v = *reinterpret_cast<const uint4 *>(br.g0 + off);
@@ -82,7 +90,8 @@ __device__ __forceinline__ void stage_chunk(InflateLds &s, const BitIn &br, uint
 }
 
 // keep the chunk that holds the current byte and the next one staged (reads go up to ~20 bytes ahead)
-__device__ __forceinline__ void ensure(InflateLds &s, BitIn &br, uint32_t lane) {
+template <class L>
+__device__ __forceinline__ void ensure(L &s, BitIn &br, uint32_t lane) {
     uint32_t c = (uint32_t)(br.bitpos >> 13);  // 8192 bits per chunk
     while (c + 1 >= br.loaded) {
         stage_chunk(s, br, br.loaded, lane);
@@ -91,7 +100,8 @@ __device__ __forceinline__ void ensure(InflateLds &s, BitIn &br, uint32_t lane) 
 }
 
 // 64 bits starting at absolute bit `o` (per lane), >= 57 of them valid
-__device__ __forceinline__ unsigned long long peek_at(const InflateLds &s, unsigned long long o) {
+template <class L>
+__device__ __forceinline__ unsigned long long peek_at(const L &s, unsigned long long o) {
     uint32_t byte = (uint32_t)(o >> 3);
     uint32_t a = byte & ~3u;
     uint32_t w0 = *reinterpret_cast<const uint32_t *>(s.in + (a & (kInRing - 1)));
@@ -103,13 +113,15 @@ __device__ __forceinline__ unsigned long long peek_at(const InflateLds &s, unsig
     if (sh) v |= (unsigned long long)w2 << (64 - sh);
     return v;
 }
-__device__ __forceinline__ unsigned long long peek(InflateLds &s, BitIn &br, uint32_t lane) {
+template <class L>
+__device__ __forceinline__ unsigned long long peek(L &s, BitIn &br, uint32_t lane) {
     ensure(s, br, lane);
     unsigned long long v = peek_at(s, br.bitpos);
     uint32_t lo = sgpr((uint32_t)v), hi = sgpr((uint32_t)(v >> 32));
     return ((unsigned long long)hi << 32) | lo;
 }
-__device__ __forceinline__ uint32_t getbits(InflateLds &s, BitIn &br, uint32_t n, uint32_t lane) {
+template <class L>
+__device__ __forceinline__ uint32_t getbits(L &s, BitIn &br, uint32_t n, uint32_t lane) {
     unsigned long long v = peek(s, br, lane);
     br.bitpos += n;
     return (uint32_t)v & (n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u));
@@ -225,7 +237,8 @@ __device__ __forceinline__ uint32_t decode_slow(unsigned long long bits, const u
 }
 
 // decode one symbol serially (block headers); returns 0xFFFFFFFF on an invalid code
-__device__ __forceinline__ uint32_t decode_sym(InflateLds &s, BitIn &br, const uint16_t *lut, uint32_t bits,
+template <class L>
+__device__ __forceinline__ uint32_t decode_sym(L &s, BitIn &br, const uint16_t *lut, uint32_t bits,
                                                const uint16_t *sorted, const uint16_t *count, uint32_t lane) {
     unsigned long long v = peek(s, br, lane);
     uint32_t e = sgpr(lut[(uint32_t)v & ((1u << bits) - 1u)]);
@@ -240,7 +253,8 @@ __device__ __forceinline__ uint32_t decode_sym(InflateLds &s, BitIn &br, const u
 }
 
 // one symbol decoded bit by bit by every lane uniformly (tokens the primary tables cannot resolve)
-__device__ __forceinline__ uint32_t decode_serial(InflateLds &s, BitIn &br, const uint16_t *sorted, const uint16_t *count,
+template <class L>
+__device__ __forceinline__ uint32_t decode_serial(L &s, BitIn &br, const uint16_t *sorted, const uint16_t *count,
                                                   uint32_t lane) {
     unsigned long long v = peek(s, br, lane);
     uint32_t l = 0;
@@ -249,19 +263,22 @@ __device__ __forceinline__ uint32_t decode_serial(InflateLds &s, BitIn &br, cons
     return sym;
 }
 
-// flush every completed 1 KiB segment of the window ring to HBM
-__device__ __forceinline__ void flush_segments(InflateLds &s, uint8_t *out, unsigned long long out_off, uint32_t &flushed,
+// flush every completed 1024-element segment of the window ring to HBM (bytes: 16 B per lane; symbols: 32 B)
+template <class L>
+__device__ __forceinline__ void flush_segments(L &s, typename L::Elem *out, unsigned long long out_off, uint32_t &flushed,
                                                uint32_t pos, uint32_t lane) {
+    using Elem = typename L::Elem;
     while (flushed + 1024 <= pos) {
-        uint4 v = *reinterpret_cast<const uint4 *>(s.win + ((flushed & (kWinBytes - 1)) + lane * 16));
-        // the member's out_off is arbitrary: fall back to byte stores when the destination is not 16-byte aligned
-        uint8_t *dst = out + out_off + flushed + lane * 16;
+        const Elem *src = s.win + ((flushed & (kWinBytes - 1)) + lane * 16);
+        Elem *dst = out + out_off + flushed + lane * 16;
+        // the output offset is arbitrary: fall back to element stores when the destination is not 16-byte aligned
         if ((((uintptr_t)dst) & 15) == 0) {
-            *reinterpret_cast<uint4 *>(dst) = v;
-        } else {
-            uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int k = 0; k < 16; k++) dst[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+            for (uint32_t k = 0; k < sizeof(Elem); k++)
+                reinterpret_cast<uint4 *>(dst)[k] = reinterpret_cast<const uint4 *>(src)[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) dst[k] = src[k];
         }
         flushed += 1024;
     }
@@ -270,28 +287,49 @@ __device__ __forceinline__ void flush_segments(InflateLds &s, uint8_t *out, unsi
 // token kinds of the speculative decode
 static constexpr uint32_t kLit = 0, kMatch = 1, kEob = 2, kSlow = 3, kBad = 4;
 
-__global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ d_comp, uint8_t *__restrict__ d_out,
-                                                const InflateMember *__restrict__ members, InflateStatus *status,
-                                                uint32_t n_members) {
-    __shared__ __attribute__((aligned(16))) InflateLds s;
+// One decode job of a wavefront.  Plain members: start_bit = stop_bit = 0, the window in front is empty.
+struct InflateJob {
+    unsigned long long comp_off;   // byte offset of the DEFLATE stream (or of the member's stream for a chunk)
+    unsigned long long comp_size;  // bytes readable from comp_off
+    unsigned long long out_off;    // element offset of the output in d_out
+    unsigned long long out_cap;    // elements it may produce
+    unsigned long long start_bit;  // first bit to decode, relative to comp_off (a block header)
+    unsigned long long stop_bit;   // 0: decode to the final block; else stop at the first block boundary >= it
+};
+struct InflateJobStatus {
+    unsigned int code;             // as InflateStatus
+    unsigned int final_block;      // the stream's final block was decoded
+    unsigned long long produced;   // elements written
+    unsigned long long end_bit;    // bit after the last decoded block, relative to comp_off
+};
+
+template <bool SYM>
+__device__ __forceinline__ void inflate_job(InflateLdsT<SYM> &s, const uint8_t *__restrict__ d_comp,
+                                            typename InflateLdsT<SYM>::Elem *__restrict__ d_out, const InflateJob mb,
+                                            InflateJobStatus *st_out) {
+    using Elem = typename InflateLdsT<SYM>::Elem;
     const uint32_t lane = threadIdx.x;
-    for (uint32_t m = blockIdx.x; m < n_members; m += gridDim.x) {
-        const InflateMember mb = members[m];
+    {
         BitIn br;
         const unsigned long long a0 = mb.comp_off & ~15ull;
         br.g0 = d_comp + a0;
         const uint32_t skip = (uint32_t)(mb.comp_off - a0);
         unsigned long long lim = mb.comp_size + skip;
         br.limit = lim > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)lim;
-        br.bitpos = (unsigned long long)skip * 8;
-        br.loaded = 0;
+        br.bitpos = (unsigned long long)skip * 8 + mb.start_bit;
+        br.loaded = (uint32_t)(br.bitpos >> 13);  // staging starts at the chunk that holds the first bit
         __syncthreads();
         ensure(s, br, lane);
 
         uint32_t pos = 0, flushed = 0, err = 0;
         const unsigned long long cap = mb.out_cap;
         bool last = false;
-        while (!last && !err) {
+        const unsigned long long stop_at = mb.stop_bit ? (unsigned long long)skip * 8 + mb.stop_bit : 0;
+        while (!last && !err && !(stop_at && br.bitpos >= stop_at)) {
+            if ((br.bitpos >> 3) >= br.limit) {  // ran off the end of the input
+                err = 5;
+                break;
+            }
             uint32_t hdr3 = getbits(s, br, 3, lane);
             last = (hdr3 & 1) != 0;
             uint32_t type = hdr3 >> 1;
@@ -312,7 +350,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ d_co
                 for (uint32_t i = 0; i < len; i += 64) {
                     ensure(s, br, lane);
                     uint32_t n = len - i < 64 ? len - i : 64;
-                    if (lane < n) s.win[(pos + i + lane) & (kWinBytes - 1)] = s.in[((uint32_t)(br.bitpos >> 3) + lane) & (kInRing - 1)];
+                    if (lane < n) s.win[(pos + i + lane) & (kWinBytes - 1)] = (Elem)s.in[((uint32_t)(br.bitpos >> 3) + lane) & (kInRing - 1)];
                     br.bitpos += 8ull * n;
                     flush_segments(s, d_out, mb.out_off, flushed, pos + i + n, lane);
                 }
@@ -474,7 +512,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ d_co
                             break;
                         }
                         uint32_t rank = (uint32_t)__popcll(seg & ((1ull << lane) - 1ull));
-                        if ((seg >> lane) & 1ull) s.win[(pos + rank) & (kWinBytes - 1)] = (uint8_t)val;
+                        if ((seg >> lane) & 1ull) s.win[(pos + rank) & (kWinBytes - 1)] = (Elem)val;
                         uint32_t np = pos + n;
                         if ((np >> 10) != (pos >> 10)) flush_segments(s, d_out, mb.out_off, flushed, np, lane);
                         pos = np;
@@ -484,14 +522,19 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ d_co
                     const uint32_t x = __builtin_amdgcn_readlane(val, upto);
                     if (k == kMatch) {
                         uint32_t len = x & 0xFFFFu, dist = x >> 16;
-                        if (dist > pos || (unsigned long long)pos + len > cap) {
-                            err = dist > pos ? 3 : 4;
+                        if ((!SYM && dist > pos) || (unsigned long long)pos + len > cap) {
+                            err = (!SYM && dist > pos) ? 3 : 4;
                             break;
                         }
                         // all lanes copy; the source index is folded into [pos - dist, pos) so overlaps are exact
                         for (uint32_t i = lane; i < len; i += 64) {
-                            uint32_t src = pos - dist + (dist >= len ? i : i % dist);
-                            s.win[(pos + i) & (kWinBytes - 1)] = s.win[src & (kWinBytes - 1)];
+                            const long long src = (long long)pos - (long long)dist + (long long)(dist >= len ? i : i % dist);
+                            Elem x;
+                            if (SYM && src < 0)  // a byte of the 32 KiB in front of this decode: named, resolved later
+                                x = (Elem)(0x8000u | (uint32_t)(32768 + src));
+                            else
+                                x = s.win[(uint32_t)src & (kWinBytes - 1)];
+                            s.win[(pos + i) & (kWinBytes - 1)] = x;
                         }
                         uint32_t np = pos + len;
                         if ((np >> 10) != (pos >> 10)) flush_segments(s, d_out, mb.out_off, flushed, np, lane);
@@ -515,7 +558,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ d_co
                         if (pos >= cap) {
                             err = 4;
                         } else {
-                            if (lane == 0) s.win[pos & (kWinBytes - 1)] = (uint8_t)sym;
+                            if (lane == 0) s.win[pos & (kWinBytes - 1)] = (Elem)sym;
                             pos++;
                             if ((pos & 1023) == 0) flush_segments(s, d_out, mb.out_off, flushed, pos, lane);
                         }
@@ -531,12 +574,17 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ d_co
                             err = 3;
                         } else {
                             uint32_t dist = kDistBase[ds] + getbits(s, br, kDistExtra[ds], lane);
-                            if (dist > pos || (unsigned long long)pos + len > cap) {
-                                err = dist > pos ? 3 : 4;
+                            if ((!SYM && dist > pos) || (unsigned long long)pos + len > cap) {
+                                err = (!SYM && dist > pos) ? 3 : 4;
                             } else {
                                 for (uint32_t i = lane; i < len; i += 64) {
-                                    uint32_t src = pos - dist + (dist >= len ? i : i % dist);
-                                    s.win[(pos + i) & (kWinBytes - 1)] = s.win[src & (kWinBytes - 1)];
+                                    const long long src = (long long)pos - (long long)dist + (long long)(dist >= len ? i : i % dist);
+                                    Elem x;
+                                    if (SYM && src < 0)
+                                        x = (Elem)(0x8000u | (uint32_t)(32768 + src));
+                                    else
+                                        x = s.win[(uint32_t)src & (kWinBytes - 1)];
+                                    s.win[(pos + i) & (kWinBytes - 1)] = x;
                                 }
                                 uint32_t np = pos + len;
                                 if ((np >> 10) != (pos >> 10)) flush_segments(s, d_out, mb.out_off, flushed, np, lane);
@@ -552,12 +600,39 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ d_co
             for (uint32_t i = flushed + lane; i < pos; i += 64) d_out[mb.out_off + i] = s.win[i & (kWinBytes - 1)];
         }
         if (lane == 0) {
-            InflateStatus st;
+            InflateJobStatus st;
             st.code = err;
-            st.pad = 0;
+            st.final_block = last ? 1u : 0u;
             st.produced = pos;
+            st.end_bit = br.bitpos - (unsigned long long)skip * 8;
+            *st_out = st;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ d_comp, uint8_t *__restrict__ d_out,
+                                                const InflateMember *__restrict__ members, InflateStatus *status,
+                                                uint32_t n_members) {
+    __shared__ __attribute__((aligned(16))) InflateLdsT<false> s;
+    __shared__ InflateJobStatus s_st;
+    for (uint32_t m = blockIdx.x; m < n_members; m += gridDim.x) {
+        const InflateMember mb = members[m];
+        InflateJob jb;
+        jb.comp_off = mb.comp_off;
+        jb.comp_size = mb.comp_size;
+        jb.out_off = mb.out_off;
+        jb.out_cap = mb.out_cap;
+        jb.start_bit = 0;
+        jb.stop_bit = 0;
+        inflate_job<false>(s, d_comp, d_out, jb, &s_st);
+        if (threadIdx.x == 0) {
+            InflateStatus st;
+            st.code = s_st.code;
+            st.pad = 0;
+            st.produced = s_st.produced;
             // consumed: bytes up to the byte boundary after the final block, relative to comp_off
-            st.consumed = ((br.bitpos + 7) >> 3) - skip;
+            st.consumed = (s_st.end_bit + 7) >> 3;
             status[m] = st;
         }
         __syncthreads();
