@@ -15,602 +15,9 @@
 //     copied by all lanes (source index folded modulo the distance, so overlapping copies are exact);
 //   * every completed 1 KiB of the ring is flushed to HBM with 16 B/lane stores.
 // LDS: 32 KiB window + 2 KiB input + ~4.5 KiB tables => 4 waves per CU, 1024 members in flight.
-#include <type_traits>
-
-#include "exg_common.hpp"
+#include "exg_inflate_core.hpp"
 
 namespace exg {
-
-struct InflateMember {
-    unsigned long long comp_off;   // offset of the DEFLATE stream in d_comp
-    unsigned long long comp_size;  // bytes available from comp_off (deflate data + trailer)
-    unsigned long long out_off;    // where the member's output starts in d_out
-    unsigned long long out_cap;    // bytes it may produce (ISIZE when known)
-};
-
-struct InflateStatus {
-    unsigned int code;             // 0 ok; 1 bad block type / stored len; 2 bad code lengths; 3 bad symbol or distance;
-                                   // 4 output overflow; 5 input exhausted
-    unsigned int pad;
-    unsigned long long produced;   // bytes written
-    unsigned long long consumed;   // compressed bytes consumed (from comp_off, byte aligned after the final block)
-};
-
-static constexpr int kWinBytes = 32768;
-static constexpr int kInRing = 2048;
-static constexpr int kLitBits = 10, kDistBits = 9;
-
-// SYM = false: the window holds bytes (a gzip member decoded from its first bit).
-// SYM = true:  the window holds 16-bit symbols — a byte, or 0x8000 | i for "byte i of the 32 KiB in front of where
-//              this decode started", which are not known yet (exg_inflate_stream: one big member decoded in chunks).
-template <bool SYM>
-struct InflateLdsT {
-    using Elem = typename std::conditional<SYM, uint16_t, uint8_t>::type;
-    Elem win[kWinBytes];
-    uint8_t in[kInRing];
-    // Primary tables, 0 = code longer than the table (or unused).  The entries carry what the token needs, so a
-    // decode is peek -> lit_lut -> dist_lut, three dependent LDS levels instead of five:
-    //   lit_lut  literal: bits 0-3 code length, 4-11 byte, 12 end-of-block, 13 invalid symbol
-    //            length : bit 15, bits 0-3 code length, 4-6 extra bit count, 7-14 base length - 3
-    //   dist_lut bits 0-3 code length, 4-7 extra bit count, 8 invalid symbol, 16-30 base distance
-    //            (the code-length alphabet of a dynamic header borrows it as a plain u16 table)
-    uint16_t lit_lut[1 << kLitBits];
-    uint32_t dist_lut[1 << kDistBits];
-    uint16_t lit_sorted[288], dist_sorted[32];   // symbols ordered by (length, symbol) — canonical decode
-    uint16_t lit_count[16], dist_count[16];
-    uint8_t lens[384];  // [0,288) literal/length, [288,320) distance; [32,348) scratch while a dynamic header is read
-};
-
-__device__ __constant__ unsigned short kLenBase[29] = {3,  4,  5,  6,  7,  8,  9,  10, 11,  13,  15,  17,  19,  23, 27,
-                                                      31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__device__ __constant__ unsigned char kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__device__ __constant__ unsigned short kDistBase[30] = {1,   2,   3,   4,   5,   7,    9,    13,   17,   25,
-                                                       33,  49,  65,  97,  129, 193,  257,  385,  513,  769,
-                                                       1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__device__ __constant__ unsigned char kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
-__device__ __constant__ unsigned char kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-
-__device__ __forceinline__ uint32_t sgpr(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
-
-// ---- bit input: absolute bit position + a 2 KiB LDS ring of the compressed bytes --------------------------
-struct BitIn {
-    unsigned long long bitpos;  // next bit, relative to g0 (wave uniform)
-    uint32_t loaded;            // input chunks [0, loaded) (1 KiB each) have been staged
-    uint32_t limit;             // bytes available relative to g0
-    const uint8_t *g0;          // 16-byte aligned global address of chunk 0
-};
-
-// stage 1 KiB chunk c of the compressed input (coalesced, 16 B per lane)
-template <class L>
-__device__ __forceinline__ void stage_chunk(L &s, const BitIn &br, uint32_t c, uint32_t lane) {
-    uint32_t off = c * 1024 + lane * 16;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (off < ((br.limit + 15) & ~15u)) v = *reinterpret_cast<const uint4 *>(br.g0 + off);
-    *reinterpret_cast<uint4 *>(s.in + ((c & 1) * 1024 + lane * 16)) = v;
-}
-
-// keep the chunk that holds the current byte and the next one staged (reads go up to ~20 bytes ahead)
-template <class L>
-__device__ __forceinline__ void ensure(L &s, BitIn &br, uint32_t lane) {
-    uint32_t c = (uint32_t)(br.bitpos >> 13);  // 8192 bits per chunk
-    while (c + 1 >= br.loaded) {
-        stage_chunk(s, br, br.loaded, lane);
-        br.loaded++;
-    }
-}
-
-// 64 bits starting at absolute bit `o` (per lane), >= 57 of them valid
-template <class L>
-__device__ __forceinline__ unsigned long long peek_at(const L &s, unsigned long long o) {
-    uint32_t byte = (uint32_t)(o >> 3);
-    uint32_t a = byte & ~3u;
-    uint32_t w0 = *reinterpret_cast<const uint32_t *>(s.in + (a & (kInRing - 1)));
-    uint32_t w1 = *reinterpret_cast<const uint32_t *>(s.in + ((a + 4) & (kInRing - 1)));
-    uint32_t w2 = *reinterpret_cast<const uint32_t *>(s.in + ((a + 8) & (kInRing - 1)));
-    uint32_t sh = 8 * (byte & 3u) + (uint32_t)(o & 7);  // 0..31
-    unsigned long long lo = ((unsigned long long)w1 << 32) | w0;
-    unsigned long long v = lo >> sh;
-    if (sh) v |= (unsigned long long)w2 << (64 - sh);
-    return v;
-}
-template <class L>
-__device__ __forceinline__ unsigned long long peek(L &s, BitIn &br, uint32_t lane) {
-    ensure(s, br, lane);
-    unsigned long long v = peek_at(s, br.bitpos);
-    uint32_t lo = sgpr((uint32_t)v), hi = sgpr((uint32_t)(v >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
-template <class L>
-__device__ __forceinline__ uint32_t getbits(L &s, BitIn &br, uint32_t n, uint32_t lane) {
-    unsigned long long v = peek(s, br, lane);
-    br.bitpos += n;
-    return (uint32_t)v & (n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u));
-}
-
-// Build one decode table from code lengths lens[0..n): LUT (primary `bits`), sorted symbols, counts.
-// Returns false when the lengths are over-subscribed or incomplete (except the single-code cases zlib allows).
-struct EncPlain {  // (symbol << 4) | length
-    __device__ __forceinline__ uint16_t operator()(uint32_t sym, uint32_t l) const { return (uint16_t)((sym << 4) | l); }
-};
-struct EncLit {
-    __device__ __forceinline__ uint16_t operator()(uint32_t sym, uint32_t l) const {
-        if (sym < 256) return (uint16_t)((sym << 4) | l);
-        if (sym == 256) return (uint16_t)((1u << 12) | l);
-        if (sym > 285) return (uint16_t)((1u << 13) | l);
-        const uint32_t si = sym - 257;
-        return (uint16_t)(0x8000u | ((uint32_t)(kLenBase[si] - 3) << 7) | ((uint32_t)kLenExtra[si] << 4) | l);
-    }
-};
-struct EncDist {
-    __device__ __forceinline__ uint32_t operator()(uint32_t sym, uint32_t l) const {
-        if (sym > 29) return (1u << 8) | l;
-        return ((uint32_t)kDistBase[sym] << 16) | ((uint32_t)kDistExtra[sym] << 4) | l;
-    }
-};
-
-template <class Lut, class Enc>
-__device__ bool build_table(const uint8_t *lens, uint32_t n, Lut *lut, uint32_t bits, uint16_t *sorted, uint16_t *count,
-                            uint32_t lane, Enc enc) {
-    for (uint32_t e = lane; e < (1u << bits); e += 64) lut[e] = 0;
-    // counts per length
-    uint32_t cnt[16];
-#pragma unroll
-    for (int L = 0; L < 16; L++) cnt[L] = 0;
-    for (uint32_t base = 0; base < n; base += 64) {
-        uint32_t sym = base + lane;
-        uint32_t l = sym < n ? lens[sym] : 0;
-#pragma unroll
-        for (int L = 1; L < 16; L++) cnt[L] += __popcll(__ballot(l == (uint32_t)L));
-    }
-    // canonical first codes and offsets into `sorted`
-    uint32_t first[16], offs[16];
-    uint32_t code = 0, off = 0;
-    int left = 1;
-    bool bad = false;
-#pragma unroll
-    for (int L = 1; L < 16; L++) {
-        left = (left << 1) - (int)cnt[L];
-        if (left < 0) bad = true;
-        code = (code + cnt[L - 1]) << 1;
-        first[L] = code;
-        offs[L] = off;
-        off += cnt[L];
-    }
-    first[0] = 0;
-    offs[0] = 0;
-#pragma unroll
-    for (int L = 0; L < 16; L++)
-        if (lane == (uint32_t)L) count[L] = (uint16_t)(L ? cnt[L] : 0);
-    if (bad) return false;
-    // incomplete codes are only legal with a single code of length 1 (zlib / puff behaviour)
-    if (left > 0 && !(off == 1 && cnt[1] == 1) && off != 0) return false;
-    // per symbol: canonical code = first[len] + rank among equal lengths, in symbol order
-    uint32_t run[16];
-#pragma unroll
-    for (int L = 0; L < 16; L++) run[L] = 0;
-    for (uint32_t base = 0; base < n; base += 64) {
-        uint32_t sym = base + lane;
-        uint32_t l = sym < n ? lens[sym] : 0;
-        uint32_t rank = 0, f = 0, o = 0;
-#pragma unroll
-        for (int L = 1; L < 16; L++) {
-            unsigned long long m = __ballot(l == (uint32_t)L);
-            if (l == (uint32_t)L) {
-                rank = run[L] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                f = first[L];
-                o = offs[L];
-            }
-            run[L] += (uint32_t)__popcll(m);
-        }
-        if (l) {
-            sorted[o + rank] = (uint16_t)sym;
-            if (l <= bits) {
-                uint32_t c = f + rank;
-                uint32_t r = __brev(c) >> (32 - l);  // codes are sent MSB first
-                const Lut entry = enc(sym, l);
-                for (uint32_t e = r; e < (1u << bits); e += 1u << l) lut[e] = entry;
-            }
-        }
-    }
-    return true;
-}
-
-// canonical decode, bit by bit, of the code at the front of `bits` (codes longer than the primary table; rare)
-__device__ __forceinline__ uint32_t decode_slow(unsigned long long bits, const uint16_t *sorted, const uint16_t *count,
-                                                uint32_t *len_out) {
-    uint32_t code = 0, first = 0, index = 0;
-    for (uint32_t len = 1; len <= 15; len++) {
-        code |= (uint32_t)bits & 1u;
-        bits >>= 1;
-        uint32_t c = count[len];
-        if (code < first + c) {
-            *len_out = len;
-            return sorted[index + (code - first)];
-        }
-        index += c;
-        first += c;
-        first <<= 1;
-        code <<= 1;
-    }
-    *len_out = 0;
-    return 0xFFFFFFFFu;
-}
-
-// decode one symbol serially (block headers); returns 0xFFFFFFFF on an invalid code
-template <class L>
-__device__ __forceinline__ uint32_t decode_sym(L &s, BitIn &br, const uint16_t *lut, uint32_t bits,
-                                               const uint16_t *sorted, const uint16_t *count, uint32_t lane) {
-    unsigned long long v = peek(s, br, lane);
-    uint32_t e = sgpr(lut[(uint32_t)v & ((1u << bits) - 1u)]);
-    if (e) {
-        br.bitpos += e & 15;
-        return e >> 4;
-    }
-    uint32_t l = 0;
-    uint32_t sym = sgpr(decode_slow(v, sorted, count, &l));
-    br.bitpos += sgpr(l);
-    return sym;
-}
-
-// one symbol decoded bit by bit by every lane uniformly (tokens the primary tables cannot resolve)
-template <class L>
-__device__ __forceinline__ uint32_t decode_serial(L &s, BitIn &br, const uint16_t *sorted, const uint16_t *count,
-                                                  uint32_t lane) {
-    unsigned long long v = peek(s, br, lane);
-    uint32_t l = 0;
-    uint32_t sym = sgpr(decode_slow(v, sorted, count, &l));
-    br.bitpos += sgpr(l);
-    return sym;
-}
-
-// flush every completed 1024-element segment of the window ring to HBM (bytes: 16 B per lane; symbols: 32 B)
-template <class L>
-__device__ __forceinline__ void flush_segments(L &s, typename L::Elem *out, unsigned long long out_off, uint32_t &flushed,
-                                               uint32_t pos, uint32_t lane) {
-    using Elem = typename L::Elem;
-    while (flushed + 1024 <= pos) {
-        const Elem *src = s.win + ((flushed & (kWinBytes - 1)) + lane * 16);
-        Elem *dst = out + out_off + flushed + lane * 16;
-        // the output offset is arbitrary: fall back to element stores when the destination is not 16-byte aligned
-        if ((((uintptr_t)dst) & 15) == 0) {
-#pragma unroll
-            for (uint32_t k = 0; k < sizeof(Elem); k++)
-                reinterpret_cast<uint4 *>(dst)[k] = reinterpret_cast<const uint4 *>(src)[k];
-        } else {
-#pragma unroll
-            for (int k = 0; k < 16; k++) dst[k] = src[k];
-        }
-        flushed += 1024;
-    }
-}
-
-// token kinds of the speculative decode
-static constexpr uint32_t kLit = 0, kMatch = 1, kEob = 2, kSlow = 3, kBad = 4;
-
-// One decode job of a wavefront.  Plain members: start_bit = stop_bit = 0, the window in front is empty.
-struct InflateJob {
-    unsigned long long comp_off;   // byte offset of the DEFLATE stream (or of the member's stream for a chunk)
-    unsigned long long comp_size;  // bytes readable from comp_off
-    unsigned long long out_off;    // element offset of the output in d_out
-    unsigned long long out_cap;    // elements it may produce
-    unsigned long long start_bit;  // first bit to decode, relative to comp_off (a block header)
-    unsigned long long stop_bit;   // 0: decode to the final block; else stop at the first block boundary >= it
-};
-struct InflateJobStatus {
-    unsigned int code;             // as InflateStatus
-    unsigned int final_block;      // the stream's final block was decoded
-    unsigned long long produced;   // elements written
-    unsigned long long end_bit;    // bit after the last decoded block, relative to comp_off
-};
-
-template <bool SYM>
-__device__ __forceinline__ void inflate_job(InflateLdsT<SYM> &s, const uint8_t *__restrict__ d_comp,
-                                            typename InflateLdsT<SYM>::Elem *__restrict__ d_out, const InflateJob mb,
-                                            InflateJobStatus *st_out) {
-    using Elem = typename InflateLdsT<SYM>::Elem;
-    const uint32_t lane = threadIdx.x;
-    {
-        BitIn br;
-        const unsigned long long a0 = mb.comp_off & ~15ull;
-        br.g0 = d_comp + a0;
-        const uint32_t skip = (uint32_t)(mb.comp_off - a0);
-        unsigned long long lim = mb.comp_size + skip;
-        br.limit = lim > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)lim;
-        br.bitpos = (unsigned long long)skip * 8 + mb.start_bit;
-        br.loaded = (uint32_t)(br.bitpos >> 13);  // staging starts at the chunk that holds the first bit
-        __syncthreads();
-        ensure(s, br, lane);
-
-        uint32_t pos = 0, flushed = 0, err = 0;
-        const unsigned long long cap = mb.out_cap;
-        bool last = false;
-        const unsigned long long stop_at = mb.stop_bit ? (unsigned long long)skip * 8 + mb.stop_bit : 0;
-        while (!last && !err && !(stop_at && br.bitpos >= stop_at)) {
-            if ((br.bitpos >> 3) >= br.limit) {  // ran off the end of the input
-                err = 5;
-                break;
-            }
-            uint32_t hdr3 = getbits(s, br, 3, lane);
-            last = (hdr3 & 1) != 0;
-            uint32_t type = hdr3 >> 1;
-            if (type == 0) {
-                // stored: skip to a byte boundary, LEN / NLEN, raw bytes
-                br.bitpos = (br.bitpos + 7) & ~7ull;
-                uint32_t ln = getbits(s, br, 32, lane);
-                uint32_t len = ln & 0xFFFFu, nlen = ln >> 16;
-                if ((len ^ 0xFFFFu) != nlen) {
-                    err = 1;
-                    break;
-                }
-                if ((unsigned long long)pos + len > cap) {
-                    err = 4;
-                    break;
-                }
-                // 64 bytes per step, lane = byte
-                for (uint32_t i = 0; i < len; i += 64) {
-                    ensure(s, br, lane);
-                    uint32_t n = len - i < 64 ? len - i : 64;
-                    if (lane < n) s.win[(pos + i + lane) & (kWinBytes - 1)] = (Elem)s.in[((uint32_t)(br.bitpos >> 3) + lane) & (kInRing - 1)];
-                    br.bitpos += 8ull * n;
-                    flush_segments(s, d_out, mb.out_off, flushed, pos + i + n, lane);
-                }
-                pos += len;
-                continue;
-            }
-            if (type == 3) {
-                err = 1;
-                break;
-            }
-            uint32_t nlit, ndist;
-            if (type == 1) {
-                for (uint32_t i = lane; i < 288; i += 64) s.lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
-                if (lane < 32) s.lens[288 + lane] = 5;  // 32 codes make the fixed distance code complete; 30, 31 are invalid
-                nlit = 288;
-                ndist = 32;
-            } else {
-                uint32_t h14 = getbits(s, br, 14, lane);
-                nlit = (h14 & 31) + 257;
-                ndist = ((h14 >> 5) & 31) + 1;
-                uint32_t ncode = (h14 >> 10) + 4;
-                if (nlit > 286 || ndist > 30) {
-                    err = 2;
-                    break;
-                }
-                if (lane < 19) s.lens[lane] = 0;
-                {
-                    // 19 x 3 bits = 57 bits: one peek
-                    unsigned long long v = peek(s, br, lane);
-                    if (lane < ncode) s.lens[kClOrder[lane]] = (uint8_t)((v >> (3 * lane)) & 7);
-                    br.bitpos += 3ull * ncode;
-                }
-                // the code-length code reuses the distance table storage (7-bit codes, 19 symbols)
-                uint16_t *cl_lut = reinterpret_cast<uint16_t *>(s.dist_lut);  // borrowed until the real tables are built
-                if (!build_table(s.lens, 19, cl_lut, 7, s.dist_sorted, s.dist_count, lane, EncPlain())) {
-                    err = 2;
-                    break;
-                }
-                uint32_t idx = 0, prev = 0;
-                while (idx < nlit + ndist) {
-                    uint32_t sym = decode_sym(s, br, cl_lut, 7, s.dist_sorted, s.dist_count, lane);
-                    if (sym == 0xFFFFFFFFu) {
-                        err = 2;
-                        break;
-                    }
-                    uint32_t rep = 1, val = sym;
-                    if (sym == 16) {
-                        if (idx == 0) {
-                            err = 2;
-                            break;
-                        }
-                        val = prev;
-                        rep = 3 + getbits(s, br, 2, lane);
-                    } else if (sym == 17) {
-                        val = 0;
-                        rep = 3 + getbits(s, br, 3, lane);
-                    } else if (sym == 18) {
-                        val = 0;
-                        rep = 11 + getbits(s, br, 7, lane);
-                    }
-                    if (idx + rep > nlit + ndist) {
-                        err = 2;
-                        break;
-                    }
-                    for (uint32_t k = lane; k < rep; k += 64) s.lens[32 + idx + k] = (uint8_t)val;
-                    idx += rep;
-                    prev = val;
-                }
-                if (err) break;
-                // move to their final places: literal/length lengths at [0, nlit), distance at [288, 288+ndist)
-                uint8_t lv[5];
-#pragma unroll
-                for (int k = 0; k < 5; k++) {
-                    uint32_t i = k * 64 + lane;
-                    lv[k] = i < nlit + ndist ? s.lens[32 + i] : 0;
-                }
-#pragma unroll
-                for (int k = 0; k < 5; k++) {
-                    uint32_t i = k * 64 + lane;
-                    if (i < nlit)
-                        s.lens[i] = lv[k];
-                    else if (i < nlit + ndist)
-                        s.lens[288 + (i - nlit)] = lv[k];
-                }
-            }
-            if (!build_table(s.lens, nlit, s.lit_lut, kLitBits, s.lit_sorted, s.lit_count, lane, EncLit()) ||
-                !build_table(s.lens + 288, ndist, s.dist_lut, kDistBits, s.dist_sorted, s.dist_count, lane, EncDist())) {
-                err = 2;
-                break;
-            }
-            // ---- tokens of the block: 64 speculative decodes per step, then the true chain ----------------
-            bool eob = false;
-            while (!eob && !err) {
-                ensure(s, br, lane);
-                // lane l decodes the token that would start at bit bitpos + l
-                unsigned long long v = peek_at(s, br.bitpos + lane);
-                uint32_t kind, tl, val = 0;
-                {
-                    const uint32_t e = s.lit_lut[(uint32_t)v & ((1u << kLitBits) - 1u)];
-                    const uint32_t l1 = e & 15;
-                    if (e == 0) {  // longer than the primary table: decoded serially IF it is a real token start
-                        kind = kSlow;
-                        tl = 0;
-                    } else if (!(e & 0x8000u)) {
-                        kind = (e & (1u << 13)) ? kBad : (e & (1u << 12)) ? kEob : kLit;
-                        tl = kind == kBad ? 1 : l1;
-                        val = (e >> 4) & 0xFFu;
-                    } else {
-                        const uint32_t lx = (e >> 4) & 7u;
-                        const uint32_t len = ((e >> 7) & 0xFFu) + 3u + ((uint32_t)(v >> l1) & ((1u << lx) - 1u));
-                        const uint32_t t = l1 + lx;
-                        const unsigned long long v2 = v >> t;
-                        const uint32_t de = s.dist_lut[(uint32_t)v2 & ((1u << kDistBits) - 1u)];
-                        const uint32_t l2 = de & 15, dx = (de >> 4) & 15u;
-                        if (de == 0) {
-                            kind = kSlow;
-                            tl = 0;
-                        } else if (de & (1u << 8)) {
-                            kind = kBad;
-                            tl = 1;
-                        } else {
-                            const uint32_t dist = (de >> 16) + ((uint32_t)(v2 >> l2) & ((1u << dx) - 1u));
-                            kind = kMatch;
-                            tl = t + l2 + dx;  // <= 15 + 5 + 15 + 13 = 48 bits
-                            val = len | (dist << 16);
-                        }
-                    }
-                }
-                // the real chain from offset 0: one readlane per token marks the token starts ...
-                unsigned long long marks = 0;
-                uint32_t cur = 0;
-                bool slow_token = false;
-                while (cur < 64) {
-                    uint32_t t = __builtin_amdgcn_readlane(tl, cur);
-                    if (t == 0) {  // kSlow: the window ends in front of it
-                        slow_token = true;
-                        break;
-                    }
-                    marks |= 1ull << cur;
-                    cur += t;
-                }
-                // ... then runs of literals go out in ONE step (rank = popcount of the marks below the lane);
-                // only matches / end-of-block / bad codes are handled one at a time, in order
-                const unsigned long long m_lit = __ballot(kind == kLit) & marks;
-                unsigned long long m_other = marks & ~m_lit;
-                uint32_t from = 0, advance = cur;
-                for (;;) {
-                    const uint32_t upto = m_other ? (uint32_t)__ffsll((long long)m_other) - 1 : 64u;
-                    unsigned long long seg = m_lit;
-                    if (upto < 64) seg &= (1ull << upto) - 1ull;
-                    if (from >= 64)
-                        seg = 0;
-                    else if (from)
-                        seg &= ~((1ull << from) - 1ull);
-                    const uint32_t n = (uint32_t)__popcll(seg);
-                    if (n) {
-                        if ((unsigned long long)pos + n > cap) {
-                            err = 4;
-                            break;
-                        }
-                        uint32_t rank = (uint32_t)__popcll(seg & ((1ull << lane) - 1ull));
-                        if ((seg >> lane) & 1ull) s.win[(pos + rank) & (kWinBytes - 1)] = (Elem)val;
-                        uint32_t np = pos + n;
-                        if ((np >> 10) != (pos >> 10)) flush_segments(s, d_out, mb.out_off, flushed, np, lane);
-                        pos = np;
-                    }
-                    if (upto == 64) break;
-                    const uint32_t k = __builtin_amdgcn_readlane(kind, upto);
-                    const uint32_t x = __builtin_amdgcn_readlane(val, upto);
-                    if (k == kMatch) {
-                        uint32_t len = x & 0xFFFFu, dist = x >> 16;
-                        if ((!SYM && dist > pos) || (unsigned long long)pos + len > cap) {
-                            err = (!SYM && dist > pos) ? 3 : 4;
-                            break;
-                        }
-                        // all lanes copy; the source index is folded into [pos - dist, pos) so overlaps are exact
-                        for (uint32_t i = lane; i < len; i += 64) {
-                            const long long src = (long long)pos - (long long)dist + (long long)(dist >= len ? i : i % dist);
-                            Elem x;
-                            if (SYM && src < 0)  // a byte of the 32 KiB in front of this decode: named, resolved later
-                                x = (Elem)(0x8000u | (uint32_t)(32768 + src));
-                            else
-                                x = s.win[(uint32_t)src & (kWinBytes - 1)];
-                            s.win[(pos + i) & (kWinBytes - 1)] = x;
-                        }
-                        uint32_t np = pos + len;
-                        if ((np >> 10) != (pos >> 10)) flush_segments(s, d_out, mb.out_off, flushed, np, lane);
-                        pos = np;
-                    } else if (k == kEob) {
-                        advance = upto + __builtin_amdgcn_readlane(tl, upto);
-                        eob = true;
-                        break;
-                    } else {
-                        err = 3;
-                        break;
-                    }
-                    m_other &= m_other - 1;
-                    from = upto + 1;
-                }
-                br.bitpos += advance;
-                if (slow_token && !eob && !err) {
-                    // one token with a code longer than the primary tables, decoded by every lane uniformly
-                    uint32_t sym = decode_serial(s, br, s.lit_sorted, s.lit_count, lane);
-                    if (sym < 256) {
-                        if (pos >= cap) {
-                            err = 4;
-                        } else {
-                            if (lane == 0) s.win[pos & (kWinBytes - 1)] = (Elem)sym;
-                            pos++;
-                            if ((pos & 1023) == 0) flush_segments(s, d_out, mb.out_off, flushed, pos, lane);
-                        }
-                    } else if (sym == 256) {
-                        eob = true;
-                    } else if (sym > 285) {
-                        err = 3;
-                    } else {
-                        sym -= 257;
-                        uint32_t len = kLenBase[sym] + getbits(s, br, kLenExtra[sym], lane);
-                        uint32_t ds = decode_serial(s, br, s.dist_sorted, s.dist_count, lane);
-                        if (ds > 29) {
-                            err = 3;
-                        } else {
-                            uint32_t dist = kDistBase[ds] + getbits(s, br, kDistExtra[ds], lane);
-                            if ((!SYM && dist > pos) || (unsigned long long)pos + len > cap) {
-                                err = (!SYM && dist > pos) ? 3 : 4;
-                            } else {
-                                for (uint32_t i = lane; i < len; i += 64) {
-                                    const long long src = (long long)pos - (long long)dist + (long long)(dist >= len ? i : i % dist);
-                                    Elem x;
-                                    if (SYM && src < 0)
-                                        x = (Elem)(0x8000u | (uint32_t)(32768 + src));
-                                    else
-                                        x = s.win[(uint32_t)src & (kWinBytes - 1)];
-                                    s.win[(pos + i) & (kWinBytes - 1)] = x;
-                                }
-                                uint32_t np = pos + len;
-                                if ((np >> 10) != (pos >> 10)) flush_segments(s, d_out, mb.out_off, flushed, np, lane);
-                                pos = np;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        // tail: the bytes after the last full segment
-        if (!err) {
-            for (uint32_t i = flushed + lane; i < pos; i += 64) d_out[mb.out_off + i] = s.win[i & (kWinBytes - 1)];
-        }
-        if (lane == 0) {
-            InflateJobStatus st;
-            st.code = err;
-            st.final_block = last ? 1u : 0u;
-            st.produced = pos;
-            st.end_bit = br.bitpos - (unsigned long long)skip * 8;
-            *st_out = st;
-        }
-        __syncthreads();
-    }
-}
-
 __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ d_comp, uint8_t *__restrict__ d_out,
                                                 const InflateMember *__restrict__ members, InflateStatus *status,
                                                 uint32_t n_members) {

@@ -1,0 +1,414 @@
+// exg_inflate_stream.hip — ONE big DEFLATE stream (what gzip / pigz write: a single gzip member) inflated by many
+// wavefronts at once.  exg_inflate.hip parallelises over members, so such a file would run on one wavefront
+// (10 MB/s, measured); here the stream is cut into chunks of compressed bytes that are decoded concurrently.
+//
+// Replaces the same reference code as exg_inflate.hip (DataFusion 28 `FileCompressionType::convert_stream` ->
+// async-compression -> flate2, rust/src/arrow_reader.rs:60-91) for this input shape.  The method is the one of
+// pugz / rapidgzip, restated for wavefronts:
+//   1. k_find_blocks   a wave per chunk boundary looks for the first deflate block that starts at or after it:
+//                      every lane tests one bit offset with a cheap filter (BTYPE = dynamic, HLIT / HDIST in range,
+//                      the code-length code complete: Kraft sum exactly 1), survivors are validated by really
+//                      decoding from there (header, tables, the first few hundred symbols);
+//   2. k_inflate_chunks the ordinary decoder (exg_inflate_core.hpp) from each found block start up to the next one,
+//                      with a window of 16-bit symbols: a byte, or "byte i of the 32 KiB in front of this chunk"
+//                      (not known yet);
+//   3. the host checks that every chunk ended exactly where the next one started (a false block start — rare —
+//      makes the previous chunk run on through it) ;
+//   4. k_windows       chunk by chunk (sequential, 32 Ki symbols each): the last 32 KiB of output before every chunk;
+//   5. k_resolve       all symbols -> bytes in parallel (markers looked up in their chunk's window).
+// Everything stays in HBM; the host only sees bit positions and counts.
+#include <stdio.h>
+#include <stdlib.h>
+#include <time.h>
+
+#include <algorithm>
+#include <map>
+#include <memory>
+#include <vector>
+
+#include "exg_inflate_core.hpp"
+
+namespace exg {
+
+namespace {
+
+static constexpr uint32_t kProbeSymbols = 320;  // a candidate block start must decode this far without an error
+
+// ---- 1. block finder ---------------------------------------------------------------------------------------------------
+struct FindJob {
+    unsigned long long comp_off, comp_size;  // the stream
+    unsigned long long from_bit, to_bit;     // search [from_bit, to_bit) relative to comp_off
+};
+
+// cheap per-lane filter on the 64 + 64 bits that start at a candidate offset: could a dynamic block begin here?
+__device__ __forceinline__ bool header_filter(unsigned long long v, unsigned long long v17) {
+    if ((v & 7ull) != 4ull) return false;  // BFINAL = 0 (a final block mid-stream is never needed as a chunk start:
+                                           // the chunk in front simply runs to the end), BTYPE = 10 (dynamic Huffman)
+    const uint32_t hlit = (uint32_t)(v >> 3) & 31u, hdist = (uint32_t)(v >> 8) & 31u, hclen = (uint32_t)(v >> 13) & 15u;
+    if (hlit > 29 || hdist > 29) return false;
+    // code-length code: hclen + 4 lengths of 3 bits from bit 17; it must be complete (zlib writes complete codes)
+    const uint32_t n = hclen + 4;
+    uint32_t kraft = 0, used = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 19; i++) {
+        const uint32_t l = i < n ? (uint32_t)(v17 >> (3 * i)) & 7u : 0u;
+        if (l) kraft += 128u >> l, used++;
+    }
+    return kraft == 128u && used >= 2;
+}
+
+__global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ d_comp, const FindJob *__restrict__ jobs,
+                                                    unsigned long long *found, uint16_t *d_scratch, uint32_t n_jobs) {
+    __shared__ __attribute__((aligned(16))) InflateLdsT<true> s;
+    __shared__ InflateJobStatus s_st;
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t j = blockIdx.x; j < n_jobs; j += gridDim.x) {
+        const FindJob fj = jobs[j];
+        const unsigned long long a0 = fj.comp_off & ~15ull;
+        const uint32_t skip = (uint32_t)(fj.comp_off - a0);
+        unsigned long long result = ~0ull;
+        for (unsigned long long base = fj.from_bit; base < fj.to_bit && result == ~0ull; base += 64) {
+            // stage the input around `base` and let every lane look at its own offset
+            BitIn br;
+            br.g0 = d_comp + a0;
+            unsigned long long lim = fj.comp_size + skip;
+            br.limit = lim > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)lim;
+            br.bitpos = (unsigned long long)skip * 8 + base;
+            br.loaded = (uint32_t)(br.bitpos >> 13);
+            __syncthreads();
+            ensure(s, br, lane);
+            br.bitpos += 64 + 17 + 64;  // the filter reads up to here: keep the next chunk staged too
+            ensure(s, br, lane);
+            const unsigned long long o = (unsigned long long)skip * 8 + base + lane;
+            const bool in_range = base + lane < fj.to_bit && ((o + 17 + 64) >> 3) < br.limit;
+            const bool pass = in_range && header_filter(peek_at(s, o), peek_at(s, o + 17));
+            unsigned long long cand = __ballot(pass);
+            while (cand && result == ~0ull) {
+                const uint32_t l = (uint32_t)__ffsll((long long)cand) - 1;
+                cand &= cand - 1;
+                // Real decode from there.  A valid header alone is not enough (about one boundary in ten of a FASTQ
+                // stream had a false one in front of the real block start): the WHOLE block must decode, and what
+                // follows it must again be a block that decodes (its header + the first kProbeSymbols symbols).
+                InflateJob jb;
+                jb.comp_off = fj.comp_off;
+                jb.comp_size = fj.comp_size;
+                jb.out_off = 0;
+                jb.out_cap = 1ull << 26;  // nothing is stored: the bound only stops a runaway decode
+                jb.start_bit = base + l;
+                jb.stop_bit = base + l + 1;
+                inflate_job<true>(s, d_comp, (uint16_t *)nullptr, jb, &s_st);
+                uint32_t code = s_st.code;
+                const bool final1 = s_st.final_block != 0;
+                const unsigned long long end1 = s_st.end_bit;
+                __syncthreads();
+                if (final1) code = 1;
+                if (code == 0) {
+                    jb.out_cap = kProbeSymbols;
+                    jb.start_bit = end1;
+                    jb.stop_bit = end1 + 1;
+                    inflate_job<true>(s, d_comp, (uint16_t *)nullptr, jb, &s_st);
+                    code = s_st.code == 4 ? 0u : s_st.code;
+                    __syncthreads();
+                }
+                if (code == 0) result = base + l;
+            }
+        }
+        if (lane == 0) found[j] = result;
+        __syncthreads();
+    }
+}
+
+// ---- 2. chunk decode -----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_inflate_chunks(const uint8_t *__restrict__ d_comp, uint16_t *__restrict__ d_sym,
+                                                       const InflateJob *__restrict__ jobs, InflateJobStatus *status,
+                                                       uint32_t n_jobs) {
+    __shared__ __attribute__((aligned(16))) InflateLdsT<true> s;
+    for (uint32_t j = blockIdx.x; j < n_jobs; j += gridDim.x) inflate_job<true>(s, d_comp, d_sym, jobs[j], &status[j]);
+}
+
+// ---- 4. windows ----------------------------------------------------------------------------------------------------------
+struct ChunkOut {
+    const uint16_t *sym;         // the chunk's symbols
+    unsigned long long n;        // symbols (= bytes) it produced
+    unsigned long long out_off;  // where its bytes go in the output
+};
+// windows[c] = the 32 KiB of output in front of chunk c (windows[0] is empty: zeros).  One workgroup, chunk by chunk.
+__global__ __launch_bounds__(1024) void k_windows(const ChunkOut *__restrict__ chunks, uint8_t *windows, uint32_t n_chunks,
+                                                  uint32_t *bad) {
+    for (uint32_t c = 0; c + 1 < n_chunks; c++) {
+        const ChunkOut ch = chunks[c];
+        const uint8_t *wprev = windows + (size_t)c * 32768;
+        uint8_t *wnext = windows + (size_t)(c + 1) * 32768;
+        // byte i of the next window = byte (n + i - 32768) of (this chunk's output), or of the previous window
+        for (uint32_t i = threadIdx.x; i < 32768; i += 1024) {
+            const long long k = (long long)ch.n + (long long)i - 32768;
+            uint8_t b;
+            if (k >= 0) {
+                const uint16_t sy = ch.sym[k];
+                b = sy & 0x8000u ? wprev[sy & 0x7FFFu] : (uint8_t)sy;
+                if ((sy & 0x8000u) && c == 0) atomicOr(bad, 1u);  // nothing precedes the first chunk
+            } else {
+                b = wprev[32768 + k];
+            }
+            wnext[i] = b;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+// ---- 5. resolve ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resolve(const ChunkOut *__restrict__ chunks, const uint8_t *__restrict__ windows,
+                                                 uint8_t *__restrict__ d_out, uint32_t n_chunks, uint32_t *bad) {
+    // blockIdx.y = chunk; 16 symbols per thread -> one 16-byte store when the destination is aligned
+    const uint32_t c = blockIdx.y;
+    const ChunkOut ch = chunks[c];
+    const uint8_t *w = windows + (size_t)c * 32768;
+    for (unsigned long long g = (unsigned long long)blockIdx.x * 256 + threadIdx.x; g * 16 < ch.n; g += (unsigned long long)gridDim.x * 256) {
+        const unsigned long long i0 = g * 16;
+        uint8_t b[16];
+        const uint32_t cnt = ch.n - i0 < 16 ? (uint32_t)(ch.n - i0) : 16u;
+#pragma unroll
+        for (uint32_t k = 0; k < 16; k++) {
+            uint16_t sy = k < cnt ? ch.sym[i0 + k] : (uint16_t)0;
+            b[k] = sy & 0x8000u ? w[sy & 0x7FFFu] : (uint8_t)sy;
+            if ((sy & 0x8000u) && c == 0) atomicOr(bad, 1u);  // nothing precedes the first chunk
+        }
+        uint8_t *dst = d_out + ch.out_off + i0;
+        if (cnt == 16 && (((uintptr_t)dst) & 15) == 0) {
+            uint4 v;
+            v.x = b[0] | (b[1] << 8) | (b[2] << 16) | ((uint32_t)b[3] << 24);
+            v.y = b[4] | (b[5] << 8) | (b[6] << 16) | ((uint32_t)b[7] << 24);
+            v.z = b[8] | (b[9] << 8) | (b[10] << 16) | ((uint32_t)b[11] << 24);
+            v.w = b[12] | (b[13] << 8) | (b[14] << 16) | ((uint32_t)b[15] << 24);
+            *reinterpret_cast<uint4 *>(dst) = v;
+        } else {
+            for (uint32_t k = 0; k < cnt; k++) dst[k] = b[k];
+        }
+    }
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t n) {
+        if (p) (void)hipFree(p), p = nullptr;
+        return hipMalloc(&p, n ? n : 16);
+    }
+};
+
+}  // namespace
+}  // namespace exg
+
+using namespace exg;
+
+static double st_now() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+#define ST_TRACE(...)                                   \
+    do {                                                \
+        if (getenv("EXG_TRACE")) fprintf(stderr, __VA_ARGS__); \
+    } while (0)
+
+#define ST_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            ::exg::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return EXG_E_HIP;                                                                     \
+        }                                                                                         \
+    } while (0)
+
+// d_comp: the file's compressed bytes on the device (16-byte aligned); the DEFLATE stream of the member starts at
+// comp_off and at most comp_size bytes may be read.  On success *d_out_p is a hipMalloc'd buffer (caller frees) holding
+// *produced inflated bytes (+ 64 bytes of zeroed slack) and *consumed the compressed bytes used (byte aligned after the
+// final block).  Synchronises `stream` several times (it returns sizes to the host).
+extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint64_t comp_size, uint64_t chunk_bytes,
+                                  void **d_out_p, uint64_t *produced, uint64_t *consumed, void *stream_v) {
+    hipStream_t stream = (hipStream_t)stream_v;
+    const uint8_t *d_comp = (const uint8_t *)d_comp_v;
+    if (!d_comp || !d_out_p || !produced || !consumed || ((uintptr_t)d_comp & 15)) {
+        set_error("exg_inflate_stream: bad arguments");
+        return EXG_E_INVALID_ARG;
+    }
+    *d_out_p = nullptr;
+    *produced = *consumed = 0;
+    if (chunk_bytes < 65536) chunk_bytes = 65536;
+    const double t_begin = st_now();
+    const uint64_t total_bits = comp_size * 8;
+    // ---- 1. block starts near the chunk boundaries
+    const uint32_t n_bound = (uint32_t)std::min<uint64_t>((comp_size + chunk_bytes - 1) / chunk_bytes, 1u << 20);
+    std::vector<uint64_t> starts;  // bit offsets of the chunk starts (sorted, unique); starts[0] = 0
+    starts.push_back(0);
+    if (n_bound > 1) {
+        std::vector<FindJob> fj(n_bound - 1);
+        for (uint32_t k = 1; k < n_bound; k++) {
+            fj[k - 1].comp_off = comp_off;
+            fj[k - 1].comp_size = comp_size;
+            fj[k - 1].from_bit = (uint64_t)k * chunk_bytes * 8;
+            fj[k - 1].to_bit = std::min<uint64_t>((uint64_t)(k + 1) * chunk_bytes * 8, total_bits);
+        }
+        DevBuf d_fj, d_found, d_scratch;
+        ST_HIP(d_fj.alloc(fj.size() * sizeof(FindJob)));
+        ST_HIP(d_found.alloc(fj.size() * 8));
+        ST_HIP(d_scratch.alloc(fj.size() * 1024 * 2));
+        ST_HIP(hipMemcpyAsync(d_fj.p, fj.data(), fj.size() * sizeof(FindJob), hipMemcpyHostToDevice, stream));
+        const uint32_t grid = (uint32_t)std::min<size_t>(fj.size(), 512);
+        hipLaunchKernelGGL(k_find_blocks, dim3(grid), dim3(64), 0, stream, d_comp, (const FindJob *)d_fj.p,
+                           (unsigned long long *)d_found.p, (uint16_t *)d_scratch.p, (uint32_t)fj.size());
+        ST_HIP(hipGetLastError());
+        std::vector<uint64_t> found(fj.size());
+        ST_HIP(hipMemcpyAsync(found.data(), d_found.p, found.size() * 8, hipMemcpyDeviceToHost, stream));
+        ST_HIP(hipStreamSynchronize(stream));
+        for (uint64_t f : found)
+            if (f != ~0ull && f > starts.back()) starts.push_back(f);
+        ST_TRACE("[exg] inflate stream: %u boundaries searched, %zu block starts found, %.1f ms\n", n_bound - 1, starts.size() - 1,
+                 (st_now() - t_begin) * 1e3);
+    }
+    // ---- 2 + 3. decode every candidate chunk, then walk the chain of chunks from bit 0: a chunk counts only if it
+    // starts exactly where the previous one ended.  A false block start is simply never reached (the chunk in front
+    // of it runs on to the next real boundary); if that boundary is not a candidate either, the piece from there to
+    // the next candidate is decoded in another round.
+    struct Piece {
+        InflateJobStatus st;
+        const uint16_t *sym;
+        uint64_t stop_bit;
+    };
+    std::map<uint64_t, Piece> decoded;
+    std::vector<std::unique_ptr<DevBuf>> sym_bufs;
+    // exact_cap != 0: one job whose output size is known; measure_only: decode without storing (its size is the answer)
+    auto run_jobs = [&](const std::vector<std::pair<uint64_t, uint64_t>> &spans, uint64_t cap_factor, uint64_t exact_cap,
+                        bool measure_only, InflateJobStatus *measured) -> int {
+        const uint32_t n = (uint32_t)spans.size();
+        std::vector<InflateJob> jobs(n);
+        std::vector<uint64_t> off(n + 1, 0);
+        for (uint32_t k = 0; k < n; k++) {
+            const uint64_t end_bit = spans[k].second ? spans[k].second : total_bits;
+            jobs[k].comp_off = comp_off;
+            jobs[k].comp_size = comp_size;
+            jobs[k].out_off = off[k];
+            jobs[k].out_cap = measure_only ? (comp_size - spans[k].first / 8) * 1032 + 65536 : exact_cap ? exact_cap : (end_bit - spans[k].first + 7) / 8 * cap_factor + 65536;
+            if (measure_only) continue;
+            jobs[k].start_bit = spans[k].first;
+            jobs[k].stop_bit = spans[k].second;
+            off[k + 1] = off[k] + ((jobs[k].out_cap + 15) & ~15ull);
+        }
+        sym_bufs.emplace_back(new DevBuf());
+        DevBuf &d_sym = *sym_bufs.back();
+        DevBuf d_jobs, d_st;
+        if (!measure_only) ST_HIP(d_sym.alloc(off[n] * 2 + 64));
+        ST_HIP(d_jobs.alloc(n * sizeof(InflateJob)));
+        ST_HIP(d_st.alloc(n * sizeof(InflateJobStatus)));
+        ST_HIP(hipMemcpyAsync(d_jobs.p, jobs.data(), n * sizeof(InflateJob), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(k_inflate_chunks, dim3(std::min<uint32_t>(n, 2048)), dim3(64), 0, stream, d_comp, (uint16_t *)d_sym.p,
+                           (const InflateJob *)d_jobs.p, (InflateJobStatus *)d_st.p, n);
+        ST_HIP(hipGetLastError());
+        std::vector<InflateJobStatus> st(n);
+        ST_HIP(hipMemcpyAsync(st.data(), d_st.p, n * sizeof(InflateJobStatus), hipMemcpyDeviceToHost, stream));
+        ST_HIP(hipStreamSynchronize(stream));
+        if (measure_only) {
+            *measured = st[0];
+            return EXG_OK;
+        }
+        for (uint32_t k = 0; k < n; k++) decoded[spans[k].first] = Piece{st[k], (const uint16_t *)d_sym.p + off[k], spans[k].second};
+        ST_TRACE("[exg] inflate stream: decoded %u piece(s), at %.1f ms\n", n, (st_now() - t_begin) * 1e3);
+        return EXG_OK;
+    };
+    {
+        std::vector<std::pair<uint64_t, uint64_t>> spans;
+        for (size_t k = 0; k < starts.size(); k++) spans.emplace_back(starts[k], k + 1 < starts.size() ? starts[k + 1] : 0);
+        int rc = run_jobs(spans, 8, 0, false, nullptr);
+        if (rc) return rc;
+    }
+    std::vector<ChunkOut> co;
+    uint64_t total = 0, end_bit = 0;
+    {
+        uint64_t e = 0;
+        for (int rounds = 0;; ) {
+            auto it = decoded.find(e);
+            if (it == decoded.end() || it->second.st.code == 4) {
+                // nothing decoded from this (real) boundary yet, or its output did not fit: one more job.  An output that
+                // did not fit is first MEASURED (decoded without storing), then decoded into a buffer of that size: growing
+                // the buffer blindly would re-decode again and again — and on a corrupt stream for minutes.
+                // every false block start can break the chain once; more breaks than candidates = garbage after a corruption
+                if (++rounds > (int)starts.size() + 8) {
+                    set_error("corrupt deflate stream (the chunk chain does not settle after bit %llu)", (unsigned long long)e);
+                    return EXG_E_PARSE;
+                }
+                auto nxt = std::upper_bound(starts.begin(), starts.end(), e);
+                const std::vector<std::pair<uint64_t, uint64_t>> span = {{e, nxt == starts.end() ? 0 : *nxt}};
+                ST_TRACE("[exg] inflate stream: chain stands at bit %llu (%s)\n", (unsigned long long)e,
+                         it == decoded.end() ? "no piece starts here" : "output did not fit");
+                uint64_t exact = 0;
+                if (it != decoded.end()) {
+                    InflateJobStatus m;
+                    int rc = run_jobs(span, 0, 0, true, &m);
+                    if (rc) return rc;
+                    if (m.code) {
+                        set_error("corrupt deflate stream (code %u after bit %llu)", m.code, (unsigned long long)e);
+                        return EXG_E_PARSE;
+                    }
+                    exact = m.produced + 64;
+                }
+                int rc = run_jobs(span, 8, exact, false, nullptr);
+                if (rc) return rc;
+                if (exact && decoded[e].st.code == 4) {
+                    set_error("exg_inflate_stream: a chunk produced more than its measured size");
+                    return EXG_E_PARSE;
+                }
+                continue;
+            }
+            const Piece &pc = it->second;
+            if (pc.st.code) {
+                set_error("corrupt deflate stream (code %u at bit %llu)", pc.st.code, (unsigned long long)e);
+                return EXG_E_PARSE;
+            }
+            co.push_back(ChunkOut{pc.sym, pc.st.produced, total});
+            total += pc.st.produced;
+            end_bit = pc.st.end_bit;
+            if (pc.st.final_block) break;
+            if (pc.st.end_bit <= e) {
+                set_error("exg_inflate_stream: no progress at bit %llu", (unsigned long long)e);
+                return EXG_E_PARSE;
+            }
+            e = pc.st.end_bit;
+        }
+    }
+    // ---- 4 + 5. windows, then bytes
+    const uint32_t n = (uint32_t)co.size();
+    DevBuf d_co, d_win, d_bad;
+    void *d_out = nullptr;
+    ST_HIP(d_co.alloc(n * sizeof(ChunkOut)));
+    ST_HIP(d_win.alloc((size_t)n * 32768));
+    ST_HIP(d_bad.alloc(4));
+    ST_HIP(hipMalloc(&d_out, total + 64));
+    ST_HIP(hipMemcpyAsync(d_co.p, co.data(), n * sizeof(ChunkOut), hipMemcpyHostToDevice, stream));
+    ST_HIP(hipMemsetAsync(d_win.p, 0, 32768, stream));
+    ST_HIP(hipMemsetAsync(d_bad.p, 0, 4, stream));
+    ST_HIP(hipMemsetAsync((char *)d_out + total, 0, 64, stream));
+    hipLaunchKernelGGL(k_windows, dim3(1), dim3(1024), 0, stream, (const ChunkOut *)d_co.p, (uint8_t *)d_win.p, n, (uint32_t *)d_bad.p);
+    hipLaunchKernelGGL(k_resolve, dim3(256, n), dim3(256), 0, stream, (const ChunkOut *)d_co.p, (const uint8_t *)d_win.p,
+                       (uint8_t *)d_out, n, (uint32_t *)d_bad.p);
+    uint32_t bad = 0;
+    hipError_t he = hipGetLastError();
+    if (he == hipSuccess) he = hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(stream);
+    if (he != hipSuccess || bad) {
+        (void)hipFree(d_out);
+        if (bad)
+            set_error("corrupt deflate stream (distance before the start of the output)");
+        else
+            set_error("inflate stream kernels failed: %s", hipGetErrorString(he));
+        return bad ? EXG_E_PARSE : EXG_E_HIP;
+    }
+    ST_TRACE("[exg] inflate stream: %u chunks in the chain, %llu bytes, %.1f ms in all\n", n, (unsigned long long)total,
+             (st_now() - t_begin) * 1e3);
+    *d_out_p = d_out;
+    *produced = total;
+    *consumed = (end_bit + 7) / 8;
+    return EXG_OK;
+}

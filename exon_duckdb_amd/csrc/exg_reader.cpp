@@ -150,6 +150,24 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
         int rc = exg_gzip_index(comp, n, start, members.data(), members.size(), &k, &total, &open_ended);
         if (rc) return fail(r, rc, std::string(exg_last_error_message()) + " in '" + path + "'");
         if (k == 0) break;
+        // one big member of unknown size (what gzip / pigz write): per-member parallelism would put the whole file
+        // on ONE wavefront — decode it in chunks instead (exg_inflate_stream.hip)
+        static const uint64_t stream_min = getenv("EXG_STREAM_MIN_BYTES") ? strtoull(getenv("EXG_STREAM_MIN_BYTES"), nullptr, 10) : (4ull << 20);
+        if (k == 1 && open_ended && !d_out && members[0].comp_size >= stream_min && !getenv("EXG_NO_STREAM_INFLATE")) {
+            // ~2048 chunks (4 per wavefront slot of the chip), at least 128 KiB each (a block is 20-60 KB of input)
+            uint64_t chunk = std::max<uint64_t>(128u << 10, (members[0].comp_size / 2048 + 65535) & ~65535ull);
+            if (getenv("EXG_STREAM_CHUNK_BYTES")) chunk = strtoull(getenv("EXG_STREAM_CHUNK_BYTES"), nullptr, 10);
+            uint64_t produced = 0, consumed = 0;
+            void *d_big = nullptr;
+            rc = exg_inflate_stream(d_comp, members[0].comp_off, members[0].comp_size, chunk, &d_big, &produced, &consumed, r->stream);
+            if (rc) return fail(r, rc, std::string(exg_last_error_message()) + " in '" + path + "'");
+            d_out = d_big;
+            d_out_cap = produced + 64;
+            produced_total = produced;
+            out_cap_total = produced;
+            start = members[0].comp_off + consumed + 8;
+            continue;
+        }
         out_cap_total = total;
         if (out_cap_total + 64 > d_out_cap) {  // grow the output (members of earlier rounds are kept)
             void *nd = nullptr;

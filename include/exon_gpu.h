@@ -242,6 +242,14 @@ int exg_gzip_index(const uint8_t *data, uint64_t n, uint64_t start, exg_inflate_
 int exg_inflate_members(const void *d_comp, void *d_out, const exg_inflate_member *d_members,
                         exg_inflate_status *d_status, uint32_t n_members, void *stream);
 
+/* ONE big DEFLATE stream (a single-member gzip file) decoded by many wavefronts: block starts are searched near
+ * every chunk_bytes of compressed input, the chunks are decoded concurrently with an unknown window and stitched
+ * (pugz / rapidgzip method).  d_comp: the compressed bytes on the device, 16-byte aligned; the stream starts at
+ * comp_off, at most comp_size bytes are read.  On success *d_out is a hipMalloc'd buffer the caller hipFree()s
+ * (*produced bytes + 64 zeroed), *consumed the compressed bytes used.  Synchronises the stream. */
+int exg_inflate_stream(const void *d_comp, uint64_t comp_off, uint64_t comp_size, uint64_t chunk_bytes, void **d_out,
+                       uint64_t *produced, uint64_t *consumed, void *stream);
+
 /* Deterministic synthetic inputs, generated on the device so the bench
  * needs no PCIe traffic: writes file bytes [file_offset, file_offset+n_bytes) to d_out. */
 #define EXG_SYNTH_FASTQ_SEED 0xE0A5EED0001ull

@@ -1,0 +1,115 @@
+"""One big DEFLATE stream decoded in chunks (exg_inflate_stream: block finder, 16-bit-symbol chunk decode, window
+propagation, marker resolution) against zlib: FASTQ / VCF / text / random-ish data at several compression levels
+and chunk sizes, streams with stored and fixed blocks, truncated and corrupted streams, and the same files through
+the reader (`read_fastq('x.fastq.gz')` with a single gzip member)."""
+import ctypes as C
+import gzip
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def stream_inflate(lib, raw_deflate: bytes, chunk_bytes, pad_front=0):
+    import torch
+    from exon_duckdb_amd import device
+    lib.exg_inflate_stream.restype = C.c_int
+    lib.exg_inflate_stream.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p),
+                                       C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p]
+    data = b"\xAA" * pad_front + raw_deflate + b"\x55" * 8   # a header in front, a trailer behind (like gzip)
+    d_comp = device.upload(data)
+    out = C.c_void_p()
+    produced, consumed = C.c_uint64(0), C.c_uint64(0)
+    rc = lib.exg_inflate_stream(C.c_void_p(d_comp.data_ptr()), pad_front, len(data) - pad_front, chunk_bytes, C.byref(out),
+                                C.byref(produced), C.byref(consumed), device.stream_ptr())
+    if rc != 0:
+        return rc, None, 0
+    n = produced.value
+    host = (C.c_uint8 * max(n, 1))()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert hip.hipMemcpy(host, out, n, 2) == 0
+    hip.hipFree.argtypes = [C.c_void_p]
+    hip.hipFree(out)
+    return 0, bytes(host)[:n], consumed.value
+
+
+def deflate(payload, level=6, strategy=zlib.Z_DEFAULT_STRATEGY):
+    co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+    return co.compress(payload) + co.flush()
+
+
+def payloads(oracle):
+    rng = np.random.default_rng(12)
+    fq = bytes(oracle.synth_fastq(332 * 60000))                         # 20 MB of FASTQ-150
+    vcf = bytes(oracle.synth_vcf(150000))
+    text = (b"the quick brown fox jumps over the lazy dog; " * 7 + b"\n") * 40000
+    words = np.array([b"alpha", b"beta", b"gamma", b"delta", b"ACGT", b"\t", b"\n", b"0.125", b"PASS", b"rs"], dtype=object)
+    mix = b"".join(words[rng.integers(0, len(words), 2_000_000)])
+    noisy = bytes(rng.integers(0, 256, 3_000_000, dtype=np.uint8)) + fq[:3_000_000]   # stored blocks, then dynamic
+    return {"fastq": fq, "vcf": vcf, "text": text, "mix": mix, "noisy": noisy}
+
+
+@pytest.fixture(scope="module")
+def data(oracle):
+    return payloads(oracle)
+
+
+@pytest.mark.parametrize("name", ["fastq", "vcf", "text", "mix", "noisy"])
+@pytest.mark.parametrize("level", [1, 6, 9])
+def test_stream_against_zlib(gpu, data, name, level):
+    payload = data[name]
+    comp = deflate(payload, level)
+    for chunk, pad in ((1 << 20, 10), (200_000, 13)):
+        rc, got, consumed = stream_inflate(gpu, comp, chunk, pad_front=pad)
+        assert rc == 0, gpu.exg_last_error_message()
+        assert got == payload, (name, level, chunk, len(got), len(payload))
+        assert consumed == len(comp)
+
+
+def test_fixed_huffman_and_tiny_streams(gpu):
+    for payload in (b"", b"a", b"hello hello hello hello", bytes(range(256)) * 300):
+        comp = deflate(payload, 6, zlib.Z_FIXED)
+        rc, got, consumed = stream_inflate(gpu, comp, 65536)
+        assert rc == 0 and got == payload and consumed == len(comp)
+
+
+def test_corrupt_and_truncated_streams_fail(gpu, data):
+    comp = bytearray(deflate(data["fastq"][:4_000_000], 6))
+    rc, _, _ = stream_inflate(gpu, bytes(comp[: len(comp) // 2]), 1 << 18)        # truncated: no final block
+    assert rc != 0
+    comp[len(comp) // 3] ^= 0x5A                                                    # a flipped byte in the middle
+    rc, got, _ = stream_inflate(gpu, bytes(comp), 1 << 18)
+    assert rc != 0 or got != data["fastq"][:4_000_000]                              # never silently "fine"
+
+
+def test_reader_single_member_gzip(gpu, oracle, tmp_path, monkeypatch):
+    """read_fastq on a plain `gzip` file (one member): count, rows, and the same answer as the per-member path."""
+    from exon_duckdb_amd import table_function
+    raw = bytes(oracle.synth_fastq_ragged(40000))
+    p = tmp_path / "single.fastq.gz"
+    p.write_bytes(gzip.compress(raw, 6, mtime=0))
+    assert os.path.getsize(p) > (1 << 20)
+    monkeypatch.setenv("EXG_STREAM_MIN_BYTES", str(1 << 16))
+    monkeypatch.setenv("EXG_STREAM_CHUNK_BYTES", str(1 << 17))
+    con = table_function.connect()
+    rel = con.table_function("read_fastq", str(p))
+    exp = oracle.fastq_parse(raw, want_string_t=False)
+    want = list(zip(*[exp.columns[k].to_list() for k in ("name", "description", "sequence", "quality_scores")]))
+    assert rel.count() == len(want) == 40000
+    assert rel.fetchall() == want
+    monkeypatch.setenv("EXG_NO_STREAM_INFLATE", "1")
+    assert con.table_function("read_fastq", str(p)).fetchall(limit=2000) == want[:2000]   # one wavefront: slow but equal
+
+
+def test_concatenated_big_members(gpu, oracle, tmp_path, monkeypatch):
+    from exon_duckdb_amd import table_function
+    raw = bytes(oracle.synth_fastq(332 * 30000))
+    p = tmp_path / "two.fastq.gz"
+    p.write_bytes(gzip.compress(raw[: 332 * 20000], 6, mtime=0) + gzip.compress(raw[332 * 20000:], 6, mtime=0))
+    monkeypatch.setenv("EXG_STREAM_MIN_BYTES", str(1 << 16))
+    con = table_function.connect()
+    assert con.table_function("read_fastq", str(p)).count() == 30000
