@@ -91,9 +91,11 @@ __global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ 
                 // follows it must again be a block that decodes (its header + the first kProbeSymbols symbols).
                 InflateJob jb;
                 jb.comp_off = fj.comp_off;
-                jb.comp_size = fj.comp_size;
+                // a block longer than 512 KiB of input is not accepted as a chunk start: garbage behind a false header
+                // can run for millions of symbols before it meets an end-of-block code (seen: 4.5 s in the finder)
+                jb.comp_size = std::min<unsigned long long>(fj.comp_size, ((base + l) >> 3) + (512u << 10));
                 jb.out_off = 0;
-                jb.out_cap = 1ull << 26;  // nothing is stored: the bound only stops a runaway decode
+                jb.out_cap = 1ull << 24;  // nothing is stored: the bound only stops a runaway decode
                 jb.start_bit = base + l;
                 jb.stop_bit = base + l + 1;
                 inflate_job<true>(s, d_comp, (uint16_t *)nullptr, jb, &s_st);
@@ -103,6 +105,7 @@ __global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ 
                 __syncthreads();
                 if (final1) code = 1;
                 if (code == 0) {
+                    jb.comp_size = fj.comp_size;
                     jb.out_cap = kProbeSymbols;
                     jb.start_bit = end1;
                     jb.stop_bit = end1 + 1;

@@ -2,7 +2,7 @@
 import gzip, os, struct, sys, time, zlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from exon_duckdb_amd import device, table_function
-n_rec = 400_000
+n_rec = int(os.environ.get("GZ_RECORDS", "400000"))
 raw = device.synth_fastq(332 * n_rec)[: 332 * n_rec].cpu().numpy().tobytes()
 single = "/tmp/exg_single.fastq.gz"
 open(single, "wb").write(gzip.compress(raw, 6, mtime=0))
