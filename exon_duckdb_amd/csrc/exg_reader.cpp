@@ -39,7 +39,7 @@ PinnedBlock::~PinnedBlock() {
     if (mapped)
         munmap(p, mapped);
     else if (pooled)
-        global_pool()->give((char *)p, n);
+        global_pool()->give((char *)p, cap);
     else
         (void)hipHostFree(p);
 }
@@ -211,14 +211,22 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
         }
     }
     // host copy of the inflated bytes: this is what the string_t payload pointers address
+    // (the copy itself is made by the first batch that hands out columns: COUNT(*) never needs it)
     auto out_blk = std::make_shared<PinnedBlock>();
     out_blk->n = produced_total;
-    hipError_t he = hipHostMalloc(&out_blk->p, produced_total + 64, hipHostMallocDefault);
-    if (he != hipSuccess) return fail(r, EXG_E_HIP, std::string("hipHostMalloc failed: ") + hipGetErrorString(he));
-    if (produced_total) RD_HIP(r, hipMemcpyAsync(out_blk->p, d_out, produced_total, hipMemcpyDeviceToHost, r->stream));
+    size_t blk_cap = produced_total + 64;
+    out_blk->p = global_pool()->take(&blk_cap);
+    if (!out_blk->p) return fail(r, EXG_E_HIP, "out of pinned host memory for the inflated bytes");
+    out_blk->cap = blk_cap;
+    out_blk->pooled = true;
     if (d_out) RD_HIP(r, hipMemsetAsync((char *)d_out + produced_total, 0, 64, r->stream));
     RD_HIP(r, hipStreamSynchronize(r->stream));
-    memset((char *)out_blk->p + produced_total, 0, 64);
+    r->gz_host_pending = true;
+    if (r->format == EXG_FMT_VCF) {  // the header is parsed on the host right away
+        RD_HIP(r, hipMemcpyAsync(out_blk->p, d_out, produced_total + 64, hipMemcpyDeviceToHost, r->stream));
+        RD_HIP(r, hipStreamSynchronize(r->stream));
+        r->gz_host_pending = false;
+    }
     blk = out_blk;
     r->d_file = d_out;
     r->d_file_bytes = produced_total;
@@ -359,12 +367,13 @@ int upload_range(exg_reader *r, uint64_t off, uint64_t n, int slot, hipStream_t 
     if (stg.n < padded) {
         RD_HIP(r, hipStreamSynchronize(r->stream));
         RD_HIP(r, hipStreamSynchronize(r->up_stream));
-        if (stg.p) global_pool()->give((char *)stg.p, stg.n), stg.p = nullptr, stg.n = 0;
+        if (stg.p) global_pool()->give((char *)stg.p, stg.cap), stg.p = nullptr, stg.n = 0;
         double t0 = now_s();
         size_t want = (size_t)std::max<uint64_t>(padded, std::min<uint64_t>(r->d_in_cap, r->file->n + 16)) + 64;
         stg.p = global_pool()->take(&want);
         if (!stg.p) return fail(r, EXG_E_HIP, "out of pinned host memory");
         stg.n = want;
+        stg.cap = want;
         stg.pooled = true;
         TRACE("pinned staging", t0);
     }
@@ -434,6 +443,11 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         uint64_t lead = 0;
         uint64_t batch_end = r->file_pos + n;  // file offset one past the bytes of this batch
         if (r->d_file) {
+            if (r->gz_host_pending && !count_only) {
+                // host copy of the inflated bytes: this is what the string_t payload pointers address
+                RD_HIP(r, hipMemcpyAsync(r->file->p, r->d_file, r->d_file_bytes + 64, hipMemcpyDeviceToHost, r->stream));
+                r->gz_host_pending = false;
+            }
             lead = r->file_pos & 15;
             d_input = (const uint8_t *)r->d_file + (r->file_pos - lead);
             h -= lead;

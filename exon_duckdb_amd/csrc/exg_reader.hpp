@@ -15,7 +15,8 @@ struct PinnedBlock {  // host memory: pinned (hipHostMalloc) or a read-only file
     void *p = nullptr;
     size_t n = 0;
     size_t mapped = 0;  // != 0: p is an mmap of that many bytes
-    bool pooled = false;  // p came from the BlockPool and goes back to it
+    bool pooled = false;  // p came from the BlockPool (block size `cap`) and goes back to it
+    size_t cap = 0;
     ~PinnedBlock();
 };
 
@@ -220,6 +221,7 @@ struct exg_reader {
     size_t host_hint = 0;  // pinned bytes the previous batch's host vectors needed
     std::vector<std::pair<void **, size_t>> dev_allocs;  // pooled device buffers of this reader (slot, bytes)
     int dev_alloc(void **slot, size_t bytes);
+    bool gz_host_pending = false;  // gzip: the host copy of the inflated bytes (the string_t payload) is not made yet
     bool worst_case_rows = false;
     // exg_open_args.filters: postfix program + constants in device memory, a row map and one column of scratch
     bool has_filter = false;
