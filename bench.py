@@ -43,7 +43,7 @@ def cpu_baseline(seconds_target=12.0):
     # upper bound for a CPU build that shards byte ranges over every host core (SURVEY §8 D5 ii): the same loop
     # on all cores at once, each over the whole sample
     cores = os.cpu_count() or 1
-    per_thread = max(1, int(reps * 0.5))
+    per_thread = max(1, min(4, 512 // cores))  # ~10 s of wall clock whatever the core count
     t1 = time.perf_counter()
     total_mt = pyoracle.fastq_scan_baseline_mt(data, cores, per_thread)
     dt_mt = time.perf_counter() - t1
