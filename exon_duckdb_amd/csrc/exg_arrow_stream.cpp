@@ -791,6 +791,67 @@ ReaderResult result_error(const std::string &msg) {
 
 }  // namespace
 
+// ---- host-only introspection (no device is touched): what the CPU tests check ---------------------------------------
+// The postfix program a `filters` text compiles to, e.g.  "name = 'a' | pos >= 5 | AND".  Columns are those of the
+// format's schema (VCF: the flat ones; nested columns are refused like in new_reader).  Returns 0, or -1 with the
+// parser's message in `out`.
+extern "C" int exg_filter_explain(const char *file_format, const char *filters, char *out, size_t cap) {
+    std::vector<exg_rd::FilterColumn> cols;
+    const std::string fmt = file_format ? file_format : "";
+    if (fmt == "fastq")
+        cols = {{"name", 'u'}, {"description", 'u'}, {"sequence", 'u'}, {"quality_scores", 'u'}};
+    else if (fmt == "fasta")
+        cols = {{"id", 'u'}, {"description", 'u'}, {"sequence", 'u'}};
+    else
+        cols = {{"chrom", 'u'}, {"pos", 'l'}, {"id", 'x'}, {"ref", 'u'}, {"alt", 'x'}, {"qual", 'f'}, {"filter", 'x'}, {"info", 'x'}, {"formats", 'x'}};
+    const std::string text = filters ? filters : "";
+    exg_rd::FilterParser fp(text, cols);
+    std::string res;
+    int rc = 0;
+    if (!fp.parse()) {
+        res = fp.err;
+        rc = -1;
+    } else {
+        static const char *cmp[] = {"=", "!=", "<", "<=", ">", ">="};
+        for (uint32_t k = 0; k < fp.prog.n_ops; k++) {
+            const ea::FilterOp &op = fp.prog.ops[k];
+            if (k) res += " | ";
+            if (op.op == ea::kOpAnd) res += "AND";
+            else if (op.op == ea::kOpOr) res += "OR";
+            else if (op.op == ea::kOpIsNull) res += cols[op.col].name + " isnull";
+            else if (op.op == ea::kOpIsNotNull) res += cols[op.col].name + " notnull";
+            else {
+                res += cols[op.col].name + " " + cmp[op.cmp] + " ";
+                if (op.lit == ea::kLitStr) res += "'" + fp.consts.substr(op.str_off, op.str_len) + "'";
+                else if (op.lit == ea::kLitInt) res += std::to_string(op.i);
+                else {
+                    char b[64];
+                    snprintf(b, sizeof b, "%g", op.f);
+                    res += b;
+                }
+            }
+        }
+    }
+    if (out && cap) snprintf(out, cap, "%s", res.c_str());
+    return rc;
+}
+
+// The INFO / FORMAT keys a VCF header declares, as "INFO DP:i AF:[f] DB:b ANN:u | FORMAT GT:u AD:[i]".
+extern "C" int exg_vcf_header_explain(const char *header, size_t n, char *out, size_t cap) {
+    std::vector<KeyDef> info, format;
+    parse_vcf_header(header, n, &info, &format);
+    auto one = [](const KeyDef &k) {
+        const char *t = k.type == ea::kVtInt ? "i" : k.type == ea::kVtFloat ? "f" : k.type == ea::kVtFlag ? "b" : "u";
+        return k.id + ":" + (k.is_list ? std::string("[") + t + "]" : std::string(t));
+    };
+    std::string res = "INFO";
+    for (auto &k : info) res += " " + one(k);
+    res += " | FORMAT";
+    for (auto &k : format) res += " " + one(k);
+    if (out && cap) snprintf(out, cap, "%s", res.c_str());
+    return 0;
+}
+
 extern "C" ReaderResult new_reader(ArrowArrayStream *stream_ptr, const char *uri, uintptr_t batch_size, const char *compression,
                                    const char *file_format, const char *filters) {
     if (!stream_ptr || !uri || !file_format) return result_error("new_reader: null argument");

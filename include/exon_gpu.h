@@ -366,6 +366,11 @@ typedef struct ReaderResult {
  *   filters:     NULL / "" or the predicate text FilterToString renders (module.cpp:158-214):
  *                <column> (= | != | <> | < | <= | > | >=) <literal>, <column> IS [NOT] NULL, AND, OR
  *                with SQL precedence; it is applied as `SELECT * FROM exon_table WHERE <filters>` (:125-141). */
+/* Host-only helpers (no device needed): the postfix program a `filters` text compiles to / the typed keys a VCF
+ * header declares, as text.  Used by the CPU tests of the host logic; 0 on success, -1 + message on a parse error. */
+int exg_filter_explain(const char *file_format, const char *filters, char *out, size_t cap);
+int exg_vcf_header_explain(const char *header, size_t n, char *out, size_t cap);
+
 ReaderResult new_reader(struct ArrowArrayStream *stream_ptr, const char *uri, uintptr_t batch_size,
                         const char *compression, const char *file_format, const char *filters);
 

@@ -1,0 +1,90 @@
+"""CPU checks of the host logic behind new_reader / exg_open: the `filters` grammar (what the reference's FilterToString
+renders, exon/src/exon/arrow_table_function/module.cpp:158-214, evaluated by DataFusion with SQL precedence) and the
+VCF header -> typed INFO / FORMAT keys mapping.  No device is touched."""
+import ctypes as C
+
+import pytest
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from exon_duckdb_amd import load_library
+    l = load_library()
+    l.exg_filter_explain.restype = C.c_int
+    l.exg_filter_explain.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
+    l.exg_vcf_header_explain.restype = C.c_int
+    l.exg_vcf_header_explain.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    return l
+
+
+def explain(lib, fmt, text):
+    buf = C.create_string_buffer(2048)
+    rc = lib.exg_filter_explain(fmt.encode(), text.encode(), buf, 2048)
+    return rc, buf.value.decode()
+
+
+def test_filter_to_string_forms(lib):
+    # FilterToString output for a ConstantFilter / IS NULL / IS NOT NULL (module.cpp:162-199)
+    assert explain(lib, "fasta", "id='a'") == (0, "id = 'a'")
+    assert explain(lib, "fastq", "description IS NULL") == (0, "description isnull")
+    assert explain(lib, "fastq", "description IS NOT NULL") == (0, "description notnull")
+    assert explain(lib, "vcf", "pos>=1000") == (0, "pos >= 1000")
+    assert explain(lib, "vcf", "qual>30.5") == (0, "qual > 30.5")
+    assert explain(lib, "vcf", "pos!=7") == (0, "pos != 7")
+
+
+def test_and_binds_tighter_than_or_without_parentheses(lib):
+    # the reference joins with " AND " / " OR " and never parenthesises (module.cpp:173-189): SQL precedence decides
+    assert explain(lib, "fastq", "name='a' OR name='b' AND sequence<'C'") == \
+        (0, "name = 'a' | name = 'b' | sequence < 'C' | AND | OR")
+    assert explain(lib, "fastq", "name='a' AND name='b' OR sequence<'C'") == \
+        (0, "name = 'a' | name = 'b' | AND | sequence < 'C' | OR")
+    assert explain(lib, "fastq", "(name='a' OR name='b') AND sequence<'C'")[1].endswith("OR | sequence < 'C' | AND")
+
+
+def test_literals_and_names(lib):
+    assert explain(lib, "fastq", "name='it''s'") == (0, "name = 'it's'")          # Value::ToSQLString doubles quotes
+    assert explain(lib, "fastq", 'NAME = \'x\'') == (0, "name = 'x'")             # column names are case-insensitive
+    assert explain(lib, "fastq", '"name"<>\'x\'') == (0, "name != 'x'")
+    assert explain(lib, "vcf", "qual<=1e-3")[1] == "qual <= 0.001"
+    assert explain(lib, "vcf", "pos>-5") == (0, "pos > -5")
+
+
+@pytest.mark.parametrize("fmt,text", [
+    ("fastq", "nope='x'"), ("fastq", "name="), ("fastq", "name='x"), ("fastq", "name='x' AND"), ("fastq", "name 'x'"),
+    ("vcf", "alt='A'"), ("vcf", "info IS NULL"), ("vcf", "pos='a'"), ("fastq", "name=5"), ("fastq", "(name='a'"),
+])
+def test_filter_errors(lib, fmt, text):
+    rc, msg = explain(lib, fmt, text)
+    assert rc == -1 and msg
+
+
+def test_vcf_header_keys(lib):
+    hdr = (b"##fileformat=VCFv4.2\n"
+           b"##INFO=<ID=DP,Number=1,Type=Integer,Description=\"d\">\n"
+           b"##INFO=<ID=AF,Number=A,Type=Float,Description=\"with, comma and \\\"quotes\\\"\">\n"
+           b"##INFO=<ID=DB,Number=0,Type=Flag,Description=\"f\">\n"
+           b"##INFO=<ID=ANN,Number=.,Type=String,Description=\"s\">\n"
+           b"##INFO=<ID=DP,Number=1,Type=Float,Description=\"second definition ignored\">\n"
+           b"##FILTER=<ID=q10,Description=\"x\">\n"
+           b"##FORMAT=<ID=GT,Number=1,Type=String,Description=\"g\">\r\n"
+           b"##FORMAT=<ID=AD,Number=R,Type=Integer,Description=\"r\">\n"
+           b"##FORMAT=<ID=C,Number=1,Type=Character,Description=\"c\">\n"
+           b"#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\n"
+           b"1\t5\t.\tA\tC\t.\t.\tDP=1\n")
+    buf = C.create_string_buffer(2048)
+    assert lib.exg_vcf_header_explain(hdr, len(hdr), buf, 2048) == 0
+    assert buf.value.decode() == "INFO DP:i AF:[f] DB:b ANN:[u] | FORMAT GT:u AD:[i] C:u"
+
+
+def test_vcf_header_keys_match_the_oracle(lib, oracle, golden_dir):
+    import os
+    for name in ("vcf/index.vcf", "vcf/vcf_file.vcf", "vcf/vcf_meta_meta.vcf"):
+        data = open(os.path.join(golden_dir, name), "rb").read()
+        info, fmt = oracle.vcf_header_keys(data)
+        t = {"Integer": "i", "Float": "f", "Flag": "b", "String": "u"}
+        want = "INFO" + "".join(f" {k}:{'[' + t[ty] + ']' if ls else t[ty]}" for k, ty, ls in info) + " | FORMAT" + \
+               "".join(f" {k}:{'[' + t[ty] + ']' if ls else t[ty]}" for k, ty, ls in fmt)
+        buf = C.create_string_buffer(8192)
+        assert lib.exg_vcf_header_explain(data, len(data), buf, 8192) == 0
+        assert buf.value.decode() == want, name
