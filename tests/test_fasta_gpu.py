@@ -165,3 +165,54 @@ def test_shards_are_refused(gpu, oracle):
     scan = device.FastaScan(len(data))
     with pytest.raises(ExgError):
         scan.launch(d_in, flags=abi.EXG_F_BOF)          # not at EOF: a record could be cut
+
+
+# ---- features placed exactly on the boundaries of the tiled implementation (16 B chunks, 1 KiB rows, 16 KiB tiles) ----
+
+def _pad_to(buf: bytearray, target: int, line=60):
+    """append sequence lines until len(buf) == target (the last line is cut to fit, still newline-terminated)"""
+    while len(buf) < target:
+        room = target - len(buf)
+        if room == 1:
+            buf += b"\n"           # an empty line
+            break
+        n = min(line, room - 1)
+        buf += b"ACGT" * (n // 4) + b"A" * (n % 4) + b"\n"
+    assert len(buf) == target
+    return buf
+
+
+@pytest.mark.parametrize("boundary", [16, 1024, 4096, 16384, 32768])
+@pytest.mark.parametrize("shift", [-2, -1, 0, 1])
+def test_features_on_tile_boundaries(gpu, oracle, boundary, shift):
+    # a definition line whose '>' sits at boundary + shift: the newline in front of it, the '>' and the line body
+    # fall on different sides of a chunk / row / tile edge
+    buf = bytearray(b">f r\n")
+    _pad_to(buf, boundary + shift)
+    buf += b">second some description\r\nACGTACGT\r\nTT\n>third\nGG"
+    check(oracle, bytes(buf))
+    # the same with the definition line itself running across the boundary
+    buf = bytearray(b">f\n")
+    _pad_to(buf, max(boundary + shift - 10, len(buf)))
+    buf += b">a_long_identifier_that_crosses description text\nACGT\n"
+    check(oracle, bytes(buf))
+
+
+def test_tiles_without_a_newline(gpu, oracle):
+    # single-line sequences far longer than a tile: dozens of tiles have no line start at all, in both states
+    # (inside a sequence line, and inside a 40 KB definition line)
+    rng = np.random.default_rng(3)
+    seq = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), 200_000))
+    long_def = b">id " + b"x" * 40_000
+    data = b">one\n" + seq + b"\n" + long_def + b"\n" + seq[:70_000] + b"\r\n>three d\n" + seq[:20] + b"\n"
+    res = check(oracle, data)
+    assert res.n_records == 3
+
+
+def test_cr_and_lf_split_by_boundaries(gpu, oracle):
+    for boundary in (64, 1024, 16384, 32768):
+        buf = bytearray(b">r\n")
+        _pad_to(buf, boundary - 20)
+        buf += b"ACGTACGTACGTACGTACG\r\nACGT\r\n>x\r\nAA\r"      # "\r" is the last byte of the chunk / row / tile, "\n" the first of the next
+        assert buf[boundary - 1:boundary + 1] == b"\r\n"
+        check(oracle, bytes(buf))
