@@ -171,7 +171,11 @@ struct StreamState {
     uint64_t batch_row = 0;
     std::string last_error;
     size_t host_hint = 0;  // pinned bytes the previous batch needed
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copy_ev = nullptr;
     ~StreamState() {
+        if (copy_ev) (void)hipEventDestroy(copy_ev);
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
         for (void *p : {d_consts, d_prog, d_info_names, d_format_names})
             if (p) (void)hipFree(p);
         arena.reset();
@@ -212,10 +216,16 @@ struct Emit {
         }
         return v;
     }
+    // copies back run on their own stream, behind an event on the kernels' stream: the next column's scans and copies
+    // on the device overlap with this column's bytes crossing PCIe
     const uint8_t *to_host(const void *d, size_t bytes) {
         void *h = halloc(bytes);
-        if (h && bytes && hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s) != hipSuccess && !rc)
-            rc = fail(r, EXG_E_HIP, "D2H copy failed in the Arrow emitter");
+        if (h && bytes) {
+            hipError_t e = hipEventRecord(st->copy_ev, s);
+            if (e == hipSuccess) e = hipStreamWaitEvent(st->copy_stream, st->copy_ev, 0);
+            if (e == hipSuccess) e = hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, st->copy_stream);
+            if (e != hipSuccess && !rc) rc = fail(r, EXG_E_HIP, "D2H copy failed in the Arrow emitter");
+        }
         return (const uint8_t *)h;
     }
     static size_t bitmap_bytes(uint64_t m) { return (size_t)((m + 63) / 64) * 8; }
@@ -435,7 +445,15 @@ int arrow_emit(exg_reader *r, const ScanCtx &ctx) {
         if ((st->arena.base = (char *)dev_pool()->take(r->device, cap))) st->arena.cap = cap;
     }
     EM_TRACE("arena");
+    if (!st->copy_stream) {
+        EM_HIP(hipStreamCreateWithFlags(&st->copy_stream, hipStreamNonBlocking));
+        EM_HIP(hipEventCreateWithFlags(&st->copy_ev, hipEventDisableTiming));
+    }
     auto batch = std::make_shared<ABatch>();
+    struct CopyDrain {  // whatever way this function is left, no copy may still be writing into the batch's blocks
+        hipStream_t cs;
+        ~CopyDrain() { (void)hipStreamSynchronize(cs); }
+    } drain{st->copy_stream};
     batch->host.reserve(st->host_hint);
     Emit em;
     em.r = r;
@@ -577,9 +595,10 @@ int arrow_emit(exg_reader *r, const ScanCtx &ctx) {
     }
     if (em.rc) return em.rc;
     EM_TRACE("formats / columns");
-    const uint64_t err = em.fetch_u64((const uint64_t *)em.d_err);  // also drains the D2H copies
+    const uint64_t err = em.fetch_u64((const uint64_t *)em.d_err);
     if (em.rc) return em.rc;
     EM_HIP(hipStreamSynchronize(r->stream));
+    EM_HIP(hipStreamSynchronize(st->copy_stream));  // every buffer has landed
     uint64_t n_rows = n;
     if (err != ~0ull) {
         // a typed value did not parse: rows before it are delivered, then the error (like the scan's own errors)
