@@ -175,6 +175,20 @@ def main():
         ms = sorted(a.elapsed_time(b) for a, b in ev)
         avg_ms = sum(ms) / len(ms)
         achieved = n_bytes / (avg_ms * 1e-3) / 1e9
+        # the same box's read-only stream rate: exg_count_newlines over the same buffer — every
+        # byte leaves HBM once, nothing is written
+        cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+        ro = []
+        for i in range(6):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            device.check(lib.exg_count_newlines(C.c_void_p(d_in.data_ptr()), halo, n_bytes, C.c_void_p(cnt.data_ptr()),
+                                                device.stream_ptr()))
+            b.record()
+            torch.cuda.synchronize()
+            if i:
+                ro.append(a.elapsed_time(b))
+        read_only = (n_bytes - halo) / (sum(ro) / len(ro) * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_fastq_fused.json")
         if os.path.exists(pmc):
@@ -212,6 +226,8 @@ def main():
                 "algorithmic_bytes_per_launch": n_bytes,
                 "avg_launch_ms": avg_ms,
                 "min_launch_ms": ms[0],
+                "read_only_stream_GBps": read_only,
+                "frac_of_read_only_stream": achieved / read_only,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

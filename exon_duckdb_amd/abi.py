@@ -114,6 +114,22 @@ class FastaScanArgs(C.Structure):
     ]
 
 
+class QualityListArgs(C.Structure):
+    _fields_ = [
+        ("d_strings", C.c_void_p),
+        ("n_rows", C.c_uint64),
+        ("d_payload", C.c_void_p),
+        ("payload_base", C.c_uint64),
+        ("d_entries", C.c_void_p),
+        ("d_values", C.c_void_p),
+        ("values_capacity", C.c_uint64),
+        ("d_total", C.c_void_p),
+        ("d_workspace", C.c_void_p),
+        ("workspace_bytes", C.c_uint64),
+        ("stream", C.c_void_p),
+    ]
+
+
 class InflateMember(C.Structure):
     _fields_ = [("comp_off", C.c_uint64), ("comp_size", C.c_uint64), ("out_off", C.c_uint64), ("out_cap", C.c_uint64)]
 
@@ -137,5 +153,7 @@ SIGNATURES = {
     "exg_inflate_members": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "exg_fetch_result": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(ScanResult)]),
     "exg_count_newlines": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "exg_quality_list_workspace_bytes": (C.c_uint64, [C.c_uint64]),
+    "exg_quality_score_list": (C.c_int, [C.POINTER(QualityListArgs)]),
     "exg_synth_fastq": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
 }

@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include "exg_arrow.hpp"
 #include "exg_fastq.hpp"
 
 namespace exg {
@@ -121,4 +122,36 @@ extern "C" int exg_fastq_scan(const exg_fastq_scan_args *a) {
             set_error("exg_fastq_scan: unknown algo %u", a->algo);
             return EXG_E_INVALID_ARG;
     }
+}
+
+// ---- quality_score_string_to_list --------------------------------------------------------------------------------
+// workspace: goff (n + 1 u64) | scan scratch
+extern "C" uint64_t exg_quality_list_workspace_bytes(uint64_t n_rows) {
+    return (n_rows + 1 + arrow::scan_tmp_entries(n_rows)) * 8 + 64;
+}
+
+extern "C" int exg_quality_score_list(const exg_quality_list_args *a) {
+    if (!a || !a->d_total || !a->d_workspace || (a->n_rows && (!a->d_strings || !a->d_entries)) ||
+        (a->values_capacity && !a->d_values) || ((uintptr_t)a->d_values & 15) || ((uintptr_t)a->d_workspace & 7)) {
+        set_error("exg_quality_score_list: bad arguments (null pointer or unaligned values / workspace)");
+        return EXG_E_INVALID_ARG;
+    }
+    if (a->workspace_bytes < exg_quality_list_workspace_bytes(a->n_rows)) {
+        set_error("exg_quality_score_list: workspace too small (%llu bytes, need %llu)", (unsigned long long)a->workspace_bytes,
+                  (unsigned long long)exg_quality_list_workspace_bytes(a->n_rows));
+        return EXG_E_INVALID_ARG;
+    }
+    hipStream_t s = (hipStream_t)a->stream;
+    uint64_t *d_goff = (uint64_t *)a->d_workspace;
+    uint64_t *d_tmp = d_goff + a->n_rows + 1;
+    if (!a->n_rows) {
+        EXG_HIP_CHECK(hipMemsetAsync(a->d_total, 0, 8, s));
+        return EXG_OK;
+    }
+    const arrow::StrCol col{a->d_strings, (const uint8_t *)a->d_payload, a->payload_base};
+    arrow::utf8_goff_from_col(col, nullptr, a->n_rows, d_goff, d_tmp, s);
+    EXG_HIP_CHECK(hipMemcpyAsync(a->d_total, d_goff + a->n_rows, 8, hipMemcpyDeviceToDevice, s));
+    arrow::quality_list(col, a->n_rows, d_goff, (arrow::ListEntry *)a->d_entries, a->d_values, a->values_capacity, s);
+    EXG_HIP_CHECK(hipGetLastError());
+    return EXG_OK;
 }

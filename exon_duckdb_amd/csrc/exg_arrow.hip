@@ -180,6 +180,62 @@ void utf8_copy_from_views(const View *d_views, uint64_t n, const uint64_t *d_gof
     launch_copy(ViewGet{d_views}, n, d_goff, d_values, d_big, big_cap, stream);
 }
 
+// ---- quality_score_string_to_list -------------------------------------------------------------------------------
+// Same shape as k_utf8_copy (workgroup = 256 consecutive strings = one contiguous range of the child vector),
+// but every source byte widens to an int32, so a thread produces four values and stores them as one 16-byte
+// group on the child vector's own 16-byte grid.  No big-string side path: the loop is output-centric.
+__global__ __launch_bounds__(256) void k_quality_list(ColGet g, uint64_t n, const uint64_t *__restrict__ goff,
+                                                      ListEntry *entries, int32_t *values, uint64_t values_cap) {
+    __shared__ uint64_t s_off[257];
+    __shared__ const uint8_t *s_src[256];
+    if (goff[n] > values_cap) return;
+    const uint64_t j0 = (uint64_t)blockIdx.x * 256;
+    const uint32_t cnt = (uint32_t)(n - j0 < 256 ? n - j0 : 256);
+    const uint32_t t = threadIdx.x;
+    for (uint32_t k = t; k <= cnt; k += 256) s_off[k] = goff[j0 + k];
+    if (t < cnt) {
+        uint32_t len;
+        s_src[t] = g.ptr(j0 + t, &len);
+    }
+    __syncthreads();
+    if (t < cnt) entries[j0 + t] = ListEntry{s_off[t], s_off[t + 1] - s_off[t]};
+    const uint64_t A = s_off[0], B = s_off[cnt];
+    for (uint64_t w = (A & ~3ull) + (uint64_t)t * 4; w < B; w += 1024) {
+        const uint64_t b = w > A ? w : A;
+        uint32_t lo = 0, hi = cnt;  // largest e < cnt with s_off[e] <= b
+        while (hi - lo > 1) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (s_off[mid] <= b)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        uint32_t e = lo;
+        int32_t v[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint64_t o = w + r;
+            if (o >= A && o < B) {
+                while (s_off[e + 1] <= o) e++;
+                v[r] = (int32_t)(int8_t)s_src[e][o - s_off[e]] - 33;
+            }
+        }
+        if (w >= A && w + 4 <= B) {
+            *reinterpret_cast<int4 *>(values + w) = make_int4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (w + r >= A && w + r < B) values[w + r] = v[r];
+        }
+    }
+}
+void quality_list(const StrCol &c, uint64_t n, const uint64_t *d_goff, ListEntry *d_entries, int32_t *d_values,
+                  uint64_t values_cap, hipStream_t stream) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_quality_list, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, ColGet{c, nullptr}, n, d_goff,
+                       d_entries, d_values, values_cap);
+}
+
 __global__ __launch_bounds__(256) void k_rebase(const uint64_t *__restrict__ goff, uint64_t n, uint64_t chunk_rows,
                                                 int32_t *off32, uint64_t *chunk_base) {
     const uint64_t n_chunks = (n + chunk_rows - 1) / chunk_rows;

@@ -47,6 +47,16 @@ void rebase_offsets(const uint64_t *d_goff, uint64_t n, uint64_t chunk_rows, int
 // off32[i] = (int32) goff[i], i = 0..n (absolute offsets: list columns and their children)
 void narrow_offsets(const uint64_t *d_goff, uint64_t n, int32_t *d_off32, hipStream_t stream);
 
+// ---- quality_score_string_to_list (exon/src/exon/fastq_functions/module.cpp:28-54) ------------------------------
+// DuckDB LIST(INTEGER) of a VARCHAR column: entries[j] = {goff[j], goff[j+1] - goff[j]} (list_entry_t) and
+// values[goff[j] + i] = (int32)(signed char)byte i of string j - 33.  d_goff comes from utf8_goff_from_col.
+// Nothing is written when goff[n] > values_cap (the caller reads goff[n] to find out).
+struct ListEntry {
+    uint64_t offset, length;
+};
+void quality_list(const StrCol &c, uint64_t n, const uint64_t *d_goff, ListEntry *d_entries, int32_t *d_values,
+                  uint64_t values_cap, hipStream_t stream);
+
 // ---- row selection (filters) ------------------------------------------------------------------------
 enum : uint8_t { kColStr = 0, kColI64 = 1, kColF32 = 2 };
 enum : uint8_t { kOpCmp = 0, kOpIsNull = 1, kOpIsNotNull = 2, kOpAnd = 3, kOpOr = 4 };

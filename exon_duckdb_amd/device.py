@@ -88,6 +88,37 @@ class FastqScan:
         return cols, words
 
 
+def quality_score_string_to_list(strings, n_rows, d_payload, payload_base, values_capacity=None):
+    """quality_score_string_to_list (reference fastq_functions/module.cpp:28-54) on a VARCHAR column that is still
+    in HBM: `strings` is a [cap, 2] int64 tensor of string_t (e.g. FastqScan.cols[3]), `d_payload` the buffer its
+    pointers address.  Returns (entries [n_rows, 2] int64 = DuckDB list_entry_t {offset, length}, values int32,
+    total): total > len(values) means the capacity was too small and nothing was written."""
+    torch = _torch()
+    lib = load_library()
+    dev = strings.device
+    cap = int(values_capacity if values_capacity is not None else d_payload.numel())
+    entries = torch.empty((max(n_rows, 1), 2), dtype=torch.int64, device=dev)
+    values = torch.empty(max(cap, 4), dtype=torch.int32, device=dev)
+    total = torch.zeros(1, dtype=torch.int64, device=dev)
+    ws_bytes = int(lib.exg_quality_list_workspace_bytes(n_rows))
+    ws = torch.empty((ws_bytes + 7) // 8, dtype=torch.int64, device=dev)
+    a = abi.QualityListArgs()
+    a.d_strings = strings.data_ptr()
+    a.n_rows = n_rows
+    a.d_payload = d_payload.data_ptr()
+    a.payload_base = payload_base
+    a.d_entries = entries.data_ptr()
+    a.d_values = values.data_ptr()
+    a.values_capacity = cap
+    a.d_total = total.data_ptr()
+    a.d_workspace = ws.data_ptr()
+    a.workspace_bytes = ws_bytes
+    a.stream = stream_ptr().value
+    check(lib.exg_quality_score_list(C.byref(a)))
+    t = int(total.item())
+    return entries[:n_rows], values[:min(t, cap)], t
+
+
 class VcfScan:
     """Reusable output + workspace buffers for exg_vcf_scan."""
 

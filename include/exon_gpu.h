@@ -220,6 +220,33 @@ int exg_count_newlines(const void *d_input, uint64_t begin, uint64_t end, uint64
  * receives 0..3, or 0xFFFFFFFF when no or several phases fit (caller falls back to counting). */
 int exg_fastq_guess_phase(const void *d_input, uint64_t n_bytes, uint64_t lead, uint32_t *d_phase, void *stream);
 
+/* ---- quality_score_string_to_list on device-resident columns ----------------------------------------
+ * Replaces the scalar function of exon/src/exon/fastq_functions/module.cpp:28-54 (one INTEGER per byte of the
+ * string, value = (char)c - 33, `char` signed as on x86-64) for a VARCHAR column that is still in HBM — the
+ * quality_scores column exg_fastq_scan just wrote.  Output is DuckDB's LIST(INTEGER) layout: one
+ * list_entry_t {offset, length} per row + the child INTEGER vector.  NULL rows (16 zero bytes) give empty
+ * entries; the list column's validity is the input column's validity. */
+typedef struct exg_list_entry_t {
+    uint64_t offset; /* first child value of the row */
+    uint64_t length;
+} exg_list_entry_t;
+typedef struct exg_quality_list_args {
+    const exg_string_t *d_strings; /* device, n_rows entries */
+    uint64_t n_rows;
+    const void *d_payload;       /* device bytes the non-inlined strings point into */
+    uint64_t payload_base;       /* string_t.ptr - payload_base = byte offset in d_payload */
+    exg_list_entry_t *d_entries; /* out: device, n_rows entries */
+    int32_t *d_values;           /* out: device, 16-byte aligned, values_capacity entries */
+    uint64_t values_capacity;
+    uint64_t *d_total; /* out: device u64, number of child values; > values_capacity => entries and values untouched */
+    void *d_workspace; /* device, exg_quality_list_workspace_bytes(n_rows) */
+    uint64_t workspace_bytes;
+    void *stream;
+} exg_quality_list_args;
+uint64_t exg_quality_list_workspace_bytes(uint64_t n_rows);
+/* Enqueue on args->stream; asynchronous. */
+int exg_quality_score_list(const exg_quality_list_args *args);
+
 /* ---- device inflate (gzip / BGZF members; replaces flate2 behind rust/src/arrow_reader.rs:60-91) ---- */
 typedef struct exg_inflate_member {
     uint64_t comp_off;  /* offset of the member's DEFLATE stream (after the gzip header) in d_comp */

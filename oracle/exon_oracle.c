@@ -989,3 +989,19 @@ const char *orc_replacement_scan(const char *uri) {
     }
     return file_type_from_ext(ext, ext_n);
 }
+
+/* fastq_functions/module.cpp:37-49: `for (auto c : string_value) push_back(Value::INTEGER(c - 33))` — c is a
+ * (signed) char, so bytes >= 0x80 give values below -33. */
+void orc_quality_score_list(const uint8_t *values, const int64_t *offsets, const uint8_t *valid, int64_t n_rows,
+                            uint64_t *entries, int32_t *out_values) {
+    uint64_t w = 0;
+    for (int64_t r = 0; r < n_rows; r++) {
+        entries[2 * r] = w;
+        if (valid && !valid[r]) {
+            entries[2 * r + 1] = 0;
+            continue;
+        }
+        for (int64_t i = offsets[r]; i < offsets[r + 1]; i++) out_values[w++] = (int32_t)(signed char)values[i] - 33;
+        entries[2 * r + 1] = w - entries[2 * r];
+    }
+}

@@ -101,6 +101,13 @@ void orc_utf8_to_string_t(const orc_utf8_col *col, int64_t row0, int64_t n, int 
 int orc_parse_f32_text(const uint8_t *p, uint64_t n, float *out);
 int orc_parse_i32_text(const uint8_t *p, uint64_t n, int32_t *out);
 
+/* quality_score_string_to_list (reference: exon/src/exon/fastq_functions/module.cpp:28-54): for every row
+ * one list of INTEGERs, value = (char)byte - 33 with `char` signed (x86-64).  entries[2r] = offset of row r's
+ * first child value, entries[2r+1] = its length (DuckDB list_entry_t); out_values holds offsets[n_rows]
+ * values.  Rows with valid[r] == 0 (valid may be NULL) give an empty entry. */
+void orc_quality_score_list(const uint8_t *values, const int64_t *offsets, const uint8_t *valid, int64_t n_rows,
+                            uint64_t *entries, int32_t *out_values);
+
 /* Rust core::str::from_utf8 acceptance test. */
 int orc_is_valid_utf8(const uint8_t *p, uint64_t n);
 

@@ -78,6 +78,8 @@ def lib():
                                            C.c_void_p, C.c_void_p]
         l.orc_parse_f32_text.restype = C.c_int
         l.orc_parse_f32_text.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(C.c_float)]
+        l.orc_quality_score_list.restype = None
+        l.orc_quality_score_list.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         l.orc_parse_i32_text.restype = C.c_int
         l.orc_parse_i32_text.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(C.c_int32)]
         l.orc_is_valid_utf8.restype = C.c_int
@@ -219,6 +221,19 @@ def parse_f32_text(b: bytes):
 def parse_i32_text(b: bytes):
     v = C.c_int32(0)
     return int(v.value) if lib().orc_parse_i32_text(b, len(b), C.byref(v)) else None
+
+
+def quality_score_string_to_list(col):
+    """(entries u64[n, 2] = {offset, length}, values i32) of a Column (fastq_functions/module.cpp:28-54)."""
+    n = len(col.offsets) - 1
+    offsets = np.ascontiguousarray(col.offsets, np.int64)
+    values = np.ascontiguousarray(col.values, np.uint8)
+    valid = None if getattr(col, "valid", None) is None else np.ascontiguousarray(col.valid, np.uint8)
+    entries = np.zeros((n, 2), np.uint64)
+    out = np.zeros(max(int(offsets[n]), 1), np.int32)
+    lib().orc_quality_score_list(values.ctypes.data, offsets.ctypes.data, valid.ctypes.data if valid is not None else None,
+                                 n, entries.ctypes.data, out.ctypes.data)
+    return entries, out[:int(entries[:, 1].sum())]
 
 
 def vcf_header_keys(data: bytes):

@@ -1,5 +1,6 @@
 """Named tests for the [RECALLED] noodles / exon rules the oracle restates beyond what the
 reference's sqllogictests pin (parity UNPINNED): a run against a real exon build can falsify each."""
+import numpy as np
 import pytest
 
 PE = dict(NAME=1, PLUS=2, EOF=3, UTF8=4, FA_PREFIX=5, FA_NAME=6, FA_EMPTY=7, VCF_FIELD=8, VCF_POS=9, VCF_QUAL=10,
@@ -260,3 +261,34 @@ def test_vcf_typed_bad_number_is_a_record_error(oracle):
     assert err == 0 and rows == []
     assert oracle.parse_i32_text(b"2147483647") == 2147483647 and oracle.parse_i32_text(b"2147483648") is None
     assert oracle.parse_i32_text(b"-2147483648") == -2147483648 and oracle.parse_i32_text(b"+") is None
+
+
+# ---- quality_score_string_to_list (fastq_functions/module.cpp:28-54) — parity unpinned: no sqllogictest calls it ----
+def test_quality_score_list_is_byte_minus_33_signed(oracle):
+    class Col:
+        offsets = np.array([0, 3, 3, 5], np.int64)
+        values = np.frombuffer(b"!I@\x80\xff", np.uint8)
+        valid = None
+
+    entries, values = oracle.quality_score_string_to_list(Col)
+    assert entries.tolist() == [[0, 3], [3, 0], [3, 2]]
+    assert values.tolist() == [0, 40, 31, -128 - 33, -1 - 33]
+
+
+def test_quality_score_list_null_rows_are_empty(oracle):
+    class Col:
+        offsets = np.array([0, 2, 4], np.int64)
+        values = np.frombuffer(b"!!II", np.uint8)
+        valid = np.array([0, 1], np.uint8)
+
+    entries, values = oracle.quality_score_string_to_list(Col)
+    assert entries.tolist() == [[0, 0], [0, 2]]
+    assert values.tolist() == [40, 40]
+
+
+def test_quality_score_list_golden_record(oracle, golden_dir):
+    exp = oracle.fastq_parse(open(f"{golden_dir}/test.fastq", "rb").read())
+    entries, values = oracle.quality_score_string_to_list(exp.columns["quality_scores"])
+    q0 = b"!''*((((***+))%%%++)(%%%%).1***-+*''))**55CCF>>>>>>CCCCCCC65"   # test_fastq_scan.test:35-41
+    assert entries[0].tolist() == [0, len(q0)]
+    assert values[: len(q0)].tolist() == [c - 33 for c in q0]
