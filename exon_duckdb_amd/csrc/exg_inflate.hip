@@ -15,13 +15,16 @@
 //     copied by all lanes (source index folded modulo the distance, so overlapping copies are exact);
 //   * every completed 1 KiB of the ring is flushed to HBM with 16 B/lane stores.
 // LDS: 32 KiB window + 2 KiB input + ~4.5 KiB tables => 4 waves per CU, 1024 members in flight.
+#include <stdlib.h>
+
 #include "exg_inflate_core.hpp"
 
 namespace exg {
-__global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ d_comp, uint8_t *__restrict__ d_out,
+template <uint32_t RING>
+__global__ __launch_bounds__(64, RING <= 2048 ? 5 : 1) void k_inflate(const uint8_t *__restrict__ d_comp, uint8_t *d_out,
                                                 const InflateMember *__restrict__ members, InflateStatus *status,
                                                 uint32_t n_members) {
-    __shared__ __attribute__((aligned(16))) InflateLdsT<false> s;
+    __shared__ __attribute__((aligned(16))) InflateLdsT<false, RING> s;
     __shared__ InflateJobStatus s_st;
     for (uint32_t m = blockIdx.x; m < n_members; m += gridDim.x) {
         const InflateMember mb = members[m];
@@ -32,7 +35,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ d_co
         jb.out_cap = mb.out_cap;
         jb.start_bit = 0;
         jb.stop_bit = 0;
-        inflate_job<false>(s, d_comp, d_out, jb, &s_st);
+        inflate_job<false, RING>(s, d_comp, d_out, jb, &s_st);
         if (threadIdx.x == 0) {
             InflateStatus st;
             st.code = s_st.code;
@@ -59,9 +62,22 @@ extern "C" int exg_inflate_members(const void *d_comp, void *d_out, const exg_in
         exg::set_error("exg_inflate_members: bad arguments (null or unaligned compressed buffer)");
         return EXG_E_INVALID_ARG;
     }
-    uint32_t grid = n_members < 4096 ? n_members : 4096;
-    hipLaunchKernelGGL(exg::k_inflate, dim3(grid), dim3(64), 0, (hipStream_t)stream, (const uint8_t *)d_comp,
-                       (uint8_t *)d_out, (const exg::InflateMember *)d_members, (exg::InflateStatus *)d_status, n_members);
+    uint32_t grid = n_members < 8192 ? n_members : 8192;
+    static const int ring = [] {
+        const char *e = getenv("EXG_INFLATE_RING");  // A/B switch: LDS ring elements (32768 = the whole window in LDS)
+        return e ? atoi(e) : 2048;
+    }();
+#define EXG_LAUNCH_INFLATE(R)                                                                                          \
+    hipLaunchKernelGGL(exg::k_inflate<R>, dim3(grid), dim3(64), 0, (hipStream_t)stream, (const uint8_t *)d_comp,       \
+                       (uint8_t *)d_out, (const exg::InflateMember *)d_members, (exg::InflateStatus *)d_status, n_members)
+    switch (ring) {
+        case 4096: EXG_LAUNCH_INFLATE(4096); break;
+        case 8192: EXG_LAUNCH_INFLATE(8192); break;
+        case 16384: EXG_LAUNCH_INFLATE(16384); break;
+        case 32768: EXG_LAUNCH_INFLATE(32768); break;
+        default: EXG_LAUNCH_INFLATE(2048); break;
+    }
+#undef EXG_LAUNCH_INFLATE
     EXG_HIP_CHECK(hipGetLastError());
     return EXG_OK;
 }

@@ -23,25 +23,34 @@ struct InflateStatus {
 };
 
 static constexpr int kWinBytes = 32768;
-static constexpr int kInRing = 2048;
+static constexpr int kInRing = 1024;                 // two chunks of the compressed input
+static constexpr int kInChunk = kInRing / 2, kInChunkBitsLog2 = 12;  // 512 B = 4096 bits
 static constexpr int kLitBits = 10, kDistBits = 9;
 
 // SYM = false: the window holds bytes (a gzip member decoded from its first bit).
 // SYM = true:  the window holds 16-bit symbols — a byte, or 0x8000 | i for "byte i of the 32 KiB in front of where
 //              this decode started", which are not known yet (exg_inflate_stream: one big member decoded in chunks).
-template <bool SYM>
+// RING = 32 Ki: the whole window is an LDS ring (39 KiB / 72 KiB per wave: 4 / 2 waves per CU).
+// RING < 32 Ki: the ring holds the newest RING elements only; a match that reaches further back reads the output the
+//               wave flushed to HBM earlier (RING = 4 Ki: 11 KiB / 15 KiB per wave => 3-4 waves per SIMD, which is
+//               what hides the latency of this serial decode).  A decode without output (d_out = NULL) copies nothing.
+template <bool SYM, uint32_t RING = kWinBytes>
 struct InflateLdsT {
     using Elem = typename std::conditional<SYM, uint16_t, uint8_t>::type;
-    Elem win[kWinBytes];
+    static_assert(RING >= 2048 && RING <= kWinBytes && (RING & (RING - 1)) == 0, "ring: power of two, >= 1 KiB flush + a match");
+    static constexpr uint32_t kRing = RING;
+    static constexpr bool kGlobalWindow = RING < kWinBytes;
+    Elem win[kRing];
     uint8_t in[kInRing];
     // Primary tables, 0 = code longer than the table (or unused).  The entries carry what the token needs, so a
     // decode is peek -> lit_lut -> dist_lut, three dependent LDS levels instead of five:
     //   lit_lut  literal: bits 0-3 code length, 4-11 byte, 12 end-of-block, 13 invalid symbol
     //            length : bit 15, bits 0-3 code length, 4-6 extra bit count, 7-14 base length - 3
-    //   dist_lut bits 0-3 code length, 4-7 extra bit count, 8 invalid symbol, 16-30 base distance
+    //   dist_lut bits 0-3 code length, 4-8 distance symbol, 9 invalid symbol (base and extra bit count are arithmetic:
+    //            dist_base_extra)
     //            (the code-length alphabet of a dynamic header borrows it as a plain u16 table)
     uint16_t lit_lut[1 << kLitBits];
-    uint32_t dist_lut[1 << kDistBits];
+    uint16_t dist_lut[1 << kDistBits];
     uint16_t lit_sorted[288], dist_sorted[32];   // symbols ordered by (length, symbol) — canonical decode
     uint16_t lit_count[16], dist_count[16];
     uint8_t lens[384];  // [0,288) literal/length, [288,320) distance; [32,348) scratch while a dynamic header is read
@@ -66,19 +75,19 @@ struct BitIn {
     const uint8_t *g0;          // 16-byte aligned global address of chunk 0
 };
 
-// stage 1 KiB chunk c of the compressed input (coalesced, 16 B per lane)
+// stage 512-byte chunk c of the compressed input (coalesced, 8 B per lane)
 template <class L>
 __device__ __forceinline__ void stage_chunk(L &s, const BitIn &br, uint32_t c, uint32_t lane) {
-    uint32_t off = c * 1024 + lane * 16;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (off < ((br.limit + 15) & ~15u)) v = *reinterpret_cast<const uint4 *>(br.g0 + off);
-    *reinterpret_cast<uint4 *>(s.in + ((c & 1) * 1024 + lane * 16)) = v;
+    uint32_t off = c * kInChunk + lane * 8;
+    uint2 v = make_uint2(0, 0);
+    if (off < ((br.limit + 15) & ~15u)) v = *reinterpret_cast<const uint2 *>(br.g0 + off);
+    *reinterpret_cast<uint2 *>(s.in + ((c & 1) * kInChunk + lane * 8)) = v;
 }
 
 // keep the chunk that holds the current byte and the next one staged (reads go up to ~20 bytes ahead)
 template <class L>
 __device__ __forceinline__ void ensure(L &s, BitIn &br, uint32_t lane) {
-    uint32_t c = (uint32_t)(br.bitpos >> 13);  // 8192 bits per chunk
+    uint32_t c = (uint32_t)(br.bitpos >> kInChunkBitsLog2);
     while (c + 1 >= br.loaded) {
         stage_chunk(s, br, br.loaded, lane);
         br.loaded++;
@@ -128,11 +137,18 @@ struct EncLit {
     }
 };
 struct EncDist {
-    __device__ __forceinline__ uint32_t operator()(uint32_t sym, uint32_t l) const {
-        if (sym > 29) return (1u << 8) | l;
-        return ((uint32_t)kDistBase[sym] << 16) | ((uint32_t)kDistExtra[sym] << 4) | l;
+    __device__ __forceinline__ uint16_t operator()(uint32_t sym, uint32_t l) const {
+        if (sym > 29) return (uint16_t)((1u << 9) | l);
+        return (uint16_t)((sym << 4) | l);
     }
 };
+// RFC 1951 distance symbol -> base distance and extra bit count without a table: symbols come in pairs that
+// double the range (kDistBase / kDistExtra hold the same numbers for the serial path)
+__device__ __forceinline__ void dist_base_extra(uint32_t sym, uint32_t *base, uint32_t *extra) {
+    const uint32_t dx = sym < 2 ? 0u : (sym >> 1) - 1u;
+    *extra = dx;
+    *base = sym < 2 ? sym + 1u : ((2u | (sym & 1u)) << dx) + 1u;
+}
 
 template <class Lut, class Enc>
 __device__ inline bool build_table(const uint8_t *lens, uint32_t n, Lut *lut, uint32_t bits, uint16_t *sorted, uint16_t *count,
@@ -254,8 +270,9 @@ template <class L>
 __device__ __forceinline__ void flush_segments(L &s, typename L::Elem *out, unsigned long long out_off, uint32_t &flushed,
                                                uint32_t pos, uint32_t lane) {
     using Elem = typename L::Elem;
+    const bool any = flushed + 1024 <= pos;
     while (flushed + 1024 <= pos) {
-        const Elem *src = s.win + ((flushed & (kWinBytes - 1)) + lane * 16);
+        const Elem *src = s.win + ((flushed & (L::kRing - 1)) + lane * 16);
         Elem *dst = out + out_off + flushed + lane * 16;
         // the output offset is arbitrary: fall back to element stores when the destination is not 16-byte aligned
         if (!out) {
@@ -269,6 +286,32 @@ __device__ __forceinline__ void flush_segments(L &s, typename L::Elem *out, unsi
             for (int k = 0; k < 16; k++) dst[k] = src[k];
         }
         flushed += 1024;
+    }
+    // later matches of this wave read these bytes back through the CU's own L1 (write-through, coherent inside a
+    // workgroup): the stores only have to be complete first
+    if (L::kGlobalWindow && any && out) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+}
+
+// LZ77 copy of `len` elements from `dist` back, all lanes; the source index is folded into [pos - dist, pos) so
+// overlapping copies are exact
+template <class L>
+__device__ __forceinline__ void copy_match(L &s, typename L::Elem *out, unsigned long long out_off, uint32_t pos, uint32_t len,
+                                           uint32_t dist, uint32_t lane) {
+    using Elem = typename L::Elem;
+    constexpr bool SYM = sizeof(Elem) == 2;
+    if (L::kGlobalWindow && !out) return;  // probing decode: the output never steers the decode
+    for (uint32_t i = lane; i < len; i += 64) {
+        const long long src = (long long)pos - (long long)dist + (long long)(dist >= len ? i : i % dist);
+        Elem x;
+        if (SYM && src < 0) {  // a byte of the 32 KiB in front of this decode: named, resolved later
+            x = (Elem)(0x8000u | (uint32_t)(32768 + src));
+        } else if (!L::kGlobalWindow || (uint32_t)src + L::kRing >= pos + len) {
+            x = s.win[(uint32_t)src & (L::kRing - 1)];
+        } else {
+            // older than the ring: flushed at least 1 KiB ago (src < pos + 258 - kRing < flushed)
+            x = __hip_atomic_load(out + out_off + (uint32_t)src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        s.win[(pos + i) & (L::kRing - 1)] = x;
     }
 }
 
@@ -291,11 +334,12 @@ struct InflateJobStatus {
     unsigned long long end_bit;    // bit after the last decoded block, relative to comp_off
 };
 
-template <bool SYM>
-__device__ __forceinline__ void inflate_job(InflateLdsT<SYM> &s, const uint8_t *__restrict__ d_comp,
-                                            typename InflateLdsT<SYM>::Elem *__restrict__ d_out, const InflateJob mb,
+template <bool SYM, uint32_t RING = kWinBytes>
+__device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uint8_t *__restrict__ d_comp,
+                                            typename InflateLdsT<SYM, RING>::Elem *d_out, const InflateJob mb,
                                             InflateJobStatus *st_out) {
-    using Elem = typename InflateLdsT<SYM>::Elem;
+    using Elem = typename InflateLdsT<SYM, RING>::Elem;
+    constexpr uint32_t kRingMask = RING - 1;
     const uint32_t lane = threadIdx.x;
     {
         BitIn br;
@@ -305,7 +349,7 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM> &s, const uint8_t *
         unsigned long long lim = mb.comp_size + skip;
         br.limit = lim > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)lim;
         br.bitpos = (unsigned long long)skip * 8 + mb.start_bit;
-        br.loaded = (uint32_t)(br.bitpos >> 13);  // staging starts at the chunk that holds the first bit
+        br.loaded = (uint32_t)(br.bitpos >> kInChunkBitsLog2);  // staging starts at the chunk that holds the first bit
         __syncthreads();
         ensure(s, br, lane);
 
@@ -338,7 +382,7 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM> &s, const uint8_t *
                 for (uint32_t i = 0; i < len; i += 64) {
                     ensure(s, br, lane);
                     uint32_t n = len - i < 64 ? len - i : 64;
-                    if (lane < n) s.win[(pos + i + lane) & (kWinBytes - 1)] = (Elem)s.in[((uint32_t)(br.bitpos >> 3) + lane) & (kInRing - 1)];
+                    if (lane < n) s.win[(pos + i + lane) & kRingMask] = (Elem)s.in[((uint32_t)(br.bitpos >> 3) + lane) & (kInRing - 1)];
                     br.bitpos += 8ull * n;
                     flush_segments(s, d_out, mb.out_off, flushed, pos + i + n, lane);
                 }
@@ -372,7 +416,7 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM> &s, const uint8_t *
                     br.bitpos += 3ull * ncode;
                 }
                 // the code-length code reuses the distance table storage (7-bit codes, 19 symbols)
-                uint16_t *cl_lut = reinterpret_cast<uint16_t *>(s.dist_lut);  // borrowed until the real tables are built
+                uint16_t *cl_lut = s.dist_lut;  // borrowed until the real tables are built
                 if (!build_table(s.lens, 19, cl_lut, 7, s.dist_sorted, s.dist_count, lane, EncPlain())) {
                     err = 2;
                     break;
@@ -456,15 +500,17 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM> &s, const uint8_t *
                         const uint32_t t = l1 + lx;
                         const unsigned long long v2 = v >> t;
                         const uint32_t de = s.dist_lut[(uint32_t)v2 & ((1u << kDistBits) - 1u)];
-                        const uint32_t l2 = de & 15, dx = (de >> 4) & 15u;
+                        const uint32_t l2 = de & 15;
+                        uint32_t dbase, dx;
+                        dist_base_extra((de >> 4) & 31u, &dbase, &dx);
                         if (de == 0) {
                             kind = kSlow;
                             tl = 0;
-                        } else if (de & (1u << 8)) {
+                        } else if (de & (1u << 9)) {
                             kind = kBad;
                             tl = 1;
                         } else {
-                            const uint32_t dist = (de >> 16) + ((uint32_t)(v2 >> l2) & ((1u << dx) - 1u));
+                            const uint32_t dist = dbase + ((uint32_t)(v2 >> l2) & ((1u << dx) - 1u));
                             kind = kMatch;
                             tl = t + l2 + dx;  // <= 15 + 5 + 15 + 13 = 48 bits
                             val = len | (dist << 16);
@@ -504,7 +550,7 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM> &s, const uint8_t *
                             break;
                         }
                         uint32_t rank = (uint32_t)__popcll(seg & ((1ull << lane) - 1ull));
-                        if ((seg >> lane) & 1ull) s.win[(pos + rank) & (kWinBytes - 1)] = (Elem)val;
+                        if ((seg >> lane) & 1ull) s.win[(pos + rank) & kRingMask] = (Elem)val;
                         uint32_t np = pos + n;
                         if ((np >> 10) != (pos >> 10)) flush_segments(s, d_out, mb.out_off, flushed, np, lane);
                         pos = np;
@@ -518,16 +564,7 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM> &s, const uint8_t *
                             err = (!SYM && dist > pos) ? 3 : 4;
                             break;
                         }
-                        // all lanes copy; the source index is folded into [pos - dist, pos) so overlaps are exact
-                        for (uint32_t i = lane; i < len; i += 64) {
-                            const long long src = (long long)pos - (long long)dist + (long long)(dist >= len ? i : i % dist);
-                            Elem x;
-                            if (SYM && src < 0)  // a byte of the 32 KiB in front of this decode: named, resolved later
-                                x = (Elem)(0x8000u | (uint32_t)(32768 + src));
-                            else
-                                x = s.win[(uint32_t)src & (kWinBytes - 1)];
-                            s.win[(pos + i) & (kWinBytes - 1)] = x;
-                        }
+                        copy_match(s, d_out, mb.out_off, pos, len, dist, lane);
                         uint32_t np = pos + len;
                         if ((np >> 10) != (pos >> 10)) flush_segments(s, d_out, mb.out_off, flushed, np, lane);
                         pos = np;
@@ -550,7 +587,7 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM> &s, const uint8_t *
                         if (pos >= cap) {
                             err = 4;
                         } else {
-                            if (lane == 0) s.win[pos & (kWinBytes - 1)] = (Elem)sym;
+                            if (lane == 0) s.win[pos & kRingMask] = (Elem)sym;
                             pos++;
                             if ((pos & 1023) == 0) flush_segments(s, d_out, mb.out_off, flushed, pos, lane);
                         }
@@ -569,15 +606,7 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM> &s, const uint8_t *
                             if ((!SYM && dist > pos) || (unsigned long long)pos + len > cap) {
                                 err = (!SYM && dist > pos) ? 3 : 4;
                             } else {
-                                for (uint32_t i = lane; i < len; i += 64) {
-                                    const long long src = (long long)pos - (long long)dist + (long long)(dist >= len ? i : i % dist);
-                                    Elem x;
-                                    if (SYM && src < 0)
-                                        x = (Elem)(0x8000u | (uint32_t)(32768 + src));
-                                    else
-                                        x = s.win[(uint32_t)src & (kWinBytes - 1)];
-                                    s.win[(pos + i) & (kWinBytes - 1)] = x;
-                                }
+                                copy_match(s, d_out, mb.out_off, pos, len, dist, lane);
                                 uint32_t np = pos + len;
                                 if ((np >> 10) != (pos >> 10)) flush_segments(s, d_out, mb.out_off, flushed, np, lane);
                                 pos = np;
@@ -589,7 +618,7 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM> &s, const uint8_t *
         }
         // tail: the bytes after the last full segment
         if (!err && d_out) {
-            for (uint32_t i = flushed + lane; i < pos; i += 64) d_out[mb.out_off + i] = s.win[i & (kWinBytes - 1)];
+            for (uint32_t i = flushed + lane; i < pos; i += 64) d_out[mb.out_off + i] = s.win[i & kRingMask];
         }
         if (lane == 0) {
             InflateJobStatus st;

@@ -22,6 +22,7 @@
 #include <time.h>
 
 #include <algorithm>
+#include <iterator>
 #include <map>
 #include <memory>
 #include <vector>
@@ -59,7 +60,8 @@ __device__ __forceinline__ bool header_filter(unsigned long long v, unsigned lon
 
 __global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ d_comp, const FindJob *__restrict__ jobs,
                                                     unsigned long long *found, uint16_t *d_scratch, uint32_t n_jobs) {
-    __shared__ __attribute__((aligned(16))) InflateLdsT<true> s;
+    // probing decodes keep nothing: the smallest ring (11 KiB of LDS per wave instead of 72 KiB)
+    __shared__ __attribute__((aligned(16))) InflateLdsT<true, 2048> s;
     __shared__ InflateJobStatus s_st;
     const uint32_t lane = threadIdx.x;
     for (uint32_t j = blockIdx.x; j < n_jobs; j += gridDim.x) {
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ 
             unsigned long long lim = fj.comp_size + skip;
             br.limit = lim > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)lim;
             br.bitpos = (unsigned long long)skip * 8 + base;
-            br.loaded = (uint32_t)(br.bitpos >> 13);
+            br.loaded = (uint32_t)(br.bitpos >> kInChunkBitsLog2);
             __syncthreads();
             ensure(s, br, lane);
             br.bitpos += 64 + 17 + 64;  // the filter reads up to here: keep the next chunk staged too
@@ -91,14 +93,16 @@ __global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ 
                 // follows it must again be a block that decodes (its header + the first kProbeSymbols symbols).
                 InflateJob jb;
                 jb.comp_off = fj.comp_off;
-                // a block longer than 512 KiB of input is not accepted as a chunk start: garbage behind a false header
-                // can run for millions of symbols before it meets an end-of-block code (seen: 4.5 s in the finder)
-                jb.comp_size = std::min<unsigned long long>(fj.comp_size, ((base + l) >> 3) + (512u << 10));
+                // a block longer than 128 KiB of input is not accepted as a chunk start (zlib closes a block after 16 Ki
+                // symbols: 20-60 KB of FASTQ): garbage behind a false header can run for millions of symbols before it
+                // meets an end-of-block code, and one such candidate holds the whole finder up (seen: 4.5 s without a
+                // bound, 230 ms with 512 KiB).  A real block beyond the bound only costs a chunk start.
+                jb.comp_size = std::min<unsigned long long>(fj.comp_size, ((base + l) >> 3) + (128u << 10));
                 jb.out_off = 0;
-                jb.out_cap = 1ull << 24;  // nothing is stored: the bound only stops a runaway decode
+                jb.out_cap = 1ull << 22;  // nothing is stored: the bound only stops a runaway decode
                 jb.start_bit = base + l;
                 jb.stop_bit = base + l + 1;
-                inflate_job<true>(s, d_comp, (uint16_t *)nullptr, jb, &s_st);
+                inflate_job<true, 2048>(s, d_comp, (uint16_t *)nullptr, jb, &s_st);
                 uint32_t code = s_st.code;
                 const bool final1 = s_st.final_block != 0;
                 const unsigned long long end1 = s_st.end_bit;
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ 
                     jb.out_cap = kProbeSymbols;
                     jb.start_bit = end1;
                     jb.stop_bit = end1 + 1;
-                    inflate_job<true>(s, d_comp, (uint16_t *)nullptr, jb, &s_st);
+                    inflate_job<true, 2048>(s, d_comp, (uint16_t *)nullptr, jb, &s_st);
                     code = s_st.code == 4 ? 0u : s_st.code;
                     __syncthreads();
                 }
@@ -122,11 +126,12 @@ __global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ 
 }
 
 // ---- 2. chunk decode -----------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_inflate_chunks(const uint8_t *__restrict__ d_comp, uint16_t *__restrict__ d_sym,
+template <uint32_t RING>
+__global__ __launch_bounds__(64) void k_inflate_chunks(const uint8_t *__restrict__ d_comp, uint16_t *d_sym,
                                                        const InflateJob *__restrict__ jobs, InflateJobStatus *status,
                                                        uint32_t n_jobs) {
-    __shared__ __attribute__((aligned(16))) InflateLdsT<true> s;
-    for (uint32_t j = blockIdx.x; j < n_jobs; j += gridDim.x) inflate_job<true>(s, d_comp, d_sym, jobs[j], &status[j]);
+    __shared__ __attribute__((aligned(16))) InflateLdsT<true, RING> s;
+    for (uint32_t j = blockIdx.x; j < n_jobs; j += gridDim.x) inflate_job<true, RING>(s, d_comp, d_sym, jobs[j], &status[j]);
 }
 
 // ---- 4. windows ----------------------------------------------------------------------------------------------------------
@@ -247,26 +252,36 @@ extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint6
     const uint32_t n_bound = (uint32_t)std::min<uint64_t>((comp_size + chunk_bytes - 1) / chunk_bytes, 1u << 20);
     std::vector<uint64_t> starts;  // bit offsets of the chunk starts (sorted, unique); starts[0] = 0
     starts.push_back(0);
-    if (n_bound > 1) {
-        std::vector<FindJob> fj(n_bound - 1);
-        for (uint32_t k = 1; k < n_bound; k++) {
-            fj[k - 1].comp_off = comp_off;
-            fj[k - 1].comp_size = comp_size;
-            fj[k - 1].from_bit = (uint64_t)k * chunk_bytes * 8;
-            fj[k - 1].to_bit = std::min<uint64_t>((uint64_t)(k + 1) * chunk_bytes * 8, total_bits);
+    // first block start in each [from, to) (bit ranges), ~0 where none was found
+    auto find_starts = [&](const std::vector<std::pair<uint64_t, uint64_t>> &ranges, std::vector<uint64_t> *found) -> int {
+        std::vector<FindJob> fj(ranges.size());
+        for (size_t k = 0; k < ranges.size(); k++) {
+            fj[k].comp_off = comp_off;
+            fj[k].comp_size = comp_size;
+            fj[k].from_bit = ranges[k].first;
+            fj[k].to_bit = ranges[k].second;
         }
         DevBuf d_fj, d_found, d_scratch;
         ST_HIP(d_fj.alloc(fj.size() * sizeof(FindJob)));
         ST_HIP(d_found.alloc(fj.size() * 8));
-        ST_HIP(d_scratch.alloc(fj.size() * 1024 * 2));
+        ST_HIP(d_scratch.alloc(16));
         ST_HIP(hipMemcpyAsync(d_fj.p, fj.data(), fj.size() * sizeof(FindJob), hipMemcpyHostToDevice, stream));
-        const uint32_t grid = (uint32_t)std::min<size_t>(fj.size(), 512);
+        const uint32_t grid = (uint32_t)std::min<size_t>(fj.size(), 8192);
         hipLaunchKernelGGL(k_find_blocks, dim3(grid), dim3(64), 0, stream, d_comp, (const FindJob *)d_fj.p,
                            (unsigned long long *)d_found.p, (uint16_t *)d_scratch.p, (uint32_t)fj.size());
         ST_HIP(hipGetLastError());
-        std::vector<uint64_t> found(fj.size());
-        ST_HIP(hipMemcpyAsync(found.data(), d_found.p, found.size() * 8, hipMemcpyDeviceToHost, stream));
+        found->resize(fj.size());
+        ST_HIP(hipMemcpyAsync(found->data(), d_found.p, found->size() * 8, hipMemcpyDeviceToHost, stream));
         ST_HIP(hipStreamSynchronize(stream));
+        return EXG_OK;
+    };
+    if (n_bound > 1) {
+        std::vector<std::pair<uint64_t, uint64_t>> ranges;
+        for (uint32_t k = 1; k < n_bound; k++)
+            ranges.emplace_back((uint64_t)k * chunk_bytes * 8, std::min<uint64_t>((uint64_t)(k + 1) * chunk_bytes * 8, total_bits));
+        std::vector<uint64_t> found;
+        int rc = find_starts(ranges, &found);
+        if (rc) return rc;
         for (uint64_t f : found)
             if (f != ~0ull && f > starts.back()) starts.push_back(f);
         ST_TRACE("[exg] inflate stream: %u boundaries searched, %zu block starts found, %.1f ms\n", n_bound - 1, starts.size() - 1,
@@ -303,12 +318,28 @@ extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint6
         sym_bufs.emplace_back(new DevBuf());
         DevBuf &d_sym = *sym_bufs.back();
         DevBuf d_jobs, d_st;
+        const double t_alloc = st_now();
         if (!measure_only) ST_HIP(d_sym.alloc(off[n] * 2 + 64));
         ST_HIP(d_jobs.alloc(n * sizeof(InflateJob)));
         ST_HIP(d_st.alloc(n * sizeof(InflateJobStatus)));
+        ST_TRACE("[exg] inflate stream: symbol buffer %.2f GB allocated in %.1f ms\n", off[n] * 2 / 1e9, (st_now() - t_alloc) * 1e3);
         ST_HIP(hipMemcpyAsync(d_jobs.p, jobs.data(), n * sizeof(InflateJob), hipMemcpyHostToDevice, stream));
-        hipLaunchKernelGGL(k_inflate_chunks, dim3(std::min<uint32_t>(n, 2048)), dim3(64), 0, stream, d_comp, (uint16_t *)d_sym.p,
-                           (const InflateJob *)d_jobs.p, (InflateJobStatus *)d_st.p, n);
+        static const int ring = [] {
+            const char *e = getenv("EXG_STREAM_RING");  // A/B switch: 32768 = the whole symbol window in LDS (72 KiB)
+            return e ? atoi(e) : 4096;
+        }();
+        if (ring == 32768)
+            hipLaunchKernelGGL(k_inflate_chunks<32768>, dim3(std::min<uint32_t>(n, 8192)), dim3(64), 0, stream, d_comp,
+                               (uint16_t *)d_sym.p, (const InflateJob *)d_jobs.p, (InflateJobStatus *)d_st.p, n);
+        else if (ring == 2048)
+            hipLaunchKernelGGL(k_inflate_chunks<2048>, dim3(std::min<uint32_t>(n, 8192)), dim3(64), 0, stream, d_comp,
+                               (uint16_t *)d_sym.p, (const InflateJob *)d_jobs.p, (InflateJobStatus *)d_st.p, n);
+        else if (ring == 8192)
+            hipLaunchKernelGGL(k_inflate_chunks<8192>, dim3(std::min<uint32_t>(n, 8192)), dim3(64), 0, stream, d_comp,
+                               (uint16_t *)d_sym.p, (const InflateJob *)d_jobs.p, (InflateJobStatus *)d_st.p, n);
+        else
+            hipLaunchKernelGGL(k_inflate_chunks<4096>, dim3(std::min<uint32_t>(n, 8192)), dim3(64), 0, stream, d_comp,
+                               (uint16_t *)d_sym.p, (const InflateJob *)d_jobs.p, (InflateJobStatus *)d_st.p, n);
         ST_HIP(hipGetLastError());
         std::vector<InflateJobStatus> st(n);
         ST_HIP(hipMemcpyAsync(st.data(), d_st.p, n * sizeof(InflateJobStatus), hipMemcpyDeviceToHost, stream));
@@ -330,55 +361,119 @@ extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint6
     std::vector<ChunkOut> co;
     uint64_t total = 0, end_bit = 0;
     {
-        uint64_t e = 0;
-        for (int rounds = 0;; ) {
-            auto it = decoded.find(e);
-            if (it == decoded.end() || it->second.st.code == 4) {
-                // nothing decoded from this (real) boundary yet, or its output did not fit: one more job.  An output that
-                // did not fit is first MEASURED (decoded without storing), then decoded into a buffer of that size: growing
-                // the buffer blindly would re-decode again and again — and on a corrupt stream for minutes.
-                // every false block start can break the chain once; more breaks than candidates = garbage after a corruption
-                if (++rounds > (int)starts.size() + 8) {
-                    set_error("corrupt deflate stream (the chunk chain does not settle after bit %llu)", (unsigned long long)e);
+        // Every round walks the chain from bit 0.  Where it stands at a bit no piece starts from (the candidate behind
+        // it was a false block start, so the piece in front ran on to the next REAL boundary e), the walk jumps to the
+        // next candidate to collect the other breaks of this round too; then every gap [e, next candidate) is cut at
+        // block starts found inside it and all the pieces are decoded at once — a gap costs a round of short decodes,
+        // not a chunk-long decode by one wavefront (measured: 72 ms per gap on a 1 GB file before).
+        const uint64_t sub_bits = 8ull * std::max<uint64_t>(32768, std::min<uint64_t>(chunk_bytes / 8, 65536));
+        const int max_rounds = (int)starts.size() + 8;  // every false block start can break the chain once
+        uint64_t last_first_break = 0;
+        for (int rounds = 0;; rounds++) {
+            co.clear();
+            total = 0;
+            std::vector<std::pair<uint64_t, uint64_t>> gaps;  // [e, next candidate or 0 = end of stream)
+            uint64_t refit = ~0ull;                             // a piece whose output did not fit
+            bool done = false;
+            for (uint64_t e = 0;;) {
+                auto it = decoded.find(e);
+                if (it == decoded.end()) {
+                    auto nxt = std::upper_bound(starts.begin(), starts.end(), e);
+                    gaps.emplace_back(e, nxt == starts.end() ? 0 : *nxt);
+                    if (nxt == starts.end()) break;
+                    e = *nxt;
+                    continue;
+                }
+                const Piece &pc = it->second;
+                if (pc.st.code == 4) {
+                    if (gaps.empty()) refit = e;
+                    break;
+                }
+                if (pc.st.code) {
+                    if (!gaps.empty()) break;  // behind a break the walk is only a guess: settle the gaps first
+                    set_error("corrupt deflate stream (code %u at bit %llu)", pc.st.code, (unsigned long long)e);
                     return EXG_E_PARSE;
                 }
-                auto nxt = std::upper_bound(starts.begin(), starts.end(), e);
-                const std::vector<std::pair<uint64_t, uint64_t>> span = {{e, nxt == starts.end() ? 0 : *nxt}};
-                ST_TRACE("[exg] inflate stream: chain stands at bit %llu (%s)\n", (unsigned long long)e,
-                         it == decoded.end() ? "no piece starts here" : "output did not fit");
-                uint64_t exact = 0;
-                if (it != decoded.end()) {
-                    InflateJobStatus m;
-                    int rc = run_jobs(span, 0, 0, true, &m);
-                    if (rc) return rc;
-                    if (m.code) {
-                        set_error("corrupt deflate stream (code %u after bit %llu)", m.code, (unsigned long long)e);
-                        return EXG_E_PARSE;
-                    }
-                    exact = m.produced + 64;
+                if (gaps.empty()) {
+                    co.push_back(ChunkOut{pc.sym, pc.st.produced, total});
+                    total += pc.st.produced;
+                    end_bit = pc.st.end_bit;
                 }
-                int rc = run_jobs(span, 8, exact, false, nullptr);
+                if (pc.st.final_block) {
+                    done = gaps.empty();
+                    break;
+                }
+                if (pc.st.end_bit <= e) {
+                    if (!gaps.empty()) break;
+                    set_error("exg_inflate_stream: no progress at bit %llu", (unsigned long long)e);
+                    return EXG_E_PARSE;
+                }
+                e = pc.st.end_bit;
+            }
+            if (done) break;
+            const uint64_t first_break = gaps.empty() ? refit : gaps[0].first;
+            if (rounds >= max_rounds || (rounds && first_break <= last_first_break && refit == ~0ull)) {
+                set_error("corrupt deflate stream (the chunk chain does not settle after bit %llu)", (unsigned long long)first_break);
+                return EXG_E_PARSE;
+            }
+            last_first_break = first_break;
+            if (refit != ~0ull) {
+                // An output that did not fit is first MEASURED (decoded without storing), then decoded into a buffer of
+                // that size: growing the buffer blindly would re-decode again and again — on a corrupt stream for minutes.
+                ST_TRACE("[exg] inflate stream: chain stands at bit %llu (output did not fit)\n", (unsigned long long)refit);
+                const std::vector<std::pair<uint64_t, uint64_t>> span = {{refit, decoded[refit].stop_bit}};
+                InflateJobStatus m;
+                int rc = run_jobs(span, 0, 0, true, &m);
                 if (rc) return rc;
-                if (exact && decoded[e].st.code == 4) {
+                if (m.code) {
+                    set_error("corrupt deflate stream (code %u after bit %llu)", m.code, (unsigned long long)refit);
+                    return EXG_E_PARSE;
+                }
+                rc = run_jobs(span, 8, m.produced + 64, false, nullptr);
+                if (rc) return rc;
+                if (decoded[refit].st.code == 4) {
                     set_error("exg_inflate_stream: a chunk produced more than its measured size");
                     return EXG_E_PARSE;
                 }
                 continue;
             }
-            const Piece &pc = it->second;
-            if (pc.st.code) {
-                set_error("corrupt deflate stream (code %u at bit %llu)", pc.st.code, (unsigned long long)e);
+            // cut the gaps
+            std::vector<std::pair<uint64_t, uint64_t>> ranges;
+            for (auto &g : gaps) {
+                const uint64_t g_end = g.second ? g.second : total_bits;
+                for (uint64_t b = g.first + sub_bits; b + sub_bits / 2 < g_end; b += sub_bits)
+                    ranges.emplace_back(b, std::min<uint64_t>(b + sub_bits, g_end));
+            }
+            std::vector<uint64_t> fresh;
+            for (auto &g : gaps) fresh.push_back(g.first);
+            if (!ranges.empty()) {
+                std::vector<uint64_t> found;
+                int rc = find_starts(ranges, &found);
+                if (rc) return rc;
+                for (uint64_t f : found)
+                    if (f != ~0ull) fresh.push_back(f);
+            }
+            std::sort(fresh.begin(), fresh.end());
+            fresh.erase(std::unique(fresh.begin(), fresh.end()), fresh.end());
+            {
+                std::vector<uint64_t> merged;
+                std::set_union(starts.begin(), starts.end(), fresh.begin(), fresh.end(), std::back_inserter(merged));
+                starts.swap(merged);
+            }
+            std::vector<std::pair<uint64_t, uint64_t>> spans;
+            for (uint64_t f : fresh) {
+                if (decoded.count(f)) continue;
+                auto nxt = std::upper_bound(starts.begin(), starts.end(), f);
+                spans.emplace_back(f, nxt == starts.end() ? 0 : *nxt);
+            }
+            ST_TRACE("[exg] inflate stream: %zu break(s) in the chain, first at bit %llu: %zu piece(s) to decode\n", gaps.size(),
+                     (unsigned long long)gaps[0].first, spans.size());
+            if (spans.empty()) {
+                set_error("exg_inflate_stream: the chain breaks at bit %llu although a piece starts there", (unsigned long long)gaps[0].first);
                 return EXG_E_PARSE;
             }
-            co.push_back(ChunkOut{pc.sym, pc.st.produced, total});
-            total += pc.st.produced;
-            end_bit = pc.st.end_bit;
-            if (pc.st.final_block) break;
-            if (pc.st.end_bit <= e) {
-                set_error("exg_inflate_stream: no progress at bit %llu", (unsigned long long)e);
-                return EXG_E_PARSE;
-            }
-            e = pc.st.end_bit;
+            int rc = run_jobs(spans, 8, 0, false, nullptr);
+            if (rc) return rc;
         }
     }
     // ---- 4 + 5. windows, then bytes

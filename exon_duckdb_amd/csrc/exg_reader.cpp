@@ -126,9 +126,28 @@ int list_files(exg_reader *r, const std::string &path) {
     return EXG_OK;
 }
 
+static double now_s() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + ts.tv_nsec * 1e-9;
+}
+static bool trace_on() {
+    static int on = getenv("EXG_TRACE") ? 1 : 0;
+    return on;
+}
+#define TRACE(label, t0)                                                            \
+    do {                                                                            \
+        if (trace_on()) fprintf(stderr, "[exg] %-22s %.1f ms\n", label, (now_s() - (t0)) * 1e3); \
+    } while (0)
+
 // gzip input: H2D the compressed bytes, inflate every member on the device (exg_inflate.hip), keep the
 // inflated bytes in HBM for the scan and bring one copy back for the DataChunk payload.
 int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::string &path) {
+    double t_all = now_s();
+    struct TraceAll {
+        double t0;
+        ~TraceAll() { TRACE("gz: inflate_file total", t0); }
+    } trace_all{t_all};
     const uint8_t *comp = (const uint8_t *)blk->p;
     const uint64_t n = blk->n;
     if (n == 0) return fail(r, EXG_E_PARSE, "empty gzip file '" + path + "'");
@@ -138,8 +157,13 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
         void *p;
         ~Free() { if (p) (void)hipFree(p); }
     } free_comp{d_comp};
+    double t_h2d = now_s();
     RD_HIP(r, hipMemcpyAsync(d_comp, comp, n, hipMemcpyHostToDevice, r->stream));
-    std::vector<exg_inflate_member> members(std::max<uint64_t>(16, n / 18 + 4));
+    if (trace_on()) (void)hipStreamSynchronize(r->stream);
+    TRACE("gz: h2d compressed", t_h2d);
+    // worst case one member per 18 bytes; NOT value-initialised (a 0.5 GB file would zero 1 GB here: measured 240 ms)
+    const uint64_t members_cap = std::max<uint64_t>(16, n / 18 + 4);
+    std::unique_ptr<exg_inflate_member[]> members(new exg_inflate_member[members_cap]);
     uint64_t out_cap_total = 0, produced_total = 0;
     void *d_out = nullptr;
     uint64_t d_out_cap = 0;
@@ -147,7 +171,9 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
     while (start < n) {
         uint64_t k = 0, total = produced_total;
         int open_ended = 0;
-        int rc = exg_gzip_index(comp, n, start, members.data(), members.size(), &k, &total, &open_ended);
+        double t_idx = now_s();
+        int rc = exg_gzip_index(comp, n, start, members.get(), members_cap, &k, &total, &open_ended);
+        TRACE("gz: member index", t_idx);
         if (rc) return fail(r, rc, std::string(exg_last_error_message()) + " in '" + path + "'");
         if (k == 0) break;
         // one big member of unknown size (what gzip / pigz write): per-member parallelism would put the whole file
@@ -185,13 +211,15 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
         RD_HIP(r, hipMalloc(&d_members, k * sizeof(exg_inflate_member)));
         RD_HIP(r, hipMalloc(&d_status, k * sizeof(exg_inflate_status)));
         Free fm{d_members}, fs{d_status};
-        RD_HIP(r, hipMemcpyAsync(d_members, members.data(), k * sizeof(exg_inflate_member), hipMemcpyHostToDevice, r->stream));
+        RD_HIP(r, hipMemcpyAsync(d_members, members.get(), k * sizeof(exg_inflate_member), hipMemcpyHostToDevice, r->stream));
+        double t_inf = now_s();
         rc = exg_inflate_members(d_comp, d_out, (const exg_inflate_member *)d_members, (exg_inflate_status *)d_status,
                                  (uint32_t)k, r->stream);
         if (rc) return fail(r, rc, exg_last_error_message());
         std::vector<exg_inflate_status> st(k);
         RD_HIP(r, hipMemcpyAsync(st.data(), d_status, k * sizeof(exg_inflate_status), hipMemcpyDeviceToHost, r->stream));
         RD_HIP(r, hipStreamSynchronize(r->stream));
+        TRACE("gz: inflate members", t_inf);
         for (uint64_t i = 0; i < k; i++) {
             const bool sized = !(open_ended && i + 1 == k);
             if (st[i].code || (sized && st[i].produced != members[i].out_cap)) {
@@ -212,6 +240,7 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
     }
     // host copy of the inflated bytes: this is what the string_t payload pointers address
     // (the copy itself is made by the first batch that hands out columns: COUNT(*) never needs it)
+    double t_pin = now_s();
     auto out_blk = std::make_shared<PinnedBlock>();
     out_blk->n = produced_total;
     size_t blk_cap = produced_total + 64;
@@ -221,6 +250,7 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
     out_blk->pooled = true;
     if (d_out) RD_HIP(r, hipMemsetAsync((char *)d_out + produced_total, 0, 64, r->stream));
     RD_HIP(r, hipStreamSynchronize(r->stream));
+    TRACE("gz: pinned host block", t_pin);
     r->gz_host_pending = true;
     if (r->format == EXG_FMT_VCF) {  // the header is parsed on the host right away
         RD_HIP(r, hipMemcpyAsync(out_blk->p, d_out, produced_total + 64, hipMemcpyDeviceToHost, r->stream));
@@ -232,20 +262,6 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
     r->d_file_bytes = produced_total;
     return EXG_OK;
 }
-
-static double now_s() {
-    struct timespec ts;
-    clock_gettime(CLOCK_MONOTONIC, &ts);
-    return ts.tv_sec + ts.tv_nsec * 1e-9;
-}
-static bool trace_on() {
-    static int on = getenv("EXG_TRACE") ? 1 : 0;
-    return on;
-}
-#define TRACE(label, t0)                                                            \
-    do {                                                                            \
-        if (trace_on()) fprintf(stderr, "[exg] %-22s %.1f ms\n", label, (now_s() - (t0)) * 1e3); \
-    } while (0)
 
 int open_next_file(exg_reader *r) {
     const std::string &p = r->files[r->file_idx++];
