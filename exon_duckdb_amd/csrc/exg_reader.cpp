@@ -140,6 +140,21 @@ static bool trace_on() {
         if (trace_on()) fprintf(stderr, "[exg] %-22s %.1f ms\n", label, (now_s() - (t0)) * 1e3); \
     } while (0)
 
+// pinned host block for the inflated bytes of the current file + the copy back (enqueued on r->stream)
+static int gz_host_copy(exg_reader *r) {
+    double t_pin = now_s();
+    PinnedBlock &b = *r->file;
+    size_t cap = b.n + 64;
+    b.p = global_pool()->take(&cap);
+    if (!b.p) return fail(r, EXG_E_HIP, "out of pinned host memory for the inflated bytes");
+    b.cap = cap;
+    b.pooled = true;
+    TRACE("gz: pinned host block", t_pin);
+    RD_HIP(r, hipMemcpyAsync(b.p, r->d_file, r->d_file_bytes + 64, hipMemcpyDeviceToHost, r->stream));
+    r->gz_host_pending = false;
+    return EXG_OK;
+}
+
 // gzip input: H2D the compressed bytes, inflate every member on the device (exg_inflate.hip), keep the
 // inflated bytes in HBM for the scan and bring one copy back for the DataChunk payload.
 int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::string &path) {
@@ -238,28 +253,22 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
             start = n;
         }
     }
-    // host copy of the inflated bytes: this is what the string_t payload pointers address
-    // (the copy itself is made by the first batch that hands out columns: COUNT(*) never needs it)
-    double t_pin = now_s();
+    // host copy of the inflated bytes: this is what the string_t payload pointers address.  Block and copy are
+    // made by the first batch that hands out columns (gz_host_copy): COUNT(*) never needs them.
     auto out_blk = std::make_shared<PinnedBlock>();
     out_blk->n = produced_total;
-    size_t blk_cap = produced_total + 64;
-    out_blk->p = global_pool()->take(&blk_cap);
-    if (!out_blk->p) return fail(r, EXG_E_HIP, "out of pinned host memory for the inflated bytes");
-    out_blk->cap = blk_cap;
-    out_blk->pooled = true;
     if (d_out) RD_HIP(r, hipMemsetAsync((char *)d_out + produced_total, 0, 64, r->stream));
     RD_HIP(r, hipStreamSynchronize(r->stream));
-    TRACE("gz: pinned host block", t_pin);
     r->gz_host_pending = true;
-    if (r->format == EXG_FMT_VCF) {  // the header is parsed on the host right away
-        RD_HIP(r, hipMemcpyAsync(out_blk->p, d_out, produced_total + 64, hipMemcpyDeviceToHost, r->stream));
-        RD_HIP(r, hipStreamSynchronize(r->stream));
-        r->gz_host_pending = false;
-    }
     blk = out_blk;
     r->d_file = d_out;
     r->d_file_bytes = produced_total;
+    if (r->format == EXG_FMT_VCF) {  // the header is parsed on the host right away
+        r->file = blk;
+        int rc = gz_host_copy(r);
+        if (rc) return rc;
+        RD_HIP(r, hipStreamSynchronize(r->stream));
+    }
     return EXG_OK;
 }
 
@@ -454,16 +463,13 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         // H2D copy.  In the first two cases the batch start is only byte aligned: the buffer starts at the
         // 16-byte boundary below it and `lead` skips the tail of the previous record (whose last '\n' is
         // then inside the buffer).
-        const uint8_t *h = (const uint8_t *)r->file->p + r->file_pos;
+        // (the Arrow stream builds its value buffers on the device: it never needs the host copy either)
+        if (r->d_file && r->gz_host_pending && !count_only && !r->arrow_emit && (rc = gz_host_copy(r))) return rc;
+        const uint8_t *h = (const uint8_t *)r->file->p + r->file_pos;  // gzip + COUNT(*): no host copy, h is never read
         const void *d_input = nullptr;
         uint64_t lead = 0;
         uint64_t batch_end = r->file_pos + n;  // file offset one past the bytes of this batch
         if (r->d_file) {
-            if (r->gz_host_pending && !count_only) {
-                // host copy of the inflated bytes: this is what the string_t payload pointers address
-                RD_HIP(r, hipMemcpyAsync(r->file->p, r->d_file, r->d_file_bytes + 64, hipMemcpyDeviceToHost, r->stream));
-                r->gz_host_pending = false;
-            }
             lead = r->file_pos & 15;
             d_input = (const uint8_t *)r->d_file + (r->file_pos - lead);
             h -= lead;
