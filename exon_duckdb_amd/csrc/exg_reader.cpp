@@ -140,19 +140,31 @@ static bool trace_on() {
         if (trace_on()) fprintf(stderr, "[exg] %-22s %.1f ms\n", label, (now_s() - (t0)) * 1e3); \
     } while (0)
 
-// pinned host block for the inflated bytes of the current file + the copy back (enqueued on r->stream)
-static int gz_host_copy(exg_reader *r) {
-    double t_pin = now_s();
-    PinnedBlock &b = *r->file;
-    size_t cap = b.n + 64;
-    b.p = global_pool()->take(&cap);
-    if (!b.p) return fail(r, EXG_E_HIP, "out of pinned host memory for the inflated bytes");
-    b.cap = cap;
-    b.pooled = true;
-    TRACE("gz: pinned host block", t_pin);
-    RD_HIP(r, hipMemcpyAsync(b.p, r->d_file, r->d_file_bytes + 64, hipMemcpyDeviceToHost, r->stream));
-    r->gz_host_pending = false;
-    return EXG_OK;
+// gzip + VCF: the header is parsed on the host, so the leading '#' lines of the inflated bytes come back
+// (blk->p then holds a prefix of the file, blk->n stays the inflated size; the DataChunk payload travels per batch)
+static int gz_host_header(exg_reader *r, PinnedBlock &b, const void *d_file) {
+    for (size_t want = 4u << 20;; want *= 8) {
+        const size_t len = std::min<size_t>(want, b.n);
+        if (b.p) global_pool()->give((char *)b.p, b.cap), b.p = nullptr;
+        size_t cap = len + 64;
+        b.p = global_pool()->take(&cap);
+        if (!b.p) return fail(r, EXG_E_HIP, "out of pinned host memory for the VCF header");
+        b.cap = cap;
+        b.pooled = true;
+        RD_HIP(r, hipMemcpyAsync(b.p, d_file, len, hipMemcpyDeviceToHost, r->stream));
+        RD_HIP(r, hipStreamSynchronize(r->stream));
+        // complete when a line that does not start with '#' begins inside the prefix (or the prefix is the file)
+        const char *d = (const char *)b.p;
+        size_t pos = 0;
+        while (pos < len && d[pos] == '#') {
+            const void *nl = memchr(d + pos, '\n', len - pos);
+            pos = nl ? (size_t)((const char *)nl - d) + 1 : len;
+        }
+        if (pos < len || len == b.n) {
+            r->gz_header_prefix = len;
+            return EXG_OK;
+        }
+    }
 }
 
 // gzip input: H2D the compressed bytes, inflate every member on the device (exg_inflate.hip), keep the
@@ -253,21 +265,20 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
             start = n;
         }
     }
-    // host copy of the inflated bytes: this is what the string_t payload pointers address.  Block and copy are
-    // made by the first batch that hands out columns (gz_host_copy): COUNT(*) never needs them.
+    // The inflated bytes stay in HBM.  What the string_t payload pointers address is a host copy made batch by
+    // batch (next_batch: one pooled pinned block per device batch, kept alive by its chunks) — COUNT(*) and the
+    // Arrow stream never need one; the block handed back here only knows the inflated size.
     auto out_blk = std::make_shared<PinnedBlock>();
     out_blk->n = produced_total;
     if (d_out) RD_HIP(r, hipMemsetAsync((char *)d_out + produced_total, 0, 64, r->stream));
     RD_HIP(r, hipStreamSynchronize(r->stream));
-    r->gz_host_pending = true;
     blk = out_blk;
     r->d_file = d_out;
     r->d_file_bytes = produced_total;
-    if (r->format == EXG_FMT_VCF) {  // the header is parsed on the host right away
-        r->file = blk;
-        int rc = gz_host_copy(r);
+    r->gz_header_prefix = 0;
+    if (r->format == EXG_FMT_VCF && produced_total) {
+        int rc = gz_host_header(r, *blk, d_out);
         if (rc) return rc;
-        RD_HIP(r, hipStreamSynchronize(r->stream));
     }
     return EXG_OK;
 }
@@ -316,12 +327,13 @@ int open_next_file(exg_reader *r) {
     if (r->format == EXG_FMT_VCF) {
         // header = the leading '#' lines (noodles-vcf read_header); it must hold the #CHROM line
         const char *d = (const char *)blk->p;
+        const size_t hn = r->d_file ? (size_t)r->gz_header_prefix : blk->n;  // gzip: only the header prefix is on the host
         size_t pos = 0;
         bool chrom = false;
-        while (pos < blk->n && d[pos] == '#') {
-            if (blk->n - pos >= 6 && memcmp(d + pos, "#CHROM", 6) == 0) chrom = true;
-            const void *nl = memchr(d + pos, '\n', blk->n - pos);
-            pos = nl ? (size_t)((const char *)nl - d) + 1 : blk->n;
+        while (pos < hn && d[pos] == '#') {
+            if (hn - pos >= 6 && memcmp(d + pos, "#CHROM", 6) == 0) chrom = true;
+            const void *nl = memchr(d + pos, '\n', hn - pos);
+            pos = nl ? (size_t)((const char *)nl - d) + 1 : hn;
         }
         if (!chrom) return fail(r, EXG_E_PARSE, std::string(exg_parse_error_string(EXG_PE_VCF_NO_HEADER)) + " in '" + p + "'");
         r->vcf_header_bytes = pos;
@@ -463,17 +475,28 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         // H2D copy.  In the first two cases the batch start is only byte aligned: the buffer starts at the
         // 16-byte boundary below it and `lead` skips the tail of the previous record (whose last '\n' is
         // then inside the buffer).
-        // (the Arrow stream builds its value buffers on the device: it never needs the host copy either)
-        if (r->d_file && r->gz_host_pending && !count_only && !r->arrow_emit && (rc = gz_host_copy(r))) return rc;
-        const uint8_t *h = (const uint8_t *)r->file->p + r->file_pos;  // gzip + COUNT(*): no host copy, h is never read
+        const uint8_t *h = (const uint8_t *)r->file->p + r->file_pos;
         const void *d_input = nullptr;
         uint64_t lead = 0;
         uint64_t batch_end = r->file_pos + n;  // file offset one past the bytes of this batch
+        std::shared_ptr<PinnedBlock> gz_payload;  // gzip: this batch's inflated bytes on the host (string_t payload)
         if (r->d_file) {
             lead = r->file_pos & 15;
             d_input = (const uint8_t *)r->d_file + (r->file_pos - lead);
-            h -= lead;
             n += lead;
+            if (!count_only && !r->arrow_emit) {
+                gz_payload = std::make_shared<PinnedBlock>();
+                size_t cap = n + 64;
+                gz_payload->p = global_pool()->take(&cap);
+                if (!gz_payload->p) return fail(r, EXG_E_HIP, "out of pinned host memory for the inflated bytes");
+                gz_payload->cap = cap;
+                gz_payload->pooled = true;
+                gz_payload->n = n;
+                h = (const uint8_t *)gz_payload->p;
+            } else {
+                // COUNT(*) / the Arrow stream: no host copy; h is only the base the device subtracts again
+                h = (const uint8_t *)(uintptr_t)0x100000000000ull + (r->file_pos - lead);
+            }
         } else if (r->pf.valid && want == r->device_batch_bytes && r->file_pos >= r->pf.file_start &&
                    r->file_pos < r->pf.file_start + r->pf.len) {
             const uint64_t off = r->file_pos - r->pf.file_start;
@@ -657,7 +680,8 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         } else if (k && !count_only) {
             if (!b) b = std::make_shared<Batch>();
             b->host.reserve(r->host_hint);
-            b->file = r->file;
+            b->file = gz_payload ? gz_payload : r->file;
+            if (gz_payload) RD_HIP(r, hipMemcpyAsync(gz_payload->p, d_input, n, hipMemcpyDeviceToHost, r->stream));
             b->n_rows = k;
             const int ns = n_string_cols(r->format);
             // schema order (exg_schema_of): VCF exposes parsed POS / QUAL in place of their raw text

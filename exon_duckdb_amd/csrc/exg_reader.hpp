@@ -221,7 +221,7 @@ struct exg_reader {
     size_t host_hint = 0;  // pinned bytes the previous batch's host vectors needed
     std::vector<std::pair<void **, size_t>> dev_allocs;  // pooled device buffers of this reader (slot, bytes)
     int dev_alloc(void **slot, size_t bytes);
-    bool gz_host_pending = false;  // gzip: the host copy of the inflated bytes (the string_t payload) is not made yet
+    uint64_t gz_header_prefix = 0;  // gzip + VCF: bytes of the inflated file's start held in file->p (header parse)
     bool worst_case_rows = false;
     // exg_open_args.filters: postfix program + constants in device memory, a row map and one column of scratch
     bool has_filter = false;
