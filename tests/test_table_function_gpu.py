@@ -335,3 +335,28 @@ def test_filter_on_unknown_column_is_a_bind_time_error(gpu, golden_dir):
     r = C.c_void_p()
     assert lib.exg_open(C.byref(a), C.byref(r)) != 0
     assert b"could not execute sql" in lib.exg_last_error_message()
+
+
+def test_gzip_vcf_with_a_header_longer_than_the_first_host_prefix(con, oracle, tmp_path, monkeypatch):
+    # gzip + VCF: only the header prefix of the inflated bytes comes back to the host (4 MiB first, then more);
+    # the rows' payload travels batch by batch
+    import gzip
+
+    body = bytes(oracle.synth_vcf(3000))
+    lines = body.split(b"\n")
+    k = next(i for i, ln in enumerate(lines) if ln.startswith(b"#CHROM"))
+    filler = b"".join(b"##contig=<ID=scaffold_%07d,length=%d>\n" % (i, 1000 + i) for i in range(120_000))   # ~5.6 MB
+    assert len(filler) > (4 << 20)
+    data = b"\n".join(lines[:k]) + b"\n" + filler + b"\n".join(lines[k:])
+    exp = oracle.vcf_parse(data)
+    assert exp.error_code == 0 and exp.n_rows == 3000
+    (tmp_path / "long_header.vcf.gz").write_bytes(gzip.compress(data, 6, mtime=0))
+    (tmp_path / "long_header.vcf").write_bytes(data)
+    for batch in (None, "65536"):
+        if batch:
+            monkeypatch.setenv("EXG_DEVICE_BATCH_BYTES", batch)
+        plain = con.table_function("read_vcf", str(tmp_path / "long_header.vcf")).fetchall()
+        rel = con.table_function("read_vcf", str(tmp_path / "long_header.vcf.gz"))
+        assert rel.count() == 3000
+        assert rel.fetchall() == plain
+    assert plain[0][0] == exp.columns["chrom"].row(0)
