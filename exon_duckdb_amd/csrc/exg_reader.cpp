@@ -415,9 +415,10 @@ int upload_range(exg_reader *r, uint64_t off, uint64_t n, int slot, hipStream_t 
         TRACE("pinned staging", t0);
     }
     double t0 = now_s();
-    const size_t slice = 8u << 20;
+    static const size_t slice = getenv("EXG_IO_SLICE_MB") ? ((size_t)std::max(1, atoi(getenv("EXG_IO_SLICE_MB"))) << 20) : (8u << 20);
     const size_t n_slices = (n + slice - 1) / slice;
-    unsigned nt = (unsigned)std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), std::min<size_t>(n_slices, 8));
+    static const size_t max_io_threads = getenv("EXG_IO_THREADS") ? (size_t)std::max(1, atoi(getenv("EXG_IO_THREADS"))) : 8;
+    unsigned nt = (unsigned)std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), std::min<size_t>(n_slices, max_io_threads));
     std::atomic<size_t> next{0};
     std::atomic<int> bad{0};
     const int fd = r->fd_keep->fd;
