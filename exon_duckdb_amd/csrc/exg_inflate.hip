@@ -35,6 +35,8 @@ __global__ __launch_bounds__(64, RING <= 2048 ? 5 : 1) void k_inflate(const uint
         jb.out_cap = mb.out_cap;
         jb.start_bit = 0;
         jb.stop_bit = 0;
+        jb.text_probe = 0;
+        jb.pad = 0;
         inflate_job<false, RING>(s, d_comp, d_out, jb, &s_st);
         if (threadIdx.x == 0) {
             InflateStatus st;

@@ -16,7 +16,7 @@ struct InflateMember {
 
 struct InflateStatus {
     unsigned int code;             // 0 ok; 1 bad block type / stored len; 2 bad code lengths; 3 bad symbol or distance;
-                                   // 4 output overflow; 5 input exhausted
+                                   // 4 output overflow; 5 input exhausted; 6 not text (InflateJob::text_probe)
     unsigned int pad;
     unsigned long long produced;   // bytes written
     unsigned long long consumed;   // compressed bytes consumed (from comp_off, byte aligned after the final block)
@@ -326,6 +326,8 @@ struct InflateJob {
     unsigned long long out_cap;    // elements it may produce
     unsigned long long start_bit;  // first bit to decode, relative to comp_off (a block header)
     unsigned long long stop_bit;   // 0: decode to the final block; else stop at the first block boundary >= it
+    unsigned int text_probe;       // != 0: a literal that is a control character (not \t \n \r) ends the decode with code 6
+    unsigned int pad;
 };
 struct InflateJobStatus {
     unsigned int code;             // as InflateStatus
@@ -545,6 +547,13 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                         seg &= ~((1ull << from) - 1ull);
                     const uint32_t n = (uint32_t)__popcll(seg);
                     if (n) {
+                        if (mb.text_probe) {
+                            const bool ctl = ((seg >> lane) & 1ull) && (val < 9u || (val > 13u && val < 32u) || val == 127u);
+                            if (__ballot(ctl)) {
+                                err = 6;
+                                break;
+                            }
+                        }
                         if ((unsigned long long)pos + n > cap) {
                             err = 4;
                             break;

@@ -34,11 +34,18 @@ namespace exg {
 namespace {
 
 static constexpr uint32_t kProbeSymbols = 320;  // a candidate block start must decode this far without an error
+// Text streams (FASTA / FASTQ / VCF are): a false block start decodes garbage — literals spread over all 256 byte
+// values — so a control character among its literals gives it away within a few dozen symbols, while nothing else
+// does before its end-of-block code (a valid header makes random bits decode "validly", with the very symbol
+// statistics the code was built for: ~one real block's worth of work per false candidate, 14-68 ms of finder time
+// depending on which boundaries met one).  A candidate that decodes this many symbols of clean text is accepted.
+static constexpr uint32_t kTextProbeSymbols = 4096;
 
 // ---- 1. block finder ---------------------------------------------------------------------------------------------------
 struct FindJob {
     unsigned long long comp_off, comp_size;  // the stream
     unsigned long long from_bit, to_bit;     // search [from_bit, to_bit) relative to comp_off
+    unsigned int text, pad;                  // text != 0: the stream inflates to text (see kTextProbeSymbols)
 };
 
 // cheap per-lane filter on the 64 + 64 bits that start at a candidate offset: could a dynamic block begin here?
@@ -93,6 +100,21 @@ __global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ 
                 // follows it must again be a block that decodes (its header + the first kProbeSymbols symbols).
                 InflateJob jb;
                 jb.comp_off = fj.comp_off;
+                jb.text_probe = fj.text;
+                jb.pad = 0;
+                if (fj.text) {
+                    jb.comp_size = fj.comp_size;
+                    jb.out_off = 0;
+                    jb.out_cap = kTextProbeSymbols;
+                    jb.start_bit = base + l;
+                    jb.stop_bit = 0;
+                    inflate_job<true, 2048>(s, d_comp, (uint16_t *)nullptr, jb, &s_st);
+                    const uint32_t code = s_st.code;
+                    const bool fin = s_st.final_block != 0;
+                    __syncthreads();
+                    if (code == 4 || (code == 0 && fin)) result = base + l;  // clean text this far (or to the end of the stream)
+                    continue;
+                }
                 // a block longer than 128 KiB of input is not accepted as a chunk start (zlib closes a block after 16 Ki
                 // symbols: 20-60 KB of FASTQ): garbage behind a false header can run for millions of symbols before it
                 // meets an end-of-block code, and one such candidate holds the whole finder up (seen: 4.5 s without a
@@ -284,6 +306,7 @@ extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint6
     std::vector<uint64_t> starts;  // bit offsets of the chunk starts (sorted, unique); starts[0] = 0
     starts.push_back(0);
     // first block start in each [from, to) (bit ranges), ~0 where none was found
+    bool text_mode = !getenv("EXG_STREAM_NO_TEXT_PROBE");
     auto find_starts = [&](const std::vector<std::pair<uint64_t, uint64_t>> &ranges, std::vector<uint64_t> *found) -> int {
         std::vector<FindJob> fj(ranges.size());
         for (size_t k = 0; k < ranges.size(); k++) {
@@ -291,6 +314,8 @@ extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint6
             fj[k].comp_size = comp_size;
             fj[k].from_bit = ranges[k].first;
             fj[k].to_bit = ranges[k].second;
+            fj[k].text = text_mode ? 1u : 0u;
+            fj[k].pad = 0;
         }
         DevBuf d_fj, d_found, d_scratch;
         ST_HIP(d_fj.alloc(fj.size() * sizeof(FindJob)));
@@ -313,6 +338,17 @@ extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint6
         std::vector<uint64_t> found;
         int rc = find_starts(ranges, &found);
         if (rc) return rc;
+        if (text_mode) {
+            // not text after all (fewer than half of the boundaries found a start): validate by whole blocks instead
+            size_t hits = 0;
+            for (uint64_t f : found) hits += f != ~0ull;
+            if (hits * 2 < found.size()) {
+                ST_TRACE("[exg] inflate stream: only %zu of %zu boundaries have a text block start: binary search mode\n", hits, found.size());
+                text_mode = false;
+                rc = find_starts(ranges, &found);
+                if (rc) return rc;
+            }
+        }
         for (uint64_t f : found)
             if (f != ~0ull && f > starts.back()) starts.push_back(f);
         ST_TRACE("[exg] inflate stream: %u boundaries searched, %zu block starts found, %.1f ms\n", n_bound - 1, starts.size() - 1,
@@ -322,6 +358,20 @@ extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint6
     // starts exactly where the previous one ended.  A false block start is simply never reached (the chunk in front
     // of it runs on to the next real boundary); if that boundary is not a candidate either, the piece from there to
     // the next candidate is decoded in another round.
+    // Symbol buffer: cap_factor0 symbols per compressed byte and piece.  8 covers most text, but 16 B per compressed
+    // byte is 9 GB for a 0.5 GB file (and hipMalloc of that was seen to take 0.5 s): when the stream runs to the end
+    // of the buffer, the gzip trailer's ISIZE (mod 2^32) gives the real ratio; pieces that still overflow are refitted.
+    uint64_t cap_factor0 = 8;
+    if (comp_size >= 8) {
+        uint32_t isize = 0;
+        ST_HIP(hipMemcpyAsync(&isize, d_comp + comp_off + comp_size - 4, 4, hipMemcpyDeviceToHost, stream));
+        ST_HIP(hipStreamSynchronize(stream));
+        uint64_t est = isize;
+        while (est < comp_size) est += 1ull << 32;  // deflate does not expand text
+        const double ratio = (double)est / (double)comp_size;
+        if (ratio < 64.0) cap_factor0 = std::min<uint64_t>(8, std::max<uint64_t>(3, (uint64_t)(ratio * 1.5 + 1.0)));
+        ST_TRACE("[exg] inflate stream: ISIZE hints at ratio %.2f: %llu symbols per compressed byte\n", ratio, (unsigned long long)cap_factor0);
+    }
     struct Piece {
         InflateJobStatus st;
         const uint16_t *sym;
@@ -330,8 +380,9 @@ extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint6
     std::map<uint64_t, Piece> decoded;
     std::vector<std::unique_ptr<DevBuf>> sym_bufs;
     // exact_cap != 0: one job whose output size is known; measure_only: decode without storing (its size is the answer)
-    auto run_jobs = [&](const std::vector<std::pair<uint64_t, uint64_t>> &spans, uint64_t cap_factor, uint64_t exact_cap,
-                        bool measure_only, InflateJobStatus *measured) -> int {
+    auto run_jobs = [&](const std::vector<std::pair<uint64_t, uint64_t>> &spans, uint64_t cap_factor,
+                        const std::vector<uint64_t> *exact_caps, bool measure_only,
+                        std::vector<InflateJobStatus> *measured) -> int {
         const uint32_t n = (uint32_t)spans.size();
         std::vector<InflateJob> jobs(n);
         std::vector<uint64_t> off(n + 1, 0);
@@ -340,10 +391,10 @@ extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint6
             jobs[k].comp_off = comp_off;
             jobs[k].comp_size = comp_size;
             jobs[k].out_off = off[k];
-            jobs[k].out_cap = measure_only ? (comp_size - spans[k].first / 8) * 1032 + 65536 : exact_cap ? exact_cap : (end_bit - spans[k].first + 7) / 8 * cap_factor + 65536;
-            if (measure_only) continue;
+            jobs[k].out_cap = measure_only ? (comp_size - spans[k].first / 8) * 1032 + 65536 : exact_caps ? (*exact_caps)[k] : (end_bit - spans[k].first + 7) / 8 * cap_factor + 65536;
             jobs[k].start_bit = spans[k].first;
             jobs[k].stop_bit = spans[k].second;
+            if (measure_only) continue;
             off[k + 1] = off[k] + ((jobs[k].out_cap + 15) & ~15ull);
         }
         sym_bufs.emplace_back(new DevBuf());
@@ -376,7 +427,7 @@ extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint6
         ST_HIP(hipMemcpyAsync(st.data(), d_st.p, n * sizeof(InflateJobStatus), hipMemcpyDeviceToHost, stream));
         ST_HIP(hipStreamSynchronize(stream));
         if (measure_only) {
-            *measured = st[0];
+            *measured = st;
             return EXG_OK;
         }
         for (uint32_t k = 0; k < n; k++) decoded[spans[k].first] = Piece{st[k], (const uint16_t *)d_sym.p + off[k], spans[k].second};
@@ -386,7 +437,7 @@ extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint6
     {
         std::vector<std::pair<uint64_t, uint64_t>> spans;
         for (size_t k = 0; k < starts.size(); k++) spans.emplace_back(starts[k], k + 1 < starts.size() ? starts[k + 1] : 0);
-        int rc = run_jobs(spans, 8, 0, false, nullptr);
+        int rc = run_jobs(spans, cap_factor0, nullptr, false, nullptr);
         if (rc) return rc;
     }
     std::vector<ChunkOut> co;
@@ -449,18 +500,26 @@ extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint6
             }
             last_first_break = first_break;
             if (refit != ~0ull) {
-                // An output that did not fit is first MEASURED (decoded without storing), then decoded into a buffer of
-                // that size: growing the buffer blindly would re-decode again and again — on a corrupt stream for minutes.
-                ST_TRACE("[exg] inflate stream: chain stands at bit %llu (output did not fit)\n", (unsigned long long)refit);
-                const std::vector<std::pair<uint64_t, uint64_t>> span = {{refit, decoded[refit].stop_bit}};
-                InflateJobStatus m;
-                int rc = run_jobs(span, 0, 0, true, &m);
+                // Outputs that did not fit (every such piece at once) are first MEASURED (decoded without storing), then
+                // decoded into buffers of those sizes: growing a buffer blindly would re-decode again and again — on a
+                // corrupt stream for minutes.
+                std::vector<std::pair<uint64_t, uint64_t>> spans;
+                for (auto &kv : decoded)
+                    if (kv.second.st.code == 4) spans.emplace_back(kv.first, kv.second.stop_bit);
+                ST_TRACE("[exg] inflate stream: chain stands at bit %llu (output did not fit; %zu such piece(s))\n",
+                         (unsigned long long)refit, spans.size());
+                std::vector<InflateJobStatus> m;
+                int rc = run_jobs(spans, 0, nullptr, true, &m);
                 if (rc) return rc;
-                if (m.code) {
-                    set_error("corrupt deflate stream (code %u after bit %llu)", m.code, (unsigned long long)refit);
-                    return EXG_E_PARSE;
+                std::vector<uint64_t> caps(spans.size());
+                for (size_t k = 0; k < spans.size(); k++) {
+                    if (m[k].code && spans[k].first == refit) {
+                        set_error("corrupt deflate stream (code %u after bit %llu)", m[k].code, (unsigned long long)refit);
+                        return EXG_E_PARSE;
+                    }
+                    caps[k] = m[k].produced + 64;
                 }
-                rc = run_jobs(span, 8, m.produced + 64, false, nullptr);
+                rc = run_jobs(spans, 0, &caps, false, nullptr);
                 if (rc) return rc;
                 if (decoded[refit].st.code == 4) {
                     set_error("exg_inflate_stream: a chunk produced more than its measured size");
@@ -503,7 +562,7 @@ extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint6
                 set_error("exg_inflate_stream: the chain breaks at bit %llu although a piece starts there", (unsigned long long)gaps[0].first);
                 return EXG_E_PARSE;
             }
-            int rc = run_jobs(spans, 8, 0, false, nullptr);
+            int rc = run_jobs(spans, cap_factor0, nullptr, false, nullptr);
             if (rc) return rc;
         }
     }

@@ -50,7 +50,14 @@ def payloads(oracle):
     words = np.array([b"alpha", b"beta", b"gamma", b"delta", b"ACGT", b"\t", b"\n", b"0.125", b"PASS", b"rs"], dtype=object)
     mix = b"".join(words[rng.integers(0, len(words), 2_000_000)])
     noisy = bytes(rng.integers(0, 256, 3_000_000, dtype=np.uint8)) + fq[:3_000_000]   # stored blocks, then dynamic
-    return {"fastq": fq, "vcf": vcf, "text": text, "mix": mix, "noisy": noisy}
+    # compressible but NOT text (dynamic blocks whose literals are control bytes): the block finder's text probe
+    # finds no start, the search falls back to whole-block validation
+    binary = (np.arange(3_000_000, dtype=np.uint32) // 7 * 2654435761 % 1000).astype(np.uint16).tobytes()
+    # text with a few control / non-ASCII bytes sprinkled in (legal UTF-8 in a description, a stray 0x01)
+    dirty = bytearray(fq[:6_000_000])
+    for k in range(0, len(dirty), 50_021):
+        dirty[k] = (0x01, 0xC3, 0xA9, 0x7F)[(k // 50_021) % 4]
+    return {"fastq": fq, "vcf": vcf, "text": text, "mix": mix, "noisy": noisy, "binary": binary, "dirty": bytes(dirty)}
 
 
 @pytest.fixture(scope="module")
@@ -58,7 +65,7 @@ def data(oracle):
     return payloads(oracle)
 
 
-@pytest.mark.parametrize("name", ["fastq", "vcf", "text", "mix", "noisy"])
+@pytest.mark.parametrize("name", ["fastq", "vcf", "text", "mix", "noisy", "binary", "dirty"])
 @pytest.mark.parametrize("level", [1, 6, 9])
 def test_stream_against_zlib(gpu, data, name, level):
     payload = data[name]
