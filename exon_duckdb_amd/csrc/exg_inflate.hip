@@ -20,7 +20,7 @@
 #include "exg_inflate_core.hpp"
 
 namespace exg {
-template <uint32_t RING>
+template <uint32_t RING, int EMIT>
 __global__ __launch_bounds__(64, RING <= 2048 ? 5 : 1) void k_inflate(const uint8_t *__restrict__ d_comp, uint8_t *d_out,
                                                 const InflateMember *__restrict__ members, InflateStatus *status,
                                                 uint32_t n_members) {
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(64, RING <= 2048 ? 5 : 1) void k_inflate(const uint
         jb.stop_bit = 0;
         jb.text_probe = 0;
         jb.pad = 0;
-        inflate_job<false, RING>(s, d_comp, d_out, jb, &s_st);
+        inflate_job<false, RING, EMIT>(s, d_comp, d_out, jb, &s_st);
         if (threadIdx.x == 0) {
             InflateStatus st;
             st.code = s_st.code;
@@ -69,15 +69,18 @@ extern "C" int exg_inflate_members(const void *d_comp, void *d_out, const exg_in
         const char *e = getenv("EXG_INFLATE_RING");  // A/B switch: LDS ring elements (32768 = the whole window in LDS)
         return e ? atoi(e) : 2048;
     }();
-#define EXG_LAUNCH_INFLATE(R)                                                                                          \
-    hipLaunchKernelGGL(exg::k_inflate<R>, dim3(grid), dim3(64), 0, (hipStream_t)stream, (const uint8_t *)d_comp,       \
+    static const int emit = getenv("EXG_INFLATE_EMIT") ? atoi(getenv("EXG_INFLATE_EMIT")) : 1;  // A/B switch (0 = first form)
+#define EXG_LAUNCH_INFLATE(R, E)                                                                                       \
+    hipLaunchKernelGGL((exg::k_inflate<R, E>), dim3(grid), dim3(64), 0, (hipStream_t)stream, (const uint8_t *)d_comp,  \
                        (uint8_t *)d_out, (const exg::InflateMember *)d_members, (exg::InflateStatus *)d_status, n_members)
-    switch (ring) {
-        case 4096: EXG_LAUNCH_INFLATE(4096); break;
-        case 8192: EXG_LAUNCH_INFLATE(8192); break;
-        case 16384: EXG_LAUNCH_INFLATE(16384); break;
-        case 32768: EXG_LAUNCH_INFLATE(32768); break;
-        default: EXG_LAUNCH_INFLATE(2048); break;
+    if (emit == 0) {
+        EXG_LAUNCH_INFLATE(2048, 0);
+    } else {
+        switch (ring) {
+            case 4096: EXG_LAUNCH_INFLATE(4096, 1); break;
+            case 32768: EXG_LAUNCH_INFLATE(32768, 1); break;
+            default: EXG_LAUNCH_INFLATE(2048, 1); break;
+        }
     }
 #undef EXG_LAUNCH_INFLATE
     EXG_HIP_CHECK(hipGetLastError());

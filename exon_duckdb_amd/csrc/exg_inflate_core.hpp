@@ -292,28 +292,51 @@ __device__ __forceinline__ void flush_segments(L &s, typename L::Elem *out, unsi
     if (L::kGlobalWindow && any && out) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 }
 
-// LZ77 copy of `len` elements from `dist` back, all lanes; the source index is folded into [pos - dist, pos) so
-// overlapping copies are exact
+// LZ77 copy of `len` elements from `dist` back to position `pos`, all lanes; the source index is folded into
+// [pos - dist, pos) so overlapping copies are exact.  `hi` = one past the highest position written to the ring so far
+// (>= pos + len): a ring slot still holds position p iff p + RING >= hi; anything older was flushed to HBM.
 template <class L>
 __device__ __forceinline__ void copy_match(L &s, typename L::Elem *out, unsigned long long out_off, uint32_t pos, uint32_t len,
-                                           uint32_t dist, uint32_t lane) {
+                                           uint32_t dist, uint32_t hi, uint32_t lane) {
     using Elem = typename L::Elem;
     constexpr bool SYM = sizeof(Elem) == 2;
     if (L::kGlobalWindow && !out) return;  // probing decode: the output never steers the decode
+    // the common shape — one pass, no overlap, the whole source on one side of the ring — decided on the scalar unit
+    if (dist >= len && len <= 64 && pos >= dist) {
+        const uint32_t src0 = pos - dist;
+        if (!L::kGlobalWindow || src0 + L::kRing >= hi) {
+            if (lane < len) {
+                const Elem x = s.win[(src0 + lane) & (L::kRing - 1)];
+                s.win[(pos + lane) & (L::kRing - 1)] = x;
+            }
+            return;
+        }
+        if (src0 + len - 1 + L::kRing < hi) {
+            if (lane < len) {
+                const Elem x = __hip_atomic_load(out + out_off + src0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                s.win[(pos + lane) & (L::kRing - 1)] = x;
+            }
+            return;
+        }
+    }
     for (uint32_t i = lane; i < len; i += 64) {
         const long long src = (long long)pos - (long long)dist + (long long)(dist >= len ? i : i % dist);
         Elem x;
         if (SYM && src < 0) {  // a byte of the 32 KiB in front of this decode: named, resolved later
             x = (Elem)(0x8000u | (uint32_t)(32768 + src));
-        } else if (!L::kGlobalWindow || (uint32_t)src + L::kRing >= pos + len) {
+        } else if (!L::kGlobalWindow || (uint32_t)src + L::kRing >= hi) {
             x = s.win[(uint32_t)src & (L::kRing - 1)];
         } else {
-            // older than the ring: flushed at least 1 KiB ago (src < pos + 258 - kRing < flushed)
+            // older than the ring: flushed at least 1 KiB ago (src < hi - kRing < flushed)
             x = __hip_atomic_load(out + out_off + (uint32_t)src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         s.win[(pos + i) & (L::kRing - 1)] = x;
     }
 }
+
+// a speculative step emits at most kStepOut elements + one match: with the flush lag of < 1 KiB the ring (>= 2 Ki)
+// never wraps onto elements that are not flushed yet
+static constexpr uint32_t kStepOut = 512;
 
 // token kinds of the speculative decode
 static constexpr uint32_t kLit = 0, kMatch = 1, kEob = 2, kSlow = 3, kBad = 4;
@@ -336,7 +359,10 @@ struct InflateJobStatus {
     unsigned long long end_bit;    // bit after the last decoded block, relative to comp_off
 };
 
-template <bool SYM, uint32_t RING = kWinBytes>
+// EMIT = 1: the tokens of a step are placed by a prefix sum over their output lengths (all literals in one store,
+//           then the matches in order); EMIT = 0: literal runs and matches one after the other (the first form, kept
+//           as the A/B partner).
+template <bool SYM, uint32_t RING = kWinBytes, int EMIT = 1>
 __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uint8_t *__restrict__ d_comp,
                                             typename InflateLdsT<SYM, RING>::Elem *d_out, const InflateJob mb,
                                             InflateJobStatus *st_out) {
@@ -532,11 +558,70 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                     marks |= 1ull << cur;
                     cur += t;
                 }
+                uint32_t advance = cur;
+                if constexpr (EMIT == 1) {
+                    // ---- placement by prefix sum ---------------------------------------------------------------
+                    const bool real = (marks >> lane) & 1ull;
+                    const unsigned long long m_stop = __ballot(real && (kind == kEob || kind == kBad));
+                    const uint32_t stop_lane = m_stop ? (uint32_t)__ffsll((long long)m_stop) - 1 : 64u;
+                    const bool live = real && lane < stop_lane;  // literals and matches in front of an end-of-block
+                    const uint32_t olen = live ? (kind == kLit ? 1u : (val & 0xFFFFu)) : 0u;
+                    const uint32_t incl = wave_incl_sum_dpp(olen);
+                    const uint32_t excl = incl - olen;
+                    const bool keep = live && excl < kStepOut;
+                    const unsigned long long m_keep = __ballot(keep);
+                    const unsigned long long m_drop = __ballot(live) & ~m_keep;  // pushed to the next step
+                    const uint32_t total = m_keep ? __builtin_amdgcn_readlane(incl, 63 - __clzll((long long)m_keep)) : 0u;
+                    if ((unsigned long long)pos + total > cap) {
+                        err = 4;
+                        break;
+                    }
+                    if (mb.text_probe) {
+                        const bool ctl = keep && kind == kLit && (val < 9u || (val > 13u && val < 32u) || val == 127u);
+                        if (__ballot(ctl)) {
+                            err = 6;
+                            break;
+                        }
+                    }
+                    const uint32_t hi = pos + total;
+                    if (keep && kind == kLit) s.win[(pos + excl) & kRingMask] = (Elem)val;
+                    unsigned long long m_match = __ballot(keep && kind == kMatch);
+                    while (m_match) {
+                        const uint32_t l = (uint32_t)__ffsll((long long)m_match) - 1;
+                        m_match &= m_match - 1;
+                        const uint32_t x = __builtin_amdgcn_readlane(val, l);
+                        const uint32_t dest = pos + __builtin_amdgcn_readlane(excl, l);
+                        const uint32_t len = x & 0xFFFFu, dist = x >> 16;
+                        if (!SYM && dist > dest) {
+                            err = 3;
+                            break;
+                        }
+                        // everything below `dest` is complete (literals were placed first): flush it, so that what the
+                        // copy reads from HBM is there
+                        if (flushed + 1024 <= dest) flush_segments(s, d_out, mb.out_off, flushed, dest, lane);
+                        copy_match(s, d_out, mb.out_off, dest, len, dist, hi, lane);
+                    }
+                    if (err) break;
+                    pos = hi;
+                    if (flushed + 1024 <= pos) flush_segments(s, d_out, mb.out_off, flushed, pos, lane);
+                    if (m_drop) {
+                        advance = (uint32_t)__ffsll((long long)m_drop) - 1;
+                        slow_token = false;
+                    } else if (stop_lane < 64) {
+                        if (__builtin_amdgcn_readlane(kind, stop_lane) == kEob) {
+                            advance = stop_lane + __builtin_amdgcn_readlane(tl, stop_lane);
+                            eob = true;
+                        } else {
+                            err = 3;
+                            break;
+                        }
+                    }
+                } else {
                 // ... then runs of literals go out in ONE step (rank = popcount of the marks below the lane);
                 // only matches / end-of-block / bad codes are handled one at a time, in order
                 const unsigned long long m_lit = __ballot(kind == kLit) & marks;
                 unsigned long long m_other = marks & ~m_lit;
-                uint32_t from = 0, advance = cur;
+                uint32_t from = 0;
                 for (;;) {
                     const uint32_t upto = m_other ? (uint32_t)__ffsll((long long)m_other) - 1 : 64u;
                     unsigned long long seg = m_lit;
@@ -573,7 +658,7 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                             err = (!SYM && dist > pos) ? 3 : 4;
                             break;
                         }
-                        copy_match(s, d_out, mb.out_off, pos, len, dist, lane);
+                        copy_match(s, d_out, mb.out_off, pos, len, dist, pos + len, lane);
                         uint32_t np = pos + len;
                         if ((np >> 10) != (pos >> 10)) flush_segments(s, d_out, mb.out_off, flushed, np, lane);
                         pos = np;
@@ -587,6 +672,7 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                     }
                     m_other &= m_other - 1;
                     from = upto + 1;
+                }
                 }
                 br.bitpos += advance;
                 if (slow_token && !eob && !err) {
@@ -615,7 +701,7 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                             if ((!SYM && dist > pos) || (unsigned long long)pos + len > cap) {
                                 err = (!SYM && dist > pos) ? 3 : 4;
                             } else {
-                                copy_match(s, d_out, mb.out_off, pos, len, dist, lane);
+                                copy_match(s, d_out, mb.out_off, pos, len, dist, pos + len, lane);
                                 uint32_t np = pos + len;
                                 if ((np >> 10) != (pos >> 10)) flush_segments(s, d_out, mb.out_off, flushed, np, lane);
                                 pos = np;
