@@ -549,20 +549,30 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                 unsigned long long marks = 0;
                 uint32_t cur = 0;
                 bool slow_token = false;
-                while (cur < 64) {
-                    uint32_t t = __builtin_amdgcn_readlane(tl, cur);
-                    if (t == 0) {  // kSlow: the window ends in front of it
-                        slow_token = true;
-                        break;
+                if constexpr (EMIT == 1) {
+                    // (a token for the serial decoder hops out of the window: the loop body is six scalar instructions,
+                    // and the scalar unit — one per CU, shared by 20 wavefronts — is the busiest one in this kernel)
+                    const uint32_t hop = kind == kSlow ? 64u : tl;
+                    do {
+                        marks |= 1ull << cur;
+                        cur += __builtin_amdgcn_readlane(hop, cur);
+                    } while (cur < 64);
+                } else {
+                    while (cur < 64) {
+                        uint32_t t = __builtin_amdgcn_readlane(tl, cur);
+                        if (t == 0) {  // kSlow: the window ends in front of it
+                            slow_token = true;
+                            break;
+                        }
+                        marks |= 1ull << cur;
+                        cur += t;
                     }
-                    marks |= 1ull << cur;
-                    cur += t;
                 }
                 uint32_t advance = cur;
                 if constexpr (EMIT == 1) {
                     // ---- placement by prefix sum ---------------------------------------------------------------
                     const bool real = (marks >> lane) & 1ull;
-                    const unsigned long long m_stop = __ballot(real && (kind == kEob || kind == kBad));
+                    const unsigned long long m_stop = __ballot(real && (kind == kEob || kind == kBad || kind == kSlow));
                     const uint32_t stop_lane = m_stop ? (uint32_t)__ffsll((long long)m_stop) - 1 : 64u;
                     const bool live = real && lane < stop_lane;  // literals and matches in front of an end-of-block
                     const uint32_t olen = live ? (kind == kLit ? 1u : (val & 0xFFFFu)) : 0u;
@@ -606,11 +616,14 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                     if (flushed + 1024 <= pos) flush_segments(s, d_out, mb.out_off, flushed, pos, lane);
                     if (m_drop) {
                         advance = (uint32_t)__ffsll((long long)m_drop) - 1;
-                        slow_token = false;
                     } else if (stop_lane < 64) {
-                        if (__builtin_amdgcn_readlane(kind, stop_lane) == kEob) {
+                        const uint32_t k = __builtin_amdgcn_readlane(kind, stop_lane);
+                        if (k == kEob) {
                             advance = stop_lane + __builtin_amdgcn_readlane(tl, stop_lane);
                             eob = true;
+                        } else if (k == kSlow) {
+                            advance = stop_lane;  // decoded by every lane uniformly below
+                            slow_token = true;
                         } else {
                             err = 3;
                             break;
