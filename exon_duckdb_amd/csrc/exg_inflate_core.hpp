@@ -75,6 +75,24 @@ struct BitIn {
     const uint8_t *g0;          // 16-byte aligned global address of chunk 0
 };
 
+// Bit positions inside a decode are relative to a 16-byte aligned address close to where it STARTS (not to the
+// start of the stream): byte offsets stay 32-bit however far into a multi-GB member a chunk begins.
+struct BitBase {
+    const uint8_t *g0;   // aligned address the local bit positions count from
+    long long rel_bits;  // local position 0 = this bit of the stream (relative to comp_off; >= -120)
+    uint32_t limit;      // bytes readable from g0 (clamped: one decode reads < 4 GiB of input)
+};
+__device__ __forceinline__ BitBase bit_base(const uint8_t *d_comp, unsigned long long comp_off, unsigned long long comp_size,
+                                            unsigned long long first_bit) {
+    const unsigned long long a0 = (comp_off + (first_bit >> 3)) & ~15ull;
+    BitBase b;
+    b.g0 = d_comp + a0;
+    b.rel_bits = ((long long)a0 - (long long)comp_off) * 8;
+    const unsigned long long avail = comp_off + comp_size - a0;
+    b.limit = avail > 0xFFFFFF00ull ? 0xFFFFFF00u : (uint32_t)avail;
+    return b;
+}
+
 // stage 512-byte chunk c of the compressed input (coalesced, 8 B per lane)
 template <class L>
 __device__ __forceinline__ void stage_chunk(L &s, const BitIn &br, uint32_t c, uint32_t lane) {
@@ -371,22 +389,21 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
     const uint32_t lane = threadIdx.x;
     {
         BitIn br;
-        const unsigned long long a0 = mb.comp_off & ~15ull;
-        br.g0 = d_comp + a0;
-        const uint32_t skip = (uint32_t)(mb.comp_off - a0);
-        unsigned long long lim = mb.comp_size + skip;
-        br.limit = lim > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)lim;
-        br.bitpos = (unsigned long long)skip * 8 + mb.start_bit;
+        const BitBase bb = bit_base(d_comp, mb.comp_off, mb.comp_size, mb.start_bit);
+        br.g0 = bb.g0;
+        br.limit = bb.limit;
+        br.bitpos = (unsigned long long)((long long)mb.start_bit - bb.rel_bits);
         br.loaded = (uint32_t)(br.bitpos >> kInChunkBitsLog2);  // staging starts at the chunk that holds the first bit
         __syncthreads();
         ensure(s, br, lane);
 
         uint32_t pos = 0, flushed = 0, err = 0;
-        const unsigned long long cap = mb.out_cap;
+        // positions are 32-bit: one job produces less than 4 GiB, and the bound is compared on the scalar unit
+        const uint32_t cap = mb.out_cap > 0xFFFF0000ull ? 0xFFFF0000u : (uint32_t)mb.out_cap;
         bool last = false;
-        const unsigned long long stop_at = mb.stop_bit ? (unsigned long long)skip * 8 + mb.stop_bit : 0;
+        const unsigned long long stop_at = mb.stop_bit ? (unsigned long long)((long long)mb.stop_bit - bb.rel_bits) : 0;
         while (!last && !err && !(stop_at && br.bitpos >= stop_at)) {
-            if ((br.bitpos >> 3) >= br.limit) {  // ran off the end of the input
+            if ((uint32_t)(br.bitpos >> 3) >= br.limit) {  // ran off the end of the input
                 err = 5;
                 break;
             }
@@ -402,7 +419,7 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                     err = 1;
                     break;
                 }
-                if ((unsigned long long)pos + len > cap) {
+                if (pos + len > cap) {
                     err = 4;
                     break;
                 }
@@ -504,7 +521,7 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
             // ---- tokens of the block: 64 speculative decodes per step, then the true chain ----------------
             bool eob = false;
             while (!eob && !err) {
-                if ((br.bitpos >> 3) > (unsigned long long)br.limit + 8) {  // decoding the zero padding behind the input
+                if ((uint32_t)(br.bitpos >> 3) > br.limit + 8) {  // decoding the zero padding behind the input
                     err = 5;
                     break;
                 }
@@ -582,7 +599,7 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                     const unsigned long long m_keep = __ballot(keep);
                     const unsigned long long m_drop = __ballot(live) & ~m_keep;  // pushed to the next step
                     const uint32_t total = m_keep ? __builtin_amdgcn_readlane(incl, 63 - __clzll((long long)m_keep)) : 0u;
-                    if ((unsigned long long)pos + total > cap) {
+                    if (pos + total > cap) {
                         err = 4;
                         break;
                     }
@@ -652,7 +669,7 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                                 break;
                             }
                         }
-                        if ((unsigned long long)pos + n > cap) {
+                        if (pos + n > cap) {
                             err = 4;
                             break;
                         }
@@ -667,7 +684,7 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                     const uint32_t x = __builtin_amdgcn_readlane(val, upto);
                     if (k == kMatch) {
                         uint32_t len = x & 0xFFFFu, dist = x >> 16;
-                        if ((!SYM && dist > pos) || (unsigned long long)pos + len > cap) {
+                        if ((!SYM && dist > pos) || pos + len > cap) {
                             err = (!SYM && dist > pos) ? 3 : 4;
                             break;
                         }
@@ -711,7 +728,7 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                             err = 3;
                         } else {
                             uint32_t dist = kDistBase[ds] + getbits(s, br, kDistExtra[ds], lane);
-                            if ((!SYM && dist > pos) || (unsigned long long)pos + len > cap) {
+                            if ((!SYM && dist > pos) || pos + len > cap) {
                                 err = (!SYM && dist > pos) ? 3 : 4;
                             } else {
                                 copy_match(s, d_out, mb.out_off, pos, len, dist, pos + len, lane);
@@ -733,7 +750,7 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
             st.code = err;
             st.final_block = last ? 1u : 0u;
             st.produced = pos;
-            st.end_bit = br.bitpos - (unsigned long long)skip * 8;
+            st.end_bit = (unsigned long long)((long long)br.bitpos + bb.rel_bits);
             *st_out = st;
         }
         __syncthreads();

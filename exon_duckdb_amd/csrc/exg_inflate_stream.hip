@@ -73,22 +73,20 @@ __global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ 
     const uint32_t lane = threadIdx.x;
     for (uint32_t j = blockIdx.x; j < n_jobs; j += gridDim.x) {
         const FindJob fj = jobs[j];
-        const unsigned long long a0 = fj.comp_off & ~15ull;
-        const uint32_t skip = (uint32_t)(fj.comp_off - a0);
         unsigned long long result = ~0ull;
         for (unsigned long long base = fj.from_bit; base < fj.to_bit && result == ~0ull; base += 64) {
             // stage the input around `base` and let every lane look at its own offset
             BitIn br;
-            br.g0 = d_comp + a0;
-            unsigned long long lim = fj.comp_size + skip;
-            br.limit = lim > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)lim;
-            br.bitpos = (unsigned long long)skip * 8 + base;
+            const BitBase bb = bit_base(d_comp, fj.comp_off, fj.comp_size, base);
+            br.g0 = bb.g0;
+            br.limit = bb.limit;
+            br.bitpos = (unsigned long long)((long long)base - bb.rel_bits);
             br.loaded = (uint32_t)(br.bitpos >> kInChunkBitsLog2);
             __syncthreads();
             ensure(s, br, lane);
             br.bitpos += 64 + 17 + 64;  // the filter reads up to here: keep the next chunk staged too
             ensure(s, br, lane);
-            const unsigned long long o = (unsigned long long)skip * 8 + base + lane;
+            const unsigned long long o = (unsigned long long)((long long)base - bb.rel_bits) + lane;
             const bool in_range = base + lane < fj.to_bit && ((o + 17 + 64) >> 3) < br.limit;
             const bool pass = in_range && header_filter(peek_at(s, o), peek_at(s, o + 17));
             unsigned long long cand = __ballot(pass);
