@@ -612,21 +612,50 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                     }
                     const uint32_t hi = pos + total;
                     if (keep && kind == kLit) s.win[(pos + excl) & kRingMask] = (Elem)val;
-                    unsigned long long m_match = __ballot(keep && kind == kMatch);
-                    while (m_match) {
-                        const uint32_t l = (uint32_t)__ffsll((long long)m_match) - 1;
-                        m_match &= m_match - 1;
-                        const uint32_t x = __builtin_amdgcn_readlane(val, l);
-                        const uint32_t dest = pos + __builtin_amdgcn_readlane(excl, l);
-                        const uint32_t len = x & 0xFFFFu, dist = x >> 16;
-                        if (!SYM && dist > dest) {
-                            err = 3;
-                            break;
+                    // matches, in order.  What can be decided per token is decided on the VALU for all tokens at once
+                    // (class of the copy, source, bounds): the scalar loop only reads a descriptor per match.  No flush
+                    // inside a step: the ring holds [flushed, hi) (< 1 KiB of lag + kStepOut + one match), and what a
+                    // copy reads from HBM (older than hi - RING) was flushed before the step began.
+                    const bool is_m = keep && kind == kMatch;
+                    const uint32_t dest_l = pos + excl, len_l = val & 0xFFFFu, dist_l = val >> 16;
+                    if (!SYM && __ballot(is_m && dist_l > dest_l)) {
+                        err = 3;
+                        break;
+                    }
+                    if (!(InflateLdsT<SYM, RING>::kGlobalWindow && !d_out)) {  // a probing decode copies nothing
+                        const uint32_t src0_l = dest_l - dist_l;
+                        uint32_t cls = 2;  // 0: one pass out of the ring, 1: one pass out of HBM, 2: the general copy
+                        if (dist_l >= len_l && len_l <= 64u && dest_l >= dist_l) {
+                            if (!InflateLdsT<SYM, RING>::kGlobalWindow || src0_l + RING >= hi)
+                                cls = 0;
+                            else if (src0_l + len_l - 1 + RING < hi)
+                                cls = 1;
                         }
-                        // everything below `dest` is complete (literals were placed first): flush it, so that what the
-                        // copy reads from HBM is there
-                        if (flushed + 1024 <= dest) flush_segments(s, d_out, mb.out_off, flushed, dest, lane);
-                        copy_match(s, d_out, mb.out_off, dest, len, dist, hi, lane);
+                        const uint32_t desc_l = cls | (len_l << 2);
+                        unsigned long long m_match = __ballot(is_m);
+                        while (m_match) {
+                            const uint32_t l = (uint32_t)__ffsll((long long)m_match) - 1;
+                            m_match &= m_match - 1;
+                            const uint32_t desc = __builtin_amdgcn_readlane(desc_l, l);
+                            const uint32_t dest = __builtin_amdgcn_readlane(dest_l, l);
+                            const uint32_t len = desc >> 2;
+                            if ((desc & 3u) == 0) {
+                                const uint32_t src0 = __builtin_amdgcn_readlane(src0_l, l);
+                                if (lane < len) {
+                                    const Elem x = s.win[(src0 + lane) & kRingMask];
+                                    s.win[(dest + lane) & kRingMask] = x;
+                                }
+                            } else if ((desc & 3u) == 1) {
+                                const uint32_t src0 = __builtin_amdgcn_readlane(src0_l, l);
+                                if (lane < len) {
+                                    const Elem x = __hip_atomic_load(d_out + mb.out_off + src0 + lane, __ATOMIC_RELAXED,
+                                                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    s.win[(dest + lane) & kRingMask] = x;
+                                }
+                            } else {
+                                copy_match(s, d_out, mb.out_off, dest, len, __builtin_amdgcn_readlane(dist_l, l), hi, lane);
+                            }
+                        }
                     }
                     if (err) break;
                     pos = hi;
