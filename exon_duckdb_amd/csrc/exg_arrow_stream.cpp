@@ -931,7 +931,7 @@ extern "C" ReaderResult new_reader(ArrowArrayStream *stream_ptr, const char *uri
             return result_error("could not register table: " + r->error);
         r->file.reset();
         r->fd_keep.reset();
-        if (r->d_file) (void)hipFree(r->d_file), r->d_file = nullptr;
+        if (r->d_file) dev_pool()->give(r->device, r->d_file, r->d_file_cap), r->d_file = nullptr;
         r->file_idx = 0;
         r->file_pos = 0;
         r->file_done = true;

@@ -83,7 +83,7 @@ exg_reader::~exg_reader() {
     if (d_res) (void)hipFree(d_res);
     if (d_filter_prog) (void)hipFree(d_filter_prog);
     if (d_filter_consts) (void)hipFree(d_filter_consts);
-    if (d_file) (void)hipFree(d_file);
+    if (d_file) exg_rd::dev_pool()->give(device, d_file, d_file_cap);
     if (up_done) (void)hipEventDestroy(up_done);
     if (up_stream) (void)hipStreamDestroy(up_stream);
     if (stream) (void)hipStreamDestroy(stream);
@@ -167,6 +167,70 @@ static int gz_host_header(exg_reader *r, PinnedBlock &b, const void *d_file) {
     }
 }
 
+// The whole (compressed) file -> d_dst on r->stream: windows of 256 MiB through two pooled pinned blocks, each window
+// read by parallel pread and sent slice by slice (the mechanism of upload_range; a hipMemcpyAsync straight from the
+// page-cache mapping is a pageable copy: one staging thread inside the runtime, 10-33 GB/s depending on the box).
+static int upload_file(exg_reader *r, void *d_dst, uint64_t n) {
+    const size_t window = 256u << 20, slice = 8u << 20;
+    const int fd = r->fd_keep->fd;
+    char *blk[2] = {nullptr, nullptr};
+    size_t cap[2] = {0, 0};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    struct Cleanup {
+        exg_reader *r;
+        char **blk;
+        size_t *cap;
+        hipEvent_t *ev;
+        ~Cleanup() {
+            (void)hipStreamSynchronize(r->stream);  // the blocks are sources of copies in flight
+            for (int k = 0; k < 2; k++) {
+                if (blk[k]) global_pool()->give(blk[k], cap[k]);
+                if (ev[k]) (void)hipEventDestroy(ev[k]);
+            }
+        }
+    } cleanup{r, blk, cap, ev};
+    for (int k = 0; k < 2 && (uint64_t)k * window < n; k++) {
+        cap[k] = (size_t)std::min<uint64_t>(window, n - (uint64_t)k * window) + 64;
+        blk[k] = global_pool()->take(&cap[k]);
+        if (!blk[k]) return fail(r, EXG_E_HIP, "out of pinned host memory");
+        RD_HIP(r, hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+    }
+    uint64_t off = 0;
+    for (uint64_t w = 0; off < n; w++) {
+        const int b = (int)(w & 1);
+        if (w >= 2) RD_HIP(r, hipEventSynchronize(ev[b]));  // the block's previous window has left
+        const size_t len = (size_t)std::min<uint64_t>(window, n - off);
+        const size_t n_slices = (len + slice - 1) / slice;
+        std::atomic<size_t> next{0};
+        std::atomic<int> bad{0};
+        auto work = [&]() {
+            for (size_t i = next.fetch_add(1); i < n_slices; i = next.fetch_add(1)) {
+                const size_t o = i * slice, sl = std::min<size_t>(slice, len - o);
+                size_t got = 0;
+                while (got < sl) {
+                    ssize_t k = pread(fd, blk[b] + o + got, sl - got, (off_t)(off + o + got));
+                    if (k <= 0) {
+                        bad = 1;
+                        return;
+                    }
+                    got += (size_t)k;
+                }
+                if (hipMemcpyAsync((char *)d_dst + off + o, blk[b] + o, sl, hipMemcpyHostToDevice, r->stream) != hipSuccess) bad = 2;
+            }
+        };
+        const unsigned nt = (unsigned)std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), std::min<size_t>(n_slices, 8));
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
+        if (bad == 1) return fail(r, EXG_E_IO, "short read");
+        if (bad == 2) return fail(r, EXG_E_HIP, "hipMemcpyAsync failed");
+        RD_HIP(r, hipEventRecord(ev[b], r->stream));
+        off += len;
+    }
+    return EXG_OK;
+}
+
 // gzip input: H2D the compressed bytes, inflate every member on the device (exg_inflate.hip), keep the
 // inflated bytes in HBM for the scan and bring one copy back for the DataChunk payload.
 int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::string &path) {
@@ -178,30 +242,63 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
     const uint8_t *comp = (const uint8_t *)blk->p;
     const uint64_t n = blk->n;
     if (n == 0) return fail(r, EXG_E_PARSE, "empty gzip file '" + path + "'");
-    void *d_comp = nullptr;
-    RD_HIP(r, hipMalloc(&d_comp, n + 64));
+    // the big device buffers (compressed bytes, inflated bytes) come from the device pool: a query that opens the
+    // same file again finds them there (hipMalloc / hipFree of tens of GB were seen to cost up to 0.9 s per open)
+    struct Pooled {
+        int dev;
+        void *p;
+        size_t sz;
+        ~Pooled() { if (p) exg_rd::dev_pool()->give(dev, p, sz); }
+    };
+    void *d_comp = exg_rd::dev_pool()->take(r->device, n + 64);
+    if (!d_comp) return fail(r, EXG_E_HIP, "out of device memory for the compressed file");
+    Pooled free_comp{r->device, d_comp, (size_t)(n + 64)};
     struct Free {
         void *p;
         ~Free() { if (p) (void)hipFree(p); }
-    } free_comp{d_comp};
-    double t_h2d = now_s();
-    RD_HIP(r, hipMemcpyAsync(d_comp, comp, n, hipMemcpyHostToDevice, r->stream));
-    if (trace_on()) (void)hipStreamSynchronize(r->stream);
-    TRACE("gz: h2d compressed", t_h2d);
+    };
     // worst case one member per 18 bytes; NOT value-initialised (a 0.5 GB file would zero 1 GB here: measured 240 ms)
     const uint64_t members_cap = std::max<uint64_t>(16, n / 18 + 4);
     std::unique_ptr<exg_inflate_member[]> members(new exg_inflate_member[members_cap]);
+    // the member index of the first round (a pointer chase through the page cache: 110 ms per 10 GB of BGZF) is
+    // made on a second host thread while the compressed bytes travel
+    struct FirstIndex {
+        uint64_t k = 0, total = 0;
+        int open_ended = 0, rc = 0;
+        std::string err;
+        double ms = 0;
+    } first;
+    std::thread index_thread([&] {
+        double t0 = now_s();
+        first.rc = exg_gzip_index(comp, n, 0, members.get(), members_cap, &first.k, &first.total, &first.open_ended);
+        if (first.rc) first.err = exg_last_error_message();  // the message is thread-local
+        first.ms = (now_s() - t0) * 1e3;
+    });
+    double t_h2d = now_s();
+    {
+        int rc = upload_file(r, d_comp, n);
+        if (trace_on()) (void)hipStreamSynchronize(r->stream);
+        TRACE("gz: h2d compressed", t_h2d);
+        index_thread.join();
+        if (rc) return rc;
+    }
+    if (trace_on()) fprintf(stderr, "[exg] %-22s %.1f ms (beside the upload)\n", "gz: member index", first.ms);
     uint64_t out_cap_total = 0, produced_total = 0;
     void *d_out = nullptr;
     uint64_t d_out_cap = 0;
     uint64_t start = 0;
     while (start < n) {
         uint64_t k = 0, total = produced_total;
-        int open_ended = 0;
-        double t_idx = now_s();
-        int rc = exg_gzip_index(comp, n, start, members.get(), members_cap, &k, &total, &open_ended);
-        TRACE("gz: member index", t_idx);
-        if (rc) return fail(r, rc, std::string(exg_last_error_message()) + " in '" + path + "'");
+        int open_ended = 0, rc = 0;
+        if (start == 0) {
+            k = first.k, total = first.total, open_ended = first.open_ended, rc = first.rc;
+            if (rc) return fail(r, rc, first.err + " in '" + path + "'");
+        } else {
+            double t_idx = now_s();
+            rc = exg_gzip_index(comp, n, start, members.get(), members_cap, &k, &total, &open_ended);
+            TRACE("gz: member index", t_idx);
+            if (rc) return fail(r, rc, std::string(exg_last_error_message()) + " in '" + path + "'");
+        }
         if (k == 0) break;
         // one big member of unknown size (what gzip / pigz write): per-member parallelism would put the whole file
         // on ONE wavefront — decode it in chunks instead (exg_inflate_stream.hip)
@@ -223,13 +320,16 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
         }
         out_cap_total = total;
         if (out_cap_total + 64 > d_out_cap) {  // grow the output (members of earlier rounds are kept)
-            void *nd = nullptr;
             uint64_t ncap = out_cap_total + 64;
-            RD_HIP(r, hipMalloc(&nd, ncap));
+            void *nd = exg_rd::dev_pool()->take(r->device, ncap);
+            if (!nd) {
+                if (d_out) exg_rd::dev_pool()->give(r->device, d_out, d_out_cap);
+                return fail(r, EXG_E_HIP, "out of device memory for the inflated file");
+            }
             if (d_out) {
                 RD_HIP(r, hipMemcpyAsync(nd, d_out, produced_total, hipMemcpyDeviceToDevice, r->stream));
                 RD_HIP(r, hipStreamSynchronize(r->stream));
-                (void)hipFree(d_out);
+                exg_rd::dev_pool()->give(r->device, d_out, d_out_cap);
             }
             d_out = nd;
             d_out_cap = ncap;
@@ -250,7 +350,7 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
         for (uint64_t i = 0; i < k; i++) {
             const bool sized = !(open_ended && i + 1 == k);
             if (st[i].code || (sized && st[i].produced != members[i].out_cap)) {
-                if (d_out) (void)hipFree(d_out);
+                if (d_out) exg_rd::dev_pool()->give(r->device, d_out, d_out_cap);
                 return fail(r, EXG_E_PARSE, "corrupt deflate stream (member " + std::to_string(i) + ", code " +
                                                 std::to_string(st[i].code) + ") in '" + path + "'");
             }
@@ -274,6 +374,7 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
     RD_HIP(r, hipStreamSynchronize(r->stream));
     blk = out_blk;
     r->d_file = d_out;
+    r->d_file_cap = d_out_cap;
     r->d_file_bytes = produced_total;
     r->gz_header_prefix = 0;
     if (r->format == EXG_FMT_VCF && produced_total) {
@@ -314,7 +415,7 @@ int open_next_file(exg_reader *r) {
     r->fd_keep.reset(new exg_reader::FdCloser{fd});
     TRACE("mmap(file)", t0);
     (void)t_all;
-    if (r->d_file) (void)hipFree(r->d_file), r->d_file = nullptr;
+    if (r->d_file) exg_rd::dev_pool()->give(r->device, r->d_file, r->d_file_cap), r->d_file = nullptr;
     if (r->compression == kGzip) {
         int rc = inflate_file(r, blk, p);  // replaces blk by the inflated bytes (host copy) and sets d_file
         if (rc) return rc;

@@ -86,7 +86,7 @@ struct DevPool {
     std::mutex mu;
     std::vector<Blk> free_blocks;
     size_t pooled_bytes = 0;
-    static constexpr size_t kMaxPooled = 16ull << 30;
+    static constexpr size_t kMaxPooled = 64ull << 30;  // of 288 GB; trimmed when a hipMalloc fails
     void *take(int dev, size_t sz) {
         {
             std::lock_guard<std::mutex> g(mu);
@@ -239,6 +239,7 @@ struct exg_reader {
     std::unique_ptr<FdCloser> fd_keep;  // current file (pread source of the bounce buffer)
     exg_rd::PinnedBlock staging[2];  // pinned bounce buffers for H2D, one per slot (the file itself is only mapped)
     void *d_file = nullptr;  // gzip input: the inflated bytes live here and are scanned in place
+    size_t d_file_cap = 0;   // its allocation size (it goes back to the device pool)
     uint64_t d_file_bytes = 0;
 
     // current batch
