@@ -61,7 +61,15 @@ static bool parse_compression(const std::string &s, Compression *out) {
 exg_reader::FdCloser::~FdCloser() {
     if (fd >= 0) close(fd);
 }
+int exg_reader::join_prefetch() {
+    if (pf_thread.joinable()) pf_thread.join();
+    const int rc = pf_rc;
+    pf_rc = 0;
+    if (rc) pf.valid = false;
+    return rc;
+}
 void exg_reader::free_device() {
+    (void)join_prefetch();
     if (up_stream) (void)hipStreamSynchronize(up_stream);
     pf.valid = false;
     d_in = nullptr;
@@ -204,6 +212,7 @@ static int upload_file(exg_reader *r, void *d_dst, uint64_t n) {
         std::atomic<size_t> next{0};
         std::atomic<int> bad{0};
         auto work = [&]() {
+            (void)hipSetDevice(r->device);
             for (size_t i = next.fetch_add(1); i < n_slices; i = next.fetch_add(1)) {
                 const size_t o = i * slice, sl = std::min<size_t>(slice, len - o);
                 size_t got = 0;
@@ -420,6 +429,7 @@ int open_next_file(exg_reader *r) {
         int rc = inflate_file(r, blk, p);  // replaces blk by the inflated bytes (host copy) and sets d_file
         if (rc) return rc;
     }
+    (void)r->join_prefetch();
     if (r->pf.valid && r->up_stream) (void)hipStreamSynchronize(r->up_stream);  // a prefetch of the previous file
     r->pf.valid = false;
     r->file = blk;
@@ -526,6 +536,7 @@ int upload_range(exg_reader *r, uint64_t off, uint64_t n, int slot, hipStream_t 
     char *dst = (char *)stg.p;
     char *d_dst = (char *)r->d_in_slot[slot];
     auto work = [&]() {
+        (void)hipSetDevice(r->device);
         for (size_t i = next.fetch_add(1); i < n_slices; i = next.fetch_add(1)) {
             size_t o = i * slice, len = std::min<size_t>(slice, n - o), got = 0;
             while (got < len) {
@@ -577,6 +588,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         // H2D copy.  In the first two cases the batch start is only byte aligned: the buffer starts at the
         // 16-byte boundary below it and `lead` skips the tail of the previous record (whose last '\n' is
         // then inside the buffer).
+        if ((rc = r->join_prefetch())) return rc;  // the upload thread of the previous call (its error is this call's)
         const uint8_t *h = (const uint8_t *)r->file->p + r->file_pos;
         const void *d_input = nullptr;
         uint64_t lead = 0;
@@ -721,9 +733,15 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             const uint64_t len = std::min<uint64_t>(r->file->n - start, r->device_batch_bytes + slack);
             const int other = r->cur_slot ^ 1;
             if (len + 16 <= r->d_in_cap && r->d_in_slot[other]) {
-                int rc3 = upload_range(r, start, len, other, r->up_stream);
-                if (rc3) return rc3;
-                RD_HIP(r, hipEventRecord(r->up_done, r->up_stream));
+                // on a host thread of its own: pread + the H2D enqueue block their caller for as long as the bytes take
+                // to leave (5.5 ms per 256 MiB), and this thread has columns to copy back / Arrow buffers to build
+                r->pf_rc = 0;
+                r->pf_thread = std::thread([r, start, len, other] {
+                    (void)hipSetDevice(r->device);
+                    int rc3 = upload_range(r, start, len, other, r->up_stream);
+                    if (!rc3 && hipEventRecord(r->up_done, r->up_stream) != hipSuccess) rc3 = EXG_E_HIP;
+                    r->pf_rc = rc3;
+                });
                 r->pf.valid = true;
                 r->pf.file_start = start;
                 r->pf.len = len;

@@ -3,6 +3,7 @@
 #pragma once
 #include <algorithm>
 #include <memory>
+#include <thread>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -212,6 +213,9 @@ struct exg_reader {
     void *d_in_slot[2] = {nullptr, nullptr};
     hipStream_t up_stream = nullptr;
     hipEvent_t up_done = nullptr;
+    std::thread pf_thread;  // the prefetch's pread + H2D enqueue (joined by the next call that looks at pf)
+    int pf_rc = 0;
+    int join_prefetch();
     struct Prefetch {
         bool valid = false;
         uint64_t file_start = 0, len = 0;  // file bytes [file_start, file_start + len) are (being) uploaded
