@@ -295,6 +295,13 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
     uint64_t out_cap_total = 0, produced_total = 0;
     void *d_out = nullptr;
     uint64_t d_out_cap = 0;
+    // whatever way this function is left, the output buffer goes back to the pool unless it became r->d_file
+    struct OutGuard {
+        int dev;
+        void **p;
+        uint64_t *cap;
+        ~OutGuard() { if (*p) exg_rd::dev_pool()->give(dev, *p, (size_t)*cap); }
+    } out_guard{r->device, &d_out, &d_out_cap};
     uint64_t start = 0;
     while (start < n) {
         uint64_t k = 0, total = produced_total;
@@ -331,14 +338,16 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
         if (out_cap_total + 64 > d_out_cap) {  // grow the output (members of earlier rounds are kept)
             uint64_t ncap = out_cap_total + 64;
             void *nd = exg_rd::dev_pool()->take(r->device, ncap);
-            if (!nd) {
-                if (d_out) exg_rd::dev_pool()->give(r->device, d_out, d_out_cap);
-                return fail(r, EXG_E_HIP, "out of device memory for the inflated file");
-            }
+            if (!nd) return fail(r, EXG_E_HIP, "out of device memory for the inflated file");
             if (d_out) {
-                RD_HIP(r, hipMemcpyAsync(nd, d_out, produced_total, hipMemcpyDeviceToDevice, r->stream));
-                RD_HIP(r, hipStreamSynchronize(r->stream));
+                hipError_t he = hipMemcpyAsync(nd, d_out, produced_total, hipMemcpyDeviceToDevice, r->stream);
+                if (he == hipSuccess) he = hipStreamSynchronize(r->stream);
                 exg_rd::dev_pool()->give(r->device, d_out, d_out_cap);
+                d_out = nullptr;
+                if (he != hipSuccess) {
+                    exg_rd::dev_pool()->give(r->device, nd, ncap);
+                    return fail(r, EXG_E_HIP, std::string("copy of the inflated bytes failed: ") + hipGetErrorString(he));
+                }
             }
             d_out = nd;
             d_out_cap = ncap;
@@ -359,7 +368,6 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
         for (uint64_t i = 0; i < k; i++) {
             const bool sized = !(open_ended && i + 1 == k);
             if (st[i].code || (sized && st[i].produced != members[i].out_cap)) {
-                if (d_out) exg_rd::dev_pool()->give(r->device, d_out, d_out_cap);
                 return fail(r, EXG_E_PARSE, "corrupt deflate stream (member " + std::to_string(i) + ", code " +
                                                 std::to_string(st[i].code) + ") in '" + path + "'");
             }
@@ -384,10 +392,11 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
     blk = out_blk;
     r->d_file = d_out;
     r->d_file_cap = d_out_cap;
+    d_out = nullptr;  // owned by the reader from here on (gz_host_header below reads r->d_file)
     r->d_file_bytes = produced_total;
     r->gz_header_prefix = 0;
     if (r->format == EXG_FMT_VCF && produced_total) {
-        int rc = gz_host_header(r, *blk, d_out);
+        int rc = gz_host_header(r, *blk, r->d_file);
         if (rc) return rc;
     }
     return EXG_OK;
