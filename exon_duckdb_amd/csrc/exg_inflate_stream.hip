@@ -406,19 +406,19 @@ extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint6
         ST_HIP(hipMemcpyAsync(d_jobs.p, jobs.data(), n * sizeof(InflateJob), hipMemcpyHostToDevice, stream));
         static const int ring = [] {
             const char *e = getenv("EXG_STREAM_RING");  // A/B switch: 32768 = the whole symbol window in LDS (72 KiB)
-            return e ? atoi(e) : 4096;
+            return e ? atoi(e) : 2048;
         }();
         if (ring == 32768)
             hipLaunchKernelGGL(k_inflate_chunks<32768>, dim3(std::min<uint32_t>(n, 8192)), dim3(64), 0, stream, d_comp,
                                (uint16_t *)d_sym.p, (const InflateJob *)d_jobs.p, (InflateJobStatus *)d_st.p, n);
-        else if (ring == 2048)
-            hipLaunchKernelGGL(k_inflate_chunks<2048>, dim3(std::min<uint32_t>(n, 8192)), dim3(64), 0, stream, d_comp,
+        else if (ring == 4096)
+            hipLaunchKernelGGL(k_inflate_chunks<4096>, dim3(std::min<uint32_t>(n, 8192)), dim3(64), 0, stream, d_comp,
                                (uint16_t *)d_sym.p, (const InflateJob *)d_jobs.p, (InflateJobStatus *)d_st.p, n);
         else if (ring == 8192)
             hipLaunchKernelGGL(k_inflate_chunks<8192>, dim3(std::min<uint32_t>(n, 8192)), dim3(64), 0, stream, d_comp,
                                (uint16_t *)d_sym.p, (const InflateJob *)d_jobs.p, (InflateJobStatus *)d_st.p, n);
         else
-            hipLaunchKernelGGL(k_inflate_chunks<4096>, dim3(std::min<uint32_t>(n, 8192)), dim3(64), 0, stream, d_comp,
+            hipLaunchKernelGGL(k_inflate_chunks<2048>, dim3(std::min<uint32_t>(n, 8192)), dim3(64), 0, stream, d_comp,
                                (uint16_t *)d_sym.p, (const InflateJob *)d_jobs.p, (InflateJobStatus *)d_st.p, n);
         ST_HIP(hipGetLastError());
         std::vector<InflateJobStatus> st(n);
