@@ -13,6 +13,8 @@
 // 64 B/record of string_t + validity cross PCIe on the way back.  Chunks are 2048-row slices of the
 // batch's host vectors; buffers are reference counted until exg_release_chunk.
 #include <dirent.h>
+#include <pthread.h>
+#include <sched.h>
 #include <errno.h>
 #include <fcntl.h>
 #include <stdlib.h>
@@ -57,6 +59,43 @@ static bool parse_compression(const std::string &s, Compression *out) {
 }
 
 }  // namespace exg_rd
+
+// The reader's own I/O threads (pread into the pinned bounce buffers, H2D enqueue) run on the CPUs of the NUMA node the
+// GPU hangs off (sysfs local_cpulist of its PCI function): the bounce buffers are local to the DMA engine, and a file
+// that is read cold lands in that node's page cache.  Best effort — a cpuset that forbids it is not an error.
+static void pin_to_device_node(int device) {
+    struct Mask {
+        bool ok = false;
+        cpu_set_t set;
+    };
+    static Mask masks[64];
+    static std::once_flag once[64];
+    if (device < 0 || device >= 64 || getenv("EXG_NO_NUMA_PIN")) return;
+    std::call_once(once[device], [device] {
+        char bdf[64] = {0};
+        if (hipDeviceGetPCIBusId(bdf, sizeof bdf, device) != hipSuccess) return;
+        for (char *c = bdf; *c; c++) *c = (char)tolower(*c);
+        const std::string path = std::string("/sys/bus/pci/devices/") + bdf + "/local_cpulist";
+        FILE *f = fopen(path.c_str(), "r");
+        if (!f) return;
+        char line[4096] = {0};
+        const bool got = fgets(line, sizeof line, f) != nullptr;
+        fclose(f);
+        if (!got) return;
+        Mask &m = masks[device];
+        CPU_ZERO(&m.set);
+        int n_cpus = 0;
+        for (char *tok = strtok(line, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+            int a = 0, b = 0;
+            const int k = sscanf(tok, "%d-%d", &a, &b);
+            if (k == 1) b = a;
+            if (k < 1) continue;
+            for (int c = a; c <= b && c < CPU_SETSIZE; c++) CPU_SET(c, &m.set), n_cpus++;
+        }
+        m.ok = n_cpus > 0;
+    });
+    if (masks[device].ok) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &masks[device].set);
+}
 
 exg_reader::FdCloser::~FdCloser() {
     if (fd >= 0) close(fd);
@@ -211,8 +250,9 @@ static int upload_file(exg_reader *r, void *d_dst, uint64_t n) {
         const size_t n_slices = (len + slice - 1) / slice;
         std::atomic<size_t> next{0};
         std::atomic<int> bad{0};
-        auto work = [&]() {
+        auto work = [&](bool own_thread) {
             (void)hipSetDevice(r->device);
+            if (own_thread) pin_to_device_node(r->device);
             for (size_t i = next.fetch_add(1); i < n_slices; i = next.fetch_add(1)) {
                 const size_t o = i * slice, sl = std::min<size_t>(slice, len - o);
                 size_t got = 0;
@@ -229,8 +269,8 @@ static int upload_file(exg_reader *r, void *d_dst, uint64_t n) {
         };
         const unsigned nt = (unsigned)std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), std::min<size_t>(n_slices, 8));
         std::vector<std::thread> th;
-        for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
-        work();
+        for (unsigned t = 1; t < nt; t++) th.emplace_back(work, true);
+        work(false);
         for (auto &t : th) t.join();
         if (bad == 1) return fail(r, EXG_E_IO, "short read");
         if (bad == 2) return fail(r, EXG_E_HIP, "hipMemcpyAsync failed");
@@ -545,8 +585,9 @@ int upload_range(exg_reader *r, uint64_t off, uint64_t n, int slot, hipStream_t 
     const int fd = r->fd_keep->fd;
     char *dst = (char *)stg.p;
     char *d_dst = (char *)r->d_in_slot[slot];
-    auto work = [&]() {
+    auto work = [&](bool own_thread) {
         (void)hipSetDevice(r->device);
+        if (own_thread) pin_to_device_node(r->device);
         for (size_t i = next.fetch_add(1); i < n_slices; i = next.fetch_add(1)) {
             size_t o = i * slice, len = std::min<size_t>(slice, n - o), got = 0;
             while (got < len) {
@@ -566,8 +607,8 @@ int upload_range(exg_reader *r, uint64_t off, uint64_t n, int slot, hipStream_t 
         }
     };
     std::vector<std::thread> th;
-    for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
-    work();
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(work, true);
+    work(false);
     for (auto &t : th) t.join();
     if (bad == 1) return fail(r, EXG_E_IO, "short read");
     if (bad == 2) return fail(r, EXG_E_HIP, "hipMemcpyAsync failed");
@@ -748,6 +789,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
                 r->pf_rc = 0;
                 r->pf_thread = std::thread([r, start, len, other] {
                     (void)hipSetDevice(r->device);
+                    pin_to_device_node(r->device);
                     int rc3 = upload_range(r, start, len, other, r->up_stream);
                     if (!rc3 && hipEventRecord(r->up_done, r->up_stream) != hipSuccess) rc3 = EXG_E_HIP;
                     r->pf_rc = rc3;
