@@ -53,6 +53,43 @@ __device__ int parse_f32(const Src &src, int s, int e, float *out) {
             return 0;
         }
     }
+    // The usual literal — digits with at most one '.', no exponent, at most 7 significant digits ("50.0", "0.0312") —
+    // in 32-bit arithmetic: the mantissa (< 2^24) and 10^k (k <= 10) are both exact floats, so ONE correctly rounded
+    // float division is the correctly rounded result (Clinger's fast path; HIP compiles `/` on floats correctly
+    // rounded).  Anything else (exponent, more digits, a syntax error) falls through to the general code below.
+    if (n <= 12) {
+        uint32_t m32 = 0;
+        int sig32 = 0, frac = 0, nd32 = 0;
+        bool dot = false, plain = true;
+        for (int j = i; j < e; j++) {
+            const uint32_t ch = src.b(j);
+            if (ch == '.') {
+                if (dot) plain = false;
+                dot = true;
+                continue;
+            }
+            const uint32_t d = ch - '0';
+            if (d > 9u) {
+                plain = false;
+                break;
+            }
+            nd32++;
+            if (m32 || d) {
+                m32 = m32 * 10u + d;
+                sig32++;
+            }
+            if (dot) frac++;
+        }
+        if (plain && nd32 > 0 && sig32 <= 7 && frac <= 10) {
+            static constexpr float kPow10f[11] = {1e0f, 1e1f, 1e2f, 1e3f, 1e4f, 1e5f, 1e6f, 1e7f, 1e8f, 1e9f, 1e10f};
+            float p = 1.0f;
+#pragma unroll
+            for (int k = 1; k <= 10; k++) p = frac == k ? kPow10f[k] : p;  // a select chain, not a memory table
+            const float f = m32 ? (float)m32 / p : 0.0f;
+            *out = neg ? -f : f;
+            return 0;
+        }
+    }
     unsigned long long m = 0;
     int nd = 0, sig = 0, e10 = 0;
     bool inexact = false, seen_dot = false;
@@ -119,6 +156,16 @@ __device__ bool parse_pos(const Src &src, int s, int e, long long *out) {
     int i = s;
     if (i < e && src.b(i) == '+') i++;
     if (i >= e) return false;
+    if (e - i <= 9) {  // cannot overflow 32 bits: one multiply-add per digit (the 64-bit form checks a quotient per digit)
+        uint32_t v32 = 0;
+        for (; i < e; i++) {
+            const uint32_t d = src.b(i) - '0';
+            if (d > 9u) return false;
+            v32 = v32 * 10u + d;
+        }
+        *out = (long long)v32;
+        return true;
+    }
     unsigned long long v = 0;
     for (; i < e; i++) {
         uint32_t c = src.b(i);

@@ -171,6 +171,23 @@ def test_qual_parse_is_correctly_rounded(gpu, oracle, algo):
     check(oracle, data, algo)
 
 
+def test_short_decimal_qual_and_pos_fast_paths_are_exact(gpu, oracle):
+    # the 32-bit paths of the number parsers (<= 7 significant digits / <= 9 POS digits) and their neighbours:
+    # every m / 10^k for m < 30000, k = 1..4, forms around the 7-digit and 12-character limits, POS of 1..19 digits
+    quals = [b"%d.%0*d" % (m // 10 ** k, k, m % 10 ** k) for k in (1, 2, 3, 4) for m in range(0, 30000, 1 if k < 3 else 7)]
+    quals += [b"9999999", b"10000000", b"1234567.8", b"0.1234567", b"0.12345678", b"0.00000001", b".5", b"5.", b"+7.25",
+              b"-0.0", b"00012.50", b"0.0000000001", b"16777217", b"16777216.0", b"8388608.5", b"0.1", b"0.3", b"100.0"]
+    poss = [b"1", b"+1", b"999999999", b"1000000000", b"4294967295", b"4294967296", b"123456789012345678",
+            b"9223372036854775807", b"000000000000000000012"]
+    lines = [b"1\t5\t.\tA\tC\t" + q + b"\tPASS\t.\n" for q in quals]
+    lines += [b"1\t" + p + b"\t.\tA\tC\t1.5\tPASS\t.\n" for p in poss]
+    for algo in (abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS):
+        check(oracle, HDR + b"".join(lines), algo)
+    for bad in (b"9223372036854775808", b"12a", b"+", b""):
+        res = check(oracle, HDR + b"1\t" + bad + b"\t.\tA\tC\t1.5\tPASS\t.\n", abi.EXG_ALGO_AUTO)
+        assert res.error_code != 0
+
+
 @pytest.mark.parametrize("algo", [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS])
 def test_projection_and_capacity(gpu, oracle, algo):
     from exon_duckdb_amd import device
