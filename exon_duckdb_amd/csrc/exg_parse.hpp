@@ -184,6 +184,16 @@ __device__ bool parse_i32(const Src &src, int s, int e, int *out) {
     bool neg = false;
     if (i < e && (src.b(i) == '+' || src.b(i) == '-')) neg = src.b(i++) == '-';
     if (i >= e) return false;
+    if (e - i <= 9) {  // cannot overflow: 32-bit multiply-adds
+        uint32_t v32 = 0;
+        for (; i < e; i++) {
+            const uint32_t d = src.b(i) - '0';
+            if (d > 9u) return false;
+            v32 = v32 * 10u + d;
+        }
+        *out = neg ? -(int)v32 : (int)v32;
+        return true;
+    }
     long long v = 0;
     for (; i < e; i++) {
         uint32_t c = src.b(i);
