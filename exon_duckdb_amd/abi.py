@@ -1,7 +1,8 @@
 """ctypes mirror of include/exon_gpu.h (keep in sync with the header; tests check sizes)."""
 import ctypes as C
 
-EXG_ABI_VERSION = 2
+EXG_ABI_VERSION = 3
+EXG_TYPE_VARCHAR, EXG_TYPE_BIGINT, EXG_TYPE_FLOAT = 1, 2, 3
 EXG_VECTOR_SIZE = 2048
 
 EXG_OK = 0
@@ -128,6 +129,12 @@ class QualityListArgs(C.Structure):
         ("workspace_bytes", C.c_uint64),
         ("stream", C.c_void_p),
     ]
+
+
+class OpenArgs(C.Structure):
+    _fields_ = [("path", C.c_char_p), ("file_format", C.c_char_p), ("compression", C.c_char_p), ("batch_rows", C.c_uint64),
+                ("device", C.c_int), ("device_batch_bytes", C.c_uint64), ("filters", C.c_char_p),
+                ("shard_index", C.c_uint32), ("shard_count", C.c_uint32)]
 
 
 class InflateMember(C.Structure):

@@ -128,6 +128,7 @@ int exg_reader::dev_alloc(void **slot, size_t bytes) {
 exg_reader::~exg_reader() {
     free_device();
     if (d_res) (void)hipFree(d_res);
+    if (d_phase) (void)hipFree(d_phase);
     if (d_filter_prog) (void)hipFree(d_filter_prog);
     if (d_filter_consts) (void)hipFree(d_filter_consts);
     if (d_file) exg_rd::dev_pool()->give(device, d_file, d_file_cap);
@@ -500,6 +501,19 @@ int open_next_file(exg_reader *r) {
         r->vcf_header_bytes = pos;
         r->file_pos = pos;
     }
+    // byte-range shard of this file: [lo, hi) of the bytes behind the header; records / lines belong to the shard they END in
+    r->range_hi = blk->n;
+    r->shard_first = false;
+    if (r->shard_count > 1) {
+        const uint64_t base = r->file_pos, span = blk->n - base;
+        const uint64_t lo = base + (uint64_t)((unsigned __int128)span * r->shard_index / r->shard_count);
+        const uint64_t hi = r->shard_index + 1 == r->shard_count
+                                ? blk->n
+                                : base + (uint64_t)((unsigned __int128)span * (r->shard_index + 1) / r->shard_count);
+        r->file_pos = lo;
+        r->range_hi = hi;
+        r->shard_first = lo > base;
+    }
     return EXG_OK;
 }
 
@@ -507,6 +521,8 @@ int open_next_file(exg_reader *r) {
 // prefetch starts this many bytes before the end of the current batch; a batch whose unconsumed tail is
 // longer (one giant record) falls back to the synchronous upload.
 static constexpr uint64_t kPrefetchSlack = 1u << 20;
+// bytes in front of a shard that travel with its first batch (the beginning of the record that ends behind the cut)
+static constexpr uint64_t kShardHalo = 1u << 20;
 
 int n_string_cols(int format) { return format == EXG_FMT_FASTQ ? 4 : format == EXG_FMT_FASTA ? 3 : 9; }
 
@@ -625,15 +641,25 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
     uint64_t want = r->device_batch_bytes;
     double t_batch = now_s();
     for (;;) {
-        const uint64_t remaining = r->file->n - r->file_pos;
+        const uint64_t remaining = r->range_hi > r->file_pos ? r->range_hi - r->file_pos : 0;
         if (remaining == 0) {
             r->file_done = true;
             return EXG_OK;
         }
         if (r->format == EXG_FMT_FASTA) want = remaining;  // a FASTA record can span the whole file: one batch
         uint64_t n = std::min<uint64_t>(want, remaining);
-        bool eof = n == remaining;
-        int rc = ensure_device(r, n + 16);
+        bool range_end = n == remaining;                    // the batch reaches the end of this reader's bytes ...
+        bool eof = range_end && r->range_hi == r->file->n;  // ... which is the end of the file unless a later shard follows
+        // first batch of a shard that begins inside the file: up to 1 MiB in front of it travels along (`lead`), so that
+        // the record / line that ends behind the cut — it belongs to this shard — has its beginning in the buffer
+        uint64_t shard_halo = 0;
+        if (r->shard_first) {
+            static const uint64_t halo_max = getenv("EXG_SHARD_HALO") ? strtoull(getenv("EXG_SHARD_HALO"), nullptr, 10) : kShardHalo;
+            const uint64_t base = r->format == EXG_FMT_VCF ? r->vcf_header_bytes : 0;
+            const uint64_t from = r->file_pos - std::min<uint64_t>(halo_max, r->file_pos - base);
+            shard_halo = r->file_pos - std::max<uint64_t>(base, from & ~15ull);
+        }
+        int rc = ensure_device(r, n + shard_halo + 16);
         if (rc) return rc;
         // Input of the scan: the inflated bytes already in HBM (gzip), the prefetched slot, or a synchronous
         // H2D copy.  In the first two cases the batch start is only byte aligned: the buffer starts at the
@@ -671,7 +697,8 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             d_input = (const uint8_t *)r->d_in + (off - lead);
             batch_end = r->pf.file_start + r->pf.len;
             n = batch_end - r->file_pos + lead;
-            eof = batch_end == r->file->n;
+            range_end = batch_end == r->range_hi;
+            eof = range_end && r->range_hi == r->file->n;
             h -= lead;
             r->pf.valid = false;
             RD_HIP(r, hipStreamWaitEvent(r->stream, r->up_done, 0));
@@ -679,13 +706,47 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             if (r->pf.valid) RD_HIP(r, hipStreamSynchronize(r->up_stream));  // a prefetch that missed: let it land first
             r->pf.valid = false;
             r->d_in = r->d_in_slot[r->cur_slot];
-            int rc2 = upload_range(r, r->file_pos, n, r->cur_slot, r->stream);
+            lead = shard_halo;
+            int rc2 = upload_range(r, r->file_pos - lead, n + lead, r->cur_slot, r->stream);
             if (rc2) return rc2;
             d_input = r->d_in;
+            n += lead;
+            h -= lead;
+        }
+        uint64_t first_line_index = 0;
+        if (lead && r->shard_first && r->format == EXG_FMT_FASTQ) {
+            // the 4-line phase of the line that holds the shard's first byte, from the bytes around the cut ('@' opens a
+            // record but also quality lines, so several records are looked at: exg_fastq_guess_phase)
+            if (!r->d_phase) RD_HIP(r, hipMalloc(&r->d_phase, 16));
+            uint32_t guess = 0xFFFFFFFFu;
+            rc = exg_fastq_guess_phase(d_input, n, lead, (uint32_t *)r->d_phase, r->stream);
+            if (rc) return fail(r, rc, exg_last_error_message());
+            RD_HIP(r, hipMemcpyAsync(&guess, r->d_phase, 4, hipMemcpyDeviceToHost, r->stream));
+            RD_HIP(r, hipStreamSynchronize(r->stream));
+            if (guess <= 3) {
+                const bool prev_is_nl = ((const uint8_t *)r->file->p)[r->file_pos - 1] == '\n';
+                first_line_index = prev_is_nl ? guess : (guess + 3) % 4;
+            } else {
+                // too few lines around the cut to tell (a tiny file, a tiny shard) or several phases fit: count the
+                // newlines in front of it — exact, and only as slow as a memchr over the page cache
+                const char *d = (const char *)r->file->p;
+                uint64_t nl = 0;
+                for (const char *q = d, *end = d + r->file_pos; q < end;) {
+                    const void *hit = memchr(q, '\n', (size_t)(end - q));
+                    if (!hit) break;
+                    nl++;
+                    q = (const char *)hit + 1;
+                }
+                first_line_index = nl;
+            }
         }
         exg_scan_result res;
         const bool no_store = count_only && !r->has_filter;  // a predicate needs the columns even for COUNT(*)
-        const uint32_t fl = (lead ? 0u : EXG_F_BOF) | (eof ? EXG_F_EOF : 0u) | (no_store ? EXG_F_NO_STORE : 0u);
+        // a line starts at d_input[0] when the batch is record aligned, or when a shard's halo reaches back to the
+        // first byte behind the header
+        const bool at_line_start = lead == 0 || (r->shard_first && shard_halo && lead == shard_halo &&
+                                                 r->file_pos - lead == (r->format == EXG_FMT_VCF ? r->vcf_header_bytes : 0));
+        const uint32_t fl = (at_line_start ? EXG_F_BOF : 0u) | (eof ? EXG_F_EOF : 0u) | (no_store ? EXG_F_NO_STORE : 0u);
         std::shared_ptr<Batch> b;
         if (r->format == EXG_FMT_FASTQ) {
             exg_fastq_scan_args a;
@@ -693,6 +754,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             a.d_input = d_input;
             a.n_bytes = n;
             a.lead = lead;
+            a.first_line_index = first_line_index;
             a.payload_base = (uint64_t)(uintptr_t)h;
             a.flags = fl;
             a.algo = EXG_ALGO_AUTO;
@@ -766,7 +828,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             r->worst_case_rows = true;
             continue;
         }
-        if (res.n_records == 0 && !res.error_code && !eof) {
+        if (res.n_records == 0 && !res.error_code && !eof && !range_end) {
             want *= 2;  // not even one complete record in the batch: widen it
             continue;
         }
@@ -777,11 +839,11 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         double t_pf = now_s();
         // While the columns travel back (and the consumer works through the chunks): start moving the bytes
         // the next batch will need into the other slot.
-        if (!eof && !res.error_code && !r->d_file && r->format != EXG_FMT_FASTA && want == r->device_batch_bytes &&
+        if (!range_end && !res.error_code && !r->d_file && r->format != EXG_FMT_FASTA && want == r->device_batch_bytes &&
             !getenv("EXG_NO_PREFETCH")) {
             const uint64_t slack = std::min<uint64_t>(kPrefetchSlack, (batch_end - r->file_pos) / 2);
             const uint64_t start = (batch_end - slack) & ~15ull;
-            const uint64_t len = std::min<uint64_t>(r->file->n - start, r->device_batch_bytes + slack);
+            const uint64_t len = std::min<uint64_t>(r->range_hi - start, r->device_batch_bytes + slack);
             const int other = r->cur_slot ^ 1;
             if (len + 16 <= r->d_in_cap && r->d_in_slot[other]) {
                 // on a host thread of its own: pread + the H2D enqueue block their caller for as long as the bytes take
@@ -897,10 +959,19 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             r->host_hint = b->host.total + b->host.total / 8 + (1u << 20);
             r->batch = b;
         }
-        if (res.error_code || eof)
+        r->shard_first = false;
+        if (res.error_code || eof) {
             r->file_done = true;
-        else
+        } else {
             r->file_pos += res.consumed_bytes - lead;
+            if (range_end) {
+                // what is left belongs to the next shard, whose halo must reach back to where that record begins
+                r->file_done = true;
+                if (batch_end - r->file_pos > kShardHalo)
+                    return fail(r, EXG_E_UNSUPPORTED, "a record longer than the 1 MiB shard halo crosses the shard boundary at byte " +
+                                                          std::to_string(batch_end) + " of '" + r->files[r->file_idx - 1] + "'");
+            }
+        }
         TRACE("batch (h2d+scan+d2h)", t_batch);
         return EXG_OK;
     }
@@ -948,6 +1019,16 @@ extern "C" int exg_open(const exg_open_args *args, exg_reader **out) {
     else if (const char *e = getenv("EXG_DEVICE_BATCH_BYTES"))  // tuning / test knob
         r->device_batch_bytes = std::max<uint64_t>(4096, (strtoull(e, nullptr, 10) + 15) / 16 * 16);
     r->device = args->device;
+    r->shard_count = args->shard_count ? args->shard_count : 1;
+    r->shard_index = args->shard_index;
+    if (r->shard_index >= r->shard_count) {
+        exg::set_error("exg_open: shard_index %u is not below shard_count %u", r->shard_index, r->shard_count);
+        return EXG_E_INVALID_ARG;
+    }
+    if (r->shard_count > 1 && (r->format == EXG_FMT_FASTA || r->compression == kGzip)) {
+        exg::set_error("byte-range shards are for FASTQ and VCF text: a FASTA record can span the file, a gzip stream has no cut points");
+        return EXG_E_UNSUPPORTED;
+    }
     int rc = list_files(r.get(), path);
     if (rc) return rc;
     if (r->compression != kNone && r->compression != kGzip) {

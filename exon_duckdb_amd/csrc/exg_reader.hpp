@@ -225,6 +225,10 @@ struct exg_reader {
     size_t host_hint = 0;  // pinned bytes the previous batch's host vectors needed
     std::vector<std::pair<void **, size_t>> dev_allocs;  // pooled device buffers of this reader (slot, bytes)
     int dev_alloc(void **slot, size_t bytes);
+    uint32_t shard_index = 0, shard_count = 1;  // byte-range shards of every file (exg_open_args)
+    uint64_t range_hi = 0;    // this reader's bytes of the current file end here (file size without shards)
+    bool shard_first = false; // the next batch is the first of a shard that begins inside the file: halo + phase
+    void *d_phase = nullptr;  // device u32 for exg_fastq_guess_phase
     uint64_t gz_header_prefix = 0;  // gzip + VCF: bytes of the inflated file's start held in file->p (header parse)
     bool worst_case_rows = false;
     // exg_open_args.filters: postfix program + constants in device memory, a row map and one column of scratch

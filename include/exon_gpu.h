@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define EXG_ABI_VERSION 2
+#define EXG_ABI_VERSION 3
 
 /* DuckDB v0.8.1 STANDARD_VECTOR_SIZE; the reference asks the Rust side for
  * batches of exactly this many rows (module.cpp:83, :233). */
@@ -297,6 +297,12 @@ typedef struct exg_open_args {
     const char *filters;     /* NULL / "" or the predicate FilterToString renders (module.cpp:158-214), same grammar as
                               * new_reader's: evaluated on the device, only the rows where it is TRUE are copied back.
                               * VCF id / alt / filter / info / formats are VARCHAR at this boundary and may be compared. */
+    uint32_t shard_index;    /* byte-range shards of every file: this reader yields the records / lines that */
+    uint32_t shard_count;    /* END in its 1/shard_count of the bytes behind the header; 0 or 1 = the whole file.  One process
+                              * per GPU opens the same path with its rank: the shards partition the rows, in file order, with
+                              * no exchange (the FASTQ 4-line phase at a cut is found from the bytes around it).  A record
+                              * longer than the 1 MiB halo across a cut is an error, never a silent loss.  FASTA (a record
+                              * can span the file) and gzip inputs are not sharded: EXG_E_UNSUPPORTED. */
 } exg_open_args;
 
 #define EXG_TYPE_VARCHAR 1

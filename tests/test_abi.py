@@ -33,7 +33,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert os.path.exists(LIB_PATH)
     missing = [f for f in declared_functions() if not hasattr(lib, f)]
     assert not missing, f"declared in include/exon_gpu.h but not exported: {missing}"
-    assert lib.exg_abi_version() == 2
+    assert lib.exg_abi_version() == 3
     lib.exg_parse_error_string.restype = C.c_char_p
     assert lib.exg_parse_error_string(1) == b"invalid name prefix"
 

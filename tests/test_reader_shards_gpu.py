@@ -1,0 +1,108 @@
+"""Byte-range shards at the reader boundary (exg_open_args.shard_index / shard_count): the shards of a
+file partition its rows, in file order, whatever the cut points hit — mid record, mid line, on a quality line that
+starts with '@', inside the VCF header."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def whole(path, fmt):
+    from exon_duckdb_amd.reader import ShardReader
+    r = ShardReader(path, fmt)
+    rows = r.rows()
+    r.close()
+    return rows
+
+
+def sharded(path, fmt, n, **kw):
+    from exon_duckdb_amd.reader import ShardReader
+    rows, counts = [], []
+    for i in range(n):
+        r = ShardReader(path, fmt, shard_index=i, shard_count=n, **kw)
+        part = r.rows()
+        r.close()
+        c = ShardReader(path, fmt, shard_index=i, shard_count=n, **kw)
+        counts.append(c.count())
+        c.close()
+        assert counts[-1] == len(part)
+        rows.extend(part)
+    return rows, counts
+
+
+@pytest.mark.parametrize("n_shards", [2, 3, 8, 61])
+def test_fastq_shards_partition_the_rows(gpu, oracle, tmp_path, n_shards):
+    data = bytes(oracle.synth_fastq_ragged(30000))          # ragged: CRLF, missing descriptions, no final newline
+    p = tmp_path / "ragged.fastq"
+    p.write_bytes(data)
+    want = whole(str(p), "fastq")
+    assert len(want) == 30000
+    got, counts = sharded(str(p), "fastq", n_shards)
+    assert got == want
+    assert sum(counts) == 30000 and min(counts) > 0
+
+
+def test_fastq_150_quality_lines_that_start_with_at(gpu, oracle, tmp_path):
+    # 1/41 of the quality lines of the synthetic FASTQ-150 start with '@': cuts land on them, the phase must hold
+    data = bytes(oracle.synth_fastq(332 * 50000))
+    p = tmp_path / "f150.fastq"
+    p.write_bytes(data)
+    want = whole(str(p), "fastq")
+    for n in (7, 97):
+        got, _ = sharded(str(p), "fastq", n)
+        assert got == want
+
+
+def test_shards_with_small_device_batches_and_small_halo(gpu, oracle, tmp_path, monkeypatch):
+    data = bytes(oracle.synth_fastq_ragged(20000))
+    p = tmp_path / "r.fastq"
+    p.write_bytes(data)
+    want = whole(str(p), "fastq")
+    monkeypatch.setenv("EXG_SHARD_HALO", "4096")
+    got, _ = sharded(str(p), "fastq", 5, device_batch_bytes=65536)
+    assert got == want
+
+
+@pytest.mark.parametrize("n_shards", [2, 5, 33])
+def test_vcf_shards_partition_the_rows(gpu, oracle, tmp_path, n_shards):
+    data = bytes(oracle.synth_vcf(20000))
+    p = tmp_path / "s.vcf"
+    p.write_bytes(data)
+    want = whole(str(p), "vcf")
+    assert len(want) == 20000
+    got, counts = sharded(str(p), "vcf", n_shards)
+    assert got == want and sum(counts) == 20000
+
+
+def test_more_shards_than_records(gpu, golden_dir):
+    want = whole(f"{golden_dir}/test.fastq", "fastq")
+    got, counts = sharded(f"{golden_dir}/test.fastq", "fastq", 16)
+    assert got == want and sum(counts) == 2
+    want = whole(f"{golden_dir}/vcf/index.vcf", "vcf")
+    got, _ = sharded(f"{golden_dir}/vcf/index.vcf", "vcf", 9)
+    assert got == want and len(got) == 621
+
+
+def test_unshardable_inputs_fail_loudly(gpu, golden_dir):
+    from exon_duckdb_amd._lib import ExgError
+    from exon_duckdb_amd.reader import ShardReader
+    for path, fmt in ((f"{golden_dir}/test.fasta", "fasta"), (f"{golden_dir}/test.fastq.gz", "fastq")):
+        with pytest.raises(ExgError):
+            ShardReader(path, fmt, shard_index=0, shard_count=2)
+    with pytest.raises(ExgError):
+        ShardReader(f"{golden_dir}/test.fastq", "fastq", shard_index=2, shard_count=2)
+
+
+def test_record_longer_than_the_halo_across_a_cut_is_an_error(gpu, tmp_path, monkeypatch):
+    from exon_duckdb_amd._lib import ExgError
+    from exon_duckdb_amd.reader import ShardReader
+    # one 3 MB read in the middle of short ones: the cut of 2 shards falls inside it
+    short = b"".join(b"@r%d\nACGT\n+\nIIII\n" % i for i in range(1000))
+    long_read = b"@long\n" + b"A" * 3_000_000 + b"\n+\n" + b"I" * 3_000_000 + b"\n"
+    p = tmp_path / "long.fastq"
+    p.write_bytes(short + long_read + short)
+    r = ShardReader(str(p), "fastq", shard_index=0, shard_count=2)
+    with pytest.raises(ExgError, match="halo"):
+        r.rows()
+    r.close()
+    assert len(whole(str(p), "fastq")) == 2001

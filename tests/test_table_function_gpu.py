@@ -327,11 +327,9 @@ def test_filter_on_unknown_column_is_a_bind_time_error(gpu, golden_dir):
     from exon_duckdb_amd.table_function import _lib  # noqa: F401  (binds the library)
     from exon_duckdb_amd import load_library
 
-    class OpenArgs(C.Structure):
-        _fields_ = [("path", C.c_char_p), ("file_format", C.c_char_p), ("compression", C.c_char_p), ("batch_rows", C.c_uint64),
-                    ("device", C.c_int), ("device_batch_bytes", C.c_uint64), ("filters", C.c_char_p)]
+    from exon_duckdb_amd.abi import OpenArgs
     lib = load_library()
-    a = OpenArgs(G(golden_dir, "test.fastq").encode(), b"fastq", None, 2048, 0, 0, b"nope='x'")
+    a = OpenArgs(G(golden_dir, "test.fastq").encode(), b"fastq", None, 2048, 0, 0, b"nope='x'", 0, 0)
     r = C.c_void_p()
     assert lib.exg_open(C.byref(a), C.byref(r)) != 0
     assert b"could not execute sql" in lib.exg_last_error_message()
