@@ -106,3 +106,4 @@ def test_record_longer_than_the_halo_across_a_cut_is_an_error(gpu, tmp_path, mon
         r.rows()
     r.close()
     assert len(whole(str(p), "fastq")) == 2001
+
