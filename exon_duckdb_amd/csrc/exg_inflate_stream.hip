@@ -296,7 +296,7 @@ extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint6
     }
     *d_out_p = nullptr;
     *produced = *consumed = 0;
-    if (chunk_bytes < 65536) chunk_bytes = 65536;
+    if (chunk_bytes < 32768) chunk_bytes = 32768;
     const double t_begin = st_now();
     const uint64_t total_bits = comp_size * 8;
     // ---- 1. block starts near the chunk boundaries

@@ -359,11 +359,11 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
         if (k == 0) break;
         // one big member of unknown size (what gzip / pigz write): per-member parallelism would put the whole file
         // on ONE wavefront — decode it in chunks instead (exg_inflate_stream.hip)
-        static const uint64_t stream_min = getenv("EXG_STREAM_MIN_BYTES") ? strtoull(getenv("EXG_STREAM_MIN_BYTES"), nullptr, 10) : (4ull << 20);
+        static const uint64_t stream_min = getenv("EXG_STREAM_MIN_BYTES") ? strtoull(getenv("EXG_STREAM_MIN_BYTES"), nullptr, 10) : (128ull << 10);  // (one wavefront does ~13 MB/s: 4 MB took 0.3 s)
         if (k == 1 && open_ended && !d_out && members[0].comp_size >= stream_min && !getenv("EXG_NO_STREAM_INFLATE")) {
-            // one piece per decoding wavefront the chip holds (5120; the gap rounds add a few), at least 64 KiB each
-            // (a block is 20-60 KB of input): the chunk decode lasts as long as its longest piece
-            uint64_t chunk = std::max<uint64_t>(64u << 10, (members[0].comp_size / 4800 + 16383) & ~16383ull);
+            // one piece per decoding wavefront the chip holds (5120; the gap rounds add a few), at least 32 KiB each
+            // (a block is 20-60 KB of input): a small file's decode lasts as long as one piece
+            uint64_t chunk = std::max<uint64_t>(32u << 10, (members[0].comp_size / 4800 + 16383) & ~16383ull);
             if (getenv("EXG_STREAM_CHUNK_BYTES")) chunk = strtoull(getenv("EXG_STREAM_CHUNK_BYTES"), nullptr, 10);
             uint64_t produced = 0, consumed = 0;
             void *d_big = nullptr;
