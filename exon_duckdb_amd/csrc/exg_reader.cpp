@@ -360,7 +360,16 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
         // one big member of unknown size (what gzip / pigz write): per-member parallelism would put the whole file
         // on ONE wavefront — decode it in chunks instead (exg_inflate_stream.hip)
         static const uint64_t stream_min = getenv("EXG_STREAM_MIN_BYTES") ? strtoull(getenv("EXG_STREAM_MIN_BYTES"), nullptr, 10) : (128ull << 10);  // (one wavefront does ~13 MB/s: 4 MB took 0.3 s)
-        if (k == 1 && open_ended && !d_out && members[0].comp_size >= stream_min && !getenv("EXG_NO_STREAM_INFLATE")) {
+        const bool stream_ok = !getenv("EXG_NO_STREAM_INFLATE");
+        uint64_t resume = 0;  // != 0: where the next round starts (the gzip header of a member left out of this one)
+        if (k > 1 && open_ended && stream_ok && members[k - 1].comp_size >= stream_min) {
+            // sized members followed by a big one of unknown size: these first, the big one in a round of its own
+            k--;
+            open_ended = 0;
+            total = members[k].out_off;                                 // the sum up to the member left out
+            resume = members[k - 1].comp_off + members[k - 1].comp_size;  // sized member: its end is the next header
+        }
+        if (k == 1 && open_ended && stream_ok && members[0].comp_size >= stream_min) {
             // one piece per decoding wavefront the chip holds (5120; the gap rounds add a few), at least 32 KiB each
             // (a block is 20-60 KB of input): a small file's decode lasts as long as one piece
             uint64_t chunk = std::max<uint64_t>(32u << 10, (members[0].comp_size / 4800 + 16383) & ~16383ull);
@@ -369,10 +378,28 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
             void *d_big = nullptr;
             rc = exg_inflate_stream(d_comp, members[0].comp_off, members[0].comp_size, chunk, &d_big, &produced, &consumed, r->stream);
             if (rc) return fail(r, rc, std::string(exg_last_error_message()) + " in '" + path + "'");
-            d_out = d_big;
-            d_out_cap = produced + 64;
-            produced_total = produced;
-            out_cap_total = produced;
+            if (!d_out) {
+                d_out = d_big;
+                d_out_cap = produced + 64;
+                produced_total = produced;
+            } else {
+                // a later member of a concatenation (`cat a.gz b.gz`): its bytes go behind what is there
+                const uint64_t ncap = produced_total + produced + 64;
+                void *nd = exg_rd::dev_pool()->take(r->device, ncap);
+                hipError_t he = nd ? hipMemcpyAsync(nd, d_out, produced_total, hipMemcpyDeviceToDevice, r->stream) : hipErrorOutOfMemory;
+                if (he == hipSuccess) he = hipMemcpyAsync((char *)nd + produced_total, d_big, produced, hipMemcpyDeviceToDevice, r->stream);
+                if (he == hipSuccess) he = hipStreamSynchronize(r->stream);
+                exg_rd::dev_pool()->give(r->device, d_big, produced + 64);
+                if (he != hipSuccess) {
+                    if (nd) exg_rd::dev_pool()->give(r->device, nd, ncap);
+                    return fail(r, EXG_E_HIP, std::string("appending the inflated member failed: ") + hipGetErrorString(he));
+                }
+                exg_rd::dev_pool()->give(r->device, d_out, d_out_cap);
+                d_out = nd;
+                d_out_cap = ncap;
+                produced_total += produced;
+            }
+            out_cap_total = produced_total;
             start = members[0].comp_off + consumed + 8;
             continue;
         }
@@ -421,7 +448,7 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
             start = m.comp_off + st[k - 1].consumed + 8;
         } else {
             produced_total = out_cap_total;
-            start = n;
+            start = resume ? resume : n;
         }
     }
     // The inflated bytes stay in HBM.  What the string_t payload pointers address is a host copy made batch by

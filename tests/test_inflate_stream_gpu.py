@@ -120,3 +120,41 @@ def test_concatenated_big_members(gpu, oracle, tmp_path, monkeypatch):
     monkeypatch.setenv("EXG_STREAM_MIN_BYTES", str(1 << 16))
     con = table_function.connect()
     assert con.table_function("read_fastq", str(p)).count() == 30000
+
+
+def test_cat_of_big_members_and_bgzf_blocks(gpu, oracle, tmp_path):
+    """`cat a.gz b.gz`-style inputs: every big member of unknown size takes the chunked decode (a later one used to
+    fall to ONE wavefront: 13 MB/s), sized BGZF blocks in between take the per-member kernel; the rows are the
+    concatenation."""
+    import struct
+
+    from exon_duckdb_amd import table_function
+    raw = bytes(oracle.synth_fastq_ragged(9000, seed=77))
+    # cut at record boundaries so that every part is a FASTQ file of its own
+    lines = raw.split(b"\n")
+    rec_bytes = [sum(len(x) + 1 for x in lines[i:i + 4]) for i in range(0, len(lines) - (len(lines) % 4), 4)]
+    cuts = [2500, 4000, 6500]
+    offs = [0] + [sum(rec_bytes[:c]) for c in cuts] + [len(raw)]
+    parts = [raw[offs[i]:offs[i + 1]] for i in range(4)]
+
+    def bgzf(data):
+        out = []
+        for i in range(0, len(data), 65280):
+            chunk = data[i:i + 65280]
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            d = co.compress(chunk) + co.flush()
+            out.append(b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\0\xff" + struct.pack("<H", 6) + b"BC" +
+                       struct.pack("<HH", 2, 12 + 6 + len(d) + 8 - 1) + d + struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+        return b"".join(out)
+
+    blob = gzip.compress(parts[0], 6, mtime=0) + bgzf(parts[1]) + gzip.compress(parts[2], 6, mtime=0) + gzip.compress(parts[3], 6, mtime=0)
+    assert all(len(gzip.compress(p, 6, mtime=0)) > (128 << 10) for p in (parts[0], parts[2], parts[3]))
+    p = tmp_path / "cat.fastq.gz"
+    p.write_bytes(blob)
+    q = tmp_path / "cat.fastq"
+    q.write_bytes(raw)
+    con = table_function.connect()
+    want = con.table_function("read_fastq", str(q)).fetchall()
+    rel = con.table_function("read_fastq", str(p))
+    assert rel.count() == len(want) == 9000
+    assert rel.fetchall() == want
