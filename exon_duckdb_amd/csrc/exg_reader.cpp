@@ -734,7 +734,15 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             r->pf.valid = false;
             r->d_in = r->d_in_slot[r->cur_slot];
             lead = shard_halo;
-            int rc2 = upload_range(r, r->file_pos - lead, n + lead, r->cur_slot, r->stream);
+            int rc2;
+            if (r->format == EXG_FMT_FASTA && r->file_pos == 0 && n > (512ull << 20)) {
+                // a whole genome in one batch: through two 256 MiB pinned windows, not one pinned block of its size
+                rc2 = upload_file(r, r->d_in, n);
+                if (!rc2 && hipMemsetAsync((char *)r->d_in + n, 0, 16, r->stream) != hipSuccess)
+                    rc2 = fail(r, EXG_E_HIP, "hipMemsetAsync failed");
+            } else {
+                rc2 = upload_range(r, r->file_pos - lead, n + lead, r->cur_slot, r->stream);
+            }
             if (rc2) return rc2;
             d_input = r->d_in;
             n += lead;
