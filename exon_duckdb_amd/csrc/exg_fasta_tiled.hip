@@ -69,9 +69,20 @@ __device__ __forceinline__ uint32_t byte_of(const uint4 v, uint32_t b) {  // b <
     return (w >> (8 * (b & 3))) & 0xFFu;
 }
 
-__device__ __forceinline__ Chunk classify16(const uint4 v, const uint8_t *__restrict__ d_in, uint64_t o, uint64_t n_bytes) {
+// the byte behind every lane's chunk (input offset o + 16; 0 behind the end of the input): the first byte of the lane
+// above — one DPP wave shift — and, for lane 63, of the row after this one (`next_row_first`, when the caller has it in
+// registers) or a single-lane load
+__device__ __forceinline__ uint32_t byte_after_chunk(const uint4 v, bool have_next_row, uint32_t next_row_first,
+                                                     const uint8_t *__restrict__ d_in, uint64_t o, uint64_t n_bytes) {
+    uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v.x & 0xFFu), 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+    if ((threadIdx.x & 63) == 63) nb = have_next_row ? next_row_first : (o + 16 < n_bytes ? (uint32_t)d_in[o + 16] : 0u);
+    return nb;
+}
+
+// `full`: the whole row lies inside the input (wave uniform): no per-lane bounds
+__device__ __forceinline__ Chunk classify16(const uint4 v, uint32_t next_byte, bool full, uint64_t o, uint64_t n_bytes) {
     Chunk c;
-    const uint32_t valid = o >= n_bytes ? 0u : below((uint32_t)(n_bytes - o < 16 ? n_bytes - o : 16));
+    const uint32_t valid = full ? 0xFFFFu : (o >= n_bytes ? 0u : below((uint32_t)(n_bytes - o < 16 ? n_bytes - o : 16)));
     const uint32_t nl = match16(v, 0x0A0A0A0Au) & valid;
     c.hi = ((v.x | v.y | v.z | v.w) & 0x80808080u) != 0;  // bytes past the end are zero
     c.nl = nl;
@@ -84,15 +95,14 @@ __device__ __forceinline__ Chunk classify16(const uint4 v, const uint8_t *__rest
         // CR only in front of a real LF (a CR at byte 15 is looked at below, by its own chunk)
         if (b > 0 && byte_of(v, b - 1) == '\r') strip |= 1u << (b - 1);
         // the line that starts after this newline
-        const uint32_t next = b < 15 ? ((valid >> (b + 1)) & 1u ? byte_of(v, b + 1) : 0u)
-                                     : (o + 16 < n_bytes ? (uint32_t)d_in[o + 16] : 0u);
+        const uint32_t next = b < 15 ? ((valid >> (b + 1)) & 1u ? byte_of(v, b + 1) : 0u) : next_byte;
         if (next == '>') {
             def_after |= 1u << b;
             const uint32_t e = m ? (uint32_t)__ffs((int)m) - 1 : 16u;  // up to the next newline
             def_region |= below(e) & ~below(b + 1);
         }
     }
-    if ((v.w >> 24) == '\r' && (valid >> 15) && o + 16 < n_bytes && d_in[o + 16] == '\n') strip |= 1u << 15;
+    if ((v.w >> 24) == '\r' && (valid >> 15) && next_byte == '\n') strip |= 1u << 15;
     c.def_after = def_after;
     c.last_is_def = c.has_nl && ((def_after >> (31 - __clz((int)nl))) & 1u);
     const uint32_t first = c.has_nl ? (uint32_t)__ffs((int)nl) - 1 : 16u;
@@ -152,8 +162,9 @@ __global__ __launch_bounds__(kThreads) void k_fa_tile_count(FastaDev a, TileArra
     for (uint64_t tile = wave; tile < n_tiles; tile += n_waves) {
         bool def0;
         Carry carry = tile_carry(a, tile, &def0);
-        // packed per-lane sums: [0,16) bytes after a known state, [16,32) head bytes, [32,48) definitions, [48,63) newlines
-        unsigned long long acc = (def0 && lane == 0) ? 1ull << 32 : 0ull;
+        // packed per-lane sums (<= 256 each): accA = bytes after a known state | head bytes << 16, accB = definitions |
+        // newlines << 16
+        uint32_t accA = 0, accB = (def0 && lane == 0) ? 1u : 0u;
         bool any_hi = false;
 #pragma unroll 1
         for (int g = 0; g < 4; g++) {
@@ -165,21 +176,23 @@ __global__ __launch_bounds__(kThreads) void k_fa_tile_count(FastaDev a, TileArra
                 const uint64_t off = gbase + (uint64_t)k * 1024 + (uint64_t)lane * 16;
                 v[k] = off < a.n_bytes ? *reinterpret_cast<const uint4 *>(a.d_in + off) : make_uint4(0, 0, 0, 0);
             }
+            const bool full = gbase + 4096 + 16 <= a.n_bytes;  // the four rows and the byte behind them
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint64_t o = gbase + (uint64_t)k * 1024 + (uint64_t)lane * 16;
-                const Chunk c = classify16(v[k], a.d_in, o, a.n_bytes);
+                const uint32_t nb = byte_after_chunk(v[k], k < 3, k < 3 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)v[k < 3 ? k + 1 : 3].x) & 0xFFu : 0u,
+                                                     a.d_in, o, a.n_bytes);
+                const Chunk c = classify16(v[k], nb, full, o, a.n_bytes);
                 const Carry st = lane_state(c, carry);
-                const unsigned long long known = (unsigned long long)__popc(c.pay_known), head = (unsigned long long)__popc(c.pay_head);
+                const uint32_t known = (uint32_t)__popc(c.pay_known), head = (uint32_t)__popc(c.pay_head);
                 // a lane whose state is known counts its head bytes itself; otherwise they are the tile's head
-                acc += known + ((st.resolved && !st.in_def) ? head : 0ull);
-                acc += (st.resolved ? 0ull : head) << 16;
-                acc += (unsigned long long)__popc(c.def_after) << 32;
-                acc += (unsigned long long)__popc(c.nl) << 48;
+                accA += known + ((st.resolved && !st.in_def) ? head : 0u) + ((st.resolved ? 0u : head) << 16);
+                accB += (uint32_t)__popc(c.def_after) + ((uint32_t)__popc(c.nl) << 16);
                 any_hi = any_hi || c.hi;
             }
         }
-        const unsigned long long tot = wave_sum64(acc);
+        // (64 lanes x 256 < 2^16: the fields do not run into each other)
+        const unsigned long long tot = wave_sum64((unsigned long long)accA | ((unsigned long long)accB << 32));
         const bool hi = __ballot(any_hi) != 0;
         if (lane == 0) {
             t.desc[tile] = pack_desc((uint32_t)((tot >> 32) & 0xFFFFu), (uint32_t)(tot & 0xFFFFu), (uint32_t)((tot >> 16) & 0xFFFFu),
@@ -373,7 +386,10 @@ __global__ __launch_bounds__(kThreads) void k_fa_tile_emit(FastaDev a, TileArray
             const uint4 v = v_next;
             if (row < 15 && o + 1024 < a.n_bytes) v_next = *reinterpret_cast<const uint4 *>(a.d_in + o + 1024);  // next row in flight
             else v_next = make_uint4(0, 0, 0, 0);
-            const Chunk c = classify16(v, a.d_in, o, a.n_bytes);
+            const bool have_next = row < 15 && rbase + 1024 < a.n_bytes;
+            const uint32_t nb = byte_after_chunk(v, have_next, (uint32_t)__builtin_amdgcn_readfirstlane((int)v_next.x) & 0xFFu, a.d_in, o,
+                                                 a.n_bytes);
+            const Chunk c = classify16(v, nb, rbase + 1024 + 16 <= a.n_bytes, o, a.n_bytes);
             const Carry st = lane_state(c, carry);
             const bool in_def = st.resolved ? st.in_def : tile_in_def;
             const uint32_t pay = c.pay_known | (in_def ? 0u : c.pay_head);
