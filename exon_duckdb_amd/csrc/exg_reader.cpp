@@ -188,6 +188,8 @@ static bool trace_on() {
         if (trace_on()) fprintf(stderr, "[exg] %-22s %.1f ms\n", label, (now_s() - (t0)) * 1e3); \
     } while (0)
 
+static constexpr uint64_t kShardHaloBytes = 1u << 20;  // (= kShardHalo, which is defined with the batch logic below)
+
 // gzip + VCF: the header is parsed on the host, so the leading '#' lines of the inflated bytes come back
 // (blk->p then holds a prefix of the file, blk->n stays the inflated size; the DataChunk payload travels per batch)
 static int gz_host_header(exg_reader *r, PinnedBlock &b, const void *d_file) {
@@ -218,7 +220,7 @@ static int gz_host_header(exg_reader *r, PinnedBlock &b, const void *d_file) {
 // The whole (compressed) file -> d_dst on r->stream: windows of 256 MiB through two pooled pinned blocks, each window
 // read by parallel pread and sent slice by slice (the mechanism of upload_range; a hipMemcpyAsync straight from the
 // page-cache mapping is a pageable copy: one staging thread inside the runtime, 10-33 GB/s depending on the box).
-static int upload_file(exg_reader *r, void *d_dst, uint64_t n) {
+static int upload_file(exg_reader *r, void *d_dst, uint64_t n, uint64_t file_off = 0) {
     const size_t window = 256u << 20, slice = 8u << 20;
     const int fd = r->fd_keep->fd;
     char *blk[2] = {nullptr, nullptr};
@@ -258,7 +260,7 @@ static int upload_file(exg_reader *r, void *d_dst, uint64_t n) {
                 const size_t o = i * slice, sl = std::min<size_t>(slice, len - o);
                 size_t got = 0;
                 while (got < sl) {
-                    ssize_t k = pread(fd, blk[b] + o + got, sl - got, (off_t)(off + o + got));
+                    ssize_t k = pread(fd, blk[b] + o + got, sl - got, (off_t)(file_off + off + o + got));
                     if (k <= 0) {
                         bad = 1;
                         return;
@@ -281,6 +283,162 @@ static int upload_file(exg_reader *r, void *d_dst, uint64_t n) {
     return EXG_OK;
 }
 
+// BGZF input read as shard `shard_index` of `shard_count`: the members are divided among the shards (the index costs a
+// pointer chase, no decode), this reader uploads and inflates only its own members plus ~1 MiB of members in front of
+// them — the halo that holds the beginning of the record that ends behind the cut — and scans them like a text shard.
+// One BGZF member at `pos` (RFC 1952 header with FEXTRA and a 'BC' subfield, as bgzip / htslib write it):
+// fills m (out_off = 0) and returns the offset of the next member, or 0 when this is not such a header.
+static uint64_t bgzf_member_at(const uint8_t *d, uint64_t n, uint64_t pos, exg_inflate_member *m) {
+    if (pos + 18 > n || d[pos] != 0x1f || d[pos + 1] != 0x8b || d[pos + 2] != 8 || d[pos + 3] != 4) return 0;
+    const uint64_t xlen = d[pos + 10] | ((uint64_t)d[pos + 11] << 8);
+    if (pos + 12 + xlen > n) return 0;
+    int64_t bsize = -1;
+    for (uint64_t q = pos + 12; q + 4 <= pos + 12 + xlen;) {
+        const uint64_t slen = d[q + 2] | ((uint64_t)d[q + 3] << 8);
+        if (d[q] == 'B' && d[q + 1] == 'C' && slen == 2 && q + 6 <= pos + 12 + xlen) bsize = d[q + 4] | ((int64_t)d[q + 5] << 8);
+        q += 4 + slen;
+    }
+    if (bsize < 0) return 0;
+    const uint64_t end = pos + (uint64_t)bsize + 1, p = pos + 12 + xlen;
+    if (end > n || end < p + 8) return 0;
+    m->comp_off = p;
+    m->comp_size = end - p;
+    m->out_off = 0;
+    m->out_cap = d[end - 4] | ((uint64_t)d[end - 3] << 8) | ((uint64_t)d[end - 2] << 16) | ((uint64_t)d[end - 1] << 24);
+    return m->out_cap <= 65536 ? end : 0;
+}
+// first member that starts at or after `from`: a header whose chain holds for four more members (or runs into the
+// end of the file) — the signature alone also occurs inside compressed data
+static uint64_t bgzf_find(const uint8_t *d, uint64_t n, uint64_t from) {
+    for (uint64_t pos = from; pos + 18 <= n; pos++) {
+        if (d[pos] != 0x1f) {
+            const void *hit = memchr(d + pos, 0x1f, (size_t)(n - pos));
+            if (!hit) return n;
+            pos = (uint64_t)((const uint8_t *)hit - d);
+            if (pos + 18 > n) return n;
+        }
+        exg_inflate_member m;
+        uint64_t q = pos;
+        int hops = 0;
+        while (hops < 5 && q < n) {
+            const uint64_t nx = bgzf_member_at(d, n, q, &m);
+            if (!nx) break;
+            q = nx;
+            hops++;
+        }
+        if (hops == 5 || (hops > 0 && q == n)) return pos;
+    }
+    return n;
+}
+
+// BGZF input read as shard `shard_index` of `shard_count`: a member belongs to the shard in whose 1/shard_count of the
+// FILE's bytes its header begins.  The reader finds its members without indexing the file (a header search near the
+// cut, then a walk through its own range: a pointer chase over the whole file costs 110 ms per 10 GB), uploads and
+// inflates only them plus ~1 MiB of members in front — the halo that holds the beginning of the record that ends behind
+// the cut — and scans them like a text shard.
+static int inflate_file_shard(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::string &path) {
+    const uint8_t *comp = (const uint8_t *)blk->p;
+    const uint64_t n = blk->n;
+    {
+        exg_inflate_member probe;
+        if (!bgzf_member_at(comp, n, 0, &probe))
+            return fail(r, EXG_E_UNSUPPORTED, "shards of a gzip input need BGZF framing (every member carries its size): '" + path + "'");
+    }
+    const uint64_t lo = (uint64_t)((unsigned __int128)n * r->shard_index / r->shard_count);
+    const uint64_t hi = r->shard_index + 1 == r->shard_count ? n : (uint64_t)((unsigned __int128)n * (r->shard_index + 1) / r->shard_count);
+    // candidates for the halo: members that begin in the ~1.5 MiB of file in front of the cut (BGZF does not expand)
+    std::vector<exg_inflate_member> mem;
+    std::vector<uint64_t> hdr;  // where each member's gzip header begins
+    const uint64_t back = kShardHaloBytes + (kShardHaloBytes >> 1);
+    uint64_t pos = lo == 0 ? 0 : bgzf_find(comp, n, lo > back ? lo - back : 0);
+    uint64_t m0 = 0;  // index in `mem` of the first own member
+    bool seen_own = false;
+    while (pos < hi && pos < n) {
+        exg_inflate_member m;
+        const uint64_t nx = bgzf_member_at(comp, n, pos, &m);
+        if (!nx) return fail(r, EXG_E_PARSE, "not a BGZF member at byte " + std::to_string(pos) + " of '" + path + "'");
+        if (!seen_own && pos >= lo) {
+            seen_own = true;
+            m0 = mem.size();
+        }
+        mem.push_back(m);
+        hdr.push_back(pos);
+        pos = nx;
+    }
+    if (!seen_own) m0 = mem.size();
+    const uint64_t m1 = mem.size();
+    // keep only ~1 MiB (inflated) of the members in front
+    uint64_t h0 = m0, halo_bytes = 0;
+    while (h0 > 0 && halo_bytes < kShardHaloBytes) halo_bytes += mem[--h0].out_cap;
+    const bool halo_from_file_start = h0 == 0 && !hdr.empty() && hdr[0] == 0;  // byte 0 of the inflated halo begins a line
+    exg_inflate_member *members = mem.data();
+    {
+        uint64_t out = 0;
+        for (uint64_t i = h0; i < m1; i++) {
+            members[i].out_off = out;
+            out += members[i].out_cap;
+        }
+    }
+    int rc = 0;
+    auto out_blk = std::make_shared<PinnedBlock>();
+    r->range_preset = true;
+    r->preset_pos = 0;
+    r->range_eof = hi == n;
+    r->data0_is_line_start = true;
+    r->d_file = nullptr;
+    r->d_file_bytes = 0;
+    r->gz_header_prefix = 0;
+    if (m1 == m0) {  // more shards than members: nothing here
+        blk = out_blk;
+        return EXG_OK;
+    }
+    const uint64_t c0 = hdr[h0];  // the gzip header of member h0
+    const uint64_t c0a = c0 & ~15ull, c1 = members[m1 - 1].comp_off + members[m1 - 1].comp_size;
+    const uint64_t out0 = members[h0].out_off, out_total = members[m1 - 1].out_off + members[m1 - 1].out_cap - out0;
+    struct Pooled {
+        int dev;
+        void *p;
+        size_t sz;
+        ~Pooled() { if (p) exg_rd::dev_pool()->give(dev, p, sz); }
+    };
+    Pooled comp_buf{r->device, exg_rd::dev_pool()->take(r->device, c1 - c0a + 64), (size_t)(c1 - c0a + 64)};
+    Pooled out_buf{r->device, exg_rd::dev_pool()->take(r->device, out_total + 64), (size_t)(out_total + 64)};
+    if (!comp_buf.p || !out_buf.p) return fail(r, EXG_E_HIP, "out of device memory for the shard's members");
+    if ((rc = upload_file(r, comp_buf.p, c1 - c0a, c0a))) return rc;
+    const uint64_t cnt = m1 - h0;
+    for (uint64_t i = h0; i < m1; i++) members[i].comp_off -= c0a, members[i].out_off -= out0;
+    void *d_members = nullptr, *d_status = nullptr;
+    struct Free {
+        void *p;
+        ~Free() { if (p) (void)hipFree(p); }
+    };
+    RD_HIP(r, hipMalloc(&d_members, cnt * sizeof(exg_inflate_member)));
+    Free fm{d_members};
+    RD_HIP(r, hipMalloc(&d_status, cnt * sizeof(exg_inflate_status)));
+    Free fs{d_status};
+    RD_HIP(r, hipMemcpyAsync(d_members, members + h0, cnt * sizeof(exg_inflate_member), hipMemcpyHostToDevice, r->stream));
+    rc = exg_inflate_members(comp_buf.p, out_buf.p, (const exg_inflate_member *)d_members, (exg_inflate_status *)d_status, (uint32_t)cnt,
+                             r->stream);
+    if (rc) return fail(r, rc, exg_last_error_message());
+    std::vector<exg_inflate_status> st(cnt);
+    RD_HIP(r, hipMemcpyAsync(st.data(), d_status, cnt * sizeof(exg_inflate_status), hipMemcpyDeviceToHost, r->stream));
+    RD_HIP(r, hipMemsetAsync((char *)out_buf.p + out_total, 0, 64, r->stream));
+    RD_HIP(r, hipStreamSynchronize(r->stream));
+    for (uint64_t i = 0; i < cnt; i++)
+        if (st[i].code || st[i].produced != members[h0 + i].out_cap)
+            return fail(r, EXG_E_PARSE, "corrupt deflate stream (member " + std::to_string(h0 + i) + ", code " + std::to_string(st[i].code) +
+                                            ") in '" + path + "'");
+    out_blk->n = out_total;
+    blk = out_blk;
+    r->d_file = out_buf.p;
+    r->d_file_cap = out_buf.sz;
+    out_buf.p = nullptr;  // owned by the reader now
+    r->d_file_bytes = out_total;
+    r->preset_pos = members[m0].out_off;  // (rebased) = inflated bytes of the halo members
+    r->data0_is_line_start = halo_from_file_start;
+    return EXG_OK;
+}
+
 // gzip input: H2D the compressed bytes, inflate every member on the device (exg_inflate.hip), keep the
 // inflated bytes in HBM for the scan and bring one copy back for the DataChunk payload.
 int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::string &path) {
@@ -292,6 +450,7 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
     const uint8_t *comp = (const uint8_t *)blk->p;
     const uint64_t n = blk->n;
     if (n == 0) return fail(r, EXG_E_PARSE, "empty gzip file '" + path + "'");
+    if (r->shard_count > 1) return inflate_file_shard(r, blk, path);
     // the big device buffers (compressed bytes, inflated bytes) come from the device pool: a query that opens the
     // same file again finds them there (hipMalloc / hipFree of tens of GB were seen to cost up to 0.9 s per open)
     struct Pooled {
@@ -503,6 +662,9 @@ int open_next_file(exg_reader *r) {
     TRACE("mmap(file)", t0);
     (void)t_all;
     if (r->d_file) exg_rd::dev_pool()->give(r->device, r->d_file, r->d_file_cap), r->d_file = nullptr;
+    r->range_preset = false;
+    r->range_eof = true;
+    r->data0_is_line_start = true;
     if (r->compression == kGzip) {
         int rc = inflate_file(r, blk, p);  // replaces blk by the inflated bytes (host copy) and sets d_file
         if (rc) return rc;
@@ -531,7 +693,10 @@ int open_next_file(exg_reader *r) {
     // byte-range shard of this file: [lo, hi) of the bytes behind the header; records / lines belong to the shard they END in
     r->range_hi = blk->n;
     r->shard_first = false;
-    if (r->shard_count > 1) {
+    if (r->range_preset) {  // BGZF shard: the members were chosen in inflate_file_shard
+        r->file_pos = r->preset_pos;
+        r->shard_first = r->preset_pos > 0;
+    } else if (r->shard_count > 1) {
         const uint64_t base = r->file_pos, span = blk->n - base;
         const uint64_t lo = base + (uint64_t)((unsigned __int128)span * r->shard_index / r->shard_count);
         const uint64_t hi = r->shard_index + 1 == r->shard_count
@@ -540,6 +705,7 @@ int open_next_file(exg_reader *r) {
         r->file_pos = lo;
         r->range_hi = hi;
         r->shard_first = lo > base;
+        r->range_eof = hi == blk->n;
     }
     return EXG_OK;
 }
@@ -550,6 +716,7 @@ int open_next_file(exg_reader *r) {
 static constexpr uint64_t kPrefetchSlack = 1u << 20;
 // bytes in front of a shard that travel with its first batch (the beginning of the record that ends behind the cut)
 static constexpr uint64_t kShardHalo = 1u << 20;
+static_assert(kShardHalo == kShardHaloBytes, "one halo size");
 
 int n_string_cols(int format) { return format == EXG_FMT_FASTQ ? 4 : format == EXG_FMT_FASTA ? 3 : 9; }
 
@@ -676,7 +843,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         if (r->format == EXG_FMT_FASTA) want = remaining;  // a FASTA record can span the whole file: one batch
         uint64_t n = std::min<uint64_t>(want, remaining);
         bool range_end = n == remaining;                    // the batch reaches the end of this reader's bytes ...
-        bool eof = range_end && r->range_hi == r->file->n;  // ... which is the end of the file unless a later shard follows
+        bool eof = range_end && r->range_eof;               // ... which is the end of the file unless a later shard follows
         // first batch of a shard that begins inside the file: up to 1 MiB in front of it travels along (`lead`), so that
         // the record / line that ends behind the cut — it belongs to this shard — has its beginning in the buffer
         uint64_t shard_halo = 0;
@@ -699,7 +866,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         uint64_t batch_end = r->file_pos + n;  // file offset one past the bytes of this batch
         std::shared_ptr<PinnedBlock> gz_payload;  // gzip: this batch's inflated bytes on the host (string_t payload)
         if (r->d_file) {
-            lead = r->file_pos & 15;
+            lead = r->shard_first ? shard_halo : (r->file_pos & 15);
             d_input = (const uint8_t *)r->d_file + (r->file_pos - lead);
             n += lead;
             if (!count_only && !r->arrow_emit) {
@@ -725,7 +892,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             batch_end = r->pf.file_start + r->pf.len;
             n = batch_end - r->file_pos + lead;
             range_end = batch_end == r->range_hi;
-            eof = range_end && r->range_hi == r->file->n;
+            eof = range_end && r->range_eof;
             h -= lead;
             r->pf.valid = false;
             RD_HIP(r, hipStreamWaitEvent(r->stream, r->up_done, 0));
@@ -759,8 +926,24 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             RD_HIP(r, hipMemcpyAsync(&guess, r->d_phase, 4, hipMemcpyDeviceToHost, r->stream));
             RD_HIP(r, hipStreamSynchronize(r->stream));
             if (guess <= 3) {
-                const bool prev_is_nl = ((const uint8_t *)r->file->p)[r->file_pos - 1] == '\n';
-                first_line_index = prev_is_nl ? guess : (guess + 3) % 4;
+                uint8_t prev = 0;
+                if (r->d_file) {
+                    RD_HIP(r, hipMemcpyAsync(&prev, (const uint8_t *)r->d_file + r->file_pos - 1, 1, hipMemcpyDeviceToHost, r->stream));
+                    RD_HIP(r, hipStreamSynchronize(r->stream));
+                } else {
+                    prev = ((const uint8_t *)r->file->p)[r->file_pos - 1];
+                }
+                first_line_index = prev == '\n' ? guess : (guess + 3) % 4;
+            } else if (r->d_file) {
+                // BGZF shard: exact only when the halo begins with the file (the newlines in front are then all in HBM)
+                if (!(r->data0_is_line_start && lead == r->file_pos))
+                    return fail(r, EXG_E_PARSE, "cannot tell the FASTQ record phase at the shard boundary of '" + r->files[r->file_idx - 1] + "'");
+                unsigned long long nl = 0;
+                rc = exg_count_newlines(r->d_file, 0, r->file_pos, (uint64_t *)r->d_phase, r->stream);
+                if (rc) return fail(r, rc, exg_last_error_message());
+                RD_HIP(r, hipMemcpyAsync(&nl, r->d_phase, 8, hipMemcpyDeviceToHost, r->stream));
+                RD_HIP(r, hipStreamSynchronize(r->stream));
+                first_line_index = nl;
             } else {
                 // too few lines around the cut to tell (a tiny file, a tiny shard) or several phases fit: count the
                 // newlines in front of it — exact, and only as slow as a memchr over the page cache
@@ -779,7 +962,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         const bool no_store = count_only && !r->has_filter;  // a predicate needs the columns even for COUNT(*)
         // a line starts at d_input[0] when the batch is record aligned, or when a shard's halo reaches back to the
         // first byte behind the header
-        const bool at_line_start = lead == 0 || (r->shard_first && shard_halo && lead == shard_halo &&
+        const bool at_line_start = lead == 0 || (r->shard_first && shard_halo && lead == shard_halo && r->data0_is_line_start &&
                                                  r->file_pos - lead == (r->format == EXG_FMT_VCF ? r->vcf_header_bytes : 0));
         const uint32_t fl = (at_line_start ? EXG_F_BOF : 0u) | (eof ? EXG_F_EOF : 0u) | (no_store ? EXG_F_NO_STORE : 0u);
         std::shared_ptr<Batch> b;
@@ -1060,8 +1243,9 @@ extern "C" int exg_open(const exg_open_args *args, exg_reader **out) {
         exg::set_error("exg_open: shard_index %u is not below shard_count %u", r->shard_index, r->shard_count);
         return EXG_E_INVALID_ARG;
     }
-    if (r->shard_count > 1 && (r->format == EXG_FMT_FASTA || r->compression == kGzip)) {
-        exg::set_error("byte-range shards are for FASTQ and VCF text: a FASTA record can span the file, a gzip stream has no cut points");
+    if (r->shard_count > 1 && (r->format == EXG_FMT_FASTA || (r->compression == kGzip && r->format != EXG_FMT_FASTQ))) {
+        exg::set_error("shards are for FASTQ and VCF text and for BGZF FASTQ: a FASTA record can span the file, a gzip VCF "
+                       "would need its header on every rank");
         return EXG_E_UNSUPPORTED;
     }
     int rc = list_files(r.get(), path);

@@ -228,6 +228,10 @@ struct exg_reader {
     uint32_t shard_index = 0, shard_count = 1;  // byte-range shards of every file (exg_open_args)
     uint64_t range_hi = 0;    // this reader's bytes of the current file end here (file size without shards)
     bool shard_first = false; // the next batch is the first of a shard that begins inside the file: halo + phase
+    bool range_eof = true;    // range_hi is the end of the file's data (a later shard follows otherwise)
+    bool range_preset = false;  // BGZF shard: inflate_file chose the members, file_pos / range_hi refer to ITS inflated bytes
+    uint64_t preset_pos = 0;    // ... first owned inflated byte (what is in front of it is the halo)
+    bool data0_is_line_start = true;  // byte 0 of the data (behind the header) begins a line (not so for a BGZF shard's halo)
     void *d_phase = nullptr;  // device u32 for exg_fastq_guess_phase
     uint64_t gz_header_prefix = 0;  // gzip + VCF: bytes of the inflated file's start held in file->p (header parse)
     bool worst_case_rows = false;

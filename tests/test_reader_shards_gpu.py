@@ -83,12 +83,54 @@ def test_more_shards_than_records(gpu, golden_dir):
     assert got == want and len(got) == 621
 
 
+def _bgzf(data, block=65280):
+    import struct
+    import zlib
+    out = []
+    for i in range(0, len(data), block):
+        chunk = data[i:i + block]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        d = co.compress(chunk) + co.flush()
+        out.append(b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\0\xff" + struct.pack("<H", 6) + b"BC" +
+                   struct.pack("<HH", 2, 12 + 6 + len(d) + 8 - 1) + d + struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+    return b"".join(out) + bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")   # + BGZF EOF marker
+
+
+@pytest.mark.parametrize("n_shards", [2, 3, 8, 40])
+@pytest.mark.parametrize("block", [65280, 5000])
+def test_bgzf_fastq_shards_by_member_ranges(gpu, oracle, tmp_path, n_shards, block):
+    # BGZF: the members are divided among the shards, each rank uploads and inflates only its own (+ a halo of
+    # members in front); 5000-byte members put ~200 of them into the 1 MiB halo, 65280-byte ones ~17
+    data = bytes(oracle.synth_fastq_ragged(25000))
+    plain = tmp_path / "p.fastq"
+    plain.write_bytes(data)
+    gz = tmp_path / "p.fastq.gz"
+    gz.write_bytes(_bgzf(data, block))
+    want = whole(str(plain), "fastq")
+    assert whole(str(gz), "fastq") == want
+    got, counts = sharded(str(gz), "fastq", n_shards)
+    assert got == want and sum(counts) == 25000
+
+
+def test_bgzf_more_shards_than_members(gpu, golden_dir, tmp_path):
+    data = open(f"{golden_dir}/test.fastq", "rb").read()
+    gz = tmp_path / "t.fastq.gz"
+    gz.write_bytes(_bgzf(data))
+    got, counts = sharded(str(gz), "fastq", 7)
+    assert got == whole(f"{golden_dir}/test.fastq", "fastq") and sum(counts) == 2
+
+
 def test_unshardable_inputs_fail_loudly(gpu, golden_dir):
     from exon_duckdb_amd._lib import ExgError
     from exon_duckdb_amd.reader import ShardReader
-    for path, fmt in ((f"{golden_dir}/test.fasta", "fasta"), (f"{golden_dir}/test.fastq.gz", "fastq")):
-        with pytest.raises(ExgError):
-            ShardReader(path, fmt, shard_index=0, shard_count=2)
+    with pytest.raises(ExgError):
+        ShardReader(f"{golden_dir}/test.fasta", "fasta", shard_index=0, shard_count=2)
+    with pytest.raises(ExgError):
+        ShardReader(f"{golden_dir}/vcf/index.vcf.gz", "vcf", shard_index=0, shard_count=2)
+    r = ShardReader(f"{golden_dir}/test.fastq.gz", "fastq", shard_index=0, shard_count=2)   # plain gzip: no member sizes
+    with pytest.raises(ExgError, match="BGZF"):
+        r.rows()
+    r.close()
     with pytest.raises(ExgError):
         ShardReader(f"{golden_dir}/test.fastq", "fastq", shard_index=2, shard_count=2)
 
