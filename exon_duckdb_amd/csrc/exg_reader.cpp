@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <memory>
 #include <string>
 #include <thread>
@@ -220,25 +221,43 @@ static int gz_host_header(exg_reader *r, PinnedBlock &b, const void *d_file) {
 // The whole (compressed) file -> d_dst on r->stream: windows of 256 MiB through two pooled pinned blocks, each window
 // read by parallel pread and sent slice by slice (the mechanism of upload_range; a hipMemcpyAsync straight from the
 // page-cache mapping is a pageable copy: one staging thread inside the runtime, 10-33 GB/s depending on the box).
-static int upload_file(exg_reader *r, void *d_dst, uint64_t n, uint64_t file_off = 0) {
-    const size_t window = 256u << 20, slice = 8u << 20;
+static constexpr size_t kUploadWindow = 256u << 20;
+// a consumer that follows the upload window by window (events recorded on the upload's stream)
+struct UploadProgress {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<hipEvent_t> done;  // one per window, created by the consumer
+    size_t recorded = 0;
+    bool finished = false;
+    int rc = 0;
+    // window w has been enqueued (true) / the upload ended without it (false)
+    bool wait_for(size_t w) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return recorded > w || finished; });
+        return recorded > w;
+    }
+};
+static int upload_file(exg_reader *r, void *d_dst, uint64_t n, uint64_t file_off = 0, hipStream_t st = nullptr,
+                       UploadProgress *prog = nullptr) {
+    if (!st) st = r->stream;
+    const size_t window = kUploadWindow, slice = 8u << 20;
     const int fd = r->fd_keep->fd;
     char *blk[2] = {nullptr, nullptr};
     size_t cap[2] = {0, 0};
     hipEvent_t ev[2] = {nullptr, nullptr};
     struct Cleanup {
-        exg_reader *r;
+        hipStream_t st;
         char **blk;
         size_t *cap;
         hipEvent_t *ev;
         ~Cleanup() {
-            (void)hipStreamSynchronize(r->stream);  // the blocks are sources of copies in flight
+            (void)hipStreamSynchronize(st);  // the blocks are sources of copies in flight
             for (int k = 0; k < 2; k++) {
                 if (blk[k]) global_pool()->give(blk[k], cap[k]);
                 if (ev[k]) (void)hipEventDestroy(ev[k]);
             }
         }
-    } cleanup{r, blk, cap, ev};
+    } cleanup{st, blk, cap, ev};
     for (int k = 0; k < 2 && (uint64_t)k * window < n; k++) {
         cap[k] = (size_t)std::min<uint64_t>(window, n - (uint64_t)k * window) + 64;
         blk[k] = global_pool()->take(&cap[k]);
@@ -267,7 +286,7 @@ static int upload_file(exg_reader *r, void *d_dst, uint64_t n, uint64_t file_off
                     }
                     got += (size_t)k;
                 }
-                if (hipMemcpyAsync((char *)d_dst + off + o, blk[b] + o, sl, hipMemcpyHostToDevice, r->stream) != hipSuccess) bad = 2;
+                if (hipMemcpyAsync((char *)d_dst + off + o, blk[b] + o, sl, hipMemcpyHostToDevice, st) != hipSuccess) bad = 2;
             }
         };
         const unsigned nt = (unsigned)std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), std::min<size_t>(n_slices, 8));
@@ -277,7 +296,13 @@ static int upload_file(exg_reader *r, void *d_dst, uint64_t n, uint64_t file_off
         for (auto &t : th) t.join();
         if (bad == 1) return fail(r, EXG_E_IO, "short read");
         if (bad == 2) return fail(r, EXG_E_HIP, "hipMemcpyAsync failed");
-        RD_HIP(r, hipEventRecord(ev[b], r->stream));
+        RD_HIP(r, hipEventRecord(ev[b], st));
+        if (prog) {
+            RD_HIP(r, hipEventRecord(prog->done[w], st));
+            std::lock_guard<std::mutex> g(prog->mu);
+            prog->recorded = (size_t)w + 1;
+            prog->cv.notify_all();
+        }
         off += len;
     }
     return EXG_OK;
@@ -329,6 +354,59 @@ static uint64_t bgzf_find(const uint8_t *d, uint64_t n, uint64_t from) {
         if (hops == 5 || (hops > 0 && q == n)) return pos;
     }
     return n;
+}
+
+// Member index of a pure BGZF file by several host threads (the serial pointer chase through the page cache costs
+// 110-150 ms per 10 GB: ~190 ns of cache misses per member): every thread finds a header near its cut, then walks to
+// the next thread's start.  false: not (only) BGZF, or a walk did not land on its neighbour's start — the caller falls
+// back to the serial RFC 1952 index.
+static bool bgzf_parallel_index(const uint8_t *d, uint64_t n, exg_inflate_member *members, uint64_t cap, uint64_t *k_out,
+                                uint64_t *total_out) {
+    exg_inflate_member probe;
+    if (!n || !bgzf_member_at(d, n, 0, &probe)) return false;
+    const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(8, n >> 24));  // 16 MiB per thread at least
+    std::vector<uint64_t> starts(T + 1, n);
+    starts[0] = 0;
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < T; t++)
+            th.emplace_back([&, t] { starts[t] = bgzf_find(d, n, (uint64_t)((unsigned __int128)n * t / T)); });
+        for (auto &x : th) x.join();
+    }
+    for (unsigned t = 1; t <= T; t++)
+        if (starts[t] < starts[t - 1]) return false;
+    std::vector<std::vector<exg_inflate_member>> parts(T);
+    std::vector<int> ok(T, 0);
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < T; t++)
+            th.emplace_back([&, t] {
+                uint64_t pos = starts[t];
+                auto &v = parts[t];
+                v.reserve((size_t)((starts[t + 1] - starts[t]) / 8192 + 64));
+                while (pos < starts[t + 1]) {
+                    exg_inflate_member m;
+                    const uint64_t nx = bgzf_member_at(d, n, pos, &m);
+                    if (!nx) return;
+                    v.push_back(m);
+                    pos = nx;
+                }
+                ok[t] = pos == starts[t + 1];
+            });
+        for (auto &x : th) x.join();
+    }
+    uint64_t k = 0, out = 0;
+    for (unsigned t = 0; t < T; t++) {
+        if (!ok[t] || k + parts[t].size() > cap) return false;
+        for (auto &m : parts[t]) {
+            m.out_off = out;
+            out += m.out_cap;
+            members[k++] = m;
+        }
+    }
+    *k_out = k;
+    *total_out = out;
+    return true;
 }
 
 // BGZF input read as shard `shard_index` of `shard_count`: a member belongs to the shard in whose 1/shard_count of the
@@ -479,18 +557,48 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
     } first;
     std::thread index_thread([&] {
         double t0 = now_s();
-        first.rc = exg_gzip_index(comp, n, 0, members.get(), members_cap, &first.k, &first.total, &first.open_ended);
-        if (first.rc) first.err = exg_last_error_message();  // the message is thread-local
+        if (!bgzf_parallel_index(comp, n, members.get(), members_cap, &first.k, &first.total)) {
+            first.k = first.total = 0;
+            first.rc = exg_gzip_index(comp, n, 0, members.get(), members_cap, &first.k, &first.total, &first.open_ended);
+            if (first.rc) first.err = exg_last_error_message();  // the message is thread-local
+        }
         first.ms = (now_s() - t0) * 1e3;
     });
+    struct Joiner {
+        std::thread *t;
+        ~Joiner() { if (t->joinable()) t->join(); }
+    } index_joiner{&index_thread};
+    // the compressed bytes travel on a stream of their own, window by window, from a host thread of their own
     double t_h2d = now_s();
-    {
-        int rc = upload_file(r, d_comp, n);
-        if (trace_on()) (void)hipStreamSynchronize(r->stream);
-        TRACE("gz: h2d compressed", t_h2d);
-        index_thread.join();
-        if (rc) return rc;
-    }
+    hipStream_t up = nullptr;
+    RD_HIP(r, hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
+    UploadProgress prog;
+    prog.done.resize((size_t)((n + kUploadWindow - 1) / kUploadWindow), nullptr);
+    struct UpGuard {
+        hipStream_t up;
+        UploadProgress *prog;
+        std::thread *th;
+        ~UpGuard() {
+            if (th->joinable()) th->join();
+            (void)hipStreamSynchronize(up);
+            for (hipEvent_t e : prog->done)
+                if (e) (void)hipEventDestroy(e);
+            (void)hipStreamDestroy(up);
+        }
+    };
+    std::thread up_thread;
+    UpGuard up_guard{up, &prog, &up_thread};
+    for (auto &e : prog.done) RD_HIP(r, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    up_thread = std::thread([&] {
+        (void)hipSetDevice(r->device);
+        pin_to_device_node(r->device);
+        const int rc = upload_file(r, d_comp, n, 0, up, &prog);
+        std::lock_guard<std::mutex> g(prog.mu);
+        prog.rc = rc;
+        prog.finished = true;
+        prog.cv.notify_all();
+    });
+    index_thread.join();
     if (trace_on()) fprintf(stderr, "[exg] %-22s %.1f ms (beside the upload)\n", "gz: member index", first.ms);
     uint64_t out_cap_total = 0, produced_total = 0;
     void *d_out = nullptr;
@@ -503,6 +611,51 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
         ~OutGuard() { if (*p) exg_rd::dev_pool()->give(dev, *p, (size_t)*cap); }
     } out_guard{r->device, &d_out, &d_out_cap};
     uint64_t start = 0;
+    if (!first.rc && first.k && !first.open_ended && !getenv("EXG_NO_GZ_PIPELINE")) {
+        // BGZF: every member's place is known — the members of a window are inflated as soon as the window has arrived,
+        // while the next windows are still on their way
+        const uint64_t k = first.k;
+        d_out_cap = first.total + 64;
+        d_out = exg_rd::dev_pool()->take(r->device, d_out_cap);
+        if (!d_out) return fail(r, EXG_E_HIP, "out of device memory for the inflated file");
+        void *d_members = nullptr, *d_status = nullptr;
+        RD_HIP(r, hipMalloc(&d_members, k * sizeof(exg_inflate_member)));
+        Free fm{d_members};
+        RD_HIP(r, hipMalloc(&d_status, k * sizeof(exg_inflate_status)));
+        Free fs{d_status};
+        RD_HIP(r, hipMemcpyAsync(d_members, members.get(), k * sizeof(exg_inflate_member), hipMemcpyHostToDevice, r->stream));
+        uint64_t i0 = 0;
+        for (size_t w = 0; w < prog.done.size(); w++) {
+            if (!prog.wait_for(w)) break;  // the upload failed: its error is reported below
+            RD_HIP(r, hipStreamWaitEvent(r->stream, prog.done[w], 0));
+            const uint64_t ready = std::min<uint64_t>(n, (uint64_t)(w + 1) * kUploadWindow);
+            uint64_t i1 = i0;
+            while (i1 < k && members[i1].comp_off + members[i1].comp_size <= ready) i1++;
+            if (i1 > i0) {
+                int rc = exg_inflate_members(d_comp, d_out, (const exg_inflate_member *)d_members + i0, (exg_inflate_status *)d_status + i0,
+                                             (uint32_t)(i1 - i0), r->stream);
+                if (rc) return fail(r, rc, exg_last_error_message());
+            }
+            i0 = i1;
+        }
+        up_thread.join();
+        if (prog.rc) return prog.rc;
+        std::vector<exg_inflate_status> st(k);
+        RD_HIP(r, hipMemcpyAsync(st.data(), d_status, k * sizeof(exg_inflate_status), hipMemcpyDeviceToHost, r->stream));
+        RD_HIP(r, hipStreamSynchronize(r->stream));
+        TRACE("gz: h2d + inflate", t_h2d);
+        for (uint64_t i = 0; i < k; i++)
+            if (i >= i0 || st[i].code || st[i].produced != members[i].out_cap)
+                return fail(r, EXG_E_PARSE, "corrupt deflate stream (member " + std::to_string(i) + ", code " + std::to_string(st[i].code) +
+                                                ") in '" + path + "'");
+        produced_total = out_cap_total = first.total;
+        start = n;
+    } else {
+        up_thread.join();
+        if (prog.rc) return prog.rc;
+        RD_HIP(r, hipStreamSynchronize(up));
+        TRACE("gz: h2d compressed", t_h2d);
+    }
     while (start < n) {
         uint64_t k = 0, total = produced_total;
         int open_ended = 0, rc = 0;
