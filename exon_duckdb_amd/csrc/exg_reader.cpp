@@ -682,9 +682,10 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
             resume = members[k - 1].comp_off + members[k - 1].comp_size;  // sized member: its end is the next header
         }
         if (k == 1 && open_ended && stream_ok && members[0].comp_size >= stream_min) {
-            // one piece per decoding wavefront the chip holds (5120; the gap rounds add a few), at least 32 KiB each
+            // at most one piece per decoding wavefront the chip holds (the symbol decoder: 4 per SIMD = 4096; a few more
+            // pieces than slots would cost a second round for them alone: 4756 pieces took 43 ms, 3830 take 35), at least 32 KiB each
             // (a block is 20-60 KB of input): a small file's decode lasts as long as one piece
-            uint64_t chunk = std::max<uint64_t>(32u << 10, (members[0].comp_size / 4800 + 16383) & ~16383ull);
+            uint64_t chunk = std::max<uint64_t>(32u << 10, (members[0].comp_size / 3900 + 16383) & ~16383ull);
             if (getenv("EXG_STREAM_CHUNK_BYTES")) chunk = strtoull(getenv("EXG_STREAM_CHUNK_BYTES"), nullptr, 10);
             uint64_t produced = 0, consumed = 0;
             void *d_big = nullptr;
