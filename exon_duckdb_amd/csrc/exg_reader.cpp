@@ -445,6 +445,16 @@ static int inflate_file_shard(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, 
     }
     if (!seen_own) m0 = mem.size();
     const uint64_t m1 = mem.size();
+    // does any inflated byte follow this reader's members?  (the empty BGZF end marker — or a later shard that owns
+    // nothing else — must not keep the shard with the file's last record from seeing the end of the file)
+    bool bytes_follow = false;
+    for (uint64_t q = pos; q < n && !bytes_follow;) {
+        exg_inflate_member m;
+        const uint64_t nx = bgzf_member_at(comp, n, q, &m);
+        if (!nx) return fail(r, EXG_E_PARSE, "not a BGZF member at byte " + std::to_string(q) + " of '" + path + "'");
+        bytes_follow = m.out_cap != 0;
+        q = nx;
+    }
     // keep only ~1 MiB (inflated) of the members in front
     uint64_t h0 = m0, halo_bytes = 0;
     while (h0 > 0 && halo_bytes < kShardHaloBytes) halo_bytes += mem[--h0].out_cap;
@@ -461,7 +471,7 @@ static int inflate_file_shard(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, 
     auto out_blk = std::make_shared<PinnedBlock>();
     r->range_preset = true;
     r->preset_pos = 0;
-    r->range_eof = hi == n;
+    r->range_eof = !bytes_follow;
     r->data0_is_line_start = true;
     r->d_file = nullptr;
     r->d_file_bytes = 0;

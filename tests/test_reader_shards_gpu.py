@@ -149,3 +149,26 @@ def test_record_longer_than_the_halo_across_a_cut_is_an_error(gpu, tmp_path, mon
     r.close()
     assert len(whole(str(p), "fastq")) == 2001
 
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("EXG_SHARD_FUZZ", "12"))))
+def test_random_shard_geometry(gpu, oracle, tmp_path, monkeypatch, seed):
+    # random record counts, shard counts, halo sizes and device batch sizes; text and BGZF (random member sizes)
+    rng = np.random.default_rng(500 + seed)
+    n_rec = int(rng.integers(1, 6000))
+    fmt = "fastq" if seed % 3 else "vcf"
+    data = bytes(oracle.synth_fastq_ragged(n_rec, seed=900 + seed)) if fmt == "fastq" else bytes(oracle.synth_vcf(n_rec))
+    p = tmp_path / f"g.{fmt}"
+    p.write_bytes(data)
+    want = whole(str(p), fmt)
+    assert len(want) == n_rec
+    monkeypatch.setenv("EXG_SHARD_HALO", str(int(rng.choice([2048, 4096, 65536, 1 << 20]))))
+    n_shards = int(rng.integers(2, 50))
+    batch = int(rng.choice([0, 16384, 65536, 1 << 20]))
+    got, counts = sharded(str(p), fmt, n_shards, device_batch_bytes=batch)
+    assert got == want and sum(counts) == n_rec, (seed, fmt, n_rec, n_shards, batch)
+    if fmt == "fastq":
+        gz = tmp_path / "g.fastq.gz"
+        gz.write_bytes(_bgzf(data, int(rng.integers(300, 65280))))
+        got, counts = sharded(str(gz), "fastq", n_shards, device_batch_bytes=batch)
+        assert got == want and sum(counts) == n_rec, (seed, "bgzf", n_rec, n_shards, batch)
