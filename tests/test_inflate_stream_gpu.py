@@ -158,3 +158,39 @@ def test_cat_of_big_members_and_bgzf_blocks(gpu, oracle, tmp_path):
     rel = con.table_function("read_fastq", str(p))
     assert rel.count() == len(want) == 9000
     assert rel.fetchall() == want
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("EXG_GZ_FUZZ", "12"))))
+def test_random_gzip_compositions(gpu, oracle, tmp_path, seed):
+    """Files glued together from plain gzip members and runs of BGZF blocks of random sizes (around the 128 KiB
+    switch between one wavefront and the chunked decode): rows and COUNT(*) equal the plain file's."""
+    import struct
+
+    from exon_duckdb_amd import table_function
+    rng = np.random.default_rng(7000 + seed)
+    n_parts = int(rng.integers(1, 7))
+    recs = [int(rng.integers(1, 4000)) for _ in range(n_parts)]
+    raw = bytes(oracle.synth_fastq(332 * sum(recs)))           # fixed-size records: any multiple of 332 is a cut
+    blob, off = [], 0
+    for k, n in enumerate(recs):
+        part = raw[off:off + 332 * n]
+        off += 332 * n
+        if rng.integers(0, 2):
+            block = int(rng.integers(500, 65280))
+            for i in range(0, len(part), block):
+                chunk = part[i:i + block]
+                co = zlib.compressobj(int(rng.integers(1, 10)), zlib.DEFLATED, -15)
+                d = co.compress(chunk) + co.flush()
+                blob.append(b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\0\xff" + struct.pack("<H", 6) + b"BC" +
+                            struct.pack("<HH", 2, 12 + 6 + len(d) + 8 - 1) + d + struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+        else:
+            blob.append(gzip.compress(part, int(rng.integers(1, 10)), mtime=0))
+    p = tmp_path / "mix.fastq.gz"
+    p.write_bytes(b"".join(blob))
+    q = tmp_path / "mix.fastq"
+    q.write_bytes(raw)
+    con = table_function.connect()
+    want = con.table_function("read_fastq", str(q)).fetchall()
+    rel = con.table_function("read_fastq", str(p))
+    assert rel.count() == len(want) == sum(recs), (seed, recs)
+    assert rel.fetchall() == want, (seed, recs)
