@@ -424,6 +424,61 @@ static int inflate_file_shard(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, 
     }
     const uint64_t lo = (uint64_t)((unsigned __int128)n * r->shard_index / r->shard_count);
     const uint64_t hi = r->shard_index + 1 == r->shard_count ? n : (uint64_t)((unsigned __int128)n * (r->shard_index + 1) / r->shard_count);
+    // VCF: every rank needs the header (schema, and where the data begins): the leading members are inflated until the
+    // '#' lines end; their text stays on the host as the file block's prefix, like in the unsharded gzip path
+    auto out_blk = std::make_shared<PinnedBlock>();
+    uint64_t header_members_end = 0;  // compressed offset behind the members that were needed for the header
+    r->gz_header_prefix = 0;
+    if (r->format == EXG_FMT_VCF) {
+        for (uint64_t want = 16;; want *= 8) {
+            std::vector<exg_inflate_member> hm;
+            uint64_t q = 0, out = 0;
+            while (q < n && hm.size() < want) {
+                exg_inflate_member m;
+                const uint64_t nx = bgzf_member_at(comp, n, q, &m);
+                if (!nx) return fail(r, EXG_E_PARSE, "not a BGZF member at byte " + std::to_string(q) + " of '" + path + "'");
+                m.out_off = out;
+                out += m.out_cap;
+                hm.push_back(m);
+                q = nx;
+            }
+            struct Pooled {
+                int dev;
+                void *p;
+                size_t sz;
+                ~Pooled() { if (p) exg_rd::dev_pool()->give(dev, p, sz); }
+            };
+            Pooled dc{r->device, exg_rd::dev_pool()->take(r->device, q + 64), (size_t)(q + 64)};
+            Pooled dd{r->device, exg_rd::dev_pool()->take(r->device, out + 64), (size_t)(out + 64)};
+            Pooled dm{r->device, exg_rd::dev_pool()->take(r->device, hm.size() * 56 + 64), hm.size() * 56 + 64};
+            if (!dc.p || !dd.p || !dm.p) return fail(r, EXG_E_HIP, "out of device memory for the VCF header members");
+            int rc0 = upload_file(r, dc.p, q, 0);
+            if (rc0) return rc0;
+            exg_inflate_status *d_st = (exg_inflate_status *)((char *)dm.p + hm.size() * sizeof(exg_inflate_member));
+            RD_HIP(r, hipMemcpyAsync(dm.p, hm.data(), hm.size() * sizeof(exg_inflate_member), hipMemcpyHostToDevice, r->stream));
+            rc0 = exg_inflate_members(dc.p, dd.p, (const exg_inflate_member *)dm.p, d_st, (uint32_t)hm.size(), r->stream);
+            if (rc0) return fail(r, rc0, exg_last_error_message());
+            if (out_blk->p) global_pool()->give((char *)out_blk->p, out_blk->cap), out_blk->p = nullptr;
+            size_t cap = out + 64;
+            out_blk->p = global_pool()->take(&cap);
+            if (!out_blk->p) return fail(r, EXG_E_HIP, "out of pinned host memory for the VCF header");
+            out_blk->cap = cap;
+            out_blk->pooled = true;
+            RD_HIP(r, hipMemcpyAsync(out_blk->p, dd.p, out, hipMemcpyDeviceToHost, r->stream));
+            RD_HIP(r, hipStreamSynchronize(r->stream));
+            const char *d = (const char *)out_blk->p;
+            uint64_t hpos = 0;
+            while (hpos < out && d[hpos] == '#') {
+                const void *nl = memchr(d + hpos, '\n', (size_t)(out - hpos));
+                hpos = nl ? (uint64_t)((const char *)nl - d) + 1 : out;
+            }
+            if (hpos < out || q >= n) {
+                r->gz_header_prefix = out;
+                header_members_end = q;
+                break;
+            }
+        }
+    }
     // candidates for the halo: members that begin in the ~1.5 MiB of file in front of the cut (BGZF does not expand)
     std::vector<exg_inflate_member> mem;
     std::vector<uint64_t> hdr;  // where each member's gzip header begins
@@ -444,7 +499,7 @@ static int inflate_file_shard(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, 
         pos = nx;
     }
     if (!seen_own) m0 = mem.size();
-    const uint64_t m1 = mem.size();
+    uint64_t m1 = mem.size();
     // does any inflated byte follow this reader's members?  (the empty BGZF end marker — or a later shard that owns
     // nothing else — must not keep the shard with the file's last record from seeing the end of the file)
     bool bytes_follow = false;
@@ -458,6 +513,28 @@ static int inflate_file_shard(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, 
     // keep only ~1 MiB (inflated) of the members in front
     uint64_t h0 = m0, halo_bytes = 0;
     while (h0 > 0 && halo_bytes < kShardHaloBytes) halo_bytes += mem[--h0].out_cap;
+    if (h0 < m1 && hdr[h0] != 0 && hdr[h0] < header_members_end) {
+        // the halo would begin among the members that hold the VCF header: take everything from the start of the
+        // file instead, so that the header's end is a known offset of this buffer
+        std::vector<exg_inflate_member> front;
+        std::vector<uint64_t> front_hdr;
+        for (uint64_t q = 0; q < hdr[h0];) {
+            exg_inflate_member m;
+            const uint64_t nx = bgzf_member_at(comp, n, q, &m);
+            if (!nx) return fail(r, EXG_E_PARSE, "not a BGZF member at byte " + std::to_string(q) + " of '" + path + "'");
+            front.push_back(m);
+            front_hdr.push_back(q);
+            q = nx;
+        }
+        mem.erase(mem.begin(), mem.begin() + (long)h0);
+        hdr.erase(hdr.begin(), hdr.begin() + (long)h0);
+        m0 -= h0;
+        mem.insert(mem.begin(), front.begin(), front.end());
+        hdr.insert(hdr.begin(), front_hdr.begin(), front_hdr.end());
+        m0 += front.size();
+        h0 = 0;
+    }
+    m1 = mem.size();
     const bool halo_from_file_start = h0 == 0 && !hdr.empty() && hdr[0] == 0;  // byte 0 of the inflated halo begins a line
     exg_inflate_member *members = mem.data();
     {
@@ -468,14 +545,12 @@ static int inflate_file_shard(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, 
         }
     }
     int rc = 0;
-    auto out_blk = std::make_shared<PinnedBlock>();
     r->range_preset = true;
     r->preset_pos = 0;
     r->range_eof = !bytes_follow;
     r->data0_is_line_start = true;
     r->d_file = nullptr;
     r->d_file_bytes = 0;
-    r->gz_header_prefix = 0;
     if (m1 == m0) {  // more shards than members: nothing here
         blk = out_blk;
         return EXG_OK;
@@ -842,7 +917,7 @@ int open_next_file(exg_reader *r) {
     if (r->format == EXG_FMT_VCF) {
         // header = the leading '#' lines (noodles-vcf read_header); it must hold the #CHROM line
         const char *d = (const char *)blk->p;
-        const size_t hn = r->d_file ? (size_t)r->gz_header_prefix : blk->n;  // gzip: only the header prefix is on the host
+        const size_t hn = r->compression == kGzip ? (size_t)r->gz_header_prefix : blk->n;  // gzip: only the header prefix is on the host
         size_t pos = 0;
         bool chrom = false;
         while (pos < hn && d[pos] == '#') {
@@ -857,9 +932,12 @@ int open_next_file(exg_reader *r) {
     // byte-range shard of this file: [lo, hi) of the bytes behind the header; records / lines belong to the shard they END in
     r->range_hi = blk->n;
     r->shard_first = false;
+    r->data_base = r->file_pos;  // 0, or the end of the VCF header
     if (r->range_preset) {  // BGZF shard: the members were chosen in inflate_file_shard
-        r->file_pos = r->preset_pos;
-        r->shard_first = r->preset_pos > 0;
+        // its buffer begins with the file (header and all) or somewhere behind the header
+        r->data_base = r->data0_is_line_start ? r->data_base : 0;
+        r->file_pos = std::max<uint64_t>(r->preset_pos, r->data_base);
+        r->shard_first = r->file_pos > r->data_base;
     } else if (r->shard_count > 1) {
         const uint64_t base = r->file_pos, span = blk->n - base;
         const uint64_t lo = base + (uint64_t)((unsigned __int128)span * r->shard_index / r->shard_count);
@@ -1013,9 +1091,11 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         uint64_t shard_halo = 0;
         if (r->shard_first) {
             static const uint64_t halo_max = getenv("EXG_SHARD_HALO") ? strtoull(getenv("EXG_SHARD_HALO"), nullptr, 10) : kShardHalo;
-            const uint64_t base = r->format == EXG_FMT_VCF ? r->vcf_header_bytes : 0;
+            const uint64_t base = r->data_base;
             const uint64_t from = r->file_pos - std::min<uint64_t>(halo_max, r->file_pos - base);
-            shard_halo = r->file_pos - std::max<uint64_t>(base, from & ~15ull);
+            // (a buffer that already lives in HBM must be entered at a 16-byte boundary: a few bytes of the header's
+            // last line may then come along in front — they end inside the halo and are nobody's rows)
+            shard_halo = r->file_pos - (r->d_file ? (std::max<uint64_t>(base, from) & ~15ull) : std::max<uint64_t>(base, from & ~15ull));
         }
         int rc = ensure_device(r, n + shard_halo + 16);
         if (rc) return rc;
@@ -1127,7 +1207,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         // a line starts at d_input[0] when the batch is record aligned, or when a shard's halo reaches back to the
         // first byte behind the header
         const bool at_line_start = lead == 0 || (r->shard_first && shard_halo && lead == shard_halo && r->data0_is_line_start &&
-                                                 r->file_pos - lead == (r->format == EXG_FMT_VCF ? r->vcf_header_bytes : 0));
+                                                 r->file_pos - lead == r->data_base);
         const uint32_t fl = (at_line_start ? EXG_F_BOF : 0u) | (eof ? EXG_F_EOF : 0u) | (no_store ? EXG_F_NO_STORE : 0u);
         std::shared_ptr<Batch> b;
         if (r->format == EXG_FMT_FASTQ) {
@@ -1407,9 +1487,8 @@ extern "C" int exg_open(const exg_open_args *args, exg_reader **out) {
         exg::set_error("exg_open: shard_index %u is not below shard_count %u", r->shard_index, r->shard_count);
         return EXG_E_INVALID_ARG;
     }
-    if (r->shard_count > 1 && (r->format == EXG_FMT_FASTA || (r->compression == kGzip && r->format != EXG_FMT_FASTQ))) {
-        exg::set_error("shards are for FASTQ and VCF text and for BGZF FASTQ: a FASTA record can span the file, a gzip VCF "
-                       "would need its header on every rank");
+    if (r->shard_count > 1 && r->format == EXG_FMT_FASTA) {
+        exg::set_error("shards are for FASTQ and VCF (text or BGZF): a FASTA record can span the file");
         return EXG_E_UNSUPPORTED;
     }
     int rc = list_files(r.get(), path);

@@ -231,6 +231,7 @@ struct exg_reader {
     bool range_eof = true;    // range_hi is the end of the file's data (a later shard follows otherwise)
     bool range_preset = false;  // BGZF shard: inflate_file chose the members, file_pos / range_hi refer to ITS inflated bytes
     uint64_t preset_pos = 0;    // ... first owned inflated byte (what is in front of it is the halo)
+    uint64_t data_base = 0;           // first data byte in the coordinates of file_pos (behind the VCF header; 0 in a BGZF shard's own buffer)
     bool data0_is_line_start = true;  // byte 0 of the data (behind the header) begins a line (not so for a BGZF shard's halo)
     void *d_phase = nullptr;  // device u32 for exg_fastq_guess_phase
     uint64_t gz_header_prefix = 0;  // gzip + VCF: bytes of the inflated file's start held in file->p (header parse)

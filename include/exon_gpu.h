@@ -301,10 +301,11 @@ typedef struct exg_open_args {
     uint32_t shard_count;    /* END in its 1/shard_count of the bytes behind the header; 0 or 1 = the whole file.  One process
                               * per GPU opens the same path with its rank: the shards partition the rows, in file order, with
                               * no exchange (the FASTQ 4-line phase at a cut is found from the bytes around it).  A record
-                              * longer than the 1 MiB halo across a cut is an error, never a silent loss.  BGZF FASTQ is
-                              * sharded by members (a member belongs to the shard in whose bytes its header begins; each rank
-                              * uploads and inflates only its own members + a halo of members in front).  Not sharded
-                              * (EXG_E_UNSUPPORTED): FASTA (a record can span the file), gzip without member sizes, gzip VCF. */
+                              * longer than the 1 MiB halo across a cut is an error, never a silent loss.  BGZF inputs
+                              * (bgzip FASTQ / VCF) are sharded by members (a member belongs to the shard in whose bytes its
+                              * header begins; each rank uploads and inflates only its own members + a halo of members in
+                              * front, a VCF also the leading members that hold the header).  Not sharded
+                              * (EXG_E_UNSUPPORTED): FASTA (a record can span the file), gzip without member sizes. */
 } exg_open_args;
 
 #define EXG_TYPE_VARCHAR 1
