@@ -938,6 +938,28 @@ int open_next_file(exg_reader *r) {
         r->data_base = r->data0_is_line_start ? r->data_base : 0;
         r->file_pos = std::max<uint64_t>(r->preset_pos, r->data_base);
         r->shard_first = r->file_pos > r->data_base;
+    } else if (r->shard_count > 1 && r->format == EXG_FMT_FASTA) {
+        // FASTA: a record belongs to the shard in whose bytes its '>' line BEGINS, and a shard is the run of whole
+        // records from its first such line to the next shard's — scanned like a file of its own (a record is never
+        // cut, however long its sequence: the run simply reaches as far as it has to)
+        const char *d = (const char *)blk->p;
+        const uint64_t N = blk->n;
+        auto first_record_at_or_after = [&](uint64_t pos) -> uint64_t {
+            if (pos == 0) return 0;
+            for (uint64_t q = pos - 1; q + 1 < N;) {  // a line start is the byte behind a newline
+                const void *hit = memchr(d + q, '\n', (size_t)(N - q));
+                if (!hit) return N;
+                q = (uint64_t)((const char *)hit - d) + 1;
+                if (q < N && d[q] == '>') return q;
+            }
+            return N;
+        };
+        const uint64_t lo = (uint64_t)((unsigned __int128)N * r->shard_index / r->shard_count);
+        const uint64_t hi = r->shard_index + 1 == r->shard_count ? N : (uint64_t)((unsigned __int128)N * (r->shard_index + 1) / r->shard_count);
+        r->file_pos = first_record_at_or_after(lo);
+        r->range_hi = hi == N ? N : first_record_at_or_after(hi);
+        if (r->range_hi < r->file_pos) r->range_hi = r->file_pos;
+        r->range_eof = true;  // the run is a FASTA file of its own
     } else if (r->shard_count > 1) {
         const uint64_t base = r->file_pos, span = blk->n - base;
         const uint64_t lo = base + (uint64_t)((unsigned __int128)span * r->shard_index / r->shard_count);
@@ -1146,9 +1168,9 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             r->d_in = r->d_in_slot[r->cur_slot];
             lead = shard_halo;
             int rc2;
-            if (r->format == EXG_FMT_FASTA && r->file_pos == 0 && n > (512ull << 20)) {
+            if (r->format == EXG_FMT_FASTA && n > (512ull << 20)) {
                 // a whole genome in one batch: through two 256 MiB pinned windows, not one pinned block of its size
-                rc2 = upload_file(r, r->d_in, n);
+                rc2 = upload_file(r, r->d_in, n, r->file_pos);
                 if (!rc2 && hipMemsetAsync((char *)r->d_in + n, 0, 16, r->stream) != hipSuccess)
                     rc2 = fail(r, EXG_E_HIP, "hipMemsetAsync failed");
             } else {
@@ -1487,8 +1509,8 @@ extern "C" int exg_open(const exg_open_args *args, exg_reader **out) {
         exg::set_error("exg_open: shard_index %u is not below shard_count %u", r->shard_index, r->shard_count);
         return EXG_E_INVALID_ARG;
     }
-    if (r->shard_count > 1 && r->format == EXG_FMT_FASTA) {
-        exg::set_error("shards are for FASTQ and VCF (text or BGZF): a FASTA record can span the file");
+    if (r->shard_count > 1 && r->format == EXG_FMT_FASTA && r->compression == kGzip) {
+        exg::set_error("a gzip FASTA is not sharded: the records' '>' lines are found in the text");
         return EXG_E_UNSUPPORTED;
     }
     int rc = list_files(r.get(), path);

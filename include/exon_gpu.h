@@ -304,8 +304,9 @@ typedef struct exg_open_args {
                               * longer than the 1 MiB halo across a cut is an error, never a silent loss.  BGZF inputs
                               * (bgzip FASTQ / VCF) are sharded by members (a member belongs to the shard in whose bytes its
                               * header begins; each rank uploads and inflates only its own members + a halo of members in
-                              * front, a VCF also the leading members that hold the header).  Not sharded
-                              * (EXG_E_UNSUPPORTED): FASTA (a record can span the file), gzip without member sizes. */
+                              * front, a VCF also the leading members that hold the header).  FASTA: a record belongs to
+                              * the shard in whose bytes its '>' line begins; a shard is that run of whole records.  Not
+                              * sharded (EXG_E_UNSUPPORTED): gzip without member sizes, gzip FASTA. */
 } exg_open_args;
 
 #define EXG_TYPE_VARCHAR 1

@@ -124,7 +124,7 @@ def test_unshardable_inputs_fail_loudly(gpu, golden_dir):
     from exon_duckdb_amd._lib import ExgError
     from exon_duckdb_amd.reader import ShardReader
     with pytest.raises(ExgError):
-        ShardReader(f"{golden_dir}/test.fasta", "fasta", shard_index=0, shard_count=2)
+        ShardReader(f"{golden_dir}/test.fasta.gz", "fasta", shard_index=0, shard_count=2)
     r = ShardReader(f"{golden_dir}/test.fastq.gz", "fastq", shard_index=0, shard_count=2)   # plain gzip: no member sizes
     with pytest.raises(ExgError, match="BGZF"):
         r.rows()
@@ -154,8 +154,9 @@ def test_random_shard_geometry(gpu, oracle, tmp_path, monkeypatch, seed):
     # random record counts, shard counts, halo sizes and device batch sizes; text and BGZF (random member sizes)
     rng = np.random.default_rng(500 + seed)
     n_rec = int(rng.integers(1, 6000))
-    fmt = "fastq" if seed % 3 else "vcf"
-    data = bytes(oracle.synth_fastq_ragged(n_rec, seed=900 + seed)) if fmt == "fastq" else bytes(oracle.synth_vcf(n_rec))
+    fmt = ("vcf", "fastq", "fastq", "fasta")[seed % 4]
+    data = bytes(oracle.synth_fastq_ragged(n_rec, seed=900 + seed)) if fmt == "fastq" else \
+        bytes(oracle.synth_vcf(n_rec)) if fmt == "vcf" else bytes(oracle.synth_fasta(n_rec, seed=900 + seed))
     p = tmp_path / f"g.{fmt}"
     p.write_bytes(data)
     want = whole(str(p), fmt)
@@ -165,6 +166,8 @@ def test_random_shard_geometry(gpu, oracle, tmp_path, monkeypatch, seed):
     batch = int(rng.choice([0, 16384, 65536, 1 << 20]))
     got, counts = sharded(str(p), fmt, n_shards, device_batch_bytes=batch)
     assert got == want and sum(counts) == n_rec, (seed, fmt, n_rec, n_shards, batch)
+    if fmt == "fasta":
+        return                                      # (a gzip FASTA is not sharded)
     gz = tmp_path / f"g.{fmt}.gz"
     gz.write_bytes(_bgzf(data, int(rng.integers(300, 65280))))
     got, counts = sharded(str(gz), fmt, n_shards, device_batch_bytes=batch)
@@ -191,3 +194,21 @@ def test_bgzip_vcf_shards_with_a_header_of_many_members(gpu, oracle, golden_dir,
     assert len(want) == 5000
     got, counts = sharded(str(gz), "vcf", n_shards)
     assert got == want and sum(counts) == 5000
+
+
+@pytest.mark.parametrize("n_shards", [2, 5, 33])
+def test_fasta_shards_are_runs_of_whole_records(gpu, oracle, golden_dir, tmp_path, n_shards):
+    # a record belongs to the shard in whose bytes its '>' line begins; one 3 MB sequence in the middle spans several
+    # shards' byte ranges and is still one row of one shard
+    recs = bytes(oracle.synth_fasta(1500))
+    big = b">chrBig a long one\n" + b"\n".join(b"ACGT" * 15 for _ in range(50_000)) + b"\n"
+    data = recs + big + recs.replace(b">", b">second_")
+    p = tmp_path / "s.fasta"
+    p.write_bytes(data)
+    want = whole(str(p), "fasta")
+    assert len(want) == 3001
+    got, counts = sharded(str(p), "fasta", n_shards)
+    assert got == want and sum(counts) == 3001
+    want = whole(f"{golden_dir}/test.fasta", "fasta")
+    got, _ = sharded(f"{golden_dir}/test.fasta", "fasta", n_shards)
+    assert got == want and len(got) == 2
