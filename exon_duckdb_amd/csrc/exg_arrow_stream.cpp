@@ -172,10 +172,11 @@ struct StreamState {
     std::string last_error;
     size_t host_hint = 0;  // pinned bytes the previous batch needed
     hipStream_t copy_stream = nullptr;
+    int copy_dev = 0;
     hipEvent_t copy_ev = nullptr;
     ~StreamState() {
         if (copy_ev) (void)hipEventDestroy(copy_ev);
-        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        if (copy_stream) stream_pool()->give(copy_dev, copy_stream);
         for (void *p : {d_consts, d_prog, d_info_names, d_format_names})
             if (p) (void)hipFree(p);
         arena.reset();
@@ -446,7 +447,8 @@ int arrow_emit(exg_reader *r, const ScanCtx &ctx) {
     }
     EM_TRACE("arena");
     if (!st->copy_stream) {
-        EM_HIP(hipStreamCreateWithFlags(&st->copy_stream, hipStreamNonBlocking));
+        EM_HIP(stream_pool()->take(r->device, &st->copy_stream));
+        st->copy_dev = r->device;
         EM_HIP(hipEventCreateWithFlags(&st->copy_ev, hipEventDisableTiming));
     }
     auto batch = std::make_shared<ABatch>();

@@ -134,8 +134,8 @@ exg_reader::~exg_reader() {
     if (d_filter_consts) (void)hipFree(d_filter_consts);
     if (d_file) exg_rd::dev_pool()->give(device, d_file, d_file_cap);
     if (up_done) (void)hipEventDestroy(up_done);
-    if (up_stream) (void)hipStreamDestroy(up_stream);
-    if (stream) (void)hipStreamDestroy(stream);
+    exg_rd::stream_pool()->give(device, up_stream);
+    exg_rd::stream_pool()->give(device, stream);
 }
 
 namespace exg_rd {
@@ -656,10 +656,11 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
     // the compressed bytes travel on a stream of their own, window by window, from a host thread of their own
     double t_h2d = now_s();
     hipStream_t up = nullptr;
-    RD_HIP(r, hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
+    RD_HIP(r, exg_rd::stream_pool()->take(r->device, &up));
     UploadProgress prog;
     prog.done.resize((size_t)((n + kUploadWindow - 1) / kUploadWindow), nullptr);
     struct UpGuard {
+        int dev;
         hipStream_t up;
         UploadProgress *prog;
         std::thread *th;
@@ -668,11 +669,11 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
             (void)hipStreamSynchronize(up);
             for (hipEvent_t e : prog->done)
                 if (e) (void)hipEventDestroy(e);
-            (void)hipStreamDestroy(up);
+            exg_rd::stream_pool()->give(dev, up);
         }
     };
     std::thread up_thread;
-    UpGuard up_guard{up, &prog, &up_thread};
+    UpGuard up_guard{r->device, up, &prog, &up_thread};
     for (auto &e : prog.done) RD_HIP(r, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     up_thread = std::thread([&] {
         (void)hipSetDevice(r->device);
@@ -1009,7 +1010,7 @@ int ensure_device(exg_reader *r, uint64_t need_bytes) {
     r->d_in = r->d_in_slot[0];
     r->cur_slot = 0;
     if (!r->up_stream) {
-        RD_HIP(r, hipStreamCreateWithFlags(&r->up_stream, hipStreamNonBlocking));
+        RD_HIP(r, exg_rd::stream_pool()->take(r->device, &r->up_stream));
         RD_HIP(r, hipEventCreateWithFlags(&r->up_done, hipEventDisableTiming));
     }
     if ((arc = r->dev_alloc(&r->d_ws, r->ws_bytes))) return arc;
@@ -1521,7 +1522,7 @@ extern "C" int exg_open(const exg_open_args *args, exg_reader **out) {
     }
     if (exg_device_count() < 1) return EXG_E_NO_DEVICE;
     hipError_t he = hipSetDevice(r->device);
-    if (he == hipSuccess) he = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
+    if (he == hipSuccess) he = exg_rd::stream_pool()->take(r->device, &r->stream);
     if (he != hipSuccess) {
         exg::set_error("cannot initialise device %d: %s", r->device, hipGetErrorString(he));
         return EXG_E_HIP;

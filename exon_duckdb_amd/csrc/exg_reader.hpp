@@ -78,6 +78,39 @@ inline std::shared_ptr<BlockPool> global_pool() {
 // Device buffers of a reader (input slots, workspace, column vectors, the Arrow emitter's arena) are the same
 // sizes scan after scan; mapping and unmapping gigabytes of HBM per open costs tens of ms and was seen to
 // stall later GPU work for far longer.  They go round through this pool instead (exact size match).
+// HIP streams are expensive to create (a hardware queue each: ~1 ms measured per reader open) and a query on a small
+// file needs two: they are recycled process-wide, per device; a stream goes back synchronised.
+struct StreamPool {
+    std::mutex mu;
+    std::vector<std::pair<int, hipStream_t>> free_streams;
+    hipError_t take(int dev, hipStream_t *out) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            for (size_t i = 0; i < free_streams.size(); i++)
+                if (free_streams[i].first == dev) {
+                    *out = free_streams[i].second;
+                    free_streams.erase(free_streams.begin() + (long)i);
+                    return hipSuccess;
+                }
+        }
+        return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+    }
+    void give(int dev, hipStream_t s) {
+        if (!s) return;
+        (void)hipStreamSynchronize(s);
+        std::lock_guard<std::mutex> g(mu);
+        if (free_streams.size() < 32) {
+            free_streams.emplace_back(dev, s);
+            return;
+        }
+        (void)hipStreamDestroy(s);
+    }
+};
+inline StreamPool *stream_pool() {
+    static StreamPool *pool = new StreamPool();  // never destroyed, like the other pools
+    return pool;
+}
+
 struct DevPool {
     struct Blk {
         int dev;
