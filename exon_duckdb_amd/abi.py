@@ -158,6 +158,7 @@ SIGNATURES = {
     "exg_gzip_index": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
                                  C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "exg_inflate_members": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "exg_zstd_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_void_p]),
     "exg_fetch_result": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(ScanResult)]),
     "exg_count_newlines": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
     "exg_quality_list_workspace_bytes": (C.c_uint64, [C.c_uint64]),

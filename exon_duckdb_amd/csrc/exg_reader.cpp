@@ -870,6 +870,44 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
     return EXG_OK;
 }
 
+// zstd input (.zst, compression='zstd'): H2D the compressed bytes, decode every frame on the device (exg_zstd.hip: the
+// host only walks the frame / block headers of the mapped file), keep the bytes in HBM for the scan — the rest of the
+// reader treats them exactly like an inflated gzip file (r->d_file).
+int zstd_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::string &path) {
+    double t_all = now_s();
+    const uint64_t n = blk->n;
+    struct Pooled {
+        int dev;
+        void *p;
+        size_t sz;
+        ~Pooled() { if (p) exg_rd::dev_pool()->give(dev, p, sz); }
+    };
+    Pooled comp{r->device, exg_rd::dev_pool()->take(r->device, n + 64), (size_t)(n + 64)};
+    if (!comp.p) return fail(r, EXG_E_HIP, "out of device memory for the compressed file");
+    if (n) {
+        int rc = upload_file(r, comp.p, n, 0);
+        if (rc) return rc;
+    }
+    RD_HIP(r, hipMemsetAsync((char *)comp.p + n, 0, 64, r->stream));
+    void *d_out = nullptr;
+    uint64_t produced = 0;
+    int rc = exg_zstd_decode((const uint8_t *)blk->p, comp.p, n, &d_out, &produced, r->stream);
+    if (rc) return fail(r, rc, std::string(exg_last_error_message()) + " in '" + path + "'");
+    TRACE("zstd: h2d + decode", t_all);
+    auto out_blk = std::make_shared<PinnedBlock>();
+    out_blk->n = produced;
+    blk = out_blk;
+    r->d_file = d_out;
+    r->d_file_cap = produced + 64;
+    r->d_file_bytes = produced;
+    r->gz_header_prefix = 0;
+    if (r->format == EXG_FMT_VCF && produced) {
+        rc = gz_host_header(r, *blk, r->d_file);
+        if (rc) return rc;
+    }
+    return EXG_OK;
+}
+
 int open_next_file(exg_reader *r) {
     const std::string &p = r->files[r->file_idx++];
     double t_all = now_s();
@@ -908,6 +946,9 @@ int open_next_file(exg_reader *r) {
     if (r->compression == kGzip) {
         int rc = inflate_file(r, blk, p);  // replaces blk by the inflated bytes (host copy) and sets d_file
         if (rc) return rc;
+    } else if (r->compression == kZstd) {
+        int rc = zstd_file(r, blk, p);
+        if (rc) return rc;
     }
     (void)r->join_prefetch();
     if (r->pf.valid && r->up_stream) (void)hipStreamSynchronize(r->up_stream);  // a prefetch of the previous file
@@ -918,7 +959,7 @@ int open_next_file(exg_reader *r) {
     if (r->format == EXG_FMT_VCF) {
         // header = the leading '#' lines (noodles-vcf read_header); it must hold the #CHROM line
         const char *d = (const char *)blk->p;
-        const size_t hn = r->compression == kGzip ? (size_t)r->gz_header_prefix : blk->n;  // gzip: only the header prefix is on the host
+        const size_t hn = r->compression != kNone ? (size_t)r->gz_header_prefix : blk->n;  // gzip / zstd: only the header prefix is on the host
         size_t pos = 0;
         bool chrom = false;
         while (pos < hn && d[pos] == '#') {
@@ -1516,8 +1557,12 @@ extern "C" int exg_open(const exg_open_args *args, exg_reader **out) {
     }
     int rc = list_files(r.get(), path);
     if (rc) return rc;
-    if (r->compression != kNone && r->compression != kGzip) {
-        exg::set_error("compression is not supported: only gzip has a device decoder, and there is no CPU fallback");
+    if (r->compression != kNone && r->compression != kGzip && r->compression != kZstd) {
+        exg::set_error("compression is not supported: gzip and zstd have device decoders, bzip2 / xz do not, and there is no CPU fallback");
+        return EXG_E_UNSUPPORTED;
+    }
+    if (r->shard_count > 1 && r->compression == kZstd) {
+        exg::set_error("a zstd input is not sharded (its frames are decoded by the whole device at once)");
         return EXG_E_UNSUPPORTED;
     }
     if (exg_device_count() < 1) return EXG_E_NO_DEVICE;

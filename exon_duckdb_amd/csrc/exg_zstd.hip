@@ -1,0 +1,955 @@
+// exg_zstd.hip — Zstandard (RFC 8878) frames decoded on the device (gfx950).  See exg_zstd.hpp for what it replaces and
+// why the stages are cut where they are.  Stages, all launched back to back on one stream:
+//
+//   k_zst_literals   one wavefront per compressed block: the literals section.  Raw / RLE literals are wave-wide copies;
+//                    Huffman literals: the tree description (direct 4-bit weights, or FSE-coded weights) becomes a
+//                    single-lookup table of 2^log entries in LDS, then lanes 0-3 decode the four streams (a block has four
+//                    independent backward bitstreams — that is all the parallelism the format offers inside a block; the
+//                    chip gets its occupancy from the number of blocks in flight).
+//   k_zst_sequences  one wavefront per compressed block: the three FSE tables (predefined / RLE / described / repeated
+//                    from an earlier block, whose description is simply parsed again) go to LDS; lane 0 walks the
+//                    backward bitstream and writes (literal length, match length, offset) per sequence.  Offsets that
+//                    are repeat codes cannot be resolved without the previous blocks' history — they are emitted
+//                    symbolically ("incoming slot j minus k"), and the block's effect on the history likewise.
+//   k_zst_scan       one wavefront over all blocks in file order: output offsets (prefix sum) and the repeat-offset
+//                    history at every block's start (composition of the blocks' symbolic updates).
+//   k_zst_exec       one wavefront per chunk (a run of blocks of one frame): literal runs and LZ77 copies into a ring of
+//                    the newest elements in LDS; completed 1 KiB segments leave for HBM with 16 B / lane stores, and a
+//                    match that reaches behind the ring reads what the wave itself flushed earlier (through the CU's own
+//                    L1: a workgroup-scope release after the flush is all the ordering it takes — the k_inflate design).
+//   k_zst_xxh64      the frame's content checksum (XXH64, a serial recurrence: four lanes carry its four accumulators).
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "exg_common.hpp"
+#include "exg_zstd.hpp"
+
+namespace exg {
+namespace zst {
+
+// ---- bit access ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t ld64(const uint8_t *p) {
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);  // one global_load_dwordx2: unaligned access is on for amdhsa
+    return v;
+}
+__device__ __forceinline__ void st64(uint8_t *p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
+
+// 8 bytes of a stream starting at byte idx (may be negative: bytes in front of the stream read as zero, which is what
+// an over-read backward bitstream delivers, RFC 8878 4.1)
+__device__ __forceinline__ uint64_t ld64_guard(const uint8_t *base, long long idx) {
+    if (idx >= 0) return ld64(base + idx);
+    if (idx <= -8) return 0;
+    uint64_t v = 0;
+    for (int j = (int)-idx; j < 8; j++) v |= (uint64_t)base[idx + j] << (8 * j);
+    return v;
+}
+
+// backward bitstream: the last byte holds the end mark (its highest set bit); bits are taken from there downwards
+struct BitsRev {
+    const uint8_t *base;
+    long long idx;  // stream byte the container starts at
+    uint64_t c;     // 8 stream bytes, little endian: the next bit to read is bit 63 - used
+    uint32_t used;
+    __device__ __forceinline__ bool init(const uint8_t *p, long long len) {
+        base = p;
+        if (len <= 0) return false;
+        if (p[len - 1] == 0) return false;
+        idx = len - 8;
+        c = ld64_guard(p, idx);
+        used = (uint32_t)__clzll((long long)c) + 1;
+        return true;
+    }
+    __device__ __forceinline__ void refill() {
+        idx -= used >> 3;
+        used &= 7;
+        c = ld64_guard(base, idx);
+    }
+    __device__ __forceinline__ void need(uint32_t n) {
+        if (used + n > 64) refill();
+    }
+    __device__ __forceinline__ uint32_t peek(uint32_t n) const { return n ? (uint32_t)((c << used) >> (64 - n)) : 0u; }
+    __device__ __forceinline__ uint32_t read(uint32_t n) {  // need(n) first
+        const uint32_t v = peek(n);
+        used += n;
+        return v;
+    }
+    __device__ __forceinline__ long long left() const { return idx * 8 + 64 - (long long)used; }
+};
+
+__device__ __forceinline__ uint32_t fwd_peek(const uint8_t *p, uint32_t bit, uint32_t n) {
+    return (uint32_t)(ld64(p + (bit >> 3)) >> (bit & 7)) & ((1u << n) - 1);
+}
+__device__ __forceinline__ int hb32(uint32_t v) { return 31 - __clz((int)v); }
+
+// ---- FSE ----------------------------------------------------------------------------------------------------------
+// table entry: symbol | nbBits << 8 | newStateBase << 16
+// RFC 8878 4.1.1: normalised counts from a forward bitstream.  Returns the bytes consumed or -1.  One lane.
+__device__ int fse_read_norm(const uint8_t *p, int len, int max_log, int max_sym, int16_t *norm, int *n_sym, int *log_out) {
+    if (len < 1) return -1;
+    uint32_t bit = 0;
+    const int log = 5 + (int)fwd_peek(p, bit, 4);
+    bit += 4;
+    if (log > max_log) return -1;
+    int remaining = 1 << log, s = 0;
+    while (remaining > 0 && s <= max_sym) {
+        const int nb = hb32((uint32_t)remaining + 1) + 1;
+        if ((int)((bit + nb + 7) >> 3) > len + 4) return -1;
+        uint32_t val = fwd_peek(p, bit, nb);
+        const uint32_t lower = (1u << (nb - 1)) - 1, thresh = (1u << nb) - 1 - ((uint32_t)remaining + 1);
+        if ((val & lower) < thresh) {
+            bit += nb - 1;
+            val &= lower;
+        } else {
+            bit += nb;
+            if (val > lower) val -= thresh;
+        }
+        const int proba = (int)val - 1;
+        remaining -= proba < 0 ? -proba : proba;
+        norm[s++] = (int16_t)proba;
+        if (proba == 0) {
+            for (;;) {
+                const int rep = (int)fwd_peek(p, bit, 2);
+                bit += 2;
+                for (int i = 0; i < rep && s <= max_sym; i++) norm[s++] = 0;
+                if (rep != 3) break;
+                if ((int)(bit >> 3) > len + 4) return -1;
+            }
+        }
+    }
+    if (remaining != 0 || s > max_sym + 1) return -1;
+    const int bytes = (int)((bit + 7) >> 3);
+    if (bytes > len) return -1;
+    *n_sym = s;
+    *log_out = log;
+    return bytes;
+}
+// decoding table from normalised counts (one lane; `next` is scratch of 64 entries)
+__device__ int fse_build(uint32_t *tab, const int16_t *norm, int n_sym, int log, uint16_t *next) {
+    const int size = 1 << log;
+    int high = size;
+    for (int s = 0; s < n_sym; s++)
+        if (norm[s] == -1) {
+            tab[--high] = (uint32_t)s;
+            next[s] = 1;
+        }
+    const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+    int pos = 0;
+    for (int s = 0; s < n_sym; s++) {
+        const int c = norm[s];
+        if (c <= 0) continue;
+        next[s] = (uint16_t)c;
+        for (int i = 0; i < c; i++) {
+            tab[pos] = (uint32_t)s;
+            do {
+                pos = (pos + step) & mask;
+            } while (pos >= high);
+        }
+    }
+    if (pos != 0) return -1;
+    for (int i = 0; i < size; i++) {
+        const uint32_t s = tab[i];
+        const uint32_t x = next[s]++;
+        const uint32_t nb = (uint32_t)(log - hb32(x));
+        tab[i] = s | (nb << 8) | (((x << nb) - (uint32_t)size) << 16);
+    }
+    return 0;
+}
+
+// ---- literals -------------------------------------------------------------------------------------------------------
+struct LitLds {
+    uint16_t tab[2048];  // symbol | nbBits << 8, indexed by the next `log` bits
+    uint32_t fse[64];    // weights' FSE table (accuracy log <= 6)
+    int16_t norm[64];
+    uint16_t next[64];
+    uint8_t w[256];
+    uint32_t rank_start[16];
+    int result;  // tree description bytes, or -1
+    int log;
+};
+
+// Huffman tree description at p (at most `avail` bytes) -> s.tab.  Lane 0 works, the wave waits.  RFC 8878 4.2.1.
+__device__ void huf_build(LitLds &s, const uint8_t *p, int avail, uint32_t lane) {
+    if (lane == 0) {
+        int res = -1, n = 0;
+        do {
+            if (avail < 1) break;
+            const int hdr = p[0];
+            if (hdr >= 128) {  // direct: 4 bits per weight
+                n = hdr - 127;
+                const int bytes = (n + 1) / 2;
+                if (1 + bytes > avail) break;
+                for (int i = 0; i < n; i++) s.w[i] = (i & 1) ? (p[1 + i / 2] & 15) : (p[1 + i / 2] >> 4);
+                res = 1 + bytes;
+            } else {  // FSE-coded weights, two interleaved states
+                if (hdr == 0 || 1 + hdr > avail) break;
+                int ns = 0, log = 0;
+                const int used = fse_read_norm(p + 1, hdr, 6, 12, s.norm, &ns, &log);
+                if (used < 0) break;
+                if (fse_build(s.fse, s.norm, ns, log, s.next)) break;
+                BitsRev b;
+                if (!b.init(p + 1 + used, hdr - used)) break;
+                b.need(2 * log);
+                uint32_t s1 = b.read(log), s2 = b.read(log);
+                bool bad = false;
+                for (;;) {
+                    if (n >= 254) { bad = true; break; }
+                    uint32_t e = s.fse[s1];
+                    s.w[n++] = (uint8_t)e;
+                    b.need((e >> 8) & 255);
+                    s1 = (e >> 16) + b.read((e >> 8) & 255);
+                    if (b.left() < 0) {
+                        s.w[n++] = (uint8_t)s.fse[s2];
+                        break;
+                    }
+                    if (n >= 254) { bad = true; break; }
+                    e = s.fse[s2];
+                    s.w[n++] = (uint8_t)e;
+                    b.need((e >> 8) & 255);
+                    s2 = (e >> 16) + b.read((e >> 8) & 255);
+                    if (b.left() < 0) {
+                        s.w[n++] = (uint8_t)s.fse[s1];
+                        break;
+                    }
+                }
+                if (bad) break;
+                res = 1 + hdr;
+            }
+            // weights -> code lengths; the last weight is implied (the total must become a power of two)
+            uint32_t total = 0, cnt[13];
+            for (int k = 0; k < 13; k++) cnt[k] = 0;
+            bool ok = true;
+            for (int i = 0; i < n; i++) {
+                const uint32_t w = s.w[i];
+                if (w > 11) { ok = false; break; }
+                total += w ? 1u << (w - 1) : 0u;
+                cnt[w]++;
+            }
+            if (!ok || total == 0) { res = -1; break; }
+            const int log = hb32(total) + 1;
+            const uint32_t rest = (1u << log) - total;
+            if (log > 11 || (rest & (rest - 1))) { res = -1; break; }
+            const uint32_t lastw = (uint32_t)hb32(rest) + 1;
+            s.w[n++] = (uint8_t)lastw;
+            cnt[lastw]++;
+            if (cnt[1] < 2 || (cnt[1] & 1)) { res = -1; break; }  // libzstd (HUF_readStats): an even number >= 2 of the longest codes
+            uint32_t pos = 0;
+            for (int k = 1; k <= log; k++) {
+                s.rank_start[k] = pos;
+                pos += cnt[k] << (k - 1);
+            }
+            for (int i = 0; i < n; i++) {
+                const uint32_t w = s.w[i];
+                if (!w) continue;
+                const uint32_t len = 1u << (w - 1), at = s.rank_start[w];
+                const uint16_t e = (uint16_t)((uint32_t)i | ((uint32_t)(log + 1 - (int)w) << 8));
+                for (uint32_t j = 0; j < len; j++) s.tab[at + j] = e;
+                s.rank_start[w] = at + len;
+            }
+            s.log = log;
+        } while (0);
+        s.result = res;
+    }
+    __syncthreads();
+}
+
+// one Huffman stream of `nout` symbols -> out.  false: the stream does not end where its symbols do.
+__device__ bool huf_stream(const LitLds &s, const uint8_t *p, long long len, uint8_t *out, uint32_t nout) {
+    BitsRev b;
+    if (!b.init(p, len)) return false;
+    const uint32_t log = (uint32_t)s.log;
+    uint32_t i = 0;
+    // head: bytes until the output address is 8-byte aligned, then 8 symbols per store
+    while (i < nout && (((uintptr_t)(out + i)) & 7)) {
+        b.need(log);
+        const uint32_t e = s.tab[b.peek(log)];
+        b.used += e >> 8;
+        out[i++] = (uint8_t)e;
+    }
+    while (i + 8 <= nout) {
+        uint64_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            b.need(log);
+            const uint32_t e = s.tab[b.peek(log)];
+            b.used += e >> 8;
+            acc |= (uint64_t)(e & 255) << (8 * k);
+        }
+        *reinterpret_cast<uint64_t *>(out + i) = acc;
+        i += 8;
+    }
+    while (i < nout) {
+        b.need(log);
+        const uint32_t e = s.tab[b.peek(log)];
+        b.used += e >> 8;
+        out[i++] = (uint8_t)e;
+    }
+    return b.left() == 0;
+}
+
+__device__ __forceinline__ void block_fail(Block *blocks, uint32_t b, uint32_t code) { atomicCAS(&blocks[b].status, 0u, code); }
+
+__global__ __launch_bounds__(64) void k_zst_literals(const uint8_t *__restrict__ comp, Block *blocks, uint32_t nb, uint8_t *lit) {
+    __shared__ LitLds s;
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        const Block B = blocks[b];
+        if (B.type != 2) continue;
+        const uint8_t *p = comp + B.src_off;
+        uint8_t *out = lit + B.lit_off;
+        const uint32_t regen = B.lit_regen;
+        if (B.lit_type == 0) {
+            const uint8_t *src = p + B.lit_hdr;
+            for (uint32_t i = lane; i < regen; i += 64) out[i] = src[i];
+        } else if (B.lit_type == 1) {
+            const uint8_t v = p[B.lit_hdr];
+            for (uint32_t i = lane; i < regen; i += 64) out[i] = v;
+        } else {
+            const Block S = blocks[B.huf_src];
+            huf_build(s, comp + S.src_off + S.lit_hdr, (int)S.lit_csize, lane);
+            const int tree = s.result;
+            if (tree < 0) {
+                if (lane == 0) block_fail(blocks, b, kErrHuffman);
+            } else {
+                const uint8_t *st = p + B.lit_hdr + (B.lit_type == 2 ? tree : 0);
+                const long long left = (long long)B.lit_csize - (B.lit_type == 2 ? tree : 0);
+                bool ok = true;
+                if (B.lit_streams == 1) {
+                    if (lane == 0) ok = left >= 1 && huf_stream(s, st, left, out, regen);
+                } else {
+                    // jump table: three 16-bit stream sizes; the fourth is the rest (4.2.2)
+                    bool geo = left >= 10;  // libzstd: jump table + at least one byte per stream
+                    uint32_t s1 = 0, s2 = 0, s3 = 0;
+                    long long s4 = 0;
+                    const uint32_t per = (regen + 3) / 4;
+                    if (geo) {
+                        s1 = st[0] | ((uint32_t)st[1] << 8);
+                        s2 = st[2] | ((uint32_t)st[3] << 8);
+                        s3 = st[4] | ((uint32_t)st[5] << 8);
+                        s4 = left - 6 - (long long)s1 - s2 - s3;
+                        geo = s4 >= 1 && s1 >= 1 && s2 >= 1 && s3 >= 1 && 3 * per <= regen;
+                    }
+                    if (!geo) {
+                        ok = false;
+                    } else if (lane < 4) {
+                        const uint8_t *a = st + 6;
+                        const uint32_t start = lane == 0 ? 0 : lane == 1 ? s1 : lane == 2 ? s1 + s2 : s1 + s2 + s3;
+                        const long long len = lane == 0 ? s1 : lane == 1 ? s2 : lane == 2 ? s3 : s4;
+                        const uint32_t nout = lane < 3 ? per : regen - 3 * per;
+                        ok = huf_stream(s, a + start, len, out + lane * per, nout);
+                    }
+                }
+                if (!__all(ok) && lane == 0) block_fail(blocks, b, kErrHuffman);
+            }
+            __syncthreads();  // s is rebuilt for the next block
+        }
+    }
+}
+
+// ---- sequences --------------------------------------------------------------------------------------------------------
+__constant__ int16_t kLLDef[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+__constant__ int16_t kMLDef[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                   1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+__constant__ int16_t kOFDef[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+// base | extra bits << 24 (RFC 8878 3.1.1.3.2.1.1)
+__constant__ uint32_t kLLCode[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15,
+                                     16 | (1u << 24), 18 | (1u << 24), 20 | (1u << 24), 22 | (1u << 24), 24 | (2u << 24), 28 | (2u << 24),
+                                     32 | (3u << 24), 40 | (3u << 24), 48 | (4u << 24), 64 | (6u << 24), 128 | (7u << 24), 256 | (8u << 24),
+                                     512 | (9u << 24), 1024 | (10u << 24), 2048 | (11u << 24), 4096 | (12u << 24), 8192 | (13u << 24),
+                                     16384 | (14u << 24), 32768 | (15u << 24), 65536 | (16u << 24)};
+__constant__ uint32_t kMLCode[53] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34,
+                                     35 | (1u << 24), 37 | (1u << 24), 39 | (1u << 24), 41 | (1u << 24), 43 | (2u << 24), 47 | (2u << 24),
+                                     51 | (3u << 24), 59 | (3u << 24), 67 | (4u << 24), 83 | (4u << 24), 99 | (5u << 24), 131 | (7u << 24),
+                                     259 | (8u << 24), 515 | (9u << 24), 1027 | (10u << 24), 2051 | (11u << 24), 4099 | (12u << 24),
+                                     8195 | (13u << 24), 16387 | (14u << 24), 32771 | (15u << 24), 65539 | (16u << 24)};
+
+struct SeqLds {
+    uint32_t tab[3][512];  // LL, OF (256 used), ML
+    uint32_t ll_code[36], ml_code[53];
+    int16_t norm[64];
+    uint16_t next[64];
+    int log[3];
+    int result;
+    uint32_t q_off;  // where the block's bitstream begins (offset from the block start)
+};
+
+// table t (0 LL, 1 OF, 2 ML) as block S's sequences section defines it (its mode there is not Repeat).  One lane.
+// *after: when S is the block being decoded, the offset just behind the table's description.
+__device__ int seq_table_from(SeqLds &s, int t, const uint8_t *comp, const Block &S, uint32_t *after) {
+    const int max_log[3] = {9, 8, 9}, max_sym[3] = {35, 31, 52};
+    const uint8_t *p = comp + S.src_off, *end = p + S.src_size;
+    const uint8_t *q = p + S.seq_hdr;
+    const int modes = *q++;
+    const int m[3] = {modes >> 6, (modes >> 4) & 3, (modes >> 2) & 3};
+    for (int u = 0; u <= t; u++) {
+        const bool want = u == t;
+        if (m[u] == 1) {
+            if (q >= end) return -1;
+            if (want) {
+                if (*q > max_sym[u]) return -1;
+                s.tab[t][0] = *q;  // nbBits 0, base 0
+                s.log[t] = 0;
+            }
+            q++;
+        } else if (m[u] == 2) {
+            int ns = 0, log = 0;
+            const int used = fse_read_norm(q, (int)(end - q), max_log[u], max_sym[u], s.norm, &ns, &log);
+            if (used < 0) return -1;
+            if (want) {
+                if (fse_build(s.tab[t], s.norm, ns, log, s.next)) return -1;
+                s.log[t] = log;
+            }
+            q += used;
+        } else if (m[u] == 0) {
+            if (want) {
+                const int16_t *def = t == 0 ? kLLDef : t == 1 ? kOFDef : kMLDef;
+                const int n = t == 0 ? 36 : t == 1 ? 29 : 53, log = t == 1 ? 5 : 6;
+                for (int i = 0; i < n; i++) s.norm[i] = def[i];
+                if (fse_build(s.tab[t], s.norm, n, log, s.next)) return -1;
+                s.log[t] = log;
+            }
+        } else if (want) {
+            return -1;  // a Repeat entry is never a source
+        }
+    }
+    if (after) *after = (uint32_t)(q - p);
+    return 0;
+}
+
+__device__ __forceinline__ uint32_t rep_dec(uint32_t code, bool *bad) {  // "that offset minus one"
+    if (code & kRepSym) return code + 1;
+    if (code <= 1) *bad = true;
+    return code - 1;
+}
+
+__global__ __launch_bounds__(64) void k_zst_sequences(const uint8_t *__restrict__ comp, Block *blocks, uint32_t nb, uint32_t *d_ll,
+                                                      uint32_t *d_ml, uint32_t *d_off) {
+    __shared__ SeqLds s;
+    const uint32_t lane = threadIdx.x;
+    if (lane < 36) s.ll_code[lane] = kLLCode[lane];
+    if (lane < 53) s.ml_code[lane] = kMLCode[lane];
+    __syncthreads();
+    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        const Block B = blocks[b];
+        if (B.type != 2) continue;
+        if (B.nseq == 0) {
+            if (lane == 0) {
+                blocks[b].out_size = B.lit_regen;
+                blocks[b].rep_out[0] = kRepSym;
+                blocks[b].rep_out[1] = kRepSym | (1u << 29);
+                blocks[b].rep_out[2] = kRepSym | (2u << 29);
+            }
+            continue;
+        }
+        if (lane == 0) {
+            uint32_t err = 0;
+            do {
+                // the three tables: this block's own descriptions, or the block they are repeated from
+                uint32_t q_off = B.seq_hdr + 1;
+                bool bad_tab = false;
+                for (int t = 0; t < 3 && !bad_tab; t++) {
+                    if (B.tbl_src[t] == b) {
+                        if (seq_table_from(s, t, comp, B, &q_off)) bad_tab = true;
+                    } else {
+                        const Block S = blocks[B.tbl_src[t]];
+                        if (seq_table_from(s, t, comp, S, nullptr)) bad_tab = true;
+                    }
+                }
+                if (bad_tab) { err = kErrFse; break; }
+                const uint8_t *p = comp + B.src_off;
+                if (q_off >= B.src_size) { err = kErrSequences; break; }
+                BitsRev br;
+                if (!br.init(p + q_off, (long long)B.src_size - q_off)) { err = kErrSequences; break; }
+                const uint32_t llog = (uint32_t)s.log[0], olog = (uint32_t)s.log[1], mlog = (uint32_t)s.log[2];
+                br.need(llog + olog + mlog);
+                uint32_t sl = br.read(llog), so = br.read(olog), sm = br.read(mlog);
+                if (br.left() < 0) { err = kErrSequences; break; }
+                uint32_t r0 = kRepSym, r1 = kRepSym | (1u << 29), r2 = kRepSym | (2u << 29);
+                uint32_t sum_ll = 0, sum_ml = 0;
+                uint32_t *o_ll = d_ll + B.seq_off, *o_ml = d_ml + B.seq_off, *o_off = d_off + B.seq_off;
+                bool bad = false, bad_off = false;
+                for (uint32_t i = 0; i < B.nseq; i++) {
+                    const uint32_t el = s.tab[0][sl], eo = s.tab[1][so], em = s.tab[2][sm];
+                    const uint32_t lc = el & 255, oc = eo & 255, mc = em & 255;
+                    if (lc > 35 || oc > 31 || mc > 52) { bad = true; break; }
+                    br.need(oc);
+                    const uint32_t ov = (1u << oc) + br.read(oc);
+                    const uint32_t mcode = s.ml_code[mc], lcode = s.ll_code[lc];
+                    br.need((mcode >> 24) + (lcode >> 24));
+                    const uint32_t ml = (mcode & 0xFFFFFFu) + br.read(mcode >> 24);
+                    const uint32_t ll = (lcode & 0xFFFFFFu) + br.read(lcode >> 24);
+                    if (i + 1 < B.nseq) {
+                        const uint32_t nl = (el >> 8) & 255, nm = (em >> 8) & 255, no = (eo >> 8) & 255;
+                        br.need(nl + nm + no);
+                        sl = (el >> 16) + br.read(nl);
+                        sm = (em >> 16) + br.read(nm);
+                        so = (eo >> 16) + br.read(no);
+                    }
+                    uint32_t code;
+                    if (ov > 3) {
+                        code = ov - 3;
+                        if (code >= (1u << 29)) { bad_off = true; break; }  // beyond any window this decoder accepts
+                        r2 = r1, r1 = r0, r0 = code;
+                    } else {
+                        const uint32_t idx = ov - 1 + (ll == 0 ? 1u : 0u);
+                        if (idx == 0) {
+                            code = r0;
+                        } else {
+                            code = idx == 1 ? r1 : idx == 2 ? r2 : rep_dec(r0, &bad_off);
+                            if (idx > 1) r2 = r1;
+                            r1 = r0;
+                            r0 = code;
+                        }
+                    }
+                    o_ll[i] = ll;
+                    o_ml[i] = ml;
+                    o_off[i] = code;
+                    sum_ll += ll;
+                    sum_ml += ml;
+                    if (sum_ll > kBlockMax || sum_ml > kBlockMax) { bad = true; break; }
+                }
+                if (bad_off) { err = kErrOffset; break; }
+                if (bad || br.left() != 0) { err = kErrSequences; break; }
+                if (sum_ll > B.lit_regen) { err = kErrSequences; break; }
+                if (B.lit_regen + sum_ml > kBlockMax) { err = kErrSize; break; }
+                blocks[b].out_size = B.lit_regen + sum_ml;
+                blocks[b].rep_out[0] = r0;
+                blocks[b].rep_out[1] = r1;
+                blocks[b].rep_out[2] = r2;
+            } while (0);
+            if (err) block_fail(blocks, b, err);
+        }
+        __syncthreads();
+    }
+}
+
+// ---- scan: output offsets and the repeat-offset history at every block's start -----------------------------------
+__device__ __forceinline__ uint32_t rep_apply(uint32_t code, uint32_t r0, uint32_t r1, uint32_t r2, bool *bad) {
+    if (!(code & kRepSym)) return code;
+    const uint32_t slot = (code >> 29) & 3, k = code & 0x1FFFFFFFu;
+    const uint32_t base = slot == 0 ? r0 : slot == 1 ? r1 : r2;
+    if (base <= k) {
+        *bad = true;
+        return 1;
+    }
+    return base - k;
+}
+
+__global__ __launch_bounds__(64) void k_zst_scan(Block *blocks, uint32_t nb, uint64_t *total_out) {
+    const uint32_t lane = threadIdx.x;
+    uint64_t run = 0;
+    uint32_t r0 = 1, r1 = 4, r2 = 8;  // wave-uniform
+    for (uint32_t g = 0; g < nb; g += 64) {
+        const uint32_t i = g + lane;
+        const bool valid = i < nb;
+        uint32_t out_size = 0, first = 0, has = 0, c0 = 0, c1 = 0, c2 = 0;
+        if (valid) {
+            const Block *B = blocks + i;
+            out_size = B->status ? 0u : B->out_size;
+            first = B->first_of_frame;
+            has = B->type == 2 && B->nseq > 0 && B->status == 0;
+            c0 = B->rep_out[0], c1 = B->rep_out[1], c2 = B->rep_out[2];
+        }
+        const uint32_t incl = wave_incl_sum(out_size);
+        const uint32_t cnt = nb - g < 64 ? nb - g : 64;
+        uint32_t in0 = 0, in1 = 0, in2 = 0;
+        bool my_bad = false;
+        for (uint32_t j = 0; j < cnt; j++) {
+            if (__builtin_amdgcn_readlane(first, j)) r0 = 1, r1 = 4, r2 = 8;
+            if (lane == j) in0 = r0, in1 = r1, in2 = r2;
+            if (__builtin_amdgcn_readlane(has, j)) {
+                bool bad = false;
+                const uint32_t n0 = rep_apply(__builtin_amdgcn_readlane(c0, j), r0, r1, r2, &bad);
+                const uint32_t n1 = rep_apply(__builtin_amdgcn_readlane(c1, j), r0, r1, r2, &bad);
+                const uint32_t n2 = rep_apply(__builtin_amdgcn_readlane(c2, j), r0, r1, r2, &bad);
+                r0 = n0, r1 = n1, r2 = n2;
+                if (bad && lane == j) my_bad = true;
+            }
+        }
+        if (valid) {
+            Block *B = blocks + i;
+            B->out_off = run + incl - out_size;
+            B->rep_in[0] = in0, B->rep_in[1] = in1, B->rep_in[2] = in2;
+            if (my_bad) atomicCAS(&B->status, 0u, (uint32_t)kErrOffset);
+        }
+        run += __builtin_amdgcn_readlane(incl, 63);
+    }
+    if (lane == 0) *total_out = run;
+}
+
+// ---- execution of the sequences -------------------------------------------------------------------------------------
+template <bool SYM>
+struct ExecCfg {
+    using Elem = uint8_t;
+    static constexpr uint32_t kRing = 4096;
+};
+template <>
+struct ExecCfg<true> {
+    using Elem = uint32_t;
+    static constexpr uint32_t kRing = 2048;
+};
+static constexpr uint32_t kPiece = 1024;  // elements emitted between two flush checks (ring >= 2 * kPiece)
+
+template <bool SYM>
+struct Exec {
+    using Elem = typename ExecCfg<SYM>::Elem;
+    static constexpr uint32_t kRing = ExecCfg<SYM>::kRing, kMask = kRing - 1;
+    Elem *ring;          // LDS
+    Elem *out;           // the element array in HBM (bytes: the output; symbols: d_sym)
+    uint64_t start;      // element index of the chunk's first element
+    uint64_t abs;        // ... of the next element
+    uint64_t flushed;    // elements below this index are in HBM
+    uint32_t lane;
+
+    // completed 1024-element segments (on the absolute 1024 grid, so that all but the first are 16-byte aligned) -> HBM
+    __device__ __forceinline__ void flush(bool all) {
+        bool any = false;
+        for (;;) {
+            uint64_t next = (flushed | 1023ull) + 1;
+            if (next > abs) {
+                if (!all || flushed == abs) break;
+                next = abs;
+            }
+            const uint32_t n = (uint32_t)(next - flushed);
+            if (n == 1024) {
+                const Elem *src = ring + ((uint32_t)flushed & kMask) + lane * 16;
+                Elem *dst = out + flushed + lane * 16;
+#pragma unroll
+                for (uint32_t k = 0; k < sizeof(Elem); k++) reinterpret_cast<uint4 *>(dst)[k] = reinterpret_cast<const uint4 *>(src)[k];
+            } else {
+                for (uint32_t e = lane; e < n; e += 64) out[flushed + e] = ring[(uint32_t)(flushed + e) & kMask];
+            }
+            flushed = next;
+            any = true;
+        }
+        // later matches read these elements back through the CU's own L1 (write-through, coherent inside a workgroup):
+        // the stores only have to be complete first
+        if (any) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    }
+    __device__ __forceinline__ void put_bytes(const uint8_t *src, uint32_t n) {
+        for (uint32_t done = 0; done < n;) {
+            const uint32_t piece = n - done < kPiece ? n - done : kPiece;
+            for (uint32_t i = lane; i < piece; i += 64) ring[(uint32_t)(abs + i) & kMask] = (Elem)src[done + i];
+            abs += piece;
+            done += piece;
+            flush(false);
+        }
+    }
+    __device__ __forceinline__ void put_fill(uint8_t v, uint32_t n) {
+        for (uint32_t done = 0; done < n;) {
+            const uint32_t piece = n - done < kPiece ? n - done : kPiece;
+            for (uint32_t i = lane; i < piece; i += 64) ring[(uint32_t)(abs + i) & kMask] = (Elem)v;
+            abs += piece;
+            done += piece;
+            flush(false);
+        }
+    }
+    // LZ77 copy: `len` elements from `off` back; the source index is folded into [match start - off, match start), so an
+    // overlapping copy is exact whatever the order the lanes work in
+    __device__ __forceinline__ void put_match(uint32_t off, uint32_t len) {
+        const uint64_t m0 = abs;  // match start
+        for (uint32_t done = 0; done < len;) {
+            const uint32_t piece = len - done < kPiece ? len - done : kPiece;
+            const uint64_t hi = abs + piece;
+            for (uint32_t i = lane; i < piece; i += 64) {
+                const uint32_t k = done + i;
+                const uint32_t rel = off >= len ? k : k % off;
+                Elem x;
+                if (SYM && m0 + rel < start + off) {
+                    // in front of the chunk: "the byte d in front of the chunk's first", resolved once the bytes there are final
+                    x = (Elem)(kSymRef | (uint32_t)(start + off - (m0 + rel)));
+                } else {
+                    const uint64_t src = m0 - off + rel;
+                    if (src + kRing >= hi)
+                        x = ring[(uint32_t)src & kMask];
+                    else  // older than the ring: flushed at least 1 KiB ago
+                        x = __hip_atomic_load(out + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                ring[(uint32_t)(abs + i) & kMask] = x;
+            }
+            abs += piece;
+            done += piece;
+            flush(false);
+        }
+    }
+};
+
+template <bool SYM>
+__global__ __launch_bounds__(64) void k_zst_exec(const uint8_t *__restrict__ comp, Block *blocks, const Chunk *chunks, uint32_t n_chunks,
+                                                 const uint8_t *__restrict__ lit, const uint32_t *__restrict__ d_ll,
+                                                 const uint32_t *__restrict__ d_ml, const uint32_t *__restrict__ d_off,
+                                                 typename ExecCfg<SYM>::Elem *out, uint32_t *chunk_status) {
+    using Elem = typename ExecCfg<SYM>::Elem;
+    __shared__ __attribute__((aligned(16))) Elem ring[ExecCfg<SYM>::kRing];
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        const Chunk C = chunks[c];
+        if ((C.symbolic != 0) != SYM) continue;
+        Exec<SYM> ex;
+        ex.ring = ring;
+        ex.out = out;
+        ex.lane = lane;
+        ex.start = ex.abs = ex.flushed = C.elem_off;
+        const uint64_t frame_pos0 = C.out_off - C.frame_out_off;  // bytes of the frame in front of the chunk
+        uint32_t err = 0;
+        for (uint32_t bi = 0; bi < C.n_blocks && !err; bi++) {
+            const uint32_t b = C.first_block + bi;
+            const Block B = blocks[b];
+            if (B.type == 0) {
+                ex.put_bytes(comp + B.src_off, B.src_size);
+            } else if (B.type == 1) {
+                ex.put_fill(comp[B.src_off], B.src_size);
+            } else {
+                const uint8_t *L = lit + B.lit_off;
+                uint32_t lit_pos = 0;
+                for (uint32_t g = 0; g < B.nseq && !err; g += 64) {
+                    const uint32_t i = g + lane;
+                    const bool valid = i < B.nseq;
+                    uint32_t ll = 0, ml = 0, off = 1;
+                    bool bad = false;
+                    if (valid) {
+                        ll = d_ll[B.seq_off + i];
+                        ml = d_ml[B.seq_off + i];
+                        const uint32_t code = d_off[B.seq_off + i];
+                        if (code & kRepSym) {
+                            const uint32_t slot = (code >> 29) & 3, k = code & 0x1FFFFFFFu;
+                            const uint32_t base = B.rep_in[slot];
+                            bad = base <= k;
+                            off = bad ? 1u : base - k;
+                        } else {
+                            off = code;
+                            bad = code == 0;
+                        }
+                    }
+                    if (__any(bad)) {
+                        err = kErrOffset;
+                        break;
+                    }
+                    const uint32_t ll_incl = wave_incl_sum(ll);
+                    const uint32_t cnt = B.nseq - g < 64 ? B.nseq - g : 64;
+                    for (uint32_t j = 0; j < cnt; j++) {
+                        const uint32_t L_j = __builtin_amdgcn_readlane(ll, j), M_j = __builtin_amdgcn_readlane(ml, j);
+                        const uint32_t O_j = __builtin_amdgcn_readlane(off, j);
+                        const uint32_t lsrc = lit_pos + __builtin_amdgcn_readlane(ll_incl, j) - L_j;
+                        if (L_j) ex.put_bytes(L + lsrc, L_j);
+                        // libzstd: a match may reach back to the first byte of the frame's content, not beyond
+                        if ((uint64_t)O_j > frame_pos0 + (ex.abs - ex.start)) {
+                            err = kErrOffset;
+                            break;
+                        }
+                        ex.put_match(O_j, M_j);
+                    }
+                    lit_pos += __builtin_amdgcn_readlane(ll_incl, 63);
+                }
+                if (!err && lit_pos < B.lit_regen) ex.put_bytes(L + lit_pos, B.lit_regen - lit_pos);
+            }
+        }
+        ex.flush(true);
+        if (lane == 0) chunk_status[c] = err;
+        __syncthreads();
+    }
+}
+
+// ---- XXH64 of a frame's content (RFC 8878 3.1.1: Content_Checksum = its low 32 bits, seed 0) ----------------------
+static constexpr uint64_t XP1 = 11400714785074694791ull, XP2 = 14029467366897019727ull, XP3 = 1609587929392839161ull,
+                          XP4 = 9650029242287828579ull, XP5 = 2870177450012600261ull;
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+__device__ __forceinline__ uint64_t xround(uint64_t acc, uint64_t in) { return rotl64(acc + in * XP2, 31) * XP1; }
+__device__ __forceinline__ uint64_t xmerge(uint64_t h, uint64_t v) { return (h ^ xround(0, v)) * XP1 + XP4; }
+
+__global__ __launch_bounds__(64) void k_zst_xxh64(const uint8_t *__restrict__ out, const Frame *frames, uint32_t nf, uint64_t max_bytes,
+                                                  uint32_t *frame_status) {
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t f = blockIdx.x; f < nf; f += gridDim.x) {
+        const Frame F = frames[f];
+        if (!F.has_checksum || F.out_size > max_bytes) continue;
+        const uint8_t *p = out + F.out_off;
+        const uint64_t n = F.out_size, stripes = n / 32;
+        // the four accumulators are four independent serial chains: lanes 0-3
+        uint64_t acc = lane == 0 ? XP1 + XP2 : lane == 1 ? XP2 : lane == 2 ? 0 : 0 - XP1;
+        if (lane < 4) {
+            const uint8_t *q = p + 8 * lane;
+            uint64_t s = 0;
+            for (; s + 8 <= stripes; s += 8) {
+                uint64_t x[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) x[k] = ld64(q + 32 * (s + k));
+#pragma unroll
+                for (int k = 0; k < 8; k++) acc = xround(acc, x[k]);
+            }
+            for (; s < stripes; s++) acc = xround(acc, ld64(q + 32 * s));
+        }
+        const uint64_t v1 = __shfl((unsigned long long)acc, 0, 64), v2 = __shfl((unsigned long long)acc, 1, 64),
+                       v3 = __shfl((unsigned long long)acc, 2, 64), v4 = __shfl((unsigned long long)acc, 3, 64);
+        if (lane == 0) {
+            uint64_t h;
+            if (n >= 32) {
+                h = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
+                h = xmerge(h, v1), h = xmerge(h, v2), h = xmerge(h, v3), h = xmerge(h, v4);
+            } else {
+                h = XP5;
+            }
+            h += n;
+            const uint8_t *t = p + stripes * 32, *end = p + n;
+            while (t + 8 <= end) {
+                h ^= xround(0, ld64(t));
+                h = rotl64(h, 27) * XP1 + XP4;
+                t += 8;
+            }
+            if (t + 4 <= end) {
+                uint32_t w;
+                __builtin_memcpy(&w, t, 4);
+                h ^= (uint64_t)w * XP1;
+                h = rotl64(h, 23) * XP2 + XP3;
+                t += 4;
+            }
+            while (t < end) {
+                h ^= (*t++) * XP5;
+                h = rotl64(h, 11) * XP1;
+            }
+            h ^= h >> 33, h *= XP2, h ^= h >> 29, h *= XP3, h ^= h >> 32;
+            frame_status[f] = (uint32_t)h == F.checksum ? 0u : (uint32_t)kErrChecksum;
+        }
+    }
+}
+
+// ---- symbol chunks: resolve "the byte d in front of the chunk" once everything in front of the chunk is final -----
+__global__ __launch_bounds__(256) void k_zst_resolve(const uint32_t *__restrict__ sym, uint64_t elem_off, uint8_t *out, uint64_t out_off,
+                                                     uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t x = sym[elem_off + i];
+    out[out_off + i] = (x & kSymRef) ? out[out_off - (x & ~kSymRef)] : (uint8_t)x;
+}
+
+static const char *status_text(uint32_t code) {
+    switch (code) {
+        case kErrChecksum: return "Restored data doesn't match checksum";
+        case kErrSize: return "Data corruption detected (size)";
+        case kErrOffset: return "Data corruption detected (offset)";
+        case kErrHuffman: return "Data corruption detected (Huffman literals)";
+        case kErrFse: return "Data corruption detected (FSE table)";
+        case kErrSequences: return "Data corruption detected (sequences)";
+        default: return "Data corruption detected";
+    }
+}
+
+}  // namespace zst
+}  // namespace exg
+
+// ---- C-ABI ----------------------------------------------------------------------------------------------------------
+// All frames of a zstd stream (concatenated frames and skippable frames included, as ZSTD_decompressStream reads them).
+// h_comp: the compressed bytes on the host (only headers are read: the frame / block walk); d_comp: the same bytes on the
+// device, readable to n + 16.  On success *d_out is a hipMalloc'd buffer the caller hipFree()s (*produced bytes + 64
+// zeroed).  Synchronises the stream.  Errors: EXG_E_PARSE with libzstd's wording in exg_last_error_message().
+extern "C" int exg_zstd_decode(const uint8_t *h_comp, const void *d_comp_v, uint64_t n, void **d_out_p, uint64_t *produced, void *stream_v) {
+    using namespace exg;
+    using namespace exg::zst;
+    if (!h_comp || !d_comp_v || !d_out_p || !produced) {
+        set_error("exg_zstd_decode: null argument");
+        return EXG_E_INVALID_ARG;
+    }
+    *d_out_p = nullptr;
+    *produced = 0;
+    hipStream_t st = (hipStream_t)stream_v;
+    const uint8_t *d_comp = (const uint8_t *)d_comp_v;
+    Index idx;
+    if (!build_index(h_comp, n, idx)) {
+        set_error("%s", idx.error.c_str());
+        return EXG_E_PARSE;
+    }
+    struct Dev {
+        void *p = nullptr;
+        ~Dev() {
+            if (p) (void)hipFree(p);
+        }
+        hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    };
+    const uint32_t nb = (uint32_t)idx.blocks.size(), nf = (uint32_t)idx.frames.size();
+    Dev d_blocks, d_lit, d_ll, d_ml, d_off, d_meta, d_frames, d_chunks, d_status, d_out;
+    EXG_HIP_CHECK(d_meta.alloc(64));
+    uint64_t total = 0;
+    if (nb) {
+        EXG_HIP_CHECK(d_blocks.alloc((size_t)nb * sizeof(Block)));
+        EXG_HIP_CHECK(d_lit.alloc(idx.lit_bytes + 64));
+        EXG_HIP_CHECK(d_ll.alloc(idx.n_seq * 4 + 16));
+        EXG_HIP_CHECK(d_ml.alloc(idx.n_seq * 4 + 16));
+        EXG_HIP_CHECK(d_off.alloc(idx.n_seq * 4 + 16));
+        EXG_HIP_CHECK(hipMemcpyAsync(d_blocks.p, idx.blocks.data(), (size_t)nb * sizeof(Block), hipMemcpyHostToDevice, st));
+        const uint32_t grid = nb < 16384 ? nb : 16384;
+        hipLaunchKernelGGL(k_zst_literals, dim3(grid), dim3(64), 0, st, d_comp, (Block *)d_blocks.p, nb, (uint8_t *)d_lit.p);
+        hipLaunchKernelGGL(k_zst_sequences, dim3(grid), dim3(64), 0, st, d_comp, (Block *)d_blocks.p, nb, (uint32_t *)d_ll.p, (uint32_t *)d_ml.p,
+                           (uint32_t *)d_off.p);
+        hipLaunchKernelGGL(k_zst_scan, dim3(1), dim3(64), 0, st, (Block *)d_blocks.p, nb, (uint64_t *)d_meta.p);
+        EXG_HIP_CHECK(hipGetLastError());
+        EXG_HIP_CHECK(hipMemcpyAsync(idx.blocks.data(), d_blocks.p, (size_t)nb * sizeof(Block), hipMemcpyDeviceToHost, st));
+        EXG_HIP_CHECK(hipMemcpyAsync(&total, d_meta.p, 8, hipMemcpyDeviceToHost, st));
+        EXG_HIP_CHECK(hipStreamSynchronize(st));
+        for (uint32_t b = 0; b < nb; b++)
+            if (idx.blocks[b].status) {
+                set_error("%s (zstd block %u at byte %llu)", status_text(idx.blocks[b].status), b, (unsigned long long)idx.blocks[b].src_off);
+                return EXG_E_PARSE;
+            }
+    }
+    // frames: where their content lies, and the size their header promised
+    std::vector<Chunk> chunks;
+    for (uint32_t f = 0; f < nf; f++) {
+        Frame &F = idx.frames[f];
+        F.out_off = F.n_blocks ? idx.blocks[F.first_block].out_off : total;
+        uint64_t sz = 0;
+        for (uint32_t b = 0; b < F.n_blocks; b++) sz += idx.blocks[F.first_block + b].out_size;
+        F.out_size = sz;
+        if (F.content_size != ~0ull && F.content_size != sz) {
+            set_error("Data corruption detected (zstd frame %u regenerates %llu bytes, its header says %llu)", f, (unsigned long long)sz,
+                      (unsigned long long)F.content_size);
+            return EXG_E_PARSE;
+        }
+        if (!F.n_blocks) continue;
+        Chunk c;
+        memset(&c, 0, sizeof c);
+        c.first_block = F.first_block;
+        c.n_blocks = F.n_blocks;
+        c.out_off = c.frame_out_off = c.elem_off = F.out_off;
+        c.symbolic = 0;
+        chunks.push_back(c);
+    }
+    EXG_HIP_CHECK(d_out.alloc(total + 64));
+    EXG_HIP_CHECK(hipMemsetAsync((char *)d_out.p + total, 0, 64, st));
+    const uint32_t nc = (uint32_t)chunks.size();
+    if (nc) {
+        EXG_HIP_CHECK(d_chunks.alloc((size_t)nc * sizeof(Chunk)));
+        EXG_HIP_CHECK(d_frames.alloc((size_t)nf * sizeof(Frame)));
+        EXG_HIP_CHECK(d_status.alloc(((size_t)nc + nf) * 4));
+        EXG_HIP_CHECK(hipMemsetAsync(d_status.p, 0, ((size_t)nc + nf) * 4, st));
+        EXG_HIP_CHECK(hipMemcpyAsync(d_chunks.p, chunks.data(), (size_t)nc * sizeof(Chunk), hipMemcpyHostToDevice, st));
+        EXG_HIP_CHECK(hipMemcpyAsync(d_frames.p, idx.frames.data(), (size_t)nf * sizeof(Frame), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_zst_exec<false>, dim3(nc < 16384 ? nc : 16384), dim3(64), 0, st, d_comp, (Block *)d_blocks.p, (const Chunk *)d_chunks.p, nc,
+                           (const uint8_t *)d_lit.p, (const uint32_t *)d_ll.p, (const uint32_t *)d_ml.p, (const uint32_t *)d_off.p,
+                           (uint8_t *)d_out.p, (uint32_t *)d_status.p);
+        static const uint64_t verify_max = getenv("EXG_ZSTD_VERIFY_MAX") ? strtoull(getenv("EXG_ZSTD_VERIFY_MAX"), nullptr, 10) : (256ull << 20);
+        hipLaunchKernelGGL(k_zst_xxh64, dim3(nf < 16384 ? nf : 16384), dim3(64), 0, st, (const uint8_t *)d_out.p, (const Frame *)d_frames.p, nf,
+                           verify_max, (uint32_t *)d_status.p + nc);
+        EXG_HIP_CHECK(hipGetLastError());
+        std::vector<uint32_t> status((size_t)nc + nf);
+        EXG_HIP_CHECK(hipMemcpyAsync(status.data(), d_status.p, status.size() * 4, hipMemcpyDeviceToHost, st));
+        EXG_HIP_CHECK(hipStreamSynchronize(st));
+        for (uint32_t c = 0; c < nc; c++)
+            if (status[c]) {
+                set_error("%s (zstd blocks %u..%u)", status_text(status[c]), chunks[c].first_block, chunks[c].first_block + chunks[c].n_blocks - 1);
+                return EXG_E_PARSE;
+            }
+        for (uint32_t f = 0; f < nf; f++)
+            if (status[nc + f]) {
+                set_error("%s (zstd frame %u)", status_text(status[nc + f]), f);
+                return EXG_E_PARSE;
+            }
+    } else {
+        EXG_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    *d_out_p = d_out.p;
+    d_out.p = nullptr;
+    *produced = total;
+    return EXG_OK;
+}

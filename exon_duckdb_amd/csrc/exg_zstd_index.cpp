@@ -1,0 +1,181 @@
+// exg_zstd_index.cpp — host walk over the frames and blocks of a Zstandard stream (RFC 8878 3.1).  Nothing is decoded
+// here: the walk reads the frame header, the 3-byte block headers and, inside a compressed block, the few bytes that say
+// how large its literals are, how many sequences it holds and which tables it defines or repeats — so that the device can
+// decode all blocks at once (exg_zstd.hip).  The error texts are libzstd's (what the reference's zstd 0.12.3 would raise).
+#include <string.h>
+
+#include "exg_zstd.hpp"
+
+namespace exg {
+namespace zst {
+
+static inline uint32_t rd24(const uint8_t *p) { return p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16); }
+static inline uint32_t rd32(const uint8_t *p) { return rd24(p) | ((uint32_t)p[3] << 24); }
+
+static bool fail(Index &idx, const char *what, uint64_t at) {
+    idx.error = std::string(what) + " (zstd, byte " + std::to_string(at) + ")";
+    return false;
+}
+
+bool build_index(const uint8_t *data, uint64_t n, Index &idx) {
+    static const char *kSrcSize = "Src size is incorrect", *kCorrupt = "Data corruption detected";
+    uint64_t pos = 0;
+    while (pos < n) {
+        if (n - pos < 4) return fail(idx, kSrcSize, pos);
+        const uint32_t magic = rd32(data + pos);
+        if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {  // skippable frame (3.1.2)
+            if (n - pos < 8) return fail(idx, kSrcSize, pos);
+            const uint64_t sz = rd32(data + pos + 4);
+            if (n - pos - 8 < sz) return fail(idx, kSrcSize, pos);
+            pos += 8 + sz;
+            continue;
+        }
+        if (magic != 0xFD2FB528u) return fail(idx, "Unknown frame descriptor", pos);
+        const uint64_t frame_at = pos;
+        pos += 4;
+        if (pos >= n) return fail(idx, kSrcSize, frame_at);
+        const uint8_t fhd = data[pos++];
+        const int fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, did_flag = fhd & 3;
+        if (fhd & 8) return fail(idx, "Unsupported frame parameter", frame_at);  // reserved bit
+        Frame fr;
+        memset(&fr, 0, sizeof fr);
+        fr.content_size = ~0ull;
+        fr.has_checksum = (fhd >> 2) & 1;
+        if (!single) {
+            if (pos >= n) return fail(idx, kSrcSize, frame_at);
+            const uint8_t wd = data[pos++];
+            const int wlog = 10 + (wd >> 3);
+            if (wlog > 31) return fail(idx, "Frame requires too much memory for decoding", frame_at);
+            fr.window = (1ull << wlog) + ((1ull << wlog) >> 3) * (wd & 7);
+        }
+        static const int did_bytes[4] = {0, 1, 2, 4};
+        if (n - pos < (uint64_t)did_bytes[did_flag]) return fail(idx, kSrcSize, frame_at);
+        uint32_t did = 0;
+        for (int i = 0; i < did_bytes[did_flag]; i++) did |= (uint32_t)data[pos + i] << (8 * i);
+        pos += did_bytes[did_flag];
+        if (did) return fail(idx, "Dictionary mismatch", frame_at);  // the reference passes no dictionary
+        const int fcs_bytes = fcs_flag == 0 ? single : fcs_flag == 1 ? 2 : fcs_flag == 2 ? 4 : 8;
+        if (n - pos < (uint64_t)fcs_bytes) return fail(idx, kSrcSize, frame_at);
+        if (fcs_bytes) {
+            uint64_t v = 0;
+            for (int i = 0; i < fcs_bytes; i++) v |= (uint64_t)data[pos + i] << (8 * i);
+            if (fcs_bytes == 2) v += 256;
+            fr.content_size = v;
+            pos += fcs_bytes;
+        }
+        if (single) fr.window = fr.content_size;
+        if (fr.window > kWindowMax) return fail(idx, "Frame requires too much memory for decoding", frame_at);
+        fr.first_block = (uint32_t)idx.blocks.size();
+        const uint32_t frame_id = (uint32_t)idx.frames.size();
+        uint32_t huf_src = kNone, tbl_src[3] = {kNone, kNone, kNone};
+        for (;;) {
+            if (n - pos < 3) return fail(idx, kSrcSize, pos);
+            const uint32_t bh = rd24(data + pos);
+            pos += 3;
+            const int last = bh & 1, type = (bh >> 1) & 3;
+            const uint32_t bsize = bh >> 3;
+            if (type == 3 || bsize > kBlockMax) return fail(idx, kCorrupt, pos - 3);
+            if (idx.blocks.size() >= 0xFFFFFFF0u) return fail(idx, "too many blocks", pos);
+            Block b;
+            memset(&b, 0, sizeof b);
+            b.src_off = pos;
+            b.src_size = bsize;
+            b.type = (uint8_t)type;
+            b.first_of_frame = idx.blocks.size() == fr.first_block;
+            b.frame = frame_id;
+            b.huf_src = kNone;
+            b.tbl_src[0] = b.tbl_src[1] = b.tbl_src[2] = kNone;
+            const uint32_t self = (uint32_t)idx.blocks.size();
+            if (type == 1) {
+                if (n - pos < 1) return fail(idx, kSrcSize, pos);
+                b.out_size = bsize;
+                idx.known_out += bsize;
+                pos += 1;
+            } else if (type == 0) {
+                if (n - pos < bsize) return fail(idx, kSrcSize, pos);
+                b.out_size = bsize;
+                idx.known_out += bsize;
+                pos += bsize;
+            } else {
+                if (n - pos < bsize) return fail(idx, kSrcSize, pos);
+                const uint8_t *p = data + pos;
+                if (bsize < 3) return fail(idx, kCorrupt, pos);  // libzstd: MIN_CBLOCK_SIZE
+                const int ltype = p[0] & 3, sf = (p[0] >> 2) & 3;
+                uint32_t regen, csize = 0, hsz, streams = 1;
+                if (ltype < 2) {
+                    if (!(sf & 1)) hsz = 1, regen = p[0] >> 3;
+                    else if (sf == 1) hsz = 2, regen = (p[0] >> 4) | ((uint32_t)p[1] << 4);
+                    else {
+                        if (bsize < 3) return fail(idx, kCorrupt, pos);
+                        hsz = 3, regen = (p[0] >> 4) | ((uint32_t)p[1] << 4) | ((uint32_t)p[2] << 12);
+                    }
+                } else {
+                    if (bsize < 5) return fail(idx, kCorrupt, pos);  // libzstd: a compressed literals section needs 5 bytes of input
+                    uint64_t v = 0;
+                    for (int i = 0; i < 5; i++) v |= (uint64_t)p[i] << (8 * i);
+                    if (sf == 0) hsz = 3, regen = (v >> 4) & 1023, csize = (v >> 14) & 1023;
+                    else if (sf == 1) hsz = 3, streams = 4, regen = (v >> 4) & 1023, csize = (v >> 14) & 1023;
+                    else if (sf == 2) hsz = 4, streams = 4, regen = (v >> 4) & 16383, csize = (uint32_t)(v >> 18) & 16383;
+                    else hsz = 5, streams = 4, regen = (v >> 4) & 262143, csize = (uint32_t)(v >> 22) & 262143;
+                }
+                if (regen > kBlockMax) return fail(idx, kCorrupt, pos);
+                const uint64_t lit_end = (uint64_t)hsz + (ltype == 0 ? regen : ltype == 1 ? 1 : csize);
+                if (lit_end + 1 > bsize) return fail(idx, kCorrupt, pos);  // the sequence count follows
+                if (ltype == 2) huf_src = self;
+                if (ltype == 3 && huf_src == kNone) return fail(idx, "Dictionary mismatch", pos);  // libzstd: dictionary_corrupted
+                b.lit_type = (uint8_t)ltype;
+                b.lit_streams = (uint8_t)streams;
+                b.lit_hdr = hsz;
+                b.lit_regen = regen;
+                b.lit_csize = csize;
+                b.huf_src = ltype >= 2 ? huf_src : kNone;
+                const uint8_t *q = p + lit_end, *end = p + bsize;
+                uint32_t nseq = *q++;
+                if (nseq >= 128) {
+                    if (nseq == 255) {
+                        if (q + 2 > end) return fail(idx, kCorrupt, pos);
+                        nseq = q[0] + ((uint32_t)q[1] << 8) + 0x7F00;
+                        q += 2;
+                    } else {
+                        if (q + 1 > end) return fail(idx, kCorrupt, pos);
+                        nseq = ((nseq - 128) << 8) + q[0];
+                        q += 1;
+                    }
+                }
+                b.nseq = nseq;
+                if (nseq == 0) {
+                    if (q != end) return fail(idx, kCorrupt, pos);
+                } else {
+                    if (q >= end) return fail(idx, kCorrupt, pos);
+                    const int modes = *q;
+                    if (modes & 3) return fail(idx, kCorrupt, pos);
+                    b.seq_hdr = (uint32_t)(q - p);
+                    const int m[3] = {modes >> 6, (modes >> 4) & 3, (modes >> 2) & 3};
+                    for (int t = 0; t < 3; t++) {
+                        if (m[t] != 3) tbl_src[t] = self;
+                        else if (tbl_src[t] == kNone) return fail(idx, kCorrupt, pos);  // Repeat_Mode with nothing to repeat
+                        b.tbl_src[t] = tbl_src[t];
+                    }
+                }
+                b.lit_off = idx.lit_bytes;
+                b.seq_off = idx.n_seq;
+                idx.lit_bytes += (regen + 15) & ~15u;
+                idx.n_seq += nseq;
+                pos += bsize;
+            }
+            idx.blocks.push_back(b);
+            if (last) break;
+        }
+        fr.n_blocks = (uint32_t)idx.blocks.size() - fr.first_block;
+        if (fr.has_checksum) {
+            if (n - pos < 4) return fail(idx, kSrcSize, pos);
+            fr.checksum = rd32(data + pos);
+            pos += 4;
+        }
+        idx.frames.push_back(fr);
+    }
+    return true;
+}
+
+}  // namespace zst
+}  // namespace exg

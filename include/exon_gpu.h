@@ -24,9 +24,10 @@
  *
  *   (3) replacement_scan — same name, argument and result struct as the reference's FFI
  *       (exon/include/rust.hpp:11-13, :48), so the reference's ReplacementScan glue
- *       (module.cpp:320-382) binds to it unchanged.  `new_reader` is NOT re-exported: it returns
- *       an Arrow stream the DataChunk path no longer needs (INTEGRATION.md shows the binding that
- *       replaces its two call sites, module.cpp:98-102 and :239-243, with exg_open).
+ *       (module.cpp:320-382) binds to it unchanged; and `new_reader` (exon/include/rust.hpp:41-46),
+ *       the reference's own entry point: an Arrow C stream with the reference's schema, built on the
+ *       device (INTEGRATION.md also shows the binding that replaces its two call sites,
+ *       module.cpp:98-102 and :239-243, with the faster chunk boundary exg_open).
  *
  * Error convention: every function returns 0 on success or a negative
  * EXG_E_* code; nothing throws across this boundary.  Parse errors found by a
@@ -54,7 +55,7 @@ extern "C" {
 #define EXG_E_NO_DEVICE (-2)   /* HIP runtime / GPU missing: the product path fails loudly */
 #define EXG_E_HIP (-3)         /* a HIP call failed; see exg_last_error_message() */
 #define EXG_E_IO (-4)
-#define EXG_E_UNSUPPORTED (-5) /* e.g. zstd: no device decoder yet */
+#define EXG_E_UNSUPPORTED (-5) /* e.g. bzip2 / xz: no device decoder, and there is no CPU fallback */
 #define EXG_E_PARSE (-6)       /* reader level: a record failed to parse */
 #define EXG_E_CAPACITY (-7)    /* output arrays too small */
 #define EXG_E_NOMEM (-8)
@@ -276,6 +277,18 @@ int exg_inflate_members(const void *d_comp, void *d_out, const exg_inflate_membe
  * (*produced bytes + 64 zeroed), *consumed the compressed bytes used.  Synchronises the stream. */
 int exg_inflate_stream(const void *d_comp, uint64_t comp_off, uint64_t comp_size, uint64_t chunk_bytes, void **d_out,
                        uint64_t *produced, uint64_t *consumed, void *stream);
+
+/* ---- device zstd (RFC 8878 frames; replaces zstd 0.12.3 / libzstd 1.5.2 behind rust/src/arrow_reader.rs:73, :87-88;
+ * pinned by test_fastq_scan.test:22-32, 55-59 and test_fasta_scan.test:22-26, 45-49) --------------------------------
+ * All frames of the stream data[0, n) — concatenated frames and skippable frames included, as ZSTD_decompressStream
+ * reads them.  h_comp: the compressed bytes on the host (only frame / block headers are read there: a zstd stream states
+ * the size of every block, so the host finds all blocks by a pointer chase and the device entropy-decodes them all at
+ * once); d_comp: the same bytes on the device, readable to n + 16.  On success *d_out is a hipMalloc'd buffer the caller
+ * hipFree()s (*produced bytes + 64 zeroed).  Frames with a Content_Checksum are verified (XXH64 on the device) up to
+ * EXG_ZSTD_VERIFY_MAX bytes of content per frame (default 256 MiB: XXH64 is a serial recurrence).  Windows above
+ * 128 MiB and dictionaries are refused like libzstd's defaults do.  Synchronises the stream.
+ * Errors: EXG_E_PARSE, libzstd's wording in exg_last_error_message(). */
+int exg_zstd_decode(const uint8_t *h_comp, const void *d_comp, uint64_t n, void **d_out, uint64_t *produced, void *stream);
 
 /* Deterministic synthetic inputs, generated on the device so the bench
  * needs no PCIe traffic: writes file bytes [file_offset, file_offset+n_bytes) to d_out. */

@@ -3,7 +3,7 @@ functions (bind / init_global / init_local / scan over the reader-level C-ABI an
 
 test/sql/exondb-release-with-deb-info/test_fastq_scan.test, test_fasta_scan.test,
 test_vcf_record_scan.test — same fixtures (tests/golden/), same expected values.  Statements on
-.gz / .zst inputs are expected to fail LOUDLY for now (no device inflate yet, and no CPU fallback)."""
+.gz and .zst inputs are decoded on the device (there is no CPU fallback)."""
 import os
 
 import pytest
@@ -72,11 +72,22 @@ def test_fastq_gzip(con, golden_dir, name, compression):
 
 
 @pytest.mark.parametrize("name,compression", [("test.fastq.zst", None), ("test.fastq.zstd", "zstd")])
-def test_fastq_zstd_fails_loudly(con, golden_dir, name, compression):
-    # (:23-32) zstd has no device decoder: the statement must error, never fall back to a CPU
+def test_fastq_zstd(con, golden_dir, name, compression):
+    # SELECT count(*) FROM read_fastq('…/test.fastq.zst'); / ('…/test.fastq.zstd', compression='zstd')  -> 2   (:22-32)
+    rel = con.table_function("read_fastq", G(golden_dir, name), compression=compression)
+    assert rel.count() == 2
+    # the fixture is test.fastq.gz's text compressed with zstd (265 bytes; record 1 has no description there)
+    assert rel.fetchall() == con.table_function("read_fastq", G(golden_dir, "test.fastq.gz")).fetchall()
+    assert rel.fetchall(columns=["name", "description"]) == [(b"SEQ_ID", None), (b"SEQ_ID2", None)]
+    if compression is None:
+        assert con.from_path(G(golden_dir, name)).count() == 2     # SELECT count(*) FROM '…/test.fastq.zst';   (:55-59)
+
+
+def test_fastq_zstd_without_the_option_is_not_zstd(con, golden_dir):
+    # only `gz` / `zst` are sniffed (arrow_reader.rs:71-75): '.zstd' without compression='zstd' is read as text and fails
     from exon_duckdb_amd import ExgError
-    with pytest.raises(ExgError, match="not supported"):
-        con.table_function("read_fastq", G(golden_dir, name), compression=compression).count()
+    with pytest.raises(ExgError):
+        con.table_function("read_fastq", G(golden_dir, "test.fastq.zstd")).count()
 
 
 # ---- test_fasta_scan.test / test_fasta_copy.test -------------------------------------------------------
@@ -116,12 +127,12 @@ def test_fasta_gzip(con, golden_dir):
     assert rel.fetchall() == [(b"a", b"description", b"ATCG"), (b"b", b"description2", b"ATCG")] * 2
 
 
-def test_fasta_zstd_fails_loudly(con, golden_dir):
-    from exon_duckdb_amd import ExgError
-    with pytest.raises(ExgError, match="not supported"):
-        con.table_function("read_fasta", G(golden_dir, "test.fasta.zst")).count()              # (:46-49)
-    with pytest.raises(ExgError, match="not supported"):
-        con.table_function("read_fasta", G(golden_dir, "test.fasta.zstd"), compression="zstd").count()   # (:22-26)
+def test_fasta_zstd(con, golden_dir):
+    assert con.table_function("read_fasta", G(golden_dir, "test.fasta.zstd"), compression="zstd").count() == 2   # (:22-26)
+    assert con.table_function("read_fasta", G(golden_dir, "test.fasta.zst")).count() == 2                          # (:46-49)
+    assert con.from_path(G(golden_dir, "test.fasta.zst")).count() == 2
+    assert con.table_function("read_fasta", G(golden_dir, "test.fasta.zst")).fetchall() == [
+        (b"a", b"description", b"ATCG"), (b"b", b"description2", b"ATCG")]
 
 
 # ---- test_vcf_record_scan.test ---------------------------------------------------------------------------

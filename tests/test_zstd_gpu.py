@@ -1,0 +1,155 @@
+"""zstd on the device (exg_zstd_decode) against libzstd: every compression level, block type and table mode the encoder
+produces, multi-frame / skippable frames / checksums / missing content size / small windows, the reference's own .zst
+fixtures, and corrupted or truncated streams (an error wherever libzstd gives one)."""
+import ctypes as C
+import os
+import random
+
+import numpy as np
+import pytest
+
+from zstd_util import compress, decompress_stream, fastq_text, skippable
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def zstd_decode(lib, comp: bytes):
+    """-> (rc, bytes | message)"""
+    from exon_duckdb_amd import device
+    d_comp = device.upload(comp)
+    host = C.create_string_buffer(comp, len(comp))
+    out = C.c_void_p()
+    produced = C.c_uint64(0)
+    rc = lib.exg_zstd_decode(C.cast(host, C.c_void_p), C.c_void_p(d_comp.data_ptr()), len(comp), C.byref(out), C.byref(produced),
+                             device.stream_ptr())
+    if rc != 0:
+        return rc, lib.exg_last_error_message().decode()
+    n = produced.value
+    buf = (C.c_uint8 * max(n, 1))()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert hip.hipMemcpy(buf, out, n, 2) == 0
+    hip.hipFree.argtypes = [C.c_void_p]
+    hip.hipFree(out)
+    return 0, bytes(buf)[:n]
+
+
+def payloads():
+    r = random.Random(5)
+    mixed = bytearray()
+    for i in range(40):
+        mixed += os.urandom(r.randint(1, 5000)) if i % 3 == 0 else fastq_text(r.randint(1, 400), i) if i % 3 == 1 else bytes(
+            [r.randint(0, 255)]) * r.randint(1, 9000)
+    return {
+        "empty": b"",
+        "one": b"a",
+        "short": b"abc" * 5,
+        "zeros": b"\0" * 100000,
+        "ramp": bytes(range(256)) * 100,
+        "random": os.urandom(300000),
+        "fastq_small": fastq_text(3000),
+        "fastq": fastq_text(20000, 7),
+        "runs": b"A" * 70000 + os.urandom(1000) + b"A" * 70000,
+        "acgtn": bytes(r.choice(b"ACGTN") for _ in range(400000)),
+        "vcf_lines": b"chr1\t12345\trs99\tA\tG\t50.0\tPASS\tDP=10;AF=0.5\n" * 8000,
+        "mixed": bytes(mixed),
+    }
+
+
+@pytest.fixture(scope="module")
+def data():
+    return payloads()
+
+
+@pytest.mark.parametrize("name", list(payloads().keys()))
+def test_levels_and_checksums(gpu, data, name):
+    d = data[name]
+    for level in (1, 2, 3, 4, 5, 7, 9, 12, 15, 19, -1, -5):
+        for ck in (False, True):
+            comp = compress(d, level, ck)
+            rc, out = zstd_decode(gpu, comp)
+            assert rc == 0, (name, level, ck, out)
+            assert out == d, (name, level, ck, len(out), len(d))
+
+
+def test_reference_fixtures(gpu):
+    for f, first in (("test.fastq.zst", b"@SEQ_ID"), ("test.fastq.zstd", b"@SEQ_ID"), ("test.fasta.zst", b">a desc"), ("test.fasta.zstd", b">a desc")):
+        comp = open(os.path.join(GOLDEN, f), "rb").read()
+        ok, want = decompress_stream(comp)
+        assert ok
+        rc, out = zstd_decode(gpu, comp)
+        assert rc == 0, out
+        assert out == want and out.startswith(first)
+    # the fixture holds the same text as test.fastq.gz (record 1 without a description), not test.fastq's
+    import gzip
+    plain = gzip.decompress(open(os.path.join(GOLDEN, "test.fastq.gz"), "rb").read())
+    rc, out = zstd_decode(gpu, open(os.path.join(GOLDEN, "test.fastq.zst"), "rb").read())
+    assert out == plain
+
+
+def test_multi_frame_skippable_window_no_content_size(gpu, data):
+    d = fastq_text(30000, 3)
+    comp = (compress(d[:100000], 3, True) + skippable(b"hello", 3) + compress(d[100000:], 19, True, window_log=12, content_size=False)
+            + compress(b"", 3) + skippable(b"") + compress(b"tail", 1, True))
+    ok, want = decompress_stream(comp)
+    assert ok and want == d + b"tail"
+    rc, out = zstd_decode(gpu, comp)
+    assert rc == 0, out
+    assert out == want
+    comp = compress(d, 5, True, window_log=10, content_size=False)
+    rc, out = zstd_decode(gpu, comp)
+    assert rc == 0 and out == d
+    # many small frames (what pzstd / a chunked writer produces)
+    parts = [d[i:i + 7001] for i in range(0, len(d), 7001)]
+    comp = b"".join(compress(p, 1 + i % 7, i % 2 == 0) for i, p in enumerate(parts))
+    rc, out = zstd_decode(gpu, comp)
+    assert rc == 0 and out == d
+    # only skippable frames / nothing at all
+    assert zstd_decode(gpu, skippable(b"x" * 100)) == (0, b"")
+    assert zstd_decode(gpu, b"") == (0, b"")
+
+
+def test_big_frame_many_blocks(gpu):
+    d = fastq_text(150000, 11)  # ~45 MB: hundreds of blocks, repeated tables, treeless literals
+    for level, wl in ((1, 0), (3, 0), (6, 17), (19, 0)):
+        comp = compress(d, level, True, window_log=wl)
+        rc, out = zstd_decode(gpu, comp)
+        assert rc == 0, out
+        assert out == d, (level, wl)
+
+
+def test_corrupt_streams_fail_like_libzstd(gpu, data):
+    d = data["fastq"]
+    r = random.Random(9)
+    comp = compress(d, 3, True)
+    # truncations
+    for cut in (1, 3, 4, 5, 9, 20, len(comp) // 2, len(comp) - 5, len(comp) - 1):
+        ok, _ = decompress_stream(comp[:cut])
+        assert not ok
+        rc, msg = zstd_decode(gpu, comp[:cut])
+        assert rc != 0, cut
+    # bit flips: the device must fail wherever libzstd fails, and agree byte for byte where libzstd accepts
+    n_err = 0
+    for trial in range(200):
+        b = bytearray(comp)
+        k = r.randrange(len(b))
+        b[k] ^= 1 << r.randrange(8)
+        ok, want = decompress_stream(bytes(b))
+        rc, out = zstd_decode(gpu, bytes(b))
+        if ok:
+            assert rc == 0 and out == want, (trial, k)
+        else:
+            n_err += 1
+            assert rc != 0, (trial, k, want)
+    assert n_err > 150  # the checksum catches what the entropy stages let through
+    # garbage, wrong magic, a dictionary id, a window beyond libzstd's default limit
+    assert zstd_decode(gpu, b"not zstd at all")[0] != 0
+    assert zstd_decode(gpu, b"\x28\xb5\x2f\xfd\x01\x58\x07\x00\x00\x00")[0] != 0  # Dictionary_ID flag set
+    huge = compress(b"x" * 1000, 3, False, content_size=False)
+    b = bytearray(huge)
+    assert not (b[4] & 0x20)  # not single-segment: byte 5 is the window descriptor
+    b[5] = (18 << 3)          # window log 28
+    assert not decompress_stream(bytes(b))[0]
+    assert zstd_decode(gpu, bytes(b))[0] != 0
