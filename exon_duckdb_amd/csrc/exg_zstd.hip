@@ -20,6 +20,7 @@
 //   k_zst_xxh64      the frame's content checksum (XXH64, a serial recurrence: four lanes carry its four accumulators).
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
 
@@ -818,10 +819,35 @@ __global__ __launch_bounds__(64) void k_zst_xxh64(const uint8_t *__restrict__ ou
 // ---- symbol chunks: resolve "the byte d in front of the chunk" once everything in front of the chunk is final -----
 __global__ __launch_bounds__(256) void k_zst_resolve(const uint32_t *__restrict__ sym, uint64_t elem_off, uint8_t *out, uint64_t out_off,
                                                      uint64_t n) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    // four elements per thread: one 16-byte load of symbols (elem_off is a multiple of 4), one 4-byte store
+    const uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
-    const uint32_t x = sym[elem_off + i];
-    out[out_off + i] = (x & kSymRef) ? out[out_off - (x & ~kSymRef)] : (uint8_t)x;
+    const uint8_t *base = out + out_off;
+    if (i + 4 <= n) {
+        const uint4 x = *reinterpret_cast<const uint4 *>(sym + elem_off + i);
+        const uint32_t b0 = (x.x & kSymRef) ? *(base - (x.x & ~kSymRef)) : (x.x & 255);
+        const uint32_t b1 = (x.y & kSymRef) ? *(base - (x.y & ~kSymRef)) : (x.y & 255);
+        const uint32_t b2 = (x.z & kSymRef) ? *(base - (x.z & ~kSymRef)) : (x.z & 255);
+        const uint32_t b3 = (x.w & kSymRef) ? *(base - (x.w & ~kSymRef)) : (x.w & 255);
+        const uint32_t w = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        __builtin_memcpy(out + out_off + i, &w, 4);
+    } else {
+        for (uint64_t k = i; k < n; k++) {
+            const uint32_t x = sym[elem_off + k];
+            out[out_off + k] = (x & kSymRef) ? *(base - (x & ~kSymRef)) : (uint8_t)x;
+        }
+    }
+}
+
+static double now_ms() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+static double sync_ms(hipStream_t st) {
+    (void)hipStreamSynchronize(st);
+    return now_ms();
 }
 
 static const char *status_text(uint32_t code) {
@@ -855,6 +881,8 @@ extern "C" int exg_zstd_decode(const uint8_t *h_comp, const void *d_comp_v, uint
     *produced = 0;
     hipStream_t st = (hipStream_t)stream_v;
     const uint8_t *d_comp = (const uint8_t *)d_comp_v;
+    static const bool trace = getenv("EXG_TRACE") != nullptr;
+    const double t_begin = trace ? now_ms() : 0;
     Index idx;
     if (!build_index(h_comp, n, idx)) {
         set_error("%s", idx.error.c_str());
@@ -868,7 +896,8 @@ extern "C" int exg_zstd_decode(const uint8_t *h_comp, const void *d_comp_v, uint
         hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
     };
     const uint32_t nb = (uint32_t)idx.blocks.size(), nf = (uint32_t)idx.frames.size();
-    Dev d_blocks, d_lit, d_ll, d_ml, d_off, d_meta, d_frames, d_chunks, d_status, d_out;
+    const double t_index = trace ? now_ms() : 0;
+    Dev d_blocks, d_lit, d_ll, d_ml, d_off, d_meta, d_frames, d_chunks, d_status, d_out, d_sym;
     EXG_HIP_CHECK(d_meta.alloc(64));
     uint64_t total = 0;
     if (nb) {
@@ -893,8 +922,14 @@ extern "C" int exg_zstd_decode(const uint8_t *h_comp, const void *d_comp_v, uint
                 return EXG_E_PARSE;
             }
     }
-    // frames: where their content lies, and the size their header promised
+    // frames: where their content lies, and the size their header promised.  Chunks: a frame is cut into runs of whole
+    // blocks of about `target` bytes, one wavefront each.  The first chunk of a frame writes bytes; every later one cannot
+    // know what lies in front of it while it runs, so it writes 32-bit symbols — a byte, or "the byte d in front of this
+    // chunk" — that are resolved chunk by chunk, in order, once everything in front is final (k_zst_resolve).
+    static const uint64_t target_env = getenv("EXG_ZSTD_CHUNK_BYTES") ? strtoull(getenv("EXG_ZSTD_CHUNK_BYTES"), nullptr, 10) : 0;
+    const uint64_t target = target_env ? target_env : std::min<uint64_t>(2u << 20, std::max<uint64_t>(128u << 10, total / 4096));
     std::vector<Chunk> chunks;
+    uint64_t sym_elems = 0;
     for (uint32_t f = 0; f < nf; f++) {
         Frame &F = idx.frames[f];
         F.out_off = F.n_blocks ? idx.blocks[F.first_block].out_off : total;
@@ -906,35 +941,99 @@ extern "C" int exg_zstd_decode(const uint8_t *h_comp, const void *d_comp_v, uint
                       (unsigned long long)F.content_size);
             return EXG_E_PARSE;
         }
-        if (!F.n_blocks) continue;
-        Chunk c;
-        memset(&c, 0, sizeof c);
-        c.first_block = F.first_block;
-        c.n_blocks = F.n_blocks;
-        c.out_off = c.frame_out_off = c.elem_off = F.out_off;
-        c.symbolic = 0;
-        chunks.push_back(c);
+        for (uint32_t b = 0; b < F.n_blocks;) {
+            Chunk c;
+            memset(&c, 0, sizeof c);
+            c.first_block = F.first_block + b;
+            c.out_off = idx.blocks[c.first_block].out_off;
+            c.frame_out_off = F.out_off;
+            uint64_t got = 0;
+            while (b < F.n_blocks && (got < target || c.n_blocks == 0)) got += idx.blocks[F.first_block + b].out_size, b++, c.n_blocks++;
+            c.symbolic = c.first_block != F.first_block;
+            c.elem_off = c.symbolic ? sym_elems : c.out_off;
+            if (c.symbolic) sym_elems += got;
+            chunks.push_back(c);
+        }
     }
+    const double t_entropy = trace ? sync_ms(st) : 0;
     EXG_HIP_CHECK(d_out.alloc(total + 64));
     EXG_HIP_CHECK(hipMemsetAsync((char *)d_out.p + total, 0, 64, st));
     const uint32_t nc = (uint32_t)chunks.size();
+    double t_exec = 0, t_resolve = 0;
     if (nc) {
+        // symbol chunks are executed and resolved in rounds that fit the symbol buffer (4 bytes per output byte)
+        static const uint64_t sym_cap_env = getenv("EXG_ZSTD_SYM_BYTES") ? strtoull(getenv("EXG_ZSTD_SYM_BYTES"), nullptr, 10) : (32ull << 30);
+        const uint64_t sym_cap = std::max<uint64_t>(sym_cap_env / 4, 1);
         EXG_HIP_CHECK(d_chunks.alloc((size_t)nc * sizeof(Chunk)));
         EXG_HIP_CHECK(d_frames.alloc((size_t)nf * sizeof(Frame)));
         EXG_HIP_CHECK(d_status.alloc(((size_t)nc + nf) * 4));
         EXG_HIP_CHECK(hipMemsetAsync(d_status.p, 0, ((size_t)nc + nf) * 4, st));
+        // chunk sizes (bytes of output) and the rounds
+        std::vector<uint64_t> csize(nc);
+        for (uint32_t c = 0; c < nc; c++) {
+            uint64_t sz = 0;
+            for (uint32_t b = 0; b < chunks[c].n_blocks; b++) sz += idx.blocks[chunks[c].first_block + b].out_size;
+            csize[c] = sz;
+        }
+        struct Round {
+            uint32_t c0, c1;
+        };
+        std::vector<Round> rounds;
+        uint64_t sym_need = 0;
+        {
+            uint32_t c0 = 0;
+            uint64_t fill = 0;
+            for (uint32_t c = 0; c < nc; c++) {
+                if (chunks[c].symbolic) {
+                    if (fill && fill + csize[c] + 4 > sym_cap) {
+                        rounds.push_back(Round{c0, c});
+                        c0 = c;
+                        fill = 0;
+                    }
+                    chunks[c].elem_off = fill;
+                    fill += (csize[c] + 3) & ~3ull;
+                    sym_need = std::max(sym_need, fill);
+                }
+            }
+            rounds.push_back(Round{c0, nc});
+        }
+        if (sym_need) EXG_HIP_CHECK(d_sym.alloc(sym_need * 4 + 64));
         EXG_HIP_CHECK(hipMemcpyAsync(d_chunks.p, chunks.data(), (size_t)nc * sizeof(Chunk), hipMemcpyHostToDevice, st));
         EXG_HIP_CHECK(hipMemcpyAsync(d_frames.p, idx.frames.data(), (size_t)nf * sizeof(Frame), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_zst_exec<false>, dim3(nc < 16384 ? nc : 16384), dim3(64), 0, st, d_comp, (Block *)d_blocks.p, (const Chunk *)d_chunks.p, nc,
-                           (const uint8_t *)d_lit.p, (const uint32_t *)d_ll.p, (const uint32_t *)d_ml.p, (const uint32_t *)d_off.p,
-                           (uint8_t *)d_out.p, (uint32_t *)d_status.p);
-        static const uint64_t verify_max = getenv("EXG_ZSTD_VERIFY_MAX") ? strtoull(getenv("EXG_ZSTD_VERIFY_MAX"), nullptr, 10) : (256ull << 20);
+        for (const Round &R : rounds) {
+            const uint32_t cnt = R.c1 - R.c0, grid = cnt < 16384 ? cnt : 16384;
+            const double t0 = trace ? sync_ms(st) : 0;
+            hipLaunchKernelGGL(k_zst_exec<false>, dim3(grid), dim3(64), 0, st, d_comp, (Block *)d_blocks.p, (const Chunk *)d_chunks.p + R.c0, cnt,
+                               (const uint8_t *)d_lit.p, (const uint32_t *)d_ll.p, (const uint32_t *)d_ml.p, (const uint32_t *)d_off.p,
+                               (uint8_t *)d_out.p, (uint32_t *)d_status.p + R.c0);
+            if (sym_need)
+                hipLaunchKernelGGL(k_zst_exec<true>, dim3(grid), dim3(64), 0, st, d_comp, (Block *)d_blocks.p, (const Chunk *)d_chunks.p + R.c0, cnt,
+                                   (const uint8_t *)d_lit.p, (const uint32_t *)d_ll.p, (const uint32_t *)d_ml.p, (const uint32_t *)d_off.p,
+                                   (uint32_t *)d_sym.p, (uint32_t *)d_status.p + R.c0);
+            const double t1 = trace ? sync_ms(st) : 0;
+            for (uint32_t c = R.c0; c < R.c1; c++)
+                if (chunks[c].symbolic && csize[c])
+                    hipLaunchKernelGGL(k_zst_resolve, dim3((uint32_t)((csize[c] + 1023) / 1024)), dim3(256), 0, st, (const uint32_t *)d_sym.p,
+                                       chunks[c].elem_off, (uint8_t *)d_out.p, chunks[c].out_off, csize[c]);
+            if (trace) {
+                (void)hipStreamSynchronize(st);
+                t_exec += t1 - t0;
+                t_resolve += now_ms() - t1;
+            }
+        }
+        static const uint64_t verify_max = getenv("EXG_ZSTD_VERIFY_MAX") ? strtoull(getenv("EXG_ZSTD_VERIFY_MAX"), nullptr, 10) : (64ull << 20);  // ~0.55 GB/s per frame: 64 MiB = 0.12 s
+        const double t2 = trace ? now_ms() : 0;
         hipLaunchKernelGGL(k_zst_xxh64, dim3(nf < 16384 ? nf : 16384), dim3(64), 0, st, (const uint8_t *)d_out.p, (const Frame *)d_frames.p, nf,
                            verify_max, (uint32_t *)d_status.p + nc);
         EXG_HIP_CHECK(hipGetLastError());
         std::vector<uint32_t> status((size_t)nc + nf);
         EXG_HIP_CHECK(hipMemcpyAsync(status.data(), d_status.p, status.size() * 4, hipMemcpyDeviceToHost, st));
         EXG_HIP_CHECK(hipStreamSynchronize(st));
+        if (trace)
+            fprintf(stderr, "[exg] zstd: %u blocks, %u chunks (target %llu KiB, %zu round(s)), index %.1f ms, entropy+scan %.1f ms, exec %.1f ms, resolve %.1f ms, "
+                            "xxh64 %.1f ms, %.1f MB out\n",
+                    nb, nc, (unsigned long long)(target >> 10), rounds.size(), t_index - t_begin, t_entropy - t_index, t_exec, t_resolve, now_ms() - t2,
+                    total / 1e6);
         for (uint32_t c = 0; c < nc; c++)
             if (status[c]) {
                 set_error("%s (zstd blocks %u..%u)", status_text(status[c]), chunks[c].first_block, chunks[c].first_block + chunks[c].n_blocks - 1);

@@ -153,3 +153,77 @@ def test_corrupt_streams_fail_like_libzstd(gpu, data):
     b[5] = (18 << 3)          # window log 28
     assert not decompress_stream(bytes(b))[0]
     assert zstd_decode(gpu, bytes(b))[0] != 0
+
+
+# ---- through the reader (exg_open) and the reference's FFI (new_reader) -----------------------------------------------
+
+def test_reader_fastq_zst_equals_plain(gpu, tmp_path, monkeypatch):
+    from exon_duckdb_amd.reader import ShardReader
+    text = fastq_text(40000, 21)
+    plain = tmp_path / "r.fastq"
+    plain.write_bytes(text)
+    # one frame; many frames + a skippable one; a frame without content size and a 4 KiB window
+    variants = {
+        "one.fastq.zst": compress(text, 3, True),
+        "many.fastq.zst": b"".join(compress(text[i:i + 300001], 1 + (i // 300001) % 5, True) for i in range(0, len(text), 300001)) + skippable(b"idx"),
+        "win.fastq.zst": compress(text, 9, False, window_log=12, content_size=False),
+    }
+    monkeypatch.setenv("EXG_DEVICE_BATCH_BYTES", str(1 << 20))  # several device batches over the decoded bytes
+    want = ShardReader(str(plain), "fastq").rows()
+    assert len(want) == 40000
+    for name, comp in variants.items():
+        p = tmp_path / name
+        p.write_bytes(comp)
+        assert ShardReader(str(p), "fastq").count() == 40000, name
+        assert ShardReader(str(p), "fastq").rows() == want, name
+    # explicit compression on a name that says nothing
+    q = tmp_path / "noext"
+    q.write_bytes(variants["one.fastq.zst"])
+    assert ShardReader(str(q), "fastq", compression="zstd").count() == 40000
+    # shards of a zstd input are refused loudly
+    from exon_duckdb_amd import ExgError
+    with pytest.raises(ExgError):
+        ShardReader(str(tmp_path / "one.fastq.zst"), "fastq", shard_index=0, shard_count=2)
+
+
+def test_reader_vcf_and_fasta_zst(gpu, golden_dir, tmp_path):
+    from exon_duckdb_amd.reader import ShardReader
+    vcf = open(os.path.join(golden_dir, "vcf", "index.vcf"), "rb").read()
+    p = tmp_path / "index.vcf.zst"
+    p.write_bytes(compress(vcf, 5, True))
+    assert ShardReader(str(p), "vcf").count() == 621
+    assert ShardReader(str(p), "vcf").rows() == ShardReader(os.path.join(golden_dir, "vcf", "index.vcf"), "vcf").rows()
+    fa = b"".join(b">s%d some text\n" % i + b"ACGTTGCA" * (5 + i % 40) + b"\nGGCC\n" for i in range(5000))
+    q = tmp_path / "x.fasta.zst"
+    q.write_bytes(compress(fa, 3, True))
+    (tmp_path / "x.fasta").write_bytes(fa)
+    assert ShardReader(str(q), "fasta").rows() == ShardReader(str(tmp_path / "x.fasta"), "fasta").rows()
+
+
+def test_new_reader_zst(gpu, golden_dir, tmp_path):
+    from exon_duckdb_amd import arrow
+    t = arrow.new_reader(os.path.join(golden_dir, "test.fastq.zst"), "fastq").read_all()
+    assert t.num_rows == 2 and t.column("name").to_pylist() == ["SEQ_ID", "SEQ_ID2"]
+    t = arrow.new_reader(os.path.join(golden_dir, "test.fasta.zstd"), "fasta", compression="zstd").read_all()
+    assert t.num_rows == 2 and t.column("id").to_pylist() == ["a", "b"]
+    vcf = open(os.path.join(golden_dir, "vcf", "index.vcf"), "rb").read()
+    p = tmp_path / "index.vcf.zst"
+    p.write_bytes(compress(vcf, 3, True))
+    a = arrow.new_reader(str(p), "vcf").read_all()
+    b = arrow.new_reader(os.path.join(golden_dir, "vcf", "index.vcf"), "vcf").read_all()
+    assert a.equals(b) and a.num_rows == 621
+
+
+def test_reader_corrupt_zst_is_an_error(gpu, tmp_path):
+    from exon_duckdb_amd import ExgError
+    from exon_duckdb_amd.reader import ShardReader
+    comp = bytearray(compress(fastq_text(5000, 2), 3, True))
+    comp[len(comp) // 3] ^= 0x40
+    p = tmp_path / "bad.fastq.zst"
+    p.write_bytes(bytes(comp))
+    assert not decompress_stream(bytes(comp))[0]
+    with pytest.raises(ExgError):
+        ShardReader(str(p), "fastq").count()
+    (tmp_path / "cut.fastq.zst").write_bytes(bytes(compress(fastq_text(5000, 2), 3, True)[:-7]))
+    with pytest.raises(ExgError):
+        ShardReader(str(tmp_path / "cut.fastq.zst"), "fastq").count()
