@@ -742,6 +742,7 @@ int stream_get_schema(ArrowArrayStream *s, ArrowSchema *out) {
 int stream_get_next(ArrowArrayStream *s, ArrowArray *out) {
     StreamState *st = (StreamState *)s->private_data;
     exg_reader *r = st->r;
+    DeviceGuard guard(r->device);
     memset(out, 0, sizeof *out);
     for (;;) {
         if (st->batch && st->batch_row < st->batch->n_rows) {
@@ -798,6 +799,7 @@ const char *stream_last_error(ArrowArrayStream *s) {
 void stream_release(ArrowArrayStream *s) {
     if (!s || !s->release) return;
     StreamState *st = (StreamState *)s->private_data;
+    DeviceGuard guard(st->r->device);
     st->batch.reset();
     std::shared_ptr<void> last = std::move(st->r->arrow_state);
     last.reset();  // deletes st, and the reader with it
@@ -890,6 +892,7 @@ extern "C" ReaderResult new_reader(ArrowArrayStream *stream_ptr, const char *uri
         if (m.rfind("could not", 0) != 0) m = "could not register table: " + m;
         return result_error(m);
     }
+    DeviceGuard guard(r->device);
     auto st = std::make_shared<StreamState>();
     st->r = r;
     // The VCF schema needs the first file's header, like register_exon_table (arrow_reader.rs:118-123).  The file

@@ -127,6 +127,7 @@ int exg_reader::dev_alloc(void **slot, size_t bytes) {
     return EXG_OK;
 }
 exg_reader::~exg_reader() {
+    exg_rd::DeviceGuard guard(device);
     free_device();
     if (d_res) (void)hipFree(d_res);
     if (d_phase) (void)hipFree(d_phase);
@@ -1565,9 +1566,14 @@ extern "C" int exg_open(const exg_open_args *args, exg_reader **out) {
         exg::set_error("a zstd input is not sharded (its frames are decoded by the whole device at once)");
         return EXG_E_UNSUPPORTED;
     }
-    if (exg_device_count() < 1) return EXG_E_NO_DEVICE;
-    hipError_t he = hipSetDevice(r->device);
-    if (he == hipSuccess) he = exg_rd::stream_pool()->take(r->device, &r->stream);
+    const int n_dev = exg_device_count();
+    if (n_dev < 1) return EXG_E_NO_DEVICE;
+    if (r->device < 0 || r->device >= n_dev) {
+        exg::set_error("exg_open: device %d does not exist (%d visible)", r->device, n_dev);
+        return EXG_E_INVALID_ARG;
+    }
+    DeviceGuard guard(r->device);
+    hipError_t he = exg_rd::stream_pool()->take(r->device, &r->stream);
     if (he != hipSuccess) {
         exg::set_error("cannot initialise device %d: %s", r->device, hipGetErrorString(he));
         return EXG_E_HIP;
@@ -1627,6 +1633,7 @@ extern "C" int exg_schema_of(exg_reader *r, exg_schema *out) {
 
 extern "C" int exg_next_chunk(exg_reader *r, exg_chunk *out) {
     if (!r || !out) return EXG_E_INVALID_ARG;
+    DeviceGuard guard(r->device);
     memset(out, 0, sizeof *out);
     for (;;) {
         if (r->batch && r->batch_row < r->batch->n_rows) {
@@ -1673,6 +1680,7 @@ extern "C" void exg_release_chunk(exg_reader *, exg_chunk *chunk) {
 
 extern "C" int exg_count_only(exg_reader *r, uint64_t *n_rows) {
     if (!r || !n_rows) return EXG_E_INVALID_ARG;
+    DeviceGuard guard(r->device);
     uint64_t total = 0;
     for (;;) {
         if (r->pending_error) {

@@ -12,6 +12,23 @@
 
 namespace exg_rd {
 
+// HIP's current device is per host thread: every entry point that touches a reader runs with the reader's device
+// current (the consumer may call from any thread — DuckDB binds on one thread and scans on others — and a process may
+// hold readers on several devices), and leaves the caller's device as it found it.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched && prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 struct PinnedBlock {  // host memory: pinned (hipHostMalloc) or a read-only file mapping
     void *p = nullptr;
     size_t n = 0;
@@ -93,6 +110,7 @@ struct StreamPool {
                     return hipSuccess;
                 }
         }
+        DeviceGuard g(dev);
         return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
     }
     void give(int dev, hipStream_t s) {
@@ -132,6 +150,7 @@ struct DevPool {
                     return p;
                 }
         }
+        DeviceGuard g(dev);
         void *p = nullptr;
         if (hipMalloc(&p, sz) != hipSuccess) {
             trim(0);  // give the cached blocks back and try once more

@@ -212,3 +212,34 @@ def test_fasta_shards_are_runs_of_whole_records(gpu, oracle, golden_dir, tmp_pat
     want = whole(f"{golden_dir}/test.fasta", "fasta")
     got, _ = sharded(f"{golden_dir}/test.fasta", "fasta", n_shards)
     assert got == want and len(got) == 2
+
+
+def test_open_on_one_thread_scan_on_another(gpu, tmp_path, oracle):
+    """HIP's current device is per thread: every reader entry point switches to the reader's device itself (DuckDB binds
+    on one thread and scans on others)."""
+    import threading
+    from exon_duckdb_amd.reader import ShardReader
+    data = bytes(oracle.synth_fastq(332 * 5000))
+    p = tmp_path / "t.fastq"
+    p.write_bytes(data)
+    want = ShardReader(str(p), "fastq").rows()
+    box = {}
+
+    def opener():
+        box["r"] = ShardReader(str(p), "fastq")
+
+    def scanner():
+        box["rows"] = box["r"].rows()
+
+    def closer():
+        box["r"].close()
+
+    for fn in (opener, scanner, closer):
+        t = threading.Thread(target=fn)
+        t.start()
+        t.join()
+    assert box["rows"] == want and len(want) == 5000
+    # a device that does not exist is an argument error, not a crash
+    from exon_duckdb_amd import ExgError
+    with pytest.raises(ExgError):
+        ShardReader(str(p), "fastq", device=63)
