@@ -27,20 +27,47 @@ using idx_t = uint64_t;
 static constexpr idx_t STANDARD_VECTOR_SIZE = EXG_VECTOR_SIZE;
 static constexpr idx_t COLUMN_IDENTIFIER_ROW_ID = (idx_t)-1;
 
-enum class LogicalTypeId { VARCHAR = EXG_TYPE_VARCHAR, BIGINT = EXG_TYPE_BIGINT, FLOAT = EXG_TYPE_FLOAT };
+enum class LogicalTypeId {
+    VARCHAR = EXG_TYPE_VARCHAR,
+    BIGINT = EXG_TYPE_BIGINT,
+    FLOAT = EXG_TYPE_FLOAT,
+    INTEGER = EXG_TYPE_INTEGER,
+    BOOLEAN = EXG_TYPE_BOOLEAN,
+    LIST = EXG_TYPE_LIST,
+    STRUCT = EXG_TYPE_STRUCT
+};
 
+// duckdb::LogicalType: LIST carries its child type (ListType::GetChildType), STRUCT its named fields
+// (StructType::GetChildTypes) — here one vector of (name, type) for both
 struct LogicalType {
-    LogicalTypeId id;
-    bool operator==(const LogicalType &o) const { return id == o.id; }
+    LogicalTypeId id = LogicalTypeId::VARCHAR;
+    std::vector<std::pair<std::string, LogicalType>> children;
+    LogicalType() = default;
+    LogicalType(LogicalTypeId i) : id(i) {}
+    static LogicalType LIST(LogicalType child) {
+        LogicalType t(LogicalTypeId::LIST);
+        t.children.emplace_back("", std::move(child));
+        return t;
+    }
+    static LogicalType STRUCT(std::vector<std::pair<std::string, LogicalType>> fields) {
+        LogicalType t(LogicalTypeId::STRUCT);
+        t.children = std::move(fields);
+        return t;
+    }
+    bool operator==(const LogicalType &o) const { return id == o.id && children == o.children; }
 };
 
 using string_t = exg_string_t;
 
-// A flat vector that references memory owned by `buffer` (DuckDB: Vector + VectorBuffer).
+// A flat vector that references memory owned by `buffer` (DuckDB: Vector + VectorBuffer).  LIST: data = list_entry_t[]
+// and children[0] = the child vector (ListVector::GetEntry / SetListSize = its length); STRUCT: children = the entries
+// (StructVector::GetEntries).
 struct Vector {
     LogicalType type{LogicalTypeId::VARCHAR};
     void *data = nullptr;
     uint64_t *validity = nullptr;  // nullptr = all rows valid
+    idx_t length = 0;              // rows (top level) / list size (children)
+    std::vector<Vector> children;
     std::shared_ptr<void> buffer;  // keeps data + string payload alive
 };
 

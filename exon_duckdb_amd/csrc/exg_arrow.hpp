@@ -159,5 +159,23 @@ void cells_list_views(const CellSrc &s, uint64_t n, const uint64_t *d_goff, View
 // validity bits of a view array (bit j = views[j].valid)
 void views_validity(const View *d_views, uint64_t n, uint64_t *d_valid, hipStream_t);
 
+// ---- DuckDB vector layouts of the nested columns (the chunk boundary, exg_next_chunk) -------------------------------
+// string views -> duckdb::string_t (payload zero-copy: ptr = payload_base + (view.p - d_base)); invalid views -> 16 zero bytes
+void views_to_string_t(const View *d_views, uint64_t m, const uint8_t *d_base, uint64_t payload_base, exg_string_t *d_out,
+                       hipStream_t stream);
+// LIST parents over rows: entries[i] = {goff[i] - goff[i - i % chunk_rows], goff[i + 1] - goff[i]} — offsets are relative to
+// the first child element of the row's DataChunk, so a chunk's child vector is a slice of the batch-wide child array
+void list_entries_rows(const uint64_t *d_goff, uint64_t n, uint64_t chunk_rows, ListEntry *d_entries, hipStream_t stream);
+// LIST parents over the elements of an outer list (FORMAT lists per sample): elem_row[s] = row of element s,
+// outer_goff[row] = first element of a row; offsets relative to the first inner element of the row's DataChunk
+void list_entries_elems(const uint64_t *d_goff, uint64_t m, const uint32_t *d_elem_row, const uint64_t *d_outer_goff,
+                        uint64_t chunk_rows, ListEntry *d_entries, hipStream_t stream);
+// out[c] = goff[min(c * chunk_rows, n)], c = 0..n_chunks: where every DataChunk's children begin
+void chunk_bases_rows(const uint64_t *d_goff, uint64_t n, uint64_t chunk_rows, uint64_t n_chunks, uint64_t *d_out, hipStream_t stream);
+// out[c] = goff[idx[c]], c = 0..n_chunks (second level)
+void chunk_bases_pick(const uint64_t *d_goff, const uint64_t *d_idx, uint64_t n_chunks, uint64_t *d_out, hipStream_t stream);
+// DuckDB BOOLEAN: one byte per value out of a bitmap
+void bits_to_bytes(const uint64_t *d_bits, uint64_t m, uint8_t *d_out, hipStream_t stream);
+
 }  // namespace arrow
 }  // namespace exg

@@ -174,13 +174,17 @@ struct StreamState {
     hipStream_t copy_stream = nullptr;
     int copy_dev = 0;
     hipEvent_t copy_ev = nullptr;
+    bool owns_reader = true;  // new_reader: the stream owns its reader; chunk mode: the reader owns this state
+    // chunk mode: the columns' exg_type trees (node arrays and names live here)
+    std::vector<std::unique_ptr<exg_type[]>> type_nodes;
+    exg_type type_roots[16];
     ~StreamState() {
         if (copy_ev) (void)hipEventDestroy(copy_ev);
         if (copy_stream) stream_pool()->give(copy_dev, copy_stream);
         for (void *p : {d_consts, d_prog, d_info_names, d_format_names})
             if (p) (void)hipFree(p);
         arena.reset();
-        delete r;
+        if (owns_reader) delete r;
     }
 };
 
@@ -193,7 +197,7 @@ struct StreamState {
 struct Emit {
     exg_reader *r;
     StreamState *st;
-    ABatch *out;
+    HostArena *host;  // pinned memory of the batch being built
     hipStream_t s;
     uint64_t n;                 // output rows
     const uint32_t *d_row_map;  // NULL: identity
@@ -206,7 +210,7 @@ struct Emit {
         return p;
     }
     void *halloc(size_t bytes) {
-        void *p = out->host.alloc(bytes);
+        void *p = host->alloc(bytes);
         if (!p && !rc) rc = fail(r, EXG_E_HIP, "out of pinned host memory in the Arrow emitter");
         return p;
     }
@@ -400,6 +404,145 @@ struct Emit {
     }
 };
 
+// ---- the same columns in DuckDB's vector layouts (chunk boundary) ----------------------------------------------------
+struct DuckEmit {
+    Emit &em;
+    uint64_t B, n_chunks;       // rows per DataChunk, chunks of this batch
+    const uint8_t *d_base;      // the scanned text on the device ...
+    uint64_t payload_base;      // ... and the host address its bytes have in the chunk's payload
+
+    NVec strings_from_views(const ea::View *d_views, uint64_t m, const uint64_t *h_validity) {
+        NVec v;
+        v.type = EXG_TYPE_VARCHAR;
+        v.elem = 16;
+        v.length = m;
+        v.validity = h_validity;
+        exg_string_t *d = (exg_string_t *)em.dalloc(m * 16 + 16);
+        if (em.rc) return v;
+        ea::views_to_string_t(d_views, m, d_base, payload_base, d, em.s);
+        v.data = em.to_host(d, m * 16);
+        return v;
+    }
+    // the n_chunks + 1 places where the chunks' elements begin, on the host (valid after the final sync) and on the device
+    const uint64_t *bases_rows(const uint64_t *d_goff, uint64_t n, uint64_t **d_out) {
+        uint64_t *d = (uint64_t *)em.dalloc((n_chunks + 1) * 8);
+        if (em.rc) return nullptr;
+        ea::chunk_bases_rows(d_goff, n, B, n_chunks, d, em.s);
+        if (d_out) *d_out = d;
+        return (const uint64_t *)em.to_host(d, (n_chunks + 1) * 8);
+    }
+    // LIST(VARCHAR) out of a raw column split on `sep`
+    NVec list_of_strings(const ea::StrCol &c, uint8_t sep) {
+        NVec v;
+        v.type = EXG_TYPE_LIST;
+        v.elem = 16;
+        v.length = em.n;
+        const uint64_t n = em.n;
+        uint64_t *d_goff = (uint64_t *)em.dalloc((n + 1) * 8);
+        uint64_t *d_tmp = (uint64_t *)em.dalloc(ea::scan_tmp_entries(n) * 8);
+        if (em.rc) return v;
+        ea::list_counts(c, em.d_row_map, n, sep, d_goff, d_tmp, em.s);
+        const uint64_t total = em.fetch_u64(d_goff + n);
+        ea::View *d_views = (ea::View *)em.dalloc(total * sizeof(ea::View) + 16);
+        ea::ListEntry *d_entries = (ea::ListEntry *)em.dalloc(n * 16);
+        if (em.rc) return v;
+        ea::list_views(c, em.d_row_map, n, sep, d_goff, d_views, em.s);
+        ea::list_entries_rows(d_goff, n, B, d_entries, em.s);
+        v.data = em.to_host(d_entries, n * 16);
+        v.child_base = bases_rows(d_goff, n, nullptr);
+        v.children.push_back(strings_from_views(d_views, total, nullptr));
+        return v;
+    }
+    // the typed children of INFO (elements = output rows) or FORMAT (elements = samples: d_elem_row / d_outer_goff /
+    // d_outer_bases describe the enclosing list)
+    std::vector<NVec> cell_children(const std::vector<KeyDef> &keys, ea::CellSrc src, uint64_t m, uint32_t err_code,
+                                    const uint32_t *d_elem_row, const uint64_t *d_outer_goff, const uint64_t *d_outer_bases) {
+        std::vector<NVec> kids;
+        for (size_t k = 0; k < keys.size() && !em.rc; k++) {
+            src.key = (uint32_t)k;
+            const KeyDef &kd = keys[k];
+            NVec col;
+            col.length = m;
+            uint64_t *d_valid = (uint64_t *)em.dalloc(Emit::bitmap_bytes(m));
+            if (em.rc) break;
+            if (!kd.is_list) {
+                if (kd.type == ea::kVtInt || kd.type == ea::kVtFloat) {
+                    void *d_vals = em.dalloc(m * 4);
+                    if (em.rc) break;
+                    if (kd.type == ea::kVtInt)
+                        ea::cells_to_i32(src, m, (int32_t *)d_vals, d_valid, em.d_err, err_code, em.s);
+                    else
+                        ea::cells_to_f32(src, m, (float *)d_vals, d_valid, em.d_err, err_code, em.s);
+                    col.type = kd.type == ea::kVtInt ? EXG_TYPE_INTEGER : EXG_TYPE_FLOAT;
+                    col.elem = 4;
+                    col.data = em.to_host(d_vals, m * 4);
+                    col.validity = (const uint64_t *)em.to_host(d_valid, Emit::bitmap_bytes(m));
+                } else if (kd.type == ea::kVtFlag) {
+                    uint64_t *d_bits = (uint64_t *)em.dalloc(Emit::bitmap_bytes(m));
+                    uint8_t *d_bytes = (uint8_t *)em.dalloc(m + 16);
+                    if (em.rc) break;
+                    ea::cells_to_flag(src, m, d_bits, d_valid, em.s);
+                    ea::bits_to_bytes(d_bits, m, d_bytes, em.s);
+                    col.type = EXG_TYPE_BOOLEAN;
+                    col.elem = 1;
+                    col.data = em.to_host(d_bytes, m);
+                    col.validity = (const uint64_t *)em.to_host(d_valid, Emit::bitmap_bytes(m));
+                } else {
+                    ea::View *d_views = (ea::View *)em.dalloc(m * sizeof(ea::View) + 16);
+                    if (em.rc) break;
+                    ea::cells_to_views(src, m, d_views, d_valid, em.s);
+                    col = strings_from_views(d_views, m, (const uint64_t *)em.to_host(d_valid, Emit::bitmap_bytes(m)));
+                }
+            } else {
+                uint64_t *d_goff = (uint64_t *)em.dalloc((m + 1) * 8);
+                uint64_t *d_tmp = (uint64_t *)em.dalloc(ea::scan_tmp_entries(m) * 8);
+                if (em.rc) break;
+                ea::cells_list_counts(src, m, d_goff, d_tmp, d_valid, em.s);
+                const uint64_t total = em.fetch_u64(d_goff + m);
+                col.type = EXG_TYPE_LIST;
+                col.elem = 16;
+                ea::ListEntry *d_entries = (ea::ListEntry *)em.dalloc(m * 16 + 16);
+                uint32_t *d_cv = (uint32_t *)em.dalloc(Emit::bitmap_bytes(total));
+                uint64_t *d_cb = (uint64_t *)em.dalloc((n_chunks + 1) * 8);
+                if (em.rc) break;
+                if (d_elem_row) {
+                    ea::list_entries_elems(d_goff, m, d_elem_row, d_outer_goff, B, d_entries, em.s);
+                    ea::chunk_bases_pick(d_goff, d_outer_bases, n_chunks, d_cb, em.s);
+                } else {
+                    ea::list_entries_rows(d_goff, m, B, d_entries, em.s);
+                    ea::chunk_bases_rows(d_goff, m, B, n_chunks, d_cb, em.s);
+                }
+                (void)hipMemsetAsync(d_cv, 0, Emit::bitmap_bytes(total), em.s);
+                col.data = em.to_host(d_entries, m * 16);
+                col.validity = (const uint64_t *)em.to_host(d_valid, Emit::bitmap_bytes(m));
+                col.child_base = (const uint64_t *)em.to_host(d_cb, (n_chunks + 1) * 8);
+                NVec child;
+                child.length = total;
+                if (kd.type == ea::kVtInt || kd.type == ea::kVtFloat) {
+                    void *d_vals = em.dalloc(total * 4);
+                    if (em.rc) break;
+                    if (kd.type == ea::kVtInt)
+                        ea::cells_list_i32(src, m, d_goff, (int32_t *)d_vals, d_cv, em.d_err, err_code, em.s);
+                    else
+                        ea::cells_list_f32(src, m, d_goff, (float *)d_vals, d_cv, em.d_err, err_code, em.s);
+                    child.type = kd.type == ea::kVtInt ? EXG_TYPE_INTEGER : EXG_TYPE_FLOAT;
+                    child.elem = 4;
+                    child.data = em.to_host(d_vals, total * 4);
+                    child.validity = (const uint64_t *)em.to_host(d_cv, Emit::bitmap_bytes(total));
+                } else {
+                    ea::View *d_views = (ea::View *)em.dalloc(total * sizeof(ea::View) + 16);
+                    if (em.rc) break;
+                    ea::cells_list_views(src, m, d_goff, d_views, d_cv, em.s);
+                    child = strings_from_views(d_views, total, (const uint64_t *)em.to_host(d_cv, Emit::bitmap_bytes(total)));
+                }
+                col.children.push_back(std::move(child));
+            }
+            kids.push_back(std::move(col));
+        }
+        return kids;
+    }
+};
+
 int upload_keys(exg_reader *r, const std::vector<KeyDef> &keys, ea::VtKeys *vt, void **d_names) {
     if (keys.size() > (size_t)ea::kMaxVtKeys)
         return fail(r, EXG_E_UNSUPPORTED, "VCF header declares more than " + std::to_string(ea::kMaxVtKeys) + " INFO or FORMAT keys");
@@ -460,7 +603,7 @@ int arrow_emit(exg_reader *r, const ScanCtx &ctx) {
     Emit em;
     em.r = r;
     em.st = st;
-    em.out = batch.get();
+    em.host = &batch->host;
     em.s = r->stream;
     em.n = ctx.n_records;
     em.d_row_map = nullptr;
@@ -813,6 +956,185 @@ ReaderResult result_error(const std::string &msg) {
 }
 
 }  // namespace
+
+// ---- the nested VCF columns at the chunk boundary (exg_next_chunk): DuckDB vector layouts built on the device -------
+namespace exg_rd {
+
+static exg_type *alloc_types(StreamState *st, size_t n) {
+    st->type_nodes.emplace_back(new exg_type[n ? n : 1]());
+    return st->type_nodes.back().get();
+}
+static exg_type leaf(int type, const char *name, int nullable) {
+    exg_type t;
+    memset(&t, 0, sizeof t);
+    t.type = type, t.name = name, t.nullable = nullable;
+    return t;
+}
+static exg_type list_of(StreamState *st, const char *name, const exg_type &item, int nullable) {
+    exg_type t = leaf(EXG_TYPE_LIST, name, nullable);
+    exg_type *c = alloc_types(st, 1);
+    c[0] = item;
+    t.n_children = 1;
+    t.children = c;
+    return t;
+}
+static exg_type key_type(StreamState *st, const KeyDef &k) {
+    const int base = k.type == ea::kVtInt ? EXG_TYPE_INTEGER : k.type == ea::kVtFloat ? EXG_TYPE_FLOAT : k.type == ea::kVtFlag ? EXG_TYPE_BOOLEAN : EXG_TYPE_VARCHAR;
+    if (!k.is_list) return leaf(base, k.id.c_str(), 1);
+    return list_of(st, k.id.c_str(), leaf(base, "item", 1), 1);
+}
+static exg_type struct_of(StreamState *st, const char *name, const std::vector<KeyDef> &keys, int nullable) {
+    exg_type t = leaf(EXG_TYPE_STRUCT, name, nullable);
+    exg_type *c = alloc_types(st, keys.size());
+    for (size_t k = 0; k < keys.size(); k++) c[k] = key_type(st, keys[k]);
+    t.n_children = (int)keys.size();
+    t.children = c;
+    return t;
+}
+
+int nested_prepare(exg_reader *r) {
+    if (r->nested_state || r->format != EXG_FMT_VCF) return EXG_OK;
+    if (!r->file) {  // the schema is the first file's header (like register_exon_table, arrow_reader.rs:118-123)
+        if (r->file_idx >= r->files.size()) return fail(r, EXG_E_IO, "no input file");
+        int rc = open_next_file(r);
+        if (rc) return rc;
+    }
+    auto st = std::make_shared<StreamState>();
+    st->r = r;
+    st->owns_reader = false;
+    parse_vcf_header((const char *)r->file->p, (size_t)r->vcf_header_bytes, &st->info_keys, &st->format_keys);
+    int rc;
+    if ((rc = upload_keys(r, st->info_keys, &st->info_vt, &st->d_info_names)) ||
+        (rc = upload_keys(r, st->format_keys, &st->format_vt, &st->d_format_names)))
+        return rc;
+    exg_type *t = st->type_roots;
+    t[0] = leaf(EXG_TYPE_VARCHAR, "chrom", 0);
+    t[1] = leaf(EXG_TYPE_BIGINT, "pos", 0);
+    t[2] = list_of(st.get(), "id", leaf(EXG_TYPE_VARCHAR, "item", 1), 1);
+    t[3] = leaf(EXG_TYPE_VARCHAR, "ref", 0);
+    t[4] = list_of(st.get(), "alt", leaf(EXG_TYPE_VARCHAR, "item", 1), 1);
+    t[5] = leaf(EXG_TYPE_FLOAT, "qual", 1);
+    t[6] = list_of(st.get(), "filter", leaf(EXG_TYPE_VARCHAR, "item", 1), 1);
+    t[7] = struct_of(st.get(), "info", st->info_keys, 1);
+    t[8] = list_of(st.get(), "formats", struct_of(st.get(), "item", st->format_keys, 1), 1);
+    r->nested_state = st;
+    return EXG_OK;
+}
+
+void nested_schema(exg_reader *r, exg_schema *out) {
+    StreamState *st = (StreamState *)r->nested_state.get();
+    if (!st) return;
+    for (int c = 0; c < 9; c++) {
+        out->tree[c] = &st->type_roots[c];
+        out->types[c] = st->type_roots[c].type;
+        out->nullable[c] = st->type_roots[c].nullable;
+    }
+}
+
+// Columns id, alt, filter, info, formats of one scanned batch -> b->nested (the flat columns are copied by next_batch).
+// *n_rows: in = rows of the batch, out = rows to hand out (a typed value that does not parse ends the stream there).
+int nested_emit(exg_reader *r, const ScanCtx &ctx, Batch *b, const uint32_t *d_row_map, uint64_t *n_rows) {
+    StreamState *st = (StreamState *)r->nested_state.get();
+    if (!st) return fail(r, EXG_E_INVALID_ARG, "nested_emit without nested_prepare");
+    st->arena.reset();
+    if (!st->arena.base) {
+        size_t cap = (size_t)std::min<uint64_t>(r->d_in_cap * 3 + (64u << 20), 6ull << 30);
+        cap = (cap + 4095) & ~(size_t)4095;
+        st->arena.dev = r->device;
+        if ((st->arena.base = (char *)dev_pool()->take(r->device, cap))) st->arena.cap = cap;
+    }
+    if (!st->copy_stream) {
+        EM_HIP(stream_pool()->take(r->device, &st->copy_stream));
+        st->copy_dev = r->device;
+        EM_HIP(hipEventCreateWithFlags(&st->copy_ev, hipEventDisableTiming));
+    }
+    struct CopyDrain {
+        hipStream_t cs;
+        ~CopyDrain() { (void)hipStreamSynchronize(cs); }
+    } drain{st->copy_stream};
+    const uint64_t n = *n_rows, B = r->batch_rows;
+    Emit em;
+    em.r = r;
+    em.st = st;
+    em.host = &b->host;
+    em.s = r->stream;
+    em.n = n;
+    em.d_row_map = d_row_map;
+    em.d_err = (unsigned long long *)em.dalloc(8);
+    if (em.rc) return em.rc;
+    EM_HIP(hipMemsetAsync(em.d_err, 0xFF, 8, r->stream));
+    const uint8_t *d_base = (const uint8_t *)ctx.d_input;
+    const uint64_t pb = (uint64_t)(uintptr_t)ctx.h;
+    auto str_col = [&](int c) { return ea::StrCol{(const exg_string_t *)r->d_cols[c], d_base, pb}; };
+    DuckEmit de{em, B, (n + B - 1) / B, d_base, pb};
+    b->nested.assign(9, NVec());
+    b->nested[2] = de.list_of_strings(str_col(2), ';');
+    b->nested[4] = de.list_of_strings(str_col(4), ',');
+    b->nested[6] = de.list_of_strings(str_col(6), ';');
+    if (em.rc) return em.rc;
+    {  // info
+        NVec info;
+        info.type = EXG_TYPE_STRUCT;
+        info.length = n;
+        const uint32_t K = st->info_vt.n;
+        if (K) {
+            ea::VtCell *d_cells = (ea::VtCell *)em.dalloc((size_t)n * K * sizeof(ea::VtCell));
+            if (em.rc) return em.rc;
+            ea::info_cells(str_col(7), d_row_map, n, st->info_vt, d_cells, r->stream);
+            ea::CellSrc src{d_cells, K, 0, str_col(7), d_row_map, nullptr, nullptr};
+            info.children = de.cell_children(st->info_keys, src, n, EXG_PE_VCF_INFO, nullptr, nullptr, nullptr);
+        }
+        b->nested[7] = std::move(info);
+    }
+    if (em.rc) return em.rc;
+    {  // formats
+        NVec fl;
+        fl.type = EXG_TYPE_LIST;
+        fl.elem = 16;
+        fl.length = n;
+        uint64_t *d_goff = (uint64_t *)em.dalloc((n + 1) * 8);
+        uint64_t *d_tmp = (uint64_t *)em.dalloc(ea::scan_tmp_entries(n) * 8);
+        ea::ListEntry *d_entries = (ea::ListEntry *)em.dalloc(n * 16 + 16);
+        if (em.rc) return em.rc;
+        ea::sample_counts(str_col(8), (const uint64_t *)r->d_valid[1], d_row_map, n, d_goff, d_tmp, r->stream);
+        const uint64_t S = em.fetch_u64(d_goff + n);
+        ea::list_entries_rows(d_goff, n, B, d_entries, r->stream);
+        fl.data = em.to_host(d_entries, n * 16);
+        uint64_t *d_sb = nullptr;
+        fl.child_base = de.bases_rows(d_goff, n, &d_sb);
+        NVec item;
+        item.type = EXG_TYPE_STRUCT;
+        item.length = S;
+        const uint32_t K = st->format_vt.n;
+        if (K && !em.rc) {
+            ea::VtCell *d_cells = (ea::VtCell *)em.dalloc((size_t)S * K * sizeof(ea::VtCell) + 16);
+            ea::View *d_fields = (ea::View *)em.dalloc((size_t)S * sizeof(ea::View) + 16);
+            uint32_t *d_srow = (uint32_t *)em.dalloc((size_t)S * 4 + 16);
+            if (em.rc) return em.rc;
+            ea::sample_cells(str_col(8), d_row_map, n, d_goff, st->format_vt, d_cells, d_fields, d_srow, r->stream);
+            ea::CellSrc src{d_cells, K, 0, ea::StrCol{nullptr, nullptr, 0}, nullptr, d_fields, d_srow};
+            item.children = de.cell_children(st->format_keys, src, S, EXG_PE_VCF_FORMAT, d_srow, d_goff, d_sb);
+        }
+        fl.children.push_back(std::move(item));
+        b->nested[8] = std::move(fl);
+    }
+    if (em.rc) return em.rc;
+    const uint64_t err = em.fetch_u64((const uint64_t *)em.d_err);
+    if (em.rc) return em.rc;
+    EM_HIP(hipStreamSynchronize(r->stream));
+    EM_HIP(hipStreamSynchronize(st->copy_stream));
+    if (err != ~0ull) {
+        // a typed value did not parse: the rows in front of it are handed out, then the error (like the scan's own errors)
+        *n_rows = err >> 8;
+        if (!r->pending_error) {
+            r->pending_error = (uint32_t)(err & 0xFF);
+            r->pending_error_offset = 0;
+        }
+    }
+    return EXG_OK;
+}
+
+}  // namespace exg_rd
 
 // ---- host-only introspection (no device is touched): what the CPU tests check ---------------------------------------
 // The postfix program a `filters` text compiles to, e.g.  "name = 'a' | pos >= 5 | AND".  Columns are those of the

@@ -1448,7 +1448,12 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             // schema order (exg_schema_of): VCF exposes parsed POS / QUAL in place of their raw text
             b->n_cols = ns;
             const size_t vw = (size_t)((k + 63) / 64) * 8;
+            const bool nested_vcf = r->format == EXG_FMT_VCF;  // id, alt, filter, info, formats: built by nested_emit below
             for (int c = 0; c < ns; c++) {
+                if (nested_vcf && (c == 2 || c == 4 || c >= 6)) {
+                    b->elem[c] = 0;
+                    continue;
+                }
                 const void *src = r->d_cols[c];
                 uint32_t es = 16;
                 if (r->format == EXG_FMT_VCF && c == 1) src = r->d_pos, es = 8;
@@ -1476,7 +1481,17 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
                 return EXG_OK;
             };
             if (r->format == EXG_FMT_VCF) {
-                if ((rc = copy_validity(5, r->d_valid[0])) || (rc = copy_validity(8, r->d_valid[1]))) return rc;
+                if ((rc = copy_validity(5, r->d_valid[0]))) return rc;
+                if (!r->nested_state && (rc = nested_prepare(r))) return rc;
+                ScanCtx ctx;
+                ctx.d_input = d_input;
+                ctx.h = h;
+                ctx.n_records = k;
+                ctx.res = res;
+                ctx.h_seq_payload = nullptr;
+                uint64_t deliver = k;
+                if ((rc = nested_emit(r, ctx, b.get(), row_map, &deliver))) return rc;
+                b->n_rows = deliver;
             } else {
                 if ((rc = copy_validity(1, r->d_valid[0]))) return rc;
             }
@@ -1507,6 +1522,8 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
 }  // namespace exg_rd
 
 using namespace exg_rd;
+
+static void flat_schema(const exg_reader *r, exg_schema *out);
 
 extern "C" int exg_open(const exg_open_args *args, exg_reader **out) {
     if (!args || !out || !args->path || !args->file_format) {
@@ -1581,10 +1598,10 @@ extern "C" int exg_open(const exg_open_args *args, exg_reader **out) {
     if (args->filters && *args->filters) {
         // `SELECT * FROM exon_table WHERE <filters>` (arrow_reader.rs:125-141), evaluated on the device
         exg_schema sch;
-        exg_schema_of(r.get(), &sch);
-        std::vector<FilterColumn> fcols;
+        flat_schema(r.get(), &sch);
+        std::vector<FilterColumn> fcols;  // nested columns ('x') are refused by the parser, like in new_reader
         for (int c = 0; c < sch.n_columns; c++)
-            fcols.push_back({sch.names[c], sch.types[c] == EXG_TYPE_BIGINT ? 'l' : sch.types[c] == EXG_TYPE_FLOAT ? 'f' : 'u'});
+            fcols.push_back({sch.names[c], sch.types[c] == EXG_TYPE_BIGINT ? 'l' : sch.types[c] == EXG_TYPE_FLOAT ? 'f' : sch.types[c] == EXG_TYPE_VARCHAR ? 'u' : 'x'});
         const std::string text = args->filters;
         FilterParser fp(text, fcols);
         if (!fp.parse()) {
@@ -1605,30 +1622,76 @@ extern "C" int exg_open(const exg_open_args *args, exg_reader **out) {
     return EXG_OK;
 }
 
-extern "C" int exg_schema_of(exg_reader *r, exg_schema *out) {
-    if (!r || !out) return EXG_E_INVALID_ARG;
+// names / types of the columns; no file is touched (the VCF trees come from nested_schema)
+static void flat_schema(const exg_reader *r, exg_schema *out) {
+    static const exg_type fastq_t[4] = {{EXG_TYPE_VARCHAR, 0, "name", 0, nullptr}, {EXG_TYPE_VARCHAR, 1, "description", 0, nullptr},
+                                        {EXG_TYPE_VARCHAR, 0, "sequence", 0, nullptr}, {EXG_TYPE_VARCHAR, 0, "quality_scores", 0, nullptr}};
+    static const exg_type fasta_t[3] = {{EXG_TYPE_VARCHAR, 0, "id", 0, nullptr}, {EXG_TYPE_VARCHAR, 1, "description", 0, nullptr},
+                                        {EXG_TYPE_VARCHAR, 0, "sequence", 0, nullptr}};
     memset(out, 0, sizeof *out);
     if (r->format == EXG_FMT_FASTQ) {
         // order pinned by test_fastq_scan.test:35-41; names as exon 0.2.6 registers them
-        static const char *n[] = {"name", "description", "sequence", "quality_scores"};
         out->n_columns = 4;
-        for (int i = 0; i < 4; i++) out->names[i] = n[i], out->types[i] = EXG_TYPE_VARCHAR;
-        out->nullable[1] = 1;
+        for (int i = 0; i < 4; i++) out->names[i] = fastq_t[i].name, out->types[i] = EXG_TYPE_VARCHAR, out->nullable[i] = fastq_t[i].nullable, out->tree[i] = &fastq_t[i];
     } else if (r->format == EXG_FMT_FASTA) {
         // `id` pinned by test_fasta_scan.test:34-37, order + NULL description by test_fasta_copy.test:75-80
-        static const char *n[] = {"id", "description", "sequence"};
         out->n_columns = 3;
-        for (int i = 0; i < 3; i++) out->names[i] = n[i], out->types[i] = EXG_TYPE_VARCHAR;
-        out->nullable[1] = 1;
+        for (int i = 0; i < 3; i++) out->names[i] = fasta_t[i].name, out->types[i] = EXG_TYPE_VARCHAR, out->nullable[i] = fasta_t[i].nullable, out->tree[i] = &fasta_t[i];
     } else {
+        // test_vcf_record_scan.test:10-19: alt is a LIST, info a STRUCT (module.cpp:126-147 maps exon's Arrow schema)
         static const char *n[] = {"chrom", "pos", "id", "ref", "alt", "qual", "filter", "info", "formats"};
+        static const int t[] = {EXG_TYPE_VARCHAR, EXG_TYPE_BIGINT, EXG_TYPE_LIST, EXG_TYPE_VARCHAR, EXG_TYPE_LIST, EXG_TYPE_FLOAT, EXG_TYPE_LIST, EXG_TYPE_STRUCT, EXG_TYPE_LIST};
         out->n_columns = 9;
-        for (int i = 0; i < 9; i++) out->names[i] = n[i], out->types[i] = EXG_TYPE_VARCHAR;
-        out->types[1] = EXG_TYPE_BIGINT;
-        out->types[5] = EXG_TYPE_FLOAT;
-        out->nullable[5] = out->nullable[8] = 1;
+        for (int i = 0; i < 9; i++) out->names[i] = n[i], out->types[i] = t[i], out->nullable[i] = !(i == 0 || i == 1 || i == 3);
+    }
+}
+
+extern "C" int exg_schema_of(exg_reader *r, exg_schema *out) {
+    if (!r || !out) return EXG_E_INVALID_ARG;
+    flat_schema(r, out);
+    if (r->format == EXG_FMT_VCF) {
+        DeviceGuard guard(r->device);
+        int rc = nested_prepare(r);  // the INFO / FORMAT keys of the first file's header are part of the schema
+        if (rc) return rc;
+        nested_schema(r, out);
     }
     return EXG_OK;
+}
+
+// elements [e0, e1) of a nested node as the vector of DataChunk `chunk`: data is a slice of the batch-wide array; validity
+// too when the slice begins on a word boundary, else its bits are shifted into words of their own; the children of a LIST
+// are the elements between the chunk's bases, those of a STRUCT share the parent's range
+static void slice_vector(const NVec &v, uint64_t e0, uint64_t e1, uint64_t chunk, ChunkKeep *keep, exg_vector *out) {
+    memset(out, 0, sizeof *out);
+    out->length = e1 - e0;
+    out->data = v.data ? (void *)((const char *)v.data + e0 * v.elem) : nullptr;
+    if (v.validity) {
+        if ((e0 & 63) == 0) {
+            out->validity = (uint64_t *)v.validity + e0 / 64;
+        } else {
+            const uint64_t n = e1 - e0, words = (n + 63) / 64, sh = e0 & 63;
+            keep->words.emplace_back(new uint64_t[words ? words : 1]);
+            uint64_t *w = keep->words.back().get();
+            const uint64_t last_word = (e1 + 63) / 64;  // words of the source that exist
+            for (uint64_t i = 0; i < words; i++) {
+                const uint64_t lo = v.validity[e0 / 64 + i] >> sh;
+                const uint64_t hi = e0 / 64 + i + 1 < last_word ? v.validity[e0 / 64 + i + 1] << (64 - sh) : 0;
+                w[i] = lo | hi;
+            }
+            out->validity = w;
+        }
+    }
+    if (v.children.empty()) return;
+    keep->nodes.emplace_back(new exg_vector[v.children.size()]);
+    exg_vector *kids = keep->nodes.back().get();
+    for (size_t i = 0; i < v.children.size(); i++) {
+        if (v.type == EXG_TYPE_LIST)
+            slice_vector(v.children[i], v.child_base[chunk], v.child_base[chunk + 1], chunk, keep, &kids[i]);
+        else
+            slice_vector(v.children[i], e0, e1, chunk, keep, &kids[i]);
+    }
+    out->n_children = (int)v.children.size();
+    out->children = kids;
 }
 
 extern "C" int exg_next_chunk(exg_reader *r, exg_chunk *out) {
@@ -1641,11 +1704,24 @@ extern "C" int exg_next_chunk(exg_reader *r, exg_chunk *out) {
             uint64_t n = std::min<uint64_t>(r->batch_rows, r->batch->n_rows - row0);
             out->n_rows = n;
             out->n_columns = r->batch->n_cols;
+            ChunkKeep *keep = new ChunkKeep();
+            keep->batch = r->batch;
+            const uint64_t chunk = row0 / r->batch_rows;
             for (int c = 0; c < r->batch->n_cols; c++) {
-                out->data[c] = (char *)r->batch->cols[c] + row0 * r->batch->elem[c];
-                out->validity[c] = r->batch->validity[c] ? (uint64_t *)r->batch->validity[c] + row0 / 64 : nullptr;
+                exg_vector &v = keep->top[c];
+                if ((size_t)c < r->batch->nested.size() && r->batch->nested[c].type) {
+                    slice_vector(r->batch->nested[c], row0, row0 + n, chunk, keep, &v);
+                } else {
+                    memset(&v, 0, sizeof v);
+                    v.data = (char *)r->batch->cols[c] + row0 * r->batch->elem[c];
+                    v.validity = r->batch->validity[c] ? (uint64_t *)r->batch->validity[c] + row0 / 64 : nullptr;
+                    v.length = n;
+                }
+                out->data[c] = v.data;
+                out->validity[c] = v.validity;
+                out->vectors[c] = &v;
             }
-            out->keepalive = new ChunkKeep{r->batch};
+            out->keepalive = keep;
             r->batch_row += n;
             return EXG_OK;
         }

@@ -21,6 +21,7 @@ struct DeviceGuard {
     explicit DeviceGuard(int dev) {
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
         if (prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+        if (prev != dev && !switched) (void)hipGetLastError();  // (a sticky error would surface at the next launch check)
     }
     ~DeviceGuard() {
         if (switched && prev >= 0) (void)hipSetDevice(prev);
@@ -215,6 +216,20 @@ struct HostArena {  // pinned blocks that live as long as the batch they back
     }
 };
 
+// One node of a nested column (LIST / STRUCT and what is inside) of a device batch, on the host.  A node has an index
+// space — rows for a top-level column, the elements of the enclosing list otherwise — and a DataChunk is a slice of it:
+// rows [cB, cB + B) for row space, [base[c], base[c + 1]) for the children of a LIST, where base = the list node's
+// child_base (n_chunks + 1 entries, made on the device together with the chunk-relative list entries).
+struct NVec {
+    int type = 0;                        // EXG_TYPE_*; 0: not a nested column
+    const void *data = nullptr;          // batch-wide array in the batch's pinned arena
+    const uint64_t *validity = nullptr;  // bit per element, or NULL
+    uint32_t elem = 0;                   // bytes per element
+    uint64_t length = 0;
+    const uint64_t *child_base = nullptr;  // LIST: where every chunk's elements begin in children[0]
+    std::vector<NVec> children;
+};
+
 struct Batch {  // host vectors of one device batch, shared by its chunks
     std::shared_ptr<PinnedBlock> file;
     HostArena host;
@@ -224,10 +239,15 @@ struct Batch {  // host vectors of one device batch, shared by its chunks
     void *validity[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // NULL => all valid
     void *payload = nullptr;  // FASTA: compacted sequences
     uint64_t n_rows = 0;
+    std::vector<NVec> nested;  // per column; type == 0 for the flat ones
 };
 
 struct ChunkKeep {
     std::shared_ptr<Batch> batch;
+    // the chunk's exg_vector trees and the validity words of slices that do not begin on a word boundary
+    std::vector<std::unique_ptr<exg_vector[]>> nodes;
+    std::vector<std::unique_ptr<uint64_t[]>> words;
+    exg_vector top[16];
 };
 
 enum Compression { kNone, kGzip, kZstd, kBzip2, kXz };
@@ -316,6 +336,8 @@ struct exg_reader {
     // Arrow mode (new_reader): the columns stay on the device and `arrow_emit` turns them into Arrow buffers
     int (*arrow_emit)(exg_reader *, const exg_rd::ScanCtx &) = nullptr;
     std::shared_ptr<void> arrow_state;
+    // chunk mode, VCF: the INFO / FORMAT keys of the header, the schema trees, the emitter's device arena
+    std::shared_ptr<void> nested_state;
 
     void free_device();
     ~exg_reader();
@@ -326,4 +348,9 @@ int fail(exg_reader *r, int code, const std::string &msg);
 int open_next_file(exg_reader *r);
 // Scan the next device batch of the current file (see exg_reader.cpp)
 int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out);
+// exg_arrow_stream.cpp — the nested VCF columns at the chunk boundary (DuckDB vector layouts built on the device):
+// header keys + schema trees (needs the first file open), and the columns of one scanned batch
+int nested_prepare(exg_reader *r);
+void nested_schema(exg_reader *r, exg_schema *out);
+int nested_emit(exg_reader *r, const ScanCtx &ctx, Batch *b, const uint32_t *d_row_map, uint64_t *n_rows);
 }  // namespace exg_rd

@@ -55,6 +55,30 @@ struct ChunkBuffer {  // VectorBuffer: releases the engine chunk when the last V
     ~ChunkBuffer() { exg_release_chunk(reader, &chunk); }
 };
 
+// the DuckDB type of a column (module.cpp:126-147 does this from the Arrow schema: GetArrowLogicalType)
+static LogicalType ToLogical(const exg_type &t) {
+    switch (t.type) {
+        case EXG_TYPE_LIST: return LogicalType::LIST(ToLogical(t.children[0]));
+        case EXG_TYPE_STRUCT: {
+            std::vector<std::pair<std::string, LogicalType>> fields;
+            for (int i = 0; i < t.n_children; i++) fields.emplace_back(t.children[i].name, ToLogical(t.children[i]));
+            return LogicalType::STRUCT(std::move(fields));
+        }
+        default: return LogicalType((LogicalTypeId)t.type);
+    }
+}
+
+// an engine vector as a DuckDB Vector referencing the engine's host buffers (kept alive by `keep`)
+static void WrapVector(const exg_vector &src, const LogicalType &type, const std::shared_ptr<void> &keep, Vector &dst) {
+    dst.type = type;
+    dst.data = src.data;
+    dst.validity = src.validity;
+    dst.length = src.length;
+    dst.buffer = keep;
+    dst.children.resize((size_t)src.n_children);
+    for (int i = 0; i < src.n_children; i++) WrapVector(src.children[i], type.children.at((size_t)i).second, keep, dst.children[(size_t)i]);
+}
+
 static exg_reader *open_reader(const ExonScanFunctionData &d, const std::string &filter_clause = "") {
     exg_open_args a;
     memset(&a, 0, sizeof a);
@@ -129,12 +153,14 @@ struct WTArrowTableFunction {
         exg_reader *r = open_reader(*result);
         exg_schema sch;
         int rc = exg_schema_of(r, &sch);
+        if (rc == EXG_OK)
+            for (int i = 0; i < sch.n_columns; i++) {
+                return_types.push_back(ToLogical(*sch.tree[i]));  // (the trees are the reader's: convert before it closes)
+                names.emplace_back(sch.names[i]);
+            }
+        const std::string why = rc == EXG_OK ? "" : exg_reader_error(r);
         exg_close(r);
-        if (rc != EXG_OK) throw std::runtime_error("Failed to get schema");  // module.cpp:112-119
-        for (int i = 0; i < sch.n_columns; i++) {
-            return_types.push_back(LogicalType{(LogicalTypeId)sch.types[i]});
-            names.emplace_back(sch.names[i]);
-        }
+        if (rc != EXG_OK) throw std::runtime_error("Failed to get schema: " + why);  // module.cpp:112-119
         result->all_names = names;
         result->all_types = return_types;
         return result;
@@ -182,12 +208,7 @@ struct WTArrowTableFunction {
         output.SetCardinality(buf->chunk.n_rows);
         for (idx_t col : gs.column_ids) {
             Vector v;
-            if (col != COLUMN_IDENTIFIER_ROW_ID) {
-                v.type = data.all_types.at(col);
-                v.data = buf->chunk.data[col];
-                v.validity = buf->chunk.validity[col];
-                v.buffer = buf;
-            }
+            if (col != COLUMN_IDENTIFIER_ROW_ID) WrapVector(*buf->chunk.vectors[col], data.all_types.at(col), buf, v);
             output.data.push_back(std::move(v));
         }
     }
@@ -196,13 +217,13 @@ struct WTArrowTableFunction {
     static void Register(const std::string &name, const std::string &file_type, Catalog &catalog) {
         TableFunction scan;
         scan.name = name;
-        scan.arguments = {LogicalType{LogicalTypeId::VARCHAR}};
+        scan.arguments = {LogicalType(LogicalTypeId::VARCHAR)};
         scan.function = Scan;
         scan.bind = FileTypeBind;
         scan.init_global = InitGlobal;
         scan.init_local = InitLocal;
         scan.function_info = std::make_shared<WTArrowTableScanInfo>(file_type);
-        scan.named_parameters["compression"] = LogicalType{LogicalTypeId::VARCHAR};
+        scan.named_parameters["compression"] = LogicalType(LogicalTypeId::VARCHAR);
         scan.projection_pushdown = true;
         scan.filter_pushdown = true;
         catalog.CreateTableFunction(scan);
@@ -254,7 +275,38 @@ struct exon_tf_handle {
     std::vector<LogicalType> types;
     std::vector<std::string> names;
     DataChunk chunk;
+    // exg_type / exg_vector trees handed to the Python side (rebuilt per call)
+    std::vector<std::unique_ptr<exg_type[]>> type_nodes;
+    std::vector<std::unique_ptr<exg_vector[]>> vec_nodes;
+    exg_type type_roots[16];
+    exg_vector vec_roots[16];
 };
+
+static void export_type(exon_tf_handle *h, const LogicalType &t, const char *name, exg_type *out) {
+    memset(out, 0, sizeof *out);
+    out->type = (int)t.id;
+    out->name = name;
+    out->nullable = 1;
+    if (t.children.empty()) return;
+    h->type_nodes.emplace_back(new exg_type[t.children.size()]);
+    exg_type *kids = h->type_nodes.back().get();
+    for (size_t i = 0; i < t.children.size(); i++)
+        export_type(h, t.children[i].second, t.id == LogicalTypeId::LIST ? "item" : t.children[i].first.c_str(), &kids[i]);
+    out->n_children = (int)t.children.size();
+    out->children = kids;
+}
+static void export_vector(exon_tf_handle *h, const Vector &v, exg_vector *out) {
+    memset(out, 0, sizeof *out);
+    out->data = v.data;
+    out->validity = v.validity;
+    out->length = v.length;
+    if (v.children.empty()) return;
+    h->vec_nodes.emplace_back(new exg_vector[v.children.size()]);
+    exg_vector *kids = h->vec_nodes.back().get();
+    for (size_t i = 0; i < v.children.size(); i++) export_vector(h, v.children[i], &kids[i]);
+    out->n_children = (int)v.children.size();
+    out->children = kids;
+}
 
 namespace exg {
 void set_error(const char *fmt, ...);
@@ -297,9 +349,12 @@ extern "C" int exon_tf_bind(const char *fn_name, const char *path, const char *c
 extern "C" int exon_tf_schema(exon_tf_handle *h, exg_schema *out) {
     memset(out, 0, sizeof *out);
     out->n_columns = (int)h->names.size();
+    h->type_nodes.clear();
     for (int i = 0; i < out->n_columns; i++) {
         out->names[i] = h->names[i].c_str();
         out->types[i] = (int)h->types[i].id;
+        export_type(h, h->types[i], out->names[i], &h->type_roots[i]);
+        out->tree[i] = &h->type_roots[i];
     }
     return EXG_OK;
 }
@@ -385,9 +440,12 @@ extern "C" int exon_tf_scan(exon_tf_handle *h, exg_chunk *out) {
     }
     out->n_rows = h->chunk.size();
     out->n_columns = (int)h->chunk.data.size();
+    h->vec_nodes.clear();
     for (int i = 0; i < out->n_columns && i < 16; i++) {
         out->data[i] = h->chunk.data[i].data;
         out->validity[i] = h->chunk.data[i].validity;
+        export_vector(h, h->chunk.data[i], &h->vec_roots[i]);
+        out->vectors[i] = &h->vec_roots[i];
     }
     return EXG_OK;
 }

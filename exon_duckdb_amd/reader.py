@@ -2,16 +2,14 @@
 one process per GPU opens the same path with shard_index = its rank (include/exon_gpu.h, exg_open_args)."""
 import ctypes as C
 
-import numpy as np
-
 from . import abi
 from ._lib import ExgError, load_library
-from .table_function import Chunk, Schema, _decode_strings
+from .table_function import Chunk, Schema, decode_vector, type_tree
 
 
 class ShardReader:
     def __init__(self, path, file_format, shard_index=0, shard_count=1, compression=None, device=0, device_batch_bytes=0,
-                 filters=None):
+                 filters=None, batch_rows=2048):
         self._l = load_library()
         self._l.exg_open.argtypes = [C.POINTER(abi.OpenArgs), C.POINTER(C.c_void_p)]
         self._l.exg_next_chunk.argtypes = [C.c_void_p, C.POINTER(Chunk)]
@@ -21,16 +19,22 @@ class ShardReader:
         self._l.exg_reader_error.restype = C.c_char_p
         self._l.exg_reader_error.argtypes = [C.c_void_p]
         self._l.exg_close.argtypes = [C.c_void_p]
-        a = abi.OpenArgs(path.encode(), file_format.encode(), compression.encode() if compression else None, 2048, device,
+        a = abi.OpenArgs(path.encode(), file_format.encode(), compression.encode() if compression else None, batch_rows, device,
                          device_batch_bytes, filters.encode() if filters else None, shard_index, shard_count)
         self._r = C.c_void_p()
         rc = self._l.exg_open(C.byref(a), C.byref(self._r))
         if rc != 0:
             raise ExgError(rc, self._l.exg_last_error_message().decode("utf-8", "replace"))
         sch = Schema()
-        self._l.exg_schema_of(self._r, C.byref(sch))
+        rc = self._l.exg_schema_of(self._r, C.byref(sch))
+        if rc != 0:
+            msg = (self._l.exg_reader_error(self._r) or b"").decode("utf-8", "replace")
+            self._l.exg_close(self._r)
+            self._r = C.c_void_p()
+            raise ExgError(rc, msg)
         self.names = [sch.names[i].decode() for i in range(sch.n_columns)]
         self.types = [sch.types[i] for i in range(sch.n_columns)]
+        self.trees = [type_tree(sch.tree[i].contents) for i in range(sch.n_columns)]
 
     def _fail(self, rc):
         raise ExgError(rc, (self._l.exg_reader_error(self._r) or b"").decode("utf-8", "replace"))
@@ -53,19 +57,7 @@ class ShardReader:
             n = int(ch.n_rows)
             if n == 0:
                 return out
-            cols = []
-            for k, t in enumerate(self.types):
-                if t == abi.EXG_TYPE_VARCHAR:
-                    cols.append(_decode_strings(ch.data[k], ch.validity[k], n))
-                else:
-                    dt = np.int64 if t == abi.EXG_TYPE_BIGINT else np.float32
-                    arr = np.ctypeslib.as_array(C.cast(ch.data[k], C.POINTER(C.c_uint8)), shape=(n * np.dtype(dt).itemsize,)).view(dt).copy()
-                    vals = arr.tolist()
-                    if ch.validity[k]:
-                        words = np.ctypeslib.as_array(C.cast(ch.validity[k], C.POINTER(C.c_uint64)), shape=((n + 63) // 64,))
-                        v = np.unpackbits(words.view(np.uint8), bitorder="little")[:n]
-                        vals = [x if ok else None for x, ok in zip(vals, v)]
-                    cols.append(vals)
+            cols = [decode_vector(ch.vectors[k].contents, self.trees[k]) for k in range(len(self.names))]
             out.extend(zip(*cols))
             self._l.exg_release_chunk(self._r, C.byref(ch))
 

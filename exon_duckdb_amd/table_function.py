@@ -18,13 +18,88 @@ from ._lib import ExgError, load_library
 ROW_ID = (1 << 64) - 1
 
 
+class ExgType(C.Structure):
+    pass
+
+
+ExgType._fields_ = [("type", C.c_int), ("nullable", C.c_int), ("name", C.c_char_p), ("n_children", C.c_int),
+                    ("children", C.POINTER(ExgType))]
+
+
+class ExgVector(C.Structure):
+    pass
+
+
+ExgVector._fields_ = [("data", C.c_void_p), ("validity", C.c_void_p), ("length", C.c_uint64), ("n_children", C.c_int),
+                      ("children", C.POINTER(ExgVector))]
+
+
 class Schema(C.Structure):
-    _fields_ = [("n_columns", C.c_int), ("names", C.c_char_p * 16), ("types", C.c_int * 16), ("nullable", C.c_int * 16)]
+    _fields_ = [("n_columns", C.c_int), ("names", C.c_char_p * 16), ("types", C.c_int * 16), ("nullable", C.c_int * 16),
+                ("tree", C.POINTER(ExgType) * 16)]
 
 
 class Chunk(C.Structure):
     _fields_ = [("n_rows", C.c_uint64), ("n_columns", C.c_int), ("data", C.c_void_p * 16),
-                ("validity", C.c_void_p * 16), ("keepalive", C.c_void_p)]
+                ("validity", C.c_void_p * 16), ("keepalive", C.c_void_p), ("vectors", C.POINTER(ExgVector) * 16)]
+
+
+def type_tree(t):
+    """exg_type -> a plain Python description that outlives the reader: (type id, name, [children])"""
+    return (int(t.type), (t.name or b"").decode(), [type_tree(t.children[i]) for i in range(t.n_children)])
+
+
+def type_sql(tree):
+    """the DuckDB spelling of a type tree, e.g. STRUCT(DP INTEGER, AF FLOAT[])"""
+    tid, _, kids = tree
+    if tid == abi.EXG_TYPE_LIST:
+        return type_sql(kids[0]) + "[]"
+    if tid == abi.EXG_TYPE_STRUCT:
+        return "STRUCT(" + ", ".join(f"{k[1]} {type_sql(k)}" for k in kids) + ")"
+    return {abi.EXG_TYPE_VARCHAR: "VARCHAR", abi.EXG_TYPE_BIGINT: "BIGINT", abi.EXG_TYPE_FLOAT: "FLOAT",
+            abi.EXG_TYPE_INTEGER: "INTEGER", abi.EXG_TYPE_BOOLEAN: "BOOLEAN"}[tid]
+
+
+def _valid_bits(validity_ptr, n):
+    if not validity_ptr or n == 0:
+        return None
+    words = np.ctypeslib.as_array(C.cast(validity_ptr, C.POINTER(C.c_uint64)), shape=((n + 63) // 64,))
+    return np.unpackbits(words.view(np.uint8), bitorder="little")[:n]
+
+
+def decode_vector(vec, tree):
+    """One exg_vector (DuckDB layout) -> list of Python values: bytes / int / float / bool / list / dict / None."""
+    tid, _, kids = tree
+    n = int(vec.length)
+    if tid == abi.EXG_TYPE_VARCHAR:
+        return _decode_strings(vec.data, vec.validity, n) if n else []
+    valid = _valid_bits(vec.validity, n)
+    if tid == abi.EXG_TYPE_LIST:
+        child = decode_vector(vec.children[0], kids[0])
+        out = []
+        if n:
+            ent = np.ctypeslib.as_array(C.cast(vec.data, C.POINTER(C.c_uint64)), shape=(2 * n,)).reshape(n, 2)
+            for i in range(n):
+                if valid is not None and not valid[i]:
+                    out.append(None)
+                else:
+                    o, l = int(ent[i, 0]), int(ent[i, 1])
+                    assert o + l <= len(child), "list entry outside the chunk's child vector"
+                    out.append(child[o:o + l])
+        return out
+    if tid == abi.EXG_TYPE_STRUCT:
+        cols = [decode_vector(vec.children[i], kids[i]) for i in range(vec.n_children)]
+        names = [k[1] for k in kids]
+        return [None if (valid is not None and not valid[i]) else {nm: c[i] for nm, c in zip(names, cols)} for i in range(n)]
+    dt = {abi.EXG_TYPE_BIGINT: np.int64, abi.EXG_TYPE_FLOAT: np.float32, abi.EXG_TYPE_INTEGER: np.int32,
+          abi.EXG_TYPE_BOOLEAN: np.uint8}[tid]
+    if n == 0:
+        return []
+    arr = np.ctypeslib.as_array(C.cast(vec.data, C.POINTER(C.c_uint8)), shape=(n * np.dtype(dt).itemsize,)).view(dt).copy()
+    vals = [bool(x) for x in arr] if tid == abi.EXG_TYPE_BOOLEAN else arr.tolist()
+    if valid is not None:
+        vals = [x if ok else None for x, ok in zip(vals, valid)]
+    return vals
 
 
 class FilterNode(C.Structure):
@@ -134,6 +209,7 @@ class Relation:
         self._l.exon_tf_schema(h, C.byref(sch))
         self.names = [sch.names[i].decode() for i in range(sch.n_columns)]
         self.types = [sch.types[i] for i in range(sch.n_columns)]
+        self.trees = [type_tree(sch.tree[i].contents) for i in range(sch.n_columns)]
         self._l.exon_tf_close(h)
 
     def _scan(self, column_ids, filters=None):
@@ -189,20 +265,7 @@ class Relation:
         rows = []
         for ch in self._scan(ids, filters):
             n = int(ch.n_rows)
-            decoded = []
-            for k, cid in enumerate(ids[:len(cols)]):
-                t = self.types[cid]
-                if t == abi_type("VARCHAR"):
-                    decoded.append(_decode_strings(ch.data[k], ch.validity[k], n))
-                else:
-                    dt = np.int64 if t == abi_type("BIGINT") else np.float32
-                    arr = np.ctypeslib.as_array(C.cast(ch.data[k], C.POINTER(C.c_uint8)), shape=(n * np.dtype(dt).itemsize,)).view(dt).copy()
-                    vals = arr.tolist()
-                    if ch.validity[k]:
-                        words = np.ctypeslib.as_array(C.cast(ch.validity[k], C.POINTER(C.c_uint64)), shape=((n + 63) // 64,))
-                        v = np.unpackbits(words.view(np.uint8), bitorder="little")[:n]
-                        vals = [x if ok else None for x, ok in zip(vals, v)]
-                    decoded.append(vals)
+            decoded = [decode_vector(ch.vectors[k].contents, self.trees[cid]) for k, cid in enumerate(ids[:len(cols)])]
             for i in range(n):
                 row = tuple(d[i] for d in decoded)
                 if where is None or where(dict(zip(cols, row))):
@@ -213,7 +276,7 @@ class Relation:
 
 
 def abi_type(name):
-    return {"VARCHAR": 1, "BIGINT": 2, "FLOAT": 3}[name]
+    return {"VARCHAR": 1, "BIGINT": 2, "FLOAT": 3, "INTEGER": 4, "BOOLEAN": 5, "LIST": 6, "STRUCT": 7}[name]
 
 
 class Connection:

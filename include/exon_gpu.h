@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define EXG_ABI_VERSION 3
+#define EXG_ABI_VERSION 4
 
 /* DuckDB v0.8.1 STANDARD_VECTOR_SIZE; the reference asks the Rust side for
  * batches of exactly this many rows (module.cpp:83, :233). */
@@ -309,7 +309,7 @@ typedef struct exg_open_args {
     uint64_t device_batch_bytes; /* bytes shipped to HBM per launch; 0 => default */
     const char *filters;     /* NULL / "" or the predicate FilterToString renders (module.cpp:158-214), same grammar as
                               * new_reader's: evaluated on the device, only the rows where it is TRUE are copied back.
-                              * VCF id / alt / filter / info / formats are VARCHAR at this boundary and may be compared. */
+                              * Nested columns (VCF id / alt / filter / info / formats) are refused, like in new_reader. */
     uint32_t shard_index;    /* byte-range shards of every file: this reader yields the records / lines that */
     uint32_t shard_count;    /* END in its 1/shard_count of the bytes behind the header; 0 or 1 = the whole file.  One process
                               * per GPU opens the same path with its rank: the shards partition the rows, in file order, with
@@ -325,23 +325,53 @@ typedef struct exg_open_args {
 #define EXG_TYPE_VARCHAR 1
 #define EXG_TYPE_BIGINT 2
 #define EXG_TYPE_FLOAT 3
+#define EXG_TYPE_INTEGER 4 /* int32_t */
+#define EXG_TYPE_BOOLEAN 5 /* one byte per value (DuckDB BOOLEAN) */
+#define EXG_TYPE_LIST 6    /* data = exg_list_entry_t[] (DuckDB list_entry_t), children[0] = the elements */
+#define EXG_TYPE_STRUCT 7  /* no data of its own; children = the fields, each as long as the parent */
+
+/* The full type of a column.  The VCF columns carry the reference's schema (what DuckDB's Arrow conversion makes of
+ * exon's Arrow schema, exon/src/exon/arrow_table_function/module.cpp:126-147; pinned by test_vcf_record_scan.test:10-19):
+ * id / alt / filter LIST(VARCHAR), info STRUCT(<##INFO keys>), formats LIST(STRUCT(<##FORMAT keys>)), a key with
+ * Number != 1 being a LIST of its type. */
+typedef struct exg_type {
+    int type; /* EXG_TYPE_* */
+    int nullable;
+    const char *name; /* column / field name; "item" for list elements */
+    int n_children;
+    const struct exg_type *children;
+} exg_type;
+
+/* One DuckDB vector of a chunk, same shape as its exg_type: flat data + validity (bit i = element i valid; NULL = all
+ * valid) + children.  LIST: data = exg_list_entry_t[length] whose offsets are relative to children[0] as handed out
+ * here (the child vector of THIS chunk).  STRUCT: data = NULL.  All memory is owned by the chunk's keepalive. */
+typedef struct exg_vector {
+    void *data;
+    uint64_t *validity;
+    uint64_t length;
+    int n_children;
+    const struct exg_vector *children;
+} exg_vector;
 
 typedef struct exg_schema {
     int n_columns;
     const char *names[16]; /* owned by the reader */
-    int types[16];
+    int types[16];         /* EXG_TYPE_* of the column itself */
     int nullable[16];
+    const exg_type *tree[16]; /* the column's full type (owned by the reader) */
 } exg_schema;
 
 typedef struct exg_chunk {
     uint64_t n_rows;           /* 0 => end of stream */
     int n_columns;
-    void *data[16];            /* host pointers: exg_string_t[n_rows] / int64_t[] / float[] */
+    void *data[16];            /* host pointers: exg_string_t[n_rows] / int64_t[] / float[] / exg_list_entry_t[] (STRUCT: NULL) */
     uint64_t *validity[16];    /* NULL => all valid; else ceil(n_rows/64) words */
     void *keepalive;           /* opaque; payload + vectors stay valid until exg_release_chunk */
+    const exg_vector *vectors[16]; /* every column as a vector tree (data / validity above are vectors[c]'s own) */
 } exg_chunk;
 
 int exg_open(const exg_open_args *args, exg_reader **out);
+/* VCF: opens the first file (the INFO / FORMAT keys of its header are the schema), so it can fail like a scan can. */
 int exg_schema_of(exg_reader *r, exg_schema *out);
 int exg_next_chunk(exg_reader *r, exg_chunk *out);
 void exg_release_chunk(exg_reader *r, exg_chunk *chunk);

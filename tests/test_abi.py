@@ -33,7 +33,8 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert os.path.exists(LIB_PATH)
     missing = [f for f in declared_functions() if not hasattr(lib, f)]
     assert not missing, f"declared in include/exon_gpu.h but not exported: {missing}"
-    assert lib.exg_abi_version() == 3
+    from exon_duckdb_amd import abi
+    assert lib.exg_abi_version() == abi.EXG_ABI_VERSION == 4
     lib.exg_parse_error_string.restype = C.c_char_p
     assert lib.exg_parse_error_string(1) == b"invalid name prefix"
 
@@ -52,11 +53,11 @@ def test_no_gpu_means_a_loud_error_not_a_fallback():
 
 def test_ctypes_mirrors_match_the_c_layout(tmp_path):
     from exon_duckdb_amd import abi
-    from exon_duckdb_amd.table_function import Chunk, Schema
+    from exon_duckdb_amd.table_function import Chunk, ExgType, ExgVector, Schema
 
     structs = {"exg_scan_result": abi.ScanResult, "exg_fastq_scan_args": abi.FastqScanArgs,
                "exg_vcf_scan_args": abi.VcfScanArgs, "exg_fasta_scan_args": abi.FastaScanArgs,
-               "exg_chunk": Chunk, "exg_schema": Schema}
+               "exg_chunk": Chunk, "exg_schema": Schema, "exg_type": ExgType, "exg_vector": ExgVector}
     prog = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
     for cname, cls in structs.items():
         prog.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

@@ -149,9 +149,8 @@ def test_vcf_row0(con, golden_dir):
     rel = con.table_function("read_vcf_file_records", G(golden_dir, "vcf/index.vcf"))
     assert rel.names == ["chrom", "pos", "id", "ref", "alt", "qual", "filter", "info", "formats"]
     chrom, pos, ref, alt, qual, info = rel.fetchall(columns=["chrom", "pos", "ref", "alt", "qual", "info"], limit=1)[0]
-    assert (chrom, pos, ref, alt.split(b","), qual) == (b"1", 9999919, b"G", [b"<*>"], 0.0)
-    kv = dict(x.split(b"=", 1) if b"=" in x else (x, None) for x in info.split(b";"))
-    assert b"INDEL" not in kv and int(kv[b"DP"]) == 1       # info.indel IS NULL, info.dp = 1
+    # alt is a LIST, info a STRUCT: -> 1, 9999919, G, [<*>], 0.0, NULL, 1
+    assert (chrom, pos, ref, alt, qual, info["INDEL"], info["DP"]) == (b"1", 9999919, b"G", [b"<*>"], 0.0, None, 1)
 
 
 def test_vcf_bgzf(con, golden_dir):
@@ -159,14 +158,16 @@ def test_vcf_bgzf(con, golden_dir):
     rel = con.table_function("read_vcf_file_records", G(golden_dir, "vcf/index.vcf.gz"))
     assert rel.count() == 621
     chrom, pos, ref, alt, qual = rel.fetchall(columns=["chrom", "pos", "ref", "alt", "qual"], limit=1)[0]
-    assert (chrom, pos, ref, alt, qual) == (b"1", 9999919, b"G", b"<*>", 0.0)
+    assert (chrom, pos, ref, alt, qual) == (b"1", 9999919, b"G", [b"<*>"], 0.0)
     plain = con.table_function("read_vcf_file_records", G(golden_dir, "vcf/index.vcf")).fetchall()
     assert rel.fetchall() == plain
 
 
 def test_vcf_nulls(con, golden_dir):
     rows = con.table_function("read_vcf_file_records", G(golden_dir, "vcf/vcf_meta_meta.vcf")).fetchall()
-    assert rows == [(b"1", 123, b"test", b"TC", b"T", None, b".", b".", None)]
+    # id [test], alt [T], QUAL '.' -> NULL, FILTER '.' -> [], INFO '.' -> a struct of NULLs, no FORMAT column -> no samples
+    assert len(rows) == 1 and rows[0][:7] == (b"1", 123, [b"test"], b"TC", [b"T"], None, [])
+    assert rows[0][7] is not None and all(v is None for v in rows[0][7].values()) and rows[0][8] == []
 
 
 # ---- chunking: the reference asks for STANDARD_VECTOR_SIZE rows per batch (module.cpp:83) ----------------------
@@ -239,6 +240,7 @@ def test_vcf_streams_through_several_batches(con, oracle, tmp_path, monkeypatch)
     import gzip
     data = bytes(oracle.synth_vcf(5000))
     exp = oracle.vcf_parse(data)
+    typed, _ = oracle.vcf_typed_rows(data)
     (tmp_path / "v.vcf").write_bytes(data)
     (tmp_path / "v.vcf.gz").write_bytes(gzip.compress(data, mtime=0))
     want_pos = exp.extra["pos"].tolist()
@@ -250,7 +252,8 @@ def test_vcf_streams_through_several_batches(con, oracle, tmp_path, monkeypatch)
             assert rel.count() == 5000
             rows = rel.fetchall(columns=["chrom", "pos", "info"])
             assert [r[1] for r in rows] == want_pos
-            assert rows[4999][2] == exp.columns["info"].row(4999)
+            assert {k: (v.decode() if isinstance(v, bytes) else v) for k, v in rows[4999][2].items()}.keys() == typed[4999]["info"].keys()
+            assert rows[4999][2]["DP"] == typed[4999]["info"]["DP"]
 
 
 def test_prefetch_miss_and_batch_growth(con, oracle, tmp_path, monkeypatch):
@@ -324,7 +327,7 @@ def test_filter_pushdown_vcf(con, oracle, tmp_path, monkeypatch):
         ({"chrom": F.cmp("=", b"7"), "pos": F.and_(F.cmp(">=", 3000), F.cmp("<", 9000))},
          lambda r: r["chrom"] == b"7" and 3000 <= r["pos"] < 9000),
         ({"qual": F.or_(F.isnull(), F.cmp(">", 900.5))}, lambda r: r["qual"] is None or r["qual"] > 900.5),
-        ({"info": F.cmp(">=", b"DP=5"), "filter": F.cmp("!=", b"PASS")}, lambda r: r["info"] >= b"DP=5" and r["filter"] != b"PASS"),
+        ({"ref": F.cmp(">=", b"C"), "chrom": F.cmp("!=", b"1")}, lambda r: r["ref"] >= b"C" and r["chrom"] != b"1"),
     ]
     for filters, pred in cases:
         want = rel.fetchall(where=pred)
