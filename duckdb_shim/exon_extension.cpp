@@ -1,14 +1,17 @@
-// duckdb_shim/exon_extension.cpp — the REAL DuckDB v0.8.1 binding of libexon_gpu.so.
+// duckdb_shim/exon_extension.cpp — the REAL DuckDB v0.8.1 binding of libexon_gpu.so: `LOAD exon`.
 //
-// Compiled only where DuckDB's headers exist (the reference's `duckdb/` submodule is empty and no
-// DuckDB header is present on the build box, so this file is not part of build()).  It is the
-// mechanical mapping of csrc/exon_table_function.cpp (which runs against csrc/duck_mini.hpp and is
-// what the tests drive) onto duckdb::TableFunction, and replaces, in the reference tree,
-//   exon/src/exon/arrow_table_function/module.cpp   (Register / FileTypeBind / InitGlobal / Scan)
+// All of the glue's logic — bind / init_global (shard plan, FilterToString) / init_local (one reader per shard and device) /
+// scan / batch index / replacement scan — is exon_duckdb_amd/csrc/exon_table_function.hpp, written once against a traits
+// struct.  This file is that header instantiated over DuckDB's own classes: the traits (how a LogicalType and a Vector are
+// made in DuckDB), thin wrappers with DuckDB's callback signatures, and the registrations.  The same header instantiated
+// over csrc/testing/duck_mini.hpp is what the GPU test-suite drives (csrc/testing/exon_tf_harness.cpp), so the logic is
+// compiled and tested on the build box; THIS file needs DuckDB's headers, which do not exist there (the reference's
+// `duckdb/` submodule is empty), and is therefore not part of build().  It replaces, in the reference tree,
+//   exon/src/exon/arrow_table_function/module.cpp   (Register / FileTypeBind / InitGlobal / Scan / ReplacementScan)
 //   exon/src/exon_extension.cpp:47-58,79            (registrations of the three formats + replacement scan)
 // Build (out-of-tree extension, like the reference's CMakeLists.txt:131-146, minus Rust/Corrosion):
-//   c++ -std=c++17 -fPIC -shared -DDUCKDB_BUILD_LOADABLE_EXTENSION -I<duckdb>/src/include \
-//       -I../include exon_extension.cpp -L../exon_duckdb_amd/lib -lexon_gpu -o exon.duckdb_extension
+//   c++ -std=c++17 -fPIC -shared -DDUCKDB_BUILD_LOADABLE_EXTENSION -I<duckdb>/src/include -I../include \
+//       -I../exon_duckdb_amd/csrc exon_extension.cpp -L../exon_duckdb_amd/lib -lexon_gpu -o exon.duckdb_extension
 #define DUCKDB_EXTENSION_MAIN
 #include "duckdb.hpp"
 #include "duckdb/common/types/vector_buffer.hpp"
@@ -16,214 +19,183 @@
 #include "duckdb/main/extension_util.hpp"
 #include "duckdb/parser/expression/constant_expression.hpp"
 #include "duckdb/parser/expression/function_expression.hpp"
-#include "duckdb/parser/parsed_data/create_table_function_info.hpp"
 #include "duckdb/parser/tableref/table_function_ref.hpp"
 #include "duckdb/planner/filter/conjunction_filter.hpp"
 #include "duckdb/planner/filter/constant_filter.hpp"
 #include "duckdb/planner/table_filter.hpp"
 
-#include "exon_gpu.h"
+#include "exon_table_function.hpp"
 
 namespace exon {
 using namespace duckdb;
 
 static_assert(sizeof(string_t) == sizeof(exg_string_t), "exg_string_t must be duckdb::string_t");
+static_assert(sizeof(list_entry_t) == sizeof(exg_list_entry_t), "exg_list_entry_t must be duckdb::list_entry_t");
 static_assert(STANDARD_VECTOR_SIZE == EXG_VECTOR_SIZE, "chunks are STANDARD_VECTOR_SIZE rows");
 
+// keeps the engine chunk (vectors + pinned payload) alive as long as a Vector references it
+struct ExonChunkBuffer : public VectorBuffer {
+	explicit ExonChunkBuffer(std::shared_ptr<exon_scan::ExonChunk> keep_p)
+	    : VectorBuffer(VectorBufferType::OPAQUE_BUFFER), keep(std::move(keep_p)) {
+	}
+	std::shared_ptr<exon_scan::ExonChunk> keep;
+};
+
+struct RealDuck {
+	using idx_t = duckdb::idx_t;
+	using LogicalType = duckdb::LogicalType;
+	using DataChunk = duckdb::DataChunk;
+	using FunctionData = duckdb::TableFunctionData;
+	using GlobalTableFunctionState = duckdb::GlobalTableFunctionState;
+	using LocalTableFunctionState = duckdb::LocalTableFunctionState;
+	using TableFilter = duckdb::TableFilter;
+	using ConstantFilter = duckdb::ConstantFilter;
+	using ConjunctionFilter = duckdb::ConjunctionFilter; // base of ConjunctionAndFilter / ConjunctionOrFilter
+	using TableFilterSet = duckdb::TableFilterSet;
+	using TableFilterType = duckdb::TableFilterType;
+	static constexpr idx_t RowId = COLUMN_IDENTIFIER_ROW_ID;
+	static constexpr idx_t VectorSize = STANDARD_VECTOR_SIZE;
+
+	// module.cpp:126-147 (there: ArrowTableFunction::GetArrowLogicalType over the Arrow schema)
+	static LogicalType ToLogical(const exg_type &t) {
+		switch (t.type) {
+		case EXG_TYPE_BIGINT:
+			return LogicalType::BIGINT;
+		case EXG_TYPE_FLOAT:
+			return LogicalType::FLOAT;
+		case EXG_TYPE_INTEGER:
+			return LogicalType::INTEGER;
+		case EXG_TYPE_BOOLEAN:
+			return LogicalType::BOOLEAN;
+		case EXG_TYPE_LIST:
+			return LogicalType::LIST(ToLogical(t.children[0]));
+		case EXG_TYPE_STRUCT: {
+			child_list_t<LogicalType> fields;
+			for (int i = 0; i < t.n_children; i++) {
+				fields.emplace_back(t.children[i].name, ToLogical(t.children[i]));
+			}
+			return LogicalType::STRUCT(std::move(fields));
+		}
+		default:
+			return LogicalType::VARCHAR;
+		}
+	}
+
+	// an engine vector as a DuckDB Vector that references the engine's host buffers (zero-copy)
+	static void Wrap(Vector &vec, const LogicalType &type, const exg_vector &src, const buffer_ptr<VectorBuffer> &keep) {
+		if (src.validity) {
+			FlatVector::Validity(vec).Initialize(reinterpret_cast<validity_t *>(src.validity));
+		}
+		switch (type.id()) {
+		case LogicalTypeId::LIST: {
+			FlatVector::SetData(vec, data_ptr_cast(src.data)); // list_entry_t[], offsets relative to this chunk's child
+			auto &child = ListVector::GetEntry(vec);
+			Wrap(child, ListType::GetChildType(type), src.children[0], keep);
+			ListVector::SetListSize(vec, src.children[0].length);
+			break;
+		}
+		case LogicalTypeId::STRUCT: {
+			auto &entries = StructVector::GetEntries(vec);
+			auto &fields = StructType::GetChildTypes(type);
+			for (idx_t i = 0; i < entries.size(); i++) {
+				Wrap(*entries[i], fields[i].second, src.children[i], keep);
+			}
+			break;
+		}
+		case LogicalTypeId::VARCHAR:
+			FlatVector::SetData(vec, data_ptr_cast(src.data)); // string_t[]; payload kept alive through the aux buffer
+			vec.SetAuxiliary(keep);
+			break;
+		default:
+			FlatVector::SetData(vec, data_ptr_cast(src.data));
+			vec.SetAuxiliary(keep);
+			break;
+		}
+	}
+	static void Reference(DataChunk &out, idx_t col, const LogicalType &type, const exg_vector &src,
+	                      std::shared_ptr<exon_scan::ExonChunk> keep) {
+		Wrap(out.data[col], type, src, make_buffer<ExonChunkBuffer>(std::move(keep)));
+	}
+	static void SetCardinality(DataChunk &out, idx_t n) {
+		out.SetCardinality(n);
+	}
+	static std::string ComparisonOperator(const ConstantFilter &f) {
+		return ExpressionTypeToOperator(f.comparison_type);
+	}
+	static std::string ConstantSQL(const ConstantFilter &f) {
+		return f.constant.ToSQLString();
+	}
+};
+
+using TF = exon_scan::ExonTableFunction<RealDuck>;
+
+// exon/include/exon/arrow_table_function/module.hpp:29-35
 struct WTArrowTableScanInfo : public TableFunctionInfo {
 	explicit WTArrowTableScanInfo(string file_type_p) : file_type(std::move(file_type_p)) {
 	}
 	string file_type;
 };
 
-struct ExonScanFunctionData : public TableFunctionData {
-	string file_type, compression, file_name;
-	vector<LogicalType> all_types;
-	vector<string> all_names;
-};
-
-struct ExonScanGlobalState : public GlobalTableFunctionState {
-	exg_reader *reader = nullptr;
-	vector<column_t> column_ids;
-	bool count_only = false, counted = false;
-	uint64_t count_remaining = 0;
-	~ExonScanGlobalState() override {
-		if (reader) {
-			exg_close(reader);
-		}
-	}
-	idx_t MaxThreads() const override {
-		return 1;
-	}
-};
-
-// keeps the engine chunk (vectors + pinned payload) alive as long as a Vector references it
-struct ExonChunkBuffer : public VectorBuffer {
-	ExonChunkBuffer(exg_reader *r, exg_chunk c) : VectorBuffer(VectorBufferType::OPAQUE_BUFFER), reader(r), chunk(c) {
-	}
-	~ExonChunkBuffer() override {
-		exg_release_chunk(reader, &chunk);
-	}
-	exg_reader *reader;
-	exg_chunk chunk;
-};
-
-// the reference's FilterToString (module.cpp:158-214), unchanged in what it renders
-static string FilterToString(const TableFilter &filter, const string &column_name) {
-	switch (filter.filter_type) {
-	case TableFilterType::CONSTANT_COMPARISON: {
-		auto &cf = (const ConstantFilter &)filter;
-		return column_name + ExpressionTypeToOperator(cf.comparison_type) + cf.constant.ToSQLString();
-	}
-	case TableFilterType::CONJUNCTION_AND: {
-		vector<string> parts;
-		for (auto &c : ((const ConjunctionAndFilter &)filter).child_filters) {
-			parts.push_back(FilterToString(*c, column_name));
-		}
-		return StringUtil::Join(parts, " AND ");
-	}
-	case TableFilterType::CONJUNCTION_OR: {
-		vector<string> parts;
-		for (auto &c : ((const ConjunctionOrFilter &)filter).child_filters) {
-			parts.push_back(FilterToString(*c, column_name));
-		}
-		return StringUtil::Join(parts, " OR ");
-	}
-	case TableFilterType::IS_NOT_NULL:
-		return column_name + " IS NOT NULL";
-	case TableFilterType::IS_NULL:
-		return column_name + " IS NULL";
-	default:
-		throw NotImplementedException("FilterToString: filter type not implemented");
-	}
-}
-
-static exg_reader *OpenReader(const ExonScanFunctionData &d, const string &filter_clause = "") {
-	exg_open_args a {};
-	a.filters = filter_clause.empty() ? nullptr : filter_clause.c_str(); // evaluated on the device
-	a.path = d.file_name.c_str();
-	a.file_format = d.file_type.c_str();
-	a.compression = d.compression == "auto_detect" ? nullptr : d.compression.c_str();
-	a.batch_rows = STANDARD_VECTOR_SIZE;
-	exg_reader *r = nullptr;
-	if (exg_open(&a, &r) != EXG_OK) {
-		throw std::runtime_error(exg_last_error_message());
-	}
-	return r;
-}
-
-static LogicalType ToLogical(int t) {
-	return t == EXG_TYPE_BIGINT ? LogicalType::BIGINT : t == EXG_TYPE_FLOAT ? LogicalType::FLOAT : LogicalType::VARCHAR;
-}
-
 static unique_ptr<FunctionData> FileTypeBind(ClientContext &, TableFunctionBindInput &input,
                                              vector<LogicalType> &return_types, vector<string> &names) {
 	auto &info = input.info->Cast<WTArrowTableScanInfo>();
-	auto result = make_uniq<ExonScanFunctionData>();
-	result->file_name = input.inputs[0].GetValue<string>();
-	result->compression = "auto_detect";
+	string compression;
 	for (auto &kv : input.named_parameters) {
 		if (kv.first == "compression") {
-			result->compression = kv.second.GetValue<string>();
+			compression = kv.second.GetValue<string>();
 		}
 	}
-	result->file_type = info.file_type;
-	exg_reader *r = OpenReader(*result);
-	exg_schema sch;
-	int rc = exg_schema_of(r, &sch);
-	exg_close(r);
-	if (rc != EXG_OK) {
-		throw std::runtime_error("Failed to get schema");
+	std::vector<LogicalType> types;
+	std::vector<std::string> col_names;
+	auto result = TF::Bind(input.inputs[0].GetValue<string>(), compression, info.file_type, types, col_names);
+	for (auto &t : types) {
+		return_types.push_back(t);
 	}
-	for (int i = 0; i < sch.n_columns; i++) {
-		return_types.push_back(ToLogical(sch.types[i]));
-		names.emplace_back(sch.names[i]);
+	for (auto &n : col_names) {
+		names.push_back(n);
 	}
-	result->all_types = return_types;
-	result->all_names = names;
-	return std::move(result);
+	return unique_ptr<FunctionData>(result.release());
 }
 
 static unique_ptr<GlobalTableFunctionState> InitGlobal(ClientContext &, TableFunctionInitInput &input) {
-	auto &data = input.bind_data->Cast<ExonScanFunctionData>();
-	auto gs = make_uniq<ExonScanGlobalState>();
-	gs->column_ids = input.column_ids;
-	gs->count_only = true;
-	for (auto c : input.column_ids) {
-		gs->count_only = gs->count_only && c == COLUMN_IDENTIFIER_ROW_ID;
-	}
-	string filter_clause;
-	if (input.filters) { // module.cpp:222-226
-		vector<string> parts;
-		for (auto &f : input.filters->filters) {
-			parts.push_back(FilterToString(*f.second, data.all_names[input.column_ids[f.first]]));
-		}
-		filter_clause = StringUtil::Join(parts, " AND ");
-	}
-	gs->reader = OpenReader(data, filter_clause);
-	return std::move(gs);
+	auto &data = input.bind_data->Cast<TF::BindData>();
+	std::vector<idx_t> column_ids(input.column_ids.begin(), input.column_ids.end());
+	return unique_ptr<GlobalTableFunctionState>(TF::InitGlobal(data, column_ids, input.filters.get()).release());
+}
+
+static unique_ptr<LocalTableFunctionState> InitLocal(ExecutionContext &, TableFunctionInitInput &input,
+                                                     GlobalTableFunctionState *gs) {
+	return unique_ptr<LocalTableFunctionState>(
+	    TF::InitLocal(input.bind_data->Cast<TF::BindData>(), gs->Cast<TF::GlobalState>()).release());
 }
 
 static void Scan(ClientContext &, TableFunctionInput &input, DataChunk &output) {
-	auto &gs = input.global_state->Cast<ExonScanGlobalState>();
-	if (gs.count_only) {
-		if (!gs.counted) {
-			if (exg_count_only(gs.reader, &gs.count_remaining) != EXG_OK) {
-				throw std::runtime_error(exg_reader_error(gs.reader));
-			}
-			gs.counted = true;
-		}
-		idx_t n = MinValue<idx_t>(STANDARD_VECTOR_SIZE, gs.count_remaining);
-		gs.count_remaining -= n;
-		output.SetCardinality(n);
+	if (!input.local_state) { // module.cpp:259-261
 		return;
 	}
-	exg_chunk c;
-	if (exg_next_chunk(gs.reader, &c) != EXG_OK) {
-		throw std::runtime_error(exg_reader_error(gs.reader));
-	}
-	if (c.n_rows == 0) {
-		return; // output.size() == 0 ends the scan
-	}
-	auto buffer = make_buffer<ExonChunkBuffer>(gs.reader, c);
-	output.SetCardinality(c.n_rows);
-	for (idx_t i = 0; i < gs.column_ids.size(); i++) {
-		auto col = gs.column_ids[i];
-		if (col == COLUMN_IDENTIFIER_ROW_ID) {
-			continue;
-		}
-		auto &vec = output.data[i];
-		FlatVector::SetData(vec, data_ptr_cast(c.data[col])); // zero-copy: string_t array of the engine
-		vec.SetAuxiliary(buffer);
-		if (c.validity[col]) {
-			FlatVector::Validity(vec).Initialize(reinterpret_cast<validity_t *>(c.validity[col]));
-		}
-	}
+	TF::Scan(input.bind_data->Cast<TF::BindData>(), input.global_state->Cast<TF::GlobalState>(),
+	         &input.local_state->Cast<TF::LocalState>(), output);
 }
 
+static idx_t GetBatchIndex(ClientContext &, const FunctionData *, LocalTableFunctionState *ls, GlobalTableFunctionState *) {
+	return TF::BatchIndex(ls->Cast<TF::LocalState>());
+}
+
+// module.cpp:296-318
 static void Register(const string &name, const string &file_type, DatabaseInstance &db) {
-	TableFunction scan(name, {LogicalType::VARCHAR}, Scan, FileTypeBind, InitGlobal);
+	TableFunction scan(name, {LogicalType::VARCHAR}, Scan, FileTypeBind, InitGlobal, InitLocal);
 	scan.function_info = make_shared<WTArrowTableScanInfo>(file_type);
 	scan.named_parameters["compression"] = LogicalType::VARCHAR;
+	scan.get_batch_index = GetBatchIndex;
 	scan.projection_pushdown = true;
 	scan.filter_pushdown = true; // like the reference (module.cpp:311); the predicate runs on the device
 	ExtensionUtil::RegisterFunction(db, scan);
 }
 
+// module.cpp:320-382
 static unique_ptr<TableRef> ReplacementScan(ClientContext &, const string &table_name, ReplacementScanData *) {
-	auto lower = StringUtil::Lower(table_name);
-	auto res = replacement_scan(lower.c_str()); // same symbol and struct as exon/include/rust.hpp:11-13,48
-	if (!res.file_type) {
-		return nullptr;
-	}
-	string ft(res.file_type), fn;
-	if (ft == "FASTA") {
-		fn = "read_fasta";
-	} else if (ft == "FASTQ") {
-		fn = "read_fastq";
-	} else if (ft == "VCF") {
-		fn = "read_vcf_file_records";
-	} else {
+	const string fn = TF::ReplacementFunction(table_name);
+	if (fn.empty()) {
 		return nullptr;
 	}
 	auto ref = make_uniq<TableFunctionRef>();
@@ -233,20 +205,20 @@ static unique_ptr<TableRef> ReplacementScan(ClientContext &, const string &table
 	return std::move(ref);
 }
 
+// exon/src/exon_extension.cpp:25-96, restricted to the path
 static void LoadInternal(DatabaseInstance &db) {
-	Register("read_fasta", "fasta", db);
-	Register("read_fastq", "fastq", db);
-	Register("read_vcf_file_records", "vcf", db);
-	Register("read_vcf", "vcf", db);
+	for (const auto &reg : exon_scan::kRegistrations) {
+		Register(reg.name, reg.file_type, db);
+	}
 	DBConfig::GetConfig(db).replacement_scans.emplace_back(ReplacementScan);
 }
 } // namespace exon
 
 extern "C" {
-DUCKDB_EXTENSION_API void exon_init(duckdb::DatabaseInstance &db) {
+DUCKDB_EXTENSION_API void exon_init(duckdb::DatabaseInstance &db) { // exon_extension.cpp:110-116
 	exon::LoadInternal(db);
 }
-DUCKDB_EXTENSION_API const char *exon_version() {
+DUCKDB_EXTENSION_API const char *exon_version() { // exon_extension.cpp:118-122
 	return duckdb::DuckDB::LibraryVersion();
 }
 }

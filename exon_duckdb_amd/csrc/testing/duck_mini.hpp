@@ -7,8 +7,9 @@
 //   ValidityMask words  == uint64_t[STANDARD_VECTOR_SIZE / 64], bit set = valid, nullptr = all valid
 //   STANDARD_VECTOR_SIZE == 2048
 // The classes below keep DuckDB's names and member meaning (duckdb/function/table_function.hpp) so
-// that duckdb_shim/exon_extension.cpp — the real binding, compiled where DuckDB headers exist — is
-// a mechanical mapping.
+// that csrc/exon_table_function.hpp — the glue, written once against a traits struct — compiles against
+// them exactly as it compiles against DuckDB's own classes in duckdb_shim/exon_extension.cpp.
+// TEST SCAFFOLDING: linked into libexon_tf_test.so, never into the product library.
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
@@ -19,7 +20,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/exon_gpu.h"
+#include "exon_gpu.h"
 
 namespace exon_amd {
 
@@ -177,6 +178,7 @@ struct TableFunction {
     using init_local_t =
         std::function<std::unique_ptr<LocalTableFunctionState>(TableFunctionInitInput &, GlobalTableFunctionState *)>;
     using function_t = std::function<void(TableFunctionInput &, DataChunk &)>;
+    using batch_index_t = std::function<idx_t(const FunctionData *, LocalTableFunctionState *, GlobalTableFunctionState *)>;
 
     std::string name;
     std::vector<LogicalType> arguments;
@@ -184,6 +186,7 @@ struct TableFunction {
     bind_t bind;
     init_global_t init_global;
     init_local_t init_local;
+    batch_index_t get_batch_index;
     std::map<std::string, LogicalType> named_parameters;
     std::shared_ptr<TableFunctionInfo> function_info;
     bool projection_pushdown = false;

@@ -1,0 +1,327 @@
+// exon_tf_harness.cpp — TEST SCAFFOLDING (libexon_tf_test.so, not the product): csrc/exon_table_function.hpp instantiated
+// with the DuckDB API slice of duck_mini.hpp, a catalog, and C entry points that let the Python parity tests play DuckDB's
+// part — look a table function up, bind, init_global, init_local on several threads, pull DataChunks until an empty one
+// (tests/test_table_function*.py read like the reference's sqllogictests).
+#include <algorithm>
+
+#include "duck_mini.hpp"
+#include "exon_table_function.hpp"
+
+namespace exon_amd {
+
+// the traits that name duck_mini's types; duckdb_shim/exon_extension.cpp has the same struct over DuckDB's own
+struct MiniDuck {
+    using idx_t = exon_amd::idx_t;
+    using LogicalType = exon_amd::LogicalType;
+    using DataChunk = exon_amd::DataChunk;
+    using FunctionData = exon_amd::FunctionData;
+    using GlobalTableFunctionState = exon_amd::GlobalTableFunctionState;
+    using LocalTableFunctionState = exon_amd::LocalTableFunctionState;
+    using TableFilter = exon_amd::TableFilter;
+    using ConstantFilter = exon_amd::ConstantFilter;
+    using ConjunctionFilter = exon_amd::ConjunctionFilter;
+    using TableFilterSet = exon_amd::TableFilterSet;
+    using TableFilterType = exon_amd::TableFilterType;
+    static constexpr idx_t RowId = COLUMN_IDENTIFIER_ROW_ID;
+    static constexpr idx_t VectorSize = STANDARD_VECTOR_SIZE;
+
+    // module.cpp:126-147 (there: GetArrowLogicalType over the Arrow schema)
+    static LogicalType ToLogical(const exg_type &t) {
+        switch (t.type) {
+            case EXG_TYPE_LIST: return LogicalType::LIST(ToLogical(t.children[0]));
+            case EXG_TYPE_STRUCT: {
+                std::vector<std::pair<std::string, LogicalType>> fields;
+                for (int i = 0; i < t.n_children; i++) fields.emplace_back(t.children[i].name, ToLogical(t.children[i]));
+                return LogicalType::STRUCT(std::move(fields));
+            }
+            default: return LogicalType((LogicalTypeId)t.type);
+        }
+    }
+    static void Wrap(const exg_vector &src, const LogicalType &type, const std::shared_ptr<void> &keep, Vector &dst) {
+        dst.type = type;
+        dst.data = src.data;
+        dst.validity = src.validity;
+        dst.length = src.length;
+        dst.buffer = keep;
+        dst.children.resize((size_t)src.n_children);
+        for (int i = 0; i < src.n_children; i++) Wrap(src.children[i], type.children.at((size_t)i).second, keep, dst.children[(size_t)i]);
+    }
+    static void Reference(DataChunk &out, idx_t col, const LogicalType &type, const exg_vector &src, std::shared_ptr<exon_scan::ExonChunk> keep) {
+        if (out.data.size() <= col) out.data.resize(col + 1);
+        Wrap(src, type, keep, out.data[col]);
+    }
+    static void SetCardinality(DataChunk &out, idx_t n) {
+        if (n == 0) out.Reset();
+        out.SetCardinality(n);
+    }
+    // ExpressionTypeToOperator (duckdb/common/enums/expression_type.cpp) for the comparison types a filter carries
+    static std::string ComparisonOperator(const ConstantFilter &f) {
+        switch (f.comparison_type) {
+            case ExpressionType::COMPARE_EQUAL: return "=";
+            case ExpressionType::COMPARE_NOTEQUAL: return "!=";
+            case ExpressionType::COMPARE_LESSTHAN: return "<";
+            case ExpressionType::COMPARE_GREATERTHAN: return ">";
+            case ExpressionType::COMPARE_LESSTHANOREQUALTO: return "<=";
+            default: return ">=";
+        }
+    }
+    static std::string ConstantSQL(const ConstantFilter &f) { return f.constant.ToSQLString(); }
+};
+
+using TF = exon_scan::ExonTableFunction<MiniDuck>;
+
+// exon/include/exon/arrow_table_function/module.hpp:29-35
+struct WTArrowTableScanInfo : public TableFunctionInfo {
+    explicit WTArrowTableScanInfo(std::string file_type_p) : file_type(std::move(file_type_p)) {}
+    std::string file_type;
+};
+
+// module.cpp:296-318
+static void Register(const std::string &name, const std::string &file_type, Catalog &catalog) {
+    TableFunction scan;
+    scan.name = name;
+    scan.arguments = {LogicalType(LogicalTypeId::VARCHAR)};
+    scan.bind = [](TableFunctionBindInput &input, std::vector<LogicalType> &return_types, std::vector<std::string> &names) {
+        auto &info = static_cast<const WTArrowTableScanInfo &>(*input.info);
+        std::string compression;
+        for (auto &kv : input.named_parameters)
+            if (kv.first == "compression") compression = kv.second;
+        return std::unique_ptr<FunctionData>(TF::Bind(input.inputs.at(0), compression, info.file_type, return_types, names));
+    };
+    scan.init_global = [](TableFunctionInitInput &input) {
+        return std::unique_ptr<GlobalTableFunctionState>(
+            TF::InitGlobal(static_cast<const TF::BindData &>(*input.bind_data), input.column_ids, input.filters));
+    };
+    scan.init_local = [](TableFunctionInitInput &input, GlobalTableFunctionState *gs) {
+        return std::unique_ptr<LocalTableFunctionState>(
+            TF::InitLocal(static_cast<const TF::BindData &>(*input.bind_data), static_cast<TF::GlobalState &>(*gs)));
+    };
+    scan.function = [](TableFunctionInput &input, DataChunk &output) {
+        TF::Scan(static_cast<const TF::BindData &>(*input.bind_data), static_cast<TF::GlobalState &>(*input.global_state),
+                 static_cast<TF::LocalState *>(input.local_state), output);
+    };
+    scan.get_batch_index = [](const FunctionData *, LocalTableFunctionState *ls, GlobalTableFunctionState *) {
+        return TF::BatchIndex(static_cast<const TF::LocalState &>(*ls));
+    };
+    scan.function_info = std::make_shared<WTArrowTableScanInfo>(file_type);
+    scan.named_parameters["compression"] = LogicalType(LogicalTypeId::VARCHAR);
+    scan.projection_pushdown = true;
+    scan.filter_pushdown = true;  // module.cpp:311; the predicate is evaluated on the device
+    catalog.CreateTableFunction(scan);
+}
+
+// exon/src/exon_extension.cpp:25-96, restricted to the path
+void LoadInternal(Catalog &catalog) {
+    for (const auto &reg : exon_scan::kRegistrations) Register(reg.name, reg.file_type, catalog);
+}
+
+}  // namespace exon_amd
+
+// ---- C entry points used by the Python parity tests (exon_duckdb_amd/table_function.py) ---------------------------
+using namespace exon_amd;
+
+struct exon_tf_local {
+    std::unique_ptr<LocalTableFunctionState> state;
+    DataChunk chunk;
+    std::vector<std::unique_ptr<exg_vector[]>> vec_nodes;
+    exg_vector vec_roots[16];
+};
+
+struct exon_tf_handle {
+    const TableFunction *fn = nullptr;
+    std::unique_ptr<FunctionData> bind_data;
+    std::unique_ptr<GlobalTableFunctionState> global;
+    TableFunctionInitInput init;
+    TableFilterSet filter_set;
+    std::vector<std::unique_ptr<exon_tf_local>> locals;
+    std::mutex mu;
+    std::vector<LogicalType> types;
+    std::vector<std::string> names;
+    // exg_type trees handed to the Python side
+    std::vector<std::unique_ptr<exg_type[]>> type_nodes;
+    exg_type type_roots[16];
+};
+
+static thread_local std::string g_tf_error;
+extern "C" const char *exon_tf_last_error(void) { return g_tf_error.c_str(); }
+
+static void export_type(exon_tf_handle *h, const LogicalType &t, const char *name, exg_type *out) {
+    memset(out, 0, sizeof *out);
+    out->type = (int)t.id;
+    out->name = name;
+    out->nullable = 1;
+    if (t.children.empty()) return;
+    h->type_nodes.emplace_back(new exg_type[t.children.size()]);
+    exg_type *kids = h->type_nodes.back().get();
+    for (size_t i = 0; i < t.children.size(); i++)
+        export_type(h, t.children[i].second, t.id == LogicalTypeId::LIST ? "item" : t.children[i].first.c_str(), &kids[i]);
+    out->n_children = (int)t.children.size();
+    out->children = kids;
+}
+static void export_vector(exon_tf_local *l, const Vector &v, exg_vector *out) {
+    memset(out, 0, sizeof *out);
+    out->data = v.data;
+    out->validity = v.validity;
+    out->length = v.length;
+    if (v.children.empty()) return;
+    l->vec_nodes.emplace_back(new exg_vector[v.children.size()]);
+    exg_vector *kids = l->vec_nodes.back().get();
+    for (size_t i = 0; i < v.children.size(); i++) export_vector(l, v.children[i], &kids[i]);
+    out->n_children = (int)v.children.size();
+    out->children = kids;
+}
+
+static Catalog &the_catalog() {
+    static Catalog c = [] {
+        Catalog x;
+        LoadInternal(x);
+        return x;
+    }();
+    return c;
+}
+
+extern "C" int exon_tf_catalog_has(const char *name) { return the_catalog().GetTableFunction(name) != nullptr; }
+
+extern "C" int exon_tf_bind(const char *fn_name, const char *path, const char *compression, exon_tf_handle **out) {
+    *out = nullptr;
+    const TableFunction *fn = the_catalog().GetTableFunction(fn_name);
+    if (!fn) {
+        g_tf_error = std::string("Catalog Error: Table Function with name ") + fn_name + " does not exist!";
+        return EXG_E_INVALID_ARG;
+    }
+    auto h = std::make_unique<exon_tf_handle>();
+    h->fn = fn;
+    TableFunctionBindInput in;
+    in.inputs.push_back(path);
+    if (compression) in.named_parameters["compression"] = compression;
+    in.info = fn->function_info.get();
+    try {
+        h->bind_data = fn->bind(in, h->types, h->names);
+    } catch (const std::exception &e) {
+        g_tf_error = e.what();
+        return EXG_E_IO;
+    }
+    *out = h.release();
+    return EXG_OK;
+}
+
+extern "C" int exon_tf_schema(exon_tf_handle *h, exg_schema *out) {
+    memset(out, 0, sizeof *out);
+    out->n_columns = (int)h->names.size();
+    h->type_nodes.clear();
+    for (int i = 0; i < out->n_columns; i++) {
+        out->names[i] = h->names[i].c_str();
+        out->types[i] = (int)h->types[i].id;
+        export_type(h, h->types[i], out->names[i], &h->type_roots[i]);
+        out->tree[i] = &h->type_roots[i];
+    }
+    return EXG_OK;
+}
+
+// A TableFilterSet, described as a flat pre-order list of nodes:
+//   kind 0 constant comparison (cmp = ExpressionType value, constant text, const_type = column type id),
+//   1 IS NULL, 2 IS NOT NULL, 3 OR / 4 AND with n_children following nodes; `column` = key of the set
+//   (index into column_ids) on top-level nodes.
+struct exon_tf_filter_node {
+    int kind, column, cmp, const_type, n_children;
+    const char *constant;
+};
+static std::unique_ptr<TableFilter> build_filter(const exon_tf_filter_node *nodes, int n, int *pos) {
+    if (*pos >= n) throw std::runtime_error("malformed filter description");
+    const exon_tf_filter_node &nd = nodes[(*pos)++];
+    switch (nd.kind) {
+        case 0: {
+            Value v;
+            v.type = (LogicalTypeId)nd.const_type;
+            v.str = nd.constant ? nd.constant : "";
+            if (v.type == LogicalTypeId::BIGINT) v.i = strtoll(v.str.c_str(), nullptr, 10);
+            if (v.type == LogicalTypeId::FLOAT) v.f = strtod(v.str.c_str(), nullptr);
+            return std::make_unique<ConstantFilter>((ExpressionType)nd.cmp, v);
+        }
+        case 1: return std::make_unique<IsNullFilter>();
+        case 2: return std::make_unique<IsNotNullFilter>();
+        default: {
+            auto cj = std::make_unique<ConjunctionFilter>(nd.kind == 4 ? TableFilterType::CONJUNCTION_AND : TableFilterType::CONJUNCTION_OR);
+            for (int k = 0; k < nd.n_children; k++) cj->child_filters.push_back(build_filter(nodes, n, pos));
+            return cj;
+        }
+    }
+}
+
+// init_global (DuckDB calls it once, on the thread that starts the pipeline).  Returns MaxThreads() in *max_threads.
+extern "C" int exon_tf_init_global(exon_tf_handle *h, const uint64_t *column_ids, int n, const exon_tf_filter_node *nodes, int n_nodes,
+                                   uint64_t *max_threads) {
+    h->init.bind_data = h->bind_data.get();
+    h->init.column_ids.assign(column_ids, column_ids + n);
+    try {
+        if (!h->fn->filter_pushdown && n_nodes) throw std::runtime_error("filter pushdown is off for this function");
+        int pos = 0;
+        while (pos < n_nodes) {
+            const idx_t key = (idx_t)nodes[pos].column;
+            h->filter_set.filters[key] = build_filter(nodes, n_nodes, &pos);
+        }
+        h->init.filters = n_nodes ? &h->filter_set : nullptr;
+        h->global = h->fn->init_global(h->init);
+    } catch (const std::exception &e) {
+        g_tf_error = e.what();
+        return EXG_E_IO;
+    }
+    if (max_threads) *max_threads = h->global->MaxThreads();
+    return EXG_OK;
+}
+
+// init_local: once per scan thread (<= MaxThreads()), on that thread.  *local_id identifies the thread's state.
+extern "C" int exon_tf_init_local(exon_tf_handle *h, int *local_id) {
+    auto l = std::make_unique<exon_tf_local>();
+    try {
+        l->state = h->fn->init_local(h->init, h->global.get());
+    } catch (const std::exception &e) {
+        g_tf_error = e.what();
+        return EXG_E_IO;
+    }
+    std::lock_guard<std::mutex> g(h->mu);
+    h->locals.push_back(std::move(l));
+    *local_id = (int)h->locals.size() - 1;
+    return EXG_OK;
+}
+
+// One call of TableFunction::function on a thread's local state.  n_rows == 0 => that thread's stream has ended.
+// data / validity / vectors follow column_ids order; *batch_index = get_batch_index after the call.
+extern "C" int exon_tf_scan(exon_tf_handle *h, int local_id, exg_chunk *out, uint64_t *batch_index) {
+    memset(out, 0, sizeof *out);
+    exon_tf_local *l;
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        l = h->locals.at((size_t)local_id).get();
+    }
+    TableFunctionInput in;
+    in.bind_data = h->bind_data.get();
+    in.local_state = l->state.get();
+    in.global_state = h->global.get();
+    try {
+        h->fn->function(in, l->chunk);
+    } catch (const std::exception &e) {
+        g_tf_error = e.what();
+        return EXG_E_PARSE;
+    }
+    out->n_rows = l->chunk.size();
+    out->n_columns = (int)l->chunk.data.size();
+    l->vec_nodes.clear();
+    for (int i = 0; i < out->n_columns && i < 16; i++) {
+        out->data[i] = l->chunk.data[i].data;
+        out->validity[i] = l->chunk.data[i].validity;
+        export_vector(l, l->chunk.data[i], &l->vec_roots[i]);
+        out->vectors[i] = &l->vec_roots[i];
+    }
+    if (batch_index) *batch_index = h->fn->get_batch_index(in.bind_data, in.local_state, in.global_state);
+    return EXG_OK;
+}
+
+extern "C" void exon_tf_close(exon_tf_handle *h) { delete h; }
+
+extern "C" int exon_replacement_scan(const char *table_name, char *out_fn, size_t cap) {
+    std::string f = TF::ReplacementFunction(table_name);
+    if (f.empty() || f.size() + 1 > cap) return 0;
+    memcpy(out_fn, f.c_str(), f.size() + 1);
+    return 1;
+}

@@ -148,33 +148,41 @@ def _flatten(node, column, const_type, out):
             _flatten(ch, column, const_type, out)
 
 
-_bound = False
+_tf = None
 
 
 def _lib():
-    global _bound
-    l = load_library()
-    if not _bound:
+    """libexon_tf_test.so: the table-function glue (csrc/exon_table_function.hpp) instantiated over the DuckDB API slice
+    of csrc/testing/duck_mini.hpp — test scaffolding, built next to the product library and linked against it."""
+    global _tf
+    if _tf is None:
+        import os
+        load_library()  # the product library first (the harness links against it)
+        from . import build as _build
+        if not os.path.exists(_build.TEST_LIB):
+            _build.build(verbose=False)
+        l = C.CDLL(_build.TEST_LIB)
+        l.exon_tf_last_error.restype = C.c_char_p
         l.exon_tf_catalog_has.restype = C.c_int
         l.exon_tf_catalog_has.argtypes = [C.c_char_p]
         l.exon_tf_bind.restype = C.c_int
         l.exon_tf_bind.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
         l.exon_tf_schema.argtypes = [C.c_void_p, C.POINTER(Schema)]
-        l.exon_tf_init.restype = C.c_int
-        l.exon_tf_init.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
-        l.exon_tf_init_filtered.restype = C.c_int
-        l.exon_tf_init_filtered.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int, C.POINTER(FilterNode), C.c_int]
+        l.exon_tf_init_global.restype = C.c_int
+        l.exon_tf_init_global.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int, C.POINTER(FilterNode), C.c_int, C.POINTER(C.c_uint64)]
+        l.exon_tf_init_local.restype = C.c_int
+        l.exon_tf_init_local.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         l.exon_tf_scan.restype = C.c_int
-        l.exon_tf_scan.argtypes = [C.c_void_p, C.POINTER(Chunk)]
+        l.exon_tf_scan.argtypes = [C.c_void_p, C.c_int, C.POINTER(Chunk), C.POINTER(C.c_uint64)]
         l.exon_tf_close.argtypes = [C.c_void_p]
         l.exon_replacement_scan.restype = C.c_int
         l.exon_replacement_scan.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
-        _bound = True
-    return l
+        _tf = l
+    return _tf
 
 
 def _err(l):
-    return l.exg_last_error_message().decode("utf-8", "replace")
+    return (l.exon_tf_last_error() or b"").decode("utf-8", "replace")
 
 
 def _decode_strings(ptr, validity_ptr, n):
@@ -212,7 +220,10 @@ class Relation:
         self.trees = [type_tree(sch.tree[i].contents) for i in range(sch.n_columns)]
         self._l.exon_tf_close(h)
 
-    def _scan(self, column_ids, filters=None):
+    def _scan(self, column_ids, filters=None, decode=None):
+        """Plays DuckDB: init_global once, init_local + the scan loop on MaxThreads() threads (one per shard the glue
+        planned), every chunk handed to `decode` while it is alive.  -> [(batch_index, n_rows, decoded)] in batch order."""
+        import threading
         h = C.c_void_p()
         rc = self._l.exon_tf_bind(self.fn_name.encode(), self.path.encode(),
                                   self.compression.encode() if self.compression else None, C.byref(h))
@@ -220,25 +231,47 @@ class Relation:
             raise ExgError(rc, _err(self._l))
         try:
             ids = (C.c_uint64 * len(column_ids))(*column_ids)
-            if filters:
+            nodes = []
+            for name, node in (filters or {}).items():
                 # TableFilterSet: keyed by the position of the column in column_ids (module.cpp:201-214)
-                nodes = []
-                for name, node in filters.items():
-                    cid = self.names.index(name)
-                    _flatten(node, list(column_ids).index(cid), self.types[cid], nodes)
-                arr = (FilterNode * len(nodes))(*nodes)
-                rc = self._l.exon_tf_init_filtered(h, ids, len(column_ids), arr, len(nodes))
-            else:
-                rc = self._l.exon_tf_init(h, ids, len(column_ids))
-            if rc != 0:
+                cid = self.names.index(name)
+                _flatten(node, list(column_ids).index(cid), self.types[cid], nodes)
+            arr = (FilterNode * max(1, len(nodes)))(*nodes)
+            max_threads = C.c_uint64(1)
+            if self._l.exon_tf_init_global(h, ids, len(column_ids), arr, len(nodes), C.byref(max_threads)) != 0:
                 raise ExgError(abi.EXG_E_IO, _err(self._l))
-            while True:
-                ch = Chunk()
-                if self._l.exon_tf_scan(h, C.byref(ch)) != 0:
-                    raise ExgError(abi.EXG_E_PARSE, _err(self._l))
-                if ch.n_rows == 0:
+            self.last_max_threads = int(max_threads.value)
+            out, errors = [], []
+            lock = threading.Lock()
+
+            def worker():
+                lid = C.c_int(0)
+                if self._l.exon_tf_init_local(h, C.byref(lid)) != 0:
+                    with lock:
+                        errors.append(ExgError(abi.EXG_E_IO, _err(self._l)))
                     return
-                yield ch
+                while True:
+                    ch = Chunk()
+                    bi = C.c_uint64(0)
+                    if self._l.exon_tf_scan(h, lid, C.byref(ch), C.byref(bi)) != 0:
+                        with lock:
+                            errors.append(ExgError(abi.EXG_E_PARSE, _err(self._l)))
+                        return
+                    if ch.n_rows == 0:
+                        return
+                    item = (int(bi.value), int(ch.n_rows), decode(ch) if decode else None)
+                    with lock:
+                        out.append(item)
+
+            threads = [threading.Thread(target=worker) for _ in range(self.last_max_threads)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            if errors:
+                raise errors[0]
+            out.sort(key=lambda x: x[0])
+            return out
         finally:
             self._l.exon_tf_close(h)
 
@@ -247,25 +280,27 @@ class Relation:
         ids = [ROW_ID]
         if filters:
             ids += [self.names.index(c) for c in filters]
-        return sum(int(ch.n_rows) for ch in self._scan(ids, filters))
+        return sum(n for _, n, _ in self._scan(ids, filters))
 
     def chunk_sizes(self, columns=None):
         cols = self.names if columns is None else columns
-        return [int(ch.n_rows) for ch in self._scan([self.names.index(c) for c in cols])]
+        return [n for _, n, _ in self._scan([self.names.index(c) for c in cols])]
 
     def fetchall(self, columns=None, limit=None, where=None, filters=None):
-        """SELECT columns ... [WHERE where(row_dict)] [LIMIT limit] -> list of tuples (bytes/None/int/float).
-        `filters` = {column: F....}: pushed down into the scan like DuckDB's TableFilterSet; `where` = a Python
-        predicate applied above the scan."""
+        """SELECT columns ... [WHERE where(row_dict)] [LIMIT limit] -> list of tuples (bytes/None/int/float/list/dict),
+        in file order (chunks sorted by get_batch_index).  `filters` = {column: F....}: pushed down into the scan like
+        DuckDB's TableFilterSet; `where` = a Python predicate applied above the scan."""
         cols = self.names if columns is None else columns
         ids = [self.names.index(c) for c in cols]
         for c in (filters or {}):                     # DuckDB keeps filter columns in column_ids
             if self.names.index(c) not in ids:
                 ids.append(self.names.index(c))
+
+        def decode(ch):
+            return [decode_vector(ch.vectors[k].contents, self.trees[cid]) for k, cid in enumerate(ids[:len(cols)])]
+
         rows = []
-        for ch in self._scan(ids, filters):
-            n = int(ch.n_rows)
-            decoded = [decode_vector(ch.vectors[k].contents, self.trees[cid]) for k, cid in enumerate(ids[:len(cols)])]
+        for _, n, decoded in self._scan(ids, filters, decode):
             for i in range(n):
                 row = tuple(d[i] for d in decoded)
                 if where is None or where(dict(zip(cols, row))):

@@ -372,3 +372,80 @@ def test_gzip_vcf_with_a_header_longer_than_the_first_host_prefix(con, oracle, t
         assert rel.count() == 3000
         assert rel.fetchall() == plain
     assert plain[0][0] == exp.columns["chrom"].row(0)
+
+
+# ---- several scan threads inside one process: init_global plans shards, every init_local opens its shard on its device ----
+
+def test_small_inputs_scan_on_one_thread(con, golden_dir):
+    rel = con.table_function("read_fastq", G(golden_dir, "test.fastq"))
+    assert rel.count() == 2 and rel.last_max_threads == 1      # MaxThreads() == 1: nothing to shard
+
+
+@pytest.mark.parametrize("n_shards", [2, 5])
+def test_parallel_scan_threads_partition_the_rows(con, oracle, tmp_path, monkeypatch, n_shards):
+    """EXON_GPU_SHARDS forces what a multi-GPU box plans by itself (one shard per device): MaxThreads() scan threads, each
+    with its own reader on its own byte range; together they return the unsharded rows, in file order by batch index,
+    and COUNT(*) is the sum of the shards' counts."""
+    import gzip
+    fq = bytes(oracle.synth_fastq(332 * 30000))
+    vcf = bytes(oracle.synth_vcf(20000))
+    fa = bytes(oracle.synth_fasta(3000, seed=77))
+    (tmp_path / "p.fastq").write_bytes(fq)
+    (tmp_path / "p.vcf").write_bytes(vcf)
+    (tmp_path / "p.fasta").write_bytes(fa)
+    (tmp_path / "one.fastq.gz").write_bytes(gzip.compress(fq[:332 * 3000], mtime=0))   # not BGZF: one shard
+    want = {}
+    for name, fn in (("p.fastq", "read_fastq"), ("p.vcf", "read_vcf"), ("p.fasta", "read_fasta")):
+        rel = con.table_function(fn, str(tmp_path / name))
+        want[name] = rel.fetchall()
+        assert rel.last_max_threads == 1
+    monkeypatch.setenv("EXON_GPU_SHARDS", str(n_shards))
+    monkeypatch.setenv("EXG_DEVICE_BATCH_BYTES", str(1 << 20))
+    for name, fn in (("p.fastq", "read_fastq"), ("p.vcf", "read_vcf"), ("p.fasta", "read_fasta")):
+        rel = con.table_function(fn, str(tmp_path / name))
+        rows = rel.fetchall()
+        assert rel.last_max_threads == n_shards
+        assert rows == want[name], name
+        assert rel.count() == len(want[name])
+    rel = con.table_function("read_fastq", str(tmp_path / "one.fastq.gz"))
+    assert rel.count() == 3000 and rel.last_max_threads == 1
+    # a pushed-down filter runs in every shard
+    from exon_duckdb_amd.table_function import F
+    rel = con.table_function("read_vcf", str(tmp_path / "p.vcf"))
+    got = rel.fetchall(columns=["chrom", "pos"], filters={"chrom": F.cmp("=", b"7")})
+    assert got == [(c, p) for c, p, *_ in want["p.vcf"] if c == b"7"] and len(got) > 0
+
+
+def test_parallel_scan_of_bgzf(con, oracle, tmp_path, monkeypatch):
+    from test_reader_shards_gpu import _bgzf as bgzf
+    fq = bytes(oracle.synth_fastq(332 * 20000))
+    (tmp_path / "b.fastq.gz").write_bytes(bgzf(fq, 65280))
+    rel = con.table_function("read_fastq", str(tmp_path / "b.fastq.gz"))
+    want = rel.fetchall()
+    assert len(want) == 20000
+    monkeypatch.setenv("EXON_GPU_SHARDS", "4")
+    rel = con.table_function("read_fastq", str(tmp_path / "b.fastq.gz"))
+    assert rel.fetchall() == want and rel.last_max_threads == 4
+    assert rel.count() == 20000
+
+
+def test_plan_shards_policy(gpu, golden_dir, tmp_path, monkeypatch):
+    import ctypes as C
+    from exon_duckdb_amd.abi import OpenArgs
+    gpu.exg_plan_shards.argtypes = [C.POINTER(OpenArgs), C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.c_uint32]
+
+    def plan(path, fmt, compression=None):
+        a = OpenArgs(path.encode(), fmt.encode(), compression, 2048, 0, 0, None, 0, 0)
+        n = C.c_uint32(0)
+        dev = (C.c_int * 64)()
+        assert gpu.exg_plan_shards(C.byref(a), C.byref(n), dev, 64) == 0
+        return n.value, list(dev[:n.value])
+
+    assert plan(G(golden_dir, "test.fastq"), "fastq") == (1, [0])
+    monkeypatch.setenv("EXON_GPU_SHARDS", "3")
+    n_dev = gpu.exg_device_count()
+    assert plan(G(golden_dir, "test.fastq"), "fastq") == (3, [i % n_dev for i in range(3)])
+    assert plan(G(golden_dir, "vcf/index.vcf.gz"), "vcf")[0] == 3            # BGZF: members carry their size
+    assert plan(G(golden_dir, "test.fastq.gz"), "fastq")[0] == 1             # plain gzip: not sharded
+    assert plan(G(golden_dir, "test.fastq.zst"), "fastq")[0] == 1            # zstd: not sharded
+    assert plan(G(golden_dir, "test.fasta.gz"), "fasta")[0] == 1
