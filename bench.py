@@ -1,30 +1,42 @@
 #!/usr/bin/env python3
 """bench.py — FASTQ records/s into DataChunk column vectors on MI355X (BASELINE.json metric).
 
-A step = one pass of the hot path (exg_fastq_scan through the C-ABI) over one device-resident
-batch of synthetic 150 bp FASTQ (332 B/record, generated in HBM by exg_synth_fastq).  N=1 runs
-BASELINE configs[1] (10 GB on one MI355X).  N>1: one process per GPU (torch.distributed, RCCL),
-the file is byte-range sharded — each rank scans its own 10 GB shard of an N x 10 GB file whose
-cut points are NOT record aligned (1 KiB halo, global line phase from the shard-local structure,
-verified by an all_gather of the newline counts) — weak scaling, no collective on the data path;
-one all_reduce of the record counts per step (the COUNT(*) of config 5).
+Headline (`value`): a step = `launches_per_step` passes of the hot path (exg_fastq_scan through the C-ABI) over one
+device-resident batch of synthetic 150 bp FASTQ (332 B/record, generated in HBM by exg_synth_fastq); the default 20 steps
+x 20 launches keep the timed region above one second.  N=1 runs BASELINE configs[1] (10 GB on one MI355X).  N>1: one
+process per GPU (torch.distributed, RCCL); the file is byte-range sharded, 12.5 GB per GPU (N=8 is configs[4]: 100 GB) —
+each rank scans its own shard of the N x 12.5 GB file whose cut points are NOT record aligned (1 KiB halo, global line
+phase from the shard-local structure, verified by an all_gather of the newline counts) — weak scaling, no collective on
+the data path; one all_reduce of the record counts per launch (the COUNT(*) of config 5).  After the timed loop the
+output of the last launch is verified on the device against the generator's closed forms (`verified`).
+
+Beside it (rank 0, N=1, skipped with --no-configs): `configs` — BASELINE configs[0] (SELECT COUNT(*) on a 1 MB FASTA
+through the reader: latency), configs[2] (8-column VCF scan, 5 GB generated in HBM by exg_synth_vcf) and configs[3]
+(read_fastq on BGZF: members deflated on the host cores, inflated + scanned on the device, COUNT(*) through the reader) —
+and `end_to_end` (FASTQ file in the page cache -> host DataChunks through exg_open / exg_next_chunk, PCIe inclusive;
+never `value`).  With N>1 the same file-level leg runs sharded (`reader_sharded`: every rank opens the same file with
+shard_index = rank).  `cpu_baseline` times the oracle (CPU restatement) on the host cores.
 """
 import argparse
+import ctypes as C
 import json
 import os
+import struct
 import sys
+import tempfile
 import time
+import zlib
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 REC = 332
+BASE = 0x100000000000  # payload_base of the device-level launches
 
 
 def cpu_baseline(seconds_target=12.0):
     """Oracle ("port") timed on one host core, like the reference (one core per file)."""
-    import numpy as np
     from oracle import pyoracle
 
     n_rec = 1_000_000  # 332 MB sample of the same workload
@@ -59,14 +71,235 @@ def cpu_baseline(seconds_target=12.0):
     }
 
 
+def verify_fastq(torch, scan, n_rec, base, first_record):
+    """The columns the last launch left in HBM against the generator's closed forms, every row: record r of this buffer
+    is global record k = first_record + r of the synthetic file; its four string_t hold the field lengths 15 / 10 / 150 /
+    150, out-of-line pointers base + 332 k + field offset, the name prefix "SYN" + first digit of k, the inlined
+    description "d:N:0:ACGT" with d = k mod 4; every description is valid."""
+    k = first_record + torch.arange(n_rec, device="cuda", dtype=torch.int64)
+    ok = True
+    for col, (off, ln) in zip(scan.cols, [(1, 15), (17, 10), (28, 150), (181, 150)]):
+        c = col[:n_rec]
+        ok &= bool(((c[:, 0] & 0xFFFFFFFF) == ln).all())
+        if ln > 12:
+            ok &= bool((c[:, 1] == base + REC * k + off).all())
+    first_digit = (k // 10 ** 11) % 10
+    want_prefix = 0x53 | (0x59 << 8) | (0x4E << 16) | ((0x30 + first_digit) << 24)
+    ok &= bool((((scan.cols[0][:n_rec, 0] >> 32) & 0xFFFFFFFF) == want_prefix).all())
+    want_desc = (0x30 + (k & 3)) | (0x3A << 8) | (0x4E << 16) | (0x3A << 24)
+    ok &= bool((((scan.cols[1][:n_rec, 0] >> 32) & 0xFFFFFFFF) == want_desc).all())
+    words = (n_rec + 63) // 64
+    if words > 1:
+        ok &= bool((scan.validity[: words - 1] == -1).all())
+    return ok
+
+
+def timed_launches(torch, fn, reps, warm=2):
+    """average device time of fn() in ms, HIP events on the launch stream"""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in ev)
+    return sum(ms) / len(ms), ms[0]
+
+
+def open_reader(lib, path, fmt, shard=(0, 1), device_index=0):
+    from exon_duckdb_amd import abi
+    lib.exg_open.argtypes = [C.POINTER(abi.OpenArgs), C.POINTER(C.c_void_p)]
+    lib.exg_count_only.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.exg_drain_chunks.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.exg_close.argtypes = [C.c_void_p]
+    a = abi.OpenArgs(path.encode(), fmt.encode(), None, 2048, device_index, 0, None, shard[0], shard[1])
+    r = C.c_void_p()
+    rc = lib.exg_open(C.byref(a), C.byref(r))
+    assert rc == 0, lib.exg_last_error_message()
+    return r
+
+
+def reader_count(lib, path, fmt, shard=(0, 1), device_index=0):
+    r = open_reader(lib, path, fmt, shard, device_index)
+    n = C.c_uint64(0)
+    t0 = time.perf_counter()
+    rc = lib.exg_count_only(r, C.byref(n))
+    dt = time.perf_counter() - t0
+    assert rc == 0, lib.exg_last_error_message()
+    lib.exg_close(r)
+    return int(n.value), dt
+
+
+def reader_chunks(lib, path, fmt, shard=(0, 1), device_index=0):
+    r = open_reader(lib, path, fmt, shard, device_index)
+    rows, chunks = C.c_uint64(0), C.c_uint64(0)
+    t0 = time.perf_counter()
+    rc = lib.exg_drain_chunks(r, C.byref(rows), C.byref(chunks))
+    dt = time.perf_counter() - t0
+    assert rc == 0, lib.exg_last_error_message()
+    lib.exg_close(r)
+    return int(rows.value), int(chunks.value), dt
+
+
+def scratch_dir(need_bytes=0):
+    """a directory for the file-level legs: shared memory when it has the room, else the temp dir -> (path, free bytes)"""
+    import shutil
+    best = None
+    for d in ("/dev/shm", tempfile.gettempdir()):
+        if os.path.isdir(d) and os.access(d, os.W_OK):
+            free = shutil.disk_usage(d).free
+            if best is None or (best[1] < need_bytes and free > best[1]):
+                best = (d, free)
+    return tempfile.mkdtemp(prefix="exg_bench_", dir=best[0]), best[1]
+
+
+def write_device_bytes(torch, t, n, path):
+    """device tensor -> file, through 1 GiB host slices"""
+    with open(path, "wb") as f:
+        for o in range(0, n, 1 << 30):
+            f.write(t[o:min(n, o + (1 << 30))].cpu().numpy().tobytes())
+
+
+def _bgzf_worker(args):
+    path, lo, hi, out_path = args
+    with open(path, "rb") as f, open(out_path, "wb") as out:
+        f.seek(lo)
+        left = hi - lo
+        while left > 0:
+            chunk = f.read(min(65280, left))
+            left -= len(chunk)
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            d = co.compress(chunk) + co.flush()
+            out.write(b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(d) + 8 - 1)
+                      + d + struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+    return os.path.getsize(out_path)
+
+
+def build_bgzf(plain_path, n_bytes, out_path, workers):
+    """BASELINE config 4's input: the FASTQ stream cut into 65 280-byte members, each deflated (zlib level 6) with BGZF
+    framing, by `workers` host processes (input preparation; not timed)."""
+    import multiprocessing as mp
+    per = (n_bytes // workers + 65279) // 65280 * 65280
+    jobs = [(plain_path, lo, min(n_bytes, lo + per), f"{out_path}.part{i}") for i, lo in enumerate(range(0, n_bytes, per))]
+    with mp.get_context("spawn").Pool(min(workers, len(jobs))) as pool:
+        sizes = pool.map(_bgzf_worker, jobs)
+    with open(out_path, "wb") as out:
+        for (_, _, _, part), sz in zip(jobs, sizes):
+            with open(part, "rb") as f:  # in-kernel copy (tmpfs -> tmpfs)
+                done = 0
+                while done < sz:
+                    done += os.sendfile(out.fileno(), f.fileno(), done, min(sz - done, 1 << 30))
+            os.unlink(part)
+        out.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))  # the BGZF end marker
+    return sum(sizes) + 28
+
+
+def run_configs(torch, lib, args):
+    """BASELINE configs 1, 3, 4 and the end-to-end leg on one GPU -> dicts for the bench line"""
+    from exon_duckdb_amd import abi, device
+    out = {}
+    cores = os.cpu_count() or 1
+    n_e2e = int(args.e2e_gb * 1e9) // REC * REC
+    budget = cores * 30e6 * 25                       # config 4's input: ~25 s of host deflate at ~30 MB/s per core
+    n_gz_in = int(min(args.gz_gb * 1e9 * 1.93, budget)) // REC * REC
+    tmp, free = scratch_dir(int(1.6 * max(n_e2e, n_gz_in)))
+    if 1.6 * max(n_e2e, n_gz_in) > 0.8 * free:      # (plain file + its BGZF form must fit)
+        n_gz_in = n_e2e = int(0.8 * free / 1.6) // REC * REC
+    try:
+        # ---- config 1: SELECT COUNT(*) FROM read_fasta() on a 1 MB FASTA (plumbing + latency) -----------------------
+        d_fa, n_fa = device.synth_fasta(600)
+        p_fa = os.path.join(tmp, "c1.fasta")
+        write_device_bytes(torch, d_fa, n_fa, p_fa)
+        ts = []
+        for _ in range(25):
+            n, dt = reader_count(lib, p_fa, "fasta")
+            assert n == 600
+            ts.append(dt)
+        ts.sort()
+        scan = device.FastaScan(n_fa)
+        ms, _ = timed_launches(torch, lambda: scan.launch(d_fa, payload_base=BASE), 20)
+        res = scan.fetch()
+        out["config1_fasta_1MB_count"] = {
+            "workload": f"SELECT COUNT(*) FROM read_fasta('{n_fa} B synthetic FASTA, 600 records'): open + upload + scan + close",
+            "algorithmic_bytes": n_fa, "ms": ts[len(ts) // 2] * 1e3, "ms_min": ts[0] * 1e3, "device_scan_ms": ms,
+            "GB/s": n_fa / (ts[len(ts) // 2]) / 1e9, "frac": None, "verified": bool(res.n_records == 600 and res.error_code == 0)}
+        del d_fa, scan
+        # ---- config 3: read_vcf 8-column scan, 5 GB generated in HBM (non-periodic) --------------------------------
+        n_lines = int(args.vcf_gb * 1e9 / 48.65)
+        d_vcf, n_vcf = device.synth_vcf(n_lines)
+        hdr = bytes(d_vcf[:4096].cpu().numpy()).index(b"#CHROM")
+        hdr = hdr + bytes(d_vcf[hdr:hdr + 256].cpu().numpy()).index(b"\n") + 1
+        vs = device.VcfScan(n_vcf, capacity_records=n_lines + 16)
+        ms, ms_min = timed_launches(torch, lambda: vs.launch(d_vcf, n_bytes=n_vcf, lead=hdr, payload_base=BASE), 8)
+        res = vs.fetch()
+        per_chrom = n_lines // 22 + 1
+        i = torch.arange(n_lines, device="cuda", dtype=torch.int64)
+        pos_ok = bool((((vs.pos[:n_lines] - 1) // 37) == (i % per_chrom)).all())   # POS = (i mod per_chrom) * 37 + 1 + (h & 31)
+        chrom = i // per_chrom + 1                                               # CHROM = i / per_chrom + 1, inlined decimal
+        c0 = vs.cols[0][:n_lines, 0]
+        want = torch.where(chrom < 10, 1 | ((0x30 + chrom) << 32), 2 | ((0x30 + chrom // 10) << 32) | ((0x30 + chrom % 10) << 40))
+        chrom_ok = bool((c0 == want).all())
+        out["config3_vcf_8col"] = {
+            "workload": f"read_vcf 8(+1)-column scan, {n_vcf / 1e9:.2f} GB synthetic VCF ({n_lines} lines, exg_synth_vcf), all columns + typed POS / QUAL",
+            "algorithmic_bytes": n_vcf, "ms": ms, "ms_min": ms_min, "GB/s": n_vcf / (ms * 1e-3) / 1e9,
+            "frac": n_vcf / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "lines_per_s": n_lines / (ms * 1e-3),
+            "verified": bool(res.error_code == 0 and res.n_records == n_lines and pos_ok and chrom_ok)}
+        del d_vcf, vs, i, chrom, c0, want
+        torch.cuda.empty_cache()
+        # ---- end to end: FASTQ file in the page cache -> host DataChunks (PCIe inclusive) -------------------------------
+        n_file = max(n_e2e, n_gz_in)                  # one file serves both legs: config 4 deflates its first n_gz_in bytes
+        p_fq = os.path.join(tmp, "e2e.fastq")
+        with open(p_fq, "wb") as f:
+            step = (1 << 30) // REC * REC
+            for o in range(0, n_file, step):
+                m = min(step, n_file - o)
+                f.write(device.synth_fastq(m, file_offset=o)[:m].cpu().numpy().tobytes())
+        n_e2e = n_file
+        torch.cuda.empty_cache()
+        reader_count(lib, p_fq, "fastq")  # warm: pools, page cache
+        n, dt_c = min((reader_count(lib, p_fq, "fastq") for _ in range(3)), key=lambda x: x[1])
+        rows, chunks, dt_r = min((reader_chunks(lib, p_fq, "fastq") for _ in range(3)), key=lambda x: x[2])
+        out["end_to_end"] = {
+            "workload": f"read_fastq, {n_e2e / 1e9:.1f} GB FASTQ-150 file in the page cache -> host DataChunks (exg_open / exg_next_chunk), PCIe inclusive",
+            "algorithmic_bytes": n_e2e, "ms": dt_r * 1e3, "GB/s": n_e2e / dt_r / 1e9, "records_per_s": rows / dt_r, "chunks": chunks,
+            "count_only_ms": dt_c * 1e3, "count_only_GB/s": n_e2e / dt_c / 1e9, "frac": None,
+            "verified": bool(rows == n == n_e2e // REC and chunks >= (rows + 2047) // 2048)}
+        # ---- config 4: read_fastq on BGZF (device inflate feeding the scan) ------------------------------------------------
+        p_gz = os.path.join(tmp, "c4.fastq.gz")
+        t0 = time.perf_counter()
+        comp = build_bgzf(p_fq, n_gz_in, p_gz, max(1, min(cores - 2, 192)))
+        t_build = time.perf_counter() - t0
+        reader_count(lib, p_gz, "fastq")
+        n, dt_g = min((reader_count(lib, p_gz, "fastq") for _ in range(3)), key=lambda x: x[1])
+        out["config4_fastq_bgzf"] = {
+            "workload": f"SELECT COUNT(*) FROM read_fastq('x.fastq.gz'): {comp / 1e9:.2f} GB of BGZF (65 280-byte members, zlib level 6) = "
+                        f"{n_gz_in / 1e9:.2f} GB of FASTQ-150, file in the page cache, inflate + scan on the device",
+            "compressed_bytes": comp, "algorithmic_bytes": comp + 2 * n_gz_in, "ms": dt_g * 1e3, "GB/s": n_gz_in / dt_g / 1e9,
+            "GB/s_compressed": comp / dt_g / 1e9, "records_per_s": n / dt_g, "frac": (comp + 2 * n_gz_in) / dt_g / 1e9 / HBM_PEAK_GBPS,
+            "input_build_s": t_build, "verified": bool(n == n_gz_in // REC)}
+    finally:
+        for f in os.listdir(tmp):
+            os.unlink(os.path.join(tmp, f))
+        os.rmdir(tmp)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--gb", type=float, default=10.0, help="shard size per GPU in GB (1e9 bytes)")
+    ap.add_argument("--launches-per-step", type=int, default=20, help="scan launches per step (keeps the timed region above 1 s)")
+    ap.add_argument("--gb", type=float, default=None, help="shard size per GPU in GB (1e9 bytes); default 10 (N=1), 12.5 (N>1: N=8 is 100 GB)")
     ap.add_argument("--algo", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the configs / end_to_end legs")
+    ap.add_argument("--vcf-gb", type=float, default=5.0)
+    ap.add_argument("--e2e-gb", type=float, default=4.0)
+    ap.add_argument("--gz-gb", type=float, default=10.0, help="config 4: compressed GB asked for (bounded by the e2e file and the host's deflate budget)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; default) | gloo (functional test of the N>1 path)")
     ap.add_argument("--single-device", action="store_true", help="test only: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
@@ -95,17 +328,18 @@ def main():
 
     from exon_duckdb_amd import sharding
 
-    # file = world x args.gb GB of FASTQ-150, cut at 16-byte boundaries (NOT record boundaries)
-    file_bytes = (world * int(args.gb * 1e9)) // REC * REC     # the file ends on a record boundary
+    gb = args.gb if args.gb is not None else (10.0 if world == 1 else 12.5)
+    L = max(1, args.launches_per_step)
+    # file = world x gb GB of FASTQ-150, cut at 16-byte boundaries (NOT record boundaries)
+    file_bytes = int(world * gb * 1e9) // REC * REC     # the file ends on a record boundary
     sh = sharding.plan_shards(file_bytes, world, halo=1024)[rank]
-    halo, start, n_bytes = sh.halo, sh.start, sh.n_bytes
+    halo, n_bytes = sh.halo, sh.n_bytes
     d_in = device.synth_fastq(n_bytes, file_offset=sh.load_offset)
     cap = n_bytes // REC + 16
     scan = device.FastqScan(n_bytes, capacity_records=cap)
 
     # 4-line phase of the shard start, guessed from the shard's own bytes (one tiny kernel, once);
-    # every step re-verifies it against the exact newline counts the scans return (all_gather).
-    import ctypes as C
+    # every launch re-verifies it against the exact newline counts the scans return (all_gather).
     ph = torch.zeros(1, dtype=torch.int32, device="cuda")
     device.check(lib.exg_fastq_guess_phase(C.c_void_p(d_in.data_ptr()), n_bytes, halo, C.c_void_p(ph.data_ptr()),
                                            device.stream_ptr()))
@@ -116,14 +350,26 @@ def main():
     prev_is_nl = True if sh.start == 0 else bool(int(d_in[halo - 1].item()) == 10)
     first_line_index = guess if prev_is_nl else (guess - 1) % 4
     flags = (abi.EXG_F_BOF if sh.is_first else 0) | (abi.EXG_F_EOF if sh.is_last else 0)
+    payload_base = BASE + sh.load_offset
 
-    def step():
+    def launch():
         scan.launch(d_in, n_bytes=n_bytes, lead=halo, first_line_index=first_line_index,
-                    payload_base=0x100000000000 + sh.load_offset, flags=flags, algo=args.algo)
+                    payload_base=payload_base, flags=flags, algo=args.algo)
 
     total = torch.zeros(1, dtype=torch.int64, device=coll_dev)
     lines = torch.zeros(1, dtype=torch.int64, device=coll_dev)
     line_counts = [torch.zeros(1, dtype=torch.int64, device=coll_dev) for _ in range(world)]
+
+    def step():
+        for _ in range(L):
+            launch()
+            if world > 1:
+                # per launch: all_gather of the exact newline counts (verifies the phase guess) and the
+                # COUNT(*) all_reduce — 8 bytes per rank each, no byte of the file crosses xGMI
+                lines.copy_(scan.result[1:2])
+                dist.all_gather(line_counts, lines)
+                total.copy_(scan.result[:1])
+                dist.all_reduce(total)
 
     def barrier():
         if world > 1:
@@ -137,20 +383,10 @@ def main():
     assert res.error_code == 0 and not (res.flags & abi.EXG_RF_FALLBACK), (res.error_code, res.flags)
     n_rec_local = int(res.n_records)
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[i][0].record()
+    for _ in range(args.steps):
         step()
-        ev[i][1].record()
-        if world > 1:
-            # per step: all_gather of the exact newline counts (verifies the phase guess) and the
-            # COUNT(*) all_reduce — 8 bytes per rank each, no byte of the file crosses xGMI
-            lines.copy_(scan.result[1:2])
-            dist.all_gather(line_counts, lines)
-            total.copy_(scan.result[:1])
-            dist.all_reduce(total)
     barrier()
     dt = time.perf_counter() - t0
     res = scan.fetch()
@@ -158,45 +394,51 @@ def main():
     if world > 1:
         exact = sharding.first_line_index_from_counts([int(c.item()) for c in line_counts], rank)
         assert sharding.phase_is_consistent(first_line_index % 4, exact), "phase guess contradicted by the exact counts"
+    # per-launch device time of the scan from HIP events on the launch stream, outside the wall-clock region (recording
+    # 2 x steps x launches events inside it would sit in the measured loop); the dominant kernel is k_fused<FastqFormat>
+    avg_ms, min_ms = timed_launches(torch, launch, 20, warm=0)
+
+    # the columns the last launch left in HBM, every row, against the generator's closed forms: records owned by this
+    # shard are those whose LAST line ends in it
+    verified = verify_fastq(torch, scan, n_rec_local, BASE, _first_owned_record(sh))
 
     t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
     nrec = torch.tensor([n_rec_local], dtype=torch.int64, device=coll_dev)
+    ver = torch.tensor([1 if verified else 0], dtype=torch.int64, device=coll_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(nrec)
+        dist.all_reduce(ver, op=dist.ReduceOp.MIN)
         assert int(total.item()) == int(nrec.item()), "COUNT(*) all_reduce disagrees"
     dt = float(t.item())
     total_records = int(nrec.item())
     assert total_records == file_bytes // REC, (total_records, file_bytes // REC)
+    verified = bool(int(ver.item()))
+    assert verified, "the scan's output differs from the generator's closed forms"
+
+    # reader level, sharded: every rank opens the same file with its rank (file -> COUNT(*) per shard, PCIe inclusive)
+    reader_sharded = None
+    if world > 1 and not args.no_configs:
+        reader_sharded = sharded_reader_leg(torch, dist, lib, device, world, rank, local_rank, coll_dev, args)
 
     if rank == 0:
-        # per-launch device time of the scan (all kernels of one exg_fastq_scan call) from HIP events
-        # on the launch stream; the dominant kernel is k_fastq_fused (see profiles/)
-        ms = sorted(a.elapsed_time(b) for a, b in ev)
-        avg_ms = sum(ms) / len(ms)
         achieved = n_bytes / (avg_ms * 1e-3) / 1e9
         # the same box's read-only stream rate: exg_count_newlines over the same buffer — every
         # byte leaves HBM once, nothing is written
         cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
-        ro = []
-        for i in range(6):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            device.check(lib.exg_count_newlines(C.c_void_p(d_in.data_ptr()), halo, n_bytes, C.c_void_p(cnt.data_ptr()),
-                                                device.stream_ptr()))
-            b.record()
-            torch.cuda.synchronize()
-            if i:
-                ro.append(a.elapsed_time(b))
-        read_only = (n_bytes - halo) / (sum(ro) / len(ro) * 1e-3) / 1e9
-        traffic = None
+        ro_ms, _ = timed_launches(torch, lambda: device.check(lib.exg_count_newlines(C.c_void_p(d_in.data_ptr()), halo, n_bytes,
+                                                                                     C.c_void_p(cnt.data_ptr()), device.stream_ptr())), 5, warm=1)
+        read_only = (n_bytes - halo) / (ro_ms * 1e-3) / 1e9
+        traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_fastq_fused.json")
         if os.path.exists(pmc):
             with open(pmc) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch_10GB")
+                j = json.load(f)
+            traffic = j.get("hbm_bytes_per_launch_10GB")
+            traffic_src = "profiles/pmc_fastq_fused.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, gfx950 corrections; not re-measured in this run)"
         out = {
             "metric": "FASTQ records/sec into DataChunks",
-            "value": total_records * args.steps / dt,
+            "value": total_records * L * args.steps / dt,
             "unit": "records/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -207,13 +449,17 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
+            "verified": verified,
             "config": {
                 "workload": f"read_fastq on {file_bytes / 1e9:.0f} GB synthetic 150 bp FASTQ "
                             f"({REC} B/record, {total_records} records), {world}x MI355X, byte-range shards",
                 "file_bytes": file_bytes,
                 "bytes_per_gpu": n_bytes,
+                "launches_per_step": L,
+                "ms_per_launch": dt / args.steps / L * 1e3,
                 "algo": {0: "auto(fused+gated general path)", 1: "multipass", 2: "fused"}[args.algo],
                 "columns": "name,description,sequence,quality_scores as duckdb::string_t + validity",
+                "verification": "every row of the last launch's four columns + validity against the generator's closed forms, on the device",
             },
             "roofline": {
                 "bound": "hbm",
@@ -222,19 +468,70 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic,
-                "kernel": "exg_fastq_scan launch (k_fastq_fused dominant)",
+                "traffic_source": traffic_src,
+                "kernel": "exg_fastq_scan launch (k_fused<FastqFormat> dominant)",
                 "algorithmic_bytes_per_launch": n_bytes,
                 "avg_launch_ms": avg_ms,
-                "min_launch_ms": ms[0],
+                "min_launch_ms": min_ms,
                 "read_only_stream_GBps": read_only,
                 "frac_of_read_only_stream": achieved / read_only,
             },
         }
+        if reader_sharded:
+            out["reader_sharded"] = reader_sharded
+        if world == 1 and not args.no_configs:
+            del scan, d_in
+            torch.cuda.empty_cache()
+            cfg = run_configs(torch, lib, args)
+            out["end_to_end"] = cfg.pop("end_to_end")
+            out["configs"] = cfg
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def _first_owned_record(sh):
+    """global index of the first record whose last line ends at or after the shard's first byte (records are 332 bytes:
+    record k ends at byte 332 (k + 1) - 1)"""
+    if sh.is_first:
+        return 0
+    return sh.start // REC  # the record that holds byte `start` ends at or after it
+
+
+def sharded_reader_leg(torch, dist, lib, device, world, rank, local_rank, coll_dev, args):
+    """N ranks, one file: rank 0 writes world x e2e_gb GB of FASTQ-150 to shared memory, every rank opens it with
+    shard_index = rank on its own device and counts its shard; value = rows of all shards / slowest rank's time."""
+    tmp = None
+    n_file = int(world * args.e2e_gb * 1e9) // REC * REC
+    path_holder = [None]
+    if rank == 0:
+        tmp, _ = scratch_dir(n_file)
+        path_holder[0] = os.path.join(tmp, "sharded.fastq")
+        with open(path_holder[0], "wb") as f:
+            step = (1 << 30) // REC * REC
+            for o in range(0, n_file, step):
+                m = min(step, n_file - o)
+                f.write(device.synth_fastq(m, file_offset=o)[:m].cpu().numpy().tobytes())
+    dist.broadcast_object_list(path_holder, src=0)
+    path = path_holder[0]
+    dist.barrier()
+    dev = 0 if args.single_device else local_rank
+    reader_count(lib, path, "fastq", (rank, world), dev)  # warm
+    dist.barrier()
+    n, dt = reader_count(lib, path, "fastq", (rank, world), dev)
+    t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+    rows = torch.tensor([n], dtype=torch.int64, device=coll_dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(rows)
+    dist.barrier()
+    if rank == 0:
+        os.unlink(path)
+        os.rmdir(tmp)
+    return {"workload": f"COUNT(*) of one {n_file / 1e9:.1f} GB FASTQ-150 file in shared memory, {world} readers with shard_index = rank (exg_open), PCIe inclusive",
+            "algorithmic_bytes": n_file, "ms": float(t.item()) * 1e3, "GB/s": n_file / float(t.item()) / 1e9,
+            "records_per_s": int(rows.item()) / float(t.item()), "verified": bool(int(rows.item()) == n_file // REC)}
 
 
 if __name__ == "__main__":

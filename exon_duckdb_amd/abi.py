@@ -164,4 +164,7 @@ SIGNATURES = {
     "exg_quality_list_workspace_bytes": (C.c_uint64, [C.c_uint64]),
     "exg_quality_score_list": (C.c_int, [C.POINTER(QualityListArgs)]),
     "exg_synth_fastq": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "exg_synth_vcf": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]),
+    "exg_synth_fasta": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]),
+    "exg_plan_shards": (C.c_int, [C.POINTER(OpenArgs), C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.c_uint32]),
 }

@@ -1857,6 +1857,22 @@ extern "C" int exg_count_only(exg_reader *r, uint64_t *n_rows) {
     return EXG_OK;
 }
 
+// Pull and release every remaining chunk — what a consumer that only walks the DataChunks does (bench.py's end-to-end
+// leg: file in the page cache -> host DataChunks, without an interpreter in the loop).
+extern "C" int exg_drain_chunks(exg_reader *r, uint64_t *n_rows, uint64_t *n_chunks) {
+    if (!r || !n_rows || !n_chunks) return EXG_E_INVALID_ARG;
+    *n_rows = *n_chunks = 0;
+    for (;;) {
+        exg_chunk c;
+        const int rc = exg_next_chunk(r, &c);
+        if (rc) return rc;
+        if (c.n_rows == 0) return EXG_OK;
+        *n_rows += c.n_rows;
+        *n_chunks += 1;
+        exg_release_chunk(r, &c);
+    }
+}
+
 extern "C" const char *exg_reader_error(exg_reader *r) { return r ? r->error.c_str() : ""; }
 
 extern "C" void exg_close(exg_reader *r) { delete r; }

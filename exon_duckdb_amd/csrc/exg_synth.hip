@@ -1,6 +1,12 @@
 // exg_synth.hip — deterministic synthetic FASTQ generated in HBM (bench / tests input only).
 // Byte-for-byte the generator SURVEY.md §8 D2 specifies; tests compare it with the oracle's.
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+
 #include "exg_common.hpp"
+#include "exg_scan.hpp"
 
 namespace exg {
 
@@ -61,7 +67,208 @@ __global__ __launch_bounds__(256) void k_synth_fastq(uint8_t *__restrict__ out, 
     }
 }
 
+// ---- VCF-8 and FASTA: variable-length lines / records, so the generator runs in two passes — lengths ->
+// exclusive scan -> every line (record) written at its offset.  Byte for byte the oracle's orc_synth_vcf / orc_synth_fasta.
+__device__ __forceinline__ uint32_t dec_digits(uint64_t v) {
+    uint32_t n = 1;
+    while (v >= 10) v /= 10, n++;
+    return n;
+}
+__device__ __forceinline__ uint32_t put_dec(uint8_t *p, uint64_t v) {
+    const uint32_t n = dec_digits(v);
+    for (uint32_t i = n; i-- > 0;) p[i] = (uint8_t)('0' + v % 10), v /= 10;
+    return n;
+}
+__device__ __forceinline__ uint32_t put_dec_pad(uint8_t *p, uint64_t v, uint32_t width) {
+    for (uint32_t i = width; i-- > 0;) p[i] = (uint8_t)('0' + v % 10), v /= 10;
+    return width;
+}
+__device__ __forceinline__ uint32_t put_str(uint8_t *p, const char *s) {
+    uint32_t n = 0;
+    while (s[n]) p[n] = (uint8_t)s[n], n++;
+    return n;
+}
+// one data line into buf (<= 96 bytes); returns its length
+__device__ uint32_t synth_vcf_line(uint64_t seed, uint64_t i, uint64_t per_chrom, uint8_t *buf) {
+    const uint64_t h = synth_word(seed, i, 0), h2 = synth_word(seed, i, 1);
+    uint32_t n = 0;
+    n += put_dec(buf + n, i / per_chrom + 1);
+    buf[n++] = '\t';
+    n += put_dec(buf + n, (i % per_chrom) * 37 + 1 + (h & 31));
+    buf[n++] = '\t';
+    if (h & 0x100) {
+        buf[n++] = 'r', buf[n++] = 's';
+        n += put_dec_pad(buf + n, h2 % 1000000000ull, 9);
+    } else {
+        buf[n++] = '.';
+    }
+    buf[n++] = '\t';
+    buf[n++] = (uint8_t) "ACGT"[(h >> 10) & 3];
+    buf[n++] = '\t';
+    if (((h >> 12) & 7) == 0)
+        n += put_str(buf + n, "A,C");
+    else
+        buf[n++] = (uint8_t) "ACGT"[(h >> 15) & 3];
+    buf[n++] = '\t';
+    if (((h >> 20) & 15) != 0) {
+        const uint64_t v = (h >> 24) % 10000;  // "%.1f" of v / 10.0
+        n += put_dec(buf + n, v / 10);
+        buf[n++] = '.';
+        buf[n++] = (uint8_t)('0' + v % 10);
+    } else {
+        buf[n++] = '.';
+    }
+    buf[n++] = '\t';
+    const uint32_t f = (uint32_t)(h >> 40) & 3;
+    n += put_str(buf + n, f == 1 ? "." : f == 2 ? "q10" : "PASS");
+    buf[n++] = '\t';
+    n += put_str(buf + n, "DP=");
+    n += put_dec(buf + n, h2 % 500);
+    n += put_str(buf + n, ";AF=0.");  // "%.4f" of a value below 1
+    n += put_dec_pad(buf + n, (h2 >> 16) % 10000, 4);
+    if ((h2 >> 40) & 1) n += put_str(buf + n, ";DB");
+    buf[n++] = '\n';
+    return n;
+}
+struct VcfLenF {
+    uint64_t seed, per_chrom;
+    __device__ uint64_t operator()(uint64_t i) const {
+        uint8_t buf[96];
+        return synth_vcf_line(seed, i, per_chrom, buf);
+    }
+};
+__global__ __launch_bounds__(256) void k_synth_vcf(uint8_t *out, uint64_t n_lines, uint64_t seed, uint64_t per_chrom,
+                                                   const uint64_t *__restrict__ off) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_lines; i += (uint64_t)gridDim.x * 256) {
+        uint8_t buf[96];
+        const uint32_t n = synth_vcf_line(seed, i, per_chrom, buf);
+        uint8_t *dst = out + off[i];
+        for (uint32_t k = 0; k < n; k++) dst[k] = buf[k];
+    }
+}
+
+__device__ __forceinline__ void synth_fasta_shape(uint64_t seed, uint64_t k, uint64_t *total, uint64_t *lines) {
+    const uint64_t h = synth_word(seed, k, 1000);
+    *lines = 5 + h % 46;
+    *total = (*lines - 1) * 60 + 1 + (h >> 8) % 60;
+}
+__device__ uint32_t synth_fasta_header(uint64_t k, uint64_t total, uint8_t *buf) {
+    uint32_t n = put_str(buf, ">seq");
+    n += put_dec(buf + n, k);
+    if (k % 3 != 2) {
+        n += put_str(buf + n, " synthetic record ");
+        n += put_dec(buf + n, k);
+        n += put_str(buf + n, " len=");
+        n += put_dec(buf + n, total);
+    }
+    buf[n++] = '\n';
+    return n;
+}
+struct FastaLenF {
+    uint64_t seed;
+    __device__ uint64_t operator()(uint64_t k) const {
+        uint64_t total, lines;
+        synth_fasta_shape(seed, k, &total, &lines);
+        uint8_t buf[96];
+        return synth_fasta_header(k, total, buf) + total + lines;
+    }
+};
+__global__ __launch_bounds__(256) void k_synth_fasta(uint8_t *out, uint64_t n_records, uint64_t seed, const uint64_t *__restrict__ off) {
+    for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < n_records; k += (uint64_t)gridDim.x * 256) {
+        uint64_t total, lines;
+        synth_fasta_shape(seed, k, &total, &lines);
+        uint8_t buf[96];
+        const uint32_t hn = synth_fasta_header(k, total, buf);
+        uint8_t *dst = out + off[k];
+        for (uint32_t i = 0; i < hn; i++) dst[i] = buf[i];
+        dst += hn;
+        uint64_t w = 0;
+        for (uint64_t i = 0; i < total; i++) {
+            if ((i & 31) == 0) w = synth_word(seed, k, i / 32);
+            *dst++ = (uint8_t) "ACGT"[(w >> (2 * (i % 32))) & 3];
+            if (i % 60 == 59 || i + 1 == total) *dst++ = '\n';
+        }
+    }
+}
+
+template <class F, class K>
+static int synth_two_pass(F len_f, K write, uint8_t *d_out, uint64_t cap, uint64_t n, const char *header, uint64_t *n_bytes, hipStream_t st) {
+    const uint64_t hn = header ? strlen(header) : 0;
+    uint64_t *d_off = nullptr, *d_tmp = nullptr;
+    EXG_HIP_CHECK(hipMalloc(&d_off, (n + 1) * 8 + 16));
+    if (hipMalloc(&d_tmp, xscan_tmp_entries(n) * 8 + 16) != hipSuccess) {
+        (void)hipFree(d_off);
+        set_error("exg_synth: out of device memory");
+        return EXG_E_HIP;
+    }
+    launch_xscan(len_f, n, d_off, d_tmp, st);
+    uint64_t total = 0;
+    hipError_t e = hipMemcpyAsync(&total, d_off + n, 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    int rc = EXG_OK;
+    if (e != hipSuccess) {
+        set_error("exg_synth: %s", hipGetErrorString(e));
+        rc = EXG_E_HIP;
+    } else if (hn + total > cap) {
+        set_error("exg_synth: %llu bytes do not fit the buffer of %llu", (unsigned long long)(hn + total), (unsigned long long)cap);
+        rc = EXG_E_CAPACITY;
+    } else {
+        if (hn) e = hipMemcpyAsync(d_out, header, hn, hipMemcpyHostToDevice, st);
+        if (n) write(d_out + hn, d_off);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) {
+            set_error("exg_synth: %s", hipGetErrorString(e));
+            rc = EXG_E_HIP;
+        }
+        *n_bytes = hn + total;
+    }
+    (void)hipFree(d_off);
+    (void)hipFree(d_tmp);
+    return rc;
+}
+
 }  // namespace exg
+
+// VCF-8 of SURVEY.md §8 D2 (header + n_lines data lines of ~49 bytes) generated on the device; *n_bytes = what was
+// written (<= cap, else EXG_E_CAPACITY).  Synchronises the stream (bench / tests input only).
+extern "C" int exg_synth_vcf(void *d_out, uint64_t cap, uint64_t n_lines, uint64_t seed, uint64_t *n_bytes, void *stream) {
+    using namespace exg;
+    if (!d_out || !n_bytes) {
+        set_error("exg_synth_vcf: null argument");
+        return EXG_E_INVALID_ARG;
+    }
+    std::string header = "##fileformat=VCFv4.2\n";
+    for (int c = 1; c <= 22; c++) header += "##contig=<ID=" + std::to_string(c) + ">\n";
+    header +=
+        "##INFO=<ID=DP,Number=1,Type=Integer,Description=\"Depth\">\n"
+        "##INFO=<ID=AF,Number=1,Type=Float,Description=\"Allele frequency\">\n"
+        "##INFO=<ID=DB,Number=0,Type=Flag,Description=\"dbSNP membership\">\n"
+        "##INFO=<ID=ANN,Number=1,Type=String,Description=\"Annotation\">\n"
+        "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n";
+    const uint64_t per_chrom = n_lines / 22 + 1;
+    hipStream_t st = (hipStream_t)stream;
+    auto write = [&](uint8_t *out, const uint64_t *d_off) {
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((n_lines + 255) / 256, 65536);
+        hipLaunchKernelGGL(k_synth_vcf, dim3(grid), dim3(256), 0, st, out, n_lines, seed, per_chrom, d_off);
+    };
+    return synth_two_pass(VcfLenF{seed, per_chrom}, write, (uint8_t *)d_out, cap, n_lines, header.c_str(), n_bytes, st);
+}
+
+// FASTA of SURVEY.md §8 D2 (60-column wrapped sequences of 5..50 lines, every 3rd record without description).
+extern "C" int exg_synth_fasta(void *d_out, uint64_t cap, uint64_t n_records, uint64_t seed, uint64_t *n_bytes, void *stream) {
+    using namespace exg;
+    if (!d_out || !n_bytes) {
+        set_error("exg_synth_fasta: null argument");
+        return EXG_E_INVALID_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    auto write = [&](uint8_t *out, const uint64_t *d_off) {
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((n_records + 255) / 256, 65536);
+        hipLaunchKernelGGL(k_synth_fasta, dim3(grid), dim3(256), 0, st, out, n_records, seed, d_off);
+    };
+    return synth_two_pass(FastaLenF{seed}, write, (uint8_t *)d_out, cap, n_records, nullptr, n_bytes, st);
+}
 
 extern "C" int exg_synth_fastq(void *d_out, uint64_t file_offset, uint64_t n_bytes, uint64_t seed, void *stream) {
     if (!d_out || ((uintptr_t)d_out & 15)) {

@@ -41,6 +41,24 @@ def synth_fastq(n_bytes, file_offset=0, seed=abi.EXG_SYNTH_FASTQ_SEED, device="c
     return t
 
 
+def _synth_two_pass(fn, n_units, cap, seed, device):
+    torch = _torch()
+    out = torch.zeros(cap + 64, dtype=torch.uint8, device=device)
+    n = C.c_uint64(0)
+    check(fn(C.c_void_p(out.data_ptr()), cap, n_units, seed, C.byref(n), stream_ptr()))
+    return out, int(n.value)
+
+
+def synth_vcf(n_lines, seed=abi.EXG_SYNTH_VCF_SEED, device="cuda"):
+    """VCF-8 of SURVEY.md §8 D2 generated in HBM -> (uint8 tensor, n_bytes); same bytes as the oracle's synth_vcf."""
+    return _synth_two_pass(load_library().exg_synth_vcf, n_lines, 1024 + 64 * n_lines, seed, device)
+
+
+def synth_fasta(n_records, seed=0xE0A5EED0003, device="cuda"):
+    """FASTA of SURVEY.md §8 D2 generated in HBM -> (uint8 tensor, n_bytes)."""
+    return _synth_two_pass(load_library().exg_synth_fasta, n_records, 4096 + 3200 * n_records, seed, device)
+
+
 class FastqScan:
     """Reusable output + workspace buffers for exg_fastq_scan on one device buffer size."""
 

@@ -296,6 +296,12 @@ int exg_zstd_decode(const uint8_t *h_comp, const void *d_comp, uint64_t n, void 
 #define EXG_SYNTH_VCF_SEED 0xE0A5EED0002ull
 #define EXG_SYNTH_FASTQ_RECORD_BYTES 332
 int exg_synth_fastq(void *d_out, uint64_t file_offset, uint64_t n_bytes, uint64_t seed, void *stream);
+/* VCF-8 (header + n_lines data lines, ~49 bytes each) and FASTA (n_records records of 5..50 60-column lines) of the same
+ * section: lines / records vary in length, so these run lengths -> scan -> write; *n_bytes = bytes written (EXG_E_CAPACITY
+ * when they exceed cap).  Synchronise the stream. */
+#define EXG_SYNTH_FASTA_SEED 0xE0A5EED0003ull
+int exg_synth_vcf(void *d_out, uint64_t cap, uint64_t n_lines, uint64_t seed, uint64_t *n_bytes, void *stream);
+int exg_synth_fasta(void *d_out, uint64_t cap, uint64_t n_records, uint64_t seed, uint64_t *n_bytes, void *stream);
 
 /* ---- (2) reader level ----------------------------------------------------------- */
 typedef struct exg_reader exg_reader;
@@ -383,6 +389,8 @@ int exg_next_chunk(exg_reader *r, exg_chunk *out);
 void exg_release_chunk(exg_reader *r, exg_chunk *chunk);
 /* COUNT(*) fast path: no column is materialised. */
 int exg_count_only(exg_reader *r, uint64_t *n_rows);
+/* Pull and release every remaining chunk (a consumer that only walks the DataChunks): rows and chunks handed out. */
+int exg_drain_chunks(exg_reader *r, uint64_t *n_rows, uint64_t *n_chunks);
 const char *exg_reader_error(exg_reader *r);
 void exg_close(exg_reader *r);
 

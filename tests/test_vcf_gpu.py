@@ -257,3 +257,17 @@ def test_config3_full_size_properties(gpu, oracle):
     q = scan.qual[: T * L].view(T, L).view(torch.int32)
     valid = torch.from_numpy(qv.astype(np.bool_)).cuda()
     assert bool((q[:, valid] == q[0, valid]).all())
+
+
+def test_device_generators_match_the_oracle(gpu, oracle):
+    """exg_synth_vcf / exg_synth_fasta (two passes: lengths -> scan -> write) produce the oracle's bytes: bench.py takes its
+    VCF and FASTA inputs from them (the bench may not touch the oracle outside its cpu_baseline leg)."""
+    from exon_duckdb_amd import device
+    for n in (1, 22, 1000, 50001):
+        t, nb = device.synth_vcf(n)
+        want = bytes(oracle.synth_vcf(n))
+        assert nb == len(want) and bytes(t[:nb].cpu().numpy()) == want, n
+    for n in (1, 3, 500, 4001):
+        t, nb = device.synth_fasta(n)
+        want = bytes(oracle.synth_fasta(n))
+        assert nb == len(want) and bytes(t[:nb].cpu().numpy()) == want, n
