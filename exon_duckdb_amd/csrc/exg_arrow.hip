@@ -409,7 +409,8 @@ void gather_u32(const uint32_t *d_in, const uint32_t *d_row_map, uint64_t n_out,
 
 // ---- DuckDB vector layouts of the nested columns -------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_views_to_string_t(const View *__restrict__ views, uint64_t m, const uint8_t *d_base,
-                                                           uint64_t payload_base, uint4 *out) {
+                                                           uint64_t payload_base, const uint8_t *d_side, uint64_t side_bytes,
+                                                           uint64_t side_payload_base, uint4 *out) {
     for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < m; j += (uint64_t)gridDim.x * 256) {
         const View v = views[j];
         uint4 r = make_uint4(0, 0, 0, 0);
@@ -421,18 +422,20 @@ __global__ __launch_bounds__(256) void k_views_to_string_t(const View *__restric
                 r.y = w[0], r.z = w[1], r.w = w[2];
             } else {
                 r.y = (uint32_t)v.p[0] | ((uint32_t)v.p[1] << 8) | ((uint32_t)v.p[2] << 16) | ((uint32_t)v.p[3] << 24);
-                const uint64_t p = payload_base + (uint64_t)(v.p - d_base);
+                const bool in_side = d_side && v.p >= d_side && v.p < d_side + side_bytes;
+                const uint64_t p = in_side ? side_payload_base + (uint64_t)(v.p - d_side) : payload_base + (uint64_t)(v.p - d_base);
                 r.z = (uint32_t)p, r.w = (uint32_t)(p >> 32);
             }
         }
         out[j] = r;
     }
 }
-void views_to_string_t(const View *d_views, uint64_t m, const uint8_t *d_base, uint64_t payload_base, exg_string_t *d_out,
-                       hipStream_t stream) {
+void views_to_string_t(const View *d_views, uint64_t m, const uint8_t *d_base, uint64_t payload_base, const uint8_t *d_side,
+                       uint64_t side_bytes, uint64_t side_payload_base, exg_string_t *d_out, hipStream_t stream) {
     if (!m) return;
     uint32_t grid = (uint32_t)((m + 255) / 256 < 8192 ? (m + 255) / 256 : 8192);
-    hipLaunchKernelGGL(k_views_to_string_t, dim3(grid), dim3(256), 0, stream, d_views, m, d_base, payload_base, (uint4 *)d_out);
+    hipLaunchKernelGGL(k_views_to_string_t, dim3(grid), dim3(256), 0, stream, d_views, m, d_base, payload_base, d_side, side_bytes,
+                       side_payload_base, (uint4 *)d_out);
 }
 
 __global__ __launch_bounds__(256) void k_list_entries_rows(const uint64_t *__restrict__ goff, uint64_t n, uint64_t chunk_rows,

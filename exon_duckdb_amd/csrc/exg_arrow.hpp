@@ -156,13 +156,28 @@ void cells_list_i32(const CellSrc &s, uint64_t n, const uint64_t *d_goff, int32_
 void cells_list_f32(const CellSrc &s, uint64_t n, const uint64_t *d_goff, float *d_values, uint32_t *d_child_valid,
                     unsigned long long *d_err, uint32_t err_code, hipStream_t);
 void cells_list_views(const CellSrc &s, uint64_t n, const uint64_t *d_goff, View *d_views, uint32_t *d_child_valid, hipStream_t);
+// String / Character values are percent-decoded (noodles-vcf 0.34: percent_encoding::percent_decode(..).decode_utf8()):
+// "%3B" -> ';'.  Almost no value holds an escape, so: pass 1 adds up the decoded lengths of the views that do
+// (*d_total, zeroed by the caller; 0 = nothing to do); pass 2 decodes those into d_side (bump allocation through
+// *d_cursor, zeroed by the caller) and points the views there.  A decoded value that is not UTF-8 is a value error:
+// atomicMin(*d_err, (row << 8) | err_code), row = d_elem_row[parent] / parent, parent = the list (d_parent_goff, n_parent)
+// the element belongs to / the element itself.
+struct PercentRows {
+    const uint64_t *d_parent_goff;  // NULL: the views are not list elements
+    uint64_t n_parent;
+    const uint32_t *d_elem_row;     // NULL: the parent index is the row
+};
+void percent_count(const View *d_views, uint64_t m, unsigned long long *d_total, hipStream_t);
+void percent_decode(View *d_views, uint64_t m, uint8_t *d_side, unsigned long long *d_cursor, const PercentRows &rows,
+                    unsigned long long *d_err, uint32_t err_code, hipStream_t);
 // validity bits of a view array (bit j = views[j].valid)
 void views_validity(const View *d_views, uint64_t n, uint64_t *d_valid, hipStream_t);
 
 // ---- DuckDB vector layouts of the nested columns (the chunk boundary, exg_next_chunk) -------------------------------
 // string views -> duckdb::string_t (payload zero-copy: ptr = payload_base + (view.p - d_base)); invalid views -> 16 zero bytes
-void views_to_string_t(const View *d_views, uint64_t m, const uint8_t *d_base, uint64_t payload_base, exg_string_t *d_out,
-                       hipStream_t stream);
+// (views that point into [d_side, d_side + side_bytes) — percent-decoded values — get ptr = side_payload_base + offset)
+void views_to_string_t(const View *d_views, uint64_t m, const uint8_t *d_base, uint64_t payload_base, const uint8_t *d_side,
+                       uint64_t side_bytes, uint64_t side_payload_base, exg_string_t *d_out, hipStream_t stream);
 // LIST parents over rows: entries[i] = {goff[i] - goff[i - i % chunk_rows], goff[i + 1] - goff[i]} — offsets are relative to
 // the first child element of the row's DataChunk, so a chunk's child vector is a slice of the batch-wide child array
 void list_entries_rows(const uint64_t *d_goff, uint64_t n, uint64_t chunk_rows, ListEntry *d_entries, hipStream_t stream);

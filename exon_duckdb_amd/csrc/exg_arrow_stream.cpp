@@ -235,6 +235,25 @@ struct Emit {
     }
     static size_t bitmap_bytes(uint64_t m) { return (size_t)((m + 63) / 64) * 8; }
 
+    // String / Character values are percent-decoded (noodles-vcf 0.34): the views that hold a %XX escape are decoded
+    // into a side buffer on the device and point there afterwards.  *side_bytes == 0: no value held an escape.
+    void decode_percent(ea::View *d_views, uint64_t m, const ea::PercentRows &rows, uint32_t err_code, uint8_t **d_side, uint64_t *side_bytes) {
+        *d_side = nullptr;
+        *side_bytes = 0;
+        if (!m) return;
+        unsigned long long *d_cnt = (unsigned long long *)dalloc(16);
+        if (rc) return;
+        (void)hipMemsetAsync(d_cnt, 0, 16, s);
+        ea::percent_count(d_views, m, d_cnt, s);
+        const uint64_t total = fetch_u64((const uint64_t *)d_cnt);
+        if (!total || rc) return;
+        uint8_t *side = (uint8_t *)dalloc(total + 16);
+        if (rc) return;
+        ea::percent_decode(d_views, m, side, d_cnt + 1, rows, d_err, err_code, s);
+        *d_side = side;
+        *side_bytes = total;
+    }
+
     // validity of a row-space column whose source bitmap is indexed by scan rows
     const uint8_t *row_validity(const uint64_t *d_src) {
         if (!d_src) return nullptr;
@@ -357,6 +376,9 @@ struct Emit {
                     ea::View *d_views = (ea::View *)dalloc(m * sizeof(ea::View));
                     if (rc) break;
                     ea::cells_to_views(src, m, d_views, d_valid, s);
+                    uint8_t *d_side;
+                    uint64_t side_bytes;
+                    decode_percent(d_views, m, ea::PercentRows{nullptr, 0, src.d_elem_row}, err_code, &d_side, &side_bytes);
                     col = utf8_abs(d_views, m, to_host(d_valid, bitmap_bytes(m)));
                 }
             } else {
@@ -394,6 +416,9 @@ struct Emit {
                     ea::View *d_views = (ea::View *)dalloc(total * sizeof(ea::View));
                     if (rc) break;
                     ea::cells_list_views(src, m, d_goff, d_views, d_cv, s);
+                    uint8_t *d_side;
+                    uint64_t side_bytes;
+                    decode_percent(d_views, total, ea::PercentRows{d_goff, m, src.d_elem_row}, err_code, &d_side, &side_bytes);
                     child = utf8_abs(d_views, total, to_host(d_cv, bitmap_bytes(total)));
                 }
                 col.children.push_back(std::move(child));
@@ -411,15 +436,22 @@ struct DuckEmit {
     const uint8_t *d_base;      // the scanned text on the device ...
     uint64_t payload_base;      // ... and the host address its bytes have in the chunk's payload
 
-    NVec strings_from_views(const ea::View *d_views, uint64_t m, const uint64_t *h_validity) {
+    // rows != NULL: String / Character values of INFO / FORMAT, percent-decoded first (the decoded bytes travel in a side
+    // block of the batch's pinned arena; everything else stays a zero-copy pointer into the chunk's payload)
+    NVec strings_from_views(ea::View *d_views, uint64_t m, const uint64_t *h_validity, const ea::PercentRows *rows = nullptr,
+                            uint32_t err_code = 0) {
         NVec v;
         v.type = EXG_TYPE_VARCHAR;
         v.elem = 16;
         v.length = m;
         v.validity = h_validity;
+        uint8_t *d_side = nullptr;
+        uint64_t side_bytes = 0, side_host = 0;
+        if (rows) em.decode_percent(d_views, m, *rows, err_code, &d_side, &side_bytes);
+        if (side_bytes) side_host = (uint64_t)(uintptr_t)em.to_host(d_side, side_bytes);
         exg_string_t *d = (exg_string_t *)em.dalloc(m * 16 + 16);
         if (em.rc) return v;
-        ea::views_to_string_t(d_views, m, d_base, payload_base, d, em.s);
+        ea::views_to_string_t(d_views, m, d_base, payload_base, d_side, side_bytes, side_host, d, em.s);
         v.data = em.to_host(d, m * 16);
         return v;
     }
@@ -450,7 +482,7 @@ struct DuckEmit {
         ea::list_entries_rows(d_goff, n, B, d_entries, em.s);
         v.data = em.to_host(d_entries, n * 16);
         v.child_base = bases_rows(d_goff, n, nullptr);
-        v.children.push_back(strings_from_views(d_views, total, nullptr));
+        v.children.push_back(strings_from_views(d_views, total, nullptr));  // (id / alt / filter are not percent-decoded)
         return v;
     }
     // the typed children of INFO (elements = output rows) or FORMAT (elements = samples: d_elem_row / d_outer_goff /
@@ -491,7 +523,8 @@ struct DuckEmit {
                     ea::View *d_views = (ea::View *)em.dalloc(m * sizeof(ea::View) + 16);
                     if (em.rc) break;
                     ea::cells_to_views(src, m, d_views, d_valid, em.s);
-                    col = strings_from_views(d_views, m, (const uint64_t *)em.to_host(d_valid, Emit::bitmap_bytes(m)));
+                    const ea::PercentRows pr{nullptr, 0, src.d_elem_row};
+                    col = strings_from_views(d_views, m, (const uint64_t *)em.to_host(d_valid, Emit::bitmap_bytes(m)), &pr, err_code);
                 }
             } else {
                 uint64_t *d_goff = (uint64_t *)em.dalloc((m + 1) * 8);
@@ -533,7 +566,8 @@ struct DuckEmit {
                     ea::View *d_views = (ea::View *)em.dalloc(total * sizeof(ea::View) + 16);
                     if (em.rc) break;
                     ea::cells_list_views(src, m, d_goff, d_views, d_cv, em.s);
-                    child = strings_from_views(d_views, total, (const uint64_t *)em.to_host(d_cv, Emit::bitmap_bytes(total)));
+                    const ea::PercentRows pr{d_goff, m, src.d_elem_row};
+                    child = strings_from_views(d_views, total, (const uint64_t *)em.to_host(d_cv, Emit::bitmap_bytes(total)), &pr, err_code);
                 }
                 col.children.push_back(std::move(child));
             }

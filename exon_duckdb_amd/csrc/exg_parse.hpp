@@ -2,30 +2,21 @@
 // columns.  `Src` is any byte source with `uint32_t b(int i) const`.
 #pragma once
 #include "exg_common.hpp"
+#include "exg_float_el.hpp"
 
 namespace exg {
 
 // ---- exact decimal -> float32 ---------------------------------------------------------------------
-// f32::from_str is correctly rounded.  Device domain: <= 15 significant digits (mantissa < 2^53),
-// |decimal exponent| <= 22, result 0 or a normal float.  One correctly rounded f64 operation
-// (Clinger) + an FMA-exact residual decides the single case a double-rounded conversion could get
-// wrong (the f64 result sitting exactly on a float rounding boundary).  Literals outside the
-// domain are reported (EXG_PE_VCF_BAD_QUAL + EXG_RF_QUAL_RANGE), never mis-rounded.
-static __device__ __constant__ double kPow10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
-                                             1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+// f32::from_str is correctly rounded for every literal.  Here: literals of at most 7 significant digits without an
+// exponent take Clinger's fast path in f32 (one correctly rounded division); everything else goes through the
+// Eisel-Lemire algorithm on the first 19 significant digits (exg_float_el.hpp: exact for any 64-bit significand and any
+// exponent, subnormals and overflow to infinity included).  A literal with MORE than 19 significant digits is decided by
+// converting both ends of the interval its first 19 digits pin down — [w, w + 1] x 10^q; they round to the same float
+// unless a rounding boundary falls strictly inside an interval of relative width 10^-19 (about one literal in 10^11;
+// a boundary AT one of the two ends — "halfway, then zeros, then a 1" — is decided by the side the literal lies on): only then
+// the literal is reported (EXG_PE_VCF_BAD_QUAL + EXG_RF_QUAL_RANGE) rather than risk a wrong bit.
 
-__device__ __forceinline__ float round_exact(double q, double resid) {
-    // true value = q + (something with the sign of resid, magnitude < 1/2 ulp(q))
-    float f = (float)q;  // round to nearest even of q itself
-    unsigned long long b = (unsigned long long)__double_as_longlong(q);
-    if ((b & 0x1FFFFFFFull) == 0x10000000ull && resid != 0.0) {
-        float t = (float)__longlong_as_double((long long)(b & ~0x1FFFFFFFull));  // q truncated to 24 bits
-        f = resid > 0.0 ? __uint_as_float(__float_as_uint(t) + 1u) : t;
-    }
-    return f;
-}
-
-// status: 0 ok, 1 syntax error, 2 outside the exact device domain
+// status: 0 ok, 1 syntax error, 2 more than 19 significant digits AND a rounding boundary within 10^-19 of them
 template <class Src>
 __device__ int parse_f32(const Src &src, int s, int e, float *out) {
     int i = s;
@@ -133,20 +124,17 @@ __device__ int parse_f32(const Src &src, int s, int e, float *out) {
         *out = neg ? -0.0f : 0.0f;
         return 0;
     }
-    if (inexact || m >= (1ull << 53) || e10 < -22 || e10 > 22) return 2;
-    double dm = (double)m, q, resid;
-    if (e10 < 0) {
-        double p = kPow10[-e10];
-        q = dm / p;
-        resid = __fma_rn(-q, p, dm);  // m - q p, exact
-    } else {
-        double p = kPow10[e10];
-        q = dm * p;
-        resid = __fma_rn(dm, p, -q);  // m p - q, exact
+    bool tie_lo = false, tie_hi = false;
+    uint32_t bits = el_f32_bits(m, e10, &tie_lo);
+    if (inexact) {
+        // the literal lies strictly inside (m, m + 1) x 10^e10
+        const uint32_t up = el_f32_bits(m + 1, e10, &tie_hi);
+        if (up != bits) {
+            if (tie_lo) bits = up;       // just above an exact halfway point ("16777217.000...01"): rounds up
+            else if (!tie_hi) return 2;  // (just below one: rounds down = bits) else the boundary is inside the interval
+        }
     }
-    if (!(q >= 1.1754943508222875e-38 && q <= 3.4028234663852886e38)) return 2;
-    float f = round_exact(q, resid);
-    *out = neg ? -f : f;
+    *out = __uint_as_float(bits | (neg ? 0x80000000u : 0u));
     return 0;
 }
 

@@ -109,6 +109,11 @@ __device__ __forceinline__ VcfRowInfo vcf_line(const Src &src, int s, int e, con
             r.code = EXG_PE_VCF_BAD_QUAL | (st == 2 ? 0x80u : 0u);
             return r;
         }
+        // noodles-vcf 0.34 record::QualityScore: TryFrom<f32> refuses n < 0.0 (so -1, -inf; not -0, not NaN)
+        if (qual_v < 0.0f) {
+            r.code = EXG_PE_VCF_BAD_QUAL;
+            return r;
+        }
         r.qual_valid = true;
     }
     r.rest_valid = found == 8;

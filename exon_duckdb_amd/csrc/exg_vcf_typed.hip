@@ -322,6 +322,63 @@ __global__ __launch_bounds__(256) void k_cells_list(CellGet g, uint64_t n, const
     }
 }
 
+// ---- percent-decoding of String / Character values --------------------------------------------------------------------
+__device__ __forceinline__ int hex_val(uint32_t c) {
+    if (c - '0' <= 9u) return (int)(c - '0');
+    c |= 0x20;
+    if (c - 'a' <= 5u) return (int)(c - 'a') + 10;
+    return -1;
+}
+// decoded length of p[0, len) when it holds at least one %XX escape, else 0 (nothing to decode)
+__device__ __forceinline__ uint32_t percent_len(const uint8_t *p, uint32_t len) {
+    uint32_t esc = 0;
+    for (uint32_t i = 0; i + 2 < len; i++)
+        if (p[i] == '%' && hex_val(p[i + 1]) >= 0 && hex_val(p[i + 2]) >= 0) esc++, i += 2;
+    return esc ? len - 2 * esc : 0u;
+}
+__global__ __launch_bounds__(256) void k_percent_count(const View *__restrict__ views, uint64_t m, unsigned long long *total) {
+    unsigned long long mine = 0;
+    for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < m; j += (uint64_t)gridDim.x * 256) {
+        const View v = views[j];
+        if (v.valid && v.len >= 3) mine += percent_len(v.p, v.len);
+    }
+    if (mine) atomicAdd(total, mine);
+}
+__global__ __launch_bounds__(256) void k_percent_decode(View *views, uint64_t m, uint8_t *side, unsigned long long *cursor, PercentRows rows,
+                                                        unsigned long long *err, uint32_t err_code) {
+    for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < m; j += (uint64_t)gridDim.x * 256) {
+        const View v = views[j];
+        if (!v.valid || v.len < 3) continue;
+        const uint32_t dl = percent_len(v.p, v.len);
+        if (!dl) continue;
+        uint8_t *dst = side + atomicAdd(cursor, (unsigned long long)dl);
+        uint32_t o = 0;
+        for (uint32_t i = 0; i < v.len; i++) {
+            int h, l;
+            if (v.p[i] == '%' && i + 2 < v.len && (h = hex_val(v.p[i + 1])) >= 0 && (l = hex_val(v.p[i + 2])) >= 0) {
+                dst[o++] = (uint8_t)(h * 16 + l);
+                i += 2;
+            } else {
+                dst[o++] = v.p[i];
+            }
+        }
+        views[j] = View{dst, dl, 1u};
+        if (!utf8_valid_global(dst, 0, dl)) {  // percent_decode(..).decode_utf8() fails: a value error of the row
+            uint64_t parent = j;
+            if (rows.d_parent_goff) {  // the list the element belongs to: last parent whose first element is <= j
+                uint64_t lo = 0, hi = rows.n_parent;
+                while (lo + 1 < hi) {
+                    const uint64_t mid = (lo + hi) / 2;
+                    if (rows.d_parent_goff[mid] <= j) lo = mid; else hi = mid;
+                }
+                parent = lo;
+            }
+            const unsigned long long row = rows.d_elem_row ? rows.d_elem_row[parent] : parent;
+            atomicMin(err, (row << 8) | err_code);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_views_validity(const View *views, uint64_t n, uint64_t *valid) {
     const uint64_t n_pad = (n + 63) & ~63ull;
     for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < n_pad; j += (uint64_t)gridDim.x * 256) {
@@ -401,6 +458,15 @@ void cells_list_views(const CellSrc &s, uint64_t n, const uint64_t *d_goff, View
     if (!n) return;
     hipLaunchKernelGGL(k_cells_list<kVtString>, dim3(grid_for(n)), dim3(256), 0, stream, CellGet{s}, n, d_goff, (void *)d_views,
                        d_child_valid, (unsigned long long *)nullptr, 0u);
+}
+void percent_count(const View *d_views, uint64_t m, unsigned long long *d_total, hipStream_t stream) {
+    if (!m) return;
+    hipLaunchKernelGGL(k_percent_count, dim3(grid_for(m)), dim3(256), 0, stream, d_views, m, d_total);
+}
+void percent_decode(View *d_views, uint64_t m, uint8_t *d_side, unsigned long long *d_cursor, const PercentRows &rows,
+                    unsigned long long *d_err, uint32_t err_code, hipStream_t stream) {
+    if (!m) return;
+    hipLaunchKernelGGL(k_percent_decode, dim3(grid_for(m)), dim3(256), 0, stream, d_views, m, d_side, d_cursor, rows, d_err, err_code);
 }
 void views_validity(const View *d_views, uint64_t n, uint64_t *d_valid, hipStream_t stream) {
     if (!n) return;

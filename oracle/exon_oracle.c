@@ -431,7 +431,7 @@ static int ci_eq(const uint8_t *p, uint64_t n, const char *s) {
 }
 
 static int parse_f32(const uint8_t *p, uint64_t n, float *out) {
-    if (n == 0 || n > 400) return 0;
+    if (n == 0) return 0;
     uint64_t i = 0;
     int neg = 0;
     if (p[0] == '+' || p[0] == '-') {
@@ -461,10 +461,11 @@ static int parse_f32(const uint8_t *p, uint64_t n, float *out) {
         if (ne == 0) return 0;
     }
     if (i != n) return 0;
-    char tmp[408];
+    char small[408], *tmp = n < sizeof small ? small : (char *)malloc((size_t)n + 1);
     memcpy(tmp, p, (size_t)n);
     tmp[n] = 0;
-    *out = strtof(tmp, NULL);
+    *out = strtof(tmp, NULL); /* glibc: correctly rounded whatever the number of digits */
+    if (tmp != small) free(tmp);
     return 1;
 }
 
@@ -554,7 +555,9 @@ int64_t orc_vcf_parse(const uint8_t *buf, uint64_t n, orc_vcf_table *out) {
         int q_valid = 1;
         if (fe[5] - fs[5] == 1 && buf[fs[5]] == '.')
             q_valid = 0;
-        else if (!parse_f32(buf + fs[5], fe[5] - fs[5], &q)) {
+        else if (!parse_f32(buf + fs[5], fe[5] - fs[5], &q) || q < 0.0f) {
+            /* noodles-vcf 0.34 record::QualityScore: f32::from_str, then TryFrom<f32> refuses n < 0.0 — "-1" and
+             * "-inf" are errors, "-0" (not < 0) and "nan" (no ordering) are not */
             set_err(&out->err, 10, (uint64_t)rows, rec_off, "invalid quality score");
             break;
         }

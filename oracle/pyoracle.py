@@ -278,6 +278,22 @@ class TypedValueError(ValueError):
     pass
 
 
+def percent_decode(t: bytes) -> bytes:
+    """percent_encoding::percent_decode (what noodles-vcf 0.34 applies to String / Character values of INFO and of the
+    samples, rust/Cargo.lock:2193-2194): '%' followed by two hex digits becomes that byte; any other '%' stays."""
+    out = bytearray()
+    i = 0
+    hexd = b"0123456789abcdefABCDEF"
+    while i < len(t):
+        if t[i] == 0x25 and i + 2 < len(t) and t[i + 1] in hexd and t[i + 2] in hexd:
+            out.append(int(t[i + 1:i + 3], 16))
+            i += 3
+        else:
+            out.append(t[i])
+            i += 1
+    return bytes(out)
+
+
 def _typed(text: bytes, ty, is_list):
     """value text (after '=') -> python value; None for the missing value '.'"""
     def one(t):
@@ -286,7 +302,10 @@ def _typed(text: bytes, ty, is_list):
         elif ty == "Float":
             v = parse_f32_text(t)
         else:
-            return t.decode("utf-8")
+            try:
+                return percent_decode(t).decode("utf-8")   # .decode_utf8(): a decoded value that is not UTF-8 is an error
+            except UnicodeDecodeError:
+                raise TypedValueError(t)
         if v is None:
             raise TypedValueError(t)
         return v

@@ -216,13 +216,16 @@ def test_vcf_typed_edge_cases(nr, oracle, tmp_path):
         b"4\t40\tx\tAC\tA\t7\tPASS\tDP=-12;DP=13;AF=3\tPL:GT\t1.5,2.5e1,-0.125:1\t.:\t.:.",
         b"5\t50\tx\tAC\tA\t7\tPASS\tANN=;DP",
         b"6\t60\tx\tAC\tA\t7\tPASS\tDP=2147483647;AF=inf,NaN,-infinity\tGT",
+        # String / Character values are percent-decoded (INFO and samples); ids, alts and filters are not
+        b"7\t70\ta%3Bb\tA\t<%41>\t7\tq%31\tANN=a%3Bb,c%2C%25,%zz,%4,100%,%e2%82%ac" + b"x" * 20 + b";CH=%41\tGT:AD\t0%2F1:1\t%7c:2\t" + b"%2e" * 9,
     ]
     data = HEADER + b"\n".join(lines) + b"\n"
     (tmp_path / "e.vcf").write_bytes(data)
     exp, err = oracle.vcf_typed_rows(data)
-    assert err is None and len(exp) == 6
+    assert err is None and len(exp) == 7
     got = nr(str(tmp_path / "e.vcf"), "vcf").read_all().to_pylist()
-    assert len(got) == 6
+    assert len(got) == 7
+    assert got[6]["info"]["ANN"] == ["a;b", "c,%", "%zz", "%4", "100%", "\u20ac" + "x" * 20] and got[6]["formats"][0]["GT"] == "0/1"
     for g, e in zip(got, exp):
         assert same(g, e), (g, e)
     assert got[0]["info"]["AF"] == [0.5, None, pytest.approx(0.01)] and got[0]["info"]["DB"] is True

@@ -175,6 +175,47 @@ def test_vcf_errors(oracle):
     assert r.n_rows == 1 and r.error_code == PE["VCF_FIELD"]   # blank data line
 
 
+def test_vcf_qual_negative_is_an_error_but_negative_zero_and_nan_are_not(oracle):
+    # noodles-vcf 0.34 record::QualityScore: f32::from_str, then TryFrom<f32> refuses n < 0.0
+    line = lambda q: HDR + b"1\t5\t.\tA\tC\t" + q + b"\tPASS\t.\n"  # noqa: E731
+    for bad in (b"-1", b"-0.5", b"-1e-45", b"-inf", b"-Infinity"):
+        assert oracle.vcf_parse(line(bad)).error_code == PE["VCF_QUAL"], bad
+    for ok in (b"-0", b"-0.0", b"-0e5", b"-1e-50", b"nan", b"-nan", b"NaN", b"inf", b"+Infinity", b"0", b"1e39"):
+        r = oracle.vcf_parse(line(ok))
+        assert r.error_code == 0 and r.n_rows == 1, ok
+
+
+def test_vcf_float_literals_of_any_length_are_correctly_rounded(oracle):
+    # f32::from_str is correctly rounded whatever the number of digits: checked against exact rational arithmetic
+    import struct
+    from fractions import Fraction
+
+    def nearest_f32(lit):
+        v = Fraction(lit)
+        if v == 0:
+            return 0.0
+        import math
+        e = math.floor(math.log2(v)) if v > 0 else 0
+        while Fraction(2) ** e > v:
+            e -= 1
+        while Fraction(2) ** (e + 1) <= v:
+            e += 1
+        e = max(e, -126)
+        q = v / Fraction(2) ** (e - 23)           # in units of the ulp
+        n = q.numerator // q.denominator
+        rem = q - n
+        if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and n % 2 == 1):
+            n += 1
+        x = float(n) * 2.0 ** (e - 23)
+        return struct.unpack("<f", struct.pack("<f", x))[0] if x < 3.5e38 else float("inf")
+
+    for lit in ("16777217", "16777217.00000000000000000000001", "0.1000000014901161193847656250000000000000000000000000001",
+                "1.00000005960464477539062500000000000000001", "1.000000059604644775390625", "9007199254740993", "1e-45", "7e-46",
+                "7.1e-46", "3.4028235677973366e38", "1." + "7" * 600, "2.7182818284590452353602874713527"):
+        got = oracle.parse_f32_text(lit.encode())
+        assert got == nearest_f32(lit), lit
+
+
 def test_vcf_last_line_without_newline_and_crlf(oracle):
     r = oracle.vcf_parse(HDR + b"1\t5\t.\tA\tC\t3.5\tPASS\tX\r\n1\t7\t.\tA\tC\t.\t.\tY")
     assert r.n_rows == 2 and rows(r)[0][7] == b"X" and rows(r)[1][7] == b"Y"
@@ -227,6 +268,18 @@ def test_vcf_typed_header_keys_in_header_order_first_definition_wins(oracle):
     info, fmt = oracle.vcf_header_keys(VCF_HDR)
     assert info == [("DP", "Integer", False), ("AF", "Float", True), ("DB", "Flag", False), ("ANN", "String", True)]
     assert fmt == [("GT", "String", False), ("AD", "Integer", True)]
+
+
+def test_vcf_typed_strings_are_percent_decoded(oracle):
+    # noodles-vcf 0.34 (rust/Cargo.lock:2193-2194): String / Character values of INFO and of the samples go through
+    # percent_encoding::percent_decode(..).decode_utf8(); ids, alts, filters and keys do not
+    assert oracle.percent_decode(b"a%3Bb%2c%25") == b"a;b,%" and oracle.percent_decode(b"%zz%4%") == b"%zz%4%"
+    hdr = (b"##fileformat=VCFv4.2\n##INFO=<ID=S,Number=.,Type=String,Description=\"s\">\n##FORMAT=<ID=GT,Number=1,Type=String,Description=\"g\">\n"
+           b"#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tX\n")
+    rows, err = oracle.vcf_typed_rows(hdr + b"1\t5\ti%3B\tA\tC\t.\tf%3B\tS=a%3Bb,%e2%82%ac\tGT\t0%2F1\n")
+    assert err is None and rows[0]["info"]["S"] == ["a;b", "\u20ac"] and rows[0]["formats"][0]["GT"] == "0/1"
+    assert rows[0]["id"] == ["i%3B"] and rows[0]["filter"] == ["f%3B"]
+    assert oracle.vcf_typed_rows(hdr + b"1\t5\t.\tA\tC\t.\t.\tS=%ff\tGT\t0\n")[1] == 0      # not UTF-8 after decoding: a value error
 
 
 def test_vcf_typed_lists_split_and_missing_is_empty(oracle):

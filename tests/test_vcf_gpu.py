@@ -118,9 +118,13 @@ EDGE = {
     "bad_qual": HDR + b"1\t5\t.\tA\tC\tabc\tPASS\t.\n",
     "qual_forms": HDR + b"".join(b"1\t5\t.\tA\tC\t" + q + b"\tPASS\t.\n" for q in
                                  [b"0", b"0.0", b"59.2", b"12.9", b"1e2", b"1E+2", b"2.5e-3", b".5", b"5.", b"+7.25",
-                                  b"-0", b"inf", b"-Infinity", b"NaN", b"3000", b"16777217", b"0.1", b"0.3",
+                                  b"-0", b"inf", b"Infinity", b"NaN", b"3000", b"16777217", b"0.1", b"0.3",
                                   b"123456.789", b"1.17549435e-38"[:0] + b"9.999999e9", b"000012.50"]),
     "qual_bad_forms": HDR + b"1\t5\t.\tA\tC\t1e\tPASS\t.\n",
+    # noodles-vcf 0.34 QualityScore refuses n < 0.0: "-1" and "-inf" are errors; "-0", "-0.0", "nan", "-nan" are not
+    "qual_negative": HDR + b"1\t5\t.\tA\tC\t-0\tPASS\t.\n1\t6\t.\tA\tC\t-1\tPASS\t.\n1\t7\t.\tA\tC\t2\tPASS\t.\n",
+    "qual_negative_small": HDR + b"1\t5\t.\tA\tC\t-nan\tPASS\t.\n1\t6\t.\tA\tC\t-1e-50\tPASS\t.\n1\t6\t.\tA\tC\t-1e-45\tPASS\t.\n",
+    "qual_negative_inf": HDR + b"1\t5\t.\tA\tC\t-0.0\tPASS\t.\n1\t6\t.\tA\tC\t-Infinity\tPASS\t.\n",
     "qual_dot_only": HDR + b"1\t5\t.\tA\tC\t..\tPASS\t.\n",
     "long_info": HDR + b"1\t5\t.\tA\tC\t1\tPASS\t" + b"K=" + b"v" * 700 + b"\tGT\t0/1\n" + b"1\t6\t.\tA\tC\t1\tPASS\tS\n",
     "first_error_wins": HDR + b"1\t5\t.\tA\tC\t.\tPASS\t.\n1\tzz\t.\tA\tC\t.\tPASS\t.\n1\t5\t.\tA\n",
@@ -169,6 +173,54 @@ def test_qual_parse_is_correctly_rounded(gpu, oracle, algo):
             quals.append(b"%de%d" % (rng.integers(1, 10 ** 9), rng.integers(-20, 15)))
     data = HDR + b"".join(b"1\t5\t.\tA\tC\t" + q + b"\tPASS\t.\n" for q in quals)
     check(oracle, data, algo)
+
+
+def test_long_and_extreme_qual_literals_are_exact(gpu, oracle):
+    """Beyond Clinger's fast path: 8 .. 19 significant digits, exponents of any size, subnormals, overflow to infinity,
+    exact halfway points (Eisel-Lemire on the first 19 digits), and literals of 20 .. 700 digits (decided by the two ends
+    of the interval their first 19 digits pin down) — bit for bit the oracle's strtof."""
+    rng = np.random.default_rng(77)
+    quals = [b"16777217", b"16777216.000000000000000000000", b"16777217.0000000000000000000000001", b"16777218.99999999999999999999",
+             b"0.100000001490116119384765625", b"0.1000000014901161193847656250000000000000000000000000001",
+             b"3.4028234663852886e38", b"3.4028235677973366e38", b"3.40282357e38", b"1e39", b"123456789e31", b"1e-45", b"7e-46", b"7.1e-46",
+             b"1.401298464324817e-45", b"1.17549435e-38", b"1.1754942e-38", b"5.877471754111438e-39", b"1e-60", b"0e999999", b"1e+38", b"1E-38",
+             b"9007199254740993", b"9007199254740992.5", b"18446744073709551615", b"18446744073709551616", b"99999999999999999999999999999999999999",
+             b"0." + b"0" * 40 + b"123456789", b"1" + b"0" * 38, b"1" + b"0" * 39, b"0.3333333333333333333333333333333333", b"2.7182818284590452353602874713527",
+             b"1." + b"7" * 600, b"8" * 30 + b"." + b"8" * 30 + b"e-25"]
+    for _ in range(3000):
+        nd = int(rng.integers(8, 40))
+        digits = "".join(str(int(d)) for d in rng.integers(0, 10, nd))
+        dot = int(rng.integers(0, nd + 1))
+        lit = (digits[:dot] or "0") + "." + digits[dot:] if rng.random() < 0.8 else digits
+        if rng.random() < 0.5:
+            lit += "e%d" % int(rng.integers(-60, 45))
+        quals.append(lit.encode())
+    # python-style reprs (17 significant digits) of floats and of float32 values
+    for _ in range(1500):
+        x = float(rng.random() * 10.0 ** int(rng.integers(-30, 30)))
+        quals.append(repr(x).encode())
+        quals.append(repr(float(np.float32(x))).encode())
+    lines = [b"1\t5\t.\tA\tC\t" + q + b"\tPASS\t.\n" for q in quals]
+    for algo in (abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS):
+        res = check(oracle, HDR + b"".join(lines), algo)
+        assert res.error_code == 0 and res.n_records == len(quals)
+
+
+def test_a_long_literal_on_a_rounding_boundary_fails_loudly(gpu, oracle):
+    """More than 19 significant digits AND a float rounding boundary strictly inside the interval their first 19 digits pin
+    down (relative width 10^-19) — about one literal in 10^11: the device reports it (EXG_PE_VCF_BAD_QUAL + EXG_RF_QUAL_RANGE) instead of risking a wrong bit; the
+    oracle (strtof) and the reference (Rust's dec2flt slow path) decide it.  Here: halfway between 1.0 and its
+    successor, plus 10^-41."""
+    from exon_duckdb_amd import device
+    lit = b"1.00000005960464477539062500000000000000001"
+    data = HDR + b"1\t5\t.\tA\tC\t2\tPASS\t.\n1\t6\t.\tA\tC\t" + lit + b"\tPASS\t.\n"
+    exp = oracle.vcf_parse(data)
+    assert exp.error_code == 0 and float(exp.extra["qual"][1]) == float(np.float32(1.0000001192092896))
+    d_in = device.upload(data)
+    scan = device.VcfScan(len(data))
+    scan.launch(d_in, lead=header_bytes(data))
+    res = scan.fetch()
+    assert res.error_code == abi.EXG_PE_VCF_BAD_QUAL and res.error_record == 1 and (res.flags & abi.EXG_RF_QUAL_RANGE)
 
 
 def test_short_decimal_qual_and_pos_fast_paths_are_exact(gpu, oracle):

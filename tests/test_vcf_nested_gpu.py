@@ -91,6 +91,8 @@ def edge_lines():
         b"4\t40\tx\tAC\tA\t7\tPASS\tDP=-12;DP=13;AF=3\tPL:GT\t1.5,2.5e1,-0.125:1\t.:\t.:.",
         b"5\t50\tx\tAC\tA\t7\tPASS\tANN=;DP",
         b"6\t60\tx\tAC\tA\t7\tPASS\tDP=2147483647;AF=inf,NaN,-infinity\tGT",
+        # String / Character values are percent-decoded (INFO and samples); ids, alts and filters are not
+        b"7\t70\ta%3Bb\tA\t<%41>\t7\tq%31\tANN=a%3Bb,c%2C%25,%zz,%4,100%,%e2%82%ac" + b"x" * 20 + b";CH=%41\tGT:AD\t0%2F1:1\t%7c:2\t" + b"%2e" * 9,
     ]
 
 
@@ -117,6 +119,23 @@ def test_typed_edge_cases(gpu, oracle, tmp_path, batch_rows):
     assert all(same(g, e) for g, e in zip(reader_rows(str(tmp_path / "l.vcf"), batch_rows), exp))
     (tmp_path / "l.vcf.gz").write_bytes(gzip.compress(data))
     assert all(same(g, e) for g, e in zip(reader_rows(str(tmp_path / "l.vcf.gz"), batch_rows), exp))
+
+
+def test_percent_decoding(gpu, oracle, tmp_path):
+    from exon_duckdb_amd import ExgError
+    from exon_duckdb_amd.reader import ShardReader
+    data = HEADER + edge_lines()[6] + b"\n"
+    (tmp_path / "p.vcf").write_bytes(data)
+    row = reader_rows(str(tmp_path / "p.vcf"))[0]
+    assert row["info"]["ANN"] == ["a;b", "c,%", "%zz", "%4", "100%", "\u20ac" + "x" * 20] and row["info"]["CH"] == "A"
+    assert row["id"] == ["a%3Bb"] and row["alt"] == ["<%41>"] and row["filter"] == ["q%31"]
+    assert [s["GT"] for s in row["formats"]] == ["0/1", "|", "." * 9]
+    # a decoded value that is not UTF-8 is a value error of its row (percent_decode(..).decode_utf8())
+    bad = HEADER + b"1\t10\t.\tA\tC\t1\tPASS\tDP=5\n1\t11\t.\tA\tC\t1\tPASS\tANN=ok,%ff\n1\t12\t.\tA\tC\t1\tPASS\tDP=6\n"
+    (tmp_path / "b.vcf").write_bytes(bad)
+    assert oracle.vcf_typed_rows(bad)[1] == 1
+    with pytest.raises(ExgError):
+        ShardReader(str(tmp_path / "b.vcf"), "vcf").rows()
 
 
 def test_typed_value_error_after_the_rows_in_front(gpu, oracle, tmp_path):
