@@ -1,0 +1,140 @@
+// exg_crc32.hip — CRC-32 (IEEE 802.3, the gzip trailer's checksum, RFC 1952 2.3.1) of inflated bytes that are already in
+// HBM.  The reference's decoders verify it (flate2 1.0.26 GzDecoder / MultiGzDecoder, noodles-bgzf: "corrupt gzip stream
+// does not have a matching checksum", rust/Cargo.lock:1328-1329, behind rust/src/arrow_reader.rs:60-91); so does this.
+//
+// One wavefront per segment (a BGZF member's <= 64 KiB of output; longer outputs are cut into segments and the host
+// combines the segments' checksums — arithmetic on 32-bit values, exg_crc32_combine).  The 64 lanes take 64 consecutive
+// slices of L = ceil(len / 64) bytes, aligned to the END of the piece so that the bytes behind lane i's slice are exactly
+// (63 - i) L: every lane runs the table-driven byte recurrence over its slice from state 0 (the lane that holds the piece's
+// first byte from the running state), and six combine levels add the lanes up — a state followed by n bytes of anything is
+// that state times x^(8n) mod P, one carry-less multiply-reduce (32 shift-xor steps), the multiplier squared per level.
+#include "exg_common.hpp"
+
+namespace exg {
+
+static constexpr uint32_t kCrcPoly = 0xEDB88320u;
+
+// a(x) b(x) mod P in the reflected representation (bit 31 = x^0), as in zlib's crc32.c multmodp
+__host__ __device__ inline uint32_t crc_multmodp(uint32_t a, uint32_t b) {
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) {
+            p ^= b;
+            if ((a & (m - 1)) == 0) break;
+        }
+        m >>= 1;
+        b = b & 1 ? (b >> 1) ^ kCrcPoly : b >> 1;
+    }
+    return p;
+}
+// x^(n 2^k) mod P
+__host__ __device__ inline uint32_t crc_x2nmodp(uint64_t n, uint32_t k) {
+    uint32_t p = 1u << 31;  // x^0
+    uint32_t sq = 1u << 30; // x^1
+    for (uint32_t i = 0; i < k; i++) sq = crc_multmodp(sq, sq);  // x^(2^k)
+    while (n) {
+        if (n & 1) p = crc_multmodp(sq, p);
+        n >>= 1;
+        if (n) sq = crc_multmodp(sq, sq);
+    }
+    return p;
+}
+
+struct CrcSeg {
+    uint64_t off;  // first byte in d_data
+    uint64_t len;
+};
+
+__device__ __forceinline__ uint32_t crc_bytes(const uint32_t *tab, const uint8_t *p, uint64_t n, uint32_t c) {
+    // head to a 4-byte boundary, then a dword per load
+    while (n && ((uintptr_t)p & 3)) {
+        c = tab[(c ^ *p++) & 0xFF] ^ (c >> 8);
+        n--;
+    }
+    for (; n >= 4; n -= 4, p += 4) {
+        c ^= *reinterpret_cast<const uint32_t *>(p);
+        c = tab[c & 0xFF] ^ (c >> 8);
+        c = tab[c & 0xFF] ^ (c >> 8);
+        c = tab[c & 0xFF] ^ (c >> 8);
+        c = tab[c & 0xFF] ^ (c >> 8);
+    }
+    while (n--) c = tab[(c ^ *p++) & 0xFF] ^ (c >> 8);
+    return c;
+}
+
+// MODE 0: segs[] given.  MODE 1: segment i = the output of inflate member i (members[i].out_off, status[i].produced).
+template <int MODE>
+__global__ __launch_bounds__(64) void k_crc32(const uint8_t *__restrict__ data, const CrcSeg *__restrict__ segs, const exg_inflate_member *members,
+                                              const exg_inflate_status *status, uint32_t n_segs, uint32_t *crc_out) {
+    __shared__ uint32_t tab[256];
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t t = lane; t < 256; t += 64) {
+        uint32_t c = t;
+        for (int k = 0; k < 8; k++) c = c & 1 ? (c >> 1) ^ kCrcPoly : c >> 1;
+        tab[t] = c;
+    }
+    __syncthreads();
+    for (uint32_t sidx = blockIdx.x; sidx < n_segs; sidx += gridDim.x) {
+        uint64_t off, len;
+        if (MODE == 0) {
+            off = segs[sidx].off, len = segs[sidx].len;
+        } else {
+            off = members[sidx].out_off, len = status[sidx].code ? 0 : status[sidx].produced;
+        }
+        uint32_t state = 0xFFFFFFFFu;  // wave-uniform running state
+        for (uint64_t done = 0; done < len; done += 65536) {
+            const uint32_t ln = (uint32_t)(len - done < 65536 ? len - done : 65536);
+            const uint32_t L = (ln + 63) / 64;
+            const long long lo = (long long)ln - (long long)(64 - lane) * L, hi = (long long)ln - (long long)(63 - lane) * L;
+            uint32_t c = 0;
+            if (hi > 0) {
+                const long long a = lo > 0 ? lo : 0;
+                c = crc_bytes(tab, data + off + done + a, (uint64_t)(hi - a), lo <= 0 ? state : 0u);
+            }
+            // lanes -> one state: level d folds lane i + d into lane i with the multiplier x^(8 d L)
+            uint32_t M = crc_x2nmodp(L, 3);
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t other = __shfl_down(c, d, 64);
+                c = crc_multmodp(M, c) ^ other;  // (only lanes that are multiples of 2d keep a meaningful value)
+                M = crc_multmodp(M, M);
+            }
+            state = __builtin_amdgcn_readfirstlane(c);
+        }
+        if (lane == 0) crc_out[sidx] = state ^ 0xFFFFFFFFu;
+    }
+}
+
+}  // namespace exg
+
+// CRC-32 of n_segs byte ranges of d_data (device): d_segs[i] = {offset, length}; d_crc[i] receives the finished checksum
+// (init and final xor 0xFFFFFFFF applied).  Asynchronous.
+extern "C" int exg_crc32_segments(const void *d_data, const exg_crc_segment *d_segs, uint32_t n_segs, uint32_t *d_crc, void *stream) {
+    static_assert(sizeof(exg_crc_segment) == sizeof(exg::CrcSeg), "layout");
+    if (!n_segs) return EXG_OK;
+    if (!d_data || !d_segs || !d_crc) {
+        exg::set_error("exg_crc32_segments: null argument");
+        return EXG_E_INVALID_ARG;
+    }
+    hipLaunchKernelGGL((exg::k_crc32<0>), dim3(n_segs < 16384 ? n_segs : 16384), dim3(64), 0, (hipStream_t)stream, (const uint8_t *)d_data,
+                       (const exg::CrcSeg *)d_segs, nullptr, nullptr, n_segs, d_crc);
+    EXG_HIP_CHECK(hipGetLastError());
+    return EXG_OK;
+}
+// ... of the outputs of exg_inflate_members (d_members[i].out_off, d_status[i].produced bytes), in the same order
+extern "C" int exg_crc32_members(const void *d_out, const exg_inflate_member *d_members, const exg_inflate_status *d_status, uint32_t n_members,
+                                 uint32_t *d_crc, void *stream) {
+    if (!n_members) return EXG_OK;
+    if (!d_out || !d_members || !d_status || !d_crc) {
+        exg::set_error("exg_crc32_members: null argument");
+        return EXG_E_INVALID_ARG;
+    }
+    hipLaunchKernelGGL((exg::k_crc32<1>), dim3(n_members < 16384 ? n_members : 16384), dim3(64), 0, (hipStream_t)stream, (const uint8_t *)d_out,
+                       nullptr, d_members, d_status, n_members, d_crc);
+    EXG_HIP_CHECK(hipGetLastError());
+    return EXG_OK;
+}
+// Host: the checksum of A followed by B from crc(A), crc(B) and len(B) (zlib's crc32_combine)
+extern "C" uint32_t exg_crc32_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) {
+    return exg::crc_multmodp(exg::crc_x2nmodp(len_b, 3), crc_a) ^ crc_b;
+}

@@ -73,7 +73,11 @@ extern "C" int exg_gzip_index(const uint8_t *data, uint64_t n, uint64_t start, e
             m.comp_size = n - p;
             uint64_t isize = data[n - 4] | ((uint64_t)data[n - 3] << 8) | ((uint64_t)data[n - 2] << 16) |
                              ((uint64_t)data[n - 1] << 24);
-            uint64_t bound = (n - p) * 8 + 65536;
+            // DEFLATE expands at most 1032:1.  A small member (what stays on the one-wavefront path: below 128 KiB of
+            // input) gets that bound — `cat a.vcf.gz b.vcf.gz` of highly compressible members must not be reported as
+            // corrupt for outgrowing a guessed ratio; a big one is decoded in chunks (exg_inflate_stream sizes its own
+            // output), and 8:1 + ISIZE only bounds the fallback with that path switched off
+            uint64_t bound = (n - p) < (128u << 10) ? (n - p) * 1032 + 65536 : (n - p) * 8 + 65536;
             m.out_cap = isize > bound ? isize : bound;
             out += m.out_cap;
             k++;

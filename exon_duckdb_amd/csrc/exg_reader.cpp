@@ -309,6 +309,75 @@ static int upload_file(exg_reader *r, void *d_dst, uint64_t n, uint64_t file_off
     return EXG_OK;
 }
 
+// ---- gzip trailers (RFC 1952 2.3.1): CRC-32 and ISIZE of every member, verified like flate2 / noodles-bgzf verify them ----
+static uint32_t rd_le32(const uint8_t *p) { return p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+// Members [0, count) were inflated by exg_inflate_members(d_out, d_members, d_status) on r->stream: their checksums are
+// computed on the device behind it and compared with the trailers in the compressed bytes on the host (`comp`; a
+// member's comp_off is relative to comp + bias).  open_last: the last member ran to its own end (trailer behind the bytes
+// it consumed).  Also returns the members' statuses (st).
+static int check_members(exg_reader *r, const uint8_t *comp, uint64_t n_comp, uint64_t bias, const void *d_out, const exg_inflate_member *d_members,
+                         const exg_inflate_status *d_status, const exg_inflate_member *h_members, uint64_t count, bool open_last,
+                         std::vector<exg_inflate_status> &st, const std::string &path) {
+    if (!count) return EXG_OK;
+    struct Pooled {
+        int dev;
+        void *p;
+        size_t sz;
+        ~Pooled() { if (p) exg_rd::dev_pool()->give(dev, p, sz); }
+    };
+    const size_t crc_bytes = ((count * 4 + 4095) & ~(size_t)4095) + (1u << 20);
+    Pooled d_crc{r->device, exg_rd::dev_pool()->take(r->device, crc_bytes), crc_bytes};
+    if (!d_crc.p) return fail(r, EXG_E_HIP, "out of device memory for the member checksums");
+    int rc = exg_crc32_members(d_out, d_members, d_status, (uint32_t)count, (uint32_t *)d_crc.p, r->stream);
+    if (rc) return fail(r, rc, exg_last_error_message());
+    st.resize(count);
+    std::vector<uint32_t> crc(count);
+    RD_HIP(r, hipMemcpyAsync(st.data(), d_status, count * sizeof(exg_inflate_status), hipMemcpyDeviceToHost, r->stream));
+    RD_HIP(r, hipMemcpyAsync(crc.data(), d_crc.p, count * 4, hipMemcpyDeviceToHost, r->stream));
+    RD_HIP(r, hipStreamSynchronize(r->stream));
+    for (uint64_t i = 0; i < count; i++) {
+        const bool open = open_last && i + 1 == count;
+        if (st[i].code || (!open && st[i].produced != h_members[i].out_cap))
+            return fail(r, EXG_E_PARSE, "corrupt deflate stream (member " + std::to_string(i) + ", code " + std::to_string(st[i].code) + ") in '" + path + "'");
+        const uint64_t trailer = bias + h_members[i].comp_off + (open ? st[i].consumed : h_members[i].comp_size - 8);
+        if (trailer + 8 > n_comp) return fail(r, EXG_E_PARSE, "truncated gzip member (no trailer) in '" + path + "'");
+        if (rd_le32(comp + trailer) != crc[i] || rd_le32(comp + trailer + 4) != (uint32_t)st[i].produced)
+            return fail(r, EXG_E_PARSE, "corrupt gzip stream does not have a matching checksum (member " + std::to_string(i) + " of '" + path + "')");
+    }
+    return EXG_OK;
+}
+
+// one long output (exg_inflate_stream) against its trailer at comp[trailer]: 64 KiB segments on the device, combined here
+static int check_stream(exg_reader *r, const uint8_t *comp, uint64_t n_comp, uint64_t trailer, const void *d_out, uint64_t produced, const std::string &path) {
+    if (trailer + 8 > n_comp) return fail(r, EXG_E_PARSE, "truncated gzip member (no trailer) in '" + path + "'");
+    const uint64_t seg = 65536, n_seg = (produced + seg - 1) / seg;
+    uint32_t total = 0;  // crc32 of nothing
+    if (n_seg) {
+        std::vector<exg_crc_segment> segs(n_seg);
+        for (uint64_t i = 0; i < n_seg; i++) segs[i] = exg_crc_segment{i * seg, std::min<uint64_t>(seg, produced - i * seg)};
+        void *d = nullptr;
+        RD_HIP(r, hipMalloc(&d, n_seg * (sizeof(exg_crc_segment) + 4) + 64));
+        struct Free {
+            void *p;
+            ~Free() { (void)hipFree(p); }
+        } fr{d};
+        uint32_t *d_crc = (uint32_t *)((char *)d + n_seg * sizeof(exg_crc_segment));
+        RD_HIP(r, hipMemcpyAsync(d, segs.data(), n_seg * sizeof(exg_crc_segment), hipMemcpyHostToDevice, r->stream));
+        int rc = exg_crc32_segments(d_out, (const exg_crc_segment *)d, (uint32_t)n_seg, d_crc, r->stream);
+        if (rc) return fail(r, rc, exg_last_error_message());
+        std::vector<uint32_t> crc(n_seg);
+        RD_HIP(r, hipMemcpyAsync(crc.data(), d_crc, n_seg * 4, hipMemcpyDeviceToHost, r->stream));
+        RD_HIP(r, hipStreamSynchronize(r->stream));
+        // fold: all segments but the last have the same length, so the multiplier x^(8 len) is the same one
+        total = crc[0];
+        for (uint64_t i = 1; i < n_seg; i++) total = exg_crc32_combine(total, crc[i], segs[i].len);
+    }
+    if (rd_le32(comp + trailer) != total || rd_le32(comp + trailer + 4) != (uint32_t)produced)
+        return fail(r, EXG_E_PARSE, "corrupt gzip stream does not have a matching checksum ('" + path + "')");
+    return EXG_OK;
+}
+
 // BGZF input read as shard `shard_index` of `shard_count`: the members are divided among the shards (the index costs a
 // pointer chase, no decode), this reader uploads and inflates only its own members plus ~1 MiB of members in front of
 // them — the halo that holds the beginning of the record that ends behind the cut — and scans them like a text shard.
@@ -459,6 +528,10 @@ static int inflate_file_shard(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, 
             RD_HIP(r, hipMemcpyAsync(dm.p, hm.data(), hm.size() * sizeof(exg_inflate_member), hipMemcpyHostToDevice, r->stream));
             rc0 = exg_inflate_members(dc.p, dd.p, (const exg_inflate_member *)dm.p, d_st, (uint32_t)hm.size(), r->stream);
             if (rc0) return fail(r, rc0, exg_last_error_message());
+            {
+                std::vector<exg_inflate_status> hst;
+                if ((rc0 = check_members(r, comp, n, 0, dd.p, (const exg_inflate_member *)dm.p, d_st, hm.data(), hm.size(), false, hst, path))) return rc0;
+            }
             if (out_blk->p) global_pool()->give((char *)out_blk->p, out_blk->cap), out_blk->p = nullptr;
             size_t cap = out + 64;
             out_blk->p = global_pool()->take(&cap);
@@ -584,14 +657,11 @@ static int inflate_file_shard(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, 
     rc = exg_inflate_members(comp_buf.p, out_buf.p, (const exg_inflate_member *)d_members, (exg_inflate_status *)d_status, (uint32_t)cnt,
                              r->stream);
     if (rc) return fail(r, rc, exg_last_error_message());
-    std::vector<exg_inflate_status> st(cnt);
-    RD_HIP(r, hipMemcpyAsync(st.data(), d_status, cnt * sizeof(exg_inflate_status), hipMemcpyDeviceToHost, r->stream));
+    std::vector<exg_inflate_status> st;
     RD_HIP(r, hipMemsetAsync((char *)out_buf.p + out_total, 0, 64, r->stream));
-    RD_HIP(r, hipStreamSynchronize(r->stream));
-    for (uint64_t i = 0; i < cnt; i++)
-        if (st[i].code || st[i].produced != members[h0 + i].out_cap)
-            return fail(r, EXG_E_PARSE, "corrupt deflate stream (member " + std::to_string(h0 + i) + ", code " + std::to_string(st[i].code) +
-                                            ") in '" + path + "'");
+    if ((rc = check_members(r, comp, n, c0a, out_buf.p, (const exg_inflate_member *)d_members, (const exg_inflate_status *)d_status, members + h0, cnt,
+                            false, st, path)))
+        return rc;
     out_blk->n = out_total;
     blk = out_blk;
     r->d_file = out_buf.p;
@@ -727,14 +797,12 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
         }
         up_thread.join();
         if (prog.rc) return prog.rc;
-        std::vector<exg_inflate_status> st(k);
-        RD_HIP(r, hipMemcpyAsync(st.data(), d_status, k * sizeof(exg_inflate_status), hipMemcpyDeviceToHost, r->stream));
-        RD_HIP(r, hipStreamSynchronize(r->stream));
-        TRACE("gz: h2d + inflate", t_h2d);
-        for (uint64_t i = 0; i < k; i++)
-            if (i >= i0 || st[i].code || st[i].produced != members[i].out_cap)
-                return fail(r, EXG_E_PARSE, "corrupt deflate stream (member " + std::to_string(i) + ", code " + std::to_string(st[i].code) +
-                                                ") in '" + path + "'");
+        if (i0 < k) return fail(r, EXG_E_PARSE, "truncated gzip member in '" + path + "'");
+        std::vector<exg_inflate_status> st;
+        int crc_rc = check_members(r, comp, n, 0, d_out, (const exg_inflate_member *)d_members, (const exg_inflate_status *)d_status, members.get(), k,
+                                   false, st, path);
+        TRACE("gz: h2d + inflate + crc32", t_h2d);
+        if (crc_rc) return crc_rc;
         produced_total = out_cap_total = first.total;
         start = n;
     } else {
@@ -778,6 +846,10 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
             void *d_big = nullptr;
             rc = exg_inflate_stream(d_comp, members[0].comp_off, members[0].comp_size, chunk, &d_big, &produced, &consumed, r->stream);
             if (rc) return fail(r, rc, std::string(exg_last_error_message()) + " in '" + path + "'");
+            if ((rc = check_stream(r, comp, n, members[0].comp_off + consumed, d_big, produced, path))) {
+                exg_rd::dev_pool()->give(r->device, d_big, produced + 64);
+                return rc;
+            }
             if (!d_out) {
                 d_out = d_big;
                 d_out_cap = produced + 64;
@@ -830,17 +902,11 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
         rc = exg_inflate_members(d_comp, d_out, (const exg_inflate_member *)d_members, (exg_inflate_status *)d_status,
                                  (uint32_t)k, r->stream);
         if (rc) return fail(r, rc, exg_last_error_message());
-        std::vector<exg_inflate_status> st(k);
-        RD_HIP(r, hipMemcpyAsync(st.data(), d_status, k * sizeof(exg_inflate_status), hipMemcpyDeviceToHost, r->stream));
-        RD_HIP(r, hipStreamSynchronize(r->stream));
-        TRACE("gz: inflate members", t_inf);
-        for (uint64_t i = 0; i < k; i++) {
-            const bool sized = !(open_ended && i + 1 == k);
-            if (st[i].code || (sized && st[i].produced != members[i].out_cap)) {
-                return fail(r, EXG_E_PARSE, "corrupt deflate stream (member " + std::to_string(i) + ", code " +
-                                                std::to_string(st[i].code) + ") in '" + path + "'");
-            }
-        }
+        std::vector<exg_inflate_status> st;
+        rc = check_members(r, comp, n, 0, d_out, (const exg_inflate_member *)d_members, (const exg_inflate_status *)d_status, members.get(), k,
+                           open_ended != 0, st, path);
+        TRACE("gz: inflate members + crc32", t_inf);
+        if (rc) return rc;
         if (open_ended) {
             // the last member ran to its own end: compact its output, continue after its 8-byte trailer
             const exg_inflate_member &m = members[k - 1];

@@ -270,6 +270,19 @@ int exg_gzip_index(const uint8_t *data, uint64_t n, uint64_t start, exg_inflate_
 int exg_inflate_members(const void *d_comp, void *d_out, const exg_inflate_member *d_members,
                         exg_inflate_status *d_status, uint32_t n_members, void *stream);
 
+/* CRC-32 (the gzip trailer's checksum) of inflated bytes in HBM — the reference's decoders verify it (flate2 GzDecoder /
+ * noodles-bgzf: "corrupt gzip stream does not have a matching checksum"), and so does the reader for every member.
+ * One wavefront per segment; exg_crc32_members takes the segments from an exg_inflate_members call (out_off, produced).
+ * Longer outputs are cut into segments whose checksums the host combines (exg_crc32_combine = zlib's crc32_combine). */
+typedef struct exg_crc_segment {
+    uint64_t off; /* first byte in d_data */
+    uint64_t len;
+} exg_crc_segment;
+int exg_crc32_segments(const void *d_data, const exg_crc_segment *d_segs, uint32_t n_segs, uint32_t *d_crc, void *stream);
+int exg_crc32_members(const void *d_out, const exg_inflate_member *d_members, const exg_inflate_status *d_status, uint32_t n_members,
+                      uint32_t *d_crc, void *stream);
+uint32_t exg_crc32_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);
+
 /* ONE big DEFLATE stream (a single-member gzip file) decoded by many wavefronts: block starts are searched near
  * every chunk_bytes of compressed input, the chunks are decoded concurrently with an unknown window and stitched
  * (pugz / rapidgzip method).  d_comp: the compressed bytes on the device, 16-byte aligned; the stream starts at
