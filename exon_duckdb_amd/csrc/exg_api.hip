@@ -77,6 +77,10 @@ extern "C" int exg_fastq_scan(const exg_fastq_scan_args *a) {
         set_error("exg_fastq_scan: bad arguments (null pointer, unaligned input or lead > n_bytes)");
         return EXG_E_INVALID_ARG;
     }
+    if (a->flags & ~EXG_F_ALL) {
+        set_error("exg_fastq_scan: unknown flag bits 0x%x", a->flags & ~EXG_F_ALL);
+        return EXG_E_INVALID_ARG;
+    }
     if (a->capacity_records && !(a->flags & EXG_F_NO_STORE) &&
         (!a->d_name || !a->d_description || !a->d_sequence || !a->d_quality || !a->d_description_validity)) {
         set_error("exg_fastq_scan: null output column");

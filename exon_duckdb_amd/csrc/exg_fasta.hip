@@ -436,6 +436,10 @@ extern "C" int exg_fasta_scan(const exg_fasta_scan_args *a) {
         set_error("exg_fasta_scan: bad arguments (null pointer or unaligned input)");
         return EXG_E_INVALID_ARG;
     }
+    if (a->flags & ~EXG_F_ALL) {
+        set_error("exg_fasta_scan: unknown flag bits 0x%x", a->flags & ~EXG_F_ALL);
+        return EXG_E_INVALID_ARG;
+    }
     if (a->lead != 0 || (a->flags & (EXG_F_BOF | EXG_F_EOF)) != (EXG_F_BOF | EXG_F_EOF)) {
         set_error("exg_fasta_scan: whole-file buffers only (lead = 0, EXG_F_BOF | EXG_F_EOF): a FASTA record can "
                   "span the whole input");

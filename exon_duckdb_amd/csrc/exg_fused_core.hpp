@@ -236,7 +236,11 @@ __global__ __launch_bounds__(kThreads, F::kMinWavesPerSimd) void k_fused(typenam
     // DEV ONLY (tools/dev_probe.py): flags bits 8..11 select ablations on the synthetic FASTQ-150 file
     //   1: analytic prefix instead of the scanner   2: 1 + no output stores
     //   3: 1 + no emission at all                    4: scanner, no emission
-    const uint32_t dev_mode = (a.flags >> 8) & 15u;
+#ifdef EXG_DEV_PROBE
+    const uint32_t dev_mode = (a.flags >> 8) & 15u;  // ablations of tools/dev_probe.py (no prefix wait / no stores / no emission)
+#else
+    constexpr uint32_t dev_mode = 0;  // the product build carries no work-skipping mode (EXG_CXXFLAGS=-DEXG_DEV_PROBE builds them in)
+#endif
     if (blockIdx.x == 0) {  // the scanner: one wave, no tile
         if (wave == 0 && !(dev_mode >= 1 && dev_mode <= 3)) scanner_wave<F::kHalves * kTile>(a.d_in, a.n_bytes, tileA, tileP, n_super, lane);
         return;

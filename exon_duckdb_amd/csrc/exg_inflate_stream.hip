@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "exg_inflate_core.hpp"
+#include "exg_reader.hpp"
 
 namespace exg {
 
@@ -571,7 +572,8 @@ extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint6
     ST_HIP(d_co.alloc(n * sizeof(ChunkOut)));
     ST_HIP(d_win.alloc((size_t)n * 32768));
     ST_HIP(d_bad.alloc(4));
-    ST_HIP(hipMalloc(&d_out, total + 64));
+    // (allocated at the device pool's size class: the reader hands the buffer to that pool when the file is done)
+    ST_HIP(hipMalloc(&d_out, exg_rd::DevPool::size_class(total + 64)));
     ST_HIP(hipMemcpyAsync(d_co.p, co.data(), n * sizeof(ChunkOut), hipMemcpyHostToDevice, stream));
     ST_HIP(hipMemsetAsync(d_win.p, 0, 32768, stream));
     ST_HIP(hipMemsetAsync(d_bad.p, 0, 4, stream));

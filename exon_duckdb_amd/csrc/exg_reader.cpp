@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <functional>
 #include <memory>
 #include <string>
 #include <thread>
@@ -1341,6 +1342,8 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
                                                  r->file_pos - lead == r->data_base);
         const uint32_t fl = (at_line_start ? EXG_F_BOF : 0u) | (eof ? EXG_F_EOF : 0u) | (no_store ? EXG_F_NO_STORE : 0u);
         std::shared_ptr<Batch> b;
+        bool fused_first = false;
+        std::function<int()> rescan_general;
         if (r->format == EXG_FMT_FASTQ) {
             exg_fastq_scan_args a;
             memset(&a, 0, sizeof a);
@@ -1350,7 +1353,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             a.first_line_index = first_line_index;
             a.payload_base = (uint64_t)(uintptr_t)h;
             a.flags = fl;
-            a.algo = EXG_ALGO_AUTO;
+            a.algo = EXG_ALGO_FUSED;
             a.d_name = (exg_string_t *)r->d_cols[0];
             a.d_description = (exg_string_t *)r->d_cols[1];
             a.d_sequence = (exg_string_t *)r->d_cols[2];
@@ -1362,6 +1365,11 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             a.d_result = (exg_scan_result *)r->d_res;
             a.stream = r->stream;
             rc = exg_fastq_scan(&a);
+            fused_first = true;
+            rescan_general = [a]() mutable {
+                a.algo = EXG_ALGO_MULTIPASS;
+                return exg_fastq_scan(&a);
+            };
         } else if (r->format == EXG_FMT_VCF) {
             exg_vcf_scan_args a;
             memset(&a, 0, sizeof a);
@@ -1370,7 +1378,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             a.lead = lead;
             a.payload_base = (uint64_t)(uintptr_t)h;
             a.flags = fl;
-            a.algo = EXG_ALGO_AUTO;
+            a.algo = EXG_ALGO_FUSED;
             for (int c = 0; c < 9; c++) a.d_fields[c] = (exg_string_t *)r->d_cols[c];
             a.d_pos = (int64_t *)r->d_pos;
             a.d_qual = (float *)r->d_qual;
@@ -1382,6 +1390,11 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             a.d_result = (exg_scan_result *)r->d_res;
             a.stream = r->stream;
             rc = exg_vcf_scan(&a);
+            fused_first = true;
+            rescan_general = [a]() mutable {
+                a.algo = EXG_ALGO_MULTIPASS;
+                return exg_vcf_scan(&a);
+            };
         } else {
             b = std::make_shared<Batch>();
             if (!count_only) {
@@ -1411,6 +1424,15 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         double t_scan = now_s();
         rc = exg_fetch_result((const exg_scan_result *)r->d_res, r->stream, &res);
         if (rc) return fail(r, rc, exg_last_error_message());
+        if (fused_first && (res.flags & EXG_RF_FALLBACK)) {
+            // a record longer than the fused kernel's window, a byte >= 0x80, ...: the general path, on the same batch
+            // (the reader launches it only now — EXG_ALGO_AUTO would enqueue its ten gated kernels behind every scan)
+            rc = rescan_general();
+            if (rc) return fail(r, rc, exg_last_error_message());
+            rc = exg_fetch_result((const exg_scan_result *)r->d_res, r->stream, &res);
+            if (rc) return fail(r, rc, exg_last_error_message());
+            res.flags |= EXG_RF_FALLBACK;
+        }
         TRACE("wait(h2d) + scan", t_scan);
         if (res.flags & EXG_RF_INDEX_OVERFLOW)
             return fail(r, EXG_E_CAPACITY, "line index overflow in the general path (pathological line density)");
@@ -1937,6 +1959,15 @@ extern "C" int exg_drain_chunks(exg_reader *r, uint64_t *n_rows, uint64_t *n_chu
         *n_chunks += 1;
         exg_release_chunk(r, &c);
     }
+}
+
+// Give back what the process-wide pools hold (device buffers, pinned host blocks, streams of closed readers): for the
+// extension's unload / idle path — a long-lived DuckDB process sharing the GPU should not sit on tens of GB it no longer
+// uses.  Readers that are open keep what they hold.
+extern "C" void exg_trim_pools(void) {
+    exg_rd::dev_pool()->trim(0);
+    exg_rd::global_pool()->trim();
+    exg_rd::stream_pool()->trim();
 }
 
 extern "C" const char *exg_reader_error(exg_reader *r) { return r ? r->error.c_str() : ""; }

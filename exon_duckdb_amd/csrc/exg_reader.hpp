@@ -1,6 +1,8 @@
 // exg_reader.hpp — internals of the reader level shared by exg_reader.cpp (DuckDB-shaped chunks) and
 // exg_arrow_stream.cpp (the reference's new_reader: Arrow record batches).
 #pragma once
+#include <stdlib.h>
+
 #include <algorithm>
 #include <memory>
 #include <thread>
@@ -81,6 +83,12 @@ struct BlockPool {
         }
         (void)hipHostFree(p);
     }
+    void trim() {
+        std::lock_guard<std::mutex> g(mu);
+        for (auto &b : free_blocks) (void)hipHostFree(b.first);
+        free_blocks.clear();
+        pooled_bytes = 0;
+    }
     ~BlockPool() {
         for (auto &b : free_blocks) (void)hipHostFree(b.first);
     }
@@ -124,6 +132,11 @@ struct StreamPool {
         }
         (void)hipStreamDestroy(s);
     }
+    void trim() {
+        std::lock_guard<std::mutex> g(mu);
+        for (auto &e : free_streams) (void)hipStreamDestroy(e.second);
+        free_streams.clear();
+    }
 };
 inline StreamPool *stream_pool() {
     static StreamPool *pool = new StreamPool();  // never destroyed, like the other pools
@@ -139,8 +152,24 @@ struct DevPool {
     std::mutex mu;
     std::vector<Blk> free_blocks;
     size_t pooled_bytes = 0;
-    static constexpr size_t kMaxPooled = 64ull << 30;  // of 288 GB; trimmed when a hipMalloc fails
+    // of 288 GB; trimmed when a hipMalloc fails, by exg_trim_pools(), and bounded by EXG_POOL_MAX_GB (default 64)
+    static size_t max_pooled() {
+        static const size_t v = [] {
+            const char *e = getenv("EXG_POOL_MAX_GB");
+            return (size_t)(e ? strtoull(e, nullptr, 10) : 64) << 30;
+        }();
+        return v;
+    }
+    // Requests are rounded up to a size class — eight per octave (at most 12.5 % over) — so that the buffers of one file
+    // serve the next file of about the same size; an exact-size pool kept one block per distinct byte count alive.
+    static size_t size_class(size_t sz) {
+        if (sz <= (1u << 20)) return (sz + 4095) & ~(size_t)4095;
+        size_t step = (size_t)1 << (63 - __builtin_clzll((unsigned long long)sz));  // largest power of two <= sz
+        step >>= 3;
+        return (sz + step - 1) & ~(step - 1);
+    }
     void *take(int dev, size_t sz) {
+        sz = size_class(sz);
         {
             std::lock_guard<std::mutex> g(mu);
             for (size_t i = 0; i < free_blocks.size(); i++)
@@ -154,16 +183,21 @@ struct DevPool {
         DeviceGuard g(dev);
         void *p = nullptr;
         if (hipMalloc(&p, sz) != hipSuccess) {
+            (void)hipGetLastError();
             trim(0);  // give the cached blocks back and try once more
-            if (hipMalloc(&p, sz) != hipSuccess) return nullptr;
+            if (hipMalloc(&p, sz) != hipSuccess) {
+                (void)hipGetLastError();
+                return nullptr;
+            }
         }
         return p;
     }
-    void give(int dev, void *p, size_t sz) {
+    void give(int dev, void *p, size_t sz) {  // sz: what take() was asked for (or any size of the same class)
         if (!p) return;
+        sz = size_class(sz);
         {
             std::lock_guard<std::mutex> g(mu);
-            if (sz >= (1u << 20) && pooled_bytes + sz <= kMaxPooled) {
+            if (sz >= (1u << 20) && pooled_bytes + sz <= max_pooled()) {
                 free_blocks.push_back(Blk{dev, p, sz});
                 pooled_bytes += sz;
                 return;

@@ -452,6 +452,10 @@ extern "C" int exg_vcf_scan(const exg_vcf_scan_args *a) {
         set_error("exg_vcf_scan: bad arguments (null pointer, unaligned input or lead > n_bytes)");
         return EXG_E_INVALID_ARG;
     }
+    if (a->flags & ~EXG_F_ALL) {
+        set_error("exg_vcf_scan: unknown flag bits 0x%x", a->flags & ~EXG_F_ALL);
+        return EXG_E_INVALID_ARG;
+    }
     FastqWsLayout l = fastq_ws_layout(a->n_bytes, a->workspace_bytes);
     if (a->workspace_bytes < fastq_ws_layout(a->n_bytes, 0).off_nl_pos + 64) {
         set_error("exg_vcf_scan: workspace too small");

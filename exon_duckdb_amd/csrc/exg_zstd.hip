@@ -25,6 +25,7 @@
 #include <algorithm>
 
 #include "exg_common.hpp"
+#include "exg_reader.hpp"
 #include "exg_zstd.hpp"
 
 namespace exg {
@@ -956,7 +957,8 @@ extern "C" int exg_zstd_decode(const uint8_t *h_comp, const void *d_comp_v, uint
         }
     }
     const double t_entropy = trace ? sync_ms(st) : 0;
-    EXG_HIP_CHECK(d_out.alloc(total + 64));
+    // (allocated at the device pool's size class: the reader hands the buffer to that pool when the file is done)
+    EXG_HIP_CHECK(d_out.alloc(exg_rd::DevPool::size_class(total + 64)));
     EXG_HIP_CHECK(hipMemsetAsync((char *)d_out.p + total, 0, 64, st));
     const uint32_t nc = (uint32_t)chunks.size();
     double t_exec = 0, t_resolve = 0;

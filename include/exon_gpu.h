@@ -105,6 +105,7 @@ typedef union exg_string_t {
 #define EXG_F_BOF 1u /* a line starts at d_input[0] (start of file, or a record-aligned batch) */
 #define EXG_F_EOF 2u /* d_input[n_bytes-1] is the last byte of the file */
 #define EXG_F_NO_STORE 4u /* COUNT(*) path: parse and validate every record, write no column (capacity ignored) */
+#define EXG_F_ALL 7u      /* any other bit is refused (EXG_E_INVALID_ARG) */
 
 /* result flags */
 #define EXG_RF_NON_ASCII 1u /* a byte >= 0x80 was seen; UTF-8 was validated by the slow kernel */
@@ -405,6 +406,9 @@ int exg_count_only(exg_reader *r, uint64_t *n_rows);
 /* Pull and release every remaining chunk (a consumer that only walks the DataChunks): rows and chunks handed out. */
 int exg_drain_chunks(exg_reader *r, uint64_t *n_rows, uint64_t *n_chunks);
 const char *exg_reader_error(exg_reader *r);
+/* Device buffers, pinned host blocks and HIP streams of closed readers are recycled process-wide (size classes, at most
+ * EXG_POOL_MAX_GB = 64 GB of HBM): this gives them back (the extension's unload / idle path). */
+void exg_trim_pools(void);
 void exg_close(exg_reader *r);
 
 /* ---- (3) reference-FFI compatible ------------------------------------------------------ */

@@ -1,0 +1,91 @@
+// Sanitizer driver of the host-only pieces of libexon_gpu (tests/test_host_asan.py builds it with
+// -fsanitize=address,undefined and runs it): the gzip member index (exg_gzip.cpp), the zstd frame / block walk
+// (exg_zstd_index.cpp) and the `filters` parser (exg_filter.hpp) on valid inputs, on truncations of them and on random
+// mutations — every byte these parsers read comes from a user's file or query text.
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <random>
+#include <string>
+#include <vector>
+
+#include "exg_filter.hpp"
+#include "exg_zstd.hpp"
+
+namespace exg {
+void set_error(const char *, ...) {}
+}  // namespace exg
+
+static std::vector<uint8_t> read_file(const char *path) {
+    std::vector<uint8_t> v;
+    FILE *f = fopen(path, "rb");
+    if (!f) return v;
+    uint8_t buf[65536];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) v.insert(v.end(), buf, buf + n);
+    fclose(f);
+    return v;
+}
+
+int main(int argc, char **argv) {
+    std::mt19937_64 rng(99);
+    long runs = 0;
+    // argv: files (gzip / zstd streams written by the test)
+    for (int a = 1; a < argc; a++) {
+        const std::vector<uint8_t> base = read_file(argv[a]);
+        if (base.empty()) return 2;
+        for (int trial = 0; trial < 400; trial++) {
+            std::vector<uint8_t> d = base;
+            if (trial % 4 == 1) d.resize(rng() % (d.size() + 1));
+            if (trial % 4 >= 2)
+                for (int k = 0; k < 1 + (int)(rng() % 4); k++) d[rng() % d.size()] ^= (uint8_t)(1u << (rng() % 8));
+            // the parsers get exactly d.size() readable bytes (a heap block of that size: ASan sees any over-read)
+            uint8_t *p = (uint8_t *)malloc(d.size() ? d.size() : 1);
+            memcpy(p, d.data(), d.size());
+            {
+                std::vector<exg_inflate_member> members(d.size() / 18 + 8);
+                uint64_t k = 0, total = 0;
+                int open_ended = 0;
+                (void)exg_gzip_index(p, d.size(), 0, members.data(), members.size(), &k, &total, &open_ended);
+            }
+            {
+                exg::zst::Index idx;
+                (void)exg::zst::build_index(p, d.size(), idx);
+                for (const auto &b : idx.blocks)
+                    if (b.src_off + (b.type == 1 ? 1 : b.src_size) > d.size()) return 3;  // a block the walk accepted must lie inside the input
+            }
+            free(p);
+            runs++;
+        }
+    }
+    // the filter grammar on well-formed and mangled predicates
+    const std::vector<exg_rd::FilterColumn> cols = {{"chrom", 'u'}, {"pos", 'l'}, {"id", 'x'}, {"qual", 'f'}};
+    const char *seeds[] = {"chrom='7' AND pos>=3000 AND pos<9000", "qual IS NULL OR qual>900.5", "\"chrom\"!='a''b' AND (pos<>1 OR qual<=1e3)",
+                           "id='x'", "pos=", "((((chrom='1'", "qual>'abc'", "chrom IS NOT NULL AND chrom IS NULL OR pos>1 OR pos>2 OR pos>3"};
+    for (const char *sd : seeds)
+        for (int trial = 0; trial < 300; trial++) {
+            std::string t = sd;
+            if (trial) {
+                for (int k = 0; k < 1 + (int)(rng() % 3); k++) {
+                    const size_t at = rng() % (t.size() + 1);
+                    switch (rng() % 3) {
+                        case 0: t.insert(at, 1, (char)(32 + rng() % 95)); break;
+                        case 1: if (!t.empty()) t.erase(at % t.size(), 1); break;
+                        default: if (!t.empty()) t[at % t.size()] = (char)(rng() % 256); break;
+                    }
+                }
+            }
+            exg_rd::FilterParser fp(t, cols);
+            (void)fp.parse();
+            runs++;
+        }
+    // a long conjunction must be refused, not overflow the program
+    std::string big = "pos>0";
+    for (int i = 0; i < 100; i++) big += " AND pos>" + std::to_string(i);
+    exg_rd::FilterParser fp(big, cols);
+    if (fp.parse()) return 4;
+    printf("%ld runs\n", runs);
+    return 0;
+}
