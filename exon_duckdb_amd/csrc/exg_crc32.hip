@@ -45,20 +45,25 @@ struct CrcSeg {
     uint64_t len;
 };
 
-__device__ __forceinline__ uint32_t crc_bytes(const uint32_t *tab, const uint8_t *p, uint64_t n, uint32_t c) {
-    // head to a 4-byte boundary, then a dword per load
-    while (n && ((uintptr_t)p & 3)) {
-        c = tab[(c ^ *p++) & 0xFF] ^ (c >> 8);
+// slicing-by-4 (Kounavis & Berry): tab[k][b] = the state after byte b followed by k zero bytes, so a dword costs four
+// INDEPENDENT lookups instead of a chain of four; 16 bytes per load
+__device__ __forceinline__ uint32_t crc_dword(const uint32_t (*tab)[256], uint32_t c, uint32_t w) {
+    c ^= w;
+    return tab[3][c & 0xFF] ^ tab[2][(c >> 8) & 0xFF] ^ tab[1][(c >> 16) & 0xFF] ^ tab[0][c >> 24];
+}
+__device__ __forceinline__ uint32_t crc_bytes(const uint32_t (*tab)[256], const uint8_t *p, uint64_t n, uint32_t c) {
+    while (n && ((uintptr_t)p & 15)) {  // head to a 16-byte boundary
+        c = tab[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
         n--;
     }
-    for (; n >= 4; n -= 4, p += 4) {
-        c ^= *reinterpret_cast<const uint32_t *>(p);
-        c = tab[c & 0xFF] ^ (c >> 8);
-        c = tab[c & 0xFF] ^ (c >> 8);
-        c = tab[c & 0xFF] ^ (c >> 8);
-        c = tab[c & 0xFF] ^ (c >> 8);
+    for (; n >= 16; n -= 16, p += 16) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(p);
+        c = crc_dword(tab, c, v.x);
+        c = crc_dword(tab, c, v.y);
+        c = crc_dword(tab, c, v.z);
+        c = crc_dword(tab, c, v.w);
     }
-    while (n--) c = tab[(c ^ *p++) & 0xFF] ^ (c >> 8);
+    while (n--) c = tab[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
     return c;
 }
 
@@ -66,14 +71,21 @@ __device__ __forceinline__ uint32_t crc_bytes(const uint32_t *tab, const uint8_t
 template <int MODE>
 __global__ __launch_bounds__(64) void k_crc32(const uint8_t *__restrict__ data, const CrcSeg *__restrict__ segs, const exg_inflate_member *members,
                                               const exg_inflate_status *status, uint32_t n_segs, uint32_t *crc_out) {
-    __shared__ uint32_t tab[256];
+    __shared__ uint32_t tab[4][256];
     const uint32_t lane = threadIdx.x;
     for (uint32_t t = lane; t < 256; t += 64) {
         uint32_t c = t;
         for (int k = 0; k < 8; k++) c = c & 1 ? (c >> 1) ^ kCrcPoly : c >> 1;
-        tab[t] = c;
+        tab[0][t] = c;
     }
     __syncthreads();
+    for (int k = 1; k < 4; k++) {
+        for (uint32_t t = lane; t < 256; t += 64) {
+            const uint32_t c = tab[k - 1][t];
+            tab[k][t] = tab[0][c & 0xFF] ^ (c >> 8);
+        }
+        __syncthreads();
+    }
     for (uint32_t sidx = blockIdx.x; sidx < n_segs; sidx += gridDim.x) {
         uint64_t off, len;
         if (MODE == 0) {

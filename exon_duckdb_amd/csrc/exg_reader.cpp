@@ -319,7 +319,7 @@ static uint32_t rd_le32(const uint8_t *p) { return p[0] | ((uint32_t)p[1] << 8) 
 // it consumed).  Also returns the members' statuses (st).
 static int check_members(exg_reader *r, const uint8_t *comp, uint64_t n_comp, uint64_t bias, const void *d_out, const exg_inflate_member *d_members,
                          const exg_inflate_status *d_status, const exg_inflate_member *h_members, uint64_t count, bool open_last,
-                         std::vector<exg_inflate_status> &st, const std::string &path) {
+                         std::vector<exg_inflate_status> &st, const std::string &path, const uint32_t *d_crc_ready = nullptr) {
     if (!count) return EXG_OK;
     struct Pooled {
         int dev;
@@ -328,14 +328,16 @@ static int check_members(exg_reader *r, const uint8_t *comp, uint64_t n_comp, ui
         ~Pooled() { if (p) exg_rd::dev_pool()->give(dev, p, sz); }
     };
     const size_t crc_bytes = ((count * 4 + 4095) & ~(size_t)4095) + (1u << 20);
-    Pooled d_crc{r->device, exg_rd::dev_pool()->take(r->device, crc_bytes), crc_bytes};
-    if (!d_crc.p) return fail(r, EXG_E_HIP, "out of device memory for the member checksums");
-    int rc = exg_crc32_members(d_out, d_members, d_status, (uint32_t)count, (uint32_t *)d_crc.p, r->stream);
-    if (rc) return fail(r, rc, exg_last_error_message());
+    Pooled d_crc{r->device, d_crc_ready ? nullptr : exg_rd::dev_pool()->take(r->device, crc_bytes), crc_bytes};
+    if (!d_crc_ready) {
+        if (!d_crc.p) return fail(r, EXG_E_HIP, "out of device memory for the member checksums");
+        int rc = exg_crc32_members(d_out, d_members, d_status, (uint32_t)count, (uint32_t *)d_crc.p, r->stream);
+        if (rc) return fail(r, rc, exg_last_error_message());
+    }
     st.resize(count);
     std::vector<uint32_t> crc(count);
     RD_HIP(r, hipMemcpyAsync(st.data(), d_status, count * sizeof(exg_inflate_status), hipMemcpyDeviceToHost, r->stream));
-    RD_HIP(r, hipMemcpyAsync(crc.data(), d_crc.p, count * 4, hipMemcpyDeviceToHost, r->stream));
+    RD_HIP(r, hipMemcpyAsync(crc.data(), d_crc_ready ? (const void *)d_crc_ready : d_crc.p, count * 4, hipMemcpyDeviceToHost, r->stream));
     RD_HIP(r, hipStreamSynchronize(r->stream));
     for (uint64_t i = 0; i < count; i++) {
         const bool open = open_last && i + 1 == count;
@@ -782,6 +784,9 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
         RD_HIP(r, hipMalloc(&d_status, k * sizeof(exg_inflate_status)));
         Free fs{d_status};
         RD_HIP(r, hipMemcpyAsync(d_members, members.get(), k * sizeof(exg_inflate_member), hipMemcpyHostToDevice, r->stream));
+        void *d_crc_all = nullptr;
+        RD_HIP(r, hipMalloc(&d_crc_all, k * 4 + 64));
+        Free fc{d_crc_all};
         uint64_t i0 = 0;
         for (size_t w = 0; w < prog.done.size(); w++) {
             if (!prog.wait_for(w)) break;  // the upload failed: its error is reported below
@@ -792,6 +797,10 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
             if (i1 > i0) {
                 int rc = exg_inflate_members(d_comp, d_out, (const exg_inflate_member *)d_members + i0, (exg_inflate_status *)d_status + i0,
                                              (uint32_t)(i1 - i0), r->stream);
+                // ... and their checksums right behind them, while the next windows still travel
+                if (!rc)
+                    rc = exg_crc32_members(d_out, (const exg_inflate_member *)d_members + i0, (const exg_inflate_status *)d_status + i0,
+                                           (uint32_t)(i1 - i0), (uint32_t *)d_crc_all + i0, r->stream);
                 if (rc) return fail(r, rc, exg_last_error_message());
             }
             i0 = i1;
@@ -801,7 +810,7 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
         if (i0 < k) return fail(r, EXG_E_PARSE, "truncated gzip member in '" + path + "'");
         std::vector<exg_inflate_status> st;
         int crc_rc = check_members(r, comp, n, 0, d_out, (const exg_inflate_member *)d_members, (const exg_inflate_status *)d_status, members.get(), k,
-                                   false, st, path);
+                                   false, st, path, (const uint32_t *)d_crc_all);
         TRACE("gz: h2d + inflate + crc32", t_h2d);
         if (crc_rc) return crc_rc;
         produced_total = out_cap_total = first.total;

@@ -1,22 +1,26 @@
 #!/bin/bash
 # Round profile collection, run on the GPU box from the repo root:
-#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r01_d'
+#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r02_a'
 # Writes gpurun_out/<tag>_*; tools/pmc_summary.py then condenses them into profiles/.
 set -u
-TAG=${1:-r01_d}
+TAG=${1:-r02_a}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd $ROOT
-python3 bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+# the bench line as the driver takes it (all configs, cpu baseline)
+python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt -o kt --output-format csv -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_kt.log 2>&1
+# headline kernel: per-kernel times of the same command (without the side legs), then the HBM counters in passes of their own
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt -o kt --output-format csv -- python3 $ROOT/bench.py --no-configs --no-cpu-baseline > $OUT/${TAG}_kt.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c -d $OUT/${TAG}_pmc_$c -o pmc --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c -d $OUT/${TAG}_pmc_$c -o pmc --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --launches-per-step 2 --no-configs --no-cpu-baseline > $OUT/${TAG}_pmc_$c.log 2>&1
 done
-ls -R $OUT | head -50
-# inflate kernels (BGZF members; single-member stream through the reader)
-rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_inflate -o kt --output-format csv -- python3 $ROOT/tools/bench_inflate.py > $OUT/${TAG}_kt_inflate.log 2>&1
+# the configs legs (config 1 FASTA, config 3 VCF, config 4 BGZF inflate + CRC-32, end to end): every kernel of them
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_configs -o kt --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --launches-per-step 2 --no-cpu-baseline --gz-gb 2 --e2e-gb 2 > $OUT/${TAG}_kt_configs.log 2>&1
+# zstd decode (512 MB single frame, level 3)
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_zstd -o kt --output-format csv -- python3 $ROOT/tools/zstd_probe.py 512 > $OUT/${TAG}_kt_zstd.log 2>&1
+# single-member gzip through the reader (chunked decode)
 GZ_RECORDS=800000 GZ_ONLY_SINGLE=1 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_gzstream -o kt --output-format csv -- python3 $ROOT/tools/gz_probe.py > $OUT/${TAG}_kt_gzstream.log 2>&1
-ls $OUT/${TAG}_kt_inflate $OUT/${TAG}_kt_gzstream
+find $OUT -name "*kernel_stats.csv" -newer $OUT/${TAG}_bench.json | head

@@ -51,6 +51,10 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         w.writerows(rows)
     vals = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == c]
     res[c] = sum(vals) / len(vals)
+for leg in ("configs", "zstd", "gzstream"):
+    st = find(f"{tag}_kt_{leg}/**/*kernel_stats.csv")
+    if st:
+        shutil.copy(st, os.path.join(prof, f"{tag}_{leg}_kernel_stats.csv"))
 b = os.path.join(out, f"{tag}_bench.json")
 if os.path.exists(b):
     shutil.copy(b, os.path.join(prof, f"{tag}_bench.json"))
