@@ -594,34 +594,40 @@ struct ExecCfg<true> {
 };
 static constexpr uint32_t kPiece = 1024;  // elements emitted between two flush checks (ring >= 2 * kPiece)
 
+// Positions are 32-bit and relative to the chunk's first element (a chunk is a few MiB); `bias` = that element's index
+// mod 1024, so that ring slots and the 1024-element flush grid follow the ABSOLUTE index (full segments are 16-byte
+// aligned in HBM whatever the chunk's offset).  Almost every copy is short (a literal run or a match of a few elements):
+// those take one masked wave instruction and a boundary test — the general loops are for the long ones.
 template <bool SYM>
 struct Exec {
     using Elem = typename ExecCfg<SYM>::Elem;
     static constexpr uint32_t kRing = ExecCfg<SYM>::kRing, kMask = kRing - 1;
-    Elem *ring;          // LDS
-    Elem *out;           // the element array in HBM (bytes: the output; symbols: d_sym)
-    uint64_t start;      // element index of the chunk's first element
-    uint64_t abs;        // ... of the next element
-    uint64_t flushed;    // elements below this index are in HBM
+    static constexpr uint32_t kStage = 1024;  // elements of far-match sources staged per 64-sequence group
+    Elem *ring;        // LDS
+    Elem *out0;        // the chunk's first element in HBM (bytes: the output; symbols: d_sym)
+    uint32_t bias;     // (index of the chunk's first element) & 1023
+    uint32_t pos;      // elements emitted so far
+    uint32_t flushed;  // elements [0, flushed) are in HBM
     uint32_t lane;
 
-    // completed 1024-element segments (on the absolute 1024 grid, so that all but the first are 16-byte aligned) -> HBM
+    __device__ __forceinline__ uint32_t slot(uint32_t p) const { return (bias + p) & kMask; }
+    // completed 1024-element segments of the absolute grid -> HBM
     __device__ __forceinline__ void flush(bool all) {
         bool any = false;
         for (;;) {
-            uint64_t next = (flushed | 1023ull) + 1;
-            if (next > abs) {
-                if (!all || flushed == abs) break;
-                next = abs;
+            uint32_t next = ((bias + flushed) | 1023u) + 1 - bias;
+            if (next > pos) {
+                if (!all || flushed == pos) break;
+                next = pos;
             }
-            const uint32_t n = (uint32_t)(next - flushed);
+            const uint32_t n = next - flushed;
             if (n == 1024) {
-                const Elem *src = ring + ((uint32_t)flushed & kMask) + lane * 16;
-                Elem *dst = out + flushed + lane * 16;
+                const Elem *src = ring + slot(flushed) + lane * 16;
+                Elem *dst = out0 + flushed + lane * 16;
 #pragma unroll
                 for (uint32_t k = 0; k < sizeof(Elem); k++) reinterpret_cast<uint4 *>(dst)[k] = reinterpret_cast<const uint4 *>(src)[k];
             } else {
-                for (uint32_t e = lane; e < n; e += 64) out[flushed + e] = ring[(uint32_t)(flushed + e) & kMask];
+                for (uint32_t e = lane; e < n; e += 64) out0[flushed + e] = ring[slot(flushed + e)];
             }
             flushed = next;
             any = true;
@@ -630,126 +636,191 @@ struct Exec {
         // the stores only have to be complete first
         if (any) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     }
-    __device__ __forceinline__ void put_bytes(const uint8_t *src, uint32_t n) {
+    __device__ __forceinline__ void advance(uint32_t n) {
+        pos += n;
+        if (((bias + pos) ^ (bias + flushed)) >> 10) flush(false);  // a 1024 boundary was crossed
+    }
+    template <class Src>
+    __device__ __forceinline__ void put_from(const Src *src, uint32_t n) {  // src: LDS or HBM, elements or bytes
+        if (n <= 64) {
+            if (lane < n) ring[slot(pos + lane)] = (Elem)src[lane];
+            advance(n);
+            return;
+        }
         for (uint32_t done = 0; done < n;) {
             const uint32_t piece = n - done < kPiece ? n - done : kPiece;
-            for (uint32_t i = lane; i < piece; i += 64) ring[(uint32_t)(abs + i) & kMask] = (Elem)src[done + i];
-            abs += piece;
+            for (uint32_t i = lane; i < piece; i += 64) ring[slot(pos + i)] = (Elem)src[done + i];
             done += piece;
-            flush(false);
+            advance(piece);
         }
     }
+    __device__ __forceinline__ void put_bytes(const uint8_t *src, uint32_t n) { put_from(src, n); }
+    __device__ __forceinline__ void put_lds(const uint8_t *src, uint32_t n) { put_from(src, n); }
+    __device__ __forceinline__ void put_staged(const Elem *src, uint32_t n) { put_from(src, n); }
     __device__ __forceinline__ void put_fill(uint8_t v, uint32_t n) {
         for (uint32_t done = 0; done < n;) {
             const uint32_t piece = n - done < kPiece ? n - done : kPiece;
-            for (uint32_t i = lane; i < piece; i += 64) ring[(uint32_t)(abs + i) & kMask] = (Elem)v;
-            abs += piece;
+            for (uint32_t i = lane; i < piece; i += 64) ring[slot(pos + i)] = (Elem)v;
             done += piece;
-            flush(false);
+            advance(piece);
         }
+    }
+    // one element of a match's source: chunk-relative position s (negative: in front of the chunk — symbol chunks only)
+    __device__ __forceinline__ Elem fetch(int32_t s, uint32_t hi) const {
+        if (SYM && s < 0) return (Elem)(kSymRef | (uint32_t)(-s));  // "the byte d in front of the chunk's first"
+        if ((uint32_t)s + kRing >= hi) return ring[slot((uint32_t)s)];
+        return __hip_atomic_load(out0 + (uint32_t)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // flushed >= 1 KiB ago
     }
     // LZ77 copy: `len` elements from `off` back; the source index is folded into [match start - off, match start), so an
     // overlapping copy is exact whatever the order the lanes work in
     __device__ __forceinline__ void put_match(uint32_t off, uint32_t len) {
-        const uint64_t m0 = abs;  // match start
+        const int32_t s0 = (int32_t)pos - (int32_t)off;  // source of the match's first element
+        if (len <= 64 && off >= len) {  // the usual shape: short, no overlap
+            if (lane < len) ring[slot(pos + lane)] = fetch(s0 + (int32_t)lane, pos + len);
+            advance(len);
+            return;
+        }
         for (uint32_t done = 0; done < len;) {
             const uint32_t piece = len - done < kPiece ? len - done : kPiece;
-            const uint64_t hi = abs + piece;
+            const uint32_t hi = pos + piece;
             for (uint32_t i = lane; i < piece; i += 64) {
                 const uint32_t k = done + i;
-                const uint32_t rel = off >= len ? k : k % off;
-                Elem x;
-                if (SYM && m0 + rel < start + off) {
-                    // in front of the chunk: "the byte d in front of the chunk's first", resolved once the bytes there are final
-                    x = (Elem)(kSymRef | (uint32_t)(start + off - (m0 + rel)));
-                } else {
-                    const uint64_t src = m0 - off + rel;
-                    if (src + kRing >= hi)
-                        x = ring[(uint32_t)src & kMask];
-                    else  // older than the ring: flushed at least 1 KiB ago
-                        x = __hip_atomic_load(out + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                ring[(uint32_t)(abs + i) & kMask] = x;
+                ring[slot(pos + i)] = fetch(s0 + (int32_t)(off >= len ? k : k % off), hi);
             }
-            abs += piece;
             done += piece;
-            flush(false);
+            advance(piece);
         }
     }
 };
 
+static constexpr uint32_t kLitStage = 4096;  // bytes of a 64-sequence group's literals staged in LDS
+
+// one chunk (a run of blocks of one frame) by one wavefront
 template <bool SYM>
-__global__ __launch_bounds__(64) void k_zst_exec(const uint8_t *__restrict__ comp, Block *blocks, const Chunk *chunks, uint32_t n_chunks,
-                                                 const uint8_t *__restrict__ lit, const uint32_t *__restrict__ d_ll,
-                                                 const uint32_t *__restrict__ d_ml, const uint32_t *__restrict__ d_off,
-                                                 typename ExecCfg<SYM>::Elem *out, uint32_t *chunk_status) {
-    using Elem = typename ExecCfg<SYM>::Elem;
-    __shared__ __attribute__((aligned(16))) Elem ring[ExecCfg<SYM>::kRing];
-    const uint32_t lane = threadIdx.x;
-    for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-        const Chunk C = chunks[c];
-        if ((C.symbolic != 0) != SYM) continue;
-        Exec<SYM> ex;
-        ex.ring = ring;
-        ex.out = out;
-        ex.lane = lane;
-        ex.start = ex.abs = ex.flushed = C.elem_off;
-        const uint64_t frame_pos0 = C.out_off - C.frame_out_off;  // bytes of the frame in front of the chunk
-        uint32_t err = 0;
-        for (uint32_t bi = 0; bi < C.n_blocks && !err; bi++) {
-            const uint32_t b = C.first_block + bi;
-            const Block B = blocks[b];
-            if (B.type == 0) {
-                ex.put_bytes(comp + B.src_off, B.src_size);
-            } else if (B.type == 1) {
-                ex.put_fill(comp[B.src_off], B.src_size);
-            } else {
-                const uint8_t *L = lit + B.lit_off;
-                uint32_t lit_pos = 0;
-                for (uint32_t g = 0; g < B.nseq && !err; g += 64) {
-                    const uint32_t i = g + lane;
-                    const bool valid = i < B.nseq;
-                    uint32_t ll = 0, ml = 0, off = 1;
-                    bool bad = false;
-                    if (valid) {
-                        ll = d_ll[B.seq_off + i];
-                        ml = d_ml[B.seq_off + i];
-                        const uint32_t code = d_off[B.seq_off + i];
-                        if (code & kRepSym) {
-                            const uint32_t slot = (code >> 29) & 3, k = code & 0x1FFFFFFFu;
-                            const uint32_t base = B.rep_in[slot];
-                            bad = base <= k;
-                            off = bad ? 1u : base - k;
-                        } else {
-                            off = code;
-                            bad = code == 0;
-                        }
+__device__ void exec_chunk(const Chunk &C, typename ExecCfg<SYM>::Elem *ring, uint32_t *lit_stage, typename ExecCfg<SYM>::Elem *match_stage,
+                           const uint8_t *__restrict__ comp,
+                           const Block *blocks, const uint8_t *__restrict__ lit, const uint32_t *__restrict__ d_ll,
+                           const uint32_t *__restrict__ d_ml, const uint32_t *__restrict__ d_off, typename ExecCfg<SYM>::Elem *out,
+                           uint32_t *status_out, uint32_t lane) {
+    Exec<SYM> ex;
+    ex.ring = ring;
+    ex.out0 = out + C.elem_off;
+    ex.bias = (uint32_t)(C.elem_off & 1023);
+    ex.pos = ex.flushed = 0;
+    ex.lane = lane;
+    const uint64_t frame_pos0 = C.out_off - C.frame_out_off;  // bytes of the frame in front of the chunk
+    const uint8_t *stage8 = reinterpret_cast<const uint8_t *>(lit_stage);
+    uint32_t err = 0;
+    for (uint32_t bi = 0; bi < C.n_blocks && !err; bi++) {
+        const uint32_t b = C.first_block + bi;
+        const Block B = blocks[b];
+        if (B.type == 0) {
+            ex.put_bytes(comp + B.src_off, B.src_size);
+        } else if (B.type == 1) {
+            ex.put_fill(comp[B.src_off], B.src_size);
+        } else {
+            const uint8_t *L = lit + B.lit_off;
+            uint32_t lit_pos = 0;
+            for (uint32_t g = 0; g < B.nseq && !err; g += 64) {
+                const uint32_t i = g + lane;
+                const bool valid = i < B.nseq;
+                uint32_t ll = 0, ml = 0, off = 1;
+                bool bad = false;
+                if (valid) {
+                    ll = d_ll[B.seq_off + i];
+                    ml = d_ml[B.seq_off + i];
+                    const uint32_t code = d_off[B.seq_off + i];
+                    if (code & kRepSym) {
+                        const uint32_t slot = (code >> 29) & 3, k = code & 0x1FFFFFFFu;
+                        const uint32_t base = B.rep_in[slot];
+                        bad = base <= k;
+                        off = bad ? 1u : base - k;
+                    } else {
+                        off = code;
+                        bad = code == 0;
                     }
-                    if (__any(bad)) {
+                }
+                if (__any(bad)) {
+                    err = kErrOffset;
+                    break;
+                }
+                const uint32_t ll_incl = wave_incl_sum(ll);
+                const uint32_t cnt = B.nseq - g < 64 ? B.nseq - g : 64;
+                const uint32_t group_lits = __builtin_amdgcn_readlane(ll_incl, 63);
+                // The literals of the group's sequences are one contiguous run of the literal buffer: staged in LDS by
+                // the whole wave at once (dword loads from the 4-byte boundary below), so that the per-sequence copies
+                // below do not each wait for HBM — that wait, once per sequence, was most of a chunk's time.
+                const uint32_t mis = (uint32_t)((uintptr_t)(L + lit_pos) & 3);
+                const bool staged = group_lits + mis <= kLitStage;
+                if (staged && group_lits) {
+                    const uint32_t *src = reinterpret_cast<const uint32_t *>(L + lit_pos - mis);
+                    const uint32_t words = (group_lits + mis + 3) / 4;
+                    for (uint32_t w = lane; w < words; w += 64) lit_stage[w] = src[w];
+                }
+                // Far matches: a match whose whole source already lies in HBM (flushed before this group began) would cost
+                // one exposed memory round trip per sequence — with short matches found far back (DNA) that was ~1.4 us of
+                // every sequence.  Every lane fetches ITS sequence's source into LDS (independent loads, all in flight
+                // together); the sequence loop below then copies LDS -> LDS.  Where a sequence's output begins is a prefix
+                // sum away (out_incl), so its source position is known before anything of the group is executed.
+                const uint32_t out_incl = wave_incl_sum(ll + ml);
+                const uint32_t m_pos = ex.pos + (out_incl - ml);  // where my match begins (chunk-relative)
+                bool far = false;
+                if (valid && ml && off <= m_pos)                      // the source lies inside this chunk ...
+                    far = off >= ml && m_pos - off + ml <= ex.flushed;  // ... and all of it is in HBM already
+                const uint32_t far_incl = wave_incl_sum(far ? ml : 0u);
+                uint32_t far_off = far_incl - (far ? ml : 0u);
+                if (far && far_incl > Exec<SYM>::kStage) far = false;     // (what does not fit is read the slow way)
+                if (far) {
+                    const typename ExecCfg<SYM>::Elem *src = ex.out0 + (m_pos - off);
+                    for (uint32_t k = 0; k < ml; k++) match_stage[far_off + k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                const unsigned long long far_mask = __ballot(far);
+                for (uint32_t j = 0; j < cnt; j++) {
+                    const uint32_t L_j = __builtin_amdgcn_readlane(ll, j), M_j = __builtin_amdgcn_readlane(ml, j);
+                    const uint32_t O_j = __builtin_amdgcn_readlane(off, j);
+                    const uint32_t lrel = __builtin_amdgcn_readlane(ll_incl, j) - L_j;
+                    if (L_j) {
+                        if (staged)
+                            ex.put_lds(stage8 + mis + lrel, L_j);
+                        else
+                            ex.put_bytes(L + lit_pos + lrel, L_j);
+                    }
+                    // libzstd: a match may reach back to the first byte of the frame's content, not beyond
+                    if (O_j > ex.pos && (uint64_t)O_j > frame_pos0 + ex.pos) {
                         err = kErrOffset;
                         break;
                     }
-                    const uint32_t ll_incl = wave_incl_sum(ll);
-                    const uint32_t cnt = B.nseq - g < 64 ? B.nseq - g : 64;
-                    for (uint32_t j = 0; j < cnt; j++) {
-                        const uint32_t L_j = __builtin_amdgcn_readlane(ll, j), M_j = __builtin_amdgcn_readlane(ml, j);
-                        const uint32_t O_j = __builtin_amdgcn_readlane(off, j);
-                        const uint32_t lsrc = lit_pos + __builtin_amdgcn_readlane(ll_incl, j) - L_j;
-                        if (L_j) ex.put_bytes(L + lsrc, L_j);
-                        // libzstd: a match may reach back to the first byte of the frame's content, not beyond
-                        if ((uint64_t)O_j > frame_pos0 + (ex.abs - ex.start)) {
-                            err = kErrOffset;
-                            break;
-                        }
+                    if ((far_mask >> j) & 1)
+                        ex.put_staged(match_stage + __builtin_amdgcn_readlane(far_off, j), M_j);
+                    else
                         ex.put_match(O_j, M_j);
-                    }
-                    lit_pos += __builtin_amdgcn_readlane(ll_incl, 63);
                 }
-                if (!err && lit_pos < B.lit_regen) ex.put_bytes(L + lit_pos, B.lit_regen - lit_pos);
+                lit_pos += group_lits;
             }
+            if (!err && lit_pos < B.lit_regen) ex.put_bytes(L + lit_pos, B.lit_regen - lit_pos);
         }
-        ex.flush(true);
-        if (lane == 0) chunk_status[c] = err;
+    }
+    ex.flush(true);
+    if (lane == 0) *status_out = err;
+}
+
+// byte chunks (the first of every frame) and symbol chunks in ONE launch: a lone byte chunk — one wavefront, ~5 ms for a
+// 128 KiB block — used to run ahead of the symbol chunks in a launch of its own
+__global__ __launch_bounds__(64) void k_zst_exec(const uint8_t *__restrict__ comp, const Block *blocks, const Chunk *chunks, uint32_t n_chunks,
+                                                 const uint8_t *__restrict__ lit, const uint32_t *__restrict__ d_ll,
+                                                 const uint32_t *__restrict__ d_ml, const uint32_t *__restrict__ d_off, uint8_t *out_bytes,
+                                                 uint32_t *out_syms, uint32_t *chunk_status) {
+    __shared__ __attribute__((aligned(16))) uint32_t ring[ExecCfg<true>::kRing];  // 8 KiB: 2 Ki symbols, or 4 Ki bytes
+    __shared__ __attribute__((aligned(16))) uint32_t lit_stage[kLitStage / 4 + 4];
+    __shared__ __attribute__((aligned(16))) uint32_t match_stage[Exec<true>::kStage];  // 4 KiB: 1 Ki symbols (bytes use a quarter)
+    static_assert(sizeof(ring) >= ExecCfg<false>::kRing, "the byte ring fits");
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        const Chunk C = chunks[c];
+        if (C.symbolic)
+            exec_chunk<true>(C, ring, lit_stage, match_stage, comp, blocks, lit, d_ll, d_ml, d_off, out_syms, chunk_status + c, lane);
+        else
+            exec_chunk<false>(C, reinterpret_cast<uint8_t *>(ring), lit_stage, reinterpret_cast<uint8_t *>(match_stage), comp, blocks, lit, d_ll, d_ml, d_off, out_bytes, chunk_status + c, lane);
         __syncthreads();
     }
 }
@@ -889,16 +960,28 @@ extern "C" int exg_zstd_decode(const uint8_t *h_comp, const void *d_comp_v, uint
         set_error("%s", idx.error.c_str());
         return EXG_E_PARSE;
     }
+    // temporaries come from (and go back to) the process-wide device pool: hipMalloc / hipFree of the multi-GB symbol
+    // and sequence buffers cost more than the decode (the same 4 GB decode: 0.20 s with warm buffers, 0.4 - 1.2 s without)
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
     struct Dev {
+        int dev;
         void *p = nullptr;
+        size_t sz = 0;
+        explicit Dev(int d) : dev(d) {}
         ~Dev() {
-            if (p) (void)hipFree(p);
+            if (p) exg_rd::dev_pool()->give(dev, p, sz);
         }
-        hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+        hipError_t alloc(size_t bytes) {
+            sz = bytes ? bytes : 16;
+            p = exg_rd::dev_pool()->take(dev, sz);
+            return p ? hipSuccess : hipErrorOutOfMemory;
+        }
     };
     const uint32_t nb = (uint32_t)idx.blocks.size(), nf = (uint32_t)idx.frames.size();
     const double t_index = trace ? now_ms() : 0;
-    Dev d_blocks, d_lit, d_ll, d_ml, d_off, d_meta, d_frames, d_chunks, d_status, d_out, d_sym;
+    Dev d_blocks(cur_dev), d_lit(cur_dev), d_ll(cur_dev), d_ml(cur_dev), d_off(cur_dev), d_meta(cur_dev), d_frames(cur_dev), d_chunks(cur_dev),
+        d_status(cur_dev), d_out(cur_dev), d_sym(cur_dev);
     EXG_HIP_CHECK(d_meta.alloc(64));
     uint64_t total = 0;
     if (nb) {
@@ -909,9 +992,34 @@ extern "C" int exg_zstd_decode(const uint8_t *h_comp, const void *d_comp_v, uint
         EXG_HIP_CHECK(d_off.alloc(idx.n_seq * 4 + 16));
         EXG_HIP_CHECK(hipMemcpyAsync(d_blocks.p, idx.blocks.data(), (size_t)nb * sizeof(Block), hipMemcpyHostToDevice, st));
         const uint32_t grid = nb < 16384 ? nb : 16384;
-        hipLaunchKernelGGL(k_zst_literals, dim3(grid), dim3(64), 0, st, d_comp, (Block *)d_blocks.p, nb, (uint8_t *)d_lit.p);
+        // the two entropy stages are independent of each other (both run one or four LANES per wavefront: the chip is far
+        // from full with either): literals on a second stream beside the sequences
+        const int dev = cur_dev;
+        hipStream_t st2 = nullptr;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        const bool side = exg_rd::stream_pool()->take(dev, &st2) == hipSuccess && hipEventCreateWithFlags(&ev0, hipEventDisableTiming) == hipSuccess &&
+                          hipEventCreateWithFlags(&ev1, hipEventDisableTiming) == hipSuccess;
+        if (side) {
+            (void)hipEventRecord(ev0, st);
+            (void)hipStreamWaitEvent(st2, ev0, 0);
+        }
+        hipLaunchKernelGGL(k_zst_literals, dim3(grid), dim3(64), 0, side ? st2 : st, d_comp, (Block *)d_blocks.p, nb, (uint8_t *)d_lit.p);
         hipLaunchKernelGGL(k_zst_sequences, dim3(grid), dim3(64), 0, st, d_comp, (Block *)d_blocks.p, nb, (uint32_t *)d_ll.p, (uint32_t *)d_ml.p,
                            (uint32_t *)d_off.p);
+        if (side) {
+            (void)hipEventRecord(ev1, st2);
+            (void)hipStreamWaitEvent(st, ev1, 0);
+        }
+        struct SideGuard {
+            int dev;
+            hipStream_t s;
+            hipEvent_t a, b;
+            ~SideGuard() {
+                if (a) (void)hipEventDestroy(a);
+                if (b) (void)hipEventDestroy(b);
+                if (s) exg_rd::stream_pool()->give(dev, s);  // (synchronises it)
+            }
+        } side_guard{dev, st2, ev0, ev1};
         hipLaunchKernelGGL(k_zst_scan, dim3(1), dim3(64), 0, st, (Block *)d_blocks.p, nb, (uint64_t *)d_meta.p);
         EXG_HIP_CHECK(hipGetLastError());
         EXG_HIP_CHECK(hipMemcpyAsync(idx.blocks.data(), d_blocks.p, (size_t)nb * sizeof(Block), hipMemcpyDeviceToHost, st));
@@ -958,7 +1066,7 @@ extern "C" int exg_zstd_decode(const uint8_t *h_comp, const void *d_comp_v, uint
     }
     const double t_entropy = trace ? sync_ms(st) : 0;
     // (allocated at the device pool's size class: the reader hands the buffer to that pool when the file is done)
-    EXG_HIP_CHECK(d_out.alloc(exg_rd::DevPool::size_class(total + 64)));
+    EXG_HIP_CHECK(d_out.alloc(total + 64));  // (the pool rounds to its size class: the reader hands the buffer back to it)
     EXG_HIP_CHECK(hipMemsetAsync((char *)d_out.p + total, 0, 64, st));
     const uint32_t nc = (uint32_t)chunks.size();
     double t_exec = 0, t_resolve = 0;
@@ -1005,13 +1113,9 @@ extern "C" int exg_zstd_decode(const uint8_t *h_comp, const void *d_comp_v, uint
         for (const Round &R : rounds) {
             const uint32_t cnt = R.c1 - R.c0, grid = cnt < 16384 ? cnt : 16384;
             const double t0 = trace ? sync_ms(st) : 0;
-            hipLaunchKernelGGL(k_zst_exec<false>, dim3(grid), dim3(64), 0, st, d_comp, (Block *)d_blocks.p, (const Chunk *)d_chunks.p + R.c0, cnt,
+            hipLaunchKernelGGL(k_zst_exec, dim3(grid), dim3(64), 0, st, d_comp, (const Block *)d_blocks.p, (const Chunk *)d_chunks.p + R.c0, cnt,
                                (const uint8_t *)d_lit.p, (const uint32_t *)d_ll.p, (const uint32_t *)d_ml.p, (const uint32_t *)d_off.p,
-                               (uint8_t *)d_out.p, (uint32_t *)d_status.p + R.c0);
-            if (sym_need)
-                hipLaunchKernelGGL(k_zst_exec<true>, dim3(grid), dim3(64), 0, st, d_comp, (Block *)d_blocks.p, (const Chunk *)d_chunks.p + R.c0, cnt,
-                                   (const uint8_t *)d_lit.p, (const uint32_t *)d_ll.p, (const uint32_t *)d_ml.p, (const uint32_t *)d_off.p,
-                                   (uint32_t *)d_sym.p, (uint32_t *)d_status.p + R.c0);
+                               (uint8_t *)d_out.p, (uint32_t *)d_sym.p, (uint32_t *)d_status.p + R.c0);
             const double t1 = trace ? sync_ms(st) : 0;
             for (uint32_t c = R.c0; c < R.c1; c++)
                 if (chunks[c].symbolic && csize[c])
@@ -1049,7 +1153,7 @@ extern "C" int exg_zstd_decode(const uint8_t *h_comp, const void *d_comp_v, uint
     } else {
         EXG_HIP_CHECK(hipStreamSynchronize(st));
     }
-    *d_out_p = d_out.p;
+    *d_out_p = d_out.p;  // the caller's from here on (hipFree, or exg_rd::dev_pool()->give(dev, p, produced + 64))
     d_out.p = nullptr;
     *produced = total;
     return EXG_OK;
