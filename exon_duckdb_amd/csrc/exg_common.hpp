@@ -46,6 +46,32 @@ __device__ __forceinline__ uint32_t match16(uint4 v, uint32_t pat4) {
 
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 
+// 16 bytes of the input stream / of an output column.  The input is read once (twice by the FASTA passes, far apart) and
+// the columns are written once: non-temporal accesses.  A/B inside one box (tools/ab_bench.sh, ab_vcf.sh, ab_fasta.sh;
+// -DEXG_NO_NT builds the plain form): FASTQ 2.34 -> 2.27 ms per 10 GB, VCF 5.07 -> 4.86 ms per 5.25 GB, FASTA
+// 1.10 -> 1.08 ms per GB; loads alone or stores alone gave a third of that or nothing.
+#ifndef EXG_NO_NT
+#define EXG_NT_LOAD 1
+#define EXG_NT_STORE 1
+#endif
+typedef uint32_t exg_v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_stream16(const uint8_t *p) {
+#ifdef EXG_NT_LOAD
+    const exg_v4u v = __builtin_nontemporal_load(reinterpret_cast<const exg_v4u *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const uint4 *>(p);
+#endif
+}
+__device__ __forceinline__ void st_stream16(uint4 *p, uint4 v) {
+#ifdef EXG_NT_STORE
+    exg_v4u w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<exg_v4u *>(p));
+#else
+    *p = v;
+#endif
+}
+
 // inclusive wave64 prefix sum
 __device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v) {
 #pragma unroll

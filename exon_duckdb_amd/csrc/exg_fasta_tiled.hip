@@ -174,7 +174,7 @@ __global__ __launch_bounds__(kThreads) void k_fa_tile_count(FastaDev a, TileArra
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint64_t off = gbase + (uint64_t)k * 1024 + (uint64_t)lane * 16;
-                v[k] = off < a.n_bytes ? *reinterpret_cast<const uint4 *>(a.d_in + off) : make_uint4(0, 0, 0, 0);
+                v[k] = off < a.n_bytes ? ld_stream16(a.d_in + off) : make_uint4(0, 0, 0, 0);
             }
             const bool full = gbase + 4096 + 16 <= a.n_bytes;  // the four rows and the byte behind them
 #pragma unroll
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(kThreads) void k_fa_tile_emit(FastaDev a, TileArray
         uint4 v_next = make_uint4(0, 0, 0, 0);
         {
             const uint64_t off = tile * kTile + (uint64_t)lane * 16;
-            if (off < a.n_bytes) v_next = *reinterpret_cast<const uint4 *>(a.d_in + off);
+            if (off < a.n_bytes) v_next = ld_stream16(a.d_in + off);
         }
 #pragma unroll 1
         for (int row = 0; row < 16; row++) {
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(kThreads) void k_fa_tile_emit(FastaDev a, TileArray
             if (rbase >= a.n_bytes) break;
             const uint64_t o = rbase + (uint64_t)lane * 16;
             const uint4 v = v_next;
-            if (row < 15 && o + 1024 < a.n_bytes) v_next = *reinterpret_cast<const uint4 *>(a.d_in + o + 1024);  // next row in flight
+            if (row < 15 && o + 1024 < a.n_bytes) v_next = ld_stream16(a.d_in + o + 1024);  // next row in flight
             else v_next = make_uint4(0, 0, 0, 0);
             const bool have_next = row < 15 && rbase + 1024 < a.n_bytes;
             const uint32_t nb = byte_after_chunk(v, have_next, (uint32_t)__builtin_amdgcn_readfirstlane((int)v_next.x) & 0xFFu, a.d_in, o,
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(kThreads) void k_fa_tile_emit(FastaDev a, TileArray
                         ov.y = __builtin_amdgcn_alignbyte(w2, w1, sh);
                         ov.z = __builtin_amdgcn_alignbyte(w3, w2, sh);
                         ov.w = __builtin_amdgcn_alignbyte(w4, w3, sh);
-                        *reinterpret_cast<uint4 *>(dst0 + so) = ov;
+                        st_stream16(reinterpret_cast<uint4 *>(dst0 + so), ov);
                     } else {
                         for (int bb = 0; bb < 16; bb++) {
                             const int32_t pp = so + bb;

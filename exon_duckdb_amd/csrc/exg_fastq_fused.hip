@@ -153,7 +153,7 @@ __device__ __forceinline__ void fastq_emit_half(const L &s, const FastqDev &a, S
             // dev_mode 2 keeps the values live but (practically) never stores
             if (!no_store && (dev_mode != 2 || (val.x ^ val.y ^ val.z ^ val.w) == 0x9E3779B9u)) {
                 exg_string_t *col = wave == 0 ? a.d_name : wave == 1 ? a.d_desc : wave == 2 ? a.d_seq : a.d_qual;
-                reinterpret_cast<uint4 *>(col)[out] = val;
+                st_stream16(reinterpret_cast<uint4 *>(col) + out, val);
             }
         }
         if (wave == 1 && !no_store) {

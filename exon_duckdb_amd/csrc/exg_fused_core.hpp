@@ -258,12 +258,12 @@ __global__ __launch_bounds__(kThreads, F::kMinWavesPerSimd) void k_fused(typenam
     if (lim_s == kSuper) {
         const uint8_t *mine = d_in + super_off + (uint64_t)tid * 16;
 #pragma unroll
-        for (int j = 0; j < kHalves * kRows; j++) v[j] = *reinterpret_cast<const uint4 *>(mine + j * (kThreads * 16));
+        for (int j = 0; j < kHalves * kRows; j++) v[j] = ld_stream16(mine + j * (kThreads * 16));
     } else {
 #pragma unroll
         for (int j = 0; j < kHalves * kRows; j++) {
             uint64_t off = super_off + (uint64_t)(j * kThreads + tid) * 16;
-            v[j] = off < n_pad ? *reinterpret_cast<const uint4 *>(d_in + off) : make_uint4(0, 0, 0, 0);
+            v[j] = off < n_pad ? ld_stream16(d_in + off) : make_uint4(0, 0, 0, 0);
         }
     }
     uint4 wv = make_uint4(0, 0, 0, 0);

@@ -123,12 +123,12 @@ __device__ __forceinline__ VcfRowInfo vcf_line(const Src &src, int s, int e, con
         int fs = s;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            if (a.d_fields[k]) reinterpret_cast<uint4 *>(a.d_fields[k])[out] = src.str(fs, (uint32_t)(t[k] - fs));
+            if (a.d_fields[k]) st_stream16(reinterpret_cast<uint4 *>(a.d_fields[k]) + out, src.str(fs, (uint32_t)(t[k] - fs)));
             fs = t[k] + 1;
         }
         if (a.d_fields[8]) {
             uint4 z = {0, 0, 0, 0};
-            reinterpret_cast<uint4 *>(a.d_fields[8])[out] = r.rest_valid ? src.str(fs, (uint32_t)(e - fs)) : z;
+            st_stream16(reinterpret_cast<uint4 *>(a.d_fields[8]) + out, r.rest_valid ? src.str(fs, (uint32_t)(e - fs)) : z);
         }
     }
     return r;

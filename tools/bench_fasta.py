@@ -1,21 +1,21 @@
-"""FASTA scan throughput (GPU box): 60-column wrapped records and long single-line records."""
+"""FASTA scan throughput (GPU box): ~1 GB of 60-column wrapped records generated in HBM by exg_synth_fasta."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
-from exon_duckdb_amd import abi, device
-from oracle import pyoracle
+import torch
+from exon_duckdb_amd import device
 torch.cuda.set_device(0)
-def time_ms(fn, reps=5, warm=1):
-    for _ in range(warm): fn()
-    torch.cuda.synchronize(); ev=[]
-    for _ in range(reps):
-        a,b=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True); a.record(); fn(); b.record(); ev.append((a,b))
-    torch.cuda.synchronize(); t=sorted(x.elapsed_time(y) for x,y in ev); return t[len(t)//2]
-out={}
-body = pyoracle.synth_fasta(20000)                    # ~33 MB, 60-col lines
-for label, data in (("wrapped60", np.tile(body, 30)),):
-    n=len(data); d_in=device.upload(data.tobytes()); scan=device.FastaScan(n, capacity_records=20000*30+16)
-    ms=time_ms(lambda: scan.launch(d_in)); r=scan.fetch()
-    assert r.error_code==0 and r.n_records==20000*30, (r.error_code, r.n_records)
-    out[label]={"bytes":n,"records":int(r.n_records),"ms":ms,"GBps":n/ms/1e6}
-print(json.dumps(out,indent=1))
+n_rec = int(os.environ.get("FASTA_RECORDS", "600000"))
+d_in, n = device.synth_fasta(n_rec)
+scan = device.FastaScan(n, capacity_records=n_rec + 16)
+for _ in range(2):
+    scan.launch(d_in)
+torch.cuda.synchronize()
+ev = []
+for _ in range(7):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); scan.launch(d_in); b.record(); ev.append((a, b))
+torch.cuda.synchronize()
+ms = sorted(x.elapsed_time(y) for x, y in ev)[3]
+r = scan.fetch()
+assert r.error_code == 0 and r.n_records == n_rec, (r.error_code, r.n_records)
+print(json.dumps({"bytes": n, "records": n_rec, "ms": ms, "GBps": n / ms / 1e6}))
