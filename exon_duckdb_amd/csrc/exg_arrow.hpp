@@ -141,6 +141,20 @@ struct CellSrc {
     const View *d_fields;        // FORMAT: the samples' texts (col unused)
     const uint32_t *d_elem_row;  // FORMAT: output row of every sample (error reporting); NULL: j itself
 };
+// Float literals the kernels cannot decide with 19 digits (exg_parse.hpp status 2) are decided exactly by a one-block
+// fix-up launch behind them (exg_float_slow.hpp): the list lives right behind the error word — d_err points at an ErrBlock.
+struct SlowF32 {
+    const uint8_t *p;
+    uint32_t len, pad;
+    float *dst;
+    unsigned long long row;
+};
+struct ErrBlock {
+    unsigned long long err;  // atomicMin((row << 8) | code); ~0 = none
+    unsigned int n_slow, pad;
+    SlowF32 slow[256];  // per kernel call; one more is a value error of its row
+};
+static constexpr unsigned int kSlowF32 = 256;
 // scalar children: values + validity (bit j); errors: atomicMin(*d_err, (row << 8) | err_code)
 void cells_to_i32(const CellSrc &s, uint64_t n, int32_t *d_values, uint64_t *d_valid, unsigned long long *d_err,
                   uint32_t err_code, hipStream_t);

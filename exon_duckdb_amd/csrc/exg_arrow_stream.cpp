@@ -651,9 +651,10 @@ int arrow_emit(exg_reader *r, const ScanCtx &ctx) {
         }
         return sc;
     };
-    em.d_err = (unsigned long long *)em.dalloc(8);
+    em.d_err = (unsigned long long *)em.dalloc(sizeof(ea::ErrBlock));  // the error word + the list of literals for the exact float parser
     if (em.rc) return em.rc;
     EM_HIP(hipMemsetAsync(em.d_err, 0xFF, 8, r->stream));
+    EM_HIP(hipMemsetAsync(em.d_err + 1, 0, 8, r->stream));
 
     if (st->has_filter) {
         ea::FilterCols fc;
@@ -1094,9 +1095,10 @@ int nested_emit(exg_reader *r, const ScanCtx &ctx, Batch *b, const uint32_t *d_r
     em.s = r->stream;
     em.n = n;
     em.d_row_map = d_row_map;
-    em.d_err = (unsigned long long *)em.dalloc(8);
+    em.d_err = (unsigned long long *)em.dalloc(sizeof(ea::ErrBlock));  // the error word + the list of literals for the exact float parser
     if (em.rc) return em.rc;
     EM_HIP(hipMemsetAsync(em.d_err, 0xFF, 8, r->stream));
+    EM_HIP(hipMemsetAsync(em.d_err + 1, 0, 8, r->stream));
     const uint8_t *d_base = (const uint8_t *)ctx.d_input;
     const uint64_t pb = (uint64_t)(uintptr_t)ctx.h;
     auto str_col = [&](int c) { return ea::StrCol{(const exg_string_t *)r->d_cols[c], d_base, pb}; };

@@ -220,7 +220,8 @@ __global__ void k_init_hdr(ScanWsHeader *hdr, uint64_t lines_cap, uint32_t mode)
     unsigned int overflow = hdr->overflow;
     if (mode == 1 && overflow == 0) return;
     ScanWsHeader h;
-    for (int i = 0; i < 21; i++) h.pad[i] = 0;
+    h.n_slow = h.slow_pad = 0;
+    for (unsigned int i = 0; i < kSlowLiterals; i++) h.slow[i].off = 0, h.slow[i].len = 0, h.slow[i].row = 0;
     h.last_qend = 0;
     h.total_nl = h.total_lines = h.halo_nl = h.n_unresolved = 0;
     h.err_word = kNoError;

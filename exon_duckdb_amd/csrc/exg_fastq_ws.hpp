@@ -28,8 +28,16 @@ struct alignas(256) ScanWsHeader {
     unsigned long long err_off;      // atomicMin: start offset of a failing record; ~0 = none
     unsigned long long consumed;     // atomicMax: offset just past the last owned quality line
     unsigned long long last_qend;    // atomicMax: offset just past the last quality line, owned or not
-    unsigned long long pad[21];
+    // VCF: QUAL literals the scan kernel could not decide with 19 digits (exg_parse.hpp, status 2): decided exactly by
+    // the finalize kernel (exg_float_slow.hpp).  Ten per launch; an eleventh is reported (EXG_RF_QUAL_RANGE).
+    unsigned int n_slow, slow_pad;
+    struct SlowLiteral {
+        unsigned long long off;  // input offset of the literal
+        unsigned int len;
+        unsigned int row;        // output row whose QUAL it is
+    } slow[10];
 };
+static constexpr unsigned int kSlowLiterals = 10;
 static_assert(sizeof(ScanWsHeader) == 256, "header is 256 bytes");
 
 struct FastqWsLayout {

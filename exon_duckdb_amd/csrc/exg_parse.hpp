@@ -14,7 +14,8 @@ namespace exg {
 // converting both ends of the interval its first 19 digits pin down — [w, w + 1] x 10^q; they round to the same float
 // unless a rounding boundary falls strictly inside an interval of relative width 10^-19 (about one literal in 10^11;
 // a boundary AT one of the two ends — "halfway, then zeros, then a 1" — is decided by the side the literal lies on): only then
-// the literal is reported (EXG_PE_VCF_BAD_QUAL + EXG_RF_QUAL_RANGE) rather than risk a wrong bit.
+// the kernel returns status 2 and its caller hands the literal to the exact big-integer parser (exg_float_slow.hpp), which
+// runs in one-block fix-up code behind the scan (k_vcf_finalize) / the typed-column kernels (k_f32_slow).
 
 // status: 0 ok, 1 syntax error, 2 more than 19 significant digits AND a rounding boundary within 10^-19 of them
 template <class Src>

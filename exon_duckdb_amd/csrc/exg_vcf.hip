@@ -17,6 +17,7 @@
 #include "exg_lines.hpp"
 
 #include "exg_parse.hpp"
+#include "exg_float_slow.hpp"
 
 namespace exg {
 
@@ -39,6 +40,7 @@ struct VcfDev {
 struct VcfRowInfo {
     bool qual_valid, rest_valid;
     uint32_t code;
+    int slow_s, slow_len;  // slow_len > 0: the QUAL literal [slow_s, slow_s + slow_len) is left to the exact parser
 };
 
 // One data line [s, e) (CR already stripped), stored straight to row `out` (store == false: validate
@@ -51,6 +53,7 @@ __device__ __forceinline__ VcfRowInfo vcf_line(const Src &src, int s, int e, con
     r.code = 0;
     r.qual_valid = false;
     r.rest_valid = false;
+    r.slow_s = r.slow_len = 0;
     // positions of the first 8 tabs (e when there are fewer)
     int t[8];
 #pragma unroll
@@ -105,8 +108,14 @@ __device__ __forceinline__ VcfRowInfo vcf_line(const Src &src, int s, int e, con
     float qual_v = 0.f;
     if (!(t[5] - (t[4] + 1) == 1 && src.b(t[4] + 1) == '.')) {
         int st = parse_f32(src, t[4] + 1, t[5], &qual_v);
+        if (st == 2) {  // > 19 digits astride a rounding boundary: value (and sign check) by the finalize kernel
+            r.slow_s = t[4] + 1;
+            r.slow_len = t[5] - (t[4] + 1);
+            qual_v = 0.f;
+            st = 0;
+        }
         if (st) {
-            r.code = EXG_PE_VCF_BAD_QUAL | (st == 2 ? 0x80u : 0u);
+            r.code = EXG_PE_VCF_BAD_QUAL;
             return r;
         }
         // noodles-vcf 0.34 record::QualityScore: TryFrom<f32> refuses n < 0.0 (so -1, -inf; not -0, not NaN)
@@ -151,9 +160,20 @@ __device__ __forceinline__ void store_validity64(uint64_t *words, unsigned long 
 }
 
 __device__ __forceinline__ void vcf_report(ScanWsHeader *hdr, uint32_t code, unsigned long long out, uint64_t line_off) {
-    if (code & 0x80u) atomicOr(&hdr->flags, EXG_RF_QUAL_RANGE);
     atomicMin(&hdr->err_word, (out << 8) | (code & 0x7Fu));
     atomicMin(&hdr->err_off, (unsigned long long)line_off);
+}
+// a QUAL literal for the exact parser (k_vcf_finalize); the list holds ten per launch, an eleventh is an error
+__device__ __forceinline__ void vcf_slow_qual(ScanWsHeader *hdr, uint64_t lit_off, uint32_t len, unsigned long long out, uint64_t line_off) {
+    const unsigned int k = atomicAdd(&hdr->n_slow, 1u);
+    if (k < kSlowLiterals && out <= 0xFFFFFFFFull) {
+        hdr->slow[k].off = lit_off;
+        hdr->slow[k].len = len;
+        hdr->slow[k].row = (unsigned int)out;
+    } else {
+        atomicOr(&hdr->flags, EXG_RF_QUAL_RANGE);
+        vcf_report(hdr, EXG_PE_VCF_BAD_QUAL, out, line_off);
+    }
 }
 
 // ---- fused ------------------------------------------------------------------------------------------
@@ -230,6 +250,7 @@ struct VcfFormat {
                     if (e1 > s0 && !(c.is_eof_tile && e1 == c.lim_e) && ldb(s, e1 - 1) == '\r') e1--;
                     VcfRowInfo r = vcf_line(src, s0, e1, a, (unsigned long long)out, !no_store && dev_mode != 2);
                     if (r.code) vcf_report(hdr, r.code, (unsigned long long)out, c.tile_off + s0 - kWin);
+                    else if (r.slow_len) vcf_slow_qual(hdr, c.tile_off + r.slow_s - kWin, (uint32_t)r.slow_len, (unsigned long long)out, c.tile_off + s0 - kWin);
                     qv = r.qual_valid;
                     rv = r.rest_valid;
                 }
@@ -303,6 +324,7 @@ __global__ __launch_bounds__(256) void k_vcf_lines(VcfDev a, const uint64_t *__r
                     if (!utf8_valid_global(a.d_in, s0, e1)) r.code = EXG_PE_INVALID_UTF8;
                 }
                 if (r.code) vcf_report(hdr, r.code, out, s0);
+                else if (r.slow_len) vcf_slow_qual(hdr, s0 + (uint64_t)r.slow_s, (uint32_t)r.slow_len, out, s0);
                 qv = r.qual_valid;
                 rv = r.rest_valid;
             }
@@ -327,6 +349,23 @@ __global__ __launch_bounds__(256) void k_vcf_finalize(VcfDev a, ScanWsHeader *hd
     if (threadIdx.x == 0) {
         s_qend = 0;
         s_found = 0;
+    }
+    // QUAL literals left to the exact parser: one thread each (big-integer arithmetic in this kernel only)
+    {
+        const unsigned int n_slow = hdr->n_slow < kSlowLiterals ? hdr->n_slow : kSlowLiterals;
+        if (threadIdx.x < n_slow && !(fused && hdr->overflow)) {
+            const ScanWsHeader::SlowLiteral lit = hdr->slow[threadIdx.x];
+            uint32_t bits = 0;
+            const int rc = f32_parse_exact(a.d_in + lit.off, (int)lit.len, &bits);
+            const float v = __uint_as_float(bits);
+            if (rc || v < 0.0f) {
+                unsigned long long line = lit.off;  // the record's offset = the start of its line
+                while (line > 0 && a.d_in[line - 1] != '\n') line--;
+                vcf_report(hdr, EXG_PE_VCF_BAD_QUAL, lit.row, line);
+            }
+            else if (a.d_qual && !(a.flags & EXG_F_NO_STORE) && lit.row < a.capacity)
+                a.d_qual[lit.row] = v;
+        }
     }
     __syncthreads();
     if (fused && !hdr->overflow) {

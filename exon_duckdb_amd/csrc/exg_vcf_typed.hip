@@ -15,6 +15,7 @@
 // Numbers that do not parse are a record error (EXG_PE_VCF_INFO / EXG_PE_VCF_FORMAT).
 #include "exg_arrow.hpp"
 #include "exg_parse.hpp"
+#include "exg_float_slow.hpp"
 #include "exg_scan.hpp"
 
 namespace exg {
@@ -195,6 +196,28 @@ struct CellGet {
     __device__ __forceinline__ unsigned long long err_row(uint64_t j) const { return s.d_elem_row ? s.d_elem_row[j] : j; }
 };
 
+// status 2 of parse_f32: hand the literal to the exact parser (k_f32_slow); false when the list is full
+__device__ __forceinline__ bool defer_f32(unsigned long long *err, const uint8_t *p, uint32_t len, float *dst, unsigned long long row) {
+    ErrBlock *eb = reinterpret_cast<ErrBlock *>(err);
+    const unsigned int k = atomicAdd(&eb->n_slow, 1u);
+    if (k >= kSlowF32) return false;
+    eb->slow[k] = SlowF32{p, len, 0u, dst, row};
+    return true;
+}
+__global__ __launch_bounds__(64) void k_f32_slow(ErrBlock *eb, uint32_t err_code) {
+    const unsigned int n = eb->n_slow < kSlowF32 ? eb->n_slow : kSlowF32;
+    for (unsigned int i = threadIdx.x; i < n; i += 64) {
+        const SlowF32 e = eb->slow[i];
+        uint32_t bits = 0;
+        if (f32_parse_exact(e.p, (int)e.len, &bits))
+            atomicMin(&eb->err, (e.row << 8) | err_code);
+        else
+            *e.dst = __uint_as_float(bits);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) eb->n_slow = 0;
+}
+
 template <int kType>  // kVtInt / kVtFloat
 __global__ __launch_bounds__(256) void k_cells_scalar(CellGet g, uint64_t n, void *values, uint64_t *valid,
                                                       unsigned long long *err, uint32_t err_code) {
@@ -210,8 +233,10 @@ __global__ __launch_bounds__(256) void k_cells_scalar(CellGet g, uint64_t n, voi
                 bool parsed;
                 if (kType == kVtInt)
                     parsed = parse_i32(PtrSrc{p}, 0, (int)len, &iv);
-                else
-                    parsed = parse_f32(PtrSrc{p}, 0, (int)len, &fv) == 0;
+                else {
+                    const int st = parse_f32(PtrSrc{p}, 0, (int)len, &fv);
+                    parsed = st == 0 || (st == 2 && defer_f32(err, p, len, (float *)values + j, g.err_row(j)));
+                }
                 if (parsed)
                     ok = true;
                 else
@@ -308,9 +333,12 @@ __global__ __launch_bounds__(256) void k_cells_list(CellGet g, uint64_t n, const
                     ((int32_t *)values)[o] = v;
                 } else {
                     float v = 0.f;
-                    if (ok && parse_f32(PtrSrc{p + s}, 0, (int)el, &v) != 0) {
-                        ok = false;
-                        atomicMin(err, (g.err_row(j) << 8) | err_code);
+                    if (ok) {
+                        const int st = parse_f32(PtrSrc{p + s}, 0, (int)el, &v);
+                        if (st != 0 && !(st == 2 && defer_f32(err, p + s, el, (float *)values + o, g.err_row(j)))) {
+                            ok = false;
+                            atomicMin(err, (g.err_row(j) << 8) | err_code);
+                        }
                     }
                     ((float *)values)[o] = v;
                 }
@@ -427,6 +455,7 @@ void cells_to_f32(const CellSrc &s, uint64_t n, float *d_values, uint64_t *d_val
     if (!n) return;
     hipLaunchKernelGGL(k_cells_scalar<kVtFloat>, dim3(grid_for(n)), dim3(256), 0, stream, CellGet{s}, n, (void *)d_values,
                        d_valid, d_err, err_code);
+    hipLaunchKernelGGL(k_f32_slow, dim3(1), dim3(64), 0, stream, reinterpret_cast<ErrBlock *>(d_err), err_code);
 }
 void cells_to_flag(const CellSrc &s, uint64_t n, uint64_t *d_bits, uint64_t *d_valid, hipStream_t stream) {
     if (!n) return;
@@ -452,6 +481,7 @@ void cells_list_f32(const CellSrc &s, uint64_t n, const uint64_t *d_goff, float 
     if (!n) return;
     hipLaunchKernelGGL(k_cells_list<kVtFloat>, dim3(grid_for(n)), dim3(256), 0, stream, CellGet{s}, n, d_goff, (void *)d_values,
                        d_child_valid, d_err, err_code);
+    hipLaunchKernelGGL(k_f32_slow, dim3(1), dim3(64), 0, stream, reinterpret_cast<ErrBlock *>(d_err), err_code);
 }
 void cells_list_views(const CellSrc &s, uint64_t n, const uint64_t *d_goff, View *d_views, uint32_t *d_child_valid,
                       hipStream_t stream) {

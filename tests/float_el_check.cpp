@@ -7,8 +7,34 @@
 #include <string.h>
 #include <math.h>
 #include <random>
-#include "exg_float_el.hpp"
-int main() {
+#include "exg_float_slow.hpp"
+// literals from a file (one per line): the exact parser against strtof
+static long check_file(const char *path) {
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    static char line[8192];
+    long n = 0, bad = 0;
+    while (fgets(line, sizeof line, f)) {
+        size_t len = strlen(line);
+        while (len && (line[len - 1] == '\n' || line[len - 1] == '\r')) line[--len] = 0;
+        if (!len) continue;
+        float want = strtof(line, nullptr);
+        uint32_t wb, gb = 0;
+        memcpy(&wb, &want, 4);
+        const int rc = exg::f32_parse_exact((const uint8_t *)line, (int)len, &gb);
+        n++;
+        if (rc != 0 || (gb != wb && !(want != want && (gb & 0x7FFFFFFFu) > 0x7F800000u))) {
+            if (bad < 20) printf("EXACT MISMATCH %.60s... rc %d got %08x want %08x\n", line, rc, gb, wb);
+            bad++;
+        }
+    }
+    fclose(f);
+    printf("%ld literals from %s, %ld bad\n", n, path, bad);
+    return bad;
+}
+
+int main(int argc, char **argv) {
+    if (argc > 1) return check_file(argv[1]) != 0;
     std::mt19937_64 rng(12345);
     long bad = 0, n = 0;
     auto check = [&](uint64_t w, int q) {

@@ -181,6 +181,7 @@ def test_long_and_extreme_qual_literals_are_exact(gpu, oracle):
     of the interval their first 19 digits pin down) — bit for bit the oracle's strtof."""
     rng = np.random.default_rng(77)
     quals = [b"16777217", b"16777216.000000000000000000000", b"16777217.0000000000000000000000001", b"16777218.99999999999999999999",
+             b"1.00000005960464477539062500000000000000001",
              b"0.100000001490116119384765625", b"0.1000000014901161193847656250000000000000000000000000001",
              b"3.4028234663852886e38", b"3.4028235677973366e38", b"3.40282357e38", b"1e39", b"123456789e31", b"1e-45", b"7e-46", b"7.1e-46",
              b"1.401298464324817e-45", b"1.17549435e-38", b"1.1754942e-38", b"5.877471754111438e-39", b"1e-60", b"0e999999", b"1e+38", b"1E-38",
@@ -206,21 +207,32 @@ def test_long_and_extreme_qual_literals_are_exact(gpu, oracle):
         assert res.error_code == 0 and res.n_records == len(quals)
 
 
-def test_a_long_literal_on_a_rounding_boundary_fails_loudly(gpu, oracle):
+def test_long_literals_astride_a_rounding_boundary_are_decided_exactly(gpu, oracle):
     """More than 19 significant digits AND a float rounding boundary strictly inside the interval their first 19 digits pin
-    down (relative width 10^-19) — about one literal in 10^11: the device reports it (EXG_PE_VCF_BAD_QUAL + EXG_RF_QUAL_RANGE) instead of risking a wrong bit; the
-    oracle (strtof) and the reference (Rust's dec2flt slow path) decide it.  Here: halfway between 1.0 and its
-    successor, plus 10^-41."""
+    down: the scan kernel hands the literal to the exact (big-integer) parser that runs in the finalize kernel
+    (exg_float_slow.hpp) — what Rust's dec2flt slow path decides.  Up to ten per launch; an eleventh is reported
+    (EXG_PE_VCF_BAD_QUAL + EXG_RF_QUAL_RANGE), never mis-rounded."""
     from exon_duckdb_amd import device
-    lit = b"1.00000005960464477539062500000000000000001"
-    data = HDR + b"1\t5\t.\tA\tC\t2\tPASS\t.\n1\t6\t.\tA\tC\t" + lit + b"\tPASS\t.\n"
-    exp = oracle.vcf_parse(data)
-    assert exp.error_code == 0 and float(exp.extra["qual"][1]) == float(np.float32(1.0000001192092896))
+    base = "1.000000059604644775390625"          # halfway between 1.0 and its successor
+    lits = [base + "0" * 15 + "1", base[:-1] + "4" + "9" * 20, base + "0" * 40, "2.00000011920928955078125" + "0" * 9 + "3",
+            "-0.000000000000000000000000000000000000000000000700649232162408535461864791644958065640130970938257885878534141944895541342930300743319094181060791015626",
+            "340282356779733661637539395458142568447.9999999", "16777219.000000000000000000001", "8388609.4999999999999999999999", "0.1" + "0" * 30 + "1"]
+    lits = [l.encode() for l in lits]
+    for algo in (abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS):
+        data = HDR + b"".join(b"1\t%d\t.\tA\tC\t" % (5 + k) + q + b"\tPASS\t.\n" for k, q in enumerate(lits) if not q.startswith(b"-"))
+        res = check(oracle, data, algo)
+        assert res.error_code == 0 and res.n_records == len(lits) - 1 and not (res.flags & abi.EXG_RF_QUAL_RANGE)
+        # the negative one (-7.006e-46 rounds to -1.4e-45 < 0): an error of ITS row, found by the exact parser
+        data = HDR + b"1\t5\t.\tA\tC\t2\tPASS\t.\n1\t6\t.\tA\tC\t" + lits[4] + b"\tPASS\t.\n1\t7\t.\tA\tC\t3\tPASS\t.\n"
+        res = check(oracle, data, algo)
+        assert res.error_code == abi.EXG_PE_VCF_BAD_QUAL and res.error_record == 1
+    # eleven such literals in one launch: the list holds ten
+    data = HDR + b"".join(b"1\t%d\t.\tA\tC\t" % k + lits[0] + b"\tPASS\t.\n" for k in range(11))
     d_in = device.upload(data)
     scan = device.VcfScan(len(data))
     scan.launch(d_in, lead=header_bytes(data))
     res = scan.fetch()
-    assert res.error_code == abi.EXG_PE_VCF_BAD_QUAL and res.error_record == 1 and (res.flags & abi.EXG_RF_QUAL_RANGE)
+    assert res.error_code == abi.EXG_PE_VCF_BAD_QUAL and (res.flags & abi.EXG_RF_QUAL_RANGE)
 
 
 def test_short_decimal_qual_and_pos_fast_paths_are_exact(gpu, oracle):

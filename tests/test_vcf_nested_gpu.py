@@ -91,6 +91,8 @@ def edge_lines():
         b"4\t40\tx\tAC\tA\t7\tPASS\tDP=-12;DP=13;AF=3\tPL:GT\t1.5,2.5e1,-0.125:1\t.:\t.:.",
         b"5\t50\tx\tAC\tA\t7\tPASS\tANN=;DP",
         b"6\t60\tx\tAC\tA\t7\tPASS\tDP=2147483647;AF=inf,NaN,-infinity\tGT",
+        # Float values of more than 19 digits astride a rounding boundary: decided exactly (exg_float_slow.hpp)
+        b"8\t80\tx\tA\tC\t7\tPASS\tAF=1.00000005960464477539062500000000000000001,0.5,2.00000011920928955078125000000001\tGT:PL\t0:1.0000000596046447753906250000001",
         # String / Character values are percent-decoded (INFO and samples); ids, alts and filters are not
         b"7\t70\ta%3Bb\tA\t<%41>\t7\tq%31\tANN=a%3Bb,c%2C%25,%zz,%4,100%,%e2%82%ac" + b"x" * 20 + b";CH=%41\tGT:AD\t0%2F1:1\t%7c:2\t" + b"%2e" * 9,
     ]
@@ -124,7 +126,7 @@ def test_typed_edge_cases(gpu, oracle, tmp_path, batch_rows):
 def test_percent_decoding(gpu, oracle, tmp_path):
     from exon_duckdb_amd import ExgError
     from exon_duckdb_amd.reader import ShardReader
-    data = HEADER + edge_lines()[6] + b"\n"
+    data = HEADER + edge_lines()[7] + b"\n"
     (tmp_path / "p.vcf").write_bytes(data)
     row = reader_rows(str(tmp_path / "p.vcf"))[0]
     assert row["info"]["ANN"] == ["a;b", "c,%", "%zz", "%4", "100%", "\u20ac" + "x" * 20] and row["info"]["CH"] == "A"
