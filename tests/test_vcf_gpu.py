@@ -323,6 +323,84 @@ def test_config3_full_size_properties(gpu, oracle):
     assert bool((q[:, valid] == q[0, valid]).all())
 
 
+def test_config3_full_size_generated(gpu, oracle):
+    """BASELINE.json configs[2] at its full size on a NON-periodic input: ~5 GB (about 103 M lines) from the device
+    generator.  Three windows of whole lines (head, middle, tail; 60 k lines each) are parsed by the oracle and compared bit
+    for bit with the same rows of the 5 GB launch; every row is covered by size-independent properties: the generator's
+    closed forms for CHROM and POS, and the byte ledger (the lengths of a row's eight fields + its eight separators, summed
+    over all rows, is the body's byte count; out-of-line pointers increase strictly with the row)."""
+    import torch
+    from exon_duckdb_amd import device
+
+    n_lines = int(5e9 / 48.65)
+    d_in, n = device.synth_vcf(n_lines)
+    head = bytes(d_in[:4096].cpu().numpy())
+    hdr = header_bytes(head[: head.index(b"\n1\t") + 1])
+    scan = device.VcfScan(n, capacity_records=n_lines + 16)
+    scan.launch(d_in, n_bytes=n, lead=hdr, payload_base=BASE, algo=abi.EXG_ALGO_AUTO)
+    res = scan.fetch()
+    assert res.error_code == 0 and res.n_records == n_lines and res.consumed_bytes == n
+    assert not (res.flags & abi.EXG_RF_FALLBACK)
+
+    def newlines_before(a):
+        tot = 0
+        for o in range(hdr, a, 1 << 30):
+            tot += int((d_in[o:min(a, o + (1 << 30))] == 10).sum().item())
+        return tot
+
+    K = 60_000
+    for start in (hdr, n // 2, None):
+        if start is None:                       # the last K lines
+            w = bytes(d_in[n - K * 80:n].cpu().numpy())
+            cut = len(w)
+            for _ in range(K + 1):
+                cut = w.rfind(b"\n", 0, cut)
+            a, b = n - K * 80 + cut + 1, n
+        else:
+            a = start
+            if a != hdr:
+                a += bytes(d_in[a:a + 4096].cpu().numpy()).index(b"\n") + 1
+            w = bytes(d_in[a:a + K * 80].cpu().numpy())
+            cut = -1
+            for _ in range(K):
+                cut = w.index(b"\n", cut + 1)
+            b = a + cut + 1
+        r0 = newlines_before(a)
+        window = head[:hdr] + bytes(d_in[a:b].cpu().numpy())
+        exp = oracle.vcf_parse(window, payload_base=BASE + a - hdr)
+        assert exp.error_code == 0 and exp.n_rows == K
+        for k, name in enumerate(oracle.VCF_FIELDS):
+            got = scan.cols[k][r0:r0 + K].cpu().numpy().view(np.uint8).reshape(K, 16)
+            assert np.array_equal(got, exp.string_t[name][0]), (name, start)
+        assert np.array_equal(scan.pos[r0:r0 + K].cpu().numpy(), exp.extra["pos"])
+        qv = exp.extra["qual_valid"].astype(bool)
+        gq = scan.qual[r0:r0 + K].cpu().numpy().view(np.uint32)
+        assert np.array_equal(gq[qv], exp.extra["qual"].view(np.uint32)[qv])
+        if r0 % 64 == 0:
+            assert np.array_equal(bits(scan.qual_valid[r0 // 64:(r0 + K + 63) // 64].cpu().numpy().view(np.uint64), K),
+                                  exp.extra["qual_valid"])
+    # every row: closed forms + the byte ledger
+    per_chrom = n_lines // 22 + 1
+    i = torch.arange(n_lines, device="cuda", dtype=torch.int64)
+    assert bool((((scan.pos[:n_lines] - 1) // 37) == (i % per_chrom)).all())
+    chrom = i // per_chrom + 1
+    want = torch.where(chrom < 10, 1 | ((0x30 + chrom) << 32), 2 | ((0x30 + chrom // 10) << 32) | ((0x30 + chrom % 10) << 40))
+    assert bool((scan.cols[0][:n_lines, 0] == want).all())
+    del i, chrom, want
+    total = 0
+    for k in range(8):
+        lens = scan.cols[k][:n_lines, 0] & 0xFFFFFFFF
+        total += int(lens.sum().item())
+        ptr = scan.cols[k][:n_lines, 1]
+        out = lens > 12
+        p = ptr[out]
+        if p.numel() > 1:
+            assert bool((p[1:] > p[:-1]).all()), k
+            assert int(p[0].item()) >= BASE + hdr and int(p[-1].item()) < BASE + n
+        del lens, ptr, out, p
+    assert total + 8 * n_lines == n - hdr
+
+
 def test_device_generators_match_the_oracle(gpu, oracle):
     """exg_synth_vcf / exg_synth_fasta (two passes: lengths -> scan -> write) produce the oracle's bytes: bench.py takes its
     VCF and FASTA inputs from them (the bench may not touch the oracle outside its cpu_baseline leg)."""
