@@ -83,6 +83,8 @@ struct Chunk {
     uint64_t elem_off;       // where the chunk's elements go: byte chunks = out_off, symbol chunks = offset in d_sym
     uint32_t symbolic;       // 1: elements are 32-bit symbols (a byte, or "the byte d in front of the chunk": kSymRef | d)
     uint32_t pad;
+    uint64_t size;           // bytes of output
+    uint64_t byte_end;       // end of its frame's first chunk: the frame's positions below it are bytes from the start
 };
 static constexpr uint32_t kSymRef = 0x80000000u;
 
