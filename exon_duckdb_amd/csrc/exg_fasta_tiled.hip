@@ -350,6 +350,63 @@ __device__ void emit_definition(const FastaDev &a, ScanWsHeader *hdr, uint64_t r
     }
 }
 
+// The kept bytes of one lane's chunk -> their place in the compacted group in LDS (any byte offset).  A chunk is all
+// sequence (one 16-byte store), or sequence with ONE run of bytes taken out — a newline, CR LF, the head of a definition line
+// up to the end of the chunk, its tail from the start — which is closed in registers (a 128-bit shift and a byte select) and
+// stored as 8 + 4 + 2 + 1 bytes; anything else (two newlines in 16 bytes) goes byte by byte.
+typedef uint32_t fa_v4u __attribute__((ext_vector_type(4), aligned(1)));
+typedef uint64_t fa_u64u __attribute__((aligned(1)));
+typedef uint32_t fa_u32u __attribute__((aligned(1)));
+typedef uint16_t fa_u16u __attribute__((aligned(1)));
+
+__device__ __forceinline__ void lds_store_kept(uint8_t *dst, const uint4 v, uint32_t pay) {
+    if (pay == 0xFFFFu) {
+        fa_v4u x = {v.x, v.y, v.z, v.w};
+        *reinterpret_cast<fa_v4u *>(dst) = x;
+        return;
+    }
+    const uint32_t z = ~pay & 0xFFFFu;             // bytes taken out (not zero here)
+    const uint32_t b = (uint32_t)__ffs((int)z) - 1;  // the first of them
+    const uint32_t zz = z >> b;
+    if ((zz & (zz + 1u)) == 0) {
+        const uint32_t s = (uint32_t)__popc(z);  // one run [b, b + s), s < 16: close it
+        const uint64_t lo = (uint64_t)v.x | ((uint64_t)v.y << 32), hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+        uint64_t slo, shi;  // the chunk shifted down by s bytes
+        if (s >= 8) {
+            slo = hi >> (8 * (s - 8));
+            shi = 0;
+        } else {
+            slo = (lo >> (8 * s)) | (hi << (64 - 8 * s));
+            shi = hi >> (8 * s);
+        }
+        const uint64_t mlo = b >= 8 ? ~0ull : ((1ull << (8 * b)) - 1ull), mhi = b > 8 ? ((1ull << (8 * (b - 8))) - 1ull) : 0ull;
+        uint64_t r = (lo & mlo) | (slo & ~mlo);
+        const uint64_t rhi = (hi & mhi) | (shi & ~mhi);
+        const uint32_t k = 16 - s;
+        if (k & 8) {
+            *reinterpret_cast<fa_u64u *>(dst) = r;
+            dst += 8;
+            r = rhi;
+        }
+        if (k & 4) {
+            *reinterpret_cast<fa_u32u *>(dst) = (uint32_t)r;
+            dst += 4;
+            r >>= 32;
+        }
+        if (k & 2) {
+            *reinterpret_cast<fa_u16u *>(dst) = (uint16_t)r;
+            dst += 2;
+            r >>= 16;
+        }
+        if (k & 1) *dst = (uint8_t)r;
+        return;
+    }
+    const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 16; q++)
+        if (pay & (1u << q)) *dst++ = (uint8_t)(words[q >> 2] >> (8 * (q & 3)));
+}
+
 __global__ __launch_bounds__(kThreads) void k_fa_tile_emit(FastaDev a, TileArrays t, ScanWsHeader *hdr, uint64_t n_tiles) {
     // per wave: the sequence bytes of four rows (4 KiB of input), compacted, on their way to the payload
     __shared__ __attribute__((aligned(16))) uint32_t s_out_all[kThreads / 64][4096 / 4 + 8];
@@ -411,54 +468,41 @@ __global__ __launch_bounds__(kThreads) void k_fa_tile_emit(FastaDev a, TileArray
                 r++;
                 d &= d - 1;
             }
-            if (!no_store && pay) {
-                // my sequence bytes -> their place in the compacted group (every register index is static)
-                const uint32_t words[4] = {v.x, v.y, v.z, v.w};
-                uint32_t w = my_off;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const uint32_t nib = (pay >> (4 * q)) & 0xFu;
-                    if (nib == 0xFu) {
-                        __builtin_memcpy(out8 + w, &words[q], 4);
-                        w += 4;
-                    } else if (nib) {
-#pragma unroll
-                        for (int bb = 0; bb < 4; bb++)
-                            if (nib & (1u << bb)) out8[w++] = (uint8_t)(words[q] >> (8 * bb));
-                    }
-                }
-            }
+            if (!no_store && pay) lds_store_kept(out8 + my_off, v, pay);
             g_out += tot & 0xFFFFu;
             rec_at += tot >> 16;
             const bool last_row = row == 15 || rbase + 1024 >= a.n_bytes;
             if (!no_store && g_out && ((row & 3) == 3 || last_row)) {  // (uniform per wave)
                 wave_sync();
-                // compacted rows -> payload, 16 bytes per store on the destination's grid
+                // compacted rows -> payload: the bytes up to the payload's 16-byte grid once per tile (a byte per lane), then
+                // whole 16-byte groups (LDS reads need no alignment on gfx950); what is left over (< 16 bytes) moves to the
+                // front of the buffer and leaves with the next rows, or byte by byte behind the tile's last row
                 uint8_t *dst0 = a.d_payload + pay_at;
-                const uint32_t mis = (uint32_t)((uintptr_t)dst0 & 15);
-                const uint32_t n_groups = (g_out + mis + 15) / 16;
-                for (uint32_t q = lane; q < n_groups; q += 64) {
-                    const int32_t so = (int32_t)(q * 16) - (int32_t)mis;  // offset in s_out of the group's first byte
-                    if (so >= 0 && (uint32_t)so + 16 <= g_out) {
-                        const uint32_t base = (uint32_t)so >> 2, sh = (uint32_t)so & 3;
-                        const uint32_t w0 = s_out[base], w1 = s_out[base + 1], w2 = s_out[base + 2], w3 = s_out[base + 3],
-                                       w4 = s_out[base + 4];
+                const uint32_t head = (16u - (uint32_t)((uintptr_t)dst0 & 15)) & 15u;
+                uint32_t written = 0;
+                if (g_out >= head) {
+                    const uint32_t n_full = (g_out - head) / 16;
+                    if (lane < head) dst0[lane] = out8[lane];
+                    for (uint32_t q = lane; q < n_full; q += 64) {
+                        const fa_v4u lv = *reinterpret_cast<const fa_v4u *>(out8 + head + q * 16);
                         uint4 ov;
-                        ov.x = __builtin_amdgcn_alignbyte(w1, w0, sh);
-                        ov.y = __builtin_amdgcn_alignbyte(w2, w1, sh);
-                        ov.z = __builtin_amdgcn_alignbyte(w3, w2, sh);
-                        ov.w = __builtin_amdgcn_alignbyte(w4, w3, sh);
-                        st_stream16(reinterpret_cast<uint4 *>(dst0 + so), ov);
-                    } else {
-                        for (int bb = 0; bb < 16; bb++) {
-                            const int32_t pp = so + bb;
-                            if (pp >= 0 && (uint32_t)pp < g_out) dst0[pp] = out8[pp];
-                        }
+                        ov.x = lv.x, ov.y = lv.y, ov.z = lv.z, ov.w = lv.w;
+                        st_stream16(reinterpret_cast<uint4 *>(dst0 + head + q * 16), ov);
                     }
+                    written = head + n_full * 16;
+                }
+                const uint32_t rem = g_out - written;  // < 16 (or all of it, when it does not reach the grid)
+                if (last_row) {
+                    if (lane < rem) dst0[written + lane] = out8[written + lane];
+                    written = g_out;
+                } else if (written) {
+                    const uint8_t x = lane < rem ? out8[written + lane] : (uint8_t)0;
+                    wave_sync();
+                    if (lane < rem) out8[lane] = x;
                 }
                 wave_sync();
-                pay_at += g_out;
-                g_out = 0;
+                pay_at += written;
+                g_out -= written;
             }
             if (no_store) {
                 pay_at += g_out;
