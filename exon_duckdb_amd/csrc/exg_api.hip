@@ -72,9 +72,9 @@ extern "C" int exg_fetch_result(const exg_scan_result *d_result, void *stream, e
 }
 
 extern "C" int exg_fastq_scan(const exg_fastq_scan_args *a) {
-    if (!a || !a->d_result || !a->d_workspace || (a->n_bytes && !a->d_input) || ((uintptr_t)a->d_input & 15) ||
+    if (!a || !a->d_result || !a->d_workspace || ((uintptr_t)a->d_workspace & 255) || (a->n_bytes && !a->d_input) || ((uintptr_t)a->d_input & 15) ||
         a->lead > a->n_bytes) {
-        set_error("exg_fastq_scan: bad arguments (null pointer, unaligned input or lead > n_bytes)");
+        set_error("exg_fastq_scan: bad arguments (null pointer, unaligned input or workspace, or lead > n_bytes)");
         return EXG_E_INVALID_ARG;
     }
     if (a->flags & ~EXG_F_ALL) {

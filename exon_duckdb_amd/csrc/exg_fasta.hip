@@ -432,8 +432,9 @@ __global__ void k_init_hdr(ScanWsHeader *hdr, uint64_t lines_cap, uint32_t mode)
 using namespace exg;
 
 extern "C" int exg_fasta_scan(const exg_fasta_scan_args *a) {
-    if (!a || !a->d_result || !a->d_workspace || (a->n_bytes && !a->d_input) || ((uintptr_t)a->d_input & 15)) {
-        set_error("exg_fasta_scan: bad arguments (null pointer or unaligned input)");
+    if (!a || !a->d_result || !a->d_workspace || ((uintptr_t)a->d_workspace & 255) || (a->n_bytes && !a->d_input) ||
+        ((uintptr_t)a->d_input & 15)) {
+        set_error("exg_fasta_scan: bad arguments (null pointer, unaligned input or workspace)");
         return EXG_E_INVALID_ARG;
     }
     if (a->flags & ~EXG_F_ALL) {

@@ -203,87 +203,156 @@ __global__ __launch_bounds__(kThreads) void k_fa_tile_count(FastaDev a, TileArra
 }
 
 // ---- tile scan ---------------------------------------------------------------------------------------------------------------
-// One workgroup, 4096 tiles per step (four consecutive tiles per thread): the begin-inside-a-definition bit of
-// every tile (nearest newline to the left: inside the thread, then ballots inside the wave, 16 wave summaries in
-// LDS, a carry across steps), then the two prefix sums (32-bit DPP scans per step, 64-bit running totals).
+// A workgroup per 4096 tiles (four consecutive tiles per thread).  What lies in front of its tiles — records, sequence bytes, the
+// line state, newlines — is the ordered composition of all earlier descriptors, which every workgroup works out for itself (a
+// contiguous slice per thread, a shuffle tree, sixteen wave results: ~0.5 MB of descriptors per GB of input, out of L2) instead
+// of waiting for its predecessors: one workgroup walking all tiles took 84 us per GB.  Then, for its own tiles: the
+// begin-inside-a-definition bit (nearest newline to the left: inside the thread, ballots inside the wave, 16 wave summaries in
+// LDS) and the two prefix sums (32-bit DPP scans, 64-bit bases).
+struct TileSum {
+    unsigned long long defs, after, head, nls;  // head: sequence bytes in front of the first newline (their line's kind comes from the left)
+    uint32_t has, tail;                         // a newline inside; what follows the last one is a definition line
+};
+__device__ __forceinline__ TileSum tile_sum_of(unsigned long long d) {
+    TileSum e;
+    e.defs = d & 0x3FFFull;
+    e.after = (d >> kDAfter) & 0x7FFFull;
+    e.head = (d >> kDHead) & 0x7FFFull;
+    e.nls = (d >> kDNl) & 0x7FFFull;
+    e.has = (uint32_t)((d >> kDHas) & 1ull);
+    e.tail = (uint32_t)((d >> kDTail) & 1ull);
+    return e;
+}
+// a then b
+__device__ __forceinline__ TileSum compose(const TileSum &a, const TileSum &b) {
+    TileSum r;
+    r.defs = a.defs + b.defs;
+    r.nls = a.nls + b.nls;
+    if (a.has) {
+        r.after = a.after + b.after + (a.tail ? 0ull : b.head);
+        r.head = a.head;
+        r.has = 1;
+        r.tail = b.has ? b.tail : a.tail;
+    } else {
+        r.after = b.after;
+        r.head = a.head + b.head;
+        r.has = b.has;
+        r.tail = b.tail;
+    }
+    return r;
+}
+__device__ __forceinline__ TileSum shfl_down_sum(const TileSum &e, int d) {
+    TileSum r;
+    r.defs = __shfl_down(e.defs, d, 64);
+    r.after = __shfl_down(e.after, d, 64);
+    r.head = __shfl_down(e.head, d, 64);
+    r.nls = __shfl_down(e.nls, d, 64);
+    const uint32_t f = __shfl_down(e.has | (e.tail << 1), d, 64);
+    r.has = f & 1u;
+    r.tail = f >> 1;
+    return r;
+}
+
 __global__ __launch_bounds__(1024) void k_fa_tile_scan(FastaDev a, TileArrays t, ScanWsHeader *hdr, uint64_t n_tiles) {
     __shared__ unsigned long long s_a[16], s_b[16];
     __shared__ uint32_t s_has[16], s_def[16];
-    __shared__ unsigned long long s_ra, s_rb;
-    __shared__ uint32_t s_carry;
+    __shared__ TileSum s_front[16];
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_ra = s_rb = 0, s_carry = 0;
-    __syncthreads();
-    unsigned long long nl_sum = 0;
-    for (uint64_t base = 0; base < n_tiles; base += 4096) {
-        const uint64_t i0 = base + (uint64_t)threadIdx.x * 4;
-        unsigned long long d[4];
+    const uint64_t base = (uint64_t)blockIdx.x * 4096;
+    // ---- everything in front of this workgroup's tiles
+    TileSum front = {0, 0, 0, 0, 0, 0};
+    if (base) {
+        // a thread's slice is whole 128-byte lines of descriptors, read with 16-byte loads: a line is fetched once (8-byte loads at
+        // a stride of hundreds of bytes pulled 110 MB through the L1s for 0.5 MB of descriptors: 40 us)
+        const uint64_t per = (((base + 1023) / 1024) + 15) & ~15ull, i0 = (uint64_t)threadIdx.x * per, i1 = i0 + per < base ? i0 + per : base;
+        TileSum e = {0, 0, 0, 0, 0, 0};
+        for (uint64_t i = i0; i < i1; i += 16) {
+            ulonglong2 dd[8];
 #pragma unroll
-        for (int j = 0; j < 4; j++) d[j] = i0 + j < n_tiles ? t.desc[i0 + j] : 0ull;
-        // the thread's own four tiles: does any have a newline, and what follows the last one
-        bool has = false, tail = false;
+            for (int j = 0; j < 8; j++) dd[j] = i + 2 * j < i1 ? *reinterpret_cast<const ulonglong2 *>(t.desc + i + 2 * j) : make_ulonglong2(0, 0);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if ((d[j] >> kDHas) & 1ull) has = true, tail = (d[j] >> kDTail) & 1ull;
-            nl_sum += (d[j] >> kDNl) & 0x7FFFull;
-        }
-        const unsigned long long bs = __ballot(has), bd = __ballot(tail);
-        if (lane == 0) {
-            s_has[w] = bs != 0;
-            s_def[w] = bs ? (uint32_t)((bd >> (63 - __clzll((long long)bs))) & 1ull) : 0u;
-        }
-        __syncthreads();
-        bool in_def = s_carry != 0;  // state entering the thread's first tile
-        for (uint32_t k = 0; k < w; k++)
-            if (s_has[k]) in_def = s_def[k] != 0;
-        const unsigned long long left = bs & mask_below(lane);
-        if (left) in_def = (bd >> (63 - __clzll((long long)left))) & 1ull;
-        bool st[4];
-        uint32_t ca[4], cb[4], sa = 0, sb = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            st[j] = in_def;
-            ca[j] = (uint32_t)(d[j] & 0x3FFFull);
-            cb[j] = (uint32_t)((d[j] >> kDAfter) & 0x7FFFull) + (in_def ? 0u : (uint32_t)((d[j] >> kDHead) & 0x7FFFull));
-            sa += ca[j];
-            sb += cb[j];
-            if ((d[j] >> kDHas) & 1ull) in_def = (d[j] >> kDTail) & 1ull;
-        }
-        const unsigned long long ia = wave_incl_sum_dpp(sa), ib = wave_incl_sum_dpp(sb);
-        if (lane == 63) s_a[w] = ia, s_b[w] = ib;
-        __syncthreads();
-        unsigned long long fa = 0, fb = 0, za = 0, zb = 0;
-        for (uint32_t k = 0; k < 16; k++) {
-            if (k < w) fa += s_a[k], fb += s_b[k];
-            za += s_a[k], zb += s_b[k];
-        }
-        unsigned long long ra = s_ra + fa + ia - sa, rb = s_rb + fb + ib - sb;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (i0 + j < n_tiles) {
-                t.rec_before[i0 + j] = ra;
-                t.pay_before[i0 + j] = rb | ((unsigned long long)st[j] << 63);
+            for (int j = 0; j < 8; j++) {
+                if (i + 2 * j < i1) e = compose(e, tile_sum_of(dd[j].x));
+                if (i + 2 * j + 1 < i1) e = compose(e, tile_sum_of(dd[j].y));
             }
-            ra += ca[j];
-            rb += cb[j];
         }
-        bool carry = s_carry != 0;
-        for (uint32_t k = 0; k < 16; k++)
-            if (s_has[k]) carry = s_def[k] != 0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const TileSum o = shfl_down_sum(e, d);
+            if ((lane & (2 * d - 1)) == 0) e = compose(e, o);
+        }
+        if (lane == 0) s_front[w] = e;
         __syncthreads();
-        if (threadIdx.x == 0) s_ra += za, s_rb += zb, s_carry = carry;
-        __syncthreads();
+        for (uint32_t k = 0; k < 16; k++) front = compose(front, s_front[k]);
     }
-    // newlines of the whole input
+    const unsigned long long r0 = front.defs, p0 = front.after + front.head;  // (the input begins outside a definition line)
+    const bool carry0 = front.has && front.tail;
+    // ---- its own tiles
+    const uint64_t i0 = base + (uint64_t)threadIdx.x * 4;
+    unsigned long long d[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) d[j] = i0 + j < n_tiles ? t.desc[i0 + j] : 0ull;
+    // the thread's own four tiles: does any have a newline, and what follows the last one
+    bool has = false, tail = false;
+    unsigned long long nl_sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if ((d[j] >> kDHas) & 1ull) has = true, tail = (d[j] >> kDTail) & 1ull;
+        nl_sum += (d[j] >> kDNl) & 0x7FFFull;
+    }
+    const unsigned long long bs = __ballot(has), bd = __ballot(tail);
+    if (lane == 0) {
+        s_has[w] = bs != 0;
+        s_def[w] = bs ? (uint32_t)((bd >> (63 - __clzll((long long)bs))) & 1ull) : 0u;
+    }
+    __syncthreads();
+    bool in_def = carry0;  // state entering the thread's first tile
+    for (uint32_t k = 0; k < w; k++)
+        if (s_has[k]) in_def = s_def[k] != 0;
+    const unsigned long long left = bs & mask_below(lane);
+    if (left) in_def = (bd >> (63 - __clzll((long long)left))) & 1ull;
+    bool st[4];
+    uint32_t ca[4], cb[4], sa = 0, sb = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        st[j] = in_def;
+        ca[j] = (uint32_t)(d[j] & 0x3FFFull);
+        cb[j] = (uint32_t)((d[j] >> kDAfter) & 0x7FFFull) + (in_def ? 0u : (uint32_t)((d[j] >> kDHead) & 0x7FFFull));
+        sa += ca[j];
+        sb += cb[j];
+        if ((d[j] >> kDHas) & 1ull) in_def = (d[j] >> kDTail) & 1ull;
+    }
+    const unsigned long long ia = wave_incl_sum_dpp(sa), ib = wave_incl_sum_dpp(sb);
+    if (lane == 63) s_a[w] = ia, s_b[w] = ib;
+    __syncthreads();
+    unsigned long long fa = 0, fb = 0, za = 0, zb = 0;
+    for (uint32_t k = 0; k < 16; k++) {
+        if (k < w) fa += s_a[k], fb += s_b[k];
+        za += s_a[k], zb += s_b[k];
+    }
+    unsigned long long ra = r0 + fa + ia - sa, rb = p0 + fb + ib - sb;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (i0 + j < n_tiles) {
+            t.rec_before[i0 + j] = ra;
+            t.pay_before[i0 + j] = rb | ((unsigned long long)st[j] << 63);
+        }
+        ra += ca[j];
+        rb += cb[j];
+    }
+    if (blockIdx.x != gridDim.x - 1) return;
+    // the last workgroup: totals of the whole input
+    __syncthreads();
     nl_sum = wave_sum64(nl_sum);
     if (lane == 0) s_a[w] = nl_sum;
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned long long total_nl = 0;
+        unsigned long long total_nl = front.nls;
         for (uint32_t k = 0; k < 16; k++) total_nl += s_a[k];
-        t.rec_before[n_tiles] = s_ra;
-        t.pay_before[n_tiles] = s_rb;
-        if (s_ra <= t.rec_cap) t.rec_start[s_ra] = s_rb;  // sentinel: end of the last record's sequence
+        const unsigned long long n_rec = r0 + za, n_pay = p0 + zb;
+        t.rec_before[n_tiles] = n_rec;
+        t.pay_before[n_tiles] = n_pay;
+        if (n_rec <= t.rec_cap) t.rec_start[n_rec] = n_pay;  // sentinel: end of the last record's sequence
         hdr->total_nl = total_nl;
         hdr->total_lines = total_nl + ((a.n_bytes && a.d_in[a.n_bytes - 1] != '\n') ? 1 : 0);
     }
@@ -307,25 +376,23 @@ struct ByteReader {
     }
 };
 
-__device__ void emit_definition(const FastaDev &a, ScanWsHeader *hdr, uint64_t r, uint64_t s) {
+// `in` = where the line's bytes are read from, indexed by INPUT offset: the input itself, or (k_fa_tile_defs) a copy of the
+// line's first bytes in LDS, biased by the line's offset — the walk, the trims and the two string_t read the line a dozen
+// times, byte by byte, and each read from HBM is a dependent round trip.  `limit` = end of what `in` holds (the input's end
+// when it holds the whole line).
+__device__ void emit_definition(const FastaDev &a, ScanWsHeader *hdr, uint64_t r, uint64_t s, const uint8_t *in, uint64_t raw_end) {
     const bool no_store = (a.flags & EXG_F_NO_STORE) != 0;
-    if (!no_store && r >= a.capacity) {
-        atomicOr(&hdr->flags, EXG_RF_CAPACITY);
-        return;
-    }
-    ByteReader rd;
-    rd.p = a.d_in;
-    // one walk: the end of the id (first ASCII whitespace) and the end of the line
-    uint64_t raw_end = s, id_e = ~0ull;
-    for (; raw_end < a.n_bytes; raw_end++) {
-        const uint32_t ch = rd.get(raw_end);
-        if (ch == '\n') break;
-        if (id_e == ~0ull && raw_end > s && is_ascii_ws(ch)) id_e = raw_end;
-    }
+    // the end of the id (first ASCII whitespace)
+    uint64_t id_e = ~0ull;
+    for (uint64_t i = s + 1; i < raw_end; i++)
+        if (is_ascii_ws(in[i])) {
+            id_e = i;
+            break;
+        }
     uint64_t e = raw_end;
-    if (raw_end < a.n_bytes && e > s && a.d_in[e - 1] == '\r') e--;  // CR only in front of a real LF
+    if (raw_end < a.n_bytes && e > s && in[e - 1] == '\r') e--;  // CR only in front of a real LF
     uint32_t code = 0;
-    if ((hdr->flags & EXG_RF_NON_ASCII) && !utf8_valid_global(a.d_in, s, e)) code = EXG_PE_INVALID_UTF8;
+    if ((hdr->flags & EXG_RF_NON_ASCII) && !utf8_valid_global(in, s, e)) code = EXG_PE_INVALID_UTF8;
     const uint64_t id_s = s + 1;
     if (id_e == ~0ull || id_e > e) id_e = e;
     if (id_e < id_s) id_e = id_s;
@@ -334,8 +401,8 @@ __device__ void emit_definition(const FastaDev &a, ScanWsHeader *hdr, uint64_t r
     uint64_t d_s = has_desc ? id_e + 1 : e, d_e = e;
     if (has_desc) {
         int l;
-        while (d_s < d_e && (l = ws_len_fwd(a.d_in, d_s, d_e)) > 0) d_s += (uint64_t)l;
-        while (d_e > d_s && (l = ws_len_bwd(a.d_in, d_s, d_e)) > 0) d_e -= (uint64_t)l;
+        while (d_s < d_e && (l = ws_len_fwd(in, d_s, d_e)) > 0) d_s += (uint64_t)l;
+        while (d_e > d_s && (l = ws_len_bwd(in, d_s, d_e)) > 0) d_e -= (uint64_t)l;
     }
     if (!code && (id_e - id_s > 0xFFFFFFFFull || d_e - d_s > 0xFFFFFFFFull)) code = EXG_PE_FIELD_TOO_LONG;
     if (code) {
@@ -344,8 +411,8 @@ __device__ void emit_definition(const FastaDev &a, ScanWsHeader *hdr, uint64_t r
     }
     if (!no_store) {
         const uint4 z = {0, 0, 0, 0};
-        reinterpret_cast<uint4 *>(a.d_id)[r] = make_string_global(a.d_in, id_s, id_e - id_s, a.payload_base);
-        reinterpret_cast<uint4 *>(a.d_desc)[r] = has_desc ? make_string_global(a.d_in, d_s, d_e - d_s, a.payload_base) : z;
+        reinterpret_cast<uint4 *>(a.d_id)[r] = make_string_global(in, id_s, id_e - id_s, a.payload_base);
+        reinterpret_cast<uint4 *>(a.d_desc)[r] = has_desc ? make_string_global(in, d_s, d_e - d_s, a.payload_base) : z;
         if (has_desc) atomicOr((unsigned long long *)&a.d_desc_valid[r >> 6], 1ull << (r & 63));
     }
 }
@@ -512,13 +579,56 @@ __global__ __launch_bounds__(kThreads) void k_fa_tile_emit(FastaDev a, TileArray
     }
 }
 
-// id / description of every record, a thread per record: the walk over a definition line is a chain of dependent
-// byte loads from HBM (~15 us) — inside the emit pass it stalled a whole wavefront for the one lane that owned a '>'
+// id / description of every record, a thread per record.  The thread first copies the line's first 128 bytes into LDS — eight
+// independent 16-byte loads, one round trip — and parses the copy; only a longer definition line is walked in HBM (a chain
+// of dependent loads, ~15 us: inside the emit pass it stalled a whole wavefront for the one lane that owned a '>').
+static constexpr uint32_t kDefStage = 128, kDefStride = kDefStage / 4 + 1;  // dwords per thread: the odd stride spreads the banks
 __global__ __launch_bounds__(256) void k_fa_tile_defs(FastaDev a, TileArrays t, ScanWsHeader *hdr, uint64_t n_tiles) {
+    __shared__ uint32_t s_line[256 * kDefStride];
     uint64_t n_rec = t.rec_before[n_tiles];
     if (n_rec > t.rec_cap) n_rec = t.rec_cap;
-    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rec; r += (uint64_t)gridDim.x * blockDim.x)
-        emit_definition(a, hdr, r, t.rec_def_off[r]);
+    const bool no_store = (a.flags & EXG_F_NO_STORE) != 0;
+    uint32_t *slot = s_line + threadIdx.x * kDefStride;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rec; r += (uint64_t)gridDim.x * blockDim.x) {
+        if (!no_store && r >= a.capacity) {
+            atomicOr(&hdr->flags, EXG_RF_CAPACITY);
+            continue;
+        }
+        const uint64_t s = t.rec_def_off[r];
+        const uint32_t avail = a.n_bytes - s < kDefStage ? (uint32_t)(a.n_bytes - s) : kDefStage;
+        typedef uint32_t v4u_u __attribute__((ext_vector_type(4), aligned(1)));
+        v4u_u q[kDefStage / 16];
+#pragma unroll
+        for (uint32_t k = 0; k < kDefStage / 16; k++) {
+            q[k] = (v4u_u){0, 0, 0, 0};
+            if (16 * k + 16 <= avail) {
+                q[k] = *reinterpret_cast<const v4u_u *>(a.d_in + s + 16 * k);
+            } else if (16 * k < avail) {  // the input's last bytes
+                uint32_t w[4] = {0, 0, 0, 0};
+                for (uint32_t j = 16 * k; j < avail; j++) w[(j & 15) >> 2] |= (uint32_t)a.d_in[s + j] << (8 * (j & 3));
+                q[k] = (v4u_u){w[0], w[1], w[2], w[3]};
+            }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kDefStage / 16; k++) {
+            slot[4 * k] = q[k].x;
+            slot[4 * k + 1] = q[k].y;
+            slot[4 * k + 2] = q[k].z;
+            slot[4 * k + 3] = q[k].w;
+        }
+        const uint8_t *line = reinterpret_cast<const uint8_t *>(slot);
+        uint32_t len = 0;
+        while (len < avail && line[len] != '\n') len++;
+        if (len < avail || s + avail == a.n_bytes) {
+            emit_definition(a, hdr, r, s, line - s, s + len);  // the whole line is in the copy
+        } else {
+            uint64_t raw_end = s + avail;
+            ByteReader rd;
+            rd.p = a.d_in;
+            while (raw_end < a.n_bytes && rd.get(raw_end) != '\n') raw_end++;
+            emit_definition(a, hdr, r, s, a.d_in, raw_end);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_fa_tile_strings(FastaDev a, TileArrays t, ScanWsHeader *hdr, uint64_t n_tiles) {
@@ -600,7 +710,7 @@ int run_fasta_tiled(const FastaDev &dev, uint8_t *ws, const FastqWsLayout &l, ex
     hipLaunchKernelGGL(k_init_hdr, dim3(1), dim3(1), 0, stream, hdr, l.lines_cap, 0u);
     const uint32_t grid = (uint32_t)(n_tiles < 16384 ? (n_tiles ? n_tiles : 1) : 16384);
     if (n_tiles) hipLaunchKernelGGL(k_fa_tile_count, dim3(grid), dim3(kThreads), 0, stream, dev, t, hdr, n_tiles);
-    hipLaunchKernelGGL(k_fa_tile_scan, dim3(1), dim3(1024), 0, stream, dev, t, hdr, n_tiles);
+    hipLaunchKernelGGL(k_fa_tile_scan, dim3((uint32_t)(n_tiles ? (n_tiles + 4095) / 4096 : 1)), dim3(1024), 0, stream, dev, t, hdr, n_tiles);
     if (n_tiles) hipLaunchKernelGGL(k_fa_tile_emit, dim3(grid), dim3(kThreads), 0, stream, dev, t, hdr, n_tiles);
     const uint64_t est_rec = dev.n_bytes / 64 + 256;
     const uint32_t sgrid = (uint32_t)((est_rec + 255) / 256 < 4096 ? (est_rec + 255) / 256 : 4096);

@@ -486,9 +486,9 @@ static int run_vcf_fused(const VcfDev &dev, uint8_t *ws, const FastqWsLayout &l,
 using namespace exg;
 
 extern "C" int exg_vcf_scan(const exg_vcf_scan_args *a) {
-    if (!a || !a->d_result || !a->d_workspace || (a->n_bytes && !a->d_input) || ((uintptr_t)a->d_input & 15) ||
-        a->lead > a->n_bytes) {
-        set_error("exg_vcf_scan: bad arguments (null pointer, unaligned input or lead > n_bytes)");
+    if (!a || !a->d_result || !a->d_workspace || ((uintptr_t)a->d_workspace & 255) || (a->n_bytes && !a->d_input) ||
+        ((uintptr_t)a->d_input & 15) || a->lead > a->n_bytes) {
+        set_error("exg_vcf_scan: bad arguments (null pointer, unaligned input or workspace, or lead > n_bytes)");
         return EXG_E_INVALID_ARG;
     }
     if (a->flags & ~EXG_F_ALL) {

@@ -113,7 +113,8 @@ typedef union exg_string_t {
 #define EXG_RF_FALLBACK 4u  /* the fused kernel met a record larger than its LDS window and the general kernel ran */
 #define EXG_RF_CAPACITY 8u  /* more records than capacity_records: the surplus was not written */
 #define EXG_RF_INDEX_OVERFLOW 16u /* general path: more lines than the workspace can index (enlarge d_workspace) */
-#define EXG_RF_QUAL_RANGE 32u /* VCF: a QUAL literal outside the exact device range (> 15 digits or |exp10| > 22) was rejected */
+#define EXG_RF_QUAL_RANGE 32u /* VCF: more than ten QUAL literals of one launch needed the exact big-integer parser (> 19 digits astride a
+                                 float rounding boundary); the eleventh was rejected */
 
 /* algorithm selector (exg_*_scan_args.algo) */
 #define EXG_ALGO_AUTO 0
@@ -149,7 +150,7 @@ typedef struct exg_fastq_scan_args {
     exg_string_t *d_quality;
     uint64_t *d_description_validity; /* device, ceil(capacity/64) words, bit r = row r valid */
     uint64_t capacity_records;
-    void *d_workspace; /* device, exg_scan_workspace_bytes(EXG_FMT_FASTQ, n_bytes) */
+    void *d_workspace; /* device, exg_scan_workspace_bytes(EXG_FMT_FASTQ, n_bytes), 256-byte aligned (any hipMalloc pointer is) */
     uint64_t workspace_bytes;
     exg_scan_result *d_result; /* device, 64 bytes */
     void *stream;              /* hipStream_t (NULL = default stream) */

@@ -216,3 +216,44 @@ def test_cr_and_lf_split_by_boundaries(gpu, oracle):
         buf += b"ACGTACGTACGTACGTACG\r\nACGT\r\n>x\r\nAA\r"      # "\r" is the last byte of the chunk / row / tile, "\n" the first of the next
         assert buf[boundary - 1:boundary + 1] == b"\r\n"
         check(oracle, bytes(buf))
+
+
+def test_large_input_both_forms_agree(gpu, oracle):
+    """~100 MB (60 k records, > 6 000 tiles: several tile-scan workgroups, each composing the descriptors in front of it):
+    the tiled form against the line-index form column for column on the device, and against the oracle through the
+    payload bytes, the id / description / sequence lengths and the description validity."""
+    import torch
+    from exon_duckdb_amd import device
+
+    n_rec = 60_000
+    d_in, n = device.synth_fasta(n_rec)
+    outs = []
+    for algo in ALGOS:
+        scan = device.FastaScan(n, capacity_records=n_rec + 16)
+        scan.launch(d_in, payload_base=BASE, seq_payload_base=SEQ_BASE, algo=algo)
+        res = scan.fetch()
+        assert res.error_code == 0 and res.n_records == n_rec and res.consumed_bytes == n
+        outs.append((scan, res))
+    (s0, r0), (s1, r1) = outs
+    assert r0.payload_bytes == r1.payload_bytes
+    for k in range(3):
+        assert torch.equal(s0.cols[k][:n_rec], s1.cols[k][:n_rec]), k
+    nw = (n_rec + 63) // 64
+    assert torch.equal(s0.validity[:nw - 1], s1.validity[:nw - 1])
+    assert torch.equal(s0.payload[:r0.payload_bytes], s1.payload[:r1.payload_bytes])
+    data = bytes(d_in[:n].cpu().numpy())
+    exp = oracle.fasta_parse(data)
+    assert exp.n_rows == n_rec and exp.error_code == 0
+    cols, words, payload = s0.host(n_rec, int(r0.payload_bytes))
+    assert payload.tobytes() == exp.columns["sequence"].values.tobytes()
+    valid = np.unpackbits(words.view(np.uint8), bitorder="little")[:n_rec]
+    assert np.array_equal(valid, exp.columns["description"].valid)
+    for k, name in enumerate(["id", "description", "sequence"]):
+        lens = cols[k][:, :4].copy().view(np.uint32)[:, 0]
+        want = exp.columns[name].lengths() * (exp.columns[name].valid != 0)
+        assert np.array_equal(lens, want), name
+    # sequence string_t: pointers are the oracle's payload offsets
+    seq = cols[2]
+    ptr = seq[:, 8:16].copy().view(np.uint64)[:, 0]
+    long_rows = exp.columns["sequence"].lengths() > 12
+    assert np.array_equal(ptr[long_rows] - SEQ_BASE, exp.columns["sequence"].offsets[:-1][long_rows].astype(np.uint64))
