@@ -66,12 +66,12 @@ __device__ __forceinline__ uint32_t ldw(const L &s, uint32_t e_aligned) {
 }
 template <class L>
 __device__ __forceinline__ uint32_t ldb(const L &s, int e) { return s.bytes[e]; }
-// 4 bytes at extended offset e (any alignment)
+// 4 bytes at extended offset e (any alignment: LDS accesses need none on gfx950)
+typedef uint32_t lds_u32u __attribute__((aligned(1)));
+typedef uint32_t lds_v3u __attribute__((ext_vector_type(3), aligned(1)));
 template <class L>
 __device__ __forceinline__ uint32_t ldu32(const L &s, int e) {
-    uint32_t a = (uint32_t)e & ~3u;
-    uint32_t lo = ldw(s, a), hi = ldw(s, a + 4);
-    return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)e & 3u);
+    return *reinterpret_cast<const lds_u32u *>(s.bytes + e);
 }
 
 // duckdb::string_t of the field [e, e+len); ptr_of_e0 = payload pointer of extended offset 0
@@ -79,19 +79,18 @@ template <class L>
 __device__ __forceinline__ uint4 make_string_lds(const L &s, int e, uint32_t len, uint64_t ptr_of_e0) {
     uint4 r;
     r.x = len;
-    uint32_t w0 = ldu32(s, e);
     if (len <= EXG_INLINE_LENGTH) {
-        uint32_t w1 = ldu32(s, e + 4), w2 = ldu32(s, e + 8);
+        const lds_v3u w = *reinterpret_cast<const lds_v3u *>(s.bytes + e);  // one 12-byte read
         uint32_t m0 = len >= 4 ? 0xFFFFFFFFu : ((1u << (8 * len)) - 1u);
         uint32_t l1 = len > 4 ? len - 4 : 0, l2 = len > 8 ? len - 8 : 0;
         uint32_t m1 = l1 >= 4 ? 0xFFFFFFFFu : ((1u << (8 * l1)) - 1u);
         uint32_t m2 = l2 >= 4 ? 0xFFFFFFFFu : ((1u << (8 * l2)) - 1u);
-        r.y = w0 & m0;
-        r.z = w1 & m1;
-        r.w = w2 & m2;
+        r.y = w.x & m0;
+        r.z = w.y & m1;
+        r.w = w.z & m2;
     } else {
         uint64_t ptr = ptr_of_e0 + (uint64_t)e;
-        r.y = w0;
+        r.y = ldu32(s, e);
         r.z = (uint32_t)ptr;
         r.w = (uint32_t)(ptr >> 32);
     }
