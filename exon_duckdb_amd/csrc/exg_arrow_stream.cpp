@@ -955,6 +955,10 @@ int stream_get_next(ArrowArrayStream *s, ArrowArray *out) {
             return EIO;
         }
         if (r->file_done) {
+            if (r->join_zstd_check()) {
+                st->last_error = r->error;
+                return EIO;
+            }
             if (r->file_idx >= r->files.size()) return 0;  // out->release == NULL: end of stream
             if (open_next_file(r)) {
                 st->last_error = r->error;
@@ -1294,6 +1298,7 @@ extern "C" ReaderResult new_reader(ArrowArrayStream *stream_ptr, const char *uri
             return result_error("could not register table: " + r->error);
         r->file.reset();
         r->fd_keep.reset();
+        if (r->join_zstd_check()) return result_error("could not register table: " + r->error);
         if (r->d_file) dev_pool()->give(r->device, r->d_file, r->d_file_cap), r->d_file = nullptr;
         r->file_idx = 0;
         r->file_pos = 0;

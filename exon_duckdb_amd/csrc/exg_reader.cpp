@@ -35,6 +35,7 @@
 
 #include "exg_filter.hpp"
 #include "exg_reader.hpp"
+#include "exg_zstd.hpp"
 
 namespace exg_rd {
 
@@ -127,8 +128,16 @@ int exg_reader::dev_alloc(void **slot, size_t bytes) {
     dev_allocs.emplace_back(slot, bytes);
     return EXG_OK;
 }
+int exg_reader::join_zstd_check() {
+    if (zst_check.joinable()) zst_check.join();
+    if (!zst_check_rc) return EXG_OK;
+    const int rc = zst_check_rc;
+    zst_check_rc = 0;
+    return exg_rd::fail(this, rc, zst_check_error);
+}
 exg_reader::~exg_reader() {
     exg_rd::DeviceGuard guard(device);
+    if (zst_check.joinable()) zst_check.join();
     free_device();
     if (d_res) (void)hipFree(d_res);
     if (d_phase) (void)hipFree(d_phase);
@@ -968,9 +977,20 @@ int zstd_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::strin
     RD_HIP(r, hipMemsetAsync((char *)comp.p + n, 0, 64, r->stream));
     void *d_out = nullptr;
     uint64_t produced = 0;
-    int rc = exg_zstd_decode((const uint8_t *)blk->p, comp.p, n, &d_out, &produced, r->stream);
+    std::vector<exg::zst::PendingCheck> pending;
+    int rc = exg::zst::decode((const uint8_t *)blk->p, comp.p, n, &d_out, &produced, r->stream, &pending);
     if (rc) return fail(r, rc, std::string(exg_last_error_message()) + " in '" + path + "'");
     TRACE("zstd: h2d + decode", t_all);
+    if (!pending.empty()) {
+        r->zst_check = std::thread([r, pending, d_out, path]() {
+            std::string err;
+            const int vrc = exg::zst::host_verify(d_out, pending, r->device, &err);
+            if (vrc) {
+                r->zst_check_error = err + " in '" + path + "'";
+                r->zst_check_rc = vrc;
+            }
+        });
+    }
     auto out_blk = std::make_shared<PinnedBlock>();
     out_blk->n = produced;
     blk = out_blk;
@@ -986,6 +1006,7 @@ int zstd_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::strin
 }
 
 int open_next_file(exg_reader *r) {
+    if (int jrc = r->join_zstd_check()) return jrc;
     const std::string &p = r->files[r->file_idx++];
     double t_all = now_s();
     int fd = open(p.c_str(), O_RDONLY);
@@ -1909,6 +1930,7 @@ extern "C" int exg_next_chunk(exg_reader *r, exg_chunk *out) {
             return fail(r, EXG_E_PARSE, msg);
         }
         if (r->file_done) {
+            if (int jrc = r->join_zstd_check()) return jrc;
             if (r->file_idx >= r->files.size()) {
                 r->batch.reset();
                 return EXG_OK;  // n_rows == 0: end of stream
@@ -1941,6 +1963,7 @@ extern "C" int exg_count_only(exg_reader *r, uint64_t *n_rows) {
             return fail(r, EXG_E_PARSE, msg);
         }
         if (r->file_done) {
+            if (int jrc = r->join_zstd_check()) return jrc;
             if (r->file_idx >= r->files.size()) break;
             int rc = open_next_file(r);
             if (rc) return rc;

@@ -357,6 +357,13 @@ struct exg_reader {
     };
     std::unique_ptr<FdCloser> fd_keep;  // current file (pread source of the bounce buffer)
     exg_rd::PinnedBlock staging[2];  // pinned bounce buffers for H2D, one per slot (the file itself is only mapped)
+    // zstd: frames too large for the device's serial XXH64 are hashed on the host, from a copy that travels back while the
+    // scan runs; the result is looked at when the file's last batch has been handed out (a streaming decoder reports a
+    // checksum mismatch at the end of the frame too), and before d_file is let go
+    std::thread zst_check;
+    int zst_check_rc = 0;
+    std::string zst_check_error;
+    int join_zstd_check();
     void *d_file = nullptr;  // gzip input: the inflated bytes live here and are scanned in place
     size_t d_file_cap = 0;   // its allocation size (it goes back to the device pool)
     uint64_t d_file_bytes = 0;

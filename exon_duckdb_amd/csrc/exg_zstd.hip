@@ -26,6 +26,7 @@
 
 #include "exg_common.hpp"
 #include "exg_reader.hpp"
+#include "exg_xxh64.hpp"
 #include "exg_zstd.hpp"
 
 namespace exg {
@@ -997,9 +998,65 @@ static const char *status_text(uint32_t code) {
 // h_comp: the compressed bytes on the host (only headers are read: the frame / block walk); d_comp: the same bytes on the
 // device, readable to n + 16.  On success *d_out is a hipMalloc'd buffer the caller hipFree()s (*produced bytes + 64
 // zeroed).  Synchronises the stream.  Errors: EXG_E_PARSE with libzstd's wording in exg_last_error_message().
-extern "C" int exg_zstd_decode(const uint8_t *h_comp, const void *d_comp_v, uint64_t n, void **d_out_p, uint64_t *produced, void *stream_v) {
-    using namespace exg;
-    using namespace exg::zst;
+namespace exg {
+namespace zst {
+
+int host_verify(const void *d_out, const std::vector<PendingCheck> &pending, int device, std::string *err) {
+    if (pending.empty()) return EXG_OK;
+    exg_rd::DeviceGuard guard(device);
+    hipStream_t st = nullptr;
+    if (exg_rd::stream_pool()->take(device, &st) != hipSuccess) {
+        *err = "zstd checksum verification: no HIP stream";
+        return EXG_E_HIP;
+    }
+    constexpr size_t kPiece = 32u << 20;
+    auto pool = exg_rd::global_pool();
+    char *buf[2] = {nullptr, nullptr};
+    size_t cap[2] = {kPiece, kPiece};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int rc = EXG_OK;
+    for (int k = 0; k < 2 && !rc; k++) {
+        buf[k] = pool->take(&cap[k]);
+        if (!buf[k] || hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess) {
+            *err = "zstd checksum verification: out of pinned host memory";
+            rc = EXG_E_HIP;
+        }
+    }
+    for (size_t f = 0; f < pending.size() && !rc; f++) {
+        const PendingCheck &P = pending[f];
+        const uint8_t *src = (const uint8_t *)d_out + P.out_off;
+        Xxh64 h;
+        const uint64_t n_pieces = (P.size + kPiece - 1) / kPiece;
+        auto issue = [&](uint64_t i) {
+            const uint64_t off = i * kPiece, len = std::min<uint64_t>(kPiece, P.size - off);
+            hipError_t e = hipMemcpyAsync(buf[i & 1], src + off, len, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipEventRecord(ev[i & 1], st);
+            return e;
+        };
+        hipError_t e = n_pieces ? issue(0) : hipSuccess;
+        for (uint64_t i = 0; i < n_pieces && e == hipSuccess; i++) {
+            if (i + 1 < n_pieces) e = issue(i + 1);  // the next piece travels while this one is hashed
+            if (e == hipSuccess) e = hipEventSynchronize(ev[i & 1]);
+            if (e == hipSuccess) h.update((const uint8_t *)buf[i & 1], (size_t)std::min<uint64_t>(kPiece, P.size - i * kPiece));
+        }
+        if (e != hipSuccess) {
+            *err = std::string("zstd checksum verification: ") + hipGetErrorString(e);
+            rc = EXG_E_HIP;
+        } else if ((uint32_t)h.digest() != P.expect) {
+            *err = std::string(status_text(kErrChecksum)) + " (zstd frame " + std::to_string(P.frame) + ")";
+            rc = EXG_E_PARSE;
+        }
+    }
+    (void)hipStreamSynchronize(st);
+    for (int k = 0; k < 2; k++) {
+        if (ev[k]) (void)hipEventDestroy(ev[k]);
+        if (buf[k]) pool->give(buf[k], cap[k]);
+    }
+    exg_rd::stream_pool()->give(device, st);
+    return rc;
+}
+
+int decode(const uint8_t *h_comp, const void *d_comp_v, uint64_t n, void **d_out_p, uint64_t *produced, void *stream_v, std::vector<PendingCheck> *pending) {
     if (!h_comp || !d_comp_v || !d_out_p || !produced) {
         set_error("exg_zstd_decode: null argument");
         return EXG_E_INVALID_ARG;
@@ -1236,6 +1293,11 @@ extern "C" int exg_zstd_decode(const uint8_t *h_comp, const void *d_comp_v, uint
                 set_error("%s (zstd frame %u)", status_text(status[nc + f]), f);
                 return EXG_E_PARSE;
             }
+        if (pending)
+            for (uint32_t f = 0; f < nf; f++) {
+                const Frame &F = idx.frames[f];
+                if (F.has_checksum && F.out_size > verify_max) pending->push_back(PendingCheck{F.out_off, F.out_size, F.checksum, f});
+            }
     } else {
         EXG_HIP_CHECK(hipStreamSynchronize(st));
     }
@@ -1243,4 +1305,24 @@ extern "C" int exg_zstd_decode(const uint8_t *h_comp, const void *d_comp_v, uint
     d_out.p = nullptr;
     *produced = total;
     return EXG_OK;
+}
+
+}  // namespace zst
+}  // namespace exg
+
+extern "C" int exg_zstd_decode(const uint8_t *h_comp, const void *d_comp, uint64_t n, void **d_out, uint64_t *produced, void *stream) {
+    std::vector<exg::zst::PendingCheck> pending;
+    int rc = exg::zst::decode(h_comp, d_comp, n, d_out, produced, stream, &pending);
+    if (rc || pending.empty()) return rc;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::string err;
+    rc = exg::zst::host_verify(*d_out, pending, dev, &err);
+    if (rc) {
+        exg_rd::dev_pool()->give(dev, *d_out, (size_t)*produced + 64);
+        *d_out = nullptr;
+        *produced = 0;
+        exg::set_error("%s", err.c_str());
+    }
+    return rc;
 }

@@ -88,6 +88,13 @@ struct Chunk {
 };
 static constexpr uint32_t kSymRef = 0x80000000u;
 
+// a frame whose Content_Checksum the device did not verify (more than EXG_ZSTD_VERIFY_MAX bytes of content): verified on
+// the host from a copy of the decoded bytes (host_verify)
+struct PendingCheck {
+    uint64_t out_off, size;
+    uint32_t expect, frame;
+};
+
 struct Index {
     std::vector<Block> blocks;
     std::vector<Frame> frames;
@@ -99,6 +106,12 @@ struct Index {
 
 // Host: walk the frames and blocks of data[0, n).  false + idx.error on a malformed stream.
 bool build_index(const uint8_t *data, uint64_t n, Index &idx);
+
+// exg_zstd_decode (include/exon_gpu.h) without the host half of the checksum verification: the frames left to it come back
+// in *pending (NULL: they stay unverified).  host_verify: copies each such frame from d_out in pieces and hashes it (XXH64)
+// on the calling thread, on a stream of its own; EXG_E_PARSE + *err ("Restored data doesn't match checksum ...") on a mismatch.
+int decode(const uint8_t *h_comp, const void *d_comp, uint64_t n, void **d_out, uint64_t *produced, void *stream, std::vector<PendingCheck> *pending);
+int host_verify(const void *d_out, const std::vector<PendingCheck> &pending, int device, std::string *err);
 
 }  // namespace zst
 }  // namespace exg

@@ -299,8 +299,10 @@ int exg_inflate_stream(const void *d_comp, uint64_t comp_off, uint64_t comp_size
  * reads them.  h_comp: the compressed bytes on the host (only frame / block headers are read there: a zstd stream states
  * the size of every block, so the host finds all blocks by a pointer chase and the device entropy-decodes them all at
  * once); d_comp: the same bytes on the device, readable to n + 16.  On success *d_out is a hipMalloc'd buffer the caller
- * hipFree()s (*produced bytes + 64 zeroed).  Frames with a Content_Checksum are verified (XXH64 on the device) up to
- * EXG_ZSTD_VERIFY_MAX bytes of content per frame (default 64 MiB: XXH64 is a serial recurrence, ~0.55 GB/s per frame on a GPU).  Windows above
+ * hipFree()s (*produced bytes + 64 zeroed).  Every frame with a Content_Checksum is verified: XXH64 on the device up to
+ * EXG_ZSTD_VERIFY_MAX bytes of content per frame (default 64 MiB: the hash is a serial recurrence, ~0.55 GB/s per frame on a
+ * GPU), larger frames on the host from a copy that comes back in 32 MiB pieces (~20 GB/s; a reader does this on a thread
+ * of its own while it scans, and reports a mismatch when the file's last batch is out).  Windows above
  * 128 MiB and dictionaries are refused like libzstd's defaults do.  Synchronises the stream.
  * Errors: EXG_E_PARSE, libzstd's wording in exg_last_error_message(). */
 int exg_zstd_decode(const uint8_t *h_comp, const void *d_comp, uint64_t n, void **d_out, uint64_t *produced, void *stream);

@@ -227,3 +227,42 @@ def test_reader_corrupt_zst_is_an_error(gpu, tmp_path):
     (tmp_path / "cut.fastq.zst").write_bytes(bytes(compress(fastq_text(5000, 2), 3, True)[:-7]))
     with pytest.raises(ExgError):
         ShardReader(str(tmp_path / "cut.fastq.zst"), "fastq").count()
+
+
+def test_big_frame_checksum_is_verified_on_the_host(gpu, tmp_path):
+    """A frame above the device's XXH64 limit (64 MiB of content; the hash is a serial recurrence): its decoded bytes travel
+    back in pieces and a host thread hashes them.  A right checksum passes; one wrong bit in it is libzstd's error — from
+    exg_zstd_decode at once, from a reader once the file's last batch has been handed out (the rows in front of it are
+    delivered, as a streaming decoder would)."""
+    from exon_duckdb_amd import ExgError, device
+    from exon_duckdb_amd.reader import ShardReader
+    n_rec = 230_000
+    d = bytes(device.synth_fastq(332 * n_rec)[: 332 * n_rec].cpu().numpy())
+    assert len(d) > (64 << 20)
+    comp = compress(d, 1, True)
+    rc, out = zstd_decode(gpu, comp)
+    assert rc == 0 and out == d
+    bad = bytearray(comp)
+    bad[-1] ^= 0x01  # the frame's last four bytes are the checksum
+    assert not decompress_stream(bytes(bad))[0]
+    rc, msg = zstd_decode(gpu, bytes(bad))
+    assert rc != 0 and "checksum" in msg, msg
+    good_p, bad_p = tmp_path / "good.fastq.zst", tmp_path / "bad.fastq.zst"
+    good_p.write_bytes(comp)
+    bad_p.write_bytes(bytes(bad))
+    assert ShardReader(str(good_p), "fastq").count() == n_rec
+    with pytest.raises(ExgError, match="checksum"):
+        ShardReader(str(bad_p), "fastq").count()
+    rd = ShardReader(str(bad_p), "fastq")
+    from exon_duckdb_amd.table_function import Chunk
+    seen, rc = 0, 0
+    while True:
+        ch = Chunk()
+        rc = rd._l.exg_next_chunk(rd._r, C.byref(ch))
+        if rc != 0 or ch.n_rows == 0:
+            break
+        seen += int(ch.n_rows)
+        rd._l.exg_release_chunk(rd._r, C.byref(ch))
+    assert rc != 0 and seen == n_rec
+    with pytest.raises(ExgError, match="checksum"):
+        rd._fail(rc)
