@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "exg_filter.hpp"
+#include "exg_xxh64.hpp"
 #include "exg_zstd.hpp"
 
 namespace exg {
@@ -86,6 +87,31 @@ int main(int argc, char **argv) {
     for (int i = 0; i < 100; i++) big += " AND pos>" + std::to_string(i);
     exg_rd::FilterParser fp(big, cols);
     if (fp.parse()) return 4;
+    // host XXH64 (the checksum of big zstd frames): the specification's known answers, and any way of cutting the input
+    // into updates gives the one-shot digest
+    {
+        auto one = [](const uint8_t *p, size_t n) {
+            exg::Xxh64 h;
+            h.update(p, n);
+            return h.digest();
+        };
+        if (one((const uint8_t *)"", 0) != 0xEF46DB3751D8E999ull) return 5;
+        if (one((const uint8_t *)"a", 1) != 0xD24EC4F1A98C6E5Bull) return 5;
+        if (one((const uint8_t *)"abc", 3) != 0x44BC2CF5AD770999ull) return 5;
+        std::vector<uint8_t> buf(5000);
+        for (auto &b : buf) b = (uint8_t)rng();
+        for (int trial = 0; trial < 300; trial++) {
+            const size_t n = rng() % (buf.size() + 1);
+            exg::Xxh64 h;
+            for (size_t at = 0; at < n;) {
+                const size_t want = 1 + rng() % 97, k = want < n - at ? want : n - at;
+                h.update(buf.data() + at, k);
+                at += k;
+            }
+            if (h.digest() != one(buf.data(), n)) return 6;
+            runs++;
+        }
+    }
     printf("%ld runs\n", runs);
     return 0;
 }
