@@ -23,4 +23,9 @@ rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_configs -o kt --output-format
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_zstd -o kt --output-format csv -- python3 $ROOT/tools/zstd_probe.py 512 > $OUT/${TAG}_kt_zstd.log 2>&1
 # single-member gzip through the reader (chunked decode)
 GZ_RECORDS=800000 GZ_ONLY_SINGLE=1 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_gzstream -o kt --output-format csv -- python3 $ROOT/tools/gz_probe.py > $OUT/${TAG}_kt_gzstream.log 2>&1
+# FASTA (1 GB), VCF (5 GB), BGZF inflate alone: per-kernel times
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_fasta -o kt --output-format csv -- python3 $ROOT/tools/bench_fasta.py > $OUT/${TAG}_kt_fasta.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_vcf -o kt --output-format csv -- python3 $ROOT/tools/bench_vcf.py > $OUT/${TAG}_kt_vcf.log 2>&1
+INFLATE_K=32 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_inflate -o kt --output-format csv -- python3 $ROOT/tools/bench_inflate.py > $OUT/${TAG}_kt_inflate.log 2>&1
+cd $ROOT && bash tools/pmc_inflate.sh $TAG > $OUT/${TAG}_pmcinf.log 2>&1; cd /tmp
 find $OUT -name "*kernel_stats.csv" -newer $OUT/${TAG}_bench.json | head

@@ -51,10 +51,23 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         w.writerows(rows)
     vals = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == c]
     res[c] = sum(vals) / len(vals)
-for leg in ("configs", "zstd", "gzstream"):
+for leg in ("configs", "zstd", "gzstream", "fasta", "vcf", "inflate"):
     st = find(f"{tag}_kt_{leg}/**/*kernel_stats.csv")
     if st:
         shutil.copy(st, os.path.join(prof, f"{tag}_{leg}_kernel_stats.csv"))
+# SQ activity counters of k_inflate (tools/pmc_inflate.sh): averages per counter
+import collections
+acc = collections.defaultdict(list)
+for fcsv in glob.glob(os.path.join(out, f"{tag}_pmcinf_*", "**", "*counter_collection.csv"), recursive=True):
+    with open(fcsv) as f:
+        for r in csv.DictReader(f):
+            if "k_inflate" in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+if acc:
+    with open(os.path.join(prof, f"{tag}_pmc_sq_k_inflate.csv"), "w") as f:
+        f.write("counter,average_per_dispatch,dispatches\n")
+        for k in sorted(acc):
+            f.write(f"{k},{sum(acc[k]) / len(acc[k])},{len(acc[k])}\n")
 b = os.path.join(out, f"{tag}_bench.json")
 if os.path.exists(b):
     shutil.copy(b, os.path.join(prof, f"{tag}_bench.json"))
