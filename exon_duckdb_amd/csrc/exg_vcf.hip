@@ -184,6 +184,10 @@ struct LdsSrc {
     const uint16_t *tabs;  // '\t' bitmap of the staged half (bit p = byte kWin + p)
     __device__ __forceinline__ uint32_t b(int e) const { return ldb(s, e); }
     __device__ __forceinline__ uint32_t u32(int e) const { return ldu32(s, e); }  // reads stay inside the LDS slack
+    __device__ __forceinline__ void u96(int e, uint32_t *w0, uint32_t *w1, uint32_t *w2) const {  // 12 bytes, one read
+        const lds_v3u w = *reinterpret_cast<const lds_v3u *>(s.bytes + e);
+        *w0 = w.x, *w1 = w.y, *w2 = w.z;
+    }
     // tab bits of the 64 bytes starting at extended offset e (only for lines that start inside the half)
     __device__ __forceinline__ bool tab_bits(int e, unsigned long long *out) const {
         const int p = e - kWin;
@@ -279,6 +283,9 @@ struct GlobalSrc {
         for (int k = 0; k < 4; k++)
             if (o + k < limit) w |= (uint32_t)p[o + k] << (8 * k);
         return w;
+    }
+    __device__ __forceinline__ void u96(int i, uint32_t *w0, uint32_t *w1, uint32_t *w2) const {
+        *w0 = u32(i), *w1 = u32(i + 4), *w2 = u32(i + 8);
     }
     __device__ __forceinline__ uint4 str(int i, uint32_t len) const {
         return make_string_global(p, base + (uint64_t)(int64_t)i, len, payload_base);

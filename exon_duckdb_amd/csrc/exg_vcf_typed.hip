@@ -39,7 +39,15 @@ struct ColGet2 {
 
 struct PtrSrc {
     const uint8_t *p;
+    int n;  // bytes of the literal: nothing behind them is read
     __device__ __forceinline__ uint32_t b(int i) const { return p[i]; }
+    __device__ __forceinline__ void u96(int i, uint32_t *w0, uint32_t *w1, uint32_t *w2) const {
+        uint32_t w[3] = {0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 12; k++)
+            if (i + k < n) w[k >> 2] |= (uint32_t)p[i + k] << (8 * (k & 3));
+        *w0 = w[0], *w1 = w[1], *w2 = w[2];
+    }
 };
 
 inline uint32_t grid_for(uint64_t n) { return (uint32_t)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192); }
@@ -232,9 +240,9 @@ __global__ __launch_bounds__(256) void k_cells_scalar(CellGet g, uint64_t n, voi
             if (g.get(j, &p, &len) == 2 && !is_missing(p, len)) {
                 bool parsed;
                 if (kType == kVtInt)
-                    parsed = parse_i32(PtrSrc{p}, 0, (int)len, &iv);
+                    parsed = parse_i32(PtrSrc{p, (int)len}, 0, (int)len, &iv);
                 else {
-                    const int st = parse_f32(PtrSrc{p}, 0, (int)len, &fv);
+                    const int st = parse_f32(PtrSrc{p, (int)len}, 0, (int)len, &fv);
                     parsed = st == 0 || (st == 2 && defer_f32(err, p, len, (float *)values + j, g.err_row(j)));
                 }
                 if (parsed)
@@ -326,7 +334,7 @@ __global__ __launch_bounds__(256) void k_cells_list(CellGet g, uint64_t n, const
                     ((View *)values)[o] = ok ? View{p + s, el, 1u} : View{nullptr, 0u, 0u};
                 } else if (kType == kVtInt) {
                     int v = 0;
-                    if (ok && !parse_i32(PtrSrc{p + s}, 0, (int)el, &v)) {
+                    if (ok && !parse_i32(PtrSrc{p + s, (int)el}, 0, (int)el, &v)) {
                         ok = false;
                         atomicMin(err, (g.err_row(j) << 8) | err_code);
                     }
@@ -334,7 +342,7 @@ __global__ __launch_bounds__(256) void k_cells_list(CellGet g, uint64_t n, const
                 } else {
                     float v = 0.f;
                     if (ok) {
-                        const int st = parse_f32(PtrSrc{p + s}, 0, (int)el, &v);
+                        const int st = parse_f32(PtrSrc{p + s, (int)el}, 0, (int)el, &v);
                         if (st != 0 && !(st == 2 && defer_f32(err, p + s, el, (float *)values + o, g.err_row(j)))) {
                             ok = false;
                             atomicMin(err, (g.err_row(j) << 8) | err_code);
