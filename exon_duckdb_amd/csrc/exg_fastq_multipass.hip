@@ -221,7 +221,7 @@ __global__ void k_init_hdr(ScanWsHeader *hdr, uint64_t lines_cap, uint32_t mode)
     if (mode == 1 && overflow == 0) return;
     ScanWsHeader h;
     h.n_slow = h.slow_pad = 0;
-    for (unsigned int i = 0; i < kSlowLiterals; i++) h.slow[i].off = 0, h.slow[i].len = 0, h.slow[i].row = 0;
+    for (unsigned int i = 0; i < 20; i++) h.reserved[i] = 0;
     h.last_qend = 0;
     h.total_nl = h.total_lines = h.halo_nl = h.n_unresolved = 0;
     h.err_word = kNoError;

@@ -28,16 +28,16 @@ struct alignas(256) ScanWsHeader {
     unsigned long long err_off;      // atomicMin: start offset of a failing record; ~0 = none
     unsigned long long consumed;     // atomicMax: offset just past the last owned quality line
     unsigned long long last_qend;    // atomicMax: offset just past the last quality line, owned or not
-    // VCF: QUAL literals the scan kernel could not decide with 19 digits (exg_parse.hpp, status 2): decided exactly by
-    // the finalize kernel (exg_float_slow.hpp).  Ten per launch; an eleventh is reported (EXG_RF_QUAL_RANGE).
+    // VCF: QUAL literals the scan kernel could not decide with 19 digits (exg_parse.hpp, status 2) are listed in the
+    // workspace (FastqWsLayout::off_slow) and decided exactly by the finalize kernel (exg_float_slow.hpp).
     unsigned int n_slow, slow_pad;
-    struct SlowLiteral {
-        unsigned long long off;  // input offset of the literal
-        unsigned int len;
-        unsigned int row;        // output row whose QUAL it is
-    } slow[10];
+    unsigned long long reserved[20];
 };
-static constexpr unsigned int kSlowLiterals = 10;
+struct SlowLiteral {
+    unsigned long long off;  // input offset of the literal
+    unsigned int len;
+    unsigned int row;        // output row whose QUAL it is
+};
 static_assert(sizeof(ScanWsHeader) == 256, "header is 256 bytes");
 
 struct FastqWsLayout {
@@ -47,6 +47,8 @@ struct FastqWsLayout {
     uint64_t off_tile_offsets;  // u64[n_tiles_mp]
     uint64_t off_tile_desc;     // u64[n_tiles_fused] look-back descriptors + u64[n_tiles_fused] tile_qend
     uint64_t off_block_sums;    // 2 x u64[lines / 4096 + 2] (FASTA device-wide scans: records, payload)
+    uint64_t off_slow;          // SlowLiteral[slow_cap] (VCF: QUAL literals for the exact parser)
+    uint64_t slow_cap;          // one per 32 bytes of input, at most 4096: a literal of that class has more than 19 digits
     uint64_t off_nl_pos;        // u64[lines_cap]
     uint64_t lines_cap;
     uint64_t total_bytes;
@@ -75,6 +77,9 @@ static inline FastqWsLayout fastq_ws_layout(uint64_t n_bytes, uint64_t ws_bytes_
     want += 8;
     l.off_block_sums = at;
     at = round_up(at + ((n_bytes + 16) / 4096 + 4) * 16, 256);  // 2 sums per block; lines <= bytes + 1, whatever the workspace size
+    l.slow_cap = n_bytes / 32 + 16 < 4096 ? n_bytes / 32 + 16 : 4096;
+    l.off_slow = at;
+    at = round_up(at + l.slow_cap * sizeof(SlowLiteral), 256);
     l.off_nl_pos = at;
     if (ws_bytes_or_0) {
         uint64_t avail = ws_bytes_or_0 > at ? (ws_bytes_or_0 - at) / (8 * n_line_arrays) : 0;

@@ -35,6 +35,8 @@ struct VcfDev {
     uint64_t *d_qual_valid;
     uint64_t *d_formats_valid;
     uint64_t capacity;
+    SlowLiteral *d_slow;  // workspace list of the QUAL literals left to the exact parser
+    uint64_t slow_cap;
 };
 
 struct VcfRowInfo {
@@ -163,13 +165,16 @@ __device__ __forceinline__ void vcf_report(ScanWsHeader *hdr, uint32_t code, uns
     atomicMin(&hdr->err_word, (out << 8) | (code & 0x7Fu));
     atomicMin(&hdr->err_off, (unsigned long long)line_off);
 }
-// a QUAL literal for the exact parser (k_vcf_finalize); the list holds ten per launch, an eleventh is an error
-__device__ __forceinline__ void vcf_slow_qual(ScanWsHeader *hdr, uint64_t lit_off, uint32_t len, unsigned long long out, uint64_t line_off) {
+// a QUAL literal for the exact parser (k_vcf_finalize).  The list holds one literal per 32 bytes of input, at most 4096 per
+// launch (such a literal has more than 19 digits and sits astride a float rounding boundary: one in 10^11 by chance); more
+// than that is an error (EXG_RF_QUAL_RANGE)
+__device__ __forceinline__ void vcf_slow_qual(ScanWsHeader *hdr, const VcfDev &a, uint64_t lit_off, uint32_t len, unsigned long long out,
+                                              uint64_t line_off) {
     const unsigned int k = atomicAdd(&hdr->n_slow, 1u);
-    if (k < kSlowLiterals && out <= 0xFFFFFFFFull) {
-        hdr->slow[k].off = lit_off;
-        hdr->slow[k].len = len;
-        hdr->slow[k].row = (unsigned int)out;
+    if (k < a.slow_cap && out <= 0xFFFFFFFFull) {
+        a.d_slow[k].off = lit_off;
+        a.d_slow[k].len = len;
+        a.d_slow[k].row = (unsigned int)out;
     } else {
         atomicOr(&hdr->flags, EXG_RF_QUAL_RANGE);
         vcf_report(hdr, EXG_PE_VCF_BAD_QUAL, out, line_off);
@@ -254,7 +259,7 @@ struct VcfFormat {
                     if (e1 > s0 && !(c.is_eof_tile && e1 == c.lim_e) && ldb(s, e1 - 1) == '\r') e1--;
                     VcfRowInfo r = vcf_line(src, s0, e1, a, (unsigned long long)out, !no_store && dev_mode != 2);
                     if (r.code) vcf_report(hdr, r.code, (unsigned long long)out, c.tile_off + s0 - kWin);
-                    else if (r.slow_len) vcf_slow_qual(hdr, c.tile_off + r.slow_s - kWin, (uint32_t)r.slow_len, (unsigned long long)out, c.tile_off + s0 - kWin);
+                    else if (r.slow_len) vcf_slow_qual(hdr, a, c.tile_off + r.slow_s - kWin, (uint32_t)r.slow_len, (unsigned long long)out, c.tile_off + s0 - kWin);
                     qv = r.qual_valid;
                     rv = r.rest_valid;
                 }
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(256) void k_vcf_lines(VcfDev a, const uint64_t *__r
                     if (!utf8_valid_global(a.d_in, s0, e1)) r.code = EXG_PE_INVALID_UTF8;
                 }
                 if (r.code) vcf_report(hdr, r.code, out, s0);
-                else if (r.slow_len) vcf_slow_qual(hdr, s0 + (uint64_t)r.slow_s, (uint32_t)r.slow_len, out, s0);
+                else if (r.slow_len) vcf_slow_qual(hdr, a, s0 + (uint64_t)r.slow_s, (uint32_t)r.slow_len, out, s0);
                 qv = r.qual_valid;
                 rv = r.rest_valid;
             }
@@ -359,9 +364,9 @@ __global__ __launch_bounds__(256) void k_vcf_finalize(VcfDev a, ScanWsHeader *hd
     }
     // QUAL literals left to the exact parser: one thread each (big-integer arithmetic in this kernel only)
     {
-        const unsigned int n_slow = hdr->n_slow < kSlowLiterals ? hdr->n_slow : kSlowLiterals;
-        if (threadIdx.x < n_slow && !(fused && hdr->overflow)) {
-            const ScanWsHeader::SlowLiteral lit = hdr->slow[threadIdx.x];
+        const unsigned int n_slow = hdr->n_slow < a.slow_cap ? hdr->n_slow : (unsigned int)a.slow_cap;
+        for (unsigned int k = threadIdx.x; k < n_slow && !(fused && hdr->overflow); k += blockDim.x) {
+            const SlowLiteral lit = a.d_slow[k];
             uint32_t bits = 0;
             const int rc = f32_parse_exact(a.d_in + lit.off, (int)lit.len, &bits);
             const float v = __uint_as_float(bits);
@@ -523,6 +528,8 @@ extern "C" int exg_vcf_scan(const exg_vcf_scan_args *a) {
     dev.capacity = a->capacity_records;
     hipStream_t stream = (hipStream_t)a->stream;
     uint8_t *ws = (uint8_t *)a->d_workspace;
+    dev.d_slow = reinterpret_cast<SlowLiteral *>(ws + l.off_slow);
+    dev.slow_cap = l.slow_cap;
     if (a->capacity_records && !(a->flags & EXG_F_NO_STORE)) {
         size_t vb = (size_t)((a->capacity_records + 63) / 64) * 8;
         if (dev.d_qual_valid) EXG_HIP_CHECK(hipMemsetAsync(dev.d_qual_valid, 0, vb, stream));

@@ -113,8 +113,8 @@ typedef union exg_string_t {
 #define EXG_RF_FALLBACK 4u  /* the fused kernel met a record larger than its LDS window and the general kernel ran */
 #define EXG_RF_CAPACITY 8u  /* more records than capacity_records: the surplus was not written */
 #define EXG_RF_INDEX_OVERFLOW 16u /* general path: more lines than the workspace can index (enlarge d_workspace) */
-#define EXG_RF_QUAL_RANGE 32u /* VCF: more than ten QUAL literals of one launch needed the exact big-integer parser (> 19 digits astride a
-                                 float rounding boundary); the eleventh was rejected */
+#define EXG_RF_QUAL_RANGE 32u /* VCF: more QUAL literals of one launch needed the exact big-integer parser (> 19 digits astride a float
+                                 rounding boundary) than its list holds (one per 32 bytes of input, at most 4096); the next was rejected */
 
 /* algorithm selector (exg_*_scan_args.algo) */
 #define EXG_ALGO_AUTO 0

@@ -210,7 +210,7 @@ def test_long_and_extreme_qual_literals_are_exact(gpu, oracle):
 def test_long_literals_astride_a_rounding_boundary_are_decided_exactly(gpu, oracle):
     """More than 19 significant digits AND a float rounding boundary strictly inside the interval their first 19 digits pin
     down: the scan kernel hands the literal to the exact (big-integer) parser that runs in the finalize kernel
-    (exg_float_slow.hpp) — what Rust's dec2flt slow path decides.  Up to ten per launch; an eleventh is reported
+    (exg_float_slow.hpp) — what Rust's dec2flt slow path decides.  Up to 4096 per launch; one more is reported
     (EXG_PE_VCF_BAD_QUAL + EXG_RF_QUAL_RANGE), never mis-rounded."""
     from exon_duckdb_amd import device
     base = "1.000000059604644775390625"          # halfway between 1.0 and its successor
@@ -226,8 +226,15 @@ def test_long_literals_astride_a_rounding_boundary_are_decided_exactly(gpu, orac
         data = HDR + b"1\t5\t.\tA\tC\t2\tPASS\t.\n1\t6\t.\tA\tC\t" + lits[4] + b"\tPASS\t.\n1\t7\t.\tA\tC\t3\tPASS\t.\n"
         res = check(oracle, data, algo)
         assert res.error_code == abi.EXG_PE_VCF_BAD_QUAL and res.error_record == 1
-    # eleven such literals in one launch: the list holds ten
-    data = HDR + b"".join(b"1\t%d\t.\tA\tC\t" % k + lits[0] + b"\tPASS\t.\n" for k in range(11))
+    # hundreds of such literals in one launch: all decided exactly (the list lives in the workspace: one entry per 32 bytes
+    # of input, at most 4096)
+    many = [lits[k % 4] for k in range(700)]
+    data = HDR + b"".join(b"1\t%d\t.\tA\tC\t" % (5 + k) + q + b"\tPASS\t.\n" for k, q in enumerate(many))
+    for algo in (abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS):
+        res = check(oracle, data, algo)
+        assert res.error_code == 0 and res.n_records == len(many) and not (res.flags & abi.EXG_RF_QUAL_RANGE)
+    # more than the list can hold (4096 per launch): reported, never mis-rounded
+    data = HDR + b"".join(b"1\t%d\t.\tA\tC\t" % k + lits[0] + b"\tPASS\t.\n" for k in range(4200))
     d_in = device.upload(data)
     scan = device.VcfScan(len(data))
     scan.launch(d_in, lead=header_bytes(data))
