@@ -152,9 +152,9 @@ struct SlowF32 {
 struct ErrBlock {
     unsigned long long err;  // atomicMin((row << 8) | code); ~0 = none
     unsigned int n_slow, pad;
-    SlowF32 slow[256];  // per kernel call; one more is a value error of its row
+    SlowF32 slow[4096];  // per kernel call; one more is a value error of its row
 };
-static constexpr unsigned int kSlowF32 = 256;
+static constexpr unsigned int kSlowF32 = 4096;
 // scalar children: values + validity (bit j); errors: atomicMin(*d_err, (row << 8) | err_code)
 void cells_to_i32(const CellSrc &s, uint64_t n, int32_t *d_values, uint64_t *d_valid, unsigned long long *d_err,
                   uint32_t err_code, hipStream_t);
