@@ -65,23 +65,26 @@ extern "C" int exg_inflate_members(const void *d_comp, void *d_out, const exg_in
         return EXG_E_INVALID_ARG;
     }
     uint32_t grid = n_members < 8192 ? n_members : 8192;
-    static const int ring = [] {
-        const char *e = getenv("EXG_INFLATE_RING");  // A/B switch: LDS ring elements (32768 = the whole window in LDS)
-        return e ? atoi(e) : 2048;
-    }();
-    static const int emit = getenv("EXG_INFLATE_EMIT") ? atoi(getenv("EXG_INFLATE_EMIT")) : 1;  // A/B switch (0 = first form)
-#define EXG_LAUNCH_INFLATE(R, E)                                                                                       \
+#define EXG_LAUNCH_INFLATE(R, E, OUT)                                                                                  \
     hipLaunchKernelGGL((exg::k_inflate<R, E>), dim3(grid), dim3(64), 0, (hipStream_t)stream, (const uint8_t *)d_comp,  \
-                       (uint8_t *)d_out, (const exg::InflateMember *)d_members, (exg::InflateStatus *)d_status, n_members)
+                       (uint8_t *)(OUT), (const exg::InflateMember *)d_members, (exg::InflateStatus *)d_status, n_members)
+#ifdef EXG_DEV_PROBE
+    // development builds only (tools/ab_inflate.sh): the ring size, the first form of the emit step, a decode that keeps nothing
+    static const int ring = getenv("EXG_INFLATE_RING") ? atoi(getenv("EXG_INFLATE_RING")) : 2048;
+    static const int emit = getenv("EXG_INFLATE_EMIT") ? atoi(getenv("EXG_INFLATE_EMIT")) : 1;
+    void *out = getenv("EXG_INFLATE_NOOUT") ? nullptr : d_out;
     if (emit == 0) {
-        EXG_LAUNCH_INFLATE(2048, 0);
+        EXG_LAUNCH_INFLATE(2048, 0, out);
     } else {
         switch (ring) {
-            case 4096: EXG_LAUNCH_INFLATE(4096, 1); break;
-            case 32768: EXG_LAUNCH_INFLATE(32768, 1); break;
-            default: EXG_LAUNCH_INFLATE(2048, 1); break;
+            case 4096: EXG_LAUNCH_INFLATE(4096, 1, out); break;
+            case 32768: EXG_LAUNCH_INFLATE(32768, 1, out); break;
+            default: EXG_LAUNCH_INFLATE(2048, 1, out); break;
         }
     }
+#else
+    EXG_LAUNCH_INFLATE(2048, 1, d_out);
+#endif
 #undef EXG_LAUNCH_INFLATE
     EXG_HIP_CHECK(hipGetLastError());
     return EXG_OK;
