@@ -235,78 +235,98 @@ def run_configs(torch, lib, args):
     tmp, free = scratch_dir(int(1.6 * max(n_e2e, n_gz_in)))
     if 1.6 * max(n_e2e, n_gz_in) > 0.8 * free:      # (plain file + its BGZF form must fit)
         n_gz_in = n_e2e = int(0.8 * free / 1.6) // REC * REC
+    def leg(fn, *keys):
+        """a side leg of the bench line: what goes wrong in it is reported in its own object(s)"""
+        try:
+            fn()
+        except Exception as e:  # noqa: BLE001
+            for k in keys:
+                out.setdefault(k, {"error": f"{type(e).__name__}: {e}"})
+            torch.cuda.empty_cache()
+
     try:
-        # ---- config 1: SELECT COUNT(*) FROM read_fasta() on a 1 MB FASTA (plumbing + latency) -----------------------
-        d_fa, n_fa = device.synth_fasta(600)
-        p_fa = os.path.join(tmp, "c1.fasta")
-        write_device_bytes(torch, d_fa, n_fa, p_fa)
-        ts = []
-        for _ in range(25):
-            n, dt = reader_count(lib, p_fa, "fasta")
-            assert n == 600
-            ts.append(dt)
-        ts.sort()
-        scan = device.FastaScan(n_fa)
-        ms, _ = timed_launches(torch, lambda: scan.launch(d_fa, payload_base=BASE), 20)
-        res = scan.fetch()
-        out["config1_fasta_1MB_count"] = {
-            "workload": f"SELECT COUNT(*) FROM read_fasta('{n_fa} B synthetic FASTA, 600 records'): open + upload + scan + close",
-            "algorithmic_bytes": n_fa, "ms": ts[len(ts) // 2] * 1e3, "ms_min": ts[0] * 1e3, "device_scan_ms": ms,
-            "GB/s": n_fa / (ts[len(ts) // 2]) / 1e9, "frac": None, "verified": bool(res.n_records == 600 and res.error_code == 0)}
-        del d_fa, scan
-        # ---- config 3: read_vcf 8-column scan, 5 GB generated in HBM (non-periodic) --------------------------------
-        n_lines = int(args.vcf_gb * 1e9 / 48.65)
-        d_vcf, n_vcf = device.synth_vcf(n_lines)
-        hdr = bytes(d_vcf[:4096].cpu().numpy()).index(b"#CHROM")
-        hdr = hdr + bytes(d_vcf[hdr:hdr + 256].cpu().numpy()).index(b"\n") + 1
-        vs = device.VcfScan(n_vcf, capacity_records=n_lines + 16)
-        ms, ms_min = timed_launches(torch, lambda: vs.launch(d_vcf, n_bytes=n_vcf, lead=hdr, payload_base=BASE), 8)
-        res = vs.fetch()
-        per_chrom = n_lines // 22 + 1
-        i = torch.arange(n_lines, device="cuda", dtype=torch.int64)
-        pos_ok = bool((((vs.pos[:n_lines] - 1) // 37) == (i % per_chrom)).all())   # POS = (i mod per_chrom) * 37 + 1 + (h & 31)
-        chrom = i // per_chrom + 1                                               # CHROM = i / per_chrom + 1, inlined decimal
-        c0 = vs.cols[0][:n_lines, 0]
-        want = torch.where(chrom < 10, 1 | ((0x30 + chrom) << 32), 2 | ((0x30 + chrom // 10) << 32) | ((0x30 + chrom % 10) << 40))
-        chrom_ok = bool((c0 == want).all())
-        out["config3_vcf_8col"] = {
-            "workload": f"read_vcf 8(+1)-column scan, {n_vcf / 1e9:.2f} GB synthetic VCF ({n_lines} lines, exg_synth_vcf), all columns + typed POS / QUAL",
-            "algorithmic_bytes": n_vcf, "ms": ms, "ms_min": ms_min, "GB/s": n_vcf / (ms * 1e-3) / 1e9,
-            "frac": n_vcf / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "lines_per_s": n_lines / (ms * 1e-3),
-            "verified": bool(res.error_code == 0 and res.n_records == n_lines and pos_ok and chrom_ok)}
-        del d_vcf, vs, i, chrom, c0, want
-        torch.cuda.empty_cache()
-        # ---- end to end: FASTQ file in the page cache -> host DataChunks (PCIe inclusive) -------------------------------
-        n_file = max(n_e2e, n_gz_in)                  # one file serves both legs: config 4 deflates its first n_gz_in bytes
-        p_fq = os.path.join(tmp, "e2e.fastq")
-        with open(p_fq, "wb") as f:
-            step = (1 << 30) // REC * REC
-            for o in range(0, n_file, step):
-                m = min(step, n_file - o)
-                f.write(device.synth_fastq(m, file_offset=o)[:m].cpu().numpy().tobytes())
-        n_e2e = n_file
-        torch.cuda.empty_cache()
-        reader_count(lib, p_fq, "fastq")  # warm: pools, page cache
-        n, dt_c = min((reader_count(lib, p_fq, "fastq") for _ in range(3)), key=lambda x: x[1])
-        rows, chunks, dt_r = min((reader_chunks(lib, p_fq, "fastq") for _ in range(3)), key=lambda x: x[2])
-        out["end_to_end"] = {
-            "workload": f"read_fastq, {n_e2e / 1e9:.1f} GB FASTQ-150 file in the page cache -> host DataChunks (exg_open / exg_next_chunk), PCIe inclusive",
-            "algorithmic_bytes": n_e2e, "ms": dt_r * 1e3, "GB/s": n_e2e / dt_r / 1e9, "records_per_s": rows / dt_r, "chunks": chunks,
-            "count_only_ms": dt_c * 1e3, "count_only_GB/s": n_e2e / dt_c / 1e9, "frac": None,
-            "verified": bool(rows == n == n_e2e // REC and chunks >= (rows + 2047) // 2048)}
-        # ---- config 4: read_fastq on BGZF (device inflate feeding the scan) ------------------------------------------------
-        p_gz = os.path.join(tmp, "c4.fastq.gz")
-        t0 = time.perf_counter()
-        comp = build_bgzf(p_fq, n_gz_in, p_gz, max(1, min(cores, 192)))
-        t_build = time.perf_counter() - t0
-        reader_count(lib, p_gz, "fastq")
-        n, dt_g = min((reader_count(lib, p_gz, "fastq") for _ in range(3)), key=lambda x: x[1])
-        out["config4_fastq_bgzf"] = {
-            "workload": f"SELECT COUNT(*) FROM read_fastq('x.fastq.gz'): {comp / 1e9:.2f} GB of BGZF (65 280-byte members, zlib level 6) = "
-                        f"{n_gz_in / 1e9:.2f} GB of FASTQ-150, file in the page cache, inflate + scan on the device",
-            "compressed_bytes": comp, "algorithmic_bytes": comp + 2 * n_gz_in, "ms": dt_g * 1e3, "GB/s": n_gz_in / dt_g / 1e9,
-            "GB/s_compressed": comp / dt_g / 1e9, "records_per_s": n / dt_g, "frac": (comp + 2 * n_gz_in) / dt_g / 1e9 / HBM_PEAK_GBPS,
-            "input_build_s": t_build, "input_deflate_pool_s": getattr(build_bgzf, "pool_s", None), "verified": bool(n == n_gz_in // REC)}
+        def config1():
+            # ---- config 1: SELECT COUNT(*) FROM read_fasta() on a 1 MB FASTA (plumbing + latency) -----------------------
+            d_fa, n_fa = device.synth_fasta(600)
+            p_fa = os.path.join(tmp, "c1.fasta")
+            write_device_bytes(torch, d_fa, n_fa, p_fa)
+            ts = []
+            for _ in range(25):
+                n, dt = reader_count(lib, p_fa, "fasta")
+                assert n == 600
+                ts.append(dt)
+            ts.sort()
+            scan = device.FastaScan(n_fa)
+            ms, _ = timed_launches(torch, lambda: scan.launch(d_fa, payload_base=BASE), 20)
+            res = scan.fetch()
+            out["config1_fasta_1MB_count"] = {
+                "workload": f"SELECT COUNT(*) FROM read_fasta('{n_fa} B synthetic FASTA, 600 records'): open + upload + scan + close",
+                "algorithmic_bytes": n_fa, "ms": ts[len(ts) // 2] * 1e3, "ms_min": ts[0] * 1e3, "device_scan_ms": ms,
+                "GB/s": n_fa / (ts[len(ts) // 2]) / 1e9, "frac": None, "verified": bool(res.n_records == 600 and res.error_code == 0)}
+            del d_fa, scan
+
+        def config3():
+            # ---- config 3: read_vcf 8-column scan, 5 GB generated in HBM (non-periodic) --------------------------------
+            n_lines = int(args.vcf_gb * 1e9 / 48.65)
+            d_vcf, n_vcf = device.synth_vcf(n_lines)
+            hdr = bytes(d_vcf[:4096].cpu().numpy()).index(b"#CHROM")
+            hdr = hdr + bytes(d_vcf[hdr:hdr + 256].cpu().numpy()).index(b"\n") + 1
+            vs = device.VcfScan(n_vcf, capacity_records=n_lines + 16)
+            ms, ms_min = timed_launches(torch, lambda: vs.launch(d_vcf, n_bytes=n_vcf, lead=hdr, payload_base=BASE), 8)
+            res = vs.fetch()
+            per_chrom = n_lines // 22 + 1
+            i = torch.arange(n_lines, device="cuda", dtype=torch.int64)
+            pos_ok = bool((((vs.pos[:n_lines] - 1) // 37) == (i % per_chrom)).all())   # POS = (i mod per_chrom) * 37 + 1 + (h & 31)
+            chrom = i // per_chrom + 1                                               # CHROM = i / per_chrom + 1, inlined decimal
+            c0 = vs.cols[0][:n_lines, 0]
+            want = torch.where(chrom < 10, 1 | ((0x30 + chrom) << 32), 2 | ((0x30 + chrom // 10) << 32) | ((0x30 + chrom % 10) << 40))
+            chrom_ok = bool((c0 == want).all())
+            out["config3_vcf_8col"] = {
+                "workload": f"read_vcf 8(+1)-column scan, {n_vcf / 1e9:.2f} GB synthetic VCF ({n_lines} lines, exg_synth_vcf), all columns + typed POS / QUAL",
+                "algorithmic_bytes": n_vcf, "ms": ms, "ms_min": ms_min, "GB/s": n_vcf / (ms * 1e-3) / 1e9,
+                "frac": n_vcf / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "lines_per_s": n_lines / (ms * 1e-3),
+                "verified": bool(res.error_code == 0 and res.n_records == n_lines and pos_ok and chrom_ok)}
+            del d_vcf, vs, i, chrom, c0, want
+            torch.cuda.empty_cache()
+
+        def files():
+            nonlocal n_e2e
+            # ---- end to end: FASTQ file in the page cache -> host DataChunks (PCIe inclusive) -------------------------------
+            n_file = max(n_e2e, n_gz_in)                  # one file serves both legs: config 4 deflates its first n_gz_in bytes
+            p_fq = os.path.join(tmp, "e2e.fastq")
+            with open(p_fq, "wb") as f:
+                step = (1 << 30) // REC * REC
+                for o in range(0, n_file, step):
+                    m = min(step, n_file - o)
+                    f.write(device.synth_fastq(m, file_offset=o)[:m].cpu().numpy().tobytes())
+            n_e2e = n_file
+            torch.cuda.empty_cache()
+            reader_count(lib, p_fq, "fastq")  # warm: pools, page cache
+            n, dt_c = min((reader_count(lib, p_fq, "fastq") for _ in range(3)), key=lambda x: x[1])
+            rows, chunks, dt_r = min((reader_chunks(lib, p_fq, "fastq") for _ in range(3)), key=lambda x: x[2])
+            out["end_to_end"] = {
+                "workload": f"read_fastq, {n_e2e / 1e9:.1f} GB FASTQ-150 file in the page cache -> host DataChunks (exg_open / exg_next_chunk), PCIe inclusive",
+                "algorithmic_bytes": n_e2e, "ms": dt_r * 1e3, "GB/s": n_e2e / dt_r / 1e9, "records_per_s": rows / dt_r, "chunks": chunks,
+                "count_only_ms": dt_c * 1e3, "count_only_GB/s": n_e2e / dt_c / 1e9, "frac": None,
+                "verified": bool(rows == n == n_e2e // REC and chunks >= (rows + 2047) // 2048)}
+            # ---- config 4: read_fastq on BGZF (device inflate feeding the scan) ------------------------------------------------
+            p_gz = os.path.join(tmp, "c4.fastq.gz")
+            t0 = time.perf_counter()
+            comp = build_bgzf(p_fq, n_gz_in, p_gz, max(1, min(cores, 192)))
+            t_build = time.perf_counter() - t0
+            reader_count(lib, p_gz, "fastq")
+            n, dt_g = min((reader_count(lib, p_gz, "fastq") for _ in range(3)), key=lambda x: x[1])
+            out["config4_fastq_bgzf"] = {
+                "workload": f"SELECT COUNT(*) FROM read_fastq('x.fastq.gz'): {comp / 1e9:.2f} GB of BGZF (65 280-byte members, zlib level 6) = "
+                            f"{n_gz_in / 1e9:.2f} GB of FASTQ-150, file in the page cache, inflate + scan on the device",
+                "compressed_bytes": comp, "algorithmic_bytes": comp + 2 * n_gz_in, "ms": dt_g * 1e3, "GB/s": n_gz_in / dt_g / 1e9,
+                "GB/s_compressed": comp / dt_g / 1e9, "records_per_s": n / dt_g, "frac": (comp + 2 * n_gz_in) / dt_g / 1e9 / HBM_PEAK_GBPS,
+                "input_build_s": t_build, "input_deflate_pool_s": getattr(build_bgzf, "pool_s", None), "verified": bool(n == n_gz_in // REC)}
+
+
+        leg(config1, "config1_fasta_1MB_count")
+        leg(config3, "config3_vcf_8col")
+        leg(files, "end_to_end", "config4_fastq_bgzf")
     finally:
         for f in os.listdir(tmp):
             os.unlink(os.path.join(tmp, f))
@@ -511,11 +531,18 @@ def main():
         if world == 1 and not args.no_configs:
             del scan, d_in
             torch.cuda.empty_cache()
-            cfg = run_configs(torch, lib, args)
-            out["end_to_end"] = cfg.pop("end_to_end")
+            # side legs: a failure in one of them (no scratch space, ...) is reported in its object, never at the cost of the line
+            try:
+                cfg = run_configs(torch, lib, args)
+            except Exception as e:  # noqa: BLE001
+                cfg = {"end_to_end": {"error": f"{type(e).__name__}: {e}"}, "error": f"{type(e).__name__}: {e}"}
+            out["end_to_end"] = cfg.pop("end_to_end", None)
             out["configs"] = cfg
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
@@ -530,37 +557,67 @@ def _first_owned_record(sh):
 
 
 def sharded_reader_leg(torch, dist, lib, device, world, rank, local_rank, coll_dev, args):
-    """N ranks, one file: rank 0 writes world x e2e_gb GB of FASTQ-150 to shared memory, every rank opens it with
-    shard_index = rank on its own device and counts its shard; value = rows of all shards / slowest rank's time."""
+    """N ranks, one file: rank 0 writes world x e2e_gb GB of FASTQ-150 to shared memory (less when it has not the room),
+    every rank opens it with shard_index = rank on its own device and counts its shard; value = rows of all shards /
+    slowest rank's time.  A side leg: whatever goes wrong in it is reported in its own object and never takes the headline
+    down (every rank reaches every collective)."""
     tmp = None
-    n_file = int(world * args.e2e_gb * 1e9) // REC * REC
-    path_holder = [None]
+    plan = [None, 0, ""]          # path, bytes, why not
     if rank == 0:
-        tmp, _ = scratch_dir(n_file)
-        path_holder[0] = os.path.join(tmp, "sharded.fastq")
-        with open(path_holder[0], "wb") as f:
-            step = (1 << 30) // REC * REC
-            for o in range(0, n_file, step):
-                m = min(step, n_file - o)
-                f.write(device.synth_fastq(m, file_offset=o)[:m].cpu().numpy().tobytes())
-    dist.broadcast_object_list(path_holder, src=0)
-    path = path_holder[0]
+        try:
+            want = int(world * args.e2e_gb * 1e9) // REC * REC
+            tmp, free = scratch_dir(want)
+            n_file = min(want, int(0.45 * free)) // REC * REC
+            if n_file < world * (64 << 20):
+                plan[2] = f"no room for the shared file ({free / 1e9:.1f} GB free)"
+            else:
+                plan[0], plan[1] = os.path.join(tmp, "sharded.fastq"), n_file
+                with open(plan[0], "wb") as f:
+                    step = (1 << 30) // REC * REC
+                    for o in range(0, n_file, step):
+                        m = min(step, n_file - o)
+                        f.write(device.synth_fastq(m, file_offset=o)[:m].cpu().numpy().tobytes())
+        except Exception as e:      # noqa: BLE001 (disk full, ...)
+            plan[0], plan[2] = None, f"{type(e).__name__}: {e}"
+    dist.broadcast_object_list(plan, src=0)
+    path, n_file, why = plan
+    out = None
+    if path is None:
+        out = {"skipped": why}
+    else:
+        dev = 0 if args.single_device else local_rank
+        n, dt, err = 0, 0.0, ""
+        try:
+            reader_count(lib, path, "fastq", (rank, world), dev)  # warm
+        except Exception as e:      # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"
+        dist.barrier()
+        if not err:
+            try:
+                n, dt = reader_count(lib, path, "fastq", (rank, world), dev)
+            except Exception as e:  # noqa: BLE001
+                err = f"{type(e).__name__}: {e}"
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+        rows = torch.tensor([n], dtype=torch.int64, device=coll_dev)
+        bad = torch.tensor([1 if err else 0], dtype=torch.int64, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rows)
+        dist.all_reduce(bad)
+        if int(bad.item()):
+            out = {"skipped": f"{int(bad.item())} rank(s) failed" + (f" (rank {rank}: {err})" if err else "")}
+        else:
+            out = {"workload": f"COUNT(*) of one {n_file / 1e9:.1f} GB FASTQ-150 file in shared memory, {world} readers with shard_index = rank (exg_open), PCIe inclusive",
+                   "algorithmic_bytes": n_file, "ms": float(t.item()) * 1e3, "GB/s": n_file / float(t.item()) / 1e9,
+                   "records_per_s": int(rows.item()) / float(t.item()), "verified": bool(int(rows.item()) == n_file // REC)}
     dist.barrier()
-    dev = 0 if args.single_device else local_rank
-    reader_count(lib, path, "fastq", (rank, world), dev)  # warm
-    dist.barrier()
-    n, dt = reader_count(lib, path, "fastq", (rank, world), dev)
-    t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
-    rows = torch.tensor([n], dtype=torch.int64, device=coll_dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dist.all_reduce(rows)
-    dist.barrier()
-    if rank == 0:
-        os.unlink(path)
-        os.rmdir(tmp)
-    return {"workload": f"COUNT(*) of one {n_file / 1e9:.1f} GB FASTQ-150 file in shared memory, {world} readers with shard_index = rank (exg_open), PCIe inclusive",
-            "algorithmic_bytes": n_file, "ms": float(t.item()) * 1e3, "GB/s": n_file / float(t.item()) / 1e9,
-            "records_per_s": int(rows.item()) / float(t.item()), "verified": bool(int(rows.item()) == n_file // REC)}
+    if rank == 0 and tmp:
+        try:
+            if plan[0] and os.path.exists(plan[0]):
+                os.unlink(plan[0])
+            os.rmdir(tmp)
+        except OSError:
+            pass
+    return out
 
 
 if __name__ == "__main__":

@@ -243,3 +243,28 @@ def test_open_on_one_thread_scan_on_another(gpu, tmp_path, oracle):
     from exon_duckdb_amd import ExgError
     with pytest.raises(ExgError):
         ShardReader(str(p), "fastq", device=63)
+
+
+def test_bench_two_ranks_on_one_gpu(gpu):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), here with two ranks sharing
+    cuda:0 over gloo: the byte-range shards, the phase all_gather, the COUNT(*) all_reduce, the closed-form verification of
+    both shards and the reader-level leg must produce one JSON line with the whole-job numbers."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--launches-per-step", "2", "--gb", "0.5", "--e2e-gb", "0.25", "--backend", "gloo", "--single-device"]
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["verified"] is True
+    assert j["config"]["file_bytes"] == int(2 * 0.5e9) // 332 * 332
+    assert abs(j["value"] - (j["config"]["file_bytes"] // 332) * 2 * 2 / (j["ms_per_step"] * 2 / 1e3)) < 1e-3 * j["value"]
+    rs = j["reader_sharded"]
+    assert rs.get("verified") is True, rs
