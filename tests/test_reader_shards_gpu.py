@@ -268,3 +268,25 @@ def test_bench_two_ranks_on_one_gpu(gpu):
     assert abs(j["value"] - (j["config"]["file_bytes"] // 332) * 2 * 2 / (j["ms_per_step"] * 2 / 1e3)) < 1e-3 * j["value"]
     rs = j["reader_sharded"]
     assert rs.get("verified") is True, rs
+
+
+def test_rccl_initialises_and_reduces_on_this_image(gpu):
+    """bench.py's N > 1 collectives run over RCCL (torch's "nccl" backend).  A one-GPU box cannot run two ranks on it, but it
+    can prove that the library loads, a communicator comes up and the three collectives the bench uses complete on the device."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import os, torch, torch.distributed as dist\n"
+        "os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29519')\n"
+        "os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', device_id=torch.device('cuda', 0))\n"
+        "t = torch.tensor([41], dtype=torch.int64, device='cuda'); dist.all_reduce(t)\n"
+        "g = [torch.zeros(1, dtype=torch.int64, device='cuda')]; dist.all_gather(g, t + 1)\n"
+        "m = torch.tensor([1.5], dtype=torch.float64, device='cuda'); dist.all_reduce(m, op=dist.ReduceOp.MAX)\n"
+        "dist.barrier(); torch.cuda.synchronize()\n"
+        "assert int(t.item()) == 41 and int(g[0].item()) == 42 and float(m.item()) == 1.5\n"
+        "dist.destroy_process_group(); print('rccl ok')\n")
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ))
+    assert res.returncode == 0 and "rccl ok" in res.stdout, res.stdout[-1000:] + res.stderr[-3000:]
