@@ -21,6 +21,8 @@
 //           k_fa_tile_strings sequence string_t (length = next record's payload offset - own)
 // Traffic: 2 reads + 1 write of the file (the multipass form: ~5 reads + 3 writes of it plus 40 B per
 // line of index).  Algorithmic bytes: file read once + sequence bytes written once.
+#include <stdlib.h>
+
 #include "exg_fasta.hpp"
 
 namespace exg {
@@ -47,6 +49,12 @@ struct TileArrays {
     uint64_t *rec_start;       // [n_rec + 1] payload offset of every record's sequence
     uint64_t *rec_def_off;     // [n_rec] input offset of every record's '>'
     uint64_t rec_cap;          // records the two arrays can hold (more is reported as EXG_RF_INDEX_OVERFLOW)
+    uint64_t *totals;          // [0] records, [1] sequence bytes of the whole input (written by the scan)
+    // single pass (k_fa_fused): what a super-tile publishes and what the scanner answers
+    unsigned long long *f_agg;   // [n_super] packed aggregate, bit 63 = published
+    unsigned int *f_nl;          // [n_super] its newline count, bit 31 = published
+    unsigned long long *f_rec;   // [n_super] records in front of it, bit 63 = answered
+    unsigned long long *f_pay;   // [n_super] sequence bytes in front of it, bit 62 = it begins inside a definition line, bit 63 = answered
 };
 
 // ---- the 16 bytes of one lane (a wave instruction = 1 KiB, coalesced) -----------------------------------------------
@@ -80,7 +88,8 @@ __device__ __forceinline__ uint32_t byte_after_chunk(const uint4 v, bool have_ne
 }
 
 // `full`: the whole row lies inside the input (wave uniform): no per-lane bounds
-__device__ __forceinline__ Chunk classify16(const uint4 v, uint32_t next_byte, bool full, uint64_t o, uint64_t n_bytes) {
+template <class Off>  // offsets as the caller has them: absolute (64-bit) or relative to a wave-uniform base (32-bit)
+__device__ __forceinline__ Chunk classify16(const uint4 v, uint32_t next_byte, bool full, Off o, Off n_bytes) {
     Chunk c;
     const uint32_t valid = full ? 0xFFFFu : (o >= n_bytes ? 0u : below((uint32_t)(n_bytes - o < 16 ? n_bytes - o : 16)));
     const uint32_t nl = match16(v, 0x0A0A0A0Au) & valid;
@@ -352,6 +361,8 @@ __global__ __launch_bounds__(1024) void k_fa_tile_scan(FastaDev a, TileArrays t,
         const unsigned long long n_rec = r0 + za, n_pay = p0 + zb;
         t.rec_before[n_tiles] = n_rec;
         t.pay_before[n_tiles] = n_pay;
+        t.totals[0] = n_rec;
+        t.totals[1] = n_pay;
         if (n_rec <= t.rec_cap) t.rec_start[n_rec] = n_pay;  // sentinel: end of the last record's sequence
         hdr->total_nl = total_nl;
         hdr->total_lines = total_nl + ((a.n_bytes && a.d_in[a.n_bytes - 1] != '\n') ? 1 : 0);
@@ -579,13 +590,298 @@ __global__ __launch_bounds__(kThreads) void k_fa_tile_emit(FastaDev a, TileArray
     }
 }
 
+// ---- single pass ----------------------------------------------------------------------------------------------------------------
+// The count pass and the emit pass classify every row twice (~110 of their 172 / 215 VALU per KiB) and read the input twice.
+// k_fa_fused does both in one visit: a workgroup owns a 32 KiB super-tile, a wave 8 KiB of it (eight 1 KiB rows, loaded once
+// and kept in registers); the wave walks its rows as the count pass does and keeps, per row and lane, the two possible
+// sequence-byte masks (the wave begins outside / inside a definition line) and the definition mask; the workgroup's
+// aggregate — the monoid of k_fa_tile_scan — is published, ONE scanner wave (block 0) turns the published aggregates into
+// exclusive prefixes in order (the line state of 64 super-tiles by two ballots, the sums by DPP scans), and the waves emit
+// from their registers as soon as their prefix has arrived.  Blocks are dispatched in order and publish before they
+// wait, so the scanner never waits for a block behind a waiting one; should an aggregate still be missing after 40 us,
+// the scanner computes it from the input itself.
+static constexpr uint32_t kSuper = 32768, kWaveSpan = kSuper / (kThreads / 64), kWaveRows = kWaveSpan / 1024;
+static constexpr unsigned long long kFPub = 1ull << 63;
+static constexpr int kFHas = 62, kFTail = 61, kFAfter = 15, kFHead = 31;  // [0,15) definitions, [15,31) after, [31,47) head
+static constexpr unsigned int kFPubNl = 1u << 31;
+
+__device__ __forceinline__ unsigned long long fa_ld(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void fa_st(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the aggregate of input bytes [base, base + span) by one wave, straight from the input (scanner's helping path)
+__device__ TileSum fa_span_sum(const FastaDev &a, uint64_t base, uint32_t span, uint32_t lane) {
+    const bool def0 = base == 0 && a.n_bytes > 0 && a.d_in[0] == '>';
+    Carry carry = {base == 0, def0};
+    uint32_t accA = 0, accB = (def0 && lane == 0) ? 1u : 0u;
+    for (uint32_t row = 0; row * 1024 < span; row++) {
+        const uint64_t rbase = base + (uint64_t)row * 1024;
+        if (rbase >= a.n_bytes) break;
+        const uint64_t o = rbase + (uint64_t)lane * 16;
+        const uint4 v = o < a.n_bytes ? *reinterpret_cast<const uint4 *>(a.d_in + o) : make_uint4(0, 0, 0, 0);
+        const uint32_t nb = byte_after_chunk(v, false, 0u, a.d_in, o, a.n_bytes);
+        const Chunk c = classify16(v, nb, rbase + 1024 + 16 <= a.n_bytes, o, a.n_bytes);
+        const Carry st = lane_state(c, carry);
+        const uint32_t known = (uint32_t)__popc(c.pay_known), head = (uint32_t)__popc(c.pay_head);
+        accA += known + ((st.resolved && !st.in_def) ? head : 0u) + ((st.resolved ? 0u : head) << 16);
+        accB += (uint32_t)__popc(c.def_after) + ((uint32_t)__popc(c.nl) << 16);
+    }
+    const unsigned long long tot = wave_sum64((unsigned long long)accA | ((unsigned long long)accB << 32));
+    TileSum e;
+    e.after = tot & 0xFFFFull, e.head = (tot >> 16) & 0xFFFFull, e.defs = (tot >> 32) & 0xFFFFull, e.nls = tot >> 48;
+    e.has = carry.resolved, e.tail = carry.in_def;
+    return e;
+}
+
+// block 0, wave 0: exclusive prefixes of the published aggregates, in order
+__device__ void fa_scanner(const FastaDev &a, const TileArrays &t, ScanWsHeader *hdr, uint32_t n_super, uint32_t lane) {
+    __builtin_amdgcn_s_setprio(3);
+    constexpr int kBatches = 4;
+    uint64_t next = 0;
+    unsigned long long rec = 0, pay = 0, nls = 0;
+    bool in_def = false;  // the input begins outside a definition line
+    unsigned long long t_last = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+    // one batch: lanes [0, r) hold consecutive aggregates
+    auto absorb = [&](unsigned long long d, unsigned int nl, uint32_t r) {
+        const bool mine = lane < r;
+        const bool has = mine && ((d >> kFHas) & 1ull), tail = mine && ((d >> kFTail) & 1ull);
+        const uint32_t defs = mine ? (uint32_t)(d & 0x7FFFull) : 0u, after = mine ? (uint32_t)((d >> kFAfter) & 0xFFFFull) : 0u,
+                       head = mine ? (uint32_t)((d >> kFHead) & 0xFFFFull) : 0u, nlc = mine ? (nl & ~kFPubNl) : 0u;
+        const unsigned long long bs = __ballot(has), bd = __ballot(tail);
+        const unsigned long long left = bs & mask_below(lane);
+        const bool st = left ? ((bd >> (63 - __clzll((long long)left))) & 1ull) != 0 : in_def;
+        const uint32_t mine_pay = after + (st ? 0u : head);
+        const uint32_t inc_d = wave_incl_sum_dpp(defs), inc_p = wave_incl_sum_dpp(mine_pay), inc_n = wave_incl_sum_dpp(nlc);
+        if (mine) {
+            fa_st(&t.f_rec[next + lane], kFPub | (rec + inc_d - defs));
+            fa_st(&t.f_pay[next + lane], kFPub | ((unsigned long long)st << 62) | (pay + inc_p - mine_pay));
+        }
+        rec += (uint32_t)__builtin_amdgcn_readlane((int)inc_d, 63);
+        pay += (uint32_t)__builtin_amdgcn_readlane((int)inc_p, 63);
+        nls += (uint32_t)__builtin_amdgcn_readlane((int)inc_n, 63);
+        if (bs) in_def = ((bd >> (63 - __clzll((long long)bs))) & 1ull) != 0;
+        next += r;
+    };
+    while (next < n_super) {
+        unsigned long long d[kBatches];
+        unsigned int c[kBatches];
+#pragma unroll
+        for (int k = 0; k < kBatches; k++) {
+            const uint64_t idx = next + (uint64_t)k * 64 + lane;
+            d[k] = idx < n_super ? fa_ld(&t.f_agg[idx]) : 0ull;
+            c[k] = idx < n_super ? __hip_atomic_load(&t.f_nl[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        }
+        bool progressed = false;
+#pragma unroll
+        for (int k = 0; k < kBatches; k++) {
+            const unsigned long long rdy = __ballot((d[k] & kFPub) != 0 && (c[k] & kFPubNl) != 0);
+            const uint32_t r = rdy == ~0ull ? 64u : (uint32_t)__ffsll((long long)~rdy) - 1;  // leading run of published ones
+            if (r > 0) {
+                absorb(d[k], c[k], r);
+                progressed = true;
+            }
+            if (r < 64) break;
+        }
+        if (progressed) {
+            t_last = __builtin_amdgcn_s_memrealtime();
+        } else if (__builtin_amdgcn_s_memrealtime() - t_last > 4000) {
+            // ~40 us without the next aggregate: its block may not have been dispatched yet; progress never depends on that
+            const TileSum e = fa_span_sum(a, next * kSuper, kSuper, lane);
+            const unsigned long long dd = kFPub | ((unsigned long long)e.has << kFHas) | ((unsigned long long)e.tail << kFTail) | e.defs |
+                                          (e.after << kFAfter) | (e.head << kFHead);
+            absorb(dd, kFPubNl | (unsigned int)e.nls, 1);
+            t_last = __builtin_amdgcn_s_memrealtime();
+        } else {
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    if (lane == 0) {
+        t.totals[0] = rec;
+        t.totals[1] = pay;
+        if (rec <= t.rec_cap) t.rec_start[rec] = pay;  // sentinel: end of the last record's sequence
+        hdr->total_nl = nls;
+        hdr->total_lines = nls + ((a.n_bytes && a.d_in[a.n_bytes - 1] != '\n') ? 1 : 0);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_fa_fused(FastaDev a, TileArrays t, ScanWsHeader *hdr, uint32_t n_super) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_out_all[kThreads / 64][4096 / 4 + 8];
+    __shared__ TileSum s_agg[kThreads / 64];
+    __shared__ unsigned long long s_pre_rec, s_pre_pay;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (a scalar: what hangs off it is wave uniform)
+    if (blockIdx.x == 0) {  // the scanner: one wave, no tile
+        if (wave == 0) fa_scanner(a, t, hdr, n_super, lane);
+        return;
+    }
+    const uint32_t st_i = blockIdx.x - 1;
+    const uint64_t wbase = (uint64_t)st_i * kSuper + (uint64_t)wave * kWaveSpan;  // this wave's 8 KiB (wave uniform)
+    const bool no_store = (a.flags & EXG_F_NO_STORE) != 0;
+    // input bytes from wbase on, clamped: every per-lane offset and bound below is 32-bit against a wave-uniform base
+    const uint32_t avail = wbase >= a.n_bytes ? 0u : (a.n_bytes - wbase > 0x40000000ull ? 0x40000000u : (uint32_t)(a.n_bytes - wbase));
+    const uint8_t *wp = a.d_in + wbase;
+    const uint32_t lo = lane * 16;
+    // ---- the wave's rows, once
+    uint4 v[kWaveRows];
+#pragma unroll
+    for (int j = 0; j < (int)kWaveRows; j++) {
+        const uint32_t off = (uint32_t)j * 1024 + lo;
+        v[j] = off < avail ? ld_stream16(wp + off) : make_uint4(0, 0, 0, 0);
+    }
+    // ---- the walk of the count pass; what the emission needs of it stays in registers
+    const bool first = st_i == 0 && wave == 0;
+    const bool def0 = first && a.n_bytes > 0 && a.d_in[0] == '>';
+    Carry carry = {first, def0};
+    uint32_t accA = 0, accB = (def0 && lane == 0) ? 1u : 0u;
+    uint32_t pm[kWaveRows], dm[kWaveRows];  // sequence bytes if the wave begins outside | inside (<< 16) a definition line; definitions
+    bool any_hi = false;
+#pragma unroll
+    for (int j = 0; j < (int)kWaveRows; j++) {
+        const uint32_t rrel = (uint32_t)j * 1024;
+        pm[j] = 0, dm[j] = 0;
+        if (rrel < avail) {  // (wave uniform)
+            const uint32_t orel = rrel + lo;
+            const bool have_next = j + 1 < (int)kWaveRows;
+            // the byte behind every lane's chunk: the first byte of the lane above (one DPP wave shift); for lane 63 the first
+            // byte of the next row (in registers) or, behind the wave's last row, one byte of the input
+            const uint32_t next_row_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[have_next ? j + 1 : j].x) & 0xFFu;  // (all lanes)
+            uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v[j].x & 0xFFu), 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+            if (lane == 63) nb = have_next ? next_row_first : (orel + 16 < avail ? (uint32_t)wp[orel + 16] : 0u);
+            const Chunk c = classify16(v[j], nb, rrel + 1024 + 16 <= avail, orel, avail);
+            const Carry stt = lane_state(c, carry);
+            const uint32_t known = (uint32_t)__popc(c.pay_known), head = (uint32_t)__popc(c.pay_head);
+            accA += known + ((stt.resolved && !stt.in_def) ? head : 0u) + ((stt.resolved ? 0u : head) << 16);
+            accB += (uint32_t)__popc(c.def_after) + ((uint32_t)__popc(c.nl) << 16);
+            any_hi = any_hi || c.hi;
+            const uint32_t out_of_def = c.pay_known | ((stt.resolved ? !stt.in_def : true) ? c.pay_head : 0u);
+            const uint32_t in_a_def = c.pay_known | ((stt.resolved ? !stt.in_def : false) ? c.pay_head : 0u);
+            pm[j] = out_of_def | (in_a_def << 16);
+            dm[j] = c.def_after;
+        }
+    }
+    {
+        const unsigned long long tot = wave_sum64((unsigned long long)accA | ((unsigned long long)accB << 32));
+        const bool hi = __ballot(any_hi) != 0;
+        if (lane == 0) {
+            TileSum e;
+            e.after = tot & 0xFFFFull, e.head = (tot >> 16) & 0xFFFFull, e.defs = (tot >> 32) & 0xFFFFull, e.nls = tot >> 48;
+            e.has = carry.resolved, e.tail = carry.in_def;
+            s_agg[wave] = e;
+            if (hi) atomicOr(&hdr->flags, EXG_RF_NON_ASCII);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        TileSum e = s_agg[0];
+        for (uint32_t k = 1; k < kThreads / 64; k++) e = compose(e, s_agg[k]);
+        __hip_atomic_store(&t.f_nl[st_i], kFPubNl | (unsigned int)e.nls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fa_st(&t.f_agg[st_i], kFPub | ((unsigned long long)e.has << kFHas) | ((unsigned long long)e.tail << kFTail) | e.defs |
+                                  (e.after << kFAfter) | (e.head << kFHead));
+        // ... and wait for the answer
+        unsigned long long r, p;
+        for (;;) {
+            r = fa_ld(&t.f_rec[st_i]);
+            p = fa_ld(&t.f_pay[st_i]);
+            if ((r & kFPub) && (p & kFPub)) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        s_pre_rec = r & ~kFPub;
+        s_pre_pay = p & ~kFPub;
+    }
+    __syncthreads();
+    // ---- this wave's own prefix: the super-tile's, then the waves in front of it
+    uint64_t rec_at = s_pre_rec, pay_at = s_pre_pay & ~(1ull << 62);
+    bool wave_in_def = (s_pre_pay >> 62) & 1ull;
+    for (uint32_t k = 0; k < wave; k++) {
+        const TileSum e = s_agg[k];
+        rec_at += e.defs;
+        pay_at += e.after + (wave_in_def ? 0ull : e.head);
+        if (e.has) wave_in_def = e.tail != 0;
+    }
+    if (def0) {  // the definition at offset 0: no newline announces it
+        if (lane == 0 && rec_at < t.rec_cap) {
+            t.rec_start[rec_at] = 0;
+            t.rec_def_off[rec_at] = 0;
+        }
+        rec_at++;
+    }
+    // ---- emission, as in k_fa_tile_emit, from the registers
+    uint32_t *s_out = s_out_all[wave];
+    uint8_t *out8 = reinterpret_cast<uint8_t *>(s_out);
+    uint32_t g_out = 0;
+#pragma unroll
+    for (int j = 0; j < (int)kWaveRows; j++) {
+        const uint32_t rrel = (uint32_t)j * 1024;
+        if (rrel < avail) {
+            const uint32_t orel = rrel + lo;
+            const uint32_t pay = wave_in_def ? pm[j] >> 16 : pm[j] & 0xFFFFu;
+            const uint32_t cnt = (uint32_t)__popc(pay) | ((uint32_t)__popc(dm[j]) << 16);
+            const uint32_t incl = wave_incl_sum_dpp(cnt);
+            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            const uint32_t excl = incl - cnt;
+            const uint32_t my_off = g_out + (excl & 0xFFFFu);
+            uint32_t d = dm[j];
+            uint64_t r = rec_at + (excl >> 16);
+            while (d) {
+                const uint32_t b = (uint32_t)__ffs((int)d) - 1;
+                if (r < t.rec_cap && orel + b + 1 < avail) {
+                    t.rec_start[r] = pay_at + my_off + (uint32_t)__popc(pay & below(b));
+                    t.rec_def_off[r] = wbase + orel + b + 1;
+                }
+                r++;
+                d &= d - 1;
+            }
+            if (!no_store && pay) lds_store_kept(out8 + my_off, v[j], pay);
+            g_out += tot & 0xFFFFu;
+            rec_at += tot >> 16;
+            const bool last_row = j + 1 == (int)kWaveRows || rrel + 1024 >= avail;
+            if (!no_store && g_out && ((j & 3) == 3 || last_row)) {  // (uniform per wave)
+                wave_sync();
+                uint8_t *dst0 = a.d_payload + pay_at;
+                const uint32_t head = (16u - (uint32_t)((uintptr_t)dst0 & 15)) & 15u;
+                uint32_t written = 0;
+                if (g_out >= head) {
+                    const uint32_t n_full = (g_out - head) / 16;
+                    if (lane < head) dst0[lane] = out8[lane];
+                    for (uint32_t q = lane; q < n_full; q += 64) {
+                        const fa_v4u lv = *reinterpret_cast<const fa_v4u *>(out8 + head + q * 16);
+                        uint4 ov;
+                        ov.x = lv.x, ov.y = lv.y, ov.z = lv.z, ov.w = lv.w;
+                        st_stream16(reinterpret_cast<uint4 *>(dst0 + head + q * 16), ov);
+                    }
+                    written = head + n_full * 16;
+                }
+                const uint32_t rem = g_out - written;
+                if (last_row) {
+                    if (lane < rem) dst0[written + lane] = out8[written + lane];
+                    written = g_out;
+                } else if (written) {
+                    const uint8_t x = lane < rem ? out8[written + lane] : (uint8_t)0;
+                    wave_sync();
+                    if (lane < rem) out8[lane] = x;
+                }
+                wave_sync();
+                pay_at += written;
+                g_out -= written;
+            }
+            if (no_store) {
+                pay_at += g_out;
+                g_out = 0;
+            }
+        }
+    }
+}
+
 // id / description of every record, a thread per record.  The thread first copies the line's first 128 bytes into LDS — eight
 // independent 16-byte loads, one round trip — and parses the copy; only a longer definition line is walked in HBM (a chain
 // of dependent loads, ~15 us: inside the emit pass it stalled a whole wavefront for the one lane that owned a '>').
 static constexpr uint32_t kDefStage = 128, kDefStride = kDefStage / 4 + 1;  // dwords per thread: the odd stride spreads the banks
 __global__ __launch_bounds__(256) void k_fa_tile_defs(FastaDev a, TileArrays t, ScanWsHeader *hdr, uint64_t n_tiles) {
     __shared__ uint32_t s_line[256 * kDefStride];
-    uint64_t n_rec = t.rec_before[n_tiles];
+    uint64_t n_rec = t.totals[0];
     if (n_rec > t.rec_cap) n_rec = t.rec_cap;
     const bool no_store = (a.flags & EXG_F_NO_STORE) != 0;
     uint32_t *slot = s_line + threadIdx.x * kDefStride;
@@ -633,7 +929,7 @@ __global__ __launch_bounds__(256) void k_fa_tile_defs(FastaDev a, TileArrays t, 
 
 __global__ __launch_bounds__(256) void k_fa_tile_strings(FastaDev a, TileArrays t, ScanWsHeader *hdr, uint64_t n_tiles) {
     if (a.flags & EXG_F_NO_STORE) return;
-    uint64_t n_rec = t.rec_before[n_tiles];
+    uint64_t n_rec = t.totals[0];
     if (n_rec > t.rec_cap) n_rec = t.rec_cap;
     const uint64_t n = n_rec < a.capacity ? n_rec : a.capacity;
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
@@ -654,12 +950,12 @@ __global__ __launch_bounds__(256) void k_fa_tile_strings(FastaDev a, TileArrays 
 
 __global__ void k_fa_tile_finalize(FastaDev a, TileArrays t, ScanWsHeader *hdr, uint64_t n_tiles, exg_scan_result *res) {
     if (threadIdx.x || blockIdx.x) return;
-    const uint64_t n_owned = t.rec_before[n_tiles];
+    const uint64_t n_owned = t.totals[0];
     exg_scan_result r;
     r.n_lines = hdr->total_lines;
     r.flags = hdr->flags;
     if (n_owned > t.rec_cap) r.flags |= EXG_RF_INDEX_OVERFLOW;
-    r.payload_bytes = t.pay_before[n_tiles];
+    r.payload_bytes = t.totals[1];
     r.reserved = 0;
     r.error_code = 0;
     r.error_offset = ~0ull;
@@ -698,9 +994,6 @@ int run_fasta_tiled(const FastaDev &dev, uint8_t *ws, const FastqWsLayout &l, ex
     TileArrays t;
     // 24 B per 16 KiB tile live in the fused kernels' descriptor region; the per-record arrays in the line arrays
     unsigned long long *region = reinterpret_cast<unsigned long long *>(ws + l.off_tile_desc);
-    t.desc = region;
-    t.rec_before = reinterpret_cast<uint64_t *>(region + (n_tiles + 1));
-    t.pay_before = reinterpret_cast<uint64_t *>(region + 2 * (n_tiles + 1));
     uint64_t *base = reinterpret_cast<uint64_t *>(ws + l.off_nl_pos);
     t.rec_start = base;
     t.rec_def_off = base + (l.lines_cap + 2);
@@ -708,10 +1001,34 @@ int run_fasta_tiled(const FastaDev &dev, uint8_t *ws, const FastqWsLayout &l, ex
     // records <= lines: the per-record arrays hold lines_cap + 2 entries each (a file with more definition
     // lines than that is reported like a line-index overflow)
     hipLaunchKernelGGL(k_init_hdr, dim3(1), dim3(1), 0, stream, hdr, l.lines_cap, 0u);
-    const uint32_t grid = (uint32_t)(n_tiles < 16384 ? (n_tiles ? n_tiles : 1) : 16384);
-    if (n_tiles) hipLaunchKernelGGL(k_fa_tile_count, dim3(grid), dim3(kThreads), 0, stream, dev, t, hdr, n_tiles);
-    hipLaunchKernelGGL(k_fa_tile_scan, dim3((uint32_t)(n_tiles ? (n_tiles + 4095) / 4096 : 1)), dim3(1024), 0, stream, dev, t, hdr, n_tiles);
-    if (n_tiles) hipLaunchKernelGGL(k_fa_tile_emit, dim3(grid), dim3(kThreads), 0, stream, dev, t, hdr, n_tiles);
+    static const bool two_pass = getenv("EXG_FASTA_TWO_PASS") != nullptr;
+    if (!two_pass) {
+        // single pass: 28 B per 32 KiB super-tile (the region holds 24 B per 16 KiB)
+        const uint64_t n_super = (dev.n_bytes + kSuper - 1) / kSuper;
+        if (n_super > 0x7FFFFFF0ull) {
+            set_error("exg_fasta_scan: buffer too large for one launch (%llu super-tiles)", (unsigned long long)n_super);
+            return EXG_E_INVALID_ARG;
+        }
+        t.desc = nullptr, t.rec_before = nullptr, t.pay_before = nullptr;
+        t.f_agg = region;
+        t.f_rec = region + n_super;
+        t.f_pay = region + 2 * n_super;
+        t.totals = reinterpret_cast<uint64_t *>(region + 3 * n_super);
+        t.f_nl = reinterpret_cast<unsigned int *>(region + 3 * n_super + 2);
+        EXG_HIP_CHECK(hipMemsetAsync(region, 0, (size_t)(3 * n_super + 2) * 8 + (size_t)n_super * 4, stream));
+        hipLaunchKernelGGL(k_fa_fused, dim3((uint32_t)n_super + 1), dim3(kThreads), 0, stream, dev, t, hdr, (uint32_t)n_super);
+    } else {
+        t.desc = region;
+        t.rec_before = reinterpret_cast<uint64_t *>(region + (n_tiles + 1));
+        t.pay_before = reinterpret_cast<uint64_t *>(region + 2 * (n_tiles + 1));
+        t.totals = reinterpret_cast<uint64_t *>(region + 3 * (n_tiles + 1));
+        t.f_agg = t.f_rec = t.f_pay = nullptr;
+        t.f_nl = nullptr;
+        const uint32_t grid = (uint32_t)(n_tiles < 16384 ? (n_tiles ? n_tiles : 1) : 16384);
+        if (n_tiles) hipLaunchKernelGGL(k_fa_tile_count, dim3(grid), dim3(kThreads), 0, stream, dev, t, hdr, n_tiles);
+        hipLaunchKernelGGL(k_fa_tile_scan, dim3((uint32_t)(n_tiles ? (n_tiles + 4095) / 4096 : 1)), dim3(1024), 0, stream, dev, t, hdr, n_tiles);
+        if (n_tiles) hipLaunchKernelGGL(k_fa_tile_emit, dim3(grid), dim3(kThreads), 0, stream, dev, t, hdr, n_tiles);
+    }
     const uint64_t est_rec = dev.n_bytes / 64 + 256;
     const uint32_t sgrid = (uint32_t)((est_rec + 255) / 256 < 4096 ? (est_rec + 255) / 256 : 4096);
     hipLaunchKernelGGL(k_fa_tile_defs, dim3(sgrid), dim3(256), 0, stream, dev, t, hdr, n_tiles);
