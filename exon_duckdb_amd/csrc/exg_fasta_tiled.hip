@@ -1,56 +1,36 @@
-// exg_fasta_tiled.hip — FASTA record scan in two passes over 16 KiB tiles.
+// exg_fasta_tiled.hip — FASTA record scan in ONE pass over 32 KiB super-tiles.
 //
 // Same semantics as exg_fasta.hip (noodles-fasta 0.27.0 read_definition / read_sequence as driven by
 // exon 0.2.6; reached from rust/src/arrow_reader.rs:116-153): a line whose first byte is '>' defines a
 // record (id to the first ASCII whitespace, the rest trimmed = description); the sequence is every
 // following line with LF (and a CR before it) removed, concatenated in a compacted payload buffer.
 //
-// What a tile needs from the bytes in front of it is tiny — records before it, sequence bytes before it
+// What a run of bytes needs from the bytes in front of it is tiny — records before it, sequence bytes before it
 // and one bit (does it begin inside a definition line) — so no line index is built:
-//   pass 1  k_fa_tile_count   a workgroup per tile, 64 contiguous bytes per thread held in registers:
-//                             newline / '>' / CR masks, line starts, definition-line extents ->
-//                             descriptor {definitions, sequence bytes after the first line start,
-//                             sequence bytes before it (they count only if the tile begins outside a
-//                             definition line), has a line start, last line is a definition}
-//           k_fa_tile_scan    one workgroup: resolves the begin-inside-a-definition bit tile by tile
-//                             (64 tiles per step with ballots), then a two-quantity prefix sum
-//   pass 2  k_fa_tile_emit    re-reads the tile (second and last read of the input), compacts the
-//                             sequence bytes through LDS and writes them with 16-byte stores at the
-//                             tile's payload offset; the threads that own a '>' at a line start write the
-//                             record's id / description string_t and its payload offset
-//           k_fa_tile_strings sequence string_t (length = next record's payload offset - own)
-// Traffic: 2 reads + 1 write of the file (the multipass form: ~5 reads + 3 writes of it plus 40 B per
-// line of index).  Algorithmic bytes: file read once + sequence bytes written once.
-#include <stdlib.h>
-
+//   k_fa_fused         a workgroup per super-tile, a wave per 8 KiB of it (eight 1 KiB rows kept in registers): newline /
+//                      '>' / CR classification, the line state carried from row to row by ballots, the super-tile's aggregate
+//                      published; one scanner wave (block 0) turns the aggregates into exclusive prefixes in order; the
+//                      waves then compact their sequence bytes through LDS into the payload and record, for every '>' at a
+//                      line start, the record's payload offset and the offset of its definition line
+//   k_fa_tile_defs     id / description string_t of every record (thread = record, the line parsed from an LDS copy)
+//   k_fa_tile_strings  sequence string_t (length = next record's payload offset - own)
+// Traffic: 1 read + 1 write of the file (the first tiled form read it twice: a count pass, a scan, an emit pass; the
+// multipass form: ~5 reads + 3 writes of it plus 40 B per line of index).  Algorithmic bytes: file read once + sequence
+// bytes written once.
 #include "exg_fasta.hpp"
 
 namespace exg {
 
 namespace {
 
-static constexpr uint32_t kTile = 16384;
-static constexpr uint32_t kThreads = 256;  // x 64 bytes
-
-// tile descriptor (one u64):  [0,14) definitions  [14,29) bytes_after  [29,44) bytes_head  44 has a newline
-// 45 the line after its last newline is a definition
-// [47,62) newlines (a per-tile atomicAdd on one counter would cost more than the whole pass: ~88 atomics/us)
-static constexpr int kDAfter = 14, kDHead = 29, kDHas = 44, kDTail = 45, kDNl = 47;
-__device__ __forceinline__ unsigned long long pack_desc(uint32_t defs, uint32_t after, uint32_t head, bool has_nl,
-                                                        bool tail_def, uint32_t nls) {
-    return (unsigned long long)defs | ((unsigned long long)after << kDAfter) | ((unsigned long long)head << kDHead) |
-           ((unsigned long long)has_nl << kDHas) | ((unsigned long long)tail_def << kDTail) | ((unsigned long long)nls << kDNl);
-}
+static constexpr uint32_t kThreads = 256;  // four waves
 
 struct TileArrays {
-    unsigned long long *desc;  // [n_tiles]
-    uint64_t *rec_before;      // [n_tiles + 1]
-    uint64_t *pay_before;      // [n_tiles + 1]  bit 63: the tile begins inside a definition line
     uint64_t *rec_start;       // [n_rec + 1] payload offset of every record's sequence
     uint64_t *rec_def_off;     // [n_rec] input offset of every record's '>'
     uint64_t rec_cap;          // records the two arrays can hold (more is reported as EXG_RF_INDEX_OVERFLOW)
-    uint64_t *totals;          // [0] records, [1] sequence bytes of the whole input (written by the scan)
-    // single pass (k_fa_fused): what a super-tile publishes and what the scanner answers
+    uint64_t *totals;          // [0] records, [1] sequence bytes of the whole input (written by the scanner)
+    // what a super-tile publishes and what the scanner answers
     unsigned long long *f_agg;   // [n_super] packed aggregate, bit 63 = published
     unsigned int *f_nl;          // [n_super] its newline count, bit 31 = published
     unsigned long long *f_rec;   // [n_super] records in front of it, bit 63 = answered
@@ -156,82 +136,13 @@ __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
     return __shfl(v, 0, 64);
 }
 
-// The input begins at a line start: tile 0 enters with a known state (and, if its first byte is '>', with a
-// definition that no newline announces).
-__device__ __forceinline__ Carry tile_carry(const FastaDev &a, uint64_t tile, bool *def_at_zero) {
-    *def_at_zero = tile == 0 && a.n_bytes > 0 && a.d_in[0] == '>';
-    Carry c = {tile == 0, *def_at_zero};
-    return c;
-}
-
-// ---- pass 1 --------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_fa_tile_count(FastaDev a, TileArrays t, ScanWsHeader *hdr, uint64_t n_tiles) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint64_t wave = (uint64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * (kThreads / 64);
-    for (uint64_t tile = wave; tile < n_tiles; tile += n_waves) {
-        bool def0;
-        Carry carry = tile_carry(a, tile, &def0);
-        // packed per-lane sums (<= 256 each): accA = bytes after a known state | head bytes << 16, accB = definitions |
-        // newlines << 16
-        uint32_t accA = 0, accB = (def0 && lane == 0) ? 1u : 0u;
-        bool any_hi = false;
-#pragma unroll 1
-        for (int g = 0; g < 4; g++) {
-            const uint64_t gbase = tile * kTile + (uint64_t)g * 4096;
-            if (gbase >= a.n_bytes) break;
-            uint4 v[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint64_t off = gbase + (uint64_t)k * 1024 + (uint64_t)lane * 16;
-                v[k] = off < a.n_bytes ? ld_stream16(a.d_in + off) : make_uint4(0, 0, 0, 0);
-            }
-            const bool full = gbase + 4096 + 16 <= a.n_bytes;  // the four rows and the byte behind them
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint64_t o = gbase + (uint64_t)k * 1024 + (uint64_t)lane * 16;
-                const uint32_t nb = byte_after_chunk(v[k], k < 3, k < 3 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)v[k < 3 ? k + 1 : 3].x) & 0xFFu : 0u,
-                                                     a.d_in, o, a.n_bytes);
-                const Chunk c = classify16(v[k], nb, full, o, a.n_bytes);
-                const Carry st = lane_state(c, carry);
-                const uint32_t known = (uint32_t)__popc(c.pay_known), head = (uint32_t)__popc(c.pay_head);
-                // a lane whose state is known counts its head bytes itself; otherwise they are the tile's head
-                accA += known + ((st.resolved && !st.in_def) ? head : 0u) + ((st.resolved ? 0u : head) << 16);
-                accB += (uint32_t)__popc(c.def_after) + ((uint32_t)__popc(c.nl) << 16);
-                any_hi = any_hi || c.hi;
-            }
-        }
-        // (64 lanes x 256 < 2^16: the fields do not run into each other)
-        const unsigned long long tot = wave_sum64((unsigned long long)accA | ((unsigned long long)accB << 32));
-        const bool hi = __ballot(any_hi) != 0;
-        if (lane == 0) {
-            t.desc[tile] = pack_desc((uint32_t)((tot >> 32) & 0xFFFFu), (uint32_t)(tot & 0xFFFFu), (uint32_t)((tot >> 16) & 0xFFFFu),
-                                     carry.resolved, carry.in_def, (uint32_t)(tot >> 48));
-            if (hi) atomicOr(&hdr->flags, EXG_RF_NON_ASCII);
-        }
-    }
-}
-
-// ---- tile scan ---------------------------------------------------------------------------------------------------------------
-// A workgroup per 4096 tiles (four consecutive tiles per thread).  What lies in front of its tiles — records, sequence bytes, the
-// line state, newlines — is the ordered composition of all earlier descriptors, which every workgroup works out for itself (a
-// contiguous slice per thread, a shuffle tree, sixteen wave results: ~0.5 MB of descriptors per GB of input, out of L2) instead
-// of waiting for its predecessors: one workgroup walking all tiles took 84 us per GB.  Then, for its own tiles: the
-// begin-inside-a-definition bit (nearest newline to the left: inside the thread, ballots inside the wave, 16 wave summaries in
-// LDS) and the two prefix sums (32-bit DPP scans, 64-bit bases).
+// ---- what a run of bytes contributes, and how two adjacent runs combine -----------------------------------------------------
+// (definitions, sequence bytes after the run's first newline, sequence bytes in front of it — they count only if the run
+// begins outside a definition line —, newlines, has-a-newline, what follows the last one): an ordered monoid
 struct TileSum {
     unsigned long long defs, after, head, nls;  // head: sequence bytes in front of the first newline (their line's kind comes from the left)
     uint32_t has, tail;                         // a newline inside; what follows the last one is a definition line
 };
-__device__ __forceinline__ TileSum tile_sum_of(unsigned long long d) {
-    TileSum e;
-    e.defs = d & 0x3FFFull;
-    e.after = (d >> kDAfter) & 0x7FFFull;
-    e.head = (d >> kDHead) & 0x7FFFull;
-    e.nls = (d >> kDNl) & 0x7FFFull;
-    e.has = (uint32_t)((d >> kDHas) & 1ull);
-    e.tail = (uint32_t)((d >> kDTail) & 1ull);
-    return e;
-}
 // a then b
 __device__ __forceinline__ TileSum compose(const TileSum &a, const TileSum &b) {
     TileSum r;
@@ -249,124 +160,6 @@ __device__ __forceinline__ TileSum compose(const TileSum &a, const TileSum &b) {
         r.tail = b.tail;
     }
     return r;
-}
-__device__ __forceinline__ TileSum shfl_down_sum(const TileSum &e, int d) {
-    TileSum r;
-    r.defs = __shfl_down(e.defs, d, 64);
-    r.after = __shfl_down(e.after, d, 64);
-    r.head = __shfl_down(e.head, d, 64);
-    r.nls = __shfl_down(e.nls, d, 64);
-    const uint32_t f = __shfl_down(e.has | (e.tail << 1), d, 64);
-    r.has = f & 1u;
-    r.tail = f >> 1;
-    return r;
-}
-
-__global__ __launch_bounds__(1024) void k_fa_tile_scan(FastaDev a, TileArrays t, ScanWsHeader *hdr, uint64_t n_tiles) {
-    __shared__ unsigned long long s_a[16], s_b[16];
-    __shared__ uint32_t s_has[16], s_def[16];
-    __shared__ TileSum s_front[16];
-    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint64_t base = (uint64_t)blockIdx.x * 4096;
-    // ---- everything in front of this workgroup's tiles
-    TileSum front = {0, 0, 0, 0, 0, 0};
-    if (base) {
-        // a thread's slice is whole 128-byte lines of descriptors, read with 16-byte loads: a line is fetched once (8-byte loads at
-        // a stride of hundreds of bytes pulled 110 MB through the L1s for 0.5 MB of descriptors: 40 us)
-        const uint64_t per = (((base + 1023) / 1024) + 15) & ~15ull, i0 = (uint64_t)threadIdx.x * per, i1 = i0 + per < base ? i0 + per : base;
-        TileSum e = {0, 0, 0, 0, 0, 0};
-        for (uint64_t i = i0; i < i1; i += 16) {
-            ulonglong2 dd[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) dd[j] = i + 2 * j < i1 ? *reinterpret_cast<const ulonglong2 *>(t.desc + i + 2 * j) : make_ulonglong2(0, 0);
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                if (i + 2 * j < i1) e = compose(e, tile_sum_of(dd[j].x));
-                if (i + 2 * j + 1 < i1) e = compose(e, tile_sum_of(dd[j].y));
-            }
-        }
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const TileSum o = shfl_down_sum(e, d);
-            if ((lane & (2 * d - 1)) == 0) e = compose(e, o);
-        }
-        if (lane == 0) s_front[w] = e;
-        __syncthreads();
-        for (uint32_t k = 0; k < 16; k++) front = compose(front, s_front[k]);
-    }
-    const unsigned long long r0 = front.defs, p0 = front.after + front.head;  // (the input begins outside a definition line)
-    const bool carry0 = front.has && front.tail;
-    // ---- its own tiles
-    const uint64_t i0 = base + (uint64_t)threadIdx.x * 4;
-    unsigned long long d[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) d[j] = i0 + j < n_tiles ? t.desc[i0 + j] : 0ull;
-    // the thread's own four tiles: does any have a newline, and what follows the last one
-    bool has = false, tail = false;
-    unsigned long long nl_sum = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        if ((d[j] >> kDHas) & 1ull) has = true, tail = (d[j] >> kDTail) & 1ull;
-        nl_sum += (d[j] >> kDNl) & 0x7FFFull;
-    }
-    const unsigned long long bs = __ballot(has), bd = __ballot(tail);
-    if (lane == 0) {
-        s_has[w] = bs != 0;
-        s_def[w] = bs ? (uint32_t)((bd >> (63 - __clzll((long long)bs))) & 1ull) : 0u;
-    }
-    __syncthreads();
-    bool in_def = carry0;  // state entering the thread's first tile
-    for (uint32_t k = 0; k < w; k++)
-        if (s_has[k]) in_def = s_def[k] != 0;
-    const unsigned long long left = bs & mask_below(lane);
-    if (left) in_def = (bd >> (63 - __clzll((long long)left))) & 1ull;
-    bool st[4];
-    uint32_t ca[4], cb[4], sa = 0, sb = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        st[j] = in_def;
-        ca[j] = (uint32_t)(d[j] & 0x3FFFull);
-        cb[j] = (uint32_t)((d[j] >> kDAfter) & 0x7FFFull) + (in_def ? 0u : (uint32_t)((d[j] >> kDHead) & 0x7FFFull));
-        sa += ca[j];
-        sb += cb[j];
-        if ((d[j] >> kDHas) & 1ull) in_def = (d[j] >> kDTail) & 1ull;
-    }
-    const unsigned long long ia = wave_incl_sum_dpp(sa), ib = wave_incl_sum_dpp(sb);
-    if (lane == 63) s_a[w] = ia, s_b[w] = ib;
-    __syncthreads();
-    unsigned long long fa = 0, fb = 0, za = 0, zb = 0;
-    for (uint32_t k = 0; k < 16; k++) {
-        if (k < w) fa += s_a[k], fb += s_b[k];
-        za += s_a[k], zb += s_b[k];
-    }
-    unsigned long long ra = r0 + fa + ia - sa, rb = p0 + fb + ib - sb;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        if (i0 + j < n_tiles) {
-            t.rec_before[i0 + j] = ra;
-            t.pay_before[i0 + j] = rb | ((unsigned long long)st[j] << 63);
-        }
-        ra += ca[j];
-        rb += cb[j];
-    }
-    if (blockIdx.x != gridDim.x - 1) return;
-    // the last workgroup: totals of the whole input
-    __syncthreads();
-    nl_sum = wave_sum64(nl_sum);
-    if (lane == 0) s_a[w] = nl_sum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long total_nl = front.nls;
-        for (uint32_t k = 0; k < 16; k++) total_nl += s_a[k];
-        const unsigned long long n_rec = r0 + za, n_pay = p0 + zb;
-        t.rec_before[n_tiles] = n_rec;
-        t.pay_before[n_tiles] = n_pay;
-        t.totals[0] = n_rec;
-        t.totals[1] = n_pay;
-        if (n_rec <= t.rec_cap) t.rec_start[n_rec] = n_pay;  // sentinel: end of the last record's sequence
-        hdr->total_nl = total_nl;
-        hdr->total_lines = total_nl + ((a.n_bytes && a.d_in[a.n_bytes - 1] != '\n') ? 1 : 0);
-    }
 }
 
 // ---- pass 2 --------------------------------------------------------------------------------------------------------------
@@ -485,117 +278,12 @@ __device__ __forceinline__ void lds_store_kept(uint8_t *dst, const uint4 v, uint
         if (pay & (1u << q)) *dst++ = (uint8_t)(words[q >> 2] >> (8 * (q & 3)));
 }
 
-__global__ __launch_bounds__(kThreads) void k_fa_tile_emit(FastaDev a, TileArrays t, ScanWsHeader *hdr, uint64_t n_tiles) {
-    // per wave: the sequence bytes of four rows (4 KiB of input), compacted, on their way to the payload
-    __shared__ __attribute__((aligned(16))) uint32_t s_out_all[kThreads / 64][4096 / 4 + 8];
-    const uint32_t lane = threadIdx.x & 63;
-    uint32_t *s_out = s_out_all[threadIdx.x >> 6];
-    uint8_t *out8 = reinterpret_cast<uint8_t *>(s_out);
-    const bool no_store = (a.flags & EXG_F_NO_STORE) != 0;
-    const uint64_t wave = (uint64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * (kThreads / 64);
-    for (uint64_t tile = wave; tile < n_tiles; tile += n_waves) {
-        const unsigned long long pb = t.pay_before[tile];
-        bool def0;
-        Carry carry = tile_carry(a, tile, &def0);
-        const bool tile_in_def = pb >> 63;
-        uint64_t pay_at = pb & ~(1ull << 63);  // payload offset of the current group of rows
-        uint64_t rec_at = t.rec_before[tile];
-        if (def0) {  // the definition at offset 0: no newline announces it
-            if (lane == 0 && rec_at < t.rec_cap) {
-                t.rec_start[rec_at] = 0;
-                t.rec_def_off[rec_at] = 0;
-            }
-            rec_at++;
-        }
-        uint32_t g_out = 0;  // sequence bytes compacted in LDS and not yet written (wave uniform)
-        uint4 v_next = make_uint4(0, 0, 0, 0);
-        {
-            const uint64_t off = tile * kTile + (uint64_t)lane * 16;
-            if (off < a.n_bytes) v_next = ld_stream16(a.d_in + off);
-        }
-#pragma unroll 1
-        for (int row = 0; row < 16; row++) {
-            const uint64_t rbase = tile * kTile + (uint64_t)row * 1024;
-            if (rbase >= a.n_bytes) break;
-            const uint64_t o = rbase + (uint64_t)lane * 16;
-            const uint4 v = v_next;
-            if (row < 15 && o + 1024 < a.n_bytes) v_next = ld_stream16(a.d_in + o + 1024);  // next row in flight
-            else v_next = make_uint4(0, 0, 0, 0);
-            const bool have_next = row < 15 && rbase + 1024 < a.n_bytes;
-            const uint32_t nb = byte_after_chunk(v, have_next, (uint32_t)__builtin_amdgcn_readfirstlane((int)v_next.x) & 0xFFu, a.d_in, o,
-                                                 a.n_bytes);
-            const Chunk c = classify16(v, nb, rbase + 1024 + 16 <= a.n_bytes, o, a.n_bytes);
-            const Carry st = lane_state(c, carry);
-            const bool in_def = st.resolved ? st.in_def : tile_in_def;
-            const uint32_t pay = c.pay_known | (in_def ? 0u : c.pay_head);
-            // one scan for both counts: sequence bytes (<= 1024 per row) and definitions (<= 512)
-            const uint32_t cnt = (uint32_t)__popc(pay) | ((uint32_t)__popc(c.def_after) << 16);
-            const uint32_t incl = wave_incl_sum_dpp(cnt);
-            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            const uint32_t excl = incl - cnt;
-            const uint32_t my_off = g_out + (excl & 0xFFFFu);
-            // definitions announced by my newlines
-            uint32_t d = c.def_after;
-            uint64_t r = rec_at + (excl >> 16);
-            while (d) {
-                const uint32_t b = (uint32_t)__ffs((int)d) - 1;
-                if (r < t.rec_cap && o + b + 1 < a.n_bytes) {
-                    t.rec_start[r] = pay_at + my_off + (uint32_t)__popc(pay & below(b));
-                    t.rec_def_off[r] = o + b + 1;
-                }
-                r++;
-                d &= d - 1;
-            }
-            if (!no_store && pay) lds_store_kept(out8 + my_off, v, pay);
-            g_out += tot & 0xFFFFu;
-            rec_at += tot >> 16;
-            const bool last_row = row == 15 || rbase + 1024 >= a.n_bytes;
-            if (!no_store && g_out && ((row & 3) == 3 || last_row)) {  // (uniform per wave)
-                wave_sync();
-                // compacted rows -> payload: the bytes up to the payload's 16-byte grid once per tile (a byte per lane), then
-                // whole 16-byte groups (LDS reads need no alignment on gfx950); what is left over (< 16 bytes) moves to the
-                // front of the buffer and leaves with the next rows, or byte by byte behind the tile's last row
-                uint8_t *dst0 = a.d_payload + pay_at;
-                const uint32_t head = (16u - (uint32_t)((uintptr_t)dst0 & 15)) & 15u;
-                uint32_t written = 0;
-                if (g_out >= head) {
-                    const uint32_t n_full = (g_out - head) / 16;
-                    if (lane < head) dst0[lane] = out8[lane];
-                    for (uint32_t q = lane; q < n_full; q += 64) {
-                        const fa_v4u lv = *reinterpret_cast<const fa_v4u *>(out8 + head + q * 16);
-                        uint4 ov;
-                        ov.x = lv.x, ov.y = lv.y, ov.z = lv.z, ov.w = lv.w;
-                        st_stream16(reinterpret_cast<uint4 *>(dst0 + head + q * 16), ov);
-                    }
-                    written = head + n_full * 16;
-                }
-                const uint32_t rem = g_out - written;  // < 16 (or all of it, when it does not reach the grid)
-                if (last_row) {
-                    if (lane < rem) dst0[written + lane] = out8[written + lane];
-                    written = g_out;
-                } else if (written) {
-                    const uint8_t x = lane < rem ? out8[written + lane] : (uint8_t)0;
-                    wave_sync();
-                    if (lane < rem) out8[lane] = x;
-                }
-                wave_sync();
-                pay_at += written;
-                g_out -= written;
-            }
-            if (no_store) {
-                pay_at += g_out;
-                g_out = 0;
-            }
-        }
-    }
-}
-
-// ---- single pass ----------------------------------------------------------------------------------------------------------------
-// The count pass and the emit pass classify every row twice (~110 of their 172 / 215 VALU per KiB) and read the input twice.
-// k_fa_fused does both in one visit: a workgroup owns a 32 KiB super-tile, a wave 8 KiB of it (eight 1 KiB rows, loaded once
+// ---- the scan ---------------------------------------------------------------------------------------------------------------------
+// (The first tiled form was a count pass, a one-workgroup scan and an emit pass: every row classified twice, the input read
+// twice, 0.80 ms per GB.)  k_fa_fused does it in one visit: a workgroup owns a 32 KiB super-tile, a wave 8 KiB of it (eight 1 KiB rows, loaded once
 // and kept in registers); the wave walks its rows as the count pass does and keeps, per row and lane, the two possible
 // sequence-byte masks (the wave begins outside / inside a definition line) and the definition mask; the workgroup's
-// aggregate — the monoid of k_fa_tile_scan — is published, ONE scanner wave (block 0) turns the published aggregates into
+// aggregate — the monoid above — is published, ONE scanner wave (block 0) turns the published aggregates into
 // exclusive prefixes in order (the line state of 64 super-tiles by two ballots, the sums by DPP scans), and the waves emit
 // from their registers as soon as their prefix has arrived.  Blocks are dispatched in order and publish before they
 // wait, so the scanner never waits for a block behind a waiting one; should an aggregate still be missing after 40 us,
@@ -731,7 +419,7 @@ __global__ __launch_bounds__(kThreads) void k_fa_fused(FastaDev a, TileArrays t,
         const uint32_t off = (uint32_t)j * 1024 + lo;
         v[j] = off < avail ? ld_stream16(wp + off) : make_uint4(0, 0, 0, 0);
     }
-    // ---- the walk of the count pass; what the emission needs of it stays in registers
+    // ---- the walk: line state from row to row; what the emission needs of it stays in registers
     const bool first = st_i == 0 && wave == 0;
     const bool def0 = first && a.n_bytes > 0 && a.d_in[0] == '>';
     Carry carry = {first, def0};
@@ -808,7 +496,7 @@ __global__ __launch_bounds__(kThreads) void k_fa_fused(FastaDev a, TileArrays t,
         }
         rec_at++;
     }
-    // ---- emission, as in k_fa_tile_emit, from the registers
+    // ---- emission from the registers
     uint32_t *s_out = s_out_all[wave];
     uint8_t *out8 = reinterpret_cast<uint8_t *>(s_out);
     uint32_t g_out = 0;
@@ -879,7 +567,7 @@ __global__ __launch_bounds__(kThreads) void k_fa_fused(FastaDev a, TileArrays t,
 // independent 16-byte loads, one round trip — and parses the copy; only a longer definition line is walked in HBM (a chain
 // of dependent loads, ~15 us: inside the emit pass it stalled a whole wavefront for the one lane that owned a '>').
 static constexpr uint32_t kDefStage = 128, kDefStride = kDefStage / 4 + 1;  // dwords per thread: the odd stride spreads the banks
-__global__ __launch_bounds__(256) void k_fa_tile_defs(FastaDev a, TileArrays t, ScanWsHeader *hdr, uint64_t n_tiles) {
+__global__ __launch_bounds__(256) void k_fa_tile_defs(FastaDev a, TileArrays t, ScanWsHeader *hdr) {
     __shared__ uint32_t s_line[256 * kDefStride];
     uint64_t n_rec = t.totals[0];
     if (n_rec > t.rec_cap) n_rec = t.rec_cap;
@@ -927,7 +615,7 @@ __global__ __launch_bounds__(256) void k_fa_tile_defs(FastaDev a, TileArrays t, 
     }
 }
 
-__global__ __launch_bounds__(256) void k_fa_tile_strings(FastaDev a, TileArrays t, ScanWsHeader *hdr, uint64_t n_tiles) {
+__global__ __launch_bounds__(256) void k_fa_tile_strings(FastaDev a, TileArrays t, ScanWsHeader *hdr) {
     if (a.flags & EXG_F_NO_STORE) return;
     uint64_t n_rec = t.totals[0];
     if (n_rec > t.rec_cap) n_rec = t.rec_cap;
@@ -948,7 +636,7 @@ __global__ __launch_bounds__(256) void k_fa_tile_strings(FastaDev a, TileArrays 
     }
 }
 
-__global__ void k_fa_tile_finalize(FastaDev a, TileArrays t, ScanWsHeader *hdr, uint64_t n_tiles, exg_scan_result *res) {
+__global__ void k_fa_tile_finalize(FastaDev a, TileArrays t, ScanWsHeader *hdr, exg_scan_result *res) {
     if (threadIdx.x || blockIdx.x) return;
     const uint64_t n_owned = t.totals[0];
     exg_scan_result r;
@@ -990,9 +678,9 @@ __global__ void k_init_hdr(ScanWsHeader *hdr, uint64_t lines_cap, uint32_t mode)
 
 int run_fasta_tiled(const FastaDev &dev, uint8_t *ws, const FastqWsLayout &l, exg_scan_result *d_result, hipStream_t stream) {
     ScanWsHeader *hdr = reinterpret_cast<ScanWsHeader *>(ws);
-    const uint64_t n_tiles = (dev.n_bytes + kTile - 1) / kTile;
     TileArrays t;
-    // 24 B per 16 KiB tile live in the fused kernels' descriptor region; the per-record arrays in the line arrays
+    // 28 B per 32 KiB super-tile live in the fused kernels' descriptor region (24 B per 16 KiB); the per-record arrays in
+    // the line arrays
     unsigned long long *region = reinterpret_cast<unsigned long long *>(ws + l.off_tile_desc);
     uint64_t *base = reinterpret_cast<uint64_t *>(ws + l.off_nl_pos);
     t.rec_start = base;
@@ -1000,40 +688,24 @@ int run_fasta_tiled(const FastaDev &dev, uint8_t *ws, const FastqWsLayout &l, ex
     t.rec_cap = l.lines_cap;
     // records <= lines: the per-record arrays hold lines_cap + 2 entries each (a file with more definition
     // lines than that is reported like a line-index overflow)
-    hipLaunchKernelGGL(k_init_hdr, dim3(1), dim3(1), 0, stream, hdr, l.lines_cap, 0u);
-    static const bool two_pass = getenv("EXG_FASTA_TWO_PASS") != nullptr;
-    if (!two_pass) {
-        // single pass: 28 B per 32 KiB super-tile (the region holds 24 B per 16 KiB)
-        const uint64_t n_super = (dev.n_bytes + kSuper - 1) / kSuper;
-        if (n_super > 0x7FFFFFF0ull) {
-            set_error("exg_fasta_scan: buffer too large for one launch (%llu super-tiles)", (unsigned long long)n_super);
-            return EXG_E_INVALID_ARG;
-        }
-        t.desc = nullptr, t.rec_before = nullptr, t.pay_before = nullptr;
-        t.f_agg = region;
-        t.f_rec = region + n_super;
-        t.f_pay = region + 2 * n_super;
-        t.totals = reinterpret_cast<uint64_t *>(region + 3 * n_super);
-        t.f_nl = reinterpret_cast<unsigned int *>(region + 3 * n_super + 2);
-        EXG_HIP_CHECK(hipMemsetAsync(region, 0, (size_t)(3 * n_super + 2) * 8 + (size_t)n_super * 4, stream));
-        hipLaunchKernelGGL(k_fa_fused, dim3((uint32_t)n_super + 1), dim3(kThreads), 0, stream, dev, t, hdr, (uint32_t)n_super);
-    } else {
-        t.desc = region;
-        t.rec_before = reinterpret_cast<uint64_t *>(region + (n_tiles + 1));
-        t.pay_before = reinterpret_cast<uint64_t *>(region + 2 * (n_tiles + 1));
-        t.totals = reinterpret_cast<uint64_t *>(region + 3 * (n_tiles + 1));
-        t.f_agg = t.f_rec = t.f_pay = nullptr;
-        t.f_nl = nullptr;
-        const uint32_t grid = (uint32_t)(n_tiles < 16384 ? (n_tiles ? n_tiles : 1) : 16384);
-        if (n_tiles) hipLaunchKernelGGL(k_fa_tile_count, dim3(grid), dim3(kThreads), 0, stream, dev, t, hdr, n_tiles);
-        hipLaunchKernelGGL(k_fa_tile_scan, dim3((uint32_t)(n_tiles ? (n_tiles + 4095) / 4096 : 1)), dim3(1024), 0, stream, dev, t, hdr, n_tiles);
-        if (n_tiles) hipLaunchKernelGGL(k_fa_tile_emit, dim3(grid), dim3(kThreads), 0, stream, dev, t, hdr, n_tiles);
+    const uint64_t n_super = (dev.n_bytes + kSuper - 1) / kSuper;
+    if (n_super > 0x7FFFFFF0ull) {
+        set_error("exg_fasta_scan: buffer too large for one launch (%llu super-tiles)", (unsigned long long)n_super);
+        return EXG_E_INVALID_ARG;
     }
+    t.f_agg = region;
+    t.f_rec = region + n_super;
+    t.f_pay = region + 2 * n_super;
+    t.totals = reinterpret_cast<uint64_t *>(region + 3 * n_super);
+    t.f_nl = reinterpret_cast<unsigned int *>(region + 3 * n_super + 2);
+    hipLaunchKernelGGL(k_init_hdr, dim3(1), dim3(1), 0, stream, hdr, l.lines_cap, 0u);
+    EXG_HIP_CHECK(hipMemsetAsync(region, 0, (size_t)(3 * n_super + 2) * 8 + (size_t)n_super * 4, stream));
+    hipLaunchKernelGGL(k_fa_fused, dim3((uint32_t)n_super + 1), dim3(kThreads), 0, stream, dev, t, hdr, (uint32_t)n_super);
     const uint64_t est_rec = dev.n_bytes / 64 + 256;
     const uint32_t sgrid = (uint32_t)((est_rec + 255) / 256 < 4096 ? (est_rec + 255) / 256 : 4096);
-    hipLaunchKernelGGL(k_fa_tile_defs, dim3(sgrid), dim3(256), 0, stream, dev, t, hdr, n_tiles);
-    hipLaunchKernelGGL(k_fa_tile_strings, dim3(sgrid), dim3(256), 0, stream, dev, t, hdr, n_tiles);
-    hipLaunchKernelGGL(k_fa_tile_finalize, dim3(1), dim3(1), 0, stream, dev, t, hdr, n_tiles, d_result);
+    hipLaunchKernelGGL(k_fa_tile_defs, dim3(sgrid), dim3(256), 0, stream, dev, t, hdr);
+    hipLaunchKernelGGL(k_fa_tile_strings, dim3(sgrid), dim3(256), 0, stream, dev, t, hdr);
+    hipLaunchKernelGGL(k_fa_tile_finalize, dim3(1), dim3(1), 0, stream, dev, t, hdr, d_result);
     EXG_HIP_CHECK(hipGetLastError());
     return EXG_OK;
 }
