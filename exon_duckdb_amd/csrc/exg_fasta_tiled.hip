@@ -17,6 +17,8 @@
 // Traffic: 1 read + 1 write of the file (the first tiled form read it twice: a count pass, a scan, an emit pass; the
 // multipass form: ~5 reads + 3 writes of it plus 40 B per line of index).  Algorithmic bytes: file read once + sequence
 // bytes written once.
+#include <stdlib.h>
+
 #include "exg_fasta.hpp"
 
 namespace exg {
@@ -325,7 +327,7 @@ __device__ TileSum fa_span_sum(const FastaDev &a, uint64_t base, uint32_t span, 
 }
 
 // block 0, wave 0: exclusive prefixes of the published aggregates, in order
-__device__ void fa_scanner(const FastaDev &a, const TileArrays &t, ScanWsHeader *hdr, uint32_t n_super, uint32_t lane) {
+__device__ void fa_scanner(const FastaDev &a, const TileArrays &t, ScanWsHeader *hdr, uint32_t n_super, uint32_t help_ticks, uint32_t lane) {
     __builtin_amdgcn_s_setprio(3);
     constexpr int kBatches = 4;
     uint64_t next = 0;
@@ -375,8 +377,8 @@ __device__ void fa_scanner(const FastaDev &a, const TileArrays &t, ScanWsHeader 
         }
         if (progressed) {
             t_last = __builtin_amdgcn_s_memrealtime();
-        } else if (__builtin_amdgcn_s_memrealtime() - t_last > 4000) {
-            // ~40 us without the next aggregate: its block may not have been dispatched yet; progress never depends on that
+        } else if (__builtin_amdgcn_s_memrealtime() - t_last >= help_ticks) {
+            // ~40 us (help_ticks of the 100 MHz clock) without the next aggregate: its block may not have been dispatched yet; progress never depends on that
             const TileSum e = fa_span_sum(a, next * kSuper, kSuper, lane);
             const unsigned long long dd = kFPub | ((unsigned long long)e.has << kFHas) | ((unsigned long long)e.tail << kFTail) | e.defs |
                                           (e.after << kFAfter) | (e.head << kFHead);
@@ -395,14 +397,14 @@ __device__ void fa_scanner(const FastaDev &a, const TileArrays &t, ScanWsHeader 
     }
 }
 
-__global__ __launch_bounds__(kThreads) void k_fa_fused(FastaDev a, TileArrays t, ScanWsHeader *hdr, uint32_t n_super) {
+__global__ __launch_bounds__(kThreads) void k_fa_fused(FastaDev a, TileArrays t, ScanWsHeader *hdr, uint32_t n_super, uint32_t help_ticks) {
     __shared__ __attribute__((aligned(16))) uint32_t s_out_all[kThreads / 64][4096 / 4 + 8];
     __shared__ TileSum s_agg[kThreads / 64];
     __shared__ unsigned long long s_pre_rec, s_pre_pay;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (a scalar: what hangs off it is wave uniform)
     if (blockIdx.x == 0) {  // the scanner: one wave, no tile
-        if (wave == 0) fa_scanner(a, t, hdr, n_super, lane);
+        if (wave == 0) fa_scanner(a, t, hdr, n_super, help_ticks, lane);
         return;
     }
     const uint32_t st_i = blockIdx.x - 1;
@@ -700,7 +702,9 @@ int run_fasta_tiled(const FastaDev &dev, uint8_t *ws, const FastqWsLayout &l, ex
     t.f_nl = reinterpret_cast<unsigned int *>(region + 3 * n_super + 2);
     hipLaunchKernelGGL(k_init_hdr, dim3(1), dim3(1), 0, stream, hdr, l.lines_cap, 0u);
     EXG_HIP_CHECK(hipMemsetAsync(region, 0, (size_t)(3 * n_super + 2) * 8 + (size_t)n_super * 4, stream));
-    hipLaunchKernelGGL(k_fa_fused, dim3((uint32_t)n_super + 1), dim3(kThreads), 0, stream, dev, t, hdr, (uint32_t)n_super);
+    // (EXG_FASTA_HELP_TICKS = 0 makes the scanner compute every aggregate it does not find at once: the tests' way into that path)
+    static const uint32_t help_ticks = getenv("EXG_FASTA_HELP_TICKS") ? (uint32_t)strtoul(getenv("EXG_FASTA_HELP_TICKS"), nullptr, 10) : 4000u;
+    hipLaunchKernelGGL(k_fa_fused, dim3((uint32_t)n_super + 1), dim3(kThreads), 0, stream, dev, t, hdr, (uint32_t)n_super, help_ticks);
     const uint64_t est_rec = dev.n_bytes / 64 + 256;
     const uint32_t sgrid = (uint32_t)((est_rec + 255) / 256 < 4096 ? (est_rec + 255) / 256 : 4096);
     hipLaunchKernelGGL(k_fa_tile_defs, dim3(sgrid), dim3(256), 0, stream, dev, t, hdr);

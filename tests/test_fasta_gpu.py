@@ -257,3 +257,34 @@ def test_large_input_both_forms_agree(gpu, oracle):
     ptr = seq[:, 8:16].copy().view(np.uint64)[:, 0]
     long_rows = exp.columns["sequence"].lengths() > 12
     assert np.array_equal(ptr[long_rows] - SEQ_BASE, exp.columns["sequence"].offsets[:-1][long_rows].astype(np.uint64))
+
+
+def test_scanner_helping_path(gpu, oracle):
+    """k_fa_fused's scanner computes a super-tile's aggregate itself when the super-tile's workgroup has not published it in
+    time (progress must not depend on the dispatch order).  With EXG_FASTA_HELP_TICKS=0 it does so for every aggregate it
+    does not find at once: the output must not change.  (A process of its own: the library reads the variable once.)"""
+    import subprocess
+    import sys
+    code = (
+        "import sys, os\n"
+        "sys.path.insert(0, %r)\n"
+        "import torch\n"
+        "from exon_duckdb_amd import abi, device\n"
+        "n_rec = 40000\n"
+        "d_in, n = device.synth_fasta(n_rec)\n"
+        "outs = []\n"
+        "for algo in (abi.EXG_ALGO_AUTO, abi.EXG_ALGO_MULTIPASS):\n"
+        "    s = device.FastaScan(n, capacity_records=n_rec + 16)\n"
+        "    for rep in range(5 if algo == abi.EXG_ALGO_AUTO else 1):\n"
+        "        s.launch(d_in, algo=algo)\n"
+        "        r = s.fetch()\n"
+        "        assert r.error_code == 0 and r.n_records == n_rec and r.consumed_bytes == n, (r.error_code, r.n_records)\n"
+        "    outs.append((s, r))\n"
+        "(a, ra), (b, rb) = outs\n"
+        "assert ra.payload_bytes == rb.payload_bytes\n"
+        "for k in range(3):\n"
+        "    assert torch.equal(a.cols[k][:n_rec], b.cols[k][:n_rec]), k\n"
+        "assert torch.equal(a.payload[:ra.payload_bytes], b.payload[:rb.payload_bytes])\n"
+        "print('helping ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, EXG_FASTA_HELP_TICKS="0"))
+    assert res.returncode == 0 and "helping ok" in res.stdout, res.stdout[-1000:] + res.stderr[-3000:]
