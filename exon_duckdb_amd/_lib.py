@@ -34,6 +34,13 @@ def load_library(path=None):
     if not os.path.exists(p):
         raise ExgError(abi.EXG_E_NO_DEVICE, f"{p} not found: run `python __graft_entry__.py build` "
                        "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    # PyTorch bundles a HIP runtime of its own; two HIP runtimes in one process do not share the GPU (whichever comes second
+    # sees no device).  Whoever uses this package beside torch (the tests, bench.py, smoke()) therefore gets torch's runtime
+    # loaded first — libexon_gpu.so then binds to the copy that is already there.  Without torch nothing changes.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # noqa: BLE001
+        pass
     l = C.CDLL(p)
     for name, (res, args) in abi.SIGNATURES.items():
         fn = getattr(l, name)
