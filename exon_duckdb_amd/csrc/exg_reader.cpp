@@ -328,7 +328,8 @@ static uint32_t rd_le32(const uint8_t *p) { return p[0] | ((uint32_t)p[1] << 8) 
 // it consumed).  Also returns the members' statuses (st).
 static int check_members(exg_reader *r, const uint8_t *comp, uint64_t n_comp, uint64_t bias, const void *d_out, const exg_inflate_member *d_members,
                          const exg_inflate_status *d_status, const exg_inflate_member *h_members, uint64_t count, bool open_last,
-                         std::vector<exg_inflate_status> &st, const std::string &path, const uint32_t *d_crc_ready = nullptr) {
+                         std::vector<exg_inflate_status> &st, const std::string &path, const uint32_t *d_crc_ready = nullptr,
+                         const uint32_t *h_crc_expect = nullptr) {
     if (!count) return EXG_OK;
     struct Pooled {
         int dev;
@@ -352,6 +353,11 @@ static int check_members(exg_reader *r, const uint8_t *comp, uint64_t n_comp, ui
         const bool open = open_last && i + 1 == count;
         if (st[i].code || (!open && st[i].produced != h_members[i].out_cap))
             return fail(r, EXG_E_PARSE, "corrupt deflate stream (member " + std::to_string(i) + ", code " + std::to_string(st[i].code) + ") in '" + path + "'");
+        if (h_crc_expect && !open) {  // the index walk read the trailer already (ISIZE = out_cap, compared above)
+            if (h_crc_expect[i] != crc[i])
+                return fail(r, EXG_E_PARSE, "corrupt gzip stream does not have a matching checksum (member " + std::to_string(i) + " of '" + path + "')");
+            continue;
+        }
         const uint64_t trailer = bias + h_members[i].comp_off + (open ? st[i].consumed : h_members[i].comp_size - 8);
         if (trailer + 8 > n_comp) return fail(r, EXG_E_PARSE, "truncated gzip member (no trailer) in '" + path + "'");
         if (rd_le32(comp + trailer) != crc[i] || rd_le32(comp + trailer + 4) != (uint32_t)st[i].produced)
@@ -393,47 +399,99 @@ static int check_stream(exg_reader *r, const uint8_t *comp, uint64_t n_comp, uin
 // BGZF input read as shard `shard_index` of `shard_count`: the members are divided among the shards (the index costs a
 // pointer chase, no decode), this reader uploads and inflates only its own members plus ~1 MiB of members in front of
 // them — the halo that holds the beginning of the record that ends behind the cut — and scans them like a text shard.
+// The few bytes the BGZF walk looks at — a member's header, the trailer right in front of the next header — read with pread
+// into a small window, NOT through the file's mapping: a fault on the mapping maps sixteen pages (fault-around), two faults
+// per 18 KB member map the whole file, and unmapping a 5 GB file that had been mapped that way cost 80-120 ms (page-table
+// teardown, TLB shootdowns on a 256-thread host) behind a 300 ms decode; the walk itself was page-fault bound (35-55 ms
+// per 5 GB on eight threads).  fd < 0: the bytes are in memory at `map`.
+struct Peek {
+    const uint8_t *map;
+    int fd;
+    uint64_t n;
+    uint8_t buf[512];
+    uint64_t b0 = ~0ull, b1 = 0;  // buf holds file bytes [b0, b1)
+    Peek(const uint8_t *m, int f, uint64_t size) : map(m), fd(f), n(size) {}
+    // file bytes [off, off + len), len <= 256; nullptr past the end of the file
+    const uint8_t *at(uint64_t off, size_t len) {
+        if (off + len > n) return nullptr;
+        if (fd < 0) return map + off;
+        if (off >= b0 && off + len <= b1) return buf + (off - b0);
+        const size_t want = (size_t)std::min<uint64_t>(sizeof buf, n - off);
+        size_t got = 0;
+        while (got < want) {
+            const ssize_t k = pread(fd, buf + got, want - got, (off_t)(off + got));
+            if (k <= 0) break;
+            got += (size_t)k;
+        }
+        if (got < len) return nullptr;
+        b0 = off, b1 = off + got;
+        return buf;
+    }
+};
+
 // One BGZF member at `pos` (RFC 1952 header with FEXTRA and a 'BC' subfield, as bgzip / htslib write it):
-// fills m (out_off = 0) and returns the offset of the next member, or 0 when this is not such a header.
-static uint64_t bgzf_member_at(const uint8_t *d, uint64_t n, uint64_t pos, exg_inflate_member *m) {
-    if (pos + 18 > n || d[pos] != 0x1f || d[pos + 1] != 0x8b || d[pos + 2] != 8 || d[pos + 3] != 4) return 0;
-    const uint64_t xlen = d[pos + 10] | ((uint64_t)d[pos + 11] << 8);
-    if (pos + 12 + xlen > n) return 0;
+// fills m (out_off = 0), *crc = the trailer's CRC-32, and returns the offset of the next member, or 0 when this is not such
+// a header.
+static uint64_t bgzf_member_at(Peek &f, uint64_t pos, exg_inflate_member *m, uint32_t *crc = nullptr) {
+    const uint8_t *h = f.at(pos, 18);
+    if (!h || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || h[3] != 4) return 0;
+    const uint64_t xlen = h[10] | ((uint64_t)h[11] << 8);
+    if (xlen > 240 || !(h = f.at(pos, 12 + (size_t)xlen))) return 0;  // (bgzip writes 6; anything long is not BGZF to this walk)
     int64_t bsize = -1;
-    for (uint64_t q = pos + 12; q + 4 <= pos + 12 + xlen;) {
-        const uint64_t slen = d[q + 2] | ((uint64_t)d[q + 3] << 8);
-        if (d[q] == 'B' && d[q + 1] == 'C' && slen == 2 && q + 6 <= pos + 12 + xlen) bsize = d[q + 4] | ((int64_t)d[q + 5] << 8);
+    for (uint64_t q = 12; q + 4 <= 12 + xlen;) {
+        const uint64_t slen = h[q + 2] | ((uint64_t)h[q + 3] << 8);
+        if (h[q] == 'B' && h[q + 1] == 'C' && slen == 2 && q + 6 <= 12 + xlen) bsize = h[q + 4] | ((int64_t)h[q + 5] << 8);
         q += 4 + slen;
     }
     if (bsize < 0) return 0;
     const uint64_t end = pos + (uint64_t)bsize + 1, p = pos + 12 + xlen;
-    if (end > n || end < p + 8) return 0;
+    if (end > f.n || end < p + 8) return 0;
+    // the trailer: the window read for it also holds the next member's header
+    const uint8_t *t = f.at(end - 8, 8);
+    if (!t) return 0;
     m->comp_off = p;
     m->comp_size = end - p;
     m->out_off = 0;
-    m->out_cap = d[end - 4] | ((uint64_t)d[end - 3] << 8) | ((uint64_t)d[end - 2] << 16) | ((uint64_t)d[end - 1] << 24);
+    m->out_cap = t[4] | ((uint64_t)t[5] << 8) | ((uint64_t)t[6] << 16) | ((uint64_t)t[7] << 24);
+    if (crc) *crc = t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
     return m->out_cap <= 65536 ? end : 0;
 }
 // first member that starts at or after `from`: a header whose chain holds for four more members (or runs into the
 // end of the file) — the signature alone also occurs inside compressed data
-static uint64_t bgzf_find(const uint8_t *d, uint64_t n, uint64_t from) {
-    for (uint64_t pos = from; pos + 18 <= n; pos++) {
-        if (d[pos] != 0x1f) {
-            const void *hit = memchr(d + pos, 0x1f, (size_t)(n - pos));
-            if (!hit) return n;
-            pos = (uint64_t)((const uint8_t *)hit - d);
+static uint64_t bgzf_find(const uint8_t *d, int fd, uint64_t n, uint64_t from) {
+    Peek f(d, fd, n);
+    uint8_t chunk[4096];
+    for (uint64_t base = from; base + 18 <= n;) {
+        // candidates: 0x1f bytes of the next 4 KiB
+        const size_t len = (size_t)std::min<uint64_t>(sizeof chunk, n - base);
+        const uint8_t *c = d + base;
+        if (fd >= 0) {
+            size_t got = 0;
+            while (got < len) {
+                const ssize_t k = pread(fd, chunk + got, len - got, (off_t)(base + got));
+                if (k <= 0) return n;
+                got += (size_t)k;
+            }
+            c = chunk;
+        }
+        for (size_t i = 0; i < len;) {
+            const void *hit = memchr(c + i, 0x1f, len - i);
+            if (!hit) break;
+            const uint64_t pos = base + (uint64_t)((const uint8_t *)hit - c);
             if (pos + 18 > n) return n;
+            exg_inflate_member m;
+            uint64_t q = pos;
+            int hops = 0;
+            while (hops < 5 && q < n) {
+                const uint64_t nx = bgzf_member_at(f, q, &m);
+                if (!nx) break;
+                q = nx;
+                hops++;
+            }
+            if (hops == 5 || (hops > 0 && q == n)) return pos;
+            i = (size_t)(pos - base) + 1;
         }
-        exg_inflate_member m;
-        uint64_t q = pos;
-        int hops = 0;
-        while (hops < 5 && q < n) {
-            const uint64_t nx = bgzf_member_at(d, n, q, &m);
-            if (!nx) break;
-            q = nx;
-            hops++;
-        }
-        if (hops == 5 || (hops > 0 && q == n)) return pos;
+        base += len;
     }
     return n;
 }
@@ -442,35 +500,46 @@ static uint64_t bgzf_find(const uint8_t *d, uint64_t n, uint64_t from) {
 // 110-150 ms per 10 GB: ~190 ns of cache misses per member): every thread finds a header near its cut, then walks to
 // the next thread's start.  false: not (only) BGZF, or a walk did not land on its neighbour's start — the caller falls
 // back to the serial RFC 1952 index.
-static bool bgzf_parallel_index(const uint8_t *d, uint64_t n, exg_inflate_member *members, uint64_t cap, uint64_t *k_out,
-                                uint64_t *total_out) {
+static bool bgzf_parallel_index(const uint8_t *d, int fd, uint64_t n, exg_inflate_member *members, uint64_t cap, uint64_t *k_out,
+                                uint64_t *total_out, std::vector<uint32_t> *crc_out) {
     exg_inflate_member probe;
-    if (!n || !bgzf_member_at(d, n, 0, &probe)) return false;
-    const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(8, n >> 24));  // 16 MiB per thread at least
+    {
+        Peek f(d, fd, n);
+        if (!n || !bgzf_member_at(f, 0, &probe)) return false;
+    }
+    // (a pread per member, ~5 us each here: the walk scales with its threads until the cores run out)
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min(32u, hw), n >> 24));  // 16 MiB per thread at least
     std::vector<uint64_t> starts(T + 1, n);
     starts[0] = 0;
     {
         std::vector<std::thread> th;
         for (unsigned t = 1; t < T; t++)
-            th.emplace_back([&, t] { starts[t] = bgzf_find(d, n, (uint64_t)((unsigned __int128)n * t / T)); });
+            th.emplace_back([&, t] { starts[t] = bgzf_find(d, fd, n, (uint64_t)((unsigned __int128)n * t / T)); });
         for (auto &x : th) x.join();
     }
     for (unsigned t = 1; t <= T; t++)
         if (starts[t] < starts[t - 1]) return false;
     std::vector<std::vector<exg_inflate_member>> parts(T);
+    std::vector<std::vector<uint32_t>> crcs(T);
     std::vector<int> ok(T, 0);
     {
         std::vector<std::thread> th;
         for (unsigned t = 0; t < T; t++)
             th.emplace_back([&, t] {
+                Peek f(d, fd, n);
                 uint64_t pos = starts[t];
                 auto &v = parts[t];
+                auto &cv = crcs[t];
                 v.reserve((size_t)((starts[t + 1] - starts[t]) / 8192 + 64));
+                cv.reserve(v.capacity());
                 while (pos < starts[t + 1]) {
                     exg_inflate_member m;
-                    const uint64_t nx = bgzf_member_at(d, n, pos, &m);
+                    uint32_t crc = 0;
+                    const uint64_t nx = bgzf_member_at(f, pos, &m, &crc);
                     if (!nx) return;
                     v.push_back(m);
+                    cv.push_back(crc);
                     pos = nx;
                 }
                 ok[t] = pos == starts[t + 1];
@@ -478,6 +547,7 @@ static bool bgzf_parallel_index(const uint8_t *d, uint64_t n, exg_inflate_member
         for (auto &x : th) x.join();
     }
     uint64_t k = 0, out = 0;
+    if (crc_out) crc_out->clear();
     for (unsigned t = 0; t < T; t++) {
         if (!ok[t] || k + parts[t].size() > cap) return false;
         for (auto &m : parts[t]) {
@@ -485,6 +555,7 @@ static bool bgzf_parallel_index(const uint8_t *d, uint64_t n, exg_inflate_member
             out += m.out_cap;
             members[k++] = m;
         }
+        if (crc_out) crc_out->insert(crc_out->end(), crcs[t].begin(), crcs[t].end());
     }
     *k_out = k;
     *total_out = out;
@@ -499,9 +570,11 @@ static bool bgzf_parallel_index(const uint8_t *d, uint64_t n, exg_inflate_member
 static int inflate_file_shard(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::string &path) {
     const uint8_t *comp = (const uint8_t *)blk->p;
     const uint64_t n = blk->n;
+    const int fd = r->fd_keep ? r->fd_keep->fd : -1;
+    Peek peek(comp, fd, n);
     {
         exg_inflate_member probe;
-        if (!bgzf_member_at(comp, n, 0, &probe))
+        if (!bgzf_member_at(peek, 0, &probe))
             return fail(r, EXG_E_UNSUPPORTED, "shards of a gzip input need BGZF framing (every member carries its size): '" + path + "'");
     }
     const uint64_t lo = (uint64_t)((unsigned __int128)n * r->shard_index / r->shard_count);
@@ -517,7 +590,7 @@ static int inflate_file_shard(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, 
             uint64_t q = 0, out = 0;
             while (q < n && hm.size() < want) {
                 exg_inflate_member m;
-                const uint64_t nx = bgzf_member_at(comp, n, q, &m);
+                const uint64_t nx = bgzf_member_at(peek, q, &m);
                 if (!nx) return fail(r, EXG_E_PARSE, "not a BGZF member at byte " + std::to_string(q) + " of '" + path + "'");
                 m.out_off = out;
                 out += m.out_cap;
@@ -569,12 +642,12 @@ static int inflate_file_shard(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, 
     std::vector<exg_inflate_member> mem;
     std::vector<uint64_t> hdr;  // where each member's gzip header begins
     const uint64_t back = kShardHaloBytes + (kShardHaloBytes >> 1);
-    uint64_t pos = lo == 0 ? 0 : bgzf_find(comp, n, lo > back ? lo - back : 0);
+    uint64_t pos = lo == 0 ? 0 : bgzf_find(comp, fd, n, lo > back ? lo - back : 0);
     uint64_t m0 = 0;  // index in `mem` of the first own member
     bool seen_own = false;
     while (pos < hi && pos < n) {
         exg_inflate_member m;
-        const uint64_t nx = bgzf_member_at(comp, n, pos, &m);
+        const uint64_t nx = bgzf_member_at(peek, pos, &m);
         if (!nx) return fail(r, EXG_E_PARSE, "not a BGZF member at byte " + std::to_string(pos) + " of '" + path + "'");
         if (!seen_own && pos >= lo) {
             seen_own = true;
@@ -591,7 +664,7 @@ static int inflate_file_shard(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, 
     bool bytes_follow = false;
     for (uint64_t q = pos; q < n && !bytes_follow;) {
         exg_inflate_member m;
-        const uint64_t nx = bgzf_member_at(comp, n, q, &m);
+        const uint64_t nx = bgzf_member_at(peek, q, &m);
         if (!nx) return fail(r, EXG_E_PARSE, "not a BGZF member at byte " + std::to_string(q) + " of '" + path + "'");
         bytes_follow = m.out_cap != 0;
         q = nx;
@@ -606,7 +679,7 @@ static int inflate_file_shard(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, 
         std::vector<uint64_t> front_hdr;
         for (uint64_t q = 0; q < hdr[h0];) {
             exg_inflate_member m;
-            const uint64_t nx = bgzf_member_at(comp, n, q, &m);
+            const uint64_t nx = bgzf_member_at(peek, q, &m);
             if (!nx) return fail(r, EXG_E_PARSE, "not a BGZF member at byte " + std::to_string(q) + " of '" + path + "'");
             front.push_back(m);
             front_hdr.push_back(q);
@@ -722,10 +795,12 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
         int open_ended = 0, rc = 0;
         std::string err;
         double ms = 0;
+        std::vector<uint32_t> crc;  // BGZF walk: the members' trailer checksums (their ISIZE is out_cap)
     } first;
     std::thread index_thread([&] {
         double t0 = now_s();
-        if (!bgzf_parallel_index(comp, n, members.get(), members_cap, &first.k, &first.total)) {
+        if (!bgzf_parallel_index(comp, r->fd_keep ? r->fd_keep->fd : -1, n, members.get(), members_cap, &first.k, &first.total, &first.crc)) {
+            first.crc.clear();
             first.k = first.total = 0;
             first.rc = exg_gzip_index(comp, n, 0, members.get(), members_cap, &first.k, &first.total, &first.open_ended);
             if (first.rc) first.err = exg_last_error_message();  // the message is thread-local
@@ -819,7 +894,7 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
         if (i0 < k) return fail(r, EXG_E_PARSE, "truncated gzip member in '" + path + "'");
         std::vector<exg_inflate_status> st;
         int crc_rc = check_members(r, comp, n, 0, d_out, (const exg_inflate_member *)d_members, (const exg_inflate_status *)d_status, members.get(), k,
-                                   false, st, path, (const uint32_t *)d_crc_all);
+                                   false, st, path, (const uint32_t *)d_crc_all, first.crc.size() == k ? first.crc.data() : nullptr);
         TRACE("gz: h2d + inflate + crc32", t_h2d);
         if (crc_rc) return crc_rc;
         produced_total = out_cap_total = first.total;
