@@ -339,7 +339,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--launches-per-step", type=int, default=20, help="scan launches per step (keeps the timed region above 1 s)")
+    ap.add_argument("--launches-per-step", type=int, default=24, help="scan launches per step (keeps the timed region above 1 s: 20 steps x 24 x 2.3 ms)")
     ap.add_argument("--gb", type=float, default=None, help="shard size per GPU in GB (1e9 bytes); default 10 (N=1), 12.5 (N>1: N=8 is 100 GB)")
     ap.add_argument("--algo", type=int, default=2, help="2 = the fused scan alone, which is what the reader launches per batch (it re-runs the "
                     "general path only when a launch reports EXG_RF_FALLBACK; asserted clear here); 0 = fused + the gated general-path launches")
