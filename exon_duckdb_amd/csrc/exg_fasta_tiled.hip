@@ -583,28 +583,36 @@ __global__ __launch_bounds__(256) void k_fa_tile_defs(FastaDev a, TileArrays t, 
         const uint64_t s = t.rec_def_off[r];
         const uint32_t avail = a.n_bytes - s < kDefStage ? (uint32_t)(a.n_bytes - s) : kDefStage;
         typedef uint32_t v4u_u __attribute__((ext_vector_type(4), aligned(1)));
-        v4u_u q[kDefStage / 16];
-#pragma unroll
-        for (uint32_t k = 0; k < kDefStage / 16; k++) {
-            q[k] = (v4u_u){0, 0, 0, 0};
-            if (16 * k + 16 <= avail) {
-                q[k] = *reinterpret_cast<const v4u_u *>(a.d_in + s + 16 * k);
-            } else if (16 * k < avail) {  // the input's last bytes
-                uint32_t w[4] = {0, 0, 0, 0};
-                for (uint32_t j = 16 * k; j < avail; j++) w[(j & 15) >> 2] |= (uint32_t)a.d_in[s + j] << (8 * (j & 3));
-                q[k] = (v4u_u){w[0], w[1], w[2], w[3]};
-            }
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < kDefStage / 16; k++) {
-            slot[4 * k] = q[k].x;
-            slot[4 * k + 1] = q[k].y;
-            slot[4 * k + 2] = q[k].z;
-            slot[4 * k + 3] = q[k].w;
-        }
         const uint8_t *line = reinterpret_cast<const uint8_t *>(slot);
         uint32_t len = 0;
-        while (len < avail && line[len] != '\n') len++;
+        // 64 bytes first (most definition lines end there: half the lines fetched), the other 64 only when they do not
+        for (uint32_t half = 0; half < 2; half++) {
+            const uint32_t k0 = half * (kDefStage / 32);
+            if (16 * k0 >= avail) break;
+            v4u_u q[kDefStage / 32];
+#pragma unroll
+            for (uint32_t k = 0; k < kDefStage / 32; k++) {
+                const uint32_t kk = k0 + k;
+                q[k] = (v4u_u){0, 0, 0, 0};
+                if (16 * kk + 16 <= avail) {
+                    q[k] = *reinterpret_cast<const v4u_u *>(a.d_in + s + 16 * kk);
+                } else if (16 * kk < avail) {  // the input's last bytes
+                    uint32_t w[4] = {0, 0, 0, 0};
+                    for (uint32_t j = 16 * kk; j < avail; j++) w[(j & 15) >> 2] |= (uint32_t)a.d_in[s + j] << (8 * (j & 3));
+                    q[k] = (v4u_u){w[0], w[1], w[2], w[3]};
+                }
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < kDefStage / 32; k++) {
+                slot[4 * (k0 + k)] = q[k].x;
+                slot[4 * (k0 + k) + 1] = q[k].y;
+                slot[4 * (k0 + k) + 2] = q[k].z;
+                slot[4 * (k0 + k) + 3] = q[k].w;
+            }
+            const uint32_t upto = avail < (half + 1) * (kDefStage / 2) ? avail : (half + 1) * (kDefStage / 2);
+            while (len < upto && line[len] != '\n') len++;
+            if (len < upto) break;  // the newline is in
+        }
         if (len < avail || s + avail == a.n_bytes) {
             emit_definition(a, hdr, r, s, line - s, s + len);  // the whole line is in the copy
         } else {
