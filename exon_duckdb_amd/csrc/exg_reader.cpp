@@ -500,22 +500,25 @@ static uint64_t bgzf_find(const uint8_t *d, int fd, uint64_t n, uint64_t from) {
 // 110-150 ms per 10 GB: ~190 ns of cache misses per member): every thread finds a header near its cut, then walks to
 // the next thread's start.  false: not (only) BGZF, or a walk did not land on its neighbour's start — the caller falls
 // back to the serial RFC 1952 index.
+// upto < n: only the members whose header begins in front of the first member that starts at or behind `upto` (the head of
+// the file, for a decode that starts before the whole index is there).
 static bool bgzf_parallel_index(const uint8_t *d, int fd, uint64_t n, exg_inflate_member *members, uint64_t cap, uint64_t *k_out,
-                                uint64_t *total_out, std::vector<uint32_t> *crc_out) {
+                                uint64_t *total_out, std::vector<uint32_t> *crc_out, uint64_t upto = ~0ull) {
     exg_inflate_member probe;
     {
         Peek f(d, fd, n);
         if (!n || !bgzf_member_at(f, 0, &probe)) return false;
     }
+    const uint64_t limit = upto >= n ? n : bgzf_find(d, fd, n, upto);
     // (a pread per member, ~5 us each here: the walk scales with its threads until the cores run out)
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min(32u, hw), n >> 24));  // 16 MiB per thread at least
-    std::vector<uint64_t> starts(T + 1, n);
+    const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min(32u, hw), limit >> 24));  // 16 MiB per thread at least
+    std::vector<uint64_t> starts(T + 1, limit);
     starts[0] = 0;
     {
         std::vector<std::thread> th;
         for (unsigned t = 1; t < T; t++)
-            th.emplace_back([&, t] { starts[t] = bgzf_find(d, fd, n, (uint64_t)((unsigned __int128)n * t / T)); });
+            th.emplace_back([&, t] { starts[t] = std::min(limit, bgzf_find(d, fd, n, (uint64_t)((unsigned __int128)limit * t / T))); });
         for (auto &x : th) x.join();
     }
     for (unsigned t = 1; t <= T; t++)
@@ -842,8 +845,6 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
         prog.finished = true;
         prog.cv.notify_all();
     });
-    index_thread.join();
-    if (trace_on()) fprintf(stderr, "[exg] %-22s %.1f ms (beside the upload)\n", "gz: member index", first.ms);
     uint64_t out_cap_total = 0, produced_total = 0;
     void *d_out = nullptr;
     uint64_t d_out_cap = 0;
@@ -854,14 +855,95 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
         uint64_t *cap;
         ~OutGuard() { if (*p) exg_rd::dev_pool()->give(dev, *p, (size_t)*cap); }
     } out_guard{r->device, &d_out, &d_out_cap};
+    // A big file's index takes ~30 ms (a pread per member) and its first window is on the device after 5: the members of
+    // that window are indexed on their own (1-2 ms), the output buffer is sized from their ratio (+ 25 %), and they are
+    // inflated while the full index is still being made.  Should the file turn out larger than the estimate, what has been
+    // inflated moves into a buffer of the right size (a device copy of one window's output).
+    struct Head {
+        std::vector<exg_inflate_member> m;
+        uint64_t k = 0, total = 0, launched = 0;
+        void *d_m = nullptr, *d_s = nullptr, *d_c = nullptr;
+        ~Head() {
+            if (d_m) (void)hipFree(d_m);
+            if (d_s) (void)hipFree(d_s);
+            if (d_c) (void)hipFree(d_c);
+        }
+    } head;
+    static const bool no_pipeline = getenv("EXG_NO_GZ_PIPELINE") != nullptr;
+    if (!no_pipeline && n > 2 * (uint64_t)kUploadWindow) {
+        // (the full index of a 5 GB file takes ~33 ms here, the upload moves a window in ~5: three windows keep the device busy
+        // until the index is there)
+        const uint64_t head_windows = std::min<uint64_t>(3, n / kUploadWindow - 1), head_bytes = head_windows * kUploadWindow;
+        head.m.resize(head_bytes / 1024 + 64);  // (a member per KiB: anything denser is left to the full index)
+        if (bgzf_parallel_index(comp, r->fd_keep ? r->fd_keep->fd : -1, n, head.m.data(), head.m.size(), &head.k, &head.total, nullptr, head_bytes) &&
+            head.k) {
+            const exg_inflate_member &last = head.m[head.k - 1];
+            const uint64_t comp_bytes = last.comp_off + last.comp_size;
+            // (EXG_GZ_HEAD_EST_PCT: the tests' way into the "estimate was short" path)
+            static const double est_scale = getenv("EXG_GZ_HEAD_EST_PCT") ? atof(getenv("EXG_GZ_HEAD_EST_PCT")) / 100.0 : 1.25;
+            const double est = (double)head.total / (double)comp_bytes * (double)n * est_scale + (est_scale >= 1.0 ? (double)(64u << 20) : 0.0);
+            d_out_cap = std::max<uint64_t>((uint64_t)est, head.total) + 64;  // (what the head itself produces always fits)
+            d_out = exg_rd::dev_pool()->take(r->device, d_out_cap);
+            if (d_out && hipMalloc(&head.d_m, head.k * sizeof(exg_inflate_member)) == hipSuccess &&
+                hipMalloc(&head.d_s, head.k * sizeof(exg_inflate_status)) == hipSuccess && hipMalloc(&head.d_c, head.k * 4 + 64) == hipSuccess) {
+                RD_HIP(r, hipMemcpyAsync(head.d_m, head.m.data(), head.k * sizeof(exg_inflate_member), hipMemcpyHostToDevice, r->stream));
+                for (uint64_t w = 0; w < head_windows && prog.wait_for((size_t)w); w++) {
+                    RD_HIP(r, hipStreamWaitEvent(r->stream, prog.done[w], 0));
+                    const uint64_t ready = std::min<uint64_t>(n, (w + 1) * kUploadWindow);
+                    uint64_t q = head.launched;
+                    while (q < head.k && head.m[q].comp_off + head.m[q].comp_size <= ready) q++;
+                    if (q > head.launched) {
+                        const uint64_t q0 = head.launched;
+                        int rc = exg_inflate_members(d_comp, d_out, (const exg_inflate_member *)head.d_m + q0, (exg_inflate_status *)head.d_s + q0,
+                                                     (uint32_t)(q - q0), r->stream);
+                        if (!rc)
+                            rc = exg_crc32_members(d_out, (const exg_inflate_member *)head.d_m + q0, (const exg_inflate_status *)head.d_s + q0,
+                                                   (uint32_t)(q - q0), (uint32_t *)head.d_c + q0, r->stream);
+                        if (rc) return fail(r, rc, exg_last_error_message());
+                        head.launched = q;
+                    }
+                }
+            }
+        }
+    }
+    index_thread.join();
+    if (trace_on()) fprintf(stderr, "[exg] %-22s %.1f ms (beside the upload)\n", "gz: member index", first.ms);
     uint64_t start = 0;
-    if (!first.rc && first.k && !first.open_ended && !getenv("EXG_NO_GZ_PIPELINE")) {
+    const bool pipeline = !first.rc && first.k && !first.open_ended && !no_pipeline;
+    if (head.launched) {
+        // does the head agree with the full index?  (it must: the same walk over the same bytes)
+        bool same = pipeline && head.launched <= first.k;
+        for (uint64_t i = 0; same && i < head.launched; i++)
+            same = members[i].comp_off == head.m[i].comp_off && members[i].comp_size == head.m[i].comp_size && members[i].out_off == head.m[i].out_off &&
+                   members[i].out_cap == head.m[i].out_cap;
+        if (!same) {
+            RD_HIP(r, hipStreamSynchronize(r->stream));
+            head.launched = 0;
+        }
+    }
+    if (!pipeline && d_out) {  // not (only) BGZF after all: the general path allocates for itself
+        RD_HIP(r, hipStreamSynchronize(r->stream));
+        exg_rd::dev_pool()->give(r->device, d_out, (size_t)d_out_cap);
+        d_out = nullptr, d_out_cap = 0;
+    }
+    if (pipeline) {
         // BGZF: every member's place is known — the members of a window are inflated as soon as the window has arrived,
         // while the next windows are still on their way
         const uint64_t k = first.k;
-        d_out_cap = first.total + 64;
-        d_out = exg_rd::dev_pool()->take(r->device, d_out_cap);
-        if (!d_out) return fail(r, EXG_E_HIP, "out of device memory for the inflated file");
+        if (!d_out || first.total + 64 > d_out_cap) {
+            const uint64_t cap2 = first.total + 64;
+            void *p2 = exg_rd::dev_pool()->take(r->device, cap2);
+            if (!p2) return fail(r, EXG_E_HIP, "out of device memory for the inflated file");
+            if (d_out) {
+                if (head.launched) {
+                    const exg_inflate_member &lm = members[head.launched - 1];
+                    RD_HIP(r, hipMemcpyAsync(p2, d_out, lm.out_off + lm.out_cap, hipMemcpyDeviceToDevice, r->stream));
+                }
+                RD_HIP(r, hipStreamSynchronize(r->stream));  // (the estimate was short: rare, and the old buffer leaves now)
+                exg_rd::dev_pool()->give(r->device, d_out, (size_t)d_out_cap);
+            }
+            d_out = p2, d_out_cap = cap2;
+        }
         void *d_members = nullptr, *d_status = nullptr;
         RD_HIP(r, hipMalloc(&d_members, k * sizeof(exg_inflate_member)));
         Free fm{d_members};
@@ -871,7 +953,11 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
         void *d_crc_all = nullptr;
         RD_HIP(r, hipMalloc(&d_crc_all, k * 4 + 64));
         Free fc{d_crc_all};
-        uint64_t i0 = 0;
+        uint64_t i0 = head.launched;
+        if (i0) {  // the head's statuses and checksums take their places in the tables of the whole file
+            RD_HIP(r, hipMemcpyAsync(d_status, head.d_s, i0 * sizeof(exg_inflate_status), hipMemcpyDeviceToDevice, r->stream));
+            RD_HIP(r, hipMemcpyAsync(d_crc_all, head.d_c, i0 * 4, hipMemcpyDeviceToDevice, r->stream));
+        }
         for (size_t w = 0; w < prog.done.size(); w++) {
             if (!prog.wait_for(w)) break;  // the upload failed: its error is reported below
             RD_HIP(r, hipStreamWaitEvent(r->stream, prog.done[w], 0));
