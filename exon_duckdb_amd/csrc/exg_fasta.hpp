@@ -1,5 +1,5 @@
 // exg_fasta.hpp — what the two FASTA implementations (exg_fasta.hip: multipass over a line index;
-// exg_fasta_tiled.hip: two passes over 16 KiB tiles) share.
+// exg_fasta_tiled.hip: one pass over 32 KiB super-tiles) share.
 #pragma once
 #include "exg_fastq_ws.hpp"
 
@@ -45,7 +45,7 @@ __device__ inline int ws_len_bwd(const uint8_t *p, uint64_t s, uint64_t e) {
 
 #endif
 
-// two passes over 16 KiB tiles (exg_fasta_tiled.hip); the multipass form stays as its differential partner
+// one pass over 32 KiB super-tiles (exg_fasta_tiled.hip); the multipass form stays as its differential partner
 int run_fasta_tiled(const FastaDev &dev, uint8_t *ws, const FastqWsLayout &l, exg_scan_result *d_result, hipStream_t stream);
 
 }  // namespace exg

@@ -283,7 +283,7 @@ __device__ __forceinline__ void lds_store_kept(uint8_t *dst, const uint4 v, uint
 // ---- the scan ---------------------------------------------------------------------------------------------------------------------
 // (The first tiled form was a count pass, a one-workgroup scan and an emit pass: every row classified twice, the input read
 // twice, 0.80 ms per GB.)  k_fa_fused does it in one visit: a workgroup owns a 32 KiB super-tile, a wave 8 KiB of it (eight 1 KiB rows, loaded once
-// and kept in registers); the wave walks its rows as the count pass does and keeps, per row and lane, the two possible
+// and kept in registers); the wave walks its rows, carrying the line state, and keeps, per row and lane, the two possible
 // sequence-byte masks (the wave begins outside / inside a definition line) and the definition mask; the workgroup's
 // aggregate — the monoid above — is published, ONE scanner wave (block 0) turns the published aggregates into
 // exclusive prefixes in order (the line state of 64 super-tiles by two ballots, the sums by DPP scans), and the waves emit
@@ -565,9 +565,10 @@ __global__ __launch_bounds__(kThreads) void k_fa_fused(FastaDev a, TileArrays t,
     }
 }
 
-// id / description of every record, a thread per record.  The thread first copies the line's first 128 bytes into LDS — eight
-// independent 16-byte loads, one round trip — and parses the copy; only a longer definition line is walked in HBM (a chain
-// of dependent loads, ~15 us: inside the emit pass it stalled a whole wavefront for the one lane that owned a '>').
+// id / description of every record, a thread per record.  The thread copies the head of the line into LDS — 64 bytes (four
+// independent 16-byte loads, one round trip), the next 64 only if the newline is not among them — and parses the copy; only a
+// longer definition line is walked in HBM (a chain of dependent loads, ~15 us: inside the scan it would stall a whole
+// wavefront for the one lane that owns a '>').
 static constexpr uint32_t kDefStage = 128, kDefStride = kDefStage / 4 + 1;  // dwords per thread: the odd stride spreads the banks
 __global__ __launch_bounds__(256) void k_fa_tile_defs(FastaDev a, TileArrays t, ScanWsHeader *hdr) {
     __shared__ uint32_t s_line[256 * kDefStride];

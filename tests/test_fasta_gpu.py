@@ -17,7 +17,7 @@ BASE = 0x7D0000000000
 SEQ_BASE = 0x7C0000000000
 
 
-# both device implementations: EXG_ALGO_AUTO = two passes over tiles, EXG_ALGO_MULTIPASS = line index
+# both device implementations: EXG_ALGO_AUTO = one pass over super-tiles (k_fa_fused), EXG_ALGO_MULTIPASS = line index
 ALGOS = [abi.EXG_ALGO_AUTO, abi.EXG_ALGO_MULTIPASS]
 
 
