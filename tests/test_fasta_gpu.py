@@ -167,7 +167,8 @@ def test_shards_are_refused(gpu, oracle):
         scan.launch(d_in, flags=abi.EXG_F_BOF)          # not at EOF: a record could be cut
 
 
-# ---- features placed exactly on the boundaries of the tiled implementation (16 B chunks, 1 KiB rows, 16 KiB tiles) ----
+# ---- features placed exactly on the boundaries of the tiled implementation (16 B chunks, 1 KiB rows, 8 KiB wave spans,
+# ---- 32 KiB super-tiles = workgroups; 16 KiB was the first form's tile) ----
 
 def _pad_to(buf: bytearray, target: int, line=60):
     """append sequence lines until len(buf) == target (the last line is cut to fit, still newline-terminated)"""
@@ -182,7 +183,7 @@ def _pad_to(buf: bytearray, target: int, line=60):
     return buf
 
 
-@pytest.mark.parametrize("boundary", [16, 1024, 4096, 16384, 32768])
+@pytest.mark.parametrize("boundary", [16, 1024, 4096, 8192, 16384, 24576, 32768, 65536, 98304])
 @pytest.mark.parametrize("shift", [-2, -1, 0, 1])
 def test_features_on_tile_boundaries(gpu, oracle, boundary, shift):
     # a definition line whose '>' sits at boundary + shift: the newline in front of it, the '>' and the line body
@@ -210,12 +211,38 @@ def test_tiles_without_a_newline(gpu, oracle):
 
 
 def test_cr_and_lf_split_by_boundaries(gpu, oracle):
-    for boundary in (64, 1024, 16384, 32768):
+    for boundary in (64, 1024, 8192, 16384, 32768, 65536):
         buf = bytearray(b">r\n")
         _pad_to(buf, boundary - 20)
         buf += b"ACGTACGTACGTACGTACG\r\nACGT\r\n>x\r\nAA\r"      # "\r" is the last byte of the chunk / row / tile, "\n" the first of the next
         assert buf[boundary - 1:boundary + 1] == b"\r\n"
         check(oracle, bytes(buf))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_multi_super_tile_fuzz(gpu, oracle, seed):
+    """100-400 KB inputs (several super-tiles, so the scanner's prefixes, the line state across workgroups and the waves'
+    own prefixes all matter) with line lengths from 1 to 20 000, CRLF, empty lines, definition lines of any length, and a
+    few byte-level mutations: both device forms against the oracle."""
+    rng = np.random.default_rng(7000 + seed)
+    parts = []
+    total = 0
+    target = int(rng.integers(100_000, 400_000))
+    while total < target:
+        kind = rng.integers(0, 10)
+        if kind < 2:
+            ln = b">" + bytes(rng.choice(np.frombuffer(b"abcXYZ09 _\t", np.uint8), int(rng.integers(1, 300 if kind else 40_000))))
+        else:
+            width = int(rng.choice([1, 2, 15, 16, 17, 60, 61, 70, 80, 1023, 1024, 1025, 8191, 8192, 20_000]))
+            ln = bytes(rng.choice(np.frombuffer(b"ACGTN", np.uint8), int(rng.integers(0, width + 1))))
+        ln += b"\r\n" if rng.integers(0, 8) == 0 else b"\n"
+        parts.append(ln)
+        total += len(ln)
+    data = b">first record\n" + b"".join(parts)
+    check(oracle, data)
+    import test_fuzz_gpu as FZ
+    for _ in range(3):
+        check(oracle, FZ.mutate(data, rng, int(rng.integers(1, 5))))
 
 
 def test_large_input_both_forms_agree(gpu, oracle):
