@@ -259,6 +259,65 @@ def test_short_decimal_qual_and_pos_fast_paths_are_exact(gpu, oracle):
         assert res.error_code != 0
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_random_number_fields(gpu, oracle, seed):
+    """POS and QUAL literals of random shape — the register fast paths (one 12-byte read, <= 9 digits / the usual decimal),
+    their limits, and everything that falls through to the general parsers — in lines of random neighbours so that the wave's
+    longest literal, the lanes' activity and the 12-byte reads past short fields all vary: bit-exact against the oracle,
+    valid files and (one bad literal at a random row) failing ones."""
+    rng = np.random.default_rng(9000 + seed)
+
+    def digits(n, lead_zero=False):
+        d = "".join(str(int(x)) for x in rng.integers(0, 10, n))
+        return d if lead_zero or n == 0 else (str(int(rng.integers(1, 10))) + d[1:])
+
+    def pos():
+        k = rng.integers(0, 10)
+        if k < 6:
+            p = digits(int(rng.integers(1, 10)), lead_zero=bool(rng.integers(0, 2)))
+        elif k < 8:
+            p = digits(int(rng.integers(10, 19)))
+        else:
+            p = "0" * int(rng.integers(1, 12)) + digits(int(rng.integers(1, 8)))
+        return ("+" if rng.integers(0, 6) == 0 else "") + p
+
+    def qual():
+        k = rng.integers(0, 12)
+        if k == 0:
+            return "."
+        sign = ["", "", "", "+"][int(rng.integers(0, 4))]
+        ip, fp = digits(int(rng.integers(0, 8)), True), digits(int(rng.integers(0, 8)), True)
+        if k < 7:
+            body = (ip or "0") + ("." + fp if rng.integers(0, 3) else "")
+        elif k < 9:
+            body = (ip + "." + fp) if (ip or fp) else "0."
+        elif k == 9:
+            body = digits(int(rng.integers(1, 4)), True) + "." + digits(int(rng.integers(1, 4)), True) + "e" + ["", "-", "+"][int(rng.integers(0, 3))] + str(int(rng.integers(0, 40)))
+        elif k == 10:
+            body = digits(int(rng.integers(8, 30))) + "." + digits(int(rng.integers(0, 30)), True)
+        else:
+            body = ["inf", "Infinity", "nan", "NaN", "0", "00", "1e0", "12345678", "0.000001"][int(rng.integers(0, 9))]
+        return sign + body
+
+    rows = [b"%d\t%s\t.\tA\tC\t%s\tPASS\tDP=%d\n" % (1 + i % 22, pos().encode(), qual().encode(), int(rng.integers(0, 1000)))
+            for i in range(3000)]
+    data = HDR + b"".join(rows)
+    for algo in (abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS):
+        res = check(oracle, data, algo)
+        assert res.error_code == 0 and res.n_records == len(rows)
+    bad_lits = [b"12a4", b"1..2", b"--1", b"1e", b"e5", b"+", b"1 2", b"0x10", b"-5", b"-inf"]
+    for _ in range(4):
+        r = int(rng.integers(0, len(rows)))
+        bad = bad_lits[int(rng.integers(0, len(bad_lits)))]
+        field = 1 if (rng.integers(0, 2) and not bad.startswith(b"-")) else 5
+        cols = rows[r].split(b"\t")
+        cols[field] = bad
+        broken = HDR + b"".join(rows[:r]) + b"\t".join(cols) + b"".join(rows[r + 1:])
+        for algo in (abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS):
+            res = check(oracle, broken, algo)
+            assert res.error_code != 0 and res.error_record == r, (bad, field)
+
+
 @pytest.mark.parametrize("algo", [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS])
 def test_projection_and_capacity(gpu, oracle, algo):
     from exon_duckdb_amd import device
