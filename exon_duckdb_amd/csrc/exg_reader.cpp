@@ -958,23 +958,51 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
             RD_HIP(r, hipMemcpyAsync(d_status, head.d_s, i0 * sizeof(exg_inflate_status), hipMemcpyDeviceToDevice, r->stream));
             RD_HIP(r, hipMemcpyAsync(d_crc_all, head.d_c, i0 * 4, hipMemcpyDeviceToDevice, r->stream));
         }
+        // A window holds ~3 900 members and the device holds 5 120 wavefronts: one launch does not fill it, and on ONE stream
+        // the next window's launch waits for the stragglers of this one.  The windows therefore go round three streams
+        // (the members are independent of each other); the reader's own stream waits for the other two at the end.
+        struct Side {
+            int dev;
+            hipStream_t s[2] = {nullptr, nullptr};
+            hipEvent_t tables = nullptr, done[2] = {nullptr, nullptr};
+            ~Side() {
+                for (int i = 0; i < 2; i++) {
+                    if (done[i]) (void)hipEventDestroy(done[i]);
+                    if (s[i]) exg_rd::stream_pool()->give(dev, s[i]);
+                }
+                if (tables) (void)hipEventDestroy(tables);
+            }
+        } side{r->device};
+        bool fan = hipEventCreateWithFlags(&side.tables, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < 2 && fan; i++)
+            fan = exg_rd::stream_pool()->take(r->device, &side.s[i]) == hipSuccess && hipEventCreateWithFlags(&side.done[i], hipEventDisableTiming) == hipSuccess;
+        if (fan) {
+            RD_HIP(r, hipEventRecord(side.tables, r->stream));  // the member table (and the head's results) are on r->stream
+            for (int i = 0; i < 2; i++) RD_HIP(r, hipStreamWaitEvent(side.s[i], side.tables, 0));
+        }
         for (size_t w = 0; w < prog.done.size(); w++) {
             if (!prog.wait_for(w)) break;  // the upload failed: its error is reported below
-            RD_HIP(r, hipStreamWaitEvent(r->stream, prog.done[w], 0));
+            hipStream_t ws = fan && w % 3 ? side.s[w % 3 - 1] : r->stream;
+            RD_HIP(r, hipStreamWaitEvent(ws, prog.done[w], 0));
             const uint64_t ready = std::min<uint64_t>(n, (uint64_t)(w + 1) * kUploadWindow);
             uint64_t i1 = i0;
             while (i1 < k && members[i1].comp_off + members[i1].comp_size <= ready) i1++;
             if (i1 > i0) {
                 int rc = exg_inflate_members(d_comp, d_out, (const exg_inflate_member *)d_members + i0, (exg_inflate_status *)d_status + i0,
-                                             (uint32_t)(i1 - i0), r->stream);
+                                             (uint32_t)(i1 - i0), ws);
                 // ... and their checksums right behind them, while the next windows still travel
                 if (!rc)
                     rc = exg_crc32_members(d_out, (const exg_inflate_member *)d_members + i0, (const exg_inflate_status *)d_status + i0,
-                                           (uint32_t)(i1 - i0), (uint32_t *)d_crc_all + i0, r->stream);
+                                           (uint32_t)(i1 - i0), (uint32_t *)d_crc_all + i0, ws);
                 if (rc) return fail(r, rc, exg_last_error_message());
             }
             i0 = i1;
         }
+        if (fan)
+            for (int i = 0; i < 2; i++) {
+                RD_HIP(r, hipEventRecord(side.done[i], side.s[i]));
+                RD_HIP(r, hipStreamWaitEvent(r->stream, side.done[i], 0));
+            }
         up_thread.join();
         if (prog.rc) return prog.rc;
         if (i0 < k) return fail(r, EXG_E_PARSE, "truncated gzip member in '" + path + "'");
