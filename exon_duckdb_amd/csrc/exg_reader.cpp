@@ -104,14 +104,28 @@ exg_reader::FdCloser::~FdCloser() {
     if (fd >= 0) close(fd);
 }
 int exg_reader::join_prefetch() {
-    if (pf_thread.joinable()) pf_thread.join();
-    const int rc = pf_rc;
-    pf_rc = 0;
+    int rc = 0;
+    for (int k = 0; k < 2; k++) {
+        if (pf2.valid && pf2.slot == k) continue;  // (the batch after the coming one: not this call's)
+        if (up_thread_of[k].joinable()) up_thread_of[k].join();
+        if (up_rc_of[k] && !rc) rc = up_rc_of[k];
+        up_rc_of[k] = 0;
+    }
     if (rc) pf.valid = false;
     return rc;
 }
+void exg_reader::drop_prefetch2() {
+    for (int k = 0; k < 2; k++)
+        if (pf2.valid && pf2.slot == k && up_thread_of[k].joinable()) {
+            up_thread_of[k].join();
+            up_rc_of[k] = 0;
+        }
+    if (pf2.valid && up_stream) (void)hipStreamSynchronize(up_stream);
+    pf2.valid = false;
+}
 void exg_reader::free_device() {
     (void)join_prefetch();
+    drop_prefetch2();
     if (up_stream) (void)hipStreamSynchronize(up_stream);
     pf.valid = false;
     d_in = nullptr;
@@ -144,7 +158,8 @@ exg_reader::~exg_reader() {
     if (d_filter_prog) (void)hipFree(d_filter_prog);
     if (d_filter_consts) (void)hipFree(d_filter_consts);
     if (d_file) exg_rd::dev_pool()->give(device, d_file, d_file_cap);
-    if (up_done) (void)hipEventDestroy(up_done);
+    for (int k = 0; k < 2; k++)
+        if (up_done_of[k]) (void)hipEventDestroy(up_done_of[k]);
     exg_rd::stream_pool()->give(device, up_stream);
     exg_rd::stream_pool()->give(device, stream);
 }
@@ -1238,6 +1253,7 @@ int open_next_file(exg_reader *r) {
         if (rc) return rc;
     }
     (void)r->join_prefetch();
+    r->drop_prefetch2();
     if (r->pf.valid && r->up_stream) (void)hipStreamSynchronize(r->up_stream);  // a prefetch of the previous file
     r->pf.valid = false;
     r->file = blk;
@@ -1339,7 +1355,7 @@ int ensure_device(exg_reader *r, uint64_t need_bytes) {
     r->cur_slot = 0;
     if (!r->up_stream) {
         RD_HIP(r, exg_rd::stream_pool()->take(r->device, &r->up_stream));
-        RD_HIP(r, hipEventCreateWithFlags(&r->up_done, hipEventDisableTiming));
+        for (int k = 0; k < 2; k++) RD_HIP(r, hipEventCreateWithFlags(&r->up_done_of[k], hipEventDisableTiming));
     }
     if ((arc = r->dev_alloc(&r->d_ws, r->ws_bytes))) return arc;
     for (int k = 0; k < 2; k++)
@@ -1419,6 +1435,23 @@ int upload_range(exg_reader *r, uint64_t off, uint64_t n, int slot, hipStream_t 
     return EXG_OK;
 }
 
+// an upload of file bytes [start, start + len) into input slot `slot`, on a host thread of its own: pread + the H2D enqueue
+// block their caller for as long as the bytes take to leave (5.5 ms per 256 MiB)
+static void start_upload(exg_reader *r, exg_reader::Prefetch *which, uint64_t start, uint64_t len, int slot) {
+    r->up_rc_of[slot] = 0;
+    r->up_thread_of[slot] = std::thread([r, start, len, slot] {
+        (void)hipSetDevice(r->device);
+        pin_to_device_node(r->device);
+        int rc3 = upload_range(r, start, len, slot, r->up_stream);
+        if (!rc3 && hipEventRecord(r->up_done_of[slot], r->up_stream) != hipSuccess) rc3 = EXG_E_HIP;
+        r->up_rc_of[slot] = rc3;
+    });
+    which->valid = true;
+    which->file_start = start;
+    which->len = len;
+    which->slot = slot;
+}
+
 // Scan the next device batch of the current file.  On return r->batch holds its host vectors
 // (n_rows may be 0 when the file is exhausted).  count_only: no column leaves the device.
 int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
@@ -1454,6 +1487,21 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         // H2D copy.  In the first two cases the batch start is only byte aligned: the buffer starts at the
         // 16-byte boundary below it and `lead` skips the tail of the previous record (whose last '\n' is
         // then inside the buffer).
+        // The batch about to be scanned is on its way (or there); if its upload is the one this call will use, the batch
+        // AFTER it starts travelling now, into the slot of the batch that was scanned last (free: its columns have left) —
+        // issued after this call's scan, an upload began only when the link had already been idle for a scan + a D2H.
+        static const bool no_prefetch = getenv("EXG_NO_PREFETCH") != nullptr;
+        if (!no_prefetch && r->pf.valid && !r->pf2.valid && !r->d_file && r->format != EXG_FMT_FASTA && want == r->device_batch_bytes &&
+            r->file_pos >= r->pf.file_start && r->file_pos < r->pf.file_start + r->pf.len && r->d_in_slot[r->pf.slot ^ 1] &&
+            !r->up_thread_of[r->pf.slot ^ 1].joinable()) {
+            const uint64_t end1 = r->pf.file_start + r->pf.len;  // where the coming batch's bytes end
+            if (end1 < r->range_hi) {
+                const uint64_t slack = std::min<uint64_t>(kPrefetchSlack, (end1 - r->file_pos) / 2);
+                const uint64_t start = (end1 - slack) & ~15ull;
+                const uint64_t len = std::min<uint64_t>(r->range_hi - start, r->device_batch_bytes + slack);
+                if (len + 16 <= r->d_in_cap) start_upload(r, &r->pf2, start, len, r->pf.slot ^ 1);
+            }
+        }
         if ((rc = r->join_prefetch())) return rc;  // the upload thread of the previous call (its error is this call's)
         const uint8_t *h = (const uint8_t *)r->file->p + r->file_pos;
         const void *d_input = nullptr;
@@ -1490,7 +1538,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             eof = range_end && r->range_eof;
             h -= lead;
             r->pf.valid = false;
-            RD_HIP(r, hipStreamWaitEvent(r->stream, r->up_done, 0));
+            RD_HIP(r, hipStreamWaitEvent(r->stream, r->up_done_of[r->cur_slot], 0));
         } else {
             if (r->pf.valid) RD_HIP(r, hipStreamSynchronize(r->up_stream));  // a prefetch that missed: let it land first
             r->pf.valid = false;
@@ -1671,30 +1719,24 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             r->pending_error_offset = r->file_pos - lead + res.error_offset;
         }
         double t_pf = now_s();
-        // While the columns travel back (and the consumer works through the chunks): start moving the bytes
-        // the next batch will need into the other slot.
-        if (!range_end && !res.error_code && !r->d_file && r->format != EXG_FMT_FASTA && want == r->device_batch_bytes &&
-            !getenv("EXG_NO_PREFETCH")) {
+        // While the columns travel back (and the consumer works through the chunks): the bytes the next batch will need
+        // move into the other slot — unless they left at the top of this call already (pf2), which is the steady state
+        {
+            const bool can = !range_end && !res.error_code && !r->d_file && r->format != EXG_FMT_FASTA && want == r->device_batch_bytes && !no_prefetch;
             const uint64_t slack = std::min<uint64_t>(kPrefetchSlack, (batch_end - r->file_pos) / 2);
             const uint64_t start = (batch_end - slack) & ~15ull;
             const uint64_t len = std::min<uint64_t>(r->range_hi - start, r->device_batch_bytes + slack);
             const int other = r->cur_slot ^ 1;
-            if (len + 16 <= r->d_in_cap && r->d_in_slot[other]) {
-                // on a host thread of its own: pread + the H2D enqueue block their caller for as long as the bytes take
-                // to leave (5.5 ms per 256 MiB), and this thread has columns to copy back / Arrow buffers to build
-                r->pf_rc = 0;
-                r->pf_thread = std::thread([r, start, len, other] {
-                    (void)hipSetDevice(r->device);
-                    pin_to_device_node(r->device);
-                    int rc3 = upload_range(r, start, len, other, r->up_stream);
-                    if (!rc3 && hipEventRecord(r->up_done, r->up_stream) != hipSuccess) rc3 = EXG_E_HIP;
-                    r->pf_rc = rc3;
-                });
-                r->pf.valid = true;
-                r->pf.file_start = start;
-                r->pf.len = len;
-                r->pf.slot = other;
+            if (r->pf2.valid) {
+                if (can && r->pf2.file_start == start && r->pf2.len == len && r->pf2.slot == other) {
+                    r->pf = r->pf2;
+                    r->pf2.valid = false;
+                } else {
+                    r->drop_prefetch2();  // (the batch turned out otherwise: an error, a retry, the end of the range)
+                }
             }
+            if (can && !r->pf.valid && len + 16 <= r->d_in_cap && r->d_in_slot[other] && !r->up_thread_of[other].joinable())
+                start_upload(r, &r->pf, start, len, other);
         }
         TRACE("prefetch issue", t_pf);
         uint64_t k = res.n_records;

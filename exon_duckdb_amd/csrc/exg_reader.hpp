@@ -318,15 +318,20 @@ struct exg_reader {
     void *d_in = nullptr, *d_ws = nullptr, *d_res = nullptr;  // d_in = the slot the current batch sits in
     void *d_in_slot[2] = {nullptr, nullptr};
     hipStream_t up_stream = nullptr;
-    hipEvent_t up_done = nullptr;
-    std::thread pf_thread;  // the prefetch's pread + H2D enqueue (joined by the next call that looks at pf)
-    int pf_rc = 0;
-    int join_prefetch();
+    // per input slot: the thread of the upload that is filling it (pread + H2D enqueue), its result, the event behind its copies
+    std::thread up_thread_of[2];
+    int up_rc_of[2] = {0, 0};
+    hipEvent_t up_done_of[2] = {nullptr, nullptr};
+    int join_prefetch();  // the upload of the batch this call is about to use (pf)
     struct Prefetch {
         bool valid = false;
         uint64_t file_start = 0, len = 0;  // file bytes [file_start, file_start + len) are (being) uploaded
         int slot = 0;
     } pf;
+    // a second upload in flight: the batch AFTER the one that is about to be scanned starts travelling as soon as that one's
+    // own upload is known to cover it (the slot of the batch before is free by then), so that the link never waits for a scan
+    Prefetch pf2;
+    void drop_prefetch2();  // join + let it land + forget
     int cur_slot = 0;
     size_t host_hint = 0;  // pinned bytes the previous batch's host vectors needed
     std::vector<std::pair<void **, size_t>> dev_allocs;  // pooled device buffers of this reader (slot, bytes)
