@@ -1174,15 +1174,19 @@ int zstd_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::strin
     };
     Pooled comp{r->device, exg_rd::dev_pool()->take(r->device, n + 64), (size_t)(n + 64)};
     if (!comp.p) return fail(r, EXG_E_HIP, "out of device memory for the compressed file");
-    if (n) {
-        int rc = upload_file(r, comp.p, n, 0);
-        if (rc) return rc;
-    }
+    // the host's walk over the frame / block headers runs beside the upload
+    exg::zst::Index idx;
+    bool idx_ok = false;
+    std::thread idx_thread([&] { idx_ok = exg::zst::build_index((const uint8_t *)blk->p, n, idx); });
+    int up_rc = n ? upload_file(r, comp.p, n, 0) : EXG_OK;
+    idx_thread.join();
+    if (up_rc) return up_rc;
+    if (!idx_ok) return fail(r, EXG_E_PARSE, idx.error + " in '" + path + "'");
     RD_HIP(r, hipMemsetAsync((char *)comp.p + n, 0, 64, r->stream));
     void *d_out = nullptr;
     uint64_t produced = 0;
     std::vector<exg::zst::PendingCheck> pending;
-    int rc = exg::zst::decode((const uint8_t *)blk->p, comp.p, n, &d_out, &produced, r->stream, &pending);
+    int rc = exg::zst::decode((const uint8_t *)blk->p, comp.p, n, &d_out, &produced, r->stream, &pending, &idx);
     if (rc) return fail(r, rc, std::string(exg_last_error_message()) + " in '" + path + "'");
     TRACE("zstd: h2d + decode", t_all);
     if (!pending.empty()) {

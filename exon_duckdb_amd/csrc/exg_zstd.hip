@@ -1056,7 +1056,8 @@ int host_verify(const void *d_out, const std::vector<PendingCheck> &pending, int
     return rc;
 }
 
-int decode(const uint8_t *h_comp, const void *d_comp_v, uint64_t n, void **d_out_p, uint64_t *produced, void *stream_v, std::vector<PendingCheck> *pending) {
+int decode(const uint8_t *h_comp, const void *d_comp_v, uint64_t n, void **d_out_p, uint64_t *produced, void *stream_v, std::vector<PendingCheck> *pending,
+           Index *prebuilt) {
     if (!h_comp || !d_comp_v || !d_out_p || !produced) {
         set_error("exg_zstd_decode: null argument");
         return EXG_E_INVALID_ARG;
@@ -1067,8 +1068,9 @@ int decode(const uint8_t *h_comp, const void *d_comp_v, uint64_t n, void **d_out
     const uint8_t *d_comp = (const uint8_t *)d_comp_v;
     static const bool trace = getenv("EXG_TRACE") != nullptr;
     const double t_begin = trace ? now_ms() : 0;
-    Index idx;
-    if (!build_index(h_comp, n, idx)) {
+    Index own;
+    Index &idx = prebuilt ? *prebuilt : own;  // (a reader walks the headers while the compressed bytes travel)
+    if (!prebuilt && !build_index(h_comp, n, idx)) {
         set_error("%s", idx.error.c_str());
         return EXG_E_PARSE;
     }
@@ -1312,7 +1314,7 @@ int decode(const uint8_t *h_comp, const void *d_comp_v, uint64_t n, void **d_out
 
 extern "C" int exg_zstd_decode(const uint8_t *h_comp, const void *d_comp, uint64_t n, void **d_out, uint64_t *produced, void *stream) {
     std::vector<exg::zst::PendingCheck> pending;
-    int rc = exg::zst::decode(h_comp, d_comp, n, d_out, produced, stream, &pending);
+    int rc = exg::zst::decode(h_comp, d_comp, n, d_out, produced, stream, &pending, nullptr);
     if (rc || pending.empty()) return rc;
     int dev = 0;
     (void)hipGetDevice(&dev);
