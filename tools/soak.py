@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from exon_duckdb_amd import device, table_function
 from exon_duckdb_amd.arrow import new_reader
-from exon_duckdb_amd.table_function import _decode_strings, Chunk
+from exon_duckdb_amd.table_function import _decode_strings
 
 GB = float(os.environ.get("SOAK_GB", "8"))
 n_rec = int(GB * 1e9) // 332
@@ -22,12 +22,20 @@ t0 = time.time(); n = rel.count(); dt = time.time() - t0
 assert n == n_rec
 print(f"count {n} in {dt:.2f} s = {n_rec*332/dt/1e9:.1f} GB/s", flush=True)
 # chunks: first and last name of every chunk must be SYN%012d of its row index
-t0 = time.time(); row = 0; n_chunks = 0
-for ch in rel._scan([0, 1]):
+t0 = time.time()
+seen = [0]
+def first_last(ch):
+    # (called while the chunk is alive) first and last name of every 257th chunk
+    seen[0] += 1
+    if seen[0] % 257 != 1:
+        return None
     k = int(ch.n_rows)
-    names = _decode_strings(ch.data[0], None, k) if n_chunks % 257 == 0 else None
+    names = _decode_strings(ch.vectors[0].contents.data, None, k)
+    return names[0], names[-1]
+row = 0; n_chunks = 0
+for _, k, names in rel._scan([0, 1], decode=first_last):
     if names is not None:
-        assert names[0] == b"SYN%012d" % row and names[-1] == b"SYN%012d" % (row + k - 1), (row, names[0])
+        assert names[0] == b"SYN%012d" % row and names[1] == b"SYN%012d" % (row + k - 1), (row, names[0])
     row += k; n_chunks += 1
 dt = time.time() - t0
 assert row == n_rec
