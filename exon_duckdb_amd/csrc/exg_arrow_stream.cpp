@@ -18,6 +18,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "exg_arrow.hpp"
@@ -169,6 +170,11 @@ struct StreamState {
     DevArena arena;
     std::shared_ptr<ABatch> batch;
     uint64_t batch_row = 0;
+    // the device batch AFTER the one being handed out is produced on a thread of its own (scan, Arrow buffers, their way
+    // back over PCIe: ~6 ms per 256 MiB) while the consumer walks the ~400 record batches of the current one
+    std::shared_ptr<ABatch> produced;  // written by arrow_emit
+    std::thread producer;
+    int produced_state = 0;            // 1 a batch, 2 end of stream, 3 error (last_error)
     std::string last_error;
     size_t host_hint = 0;  // pinned bytes the previous batch needed
     hipStream_t copy_stream = nullptr;
@@ -688,8 +694,7 @@ int arrow_emit(exg_reader *r, const ScanCtx &ctx) {
     }
     const uint64_t n = em.n;
     if (n == 0) {
-        st->batch.reset();
-        st->batch_row = 0;
+        st->produced.reset();
         return EXG_OK;
     }
     std::vector<AColumn> &cols = batch->cols;
@@ -802,8 +807,7 @@ int arrow_emit(exg_reader *r, const ScanCtx &ctx) {
     EM_TRACE("drain");
     st->host_hint = batch->host.total + batch->host.total / 8 + (1u << 20);
     batch->n_rows = n_rows;
-    st->batch = n_rows ? batch : nullptr;
-    st->batch_row = 0;
+    st->produced = n_rows ? batch : nullptr;
     EM_TRACE("swap batch");
     return EXG_OK;
 }
@@ -917,13 +921,57 @@ int stream_get_schema(ArrowArrayStream *s, ArrowSchema *out) {
     return 0;
 }
 
+// the next device batch with rows (st->produced), the end of the stream, or an error: everything that touches the reader
+static void produce(StreamState *st) {
+    exg_reader *r = st->r;
+    DeviceGuard guard(r->device);
+    st->produced.reset();
+    for (;;) {
+        if (r->pending_error) {
+            st->last_error = std::string(exg_parse_error_string(r->pending_error)) + " in " + r->files[r->file_idx - 1];
+            r->pending_error = 0;
+            r->file_done = true;
+            r->file_idx = r->files.size();
+            st->produced_state = 3;
+            return;
+        }
+        if (r->file_done) {
+            if (r->join_zstd_check()) {
+                st->last_error = r->error;
+                st->produced_state = 3;
+                return;
+            }
+            if (r->file_idx >= r->files.size()) {
+                st->produced_state = 2;
+                return;
+            }
+            if (open_next_file(r)) {
+                st->last_error = r->error;
+                st->produced_state = 3;
+                return;
+            }
+        }
+        uint64_t k;
+        if (next_batch(r, false, &k)) {
+            st->last_error = r->error;
+            st->produced_state = 3;
+            return;
+        }
+        if (st->produced && st->produced->n_rows) {
+            st->produced_state = 1;
+            return;
+        }
+    }
+}
+
 int stream_get_next(ArrowArrayStream *s, ArrowArray *out) {
     StreamState *st = (StreamState *)s->private_data;
     exg_reader *r = st->r;
-    DeviceGuard guard(r->device);
     memset(out, 0, sizeof *out);
     for (;;) {
         if (st->batch && st->batch_row < st->batch->n_rows) {
+            // the first record batch of a device batch: the next device batch starts being made
+            if (st->batch_row == 0 && !st->producer.joinable() && st->produced_state == 0) st->producer = std::thread(produce, st);
             const uint64_t row0 = st->batch_row, B = r->batch_rows;
             const uint64_t len = std::min<uint64_t>(B, st->batch->n_rows - row0);
             auto *p = new ArrayPriv();
@@ -947,29 +995,14 @@ int stream_get_next(ArrowArrayStream *s, ArrowArray *out) {
             return 0;
         }
         st->batch.reset();
-        if (r->pending_error) {
-            st->last_error = std::string(exg_parse_error_string(r->pending_error)) + " in " + r->files[r->file_idx - 1];
-            r->pending_error = 0;
-            r->file_done = true;
-            r->file_idx = r->files.size();
-            return EIO;
-        }
-        if (r->file_done) {
-            if (r->join_zstd_check()) {
-                st->last_error = r->error;
-                return EIO;
-            }
-            if (r->file_idx >= r->files.size()) return 0;  // out->release == NULL: end of stream
-            if (open_next_file(r)) {
-                st->last_error = r->error;
-                return EIO;
-            }
-        }
-        uint64_t k;
-        if (next_batch(r, false, &k)) {
-            st->last_error = r->error;
-            return EIO;
-        }
+        if (st->producer.joinable()) st->producer.join();
+        if (st->produced_state == 0) produce(st);  // (the first batch of the stream: nothing is under way yet)
+        const int state = st->produced_state;
+        if (state == 3) return EIO;                // (sticky: the stream is over)
+        if (state == 2) return 0;                  // out->release == NULL: end of stream
+        st->produced_state = 0;
+        st->batch = std::move(st->produced);
+        st->batch_row = 0;
     }
 }
 
@@ -981,8 +1014,10 @@ const char *stream_last_error(ArrowArrayStream *s) {
 void stream_release(ArrowArrayStream *s) {
     if (!s || !s->release) return;
     StreamState *st = (StreamState *)s->private_data;
+    if (st->producer.joinable()) st->producer.join();
     DeviceGuard guard(st->r->device);
     st->batch.reset();
+    st->produced.reset();
     std::shared_ptr<void> last = std::move(st->r->arrow_state);
     last.reset();  // deletes st, and the reader with it
     s->release = nullptr;
