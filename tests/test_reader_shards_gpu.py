@@ -245,6 +245,13 @@ def test_open_on_one_thread_scan_on_another(gpu, tmp_path, oracle):
         ShardReader(str(p), "fastq", device=63)
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def test_bench_two_ranks_on_one_gpu(gpu):
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), here with two ranks sharing
     cuda:0 over gloo: the byte-range shards, the phase all_gather, the COUNT(*) all_reduce, the closed-form verification of
@@ -256,7 +263,7 @@ def test_bench_two_ranks_on_one_gpu(gpu):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--launches-per-step", "2", "--gb", "0.5", "--e2e-gb", "0.25", "--backend", "gloo", "--single-device"]
     res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
@@ -278,7 +285,7 @@ def test_rccl_initialises_and_reduces_on_this_image(gpu):
     import sys
     code = (
         "import os, torch, torch.distributed as dist\n"
-        "os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29519')\n"
+        "os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '%d')\n"
         "os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')\n"
         "torch.cuda.set_device(0)\n"
         "dist.init_process_group('nccl', device_id=torch.device('cuda', 0))\n"
@@ -287,6 +294,6 @@ def test_rccl_initialises_and_reduces_on_this_image(gpu):
         "m = torch.tensor([1.5], dtype=torch.float64, device='cuda'); dist.all_reduce(m, op=dist.ReduceOp.MAX)\n"
         "dist.barrier(); torch.cuda.synchronize()\n"
         "assert int(t.item()) == 41 and int(g[0].item()) == 42 and float(m.item()) == 1.5\n"
-        "dist.destroy_process_group(); print('rccl ok')\n")
+        "dist.destroy_process_group(); print('rccl ok')\n") % _free_port()
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ))
     assert res.returncode == 0 and "rccl ok" in res.stdout, res.stdout[-1000:] + res.stderr[-3000:]
