@@ -108,10 +108,12 @@ Field key_field(const KeyDef &k) {
 }
 
 // ---- memory ------------------------------------------------------------------------------------------------------------------
-struct DevArena {  // bump allocator, reset per batch; overflow goes to hipMalloc'd extras
+struct DevArena {  // bump allocator, reset per batch; what does not fit comes from the device pool, and the next batch's
+                   // arena is as large as this batch turned out to need (hipMalloc / hipFree per batch cost milliseconds)
     char *base = nullptr;
-    size_t cap = 0, used = 0, extra_bytes = 0;
-    std::vector<void *> extra;
+    size_t cap = 0, used = 0, extra_bytes = 0, need = 0;
+    std::vector<std::pair<void *, size_t>> extra;
+    int dev = 0;
     void *alloc(size_t n) {
         n = (n + 255) & ~(size_t)255;
         if (n == 0) n = 256;
@@ -120,19 +122,33 @@ struct DevArena {  // bump allocator, reset per batch; overflow goes to hipMallo
             used += n;
             return p;
         }
-        void *p = nullptr;
-        if (hipMalloc(&p, n) != hipSuccess) return nullptr;
-        extra.push_back(p);
-        extra_bytes += n;
+        const size_t sz = n < (1u << 20) ? (1u << 20) : n;  // (the pool keeps blocks of 1 MiB and more)
+        void *p = dev_pool()->take(dev, sz);
+        if (!p) return nullptr;
+        extra.emplace_back(p, sz);
+        extra_bytes += sz;
         return p;
     }
     void reset() {
-        for (void *p : extra) (void)hipFree(p);
+        need = used + extra_bytes;
+        for (auto &e : extra) dev_pool()->give(dev, e.first, e.second);
         extra.clear();
         used = 0;
         extra_bytes = 0;
     }
-    int dev = 0;
+    // before a batch: an arena of `want` bytes, or — when the batch before overflowed it — of what that one needed + 25 %
+    void prepare(int device, size_t want) {
+        dev = device;
+        if (base && need > cap) {
+            dev_pool()->give(dev, base, cap);
+            base = nullptr, cap = 0;
+            want = std::max(want, need + need / 4);
+        }
+        if (!base) {
+            want = (want + 4095) & ~(size_t)4095;
+            if ((base = (char *)dev_pool()->take(dev, want))) cap = want;
+        }
+    }
     ~DevArena() {
         reset();
         if (base) dev_pool()->give(dev, base, cap);
@@ -621,13 +637,9 @@ int arrow_emit(exg_reader *r, const ScanCtx &ctx) {
     StreamState *st = (StreamState *)r->arrow_state.get();
     double em_t0 = em_now();
     st->arena.reset();
-    if (!st->arena.base) {
-        // sized for the typical batch: offsets + values + views of every column; anything beyond goes to hipMalloc
-        size_t cap = (size_t)std::min<uint64_t>(r->d_in_cap * 3 + (64u << 20), 6ull << 30);
-        cap = (cap + 4095) & ~(size_t)4095;
-        st->arena.dev = r->device;
-        if ((st->arena.base = (char *)dev_pool()->take(r->device, cap))) st->arena.cap = cap;
-    }
+    // sized for the typical batch: offsets + values + views of every column; what a batch needs beyond that comes from the
+    // pool and enlarges the arena of the next one
+    st->arena.prepare(r->device, (size_t)std::min<uint64_t>(r->d_in_cap * 3 + (64u << 20), 6ull << 30));
     EM_TRACE("arena");
     if (!st->copy_stream) {
         EM_HIP(stream_pool()->take(r->device, &st->copy_stream));
@@ -1111,12 +1123,7 @@ int nested_emit(exg_reader *r, const ScanCtx &ctx, Batch *b, const uint32_t *d_r
     StreamState *st = (StreamState *)r->nested_state.get();
     if (!st) return fail(r, EXG_E_INVALID_ARG, "nested_emit without nested_prepare");
     st->arena.reset();
-    if (!st->arena.base) {
-        size_t cap = (size_t)std::min<uint64_t>(r->d_in_cap * 3 + (64u << 20), 6ull << 30);
-        cap = (cap + 4095) & ~(size_t)4095;
-        st->arena.dev = r->device;
-        if ((st->arena.base = (char *)dev_pool()->take(r->device, cap))) st->arena.cap = cap;
-    }
+    st->arena.prepare(r->device, (size_t)std::min<uint64_t>(r->d_in_cap * 3 + (64u << 20), 6ull << 30));
     if (!st->copy_stream) {
         EM_HIP(stream_pool()->take(r->device, &st->copy_stream));
         st->copy_dev = r->device;
