@@ -49,6 +49,27 @@ PinnedBlock::~PinnedBlock() {
         (void)hipHostFree(p);
 }
 
+// a device buffer from the pool for the length of a scope. The stream that used it is waited for before the block goes
+// back (idle already on the normal path; an error return may leave work in flight, and the pool is process-wide)
+struct PoolBuf {
+    int dev;
+    hipStream_t stream;
+    void *p = nullptr;
+    size_t sz = 0;
+    PoolBuf(int d, hipStream_t s) : dev(d), stream(s) {}
+    PoolBuf(const PoolBuf &) = delete;
+    PoolBuf &operator=(const PoolBuf &) = delete;
+    void *take(size_t bytes) {
+        sz = bytes ? bytes : 16;
+        return p = exg_rd::dev_pool()->take(dev, sz);
+    }
+    ~PoolBuf() {
+        if (!p) return;
+        (void)hipStreamSynchronize(stream);
+        exg_rd::dev_pool()->give(dev, p, sz);
+    }
+};
+
 // DataFusion 28 FileCompressionType::from_str as used at rust/src/arrow_reader.rs:87-88
 static bool parse_compression(const std::string &s, Compression *out) {
     std::string u;
@@ -153,8 +174,8 @@ exg_reader::~exg_reader() {
     exg_rd::DeviceGuard guard(device);
     if (zst_check.joinable()) zst_check.join();
     free_device();
-    if (d_res) (void)hipFree(d_res);
-    if (d_phase) (void)hipFree(d_phase);
+    if (d_res) exg_rd::dev_pool()->give(device, d_res, 4096);
+    if (d_phase) exg_rd::dev_pool()->give(device, d_phase, 4096);
     if (d_filter_prog) (void)hipFree(d_filter_prog);
     if (d_filter_consts) (void)hipFree(d_filter_consts);
     if (d_file) exg_rd::dev_pool()->give(device, d_file, d_file_cap);
@@ -389,12 +410,9 @@ static int check_stream(exg_reader *r, const uint8_t *comp, uint64_t n_comp, uin
     if (n_seg) {
         std::vector<exg_crc_segment> segs(n_seg);
         for (uint64_t i = 0; i < n_seg; i++) segs[i] = exg_crc_segment{i * seg, std::min<uint64_t>(seg, produced - i * seg)};
-        void *d = nullptr;
-        RD_HIP(r, hipMalloc(&d, n_seg * (sizeof(exg_crc_segment) + 4) + 64));
-        struct Free {
-            void *p;
-            ~Free() { (void)hipFree(p); }
-        } fr{d};
+        PoolBuf fr(r->device, r->stream);
+        void *d = fr.take(n_seg * (sizeof(exg_crc_segment) + 4) + 64);
+        if (!d) return fail(r, EXG_E_HIP, "out of device memory for the checksum segments");
         uint32_t *d_crc = (uint32_t *)((char *)d + n_seg * sizeof(exg_crc_segment));
         RD_HIP(r, hipMemcpyAsync(d, segs.data(), n_seg * sizeof(exg_crc_segment), hipMemcpyHostToDevice, r->stream));
         int rc = exg_crc32_segments(d_out, (const exg_crc_segment *)d, (uint32_t)n_seg, d_crc, r->stream);
@@ -747,15 +765,9 @@ static int inflate_file_shard(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, 
     if ((rc = upload_file(r, comp_buf.p, c1 - c0a, c0a))) return rc;
     const uint64_t cnt = m1 - h0;
     for (uint64_t i = h0; i < m1; i++) members[i].comp_off -= c0a, members[i].out_off -= out0;
-    void *d_members = nullptr, *d_status = nullptr;
-    struct Free {
-        void *p;
-        ~Free() { if (p) (void)hipFree(p); }
-    };
-    RD_HIP(r, hipMalloc(&d_members, cnt * sizeof(exg_inflate_member)));
-    Free fm{d_members};
-    RD_HIP(r, hipMalloc(&d_status, cnt * sizeof(exg_inflate_status)));
-    Free fs{d_status};
+    PoolBuf fm(r->device, r->stream), fs(r->device, r->stream);
+    void *d_members = fm.take(cnt * sizeof(exg_inflate_member)), *d_status = fs.take(cnt * sizeof(exg_inflate_status));
+    if (!d_members || !d_status) return fail(r, EXG_E_HIP, "out of device memory for the member table");
     RD_HIP(r, hipMemcpyAsync(d_members, members + h0, cnt * sizeof(exg_inflate_member), hipMemcpyHostToDevice, r->stream));
     rc = exg_inflate_members(comp_buf.p, out_buf.p, (const exg_inflate_member *)d_members, (exg_inflate_status *)d_status, (uint32_t)cnt,
                              r->stream);
@@ -799,10 +811,6 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
     void *d_comp = exg_rd::dev_pool()->take(r->device, n + 64);
     if (!d_comp) return fail(r, EXG_E_HIP, "out of device memory for the compressed file");
     Pooled free_comp{r->device, d_comp, (size_t)(n + 64)};
-    struct Free {
-        void *p;
-        ~Free() { if (p) (void)hipFree(p); }
-    };
     // worst case one member per 18 bytes; NOT value-initialised (a 0.5 GB file would zero 1 GB here: measured 240 ms)
     const uint64_t members_cap = std::max<uint64_t>(16, n / 18 + 4);
     std::unique_ptr<exg_inflate_member[]> members(new exg_inflate_member[members_cap]);
@@ -878,12 +886,9 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
         std::vector<exg_inflate_member> m;
         uint64_t k = 0, total = 0, launched = 0;
         void *d_m = nullptr, *d_s = nullptr, *d_c = nullptr;
-        ~Head() {
-            if (d_m) (void)hipFree(d_m);
-            if (d_s) (void)hipFree(d_s);
-            if (d_c) (void)hipFree(d_c);
-        }
-    } head;
+        PoolBuf bm, bs, bc;
+        Head(int dev, hipStream_t s) : bm(dev, s), bs(dev, s), bc(dev, s) {}
+    } head(r->device, r->stream);
     static const bool no_pipeline = getenv("EXG_NO_GZ_PIPELINE") != nullptr;
     if (!no_pipeline && n > 2 * (uint64_t)kUploadWindow) {
         // (the full index of a 5 GB file takes ~33 ms here, the upload moves a window in ~5: three windows keep the device busy
@@ -899,8 +904,8 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
             const double est = (double)head.total / (double)comp_bytes * (double)n * est_scale + (est_scale >= 1.0 ? (double)(64u << 20) : 0.0);
             d_out_cap = std::max<uint64_t>((uint64_t)est, head.total) + 64;  // (what the head itself produces always fits)
             d_out = exg_rd::dev_pool()->take(r->device, d_out_cap);
-            if (d_out && hipMalloc(&head.d_m, head.k * sizeof(exg_inflate_member)) == hipSuccess &&
-                hipMalloc(&head.d_s, head.k * sizeof(exg_inflate_status)) == hipSuccess && hipMalloc(&head.d_c, head.k * 4 + 64) == hipSuccess) {
+            if (d_out && (head.d_m = head.bm.take(head.k * sizeof(exg_inflate_member))) && (head.d_s = head.bs.take(head.k * sizeof(exg_inflate_status))) &&
+                (head.d_c = head.bc.take(head.k * 4 + 64))) {
                 RD_HIP(r, hipMemcpyAsync(head.d_m, head.m.data(), head.k * sizeof(exg_inflate_member), hipMemcpyHostToDevice, r->stream));
                 for (uint64_t w = 0; w < head_windows && prog.wait_for((size_t)w); w++) {
                     RD_HIP(r, hipStreamWaitEvent(r->stream, prog.done[w], 0));
@@ -959,15 +964,11 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
             }
             d_out = p2, d_out_cap = cap2;
         }
-        void *d_members = nullptr, *d_status = nullptr;
-        RD_HIP(r, hipMalloc(&d_members, k * sizeof(exg_inflate_member)));
-        Free fm{d_members};
-        RD_HIP(r, hipMalloc(&d_status, k * sizeof(exg_inflate_status)));
-        Free fs{d_status};
+        PoolBuf fm(r->device, r->stream), fs(r->device, r->stream), fc(r->device, r->stream);
+        void *d_members = fm.take(k * sizeof(exg_inflate_member)), *d_status = fs.take(k * sizeof(exg_inflate_status));
+        void *d_crc_all = fc.take(k * 4 + 64);
+        if (!d_members || !d_status || !d_crc_all) return fail(r, EXG_E_HIP, "out of device memory for the member table");
         RD_HIP(r, hipMemcpyAsync(d_members, members.get(), k * sizeof(exg_inflate_member), hipMemcpyHostToDevice, r->stream));
-        void *d_crc_all = nullptr;
-        RD_HIP(r, hipMalloc(&d_crc_all, k * 4 + 64));
-        Free fc{d_crc_all};
         uint64_t i0 = head.launched;
         if (i0) {  // the head's statuses and checksums take their places in the tables of the whole file
             RD_HIP(r, hipMemcpyAsync(d_status, head.d_s, i0 * sizeof(exg_inflate_status), hipMemcpyDeviceToDevice, r->stream));
@@ -983,7 +984,10 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
             ~Side() {
                 for (int i = 0; i < 2; i++) {
                     if (done[i]) (void)hipEventDestroy(done[i]);
-                    if (s[i]) exg_rd::stream_pool()->give(dev, s[i]);
+                    if (s[i]) {
+                        (void)hipStreamSynchronize(s[i]);  // idle already unless this is an error return
+                        exg_rd::stream_pool()->give(dev, s[i]);
+                    }
                 }
                 if (tables) (void)hipEventDestroy(tables);
             }
@@ -1116,10 +1120,9 @@ int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::st
             d_out = nd;
             d_out_cap = ncap;
         }
-        void *d_members = nullptr, *d_status = nullptr;
-        RD_HIP(r, hipMalloc(&d_members, k * sizeof(exg_inflate_member)));
-        RD_HIP(r, hipMalloc(&d_status, k * sizeof(exg_inflate_status)));
-        Free fm{d_members}, fs{d_status};
+        PoolBuf fm(r->device, r->stream), fs(r->device, r->stream);
+        void *d_members = fm.take(k * sizeof(exg_inflate_member)), *d_status = fs.take(k * sizeof(exg_inflate_status));
+        if (!d_members || !d_status) return fail(r, EXG_E_HIP, "out of device memory for the member table");
         RD_HIP(r, hipMemcpyAsync(d_members, members.get(), k * sizeof(exg_inflate_member), hipMemcpyHostToDevice, r->stream));
         double t_inf = now_s();
         rc = exg_inflate_members(d_comp, d_out, (const exg_inflate_member *)d_members, (exg_inflate_status *)d_status,
@@ -1376,7 +1379,7 @@ int ensure_device(exg_reader *r, uint64_t need_bytes) {
         if ((arc = r->dev_alloc(&r->d_gather, r->cap_records * 16))) return arc;
         if ((arc = r->dev_alloc(&r->d_filter_tmp, (r->cap_records + 1 + exg::arrow::scan_tmp_entries(r->cap_records)) * 8))) return arc;
     }
-    if (!r->d_res) RD_HIP(r, hipMalloc(&r->d_res, sizeof(exg_scan_result)));
+    if (!r->d_res && !(r->d_res = exg_rd::dev_pool()->take(r->device, 4096))) return fail(r, EXG_E_HIP, "out of device memory");
     return EXG_OK;
 }
 
@@ -1566,7 +1569,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         if (lead && r->shard_first && r->format == EXG_FMT_FASTQ) {
             // the 4-line phase of the line that holds the shard's first byte, from the bytes around the cut ('@' opens a
             // record but also quality lines, so several records are looked at: exg_fastq_guess_phase)
-            if (!r->d_phase) RD_HIP(r, hipMalloc(&r->d_phase, 16));
+            if (!r->d_phase && !(r->d_phase = exg_rd::dev_pool()->take(r->device, 4096))) return fail(r, EXG_E_HIP, "out of device memory");
             uint32_t guess = 0xFFFFFFFFu;
             rc = exg_fastq_guess_phase(d_input, n, lead, (uint32_t *)r->d_phase, r->stream);
             if (rc) return fail(r, rc, exg_last_error_message());

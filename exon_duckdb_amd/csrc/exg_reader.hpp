@@ -197,7 +197,7 @@ struct DevPool {
         sz = size_class(sz);
         {
             std::lock_guard<std::mutex> g(mu);
-            if (sz >= (1u << 20) && pooled_bytes + sz <= max_pooled()) {
+            if (pooled_bytes + sz <= max_pooled()) {  // (small blocks too: a hipMalloc / hipFree pair per open or per file is 0.1-1 ms)
                 free_blocks.push_back(Blk{dev, p, sz});
                 pooled_bytes += sz;
                 return;
