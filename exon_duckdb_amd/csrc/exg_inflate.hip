@@ -19,6 +19,10 @@
 
 #include "exg_inflate_core.hpp"
 
+#ifndef EXG_INFLATE_EMIT
+#define EXG_INFLATE_EMIT 2  // 128 bit offsets per speculative step (1: 64)
+#endif
+
 namespace exg {
 template <uint32_t RING, int EMIT>
 __global__ __launch_bounds__(64, RING <= 2048 ? 5 : 1) void k_inflate(const uint8_t *__restrict__ d_comp, uint8_t *d_out,
@@ -83,7 +87,7 @@ extern "C" int exg_inflate_members(const void *d_comp, void *d_out, const exg_in
         }
     }
 #else
-    EXG_LAUNCH_INFLATE(2048, 1, d_out);
+    EXG_LAUNCH_INFLATE(2048, EXG_INFLATE_EMIT, d_out);
 #endif
 #undef EXG_LAUNCH_INFLATE
     EXG_HIP_CHECK(hipGetLastError());

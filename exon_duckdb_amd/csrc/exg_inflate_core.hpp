@@ -126,6 +126,20 @@ __device__ __forceinline__ unsigned long long peek_at(const L &s, unsigned long 
     if (sh) v |= (unsigned long long)w2 << (64 - sh);
     return v;
 }
+// 128 bits starting at absolute bit `o` (per lane), as two 64-bit windows (lo, hi): five dwords, four funnel shifts
+template <class L>
+__device__ __forceinline__ void peek2_at(const L &s, unsigned long long o, uint32_t &lo_a, uint32_t &hi_a, uint32_t &lo_b, uint32_t &hi_b) {
+    const uint32_t byte = (uint32_t)(o >> 3);
+    const uint32_t a = byte & ~3u;
+    uint32_t w[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) w[i] = *reinterpret_cast<const uint32_t *>(s.in + ((a + 4 * i) & (kInRing - 1)));
+    const uint32_t sh = 8 * (byte & 3u) + (uint32_t)(o & 7);  // 0..31
+    lo_a = __builtin_amdgcn_alignbit(w[1], w[0], sh);
+    hi_a = __builtin_amdgcn_alignbit(w[2], w[1], sh);
+    lo_b = __builtin_amdgcn_alignbit(w[3], w[2], sh);
+    hi_b = __builtin_amdgcn_alignbit(w[4], w[3], sh);
+}
 template <class L>
 __device__ __forceinline__ unsigned long long peek(L &s, BitIn &br, uint32_t lane) {
     ensure(s, br, lane);
@@ -526,10 +540,9 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                     break;
                 }
                 ensure(s, br, lane);
-                // lane l decodes the token that would start at bit bitpos + l
-                unsigned long long v = peek_at(s, br.bitpos + lane);
-                uint32_t kind, tl, val = 0;
-                {
+                // the token that would start at the first bit of v
+                auto spec = [&](unsigned long long v, uint32_t &kind, uint32_t &tl, uint32_t &val) {
+                    val = 0;
                     const uint32_t e = s.lit_lut[(uint32_t)v & ((1u << kLitBits) - 1u)];
                     const uint32_t l1 = e & 15;
                     if (e == 0) {  // longer than the primary table: decoded serially IF it is a real token start
@@ -561,11 +574,167 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                             val = len | (dist << 16);
                         }
                     }
-                }
+                };
+                uint32_t advance;
+                bool slow_token = false;
+                if constexpr (EMIT == 2) {
+                    // ---- 128 bit offsets per step: lane l decodes the tokens that would start at bits l and 64 + l.  What a
+                    // step costs besides its tokens (staging check, window reads, ballots, the scan, the flush test and most of
+                    // all the dependent LDS round trips window -> table -> table -> ring) is paid once per 16 input bytes
+                    // Both windows go through the tables side by side and without branches (every lane looks a distance up,
+                    // a literal's lookup is dropped by a select): the LDS round trips of the two overlap.  All of it is 32-bit
+                    // work: a token's code and extra bits lie in the low 48 bits of its window
+                    uint32_t lo_a, hi_a, lo_b, hi_b;
+                    peek2_at(s, br.bitpos + lane, lo_a, hi_a, lo_b, hi_b);
+                    const uint32_t e_a = s.lit_lut[lo_a & ((1u << kLitBits) - 1u)], e_b = s.lit_lut[lo_b & ((1u << kLitBits) - 1u)];
+                    auto dist_index = [&](uint32_t lo, uint32_t hi, uint32_t e, uint32_t &len, uint32_t &t, uint32_t &v2) {
+                        const uint32_t l1 = e & 15u, lx = (e >> 4) & 7u;
+                        len = ((e >> 7) & 0xFFu) + 3u + __builtin_amdgcn_ubfe(lo, l1, lx);
+                        t = l1 + lx;                             // <= 20
+                        v2 = __builtin_amdgcn_alignbit(hi, lo, t);  // bits [t, t + 32) of the window: distance code + extra bits <= 28
+                        return v2 & ((1u << kDistBits) - 1u);
+                    };
+                    uint32_t len_a, t_a, v2_a, len_b, t_b, v2_b;
+                    const uint32_t di_a = dist_index(lo_a, hi_a, e_a, len_a, t_a, v2_a), di_b = dist_index(lo_b, hi_b, e_b, len_b, t_b, v2_b);
+                    const uint32_t de_a = s.dist_lut[di_a], de_b = s.dist_lut[di_b];
+                    auto token = [&](uint32_t e, uint32_t de, uint32_t len, uint32_t t, uint32_t v2, uint32_t &kind, uint32_t &tl, uint32_t &val) {
+                        const uint32_t l2 = de & 15u;
+                        uint32_t dbase, dx;
+                        dist_base_extra((de >> 4) & 31u, &dbase, &dx);
+                        const uint32_t dist = dbase + __builtin_amdgcn_ubfe(v2, l2, dx);
+                        const bool bad_n = e & (1u << 13), bad_m = de & (1u << 9);
+                        const uint32_t kind_n = e == 0 ? kSlow : bad_n ? kBad : (e & (1u << 12)) ? kEob : kLit;
+                        const uint32_t tl_n = e == 0 ? 0u : bad_n ? 1u : (e & 15u);
+                        const uint32_t kind_m = de == 0 ? kSlow : bad_m ? kBad : kMatch;
+                        const uint32_t tl_m = de == 0 ? 0u : bad_m ? 1u : t + l2 + dx;  // <= 15 + 5 + 15 + 13 = 48 bits
+                        const bool is_len = e & 0x8000u;
+                        kind = is_len ? kind_m : kind_n;
+                        tl = is_len ? tl_m : tl_n;
+                        val = is_len ? (len | (dist << 16)) : ((e >> 4) & 0xFFu);
+                    };
+                    uint32_t kind_a, tl_a, val_a, kind_b, tl_b, val_b;
+                    token(e_a, de_a, len_a, t_a, v2_a, kind_a, tl_a, val_a);
+                    token(e_b, de_b, len_b, t_b, v2_b, kind_b, tl_b, val_b);
+                    // the real chain from offset 0 (a token for the serial decoder hops out of both windows)
+                    unsigned long long marks_a = 0, marks_b = 0;
+                    uint32_t cur = 0;
+                    {
+                        const uint32_t hop_a = kind_a == kSlow ? 128u : tl_a, hop_b = kind_b == kSlow ? 64u : tl_b;
+                        do {
+                            marks_a |= 1ull << cur;
+                            cur += __builtin_amdgcn_readlane(hop_a, cur);
+                        } while (cur < 64);
+                        cur -= 64;
+                        while (cur < 64) {
+                            marks_b |= 1ull << cur;
+                            cur += __builtin_amdgcn_readlane(hop_b, cur);
+                        }
+                        cur += 64;
+                    }
+                    advance = cur;
+                    const bool real_a = (marks_a >> lane) & 1ull, real_b = (marks_b >> lane) & 1ull;
+                    const unsigned long long m_stop_a = __ballot(real_a && kind_a >= kEob), m_stop_b = __ballot(real_b && kind_b >= kEob);
+                    const uint32_t stop_pos = m_stop_a ? (uint32_t)__ffsll((long long)m_stop_a) - 1
+                                              : m_stop_b ? 64u + (uint32_t)__ffsll((long long)m_stop_b) - 1 : 128u;
+                    const bool live_a = real_a && lane < stop_pos, live_b = real_b && lane + 64u < stop_pos;
+                    const uint32_t olen_a = live_a ? (kind_a == kLit ? 1u : (val_a & 0xFFFFu)) : 0u;
+                    const uint32_t olen_b = live_b ? (kind_b == kLit ? 1u : (val_b & 0xFFFFu)) : 0u;
+                    const uint32_t incl_a = wave_incl_sum_dpp(olen_a);
+                    const uint32_t incl_b = wave_incl_sum_dpp(olen_b) + __builtin_amdgcn_readlane(incl_a, 63);
+                    const uint32_t excl_a = incl_a - olen_a, excl_b = incl_b - olen_b;
+                    const bool keep_a = live_a && excl_a < kStepOut, keep_b = live_b && excl_b < kStepOut;
+                    const unsigned long long m_keep_a = __ballot(keep_a), m_keep_b = __ballot(keep_b);
+                    const unsigned long long m_drop_a = __ballot(live_a) & ~m_keep_a, m_drop_b = __ballot(live_b) & ~m_keep_b;
+                    const uint32_t total = m_keep_b   ? __builtin_amdgcn_readlane(incl_b, 63 - __clzll((long long)m_keep_b))
+                                           : m_keep_a ? __builtin_amdgcn_readlane(incl_a, 63 - __clzll((long long)m_keep_a)) : 0u;
+                    if (pos + total > cap) {
+                        err = 4;
+                        break;
+                    }
+                    if (mb.text_probe) {
+                        const bool ctl_a = keep_a && kind_a == kLit && (val_a < 9u || (val_a > 13u && val_a < 32u) || val_a == 127u);
+                        const bool ctl_b = keep_b && kind_b == kLit && (val_b < 9u || (val_b > 13u && val_b < 32u) || val_b == 127u);
+                        if (__ballot(ctl_a || ctl_b)) {
+                            err = 6;
+                            break;
+                        }
+                    }
+                    const uint32_t hi = pos + total;
+                    if (keep_a && kind_a == kLit) s.win[(pos + excl_a) & kRingMask] = (Elem)val_a;
+                    if (keep_b && kind_b == kLit) s.win[(pos + excl_b) & kRingMask] = (Elem)val_b;
+                    // matches in order, the first window's then the second's (see the one-window form below)
+                    auto matches = [&](bool keep, uint32_t kind, uint32_t val, uint32_t excl) {
+                        const bool is_m = keep && kind == kMatch;
+                        const uint32_t dest_l = pos + excl, len_l = val & 0xFFFFu, dist_l = val >> 16;
+                        if (!SYM && __ballot(is_m && dist_l > dest_l)) {
+                            err = 3;
+                            return;
+                        }
+                        if (InflateLdsT<SYM, RING>::kGlobalWindow && !d_out) return;  // a probing decode copies nothing
+                        const uint32_t src0_l = dest_l - dist_l;
+                        uint32_t cls = 2;
+                        if (dist_l >= len_l && len_l <= 64u && dest_l >= dist_l) {
+                            if (!InflateLdsT<SYM, RING>::kGlobalWindow || src0_l + RING >= hi)
+                                cls = 0;
+                            else if (src0_l + len_l - 1 + RING < hi)
+                                cls = 1;
+                        }
+                        const uint32_t desc_l = cls | (len_l << 2);
+                        unsigned long long m_match = __ballot(is_m);
+                        while (m_match) {
+                            const uint32_t l = (uint32_t)__ffsll((long long)m_match) - 1;
+                            m_match &= m_match - 1;
+                            const uint32_t desc = __builtin_amdgcn_readlane(desc_l, l);
+                            const uint32_t dest = __builtin_amdgcn_readlane(dest_l, l);
+                            const uint32_t len = desc >> 2;
+                            if ((desc & 3u) == 0) {
+                                const uint32_t src0 = __builtin_amdgcn_readlane(src0_l, l);
+                                if (lane < len) {
+                                    const Elem x = s.win[(src0 + lane) & kRingMask];
+                                    s.win[(dest + lane) & kRingMask] = x;
+                                }
+                            } else if ((desc & 3u) == 1) {
+                                const uint32_t src0 = __builtin_amdgcn_readlane(src0_l, l);
+                                if (lane < len) {
+                                    const Elem x = __hip_atomic_load(d_out + mb.out_off + src0 + lane, __ATOMIC_RELAXED,
+                                                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    s.win[(dest + lane) & kRingMask] = x;
+                                }
+                            } else {
+                                copy_match(s, d_out, mb.out_off, dest, len, __builtin_amdgcn_readlane(dist_l, l), hi, lane);
+                            }
+                        }
+                    };
+                    matches(keep_a, kind_a, val_a, excl_a);
+                    if (!err) matches(keep_b, kind_b, val_b, excl_b);
+                    if (err) break;
+                    pos = hi;
+                    if (flushed + 1024 <= pos) flush_segments(s, d_out, mb.out_off, flushed, pos, lane);
+                    if (m_drop_a) {
+                        advance = (uint32_t)__ffsll((long long)m_drop_a) - 1;
+                    } else if (m_drop_b) {
+                        advance = 64u + (uint32_t)__ffsll((long long)m_drop_b) - 1;
+                    } else if (stop_pos < 128) {
+                        const uint32_t sl = stop_pos & 63u;
+                        const uint32_t k = stop_pos < 64 ? __builtin_amdgcn_readlane(kind_a, sl) : __builtin_amdgcn_readlane(kind_b, sl);
+                        if (k == kEob) {
+                            advance = stop_pos + (stop_pos < 64 ? __builtin_amdgcn_readlane(tl_a, sl) : __builtin_amdgcn_readlane(tl_b, sl));
+                            eob = true;
+                        } else if (k == kSlow) {
+                            advance = stop_pos;  // decoded by every lane uniformly below
+                            slow_token = true;
+                        } else {
+                            err = 3;
+                            break;
+                        }
+                    }
+                } else {
+                // lane l decodes the token that would start at bit bitpos + l
+                uint32_t kind, tl, val;
+                spec(peek_at(s, br.bitpos + lane), kind, tl, val);
                 // the real chain from offset 0: one readlane per token marks the token starts ...
                 unsigned long long marks = 0;
                 uint32_t cur = 0;
-                bool slow_token = false;
                 if constexpr (EMIT == 1) {
                     // (a token for the serial decoder hops out of the window: the loop body is six scalar instructions,
                     // and the scalar unit — one per CU, shared by 20 wavefronts — is the busiest one in this kernel)
@@ -585,7 +754,7 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                         cur += t;
                     }
                 }
-                uint32_t advance = cur;
+                advance = cur;
                 if constexpr (EMIT == 1) {
                     // ---- placement by prefix sum ---------------------------------------------------------------
                     const bool real = (marks >> lane) & 1ull;
@@ -731,6 +900,7 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                     }
                     m_other &= m_other - 1;
                     from = upto + 1;
+                }
                 }
                 }
                 br.bitpos += advance;
