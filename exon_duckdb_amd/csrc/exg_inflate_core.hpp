@@ -25,6 +25,7 @@ struct InflateStatus {
 static constexpr int kWinBytes = 32768;
 static constexpr int kInRing = 1024;                 // two chunks of the compressed input
 static constexpr int kInChunk = kInRing / 2, kInChunkBitsLog2 = 12;  // 512 B = 4096 bits
+static constexpr int kInMirror = 64;
 static constexpr int kLitBits = 10, kDistBits = 9;
 
 // SYM = false: the window holds bytes (a gzip member decoded from its first bit).
@@ -40,8 +41,8 @@ struct InflateLdsT {
     static_assert(RING >= 2048 && RING <= kWinBytes && (RING & (RING - 1)) == 0, "ring: power of two, >= 1 KiB flush + a match");
     static constexpr uint32_t kRing = RING;
     static constexpr bool kGlobalWindow = RING < kWinBytes;
-    Elem win[kRing];
-    uint8_t in[kInRing];
+    Elem win[kRing + 16 / sizeof(Elem)];  // + a spare element: where the lanes without a literal store theirs
+    uint8_t in[kInRing + kInMirror];  // + the first bytes of the ring again: a window read never wraps
     // Primary tables, 0 = code longer than the table (or unused).  The entries carry what the token needs, so a
     // decode is peek -> lit_lut -> dist_lut, three dependent LDS levels instead of five:
     //   lit_lut  literal: bits 0-3 code length, 4-11 byte, 12 end-of-block, 13 invalid symbol
@@ -66,6 +67,17 @@ static __device__ __constant__ unsigned char kDistExtra[30] = {0, 0, 0, 0, 1, 1,
 static __device__ __constant__ unsigned char kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 __device__ __forceinline__ uint32_t sgpr(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+// per lane: bit `lane` of a wave-uniform mask ? if1 : if0 — one v_cndmask with the mask as its scalar operand
+__device__ __forceinline__ uint32_t mask_sel(unsigned long long m, uint32_t if0, uint32_t if1) {
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if0), "v"(if1), "s"(m));
+    return r;
+}
+__device__ __forceinline__ uint32_t mask_sel0(unsigned long long m, uint32_t if1) {
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(if1), "s"(m));
+    return r;
+}
 
 // ---- bit input: absolute bit position + a 2 KiB LDS ring of the compressed bytes --------------------------
 struct BitIn {
@@ -100,6 +112,7 @@ __device__ __forceinline__ void stage_chunk(L &s, const BitIn &br, uint32_t c, u
     uint2 v = make_uint2(0, 0);
     if (off < ((br.limit + 15) & ~15u)) v = *reinterpret_cast<const uint2 *>(br.g0 + off);
     *reinterpret_cast<uint2 *>(s.in + ((c & 1) * kInChunk + lane * 8)) = v;
+    if (!(c & 1) && lane < kInMirror / 8) *reinterpret_cast<uint2 *>(s.in + (kInRing + lane * 8)) = v;
 }
 
 // keep the chunk that holds the current byte and the next one staged (reads go up to ~20 bytes ahead)
@@ -126,19 +139,20 @@ __device__ __forceinline__ unsigned long long peek_at(const L &s, unsigned long 
     if (sh) v |= (unsigned long long)w2 << (64 - sh);
     return v;
 }
-// 128 bits starting at absolute bit `o` (per lane), as two 64-bit windows (lo, hi): five dwords, four funnel shifts
-template <class L>
-__device__ __forceinline__ void peek2_at(const L &s, unsigned long long o, uint32_t &lo_a, uint32_t &hi_a, uint32_t &lo_b, uint32_t &hi_b) {
-    const uint32_t byte = (uint32_t)(o >> 3);
-    const uint32_t a = byte & ~3u;
-    uint32_t w[5];
+// NW x 64 bits starting at bit `o` (per lane; the low 32 bits of the absolute position), as 64-bit windows (lo, hi): 2 NW + 1 dwords, 2 NW funnel shifts
+template <int NW, class L>
+__device__ __forceinline__ void peekn_at(const L &s, uint32_t o, uint32_t (&lo)[NW], uint32_t (&hi)[NW]) {
+    static_assert(4 * (2 * NW + 1) <= kInMirror + 4, "the mirror covers one window read");
+    const uint32_t a = (o >> 3) & (kInRing - 4);  // (the ring's size in bits divides 2^32)
+    uint32_t w[2 * NW + 1];
 #pragma unroll
-    for (int i = 0; i < 5; i++) w[i] = *reinterpret_cast<const uint32_t *>(s.in + ((a + 4 * i) & (kInRing - 1)));
-    const uint32_t sh = 8 * (byte & 3u) + (uint32_t)(o & 7);  // 0..31
-    lo_a = __builtin_amdgcn_alignbit(w[1], w[0], sh);
-    hi_a = __builtin_amdgcn_alignbit(w[2], w[1], sh);
-    lo_b = __builtin_amdgcn_alignbit(w[3], w[2], sh);
-    hi_b = __builtin_amdgcn_alignbit(w[4], w[3], sh);
+    for (int i = 0; i < 2 * NW + 1; i++) w[i] = *reinterpret_cast<const uint32_t *>(s.in + a + 4 * i);
+    const uint32_t sh = o & 31u;
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+        lo[k] = __builtin_amdgcn_alignbit(w[2 * k + 1], w[2 * k], sh);
+        hi[k] = __builtin_amdgcn_alignbit(w[2 * k + 2], w[2 * k + 1], sh);
+    }
 }
 template <class L>
 __device__ __forceinline__ unsigned long long peek(L &s, BitIn &br, uint32_t lane) {
@@ -577,96 +591,122 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                 };
                 uint32_t advance;
                 bool slow_token = false;
-                if constexpr (EMIT == 2) {
-                    // ---- 128 bit offsets per step: lane l decodes the tokens that would start at bits l and 64 + l.  What a
-                    // step costs besides its tokens (staging check, window reads, ballots, the scan, the flush test and most of
-                    // all the dependent LDS round trips window -> table -> table -> ring) is paid once per 16 input bytes
-                    // Both windows go through the tables side by side and without branches (every lane looks a distance up,
-                    // a literal's lookup is dropped by a select): the LDS round trips of the two overlap.  All of it is 32-bit
-                    // work: a token's code and extra bits lie in the low 48 bits of its window
-                    uint32_t lo_a, hi_a, lo_b, hi_b;
-                    peek2_at(s, br.bitpos + lane, lo_a, hi_a, lo_b, hi_b);
-                    const uint32_t e_a = s.lit_lut[lo_a & ((1u << kLitBits) - 1u)], e_b = s.lit_lut[lo_b & ((1u << kLitBits) - 1u)];
-                    auto dist_index = [&](uint32_t lo, uint32_t hi, uint32_t e, uint32_t &len, uint32_t &t, uint32_t &v2) {
-                        const uint32_t l1 = e & 15u, lx = (e >> 4) & 7u;
-                        len = ((e >> 7) & 0xFFu) + 3u + __builtin_amdgcn_ubfe(lo, l1, lx);
-                        t = l1 + lx;                             // <= 20
-                        v2 = __builtin_amdgcn_alignbit(hi, lo, t);  // bits [t, t + 32) of the window: distance code + extra bits <= 28
-                        return v2 & ((1u << kDistBits) - 1u);
-                    };
-                    uint32_t len_a, t_a, v2_a, len_b, t_b, v2_b;
-                    const uint32_t di_a = dist_index(lo_a, hi_a, e_a, len_a, t_a, v2_a), di_b = dist_index(lo_b, hi_b, e_b, len_b, t_b, v2_b);
-                    const uint32_t de_a = s.dist_lut[di_a], de_b = s.dist_lut[di_b];
-                    auto token = [&](uint32_t e, uint32_t de, uint32_t len, uint32_t t, uint32_t v2, uint32_t &kind, uint32_t &tl, uint32_t &val) {
-                        const uint32_t l2 = de & 15u;
-                        uint32_t dbase, dx;
-                        dist_base_extra((de >> 4) & 31u, &dbase, &dx);
-                        const uint32_t dist = dbase + __builtin_amdgcn_ubfe(v2, l2, dx);
-                        const bool bad_n = e & (1u << 13), bad_m = de & (1u << 9);
-                        const uint32_t kind_n = e == 0 ? kSlow : bad_n ? kBad : (e & (1u << 12)) ? kEob : kLit;
-                        const uint32_t tl_n = e == 0 ? 0u : bad_n ? 1u : (e & 15u);
-                        const uint32_t kind_m = de == 0 ? kSlow : bad_m ? kBad : kMatch;
-                        const uint32_t tl_m = de == 0 ? 0u : bad_m ? 1u : t + l2 + dx;  // <= 15 + 5 + 15 + 13 = 48 bits
-                        const bool is_len = e & 0x8000u;
-                        kind = is_len ? kind_m : kind_n;
-                        tl = is_len ? tl_m : tl_n;
-                        val = is_len ? (len | (dist << 16)) : ((e >> 4) & 0xFFu);
-                    };
-                    uint32_t kind_a, tl_a, val_a, kind_b, tl_b, val_b;
-                    token(e_a, de_a, len_a, t_a, v2_a, kind_a, tl_a, val_a);
-                    token(e_b, de_b, len_b, t_b, v2_b, kind_b, tl_b, val_b);
-                    // the real chain from offset 0 (a token for the serial decoder hops out of both windows)
-                    unsigned long long marks_a = 0, marks_b = 0;
-                    uint32_t cur = 0;
-                    {
-                        const uint32_t hop_a = kind_a == kSlow ? 128u : tl_a, hop_b = kind_b == kSlow ? 64u : tl_b;
-                        do {
-                            marks_a |= 1ull << cur;
-                            cur += __builtin_amdgcn_readlane(hop_a, cur);
-                        } while (cur < 64);
-                        cur -= 64;
-                        while (cur < 64) {
-                            marks_b |= 1ull << cur;
-                            cur += __builtin_amdgcn_readlane(hop_b, cur);
-                        }
-                        cur += 64;
+                if constexpr (EMIT >= 2) {
+                    // ---- NW x 64 bit offsets per step: lane l decodes the tokens that would start at bits l, 64 + l, ...  What
+                    // a step costs besides its tokens (staging check, window reads, the flush test and most of all the dependent
+                    // LDS round trips window -> table -> table -> ring) is paid once per NW x 8 input bytes.
+                    // The windows go through the tables side by side and without branches (every lane looks a distance up, a
+                    // literal's lookup is dropped by a select): their LDS round trips overlap.  All of it is 32-bit work (a
+                    // token's code and extra bits lie in the low 48 bits of its window), and what is wave-uniform — which
+                    // lanes are token starts, live, kept — stays in scalar masks (mask_sel) instead of per-lane flags:
+                    // the vector unit is the busiest one in this kernel
+                    constexpr int NW = EMIT;
+                    uint32_t lo[NW], hi[NW], e[NW], de[NW], tt[NW], v2[NW];
+                    peekn_at<NW>(s, (uint32_t)br.bitpos + lane, lo, hi);
+#pragma unroll
+                    for (int k = 0; k < NW; k++) e[k] = s.lit_lut[lo[k] & ((1u << kLitBits) - 1u)];
+#pragma unroll
+                    for (int k = 0; k < NW; k++) {
+                        tt[k] = (e[k] & 15u) + ((e[k] >> 4) & 7u);              // code + extra bits of a length: <= 20
+                        v2[k] = __builtin_amdgcn_alignbit(hi[k], lo[k], tt[k]);  // bits [t, t + 32): distance code + extra bits <= 28
+                        de[k] = s.dist_lut[v2[k] & ((1u << kDistBits) - 1u)];
                     }
-                    advance = cur;
-                    const bool real_a = (marks_a >> lane) & 1ull, real_b = (marks_b >> lane) & 1ull;
-                    const unsigned long long m_stop_a = __ballot(real_a && kind_a >= kEob), m_stop_b = __ballot(real_b && kind_b >= kEob);
-                    const uint32_t stop_pos = m_stop_a ? (uint32_t)__ffsll((long long)m_stop_a) - 1
-                                              : m_stop_b ? 64u + (uint32_t)__ffsll((long long)m_stop_b) - 1 : 128u;
-                    const bool live_a = real_a && lane < stop_pos, live_b = real_b && lane + 64u < stop_pos;
-                    const uint32_t olen_a = live_a ? (kind_a == kLit ? 1u : (val_a & 0xFFFFu)) : 0u;
-                    const uint32_t olen_b = live_b ? (kind_b == kLit ? 1u : (val_b & 0xFFFFu)) : 0u;
-                    const uint32_t incl_a = wave_incl_sum_dpp(olen_a);
-                    const uint32_t incl_b = wave_incl_sum_dpp(olen_b) + __builtin_amdgcn_readlane(incl_a, 63);
-                    const uint32_t excl_a = incl_a - olen_a, excl_b = incl_b - olen_b;
-                    const bool keep_a = live_a && excl_a < kStepOut, keep_b = live_b && excl_b < kStepOut;
-                    const unsigned long long m_keep_a = __ballot(keep_a), m_keep_b = __ballot(keep_b);
-                    const unsigned long long m_drop_a = __ballot(live_a) & ~m_keep_a, m_drop_b = __ballot(live_b) & ~m_keep_b;
-                    const uint32_t total = m_keep_b   ? __builtin_amdgcn_readlane(incl_b, 63 - __clzll((long long)m_keep_b))
-                                           : m_keep_a ? __builtin_amdgcn_readlane(incl_a, 63 - __clzll((long long)m_keep_a)) : 0u;
+                    uint32_t tl[NW], val[NW], olen1[NW];
+                    unsigned long long len_mask[NW], stop_mask[NW];
+#pragma unroll
+                    for (int k = 0; k < NW; k++) {
+                        const uint32_t l1 = e[k] & 15u, lx = (e[k] >> 4) & 7u, l2 = de[k] & 15u;
+                        // distance symbol 2 h + b: h = 0 -> base b + 1, no extra bits; else base ((2 | b) << (h - 1)) + 1
+                        const uint32_t h = (de[k] >> 5) & 15u, b = (de[k] >> 4) & 1u;
+                        const uint32_t dx = __builtin_elementwise_sub_sat(h, 1u);
+                        const uint32_t dist = (((min(h, 1u) << 1) | b) << dx) + __builtin_amdgcn_ubfe(v2[k], l2, dx) + 1u;
+                        const uint32_t len = ((e[k] >> 7) & 0xFFu) + __builtin_amdgcn_ubfe(lo[k], l1, lx) + 3u;
+                        const bool is_len = e[k] & 0x8000u;
+                        len_mask[k] = __ballot(is_len);
+                        val[k] = is_len ? (len | (dist << 16)) : ((e[k] >> 4) & 0xFFu);
+                        olen1[k] = is_len ? len : 1u;
+                        // every lane hops at least one bit (an entry of 0 has no length): the walk runs on through a token it
+                        // cannot use, what lies behind the first such token is dropped below
+                        tl[k] = max(is_len ? tt[k] + l2 + dx : l1, 1u);  // <= 15 + 5 + 15 + 13 = 48 bits
+                        // tokens that end the step: end-of-block, invalid symbols (bits 12 / 13 of a literal entry, bit 9 of a
+                        // distance entry) and codes longer than the tables (entry 0).  Valid entries are 1 .. 0xFFF / 1 .. 0x1FF
+                        const uint32_t y = is_len ? de[k] << 3 : e[k];
+                        stop_mask[k] = __ballot(y - 1u >= 0xFFFu);
+                    }
+                    // The real chain from offset 0, window after window.  The walk is the scalar unit's main load (~15 tokens
+                    // per window), so its loop is written out: the position is kept as cur - 64 (mod 2^32; bit set and lane
+                    // select use the low six bits), so that the add's carry is the exit test — three scalar instructions and
+                    // the readlane per token
+                    unsigned long long marks[NW];
+                    uint32_t cur = 0;
+#pragma unroll
+                    for (int k = 0; k < NW; k++) {
+                        marks[k] = 0;
+                        cur -= 64;
+                        if ((int32_t)cur < 0) {
+                            uint32_t t;
+                            asm volatile(
+                                "1:\n\t"
+                                "s_bitset1_b64 %[m], %[c]\n\t"
+                                "v_readlane_b32 %[t], %[hop], %[c]\n\t"
+                                "s_add_u32 %[c], %[c], %[t]\n\t"
+                                "s_cbranch_scc0 1b"
+                                : [m] "+s"(marks[k]), [c] "+s"(cur), [t] "=&s"(t)
+                                : [hop] "v"(tl[k])
+                                : "scc");
+                        }
+                    }
+                    advance = cur + 64u * NW;
+                    // ---- placement by prefix sum over all windows
+                    uint32_t stop_pos = 64u * NW;
+#pragma unroll
+                    for (int k = NW - 1; k >= 0; k--) {
+                        const unsigned long long m_stop = marks[k] & stop_mask[k];
+                        if (m_stop) stop_pos = 64u * k + (uint32_t)__ffsll((long long)m_stop) - 1;
+                    }
+                    uint32_t excl[NW], olen[NW], incl[NW], carry = 0, total = 0;
+                    unsigned long long live[NW], keep[NW], m_drop[NW];
+#pragma unroll
+                    for (int k = 0; k < NW; k++) {
+                        // literals and matches in front of the first token that ends the step
+                        const uint32_t n = stop_pos > 64u * k ? stop_pos - 64u * k : 0u;
+                        live[k] = marks[k] & (n >= 64 ? ~0ull : (1ull << n) - 1ull);
+                        olen[k] = mask_sel0(live[k], olen1[k]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < NW; k++) incl[k] = wave_incl_sum_dpp(olen[k]);  // (side by side: a DPP step waits for the one before)
+#pragma unroll
+                    for (int k = 0; k < NW; k++) {
+                        incl[k] += carry;
+                        carry = __builtin_amdgcn_readlane(incl[k], 63);
+                        excl[k] = incl[k] - olen[k];
+                        keep[k] = live[k] & __ballot(excl[k] < kStepOut);
+                        m_drop[k] = live[k] & ~keep[k];  // pushed to the next step
+                        if (keep[k]) total = __builtin_amdgcn_readlane(incl[k], 63 - __clzll((long long)keep[k]));
+                    }
                     if (pos + total > cap) {
                         err = 4;
                         break;
                     }
                     if (mb.text_probe) {
-                        const bool ctl_a = keep_a && kind_a == kLit && (val_a < 9u || (val_a > 13u && val_a < 32u) || val_a == 127u);
-                        const bool ctl_b = keep_b && kind_b == kLit && (val_b < 9u || (val_b > 13u && val_b < 32u) || val_b == 127u);
-                        if (__ballot(ctl_a || ctl_b)) {
+                        bool ctl = false;
+#pragma unroll
+                        for (int k = 0; k < NW; k++)
+                            ctl |= (((keep[k] & ~len_mask[k]) >> lane) & 1ull) && (val[k] < 9u || (val[k] > 13u && val[k] < 32u) || val[k] == 127u);
+                        if (__ballot(ctl)) {
                             err = 6;
                             break;
                         }
                     }
-                    const uint32_t hi = pos + total;
-                    if (keep_a && kind_a == kLit) s.win[(pos + excl_a) & kRingMask] = (Elem)val_a;
-                    if (keep_b && kind_b == kLit) s.win[(pos + excl_b) & kRingMask] = (Elem)val_b;
-                    // matches in order, the first window's then the second's (see the one-window form below)
-                    auto matches = [&](bool keep, uint32_t kind, uint32_t val, uint32_t excl) {
-                        const bool is_m = keep && kind == kMatch;
-                        const uint32_t dest_l = pos + excl, len_l = val & 0xFFFFu, dist_l = val >> 16;
-                        if (!SYM && __ballot(is_m && dist_l > dest_l)) {
+                    const uint32_t hi_pos = pos + total;
+                    // all literals in one store per window (the other lanes write to a spare element behind the ring)
+#pragma unroll
+                    for (int k = 0; k < NW; k++)
+                        s.win[mask_sel(keep[k] & ~len_mask[k], RING, (pos + excl[k]) & kRingMask)] = (Elem)val[k];
+                    // matches in order, window after window (see the one-window form below); most windows have none
+                    auto matches = [&](unsigned long long m_match, uint32_t val_k, uint32_t excl_k) {
+                        const uint32_t dest_l = pos + excl_k, len_l = val_k & 0xFFFFu, dist_l = val_k >> 16;
+                        if (!SYM && (m_match & __ballot(dist_l > dest_l))) {
                             err = 3;
                             return;
                         }
@@ -674,55 +714,67 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                         const uint32_t src0_l = dest_l - dist_l;
                         uint32_t cls = 2;
                         if (dist_l >= len_l && len_l <= 64u && dest_l >= dist_l) {
-                            if (!InflateLdsT<SYM, RING>::kGlobalWindow || src0_l + RING >= hi)
+                            if (!InflateLdsT<SYM, RING>::kGlobalWindow || src0_l + RING >= hi_pos)
                                 cls = 0;
-                            else if (src0_l + len_l - 1 + RING < hi)
+                            else if (src0_l + len_l - 1 + RING < hi_pos)
                                 cls = 1;
                         }
                         const uint32_t desc_l = cls | (len_l << 2);
-                        unsigned long long m_match = __ballot(is_m);
                         while (m_match) {
                             const uint32_t l = (uint32_t)__ffsll((long long)m_match) - 1;
                             m_match &= m_match - 1;
                             const uint32_t desc = __builtin_amdgcn_readlane(desc_l, l);
                             const uint32_t dest = __builtin_amdgcn_readlane(dest_l, l);
-                            const uint32_t len = desc >> 2;
+                            const uint32_t mlen = desc >> 2;
                             if ((desc & 3u) == 0) {
                                 const uint32_t src0 = __builtin_amdgcn_readlane(src0_l, l);
-                                if (lane < len) {
+                                if (lane < mlen) {
                                     const Elem x = s.win[(src0 + lane) & kRingMask];
                                     s.win[(dest + lane) & kRingMask] = x;
                                 }
                             } else if ((desc & 3u) == 1) {
                                 const uint32_t src0 = __builtin_amdgcn_readlane(src0_l, l);
-                                if (lane < len) {
+                                if (lane < mlen) {
                                     const Elem x = __hip_atomic_load(d_out + mb.out_off + src0 + lane, __ATOMIC_RELAXED,
                                                                      __HIP_MEMORY_SCOPE_WORKGROUP);
                                     s.win[(dest + lane) & kRingMask] = x;
                                 }
                             } else {
-                                copy_match(s, d_out, mb.out_off, dest, len, __builtin_amdgcn_readlane(dist_l, l), hi, lane);
+                                copy_match(s, d_out, mb.out_off, dest, mlen, __builtin_amdgcn_readlane(dist_l, l), hi_pos, lane);
                             }
                         }
                     };
-                    matches(keep_a, kind_a, val_a, excl_a);
-                    if (!err) matches(keep_b, kind_b, val_b, excl_b);
+#pragma unroll
+                    for (int k = 0; k < NW; k++) {
+                        const unsigned long long m_match = keep[k] & len_mask[k];
+                        if (m_match && !err) matches(m_match, val[k], excl[k]);
+                    }
                     if (err) break;
-                    pos = hi;
+                    pos = hi_pos;
                     if (flushed + 1024 <= pos) flush_segments(s, d_out, mb.out_off, flushed, pos, lane);
-                    if (m_drop_a) {
-                        advance = (uint32_t)__ffsll((long long)m_drop_a) - 1;
-                    } else if (m_drop_b) {
-                        advance = 64u + (uint32_t)__ffsll((long long)m_drop_b) - 1;
-                    } else if (stop_pos < 128) {
-                        const uint32_t sl = stop_pos & 63u;
-                        const uint32_t k = stop_pos < 64 ? __builtin_amdgcn_readlane(kind_a, sl) : __builtin_amdgcn_readlane(kind_b, sl);
-                        if (k == kEob) {
-                            advance = stop_pos + (stop_pos < 64 ? __builtin_amdgcn_readlane(tl_a, sl) : __builtin_amdgcn_readlane(tl_b, sl));
-                            eob = true;
-                        } else if (k == kSlow) {
-                            advance = stop_pos;  // decoded by every lane uniformly below
+                    bool dropped = false;
+#pragma unroll
+                    for (int k = NW - 1; k >= 0; k--)
+                        if (m_drop[k]) {
+                            advance = 64u * k + (uint32_t)__ffsll((long long)m_drop[k]) - 1;
+                            dropped = true;
+                        }
+                    if (!dropped && stop_pos < 64u * NW) {
+                        // what ended the step: the entries of that token
+                        const uint32_t sl = stop_pos & 63u, sk = stop_pos >> 6;
+                        uint32_t e_s = 0, de_s = 0;
+#pragma unroll
+                        for (int k = 0; k < NW; k++)
+                            if (sk == (uint32_t)k) {
+                                e_s = __builtin_amdgcn_readlane(e[k], sl);
+                                de_s = __builtin_amdgcn_readlane(de[k], sl);
+                            }
+                        if (e_s & 0x8000u ? de_s == 0 : e_s == 0) {
+                            advance = stop_pos;  // a code longer than the tables: decoded by every lane uniformly below
                             slow_token = true;
+                        } else if (!(e_s & 0x8000u) && (e_s & 0x3000u) == 0x1000u) {
+                            advance = stop_pos + (e_s & 15u);
+                            eob = true;
                         } else {
                             err = 3;
                             break;
