@@ -19,10 +19,6 @@
 
 #include "exg_inflate_core.hpp"
 
-#ifndef EXG_INFLATE_EMIT
-#define EXG_INFLATE_EMIT 2  // 128 bit offsets per speculative step (1: 64)
-#endif
-
 namespace exg {
 template <uint32_t RING, int EMIT>
 __global__ __launch_bounds__(64, RING <= 2048 ? 5 : 1) void k_inflate(const uint8_t *__restrict__ d_comp, uint8_t *d_out,
@@ -75,15 +71,19 @@ extern "C" int exg_inflate_members(const void *d_comp, void *d_out, const exg_in
 #ifdef EXG_DEV_PROBE
     // development builds only (tools/ab_inflate.sh): the ring size, the first form of the emit step, a decode that keeps nothing
     static const int ring = getenv("EXG_INFLATE_RING") ? atoi(getenv("EXG_INFLATE_RING")) : 2048;
-    static const int emit = getenv("EXG_INFLATE_EMIT") ? atoi(getenv("EXG_INFLATE_EMIT")) : 1;
+    static const int emit = getenv("EXG_INFLATE_EMIT") ? atoi(getenv("EXG_INFLATE_EMIT")) : EXG_INFLATE_EMIT;
     void *out = getenv("EXG_INFLATE_NOOUT") ? nullptr : d_out;
     if (emit == 0) {
         EXG_LAUNCH_INFLATE(2048, 0, out);
+    } else if (emit == 1) {
+        EXG_LAUNCH_INFLATE(2048, 1, out);
+    } else if (emit == 2) {
+        EXG_LAUNCH_INFLATE(2048, 2, out);
     } else {
         switch (ring) {
-            case 4096: EXG_LAUNCH_INFLATE(4096, 1, out); break;
-            case 32768: EXG_LAUNCH_INFLATE(32768, 1, out); break;
-            default: EXG_LAUNCH_INFLATE(2048, 1, out); break;
+            case 4096: EXG_LAUNCH_INFLATE(4096, 4, out); break;
+            case 32768: EXG_LAUNCH_INFLATE(32768, 4, out); break;
+            default: EXG_LAUNCH_INFLATE(2048, 4, out); break;
         }
     }
 #else

@@ -405,10 +405,16 @@ struct InflateJobStatus {
     unsigned long long end_bit;    // bit after the last decoded block, relative to comp_off
 };
 
-// EMIT = 1: the tokens of a step are placed by a prefix sum over their output lengths (all literals in one store,
-//           then the matches in order); EMIT = 0: literal runs and matches one after the other (the first form, kept
-//           as the A/B partner).
-template <bool SYM, uint32_t RING = kWinBytes, int EMIT = 1>
+// EMIT = 2, 4: EMIT x 64 bit offsets per speculative step, two or four windows per lane (4: +2.5 % on FASTQ and VCF
+//           over 2; input that deflates 600-fold — where a step's output limit drops most of what it decoded — runs
+//           at 256 instead of 380 GB/s of output, far above every stage around it);
+// EMIT = 1: one window, the tokens of a step placed by a prefix sum over their output lengths (all literals in one
+//           store, then the matches in order); EMIT = 0: literal runs and matches one after the other (the first
+//           form).  Both kept as A/B partners (-DEXG_INFLATE_EMIT=...).
+#ifndef EXG_INFLATE_EMIT
+#define EXG_INFLATE_EMIT 4
+#endif
+template <bool SYM, uint32_t RING = kWinBytes, int EMIT = EXG_INFLATE_EMIT>
 __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uint8_t *__restrict__ d_comp,
                                             typename InflateLdsT<SYM, RING>::Elem *d_out, const InflateJob mb,
                                             InflateJobStatus *st_out) {

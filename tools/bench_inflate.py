@@ -1,11 +1,22 @@
-"""BGZF inflate alone (for profiling): 33 MB of FASTQ-150 in 65 280-byte members, replicated 32x = 1 GB of output."""
+"""BGZF inflate alone (for profiling): 33 MB of FASTQ-150 (INFLATE_DATA: vcf, fasta, zeros) in 65 280-byte members, replicated
+INFLATE_K (32) times = 1 GB of output."""
 import ctypes as C, json, os, struct, sys, zlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from exon_duckdb_amd import abi, device, load_library
 lib = load_library()
 torch.cuda.set_device(0)
-sample = device.synth_fastq(332 * 100_000)[: 332 * 100_000].cpu().numpy().tobytes()
+kind = os.environ.get("INFLATE_DATA", "fastq")   # fastq | vcf | fasta | zeros (how the step copes with other token mixes)
+if kind == "vcf":
+    t, n = device.synth_vcf(600_000)
+    sample = t[:n].cpu().numpy().tobytes()
+elif kind == "fasta":
+    t, n = device.synth_fasta(20_000)
+    sample = t[:n].cpu().numpy().tobytes()
+elif kind == "zeros":
+    sample = bytes(32 << 20)
+else:
+    sample = device.synth_fastq(332 * 100_000)[: 332 * 100_000].cpu().numpy().tobytes()
 members, comp, pos = [], [], 0
 for i in range(0, len(sample), 65280):
     chunk = sample[i:i + 65280]
@@ -40,4 +51,4 @@ torch.cuda.synchronize()
 ms = sorted(x.elapsed_time(y) for x, y in ev)[1]
 if not os.environ.get("EXG_INFLATE_NOOUT"):  # (development build: a decode that keeps nothing)
     assert bytes(d_out[:U].cpu().numpy().tobytes()) == sample
-print(json.dumps({"members": len(all_members), "out_bytes": U * K, "ms": ms, "out_GBps": U * K / ms / 1e6}))
+print(json.dumps({"data": kind, "ratio": round(U / Cn, 2), "members": len(all_members), "out_bytes": U * K, "ms": ms, "out_GBps": U * K / ms / 1e6}))
