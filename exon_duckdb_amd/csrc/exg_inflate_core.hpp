@@ -656,7 +656,20 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                                 "s_bitset1_b64 %[m], %[c]\n\t"
                                 "v_readlane_b32 %[t], %[hop], %[c]\n\t"
                                 "s_add_u32 %[c], %[c], %[t]\n\t"
-                                "s_cbranch_scc0 1b"
+                                "s_cbranch_scc1 2f\n\t"
+                                "s_bitset1_b64 %[m], %[c]\n\t"
+                                "v_readlane_b32 %[t], %[hop], %[c]\n\t"
+                                "s_add_u32 %[c], %[c], %[t]\n\t"
+                                "s_cbranch_scc1 2f\n\t"
+                                "s_bitset1_b64 %[m], %[c]\n\t"
+                                "v_readlane_b32 %[t], %[hop], %[c]\n\t"
+                                "s_add_u32 %[c], %[c], %[t]\n\t"
+                                "s_cbranch_scc1 2f\n\t"
+                                "s_bitset1_b64 %[m], %[c]\n\t"
+                                "v_readlane_b32 %[t], %[hop], %[c]\n\t"
+                                "s_add_u32 %[c], %[c], %[t]\n\t"
+                                "s_cbranch_scc0 1b\n"
+                                "2:"
                                 : [m] "+s"(marks[k]), [c] "+s"(cur), [t] "=&s"(t)
                                 : [hop] "v"(tl[k])
                                 : "scc");
