@@ -21,11 +21,11 @@
 
 namespace exg {
 template <uint32_t RING, int EMIT>
-__global__ __launch_bounds__(64, RING <= 2048 ? 5 : 1) void k_inflate(const uint8_t *__restrict__ d_comp, uint8_t *d_out,
+__global__ __launch_bounds__(64, RING <= 2048 ? 6 : 1) void k_inflate(const uint8_t *__restrict__ d_comp, uint8_t *d_out,
                                                 const InflateMember *__restrict__ members, InflateStatus *status,
                                                 uint32_t n_members) {
     __shared__ __attribute__((aligned(16))) InflateLdsT<false, RING> s;
-    __shared__ InflateJobStatus s_st;
+    InflateJobStatus s_st;  // written and read by lane 0 only (registers: LDS decides how many members a CU decodes at once)
     for (uint32_t m = blockIdx.x; m < n_members; m += gridDim.x) {
         const InflateMember mb = members[m];
         InflateJob jb;
@@ -66,9 +66,11 @@ extern "C" int exg_inflate_members(const void *d_comp, void *d_out, const exg_in
     }
     uint32_t grid = n_members < 8192 ? n_members : 8192;
 #define EXG_LAUNCH_INFLATE(R, E, OUT)                                                                                  \
-    hipLaunchKernelGGL((exg::k_inflate<R, E>), dim3(grid), dim3(64), 0, (hipStream_t)stream, (const uint8_t *)d_comp,  \
+    hipLaunchKernelGGL((exg::k_inflate<R, E>), dim3(grid), dim3(64), dyn_lds, (hipStream_t)stream, (const uint8_t *)d_comp,  \
                        (uint8_t *)(OUT), (const exg::InflateMember *)d_members, (exg::InflateStatus *)d_status, n_members)
+    unsigned dyn_lds = 0;
 #ifdef EXG_DEV_PROBE
+    dyn_lds = getenv("EXG_INFLATE_DYNLDS") ? atoi(getenv("EXG_INFLATE_DYNLDS")) : 0;  // (occupancy experiments)
     // development builds only (tools/ab_inflate.sh): the ring size, the first form of the emit step, a decode that keeps nothing
     static const int ring = getenv("EXG_INFLATE_RING") ? atoi(getenv("EXG_INFLATE_RING")) : 2048;
     static const int emit = getenv("EXG_INFLATE_EMIT") ? atoi(getenv("EXG_INFLATE_EMIT")) : EXG_INFLATE_EMIT;

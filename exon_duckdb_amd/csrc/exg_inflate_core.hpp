@@ -23,9 +23,9 @@ struct InflateStatus {
 };
 
 static constexpr int kWinBytes = 32768;
-static constexpr int kInRing = 1024;                 // two chunks of the compressed input
-static constexpr int kInChunk = kInRing / 2, kInChunkBitsLog2 = 12;  // 512 B = 4096 bits
-static constexpr int kInMirror = 64;
+static constexpr int kInRing = 512;                  // two chunks of the compressed input
+static constexpr int kInChunk = kInRing / 2, kInChunkBitsLog2 = 11;  // 256 B = 2048 bits
+static constexpr int kInMirror = 40;
 static constexpr int kLitBits = 10, kDistBits = 9;
 
 // SYM = false: the window holds bytes (a gzip member decoded from its first bit).
@@ -52,9 +52,16 @@ struct InflateLdsT {
     //            (the code-length alphabet of a dynamic header borrows it as a plain u16 table)
     uint16_t lit_lut[1 << kLitBits];
     uint16_t dist_lut[1 << kDistBits];
-    uint16_t lit_sorted[288], dist_sorted[32];   // symbols ordered by (length, symbol) — canonical decode
+    // lit_sorted / dist_sorted: symbols ordered by (length, symbol) — canonical decode of the codes longer than the tables.
+    // lens: code lengths while a block header is read — [0,288) literal/length, [288,320) distance; [32,348) scratch while a
+    // dynamic header is read.  They share their storage with lit_sorted (LDS decides how many members a CU decodes at once):
+    // build_table reads all the lengths before it writes, and the distance table is built first
+    union {
+        uint16_t lit_sorted[288];
+        uint8_t lens[384];
+    };
+    uint16_t dist_sorted[32];
     uint16_t lit_count[16], dist_count[16];
-    uint8_t lens[384];  // [0,288) literal/length, [288,320) distance; [32,348) scratch while a dynamic header is read
 };
 
 static __device__ __constant__ unsigned short kLenBase[29] = {3,  4,  5,  6,  7,  8,  9,  10, 11,  13,  15,  17,  19,  23, 27,
@@ -68,12 +75,19 @@ static __device__ __constant__ unsigned char kClOrder[19] = {16, 17, 18, 0, 8, 7
 
 __device__ __forceinline__ uint32_t sgpr(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
 // per lane: bit `lane` of a wave-uniform mask ? if1 : if0 — one v_cndmask with the mask as its scalar operand
+// (readfirstlane: free where the compiler knows the mask to be uniform; where it does not — a decode inside a loop whose
+// exit it takes for divergent — it is what puts the mask into scalar registers)
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long m) {
+    return ((unsigned long long)sgpr((uint32_t)(m >> 32)) << 32) | sgpr((uint32_t)m);  // (the builtin returns int: sgpr() is unsigned)
+}
 __device__ __forceinline__ uint32_t mask_sel(unsigned long long m, uint32_t if0, uint32_t if1) {
+    m = uniform64(m);
     uint32_t r;
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if0), "v"(if1), "s"(m));
     return r;
 }
 __device__ __forceinline__ uint32_t mask_sel0(unsigned long long m, uint32_t if1) {
+    m = uniform64(m);
     uint32_t r;
     asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(if1), "s"(m));
     return r;
@@ -82,7 +96,9 @@ __device__ __forceinline__ uint32_t mask_sel0(unsigned long long m, uint32_t if1
 // ---- bit input: absolute bit position + a 2 KiB LDS ring of the compressed bytes --------------------------
 struct BitIn {
     unsigned long long bitpos;  // next bit, relative to g0 (wave uniform)
-    uint32_t loaded;            // input chunks [0, loaded) (1 KiB each) have been staged
+    uint32_t loaded;            // input chunks [0, loaded) (256 B each) have been staged
+    uint32_t pre;               // this lane's dword of chunk `loaded`: loaded from HBM when the chunk in front of it was
+                                // staged, so the load's latency passes while that chunk is decoded
     uint32_t limit;             // bytes available relative to g0
     const uint8_t *g0;          // 16-byte aligned global address of chunk 0
 };
@@ -105,23 +121,26 @@ __device__ __forceinline__ BitBase bit_base(const uint8_t *d_comp, unsigned long
     return b;
 }
 
-// stage 512-byte chunk c of the compressed input (coalesced, 8 B per lane)
-template <class L>
-__device__ __forceinline__ void stage_chunk(L &s, const BitIn &br, uint32_t c, uint32_t lane) {
-    uint32_t off = c * kInChunk + lane * 8;
-    uint2 v = make_uint2(0, 0);
-    if (off < ((br.limit + 15) & ~15u)) v = *reinterpret_cast<const uint2 *>(br.g0 + off);
-    *reinterpret_cast<uint2 *>(s.in + ((c & 1) * kInChunk + lane * 8)) = v;
-    if (!(c & 1) && lane < kInMirror / 8) *reinterpret_cast<uint2 *>(s.in + (kInRing + lane * 8)) = v;
+// this lane's dword of 256-byte chunk c of the compressed input (coalesced, 4 B per lane)
+__device__ __forceinline__ uint32_t chunk_word(const BitIn &br, uint32_t c, uint32_t lane) {
+    const uint32_t off = c * kInChunk + lane * 4;
+    return off < ((br.limit + 15) & ~15u) ? *reinterpret_cast<const uint32_t *>(br.g0 + off) : 0u;
+}
+// staging starts at the chunk that holds bit br.bitpos
+__device__ __forceinline__ void start_input(BitIn &br, uint32_t lane) {
+    br.loaded = (uint32_t)(br.bitpos >> kInChunkBitsLog2);
+    br.pre = chunk_word(br, br.loaded, lane);
 }
 
-// keep the chunk that holds the current byte and the next one staged (reads go up to ~20 bytes ahead)
+// keep the chunk that holds the current byte and the next one staged (reads go up to ~40 bytes ahead)
 template <class L>
 __device__ __forceinline__ void ensure(L &s, BitIn &br, uint32_t lane) {
     uint32_t c = (uint32_t)(br.bitpos >> kInChunkBitsLog2);
     while (c + 1 >= br.loaded) {
-        stage_chunk(s, br, br.loaded, lane);
+        *reinterpret_cast<uint32_t *>(s.in + ((br.loaded & 1) * kInChunk + lane * 4)) = br.pre;
+        if (!(br.loaded & 1) && lane < kInMirror / 4) *reinterpret_cast<uint32_t *>(s.in + (kInRing + lane * 4)) = br.pre;
         br.loaded++;
+        br.pre = chunk_word(br, br.loaded, lane);
     }
 }
 
@@ -200,15 +219,22 @@ template <class Lut, class Enc>
 __device__ inline bool build_table(const uint8_t *lens, uint32_t n, Lut *lut, uint32_t bits, uint16_t *sorted, uint16_t *count,
                             uint32_t lane, Enc enc) {
     for (uint32_t e = lane; e < (1u << bits); e += 64) lut[e] = 0;
+    // all the lengths (n <= 320) are read before anything is written: `sorted` may lie over `lens`
+    uint32_t lv[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const uint32_t sym = k * 64 + lane;
+        lv[k] = sym < n ? lens[sym] : 0;
+    }
     // counts per length
     uint32_t cnt[16];
 #pragma unroll
     for (int L = 0; L < 16; L++) cnt[L] = 0;
-    for (uint32_t base = 0; base < n; base += 64) {
-        uint32_t sym = base + lane;
-        uint32_t l = sym < n ? lens[sym] : 0;
 #pragma unroll
-        for (int L = 1; L < 16; L++) cnt[L] += __popcll(__ballot(l == (uint32_t)L));
+    for (int k = 0; k < 5; k++) {
+        if ((uint32_t)k * 64 >= n) break;
+#pragma unroll
+        for (int L = 1; L < 16; L++) cnt[L] += __popcll(__ballot(lv[k] == (uint32_t)L));
     }
     // canonical first codes and offsets into `sorted`
     uint32_t first[16], offs[16];
@@ -236,9 +262,11 @@ __device__ inline bool build_table(const uint8_t *lens, uint32_t n, Lut *lut, ui
     uint32_t run[16];
 #pragma unroll
     for (int L = 0; L < 16; L++) run[L] = 0;
-    for (uint32_t base = 0; base < n; base += 64) {
-        uint32_t sym = base + lane;
-        uint32_t l = sym < n ? lens[sym] : 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        if ((uint32_t)k * 64 >= n) break;
+        const uint32_t sym = k * 64 + lane;
+        const uint32_t l = lv[k];
         uint32_t rank = 0, f = 0, o = 0;
 #pragma unroll
         for (int L = 1; L < 16; L++) {
@@ -427,7 +455,7 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
         br.g0 = bb.g0;
         br.limit = bb.limit;
         br.bitpos = (unsigned long long)((long long)mb.start_bit - bb.rel_bits);
-        br.loaded = (uint32_t)(br.bitpos >> kInChunkBitsLog2);  // staging starts at the chunk that holds the first bit
+        start_input(br, lane);
         __syncthreads();
         ensure(s, br, lane);
 
@@ -547,8 +575,8 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                         s.lens[288 + (i - nlit)] = lv[k];
                 }
             }
-            if (!build_table(s.lens, nlit, s.lit_lut, kLitBits, s.lit_sorted, s.lit_count, lane, EncLit()) ||
-                !build_table(s.lens + 288, ndist, s.dist_lut, kDistBits, s.dist_sorted, s.dist_count, lane, EncDist())) {
+            if (!build_table(s.lens + 288, ndist, s.dist_lut, kDistBits, s.dist_sorted, s.dist_count, lane, EncDist()) ||
+                !build_table(s.lens, nlit, s.lit_lut, kLitBits, s.lit_sorted, s.lit_count, lane, EncLit())) {
                 err = 2;
                 break;
             }

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ 
             br.g0 = bb.g0;
             br.limit = bb.limit;
             br.bitpos = (unsigned long long)((long long)base - bb.rel_bits);
-            br.loaded = (uint32_t)(br.bitpos >> kInChunkBitsLog2);
+            start_input(br, lane);
             __syncthreads();
             ensure(s, br, lane);
             br.bitpos += 64 + 17 + 64;  // the filter reads up to here: keep the next chunk staged too
