@@ -704,32 +704,56 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                         }
                     }
                     advance = cur + 64u * NW;
-                    // ---- placement by prefix sum over all windows
+                    // ---- placement by prefix sum over all windows.  The common step has no token that ends it and emits less
+                    // than its limit: then every token start is live and kept, and the masks are the walk's marks as they are
                     uint32_t stop_pos = 64u * NW;
-#pragma unroll
-                    for (int k = NW - 1; k >= 0; k--) {
-                        const unsigned long long m_stop = marks[k] & stop_mask[k];
-                        if (m_stop) stop_pos = 64u * k + (uint32_t)__ffsll((long long)m_stop) - 1;
-                    }
-                    uint32_t excl[NW], olen[NW], incl[NW], carry = 0, total = 0;
-                    unsigned long long live[NW], keep[NW], m_drop[NW];
+                    unsigned long long live[NW], any_stop = 0;
 #pragma unroll
                     for (int k = 0; k < NW; k++) {
-                        // literals and matches in front of the first token that ends the step
-                        const uint32_t n = stop_pos > 64u * k ? stop_pos - 64u * k : 0u;
-                        live[k] = marks[k] & (n >= 64 ? ~0ull : (1ull << n) - 1ull);
-                        olen[k] = mask_sel0(live[k], olen1[k]);
+                        live[k] = marks[k];
+                        any_stop |= marks[k] & stop_mask[k];
                     }
+                    if (any_stop) {
+#pragma unroll
+                        for (int k = NW - 1; k >= 0; k--) {
+                            const unsigned long long m_stop = marks[k] & stop_mask[k];
+                            if (m_stop) stop_pos = 64u * k + (uint32_t)__ffsll((long long)m_stop) - 1;
+                        }
+#pragma unroll
+                        for (int k = 0; k < NW; k++) {
+                            // literals and matches in front of the first token that ends the step
+                            const uint32_t n = max(stop_pos, 64u * k) - 64u * k;
+                            live[k] &= n >= 64 ? ~0ull : (1ull << n) - 1ull;
+                        }
+                    }
+                    uint32_t excl[NW], olen[NW], incl[NW], carry = 0, total = 0;
+                    unsigned long long keep[NW];
+#pragma unroll
+                    for (int k = 0; k < NW; k++) olen[k] = mask_sel0(live[k], olen1[k]);
 #pragma unroll
                     for (int k = 0; k < NW; k++) incl[k] = wave_incl_sum_dpp(olen[k]);  // (side by side: a DPP step waits for the one before)
 #pragma unroll
                     for (int k = 0; k < NW; k++) {
-                        incl[k] += carry;
-                        carry = __builtin_amdgcn_readlane(incl[k], 63);
-                        excl[k] = incl[k] - olen[k];
-                        keep[k] = live[k] & __ballot(excl[k] < kStepOut);
-                        m_drop[k] = live[k] & ~keep[k];  // pushed to the next step
-                        if (keep[k]) total = __builtin_amdgcn_readlane(incl[k], 63 - __clzll((long long)keep[k]));
+                        excl[k] = incl[k] - olen[k] + carry;
+                        carry += __builtin_amdgcn_readlane(incl[k], 63);
+                        keep[k] = live[k];
+                    }
+                    total = carry;
+                    uint32_t drop_pos = 64u * NW;  // the first token pushed to the next step
+                    if (carry > kStepOut) {
+                        total = 0;
+#pragma unroll
+                        for (int k = NW - 1; k >= 0; k--) {
+                            keep[k] = live[k] & __ballot(excl[k] < kStepOut);
+                            const unsigned long long m_drop = live[k] & ~keep[k];
+                            if (m_drop) drop_pos = 64u * k + (uint32_t)__ffsll((long long)m_drop) - 1;
+                        }
+#pragma unroll
+                        for (int k = 0; k < NW; k++)
+                            if (keep[k]) {
+                                const uint32_t l = 63 - __clzll((long long)keep[k]);
+                                total = __builtin_amdgcn_readlane(excl[k], l) + __builtin_amdgcn_readlane(olen[k], l);
+                            }
                     }
                     if (pos + total > cap) {
                         err = 4;
@@ -799,14 +823,9 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                     if (err) break;
                     pos = hi_pos;
                     if (flushed + 1024 <= pos) flush_segments(s, d_out, mb.out_off, flushed, pos, lane);
-                    bool dropped = false;
-#pragma unroll
-                    for (int k = NW - 1; k >= 0; k--)
-                        if (m_drop[k]) {
-                            advance = 64u * k + (uint32_t)__ffsll((long long)m_drop[k]) - 1;
-                            dropped = true;
-                        }
-                    if (!dropped && stop_pos < 64u * NW) {
+                    if (drop_pos < 64u * NW) {
+                        advance = drop_pos;
+                    } else if (stop_pos < 64u * NW) {
                         // what ended the step: the entries of that token
                         const uint32_t sl = stop_pos & 63u, sk = stop_pos >> 6;
                         uint32_t e_s = 0, de_s = 0;
