@@ -647,6 +647,7 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                     }
                     uint32_t tl[NW], val[NW], olen1[NW];
                     unsigned long long len_mask[NW], stop_mask[NW];
+                    const uint32_t one = 1;
 #pragma unroll
                     for (int k = 0; k < NW; k++) {
                         const uint32_t l1 = e[k] & 15u, lx = (e[k] >> 4) & 7u, l2 = de[k] & 15u;
@@ -655,16 +656,17 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                         const uint32_t dx = __builtin_elementwise_sub_sat(h, 1u);
                         const uint32_t dist = (((min(h, 1u) << 1) | b) << dx) + __builtin_amdgcn_ubfe(v2[k], l2, dx) + 1u;
                         const uint32_t len = ((e[k] >> 7) & 0xFFu) + __builtin_amdgcn_ubfe(lo[k], l1, lx) + 3u;
-                        const bool is_len = e[k] & 0x8000u;
-                        len_mask[k] = __ballot(is_len);
-                        val[k] = is_len ? (len | (dist << 16)) : ((e[k] >> 4) & 0xFFu);
-                        olen1[k] = is_len ? len : 1u;
+                        // (one compare; the selects take its mask as their scalar operand — left to the compiler the
+                        // predicate is evaluated three times and the length / distance arithmetic is put behind a branch)
+                        len_mask[k] = __ballot((e[k] & 0x8000u) != 0);
+                        val[k] = mask_sel(len_mask[k], (e[k] >> 4) & 0xFFu, len | (dist << 16));
+                        olen1[k] = mask_sel(len_mask[k], one, len);
                         // every lane hops at least one bit (an entry of 0 has no length): the walk runs on through a token it
                         // cannot use, what lies behind the first such token is dropped below
-                        tl[k] = max(is_len ? tt[k] + l2 + dx : l1, 1u);  // <= 15 + 5 + 15 + 13 = 48 bits
+                        tl[k] = max(mask_sel(len_mask[k], l1, tt[k] + l2 + dx), 1u);  // <= 15 + 5 + 15 + 13 = 48 bits
                         // tokens that end the step: end-of-block, invalid symbols (bits 12 / 13 of a literal entry, bit 9 of a
                         // distance entry) and codes longer than the tables (entry 0).  Valid entries are 1 .. 0xFFF / 1 .. 0x1FF
-                        const uint32_t y = is_len ? de[k] << 3 : e[k];
+                        const uint32_t y = mask_sel(len_mask[k], e[k], de[k] << 3);
                         stop_mask[k] = __ballot(y - 1u >= 0xFFFu);
                     }
                     // The real chain from offset 0, window after window.  The walk is the scalar unit's main load (~15 tokens
