@@ -645,21 +645,20 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                         v2[k] = __builtin_amdgcn_alignbit(hi[k], lo[k], tt[k]);  // bits [t, t + 32): distance code + extra bits <= 28
                         de[k] = s.dist_lut[v2[k] & ((1u << kDistBits) - 1u)];
                     }
-                    uint32_t tl[NW], val[NW], olen1[NW];
+                    uint32_t tl[NW], dxs[NW], olen1[NW];
                     unsigned long long len_mask[NW], stop_mask[NW];
                     const uint32_t one = 1;
 #pragma unroll
                     for (int k = 0; k < NW; k++) {
                         const uint32_t l1 = e[k] & 15u, lx = (e[k] >> 4) & 7u, l2 = de[k] & 15u;
                         // distance symbol 2 h + b: h = 0 -> base b + 1, no extra bits; else base ((2 | b) << (h - 1)) + 1
-                        const uint32_t h = (de[k] >> 5) & 15u, b = (de[k] >> 4) & 1u;
-                        const uint32_t dx = __builtin_elementwise_sub_sat(h, 1u);
-                        const uint32_t dist = (((min(h, 1u) << 1) | b) << dx) + __builtin_amdgcn_ubfe(v2[k], l2, dx) + 1u;
+                        // (the distance itself is decoded where a match is copied: most windows have none)
+                        const uint32_t dx = __builtin_elementwise_sub_sat((de[k] >> 5) & 15u, 1u);
+                        dxs[k] = dx;
                         const uint32_t len = ((e[k] >> 7) & 0xFFu) + __builtin_amdgcn_ubfe(lo[k], l1, lx) + 3u;
                         // (one compare; the selects take its mask as their scalar operand — left to the compiler the
                         // predicate is evaluated three times and the length / distance arithmetic is put behind a branch)
                         len_mask[k] = __ballot((e[k] & 0x8000u) != 0);
-                        val[k] = mask_sel(len_mask[k], (e[k] >> 4) & 0xFFu, len | (dist << 16));
                         olen1[k] = mask_sel(len_mask[k], one, len);
                         // every lane hops at least one bit (an entry of 0 has no length): the walk runs on through a token it
                         // cannot use, what lies behind the first such token is dropped below
@@ -765,7 +764,10 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                         bool ctl = false;
 #pragma unroll
                         for (int k = 0; k < NW; k++)
-                            ctl |= (((keep[k] & ~len_mask[k]) >> lane) & 1ull) && (val[k] < 9u || (val[k] > 13u && val[k] < 32u) || val[k] == 127u);
+                        {
+                            const uint32_t c = (e[k] >> 4) & 0xFFu;
+                            ctl |= (((keep[k] & ~len_mask[k]) >> lane) & 1ull) && (c < 9u || (c > 13u && c < 32u) || c == 127u);
+                        }
                         if (__ballot(ctl)) {
                             err = 6;
                             break;
@@ -775,10 +777,12 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                     // all literals in one store per window (the other lanes write to a spare element behind the ring)
 #pragma unroll
                     for (int k = 0; k < NW; k++)
-                        s.win[mask_sel(keep[k] & ~len_mask[k], RING, (pos + excl[k]) & kRingMask)] = (Elem)val[k];
+                        s.win[mask_sel(keep[k] & ~len_mask[k], RING, (pos + excl[k]) & kRingMask)] = (Elem)((e[k] >> 4) & 0xFFu);
                     // matches in order, window after window (see the one-window form below); most windows have none
-                    auto matches = [&](unsigned long long m_match, uint32_t val_k, uint32_t excl_k) {
-                        const uint32_t dest_l = pos + excl_k, len_l = val_k & 0xFFFFu, dist_l = val_k >> 16;
+                    auto matches = [&](unsigned long long m_match, uint32_t len_l, uint32_t de_k, uint32_t v2_k, uint32_t dx_k, uint32_t excl_k) {
+                        const uint32_t h = (de_k >> 5) & 15u, b = (de_k >> 4) & 1u;
+                        const uint32_t dist_l = (((min(h, 1u) << 1) | b) << dx_k) + __builtin_amdgcn_ubfe(v2_k, de_k & 15u, dx_k) + 1u;
+                        const uint32_t dest_l = pos + excl_k;
                         if (!SYM && (m_match & __ballot(dist_l > dest_l))) {
                             err = 3;
                             return;
@@ -820,7 +824,7 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
 #pragma unroll
                     for (int k = 0; k < NW; k++) {
                         const unsigned long long m_match = keep[k] & len_mask[k];
-                        if (m_match && !err) matches(m_match, val[k], excl[k]);
+                        if (m_match && !err) matches(m_match, olen1[k], de[k], v2[k], dxs[k], excl[k]);
                     }
                     if (err) break;
                     pos = hi_pos;
