@@ -13,7 +13,7 @@ output of the last launch is verified on the device against the generator's clos
 Beside it (rank 0, N=1, skipped with --no-configs): `configs` — BASELINE configs[0] (SELECT COUNT(*) on a 1 MB FASTA
 through the reader: latency), configs[2] (8-column VCF scan, 5 GB generated in HBM by exg_synth_vcf) and configs[3]
 (read_fastq on BGZF: members deflated on the host cores, inflated + scanned on the device, COUNT(*) through the reader) —
-and `end_to_end` (FASTQ file in the page cache -> host DataChunks through exg_open / exg_next_chunk, PCIe inclusive;
+and `end_to_end` / `configs.end_to_end_vcf` (file in the page cache -> host DataChunks through exg_open / exg_next_chunk, PCIe inclusive;
 never `value`).  With N>1 the same file-level leg runs sharded (`reader_sharded`: every rank opens the same file with
 shard_index = rank).  `cpu_baseline` times the oracle (CPU restatement) on the host cores.
 """
@@ -324,9 +324,30 @@ def run_configs(torch, lib, args):
                 "input_build_s": t_build, "input_deflate_pool_s": getattr(build_bgzf, "pool_s", None), "verified": bool(n == n_gz_in // REC)}
 
 
+        def vcf_file():
+            # ---- read_vcf end to end: VCF-8 file in the page cache -> host DataChunks, every column of the reference's schema
+            # (nested alt / filter / info included).  DuckDB's vectors are ~3.3x the text, so this leg is bound by the D2H link
+            for f in os.listdir(tmp):                      # the FASTQ legs' files are done with
+                os.unlink(os.path.join(tmp, f))
+            n_lines = int(min(args.vcf_gb, 2.0) * 1e9 / 48.65)
+            d_vcf, n_vcf = device.synth_vcf(n_lines)
+            p_vcf = os.path.join(tmp, "e2e.vcf")
+            write_device_bytes(torch, d_vcf, n_vcf, p_vcf)
+            del d_vcf
+            torch.cuda.empty_cache()
+            reader_count(lib, p_vcf, "vcf")
+            n, dt_c = min((reader_count(lib, p_vcf, "vcf") for _ in range(3)), key=lambda x: x[1])
+            rows, chunks, dt_r = min((reader_chunks(lib, p_vcf, "vcf") for _ in range(3)), key=lambda x: x[2])
+            out["end_to_end_vcf"] = {
+                "workload": f"read_vcf, {n_vcf / 1e9:.2f} GB VCF-8 file in the page cache -> host DataChunks of all 8 columns (exg_open / exg_next_chunk), PCIe inclusive",
+                "algorithmic_bytes": n_vcf, "ms": dt_r * 1e3, "GB/s": n_vcf / dt_r / 1e9, "records_per_s": rows / dt_r, "chunks": chunks,
+                "count_only_ms": dt_c * 1e3, "count_only_GB/s": n_vcf / dt_c / 1e9, "frac": None,
+                "verified": bool(rows == n == n_lines and chunks >= (rows + 2047) // 2048)}
+
         leg(config1, "config1_fasta_1MB_count")
         leg(config3, "config3_vcf_8col")
         leg(files, "end_to_end", "config4_fastq_bgzf")
+        leg(vcf_file, "end_to_end_vcf")
     finally:
         for f in os.listdir(tmp):
             os.unlink(os.path.join(tmp, f))
