@@ -248,14 +248,30 @@ __global__ __launch_bounds__(256) void k_resolve(const ChunkOut *__restrict__ ch
     }
 }
 
+// Scratch of one call, from the library's device pool: a 5 GB stream needs a 29 GB symbol buffer, and hipMalloc of that
+// was measured at 0.24 - 1.3 s (per call; the pool pays it once).  The call's stream is waited for before a block goes back
+// (idle already on the normal path: the results of every stage are read on the host)
+thread_local hipStream_t t_call_stream = nullptr;  // the stream of the exg_inflate_stream call this thread is in
 struct DevBuf {
     void *p = nullptr;
-    ~DevBuf() {
-        if (p) (void)hipFree(p);
+    size_t sz = 0;
+    int dev = 0;
+    hipStream_t stream = t_call_stream;
+    DevBuf() { (void)hipGetDevice(&dev); }
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    void release() {
+        if (!p) return;
+        (void)hipStreamSynchronize(stream);
+        exg_rd::dev_pool()->give(dev, p, sz);
+        p = nullptr;
     }
+    ~DevBuf() { release(); }
     hipError_t alloc(size_t n) {
-        if (p) (void)hipFree(p), p = nullptr;
-        return hipMalloc(&p, n ? n : 16);
+        release();
+        sz = n ? n : 16;
+        p = exg_rd::dev_pool()->take(dev, sz);
+        return p ? hipSuccess : hipErrorOutOfMemory;
     }
 };
 
@@ -290,6 +306,7 @@ static double st_now() {
 extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint64_t comp_size, uint64_t chunk_bytes,
                                   void **d_out_p, uint64_t *produced, uint64_t *consumed, void *stream_v) {
     hipStream_t stream = (hipStream_t)stream_v;
+    t_call_stream = stream;
     const uint8_t *d_comp = (const uint8_t *)d_comp_v;
     if (!d_comp || !d_out_p || !produced || !consumed || ((uintptr_t)d_comp & 15)) {
         set_error("exg_inflate_stream: bad arguments");
@@ -573,7 +590,12 @@ extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint6
     ST_HIP(d_win.alloc((size_t)n * 32768));
     ST_HIP(d_bad.alloc(4));
     // (allocated at the device pool's size class: the reader hands the buffer to that pool when the file is done)
-    ST_HIP(hipMalloc(&d_out, exg_rd::DevPool::size_class(total + 64)));
+    {
+        int dev = 0;
+        ST_HIP(hipGetDevice(&dev));
+        d_out = exg_rd::dev_pool()->take(dev, total + 64);
+        if (!d_out) ST_HIP(hipErrorOutOfMemory);
+    }
     ST_HIP(hipMemcpyAsync(d_co.p, co.data(), n * sizeof(ChunkOut), hipMemcpyHostToDevice, stream));
     ST_HIP(hipMemsetAsync(d_win.p, 0, 32768, stream));
     ST_HIP(hipMemsetAsync(d_bad.p, 0, 4, stream));
