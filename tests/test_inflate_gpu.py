@@ -100,6 +100,25 @@ def test_overlapping_matches_and_far_distances(gpu):
     roundtrip(gpu, payload, gzip.compress(payload, mtime=0))
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_many_tiny_blocks(gpu, seed):
+    """a block end every few bytes (sync / full flushes at random places, all three block types): the token that ends a
+    speculative step — end-of-block — falls into every window and every lane of the step, with block headers, empty stored
+    blocks and byte alignment right behind it"""
+    rng = np.random.default_rng(seed)
+    text = fastq_like(120) + b"\0" * 3000 + bytes(rng.integers(0, 256, 4000, dtype=np.uint8)) + b"ACGT" * 2000
+    for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY):
+        co = zlib.compressobj(6, zlib.DEFLATED, 31, 8, strategy)
+        out, pos = [], 0
+        while pos < len(text):
+            n = int(rng.integers(1, 200))
+            out.append(co.compress(text[pos:pos + n]))
+            out.append(co.flush(zlib.Z_FULL_FLUSH if rng.integers(0, 4) == 0 else zlib.Z_SYNC_FLUSH))
+            pos += n
+        out.append(co.flush())
+        roundtrip(gpu, text, b"".join(out))
+
+
 def test_long_codes(gpu):
     # a skewed byte distribution forces code lengths > 10 bits (secondary canonical decode)
     rng = np.random.default_rng(9)

@@ -77,6 +77,28 @@ def test_stream_against_zlib(gpu, data, name, level):
         assert consumed == len(comp)
 
 
+@pytest.mark.parametrize("seed", [1, 2])
+def test_stream_with_flush_points(gpu, data, seed):
+    """pigz-style streams: sync / full flushes (an empty stored block, byte alignment) between blocks of a few bytes to a few
+    hundred KB — block ends in every lane of a speculative step, chunk ends next to empty stored blocks"""
+    rng = np.random.default_rng(seed)
+    payload = data["fastq"][:6_000_000] + data["text"][:1_000_000]
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    out, pos = [], 0
+    while pos < len(payload):
+        n = int(rng.integers(1, 400)) if rng.integers(0, 3) == 0 else int(rng.integers(20_000, 300_000))
+        out.append(co.compress(payload[pos:pos + n]))
+        out.append(co.flush(zlib.Z_FULL_FLUSH if rng.integers(0, 4) == 0 else zlib.Z_SYNC_FLUSH))
+        pos += n
+    out.append(co.flush())
+    comp = b"".join(out)
+    for chunk, pad in ((1 << 20, 3), (150_000, 16)):
+        rc, got, consumed = stream_inflate(gpu, comp, chunk, pad_front=pad)
+        assert rc == 0, gpu.exg_last_error_message()
+        assert got == payload
+        assert consumed == len(comp)
+
+
 def test_fixed_huffman_and_tiny_streams(gpu):
     for payload in (b"", b"a", b"hello hello hello hello", bytes(range(256)) * 300):
         comp = deflate(payload, 6, zlib.Z_FIXED)
