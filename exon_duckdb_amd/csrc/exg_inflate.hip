@@ -6,15 +6,17 @@
 // carry their compressed size in the 'BC' extra subfield, so they are found without decoding and are
 // inflated in parallel); the inflated bytes stay in HBM and feed the scan kernels directly.
 //
-// Kernel shape: block = 1 wave (64 lanes).  Every lane runs the same (uniform) decoder — bit buffer
-// and positions live in SGPRs — so no broadcast is needed; the lanes split the work that is parallel:
-//   * compressed bytes are staged through a 2 KiB LDS ring with coalesced 16 B/lane loads;
-//   * Huffman tables (10-bit / 9-bit primary LUTs in LDS + canonical count/offset arrays for the
-//     rare longer codes) are built cooperatively: canonical codes by wave ballots, LUT fill per symbol;
-//   * the 32 KiB sliding window is an LDS ring: literals are single LDS byte writes, LZ77 matches are
-//     copied by all lanes (source index folded modulo the distance, so overlapping copies are exact);
-//   * every completed 1 KiB of the ring is flushed to HBM with 16 B/lane stores.
-// LDS: 32 KiB window + 2 KiB input + ~4.5 KiB tables => 4 waves per CU, 1024 members in flight.
+// Kernel shape: block = 1 wave (64 lanes); the decoder body is exg_inflate_core.hpp.  Block headers
+// are decoded by all lanes uniformly (bit position and output position live in SGPRs); inside a Huffman block the lanes
+// decode speculatively the tokens that would start at the next 4 x 64 bit offsets, one scalar walk marks the real ones,
+// a prefix sum places them:
+//   * compressed bytes are staged through a 512-byte LDS ring (two 256-byte chunks, the next chunk's load in flight);
+//   * Huffman tables (10-bit / 9-bit primary LUTs in LDS + canonical count / sorted-symbol arrays for the rare longer
+//     codes) are built cooperatively: canonical codes by wave ballots, LUT fill per symbol;
+//   * the newest 2 Ki bytes of the window are an LDS ring, older bytes are read back from the output the wave itself
+//     flushed to HBM (every completed 1 KiB, 16 B/lane stores); matches are copied by all lanes (source index folded
+//     modulo the distance, so overlapping copies are exact).
+// LDS: 6.4 KiB per member, 80 VGPRs => 6 waves per SIMD, 24 members per CU, 6144 in flight.
 #include <stdlib.h>
 
 #include "exg_inflate_core.hpp"

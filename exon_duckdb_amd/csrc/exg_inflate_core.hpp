@@ -25,7 +25,7 @@ struct InflateStatus {
 static constexpr int kWinBytes = 32768;
 static constexpr int kInRing = 512;                  // two chunks of the compressed input
 static constexpr int kInChunk = kInRing / 2, kInChunkBitsLog2 = 11;  // 256 B = 2048 bits
-static constexpr int kInMirror = 40;
+static constexpr int kInMirror = 40;                 // the ring's first bytes again behind it: one window read (36 B) never wraps
 static constexpr int kLitBits = 10, kDistBits = 9;
 
 // SYM = false: the window holds bytes (a gzip member decoded from its first bit).
@@ -33,8 +33,8 @@ static constexpr int kLitBits = 10, kDistBits = 9;
 //              this decode started", which are not known yet (exg_inflate_stream: one big member decoded in chunks).
 // RING = 32 Ki: the whole window is an LDS ring (39 KiB / 72 KiB per wave: 4 / 2 waves per CU).
 // RING < 32 Ki: the ring holds the newest RING elements only; a match that reaches further back reads the output the
-//               wave flushed to HBM earlier (RING = 4 Ki: 11 KiB / 15 KiB per wave => 3-4 waves per SIMD, which is
-//               what hides the latency of this serial decode).  A decode without output (d_out = NULL) copies nothing.
+//               wave flushed to HBM earlier (RING = 2 Ki: 6.4 KiB / 8.5 KiB per wave => 6 / 4-5 waves per SIMD, which
+//               is what hides the latency of this serial decode).  A decode without output (d_out = NULL) copies nothing.
 template <bool SYM, uint32_t RING = kWinBytes>
 struct InflateLdsT {
     using Elem = typename std::conditional<SYM, uint16_t, uint8_t>::type;
