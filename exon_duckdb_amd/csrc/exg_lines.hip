@@ -199,8 +199,19 @@ __global__ __launch_bounds__(256) void k_count_range(const uint8_t *__restrict__
     uint64_t a0 = begin & ~15ull;
     uint64_t n_chunks = (end > a0) ? (end - a0 + 15) / 16 : 0;
     unsigned long long cnt = 0;
-    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks;
-         c += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // the body of the range: four 16-byte loads in flight per lane (one load per trip reads at 5.5 TB/s, four at the
+    // box's streaming rate), no masks — only the first and the last chunk of the range can reach outside it
+    const uint64_t c_lo = begin > a0 ? 1 : 0, c_hi = (a0 + n_chunks * 16 > end) ? n_chunks - 1 : n_chunks;
+    for (; c + 3 * stride < c_hi && c >= c_lo; c += 4 * stride) {
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = ld_stream16(d_in + a0 + (c + k * stride) * 16);
+#pragma unroll
+        for (int k = 0; k < 4; k++) cnt += __popc(match16(v[k], 0x0A0A0A0Au));
+    }
+    for (; c < n_chunks; c += stride) {
         uint64_t off = a0 + c * 16;
         uint4 v = *reinterpret_cast<const uint4 *>(d_in + off);
         uint32_t m = match16(v, 0x0A0A0A0Au);

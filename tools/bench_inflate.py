@@ -20,7 +20,7 @@ else:
 members, comp, pos = [], [], 0
 for i in range(0, len(sample), 65280):
     chunk = sample[i:i + 65280]
-    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    co = zlib.compressobj(6, zlib.DEFLATED, -15, int(os.environ.get("INFLATE_MEMLEVEL", "8")))  # (memLevel 9: half as many blocks per member)
     raw = co.compress(chunk) + co.flush()
     blk = (b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(raw) + 8 - 1)
            + raw + struct.pack("<II", zlib.crc32(chunk), len(chunk)))
