@@ -590,12 +590,10 @@ extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint6
     ST_HIP(d_win.alloc((size_t)n * 32768));
     ST_HIP(d_bad.alloc(4));
     // (allocated at the device pool's size class: the reader hands the buffer to that pool when the file is done)
-    {
-        int dev = 0;
-        ST_HIP(hipGetDevice(&dev));
-        d_out = exg_rd::dev_pool()->take(dev, total + 64);
-        if (!d_out) ST_HIP(hipErrorOutOfMemory);
-    }
+    int out_dev = 0;
+    ST_HIP(hipGetDevice(&out_dev));
+    d_out = exg_rd::dev_pool()->take(out_dev, total + 64);
+    if (!d_out) ST_HIP(hipErrorOutOfMemory);
     ST_HIP(hipMemcpyAsync(d_co.p, co.data(), n * sizeof(ChunkOut), hipMemcpyHostToDevice, stream));
     ST_HIP(hipMemsetAsync(d_win.p, 0, 32768, stream));
     ST_HIP(hipMemsetAsync(d_bad.p, 0, 4, stream));
@@ -619,7 +617,7 @@ extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint6
     if (he == hipSuccess) he = hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, stream);
     if (he == hipSuccess) he = hipStreamSynchronize(stream);
     if (he != hipSuccess || bad) {
-        (void)hipFree(d_out);
+        exg_rd::dev_pool()->give(out_dev, d_out, total + 64);
         if (bad)
             set_error("corrupt deflate stream (distance before the start of the output)");
         else
