@@ -1,7 +1,7 @@
 """ctypes mirror of include/exon_gpu.h (keep in sync with the header; tests check sizes)."""
 import ctypes as C
 
-EXG_ABI_VERSION = 4
+EXG_ABI_VERSION = 5
 EXG_TYPE_VARCHAR, EXG_TYPE_BIGINT, EXG_TYPE_FLOAT, EXG_TYPE_INTEGER, EXG_TYPE_BOOLEAN, EXG_TYPE_LIST, EXG_TYPE_STRUCT = 1, 2, 3, 4, 5, 6, 7
 EXG_VECTOR_SIZE = 2048
 

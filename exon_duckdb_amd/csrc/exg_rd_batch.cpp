@@ -1,0 +1,604 @@
+// exg_rd_batch.cpp — reader level: a file is opened (mapped, or handed to a decoder), then scanned one device batch at a
+// time: bytes -> HBM (prefetched slot / decoded segment / synchronous upload) -> scan kernels -> the batch's host vectors.
+// Replaces exon's BatchReader::read_batch loop behind the stream `new_reader` returns (rust/src/arrow_reader.rs:116-153)
+// and the per-batch pull in WTArrowTableFunction::Scan (exon/src/exon/arrow_table_function/module.cpp:257-294).
+//
+// Data layout: device batches are record aligned (each starts on the first byte after the last complete record of the
+// previous one); the kernels emit string_t whose pointers address host memory (the file's mapping, or the pinned block that
+// receives a decoded batch), i.e. the DataChunk payload is zero-copy and only 64 B/record of string_t + validity cross
+// PCIe on the way back.  Chunks are 2048-row slices of the batch's host vectors, reference counted until
+// exg_release_chunk.
+#include <errno.h>
+#include <fcntl.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <functional>
+#include <memory>
+#include <thread>
+
+#include "exg_filter.hpp"
+#include "exg_rd_internal.hpp"
+
+namespace exg_rd {
+
+int open_next_file(exg_reader *r) {
+    if (int jrc = r->join_zstd_check()) return jrc;
+    const std::string &p = r->files[r->file_idx++];
+    double t_all = now_s();
+    int fd = open(p.c_str(), O_RDONLY);
+    if (fd < 0) return fail(r, EXG_E_IO, "cannot open '" + p + "': " + strerror(errno));
+    struct stat st;
+    fstat(fd, &st);
+    // The file is mapped, not copied: DataChunk strings point straight into the page cache mapping
+    // (kept alive by the chunks); bytes travel to the device through a pinned bounce buffer.
+    auto blk = std::make_shared<PinnedBlock>();
+    blk->n = (size_t)st.st_size;
+    double t0 = now_s();
+    if (blk->n) {
+        void *m = mmap(nullptr, blk->n, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) {
+            close(fd);
+            return fail(r, EXG_E_IO, "cannot map '" + p + "': " + strerror(errno));
+        }
+        blk->p = m;
+        blk->mapped = blk->n;
+    } else {
+        hipError_t he = hipHostMalloc(&blk->p, 64, hipHostMallocDefault);
+        if (he != hipSuccess) {
+            close(fd);
+            return fail(r, EXG_E_HIP, std::string("hipHostMalloc failed: ") + hipGetErrorString(he));
+        }
+        memset(blk->p, 0, 64);
+    }
+    r->fd_keep.reset(new exg_reader::FdCloser{fd});
+    TRACE("mmap(file)", t0);
+    (void)t_all;
+    if (r->d_file) exg_rd::dev_pool()->give(r->device, r->d_file, r->d_file_cap), r->d_file = nullptr;
+    r->range_preset = false;
+    r->range_eof = true;
+    r->data0_is_line_start = true;
+    if (r->compression == kGzip) {
+        int rc = inflate_file(r, blk, p);  // replaces blk by the inflated bytes (host copy) and sets d_file
+        if (rc) return rc;
+    } else if (r->compression == kZstd) {
+        int rc = zstd_file(r, blk, p);
+        if (rc) return rc;
+    }
+    (void)r->join_prefetch();
+    r->drop_prefetch2();
+    if (r->pf.valid && r->up_stream) (void)hipStreamSynchronize(r->up_stream);  // a prefetch of the previous file
+    r->pf.valid = false;
+    r->file = blk;
+    r->file_pos = 0;
+    r->file_done = false;
+    if (r->format == EXG_FMT_VCF) {
+        // header = the leading '#' lines (noodles-vcf read_header); it must hold the #CHROM line
+        const char *d = (const char *)blk->p;
+        const size_t hn = r->compression != kNone ? (size_t)r->gz_header_prefix : blk->n;  // gzip / zstd: only the header prefix is on the host
+        size_t pos = 0;
+        bool chrom = false;
+        while (pos < hn && d[pos] == '#') {
+            if (hn - pos >= 6 && memcmp(d + pos, "#CHROM", 6) == 0) chrom = true;
+            const void *nl = memchr(d + pos, '\n', hn - pos);
+            pos = nl ? (size_t)((const char *)nl - d) + 1 : hn;
+        }
+        if (!chrom) return fail(r, EXG_E_PARSE, std::string(exg_parse_error_string(EXG_PE_VCF_NO_HEADER)) + " in '" + p + "'");
+        r->vcf_header_bytes = pos;
+        r->file_pos = pos;
+    }
+    // byte-range shard of this file: [lo, hi) of the bytes behind the header; records / lines belong to the shard they END in
+    r->range_hi = blk->n;
+    r->shard_first = false;
+    r->data_base = r->file_pos;  // 0, or the end of the VCF header
+    if (r->range_preset) {  // BGZF shard: the members were chosen in inflate_file_shard
+        // its buffer begins with the file (header and all) or somewhere behind the header
+        r->data_base = r->data0_is_line_start ? r->data_base : 0;
+        r->file_pos = std::max<uint64_t>(r->preset_pos, r->data_base);
+        r->shard_first = r->file_pos > r->data_base;
+    } else if (r->shard_count > 1 && r->format == EXG_FMT_FASTA) {
+        // FASTA: a record belongs to the shard in whose bytes its '>' line BEGINS, and a shard is the run of whole
+        // records from its first such line to the next shard's — scanned like a file of its own (a record is never
+        // cut, however long its sequence: the run simply reaches as far as it has to)
+        const char *d = (const char *)blk->p;
+        const uint64_t N = blk->n;
+        auto first_record_at_or_after = [&](uint64_t pos) -> uint64_t {
+            if (pos == 0) return 0;
+            for (uint64_t q = pos - 1; q + 1 < N;) {  // a line start is the byte behind a newline
+                const void *hit = memchr(d + q, '\n', (size_t)(N - q));
+                if (!hit) return N;
+                q = (uint64_t)((const char *)hit - d) + 1;
+                if (q < N && d[q] == '>') return q;
+            }
+            return N;
+        };
+        const uint64_t lo = (uint64_t)((unsigned __int128)N * r->shard_index / r->shard_count);
+        const uint64_t hi = r->shard_index + 1 == r->shard_count ? N : (uint64_t)((unsigned __int128)N * (r->shard_index + 1) / r->shard_count);
+        r->file_pos = first_record_at_or_after(lo);
+        r->range_hi = hi == N ? N : first_record_at_or_after(hi);
+        if (r->range_hi < r->file_pos) r->range_hi = r->file_pos;
+        r->range_eof = true;  // the run is a FASTA file of its own
+    } else if (r->shard_count > 1) {
+        const uint64_t base = r->file_pos, span = blk->n - base;
+        const uint64_t lo = base + (uint64_t)((unsigned __int128)span * r->shard_index / r->shard_count);
+        const uint64_t hi = r->shard_index + 1 == r->shard_count
+                                ? blk->n
+                                : base + (uint64_t)((unsigned __int128)span * (r->shard_index + 1) / r->shard_count);
+        r->file_pos = lo;
+        r->range_hi = hi;
+        r->shard_first = lo > base;
+        r->range_eof = hi == blk->n;
+    }
+    return EXG_OK;
+}
+
+int n_string_cols(int format) { return format == EXG_FMT_FASTQ ? 4 : format == EXG_FMT_FASTA ? 3 : 9; }
+
+int ensure_device(exg_reader *r, uint64_t need_bytes) {
+    if (r->d_in && need_bytes <= r->d_in_cap) return EXG_OK;
+    if (r->d_in) {
+        RD_HIP(r, hipStreamSynchronize(r->stream));
+        r->free_device();
+    }
+    if (r->format != EXG_FMT_FASTA && r->file)  // room for a prefetched batch (its slack included), small files stay small
+        need_bytes = std::max<uint64_t>(need_bytes, std::min<uint64_t>(r->device_batch_bytes, r->file->n) + kPrefetchSlack + 64);
+    uint64_t cap = std::max<uint64_t>(need_bytes, 1 << 16);
+    r->d_in_cap = cap;
+    // Rows the output vectors can hold.  Realistic density first (a FASTQ record under 32 bytes, a FASTA record
+    // or a VCF line under 16 would be unusual) — the worst case (FASTQ "@\n\n+\n" = 5 bytes, FASTA ">a\n" minus
+    // LF, a blank VCF line) would pin 16 B x 9 columns per input BYTE of device memory; a batch that does
+    // overflow is reported by the kernels (EXG_RF_CAPACITY) and rescanned with worst-case vectors.
+    const uint64_t div = r->worst_case_rows ? (r->format == EXG_FMT_FASTQ ? 5 : r->format == EXG_FMT_FASTA ? 2 : 1)
+                                            : (r->format == EXG_FMT_FASTQ ? 32 : 16);
+    r->cap_records = cap / div + 4096;
+    r->ws_bytes = exg_scan_workspace_bytes(r->format, cap);
+    // FASTA scans the whole file as one batch: one slot
+    int arc = 0;
+    for (int k = 0; k < (r->format == EXG_FMT_FASTA ? 1 : 2); k++)
+        if ((arc = r->dev_alloc(&r->d_in_slot[k], cap + 64))) return arc;
+    r->d_in = r->d_in_slot[0];
+    r->cur_slot = 0;
+    if (!r->up_stream) {
+        RD_HIP(r, exg_rd::stream_pool()->take(r->device, &r->up_stream));
+        for (int k = 0; k < 2; k++) RD_HIP(r, hipEventCreateWithFlags(&r->up_done_of[k], hipEventDisableTiming));
+    }
+    if ((arc = r->dev_alloc(&r->d_ws, r->ws_bytes))) return arc;
+    for (int k = 0; k < 2; k++)
+        if ((arc = r->dev_alloc(&r->d_valid[k], (r->cap_records + 63) / 64 * 8))) return arc;
+    for (int c = 0; c < n_string_cols(r->format); c++)
+        if ((arc = r->dev_alloc(&r->d_cols[c], r->cap_records * 16))) return arc;
+    if (r->format == EXG_FMT_VCF) {
+        if ((arc = r->dev_alloc(&r->d_pos, r->cap_records * 8))) return arc;
+        if ((arc = r->dev_alloc(&r->d_qual, r->cap_records * 4))) return arc;
+    }
+    if (r->format == EXG_FMT_FASTA && (arc = r->dev_alloc(&r->d_payload, cap + 64))) return arc;
+    if (r->has_filter) {
+        if ((arc = r->dev_alloc(&r->d_row_map, r->cap_records * 4 + 64))) return arc;
+        if ((arc = r->dev_alloc(&r->d_gather, r->cap_records * 16))) return arc;
+        if ((arc = r->dev_alloc(&r->d_filter_tmp, (r->cap_records + 1 + exg::arrow::scan_tmp_entries(r->cap_records)) * 8))) return arc;
+    }
+    if (!r->d_res && !(r->d_res = exg_rd::dev_pool()->take(r->device, 4096))) return fail(r, EXG_E_HIP, "out of device memory");
+    return EXG_OK;
+}
+
+// Scan the next device batch of the current file.  On return r->batch holds its host vectors
+// (n_rows may be 0 when the file is exhausted).  count_only: no column leaves the device.
+int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
+    *n_records_out = 0;
+    r->batch.reset();
+    r->batch_row = 0;
+    uint64_t want = r->device_batch_bytes;
+    double t_batch = now_s();
+    for (;;) {
+        const uint64_t remaining = r->range_hi > r->file_pos ? r->range_hi - r->file_pos : 0;
+        if (remaining == 0) {
+            r->file_done = true;
+            return EXG_OK;
+        }
+        if (r->format == EXG_FMT_FASTA) want = remaining;  // a FASTA record can span the whole file: one batch
+        uint64_t n = std::min<uint64_t>(want, remaining);
+        bool range_end = n == remaining;                    // the batch reaches the end of this reader's bytes ...
+        bool eof = range_end && r->range_eof;               // ... which is the end of the file unless a later shard follows
+        // first batch of a shard that begins inside the file: up to 1 MiB in front of it travels along (`lead`), so that
+        // the record / line that ends behind the cut — it belongs to this shard — has its beginning in the buffer
+        uint64_t shard_halo = 0;
+        if (r->shard_first) {
+            static const uint64_t halo_max = getenv("EXG_SHARD_HALO") ? strtoull(getenv("EXG_SHARD_HALO"), nullptr, 10) : kShardHalo;
+            const uint64_t base = r->data_base;
+            const uint64_t from = r->file_pos - std::min<uint64_t>(halo_max, r->file_pos - base);
+            // (a buffer that already lives in HBM must be entered at a 16-byte boundary: a few bytes of the header's
+            // last line may then come along in front — they end inside the halo and are nobody's rows)
+            shard_halo = r->file_pos - (r->d_file ? (std::max<uint64_t>(base, from) & ~15ull) : std::max<uint64_t>(base, from & ~15ull));
+        }
+        int rc = ensure_device(r, n + shard_halo + 16);
+        if (rc) return rc;
+        // Input of the scan: the inflated bytes already in HBM (gzip), the prefetched slot, or a synchronous
+        // H2D copy.  In the first two cases the batch start is only byte aligned: the buffer starts at the
+        // 16-byte boundary below it and `lead` skips the tail of the previous record (whose last '\n' is
+        // then inside the buffer).
+        // The batch about to be scanned is on its way (or there); if its upload is the one this call will use, the batch
+        // AFTER it starts travelling now, into the slot of the batch that was scanned last (free: its columns have left) —
+        // issued after this call's scan, an upload began only when the link had already been idle for a scan + a D2H.
+        static const bool no_prefetch = getenv("EXG_NO_PREFETCH") != nullptr;
+        if (!no_prefetch && r->pf.valid && !r->pf2.valid && !r->d_file && r->format != EXG_FMT_FASTA && want == r->device_batch_bytes &&
+            r->file_pos >= r->pf.file_start && r->file_pos < r->pf.file_start + r->pf.len && r->d_in_slot[r->pf.slot ^ 1] &&
+            !r->up_thread_of[r->pf.slot ^ 1].joinable()) {
+            const uint64_t end1 = r->pf.file_start + r->pf.len;  // where the coming batch's bytes end
+            if (end1 < r->range_hi) {
+                const uint64_t slack = std::min<uint64_t>(kPrefetchSlack, (end1 - r->file_pos) / 2);
+                const uint64_t start = (end1 - slack) & ~15ull;
+                const uint64_t len = std::min<uint64_t>(r->range_hi - start, r->device_batch_bytes + slack);
+                if (len + 16 <= r->d_in_cap) start_upload(r, &r->pf2, start, len, r->pf.slot ^ 1);
+            }
+        }
+        if ((rc = r->join_prefetch())) return rc;  // the upload thread of the previous call (its error is this call's)
+        const uint8_t *h = (const uint8_t *)r->file->p + r->file_pos;
+        const void *d_input = nullptr;
+        uint64_t lead = 0;
+        uint64_t batch_end = r->file_pos + n;  // file offset one past the bytes of this batch
+        std::shared_ptr<PinnedBlock> gz_payload;  // gzip: this batch's inflated bytes on the host (string_t payload)
+        if (r->d_file) {
+            lead = r->shard_first ? shard_halo : (r->file_pos & 15);
+            d_input = (const uint8_t *)r->d_file + (r->file_pos - lead);
+            n += lead;
+            if (!count_only && !r->arrow_emit) {
+                gz_payload = std::make_shared<PinnedBlock>();
+                size_t cap = n + 64;
+                gz_payload->p = global_pool()->take(&cap);
+                if (!gz_payload->p) return fail(r, EXG_E_HIP, "out of pinned host memory for the inflated bytes");
+                gz_payload->cap = cap;
+                gz_payload->pooled = true;
+                gz_payload->n = n;
+                h = (const uint8_t *)gz_payload->p;
+            } else {
+                // COUNT(*) / the Arrow stream: no host copy; h is only the base the device subtracts again
+                h = (const uint8_t *)(uintptr_t)0x100000000000ull + (r->file_pos - lead);
+            }
+        } else if (r->pf.valid && want == r->device_batch_bytes && r->file_pos >= r->pf.file_start &&
+                   r->file_pos < r->pf.file_start + r->pf.len) {
+            const uint64_t off = r->file_pos - r->pf.file_start;
+            lead = off & 15;
+            r->cur_slot = r->pf.slot;
+            r->d_in = r->d_in_slot[r->cur_slot];
+            d_input = (const uint8_t *)r->d_in + (off - lead);
+            batch_end = r->pf.file_start + r->pf.len;
+            n = batch_end - r->file_pos + lead;
+            range_end = batch_end == r->range_hi;
+            eof = range_end && r->range_eof;
+            h -= lead;
+            r->pf.valid = false;
+            RD_HIP(r, hipStreamWaitEvent(r->stream, r->up_done_of[r->cur_slot], 0));
+        } else {
+            if (r->pf.valid) RD_HIP(r, hipStreamSynchronize(r->up_stream));  // a prefetch that missed: let it land first
+            r->pf.valid = false;
+            r->d_in = r->d_in_slot[r->cur_slot];
+            lead = shard_halo;
+            int rc2;
+            if (r->format == EXG_FMT_FASTA && n > (512ull << 20)) {
+                // a whole genome in one batch: through two 256 MiB pinned windows, not one pinned block of its size
+                rc2 = upload_file(r, r->d_in, n, r->file_pos);
+                if (!rc2 && hipMemsetAsync((char *)r->d_in + n, 0, 16, r->stream) != hipSuccess)
+                    rc2 = fail(r, EXG_E_HIP, "hipMemsetAsync failed");
+            } else {
+                rc2 = upload_range(r, r->file_pos - lead, n + lead, r->cur_slot, r->stream);
+            }
+            if (rc2) return rc2;
+            d_input = r->d_in;
+            n += lead;
+            h -= lead;
+        }
+        uint64_t first_line_index = 0;
+        if (lead && r->shard_first && r->format == EXG_FMT_FASTQ) {
+            // the 4-line phase of the line that holds the shard's first byte, from the bytes around the cut ('@' opens a
+            // record but also quality lines, so several records are looked at: exg_fastq_guess_phase)
+            if (!r->d_phase && !(r->d_phase = exg_rd::dev_pool()->take(r->device, 4096))) return fail(r, EXG_E_HIP, "out of device memory");
+            uint32_t guess = 0xFFFFFFFFu;
+            rc = exg_fastq_guess_phase(d_input, n, lead, (uint32_t *)r->d_phase, r->stream);
+            if (rc) return fail(r, rc, exg_last_error_message());
+            RD_HIP(r, hipMemcpyAsync(&guess, r->d_phase, 4, hipMemcpyDeviceToHost, r->stream));
+            RD_HIP(r, hipStreamSynchronize(r->stream));
+            if (guess <= 3) {
+                uint8_t prev = 0;
+                if (r->d_file) {
+                    RD_HIP(r, hipMemcpyAsync(&prev, (const uint8_t *)r->d_file + r->file_pos - 1, 1, hipMemcpyDeviceToHost, r->stream));
+                    RD_HIP(r, hipStreamSynchronize(r->stream));
+                } else {
+                    prev = ((const uint8_t *)r->file->p)[r->file_pos - 1];
+                }
+                first_line_index = prev == '\n' ? guess : (guess + 3) % 4;
+            } else if (r->d_file) {
+                // BGZF shard: exact only when the halo begins with the file (the newlines in front are then all in HBM)
+                if (!(r->data0_is_line_start && lead == r->file_pos))
+                    return fail(r, EXG_E_PARSE, "cannot tell the FASTQ record phase at the shard boundary of '" + r->files[r->file_idx - 1] + "'");
+                unsigned long long nl = 0;
+                rc = exg_count_newlines(r->d_file, 0, r->file_pos, (uint64_t *)r->d_phase, r->stream);
+                if (rc) return fail(r, rc, exg_last_error_message());
+                RD_HIP(r, hipMemcpyAsync(&nl, r->d_phase, 8, hipMemcpyDeviceToHost, r->stream));
+                RD_HIP(r, hipStreamSynchronize(r->stream));
+                first_line_index = nl;
+            } else {
+                // too few lines around the cut to tell (a tiny file, a tiny shard) or several phases fit: count the
+                // newlines in front of it — exact, and only as slow as a memchr over the page cache
+                const char *d = (const char *)r->file->p;
+                uint64_t nl = 0;
+                for (const char *q = d, *end = d + r->file_pos; q < end;) {
+                    const void *hit = memchr(q, '\n', (size_t)(end - q));
+                    if (!hit) break;
+                    nl++;
+                    q = (const char *)hit + 1;
+                }
+                first_line_index = nl;
+            }
+        }
+        exg_scan_result res;
+        const bool no_store = count_only && !r->has_filter;  // a predicate needs the columns even for COUNT(*)
+        // a line starts at d_input[0] when the batch is record aligned, or when a shard's halo reaches back to the
+        // first byte behind the header
+        const bool at_line_start = lead == 0 || (r->shard_first && shard_halo && lead == shard_halo && r->data0_is_line_start &&
+                                                 r->file_pos - lead == r->data_base);
+        const uint32_t fl = (at_line_start ? EXG_F_BOF : 0u) | (eof ? EXG_F_EOF : 0u) | (no_store ? EXG_F_NO_STORE : 0u);
+        std::shared_ptr<Batch> b;
+        bool fused_first = false;
+        std::function<int()> rescan_general;
+        if (r->format == EXG_FMT_FASTQ) {
+            exg_fastq_scan_args a;
+            memset(&a, 0, sizeof a);
+            a.d_input = d_input;
+            a.n_bytes = n;
+            a.lead = lead;
+            a.first_line_index = first_line_index;
+            a.payload_base = (uint64_t)(uintptr_t)h;
+            a.flags = fl;
+            a.algo = EXG_ALGO_FUSED;
+            a.d_name = (exg_string_t *)r->d_cols[0];
+            a.d_description = (exg_string_t *)r->d_cols[1];
+            a.d_sequence = (exg_string_t *)r->d_cols[2];
+            a.d_quality = (exg_string_t *)r->d_cols[3];
+            a.d_description_validity = (uint64_t *)r->d_valid[0];
+            a.capacity_records = r->cap_records;
+            a.d_workspace = r->d_ws;
+            a.workspace_bytes = r->ws_bytes;
+            a.d_result = (exg_scan_result *)r->d_res;
+            a.stream = r->stream;
+            rc = exg_fastq_scan(&a);
+            fused_first = true;
+            rescan_general = [a]() mutable {
+                a.algo = EXG_ALGO_MULTIPASS;
+                return exg_fastq_scan(&a);
+            };
+        } else if (r->format == EXG_FMT_VCF) {
+            exg_vcf_scan_args a;
+            memset(&a, 0, sizeof a);
+            a.d_input = d_input;
+            a.n_bytes = n;
+            a.lead = lead;
+            a.payload_base = (uint64_t)(uintptr_t)h;
+            a.flags = fl;
+            a.algo = EXG_ALGO_FUSED;
+            for (int c = 0; c < 9; c++) a.d_fields[c] = (exg_string_t *)r->d_cols[c];
+            a.d_pos = (int64_t *)r->d_pos;
+            a.d_qual = (float *)r->d_qual;
+            a.d_qual_validity = (uint64_t *)r->d_valid[0];
+            a.d_formats_validity = (uint64_t *)r->d_valid[1];
+            a.capacity_records = r->cap_records;
+            a.d_workspace = r->d_ws;
+            a.workspace_bytes = r->ws_bytes;
+            a.d_result = (exg_scan_result *)r->d_res;
+            a.stream = r->stream;
+            rc = exg_vcf_scan(&a);
+            fused_first = true;
+            rescan_general = [a]() mutable {
+                a.algo = EXG_ALGO_MULTIPASS;
+                return exg_vcf_scan(&a);
+            };
+        } else {
+            b = std::make_shared<Batch>();
+            if (!count_only) {
+                b->payload = b->host.alloc(n + 64);
+                if (!b->payload) return fail(r, EXG_E_HIP, "out of pinned host memory");
+            }
+            exg_fasta_scan_args a;
+            memset(&a, 0, sizeof a);
+            a.d_input = d_input;
+            a.n_bytes = n;
+            a.payload_base = (uint64_t)(uintptr_t)h;
+            a.seq_payload_base = (uint64_t)(uintptr_t)b->payload;
+            a.flags = fl;
+            a.d_id = (exg_string_t *)r->d_cols[0];
+            a.d_description = (exg_string_t *)r->d_cols[1];
+            a.d_sequence = (exg_string_t *)r->d_cols[2];
+            a.d_description_validity = (uint64_t *)r->d_valid[0];
+            a.d_seq_payload = (uint8_t *)r->d_payload;
+            a.capacity_records = r->cap_records;
+            a.d_workspace = r->d_ws;
+            a.workspace_bytes = r->ws_bytes;
+            a.d_result = (exg_scan_result *)r->d_res;
+            a.stream = r->stream;
+            rc = exg_fasta_scan(&a);
+        }
+        if (rc) return fail(r, rc, exg_last_error_message());
+        double t_scan = now_s();
+        rc = exg_fetch_result((const exg_scan_result *)r->d_res, r->stream, &res);
+        if (rc) return fail(r, rc, exg_last_error_message());
+        if (fused_first && (res.flags & EXG_RF_FALLBACK)) {
+            // a record longer than the fused kernel's window, a byte >= 0x80, ...: the general path, on the same batch
+            // (the reader launches it only now — EXG_ALGO_AUTO would enqueue its ten gated kernels behind every scan)
+            rc = rescan_general();
+            if (rc) return fail(r, rc, exg_last_error_message());
+            rc = exg_fetch_result((const exg_scan_result *)r->d_res, r->stream, &res);
+            if (rc) return fail(r, rc, exg_last_error_message());
+            res.flags |= EXG_RF_FALLBACK;
+        }
+        TRACE("wait(h2d) + scan", t_scan);
+        if (res.flags & EXG_RF_INDEX_OVERFLOW)
+            return fail(r, EXG_E_CAPACITY, "line index overflow in the general path (pathological line density)");
+        if ((res.flags & EXG_RF_CAPACITY) && !no_store) {
+            if (r->worst_case_rows) return fail(r, EXG_E_CAPACITY, "more rows than bytes allow: internal error");
+            RD_HIP(r, hipStreamSynchronize(r->stream));  // denser rows than provisioned: worst-case vectors, same batch again
+            r->free_device();
+            r->worst_case_rows = true;
+            continue;
+        }
+        if (res.n_records == 0 && !res.error_code && !eof && !range_end) {
+            want *= 2;  // not even one complete record in the batch: widen it
+            continue;
+        }
+        if (res.error_code) {
+            r->pending_error = res.error_code;
+            r->pending_error_offset = r->file_pos - lead + res.error_offset;
+        }
+        double t_pf = now_s();
+        // While the columns travel back (and the consumer works through the chunks): the bytes the next batch will need
+        // move into the other slot — unless they left at the top of this call already (pf2), which is the steady state
+        {
+            const bool can = !range_end && !res.error_code && !r->d_file && r->format != EXG_FMT_FASTA && want == r->device_batch_bytes && !no_prefetch;
+            const uint64_t slack = std::min<uint64_t>(kPrefetchSlack, (batch_end - r->file_pos) / 2);
+            const uint64_t start = (batch_end - slack) & ~15ull;
+            const uint64_t len = std::min<uint64_t>(r->range_hi - start, r->device_batch_bytes + slack);
+            const int other = r->cur_slot ^ 1;
+            if (r->pf2.valid) {
+                if (can && r->pf2.file_start == start && r->pf2.len == len && r->pf2.slot == other) {
+                    r->pf = r->pf2;
+                    r->pf2.valid = false;
+                } else {
+                    r->drop_prefetch2();  // (the batch turned out otherwise: an error, a retry, the end of the range)
+                }
+            }
+            if (can && !r->pf.valid && len + 16 <= r->d_in_cap && r->d_in_slot[other] && !r->up_thread_of[other].joinable())
+                start_upload(r, &r->pf, start, len, other);
+        }
+        TRACE("prefetch issue", t_pf);
+        uint64_t k = res.n_records;
+        const uint32_t *row_map = nullptr;
+        if (r->has_filter && k && !r->arrow_emit) {
+            // rows where the predicate is TRUE -> row map; the columns are gathered through it on their way out
+            namespace ea = exg::arrow;
+            ea::FilterCols fc;
+            memset(&fc, 0, sizeof fc);
+            const int nsc = n_string_cols(r->format);
+            for (int c = 0; c < nsc; c++) {
+                fc.kind[c] = ea::kColStr;
+                fc.data[c] = r->d_cols[c];
+                fc.d_base[c] = (const uint8_t *)d_input;
+                fc.payload_base[c] = (uint64_t)(uintptr_t)h;
+            }
+            if (r->format == EXG_FMT_VCF) {
+                fc.kind[1] = ea::kColI64, fc.data[1] = r->d_pos;
+                fc.kind[5] = ea::kColF32, fc.data[5] = r->d_qual, fc.validity[5] = (const uint64_t *)r->d_valid[0];
+                fc.validity[8] = (const uint64_t *)r->d_valid[1];
+            } else {
+                fc.validity[1] = (const uint64_t *)r->d_valid[0];
+                if (r->format == EXG_FMT_FASTA) {
+                    fc.d_base[2] = (const uint8_t *)r->d_payload;
+                    fc.payload_base[2] = (uint64_t)(uintptr_t)(b ? b->payload : nullptr);
+                }
+            }
+            uint64_t *d_goff = (uint64_t *)r->d_filter_tmp, *d_tmp = d_goff + r->cap_records + 1;
+            ea::FilterCols *d_fc = (ea::FilterCols *)r->d_gather;  // the scratch column is free until the gathers
+            RD_HIP(r, hipMemcpyAsync(d_fc, &fc, sizeof fc, hipMemcpyHostToDevice, r->stream));
+            ea::filter_rows((const ea::FilterProgram *)r->d_filter_prog, d_fc, (const uint8_t *)r->d_filter_consts, k, d_goff,
+                            d_tmp, (uint32_t *)r->d_row_map, r->stream);
+            uint64_t n_sel = 0;
+            RD_HIP(r, hipMemcpyAsync(&n_sel, d_goff + k, 8, hipMemcpyDeviceToHost, r->stream));
+            RD_HIP(r, hipStreamSynchronize(r->stream));
+            k = n_sel;
+            row_map = (const uint32_t *)r->d_row_map;
+        }
+        *n_records_out = k;
+        if (r->arrow_emit && !count_only) {
+            // new_reader: the columns stay in HBM and become Arrow buffers there (exg_arrow_stream.cpp)
+            ScanCtx ctx;
+            ctx.d_input = d_input;
+            ctx.h = h;
+            ctx.n_records = k;
+            ctx.res = res;
+            ctx.h_seq_payload = b ? (const uint8_t *)b->payload : nullptr;
+            double t_emit = now_s();
+            if (k && (rc = r->arrow_emit(r, ctx))) return rc;
+            TRACE("arrow emit", t_emit);
+        } else if (k && !count_only) {
+            if (!b) b = std::make_shared<Batch>();
+            b->host.reserve(r->host_hint);
+            b->file = gz_payload ? gz_payload : r->file;
+            if (gz_payload) RD_HIP(r, hipMemcpyAsync(gz_payload->p, d_input, n, hipMemcpyDeviceToHost, r->stream));
+            b->n_rows = k;
+            const int ns = n_string_cols(r->format);
+            // schema order (exg_schema_of): VCF exposes parsed POS / QUAL in place of their raw text
+            b->n_cols = ns;
+            const size_t vw = (size_t)((k + 63) / 64) * 8;
+            const bool nested_vcf = r->format == EXG_FMT_VCF;  // id, alt, filter, info, formats: built by nested_emit below
+            for (int c = 0; c < ns; c++) {
+                if (nested_vcf && (c == 2 || c == 4 || c >= 6)) {
+                    b->elem[c] = 0;
+                    continue;
+                }
+                const void *src = r->d_cols[c];
+                uint32_t es = 16;
+                if (r->format == EXG_FMT_VCF && c == 1) src = r->d_pos, es = 8;
+                if (r->format == EXG_FMT_VCF && c == 5) src = r->d_qual, es = 4;
+                b->elem[c] = es;
+                if (!(b->cols[c] = b->host.alloc(k * es))) return fail(r, EXG_E_HIP, "out of pinned host memory");
+                if (row_map) {
+                    if (es == 16)
+                        exg::arrow::gather_u128(src, row_map, k, r->d_gather, r->stream);
+                    else if (es == 8)
+                        exg::arrow::gather_u64((const uint64_t *)src, row_map, k, (uint64_t *)r->d_gather, r->stream);
+                    else
+                        exg::arrow::gather_u32((const uint32_t *)src, row_map, k, (uint32_t *)r->d_gather, r->stream);
+                    src = r->d_gather;
+                }
+                RD_HIP(r, hipMemcpyAsync(b->cols[c], src, k * es, hipMemcpyDeviceToHost, r->stream));
+            }
+            auto copy_validity = [&](int col, const void *d) -> int {
+                if (!(b->validity[col] = b->host.alloc(vw))) return fail(r, EXG_E_HIP, "out of pinned host memory");
+                if (row_map) {
+                    exg::arrow::gather_bits((const uint64_t *)d, row_map, k, (uint64_t *)r->d_gather, r->stream);
+                    d = r->d_gather;
+                }
+                RD_HIP(r, hipMemcpyAsync(b->validity[col], d, vw, hipMemcpyDeviceToHost, r->stream));
+                return EXG_OK;
+            };
+            if (r->format == EXG_FMT_VCF) {
+                if ((rc = copy_validity(5, r->d_valid[0]))) return rc;
+                if (!r->nested_state && (rc = nested_prepare(r))) return rc;
+                ScanCtx ctx;
+                ctx.d_input = d_input;
+                ctx.h = h;
+                ctx.n_records = k;
+                ctx.res = res;
+                ctx.h_seq_payload = nullptr;
+                uint64_t deliver = k;
+                if ((rc = nested_emit(r, ctx, b.get(), row_map, &deliver))) return rc;
+                b->n_rows = deliver;
+            } else {
+                if ((rc = copy_validity(1, r->d_valid[0]))) return rc;
+            }
+            if (r->format == EXG_FMT_FASTA && res.payload_bytes)
+                RD_HIP(r, hipMemcpyAsync(b->payload, r->d_payload, res.payload_bytes, hipMemcpyDeviceToHost, r->stream));
+            RD_HIP(r, hipStreamSynchronize(r->stream));
+            r->host_hint = b->host.total + b->host.total / 8 + (1u << 20);
+            b->seq = r->batch_seq++;
+            r->batch = b;
+        }
+        r->shard_first = false;
+        if (res.error_code || eof) {
+            r->file_done = true;
+        } else {
+            r->file_pos += res.consumed_bytes - lead;
+            if (range_end) {
+                // what is left belongs to the next shard, whose halo must reach back to where that record begins
+                r->file_done = true;
+                if (batch_end - r->file_pos > kShardHalo)
+                    return fail(r, EXG_E_UNSUPPORTED, "a record longer than the 1 MiB shard halo crosses the shard boundary at byte " +
+                                                          std::to_string(batch_end) + " of '" + r->files[r->file_idx - 1] + "'");
+            }
+        }
+        TRACE("batch (h2d+scan+d2h)", t_batch);
+        return EXG_OK;
+    }
+}
+
+}  // namespace exg_rd

@@ -1,0 +1,302 @@
+// exg_rd_io.cpp — reader level, I/O: pinned host blocks, the reader's pooled device buffers and upload threads, and the
+// page cache -> pinned bounce buffer -> HBM copies (parallel pread, each slice followed at once by its own H2D).
+// Part of the replacement of `new_reader`'s file opening / BufReader (rust/src/arrow_reader.rs:104-118).
+#include <dirent.h>
+#include <errno.h>
+#include <pthread.h>
+#include <sched.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <thread>
+
+#include "exg_rd_internal.hpp"
+
+namespace exg_rd {
+
+PinnedBlock::~PinnedBlock() {
+    if (!p) return;
+    if (mapped)
+        munmap(p, mapped);
+    else if (pooled)
+        global_pool()->give((char *)p, cap);
+    else
+        (void)hipHostFree(p);
+}
+
+// The reader's own I/O threads (pread into the pinned bounce buffers, H2D enqueue) run on the CPUs of the NUMA node the
+// GPU hangs off (sysfs local_cpulist of its PCI function): the bounce buffers are local to the DMA engine, and a file
+// that is read cold lands in that node's page cache.  Best effort — a cpuset that forbids it is not an error.
+void pin_to_device_node(int device) {
+    struct Mask {
+        bool ok = false;
+        cpu_set_t set;
+    };
+    static Mask masks[64];
+    static std::once_flag once[64];
+    if (device < 0 || device >= 64 || getenv("EXG_NO_NUMA_PIN")) return;
+    std::call_once(once[device], [device] {
+        char bdf[64] = {0};
+        if (hipDeviceGetPCIBusId(bdf, sizeof bdf, device) != hipSuccess) return;
+        for (char *c = bdf; *c; c++) *c = (char)tolower(*c);
+        const std::string path = std::string("/sys/bus/pci/devices/") + bdf + "/local_cpulist";
+        FILE *f = fopen(path.c_str(), "r");
+        if (!f) return;
+        char line[4096] = {0};
+        const bool got = fgets(line, sizeof line, f) != nullptr;
+        fclose(f);
+        if (!got) return;
+        Mask &m = masks[device];
+        CPU_ZERO(&m.set);
+        int n_cpus = 0;
+        for (char *tok = strtok(line, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+            int a = 0, b = 0;
+            const int k = sscanf(tok, "%d-%d", &a, &b);
+            if (k == 1) b = a;
+            if (k < 1) continue;
+            for (int c = a; c <= b && c < CPU_SETSIZE; c++) CPU_SET(c, &m.set), n_cpus++;
+        }
+        m.ok = n_cpus > 0;
+    });
+    if (masks[device].ok) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &masks[device].set);
+}
+
+int fail(exg_reader *r, int code, const std::string &msg) {
+    r->error = msg;
+    exg::set_error("%s", msg.c_str());
+    return code;
+}
+
+int list_files(exg_reader *r, const std::string &path) {
+    struct stat st;
+    if (path.empty() || stat(path.c_str(), &st) != 0)
+        return fail(r, EXG_E_IO, "could not register table: cannot open '" + path + "': " + strerror(errno));
+    if (S_ISDIR(st.st_mode)) {
+        // the reference lists a directory (test_fasta_scan.test:55-59, test_fastq_scan.test:65-68)
+        DIR *d = opendir(path.c_str());
+        if (!d) return fail(r, EXG_E_IO, "cannot list '" + path + "'");
+        while (dirent *e = readdir(d)) {
+            if (e->d_name[0] == '.') continue;
+            std::string p = path + (path.back() == '/' ? "" : "/") + e->d_name;
+            struct stat s2;
+            if (stat(p.c_str(), &s2) == 0 && S_ISREG(s2.st_mode)) r->files.push_back(p);
+        }
+        closedir(d);
+        std::sort(r->files.begin(), r->files.end());
+    } else {
+        r->files.push_back(path);
+    }
+    return EXG_OK;
+}
+
+}  // namespace exg_rd
+
+exg_reader::FdCloser::~FdCloser() {
+    if (fd >= 0) close(fd);
+}
+int exg_reader::join_prefetch() {
+    int rc = 0;
+    for (int k = 0; k < 2; k++) {
+        if (pf2.valid && pf2.slot == k) continue;  // (the batch after the coming one: not this call's)
+        if (up_thread_of[k].joinable()) up_thread_of[k].join();
+        if (up_rc_of[k] && !rc) rc = up_rc_of[k];
+        up_rc_of[k] = 0;
+    }
+    if (rc) pf.valid = false;
+    return rc;
+}
+void exg_reader::drop_prefetch2() {
+    for (int k = 0; k < 2; k++)
+        if (pf2.valid && pf2.slot == k && up_thread_of[k].joinable()) {
+            up_thread_of[k].join();
+            up_rc_of[k] = 0;
+        }
+    if (pf2.valid && up_stream) (void)hipStreamSynchronize(up_stream);
+    pf2.valid = false;
+}
+void exg_reader::free_device() {
+    (void)join_prefetch();
+    drop_prefetch2();
+    if (up_stream) (void)hipStreamSynchronize(up_stream);
+    pf.valid = false;
+    d_in = nullptr;
+    for (auto &a : dev_allocs) {
+        exg_rd::dev_pool()->give(device, *a.first, a.second);
+        *a.first = nullptr;
+    }
+    dev_allocs.clear();
+}
+int exg_reader::dev_alloc(void **slot, size_t bytes) {
+    bytes = (bytes + 4095) & ~(size_t)4095;
+    *slot = exg_rd::dev_pool()->take(device, bytes);
+    if (!*slot) return exg_rd::fail(this, EXG_E_HIP, "out of device memory (" + std::to_string(bytes >> 20) + " MiB)");
+    dev_allocs.emplace_back(slot, bytes);
+    return EXG_OK;
+}
+int exg_reader::join_zstd_check() {
+    if (zst_check.joinable()) zst_check.join();
+    if (!zst_check_rc) return EXG_OK;
+    const int rc = zst_check_rc;
+    zst_check_rc = 0;
+    return exg_rd::fail(this, rc, zst_check_error);
+}
+exg_reader::~exg_reader() {
+    exg_rd::DeviceGuard guard(device);
+    if (zst_check.joinable()) zst_check.join();
+    free_device();
+    if (d_res) exg_rd::dev_pool()->give(device, d_res, 4096);
+    if (d_phase) exg_rd::dev_pool()->give(device, d_phase, 4096);
+    if (d_filter_prog) (void)hipFree(d_filter_prog);
+    if (d_filter_consts) (void)hipFree(d_filter_consts);
+    if (d_file) exg_rd::dev_pool()->give(device, d_file, d_file_cap);
+    for (int k = 0; k < 2; k++)
+        if (up_done_of[k]) (void)hipEventDestroy(up_done_of[k]);
+    exg_rd::stream_pool()->give(device, up_stream);
+    exg_rd::stream_pool()->give(device, stream);
+}
+
+namespace exg_rd {
+
+bool pread_parallel(int device, int fd, uint64_t off, size_t n, char *dst, char *d_dst, hipStream_t st, bool *hip_failed) {
+    static const size_t slice = getenv("EXG_IO_SLICE_MB") ? ((size_t)std::max(1, atoi(getenv("EXG_IO_SLICE_MB"))) << 20) : (8u << 20);
+    static const size_t max_io_threads = getenv("EXG_IO_THREADS") ? (size_t)std::max(1, atoi(getenv("EXG_IO_THREADS"))) : 8;
+    const size_t n_slices = (n + slice - 1) / slice;
+    const unsigned nt = (unsigned)std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), std::min<size_t>(n_slices, max_io_threads));
+    std::atomic<size_t> next{0};
+    std::atomic<int> bad{0};
+    auto work = [&](bool own_thread) {
+        (void)hipSetDevice(device);
+        if (own_thread) pin_to_device_node(device);
+        for (size_t i = next.fetch_add(1); i < n_slices; i = next.fetch_add(1)) {
+            const size_t o = i * slice, len = std::min<size_t>(slice, n - o);
+            size_t got = 0;
+            while (got < len) {
+                const ssize_t k = pread(fd, dst + o + got, len - got, (off_t)(off + o + got));
+                if (k <= 0) {
+                    bad = 1;
+                    return;
+                }
+                got += (size_t)k;
+            }
+            if (d_dst && hipMemcpyAsync(d_dst + o, dst + o, len, hipMemcpyHostToDevice, st) != hipSuccess) bad = 2;
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(work, true);
+    work(false);
+    for (auto &t : th) t.join();
+    if (hip_failed) *hip_failed = bad == 2;
+    return bad == 0;
+}
+
+// The whole (compressed) file, or a range of it -> d_dst: windows of 256 MiB through two pooled pinned blocks, each window
+// read by parallel pread and sent slice by slice (a hipMemcpyAsync straight from the page-cache mapping is a pageable
+// copy: one staging thread inside the runtime, 10-33 GB/s depending on the box).
+int upload_file(exg_reader *r, void *d_dst, uint64_t n, uint64_t file_off, hipStream_t st, UploadProgress *prog) {
+    if (!st) st = r->stream;
+    const size_t window = kUploadWindow;
+    const int fd = r->fd_keep->fd;
+    char *blk[2] = {nullptr, nullptr};
+    size_t cap[2] = {0, 0};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    struct Cleanup {
+        hipStream_t st;
+        char **blk;
+        size_t *cap;
+        hipEvent_t *ev;
+        ~Cleanup() {
+            (void)hipStreamSynchronize(st);  // the blocks are sources of copies in flight
+            for (int k = 0; k < 2; k++) {
+                if (blk[k]) global_pool()->give(blk[k], cap[k]);
+                if (ev[k]) (void)hipEventDestroy(ev[k]);
+            }
+        }
+    } cleanup{st, blk, cap, ev};
+    for (int k = 0; k < 2 && (uint64_t)k * window < n; k++) {
+        cap[k] = (size_t)std::min<uint64_t>(window, n - (uint64_t)k * window) + 64;
+        blk[k] = global_pool()->take(&cap[k]);
+        if (!blk[k]) return fail(r, EXG_E_HIP, "out of pinned host memory");
+        RD_HIP(r, hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+    }
+    uint64_t off = 0;
+    for (uint64_t w = 0; off < n; w++) {
+        const int b = (int)(w & 1);
+        if (w >= 2) RD_HIP(r, hipEventSynchronize(ev[b]));  // the block's previous window has left
+        const size_t len = (size_t)std::min<uint64_t>(window, n - off);
+        bool hip_failed = false;
+        if (!pread_parallel(r->device, fd, file_off + off, len, blk[b], (char *)d_dst + off, st, &hip_failed))
+            return hip_failed ? fail(r, EXG_E_HIP, "hipMemcpyAsync failed") : fail(r, EXG_E_IO, "short read");
+        RD_HIP(r, hipEventRecord(ev[b], st));
+        if (prog) {
+            RD_HIP(r, hipEventRecord(prog->done[w], st));
+            std::lock_guard<std::mutex> g(prog->mu);
+            prog->recorded = (size_t)w + 1;
+            prog->cv.notify_all();
+        }
+        off += len;
+    }
+    return EXG_OK;
+}
+
+// file bytes [off, off + n) -> the slot's pinned bounce buffer (parallel pread) -> d_in_slot[slot], on `st`.
+// pread and H2D are pipelined slice by slice: a slice travels while the next ones are still being read.
+int upload_range(exg_reader *r, uint64_t off, uint64_t n, int slot, hipStream_t st) {
+    const uint64_t padded = (n + 15) / 16 * 16;
+    PinnedBlock &stg = r->staging[slot];
+    if (stg.n < padded) {
+        RD_HIP(r, hipStreamSynchronize(r->stream));
+        RD_HIP(r, hipStreamSynchronize(r->up_stream));
+        if (stg.p) global_pool()->give((char *)stg.p, stg.cap), stg.p = nullptr, stg.n = 0;
+        double t0 = now_s();
+        size_t want = (size_t)std::max<uint64_t>(padded, std::min<uint64_t>(r->d_in_cap, r->file->n + 16)) + 64;
+        stg.p = global_pool()->take(&want);
+        if (!stg.p) return fail(r, EXG_E_HIP, "out of pinned host memory");
+        stg.n = want;
+        stg.cap = want;
+        stg.pooled = true;
+        TRACE("pinned staging", t0);
+    }
+    double t0 = now_s();
+    char *dst = (char *)stg.p;
+    char *d_dst = (char *)r->d_in_slot[slot];
+    // the last slice's copy carries the zero padding up to the 16-byte boundary: read everything first when there is one
+    const uint64_t body = n & ~15ull;  // bytes that travel slice by slice
+    bool hip_failed = false;
+    if (body && !pread_parallel(r->device, r->fd_keep->fd, off, (size_t)body, dst, d_dst, st, &hip_failed))
+        return hip_failed ? fail(r, EXG_E_HIP, "hipMemcpyAsync failed") : fail(r, EXG_E_IO, "short read");
+    if (padded > body) {
+        memset(dst + body, 0, (size_t)(padded - body));
+        size_t got = 0;
+        while (body + got < n) {
+            const ssize_t k = pread(r->fd_keep->fd, dst + body + got, (size_t)(n - body) - got, (off_t)(off + body + got));
+            if (k <= 0) return fail(r, EXG_E_IO, "short read");
+            got += (size_t)k;
+        }
+        RD_HIP(r, hipMemcpyAsync(d_dst + body, dst + body, (size_t)(padded - body), hipMemcpyHostToDevice, st));
+    }
+    TRACE("pread + h2d enqueue", t0);
+    return EXG_OK;
+}
+
+// an upload of file bytes [start, start + len) into input slot `slot`, on a host thread of its own: pread + the H2D enqueue
+// block their caller for as long as the bytes take to leave (5.5 ms per 256 MiB)
+void start_upload(exg_reader *r, exg_reader::Prefetch *which, uint64_t start, uint64_t len, int slot) {
+    r->up_rc_of[slot] = 0;
+    r->up_thread_of[slot] = std::thread([r, start, len, slot] {
+        (void)hipSetDevice(r->device);
+        pin_to_device_node(r->device);
+        int rc3 = upload_range(r, start, len, slot, r->up_stream);
+        if (!rc3 && hipEventRecord(r->up_done_of[slot], r->up_stream) != hipSuccess) rc3 = EXG_E_HIP;
+        r->up_rc_of[slot] = rc3;
+    });
+    which->valid = true;
+    which->file_start = start;
+    which->len = len;
+    which->slot = slot;
+}
+
+}  // namespace exg_rd

@@ -273,6 +273,7 @@ struct Batch {  // host vectors of one device batch, shared by its chunks
     void *validity[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // NULL => all valid
     void *payload = nullptr;  // FASTA: compacted sequences
     uint64_t n_rows = 0;
+    uint64_t seq = 0;          // which device batch of its reader this is (exg_chunk.batch_no)
     std::vector<NVec> nested;  // per column; type == 0 for the flat ones
 };
 
@@ -376,6 +377,7 @@ struct exg_reader {
     // current batch
     std::shared_ptr<exg_rd::Batch> batch;
     uint64_t batch_row = 0;
+    uint64_t batch_seq = 0;  // device batches handed out so far (all files)
     uint32_t pending_error = 0;  // parse error to raise once the rows before it have been handed out
     uint64_t pending_error_offset = 0;
 

@@ -14,10 +14,15 @@
 //   * no Arrow hop: the DataChunk's vectors reference the engine's host buffers (kept alive by the vector buffer);
 //   * SEVERAL scan threads: the reference pins MaxThreads() to 1 (module.cpp:36 has an unused `max_threads = 6`).  Here
 //     init_global plans byte-range shards (exg_plan_shards: as many as there are devices, when the input can be sharded and
-//     is large enough), MaxThreads() returns that number, and every init_local claims the next shard and opens ITS reader
-//     on ITS device — one host thread and one GPU per shard inside one process, nothing exchanged between them (SURVEY §8
-//     E1).  COUNT(*) (only the row id projected) is counted per shard and summed by DuckDB's aggregate;
-//   * get_batch_index orders the chunks (shard-major), so an order-preserving plan sees the file order.
+//     is large enough) and MaxThreads() returns that number — an UPPER bound: DuckDB runs fewer scan threads when
+//     `threads` is smaller or the pipeline is not parallel.  A scan thread therefore does not own a shard for life: whenever
+//     its reader is exhausted (or it has none yet) it claims the next unclaimed shard and opens that shard's reader on that
+//     shard's device, until no shard is left — one thread scans every shard in file order, N threads scan N shards at a
+//     time on N GPUs, nothing exchanged between them.  COUNT(*) (only the row id projected) is counted per
+//     shard and summed by DuckDB's aggregate;
+//   * get_batch_index orders the chunks (shard-major, then the shard's device batches), so an order-preserving plan sees
+//     the file order; a device batch (~256 MiB of input) is one DuckDB batch, and the index stays far below DuckDB's
+//     per-pipeline increment (10^13) for any shard count the planner allows.
 //
 // What D provides: the types FunctionData, GlobalTableFunctionState, LocalTableFunctionState, LogicalType, DataChunk,
 // TableFilter, ConstantFilter, ConjunctionFilter, TableFilterSet, TableFilterType, idx_t, the constants
@@ -80,13 +85,14 @@ struct ExonTableFunction {
     struct LocalState : public D::LocalTableFunctionState {
         exg_reader *reader = nullptr;
         uint32_t shard = 0;
-        uint64_t chunk_no = 0;
+        uint64_t batch_no = 0;  // the device batch (of the current shard's reader) the last chunk came from
         bool counted = false;
         uint64_t count_remaining = 0;
         ~LocalState() override {
             if (reader) exg_close(reader);
         }
     };
+    static constexpr unsigned kBatchBits = 24;  // device batches per shard: 2^24 x 256 MiB = 4 PiB
 
     static exg_reader *OpenReader(const BindData &d, const std::string &filter_clause, uint32_t shard, uint32_t n_shards, int device) {
         exg_open_args a;
@@ -182,47 +188,73 @@ struct ExonTableFunction {
         return gs;
     }
 
-    // one per scan thread (<= MaxThreads()): claims the next shard and opens its reader on its device
-    static std::unique_ptr<LocalState> InitLocal(const BindData &data, GlobalState &gs) {
-        auto ls = std::make_unique<LocalState>();
+    // one per scan thread (<= MaxThreads(), and DuckDB may run fewer): the shards are claimed in Scan, one after the other
+    static std::unique_ptr<LocalState> InitLocal(const BindData &, GlobalState &) { return std::make_unique<LocalState>(); }
+
+    // the next unclaimed shard becomes this thread's: false when none is left
+    static bool ClaimShard(const BindData &data, GlobalState &gs, LocalState &ls) {
+        if (ls.reader) {
+            exg_close(ls.reader);  // (chunks it handed out keep their buffers alive on their own)
+            ls.reader = nullptr;
+        }
         const uint32_t shard = gs.next_shard.fetch_add(1);
-        if (shard >= gs.n_shards) return ls;  // more threads than shards: this one has nothing to scan
-        ls->shard = shard;
-        ls->reader = OpenReader(data, gs.filter_clause, shard, gs.n_shards, gs.devices[shard]);
-        return ls;
+        if (shard >= gs.n_shards) {
+            gs.next_shard.store(gs.n_shards);  // (no wrap-around, however often exhausted threads ask)
+            return false;
+        }
+        ls.shard = shard;
+        ls.batch_no = 0;
+        ls.counted = false;
+        ls.reader = OpenReader(data, gs.filter_clause, shard, gs.n_shards, gs.devices[shard]);
+        return true;
     }
 
-    // module.cpp:257-294: leaves output.size() == 0 at the end of the (thread's) stream
+    // module.cpp:257-294: leaves output.size() == 0 at the end of the (thread's) stream — here: when its reader is
+    // exhausted AND no shard is left to claim
     static void Scan(const BindData &data, GlobalState &gs, LocalState *ls, typename D::DataChunk &output) {
         if (!ls) return;  // (module.cpp:259-261)
         D::SetCardinality(output, 0);
-        if (!ls->reader) return;
-        if (gs.count_only) {
-            if (!ls->counted) {
-                if (exg_count_only(ls->reader, &ls->count_remaining) != EXG_OK) throw std::runtime_error(exg_reader_error(ls->reader));
-                ls->counted = true;
+        for (;;) {
+            if (!ls->reader && !ClaimShard(data, gs, *ls)) return;
+            if (gs.count_only) {
+                if (!ls->counted) {
+                    if (exg_count_only(ls->reader, &ls->count_remaining) != EXG_OK) throw std::runtime_error(exg_reader_error(ls->reader));
+                    ls->counted = true;
+                }
+                if (ls->count_remaining == 0) {
+                    if (!ClaimShard(data, gs, *ls)) return;
+                    continue;
+                }
+                const idx_t n = ls->count_remaining < (uint64_t)D::VectorSize ? (idx_t)ls->count_remaining : (idx_t)D::VectorSize;
+                ls->count_remaining -= n;
+                D::SetCardinality(output, n);
+                return;
             }
-            const idx_t n = ls->count_remaining < (uint64_t)D::VectorSize ? (idx_t)ls->count_remaining : (idx_t)D::VectorSize;
-            ls->count_remaining -= n;
-            D::SetCardinality(output, n);
-            ls->chunk_no++;
+            auto buf = std::make_shared<ExonChunk>();
+            buf->reader = ls->reader;
+            if (exg_next_chunk(ls->reader, &buf->chunk) != EXG_OK) throw std::runtime_error(exg_reader_error(ls->reader));
+            if (buf->chunk.n_rows == 0) {
+                if (!ClaimShard(data, gs, *ls)) return;
+                continue;
+            }
+            D::SetCardinality(output, (idx_t)buf->chunk.n_rows);
+            for (size_t i = 0; i < gs.column_ids.size(); i++) {
+                const idx_t col = gs.column_ids[i];
+                if (col == D::RowId) continue;
+                D::Reference(output, (idx_t)i, data.all_types.at(col), *buf->chunk.vectors[col], buf);
+            }
+            ls->batch_no = buf->chunk.batch_no;
             return;
         }
-        auto buf = std::make_shared<ExonChunk>();
-        buf->reader = ls->reader;
-        if (exg_next_chunk(ls->reader, &buf->chunk) != EXG_OK) throw std::runtime_error(exg_reader_error(ls->reader));
-        if (buf->chunk.n_rows == 0) return;
-        D::SetCardinality(output, (idx_t)buf->chunk.n_rows);
-        for (size_t i = 0; i < gs.column_ids.size(); i++) {
-            const idx_t col = gs.column_ids[i];
-            if (col == D::RowId) continue;
-            D::Reference(output, (idx_t)i, data.all_types.at(col), *buf->chunk.vectors[col], buf);
-        }
-        ls->chunk_no++;
     }
 
-    // TableFunction::get_batch_index: chunks of shard s come before those of shard s + 1
-    static idx_t BatchIndex(const LocalState &ls) { return ((idx_t)ls.shard << 40) + (idx_t)ls.chunk_no; }
+    // TableFunction::get_batch_index: the chunks of shard s come before those of shard s + 1, a shard's device batches in
+    // their order; the chunks of one device batch share an index (they are one DuckDB batch).  Non-decreasing per scan
+    // thread: a thread claims shards in increasing order.  64 shards x 2^24 stays below 1.1e9 (DuckDB's pipelines are 1e13 apart).
+    static idx_t BatchIndex(const LocalState &ls) {
+        const uint64_t b = ls.batch_no < ((uint64_t)1 << kBatchBits) ? ls.batch_no : ((uint64_t)1 << kBatchBits) - 1;
+        return ((idx_t)ls.shard << kBatchBits) + (idx_t)b;
+    }
 
     // module.cpp:320-382 on rust/src/arrow_reader.rs:173-197 (`replacement_scan`, same symbol as exon/include/rust.hpp:48):
     // the table function that replaces a bare 'file' reference, or "" when the name is not one of ours

@@ -41,7 +41,8 @@ class Schema(C.Structure):
 
 class Chunk(C.Structure):
     _fields_ = [("n_rows", C.c_uint64), ("n_columns", C.c_int), ("data", C.c_void_p * 16),
-                ("validity", C.c_void_p * 16), ("keepalive", C.c_void_p), ("vectors", C.POINTER(ExgVector) * 16)]
+                ("validity", C.c_void_p * 16), ("keepalive", C.c_void_p), ("vectors", C.POINTER(ExgVector) * 16),
+                ("batch_no", C.c_uint64)]
 
 
 def type_tree(t):
@@ -220,9 +221,14 @@ class Relation:
         self.trees = [type_tree(sch.tree[i].contents) for i in range(sch.n_columns)]
         self._l.exon_tf_close(h)
 
+    #: how many scan threads `_scan` runs: None = MaxThreads() (DuckDB's upper bound); DuckDB itself runs fewer when
+    #: `SET threads` is smaller or the pipeline is sequential — the tests set 1 (and other numbers below MaxThreads())
+    scan_threads = None
+
     def _scan(self, column_ids, filters=None, decode=None):
-        """Plays DuckDB: init_global once, init_local + the scan loop on MaxThreads() threads (one per shard the glue
-        planned), every chunk handed to `decode` while it is alive.  -> [(batch_index, n_rows, decoded)] in batch order."""
+        """Plays DuckDB: init_global once, init_local + the scan loop on up to MaxThreads() threads, every chunk handed
+        to `decode` while it is alive.  -> [(batch_index, n_rows, decoded)] in batch order (stable: the chunks of one
+        batch keep the order their thread produced them in)."""
         import threading
         h = C.c_void_p()
         rc = self._l.exon_tf_bind(self.fn_name.encode(), self.path.encode(),
@@ -263,7 +269,8 @@ class Relation:
                     with lock:
                         out.append(item)
 
-            threads = [threading.Thread(target=worker) for _ in range(self.last_max_threads)]
+            n_threads = self.last_max_threads if self.scan_threads is None else max(1, min(self.scan_threads, self.last_max_threads))
+            threads = [threading.Thread(target=worker) for _ in range(n_threads)]
             for t in threads:
                 t.start()
             for t in threads:

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define EXG_ABI_VERSION 4
+#define EXG_ABI_VERSION 5
 
 /* DuckDB v0.8.1 STANDARD_VECTOR_SIZE; the reference asks the Rust side for
  * batches of exactly this many rows (module.cpp:83, :233). */
@@ -391,6 +391,8 @@ typedef struct exg_chunk {
     uint64_t *validity[16];    /* NULL => all valid; else ceil(n_rows/64) words */
     void *keepalive;           /* opaque; payload + vectors stay valid until exg_release_chunk */
     const exg_vector *vectors[16]; /* every column as a vector tree (data / validity above are vectors[c]'s own) */
+    uint64_t batch_no;         /* which device batch of this reader the rows come from (0, 1, ...: non-decreasing; what the
+                                * table function reports as DuckDB's batch index, module.cpp has none: MaxThreads() == 1) */
 } exg_chunk;
 
 int exg_open(const exg_open_args *args, exg_reader **out);

@@ -429,6 +429,34 @@ def test_parallel_scan_of_bgzf(con, oracle, tmp_path, monkeypatch):
     assert rel.count() == 20000
 
 
+@pytest.mark.parametrize("scan_threads", [1, 2, 3])
+def test_fewer_scan_threads_than_shards(con, oracle, tmp_path, monkeypatch, scan_threads):
+    """MaxThreads() is an upper bound: DuckDB runs fewer scan threads under `SET threads=1`, with threads < GPUs, or
+    when the sink is not parallel (Pipeline::ScheduleParallel).  Every shard must still be scanned — a thread whose
+    reader is exhausted claims the next unclaimed shard — with the rows in file order by batch index, and every device
+    batch one DuckDB batch (its chunks share an index; indices never decrease on a thread)."""
+    from test_reader_shards_gpu import _bgzf as bgzf
+    fq = bytes(oracle.synth_fastq(332 * 30000))
+    vcf = bytes(oracle.synth_vcf(20000))
+    (tmp_path / "p.fastq").write_bytes(fq)
+    (tmp_path / "p.vcf").write_bytes(vcf)
+    (tmp_path / "b.fastq.gz").write_bytes(bgzf(fq, 65280))
+    cases = (("p.fastq", "read_fastq"), ("p.vcf", "read_vcf"), ("b.fastq.gz", "read_fastq"))
+    want = {name: con.table_function(fn, str(tmp_path / name)).fetchall() for name, fn in cases}
+    monkeypatch.setenv("EXON_GPU_SHARDS", "5")
+    monkeypatch.setenv("EXG_DEVICE_BATCH_BYTES", str(1 << 20))
+    for name, fn in cases:
+        rel = con.table_function(fn, str(tmp_path / name))
+        rel.scan_threads = scan_threads
+        rows = rel.fetchall()
+        assert rel.last_max_threads == 5
+        assert rows == want[name], name
+        assert rel.count() == len(want[name])
+        idx = [b for b, _, _ in rel._scan([0])]
+        assert idx == sorted(idx) and max(idx) < 10 ** 13
+        assert len(set(idx)) < len(idx), "a device batch of several chunks is one batch"
+
+
 def test_plan_shards_policy(gpu, golden_dir, tmp_path, monkeypatch):
     import ctypes as C
     from exon_duckdb_amd.abi import OpenArgs
