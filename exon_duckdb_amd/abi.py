@@ -168,3 +168,9 @@ SIGNATURES = {
     "exg_synth_fasta": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]),
     "exg_plan_shards": (C.c_int, [C.POINTER(OpenArgs), C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.c_uint32]),
 }
+
+
+class ReaderStats(C.Structure):
+    _fields_ = [("device_bytes_now", C.c_uint64), ("device_bytes_peak", C.c_uint64), ("device_mem_cap", C.c_uint64),
+                ("device_batch_bytes", C.c_uint64), ("device_batches", C.c_uint64), ("decoded_segments", C.c_uint64),
+                ("reserved", C.c_uint64 * 4)]

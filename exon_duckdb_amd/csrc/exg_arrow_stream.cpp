@@ -23,7 +23,7 @@
 
 #include "exg_arrow.hpp"
 #include "exg_filter.hpp"
-#include "exg_reader.hpp"
+#include "exg_rd_source.hpp"
 
 using namespace exg_rd;
 namespace ea = exg::arrow;
@@ -111,7 +111,7 @@ Field key_field(const KeyDef &k) {
 struct DevArena {  // bump allocator, reset per batch; what does not fit comes from the device pool, and the next batch's
                    // arena is as large as this batch turned out to need (hipMalloc / hipFree per batch cost milliseconds)
     char *base = nullptr;
-    size_t cap = 0, used = 0, extra_bytes = 0, need = 0;
+    size_t cap = 0, used = 0, extra_bytes = 0, need = 0, min_extra = 1u << 20;
     std::vector<std::pair<void *, size_t>> extra;
     int dev = 0;
     void *alloc(size_t n) {
@@ -122,7 +122,7 @@ struct DevArena {  // bump allocator, reset per batch; what does not fit comes f
             used += n;
             return p;
         }
-        const size_t sz = n < (1u << 20) ? (1u << 20) : n;  // (the pool keeps blocks of 1 MiB and more)
+        const size_t sz = n < min_extra ? min_extra : n;  // (1 MiB: small blocks would come one by one; 64 KiB under a memory budget)
         void *p = dev_pool()->take(dev, sz);
         if (!p) return nullptr;
         extra.emplace_back(p, sz);
@@ -639,7 +639,8 @@ int arrow_emit(exg_reader *r, const ScanCtx &ctx) {
     st->arena.reset();
     // sized for the typical batch: offsets + values + views of every column; what a batch needs beyond that comes from the
     // pool and enlarges the arena of the next one
-    st->arena.prepare(r->device, (size_t)std::min<uint64_t>(r->d_in_cap * 3 + (64u << 20), 6ull << 30));
+    st->arena.min_extra = r->mem_cap ? (64u << 10) : (1u << 20);
+    st->arena.prepare(r->device, (size_t)std::min<uint64_t>(r->mem_cap ? r->d_in_cap * 6 + (1u << 20) : r->d_in_cap * 3 + (64u << 20), 6ull << 30));
     EM_TRACE("arena");
     if (!st->copy_stream) {
         EM_HIP(stream_pool()->take(r->device, &st->copy_stream));
@@ -948,7 +949,7 @@ static void produce(StreamState *st) {
             return;
         }
         if (r->file_done) {
-            if (r->join_zstd_check()) {
+            if (r->finish_source()) {
                 st->last_error = r->error;
                 st->produced_state = 3;
                 return;
@@ -1122,8 +1123,12 @@ void nested_schema(exg_reader *r, exg_schema *out) {
 int nested_emit(exg_reader *r, const ScanCtx &ctx, Batch *b, const uint32_t *d_row_map, uint64_t *n_rows) {
     StreamState *st = (StreamState *)r->nested_state.get();
     if (!st) return fail(r, EXG_E_INVALID_ARG, "nested_emit without nested_prepare");
+    if (getenv("EXG_TRACE"))
+        fprintf(stderr, "[exg] nested emit: the batch before used %zu KiB of a %zu KiB arena + %zu extra blocks (%zu KiB)\n", st->arena.used >> 10,
+                st->arena.cap >> 10, st->arena.extra.size(), st->arena.extra_bytes >> 10);
     st->arena.reset();
-    st->arena.prepare(r->device, (size_t)std::min<uint64_t>(r->d_in_cap * 3 + (64u << 20), 6ull << 30));
+    st->arena.min_extra = r->mem_cap ? (64u << 10) : (1u << 20);
+    st->arena.prepare(r->device, (size_t)std::min<uint64_t>(r->mem_cap ? r->d_in_cap * 6 + (1u << 20) : r->d_in_cap * 3 + (64u << 20), 6ull << 30));
     if (!st->copy_stream) {
         EM_HIP(stream_pool()->take(r->device, &st->copy_stream));
         st->copy_dev = r->device;
@@ -1340,8 +1345,8 @@ extern "C" ReaderResult new_reader(ArrowArrayStream *stream_ptr, const char *uri
             return result_error("could not register table: " + r->error);
         r->file.reset();
         r->fd_keep.reset();
-        if (r->join_zstd_check()) return result_error("could not register table: " + r->error);
-        if (r->d_file) dev_pool()->give(r->device, r->d_file, r->d_file_cap), r->d_file = nullptr;
+        if (r->finish_source()) return result_error("could not register table: " + r->error);
+        r->src.reset();
         r->file_idx = 0;
         r->file_pos = 0;
         r->file_done = true;

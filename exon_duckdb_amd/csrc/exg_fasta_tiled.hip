@@ -570,9 +570,18 @@ __global__ __launch_bounds__(kThreads) void k_fa_fused(FastaDev a, TileArrays t,
 // longer definition line is walked in HBM (a chain of dependent loads, ~15 us: inside the scan it would stall a whole
 // wavefront for the one lane that owns a '>').
 static constexpr uint32_t kDefStage = 128, kDefStride = kDefStage / 4 + 1;  // dwords per thread: the odd stride spreads the banks
+// A buffer without EXG_F_EOF is a batch of a longer input: its last record is still open (its sequence may go on behind the
+// buffer), so it is nobody's row yet — the scan reports where its definition line begins (consumed_bytes) and the next batch
+// starts there.
+__device__ __forceinline__ uint64_t fa_closed_records(const FastaDev &a, const TileArrays &t) {
+    uint64_t n_rec = t.totals[0];
+    if (!(a.flags & EXG_F_EOF) && n_rec) n_rec--;
+    return n_rec;
+}
+
 __global__ __launch_bounds__(256) void k_fa_tile_defs(FastaDev a, TileArrays t, ScanWsHeader *hdr) {
     __shared__ uint32_t s_line[256 * kDefStride];
-    uint64_t n_rec = t.totals[0];
+    uint64_t n_rec = fa_closed_records(a, t);
     if (n_rec > t.rec_cap) n_rec = t.rec_cap;
     const bool no_store = (a.flags & EXG_F_NO_STORE) != 0;
     uint32_t *slot = s_line + threadIdx.x * kDefStride;
@@ -628,7 +637,7 @@ __global__ __launch_bounds__(256) void k_fa_tile_defs(FastaDev a, TileArrays t, 
 
 __global__ __launch_bounds__(256) void k_fa_tile_strings(FastaDev a, TileArrays t, ScanWsHeader *hdr) {
     if (a.flags & EXG_F_NO_STORE) return;
-    uint64_t n_rec = t.totals[0];
+    uint64_t n_rec = fa_closed_records(a, t);
     if (n_rec > t.rec_cap) n_rec = t.rec_cap;
     const uint64_t n = n_rec < a.capacity ? n_rec : a.capacity;
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
@@ -649,12 +658,14 @@ __global__ __launch_bounds__(256) void k_fa_tile_strings(FastaDev a, TileArrays 
 
 __global__ void k_fa_tile_finalize(FastaDev a, TileArrays t, ScanWsHeader *hdr, exg_scan_result *res) {
     if (threadIdx.x || blockIdx.x) return;
-    const uint64_t n_owned = t.totals[0];
+    const uint64_t n_all = t.totals[0], n_owned = fa_closed_records(a, t);
+    const bool open_tail = !(a.flags & EXG_F_EOF);
     exg_scan_result r;
     r.n_lines = hdr->total_lines;
     r.flags = hdr->flags;
-    if (n_owned > t.rec_cap) r.flags |= EXG_RF_INDEX_OVERFLOW;
-    r.payload_bytes = t.totals[1];
+    if (n_all > t.rec_cap) r.flags |= EXG_RF_INDEX_OVERFLOW;
+    // (the open record's sequence bytes were compacted like everyone's: they are simply not handed out)
+    r.payload_bytes = open_tail ? (n_all && n_all <= t.rec_cap ? t.rec_start[n_all - 1] : 0) : t.totals[1];
     r.reserved = 0;
     r.error_code = 0;
     r.error_offset = ~0ull;
@@ -667,7 +678,7 @@ __global__ void k_fa_tile_finalize(FastaDev a, TileArrays t, ScanWsHeader *hdr, 
         atomicMin(&hdr->err_word, (0ull << 8) | (e == 0 ? EXG_PE_FASTA_EMPTY_DEF : EXG_PE_FASTA_MISSING_PREFIX));
     }
     uint64_t n_rec = (n_owned < a.capacity || (a.flags & EXG_F_NO_STORE)) ? n_owned : a.capacity;
-    uint64_t consumed = a.n_bytes;
+    uint64_t consumed = open_tail ? (n_all && n_all <= t.rec_cap ? t.rec_def_off[n_all - 1] : 0) : a.n_bytes;
     const unsigned long long err = hdr->err_word;
     if (err != kNoError) {
         const uint64_t rec = err >> 8;

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void k_win_apply(const uint16_t *__restrict__ 
 
 // ---- 5. resolve ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_resolve(const ChunkOut *__restrict__ chunks, const uint8_t *__restrict__ windows,
-                                                 uint8_t *__restrict__ d_out, uint32_t n_chunks, uint32_t *bad) {
+                                                 uint8_t *__restrict__ d_out, uint32_t n_chunks, uint32_t *bad, uint32_t have_window0) {
     // blockIdx.y = chunk; 16 symbols per thread -> one 16-byte store when the destination is aligned
     const uint32_t c = blockIdx.y;
     const ChunkOut ch = chunks[c];
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void k_resolve(const ChunkOut *__restrict__ ch
         for (uint32_t k = 0; k < 16; k++) {
             uint16_t sy = k < cnt ? ch.sym[i0 + k] : (uint16_t)0;
             b[k] = sy & 0x8000u ? w[sy & 0x7FFFu] : (uint8_t)sy;
-            if ((sy & 0x8000u) && c == 0) atomicOr(bad, 1u);  // nothing precedes the first chunk
+            if ((sy & 0x8000u) && c == 0 && !have_window0) atomicOr(bad, 1u);  // nothing precedes a member's first chunk
         }
         uint8_t *dst = d_out + ch.out_off + i0;
         if (cnt == 16 && (((uintptr_t)dst) & 15) == 0) {
@@ -245,6 +245,16 @@ __global__ __launch_bounds__(256) void k_resolve(const ChunkOut *__restrict__ ch
         } else {
             for (uint32_t k = 0; k < cnt; k++) dst[k] = b[k];
         }
+    }
+}
+
+// The 32 KiB of output a later round of the same member will have in front of it: the tail of this round's bytes, topped up
+// from the window this round had in front when it produced less than that (old_win NULL: zeros).
+__global__ __launch_bounds__(256) void k_win_tail(const uint8_t *__restrict__ out, unsigned long long produced, const uint8_t *old_win,
+                                                  uint8_t *new_win) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < 32768; i += gridDim.x * 256) {
+        const long long k = (long long)produced + (long long)i - 32768;
+        new_win[i] = k >= 0 ? out[k] : (old_win ? old_win[32768 + k] : (uint8_t)0);
     }
 }
 
@@ -303,24 +313,48 @@ static double st_now() {
 // comp_off and at most comp_size bytes may be read.  On success *d_out_p is a hipMalloc'd buffer (caller frees) holding
 // *produced inflated bytes (+ 64 bytes of zeroed slack) and *consumed the compressed bytes used (byte aligned after the
 // final block).  Synchronises `stream` several times (it returns sizes to the host).
-extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint64_t comp_size, uint64_t chunk_bytes,
-                                  void **d_out_p, uint64_t *produced, uint64_t *consumed, void *stream_v) {
+//
+// One ROUND of a member (exg_inflate_round, include/exon_gpu.h) is the same with three differences: the decode starts at
+// `start_bit` (where the round before ended) with the 32 KiB that round left as the window in front of the first chunk
+// (`d_window`, updated in place for the next round); when `partial` is set more compressed bytes follow behind comp_size,
+// so the piece behind the last block start that was found is NOT decoded — the round ends at a block boundary the chain
+// reached at or behind that start, and nothing of the stream's end (trailer, ISIZE) is looked at; and `front_reserve` bytes
+// stay free in front of the output (the reader prepends the previous segment's unconsumed tail there).
+struct RoundArgs {
+    uint64_t start_bit = 0;
+    bool partial = false;
+    void *d_window = nullptr;   // 32768 bytes: in = the output in front of start_bit (have_window), out = in front of end_bit
+    bool have_window = false;
+    uint64_t front_reserve = 0;
+    double ratio_hint = 0;      // inflated / compressed seen so far (0: unknown)
+    // results
+    uint64_t out_alloc = 0;     // what *d_out was taken from the pool with (give it back with this size)
+    uint64_t end_bit = 0;
+    bool final_block = false;
+    bool need_more = false;     // partial: no block start in the window (or the chain ran out of input): retry with more bytes
+};
+static int inflate_stream_impl(const void *d_comp_v, uint64_t comp_off, uint64_t comp_size, uint64_t chunk_bytes, void **d_out_p,
+                               uint64_t *produced, RoundArgs &ra, void *stream_v) {
     hipStream_t stream = (hipStream_t)stream_v;
     t_call_stream = stream;
     const uint8_t *d_comp = (const uint8_t *)d_comp_v;
-    if (!d_comp || !d_out_p || !produced || !consumed || ((uintptr_t)d_comp & 15)) {
+    if (!d_comp || !d_out_p || !produced || ((uintptr_t)d_comp & 15)) {
         set_error("exg_inflate_stream: bad arguments");
         return EXG_E_INVALID_ARG;
     }
     *d_out_p = nullptr;
-    *produced = *consumed = 0;
+    *produced = 0;
+    ra.need_more = ra.final_block = false;
+    ra.end_bit = ra.start_bit;
     if (chunk_bytes < 32768) chunk_bytes = 32768;
     const double t_begin = st_now();
     const uint64_t total_bits = comp_size * 8;
-    // ---- 1. block starts near the chunk boundaries
-    const uint32_t n_bound = (uint32_t)std::min<uint64_t>((comp_size + chunk_bytes - 1) / chunk_bytes, 1u << 20);
-    std::vector<uint64_t> starts;  // bit offsets of the chunk starts (sorted, unique); starts[0] = 0
-    starts.push_back(0);
+    const uint64_t bit0 = ra.start_bit;
+    // ---- 1. block starts near the chunk boundaries (counted from the byte the round starts in)
+    const uint64_t byte0 = bit0 / 8;
+    const uint32_t n_bound = (uint32_t)std::min<uint64_t>((comp_size - std::min(comp_size, byte0) + chunk_bytes - 1) / chunk_bytes, 1u << 20);
+    std::vector<uint64_t> starts;  // bit offsets of the chunk starts (sorted, unique); starts[0] = where the round starts
+    starts.push_back(bit0);
     // first block start in each [from, to) (bit ranges), ~0 where none was found
     bool text_mode = !getenv("EXG_STREAM_NO_TEXT_PROBE");
     auto find_starts = [&](const std::vector<std::pair<uint64_t, uint64_t>> &ranges, std::vector<uint64_t> *found) -> int {
@@ -350,7 +384,7 @@ extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint6
     if (n_bound > 1) {
         std::vector<std::pair<uint64_t, uint64_t>> ranges;
         for (uint32_t k = 1; k < n_bound; k++)
-            ranges.emplace_back((uint64_t)k * chunk_bytes * 8, std::min<uint64_t>((uint64_t)(k + 1) * chunk_bytes * 8, total_bits));
+            ranges.emplace_back((byte0 + (uint64_t)k * chunk_bytes) * 8, std::min<uint64_t>((byte0 + (uint64_t)(k + 1) * chunk_bytes) * 8, total_bits));
         std::vector<uint64_t> found;
         int rc = find_starts(ranges, &found);
         if (rc) return rc;
@@ -370,6 +404,13 @@ extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint6
         ST_TRACE("[exg] inflate stream: %u boundaries searched, %zu block starts found, %.1f ms\n", n_bound - 1, starts.size() - 1,
                  (st_now() - t_begin) * 1e3);
     }
+    // a partial round ends at (or, behind a false start, just behind) the last block start found: what follows it is the
+    // next round's, decoded when its bytes are there
+    const uint64_t round_end = ra.partial ? starts.back() : 0;
+    if (ra.partial && starts.size() < 2) {
+        ra.need_more = true;
+        return EXG_OK;
+    }
     // ---- 2 + 3. decode every candidate chunk, then walk the chain of chunks from bit 0: a chunk counts only if it
     // starts exactly where the previous one ended.  A false block start is simply never reached (the chunk in front
     // of it runs on to the next real boundary); if that boundary is not a candidate either, the piece from there to
@@ -378,7 +419,8 @@ extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint6
     // byte is 9 GB for a 0.5 GB file (and hipMalloc of that was seen to take 0.5 s): when the stream runs to the end
     // of the buffer, the gzip trailer's ISIZE (mod 2^32) gives the real ratio; pieces that still overflow are refitted.
     uint64_t cap_factor0 = 8;
-    if (comp_size >= 8) {
+    if (ra.ratio_hint > 0 && ra.ratio_hint < 64.0) cap_factor0 = std::min<uint64_t>(8, std::max<uint64_t>(3, (uint64_t)(ra.ratio_hint * 1.5 + 1.0)));
+    if (!ra.partial && bit0 == 0 && comp_size >= 8) {
         uint32_t isize = 0;
         ST_HIP(hipMemcpyAsync(&isize, d_comp + comp_off + comp_size - 4, 4, hipMemcpyDeviceToHost, stream));
         ST_HIP(hipStreamSynchronize(stream));
@@ -452,7 +494,7 @@ extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint6
     };
     {
         std::vector<std::pair<uint64_t, uint64_t>> spans;
-        for (size_t k = 0; k < starts.size(); k++) spans.emplace_back(starts[k], k + 1 < starts.size() ? starts[k + 1] : 0);
+        for (size_t k = 0; k + (ra.partial ? 1 : 0) < starts.size(); k++) spans.emplace_back(starts[k], k + 1 < starts.size() ? starts[k + 1] : 0);
         int rc = run_jobs(spans, cap_factor0, nullptr, false, nullptr);
         if (rc) return rc;
     }
@@ -473,7 +515,12 @@ extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint6
             std::vector<std::pair<uint64_t, uint64_t>> gaps;  // [e, next candidate or 0 = end of stream)
             uint64_t refit = ~0ull;                             // a piece whose output did not fit
             bool done = false;
-            for (uint64_t e = 0;;) {
+            for (uint64_t e = bit0;;) {
+                if (ra.partial && e >= round_end) {  // a block boundary the chain reached: the round ends here
+                    done = gaps.empty();
+                    if (done) end_bit = e;
+                    break;
+                }
                 auto it = decoded.find(e);
                 if (it == decoded.end()) {
                     auto nxt = std::upper_bound(starts.begin(), starts.end(), e);
@@ -489,6 +536,10 @@ extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint6
                 }
                 if (pc.st.code) {
                     if (!gaps.empty()) break;  // behind a break the walk is only a guess: settle the gaps first
+                    if (ra.partial && (pc.st.end_bit + 7) / 8 + 64 >= comp_size) {  // ran into the end of the bytes that are here
+                        ra.need_more = true;
+                        return EXG_OK;
+                    }
                     set_error("corrupt deflate stream (code %u at bit %llu)", pc.st.code, (unsigned long long)e);
                     return EXG_E_PARSE;
                 }
@@ -499,6 +550,7 @@ extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint6
                 }
                 if (pc.st.final_block) {
                     done = gaps.empty();
+                    if (done) ra.final_block = true;
                     break;
                 }
                 if (pc.st.end_bit <= e) {
@@ -592,12 +644,31 @@ extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint6
     // (allocated at the device pool's size class: the reader hands the buffer to that pool when the file is done)
     int out_dev = 0;
     ST_HIP(hipGetDevice(&out_dev));
-    d_out = exg_rd::dev_pool()->take(out_dev, total + 64);
-    if (!d_out) ST_HIP(hipErrorOutOfMemory);
+    // whatever way the rest is left, the output goes back to the pool unless it is handed to the caller
+    struct OutGuard {
+        int dev;
+        hipStream_t st;
+        void *p = nullptr;
+        size_t sz = 0;
+        ~OutGuard() {
+            if (!p) return;
+            (void)hipStreamSynchronize(st);
+            exg_rd::dev_pool()->give(dev, p, sz);
+        }
+    } out_guard{out_dev, stream};
+    const uint64_t reserve = ra.front_reserve;
+    out_guard.sz = (size_t)(reserve + total + 64);
+    out_guard.p = exg_rd::dev_pool()->take(out_dev, out_guard.sz);
+    if (!out_guard.p) ST_HIP(hipErrorOutOfMemory);
+    for (ChunkOut &c : co) c.out_off += reserve;
+    d_out = out_guard.p;
     ST_HIP(hipMemcpyAsync(d_co.p, co.data(), n * sizeof(ChunkOut), hipMemcpyHostToDevice, stream));
-    ST_HIP(hipMemsetAsync(d_win.p, 0, 32768, stream));
+    if (ra.have_window && ra.d_window)
+        ST_HIP(hipMemcpyAsync(d_win.p, ra.d_window, 32768, hipMemcpyDeviceToDevice, stream));
+    else
+        ST_HIP(hipMemsetAsync(d_win.p, 0, 32768, stream));
     ST_HIP(hipMemsetAsync(d_bad.p, 0, 4, stream));
-    ST_HIP(hipMemsetAsync((char *)d_out + total, 0, 64, stream));
+    ST_HIP(hipMemsetAsync((char *)d_out + reserve + total, 0, 64, stream));
     {
         uint32_t group = 1;
         while (group * group < n) group++;
@@ -610,14 +681,17 @@ extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint6
         ST_HIP(hipGetLastError());
         ST_HIP(hipStreamSynchronize(stream));  // d_maps is freed when this scope ends
     }
-    hipLaunchKernelGGL(k_resolve, dim3(256, n), dim3(256), 0, stream, (const ChunkOut *)d_co.p, (const uint8_t *)d_win.p,
-                       (uint8_t *)d_out, n, (uint32_t *)d_bad.p);
+    if (n)
+        hipLaunchKernelGGL(k_resolve, dim3(256, n), dim3(256), 0, stream, (const ChunkOut *)d_co.p, (const uint8_t *)d_win.p,
+                           (uint8_t *)d_out, n, (uint32_t *)d_bad.p, ra.have_window ? 1u : 0u);
+    if (ra.d_window)  // what the next round of this member has in front of it
+        hipLaunchKernelGGL(k_win_tail, dim3(32), dim3(256), 0, stream, (const uint8_t *)d_out + reserve, (unsigned long long)total,
+                           ra.have_window ? (const uint8_t *)d_win.p : (const uint8_t *)nullptr, (uint8_t *)ra.d_window);
     uint32_t bad = 0;
     hipError_t he = hipGetLastError();
     if (he == hipSuccess) he = hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, stream);
     if (he == hipSuccess) he = hipStreamSynchronize(stream);
     if (he != hipSuccess || bad) {
-        exg_rd::dev_pool()->give(out_dev, d_out, total + 64);
         if (bad)
             set_error("corrupt deflate stream (distance before the start of the output)");
         else
@@ -627,7 +701,53 @@ extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint6
     ST_TRACE("[exg] inflate stream: %u chunks in the chain, %llu bytes, %.1f ms in all\n", n, (unsigned long long)total,
              (st_now() - t_begin) * 1e3);
     *d_out_p = d_out;
+    ra.out_alloc = out_guard.sz;
+    out_guard.p = nullptr;  // the caller's from here on
     *produced = total;
-    *consumed = (end_bit + 7) / 8;
+    ra.end_bit = end_bit;
+    return EXG_OK;
+}
+
+// d_comp: the file's compressed bytes on the device (16-byte aligned); the DEFLATE stream of the member starts at
+// comp_off and at most comp_size bytes may be read.  On success *d_out_p is a block of the library's device pool holding
+// *produced inflated bytes (+ 64 bytes of zeroed slack) — the caller gives it back with exg_free_device(p) (or hipFree: pool
+// blocks are whole allocations) — and *consumed the compressed bytes used (byte aligned after the final block).
+// Synchronises `stream` several times (it returns sizes to the host).  On any error nothing is left allocated.
+extern "C" int exg_inflate_stream(const void *d_comp_v, uint64_t comp_off, uint64_t comp_size, uint64_t chunk_bytes,
+                                  void **d_out_p, uint64_t *produced, uint64_t *consumed, void *stream_v) {
+    if (!consumed) {
+        set_error("exg_inflate_stream: bad arguments");
+        return EXG_E_INVALID_ARG;
+    }
+    *consumed = 0;
+    RoundArgs ra;
+    const int rc = inflate_stream_impl(d_comp_v, comp_off, comp_size, chunk_bytes, d_out_p, produced, ra, stream_v);
+    if (rc) return rc;
+    *consumed = (ra.end_bit + 7) / 8;
+    return EXG_OK;
+}
+
+extern "C" int exg_inflate_round(exg_inflate_round_args *a) {
+    if (!a) {
+        set_error("exg_inflate_round: null argument");
+        return EXG_E_INVALID_ARG;
+    }
+    RoundArgs ra;
+    ra.start_bit = a->start_bit;
+    ra.partial = a->partial != 0;
+    ra.d_window = a->d_window;
+    ra.have_window = a->have_window != 0;
+    ra.front_reserve = a->front_reserve;
+    ra.ratio_hint = a->ratio_hint;
+    a->d_out = nullptr;
+    a->produced = a->out_alloc = 0;
+    a->need_more = a->final_block = 0;
+    a->end_bit = a->start_bit;
+    const int rc = inflate_stream_impl(a->d_comp, a->comp_off, a->comp_size, a->chunk_bytes, &a->d_out, &a->produced, ra, a->stream);
+    if (rc) return rc;
+    a->out_alloc = ra.out_alloc;
+    a->end_bit = ra.end_bit;
+    a->final_block = ra.final_block;
+    a->need_more = ra.need_more;
     return EXG_OK;
 }

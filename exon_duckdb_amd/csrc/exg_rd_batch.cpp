@@ -20,25 +20,181 @@
 #include <memory>
 #include <thread>
 
+#include "exg_fastq_ws.hpp"
 #include "exg_filter.hpp"
-#include "exg_rd_internal.hpp"
+#include "exg_rd_source.hpp"
 
 namespace exg_rd {
 
+// ---- compressed inputs: the file becomes a stream of decoded segments (exg_rd_source.hpp) --------------------------------
+
+// room every segment leaves in front of its bytes for the tail the scan carries over (a longer tail moves into a block of its own)
+static uint64_t source_reserve(const exg_reader *r) { return std::min<uint64_t>(std::max<uint64_t>(r->device_batch_bytes / 8, 64u << 10), 8u << 20); }
+
+// The leading '#' lines of a decoded VCF come back to the host for the header parse (blk->p holds a prefix of the decoded
+// stream; the DataChunk payload travels per batch): `src` is read from its first byte until a line that does not start with
+// '#' begins inside the prefix, or the stream ends.
+static int source_header_prefix(exg_reader *r, DecodedSource *src, PinnedBlock &b) {
+    // (not more than a device batch at first: what is acquired here is the first batch's size, which sizes the scan's buffers)
+    for (uint64_t want = std::min<uint64_t>(4u << 20, r->device_batch_bytes);; want *= 8) {
+        const uint8_t *d_at = nullptr;
+        uint64_t avail = 0;
+        bool eof = false;
+        std::string msg;
+        int rc = src->acquire(0, want, &d_at, &avail, &eof, &msg);
+        if (rc) return fail(r, rc, msg);
+        const size_t len = (size_t)std::min<uint64_t>(want, avail);
+        if (b.p) global_pool()->give((char *)b.p, b.cap), b.p = nullptr;
+        size_t cap = len + 64;
+        b.p = global_pool()->take(&cap);
+        if (!b.p) return fail(r, EXG_E_HIP, "out of pinned host memory for the VCF header");
+        b.cap = cap;
+        b.pooled = true;
+        if (len) RD_HIP(r, hipMemcpyAsync(b.p, d_at, len, hipMemcpyDeviceToHost, r->stream));
+        RD_HIP(r, hipStreamSynchronize(r->stream));
+        const char *d = (const char *)b.p;
+        size_t pos = 0;
+        while (pos < len && d[pos] == '#') {
+            const void *nl = memchr(d + pos, '\n', len - pos);
+            pos = nl ? (size_t)((const char *)nl - d) + 1 : len;
+        }
+        if (pos < len || (eof && len == avail)) {
+            r->gz_header_prefix = len;
+            return EXG_OK;
+        }
+    }
+}
+
+// Shard `shard_index` of `shard_count` of a BGZF file: a member belongs to the shard in whose 1/shard_count of the FILE's
+// bytes its header begins.  The reader finds its members without indexing the file (a search for a header whose chain holds
+// near each cut: the pointer chase over a whole file costs 110 ms per 10 GB and every rank would pay it) and streams
+// [c_begin, c_end): ~1 MiB (inflated) of members in front of its own — the halo that holds the beginning of the record that
+// ends behind the cut — then its own.  Positions of the reader are offsets in THAT stream.
+static int plan_bgzf_shard(exg_reader *r, const std::string &path, uint64_t n, uint64_t *c_begin, uint64_t *c_end, uint64_t header_bytes) {
+    const int fd = r->fd_keep->fd;
+    Peek peek(nullptr, fd, n);
+    exg_inflate_member probe;
+    if (!bgzf_member_at(peek, 0, &probe))
+        return fail(r, EXG_E_UNSUPPORTED, "shards of a gzip input need BGZF framing (every member carries its size): '" + path + "'");
+    const uint64_t lo = (uint64_t)((unsigned __int128)n * r->shard_index / r->shard_count);
+    const uint64_t hi = r->shard_index + 1 == r->shard_count ? n : (uint64_t)((unsigned __int128)n * (r->shard_index + 1) / r->shard_count);
+    const uint64_t first_own = lo == 0 ? 0 : bgzf_find(nullptr, fd, n, lo);
+    *c_end = hi >= n ? n : std::max<uint64_t>(first_own, bgzf_find(nullptr, fd, n, hi));
+    // candidates for the halo: members that begin in the ~1.5 MiB of file in front of the cut (BGZF does not expand)
+    std::vector<uint64_t> hdr, out;
+    static const uint64_t halo_want = getenv("EXG_SHARD_HALO") ? strtoull(getenv("EXG_SHARD_HALO"), nullptr, 10) : kShardHalo;
+    const uint64_t back = halo_want + (halo_want >> 1) + (128u << 10);
+    for (uint64_t pos = first_own == 0 ? 0 : bgzf_find(nullptr, fd, n, lo > back ? lo - back : 0); pos < first_own;) {
+        exg_inflate_member m;
+        const uint64_t nx = bgzf_member_at(peek, pos, &m);
+        if (!nx) return fail(r, EXG_E_PARSE, "not a BGZF member at byte " + std::to_string(pos) + " of '" + path + "'");
+        hdr.push_back(pos);
+        out.push_back(m.out_cap);
+        pos = nx;
+    }
+    size_t h0 = hdr.size();
+    uint64_t halo_bytes = 0;
+    while (h0 > 0 && halo_bytes < halo_want) halo_bytes += out[--h0];
+    *c_begin = h0 < hdr.size() ? hdr[h0] : first_own;
+    // VCF: where do the members that hold the header end?  A halo that would begin among them is taken from the start of
+    // the file instead, so that the end of the header is a known offset of this reader's stream
+    if (header_bytes && *c_begin != 0) {
+        uint64_t q = 0, sum = 0;
+        while (q < n && sum < header_bytes) {
+            exg_inflate_member m;
+            const uint64_t nx = bgzf_member_at(peek, q, &m);
+            if (!nx) return fail(r, EXG_E_PARSE, "not a BGZF member at byte " + std::to_string(q) + " of '" + path + "'");
+            sum += m.out_cap;
+            q = nx;
+        }
+        if (*c_begin < q) {  // q: compressed offset behind the header's members
+            for (uint64_t pos = 0; pos < *c_begin;) {
+                exg_inflate_member m;
+                const uint64_t nx = bgzf_member_at(peek, pos, &m);
+                if (!nx) return fail(r, EXG_E_PARSE, "not a BGZF member at byte " + std::to_string(pos) + " of '" + path + "'");
+                halo_bytes += m.out_cap;
+                pos = nx;
+            }
+            *c_begin = 0;
+        }
+    }
+    if (*c_begin > *c_end) *c_begin = *c_end;
+    // does any inflated byte follow this reader's members?  (the empty BGZF end marker — or a later shard that owns nothing
+    // else — must not keep the shard with the file's last record from seeing the end of the file)
+    bool bytes_follow = false;
+    for (uint64_t q = *c_end; q < n && !bytes_follow;) {
+        exg_inflate_member m;
+        const uint64_t nx = bgzf_member_at(peek, q, &m);
+        if (!nx) return fail(r, EXG_E_PARSE, "not a BGZF member at byte " + std::to_string(q) + " of '" + path + "'");
+        bytes_follow = m.out_cap != 0;
+        q = nx;
+    }
+    r->range_preset = true;
+    r->preset_pos = halo_bytes;  // inflated bytes of the members in front of its own
+    r->range_eof = !bytes_follow;
+    r->data0_is_line_start = *c_begin == 0;  // byte 0 of the stream begins a line only when the stream begins with the file
+    return EXG_OK;
+}
+
+static int open_source(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::string &path, uint64_t n) {
+    const int fd = r->fd_keep->fd;
+    const uint64_t reserve = source_reserve(r), target = r->device_batch_bytes;
+    auto out_blk = std::make_shared<PinnedBlock>();  // (n = 0: the decoded size is not known; p: the VCF header prefix)
+    r->gz_header_prefix = 0;
+    const size_t queued = getenv("EXG_SOURCE_QUEUE") ? (size_t)std::max(1, atoi(getenv("EXG_SOURCE_QUEUE"))) : r->mem_cap ? 1 : 2;
+    auto make = [&](uint64_t c_begin, uint64_t c_end, bool bgzf_only) {
+        std::unique_ptr<SegmentProducer> prod = r->compression == kGzip ? make_gzip_producer(r, fd, c_begin, c_end, target, path, bgzf_only, reserve)
+                                                                        : make_zstd_producer(r, fd, n, target, path, reserve);
+        return std::unique_ptr<DecodedSource>(new DecodedSource(r->device, r->stream, std::move(prod), reserve, queued, &r->meter));
+    };
+    if (r->compression == kGzip && n == 0) return fail(r, EXG_E_PARSE, "empty gzip file '" + path + "'");
+    if (r->shard_count > 1) {
+        // VCF: every rank needs the header (schema, and where the data begins): read from the start of the file by a
+        // source of its own, kept on the host like in the unsharded case
+        uint64_t header_bytes = 0;
+        if (r->format == EXG_FMT_VCF) {
+            std::unique_ptr<DecodedSource> head = make(0, n, true);
+            int rc = source_header_prefix(r, head.get(), *out_blk);
+            if (rc) return rc;
+            const char *d = (const char *)out_blk->p;
+            size_t pos = 0;
+            while (pos < r->gz_header_prefix && d[pos] == '#') {
+                const void *nl = memchr(d + pos, '\n', (size_t)r->gz_header_prefix - pos);
+                pos = nl ? (size_t)((const char *)nl - d) + 1 : (size_t)r->gz_header_prefix;
+            }
+            header_bytes = pos;
+        }
+        uint64_t c_begin = 0, c_end = n;
+        int rc = plan_bgzf_shard(r, path, n, &c_begin, &c_end, header_bytes);
+        if (rc) return rc;
+        r->src = make(c_begin, c_end, true);
+    } else {
+        r->src = make(0, n, false);
+        if (r->format == EXG_FMT_VCF) {
+            int rc = source_header_prefix(r, r->src.get(), *out_blk);
+            if (rc) return rc;
+        }
+    }
+    blk = out_blk;
+    return EXG_OK;
+}
+
 int open_next_file(exg_reader *r) {
-    if (int jrc = r->join_zstd_check()) return jrc;
+    if (int jrc = r->finish_source()) return jrc;
+    r->src.reset();  // (its thread reads the previous file's descriptor)
     const std::string &p = r->files[r->file_idx++];
-    double t_all = now_s();
     int fd = open(p.c_str(), O_RDONLY);
     if (fd < 0) return fail(r, EXG_E_IO, "cannot open '" + p + "': " + strerror(errno));
     struct stat st;
     fstat(fd, &st);
-    // The file is mapped, not copied: DataChunk strings point straight into the page cache mapping
-    // (kept alive by the chunks); bytes travel to the device through a pinned bounce buffer.
     auto blk = std::make_shared<PinnedBlock>();
     blk->n = (size_t)st.st_size;
     double t0 = now_s();
-    if (blk->n) {
+    if (r->compression != kNone) {
+        // decoded by a producer thread that reads the file with pread: nothing is mapped
+    } else if (blk->n) {
+        // The file is mapped, not copied: DataChunk strings point straight into the page cache mapping
+        // (kept alive by the chunks); bytes travel to the device through a pinned bounce buffer.
         void *m = mmap(nullptr, blk->n, PROT_READ, MAP_PRIVATE, fd, 0);
         if (m == MAP_FAILED) {
             close(fd);
@@ -56,22 +212,17 @@ int open_next_file(exg_reader *r) {
     }
     r->fd_keep.reset(new exg_reader::FdCloser{fd});
     TRACE("mmap(file)", t0);
-    (void)t_all;
-    if (r->d_file) exg_rd::dev_pool()->give(r->device, r->d_file, r->d_file_cap), r->d_file = nullptr;
     r->range_preset = false;
     r->range_eof = true;
     r->data0_is_line_start = true;
-    if (r->compression == kGzip) {
-        int rc = inflate_file(r, blk, p);  // replaces blk by the inflated bytes (host copy) and sets d_file
-        if (rc) return rc;
-    } else if (r->compression == kZstd) {
-        int rc = zstd_file(r, blk, p);
-        if (rc) return rc;
-    }
     (void)r->join_prefetch();
     r->drop_prefetch2();
     if (r->pf.valid && r->up_stream) (void)hipStreamSynchronize(r->up_stream);  // a prefetch of the previous file
     r->pf.valid = false;
+    if (r->compression != kNone) {
+        int rc = open_source(r, blk, p, (uint64_t)st.st_size);  // replaces blk (decoded size unknown; VCF: the header prefix on the host)
+        if (rc) return rc;
+    }
     r->file = blk;
     r->file_pos = 0;
     r->file_done = false;
@@ -91,11 +242,11 @@ int open_next_file(exg_reader *r) {
         r->file_pos = pos;
     }
     // byte-range shard of this file: [lo, hi) of the bytes behind the header; records / lines belong to the shard they END in
-    r->range_hi = blk->n;
+    r->range_hi = r->src ? ~0ull : blk->n;  // (a decoded stream ends where its source says so)
     r->shard_first = false;
     r->data_base = r->file_pos;  // 0, or the end of the VCF header
-    if (r->range_preset) {  // BGZF shard: the members were chosen in inflate_file_shard
-        // its buffer begins with the file (header and all) or somewhere behind the header
+    if (r->range_preset) {  // BGZF shard: the members were chosen in plan_bgzf_shard
+        // its stream begins with the file (header and all) or somewhere behind the header
         r->data_base = r->data0_is_line_start ? r->data_base : 0;
         r->file_pos = std::max<uint64_t>(r->preset_pos, r->data_base);
         r->shard_first = r->file_pos > r->data_base;
@@ -138,12 +289,14 @@ int open_next_file(exg_reader *r) {
 int n_string_cols(int format) { return format == EXG_FMT_FASTQ ? 4 : format == EXG_FMT_FASTA ? 3 : 9; }
 
 int ensure_device(exg_reader *r, uint64_t need_bytes) {
-    if (r->d_in && need_bytes <= r->d_in_cap) return EXG_OK;
-    if (r->d_in) {
+    if (r->d_ws && need_bytes <= r->d_in_cap) return EXG_OK;
+    if (r->d_ws) {
         RD_HIP(r, hipStreamSynchronize(r->stream));
         r->free_device();
     }
-    if (r->format != EXG_FMT_FASTA && r->file)  // room for a prefetched batch (its slack included), small files stay small
+    if (r->src)  // segments come at about the target size + what the scan carries over: provision once
+        need_bytes = std::max<uint64_t>(need_bytes, r->device_batch_bytes + r->device_batch_bytes / 4 + r->src->reserve() + 4096);
+    else if (r->format != EXG_FMT_FASTA && r->file)  // room for a prefetched batch (its slack included), small files stay small
         need_bytes = std::max<uint64_t>(need_bytes, std::min<uint64_t>(r->device_batch_bytes, r->file->n) + kPrefetchSlack + 64);
     uint64_t cap = std::max<uint64_t>(need_bytes, 1 << 16);
     r->d_in_cap = cap;
@@ -155,9 +308,20 @@ int ensure_device(exg_reader *r, uint64_t need_bytes) {
                                             : (r->format == EXG_FMT_FASTQ ? 32 : 16);
     r->cap_records = cap / div + 4096;
     r->ws_bytes = exg_scan_workspace_bytes(r->format, cap);
-    // FASTA scans the whole file as one batch: one slot
+    if (r->mem_cap && !r->ws_full) {
+        // The general path's line index is provisioned for min(n, 1 Mi) lines whatever the batch size (8 MiB; FASTA keeps
+        // four such arrays): under a memory budget, one line per 8 bytes + 64 Ki — a denser batch is reported
+        // (EXG_RF_INDEX_OVERFLOW) and scanned again with the full workspace
+        const uint64_t arrays = r->format == EXG_FMT_FASTA ? 4 : 1;
+        const exg::FastqWsLayout l = exg::fastq_ws_layout(cap, 0, arrays);
+        const uint64_t lines = cap / 8 + 65536 + 8;
+        r->ws_bytes = std::min<uint64_t>(r->ws_bytes, l.off_nl_pos + (lines + 2) * 8 * arrays);
+    }
+    // two upload slots; FASTA batches are not prefetched: one; a decoded stream is scanned in its segments: none (FASTA:
+    // one, for the 16-byte aligned copy its scan wants)
     int arc = 0;
-    for (int k = 0; k < (r->format == EXG_FMT_FASTA ? 1 : 2); k++)
+    const int n_slots = r->format == EXG_FMT_FASTA ? 1 : r->src ? 0 : 2;
+    for (int k = 0; k < n_slots; k++)
         if ((arc = r->dev_alloc(&r->d_in_slot[k], cap + 64))) return arc;
     r->d_in = r->d_in_slot[0];
     r->cur_slot = 0;
@@ -198,7 +362,6 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             r->file_done = true;
             return EXG_OK;
         }
-        if (r->format == EXG_FMT_FASTA) want = remaining;  // a FASTA record can span the whole file: one batch
         uint64_t n = std::min<uint64_t>(want, remaining);
         bool range_end = n == remaining;                    // the batch reaches the end of this reader's bytes ...
         bool eof = range_end && r->range_eof;               // ... which is the end of the file unless a later shard follows
@@ -211,7 +374,27 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             const uint64_t from = r->file_pos - std::min<uint64_t>(halo_max, r->file_pos - base);
             // (a buffer that already lives in HBM must be entered at a 16-byte boundary: a few bytes of the header's
             // last line may then come along in front — they end inside the halo and are nobody's rows)
-            shard_halo = r->file_pos - (r->d_file ? (std::max<uint64_t>(base, from) & ~15ull) : std::max<uint64_t>(base, from & ~15ull));
+            shard_halo = r->file_pos - (r->src ? (std::max<uint64_t>(base, from) & ~15ull) : std::max<uint64_t>(base, from & ~15ull));
+        }
+        // a decoded stream: the bytes from file_pos on (and the halo in front) made contiguous in HBM — everything up to the end of
+        // the segment that holds them is this batch
+        const uint8_t *src_at = nullptr;  // device address of stream byte src_pos
+        uint64_t src_pos = 0;
+        bool src_eof = false;
+        if (r->src) {
+            src_pos = r->file_pos - shard_halo;
+            uint64_t avail = 0;
+            std::string msg;
+            int arc = r->src->acquire(src_pos, want + shard_halo, &src_at, &avail, &src_eof, &msg);
+            if (arc) return fail(r, arc, msg + (msg.find(r->files[r->file_idx - 1]) == std::string::npos ? " in '" + r->files[r->file_idx - 1] + "'" : ""));
+            r->n_segments = r->src->segments_consumed() + 1;
+            if (avail <= shard_halo && src_eof) {  // nothing behind file_pos: the stream has ended
+                r->file_done = true;
+                return EXG_OK;
+            }
+            n = avail - shard_halo;
+            range_end = src_eof;
+            eof = range_end && r->range_eof;
         }
         int rc = ensure_device(r, n + shard_halo + 16);
         if (rc) return rc;
@@ -223,7 +406,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         // AFTER it starts travelling now, into the slot of the batch that was scanned last (free: its columns have left) —
         // issued after this call's scan, an upload began only when the link had already been idle for a scan + a D2H.
         static const bool no_prefetch = getenv("EXG_NO_PREFETCH") != nullptr;
-        if (!no_prefetch && r->pf.valid && !r->pf2.valid && !r->d_file && r->format != EXG_FMT_FASTA && want == r->device_batch_bytes &&
+        if (!no_prefetch && r->pf.valid && !r->pf2.valid && !r->src && r->format != EXG_FMT_FASTA && want == r->device_batch_bytes &&
             r->file_pos >= r->pf.file_start && r->file_pos < r->pf.file_start + r->pf.len && r->d_in_slot[r->pf.slot ^ 1] &&
             !r->up_thread_of[r->pf.slot ^ 1].joinable()) {
             const uint64_t end1 = r->pf.file_start + r->pf.len;  // where the coming batch's bytes end
@@ -240,10 +423,21 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         uint64_t lead = 0;
         uint64_t batch_end = r->file_pos + n;  // file offset one past the bytes of this batch
         std::shared_ptr<PinnedBlock> gz_payload;  // gzip: this batch's inflated bytes on the host (string_t payload)
-        if (r->d_file) {
-            lead = r->shard_first ? shard_halo : (r->file_pos & 15);
-            d_input = (const uint8_t *)r->d_file + (r->file_pos - lead);
+        if (r->src) {
+            lead = shard_halo + (src_pos & 15);
+            d_input = src_at - (src_pos & 15);
             n += lead;
+            if (r->format == EXG_FMT_FASTA) {
+                // the FASTA scan wants its batch on a 16-byte boundary with nothing in front: a device copy (the decoders
+                // in front of it run at a few percent of what a copy does)
+                if (shard_halo) return fail(r, EXG_E_INVALID_ARG, "internal: a FASTA batch has no halo");
+                n -= lead;
+                RD_HIP(r, hipMemcpyAsync(r->d_in_slot[0], src_at, n, hipMemcpyDeviceToDevice, r->stream));
+                RD_HIP(r, hipMemsetAsync((char *)r->d_in_slot[0] + n, 0, 16, r->stream));
+                r->d_in = r->d_in_slot[0];
+                d_input = r->d_in;
+                lead = 0;
+            }
             if (!count_only && !r->arrow_emit) {
                 gz_payload = std::make_shared<PinnedBlock>();
                 size_t cap = n + 64;
@@ -302,19 +496,19 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             RD_HIP(r, hipStreamSynchronize(r->stream));
             if (guess <= 3) {
                 uint8_t prev = 0;
-                if (r->d_file) {
-                    RD_HIP(r, hipMemcpyAsync(&prev, (const uint8_t *)r->d_file + r->file_pos - 1, 1, hipMemcpyDeviceToHost, r->stream));
+                if (r->src) {
+                    RD_HIP(r, hipMemcpyAsync(&prev, (const uint8_t *)d_input + lead - 1, 1, hipMemcpyDeviceToHost, r->stream));
                     RD_HIP(r, hipStreamSynchronize(r->stream));
                 } else {
                     prev = ((const uint8_t *)r->file->p)[r->file_pos - 1];
                 }
                 first_line_index = prev == '\n' ? guess : (guess + 3) % 4;
-            } else if (r->d_file) {
+            } else if (r->src) {
                 // BGZF shard: exact only when the halo begins with the file (the newlines in front are then all in HBM)
                 if (!(r->data0_is_line_start && lead == r->file_pos))
                     return fail(r, EXG_E_PARSE, "cannot tell the FASTQ record phase at the shard boundary of '" + r->files[r->file_idx - 1] + "'");
                 unsigned long long nl = 0;
-                rc = exg_count_newlines(r->d_file, 0, r->file_pos, (uint64_t *)r->d_phase, r->stream);
+                rc = exg_count_newlines(d_input, 0, lead, (uint64_t *)r->d_phase, r->stream);
                 if (rc) return fail(r, rc, exg_last_error_message());
                 RD_HIP(r, hipMemcpyAsync(&nl, r->d_phase, 8, hipMemcpyDeviceToHost, r->stream));
                 RD_HIP(r, hipStreamSynchronize(r->stream));
@@ -420,6 +614,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             rc = exg_fasta_scan(&a);
         }
         if (rc) return fail(r, rc, exg_last_error_message());
+        r->n_batches++;
         double t_scan = now_s();
         rc = exg_fetch_result((const exg_scan_result *)r->d_res, r->stream, &res);
         if (rc) return fail(r, rc, exg_last_error_message());
@@ -433,6 +628,12 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             res.flags |= EXG_RF_FALLBACK;
         }
         TRACE("wait(h2d) + scan", t_scan);
+        if ((res.flags & EXG_RF_INDEX_OVERFLOW) && r->mem_cap && !r->ws_full) {
+            RD_HIP(r, hipStreamSynchronize(r->stream));  // denser lines than the budgeted workspace indexes: the full one, same batch again
+            r->free_device();
+            r->ws_full = true;
+            continue;
+        }
         if (res.flags & EXG_RF_INDEX_OVERFLOW)
             return fail(r, EXG_E_CAPACITY, "line index overflow in the general path (pathological line density)");
         if ((res.flags & EXG_RF_CAPACITY) && !no_store) {
@@ -454,7 +655,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         // While the columns travel back (and the consumer works through the chunks): the bytes the next batch will need
         // move into the other slot — unless they left at the top of this call already (pf2), which is the steady state
         {
-            const bool can = !range_end && !res.error_code && !r->d_file && r->format != EXG_FMT_FASTA && want == r->device_batch_bytes && !no_prefetch;
+            const bool can = !range_end && !res.error_code && !r->src && r->format != EXG_FMT_FASTA && want == r->device_batch_bytes && !no_prefetch;
             const uint64_t slack = std::min<uint64_t>(kPrefetchSlack, (batch_end - r->file_pos) / 2);
             const uint64_t start = (batch_end - slack) & ~15ull;
             const uint64_t len = std::min<uint64_t>(r->range_hi - start, r->device_batch_bytes + slack);
@@ -597,6 +798,9 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             }
         }
         TRACE("batch (h2d+scan+d2h)", t_batch);
+        if (trace_on())
+            fprintf(stderr, "[exg] device bytes held: %.2f MiB now, %.2f MiB at the peak (batch of %llu bytes, %llu rows)\n", r->meter.cur.load() / 1048576.0,
+                    r->meter.peak.load() / 1048576.0, (unsigned long long)n, (unsigned long long)k);
         return EXG_OK;
     }
 }

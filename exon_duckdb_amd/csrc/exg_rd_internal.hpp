@@ -99,6 +99,8 @@ struct UploadProgress {
 // file bytes [file_off, file_off + n) -> d_dst on `st` (NULL: r->stream): windows of 256 MiB through two pooled pinned
 // blocks, each window read by parallel pread and sent slice by slice
 int upload_file(exg_reader *r, void *d_dst, uint64_t n, uint64_t file_off = 0, hipStream_t st = nullptr, UploadProgress *prog = nullptr);
+// the same without a reader (a decoder thread: errors go to *err, not to the reader's message)
+int upload_fd(int device, int fd, void *d_dst, uint64_t n, uint64_t file_off, hipStream_t st, UploadProgress *prog, std::string *err);
 // file bytes [off, off + n) -> the slot's pinned bounce buffer (parallel pread) -> d_in_slot[slot], on `st`
 int upload_range(exg_reader *r, uint64_t off, uint64_t n, int slot, hipStream_t st);
 // the same on a host thread of its own (pread + the H2D enqueue block their caller for as long as the bytes take to leave)
@@ -131,10 +133,6 @@ bool bgzf_parallel_index(const uint8_t *d, int fd, uint64_t n, exg_inflate_membe
 bool parse_compression(const std::string &s, Compression *out);
 Compression compression_of(const exg_open_args *args);
 
-// ---- exg_rd_gzip.cpp / exg_rd_zstd.cpp
-int inflate_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::string &path);
-int zstd_file(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::string &path);
-int gz_host_header(exg_reader *r, PinnedBlock &b, const void *d_file);
 
 // ---- exg_rd_batch.cpp
 int n_string_cols(int format);

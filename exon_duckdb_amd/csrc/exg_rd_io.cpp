@@ -14,7 +14,7 @@
 #include <atomic>
 #include <thread>
 
-#include "exg_rd_internal.hpp"
+#include "exg_rd_source.hpp"
 
 namespace exg_rd {
 
@@ -137,22 +137,22 @@ int exg_reader::dev_alloc(void **slot, size_t bytes) {
     dev_allocs.emplace_back(slot, bytes);
     return EXG_OK;
 }
-int exg_reader::join_zstd_check() {
-    if (zst_check.joinable()) zst_check.join();
-    if (!zst_check_rc) return EXG_OK;
-    const int rc = zst_check_rc;
-    zst_check_rc = 0;
-    return exg_rd::fail(this, rc, zst_check_error);
+int exg_reader::finish_source() {
+    if (!src) return EXG_OK;
+    std::string e;
+    const int rc = src->finish(&e);
+    return rc ? exg_rd::fail(this, rc, e) : EXG_OK;
 }
+exg_reader::exg_reader() {}
 exg_reader::~exg_reader() {
     exg_rd::DeviceGuard guard(device);
-    if (zst_check.joinable()) zst_check.join();
+    exg_rd::MeterScope meter_scope(&meter);
+    src.reset();  // (its thread reads the file through fd_keep: before the descriptor closes)
     free_device();
     if (d_res) exg_rd::dev_pool()->give(device, d_res, 4096);
     if (d_phase) exg_rd::dev_pool()->give(device, d_phase, 4096);
     if (d_filter_prog) (void)hipFree(d_filter_prog);
     if (d_filter_consts) (void)hipFree(d_filter_consts);
-    if (d_file) exg_rd::dev_pool()->give(device, d_file, d_file_cap);
     for (int k = 0; k < 2; k++)
         if (up_done_of[k]) (void)hipEventDestroy(up_done_of[k]);
     exg_rd::stream_pool()->give(device, up_stream);
@@ -196,10 +196,8 @@ bool pread_parallel(int device, int fd, uint64_t off, size_t n, char *dst, char 
 // The whole (compressed) file, or a range of it -> d_dst: windows of 256 MiB through two pooled pinned blocks, each window
 // read by parallel pread and sent slice by slice (a hipMemcpyAsync straight from the page-cache mapping is a pageable
 // copy: one staging thread inside the runtime, 10-33 GB/s depending on the box).
-int upload_file(exg_reader *r, void *d_dst, uint64_t n, uint64_t file_off, hipStream_t st, UploadProgress *prog) {
-    if (!st) st = r->stream;
+int upload_fd(int device, int fd, void *d_dst, uint64_t n, uint64_t file_off, hipStream_t st, UploadProgress *prog, std::string *err) {
     const size_t window = kUploadWindow;
-    const int fd = r->fd_keep->fd;
     char *blk[2] = {nullptr, nullptr};
     size_t cap[2] = {0, 0};
     hipEvent_t ev[2] = {nullptr, nullptr};
@@ -216,30 +214,49 @@ int upload_file(exg_reader *r, void *d_dst, uint64_t n, uint64_t file_off, hipSt
             }
         }
     } cleanup{st, blk, cap, ev};
+#define UP_HIP(expr)                                                                 \
+    do {                                                                             \
+        hipError_t _e = (expr);                                                      \
+        if (_e != hipSuccess) {                                                      \
+            *err = std::string(#expr " failed: ") + hipGetErrorString(_e);           \
+            return EXG_E_HIP;                                                        \
+        }                                                                            \
+    } while (0)
     for (int k = 0; k < 2 && (uint64_t)k * window < n; k++) {
         cap[k] = (size_t)std::min<uint64_t>(window, n - (uint64_t)k * window) + 64;
         blk[k] = global_pool()->take(&cap[k]);
-        if (!blk[k]) return fail(r, EXG_E_HIP, "out of pinned host memory");
-        RD_HIP(r, hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+        if (!blk[k]) {
+            *err = "out of pinned host memory";
+            return EXG_E_HIP;
+        }
+        UP_HIP(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
     }
     uint64_t off = 0;
     for (uint64_t w = 0; off < n; w++) {
         const int b = (int)(w & 1);
-        if (w >= 2) RD_HIP(r, hipEventSynchronize(ev[b]));  // the block's previous window has left
+        if (w >= 2) UP_HIP(hipEventSynchronize(ev[b]));  // the block's previous window has left
         const size_t len = (size_t)std::min<uint64_t>(window, n - off);
         bool hip_failed = false;
-        if (!pread_parallel(r->device, fd, file_off + off, len, blk[b], (char *)d_dst + off, st, &hip_failed))
-            return hip_failed ? fail(r, EXG_E_HIP, "hipMemcpyAsync failed") : fail(r, EXG_E_IO, "short read");
-        RD_HIP(r, hipEventRecord(ev[b], st));
+        if (!pread_parallel(device, fd, file_off + off, len, blk[b], (char *)d_dst + off, st, &hip_failed)) {
+            *err = hip_failed ? "hipMemcpyAsync failed" : "short read";
+            return hip_failed ? EXG_E_HIP : EXG_E_IO;
+        }
+        UP_HIP(hipEventRecord(ev[b], st));
         if (prog) {
-            RD_HIP(r, hipEventRecord(prog->done[w], st));
+            UP_HIP(hipEventRecord(prog->done[w], st));
             std::lock_guard<std::mutex> g(prog->mu);
             prog->recorded = (size_t)w + 1;
             prog->cv.notify_all();
         }
         off += len;
     }
+#undef UP_HIP
     return EXG_OK;
+}
+int upload_file(exg_reader *r, void *d_dst, uint64_t n, uint64_t file_off, hipStream_t st, UploadProgress *prog) {
+    std::string err;
+    const int rc = upload_fd(r->device, r->fd_keep->fd, d_dst, n, file_off, st ? st : r->stream, prog, &err);
+    return rc ? fail(r, rc, err) : EXG_OK;
 }
 
 // file bytes [off, off + n) -> the slot's pinned bounce buffer (parallel pread) -> d_in_slot[slot], on `st`.

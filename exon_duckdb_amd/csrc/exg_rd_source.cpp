@@ -1,0 +1,200 @@
+// exg_rd_source.cpp — the consumer side of a decoded stream (exg_rd_source.hpp): the queue between a producer thread and
+// the scanning thread, and `acquire`, which makes the bytes a device batch needs contiguous in HBM by carrying the
+// unconsumed tail of one segment into the room in front of the next.  Replaces the BufReader in front of exon's batch
+// readers for compressed inputs (rust/src/arrow_reader.rs:60-91, 116-118).
+#include "exg_rd_source.hpp"
+
+namespace exg_rd {
+
+bool SegmentSink::cancelled() const {
+    std::lock_guard<std::mutex> g(src->mu_);
+    return src->closed_;
+}
+void *SegmentSink::take(size_t bytes) { return dev_pool()->take(src->device_, bytes ? bytes : 16); }
+void SegmentSink::give(void *p, size_t bytes) {
+    if (p) dev_pool()->give(src->device_, p, bytes ? bytes : 16);
+}
+bool SegmentSink::push(Segment &&s) {
+    std::unique_lock<std::mutex> lk(src->mu_);
+    src->cv_.wait(lk, [&] { return src->queue_.size() < src->max_queued_ || src->closed_; });
+    if (src->closed_) {
+        lk.unlock();
+        give(s.buf, s.cap);
+        s.buf = nullptr;
+        return false;
+    }
+    src->queue_.push_back(s);
+    s.buf = nullptr;
+    src->cv_.notify_all();
+    return true;
+}
+
+DecodedSource::DecodedSource(int device, hipStream_t consumer_stream, std::unique_ptr<SegmentProducer> producer, uint64_t reserve, size_t max_queued,
+                             MemMeter *meter)
+    : device_(device), stream_(consumer_stream), producer_(std::move(producer)), reserve_((reserve + 15) & ~15ull),
+      max_queued_(max_queued ? max_queued : 1), meter_(meter) {
+    thread_ = std::thread([this] {
+        (void)hipSetDevice(device_);
+        pin_to_device_node(device_);
+        MeterScope meter_scope(meter_);
+        SegmentSink sink{this};
+        std::string e;
+        int rc = EXG_E_HIP;
+        try {
+            rc = producer_->run(sink, &e);
+        } catch (const std::exception &ex) {  // (std::bad_alloc from a host vector: never let it leave the thread)
+            e = std::string("decoder thread: ") + ex.what();
+            rc = EXG_E_NOMEM;
+        }
+        std::lock_guard<std::mutex> g(mu_);
+        done_ = true;
+        rc_ = rc;
+        err_ = e;
+        cv_.notify_all();
+    });
+}
+
+DecodedSource::~DecodedSource() {
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        closed_ = true;
+        cv_.notify_all();
+    }
+    if (thread_.joinable()) thread_.join();
+    MeterScope meter_scope(meter_);
+    DeviceGuard guard(device_);
+    producer_.reset();  // (its scratch goes back before the segments: it may still hold streams with work on them)
+    (void)hipStreamSynchronize(stream_);  // a scan may still be reading the current segment
+    if (have_cur_) free_segment(cur_);
+    for (Segment &s : queue_) free_segment(s);
+    queue_.clear();
+}
+
+void DecodedSource::free_segment(Segment &s) {
+    if (!s.buf) return;
+    dev_pool()->give(device_, s.buf, s.cap);
+    s.buf = nullptr;
+}
+
+int DecodedSource::pop(Segment *out, std::string *err) {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_.wait(lk, [&] { return !queue_.empty() || done_; });
+    if (!queue_.empty()) {
+        *out = queue_.front();
+        queue_.pop_front();
+        cv_.notify_all();
+        return EXG_OK;
+    }
+    out->buf = nullptr;
+    if (rc_) {
+        *err = err_;
+        return rc_;
+    }
+    return EXG_OK;
+}
+
+int DecodedSource::finish(std::string *err) {
+    std::unique_lock<std::mutex> lk(mu_);
+    // (a producer that is blocked on a full queue cannot end: only wait for one whose last segment has been taken)
+    cv_.wait(lk, [&] { return done_ || !queue_.empty(); });
+    if (done_ && rc_) {
+        *err = err_;
+        return rc_;
+    }
+    return EXG_OK;
+}
+
+int DecodedSource::acquire(uint64_t pos, uint64_t want, const uint8_t **d_pos, uint64_t *avail, bool *eof, std::string *err) {
+    for (;;) {
+        if (!have_cur_) {
+            Segment s;
+            const int rc = pop(&s, err);
+            if (rc) return rc;
+            if (!s.buf) {  // (a producer ends with a segment marked `last`; an empty stream of segments is an internal error)
+                *err = "decoded stream ended without its last segment";
+                return EXG_E_INVALID_ARG;
+            }
+            cur_ = s;
+            have_cur_ = true;
+        }
+        if (pos < cur_.lo) {
+            *err = "decoded stream: bytes at " + std::to_string(pos) + " are not resident (" + std::to_string(cur_.lo) + " .. " + std::to_string(cur_.hi) + ")";
+            return EXG_E_INVALID_ARG;
+        }
+        if (cur_.last && pos > cur_.hi) {  // the stream ends in front of pos (a shard whose members hold only the file's header)
+            *d_pos = cur_.at(cur_.hi);
+            *avail = 0;
+            *eof = true;
+            return EXG_OK;
+        }
+        if (!cur_.last && pos > cur_.hi) {
+            // the consumer begins behind this segment (a shard whose halo starts further in): nothing of it is needed
+            (void)hipStreamSynchronize(stream_);
+            free_segment(cur_);
+            have_cur_ = false;
+            n_consumed_++;
+            continue;
+        }
+        if (cur_.last || pos + want <= cur_.hi) break;
+        Segment nx;
+        const int rc = pop(&nx, err);
+        if (rc) return rc;
+        if (!nx.buf) {
+            *err = "decoded stream ended without its last segment";
+            return EXG_E_INVALID_ARG;
+        }
+        if (nx.start != cur_.hi || nx.lo > nx.start) {
+            free_segment(nx);
+            *err = "decoded stream: segments are not consecutive";
+            return EXG_E_INVALID_ARG;
+        }
+        // the bytes the next batch needs from this segment — from the 16-byte boundary below pos — move in front of the next
+        // one, unless that one brings them along (a window a decoder kept in front of its output)
+        const uint64_t p0 = std::max<uint64_t>(pos & ~15ull, (cur_.lo & ~15ull));
+        hipError_t he = hipSuccess;
+        if (p0 < nx.lo) {
+            const uint64_t carry = nx.lo - p0;
+            if (carry <= nx.room_in_front()) {
+                he = hipMemcpyAsync((void *)nx.at(p0), cur_.at(p0), carry, hipMemcpyDeviceToDevice, stream_);
+                nx.lo = p0;
+            } else {
+                // a tail longer than the room a segment leaves in front of itself (one giant record, or a batch that was
+                // widened): both move into a block of their own
+                const uint64_t body = nx.hi - nx.lo;
+                const size_t ncap = (size_t)(reserve_ + carry + body + 64);
+                void *nb = dev_pool()->take(device_, ncap);
+                if (!nb) {
+                    free_segment(nx);
+                    *err = "out of device memory (" + std::to_string(ncap >> 20) + " MiB) for a record that spans decoded segments";
+                    return EXG_E_HIP;
+                }
+                const int64_t norg = (int64_t)p0 - (int64_t)reserve_;
+                uint8_t *base = (uint8_t *)nb + reserve_;
+                he = hipMemcpyAsync(base, cur_.at(p0), carry, hipMemcpyDeviceToDevice, stream_);
+                if (he == hipSuccess && body) he = hipMemcpyAsync(base + carry, nx.at(nx.lo), body, hipMemcpyDeviceToDevice, stream_);
+                if (he == hipSuccess) he = hipMemsetAsync(base + carry + body, 0, 64, stream_);
+                if (he == hipSuccess) he = hipStreamSynchronize(stream_);
+                free_segment(nx);
+                nx.buf = nb;
+                nx.cap = ncap;
+                nx.org = norg;
+                nx.lo = p0;
+            }
+        }
+        // the old block goes back to the (process-wide) pool: the copy out of it, and any scan still reading it, must be done
+        if (he == hipSuccess) he = hipStreamSynchronize(stream_);
+        free_segment(cur_);
+        cur_ = nx;
+        n_consumed_++;
+        if (he != hipSuccess) {
+            *err = std::string("carrying a record across decoded segments failed: ") + hipGetErrorString(he);
+            return EXG_E_HIP;
+        }
+    }
+    *d_pos = cur_.at(pos);
+    *avail = cur_.hi - pos;
+    *eof = cur_.last;
+    return EXG_OK;
+}
+
+}  // namespace exg_rd

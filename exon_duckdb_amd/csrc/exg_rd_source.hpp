@@ -1,0 +1,110 @@
+// exg_rd_source.hpp — a compressed input as a BOUNDED stream of decoded bytes in HBM.
+//
+// The reference streams any size through a BufReader + DataFusion's convert_stream (rust/src/arrow_reader.rs:60-91,
+// 116-153): its memory does not grow with the file.  Neither does this: a producer thread (gzip / BGZF:
+// exg_rd_gzip.cpp, zstd: exg_rd_zstd.cpp) uploads a window of compressed bytes, decodes it into a SEGMENT — a pooled
+// device block holding a run of decoded bytes — and hands the segments to the scanning thread through a short queue;
+// the scan consumes a segment, carries the bytes of the record it cut (the tail behind the last complete record) into
+// the free space in front of the next segment, and gives the old block back to the pool.  At any time a handful of
+// segments exist, whatever the file's size; EXG_DEVICE_MEM_CAP_MB shrinks them (tests: inputs of >= 8x the cap).
+#pragma once
+#include <stdint.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+
+#include "exg_rd_internal.hpp"
+
+namespace exg_rd {
+
+// Decoded stream bytes [lo, hi) in a pooled device block: byte x lives at buf + (x - org).  org is a multiple of 16 (and may
+// be negative), so an address is congruent to its stream offset mod 16 — a batch that begins at stream offset p is entered
+// at the 16-byte boundary below it with lead = p & 15, like a batch in an upload slot.  [lo, start) are bytes of earlier
+// segments the producer kept in front (a zstd frame's window); the room in front of lo takes the consumer's carry.
+struct Segment {
+    void *buf = nullptr;
+    size_t cap = 0;  // what the block was taken from the pool with
+    int64_t org = 0;
+    uint64_t lo = 0, start = 0, hi = 0;
+    bool last = false;  // the stream ends at hi
+    const uint8_t *at(uint64_t x) const { return (const uint8_t *)buf + ((int64_t)x - org); }
+    uint64_t room_in_front() const { return (uint64_t)((int64_t)lo - org); }
+};
+
+class DecodedSource;
+
+// what a producer sees of its source
+struct SegmentSink {
+    DecodedSource *src;
+    // hands a finished segment over (blocks while the queue is full); false: the consumer is gone — stop producing
+    bool push(Segment &&s);
+    bool cancelled() const;
+    // a pooled device block (nullptr: out of device memory) / back to the pool
+    void *take(size_t bytes);
+    void give(void *p, size_t bytes);
+};
+
+struct SegmentProducer {
+    virtual ~SegmentProducer() {}
+    // Runs on the source's own thread with the device current: decode the stream from its beginning to its end, pushing
+    // segments in order; the last one pushed has `last` set (it may be empty).  EXG_OK, or an error code + *err.
+    virtual int run(SegmentSink &sink, std::string *err) = 0;
+};
+
+class DecodedSource {
+public:
+    DecodedSource(int device, hipStream_t consumer_stream, std::unique_ptr<SegmentProducer> producer, uint64_t reserve, size_t max_queued,
+                  MemMeter *meter);
+    ~DecodedSource();
+    DecodedSource(const DecodedSource &) = delete;
+    DecodedSource &operator=(const DecodedSource &) = delete;
+
+    // Stream bytes from `pos` on, at least `want` of them unless the stream ends first, contiguous in HBM: *d_pos = the
+    // device address of byte pos (congruent to pos mod 16; the 16-byte block it lies in is readable from its beginning, and
+    // 64 bytes behind the last byte are zero), *avail = bytes from pos to the end of what is resident, *eof = the stream
+    // ends there (*avail = 0 with *eof when it ends in front of pos).  Bytes in front of `pos` may be dropped: positions
+    // never decrease from call to call.
+    // EXG_OK or the producer's error (reported when the consumer reaches it: what was decoded before it is handed out).
+    int acquire(uint64_t pos, uint64_t want, const uint8_t **d_pos, uint64_t *avail, bool *eof, std::string *err);
+    // waits for the producer to end and returns its result (a checksum that is verified behind the last segment)
+    int finish(std::string *err);
+    uint64_t reserve() const { return reserve_; }
+    uint64_t segments_consumed() const { return n_consumed_; }
+
+private:
+    friend struct SegmentSink;
+    int pop(Segment *out, std::string *err);  // next segment in order (waits); EXG_OK + out->buf == nullptr: no more
+    void free_segment(Segment &s);
+
+    int device_;
+    hipStream_t stream_;
+    std::unique_ptr<SegmentProducer> producer_;
+    uint64_t reserve_;
+    size_t max_queued_;
+    MemMeter *meter_;
+    std::thread thread_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<Segment> queue_;
+    bool done_ = false, closed_ = false;
+    int rc_ = 0;
+    std::string err_;
+    Segment cur_;
+    bool have_cur_ = false;
+    uint64_t n_consumed_ = 0;
+};
+
+// exg_rd_gzip.cpp: file bytes [c_begin, c_end) of fd are gzip members (BGZF or not, any mixture); `target` = decoded bytes per
+// segment.  bgzf_only: a member without the BGZF size field is an error (shards of a BGZF file).
+// reserve: bytes of room every segment leaves in front of its first byte (DecodedSource's `reserve`)
+std::unique_ptr<SegmentProducer> make_gzip_producer(exg_reader *r, int fd, uint64_t c_begin, uint64_t c_end, uint64_t target, const std::string &path,
+                                                    bool bgzf_only, uint64_t reserve);
+// exg_rd_zstd.cpp: zstd frames of file bytes [0, n) of fd
+std::unique_ptr<SegmentProducer> make_zstd_producer(exg_reader *r, int fd, uint64_t n, uint64_t target, const std::string &path, uint64_t reserve);
+
+}  // namespace exg_rd

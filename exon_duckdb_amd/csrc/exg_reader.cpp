@@ -48,6 +48,16 @@ extern "C" int exg_open(const exg_open_args *args, exg_reader **out) {
     if (args->device_batch_bytes) r->device_batch_bytes = (args->device_batch_bytes + 15) / 16 * 16;
     else if (const char *e = getenv("EXG_DEVICE_BATCH_BYTES"))  // tuning / test knob
         r->device_batch_bytes = std::max<uint64_t>(4096, (strtoull(e, nullptr, 10) + 15) / 16 * 16);
+    // EXG_DEVICE_MEM_CAP_MB: the device memory one reader may hold.  Device batches (and the decoded segments of a
+    // compressed input) are sized from it: a batch in flight costs about ten times its bytes (segments queued and being
+    // decoded, compressed windows, the scan's workspace and column vectors)
+    if (const char *e = getenv("EXG_DEVICE_MEM_CAP_MB")) {
+        r->mem_cap = strtoull(e, nullptr, 10) << 20;
+        // (per input byte a scan provisions 16 B x columns / 32 (FASTQ) or / 16 (VCF: 9 columns + POS + QUAL) of column
+        // vectors; a compressed input adds up to four segments and two compressed windows)
+        const uint64_t div = r->format == EXG_FMT_VCF ? 64 : r->format == EXG_FMT_FASTA ? 32 : 20;
+        if (r->mem_cap) r->device_batch_bytes = std::max<uint64_t>(64u << 10, std::min<uint64_t>(r->device_batch_bytes, (r->mem_cap / div) & ~15ull));
+    }
     r->device = args->device;
     r->shard_count = args->shard_count ? args->shard_count : 1;
     r->shard_index = args->shard_index;
@@ -137,6 +147,7 @@ extern "C" int exg_schema_of(exg_reader *r, exg_schema *out) {
     flat_schema(r, out);
     if (r->format == EXG_FMT_VCF) {
         DeviceGuard guard(r->device);
+        MeterScope meter_scope(&r->meter);
         int rc = nested_prepare(r);  // the INFO / FORMAT keys of the first file's header are part of the schema
         if (rc) return rc;
         nested_schema(r, out);
@@ -183,6 +194,7 @@ static void slice_vector(const NVec &v, uint64_t e0, uint64_t e1, uint64_t chunk
 extern "C" int exg_next_chunk(exg_reader *r, exg_chunk *out) {
     if (!r || !out) return EXG_E_INVALID_ARG;
     DeviceGuard guard(r->device);
+    MeterScope meter_scope(&r->meter);
     memset(out, 0, sizeof *out);
     for (;;) {
         if (r->batch && r->batch_row < r->batch->n_rows) {
@@ -221,7 +233,7 @@ extern "C" int exg_next_chunk(exg_reader *r, exg_chunk *out) {
             return fail(r, EXG_E_PARSE, msg);
         }
         if (r->file_done) {
-            if (int jrc = r->join_zstd_check()) return jrc;
+            if (int jrc = r->finish_source()) return jrc;
             if (r->file_idx >= r->files.size()) {
                 r->batch.reset();
                 return EXG_OK;  // n_rows == 0: end of stream
@@ -245,6 +257,7 @@ extern "C" void exg_release_chunk(exg_reader *, exg_chunk *chunk) {
 extern "C" int exg_count_only(exg_reader *r, uint64_t *n_rows) {
     if (!r || !n_rows) return EXG_E_INVALID_ARG;
     DeviceGuard guard(r->device);
+    MeterScope meter_scope(&r->meter);
     uint64_t total = 0;
     for (;;) {
         if (r->pending_error) {
@@ -254,7 +267,7 @@ extern "C" int exg_count_only(exg_reader *r, uint64_t *n_rows) {
             return fail(r, EXG_E_PARSE, msg);
         }
         if (r->file_done) {
-            if (int jrc = r->join_zstd_check()) return jrc;
+            if (int jrc = r->finish_source()) return jrc;
             if (r->file_idx >= r->files.size()) break;
             int rc = open_next_file(r);
             if (rc) return rc;
@@ -294,5 +307,26 @@ extern "C" void exg_trim_pools(void) {
 }
 
 extern "C" const char *exg_reader_error(exg_reader *r) { return r ? r->error.c_str() : ""; }
+
+extern "C" int exg_reader_stats_of(exg_reader *r, exg_reader_stats *out) {
+    if (!r || !out) return EXG_E_INVALID_ARG;
+    memset(out, 0, sizeof *out);
+    out->device_bytes_now = r->meter.cur.load();
+    out->device_bytes_peak = r->meter.peak.load();
+    out->device_mem_cap = r->mem_cap;
+    out->device_batch_bytes = r->device_batch_bytes;
+    out->device_batches = r->n_batches;
+    out->decoded_segments = r->n_segments;
+    return EXG_OK;
+}
+
+extern "C" void exg_free_device(void *d_ptr, uint64_t bytes) {
+    if (!d_ptr) return;
+    int dev = 0;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, d_ptr) == hipSuccess) dev = attr.device;
+    else (void)hipGetLastError(), (void)hipGetDevice(&dev);
+    exg_rd::dev_pool()->give(dev, d_ptr, (size_t)bytes);
+}
 
 extern "C" void exg_close(exg_reader *r) { delete r; }

@@ -4,6 +4,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <memory>
 #include <thread>
 #include <mutex>
@@ -13,6 +14,7 @@
 #include "exg_common.hpp"
 
 namespace exg_rd {
+class DecodedSource;
 
 // HIP's current device is per host thread: every entry point that touches a reader runs with the reader's device
 // current (the consumer may call from any thread — DuckDB binds on one thread and scans on others — and a process may
@@ -143,6 +145,35 @@ inline StreamPool *stream_pool() {
     return pool;
 }
 
+// Device bytes a reader holds — its own buffers, the segments and scratch of its decoder — current and high-water mark
+// (exg_reader_stats; what EXG_DEVICE_MEM_CAP_MB is checked against in the tests).  The pool charges the meter of the
+// calling thread: the reader's entry points and its worker threads run inside a MeterScope.
+struct MemMeter {
+    std::atomic<uint64_t> cur{0}, peak{0};
+    void add(uint64_t n) {
+        const uint64_t v = cur.fetch_add(n) + n;
+        uint64_t p = peak.load();
+        while (v > p && !peak.compare_exchange_weak(p, v)) {
+        }
+    }
+    void sub(uint64_t n) {
+        uint64_t c = cur.load();
+        while (!cur.compare_exchange_weak(c, c > n ? c - n : 0)) {
+        }
+    }
+};
+inline MemMeter *&tl_meter() {
+    static thread_local MemMeter *m = nullptr;
+    return m;
+}
+struct MeterScope {
+    MemMeter *prev;
+    explicit MeterScope(MemMeter *m) : prev(tl_meter()) { tl_meter() = m; }
+    ~MeterScope() { tl_meter() = prev; }
+    MeterScope(const MeterScope &) = delete;
+    MeterScope &operator=(const MeterScope &) = delete;
+};
+
 struct DevPool {
     struct Blk {
         int dev;
@@ -177,6 +208,7 @@ struct DevPool {
                     void *p = free_blocks[i].p;
                     pooled_bytes -= sz;
                     free_blocks.erase(free_blocks.begin() + (long)i);
+                    if (MemMeter *m = tl_meter()) m->add(sz);
                     return p;
                 }
         }
@@ -190,11 +222,13 @@ struct DevPool {
                 return nullptr;
             }
         }
+        if (MemMeter *m = tl_meter()) m->add(sz);
         return p;
     }
     void give(int dev, void *p, size_t sz) {  // sz: what take() was asked for (or any size of the same class)
         if (!p) return;
         sz = size_class(sz);
+        if (MemMeter *m = tl_meter()) m->sub(sz);
         {
             std::lock_guard<std::mutex> g(mu);
             if (pooled_bytes + sz <= max_pooled()) {  // (small blocks too: a hipMalloc / hipFree pair per open or per file is 0.1-1 ms)
@@ -348,6 +382,7 @@ struct exg_reader {
     void *d_phase = nullptr;  // device u32 for exg_fastq_guess_phase
     uint64_t gz_header_prefix = 0;  // gzip + VCF: bytes of the inflated file's start held in file->p (header parse)
     bool worst_case_rows = false;
+    bool ws_full = false;  // under EXG_DEVICE_MEM_CAP_MB: a batch overflowed the budgeted line index, the workspace is at full size
     // exg_open_args.filters: postfix program + constants in device memory, a row map and one column of scratch
     bool has_filter = false;
     void *d_filter_prog = nullptr, *d_filter_consts = nullptr;
@@ -363,16 +398,16 @@ struct exg_reader {
     };
     std::unique_ptr<FdCloser> fd_keep;  // current file (pread source of the bounce buffer)
     exg_rd::PinnedBlock staging[2];  // pinned bounce buffers for H2D, one per slot (the file itself is only mapped)
-    // zstd: frames too large for the device's serial XXH64 are hashed on the host, from a copy that travels back while the
-    // scan runs; the result is looked at when the file's last batch has been handed out (a streaming decoder reports a
-    // checksum mismatch at the end of the frame too), and before d_file is let go
-    std::thread zst_check;
-    int zst_check_rc = 0;
-    std::string zst_check_error;
-    int join_zstd_check();
-    void *d_file = nullptr;  // gzip input: the inflated bytes live here and are scanned in place
-    size_t d_file_cap = 0;   // its allocation size (it goes back to the device pool)
-    uint64_t d_file_bytes = 0;
+    // the decoder behind the current file has ended without an error (a checksum that is verified behind the last segment
+    // is reported when the file's last batch has been handed out, where a streaming decoder reports it too)
+    int finish_source();
+    // gzip / zstd input: the decoded bytes arrive as a bounded stream of segments in HBM and are scanned in place
+    // (exg_rd_source.hpp); positions (file_pos, range_hi, ...) are offsets in the DECODED stream
+    std::unique_ptr<exg_rd::DecodedSource> src;
+    exg_rd::MemMeter meter;      // device bytes held on behalf of this reader
+    uint64_t mem_cap = 0;        // EXG_DEVICE_MEM_CAP_MB: what the batch / segment sizes are derived from (0: defaults)
+    uint64_t n_segments = 0;     // decoded segments consumed so far
+    uint64_t n_batches = 0;      // device batches scanned so far
 
     // current batch
     std::shared_ptr<exg_rd::Batch> batch;
@@ -388,6 +423,7 @@ struct exg_reader {
     std::shared_ptr<void> nested_state;
 
     void free_device();
+    exg_reader();  // (out of line: `src` is a pointer to a type this header only declares)
     ~exg_reader();
 };
 

@@ -1057,9 +1057,13 @@ int host_verify(const void *d_out, const std::vector<PendingCheck> &pending, int
 }
 
 int decode(const uint8_t *h_comp, const void *d_comp_v, uint64_t n, void **d_out_p, uint64_t *produced, void *stream_v, std::vector<PendingCheck> *pending,
-           Index *prebuilt) {
+           Index *prebuilt, uint64_t front_reserve) {
     if (!h_comp || !d_comp_v || !d_out_p || !produced) {
         set_error("exg_zstd_decode: null argument");
+        return EXG_E_INVALID_ARG;
+    }
+    if (front_reserve & 15) {
+        set_error("exg_zstd_decode: the room in front of the output must be a multiple of 16");
         return EXG_E_INVALID_ARG;
     }
     *d_out_p = nullptr;
@@ -1180,8 +1184,9 @@ int decode(const uint8_t *h_comp, const void *d_comp_v, uint64_t n, void **d_out
     }
     const double t_entropy = trace ? sync_ms(st) : 0;
     // (allocated at the device pool's size class: the reader hands the buffer to that pool when the file is done)
-    EXG_HIP_CHECK(d_out.alloc(total + 64));  // (the pool rounds to its size class: the reader hands the buffer back to it)
-    EXG_HIP_CHECK(hipMemsetAsync((char *)d_out.p + total, 0, 64, st));
+    EXG_HIP_CHECK(d_out.alloc(front_reserve + total + 64));  // (the pool rounds to its size class: the reader hands the buffer back to it)
+    uint8_t *const out_bytes = (uint8_t *)d_out.p + front_reserve;  // the content's first byte (front_reserve: a multiple of 16)
+    EXG_HIP_CHECK(hipMemsetAsync(out_bytes + total, 0, 64, st));
     const uint32_t nc = (uint32_t)chunks.size();
     double t_exec = 0, t_resolve = 0;
     if (nc) {
@@ -1246,7 +1251,7 @@ int decode(const uint8_t *h_comp, const void *d_comp_v, uint64_t n, void **d_out
             const double t0 = trace ? sync_ms(st) : 0;
             hipLaunchKernelGGL(k_zst_exec, dim3(grid), dim3(64), 0, st, d_comp, (const Block *)d_blocks.p, (const Chunk *)d_chunks.p + R.c0, cnt,
                                (const uint8_t *)d_lit.p, (const uint32_t *)d_ll.p, (const uint32_t *)d_ml.p, (const uint32_t *)d_off.p,
-                               (uint8_t *)d_out.p, (uint32_t *)d_sym.p, (uint32_t *)d_status.p + R.c0);
+                               out_bytes, (uint32_t *)d_sym.p, (uint32_t *)d_status.p + R.c0);
             const double t1 = trace ? sync_ms(st) : 0;
             static const uint64_t group_bytes = getenv("EXG_ZSTD_RESOLVE_BYTES") ? strtoull(getenv("EXG_ZSTD_RESOLVE_BYTES"), nullptr, 10) : (512ull << 10);
             for (uint32_t k0 = 0; k0 < R.n_list;) {
@@ -1259,7 +1264,7 @@ int decode(const uint8_t *h_comp, const void *d_comp_v, uint64_t n, void **d_out
                 ra.chunks = (const Chunk *)d_chunks.p;
                 ra.sym_chunks = d_sym_list + R.list0 + k0;
                 ra.n_sym_chunks = k1 - k0;
-                ra.out = (uint8_t *)d_out.p;
+                ra.out = out_bytes;
                 ra.final_below = first.out_off;
                 ra.elem0 = first.elem_off;
                 ra.n_elems = last.elem_off + ((last.size + 3) & ~3ull) - first.elem_off;
@@ -1274,7 +1279,7 @@ int decode(const uint8_t *h_comp, const void *d_comp_v, uint64_t n, void **d_out
         }
         static const uint64_t verify_max = getenv("EXG_ZSTD_VERIFY_MAX") ? strtoull(getenv("EXG_ZSTD_VERIFY_MAX"), nullptr, 10) : (64ull << 20);  // ~0.55 GB/s per frame: 64 MiB = 0.12 s
         const double t2 = trace ? now_ms() : 0;
-        hipLaunchKernelGGL(k_zst_xxh64, dim3(nf < 16384 ? nf : 16384), dim3(64), 0, st, (const uint8_t *)d_out.p, (const Frame *)d_frames.p, nf,
+        hipLaunchKernelGGL(k_zst_xxh64, dim3(nf < 16384 ? nf : 16384), dim3(64), 0, st, (const uint8_t *)out_bytes, (const Frame *)d_frames.p, nf,
                            verify_max, (uint32_t *)d_status.p + nc);
         EXG_HIP_CHECK(hipGetLastError());
         std::vector<uint32_t> status((size_t)nc + nf);
@@ -1314,7 +1319,7 @@ int decode(const uint8_t *h_comp, const void *d_comp_v, uint64_t n, void **d_out
 
 extern "C" int exg_zstd_decode(const uint8_t *h_comp, const void *d_comp, uint64_t n, void **d_out, uint64_t *produced, void *stream) {
     std::vector<exg::zst::PendingCheck> pending;
-    int rc = exg::zst::decode(h_comp, d_comp, n, d_out, produced, stream, &pending, nullptr);
+    int rc = exg::zst::decode(h_comp, d_comp, n, d_out, produced, stream, &pending, nullptr, 0);
     if (rc || pending.empty()) return rc;
     int dev = 0;
     (void)hipGetDevice(&dev);

@@ -110,8 +110,10 @@ bool build_index(const uint8_t *data, uint64_t n, Index &idx);
 // exg_zstd_decode (include/exon_gpu.h) without the host half of the checksum verification: the frames left to it come back
 // in *pending (NULL: they stay unverified).  host_verify: copies each such frame from d_out in pieces and hashes it (XXH64)
 // on the calling thread, on a stream of its own; EXG_E_PARSE + *err ("Restored data doesn't match checksum ...") on a mismatch.
+// front_reserve (a multiple of 16): bytes left free in front of the content in *d_out (the content begins at *d_out + front_reserve;
+// the block was taken from the device pool with front_reserve + *produced + 64 bytes)
 int decode(const uint8_t *h_comp, const void *d_comp, uint64_t n, void **d_out, uint64_t *produced, void *stream, std::vector<PendingCheck> *pending,
-           Index *prebuilt = nullptr);  // prebuilt: build_index(h_comp, n) done by the caller (beside the upload)
+           Index *prebuilt = nullptr, uint64_t front_reserve = 0);  // prebuilt: build_index(h_comp, n) done by the caller (beside the upload)
 int host_verify(const void *d_out, const std::vector<PendingCheck> &pending, int device, std::string *err);
 
 }  // namespace zst

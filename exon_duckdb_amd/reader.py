@@ -61,6 +61,66 @@ class ShardReader:
             out.extend(zip(*cols))
             self._l.exg_release_chunk(self._r, C.byref(ch))
 
+    def stats(self):
+        """exg_reader_stats_of: device bytes held now / at their peak, batches scanned, decoded segments consumed."""
+        st = abi.ReaderStats()
+        self._l.exg_reader_stats_of.argtypes = [C.c_void_p, C.POINTER(abi.ReaderStats)]
+        rc = self._l.exg_reader_stats_of(self._r, C.byref(st))
+        if rc != 0:
+            self._fail(rc)
+        return {f: getattr(st, f) for f, _ in abi.ReaderStats._fields_ if f != "reserved"}
+
+    def digest(self, nested=False):
+        """(rows, blake2b over the columns of every row in file order) without building Python rows for all of them: the
+        string_t vectors are resolved with numpy, BIGINT / FLOAT columns hashed as their bytes; LIST / STRUCT columns only
+        with nested=True (decoded to Python values: slow).  What a content check of a big input needs."""
+        import hashlib
+
+        import numpy as np
+        hs = [hashlib.blake2b(digest_size=16) for _ in self.types]   # one per column: independent of the chunking
+        rows = 0
+        while True:
+            ch = Chunk()
+            rc = self._l.exg_next_chunk(self._r, C.byref(ch))
+            if rc != 0:
+                self._fail(rc)
+            n = int(ch.n_rows)
+            if n == 0:
+                return rows, hashlib.blake2b(b"".join(x.digest() for x in hs), digest_size=16).hexdigest()
+            rows += n
+            for k, t in enumerate(self.types):
+                h = hs[k]
+                if t in (abi.EXG_TYPE_BIGINT, abi.EXG_TYPE_FLOAT):
+                    width = 8 if t == abi.EXG_TYPE_BIGINT else 4
+                    vals = np.ctypeslib.as_array(C.cast(ch.data[k], C.POINTER(C.c_uint8)), shape=(n * width,)).copy()
+                    if ch.validity[k]:   # a NULL row's value is unspecified: hash zeros there
+                        words = np.ctypeslib.as_array(C.cast(ch.validity[k], C.POINTER(C.c_uint64)), shape=((n + 63) // 64,))
+                        ok = np.unpackbits(words.view(np.uint8), bitorder="little")[:n].astype(bool)
+                        vals.reshape(n, width)[~ok] = 0
+                        h.update(ok.astype(np.uint8).tobytes())   # (a byte per row: independent of the chunking)
+                    h.update(vals.tobytes())
+                    continue
+                if t != abi.EXG_TYPE_VARCHAR:
+                    if nested:
+                        h.update(repr(decode_vector(ch.vectors[k].contents, self.trees[k])).encode())
+                    continue
+                raw = np.ctypeslib.as_array(C.cast(ch.data[k], C.POINTER(C.c_uint8)), shape=(n * 16,)).reshape(n, 16)
+                lens = raw[:, :4].copy().view(np.uint32).reshape(n)
+                ptrs = raw[:, 8:16].copy().view(np.uint64).reshape(n)
+                valid = None
+                if ch.validity[k]:
+                    words = np.ctypeslib.as_array(C.cast(ch.validity[k], C.POINTER(C.c_uint64)), shape=((n + 63) // 64,))
+                    valid = np.unpackbits(words.view(np.uint8), bitorder="little")[:n]
+                for i in range(n):
+                    if valid is not None and not valid[i]:
+                        h.update(b"\xff\x00NULL")
+                    elif lens[i] <= 12:
+                        h.update(raw[i, 4:4 + lens[i]].tobytes())
+                    else:
+                        h.update(C.string_at(int(ptrs[i]), int(lens[i])))
+                    h.update(b"\x00")
+            self._l.exg_release_chunk(self._r, C.byref(ch))
+
     def close(self):
         if self._r:
             self._l.exg_close(self._r)

@@ -288,18 +288,49 @@ uint32_t exg_crc32_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);
 /* ONE big DEFLATE stream (a single-member gzip file) decoded by many wavefronts: block starts are searched near
  * every chunk_bytes of compressed input, the chunks are decoded concurrently with an unknown window and stitched
  * (pugz / rapidgzip method).  d_comp: the compressed bytes on the device, 16-byte aligned; the stream starts at
- * comp_off, at most comp_size bytes are read.  On success *d_out is a hipMalloc'd buffer the caller hipFree()s
- * (*produced bytes + 64 zeroed), *consumed the compressed bytes used.  Synchronises the stream. */
+ * comp_off, at most comp_size bytes are read.  On success *d_out is a block of the library's device pool (*produced bytes
+ * + 64 zeroed) that the caller gives back with exg_free_device() — hipFree() works too: pool blocks are whole allocations —
+ * and *consumed the compressed bytes used.  On an error nothing stays allocated.  Synchronises the stream. */
 int exg_inflate_stream(const void *d_comp, uint64_t comp_off, uint64_t comp_size, uint64_t chunk_bytes, void **d_out,
                        uint64_t *produced, uint64_t *consumed, void *stream);
+/* The same stream in ROUNDS, so that neither the compressed nor the inflated bytes of a big member have to be resident at
+ * once (the reference streams any size through a BufReader: rust/src/arrow_reader.rs:116-153): a round decodes from
+ * start_bit (a block boundary; 0 for the first round) to a block boundary near the end of the bytes that are there.
+ * Bit positions are relative to comp_off.  partial != 0: more compressed bytes follow behind comp_size — the round ends at
+ * (or just behind) the last block start found and does not look at the stream's end; need_more != 0 on return means no
+ * block start was found in the window (call again with more bytes; nothing was produced).  d_window: 32768 bytes of device
+ * memory that carry the LZ77 window from round to round (have_window = 0 for a member's first round; updated in place).
+ * front_reserve (a multiple of 16) bytes stay free in front of the output: d_out + front_reserve is its first byte. */
+typedef struct exg_inflate_round_args {
+    const void *d_comp;
+    uint64_t comp_off, comp_size;
+    uint64_t start_bit;
+    uint64_t chunk_bytes;
+    int partial;
+    int have_window;
+    void *d_window;
+    uint64_t front_reserve;
+    double ratio_hint; /* inflated / compressed bytes seen so far; 0 = unknown */
+    void *stream;
+    /* results */
+    void *d_out;        /* pool block of out_alloc bytes: exg_free_device_sized(d_out, out_alloc) */
+    uint64_t out_alloc;
+    uint64_t produced;
+    uint64_t end_bit;   /* where the next round starts */
+    int final_block;    /* the member's final block was decoded: end_bit (rounded up to a byte) is followed by the trailer */
+    int need_more;
+} exg_inflate_round_args;
+int exg_inflate_round(exg_inflate_round_args *args);
+/* Give a device block the library handed out (exg_inflate_stream, exg_inflate_round, exg_zstd_decode) back to its pool. */
+void exg_free_device(void *d_ptr, uint64_t bytes);
 
 /* ---- device zstd (RFC 8878 frames; replaces zstd 0.12.3 / libzstd 1.5.2 behind rust/src/arrow_reader.rs:73, :87-88;
  * pinned by test_fastq_scan.test:22-32, 55-59 and test_fasta_scan.test:22-26, 45-49) --------------------------------
  * All frames of the stream data[0, n) — concatenated frames and skippable frames included, as ZSTD_decompressStream
  * reads them.  h_comp: the compressed bytes on the host (only frame / block headers are read there: a zstd stream states
  * the size of every block, so the host finds all blocks by a pointer chase and the device entropy-decodes them all at
- * once); d_comp: the same bytes on the device, readable to n + 16.  On success *d_out is a hipMalloc'd buffer the caller
- * hipFree()s (*produced bytes + 64 zeroed).  Every frame with a Content_Checksum is verified: XXH64 on the device up to
+ * once); d_comp: the same bytes on the device, readable to n + 16.  On success *d_out is a block of the library's device
+ * pool (*produced bytes + 64 zeroed): exg_free_device(*d_out, *produced + 64) — hipFree works too.  Every frame with a Content_Checksum is verified: XXH64 on the device up to
  * EXG_ZSTD_VERIFY_MAX bytes of content per frame (default 64 MiB: the hash is a serial recurrence, ~0.55 GB/s per frame on a
  * GPU), larger frames on the host from a copy that comes back in 32 MiB pieces (~20 GB/s; a reader does this on a thread
  * of its own while it scans, and reports a mismatch when the file's last batch is out).  Windows above
@@ -411,6 +442,19 @@ int exg_count_only(exg_reader *r, uint64_t *n_rows);
 /* Pull and release every remaining chunk (a consumer that only walks the DataChunks): rows and chunks handed out. */
 int exg_drain_chunks(exg_reader *r, uint64_t *n_rows, uint64_t *n_chunks);
 const char *exg_reader_error(exg_reader *r);
+/* What a reader holds and has done so far.  Memory does not grow with the input: plain files travel in device batches,
+ * compressed ones are decoded into a bounded stream of segments (like the reference's BufReader + convert_stream,
+ * rust/src/arrow_reader.rs:60-91, 116-153).  EXG_DEVICE_MEM_CAP_MB=<MiB> (read at exg_open) sizes both from a budget. */
+typedef struct exg_reader_stats {
+    uint64_t device_bytes_now;   /* device memory held on behalf of this reader (pool size classes) */
+    uint64_t device_bytes_peak;  /* ... its high-water mark */
+    uint64_t device_mem_cap;     /* EXG_DEVICE_MEM_CAP_MB in bytes, 0 = not set */
+    uint64_t device_batch_bytes; /* bytes per device batch / decoded segment */
+    uint64_t device_batches;     /* scans launched */
+    uint64_t decoded_segments;   /* segments of a compressed input consumed */
+    uint64_t reserved[4];
+} exg_reader_stats;
+int exg_reader_stats_of(exg_reader *r, exg_reader_stats *out);
 /* Device buffers, pinned host blocks and HIP streams of closed readers are recycled process-wide (size classes, at most
  * EXG_POOL_MAX_GB = 64 GB of HBM): this gives them back (the extension's unload / idle path). */
 void exg_trim_pools(void);

@@ -157,14 +157,56 @@ def test_capacity(gpu, oracle):
         assert resolve(cols[0][i], data, payload.tobytes()) == exp.columns["id"].row(i)
 
 
-def test_shards_are_refused(gpu, oracle):
+def test_what_a_buffer_may_be(gpu, oracle):
+    """a buffer begins with a record (lead = 0, EXG_F_BOF); without EXG_F_EOF it is a batch (one-pass form only)"""
     from exon_duckdb_amd import device, ExgError
 
     data = bytes(oracle.synth_fasta(10))
     d_in = device.upload(data)
     scan = device.FastaScan(len(data))
     with pytest.raises(ExgError):
-        scan.launch(d_in, flags=abi.EXG_F_BOF)          # not at EOF: a record could be cut
+        scan.launch(d_in, flags=abi.EXG_F_EOF)                                       # not at a record start
+    with pytest.raises(ExgError):
+        scan.launch(d_in, flags=abi.EXG_F_BOF | abi.EXG_F_EOF, lead=16)
+    with pytest.raises(ExgError):
+        scan.launch(d_in, flags=abi.EXG_F_BOF, algo=abi.EXG_ALGO_MULTIPASS)          # the line-index form scans whole inputs
+
+
+def test_open_tail_batches(gpu, oracle):
+    """Without EXG_F_EOF the buffer is a batch of a longer input: the last record in it is still open (its sequence may
+    go on behind the buffer) and is nobody's row yet — n_records / the columns / the payload are those of the records in
+    front of it, consumed_bytes = where its definition line begins (the next batch starts there).  A batch that holds
+    only one record reports nothing (consumed 0: the caller widens it).  Cuts at every kind of place: inside a sequence
+    line, inside a definition line, right behind a newline, right in front of a '>'."""
+    import random
+    data = bytes(oracle.synth_fasta(400, seed=11))
+    starts = [0] + [i + 1 for i in range(len(data) - 1) if data[i] == 10 and data[i + 1] == 62]
+    rng = random.Random(5)
+    cuts = [rng.randrange(1, len(data)) for _ in range(40)]
+    cuts += [starts[7], starts[7] + 1, starts[7] - 1, starts[30] + 5, starts[1] - 3, len(data) - 1, 1, 17]
+    for cut in cuts:
+        buf = data[:cut]
+        res, cols, words, payload = run_gpu(buf, flags=abi.EXG_F_BOF)
+        # the open record: the last one whose '>' lies inside the buffer AND is announced by the newline in front of it
+        inside = [s for s in starts if s < cut]
+        last = inside[-1]
+        exp = oracle.fasta_parse(data[:last])
+        assert res.error_code == 0, (cut, res.error_code)
+        assert res.n_records == exp.n_rows == len(inside) - 1, cut
+        assert res.consumed_bytes == last, (cut, res.consumed_bytes, last)
+        pl = payload.tobytes()
+        assert pl == b"".join(exp.columns["sequence"].to_list()), cut
+        n = exp.n_rows
+        valid = np.unpackbits(words.view(np.uint8), bitorder="little")[:n]
+        assert np.array_equal(valid, exp.columns["description"].valid)
+        for k, name in enumerate(["id", "description", "sequence"]):
+            col = exp.columns[name]
+            for i in range(0, n, max(1, n // 25)):
+                want = col.row(i)
+                if want is None:
+                    assert not cols[k][i].any()
+                else:
+                    assert resolve(cols[k][i], buf, pl) == want, (cut, name, i)
 
 
 # ---- features placed exactly on the boundaries of the tiled implementation (16 B chunks, 1 KiB rows, 8 KiB wave spans,
