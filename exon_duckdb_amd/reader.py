@@ -70,7 +70,7 @@ class ShardReader:
             self._fail(rc)
         return {f: getattr(st, f) for f, _ in abi.ReaderStats._fields_ if f != "reserved"}
 
-    def digest(self, nested=False):
+    def digest(self, nested=False, per_column=False):
         """(rows, blake2b over the columns of every row in file order) without building Python rows for all of them: the
         string_t vectors are resolved with numpy, BIGINT / FLOAT columns hashed as their bytes; LIST / STRUCT columns only
         with nested=True (decoded to Python values: slow).  What a content check of a big input needs."""
@@ -86,6 +86,8 @@ class ShardReader:
                 self._fail(rc)
             n = int(ch.n_rows)
             if n == 0:
+                if per_column:
+                    return rows, [x.hexdigest() for x in hs]
                 return rows, hashlib.blake2b(b"".join(x.digest() for x in hs), digest_size=16).hexdigest()
             rows += n
             for k, t in enumerate(self.types):
@@ -97,7 +99,8 @@ class ShardReader:
                         words = np.ctypeslib.as_array(C.cast(ch.validity[k], C.POINTER(C.c_uint64)), shape=((n + 63) // 64,))
                         ok = np.unpackbits(words.view(np.uint8), bitorder="little")[:n].astype(bool)
                         vals.reshape(n, width)[~ok] = 0
-                        h.update(ok.astype(np.uint8).tobytes())   # (a byte per row: independent of the chunking)
+                        # (the validity byte travels with its row: independent of the chunking)
+                        vals = np.concatenate([ok.astype(np.uint8)[:, None], vals.reshape(n, width)], axis=1)
                     h.update(vals.tobytes())
                     continue
                 if t != abi.EXG_TYPE_VARCHAR:

@@ -20,16 +20,18 @@ def bgzf(data, block=65280, level=1):
     return b"".join(out) + bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
 
 
-fmt = sys.argv[1] if len(sys.argv) > 1 else "vcf"
-cap = sys.argv[2] if len(sys.argv) > 2 else "16"
-data = bytes({"vcf": lambda: pyoracle.synth_vcf(300000), "fastq": lambda: pyoracle.synth_fastq(332 * 60000),
-              "fasta": lambda: pyoracle.synth_fasta(12000, seed=5)}[fmt]())
-os.environ["EXG_DEVICE_MEM_CAP_MB"] = cap
-from exon_duckdb_amd.reader import ShardReader  # noqa: E402
+if __name__ == "__main__":
+    fmt = sys.argv[1] if len(sys.argv) > 1 else "vcf"
+    cap = sys.argv[2] if len(sys.argv) > 2 else "16"
+    data = bytes({"vcf": lambda: pyoracle.synth_vcf(300000), "fastq": lambda: pyoracle.synth_fastq(332 * 60000),
+                  "fasta": lambda: pyoracle.synth_fasta(12000, seed=5)}[fmt]())
+    os.environ["EXG_DEVICE_MEM_CAP_MB"] = cap
+    from exon_duckdb_amd.reader import ShardReader  # noqa: E402
 
-with tempfile.TemporaryDirectory() as d:
-    p = os.path.join(d, "x." + fmt + ".gz")
-    open(p, "wb").write(bgzf(data))
-    r = ShardReader(p, fmt)
-    print(r.digest(), r.stats())
-    r.close()
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "x." + fmt + ".gz")
+        open(p, "wb").write(bgzf(data))
+        r = ShardReader(p, fmt)
+        print(r.digest(), r.stats())
+        r.close()
+
