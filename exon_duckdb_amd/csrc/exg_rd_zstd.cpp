@@ -1,22 +1,116 @@
-// exg_rd_zstd.cpp — reader level, zstd inputs (.zst, compression='zstd') as a stream of decoded segments
-// (exg_rd_source.hpp): compressed bytes -> HBM -> exg_zstd.hip.  Replaces DataFusion 28
-// `FileCompressionType::ZSTD.convert_stream` -> async-compression -> zstd 0.12.3 behind rust/src/arrow_reader.rs:73, :87-88.
+// exg_rd_zstd.cpp — reader level, zstd inputs (.zst, compression='zstd') as a bounded stream of decoded segments
+// (exg_rd_source.hpp).  Replaces DataFusion 28 `FileCompressionType::ZSTD.convert_stream` -> async-compression -> zstd
+// 0.12.3 behind rust/src/arrow_reader.rs:73, :87-88 — a streaming decoder with a window, whose memory does not depend on the
+// file's size.  Neither does this one's:
+//   * the host walks the frame / block headers of the mapped file (exg_zstd_index.cpp: a pointer chase, no decoding);
+//   * the producer thread decodes the blocks in ROUNDS of about one segment of output (exg::zst::decode_round): the
+//     compressed bytes of the round's blocks travel to the device (parallel pread + H2D), all of them are entropy-decoded
+//     at once, executed in chunks and resolved — whole frames, or a part of a frame;
+//   * what a frame that goes on needs from earlier rounds travels along: the repeat offsets, up to Window_Size bytes of its
+//     output (kept in a device buffer of the producer's and laid in front of the next round's bytes — where the scan's
+//     carried tail lands too), and the compressed bytes of the blocks whose Huffman tree / FSE tables it repeats;
+//   * Content_Checksums: a frame inside one round is hashed on the device (XXH64, up to EXG_ZSTD_VERIFY_MAX bytes); a frame
+//     that is larger or spans rounds is hashed on a host thread from copies of its parts that come back over PCIe while the
+//     next round is being decoded; a mismatch is reported behind the frame's rows, where a streaming decoder reports it.
 #include <string.h>
 #include <sys/mman.h>
+#include <unistd.h>
 
+#include <algorithm>
+#include <deque>
 #include <thread>
 
 #include "exg_rd_source.hpp"
+#include "exg_xxh64.hpp"
 #include "exg_zstd.hpp"
 
 namespace exg_rd {
 
 namespace {
 
+namespace zst = exg::zst;
+
+// XXH64 of frames that span rounds (or are too large for the device's serial hash), on a thread of its own
+class FrameHasher {
+public:
+    struct Part {
+        char *p = nullptr;
+        size_t cap = 0, len = 0;
+        uint32_t frame = 0, expect = 0;
+        bool begins = false, ends = false;
+    };
+    FrameHasher() : thread_([this] { loop(); }) {}
+    ~FrameHasher() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            stop_ = true;
+            cv_.notify_all();
+        }
+        thread_.join();
+        for (Part &q : queue_) global_pool()->give(q.p, q.cap);
+    }
+    // blocks while four parts wait; false: a checksum did not match (error())
+    bool push(Part part) {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return queue_.size() < 4 || failed_; });
+        if (failed_) {
+            lk.unlock();
+            global_pool()->give(part.p, part.cap);
+            return false;
+        }
+        queue_.push_back(part);
+        cv_.notify_all();
+        return true;
+    }
+    // everything pushed has been hashed; false + error(): a mismatch
+    bool drain() {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return (queue_.empty() && !busy_) || failed_; });
+        return !failed_;
+    }
+    std::string error() {
+        std::lock_guard<std::mutex> g(mu_);
+        return error_;
+    }
+
+private:
+    void loop() {
+        exg::Xxh64 h;
+        for (;;) {
+            Part part;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return !queue_.empty() || stop_; });
+                if (queue_.empty()) return;
+                part = queue_.front();
+                queue_.pop_front();
+                busy_ = true;
+                cv_.notify_all();
+            }
+            if (part.begins) h = exg::Xxh64();
+            h.update((const uint8_t *)part.p, part.len);
+            global_pool()->give(part.p, part.cap);
+            std::lock_guard<std::mutex> g(mu_);
+            if (part.ends && (uint32_t)h.digest() != part.expect && !failed_) {
+                failed_ = true;
+                error_ = "Restored data doesn't match checksum (zstd frame " + std::to_string(part.frame) + ")";
+            }
+            busy_ = false;
+            cv_.notify_all();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<Part> queue_;
+    bool stop_ = false, failed_ = false, busy_ = false;
+    std::string error_;
+    std::thread thread_;
+};
+
 class ZstdProducer : public SegmentProducer {
 public:
     ZstdProducer(exg_reader *r, int fd, uint64_t n, uint64_t target, const std::string &path, uint64_t reserve)
-        : device_(r->device), fd_(fd), n_(n), target_(target), path_(path), reserve_((reserve + 15) & ~15ull) {}
+        : device_(r->device), fd_(fd), n_(n), target_(std::max<uint64_t>(target, 128u << 10)), path_(path), reserve_((reserve + 15) & ~15ull) {}
     int run(SegmentSink &sink, std::string *err) override;
 
 private:
@@ -26,8 +120,17 @@ private:
     uint64_t reserve_;
 };
 
+#define ZS_HIP(expr)                                                                               \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            *err = std::string(#expr " failed: ") + hipGetErrorString(_e);                         \
+            return EXG_E_HIP;                                                                      \
+        }                                                                                          \
+    } while (0)
+
 int ZstdProducer::run(SegmentSink &sink, std::string *err) {
-    // the host's walk over the frame / block headers reads the mapped file, beside the upload
+    // the host's walk over the frame / block headers reads the mapped file
     void *map = n_ ? mmap(nullptr, n_, PROT_READ, MAP_PRIVATE, fd_, 0) : nullptr;
     if (map == MAP_FAILED) {
         *err = "cannot map '" + path_ + "'";
@@ -38,6 +141,7 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
         size_t n;
         ~Unmap() { if (p) munmap(p, n); }
     } unmap{map, (size_t)n_};
+    const uint8_t *h_comp = (const uint8_t *)map;
     hipStream_t st = nullptr;
     if (stream_pool()->take(device_, &st) != hipSuccess) {
         *err = "cannot create a stream for the zstd decoder";
@@ -46,58 +150,278 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
     struct StreamBack {
         int dev;
         hipStream_t s;
-        ~StreamBack() { stream_pool()->give(dev, s); }
+        ~StreamBack() { stream_pool()->give(dev, s); }  // (synchronises it)
     } stream_back{device_, st};
-    PoolBuf comp(device_, st);
-    if (!comp.take(n_ + 64)) {
-        *err = "out of device memory for the compressed file";
-        return EXG_E_HIP;
-    }
-    exg::zst::Index idx;
-    bool idx_ok = false;
-    std::thread idx_thread([&] { idx_ok = exg::zst::build_index((const uint8_t *)map, n_, idx); });
-    std::string up_err;
-    int up_rc = n_ ? upload_fd(device_, fd_, comp.p, n_, 0, st, nullptr, &up_err) : EXG_OK;
-    idx_thread.join();
-    if (up_rc) {
-        *err = up_err;
-        return up_rc;
-    }
-    if (!idx_ok) {
+    zst::Index idx;
+    if (!zst::build_index(h_comp, n_, idx)) {
         *err = idx.error + " in '" + path_ + "'";
         return EXG_E_PARSE;
     }
-    if (hipMemsetAsync((char *)comp.p + n_, 0, 64, st) != hipSuccess) {
-        *err = "hipMemsetAsync failed";
+    const uint64_t n_blocks = idx.blocks.size();
+    // the round's compressed bytes: [the blocks whose tables are repeated (at most four) | the round's own, from a 16-byte boundary]
+    static constexpr uint64_t kSideSlot = (zst::kBlockMax + 64 + 15) & ~15ull, kSide = 4 * kSideSlot;
+    PoolBuf d_comp(device_, st), d_hist(device_, st);
+    struct Pin {
+        char *p = nullptr;
+        size_t cap = 0;
+        ~Pin() { if (p) global_pool()->give(p, cap); }
+        bool ensure(size_t n) {
+            if (n <= cap) return true;
+            if (p) global_pool()->give(p, cap);
+            size_t want = n;
+            p = global_pool()->take(&want);
+            cap = p ? want : 0;
+            return p != nullptr;
+        }
+    } pin;
+    size_t d_comp_cap = 0, d_hist_cap = 4096;
+    if (!d_hist.take(d_hist_cap)) {
+        *err = "out of device memory";
         return EXG_E_HIP;
     }
-    void *d_out = nullptr;
-    uint64_t produced = 0;
-    std::vector<exg::zst::PendingCheck> pending;
-    int rc = exg::zst::decode((const uint8_t *)map, comp.p, n_, &d_out, &produced, st, &pending, &idx, reserve_);
-    if (rc) {
-        *err = std::string(exg_last_error_message()) + " in '" + path_ + "'";
-        return rc;
-    }
-    comp.release();
-    Segment seg;
-    seg.buf = d_out;
-    seg.cap = (size_t)(reserve_ + produced + 64);
-    seg.org = -(int64_t)reserve_;
-    seg.lo = seg.start = 0;
-    seg.hi = produced;
-    seg.last = true;
-    if (!sink.push(std::move(seg))) return EXG_OK;
-    // frames too large for the device's serial XXH64 are hashed here, from a copy that travels back while the scan runs; the
-    // reader looks at the result when the file's last batch has been handed out (a streaming decoder reports a checksum
-    // mismatch at the end of the frame too) — the segment stays alive until then (DecodedSource::finish)
-    if (!pending.empty()) {
-        std::string verr;
-        const int vrc = exg::zst::host_verify((const char *)d_out + reserve_, pending, device_, &verr);
-        if (vrc) {
-            *err = verr + " in '" + path_ + "'";
-            return vrc;
+    FrameHasher hasher;
+    const uint64_t verify_max = zst::default_verify_max();
+    uint64_t d_pos = 0;             // decoded bytes produced so far
+    uint64_t b0 = 0;                // next block
+    uint32_t rep[3] = {1, 4, 8};    // repeat offsets behind block b0 - 1 (of the frame that goes on)
+    uint64_t frame_done = 0;        // bytes of the frame that holds block b0 decoded so far (0: it begins with b0)
+    uint64_t hist = 0, pad = 0;     // d_hist holds [pad | hist bytes]: the end of that frame's output so far
+    bool pushed_last = false;
+    while (b0 < n_blocks && !sink.cancelled()) {
+        // ---- the round's blocks: about one segment of output (a block regenerates at most 128 KiB)
+        uint64_t b1 = b0, est = 0;
+        while (b1 < n_blocks && (b1 == b0 || est < target_)) {
+            const zst::Block &B = idx.blocks[b1];
+            est += B.type == 2 ? zst::kBlockMax : B.src_size;  // raw / RLE: src_size is the regenerated size
+            b1++;
+            if (b1 - b0 >= 0x7FFFFF00u) break;
         }
+        zst::Round R;
+        // blocks in front of the round whose tables its blocks repeat
+        std::vector<uint64_t> extra_ids;
+        auto local_of = [&](uint32_t g) -> uint32_t {
+            if (g == zst::kNone) return zst::kNone;
+            if (g >= b0) return (uint32_t)(g - b0) + (uint32_t)extra_ids.size();  // (patched below once the extras are known)
+            for (size_t i = 0; i < extra_ids.size(); i++)
+                if (extra_ids[i] == g) return (uint32_t)i;
+            extra_ids.push_back(g);
+            return (uint32_t)extra_ids.size() - 1;
+        };
+        for (uint64_t b = b0; b < b1; b++) {  // first pass: which sources
+            const zst::Block &B = idx.blocks[b];
+            if (B.type != 2) continue;
+            if (B.huf_src != zst::kNone && B.huf_src < b0) (void)local_of(B.huf_src);
+            for (int t = 0; t < 3; t++)
+                if (B.nseq && B.tbl_src[t] != zst::kNone && B.tbl_src[t] < b0) (void)local_of(B.tbl_src[t]);
+        }
+        const uint32_t nx = (uint32_t)extra_ids.size();
+        if (nx > 4) {
+            *err = "internal: a zstd round repeats the tables of more than four earlier blocks";
+            return EXG_E_INVALID_ARG;
+        }
+        const uint64_t c_lo = idx.blocks[b0].src_off & ~15ull;
+        const zst::Block &BL = idx.blocks[b1 - 1];
+        const uint64_t c_hi = std::min<uint64_t>(n_, BL.src_off + (BL.type == 1 ? 1 : BL.src_size));
+        const uint64_t comp_len = c_hi - c_lo;
+        if (kSide + comp_len + 64 > d_comp_cap) {
+            d_comp_cap = (size_t)(kSide + comp_len + comp_len / 4 + 64);
+            if (!d_comp.take(d_comp_cap)) {
+                *err = "out of device memory for the compressed bytes of '" + path_ + "'";
+                return EXG_E_HIP;
+            }
+        }
+        if (!pin.ensure((size_t)(kSide + comp_len + 64))) {
+            *err = "out of pinned host memory";
+            return EXG_E_HIP;
+        }
+        R.blocks.reserve(nx + (b1 - b0));
+        for (uint32_t i = 0; i < nx; i++) {
+            zst::Block E = idx.blocks[extra_ids[i]];
+            const uint64_t sz = E.type == 2 ? E.src_size : 1;
+            memcpy(pin.p + i * kSideSlot, h_comp + E.src_off, (size_t)std::min<uint64_t>(sz, kSideSlot));
+            E.src_off = i * kSideSlot;
+            E.huf_src = E.tbl_src[0] = E.tbl_src[1] = E.tbl_src[2] = zst::kNone;  // (a source is only read, never decoded)
+            R.blocks.push_back(E);
+        }
+        if (nx) ZS_HIP(hipMemcpyAsync(d_comp.p, pin.p, nx * kSideSlot, hipMemcpyHostToDevice, st));
+        bool hip_failed = false;
+        if (comp_len && !pread_parallel(device_, fd_, c_lo, (size_t)comp_len, pin.p + kSide, (char *)d_comp.p + kSide, st, &hip_failed)) {
+            *err = hip_failed ? "hipMemcpyAsync failed" : "short read of '" + path_ + "'";
+            return hip_failed ? EXG_E_HIP : EXG_E_IO;
+        }
+        ZS_HIP(hipMemsetAsync((char *)d_comp.p + kSide + comp_len, 0, 64, st));
+        auto remap = [&](uint32_t g) -> uint32_t {
+            if (g == zst::kNone) return zst::kNone;
+            if (g >= b0) return (uint32_t)(g - b0) + nx;
+            for (uint32_t i = 0; i < nx; i++)
+                if (extra_ids[i] == g) return i;
+            return zst::kNone;
+        };
+        for (uint64_t b = b0; b < b1; b++) {
+            zst::Block B = idx.blocks[b];
+            B.src_off = kSide + (B.src_off - c_lo);
+            B.huf_src = remap(B.huf_src);
+            for (int t = 0; t < 3; t++) B.tbl_src[t] = remap(B.tbl_src[t]);
+            R.blocks.push_back(B);
+        }
+        R.n_extra = nx;
+        // the frames (or parts of frames) in the round
+        for (uint64_t b = b0; b < b1;) {
+            const uint32_t f = idx.blocks[b].frame;
+            const zst::Frame &F = idx.frames[f];
+            const uint64_t f_end = (uint64_t)F.first_block + F.n_blocks, e = std::min<uint64_t>(b1, f_end);
+            zst::RoundFrame rf;
+            rf.first_block = (uint32_t)(b - b0) + nx;
+            rf.n_blocks = (uint32_t)(e - b);
+            rf.frame_id = f;
+            rf.begins = b == F.first_block;
+            rf.ends = e == f_end;
+            rf.history = rf.begins ? 0 : hist;
+            rf.has_checksum = F.has_checksum;
+            rf.checksum = F.checksum;
+            R.frames.push_back(rf);
+            b = e;
+        }
+        R.rep_in[0] = rep[0], R.rep_in[1] = rep[1], R.rep_in[2] = rep[2];
+        R.d_comp = d_comp.p;
+        R.d_history = d_hist.p;
+        // the first history byte is stream byte d_pos - hist: `pad` (unused) bytes in front of it put it on the 16-byte grid the
+        // decoder's stores and the scan's loads follow (buffer coordinate 0 is 16-byte aligned, and an address must be
+        // congruent to its stream offset: pad = (d_pos - hist) & 15, also when nothing is kept)
+        R.history = pad + hist;
+        R.front_reserve = reserve_;
+        R.verify_max = verify_max;
+        R.first_block_id = b0;
+        R.comp_base = c_lo - kSide;
+        int rc = zst::decode_round(R, st);
+        if (rc) {
+            *err = std::string(exg_last_error_message()) + " in '" + path_ + "'";
+            return rc;
+        }
+        const uint64_t H = R.history;  // pad + hist
+        Segment seg;
+        seg.buf = R.d_buf;
+        seg.cap = R.alloc;
+        seg.org = (int64_t)d_pos - (int64_t)H - (int64_t)reserve_;
+        seg.lo = d_pos - hist;
+        seg.start = d_pos;
+        seg.hi = d_pos + R.produced;
+        const uint8_t *content = (const uint8_t *)R.d_buf + reserve_;  // buffer coordinate 0
+        // ---- frames: sizes, checksums
+        bool bad = false;
+        for (const zst::RoundFrame &rf : R.frames) {
+            const zst::Frame &F = idx.frames[rf.frame_id];
+            const uint64_t before = rf.begins ? 0 : frame_done;
+            if (rf.ends && F.content_size != ~0ull && F.content_size != before + rf.out_size) {
+                *err = "Data corruption detected (zstd frame " + std::to_string(rf.frame_id) + " regenerates " + std::to_string(before + rf.out_size) +
+                       " bytes, its header says " + std::to_string(F.content_size) + ") in '" + path_ + "'";
+                bad = true;
+                break;
+            }
+            if (F.has_checksum && !rf.verified) {
+                // its bytes come back in pieces and are hashed beside the next round's decode
+                constexpr uint64_t kPiece = 32u << 20;
+                for (uint64_t off = 0; off < rf.out_size || (off == 0 && rf.out_size == 0); off += kPiece) {
+                    FrameHasher::Part part;
+                    part.len = (size_t)std::min<uint64_t>(kPiece, rf.out_size - off);
+                    part.cap = part.len + 64;
+                    part.p = global_pool()->take(&part.cap);
+                    if (!part.p) {
+                        *err = "out of pinned host memory for the checksum of a zstd frame";
+                        bad = true;
+                        break;
+                    }
+                    hipError_t he = part.len ? hipMemcpyAsync(part.p, content + rf.out_off + off, part.len, hipMemcpyDeviceToHost, st) : hipSuccess;
+                    if (he == hipSuccess) he = hipStreamSynchronize(st);
+                    if (he != hipSuccess) {
+                        global_pool()->give(part.p, part.cap);
+                        *err = std::string("copying a zstd frame back for its checksum failed: ") + hipGetErrorString(he);
+                        bad = true;
+                        break;
+                    }
+                    part.frame = rf.frame_id;
+                    part.expect = F.checksum;
+                    part.begins = rf.begins && off == 0;
+                    part.ends = rf.ends && off + kPiece >= rf.out_size;
+                    if (!hasher.push(part)) {
+                        *err = hasher.error() + " in '" + path_ + "'";
+                        bad = true;
+                        break;
+                    }
+                    if (rf.out_size == 0) break;
+                }
+                if (bad) break;
+            }
+        }
+        if (bad) {
+            (void)hipStreamSynchronize(st);
+            sink.give(seg.buf, seg.cap);
+            return EXG_E_PARSE;
+        }
+        // ---- what the next round needs of this one
+        const zst::RoundFrame &lastf = R.frames.back();
+        const uint64_t last_before = lastf.begins ? 0 : frame_done;
+        if (lastf.ends) {
+            frame_done = 0, hist = 0, pad = (d_pos + R.produced) & 15;
+            rep[0] = 1, rep[1] = 4, rep[2] = 8;
+        } else {
+            frame_done = last_before + lastf.out_size;
+            rep[0] = R.rep_out[0], rep[1] = R.rep_out[1], rep[2] = R.rep_out[2];
+            const uint64_t window = idx.frames[lastf.frame_id].window;
+            const uint64_t nh = std::min<uint64_t>(std::max<uint64_t>(window, 1), frame_done);
+            const uint64_t end_pos = d_pos + R.produced;  // stream offset behind this round
+            const uint64_t npad = (end_pos - nh) & 15;
+            if (npad + nh > d_hist_cap) {
+                // (the old window's bytes are in this round's buffer too: a new block loses nothing)
+                d_hist_cap = (size_t)(npad + std::max<uint64_t>(nh, std::min<uint64_t>(window, zst::kWindowMax)) + 64);
+                if (!d_hist.take(d_hist_cap)) {
+                    sink.give(seg.buf, seg.cap);
+                    *err = "out of device memory for the window of a zstd frame";
+                    return EXG_E_HIP;
+                }
+            }
+            // the last nh bytes of [history | produced] (nh <= history of this frame + what the round added to it)
+            const uint8_t *src = content + H + R.produced - nh;
+            hipError_t he = hipMemcpyAsync((char *)d_hist.p + npad, src, nh, hipMemcpyDeviceToDevice, st);
+            if (he == hipSuccess) he = hipStreamSynchronize(st);
+            if (he != hipSuccess) {
+                sink.give(seg.buf, seg.cap);
+                *err = std::string("keeping the window of a zstd frame failed: ") + hipGetErrorString(he);
+                return EXG_E_HIP;
+            }
+            hist = nh, pad = npad;
+        }
+        d_pos = seg.hi;
+        b0 = b1;
+        seg.last = b0 >= n_blocks;
+        pushed_last = seg.last;
+        if (!sink.push(std::move(seg))) return EXG_OK;
+    }
+    // The checksums still being folded: a mismatch is this thread's result, which the reader looks at once the last
+    // segment's rows have been handed out (DecodedSource::finish) — where a streaming decoder reports it too.
+    if (!hasher.drain()) {
+        *err = hasher.error() + " in '" + path_ + "'";
+        return EXG_E_PARSE;
+    }
+    if (!pushed_last && !sink.cancelled()) {  // no block at all (an empty file, skippable frames only): the stream still ends
+        Segment seg;
+        seg.cap = (size_t)(reserve_ + 16 + 64);
+        seg.buf = sink.take(seg.cap);
+        if (!seg.buf) {
+            *err = "out of device memory";
+            return EXG_E_HIP;
+        }
+        seg.org = (int64_t)(d_pos & ~15ull) - (int64_t)reserve_;
+        seg.lo = seg.start = seg.hi = d_pos;
+        seg.last = true;
+        hipError_t he = hipMemsetAsync((char *)seg.buf + reserve_, 0, 16 + 64, st);
+        if (he == hipSuccess) he = hipStreamSynchronize(st);
+        if (he != hipSuccess) {
+            sink.give(seg.buf, seg.cap);
+            *err = std::string("hipMemsetAsync failed: ") + hipGetErrorString(he);
+            return EXG_E_HIP;
+        }
+        (void)sink.push(std::move(seg));
     }
     return EXG_OK;
 }

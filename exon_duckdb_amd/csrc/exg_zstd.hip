@@ -294,10 +294,11 @@ __device__ bool huf_stream(const LitLds &s, const uint8_t *p, long long len, uin
 
 __device__ __forceinline__ void block_fail(Block *blocks, uint32_t b, uint32_t code) { atomicCAS(&blocks[b].status, 0u, code); }
 
-__global__ __launch_bounds__(64) void k_zst_literals(const uint8_t *__restrict__ comp, Block *blocks, uint32_t nb, uint8_t *lit) {
+// (b_begin: the blocks in front of it are only there as the sources of repeated tables — a round of a longer stream)
+__global__ __launch_bounds__(64) void k_zst_literals(const uint8_t *__restrict__ comp, Block *blocks, uint32_t b_begin, uint32_t nb, uint8_t *lit) {
     __shared__ LitLds s;
     const uint32_t lane = threadIdx.x;
-    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+    for (uint32_t b = b_begin + blockIdx.x; b < nb; b += gridDim.x) {
         const Block B = blocks[b];
         if (B.type != 2) continue;
         const uint8_t *p = comp + B.src_off;
@@ -427,14 +428,14 @@ __device__ __forceinline__ uint32_t rep_dec(uint32_t code, bool *bad) {  // "tha
     return code - 1;
 }
 
-__global__ __launch_bounds__(64) void k_zst_sequences(const uint8_t *__restrict__ comp, Block *blocks, uint32_t nb, uint32_t *d_ll,
+__global__ __launch_bounds__(64) void k_zst_sequences(const uint8_t *__restrict__ comp, Block *blocks, uint32_t b_begin, uint32_t nb, uint32_t *d_ll,
                                                       uint32_t *d_ml, uint32_t *d_off) {
     __shared__ SeqLds s;
     const uint32_t lane = threadIdx.x;
     if (lane < 36) s.ll_code[lane] = kLLCode[lane];
     if (lane < 53) s.ml_code[lane] = kMLCode[lane];
     __syncthreads();
-    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+    for (uint32_t b = b_begin + blockIdx.x; b < nb; b += gridDim.x) {
         const Block B = blocks[b];
         if (B.type != 2) continue;
         if (B.nseq == 0) {
@@ -540,11 +541,17 @@ __device__ __forceinline__ uint32_t rep_apply(uint32_t code, uint32_t r0, uint32
     return base - k;
 }
 
-__global__ __launch_bounds__(64) void k_zst_scan(Block *blocks, uint32_t nb, uint64_t *total_out) {
+// state: in = {output offset of the first block, the repeat offsets in front of it (a frame that began in an earlier round)},
+//        out = {end of the last block's output, the repeat offsets behind it}
+struct ScanState {
+    unsigned long long run;
+    unsigned int rep[3], pad;
+};
+__global__ __launch_bounds__(64) void k_zst_scan(Block *blocks, uint32_t b_begin, uint32_t nb, ScanState *state) {
     const uint32_t lane = threadIdx.x;
-    uint64_t run = 0;
-    uint32_t r0 = 1, r1 = 4, r2 = 8;  // wave-uniform
-    for (uint32_t g = 0; g < nb; g += 64) {
+    uint64_t run = state->run;
+    uint32_t r0 = state->rep[0], r1 = state->rep[1], r2 = state->rep[2];  // wave-uniform
+    for (uint32_t g = b_begin; g < nb; g += 64) {
         const uint32_t i = g + lane;
         const bool valid = i < nb;
         uint32_t out_size = 0, first = 0, has = 0, c0 = 0, c1 = 0, c2 = 0;
@@ -579,7 +586,10 @@ __global__ __launch_bounds__(64) void k_zst_scan(Block *blocks, uint32_t nb, uin
         }
         run += __builtin_amdgcn_readlane(incl, 63);
     }
-    if (lane == 0) *total_out = run;
+    if (lane == 0) {
+        state->run = run;
+        state->rep[0] = r0, state->rep[1] = r1, state->rep[2] = r2;
+    }
 }
 
 // ---- execution of the sequences -------------------------------------------------------------------------------------
@@ -666,9 +676,10 @@ struct Exec {
             advance(piece);
         }
     }
-    // one element of a match's source: chunk-relative position s (negative: in front of the chunk — symbol chunks only)
+    // one element of a match's source: chunk-relative position s (negative: in front of the chunk)
     __device__ __forceinline__ Elem fetch(int32_t s, uint32_t hi) const {
         if (SYM && s < 0) return (Elem)(kSymRef | (uint32_t)(-s));  // "the byte d in front of the chunk's first"
+        if (!SYM && s < 0) return out0[(long long)s];  // a byte chunk that continues a frame: the window earlier rounds left in front
         if ((uint32_t)s + kRing >= hi) return ring[slot((uint32_t)s)];
         return __hip_atomic_load(out0 + (uint32_t)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // flushed >= 1 KiB ago
     }
@@ -1056,39 +1067,33 @@ int host_verify(const void *d_out, const std::vector<PendingCheck> &pending, int
     return rc;
 }
 
-int decode(const uint8_t *h_comp, const void *d_comp_v, uint64_t n, void **d_out_p, uint64_t *produced, void *stream_v, std::vector<PendingCheck> *pending,
-           Index *prebuilt, uint64_t front_reserve) {
-    if (!h_comp || !d_comp_v || !d_out_p || !produced) {
-        set_error("exg_zstd_decode: null argument");
-        return EXG_E_INVALID_ARG;
-    }
-    if (front_reserve & 15) {
-        set_error("exg_zstd_decode: the room in front of the output must be a multiple of 16");
-        return EXG_E_INVALID_ARG;
-    }
-    *d_out_p = nullptr;
-    *produced = 0;
+int decode_round(Round &R, void *stream_v) {
     hipStream_t st = (hipStream_t)stream_v;
-    const uint8_t *d_comp = (const uint8_t *)d_comp_v;
+    const uint8_t *d_comp = (const uint8_t *)R.d_comp;
+    R.d_buf = nullptr;
+    R.alloc = 0;
+    R.produced = 0;
+    if (!d_comp || (R.front_reserve & 15) || R.n_extra > R.blocks.size()) {
+        set_error("zstd decode: bad arguments");
+        return EXG_E_INVALID_ARG;
+    }
     static const bool trace = getenv("EXG_TRACE") != nullptr;
     const double t_begin = trace ? now_ms() : 0;
-    Index own;
-    Index &idx = prebuilt ? *prebuilt : own;  // (a reader walks the headers while the compressed bytes travel)
-    if (!prebuilt && !build_index(h_comp, n, idx)) {
-        set_error("%s", idx.error.c_str());
-        return EXG_E_PARSE;
-    }
     // temporaries come from (and go back to) the process-wide device pool: hipMalloc / hipFree of the multi-GB symbol
-    // and sequence buffers cost more than the decode (the same 4 GB decode: 0.20 s with warm buffers, 0.4 - 1.2 s without)
+    // and sequence buffers cost more than the decode (the same 4 GB decode: 0.20 s with warm buffers, 0.4 - 1.2 s without).
+    // The stream is waited for before a block goes back: an error return may leave kernels in flight.
     int cur_dev = 0;
     (void)hipGetDevice(&cur_dev);
     struct Dev {
         int dev;
+        hipStream_t st;
         void *p = nullptr;
         size_t sz = 0;
-        explicit Dev(int d) : dev(d) {}
+        Dev(int d, hipStream_t s) : dev(d), st(s) {}
         ~Dev() {
-            if (p) exg_rd::dev_pool()->give(dev, p, sz);
+            if (!p) return;
+            (void)hipStreamSynchronize(st);
+            exg_rd::dev_pool()->give(dev, p, sz);
         }
         hipError_t alloc(size_t bytes) {
             sz = bytes ? bytes : 16;
@@ -1096,20 +1101,31 @@ int decode(const uint8_t *h_comp, const void *d_comp_v, uint64_t n, void **d_out
             return p ? hipSuccess : hipErrorOutOfMemory;
         }
     };
-    const uint32_t nb = (uint32_t)idx.blocks.size(), nf = (uint32_t)idx.frames.size();
-    const double t_index = trace ? now_ms() : 0;
-    Dev d_blocks(cur_dev), d_lit(cur_dev), d_ll(cur_dev), d_ml(cur_dev), d_off(cur_dev), d_meta(cur_dev), d_frames(cur_dev), d_chunks(cur_dev),
-        d_status(cur_dev), d_out(cur_dev), d_sym(cur_dev), d_lookup(cur_dev);
+    std::vector<Block> &blocks = R.blocks;
+    const uint32_t nb = (uint32_t)blocks.size(), nx = R.n_extra, nf = (uint32_t)R.frames.size();
+    // where every block's literals and sequences go (the sources in front hold none of their own)
+    uint64_t lit_bytes = 0, n_seq = 0;
+    for (uint32_t b = nx; b < nb; b++) {
+        blocks[b].lit_off = lit_bytes;
+        blocks[b].seq_off = n_seq;
+        if (blocks[b].type == 2) lit_bytes += (blocks[b].lit_regen + 15) & ~15u, n_seq += blocks[b].nseq;
+    }
+    Dev d_blocks(cur_dev, st), d_lit(cur_dev, st), d_ll(cur_dev, st), d_ml(cur_dev, st), d_off(cur_dev, st), d_meta(cur_dev, st), d_frames(cur_dev, st),
+        d_chunks(cur_dev, st), d_status(cur_dev, st), d_out(cur_dev, st), d_sym(cur_dev, st), d_lookup(cur_dev, st);
     EXG_HIP_CHECK(d_meta.alloc(64));
-    uint64_t total = 0;
-    if (nb) {
+    const uint64_t H = R.history;
+    ScanState state;
+    state.run = H;  // buffer coordinates: [0, H) = what earlier rounds left of the frame that goes on, then this round's bytes
+    state.rep[0] = R.rep_in[0], state.rep[1] = R.rep_in[1], state.rep[2] = R.rep_in[2], state.pad = 0;
+    if (nb > nx) {
         EXG_HIP_CHECK(d_blocks.alloc((size_t)nb * sizeof(Block)));
-        EXG_HIP_CHECK(d_lit.alloc(idx.lit_bytes + 64));
-        EXG_HIP_CHECK(d_ll.alloc(idx.n_seq * 4 + 16));
-        EXG_HIP_CHECK(d_ml.alloc(idx.n_seq * 4 + 16));
-        EXG_HIP_CHECK(d_off.alloc(idx.n_seq * 4 + 16));
-        EXG_HIP_CHECK(hipMemcpyAsync(d_blocks.p, idx.blocks.data(), (size_t)nb * sizeof(Block), hipMemcpyHostToDevice, st));
-        const uint32_t grid = nb < 16384 ? nb : 16384;
+        EXG_HIP_CHECK(d_lit.alloc(lit_bytes + 64));
+        EXG_HIP_CHECK(d_ll.alloc(n_seq * 4 + 16));
+        EXG_HIP_CHECK(d_ml.alloc(n_seq * 4 + 16));
+        EXG_HIP_CHECK(d_off.alloc(n_seq * 4 + 16));
+        EXG_HIP_CHECK(hipMemcpyAsync(d_blocks.p, blocks.data(), (size_t)nb * sizeof(Block), hipMemcpyHostToDevice, st));
+        EXG_HIP_CHECK(hipMemcpyAsync(d_meta.p, &state, sizeof state, hipMemcpyHostToDevice, st));
+        const uint32_t grid = nb - nx < 16384 ? nb - nx : 16384;
         // the two entropy stages are independent of each other (both run one or four LANES per wavefront: the chip is far
         // from full with either): literals on a second stream beside the sequences
         const int dev = cur_dev;
@@ -1121,8 +1137,8 @@ int decode(const uint8_t *h_comp, const void *d_comp_v, uint64_t n, void **d_out
             (void)hipEventRecord(ev0, st);
             (void)hipStreamWaitEvent(st2, ev0, 0);
         }
-        hipLaunchKernelGGL(k_zst_literals, dim3(grid), dim3(64), 0, side ? st2 : st, d_comp, (Block *)d_blocks.p, nb, (uint8_t *)d_lit.p);
-        hipLaunchKernelGGL(k_zst_sequences, dim3(grid), dim3(64), 0, st, d_comp, (Block *)d_blocks.p, nb, (uint32_t *)d_ll.p, (uint32_t *)d_ml.p,
+        hipLaunchKernelGGL(k_zst_literals, dim3(grid), dim3(64), 0, side ? st2 : st, d_comp, (Block *)d_blocks.p, nx, nb, (uint8_t *)d_lit.p);
+        hipLaunchKernelGGL(k_zst_sequences, dim3(grid), dim3(64), 0, st, d_comp, (Block *)d_blocks.p, nx, nb, (uint32_t *)d_ll.p, (uint32_t *)d_ml.p,
                            (uint32_t *)d_off.p);
         if (side) {
             (void)hipEventRecord(ev1, st2);
@@ -1138,44 +1154,52 @@ int decode(const uint8_t *h_comp, const void *d_comp_v, uint64_t n, void **d_out
                 if (s) exg_rd::stream_pool()->give(dev, s);  // (synchronises it)
             }
         } side_guard{dev, st2, ev0, ev1};
-        hipLaunchKernelGGL(k_zst_scan, dim3(1), dim3(64), 0, st, (Block *)d_blocks.p, nb, (uint64_t *)d_meta.p);
+        hipLaunchKernelGGL(k_zst_scan, dim3(1), dim3(64), 0, st, (Block *)d_blocks.p, nx, nb, (ScanState *)d_meta.p);
         EXG_HIP_CHECK(hipGetLastError());
-        EXG_HIP_CHECK(hipMemcpyAsync(idx.blocks.data(), d_blocks.p, (size_t)nb * sizeof(Block), hipMemcpyDeviceToHost, st));
-        EXG_HIP_CHECK(hipMemcpyAsync(&total, d_meta.p, 8, hipMemcpyDeviceToHost, st));
+        EXG_HIP_CHECK(hipMemcpyAsync(blocks.data(), d_blocks.p, (size_t)nb * sizeof(Block), hipMemcpyDeviceToHost, st));
+        EXG_HIP_CHECK(hipMemcpyAsync(&state, d_meta.p, sizeof state, hipMemcpyDeviceToHost, st));
         EXG_HIP_CHECK(hipStreamSynchronize(st));
-        for (uint32_t b = 0; b < nb; b++)
-            if (idx.blocks[b].status) {
-                set_error("%s (zstd block %u at byte %llu)", status_text(idx.blocks[b].status), b, (unsigned long long)idx.blocks[b].src_off);
+        for (uint32_t b = nx; b < nb; b++)
+            if (blocks[b].status) {
+                set_error("%s (zstd block %llu at byte %llu)", status_text(blocks[b].status), (unsigned long long)(R.first_block_id + (b - nx)),
+                          (unsigned long long)(R.comp_base + blocks[b].src_off));
                 return EXG_E_PARSE;
             }
     }
-    // frames: where their content lies, and the size their header promised.  Chunks: a frame is cut into runs of whole
-    // blocks of about `target` bytes, one wavefront each.  The first chunk of a frame writes bytes; every later one cannot
-    // know what lies in front of it while it runs, so it writes 32-bit symbols — a byte, or "the byte d in front of this
-    // chunk" — that are resolved chunk by chunk, in order, once everything in front is final (k_zst_resolve).
+    const uint64_t total = state.run - H;
+    R.rep_out[0] = state.rep[0], R.rep_out[1] = state.rep[1], R.rep_out[2] = state.rep[2];
+    // frames: where their content lies.  Chunks: a frame is cut into runs of whole blocks of about `target` bytes, one
+    // wavefront each.  The first chunk of a frame (or of the part of a frame this round holds: what lies in front of it is
+    // final) writes bytes; every later one cannot know what lies in front of it while it runs, so it writes 32-bit symbols —
+    // a byte, or "the byte d in front of this chunk" — that are resolved chunk by chunk, in order, once everything in front
+    // is final (k_zst_resolve).
     static const uint64_t target_env = getenv("EXG_ZSTD_CHUNK_BYTES") ? strtoull(getenv("EXG_ZSTD_CHUNK_BYTES"), nullptr, 10) : 0;
     const uint64_t target = target_env ? target_env : std::min<uint64_t>(2u << 20, std::max<uint64_t>(128u << 10, total / 4096));
     std::vector<Chunk> chunks;
+    std::vector<Frame> dframes(nf);
     uint64_t sym_elems = 0;
     for (uint32_t f = 0; f < nf; f++) {
-        Frame &F = idx.frames[f];
-        F.out_off = F.n_blocks ? idx.blocks[F.first_block].out_off : total;
+        RoundFrame &F = R.frames[f];
+        F.out_off = F.n_blocks ? blocks[F.first_block].out_off : state.run;
         uint64_t sz = 0;
-        for (uint32_t b = 0; b < F.n_blocks; b++) sz += idx.blocks[F.first_block + b].out_size;
+        for (uint32_t b = 0; b < F.n_blocks; b++) sz += blocks[F.first_block + b].out_size;
         F.out_size = sz;
-        if (F.content_size != ~0ull && F.content_size != sz) {
-            set_error("Data corruption detected (zstd frame %u regenerates %llu bytes, its header says %llu)", f, (unsigned long long)sz,
-                      (unsigned long long)F.content_size);
-            return EXG_E_PARSE;
-        }
+        // (a match may reach back to the first byte of the frame's content — as far as it is still there: a frame that
+        // began in an earlier round has its window, not its beginning, in front of this round's bytes)
+        const uint64_t frame0 = F.begins ? F.out_off : F.out_off - std::min<uint64_t>(F.history, F.out_off);
+        memset(&dframes[f], 0, sizeof(Frame));
+        dframes[f].out_off = F.out_off;
+        dframes[f].out_size = sz;
+        dframes[f].checksum = F.checksum;
+        dframes[f].has_checksum = F.has_checksum && F.begins && F.ends;  // (a frame that spans rounds is hashed by the caller)
         for (uint32_t b = 0; b < F.n_blocks;) {
             Chunk c;
             memset(&c, 0, sizeof c);
             c.first_block = F.first_block + b;
-            c.out_off = idx.blocks[c.first_block].out_off;
-            c.frame_out_off = F.out_off;
+            c.out_off = blocks[c.first_block].out_off;
+            c.frame_out_off = frame0;
             uint64_t got = 0;
-            while (b < F.n_blocks && (got < target || c.n_blocks == 0)) got += idx.blocks[F.first_block + b].out_size, b++, c.n_blocks++;
+            while (b < F.n_blocks && (got < target || c.n_blocks == 0)) got += blocks[F.first_block + b].out_size, b++, c.n_blocks++;
             c.symbolic = c.first_block != F.first_block;
             c.elem_off = c.symbolic ? sym_elems : c.out_off;
             if (c.symbolic) sym_elems += got;
@@ -1183,10 +1207,11 @@ int decode(const uint8_t *h_comp, const void *d_comp_v, uint64_t n, void **d_out
         }
     }
     const double t_entropy = trace ? sync_ms(st) : 0;
-    // (allocated at the device pool's size class: the reader hands the buffer to that pool when the file is done)
-    EXG_HIP_CHECK(d_out.alloc(front_reserve + total + 64));  // (the pool rounds to its size class: the reader hands the buffer back to it)
-    uint8_t *const out_bytes = (uint8_t *)d_out.p + front_reserve;  // the content's first byte (front_reserve: a multiple of 16)
-    EXG_HIP_CHECK(hipMemsetAsync(out_bytes + total, 0, 64, st));
+    // (allocated at the device pool's size class: the caller hands the buffer back to that pool)
+    EXG_HIP_CHECK(d_out.alloc(R.front_reserve + H + total + 64));
+    uint8_t *const out_bytes = (uint8_t *)d_out.p + R.front_reserve;  // buffer coordinate 0
+    if (H) EXG_HIP_CHECK(hipMemcpyAsync(out_bytes, R.d_history, H, hipMemcpyDeviceToDevice, st));
+    EXG_HIP_CHECK(hipMemsetAsync(out_bytes + H + total, 0, 64, st));
     const uint32_t nc = (uint32_t)chunks.size();
     double t_exec = 0, t_resolve = 0;
     if (nc) {
@@ -1201,7 +1226,7 @@ int decode(const uint8_t *h_comp, const void *d_comp_v, uint64_t n, void **d_out
         std::vector<uint64_t> csize(nc);
         for (uint32_t c = 0; c < nc; c++) {
             uint64_t sz = 0;
-            for (uint32_t b = 0; b < chunks[c].n_blocks; b++) sz += idx.blocks[chunks[c].first_block + b].out_size;
+            for (uint32_t b = 0; b < chunks[c].n_blocks; b++) sz += blocks[chunks[c].first_block + b].out_size;
             csize[c] = sz;
             chunks[c].size = sz;
         }
@@ -1212,57 +1237,57 @@ int decode(const uint8_t *h_comp, const void *d_comp_v, uint64_t n, void **d_out
                 chunks[c].byte_end = end;
             }
         }
-        struct Round {
+        struct SymRound {
             uint32_t c0, c1;
             uint32_t list0, n_list;  // its symbolic chunks in sym_list
             uint64_t elems;
         };
-        std::vector<Round> rounds;
+        std::vector<SymRound> rounds;
         std::vector<uint32_t> sym_list;
         uint64_t sym_need = 0;
         {
-            Round R{0, 0, 0, 0, 0};
+            SymRound Q{0, 0, 0, 0, 0};
             for (uint32_t c = 0; c < nc; c++) {
                 if (chunks[c].symbolic && csize[c]) {
-                    if (R.elems && R.elems + csize[c] + 4 > sym_cap) {
-                        R.c1 = c;
-                        rounds.push_back(R);
-                        R = Round{c, 0, (uint32_t)sym_list.size(), 0, 0};
+                    if (Q.elems && Q.elems + csize[c] + 4 > sym_cap) {
+                        Q.c1 = c;
+                        rounds.push_back(Q);
+                        Q = SymRound{c, 0, (uint32_t)sym_list.size(), 0, 0};
                     }
-                    chunks[c].elem_off = R.elems;
-                    R.elems += (csize[c] + 3) & ~3ull;
-                    R.n_list++;
+                    chunks[c].elem_off = Q.elems;
+                    Q.elems += (csize[c] + 3) & ~3ull;
+                    Q.n_list++;
                     sym_list.push_back(c);
-                    sym_need = std::max(sym_need, R.elems);
+                    sym_need = std::max(sym_need, Q.elems);
                 }
             }
-            R.c1 = nc;
-            rounds.push_back(R);
+            Q.c1 = nc;
+            rounds.push_back(Q);
         }
         if (sym_need) EXG_HIP_CHECK(d_sym.alloc(sym_need * 4 + 64));
         EXG_HIP_CHECK(d_lookup.alloc((sym_list.size() + 1) * 4));
         uint32_t *d_sym_list = (uint32_t *)d_lookup.p;
         if (!sym_list.empty()) EXG_HIP_CHECK(hipMemcpyAsync(d_sym_list, sym_list.data(), sym_list.size() * 4, hipMemcpyHostToDevice, st));
         EXG_HIP_CHECK(hipMemcpyAsync(d_chunks.p, chunks.data(), (size_t)nc * sizeof(Chunk), hipMemcpyHostToDevice, st));
-        EXG_HIP_CHECK(hipMemcpyAsync(d_frames.p, idx.frames.data(), (size_t)nf * sizeof(Frame), hipMemcpyHostToDevice, st));
-        for (const Round &R : rounds) {
-            const uint32_t cnt = R.c1 - R.c0, grid = cnt < 16384 ? cnt : 16384;
+        EXG_HIP_CHECK(hipMemcpyAsync(d_frames.p, dframes.data(), (size_t)nf * sizeof(Frame), hipMemcpyHostToDevice, st));
+        for (const SymRound &Q : rounds) {
+            const uint32_t cnt = Q.c1 - Q.c0, grid = cnt < 16384 ? cnt : 16384;
             if (!cnt) continue;
             const double t0 = trace ? sync_ms(st) : 0;
-            hipLaunchKernelGGL(k_zst_exec, dim3(grid), dim3(64), 0, st, d_comp, (const Block *)d_blocks.p, (const Chunk *)d_chunks.p + R.c0, cnt,
+            hipLaunchKernelGGL(k_zst_exec, dim3(grid), dim3(64), 0, st, d_comp, (const Block *)d_blocks.p, (const Chunk *)d_chunks.p + Q.c0, cnt,
                                (const uint8_t *)d_lit.p, (const uint32_t *)d_ll.p, (const uint32_t *)d_ml.p, (const uint32_t *)d_off.p,
-                               out_bytes, (uint32_t *)d_sym.p, (uint32_t *)d_status.p + R.c0);
+                               out_bytes, (uint32_t *)d_sym.p, (uint32_t *)d_status.p + Q.c0);
             const double t1 = trace ? sync_ms(st) : 0;
             static const uint64_t group_bytes = getenv("EXG_ZSTD_RESOLVE_BYTES") ? strtoull(getenv("EXG_ZSTD_RESOLVE_BYTES"), nullptr, 10) : (512ull << 10);
-            for (uint32_t k0 = 0; k0 < R.n_list;) {
+            for (uint32_t k0 = 0; k0 < Q.n_list;) {
                 uint32_t k1 = k0;
                 uint64_t bytes = 0;
-                while (k1 < R.n_list && k1 - k0 < kGroupMax && (bytes < group_bytes || k1 == k0)) bytes += csize[sym_list[R.list0 + k1]], k1++;
-                const Chunk &first = chunks[sym_list[R.list0 + k0]], &last = chunks[sym_list[R.list0 + k1 - 1]];
+                while (k1 < Q.n_list && k1 - k0 < kGroupMax && (bytes < group_bytes || k1 == k0)) bytes += csize[sym_list[Q.list0 + k1]], k1++;
+                const Chunk &first = chunks[sym_list[Q.list0 + k0]], &last = chunks[sym_list[Q.list0 + k1 - 1]];
                 ResolveArgs ra;
                 ra.sym = (const uint32_t *)d_sym.p;
                 ra.chunks = (const Chunk *)d_chunks.p;
-                ra.sym_chunks = d_sym_list + R.list0 + k0;
+                ra.sym_chunks = d_sym_list + Q.list0 + k0;
                 ra.n_sym_chunks = k1 - k0;
                 ra.out = out_bytes;
                 ra.final_below = first.out_off;
@@ -1277,40 +1302,98 @@ int decode(const uint8_t *h_comp, const void *d_comp_v, uint64_t n, void **d_out
                 t_resolve += now_ms() - t1;
             }
         }
-        static const uint64_t verify_max = getenv("EXG_ZSTD_VERIFY_MAX") ? strtoull(getenv("EXG_ZSTD_VERIFY_MAX"), nullptr, 10) : (64ull << 20);  // ~0.55 GB/s per frame: 64 MiB = 0.12 s
         const double t2 = trace ? now_ms() : 0;
         hipLaunchKernelGGL(k_zst_xxh64, dim3(nf < 16384 ? nf : 16384), dim3(64), 0, st, (const uint8_t *)out_bytes, (const Frame *)d_frames.p, nf,
-                           verify_max, (uint32_t *)d_status.p + nc);
+                           R.verify_max, (uint32_t *)d_status.p + nc);
         EXG_HIP_CHECK(hipGetLastError());
         std::vector<uint32_t> status((size_t)nc + nf);
         EXG_HIP_CHECK(hipMemcpyAsync(status.data(), d_status.p, status.size() * 4, hipMemcpyDeviceToHost, st));
         EXG_HIP_CHECK(hipStreamSynchronize(st));
         if (trace)
-            fprintf(stderr, "[exg] zstd: %u blocks, %u chunks (target %llu KiB, %zu round(s)), index %.1f ms, entropy+scan %.1f ms, exec %.1f ms, resolve %.1f ms, "
-                            "xxh64 %.1f ms, %.1f MB out\n",
-                    nb, nc, (unsigned long long)(target >> 10), rounds.size(), t_index - t_begin, t_entropy - t_index, t_exec, t_resolve, now_ms() - t2,
-                    total / 1e6);
+            fprintf(stderr, "[exg] zstd: %u blocks, %u chunks (target %llu KiB, %zu round(s)), entropy+scan %.1f ms, exec %.1f ms, resolve %.1f ms, "
+                            "xxh64 %.1f ms, %.1f MB out (+ %.1f MB of window in front)\n",
+                    nb - nx, nc, (unsigned long long)(target >> 10), rounds.size(), t_entropy - t_begin, t_exec, t_resolve, now_ms() - t2, total / 1e6, H / 1e6);
         for (uint32_t c = 0; c < nc; c++)
             if (status[c]) {
-                set_error("%s (zstd blocks %u..%u)", status_text(status[c]), chunks[c].first_block, chunks[c].first_block + chunks[c].n_blocks - 1);
+                set_error("%s (zstd blocks %llu..%llu)", status_text(status[c]), (unsigned long long)(R.first_block_id + chunks[c].first_block - nx),
+                          (unsigned long long)(R.first_block_id + chunks[c].first_block - nx + chunks[c].n_blocks - 1));
                 return EXG_E_PARSE;
             }
-        for (uint32_t f = 0; f < nf; f++)
+        for (uint32_t f = 0; f < nf; f++) {
             if (status[nc + f]) {
-                set_error("%s (zstd frame %u)", status_text(status[nc + f]), f);
+                set_error("%s (zstd frame %u)", status_text(status[nc + f]), R.frames[f].frame_id);
                 return EXG_E_PARSE;
             }
-        if (pending)
-            for (uint32_t f = 0; f < nf; f++) {
-                const Frame &F = idx.frames[f];
-                if (F.has_checksum && F.out_size > verify_max) pending->push_back(PendingCheck{F.out_off, F.out_size, F.checksum, f});
-            }
+            R.frames[f].verified = dframes[f].has_checksum && R.frames[f].out_size <= R.verify_max;
+        }
     } else {
         EXG_HIP_CHECK(hipStreamSynchronize(st));
     }
-    *d_out_p = d_out.p;  // the caller's from here on (hipFree, or exg_rd::dev_pool()->give(dev, p, produced + 64))
+    R.d_buf = d_out.p;  // the caller's from here on (exg_rd::dev_pool()->give(dev, p, alloc))
+    R.alloc = d_out.sz;
     d_out.p = nullptr;
-    *produced = total;
+    R.produced = total;
+    return EXG_OK;
+}
+
+uint64_t default_verify_max() {
+    static const uint64_t v = getenv("EXG_ZSTD_VERIFY_MAX") ? strtoull(getenv("EXG_ZSTD_VERIFY_MAX"), nullptr, 10) : (64ull << 20);  // ~0.55 GB/s per frame: 64 MiB = 0.12 s
+    return v;
+}
+
+// the whole stream as one round
+int decode(const uint8_t *h_comp, const void *d_comp_v, uint64_t n, void **d_out_p, uint64_t *produced, void *stream_v, std::vector<PendingCheck> *pending,
+           Index *prebuilt, uint64_t front_reserve) {
+    if (!h_comp || !d_comp_v || !d_out_p || !produced) {
+        set_error("exg_zstd_decode: null argument");
+        return EXG_E_INVALID_ARG;
+    }
+    if (front_reserve & 15) {
+        set_error("exg_zstd_decode: the room in front of the output must be a multiple of 16");
+        return EXG_E_INVALID_ARG;
+    }
+    *d_out_p = nullptr;
+    *produced = 0;
+    Index own;
+    Index &idx = prebuilt ? *prebuilt : own;  // (a reader walks the headers while the compressed bytes travel)
+    if (!prebuilt && !build_index(h_comp, n, idx)) {
+        set_error("%s", idx.error.c_str());
+        return EXG_E_PARSE;
+    }
+    Round R;
+    R.blocks = idx.blocks;
+    R.d_comp = d_comp_v;
+    R.front_reserve = front_reserve;
+    R.verify_max = default_verify_max();
+    for (uint32_t f = 0; f < idx.frames.size(); f++) {
+        const Frame &F = idx.frames[f];
+        RoundFrame rf;
+        rf.first_block = F.first_block;
+        rf.n_blocks = F.n_blocks;
+        rf.frame_id = f;
+        rf.begins = rf.ends = true;
+        rf.has_checksum = F.has_checksum;
+        rf.checksum = F.checksum;
+        R.frames.push_back(rf);
+    }
+    const int rc = decode_round(R, stream_v);
+    if (rc) return rc;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    for (uint32_t f = 0; f < idx.frames.size(); f++) {
+        const Frame &F = idx.frames[f];
+        const RoundFrame &rf = R.frames[f];
+        if (F.content_size != ~0ull && F.content_size != rf.out_size) {
+            (void)hipStreamSynchronize((hipStream_t)stream_v);
+            exg_rd::dev_pool()->give(dev, R.d_buf, R.alloc);
+            set_error("Data corruption detected (zstd frame %u regenerates %llu bytes, its header says %llu)", f, (unsigned long long)rf.out_size,
+                      (unsigned long long)F.content_size);
+            return EXG_E_PARSE;
+        }
+        if (pending && F.has_checksum && !rf.verified) pending->push_back(PendingCheck{rf.out_off, rf.out_size, F.checksum, f});
+    }
+    *d_out_p = R.d_buf;
+    *produced = R.produced;
     return EXG_OK;
 }
 

@@ -107,6 +107,43 @@ struct Index {
 // Host: walk the frames and blocks of data[0, n).  false + idx.error on a malformed stream.
 bool build_index(const uint8_t *data, uint64_t n, Index &idx);
 
+// One ROUND of a stream: a run of consecutive blocks — whole frames, or a part of a frame — decoded on the device into a
+// pooled block [front_reserve | history | produced | 64 zero bytes].  A stream of any size is decoded round by round with
+// bounded memory (exg_rd_zstd.cpp), like a streaming decoder with its window: what a frame that goes on needs from earlier
+// rounds is (a) the repeat offsets behind the last block (rep_in), (b) up to Window_Size bytes of its output (`d_history`:
+// copied in front of this round's bytes, so that matches and the consumer's carried tail find them there), and (c) the
+// compressed bytes of the blocks whose Huffman tree / FSE tables are repeated: they ride in front of the round's own blocks
+// (`n_extra`: they are parsed again as table sources, not decoded; tbl_src / huf_src index THIS array).
+struct RoundFrame {
+    uint32_t first_block = 0, n_blocks = 0;  // in Round::blocks
+    uint32_t frame_id = 0;                   // (messages)
+    bool begins = true, ends = true;         // the round holds the frame's first / last block
+    uint64_t history = 0;                    // !begins: bytes of this frame in front of the round's (<= Round::history)
+    uint32_t has_checksum = 0, checksum = 0;
+    // results: where its bytes lie (buffer coordinates: 0 = the first history byte), whether the device verified its checksum
+    uint64_t out_off = 0, out_size = 0;
+    bool verified = false;
+};
+struct Round {
+    std::vector<Block> blocks;  // src_off relative to d_comp; out_size / status / rep_* / out_off come back filled
+    uint32_t n_extra = 0;
+    std::vector<RoundFrame> frames;
+    uint32_t rep_in[3] = {1, 4, 8};
+    const void *d_comp = nullptr;
+    const void *d_history = nullptr;
+    uint64_t history = 0;
+    uint64_t front_reserve = 0;  // a multiple of 16
+    uint64_t verify_max = 0;     // frames up to this many bytes that lie inside the round are hashed (XXH64) on the device
+    uint64_t first_block_id = 0, comp_base = 0;  // (messages: the stream's index of blocks[n_extra], the file offset of d_comp)
+    // results
+    void *d_buf = nullptr;  // pooled block of `alloc` bytes; content at d_buf + front_reserve + history
+    size_t alloc = 0;
+    uint64_t produced = 0;
+    uint32_t rep_out[3] = {1, 4, 8};
+};
+int decode_round(Round &R, void *stream);
+uint64_t default_verify_max();
+
 // exg_zstd_decode (include/exon_gpu.h) without the host half of the checksum verification: the frames left to it come back
 // in *pending (NULL: they stay unverified).  host_verify: copies each such frame from d_out in pieces and hashes it (XXH64)
 // on the calling thread, on a stream of its own; EXG_E_PARSE + *err ("Restored data doesn't match checksum ...") on a mismatch.

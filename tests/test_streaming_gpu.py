@@ -170,3 +170,66 @@ def test_record_that_spans_segments(gpu, oracle, tmp_path, monkeypatch):
         assert [x[0] for x in rows] == want.columns["name"].to_list()
         assert [x[2] for x in rows] == want.columns["sequence"].to_list()
         assert [x[3] for x in rows] == want.columns["quality_scores"].to_list()
+
+
+def test_zstd_larger_than_the_cap(gpu, oracle, fastq_big, tmp_path, monkeypatch):
+    """one frame (what the zstd CLI writes), with a Content_Checksum, decoded in rounds: the frame's window, its repeat
+    offsets and the blocks whose tables it repeats travel from round to round; the checksum is folded on a host thread"""
+    from zstd_util import compress
+    data, want = fastq_big
+    p = tmp_path / "big.fastq.zst"
+    p.write_bytes(compress(data, 3, True, window_log=17))
+    free, capped, st = _capped_and_not(monkeypatch, p, "fastq")
+    assert free == want, "the uncapped run differs from the oracle"
+    assert capped == want, "the capped run differs from the oracle"
+    assert st["decoded_segments"] >= 8
+
+
+@pytest.mark.parametrize("level,window_log", [(1, 0), (3, 18), (9, 20), (19, 21), (-3, 0)])
+def test_zstd_rounds_against_libzstd(gpu, oracle, tmp_path, monkeypatch, level, window_log):
+    """frames and parts of frames in rounds of many sizes: multi-frame streams (some frames smaller than a round, some
+    spanning several), skippable frames in between, with and without checksums / content sizes — the rows of the plain file"""
+    from zstd_util import compress, skippable
+    data = bytes(oracle.synth_fastq(332 * 24000))                 # 8 MB
+    want = _oracle_digest(oracle.fastq_parse(data, want_string_t=False), ["name", "description", "sequence", "quality_scores"])
+    cuts = [0, 1000, 1000 + 332 * 300 + 7, 3_000_000, 3_000_001, 6_500_000, len(data)]
+    parts = []
+    for i in range(len(cuts) - 1):
+        parts.append(compress(data[cuts[i]:cuts[i + 1]], level, i % 2 == 0, window_log=window_log, content_size=i % 3 != 1))
+        if i == 2:
+            parts.append(skippable(b"between frames"))
+    blob = b"".join(parts)
+    p = tmp_path / "m.fastq.zst"
+    p.write_bytes(blob)
+    for batch in (128 << 10, 400_000, 1 << 20, 3 << 20):
+        monkeypatch.setenv("EXG_DEVICE_BATCH_BYTES", str(batch))
+        r = _open(p, "fastq")
+        got = r.digest()
+        n_seg = r.stats()["decoded_segments"]
+        r.close()
+        assert got == want, (level, window_log, batch)
+        assert n_seg >= (len(data) // max(batch, 128 << 10)) // 2
+        r = _open(p, "fastq")
+        assert r.count() == want[0]
+        r.close()
+
+
+def test_zstd_checksum_of_a_frame_that_spans_rounds(gpu, oracle, tmp_path, monkeypatch):
+    """a wrong Content_Checksum of a frame decoded in several rounds is reported — behind the frame's rows, like a streaming
+    decoder reports it (the device hashes only frames that lie inside one round)"""
+    from exon_duckdb_amd import ExgError
+    from zstd_util import compress
+    data = bytes(oracle.synth_fastq(332 * 12000))
+    blob = bytearray(compress(data, 3, True, window_log=18))
+    blob[-1] ^= 0x40                                               # the checksum's last byte
+    p = tmp_path / "bad.fastq.zst"
+    p.write_bytes(bytes(blob))
+    monkeypatch.setenv("EXG_DEVICE_BATCH_BYTES", str(512 << 10))
+    r = _open(p, "fastq")
+    with pytest.raises(ExgError, match="checksum"):
+        r.count()
+    r.close()
+    r = _open(p, "fastq")
+    with pytest.raises(ExgError, match="checksum"):
+        r.rows()
+    r.close()
