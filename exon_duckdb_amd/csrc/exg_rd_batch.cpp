@@ -82,8 +82,8 @@ static int plan_bgzf_shard(exg_reader *r, const std::string &path, uint64_t n, u
     *c_end = hi >= n ? n : std::max<uint64_t>(first_own, bgzf_find(nullptr, fd, n, hi));
     // candidates for the halo: members that begin in the ~1.5 MiB of file in front of the cut (BGZF does not expand)
     std::vector<uint64_t> hdr, out;
-    static const uint64_t halo_want = getenv("EXG_SHARD_HALO") ? strtoull(getenv("EXG_SHARD_HALO"), nullptr, 10) : kShardHalo;
-    const uint64_t back = halo_want + (halo_want >> 1) + (128u << 10);
+    const uint64_t halo_want = r->halo_want;
+    const uint64_t back = halo_want > n ? n : halo_want + (halo_want >> 1) + (128u << 10);
     for (uint64_t pos = first_own == 0 ? 0 : bgzf_find(nullptr, fd, n, lo > back ? lo - back : 0); pos < first_own;) {
         exg_inflate_member m;
         const uint64_t nx = bgzf_member_at(peek, pos, &m);
@@ -369,7 +369,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         // the record / line that ends behind the cut — it belongs to this shard — has its beginning in the buffer
         uint64_t shard_halo = 0;
         if (r->shard_first) {
-            static const uint64_t halo_max = getenv("EXG_SHARD_HALO") ? strtoull(getenv("EXG_SHARD_HALO"), nullptr, 10) : kShardHalo;
+            const uint64_t halo_max = r->halo_want;
             const uint64_t base = r->data_base;
             const uint64_t from = r->file_pos - std::min<uint64_t>(halo_max, r->file_pos - base);
             // (a buffer that already lives in HBM must be entered at a 16-byte boundary: a few bytes of the header's
@@ -505,8 +505,17 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
                 first_line_index = prev == '\n' ? guess : (guess + 3) % 4;
             } else if (r->src) {
                 // BGZF shard: exact only when the halo begins with the file (the newlines in front are then all in HBM)
-                if (!(r->data0_is_line_start && lead == r->file_pos))
-                    return fail(r, EXG_E_PARSE, "cannot tell the FASTQ record phase at the shard boundary of '" + r->files[r->file_idx - 1] + "'");
+                if (!(r->data0_is_line_start && lead == r->file_pos)) {
+                    // (few lines in view — records far longer than the halo — or several phases fit): the stream is taken
+                    // from the start of the file, where the count is exact
+                    if (r->halo_want == ~0ull)
+                        return fail(r, EXG_E_PARSE, "cannot tell the FASTQ record phase at the shard boundary of '" + r->files[r->file_idx - 1] + "'");
+                    r->halo_want = ~0ull;
+                    r->src.reset();
+                    r->file_idx--;
+                    if ((rc = open_next_file(r))) return rc;
+                    continue;
+                }
                 unsigned long long nl = 0;
                 rc = exg_count_newlines(d_input, 0, lead, (uint64_t *)r->d_phase, r->stream);
                 if (rc) return fail(r, rc, exg_last_error_message());
@@ -628,6 +637,20 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             res.flags |= EXG_RF_FALLBACK;
         }
         TRACE("wait(h2d) + scan", t_scan);
+        if (r->shard_first && (res.flags & EXG_RF_HEAD_UNRESOLVED) && r->file_pos - shard_halo > r->data_base) {
+            // The record that ends behind the cut begins in front of the halo (a long read, a very wide VCF line): it belongs
+            // to this shard, so this shard looks further back — eight times as far, up to the first byte of the data — and
+            // scans the batch again.  (The shard in front leaves the record alone: it ends behind ITS range.)
+            RD_HIP(r, hipStreamSynchronize(r->stream));
+            r->halo_want = r->halo_want > (~0ull >> 4) ? ~0ull : r->halo_want * 8;
+            if (r->src) {
+                // a decoded stream begins with its halo: its members / frames are chosen again
+                r->src.reset();
+                r->file_idx--;
+                if ((rc = open_next_file(r))) return rc;
+            }
+            continue;
+        }
         if ((res.flags & EXG_RF_INDEX_OVERFLOW) && r->mem_cap && !r->ws_full) {
             RD_HIP(r, hipStreamSynchronize(r->stream));  // denser lines than the budgeted workspace indexes: the full one, same batch again
             r->free_device();
@@ -789,13 +812,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             r->file_done = true;
         } else {
             r->file_pos += res.consumed_bytes - lead;
-            if (range_end) {
-                // what is left belongs to the next shard, whose halo must reach back to where that record begins
-                r->file_done = true;
-                if (batch_end - r->file_pos > kShardHalo)
-                    return fail(r, EXG_E_UNSUPPORTED, "a record longer than the 1 MiB shard halo crosses the shard boundary at byte " +
-                                                          std::to_string(batch_end) + " of '" + r->files[r->file_idx - 1] + "'");
-            }
+            if (range_end) r->file_done = true;  // what is left belongs to the next shard, whose halo reaches back to where that record begins
         }
         TRACE("batch (h2d+scan+d2h)", t_batch);
         if (trace_on())

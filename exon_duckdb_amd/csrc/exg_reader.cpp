@@ -58,6 +58,7 @@ extern "C" int exg_open(const exg_open_args *args, exg_reader **out) {
         const uint64_t div = r->format == EXG_FMT_VCF ? 64 : r->format == EXG_FMT_FASTA ? 32 : 20;
         if (r->mem_cap) r->device_batch_bytes = std::max<uint64_t>(64u << 10, std::min<uint64_t>(r->device_batch_bytes, (r->mem_cap / div) & ~15ull));
     }
+    r->halo_want = getenv("EXG_SHARD_HALO") ? std::max<uint64_t>(16, strtoull(getenv("EXG_SHARD_HALO"), nullptr, 10)) : kShardHalo;
     r->device = args->device;
     r->shard_count = args->shard_count ? args->shard_count : 1;
     r->shard_index = args->shard_index;

@@ -374,6 +374,11 @@ struct exg_reader {
     uint32_t shard_index = 0, shard_count = 1;  // byte-range shards of every file (exg_open_args)
     uint64_t range_hi = 0;    // this reader's bytes of the current file end here (file size without shards)
     bool shard_first = false; // the next batch is the first of a shard that begins inside the file: halo + phase
+    // bytes in front of a shard's cut that travel with its first batch (the beginning of the record that ends behind the
+    // cut).  1 MiB (EXG_SHARD_HALO) to begin with; when the scan reports that the record begins further back
+    // (EXG_RF_HEAD_UNRESOLVED) the halo is grown eightfold and the batch scanned again, up to the first byte of the data:
+    // a record of any length across a cut is found, like the unsharded scan finds it
+    uint64_t halo_want = 0;
     bool range_eof = true;    // range_hi is the end of the file's data (a later shard follows otherwise)
     bool range_preset = false;  // BGZF shard: inflate_file chose the members, file_pos / range_hi refer to ITS inflated bytes
     uint64_t preset_pos = 0;    // ... first owned inflated byte (what is in front of it is the halo)

@@ -133,20 +133,42 @@ def test_unshardable_inputs_fail_loudly(gpu, golden_dir):
         ShardReader(f"{golden_dir}/test.fastq", "fastq", shard_index=2, shard_count=2)
 
 
-def test_record_longer_than_the_halo_across_a_cut_is_an_error(gpu, tmp_path, monkeypatch):
-    from exon_duckdb_amd._lib import ExgError
-    from exon_duckdb_amd.reader import ShardReader
-    # one 3 MB read in the middle of short ones: the cut of 2 shards falls inside it
+@pytest.mark.parametrize("n_shards", [2, 3, 7, 16])
+def test_record_longer_than_the_halo_across_a_cut(gpu, tmp_path, n_shards):
+    """A record longer than the 1 MiB halo that crosses a cut (an ultra-long read; with 16 shards it spans whole shards): it
+    belongs to the shard its last line ends in, and that shard looks as far back as it has to (EXG_RF_HEAD_UNRESOLVED ->
+    the halo grows eightfold, the batch is scanned again).  The shards partition the rows of the unsharded scan — text and
+    BGZF (whose halo is made of members: they are chosen again) — where round 2 raised an error."""
     short = b"".join(b"@r%d\nACGT\n+\nIIII\n" % i for i in range(1000))
-    long_read = b"@long\n" + b"A" * 3_000_000 + b"\n+\n" + b"I" * 3_000_000 + b"\n"
+    long_read = b"@long some description\n" + b"ACGT" * 750_000 + b"\n+\n" + b"I" * 3_000_000 + b"\n"
+    data = short + long_read + short + b"@long2\n" + b"C" * 1_500_000 + b"\n+\n" + b"#" * 1_500_000 + b"\n" + short
     p = tmp_path / "long.fastq"
-    p.write_bytes(short + long_read + short)
-    r = ShardReader(str(p), "fastq", shard_index=0, shard_count=2)
-    with pytest.raises(ExgError, match="halo"):
-        r.rows()
-    r.close()
-    assert len(whole(str(p), "fastq")) == 2001
+    p.write_bytes(data)
+    want = whole(str(p), "fastq")
+    assert len(want) == 3002
+    got, counts = sharded(str(p), "fastq", n_shards)
+    assert got == want
+    gz = tmp_path / "long.fastq.gz"
+    gz.write_bytes(_bgzf(data))
+    got, counts = sharded(str(gz), "fastq", n_shards)
+    assert got == want
 
+
+def test_vcf_line_longer_than_the_halo_across_a_cut(gpu, oracle, tmp_path):
+    """a very wide multi-sample line (3 MB of samples) across the cuts of 2 .. 5 shards"""
+    body = bytes(oracle.synth_vcf(3000))
+    lines = body.split(b"\n")
+    k = next(i for i, ln in enumerate(lines) if ln.startswith(b"#CHROM"))
+    wide = b"1\t999\t.\tA\tC\t.\t.\tDP=1\tGT\t" + b"\t".join(b"0/1" for _ in range(750_000))
+    mid = k + 1 + (len(lines) - k) // 2
+    data = b"\n".join(lines[:mid] + [wide] + lines[mid:])
+    p = tmp_path / "wide.vcf"
+    p.write_bytes(data)
+    want = whole(str(p), "vcf")
+    assert len(want) == 3001
+    for n in (2, 3, 5):
+        got, _ = sharded(str(p), "vcf", n)
+        assert [r[:2] for r in got] == [r[:2] for r in want] and len(got) == 3001
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("EXG_SHARD_FUZZ", "12"))))
