@@ -23,6 +23,7 @@
 
 #include "exg_arrow.hpp"
 #include "exg_filter.hpp"
+#include "exg_rd_fanout.hpp"
 #include "exg_rd_source.hpp"
 
 using namespace exg_rd;
@@ -196,11 +197,13 @@ struct StreamState {
     hipStream_t copy_stream = nullptr;
     int copy_dev = 0;
     hipEvent_t copy_ev = nullptr;
+    std::unique_ptr<FanOut> fan;  // several devices: the batches come from the stripes' streams (exg_rd_fanout.hpp)
     bool owns_reader = true;  // new_reader: the stream owns its reader; chunk mode: the reader owns this state
     // chunk mode: the columns' exg_type trees (node arrays and names live here)
     std::vector<std::unique_ptr<exg_type[]>> type_nodes;
     exg_type type_roots[16];
     ~StreamState() {
+        fan.reset();  // (the workers' streams end first)
         if (copy_ev) (void)hipEventDestroy(copy_ev);
         if (copy_stream) stream_pool()->give(copy_dev, copy_stream);
         for (void *p : {d_consts, d_prog, d_info_names, d_format_names})
@@ -984,7 +987,7 @@ int stream_get_next(ArrowArrayStream *s, ArrowArray *out) {
     for (;;) {
         if (st->batch && st->batch_row < st->batch->n_rows) {
             // the first record batch of a device batch: the next device batch starts being made
-            if (st->batch_row == 0 && !st->producer.joinable() && st->produced_state == 0) st->producer = std::thread(produce, st);
+            if (st->batch_row == 0 && !st->fan && !st->producer.joinable() && st->produced_state == 0) st->producer = std::thread(produce, st);
             const uint64_t row0 = st->batch_row, B = r->batch_rows;
             const uint64_t len = std::min<uint64_t>(B, st->batch->n_rows - row0);
             auto *p = new ArrayPriv();
@@ -1008,6 +1011,20 @@ int stream_get_next(ArrowArrayStream *s, ArrowArray *out) {
             return 0;
         }
         st->batch.reset();
+        if (st->fan) {
+            if (st->produced_state == 3) return EIO;
+            FanItem item;
+            std::string msg;
+            if (st->fan->next(&item, &msg)) {
+                st->last_error = msg;
+                st->produced_state = 3;
+                return EIO;
+            }
+            if (!item.batch) return 0;  // out->release == NULL: end of stream
+            st->batch = std::static_pointer_cast<ABatch>(item.batch);
+            st->batch_row = 0;
+            continue;
+        }
         if (st->producer.joinable()) st->producer.join();
         if (st->produced_state == 0) produce(st);  // (the first batch of the stream: nothing is under way yet)
         const int state = st->produced_state;
@@ -1284,30 +1301,29 @@ extern "C" int exg_vcf_header_explain(const char *header, size_t n, char *out, s
     return 0;
 }
 
-extern "C" ReaderResult new_reader(ArrowArrayStream *stream_ptr, const char *uri, uintptr_t batch_size, const char *compression,
-                                   const char *file_format, const char *filters) {
-    if (!stream_ptr || !uri || !file_format) return result_error("new_reader: null argument");
-    exg_open_args oa;
-    memset(&oa, 0, sizeof oa);
-    oa.path = uri;
-    oa.file_format = file_format;
-    oa.compression = compression;
-    oa.batch_rows = batch_size;
+// A reader in Arrow mode + its stream state: schema (VCF: from the first file's header), the `filters` program, the
+// emitter.  shard_index / shard_count / device of `oa` make it the reader of one stripe of a fan-out.
+static int build_stream(const exg_open_args &oa, const char *filters, std::shared_ptr<StreamState> *out, std::string *err) {
     exg_reader *r = nullptr;
     int rc = exg_open(&oa, &r);
     if (rc) {
         std::string m = exg_last_error_message();
         // arrow_reader.rs:93-102 / :118-123
         if (m.rfind("could not", 0) != 0) m = "could not register table: " + m;
-        return result_error(m);
+        *err = m;
+        return rc;
     }
     DeviceGuard guard(r->device);
+    MeterScope meter_scope(&r->meter);
     auto st = std::make_shared<StreamState>();
     st->r = r;
     // The VCF schema needs the first file's header, like register_exon_table (arrow_reader.rs:118-123).  The file
     // is let go again right after: the reference's bind opens a stream only for its schema and never releases
     // it (module.cpp:82-155), so a stream that was not read must not pin a mapping or inflated bytes in HBM.
-    if (r->format == EXG_FMT_VCF && open_next_file(r)) return result_error("could not register table: " + r->error);
+    if (r->format == EXG_FMT_VCF && open_next_file(r)) {
+        *err = "could not register table: " + r->error;
+        return EXG_E_IO;
+    }
     auto utf8 = [](const char *name, bool nullable) {
         Field f;
         f.name = name;
@@ -1341,12 +1357,13 @@ extern "C" ReaderResult new_reader(ArrowArrayStream *stream_ptr, const char *uri
         st->schema = {utf8("chrom", false), pos, list_utf8("id"), utf8("ref", false), list_utf8("alt"), qual,
                       list_utf8("filter"), info, formats};
         if ((rc = upload_keys(r, st->info_keys, &st->info_vt, &st->d_info_names)) ||
-            (rc = upload_keys(r, st->format_keys, &st->format_vt, &st->d_format_names)))
-            return result_error("could not register table: " + r->error);
+            (rc = upload_keys(r, st->format_keys, &st->format_vt, &st->d_format_names))) {
+            *err = "could not register table: " + r->error;
+            return rc;
+        }
         r->file.reset();
+        r->src.reset();  // (the decoder of a compressed file stops: it reads through the descriptor that closes next)
         r->fd_keep.reset();
-        if (r->finish_source()) return result_error("could not register table: " + r->error);
-        r->src.reset();
         r->file_idx = 0;
         r->file_pos = 0;
         r->file_done = true;
@@ -1357,7 +1374,10 @@ extern "C" ReaderResult new_reader(ArrowArrayStream *stream_ptr, const char *uri
         std::vector<exg_rd::FilterColumn> fcols;
         for (auto &f : st->schema) fcols.push_back({f.name, f.format == "u" ? 'u' : f.format == "l" ? 'l' : f.format == "f" ? 'f' : 'x'});
         exg_rd::FilterParser fp(text, fcols);
-        if (!fp.parse()) return result_error("could not execute sql: " + fp.err);
+        if (!fp.parse()) {
+            *err = "could not execute sql: " + fp.err;
+            return EXG_E_INVALID_ARG;
+        }
         st->has_filter = true;
         st->prog = fp.prog;
         st->consts = fp.consts;
@@ -1365,18 +1385,97 @@ extern "C" ReaderResult new_reader(ArrowArrayStream *stream_ptr, const char *uri
             hipMalloc(&st->d_prog, sizeof(ea::FilterProgram)) != hipSuccess ||
             hipMemcpy(st->d_prog, &st->prog, sizeof(ea::FilterProgram), hipMemcpyHostToDevice) != hipSuccess ||
             (!st->consts.empty() &&
-             hipMemcpy(st->d_consts, st->consts.data(), st->consts.size(), hipMemcpyHostToDevice) != hipSuccess))
-            return result_error("could not execute sql: device allocation failed");
+             hipMemcpy(st->d_consts, st->consts.data(), st->consts.size(), hipMemcpyHostToDevice) != hipSuccess)) {
+            *err = "could not execute sql: device allocation failed";
+            return EXG_E_HIP;
+        }
     }
     r->arrow_emit = arrow_emit;
     // the reader is owned by the stream state from here on
-    std::shared_ptr<StreamState> owned = st;
-    r->arrow_state = std::shared_ptr<void>(owned, owned.get());
+    r->arrow_state = std::shared_ptr<void>(st, st.get());
+    *out = st;
+    return EXG_OK;
+}
+
+extern "C" ReaderResult new_reader(ArrowArrayStream *stream_ptr, const char *uri, uintptr_t batch_size, const char *compression,
+                                   const char *file_format, const char *filters) {
+    if (!stream_ptr || !uri || !file_format) return result_error("new_reader: null argument");
+    exg_open_args oa;
+    memset(&oa, 0, sizeof oa);
+    oa.path = uri;
+    oa.file_format = file_format;
+    oa.compression = compression;
+    oa.batch_rows = batch_size;
+    oa.shard_count = 1;  // (the front reader itself reads the whole input unless it fans out below)
+    std::shared_ptr<StreamState> st;
+    std::string err;
+    if (build_stream(oa, filters, &st, &err)) return result_error(err);
+    // The reference's FFI has no shard argument and its glue pulls the stream from one thread (rust.hpp:41-46,
+    // module.cpp:36): with several devices the stream fans out by itself — stripes of the input are read by streams of
+    // their own, one worker thread and one device each, and their record batches are handed out here in file order.
+    {
+        std::vector<Stripe> stripes;
+        unsigned workers = 1;
+        if (plan_stripes(st->r, &oa, &stripes, &workers) == EXG_OK && stripes.size() > st->r->files.size()) {
+            struct Sub : FanSub {
+                std::shared_ptr<StreamState> st;
+                ~Sub() override {
+                    if (!st) return;
+                    DeviceGuard guard(st->r->device);  // (no MeterScope: the reader, and its meter, go away in here)
+                    st->produced.reset();
+                    std::shared_ptr<void> last = std::move(st->r->arrow_state);
+                    st.reset();
+                    last.reset();  // deletes the state, and the reader with it
+                }
+                int next(FanItem *item, std::string *e) override {
+                    MeterScope meter_scope(&st->r->meter);
+                    st->produced_state = 0;
+                    produce(st.get());
+                    if (st->produced_state == 3) {
+                        *e = st->last_error;
+                        return EXG_E_PARSE;
+                    }
+                    if (st->produced_state == 1) {
+                        item->rows = st->produced->n_rows;
+                        item->batch = std::move(st->produced);
+                    }
+                    return EXG_OK;
+                }
+                int count(uint64_t *, std::string *e) override {
+                    *e = "an Arrow stream is not counted";
+                    return EXG_E_UNSUPPORTED;
+                }
+            };
+            const std::string format = file_format, comp = compression ? compression : "", flt = filters ? filters : "";
+            const bool has_comp = compression != nullptr;
+            const uint64_t rows = batch_size;
+            FanOpen open = [=](const Stripe &s, std::unique_ptr<FanSub> *sub, std::string *e) -> int {
+                exg_open_args a;
+                memset(&a, 0, sizeof a);
+                a.path = s.path.c_str();
+                a.file_format = format.c_str();
+                a.compression = has_comp ? comp.c_str() : nullptr;
+                a.batch_rows = rows;
+                a.device = s.device;
+                a.shard_index = s.shard_index;
+                a.shard_count = s.shard_count ? s.shard_count : 1;
+                std::unique_ptr<Sub> x(new Sub());
+                const int rc = build_stream(a, flt.empty() ? nullptr : flt.c_str(), &x->st, e);
+                if (rc) {
+                    x->st.reset();
+                    return rc;
+                }
+                *sub = std::move(x);
+                return EXG_OK;
+            };
+            st->fan.reset(new FanOut(std::move(stripes), workers, std::move(open), 2));
+        }
+    }
     stream_ptr->get_schema = stream_get_schema;
     stream_ptr->get_next = stream_get_next;
     stream_ptr->get_last_error = stream_last_error;
     stream_ptr->release = stream_release;
-    stream_ptr->private_data = owned.get();
+    stream_ptr->private_data = st.get();
     ReaderResult ok;
     ok.error = nullptr;
     return ok;

@@ -288,6 +288,36 @@ int open_next_file(exg_reader *r) {
 
 int n_string_cols(int format) { return format == EXG_FMT_FASTQ ? 4 : format == EXG_FMT_FASTA ? 3 : 9; }
 
+int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out);
+
+int advance_batch(exg_reader *r, bool *end) {
+    *end = false;
+    for (;;) {
+        if (r->batch && r->batch_row < r->batch->n_rows) return EXG_OK;
+        if (r->pending_error) {
+            // rows before the failing record have been handed out; now surface the error
+            std::string msg = std::string(exg_parse_error_string(r->pending_error)) + " at byte " + std::to_string(r->pending_error_offset) + " of " +
+                              r->files[r->file_idx - 1];
+            r->pending_error = 0;
+            r->batch.reset();
+            return fail(r, EXG_E_PARSE, msg);
+        }
+        if (r->file_done) {
+            if (int jrc = r->finish_source()) return jrc;
+            if (r->file_idx >= r->files.size()) {
+                r->batch.reset();
+                *end = true;
+                return EXG_OK;
+            }
+            int rc = open_next_file(r);
+            if (rc) return rc;
+        }
+        uint64_t k;
+        int rc = next_batch(r, false, &k);
+        if (rc) return rc;
+    }
+}
+
 int ensure_device(exg_reader *r, uint64_t need_bytes) {
     if (r->d_ws && need_bytes <= r->d_in_cap) return EXG_OK;
     if (r->d_ws) {

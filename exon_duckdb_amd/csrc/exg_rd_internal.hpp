@@ -134,7 +134,13 @@ bool parse_compression(const std::string &s, Compression *out);
 Compression compression_of(const exg_open_args *args);
 
 
+struct Stripe;
+int plan_stripes(const exg_reader *r, const exg_open_args *args, std::vector<Stripe> *out, unsigned *n_workers);
+
 // ---- exg_rd_batch.cpp
 int n_string_cols(int format);
+// the next device batch with rows -> r->batch (false + *end: every file is exhausted); what exg_next_chunk and a fan-out
+// worker both do between two batches: pending parse errors, the end of a file, the next file
+int advance_batch(exg_reader *r, bool *end);
 
 }  // namespace exg_rd

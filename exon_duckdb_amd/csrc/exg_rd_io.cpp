@@ -14,6 +14,7 @@
 #include <atomic>
 #include <thread>
 
+#include "exg_rd_fanout.hpp"
 #include "exg_rd_source.hpp"
 
 namespace exg_rd {
@@ -147,6 +148,7 @@ exg_reader::exg_reader() {}
 exg_reader::~exg_reader() {
     exg_rd::DeviceGuard guard(device);
     exg_rd::MeterScope meter_scope(&meter);
+    fan.reset();  // (its workers close their readers)
     src.reset();  // (its thread reads the file through fd_keep: before the descriptor closes)
     free_device();
     if (d_res) exg_rd::dev_pool()->give(device, d_res, 4096);

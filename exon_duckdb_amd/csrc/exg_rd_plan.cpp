@@ -6,6 +6,7 @@
 
 #include <algorithm>
 
+#include "exg_rd_fanout.hpp"
 #include "exg_rd_internal.hpp"
 
 namespace exg_rd {
@@ -44,6 +45,57 @@ using namespace exg_rd;
 // MaxThreads() = *n_shards, init_local i opens shard i on devices[i]).  One shard per visible device when the input can
 // be sharded — text FASTQ / VCF / FASTA, or BGZF FASTQ / VCF (members carry their size) — and holds at least 256 MiB per
 // shard; otherwise one.  EXON_GPU_SHARDS=n forces n shards (tests: several shards on one device).
+// can a file of this format / compression be read as byte-range shards?  (text FASTQ / VCF / FASTA; BGZF FASTQ / VCF:
+// FEXTRA with a 'BC' subfield in the first member)
+static bool file_is_shardable(const std::string &f, const std::string &fmt_lower, Compression comp) {
+    if (comp == kNone) return true;
+    if (comp != kGzip || fmt_lower == "fasta") return false;
+    uint8_t h[18] = {0};
+    FILE *fp = fopen(f.c_str(), "rb");
+    const size_t got = fp ? fread(h, 1, sizeof h, fp) : 0;
+    if (fp) fclose(fp);
+    return got == 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) && h[12] == 'B' && h[13] == 'C';
+}
+
+namespace exg_rd {
+// The stripes a reader with shard_count = 0 fans out over (exg_rd_fanout.hpp): every file that can be sharded is cut into
+// stripes of about EXG_FANOUT_STRIPE_MB (1024) MiB, a multiple of the device count of them, stripe s on device s mod N; a
+// file that cannot be sharded is one stripe.  One device and nothing forced: one stripe per file — the caller then reads
+// the input itself.  EXON_GPU_SHARDS = n forces n stripes per shardable file (tests: several stripes on one device).
+int plan_stripes(const exg_reader *r, const exg_open_args *args, std::vector<Stripe> *out, unsigned *n_workers) {
+    out->clear();
+    const int n_dev = exg_device_count();
+    if (n_dev < 1) return EXG_E_NO_DEVICE;
+    std::string fmt = args->file_format;
+    for (char &ch : fmt) ch = (char)tolower((unsigned char)ch);
+    const char *forced = getenv("EXON_GPU_SHARDS");
+    const uint64_t stripe_bytes = (getenv("EXG_FANOUT_STRIPE_MB") ? std::max<uint64_t>(1, strtoull(getenv("EXG_FANOUT_STRIPE_MB"), nullptr, 10)) : 1024) << 20;
+    uint32_t next_dev = 0;
+    for (const std::string &f : r->files) {
+        struct stat st;
+        uint64_t bytes = stat(f.c_str(), &st) == 0 ? (uint64_t)st.st_size : 0;
+        uint32_t n = 1;
+        if (file_is_shardable(f, fmt, r->compression)) {
+            if (forced) n = (uint32_t)std::max(1, atoi(forced));
+            else if (n_dev > 1 && bytes >= (512ull << 20)) {
+                const uint64_t per_round = stripe_bytes * (uint64_t)n_dev;
+                n = (uint32_t)std::min<uint64_t>((bytes + per_round - 1) / per_round * (uint64_t)n_dev, 1u << 20);
+            }
+        }
+        for (uint32_t i = 0; i < n; i++) {
+            Stripe s;
+            s.path = f;
+            s.shard_index = i;
+            s.shard_count = n;
+            s.device = (int)(next_dev++ % (uint32_t)n_dev);
+            out->push_back(s);
+        }
+    }
+    *n_workers = getenv("EXG_FANOUT_WORKERS") ? (unsigned)std::max(1, atoi(getenv("EXG_FANOUT_WORKERS"))) : (unsigned)n_dev;
+    return EXG_OK;
+}
+}  // namespace exg_rd
+
 extern "C" int exg_plan_shards(const exg_open_args *args, uint32_t *n_shards, int *devices, uint32_t devices_cap) {
     if (!args || !args->path || !args->file_format || !n_shards || !devices || !devices_cap) {
         exg::set_error("exg_plan_shards: null argument");
@@ -59,18 +111,12 @@ extern "C" int exg_plan_shards(const exg_open_args *args, uint32_t *n_shards, in
     exg_reader tmp;
     if (list_files(&tmp, args->path) != EXG_OK) return EXG_OK;  // the open will report it
     uint64_t bytes = 0;
-    bool shardable = comp == kNone || (comp == kGzip && fmt != "fasta");
+    bool shardable = true;
     for (const std::string &f : tmp.files) {
         struct stat st;
         if (stat(f.c_str(), &st) != 0) continue;
         bytes += (uint64_t)st.st_size;
-        if (comp == kGzip && shardable) {  // BGZF: FEXTRA with a 'BC' subfield in the first member
-            uint8_t h[18] = {0};
-            FILE *fp = fopen(f.c_str(), "rb");
-            const size_t got = fp ? fread(h, 1, sizeof h, fp) : 0;
-            if (fp) fclose(fp);
-            shardable = got == 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) && h[12] == 'B' && h[13] == 'C';
-        }
+        shardable = shardable && file_is_shardable(f, fmt, comp);
     }
     uint32_t want = 1;
     if (const char *e = getenv("EXON_GPU_SHARDS")) {

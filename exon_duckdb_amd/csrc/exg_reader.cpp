@@ -12,7 +12,8 @@
 #include <vector>
 
 #include "exg_filter.hpp"
-#include "exg_rd_internal.hpp"
+#include "exg_rd_fanout.hpp"
+#include "exg_rd_source.hpp"
 
 using namespace exg_rd;
 
@@ -115,6 +116,65 @@ extern "C" int exg_open(const exg_open_args *args, exg_reader **out) {
         }
         r->has_filter = true;
     }
+    if (args->shard_count == 0) {
+        // several devices (or stripes forced): this reader becomes the front of a fan-out
+        std::vector<Stripe> stripes;
+        unsigned workers = 1;
+        if ((rc = plan_stripes(r.get(), args, &stripes, &workers))) return rc;
+        if (stripes.size() > r->files.size()) {
+            struct Sub : FanSub {
+                exg_reader *rd = nullptr;
+                ~Sub() override { exg_close(rd); }
+                int next(FanItem *item, std::string *err) override {
+                    DeviceGuard guard(rd->device);
+                    MeterScope meter_scope(&rd->meter);
+                    bool end = false;
+                    const int rc = advance_batch(rd, &end);
+                    if (rc) {
+                        *err = rd->error;
+                        return rc;
+                    }
+                    if (!end) {
+                        item->rows = rd->batch->n_rows;
+                        item->batch = rd->batch;  // the batch's host buffers outlive its reader
+                        rd->batch.reset();
+                    }
+                    return EXG_OK;
+                }
+                int count(uint64_t *rows, std::string *err) override {
+                    const int rc = exg_count_only(rd, rows);
+                    if (rc) *err = rd->error;
+                    return rc;
+                }
+            };
+            const std::string format = args->file_format, compression = args->compression ? args->compression : "", filters = args->filters ? args->filters : "";
+            const bool has_comp = args->compression != nullptr;
+            const uint64_t batch_rows = r->batch_rows, dbb = args->device_batch_bytes;
+            FanOpen open = [=](const Stripe &s, std::unique_ptr<FanSub> *sub, std::string *err) -> int {
+                exg_open_args a;
+                memset(&a, 0, sizeof a);
+                a.path = s.path.c_str();
+                a.file_format = format.c_str();
+                a.compression = has_comp ? compression.c_str() : nullptr;
+                a.batch_rows = batch_rows;
+                a.device = s.device;
+                a.device_batch_bytes = dbb;
+                a.filters = filters.empty() ? nullptr : filters.c_str();
+                a.shard_index = s.shard_index;
+                a.shard_count = s.shard_count;
+                if (a.shard_count < 1) a.shard_count = 1;
+                std::unique_ptr<Sub> x(new Sub());
+                const int orc = exg_open(&a, &x->rd);
+                if (orc) {
+                    *err = exg_last_error_message();
+                    return orc;
+                }
+                *sub = std::move(x);
+                return EXG_OK;
+            };
+            r->fan.reset(new FanOut(std::move(stripes), workers, std::move(open), 2));
+        }
+    }
     *out = r.release();
     return EXG_OK;
 }
@@ -152,6 +212,7 @@ extern "C" int exg_schema_of(exg_reader *r, exg_schema *out) {
         int rc = nested_prepare(r);  // the INFO / FORMAT keys of the first file's header are part of the schema
         if (rc) return rc;
         nested_schema(r, out);
+        if (r->fan) r->src.reset();  // (the front of a fan-out only needed the header: its decoder stops)
     }
     return EXG_OK;
 }
@@ -225,26 +286,25 @@ extern "C" int exg_next_chunk(exg_reader *r, exg_chunk *out) {
             r->batch_row += n;
             return EXG_OK;
         }
-        if (r->pending_error) {
-            // rows before the failing record have been handed out; now surface the error
-            std::string msg = std::string(exg_parse_error_string(r->pending_error)) + " at byte " +
-                              std::to_string(r->pending_error_offset) + " of " + r->files[r->file_idx - 1];
-            r->pending_error = 0;
-            r->batch.reset();
-            return fail(r, EXG_E_PARSE, msg);
-        }
-        if (r->file_done) {
-            if (int jrc = r->finish_source()) return jrc;
-            if (r->file_idx >= r->files.size()) {
+        if (r->fan) {
+            // the batches of the stripes' readers, in file order
+            FanItem item;
+            std::string msg;
+            const int rc = r->fan->next(&item, &msg);
+            if (rc) return fail(r, rc, msg);
+            if (!item.batch) {
                 r->batch.reset();
                 return EXG_OK;  // n_rows == 0: end of stream
             }
-            int rc = open_next_file(r);
-            if (rc) return rc;
+            r->batch = std::static_pointer_cast<Batch>(item.batch);
+            r->batch->seq = r->batch_seq++;
+            r->batch_row = 0;
+            continue;
         }
-        uint64_t k;
-        int rc = next_batch(r, false, &k);
+        bool end = false;
+        const int rc = advance_batch(r, &end);
         if (rc) return rc;
+        if (end) return EXG_OK;  // n_rows == 0: end of stream
     }
 }
 
@@ -259,6 +319,11 @@ extern "C" int exg_count_only(exg_reader *r, uint64_t *n_rows) {
     if (!r || !n_rows) return EXG_E_INVALID_ARG;
     DeviceGuard guard(r->device);
     MeterScope meter_scope(&r->meter);
+    if (r->fan) {
+        std::string msg;
+        const int rc = r->fan->count(n_rows, &msg);
+        return rc ? fail(r, rc, msg) : EXG_OK;
+    }
     uint64_t total = 0;
     for (;;) {
         if (r->pending_error) {

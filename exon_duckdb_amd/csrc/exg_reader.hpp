@@ -15,6 +15,7 @@
 
 namespace exg_rd {
 class DecodedSource;
+class FanOut;
 
 // HIP's current device is per host thread: every entry point that touches a reader runs with the reader's device
 // current (the consumer may call from any thread — DuckDB binds on one thread and scans on others — and a process may
@@ -409,6 +410,9 @@ struct exg_reader {
     // gzip / zstd input: the decoded bytes arrive as a bounded stream of segments in HBM and are scanned in place
     // (exg_rd_source.hpp); positions (file_pos, range_hi, ...) are offsets in the DECODED stream
     std::unique_ptr<exg_rd::DecodedSource> src;
+    // shard_count = 0 on a box with several devices: the input is read as stripes by readers of their own on all devices and
+    // handed out here in file order (exg_rd_fanout.hpp); this reader then only slices the batches into chunks
+    std::unique_ptr<exg_rd::FanOut> fan;
     exg_rd::MemMeter meter;      // device bytes held on behalf of this reader
     uint64_t mem_cap = 0;        // EXG_DEVICE_MEM_CAP_MB: what the batch / segment sizes are derived from (0: defaults)
     uint64_t n_segments = 0;     // decoded segments consumed so far

@@ -307,3 +307,34 @@ def test_filter_on_nested_column_is_refused(nr, golden_dir):
     from exon_duckdb_amd import ExgError
     with pytest.raises(ExgError, match="could not execute sql"):
         nr(G(golden_dir, "vcf/index.vcf"), "vcf", filters="alt='A'")
+
+
+# ---- several devices behind the reference's FFI: the stream fans out by itself (exg_rd_fanout.hpp) ------------------------
+
+@pytest.mark.parametrize("workers", [1, 4])
+def test_new_reader_fans_out_over_stripes(nr, oracle, tmp_path, monkeypatch, workers):
+    """`new_reader` has no shard argument (rust.hpp:41-46) and the reference's glue pulls the stream from one thread
+    (module.cpp:36): the stream cuts the input into stripes itself — forced here: 6 stripes on the one device of the test
+    box — reads them through streams of their own on worker threads and hands their record batches out in file order.  The
+    rows are those of the unsharded stream, nested VCF columns and a pushed-down filter included."""
+    fq = bytes(oracle.synth_fastq_ragged(20000))
+    vcf = bytes(oracle.synth_vcf(12000))
+    (tmp_path / "r.fastq").write_bytes(fq)
+    (tmp_path / "s.vcf").write_bytes(vcf)
+    exp_fq = fastq_rows(oracle, fq)
+    exp_vcf, err = oracle.vcf_typed_rows(vcf)
+    assert err is None
+    monkeypatch.setenv("EXON_GPU_SHARDS", "6")
+    monkeypatch.setenv("EXG_FANOUT_WORKERS", str(workers))
+    monkeypatch.setenv("EXG_DEVICE_BATCH_BYTES", str(256 << 10))
+    rows = []
+    for b in nr(str(tmp_path / "r.fastq"), "fastq", batch_size=512):
+        assert b.num_rows <= 512
+        rows.extend(b.to_pylist())
+    assert rows == exp_fq
+    rows = []
+    for b in nr(str(tmp_path / "s.vcf"), "vcf", batch_size=1024):
+        rows.extend(b.to_pylist())
+    assert len(rows) == 12000 and all(same(g, e) for g, e in zip(rows, exp_vcf))
+    rows = nr(str(tmp_path / "r.fastq"), "fastq", filters="sequence < 'C'").read_all().to_pylist()
+    assert rows == [r for r in exp_fq if r["sequence"] < "C"] and rows

@@ -319,3 +319,72 @@ def test_rccl_initialises_and_reduces_on_this_image(gpu):
         "dist.destroy_process_group(); print('rccl ok')\n") % _free_port()
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ))
     assert res.returncode == 0 and "rccl ok" in res.stdout, res.stdout[-1000:] + res.stderr[-3000:]
+
+
+# ---- shard_count = 0: one consumer-facing stream that fans out over stripes by itself (exg_rd_fanout.hpp) ---------------
+
+def _auto(path, fmt, **kw):
+    from exon_duckdb_amd.reader import ShardReader
+    r = ShardReader(path, fmt, shard_count=0, **kw)
+    rows = r.rows()
+    r.close()
+    c = ShardReader(path, fmt, shard_count=0, **kw)
+    n = c.count()
+    c.close()
+    assert n == len(rows)
+    return rows
+
+
+@pytest.mark.parametrize("workers", [1, 3, 8])
+def test_fan_out_inside_one_reader(gpu, oracle, tmp_path, monkeypatch, workers):
+    """exg_open with shard_count = 0 plans stripes (forced here: EXON_GPU_SHARDS stripes on the one device of the test box,
+    EXG_FANOUT_WORKERS threads — on an 8-GPU node: a multiple of 8 stripes of ~1 GiB, one worker and one device each) and
+    hands their batches out in file order: the rows of the unsharded scan, for every format the shards support, with small
+    device batches so that every stripe holds several; COUNT(*) sums the stripes."""
+    fq = bytes(oracle.synth_fastq_ragged(30000))
+    vcf = bytes(oracle.synth_vcf(20000))
+    fa = bytes(oracle.synth_fasta(3000, seed=77))
+    files = {"p.fastq": (fq, "fastq"), "p.vcf": (vcf, "vcf"), "p.fasta": (fa, "fasta"), "b.fastq.gz": (_bgzf(fq, 20000), "fastq"),
+             "b.vcf.gz": (_bgzf(vcf), "vcf")}
+    want = {}
+    for name, (blob, fmt) in files.items():
+        (tmp_path / name).write_bytes(blob)
+        want[name] = whole(str(tmp_path / name), fmt)
+    monkeypatch.setenv("EXON_GPU_SHARDS", "7")
+    monkeypatch.setenv("EXG_FANOUT_WORKERS", str(workers))
+    monkeypatch.setenv("EXG_DEVICE_BATCH_BYTES", str(256 << 10))
+    for name, (blob, fmt) in files.items():
+        assert _auto(str(tmp_path / name), fmt) == want[name], name
+    # a pushed-down filter runs in every stripe
+    got = _auto(str(tmp_path / "p.vcf"), "vcf", filters="chrom='7'")
+    assert got == [r for r in want["p.vcf"] if r[0] == b"7"] and got
+    # an input that cannot be sharded (plain gzip) is simply read by the reader itself
+    import gzip
+    (tmp_path / "one.fastq.gz").write_bytes(gzip.compress(fq, 1, mtime=0))
+    assert _auto(str(tmp_path / "one.fastq.gz"), "fastq") == want["p.fastq"]
+
+
+def test_fan_out_reports_a_parse_error_behind_the_rows_in_front_of_it(gpu, oracle, tmp_path, monkeypatch):
+    from exon_duckdb_amd._lib import ExgError
+    from exon_duckdb_amd.reader import ShardReader
+    from exon_duckdb_amd.table_function import Chunk
+    import ctypes as C
+    fq = bytearray(oracle.synth_fastq(332 * 20000))
+    fq[332 * 15000] = ord("X")                      # record 15000 does not start with '@'
+    p = tmp_path / "bad.fastq"
+    p.write_bytes(bytes(fq))
+    monkeypatch.setenv("EXON_GPU_SHARDS", "5")
+    monkeypatch.setenv("EXG_FANOUT_WORKERS", "3")
+    r = ShardReader(str(p), "fastq", shard_count=0)
+    seen, rc = 0, 0
+    while True:
+        ch = Chunk()
+        rc = r._l.exg_next_chunk(r._r, C.byref(ch))
+        if rc != 0 or ch.n_rows == 0:
+            break
+        seen += int(ch.n_rows)
+        r._l.exg_release_chunk(r._r, C.byref(ch))
+    assert rc != 0 and seen == 15000
+    r.close()
+    with pytest.raises(ExgError):
+        ShardReader(str(p), "fastq", shard_count=0).count()
