@@ -10,8 +10,11 @@
 //   exon/src/exon/arrow_table_function/module.cpp   (Register / FileTypeBind / InitGlobal / Scan / ReplacementScan)
 //   exon/src/exon_extension.cpp:47-58,79            (registrations of the three formats + replacement scan)
 // Build (out-of-tree extension, like the reference's CMakeLists.txt:131-146, minus Rust/Corrosion):
-//   c++ -std=c++17 -fPIC -shared -DDUCKDB_BUILD_LOADABLE_EXTENSION -I<duckdb>/src/include -I../include \
+//   c++ -std=c++17 -fPIC -shared -DDUCKDB_BUILD_LOADABLE_EXTENSION -I<duckdb>/src/include -I../include
 //       -I../exon_duckdb_amd/csrc exon_extension.cpp -L../exon_duckdb_amd/lib -lexon_gpu -o exon.duckdb_extension
+// tests/test_host_logic.py puts this file through `c++ -fsyntax-only` against declaration-only stand-ins of the ten DuckDB
+// headers it includes (tests/duckdb_stub/: signatures as in v0.8.1): every template instantiation of the glue over DuckDB's
+// types is compiled on the build box.
 #define DUCKDB_EXTENSION_MAIN
 #include "duckdb.hpp"
 #include "duckdb/common/types/vector_buffer.hpp"

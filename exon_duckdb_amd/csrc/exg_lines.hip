@@ -289,3 +289,46 @@ extern "C" int exg_fastq_guess_phase(const void *d_input, uint64_t n_bytes, uint
     EXG_HIP_CHECK(hipGetLastError());
     return EXG_OK;
 }
+
+// ---- exg_fasta_find_record --------------------------------------------------------------------------------------
+// The first FASTA record start — a '>' at the beginning of a line — at an offset in [begin, end) of d_bytes: what a shard of
+// a compressed FASTA needs at both of its ends (a record belongs to the shard in whose bytes its '>' line begins; in text
+// files the host finds it with memchr over the mapping).  The byte in front of `begin` is looked at (begin = 0: at_bof says
+// whether d_bytes[0] is the file's first byte, i.e. a line start).
+namespace exg {
+__global__ __launch_bounds__(256) void k_fasta_find_record(const uint8_t *__restrict__ d, uint64_t begin, uint64_t end, uint32_t at_bof,
+                                                           unsigned long long *d_pos) {
+    // a thread per 16 bytes (plain byte loads: any alignment); the lowest hit wins
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * 16;
+    for (uint64_t p0 = begin + ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; p0 < end; p0 += stride) {
+        if (p0 >= *(volatile unsigned long long *)d_pos) return;  // someone in front of this thread has found one already
+        const uint64_t p1 = p0 + 16 < end ? p0 + 16 : end;
+        uint8_t prev = p0 ? d[p0 - 1] : (uint8_t)(at_bof ? '\n' : 0);
+        for (uint64_t p = p0; p < p1; p++) {
+            const uint8_t c = d[p];
+            if (c == '>' && prev == '\n') {
+                atomicMin(d_pos, (unsigned long long)p);
+                return;
+            }
+            prev = c;
+        }
+    }
+}
+}  // namespace exg
+
+extern "C" int exg_fasta_find_record(const void *d_bytes, uint64_t begin, uint64_t end, int at_bof, uint64_t *d_pos, void *stream) {
+    if (!d_bytes || !d_pos || begin > end) {
+        exg::set_error("exg_fasta_find_record: bad arguments");
+        return EXG_E_INVALID_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    EXG_HIP_CHECK(hipMemsetAsync(d_pos, 0xFF, 8, s));
+    if (end > begin) {
+        const uint64_t threads = (end - begin + 15) / 16;
+        const uint64_t blocks = std::min<uint64_t>((threads + 255) / 256, 4096);
+        hipLaunchKernelGGL(exg::k_fasta_find_record, dim3((uint32_t)blocks), dim3(256), 0, s, (const uint8_t *)d_bytes, begin, end,
+                           at_bof ? 1u : 0u, (unsigned long long *)d_pos);
+        EXG_HIP_CHECK(hipGetLastError());
+    }
+    return EXG_OK;
+}

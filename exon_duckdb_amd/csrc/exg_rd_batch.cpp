@@ -65,6 +65,34 @@ static int source_header_prefix(exg_reader *r, DecodedSource *src, PinnedBlock &
     }
 }
 
+// The first FASTA record start ('>' at the beginning of a line) of a decoded stream at or behind `from` (~0: none before the
+// stream ends).  Everything from `from` on stays resident: the record that begins there is the next batch.
+static int source_find_record(exg_reader *r, uint64_t from, uint64_t *found) {
+    *found = ~0ull;
+    if (!r->d_phase && !(r->d_phase = dev_pool()->take(r->device, 4096))) return fail(r, EXG_E_HIP, "out of device memory");
+    const uint64_t base = from ? from - 1 : 0;  // (the byte in front says whether `from` begins a line)
+    for (uint64_t want = r->device_batch_bytes;; want *= 2) {
+        const uint8_t *d_at = nullptr;
+        uint64_t avail = 0;
+        bool eof = false;
+        std::string msg;
+        int rc = r->src->acquire(base, want, &d_at, &avail, &eof, &msg);
+        if (rc) return fail(r, rc, msg);
+        if (base + avail > from) {
+            unsigned long long pos = ~0ull;
+            rc = exg_fasta_find_record(d_at, from - base, avail, base == 0 && r->data0_is_line_start, (uint64_t *)r->d_phase, r->stream);
+            if (rc) return fail(r, rc, exg_last_error_message());
+            RD_HIP(r, hipMemcpyAsync(&pos, r->d_phase, 8, hipMemcpyDeviceToHost, r->stream));
+            RD_HIP(r, hipStreamSynchronize(r->stream));
+            if (pos != ~0ull) {
+                *found = base + pos;
+                return EXG_OK;
+            }
+        }
+        if (eof || avail < want) return EXG_OK;
+    }
+}
+
 // Shard `shard_index` of `shard_count` of a BGZF file: a member belongs to the shard in whose 1/shard_count of the FILE's
 // bytes its header begins.  The reader finds its members without indexing the file (a search for a header whose chain holds
 // near each cut: the pointer chase over a whole file costs 110 ms per 10 GB and every rank would pay it) and streams
@@ -142,18 +170,20 @@ static int open_source(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const s
     auto out_blk = std::make_shared<PinnedBlock>();  // (n = 0: the decoded size is not known; p: the VCF header prefix)
     r->gz_header_prefix = 0;
     const size_t queued = getenv("EXG_SOURCE_QUEUE") ? (size_t)std::max(1, atoi(getenv("EXG_SOURCE_QUEUE"))) : r->mem_cap ? 1 : 2;
-    auto make = [&](uint64_t c_begin, uint64_t c_end, bool bgzf_only) {
-        std::unique_ptr<SegmentProducer> prod = r->compression == kGzip ? make_gzip_producer(r, fd, c_begin, c_end, target, path, bgzf_only, reserve)
-                                                                        : make_zstd_producer(r, fd, n, target, path, reserve);
+    auto make = [&](uint64_t c_begin, uint64_t c_end, bool bgzf_only, const uint64_t *marks) {
+        std::unique_ptr<SegmentProducer> prod = r->compression == kGzip ? make_gzip_producer(r, fd, c_begin, c_end, target, path, bgzf_only, reserve, marks)
+                                                                        : make_zstd_producer(r, fd, n, c_begin, c_end, target, path, reserve, marks);
         return std::unique_ptr<DecodedSource>(new DecodedSource(r->device, r->stream, std::move(prod), reserve, queued, &r->meter));
     };
     if (r->compression == kGzip && n == 0) return fail(r, EXG_E_PARSE, "empty gzip file '" + path + "'");
+    r->fa_shard = false;
+    r->fa_end = ~0ull;
     if (r->shard_count > 1) {
         // VCF: every rank needs the header (schema, and where the data begins): read from the start of the file by a
         // source of its own, kept on the host like in the unsharded case
         uint64_t header_bytes = 0;
         if (r->format == EXG_FMT_VCF) {
-            std::unique_ptr<DecodedSource> head = make(0, n, true);
+            std::unique_ptr<DecodedSource> head = make(0, n, r->compression == kGzip, nullptr);
             int rc = source_header_prefix(r, head.get(), *out_blk);
             if (rc) return rc;
             const char *d = (const char *)out_blk->p;
@@ -164,12 +194,77 @@ static int open_source(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const s
             }
             header_bytes = pos;
         }
-        uint64_t c_begin = 0, c_end = n;
-        int rc = plan_bgzf_shard(r, path, n, &c_begin, &c_end, header_bytes);
-        if (rc) return rc;
-        r->src = make(c_begin, c_end, true);
+        const bool fasta = r->format == EXG_FMT_FASTA;
+        uint64_t c_begin = 0, c_end = n, marks[2] = {~0ull, ~0ull};
+        bool wait_own = false;  // where the shard's own bytes begin is told by the decoder (mark 0)
+        if (r->compression == kGzip && !fasta) {
+            int rc = plan_bgzf_shard(r, path, n, &c_begin, &c_end, header_bytes);
+            if (rc) return rc;
+        } else if (r->compression == kGzip) {
+            // bgzip FASTA: a record belongs to the shard in whose members' bytes its '>' line begins.  The stream starts one
+            // member in front of the shard's own (is their first byte a line start?) and runs on behind them until the next
+            // record start is found
+            Peek peek(nullptr, fd, n);
+            exg_inflate_member probe;
+            if (!bgzf_member_at(peek, 0, &probe))
+                return fail(r, EXG_E_UNSUPPORTED, "shards of a gzip input need BGZF framing (every member carries its size): '" + path + "'");
+            const uint64_t lo = (uint64_t)((unsigned __int128)n * r->shard_index / r->shard_count);
+            const uint64_t hi = r->shard_index + 1 == r->shard_count ? n : (uint64_t)((unsigned __int128)n * (r->shard_index + 1) / r->shard_count);
+            const uint64_t own_lo = lo == 0 ? 0 : bgzf_find(nullptr, fd, n, lo);
+            const uint64_t own_hi = hi >= n ? n : std::max<uint64_t>(own_lo, bgzf_find(nullptr, fd, n, hi));
+            c_begin = own_lo;
+            for (uint64_t pos = own_lo == 0 ? 0 : bgzf_find(nullptr, fd, n, own_lo > (192u << 10) ? own_lo - (192u << 10) : 0); pos < own_lo;) {
+                exg_inflate_member m;
+                const uint64_t nx = bgzf_member_at(peek, pos, &m);
+                if (!nx) return fail(r, EXG_E_PARSE, "not a BGZF member at byte " + std::to_string(pos) + " of '" + path + "'");
+                c_begin = pos;  // (the last member in front of the shard's own)
+                pos = nx;
+            }
+            marks[0] = own_lo;
+            marks[1] = own_hi >= n ? ~0ull : own_hi;
+            wait_own = true;
+        } else {
+            uint64_t own_lo = 0, own_hi = n;
+            bool bytes_follow = false;
+            int rc = plan_zstd_shard(r, fd, n, path, fasta ? 1 : r->halo_want, header_bytes, &c_begin, &c_end, &own_lo, &own_hi, &bytes_follow);
+            if (rc) return rc;
+            marks[0] = own_lo;
+            if (fasta) {
+                c_end = n;
+                marks[1] = own_hi >= n ? ~0ull : own_hi;
+            }
+            r->range_eof = !bytes_follow;
+            wait_own = true;
+        }
+        r->src = make(c_begin, c_end, true, marks);
+        if (wait_own) {
+            // The decoder tells where the shard's own bytes begin (mark 0) when it gets there; until then the halo's segments
+            // are taken one by one — never a blocking wait for the mark: the decoder cannot run further ahead than its queue
+            uint64_t own = 0;
+            for (uint64_t want = 1; !r->src->peek_mark(0, &own);) {
+                const uint8_t *d_at = nullptr;
+                uint64_t avail = 0;
+                bool eof = false;
+                std::string msg;
+                int rc = r->src->acquire(0, want, &d_at, &avail, &eof, &msg);
+                if (rc) return fail(r, rc, msg);
+                if (r->src->peek_mark(0, &own)) break;
+                if (eof) {
+                    own = ~0ull >> 1;  // (behind everything: the stream holds nothing of this shard's)
+                    break;
+                }
+                want = avail + 1;  // one segment more
+            }
+            r->range_preset = true;
+            r->preset_pos = own;
+            r->data0_is_line_start = c_begin == 0;
+        }
+        if (fasta) {
+            r->fa_shard = true;
+            r->range_eof = true;  // (a shard of a FASTA is a FASTA file of its own)
+        }
     } else {
-        r->src = make(0, n, false);
+        r->src = make(0, n, false, nullptr);
         if (r->format == EXG_FMT_VCF) {
             int rc = source_header_prefix(r, r->src.get(), *out_blk);
             if (rc) return rc;
@@ -245,7 +340,20 @@ int open_next_file(exg_reader *r) {
     r->range_hi = r->src ? ~0ull : blk->n;  // (a decoded stream ends where its source says so)
     r->shard_first = false;
     r->data_base = r->file_pos;  // 0, or the end of the VCF header
-    if (r->range_preset) {  // BGZF shard: the members were chosen in plan_bgzf_shard
+    if (r->fa_shard) {
+        // a shard of a compressed FASTA: the run of whole records from the first '>' line that begins in its own bytes to the
+        // first that begins behind them (found while scanning: next_batch), like a text shard's run
+        r->shard_first = false;
+        if (r->preset_pos == 0 && r->data0_is_line_start) {
+            r->file_pos = 0;
+        } else {
+            uint64_t at = ~0ull;
+            int rc = source_find_record(r, r->preset_pos, &at);
+            if (rc) return rc;
+            if (at == ~0ull) r->file_done = true;  // no record begins in this shard's bytes (or behind them)
+            else r->file_pos = at;
+        }
+    } else if (r->range_preset) {  // BGZF / zstd shard: the members / frames were chosen in open_source
         // its stream begins with the file (header and all) or somewhere behind the header
         r->data_base = r->data0_is_line_start ? r->data_base : 0;
         r->file_pos = std::max<uint64_t>(r->preset_pos, r->data_base);
@@ -384,6 +492,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
     *n_records_out = 0;
     r->batch.reset();
     r->batch_row = 0;
+    if (r->file_done) return EXG_OK;  // (opening the file found nothing of this shard's in it)
     uint64_t want = r->device_batch_bytes;
     double t_batch = now_s();
     for (;;) {
@@ -425,6 +534,32 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             n = avail - shard_halo;
             range_end = src_eof;
             eof = range_end && r->range_eof;
+            if (r->fa_shard) {
+                // where does the first record begin that is NOT this shard's?  (mark 1: the decoded offset behind its own
+                // members / frames — while it is not set, nothing handed out so far lies behind it)
+                uint64_t own_end = 0;
+                if (r->fa_end == ~0ull && r->src->peek_mark(1, &own_end)) {
+                    if (own_end <= r->file_pos) {
+                        r->fa_end = r->file_pos;
+                    } else if (own_end < src_pos + avail) {
+                        unsigned long long pos = ~0ull;
+                        if (!r->d_phase && !(r->d_phase = dev_pool()->take(r->device, 4096))) return fail(r, EXG_E_HIP, "out of device memory");
+                        arc = exg_fasta_find_record(src_at, own_end - src_pos, avail, 0, (uint64_t *)r->d_phase, r->stream);
+                        if (arc) return fail(r, arc, exg_last_error_message());
+                        RD_HIP(r, hipMemcpyAsync(&pos, r->d_phase, 8, hipMemcpyDeviceToHost, r->stream));
+                        RD_HIP(r, hipStreamSynchronize(r->stream));
+                        if (pos != ~0ull) r->fa_end = src_pos + pos;
+                    }
+                }
+                if (r->fa_end != ~0ull) {
+                    if (r->fa_end <= r->file_pos) {
+                        r->file_done = true;
+                        return EXG_OK;
+                    }
+                    n = r->fa_end - r->file_pos;
+                    range_end = eof = true;
+                }
+            }
         }
         int rc = ensure_device(r, n + shard_halo + 16);
         if (rc) return rc;

@@ -90,6 +90,7 @@ public:
     }
     int run(SegmentSink &sink, std::string *err) override;
     void set_reserve(uint64_t r) { reserve_ = (r + 15) & ~15ull; }
+    void set_marks(const uint64_t m[2]) { mark_at_[0] = m[0], mark_at_[1] = m[1]; }
 
 private:
     struct Lane {
@@ -123,6 +124,12 @@ private:
     uint64_t n_members_ = 0;   // members seen so far (error messages)
     double ratio_ = 3.0;       // inflated / compressed, running estimate (sizes the next window)
     bool pushed_last_ = false;
+    uint64_t mark_at_[2] = {~0ull, ~0ull};  // member offsets whose decoded positions the reader wants to know (a shard's boundaries)
+    bool marked_[2] = {false, false};
+    void marks(SegmentSink &sink) {  // (c_pos_ / d_pos_: the next member to be decoded and where its bytes will lie)
+        for (int i = 0; i < 2; i++)
+            if (!marked_[i] && mark_at_[i] != ~0ull && c_pos_ >= mark_at_[i]) sink.set_mark(i, d_pos_), marked_[i] = true;
+    }
     std::vector<std::unique_ptr<Lane>> lanes_;
 };
 
@@ -205,6 +212,7 @@ int GzipProducer::crc_of(const void *d, uint64_t n, hipStream_t st, uint32_t *cr
 int GzipProducer::bgzf_issue(SegmentSink &sink, Lane &l, bool *not_bgzf, std::string *err) {
     *not_bgzf = false;
     l.k = 0;
+    marks(sink);
     const uint64_t a0 = c_pos_ & ~15ull;
     // compressed bytes that should inflate to about one segment (+ a member's worth, so that a window never ends short)
     uint64_t want = (uint64_t)((double)target_ / std::max(1.0, ratio_) * 1.05) + (128u << 10);
@@ -231,6 +239,7 @@ int GzipProducer::bgzf_issue(SegmentSink &sink, Lane &l, bool *not_bgzf, std::st
         const uint64_t nx = bgzf_member_at(pk, rel, &m, &crc);
         if (!nx) break;
         if (!mem.empty() && out + m.out_cap > limit) break;
+        if (!mem.empty() && (a0 + rel == mark_at_[0] || a0 + rel == mark_at_[1])) break;  // a segment begins at every mark
         m.out_off = out;
         out += m.out_cap;
         mem.push_back(m);
@@ -591,6 +600,7 @@ int GzipProducer::big_member(SegmentSink &sink, uint64_t stream_off, std::string
 
 int GzipProducer::run(SegmentSink &sink, std::string *err) {
     while (c_pos_ < c_end_ && !sink.cancelled()) {
+        marks(sink);
         // what kind of member begins here?  (BGZF: FEXTRA with a 'BC' subfield that states the member's size)
         Peek pk(nullptr, fd_, c_end_);
         exg_inflate_member m;
@@ -612,6 +622,7 @@ int GzipProducer::run(SegmentSink &sink, std::string *err) {
         }
         if (rc) return rc;
     }
+    marks(sink);
     if (!pushed_last_ && !sink.cancelled()) {  // an empty range (a shard without members): the stream still ends
         Segment seg;
         int rc = new_segment(sink, 0, &seg, err);
@@ -637,9 +648,10 @@ int GzipProducer::run(SegmentSink &sink, std::string *err) {
 }  // namespace
 
 std::unique_ptr<SegmentProducer> make_gzip_producer(exg_reader *r, int fd, uint64_t c_begin, uint64_t c_end, uint64_t target, const std::string &path,
-                                                    bool bgzf_only, uint64_t reserve) {
+                                                    bool bgzf_only, uint64_t reserve, const uint64_t mark_at[2]) {
     std::unique_ptr<GzipProducer> p(new GzipProducer(r, fd, c_begin, c_end, target, path, bgzf_only));
     p->set_reserve(reserve);
+    if (mark_at) p->set_marks(mark_at);
     return std::unique_ptr<SegmentProducer>(p.release());
 }
 

@@ -1,13 +1,17 @@
 // exg_rd_plan.cpp — host only: which decoder an input needs (rust/src/arrow_reader.rs:60-91), how many byte-range shards
 // a scan is worth and where they run (in-process form), and the reference's `replacement_scan`
 // (rust/src/arrow_reader.rs:173-197).
+#include <fcntl.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 
 #include "exg_rd_fanout.hpp"
 #include "exg_rd_internal.hpp"
+#include "exg_zstd.hpp"
 
 namespace exg_rd {
 
@@ -45,11 +49,30 @@ using namespace exg_rd;
 // MaxThreads() = *n_shards, init_local i opens shard i on devices[i]).  One shard per visible device when the input can
 // be sharded — text FASTQ / VCF / FASTA, or BGZF FASTQ / VCF (members carry their size) — and holds at least 256 MiB per
 // shard; otherwise one.  EXON_GPU_SHARDS=n forces n shards (tests: several shards on one device).
-// can a file of this format / compression be read as byte-range shards?  (text FASTQ / VCF / FASTA; BGZF FASTQ / VCF:
-// FEXTRA with a 'BC' subfield in the first member)
+// can a file of this format / compression be read as byte-range shards?  (text; BGZF — FEXTRA with a 'BC' subfield in the
+// first member — by members; zstd with several frames by frames)
 static bool file_is_shardable(const std::string &f, const std::string &fmt_lower, Compression comp) {
+    (void)fmt_lower;
     if (comp == kNone) return true;
-    if (comp != kGzip || fmt_lower == "fasta") return false;
+    if (comp == kZstd) {
+        // by frames: worth it when the file has several (pzstd, the seekable format; the zstd CLI writes one) — the walk over
+        // the frame / block headers touches a few bytes per block of the mapping (2 ms per GB)
+        int fd = open(f.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        bool many = false;
+        if (fstat(fd, &st) == 0 && st.st_size > 0) {
+            void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) {
+                exg::zst::Index idx;
+                many = exg::zst::build_index((const uint8_t *)m, (uint64_t)st.st_size, idx) && idx.frames.size() > 1;
+                munmap(m, (size_t)st.st_size);
+            }
+        }
+        close(fd);
+        return many;
+    }
+    if (comp != kGzip) return false;
     uint8_t h[18] = {0};
     FILE *fp = fopen(f.c_str(), "rb");
     const size_t got = fp ? fread(h, 1, sizeof h, fp) : 0;

@@ -14,6 +14,13 @@ void *SegmentSink::take(size_t bytes) { return dev_pool()->take(src->device_, by
 void SegmentSink::give(void *p, size_t bytes) {
     if (p) dev_pool()->give(src->device_, p, bytes ? bytes : 16);
 }
+void SegmentSink::set_mark(int id, uint64_t pos) {
+    std::lock_guard<std::mutex> g(src->mu_);
+    if (id < 0 || id > 1) return;
+    src->mark_[id] = pos;
+    src->mark_set_[id] = true;
+    src->cv_.notify_all();
+}
 bool SegmentSink::push(Segment &&s) {
     std::unique_lock<std::mutex> lk(src->mu_);
     src->cv_.wait(lk, [&] { return src->queue_.size() < src->max_queued_ || src->closed_; });
@@ -91,6 +98,12 @@ int DecodedSource::pop(Segment *out, std::string *err) {
         return rc_;
     }
     return EXG_OK;
+}
+
+bool DecodedSource::peek_mark(int id, uint64_t *pos) {
+    std::lock_guard<std::mutex> g(mu_);
+    if (mark_set_[id]) *pos = mark_[id];
+    return mark_set_[id];
 }
 
 int DecodedSource::finish(std::string *err) {

@@ -47,6 +47,10 @@ struct SegmentSink {
     // a pooled device block (nullptr: out of device memory) / back to the pool
     void *take(size_t bytes);
     void give(void *p, size_t bytes);
+    // a shard's decoder tells where, in decoded bytes, a boundary of its compressed input lies: mark 0 = the first byte of
+    // the shard's own members / frames (what is in front is the halo), mark 1 = the first byte behind them (a FASTA shard
+    // reads on to the next record start).  Set BEFORE the segment that begins there is pushed.
+    void set_mark(int id, uint64_t pos);
 };
 
 struct SegmentProducer {
@@ -73,6 +77,9 @@ public:
     int acquire(uint64_t pos, uint64_t want, const uint8_t **d_pos, uint64_t *avail, bool *eof, std::string *err);
     // waits for the producer to end and returns its result (a checksum that is verified behind the last segment)
     int finish(std::string *err);
+    // a mark of the producer, if it has been set (never a blocking wait: the producer cannot run further ahead of the
+    // consumer than its queue allows) — while mark 1 is not set, every segment handed out so far ends at or in front of it
+    bool peek_mark(int id, uint64_t *pos);
     uint64_t reserve() const { return reserve_; }
     uint64_t segments_consumed() const { return n_consumed_; }
 
@@ -94,6 +101,8 @@ private:
     bool done_ = false, closed_ = false;
     int rc_ = 0;
     std::string err_;
+    uint64_t mark_[2] = {0, 0};
+    bool mark_set_[2] = {false, false};
     Segment cur_;
     bool have_cur_ = false;
     uint64_t n_consumed_ = 0;
@@ -102,9 +111,15 @@ private:
 // exg_rd_gzip.cpp: file bytes [c_begin, c_end) of fd are gzip members (BGZF or not, any mixture); `target` = decoded bytes per
 // segment.  bgzf_only: a member without the BGZF size field is an error (shards of a BGZF file).
 // reserve: bytes of room every segment leaves in front of its first byte (DecodedSource's `reserve`)
+// mark_at[i] (a member's offset, ~0: none): sink.set_mark(i, decoded offset of that member's first byte)
 std::unique_ptr<SegmentProducer> make_gzip_producer(exg_reader *r, int fd, uint64_t c_begin, uint64_t c_end, uint64_t target, const std::string &path,
-                                                    bool bgzf_only, uint64_t reserve);
-// exg_rd_zstd.cpp: zstd frames of file bytes [0, n) of fd
-std::unique_ptr<SegmentProducer> make_zstd_producer(exg_reader *r, int fd, uint64_t n, uint64_t target, const std::string &path, uint64_t reserve);
+                                                    bool bgzf_only, uint64_t reserve, const uint64_t mark_at[2] = nullptr);
+// exg_rd_zstd.cpp: the zstd frames of file bytes [0, n) of fd whose first byte lies in [c_begin, c_end) (the whole file: 0, n);
+// mark_at[i]: a frame's offset (~0: none)
+std::unique_ptr<SegmentProducer> make_zstd_producer(exg_reader *r, int fd, uint64_t n, uint64_t c_begin, uint64_t c_end, uint64_t target,
+                                                    const std::string &path, uint64_t reserve, const uint64_t mark_at[2] = nullptr);
+
+int plan_zstd_shard(exg_reader *r, int fd, uint64_t n, const std::string &path, uint64_t halo_want, uint64_t header_bytes, uint64_t *c_begin,
+                    uint64_t *c_end, uint64_t *own_lo, uint64_t *own_hi, bool *bytes_follow);
 
 }  // namespace exg_rd

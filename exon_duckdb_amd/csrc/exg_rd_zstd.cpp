@@ -26,9 +26,9 @@
 
 namespace exg_rd {
 
-namespace {
-
 namespace zst = exg::zst;
+
+namespace {
 
 // XXH64 of frames that span rounds (or are too large for the device's serial hash), on a thread of its own
 class FrameHasher {
@@ -109,13 +109,18 @@ private:
 
 class ZstdProducer : public SegmentProducer {
 public:
-    ZstdProducer(exg_reader *r, int fd, uint64_t n, uint64_t target, const std::string &path, uint64_t reserve)
-        : device_(r->device), fd_(fd), n_(n), target_(std::max<uint64_t>(target, 128u << 10)), path_(path), reserve_((reserve + 15) & ~15ull) {}
+    ZstdProducer(exg_reader *r, int fd, uint64_t n, uint64_t c_begin, uint64_t c_end, uint64_t target, const std::string &path, uint64_t reserve,
+                 const uint64_t mark_at[2])
+        : device_(r->device), fd_(fd), n_(n), c_begin_(c_begin), c_end_(c_end), target_(std::max<uint64_t>(target, 128u << 10)), path_(path),
+          reserve_((reserve + 15) & ~15ull) {
+        if (mark_at) mark_at_[0] = mark_at[0], mark_at_[1] = mark_at[1];
+    }
     int run(SegmentSink &sink, std::string *err) override;
 
 private:
     int device_, fd_;
-    uint64_t n_, target_;
+    uint64_t n_, c_begin_, c_end_, target_;
+    uint64_t mark_at_[2] = {~0ull, ~0ull};  // frame offsets whose decoded positions the reader wants to know (a shard's boundaries)
     std::string path_;
     uint64_t reserve_;
 };
@@ -157,7 +162,22 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
         *err = idx.error + " in '" + path_ + "'";
         return EXG_E_PARSE;
     }
-    const uint64_t n_blocks = idx.blocks.size();
+    // the frames whose first byte lies in [c_begin, c_end) (a shard decodes its own frames and a halo of frames in front)
+    uint64_t b_first = idx.blocks.size(), n_blocks = 0, b_mark[2] = {~0ull, ~0ull};
+    bool marked[2] = {false, false};
+    for (const zst::Frame &F : idx.frames) {
+        if (F.src_off >= c_begin_ && F.src_off < c_end_) {
+            b_first = std::min<uint64_t>(b_first, F.first_block);
+            n_blocks = std::max<uint64_t>(n_blocks, (uint64_t)F.first_block + F.n_blocks);
+        }
+        for (int i = 0; i < 2; i++)
+            if (mark_at_[i] != ~0ull && F.src_off >= mark_at_[i] && b_mark[i] == ~0ull) b_mark[i] = F.first_block;
+    }
+    if (b_first > n_blocks) b_first = n_blocks;
+    auto marks = [&](uint64_t b_next, uint64_t pos) {  // b_next: the next block to be decoded, pos: where its bytes will lie
+        for (int i = 0; i < 2; i++)
+            if (!marked[i] && mark_at_[i] != ~0ull && (b_next >= b_mark[i] || b_next >= n_blocks)) sink.set_mark(i, pos), marked[i] = true;
+    };
     // the round's compressed bytes: [the blocks whose tables are repeated (at most four) | the round's own, from a 16-byte boundary]
     static constexpr uint64_t kSideSlot = (zst::kBlockMax + 64 + 15) & ~15ull, kSide = 4 * kSideSlot;
     PoolBuf d_comp(device_, st), d_hist(device_, st);
@@ -182,15 +202,17 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
     FrameHasher hasher;
     const uint64_t verify_max = zst::default_verify_max();
     uint64_t d_pos = 0;             // decoded bytes produced so far
-    uint64_t b0 = 0;                // next block
+    uint64_t b0 = b_first;          // next block
     uint32_t rep[3] = {1, 4, 8};    // repeat offsets behind block b0 - 1 (of the frame that goes on)
     uint64_t frame_done = 0;        // bytes of the frame that holds block b0 decoded so far (0: it begins with b0)
     uint64_t hist = 0, pad = 0;     // d_hist holds [pad | hist bytes]: the end of that frame's output so far
     bool pushed_last = false;
     while (b0 < n_blocks && !sink.cancelled()) {
-        // ---- the round's blocks: about one segment of output (a block regenerates at most 128 KiB)
+        marks(b0, d_pos);
+        // ---- the round's blocks: about one segment of output (a block regenerates at most 128 KiB); a round ends at a mark
         uint64_t b1 = b0, est = 0;
         while (b1 < n_blocks && (b1 == b0 || est < target_)) {
+            if (b1 > b0 && (b1 == b_mark[0] || b1 == b_mark[1])) break;
             const zst::Block &B = idx.blocks[b1];
             est += B.type == 2 ? zst::kBlockMax : B.src_size;  // raw / RLE: src_size is the regenerated size
             b1++;
@@ -403,6 +425,7 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
         *err = hasher.error() + " in '" + path_ + "'";
         return EXG_E_PARSE;
     }
+    marks(n_blocks, d_pos);
     if (!pushed_last && !sink.cancelled()) {  // no block at all (an empty file, skippable frames only): the stream still ends
         Segment seg;
         seg.cap = (size_t)(reserve_ + 16 + 64);
@@ -428,8 +451,57 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
 
 }  // namespace
 
-std::unique_ptr<SegmentProducer> make_zstd_producer(exg_reader *r, int fd, uint64_t n, uint64_t target, const std::string &path, uint64_t reserve) {
-    return std::unique_ptr<SegmentProducer>(new ZstdProducer(r, fd, n, target, path, reserve));
+std::unique_ptr<SegmentProducer> make_zstd_producer(exg_reader *r, int fd, uint64_t n, uint64_t c_begin, uint64_t c_end, uint64_t target,
+                                                    const std::string &path, uint64_t reserve, const uint64_t mark_at[2]) {
+    return std::unique_ptr<SegmentProducer>(new ZstdProducer(r, fd, n, c_begin, c_end, target, path, reserve, mark_at));
+}
+
+// Shard `shard_index` of `shard_count` of a zstd file: a FRAME belongs to the shard in whose 1/shard_count of the file's bytes
+// it begins (a file of one frame — what the zstd CLI writes — is one shard's; pzstd / seekable-format files have many).
+// out: the frames to decode are those that begin in [*c_begin, *c_end) — a halo of frames in front of the shard's own (about
+// `halo_want` bytes of content, as far as the frame headers tell), then its own; own_lo / own_hi: where its own begin / end.
+int plan_zstd_shard(exg_reader *r, int fd, uint64_t n, const std::string &path, uint64_t halo_want, uint64_t header_bytes, uint64_t *c_begin,
+                    uint64_t *c_end, uint64_t *own_lo, uint64_t *own_hi, bool *bytes_follow) {
+    void *map = n ? mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
+    if (map == MAP_FAILED) return fail(r, EXG_E_IO, "cannot map '" + path + "'");
+    struct Unmap {
+        void *p;
+        size_t n;
+        ~Unmap() { if (p) munmap(p, n); }
+    } unmap{map, (size_t)n};
+    zst::Index idx;
+    if (!zst::build_index((const uint8_t *)map, n, idx)) return fail(r, EXG_E_PARSE, idx.error + " in '" + path + "'");
+    const uint64_t lo = (uint64_t)((unsigned __int128)n * r->shard_index / r->shard_count);
+    const uint64_t hi = r->shard_index + 1 == r->shard_count ? n : (uint64_t)((unsigned __int128)n * (r->shard_index + 1) / r->shard_count);
+    const size_t nf = idx.frames.size();
+    size_t f_own = 0, f_hi = 0;
+    while (f_own < nf && idx.frames[f_own].src_off < lo) f_own++;
+    f_hi = f_own;
+    while (f_hi < nf && (hi >= n || idx.frames[f_hi].src_off < hi)) f_hi++;
+    auto off_of = [&](size_t f) { return f < nf ? idx.frames[f].src_off : n; };
+    auto compressed_size = [&](size_t f) { return off_of(f + 1) - off_of(f); };
+    size_t f_begin = f_own;
+    uint64_t halo = 0;
+    while (f_begin > 0 && halo < halo_want) {
+        f_begin--;
+        const zst::Frame &F = idx.frames[f_begin];
+        halo += F.content_size != ~0ull ? F.content_size : compressed_size(f_begin);
+    }
+    if (header_bytes && f_begin > 0) {
+        // the stream must begin behind the VCF header, or with the file: known only when the frames in front state their sizes
+        uint64_t sum = 0;
+        bool known = true;
+        for (size_t f = 0; f < f_begin; f++) known = known && idx.frames[f].content_size != ~0ull, sum += known ? idx.frames[f].content_size : 0;
+        if (!known || sum < header_bytes) f_begin = 0;
+    }
+    *c_begin = off_of(f_begin);
+    *c_end = off_of(f_hi);
+    *own_lo = off_of(f_own);
+    *own_hi = off_of(f_hi);
+    *bytes_follow = false;
+    for (size_t f = f_hi; f < nf; f++)
+        if (idx.frames[f].content_size != 0) *bytes_follow = true;  // (unknown counts as content)
+    return EXG_OK;
 }
 
 }  // namespace exg_rd

@@ -67,18 +67,10 @@ extern "C" int exg_open(const exg_open_args *args, exg_reader **out) {
         exg::set_error("exg_open: shard_index %u is not below shard_count %u", r->shard_index, r->shard_count);
         return EXG_E_INVALID_ARG;
     }
-    if (r->shard_count > 1 && r->format == EXG_FMT_FASTA && r->compression == kGzip) {
-        exg::set_error("a gzip FASTA is not sharded: the records' '>' lines are found in the text");
-        return EXG_E_UNSUPPORTED;
-    }
     int rc = list_files(r.get(), path);
     if (rc) return rc;
     if (r->compression != kNone && r->compression != kGzip && r->compression != kZstd) {
         exg::set_error("compression is not supported: gzip and zstd have device decoders, bzip2 / xz do not, and there is no CPU fallback");
-        return EXG_E_UNSUPPORTED;
-    }
-    if (r->shard_count > 1 && r->compression == kZstd) {
-        exg::set_error("a zstd input is not sharded (its frames are decoded by the whole device at once)");
         return EXG_E_UNSUPPORTED;
     }
     const int n_dev = exg_device_count();

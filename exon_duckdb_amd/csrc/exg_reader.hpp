@@ -380,6 +380,8 @@ struct exg_reader {
     // (EXG_RF_HEAD_UNRESOLVED) the halo is grown eightfold and the batch scanned again, up to the first byte of the data:
     // a record of any length across a cut is found, like the unsharded scan finds it
     uint64_t halo_want = 0;
+    bool fa_shard = false;     // a shard of a compressed FASTA: file_pos is its first record, fa_end (once known) the first that is not its own
+    uint64_t fa_end = ~0ull;
     bool range_eof = true;    // range_hi is the end of the file's data (a later shard follows otherwise)
     bool range_preset = false;  // BGZF shard: inflate_file chose the members, file_pos / range_hi refer to ITS inflated bytes
     uint64_t preset_pos = 0;    // ... first owned inflated byte (what is in front of it is the halo)

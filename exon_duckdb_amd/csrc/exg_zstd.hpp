@@ -73,6 +73,7 @@ struct Frame {
     uint32_t first_block, n_blocks;
     uint32_t has_checksum, checksum;  // Content_Checksum (low 32 bits of XXH64, seed 0)
     uint64_t out_off, out_size;       // filled from the block sizes
+    uint64_t src_off;                 // where the frame begins in the file (its magic number)
 };
 
 // a run of consecutive blocks of one frame executed by one wavefront

@@ -40,6 +40,7 @@ bool build_index(const uint8_t *data, uint64_t n, Index &idx) {
         Frame fr;
         memset(&fr, 0, sizeof fr);
         fr.content_size = ~0ull;
+        fr.src_off = frame_at;
         fr.has_checksum = (fhd >> 2) & 1;
         if (!single) {
             if (pos >= n) return fail(idx, kSrcSize, frame_at);

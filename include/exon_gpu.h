@@ -218,6 +218,10 @@ int exg_fasta_scan(const exg_fasta_scan_args *args);
 int exg_fetch_result(const exg_scan_result *d_result, void *stream, exg_scan_result *out);
 /* '\n' count of d_input[begin,end) into *d_count (device u64); used for the shard phase exchange. */
 int exg_count_newlines(const void *d_input, uint64_t begin, uint64_t end, uint64_t *d_count, void *stream);
+/* The first FASTA record start ('>' at the beginning of a line) at an offset in [begin, end) of d_bytes into *d_pos (device
+ * u64; ~0 when there is none).  The byte in front of `begin` is read (begin = 0: at_bof says whether d_bytes[0] begins a
+ * line).  What a shard of a compressed FASTA needs at its ends: a record belongs to the shard its '>' line begins in. */
+int exg_fasta_find_record(const void *d_bytes, uint64_t begin, uint64_t end, int at_bof, uint64_t *d_pos, void *stream);
 /* FASTQ 4-line phase of the first line that starts at or after `lead`, decided from local
  * structure ('@' on line 0, '+' on line 2 for 8 consecutive records).  *d_phase (device u32)
  * receives 0..3, or 0xFFFFFFFF when no or several phases fit (caller falls back to counting). */

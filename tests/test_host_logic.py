@@ -2,6 +2,7 @@
 renders, exon/src/exon/arrow_table_function/module.cpp:158-214, evaluated by DataFusion with SQL precedence) and the
 VCF header -> typed INFO / FORMAT keys mapping.  No device is touched."""
 import ctypes as C
+import os
 
 import pytest
 
@@ -88,3 +89,28 @@ def test_vcf_header_keys_match_the_oracle(lib, oracle, golden_dir):
         buf = C.create_string_buffer(8192)
         assert lib.exg_vcf_header_explain(data, len(data), buf, 8192) == 0
         assert buf.value.decode() == want, name
+
+
+def test_duckdb_shim_compiles_against_the_api_stubs():
+    """duckdb_shim/exon_extension.cpp — the real `LOAD exon` binding: the glue of csrc/exon_table_function.hpp instantiated over
+    DuckDB's classes — goes through a compiler: `-fsyntax-only` against declaration-only stand-ins of the ten DuckDB v0.8.1
+    headers it includes (tests/duckdb_stub/).  DuckDB itself does not exist on the build box, so this says nothing about
+    DuckDB's behaviour; it catches every typo, wrong member and template-instantiation error of the `RealDuck` traits."""
+    import shutil
+    import subprocess
+    cxx = shutil.which("c++") or shutil.which("g++")
+    if not cxx:
+        pytest.skip("no host C++ compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [cxx, "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(root, "tests", "duckdb_stub"), "-I", os.path.join(root, "include"),
+           "-I", os.path.join(root, "exon_duckdb_amd", "csrc"), os.path.join(root, "duckdb_shim", "exon_extension.cpp")]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+
+
+def test_batch_index_stays_below_duckdbs_pipeline_increment():
+    """get_batch_index = (shard << 24) + device batch: 64 shards (the planner's limit) of 2^24 batches stay eleven thousand
+    times below the 10^13 DuckDB 0.8.1 puts between two pipelines' batch ranges (PipelineBuildState::BATCH_INCREMENT)."""
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "exon_duckdb_amd", "csrc", "exon_table_function.hpp")).read()
+    assert "kBatchBits = 24" in src
+    assert (64 << 24) + (1 << 24) < 10 ** 13 // 1000

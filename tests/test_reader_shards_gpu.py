@@ -123,8 +123,10 @@ def test_bgzf_more_shards_than_members(gpu, golden_dir, tmp_path):
 def test_unshardable_inputs_fail_loudly(gpu, golden_dir):
     from exon_duckdb_amd._lib import ExgError
     from exon_duckdb_amd.reader import ShardReader
-    with pytest.raises(ExgError):
-        ShardReader(f"{golden_dir}/test.fasta.gz", "fasta", shard_index=0, shard_count=2)
+    r = ShardReader(f"{golden_dir}/test.fasta.gz", "fasta", shard_index=0, shard_count=2)           # plain gzip: no member sizes
+    with pytest.raises(ExgError, match="BGZF"):
+        r.rows()
+    r.close()
     r = ShardReader(f"{golden_dir}/test.fastq.gz", "fastq", shard_index=0, shard_count=2)   # plain gzip: no member sizes
     with pytest.raises(ExgError, match="BGZF"):
         r.rows()
@@ -188,8 +190,6 @@ def test_random_shard_geometry(gpu, oracle, tmp_path, monkeypatch, seed):
     batch = int(rng.choice([0, 16384, 65536, 1 << 20]))
     got, counts = sharded(str(p), fmt, n_shards, device_batch_bytes=batch)
     assert got == want and sum(counts) == n_rec, (seed, fmt, n_rec, n_shards, batch)
-    if fmt == "fasta":
-        return                                      # (a gzip FASTA is not sharded)
     gz = tmp_path / f"g.{fmt}.gz"
     gz.write_bytes(_bgzf(data, int(rng.integers(300, 65280))))
     got, counts = sharded(str(gz), fmt, n_shards, device_batch_bytes=batch)
@@ -388,3 +388,73 @@ def test_fan_out_reports_a_parse_error_behind_the_rows_in_front_of_it(gpu, oracl
     r.close()
     with pytest.raises(ExgError):
         ShardReader(str(p), "fastq", shard_count=0).count()
+
+
+# ---- shards of compressed inputs beyond BGZF FASTQ / VCF: bgzip FASTA by members, zstd by frames -----------------------------
+
+@pytest.mark.parametrize("n_shards", [2, 5, 23])
+@pytest.mark.parametrize("block", [65280, 3000])
+def test_bgzip_fasta_shards(gpu, oracle, tmp_path, monkeypatch, n_shards, block):
+    """A record belongs to the shard in whose members' bytes its '>' line begins: the shard's stream starts one member in
+    front of its own (does their first byte begin a line?), its first record start is searched on the device, and it reads
+    on behind its members until the next record start (the decoder tells where its own members end: mark 1).  Records of
+    3 .. 50 lines, some longer than several members; more shards than records at 23 x 65280."""
+    data = bytes(oracle.synth_fasta(400, seed=21))
+    data += b">long one\n" + b"".join(b"ACGTACGTAC" * 6 + b"\n" for _ in range(9000)) + bytes(oracle.synth_fasta(50, seed=22))
+    p = tmp_path / "s.fasta"
+    p.write_bytes(data)
+    want = whole(str(p), "fasta")
+    gz = tmp_path / "s.fasta.gz"
+    gz.write_bytes(_bgzf(data, block))
+    monkeypatch.setenv("EXG_DEVICE_BATCH_BYTES", str(128 << 10))
+    got, counts = sharded(str(gz), "fasta", n_shards)
+    assert got == want and sum(counts) == len(want)
+
+
+def _zst_frames(data, cuts, **kw):
+    from zstd_util import compress, skippable
+    out = []
+    for i in range(len(cuts) - 1):
+        out.append(compress(data[cuts[i]:cuts[i + 1]], 3, i % 2 == 0, content_size=kw.get("content_size", True) and i % 3 != 1))
+        if i == 1:
+            out.append(skippable(b"x" * 37))
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("n_shards", [2, 3, 9])
+def test_zstd_shards_by_frames(gpu, oracle, tmp_path, monkeypatch, n_shards):
+    """A multi-frame zstd file (pzstd, the seekable format) is sharded by frames: a frame belongs to the shard in whose bytes
+    it begins; the stream of a shard begins with a halo of frames in front of its own, and the decoder tells where its own
+    bytes begin (some frames do not state their content size).  FASTQ (cuts mid record, mid line), VCF (every rank reads the
+    header from the first frames), FASTA (the shard reads on to the next record start); 9 shards over 8 frames: empty ones."""
+    import random
+    rng = random.Random(n_shards)
+    fq = bytes(oracle.synth_fastq_ragged(20000))
+    vcf = bytes(oracle.synth_vcf(15000))
+    fa = bytes(oracle.synth_fasta(2500, seed=4))
+    monkeypatch.setenv("EXG_DEVICE_BATCH_BYTES", str(256 << 10))
+    monkeypatch.setenv("EXG_SHARD_HALO", "65536")
+    for name, data, fmt in (("m.fastq", fq, "fastq"), ("m.vcf", vcf, "vcf"), ("m.fasta", fa, "fasta")):
+        cuts = sorted({0, len(data)} | {rng.randrange(1, len(data)) for _ in range(7)})
+        (tmp_path / name).write_bytes(data)
+        want = whole(str(tmp_path / name), fmt)
+        z = tmp_path / (name + ".zst")
+        z.write_bytes(_zst_frames(data, cuts))
+        assert whole(str(z), fmt) == want
+        got, counts = sharded(str(z), fmt, n_shards)
+        assert got == want and sum(counts) == len(want), (name, n_shards)
+
+
+def test_fan_out_over_compressed_fasta_and_zstd(gpu, oracle, tmp_path, monkeypatch):
+    from exon_duckdb_amd.reader import ShardReader
+    fa = bytes(oracle.synth_fasta(3000, seed=8))
+    fq = bytes(oracle.synth_fastq(332 * 20000))
+    (tmp_path / "a.fasta").write_bytes(fa)
+    (tmp_path / "a.fastq").write_bytes(fq)
+    (tmp_path / "a.fasta.gz").write_bytes(_bgzf(fa, 20000))
+    (tmp_path / "a.fastq.zst").write_bytes(_zst_frames(fq, list(range(0, len(fq), 700_001)) + [len(fq)]))
+    monkeypatch.setenv("EXON_GPU_SHARDS", "5")
+    monkeypatch.setenv("EXG_FANOUT_WORKERS", "3")
+    monkeypatch.setenv("EXG_DEVICE_BATCH_BYTES", str(256 << 10))
+    assert _auto(str(tmp_path / "a.fasta.gz"), "fasta") == whole(str(tmp_path / "a.fasta"), "fasta")
+    assert _auto(str(tmp_path / "a.fastq.zst"), "fastq") == whole(str(tmp_path / "a.fastq"), "fastq")
