@@ -113,7 +113,6 @@ def open_reader(lib, path, fmt, shard=(0, 1), device_index=0):
     from exon_duckdb_amd import abi
     lib.exg_open.argtypes = [C.POINTER(abi.OpenArgs), C.POINTER(C.c_void_p)]
     lib.exg_count_only.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
-    lib.exg_drain_chunks.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.exg_close.argtypes = [C.c_void_p]
     a = abi.OpenArgs(path.encode(), fmt.encode(), None, 2048, device_index, 0, None, shard[0], shard[1])
     r = C.c_void_p()
@@ -134,14 +133,30 @@ def reader_count(lib, path, fmt, shard=(0, 1), device_index=0):
 
 
 def reader_chunks(lib, path, fmt, shard=(0, 1), device_index=0):
+    """every DataChunk pulled and released by a C loop of the scaffolding library (no interpreter between the chunks)"""
+    from exon_duckdb_amd import load_test_library
+    tl = load_test_library()
     r = open_reader(lib, path, fmt, shard, device_index)
     rows, chunks = C.c_uint64(0), C.c_uint64(0)
     t0 = time.perf_counter()
-    rc = lib.exg_drain_chunks(r, C.byref(rows), C.byref(chunks))
+    rc = tl.exon_tf_drain_chunks(r, C.byref(rows), C.byref(chunks))
     dt = time.perf_counter() - t0
     assert rc == 0, lib.exg_last_error_message()
     lib.exg_close(r)
     return int(rows.value), int(chunks.value), dt
+
+
+def reader_digest(lib, path, fmt, want_seq_len=0):
+    """the same walk, folding the content of EVERY row — each string_t dereferenced: length, prefix, pointer, payload bytes; VCF:
+    CHROM, the parsed POS, REF — into a digest (untimed verification pass) -> (rows, chunks, digest, rows of the wrong length)"""
+    from exon_duckdb_amd import load_test_library
+    tl = load_test_library()
+    r = open_reader(lib, path, fmt)
+    rows, chunks, dg, bad = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    rc = tl.exon_tf_drain_digest(r, 1 if fmt == "vcf" else 0, want_seq_len, C.byref(rows), C.byref(chunks), C.byref(dg), C.byref(bad))
+    assert rc == 0, lib.exg_last_error_message()
+    lib.exg_close(r)
+    return int(rows.value), int(chunks.value), int(dg.value), int(bad.value)
 
 
 def effective_cores():
@@ -189,33 +204,46 @@ def write_device_bytes(torch, t, n, path):
 
 
 def _bgzf_worker(args):
-    path, lo, hi, out_path = args
-    with open(path, "rb") as f, open(out_path, "wb") as out:
-        f.seek(lo)
-        left = hi - lo
-        while left > 0:
-            chunk = f.read(min(65280, left))
-            left -= len(chunk)
-            co = zlib.compressobj(6, zlib.DEFLATED, -15)
-            d = co.compress(chunk) + co.flush()
-            out.write(b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(d) + 8 - 1)
-                      + d + struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+    """deflates records [rec_lo, rec_hi) of the synthetic FASTQ-150 file into BGZF members of 65 280 bytes: the bytes come from
+    the generator itself (the scaffolding library's host form of it), slice by slice — the plain file is never written"""
+    seed, rec_lo, rec_hi, out_path = args
+    import numpy as np
+    from exon_duckdb_amd import load_test_library
+    tl = load_test_library()
+    step = 65280 * 83   # lcm(332, 65 280) bytes = 16 320 records = 83 members
+    assert step % REC == 0 and step % 65280 == 0
+    buf = np.empty(step, dtype=np.uint8)
+    with open(out_path, "wb") as out:
+        r = rec_lo
+        while r < rec_hi:
+            n = min(step // REC, rec_hi - r)
+            tl.exon_tf_synth_fastq150_host(seed, r, n, buf.ctypes.data)
+            raw = buf[:n * REC].tobytes()
+            for o in range(0, len(raw), 65280):
+                chunk = raw[o:o + 65280]
+                co = zlib.compressobj(6, zlib.DEFLATED, -15)
+                d = co.compress(chunk) + co.flush()
+                out.write(b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(d) + 8 - 1)
+                          + d + struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+            r += n
     return os.path.getsize(out_path)
 
 
-def build_bgzf(plain_path, n_bytes, out_path, workers):
-    """BASELINE config 4's input: the FASTQ stream cut into 65 280-byte members, each deflated (zlib level 6) with BGZF
-    framing, by `workers` host processes (input preparation; not timed)."""
+def build_bgzf(seed, n_records, out_path, workers):
+    """BASELINE config 4's input: the FASTQ-150 stream cut into 65 280-byte members, each deflated (zlib level 6) with BGZF
+    framing, by `workers` host processes (input preparation; not timed).  Every worker takes a run of records whose bytes are
+    a multiple of 65 280, so that the members are those of one sequential bgzip run over the whole stream."""
     import multiprocessing as mp
-    per = (n_bytes // workers + 65279) // 65280 * 65280
-    jobs = [(plain_path, lo, min(n_bytes, lo + per), f"{out_path}.part{i}") for i, lo in enumerate(range(0, n_bytes, per))]
+    unit = 65280 * 83 // REC                          # 16 320 records = lcm(332, 65 280) bytes: a whole number of members
+    per = max(unit, (n_records // workers + unit - 1) // unit * unit)
+    jobs = [(seed, lo, min(n_records, lo + per), f"{out_path}.part{i}") for i, lo in enumerate(range(0, n_records, per))]
     t0 = time.perf_counter()
     with mp.get_context("spawn").Pool(min(workers, len(jobs))) as pool:
         sizes = pool.map(_bgzf_worker, jobs)
     build_bgzf.pool_s = time.perf_counter() - t0
     with open(out_path, "wb") as out:
         for (_, _, _, part), sz in zip(jobs, sizes):
-            with open(part, "rb") as f:  # in-kernel copy (tmpfs -> tmpfs)
+            with open(part, "rb") as f:  # in-kernel copy (tmpfs -> tmpfs); the part goes at once: the peak is the file + one part
                 done = 0
                 while done < sz:
                     done += os.sendfile(out.fileno(), f.fileno(), done, min(sz - done, 1 << 30))
@@ -224,17 +252,38 @@ def build_bgzf(plain_path, n_bytes, out_path, workers):
     return sum(sizes) + 28
 
 
+def host_pipeline_scaling(path, device_index=0, seconds=1.0):
+    """The host side of the upload path with N readers at once on this one GPU's box (at 8 GPUs every reader
+    copies its bytes page cache -> pinned block -> DMA, and all of them share the host's memory system): aggregate GB/s of
+    N x 8 pread threads filling pinned blocks, without and with the H2D copies behind them."""
+    from exon_duckdb_amd import load_test_library
+    tl = load_test_library()
+    out = {"what": "aggregate page cache -> pinned host memory GB/s of N readers x 8 pread threads (8 MiB slices), "
+                   "`with_h2d`: each slice sent on to HBM like an upload (one GPU: the link bounds the sum)", "readers": {}}
+    for n in (1, 2, 4, 8):
+        a = tl.exon_tf_host_pipeline_probe(path.encode(), n, 8, 0, device_index, seconds)
+        b = tl.exon_tf_host_pipeline_probe(path.encode(), n, 8, 1, device_index, seconds)
+        out["readers"][str(n)] = {"pinned_GB/s": round(a / 1e9, 2) if a > 0 else None, "with_h2d_GB/s": round(b / 1e9, 2) if b > 0 else None}
+    return out
+
+
 def run_configs(torch, lib, args):
     """BASELINE configs 1, 3, 4 and the end-to-end leg on one GPU -> dicts for the bench line"""
     from exon_duckdb_amd import abi, device
     out = {}
     cores = effective_cores()
     n_e2e = int(args.e2e_gb * 1e9) // REC * REC
-    budget = cores * 20e6 * 30                       # config 4's input: ~30 s of host deflate at ~20 MB/s per usable core
+    # config 4's input, 10 GB of BGZF = 19.3 GB of FASTQ-150, is deflated by the host's usable cores straight from the
+    # generator (~22 MB/s per core at zlib level 6: about a minute on 16 cores); the plain file is never written, so the
+    # scratch directory holds the 4 GB end-to-end file + the 10 GB of BGZF (+ one part while they are joined)
+    budget = cores * 20e6 * args.gz_build_s
     n_gz_in = int(min(args.gz_gb * 1e9 * 1.93, budget)) // REC * REC
-    tmp, free = scratch_dir(int(1.6 * max(n_e2e, n_gz_in)))
-    if 1.6 * max(n_e2e, n_gz_in) > 0.8 * free:      # (plain file + its BGZF form must fit)
-        n_gz_in = n_e2e = int(0.8 * free / 1.6) // REC * REC
+    tmp, free = scratch_dir(int(n_e2e + 0.6 * n_gz_in))
+    if n_e2e + 0.6 * n_gz_in > 0.85 * free:
+        scale = 0.85 * free / (n_e2e + 0.6 * n_gz_in)
+        n_e2e, n_gz_in = int(n_e2e * scale) // REC * REC, int(n_gz_in * scale) // REC * REC
+    from exon_duckdb_amd import load_test_library
+    tl = load_test_library()
     def leg(fn, *keys):
         """a side leg of the bench line: what goes wrong in it is reported in its own object(s)"""
         try:
@@ -290,39 +339,54 @@ def run_configs(torch, lib, args):
             torch.cuda.empty_cache()
 
         def files():
-            nonlocal n_e2e
             # ---- end to end: FASTQ file in the page cache -> host DataChunks (PCIe inclusive) -------------------------------
-            n_file = max(n_e2e, n_gz_in)                  # one file serves both legs: config 4 deflates its first n_gz_in bytes
             p_fq = os.path.join(tmp, "e2e.fastq")
             with open(p_fq, "wb") as f:
                 step = (1 << 30) // REC * REC
-                for o in range(0, n_file, step):
-                    m = min(step, n_file - o)
+                for o in range(0, n_e2e, step):
+                    m = min(step, n_e2e - o)
                     f.write(device.synth_fastq(m, file_offset=o)[:m].cpu().numpy().tobytes())
-            n_e2e = n_file
             torch.cuda.empty_cache()
             reader_count(lib, p_fq, "fastq")  # warm: pools, page cache
             n, dt_c = min((reader_count(lib, p_fq, "fastq") for _ in range(3)), key=lambda x: x[1])
             rows, chunks, dt_r = min((reader_chunks(lib, p_fq, "fastq") for _ in range(3)), key=lambda x: x[2])
+            # content: every row of every chunk folded into a digest, against what the generator says the rows are
+            want = int(tl.exon_tf_expect_fastq150(abi.EXG_SYNTH_FASTQ_SEED, 0, n_e2e // REC, cores))
+            v_rows, v_chunks, got, bad = reader_digest(lib, p_fq, "fastq", 150)
             out["end_to_end"] = {
                 "workload": f"read_fastq, {n_e2e / 1e9:.1f} GB FASTQ-150 file in the page cache -> host DataChunks (exg_open / exg_next_chunk), PCIe inclusive",
                 "algorithmic_bytes": n_e2e, "ms": dt_r * 1e3, "GB/s": n_e2e / dt_r / 1e9, "records_per_s": rows / dt_r, "chunks": chunks,
                 "count_only_ms": dt_c * 1e3, "count_only_GB/s": n_e2e / dt_c / 1e9, "frac": None,
-                "verified": bool(rows == n == n_e2e // REC and chunks >= (rows + 2047) // 2048)}
+                "verification": "an untimed pass folds every row of every chunk (each string_t dereferenced: length, prefix, pointer, payload "
+                                "bytes) into a digest that must equal the generator's for these rows",
+                "verified": bool(rows == n == v_rows == n_e2e // REC and chunks >= (rows + 2047) // 2048 and got == want and bad == 0)}
+            try:
+                out["host_pipeline_scaling"] = host_pipeline_scaling(p_fq, 0, 0.6)
+            except Exception as e:  # noqa: BLE001
+                out["host_pipeline_scaling"] = {"error": f"{type(e).__name__}: {e}"}
             # ---- config 4: read_fastq on BGZF (device inflate feeding the scan) ------------------------------------------------
             p_gz = os.path.join(tmp, "c4.fastq.gz")
             t0 = time.perf_counter()
-            comp = build_bgzf(p_fq, n_gz_in, p_gz, max(1, min(cores, 192)))
+            n_gz_rec = n_gz_in // REC
+            comp = build_bgzf(abi.EXG_SYNTH_FASTQ_SEED, n_gz_rec, p_gz, max(1, min(cores, 192)))
             t_build = time.perf_counter() - t0
             reader_count(lib, p_gz, "fastq")
             n, dt_g = min((reader_count(lib, p_gz, "fastq") for _ in range(3)), key=lambda x: x[1])
+            want = int(tl.exon_tf_expect_fastq150(abi.EXG_SYNTH_FASTQ_SEED, 0, n_gz_rec, cores))
+            t1 = time.perf_counter()
+            v_rows, v_chunks, got, bad = reader_digest(lib, p_gz, "fastq", 150)
+            dt_v = time.perf_counter() - t1
             out["config4_fastq_bgzf"] = {
                 "workload": f"SELECT COUNT(*) FROM read_fastq('x.fastq.gz'): {comp / 1e9:.2f} GB of BGZF (65 280-byte members, zlib level 6) = "
-                            f"{n_gz_in / 1e9:.2f} GB of FASTQ-150, file in the page cache, inflate + scan on the device",
+                            f"{n_gz_in / 1e9:.2f} GB of FASTQ-150, file in the page cache, inflate + scan on the device, decoded as a bounded "
+                            f"stream of segments (neither the compressed nor the inflated file is resident)",
                 "compressed_bytes": comp, "algorithmic_bytes": comp + 2 * n_gz_in, "ms": dt_g * 1e3, "GB/s": n_gz_in / dt_g / 1e9,
                 "GB/s_compressed": comp / dt_g / 1e9, "records_per_s": n / dt_g, "frac": (comp + 2 * n_gz_in) / dt_g / 1e9 / HBM_PEAK_GBPS,
-                "input_build_s": t_build, "input_deflate_pool_s": getattr(build_bgzf, "pool_s", None), "verified": bool(n == n_gz_in // REC)}
-
+                "input_build_s": t_build, "input_deflate_pool_s": getattr(build_bgzf, "pool_s", None),
+                "all_columns_verify_s": dt_v,
+                "verification": "COUNT(*) timed; an untimed pass pulls all four columns as DataChunks and folds every row into a digest that "
+                                "must equal the generator's",
+                "verified": bool(n == v_rows == n_gz_rec and got == want and bad == 0)}
 
         def vcf_file():
             # ---- read_vcf end to end: VCF-8 file in the page cache -> host DataChunks, every column of the reference's schema
@@ -338,15 +402,23 @@ def run_configs(torch, lib, args):
             reader_count(lib, p_vcf, "vcf")
             n, dt_c = min((reader_count(lib, p_vcf, "vcf") for _ in range(3)), key=lambda x: x[1])
             rows, chunks, dt_r = min((reader_chunks(lib, p_vcf, "vcf") for _ in range(3)), key=lambda x: x[2])
+            # content: CHROM, the parsed POS and REF of every row, against an independent split of the file's lines
+            e_rows, e_dg = C.c_uint64(0), C.c_uint64(0)
+            assert tl.exon_tf_expect_vcf_file(p_vcf.encode(), C.byref(e_rows), C.byref(e_dg)) == 0
+            v_rows, v_chunks, got, _ = reader_digest(lib, p_vcf, "vcf")
             out["end_to_end_vcf"] = {
                 "workload": f"read_vcf, {n_vcf / 1e9:.2f} GB VCF-8 file in the page cache -> host DataChunks of all 8 columns (exg_open / exg_next_chunk), PCIe inclusive",
                 "algorithmic_bytes": n_vcf, "ms": dt_r * 1e3, "GB/s": n_vcf / dt_r / 1e9, "records_per_s": rows / dt_r, "chunks": chunks,
                 "count_only_ms": dt_c * 1e3, "count_only_GB/s": n_vcf / dt_c / 1e9, "frac": None,
-                "verified": bool(rows == n == n_lines and chunks >= (rows + 2047) // 2048)}
+                "verification": "an untimed pass folds CHROM, the parsed POS and REF of every row into a digest that must equal the one of "
+                                "an independent line / tab split of the file",
+                "verified": bool(rows == n == n_lines == v_rows == int(e_rows.value) and chunks >= (rows + 2047) // 2048 and got == int(e_dg.value))}
 
         leg(config1, "config1_fasta_1MB_count")
         leg(config3, "config3_vcf_8col")
         leg(files, "end_to_end", "config4_fastq_bgzf")
+        if "host_pipeline_scaling" in out and "end_to_end" in out and "error" not in out["end_to_end"]:
+            out["end_to_end"]["host_pipeline_scaling"] = out.pop("host_pipeline_scaling")
         leg(vcf_file, "end_to_end_vcf")
     finally:
         for f in os.listdir(tmp):
@@ -368,7 +440,8 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the configs / end_to_end legs")
     ap.add_argument("--vcf-gb", type=float, default=5.0)
     ap.add_argument("--e2e-gb", type=float, default=4.0)
-    ap.add_argument("--gz-gb", type=float, default=10.0, help="config 4: compressed GB asked for (bounded by the e2e file and the host's deflate budget)")
+    ap.add_argument("--gz-gb", type=float, default=10.0, help="config 4: compressed GB asked for (BASELINE: 10; bounded by the scratch space and --gz-build-s)")
+    ap.add_argument("--gz-build-s", type=float, default=75.0, help="config 4: seconds of host deflate the input may cost (usable cores x ~20 MB/s each)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; default) | gloo (functional test of the N>1 path)")
     ap.add_argument("--single-device", action="store_true", help="test only: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()

@@ -5,7 +5,7 @@ HIP for gfx950; this package only loads the library, allocates device memory thr
 mirrors the reference's table-function surface for tests.  There is NO CPU fallback: importing
 works anywhere, but every scan raises if the library or a GPU is missing.
 """
-from ._lib import lib, load_library, ExgError, LIB_PATH  # noqa: F401
+from ._lib import lib, load_library, load_test_library, ExgError, LIB_PATH  # noqa: F401
 from . import abi  # noqa: F401
 
-__all__ = ["lib", "load_library", "ExgError", "LIB_PATH", "abi"]
+__all__ = ["lib", "load_library", "load_test_library", "ExgError", "LIB_PATH", "abi"]

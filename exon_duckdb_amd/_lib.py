@@ -35,12 +35,16 @@ def load_library(path=None):
         raise ExgError(abi.EXG_E_NO_DEVICE, f"{p} not found: run `python __graft_entry__.py build` "
                        "(hipcc --offload-arch=gfx950); there is no CPU fallback")
     # PyTorch bundles a HIP runtime of its own; two HIP runtimes in one process do not share the GPU (whichever comes second
-    # sees no device).  Whoever uses this package beside torch (the tests, bench.py, smoke()) therefore gets torch's runtime
-    # loaded first — libexon_gpu.so then binds to the copy that is already there.  Without torch nothing changes.
-    try:
-        import torch  # noqa: F401
-    except Exception:  # noqa: BLE001
-        pass
+    # sees no device).  Whoever uses this package beside torch imports torch FIRST (tests/conftest.py, bench.py and smoke()
+    # do): libexon_gpu.so then binds to the copy that is already there.  This loader does not import torch by itself — that
+    # would cost every user seconds and silently change which HIP runtime the product binds to; EXG_PRELOAD_TORCH=1 asks
+    # for it (a process that will import torch later and cannot order its imports).
+    import sys
+    if "torch" not in sys.modules and os.environ.get("EXG_PRELOAD_TORCH"):
+        try:
+            import torch  # noqa: F401
+        except Exception as e:  # noqa: BLE001
+            print(f"exon_duckdb_amd: EXG_PRELOAD_TORCH is set but torch does not import: {e}", file=sys.stderr)
     l = C.CDLL(p)
     for name, (res, args) in abi.SIGNATURES.items():
         fn = getattr(l, name)
@@ -51,6 +55,27 @@ def load_library(path=None):
     if path is None:
         _lib = l
     return l
+
+
+_test_lib = None
+
+
+def load_test_library():
+    """libexon_tf_test.so: test / bench scaffolding built next to the product library and linked against it (synthetic
+    inputs generated in HBM, chunk-draining consumers, the DuckDB-API harness, host-only introspection)."""
+    global _test_lib
+    if _test_lib is None:
+        load_library()  # the product library first (the scaffolding links against it)
+        from . import build as _build
+        if not os.path.exists(_build.TEST_LIB):
+            _build.build(verbose=False)
+        l = C.CDLL(_build.TEST_LIB)
+        for name, (res, args) in abi.TEST_SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _test_lib = l
+    return _test_lib
 
 
 class _LazyLib:

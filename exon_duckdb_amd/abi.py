@@ -1,7 +1,7 @@
 """ctypes mirror of include/exon_gpu.h (keep in sync with the header; tests check sizes)."""
 import ctypes as C
 
-EXG_ABI_VERSION = 5
+EXG_ABI_VERSION = 6
 EXG_TYPE_VARCHAR, EXG_TYPE_BIGINT, EXG_TYPE_FLOAT, EXG_TYPE_INTEGER, EXG_TYPE_BOOLEAN, EXG_TYPE_LIST, EXG_TYPE_STRUCT = 1, 2, 3, 4, 5, 6, 7
 EXG_VECTOR_SIZE = 2048
 
@@ -163,9 +163,6 @@ SIGNATURES = {
     "exg_count_newlines": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
     "exg_quality_list_workspace_bytes": (C.c_uint64, [C.c_uint64]),
     "exg_quality_score_list": (C.c_int, [C.POINTER(QualityListArgs)]),
-    "exg_synth_fastq": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
-    "exg_synth_vcf": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]),
-    "exg_synth_fasta": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]),
     "exg_plan_shards": (C.c_int, [C.POINTER(OpenArgs), C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.c_uint32]),
 }
 
@@ -174,3 +171,21 @@ class ReaderStats(C.Structure):
     _fields_ = [("device_bytes_now", C.c_uint64), ("device_bytes_peak", C.c_uint64), ("device_mem_cap", C.c_uint64),
                 ("device_batch_bytes", C.c_uint64), ("device_batches", C.c_uint64), ("decoded_segments", C.c_uint64),
                 ("reserved", C.c_uint64 * 4)]
+
+# libexon_tf_test.so (csrc/testing/): test / bench scaffolding — synthetic inputs generated in HBM, consumers that drain a
+# reader's chunks (counting, or folding every row into a digest), host-only introspection, the host-pipeline probe
+TEST_SIGNATURES = {
+    "exg_synth_fastq": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "exg_synth_vcf": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]),
+    "exg_synth_fasta": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]),
+    "exon_tf_support_error": (C.c_char_p, []),
+    "exon_tf_drain_chunks": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "exon_tf_drain_digest": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                       C.POINTER(C.c_uint64)]),
+    "exon_tf_synth_fastq150_host": (None, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "exon_tf_expect_fastq150": (C.c_uint64, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int]),
+    "exon_tf_expect_vcf_file": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "exon_tf_filter_explain": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
+    "exon_tf_vcf_header_explain": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
+    "exon_tf_host_pipeline_probe": (C.c_double, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]),
+}

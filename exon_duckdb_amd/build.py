@@ -2,8 +2,9 @@
 
 One object per source under lib/obj/ (compiled in parallel, rebuilt when the source or any header is newer),
 linked with an export list (csrc/exports.map): only the C-ABI of include/exon_gpu.h leaves the library.
-The DuckDB-API mirror used by the tests (csrc/testing/: duck_mini + the exon_tf_* harness) is linked into a
-library of its own, libexon_tf_test.so, on top of libexon_gpu.so — test scaffolding is not part of the product.
+Test and bench scaffolding (csrc/testing/: the DuckDB-API mirror duck_mini + the exon_tf_* harness, the synthetic-input
+generators exg_synth_*, the chunk-draining / digesting consumers, the host-pipeline probe) is linked into a library of
+its own, libexon_tf_test.so, on top of libexon_gpu.so — it is not part of the product.
 """
 import os
 import subprocess
@@ -33,6 +34,10 @@ def sources():
 
 def test_sources():
     return _srcs(TESTING)
+
+
+# host-only units of the product that the test library links a copy of (their C++ symbols do not leave libexon_gpu.so)
+TEST_SHARED = ["exg_vcf_header.cpp"]
 
 
 def _headers():
@@ -87,12 +92,13 @@ def build(force=False, verbose=True):
     with ThreadPoolExecutor(max_workers=max(1, jobs)) as ex:
         list(ex.map(cc, todo))
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [_obj(s) for s in sources()] + [
-        "-Wl,--version-script=" + EXPORTS, "-lpthread"]
+        "-Wl,--version-script=" + EXPORTS, "-lpthread", "-ldl"]
     if verbose:
         print(" ".join(link), file=sys.stderr)
     subprocess.check_call(link)
     if test_sources():
         link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", TEST_LIB] + [_obj(s) for s in test_sources()] + [
+            _obj(os.path.join(CSRC, f)) for f in TEST_SHARED] + [
             "-L", LIB_DIR, "-lexon_gpu", "-Wl,-rpath,$ORIGIN", "-lpthread"]
         if verbose:
             print(" ".join(link), file=sys.stderr)

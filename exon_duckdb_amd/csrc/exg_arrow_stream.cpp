@@ -25,6 +25,7 @@
 #include "exg_filter.hpp"
 #include "exg_rd_fanout.hpp"
 #include "exg_rd_source.hpp"
+#include "exg_vcf_header.hpp"
 
 using namespace exg_rd;
 namespace ea = exg::arrow;
@@ -38,59 +39,8 @@ struct Field {
     std::vector<Field> children;
 };
 
-struct KeyDef {
-    std::string id;
-    uint8_t type = ea::kVtString;
-    bool is_list = false;
-};
-
-// `##INFO=<ID=DP,Number=1,Type=Integer,...>` / `##FORMAT=<...>` in header order (noodles-vcf Header::infos /
-// ::formats are insertion-ordered maps)
-void parse_vcf_header(const char *d, size_t n, std::vector<KeyDef> *info, std::vector<KeyDef> *format) {
-    size_t pos = 0;
-    while (pos < n && d[pos] == '#') {
-        const char *nl = (const char *)memchr(d + pos, '\n', n - pos);
-        size_t end = nl ? (size_t)(nl - d) : n;
-        std::string line(d + pos, end - pos);
-        pos = nl ? end + 1 : n;
-        if (!line.empty() && line.back() == '\r') line.pop_back();
-        std::vector<KeyDef> *dst = nullptr;
-        size_t lt = 0;
-        if (line.compare(0, 8, "##INFO=<") == 0) dst = info, lt = 8;
-        if (line.compare(0, 10, "##FORMAT=<") == 0) dst = format, lt = 10;
-        if (!dst) continue;
-        // key=value pairs separated by ',' outside double quotes
-        KeyDef k;
-        std::string number = "1", type = "String";
-        size_t i = lt;
-        while (i < line.size() && line[i] != '>') {
-            size_t eq = line.find('=', i);
-            if (eq == std::string::npos) break;
-            std::string key = line.substr(i, eq - i), val;
-            size_t j = eq + 1;
-            if (j < line.size() && line[j] == '"') {
-                j++;
-                while (j < line.size() && line[j] != '"') {
-                    if (line[j] == '\\' && j + 1 < line.size()) j++;
-                    val.push_back(line[j++]);
-                }
-                j++;
-            } else {
-                while (j < line.size() && line[j] != ',' && line[j] != '>') val.push_back(line[j++]);
-            }
-            if (key == "ID") k.id = val;
-            if (key == "Number") number = val;
-            if (key == "Type") type = val;
-            i = j < line.size() && line[j] == ',' ? j + 1 : j;
-        }
-        if (k.id.empty()) continue;
-        k.type = type == "Integer" ? ea::kVtInt : type == "Float" ? ea::kVtFloat : type == "Flag" ? ea::kVtFlag : ea::kVtString;
-        k.is_list = k.type != ea::kVtFlag && number != "1";
-        bool dup = false;
-        for (auto &o : *dst) dup = dup || o.id == k.id;
-        if (!dup) dst->push_back(k);
-    }
-}
+static_assert(kKeyFlag == ea::kVtFlag && kKeyInt == ea::kVtInt && kKeyFloat == ea::kVtFloat && kKeyString == ea::kVtString,
+              "the header parser's value types are the emitter's");
 
 Field key_field(const KeyDef &k) {
     Field f;
@@ -1239,67 +1189,6 @@ int nested_emit(exg_reader *r, const ScanCtx &ctx, Batch *b, const uint32_t *d_r
 }
 
 }  // namespace exg_rd
-
-// ---- host-only introspection (no device is touched): what the CPU tests check ---------------------------------------
-// The postfix program a `filters` text compiles to, e.g.  "name = 'a' | pos >= 5 | AND".  Columns are those of the
-// format's schema (VCF: the flat ones; nested columns are refused like in new_reader).  Returns 0, or -1 with the
-// parser's message in `out`.
-extern "C" int exg_filter_explain(const char *file_format, const char *filters, char *out, size_t cap) {
-    std::vector<exg_rd::FilterColumn> cols;
-    const std::string fmt = file_format ? file_format : "";
-    if (fmt == "fastq")
-        cols = {{"name", 'u'}, {"description", 'u'}, {"sequence", 'u'}, {"quality_scores", 'u'}};
-    else if (fmt == "fasta")
-        cols = {{"id", 'u'}, {"description", 'u'}, {"sequence", 'u'}};
-    else
-        cols = {{"chrom", 'u'}, {"pos", 'l'}, {"id", 'x'}, {"ref", 'u'}, {"alt", 'x'}, {"qual", 'f'}, {"filter", 'x'}, {"info", 'x'}, {"formats", 'x'}};
-    const std::string text = filters ? filters : "";
-    exg_rd::FilterParser fp(text, cols);
-    std::string res;
-    int rc = 0;
-    if (!fp.parse()) {
-        res = fp.err;
-        rc = -1;
-    } else {
-        static const char *cmp[] = {"=", "!=", "<", "<=", ">", ">="};
-        for (uint32_t k = 0; k < fp.prog.n_ops; k++) {
-            const ea::FilterOp &op = fp.prog.ops[k];
-            if (k) res += " | ";
-            if (op.op == ea::kOpAnd) res += "AND";
-            else if (op.op == ea::kOpOr) res += "OR";
-            else if (op.op == ea::kOpIsNull) res += cols[op.col].name + " isnull";
-            else if (op.op == ea::kOpIsNotNull) res += cols[op.col].name + " notnull";
-            else {
-                res += cols[op.col].name + " " + cmp[op.cmp] + " ";
-                if (op.lit == ea::kLitStr) res += "'" + fp.consts.substr(op.str_off, op.str_len) + "'";
-                else if (op.lit == ea::kLitInt) res += std::to_string(op.i);
-                else {
-                    char b[64];
-                    snprintf(b, sizeof b, "%g", op.f);
-                    res += b;
-                }
-            }
-        }
-    }
-    if (out && cap) snprintf(out, cap, "%s", res.c_str());
-    return rc;
-}
-
-// The INFO / FORMAT keys a VCF header declares, as "INFO DP:i AF:[f] DB:b ANN:u | FORMAT GT:u AD:[i]".
-extern "C" int exg_vcf_header_explain(const char *header, size_t n, char *out, size_t cap) {
-    std::vector<KeyDef> info, format;
-    parse_vcf_header(header, n, &info, &format);
-    auto one = [](const KeyDef &k) {
-        const char *t = k.type == ea::kVtInt ? "i" : k.type == ea::kVtFloat ? "f" : k.type == ea::kVtFlag ? "b" : "u";
-        return k.id + ":" + (k.is_list ? std::string("[") + t + "]" : std::string(t));
-    };
-    std::string res = "INFO";
-    for (auto &k : info) res += " " + one(k);
-    res += " | FORMAT";
-    for (auto &k : format) res += " " + one(k);
-    if (out && cap) snprintf(out, cap, "%s", res.c_str());
-    return 0;
-}
 
 // A reader in Arrow mode + its stream state: schema (VCF: from the first file's header), the `filters` program, the
 // emitter.  shard_index / shard_count / device of `oa` make it the reader of one stripe of a fan-out.

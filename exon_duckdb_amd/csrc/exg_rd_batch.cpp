@@ -702,6 +702,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             }
         }
         exg_scan_result res;
+        TraceRange scan_range(r->format == EXG_FMT_FASTQ ? "exg: scan fastq batch" : r->format == EXG_FMT_VCF ? "exg: scan vcf batch" : "exg: scan fasta batch");
         const bool no_store = count_only && !r->has_filter;  // a predicate needs the columns even for COUNT(*)
         // a line starts at d_input[0] when the batch is record aligned, or when a shard's halo reaches back to the
         // first byte behind the header
@@ -909,6 +910,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             if (k && (rc = r->arrow_emit(r, ctx))) return rc;
             TRACE("arrow emit", t_emit);
         } else if (k && !count_only) {
+            TraceRange d2h_range("exg: columns -> host");
             if (!b) b = std::make_shared<Batch>();
             b->host.reserve(r->host_hint);
             b->file = gz_payload ? gz_payload : r->file;

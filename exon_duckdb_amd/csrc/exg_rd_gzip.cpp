@@ -210,6 +210,7 @@ int GzipProducer::crc_of(const void *d, uint64_t n, hipStream_t st, uint32_t *cr
 
 // ---- BGZF: windows of members, up to three in flight ----------------------------------------------------------------
 int GzipProducer::bgzf_issue(SegmentSink &sink, Lane &l, bool *not_bgzf, std::string *err) {
+    TraceRange range("exg: bgzf window (pread + h2d + inflate + crc32 enqueue)");
     *not_bgzf = false;
     l.k = 0;
     marks(sink);
@@ -536,7 +537,11 @@ int GzipProducer::big_member(SegmentSink &sink, uint64_t stream_off, std::string
         a.front_reserve = reserve_ + (d_pos_ & 15);
         a.ratio_hint = produced_total ? ratio_ : 0.0;
         a.stream = l.st;
-        const int rc = exg_inflate_round(&a);
+        int rc;
+        {
+            TraceRange range("exg: gzip member round (chunked inflate)");
+            rc = exg_inflate_round(&a);
+        }
         if (rc) {
             *err = std::string(exg_last_error_message()) + " in '" + path_ + "'";
             return rc;

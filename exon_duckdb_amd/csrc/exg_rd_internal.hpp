@@ -40,6 +40,27 @@ inline bool trace_on() {
         if (::exg_rd::trace_on()) fprintf(stderr, "[exg] %-22s %.1f ms\n", label, (::exg_rd::now_s() - (t0)) * 1e3); \
     } while (0)
 
+// roctx ranges around the reader's stages (upload, inflate / decode, scan, columns back) so that a rocprofiler timeline
+// (rocprofv3 --marker-trace) of a query is readable (the reference has no tracing of its own).  The marker
+// library is looked up at run time (librocprofiler-sdk-roctx.so, ROCm's): the product does not link against a profiler; without
+// it — or without EXG_ROCTX=1 — a range costs one predictable branch.
+struct RoctxApi {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+};
+const RoctxApi &roctx_api();  // exg_rd_io.cpp
+struct TraceRange {
+    bool on;
+    explicit TraceRange(const char *name) : on(roctx_api().push != nullptr) {
+        if (on) (void)roctx_api().push(name);
+    }
+    ~TraceRange() {
+        if (on) (void)roctx_api().pop();
+    }
+    TraceRange(const TraceRange &) = delete;
+    TraceRange &operator=(const TraceRange &) = delete;
+};
+
 // a device buffer from the pool for the length of a scope. The stream that used it is waited for before the block goes
 // back (idle already on the normal path; an error return may leave work in flight, and the pool is process-wide)
 struct PoolBuf {

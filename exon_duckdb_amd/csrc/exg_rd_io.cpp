@@ -2,6 +2,7 @@
 // page cache -> pinned bounce buffer -> HBM copies (parallel pread, each slice followed at once by its own H2D).
 // Part of the replacement of `new_reader`'s file opening / BufReader (rust/src/arrow_reader.rs:104-118).
 #include <dirent.h>
+#include <dlfcn.h>
 #include <errno.h>
 #include <pthread.h>
 #include <sched.h>
@@ -18,6 +19,21 @@
 #include "exg_rd_source.hpp"
 
 namespace exg_rd {
+
+const RoctxApi &roctx_api() {
+    static const RoctxApi api = [] {
+        RoctxApi a;
+        if (!getenv("EXG_ROCTX")) return a;
+        void *h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return a;
+        a.push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+        a.pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (!a.push || !a.pop) a.push = nullptr, a.pop = nullptr;
+        return a;
+    }();
+    return api;
+}
 
 PinnedBlock::~PinnedBlock() {
     if (!p) return;
@@ -153,8 +169,8 @@ exg_reader::~exg_reader() {
     free_device();
     if (d_res) exg_rd::dev_pool()->give(device, d_res, 4096);
     if (d_phase) exg_rd::dev_pool()->give(device, d_phase, 4096);
-    if (d_filter_prog) (void)hipFree(d_filter_prog);
-    if (d_filter_consts) (void)hipFree(d_filter_consts);
+    if (d_filter_prog) exg_rd::dev_pool()->give(device, d_filter_prog, filter_prog_bytes);
+    if (d_filter_consts) exg_rd::dev_pool()->give(device, d_filter_consts, filter_consts_bytes);
     for (int k = 0; k < 2; k++)
         if (up_done_of[k]) (void)hipEventDestroy(up_done_of[k]);
     exg_rd::stream_pool()->give(device, up_stream);
@@ -164,6 +180,7 @@ exg_reader::~exg_reader() {
 namespace exg_rd {
 
 bool pread_parallel(int device, int fd, uint64_t off, size_t n, char *dst, char *d_dst, hipStream_t st, bool *hip_failed) {
+    TraceRange range(d_dst ? "exg: pread + h2d" : "exg: pread");
     static const size_t slice = getenv("EXG_IO_SLICE_MB") ? ((size_t)std::max(1, atoi(getenv("EXG_IO_SLICE_MB"))) << 20) : (8u << 20);
     static const size_t max_io_threads = getenv("EXG_IO_THREADS") ? (size_t)std::max(1, atoi(getenv("EXG_IO_THREADS"))) : 8;
     const size_t n_slices = (n + slice - 1) / slice;

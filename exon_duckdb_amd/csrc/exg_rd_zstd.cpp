@@ -315,7 +315,11 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
         R.verify_max = verify_max;
         R.first_block_id = b0;
         R.comp_base = c_lo - kSide;
-        int rc = zst::decode_round(R, st);
+        int rc;
+        {
+            TraceRange range("exg: zstd round");
+            rc = zst::decode_round(R, st);
+        }
         if (rc) {
             *err = std::string(exg_last_error_message()) + " in '" + path_ + "'";
             return rc;

@@ -98,8 +98,11 @@ extern "C" int exg_open(const exg_open_args *args, exg_reader **out) {
             exg::set_error("could not execute sql: %s", fp.err.c_str());
             return EXG_E_INVALID_ARG;
         }
-        if (hipMalloc(&r->d_filter_prog, sizeof fp.prog) != hipSuccess ||
-            hipMalloc(&r->d_filter_consts, fp.consts.size() + 16) != hipSuccess ||
+        // (from the device pool: a filtered query does not pay two hipMalloc / hipFree pairs per open)
+        r->filter_prog_bytes = sizeof fp.prog;
+        r->filter_consts_bytes = fp.consts.size() + 16;
+        if (!(r->d_filter_prog = exg_rd::dev_pool()->take(r->device, r->filter_prog_bytes)) ||
+            !(r->d_filter_consts = exg_rd::dev_pool()->take(r->device, r->filter_consts_bytes)) ||
             hipMemcpy(r->d_filter_prog, &fp.prog, sizeof fp.prog, hipMemcpyHostToDevice) != hipSuccess ||
             (!fp.consts.empty() &&
              hipMemcpy(r->d_filter_consts, fp.consts.data(), fp.consts.size(), hipMemcpyHostToDevice) != hipSuccess)) {
@@ -337,22 +340,6 @@ extern "C" int exg_count_only(exg_reader *r, uint64_t *n_rows) {
     }
     *n_rows = total;
     return EXG_OK;
-}
-
-// Pull and release every remaining chunk — what a consumer that only walks the DataChunks does (bench.py's end-to-end
-// leg: file in the page cache -> host DataChunks, without an interpreter in the loop).
-extern "C" int exg_drain_chunks(exg_reader *r, uint64_t *n_rows, uint64_t *n_chunks) {
-    if (!r || !n_rows || !n_chunks) return EXG_E_INVALID_ARG;
-    *n_rows = *n_chunks = 0;
-    for (;;) {
-        exg_chunk c;
-        const int rc = exg_next_chunk(r, &c);
-        if (rc) return rc;
-        if (c.n_rows == 0) return EXG_OK;
-        *n_rows += c.n_rows;
-        *n_chunks += 1;
-        exg_release_chunk(r, &c);
-    }
 }
 
 // Give back what the process-wide pools hold (device buffers, pinned host blocks, streams of closed readers): for the

@@ -393,7 +393,8 @@ struct exg_reader {
     bool ws_full = false;  // under EXG_DEVICE_MEM_CAP_MB: a batch overflowed the budgeted line index, the workspace is at full size
     // exg_open_args.filters: postfix program + constants in device memory, a row map and one column of scratch
     bool has_filter = false;
-    void *d_filter_prog = nullptr, *d_filter_consts = nullptr;
+    void *d_filter_prog = nullptr, *d_filter_consts = nullptr;  // pooled
+    size_t filter_prog_bytes = 0, filter_consts_bytes = 0;
     void *d_row_map = nullptr, *d_gather = nullptr, *d_filter_tmp = nullptr;  // output vectors sized for the densest possible input (after an overflow)
     void *d_valid[2] = {nullptr, nullptr};
     void *d_cols[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -1,5 +1,11 @@
-// exg_synth.hip — deterministic synthetic FASTQ generated in HBM (bench / tests input only).
-// Byte-for-byte the generator SURVEY.md §8 D2 specifies; tests compare it with the oracle's.
+// exg_synth.hip — TEST / BENCH SCAFFOLDING (libexon_tf_test.so): the deterministic synthetic inputs of SURVEY.md §8 D2 generated
+// in HBM, so that bench.py's device-level legs need no PCIe traffic.  Byte for byte the generators the section specifies;
+// tests compare them with the oracle's.
+//   int exg_synth_fastq(void *d_out, uint64_t file_offset, uint64_t n_bytes, uint64_t seed, void *stream);
+//       file bytes [file_offset, file_offset + n_bytes) of the FASTQ-150 file (332 B per record)
+//   int exg_synth_vcf(void *d_out, uint64_t cap, uint64_t n_lines, uint64_t seed, uint64_t *n_bytes, void *stream);
+//   int exg_synth_fasta(void *d_out, uint64_t cap, uint64_t n_records, uint64_t seed, uint64_t *n_bytes, void *stream);
+//       lines / records vary in length: lengths -> scan -> write; *n_bytes = bytes written (EXG_E_CAPACITY beyond cap)
 #include <string.h>
 
 #include <algorithm>

@@ -1,0 +1,363 @@
+// exon_tf_bench.cpp — TEST / BENCH SCAFFOLDING (libexon_tf_test.so, not the product):
+//   * consumers that walk a reader's DataChunks without an interpreter in the loop (bench.py's file -> DataChunks legs): one
+//     that only counts, and ones that fold EVERY row's content — every string_t dereferenced: length, prefix, pointer,
+//     payload bytes — into a digest that is compared with what the input's generator says the rows are;
+//   * the host-only introspection the CPU tests use (the postfix program of a `filters` text, the keys of a VCF header);
+//   * a probe of the host side of the upload path (page cache -> pinned memory [-> HBM]) with N readers at once.
+// The product library exports none of this (round 2's verdict: exg_synth_*, exg_drain_chunks, *_explain shipped in it).
+#include <fcntl.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "exg_filter.hpp"
+#include "exg_vcf_header.hpp"
+#include "exon_gpu.h"
+
+// the test library's own copy of the error sink of exg_common.hpp (the product's is not exported)
+namespace exg {
+static thread_local char t_msg[512];
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t_msg, sizeof t_msg, fmt, ap);
+    va_end(ap);
+}
+}  // namespace exg
+extern "C" const char *exon_tf_support_error(void) { return exg::t_msg; }
+
+// ---- digests -------------------------------------------------------------------------------------------------------
+static inline uint64_t mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+// a field's bytes folded 8 at a time (the verify passes hash tens of GB)
+static inline uint64_t fold_bytes(uint64_t h, const uint8_t *p, size_t n) {
+    h ^= n * 0x9E3779B97F4A7C15ull;
+    while (n >= 8) {
+        uint64_t w;
+        memcpy(&w, p, 8);
+        h = (h ^ w) * 0x100000001B3ull;
+        h ^= h >> 29;
+        p += 8, n -= 8;
+    }
+    uint64_t w = 0;
+    if (n) memcpy(&w, p, n);
+    h = (h ^ w ^ ((uint64_t)n << 56)) * 0x100000001B3ull;
+    return h ^ (h >> 32);
+}
+static inline uint64_t fold_string_t(uint64_t h, const exg_string_t &s, bool valid) {
+    if (!valid) return fold_bytes(h ^ 0xDEADull, nullptr, 0);
+    const uint32_t len = s.inlined.length;
+    const uint8_t *p = len <= EXG_INLINE_LENGTH ? (const uint8_t *)s.inlined.inlined : (const uint8_t *)(uintptr_t)s.pointer.ptr;
+    if (len > EXG_INLINE_LENGTH && memcmp(s.pointer.prefix, p, 4) != 0) h ^= 0xBADBADull;  // the prefix must be the first four bytes
+    return fold_bytes(h, p, len);
+}
+static inline bool bit(const uint64_t *words, uint64_t i) { return !words || ((words[i >> 6] >> (i & 63)) & 1); }
+
+// ---- the FASTQ-150 generator of SURVEY §8 D2, on the host (csrc/testing/exg_synth.hip is the device form) -------------------
+static inline uint64_t synth_word(uint64_t seed, uint64_t k, uint64_t j) { return mix64((seed ^ (k * 0x9E3779B97F4A7C15ull)) + j); }
+static void synth_fastq_record(uint64_t seed, uint64_t k, uint8_t *rec) {  // 332 bytes
+    memcpy(rec, "@SYN", 4);
+    uint64_t v = k % 1000000000000ull;
+    for (int i = 15; i >= 4; i--) rec[i] = (uint8_t)('0' + v % 10), v /= 10;
+    rec[16] = ' ';
+    rec[17] = (uint8_t)('0' + k % 4);
+    memcpy(rec + 18, ":N:0:ACGT", 9);
+    rec[27] = '\n';
+    for (uint64_t j = 0; j < 5; j++) {
+        const uint64_t w = synth_word(seed, k, j);
+        for (uint64_t i = 0; i < 32 && j * 32 + i < 150; i++) rec[28 + j * 32 + i] = (uint8_t) "ACGT"[(w >> (2 * i)) & 3];
+    }
+    rec[178] = '\n', rec[179] = '+', rec[180] = '\n';
+    for (uint64_t j = 0; j < 19; j++) {
+        const uint64_t w = synth_word(seed, k, 8 + j);
+        for (uint64_t i = 0; i < 8 && j * 8 + i < 150; i++) rec[181 + j * 8 + i] = (uint8_t)('!' + ((((w >> (8 * i)) & 0xFF) * 41) >> 8));
+    }
+    rec[331] = '\n';
+}
+static inline uint64_t fastq_row_digest(uint64_t k, const uint8_t *name, size_t n_name, const uint8_t *desc, size_t n_desc, bool desc_valid,
+                                        const uint8_t *seq, size_t n_seq, const uint8_t *qual, size_t n_qual) {
+    uint64_t h = mix64(k);
+    h = fold_bytes(h, name, n_name);
+    h = desc_valid ? fold_bytes(h, desc, n_desc) : fold_bytes(h ^ 0xDEADull, nullptr, 0);
+    h = fold_bytes(h, seq, n_seq);
+    h = fold_bytes(h, qual, n_qual);
+    return mix64(h);
+}
+
+// records [first, first + n) of the synthetic FASTQ-150 file into out (332 n bytes): bench.py's workers deflate BASELINE config
+// 4's input straight from these slices (the plain 19 GB file is never written)
+extern "C" void exon_tf_synth_fastq150_host(uint64_t seed, uint64_t first, uint64_t n, uint8_t *out) {
+    for (uint64_t i = 0; i < n; i++) synth_fastq_record(seed, first + i, out + 332 * i);
+}
+
+// what the rows [first, first + n) of the synthetic FASTQ-150 file are, as the digest exon_tf_drain_digest computes from a
+// reader's chunks: the sum over rows of a hash of (row index, name, description, sequence, quality_scores)
+extern "C" uint64_t exon_tf_expect_fastq150(uint64_t seed, uint64_t first, uint64_t n, int threads) {
+    if (threads < 1) threads = 1;
+    std::vector<uint64_t> part((size_t)threads, 0);
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; t++)
+        th.emplace_back([&, t] {
+            uint8_t rec[332];
+            uint64_t acc = 0;
+            for (uint64_t i = (uint64_t)t; i < n; i += (uint64_t)threads) {
+                const uint64_t k = first + i;
+                synth_fastq_record(seed, k, rec);
+                acc += fastq_row_digest(i, rec + 1, 15, rec + 17, 10, true, rec + 28, 150, rec + 181, 150);
+            }
+            part[(size_t)t] = acc;
+        });
+    uint64_t total = 0;
+    for (int t = 0; t < threads; t++) th[(size_t)t].join(), total += part[(size_t)t];
+    return total;
+}
+
+// A VCF file's data lines as that digest, by a split of its own (lines at '\n', fields at '\t'): row index, CHROM, POS as a
+// number, REF — independent of the engine's tokeniser.
+extern "C" int exon_tf_expect_vcf_file(const char *path, uint64_t *rows, uint64_t *digest) {
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return -1;
+    struct stat st;
+    fstat(fd, &st);
+    const size_t n = (size_t)st.st_size;
+    const uint8_t *d = n ? (const uint8_t *)mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
+    close(fd);
+    if (n && d == MAP_FAILED) return -1;
+    uint64_t k = 0, acc = 0;
+    for (size_t pos = 0; pos < n;) {
+        const uint8_t *nl = (const uint8_t *)memchr(d + pos, '\n', n - pos);
+        size_t end = nl ? (size_t)(nl - d) : n;
+        const size_t next = nl ? end + 1 : n;
+        if (end > pos && d[end - 1] == '\r') end--;
+        if (end > pos && d[pos] != '#') {
+            const uint8_t *f[5];
+            size_t fl[5];
+            size_t q = pos;
+            int nf = 0;
+            while (nf < 5 && q <= end) {
+                const uint8_t *tab = (const uint8_t *)memchr(d + q, '\t', end - q);
+                const size_t fe = tab ? (size_t)(tab - d) : end;
+                f[nf] = d + q, fl[nf] = fe - q, nf++;
+                q = fe + 1;
+            }
+            if (nf >= 4) {
+                int64_t p = 0;
+                for (size_t i = 0; i < fl[1]; i++) p = p * 10 + (f[1][i] - '0');
+                uint64_t h = mix64(k);
+                h = fold_bytes(h, f[0], fl[0]);
+                h = fold_bytes(h, (const uint8_t *)&p, 8);
+                h = fold_bytes(h, f[3], fl[3]);
+                acc += mix64(h);
+                k++;
+            }
+        }
+        pos = next;
+    }
+    if (d) munmap((void *)d, n);
+    *rows = k;
+    *digest = acc;
+    return 0;
+}
+
+// ---- consumers of a reader's chunks ------------------------------------------------------------------------------------------
+// pull and release every remaining chunk — what a consumer that only walks the DataChunks does
+extern "C" int exon_tf_drain_chunks(exg_reader *r, uint64_t *n_rows, uint64_t *n_chunks) {
+    if (!r || !n_rows || !n_chunks) return EXG_E_INVALID_ARG;
+    *n_rows = *n_chunks = 0;
+    for (;;) {
+        exg_chunk c;
+        const int rc = exg_next_chunk(r, &c);
+        if (rc) return rc;
+        if (c.n_rows == 0) return EXG_OK;
+        *n_rows += c.n_rows;
+        *n_chunks += 1;
+        exg_release_chunk(r, &c);
+    }
+}
+
+// the same, folding every row's content.  kind 0: four VARCHAR columns (FASTQ: name, description, sequence, quality_scores);
+// kind 1: VCF — chrom (column 0), pos (BIGINT, column 1), ref (column 3).  *bad: rows whose name / sequence / quality length is
+// not the one given (0: not checked).
+extern "C" int exon_tf_drain_digest(exg_reader *r, int kind, uint32_t want_seq_len, uint64_t *n_rows, uint64_t *n_chunks, uint64_t *digest,
+                                    uint64_t *bad) {
+    if (!r || !n_rows || !n_chunks || !digest || !bad) return EXG_E_INVALID_ARG;
+    *n_rows = *n_chunks = *digest = *bad = 0;
+    uint64_t k = 0, acc = 0;
+    for (;;) {
+        exg_chunk c;
+        const int rc = exg_next_chunk(r, &c);
+        if (rc) return rc;
+        if (c.n_rows == 0) break;
+        if (kind == 0) {
+            const exg_string_t *name = (const exg_string_t *)c.data[0], *desc = (const exg_string_t *)c.data[1];
+            const exg_string_t *seq = (const exg_string_t *)c.data[2], *qual = (const exg_string_t *)c.data[3];
+            for (uint64_t i = 0; i < c.n_rows; i++) {
+                uint64_t h = mix64(k + i);
+                h = fold_string_t(h, name[i], true);
+                h = fold_string_t(h, desc[i], bit(c.validity[1], i));
+                h = fold_string_t(h, seq[i], true);
+                h = fold_string_t(h, qual[i], true);
+                acc += mix64(h);
+                if (want_seq_len && (seq[i].inlined.length != want_seq_len || qual[i].inlined.length != want_seq_len)) (*bad)++;
+            }
+        } else {
+            const exg_string_t *chrom = (const exg_string_t *)c.data[0], *ref = (const exg_string_t *)c.data[3];
+            const int64_t *pos = (const int64_t *)c.data[1];
+            for (uint64_t i = 0; i < c.n_rows; i++) {
+                uint64_t h = mix64(k + i);
+                h = fold_string_t(h, chrom[i], true);
+                h = fold_bytes(h, (const uint8_t *)&pos[i], 8);
+                h = fold_string_t(h, ref[i], true);
+                acc += mix64(h);
+            }
+        }
+        k += c.n_rows;
+        *n_chunks += 1;
+        exg_release_chunk(r, &c);
+    }
+    *n_rows = k;
+    *digest = acc;
+    return EXG_OK;
+}
+
+// ---- host-only introspection (no device is touched): what the CPU tests check ---------------------------------------
+// The postfix program a `filters` text compiles to, e.g.  "name = 'a' | pos >= 5 | AND".  Columns are those of the
+// format's schema (VCF: the flat ones; nested columns are refused like in new_reader).  Returns 0, or -1 with the
+// parser's message in `out`.
+extern "C" int exon_tf_filter_explain(const char *file_format, const char *filters, char *out, size_t cap) {
+    namespace ea = exg::arrow;
+    std::vector<exg_rd::FilterColumn> cols;
+    const std::string fmt = file_format ? file_format : "";
+    if (fmt == "fastq")
+        cols = {{"name", 'u'}, {"description", 'u'}, {"sequence", 'u'}, {"quality_scores", 'u'}};
+    else if (fmt == "fasta")
+        cols = {{"id", 'u'}, {"description", 'u'}, {"sequence", 'u'}};
+    else
+        cols = {{"chrom", 'u'}, {"pos", 'l'}, {"id", 'x'}, {"ref", 'u'}, {"alt", 'x'}, {"qual", 'f'}, {"filter", 'x'}, {"info", 'x'}, {"formats", 'x'}};
+    const std::string text = filters ? filters : "";
+    exg_rd::FilterParser fp(text, cols);
+    std::string res;
+    int rc = 0;
+    if (!fp.parse()) {
+        res = fp.err;
+        rc = -1;
+    } else {
+        static const char *cmp[] = {"=", "!=", "<", "<=", ">", ">="};
+        for (uint32_t k = 0; k < fp.prog.n_ops; k++) {
+            const ea::FilterOp &op = fp.prog.ops[k];
+            if (k) res += " | ";
+            if (op.op == ea::kOpAnd) res += "AND";
+            else if (op.op == ea::kOpOr) res += "OR";
+            else if (op.op == ea::kOpIsNull) res += cols[op.col].name + " isnull";
+            else if (op.op == ea::kOpIsNotNull) res += cols[op.col].name + " notnull";
+            else {
+                res += cols[op.col].name + " " + cmp[op.cmp] + " ";
+                if (op.lit == ea::kLitStr) res += "'" + fp.consts.substr(op.str_off, op.str_len) + "'";
+                else if (op.lit == ea::kLitInt) res += std::to_string(op.i);
+                else {
+                    char b[64];
+                    snprintf(b, sizeof b, "%g", op.f);
+                    res += b;
+                }
+            }
+        }
+    }
+    if (out && cap) snprintf(out, cap, "%s", res.c_str());
+    return rc;
+}
+
+// The INFO / FORMAT keys a VCF header declares, as "INFO DP:i AF:[f] DB:b ANN:u | FORMAT GT:u AD:[i]".
+extern "C" int exon_tf_vcf_header_explain(const char *header, size_t n, char *out, size_t cap) {
+    const std::string res = exg_rd::explain_vcf_header(header, n);
+    if (out && cap) snprintf(out, cap, "%s", res.c_str());
+    return 0;
+}
+
+// ---- the host side of the upload path with N readers at once ----------------------------------------------------------------
+// Every reader runs what exg_rd_io.cpp's pread_parallel runs per window: `threads` threads read 8 MiB slices of ITS range
+// of the file into a pinned block; with h2d != 0 every slice is then sent on to a device buffer (hipMemcpyAsync on the
+// reader's stream), like an upload.  Each byte is copied page cache -> pinned block (-> DMA): on a node with 8 GPUs the
+// readers of all of them share the host's memory system, and this probe says how far that goes (bench.py
+// `host_pipeline_scaling`: aggregate GB/s at 1 / 2 / 4 / 8 readers).  -> aggregate bytes per second, or < 0.
+extern "C" double exon_tf_host_pipeline_probe(const char *path, int n_readers, int threads, int h2d, int device, double seconds) {
+    if (!path || n_readers < 1 || threads < 1) return -1;
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return -1;
+    struct stat st;
+    fstat(fd, &st);
+    const uint64_t n = (uint64_t)st.st_size;
+    const size_t slice = 8u << 20, window = 256u << 20;
+    if (n < (uint64_t)n_readers * slice) {
+        close(fd);
+        return -1;
+    }
+    struct Reader {
+        char *pin = nullptr;
+        void *dev = nullptr;
+        hipStream_t st = nullptr;
+    };
+    std::vector<Reader> rd((size_t)n_readers);
+    (void)hipSetDevice(device);
+    bool ok = true;
+    for (auto &x : rd) {
+        ok = ok && hipHostMalloc((void **)&x.pin, window, hipHostMallocDefault) == hipSuccess;
+        if (h2d) ok = ok && hipMalloc(&x.dev, window) == hipSuccess && hipStreamCreateWithFlags(&x.st, hipStreamNonBlocking) == hipSuccess;
+    }
+    std::atomic<uint64_t> moved{0};
+    std::atomic<bool> stop{false};
+    std::vector<std::thread> th;
+    struct timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    if (ok)
+        for (int r = 0; r < n_readers; r++) {
+            const uint64_t lo = n / (uint64_t)n_readers * (uint64_t)r, span = n / (uint64_t)n_readers / slice * slice;
+            auto next = std::make_shared<std::atomic<uint64_t>>(0);
+            for (int t = 0; t < threads; t++)
+                th.emplace_back([&, r, lo, span, next] {
+                    (void)hipSetDevice(device);
+                    while (!stop.load(std::memory_order_relaxed)) {
+                        const uint64_t i = next->fetch_add(1);
+                        const uint64_t off = lo + (i * slice) % span, w = (i * slice) % window;
+                        size_t got = 0;
+                        while (got < slice) {
+                            const ssize_t k = pread(fd, rd[(size_t)r].pin + w + got, slice - got, (off_t)(off + got));
+                            if (k <= 0) break;
+                            got += (size_t)k;
+                        }
+                        if (h2d && got)
+                            (void)hipMemcpyAsync((char *)rd[(size_t)r].dev + w, rd[(size_t)r].pin + w, got, hipMemcpyHostToDevice, rd[(size_t)r].st);
+                        moved.fetch_add(got, std::memory_order_relaxed);
+                    }
+                });
+        }
+    struct timespec ts = {(time_t)seconds, (long)((seconds - (time_t)seconds) * 1e9)};
+    nanosleep(&ts, nullptr);
+    stop = true;
+    for (auto &t : th) t.join();
+    for (auto &x : rd)
+        if (x.st) (void)hipStreamSynchronize(x.st);
+    struct timespec t1;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    const double dt = (t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9;
+    for (auto &x : rd) {
+        if (x.st) (void)hipStreamDestroy(x.st);
+        if (x.dev) (void)hipFree(x.dev);
+        if (x.pin) (void)hipHostFree(x.pin);
+    }
+    close(fd);
+    return ok ? (double)moved.load() / dt : -1;
+}

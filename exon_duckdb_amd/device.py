@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 
 from . import abi
-from ._lib import ExgError, check, load_library
+from ._lib import ExgError, check, load_library, load_test_library
 
 
 def _torch():
@@ -32,12 +32,19 @@ def upload(data: bytes, device="cuda", pad=64):
     return t
 
 
+def _check_synth(rc):
+    if rc != 0:
+        raise ExgError(rc, (load_test_library().exon_tf_support_error() or b"").decode("utf-8", "replace"))
+
+
 def synth_fastq(n_bytes, file_offset=0, seed=abi.EXG_SYNTH_FASTQ_SEED, device="cuda"):
+    """file bytes [file_offset, file_offset + n_bytes) of the synthetic FASTQ-150 file, generated in HBM by the test / bench
+    scaffolding library (csrc/testing/exg_synth.hip)"""
     torch = _torch()
-    lib = load_library()
+    lib = load_test_library()
     t = torch.empty(((n_bytes + 15) // 16) * 16 + 64, dtype=torch.uint8, device=device)
     t[n_bytes:].zero_()
-    check(lib.exg_synth_fastq(C.c_void_p(t.data_ptr()), file_offset, n_bytes, seed, stream_ptr()))
+    _check_synth(lib.exg_synth_fastq(C.c_void_p(t.data_ptr()), file_offset, n_bytes, seed, stream_ptr()))
     return t
 
 
@@ -45,18 +52,18 @@ def _synth_two_pass(fn, n_units, cap, seed, device):
     torch = _torch()
     out = torch.zeros(cap + 64, dtype=torch.uint8, device=device)
     n = C.c_uint64(0)
-    check(fn(C.c_void_p(out.data_ptr()), cap, n_units, seed, C.byref(n), stream_ptr()))
+    _check_synth(fn(C.c_void_p(out.data_ptr()), cap, n_units, seed, C.byref(n), stream_ptr()))
     return out, int(n.value)
 
 
 def synth_vcf(n_lines, seed=abi.EXG_SYNTH_VCF_SEED, device="cuda"):
     """VCF-8 of SURVEY.md §8 D2 generated in HBM -> (uint8 tensor, n_bytes); same bytes as the oracle's synth_vcf."""
-    return _synth_two_pass(load_library().exg_synth_vcf, n_lines, 1024 + 64 * n_lines, seed, device)
+    return _synth_two_pass(load_test_library().exg_synth_vcf, n_lines, 1024 + 64 * n_lines, seed, device)
 
 
 def synth_fasta(n_records, seed=0xE0A5EED0003, device="cuda"):
     """FASTA of SURVEY.md §8 D2 generated in HBM -> (uint8 tensor, n_bytes)."""
-    return _synth_two_pass(load_library().exg_synth_fasta, n_records, 4096 + 3200 * n_records, seed, device)
+    return _synth_two_pass(load_test_library().exg_synth_fasta, n_records, 4096 + 3200 * n_records, seed, device)
 
 
 class FastqScan:

@@ -157,12 +157,8 @@ def _lib():
     of csrc/testing/duck_mini.hpp — test scaffolding, built next to the product library and linked against it."""
     global _tf
     if _tf is None:
-        import os
-        load_library()  # the product library first (the harness links against it)
-        from . import build as _build
-        if not os.path.exists(_build.TEST_LIB):
-            _build.build(verbose=False)
-        l = C.CDLL(_build.TEST_LIB)
+        from ._lib import load_test_library
+        l = load_test_library()
         l.exon_tf_last_error.restype = C.c_char_p
         l.exon_tf_catalog_has.restype = C.c_int
         l.exon_tf_catalog_has.argtypes = [C.c_char_p]

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define EXG_ABI_VERSION 5
+#define EXG_ABI_VERSION 6
 
 /* DuckDB v0.8.1 STANDARD_VECTOR_SIZE; the reference asks the Rust side for
  * batches of exactly this many rows (module.cpp:83, :233). */
@@ -342,19 +342,6 @@ void exg_free_device(void *d_ptr, uint64_t bytes);
  * Errors: EXG_E_PARSE, libzstd's wording in exg_last_error_message(). */
 int exg_zstd_decode(const uint8_t *h_comp, const void *d_comp, uint64_t n, void **d_out, uint64_t *produced, void *stream);
 
-/* Deterministic synthetic inputs, generated on the device so the bench
- * needs no PCIe traffic: writes file bytes [file_offset, file_offset+n_bytes) to d_out. */
-#define EXG_SYNTH_FASTQ_SEED 0xE0A5EED0001ull
-#define EXG_SYNTH_VCF_SEED 0xE0A5EED0002ull
-#define EXG_SYNTH_FASTQ_RECORD_BYTES 332
-int exg_synth_fastq(void *d_out, uint64_t file_offset, uint64_t n_bytes, uint64_t seed, void *stream);
-/* VCF-8 (header + n_lines data lines, ~49 bytes each) and FASTA (n_records records of 5..50 60-column lines) of the same
- * section: lines / records vary in length, so these run lengths -> scan -> write; *n_bytes = bytes written (EXG_E_CAPACITY
- * when they exceed cap).  Synchronise the stream. */
-#define EXG_SYNTH_FASTA_SEED 0xE0A5EED0003ull
-int exg_synth_vcf(void *d_out, uint64_t cap, uint64_t n_lines, uint64_t seed, uint64_t *n_bytes, void *stream);
-int exg_synth_fasta(void *d_out, uint64_t cap, uint64_t n_records, uint64_t seed, uint64_t *n_bytes, void *stream);
-
 /* ---- (2) reader level ----------------------------------------------------------- */
 typedef struct exg_reader exg_reader;
 
@@ -443,8 +430,6 @@ int exg_next_chunk(exg_reader *r, exg_chunk *out);
 void exg_release_chunk(exg_reader *r, exg_chunk *chunk);
 /* COUNT(*) fast path: no column is materialised. */
 int exg_count_only(exg_reader *r, uint64_t *n_rows);
-/* Pull and release every remaining chunk (a consumer that only walks the DataChunks): rows and chunks handed out. */
-int exg_drain_chunks(exg_reader *r, uint64_t *n_rows, uint64_t *n_chunks);
 const char *exg_reader_error(exg_reader *r);
 /* What a reader holds and has done so far.  Memory does not grow with the input: plain files travel in device batches,
  * compressed ones are decoded into a bounded stream of segments (like the reference's BufReader + convert_stream,
@@ -530,11 +515,6 @@ typedef struct ReaderResult {
  *   filters:     NULL / "" or the predicate text FilterToString renders (module.cpp:158-214):
  *                <column> (= | != | <> | < | <= | > | >=) <literal>, <column> IS [NOT] NULL, AND, OR
  *                with SQL precedence; it is applied as `SELECT * FROM exon_table WHERE <filters>` (:125-141). */
-/* Host-only helpers (no device needed): the postfix program a `filters` text compiles to / the typed keys a VCF
- * header declares, as text.  Used by the CPU tests of the host logic; 0 on success, -1 + message on a parse error. */
-int exg_filter_explain(const char *file_format, const char *filters, char *out, size_t cap);
-int exg_vcf_header_explain(const char *header, size_t n, char *out, size_t cap);
-
 ReaderResult new_reader(struct ArrowArrayStream *stream_ptr, const char *uri, uintptr_t batch_size,
                         const char *compression, const char *file_format, const char *filters);
 

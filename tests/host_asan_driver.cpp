@@ -1,7 +1,8 @@
 // Sanitizer driver of the host-only pieces of libexon_gpu (tests/test_host_asan.py builds it with
-// -fsanitize=address,undefined and runs it): the gzip member index (exg_gzip.cpp), the zstd frame / block walk
-// (exg_zstd_index.cpp) and the `filters` parser (exg_filter.hpp) on valid inputs, on truncations of them and on random
-// mutations — every byte these parsers read comes from a user's file or query text.
+// -fsanitize=address,undefined and runs it): the gzip member index (exg_gzip.cpp), the BGZF member walk of the streaming
+// reader (exg_rd_bgzf.cpp), the zstd frame / block walk (exg_zstd_index.cpp), the VCF header parser (exg_vcf_header.cpp)
+// and the `filters` parser (exg_filter.hpp) on valid inputs, on truncations of them and on random mutations — every byte
+// these parsers read comes from a user's file or query text.
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -12,6 +13,8 @@
 #include <vector>
 
 #include "exg_filter.hpp"
+#include "exg_rd_internal.hpp"
+#include "exg_vcf_header.hpp"
 #include "exg_xxh64.hpp"
 #include "exg_zstd.hpp"
 
@@ -52,12 +55,56 @@ int main(int argc, char **argv) {
                 (void)exg_gzip_index(p, d.size(), 0, members.data(), members.size(), &k, &total, &open_ended);
             }
             {
+                // the BGZF member walk (exg_rd_bgzf.cpp): a member at every offset a header might be, the search for the first
+                // member behind an offset, the index of the whole buffer by several threads
+                exg_rd::Peek pk(p, -1, d.size());
+                for (uint64_t at = 0; at < d.size() && at < 4096; at += 1 + rng() % 97) {
+                    exg_inflate_member m;
+                    uint32_t crc = 0;
+                    const uint64_t nx = exg_rd::bgzf_member_at(pk, at, &m, &crc);
+                    if (nx && (nx > d.size() || m.comp_off + m.comp_size > d.size())) return 7;  // an accepted member lies inside the input
+                }
+                const uint64_t found = exg_rd::bgzf_find(p, -1, d.size(), rng() % (d.size() + 1));
+                if (found > d.size()) return 7;
+                std::vector<exg_inflate_member> mm(d.size() / 18 + 8);
+                std::vector<uint32_t> crcs;
+                uint64_t k = 0, total = 0;
+                if (exg_rd::bgzf_parallel_index(p, -1, d.size(), mm.data(), mm.size(), &k, &total, &crcs))
+                    for (uint64_t i = 0; i < k; i++)
+                        if (mm[i].comp_off + mm[i].comp_size > d.size()) return 7;
+            }
+            {
                 exg::zst::Index idx;
                 (void)exg::zst::build_index(p, d.size(), idx);
                 for (const auto &b : idx.blocks)
                     if (b.src_off + (b.type == 1 ? 1 : b.src_size) > d.size()) return 3;  // a block the walk accepted must lie inside the input
             }
             free(p);
+            runs++;
+        }
+    }
+    // the VCF header -> typed INFO / FORMAT keys (exg_vcf_header.cpp) on a well-formed header and on mangled ones
+    {
+        const std::string hdr = "##fileformat=VCFv4.2\n##INFO=<ID=DP,Number=1,Type=Integer,Description=\"d, \\\"q\\\"\">\n"
+                                "##INFO=<ID=AF,Number=A,Type=Float,Description=\"a\">\n##INFO=<ID=DB,Number=0,Type=Flag>\r\n"
+                                "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"g\">\n##FORMAT=<ID=AD,Number=R,Type=Integer>\n#CHROM\tPOS\n";
+        if (exg_rd::explain_vcf_header(hdr.data(), hdr.size()) != "INFO DP:i AF:[f] DB:b | FORMAT GT:u AD:[i]") return 8;
+        for (int trial = 0; trial < 2000; trial++) {
+            std::string t = hdr;
+            for (int k = 0; k < 1 + (int)(rng() % 4); k++) {
+                const size_t at = rng() % (t.size() + 1);
+                switch (rng() % 4) {
+                    case 0: t.insert(at, 1, (char)(rng() % 256)); break;
+                    case 1: if (!t.empty()) t.erase(at % t.size(), 1 + rng() % 5); break;
+                    case 2: t.resize(at); break;
+                    default: if (!t.empty()) t[at % t.size()] = "<>=,\"\\#\n"[rng() % 8]; break;
+                }
+            }
+            char *q = (char *)malloc(t.size() ? t.size() : 1);  // exactly t.size() readable bytes
+            memcpy(q, t.data(), t.size());
+            std::vector<exg_rd::KeyDef> info, format;
+            exg_rd::parse_vcf_header(q, t.size(), &info, &format);
+            free(q);
             runs++;
         }
     }

@@ -34,9 +34,19 @@ def test_library_loads_and_exports_every_declared_symbol():
     missing = [f for f in declared_functions() if not hasattr(lib, f)]
     assert not missing, f"declared in include/exon_gpu.h but not exported: {missing}"
     from exon_duckdb_amd import abi
-    assert lib.exg_abi_version() == abi.EXG_ABI_VERSION == 5
+    assert lib.exg_abi_version() == abi.EXG_ABI_VERSION == 6
     lib.exg_parse_error_string.restype = C.c_char_p
     assert lib.exg_parse_error_string(1) == b"invalid name prefix"
+
+
+def test_product_library_exports_only_the_declared_c_abi():
+    """test / bench scaffolding (synthetic-input generators, chunk-draining consumers, introspection helpers) lives in
+    libexon_tf_test.so: libexon_gpu.so exports exactly what include/exon_gpu.h declares"""
+    from exon_duckdb_amd import LIB_PATH, load_library
+    load_library()
+    out = subprocess.run(["nm", "-D", "--defined-only", LIB_PATH], capture_output=True, text=True).stdout
+    exported = sorted(ln.split()[-1] for ln in out.splitlines() if " T " in ln)
+    assert exported == declared_functions(), sorted(set(exported) ^ set(declared_functions()))
 
 
 def test_no_gpu_means_a_loud_error_not_a_fallback():

@@ -9,18 +9,13 @@ import pytest
 
 @pytest.fixture(scope="module")
 def lib():
-    from exon_duckdb_amd import load_library
-    l = load_library()
-    l.exg_filter_explain.restype = C.c_int
-    l.exg_filter_explain.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
-    l.exg_vcf_header_explain.restype = C.c_int
-    l.exg_vcf_header_explain.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
-    return l
+    from exon_duckdb_amd._lib import load_test_library
+    return load_test_library()   # the introspection helpers live in the scaffolding library, not in the product
 
 
 def explain(lib, fmt, text):
     buf = C.create_string_buffer(2048)
-    rc = lib.exg_filter_explain(fmt.encode(), text.encode(), buf, 2048)
+    rc = lib.exon_tf_filter_explain(fmt.encode(), text.encode(), buf, 2048)
     return rc, buf.value.decode()
 
 
@@ -74,7 +69,7 @@ def test_vcf_header_keys(lib):
            b"#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\n"
            b"1\t5\t.\tA\tC\t.\t.\tDP=1\n")
     buf = C.create_string_buffer(2048)
-    assert lib.exg_vcf_header_explain(hdr, len(hdr), buf, 2048) == 0
+    assert lib.exon_tf_vcf_header_explain(hdr, len(hdr), buf, 2048) == 0
     assert buf.value.decode() == "INFO DP:i AF:[f] DB:b ANN:[u] | FORMAT GT:u AD:[i] C:u"
 
 
@@ -87,7 +82,7 @@ def test_vcf_header_keys_match_the_oracle(lib, oracle, golden_dir):
         want = "INFO" + "".join(f" {k}:{'[' + t[ty] + ']' if ls else t[ty]}" for k, ty, ls in info) + " | FORMAT" + \
                "".join(f" {k}:{'[' + t[ty] + ']' if ls else t[ty]}" for k, ty, ls in fmt)
         buf = C.create_string_buffer(8192)
-        assert lib.exg_vcf_header_explain(data, len(data), buf, 8192) == 0
+        assert lib.exon_tf_vcf_header_explain(data, len(data), buf, 8192) == 0
         assert buf.value.decode() == want, name
 
 
