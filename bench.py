@@ -259,11 +259,18 @@ def host_pipeline_scaling(path, device_index=0, seconds=1.0):
     from exon_duckdb_amd import load_test_library
     tl = load_test_library()
     out = {"what": "aggregate page cache -> pinned host memory GB/s of N readers x 8 pread threads (8 MiB slices), "
-                   "`with_h2d`: each slice sent on to HBM like an upload (one GPU: the link bounds the sum)", "readers": {}}
+                   "`with_h2d`: each slice sent on to HBM like an upload (one GPU: the link bounds the sum); `adaptive`: with the thread "
+                   "count the library picks when N uploads run at once on this many usable cores", "readers": {}}
+    cores = effective_cores()
+    out["usable_cores"] = cores
     for n in (1, 2, 4, 8):
         a = tl.exon_tf_host_pipeline_probe(path.encode(), n, 8, 0, device_index, seconds)
         b = tl.exon_tf_host_pipeline_probe(path.encode(), n, 8, 1, device_index, seconds)
-        out["readers"][str(n)] = {"pinned_GB/s": round(a / 1e9, 2) if a > 0 else None, "with_h2d_GB/s": round(b / 1e9, 2) if b > 0 else None}
+        # what the library does by itself when n uploads run at once: min(8, max(2, usable cores / n)) threads each
+        t = min(8, max(2, cores // n))
+        c = tl.exon_tf_host_pipeline_probe(path.encode(), n, t, 0, device_index, seconds) if t != 8 else a
+        out["readers"][str(n)] = {"pinned_GB/s": round(a / 1e9, 2) if a > 0 else None, "with_h2d_GB/s": round(b / 1e9, 2) if b > 0 else None,
+                                  "threads_each_adaptive": t, "pinned_adaptive_GB/s": round(c / 1e9, 2) if c > 0 else None}
     return out
 
 

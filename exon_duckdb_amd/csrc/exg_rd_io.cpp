@@ -179,10 +179,43 @@ exg_reader::~exg_reader() {
 
 namespace exg_rd {
 
+// CPUs this process may really use: the affinity mask and the cgroup CPU quota, not the machine's core count
+static unsigned usable_cpus() {
+    static const unsigned v = [] {
+        unsigned n = std::max(1u, std::thread::hardware_concurrency());
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min<unsigned>(n, (unsigned)std::max(1, CPU_COUNT(&set)));
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char quota[64] = {0};
+            long period = 0;
+            if (fscanf(f, "%63s %ld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0)
+                n = std::min<unsigned>(n, (unsigned)std::max(1l, atol(quota) / period));
+            fclose(f);
+        }
+        return n;
+    }();
+    return v;
+}
+// Readers that are uploading at the same time share the host's cores and memory system (one per GPU inside a fan-out, or
+// one process per GPU): eight pread threads each is right for one reader, and measured WORSE than two each when eight
+// readers run on a box with sixteen usable cores (bench.py host_pipeline_scaling: 27 GB/s against 80).
+static std::atomic<int> g_uploads_in_flight{0};
+static size_t io_threads_now() {
+    static const int forced = getenv("EXG_IO_THREADS") ? std::max(1, atoi(getenv("EXG_IO_THREADS"))) : 0;
+    if (forced) return (size_t)forced;
+    int peers = std::max(1, g_uploads_in_flight.load(std::memory_order_relaxed));
+    if (const char *e = getenv("LOCAL_WORLD_SIZE")) peers = std::max(peers, atoi(e));  // one process per GPU (torchrun)
+    return (size_t)std::min(8u, std::max(2u, usable_cpus() / (unsigned)peers));
+}
+
 bool pread_parallel(int device, int fd, uint64_t off, size_t n, char *dst, char *d_dst, hipStream_t st, bool *hip_failed) {
     TraceRange range(d_dst ? "exg: pread + h2d" : "exg: pread");
     static const size_t slice = getenv("EXG_IO_SLICE_MB") ? ((size_t)std::max(1, atoi(getenv("EXG_IO_SLICE_MB"))) << 20) : (8u << 20);
-    static const size_t max_io_threads = getenv("EXG_IO_THREADS") ? (size_t)std::max(1, atoi(getenv("EXG_IO_THREADS"))) : 8;
+    struct InFlight {
+        InFlight() { g_uploads_in_flight.fetch_add(1, std::memory_order_relaxed); }
+        ~InFlight() { g_uploads_in_flight.fetch_sub(1, std::memory_order_relaxed); }
+    } in_flight;
+    const size_t max_io_threads = io_threads_now();
     const size_t n_slices = (n + slice - 1) / slice;
     const unsigned nt = (unsigned)std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), std::min<size_t>(n_slices, max_io_threads));
     std::atomic<size_t> next{0};

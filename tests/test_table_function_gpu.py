@@ -479,44 +479,28 @@ def test_plan_shards_policy(gpu, golden_dir, tmp_path, monkeypatch):
     assert plan(G(golden_dir, "test.fasta.gz"), "fasta")[0] == 1
 
 
-def test_bgzf_head_start_and_short_estimate(gpu, tmp_path):
-    """A BGZF file of more than two upload windows (2 x 256 MiB): the members of its first windows are indexed on their
-    own and inflated while the index of the whole file is still being made, into an output buffer sized from their
-    compression ratio.  COUNT(*) and the first / last rows must be those of the plain file — also when that estimate is
-    far too small (EXG_GZ_HEAD_EST_PCT=40 in a process of its own: the library reads it once) and what has been inflated
-    has to move into a buffer of the right size."""
-    import json
-    import subprocess
+def test_bgzf_of_many_windows_in_flight(gpu, tmp_path, monkeypatch):
+    """A BGZF file of several hundred MB — the input builder of bench.py's config 4: members deflated straight from the
+    generator by a pool of processes — read as a stream of segments, three windows of members in flight (and one, two:
+    EXG_GZ_LANES): COUNT(*), every row's content (the digest of the scaffolding library against the generator's), the
+    first / last rows."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
-    from exon_duckdb_amd import device
-    n_rec = 3_600_000                                   # 1.2 GB of FASTQ-150 -> ~620 MB of BGZF
-    n_bytes = 332 * n_rec
-    plain = str(tmp_path / "big.fastq")
-    with open(plain, "wb") as f:
-        step = 332 * 1_000_000
-        for o in range(0, n_bytes, step):
-            m = min(step, n_bytes - o)
-            f.write(device.synth_fastq(m, file_offset=o)[:m].cpu().numpy().tobytes())
+    from exon_duckdb_amd import abi, load_library, load_test_library
+    from exon_duckdb_amd.reader import ShardReader
+    n_rec = 16320 * 110                                 # 596 MB of FASTQ-150 -> ~310 MB of BGZF
     gz = str(tmp_path / "big.fastq.gz")
-    comp = bench.build_bgzf(plain, n_bytes, gz, max(1, min(bench.effective_cores(), 64)))
-    assert comp > 2 * (256 << 20), comp
-    code = (
-        "import sys, json\n"
-        "sys.path.insert(0, %r)\n"
-        "from exon_duckdb_amd.reader import ShardReader\n"
-        "rd = ShardReader(%r, 'fastq')\n"
-        "n = rd.count()\n"
-        "rows = ShardReader(%r, 'fastq', device_batch_bytes=64 << 20).rows()\n"
-        "print(json.dumps({'n': n, 'rows': len(rows), 'first': [x.decode() if x else None for x in rows[0]], 'last': [x.decode() if x else None for x in rows[-1]]}))\n"
-    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), gz, gz)
-    outs = []
-    for env in ({}, {"EXG_GZ_HEAD_EST_PCT": "40"}):
-        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
-        assert res.returncode == 0, res.stdout[-1000:] + res.stderr[-3000:]
-        outs.append(json.loads(res.stdout.strip().splitlines()[-1]))
-    for o in outs:
-        assert o["n"] == n_rec and o["rows"] == n_rec
-        assert o["first"][0] == "SYN000000000000" and o["last"][0] == "SYN%012d" % (n_rec - 1)
-    assert outs[0] == outs[1]
+    comp = bench.build_bgzf(abi.EXG_SYNTH_FASTQ_SEED, n_rec, gz, max(1, min(bench.effective_cores(), 64)))
+    assert comp > (256 << 20), comp
+    want = int(load_test_library().exon_tf_expect_fastq150(abi.EXG_SYNTH_FASTQ_SEED, 0, n_rec, 8))
+    lib = load_library()
+    for lanes in ("3", "1", "2"):
+        monkeypatch.setenv("EXG_GZ_LANES", lanes)
+        rows, chunks, got, bad = bench.reader_digest(lib, gz, "fastq", 150)
+        assert rows == n_rec and got == want and bad == 0, lanes
+        assert ShardReader(gz, "fastq").count() == n_rec
+    rd = ShardReader(gz, "fastq", device_batch_bytes=64 << 20)
+    rows = rd.rows()
+    rd.close()
+    assert len(rows) == n_rec and rows[0][0] == b"SYN000000000000" and rows[-1][0] == b"SYN%012d" % (n_rec - 1)
