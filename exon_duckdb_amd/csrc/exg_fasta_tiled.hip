@@ -79,6 +79,10 @@ __device__ __forceinline__ Chunk classify16(const uint4 v, uint32_t next_byte, b
     c.nl = nl;
     c.has_nl = nl != 0;
     uint32_t def_after = 0, strip = 0, def_region = 0;
+#ifdef EXG_FA_CLASSIFY_LOOP
+    // (the first form: a loop over the chunk's newline bits — one iteration for most chunks, but a wave runs as many as its
+    // worst lane needs, and the short last line of a record in front of a definition line puts two or three newlines into one
+    // chunk about once per row: ~150 of the row's ~270 wave instructions.  Kept as the A/B partner.)
     uint32_t m = nl;
     while (m) {
         const uint32_t b = (uint32_t)__ffs((int)m) - 1;
@@ -94,6 +98,18 @@ __device__ __forceinline__ Chunk classify16(const uint4 v, uint32_t next_byte, b
         }
     }
     if ((v.w >> 24) == '\r' && (valid >> 15) && next_byte == '\n') strip |= 1u << 15;
+#else
+    // Mask arithmetic on the 16-bit byte masks, the same for every lane whatever its newlines: '>' right behind a newline
+    // opens a definition line, CR counts only right in front of a newline (bit 16 = the byte behind the chunk), and a
+    // definition line's bytes — from behind its newline up to the next one — are one borrow chain: subtracting the start
+    // bits from the stop bits sets every bit in between (each start has no other stop bit between itself and its own).
+    const uint32_t gt = (match16(v, 0x3E3E3E3Eu) & valid) | (next_byte == '>' ? 0x10000u : 0u);
+    const uint32_t cr = match16(v, 0x0D0D0D0Du) & valid;
+    def_after = nl & (gt >> 1);
+    strip = cr & ((nl | (next_byte == '\n' ? 0x10000u : 0u)) >> 1);
+    const uint32_t stops = nl | 0x10000u, starts = (def_after << 1) & 0xFFFFu;
+    def_region = (stops - starts) & ~stops & 0xFFFFu;
+#endif
     c.def_after = def_after;
     c.last_is_def = c.has_nl && ((def_after >> (31 - __clz((int)nl))) & 1u);
     const uint32_t first = c.has_nl ? (uint32_t)__ffs((int)nl) - 1 : 16u;

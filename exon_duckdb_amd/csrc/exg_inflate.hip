@@ -16,14 +16,17 @@
 //   * the newest 2 Ki bytes of the window are an LDS ring, older bytes are read back from the output the wave itself
 //     flushed to HBM (every completed 1 KiB, 16 B/lane stores); matches are copied by all lanes (source index folded
 //     modulo the distance, so overlapping copies are exact).
-// LDS: 6.4 KiB per member, 80 VGPRs => 6 waves per SIMD, 24 members per CU, 6144 in flight.
+// LDS: 5112 B per member (four granules), 64 VGPRs => 8 waves per SIMD, 32 members per CU, 8192 in flight.
 #include <stdlib.h>
 
 #include "exg_inflate_core.hpp"
 
 namespace exg {
 template <uint32_t RING, int EMIT>
-__global__ __launch_bounds__(64, RING <= 2048 ? 6 : 1) void k_inflate(const uint8_t *__restrict__ d_comp, uint8_t *d_out,
+#ifndef EXG_INFLATE_WAVES
+#define EXG_INFLATE_WAVES 8
+#endif
+__global__ __launch_bounds__(64, RING <= 2048 ? EXG_INFLATE_WAVES : 1) void k_inflate(const uint8_t *__restrict__ d_comp, uint8_t *d_out,
                                                 const InflateMember *__restrict__ members, InflateStatus *status,
                                                 uint32_t n_members) {
     __shared__ __attribute__((aligned(16))) InflateLdsT<false, RING> s;

@@ -23,10 +23,28 @@ struct InflateStatus {
 };
 
 static constexpr int kWinBytes = 32768;
-static constexpr int kInRing = 512;                  // two chunks of the compressed input
-static constexpr int kInChunk = kInRing / 2, kInChunkBitsLog2 = 11;  // 256 B = 2048 bits
+// LDS decides how many members a CU decodes at once, and this decode is a serial chain per member: what it needs is
+// co-resident waves.  Round 3: 10 / 9-bit tables, a 512-byte input ring and six waves per SIMD (6.4 KiB per member) gave 63 GB/s
+// of FASTQ; 9 / 9 bits, a 256-byte input ring (chunks of 128 B, two bytes per lane) fit 5112 B = four LDS granules: EIGHT
+// waves per SIMD, 32 members per CU, 8192 in flight -> 70 GB/s (VCF 75 -> 83, FASTA 67 -> 73), although a 9-bit literal table
+// sends more codes to the serial decoder (the same tables at six waves: 59 GB/s) and 64 VGPRs spill 30 registers
+// (tools/ab_lib.sh, one box; -DEXG_INFLATE_LIT_BITS=10 -DEXG_INFLATE_DIST_BITS=9 -DEXG_INFLATE_IN_RING=512 -DEXG_INFLATE_WAVES=6
+// builds the former shape).
+#ifndef EXG_INFLATE_IN_RING
+#define EXG_INFLATE_IN_RING 256
+#endif
+static constexpr int kInRing = EXG_INFLATE_IN_RING;  // two chunks of the compressed input (512: chunks of 256 B, a dword per lane; 256: 128 B, two bytes per lane)
+static_assert(kInRing == 512 || kInRing == 256, "two chunks of 64 dwords or of 64 half-words");
+static constexpr int kInChunk = kInRing / 2, kInChunkBitsLog2 = kInRing == 512 ? 11 : 10;  // 256 B = 2048 bits
+static constexpr int kInWord = kInChunk / 64;        // bytes of a chunk every lane loads and stages
 static constexpr int kInMirror = 40;                 // the ring's first bytes again behind it: one window read (36 B) never wraps
-static constexpr int kLitBits = 10, kDistBits = 9;
+#ifndef EXG_INFLATE_LIT_BITS
+#define EXG_INFLATE_LIT_BITS 9
+#endif
+#ifndef EXG_INFLATE_DIST_BITS
+#define EXG_INFLATE_DIST_BITS 9
+#endif
+static constexpr int kLitBits = EXG_INFLATE_LIT_BITS, kDistBits = EXG_INFLATE_DIST_BITS;
 
 // SYM = false: the window holds bytes (a gzip member decoded from its first bit).
 // SYM = true:  the window holds 16-bit symbols — a byte, or 0x8000 | i for "byte i of the 32 KiB in front of where
@@ -121,10 +139,17 @@ __device__ __forceinline__ BitBase bit_base(const uint8_t *d_comp, unsigned long
     return b;
 }
 
-// this lane's dword of 256-byte chunk c of the compressed input (coalesced, 4 B per lane)
+// this lane's word of chunk c of the compressed input (coalesced, 4 or 2 B per lane)
 __device__ __forceinline__ uint32_t chunk_word(const BitIn &br, uint32_t c, uint32_t lane) {
-    const uint32_t off = c * kInChunk + lane * 4;
-    return off < ((br.limit + 15) & ~15u) ? *reinterpret_cast<const uint32_t *>(br.g0 + off) : 0u;
+    const uint32_t off = c * kInChunk + lane * kInWord;
+    if (off >= ((br.limit + 15) & ~15u)) return 0u;
+    if constexpr (kInWord == 4) return *reinterpret_cast<const uint32_t *>(br.g0 + off);
+    return *reinterpret_cast<const uint16_t *>(br.g0 + off);
+}
+template <class L>
+__device__ __forceinline__ void stage_word(L &s, uint32_t at, uint32_t w) {
+    if constexpr (kInWord == 4) *reinterpret_cast<uint32_t *>(s.in + at) = w;
+    else *reinterpret_cast<uint16_t *>(s.in + at) = (uint16_t)w;
 }
 // staging starts at the chunk that holds bit br.bitpos
 __device__ __forceinline__ void start_input(BitIn &br, uint32_t lane) {
@@ -137,8 +162,8 @@ template <class L>
 __device__ __forceinline__ void ensure(L &s, BitIn &br, uint32_t lane) {
     uint32_t c = (uint32_t)(br.bitpos >> kInChunkBitsLog2);
     while (c + 1 >= br.loaded) {
-        *reinterpret_cast<uint32_t *>(s.in + ((br.loaded & 1) * kInChunk + lane * 4)) = br.pre;
-        if (!(br.loaded & 1) && lane < kInMirror / 4) *reinterpret_cast<uint32_t *>(s.in + (kInRing + lane * 4)) = br.pre;
+        stage_word(s, (br.loaded & 1) * kInChunk + lane * kInWord, br.pre);
+        if (!(br.loaded & 1) && lane < kInMirror / kInWord) stage_word(s, kInRing + lane * kInWord, br.pre);
         br.loaded++;
         br.pre = chunk_word(br, br.loaded, lane);
     }

@@ -3,6 +3,11 @@ import ctypes as C
 
 import numpy as np
 
+try:  # torch (allocator + streams) brings a HIP runtime of its own: it must be in the process BEFORE libexon_gpu.so binds to
+    import torch as _torch_module  # one, so the module that needs it imports it first (see _lib.load_library)
+except ImportError:  # pragma: no cover
+    _torch_module = None
+
 from . import abi
 from ._lib import ExgError, check, load_library, load_test_library
 

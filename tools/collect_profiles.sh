@@ -3,7 +3,7 @@
 #   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r02_a'
 # Writes gpurun_out/<tag>_*; tools/pmc_summary.py then condenses them into profiles/.
 set -u
-TAG=${1:-r02_a}
+TAG=${1:-r03_a}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
@@ -20,7 +20,7 @@ done
 # the configs legs (config 1 FASTA, config 3 VCF, config 4 BGZF inflate + CRC-32, end to end): every kernel of them
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_configs -o kt --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --launches-per-step 2 --no-cpu-baseline --gz-gb 2 --e2e-gb 2 > $OUT/${TAG}_kt_configs.log 2>&1
 # zstd decode (512 MB single frame, level 3)
-rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_zstd -o kt --output-format csv -- python3 $ROOT/tools/zstd_probe.py 512 > $OUT/${TAG}_kt_zstd.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_zstd -o kt --output-format csv -- python3 $ROOT/tools/zstd_stream_probe.py > $OUT/${TAG}_kt_zstd.log 2>&1
 # single-member gzip through the reader (chunked decode)
 GZ_RECORDS=800000 GZ_ONLY_SINGLE=1 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_gzstream -o kt --output-format csv -- python3 $ROOT/tools/gz_probe.py > $OUT/${TAG}_kt_gzstream.log 2>&1
 # FASTA (1 GB), VCF (5 GB), BGZF inflate alone: per-kernel times

@@ -3,6 +3,7 @@ SOAK_SEEDS (default 300) more seeds."""
 import os, sys, time, zlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+import torch  # noqa: F401  (its HIP runtime first: the library binds to the one that is there)
 from exon_duckdb_amd import load_library
 from tests.test_inflate_gpu import bgzf, roundtrip
 from tests.test_inflate_stream_gpu import stream_inflate

@@ -1,0 +1,33 @@
+"""COUNT(*) through the reader on a single-frame .zst of FASTQ-150 (level 3, checksum on) for several round sizes:
+ZST_GB (2) GB of content; run on the GPU box."""
+import os, sys, time, tempfile
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import torch
+from exon_duckdb_amd import device
+from exon_duckdb_amd.reader import ShardReader
+from zstd_util import compress
+
+gb = float(os.environ.get("ZST_GB", "2"))
+n = int(gb * 1e9) // 332 * 332
+data = device.synth_fastq(n)[:n].cpu().numpy().tobytes()
+t0 = time.time()
+comp = compress(data, 3, os.environ.get("ZST_CHECK", "1") == "1")
+print(f"compressed {n/1e9:.2f} GB -> {len(comp)/1e9:.2f} GB in {time.time()-t0:.1f} s", flush=True)
+d = tempfile.mkdtemp(dir="/dev/shm")
+p = os.path.join(d, "x.fastq.zst")
+open(p, "wb").write(comp)
+del data, comp
+for batch in os.environ.get("ZST_BATCHES", "0,536870912,1073741824,4294967296").split(","):
+    best = None
+    for _ in range(3):
+        r = ShardReader(p, "fastq", device_batch_bytes=int(batch))
+        t0 = time.perf_counter()
+        rows = r.count()
+        dt = time.perf_counter() - t0
+        st = r.stats()
+        r.close()
+        assert rows == n // 332
+        best = dt if best is None or dt < best else best
+    print(f"device_batch_bytes={int(batch) >> 20} MiB: {best*1e3:.1f} ms = {n/best/1e9:.1f} GB/s of FASTQ ({st['decoded_segments']} segments, peak {st['device_bytes_peak']>>20} MiB)", flush=True)
+os.unlink(p); os.rmdir(d)
