@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <deque>
 #include <memory>
+#include <thread>
 
 #include "exg_rd_source.hpp"
 
@@ -83,6 +84,7 @@ public:
         if (const char *e = getenv("EXG_GZ_LANES")) n_lanes_ = (size_t)std::max(1, atoi(e));
     }
     ~GzipProducer() override {
+        for (auto &l : lanes_) l->join_read();
         for (auto &l : lanes_) {
             if (l->st) stream_pool()->give(device_, l->st);  // (synchronises it: the blocks below are idle afterwards)
             if (l->ev) (void)hipEventDestroy(l->ev);
@@ -101,8 +103,22 @@ private:
         Segment seg;
         uint64_t k = 0, first_member = 0;
         std::vector<uint32_t> crc_expect;
+        // the window this lane will decode next, being read (pread + H2D enqueue) on a thread of its own while the producer
+        // waits for the device: file bytes [ra_a0, ra_a0 + ra_len)
+        std::thread ra;
+        bool ra_valid = false, ra_ok = false, ra_hip_failed = false;
+        uint64_t ra_a0 = 0, ra_len = 0;
         explicit Lane(int dev) : d_comp(dev), d_tab(dev) {}
+        void join_read() {
+            if (ra.joinable()) ra.join();
+        }
+        ~Lane() { join_read(); }
     };
+    void start_read(Lane &l, uint64_t a0, uint64_t len);
+    uint64_t window_bytes() const {  // compressed bytes that should inflate to about one segment (+ a member's worth)
+        const uint64_t want = (uint64_t)((double)target_ / std::max(1.0, ratio_) * 1.05) + (128u << 10);
+        return std::max<uint64_t>(want, 256u << 10);
+    }
     Lane *lane(size_t i, std::string *err);
     int new_segment(SegmentSink &sink, uint64_t out_bytes, Segment *seg, std::string *err);
     int bgzf_run(SegmentSink &sink, std::string *err);
@@ -214,19 +230,29 @@ int GzipProducer::bgzf_issue(SegmentSink &sink, Lane &l, bool *not_bgzf, std::st
     *not_bgzf = false;
     l.k = 0;
     marks(sink);
-    const uint64_t a0 = c_pos_ & ~15ull;
-    // compressed bytes that should inflate to about one segment (+ a member's worth, so that a window never ends short)
-    uint64_t want = (uint64_t)((double)target_ / std::max(1.0, ratio_) * 1.05) + (128u << 10);
-    want = std::max<uint64_t>(want, 256u << 10);
-    const uint64_t len = std::min<uint64_t>(want + (c_pos_ - a0), c_end_ - a0);
-    if (!l.pin.ensure((size_t)len + 64) || !l.d_comp.ensure((size_t)len + 64)) {
-        *err = "out of memory for a window of compressed bytes of '" + path_ + "'";
-        return EXG_E_HIP;
+    // The window: read ahead by this lane's thread while the producer waited for the device (it begins a little in front of
+    // where the window before was EXPECTED to end, so the member that really comes next lies inside it), or read now.
+    l.join_read();
+    uint64_t a0 = c_pos_ & ~15ull, len = 0;
+    bool have = false;
+    if (l.ra_valid) {
+        l.ra_valid = false;
+        have = l.ra_ok && c_pos_ >= l.ra_a0 && c_pos_ + (256u << 10) <= l.ra_a0 + l.ra_len;
+        if (!have && l.ra_ok && c_pos_ >= l.ra_a0 && l.ra_a0 + l.ra_len >= c_end_) have = true;  // (the file's last window)
+        if (have) a0 = l.ra_a0, len = l.ra_len;
+        else if (hipStreamSynchronize(l.st) != hipSuccess) (void)hipGetLastError();  // (its copies must not land in the buffer read next)
     }
-    bool hip_failed = false;
-    if (!pread_parallel(device_, fd_, a0, (size_t)len, l.pin.p, (char *)l.d_comp.p, l.st, &hip_failed)) {
-        *err = hip_failed ? "hipMemcpyAsync failed" : "short read of '" + path_ + "'";
-        return hip_failed ? EXG_E_HIP : EXG_E_IO;
+    if (!have) {
+        len = std::min<uint64_t>(window_bytes() + (c_pos_ - a0), c_end_ - a0);
+        if (!l.pin.ensure((size_t)len + 64) || !l.d_comp.ensure((size_t)len + 64)) {
+            *err = "out of memory for a window of compressed bytes of '" + path_ + "'";
+            return EXG_E_HIP;
+        }
+        bool hip_failed = false;
+        if (!pread_parallel(device_, fd_, a0, (size_t)len, l.pin.p, (char *)l.d_comp.p, l.st, &hip_failed)) {
+            *err = hip_failed ? "hipMemcpyAsync failed" : "short read of '" + path_ + "'";
+            return hip_failed ? EXG_E_HIP : EXG_E_IO;
+        }
     }
     // the members that are complete in the window, up to a segment's worth of output
     Peek pk((const uint8_t *)l.pin.p, -1, len);
@@ -307,6 +333,25 @@ int GzipProducer::bgzf_issue(SegmentSink &sink, Lane &l, bool *not_bgzf, std::st
     return EXG_OK;
 }
 
+// file bytes [a0, a0 + len) -> the lane's pinned block -> its device block, on a thread of the lane's (the lane is idle)
+void GzipProducer::start_read(Lane &l, uint64_t a0, uint64_t len) {
+    l.join_read();
+    l.ra_valid = false;
+    if (!l.pin.ensure((size_t)len + 64) || !l.d_comp.ensure((size_t)len + 64)) return;  // (the window is read when it is its turn)
+    l.ra_a0 = a0, l.ra_len = len;
+    l.ra_ok = false;
+    l.ra_valid = true;
+    Lane *lp = &l;
+    const int dev = device_, fd = fd_;
+    MemMeter *meter = tl_meter();
+    l.ra = std::thread([lp, dev, fd, a0, len, meter] {
+        (void)hipSetDevice(dev);
+        pin_to_device_node(dev);
+        MeterScope scope(meter);
+        lp->ra_ok = pread_parallel(dev, fd, a0, (size_t)len, lp->pin.p, (char *)lp->d_comp.p, lp->st, &lp->ra_hip_failed);
+    });
+}
+
 int GzipProducer::bgzf_finish(Lane &l, std::string *err) {
     GZ_HIP(hipEventSynchronize(l.ev));
     const exg_inflate_member *m = (const exg_inflate_member *)l.tab.p;
@@ -360,6 +405,19 @@ int GzipProducer::bgzf_run(SegmentSink &sink, std::string *err) {
             inflight.push_back(next_lane);
             next_lane = (next_lane + 1) % n_lanes;
         }
+        // the window after the ones in flight is read while this thread waits for the device below: its lane is the one that
+        // will be issued next, idle as soon as its last segment has been handed over
+        auto read_ahead = [&] {
+            static const bool off = getenv("EXG_GZ_NO_READAHEAD") != nullptr;
+            if (off || stop || c_pos_ >= c_end_ || lanes_.size() <= next_lane) return;
+            Lane &nl = *lanes_[next_lane];
+            if (nl.ra_valid || nl.ra.joinable()) return;
+            for (size_t i : inflight)
+                if (i == next_lane) return;  // still decoding
+            const uint64_t a0 = c_pos_ & ~15ull;  // (exact: every window in front of it has been walked)
+            start_read(nl, a0, std::min<uint64_t>(window_bytes() + (c_pos_ - a0), c_end_ - a0));
+        };
+        read_ahead();
         if (inflight.empty()) break;
         Lane &l = *lanes_[inflight.front()];
         std::string e2;
@@ -375,7 +433,14 @@ int GzipProducer::bgzf_run(SegmentSink &sink, std::string *err) {
             drain();
             return EXG_OK;  // the consumer is gone
         }
+        read_ahead();
         if (c_pos_ >= c_end_ && inflight.empty()) break;
+    }
+    // a window read ahead that is not going to be decoded here (another kind of member follows, or an error): let it land
+    for (auto &lp : lanes_) {
+        lp->join_read();
+        if (lp->ra_valid) (void)hipStreamSynchronize(lp->st);
+        lp->ra_valid = false;
     }
     return rc;
 }
