@@ -179,7 +179,11 @@ typedef struct exg_vcf_scan_args {
 
 /* FASTA: id, description, sequence.  The sequence is the concatenation of the
  * record's lines with terminators removed, so it is materialised in a
- * compacted payload buffer (d_seq_payload); id/description point into d_input. */
+ * compacted payload buffer (d_seq_payload); id/description point into d_input.
+ * A buffer begins with a record (lead = 0, EXG_F_BOF).  Without EXG_F_EOF it is a batch of a longer input: the last
+ * record in it is still open (its sequence may go on behind the buffer) and is left to the next batch — n_records,
+ * the columns and payload_bytes are those of the records in front of it, consumed_bytes = where its '>' line begins
+ * (0 records when the buffer holds only that one: widen the batch — a FASTA record can be as long as the input). */
 typedef struct exg_fasta_scan_args {
     const void *d_input;
     uint64_t n_bytes;
@@ -356,15 +360,22 @@ typedef struct exg_open_args {
                               * new_reader's: evaluated on the device, only the rows where it is TRUE are copied back.
                               * Nested columns (VCF id / alt / filter / info / formats) are refused, like in new_reader. */
     uint32_t shard_index;    /* byte-range shards of every file: this reader yields the records / lines that */
-    uint32_t shard_count;    /* END in its 1/shard_count of the bytes behind the header; 0 or 1 = the whole file.  One process
-                              * per GPU opens the same path with its rank: the shards partition the rows, in file order, with
-                              * no exchange (the FASTQ 4-line phase at a cut is found from the bytes around it).  A record
-                              * longer than the 1 MiB halo across a cut is an error, never a silent loss.  BGZF inputs
-                              * (bgzip FASTQ / VCF) are sharded by members (a member belongs to the shard in whose bytes its
-                              * header begins; each rank uploads and inflates only its own members + a halo of members in
-                              * front, a VCF also the leading members that hold the header).  FASTA: a record belongs to
-                              * the shard in whose bytes its '>' line begins; a shard is that run of whole records.  Not
-                              * sharded (EXG_E_UNSUPPORTED): gzip without member sizes, gzip FASTA. */
+    uint32_t shard_count;    /* END in its 1/shard_count of the bytes behind the header.  One process per GPU opens the same
+                              * path with its rank: the shards partition the rows, in file order, with no exchange (the FASTQ
+                              * 4-line phase at a cut is found from the bytes around it).  The first batch of a shard carries
+                              * 1 MiB (EXG_SHARD_HALO) of the bytes in front of its cut; when the record that ends behind the
+                              * cut begins further back, the halo grows until it holds it: a record of any length across a
+                              * cut is found, like the unsharded scan finds it.  BGZF inputs are sharded by members (a member
+                              * belongs to the shard in whose bytes its header begins; each rank uploads and inflates only its
+                              * own members + a halo of members in front, a VCF also the leading members that hold the
+                              * header), multi-frame zstd inputs by frames.  FASTA: a record belongs to the shard in whose
+                              * bytes (bgzip: members' bytes, zstd: frames' bytes) its '>' line begins; a shard is that run of
+                              * whole records.  Not sharded (EXG_E_UNSUPPORTED): gzip without member sizes.
+                              * shard_count = 1: the whole input through this one reader and its device.
+                              * shard_count = 0: the whole input, and the reader may FAN OUT by itself: on a box with several
+                              * devices (and an input that can be sharded) it cuts the input into stripes of ~1 GiB, reads
+                              * them with worker threads on all devices and hands their batches out here in file order
+                              * (exg_count_only sums them) — one consumer-facing stream, N GPUs. */
 } exg_open_args;
 
 #define EXG_TYPE_VARCHAR 1
