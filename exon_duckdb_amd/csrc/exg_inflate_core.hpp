@@ -649,6 +649,9 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                     }
                 };
                 uint32_t advance;
+#ifdef EXG_INFLATE_PAD_S
+                uint32_t advance_pad = 0;
+#endif
                 bool slow_token = false;
                 if constexpr (EMIT >= 2) {
                     // ---- NW x 64 bit offsets per step: lane l decodes the tokens that would start at bits l, 64 + l, ...  What
@@ -693,6 +696,18 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                         const uint32_t y = mask_sel(len_mask[k], e[k], de[k] << 3);
                         stop_mask[k] = __ballot(y - 1u >= 0xFFFu);
                     }
+#ifdef EXG_INFLATE_PAD_V  // development probe: what a step costs when the vector unit has this many more instructions to issue
+#pragma unroll
+                    for (int i = 0; i < EXG_INFLATE_PAD_V; i++) asm volatile("v_or_b32 %0, %0, %0" : "+v"(tl[0]));
+#endif
+#ifdef EXG_INFLATE_PAD_S  // ... and the scalar unit
+                    {
+                        uint32_t pad_s = sgpr(advance_pad);
+#pragma unroll
+                        for (int i = 0; i < EXG_INFLATE_PAD_S; i++) asm volatile("s_or_b32 %0, %0, %0" : "+s"(pad_s) : : "scc");
+                        advance_pad = pad_s;
+                    }
+#endif
                     // The real chain from offset 0, window after window.  The walk is the scalar unit's main load (~15 tokens
                     // per window), so its loop is written out: the position is kept as cur - 64 (mod 2^32; bit set and lane
                     // select use the low six bits), so that the add's carry is the exit test — three scalar instructions and

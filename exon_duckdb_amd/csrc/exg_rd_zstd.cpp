@@ -158,9 +158,13 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
         ~StreamBack() { stream_pool()->give(dev, s); }  // (synchronises it)
     } stream_back{device_, st};
     zst::Index idx;
+    std::string damage;  // a malformed or truncated stream: the rows in front of the damage first, like a streaming decoder
     if (!zst::build_index(h_comp, n_, idx)) {
-        *err = idx.error + " in '" + path_ + "'";
-        return EXG_E_PARSE;
+        damage = idx.error + " in '" + path_ + "'";
+        if (!zst::salvage_index(idx)) {
+            *err = damage;
+            return EXG_E_PARSE;
+        }
     }
     // the frames whose first byte lies in [c_begin, c_end) (a shard decodes its own frames and a halo of frames in front)
     uint64_t b_first = idx.blocks.size(), n_blocks = 0, b_mark[2] = {~0ull, ~0ull};
@@ -429,6 +433,10 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
         *err = hasher.error() + " in '" + path_ + "'";
         return EXG_E_PARSE;
     }
+    if (!damage.empty() && c_end_ >= n_ && !sink.cancelled()) {  // (the shard that reads to the end of the file reports it)
+        *err = damage;
+        return EXG_E_PARSE;
+    }
     marks(n_blocks, d_pos);
     if (!pushed_last && !sink.cancelled()) {  // no block at all (an empty file, skippable frames only): the stream still ends
         Segment seg;
@@ -474,7 +482,8 @@ int plan_zstd_shard(exg_reader *r, int fd, uint64_t n, const std::string &path, 
         ~Unmap() { if (p) munmap(p, n); }
     } unmap{map, (size_t)n};
     zst::Index idx;
-    if (!zst::build_index((const uint8_t *)map, n, idx)) return fail(r, EXG_E_PARSE, idx.error + " in '" + path + "'");
+    // (damage: the shards plan with what lies in front of it; the one that reads to the end of the file reports it behind its rows)
+    if (!zst::build_index((const uint8_t *)map, n, idx) && !zst::salvage_index(idx)) return fail(r, EXG_E_PARSE, idx.error + " in '" + path + "'");
     const uint64_t lo = (uint64_t)((unsigned __int128)n * r->shard_index / r->shard_count);
     const uint64_t hi = r->shard_index + 1 == r->shard_count ? n : (uint64_t)((unsigned __int128)n * (r->shard_index + 1) / r->shard_count);
     const size_t nf = idx.frames.size();

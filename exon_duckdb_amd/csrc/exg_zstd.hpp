@@ -103,10 +103,17 @@ struct Index {
     uint64_t n_seq = 0;
     uint64_t known_out = 0;  // sum of the raw / RLE block sizes
     std::string error;       // set when the walk fails
+    // when the walk fails inside a frame: that frame's header (its complete blocks are at blocks[open_frame.first_block ...])
+    Frame open_frame;
+    bool open_valid = false;
 };
 
 // Host: walk the frames and blocks of data[0, n).  false + idx.error on a malformed stream.
 bool build_index(const uint8_t *data, uint64_t n, Index &idx);
+// After a failed walk: keep what lies in front of the damage — the complete frames and the complete blocks of the frame that
+// was open (as a frame without a checksum or a stated size) — so that a reader can hand out their rows before it reports
+// idx.error, like a streaming decoder does with a truncated file.  false: nothing usable lies in front of it.
+bool salvage_index(Index &idx);
 
 // One ROUND of a stream: a run of consecutive blocks — whole frames, or a part of a frame — decoded on the device into a
 // pooled block [front_reserve | history | produced | 64 zero bytes].  A stream of any size is decoded round by round with

@@ -67,6 +67,8 @@ bool build_index(const uint8_t *data, uint64_t n, Index &idx) {
         if (single) fr.window = fr.content_size;
         if (fr.window > kWindowMax) return fail(idx, "Frame requires too much memory for decoding", frame_at);
         fr.first_block = (uint32_t)idx.blocks.size();
+        idx.open_frame = fr;
+        idx.open_valid = true;  // (until the frame is complete: salvage_index)
         const uint32_t frame_id = (uint32_t)idx.frames.size();
         uint32_t huf_src = kNone, tbl_src[3] = {kNone, kNone, kNone};
         for (;;) {
@@ -174,8 +176,24 @@ bool build_index(const uint8_t *data, uint64_t n, Index &idx) {
             pos += 4;
         }
         idx.frames.push_back(fr);
+        idx.open_valid = false;
     }
     return true;
+}
+
+bool salvage_index(Index &idx) {
+    const size_t whole = idx.frames.empty() ? 0 : (size_t)idx.frames.back().first_block + idx.frames.back().n_blocks;
+    if (idx.open_valid && idx.blocks.size() > idx.open_frame.first_block) {
+        Frame f = idx.open_frame;
+        f.n_blocks = (uint32_t)(idx.blocks.size() - f.first_block);
+        f.has_checksum = 0;        // (never reached)
+        f.content_size = ~0ull;    // (cannot be met)
+        idx.frames.push_back(f);
+    } else {
+        idx.blocks.resize(whole);
+    }
+    idx.open_valid = false;
+    return !idx.frames.empty();
 }
 
 }  // namespace zst

@@ -75,7 +75,16 @@ int main(int argc, char **argv) {
             }
             {
                 exg::zst::Index idx;
-                (void)exg::zst::build_index(p, d.size(), idx);
+                const bool whole = exg::zst::build_index(p, d.size(), idx);
+                // (a damaged stream: what lies in front of the damage stays usable — the frames cover the blocks exactly)
+                if (!whole && exg::zst::salvage_index(idx)) {
+                    size_t nb = 0;
+                    for (const auto &f : idx.frames) {
+                        if (f.first_block != nb || !f.n_blocks) return 3;
+                        nb += f.n_blocks;
+                    }
+                    if (nb != idx.blocks.size()) return 3;
+                }
                 for (const auto &b : idx.blocks)
                     if (b.src_off + (b.type == 1 ? 1 : b.src_size) > d.size()) return 3;  // a block the walk accepted must lie inside the input
             }

@@ -1,0 +1,171 @@
+"""The streaming sources and the fan-out under the things a consumer and a disk do to them: a reader that is closed in the
+middle of its stream (the producer thread, its lanes and queued segments must go away at once — DuckDB closes a scan as soon
+as a LIMIT is satisfied), a member / frame that is corrupt far into a stream that is decoded piece by piece (the rows in front
+of it arrive, then the error — where a streaming decoder like the reference's flate2 / zstd readers reports it — and nothing
+hangs), a file that ends in the middle of a member, and the bounded stream behind the reference's own FFI (`new_reader`)."""
+import gzip
+import time
+
+import pytest
+
+from test_streaming_gpu import CAP_MB, _bgzf, _open, _oracle_digest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fastq_mid(oracle):
+    data = bytes(oracle.synth_fastq(332 * 200000))   # 66 MB: many segments under a 16 MiB cap
+    exp = oracle.fastq_parse(data, want_string_t=False)
+    return data, _oracle_digest(exp, ["name", "description", "sequence", "quality_scores"])
+
+
+def _zstd_frames(data, frame=4 << 20, level=1):
+    from zstd_util import compress
+    return b"".join(compress(data[o:o + frame], level, True) for o in range(0, len(data), frame))
+
+
+def _files(tmp_path, data):
+    (tmp_path / "a.fastq.gz").write_bytes(_bgzf(data))
+    (tmp_path / "b.fastq.gz").write_bytes(gzip.compress(data, 1, mtime=0))
+    (tmp_path / "c.fastq.zst").write_bytes(_zstd_frames(data))
+    (tmp_path / "d.fastq").write_bytes(data)
+    return ["a.fastq.gz", "b.fastq.gz", "c.fastq.zst", "d.fastq"]
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("fan", [False, True])
+def test_close_in_the_middle_of_a_stream(gpu, fastq_mid, tmp_path, monkeypatch, fan):
+    """one chunk, then exg_close: at once, and the next reader of the same file still returns every row"""
+    from exon_duckdb_amd.reader import ShardReader
+    data, want = fastq_mid
+    names = _files(tmp_path, data)
+    monkeypatch.setenv("EXG_DEVICE_MEM_CAP_MB", str(CAP_MB))
+    if fan:
+        monkeypatch.setenv("EXON_GPU_SHARDS", "5")
+        monkeypatch.setenv("EXG_FANOUT_WORKERS", "3")
+    for name in names:
+        if fan and name == "b.fastq.gz":
+            continue   # (a single gzip member has no cut points: one stripe)
+        for n_chunks in (0, 1, 40):
+            r = ShardReader(str(tmp_path / name), "fastq", shard_count=0 if fan else 1)
+            it = 0
+            while it < n_chunks:
+                from exon_duckdb_amd.table_function import Chunk
+                import ctypes as C
+                ch = Chunk()
+                assert r._l.exg_next_chunk(r._r, C.byref(ch)) == 0
+                assert ch.n_rows > 0
+                r._l.exg_release_chunk(r._r, C.byref(ch))
+                it += 1
+            t0 = time.perf_counter()
+            r.close()
+            assert time.perf_counter() - t0 < 5.0, (name, n_chunks, "close waited for the stream")
+        r = ShardReader(str(tmp_path / name), "fastq", shard_count=0 if fan else 1)
+        assert r.digest() == want, name
+        r.close()
+
+
+def _expect_error(path, fmt, min_rows_before, compression=None, **kw):
+    """reads to the error: returns (rows delivered before it, message)"""
+    import ctypes as C
+
+    from exon_duckdb_amd._lib import ExgError
+    from exon_duckdb_amd.table_function import Chunk
+    r = _open(path, fmt, compression=compression, **kw)
+    rows = 0
+    try:
+        while True:
+            ch = Chunk()
+            rc = r._l.exg_next_chunk(r._r, C.byref(ch))
+            if rc != 0:
+                msg = (r._l.exg_reader_error(r._r) or b"").decode("utf-8", "replace")
+                assert msg, "an error code without a message"
+                assert rows >= min_rows_before, (rows, msg)
+                return rows, msg
+            if ch.n_rows == 0:
+                raise AssertionError(f"the corrupt input was read to its end without an error ({rows} rows)")
+            rows += int(ch.n_rows)
+            r._l.exg_release_chunk(r._r, C.byref(ch))
+    except ExgError:
+        raise
+    finally:
+        t0 = time.perf_counter()
+        r.close()
+        assert time.perf_counter() - t0 < 5.0
+
+
+@pytest.mark.timeout(300)
+def test_corruption_far_into_a_capped_stream(gpu, fastq_mid, tmp_path, monkeypatch):
+    """BGZF: a payload byte of a member at 70 % of the file (its CRC-32 no longer matches, or its codes break); single
+    member: a byte at 70 %; zstd: a byte inside the frame at 70 %; a file cut in the middle of a member.  The rows of the
+    segments in front arrive, then the error; the reader closes at once; a clean file reads fine afterwards."""
+    data, want = fastq_mid
+    n_rows = want[0]
+    monkeypatch.setenv("EXG_DEVICE_MEM_CAP_MB", str(CAP_MB))
+    cases = []
+    bg = bytearray(_bgzf(data))
+    at = int(len(bg) * 0.7)
+    bg[at] ^= 0x5A
+    cases.append(("bgzf_flip.fastq.gz", bytes(bg)))
+    cases.append(("bgzf_cut.fastq.gz", _bgzf(data)[: int(len(bg) * 0.7)]))
+    one = bytearray(gzip.compress(data, 1, mtime=0))
+    one[int(len(one) * 0.7)] ^= 0x5A
+    cases.append(("one_flip.fastq.gz", bytes(one)))
+    cases.append(("one_cut.fastq.gz", gzip.compress(data, 1, mtime=0)[: int(len(one) * 0.7)]))
+    zs = bytearray(_zstd_frames(data))
+    zs[int(len(zs) * 0.7)] ^= 0x5A
+    cases.append(("z_flip.fastq.zst", bytes(zs)))
+    cases.append(("z_cut.fastq.zst", _zstd_frames(data)[: int(len(zs) * 0.7)]))
+    from zstd_util import compress
+    z1 = compress(data, 1, True)                      # one frame, like the zstd CLI writes: the blocks in front of the cut
+    cases.append(("z1_cut.fastq.zst", z1[: int(len(z1) * 0.7)]))
+    for name, blob in cases:
+        p = tmp_path / name
+        p.write_bytes(blob)
+        # (a flipped byte inside a stored / literal run can leave the codes valid: then the checksum is what reports it, behind
+        # its member's or frame's rows — at most the whole input for the single member)
+        rows, msg = _expect_error(p, "fastq", min_rows_before=int(n_rows * 0.3))
+        assert rows < n_rows or "one_" in name or "check" in msg.lower() or "crc" in msg.lower(), (name, rows, msg)
+    good = tmp_path / "good.fastq.gz"
+    good.write_bytes(_bgzf(data))
+    r = _open(good, "fastq")
+    assert r.digest() == want
+    r.close()
+
+
+@pytest.mark.timeout(300)
+def test_corruption_inside_a_fan_out(gpu, fastq_mid, tmp_path, monkeypatch):
+    """stripes on worker threads: the error of the stripe that holds the corrupt member comes behind the rows of the stripes
+    in front of it, the workers of the stripes behind it are stopped by the close"""
+    data, want = fastq_mid
+    monkeypatch.setenv("EXG_DEVICE_MEM_CAP_MB", str(CAP_MB))
+    monkeypatch.setenv("EXON_GPU_SHARDS", "6")
+    monkeypatch.setenv("EXG_FANOUT_WORKERS", "3")
+    bg = bytearray(_bgzf(data))
+    bg[int(len(bg) * 0.55)] ^= 0xA5
+    p = tmp_path / "fan_flip.fastq.gz"
+    p.write_bytes(bytes(bg))
+    rows, msg = _expect_error(p, "fastq", min_rows_before=int(want[0] * 0.3), shard_count=0)
+    assert rows < want[0], msg
+
+
+@pytest.mark.timeout(300)
+def test_new_reader_under_the_cap(gpu, oracle, fastq_mid, tmp_path, monkeypatch):
+    """path (A), the reference's FFI: the Arrow stream over a BGZF input 4x the cap returns the oracle's rows, batch by batch"""
+    import hashlib
+
+    from exon_duckdb_amd.arrow import new_reader
+    data, want = fastq_mid
+    p = tmp_path / "arrow.fastq.gz"
+    p.write_bytes(_bgzf(data))
+    monkeypatch.setenv("EXG_DEVICE_MEM_CAP_MB", str(CAP_MB))
+    hs = [hashlib.blake2b(digest_size=16) for _ in range(4)]
+    n = 0
+    for b in new_reader(str(p), "fastq", batch_size=8192):
+        n += b.num_rows
+        for k, col in enumerate(b.columns):
+            for v in col.to_pylist():
+                hs[k].update(b"\xff\x00NULL" if v is None else v.encode())
+                hs[k].update(b"\x00")
+    assert (n, hashlib.blake2b(b"".join(h.digest() for h in hs), digest_size=16).hexdigest()) == want
