@@ -45,6 +45,15 @@ static constexpr int kInMirror = 40;                 // the ring's first bytes a
 #define EXG_INFLATE_DIST_BITS 9
 #endif
 static constexpr int kLitBits = EXG_INFLATE_LIT_BITS, kDistBits = EXG_INFLATE_DIST_BITS;
+#ifndef EXG_INFLATE_FAST_MATCHES
+#define EXG_INFLATE_FAST_MATCHES 8
+#endif
+static constexpr int kFastSlots = EXG_INFLATE_FAST_MATCHES ? EXG_INFLATE_FAST_MATCHES : 1;  // 0: every match takes the in-order loop (the A/B partner)
+#ifndef EXG_INFLATE_FAST_LEN
+#define EXG_INFLATE_FAST_LEN 16
+#endif
+static constexpr uint32_t kFastLen = EXG_INFLATE_FAST_LEN;  // 8: a byte per lane; 16: the lanes of a longer match copy a second byte
+static_assert(kFastLen == 8 || kFastLen == 16, "eight lanes per match, one or two bytes each");
 
 // SYM = false: the window holds bytes (a gzip member decoded from its first bit).
 // SYM = true:  the window holds 16-bit symbols — a byte, or 0x8000 | i for "byte i of the 32 KiB in front of where
@@ -78,8 +87,10 @@ struct InflateLdsT {
         uint16_t lit_sorted[288];
         uint8_t lens[384];
     };
-    uint16_t dist_sorted[32];
+    uint8_t dist_sorted[32];  // (distance symbols and the code-length alphabet fit a byte: what pays for fast_slot)
     uint16_t lit_count[16], dist_count[16];
+    // descriptors of a step's independent short matches (copied eight at a time, eight lanes each: see `fast` below)
+    uint32_t fast_slot[kFastSlots + 1];  // (+ one the lanes without a descriptor write to)
 };
 
 static __device__ __constant__ unsigned short kLenBase[29] = {3,  4,  5,  6,  7,  8,  9,  10, 11,  13,  15,  17,  19,  23, 27,
@@ -240,8 +251,8 @@ __device__ __forceinline__ void dist_base_extra(uint32_t sym, uint32_t *base, ui
     *base = sym < 2 ? sym + 1u : ((2u | (sym & 1u)) << dx) + 1u;
 }
 
-template <class Lut, class Enc>
-__device__ inline bool build_table(const uint8_t *lens, uint32_t n, Lut *lut, uint32_t bits, uint16_t *sorted, uint16_t *count,
+template <class Lut, class Enc, class Sorted>
+__device__ inline bool build_table(const uint8_t *lens, uint32_t n, Lut *lut, uint32_t bits, Sorted *sorted, uint16_t *count,
                             uint32_t lane, Enc enc) {
     for (uint32_t e = lane; e < (1u << bits); e += 64) lut[e] = 0;
     // all the lengths (n <= 320) are read before anything is written: `sorted` may lie over `lens`
@@ -304,7 +315,7 @@ __device__ inline bool build_table(const uint8_t *lens, uint32_t n, Lut *lut, ui
             run[L] += (uint32_t)__popcll(m);
         }
         if (l) {
-            sorted[o + rank] = (uint16_t)sym;
+            sorted[o + rank] = (Sorted)sym;
             if (l <= bits) {
                 uint32_t c = f + rank;
                 uint32_t r = __brev(c) >> (32 - l);  // codes are sent MSB first
@@ -317,7 +328,8 @@ __device__ inline bool build_table(const uint8_t *lens, uint32_t n, Lut *lut, ui
 }
 
 // canonical decode, bit by bit, of the code at the front of `bits` (codes longer than the primary table; rare)
-__device__ __forceinline__ uint32_t decode_slow(unsigned long long bits, const uint16_t *sorted, const uint16_t *count,
+template <class Sorted>
+__device__ __forceinline__ uint32_t decode_slow(unsigned long long bits, const Sorted *sorted, const uint16_t *count,
                                                 uint32_t *len_out) {
     uint32_t code = 0, first = 0, index = 0;
     for (uint32_t len = 1; len <= 15; len++) {
@@ -338,9 +350,9 @@ __device__ __forceinline__ uint32_t decode_slow(unsigned long long bits, const u
 }
 
 // decode one symbol serially (block headers); returns 0xFFFFFFFF on an invalid code
-template <class L>
+template <class L, class Sorted>
 __device__ __forceinline__ uint32_t decode_sym(L &s, BitIn &br, const uint16_t *lut, uint32_t bits,
-                                               const uint16_t *sorted, const uint16_t *count, uint32_t lane) {
+                                               const Sorted *sorted, const uint16_t *count, uint32_t lane) {
     unsigned long long v = peek(s, br, lane);
     uint32_t e = sgpr(lut[(uint32_t)v & ((1u << bits) - 1u)]);
     if (e) {
@@ -354,8 +366,8 @@ __device__ __forceinline__ uint32_t decode_sym(L &s, BitIn &br, const uint16_t *
 }
 
 // one symbol decoded bit by bit by every lane uniformly (tokens the primary tables cannot resolve)
-template <class L>
-__device__ __forceinline__ uint32_t decode_serial(L &s, BitIn &br, const uint16_t *sorted, const uint16_t *count,
+template <class L, class Sorted>
+__device__ __forceinline__ uint32_t decode_serial(L &s, BitIn &br, const Sorted *sorted, const uint16_t *count,
                                                   uint32_t lane) {
     unsigned long long v = peek(s, br, lane);
     uint32_t l = 0;
@@ -818,53 +830,131 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
 #pragma unroll
                     for (int k = 0; k < NW; k++)
                         s.win[mask_sel(keep[k] & ~len_mask[k], RING, (pos + excl[k]) & kRingMask)] = (Elem)((e[k] >> 4) & 0xFFu);
-                    // matches in order, window after window (see the one-window form below); most windows have none
-                    auto matches = [&](unsigned long long m_match, uint32_t len_l, uint32_t de_k, uint32_t v2_k, uint32_t dx_k, uint32_t excl_k) {
-                        const uint32_t h = (de_k >> 5) & 15u, b = (de_k >> 4) & 1u;
-                        const uint32_t dist_l = (((min(h, 1u) << 1) | b) << dx_k) + __builtin_amdgcn_ubfe(v2_k, de_k & 15u, dx_k) + 1u;
-                        const uint32_t dest_l = pos + excl_k;
-                        if (!SYM && (m_match & __ballot(dist_l > dest_l))) {
-                            err = 3;
-                            return;
-                        }
-                        if (InflateLdsT<SYM, RING>::kGlobalWindow && !d_out) return;  // a probing decode copies nothing
-                        const uint32_t src0_l = dest_l - dist_l;
-                        uint32_t cls = 2;
-                        if (dist_l >= len_l && len_l <= 64u && dest_l >= dist_l) {
-                            if (!InflateLdsT<SYM, RING>::kGlobalWindow || src0_l + RING >= hi_pos)
-                                cls = 0;
-                            else if (src0_l + len_l - 1 + RING < hi_pos)
-                                cls = 1;
-                        }
-                        const uint32_t desc_l = cls | (len_l << 2);
-                        while (m_match) {
-                            const uint32_t l = (uint32_t)__ffsll((long long)m_match) - 1;
-                            m_match &= m_match - 1;
-                            const uint32_t desc = __builtin_amdgcn_readlane(desc_l, l);
-                            const uint32_t dest = __builtin_amdgcn_readlane(dest_l, l);
-                            const uint32_t mlen = desc >> 2;
-                            if ((desc & 3u) == 0) {
-                                const uint32_t src0 = __builtin_amdgcn_readlane(src0_l, l);
-                                if (lane < mlen) {
-                                    const Elem x = s.win[(src0 + lane) & kRingMask];
-                                    s.win[(dest + lane) & kRingMask] = x;
-                                }
-                            } else if ((desc & 3u) == 1) {
-                                const uint32_t src0 = __builtin_amdgcn_readlane(src0_l, l);
-                                if (lane < mlen) {
-                                    const Elem x = __hip_atomic_load(d_out + mb.out_off + src0 + lane, __ATOMIC_RELAXED,
-                                                                     __HIP_MEMORY_SCOPE_WORKGROUP);
-                                    s.win[(dest + lane) & kRingMask] = x;
-                                }
-                            } else {
-                                copy_match(s, d_out, mb.out_off, dest, mlen, __builtin_amdgcn_readlane(dist_l, l), hi_pos, lane);
-                            }
-                        }
-                    };
+                    // ---- matches.  Most are short and reach far back (FASTQ / VCF / FASTA at zlib level 6: nine in ten are <= 8 bytes,
+                    // seven in ten come from behind the 2 KiB ring): each one handled in order costs ~17 scalar instructions and,
+                    // for a far source, an L1 / L2 round trip the wave sits out.  So the INDEPENDENT short ones go first, eight per
+                    // pass with eight lanes each: a match of <= 16 bytes whose source ends in front of the step's first match (F)
+                    // reads only bytes that are final once the literals are stored — earlier steps' output and this step's
+                    // literals — whatever the order.  Their descriptors (rank = popcount over the windows) go through fast_slot;
+                    // one ring read or one HBM read per pass serves all eight (two for the lanes of a match longer than eight).  The rest — long, overlapping, straddling the
+                    // ring's edge, fed by a match of this step, or beyond the eight slots — follow in order as before, and may
+                    // read what the fast ones wrote (they come later in the wave's LDS order).
+                    const bool copies = !(InflateLdsT<SYM, RING>::kGlobalWindow && !d_out);  // a probing decode copies nothing
+                    unsigned long long m_match[NW], any_match = 0;
 #pragma unroll
                     for (int k = 0; k < NW; k++) {
-                        const unsigned long long m_match = keep[k] & len_mask[k];
-                        if (m_match && !err) matches(m_match, olen1[k], de[k], v2[k], dxs[k], excl[k]);
+                        m_match[k] = keep[k] & len_mask[k];
+                        any_match |= m_match[k];
+                    }
+                    if (any_match) {
+                        static_assert((kFastSlots & (kFastSlots - 1)) == 0 && kFastSlots <= 8, "eight lanes per slot");
+                        uint32_t n_fast = 0, first_dest = 0;
+                        bool have_first = false;
+                        // the pending fast matches, eight lanes each (lane = 8 j + i: byte i of slot j)
+                        auto copy_fast = [&]() {
+                            const uint32_t j = lane >> 3, i = lane & 7u;
+                            const uint32_t d = s.fast_slot[j & (uint32_t)(kFastSlots - 1)];
+                            const uint32_t flen = ((d >> 10) & 15u) + 3u, fdist = ((d >> 14) & 0x7FFFu) + 1u;
+                            const bool mine = j < n_fast && i < flen, mine2 = kFastLen > 8 && j < n_fast && i + 8u < flen;
+                            const uint32_t fdest = pos + (d & 1023u) + i, fsrc = fdest - fdist;
+                            const bool two = kFastLen > 8 && __ballot(mine2) != 0;  // (wave uniform: most passes have no match longer than eight)
+                            if (mine) {
+                                const bool far = InflateLdsT<SYM, RING>::kGlobalWindow && (d >> 29);
+                                Elem x, y = 0;
+                                if (far)
+                                    x = __hip_atomic_load(d_out + mb.out_off + fsrc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                else
+                                    x = s.win[fsrc & kRingMask];
+                                if (two && mine2) {
+                                    if (far)
+                                        y = __hip_atomic_load(d_out + mb.out_off + fsrc + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    else
+                                        y = s.win[(fsrc + 8u) & kRingMask];
+                                }
+                                s.win[fdest & kRingMask] = x;
+                                if (two && mine2) s.win[(fdest + 8u) & kRingMask] = y;
+                            }
+                            n_fast = 0;
+                        };
+                        // the others of one window, in order (what can be decided per match is decided for all of them at once:
+                        // the scalar loop reads a descriptor)
+                        auto copy_in_order = [&](unsigned long long m, uint32_t len_l, uint32_t dist_k, uint32_t dest_k) {
+                            const uint32_t src0_l = dest_k - dist_k;
+                            uint32_t cls = 2;  // 0: one pass out of the ring, 1: one pass out of HBM, 2: the general copy
+                            if (dist_k >= len_l && len_l <= 64u && dest_k >= dist_k) {
+                                if (!InflateLdsT<SYM, RING>::kGlobalWindow || src0_l + RING >= hi_pos)
+                                    cls = 0;
+                                else if (src0_l + len_l - 1 + RING < hi_pos)
+                                    cls = 1;
+                            }
+                            const uint32_t desc_l = cls | (len_l << 2);
+                            while (m) {
+                                const uint32_t l = (uint32_t)__ffsll((long long)m) - 1;
+                                m &= m - 1;
+                                const uint32_t desc = __builtin_amdgcn_readlane(desc_l, l);
+                                const uint32_t dest = __builtin_amdgcn_readlane(dest_k, l);
+                                const uint32_t mlen = desc >> 2;
+                                if ((desc & 3u) == 0) {
+                                    const uint32_t src0 = __builtin_amdgcn_readlane(src0_l, l);
+                                    if (lane < mlen) {
+                                        const Elem x = s.win[(src0 + lane) & kRingMask];
+                                        s.win[(dest + lane) & kRingMask] = x;
+                                    }
+                                } else if ((desc & 3u) == 1) {
+                                    const uint32_t src0 = __builtin_amdgcn_readlane(src0_l, l);
+                                    if (lane < mlen) {
+                                        const Elem x = __hip_atomic_load(d_out + mb.out_off + src0 + lane, __ATOMIC_RELAXED,
+                                                                         __HIP_MEMORY_SCOPE_WORKGROUP);
+                                        s.win[(dest + lane) & kRingMask] = x;
+                                    }
+                                } else {
+                                    copy_match(s, d_out, mb.out_off, dest, mlen, __builtin_amdgcn_readlane(dist_k, l), hi_pos, lane);
+                                }
+                            }
+                        };
+#pragma unroll
+                        for (int k = 0; k < NW; k++) {
+                            if (m_match[k] && !err) {
+                                const uint32_t h = (de[k] >> 5) & 15u, bb = (de[k] >> 4) & 1u;
+                                const uint32_t dist_k = (((min(h, 1u) << 1) | bb) << dxs[k]) + __builtin_amdgcn_ubfe(v2[k], de[k] & 15u, dxs[k]) + 1u;
+                                const uint32_t dest_k = pos + excl[k], len_l = olen1[k];
+                                if (!SYM && (m_match[k] & __ballot(dist_k > dest_k))) {
+                                    err = 3;
+                                } else if (copies) {
+                                    unsigned long long m_slow = m_match[k];
+                                    if (EXG_INFLATE_FAST_MATCHES) {
+                                        if (!have_first) {
+                                            first_dest = __builtin_amdgcn_readlane(dest_k, (uint32_t)__ffsll((long long)m_match[k]) - 1);
+                                            have_first = true;
+                                        }
+                                        const uint32_t src0_l = dest_k - dist_k;
+                                        // the ring holds [hi_pos - RING, hi_pos): a source is read from it, or from HBM when all of it is
+                                        // older; one that straddles the edge takes the general copy.  edge = ring's first position - src0
+                                        const uint32_t edge = hi_pos - RING - src0_l;  // <= 0 (as int): in the ring; >= len: flushed
+                                        const bool far_src = InflateLdsT<SYM, RING>::kGlobalWindow && (int32_t)edge >= (int32_t)len_l;
+                                        const bool straddles = InflateLdsT<SYM, RING>::kGlobalWindow && edge - 1u < len_l - 1u;
+                                        const bool ok = len_l <= kFastLen && (!SYM || dist_k <= dest_k) && src0_l + len_l <= first_dest && !straddles;
+                                        unsigned long long m_fast = m_match[k] & __ballot(ok);
+                                        m_slow &= ~m_fast;
+                                        // excl < 1024 (a step emits <= 512 elements + one match), len - 3 in 4 bits, dist - 1 in 15
+                                        const uint32_t packed = excl[k] | ((len_l - 3u) << 10) | ((dist_k - 1u) << 14) | (far_src ? 1u << 29 : 0u);
+                                        while (m_fast) {
+                                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_fast >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_fast, n_fast));
+                                            const unsigned long long take = m_fast & __ballot(rank < (uint32_t)kFastSlots);
+                                            s.fast_slot[mask_sel(take, (uint32_t)kFastSlots, rank)] = packed;
+                                            n_fast += (uint32_t)__popcll(take);
+                                            m_fast &= ~take;
+                                            if (m_fast) copy_fast();  // the slots are full: these go, the others follow
+                                        }
+                                    }
+                                    if (m_slow) {
+                                        if (n_fast) copy_fast();  // (one of them may feed a match of this window)
+                                        copy_in_order(m_slow, len_l, dist_k, dest_k);
+                                    }
+                                }
+                            }
+                        }
+                        if (n_fast && !err) copy_fast();
                     }
                     if (err) break;
                     pos = hi_pos;

@@ -100,6 +100,41 @@ def test_overlapping_matches_and_far_distances(gpu):
     roundtrip(gpu, payload, gzip.compress(payload, mtime=0))
 
 
+def short_match_payload(seed, n):
+    """literal runs of 0-4 random bytes between copies of 3-18 bytes from chosen distances: next to the copy itself (overlap),
+    inside the step that emits it, around the edge of the decoder's 2 KiB ring, around its 1 KiB flush lag, far back, and
+    at the window's limit — what zlib turns into runs of short matches (many per step of the decoder)"""
+    rng = np.random.default_rng(seed)
+    alphabet = np.frombuffer(b"ACGTN\n@+FI#:0123456789", dtype=np.uint8)
+    out = bytearray(alphabet[rng.integers(0, len(alphabet), 64)].tobytes())
+    bands = [(1, 20), (20, 200), (900, 1100), (1980, 2120), (3000, 9000), (32700, 32768)]
+    while len(out) < n:
+        out += alphabet[rng.integers(0, len(alphabet), int(rng.integers(0, 5)))].tobytes()
+        lo, hi = bands[int(rng.integers(0, len(bands)))]
+        d = int(rng.integers(lo, hi + 1))
+        if d > len(out):
+            continue
+        ln = int(rng.integers(3, 19))
+        for _ in range(ln):          # (byte by byte: a copy may overlap itself)
+            out.append(out[-d])
+    return bytes(out[:n])
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_runs_of_short_matches_at_every_distance(gpu, seed):
+    """the batched copy of a step's independent short matches (exg_inflate_core.hpp, `fast`) against zlib: sources in the
+    ring, in HBM, across the ring's edge; copies fed by a match of the same step; more matches in a step than slots"""
+    from test_inflate_stream_gpu import deflate, stream_inflate
+    payload = short_match_payload(seed, 700_000)
+    for level in (1, 6, 9):
+        roundtrip(gpu, payload, bgzf(payload, block=[65280, 30000, 4096][seed % 3], level=level))
+        roundtrip(gpu, payload[:65000], gzip.compress(payload[:65000], level, mtime=0))
+    # the chunked decoder (16-bit symbols: a byte, or a byte of the window in front of the chunk) takes the same step
+    raw = deflate(payload, 6)
+    rc, got, consumed = stream_inflate(gpu, raw, 40_000 + 1000 * seed)
+    assert rc == 0 and got == payload and consumed == len(raw)
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_many_tiny_blocks(gpu, seed):
     """a block end every few bytes (sync / full flushes at random places, all three block types): the token that ends a

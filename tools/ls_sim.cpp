@@ -62,11 +62,12 @@ struct Tok {
     int bits;   // total bits of the token; 0 = invalid, -1 = end of block
     int out;    // bytes it produces
     int longc;  // a code longer than the primary tables
+    int dist;   // a match's distance
 };
 static int g_lit_bits = 9, g_dist_bits = 9, g_repair = 0;
-static unsigned long long g_rounds = 0, it3 = 0, g_round_hist[16];
+static unsigned long long g_rounds = 0, it3 = 0, g_round_hist[16], g_mlen[5], g_mdist[5], g_short_near = 0;
 static Tok token_at(const Bits &b, size_t pos, const Huff &hl, const Huff &hd) {
-    Tok t{0, 0, 0};
+    Tok t{0, 0, 0, 0};
     int l;
     int s = decode(b, pos, hl, &l);
     if (s < 0) return t;
@@ -87,8 +88,10 @@ static Tok token_at(const Bits &b, size_t pos, const Huff &hl, const Huff &hd) {
     int d = decode(b, pos + l + x, hd, &l2);
     if (d < 0 || d > 29) return t;
     if (l2 > g_dist_bits) t.longc = 1;
+    static const uint16_t DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
     t.bits = l + x + l2 + DE[d];
     t.out = len;
+    t.dist = DBASE[d] + (int)b.bits(pos + l + x + l2, DE[d]);
     return t;
 }
 
@@ -245,6 +248,11 @@ int main(int argc, char **argv) {
                             if (t.bits == -1) { eob = true; break; }
                             if (t.bits == 0) { fprintf(stderr, "bad token on the true chain\n"); return 2; }
                             q += t.bits; o += t.out; toks++; longs += t.longc; matches += t.out > 1;
+                            if (t.out > 1) {
+                                g_mlen[t.out <= 4 ? 0 : t.out <= 8 ? 1 : t.out <= 16 ? 2 : t.out <= 64 ? 3 : 4]++;
+                                g_mdist[t.dist < 64 ? 0 : t.dist < 900 ? 1 : t.dist < 2048 ? 2 : t.dist < 8192 ? 3 : 4]++;
+                                g_short_near += t.out <= 8 && t.dist >= 64 && t.dist < 900;
+                            }
                         }
                         itr3 = std::max(itr3, n);
                         kept++;
@@ -321,6 +329,8 @@ int main(int argc, char **argv) {
            (double)tok_total / out_total, match_total, 100.0 * match_total / tok_total,
            match_total ? (double)(out_total - (tok_total - match_total)) / match_total : 0.0, 100.0 * long_total / tok_total);
     if (g_repair) {
+        printf("  match lengths <=4 / <=8 / <=16 / <=64 / more: %llu %llu %llu %llu %llu; distances <64 / <900 / <2048 / <8192 / more: %llu %llu %llu %llu %llu; len <= 8 and 64 <= dist < 900: %llu\n",
+               g_mlen[0], g_mlen[1], g_mlen[2], g_mlen[3], g_mlen[4], g_mdist[0], g_mdist[1], g_mdist[2], g_mdist[3], g_mdist[4], g_short_near);
         printf("  rounds histogram:");
         for (int i = 0; i < 16; i++) printf(" %llu", g_round_hist[i]);
         printf("\n");
