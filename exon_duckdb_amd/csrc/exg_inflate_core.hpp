@@ -225,10 +225,17 @@ __device__ __forceinline__ uint32_t getbits(L &s, BitIn &br, uint32_t n, uint32_
 
 // Build one decode table from code lengths lens[0..n): LUT (primary `bits`), sorted symbols, counts.
 // Returns false when the lengths are over-subscribed or incomplete (except the single-code cases zlib allows).
+// kFill: what the slots of codes longer than the table (and of unused codes) hold
 struct EncPlain {  // (symbol << 4) | length
+    static constexpr uint16_t kFill = 0;
     __device__ __forceinline__ uint16_t operator()(uint32_t sym, uint32_t l) const { return (uint16_t)((sym << 4) | l); }
 };
+// literal / length slots without an entry: both stop flags and a length of ONE bit — every speculative decode hops at least one
+// bit without a max() of its own (the chain walk adds the hop to its position: a hop of 0 would never end)
+static constexpr uint32_t kLitLong = 0x3001u;
+__device__ __forceinline__ bool lit_is_long(uint32_t e) { return (e & 0xB000u) == 0x3000u; }
 struct EncLit {
+    static constexpr uint16_t kFill = (uint16_t)kLitLong;
     __device__ __forceinline__ uint16_t operator()(uint32_t sym, uint32_t l) const {
         if (sym < 256) return (uint16_t)((sym << 4) | l);
         if (sym == 256) return (uint16_t)((1u << 12) | l);
@@ -237,7 +244,11 @@ struct EncLit {
         return (uint16_t)(0x8000u | ((uint32_t)(kLenBase[si] - 3) << 7) | ((uint32_t)kLenExtra[si] << 4) | l);
     }
 };
+// (distance slots without an entry stay 0: a fill with flag bits, so that "ends the step" is one compare against 0x1000 without
+// the subtract in front of it, measured 0 .. -1.7 %: kept out)
+__device__ __forceinline__ bool dist_is_long(uint32_t de) { return de == 0; }
 struct EncDist {
+    static constexpr uint16_t kFill = 0;
     __device__ __forceinline__ uint16_t operator()(uint32_t sym, uint32_t l) const {
         if (sym > 29) return (uint16_t)((1u << 9) | l);
         return (uint16_t)((sym << 4) | l);
@@ -254,7 +265,7 @@ __device__ __forceinline__ void dist_base_extra(uint32_t sym, uint32_t *base, ui
 template <class Lut, class Enc, class Sorted>
 __device__ inline bool build_table(const uint8_t *lens, uint32_t n, Lut *lut, uint32_t bits, Sorted *sorted, uint16_t *count,
                             uint32_t lane, Enc enc) {
-    for (uint32_t e = lane; e < (1u << bits); e += 64) lut[e] = 0;
+    for (uint32_t e = lane; e < (1u << bits); e += 64) lut[e] = Enc::kFill;
     // all the lengths (n <= 320) are read before anything is written: `sorted` may lie over `lens`
     uint32_t lv[5];
 #pragma unroll
@@ -630,7 +641,7 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                     val = 0;
                     const uint32_t e = s.lit_lut[(uint32_t)v & ((1u << kLitBits) - 1u)];
                     const uint32_t l1 = e & 15;
-                    if (e == 0) {  // longer than the primary table: decoded serially IF it is a real token start
+                    if (lit_is_long(e)) {  // longer than the primary table: decoded serially IF it is a real token start
                         kind = kSlow;
                         tl = 0;
                     } else if (!(e & 0x8000u)) {
@@ -646,7 +657,7 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                         const uint32_t l2 = de & 15;
                         uint32_t dbase, dx;
                         dist_base_extra((de >> 4) & 31u, &dbase, &dx);
-                        if (de == 0) {
+                        if (dist_is_long(de)) {
                             kind = kSlow;
                             tl = 0;
                         } else if (de & (1u << 9)) {
@@ -678,7 +689,11 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                     uint32_t lo[NW], hi[NW], e[NW], de[NW], tt[NW], v2[NW];
                     peekn_at<NW>(s, (uint32_t)br.bitpos + lane, lo, hi);
 #pragma unroll
-                    for (int k = 0; k < NW; k++) e[k] = s.lit_lut[lo[k] & ((1u << kLitBits) - 1u)];
+                    for (int k = 0; k < NW; k++) {
+                        e[k] = s.lit_lut[lo[k] & ((1u << kLitBits) - 1u)];
+                        asm("" : "+v"(e[k]));  // (a 32-bit value from here on: knowing it came from 16 bits, the compiler tests bit 15 as a
+                                               // 16-bit sign and then masks every use to 16 bits again — four instructions per step)
+                    }
 #pragma unroll
                     for (int k = 0; k < NW; k++) {
                         tt[k] = (e[k] & 15u) + ((e[k] >> 4) & 7u);              // code + extra bits of a length: <= 20
@@ -698,13 +713,13 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                         const uint32_t len = ((e[k] >> 7) & 0xFFu) + __builtin_amdgcn_ubfe(lo[k], l1, lx) + 3u;
                         // (one compare; the selects take its mask as their scalar operand — left to the compiler the
                         // predicate is evaluated three times and the length / distance arithmetic is put behind a branch)
-                        len_mask[k] = __ballot((e[k] & 0x8000u) != 0);
+                        len_mask[k] = __ballot(e[k] > 0x7FFFu);  // (a 32-bit compare: the 16-bit sign test makes the compiler mask every entry to 16 bits again)
                         olen1[k] = mask_sel(len_mask[k], one, len);
-                        // every lane hops at least one bit (an entry of 0 has no length): the walk runs on through a token it
+                        // every lane hops at least one bit (kLitLong carries a length of one): the walk runs on through a token it
                         // cannot use, what lies behind the first such token is dropped below
-                        tl[k] = max(mask_sel(len_mask[k], l1, tt[k] + l2 + dx), 1u);  // <= 15 + 5 + 15 + 13 = 48 bits
+                        tl[k] = mask_sel(len_mask[k], l1, tt[k] + l2 + dx);  // 1 (kLitLong: l1 = 1) .. 15 + 5 + 15 + 13 = 48 bits
                         // tokens that end the step: end-of-block, invalid symbols (bits 12 / 13 of a literal entry, bit 9 of a
-                        // distance entry) and codes longer than the tables (entry 0).  Valid entries are 1 .. 0xFFF / 1 .. 0x1FF
+                        // distance entry) and codes longer than the tables (kLitLong / a distance entry of 0).  Valid entries are 1 .. 0xFFF / 1 .. 0x1FF
                         const uint32_t y = mask_sel(len_mask[k], e[k], de[k] << 3);
                         stop_mask[k] = __ballot(y - 1u >= 0xFFFu);
                     }
@@ -783,21 +798,44 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                     unsigned long long keep[NW];
 #pragma unroll
                     for (int k = 0; k < NW; k++) olen[k] = mask_sel0(live[k], olen1[k]);
+#ifndef EXG_INFLATE_SCAN_EACH
+                    // two windows per scan: a window's sum is at most 64 x 258 < 2^16, so two of them ride in one register through
+                    // the six DPP steps (eight vector instructions less per step; the scans run side by side: a DPP step waits
+                    // for the one before)
+                    if constexpr (NW % 2 == 0) {
+                        uint32_t pk[NW / 2];
 #pragma unroll
-                    for (int k = 0; k < NW; k++) incl[k] = wave_incl_sum_dpp(olen[k]);  // (side by side: a DPP step waits for the one before)
+                        for (int k = 0; k < NW / 2; k++) pk[k] = olen[2 * k] | (olen[2 * k + 1] << 16);
+#pragma unroll
+                        for (int k = 0; k < NW / 2; k++) pk[k] = wave_incl_sum_dpp(pk[k]);
+#pragma unroll
+                        for (int k = 0; k < NW / 2; k++) {
+                            incl[2 * k] = pk[k] & 0xFFFFu;
+                            incl[2 * k + 1] = pk[k] >> 16;
+                        }
+                    } else
+#endif
+                    {
+#pragma unroll
+                        for (int k = 0; k < NW; k++) incl[k] = wave_incl_sum_dpp(olen[k]);
+                    }
+                    // (excl = where a token's output goes: the output position itself, pos + the tokens in front — the window's carry
+                    // starts at pos, so that the stores and the matches need no add of their own)
+                    carry = pos;
 #pragma unroll
                     for (int k = 0; k < NW; k++) {
                         excl[k] = incl[k] - olen[k] + carry;
                         carry += __builtin_amdgcn_readlane(incl[k], 63);
                         keep[k] = live[k];
                     }
+                    carry -= pos;
                     total = carry;
                     uint32_t drop_pos = 64u * NW;  // the first token pushed to the next step
                     if (carry > kStepOut) {
                         total = 0;
 #pragma unroll
                         for (int k = NW - 1; k >= 0; k--) {
-                            keep[k] = live[k] & __ballot(excl[k] < kStepOut);
+                            keep[k] = live[k] & __ballot(excl[k] - pos < kStepOut);
                             const unsigned long long m_drop = live[k] & ~keep[k];
                             if (m_drop) drop_pos = 64u * k + (uint32_t)__ffsll((long long)m_drop) - 1;
                         }
@@ -805,7 +843,7 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                         for (int k = 0; k < NW; k++)
                             if (keep[k]) {
                                 const uint32_t l = 63 - __clzll((long long)keep[k]);
-                                total = __builtin_amdgcn_readlane(excl[k], l) + __builtin_amdgcn_readlane(olen[k], l);
+                                total = __builtin_amdgcn_readlane(excl[k], l) - pos + __builtin_amdgcn_readlane(olen[k], l);
                             }
                     }
                     if (pos + total > cap) {
@@ -829,7 +867,7 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                     // all literals in one store per window (the other lanes write to a spare element behind the ring)
 #pragma unroll
                     for (int k = 0; k < NW; k++)
-                        s.win[mask_sel(keep[k] & ~len_mask[k], RING, (pos + excl[k]) & kRingMask)] = (Elem)((e[k] >> 4) & 0xFFu);
+                        s.win[mask_sel(keep[k] & ~len_mask[k], RING, excl[k] & kRingMask)] = (Elem)((e[k] >> 4) & 0xFFu);
                     // ---- matches.  Most are short and reach far back (FASTQ / VCF / FASTA at zlib level 6: nine in ten are <= 8 bytes,
                     // seven in ten come from behind the 2 KiB ring): each one handled in order costs ~17 scalar instructions and,
                     // for a far source, an L1 / L2 round trip the wave sits out.  So the INDEPENDENT short ones go first, eight per
@@ -917,7 +955,7 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                             if (m_match[k] && !err) {
                                 const uint32_t h = (de[k] >> 5) & 15u, bb = (de[k] >> 4) & 1u;
                                 const uint32_t dist_k = (((min(h, 1u) << 1) | bb) << dxs[k]) + __builtin_amdgcn_ubfe(v2[k], de[k] & 15u, dxs[k]) + 1u;
-                                const uint32_t dest_k = pos + excl[k], len_l = olen1[k];
+                                const uint32_t dest_k = excl[k], len_l = olen1[k];
                                 if (!SYM && (m_match[k] & __ballot(dist_k > dest_k))) {
                                     err = 3;
                                 } else if (copies) {
@@ -937,7 +975,7 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                                         unsigned long long m_fast = m_match[k] & __ballot(ok);
                                         m_slow &= ~m_fast;
                                         // excl < 1024 (a step emits <= 512 elements + one match), len - 3 in 4 bits, dist - 1 in 15
-                                        const uint32_t packed = excl[k] | ((len_l - 3u) << 10) | ((dist_k - 1u) << 14) | (far_src ? 1u << 29 : 0u);
+                                        const uint32_t packed = (excl[k] - pos) | ((len_l - 3u) << 10) | ((dist_k - 1u) << 14) | (far_src ? 1u << 29 : 0u);
                                         while (m_fast) {
                                             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_fast >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_fast, n_fast));
                                             const unsigned long long take = m_fast & __ballot(rank < (uint32_t)kFastSlots);
@@ -971,7 +1009,7 @@ __device__ __forceinline__ void inflate_job(InflateLdsT<SYM, RING> &s, const uin
                                 e_s = __builtin_amdgcn_readlane(e[k], sl);
                                 de_s = __builtin_amdgcn_readlane(de[k], sl);
                             }
-                        if (e_s & 0x8000u ? de_s == 0 : e_s == 0) {
+                        if (e_s & 0x8000u ? dist_is_long(de_s) : lit_is_long(e_s)) {
                             advance = stop_pos;  // a code longer than the tables: decoded by every lane uniformly below
                             slow_token = true;
                         } else if (!(e_s & 0x8000u) && (e_s & 0x3000u) == 0x1000u) {
