@@ -75,22 +75,29 @@ __global__ __launch_bounds__(64) void k_find_blocks(const uint8_t *__restrict__ 
     for (uint32_t j = blockIdx.x; j < n_jobs; j += gridDim.x) {
         const FindJob fj = jobs[j];
         unsigned long long result = ~0ull;
+        // The input is staged as the search moves on — a chunk of the ring serves sixteen steps of 64 offsets, the chunk after
+        // it is on its way — and again from scratch only behind a probing decode, which uses the ring for itself.  (Staging
+        // anew for every 64 offsets put an HBM round trip into every step: 10 ms of a round's 35.)
+        BitIn br;
+        const BitBase bb = bit_base(d_comp, fj.comp_off, fj.comp_size, fj.from_bit);
+        br.g0 = bb.g0;
+        br.limit = bb.limit;
+        bool staged = false;
         for (unsigned long long base = fj.from_bit; base < fj.to_bit && result == ~0ull; base += 64) {
-            // stage the input around `base` and let every lane look at its own offset
-            BitIn br;
-            const BitBase bb = bit_base(d_comp, fj.comp_off, fj.comp_size, base);
-            br.g0 = bb.g0;
-            br.limit = bb.limit;
+            // every lane looks at its own offset
             br.bitpos = (unsigned long long)((long long)base - bb.rel_bits);
-            start_input(br, lane);
-            __syncthreads();
-            ensure(s, br, lane);
-            br.bitpos += 64 + 17 + 64;  // the filter reads up to here: keep the next chunk staged too
+            if (!staged) {
+                start_input(br, lane);
+                __syncthreads();
+                staged = true;
+            }
+            // (the chunk that holds `base` and the one behind it: the filter reads 64 + 17 + 64 + 64 bits from there, 27 bytes)
             ensure(s, br, lane);
             const unsigned long long o = (unsigned long long)((long long)base - bb.rel_bits) + lane;
             const bool in_range = base + lane < fj.to_bit && ((o + 17 + 64) >> 3) < br.limit;
             const bool pass = in_range && header_filter(peek_at(s, o), peek_at(s, o + 17));
             unsigned long long cand = __ballot(pass);
+            if (cand) staged = false;  // (the decodes below stage their own input)
             while (cand && result == ~0ull) {
                 const uint32_t l = (uint32_t)__ffsll((long long)cand) - 1;
                 cand &= cand - 1;

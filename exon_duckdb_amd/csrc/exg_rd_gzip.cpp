@@ -80,8 +80,16 @@ class GzipProducer : public SegmentProducer {
 public:
     GzipProducer(exg_reader *r, int fd, uint64_t c_begin, uint64_t c_end, uint64_t target, const std::string &path, bool bgzf_only)
         : device_(r->device), fd_(fd), c_pos_(c_begin), c_end_(c_end), target_(std::max<uint64_t>(target, 64u << 10)), path_(path), bgzf_only_(bgzf_only),
-          n_lanes_(r->mem_cap ? 2 : 3) {
+          n_lanes_(r->mem_cap ? 2 : 3), capped_(r->mem_cap != 0) {
         if (const char *e = getenv("EXG_GZ_LANES")) n_lanes_ = (size_t)std::max(1, atoi(e));
+        // A round of the chunked decoder (one big member) costs a fixed ~10 ms of dependent launches (block finder, chunk
+        // decode, window composition, resolve: each as long as its slowest wavefront) and fills the chip only from ~4000
+        // chunks on: rounds of one device batch (256 MiB) ran at 11 GB/s where rounds of 1 GiB run at 20+.  So without a
+        // memory cap (and without a deliberately small device batch) a round decodes 1 GiB; the segment is scanned in
+        // batches as usual.
+        member_round_ = target_;
+        if (!r->mem_cap && target_ >= (128ull << 20)) member_round_ = std::max<uint64_t>(target_, 1ull << 30);
+        if (const char *e = getenv("EXG_STREAM_ROUND_OUT")) member_round_ = std::max<uint64_t>(64u << 10, strtoull(e, nullptr, 10));
     }
     ~GzipProducer() override {
         for (auto &l : lanes_) l->join_read();
@@ -132,9 +140,11 @@ private:
 
     int device_, fd_;
     uint64_t c_pos_, c_end_, target_;
+    uint64_t member_round_ = 0;  // decoded bytes a round of the chunked decoder aims at
     std::string path_;
     bool bgzf_only_;
     size_t n_lanes_;  // windows of BGZF members in flight (two under a memory cap)
+    bool capped_;
     uint64_t reserve_ = 1u << 20;
     uint64_t d_pos_ = 0;       // decoded bytes produced so far
     uint64_t n_members_ = 0;   // members seen so far (error messages)
@@ -555,9 +565,24 @@ int GzipProducer::small_member(SegmentSink &sink, uint64_t stream_off, std::stri
 
 // rounds of the chunked decoder: a bounded window of compressed bytes each, the LZ77 window and the checksum carried
 int GzipProducer::big_member(SegmentSink &sink, uint64_t stream_off, std::string *err) {
-    Lane *lp = lane(0, err);
-    if (!lp) return EXG_E_HIP;
-    Lane &l = *lp;
+    // two lanes take turns: while one window is decoded, the next one is read (pread + H2D) by the other lane's thread —
+    // a round of 1 GiB reads ~0.5 GB of compressed bytes, 10 ms that used to stand in front of every round
+    Lane *lanes2[2] = {lane(0, err), nullptr};
+    if (!lanes2[0]) return EXG_E_HIP;
+    const bool ahead = !capped_ && !getenv("EXG_NO_PREFETCH");
+    if (ahead && !(lanes2[1] = lane(1, err))) return EXG_E_HIP;
+    struct DropReads {  // (whatever way this function is left: no read may still be writing into a lane's buffers)
+        Lane **l;
+        ~DropReads() {
+            for (int i = 0; i < 2; i++)
+                if (l[i]) {
+                    l[i]->join_read();
+                    if (l[i]->ra_valid && hipStreamSynchronize(l[i]->st) != hipSuccess) (void)hipGetLastError();
+                    l[i]->ra_valid = false;
+                }
+        }
+    } drop_reads{lanes2};
+    size_t li = 0;
     DevBlock d_window(device_);
     if (!d_window.ensure(32768)) {
         *err = "out of device memory";
@@ -570,20 +595,44 @@ int GzipProducer::big_member(SegmentSink &sink, uint64_t stream_off, std::string
     uint64_t grow = 1;  // window multiplier after a round that found no block start
     for (;;) {
         if (sink.cancelled()) return EXG_OK;
-        const uint64_t a0 = (bit / 8) & ~15ull;
-        uint64_t want = (uint64_t)((double)target_ / std::max(1.0, ratio_)) + (64u << 10);
+        Lane &l = *lanes2[li];
+        uint64_t a0 = (bit / 8) & ~15ull;
+        uint64_t want = (uint64_t)((double)member_round_ / std::max(1.0, ratio_)) + (64u << 10);
         want = std::max<uint64_t>(want, 256u << 10) * grow;
         if (getenv("EXG_STREAM_ROUND_BYTES")) want = strtoull(getenv("EXG_STREAM_ROUND_BYTES"), nullptr, 10) * grow;
-        const uint64_t len = std::min<uint64_t>(want, c_end_ - a0);
-        const bool partial = a0 + len < c_end_;
-        if (!l.pin.ensure((size_t)len + 64) || !l.d_comp.ensure((size_t)len + 64)) {
-            *err = "out of memory for a window of compressed bytes of '" + path_ + "'";
-            return EXG_E_HIP;
+        uint64_t len = std::min<uint64_t>(want, c_end_ - a0);
+        // the window this lane read ahead, if it holds where the round before really ended (+ a good part of a round)
+        l.join_read();
+        bool have = false;
+        if (l.ra_valid) {
+            l.ra_valid = false;
+            have = l.ra_ok && grow == 1 && a0 >= l.ra_a0 && (l.ra_a0 + l.ra_len >= c_end_ || a0 + len / 2 <= l.ra_a0 + l.ra_len);
+            if (have) {
+                a0 = l.ra_a0;  // (bytes in front of the block header are skipped by start_bit)
+                len = l.ra_len;
+            } else if (hipStreamSynchronize(l.st) != hipSuccess) {
+                (void)hipGetLastError();  // (its copies must not land in the buffer read next)
+            }
         }
-        bool hip_failed = false;
-        if (!pread_parallel(device_, fd_, a0, (size_t)len, l.pin.p, (char *)l.d_comp.p, l.st, &hip_failed)) {
-            *err = hip_failed ? "hipMemcpyAsync failed" : "short read of '" + path_ + "'";
-            return hip_failed ? EXG_E_HIP : EXG_E_IO;
+        const bool partial = a0 + len < c_end_;
+        if (!have) {
+            if (!l.pin.ensure((size_t)len + 64) || !l.d_comp.ensure((size_t)len + 64)) {
+                *err = "out of memory for a window of compressed bytes of '" + path_ + "'";
+                return EXG_E_HIP;
+            }
+            bool hip_failed = false;
+            if (!pread_parallel(device_, fd_, a0, (size_t)len, l.pin.p, (char *)l.d_comp.p, l.st, &hip_failed)) {
+                *err = hip_failed ? "hipMemcpyAsync failed" : "short read of '" + path_ + "'";
+                return hip_failed ? EXG_E_HIP : EXG_E_IO;
+            }
+        }
+        if (ahead && partial) {
+            // the round ends at a block boundary at or in front of the last block start it finds: the next window begins a few
+            // chunks in front of this one's end (read twice: ~1 % of a round)
+            const uint64_t chunk = std::max<uint64_t>(32u << 10, (len / 3900 + 16383) & ~16383ull);
+            const uint64_t slack = std::max<uint64_t>(4u << 20, 8 * chunk);
+            const uint64_t na0 = (a0 + len > slack ? a0 + len - slack : 0) & ~15ull;
+            if (na0 > a0) start_read(*lanes2[li ^ 1], na0, std::min<uint64_t>(want + slack, c_end_ - na0));
         }
         GZ_HIP(hipMemsetAsync((char *)l.d_comp.p + len, 0, 64, l.st));
         exg_inflate_round_args a;
@@ -617,6 +666,12 @@ int GzipProducer::big_member(SegmentSink &sink, uint64_t stream_off, std::string
                 return EXG_E_PARSE;
             }
             grow *= 2;
+            if (ahead) {  // (the window read ahead began where this one was expected to end: not what the bigger retry needs)
+                Lane &o = *lanes2[li ^ 1];
+                o.join_read();
+                if (o.ra_valid && hipStreamSynchronize(o.st) != hipSuccess) (void)hipGetLastError();
+                o.ra_valid = false;
+            }
             continue;
         }
         grow = 1;
@@ -665,6 +720,7 @@ int GzipProducer::big_member(SegmentSink &sink, uint64_t stream_off, std::string
         }
         pushed_last_ = false;
         if (!sink.push(std::move(seg))) return EXG_OK;
+        if (ahead) li ^= 1;
     }
 }
 
