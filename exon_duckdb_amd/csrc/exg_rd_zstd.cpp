@@ -114,6 +114,11 @@ public:
         : device_(r->device), fd_(fd), n_(n), c_begin_(c_begin), c_end_(c_end), target_(std::max<uint64_t>(target, 128u << 10)), path_(path),
           reserve_((reserve + 15) & ~15ull) {
         if (mark_at) mark_at_[0] = mark_at[0], mark_at_[1] = mark_at[1];
+        // A round's kernels are dependent launches, each as long as its slowest block's chain (~10 ms whatever the size, until
+        // the chip is full): without a memory cap a round decodes ~1 GiB instead of one device batch (exg_rd_gzip.cpp does
+        // the same for the rounds of one big gzip member)
+        if (!r->mem_cap && target_ >= (128ull << 20)) target_ = std::max<uint64_t>(target_, 1ull << 30);
+        if (const char *e = getenv("EXG_STREAM_ROUND_OUT")) target_ = std::max<uint64_t>(128u << 10, strtoull(e, nullptr, 10));
     }
     int run(SegmentSink &sink, std::string *err) override;
 
