@@ -56,7 +56,9 @@ extern "C" int exg_open(const exg_open_args *args, exg_reader **out) {
         r->mem_cap = strtoull(e, nullptr, 10) << 20;
         // (per input byte a scan provisions 16 B x columns / 32 (FASTQ) or / 16 (VCF: 9 columns + POS + QUAL) of column
         // vectors; a compressed input adds up to four segments and two compressed windows)
-        const uint64_t div = r->format == EXG_FMT_VCF ? 64 : r->format == EXG_FMT_FASTA ? 32 : 20;
+        // (24 for FASTQ: with 20 a single-member gzip under a 16 MiB cap peaked between 15.4 and 17.3 MB depending on how far the
+        // decoder thread happened to run ahead of the scan — the first round's symbol buffer is sized for the worst ratio)
+        const uint64_t div = r->format == EXG_FMT_VCF ? 64 : r->format == EXG_FMT_FASTA ? 32 : 24;
         if (r->mem_cap) r->device_batch_bytes = std::max<uint64_t>(64u << 10, std::min<uint64_t>(r->device_batch_bytes, (r->mem_cap / div) & ~15ull));
     }
     r->halo_want = getenv("EXG_SHARD_HALO") ? std::max<uint64_t>(16, strtoull(getenv("EXG_SHARD_HALO"), nullptr, 10)) : kShardHalo;

@@ -26,7 +26,22 @@ struct Xxh64 {
     }
     void stripes(const uint8_t *p, size_t n_stripes) {
         uint64_t a = v[0], b = v[1], c = v[2], d = v[3];
-        for (size_t i = 0; i < n_stripes; i++, p += 32) {
+        size_t i = 0;
+        // Two stripes = one cache line per turn, the line 1 KiB ahead asked for: the bytes come from pinned memory a DMA
+        // engine just wrote, never from a cache, and the four multiply chains leave the core's own prefetcher too little
+        // to go on (tools/xxh_bench.cpp: 3.9 -> 9.6 GB/s on the build container's core; the distance was swept 256 .. 4096)
+        for (; i + 2 <= n_stripes; i += 2, p += 64) {
+            __builtin_prefetch(p + 1024, 0, 3);
+            a = round(a, rd64(p));
+            b = round(b, rd64(p + 8));
+            c = round(c, rd64(p + 16));
+            d = round(d, rd64(p + 24));
+            a = round(a, rd64(p + 32));
+            b = round(b, rd64(p + 40));
+            c = round(c, rd64(p + 48));
+            d = round(d, rd64(p + 56));
+        }
+        for (; i < n_stripes; i++, p += 32) {
             a = round(a, rd64(p));
             b = round(b, rd64(p + 8));
             c = round(c, rd64(p + 16));
