@@ -1067,9 +1067,68 @@ int host_verify(const void *d_out, const std::vector<PendingCheck> &pending, int
     return rc;
 }
 
-int decode_round(Round &R, void *stream_v) {
+// ---- a round in three phases, so that a reader can decode round n + 1's entropy stages beside round n's execution --------------
+// begin:   the entropy stages + the scan (waits for them: the host needs the block sizes), the host's chunk plan.  Fills
+//          R.blocks' results, R.rep_out, R.frames[].out_off / out_size and R.produced — all a caller needs to prepare the
+//          round behind this one (its history size, its repeat offsets).
+// enqueue: execution, resolve, on-device checksums — launches only, on the round's stream.  R.d_history (when R.history != 0)
+//          must hold the window by now.
+// wait:    waits for them, reads the statuses; R.d_buf is the caller's from here on.
+// Temporaries come from (and go back to) the process-wide device pool: hipMalloc / hipFree of the multi-GB symbol and
+// sequence buffers cost more than the decode (the same 4 GB decode: 0.20 s with warm buffers, 0.4 - 1.2 s without).  The
+// stream is waited for before a block goes back: an error return may leave kernels in flight.
+namespace {
+struct DevTmp {
+    int dev;
+    hipStream_t st;
+    void *p = nullptr;
+    size_t sz = 0;
+    DevTmp(int d, hipStream_t s) : dev(d), st(s) {}
+    DevTmp(const DevTmp &) = delete;
+    DevTmp &operator=(const DevTmp &) = delete;
+    ~DevTmp() {
+        if (!p) return;
+        (void)hipStreamSynchronize(st);
+        exg_rd::dev_pool()->give(dev, p, sz);
+    }
+    hipError_t alloc(size_t bytes) {
+        sz = bytes ? bytes : 16;
+        p = exg_rd::dev_pool()->take(dev, sz);
+        return p ? hipSuccess : hipErrorOutOfMemory;
+    }
+};
+}  // namespace
+
+struct RoundCtx {
+    int dev;
+    hipStream_t st;
+    DevTmp d_blocks, d_lit, d_ll, d_ml, d_off, d_meta, d_frames, d_chunks, d_status, d_out, d_sym, d_lookup;
+    ScanState state;
+    uint64_t H = 0, total = 0, target = 0;
+    uint32_t nb = 0, nx = 0, nf = 0, nc = 0;
+    std::vector<Chunk> chunks;
+    std::vector<Frame> dframes;
+    // the statuses come back into pinned memory: a copy into pageable memory would hold the host until the stream is done
+    char *h_status = nullptr;
+    size_t h_status_cap = 0;
+    size_t n_rounds = 0;
+    double t_begin = 0, t_entropy = 0;
+    RoundCtx(int d, hipStream_t s)
+        : dev(d), st(s), d_blocks(d, s), d_lit(d, s), d_ll(d, s), d_ml(d, s), d_off(d, s), d_meta(d, s), d_frames(d, s), d_chunks(d, s), d_status(d, s),
+          d_out(d, s), d_sym(d, s), d_lookup(d, s) {}
+    ~RoundCtx() {
+        if (h_status) {
+            (void)hipStreamSynchronize(st);
+            exg_rd::global_pool()->give(h_status, h_status_cap);
+        }
+    }
+};
+void decode_round_abandon(RoundCtx *c) { delete c; }
+
+int decode_round_begin(Round &R, void *stream_v, RoundCtx **out_ctx) {
     hipStream_t st = (hipStream_t)stream_v;
     const uint8_t *d_comp = (const uint8_t *)R.d_comp;
+    *out_ctx = nullptr;
     R.d_buf = nullptr;
     R.alloc = 0;
     R.produced = 0;
@@ -1078,31 +1137,14 @@ int decode_round(Round &R, void *stream_v) {
         return EXG_E_INVALID_ARG;
     }
     static const bool trace = getenv("EXG_TRACE") != nullptr;
-    const double t_begin = trace ? now_ms() : 0;
-    // temporaries come from (and go back to) the process-wide device pool: hipMalloc / hipFree of the multi-GB symbol
-    // and sequence buffers cost more than the decode (the same 4 GB decode: 0.20 s with warm buffers, 0.4 - 1.2 s without).
-    // The stream is waited for before a block goes back: an error return may leave kernels in flight.
     int cur_dev = 0;
     (void)hipGetDevice(&cur_dev);
-    struct Dev {
-        int dev;
-        hipStream_t st;
-        void *p = nullptr;
-        size_t sz = 0;
-        Dev(int d, hipStream_t s) : dev(d), st(s) {}
-        ~Dev() {
-            if (!p) return;
-            (void)hipStreamSynchronize(st);
-            exg_rd::dev_pool()->give(dev, p, sz);
-        }
-        hipError_t alloc(size_t bytes) {
-            sz = bytes ? bytes : 16;
-            p = exg_rd::dev_pool()->take(dev, sz);
-            return p ? hipSuccess : hipErrorOutOfMemory;
-        }
-    };
+    std::unique_ptr<RoundCtx> ctx(new RoundCtx(cur_dev, st));
+    RoundCtx &C = *ctx;
+    C.t_begin = trace ? now_ms() : 0;
     std::vector<Block> &blocks = R.blocks;
     const uint32_t nb = (uint32_t)blocks.size(), nx = R.n_extra, nf = (uint32_t)R.frames.size();
+    C.nb = nb, C.nx = nx, C.nf = nf;
     // where every block's literals and sequences go (the sources in front hold none of their own)
     uint64_t lit_bytes = 0, n_seq = 0;
     for (uint32_t b = nx; b < nb; b++) {
@@ -1110,21 +1152,20 @@ int decode_round(Round &R, void *stream_v) {
         blocks[b].seq_off = n_seq;
         if (blocks[b].type == 2) lit_bytes += (blocks[b].lit_regen + 15) & ~15u, n_seq += blocks[b].nseq;
     }
-    Dev d_blocks(cur_dev, st), d_lit(cur_dev, st), d_ll(cur_dev, st), d_ml(cur_dev, st), d_off(cur_dev, st), d_meta(cur_dev, st), d_frames(cur_dev, st),
-        d_chunks(cur_dev, st), d_status(cur_dev, st), d_out(cur_dev, st), d_sym(cur_dev, st), d_lookup(cur_dev, st);
-    EXG_HIP_CHECK(d_meta.alloc(64));
+    EXG_HIP_CHECK(C.d_meta.alloc(64));
     const uint64_t H = R.history;
-    ScanState state;
+    C.H = H;
+    ScanState &state = C.state;
     state.run = H;  // buffer coordinates: [0, H) = what earlier rounds left of the frame that goes on, then this round's bytes
     state.rep[0] = R.rep_in[0], state.rep[1] = R.rep_in[1], state.rep[2] = R.rep_in[2], state.pad = 0;
     if (nb > nx) {
-        EXG_HIP_CHECK(d_blocks.alloc((size_t)nb * sizeof(Block)));
-        EXG_HIP_CHECK(d_lit.alloc(lit_bytes + 64));
-        EXG_HIP_CHECK(d_ll.alloc(n_seq * 4 + 16));
-        EXG_HIP_CHECK(d_ml.alloc(n_seq * 4 + 16));
-        EXG_HIP_CHECK(d_off.alloc(n_seq * 4 + 16));
-        EXG_HIP_CHECK(hipMemcpyAsync(d_blocks.p, blocks.data(), (size_t)nb * sizeof(Block), hipMemcpyHostToDevice, st));
-        EXG_HIP_CHECK(hipMemcpyAsync(d_meta.p, &state, sizeof state, hipMemcpyHostToDevice, st));
+        EXG_HIP_CHECK(C.d_blocks.alloc((size_t)nb * sizeof(Block)));
+        EXG_HIP_CHECK(C.d_lit.alloc(lit_bytes + 64));
+        EXG_HIP_CHECK(C.d_ll.alloc(n_seq * 4 + 16));
+        EXG_HIP_CHECK(C.d_ml.alloc(n_seq * 4 + 16));
+        EXG_HIP_CHECK(C.d_off.alloc(n_seq * 4 + 16));
+        EXG_HIP_CHECK(hipMemcpyAsync(C.d_blocks.p, blocks.data(), (size_t)nb * sizeof(Block), hipMemcpyHostToDevice, st));
+        EXG_HIP_CHECK(hipMemcpyAsync(C.d_meta.p, &state, sizeof state, hipMemcpyHostToDevice, st));
         const uint32_t grid = nb - nx < 16384 ? nb - nx : 16384;
         // the two entropy stages are independent of each other (both run one or four LANES per wavefront: the chip is far
         // from full with either): literals on a second stream beside the sequences
@@ -1137,9 +1178,9 @@ int decode_round(Round &R, void *stream_v) {
             (void)hipEventRecord(ev0, st);
             (void)hipStreamWaitEvent(st2, ev0, 0);
         }
-        hipLaunchKernelGGL(k_zst_literals, dim3(grid), dim3(64), 0, side ? st2 : st, d_comp, (Block *)d_blocks.p, nx, nb, (uint8_t *)d_lit.p);
-        hipLaunchKernelGGL(k_zst_sequences, dim3(grid), dim3(64), 0, st, d_comp, (Block *)d_blocks.p, nx, nb, (uint32_t *)d_ll.p, (uint32_t *)d_ml.p,
-                           (uint32_t *)d_off.p);
+        hipLaunchKernelGGL(k_zst_literals, dim3(grid), dim3(64), 0, side ? st2 : st, d_comp, (Block *)C.d_blocks.p, nx, nb, (uint8_t *)C.d_lit.p);
+        hipLaunchKernelGGL(k_zst_sequences, dim3(grid), dim3(64), 0, st, d_comp, (Block *)C.d_blocks.p, nx, nb, (uint32_t *)C.d_ll.p, (uint32_t *)C.d_ml.p,
+                           (uint32_t *)C.d_off.p);
         if (side) {
             (void)hipEventRecord(ev1, st2);
             (void)hipStreamWaitEvent(st, ev1, 0);
@@ -1154,10 +1195,10 @@ int decode_round(Round &R, void *stream_v) {
                 if (s) exg_rd::stream_pool()->give(dev, s);  // (synchronises it)
             }
         } side_guard{dev, st2, ev0, ev1};
-        hipLaunchKernelGGL(k_zst_scan, dim3(1), dim3(64), 0, st, (Block *)d_blocks.p, nx, nb, (ScanState *)d_meta.p);
+        hipLaunchKernelGGL(k_zst_scan, dim3(1), dim3(64), 0, st, (Block *)C.d_blocks.p, nx, nb, (ScanState *)C.d_meta.p);
         EXG_HIP_CHECK(hipGetLastError());
-        EXG_HIP_CHECK(hipMemcpyAsync(blocks.data(), d_blocks.p, (size_t)nb * sizeof(Block), hipMemcpyDeviceToHost, st));
-        EXG_HIP_CHECK(hipMemcpyAsync(&state, d_meta.p, sizeof state, hipMemcpyDeviceToHost, st));
+        EXG_HIP_CHECK(hipMemcpyAsync(blocks.data(), C.d_blocks.p, (size_t)nb * sizeof(Block), hipMemcpyDeviceToHost, st));
+        EXG_HIP_CHECK(hipMemcpyAsync(&state, C.d_meta.p, sizeof state, hipMemcpyDeviceToHost, st));
         EXG_HIP_CHECK(hipStreamSynchronize(st));
         for (uint32_t b = nx; b < nb; b++)
             if (blocks[b].status) {
@@ -1167,6 +1208,7 @@ int decode_round(Round &R, void *stream_v) {
             }
     }
     const uint64_t total = state.run - H;
+    C.total = total;
     R.rep_out[0] = state.rep[0], R.rep_out[1] = state.rep[1], R.rep_out[2] = state.rep[2];
     // frames: where their content lies.  Chunks: a frame is cut into runs of whole blocks of about `target` bytes, one
     // wavefront each.  The first chunk of a frame (or of the part of a frame this round holds: what lies in front of it is
@@ -1175,8 +1217,10 @@ int decode_round(Round &R, void *stream_v) {
     // is final (k_zst_resolve).
     static const uint64_t target_env = getenv("EXG_ZSTD_CHUNK_BYTES") ? strtoull(getenv("EXG_ZSTD_CHUNK_BYTES"), nullptr, 10) : 0;
     const uint64_t target = target_env ? target_env : std::min<uint64_t>(2u << 20, std::max<uint64_t>(128u << 10, total / 4096));
-    std::vector<Chunk> chunks;
-    std::vector<Frame> dframes(nf);
+    C.target = target;
+    std::vector<Chunk> &chunks = C.chunks;
+    std::vector<Frame> &dframes = C.dframes;
+    dframes.resize(nf);
     uint64_t sym_elems = 0;
     for (uint32_t f = 0; f < nf; f++) {
         RoundFrame &F = R.frames[f];
@@ -1206,22 +1250,38 @@ int decode_round(Round &R, void *stream_v) {
             chunks.push_back(c);
         }
     }
-    const double t_entropy = trace ? sync_ms(st) : 0;
+    C.t_entropy = trace ? now_ms() : 0;
+    R.produced = total;
+    *out_ctx = ctx.release();
+    return EXG_OK;
+}
+
+// (on an error the context is gone: its blocks went back to the pool behind a synchronised stream)
+int decode_round_enqueue(Round &R, RoundCtx *ctx_p) {
+    std::unique_ptr<RoundCtx> ctx(ctx_p);
+    RoundCtx &C = *ctx;
+    hipStream_t st = C.st;
+    const uint8_t *d_comp = (const uint8_t *)R.d_comp;
+    std::vector<Block> &blocks = R.blocks;
+    std::vector<Chunk> &chunks = C.chunks;
+    const uint64_t H = C.H, total = C.total;
+    const uint32_t nf = C.nf;
+    static const bool trace = getenv("EXG_TRACE") != nullptr;
     // (allocated at the device pool's size class: the caller hands the buffer back to that pool)
-    EXG_HIP_CHECK(d_out.alloc(R.front_reserve + H + total + 64));
-    uint8_t *const out_bytes = (uint8_t *)d_out.p + R.front_reserve;  // buffer coordinate 0
+    EXG_HIP_CHECK(C.d_out.alloc(R.front_reserve + H + total + 64));
+    uint8_t *const out_bytes = (uint8_t *)C.d_out.p + R.front_reserve;  // buffer coordinate 0
     if (H) EXG_HIP_CHECK(hipMemcpyAsync(out_bytes, R.d_history, H, hipMemcpyDeviceToDevice, st));
     EXG_HIP_CHECK(hipMemsetAsync(out_bytes + H + total, 0, 64, st));
     const uint32_t nc = (uint32_t)chunks.size();
-    double t_exec = 0, t_resolve = 0;
+    C.nc = nc;
     if (nc) {
         // symbol chunks are executed and resolved in rounds that fit the symbol buffer (4 bytes per output byte)
         static const uint64_t sym_cap_env = getenv("EXG_ZSTD_SYM_BYTES") ? strtoull(getenv("EXG_ZSTD_SYM_BYTES"), nullptr, 10) : (32ull << 30);
         const uint64_t sym_cap = std::max<uint64_t>(sym_cap_env / 4, 1);
-        EXG_HIP_CHECK(d_chunks.alloc((size_t)nc * sizeof(Chunk)));
-        EXG_HIP_CHECK(d_frames.alloc((size_t)nf * sizeof(Frame)));
-        EXG_HIP_CHECK(d_status.alloc(((size_t)nc + nf) * 4));
-        EXG_HIP_CHECK(hipMemsetAsync(d_status.p, 0, ((size_t)nc + nf) * 4, st));
+        EXG_HIP_CHECK(C.d_chunks.alloc((size_t)nc * sizeof(Chunk)));
+        EXG_HIP_CHECK(C.d_frames.alloc((size_t)nf * sizeof(Frame)));
+        EXG_HIP_CHECK(C.d_status.alloc(((size_t)nc + nf) * 4));
+        EXG_HIP_CHECK(hipMemsetAsync(C.d_status.p, 0, ((size_t)nc + nf) * 4, st));
         // chunk sizes (bytes of output) and the rounds
         std::vector<uint64_t> csize(nc);
         for (uint32_t c = 0; c < nc; c++) {
@@ -1264,20 +1324,32 @@ int decode_round(Round &R, void *stream_v) {
             Q.c1 = nc;
             rounds.push_back(Q);
         }
-        if (sym_need) EXG_HIP_CHECK(d_sym.alloc(sym_need * 4 + 64));
-        EXG_HIP_CHECK(d_lookup.alloc((sym_list.size() + 1) * 4));
-        uint32_t *d_sym_list = (uint32_t *)d_lookup.p;
-        if (!sym_list.empty()) EXG_HIP_CHECK(hipMemcpyAsync(d_sym_list, sym_list.data(), sym_list.size() * 4, hipMemcpyHostToDevice, st));
-        EXG_HIP_CHECK(hipMemcpyAsync(d_chunks.p, chunks.data(), (size_t)nc * sizeof(Chunk), hipMemcpyHostToDevice, st));
-        EXG_HIP_CHECK(hipMemcpyAsync(d_frames.p, dframes.data(), (size_t)nf * sizeof(Frame), hipMemcpyHostToDevice, st));
+        C.n_rounds = rounds.size();
+        if (sym_need) EXG_HIP_CHECK(C.d_sym.alloc(sym_need * 4 + 64));
+        // the tables below travel from pinned memory (pageable sources would be staged: the calls would wait)
+        const size_t list_bytes = (sym_list.size() + 1) * 4, chunk_bytes = (size_t)nc * sizeof(Chunk), frame_bytes = (size_t)nf * sizeof(Frame),
+                     status_bytes = ((size_t)nc + nf) * 4;
+        C.h_status_cap = status_bytes + list_bytes + chunk_bytes + frame_bytes + 64;
+        C.h_status = exg_rd::global_pool()->take(&C.h_status_cap);
+        if (!C.h_status) {
+            set_error("zstd decode: out of pinned host memory");
+            return EXG_E_NOMEM;
+        }
+        char *h_list = C.h_status + status_bytes, *h_chunks = h_list + list_bytes, *h_frames = h_chunks + chunk_bytes;
+        if (!sym_list.empty()) memcpy(h_list, sym_list.data(), sym_list.size() * 4);
+        memcpy(h_chunks, chunks.data(), chunk_bytes);
+        if (frame_bytes) memcpy(h_frames, C.dframes.data(), frame_bytes);
+        EXG_HIP_CHECK(C.d_lookup.alloc(list_bytes));
+        uint32_t *d_sym_list = (uint32_t *)C.d_lookup.p;
+        if (!sym_list.empty()) EXG_HIP_CHECK(hipMemcpyAsync(d_sym_list, h_list, sym_list.size() * 4, hipMemcpyHostToDevice, st));
+        EXG_HIP_CHECK(hipMemcpyAsync(C.d_chunks.p, h_chunks, chunk_bytes, hipMemcpyHostToDevice, st));
+        EXG_HIP_CHECK(hipMemcpyAsync(C.d_frames.p, h_frames, frame_bytes, hipMemcpyHostToDevice, st));
         for (const SymRound &Q : rounds) {
             const uint32_t cnt = Q.c1 - Q.c0, grid = cnt < 16384 ? cnt : 16384;
             if (!cnt) continue;
-            const double t0 = trace ? sync_ms(st) : 0;
-            hipLaunchKernelGGL(k_zst_exec, dim3(grid), dim3(64), 0, st, d_comp, (const Block *)d_blocks.p, (const Chunk *)d_chunks.p + Q.c0, cnt,
-                               (const uint8_t *)d_lit.p, (const uint32_t *)d_ll.p, (const uint32_t *)d_ml.p, (const uint32_t *)d_off.p,
-                               out_bytes, (uint32_t *)d_sym.p, (uint32_t *)d_status.p + Q.c0);
-            const double t1 = trace ? sync_ms(st) : 0;
+            hipLaunchKernelGGL(k_zst_exec, dim3(grid), dim3(64), 0, st, d_comp, (const Block *)C.d_blocks.p, (const Chunk *)C.d_chunks.p + Q.c0, cnt,
+                               (const uint8_t *)C.d_lit.p, (const uint32_t *)C.d_ll.p, (const uint32_t *)C.d_ml.p, (const uint32_t *)C.d_off.p,
+                               out_bytes, (uint32_t *)C.d_sym.p, (uint32_t *)C.d_status.p + Q.c0);
             static const uint64_t group_bytes = getenv("EXG_ZSTD_RESOLVE_BYTES") ? strtoull(getenv("EXG_ZSTD_RESOLVE_BYTES"), nullptr, 10) : (512ull << 10);
             for (uint32_t k0 = 0; k0 < Q.n_list;) {
                 uint32_t k1 = k0;
@@ -1285,8 +1357,8 @@ int decode_round(Round &R, void *stream_v) {
                 while (k1 < Q.n_list && k1 - k0 < kGroupMax && (bytes < group_bytes || k1 == k0)) bytes += csize[sym_list[Q.list0 + k1]], k1++;
                 const Chunk &first = chunks[sym_list[Q.list0 + k0]], &last = chunks[sym_list[Q.list0 + k1 - 1]];
                 ResolveArgs ra;
-                ra.sym = (const uint32_t *)d_sym.p;
-                ra.chunks = (const Chunk *)d_chunks.p;
+                ra.sym = (const uint32_t *)C.d_sym.p;
+                ra.chunks = (const Chunk *)C.d_chunks.p;
                 ra.sym_chunks = d_sym_list + Q.list0 + k0;
                 ra.n_sym_chunks = k1 - k0;
                 ra.out = out_bytes;
@@ -1296,27 +1368,33 @@ int decode_round(Round &R, void *stream_v) {
                 hipLaunchKernelGGL(k_zst_resolve, dim3((uint32_t)((ra.n_elems + 1023) / 1024)), dim3(256), 0, st, ra);
                 k0 = k1;
             }
-            if (trace) {
-                (void)hipStreamSynchronize(st);
-                t_exec += t1 - t0;
-                t_resolve += now_ms() - t1;
-            }
         }
-        const double t2 = trace ? now_ms() : 0;
-        hipLaunchKernelGGL(k_zst_xxh64, dim3(nf < 16384 ? nf : 16384), dim3(64), 0, st, (const uint8_t *)out_bytes, (const Frame *)d_frames.p, nf,
-                           R.verify_max, (uint32_t *)d_status.p + nc);
+        hipLaunchKernelGGL(k_zst_xxh64, dim3(nf < 16384 ? nf : 16384), dim3(64), 0, st, (const uint8_t *)out_bytes, (const Frame *)C.d_frames.p, nf,
+                           R.verify_max, (uint32_t *)C.d_status.p + nc);
         EXG_HIP_CHECK(hipGetLastError());
-        std::vector<uint32_t> status((size_t)nc + nf);
-        EXG_HIP_CHECK(hipMemcpyAsync(status.data(), d_status.p, status.size() * 4, hipMemcpyDeviceToHost, st));
-        EXG_HIP_CHECK(hipStreamSynchronize(st));
+        EXG_HIP_CHECK(hipMemcpyAsync(C.h_status, C.d_status.p, status_bytes, hipMemcpyDeviceToHost, st));
+    }
+    (void)trace;
+    ctx.release();
+    return EXG_OK;
+}
+
+int decode_round_wait(Round &R, RoundCtx *ctx_p) {
+    std::unique_ptr<RoundCtx> ctx(ctx_p);
+    RoundCtx &C = *ctx;
+    static const bool trace = getenv("EXG_TRACE") != nullptr;
+    EXG_HIP_CHECK(hipStreamSynchronize(C.st));
+    const uint32_t nc = C.nc, nf = C.nf, nx = C.nx;
+    if (nc) {
+        const uint32_t *status = (const uint32_t *)C.h_status;
         if (trace)
-            fprintf(stderr, "[exg] zstd: %u blocks, %u chunks (target %llu KiB, %zu round(s)), entropy+scan %.1f ms, exec %.1f ms, resolve %.1f ms, "
-                            "xxh64 %.1f ms, %.1f MB out (+ %.1f MB of window in front)\n",
-                    nb - nx, nc, (unsigned long long)(target >> 10), rounds.size(), t_entropy - t_begin, t_exec, t_resolve, now_ms() - t2, total / 1e6, H / 1e6);
+            fprintf(stderr, "[exg] zstd: %u blocks, %u chunks (target %llu KiB, %zu round(s)), entropy+scan %.1f ms, execution + resolve + xxh64 done %.1f ms "
+                            "after the round began, %.1f MB out (+ %.1f MB of window in front)\n",
+                    C.nb - nx, nc, (unsigned long long)(C.target >> 10), C.n_rounds, C.t_entropy - C.t_begin, now_ms() - C.t_begin, C.total / 1e6, C.H / 1e6);
         for (uint32_t c = 0; c < nc; c++)
             if (status[c]) {
-                set_error("%s (zstd blocks %llu..%llu)", status_text(status[c]), (unsigned long long)(R.first_block_id + chunks[c].first_block - nx),
-                          (unsigned long long)(R.first_block_id + chunks[c].first_block - nx + chunks[c].n_blocks - 1));
+                set_error("%s (zstd blocks %llu..%llu)", status_text(status[c]), (unsigned long long)(R.first_block_id + C.chunks[c].first_block - nx),
+                          (unsigned long long)(R.first_block_id + C.chunks[c].first_block - nx + C.chunks[c].n_blocks - 1));
                 return EXG_E_PARSE;
             }
         for (uint32_t f = 0; f < nf; f++) {
@@ -1324,16 +1402,22 @@ int decode_round(Round &R, void *stream_v) {
                 set_error("%s (zstd frame %u)", status_text(status[nc + f]), R.frames[f].frame_id);
                 return EXG_E_PARSE;
             }
-            R.frames[f].verified = dframes[f].has_checksum && R.frames[f].out_size <= R.verify_max;
+            R.frames[f].verified = C.dframes[f].has_checksum && R.frames[f].out_size <= R.verify_max;
         }
-    } else {
-        EXG_HIP_CHECK(hipStreamSynchronize(st));
     }
-    R.d_buf = d_out.p;  // the caller's from here on (exg_rd::dev_pool()->give(dev, p, alloc))
-    R.alloc = d_out.sz;
-    d_out.p = nullptr;
-    R.produced = total;
+    R.d_buf = C.d_out.p;  // the caller's from here on (exg_rd::dev_pool()->give(dev, p, alloc))
+    R.alloc = C.d_out.sz;
+    C.d_out.p = nullptr;
+    R.produced = C.total;
     return EXG_OK;
+}
+
+int decode_round(Round &R, void *stream_v) {
+    RoundCtx *ctx = nullptr;
+    int rc = decode_round_begin(R, stream_v, &ctx);
+    if (!rc) rc = decode_round_enqueue(R, ctx);
+    if (!rc) rc = decode_round_wait(R, ctx);
+    return rc;
 }
 
 uint64_t default_verify_max() {

@@ -150,6 +150,14 @@ struct Round {
     uint32_t rep_out[3] = {1, 4, 8};
 };
 int decode_round(Round &R, void *stream);
+// the same in three phases (exg_zstd.hip): round n + 1's entropy stages can run beside round n's execution.  begin fills
+// R.rep_out, R.frames[].out_off / out_size and R.produced; enqueue needs R.d_history; wait hands R.d_buf over.  A phase that
+// fails has disposed of the context.
+struct RoundCtx;
+int decode_round_begin(Round &R, void *stream, RoundCtx **ctx);
+int decode_round_enqueue(Round &R, RoundCtx *ctx);
+int decode_round_wait(Round &R, RoundCtx *ctx);
+void decode_round_abandon(RoundCtx *ctx);
 uint64_t default_verify_max();
 
 // exg_zstd_decode (include/exon_gpu.h) without the host half of the checksum verification: the frames left to it come back
