@@ -1067,7 +1067,12 @@ int host_verify(const void *d_out, const std::vector<PendingCheck> &pending, int
     return rc;
 }
 
-// ---- a round in three phases, so that a reader can decode round n + 1's entropy stages beside round n's execution --------------
+// ---- a round in three phases ----------------------------------------------------------------------------------------------------
+// (Written so that a reader could run round n + 1's entropy stages beside round n's execution on a second stream.  Measured
+// through the reader — two slots, two streams, two compressed windows — it gave nothing: 10.3 against 10.2 GB/s on a 4 GB
+// frame.  Every one of these kernels alone fills the CUs' LDS with its one-lane wavefronts (k_zst_exec: 16.5 KiB per wave),
+// so the other stream's kernels queue up behind instead of running beside.  The reader calls decode_round; the phases stay
+// as the function's structure.)
 // begin:   the entropy stages + the scan (waits for them: the host needs the block sizes), the host's chunk plan.  Fills
 //          R.blocks' results, R.rep_out, R.frames[].out_off / out_size and R.produced — all a caller needs to prepare the
 //          round behind this one (its history size, its repeat offsets).

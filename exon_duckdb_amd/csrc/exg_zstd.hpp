@@ -150,9 +150,9 @@ struct Round {
     uint32_t rep_out[3] = {1, 4, 8};
 };
 int decode_round(Round &R, void *stream);
-// the same in three phases (exg_zstd.hip): round n + 1's entropy stages can run beside round n's execution.  begin fills
-// R.rep_out, R.frames[].out_off / out_size and R.produced; enqueue needs R.d_history; wait hands R.d_buf over.  A phase that
-// fails has disposed of the context.
+// the same in three phases (exg_zstd.hip): begin (entropy stages, scan, chunk plan) fills R.rep_out, R.frames[].out_off /
+// out_size and R.produced; enqueue (execution, resolve, checksums: launches only) needs R.d_history; wait hands R.d_buf over.
+// A phase that fails has disposed of the context.  (Overlapping two rounds with them measured no gain: see exg_zstd.hip.)
 struct RoundCtx;
 int decode_round_begin(Round &R, void *stream, RoundCtx **ctx);
 int decode_round_enqueue(Round &R, RoundCtx *ctx);
