@@ -169,3 +169,33 @@ def test_new_reader_under_the_cap(gpu, oracle, fastq_mid, tmp_path, monkeypatch)
                 hs[k].update(b"\xff\x00NULL" if v is None else v.encode())
                 hs[k].update(b"\x00")
     assert (n, hashlib.blake2b(b"".join(h.digest() for h in hs), digest_size=16).hexdigest()) == want
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("round_out", [1 << 20, 5 << 20])
+def test_round_size_does_not_change_the_rows(gpu, fastq_mid, tmp_path, monkeypatch, round_out):
+    """No memory cap: a big gzip member is decoded in rounds by two lanes that take turns (the next window read ahead while
+    the current one is decoded), a zstd frame in rounds whose checksum is folded by the stage behind the decoder.  Small
+    rounds (EXG_STREAM_ROUND_OUT) put a 66 MB input through a dozen to sixty of them: the rows are the oracle's."""
+    from zstd_util import compress
+    data, want = fastq_mid
+    monkeypatch.delenv("EXG_DEVICE_MEM_CAP_MB", raising=False)
+    monkeypatch.setenv("EXG_STREAM_ROUND_OUT", str(round_out))
+    one = tmp_path / "one.fastq.gz"
+    one.write_bytes(gzip.compress(data, 1, mtime=0))
+    z1 = tmp_path / "one.fastq.zst"
+    z1.write_bytes(compress(data, 3, True, window_log=20))   # one frame with a checksum, a 1 MiB window carried from round to round
+    for p in (one, z1):
+        r = _open(p, "fastq")
+        got = r.digest()
+        st = r.stats()
+        r.close()
+        assert got == want, p.name
+        assert st["decoded_segments"] >= (len(data) // round_out) // 2, st
+    # a wrong checksum in the zstd frame's last four bytes: reported, behind the rows
+    bad = bytearray(z1.read_bytes())
+    bad[-1] ^= 0x40
+    zb = tmp_path / "bad.fastq.zst"
+    zb.write_bytes(bytes(bad))
+    rows, msg = _expect_error(zb, "fastq", min_rows_before=int(want[0] * 0.9))
+    assert "checksum" in msg.lower(), msg
