@@ -1305,7 +1305,7 @@ extern "C" ReaderResult new_reader(ArrowArrayStream *stream_ptr, const char *uri
     {
         std::vector<Stripe> stripes;
         unsigned workers = 1;
-        if (plan_stripes(st->r, &oa, &stripes, &workers) == EXG_OK && stripes.size() > st->r->files.size()) {
+        if (plan_stripes(st->r->files, st->r->compression, &oa, &stripes, &workers) == EXG_OK && stripes.size() > st->r->files.size()) {
             struct Sub : FanSub {
                 std::shared_ptr<StreamState> st;
                 ~Sub() override {

@@ -156,7 +156,8 @@ Compression compression_of(const exg_open_args *args);
 
 
 struct Stripe;
-int plan_stripes(const exg_reader *r, const exg_open_args *args, std::vector<Stripe> *out, unsigned *n_workers);
+int list_path(const std::string &path, std::vector<std::string> *files, std::string *err);
+int plan_stripes(const std::vector<std::string> &files, Compression compression, const exg_open_args *args, std::vector<Stripe> *out, unsigned *n_workers);
 
 // ---- exg_rd_batch.cpp
 int n_string_cols(int format);

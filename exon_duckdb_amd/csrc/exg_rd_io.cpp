@@ -89,25 +89,9 @@ int fail(exg_reader *r, int code, const std::string &msg) {
 }
 
 int list_files(exg_reader *r, const std::string &path) {
-    struct stat st;
-    if (path.empty() || stat(path.c_str(), &st) != 0)
-        return fail(r, EXG_E_IO, "could not register table: cannot open '" + path + "': " + strerror(errno));
-    if (S_ISDIR(st.st_mode)) {
-        // the reference lists a directory (test_fasta_scan.test:55-59, test_fastq_scan.test:65-68)
-        DIR *d = opendir(path.c_str());
-        if (!d) return fail(r, EXG_E_IO, "cannot list '" + path + "'");
-        while (dirent *e = readdir(d)) {
-            if (e->d_name[0] == '.') continue;
-            std::string p = path + (path.back() == '/' ? "" : "/") + e->d_name;
-            struct stat s2;
-            if (stat(p.c_str(), &s2) == 0 && S_ISREG(s2.st_mode)) r->files.push_back(p);
-        }
-        closedir(d);
-        std::sort(r->files.begin(), r->files.end());
-    } else {
-        r->files.push_back(path);
-    }
-    return EXG_OK;
+    std::string err;
+    const int rc = list_path(path, &r->files, &err);  // (exg_rd_plan.cpp: host only)
+    return rc ? fail(r, rc, err) : EXG_OK;
 }
 
 }  // namespace exg_rd

@@ -7,6 +7,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <dirent.h>
+#include <errno.h>
+
 #include <algorithm>
 
 #include "exg_rd_fanout.hpp"
@@ -81,11 +84,40 @@ static bool file_is_shardable(const std::string &f, const std::string &fmt_lower
 }
 
 namespace exg_rd {
+// the files of an input path: itself, or — a directory, which the reference lists (test_fasta_scan.test:55-59,
+// test_fastq_scan.test:65-68) — its regular files in name order
+int list_path(const std::string &path, std::vector<std::string> *files, std::string *err) {
+    struct stat st;
+    if (path.empty() || stat(path.c_str(), &st) != 0) {
+        *err = "could not register table: cannot open '" + path + "': " + strerror(errno);
+        return EXG_E_IO;
+    }
+    if (S_ISDIR(st.st_mode)) {
+        DIR *d = opendir(path.c_str());
+        if (!d) {
+            *err = "cannot list '" + path + "'";
+            return EXG_E_IO;
+        }
+        const size_t first = files->size();
+        while (dirent *e = readdir(d)) {
+            if (e->d_name[0] == '.') continue;
+            std::string p = path + (path.back() == '/' ? "" : "/") + e->d_name;
+            struct stat s2;
+            if (stat(p.c_str(), &s2) == 0 && S_ISREG(s2.st_mode)) files->push_back(p);
+        }
+        closedir(d);
+        std::sort(files->begin() + (long)first, files->end());
+    } else {
+        files->push_back(path);
+    }
+    return EXG_OK;
+}
+
 // The stripes a reader with shard_count = 0 fans out over (exg_rd_fanout.hpp): every file that can be sharded is cut into
 // stripes of about EXG_FANOUT_STRIPE_MB (1024) MiB, a multiple of the device count of them, stripe s on device s mod N; a
 // file that cannot be sharded is one stripe.  One device and nothing forced: one stripe per file — the caller then reads
 // the input itself.  EXON_GPU_SHARDS = n forces n stripes per shardable file (tests: several stripes on one device).
-int plan_stripes(const exg_reader *r, const exg_open_args *args, std::vector<Stripe> *out, unsigned *n_workers) {
+int plan_stripes(const std::vector<std::string> &files, Compression compression, const exg_open_args *args, std::vector<Stripe> *out, unsigned *n_workers) {
     out->clear();
     const int n_dev = exg_device_count();
     if (n_dev < 1) return EXG_E_NO_DEVICE;
@@ -94,11 +126,11 @@ int plan_stripes(const exg_reader *r, const exg_open_args *args, std::vector<Str
     const char *forced = getenv("EXON_GPU_SHARDS");
     const uint64_t stripe_bytes = (getenv("EXG_FANOUT_STRIPE_MB") ? std::max<uint64_t>(1, strtoull(getenv("EXG_FANOUT_STRIPE_MB"), nullptr, 10)) : 1024) << 20;
     uint32_t next_dev = 0;
-    for (const std::string &f : r->files) {
+    for (const std::string &f : files) {
         struct stat st;
         uint64_t bytes = stat(f.c_str(), &st) == 0 ? (uint64_t)st.st_size : 0;
         uint32_t n = 1;
-        if (file_is_shardable(f, fmt, r->compression)) {
+        if (file_is_shardable(f, fmt, compression)) {
             if (forced) n = (uint32_t)std::max(1, atoi(forced));
             else if (n_dev > 1 && bytes >= (512ull << 20)) {
                 const uint64_t per_round = stripe_bytes * (uint64_t)n_dev;
@@ -131,11 +163,12 @@ extern "C" int exg_plan_shards(const exg_open_args *args, uint32_t *n_shards, in
     std::string fmt = args->file_format;
     for (char &ch : fmt) ch = (char)tolower((unsigned char)ch);
     const Compression comp = compression_of(args);
-    exg_reader tmp;
-    if (list_files(&tmp, args->path) != EXG_OK) return EXG_OK;  // the open will report it
+    std::vector<std::string> files;
+    std::string list_err;
+    if (list_path(args->path, &files, &list_err) != EXG_OK) return EXG_OK;  // the open will report it
     uint64_t bytes = 0;
     bool shardable = true;
-    for (const std::string &f : tmp.files) {
+    for (const std::string &f : files) {
         struct stat st;
         if (stat(f.c_str(), &st) != 0) continue;
         bytes += (uint64_t)st.st_size;

@@ -117,7 +117,7 @@ extern "C" int exg_open(const exg_open_args *args, exg_reader **out) {
         // several devices (or stripes forced): this reader becomes the front of a fan-out
         std::vector<Stripe> stripes;
         unsigned workers = 1;
-        if ((rc = plan_stripes(r.get(), args, &stripes, &workers))) return rc;
+        if ((rc = plan_stripes(r->files, r->compression, args, &stripes, &workers))) return rc;
         if (stripes.size() > r->files.size()) {
             struct Sub : FanSub {
                 exg_reader *rd = nullptr;

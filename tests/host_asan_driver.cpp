@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "exg_filter.hpp"
+#include "exg_rd_fanout.hpp"
 #include "exg_rd_internal.hpp"
 #include "exg_vcf_header.hpp"
 #include "exg_xxh64.hpp"
@@ -21,6 +22,9 @@
 namespace exg {
 void set_error(const char *, ...) {}
 }  // namespace exg
+
+static int g_devices = 1;
+extern "C" int exg_device_count(void) { return g_devices; }  // (the planner asks the library: here the test says)
 
 static std::vector<uint8_t> read_file(const char *path) {
     std::vector<uint8_t> v;
@@ -167,6 +171,69 @@ int main(int argc, char **argv) {
             if (h.digest() != one(buf.data(), n)) return 6;
             runs++;
         }
+    }
+    // the shard planner (exg_rd_plan.cpp): every input file of this run, a directory of them, paths that do not exist, forced
+    // shard counts, few and many devices — the plan never names more shards than the caller has room for, never a device
+    // that does not exist, and every stripe of a fan-out points at a file of the input
+    {
+        const char *fmts[] = {"fastq", ""};
+        std::vector<std::string> inputs;
+        for (int i = 1; i < argc; i++) inputs.push_back(argv[i]);
+        if (argc > 1) {
+            std::string dir = argv[1];
+            const size_t slash = dir.rfind('/');
+            inputs.push_back(slash == std::string::npos ? "." : dir.substr(0, slash));  // the directory the test wrote them to
+        }
+        inputs.push_back("/nonexistent/x.fastq");
+        inputs.push_back("");
+        const char *forced[] = {nullptr, "7", "100000", "x"};
+        for (const std::string &in : inputs)
+            for (const char *f : forced)
+                for (int n_dev : {1, 8}) {
+                    g_devices = n_dev;
+                    if (f) setenv("EXON_GPU_SHARDS", f, 1);
+                    else unsetenv("EXON_GPU_SHARDS");
+                    for (const char *fmt : fmts)
+                        for (const char *comp : {(const char *)nullptr, "zstd", "??"}) {
+                            exg_open_args a;
+                            memset(&a, 0, sizeof a);
+                            a.path = in.c_str();
+                            a.file_format = fmt;
+                            a.compression = comp;
+                            a.device = n_dev - 1;
+                            int devices[16];
+                            uint32_t n = 0;
+                            const uint32_t cap = 1 + (uint32_t)(rng() % 16);
+                            if (exg_plan_shards(&a, &n, devices, cap) != EXG_OK) return 9;
+                            if (n < 1 || n > cap) return 9;
+                            for (uint32_t i = 0; i < n; i++)
+                                if (devices[i] < 0 || devices[i] >= n_dev) return 9;
+                            std::vector<std::string> files;
+                            std::string err;
+                            if (exg_rd::list_path(in, &files, &err) == EXG_OK) {
+                                std::vector<exg_rd::Stripe> stripes;
+                                unsigned workers = 0;
+                                if (exg_rd::plan_stripes(files, exg_rd::compression_of(&a), &a, &stripes, &workers) != EXG_OK) return 9;
+                                if (stripes.size() < files.size() || workers < 1) return 9;
+                                for (const auto &st : stripes) {
+                                    if (st.device < 0 || st.device >= n_dev || st.shard_index >= st.shard_count) return 9;
+                                    bool known = false;
+                                    for (const auto &fl : files) known = known || fl == st.path;
+                                    if (!known) return 9;
+                                }
+                            }
+                            runs++;
+                        }
+                }
+        unsetenv("EXON_GPU_SHARDS");
+        // the replacement scan of the reference's FFI on names of every shape
+        const char *uris[] = {"a.fasta", "a.fa.gz", "x/y.fastq.zst", "a.vcf.bz2", "noext", "", ".", "..gz", "a.FASTQ", "a.fq", "s3://b/k.vcf.gz", "a.gz", "a.b.c.d"};
+        for (const char *u : uris) {
+            ReplacementScanResult rs = replacement_scan(u);
+            (void)rs;
+            runs++;
+        }
+        (void)replacement_scan(nullptr);
     }
     printf("%ld runs\n", runs);
     return 0;
