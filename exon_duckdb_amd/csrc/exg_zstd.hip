@@ -593,27 +593,35 @@ __global__ __launch_bounds__(64) void k_zst_scan(Block *blocks, uint32_t b_begin
 }
 
 // ---- execution of the sequences -------------------------------------------------------------------------------------
+// LDS decides how many chunks a CU executes at once, and a chunk is a serial chain: with a ring of 2 Ki symbols, 4 KiB of
+// staged literals and 1 Ki staged match symbols (16.4 KiB) nine wavefronts fit a CU; half of each (EXG_ZST_EXEC_SMALL, the
+// default: 8.2 KiB) lets sixteen in — the registers' limit.  -DEXG_ZST_EXEC_SMALL=0 builds the former shape (A/B).
+#ifndef EXG_ZST_EXEC_SMALL
+#define EXG_ZST_EXEC_SMALL 1
+#endif
+static constexpr uint32_t kFlushLog2 = EXG_ZST_EXEC_SMALL ? 9 : 10;
+static constexpr uint32_t kFlush = 1u << kFlushLog2;  // elements of a segment of the absolute grid that leaves for HBM at once
+static constexpr uint32_t kPiece = kFlush;            // elements emitted between two flush checks (ring >= 2 * kPiece)
 template <bool SYM>
 struct ExecCfg {
     using Elem = uint8_t;
-    static constexpr uint32_t kRing = 4096;
+    static constexpr uint32_t kRing = 4 * kFlush;
 };
 template <>
 struct ExecCfg<true> {
     using Elem = uint32_t;
-    static constexpr uint32_t kRing = 2048;
+    static constexpr uint32_t kRing = 2 * kFlush;
 };
-static constexpr uint32_t kPiece = 1024;  // elements emitted between two flush checks (ring >= 2 * kPiece)
 
 // Positions are 32-bit and relative to the chunk's first element (a chunk is a few MiB); `bias` = that element's index
-// mod 1024, so that ring slots and the 1024-element flush grid follow the ABSOLUTE index (full segments are 16-byte
+// mod 1024, so that ring slots and the kFlush-element flush grid follow the ABSOLUTE index (full segments are 16-byte
 // aligned in HBM whatever the chunk's offset).  Almost every copy is short (a literal run or a match of a few elements):
 // those take one masked wave instruction and a boundary test — the general loops are for the long ones.
 template <bool SYM>
 struct Exec {
     using Elem = typename ExecCfg<SYM>::Elem;
     static constexpr uint32_t kRing = ExecCfg<SYM>::kRing, kMask = kRing - 1;
-    static constexpr uint32_t kStage = 1024;  // elements of far-match sources staged per 64-sequence group
+    static constexpr uint32_t kStage = kFlush;  // elements of far-match sources staged per 64-sequence group
     Elem *ring;        // LDS
     Elem *out0;        // the chunk's first element in HBM (bytes: the output; symbols: d_sym)
     uint32_t bias;     // (index of the chunk's first element) & 1023
@@ -622,21 +630,26 @@ struct Exec {
     uint32_t lane;
 
     __device__ __forceinline__ uint32_t slot(uint32_t p) const { return (bias + p) & kMask; }
-    // completed 1024-element segments of the absolute grid -> HBM
+    // completed kFlush-element segments of the absolute grid -> HBM
     __device__ __forceinline__ void flush(bool all) {
         bool any = false;
         for (;;) {
-            uint32_t next = ((bias + flushed) | 1023u) + 1 - bias;
+            uint32_t next = ((bias + flushed) | (kFlush - 1u)) + 1 - bias;
             if (next > pos) {
                 if (!all || flushed == pos) break;
                 next = pos;
             }
             const uint32_t n = next - flushed;
-            if (n == 1024) {
-                const Elem *src = ring + slot(flushed) + lane * 16;
-                Elem *dst = out0 + flushed + lane * 16;
+            if (n == kFlush) {
+                constexpr uint32_t kPerLane = kFlush / 64;  // 16 or 8 elements: 16 / 8 bytes, or 64 / 32 bytes of symbols
+                const Elem *src = ring + slot(flushed) + lane * kPerLane;
+                Elem *dst = out0 + flushed + lane * kPerLane;
+                if constexpr (kPerLane * sizeof(Elem) >= 16) {
 #pragma unroll
-                for (uint32_t k = 0; k < sizeof(Elem); k++) reinterpret_cast<uint4 *>(dst)[k] = reinterpret_cast<const uint4 *>(src)[k];
+                    for (uint32_t k = 0; k < kPerLane * sizeof(Elem) / 16; k++) reinterpret_cast<uint4 *>(dst)[k] = reinterpret_cast<const uint4 *>(src)[k];
+                } else {
+                    *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(src);
+                }
             } else {
                 for (uint32_t e = lane; e < n; e += 64) out0[flushed + e] = ring[slot(flushed + e)];
             }
@@ -649,7 +662,7 @@ struct Exec {
     }
     __device__ __forceinline__ void advance(uint32_t n) {
         pos += n;
-        if (((bias + pos) ^ (bias + flushed)) >> 10) flush(false);  // a 1024 boundary was crossed
+        if (((bias + pos) ^ (bias + flushed)) >> kFlushLog2) flush(false);  // a segment boundary was crossed
     }
     template <class Src>
     __device__ __forceinline__ void put_from(const Src *src, uint32_t n) {  // src: LDS or HBM, elements or bytes
@@ -705,7 +718,7 @@ struct Exec {
     }
 };
 
-static constexpr uint32_t kLitStage = 4096;  // bytes of a 64-sequence group's literals staged in LDS
+static constexpr uint32_t kLitStage = 4 * kFlush;  // bytes of a 64-sequence group's literals staged in LDS
 
 // one chunk (a run of blocks of one frame) by one wavefront
 template <bool SYM>
