@@ -3,7 +3,7 @@
 #   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r02_a'
 # Writes gpurun_out/<tag>_*; tools/pmc_summary.py then condenses them into profiles/.
 set -u
-TAG=${1:-r03_b}
+TAG=${1:-r03_d}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
