@@ -109,12 +109,12 @@ def timed_launches(torch, fn, reps, warm=2):
     return sum(ms) / len(ms), ms[0]
 
 
-def open_reader(lib, path, fmt, shard=(0, 1), device_index=0):
+def open_reader(lib, path, fmt, shard=(0, 1), device_index=0, columns=0):
     from exon_duckdb_amd import abi
     lib.exg_open.argtypes = [C.POINTER(abi.OpenArgs), C.POINTER(C.c_void_p)]
     lib.exg_count_only.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.exg_close.argtypes = [C.c_void_p]
-    a = abi.OpenArgs(path.encode(), fmt.encode(), None, 2048, device_index, 0, None, shard[0], shard[1])
+    a = abi.OpenArgs(path.encode(), fmt.encode(), None, 2048, device_index, 0, None, shard[0], shard[1], columns)
     r = C.c_void_p()
     rc = lib.exg_open(C.byref(a), C.byref(r))
     assert rc == 0, lib.exg_last_error_message()
@@ -132,11 +132,11 @@ def reader_count(lib, path, fmt, shard=(0, 1), device_index=0):
     return int(n.value), dt
 
 
-def reader_chunks(lib, path, fmt, shard=(0, 1), device_index=0):
+def reader_chunks(lib, path, fmt, shard=(0, 1), device_index=0, columns=0):
     """every DataChunk pulled and released by a C loop of the scaffolding library (no interpreter between the chunks)"""
     from exon_duckdb_amd import load_test_library
     tl = load_test_library()
-    r = open_reader(lib, path, fmt, shard, device_index)
+    r = open_reader(lib, path, fmt, shard, device_index, columns)
     rows, chunks = C.c_uint64(0), C.c_uint64(0)
     t0 = time.perf_counter()
     rc = tl.exon_tf_drain_chunks(r, C.byref(rows), C.byref(chunks))
@@ -146,12 +146,12 @@ def reader_chunks(lib, path, fmt, shard=(0, 1), device_index=0):
     return int(rows.value), int(chunks.value), dt
 
 
-def reader_digest(lib, path, fmt, want_seq_len=0):
+def reader_digest(lib, path, fmt, want_seq_len=0, columns=0):
     """the same walk, folding the content of EVERY row — each string_t dereferenced: length, prefix, pointer, payload bytes; VCF:
     CHROM, the parsed POS, REF — into a digest (untimed verification pass) -> (rows, chunks, digest, rows of the wrong length)"""
     from exon_duckdb_amd import load_test_library
     tl = load_test_library()
-    r = open_reader(lib, path, fmt)
+    r = open_reader(lib, path, fmt, columns=columns)
     rows, chunks, dg, bad = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
     rc = tl.exon_tf_drain_digest(r, 1 if fmt == "vcf" else 0, want_seq_len, C.byref(rows), C.byref(chunks), C.byref(dg), C.byref(bad))
     assert rc == 0, lib.exg_last_error_message()
@@ -413,7 +413,14 @@ def run_configs(torch, lib, args):
             e_rows, e_dg = C.c_uint64(0), C.c_uint64(0)
             assert tl.exon_tf_expect_vcf_file(p_vcf.encode(), C.byref(e_rows), C.byref(e_dg)) == 0
             v_rows, v_chunks, got, _ = reader_digest(lib, p_vcf, "vcf")
+            # the same scan with a projection pushed into the reader (exg_open_args.columns; DuckDB's projection_pushdown):
+            # chrom, pos, ref — every column is still parsed and typed on the device, three of nine cross PCIe
+            proj = 0b1011
+            p_rows, p_chunks, dt_p = min((reader_chunks(lib, p_vcf, "vcf", columns=proj) for _ in range(3)), key=lambda x: x[2])
+            pv_rows, _, p_got, _ = reader_digest(lib, p_vcf, "vcf", columns=proj)
             out["end_to_end_vcf"] = {
+                "projected": {"columns": "chrom, pos, ref (exg_open_args.columns)", "ms": dt_p * 1e3, "GB/s": n_vcf / dt_p / 1e9,
+                              "records_per_s": p_rows / dt_p, "verified": bool(p_rows == pv_rows == n_lines and p_got == int(e_dg.value))},
                 "workload": f"read_vcf, {n_vcf / 1e9:.2f} GB VCF-8 file in the page cache -> host DataChunks of all 8 columns (exg_open / exg_next_chunk), PCIe inclusive",
                 "algorithmic_bytes": n_vcf, "ms": dt_r * 1e3, "GB/s": n_vcf / dt_r / 1e9, "records_per_s": rows / dt_r, "chunks": chunks,
                 "count_only_ms": dt_c * 1e3, "count_only_GB/s": n_vcf / dt_c / 1e9, "frac": None,

@@ -1,7 +1,7 @@
 """ctypes mirror of include/exon_gpu.h (keep in sync with the header; tests check sizes)."""
 import ctypes as C
 
-EXG_ABI_VERSION = 6
+EXG_ABI_VERSION = 7
 EXG_TYPE_VARCHAR, EXG_TYPE_BIGINT, EXG_TYPE_FLOAT, EXG_TYPE_INTEGER, EXG_TYPE_BOOLEAN, EXG_TYPE_LIST, EXG_TYPE_STRUCT = 1, 2, 3, 4, 5, 6, 7
 EXG_VECTOR_SIZE = 2048
 
@@ -134,7 +134,7 @@ class QualityListArgs(C.Structure):
 class OpenArgs(C.Structure):
     _fields_ = [("path", C.c_char_p), ("file_format", C.c_char_p), ("compression", C.c_char_p), ("batch_rows", C.c_uint64),
                 ("device", C.c_int), ("device_batch_bytes", C.c_uint64), ("filters", C.c_char_p),
-                ("shard_index", C.c_uint32), ("shard_count", C.c_uint32)]
+                ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("columns", C.c_uint64)]
 
 
 class InflateMember(C.Structure):

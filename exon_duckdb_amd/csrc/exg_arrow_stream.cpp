@@ -178,6 +178,7 @@ struct Emit {
     const uint32_t *d_row_map;  // NULL: identity
     unsigned long long *d_err;
     int rc = 0;
+    bool copy = true;  // false: the column being built is not in the projection — built and validated on the device, not copied back
 
     void *dalloc(size_t bytes) {
         void *p = st->arena.alloc(bytes);
@@ -199,6 +200,8 @@ struct Emit {
     // copies back run on their own stream, behind an event on the kernels' stream: the next column's scans and copies
     // on the device overlap with this column's bytes crossing PCIe
     const uint8_t *to_host(const void *d, size_t bytes) {
+        static const uint8_t nowhere[64] = {0};
+        if (!copy) return nowhere;
         void *h = halloc(bytes);
         if (h && bytes) {
             hipError_t e = hipEventRecord(st->copy_ev, s);
@@ -1122,10 +1125,16 @@ int nested_emit(exg_reader *r, const ScanCtx &ctx, Batch *b, const uint32_t *d_r
     auto str_col = [&](int c) { return ea::StrCol{(const exg_string_t *)r->d_cols[c], d_base, pb}; };
     DuckEmit de{em, B, (n + B - 1) / B, d_base, pb};
     b->nested.assign(9, NVec());
+    // (columns outside the projection are built like the others — a malformed value is an error whether or not its column is
+    // selected, like in the reference — but em.copy is off for them and their NVec is dropped at the end)
+    em.copy = r->want(2);
     b->nested[2] = de.list_of_strings(str_col(2), ';');
+    em.copy = r->want(4);
     b->nested[4] = de.list_of_strings(str_col(4), ',');
+    em.copy = r->want(6);
     b->nested[6] = de.list_of_strings(str_col(6), ';');
     if (em.rc) return em.rc;
+    em.copy = r->want(7);
     {  // info
         NVec info;
         info.type = EXG_TYPE_STRUCT;
@@ -1141,6 +1150,7 @@ int nested_emit(exg_reader *r, const ScanCtx &ctx, Batch *b, const uint32_t *d_r
         b->nested[7] = std::move(info);
     }
     if (em.rc) return em.rc;
+    em.copy = r->want(8);
     {  // formats
         NVec fl;
         fl.type = EXG_TYPE_LIST;
@@ -1177,6 +1187,8 @@ int nested_emit(exg_reader *r, const ScanCtx &ctx, Batch *b, const uint32_t *d_r
     if (em.rc) return em.rc;
     EM_HIP(hipStreamSynchronize(r->stream));
     EM_HIP(hipStreamSynchronize(st->copy_stream));
+    for (int c : {2, 4, 6, 7, 8})
+        if (!r->want(c)) b->nested[(size_t)c] = NVec();  // (validated, not handed out)
     if (err != ~0ull) {
         // a typed value did not parse: the rows in front of it are handed out, then the error (like the scan's own errors)
         *n_rows = err >> 8;

@@ -914,7 +914,10 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             if (!b) b = std::make_shared<Batch>();
             b->host.reserve(r->host_hint);
             b->file = gz_payload ? gz_payload : r->file;
-            if (gz_payload) RD_HIP(r, hipMemcpyAsync(gz_payload->p, d_input, n, hipMemcpyDeviceToHost, r->stream));
+            // the projection (exg_open_args.columns): every column was parsed and validated above, only the wanted ones travel.
+            // A decoded input's bytes are what its strings point into: they travel when any string column does
+            const bool any_strings = r->format == EXG_FMT_VCF ? (r->want_cols & 0x1DDull) != 0 : (r->want_cols & ((1ull << n_string_cols(r->format)) - 1)) != 0;
+            if (gz_payload && any_strings) RD_HIP(r, hipMemcpyAsync(gz_payload->p, d_input, n, hipMemcpyDeviceToHost, r->stream));
             b->n_rows = k;
             const int ns = n_string_cols(r->format);
             // schema order (exg_schema_of): VCF exposes parsed POS / QUAL in place of their raw text
@@ -922,8 +925,9 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             const size_t vw = (size_t)((k + 63) / 64) * 8;
             const bool nested_vcf = r->format == EXG_FMT_VCF;  // id, alt, filter, info, formats: built by nested_emit below
             for (int c = 0; c < ns; c++) {
-                if (nested_vcf && (c == 2 || c == 4 || c >= 6)) {
+                if ((nested_vcf && (c == 2 || c == 4 || c >= 6)) || !r->want(c)) {
                     b->elem[c] = 0;
+                    b->cols[c] = nullptr;
                     continue;
                 }
                 const void *src = r->d_cols[c];
@@ -953,7 +957,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
                 return EXG_OK;
             };
             if (r->format == EXG_FMT_VCF) {
-                if ((rc = copy_validity(5, r->d_valid[0]))) return rc;
+                if (r->want(5) && (rc = copy_validity(5, r->d_valid[0]))) return rc;
                 if (!r->nested_state && (rc = nested_prepare(r))) return rc;
                 ScanCtx ctx;
                 ctx.d_input = d_input;
@@ -965,9 +969,9 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
                 if ((rc = nested_emit(r, ctx, b.get(), row_map, &deliver))) return rc;
                 b->n_rows = deliver;
             } else {
-                if ((rc = copy_validity(1, r->d_valid[0]))) return rc;
+                if (r->want(1) && (rc = copy_validity(1, r->d_valid[0]))) return rc;
             }
-            if (r->format == EXG_FMT_FASTA && res.payload_bytes)
+            if (r->format == EXG_FMT_FASTA && res.payload_bytes && r->want(2))
                 RD_HIP(r, hipMemcpyAsync(b->payload, r->d_payload, res.payload_bytes, hipMemcpyDeviceToHost, r->stream));
             RD_HIP(r, hipStreamSynchronize(r->stream));
             r->host_hint = b->host.total + b->host.total / 8 + (1u << 20);

@@ -64,6 +64,7 @@ extern "C" int exg_open(const exg_open_args *args, exg_reader **out) {
     r->halo_want = getenv("EXG_SHARD_HALO") ? std::max<uint64_t>(16, strtoull(getenv("EXG_SHARD_HALO"), nullptr, 10)) : kShardHalo;
     r->device = args->device;
     r->shard_count = args->shard_count ? args->shard_count : 1;
+    r->want_cols = args->columns ? args->columns : ~0ull;
     r->shard_index = args->shard_index;
     if (r->shard_index >= r->shard_count) {
         exg::set_error("exg_open: shard_index %u is not below shard_count %u", r->shard_index, r->shard_count);
@@ -146,7 +147,7 @@ extern "C" int exg_open(const exg_open_args *args, exg_reader **out) {
             };
             const std::string format = args->file_format, compression = args->compression ? args->compression : "", filters = args->filters ? args->filters : "";
             const bool has_comp = args->compression != nullptr;
-            const uint64_t batch_rows = r->batch_rows, dbb = args->device_batch_bytes;
+            const uint64_t batch_rows = r->batch_rows, dbb = args->device_batch_bytes, columns = args->columns;
             FanOpen open = [=](const Stripe &s, std::unique_ptr<FanSub> *sub, std::string *err) -> int {
                 exg_open_args a;
                 memset(&a, 0, sizeof a);
@@ -159,6 +160,7 @@ extern "C" int exg_open(const exg_open_args *args, exg_reader **out) {
                 a.filters = filters.empty() ? nullptr : filters.c_str();
                 a.shard_index = s.shard_index;
                 a.shard_count = s.shard_count;
+                a.columns = columns;
                 if (a.shard_count < 1) a.shard_count = 1;
                 std::unique_ptr<Sub> x(new Sub());
                 const int orc = exg_open(&a, &x->rd);
@@ -268,6 +270,11 @@ extern "C" int exg_next_chunk(exg_reader *r, exg_chunk *out) {
                 exg_vector &v = keep->top[c];
                 if ((size_t)c < r->batch->nested.size() && r->batch->nested[c].type) {
                     slice_vector(r->batch->nested[c], row0, row0 + n, chunk, keep, &v);
+                } else if (!r->batch->cols[c]) {  // not in the projection (exg_open_args.columns)
+                    out->data[c] = nullptr;
+                    out->validity[c] = nullptr;
+                    out->vectors[c] = nullptr;
+                    continue;
                 } else {
                     memset(&v, 0, sizeof v);
                     v.data = (char *)r->batch->cols[c] + row0 * r->batch->elem[c];

@@ -340,6 +340,8 @@ struct exg_reader {
     size_t file_idx = 0;
     uint64_t batch_rows = EXG_VECTOR_SIZE;
     uint64_t device_batch_bytes = 256ull << 20;
+    uint64_t want_cols = ~0ull;  // exg_open_args.columns: the columns whose vectors are copied back (all are parsed)
+    bool want(int c) const { return (want_cols >> c) & 1ull; }
     int device = 0;
     std::string error;
     hipStream_t stream = nullptr;

@@ -9,7 +9,8 @@ from .table_function import Chunk, Schema, decode_vector, type_tree
 
 class ShardReader:
     def __init__(self, path, file_format, shard_index=0, shard_count=1, compression=None, device=0, device_batch_bytes=0,
-                 filters=None, batch_rows=2048):
+                 filters=None, batch_rows=2048, columns=None):
+        """columns: indices (exg_schema_of order) of the columns to copy back; None = all (exg_open_args.columns)"""
         self._l = load_library()
         self._l.exg_open.argtypes = [C.POINTER(abi.OpenArgs), C.POINTER(C.c_void_p)]
         self._l.exg_next_chunk.argtypes = [C.c_void_p, C.POINTER(Chunk)]
@@ -20,7 +21,9 @@ class ShardReader:
         self._l.exg_reader_error.argtypes = [C.c_void_p]
         self._l.exg_close.argtypes = [C.c_void_p]
         a = abi.OpenArgs(path.encode(), file_format.encode(), compression.encode() if compression else None, batch_rows, device,
-                         device_batch_bytes, filters.encode() if filters else None, shard_index, shard_count)
+                         device_batch_bytes, filters.encode() if filters else None, shard_index, shard_count,
+                         sum(1 << int(c) for c in columns) if columns is not None else 0)
+        self.columns = None if columns is None else sorted(int(c) for c in columns)
         self._r = C.c_void_p()
         rc = self._l.exg_open(C.byref(a), C.byref(self._r))
         if rc != 0:
@@ -57,7 +60,11 @@ class ShardReader:
             n = int(ch.n_rows)
             if n == 0:
                 return out
-            cols = [decode_vector(ch.vectors[k].contents, self.trees[k]) for k in range(len(self.names))]
+            want = range(len(self.names)) if self.columns is None else self.columns
+            for k in range(len(self.names)):
+                if k not in want:
+                    assert not ch.vectors[k], f"column {k} was not asked for but came back"
+            cols = [decode_vector(ch.vectors[k].contents, self.trees[k]) for k in want]
             out.extend(zip(*cols))
             self._l.exg_release_chunk(self._r, C.byref(ch))
 

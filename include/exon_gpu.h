@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define EXG_ABI_VERSION 6
+#define EXG_ABI_VERSION 7
 
 /* DuckDB v0.8.1 STANDARD_VECTOR_SIZE; the reference asks the Rust side for
  * batches of exactly this many rows (module.cpp:83, :233). */
@@ -376,6 +376,12 @@ typedef struct exg_open_args {
                               * devices (and an input that can be sharded) it cuts the input into stripes of ~1 GiB, reads
                               * them with worker threads on all devices and hands their batches out here in file order
                               * (exg_count_only sums them) — one consumer-facing stream, N GPUs. */
+    uint64_t columns;        /* projection (DuckDB's projection_pushdown: module.cpp:310, input.column_ids): bit c = column c of
+                              * exg_schema_of is wanted; 0 = all.  Every column is still tokenised, typed and validated on
+                              * the device — a malformed INFO value is an error whether the column is selected or not, like in
+                              * the reference, which parses everything and projects afterwards — but only the wanted ones are
+                              * copied back: exg_chunk.vectors[c] of the others is NULL.  read_vcf's nested columns are
+                              * two thirds of its bytes over PCIe. */
 } exg_open_args;
 
 #define EXG_TYPE_VARCHAR 1

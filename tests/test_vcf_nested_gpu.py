@@ -172,3 +172,66 @@ def test_projection_and_filters(gpu, oracle, tmp_path, monkeypatch):
     # nested columns cannot be compared (DuckDB pushes no filter on LIST / STRUCT; new_reader refuses them too)
     with pytest.raises(ExgError, match="nested"):
         rel.fetchall(filters={"info": F.cmp(">=", b"DP=5")})
+
+
+def test_projection_is_pushed_into_the_reader(gpu, oracle, tmp_path, monkeypatch):
+    """exg_open_args.columns (DuckDB's projection_pushdown, module.cpp:310): only the wanted columns' vectors come back — the
+    others are NULL in the chunk — with the values of the full scan; every column is still parsed and typed on the device, so
+    a malformed INFO value is an error whether INFO is selected or not, like in the reference (which parses everything and
+    projects afterwards).  Through the table function a projection reaches the reader as that mask."""
+    from exon_duckdb_amd import ExgError
+    from exon_duckdb_amd.reader import ShardReader
+    from exon_duckdb_amd.table_function import connect
+    data = bytes(oracle.synth_vcf(6000))
+    p = tmp_path / "p.vcf"
+    p.write_bytes(data)
+    monkeypatch.setenv("EXG_DEVICE_BATCH_BYTES", str(128 << 10))
+    full = ShardReader(str(p), "vcf")
+    names = full.names
+    all_rows = full.rows()
+    full.close()
+    for want in (["chrom", "pos"], ["pos", "qual"], ["info"], ["id", "ref", "formats"], ["alt", "filter"]):
+        idx = sorted(names.index(c) for c in want)
+        r = ShardReader(str(p), "vcf", columns=idx)
+        got = r.rows()     # (asserts that the other columns' vectors are NULL)
+        r.close()
+        assert len(got) == len(all_rows)
+        assert all(same(g, tuple(row[k] for k in idx)) for g, row in zip(got, all_rows)), want
+    # the same projections through the DuckDB-shaped boundary, gzip-compressed (the inflated payload travels only for strings)
+    import gzip
+    pz = tmp_path / "p.vcf.gz"
+    pz.write_bytes(gzip.compress(data, 6, mtime=0))
+    rel = connect().table_function("read_vcf", str(pz))
+    exp, _ = oracle.vcf_typed_rows(data)
+    assert rel.fetchall(columns=["pos", "qual"]) == [(e["pos"], e["qual"]) for e in exp] or \
+        all(same(g, (e["pos"], e["qual"])) for g, e in zip(rel.fetchall(columns=["pos", "qual"]), exp))
+    got = rel.fetchall(columns=["chrom", "ref"])
+    assert [(c.decode(), r_.decode()) for c, r_ in got] == [(e["chrom"], e["ref"]) for e in exp]
+    # a value that does not parse, in a column that is NOT selected: still the reference's error
+    bad = HEADER + b"1\t10\t.\tA\tC\t1\tPASS\tDP=5\n1\t11\t.\tA\tC\t1\tPASS\tDP=five\n"
+    pb = tmp_path / "bad.vcf"
+    pb.write_bytes(bad)
+    r = ShardReader(str(pb), "vcf", columns=[0, 1])
+    with pytest.raises(ExgError):
+        r.rows()
+    r.close()
+
+
+def test_fastq_and_fasta_projections(gpu, oracle, tmp_path, monkeypatch):
+    from exon_duckdb_amd.reader import ShardReader
+    monkeypatch.setenv("EXG_DEVICE_BATCH_BYTES", str(256 << 10))
+    fq = bytes(oracle.synth_fastq_ragged(5000))
+    fa = bytes(oracle.synth_fasta(300))
+    (tmp_path / "a.fastq").write_bytes(fq)
+    (tmp_path / "a.fasta").write_bytes(fa)
+    import gzip
+    (tmp_path / "a.fastq.gz").write_bytes(gzip.compress(fq, 6, mtime=0))
+    for path, fmt, ncol in (("a.fastq", "fastq", 4), ("a.fastq.gz", "fastq", 4), ("a.fasta", "fasta", 3)):
+        r = ShardReader(str(tmp_path / path), fmt)
+        all_rows = r.rows()
+        r.close()
+        for idx in ([0], [1], [ncol - 1], [0, ncol - 1], [1, 2]):
+            r = ShardReader(str(tmp_path / path), fmt, columns=idx)
+            got = r.rows()
+            r.close()
+            assert got == [tuple(row[k] for k in idx) for row in all_rows], (path, idx)
