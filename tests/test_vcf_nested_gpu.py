@@ -235,3 +235,21 @@ def test_fastq_and_fasta_projections(gpu, oracle, tmp_path, monkeypatch):
             got = r.rows()
             r.close()
             assert got == [tuple(row[k] for k in idx) for row in all_rows], (path, idx)
+
+
+def test_projection_through_a_fan_out(gpu, oracle, tmp_path, monkeypatch):
+    """the stripes' readers of a fan-out (exg_open with shard_count = 0) take the projection along"""
+    from exon_duckdb_amd.reader import ShardReader
+    data = bytes(oracle.synth_vcf(9000))
+    p = tmp_path / "f.vcf"
+    p.write_bytes(data)
+    full = ShardReader(str(p), "vcf")
+    all_rows = full.rows()
+    full.close()
+    monkeypatch.setenv("EXON_GPU_SHARDS", "4")
+    monkeypatch.setenv("EXG_FANOUT_WORKERS", "2")
+    monkeypatch.setenv("EXG_DEVICE_BATCH_BYTES", str(96 << 10))
+    r = ShardReader(str(p), "vcf", shard_count=0, columns=[1, 3, 7])
+    got = r.rows()
+    r.close()
+    assert len(got) == len(all_rows) and all(same(g, (row[1], row[3], row[7])) for g, row in zip(got, all_rows))
