@@ -429,7 +429,8 @@ typedef struct exg_chunk {
     void *data[16];            /* host pointers: exg_string_t[n_rows] / int64_t[] / float[] / exg_list_entry_t[] (STRUCT: NULL) */
     uint64_t *validity[16];    /* NULL => all valid; else ceil(n_rows/64) words */
     void *keepalive;           /* opaque; payload + vectors stay valid until exg_release_chunk */
-    const exg_vector *vectors[16]; /* every column as a vector tree (data / validity above are vectors[c]'s own) */
+    const exg_vector *vectors[16]; /* every column as a vector tree (data / validity above are vectors[c]'s own); NULL (and
+                                * data[c] NULL) for a column outside exg_open_args.columns */
     uint64_t batch_no;         /* which device batch of this reader the rows come from (0, 1, ...: non-decreasing; what the
                                 * table function reports as DuckDB's batch index, module.cpp has none: MaxThreads() == 1) */
 } exg_chunk;
