@@ -345,7 +345,10 @@ __device__ TileSum fa_span_sum(const FastaDev &a, uint64_t base, uint32_t span, 
 // block 0, wave 0: exclusive prefixes of the published aggregates, in order
 __device__ void fa_scanner(const FastaDev &a, const TileArrays &t, ScanWsHeader *hdr, uint32_t n_super, uint32_t help_ticks, uint32_t lane) {
     __builtin_amdgcn_s_setprio(3);
-    constexpr int kBatches = 4;
+#ifndef EXG_FA_SCAN_BATCHES
+#define EXG_FA_SCAN_BATCHES 4
+#endif
+    constexpr int kBatches = EXG_FA_SCAN_BATCHES;
     uint64_t next = 0;
     unsigned long long rec = 0, pay = 0, nls = 0;
     bool in_def = false;  // the input begins outside a definition line
@@ -413,7 +416,14 @@ __device__ void fa_scanner(const FastaDev &a, const TileArrays &t, ScanWsHeader 
     }
 }
 
-__global__ __launch_bounds__(kThreads) void k_fa_fused(FastaDev a, TileArrays t, ScanWsHeader *hdr, uint32_t n_super, uint32_t help_ticks) {
+// six waves per SIMD (80 registers, 40 B of spills): 0.628 -> 0.607 ms per GB for the whole scan; seven: as five; eight (64 registers,
+// 104 B of spills): 0.75.  What was tried beside it and changed nothing: the scanner wave taking 1 / 8 / 16 batches of 64 aggregates
+// per poll instead of 4, and building the CR mask only in rows that hold a CR (23 of a row's ~280 instructions): the kernel is bound
+// neither by the scanner nor by its instruction count.
+#ifndef EXG_FA_WAVES
+#define EXG_FA_WAVES 6
+#endif
+__global__ __launch_bounds__(kThreads, EXG_FA_WAVES) void k_fa_fused(FastaDev a, TileArrays t, ScanWsHeader *hdr, uint32_t n_super, uint32_t help_ticks) {
     __shared__ __attribute__((aligned(16))) uint32_t s_out_all[kThreads / 64][4096 / 4 + 8];
     __shared__ TileSum s_agg[kThreads / 64];
     __shared__ unsigned long long s_pre_rec, s_pre_pay;
