@@ -146,14 +146,15 @@ def reader_chunks(lib, path, fmt, shard=(0, 1), device_index=0, columns=0):
     return int(rows.value), int(chunks.value), dt
 
 
-def reader_digest(lib, path, fmt, want_seq_len=0, columns=0):
+def reader_digest(lib, path, fmt, want_seq_len=0, columns=0, shard=(0, 1), device_index=0, first_row=0):
     """the same walk, folding the content of EVERY row — each string_t dereferenced: length, prefix, pointer, payload bytes; VCF:
-    CHROM, the parsed POS, REF — into a digest (untimed verification pass) -> (rows, chunks, digest, rows of the wrong length)"""
+    CHROM, the parsed POS, REF — into a digest (untimed verification pass) -> (rows, chunks, digest, rows of the wrong length).
+    A shard's rows are rows [first_row, first_row + n) of the file: the shards' digests add up to the file's."""
     from exon_duckdb_amd import load_test_library
     tl = load_test_library()
-    r = open_reader(lib, path, fmt, columns=columns)
+    r = open_reader(lib, path, fmt, shard, device_index, columns)
     rows, chunks, dg, bad = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
-    rc = tl.exon_tf_drain_digest(r, 1 if fmt == "vcf" else 0, want_seq_len, C.byref(rows), C.byref(chunks), C.byref(dg), C.byref(bad))
+    rc = tl.exon_tf_drain_digest_from(r, 1 if fmt == "vcf" else 0, want_seq_len, first_row, C.byref(rows), C.byref(chunks), C.byref(dg), C.byref(bad))
     assert rc == 0, lib.exg_last_error_message()
     lib.exg_close(r)
     return int(rows.value), int(chunks.value), int(dg.value), int(bad.value)
@@ -459,6 +460,20 @@ def main():
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; default) | gloo (functional test of the N>1 path)")
     ap.add_argument("--single-device", action="store_true", help="test only: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    # --gpus N is the number of ranks.  Without a launcher (no WORLD_SIZE in the environment) and N > 1 this process starts the N
+    # ranks itself — as a CHILD `python -m torch.distributed.run` with the same arguments, before torch is imported or any
+    # GPU call is made here (never an exec of a process that touched the GPU) — passes the ranks' output through and exits with
+    # the child's code.  Under a launcher the world must be what --gpus says.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}: start it without a launcher (it launches {args.gpus} ranks "
+              f"itself) or with --nproc-per-node {args.gpus}", file=sys.stderr)
+        raise SystemExit(2)
 
     import torch
     import torch.distributed as dist
@@ -656,6 +671,22 @@ def main():
         dist.destroy_process_group()
 
 
+def launch_ranks(n, argv):
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node n bench.py <argv>` as a child process (this process has not
+    imported torch and never touches the GPU) -> its exit code; the ranks' stdout / stderr are this process's own"""
+    import socket
+    import subprocess
+    with socket.socket() as s:          # a free port on the loopback (the container's hostname may not resolve)
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 def _first_owned_record(sh):
     """global index of the first record whose last line ends at or after the shard's first byte (records are 332 bytes:
     record k ends at byte 332 (k + 1) - 1)"""
@@ -706,17 +737,38 @@ def sharded_reader_leg(torch, dist, lib, device, world, rank, local_rank, coll_d
             except Exception as e:  # noqa: BLE001
                 err = f"{type(e).__name__}: {e}"
         t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
-        rows = torch.tensor([n], dtype=torch.int64, device=coll_dev)
         bad = torch.tensor([1 if err else 0], dtype=torch.int64, device=coll_dev)
+        counts = [torch.zeros(1, dtype=torch.int64, device=coll_dev) for _ in range(world)]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(rows)
+        dist.all_gather(counts, torch.tensor([n], dtype=torch.int64, device=coll_dev))
         dist.all_reduce(bad)
-        if int(bad.item()):
-            out = {"skipped": f"{int(bad.item())} rank(s) failed" + (f" (rank {rank}: {err})" if err else "")}
+        counts = [int(c.item()) for c in counts]
+        # content (untimed): every rank pulls all four columns of ITS shard as DataChunks and folds every row — with the row's
+        # index in the FILE, which is the sum of the shards' counts in front — into a digest; the shards' digests must add up
+        # (mod 2^64) to the generator's digest of the whole file: the shards partition the rows, in file order, bit for bit
+        dg, v_rows, wrong = 0, 0, 0
+        if not int(bad.item()):
+            try:
+                v_rows, _, dg, wrong = reader_digest(lib, path, "fastq", 150, 0, (rank, world), dev, sum(counts[:rank]))
+            except Exception as e:  # noqa: BLE001
+                err = f"{type(e).__name__}: {e}"
+        parts = [None] * world
+        dist.all_gather_object(parts, (dg, v_rows, wrong, err))
+        if int(bad.item()) or any(p[3] for p in parts):
+            out = {"skipped": "rank(s) failed: " + "; ".join(f"rank {i}: {p[3]}" for i, p in enumerate(parts) if p[3])}
         else:
+            total_rows = sum(counts)
+            verified = total_rows == n_file // REC and [p[1] for p in parts] == counts and not any(p[2] for p in parts)
+            if rank == 0 and verified:
+                from exon_duckdb_amd import abi, load_test_library
+                want = int(load_test_library().exon_tf_expect_fastq150(abi.EXG_SYNTH_FASTQ_SEED, 0, n_file // REC, effective_cores()))
+                verified = (sum(p[0] for p in parts) & (2 ** 64 - 1)) == want
             out = {"workload": f"COUNT(*) of one {n_file / 1e9:.1f} GB FASTQ-150 file in shared memory, {world} readers with shard_index = rank (exg_open), PCIe inclusive",
                    "algorithmic_bytes": n_file, "ms": float(t.item()) * 1e3, "GB/s": n_file / float(t.item()) / 1e9,
-                   "records_per_s": int(rows.item()) / float(t.item()), "verified": bool(int(rows.item()) == n_file // REC)}
+                   "records_per_s": total_rows / float(t.item()), "rows_per_shard": counts,
+                   "verification": "COUNT(*) timed; an untimed pass pulls every shard's four columns as DataChunks and folds every row (with its "
+                                   "index in the file) into a digest; the shards' digests must add up to the generator's for the whole file",
+                   "verified": bool(verified)}
     dist.barrier()
     if rank == 0 and tmp:
         try:

@@ -182,6 +182,8 @@ TEST_SIGNATURES = {
     "exon_tf_drain_chunks": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "exon_tf_drain_digest": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                        C.POINTER(C.c_uint64)]),
+    "exon_tf_drain_digest_from": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                            C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "exon_tf_synth_fastq150_host": (None, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
     "exon_tf_expect_fastq150": (C.c_uint64, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int]),
     "exon_tf_expect_vcf_file": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

@@ -82,6 +82,26 @@ void pin_to_device_node(int device) {
     if (masks[device].ok) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &masks[device].set);
 }
 
+// NUMA node of the device's PCI function (what a pinned block made with that device current is placed on): the pool's key
+int numa_node_of_device(int device) {
+    static int nodes[64];
+    static std::once_flag once[64];
+    if (device < 0 || device >= 64) return 0;
+    std::call_once(once[device], [device] {
+        nodes[device] = 0;
+        char bdf[64] = {0};
+        if (hipDeviceGetPCIBusId(bdf, sizeof bdf, device) != hipSuccess) return;
+        for (char *c = bdf; *c; c++) *c = (char)tolower(*c);
+        const std::string path = std::string("/sys/bus/pci/devices/") + bdf + "/numa_node";
+        if (FILE *f = fopen(path.c_str(), "r")) {
+            int v = -1;
+            if (fscanf(f, "%d", &v) == 1 && v >= 0) nodes[device] = v;
+            fclose(f);
+        }
+    });
+    return nodes[device];
+}
+
 int fail(exg_reader *r, int code, const std::string &msg) {
     r->error = msg;
     exg::set_error("%s", msg.c_str());

@@ -144,6 +144,10 @@ extern "C" int exg_open(const exg_open_args *args, exg_reader **out) {
                     if (rc) *err = rd->error;
                     return rc;
                 }
+                void stats(uint64_t *now, uint64_t *peak, uint64_t *batches, uint64_t *segments) override {
+                    *now = rd->meter.cur.load(), *peak = rd->meter.peak.load();
+                    *batches = rd->n_batches.load(), *segments = rd->n_segments.load();
+                }
             };
             const std::string format = args->file_format, compression = args->compression ? args->compression : "", filters = args->filters ? args->filters : "";
             const bool has_comp = args->compression != nullptr;
@@ -371,6 +375,14 @@ extern "C" int exg_reader_stats_of(exg_reader *r, exg_reader_stats *out) {
     out->device_batch_bytes = r->device_batch_bytes;
     out->device_batches = r->n_batches;
     out->decoded_segments = r->n_segments;
+    if (r->fan) {
+        // the front of a fan-out holds next to nothing itself: its stripes' readers (their own meters, on the workers' threads) do
+        const exg_rd::FanOut::Stats fs = r->fan->stats();
+        out->device_bytes_now += fs.device_bytes_now;
+        out->device_bytes_peak += fs.device_bytes_peak;
+        out->device_batches += fs.device_batches;
+        out->decoded_segments += fs.decoded_segments;
+    }
     return EXG_OK;
 }
 

@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 
+#include "exg_block_pool.hpp"
 #include "exg_common.hpp"
 
 namespace exg_rd {
@@ -44,63 +45,36 @@ struct PinnedBlock {  // host memory: pinned (hipHostMalloc) or a read-only file
     ~PinnedBlock();
 };
 
-// Pinned host blocks are expensive to create (hipHostMalloc is ~ms per 10 MiB), so they are recycled: a
-// batch returns its blocks to the pool when the consumer releases its last record batch.
-struct BlockPool {
-    std::mutex mu;
-    std::vector<std::pair<char *, size_t>> free_blocks;
-    size_t pooled_bytes = 0;
-    static constexpr size_t kMaxPooled = 6ull << 30;
-    // sizes are multiples of 32 MiB; a free block is reused for a request it fits without wasting more than
-    // half of it (batches of one scan are alike, so in the steady state the same few blocks go round)
-    static size_t size_class(size_t n) { return (std::max<size_t>(n, 1) + (32u << 20) - 1) & ~(size_t)((32u << 20) - 1); }
-    char *take(size_t *sz) {
-        *sz = size_class(*sz);
-        {
-            std::lock_guard<std::mutex> g(mu);
-            size_t best = free_blocks.size();
-            for (size_t i = 0; i < free_blocks.size(); i++)
-                if (free_blocks[i].second >= *sz && free_blocks[i].second <= 2 * *sz + (64u << 20) &&
-                    (best == free_blocks.size() || free_blocks[i].second < free_blocks[best].second))
-                    best = i;
-            if (best != free_blocks.size()) {
-                char *p = free_blocks[best].first;
-                *sz = free_blocks[best].second;
-                pooled_bytes -= *sz;
-                free_blocks.erase(free_blocks.begin() + (long)best);
-                return p;
-            }
-        }
-        void *p = nullptr;
-        if (hipHostMalloc(&p, *sz, hipHostMallocDefault) != hipSuccess) return nullptr;
-        return (char *)p;
-    }
-    void give(char *p, size_t sz) {
-        {
-            std::lock_guard<std::mutex> g(mu);
-            if (pooled_bytes + sz <= kMaxPooled) {
-                free_blocks.emplace_back(p, sz);
-                pooled_bytes += sz;
-                return;
-            }
-        }
-        (void)hipHostFree(p);
-    }
-    void trim() {
-        std::lock_guard<std::mutex> g(mu);
-        for (auto &b : free_blocks) (void)hipHostFree(b.first);
-        free_blocks.clear();
-        pooled_bytes = 0;
-    }
-    ~BlockPool() {
-        for (auto &b : free_blocks) (void)hipHostFree(b.first);
-    }
-};
-
-// one pool per process: streams come and go (the reference opens one at bind and one per scan)
+// The pool of pinned host blocks (exg_block_pool.hpp: recycled, keyed by the NUMA node of the device that was current when a
+// block was made), with HIP behind its hooks.  One pool per process: streams come and go (the reference opens one at bind
+// and one per scan).
+int numa_node_of_device(int device);  // exg_rd_io.cpp: sysfs numa_node of the device's PCI function (0 when unknown)
 inline std::shared_ptr<BlockPool> global_pool() {
     // never destroyed: hipHostFree after the HIP runtime has shut down is not safe
-    static auto *pool = new std::shared_ptr<BlockPool>(std::make_shared<BlockPool>());
+    static auto *pool = [] {
+        BlockPool::Hooks h;
+        h.alloc = [](size_t n) -> void * {
+            void *p = nullptr;
+            if (hipHostMalloc(&p, n, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                return nullptr;
+            }
+            return p;
+        };
+        h.release = [](void *p) { (void)hipHostFree(p); };
+        h.current_node = [] {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess) return 0;
+            return numa_node_of_device(dev);
+        };
+        h.n_devices = [] {
+            int n = 0;
+            if (hipGetDeviceCount(&n) != hipSuccess) n = 1;
+            return n;
+        };
+        const char *e = getenv("EXG_PINNED_POOL_MB");
+        return new std::shared_ptr<BlockPool>(std::make_shared<BlockPool>(h, e ? ((size_t)std::max(0, atoi(e)) << 20) : 0));
+    }();
     return *pool;
 }
 
@@ -420,8 +394,8 @@ struct exg_reader {
     std::unique_ptr<exg_rd::FanOut> fan;
     exg_rd::MemMeter meter;      // device bytes held on behalf of this reader
     uint64_t mem_cap = 0;        // EXG_DEVICE_MEM_CAP_MB: what the batch / segment sizes are derived from (0: defaults)
-    uint64_t n_segments = 0;     // decoded segments consumed so far
-    uint64_t n_batches = 0;      // device batches scanned so far
+    std::atomic<uint64_t> n_segments{0};  // decoded segments consumed so far (read by exg_reader_stats_of from any thread)
+    std::atomic<uint64_t> n_batches{0};   // device batches scanned so far
 
     // current batch
     std::shared_ptr<exg_rd::Batch> batch;

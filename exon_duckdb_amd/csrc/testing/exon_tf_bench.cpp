@@ -192,11 +192,13 @@ extern "C" int exon_tf_drain_chunks(exg_reader *r, uint64_t *n_rows, uint64_t *n
 // the same, folding every row's content.  kind 0: four VARCHAR columns (FASTQ: name, description, sequence, quality_scores);
 // kind 1: VCF — chrom (column 0), pos (BIGINT, column 1), ref (column 3).  *bad: rows whose name / sequence / quality length is
 // not the one given (0: not checked).
-extern "C" int exon_tf_drain_digest(exg_reader *r, int kind, uint32_t want_seq_len, uint64_t *n_rows, uint64_t *n_chunks, uint64_t *digest,
-                                    uint64_t *bad) {
+// first_row: the index of the reader's first row in the whole file (a shard's rows are rows [first_row, first_row + n) of the
+// file: the digests of all shards then add up to the file's).
+extern "C" int exon_tf_drain_digest_from(exg_reader *r, int kind, uint32_t want_seq_len, uint64_t first_row, uint64_t *n_rows, uint64_t *n_chunks,
+                                         uint64_t *digest, uint64_t *bad) {
     if (!r || !n_rows || !n_chunks || !digest || !bad) return EXG_E_INVALID_ARG;
     *n_rows = *n_chunks = *digest = *bad = 0;
-    uint64_t k = 0, acc = 0;
+    uint64_t k = first_row, acc = 0;
     for (;;) {
         exg_chunk c;
         const int rc = exg_next_chunk(r, &c);
@@ -229,9 +231,13 @@ extern "C" int exon_tf_drain_digest(exg_reader *r, int kind, uint32_t want_seq_l
         *n_chunks += 1;
         exg_release_chunk(r, &c);
     }
-    *n_rows = k;
+    *n_rows = k - first_row;
     *digest = acc;
     return EXG_OK;
+}
+extern "C" int exon_tf_drain_digest(exg_reader *r, int kind, uint32_t want_seq_len, uint64_t *n_rows, uint64_t *n_chunks, uint64_t *digest,
+                                    uint64_t *bad) {
+    return exon_tf_drain_digest_from(r, kind, want_seq_len, 0, n_rows, n_chunks, digest, bad);
 }
 
 // ---- host-only introspection (no device is touched): what the CPU tests check ---------------------------------------

@@ -7,11 +7,13 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <random>
 #include <string>
 #include <vector>
 
+#include "exg_block_pool.hpp"
 #include "exg_filter.hpp"
 #include "exg_rd_fanout.hpp"
 #include "exg_rd_internal.hpp"
@@ -234,6 +236,105 @@ int main(int argc, char **argv) {
             runs++;
         }
         (void)replacement_scan(nullptr);
+    }
+    // the pinned-block pool (exg_block_pool.hpp) over malloc / free with the "device's node" said by the test: a block goes back
+    // only to a taker on the node it was made on, the cap follows the device count, every block is released exactly once
+    {
+        static int s_node = 0, s_devices = 8;
+        static long s_live = 0;
+        exg_rd::BlockPool::Hooks h;
+        h.alloc = [](size_t n) -> void * { s_live++; return malloc(n > 4096 ? 4096 : n); };  // (the bookkeeping is what runs here)
+        h.release = [](void *p) { s_live--; free(p); };
+        h.current_node = [] { return s_node; };
+        h.n_devices = [] { return s_devices; };
+        {
+            exg_rd::BlockPool pool(h);
+            if (pool.cap() != 8 * exg_rd::BlockPool::kPerDevice) return 10;
+            size_t sz = 100u << 20;
+            s_node = 0;
+            char *a = pool.take(&sz);
+            if (!a || sz != (128u << 20)) return 10;
+            pool.give(a, sz);
+            s_node = 1;                       // a reader on the other socket: must NOT get node 0's block
+            size_t sz1 = 100u << 20;
+            char *b = pool.take(&sz1);
+            if (!b || b == a || pool.free_on_node(0) != 1) return 10;
+            pool.give(b, sz1);
+            s_node = 0;                       // back on node 0: the first block comes round
+            size_t sz2 = 90u << 20;
+            char *c = pool.take(&sz2);
+            if (c != a || sz2 != (128u << 20) || pool.n_reused != 1) return 10;
+            // a block given back from a thread whose device sits on another node keeps ITS node
+            s_node = 1;
+            pool.give(c, sz2);
+            if (pool.free_on_node(0) != 1 || pool.free_on_node(1) != 1) return 10;
+            // random traffic from "eight devices on two nodes"
+            std::vector<std::pair<char *, size_t>> held;
+            for (int it = 0; it < 4000; it++) {
+                s_node = (int)(rng() % 2);
+                if (held.empty() || rng() % 2) {
+                    size_t want = (size_t)(1 + rng() % 300) << 20;
+                    char *p = pool.take(&want);
+                    if (!p || want % (32u << 20)) return 10;
+                    held.emplace_back(p, want);
+                } else {
+                    const size_t k = rng() % held.size();
+                    pool.give(held[k].first, held[k].second);
+                    held.erase(held.begin() + (long)k);
+                }
+                if (pool.pooled() > pool.cap()) return 10;
+                runs++;
+            }
+            for (auto &x : held) pool.give(x.first, x.second);
+        }
+        if (s_live != 0) return 10;           // the pool's destructor released what it still held; nothing twice (ASan), nothing lost
+        // a small cap: blocks beyond it are released at once
+        {
+            exg_rd::BlockPool pool(h, 64u << 20);
+            size_t s1 = 1, s2 = 1, s3 = 1;
+            char *a = pool.take(&s1), *b = pool.take(&s2), *c = pool.take(&s3);
+            pool.give(a, s1), pool.give(b, s2), pool.give(c, s3);
+            if (pool.pooled() != (64u << 20) || s_live != 2) return 10;
+        }
+        if (s_live != 0) return 10;
+    }
+    // the fan-out's run-ahead (exg_rd_fanout.cpp): a worker never holds more than `depth` batches the consumer has not taken,
+    // however short its stripes are (bounded per stripe, 40 stripes of one batch each would all be produced at once)
+    {
+        struct CountingSub : exg_rd::FanSub {
+            int left;
+            explicit CountingSub(int n) : left(n) {}
+            int next(exg_rd::FanItem *out, std::string *) override {
+                if (left-- > 0) out->batch = std::make_shared<int>(left), out->rows = 1;
+                return EXG_OK;
+            }
+            int count(uint64_t *rows, std::string *) override { *rows = (uint64_t)left; return EXG_OK; }
+            void stats(uint64_t *now, uint64_t *peak, uint64_t *nb, uint64_t *ns) override { *now = 10, *peak = 20, *nb = 1, *ns = 0; }
+        };
+        for (int per_stripe : {1, 2, 5}) {
+            std::vector<exg_rd::Stripe> stripes(40);
+            exg_rd::FanOpen open = [per_stripe](const exg_rd::Stripe &, std::unique_ptr<exg_rd::FanSub> *sub, std::string *) {
+                sub->reset(new CountingSub(per_stripe));
+                return EXG_OK;
+            };
+            exg_rd::FanOut fan(stripes, 4, open, 2);
+            uint64_t rows = 0;
+            for (;;) {
+                exg_rd::FanItem it;
+                std::string err;
+                if (fan.next(&it, &err)) return 11;
+                if (!it.batch) break;
+                rows += it.rows;
+                if (rows == 3) {  // let the workers run as far as they may
+                    struct timespec ts = {0, 20000000};
+                    nanosleep(&ts, nullptr);
+                    (void)fan.stats();
+                }
+            }
+            if (rows != 40u * (uint64_t)per_stripe || fan.max_outstanding() > 2) return 11;
+            if (fan.stats().device_batches != 40) return 11;
+            runs++;
+        }
     }
     printf("%ld runs\n", runs);
     return 0;

@@ -33,7 +33,7 @@ def test_host_parsers_under_asan_ubsan(tmp_path):
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-D__HIP_PLATFORM_AMD__",
            "-I", "/opt/rocm/include", "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-o", str(exe),
            os.path.join(ROOT, "tests", "host_asan_driver.cpp"), os.path.join(CSRC, "exg_gzip.cpp"), os.path.join(CSRC, "exg_zstd_index.cpp"),
-           os.path.join(CSRC, "exg_rd_bgzf.cpp"), os.path.join(CSRC, "exg_vcf_header.cpp"), os.path.join(CSRC, "exg_rd_plan.cpp"), "-lpthread"]
+           os.path.join(CSRC, "exg_rd_bgzf.cpp"), os.path.join(CSRC, "exg_vcf_header.cpp"), os.path.join(CSRC, "exg_rd_plan.cpp"), os.path.join(CSRC, "exg_rd_fanout.cpp"), "-lpthread"]
     subprocess.check_call(cmd)
     text = fastq_text(3000, 4)
     files = {

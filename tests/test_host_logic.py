@@ -109,3 +109,35 @@ def test_batch_index_stays_below_duckdbs_pipeline_increment():
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "exon_duckdb_amd", "csrc", "exon_table_function.hpp")).read()
     assert "kBatchBits = 24" in src
     assert (64 << 24) + (1 << 24) < 10 ** 13 // 1000
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """`bench.py --gpus 2` under a 1-rank launcher (WORLD_SIZE=1) must fail loudly, before anything touches a GPU: a line
+    that says n_gpus = 1 for a run that was asked for 2 would be a wasted scaling run."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, cwd=root,
+                         capture_output=True, text=True, timeout=120)
+    assert res.returncode == 2 and "WORLD_SIZE=1" in res.stderr and not res.stdout.strip(), (res.returncode, res.stderr[-500:])
+
+
+def test_bench_without_a_launcher_starts_its_ranks():
+    """`bench.py --gpus 2` with no WORLD_SIZE starts two ranks itself (a child torch.distributed.run; nothing is exec'ed).  There
+    is no GPU here, so each rank stops at "bench.py needs a GPU" — said twice, by ranks that see WORLD_SIZE=2 — and the parent
+    exits with the launcher's non-zero code."""
+    import os
+    import subprocess
+    import sys
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the GPU form of this test is tests/test_reader_shards_gpu.py::test_bench_launches_its_own_ranks")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--backend", "gloo"], env=env,
+                         cwd=root, capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0
+    assert res.stderr.count("bench.py needs a GPU") >= 2, res.stderr[-2000:]

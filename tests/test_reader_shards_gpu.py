@@ -299,6 +299,28 @@ def test_bench_two_ranks_on_one_gpu(gpu):
     assert rs.get("verified") is True, rs
 
 
+def test_bench_launches_its_own_ranks(gpu):
+    """`python3 bench.py --gpus 2 ...` with NO launcher (what the driver's 1-GPU command line looks like with another N): the
+    script starts the two ranks itself, as a child torch.distributed.run, and its one JSON line says n_gpus = 2; the sharded
+    reader leg is verified by digest (every row of every shard, with its index in the file)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device", "--steps", "2",
+           "--warmup", "1", "--launches-per-step", "2", "--gb", "0.5", "--e2e-gb", "0.25"]
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["verified"] is True
+    rs = j["reader_sharded"]
+    assert rs.get("verified") is True and len(rs["rows_per_shard"]) == 2 and "digest" in rs["verification"], rs
+
+
 def test_rccl_initialises_and_reduces_on_this_image(gpu):
     """bench.py's N > 1 collectives run over RCCL (torch's "nccl" backend).  A one-GPU box cannot run two ranks on it, but it
     can prove that the library loads, a communicator comes up and the three collectives the bench uses complete on the device."""
