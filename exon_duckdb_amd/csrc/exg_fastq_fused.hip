@@ -7,19 +7,24 @@
 // construction called at exon/src/exon/arrow_table_function/module.cpp:289.
 //
 // Design (MI355X / gfx950, wave64, HBM-bound byte work, no MFMA):
-//   * one 256-thread workgroup per 32 KiB SUPER-TILE (block b+1 -> super-tile b).  Its bytes are
-//     loaded with coalesced 16 B/lane loads (8 per thread, all issued up front) and stay in
+//   * one 256-thread workgroup per 48 KiB SUPER-TILE (block b+1 -> super-tile b).  Its bytes are
+//     loaded with coalesced 16 B/lane loads (12 per thread, all issued up front) and stay in
 //     REGISTERS; the '\n' SWAR match, popcounts and the non-ASCII test run on the registers.
-//     The super-tile is then processed as two 16 KiB halves through ONE 17 KiB LDS buffer
+//     The super-tile is then processed as three 16 KiB halves through ONE 17 KiB LDS buffer
 //     (bytes are only parked in LDS for the random access that field extraction needs).
 //     Why: the global line index arrives ~5 us after a tile's count is published (below), and a
 //     CU can hold at most 160 KiB of LDS-staged bytes; keeping the waiting bytes in registers
-//     doubles the bytes in flight per CU (8 workgroups x 32 KiB) at 20 KiB of LDS each, which is
-//     what hides that latency;
+//     multiplies the bytes in flight per CU (6 workgroups x 48 KiB) at 24.7 KiB of LDS each, which is
+//     what hides that latency (A/B in one box: 2 halves 52.1 %, 3 halves 53.7 %, 4 halves 50.6 % of peak);
 //   * the 1 KiB that precedes a half is staged too (from memory for the first half, from the
-//     first half's tail for the second), so a record straddling the left edge is resolved from
-//     LDS; a record larger than that window raises `overflow` and the general multipass kernels
-//     redo the buffer;
+//     previous half's tail for the others), so a record straddling the left edge is resolved from
+//     LDS.  A record that begins in front of that window (a long read: every PacBio / ONT file) is
+//     not a reason to give the launch up: at most ONE such record ends in a half, its fields are
+//     slices — nothing needs its bytes but the '@' / '+' checks, the name's split and the string
+//     prefixes — so the half writes the record's newline positions as far as it knows them
+//     (FarRec, exg_fastq_ws.hpp) and k_fastq_far, a small kernel behind this one, finds the others
+//     by looking back over the tiles' counts and last-four lists and emits the row from global
+//     memory.  A half with more lines than its list holds (reads below ~45 bp) is emitted in passes;
 //   * newline ranks: packed 4x16-bit wave shuffle scan + wave totals, positions -> u16 list;
 //   * the global line index (hence the exact 4-line phase — '@' is also a quality character, so
 //     the phase is never guessed — and the output row) comes from an ordered prefix over the
@@ -59,12 +64,37 @@ __device__ __forceinline__ void fastq_emit_half(const L &s, const FastqDev &a, S
     const uint32_t n_rec = c.n_lines > i_first ? (c.n_lines - i_first + 3) / 4 : 0;
     const uint64_t ptr_of_e0 = a.payload_base + c.tile_off - kWin;
 
-    if (threadIdx.x == 0) {  // offset just past the last quality line that ends in this half (0: none)
+    if (threadIdx.x == 0 && (c.pass_base == 0 || n_rec)) {  // offset just past the last quality line that ends in this half (0: none)
         long long e = 0;
         if (n_rec) {
             e = (long long)c.tile_off + (int)s.nlist[4 + i_first + 4 * (n_rec - 1)] - kWin + 1;
             if ((unsigned long long)e > a.n_bytes) e = (long long)a.n_bytes;
         }
+        if (c.pass_base) e |= (long long)(tile_qend[tile_index] & kFarBit);  // (a later pass keeps the first pass's mark)
+#ifndef EXG_AB_NO_FAR
+        // The first record that ends here begins in front of the LDS window (a long read; only a half's first record in its
+        // first pass can): its row is k_fastq_far's.  What is known here of its five newlines — inside the half, or as codes
+        // (prev32) — goes into the half's FarRec; the loop below stores zeros in the row.  Decided here, once and by one
+        // thread, rather than inside the loop: the loop's registers are the kernel's tightest.
+        if (n_rec && s.nlist[i_first] == kNoneE) {
+            const long long out0 = (long long)q_before - (long long)n_hc;
+            const int e4 = s.nlist[4 + i_first];
+            if ((uint64_t)((int64_t)c.tile_off + e4 - kWin) >= a.lead && out0 >= 0 &&
+                ((a.flags & EXG_F_NO_STORE) || (unsigned long long)out0 < a.capacity)) {
+                FarRec f;
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    const uint32_t idx = i_first + k;
+                    f.pos[k] = idx >= 4 ? c.half * kTile + (int32_t)s.nlist[idx] - kWin : s.prev32[idx];
+                }
+                f.flags = c.is_eof_tile ? 1u : 0u;
+                f.out = out0;
+                reinterpret_cast<FarRec *>(tile_qend + 3 * fused_n_tiles(a.n_bytes))[tile_index] = f;
+                hdr->any_far = 1u;
+                e |= (long long)kFarBit;
+            }
+        }
+#endif
         tile_qend[tile_index] = (unsigned long long)e;
     }
     if (dev_mode >= 3) return;
@@ -89,15 +119,10 @@ __device__ __forceinline__ void fastq_emit_half(const L &s, const FastqDev &a, S
             const uint32_t q0 = s.nlist[i];  // newline before the name line
             uint4 val = make_uint4(0, 0, 0, 0);
             if (q0 == kNoneE) {
-                // the record starts before the window (val stays zero)
-                if (wave == 0) {
-                    if (c.first_of_buffer) {
-                        atomicAdd(&hdr->n_unresolved, 1ull);
-                        atomicOr(&hdr->flags, EXG_RF_HEAD_UNRESOLVED);
-                    } else {
-                        atomicOr(&hdr->overflow, 1u);
-                    }
-                }
+                // the record begins in front of the LDS window: k_fastq_far's row (the FarRec above); zeros are stored here
+#ifdef EXG_AB_NO_FAR
+                if (wave == 0) atomicOr(&hdr->overflow, 1u);
+#endif
             } else if (wave <= 1) {
                 // name line [s0, e0): '@' check, CR strip, split at the first ' '
                 int s0 = (int)q0 + 1, e0 = s.nlist[i + 1];
@@ -179,7 +204,10 @@ __device__ __forceinline__ void fastq_emit_half(const L &s, const FastqDev &a, S
 
 struct FastqFormat {
     using Dev = FastqDev;
-    static constexpr int kNlCap = 512;          // 197 lines per half for 150 bp reads; LDS 22.7 KB -> 7 per CU
+#ifndef EXG_FASTQ_NLCAP
+#define EXG_FASTQ_NLCAP 512
+#endif
+    static constexpr int kNlCap = EXG_FASTQ_NLCAP;  // 197 lines per half for 150 bp reads
     static constexpr bool kTabMap = false;
     static constexpr int kHalves = 3;   // 48 KiB per workgroup: A/B on one box 2 -> 3 halves +3 %, 4 halves -7 %
     static constexpr int kMinWavesPerSimd = 6;  // 80 VGPRs, no scratch: 6 x 48 KiB in flight per CU
@@ -200,6 +228,57 @@ struct FastqFormat {
     }
 };
 
+// The rows k_fused left out: one record per marked half, lines read from global memory (thread = record).  Runs behind
+// k_fused on the stream — every tile's count and last-four list is final, the look-back is plain reads.
+__global__ __launch_bounds__(256) void k_fastq_far(FastqDev a, const unsigned int *__restrict__ tileA, const int32_t *__restrict__ tileL,
+                                                   const unsigned long long *__restrict__ tile_qend, const FarRec *__restrict__ far_rec,
+                                                   ScanWsHeader *hdr, uint32_t n_halves) {
+    if (!hdr->any_far) return;
+    constexpr uint32_t kHalves = FastqFormat::kHalves;
+    constexpr uint64_t kSuper = (uint64_t)kHalves * kTile;
+    const bool no_store = (a.flags & EXG_F_NO_STORE) != 0;
+    for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n_halves; x += (uint64_t)gridDim.x * blockDim.x) {
+        if (!(tile_qend[x] & kFarBit)) continue;
+        const FarRec f = far_rec[x];
+        const uint32_t st = (uint32_t)(x / kHalves);
+        int64_t p[5];
+        const bool resolved = far_positions<5>(f, st, kSuper, tileA, tileL, (a.flags & EXG_F_BOF) != 0, p);
+        const unsigned long long out = (unsigned long long)f.out;
+        uint4 z = {0, 0, 0, 0};
+        if (!resolved) {  // the record begins in front of d_input[0]: the caller widens the halo (like the general path says it)
+            atomicAdd(&hdr->n_unresolved, 1ull);
+            atomicOr(&hdr->flags, EXG_RF_HEAD_UNRESOLVED);
+            if (!no_store) {
+                reinterpret_cast<uint4 *>(a.d_name)[out] = z;
+                reinterpret_cast<uint4 *>(a.d_desc)[out] = z;
+                reinterpret_cast<uint4 *>(a.d_seq)[out] = z;
+                reinterpret_cast<uint4 *>(a.d_qual)[out] = z;
+            }
+            continue;
+        }
+        const FastqGeom g = fastq_geometry_at(a.d_in, a.n_bytes, p);
+        uint32_t code = 0;
+        if (!g.name_ok)
+            code = EXG_PE_FASTQ_NAME_PREFIX;
+        else if (!g.plus_ok)
+            code = EXG_PE_FASTQ_PLUS_PREFIX;
+        const uint64_t lens[4] = {g.name_e - g.s[0], g.e[0] - g.desc_s, g.e[1] - g.s[1], g.e[3] - g.s[3]};
+        if (!code && (lens[0] > 0xFFFFFFFFull || lens[1] > 0xFFFFFFFFull || lens[2] > 0xFFFFFFFFull || lens[3] > 0xFFFFFFFFull))
+            code = EXG_PE_FIELD_TOO_LONG;
+        if (code) {
+            atomicMin(&hdr->err_word, (out << 8) | code);
+            atomicMin(&hdr->err_off, (unsigned long long)(p[0] + 1));
+        }
+        if (no_store) continue;
+        const bool desc_valid = lens[1] != 0;
+        reinterpret_cast<uint4 *>(a.d_name)[out] = make_string_global(a.d_in, g.s[0], lens[0], a.payload_base);
+        reinterpret_cast<uint4 *>(a.d_desc)[out] = desc_valid ? make_string_global(a.d_in, g.desc_s, lens[1], a.payload_base) : z;
+        reinterpret_cast<uint4 *>(a.d_seq)[out] = make_string_global(a.d_in, g.s[1], lens[2], a.payload_base);
+        reinterpret_cast<uint4 *>(a.d_qual)[out] = make_string_global(a.d_in, g.s[3], lens[3], a.payload_base);
+        if (desc_valid) atomicOr((unsigned long long *)&a.d_desc_valid[out >> 6], 1ull << (out & 63));
+    }
+}
+
 // Runs after k_fastq_fused on the same stream: folds the header into the 64-byte result.
 __global__ __launch_bounds__(256) void k_fastq_finalize_fused(FastqDev a, ScanWsHeader *hdr,
                                                                 const unsigned long long *__restrict__ tile_qend,
@@ -215,7 +294,7 @@ __global__ __launch_bounds__(256) void k_fastq_finalize_fused(FastqDev a, ScanWs
     if (!hdr->overflow) {
         for (int64_t base = (int64_t)n_tiles - 1; base >= 0; base -= 256) {
             int64_t t = base - threadIdx.x;
-            unsigned long long q = t >= 0 ? tile_qend[t] : 0;
+            unsigned long long q = t >= 0 ? tile_qend[t] & ~(kFarBit | kDenseBit) : 0;
             if (q) atomicMax(&s_qend, q);
             if (q) s_found = 1;
             __syncthreads();
@@ -293,14 +372,25 @@ int run_fastq_fused(const exg_fastq_scan_args *args, const FastqDev &dev, uint8_
     unsigned int *tileA = reinterpret_cast<unsigned int *>(ws + l.off_tile_desc);
     unsigned long long *tileP = reinterpret_cast<unsigned long long *>(ws + l.off_tile_desc) + l.n_tiles_fused;
     unsigned long long *tile_qend = tileP + l.n_tiles_fused;
+    int32_t *tileL = reinterpret_cast<int32_t *>(ws + l.off_tile_last4);
+    FarRec *far_rec = reinterpret_cast<FarRec *>(ws + l.off_far);
     hipLaunchKernelGGL(k_init_hdr, dim3(1), dim3(1), 0, stream, hdr, l.lines_cap, 0u);
     EXG_HIP_CHECK(hipMemsetAsync(tileA, 0, (size_t)l.n_tiles_fused * 16, stream));
     if (dev.lead) {
         int rc = exg_count_newlines(dev.d_in, 0, dev.lead, (uint64_t *)&hdr->halo_nl, stream);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_fused<FastqFormat>, dim3(n_super + 1), dim3(kThreads), 0, stream, dev, tileA, tileP, tile_qend, hdr,
-                       n_super);
+    hipLaunchKernelGGL(k_fused<FastqFormat>, dim3(n_super + 1), dim3(kThreads), 0, stream, dev, tileA, tileP, tile_qend, hdr, n_super);
+#ifndef EXG_AB_NO_EXTRA_LAUNCH
+    // halves with more lines than the LDS list holds, in passes (returns at once when the scan marked none)
+    hipLaunchKernelGGL(k_fused_dense<FastqFormat>, dim3(n_super < 1536 ? n_super : 1536), dim3(kThreads), 0, stream, dev, tileA, tileP,
+                       tile_qend, hdr, n_super);
+    {   // the rows of records that begin in front of their half's window (returns at once when there is none)
+        const uint32_t n_halves = n_super * kHalvesHost;
+        const uint32_t grid = (n_halves + 255) / 256 < 4096 ? (n_halves + 255) / 256 : 4096;
+        hipLaunchKernelGGL(k_fastq_far, dim3(grid), dim3(256), 0, stream, dev, tileA, tileL, tile_qend, far_rec, hdr, n_halves);
+    }
+#endif
     hipLaunchKernelGGL(k_fastq_finalize_fused, dim3(1), dim3(256), 0, stream, dev, hdr, tile_qend, n_super * kHalvesHost,
                        args->d_result);
     EXG_HIP_CHECK(hipGetLastError());

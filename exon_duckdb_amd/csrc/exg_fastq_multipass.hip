@@ -10,53 +10,26 @@
 
 namespace exg {
 
-struct FastqGeom {
-    uint64_t s[4], e[4];  // field lines, CR stripped: name line, sequence, plus line, quality
-    uint64_t raw_e[4];
-    uint64_t name_e, desc_s;  // split of the name line at the first ' '
-    bool name_ok, plus_ok;
-    bool resolved;
-};
-
 // Lines of candidate record j (its quality line is line iq = i0 + 4 j of the buffer).
 __device__ __forceinline__ FastqGeom fastq_geometry(const uint8_t *__restrict__ d_in, uint64_t n_bytes,
                                                      const uint64_t *__restrict__ nl_pos, int64_t iq,
                                                      bool line_starts_at_0) {
-    FastqGeom g;
-    g.resolved = true;
-    uint64_t start;
+    int64_t p[5];
     if (iq - 4 >= 0)
-        start = nl_pos[iq - 4] + 1;
+        p[0] = (int64_t)nl_pos[iq - 4];
     else if (iq - 4 == -1 && line_starts_at_0)
-        start = 0;
+        p[0] = -1;
     else {
+        FastqGeom g = {};
         g.resolved = false;
-        start = 0;
+        return g;
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        int64_t li = iq - 3 + k;
-        uint64_t raw_end = li >= 0 ? nl_pos[li] : 0;
-        if (start > raw_end) start = raw_end;  // virtual (EOF) lines are empty
-        uint64_t end = raw_end;
-        bool virt = raw_end >= n_bytes;
-        if (!virt && end > start && d_in[end - 1] == '\r') end--;
-        g.s[k] = start;
-        g.e[k] = end;
-        g.raw_e[k] = raw_end;
-        start = raw_end + 1;
+        const int64_t li = iq - 3 + k;
+        p[k + 1] = li >= 0 ? (int64_t)nl_pos[li] : 0;
     }
-    g.name_ok = g.s[0] < g.raw_e[0] && d_in[g.s[0]] == '@';
-    g.plus_ok = g.s[2] < g.raw_e[2] && d_in[g.s[2]] == '+';
-    // name = [s0+1, first ' '), description = (first ' ', e0)
-    uint64_t p = g.s[0] + 1;
-    if (p > g.e[0]) p = g.e[0];
-    uint64_t q = p;
-    while (q < g.e[0] && d_in[q] != ' ') q++;
-    g.s[0] = p;
-    g.name_e = q;
-    g.desc_s = q < g.e[0] ? q + 1 : g.e[0];
-    return g;
+    return fastq_geometry_at(d_in, n_bytes, p);
 }
 
 struct FastqCounts {
@@ -221,7 +194,8 @@ __global__ void k_init_hdr(ScanWsHeader *hdr, uint64_t lines_cap, uint32_t mode)
     if (mode == 1 && overflow == 0) return;
     ScanWsHeader h;
     h.n_slow = h.slow_pad = 0;
-    for (unsigned int i = 0; i < 20; i++) h.reserved[i] = 0;
+    h.any_far = h.any_dense = 0;
+    for (unsigned int i = 0; i < 19; i++) h.reserved[i] = 0;
     h.last_qend = 0;
     h.total_nl = h.total_lines = h.halo_nl = h.n_unresolved = 0;
     h.err_word = kNoError;

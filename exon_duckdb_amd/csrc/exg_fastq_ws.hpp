@@ -31,7 +31,9 @@ struct alignas(256) ScanWsHeader {
     // VCF: QUAL literals the scan kernel could not decide with 19 digits (exg_parse.hpp, status 2) are listed in the
     // workspace (FastqWsLayout::off_slow) and decided exactly by the finalize kernel (exg_float_slow.hpp).
     unsigned int n_slow, slow_pad;
-    unsigned long long reserved[20];
+    unsigned int any_far;            // fused kernels: some half left a record to k_*_far (plain store of 1)
+    unsigned int any_dense;          // ... some half holds more lines than the LDS list: the dense run of the kernel emits it
+    unsigned long long reserved[19];
 };
 struct SlowLiteral {
     unsigned long long off;  // input offset of the literal
@@ -40,12 +42,33 @@ struct SlowLiteral {
 };
 static_assert(sizeof(ScanWsHeader) == 256, "header is 256 bytes");
 
+// A record (FASTQ) / line (VCF) that ends in a 16 KiB half but begins before the 1 KiB window in front of it — a long read, a
+// multi-sample VCF line — has its delimiting newlines outside LDS.  The fused kernel does not give the launch up for it: it
+// writes what it knows (one FarRec per half: at most ONE such record ends in a half, the first) and k_*_far, a small kernel
+// behind it on the stream, emits these rows from global memory.  pos[k]: the record's delimiting newlines, oldest first
+// (FASTQ: 5, VCF: 2); >= 0: offset inside the half's super-tile; -1 - j: the j-th newest newline in front of the super-tile,
+// found by looking back over the tiles' counts (tileA) and last-four lists (tileL).
+struct FarRec {
+    int32_t pos[5];
+    uint32_t flags;      // bit 0: the half holds the end of the input with EXG_F_EOF (virtual EOF lines sit at n_bytes)
+    long long out;       // output row
+};
+static_assert(sizeof(FarRec) == 32, "FarRec is 32 bytes");
+static constexpr unsigned long long kFarBit = 1ull << 63;    // in tile_qend[half]: far_rec[half] is to be emitted
+static constexpr unsigned long long kDenseBit = 1ull << 62;  // in tile_qend[half]: the half is left to the dense run
+
 struct FastqWsLayout {
     uint64_t n_tiles_mp;
     uint64_t n_tiles_fused;
     uint64_t off_tile_counts;   // u32[n_tiles_mp]
     uint64_t off_tile_offsets;  // u64[n_tiles_mp]
-    uint64_t off_tile_desc;     // u64[n_tiles_fused] look-back descriptors + u64[n_tiles_fused] tile_qend
+    // one block of 72 n_tiles_fused bytes: u64 tileA[n] (u32 counts) | u64 tileP[n] | u64 tile_qend[n] | int32 tileL[n][4]: the
+    // last four newlines of every super-tile (codes like FarRec::pos) | FarRec[n].  n is a multiple of 4 and a function of
+    // n_bytes alone (fused_n_tiles), so that the kernels find tileL and FarRec[] from tile_qend without another argument or
+    // load (two more kernel arguments cost the FASTQ scan scalar registers it does not have: spills)
+    uint64_t off_tile_desc;
+    uint64_t off_tile_last4;
+    uint64_t off_far;
     uint64_t off_block_sums;    // 2 x u64[lines / 4096 + 2] (FASTA device-wide scans: records, payload)
     uint64_t off_slow;          // SlowLiteral[slow_cap] (VCF: QUAL literals for the exact parser)
     uint64_t slow_cap;          // one per 32 bytes of input, at most 4096: a literal of that class has more than 19 digits
@@ -55,6 +78,11 @@ struct FastqWsLayout {
 };
 
 static inline uint64_t round_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+// entries of the fused kernels' per-tile arrays for a buffer of n_bytes (host and device agree on it)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline uint64_t fused_n_tiles(uint64_t n_bytes) { return ((n_bytes + kFusedTileBytes - 1) / kFusedTileBytes + 2 + 3) & ~3ull; }
 
 // n_line_arrays: FASTA keeps 4 u64 arrays per line (offsets, record prefix, payload prefix, record starts).
 // nl_pos capacity: the general kernels index every line.  Worst case is one line per byte; the
@@ -63,14 +91,16 @@ static inline uint64_t round_up(uint64_t v, uint64_t a) { return (v + a - 1) / a
 static inline FastqWsLayout fastq_ws_layout(uint64_t n_bytes, uint64_t ws_bytes_or_0, uint64_t n_line_arrays = 1) {
     FastqWsLayout l;
     l.n_tiles_mp = (n_bytes + kMpTileBytes - 1) / kMpTileBytes + 1;
-    l.n_tiles_fused = (n_bytes + kFusedTileBytes - 1) / kFusedTileBytes + 2;
+    l.n_tiles_fused = fused_n_tiles(n_bytes);
     uint64_t at = sizeof(ScanWsHeader);
     l.off_tile_counts = at;
     at = round_up(at + l.n_tiles_mp * 4, 256);
     l.off_tile_offsets = at;
     at = round_up(at + l.n_tiles_mp * 8, 256);
     l.off_tile_desc = at;
-    at = round_up(at + l.n_tiles_fused * 24, 256);  // tileA, tileP, tile_qend
+    l.off_tile_last4 = at + l.n_tiles_fused * 24;
+    l.off_far = at + l.n_tiles_fused * 40;
+    at = round_up(at + l.n_tiles_fused * 72, 256);
     uint64_t want = n_bytes / 8;
     uint64_t small = n_bytes < (1ull << 20) ? n_bytes : (1ull << 20);
     if (want < small) want = small;

@@ -1,8 +1,8 @@
 // exg_fused_core.hpp — the single-pass skeleton shared by the fused record-scan kernels.
 //
 // (see exg_fastq_fused.hip for the design rationale and the measurements behind it)
-//   * 256-thread workgroup per 32 KiB super-tile held in registers, processed as two 16 KiB halves
-//     through one LDS buffer (+ the 1 KiB window that precedes the half);
+//   * 256-thread workgroup per super-tile of F::kHalves x 16 KiB held in registers, processed one 16 KiB half at a
+//     time through one LDS buffer (+ the 1 KiB window that precedes the half);
 //   * newline count published per super-tile, exclusive prefix from the central scanner wave
 //     (block 0), awaited only after half 0 has been staged;
 //   * per half: bytes -> LDS, contiguous 64 B per thread re-classified from LDS (conflict-free
@@ -13,7 +13,11 @@
 //   F::eof_extra_lines(line_index_total)  extra virtual (empty) lines at EOF besides the unterminated one
 //   F::emit_half(...)                     records ending in the staged half
 //   F::analytic_prefix(offset)            dev-only ablation hook
-//   F::kNlCap                             newline positions kept per half (LDS)
+//   F::kNlCap                             newline positions kept in LDS at a time: a half with more lines (short reads, short
+//                                         VCF lines) is emitted in passes of kNlCap lines each
+//   F::write_far(...)                     (inside emit_half) the ONE record per half that begins before the window: a FarRec
+//                                         for the k_*_far kernel behind this one (exg_fastq_ws.hpp) — any record length stays
+//                                         on this single pass over the input
 //   F::kTabMap                            also keep a '\t' bitmap of every half (VCF)
 //   F::kHalves                            16 KiB halves per workgroup (bytes waiting in registers: 16 VGPRs each)
 //   F::kMinWavesPerSimd                   occupancy the register allocator must respect (7 = 7 workgroups/CU)
@@ -57,7 +61,10 @@ struct FusedLdsT {
     uint32_t wcnt[4];   // per-wave packed (half 0 | half 1 << 16) newline counts
     unsigned long long prefix;            // '\n' in the buffer before this super-tile
     uint32_t hi_or[4];
-    uint16_t carry[4];  // the 4 newlines before the second half, relative to it
+    // the 4 newlines before the staged half / pass (oldest first) as CODES (FarRec::pos): >= 0 offset inside the super-tile,
+    // -1 - j: the j-th newest newline in front of the super-tile; nlist[0..3] holds those that lie in the LDS window
+    int32_t prev32[4];
+    int32_t carry32[4];  // ... before the NEXT half (written when a half's list is complete)
 };
 
 template <class L>
@@ -112,6 +119,14 @@ __device__ unsigned long long help_count_bytes(const uint8_t *__restrict__ d_in,
     return __shfl(cnt, 0, 64);
 }
 
+// x, but the compiler may not compute anything that depends on it ahead of this point: the three halves of a super-tile are
+// unrolled, and addresses like &s.carry32[lane] — three VALU instructions — are otherwise computed once, kept across the
+// halves and, at 80 registers, SPILLED: a scratch reload in front of an LDS access makes the wave wait (vmcnt counts loads and
+// stores alike on gfx9) for every column store it has in flight, which cost the 10 GB FASTQ launch 6 % (A/B in one box).
+__device__ __forceinline__ uint32_t opaque(uint32_t x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
 __device__ __forceinline__ unsigned long long rfl64(unsigned long long x) {  // wave-uniform value -> SGPRs
     uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
     return ((unsigned long long)hi << 32) | lo;
@@ -211,6 +226,58 @@ __device__ unsigned long long wait_prefix(const uint8_t *__restrict__ d_in, uint
     return sum;
 }
 
+// ---- k_*_far: the newline positions of a FarRec as offsets into the buffer -------------------------------------------
+// pos[k] >= 0: inside super-tile st; -1 - j: the j-th newest newline in front of it — found by walking back over the tiles:
+// tileA[t] says how many newlines tile t holds, tileL[4 t ..] its last four (slot 3 the newest; a tile with c < 4 newlines has
+// them in slots 4 - c .. 3).  With EXG_F_BOF a line begins at d_input[0]: a newline at -1.  false: a position lies in front
+// of the buffer (the record's head is not in it).  Runs behind k_fused: every word is final, plain reads.
+template <int N>
+__device__ inline bool far_positions(const FarRec &f, uint32_t st, uint64_t super_bytes, const unsigned int *__restrict__ tileA,
+                                     const int32_t *__restrict__ tileL, bool bof, int64_t *p) {
+    int need = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        if (f.pos[k] < 0 && -f.pos[k] > need) need = -f.pos[k];
+    int64_t back0 = 0, back1 = 0, back2 = 0, back3 = 0;  // the j-th newest newline in front of the super-tile
+    int found = 0;
+    for (uint32_t t = st; found < need && t > 0;) {
+        t--;
+        uint32_t c = tileA[t] & ~kFlagA;
+        if (!c) continue;
+        if (c > 4) c = 4;
+        const int4 l = *reinterpret_cast<const int4 *>(tileL + (uint64_t)t * 4);
+        const int64_t base = (int64_t)((uint64_t)t * super_bytes);
+        const int32_t e[4] = {l.w, l.z, l.y, l.x};  // newest first
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if ((uint32_t)q < c && found < need) {
+                const int64_t v = base + e[q];
+                if (found == 0) back0 = v;
+                else if (found == 1) back1 = v;
+                else if (found == 2) back2 = v;
+                else back3 = v;
+                found++;
+            }
+        }
+    }
+    if (found < need && bof) {
+        const int64_t v = -1;
+        if (found == 0) back0 = v;
+        else if (found == 1) back1 = v;
+        else if (found == 2) back2 = v;
+        else back3 = v;
+        found++;
+    }
+    if (found < need) return false;
+    const int64_t super_off = (int64_t)((uint64_t)st * super_bytes);
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const int32_t c = f.pos[k];
+        p[k] = c >= 0 ? super_off + c : c == -1 ? back0 : c == -2 ? back1 : c == -3 ? back2 : back3;
+    }
+    return true;
+}
+
 struct TileCtx {  // what emission needs besides the LDS contents (all workgroup-uniform)
     uint64_t tile_off;          // offset of the half in d_input
     unsigned long long P;       // '\n' in the buffer before the half
@@ -218,20 +285,34 @@ struct TileCtx {  // what emission needs besides the LDS contents (all workgroup
     int lim_e;                  // extended offset of the end of input inside this half (kWin + min(lim, kTile))
     bool is_eof_tile;           // the input ends in this half and EXG_F_EOF
     bool first_of_buffer;       // half 0 of super-tile 0: what precedes is before d_input[0]
+    uint32_t pass_base;         // lines of the half emitted by earlier passes (0: first pass; P and n_lines are the pass's)
+    int half;                   // index of the half inside its super-tile
 };
 
-template <class F>
-__global__ __launch_bounds__(kThreads, F::kMinWavesPerSimd) void k_fused(typename F::Dev a, unsigned int *__restrict__ tileA,
-                                                             unsigned long long *__restrict__ tileP,
-                                                             unsigned long long *__restrict__ tile_qend,
-                                                             ScanWsHeader *hdr, uint32_t n_super) {
+// The scan.  kDenseRun == false: k_fused, a workgroup per super-tile (block 0: the scanner wave).  kDenseRun == true: the run
+// behind it (k_fused_dense: a fixed grid striding over the super-tiles) over the super-tiles in which the scan marked a half
+// as DENSE — more lines end in it than the LDS list holds (FASTQ: an average line below 16 bytes) — with the prefix the
+// scanner published: the marked halves are emitted in passes of kNlCap lines, everything else is staged only (the window
+// and the 4 preceding newlines of a half come from the half in front of it).  An instance of its own so that the scan's
+// code stays what it is without it: with the pass loop inside the scan the 10 GB FASTQ launch took 2.81 ms against
+// 2.25 ms (A/B in one box) although the loop was never entered — the scan runs at the edge of its 80 registers, and a
+// register spilled in its hot path makes the wave wait for all its column stores at every reload (vmcnt counts loads and
+// stores alike on gfx9).
+template <class F, bool kDenseRun>
+__device__ __forceinline__ void fused_body(typename F::Dev a, unsigned int *__restrict__ tileA, unsigned long long *__restrict__ tileP,
+                                           unsigned long long *__restrict__ tile_qend, ScanWsHeader *hdr, uint32_t n_super) {
     using FusedLds = FusedLdsT<F::kNlCap, F::kHalves, F::kTabMap>;
     constexpr int kNlCap = F::kNlCap;
     constexpr int kHalves = F::kHalves;
     constexpr int kSuper = kTile * kHalves;
     __shared__ __attribute__((aligned(16))) FusedLds s;
     const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63, wave = tid >> 6;
+    const uint32_t lane = tid & 63;
+#ifdef EXG_AB_WAVE_VGPR
+    const uint32_t wave = tid >> 6;
+#else
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: a scalar register (and no VGPR to spill)
+#endif
     // DEV ONLY (tools/dev_probe.py): flags bits 8..11 select ablations on the synthetic FASTQ-150 file
     //   1: analytic prefix instead of the scanner   2: 1 + no output stores
     //   3: 1 + no emission at all                    4: scanner, no emission
@@ -240,11 +321,26 @@ __global__ __launch_bounds__(kThreads, F::kMinWavesPerSimd) void k_fused(typenam
 #else
     constexpr uint32_t dev_mode = 0;  // the product build carries no work-skipping mode (EXG_CXXFLAGS=-DEXG_DEV_PROBE builds them in)
 #endif
-    if (blockIdx.x == 0) {  // the scanner: one wave, no tile
-        if (wave == 0 && !(dev_mode >= 1 && dev_mode <= 3)) scanner_wave<F::kHalves * kTile>(a.d_in, a.n_bytes, tileA, tileP, n_super, lane);
-        return;
+    uint32_t st;
+    if constexpr (kDenseRun) {
+        if (!hdr->any_dense) return;
+        st = blockIdx.x;
+        if (st >= n_super) return;
+    } else {
+        if (blockIdx.x == 0) {  // the scanner: one wave, no tile
+            if (wave == 0 && !(dev_mode >= 1 && dev_mode <= 3)) scanner_wave<F::kHalves * kTile>(a.d_in, a.n_bytes, tileA, tileP, n_super, lane);
+            return;
+        }
+        st = blockIdx.x - 1;
     }
-    const uint32_t st = blockIdx.x - 1;
+    do {  // (one iteration in the scan)
+    if constexpr (kDenseRun) {
+        bool marked = false;
+#pragma unroll
+        for (int h = 0; h < kHalves; h++) marked = marked || (tile_qend[(uint64_t)st * kHalves + h] & kDenseBit) != 0;
+        if (!marked) continue;  // (workgroup-uniform)
+        __syncthreads();        // the tile before is done with the LDS
+    }
     const uint64_t super_off = (uint64_t)st * kSuper;
     const uint8_t *__restrict__ d_in = a.d_in;
     const uint64_t n_pad = (a.n_bytes + 15) & ~15ull;
@@ -299,14 +395,18 @@ __global__ __launch_bounds__(kThreads, F::kMinWavesPerSimd) void k_fused(typenam
 
     // ---- publish the super-tile count; its prefix is awaited after half 0 has been staged ---------------
     const bool analytic = dev_mode >= 1 && dev_mode <= 3;
-    if (tid == 0 && !analytic)
-        __hip_atomic_store(&tileA[st], kFlagA | n_nl_super, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (!kDenseRun) {
+        if (tid == 0 && !analytic)
+            __hip_atomic_store(&tileA[st], kFlagA | n_nl_super, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     const unsigned long long halo_nl = rfl64(hdr->halo_nl);
     // Bytes >= 0x80 need UTF-8 validation of every field (the reference builds Arrow Utf8 columns).
     // That is rare in FASTQ and is left to the general path: raise `overflow`, which gates it in.
-    if (non_ascii && tid == 0) {
-        atomicOr(&hdr->flags, EXG_RF_NON_ASCII);
-        atomicOr(&hdr->overflow, 1u);
+    if constexpr (!kDenseRun) {
+        if (non_ascii && tid == 0) {
+            atomicOr(&hdr->flags, EXG_RF_NON_ASCII);
+            atomicOr(&hdr->overflow, 1u);
+        }
     }
 
 #pragma unroll
@@ -314,15 +414,20 @@ __global__ __launch_bounds__(kThreads, F::kMinWavesPerSimd) void k_fused(typenam
         const int lim_h = lim_s - h * kTile;  // half-relative end of input
         if (h > 0 && lim_h <= 0) {
             // no input in this half: nothing ends here
-            if (tid == 0)
-                for (int hh = h; hh < kHalves; hh++) tile_qend[(uint64_t)st * kHalves + hh] = 0;
+            if constexpr (!kDenseRun) {
+                if (tid == 0)
+                    for (int hh = h; hh < kHalves; hh++) tile_qend[(uint64_t)st * kHalves + hh] = 0;
+            }
             break;
         }
         // ---- stage the half: window, bytes, newline list ------------------------------------------
         if (h == 0) {
             if (wave == 3) {
                 *reinterpret_cast<uint4 *>(s.bytes + lane * 16) = wv;
-                if (lane < 4) s.nlist[lane] = (uint16_t)kNoneE;
+                if (lane < 4) {
+                    s.nlist[lane] = (uint16_t)kNoneE;
+                    s.prev32[lane] = (int32_t)lane - 4;  // slot 3 = the newest newline in front of the super-tile
+                }
                 uint32_t wm = woff >= 0 ? match16(wv, 0x0A0A0A0Au) : 0u;
                 uint32_t wc = __popc(wm);
                 uint32_t wincl = wave_incl_sum(wc);
@@ -345,7 +450,12 @@ __global__ __launch_bounds__(kThreads, F::kMinWavesPerSimd) void k_fused(typenam
             __syncthreads();
             if (wave == 3) {
                 *reinterpret_cast<uint4 *>(s.bytes + lane * 16) = t;
-                if (lane < 4) s.nlist[lane] = s.carry[lane];
+                if (lane < 4) {
+                    const uint32_t k = opaque(lane);
+                    const int32_t code = s.carry32[k], rel = code - (h * kTile - kWin);  // e-offset in this half's buffer
+                    s.prev32[k] = code;
+                    s.nlist[k] = (code >= 0 && rel >= 0) ? (uint16_t)rel : (uint16_t)kNoneE;
+                }
             }
         }
 #pragma unroll
@@ -374,7 +484,9 @@ __global__ __launch_bounds__(kThreads, F::kMinWavesPerSimd) void k_fused(typenam
             // the half is staged while the scanner turns the published count into our prefix
             if (wave == 0) {
                 unsigned long long pre;
-                if (analytic) {
+                if constexpr (kDenseRun) {
+                    pre = st ? ld_desc(&tileP[st]) & kVal : 0ull;  // (published: the scan has completed)
+                } else if (analytic) {
                     pre = F::analytic_prefix(super_off);
                 } else {
                     pre = wait_prefix<kSuper>(d_in, a.n_bytes, tileA, tileP, st, lane);
@@ -389,6 +501,8 @@ __global__ __launch_bounds__(kThreads, F::kMinWavesPerSimd) void k_fused(typenam
         c.P = rfl64(s.prefix) + nl_before_half;
         nl_before_half += n_nl_h;
         c.first_of_buffer = st == 0 && h == 0;
+        c.pass_base = 0;
+        c.half = h;
         const bool ends_here = last_super && lim_h <= kTile;  // the input ends inside (or at the end of) this half
         c.is_eof_tile = ends_here && (a.flags & EXG_F_EOF);
         c.lim_e = (lim_h < kTile ? lim_h : kTile) + kWin;
@@ -401,27 +515,102 @@ __global__ __launch_bounds__(kThreads, F::kMinWavesPerSimd) void k_fused(typenam
             uint32_t n0 = n_lines;
             if (unterminated) n_lines++;
             n_lines += F::eof_extra_lines(P0 + c.P + n_lines);
-            if (tid == 0 && n_lines <= (uint32_t)kNlCap)
-                for (uint32_t q = n0; q < n_lines; q++) s.nlist[4 + q] = (uint16_t)c.lim_e;
+            if (tid == 0)
+                for (uint32_t q = n0; q < n_lines && q < (uint32_t)kNlCap; q++) s.nlist[4 + q] = (uint16_t)c.lim_e;
             __syncthreads();
         }
         c.n_lines = n_lines;
-        if (ends_here && tid == 0) {
-            hdr->total_nl = c.P + n_nl_h;
-            hdr->total_lines = c.P + n_lines;
+        if constexpr (!kDenseRun) {
+            if (ends_here && tid == 0) {
+                hdr->total_nl = c.P + n_nl_h;
+                hdr->total_lines = c.P + n_lines;
+            }
         }
-        if (n_lines > (uint32_t)kNlCap) {  // more lines than the list holds: general path
-            if (tid == 0) atomicOr(&hdr->overflow, 1u);
-            return;
+        const uint64_t half_index = (uint64_t)st * kHalves + h;
+        if (n_lines > (uint32_t)kNlCap) {
+            // DENSE: more lines than the list holds.  The scan marks the half and leaves it to the dense run; the dense run
+            // emits it in passes of kNlCap lines (the 4 newlines in front of a pass are the last 4 of the pass before).
+            // Both then put the half's LAST kNlCap lines into the list: what the carry below reads.
+            auto fill_list = [&](uint32_t base) {
+                unsigned long long mask = *reinterpret_cast<const unsigned long long *>(&s.bitmap[h][tid * 4]);
+                uint32_t cc = (uint32_t)__popcll(mask);
+                uint32_t inc = wave_incl_sum(cc);
+                uint32_t r = inc - cc + (wave > 0 ? s.wtot[0] : 0) + (wave > 1 ? s.wtot[1] : 0) + (wave > 2 ? s.wtot[2] : 0) - base;
+                const uint32_t e0 = kWin + tid * 64;  // (r mod 2^32: ranks below `base` compare as huge)
+                while (mask) {
+                    uint32_t b = (uint32_t)__ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    if (r < (uint32_t)kNlCap) s.nlist[4 + r] = (uint16_t)(e0 + b);
+                    r++;
+                }
+                if (tid == 0)  // virtual EOF lines (at most two) that fall into the pass
+                    for (uint32_t q = n_nl_h > base ? n_nl_h : base; q < n_lines && q < base + (uint32_t)kNlCap; q++)
+                        s.nlist[4 + q - base] = (uint16_t)c.lim_e;
+            };
+            if constexpr (!kDenseRun) {
+                if (tid == 0) {
+                    tile_qend[half_index] = kDenseBit;
+                    hdr->any_dense = 1u;
+                }
+            } else {
+#pragma unroll 1
+                for (uint32_t base = 0;;) {
+                    const uint32_t m = n_lines - base < (uint32_t)kNlCap ? n_lines - base : (uint32_t)kNlCap;
+                    c.P += base - c.pass_base;
+                    c.pass_base = base;
+                    c.n_lines = m;
+                    F::emit_half(s, a, hdr, c, halo_nl, dev_mode, lane, wave, tile_qend, half_index);
+                    base += m;
+                    if (base >= n_lines) break;
+                    uint16_t keep = 0;
+                    if (tid < 4) keep = s.nlist[m + tid];  // (m == kNlCap) the last 4 entries of this pass
+                    __syncthreads();                       // everyone is done reading the list
+                    if (tid < 4) {
+                        s.nlist[tid] = keep;
+                        s.prev32[tid] = h * kTile + (int32_t)keep - kWin;
+                    }
+                    fill_list(base);
+                    __syncthreads();
+                }
+            }
+            __syncthreads();
+            fill_list(n_lines - (uint32_t)kNlCap);
+            __syncthreads();
+            c.n_lines = (uint32_t)kNlCap;
         }
-        if (h + 1 < kHalves && tid < 4) {
-            // the 4 newlines before the next half, relative to it (entries 4+n-4 .. 4+n-1 of this list)
-            uint32_t e = s.nlist[n_lines + tid];
-            s.carry[tid] = (e != kNoneE && e >= (uint32_t)kTile) ? (uint16_t)(e - kTile) : (uint16_t)kNoneE;
+        if (tid < 4) {
+            // the 4 newlines before the next half (entries n .. n + 3 of this list, counted from nlist[0]) as CODES; the
+            // last half's are the last 4 of the super-tile: what k_*_far's look-back reads (tileL)
+            const uint32_t k = opaque(tid), idx = c.n_lines + k;
+            const int32_t code = idx >= 4 ? h * kTile + (int32_t)s.nlist[idx] - kWin : s.prev32[idx];
+            s.carry32[k] = code;
+#ifndef EXG_AB_NO_TILEL
+            if constexpr (!kDenseRun) {
+                // (no input behind this half in the super-tile)
+                if (h + 1 == kHalves || lim_s <= (h + 1) * kTile) reinterpret_cast<int32_t *>(tile_qend + fused_n_tiles(a.n_bytes))[(uint64_t)st * 4 + k] = code;
+            }
+#endif
         }
-        F::emit_half(s, a, hdr, c, halo_nl, dev_mode, lane, wave, tile_qend, (uint64_t)st * kHalves + h);
+        if constexpr (!kDenseRun) {
+            if (n_lines <= (uint32_t)kNlCap) F::emit_half(s, a, hdr, c, halo_nl, dev_mode, lane, wave, tile_qend, half_index);
+        }
         if (h + 1 < kHalves) __syncthreads();  // everyone is done reading this half
     }
+    } while (kDenseRun && (st += gridDim.x) < n_super);
+}
+
+template <class F>
+__global__ __launch_bounds__(kThreads, F::kMinWavesPerSimd) void k_fused(typename F::Dev a, unsigned int *__restrict__ tileA,
+                                                             unsigned long long *__restrict__ tileP,
+                                                             unsigned long long *__restrict__ tile_qend,
+                                                             ScanWsHeader *hdr, uint32_t n_super) {
+    fused_body<F, false>(a, tileA, tileP, tile_qend, hdr, n_super);
+}
+template <class F>
+__global__ __launch_bounds__(kThreads) void k_fused_dense(typename F::Dev a, unsigned int *__restrict__ tileA,
+                                                          unsigned long long *__restrict__ tileP,
+                                                          unsigned long long *__restrict__ tile_qend, ScanWsHeader *hdr, uint32_t n_super) {
+    fused_body<F, true>(a, tileA, tileP, tile_qend, hdr, n_super);
 }
 
 

@@ -9,8 +9,11 @@
 //
 // Two implementations behind exg_vcf_scan:
 //   * fused (exg_fused_core.hpp skeleton): thread = line, fields cut out of LDS;
-//   * general: line index (exg_lines.hip) + thread = line reading global memory — any line length
-//     (multi-sample VCF lines exceed the fused kernel's 1 KiB straddle window), non-ASCII bytes.
+//     a line that begins in front of the half's 1 KiB window (multi-sample VCF) is left to k_vcf_far behind the
+//     kernel — at most one per half, read from global memory (exg_fastq_ws.hpp FarRec) —, a half with more lines than
+//     its list holds is emitted in passes: the single pass over the input holds for any line length;
+//   * general: line index (exg_lines.hip) + thread = line reading global memory — the differential partner, and the
+//     path of inputs with non-ASCII bytes.
 // Header lines (leading '#') are found by the host and passed as `lead`: lines that end before
 // `lead` are not rows.
 #include "exg_fused_core.hpp"
@@ -220,12 +223,13 @@ struct VcfFormat {
                                                      const TileCtx &c, unsigned long long halo_nl, uint32_t dev_mode,
                                                      uint32_t lane, uint32_t wave,
                                                      unsigned long long *__restrict__ tile_qend, uint64_t tile_index) {
-        if (threadIdx.x == 0) {  // offset just past the last line that ends in this half (0: none)
+        if (threadIdx.x == 0 && (c.pass_base == 0 || c.n_lines)) {  // offset just past the last line that ends in this half (0: none)
             long long e = 0;
             if (c.n_lines) {
                 e = (long long)c.tile_off + (int)s.nlist[4 + c.n_lines - 1] - kWin + 1;
                 if ((unsigned long long)e > a.n_bytes) e = (long long)a.n_bytes;
             }
+            if (c.pass_base) e |= (long long)(tile_qend[tile_index] & kFarBit);  // (a later pass keeps the first pass's mark)
             tile_qend[tile_index] = (unsigned long long)e;
         }
         if (dev_mode >= 3) return;
@@ -248,12 +252,17 @@ struct VcfFormat {
             if (act) {
                 const uint32_t q0 = s.nlist[3 + j];  // newline before the line
                 if (q0 == kNoneE) {
-                    if (c.first_of_buffer) {
-                        atomicAdd(&hdr->n_unresolved, 1ull);
-                        atomicOr(&hdr->flags, EXG_RF_HEAD_UNRESOLVED);
-                    } else {
-                        atomicOr(&hdr->overflow, 1u);  // line longer than the window: general path
-                    }
+                    // the line begins in front of the LDS window (only the first line of a half's first pass can: thread 0):
+                    // its row is k_vcf_far's
+                    FarRec f;
+                    f.pos[0] = s.prev32[3];
+                    f.pos[1] = c.half * kTile + e1 - kWin;
+                    f.pos[2] = f.pos[3] = f.pos[4] = 0;
+                    f.flags = c.is_eof_tile ? 1u : 0u;
+                    f.out = out;
+                    reinterpret_cast<FarRec *>(tile_qend + 3 * fused_n_tiles(a.n_bytes))[tile_index] = f;
+                    hdr->any_far = 1u;
+                    tile_qend[tile_index] |= kFarBit;  // (this thread stored the word above)
                 } else {
                     int s0 = (int)q0 + 1;
                     if (e1 > s0 && !(c.is_eof_tile && e1 == c.lim_e) && ldb(s, e1 - 1) == '\r') e1--;
@@ -350,6 +359,44 @@ __global__ __launch_bounds__(256) void k_vcf_lines(VcfDev a, const uint64_t *__r
     }
 }
 
+// The rows k_fused<VcfFormat> left out: one line per marked half (it begins in front of the half's window), read from global
+// memory like the general path reads its lines.  Runs behind k_fused on the stream.
+__global__ __launch_bounds__(256) void k_vcf_far(VcfDev a, const unsigned int *__restrict__ tileA, const int32_t *__restrict__ tileL,
+                                                 const unsigned long long *__restrict__ tile_qend, const FarRec *__restrict__ far_rec,
+                                                 ScanWsHeader *hdr, uint32_t n_halves) {
+    if (!hdr->any_far) return;
+    constexpr uint32_t kHalves = VcfFormat::kHalves;
+    constexpr uint64_t kSuper = (uint64_t)kHalves * kTile;
+    const bool no_store = (a.flags & EXG_F_NO_STORE) != 0;
+    for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n_halves; x += (uint64_t)gridDim.x * blockDim.x) {
+        if (!(tile_qend[x] & kFarBit)) continue;
+        const FarRec f = far_rec[x];
+        int64_t p[2];
+        const unsigned long long out = (unsigned long long)f.out;
+        if (!far_positions<2>(f, (uint32_t)(x / kHalves), kSuper, tileA, tileL, (a.flags & EXG_F_BOF) != 0, p)) {
+            atomicAdd(&hdr->n_unresolved, 1ull);  // the line begins in front of d_input[0]: the caller widens the halo
+            atomicOr(&hdr->flags, EXG_RF_HEAD_UNRESOLVED);
+            continue;
+        }
+        uint64_t s0 = (uint64_t)(p[0] + 1), e1 = (uint64_t)p[1];
+        if (e1 - s0 > 0x7FFFFFF0ull) {
+            vcf_report(hdr, EXG_PE_FIELD_TOO_LONG, out, s0);
+            continue;
+        }
+        if (s0 > e1) s0 = e1;
+        const bool virt = e1 >= a.n_bytes;
+        if (!virt && e1 > s0 && a.d_in[e1 - 1] == '\r') e1--;
+        const GlobalSrc src{a.d_in, s0, a.payload_base, (a.n_bytes + 15) & ~15ull};
+        const VcfRowInfo r = vcf_line(src, 0, (int)(e1 - s0), a, out, !no_store);
+        if (r.code) vcf_report(hdr, r.code, out, s0);
+        else if (r.slow_len) vcf_slow_qual(hdr, a, s0 + (uint64_t)r.slow_s, (uint32_t)r.slow_len, out, s0);
+        if (!no_store) {
+            if (r.qual_valid && a.d_qual_valid) atomicOr((unsigned long long *)&a.d_qual_valid[out >> 6], 1ull << (out & 63));
+            if (r.rest_valid && a.d_formats_valid) atomicOr((unsigned long long *)&a.d_formats_valid[out >> 6], 1ull << (out & 63));
+        }
+    }
+}
+
 // Result block.  fused != 0: positions come from tile_qend; else from nl_pos.
 __global__ __launch_bounds__(256) void k_vcf_finalize(VcfDev a, ScanWsHeader *hdr,
                                                       const unsigned long long *__restrict__ tile_qend, uint32_t n_tiles,
@@ -383,7 +430,7 @@ __global__ __launch_bounds__(256) void k_vcf_finalize(VcfDev a, ScanWsHeader *hd
     if (fused && !hdr->overflow) {
         for (int64_t base = (int64_t)n_tiles - 1; base >= 0; base -= 256) {
             int64_t t = base - threadIdx.x;
-            unsigned long long q = t >= 0 ? tile_qend[t] : 0;
+            unsigned long long q = t >= 0 ? tile_qend[t] & ~(kFarBit | kDenseBit) : 0;
             if (q) atomicMax(&s_qend, q);
             if (q) s_found = 1;
             __syncthreads();
@@ -479,14 +526,23 @@ static int run_vcf_fused(const VcfDev &dev, uint8_t *ws, const FastqWsLayout &l,
     unsigned int *tileA = reinterpret_cast<unsigned int *>(ws + l.off_tile_desc);
     unsigned long long *tileP = reinterpret_cast<unsigned long long *>(ws + l.off_tile_desc) + l.n_tiles_fused;
     unsigned long long *tile_qend = tileP + l.n_tiles_fused;
+    int32_t *tileL = reinterpret_cast<int32_t *>(ws + l.off_tile_last4);
+    FarRec *far_rec = reinterpret_cast<FarRec *>(ws + l.off_far);
     hipLaunchKernelGGL(k_init_hdr, dim3(1), dim3(1), 0, stream, hdr, l.lines_cap, 0u);
     EXG_HIP_CHECK(hipMemsetAsync(tileA, 0, (size_t)l.n_tiles_fused * 16, stream));
     if (dev.lead) {
         int rc = exg_count_newlines(dev.d_in, 0, dev.lead, (uint64_t *)&hdr->halo_nl, stream);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_fused<VcfFormat>, dim3(n_super + 1), dim3(kThreads), 0, stream, dev, tileA, tileP, tile_qend, hdr,
-                       n_super);
+    hipLaunchKernelGGL(k_fused<VcfFormat>, dim3(n_super + 1), dim3(kThreads), 0, stream, dev, tileA, tileP, tile_qend, hdr, n_super);
+    // halves with more lines than the LDS list holds, in passes (returns at once when the scan marked none)
+    hipLaunchKernelGGL(k_fused_dense<VcfFormat>, dim3(n_super < 1536 ? n_super : 1536), dim3(kThreads), 0, stream, dev, tileA, tileP,
+                       tile_qend, hdr, n_super);
+    {   // the rows of lines that begin in front of their half's window (returns at once when there is none)
+        const uint32_t n_halves = n_super * kHalvesHost;
+        const uint32_t grid = (n_halves + 255) / 256 < 4096 ? (n_halves + 255) / 256 : 4096;
+        hipLaunchKernelGGL(k_vcf_far, dim3(grid), dim3(256), 0, stream, dev, tileA, tileL, tile_qend, far_rec, hdr, n_halves);
+    }
     hipLaunchKernelGGL(k_vcf_finalize, dim3(1), dim3(256), 0, stream, dev, hdr, tile_qend, n_super * kHalvesHost,
                        (const uint64_t *)nullptr, 1, d_result, (const unsigned int *)nullptr);
     EXG_HIP_CHECK(hipGetLastError());

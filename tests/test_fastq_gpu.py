@@ -180,10 +180,11 @@ def test_edge_cases(gpu, oracle, case, algo):
     check_against_oracle(oracle, EDGE_CASES[case], algo)
 
 
-# ---- records larger than the fused kernel's LDS window: general path ------------------------------------
+# ---- records larger than the fused kernel's LDS window, halves with more lines than its list: still one pass ----------
+# (more shapes: tests/test_record_shapes_gpu.py)
 
 @pytest.mark.parametrize("algo", [abi.EXG_ALGO_MULTIPASS, abi.EXG_ALGO_AUTO, abi.EXG_ALGO_FUSED])
-def test_long_reads_fall_back(gpu, oracle, algo):
+def test_long_reads_stay_on_the_single_pass(gpu, oracle, algo):
     rng = np.random.default_rng(7)
     recs = []
     for k in range(40):
@@ -191,17 +192,16 @@ def test_long_reads_fall_back(gpu, oracle, algo):
         seq = rng.choice(np.frombuffer(b"ACGT", np.uint8), ln).tobytes()
         recs.append(b"@long%d desc\n" % k + seq + b"\n+\n" + b"I" * ln + b"\n")
     data = b"".join(recs)
-    res = check_against_oracle(oracle, data, algo, expect_fallback=True)
-    if algo != abi.EXG_ALGO_FUSED:
-        assert res.n_records == 40
+    res = check_against_oracle(oracle, data, algo)
+    assert res.n_records == 40 and not (res.flags & abi.EXG_RF_FALLBACK)
 
 
-@pytest.mark.parametrize("algo", [abi.EXG_ALGO_MULTIPASS, abi.EXG_ALGO_AUTO])
+@pytest.mark.parametrize("algo", [abi.EXG_ALGO_MULTIPASS, abi.EXG_ALGO_AUTO, abi.EXG_ALGO_FUSED])
 def test_many_tiny_lines_in_one_tile(gpu, oracle, algo):
-    # > 1024 newlines in a 16 KiB tile: the fused kernel's per-tile list overflows -> general path
+    # 10 900 newlines per 16 KiB half: the fused kernel's list holds 512, the half is emitted in 22 passes
     data = b"@a\n\n+\n\n" * 5000
-    res = check_against_oracle(oracle, data, algo, expect_fallback=True)
-    assert res.n_records == 5000
+    res = check_against_oracle(oracle, data, algo)
+    assert res.n_records == 5000 and not (res.flags & abi.EXG_RF_FALLBACK)
 
 
 # ---- byte-range shards with a halo (multi-GPU layout) and record-aligned batches ---------------------------

@@ -1,0 +1,255 @@
+"""Record shapes outside the synthetic 150 bp FASTQ / 49-byte VCF line, through the C-ABI against the oracle.
+
+The reference's line readers run at one rate whatever the record length (noodles, reached at
+rust/src/arrow_reader.rs:116-153).  The fused kernels stage 16 KiB halves with a 1 KiB window in LDS; these tests pin
+that nothing but the bytes' content decides the output — long reads (HiFi-like 15 kb, ONT-like 1-100 kb, a 3 MB read that
+spans dozens of super-tiles), short reads (36 bp and shorter: more lines per half than the LDS list holds, emitted in
+passes), multi-sample VCF lines (100 and 2 504 samples) — and that NO launch gives up (`EXG_RF_FALLBACK` clear) with the
+fused kernel alone.  Bit-exact: every column vector, validity word and the result block.
+"""
+import numpy as np
+import pytest
+
+from exon_duckdb_amd import abi
+
+from test_fastq_gpu import BASE as FQ_BASE, NAMES, check_against_oracle, run_gpu as run_fastq
+from test_vcf_gpu import HDR, check as check_vcf, header_bytes
+
+pytestmark = pytest.mark.gpu
+
+FUSED_AND_PARTNER = [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS]
+
+
+def fastq_records(lengths, seed=1, crlf_every=0, desc_every=2, name_len=None):
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    out = []
+    for k, ln in enumerate(lengths):
+        ln = int(ln)
+        eol = b"\r\n" if crlf_every and k % crlf_every == 0 else b"\n"
+        name = b"@r%d" % k if name_len is None else b"@" + (b"%d" % k).rjust(name_len, b"n")
+        if desc_every and k % desc_every == 0:
+            name += b" len=%d ch=%d" % (ln, k % 512)
+        seq = rng.choice(acgt, ln).tobytes()
+        qual = (rng.integers(33, 74, ln, dtype=np.uint8)).tobytes()   # includes '@' and '+'
+        out.append(name + eol + seq + eol + b"+" + eol + qual + eol)
+    return b"".join(out)
+
+
+def no_fallback(res):
+    assert not (res.flags & abi.EXG_RF_FALLBACK), "the fused kernel gave the launch up"
+
+
+# ---- long reads ---------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("algo", FUSED_AND_PARTNER)
+@pytest.mark.parametrize("shape", ["hifi", "ont", "at_window", "mixed_short_long"])
+def test_long_reads(gpu, oracle, shape, algo):
+    rng = np.random.default_rng(11)
+    if shape == "hifi":          # ~15 kb +- 3 kb
+        lengths = np.clip(rng.normal(15000, 3000, 60), 2000, 40000)
+    elif shape == "ont":         # log-uniform 1 kb .. 100 kb
+        lengths = np.exp(rng.uniform(np.log(1000), np.log(100000), 48))
+    elif shape == "at_window":   # record sizes around the 1 KiB window and the 16 KiB half
+        lengths = [470, 480, 490, 500, 505, 510, 515, 520, 1000, 1020, 1030, 8180, 8190, 8200, 16380, 16390, 24570, 24580] * 3
+    else:                        # one long read among short ones costs nothing but itself
+        lengths = [150] * 300 + [20000] + [150] * 300 + [70000, 36, 36, 150000] + [150] * 200
+    data = fastq_records(lengths, seed=5, crlf_every=7)
+    res = check_against_oracle(oracle, data, algo)
+    assert res.n_records == len(lengths)
+    no_fallback(res)
+
+
+@pytest.mark.parametrize("algo", FUSED_AND_PARTNER)
+def test_a_read_that_spans_dozens_of_super_tiles(gpu, oracle, algo):
+    # 3 MB and 1.2 MB reads: the look-back walks over ~130 tiles without a newline
+    data = fastq_records([100, 3_000_000, 150, 1_200_000, 1, 0, 150], seed=9)
+    res = check_against_oracle(oracle, data, algo)
+    assert res.n_records == 7
+    no_fallback(res)
+
+
+@pytest.mark.parametrize("algo", FUSED_AND_PARTNER)
+@pytest.mark.parametrize("case", ["bad_at", "bad_plus", "empty_plus", "truncated_in_qual", "truncated_after_plus", "no_final_newline",
+                                  "cr_at_eof", "long_name_line", "first_error_wins"])
+def test_long_read_rules(gpu, oracle, case, algo):
+    good = fastq_records([30000, 200, 45000], seed=3)
+    seq = b"ACGT" * 9000
+    if case == "bad_at":
+        data = good + b"xlong\n" + seq + b"\n+\n" + b"I" * len(seq) + b"\n" + good
+    elif case == "bad_plus":
+        data = good + b"@long\n" + seq + b"\n-\n" + b"I" * len(seq) + b"\n" + good
+    elif case == "empty_plus":
+        data = good + b"@long\n" + seq + b"\n\n" + b"I" * len(seq) + b"\n"
+    elif case == "truncated_in_qual":
+        data = good + b"@long\n" + seq + b"\n+\n" + b"I" * 20000       # quality line unterminated at EOF: still a record
+    elif case == "truncated_after_plus":
+        data = good + b"@long\n" + seq + b"\n+\n"                      # missing quality line => empty
+    elif case == "no_final_newline":
+        data = good[:-1]
+    elif case == "cr_at_eof":
+        data = good[:-1] + b"\r"
+    elif case == "long_name_line":                                      # a 40 kB name line with its first space far in
+        data = good + b"@" + b"n" * 25000 + b" " + b"d" * 15000 + b"\n" + seq + b"\n+\n" + b"I" * len(seq) + b"\n" + good
+    else:
+        data = good + b"@a\n" + seq + b"\n-\n" + b"I" * len(seq) + b"\nzz\n" + seq + b"\n+\n" + b"I" * len(seq) + b"\n"
+    res = check_against_oracle(oracle, data, algo)
+    no_fallback(res)
+
+
+@pytest.mark.parametrize("algo", FUSED_AND_PARTNER)
+def test_long_reads_in_unaligned_shards(gpu, oracle, algo):
+    """byte-range shards with a halo over long reads: rows of the shards = rows of the file; a shard whose halo does not reach
+    the beginning of its first record says EXG_RF_HEAD_UNRESOLVED (the reader then widens the halo)"""
+    lengths = [12000, 150, 33000, 150, 150, 9000, 70000, 150, 20000, 5000, 150, 41000]
+    data = bytes(fastq_records(lengths, seed=21))
+    exp = oracle.fastq_parse(data, payload_base=FQ_BASE)
+    arr = np.frombuffer(data, np.uint8)
+    nl = np.flatnonzero(arr == 10)
+    n = len(data)
+    cuts = [0] + [16 * (n * k // 5 // 16) for k in range(1, 5)] + [n]
+    halo = 160 * 1024
+    got_cols = [[] for _ in range(4)]
+    total = 0
+    for s, e in zip(cuts[:-1], cuts[1:]):
+        h = min(halo, s)
+        h -= h % 16
+        fli = int(np.searchsorted(nl, s))             # '\n' in front of the shard's first byte (buffer offset `lead`)
+        flags = (abi.EXG_F_BOF if s - h == 0 else 0) | (abi.EXG_F_EOF if e == n else 0)
+        res, cols, words = run_fastq(data[s - h:e], algo, lead=h, first_line_index=fli, flags=flags, payload_base=FQ_BASE + s - h)
+        assert res.error_code == 0 and not (res.flags & (abi.EXG_RF_HEAD_UNRESOLVED | abi.EXG_RF_FALLBACK)), (s, e, res.flags)
+        k = int(res.n_records)
+        for c in range(4):
+            got_cols[c].append(cols[c])
+        total += k
+    assert total == exp.n_rows == len(lengths)
+    for c, name in enumerate(NAMES):
+        assert np.array_equal(np.concatenate(got_cols[c]), exp.string_t[name][0]), name
+    # a 4 KiB halo cannot hold the head of the 70 kb read when the cut falls into its quality line: said, not guessed
+    s = (int(exp.columns["quality_scores"].src_off[6]) + 30000) // 16 * 16
+    res, _, _ = run_fastq(data[s - 4096:], algo, lead=4096, first_line_index=int(np.searchsorted(nl, s)), flags=abi.EXG_F_EOF,
+                          payload_base=FQ_BASE + s - 4096)
+    assert res.flags & abi.EXG_RF_HEAD_UNRESOLVED and int(res.n_records) == len(lengths) - 6
+
+
+@pytest.mark.parametrize("algo", FUSED_AND_PARTNER)
+def test_long_reads_record_aligned_batches(gpu, oracle, algo):
+    # streaming: not at EOF, the tail record is incomplete; consumed_bytes says where to resume
+    lengths = [20000, 150, 31000, 18000, 150, 52000]
+    data = bytes(fastq_records(lengths, seed=4))
+    exp = oracle.fastq_parse(data, payload_base=FQ_BASE)
+    cut = int(exp.columns["sequence"].src_off[3]) + 5000      # inside the 4th record
+    res, cols, _ = run_fastq(data[:cut], algo, flags=abi.EXG_F_BOF)
+    assert int(res.n_records) == 3 and res.error_code == 0
+    assert int(res.consumed_bytes) == int(exp.columns["name"].src_off[3]) - 1
+    assert np.array_equal(cols[2], exp.string_t["sequence"][0][:3])
+    no_fallback(res)
+
+
+@pytest.mark.parametrize("algo", FUSED_AND_PARTNER)
+def test_long_reads_capacity_and_count_only(gpu, oracle, algo):
+    lengths = [9000] * 40
+    data = fastq_records(lengths, seed=8)
+    res, cols, _ = run_fastq(data, algo, capacity=17)
+    assert res.flags & abi.EXG_RF_CAPACITY and res.n_records == 17
+    exp = oracle.fastq_parse(bytes(data), payload_base=FQ_BASE)
+    assert np.array_equal(cols[3], exp.string_t["quality_scores"][0][:17])
+    # COUNT(*): every record validated, nothing stored
+    bad = bytes(data) + b"@x\n" + b"A" * 5000 + b"\n*\n" + b"I" * 5000 + b"\n"
+    res, _, _ = run_fastq(bad, algo, flags=abi.EXG_F_BOF | abi.EXG_F_EOF | abi.EXG_F_NO_STORE)
+    assert res.error_code == abi.EXG_PE_FASTQ_PLUS_PREFIX and res.error_record == 40 and res.n_records == 40
+    no_fallback(res)
+
+
+# ---- short reads: more lines in a half than the LDS list holds ------------------------------------------------------
+
+@pytest.mark.parametrize("algo", FUSED_AND_PARTNER)
+@pytest.mark.parametrize("shape", ["36bp", "36bp_short_names", "1bp", "empty_fields", "mixed", "crlf"])
+def test_short_reads(gpu, oracle, shape, algo):
+    rng = np.random.default_rng(2)
+    if shape == "36bp":
+        data = fastq_records([36] * 3000, seed=6, name_len=24)
+    elif shape == "36bp_short_names":
+        data = fastq_records([36] * 5000, seed=6, desc_every=0)
+    elif shape == "1bp":
+        data = fastq_records([1] * 20000, seed=6, desc_every=0)
+    elif shape == "empty_fields":
+        data = b"@\n\n+\n\n" * 12000 + b"@a b\nAC\n+\n!!\n" * 3000 + b"@\n\n+\n\n" * 7000
+    elif shape == "mixed":   # runs of tiny records between ordinary and long ones: halves of 1, 2 and 20 passes
+        data = b"".join(fastq_records([int(x)] * int(c), seed=int(c)) for x, c in
+                        [(150, 200), (0, 4000), (20000, 2), (3, 3000), (150, 100), (0, 9000), (36, 800), (9000, 3)])
+    else:
+        data = fastq_records([20] * 4000, seed=6, crlf_every=3, desc_every=5)
+    res = check_against_oracle(oracle, data, algo)
+    no_fallback(res)
+
+
+@pytest.mark.parametrize("algo", FUSED_AND_PARTNER)
+def test_short_reads_errors_and_eof(gpu, oracle, algo):
+    body = b"@r\nA\n+\n!\n" * 9000
+    for tail in [b"@r\nA\n+\n", b"@r\nA\n+", b"@r\nA\n", b"@r", b"x\nA\n+\n!\n", b"@r\nA\n-\n!\n" + b"@r\nA\n+\n!\n" * 3000]:
+        res = check_against_oracle(oracle, body + tail, algo)
+        no_fallback(res)
+
+
+# ---- wide VCF lines ---------------------------------------------------------------------------------------------------
+
+def vcf_lines(n_lines, n_samples, seed=1, crlf_every=0):
+    rng = np.random.default_rng(seed)
+    gts = [b"0|0", b"0|1", b"1|0", b"1|1", b".|."]
+    smp = b"\t".join(b"S%05d" % i for i in range(n_samples))
+    hdr = HDR[:-1] + (b"\tFORMAT\t" + smp if n_samples else b"") + b"\n"
+    out = [hdr]
+    for k in range(n_lines):
+        eol = b"\r\n" if crlf_every and k % crlf_every == 0 else b"\n"
+        qual = b"." if k % 9 == 0 else b"%d.%d" % (k % 1000, k % 10)
+        info = b"AC=%d;AF=0.%04d;AN=%d;NS=%d;DP=%d;VT=SNP" % (k % 5008, k % 10000, 2 * n_samples, n_samples, 1000 + k)
+        line = b"%d\t%d\trs%d\t%s\t%s\t%s\tPASS\t%s" % (k % 22 + 1, 10000 + 37 * k, k, b"ACGT"[k % 4:k % 4 + 1],
+                                                           b"ACGT"[(k + 1) % 4:(k + 1) % 4 + 1], qual, info)
+        if n_samples:
+            idx = rng.integers(0, 5, n_samples)
+            line += b"\tGT\t" + b"\t".join(gts[i] for i in idx)
+        out.append(line + eol)
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("algo", FUSED_AND_PARTNER)
+@pytest.mark.parametrize("n_samples,n_lines", [(100, 600), (2504, 120), (300, 300), (40000, 6)])
+def test_multisample_vcf(gpu, oracle, n_samples, n_lines, algo):
+    data = vcf_lines(n_lines, n_samples, seed=n_samples, crlf_every=11)
+    res = check_vcf(oracle, data, algo)
+    assert res.n_records == n_lines
+    no_fallback(res)
+
+
+@pytest.mark.parametrize("algo", FUSED_AND_PARTNER)
+@pytest.mark.parametrize("case", ["bad_pos", "bad_qual", "missing_field", "no_final_newline", "tabs_far_in", "first_error_wins"])
+def test_wide_vcf_line_rules(gpu, oracle, case, algo):
+    good = vcf_lines(30, 2504, seed=3)
+    wide = b"\tGT" + b"\t0|1" * 3000
+    if case == "bad_pos":
+        data = good + b"1\tx5\t.\tA\tC\t1.5\tPASS\tDP=1" + wide + b"\n"
+    elif case == "bad_qual":
+        data = good + b"1\t5\t.\tA\tC\t-1\tPASS\tDP=1" + wide + b"\n" + b"1\t6\t.\tA\tC\t2\tPASS\tDP=1" + wide + b"\n"
+    elif case == "missing_field":
+        data = good + b"1\t5\t.\tA\tC\t" + b"9" * 5000 + b"\n"
+    elif case == "no_final_newline":
+        data = good[:-1]
+    elif case == "tabs_far_in":     # the eighth tab lies 30 kB into the line (a huge INFO)
+        data = good + b"1\t5\t.\tA\tC\t3\tPASS\t" + b";".join(b"K%d=%d" % (i, i) for i in range(3000)) + wide + b"\n" + good[header_bytes(good):]
+    else:
+        data = good + b"1\t5\t.\tA\tC\tzz\tPASS\tDP=1" + wide + b"\n" + b"1\t\t.\tA\tC\t1\tPASS\tDP=1" + wide + b"\n"
+    res = check_vcf(oracle, data, algo)
+    no_fallback(res)
+
+
+@pytest.mark.parametrize("algo", FUSED_AND_PARTNER)
+def test_tiny_vcf_lines(gpu, oracle, algo):
+    # 15-byte lines: 1 092 per half, more than the list's 1 024: two passes
+    data = HDR + b"".join(b"%d\t%d\t.\tA\tC\t.\t.\t.\n" % (k % 9 + 1, k % 10) for k in range(9000))
+    res = check_vcf(oracle, data, algo)
+    assert res.n_records == 9000
+    no_fallback(res)
+    # blank lines are lines (an error at the first): 16 384 per half
+    res = check_vcf(oracle, HDR + b"1\t5\t.\tA\tC\t.\t.\t.\n" * 3 + b"\n" * 40000, algo)
+    no_fallback(res)
