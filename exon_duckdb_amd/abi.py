@@ -29,7 +29,8 @@ EXG_FMT_FASTA, EXG_FMT_FASTQ, EXG_FMT_VCF = 1, 2, 3
 EXG_F_BOF, EXG_F_EOF, EXG_F_NO_STORE = 1, 2, 4
 EXG_RF_NON_ASCII, EXG_RF_HEAD_UNRESOLVED, EXG_RF_FALLBACK, EXG_RF_CAPACITY, EXG_RF_INDEX_OVERFLOW = 1, 2, 4, 8, 16
 EXG_RF_QUAL_RANGE = 32
-EXG_ALGO_AUTO, EXG_ALGO_MULTIPASS, EXG_ALGO_FUSED = 0, 1, 2
+EXG_RF_REDO = 64
+EXG_ALGO_AUTO, EXG_ALGO_MULTIPASS, EXG_ALGO_FUSED, EXG_ALGO_FUSED_FULL = 0, 1, 2, 3
 
 EXG_SYNTH_FASTQ_SEED = 0xE0A5EED0001
 EXG_SYNTH_VCF_SEED = 0xE0A5EED0002
@@ -170,7 +171,7 @@ SIGNATURES = {
 class ReaderStats(C.Structure):
     _fields_ = [("device_bytes_now", C.c_uint64), ("device_bytes_peak", C.c_uint64), ("device_mem_cap", C.c_uint64),
                 ("device_batch_bytes", C.c_uint64), ("device_batches", C.c_uint64), ("decoded_segments", C.c_uint64),
-                ("reserved", C.c_uint64 * 4)]
+                ("scan_algo", C.c_uint64), ("reserved", C.c_uint64 * 3)]
 
 # libexon_tf_test.so (csrc/testing/): test / bench scaffolding — synthetic inputs generated in HBM, consumers that drain a
 # reader's chunks (counting, or folding every row into a digest), host-only introspection, the host-pipeline probe

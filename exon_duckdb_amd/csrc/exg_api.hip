@@ -115,9 +115,11 @@ extern "C" int exg_fastq_scan(const exg_fastq_scan_args *a) {
         case EXG_ALGO_MULTIPASS:
             return run_fastq_multipass(a, dev, ws, l, stream, false);
         case EXG_ALGO_FUSED:
-            return run_fastq_fused(a, dev, ws, l, stream);
+            return run_fastq_fused(a, dev, ws, l, stream, false);
+        case EXG_ALGO_FUSED_FULL:
+            return run_fastq_fused(a, dev, ws, l, stream, true);
         case EXG_ALGO_AUTO: {
-            int rc = run_fastq_fused(a, dev, ws, l, stream);
+            int rc = run_fastq_fused(a, dev, ws, l, stream, false);
             if (rc) return rc;
             // general kernels, gated on the device by the fused kernel's overflow word
             return run_fastq_multipass(a, dev, ws, l, stream, true);

@@ -63,9 +63,10 @@ __device__ __forceinline__ FastqGeom fastq_geometry_at(const uint8_t *__restrict
 int run_fastq_multipass(const exg_fastq_scan_args *args, const FastqDev &dev, uint8_t *ws, const FastqWsLayout &l,
                         hipStream_t stream, bool after_fused);
 
-// Fast path: single pass, decoupled look-back, LDS-staged tiles.
+// Fast path: single pass.  full = false: the lean scan, then the any-shape scan over the super-tiles it marked; true: the
+// any-shape scan alone.
 int run_fastq_fused(const exg_fastq_scan_args *args, const FastqDev &dev, uint8_t *ws, const FastqWsLayout &l,
-                    hipStream_t stream);
+                    hipStream_t stream, bool full);
 
 __global__ void k_init_hdr(ScanWsHeader *hdr, uint64_t lines_cap, uint32_t mode);
 

@@ -48,10 +48,11 @@
 namespace exg {
 
 struct FastqFormat;
+static constexpr int kFastqHalves = 3;  // 48 KiB per workgroup: A/B on one box 2 -> 3 halves +3 %, 4 halves -7 %
 
 
 // Records that END in the half staged in LDS: wave = column, lane = record.
-template <class L>
+template <int kMode, class L>
 __device__ __forceinline__ void fastq_emit_half(const L &s, const FastqDev &a, ScanWsHeader *hdr, const TileCtx &c,
                                           unsigned long long halo_nl, uint32_t dev_mode, uint32_t lane,
                                           uint32_t wave, unsigned long long *__restrict__ tile_qend,
@@ -71,12 +72,10 @@ __device__ __forceinline__ void fastq_emit_half(const L &s, const FastqDev &a, S
             if ((unsigned long long)e > a.n_bytes) e = (long long)a.n_bytes;
         }
         if (c.pass_base) e |= (long long)(tile_qend[tile_index] & kFarBit);  // (a later pass keeps the first pass's mark)
-#ifndef EXG_AB_NO_FAR
-        // The first record that ends here begins in front of the LDS window (a long read; only a half's first record in its
-        // first pass can): its row is k_fastq_far's.  What is known here of its five newlines — inside the half, or as codes
-        // (prev32) — goes into the half's FarRec; the loop below stores zeros in the row.  Decided here, once and by one
-        // thread, rather than inside the loop: the loop's registers are the kernel's tightest.
-        if (n_rec && s.nlist[i_first] == kNoneE) {
+        // (any-shape scan) The first record that ends here begins in front of the LDS window — a long read; only a half's first
+        // record in its first pass can —: its row is k_fastq_far's.  What is known here of its five newlines — inside the
+        // half, or as codes (prev32) — goes into the half's FarRec; the loop below stores zeros in the row.
+        if constexpr (kMode != kLean) if (n_rec && s.nlist[i_first] == kNoneE) {
             const long long out0 = (long long)q_before - (long long)n_hc;
             const int e4 = s.nlist[4 + i_first];
             if ((uint64_t)((int64_t)c.tile_off + e4 - kWin) >= a.lead && out0 >= 0 &&
@@ -89,12 +88,11 @@ __device__ __forceinline__ void fastq_emit_half(const L &s, const FastqDev &a, S
                 }
                 f.flags = c.is_eof_tile ? 1u : 0u;
                 f.out = out0;
-                reinterpret_cast<FarRec *>(tile_qend + 3 * fused_n_tiles(a.n_bytes))[tile_index] = f;
+                far_rec_of(tile_qend, a.n_bytes)[tile_index] = f;
                 hdr->any_far = 1u;
                 e |= (long long)kFarBit;
             }
         }
-#endif
         tile_qend[tile_index] = (unsigned long long)e;
     }
     if (dev_mode >= 3) return;
@@ -119,10 +117,14 @@ __device__ __forceinline__ void fastq_emit_half(const L &s, const FastqDev &a, S
             const uint32_t q0 = s.nlist[i];  // newline before the name line
             uint4 val = make_uint4(0, 0, 0, 0);
             if (q0 == kNoneE) {
-                // the record begins in front of the LDS window: k_fastq_far's row (the FarRec above); zeros are stored here
-#ifdef EXG_AB_NO_FAR
-                if (wave == 0) atomicOr(&hdr->overflow, 1u);
-#endif
+                // the record begins in front of the LDS window (val stays zero).  Lean scan: the any-shape run redoes this
+                // super-tile; any-shape scan: k_fastq_far's row (the FarRec above)
+                if constexpr (kMode == kLean) {
+                    if (wave == 0) {
+                        tile_redo_of(tile_qend, a.n_bytes)[tile_index / kFastqHalves] = kRedoFar;
+                        hdr->any_redo = 1u;
+                    }
+                }
             } else if (wave <= 1) {
                 // name line [s0, e0): '@' check, CR strip, split at the first ' '
                 int s0 = (int)q0 + 1, e0 = s.nlist[i + 1];
@@ -209,18 +211,19 @@ struct FastqFormat {
 #endif
     static constexpr int kNlCap = EXG_FASTQ_NLCAP;  // 197 lines per half for 150 bp reads
     static constexpr bool kTabMap = false;
-    static constexpr int kHalves = 3;   // 48 KiB per workgroup: A/B on one box 2 -> 3 halves +3 %, 4 halves -7 %
+    static constexpr int kHalves = kFastqHalves;
     static constexpr int kMinWavesPerSimd = 6;  // 80 VGPRs, no scratch: 6 x 48 KiB in flight per CU
+    static constexpr int kMinWavesPerSimdFull = 5;  // the any-shape instances: 96 VGPRs (their pass loop and FarRec code spill at 80)
     // noodles-fastq at EOF: a record that has its '+' line but no quality line gets an empty one
     __device__ static __forceinline__ uint32_t eof_extra_lines(unsigned long long total_lines) {
         return (total_lines & 3) == 3 ? 1u : 0u;
     }
-    template <class L>
+    template <int kMode, class L>
     __device__ static __forceinline__ void emit_half(const L &s, const FastqDev &a, ScanWsHeader *hdr,
                                                      const TileCtx &c, unsigned long long halo_nl, uint32_t dev_mode,
                                                      uint32_t lane, uint32_t wave,
                                                      unsigned long long *__restrict__ tile_qend, uint64_t tile_index) {
-        fastq_emit_half(s, a, hdr, c, halo_nl, dev_mode, lane, wave, tile_qend, tile_index);
+        fastq_emit_half<kMode>(s, a, hdr, c, halo_nl, dev_mode, lane, wave, tile_qend, tile_index);
     }
     __device__ static __forceinline__ unsigned long long analytic_prefix(uint64_t off) {  // FASTQ-150 synthetic
         uint64_t k = off / 332, w = off % 332;
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(256) void k_fastq_finalize_fused(FastqDev a, ScanWs
     if (!hdr->overflow) {
         for (int64_t base = (int64_t)n_tiles - 1; base >= 0; base -= 256) {
             int64_t t = base - threadIdx.x;
-            unsigned long long q = t >= 0 ? tile_qend[t] & ~(kFarBit | kDenseBit) : 0;
+            unsigned long long q = t >= 0 ? tile_qend[t] & ~kFarBit : 0;
             if (q) atomicMax(&s_qend, q);
             if (q) s_found = 1;
             __syncthreads();
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(256) void k_fastq_finalize_fused(FastqDev a, ScanWs
     }
     exg_scan_result r;
     r.n_lines = T - halo_nl;
-    r.flags = hdr->flags;
+    r.flags = hdr->flags | (hdr->any_redo ? EXG_RF_REDO : 0u);
     r.payload_bytes = 0;
     r.reserved = 0;
     r.error_code = 0;
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(256) void k_fastq_finalize_fused(FastqDev a, ScanWs
 }
 
 int run_fastq_fused(const exg_fastq_scan_args *args, const FastqDev &dev, uint8_t *ws, const FastqWsLayout &l,
-                    hipStream_t stream) {
+                    hipStream_t stream, bool full) {
     ScanWsHeader *hdr = reinterpret_cast<ScanWsHeader *>(ws);
     constexpr uint64_t kSuperBytes = (uint64_t)FastqFormat::kHalves * kTile;
     constexpr uint32_t kHalvesHost = FastqFormat::kHalves;
@@ -367,30 +370,33 @@ int run_fastq_fused(const exg_fastq_scan_args *args, const FastqDev &dev, uint8_
         return EXG_E_INVALID_ARG;
     }
     uint32_t n_super = (uint32_t)n_super64;
-    // descriptor block: tileA[n_tiles_fused], tileP[n_tiles_fused], tile_qend[n_tiles_fused]
-    // descriptor block: u32 tileA[n] (padded to n u64), u64 tileP[n], u64 tile_qend[n]
+    // descriptor block (exg_fastq_ws.hpp): u64 tileA[n] (u32 counts), u64 tileP[n], u64 tile_redo[n] (u32 marks), u64 tile_qend[n],
+    // int32 tileL[n][4], FarRec[n]
+    const uint64_t n = l.n_tiles_fused;
     unsigned int *tileA = reinterpret_cast<unsigned int *>(ws + l.off_tile_desc);
-    unsigned long long *tileP = reinterpret_cast<unsigned long long *>(ws + l.off_tile_desc) + l.n_tiles_fused;
-    unsigned long long *tile_qend = tileP + l.n_tiles_fused;
+    unsigned long long *tileP = reinterpret_cast<unsigned long long *>(ws + l.off_tile_desc) + n;
+    unsigned long long *tile_qend = tileP + 2 * n;
     int32_t *tileL = reinterpret_cast<int32_t *>(ws + l.off_tile_last4);
     FarRec *far_rec = reinterpret_cast<FarRec *>(ws + l.off_far);
     hipLaunchKernelGGL(k_init_hdr, dim3(1), dim3(1), 0, stream, hdr, l.lines_cap, 0u);
-    EXG_HIP_CHECK(hipMemsetAsync(tileA, 0, (size_t)l.n_tiles_fused * 16, stream));
+    EXG_HIP_CHECK(hipMemsetAsync(tileA, 0, (size_t)n * 24, stream));
     if (dev.lead) {
         int rc = exg_count_newlines(dev.d_in, 0, dev.lead, (uint64_t *)&hdr->halo_nl, stream);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_fused<FastqFormat>, dim3(n_super + 1), dim3(kThreads), 0, stream, dev, tileA, tileP, tile_qend, hdr, n_super);
-#ifndef EXG_AB_NO_EXTRA_LAUNCH
-    // halves with more lines than the LDS list holds, in passes (returns at once when the scan marked none)
-    hipLaunchKernelGGL(k_fused_dense<FastqFormat>, dim3(n_super < 1536 ? n_super : 1536), dim3(kThreads), 0, stream, dev, tileA, tileP,
-                       tile_qend, hdr, n_super);
+    if (full) {
+        hipLaunchKernelGGL((k_fused<FastqFormat, kFullPrimary>), dim3(n_super + 1), dim3(kThreads), 0, stream, dev, tileA, tileP, tile_qend, hdr, n_super);
+    } else {
+        hipLaunchKernelGGL((k_fused<FastqFormat, kLean>), dim3(n_super + 1), dim3(kThreads), 0, stream, dev, tileA, tileP, tile_qend, hdr, n_super);
+        // the super-tiles the lean scan marked, any shape (returns at once when it marked none)
+        hipLaunchKernelGGL((k_fused<FastqFormat, kFullRedo>), dim3(n_super < 1280 ? n_super : 1280), dim3(kThreads), 0, stream, dev, tileA, tileP,
+                           tile_qend, hdr, n_super);
+    }
     {   // the rows of records that begin in front of their half's window (returns at once when there is none)
         const uint32_t n_halves = n_super * kHalvesHost;
         const uint32_t grid = (n_halves + 255) / 256 < 4096 ? (n_halves + 255) / 256 : 4096;
         hipLaunchKernelGGL(k_fastq_far, dim3(grid), dim3(256), 0, stream, dev, tileA, tileL, tile_qend, far_rec, hdr, n_halves);
     }
-#endif
     hipLaunchKernelGGL(k_fastq_finalize_fused, dim3(1), dim3(256), 0, stream, dev, hdr, tile_qend, n_super * kHalvesHost,
                        args->d_result);
     EXG_HIP_CHECK(hipGetLastError());

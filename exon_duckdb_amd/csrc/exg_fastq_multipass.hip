@@ -194,7 +194,7 @@ __global__ void k_init_hdr(ScanWsHeader *hdr, uint64_t lines_cap, uint32_t mode)
     if (mode == 1 && overflow == 0) return;
     ScanWsHeader h;
     h.n_slow = h.slow_pad = 0;
-    h.any_far = h.any_dense = 0;
+    h.any_far = h.any_redo = 0;
     for (unsigned int i = 0; i < 19; i++) h.reserved[i] = 0;
     h.last_qend = 0;
     h.total_nl = h.total_lines = h.halo_nl = h.n_unresolved = 0;

@@ -32,7 +32,7 @@ struct alignas(256) ScanWsHeader {
     // workspace (FastqWsLayout::off_slow) and decided exactly by the finalize kernel (exg_float_slow.hpp).
     unsigned int n_slow, slow_pad;
     unsigned int any_far;            // fused kernels: some half left a record to k_*_far (plain store of 1)
-    unsigned int any_dense;          // ... some half holds more lines than the LDS list: the dense run of the kernel emits it
+    unsigned int any_redo;           // lean scan: some super-tile is marked (tile_redo) for the any-shape run behind it
     unsigned long long reserved[19];
 };
 struct SlowLiteral {
@@ -55,17 +55,17 @@ struct FarRec {
 };
 static_assert(sizeof(FarRec) == 32, "FarRec is 32 bytes");
 static constexpr unsigned long long kFarBit = 1ull << 63;    // in tile_qend[half]: far_rec[half] is to be emitted
-static constexpr unsigned long long kDenseBit = 1ull << 62;  // in tile_qend[half]: the half is left to the dense run
 
 struct FastqWsLayout {
     uint64_t n_tiles_mp;
     uint64_t n_tiles_fused;
     uint64_t off_tile_counts;   // u32[n_tiles_mp]
     uint64_t off_tile_offsets;  // u64[n_tiles_mp]
-    // one block of 72 n_tiles_fused bytes: u64 tileA[n] (u32 counts) | u64 tileP[n] | u64 tile_qend[n] | int32 tileL[n][4]: the
-    // last four newlines of every super-tile (codes like FarRec::pos) | FarRec[n].  n is a multiple of 4 and a function of
-    // n_bytes alone (fused_n_tiles), so that the kernels find tileL and FarRec[] from tile_qend without another argument or
-    // load (two more kernel arguments cost the FASTQ scan scalar registers it does not have: spills)
+    // one block of 80 n_tiles_fused bytes: u64 tileA[n] (u32 counts) | u64 tileP[n] | u64 tile_redo[n] (u32 marks; these three
+    // are zeroed per launch) | u64 tile_qend[n] | int32 tileL[n][4]: the last four newlines of every super-tile (codes like
+    // FarRec::pos) | FarRec[n].  n is a multiple of 4 and a function of n_bytes alone (fused_n_tiles), so that the kernels
+    // find tile_redo, tileL and FarRec[] from tile_qend without another argument or load (two more kernel arguments cost the
+    // FASTQ scan scalar registers it does not have: spills)
     uint64_t off_tile_desc;
     uint64_t off_tile_last4;
     uint64_t off_far;
@@ -98,9 +98,9 @@ static inline FastqWsLayout fastq_ws_layout(uint64_t n_bytes, uint64_t ws_bytes_
     l.off_tile_offsets = at;
     at = round_up(at + l.n_tiles_mp * 8, 256);
     l.off_tile_desc = at;
-    l.off_tile_last4 = at + l.n_tiles_fused * 24;
-    l.off_far = at + l.n_tiles_fused * 40;
-    at = round_up(at + l.n_tiles_fused * 72, 256);
+    l.off_tile_last4 = at + l.n_tiles_fused * 32;
+    l.off_far = at + l.n_tiles_fused * 48;
+    at = round_up(at + l.n_tiles_fused * 80, 256);
     uint64_t want = n_bytes / 8;
     uint64_t small = n_bytes < (1ull << 20) ? n_bytes : (1ull << 20);
     if (want < small) want = small;

@@ -65,6 +65,7 @@ struct FusedLdsT {
     // -1 - j: the j-th newest newline in front of the super-tile; nlist[0..3] holds those that lie in the LDS window
     int32_t prev32[4];
     int32_t carry32[4];  // ... before the NEXT half (written when a half's list is complete)
+    uint16_t carry[4];   // (lean scan) the 4 newlines before the next half, relative to it: those inside its window
 };
 
 template <class L>
@@ -289,30 +290,48 @@ struct TileCtx {  // what emission needs besides the LDS contents (all workgroup
     int half;                   // index of the half inside its super-tile
 };
 
-// The scan.  kDenseRun == false: k_fused, a workgroup per super-tile (block 0: the scanner wave).  kDenseRun == true: the run
-// behind it (k_fused_dense: a fixed grid striding over the super-tiles) over the super-tiles in which the scan marked a half
-// as DENSE — more lines end in it than the LDS list holds (FASTQ: an average line below 16 bytes) — with the prefix the
-// scanner published: the marked halves are emitted in passes of kNlCap lines, everything else is staged only (the window
-// and the 4 preceding newlines of a half come from the half in front of it).  An instance of its own so that the scan's
-// code stays what it is without it: with the pass loop inside the scan the 10 GB FASTQ launch took 2.81 ms against
-// 2.25 ms (A/B in one box) although the loop was never entered — the scan runs at the edge of its 80 registers, and a
-// register spilled in its hot path makes the wave wait for all its column stores at every reload (vmcnt counts loads and
-// stores alike on gfx9).
-template <class F, bool kDenseRun>
-__device__ __forceinline__ void fused_body(typename F::Dev a, unsigned int *__restrict__ tileA, unsigned long long *__restrict__ tileP,
-                                           unsigned long long *__restrict__ tile_qend, ScanWsHeader *hdr, uint32_t n_super) {
+// ---- the scan, in three instances -------------------------------------------------------------------------------------
+// kLean        the scan of ordinary inputs (150 bp reads, 50-byte VCF lines): what is measured as the headline.  A record
+//              that begins in front of its half's window, a half with more lines than the list holds, a super-tile whose
+//              last four newlines it cannot name: it MARKS the super-tile (tile_redo) and goes on.  It runs at the edge of
+//              its 80 registers: a register spilled in its hot path makes the wave wait for all its column stores at every
+//              reload (vmcnt counts loads and stores alike on gfx9) — with the any-shape code inside it the 10 GB FASTQ
+//              launch took 2.35 - 2.87 ms against 2.25 (A/B in one box, six forms) although that code never ran.  So the
+//              any-shape code is an instance of its own:
+// kFullRedo    behind the lean scan on the stream, a fixed grid striding over the MARKED super-tiles with the prefix the
+//              scanner published: all their halves again, any shape (below);
+// kFullPrimary the any-shape scan as the launch's only scan (EXG_ALGO_FUSED_FULL): what a reader switches to when a
+//              batch came back with marks (long reads, 36 bp reads with short names, multi-sample VCF lines) — such an
+//              input pays the lean scan once.
+// Any shape: the half's lines are emitted kNlCap at a time (the 4 newlines in front of a pass are the last 4 of the pass
+// before); the record that begins in front of the window — at most one per half — is written as a FarRec for k_*_far; the 4
+// newlines in front of a half are carried as CODES (FarRec::pos), not as window offsets.
+enum { kLean = 0, kFullPrimary = 1, kFullRedo = 2 };
+static constexpr unsigned int kRedoFar = 1u, kRedoDense = 2u, kRedoLast4 = 4u;  // tile_redo[st]: why (diagnostics; any bit = redo)
+
+// tile_redo (u32 per super-tile) lies between tileP and tile_qend: tileA | tileP | tile_redo are zeroed by one memset
+__device__ __forceinline__ unsigned int *tile_redo_of(unsigned long long *tile_qend, uint64_t n_bytes) {
+    return reinterpret_cast<unsigned int *>(tile_qend - fused_n_tiles(n_bytes));
+}
+__device__ __forceinline__ int32_t *tile_last4_of(unsigned long long *tile_qend, uint64_t n_bytes) {
+    return reinterpret_cast<int32_t *>(tile_qend + fused_n_tiles(n_bytes));
+}
+__device__ __forceinline__ FarRec *far_rec_of(unsigned long long *tile_qend, uint64_t n_bytes) {
+    return reinterpret_cast<FarRec *>(tile_qend + 3 * fused_n_tiles(n_bytes));
+}
+
+template <class F, int kMode>
+__global__ __launch_bounds__(kThreads, kMode == kLean ? F::kMinWavesPerSimd : F::kMinWavesPerSimdFull) void k_fused(
+    typename F::Dev a, unsigned int *__restrict__ tileA, unsigned long long *__restrict__ tileP, unsigned long long *__restrict__ tile_qend,
+    ScanWsHeader *hdr, uint32_t n_super) {
     using FusedLds = FusedLdsT<F::kNlCap, F::kHalves, F::kTabMap>;
     constexpr int kNlCap = F::kNlCap;
     constexpr int kHalves = F::kHalves;
     constexpr int kSuper = kTile * kHalves;
+    constexpr bool kFull = kMode != kLean;
     __shared__ __attribute__((aligned(16))) FusedLds s;
     const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63;
-#ifdef EXG_AB_WAVE_VGPR
-    const uint32_t wave = tid >> 6;
-#else
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: a scalar register (and no VGPR to spill)
-#endif
+    const uint32_t lane = tid & 63, wave = tid >> 6;
     // DEV ONLY (tools/dev_probe.py): flags bits 8..11 select ablations on the synthetic FASTQ-150 file
     //   1: analytic prefix instead of the scanner   2: 1 + no output stores
     //   3: 1 + no emission at all                    4: scanner, no emission
@@ -322,10 +341,9 @@ __device__ __forceinline__ void fused_body(typename F::Dev a, unsigned int *__re
     constexpr uint32_t dev_mode = 0;  // the product build carries no work-skipping mode (EXG_CXXFLAGS=-DEXG_DEV_PROBE builds them in)
 #endif
     uint32_t st;
-    if constexpr (kDenseRun) {
-        if (!hdr->any_dense) return;
+    if constexpr (kMode == kFullRedo) {
+        if (!hdr->any_redo) return;
         st = blockIdx.x;
-        if (st >= n_super) return;
     } else {
         if (blockIdx.x == 0) {  // the scanner: one wave, no tile
             if (wave == 0 && !(dev_mode >= 1 && dev_mode <= 3)) scanner_wave<F::kHalves * kTile>(a.d_in, a.n_bytes, tileA, tileP, n_super, lane);
@@ -333,13 +351,10 @@ __device__ __forceinline__ void fused_body(typename F::Dev a, unsigned int *__re
         }
         st = blockIdx.x - 1;
     }
-    do {  // (one iteration in the scan)
-    if constexpr (kDenseRun) {
-        bool marked = false;
-#pragma unroll
-        for (int h = 0; h < kHalves; h++) marked = marked || (tile_qend[(uint64_t)st * kHalves + h] & kDenseBit) != 0;
-        if (!marked) continue;  // (workgroup-uniform)
-        __syncthreads();        // the tile before is done with the LDS
+    for (; kMode != kFullRedo || st < n_super; st += gridDim.x) {  // (one super-tile per workgroup but in the redo run)
+    if constexpr (kMode == kFullRedo) {
+        if (!tile_redo_of(tile_qend, a.n_bytes)[st]) continue;  // (workgroup-uniform)
+        __syncthreads();                                         // the tile before is done with the LDS
     }
     const uint64_t super_off = (uint64_t)st * kSuper;
     const uint8_t *__restrict__ d_in = a.d_in;
@@ -395,14 +410,14 @@ __device__ __forceinline__ void fused_body(typename F::Dev a, unsigned int *__re
 
     // ---- publish the super-tile count; its prefix is awaited after half 0 has been staged ---------------
     const bool analytic = dev_mode >= 1 && dev_mode <= 3;
-    if constexpr (!kDenseRun) {
+    if constexpr (kMode != kFullRedo) {
         if (tid == 0 && !analytic)
             __hip_atomic_store(&tileA[st], kFlagA | n_nl_super, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const unsigned long long halo_nl = rfl64(hdr->halo_nl);
     // Bytes >= 0x80 need UTF-8 validation of every field (the reference builds Arrow Utf8 columns).
     // That is rare in FASTQ and is left to the general path: raise `overflow`, which gates it in.
-    if constexpr (!kDenseRun) {
+    if constexpr (kMode != kFullRedo) {
         if (non_ascii && tid == 0) {
             atomicOr(&hdr->flags, EXG_RF_NON_ASCII);
             atomicOr(&hdr->overflow, 1u);
@@ -414,19 +429,17 @@ __device__ __forceinline__ void fused_body(typename F::Dev a, unsigned int *__re
         const int lim_h = lim_s - h * kTile;  // half-relative end of input
         if (h > 0 && lim_h <= 0) {
             // no input in this half: nothing ends here
-            if constexpr (!kDenseRun) {
-                if (tid == 0)
-                    for (int hh = h; hh < kHalves; hh++) tile_qend[(uint64_t)st * kHalves + hh] = 0;
-            }
+            if (tid == 0)
+                for (int hh = h; hh < kHalves; hh++) tile_qend[(uint64_t)st * kHalves + hh] = 0;
             break;
         }
         // ---- stage the half: window, bytes, newline list ------------------------------------------
         if (h == 0) {
             if (wave == 3) {
                 *reinterpret_cast<uint4 *>(s.bytes + lane * 16) = wv;
-                if (lane < 4) {
-                    s.nlist[lane] = (uint16_t)kNoneE;
-                    s.prev32[lane] = (int32_t)lane - 4;  // slot 3 = the newest newline in front of the super-tile
+                if (lane < 4) s.nlist[lane] = (uint16_t)kNoneE;
+                if constexpr (kFull) {
+                    if (lane < 4) s.prev32[lane] = (int32_t)lane - 4;  // slot 3 = the newest newline in front of the super-tile
                 }
                 uint32_t wm = woff >= 0 ? match16(wv, 0x0A0A0A0Au) : 0u;
                 uint32_t wc = __popc(wm);
@@ -450,11 +463,14 @@ __device__ __forceinline__ void fused_body(typename F::Dev a, unsigned int *__re
             __syncthreads();
             if (wave == 3) {
                 *reinterpret_cast<uint4 *>(s.bytes + lane * 16) = t;
-                if (lane < 4) {
-                    const uint32_t k = opaque(lane);
-                    const int32_t code = s.carry32[k], rel = code - (h * kTile - kWin);  // e-offset in this half's buffer
-                    s.prev32[k] = code;
-                    s.nlist[k] = (code >= 0 && rel >= 0) ? (uint16_t)rel : (uint16_t)kNoneE;
+                if constexpr (kFull) {
+                    if (lane < 4) {
+                        const int32_t code = s.carry32[lane], rel = code - (h * kTile - kWin);  // e-offset in this half's buffer
+                        s.prev32[lane] = code;
+                        s.nlist[lane] = (code >= 0 && rel >= 0) ? (uint16_t)rel : (uint16_t)kNoneE;
+                    }
+                } else {
+                    if (lane < 4) s.nlist[lane] = s.carry[lane];
                 }
             }
         }
@@ -484,8 +500,8 @@ __device__ __forceinline__ void fused_body(typename F::Dev a, unsigned int *__re
             // the half is staged while the scanner turns the published count into our prefix
             if (wave == 0) {
                 unsigned long long pre;
-                if constexpr (kDenseRun) {
-                    pre = st ? ld_desc(&tileP[st]) & kVal : 0ull;  // (published: the scan has completed)
+                if constexpr (kMode == kFullRedo) {
+                    pre = st ? ld_desc(&tileP[st]) & kVal : 0ull;  // (published: the lean scan has completed)
                 } else if (analytic) {
                     pre = F::analytic_prefix(super_off);
                 } else {
@@ -520,17 +536,48 @@ __device__ __forceinline__ void fused_body(typename F::Dev a, unsigned int *__re
             __syncthreads();
         }
         c.n_lines = n_lines;
-        if constexpr (!kDenseRun) {
-            if (ends_here && tid == 0) {
-                hdr->total_nl = c.P + n_nl_h;
-                hdr->total_lines = c.P + n_lines;
-            }
+        if (ends_here && tid == 0) {
+            hdr->total_nl = c.P + n_nl_h;
+            hdr->total_lines = c.P + n_lines;
         }
         const uint64_t half_index = (uint64_t)st * kHalves + h;
-        if (n_lines > (uint32_t)kNlCap) {
-            // DENSE: more lines than the list holds.  The scan marks the half and leaves it to the dense run; the dense run
-            // emits it in passes of kNlCap lines (the 4 newlines in front of a pass are the last 4 of the pass before).
-            // Both then put the half's LAST kNlCap lines into the list: what the carry below reads.
+        if constexpr (!kFull) {
+            // ---- the lean scan ------------------------------------------------------------------------------
+            if (n_lines > (uint32_t)kNlCap) {  // more lines than the list holds: the any-shape run redoes this super-tile
+                if (tid == 0) {
+                    tile_redo_of(tile_qend, a.n_bytes)[st] = kRedoDense;
+                    hdr->any_redo = 1u;
+                }
+                return;
+            }
+            if (h + 1 < kHalves && tid < 4) {
+                // the 4 newlines before the next half, relative to it (entries 4+n-4 .. 4+n-1 of this list)
+                uint32_t e = s.nlist[n_lines + tid];
+                s.carry[tid] = (e != kNoneE && e >= (uint32_t)kTile) ? (uint16_t)(e - kTile) : (uint16_t)kNoneE;
+            }
+            if (h + 1 == kHalves || lim_s <= (h + 1) * kTile) {  // (no input behind this half in the super-tile)
+                // the super-tile's last four newlines (tileL: what k_*_far's look-back reads): slot 3 the newest.  The ones
+                // this tile holds (n_nl_super of them) must be nameable from the last half's list; if not — sparse
+                // newlines: long lines — the any-shape run redoes the super-tile and names them.
+                if (wave == 0) {
+                    const uint32_t idx = n_lines + lane;  // lanes 0 .. 3: entries n .. n + 3 counted from nlist[0]
+                    int32_t code = -1;
+                    if (lane < 4) {
+                        const uint32_t e = s.nlist[idx];
+                        code = e != kNoneE ? h * kTile + (int32_t)e - kWin : -1;
+                        tile_last4_of(tile_qend, a.n_bytes)[(uint64_t)st * 4 + lane] = code;
+                    }
+                    const uint32_t need = n_nl_super < 4u ? n_nl_super : 4u;  // slots 4 - need .. 3
+                    if (__ballot(lane < 4 && lane >= 4 - need && code < 0) != 0 && lane == 0) {
+                        tile_redo_of(tile_qend, a.n_bytes)[st] = kRedoLast4;
+                        hdr->any_redo = 1u;
+                    }
+                }
+            }
+            F::template emit_half<kLean>(s, a, hdr, c, halo_nl, dev_mode, lane, wave, tile_qend, half_index);
+        } else {
+            // ---- any shape ----------------------------------------------------------------------------------
+            // positions of the newlines of ranks [base, base + kNlCap) -> the list (a later pass of a dense half)
             auto fill_list = [&](uint32_t base) {
                 unsigned long long mask = *reinterpret_cast<const unsigned long long *>(&s.bitmap[h][tid * 4]);
                 uint32_t cc = (uint32_t)__popcll(mask);
@@ -547,70 +594,39 @@ __device__ __forceinline__ void fused_body(typename F::Dev a, unsigned int *__re
                     for (uint32_t q = n_nl_h > base ? n_nl_h : base; q < n_lines && q < base + (uint32_t)kNlCap; q++)
                         s.nlist[4 + q - base] = (uint16_t)c.lim_e;
             };
-            if constexpr (!kDenseRun) {
-                if (tid == 0) {
-                    tile_qend[half_index] = kDenseBit;
-                    hdr->any_dense = 1u;
-                }
-            } else {
+            const unsigned long long P_half = c.P;
 #pragma unroll 1
-                for (uint32_t base = 0;;) {
-                    const uint32_t m = n_lines - base < (uint32_t)kNlCap ? n_lines - base : (uint32_t)kNlCap;
-                    c.P += base - c.pass_base;
-                    c.pass_base = base;
-                    c.n_lines = m;
-                    F::emit_half(s, a, hdr, c, halo_nl, dev_mode, lane, wave, tile_qend, half_index);
-                    base += m;
-                    if (base >= n_lines) break;
-                    uint16_t keep = 0;
-                    if (tid < 4) keep = s.nlist[m + tid];  // (m == kNlCap) the last 4 entries of this pass
-                    __syncthreads();                       // everyone is done reading the list
-                    if (tid < 4) {
-                        s.nlist[tid] = keep;
-                        s.prev32[tid] = h * kTile + (int32_t)keep - kWin;
-                    }
-                    fill_list(base);
-                    __syncthreads();
+            for (uint32_t base = 0;;) {
+                const uint32_t m = n_lines - base < (uint32_t)kNlCap ? n_lines - base : (uint32_t)kNlCap;
+                c.P = P_half + base;
+                c.pass_base = base;
+                c.n_lines = m;
+                if (base + m >= n_lines && tid < 4) {
+                    // the 4 newlines before the next half (entries m .. m + 3 of the last pass's list, counted from nlist[0]) as
+                    // CODES; the last half's are the last 4 of the super-tile: tileL
+                    const uint32_t idx = m + tid;
+                    const int32_t code = idx >= 4 ? h * kTile + (int32_t)s.nlist[idx] - kWin : s.prev32[idx];
+                    s.carry32[tid] = code;
+                    if (h + 1 == kHalves || lim_s <= (h + 1) * kTile) tile_last4_of(tile_qend, a.n_bytes)[(uint64_t)st * 4 + tid] = code;
                 }
+                F::template emit_half<kFullPrimary>(s, a, hdr, c, halo_nl, dev_mode, lane, wave, tile_qend, half_index);
+                base += m;
+                if (base >= n_lines) break;
+                uint16_t keep = 0;
+                if (tid < 4) keep = s.nlist[m + tid];  // (m == kNlCap) the last 4 entries of this pass
+                __syncthreads();                       // everyone is done reading the list
+                if (tid < 4) {
+                    s.nlist[tid] = keep;
+                    s.prev32[tid] = h * kTile + (int32_t)keep - kWin;
+                }
+                fill_list(base);
+                __syncthreads();
             }
-            __syncthreads();
-            fill_list(n_lines - (uint32_t)kNlCap);
-            __syncthreads();
-            c.n_lines = (uint32_t)kNlCap;
-        }
-        if (tid < 4) {
-            // the 4 newlines before the next half (entries n .. n + 3 of this list, counted from nlist[0]) as CODES; the
-            // last half's are the last 4 of the super-tile: what k_*_far's look-back reads (tileL)
-            const uint32_t k = opaque(tid), idx = c.n_lines + k;
-            const int32_t code = idx >= 4 ? h * kTile + (int32_t)s.nlist[idx] - kWin : s.prev32[idx];
-            s.carry32[k] = code;
-#ifndef EXG_AB_NO_TILEL
-            if constexpr (!kDenseRun) {
-                // (no input behind this half in the super-tile)
-                if (h + 1 == kHalves || lim_s <= (h + 1) * kTile) reinterpret_cast<int32_t *>(tile_qend + fused_n_tiles(a.n_bytes))[(uint64_t)st * 4 + k] = code;
-            }
-#endif
-        }
-        if constexpr (!kDenseRun) {
-            if (n_lines <= (uint32_t)kNlCap) F::emit_half(s, a, hdr, c, halo_nl, dev_mode, lane, wave, tile_qend, half_index);
         }
         if (h + 1 < kHalves) __syncthreads();  // everyone is done reading this half
     }
-    } while (kDenseRun && (st += gridDim.x) < n_super);
-}
-
-template <class F>
-__global__ __launch_bounds__(kThreads, F::kMinWavesPerSimd) void k_fused(typename F::Dev a, unsigned int *__restrict__ tileA,
-                                                             unsigned long long *__restrict__ tileP,
-                                                             unsigned long long *__restrict__ tile_qend,
-                                                             ScanWsHeader *hdr, uint32_t n_super) {
-    fused_body<F, false>(a, tileA, tileP, tile_qend, hdr, n_super);
-}
-template <class F>
-__global__ __launch_bounds__(kThreads) void k_fused_dense(typename F::Dev a, unsigned int *__restrict__ tileA,
-                                                          unsigned long long *__restrict__ tileP,
-                                                          unsigned long long *__restrict__ tile_qend, ScanWsHeader *hdr, uint32_t n_super) {
-    fused_body<F, true>(a, tileA, tileP, tile_qend, hdr, n_super);
+    if constexpr (kMode != kFullRedo) break;
+    }
 }
 
 

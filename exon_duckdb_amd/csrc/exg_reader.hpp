@@ -367,6 +367,13 @@ struct exg_reader {
     uint64_t gz_header_prefix = 0;  // gzip + VCF: bytes of the inflated file's start held in file->p (header parse)
     bool worst_case_rows = false;
     bool ws_full = false;  // under EXG_DEVICE_MEM_CAP_MB: a batch overflowed the budgeted line index, the workspace is at full size
+    // Which scan a batch starts with is sticky (an input keeps its shape): EXG_ALGO_FUSED (the lean scan + the any-shape run
+    // over what it marked) until a batch comes back with EXG_RF_REDO — long reads, reads below ~45 bp, multi-sample VCF
+    // lines —, then EXG_ALGO_FUSED_FULL, the any-shape scan alone, for the rest of the input (the lean scan would mark every
+    // tile and be a pass wasted per batch).  A batch with a byte >= 0x80 takes the general path (UTF-8 validation) after the
+    // fused launch gave it up; the batches behind it start there, until one comes back without such a byte.
+    uint32_t fused_algo = EXG_ALGO_FUSED;
+    bool general_first = false;
     // exg_open_args.filters: postfix program + constants in device memory, a row map and one column of scratch
     bool has_filter = false;
     void *d_filter_prog = nullptr, *d_filter_consts = nullptr;  // pooled

@@ -209,16 +209,18 @@ struct LdsSrc {
     __device__ __forceinline__ uint4 str(int e, uint32_t len) const { return make_string_lds(s, e, len, ptr_of_e0); }
 };
 
+static constexpr int kVcfHalves = 2;
 struct VcfFormat {
     using Dev = VcfDev;
     static constexpr int kNlCap = 1024;  // short data lines are common
-    static constexpr int kHalves = 2;
+    static constexpr int kHalves = kVcfHalves;
     static constexpr bool kTabMap = true;
     static constexpr int kMinWavesPerSimd = 5;
+    static constexpr int kMinWavesPerSimdFull = 4;  // the any-shape instances (their pass loop and FarRec code want registers)
     __device__ static __forceinline__ uint32_t eof_extra_lines(unsigned long long) { return 0; }
     __device__ static __forceinline__ unsigned long long analytic_prefix(uint64_t) { return 0; }
 
-    template <class L>
+    template <int kMode, class L>
     __device__ static __forceinline__ void emit_half(const L &s, const VcfDev &a, ScanWsHeader *hdr,
                                                      const TileCtx &c, unsigned long long halo_nl, uint32_t dev_mode,
                                                      uint32_t lane, uint32_t wave,
@@ -252,17 +254,23 @@ struct VcfFormat {
             if (act) {
                 const uint32_t q0 = s.nlist[3 + j];  // newline before the line
                 if (q0 == kNoneE) {
-                    // the line begins in front of the LDS window (only the first line of a half's first pass can: thread 0):
-                    // its row is k_vcf_far's
-                    FarRec f;
-                    f.pos[0] = s.prev32[3];
-                    f.pos[1] = c.half * kTile + e1 - kWin;
-                    f.pos[2] = f.pos[3] = f.pos[4] = 0;
-                    f.flags = c.is_eof_tile ? 1u : 0u;
-                    f.out = out;
-                    reinterpret_cast<FarRec *>(tile_qend + 3 * fused_n_tiles(a.n_bytes))[tile_index] = f;
-                    hdr->any_far = 1u;
-                    tile_qend[tile_index] |= kFarBit;  // (this thread stored the word above)
+                    // the line begins in front of the LDS window (only the first line of a half's first pass can: thread 0)
+                    if constexpr (kMode == kLean) {
+                        // lean scan: the any-shape run redoes this super-tile
+                        tile_redo_of(tile_qend, a.n_bytes)[tile_index / kVcfHalves] = kRedoFar;
+                        hdr->any_redo = 1u;
+                    } else {
+                        // any-shape scan: its row is k_vcf_far's
+                        FarRec f;
+                        f.pos[0] = s.prev32[3];
+                        f.pos[1] = c.half * kTile + e1 - kWin;
+                        f.pos[2] = f.pos[3] = f.pos[4] = 0;
+                        f.flags = c.is_eof_tile ? 1u : 0u;
+                        f.out = out;
+                        far_rec_of(tile_qend, a.n_bytes)[tile_index] = f;
+                        hdr->any_far = 1u;
+                        tile_qend[tile_index] |= kFarBit;  // (this thread stored the word above)
+                    }
                 } else {
                     int s0 = (int)q0 + 1;
                     if (e1 > s0 && !(c.is_eof_tile && e1 == c.lim_e) && ldb(s, e1 - 1) == '\r') e1--;
@@ -430,7 +438,7 @@ __global__ __launch_bounds__(256) void k_vcf_finalize(VcfDev a, ScanWsHeader *hd
     if (fused && !hdr->overflow) {
         for (int64_t base = (int64_t)n_tiles - 1; base >= 0; base -= 256) {
             int64_t t = base - threadIdx.x;
-            unsigned long long q = t >= 0 ? tile_qend[t] & ~(kFarBit | kDenseBit) : 0;
+            unsigned long long q = t >= 0 ? tile_qend[t] & ~kFarBit : 0;
             if (q) atomicMax(&s_qend, q);
             if (q) s_found = 1;
             __syncthreads();
@@ -457,7 +465,7 @@ __global__ __launch_bounds__(256) void k_vcf_finalize(VcfDev a, ScanWsHeader *hd
     }
     exg_scan_result r;
     r.n_lines = n_owned;
-    r.flags = hdr->flags | (gate ? EXG_RF_FALLBACK : 0u);
+    r.flags = hdr->flags | (gate ? EXG_RF_FALLBACK : 0u) | (fused && hdr->any_redo ? EXG_RF_REDO : 0u);
     if (!fused && T > hdr->lines_cap) r.flags |= EXG_RF_INDEX_OVERFLOW;
     r.payload_bytes = 0;
     r.reserved = 0;
@@ -511,7 +519,7 @@ static int run_vcf_general(const VcfDev &dev, uint8_t *ws, const FastqWsLayout &
 }
 
 static int run_vcf_fused(const VcfDev &dev, uint8_t *ws, const FastqWsLayout &l, exg_scan_result *d_result,
-                         hipStream_t stream) {
+                         hipStream_t stream, bool full) {
     ScanWsHeader *hdr = reinterpret_cast<ScanWsHeader *>(ws);
     constexpr uint64_t kSuperBytes = (uint64_t)VcfFormat::kHalves * kTile;
     constexpr uint32_t kHalvesHost = VcfFormat::kHalves;
@@ -522,22 +530,28 @@ static int run_vcf_fused(const VcfDev &dev, uint8_t *ws, const FastqWsLayout &l,
         return EXG_E_INVALID_ARG;
     }
     uint32_t n_super = (uint32_t)n_super64;
-    // descriptor block: u32 tileA[n] (padded to n u64), u64 tileP[n], u64 tile_qend[n]
+    // descriptor block (exg_fastq_ws.hpp): u64 tileA[n] (u32 counts), u64 tileP[n], u64 tile_redo[n] (u32 marks), u64 tile_qend[n],
+    // int32 tileL[n][4], FarRec[n]
+    const uint64_t n = l.n_tiles_fused;
     unsigned int *tileA = reinterpret_cast<unsigned int *>(ws + l.off_tile_desc);
-    unsigned long long *tileP = reinterpret_cast<unsigned long long *>(ws + l.off_tile_desc) + l.n_tiles_fused;
-    unsigned long long *tile_qend = tileP + l.n_tiles_fused;
+    unsigned long long *tileP = reinterpret_cast<unsigned long long *>(ws + l.off_tile_desc) + n;
+    unsigned long long *tile_qend = tileP + 2 * n;
     int32_t *tileL = reinterpret_cast<int32_t *>(ws + l.off_tile_last4);
     FarRec *far_rec = reinterpret_cast<FarRec *>(ws + l.off_far);
     hipLaunchKernelGGL(k_init_hdr, dim3(1), dim3(1), 0, stream, hdr, l.lines_cap, 0u);
-    EXG_HIP_CHECK(hipMemsetAsync(tileA, 0, (size_t)l.n_tiles_fused * 16, stream));
+    EXG_HIP_CHECK(hipMemsetAsync(tileA, 0, (size_t)n * 24, stream));
     if (dev.lead) {
         int rc = exg_count_newlines(dev.d_in, 0, dev.lead, (uint64_t *)&hdr->halo_nl, stream);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_fused<VcfFormat>, dim3(n_super + 1), dim3(kThreads), 0, stream, dev, tileA, tileP, tile_qend, hdr, n_super);
-    // halves with more lines than the LDS list holds, in passes (returns at once when the scan marked none)
-    hipLaunchKernelGGL(k_fused_dense<VcfFormat>, dim3(n_super < 1536 ? n_super : 1536), dim3(kThreads), 0, stream, dev, tileA, tileP,
-                       tile_qend, hdr, n_super);
+    if (full) {
+        hipLaunchKernelGGL((k_fused<VcfFormat, kFullPrimary>), dim3(n_super + 1), dim3(kThreads), 0, stream, dev, tileA, tileP, tile_qend, hdr, n_super);
+    } else {
+        hipLaunchKernelGGL((k_fused<VcfFormat, kLean>), dim3(n_super + 1), dim3(kThreads), 0, stream, dev, tileA, tileP, tile_qend, hdr, n_super);
+        // the super-tiles the lean scan marked, any shape (returns at once when it marked none)
+        hipLaunchKernelGGL((k_fused<VcfFormat, kFullRedo>), dim3(n_super < 1024 ? n_super : 1024), dim3(kThreads), 0, stream, dev, tileA, tileP,
+                           tile_qend, hdr, n_super);
+    }
     {   // the rows of lines that begin in front of their half's window (returns at once when there is none)
         const uint32_t n_halves = n_super * kHalvesHost;
         const uint32_t grid = (n_halves + 255) / 256 < 4096 ? (n_halves + 255) / 256 : 4096;
@@ -595,9 +609,11 @@ extern "C" int exg_vcf_scan(const exg_vcf_scan_args *a) {
         case EXG_ALGO_MULTIPASS:
             return run_vcf_general(dev, ws, l, a->d_result, stream, false);
         case EXG_ALGO_FUSED:
-            return run_vcf_fused(dev, ws, l, a->d_result, stream);
+            return run_vcf_fused(dev, ws, l, a->d_result, stream, false);
+        case EXG_ALGO_FUSED_FULL:
+            return run_vcf_fused(dev, ws, l, a->d_result, stream, true);
         case EXG_ALGO_AUTO: {
-            int rc = run_vcf_fused(dev, ws, l, a->d_result, stream);
+            int rc = run_vcf_fused(dev, ws, l, a->d_result, stream, false);
             if (rc) return rc;
             return run_vcf_general(dev, ws, l, a->d_result, stream, true);
         }

@@ -98,6 +98,8 @@ class ShardReader:
                 return rows, hashlib.blake2b(b"".join(x.digest() for x in hs), digest_size=16).hexdigest()
             rows += n
             for k, t in enumerate(self.types):
+                if self.columns is not None and k not in self.columns:
+                    continue   # (not asked for: exg_chunk.data / vectors are NULL for it; its hash stays the empty one)
                 h = hs[k]
                 if t in (abi.EXG_TYPE_BIGINT, abi.EXG_TYPE_FLOAT):
                     width = 8 if t == abi.EXG_TYPE_BIGINT else 4

@@ -110,16 +110,22 @@ typedef union exg_string_t {
 /* result flags */
 #define EXG_RF_NON_ASCII 1u /* a byte >= 0x80 was seen; UTF-8 was validated by the slow kernel */
 #define EXG_RF_HEAD_UNRESOLVED 2u /* first owned record starts before d_input[0]: host must stitch */
-#define EXG_RF_FALLBACK 4u  /* the fused kernel met a record larger than its LDS window and the general kernel ran */
+#define EXG_RF_FALLBACK 4u  /* the fused kernels gave the launch up (a byte >= 0x80: UTF-8 validation) and the general kernels ran */
 #define EXG_RF_CAPACITY 8u  /* more records than capacity_records: the surplus was not written */
 #define EXG_RF_INDEX_OVERFLOW 16u /* general path: more lines than the workspace can index (enlarge d_workspace) */
 #define EXG_RF_QUAL_RANGE 32u /* VCF: more QUAL literals of one launch needed the exact big-integer parser (> 19 digits astride a float
                                  rounding boundary) than its list holds (one per 32 bytes of input, at most 4096); the next was rejected */
 
 /* algorithm selector (exg_*_scan_args.algo) */
+#define EXG_RF_REDO 64u     /* the lean scan marked super-tiles — a record / line that begins more than 1 KiB in front of the 16 KiB
+                             * half it ends in (long reads, multi-sample VCF), or more lines in a half than its list holds (reads
+                             * below ~45 bp) — and the any-shape run behind it redid them: the output is complete; a caller
+                             * with more batches of the same input does better with EXG_ALGO_FUSED_FULL from here on */
 #define EXG_ALGO_AUTO 0
 #define EXG_ALGO_MULTIPASS 1 /* count -> scan -> index -> fields: 4 launches, reads the input ~3x */
-#define EXG_ALGO_FUSED 2     /* single pass, decoupled look-back: reads the input once */
+#define EXG_ALGO_FUSED 2     /* single pass: the lean scan, then the any-shape scan over the super-tiles the lean one marked */
+#define EXG_ALGO_FUSED_FULL 3 /* single pass: the any-shape scan alone (any record length / line density at one rate; ~10 % below
+                               * the lean scan on 150 bp reads) */
 
 /* Written by the device (64 bytes, 8-byte aligned), copied back by exg_fetch_result. */
 typedef struct exg_scan_result {
@@ -459,7 +465,11 @@ typedef struct exg_reader_stats {
     uint64_t device_batch_bytes; /* bytes per device batch / decoded segment */
     uint64_t device_batches;     /* scans launched */
     uint64_t decoded_segments;   /* segments of a compressed input consumed */
-    uint64_t reserved[4];
+    uint64_t scan_algo;          /* EXG_ALGO_* the next device batch starts with: EXG_ALGO_FUSED until a batch came back with
+                                  * EXG_RF_REDO (long reads, reads below ~45 bp, multi-sample VCF lines), then
+                                  * EXG_ALGO_FUSED_FULL for the rest of the input; EXG_ALGO_MULTIPASS behind a batch with a byte
+                                  * >= 0x80, until one comes back without (a fan-out reader: 0) */
+    uint64_t reserved[3];
 } exg_reader_stats;
 int exg_reader_stats_of(exg_reader *r, exg_reader_stats *out);
 /* Device buffers, pinned host blocks and HIP streams of closed readers are recycled process-wide (size classes, at most

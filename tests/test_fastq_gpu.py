@@ -14,7 +14,8 @@ from exon_duckdb_amd import abi
 pytestmark = pytest.mark.gpu
 
 BASE = 0x7F0000000000  # payload_base used by all tests (pointers become BASE + file offset)
-ALGOS = [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS, abi.EXG_ALGO_AUTO]
+ALGOS = [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS, abi.EXG_ALGO_AUTO, abi.EXG_ALGO_FUSED_FULL]
+FUSED = (abi.EXG_ALGO_FUSED, abi.EXG_ALGO_FUSED_FULL)   # the lean scan + the any-shape run over what it marked; the any-shape scan alone
 NAMES = ["name", "description", "sequence", "quality_scores"]
 
 
@@ -37,7 +38,7 @@ def check_against_oracle(oracle, data, algo, expect_fallback=None):
     exp = oracle.fastq_parse(data, payload_base=BASE)
     res, cols, words = run_gpu(data, algo)
     non_ascii = any(b >= 0x80 for b in data)   # UTF-8 validation is left to the general path
-    if algo == abi.EXG_ALGO_FUSED and (res.flags & abi.EXG_RF_FALLBACK):
+    if algo in FUSED and (res.flags & abi.EXG_RF_FALLBACK):
         assert expect_fallback or non_ascii, "fused kernel unexpectedly asked for the general path"
         return res
     if non_ascii and algo == abi.EXG_ALGO_AUTO:
@@ -183,7 +184,7 @@ def test_edge_cases(gpu, oracle, case, algo):
 # ---- records larger than the fused kernel's LDS window, halves with more lines than its list: still one pass ----------
 # (more shapes: tests/test_record_shapes_gpu.py)
 
-@pytest.mark.parametrize("algo", [abi.EXG_ALGO_MULTIPASS, abi.EXG_ALGO_AUTO, abi.EXG_ALGO_FUSED])
+@pytest.mark.parametrize("algo", ALGOS)
 def test_long_reads_stay_on_the_single_pass(gpu, oracle, algo):
     rng = np.random.default_rng(7)
     recs = []
@@ -196,7 +197,7 @@ def test_long_reads_stay_on_the_single_pass(gpu, oracle, algo):
     assert res.n_records == 40 and not (res.flags & abi.EXG_RF_FALLBACK)
 
 
-@pytest.mark.parametrize("algo", [abi.EXG_ALGO_MULTIPASS, abi.EXG_ALGO_AUTO, abi.EXG_ALGO_FUSED])
+@pytest.mark.parametrize("algo", ALGOS)
 def test_many_tiny_lines_in_one_tile(gpu, oracle, algo):
     # 10 900 newlines per 16 KiB half: the fused kernel's list holds 512, the half is emitted in 22 passes
     data = b"@a\n\n+\n\n" * 5000
@@ -206,7 +207,7 @@ def test_many_tiny_lines_in_one_tile(gpu, oracle, algo):
 
 # ---- byte-range shards with a halo (multi-GPU layout) and record-aligned batches ---------------------------
 
-@pytest.mark.parametrize("algo", [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS])
+@pytest.mark.parametrize("algo", [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS, abi.EXG_ALGO_FUSED_FULL])
 @pytest.mark.parametrize("ragged", [False, True])
 def test_unaligned_shards_reassemble(gpu, oracle, algo, ragged):
     n_rec = 3000
@@ -241,7 +242,7 @@ def test_unaligned_shards_reassemble(gpu, oracle, algo, ragged):
     assert np.array_equal(np.concatenate(got_valid), exp.columns["description"].valid)
 
 
-@pytest.mark.parametrize("algo", [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS])
+@pytest.mark.parametrize("algo", [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS, abi.EXG_ALGO_FUSED_FULL])
 def test_head_record_before_buffer_is_reported(gpu, oracle, algo):
     data = bytes(oracle.synth_fastq(332 * 200))
     s = 16 * 700   # mid record, no halo and no BOF: the first owned record cannot be resolved
@@ -256,7 +257,7 @@ def test_head_record_before_buffer_is_reported(gpu, oracle, algo):
     assert not cols[0][0].any()          # the unresolved row is zeroed
 
 
-@pytest.mark.parametrize("algo", [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS])
+@pytest.mark.parametrize("algo", [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS, abi.EXG_ALGO_FUSED_FULL])
 def test_record_aligned_batches(gpu, oracle, algo):
     # streaming: not at EOF, the tail record is incomplete; consumed_bytes says where to resume
     data = bytes(oracle.synth_fastq_ragged(400))
@@ -273,7 +274,7 @@ def test_record_aligned_batches(gpu, oracle, algo):
     assert np.array_equal(cols2[3], exp.string_t["quality_scores"][0][k:])
 
 
-@pytest.mark.parametrize("algo", [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS])
+@pytest.mark.parametrize("algo", [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS, abi.EXG_ALGO_FUSED_FULL])
 def test_capacity_is_enforced(gpu, oracle, algo):
     data = oracle.synth_fastq(332 * 500)
     res, cols, _ = run_gpu(data, algo, capacity=123)

@@ -49,7 +49,7 @@ def test_fastq_fuzz(gpu, oracle, seed):
     for _ in range(6):
         data = mutate(base, rng, int(rng.integers(1, 6)))
         for algo in T_FQ.ALGOS:
-            T_FQ.check_against_oracle(oracle, data, algo, expect_fallback=None if algo != abi.EXG_ALGO_FUSED else True)
+            T_FQ.check_against_oracle(oracle, data, algo)
 
 
 @pytest.mark.parametrize("seed", range(48))
@@ -62,7 +62,7 @@ def test_vcf_fuzz(gpu, oracle, seed):
         if T_VCF.header_bytes(data) != hdr:
             continue                                  # a mutation made a new header line: host-side territory
         for algo in T_VCF.ALGOS:
-            T_VCF.check(oracle, data, algo, expect_fallback=True)
+            T_VCF.check(oracle, data, algo)
 
 
 @pytest.mark.parametrize("seed", range(48))

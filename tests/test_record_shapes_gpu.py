@@ -13,11 +13,11 @@ import pytest
 from exon_duckdb_amd import abi
 
 from test_fastq_gpu import BASE as FQ_BASE, NAMES, check_against_oracle, run_gpu as run_fastq
-from test_vcf_gpu import HDR, check as check_vcf, header_bytes
+from test_vcf_gpu import HDR, check as check_vcf, header_bytes, run_gpu as run_vcf
 
 pytestmark = pytest.mark.gpu
 
-FUSED_AND_PARTNER = [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS]
+FUSED_AND_PARTNER = [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_FUSED_FULL, abi.EXG_ALGO_MULTIPASS]
 
 
 def fastq_records(lengths, seed=1, crlf_every=0, desc_every=2, name_len=None):
@@ -38,6 +38,23 @@ def fastq_records(lengths, seed=1, crlf_every=0, desc_every=2, name_len=None):
 
 def no_fallback(res):
     assert not (res.flags & abi.EXG_RF_FALLBACK), "the fused kernel gave the launch up"
+
+
+def test_the_lean_scan_says_when_it_marked_tiles(gpu, oracle):
+    """EXG_RF_REDO: the lean scan marked super-tiles and the any-shape run redid them (complete output; a reader with more
+    batches of the input switches to EXG_ALGO_FUSED_FULL).  Clear on the synthetic 150 bp shape and under FUSED_FULL."""
+    short = bytes(oracle.synth_fastq(332 * 3000))
+    long_ = fastq_records([15000] * 20, seed=2)
+    tiny = b"@a\n\n+\n\n" * 6000
+    for data, redo in ((short, False), (long_, True), (tiny, True), (short + long_ + short, True)):
+        res, _, _ = run_fastq(data, abi.EXG_ALGO_FUSED)
+        assert bool(res.flags & abi.EXG_RF_REDO) == redo and res.error_code == 0
+        res, _, _ = run_fastq(data, abi.EXG_ALGO_FUSED_FULL)
+        assert not (res.flags & abi.EXG_RF_REDO) and res.error_code == 0
+    res, _ = run_vcf(vcf_lines(40, 2504, seed=1), abi.EXG_ALGO_FUSED)
+    assert res.flags & abi.EXG_RF_REDO
+    res, _ = run_vcf(vcf_lines(400, 3, seed=1), abi.EXG_ALGO_FUSED)
+    assert not (res.flags & abi.EXG_RF_REDO)
 
 
 # ---- long reads ---------------------------------------------------------------------------------------------------
@@ -253,3 +270,75 @@ def test_tiny_vcf_lines(gpu, oracle, algo):
     # blank lines are lines (an error at the first): 16 384 per half
     res = check_vcf(oracle, HDR + b"1\t5\t.\tA\tC\t.\t.\t.\n" * 3 + b"\n" * 40000, algo)
     no_fallback(res)
+
+
+# ---- through the reader: small device batches, the sticky choice of the scan ----------------------------------------
+
+def _reader_rows(path, fmt, **kw):
+    from exon_duckdb_amd.reader import ShardReader
+    r = ShardReader(str(path), fmt, **kw)
+    rows = r.rows()
+    st = r.stats()
+    r.close()
+    return rows, st
+
+
+def _fastq_rows(oracle, data):
+    t = oracle.fastq_parse(bytes(data), want_string_t=False)
+    assert t.error_code == 0
+    return list(zip(*[t.columns[c].to_list() for c in NAMES]))
+
+
+@pytest.mark.parametrize("compressed", [False, True])
+def test_reader_long_reads_switch_to_the_any_shape_scan(gpu, oracle, tmp_path, compressed):
+    """a long-read file in 2 MiB device batches: the first batch comes back marked (EXG_RF_REDO), the batches behind it start
+    with EXG_ALGO_FUSED_FULL; the rows are the oracle's, text and BGZF"""
+    from test_streaming_gpu import _bgzf
+    rng = np.random.default_rng(5)
+    lengths = np.exp(rng.uniform(np.log(2000), np.log(60000), 900))
+    data = fastq_records(lengths, seed=12, crlf_every=13)
+    path = tmp_path / ("long.fastq.gz" if compressed else "long.fastq")
+    path.write_bytes(_bgzf(bytes(data)) if compressed else bytes(data))
+    rows, st = _reader_rows(path, "fastq", device_batch_bytes=2 << 20)
+    assert rows == _fastq_rows(oracle, data)
+    assert st["device_batches"] >= 8 and st["scan_algo"] == abi.EXG_ALGO_FUSED_FULL
+    # 150 bp reads: the lean scan all the way
+    short = bytes(oracle.synth_fastq(332 * 40000))
+    p2 = tmp_path / "short.fastq"
+    p2.write_bytes(short)
+    rows, st = _reader_rows(p2, "fastq", device_batch_bytes=2 << 20)
+    assert len(rows) == 40000 and st["scan_algo"] == abi.EXG_ALGO_FUSED
+
+
+def test_reader_short_reads_and_wide_vcf(gpu, oracle, tmp_path):
+    data = fastq_records([36] * 60000, seed=3, desc_every=0)
+    p = tmp_path / "short36.fastq"
+    p.write_bytes(bytes(data))
+    rows, st = _reader_rows(p, "fastq", device_batch_bytes=1 << 20)
+    assert rows == _fastq_rows(oracle, data) and st["scan_algo"] == abi.EXG_ALGO_FUSED_FULL
+    vcf = vcf_lines(900, 2504, seed=4)
+    pv = tmp_path / "wide.vcf"
+    pv.write_bytes(vcf)
+    from exon_duckdb_amd.reader import ShardReader
+    r = ShardReader(str(pv), "vcf", device_batch_bytes=1 << 20, columns=[0, 1, 3, 5])
+    got = r.rows()
+    st = r.stats()
+    r.close()
+    t = oracle.vcf_parse(vcf, want_string_t=False)
+    want = list(zip(t.columns["chrom"].to_list(), [int(x) for x in t.extra["pos"]], t.columns["ref"].to_list(),
+                    [float(q) if v else None for q, v in zip(t.extra["qual"], t.extra["qual_valid"])]))
+    assert len(got) == 900 and got == want
+    assert st["scan_algo"] == abi.EXG_ALGO_FUSED_FULL
+
+
+def test_reader_non_ascii_batches_start_on_the_general_path_and_come_back(gpu, oracle, tmp_path):
+    """bytes >= 0x80 only in the first megabyte: those batches take the general path (UTF-8 validation) — the second of them
+    starts there —, the first batch without such a byte returns the reader to the fused scans"""
+    head = b"".join(("@r%d caf\u00e9\n" % k).encode() + b"ACGT" * 30 + b"\n+\n" + b"I" * 120 + b"\n" for k in range(4000))
+    tail = bytes(oracle.synth_fastq(332 * 30000))
+    data = head + tail
+    p = tmp_path / "mixed.fastq"
+    p.write_bytes(data)
+    rows, st = _reader_rows(p, "fastq", device_batch_bytes=256 << 10)
+    assert rows == _fastq_rows(oracle, data)
+    assert st["scan_algo"] == abi.EXG_ALGO_FUSED and st["device_batches"] >= 12

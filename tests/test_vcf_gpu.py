@@ -10,7 +10,8 @@ from exon_duckdb_amd import abi
 pytestmark = pytest.mark.gpu
 
 BASE = 0x7E0000000000
-ALGOS = [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS, abi.EXG_ALGO_AUTO]
+ALGOS = [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS, abi.EXG_ALGO_AUTO, abi.EXG_ALGO_FUSED_FULL]
+FUSED = (abi.EXG_ALGO_FUSED, abi.EXG_ALGO_FUSED_FULL)   # the lean scan + the any-shape run over what it marked; the any-shape scan alone
 HDR = b"##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n"
 
 
@@ -43,7 +44,7 @@ def check(oracle, data, algo, expect_fallback=False):
     exp = oracle.vcf_parse(data, payload_base=BASE)
     res, got = run_gpu(data, algo)
     non_ascii = any(b >= 0x80 for b in data)
-    if algo == abi.EXG_ALGO_FUSED and (res.flags & abi.EXG_RF_FALLBACK):
+    if algo in FUSED and (res.flags & abi.EXG_RF_FALLBACK):
         assert expect_fallback or non_ascii
         return res
     assert res.error_code == exp.error_code, (res.error_code, exp.error_code, exp.error_message)
@@ -143,7 +144,7 @@ def test_no_header_is_reported_by_the_oracle_only(oracle):
     assert oracle.vcf_parse(b"1\t5\t.\tA\tC\t.\tPASS\tDP=1\n").error_code == abi.EXG_PE_VCF_NO_HEADER
 
 
-@pytest.mark.parametrize("algo", [abi.EXG_ALGO_MULTIPASS, abi.EXG_ALGO_AUTO, abi.EXG_ALGO_FUSED])
+@pytest.mark.parametrize("algo", ALGOS)
 def test_long_lines_stay_on_the_single_pass(gpu, oracle, algo):
     # multi-sample lines longer than the fused kernel's straddle window: k_vcf_far emits them, no launch is given up
     # (more shapes: tests/test_record_shapes_gpu.py)
@@ -157,7 +158,7 @@ def test_long_lines_stay_on_the_single_pass(gpu, oracle, algo):
     assert res.n_records == 200 and not (res.flags & abi.EXG_RF_FALLBACK)
 
 
-@pytest.mark.parametrize("algo", [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS])
+@pytest.mark.parametrize("algo", [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS, abi.EXG_ALGO_FUSED_FULL])
 def test_qual_parse_is_correctly_rounded(gpu, oracle, algo):
     rng = np.random.default_rng(11)
     quals = []
@@ -318,7 +319,7 @@ def test_random_number_fields(gpu, oracle, seed):
             assert res.error_code != 0 and res.error_record == r, (bad, field)
 
 
-@pytest.mark.parametrize("algo", [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS])
+@pytest.mark.parametrize("algo", [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS, abi.EXG_ALGO_FUSED_FULL])
 def test_projection_and_capacity(gpu, oracle, algo):
     from exon_duckdb_amd import device
 
