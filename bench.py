@@ -275,6 +275,134 @@ def host_pipeline_scaling(path, device_index=0, seconds=1.0):
     return out
 
 
+def _string_t_matches(torch, col, n_rows, off, ln, base, data_t):
+    """column vector rows [0, n_rows) against (offsets, lengths) into the device buffer data_t: length word, 4-byte prefix /
+    inlined bytes, pointer = base + offset — what duckdb::string_t of those slices is (exg_string_t)"""
+    c = col[:n_rows]
+    off_t = torch.from_numpy(off).cuda()
+    ln_t = torch.from_numpy(ln).cuda()
+    ok = bool(((c[:, 0] & 0xFFFFFFFF) == ln_t).all())
+    # bytes 4..7: the first (up to) four bytes of the field
+    pref = torch.zeros_like(ln_t)
+    for j in range(4):
+        pref |= torch.where(ln_t > j, data_t[off_t + j].to(torch.int64), torch.zeros_like(ln_t)) << (8 * j)
+    ok &= bool((((c[:, 0] >> 32) & 0xFFFFFFFF) == pref).all())
+    long_ = ln_t > 12
+    ok &= bool((c[:, 1][long_] == (base + off_t)[long_]).all())
+    if bool((~long_).any()):   # inlined: bytes 8..15 hold bytes 4..11 of the field, zero padded
+        w = torch.zeros_like(ln_t)
+        for j in range(8):
+            w |= torch.where(ln_t > 4 + j, data_t[torch.clamp(off_t + 4 + j, max=data_t.numel() - 1)].to(torch.int64), torch.zeros_like(ln_t)) << (8 * j)
+        ok &= bool((c[:, 1][~long_] == w[~long_]).all())
+    return ok
+
+
+def run_record_shapes(torch, lib, args):
+    """Records of other shapes than BASELINE's 150 bp reads / 49-byte VCF lines, device resident (the
+    reference's line readers run at one rate whatever the record length): HiFi-like 15 kb and ONT-like 1-100 kb reads, 36 bp
+    reads, VCF lines of 100 and 2 504 samples.  A block of whole records from a seeded host generator
+    (exon_duckdb_amd/testing/shapes.py, checked by the oracle in tests/) is tiled to ~args.shape_gb GB in HBM.  Timed: the
+    any-shape scan alone (EXG_ALGO_FUSED_FULL) — what a reader runs from its second batch on, once the lean scan of the
+    first batch came back with EXG_RF_REDO — and, beside it, that first kind of launch (EXG_ALGO_FUSED: lean scan + any-shape
+    run over what it marked).  Verified: no launch gave up (EXG_RF_FALLBACK clear), the row count, and every row of the
+    first, a middle and the last tile against what the generator says its rows are (lengths, prefixes, pointers)."""
+    from exon_duckdb_amd import abi, device
+    from exon_duckdb_amd.testing import shapes
+    out = {}
+    target = int(args.shape_gb * 1e9)
+
+    def tiled(header, block):
+        reps = max(1, target // len(block))
+        n = len(header) + reps * len(block)
+        d = torch.zeros((n + 15) // 16 * 16 + 64, dtype=torch.uint8, device="cuda")
+        if header:
+            d[:len(header)].copy_(torch.frombuffer(bytearray(header), dtype=torch.uint8))
+        d[len(header):n] = torch.frombuffer(bytearray(block), dtype=torch.uint8).cuda().repeat(reps)
+        return d, n, reps
+
+    def fastq_leg(name, what, block, expect):
+        rows_blk = len(expect["name"][0])
+        d_in, n, reps = tiled(b"", block)
+        scan = device.FastqScan(n, capacity_records=rows_blk * reps + 16)
+        scan.launch(d_in, payload_base=BASE, algo=abi.EXG_ALGO_FUSED)
+        r1 = scan.fetch()
+        ms_first, _ = timed_launches(torch, lambda: scan.launch(d_in, payload_base=BASE, algo=abi.EXG_ALGO_FUSED), 3, warm=0)
+        ms, ms_min = timed_launches(torch, lambda: scan.launch(d_in, payload_base=BASE, algo=abi.EXG_ALGO_FUSED_FULL), 6, warm=1)
+        res = scan.fetch()
+        ok = res.error_code == 0 and r1.error_code == 0 and int(res.n_records) == rows_blk * reps == int(r1.n_records)
+        ok = ok and not ((res.flags | r1.flags) & abi.EXG_RF_FALLBACK) and bool(r1.flags & abi.EXG_RF_REDO)
+        if ok:
+            for m in sorted({0, reps // 2, reps - 1}):
+                for k, c in enumerate(["name", "description", "sequence", "quality_scores"]):
+                    col = scan.cols[k][m * rows_blk:(m + 1) * rows_blk]
+                    if expect[c] is None:
+                        ok = ok and not bool(col.any())
+                    else:
+                        off, ln = expect[c]
+                        ok = ok and _string_t_matches(torch, col, rows_blk, off + m * len(block), ln, BASE, d_in)
+        out[name] = {"workload": f"read_fastq, {what}: {n / 1e9:.2f} GB in HBM ({rows_blk * reps} records, a {len(block) / 1e6:.0f} MB block x {reps})",
+                     "algorithmic_bytes": n, "ms": ms, "ms_min": ms_min, "GB/s": n / (ms * 1e-3) / 1e9, "frac": n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "records_per_s": rows_blk * reps / (ms * 1e-3), "algo": "EXG_ALGO_FUSED_FULL (the any-shape scan alone)",
+                     "first_batch_ms": ms_first, "first_batch_GB/s": n / (ms_first * 1e-3) / 1e9,
+                     "first_batch_algo": "EXG_ALGO_FUSED (lean scan + any-shape run over the super-tiles it marked: EXG_RF_REDO)",
+                     "fallback": bool((res.flags | r1.flags) & abi.EXG_RF_FALLBACK), "verified": bool(ok)}
+        del scan, d_in
+        torch.cuda.empty_cache()
+
+    def vcf_leg(name, n_samples, n_lines):
+        hdr, block, e = shapes.vcf_multisample_block(n_lines, n_samples, seed=n_samples)
+        d_in, n, reps = tiled(hdr, block)
+        scan = device.VcfScan(n, capacity_records=n_lines * reps + 16)
+        kw = dict(n_bytes=n, lead=len(hdr), payload_base=BASE)
+        scan.launch(d_in, algo=abi.EXG_ALGO_FUSED, **kw)
+        r1 = scan.fetch()
+        ms_first, _ = timed_launches(torch, lambda: scan.launch(d_in, algo=abi.EXG_ALGO_FUSED, **kw), 3, warm=0)
+        ms, ms_min = timed_launches(torch, lambda: scan.launch(d_in, algo=abi.EXG_ALGO_FUSED_FULL, **kw), 6, warm=1)
+        res = scan.fetch()
+        ok = res.error_code == 0 and r1.error_code == 0 and int(res.n_records) == n_lines * reps == int(r1.n_records)
+        ok = ok and not ((res.flags | r1.flags) & abi.EXG_RF_FALLBACK)
+        if ok:
+            pos = torch.from_numpy(e["pos"]).cuda()
+            chrom = torch.from_numpy(e["chrom"]).cuda()
+            want_chrom = torch.where(chrom < 10, 1 | ((0x30 + chrom) << 32), 2 | ((0x30 + chrom // 10) << 32) | ((0x30 + chrom % 10) << 40))
+            for m in sorted({0, reps // 2, reps - 1}):
+                sl = slice(m * n_lines, (m + 1) * n_lines)
+                ok = ok and bool((scan.pos[sl] == pos).all()) and bool((scan.cols[0][sl][:, 0] == want_chrom).all())
+                off, ln = e["formats"]
+                ok = ok and _string_t_matches(torch, scan.cols[8][sl], n_lines, off + len(hdr) + m * len(block), ln, BASE, d_in)
+            nq = int(e["qual_valid"].sum()) * reps
+            words = (n_lines * reps + 63) // 64
+            bits = scan.qual_valid[:words].clone()
+            if (n_lines * reps) % 64:
+                bits[-1] &= (1 << ((n_lines * reps) % 64)) - 1
+            got = sum(int(((bits >> b) & 1).sum()) for b in range(64))
+            ok = ok and got == nq
+        out[name] = {"workload": f"read_vcf, lines of {n_samples} samples ({len(block) // n_lines} B each): {n / 1e9:.2f} GB in HBM "
+                                 f"({n_lines * reps} lines, a {len(block) / 1e6:.0f} MB block x {reps}), all columns + typed POS / QUAL",
+                     "algorithmic_bytes": n, "ms": ms, "ms_min": ms_min, "GB/s": n / (ms * 1e-3) / 1e9, "frac": n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "lines_per_s": n_lines * reps / (ms * 1e-3), "algo": "EXG_ALGO_FUSED_FULL (the any-shape scan alone)",
+                     "first_batch_ms": ms_first, "first_batch_GB/s": n / (ms_first * 1e-3) / 1e9,
+                     "first_batch_algo": "EXG_ALGO_FUSED (lean scan + any-shape run over the super-tiles it marked)",
+                     "lean_scan_marked_tiles": bool(r1.flags & abi.EXG_RF_REDO),
+                     "fallback": bool((res.flags | r1.flags) & abi.EXG_RF_FALLBACK), "verified": bool(ok)}
+        del scan, d_in
+        torch.cuda.empty_cache()
+
+    def leg(fn, key, *a):
+        try:
+            fn(key, *a)
+        except Exception as e:  # noqa: BLE001
+            out[key] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
+
+    leg(fastq_leg, "fastq_long_hifi", "HiFi-like reads of 15 kb +- 3 kb", *shapes.fastq_long_block(shapes.hifi_lengths(2000, seed=21), seed=21))
+    leg(fastq_leg, "fastq_long_ont", "ONT-like reads, log-uniform 1 - 100 kb", *shapes.fastq_long_block(shapes.ont_lengths(2500, seed=22), seed=22))
+    leg(fastq_leg, "fastq_short_36bp", "36 bp reads, 10-byte name lines (830 lines per 16 KiB)", *shapes.fastq_fixed_block(700000, 36, seed=23))
+    leg(vcf_leg, "vcf_multisample_100", 100, 100000)
+    leg(vcf_leg, "vcf_multisample_2504", 2504, 6000)
+    return out
+
+
 def run_configs(torch, lib, args):
     """BASELINE configs 1, 3, 4 and the end-to-end leg on one GPU -> dicts for the bench line"""
     from exon_duckdb_amd import abi, device
@@ -457,6 +585,7 @@ def main():
     ap.add_argument("--e2e-gb", type=float, default=4.0)
     ap.add_argument("--gz-gb", type=float, default=10.0, help="config 4: compressed GB asked for (BASELINE: 10; bounded by the scratch space and --gz-build-s)")
     ap.add_argument("--gz-build-s", type=float, default=75.0, help="config 4: seconds of host deflate the input may cost (usable cores x ~20 MB/s each)")
+    ap.add_argument("--shape-gb", type=float, default=4.0, help="record_shapes legs: GB of each shape tiled in HBM")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; default) | gloo (functional test of the N>1 path)")
     ap.add_argument("--single-device", action="store_true", help="test only: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
@@ -661,6 +790,10 @@ def main():
                 cfg = {"end_to_end": {"error": f"{type(e).__name__}: {e}"}, "error": f"{type(e).__name__}: {e}"}
             out["end_to_end"] = cfg.pop("end_to_end", None)
             out["configs"] = cfg
+            try:
+                out["record_shapes"] = run_record_shapes(torch, lib, args)
+            except Exception as e:  # noqa: BLE001
+                out["record_shapes"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline()

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 from exon_duckdb_amd import abi
+from exon_duckdb_amd.testing.shapes import fastq_records, vcf_lines
 
 from test_fastq_gpu import BASE as FQ_BASE, NAMES, check_against_oracle, run_gpu as run_fastq
 from test_vcf_gpu import HDR, check as check_vcf, header_bytes, run_gpu as run_vcf
@@ -18,22 +19,6 @@ from test_vcf_gpu import HDR, check as check_vcf, header_bytes, run_gpu as run_v
 pytestmark = pytest.mark.gpu
 
 FUSED_AND_PARTNER = [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_FUSED_FULL, abi.EXG_ALGO_MULTIPASS]
-
-
-def fastq_records(lengths, seed=1, crlf_every=0, desc_every=2, name_len=None):
-    rng = np.random.default_rng(seed)
-    acgt = np.frombuffer(b"ACGT", np.uint8)
-    out = []
-    for k, ln in enumerate(lengths):
-        ln = int(ln)
-        eol = b"\r\n" if crlf_every and k % crlf_every == 0 else b"\n"
-        name = b"@r%d" % k if name_len is None else b"@" + (b"%d" % k).rjust(name_len, b"n")
-        if desc_every and k % desc_every == 0:
-            name += b" len=%d ch=%d" % (ln, k % 512)
-        seq = rng.choice(acgt, ln).tobytes()
-        qual = (rng.integers(33, 74, ln, dtype=np.uint8)).tobytes()   # includes '@' and '+'
-        out.append(name + eol + seq + eol + b"+" + eol + qual + eol)
-    return b"".join(out)
 
 
 def no_fallback(res):
@@ -210,25 +195,6 @@ def test_short_reads_errors_and_eof(gpu, oracle, algo):
 
 
 # ---- wide VCF lines ---------------------------------------------------------------------------------------------------
-
-def vcf_lines(n_lines, n_samples, seed=1, crlf_every=0):
-    rng = np.random.default_rng(seed)
-    gts = [b"0|0", b"0|1", b"1|0", b"1|1", b".|."]
-    smp = b"\t".join(b"S%05d" % i for i in range(n_samples))
-    hdr = HDR[:-1] + (b"\tFORMAT\t" + smp if n_samples else b"") + b"\n"
-    out = [hdr]
-    for k in range(n_lines):
-        eol = b"\r\n" if crlf_every and k % crlf_every == 0 else b"\n"
-        qual = b"." if k % 9 == 0 else b"%d.%d" % (k % 1000, k % 10)
-        info = b"AC=%d;AF=0.%04d;AN=%d;NS=%d;DP=%d;VT=SNP" % (k % 5008, k % 10000, 2 * n_samples, n_samples, 1000 + k)
-        line = b"%d\t%d\trs%d\t%s\t%s\t%s\tPASS\t%s" % (k % 22 + 1, 10000 + 37 * k, k, b"ACGT"[k % 4:k % 4 + 1],
-                                                           b"ACGT"[(k + 1) % 4:(k + 1) % 4 + 1], qual, info)
-        if n_samples:
-            idx = rng.integers(0, 5, n_samples)
-            line += b"\tGT\t" + b"\t".join(gts[i] for i in idx)
-        out.append(line + eol)
-    return b"".join(out)
-
 
 @pytest.mark.parametrize("algo", FUSED_AND_PARTNER)
 @pytest.mark.parametrize("n_samples,n_lines", [(100, 600), (2504, 120), (300, 300), (40000, 6)])
