@@ -157,6 +157,7 @@ static int plan_bgzf_shard(exg_reader *r, const std::string &path, uint64_t n, u
         bytes_follow = m.out_cap != 0;
         q = nx;
     }
+    r->own_c_begin = first_own;
     r->range_preset = true;
     r->preset_pos = halo_bytes;  // inflated bytes of the members in front of its own
     r->range_eof = !bytes_follow;
@@ -229,6 +230,7 @@ static int open_source(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const s
             int rc = plan_zstd_shard(r, fd, n, path, fasta ? 1 : r->halo_want, header_bytes, &c_begin, &c_end, &own_lo, &own_hi, &bytes_follow);
             if (rc) return rc;
             marks[0] = own_lo;
+            r->own_c_begin = own_lo;
             if (fasta) {
                 c_end = n;
                 marks[1] = own_hi >= n ? ~0ull : own_hi;
@@ -239,21 +241,26 @@ static int open_source(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const s
         r->src = make(c_begin, c_end, true, marks);
         if (wait_own) {
             // The decoder tells where the shard's own bytes begin (mark 0) when it gets there; until then the halo's segments
-            // are taken one by one — never a blocking wait for the mark: the decoder cannot run further ahead than its queue
+            // are taken one by one — never a blocking wait for the mark: the decoder cannot run further ahead than its queue —
+            // and only the newest `keep` bytes of them stay: a halo is made of whole frames / members, and with few large
+            // frames in front of the shard everything from the stream's first byte would otherwise be resident (and copied
+            // again for every segment more) before the shard's first row
             uint64_t own = 0;
-            for (uint64_t want = 1; !r->src->peek_mark(0, &own);) {
+            const uint64_t keep = std::max<uint64_t>(fasta ? 0 : r->halo_want, 256u << 10) + (64u << 10);
+            for (uint64_t pos = 0, end = 0; !r->src->peek_mark(0, &own);) {
+                if (end - pos > keep) pos = (end - keep) & ~15ull;  // (what lies in front of it is dropped by the acquire)
                 const uint8_t *d_at = nullptr;
                 uint64_t avail = 0;
                 bool eof = false;
                 std::string msg;
-                int rc = r->src->acquire(0, want, &d_at, &avail, &eof, &msg);
+                int rc = r->src->acquire(pos, end - pos + 1, &d_at, &avail, &eof, &msg);  // one segment more
                 if (rc) return fail(r, rc, msg);
                 if (r->src->peek_mark(0, &own)) break;
                 if (eof) {
                     own = ~0ull >> 1;  // (behind everything: the stream holds nothing of this shard's)
                     break;
                 }
-                want = avail + 1;  // one segment more
+                end = pos + avail;
             }
             r->range_preset = true;
             r->preset_pos = own;
@@ -272,6 +279,47 @@ static int open_source(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const s
     }
     blk = out_blk;
     return EXG_OK;
+}
+
+// Newlines in the decoded bytes of the members / frames in front of a shard's own (file bytes [0, own_c_begin)), by a decoder
+// of their own: a segment is counted on the device and dropped, nothing but it is resident (the phase of a shard of a
+// compressed FASTQ when the bytes around the cut do not tell it: a memchr over the page cache in the text case).
+static int count_newlines_in_front(exg_reader *r, uint64_t *out) {
+    *out = 0;
+    if (!r->own_c_begin) return EXG_OK;
+    const std::string &path = r->files[r->file_idx - 1];
+    const int fd = r->fd_keep->fd;
+    struct stat st;
+    if (fstat(fd, &st)) return fail(r, EXG_E_IO, "cannot stat '" + path + "'");
+    const uint64_t reserve = source_reserve(r), target = r->device_batch_bytes;
+    std::unique_ptr<SegmentProducer> prod = r->compression == kGzip
+                                                ? make_gzip_producer(r, fd, 0, r->own_c_begin, target, path, true, reserve, nullptr)
+                                                : make_zstd_producer(r, fd, (uint64_t)st.st_size, 0, r->own_c_begin, target, path, reserve, nullptr);
+    DecodedSource head(r->device, r->stream, std::move(prod), reserve, 1, &r->meter);
+    if (!r->d_phase && !(r->d_phase = exg_rd::dev_pool()->take(r->device, 4096))) return fail(r, EXG_E_HIP, "out of device memory");
+    for (uint64_t pos = 0;;) {
+        const uint8_t *d_at = nullptr;
+        uint64_t avail = 0;
+        bool eof = false;
+        std::string msg;
+        int rc = head.acquire(pos, 1, &d_at, &avail, &eof, &msg);
+        if (rc) return fail(r, rc, msg);
+        if (avail) {
+            unsigned long long nl = 0;
+            const uint64_t skew = pos & 15;  // (an address is congruent to its stream offset mod 16)
+            rc = exg_count_newlines(d_at - skew, skew, skew + avail, (uint64_t *)r->d_phase, r->stream);
+            if (rc) return fail(r, rc, exg_last_error_message());
+            RD_HIP(r, hipMemcpyAsync(&nl, r->d_phase, 8, hipMemcpyDeviceToHost, r->stream));
+            RD_HIP(r, hipStreamSynchronize(r->stream));
+            *out += nl;
+            pos += avail;
+        }
+        if (eof) break;
+        if (!avail) return fail(r, EXG_E_HIP, "internal: a decoded source returned nothing before its end");
+    }
+    std::string e;
+    const int frc = head.finish(&e);
+    return frc ? fail(r, frc, e) : EXG_OK;
 }
 
 int open_next_file(exg_reader *r) {
@@ -310,6 +358,8 @@ int open_next_file(exg_reader *r) {
     r->range_preset = false;
     r->range_eof = true;
     r->data0_is_line_start = true;
+    r->own_c_begin = 0;
+    r->exact_nl_known = false;
     (void)r->join_prefetch();
     r->drop_prefetch2();
     if (r->pf.valid && r->up_stream) (void)hipStreamSynchronize(r->up_stream);  // a prefetch of the previous file
@@ -669,23 +719,22 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
                 }
                 first_line_index = prev == '\n' ? guess : (guess + 3) % 4;
             } else if (r->src) {
-                // BGZF shard: exact only when the halo begins with the file (the newlines in front are then all in HBM)
-                if (!(r->data0_is_line_start && lead == r->file_pos)) {
-                    // (few lines in view — records far longer than the halo — or several phases fit): the stream is taken
-                    // from the start of the file, where the count is exact
-                    if (r->halo_want == ~0ull)
-                        return fail(r, EXG_E_PARSE, "cannot tell the FASTQ record phase at the shard boundary of '" + r->files[r->file_idx - 1] + "'");
-                    r->halo_want = ~0ull;
-                    r->src.reset();
-                    r->file_idx--;
-                    if ((rc = open_next_file(r))) return rc;
-                    continue;
-                }
+                // a shard of a compressed input: exact when the halo begins with the file (the newlines in front are then all
+                // in HBM); else (few lines in view — records far longer than the halo — or several phases fit) the newlines in
+                // front of the shard's own bytes are counted by a decoder of their own, segment by segment
                 unsigned long long nl = 0;
-                rc = exg_count_newlines(d_input, 0, lead, (uint64_t *)r->d_phase, r->stream);
-                if (rc) return fail(r, rc, exg_last_error_message());
-                RD_HIP(r, hipMemcpyAsync(&nl, r->d_phase, 8, hipMemcpyDeviceToHost, r->stream));
-                RD_HIP(r, hipStreamSynchronize(r->stream));
+                if (r->data0_is_line_start && lead == r->file_pos) {
+                    rc = exg_count_newlines(d_input, 0, lead, (uint64_t *)r->d_phase, r->stream);
+                    if (rc) return fail(r, rc, exg_last_error_message());
+                    RD_HIP(r, hipMemcpyAsync(&nl, r->d_phase, 8, hipMemcpyDeviceToHost, r->stream));
+                    RD_HIP(r, hipStreamSynchronize(r->stream));
+                } else {
+                    if (!r->exact_nl_known) {
+                        if ((rc = count_newlines_in_front(r, &r->exact_nl))) return rc;
+                        r->exact_nl_known = true;
+                    }
+                    nl = r->exact_nl;
+                }
                 first_line_index = nl;
             } else {
                 // too few lines around the cut to tell (a tiny file, a tiny shard) or several phases fit: count the

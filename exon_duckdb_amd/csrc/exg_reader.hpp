@@ -356,6 +356,12 @@ struct exg_reader {
     // (EXG_RF_HEAD_UNRESOLVED) the halo is grown eightfold and the batch scanned again, up to the first byte of the data:
     // a record of any length across a cut is found, like the unsharded scan finds it
     uint64_t halo_want = 0;
+    // a shard of a compressed FASTQ whose 4-line phase cannot be told from the bytes around the cut: the newlines in front of
+    // its own bytes are COUNTED, by a decoder of their own over the members / frames in front (own_c_begin: where the shard's
+    // own begin in the file), segment by segment — the prefix is never resident
+    uint64_t own_c_begin = 0;
+    bool exact_nl_known = false;
+    uint64_t exact_nl = 0;
     bool fa_shard = false;     // a shard of a compressed FASTA: file_pos is its first record, fa_end (once known) the first that is not its own
     uint64_t fa_end = ~0ull;
     bool range_eof = true;    // range_hi is the end of the file's data (a later shard follows otherwise)

@@ -215,7 +215,10 @@ struct VcfFormat {
     static constexpr int kNlCap = 1024;  // short data lines are common
     static constexpr int kHalves = kVcfHalves;
     static constexpr bool kTabMap = true;
-    static constexpr int kMinWavesPerSimd = 5;
+#ifndef EXG_VCF_WAVES
+#define EXG_VCF_WAVES 5
+#endif
+    static constexpr int kMinWavesPerSimd = EXG_VCF_WAVES;
     static constexpr int kMinWavesPerSimdFull = 4;  // the any-shape instances (their pass loop and FarRec code want registers)
     __device__ static __forceinline__ uint32_t eof_extra_lines(unsigned long long) { return 0; }
     __device__ static __forceinline__ unsigned long long analytic_prefix(uint64_t) { return 0; }

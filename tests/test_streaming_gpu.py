@@ -233,3 +233,51 @@ def test_zstd_checksum_of_a_frame_that_spans_rounds(gpu, oracle, tmp_path, monke
     with pytest.raises(ExgError, match="checksum"):
         r.rows()
     r.close()
+
+
+def _shard_rows(path, fmt, n_shards, **kw):
+    rows, peaks = [], []
+    for k in range(n_shards):
+        r = _open(path, fmt, shard_index=k, shard_count=n_shards, **kw)
+        rows.extend(r.rows())
+        peaks.append(r.stats()["device_bytes_peak"])
+        r.close()
+    return rows, peaks
+
+
+def test_zstd_shard_behind_large_frames_holds_a_halo_not_the_frames(gpu, oracle, tmp_path, monkeypatch):
+    """three frames of ~45 MB of FASTQ each, three shards: a shard's halo is the whole frame in front of its own.  Only the
+    newest bytes of it stay resident while the decoder works its way to the shard's first byte (advisor, round 3: everything
+    from the stream's first byte was, and was copied again for every segment more)."""
+    from zstd_util import compress
+    data = bytes(oracle.synth_fastq(332 * 400000))
+    third = len(data) // 3 // 332 * 332
+    parts = [data[:third + 100], data[third + 100:2 * third + 7], data[2 * third + 7:]]   # frames cut inside records
+    p = tmp_path / "frames.fastq.zst"
+    p.write_bytes(b"".join(compress(x, 1, True) for x in parts))
+    exp = oracle.fastq_parse(data, want_string_t=False)
+    want = list(zip(*[exp.columns[c].to_list() for c in ["name", "description", "sequence", "quality_scores"]]))
+    monkeypatch.setenv("EXG_DEVICE_MEM_CAP_MB", str(CAP_MB))
+    rows, peaks = _shard_rows(p, "fastq", 3)
+    assert rows == want
+    assert max(peaks) <= CAP_MB << 20, [x >> 20 for x in peaks]
+
+
+def test_bgzf_shard_whose_phase_is_counted_holds_no_prefix(gpu, oracle, tmp_path, monkeypatch):
+    """reads of 0.4 - 2 MB behind a 64 KiB halo: the 4-line phase of a late shard cannot be told from the bytes around its cut
+    — the newlines in front of its members are counted by a decoder of their own, segment by segment, under the cap (advisor,
+    round 3: the whole decoded prefix had to be resident)."""
+    import numpy as np
+    from exon_duckdb_amd.testing.shapes import fastq_records
+    lengths = np.random.default_rng(4).integers(400_000, 2_000_000, 60)
+    data = bytes(fastq_records(lengths, seed=31))
+    assert len(data) > 8 * (CAP_MB << 20)
+    p = tmp_path / "huge_reads.fastq.gz"
+    p.write_bytes(_bgzf(data))
+    exp = oracle.fastq_parse(data, want_string_t=False)
+    want = list(zip(*[exp.columns[c].to_list() for c in ["name", "description", "sequence", "quality_scores"]]))
+    monkeypatch.setenv("EXG_SHARD_HALO", str(64 << 10))
+    monkeypatch.setenv("EXG_DEVICE_MEM_CAP_MB", str(4 * CAP_MB))   # (a 2 MB read x 2 + its window must fit a batch)
+    rows, peaks = _shard_rows(p, "fastq", 5)
+    assert rows == want
+    assert max(peaks) <= (4 * CAP_MB) << 20, [x >> 20 for x in peaks]

@@ -13,12 +13,12 @@ scan = device.VcfScan(n, capacity_records=n_lines + 16)
 out = {}
 for label, proj in (("all_columns", None), ("chrom_pos_only", {0})):
     for _ in range(2):
-        scan.launch(d_in, n_bytes=n, lead=hdr, algo=abi.EXG_ALGO_AUTO, project=proj)
+        scan.launch(d_in, n_bytes=n, lead=hdr, algo=abi.EXG_ALGO_FUSED, project=proj)
     torch.cuda.synchronize()
     ev = []
     for _ in range(7):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); scan.launch(d_in, n_bytes=n, lead=hdr, algo=abi.EXG_ALGO_AUTO, project=proj); b.record(); ev.append((a, b))
+        a.record(); scan.launch(d_in, n_bytes=n, lead=hdr, algo=abi.EXG_ALGO_FUSED, project=proj); b.record(); ev.append((a, b))
     torch.cuda.synchronize()
     ms = sorted(x.elapsed_time(y) for x, y in ev)[3]
     r = scan.fetch()
