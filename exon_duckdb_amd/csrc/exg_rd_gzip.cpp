@@ -704,7 +704,11 @@ int GzipProducer::big_member(SegmentSink &sink, uint64_t stream_off, std::string
                 trc = EXG_E_PARSE;
             }
             if (trc) {
-                sink.give(seg.buf, seg.cap);
+                // the rows of this round are handed out before the error, like a streaming decoder hands out what it decoded
+                // before it fails at the trailer (flate2 behind a BufReader: rust/src/arrow_reader.rs:60-91); the zstd
+                // producer does the same with a Content_Checksum
+                pushed_last_ = false;
+                (void)sink.push(std::move(seg));
                 return trc;
             }
             c_pos_ = trailer + 8;

@@ -151,7 +151,15 @@ int DecodedSource::acquire(uint64_t pos, uint64_t want, const uint8_t **d_pos, u
         if (cur_.last || pos + want <= cur_.hi) break;
         Segment nx;
         const int rc = pop(&nx, err);
-        if (rc) return rc;
+        if (rc) {
+            // the producer failed (a checksum behind the last block, a corrupt member further on): what was decoded in front of
+            // the error is handed out first — fewer bytes than asked for, not the stream's end —, the error at the next call
+            if (!error_deferred_ && cur_.hi > pos) {
+                error_deferred_ = true;
+                break;
+            }
+            return rc;
+        }
         if (!nx.buf) {
             *err = "decoded stream ended without its last segment";
             return EXG_E_INVALID_ARG;

@@ -105,6 +105,7 @@ private:
     bool mark_set_[2] = {false, false};
     Segment cur_;
     bool have_cur_ = false;
+    bool error_deferred_ = false;  // the producer's error was met while bytes in front of it were still to be handed out
     uint64_t n_consumed_ = 0;
 };
 

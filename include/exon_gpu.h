@@ -314,7 +314,9 @@ int exg_inflate_stream(const void *d_comp, uint64_t comp_off, uint64_t comp_size
  * (or just behind) the last block start found and does not look at the stream's end; need_more != 0 on return means no
  * block start was found in the window (call again with more bytes; nothing was produced).  d_window: 32768 bytes of device
  * memory that carry the LZ77 window from round to round (have_window = 0 for a member's first round; updated in place).
- * front_reserve (a multiple of 16) bytes stay free in front of the output: d_out + front_reserve is its first byte. */
+ * front_reserve bytes stay free in front of the output: d_out + front_reserve is its first byte (any value; a caller that
+ * wants an address congruent to the stream offset mod 16 — the decoded segments of the reader — passes reserve + (offset & 15)
+ * with a 16-byte aligned reserve). */
 typedef struct exg_inflate_round_args {
     const void *d_comp;
     uint64_t comp_off, comp_size;

@@ -199,3 +199,12 @@ def test_round_size_does_not_change_the_rows(gpu, fastq_mid, tmp_path, monkeypat
     zb.write_bytes(bytes(bad))
     rows, msg = _expect_error(zb, "fastq", min_rows_before=int(want[0] * 0.9))
     assert "checksum" in msg.lower(), msg
+    # ... and in the gzip member's trailer (CRC-32, then ISIZE): the rows of the final round too come before the error (advisor,
+    # round 3: the last round's segment — a single-member file's only one without a cap — went back to the pool unseen)
+    for at in (-5, -1):
+        bad = bytearray(one.read_bytes())
+        bad[at] ^= 0x40
+        gb = tmp_path / "bad.fastq.gz"
+        gb.write_bytes(bytes(bad))
+        rows, msg = _expect_error(gb, "fastq", min_rows_before=int(want[0] * 0.99))
+        assert "checksum" in msg.lower(), msg
