@@ -798,6 +798,15 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             a.flags = fl;
             a.algo = general_now ? EXG_ALGO_MULTIPASS : r->fused_algo;
             for (int c = 0; c < 9; c++) a.d_fields[c] = (exg_string_t *)r->d_cols[c];
+            if (!r->arrow_emit) {
+                // The projection reaches the kernel (a NULL column is skipped: 16 B per row less to write): POS / QUAL leave as
+                // numbers, their text is nobody's; CHROM / REF are written when they are selected or the predicate reads them.
+                // The other five feed the nested columns, which are built — and validated: a malformed value is the same error
+                // whether or not its column is selected — from their text
+                a.d_fields[1] = a.d_fields[5] = nullptr;
+                for (int c : {0, 3})
+                    if (!r->want(c) && !((r->filter_cols >> c) & 1ull)) a.d_fields[c] = nullptr;
+            }
             a.d_pos = (int64_t *)r->d_pos;
             a.d_qual = (float *)r->d_qual;
             a.d_qual_validity = (uint64_t *)r->d_valid[0];

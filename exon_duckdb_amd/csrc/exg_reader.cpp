@@ -113,6 +113,8 @@ extern "C" int exg_open(const exg_open_args *args, exg_reader **out) {
             return EXG_E_HIP;
         }
         r->has_filter = true;
+        for (uint32_t k = 0; k < fp.prog.n_ops; k++)
+            if (fp.prog.ops[k].op != exg::arrow::kOpAnd && fp.prog.ops[k].op != exg::arrow::kOpOr) r->filter_cols |= 1ull << fp.prog.ops[k].col;
     }
     if (args->shard_count == 0) {
         // several devices (or stripes forced): this reader becomes the front of a fan-out

@@ -382,6 +382,7 @@ struct exg_reader {
     bool general_first = false;
     // exg_open_args.filters: postfix program + constants in device memory, a row map and one column of scratch
     bool has_filter = false;
+    uint64_t filter_cols = 0;  // the columns the predicate reads (bit c: schema column c)
     void *d_filter_prog = nullptr, *d_filter_consts = nullptr;  // pooled
     size_t filter_prog_bytes = 0, filter_consts_bytes = 0;
     void *d_row_map = nullptr, *d_gather = nullptr, *d_filter_tmp = nullptr;  // output vectors sized for the densest possible input (after an overflow)
