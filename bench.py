@@ -272,6 +272,20 @@ def host_pipeline_scaling(path, device_index=0, seconds=1.0):
         c = tl.exon_tf_host_pipeline_probe(path.encode(), n, t, 0, device_index, seconds) if t != 8 else a
         out["readers"][str(n)] = {"pinned_GB/s": round(a / 1e9, 2) if a > 0 else None, "with_h2d_GB/s": round(b / 1e9, 2) if b > 0 else None,
                                   "threads_each_adaptive": t, "pinned_adaptive_GB/s": round(c / 1e9, 2) if c > 0 else None}
+    # the same bytes WITHOUT the bounce copy (round 3's verdict asked for the measurement): hipHostRegister of 256 MiB windows of the
+    # file's mapping, H2D straight from the page cache.  One reader: over one warm mapping (the windows' page-table entries exist
+    # from the second pass on) and with a fresh mapping per window (what a reader that sees every byte once pays: the registration
+    # makes 65 536 entries per window).  Not adopted: see DESIGN 5.
+    try:
+        ms1, ms3 = C.c_double(0), C.c_double(0)
+        z1 = tl.exon_tf_host_zero_bounce_probe(path.encode(), 1, 1, device_index, 1.0, C.byref(ms1))
+        z3 = tl.exon_tf_host_zero_bounce_probe(path.encode(), 1, 3, device_index, 1.0, C.byref(ms3))
+        out["zero_bounce_1_reader"] = {"what": "hipHostRegister of 256 MiB windows of the file mapping + H2D from them (no CPU copy)",
+                                       "warm_mapping_GB/s": round(z1 / 1e9, 2) if z1 > 0 else None, "warm_register_ms_per_window": round(ms1.value, 2),
+                                       "fresh_mapping_per_window_GB/s": round(z3 / 1e9, 2) if z3 > 0 else None,
+                                       "fresh_register_ms_per_window": round(ms3.value, 2), "adopted": False}
+    except Exception as e:  # noqa: BLE001
+        out["zero_bounce_1_reader"] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 

@@ -15,6 +15,8 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <memory>
 #include <string>
 #include <thread>
@@ -366,4 +368,171 @@ extern "C" double exon_tf_host_pipeline_probe(const char *path, int n_readers, i
     }
     close(fd);
     return ok ? (double)moved.load() / dt : -1;
+}
+
+
+// ---- the same question without the bounce copy ------------------------------------------------------------------------------
+// mode 1: zero-bounce — every reader maps the file and, window by window (256 MiB), REGISTERS the mapping's pages with the
+//         runtime (hipHostRegister: pins the page cache pages themselves), sends the window to the device straight from them
+//         (hipMemcpyAsync from registered memory is a DMA like one from a pinned block) and unregisters it behind the copy; a
+//         helper thread per reader registers one window ahead.  No CPU touches the bytes.  The windows cycle over ONE mapping:
+//         from the second pass on their page-table entries exist (what a file read twice through one mapping sees).
+// mode 3: the same with a FRESH mapping per window (mmap, register, send, unregister, munmap): what a reader that sees every
+//         byte once pays — the page-table entries of 65 536 pages per window are made by the registration;
+// mode 4: mode 3 with the window's entries made first by four threads (madvise MADV_POPULATE_READ on a quarter each).
+// mode 2: O_DIRECT — pread with O_DIRECT into the pinned block (no page cache, no second copy; what a cold file wants), then
+//         the H2D copy.  Returns -2 when the file system refuses O_DIRECT (tmpfs does).
+// -> aggregate bytes per second over `seconds`, or < 0.  *register_ms (mode 1): average ms per hipHostRegister + Unregister pair.
+extern "C" double exon_tf_host_zero_bounce_probe(const char *path, int n_readers, int mode, int device, double seconds, double *register_ms) {
+    if (register_ms) *register_ms = 0;
+    if (!path || n_readers < 1 || mode < 1 || mode > 4) return -1;
+    int fd = open(path, O_RDONLY | (mode == 2 ? O_DIRECT : 0));
+    if (fd < 0) return mode == 2 ? -2 : -1;
+    struct stat st;
+    fstat(fd, &st);
+    const uint64_t n = (uint64_t)st.st_size;
+    const size_t window = 256u << 20;
+    if (n < (uint64_t)n_readers * window) {
+        close(fd);
+        return -1;
+    }
+    (void)hipSetDevice(device);
+    std::atomic<uint64_t> moved{0};
+    std::atomic<bool> stop{false}, failed{false};
+    std::atomic<uint64_t> reg_ns{0}, reg_n{0};
+    auto now_ns = [] {
+        struct timespec t;
+        clock_gettime(CLOCK_MONOTONIC, &t);
+        return (uint64_t)t.tv_sec * 1000000000ull + (uint64_t)t.tv_nsec;
+    };
+    char *map = nullptr;
+    if (mode != 2) {
+        map = (char *)mmap(nullptr, n, PROT_READ, MAP_SHARED, fd, 0);
+        if (map == MAP_FAILED) {
+            close(fd);
+            return -1;
+        }
+    }
+    std::vector<std::thread> th;
+    const uint64_t t0 = now_ns();
+    for (int r = 0; r < n_readers; r++)
+        th.emplace_back([&, r] {
+            (void)hipSetDevice(device);
+            void *dev = nullptr;
+            hipStream_t s = nullptr;
+            char *pin = nullptr;
+            if (hipMalloc(&dev, window) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+                failed = true;
+                return;
+            }
+            const uint64_t lo = n / (uint64_t)n_readers * (uint64_t)r, span = n / (uint64_t)n_readers / window * window;
+            if (mode == 2) {
+                if (hipHostMalloc((void **)&pin, window, hipHostMallocDefault) != hipSuccess) failed = true;
+                for (uint64_t i = 0; !stop && !failed; i++) {
+                    const uint64_t off = lo + (i * window) % span;
+                    size_t got = 0;
+                    while (got < window) {
+                        const ssize_t k = pread(fd, pin + got, window - got, (off_t)(off + got));
+                        if (k <= 0) {
+                            failed = true;
+                            break;
+                        }
+                        got += (size_t)k;
+                    }
+                    if (hipMemcpyAsync(dev, pin, window, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) failed = true;
+                    moved += window;
+                }
+            } else {
+                // window i is registered by the helper while window i - 1 travels
+                std::mutex mu;
+                std::condition_variable cv;
+                uint64_t registered = 0, released = 0;  // windows registered / unregistered so far
+                bool done = false;
+                char *fresh[4] = {nullptr, nullptr, nullptr, nullptr};  // modes 3 / 4: the windows' own mappings
+                std::thread helper([&] {
+                    (void)hipSetDevice(device);
+                    for (uint64_t i = 0;; i++) {
+                        {
+                            std::unique_lock<std::mutex> lk(mu);
+                            cv.wait(lk, [&] { return done || i < released + 2; });  // at most two windows pinned at a time
+                            if (done) return;
+                        }
+                        const uint64_t t1 = now_ns();
+                        char *w = map + lo + (i * window) % span;
+                        if (mode >= 3) {
+                            w = (char *)mmap(nullptr, window, PROT_READ, MAP_SHARED, fd, (off_t)(lo + (i * window) % span));
+                            if (w == MAP_FAILED) {
+                                failed = true;
+                                w = nullptr;
+                            }
+                            if (w && mode == 4) {
+                                std::vector<std::thread> pop;
+                                for (int q = 0; q < 4; q++) pop.emplace_back([w, q] { (void)madvise(w + (size_t)q * (window / 4), window / 4, 22 /* MADV_POPULATE_READ */); });
+                                for (auto &t : pop) t.join();
+                            }
+                            std::lock_guard<std::mutex> g(mu);
+                            fresh[i & 3] = w;
+                        }
+                        if (w && hipHostRegister(w, window, hipHostRegisterDefault) != hipSuccess) {
+                            (void)hipGetLastError();
+                            failed = true;
+                        }
+                        reg_ns += now_ns() - t1;
+                        std::lock_guard<std::mutex> g(mu);
+                        registered = i + 1;
+                        cv.notify_all();
+                        if (failed) return;
+                    }
+                });
+                for (uint64_t i = 0; !stop && !failed; i++) {
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return registered > i || failed.load(); });
+                    }
+                    if (failed) break;
+                    char *src = map + lo + (i * window) % span;
+                    if (mode >= 3) {
+                        std::lock_guard<std::mutex> g(mu);
+                        src = fresh[i & 3];
+                    }
+                    if (hipMemcpyAsync(dev, src, window, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) failed = true;
+                    const uint64_t t1 = now_ns();
+                    (void)hipHostUnregister(src);
+                    if (mode >= 3) munmap(src, window);
+                    reg_ns += now_ns() - t1;
+                    reg_n++;
+                    moved += window;
+                    std::lock_guard<std::mutex> g(mu);
+                    released = i + 1;
+                    cv.notify_all();
+                }
+                {
+                    std::lock_guard<std::mutex> g(mu);
+                    done = true;
+                    cv.notify_all();
+                }
+                helper.join();
+                // (a window the helper registered and nobody sent)
+                {
+                    for (uint64_t i = released; i < registered; i++) {
+                        char *w = mode >= 3 ? fresh[i & 3] : map + lo + (i * window) % span;
+                        if (!w) continue;
+                        (void)hipHostUnregister(w);
+                        if (mode >= 3) munmap(w, window);
+                    }
+                }
+            }
+            if (pin) (void)hipHostFree(pin);
+            (void)hipStreamDestroy(s);
+            (void)hipFree(dev);
+        });
+    struct timespec ts = {(time_t)seconds, (long)((seconds - (time_t)seconds) * 1e9)};
+    nanosleep(&ts, nullptr);
+    stop = true;
+    for (auto &t : th) t.join();
+    const double dt = (double)(now_ns() - t0) * 1e-9;
+    if (map) munmap(map, n);
+    close(fd);
+    if (register_ms && reg_n.load()) *register_ms = (double)reg_ns.load() / (double)reg_n.load() * 1e-6;
+    return failed ? -1 : (double)moved.load() / dt;
 }
