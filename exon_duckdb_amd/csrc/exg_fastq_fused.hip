@@ -51,6 +51,13 @@ struct FastqFormat;
 static constexpr int kFastqHalves = 3;  // 48 KiB per workgroup: A/B on one box 2 -> 3 halves +3 %, 4 halves -7 %
 
 
+// a field that is not UTF-8 (exon's FASTQArrayBuilder: from_utf8 on name, description, sequence, quality): the record's error
+// unless a structural one (smaller code) is its
+__device__ __forceinline__ void fastq_report_utf8(ScanWsHeader *hdr, long long out, int64_t rec_off) {
+    atomicMin(&hdr->err_word, ((unsigned long long)out << 8) | EXG_PE_INVALID_UTF8);
+    atomicMin(&hdr->err_off, (unsigned long long)rec_off);
+}
+
 // Records that END in the half staged in LDS: wave = column, lane = record.
 template <int kMode, class L>
 __device__ __forceinline__ void fastq_emit_half(const L &s, const FastqDev &a, ScanWsHeader *hdr, const TileCtx &c,
@@ -121,7 +128,7 @@ __device__ __forceinline__ void fastq_emit_half(const L &s, const FastqDev &a, S
                 // super-tile; any-shape scan: k_fastq_far's row (the FarRec above)
                 if constexpr (kMode == kLean) {
                     if (wave == 0) {
-                        tile_redo_of(tile_qend, a.n_bytes)[tile_index / kFastqHalves] = kRedoFar;
+                        tile_redo_of(tile_qend, a.n_bytes)[opaque_s((uint32_t)(tile_index / kFastqHalves))] = kRedoFar;
                         hdr->any_redo = 1u;
                     }
                 }
@@ -156,9 +163,15 @@ __device__ __forceinline__ void fastq_emit_half(const L &s, const FastqDev &a, S
                         atomicMin(&hdr->err_off, (unsigned long long)((int64_t)c.tile_off + s0 - kWin));
                     }
                     val = make_string_lds(s, ns, (uint32_t)(sp - ns), ptr_of_e0);
+                    if constexpr (kMode != kLean) {
+                        if (c.non_ascii && !utf8_valid_lds(s, ns, sp)) fastq_report_utf8(hdr, out, (int64_t)c.tile_off + s0 - kWin);
+                    }
                 } else {
                     desc_valid = e0 > ds;
                     if (desc_valid) val = make_string_lds(s, ds, (uint32_t)(e0 - ds), ptr_of_e0);
+                    if constexpr (kMode != kLean) {
+                        if (c.non_ascii && !utf8_valid_lds(s, ds, e0)) fastq_report_utf8(hdr, out, (int64_t)c.tile_off + s0 - kWin);
+                    }
                 }
             } else {
                 // wave 2: sequence = line 1 (+ '+' check on line 2); wave 3: quality = line 3
@@ -176,6 +189,9 @@ __device__ __forceinline__ void fastq_emit_half(const L &s, const FastqDev &a, S
                     atomicMin(&hdr->err_off, (unsigned long long)((int64_t)c.tile_off + (int)q0 + 1 - kWin));
                 }
                 val = make_string_lds(s, sk, (uint32_t)(ek - sk), ptr_of_e0);
+                if constexpr (kMode != kLean) {
+                    if (c.non_ascii && !utf8_valid_lds(s, sk, ek)) fastq_report_utf8(hdr, out, (int64_t)c.tile_off + (int)q0 + 1 - kWin);
+                }
             }
             // dev_mode 2 keeps the values live but (practically) never stores
             if (!no_store && (dev_mode != 2 || (val.x ^ val.y ^ val.z ^ val.w) == 0x9E3779B9u)) {
@@ -268,6 +284,10 @@ __global__ __launch_bounds__(256) void k_fastq_far(FastqDev a, const unsigned in
         const uint64_t lens[4] = {g.name_e - g.s[0], g.e[0] - g.desc_s, g.e[1] - g.s[1], g.e[3] - g.s[3]};
         if (!code && (lens[0] > 0xFFFFFFFFull || lens[1] > 0xFFFFFFFFull || lens[2] > 0xFFFFFFFFull || lens[3] > 0xFFFFFFFFull))
             code = EXG_PE_FIELD_TOO_LONG;
+        if (!code && tiles_non_ascii(tileA, kSuper, p[0] + 1, p[4]) &&
+            !(utf8_valid_global(a.d_in, g.s[0], g.name_e) && utf8_valid_global(a.d_in, g.desc_s, g.e[0]) &&
+              utf8_valid_global(a.d_in, g.s[1], g.e[1]) && utf8_valid_global(a.d_in, g.s[3], g.e[3])))
+            code = EXG_PE_INVALID_UTF8;
         if (code) {
             atomicMin(&hdr->err_word, (out << 8) | code);
             atomicMin(&hdr->err_off, (unsigned long long)(p[0] + 1));

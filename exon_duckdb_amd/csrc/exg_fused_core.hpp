@@ -42,6 +42,9 @@ static constexpr int kRows = kTile / (kThreads * 16);  // 4 chunk rows (4 KiB ea
 static constexpr int kLdsBytes = kWin + kTile + 96;
 static constexpr uint32_t kNoneE = 0xFFFFu;
 
+static constexpr uint32_t kFlagA = 1u << 31;        // tileA[t]: the count is published
+static constexpr uint32_t kNonAsciiA = 1u << 30;    // ... and the super-tile (or the 1 KiB window in front of it) holds a byte >= 0x80
+static constexpr uint32_t kCountA = kNonAsciiA - 1; // ... the count itself (<= 49 152)
 static constexpr unsigned long long kFlag = 1ull << 63;  // descriptor word is published
 static constexpr unsigned long long kVal = (1ull << 48) - 1;
 
@@ -105,6 +108,46 @@ __device__ __forceinline__ uint4 make_string_lds(const L &s, int e, uint32_t len
     return r;
 }
 
+// core::str::from_utf8 acceptance over the LDS bytes [b, e) (extended offsets)
+template <class L>
+__device__ inline bool utf8_valid_lds(const L &s, int b, int e) {
+    int i = b;
+    while (i < e) {
+        const uint32_t c0 = ldb(s, i);
+        if (c0 < 0x80) {
+            i++;
+            continue;
+        }
+        if (c0 >= 0xC2 && c0 <= 0xDF) {
+            if (i + 1 >= e || (ldb(s, i + 1) & 0xC0) != 0x80) return false;
+            i += 2;
+        } else if (c0 >= 0xE0 && c0 <= 0xEF) {
+            if (i + 2 >= e) return false;
+            const uint32_t c1 = ldb(s, i + 1), c2 = ldb(s, i + 2);
+            const uint32_t lo = c0 == 0xE0 ? 0xA0 : 0x80, hi = c0 == 0xED ? 0x9F : 0xBF;
+            if (c1 < lo || c1 > hi || (c2 & 0xC0) != 0x80) return false;
+            i += 3;
+        } else if (c0 >= 0xF0 && c0 <= 0xF4) {
+            if (i + 3 >= e) return false;
+            const uint32_t c1 = ldb(s, i + 1), c2 = ldb(s, i + 2), c3 = ldb(s, i + 3);
+            const uint32_t lo = c0 == 0xF0 ? 0x90 : 0x80, hi = c0 == 0xF4 ? 0x8F : 0xBF;
+            if (c1 < lo || c1 > hi || (c2 & 0xC0) != 0x80 || (c3 & 0xC0) != 0x80) return false;
+            i += 4;
+        } else {
+            return false;
+        }
+    }
+    return true;
+}
+// k_*_far: does a super-tile that holds a byte of [lo, hi] — or the window in front of one — hold a byte >= 0x80?
+__device__ inline bool tiles_non_ascii(const unsigned int *__restrict__ tileA, uint64_t super_bytes, int64_t lo, int64_t hi) {
+    if (lo < 0) lo = 0;
+    if (hi < lo) return false;
+    for (uint64_t t = (uint64_t)lo / super_bytes, t1 = (uint64_t)hi / super_bytes; t <= t1; t++)
+        if (tileA[t] & kNonAsciiA) return true;
+    return false;
+}
+
 // '\n' count of bytes [b, e), by one wave, straight from global memory (helping path)
 __device__ unsigned long long help_count_bytes(const uint8_t *__restrict__ d_in, uint64_t n_bytes, uint64_t b,
                                                uint64_t e, uint32_t lane) {
@@ -128,6 +171,14 @@ __device__ __forceinline__ uint32_t opaque(uint32_t x) {
     asm volatile("" : "+v"(x));
     return x;
 }
+__device__ __forceinline__ uint32_t opaque_s(uint32_t x) {  // the same for a wave-uniform value (a scalar register)
+    asm volatile("" : "+s"(x));
+    return x;
+}
+__device__ __forceinline__ uint64_t opaque_s64(uint64_t x) {
+    asm volatile("" : "+s"(x));
+    return x;
+}
 __device__ __forceinline__ unsigned long long rfl64(unsigned long long x) {  // wave-uniform value -> SGPRs
     uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
     return ((unsigned long long)hi << 32) | lo;
@@ -141,7 +192,6 @@ __device__ __forceinline__ void st_desc(unsigned long long *p, unsigned long lon
 
 // ---- ordered prefix: central scanner --------------------------------------------------------------
 static constexpr int kScanBatches = 8;  // 1024 descriptors per scanner probe (32-bit count words keep this in registers)
-static constexpr uint32_t kFlagA = 1u << 31;
 
 template <int kSuper>
 __device__ void scanner_wave(const uint8_t *__restrict__ d_in, uint64_t n_bytes,
@@ -164,7 +214,7 @@ __device__ void scanner_wave(const uint8_t *__restrict__ d_in, uint64_t n_bytes,
             unsigned long long rdy = __ballot((d[k] & kFlagA) != 0);
             int r = rdy == ~0ull ? 64 : __ffsll((long long)~rdy) - 1;  // leading run of published counts
             if (r > 0) {
-                uint32_t c = (int)lane < r ? (d[k] & ~kFlagA) : 0u;
+                uint32_t c = (int)lane < r ? (d[k] & kCountA) : 0u;
                 uint32_t inc = wave_incl_sum(c);
                 if ((int)lane < r) st_desc(&tileP[next + lane], kFlag | (running + inc - c));
                 running += __shfl(inc, 63, 64);
@@ -211,7 +261,7 @@ __device__ unsigned long long wait_prefix(const uint8_t *__restrict__ d_in, uint
         unsigned long long x = kFlag;
         if (idx < st) {
             unsigned int a32 = __hip_atomic_load(&tileA[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            x = (a32 & kFlagA) ? (kFlag | (a32 & ~kFlagA)) : 0ull;
+            x = (a32 & kFlagA) ? (kFlag | (a32 & kCountA)) : 0ull;
         }
         unsigned long long miss = __ballot((x & kFlag) == 0);
         while (miss) {
@@ -243,7 +293,7 @@ __device__ inline bool far_positions(const FarRec &f, uint32_t st, uint64_t supe
     int found = 0;
     for (uint32_t t = st; found < need && t > 0;) {
         t--;
-        uint32_t c = tileA[t] & ~kFlagA;
+        uint32_t c = tileA[t] & kCountA;
         if (!c) continue;
         if (c > 4) c = 4;
         const int4 l = *reinterpret_cast<const int4 *>(tileL + (uint64_t)t * 4);
@@ -286,6 +336,7 @@ struct TileCtx {  // what emission needs besides the LDS contents (all workgroup
     int lim_e;                  // extended offset of the end of input inside this half (kWin + min(lim, kTile))
     bool is_eof_tile;           // the input ends in this half and EXG_F_EOF
     bool first_of_buffer;       // half 0 of super-tile 0: what precedes is before d_input[0]
+    bool non_ascii;             // the super-tile or its window holds a byte >= 0x80: the any-shape scan validates UTF-8
     uint32_t pass_base;         // lines of the half emitted by earlier passes (0: first pass; P and n_lines are the pass's)
     int half;                   // index of the half inside its super-tile
 };
@@ -307,17 +358,17 @@ struct TileCtx {  // what emission needs besides the LDS contents (all workgroup
 // before); the record that begins in front of the window — at most one per half — is written as a FarRec for k_*_far; the 4
 // newlines in front of a half are carried as CODES (FarRec::pos), not as window offsets.
 enum { kLean = 0, kFullPrimary = 1, kFullRedo = 2 };
-static constexpr unsigned int kRedoFar = 1u, kRedoDense = 2u, kRedoLast4 = 4u;  // tile_redo[st]: why (diagnostics; any bit = redo)
+static constexpr unsigned int kRedoFar = 1u, kRedoDense = 2u, kRedoLast4 = 4u, kRedoUtf8 = 8u;  // tile_redo[st]: why (diagnostics; any bit = redo)
 
 // tile_redo (u32 per super-tile) lies between tileP and tile_qend: tileA | tileP | tile_redo are zeroed by one memset
 __device__ __forceinline__ unsigned int *tile_redo_of(unsigned long long *tile_qend, uint64_t n_bytes) {
-    return reinterpret_cast<unsigned int *>(tile_qend - fused_n_tiles(n_bytes));
+    return reinterpret_cast<unsigned int *>(tile_qend - fused_n_tiles(opaque_s64(n_bytes)));  // (computed where it is used: see opaque)
 }
 __device__ __forceinline__ int32_t *tile_last4_of(unsigned long long *tile_qend, uint64_t n_bytes) {
-    return reinterpret_cast<int32_t *>(tile_qend + fused_n_tiles(n_bytes));
+    return reinterpret_cast<int32_t *>(tile_qend + fused_n_tiles(opaque_s64(n_bytes)));
 }
 __device__ __forceinline__ FarRec *far_rec_of(unsigned long long *tile_qend, uint64_t n_bytes) {
-    return reinterpret_cast<FarRec *>(tile_qend + 3 * fused_n_tiles(n_bytes));
+    return reinterpret_cast<FarRec *>(tile_qend + 3 * fused_n_tiles(opaque_s64(n_bytes)));
 }
 
 template <class F, int kMode>
@@ -412,15 +463,19 @@ __global__ __launch_bounds__(kThreads, kMode == kLean ? F::kMinWavesPerSimd : F:
     const bool analytic = dev_mode >= 1 && dev_mode <= 3;
     if constexpr (kMode != kFullRedo) {
         if (tid == 0 && !analytic)
-            __hip_atomic_store(&tileA[st], kFlagA | n_nl_super, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&tileA[st], kFlagA | n_nl_super | (non_ascii ? kNonAsciiA : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const unsigned long long halo_nl = rfl64(hdr->halo_nl);
-    // Bytes >= 0x80 need UTF-8 validation of every field (the reference builds Arrow Utf8 columns).
-    // That is rare in FASTQ and is left to the general path: raise `overflow`, which gates it in.
+    // Bytes >= 0x80 need UTF-8 validation of every field (the reference builds Arrow Utf8 columns).  That is rare and not the
+    // lean scan's business: it marks the super-tile; the any-shape scan validates the fields of the records that end here
+    // (emit_half, from LDS; a record that begins in front of the window: k_*_far, which finds the flag in tileA)
     if constexpr (kMode != kFullRedo) {
         if (non_ascii && tid == 0) {
             atomicOr(&hdr->flags, EXG_RF_NON_ASCII);
-            atomicOr(&hdr->overflow, 1u);
+            if constexpr (kMode == kLean) {
+                tile_redo_of(tile_qend, a.n_bytes)[opaque_s(st)] = kRedoUtf8;
+                hdr->any_redo = 1u;
+            }
         }
     }
 
@@ -519,6 +574,7 @@ __global__ __launch_bounds__(kThreads, kMode == kLean ? F::kMinWavesPerSimd : F:
         c.first_of_buffer = st == 0 && h == 0;
         c.pass_base = 0;
         c.half = h;
+        c.non_ascii = non_ascii;
         const bool ends_here = last_super && lim_h <= kTile;  // the input ends inside (or at the end of) this half
         c.is_eof_tile = ends_here && (a.flags & EXG_F_EOF);
         c.lim_e = (lim_h < kTile ? lim_h : kTile) + kWin;
@@ -545,7 +601,7 @@ __global__ __launch_bounds__(kThreads, kMode == kLean ? F::kMinWavesPerSimd : F:
             // ---- the lean scan ------------------------------------------------------------------------------
             if (n_lines > (uint32_t)kNlCap) {  // more lines than the list holds: the any-shape run redoes this super-tile
                 if (tid == 0) {
-                    tile_redo_of(tile_qend, a.n_bytes)[st] = kRedoDense;
+                    tile_redo_of(tile_qend, a.n_bytes)[opaque_s(st)] = kRedoDense;
                     hdr->any_redo = 1u;
                 }
                 return;
@@ -560,16 +616,17 @@ __global__ __launch_bounds__(kThreads, kMode == kLean ? F::kMinWavesPerSimd : F:
                 // this tile holds (n_nl_super of them) must be nameable from the last half's list; if not — sparse
                 // newlines: long lines — the any-shape run redoes the super-tile and names them.
                 if (wave == 0) {
-                    const uint32_t idx = n_lines + lane;  // lanes 0 .. 3: entries n .. n + 3 counted from nlist[0]
+                    const uint32_t k = opaque(lane), idx = n_lines + k;  // lanes 0 .. 3: entries n .. n + 3 counted from nlist[0]
+                    const uint32_t st_here = opaque_s(st);               // (nothing of this block may be computed ahead: see opaque)
                     int32_t code = -1;
-                    if (lane < 4) {
+                    if (k < 4) {
                         const uint32_t e = s.nlist[idx];
                         code = e != kNoneE ? h * kTile + (int32_t)e - kWin : -1;
-                        tile_last4_of(tile_qend, a.n_bytes)[(uint64_t)st * 4 + lane] = code;
+                        tile_last4_of(tile_qend, a.n_bytes)[(uint64_t)st_here * 4 + k] = code;
                     }
                     const uint32_t need = n_nl_super < 4u ? n_nl_super : 4u;  // slots 4 - need .. 3
-                    if (__ballot(lane < 4 && lane >= 4 - need && code < 0) != 0 && lane == 0) {
-                        tile_redo_of(tile_qend, a.n_bytes)[st] = kRedoLast4;
+                    if (__ballot(k < 4 && k >= 4 - need && code < 0) != 0 && k == 0) {
+                        tile_redo_of(tile_qend, a.n_bytes)[st_here] = kRedoLast4;
                         hdr->any_redo = 1u;
                     }
                 }

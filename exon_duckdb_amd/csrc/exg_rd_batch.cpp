@@ -760,7 +760,6 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         const uint32_t fl = (at_line_start ? EXG_F_BOF : 0u) | (eof ? EXG_F_EOF : 0u) | (no_store ? EXG_F_NO_STORE : 0u);
         std::shared_ptr<Batch> b;
         bool fused_first = false;
-        const bool general_now = r->general_first;
         std::function<int()> rescan_general;
         if (r->format == EXG_FMT_FASTQ) {
             exg_fastq_scan_args a;
@@ -771,7 +770,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             a.first_line_index = first_line_index;
             a.payload_base = (uint64_t)(uintptr_t)h;
             a.flags = fl;
-            a.algo = general_now ? EXG_ALGO_MULTIPASS : r->fused_algo;
+            a.algo = r->fused_algo;
             a.d_name = (exg_string_t *)r->d_cols[0];
             a.d_description = (exg_string_t *)r->d_cols[1];
             a.d_sequence = (exg_string_t *)r->d_cols[2];
@@ -783,7 +782,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             a.d_result = (exg_scan_result *)r->d_res;
             a.stream = r->stream;
             rc = exg_fastq_scan(&a);
-            fused_first = !general_now;
+            fused_first = true;
             rescan_general = [a]() mutable {
                 a.algo = EXG_ALGO_MULTIPASS;
                 return exg_fastq_scan(&a);
@@ -796,7 +795,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             a.lead = lead;
             a.payload_base = (uint64_t)(uintptr_t)h;
             a.flags = fl;
-            a.algo = general_now ? EXG_ALGO_MULTIPASS : r->fused_algo;
+            a.algo = r->fused_algo;
             for (int c = 0; c < 9; c++) a.d_fields[c] = (exg_string_t *)r->d_cols[c];
             if (!r->arrow_emit) {
                 // The projection reaches the kernel (a NULL column is skipped: 16 B per row less to write): POS / QUAL leave as
@@ -817,7 +816,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             a.d_result = (exg_scan_result *)r->d_res;
             a.stream = r->stream;
             rc = exg_vcf_scan(&a);
-            fused_first = !general_now;
+            fused_first = true;
             rescan_general = [a]() mutable {
                 a.algo = EXG_ALGO_MULTIPASS;
                 return exg_vcf_scan(&a);
@@ -853,17 +852,13 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         rc = exg_fetch_result((const exg_scan_result *)r->d_res, r->stream, &res);
         if (rc) return fail(r, rc, exg_last_error_message());
         if (fused_first && (res.flags & EXG_RF_FALLBACK)) {
-            // a byte >= 0x80 (UTF-8 validation lives in the general path): the general path, on the same batch (the reader
-            // launches it only now — EXG_ALGO_AUTO would enqueue its ten gated kernels behind every scan) — and first on the
-            // batches behind this one
+            // (no fused launch gives a batch up any more — long records, dense halves and bytes >= 0x80 are the any-shape
+            // scan's —; should one ever say so, the general path takes the batch)
             rc = rescan_general();
             if (rc) return fail(r, rc, exg_last_error_message());
             rc = exg_fetch_result((const exg_scan_result *)r->d_res, r->stream, &res);
             if (rc) return fail(r, rc, exg_last_error_message());
             res.flags |= EXG_RF_FALLBACK;
-            r->general_first = true;
-        } else if (general_now && !(res.flags & EXG_RF_NON_ASCII)) {
-            r->general_first = false;  // a batch without such a byte: back to the fused scans
         }
         if (res.flags & EXG_RF_REDO) r->fused_algo = EXG_ALGO_FUSED_FULL;  // (sticky: see exg_reader.hpp)
         TRACE("wait(h2d) + scan", t_scan);

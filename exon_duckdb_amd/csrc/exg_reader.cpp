@@ -377,7 +377,7 @@ extern "C" int exg_reader_stats_of(exg_reader *r, exg_reader_stats *out) {
     out->device_batch_bytes = r->device_batch_bytes;
     out->device_batches = r->n_batches;
     out->decoded_segments = r->n_segments;
-    out->scan_algo = r->fan ? 0 : r->general_first ? EXG_ALGO_MULTIPASS : r->fused_algo;
+    out->scan_algo = r->fan ? 0 : r->fused_algo;
     if (r->fan) {
         // the front of a fan-out holds next to nothing itself: its stripes' readers (their own meters, on the workers' threads) do
         const exg_rd::FanOut::Stats fs = r->fan->stats();

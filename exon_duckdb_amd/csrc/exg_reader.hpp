@@ -375,11 +375,9 @@ struct exg_reader {
     bool ws_full = false;  // under EXG_DEVICE_MEM_CAP_MB: a batch overflowed the budgeted line index, the workspace is at full size
     // Which scan a batch starts with is sticky (an input keeps its shape): EXG_ALGO_FUSED (the lean scan + the any-shape run
     // over what it marked) until a batch comes back with EXG_RF_REDO — long reads, reads below ~45 bp, multi-sample VCF
-    // lines —, then EXG_ALGO_FUSED_FULL, the any-shape scan alone, for the rest of the input (the lean scan would mark every
-    // tile and be a pass wasted per batch).  A batch with a byte >= 0x80 takes the general path (UTF-8 validation) after the
-    // fused launch gave it up; the batches behind it start there, until one comes back without such a byte.
+    // lines, bytes >= 0x80 —, then EXG_ALGO_FUSED_FULL, the any-shape scan alone, for the rest of the input (the lean scan
+    // would mark every tile and be a pass wasted per batch).
     uint32_t fused_algo = EXG_ALGO_FUSED;
-    bool general_first = false;
     // exg_open_args.filters: postfix program + constants in device memory, a row map and one column of scratch
     bool has_filter = false;
     uint64_t filter_cols = 0;  // the columns the predicate reads (bit c: schema column c)

@@ -260,7 +260,7 @@ struct VcfFormat {
                     // the line begins in front of the LDS window (only the first line of a half's first pass can: thread 0)
                     if constexpr (kMode == kLean) {
                         // lean scan: the any-shape run redoes this super-tile
-                        tile_redo_of(tile_qend, a.n_bytes)[tile_index / kVcfHalves] = kRedoFar;
+                        tile_redo_of(tile_qend, a.n_bytes)[opaque_s((uint32_t)(tile_index / kVcfHalves))] = kRedoFar;
                         hdr->any_redo = 1u;
                     } else {
                         // any-shape scan: its row is k_vcf_far's
@@ -278,6 +278,9 @@ struct VcfFormat {
                     int s0 = (int)q0 + 1;
                     if (e1 > s0 && !(c.is_eof_tile && e1 == c.lim_e) && ldb(s, e1 - 1) == '\r') e1--;
                     VcfRowInfo r = vcf_line(src, s0, e1, a, (unsigned long long)out, !no_store && dev_mode != 2);
+                    if constexpr (kMode != kLean) {  // noodles builds str fields: the line must be UTF-8
+                        if (!r.code && c.non_ascii && !utf8_valid_lds(s, s0, e1)) r.code = EXG_PE_INVALID_UTF8;
+                    }
                     if (r.code) vcf_report(hdr, r.code, (unsigned long long)out, c.tile_off + s0 - kWin);
                     else if (r.slow_len) vcf_slow_qual(hdr, a, c.tile_off + r.slow_s - kWin, (uint32_t)r.slow_len, (unsigned long long)out, c.tile_off + s0 - kWin);
                     qv = r.qual_valid;
@@ -398,7 +401,8 @@ __global__ __launch_bounds__(256) void k_vcf_far(VcfDev a, const unsigned int *_
         const bool virt = e1 >= a.n_bytes;
         if (!virt && e1 > s0 && a.d_in[e1 - 1] == '\r') e1--;
         const GlobalSrc src{a.d_in, s0, a.payload_base, (a.n_bytes + 15) & ~15ull};
-        const VcfRowInfo r = vcf_line(src, 0, (int)(e1 - s0), a, out, !no_store);
+        VcfRowInfo r = vcf_line(src, 0, (int)(e1 - s0), a, out, !no_store);
+        if (!r.code && tiles_non_ascii(tileA, kSuper, (int64_t)s0, (int64_t)e1) && !utf8_valid_global(a.d_in, s0, e1)) r.code = EXG_PE_INVALID_UTF8;
         if (r.code) vcf_report(hdr, r.code, out, s0);
         else if (r.slow_len) vcf_slow_qual(hdr, a, s0 + (uint64_t)r.slow_s, (uint32_t)r.slow_len, out, s0);
         if (!no_store) {

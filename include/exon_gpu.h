@@ -108,9 +108,10 @@ typedef union exg_string_t {
 #define EXG_F_ALL 7u      /* any other bit is refused (EXG_E_INVALID_ARG) */
 
 /* result flags */
-#define EXG_RF_NON_ASCII 1u /* a byte >= 0x80 was seen; UTF-8 was validated by the slow kernel */
+#define EXG_RF_NON_ASCII 1u /* a byte >= 0x80 was seen; the fields of the records around it were validated as UTF-8 */
 #define EXG_RF_HEAD_UNRESOLVED 2u /* first owned record starts before d_input[0]: host must stitch */
-#define EXG_RF_FALLBACK 4u  /* the fused kernels gave the launch up (a byte >= 0x80: UTF-8 validation) and the general kernels ran */
+#define EXG_RF_FALLBACK 4u  /* the fused kernels gave the launch up and the general kernels ran (no input shape does that any more:
+                             * kept for EXG_ALGO_AUTO's gate) */
 #define EXG_RF_CAPACITY 8u  /* more records than capacity_records: the surplus was not written */
 #define EXG_RF_INDEX_OVERFLOW 16u /* general path: more lines than the workspace can index (enlarge d_workspace) */
 #define EXG_RF_QUAL_RANGE 32u /* VCF: more QUAL literals of one launch needed the exact big-integer parser (> 19 digits astride a float
@@ -118,8 +119,8 @@ typedef union exg_string_t {
 
 /* algorithm selector (exg_*_scan_args.algo) */
 #define EXG_RF_REDO 64u     /* the lean scan marked super-tiles — a record / line that begins more than 1 KiB in front of the 16 KiB
-                             * half it ends in (long reads, multi-sample VCF), or more lines in a half than its list holds (reads
-                             * below ~45 bp) — and the any-shape run behind it redid them: the output is complete; a caller
+                             * half it ends in (long reads, multi-sample VCF), more lines in a half than its list holds (reads
+                             * below ~45 bp), or a byte >= 0x80 (UTF-8 validation) — and the any-shape run behind it redid them: the output is complete; a caller
                              * with more batches of the same input does better with EXG_ALGO_FUSED_FULL from here on */
 #define EXG_ALGO_AUTO 0
 #define EXG_ALGO_MULTIPASS 1 /* count -> scan -> index -> fields: 4 launches, reads the input ~3x */
@@ -468,9 +469,8 @@ typedef struct exg_reader_stats {
     uint64_t device_batches;     /* scans launched */
     uint64_t decoded_segments;   /* segments of a compressed input consumed */
     uint64_t scan_algo;          /* EXG_ALGO_* the next device batch starts with: EXG_ALGO_FUSED until a batch came back with
-                                  * EXG_RF_REDO (long reads, reads below ~45 bp, multi-sample VCF lines), then
-                                  * EXG_ALGO_FUSED_FULL for the rest of the input; EXG_ALGO_MULTIPASS behind a batch with a byte
-                                  * >= 0x80, until one comes back without (a fan-out reader: 0) */
+                                  * EXG_RF_REDO (long reads, reads below ~45 bp, multi-sample VCF lines, bytes >= 0x80), then
+                                  * EXG_ALGO_FUSED_FULL for the rest of the input (a fan-out reader: 0) */
     uint64_t reserved[3];
 } exg_reader_stats;
 int exg_reader_stats_of(exg_reader *r, exg_reader_stats *out);

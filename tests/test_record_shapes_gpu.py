@@ -297,9 +297,10 @@ def test_reader_short_reads_and_wide_vcf(gpu, oracle, tmp_path):
     assert st["scan_algo"] == abi.EXG_ALGO_FUSED_FULL
 
 
-def test_reader_non_ascii_batches_start_on_the_general_path_and_come_back(gpu, oracle, tmp_path):
-    """bytes >= 0x80 only in the first megabyte: those batches take the general path (UTF-8 validation) — the second of them
-    starts there —, the first batch without such a byte returns the reader to the fused scans"""
+def test_reader_non_ascii_batches(gpu, oracle, tmp_path):
+    """bytes >= 0x80 (valid UTF-8) in the first megabyte of a file read in 256 KiB batches: the lean scan marks their tiles,
+    the any-shape scan validates the fields — no batch is given up —, and the reader stays on the any-shape scan; an invalid
+    sequence far into the file is that row's error, behind the rows in front of it"""
     head = b"".join(("@r%d caf\u00e9\n" % k).encode() + b"ACGT" * 30 + b"\n+\n" + b"I" * 120 + b"\n" for k in range(4000))
     tail = bytes(oracle.synth_fastq(332 * 30000))
     data = head + tail
@@ -307,4 +308,18 @@ def test_reader_non_ascii_batches_start_on_the_general_path_and_come_back(gpu, o
     p.write_bytes(data)
     rows, st = _reader_rows(p, "fastq", device_batch_bytes=256 << 10)
     assert rows == _fastq_rows(oracle, data)
-    assert st["scan_algo"] == abi.EXG_ALGO_FUSED and st["device_batches"] >= 12
+    assert st["scan_algo"] == abi.EXG_ALGO_FUSED_FULL and st["device_batches"] >= 12
+    bad = bytearray(data)
+    at = len(head) + 332 * 20000 + 40      # inside a sequence line
+    bad[at] = 0xC3
+    p2 = tmp_path / "bad.fastq"
+    p2.write_bytes(bytes(bad))
+    from exon_duckdb_amd._lib import ExgError
+    from exon_duckdb_amd.reader import ShardReader
+    r = ShardReader(str(p2), "fastq", device_batch_bytes=256 << 10)
+    with pytest.raises(ExgError) as e:
+        r.rows()
+    r.close()
+    t = oracle.fastq_parse(bytes(bad), want_string_t=False)
+    assert t.error_code == abi.EXG_PE_INVALID_UTF8 and t.n_rows == 4000 + 20000
+    assert "utf-8" in str(e.value).lower() or "utf8" in str(e.value).lower(), str(e.value)
