@@ -227,6 +227,7 @@ struct FastqFormat {
 #endif
     static constexpr int kNlCap = EXG_FASTQ_NLCAP;  // 197 lines per half for 150 bp reads
     static constexpr bool kTabMap = false;
+    static constexpr bool kBarriers = true;   // (exg_fused_core.hpp opaque: its lean scan spills without them)
     static constexpr int kHalves = kFastqHalves;
     static constexpr int kMinWavesPerSimd = 6;  // 80 VGPRs, no scratch: 6 x 48 KiB in flight per CU
     static constexpr int kMinWavesPerSimdFull = 5;  // the any-shape instances: 96 VGPRs (their pass loop and FarRec code spill at 80)

@@ -179,6 +179,11 @@ __device__ __forceinline__ uint64_t opaque_s64(uint64_t x) {
     asm volatile("" : "+s"(x));
     return x;
 }
+// (a format says whether its lean scan wants these barriers — F::kBarriers: FASTQ does, at 80 registers; the VCF scan, at 96,
+// ran 3 % slower with them: A/B in one box)
+template <bool kOn> __device__ __forceinline__ uint32_t opaque_if(uint32_t x) { return kOn ? opaque(x) : x; }
+template <bool kOn> __device__ __forceinline__ uint32_t opaque_s_if(uint32_t x) { return kOn ? opaque_s(x) : x; }
+template <bool kOn> __device__ __forceinline__ uint64_t opaque_s64_if(uint64_t x) { return kOn ? opaque_s64(x) : x; }
 __device__ __forceinline__ unsigned long long rfl64(unsigned long long x) {  // wave-uniform value -> SGPRs
     uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
     return ((unsigned long long)hi << 32) | lo;
@@ -361,14 +366,17 @@ enum { kLean = 0, kFullPrimary = 1, kFullRedo = 2 };
 static constexpr unsigned int kRedoFar = 1u, kRedoDense = 2u, kRedoLast4 = 4u, kRedoUtf8 = 8u;  // tile_redo[st]: why (diagnostics; any bit = redo)
 
 // tile_redo (u32 per super-tile) lies between tileP and tile_qend: tileA | tileP | tile_redo are zeroed by one memset
+template <bool kBarriers = true>
 __device__ __forceinline__ unsigned int *tile_redo_of(unsigned long long *tile_qend, uint64_t n_bytes) {
-    return reinterpret_cast<unsigned int *>(tile_qend - fused_n_tiles(opaque_s64(n_bytes)));  // (computed where it is used: see opaque)
+    return reinterpret_cast<unsigned int *>(tile_qend - fused_n_tiles(opaque_s64_if<kBarriers>(n_bytes)));  // (computed where it is used: see opaque)
 }
+template <bool kBarriers = true>
 __device__ __forceinline__ int32_t *tile_last4_of(unsigned long long *tile_qend, uint64_t n_bytes) {
-    return reinterpret_cast<int32_t *>(tile_qend + fused_n_tiles(opaque_s64(n_bytes)));
+    return reinterpret_cast<int32_t *>(tile_qend + fused_n_tiles(opaque_s64_if<kBarriers>(n_bytes)));
 }
+template <bool kBarriers = true>
 __device__ __forceinline__ FarRec *far_rec_of(unsigned long long *tile_qend, uint64_t n_bytes) {
-    return reinterpret_cast<FarRec *>(tile_qend + 3 * fused_n_tiles(opaque_s64(n_bytes)));
+    return reinterpret_cast<FarRec *>(tile_qend + 3 * fused_n_tiles(opaque_s64_if<kBarriers>(n_bytes)));
 }
 
 template <class F, int kMode>
@@ -380,6 +388,7 @@ __global__ __launch_bounds__(kThreads, kMode == kLean ? F::kMinWavesPerSimd : F:
     constexpr int kHalves = F::kHalves;
     constexpr int kSuper = kTile * kHalves;
     constexpr bool kFull = kMode != kLean;
+    constexpr bool kB = F::kBarriers;
     __shared__ __attribute__((aligned(16))) FusedLds s;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63, wave = tid >> 6;
@@ -404,7 +413,7 @@ __global__ __launch_bounds__(kThreads, kMode == kLean ? F::kMinWavesPerSimd : F:
     }
     for (; kMode != kFullRedo || st < n_super; st += gridDim.x) {  // (one super-tile per workgroup but in the redo run)
     if constexpr (kMode == kFullRedo) {
-        if (!tile_redo_of(tile_qend, a.n_bytes)[st]) continue;  // (workgroup-uniform)
+        if (!tile_redo_of<kB>(tile_qend, a.n_bytes)[st]) continue;  // (workgroup-uniform)
         __syncthreads();                                         // the tile before is done with the LDS
     }
     const uint64_t super_off = (uint64_t)st * kSuper;
@@ -473,7 +482,7 @@ __global__ __launch_bounds__(kThreads, kMode == kLean ? F::kMinWavesPerSimd : F:
         if (non_ascii && tid == 0) {
             atomicOr(&hdr->flags, EXG_RF_NON_ASCII);
             if constexpr (kMode == kLean) {
-                tile_redo_of(tile_qend, a.n_bytes)[opaque_s(st)] = kRedoUtf8;
+                tile_redo_of<kB>(tile_qend, a.n_bytes)[opaque_s_if<kB>(st)] = kRedoUtf8;
                 hdr->any_redo = 1u;
             }
         }
@@ -601,7 +610,7 @@ __global__ __launch_bounds__(kThreads, kMode == kLean ? F::kMinWavesPerSimd : F:
             // ---- the lean scan ------------------------------------------------------------------------------
             if (n_lines > (uint32_t)kNlCap) {  // more lines than the list holds: the any-shape run redoes this super-tile
                 if (tid == 0) {
-                    tile_redo_of(tile_qend, a.n_bytes)[opaque_s(st)] = kRedoDense;
+                    tile_redo_of<kB>(tile_qend, a.n_bytes)[opaque_s_if<kB>(st)] = kRedoDense;
                     hdr->any_redo = 1u;
                 }
                 return;
@@ -616,17 +625,17 @@ __global__ __launch_bounds__(kThreads, kMode == kLean ? F::kMinWavesPerSimd : F:
                 // this tile holds (n_nl_super of them) must be nameable from the last half's list; if not — sparse
                 // newlines: long lines — the any-shape run redoes the super-tile and names them.
                 if (wave == 0) {
-                    const uint32_t k = opaque(lane), idx = n_lines + k;  // lanes 0 .. 3: entries n .. n + 3 counted from nlist[0]
-                    const uint32_t st_here = opaque_s(st);               // (nothing of this block may be computed ahead: see opaque)
+                    const uint32_t k = opaque_if<kB>(lane), idx = n_lines + k;  // lanes 0 .. 3: entries n .. n + 3 counted from nlist[0]
+                    const uint32_t st_here = opaque_s_if<kB>(st);               // (nothing of this block may be computed ahead: see opaque)
                     int32_t code = -1;
                     if (k < 4) {
                         const uint32_t e = s.nlist[idx];
                         code = e != kNoneE ? h * kTile + (int32_t)e - kWin : -1;
-                        tile_last4_of(tile_qend, a.n_bytes)[(uint64_t)st_here * 4 + k] = code;
+                        tile_last4_of<kB>(tile_qend, a.n_bytes)[(uint64_t)st_here * 4 + k] = code;
                     }
                     const uint32_t need = n_nl_super < 4u ? n_nl_super : 4u;  // slots 4 - need .. 3
                     if (__ballot(k < 4 && k >= 4 - need && code < 0) != 0 && k == 0) {
-                        tile_redo_of(tile_qend, a.n_bytes)[st_here] = kRedoLast4;
+                        tile_redo_of<kB>(tile_qend, a.n_bytes)[st_here] = kRedoLast4;
                         hdr->any_redo = 1u;
                     }
                 }
@@ -664,7 +673,7 @@ __global__ __launch_bounds__(kThreads, kMode == kLean ? F::kMinWavesPerSimd : F:
                     const uint32_t idx = m + tid;
                     const int32_t code = idx >= 4 ? h * kTile + (int32_t)s.nlist[idx] - kWin : s.prev32[idx];
                     s.carry32[tid] = code;
-                    if (h + 1 == kHalves || lim_s <= (h + 1) * kTile) tile_last4_of(tile_qend, a.n_bytes)[(uint64_t)st * 4 + tid] = code;
+                    if (h + 1 == kHalves || lim_s <= (h + 1) * kTile) tile_last4_of<kB>(tile_qend, a.n_bytes)[(uint64_t)st * 4 + tid] = code;
                 }
                 F::template emit_half<kFullPrimary>(s, a, hdr, c, halo_nl, dev_mode, lane, wave, tile_qend, half_index);
                 base += m;

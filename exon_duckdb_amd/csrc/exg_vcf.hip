@@ -215,6 +215,7 @@ struct VcfFormat {
     static constexpr int kNlCap = 1024;  // short data lines are common
     static constexpr int kHalves = kVcfHalves;
     static constexpr bool kTabMap = true;
+    static constexpr bool kBarriers = false;  // (exg_fused_core.hpp opaque: its lean scan ran 3 % slower with them)
 #ifndef EXG_VCF_WAVES
 #define EXG_VCF_WAVES 5
 #endif
@@ -260,7 +261,7 @@ struct VcfFormat {
                     // the line begins in front of the LDS window (only the first line of a half's first pass can: thread 0)
                     if constexpr (kMode == kLean) {
                         // lean scan: the any-shape run redoes this super-tile
-                        tile_redo_of(tile_qend, a.n_bytes)[opaque_s((uint32_t)(tile_index / kVcfHalves))] = kRedoFar;
+                        tile_redo_of<false>(tile_qend, a.n_bytes)[(uint32_t)(tile_index / kVcfHalves)] = kRedoFar;
                         hdr->any_redo = 1u;
                     } else {
                         // any-shape scan: its row is k_vcf_far's
@@ -270,7 +271,7 @@ struct VcfFormat {
                         f.pos[2] = f.pos[3] = f.pos[4] = 0;
                         f.flags = c.is_eof_tile ? 1u : 0u;
                         f.out = out;
-                        far_rec_of(tile_qend, a.n_bytes)[tile_index] = f;
+                        far_rec_of<false>(tile_qend, a.n_bytes)[tile_index] = f;
                         hdr->any_far = 1u;
                         tile_qend[tile_index] |= kFarBit;  // (this thread stored the word above)
                     }
