@@ -178,11 +178,34 @@ int DecodedSource::acquire(uint64_t pos, uint64_t want, const uint8_t **d_pos, u
             if (carry <= nx.room_in_front()) {
                 he = hipMemcpyAsync((void *)nx.at(p0), cur_.at(p0), carry, hipMemcpyDeviceToDevice, stream_);
                 nx.lo = p0;
+            } else if (nx.hi - cur_.hi <= cur_.room_behind()) {
+                // ... and that block of their own has room behind its bytes (it was made with slack, below): the next
+                // segment's bytes are appended, the tail stays where it is — a record of n segments costs n appends, not n
+                // copies of everything in front (a multi-GB FASTA record)
+                const uint64_t body = nx.hi - cur_.hi;  // (nx.start == cur_.hi; what nx keeps in front of it is here already)
+                uint8_t *dst = const_cast<uint8_t *>(cur_.at(cur_.hi));
+                if (body) he = hipMemcpyAsync(dst, nx.at(cur_.hi), body, hipMemcpyDeviceToDevice, stream_);
+                if (he == hipSuccess) he = hipMemsetAsync(dst + body, 0, 64, stream_);
+                if (he == hipSuccess) he = hipStreamSynchronize(stream_);
+                cur_.hi = nx.hi;
+                cur_.last = nx.last;
+                free_segment(nx);
+                n_consumed_++;
+                if (he != hipSuccess) {
+                    *err = std::string("carrying a record across decoded segments failed: ") + hipGetErrorString(he);
+                    return EXG_E_HIP;
+                }
+                continue;
             } else {
                 // a tail longer than the room a segment leaves in front of itself (one giant record, or a batch that was
-                // widened): both move into a block of their own
+                // widened): both move into a block of their own.  When that happens AGAIN for a tail that begins where the last
+                // one began — a record that goes on growing — the block is made with as much room behind its bytes again
+                // (geometric growth: the segments that follow are appended, above); a tail that moves on (a shard's halo while
+                // its decoder works its way to the shard's first byte) gets a block of its size, and so does every tail under EXG_DEVICE_MEM_CAP_MB
                 const uint64_t body = nx.hi - nx.lo;
-                const size_t ncap = (size_t)(reserve_ + carry + body + 64);
+                const bool growing = private_p0_ == p0 && !(meter_ && meter_->cap);  // (under a memory cap: no slack, by design)
+                private_p0_ = p0;
+                const size_t ncap = (size_t)(reserve_ + (growing ? 2 : 1) * (carry + body) + 64);
                 void *nb = dev_pool()->take(device_, ncap);
                 if (!nb) {
                     free_segment(nx);

@@ -34,6 +34,10 @@ struct Segment {
     bool last = false;  // the stream ends at hi
     const uint8_t *at(uint64_t x) const { return (const uint8_t *)buf + ((int64_t)x - org); }
     uint64_t room_in_front() const { return (uint64_t)((int64_t)lo - org); }
+    uint64_t room_behind() const {  // bytes of the block behind hi, less the 64 zero bytes that follow the last byte
+        const uint64_t used = (uint64_t)((int64_t)hi - org) + 64;
+        return cap > used ? cap - used : 0;
+    }
 };
 
 class DecodedSource;
@@ -105,6 +109,7 @@ private:
     bool mark_set_[2] = {false, false};
     Segment cur_;
     bool have_cur_ = false;
+    uint64_t private_p0_ = ~0ull;  // where the tail began that last moved into a block of its own (acquire)
     bool error_deferred_ = false;  // the producer's error was met while bytes in front of it were still to be handed out
     uint64_t n_consumed_ = 0;
 };

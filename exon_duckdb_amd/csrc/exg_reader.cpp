@@ -54,6 +54,7 @@ extern "C" int exg_open(const exg_open_args *args, exg_reader **out) {
     // decoded, compressed windows, the scan's workspace and column vectors)
     if (const char *e = getenv("EXG_DEVICE_MEM_CAP_MB")) {
         r->mem_cap = strtoull(e, nullptr, 10) << 20;
+        r->meter.cap = r->mem_cap;
         // (per input byte a scan provisions 16 B x columns / 32 (FASTQ) or / 16 (VCF: 9 columns + POS + QUAL) of column
         // vectors; a compressed input adds up to four segments and two compressed windows)
         // (24 for FASTQ: with 20 a single-member gzip under a 16 MiB cap peaked between 15.4 and 17.3 MB depending on how far the

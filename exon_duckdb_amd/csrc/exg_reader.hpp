@@ -125,6 +125,7 @@ inline StreamPool *stream_pool() {
 // calling thread: the reader's entry points and its worker threads run inside a MeterScope.
 struct MemMeter {
     std::atomic<uint64_t> cur{0}, peak{0};
+    uint64_t cap = 0;  // EXG_DEVICE_MEM_CAP_MB of the reader that owns the meter (0: none): who allocates with slack looks here
     void add(uint64_t n) {
         const uint64_t v = cur.fetch_add(n) + n;
         uint64_t p = peak.load();

@@ -448,7 +448,8 @@ int exg_open(const exg_open_args *args, exg_reader **out);
 /* How many byte-range shards a scan of this input is worth, and on which device each runs: what the table function's
  * init_global asks (MaxThreads() = *n_shards; init_local i opens shard i with device = devices[i]) — the in-process form
  * of SURVEY §8 E1: one host thread and one GPU per shard, nothing exchanged.  One shard per visible device when the input
- * can be sharded (text FASTQ / VCF / FASTA, BGZF FASTQ / VCF) and holds >= 256 MiB per shard, else 1.
+ * can be sharded (text FASTQ / VCF / FASTA; BGZF FASTQ / VCF / FASTA, by members; multi-frame zstd, by frames) and holds
+ * >= 256 MiB per shard, else 1 (single-member gzip, a single zstd frame).
  * EXON_GPU_SHARDS=n forces n (several shards on one device: how the tests exercise it on a 1-GPU box). */
 int exg_plan_shards(const exg_open_args *args, uint32_t *n_shards, int *devices, uint32_t devices_cap);
 /* VCF: opens the first file (the INFO / FORMAT keys of its header are the schema), so it can fail like a scan can. */

@@ -141,3 +141,32 @@ def test_bench_without_a_launcher_starts_its_ranks():
                          cwd=root, capture_output=True, text=True, timeout=300)
     assert res.returncode != 0
     assert res.stderr.count("bench.py needs a GPU") >= 2, res.stderr[-2000:]
+
+
+def test_falsifiability_kit_writes_every_rule_case(tmp_path):
+    """tools/falsify_kit.py: the inputs of the [RECALLED] rule tests as files + the oracle's rows + one script for a real exon
+    build; its compare.py says SAME for every case when the oracle's own rows come back"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    kit = tmp_path / "kit"
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "falsify_kit.py"), str(kit)])
+    cases = json.load(open(kit / "cases.json"))
+    assert len(cases) >= 60 and {c["format"] for c in cases} == {"fastq", "fasta", "vcf"}
+    assert all(os.path.exists(kit / c["file"]) for c in cases)
+    os.makedirs(kit / "got")
+    for c in cases:   # what a run.sh against a build that agrees with the oracle leaves behind
+        e = json.load(open(kit / "expected" / (c["case"] + ".json")))
+        if e["error"]:
+            (kit / "got" / (c["case"] + ".err")).write_text("Error: ...")
+        else:
+            (kit / "got" / (c["case"] + ".json")).write_text("".join(json.dumps(r) + "\n" for r in e["rows"]))
+    res = subprocess.run([sys.executable, "compare.py"], cwd=kit, capture_output=True, text=True)
+    assert res.returncode == 0 and res.stdout.count("SAME") == len(cases), res.stdout[-2000:]
+    # and a build that disagrees on one rule is told so
+    c = next(c for c in cases if c["case"].startswith("fastq_split_at_first_space_only"))
+    (kit / "got" / (c["case"] + ".json")).write_text(json.dumps({"name": "id a", "description": "b  c", "sequence": "AC", "quality_scores": "!!"}) + "\n")
+    res = subprocess.run([sys.executable, "compare.py"], cwd=kit, capture_output=True, text=True)
+    assert res.returncode == 1 and "DIFFERENT test_fastq_split_at_first_space_only" in res.stdout
