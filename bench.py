@@ -571,11 +571,39 @@ def run_configs(torch, lib, args):
                                 "an independent line / tab split of the file",
                 "verified": bool(rows == n == n_lines == v_rows == int(e_rows.value) and chunks >= (rows + 2047) // 2048 and got == int(e_dg.value))}
 
+        def long_reads_file():
+            # ---- read_fastq end to end on LONG reads (HiFi-like 15 kb): the first device batch comes back marked by the lean scan
+            # (EXG_RF_REDO), the reader switches to the any-shape scan for the rest of the file (exg_reader_stats.scan_algo)
+            from exon_duckdb_amd.testing import shapes
+            block, _ = shapes.fastq_long_block(shapes.hifi_lengths(2000, seed=31), seed=31)
+            reps = max(1, int(min(args.e2e_gb, 2.0) * 1e9) // len(block))
+            p_lr = os.path.join(tmp, "long.fastq")
+            with open(p_lr, "wb") as f:
+                for _ in range(reps):
+                    f.write(block)
+            n_lr = reps * len(block)
+            reader_count(lib, p_lr, "fastq")
+            n, dt_c = min((reader_count(lib, p_lr, "fastq") for _ in range(3)), key=lambda x: x[1])
+            rows, chunks, dt_r = min((reader_chunks(lib, p_lr, "fastq") for _ in range(3)), key=lambda x: x[2])
+            e_rows, e_dg = C.c_uint64(0), C.c_uint64(0)
+            assert tl.exon_tf_expect_fastq_file(p_lr.encode(), C.byref(e_rows), C.byref(e_dg)) == 0
+            v_rows, _, got, _ = reader_digest(lib, p_lr, "fastq")
+            os.unlink(p_lr)
+            out["end_to_end_long_reads"] = {
+                "workload": f"read_fastq, {n_lr / 1e9:.1f} GB file of HiFi-like reads (15 kb +- 3 kb, {2000 * reps} records) in the page cache -> host "
+                            f"DataChunks, PCIe inclusive; the reader's sticky choice: lean scan on the first batch, any-shape scan behind it",
+                "algorithmic_bytes": n_lr, "ms": dt_r * 1e3, "GB/s": n_lr / dt_r / 1e9, "records_per_s": rows / dt_r, "chunks": chunks,
+                "count_only_ms": dt_c * 1e3, "count_only_GB/s": n_lr / dt_c / 1e9, "frac": None,
+                "verification": "an untimed pass folds every row of every chunk into a digest that must equal the one of an independent four-line "
+                                "split of the file",
+                "verified": bool(rows == n == v_rows == int(e_rows.value) == 2000 * reps and got == int(e_dg.value))}
+
         leg(config1, "config1_fasta_1MB_count")
         leg(config3, "config3_vcf_8col")
         leg(files, "end_to_end", "config4_fastq_bgzf")
         if "host_pipeline_scaling" in out and "end_to_end" in out and "error" not in out["end_to_end"]:
             out["end_to_end"]["host_pipeline_scaling"] = out.pop("host_pipeline_scaling")
+        leg(long_reads_file, "end_to_end_long_reads")
         leg(vcf_file, "end_to_end_vcf")
     finally:
         for f in os.listdir(tmp):

@@ -187,6 +187,7 @@ TEST_SIGNATURES = {
                                             C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "exon_tf_synth_fastq150_host": (None, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
     "exon_tf_expect_fastq150": (C.c_uint64, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int]),
+    "exon_tf_expect_fastq_file": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "exon_tf_expect_vcf_file": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "exon_tf_filter_explain": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
     "exon_tf_vcf_header_explain": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),

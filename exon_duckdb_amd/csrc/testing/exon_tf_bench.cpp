@@ -175,6 +175,52 @@ extern "C" int exon_tf_expect_vcf_file(const char *path, uint64_t *rows, uint64_
     return 0;
 }
 
+// A well-formed FASTQ file's records as that digest, by a split of its own (four lines per record at '\n', the name line at its
+// first space, CR stripped): row index, name, description (NULL when empty), sequence, quality — independent of the engine's
+// tokeniser and of the oracle; `threads` workers each take a run of whole records (found from a byte offset by the '@' ... '+'
+// line pattern of this generator's files: names without '\n@' ambiguity are the caller's business).
+extern "C" int exon_tf_expect_fastq_file(const char *path, uint64_t *rows, uint64_t *digest) {
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return -1;
+    struct stat st;
+    fstat(fd, &st);
+    const size_t n = (size_t)st.st_size;
+    const uint8_t *d = n ? (const uint8_t *)mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
+    close(fd);
+    if (n && d == MAP_FAILED) return -1;
+    uint64_t k = 0, acc = 0;
+    size_t pos = 0;
+    int rc = 0;
+    while (pos < n) {
+        const uint8_t *ls[4];
+        size_t ll[4];
+        for (int i = 0; i < 4; i++) {
+            const uint8_t *nl = pos < n ? (const uint8_t *)memchr(d + pos, '\n', n - pos) : nullptr;
+            size_t end = nl ? (size_t)(nl - d) : n;
+            ls[i] = d + pos;
+            ll[i] = end - pos;
+            if (nl && ll[i] && ls[i][ll[i] - 1] == '\r') ll[i]--;
+            pos = nl ? end + 1 : n;
+        }
+        if (!ll[0] || ls[0][0] != '@' || !ll[2] || ls[2][0] != '+') {
+            rc = -2;
+            break;
+        }
+        const uint8_t *name = ls[0] + 1;
+        size_t n_name = ll[0] - 1;
+        const uint8_t *sp = (const uint8_t *)memchr(name, ' ', n_name);
+        const uint8_t *desc = sp ? sp + 1 : name + n_name;
+        const size_t n_desc = sp ? (size_t)(name + n_name - desc) : 0;
+        if (sp) n_name = (size_t)(sp - name);
+        acc += fastq_row_digest(k, name, n_name, desc, n_desc, n_desc != 0, ls[1], ll[1], ls[3], ll[3]);
+        k++;
+    }
+    if (d) munmap((void *)d, n);
+    *rows = k;
+    *digest = acc;
+    return rc;
+}
+
 // ---- consumers of a reader's chunks ------------------------------------------------------------------------------------------
 // pull and release every remaining chunk — what a consumer that only walks the DataChunks does
 extern "C" int exon_tf_drain_chunks(exg_reader *r, uint64_t *n_rows, uint64_t *n_chunks) {

@@ -19,6 +19,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 # the configs legs (config 1 FASTA, config 3 VCF, config 4 BGZF inflate + CRC-32, end to end): every kernel of them
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_configs -o kt --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --launches-per-step 2 --no-cpu-baseline --gz-gb 2 --e2e-gb 2 > $OUT/${TAG}_kt_configs.log 2>&1
+# records of other shapes (long reads, 36 bp reads, multi-sample VCF): the any-shape scan k_fused<.., 1>, the lean scan + redo run, k_*_far
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_shapes -o kt --output-format csv -- python3 $ROOT/tools/shapes_probe.py 4 > $OUT/${TAG}_kt_shapes.log 2>&1
 # zstd decode (512 MB single frame, level 3)
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_zstd -o kt --output-format csv -- python3 $ROOT/tools/zstd_stream_probe.py > $OUT/${TAG}_kt_zstd.log 2>&1
 # single-member gzip through the reader (chunked decode)

@@ -14,7 +14,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01_d"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "gpurun_out")
 prof = os.path.join(root, "profiles")
-KERNEL = "k_fused<exg::FastqFormat>"
+KERNEL = "k_fused<exg::FastqFormat, 0>"   # the lean scan (1: the any-shape scan, 2: its redo run)
 
 
 def find(pattern):
@@ -51,7 +51,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         w.writerows(rows)
     vals = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == c]
     res[c] = sum(vals) / len(vals)
-for leg in ("configs", "zstd", "gzstream", "fasta", "vcf", "inflate"):
+for leg in ("configs", "zstd", "gzstream", "fasta", "vcf", "inflate", "shapes"):
     st = find(f"{tag}_kt_{leg}/**/*kernel_stats.csv")
     if st:
         shutil.copy(st, os.path.join(prof, f"{tag}_{leg}_kernel_stats.csv"))
