@@ -991,146 +991,6 @@ __global__ __launch_bounds__(256) void k_zst_resolve(const ResolveArgs a) {
     }
 }
 
-// ---- the same in ONE launch ------------------------------------------------------------------------------------------------
-// The groups of a round still resolve in order — a reference that leaves its group names a position the groups in front make
-// final — but the order is kept INSIDE the launch: block b belongs to group g (block0[g] <= b < block0[g + 1]; blocks are
-// dispatched in index order, so every block of the groups in front is resident or done when one of group g spins).  A thread
-// follows its chains through the group's symbols as before WITHOUT waiting; only where a chain leaves the group into the
-// symbolic region in front (positions in [byte_end, final_below): bytes of the frame's first chunk and of earlier frames were
-// final when the execution kernel ended) it notes the position, and the block then waits for the group in front to be
-// COMPLETE — all its blocks have stored, and the group in front of IT was complete: the last block of a group to finish makes
-// that transitive —, gathers, stores, fences and counts itself done.  A round of 1 GiB was ~2 000 dependent launches at ~6 us
-// each; the hop from group to group through an agent-scope flag costs about as much as the launch did (visibility across XCDs),
-// so the gain is in what no longer waits: chains that end inside their group (most) and the kernel's head and tail.
-struct ResolveGroup {
-    uint32_t k0, n;            // its chunks: sym_list[k0 .. k0 + n)
-    uint32_t block0, n_blocks; // its blocks of the launch
-    uint64_t elem0, n_elems, final_below;
-};
-struct ResolveAllArgs {
-    const uint32_t *sym;
-    const Chunk *chunks;
-    const uint32_t *sym_list;
-    const ResolveGroup *groups;
-    uint32_t n_groups;
-    uint8_t *out;
-    unsigned int *done;  // [n_groups] blocks that have stored
-    unsigned int *flag;  // [n_groups] 1: the group and everything in front of it is final
-};
-static constexpr uint32_t kSymPending = 0x40000000u;  // (thread-local) "a byte at position `pend[j]`, final once the group in front is"
-
-__device__ __forceinline__ void wait_group_final(unsigned int *flag, uint32_t g) {
-    while (__hip_atomic_load(&flag[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(2);
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);  // (agent scope on this target: what the group in front stored is visible)
-}
-
-__global__ __launch_bounds__(256) void k_zst_resolve_all(const ResolveAllArgs a) {
-    __shared__ uint64_t s_out[kGroupMax], s_elem[kGroupMax], s_size[kGroupMax], s_bytes_below[kGroupMax], s_frame0[kGroupMax], s_byte_end[kGroupMax];
-    __shared__ uint32_t s_g;
-    __shared__ int s_any;
-    if (threadIdx.x == 0) {
-        uint32_t lo = 0, hi = a.n_groups;  // the last group whose first block is <= this block
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) / 2;
-            if (a.groups[mid].block0 <= blockIdx.x) lo = mid;
-            else hi = mid;
-        }
-        s_g = lo;
-        s_any = 0;
-    }
-    __syncthreads();
-    const uint32_t g = s_g;
-    const ResolveGroup G = a.groups[g];
-    const uint32_t n = G.n;
-    if (threadIdx.x < n) {
-        const Chunk &c = a.chunks[a.sym_list[G.k0 + threadIdx.x]];
-        s_out[threadIdx.x] = c.out_off;
-        s_elem[threadIdx.x] = c.elem_off;
-        s_size[threadIdx.x] = c.size;
-        s_byte_end[threadIdx.x] = c.byte_end;
-        s_bytes_below[threadIdx.x] = c.byte_end > G.final_below ? c.byte_end : G.final_below;
-        s_frame0[threadIdx.x] = c.frame_out_off;
-    }
-    __syncthreads();
-    const uint64_t e = G.elem0 + (uint64_t)(blockIdx.x - G.block0) * 1024 + (uint64_t)threadIdx.x * 4;
-    uint32_t x[4] = {0, 0, 0, 0}, at[4] = {0, 0, 0, 0}, nv = 0, k = 0;
-    uint64_t pend[4] = {0, 0, 0, 0}, i = 0;
-    bool mine = e < G.elem0 + G.n_elems;
-    if (mine) {
-        for (uint32_t j = 1; j < n; j++) k = s_elem[j] <= e ? j : k;
-        i = e - s_elem[k];
-        mine = i < s_size[k];  // (else: padding between two chunks)
-    }
-    bool any_pending = false;
-    if (mine) {
-        const uint64_t size = s_size[k];
-        const uint4 xv = *reinterpret_cast<const uint4 *>(a.sym + e);  // (elem_off is a multiple of 4)
-        x[0] = xv.x, x[1] = xv.y, x[2] = xv.z, x[3] = xv.w;
-        at[0] = at[1] = at[2] = at[3] = k;
-        nv = size - i < 4 ? (uint32_t)(size - i) : 4u;
-        for (;;) {
-            bool more = false;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if ((uint32_t)j >= nv || !(x[j] & kSymRef)) continue;
-                const uint64_t cs = s_out[at[j]], d = x[j] & ~kSymRef;
-                if (d == 0 || d > cs - s_frame0[at[j]]) {  // (only after a failed decode: the chunk's status says so)
-                    x[j] = 0;
-                    continue;
-                }
-                const uint64_t q = cs - d;
-                if (q < s_bytes_below[at[j]]) {
-                    if (q < s_byte_end[at[j]]) {
-                        x[j] = a.out[q];  // a byte of the frame's first chunk: final since the execution kernel
-                    } else {
-                        pend[j] = q;      // a symbol of a group in front: final once that group is
-                        x[j] = kSymPending;
-                        any_pending = true;
-                    }
-                    continue;
-                }
-                uint32_t c = 0;  // q lies in an earlier chunk of the group: the last one that starts at or before it
-                for (uint32_t m = 1; m < at[j]; m++) c = s_out[m] <= q ? m : c;
-                x[j] = a.sym[s_elem[c] + (q - s_out[c])];
-                at[j] = c;
-                more = more || (x[j] & kSymRef);
-            }
-            if (!more) break;
-        }
-    }
-    if (any_pending) s_any = 1;
-    __syncthreads();
-    if (s_any && g > 0) {  // (workgroup-uniform)
-        if (threadIdx.x == 0) wait_group_final(a.flag, g - 1);
-        __syncthreads();
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (x[j] == kSymPending && (uint32_t)j < nv) x[j] = a.out[pend[j]];
-    }
-    if (mine) {
-        uint8_t *dst = a.out + s_out[k] + i;
-        if (nv == 4) {
-            const uint32_t w = (x[0] & 255u) | ((x[1] & 255u) << 8) | ((x[2] & 255u) << 16) | (x[3] << 24);
-            __builtin_memcpy(dst, &w, 4);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 3; j++)
-                if ((uint32_t)j < nv) dst[j] = (uint8_t)x[j];
-        }
-    }
-    // this block has stored: count it; the last block of the group makes the group final behind the group in front
-    __atomic_thread_fence(__ATOMIC_RELEASE);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned int before = __hip_atomic_fetch_add(&a.done[g], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (before + 1 == G.n_blocks) {
-            if (g > 0) wait_group_final(a.flag, g - 1);
-            __hip_atomic_store(&a.flag[g], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
 static double now_ms() {
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -1269,17 +1129,16 @@ struct RoundCtx {
     // the statuses come back into pinned memory: a copy into pageable memory would hold the host until the stream is done
     char *h_status = nullptr;
     size_t h_status_cap = 0;
-    std::vector<std::unique_ptr<DevTmp>> resolve_tmp;     // the resolve launch's group tables + counters (one per round of symbols)
-    std::vector<std::pair<char *, size_t>> h_tmp;         // ... their pinned sources
     size_t n_rounds = 0;
     double t_begin = 0, t_entropy = 0;
     RoundCtx(int d, hipStream_t s)
         : dev(d), st(s), d_blocks(d, s), d_lit(d, s), d_ll(d, s), d_ml(d, s), d_off(d, s), d_meta(d, s), d_frames(d, s), d_chunks(d, s), d_status(d, s),
           d_out(d, s), d_sym(d, s), d_lookup(d, s) {}
     ~RoundCtx() {
-        if (h_status || !h_tmp.empty()) (void)hipStreamSynchronize(st);
-        if (h_status) exg_rd::global_pool()->give(h_status, h_status_cap);
-        for (auto &h : h_tmp) exg_rd::global_pool()->give(h.first, h.second);
+        if (h_status) {
+            (void)hipStreamSynchronize(st);
+            exg_rd::global_pool()->give(h_status, h_status_cap);
+        }
     }
 };
 void decode_round_abandon(RoundCtx *c) { delete c; }
@@ -1510,66 +1369,22 @@ int decode_round_enqueue(Round &R, RoundCtx *ctx_p) {
                                (const uint8_t *)C.d_lit.p, (const uint32_t *)C.d_ll.p, (const uint32_t *)C.d_ml.p, (const uint32_t *)C.d_off.p,
                                out_bytes, (uint32_t *)C.d_sym.p, (uint32_t *)C.d_status.p + Q.c0);
             static const uint64_t group_bytes = getenv("EXG_ZSTD_RESOLVE_BYTES") ? strtoull(getenv("EXG_ZSTD_RESOLVE_BYTES"), nullptr, 10) : (512ull << 10);
-            static const bool launch_per_group = getenv("EXG_ZSTD_RESOLVE_LAUNCHES") != nullptr;  // (round 3's form: A/B)
-            std::vector<ResolveGroup> groups;
-            uint32_t block0 = 0;
             for (uint32_t k0 = 0; k0 < Q.n_list;) {
                 uint32_t k1 = k0;
                 uint64_t bytes = 0;
                 while (k1 < Q.n_list && k1 - k0 < kGroupMax && (bytes < group_bytes || k1 == k0)) bytes += csize[sym_list[Q.list0 + k1]], k1++;
                 const Chunk &first = chunks[sym_list[Q.list0 + k0]], &last = chunks[sym_list[Q.list0 + k1 - 1]];
-                const uint64_t n_elems = last.elem_off + ((last.size + 3) & ~3ull) - first.elem_off;
-                if (launch_per_group) {
-                    ResolveArgs ra;
-                    ra.sym = (const uint32_t *)C.d_sym.p;
-                    ra.chunks = (const Chunk *)C.d_chunks.p;
-                    ra.sym_chunks = d_sym_list + Q.list0 + k0;
-                    ra.n_sym_chunks = k1 - k0;
-                    ra.out = out_bytes;
-                    ra.final_below = first.out_off;
-                    ra.elem0 = first.elem_off;
-                    ra.n_elems = n_elems;
-                    hipLaunchKernelGGL(k_zst_resolve, dim3((uint32_t)((ra.n_elems + 1023) / 1024)), dim3(256), 0, st, ra);
-                } else {
-                    ResolveGroup G;
-                    G.k0 = Q.list0 + k0;
-                    G.n = k1 - k0;
-                    G.block0 = block0;
-                    G.n_blocks = (uint32_t)((n_elems + 1023) / 1024);
-                    G.elem0 = first.elem_off;
-                    G.n_elems = n_elems;
-                    G.final_below = first.out_off;
-                    block0 += G.n_blocks;
-                    groups.push_back(G);
-                }
-                k0 = k1;
-            }
-            if (!groups.empty()) {
-                // the groups' table + their counters: a pooled device block per round of symbols, the table through pinned memory
-                const size_t tbl = groups.size() * sizeof(ResolveGroup), cnt = groups.size() * 8;
-                C.resolve_tmp.emplace_back(new DevTmp(C.dev, st));
-                DevTmp &d_tbl = *C.resolve_tmp.back();
-                EXG_HIP_CHECK(d_tbl.alloc(tbl + cnt + 64));
-                size_t hcap = tbl + 64;
-                char *h_tbl = exg_rd::global_pool()->take(&hcap);
-                if (!h_tbl) {
-                    set_error("zstd decode: out of pinned host memory");
-                    return EXG_E_NOMEM;
-                }
-                C.h_tmp.emplace_back(h_tbl, hcap);
-                memcpy(h_tbl, groups.data(), tbl);
-                EXG_HIP_CHECK(hipMemcpyAsync(d_tbl.p, h_tbl, tbl, hipMemcpyHostToDevice, st));
-                EXG_HIP_CHECK(hipMemsetAsync((char *)d_tbl.p + tbl, 0, cnt, st));
-                ResolveAllArgs ra;
+                ResolveArgs ra;
                 ra.sym = (const uint32_t *)C.d_sym.p;
                 ra.chunks = (const Chunk *)C.d_chunks.p;
-                ra.sym_list = d_sym_list;
-                ra.groups = (const ResolveGroup *)d_tbl.p;
-                ra.n_groups = (uint32_t)groups.size();
+                ra.sym_chunks = d_sym_list + Q.list0 + k0;
+                ra.n_sym_chunks = k1 - k0;
                 ra.out = out_bytes;
-                ra.done = (unsigned int *)((char *)d_tbl.p + tbl);
-                ra.flag = ra.done + groups.size();
-                hipLaunchKernelGGL(k_zst_resolve_all, dim3(block0), dim3(256), 0, st, ra);
+                ra.final_below = first.out_off;
+                ra.elem0 = first.elem_off;
+                ra.n_elems = last.elem_off + ((last.size + 3) & ~3ull) - first.elem_off;
+                hipLaunchKernelGGL(k_zst_resolve, dim3((uint32_t)((ra.n_elems + 1023) / 1024)), dim3(256), 0, st, ra);
+                k0 = k1;
             }
         }
         hipLaunchKernelGGL(k_zst_xxh64, dim3(nf < 16384 ? nf : 16384), dim3(64), 0, st, (const uint8_t *)out_bytes, (const Frame *)C.d_frames.p, nf,
