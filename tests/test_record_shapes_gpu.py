@@ -323,3 +323,82 @@ def test_reader_non_ascii_batches(gpu, oracle, tmp_path):
     t = oracle.fastq_parse(bytes(bad), want_string_t=False)
     assert t.error_code == abi.EXG_PE_INVALID_UTF8 and t.n_rows == 4000 + 20000
     assert "utf-8" in str(e.value).lower() or "utf8" in str(e.value).lower(), str(e.value)
+
+
+# ---- differential fuzz over shapes: random length mixes, mutations, shard cuts ------------------------------------------------
+
+def _random_fastq(rng, n_rec):
+    """records of wildly different sizes (0 .. 200 kb, heavy tail), names with and without descriptions, sporadic CRLF"""
+    kinds = rng.integers(0, 6, n_rec)
+    lengths = np.where(kinds == 0, rng.integers(0, 4, n_rec),
+              np.where(kinds == 1, rng.integers(20, 60, n_rec),
+              np.where(kinds == 2, rng.integers(100, 400, n_rec),
+              np.where(kinds == 3, rng.integers(900, 1200, n_rec),
+              np.where(kinds == 4, rng.integers(8000, 40000, n_rec), rng.integers(40000, 200000, n_rec))))))
+    return fastq_records(lengths, seed=int(rng.integers(1 << 30)), crlf_every=int(rng.integers(0, 9)), desc_every=int(rng.integers(0, 4)))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fastq_shapes_fuzz(gpu, oracle, seed):
+    from test_fuzz_gpu import mutate
+    rng = np.random.default_rng(7000 + seed)
+    base = bytes(_random_fastq(rng, int(rng.integers(5, 60))))
+    for trial in range(4):
+        data = base if trial == 0 else mutate(base, rng, int(rng.integers(1, 4)))
+        for algo in FUSED_AND_PARTNER:
+            res = check_against_oracle(oracle, data, algo)
+            no_fallback(res)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fastq_shapes_shard_cuts_fuzz(gpu, oracle, seed):
+    """random 16-byte-aligned cuts with random halos over a random mix of record sizes: the shards' rows are the file's rows, or
+    a shard says that its halo does not reach the head of its first record (and with the whole prefix as halo it has them)"""
+    rng = np.random.default_rng(8000 + seed)
+    data = bytes(_random_fastq(rng, int(rng.integers(20, 70))))
+    exp = oracle.fastq_parse(data, payload_base=FQ_BASE)
+    assert exp.error_code == 0
+    arr = np.frombuffer(data, np.uint8)
+    nl = np.flatnonzero(arr == 10)
+    n = len(data)
+    cuts = sorted({0, n} | {int(x) // 16 * 16 for x in rng.integers(1, n, int(rng.integers(1, 6)))})
+    for algo in (abi.EXG_ALGO_FUSED, abi.EXG_ALGO_FUSED_FULL):
+        got = [[] for _ in range(4)]
+        for s, e in zip(cuts[:-1], cuts[1:]):
+            halo = int(rng.choice([1024, 16384, 262144]))
+            while True:
+                h = min(halo, s) // 16 * 16
+                flags = (abi.EXG_F_BOF if s - h == 0 else 0) | (abi.EXG_F_EOF if e == n else 0)
+                res, cols, _ = run_fastq(data[s - h:e], algo, lead=h, first_line_index=int(np.searchsorted(nl, s)), flags=flags,
+                                         payload_base=FQ_BASE + s - h)
+                assert res.error_code == 0 and not (res.flags & abi.EXG_RF_FALLBACK)
+                if not (res.flags & abi.EXG_RF_HEAD_UNRESOLVED):
+                    break
+                assert h < s, "a halo that reaches the first byte of the file cannot be too short"
+                halo *= 8      # what the reader does
+            for c in range(4):
+                got[c].append(cols[c])
+        for c, name in enumerate(NAMES):
+            assert np.array_equal(np.concatenate(got[c]), exp.string_t[name][0]), (name, cuts)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_vcf_shapes_fuzz(gpu, oracle, seed):
+    from test_fuzz_gpu import mutate
+    rng = np.random.default_rng(9000 + seed)
+    lines = []
+    for k in range(int(rng.integers(5, 80))):
+        ns = int(rng.choice([0, 1, 3, 50, 300, 3000, 20000]))
+        info = b";".join(b"K%d=%d" % (i, i) for i in range(int(rng.choice([1, 3, 400]))))
+        qual = [b".", b"3", b"1e2", b"59.25"][int(rng.integers(0, 4))]
+        lines.append(b"%d\t%d\t.\tA\tC\t%s\tPASS\t%s" % (k % 22 + 1, 100 + k, qual, info) + (b"\tGT" + b"\t0/1" * ns if ns else b"") +
+                     (b"\r\n" if rng.integers(0, 7) == 0 else b"\n"))
+    base = HDR + b"".join(lines)
+    hdr = header_bytes(base)
+    for trial in range(4):
+        data = base if trial == 0 else base[:hdr] + mutate(base[hdr:], rng, int(rng.integers(1, 4)))
+        if header_bytes(data) != hdr:
+            continue
+        for algo in FUSED_AND_PARTNER:
+            res = check_vcf(oracle, data, algo)
+            no_fallback(res)
