@@ -13,6 +13,9 @@
 //     that is larger or spans rounds is hashed on a host thread from copies of its parts that come back over PCIe while the
 //     next round is being decoded; a mismatch is reported behind the frame's rows, where a streaming decoder reports it.
 #include <string.h>
+
+#include <atomic>
+#include <thread>
 #include <sys/mman.h>
 #include <unistd.h>
 
@@ -236,6 +239,24 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
         ~StreamBack() { stream_pool()->give(dev, s); }  // (synchronises it)
     } stream_back{device_, st};
     zst::Index idx;
+    const double t_idx0 = now_s();
+    // The walk below touches a few bytes of every block — a page fault per 64 KiB of the mapping (fault-around maps sixteen
+    // pages), one after the other on this thread: 80-100 ms per 2 GB, a quarter of what a 4 GB frame took end to end.  Eight
+    // threads take the faults first, a byte per 64 KiB each in turn (4-6 ms); the walk then runs at memory speed.
+    if (n_ > (8u << 20)) {
+        const unsigned nt = 8;
+        const size_t step = 64u << 10;
+        std::atomic<uint64_t> sink{0};
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++)
+            th.emplace_back([&, t] {
+                uint64_t acc = 0;
+                for (uint64_t o = (uint64_t)t * step; o < n_; o += (uint64_t)nt * step) acc += h_comp[o];
+                sink.fetch_add(acc, std::memory_order_relaxed);
+            });
+        for (auto &t : th) t.join();
+    }
+    const double t_idx1 = now_s();
     std::string damage;  // a malformed or truncated stream: the rows in front of the damage first, like a streaming decoder
     if (!zst::build_index(h_comp, n_, idx)) {
         damage = idx.error + " in '" + path_ + "'";
@@ -244,6 +265,7 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
             return EXG_E_PARSE;
         }
     }
+    if (getenv("EXG_TRACE")) fprintf(stderr, "[exg] zstd producer: index of %.1f MB (%zu blocks) %.1f ms (of which %.1f ms taking the page faults on 8 threads)\n", n_ / 1e6, idx.blocks.size(), (now_s() - t_idx0) * 1e3, (t_idx1 - t_idx0) * 1e3);
     // the frames whose first byte lies in [c_begin, c_end) (a shard decodes its own frames and a halo of frames in front)
     uint64_t b_first = idx.blocks.size(), n_blocks = 0, b_mark[2] = {~0ull, ~0ull};
     bool marked[2] = {false, false};
@@ -349,6 +371,7 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
         }
         if (nx) ZS_HIP(hipMemcpyAsync(d_comp.p, pin.p, nx * kSideSlot, hipMemcpyHostToDevice, st));
         bool hip_failed = false;
+        const double t_read0 = now_s();
         if (comp_len && !pread_parallel(device_, fd_, c_lo, (size_t)comp_len, pin.p + kSide, (char *)d_comp.p + kSide, st, &hip_failed)) {
             *err = hip_failed ? "hipMemcpyAsync failed" : "short read of '" + path_ + "'";
             return hip_failed ? EXG_E_HIP : EXG_E_IO;
@@ -398,10 +421,12 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
         R.first_block_id = b0;
         R.comp_base = c_lo - kSide;
         int rc;
+        const double t_dec0 = now_s();
         {
             TraceRange range("exg: zstd round");
             rc = zst::decode_round(R, st);
         }
+        if (getenv("EXG_TRACE")) fprintf(stderr, "[exg] zstd producer: round of %.1f MB compressed: read + h2d enqueue %.1f ms, decode %.1f ms\n", comp_len / 1e6, (t_dec0 - t_read0) * 1e3, (now_s() - t_dec0) * 1e3);
         if (rc) {
             *err = std::string(exg_last_error_message()) + " in '" + path_ + "'";
             return rc;
