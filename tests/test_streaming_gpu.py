@@ -257,10 +257,12 @@ def test_zstd_shard_behind_large_frames_holds_a_halo_not_the_frames(gpu, oracle,
     p.write_bytes(b"".join(compress(x, 1, True) for x in parts))
     exp = oracle.fastq_parse(data, want_string_t=False)
     want = list(zip(*[exp.columns[c].to_list() for c in ["name", "description", "sequence", "quality_scores"]]))
-    monkeypatch.setenv("EXG_DEVICE_MEM_CAP_MB", str(CAP_MB))
+    # (twice the other tests' cap: the 1 MiB halo a shard keeps is an allocation more than an unsharded reader makes; a frame in
+    # front of a shard decodes to 44 MB — resident, it would not fit)
+    monkeypatch.setenv("EXG_DEVICE_MEM_CAP_MB", str(2 * CAP_MB))
     rows, peaks = _shard_rows(p, "fastq", 3)
     assert rows == want
-    assert max(peaks) <= CAP_MB << 20, [x >> 20 for x in peaks]
+    assert max(peaks) <= (2 * CAP_MB) << 20, [x >> 20 for x in peaks]
 
 
 def test_bgzf_shard_whose_phase_is_counted_holds_no_prefix(gpu, oracle, tmp_path, monkeypatch):
