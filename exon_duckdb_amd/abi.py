@@ -47,7 +47,7 @@ class ScanResult(C.Structure):
         ("error_code", C.c_uint32),
         ("flags", C.c_uint32),
         ("payload_bytes", C.c_uint64),
-        ("reserved", C.c_uint64),
+        ("redo_tiles", C.c_uint64),
     ]
 
 

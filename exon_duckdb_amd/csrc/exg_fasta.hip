@@ -403,7 +403,7 @@ __global__ void k_fa_finalize(FastaDev a, FastaArrays w, ScanWsHeader *hdr, exg_
     r.flags = hdr->flags;
     if (T > hdr->lines_cap) r.flags |= EXG_RF_INDEX_OVERFLOW;
     r.payload_bytes = w.pay_pre[Tc];
-    r.reserved = 0;
+    r.redo_tiles = 0;
     r.error_code = 0;
     r.error_offset = ~0ull;
     r.error_record = ~0ull;

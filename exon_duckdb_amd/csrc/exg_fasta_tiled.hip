@@ -692,7 +692,7 @@ __global__ void k_fa_tile_finalize(FastaDev a, TileArrays t, ScanWsHeader *hdr, 
     if (n_all > t.rec_cap) r.flags |= EXG_RF_INDEX_OVERFLOW;
     // (the open record's sequence bytes were compacted like everyone's: they are simply not handed out)
     r.payload_bytes = open_tail ? (n_all && n_all <= t.rec_cap ? t.rec_start[n_all - 1] : 0) : t.totals[1];
-    r.reserved = 0;
+    r.redo_tiles = 0;
     r.error_code = 0;
     r.error_offset = ~0ull;
     r.error_record = ~0ull;

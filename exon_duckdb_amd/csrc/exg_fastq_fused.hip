@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void k_fastq_finalize_fused(FastqDev a, ScanWs
     r.n_lines = T - halo_nl;
     r.flags = hdr->flags | (hdr->any_redo ? EXG_RF_REDO : 0u);
     r.payload_bytes = 0;
-    r.reserved = 0;
+    r.redo_tiles = hdr->n_redo;
     r.error_code = 0;
     r.error_offset = ~0ull;
     r.error_record = ~0ull;

@@ -157,7 +157,7 @@ __global__ void k_fastq_finalize_mp(FastqDev a, const uint64_t *__restrict__ nl_
     r.n_lines = T - hdr->halo_nl;
     r.flags = flags;
     r.payload_bytes = 0;
-    r.reserved = 0;
+    r.redo_tiles = 0;
     r.error_code = 0;
     r.error_offset = ~0ull;
     r.error_record = ~0ull;
@@ -195,7 +195,8 @@ __global__ void k_init_hdr(ScanWsHeader *hdr, uint64_t lines_cap, uint32_t mode)
     ScanWsHeader h;
     h.n_slow = h.slow_pad = 0;
     h.any_far = h.any_redo = 0;
-    for (unsigned int i = 0; i < 19; i++) h.reserved[i] = 0;
+    h.n_redo = h.redo_pad = 0;
+    for (unsigned int i = 0; i < 18; i++) h.reserved[i] = 0;
     h.last_qend = 0;
     h.total_nl = h.total_lines = h.halo_nl = h.n_unresolved = 0;
     h.err_word = kNoError;

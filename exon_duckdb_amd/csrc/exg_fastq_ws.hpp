@@ -33,7 +33,8 @@ struct alignas(256) ScanWsHeader {
     unsigned int n_slow, slow_pad;
     unsigned int any_far;            // fused kernels: some half left a record to k_*_far (plain store of 1)
     unsigned int any_redo;           // lean scan: some super-tile is marked (tile_redo) for the any-shape run behind it
-    unsigned long long reserved[19];
+    unsigned int n_redo, redo_pad;   // super-tiles the any-shape run redid (one atomicAdd per workgroup of that run)
+    unsigned long long reserved[18];
 };
 struct SlowLiteral {
     unsigned long long off;  // input offset of the literal

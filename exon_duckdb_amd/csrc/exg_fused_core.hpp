@@ -411,10 +411,12 @@ __global__ __launch_bounds__(kThreads, kMode == kLean ? F::kMinWavesPerSimd : F:
         }
         st = blockIdx.x - 1;
     }
+    uint32_t n_redone = 0;  // (redo run) super-tiles this workgroup redid
     for (; kMode != kFullRedo || st < n_super; st += gridDim.x) {  // (one super-tile per workgroup but in the redo run)
     if constexpr (kMode == kFullRedo) {
         if (!tile_redo_of<kB>(tile_qend, a.n_bytes)[st]) continue;  // (workgroup-uniform)
         __syncthreads();                                         // the tile before is done with the LDS
+        n_redone++;
     }
     const uint64_t super_off = (uint64_t)st * kSuper;
     const uint8_t *__restrict__ d_in = a.d_in;
@@ -692,6 +694,9 @@ __global__ __launch_bounds__(kThreads, kMode == kLean ? F::kMinWavesPerSimd : F:
         if (h + 1 < kHalves) __syncthreads();  // everyone is done reading this half
     }
     if constexpr (kMode != kFullRedo) break;
+    }
+    if constexpr (kMode == kFullRedo) {
+        if (tid == 0 && n_redone) atomicAdd(&hdr->n_redo, n_redone);  // (what the caller's choice of scan for the next batch looks at)
     }
 }
 

@@ -860,7 +860,13 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             if (rc) return fail(r, rc, exg_last_error_message());
             res.flags |= EXG_RF_FALLBACK;
         }
-        if (res.flags & EXG_RF_REDO) r->fused_algo = EXG_ALGO_FUSED_FULL;  // (sticky: see exg_reader.hpp)
+        if (res.flags & EXG_RF_REDO) {
+            // sticky (exg_reader.hpp) — when the marks are the input's shape: more than an eighth of the batch's super-tiles.  The
+            // odd long read in a short-read file is cheaper redone (its tiles only) than paid for by the any-shape scan's ~20 % on
+            // every batch behind it
+            const uint64_t tile_bytes = r->format == EXG_FMT_FASTQ ? 3u * 16384u : 2u * 16384u;
+            if (res.redo_tiles * 8 > n / tile_bytes) r->fused_algo = EXG_ALGO_FUSED_FULL;
+        }
         TRACE("wait(h2d) + scan", t_scan);
         if (r->shard_first && (res.flags & EXG_RF_HEAD_UNRESOLVED) && r->file_pos - shard_halo > r->data_base) {
             // The record that ends behind the cut begins in front of the halo (a long read, a very wide VCF line): it belongs

@@ -375,9 +375,9 @@ struct exg_reader {
     bool worst_case_rows = false;
     bool ws_full = false;  // under EXG_DEVICE_MEM_CAP_MB: a batch overflowed the budgeted line index, the workspace is at full size
     // Which scan a batch starts with is sticky (an input keeps its shape): EXG_ALGO_FUSED (the lean scan + the any-shape run
-    // over what it marked) until a batch comes back with EXG_RF_REDO — long reads, reads below ~45 bp, multi-sample VCF
-    // lines, bytes >= 0x80 —, then EXG_ALGO_FUSED_FULL, the any-shape scan alone, for the rest of the input (the lean scan
-    // would mark every tile and be a pass wasted per batch).
+    // over what it marked) until a batch comes back with EXG_RF_REDO on more than an eighth of its super-tiles — long reads,
+    // reads below ~45 bp, multi-sample VCF lines, bytes >= 0x80 throughout —, then EXG_ALGO_FUSED_FULL, the any-shape scan
+    // alone, for the rest of the input (the lean scan would mark every tile and be a pass wasted per batch).
     uint32_t fused_algo = EXG_ALGO_FUSED;
     // exg_open_args.filters: postfix program + constants in device memory, a row map and one column of scratch
     bool has_filter = false;

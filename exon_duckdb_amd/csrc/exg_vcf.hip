@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256) void k_vcf_finalize(VcfDev a, ScanWsHeader *hd
     r.flags = hdr->flags | (gate ? EXG_RF_FALLBACK : 0u) | (fused && hdr->any_redo ? EXG_RF_REDO : 0u);
     if (!fused && T > hdr->lines_cap) r.flags |= EXG_RF_INDEX_OVERFLOW;
     r.payload_bytes = 0;
-    r.reserved = 0;
+    r.redo_tiles = fused ? hdr->n_redo : 0;
     r.error_code = 0;
     r.error_offset = ~0ull;
     r.error_record = ~0ull;

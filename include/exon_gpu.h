@@ -138,7 +138,9 @@ typedef struct exg_scan_result {
     uint32_t error_code;     /* EXG_PE_* */
     uint32_t flags;          /* EXG_RF_* */
     uint64_t payload_bytes;  /* FASTA: bytes written to the compacted sequence payload */
-    uint64_t reserved;
+    uint64_t redo_tiles;     /* EXG_RF_REDO: super-tiles (FASTQ: 48 KiB, VCF: 32 KiB of input each) the any-shape run redid behind the
+                              * lean scan — few: the odd long read in a short-read file, cheaper redone than scanned any-shape
+                              * throughout; most of them: an input of that shape (EXG_ALGO_FUSED_FULL from here on) */
 } exg_scan_result;
 
 /* FASTQ: 4 VARCHAR columns name, description, sequence, quality_scores

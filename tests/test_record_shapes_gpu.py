@@ -276,6 +276,26 @@ def test_reader_long_reads_switch_to_the_any_shape_scan(gpu, oracle, tmp_path, c
     assert len(rows) == 40000 and st["scan_algo"] == abi.EXG_ALGO_FUSED
 
 
+def test_reader_the_odd_long_read_does_not_change_the_scan(gpu, oracle, tmp_path):
+    """150 bp reads with a 30 kb read every ~4 MB: the lean scan marks a tile or two per batch, the any-shape run redoes them
+    (exg_scan_result.redo_tiles), and the reader stays on the lean scan — it switches when the marks are the input's shape"""
+    parts = []
+    for k in range(12):
+        parts.append(bytes(oracle.synth_fastq(332 * 12000, file_offset=332 * 12000 * k)))
+        parts.append(bytes(fastq_records([30000 + 1000 * k], seed=k)))
+    data = b"".join(parts)
+    p = tmp_path / "mostly_short.fastq"
+    p.write_bytes(data)
+    rows, st = _reader_rows(p, "fastq", device_batch_bytes=4 << 20)
+    assert rows == _fastq_rows(oracle, data)
+    assert st["device_batches"] >= 10 and st["scan_algo"] == abi.EXG_ALGO_FUSED
+    # device level: the count of redone tiles
+    res, _, _ = run_fastq(data, abi.EXG_ALGO_FUSED)
+    assert res.flags & abi.EXG_RF_REDO and 12 <= res.redo_tiles <= 40, res.redo_tiles
+    res, _, _ = run_fastq(fastq_records([15000] * 200, seed=2), abi.EXG_ALGO_FUSED)
+    assert res.redo_tiles >= (200 * 30000 // 49152) * 0.9
+
+
 def test_reader_short_reads_and_wide_vcf(gpu, oracle, tmp_path):
     data = fastq_records([36] * 60000, seed=3, desc_every=0)
     p = tmp_path / "short36.fastq"
