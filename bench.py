@@ -619,8 +619,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--launches-per-step", type=int, default=24, help="scan launches per step (keeps the timed region above 1 s: 20 steps x 24 x 2.3 ms)")
     ap.add_argument("--gb", type=float, default=None, help="shard size per GPU in GB (1e9 bytes); default 10 (N=1), 12.5 (N>1: N=8 is 100 GB)")
-    ap.add_argument("--algo", type=int, default=2, help="2 = the fused scan alone, which is what the reader launches per batch (it re-runs the "
-                    "general path only when a launch reports EXG_RF_FALLBACK; asserted clear here); 0 = fused + the gated general-path launches")
+    ap.add_argument("--algo", type=int, default=2, help="2 = the fused scan, which is what the reader launches per batch (EXG_RF_FALLBACK asserted clear); 3 = the any-shape "
+                    "scan alone (what a reader switches to on long / very short reads); 0 = fused + the gated general-path launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the configs / end_to_end legs")
     ap.add_argument("--vcf-gb", type=float, default=5.0)
@@ -800,7 +800,8 @@ def main():
                 "bytes_per_gpu": n_bytes,
                 "launches_per_step": L,
                 "ms_per_launch": dt / args.steps / L * 1e3,
-                "algo": {0: "auto(fused+gated general path)", 1: "multipass", 2: "fused (the reader's launch; EXG_RF_FALLBACK asserted clear)"}[args.algo],
+                "algo": {0: "auto(fused+gated general path)", 1: "multipass", 2: "fused (the reader's launch: the lean scan + the any-shape run over what it "
+                         "marked — nothing on this input; EXG_RF_FALLBACK asserted clear)", 3: "fused_full (the any-shape scan alone)"}[args.algo],
                 "columns": "name,description,sequence,quality_scores as duckdb::string_t + validity",
                 "verification": "every row of the last launch's four columns + validity against the generator's closed forms, on the device",
             },
