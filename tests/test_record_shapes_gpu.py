@@ -358,7 +358,7 @@ def _random_fastq(rng, n_rec):
     return fastq_records(lengths, seed=int(rng.integers(1 << 30)), crlf_every=int(rng.integers(0, 9)), desc_every=int(rng.integers(0, 4)))
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("EXG_SHAPES_FUZZ", "10"))))
 def test_fastq_shapes_fuzz(gpu, oracle, seed):
     from test_fuzz_gpu import mutate
     rng = np.random.default_rng(7000 + seed)
@@ -370,7 +370,7 @@ def test_fastq_shapes_fuzz(gpu, oracle, seed):
             no_fallback(res)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("EXG_SHAPES_FUZZ", "6"))))
 def test_fastq_shapes_shard_cuts_fuzz(gpu, oracle, seed):
     """random 16-byte-aligned cuts with random halos over a random mix of record sizes: the shards' rows are the file's rows, or
     a shard says that its halo does not reach the head of its first record (and with the whole prefix as halo it has them)"""
@@ -402,7 +402,7 @@ def test_fastq_shapes_shard_cuts_fuzz(gpu, oracle, seed):
             assert np.array_equal(np.concatenate(got[c]), exp.string_t[name][0]), (name, cuts)
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("EXG_SHAPES_FUZZ", "8"))))
 def test_vcf_shapes_fuzz(gpu, oracle, seed):
     from test_fuzz_gpu import mutate
     rng = np.random.default_rng(9000 + seed)
