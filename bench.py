@@ -323,6 +323,7 @@ def run_record_shapes(torch, lib, args):
     from exon_duckdb_amd import abi, device
     from exon_duckdb_amd.testing import shapes
     out = {}
+    only = getattr(args, "shape_only", "")   # (tools/shapes_probe.py: legs whose name begins with this)
     target = int(args.shape_gb * 1e9)
 
     def tiled(header, block):
@@ -403,6 +404,8 @@ def run_record_shapes(torch, lib, args):
         torch.cuda.empty_cache()
 
     def leg(fn, key, *a):
+        if only and not key.startswith(only):
+            return
         try:
             fn(key, *a)
         except Exception as e:  # noqa: BLE001

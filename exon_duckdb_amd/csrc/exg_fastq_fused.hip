@@ -230,7 +230,11 @@ struct FastqFormat {
     static constexpr bool kBarriers = true;   // (exg_fused_core.hpp opaque: its lean scan spills without them)
     static constexpr int kHalves = kFastqHalves;
     static constexpr int kMinWavesPerSimd = 6;  // 80 VGPRs, no scratch: 6 x 48 KiB in flight per CU
-    static constexpr int kMinWavesPerSimdFull = 5;  // the any-shape instances: 96 VGPRs (their pass loop and FarRec code spill at 80)
+#ifndef EXG_FASTQ_WAVES_FULL
+#define EXG_FASTQ_WAVES_FULL 5
+#endif
+    static constexpr int kMinWavesPerSimdRedo = 5;
+    static constexpr int kMinWavesPerSimdFull = EXG_FASTQ_WAVES_FULL;  // the any-shape instances: 96 VGPRs (their pass loop and FarRec code spill at 80)
     // noodles-fastq at EOF: a record that has its '+' line but no quality line gets an empty one
     __device__ static __forceinline__ uint32_t eof_extra_lines(unsigned long long total_lines) {
         return (total_lines & 3) == 3 ? 1u : 0u;

@@ -380,7 +380,7 @@ __device__ __forceinline__ FarRec *far_rec_of(unsigned long long *tile_qend, uin
 }
 
 template <class F, int kMode>
-__global__ __launch_bounds__(kThreads, kMode == kLean ? F::kMinWavesPerSimd : F::kMinWavesPerSimdFull) void k_fused(
+__global__ __launch_bounds__(kThreads, kMode == kLean ? F::kMinWavesPerSimd : kMode == kFullPrimary ? F::kMinWavesPerSimdFull : F::kMinWavesPerSimdRedo) void k_fused(
     typename F::Dev a, unsigned int *__restrict__ tileA, unsigned long long *__restrict__ tileP, unsigned long long *__restrict__ tile_qend,
     ScanWsHeader *hdr, uint32_t n_super) {
     using FusedLds = FusedLdsT<F::kNlCap, F::kHalves, F::kTabMap>;

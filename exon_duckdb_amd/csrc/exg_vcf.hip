@@ -209,7 +209,10 @@ struct LdsSrc {
     __device__ __forceinline__ uint4 str(int e, uint32_t len) const { return make_string_lds(s, e, len, ptr_of_e0); }
 };
 
-static constexpr int kVcfHalves = 2;
+#ifndef EXG_VCF_HALVES
+#define EXG_VCF_HALVES 2
+#endif
+static constexpr int kVcfHalves = EXG_VCF_HALVES;
 struct VcfFormat {
     using Dev = VcfDev;
     static constexpr int kNlCap = 1024;  // short data lines are common
@@ -220,7 +223,12 @@ struct VcfFormat {
 #define EXG_VCF_WAVES 5
 #endif
     static constexpr int kMinWavesPerSimd = EXG_VCF_WAVES;
-    static constexpr int kMinWavesPerSimdFull = 4;  // the any-shape instances (their pass loop and FarRec code want registers)
+#ifndef EXG_VCF_WAVES_FULL
+#define EXG_VCF_WAVES_FULL 5
+#endif
+    static constexpr int kMinWavesPerSimdRedo = 4;  // the redo launch: few tiles, latency of one tile matters, not occupancy (128 VGPRs, 28 B of scratch)
+    static constexpr int kMinWavesPerSimdFull = EXG_VCF_WAVES_FULL;  // the any-shape scan alone: 96 VGPRs + 32 B of scratch, and still 12 % faster on wide
+    // (multi-sample) lines than at 4 waves without scratch — those lines write little, so the scan is bound by bytes in flight per CU
     __device__ static __forceinline__ uint32_t eof_extra_lines(unsigned long long) { return 0; }
     __device__ static __forceinline__ unsigned long long analytic_prefix(uint64_t) { return 0; }
 
