@@ -90,17 +90,27 @@ __device__ __forceinline__ int hb32(uint32_t v) { return 31 - __clz((int)v); }
 // ---- FSE ----------------------------------------------------------------------------------------------------------
 // table entry: symbol | nbBits << 8 | newStateBase << 16
 // RFC 8878 4.1.1: normalised counts from a forward bitstream.  Returns the bytes consumed or -1.  One lane.
-__device__ int fse_read_norm(const uint8_t *p, int len, int max_log, int max_sym, int16_t *norm, int *n_sym, int *log_out) {
+__device__ __forceinline__ int fse_read_norm(const uint8_t *p, int len, int max_log, int max_sym, int16_t *norm, int *n_sym, int *log_out) {
     if (len < 1) return -1;
+    // forward bits through a register container: one global load per ~57 bits, not one per field
+    uint64_t c = ld64(p);
+    uint32_t cbit = 0;  // c = the 64 bits from bit cbit (a multiple of 8) on
+    auto peek = [&](uint32_t bit, uint32_t n) -> uint32_t {
+        if (bit + n > cbit + 64) {
+            cbit = bit & ~7u;
+            c = ld64(p + (cbit >> 3));
+        }
+        return (uint32_t)(c >> (bit - cbit)) & ((1u << n) - 1);
+    };
     uint32_t bit = 0;
-    const int log = 5 + (int)fwd_peek(p, bit, 4);
+    const int log = 5 + (int)peek(bit, 4);
     bit += 4;
     if (log > max_log) return -1;
     int remaining = 1 << log, s = 0;
     while (remaining > 0 && s <= max_sym) {
         const int nb = hb32((uint32_t)remaining + 1) + 1;
         if ((int)((bit + nb + 7) >> 3) > len + 4) return -1;
-        uint32_t val = fwd_peek(p, bit, nb);
+        uint32_t val = peek(bit, nb);
         const uint32_t lower = (1u << (nb - 1)) - 1, thresh = (1u << nb) - 1 - ((uint32_t)remaining + 1);
         if ((val & lower) < thresh) {
             bit += nb - 1;
@@ -114,7 +124,7 @@ __device__ int fse_read_norm(const uint8_t *p, int len, int max_log, int max_sym
         norm[s++] = (int16_t)proba;
         if (proba == 0) {
             for (;;) {
-                const int rep = (int)fwd_peek(p, bit, 2);
+                const int rep = (int)peek(bit, 2);
                 bit += 2;
                 for (int i = 0; i < rep && s <= max_sym; i++) norm[s++] = 0;
                 if (rep != 3) break;
@@ -130,7 +140,7 @@ __device__ int fse_read_norm(const uint8_t *p, int len, int max_log, int max_sym
     return bytes;
 }
 // decoding table from normalised counts (one lane; `next` is scratch of 64 entries)
-__device__ int fse_build(uint32_t *tab, const int16_t *norm, int n_sym, int log, uint16_t *next) {
+__device__ __forceinline__ int fse_build(uint32_t *tab, const int16_t *norm, int n_sym, int log, uint16_t *next) {
     const int size = 1 << log;
     int high = size;
     for (int s = 0; s < n_sym; s++)
@@ -162,134 +172,187 @@ __device__ int fse_build(uint32_t *tab, const int16_t *norm, int n_sym, int log,
 }
 
 // ---- literals -------------------------------------------------------------------------------------------------------
-struct LitLds {
+// A block's Huffman literals are four independent backward bitstreams: four lanes.  Like the sequences (below), a wavefront
+// per block spends the chip's issue slots on four-lane instructions (5.8 ms per 1 GiB round, and the sequences kernel
+// beside it starved of issue slots), so a wavefront takes kLitG blocks, four lanes each, with each block's single-lookup
+// table (4 KiB) in LDS; a lane reads its stream through a 128-byte ring of its own in LDS (see SeqLds), which lies over
+// the scratch the table was built with.
+static constexpr int kLitG = 8;  // blocks per wavefront
+struct LitBlk {
     uint16_t tab[2048];  // symbol | nbBits << 8, indexed by the next `log` bits
-    uint32_t fse[64];    // weights' FSE table (accuracy log <= 6)
-    int16_t norm[64];
-    uint16_t next[64];
-    uint8_t w[256];
-    uint32_t rank_start[16];
+    union {
+        struct {
+            uint32_t fse[64];  // weights' FSE table (accuracy log <= 6)
+            int16_t norm[64];
+            uint16_t next[64];
+            uint8_t w[256];
+            uint32_t rank_start[16];
+        };
+        uint32_t ring[4][2 * 64 / 4 + 1];  // a stream's bytes: byte x at ring[q] byte x & 127 (+ 1: banks)
+    };
     int result;  // tree description bytes, or -1
     int log;
 };
+struct LitLds {
+    LitBlk blk[kLitG];
+};
 
-// Huffman tree description at p (at most `avail` bytes) -> s.tab.  Lane 0 works, the wave waits.  RFC 8878 4.2.1.
-__device__ void huf_build(LitLds &s, const uint8_t *p, int avail, uint32_t lane) {
-    if (lane == 0) {
-        int res = -1, n = 0;
-        do {
-            if (avail < 1) break;
-            const int hdr = p[0];
-            if (hdr >= 128) {  // direct: 4 bits per weight
-                n = hdr - 127;
-                const int bytes = (n + 1) / 2;
-                if (1 + bytes > avail) break;
-                for (int i = 0; i < n; i++) s.w[i] = (i & 1) ? (p[1 + i / 2] & 15) : (p[1 + i / 2] >> 4);
-                res = 1 + bytes;
-            } else {  // FSE-coded weights, two interleaved states
-                if (hdr == 0 || 1 + hdr > avail) break;
-                int ns = 0, log = 0;
-                const int used = fse_read_norm(p + 1, hdr, 6, 12, s.norm, &ns, &log);
-                if (used < 0) break;
-                if (fse_build(s.fse, s.norm, ns, log, s.next)) break;
-                BitsRev b;
-                if (!b.init(p + 1 + used, hdr - used)) break;
-                b.need(2 * log);
-                uint32_t s1 = b.read(log), s2 = b.read(log);
-                bool bad = false;
-                for (;;) {
-                    if (n >= 254) { bad = true; break; }
-                    uint32_t e = s.fse[s1];
-                    s.w[n++] = (uint8_t)e;
-                    b.need((e >> 8) & 255);
-                    s1 = (e >> 16) + b.read((e >> 8) & 255);
-                    if (b.left() < 0) {
-                        s.w[n++] = (uint8_t)s.fse[s2];
-                        break;
-                    }
-                    if (n >= 254) { bad = true; break; }
-                    e = s.fse[s2];
-                    s.w[n++] = (uint8_t)e;
-                    b.need((e >> 8) & 255);
-                    s2 = (e >> 16) + b.read((e >> 8) & 255);
-                    if (b.left() < 0) {
-                        s.w[n++] = (uint8_t)s.fse[s1];
-                        break;
-                    }
+// Huffman tree description at p (at most `avail` bytes) -> s.tab, s.result, s.log.  One lane.  RFC 8878 4.2.1.
+__device__ __forceinline__ void huf_build(LitBlk &s, const uint8_t *p, int avail) {
+    int res = -1, n = 0;
+    do {
+        if (avail < 1) break;
+        const int hdr = p[0];
+        if (hdr >= 128) {  // direct: 4 bits per weight
+            n = hdr - 127;
+            const int bytes = (n + 1) / 2;
+            if (1 + bytes > avail) break;
+            for (int i = 0; i < n; i++) s.w[i] = (i & 1) ? (p[1 + i / 2] & 15) : (p[1 + i / 2] >> 4);
+            res = 1 + bytes;
+        } else {  // FSE-coded weights, two interleaved states
+            if (hdr == 0 || 1 + hdr > avail) break;
+            int ns = 0, log = 0;
+            const int used = fse_read_norm(p + 1, hdr, 6, 12, s.norm, &ns, &log);
+            if (used < 0) break;
+            if (fse_build(s.fse, s.norm, ns, log, s.next)) break;
+            BitsRev b;
+            if (!b.init(p + 1 + used, hdr - used)) break;
+            b.need(2 * log);
+            uint32_t s1 = b.read(log), s2 = b.read(log);
+            bool bad = false;
+            for (;;) {
+                if (n >= 254) { bad = true; break; }
+                uint32_t e = s.fse[s1];
+                s.w[n++] = (uint8_t)e;
+                b.need((e >> 8) & 255);
+                s1 = (e >> 16) + b.read((e >> 8) & 255);
+                if (b.left() < 0) {
+                    s.w[n++] = (uint8_t)s.fse[s2];
+                    break;
                 }
-                if (bad) break;
-                res = 1 + hdr;
+                if (n >= 254) { bad = true; break; }
+                e = s.fse[s2];
+                s.w[n++] = (uint8_t)e;
+                b.need((e >> 8) & 255);
+                s2 = (e >> 16) + b.read((e >> 8) & 255);
+                if (b.left() < 0) {
+                    s.w[n++] = (uint8_t)s.fse[s1];
+                    break;
+                }
             }
-            // weights -> code lengths; the last weight is implied (the total must become a power of two)
-            uint32_t total = 0, cnt[13];
-            for (int k = 0; k < 13; k++) cnt[k] = 0;
-            bool ok = true;
-            for (int i = 0; i < n; i++) {
-                const uint32_t w = s.w[i];
-                if (w > 11) { ok = false; break; }
-                total += w ? 1u << (w - 1) : 0u;
-                cnt[w]++;
-            }
-            if (!ok || total == 0) { res = -1; break; }
-            const int log = hb32(total) + 1;
-            const uint32_t rest = (1u << log) - total;
-            if (log > 11 || (rest & (rest - 1))) { res = -1; break; }
-            const uint32_t lastw = (uint32_t)hb32(rest) + 1;
-            s.w[n++] = (uint8_t)lastw;
-            cnt[lastw]++;
-            if (cnt[1] < 2 || (cnt[1] & 1)) { res = -1; break; }  // libzstd (HUF_readStats): an even number >= 2 of the longest codes
-            uint32_t pos = 0;
-            for (int k = 1; k <= log; k++) {
-                s.rank_start[k] = pos;
-                pos += cnt[k] << (k - 1);
-            }
-            for (int i = 0; i < n; i++) {
-                const uint32_t w = s.w[i];
-                if (!w) continue;
-                const uint32_t len = 1u << (w - 1), at = s.rank_start[w];
-                const uint16_t e = (uint16_t)((uint32_t)i | ((uint32_t)(log + 1 - (int)w) << 8));
-                for (uint32_t j = 0; j < len; j++) s.tab[at + j] = e;
-                s.rank_start[w] = at + len;
-            }
-            s.log = log;
-        } while (0);
-        s.result = res;
-    }
-    __syncthreads();
+            if (bad) break;
+            res = 1 + hdr;
+        }
+        // weights -> code lengths; the last weight is implied (the total must become a power of two)
+        uint32_t total = 0;
+        for (int k = 0; k < 13; k++) s.rank_start[k] = 0;  // (counts first, start positions below)
+        bool ok = true;
+        for (int i = 0; i < n; i++) {
+            const uint32_t w = s.w[i];
+            if (w > 11) { ok = false; break; }
+            total += w ? 1u << (w - 1) : 0u;
+            s.rank_start[w]++;
+        }
+        if (!ok || total == 0) { res = -1; break; }
+        const int log = hb32(total) + 1;
+        const uint32_t rest = (1u << log) - total;
+        if (log > 11 || (rest & (rest - 1))) { res = -1; break; }
+        const uint32_t lastw = (uint32_t)hb32(rest) + 1;
+        s.w[n++] = (uint8_t)lastw;
+        s.rank_start[lastw]++;
+        if (s.rank_start[1] < 2 || (s.rank_start[1] & 1)) { res = -1; break; }  // libzstd (HUF_readStats): an even number >= 2 of the longest codes
+        uint32_t pos = 0;
+        for (int k = 1; k <= log; k++) {
+            const uint32_t cnt = s.rank_start[k];
+            s.rank_start[k] = pos;
+            pos += cnt << (k - 1);
+        }
+        for (int i = 0; i < n; i++) {
+            const uint32_t w = s.w[i];
+            if (!w) continue;
+            const uint32_t len = 1u << (w - 1), at = s.rank_start[w];
+            const uint16_t e = (uint16_t)((uint32_t)i | ((uint32_t)(log + 1 - (int)w) << 8));
+            for (uint32_t j = 0; j < len; j++) s.tab[at + j] = e;
+            s.rank_start[w] = at + len;
+        }
+        s.log = log;
+    } while (0);
+    s.result = res;
 }
 
-// one Huffman stream of `nout` symbols -> out.  false: the stream does not end where its symbols do.
-__device__ bool huf_stream(const LitLds &s, const uint8_t *p, long long len, uint8_t *out, uint32_t nout) {
-    BitsRev b;
-    if (!b.init(p, len)) return false;
-    const uint32_t log = (uint32_t)s.log;
+// 64 bytes of the stream [sp, sp + len) for a lane's ring (seq_half_load's twin is below; this one is shared)
+struct RingHalf {
+    uint4 q[4];
+};
+__device__ __forceinline__ RingHalf ring_half_load(const uint8_t *sp, int len, int h) {
+    RingHalf r;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int x = h * 64 + 16 * k;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (h >= 0 && x < len) __builtin_memcpy(&v, sp + x, 16);  // (zeros in front of the stream; no read goes 16 bytes past its end)
+        r.q[k] = v;
+    }
+    return r;
+}
+__device__ __forceinline__ void ring_half_store(uint32_t *ring, int h, const RingHalf &v) {
+    uint32_t *dst = ring + (h & 1) * 16;  // (4-byte aligned only: the ring's stride is odd)
+#pragma unroll
+    for (int k = 0; k < 4; k++) dst[4 * k] = v.q[k].x, dst[4 * k + 1] = v.q[k].y, dst[4 * k + 2] = v.q[k].z, dst[4 * k + 3] = v.q[k].w;
+}
+
+// one Huffman stream of `nout` symbols -> out, read through `ring`.  false: the stream does not end where its symbols do.
+__device__ __forceinline__ bool huf_stream(const uint16_t *tab, uint32_t log, uint32_t *ring, const uint8_t *p, int len, uint8_t *out, uint32_t nout) {
+    if (len <= 0) return false;
+    int w_h = ((len - 1) >> 6) - 1;  // the lower of the two resident halves: stream bytes [64 w_h, 64 w_h + 128)
+    ring_half_store(ring, w_h + 1, ring_half_load(p, len, w_h + 1));
+    ring_half_store(ring, w_h, ring_half_load(p, len, w_h));
+    RingHalf below = ring_half_load(p, len, w_h - 1);  // in flight while the lane decodes
+    const uint32_t top = (ring[((uint32_t)(len - 1) >> 2) & 31u] >> (8u * ((uint32_t)(len - 1) & 3u))) & 255u;
+    if (top == 0) return false;  // no end mark in the last byte
+    const int P = 8 * (len - 1) + hb32(top);  // the stream's bits [0, P) are to be read, from the top
+    // c: the next bits, left-aligned, `avail` of them valid; wi: the 32-bit word of the stream that goes in next
+    uint64_t c = 0;
+    int avail = 0, wi = -1;
+    if (P > 0) {
+        wi = (P - 1) >> 5;
+        const int cnt = P - 32 * wi;  // 1 .. 32
+        const uint32_t word = ring[(uint32_t)wi & 31u] & (cnt == 32 ? ~0u : (1u << cnt) - 1);
+        c = (uint64_t)word << (64 - cnt);
+        avail = cnt;
+        wi--;
+    }
+    auto sym = [&]() -> uint32_t {
+        const bool rf = avail <= 32;  // (after it avail >= 33, a symbol takes at most 11)
+        const uint32_t wv = ring[(uint32_t)wi & 31u];
+        if (rf) c |= (uint64_t)wv << ((32 - avail) & 63), avail += 32, wi--;
+        const uint32_t e = tab[(uint32_t)(c >> (64 - log))];
+        c <<= e >> 8;
+        avail -= (int)(e >> 8);
+        return e & 255u;
+    };
+    auto ring_ok = [&]() {  // eight symbols take at most 88 bits: three words
+        if (4 * (wi - 3) < w_h * 64) {
+            w_h--;  // half w_h + 2 is behind the reader: the half below takes its place
+            ring_half_store(ring, w_h, below);
+            below = ring_half_load(p, len, w_h - 1);
+        }
+    };
     uint32_t i = 0;
     // head: bytes until the output address is 8-byte aligned, then 8 symbols per store
-    while (i < nout && (((uintptr_t)(out + i)) & 7)) {
-        b.need(log);
-        const uint32_t e = s.tab[b.peek(log)];
-        b.used += e >> 8;
-        out[i++] = (uint8_t)e;
-    }
+    ring_ok();
+    while (i < nout && (((uintptr_t)(out + i)) & 7)) out[i++] = (uint8_t)sym();
     while (i + 8 <= nout) {
+        ring_ok();
         uint64_t acc = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            b.need(log);
-            const uint32_t e = s.tab[b.peek(log)];
-            b.used += e >> 8;
-            acc |= (uint64_t)(e & 255) << (8 * k);
-        }
+        for (int k = 0; k < 8; k++) acc |= (uint64_t)sym() << (8 * k);
         *reinterpret_cast<uint64_t *>(out + i) = acc;
         i += 8;
     }
-    while (i < nout) {
-        b.need(log);
-        const uint32_t e = s.tab[b.peek(log)];
-        b.used += e >> 8;
-        out[i++] = (uint8_t)e;
-    }
-    return b.left() == 0;
+    ring_ok();
+    while (i < nout) out[i++] = (uint8_t)sym();
+    return 32 * (wi + 1) + avail == 0;
 }
 
 __device__ __forceinline__ void block_fail(Block *blocks, uint32_t b, uint32_t code) { atomicCAS(&blocks[b].status, 0u, code); }
@@ -297,31 +360,29 @@ __device__ __forceinline__ void block_fail(Block *blocks, uint32_t b, uint32_t c
 // (b_begin: the blocks in front of it are only there as the sources of repeated tables — a round of a longer stream)
 __global__ __launch_bounds__(64) void k_zst_literals(const uint8_t *__restrict__ comp, Block *blocks, uint32_t b_begin, uint32_t nb, uint8_t *lit) {
     __shared__ LitLds s;
-    const uint32_t lane = threadIdx.x;
-    for (uint32_t b = b_begin + blockIdx.x; b < nb; b += gridDim.x) {
-        const Block B = blocks[b];
-        if (B.type != 2) continue;
-        const uint8_t *p = comp + B.src_off;
-        uint8_t *out = lit + B.lit_off;
-        const uint32_t regen = B.lit_regen;
-        if (B.lit_type == 0) {
-            const uint8_t *src = p + B.lit_hdr;
-            for (uint32_t i = lane; i < regen; i += 64) out[i] = src[i];
-        } else if (B.lit_type == 1) {
-            const uint8_t v = p[B.lit_hdr];
-            for (uint32_t i = lane; i < regen; i += 64) out[i] = v;
-        } else {
-            const Block S = blocks[B.huf_src];
-            huf_build(s, comp + S.src_off + S.lit_hdr, (int)S.lit_csize, lane);
-            const int tree = s.result;
-            if (tree < 0) {
-                if (lane == 0) block_fail(blocks, b, kErrHuffman);
-            } else {
-                const uint8_t *st = p + B.lit_hdr + (B.lit_type == 2 ? tree : 0);
-                const long long left = (long long)B.lit_csize - (B.lit_type == 2 ? tree : 0);
-                bool ok = true;
-                if (B.lit_streams == 1) {
-                    if (lane == 0) ok = left >= 1 && huf_stream(s, st, left, out, regen);
+    const uint32_t lane = threadIdx.x, g = (lane >> 2) & (kLitG - 1), q = lane & 3;
+    for (uint32_t b0 = b_begin + blockIdx.x * kLitG; b0 < nb; b0 += gridDim.x * kLitG) {  // (wave-uniform)
+        // ---- Huffman literals: lanes 4 g .. 4 g + 3 take block b0 + g ----
+        const uint32_t b = b0 + g;
+        const Block *const Bp = blocks + (b < nb ? b : b0);
+        const bool huf = lane < 4 * kLitG && b < nb && Bp->type == 2 && Bp->lit_type >= 2;
+        LitBlk &L = s.blk[g];
+        if (huf && q == 0) {
+            const Block *const S = blocks + Bp->huf_src;
+            huf_build(L, comp + S->src_off + S->lit_hdr, (int)S->lit_csize);
+        }
+        __syncthreads();
+        if (huf) {
+            const int tree = L.result;
+            const uint32_t log = (uint32_t)L.log;
+            bool ok = tree >= 0;
+            if (ok) {
+                const uint32_t regen = Bp->lit_regen, lit_type = Bp->lit_type;
+                const uint8_t *st = comp + Bp->src_off + Bp->lit_hdr + (lit_type == 2 ? tree : 0);
+                const long long left = (long long)Bp->lit_csize - (lit_type == 2 ? tree : 0);
+                uint8_t *out = lit + Bp->lit_off;
+                if (Bp->lit_streams == 1) {
+                    if (q == 0) ok = left >= 1 && huf_stream(L.tab, log, L.ring[0], st, (int)left, out, regen);
                 } else {
                     // jump table: three 16-bit stream sizes; the fourth is the rest (4.2.2)
                     bool geo = left >= 10;  // libzstd: jump table + at least one byte per stream
@@ -337,17 +398,31 @@ __global__ __launch_bounds__(64) void k_zst_literals(const uint8_t *__restrict__
                     }
                     if (!geo) {
                         ok = false;
-                    } else if (lane < 4) {
+                    } else {
                         const uint8_t *a = st + 6;
-                        const uint32_t start = lane == 0 ? 0 : lane == 1 ? s1 : lane == 2 ? s1 + s2 : s1 + s2 + s3;
-                        const long long len = lane == 0 ? s1 : lane == 1 ? s2 : lane == 2 ? s3 : s4;
-                        const uint32_t nout = lane < 3 ? per : regen - 3 * per;
-                        ok = huf_stream(s, a + start, len, out + lane * per, nout);
+                        const uint32_t start = q == 0 ? 0 : q == 1 ? s1 : q == 2 ? s1 + s2 : s1 + s2 + s3;
+                        const long long len = q == 0 ? s1 : q == 1 ? s2 : q == 2 ? s3 : s4;
+                        const uint32_t nout = q < 3 ? per : regen - 3 * per;
+                        ok = huf_stream(L.tab, log, L.ring[q], a + start, (int)len, out + q * per, nout);
                     }
                 }
-                if (!__all(ok) && lane == 0) block_fail(blocks, b, kErrHuffman);
             }
-            __syncthreads();  // s is rebuilt for the next block
+            if (!ok) block_fail(blocks, b, kErrHuffman);
+        }
+        __syncthreads();  // the tables and rings are the next blocks' from here
+        // ---- raw and RLE literals: the whole wavefront, block after block ----
+        for (uint32_t k = 0; k < (uint32_t)kLitG && b0 + k < nb; k++) {
+            const Block *const Rp = blocks + b0 + k;
+            if (Rp->type != 2 || Rp->lit_type >= 2) continue;
+            const uint8_t *src = comp + Rp->src_off + Rp->lit_hdr;
+            uint8_t *out = lit + Rp->lit_off;
+            const uint32_t regen = Rp->lit_regen;
+            if (Rp->lit_type == 0) {
+                for (uint32_t i = lane; i < regen; i += 64) out[i] = src[i];
+            } else {
+                const uint8_t v = src[0];
+                for (uint32_t i = lane; i < regen; i += 64) out[i] = v;
+            }
         }
     }
 }
@@ -369,63 +444,110 @@ __constant__ uint32_t kMLCode[53] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15
                                      259 | (8u << 24), 515 | (9u << 24), 1027 | (10u << 24), 2051 | (11u << 24), 4099 | (12u << 24),
                                      8195 | (13u << 24), 16387 | (14u << 24), 32771 | (15u << 24), 65539 | (16u << 24)};
 
+// One lane decodes one block's sequences: the backward bitstream is a serial chain of dependent table lookups (RFC 8878
+// 4.1 offers nothing else inside a block).  A wavefront with ONE such lane still pays a full issue slot per instruction, and
+// with a wavefront per block every SIMD of the chip spent its cycles issuing single-lane instructions: 17.8 ms per 1 GiB
+// round (8 192 blocks of ~9 500 sequences), whatever the lane waited for.  So:
+//  * a wavefront takes kSeqG blocks, a lane each — one instruction stream serves them all;
+//  * a block's three tables take 2.5 KiB of LDS, not 5: an entry is the symbol and x, the state's rank among the symbol's
+//    states plus the symbol's count (16 bits); the bits to read and the next state's base follow from x in four
+//    instructions (nb = log - floor(log2 x), base = (x << nb) - 2^log).  Six wavefronts per CU: every block of a 1 GiB
+//    round is in flight at once, and the kernel's time is one block's chain;
+//  * the chain never waits for HBM and has no container to refill: a lane reads each bit field straight from a 128-byte ring
+//    of its own in LDS (two words, v_alignbit, v_bfe) at a position that follows from the code lookups — the six fields of a
+//    sequence are independent reads.  The ring is refilled 64 bytes at a time from registers that were loaded one refill
+//    earlier (the s_waitcnt in front of it also waits for the lane's stores — loads and stores share vmcnt on gfx9 — so it
+//    is paid once per ~20 sequences).
+static constexpr int kSeqG = 8;      // blocks per wavefront
+static constexpr int kSeqHalf = 64;  // bytes of a ring half: half h = stream bytes [64 h, 64 h + 64), h < 0: zeros
 struct SeqLds {
-    uint32_t tab[3][512];  // LL, OF (256 used), ML
+    uint16_t tab[kSeqG][1280];  // per block: LL [0, 512), OF [512, 768), ML [768, 1280); entry = symbol | x << 6
+    uint32_t ring[kSeqG][2 * kSeqHalf / 4 + 1];  // stream byte x of block g lives at ring[g] byte x & 127 (halves h, h + 1 resident; + 1: banks)
+    int16_t norm[kSeqG][64];
+    uint16_t next[kSeqG][64];
     uint32_t ll_code[36], ml_code[53];
-    int16_t norm[64];
-    uint16_t next[64];
-    int log[3];
-    int result;
-    uint32_t q_off;  // where the block's bitstream begins (offset from the block start)
 };
 
-// table t (0 LL, 1 OF, 2 ML) as block S's sequences section defines it (its mode there is not Repeat).  One lane.
-// *after: when S is the block being decoded, the offset just behind the table's description.
-__device__ int seq_table_from(SeqLds &s, int t, const uint8_t *comp, const Block &S, uint32_t *after) {
-    const int max_log[3] = {9, 8, 9}, max_sym[3] = {35, 31, 52};
-    const uint8_t *p = comp + S.src_off, *end = p + S.src_size;
-    const uint8_t *q = p + S.seq_hdr;
+// n (< 32) bits of the stream from bit `lowpos` up (bit k of the stream = bit k & 7 of byte k >> 3)
+__device__ __forceinline__ uint32_t seq_field(const uint32_t *ring, int lowpos, uint32_t n) {
+    const uint32_t w = (uint32_t)(lowpos >> 5);
+    const uint32_t lo = ring[w & 31u], hi = ring[(w + 1) & 31u];
+    return __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(hi, lo, (uint32_t)lowpos & 31u), 0u, n);
+}
+
+// fse_build with 16-bit entries: symbol | x << 6, x = the symbol's count + the rank of the state among the symbol's states
+__device__ __forceinline__ int fse_build_x(uint16_t *tab, const int16_t *norm, int n_sym, int log, uint16_t *next) {
+    const int size = 1 << log;
+    int high = size;
+    for (int s = 0; s < n_sym; s++)
+        if (norm[s] == -1) {
+            tab[--high] = (uint16_t)s;
+            next[s] = 1;
+        }
+    const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+    int pos = 0;
+    for (int s = 0; s < n_sym; s++) {
+        const int c = norm[s];
+        if (c <= 0) continue;
+        next[s] = (uint16_t)c;
+        for (int i = 0; i < c; i++) {
+            tab[pos] = (uint16_t)s;
+            do {
+                pos = (pos + step) & mask;
+            } while (pos >= high);
+        }
+    }
+    if (pos != 0) return -1;
+    for (int i = 0; i < size; i++) {
+        const uint32_t s = tab[i];
+        const uint32_t x = next[s]++;
+        tab[i] = (uint16_t)(s | (x << 6));
+    }
+    return 0;
+}
+
+// table t (0 LL, 1 OF, 2 ML) as the sequences section at comp[src_off + seq_hdr ...] defines it (its mode there is not
+// Repeat) -> tab, *log_out.  *after: the offset (from the block's start) just behind table t's description.  One lane.
+__device__ __forceinline__ int seq_table_from(uint16_t *tab, int16_t *norm, uint16_t *next, int *log_out, int t, const uint8_t *comp, uint64_t src_off,
+                                              uint32_t src_size, uint32_t seq_hdr, uint32_t *after) {
+    const uint8_t *p = comp + src_off, *end = p + src_size;
+    const uint8_t *q = p + seq_hdr;
     const int modes = *q++;
-    const int m[3] = {modes >> 6, (modes >> 4) & 3, (modes >> 2) & 3};
     for (int u = 0; u <= t; u++) {
         const bool want = u == t;
-        if (m[u] == 1) {
+        const int m = (modes >> (6 - 2 * u)) & 3;
+        const int max_log = u == 1 ? 8 : 9, max_sym = u == 0 ? 35 : u == 1 ? 31 : 52;
+        if (m == 1) {
             if (q >= end) return -1;
             if (want) {
-                if (*q > max_sym[u]) return -1;
-                s.tab[t][0] = *q;  // nbBits 0, base 0
-                s.log[t] = 0;
+                if (*q > max_sym) return -1;
+                tab[0] = (uint16_t)(*q | (1u << 6));  // x = 1 with log 0: no bits, base 0
+                *log_out = 0;
             }
             q++;
-        } else if (m[u] == 2) {
+        } else if (m == 2) {
             int ns = 0, log = 0;
-            const int used = fse_read_norm(q, (int)(end - q), max_log[u], max_sym[u], s.norm, &ns, &log);
+            const int used = fse_read_norm(q, (int)(end - q), max_log, max_sym, norm, &ns, &log);
             if (used < 0) return -1;
             if (want) {
-                if (fse_build(s.tab[t], s.norm, ns, log, s.next)) return -1;
-                s.log[t] = log;
+                if (fse_build_x(tab, norm, ns, log, next)) return -1;
+                *log_out = log;
             }
             q += used;
-        } else if (m[u] == 0) {
+        } else if (m == 0) {
             if (want) {
                 const int16_t *def = t == 0 ? kLLDef : t == 1 ? kOFDef : kMLDef;
                 const int n = t == 0 ? 36 : t == 1 ? 29 : 53, log = t == 1 ? 5 : 6;
-                for (int i = 0; i < n; i++) s.norm[i] = def[i];
-                if (fse_build(s.tab[t], s.norm, n, log, s.next)) return -1;
-                s.log[t] = log;
+                for (int i = 0; i < n; i++) norm[i] = def[i];
+                if (fse_build_x(tab, norm, n, log, next)) return -1;
+                *log_out = log;
             }
         } else if (want) {
             return -1;  // a Repeat entry is never a source
         }
     }
-    if (after) *after = (uint32_t)(q - p);
+    *after = (uint32_t)(q - p);
     return 0;
-}
-
-__device__ __forceinline__ uint32_t rep_dec(uint32_t code, bool *bad) {  // "that offset minus one"
-    if (code & kRepSym) return code + 1;
-    if (code <= 1) *bad = true;
-    return code - 1;
 }
 
 __global__ __launch_bounds__(64) void k_zst_sequences(const uint8_t *__restrict__ comp, Block *blocks, uint32_t b_begin, uint32_t nb, uint32_t *d_ll,
@@ -435,97 +557,114 @@ __global__ __launch_bounds__(64) void k_zst_sequences(const uint8_t *__restrict_
     if (lane < 36) s.ll_code[lane] = kLLCode[lane];
     if (lane < 53) s.ml_code[lane] = kMLCode[lane];
     __syncthreads();
-    for (uint32_t b = b_begin + blockIdx.x; b < nb; b += gridDim.x) {
-        const Block B = blocks[b];
-        if (B.type != 2) continue;
-        if (B.nseq == 0) {
-            if (lane == 0) {
-                blocks[b].out_size = B.lit_regen;
-                blocks[b].rep_out[0] = kRepSym;
-                blocks[b].rep_out[1] = kRepSym | (1u << 29);
-                blocks[b].rep_out[2] = kRepSym | (2u << 29);
-            }
+    if (lane >= kSeqG) return;  // (the wavefront's other lanes have nothing to do: no barrier follows)
+    __builtin_amdgcn_s_setprio(3);  // the longest chain of the round: its instructions go first where k_zst_literals' wavefronts share the SIMD
+    uint16_t *const tab_ll = s.tab[lane], *const tab_of = s.tab[lane] + 512, *const tab_ml = s.tab[lane] + 768;
+    uint32_t *const ring = s.ring[lane];
+    for (uint32_t b = b_begin + blockIdx.x * kSeqG + lane; b < nb; b += gridDim.x * kSeqG) {
+        const Block *const Bp = blocks + b;
+        if (Bp->type != 2) continue;
+        const uint32_t nseq = Bp->nseq, lit_regen = Bp->lit_regen;
+        if (nseq == 0) {
+            blocks[b].out_size = lit_regen;
+            blocks[b].rep_out[0] = kRepSym;
+            blocks[b].rep_out[1] = kRepSym | (1u << 29);
+            blocks[b].rep_out[2] = kRepSym | (2u << 29);
             continue;
         }
-        if (lane == 0) {
-            uint32_t err = 0;
-            do {
-                // the three tables: this block's own descriptions, or the block they are repeated from
-                uint32_t q_off = B.seq_hdr + 1;
-                bool bad_tab = false;
-                for (int t = 0; t < 3 && !bad_tab; t++) {
-                    if (B.tbl_src[t] == b) {
-                        if (seq_table_from(s, t, comp, B, &q_off)) bad_tab = true;
-                    } else {
-                        const Block S = blocks[B.tbl_src[t]];
-                        if (seq_table_from(s, t, comp, S, nullptr)) bad_tab = true;
-                    }
+        const uint64_t src_off = Bp->src_off, seq_off = Bp->seq_off;
+        const uint32_t src_size = Bp->src_size, seq_hdr = Bp->seq_hdr;
+        uint32_t err = 0;
+        do {
+            // the three tables: this block's own descriptions, or the block they are repeated from
+            uint32_t q_off = seq_hdr + 1;
+            int log3[3] = {0, 0, 0};
+            bool bad_tab = false;
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                const uint32_t sb = Bp->tbl_src[t];
+                const Block *const S = blocks + sb;
+                uint32_t after = 0;
+                if (seq_table_from(t == 0 ? tab_ll : t == 1 ? tab_of : tab_ml, s.norm[lane], s.next[lane], &log3[t], t, comp, S->src_off, S->src_size,
+                                   S->seq_hdr, &after))
+                    bad_tab = true;
+                else if (sb == b)
+                    q_off = after;
+                if (bad_tab) break;
+            }
+            if (bad_tab) { err = kErrFse; break; }
+            if (q_off >= src_size) { err = kErrSequences; break; }
+            const uint8_t *sp = comp + src_off + q_off;
+            const int len = (int)(src_size - q_off);
+            int w_h = ((len - 1) >> 6) - 1;  // the lower of the two resident halves
+            ring_half_store(ring, w_h + 1, ring_half_load(sp, len, w_h + 1));
+            ring_half_store(ring, w_h, ring_half_load(sp, len, w_h));
+            RingHalf below = ring_half_load(sp, len, w_h - 1);  // in flight while the lane decodes
+            const uint32_t top = (ring[((uint32_t)(len - 1) >> 2) & 31u] >> (8u * ((uint32_t)(len - 1) & 3u))) & 255u;
+            if (top == 0) { err = kErrSequences; break; }  // no end mark in the last byte
+            int P = 8 * (len - 1) + hb32(top);              // unread bits: the stream's bits [0, P)
+            const uint32_t llog = (uint32_t)log3[0], olog = (uint32_t)log3[1], mlog = (uint32_t)log3[2];
+            P -= (int)llog;
+            uint32_t sl = seq_field(ring, P, llog);
+            P -= (int)olog;
+            uint32_t so = seq_field(ring, P, olog);
+            P -= (int)mlog;
+            uint32_t sm = seq_field(ring, P, mlog);
+            if (P < 0) { err = kErrSequences; break; }
+            uint32_t r0 = kRepSym, r1 = kRepSym | (1u << 29), r2 = kRepSym | (2u << 29);
+            uint32_t sum_ll = 0, sum_ml = 0;
+            uint32_t *o_ll = d_ll + seq_off, *o_ml = d_ml + seq_off, *o_off = d_off + seq_off;
+            bool bad = false, bad_off = false;
+            for (uint32_t i = 0; i < nseq && !bad && !bad_off; i++) {
+                if ((P >> 3) - 16 < w_h * kSeqHalf) {  // (a sequence takes at most 89 bits and its reads begin 3 bytes below: it stays inside the ring)
+                    w_h--;  // half w_h + 2 is behind the reader: the half below takes its place
+                    ring_half_store(ring, w_h, below);
+                    below = ring_half_load(sp, len, w_h - 1);
                 }
-                if (bad_tab) { err = kErrFse; break; }
-                const uint8_t *p = comp + B.src_off;
-                if (q_off >= B.src_size) { err = kErrSequences; break; }
-                BitsRev br;
-                if (!br.init(p + q_off, (long long)B.src_size - q_off)) { err = kErrSequences; break; }
-                const uint32_t llog = (uint32_t)s.log[0], olog = (uint32_t)s.log[1], mlog = (uint32_t)s.log[2];
-                br.need(llog + olog + mlog);
-                uint32_t sl = br.read(llog), so = br.read(olog), sm = br.read(mlog);
-                if (br.left() < 0) { err = kErrSequences; break; }
-                uint32_t r0 = kRepSym, r1 = kRepSym | (1u << 29), r2 = kRepSym | (2u << 29);
-                uint32_t sum_ll = 0, sum_ml = 0;
-                uint32_t *o_ll = d_ll + B.seq_off, *o_ml = d_ml + B.seq_off, *o_off = d_off + B.seq_off;
-                bool bad = false, bad_off = false;
-                for (uint32_t i = 0; i < B.nseq; i++) {
-                    const uint32_t el = s.tab[0][sl], eo = s.tab[1][so], em = s.tab[2][sm];
-                    const uint32_t lc = el & 255, oc = eo & 255, mc = em & 255;
-                    if (lc > 35 || oc > 31 || mc > 52) { bad = true; break; }
-                    br.need(oc);
-                    const uint32_t ov = (1u << oc) + br.read(oc);
-                    const uint32_t mcode = s.ml_code[mc], lcode = s.ll_code[lc];
-                    br.need((mcode >> 24) + (lcode >> 24));
-                    const uint32_t ml = (mcode & 0xFFFFFFu) + br.read(mcode >> 24);
-                    const uint32_t ll = (lcode & 0xFFFFFFu) + br.read(lcode >> 24);
-                    if (i + 1 < B.nseq) {
-                        const uint32_t nl = (el >> 8) & 255, nm = (em >> 8) & 255, no = (eo >> 8) & 255;
-                        br.need(nl + nm + no);
-                        sl = (el >> 16) + br.read(nl);
-                        sm = (em >> 16) + br.read(nm);
-                        so = (eo >> 16) + br.read(no);
-                    }
-                    uint32_t code;
-                    if (ov > 3) {
-                        code = ov - 3;
-                        if (code >= (1u << 29)) { bad_off = true; break; }  // beyond any window this decoder accepts
-                        r2 = r1, r1 = r0, r0 = code;
-                    } else {
-                        const uint32_t idx = ov - 1 + (ll == 0 ? 1u : 0u);
-                        if (idx == 0) {
-                            code = r0;
-                        } else {
-                            code = idx == 1 ? r1 : idx == 2 ? r2 : rep_dec(r0, &bad_off);
-                            if (idx > 1) r2 = r1;
-                            r1 = r0;
-                            r0 = code;
-                        }
-                    }
-                    o_ll[i] = ll;
-                    o_ml[i] = ml;
-                    o_off[i] = code;
-                    sum_ll += ll;
-                    sum_ml += ml;
-                    if (sum_ll > kBlockMax || sum_ml > kBlockMax) { bad = true; break; }
-                }
-                if (bad_off) { err = kErrOffset; break; }
-                if (bad || br.left() != 0) { err = kErrSequences; break; }
-                if (sum_ll > B.lit_regen) { err = kErrSequences; break; }
-                if (B.lit_regen + sum_ml > kBlockMax) { err = kErrSize; break; }
-                blocks[b].out_size = B.lit_regen + sum_ml;
-                blocks[b].rep_out[0] = r0;
-                blocks[b].rep_out[1] = r1;
-                blocks[b].rep_out[2] = r2;
-            } while (0);
-            if (err) block_fail(blocks, b, err);
-        }
-        __syncthreads();
+                const uint32_t el = tab_ll[sl], eo = tab_of[so], em = tab_ml[sm];
+                const uint32_t lc = el & 63, oc = eo & 63, mc = em & 63;
+                const bool bad_sym = lc > 35 || oc > 31 || mc > 52;
+                const uint32_t mcode = s.ml_code[mc], lcode = s.ll_code[lc];
+                const uint32_t xl = el >> 6, xo = eo >> 6, xm = em >> 6;
+                const bool more = i + 1 < nseq;  // (the last sequence reads no next states)
+                const uint32_t nl = more ? llog - (uint32_t)hb32(xl) : 0u, nm = more ? mlog - (uint32_t)hb32(xm) : 0u, no = more ? olog - (uint32_t)hb32(xo) : 0u;
+                const uint32_t n1 = mcode >> 24, n2 = lcode >> 24;
+                const int p0 = P - (int)oc, p1 = p0 - (int)n1, p2 = p1 - (int)n2, p3 = p2 - (int)nl, p4 = p3 - (int)nm, p5 = p4 - (int)no;
+                const uint32_t f0 = seq_field(ring, p0, oc), f1 = seq_field(ring, p1, n1), f2 = seq_field(ring, p2, n2);
+                const uint32_t f3 = seq_field(ring, p3, nl), f4 = seq_field(ring, p4, nm), f5 = seq_field(ring, p5, no);
+                P = p5;
+                const uint32_t ov = (1u << oc) + f0;
+                const uint32_t ml = (mcode & 0xFFFFFFu) + f1;
+                const uint32_t ll = (lcode & 0xFFFFFFu) + f2;
+                sl = (xl << nl) - (1u << llog) + f3;
+                sm = (xm << nm) - (1u << mlog) + f4;
+                so = (xo << no) - (1u << olog) + f5;
+                // the offset: a new one (ov > 3), or one of the three last (RFC 8878 3.1.1.5), symbolic while it names the history
+                // in front of the block
+                const uint32_t sel = ov > 3 ? 4u : ov - 1 + (ll == 0 ? 1u : 0u);  // 0: r0, 1: r1, 2: r2, 3: r0 - 1, 4: new
+                const uint32_t dec = r0 + ((r0 & kRepSym) ? 1u : ~0u);            // "r0 minus one"
+                const uint32_t code = sel == 4 ? ov - 3 : sel == 0 ? r0 : sel == 1 ? r1 : sel == 2 ? r2 : dec;
+                if (!bad_sym && ((sel == 4 && code >= (1u << 29)) || (sel == 3 && !(r0 & kRepSym) && r0 <= 1))) bad_off = true;
+                r2 = sel >= 2 ? r1 : r2;
+                r1 = sel >= 1 ? r0 : r1;
+                r0 = code;
+                o_ll[i] = ll;
+                o_ml[i] = ml;
+                o_off[i] = code;
+                sum_ll += ll;
+                sum_ml += ml;
+                if (bad_sym || ((sum_ll > kBlockMax || sum_ml > kBlockMax) && !bad_off)) bad = true;
+            }
+            if (bad_off) { err = kErrOffset; break; }
+            if (bad || P != 0) { err = kErrSequences; break; }
+            if (sum_ll > lit_regen) { err = kErrSequences; break; }
+            if (lit_regen + sum_ml > kBlockMax) { err = kErrSize; break; }
+            blocks[b].out_size = lit_regen + sum_ml;
+            blocks[b].rep_out[0] = r0;
+            blocks[b].rep_out[1] = r1;
+            blocks[b].rep_out[2] = r2;
+        } while (0);
+        if (err) block_fail(blocks, b, err);
     }
 }
 
@@ -1196,8 +1335,8 @@ int decode_round_begin(Round &R, void *stream_v, RoundCtx **out_ctx) {
             (void)hipEventRecord(ev0, st);
             (void)hipStreamWaitEvent(st2, ev0, 0);
         }
-        hipLaunchKernelGGL(k_zst_literals, dim3(grid), dim3(64), 0, side ? st2 : st, d_comp, (Block *)C.d_blocks.p, nx, nb, (uint8_t *)C.d_lit.p);
-        hipLaunchKernelGGL(k_zst_sequences, dim3(grid), dim3(64), 0, st, d_comp, (Block *)C.d_blocks.p, nx, nb, (uint32_t *)C.d_ll.p, (uint32_t *)C.d_ml.p,
+        hipLaunchKernelGGL(k_zst_literals, dim3((grid + kLitG - 1) / kLitG), dim3(64), 0, side ? st2 : st, d_comp, (Block *)C.d_blocks.p, nx, nb, (uint8_t *)C.d_lit.p);
+        hipLaunchKernelGGL(k_zst_sequences, dim3((grid + kSeqG - 1) / kSeqG), dim3(64), 0, st, d_comp, (Block *)C.d_blocks.p, nx, nb, (uint32_t *)C.d_ll.p, (uint32_t *)C.d_ml.p,
                            (uint32_t *)C.d_off.p);
         if (side) {
             (void)hipEventRecord(ev1, st2);
