@@ -59,18 +59,14 @@ static bool file_is_shardable(const std::string &f, const std::string &fmt_lower
     if (comp == kNone) return true;
     if (comp == kZstd) {
         // by frames: worth it when the file has several (pzstd, the seekable format; the zstd CLI writes one) — the walk over
-        // the frame / block headers touches a few bytes per block of the mapping (2 ms per GB)
+        // the frame / block headers reads a few bytes per block (exg_zstd_index.cpp)
         int fd = open(f.c_str(), O_RDONLY);
         if (fd < 0) return false;
         struct stat st;
         bool many = false;
         if (fstat(fd, &st) == 0 && st.st_size > 0) {
-            void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-            if (m != MAP_FAILED) {
-                exg::zst::Index idx;
-                many = exg::zst::build_index((const uint8_t *)m, (uint64_t)st.st_size, idx) && idx.frames.size() > 1;
-                munmap(m, (size_t)st.st_size);
-            }
+            exg::zst::Index idx;
+            many = exg::zst::build_index_fd(fd, (uint64_t)st.st_size, idx) && idx.frames.size() > 1;
         }
         close(fd);
         return many;

@@ -12,11 +12,11 @@
 //   * Content_Checksums: a frame inside one round is hashed on the device (XXH64, up to EXG_ZSTD_VERIFY_MAX bytes); a frame
 //     that is larger or spans rounds is hashed on a host thread from copies of its parts that come back over PCIe while the
 //     next round is being decoded; a mismatch is reported behind the frame's rows, where a streaming decoder reports it.
+#include <errno.h>
 #include <string.h>
 
 #include <atomic>
 #include <thread>
-#include <sys/mman.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -218,18 +218,11 @@ private:
     } while (0)
 
 int ZstdProducer::run(SegmentSink &sink, std::string *err) {
-    // the host's walk over the frame / block headers reads the mapped file
-    void *map = n_ ? mmap(nullptr, n_, PROT_READ, MAP_PRIVATE, fd_, 0) : nullptr;
-    if (map == MAP_FAILED) {
-        *err = "cannot map '" + path_ + "'";
-        return EXG_E_IO;
-    }
-    struct Unmap {
-        void *p;
-        size_t n;
-        ~Unmap() { if (p) munmap(p, n); }
-    } unmap{map, (size_t)n_};
-    const uint8_t *h_comp = (const uint8_t *)map;
+    const double t_run0 = now_s();
+    struct RunTrace {
+        double t0;
+        ~RunTrace() { if (getenv("EXG_TRACE")) fprintf(stderr, "[exg] zstd producer: gone %.1f ms after it began\n", (now_s() - t0) * 1e3); }
+    } run_trace{t_run0};
     hipStream_t st = nullptr;
     if (stream_pool()->take(device_, &st) != hipSuccess) {
         *err = "cannot create a stream for the zstd decoder";
@@ -242,32 +235,18 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
     } stream_back{device_, st};
     zst::Index idx;
     const double t_idx0 = now_s();
-    // The walk below touches a few bytes of every block — a page fault per 64 KiB of the mapping (fault-around maps sixteen
-    // pages), one after the other on this thread: 80-100 ms per 2 GB, a quarter of what a 4 GB frame took end to end.  Eight
-    // threads take the faults first, a byte per 64 KiB each in turn (4-6 ms); the walk then runs at memory speed.
-    if (n_ > (8u << 20)) {
-        const unsigned nt = 8;
-        const size_t step = 64u << 10;
-        std::atomic<uint64_t> sink{0};
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nt; t++)
-            th.emplace_back([&, t] {
-                uint64_t acc = 0;
-                for (uint64_t o = (uint64_t)t * step; o < n_; o += (uint64_t)nt * step) acc += h_comp[o];
-                sink.fetch_add(acc, std::memory_order_relaxed);
-            });
-        for (auto &t : th) t.join();
-    }
-    const double t_idx1 = now_s();
+    // The walk over the frame / block headers reads the file with two small preads per block.  (It used to read a mapping of
+    // the whole file: a page fault per 64 KiB — 80-100 ms per 2 GB on this thread, 20 ms with eight threads taking the faults
+    // first — and 49 ms to unmap it again at the end, a quarter of what a 4 GB frame took end to end.)
     std::string damage;  // a malformed or truncated stream: the rows in front of the damage first, like a streaming decoder
-    if (!zst::build_index(h_comp, n_, idx)) {
+    if (!zst::build_index_fd(fd_, n_, idx)) {
         damage = idx.error + " in '" + path_ + "'";
         if (!zst::salvage_index(idx)) {
             *err = damage;
             return EXG_E_PARSE;
         }
     }
-    if (getenv("EXG_TRACE")) fprintf(stderr, "[exg] zstd producer: index of %.1f MB (%zu blocks) %.1f ms (of which %.1f ms taking the page faults on 8 threads)\n", n_ / 1e6, idx.blocks.size(), (now_s() - t_idx0) * 1e3, (t_idx1 - t_idx0) * 1e3);
+    if (getenv("EXG_TRACE")) fprintf(stderr, "[exg] zstd producer: index of %.1f MB (%zu blocks) %.1f ms\n", n_ / 1e6, idx.blocks.size(), (now_s() - t_idx0) * 1e3);
     // the frames whose first byte lies in [c_begin, c_end) (a shard decodes its own frames and a halo of frames in front)
     uint64_t b_first = idx.blocks.size(), n_blocks = 0, b_mark[2] = {~0ull, ~0ull};
     bool marked[2] = {false, false};
@@ -286,8 +265,9 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
     };
     // the round's compressed bytes: [the blocks whose tables are repeated (at most four) | the round's own, from a 16-byte boundary]
     static constexpr uint64_t kSideSlot = (zst::kBlockMax + 64 + 15) & ~15ull, kSide = 4 * kSideSlot;
-    // (two windows of compressed bytes in turn: while round n is decoded out of one, a helper thread reads round n + 1's bytes
-    // into the other and sends them on a stream of its own — 9 ms of a 59 ms round otherwise spent in front of the decode)
+    // (three windows of compressed bytes in turn: while round n is decoded out of one — and round n - 1 still executes out of
+    // the one before — a helper thread reads round n + 1's bytes into the third and sends them on a stream of its own: 9 ms of a
+    // round otherwise spent in front of the decode)
     hipStream_t st_io = nullptr;
     if (read_ahead_ && stream_pool()->take(device_, &st_io) != hipSuccess) st_io = nullptr, read_ahead_ = false;
     struct StreamBack2 {
@@ -295,8 +275,8 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
         hipStream_t s;
         ~StreamBack2() { if (s) stream_pool()->give(dev, s); }
     } stream_back2{device_, st_io};
-    PoolBuf d_comp_a(device_, st), d_comp_b(device_, st), d_hist(device_, st);
-    PoolBuf *d_comps[2] = {&d_comp_a, &d_comp_b};
+    PoolBuf d_comp_a(device_, st), d_comp_b(device_, st), d_comp_c(device_, st), d_hist(device_, st);
+    PoolBuf *d_comps[3] = {&d_comp_a, &d_comp_b, &d_comp_c};
     struct Pin {
         char *p = nullptr;
         size_t cap = 0;
@@ -309,8 +289,8 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
             cap = p ? want : 0;
             return p != nullptr;
         }
-    } pins[2];
-    size_t d_comp_caps[2] = {0, 0}, d_hist_cap = 4096;
+    } pins[3];
+    size_t d_comp_caps[3] = {0, 0, 0}, d_hist_cap = 4096;
     // where a round that begins with block b ends, and which file bytes it needs
     auto plan = [&](uint64_t from, uint64_t *to, uint64_t *lo, uint64_t *hi) {
         // (a first round of a quarter of the size, so that the consumer begins earlier, measured nothing: 325 against 311 ms)
@@ -359,12 +339,116 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
     uint64_t frame_done = 0;        // bytes of the frame that holds block b0 decoded so far (0: it begins with b0)
     uint64_t hist = 0, pad = 0;     // d_hist holds [pad | hist bytes]: the end of that frame's output so far
     bool pushed_last = false;
+    // Two rounds overlap (not under a memory cap — the second window is what read_ahead_ stands for): while round n's ~1 900
+    // dependent resolve launches run (launch latency: the chip is mostly idle), round n + 1's entropy stages, its scan and the
+    // execution of its chunks run on the other stream.  Only round n + 1's resolve needs round n's last bytes (the window): it is
+    // enqueued once round n is done, and round n's segment goes out then.  What the next round needs of a round — sizes, repeat offsets —
+    // is known when its entropy stages are (decode_round_begin); what needs its bytes is deferred (InFlight::complete).
+    hipStream_t st_b = nullptr;
+    const bool overlap = read_ahead_ && !getenv("EXG_ZSTD_NO_OVERLAP") && stream_pool()->take(device_, &st_b) == hipSuccess;
+    StreamBack2 stream_back3{device_, overlap ? st_b : nullptr};
+    struct InFlight {
+        zst::Round R;
+        zst::RoundCtx *ctx = nullptr;  // between begin and wait
+        hipStream_t st = nullptr;
+        uint64_t d_pos = 0, hist = 0;  // when the round began
+        bool last = false;
+        // the window the round leaves (0: none — its last frame ends)
+        uint64_t nh = 0, npad = 0, window = 0;
+        bool active = false;
+        ~InFlight() {
+            if (ctx) zst::decode_round_abandon(ctx);
+        }
+    } fl[2];
+    int n_round = 0;
+    InFlight *prev = nullptr;
+    // round `F` is done on the device: its window into d_hist, its segment to the hasher / the consumer
+    auto complete = [&](InFlight &F) -> int {
+        F.active = false;
+        zst::RoundCtx *ctx = F.ctx;
+        F.ctx = nullptr;
+        int rc;
+        {
+            TraceRange range("exg: zstd round (wait)");
+            rc = zst::decode_round_wait(F.R, ctx);
+        }
+        if (rc) {
+            *err = std::string(exg_last_error_message()) + " in '" + path_ + "'";
+            return rc;
+        }
+        zst::Round &R = F.R;
+        const uint64_t H = R.history;  // pad + hist
+        Segment seg;
+        seg.buf = R.d_buf;
+        seg.cap = R.alloc;
+        seg.org = (int64_t)F.d_pos - (int64_t)H - (int64_t)reserve_;
+        seg.lo = F.d_pos - F.hist;
+        seg.start = F.d_pos;
+        seg.hi = F.d_pos + R.produced;
+        seg.last = F.last;
+        const uint8_t *content = (const uint8_t *)R.d_buf + reserve_;  // buffer coordinate 0
+        FrameHasher::Job job;
+        for (const zst::RoundFrame &rf : R.frames) {
+            const zst::Frame &Fr = idx.frames[rf.frame_id];
+            if (Fr.has_checksum && !rf.verified) {
+                // its bytes come back in pieces and are hashed beside the next round's decode (FrameHasher), before the segment goes out
+                FrameHasher::Part part;
+                part.d_src = content + rf.out_off;
+                part.len = rf.out_size;
+                part.frame = rf.frame_id;
+                part.expect = Fr.checksum;
+                part.begins = rf.begins;
+                part.ends = rf.ends;
+                job.parts.push_back(part);
+            }
+        }
+        if (F.nh) {
+            if (F.npad + F.nh > d_hist_cap) {
+                // (the old window's bytes are in this round's buffer too: a new block loses nothing)
+                d_hist_cap = (size_t)(F.npad + std::max<uint64_t>(F.nh, std::min<uint64_t>(F.window, zst::kWindowMax)) + 64);
+                if (!d_hist.take(d_hist_cap)) {
+                    sink.give(seg.buf, seg.cap);
+                    *err = "out of device memory for the window of a zstd frame";
+                    return EXG_E_HIP;
+                }
+            }
+            // the last nh bytes of [history | produced] (nh <= history of this frame + what the round added to it)
+            const uint8_t *src = content + H + R.produced - F.nh;
+            hipError_t he = hipMemcpyAsync((char *)d_hist.p + F.npad, src, F.nh, hipMemcpyDeviceToDevice, F.st);
+            if (he == hipSuccess) he = hipStreamSynchronize(F.st);
+            if (he != hipSuccess) {
+                sink.give(seg.buf, seg.cap);
+                *err = std::string("keeping the window of a zstd frame failed: ") + hipGetErrorString(he);
+                return EXG_E_HIP;
+            }
+        }
+        pushed_last = seg.last;
+        job.seg = std::move(seg);
+        seg.buf = nullptr;
+        if (!hasher.submit(std::move(job))) {
+            if (hasher.gone()) return -1;  // the consumer closed the stream
+            *err = hasher.error() + " in '" + path_ + "'";
+            return EXG_E_PARSE;
+        }
+        return EXG_OK;
+    };
+    // (an error of round n + 1 is reported behind round n's rows: round n goes out first)
+    auto flush_prev = [&]() -> int {
+        if (!prev) return EXG_OK;
+        InFlight *f = prev;
+        prev = nullptr;
+        return complete(*f);
+    };
     while (b0 < n_blocks && !sink.cancelled()) {
         marks(b0, d_pos);
+        InFlight &F = fl[n_round & 1];
+        hipStream_t st_r = overlap && (n_round & 1) ? st_b : st;
+        n_round++;
         // ---- the round's blocks: about one segment of output (a block regenerates at most 128 KiB); a round ends at a mark
         uint64_t b1 = b0, c_lo = 0, c_hi = 0;
         plan(b0, &b1, &c_lo, &c_hi);
-        zst::Round R;
+        F.R = zst::Round();
+        zst::Round &R = F.R;
         // blocks in front of the round whose tables its blocks repeat
         std::vector<uint64_t> extra_ids;
         auto local_of = [&](uint32_t g) -> uint32_t {
@@ -390,11 +474,12 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
         const uint64_t comp_len = c_hi - c_lo;
         // this round's window: the one the helper thread has filled, or a read of its own
         bool have = false;
+        const double t_join0 = now_s();
         if (ahead.th.joinable()) {
             ahead.th.join();
             if (ahead.b0 == b0 && ahead.ok) {
                 cur = ahead.slot;
-                ZS_HIP(hipStreamWaitEvent(st, ahead.ev, 0));
+                ZS_HIP(hipStreamWaitEvent(st_r, ahead.ev, 0));
                 have = true;
             } else if (ahead.hip_failed) {
                 *err = "hipMemcpyAsync failed";
@@ -404,9 +489,13 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
             }
             ahead.b0 = ~0ull;
         }
-        if (!have && !ensure_window(cur, comp_len)) {
-            *err = "out of device / pinned memory for the compressed bytes of '" + path_ + "'";
-            return EXG_E_HIP;
+        if (!have) {
+            // (a read of its own goes into the window the round in flight may be reading: that round first)
+            if (int rc = flush_prev()) return rc < 0 ? EXG_OK : rc;
+            if (!ensure_window(cur, comp_len)) {
+                *err = "out of device / pinned memory for the compressed bytes of '" + path_ + "'";
+                return EXG_E_HIP;
+            }
         }
         PoolBuf &d_comp = *d_comps[cur];
         auto &pin = pins[cur];
@@ -414,23 +503,34 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
         for (uint32_t i = 0; i < nx; i++) {
             zst::Block E = idx.blocks[extra_ids[i]];
             const uint64_t sz = E.type == 2 ? E.src_size : 1;
-            memcpy(pin.p + i * kSideSlot, h_comp + E.src_off, (size_t)std::min<uint64_t>(sz, kSideSlot));
+            const size_t want = (size_t)std::min<uint64_t>(sz, kSideSlot);
+            size_t got = 0;
+            while (got < want) {
+                const ssize_t k = pread(fd_, pin.p + i * kSideSlot + got, want - got, (off_t)(E.src_off + got));
+                if (k <= 0) {
+                    if (k < 0 && errno == EINTR) continue;
+                    *err = "short read of '" + path_ + "'";
+                    return EXG_E_IO;
+                }
+                got += (size_t)k;
+            }
             E.src_off = i * kSideSlot;
             E.huf_src = E.tbl_src[0] = E.tbl_src[1] = E.tbl_src[2] = zst::kNone;  // (a source is only read, never decoded)
             R.blocks.push_back(E);
         }
-        if (nx) ZS_HIP(hipMemcpyAsync(d_comp.p, pin.p, nx * kSideSlot, hipMemcpyHostToDevice, st));
+        if (nx) ZS_HIP(hipMemcpyAsync(d_comp.p, pin.p, nx * kSideSlot, hipMemcpyHostToDevice, st_r));
         bool hip_failed = false;
         const double t_read0 = now_s();
-        if (!have && comp_len && !pread_parallel(device_, fd_, c_lo, (size_t)comp_len, pin.p + kSide, (char *)d_comp.p + kSide, st, &hip_failed)) {
+        if (!have && comp_len && !pread_parallel(device_, fd_, c_lo, (size_t)comp_len, pin.p + kSide, (char *)d_comp.p + kSide, st_r, &hip_failed)) {
             *err = hip_failed ? "hipMemcpyAsync failed" : "short read of '" + path_ + "'";
             return hip_failed ? EXG_E_HIP : EXG_E_IO;
         }
-        // the round behind this one: its bytes begin to travel now, into the other window
+        // the round behind this one: its bytes begin to travel now, into the next window (three in turn: the round in flight reads
+        // the one before this round's)
         if (read_ahead_ && b1 < n_blocks) {
             uint64_t nb1 = 0, nlo = 0, nhi = 0;
             plan(b1, &nb1, &nlo, &nhi);
-            const int other = cur ^ 1;
+            const int other = (cur + 1) % 3;
             if (ensure_window(other, nhi - nlo)) {
                 ahead.b0 = b1;
                 ahead.slot = other;
@@ -448,7 +548,7 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
                 });
             }
         }
-        if (!have) ZS_HIP(hipMemsetAsync((char *)d_comp.p + kSide + comp_len, 0, 64, st));
+        if (!have) ZS_HIP(hipMemsetAsync((char *)d_comp.p + kSide + comp_len, 0, 64, st_r));
         auto remap = [&](uint32_t g) -> uint32_t {
             if (g == zst::kNone) return zst::kNone;
             if (g >= b0) return (uint32_t)(g - b0) + nx;
@@ -467,23 +567,23 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
         // the frames (or parts of frames) in the round
         for (uint64_t b = b0; b < b1;) {
             const uint32_t f = idx.blocks[b].frame;
-            const zst::Frame &F = idx.frames[f];
-            const uint64_t f_end = (uint64_t)F.first_block + F.n_blocks, e = std::min<uint64_t>(b1, f_end);
+            const zst::Frame &Fr = idx.frames[f];
+            const uint64_t f_end = (uint64_t)Fr.first_block + Fr.n_blocks, e = std::min<uint64_t>(b1, f_end);
             zst::RoundFrame rf;
             rf.first_block = (uint32_t)(b - b0) + nx;
             rf.n_blocks = (uint32_t)(e - b);
             rf.frame_id = f;
-            rf.begins = b == F.first_block;
+            rf.begins = b == Fr.first_block;
             rf.ends = e == f_end;
             rf.history = rf.begins ? 0 : hist;
-            rf.has_checksum = F.has_checksum;
-            rf.checksum = F.checksum;
+            rf.has_checksum = Fr.has_checksum;
+            rf.checksum = Fr.checksum;
             R.frames.push_back(rf);
             b = e;
         }
         R.rep_in[0] = rep[0], R.rep_in[1] = rep[1], R.rep_in[2] = rep[2];
         R.d_comp = d_comp.p;
-        R.d_history = d_hist.p;
+        R.d_history = nullptr;  // (set when the round in front is done: d_hist may move)
         // the first history byte is stream byte d_pos - hist: `pad` (unused) bytes in front of it put it on the 16-byte grid the
         // decoder's stores and the scan's loads follow (buffer coordinate 0 is 16-byte aligned, and an address must be
         // congruent to its stream offset: pad = (d_pos - hist) & 15, also when nothing is kept)
@@ -492,58 +592,70 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
         R.verify_max = verify_max;
         R.first_block_id = b0;
         R.comp_base = c_lo - kSide;
+        F.st = st_r;
+        F.d_pos = d_pos;
+        F.hist = hist;
         int rc;
         const double t_dec0 = now_s();
         {
-            TraceRange range("exg: zstd round");
-            rc = zst::decode_round(R, st);
+            TraceRange range("exg: zstd round (entropy stages)");
+            rc = zst::decode_round_begin(R, st_r, &F.ctx);
         }
-        if (getenv("EXG_TRACE")) fprintf(stderr, "[exg] zstd producer: round of %.1f MB compressed: read + h2d enqueue %.1f ms, decode %.1f ms\n", comp_len / 1e6, (t_dec0 - t_read0) * 1e3, (now_s() - t_dec0) * 1e3);
+        const double t_dec1 = now_s();
+        if (rc) {
+            const std::string msg = std::string(exg_last_error_message()) + " in '" + path_ + "'";
+            if (int rp = flush_prev()) return rp < 0 ? EXG_OK : rp;
+            *err = msg;
+            return rc;
+        }
+        // ---- frames: sizes
+        std::string size_error;
+        for (const zst::RoundFrame &rf : R.frames) {
+            const zst::Frame &Fr = idx.frames[rf.frame_id];
+            const uint64_t before = rf.begins ? 0 : frame_done;
+            if (rf.ends && Fr.content_size != ~0ull && Fr.content_size != before + rf.out_size) {
+                size_error = "Data corruption detected (zstd frame " + std::to_string(rf.frame_id) + " regenerates " + std::to_string(before + rf.out_size) +
+                             " bytes, its header says " + std::to_string(Fr.content_size) + ") in '" + path_ + "'";
+                break;
+            }
+        }
+        // this round's chunks execute beside the round in front's resolve launches (they need nothing of it)
+        if (size_error.empty()) {
+            TraceRange range("exg: zstd round (execution enqueued)");
+            zst::RoundCtx *ctx = F.ctx;
+            F.ctx = nullptr;
+            rc = zst::decode_round_enqueue_exec(R, ctx);
+            if (!rc) F.ctx = ctx;
+            if (rc) {
+                const std::string msg = std::string(exg_last_error_message()) + " in '" + path_ + "'";
+                if (int rp = flush_prev()) return rp < 0 ? EXG_OK : rp;
+                *err = msg;
+                return rc;
+            }
+        }
+        // the round in front: done by now or soon — its window is this round's history
+        if (int rp = flush_prev()) return rp < 0 ? EXG_OK : rp;
+        if (!size_error.empty()) {
+            *err = size_error;
+            return EXG_E_PARSE;
+        }
+        R.d_history = d_hist.p;
+        {
+            TraceRange range("exg: zstd round (resolve enqueued)");
+            zst::RoundCtx *ctx = F.ctx;
+            F.ctx = nullptr;
+            rc = zst::decode_round_enqueue_resolve(R, ctx);
+            if (!rc) F.ctx = ctx;
+        }
         if (rc) {
             *err = std::string(exg_last_error_message()) + " in '" + path_ + "'";
             return rc;
         }
-        const uint64_t H = R.history;  // pad + hist
-        Segment seg;
-        seg.buf = R.d_buf;
-        seg.cap = R.alloc;
-        seg.org = (int64_t)d_pos - (int64_t)H - (int64_t)reserve_;
-        seg.lo = d_pos - hist;
-        seg.start = d_pos;
-        seg.hi = d_pos + R.produced;
-        const uint8_t *content = (const uint8_t *)R.d_buf + reserve_;  // buffer coordinate 0
-        // ---- frames: sizes, checksums
-        bool bad = false;
-        FrameHasher::Job job;
-        for (const zst::RoundFrame &rf : R.frames) {
-            const zst::Frame &F = idx.frames[rf.frame_id];
-            const uint64_t before = rf.begins ? 0 : frame_done;
-            if (rf.ends && F.content_size != ~0ull && F.content_size != before + rf.out_size) {
-                *err = "Data corruption detected (zstd frame " + std::to_string(rf.frame_id) + " regenerates " + std::to_string(before + rf.out_size) +
-                       " bytes, its header says " + std::to_string(F.content_size) + ") in '" + path_ + "'";
-                bad = true;
-                break;
-            }
-            if (F.has_checksum && !rf.verified) {
-                // its bytes come back in pieces and are hashed beside the next round's decode (FrameHasher), before the segment goes out
-                FrameHasher::Part part;
-                part.d_src = content + rf.out_off;
-                part.len = rf.out_size;
-                part.frame = rf.frame_id;
-                part.expect = F.checksum;
-                part.begins = rf.begins;
-                part.ends = rf.ends;
-                job.parts.push_back(part);
-            }
-        }
-        if (bad) {
-            (void)hipStreamSynchronize(st);
-            sink.give(seg.buf, seg.cap);
-            return EXG_E_PARSE;
-        }
+        F.active = true;
         // ---- what the next round needs of this one
         const zst::RoundFrame &lastf = R.frames.back();
         const uint64_t last_before = lastf.begins ? 0 : frame_done;
+        F.nh = F.npad = F.window = 0;
         if (lastf.ends) {
             frame_done = 0, hist = 0, pad = (d_pos + R.produced) & 15;
             rep[0] = 1, rep[1] = 4, rep[2] = 8;
@@ -553,39 +665,22 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
             const uint64_t window = idx.frames[lastf.frame_id].window;
             const uint64_t nh = std::min<uint64_t>(std::max<uint64_t>(window, 1), frame_done);
             const uint64_t end_pos = d_pos + R.produced;  // stream offset behind this round
-            const uint64_t npad = (end_pos - nh) & 15;
-            if (npad + nh > d_hist_cap) {
-                // (the old window's bytes are in this round's buffer too: a new block loses nothing)
-                d_hist_cap = (size_t)(npad + std::max<uint64_t>(nh, std::min<uint64_t>(window, zst::kWindowMax)) + 64);
-                if (!d_hist.take(d_hist_cap)) {
-                    sink.give(seg.buf, seg.cap);
-                    *err = "out of device memory for the window of a zstd frame";
-                    return EXG_E_HIP;
-                }
-            }
-            // the last nh bytes of [history | produced] (nh <= history of this frame + what the round added to it)
-            const uint8_t *src = content + H + R.produced - nh;
-            hipError_t he = hipMemcpyAsync((char *)d_hist.p + npad, src, nh, hipMemcpyDeviceToDevice, st);
-            if (he == hipSuccess) he = hipStreamSynchronize(st);
-            if (he != hipSuccess) {
-                sink.give(seg.buf, seg.cap);
-                *err = std::string("keeping the window of a zstd frame failed: ") + hipGetErrorString(he);
-                return EXG_E_HIP;
-            }
-            hist = nh, pad = npad;
+            F.nh = nh, F.npad = (end_pos - nh) & 15, F.window = window;
+            hist = nh, pad = F.npad;
         }
-        d_pos = seg.hi;
+        d_pos += R.produced;
         b0 = b1;
-        seg.last = b0 >= n_blocks;
-        pushed_last = seg.last;
-        job.seg = std::move(seg);
-        seg.buf = nullptr;
-        if (!hasher.submit(std::move(job))) {
-            if (hasher.gone()) return EXG_OK;  // the consumer closed the stream
-            *err = hasher.error() + " in '" + path_ + "'";
-            return EXG_E_PARSE;
+        F.last = b0 >= n_blocks;
+        if (getenv("EXG_TRACE"))
+            fprintf(stderr, "[exg] zstd producer: round of %.1f MB compressed: window %.1f ms, entropy stages %.1f ms, round in front + enqueue %.1f ms\n",
+                    comp_len / 1e6, (t_dec0 - t_join0) * 1e3, (t_dec1 - t_dec0) * 1e3, (now_s() - t_dec1) * 1e3);
+        prev = &F;
+        if (!overlap) {
+            if (int rp = flush_prev()) return rp < 0 ? EXG_OK : rp;
         }
     }
+    if (int rp = flush_prev()) return rp < 0 ? EXG_OK : rp;
+    if (getenv("EXG_TRACE")) fprintf(stderr, "[exg] zstd producer: last segment out %.1f ms after it began\n", (now_s() - t_run0) * 1e3);
     // The checksums still being folded: a mismatch is this thread's result, which the reader looks at once the last
     // segment's rows have been handed out (DecodedSource::finish) — where a streaming decoder reports it too.
     if (!hasher.drain()) {
@@ -633,16 +728,9 @@ std::unique_ptr<SegmentProducer> make_zstd_producer(exg_reader *r, int fd, uint6
 // `halo_want` bytes of content, as far as the frame headers tell), then its own; own_lo / own_hi: where its own begin / end.
 int plan_zstd_shard(exg_reader *r, int fd, uint64_t n, const std::string &path, uint64_t halo_want, uint64_t header_bytes, uint64_t *c_begin,
                     uint64_t *c_end, uint64_t *own_lo, uint64_t *own_hi, bool *bytes_follow) {
-    void *map = n ? mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
-    if (map == MAP_FAILED) return fail(r, EXG_E_IO, "cannot map '" + path + "'");
-    struct Unmap {
-        void *p;
-        size_t n;
-        ~Unmap() { if (p) munmap(p, n); }
-    } unmap{map, (size_t)n};
     zst::Index idx;
     // (damage: the shards plan with what lies in front of it; the one that reads to the end of the file reports it behind its rows)
-    if (!zst::build_index((const uint8_t *)map, n, idx) && !zst::salvage_index(idx)) return fail(r, EXG_E_PARSE, idx.error + " in '" + path + "'");
+    if (!zst::build_index_fd(fd, n, idx) && !zst::salvage_index(idx)) return fail(r, EXG_E_PARSE, idx.error + " in '" + path + "'");
     const uint64_t lo = (uint64_t)((unsigned __int128)n * r->shard_index / r->shard_count);
     const uint64_t hi = r->shard_index + 1 == r->shard_count ? n : (uint64_t)((unsigned __int128)n * (r->shard_index + 1) / r->shard_count);
     const size_t nf = idx.frames.size();

@@ -322,11 +322,16 @@ __device__ __forceinline__ bool huf_stream(const uint16_t *tab, uint32_t log, ui
         avail = cnt;
         wi--;
     }
+    const uint32_t peek_shift = 32 - log;
     auto sym = [&]() -> uint32_t {
-        const bool rf = avail <= 32;  // (after it avail >= 33, a symbol takes at most 11)
-        const uint32_t wv = ring[(uint32_t)wi & 31u];
-        if (rf) c |= (uint64_t)wv << ((32 - avail) & 63), avail += 32, wi--;
-        const uint32_t e = tab[(uint32_t)(c >> (64 - log))];
+        // a word goes in when 32 bits or fewer are left (after it avail >= 33, a symbol takes at most 11) — with a mask,
+        // not a branch: the lanes of a wavefront refill at different symbols
+        const uint32_t rf = avail <= 32 ? 1u : 0u;
+        const uint64_t wv = (uint64_t)ring[(uint32_t)wi & 31u] << ((32 - avail) & 63);
+        c |= wv & (0ull - (uint64_t)rf);
+        avail += (int)(rf << 5);
+        wi -= (int)rf;
+        const uint32_t e = tab[(uint32_t)(c >> 32) >> peek_shift];
         c <<= e >> 8;
         avail -= (int)(e >> 8);
         return e & 255u;
@@ -462,7 +467,8 @@ static constexpr int kSeqG = 8;      // blocks per wavefront
 static constexpr int kSeqHalf = 64;  // bytes of a ring half: half h = stream bytes [64 h, 64 h + 64), h < 0: zeros
 struct SeqLds {
     uint16_t tab[kSeqG][1280];  // per block: LL [0, 512), OF [512, 768), ML [768, 1280); entry = symbol | x << 6
-    uint32_t ring[kSeqG][2 * kSeqHalf / 4 + 1];  // stream byte x of block g lives at ring[g] byte x & 127 (halves h, h + 1 resident; + 1: banks)
+    alignas(256) uint32_t ring[kSeqG][64];  // stream byte x of block g lives at ring[g] byte x & 127 (halves h, h + 1 resident); word 32 mirrors
+                                            // word 0 (a field's two words are one ds_read2_b32), and the 256-byte stride makes the address an OR
     int16_t norm[kSeqG][64];
     uint16_t next[kSeqG][64];
     uint32_t ll_code[36], ml_code[53];
@@ -470,9 +476,16 @@ struct SeqLds {
 
 // n (< 32) bits of the stream from bit `lowpos` up (bit k of the stream = bit k & 7 of byte k >> 3)
 __device__ __forceinline__ uint32_t seq_field(const uint32_t *ring, int lowpos, uint32_t n) {
-    const uint32_t w = (uint32_t)(lowpos >> 5);
-    const uint32_t lo = ring[w & 31u], hi = ring[(w + 1) & 31u];
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(ring) + (((uint32_t)lowpos >> 3) & 0x7cu));
+    const uint32_t lo = w[0], hi = w[1];
     return __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(hi, lo, (uint32_t)lowpos & 31u), 0u, n);
+}
+// a half into the sequences' ring (its word 32 mirrors word 0)
+__device__ __forceinline__ void seq_ring_store(uint32_t *ring, int h, const RingHalf &v) {
+    uint4 *dst = reinterpret_cast<uint4 *>(ring + (h & 1) * 16);
+#pragma unroll
+    for (int k = 0; k < 4; k++) dst[k] = v.q[k];
+    if (!(h & 1)) ring[32] = v.q[0].x;
 }
 
 // fse_build with 16-bit entries: symbol | x << 6, x = the symbol's count + the rank of the state among the symbol's states
@@ -597,8 +610,8 @@ __global__ __launch_bounds__(64) void k_zst_sequences(const uint8_t *__restrict_
             const uint8_t *sp = comp + src_off + q_off;
             const int len = (int)(src_size - q_off);
             int w_h = ((len - 1) >> 6) - 1;  // the lower of the two resident halves
-            ring_half_store(ring, w_h + 1, ring_half_load(sp, len, w_h + 1));
-            ring_half_store(ring, w_h, ring_half_load(sp, len, w_h));
+            seq_ring_store(ring, w_h + 1, ring_half_load(sp, len, w_h + 1));
+            seq_ring_store(ring, w_h, ring_half_load(sp, len, w_h));
             RingHalf below = ring_half_load(sp, len, w_h - 1);  // in flight while the lane decodes
             const uint32_t top = (ring[((uint32_t)(len - 1) >> 2) & 31u] >> (8u * ((uint32_t)(len - 1) & 3u))) & 255u;
             if (top == 0) { err = kErrSequences; break; }  // no end mark in the last byte
@@ -614,20 +627,24 @@ __global__ __launch_bounds__(64) void k_zst_sequences(const uint8_t *__restrict_
             uint32_t r0 = kRepSym, r1 = kRepSym | (1u << 29), r2 = kRepSym | (2u << 29);
             uint32_t sum_ll = 0, sum_ml = 0;
             uint32_t *o_ll = d_ll + seq_off, *o_ml = d_ml + seq_off, *o_off = d_off + seq_off;
-            bool bad = false, bad_off = false;
-            for (uint32_t i = 0; i < nseq && !bad && !bad_off; i++) {
+            // (the loop is one lane's serial chain and the wavefront issues it in order: every instruction counts — flags are
+            // collected with bit operations and the offset is chosen with selects, so that no lane's case costs the others a branch)
+            uint32_t badw = 0, bad_offw = 0;
+            const uint32_t size_l = 1u << llog, size_o = 1u << olog, size_m = 1u << mlog;
+            for (uint32_t i = 0; i < nseq && !(badw | bad_offw); i++) {
                 if ((P >> 3) - 16 < w_h * kSeqHalf) {  // (a sequence takes at most 89 bits and its reads begin 3 bytes below: it stays inside the ring)
                     w_h--;  // half w_h + 2 is behind the reader: the half below takes its place
-                    ring_half_store(ring, w_h, below);
+                    seq_ring_store(ring, w_h, below);
                     below = ring_half_load(sp, len, w_h - 1);
                 }
                 const uint32_t el = tab_ll[sl], eo = tab_of[so], em = tab_ml[sm];
                 const uint32_t lc = el & 63, oc = eo & 63, mc = em & 63;
-                const bool bad_sym = lc > 35 || oc > 31 || mc > 52;
+                const uint32_t bad_sym = (uint32_t)(lc > 35) | (uint32_t)(oc > 31) | (uint32_t)(mc > 52);
                 const uint32_t mcode = s.ml_code[mc], lcode = s.ll_code[lc];
                 const uint32_t xl = el >> 6, xo = eo >> 6, xm = em >> 6;
-                const bool more = i + 1 < nseq;  // (the last sequence reads no next states)
-                const uint32_t nl = more ? llog - (uint32_t)hb32(xl) : 0u, nm = more ? mlog - (uint32_t)hb32(xm) : 0u, no = more ? olog - (uint32_t)hb32(xo) : 0u;
+                const uint32_t more = i + 1 < nseq ? ~0u : 0u;  // (the last sequence reads no next states)
+                const uint32_t nl = (llog - 31 + (uint32_t)__builtin_clz(xl)) & more, nm = (mlog - 31 + (uint32_t)__builtin_clz(xm)) & more,
+                               no = (olog - 31 + (uint32_t)__builtin_clz(xo)) & more;
                 const uint32_t n1 = mcode >> 24, n2 = lcode >> 24;
                 const int p0 = P - (int)oc, p1 = p0 - (int)n1, p2 = p1 - (int)n2, p3 = p2 - (int)nl, p4 = p3 - (int)nm, p5 = p4 - (int)no;
                 const uint32_t f0 = seq_field(ring, p0, oc), f1 = seq_field(ring, p1, n1), f2 = seq_field(ring, p2, n2);
@@ -636,15 +653,20 @@ __global__ __launch_bounds__(64) void k_zst_sequences(const uint8_t *__restrict_
                 const uint32_t ov = (1u << oc) + f0;
                 const uint32_t ml = (mcode & 0xFFFFFFu) + f1;
                 const uint32_t ll = (lcode & 0xFFFFFFu) + f2;
-                sl = (xl << nl) - (1u << llog) + f3;
-                sm = (xm << nm) - (1u << mlog) + f4;
-                so = (xo << no) - (1u << olog) + f5;
+                sl = (xl << nl) + f3 - size_l;
+                sm = (xm << nm) + f4 - size_m;
+                so = (xo << no) + f5 - size_o;
                 // the offset: a new one (ov > 3), or one of the three last (RFC 8878 3.1.1.5), symbolic while it names the history
                 // in front of the block
-                const uint32_t sel = ov > 3 ? 4u : ov - 1 + (ll == 0 ? 1u : 0u);  // 0: r0, 1: r1, 2: r2, 3: r0 - 1, 4: new
-                const uint32_t dec = r0 + ((r0 & kRepSym) ? 1u : ~0u);            // "r0 minus one"
-                const uint32_t code = sel == 4 ? ov - 3 : sel == 0 ? r0 : sel == 1 ? r1 : sel == 2 ? r2 : dec;
-                if (!bad_sym && ((sel == 4 && code >= (1u << 29)) || (sel == 3 && !(r0 & kRepSym) && r0 <= 1))) bad_off = true;
+                const uint32_t sel = ov > 3 ? 4u : ov - 1 + (uint32_t)(ll == 0);  // 0: r0, 1: r1, 2: r2, 3: r0 - 1, 4: new
+                const uint32_t r0_sym = r0 >> 31;
+                const uint32_t dec = r0 + (r0_sym << 1) - 1;  // "r0 minus one": a symbolic offset counts what was taken off
+                uint32_t code = ov - 3;
+                code = sel == 3 ? dec : code;
+                code = sel == 2 ? r2 : code;
+                code = sel == 1 ? r1 : code;
+                code = sel == 0 ? r0 : code;
+                bad_offw |= ~bad_sym & (((uint32_t)(sel == 4) & (uint32_t)(code >= (1u << 29))) | ((uint32_t)(sel == 3) & (r0_sym ^ 1u) & (uint32_t)(r0 <= 1)));
                 r2 = sel >= 2 ? r1 : r2;
                 r1 = sel >= 1 ? r0 : r1;
                 r0 = code;
@@ -653,8 +675,9 @@ __global__ __launch_bounds__(64) void k_zst_sequences(const uint8_t *__restrict_
                 o_off[i] = code;
                 sum_ll += ll;
                 sum_ml += ml;
-                if (bad_sym || ((sum_ll > kBlockMax || sum_ml > kBlockMax) && !bad_off)) bad = true;
+                badw |= bad_sym | ((uint32_t)((sum_ll > sum_ml ? sum_ll : sum_ml) > kBlockMax) & ~bad_offw);
             }
+            const bool bad = (badw & 1u) != 0, bad_off = (bad_offw & 1u) != 0;
             if (bad_off) { err = kErrOffset; break; }
             if (bad || P != 0) { err = kErrSequences; break; }
             if (sum_ll > lit_regen) { err = kErrSequences; break; }
@@ -1270,6 +1293,18 @@ struct RoundCtx {
     size_t h_status_cap = 0;
     size_t n_rounds = 0;
     double t_begin = 0, t_entropy = 0;
+    // between the two halves of the enqueue phase
+    struct SymRound {
+        uint32_t c0, c1;
+        uint32_t list0, n_list;  // its symbolic chunks in sym_list
+        uint64_t elems;
+    };
+    std::vector<SymRound> rounds;
+    std::vector<uint32_t> sym_list;
+    std::vector<uint64_t> csize;
+    uint8_t *out_bytes = nullptr;
+    uint32_t *d_sym_list = nullptr;
+    bool exec_enqueued = false;
     RoundCtx(int d, hipStream_t s)
         : dev(d), st(s), d_blocks(d, s), d_lit(d, s), d_ll(d, s), d_ml(d, s), d_off(d, s), d_meta(d, s), d_frames(d, s), d_chunks(d, s), d_status(d, s),
           d_out(d, s), d_sym(d, s), d_lookup(d, s) {}
@@ -1368,8 +1403,8 @@ int decode_round_begin(Round &R, void *stream_v, RoundCtx **out_ctx) {
     C.total = total;
     R.rep_out[0] = state.rep[0], R.rep_out[1] = state.rep[1], R.rep_out[2] = state.rep[2];
     // frames: where their content lies.  Chunks: a frame is cut into runs of whole blocks of about `target` bytes, one
-    // wavefront each.  The first chunk of a frame (or of the part of a frame this round holds: what lies in front of it is
-    // final) writes bytes; every later one cannot know what lies in front of it while it runs, so it writes 32-bit symbols —
+    // wavefront each.  The first chunk of a frame writes bytes; every other one cannot know what lies in front of it while it
+    // runs (or, the first chunk of a frame that goes on from the round in front: not yet), so it writes 32-bit symbols —
     // a byte, or "the byte d in front of this chunk" — that are resolved chunk by chunk, in order, once everything in front
     // is final (k_zst_resolve).
     static const uint64_t target_env = getenv("EXG_ZSTD_CHUNK_BYTES") ? strtoull(getenv("EXG_ZSTD_CHUNK_BYTES"), nullptr, 10) : 0;
@@ -1401,7 +1436,9 @@ int decode_round_begin(Round &R, void *stream_v, RoundCtx **out_ctx) {
             c.frame_out_off = frame0;
             uint64_t got = 0;
             while (b < F.n_blocks && (got < target || c.n_blocks == 0)) got += blocks[F.first_block + b].out_size, b++, c.n_blocks++;
-            c.symbolic = c.first_block != F.first_block;
+            // (the part of a frame that an earlier round began has the window in front of it: its first chunk writes symbols
+            // too, so that no chunk's execution waits for the round in front — only the resolve does)
+            c.symbolic = c.first_block != F.first_block || !F.begins;
             c.elem_off = c.symbolic ? sym_elems : c.out_off;
             if (c.symbolic) sym_elems += got;
             chunks.push_back(c);
@@ -1413,8 +1450,9 @@ int decode_round_begin(Round &R, void *stream_v, RoundCtx **out_ctx) {
     return EXG_OK;
 }
 
-// (on an error the context is gone: its blocks went back to the pool behind a synchronised stream)
-int decode_round_enqueue(Round &R, RoundCtx *ctx_p) {
+// enqueue, first half: the execution of the chunks (of the first symbol round: there is one unless the symbol buffer is
+// capped).  Needs nothing of the round in front — R.d_history is not read.
+int decode_round_enqueue_exec(Round &R, RoundCtx *ctx_p) {
     std::unique_ptr<RoundCtx> ctx(ctx_p);
     RoundCtx &C = *ctx;
     hipStream_t st = C.st;
@@ -1423,11 +1461,10 @@ int decode_round_enqueue(Round &R, RoundCtx *ctx_p) {
     std::vector<Chunk> &chunks = C.chunks;
     const uint64_t H = C.H, total = C.total;
     const uint32_t nf = C.nf;
-    static const bool trace = getenv("EXG_TRACE") != nullptr;
     // (allocated at the device pool's size class: the caller hands the buffer back to that pool)
     EXG_HIP_CHECK(C.d_out.alloc(R.front_reserve + H + total + 64));
     uint8_t *const out_bytes = (uint8_t *)C.d_out.p + R.front_reserve;  // buffer coordinate 0
-    if (H) EXG_HIP_CHECK(hipMemcpyAsync(out_bytes, R.d_history, H, hipMemcpyDeviceToDevice, st));
+    C.out_bytes = out_bytes;
     EXG_HIP_CHECK(hipMemsetAsync(out_bytes + H + total, 0, 64, st));
     const uint32_t nc = (uint32_t)chunks.size();
     C.nc = nc;
@@ -1440,27 +1477,25 @@ int decode_round_enqueue(Round &R, RoundCtx *ctx_p) {
         EXG_HIP_CHECK(C.d_status.alloc(((size_t)nc + nf) * 4));
         EXG_HIP_CHECK(hipMemsetAsync(C.d_status.p, 0, ((size_t)nc + nf) * 4, st));
         // chunk sizes (bytes of output) and the rounds
-        std::vector<uint64_t> csize(nc);
+        std::vector<uint64_t> &csize = C.csize;
+        csize.resize(nc);
         for (uint32_t c = 0; c < nc; c++) {
             uint64_t sz = 0;
             for (uint32_t b = 0; b < chunks[c].n_blocks; b++) sz += blocks[chunks[c].first_block + b].out_size;
             csize[c] = sz;
             chunks[c].size = sz;
         }
-        {   // a frame's first chunk holds bytes: its end is where the frame's symbols begin
+        {   // a frame's first chunk holds bytes: its end is where the frame's symbols begin (a frame that goes on from the round
+            // in front has none: an earlier end is a smaller claim, and what lies in front of a resolve group is final anyway)
             uint64_t end = 0;
             for (uint32_t c = 0; c < nc; c++) {
                 if (!chunks[c].symbolic) end = chunks[c].out_off + csize[c];
                 chunks[c].byte_end = end;
             }
         }
-        struct SymRound {
-            uint32_t c0, c1;
-            uint32_t list0, n_list;  // its symbolic chunks in sym_list
-            uint64_t elems;
-        };
-        std::vector<SymRound> rounds;
-        std::vector<uint32_t> sym_list;
+        typedef RoundCtx::SymRound SymRound;
+        std::vector<SymRound> &rounds = C.rounds;
+        std::vector<uint32_t> &sym_list = C.sym_list;
         uint64_t sym_need = 0;
         {
             SymRound Q{0, 0, 0, 0, 0};
@@ -1497,31 +1532,64 @@ int decode_round_enqueue(Round &R, RoundCtx *ctx_p) {
         memcpy(h_chunks, chunks.data(), chunk_bytes);
         if (frame_bytes) memcpy(h_frames, C.dframes.data(), frame_bytes);
         EXG_HIP_CHECK(C.d_lookup.alloc(list_bytes));
-        uint32_t *d_sym_list = (uint32_t *)C.d_lookup.p;
-        if (!sym_list.empty()) EXG_HIP_CHECK(hipMemcpyAsync(d_sym_list, h_list, sym_list.size() * 4, hipMemcpyHostToDevice, st));
+        C.d_sym_list = (uint32_t *)C.d_lookup.p;
+        if (!sym_list.empty()) EXG_HIP_CHECK(hipMemcpyAsync(C.d_sym_list, h_list, sym_list.size() * 4, hipMemcpyHostToDevice, st));
         EXG_HIP_CHECK(hipMemcpyAsync(C.d_chunks.p, h_chunks, chunk_bytes, hipMemcpyHostToDevice, st));
         EXG_HIP_CHECK(hipMemcpyAsync(C.d_frames.p, h_frames, frame_bytes, hipMemcpyHostToDevice, st));
-        for (const SymRound &Q : rounds) {
-            const uint32_t cnt = Q.c1 - Q.c0, grid = cnt < 16384 ? cnt : 16384;
-            if (!cnt) continue;
+        const SymRound &Q = rounds[0];
+        const uint32_t cnt = Q.c1 - Q.c0, grid = cnt < 16384 ? cnt : 16384;
+        if (cnt)
             hipLaunchKernelGGL(k_zst_exec, dim3(grid), dim3(64), 0, st, d_comp, (const Block *)C.d_blocks.p, (const Chunk *)C.d_chunks.p + Q.c0, cnt,
                                (const uint8_t *)C.d_lit.p, (const uint32_t *)C.d_ll.p, (const uint32_t *)C.d_ml.p, (const uint32_t *)C.d_off.p,
                                out_bytes, (uint32_t *)C.d_sym.p, (uint32_t *)C.d_status.p + Q.c0);
+        EXG_HIP_CHECK(hipGetLastError());
+    }
+    C.exec_enqueued = true;
+    ctx.release();
+    return EXG_OK;
+}
+
+// enqueue, second half: the window in front (R.d_history must hold it by now), the resolve launches, the checksums
+int decode_round_enqueue_resolve(Round &R, RoundCtx *ctx_p) {
+    std::unique_ptr<RoundCtx> ctx(ctx_p);
+    RoundCtx &C = *ctx;
+    hipStream_t st = C.st;
+    const uint8_t *d_comp = (const uint8_t *)R.d_comp;
+    std::vector<Chunk> &chunks = C.chunks;
+    const uint64_t H = C.H;
+    const uint32_t nf = C.nf, nc = C.nc;
+    uint8_t *const out_bytes = C.out_bytes;
+    if (H) EXG_HIP_CHECK(hipMemcpyAsync(out_bytes, R.d_history, H, hipMemcpyDeviceToDevice, st));
+    if (nc) {
+        typedef RoundCtx::SymRound SymRound;
+        const std::vector<uint32_t> &sym_list = C.sym_list;
+        const std::vector<uint64_t> &csize = C.csize;
+        const uint32_t *d_sym_list = C.d_sym_list;
+        const size_t status_bytes = ((size_t)nc + nf) * 4;
+        bool first = true;
+        for (const SymRound &Q : C.rounds) {
+            const uint32_t cnt = Q.c1 - Q.c0, grid = cnt < 16384 ? cnt : 16384;
+            if (!cnt) continue;
+            if (!first)  // (the first symbol round's execution went out with the first half)
+                hipLaunchKernelGGL(k_zst_exec, dim3(grid), dim3(64), 0, st, d_comp, (const Block *)C.d_blocks.p, (const Chunk *)C.d_chunks.p + Q.c0, cnt,
+                                   (const uint8_t *)C.d_lit.p, (const uint32_t *)C.d_ll.p, (const uint32_t *)C.d_ml.p, (const uint32_t *)C.d_off.p,
+                                   out_bytes, (uint32_t *)C.d_sym.p, (uint32_t *)C.d_status.p + Q.c0);
+            first = false;
             static const uint64_t group_bytes = getenv("EXG_ZSTD_RESOLVE_BYTES") ? strtoull(getenv("EXG_ZSTD_RESOLVE_BYTES"), nullptr, 10) : (512ull << 10);
             for (uint32_t k0 = 0; k0 < Q.n_list;) {
                 uint32_t k1 = k0;
                 uint64_t bytes = 0;
                 while (k1 < Q.n_list && k1 - k0 < kGroupMax && (bytes < group_bytes || k1 == k0)) bytes += csize[sym_list[Q.list0 + k1]], k1++;
-                const Chunk &first = chunks[sym_list[Q.list0 + k0]], &last = chunks[sym_list[Q.list0 + k1 - 1]];
+                const Chunk &first_c = chunks[sym_list[Q.list0 + k0]], &last = chunks[sym_list[Q.list0 + k1 - 1]];
                 ResolveArgs ra;
                 ra.sym = (const uint32_t *)C.d_sym.p;
                 ra.chunks = (const Chunk *)C.d_chunks.p;
                 ra.sym_chunks = d_sym_list + Q.list0 + k0;
                 ra.n_sym_chunks = k1 - k0;
                 ra.out = out_bytes;
-                ra.final_below = first.out_off;
-                ra.elem0 = first.elem_off;
-                ra.n_elems = last.elem_off + ((last.size + 3) & ~3ull) - first.elem_off;
+                ra.final_below = first_c.out_off;
+                ra.elem0 = first_c.elem_off;
+                ra.n_elems = last.elem_off + ((last.size + 3) & ~3ull) - first_c.elem_off;
                 hipLaunchKernelGGL(k_zst_resolve, dim3((uint32_t)((ra.n_elems + 1023) / 1024)), dim3(256), 0, st, ra);
                 k0 = k1;
             }
@@ -1531,9 +1599,15 @@ int decode_round_enqueue(Round &R, RoundCtx *ctx_p) {
         EXG_HIP_CHECK(hipGetLastError());
         EXG_HIP_CHECK(hipMemcpyAsync(C.h_status, C.d_status.p, status_bytes, hipMemcpyDeviceToHost, st));
     }
-    (void)trace;
     ctx.release();
     return EXG_OK;
+}
+
+// (on an error the context is gone: its blocks went back to the pool behind a synchronised stream)
+int decode_round_enqueue(Round &R, RoundCtx *ctx) {
+    int rc = decode_round_enqueue_exec(R, ctx);
+    if (!rc) rc = decode_round_enqueue_resolve(R, ctx);
+    return rc;
 }
 
 int decode_round_wait(Round &R, RoundCtx *ctx_p) {

@@ -110,6 +110,8 @@ struct Index {
 
 // Host: walk the frames and blocks of data[0, n).  false + idx.error on a malformed stream.
 bool build_index(const uint8_t *data, uint64_t n, Index &idx);
+// the same over file bytes [0, n) of fd, with small reads (nothing is mapped)
+bool build_index_fd(int fd, uint64_t n, Index &idx);
 // After a failed walk: keep what lies in front of the damage — the complete frames and the complete blocks of the frame that
 // was open (as a frame without a checksum or a stated size) — so that a reader can hand out their rows before it reports
 // idx.error, like a streaming decoder does with a truncated file.  false: nothing usable lies in front of it.
@@ -155,7 +157,11 @@ int decode_round(Round &R, void *stream);
 // A phase that fails has disposed of the context.  (Overlapping two rounds with them measured no gain: see exg_zstd.hip.)
 struct RoundCtx;
 int decode_round_begin(Round &R, void *stream, RoundCtx **ctx);
-int decode_round_enqueue(Round &R, RoundCtx *ctx);
+int decode_round_enqueue(Round &R, RoundCtx *ctx);  // = _exec + _resolve
+// the enqueue phase in two halves: the chunks' execution needs nothing of the round in front (a frame that goes on writes
+// symbols from its first chunk); the resolve launches need R.d_history
+int decode_round_enqueue_exec(Round &R, RoundCtx *ctx);
+int decode_round_enqueue_resolve(Round &R, RoundCtx *ctx);
 int decode_round_wait(Round &R, RoundCtx *ctx);
 void decode_round_abandon(RoundCtx *ctx);
 uint64_t default_verify_max();

@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #include <time.h>
 
 #include <random>
@@ -93,6 +94,22 @@ int main(int argc, char **argv) {
                 }
                 for (const auto &b : idx.blocks)
                     if (b.src_off + (b.type == 1 ? 1 : b.src_size) > d.size()) return 3;  // a block the walk accepted must lie inside the input
+                // the same walk over a file (small preads, what the reader runs): the same answer, block for block
+                if (runs % 8 == 0) {
+                    char name[] = "/tmp/exg_asan_zst_XXXXXX";
+                    const int fd = mkstemp(name);
+                    if (fd < 0) return 9;
+                    unlink(name);
+                    if (!d.empty() && write(fd, p, d.size()) != (ssize_t)d.size()) return 9;
+                    exg::zst::Index fi;
+                    const bool whole_f = exg::zst::build_index_fd(fd, d.size(), fi);
+                    close(fd);
+                    exg::zst::Index mi;
+                    (void)exg::zst::build_index(p, d.size(), mi);
+                    if (whole_f != whole || fi.error != mi.error || fi.blocks.size() != mi.blocks.size() || fi.frames.size() != mi.frames.size()) return 9;
+                    if (!fi.blocks.empty() && memcmp(fi.blocks.data(), mi.blocks.data(), fi.blocks.size() * sizeof fi.blocks[0])) return 9;
+                    if (!fi.frames.empty() && memcmp(fi.frames.data(), mi.frames.data(), fi.frames.size() * sizeof fi.frames[0])) return 9;
+                }
             }
             free(p);
             runs++;

@@ -25,6 +25,8 @@ for batch in os.environ.get("ZST_BATCHES", "0,536870912,1073741824,4294967296").
         t0 = time.perf_counter()
         rows = r.count()
         dt = time.perf_counter() - t0
+        if os.environ.get("EXG_TRACE"):
+            print(f"[probe] count() returned after {dt*1e3:.1f} ms", file=sys.stderr, flush=True)
         st = r.stats()
         r.close()
         assert rows == n // 332
