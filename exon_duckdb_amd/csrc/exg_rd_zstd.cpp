@@ -356,7 +356,13 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
         // the window the round leaves (0: none — its last frame ends)
         uint64_t nh = 0, npad = 0, window = 0;
         bool active = false;
+        // the ~1 900 resolve launches of a round take this long to ISSUE (~5 us each: 10 ms): a thread of their own issues them,
+        // so that the round behind begins meanwhile (its entropy stages and execution then run beside these launches on the chip)
+        std::thread launcher;
+        int launch_rc = 0;
+        std::string launch_err;
         ~InFlight() {
+            if (launcher.joinable()) launcher.join();
             if (ctx) zst::decode_round_abandon(ctx);
         }
     } fl[2];
@@ -365,6 +371,11 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
     // round `F` is done on the device: its window into d_hist, its segment to the hasher / the consumer
     auto complete = [&](InFlight &F) -> int {
         F.active = false;
+        if (F.launcher.joinable()) F.launcher.join();
+        if (F.launch_rc) {  // (the launcher has disposed of the context)
+            *err = F.launch_err + " in '" + path_ + "'";
+            return F.launch_rc;
+        }
         zst::RoundCtx *ctx = F.ctx;
         F.ctx = nullptr;
         int rc;
@@ -640,16 +651,29 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
             return EXG_E_PARSE;
         }
         R.d_history = d_hist.p;
-        {
+        F.launch_rc = 0;
+        if (overlap) {
+            MemMeter *const meter = tl_meter();
+            F.launcher = std::thread([this, &F, meter] {
+                (void)hipSetDevice(device_);
+                MeterScope scope(meter);
+                TraceRange range("exg: zstd round (resolve enqueued)");
+                zst::RoundCtx *ctx = F.ctx;
+                F.ctx = nullptr;
+                F.launch_rc = zst::decode_round_enqueue_resolve(F.R, ctx);
+                if (F.launch_rc) F.launch_err = exg_last_error_message();
+                else F.ctx = ctx;
+            });
+        } else {
             TraceRange range("exg: zstd round (resolve enqueued)");
             zst::RoundCtx *ctx = F.ctx;
             F.ctx = nullptr;
             rc = zst::decode_round_enqueue_resolve(R, ctx);
             if (!rc) F.ctx = ctx;
-        }
-        if (rc) {
-            *err = std::string(exg_last_error_message()) + " in '" + path_ + "'";
-            return rc;
+            if (rc) {
+                *err = std::string(exg_last_error_message()) + " in '" + path_ + "'";
+                return rc;
+            }
         }
         F.active = true;
         // ---- what the next round needs of this one
