@@ -91,13 +91,15 @@ public:
 
 private:
     static constexpr size_t kPiece = 32u << 20;
+    static constexpr size_t kHelpers = 4;  // threads that hash whole frames beside this one
     void fail(const std::string &what) {
         std::lock_guard<std::mutex> g(mu_);
         if (!failed_) failed_ = true, error_ = what;
         cv_.notify_all();
     }
     // one part: pieces copied into the two pinned buffers in turn, piece k + 1 on its way while piece k is hashed
-    bool hash_part(const Part &part, hipStream_t st, char *pin[2], hipEvent_t ev[2]) {
+    // (bad_frame: the lowest frame of the job whose checksum did not match — several threads hash a job's frames)
+    bool hash_part(const Part &part, hipStream_t st, char *pin[2], hipEvent_t ev[2], exg::Xxh64 &h_, std::atomic<uint32_t> &bad_frame) {
         if (part.begins) h_ = exg::Xxh64();
         const uint64_t n_pieces = (part.len + kPiece - 1) / kPiece;
         auto issue = [&](uint64_t k) -> bool {
@@ -112,10 +114,11 @@ private:
             h_.update((const uint8_t *)pin[k & 1], (size_t)std::min<uint64_t>(kPiece, part.len - k * kPiece));
         }
         if (part.ends && (uint32_t)h_.digest() != part.expect) {
-            fail("Restored data doesn't match checksum (zstd frame " + std::to_string(part.frame) + ")");
-            return true;  // (not a failed copy: the segment still goes out — the error comes behind its rows)
+            uint32_t seen = bad_frame.load();
+            while (part.frame < seen && !bad_frame.compare_exchange_weak(seen, part.frame)) {
+            }
         }
-        return true;
+        return true;  // (a mismatch is not a failed copy: the segment still goes out — the error comes behind its rows)
     }
     void loop() {
         (void)hipSetDevice(device_);
@@ -152,10 +155,53 @@ private:
                 ready = ok;
                 if (!ok) fail("out of pinned host memory (or streams) for the checksum of a zstd frame");
             }
+            // A frame that lies inside the segment is nobody's business but its own: helper threads take such frames in turn
+            // (a stream, two pinned buffers and a hash state each) while this thread folds the frame that spans segments — a file
+            // of many checksummed frames (pzstd, the seekable format) is hashed at several cores' rate, not one's.
+            std::vector<size_t> whole;
+            for (size_t i = 0; i < job.parts.size(); i++)
+                if (job.parts[i].begins && job.parts[i].ends) whole.push_back(i);
+            std::vector<std::thread> helpers;
+            std::atomic<size_t> next{0};
+            std::atomic<bool> helpers_ok{true};
+            std::atomic<uint32_t> bad_frame{~0u};
+            if (ok && whole.size() >= 2) {
+                const size_t nh = std::min<size_t>(kHelpers, whole.size());
+                for (size_t t = 0; t < nh; t++)
+                    helpers.emplace_back([&, this] {
+                        (void)hipSetDevice(device_);
+                        pin_to_device_node(device_);
+                        MeterScope scope(meter_);
+                        hipStream_t hst = nullptr;
+                        hipEvent_t hev[2] = {nullptr, nullptr};
+                        char *hpin[2] = {nullptr, nullptr};
+                        size_t hcap[2] = {kPiece + 64, kPiece + 64};
+                        bool up = stream_pool()->take(device_, &hst) == hipSuccess;
+                        for (int i = 0; i < 2 && up; i++)
+                            up = hipEventCreateWithFlags(&hev[i], hipEventDisableTiming) == hipSuccess && (hpin[i] = global_pool()->take(&hcap[i])) != nullptr;
+                        exg::Xxh64 h;
+                        for (size_t k; up && (k = next.fetch_add(1)) < whole.size();)
+                            if (!hash_part(job.parts[whole[k]], hst, hpin, hev, h, bad_frame)) up = false;
+                        if (!up) helpers_ok.store(false);
+                        if (hst && hipStreamSynchronize(hst) != hipSuccess) (void)hipGetLastError();
+                        for (int i = 0; i < 2; i++) {
+                            if (hpin[i]) global_pool()->give(hpin[i], hcap[i]);
+                            if (hev[i]) (void)hipEventDestroy(hev[i]);
+                        }
+                        if (hst) stream_pool()->give(device_, hst);
+                    });
+            }
             for (size_t i = 0; i < job.parts.size() && ok; i++) {
-                ok = hash_part(job.parts[i], st, pin, ev);
+                if (!helpers.empty() && job.parts[i].begins && job.parts[i].ends) continue;
+                ok = hash_part(job.parts[i], st, pin, ev, h_, bad_frame);
                 if (!ok) fail("copying a zstd frame back for its checksum failed");
             }
+            for (auto &t : helpers) t.join();
+            if (ok && !helpers_ok.load()) {
+                ok = false;
+                fail("copying a zstd frame back for its checksum failed");
+            }
+            if (ok && bad_frame.load() != ~0u) fail("Restored data doesn't match checksum (zstd frame " + std::to_string(bad_frame.load()) + ")");
             if (st && hipStreamSynchronize(st) != hipSuccess) (void)hipGetLastError();  // (no copy may still read the segment)
             bool pushed = false;
             if (ok) pushed = sink_->push(std::move(job.seg));
@@ -332,7 +378,10 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
         return EXG_E_HIP;
     }
     FrameHasher hasher(device_, &sink, tl_meter());
-    const uint64_t verify_max = zst::default_verify_max();
+    // A frame inside one round is hashed on the device up to this size, one wavefront per frame at ~0.55 GB/s: the round waits
+    // for the slowest of them.  1 MiB = 2 ms of a ~30 ms round; frames of 8 MiB cost 78 ms per 4 GB and frames of 64 MiB 610 ms
+    // (5.4 instead of 30.9 GB/s) when this was the decoder's 64 MiB.  Larger frames go to the hasher threads behind the decoder.
+    const uint64_t verify_max = getenv("EXG_ZSTD_VERIFY_MAX") ? zst::default_verify_max() : std::min<uint64_t>(zst::default_verify_max(), 1u << 20);
     uint64_t d_pos = 0;             // decoded bytes produced so far
     uint64_t b0 = b_first;          // next block
     uint32_t rep[3] = {1, 4, 8};    // repeat offsets behind block b0 - 1 (of the frame that goes on)
@@ -531,7 +580,6 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
         }
         if (nx) ZS_HIP(hipMemcpyAsync(d_comp.p, pin.p, nx * kSideSlot, hipMemcpyHostToDevice, st_r));
         bool hip_failed = false;
-        const double t_read0 = now_s();
         if (!have && comp_len && !pread_parallel(device_, fd_, c_lo, (size_t)comp_len, pin.p + kSide, (char *)d_comp.p + kSide, st_r, &hip_failed)) {
             *err = hip_failed ? "hipMemcpyAsync failed" : "short read of '" + path_ + "'";
             return hip_failed ? EXG_E_HIP : EXG_E_IO;

@@ -1,5 +1,6 @@
-"""COUNT(*) through the reader on a single-frame .zst of FASTQ-150 (level 3, checksum on) for several round sizes:
-ZST_GB (2) GB of content; run on the GPU box."""
+"""COUNT(*) through the reader on a .zst of FASTQ-150 (level 3; ZST_CHECK=0: no Content_Checksum) for several round sizes:
+ZST_GB (2) GB of content in ONE frame, or in frames of ZST_FRAME_MB MiB of content each (what pzstd and the seekable format
+write); run on the GPU box."""
 import os, sys, time, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -12,7 +13,13 @@ gb = float(os.environ.get("ZST_GB", "2"))
 n = int(gb * 1e9) // 332 * 332
 data = device.synth_fastq(n)[:n].cpu().numpy().tobytes()
 t0 = time.time()
-comp = compress(data, 3, os.environ.get("ZST_CHECK", "1") == "1")
+frame_mb = int(os.environ.get("ZST_FRAME_MB", "0"))
+check = os.environ.get("ZST_CHECK", "1") == "1"
+if frame_mb:
+    step = (frame_mb << 20) // 332 * 332
+    comp = b"".join(compress(data[o:o + step], 3, check) for o in range(0, n, step))
+else:
+    comp = compress(data, 3, check)
 print(f"compressed {n/1e9:.2f} GB -> {len(comp)/1e9:.2f} GB in {time.time()-t0:.1f} s", flush=True)
 d = tempfile.mkdtemp(dir="/dev/shm")
 p = os.path.join(d, "x.fastq.zst")
