@@ -13,13 +13,14 @@ gb = float(os.environ.get("ZST_GB", "2"))
 n = int(gb * 1e9) // 332 * 332
 data = device.synth_fastq(n)[:n].cpu().numpy().tobytes()
 t0 = time.time()
-frame_mb = int(os.environ.get("ZST_FRAME_MB", "0"))
+frame_mb = float(os.environ.get("ZST_FRAME_MB", "0"))   # (fractions: ZST_FRAME_MB=0.0625 = frames of 64 KiB)
+level, wlog = int(os.environ.get("ZST_LEVEL", "3")), int(os.environ.get("ZST_WLOG", "0"))
 check = os.environ.get("ZST_CHECK", "1") == "1"
 if frame_mb:
-    step = (frame_mb << 20) // 332 * 332
-    comp = b"".join(compress(data[o:o + step], 3, check) for o in range(0, n, step))
+    step = int(frame_mb * (1 << 20)) // 332 * 332
+    comp = b"".join(compress(data[o:o + step], level, check, window_log=wlog) for o in range(0, n, step))
 else:
-    comp = compress(data, 3, check)
+    comp = compress(data, level, check, window_log=wlog)
 print(f"compressed {n/1e9:.2f} GB -> {len(comp)/1e9:.2f} GB in {time.time()-t0:.1f} s", flush=True)
 d = tempfile.mkdtemp(dir="/dev/shm")
 p = os.path.join(d, "x.fastq.zst")
