@@ -66,6 +66,35 @@ def test_close_in_the_middle_of_a_stream(gpu, fastq_mid, tmp_path, monkeypatch, 
         r.close()
 
 
+@pytest.mark.timeout(300)
+def test_close_in_the_middle_of_overlapped_zstd_rounds(gpu, fastq_mid, tmp_path, monkeypatch):
+    """without a memory cap two zstd rounds overlap (round n + 1's entropy stages and execution beside round n's resolve launches,
+    which a thread of their own issues; three compressed windows, a read-ahead thread): exg_close with rounds in flight returns at
+    once, nothing is left behind for the next reader, and a whole read gives every row"""
+    from exon_duckdb_amd.reader import ShardReader
+    from exon_duckdb_amd.table_function import Chunk
+    import ctypes as C
+    data, want = fastq_mid
+    _files(tmp_path, data)
+    monkeypatch.delenv("EXG_DEVICE_MEM_CAP_MB", raising=False)
+    monkeypatch.setenv("EXG_DEVICE_BATCH_BYTES", str(1 << 20))   # rounds of ~1 MiB: dozens of them in flight one after the other
+    p = str(tmp_path / "c.fastq.zst")
+    for n_chunks in (0, 1, 7, 60):
+        r = ShardReader(p, "fastq")
+        for _ in range(n_chunks):
+            ch = Chunk()
+            assert r._l.exg_next_chunk(r._r, C.byref(ch)) == 0
+            assert ch.n_rows > 0
+            r._l.exg_release_chunk(r._r, C.byref(ch))
+        t0 = time.perf_counter()
+        r.close()
+        assert time.perf_counter() - t0 < 5.0, (n_chunks, "close waited for the stream")
+    for _ in range(2):
+        r = ShardReader(p, "fastq")
+        assert r.digest() == want
+        r.close()
+
+
 def _expect_error(path, fmt, min_rows_before, compression=None, **kw):
     """reads to the error: returns (rows delivered before it, message)"""
     import ctypes as C
