@@ -521,32 +521,37 @@ __device__ __forceinline__ int fse_build_x(uint16_t *tab, const int16_t *norm, i
 
 // table t (0 LL, 1 OF, 2 ML) as the sequences section at comp[src_off + seq_hdr ...] defines it (its mode there is not
 // Repeat) -> tab, *log_out.  *after: the offset (from the block's start) just behind table t's description.  One lane.
+// (The position is an offset that every branch advances BEFORE it looks at `want`: with a pointer post-incremented behind the
+// `if (want)` block, hipcc 7.2 dropped the increment on the path of the table that is wanted — an RLE-mode table, one byte —
+// and the bitstream began one byte early: "Data corruption detected (sequences)" on valid frames, tools/zstd_soak.py's find;
+// tests/golden/zstd_soak/.)
 __device__ __forceinline__ int seq_table_from(uint16_t *tab, int16_t *norm, uint16_t *next, int *log_out, int t, const uint8_t *comp, uint64_t src_off,
                                               uint32_t src_size, uint32_t seq_hdr, uint32_t *after) {
-    const uint8_t *p = comp + src_off, *end = p + src_size;
-    const uint8_t *q = p + seq_hdr;
-    const int modes = *q++;
+    const uint8_t *p = comp + src_off;
+    const int modes = p[seq_hdr];
+    uint32_t o = seq_hdr + 1;  // offset in the block
     for (int u = 0; u <= t; u++) {
         const bool want = u == t;
         const int m = (modes >> (6 - 2 * u)) & 3;
         const int max_log = u == 1 ? 8 : 9, max_sym = u == 0 ? 35 : u == 1 ? 31 : 52;
         if (m == 1) {
-            if (q >= end) return -1;
+            if (o >= src_size) return -1;
+            const uint32_t sym = p[o];
+            o += 1;
             if (want) {
-                if (*q > max_sym) return -1;
-                tab[0] = (uint16_t)(*q | (1u << 6));  // x = 1 with log 0: no bits, base 0
+                if (sym > (uint32_t)max_sym) return -1;
+                tab[0] = (uint16_t)(sym | (1u << 6));  // x = 1 with log 0: no bits, base 0
                 *log_out = 0;
             }
-            q++;
         } else if (m == 2) {
             int ns = 0, log = 0;
-            const int used = fse_read_norm(q, (int)(end - q), max_log, max_sym, norm, &ns, &log);
+            const int used = fse_read_norm(p + o, (int)(src_size - o), max_log, max_sym, norm, &ns, &log);
             if (used < 0) return -1;
+            o += (uint32_t)used;
             if (want) {
                 if (fse_build_x(tab, norm, ns, log, next)) return -1;
                 *log_out = log;
             }
-            q += used;
         } else if (m == 0) {
             if (want) {
                 const int16_t *def = t == 0 ? kLLDef : t == 1 ? kOFDef : kMLDef;
@@ -559,7 +564,7 @@ __device__ __forceinline__ int seq_table_from(uint16_t *tab, int16_t *norm, uint
             return -1;  // a Repeat entry is never a source
         }
     }
-    *after = (uint32_t)(q - p);
+    *after = o;
     return 0;
 }
 
@@ -761,6 +766,9 @@ __global__ __launch_bounds__(64) void k_zst_scan(Block *blocks, uint32_t b_begin
 #ifndef EXG_ZST_EXEC_SMALL
 #define EXG_ZST_EXEC_SMALL 1
 #endif
+#ifndef EXG_ZST_EXEC_BY_SEQUENCE
+#define EXG_ZST_EXEC_BY_SEQUENCE 0  // 1: the group loop of rounds 2-3 (a literal run + a match per turn), for A/B
+#endif
 static constexpr uint32_t kFlushLog2 = EXG_ZST_EXEC_SMALL ? 9 : 10;
 static constexpr uint32_t kFlush = 1u << kFlushLog2;  // elements of a segment of the absolute grid that leaves for HBM at once
 static constexpr uint32_t kPiece = kFlush;            // elements emitted between two flush checks (ring >= 2 * kPiece)
@@ -961,6 +969,7 @@ __device__ void exec_chunk(const Chunk &C, typename ExecCfg<SYM>::Elem *ring, ui
                     const typename ExecCfg<SYM>::Elem *src = ex.out0 + (m_pos - off);
                     for (uint32_t k = 0; k < ml; k++) match_stage[far_off + k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
+#if EXG_ZST_EXEC_BY_SEQUENCE
                 const unsigned long long far_mask = __ballot(far);
                 for (uint32_t j = 0; j < cnt; j++) {
                     const uint32_t L_j = __builtin_amdgcn_readlane(ll, j), M_j = __builtin_amdgcn_readlane(ml, j);
@@ -982,6 +991,79 @@ __device__ void exec_chunk(const Chunk &C, typename ExecCfg<SYM>::Elem *ring, ui
                     else
                         ex.put_match(O_j, M_j);
                 }
+#else
+                // The group's output, 64 ELEMENTS at a time (not a sequence at a time: FASTQ at level 3 has ~14 elements per
+                // sequence, and a literal run + a match per turn left most lanes idle through ~90 instructions — the kernel was
+                // bound by the chip's issue slots).  Where a sequence's output begins is out_incl away; an element finds its
+                // sequence by counting the sequence starts at or in front of it, takes what it needs of that lane (ds_bpermute),
+                // and reads its literal or its match's source.  A source inside the same 64 elements (a lower lane: sources lie
+                // in front) waits for that lane's turn; an overlapping match folds its source in front of itself first.
+                (void)cnt;
+                const uint32_t out_excl = out_incl - (ll + ml);  // where my sequence's output begins, group-relative
+                if (__any(valid && off > m_pos && (uint64_t)off > frame_pos0 + m_pos)) {  // libzstd: a match may reach back to the first
+                    err = kErrOffset;                                                       // byte of the frame's content, not beyond
+                    break;
+                }
+                const uint32_t T = __builtin_amdgcn_readlane(out_incl, 63);
+                const uint32_t G0 = ex.pos;
+                const uint32_t far_key = far ? far_off : ~0u;
+                const uint32_t lrel = ll_incl - ll;
+                uint32_t started = 0;  // sequences that began in front of the pass (wave-uniform)
+                volatile uint8_t *mark = reinterpret_cast<volatile uint8_t *>(lit_stage) + kLitStage + 16;  // (64 bytes behind the literal stage: k_zst_exec)
+                for (uint32_t done = 0; done < T; done += 64) {
+                    const uint32_t n = T - done < 64 ? T - done : 64;
+                    // which elements of the pass begin a sequence
+                    mark[lane] = 0;
+                    __builtin_amdgcn_wave_barrier();
+                    if (valid && out_excl - done < 64u) mark[out_excl - done] = 1;
+                    __builtin_amdgcn_wave_barrier();
+                    const uint32_t is_start = mark[lane];
+                    const uint32_t starts_incl = wave_incl_sum(is_start);
+                    const uint32_t j = started + starts_incl - 1;  // my sequence (element 0 of a group begins sequence 0)
+                    started += __builtin_amdgcn_readlane(starts_incl, 63);
+                    const bool act = lane < n;
+                    const uint32_t jb = (j & 63u) * 4;
+                    const uint32_t j_excl = (uint32_t)__builtin_amdgcn_ds_bpermute((int)jb, (int)out_excl);
+                    const uint32_t j_ll = (uint32_t)__builtin_amdgcn_ds_bpermute((int)jb, (int)ll);
+                    const uint32_t j_off = (uint32_t)__builtin_amdgcn_ds_bpermute((int)jb, (int)off);
+                    const uint32_t j_lrel = (uint32_t)__builtin_amdgcn_ds_bpermute((int)jb, (int)lrel);
+                    const uint32_t j_far = (uint32_t)__builtin_amdgcn_ds_bpermute((int)jb, (int)far_key);
+                    const uint32_t rel = done + lane - j_excl;  // my element's index in its sequence's output
+                    const uint32_t hi = G0 + done + n;
+                    typename ExecCfg<SYM>::Elem v = 0;
+                    bool dep = false;
+                    int32_t src = 0;
+                    if (act) {
+                        if (rel < j_ll) {
+                            v = staged ? (typename ExecCfg<SYM>::Elem)stage8[mis + j_lrel + rel] : (typename ExecCfg<SYM>::Elem)L[lit_pos + j_lrel + rel];
+                        } else {
+                            const uint32_t k = rel - j_ll;
+                            if (j_far != ~0u) {
+                                v = match_stage[j_far + k];
+                            } else {
+                                const uint32_t mstart = G0 + j_excl + j_ll;
+                                src = (int32_t)mstart - (int32_t)j_off + (int32_t)(k < j_off ? k : k % j_off);
+                                dep = src >= (int32_t)(G0 + done);
+                                if (!dep) v = ex.fetch(src, hi);
+                            }
+                        }
+                        if (!dep) ex.ring[ex.slot(G0 + done + lane)] = v;
+                    }
+                    // sources inside the pass: a lane's turn comes when its source's lane has had its own
+                    unsigned long long ready = __ballot(!act || !dep);
+                    while (ready != ~0ull) {
+                        __builtin_amdgcn_wave_barrier();
+                        const uint32_t src_lane = (uint32_t)(src - (int32_t)(G0 + done));
+                        const bool now = act && dep && ((ready >> (src_lane & 63u)) & 1ull);
+                        if (now) {
+                            ex.ring[ex.slot(G0 + done + lane)] = ex.ring[ex.slot((uint32_t)src)];
+                            dep = false;
+                        }
+                        ready |= __ballot(now);
+                    }
+                    ex.advance(n);
+                }
+#endif
                 lit_pos += group_lits;
             }
             if (!err && lit_pos < B.lit_regen) ex.put_bytes(L + lit_pos, B.lit_regen - lit_pos);
@@ -998,7 +1080,7 @@ __global__ __launch_bounds__(64) void k_zst_exec(const uint8_t *__restrict__ com
                                                  const uint32_t *__restrict__ d_ml, const uint32_t *__restrict__ d_off, uint8_t *out_bytes,
                                                  uint32_t *out_syms, uint32_t *chunk_status) {
     __shared__ __attribute__((aligned(16))) uint32_t ring[ExecCfg<true>::kRing];  // 8 KiB: 2 Ki symbols, or 4 Ki bytes
-    __shared__ __attribute__((aligned(16))) uint32_t lit_stage[kLitStage / 4 + 4];
+    __shared__ __attribute__((aligned(16))) uint32_t lit_stage[kLitStage / 4 + 4 + 16];  // + 16 bytes of slack + 64 bytes of sequence-start marks
     __shared__ __attribute__((aligned(16))) uint32_t match_stage[Exec<true>::kStage];  // 4 KiB: 1 Ki symbols (bytes use a quarter)
     static_assert(sizeof(ring) >= ExecCfg<false>::kRing, "the byte ring fits");
     const uint32_t lane = threadIdx.x;

@@ -265,3 +265,21 @@ def test_big_frame_checksum_is_verified_on_the_host(gpu, tmp_path):
     assert rc != 0 and seen == n_rec
     with pytest.raises(ExgError, match="checksum"):
         rd._fail(rc)
+
+
+def test_soak_fixtures_and_seeds(gpu):
+    """frames whose sequence tables are in RLE mode (a mode libzstd picks when every sequence of a block has the same code: small
+    windows make such blocks) — the two fixtures are seeds 482 and 253 of tools/zstd_soak.py, which the decoder refused until
+    round 4 ("Data corruption detected (sequences)": the RLE byte was not skipped) — and a run of the soak's seeds"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "tools"))
+    for f in sorted(os.listdir(os.path.join(GOLDEN, "zstd_soak"))):
+        comp = open(os.path.join(GOLDEN, "zstd_soak", f), "rb").read()
+        ok, want = decompress_stream(comp)
+        assert ok
+        rc, out = zstd_decode(gpu, comp)
+        assert rc == 0, (f, out)
+        assert out == want, f
+    import zstd_soak
+    total, failed = zstd_soak.run(list(range(40)) + [33, 236, 253, 300, 482])
+    assert not failed, failed
