@@ -3,7 +3,7 @@
 #   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r02_a'
 # Writes gpurun_out/<tag>_*; tools/pmc_summary.py then condenses them into profiles/.
 set -u
-TAG=${1:-r03_d}
+TAG=${1:-r04_c}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
@@ -21,8 +21,10 @@ done
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_configs -o kt --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --launches-per-step 2 --no-cpu-baseline --gz-gb 2 --e2e-gb 2 > $OUT/${TAG}_kt_configs.log 2>&1
 # records of other shapes (long reads, 36 bp reads, multi-sample VCF): the any-shape scan k_fused<.., 1>, the lean scan + redo run, k_*_far
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_shapes -o kt --output-format csv -- python3 $ROOT/tools/shapes_probe.py 4 > $OUT/${TAG}_kt_shapes.log 2>&1
-# zstd decode (512 MB single frame, level 3)
+# zstd through the reader (a 4 GB single frame, level 3, no Content_Checksum: three timed passes + the warm-up; the probe reads its knobs from the environment)
+export ZST_GB=4 ZST_BATCHES=0 ZST_CHECK=0
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_zstd -o kt --output-format csv -- python3 $ROOT/tools/zstd_stream_probe.py > $OUT/${TAG}_kt_zstd.log 2>&1
+unset ZST_GB ZST_BATCHES ZST_CHECK
 # single-member gzip through the reader (chunked decode)
 GZ_RECORDS=800000 GZ_ONLY_SINGLE=1 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_gzstream -o kt --output-format csv -- python3 $ROOT/tools/gz_probe.py > $OUT/${TAG}_kt_gzstream.log 2>&1
 # FASTA (1 GB), VCF (5 GB), BGZF inflate alone: per-kernel times
