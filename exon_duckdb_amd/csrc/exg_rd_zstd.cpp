@@ -108,11 +108,19 @@ private:
                    hipEventRecord(ev[k & 1], st) == hipSuccess;
         };
         if (n_pieces && !issue(0)) return false;
+        static const bool trace = getenv("EXG_TRACE") != nullptr;
+        double t_wait = 0, t_hash = 0;
         for (uint64_t k = 0; k < n_pieces; k++) {
+            const double t0 = trace ? now_s() : 0;
             if (hipEventSynchronize(ev[k & 1]) != hipSuccess) return false;
             if (k + 1 < n_pieces && !issue(k + 1)) return false;
+            const double t1 = trace ? now_s() : 0;
             h_.update((const uint8_t *)pin[k & 1], (size_t)std::min<uint64_t>(kPiece, part.len - k * kPiece));
+            if (trace) t_wait += t1 - t0, t_hash += now_s() - t1;
         }
+        if (trace && part.len >= (64u << 20))
+            fprintf(stderr, "[exg] zstd hasher: %.1f MB of frame %u: %.1f ms waiting for the copies, %.1f ms hashing (%.1f GB/s)\n", part.len / 1e6, part.frame,
+                    t_wait * 1e3, t_hash * 1e3, part.len / t_hash / 1e9);
         if (part.ends && (uint32_t)h_.digest() != part.expect) {
             uint32_t seen = bad_frame.load();
             while (part.frame < seen && !bad_frame.compare_exchange_weak(seen, part.frame)) {
