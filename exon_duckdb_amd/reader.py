@@ -113,8 +113,10 @@ class ShardReader:
                     h.update(vals.tobytes())
                     continue
                 if t != abi.EXG_TYPE_VARCHAR:
-                    if nested:
-                        h.update(repr(decode_vector(ch.vectors[k].contents, self.trees[k])).encode())
+                    if nested:   # row by row: the digest must not depend on how the rows were cut into chunks
+                        for v in decode_vector(ch.vectors[k].contents, self.trees[k]):
+                            h.update(repr(v).encode())
+                            h.update(b"\x00")
                     continue
                 raw = np.ctypeslib.as_array(C.cast(ch.data[k], C.POINTER(C.c_uint8)), shape=(n * 16,)).reshape(n, 16)
                 lens = raw[:, :4].copy().view(np.uint32).reshape(n)

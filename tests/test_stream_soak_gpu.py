@@ -36,18 +36,33 @@ def fastq_text(r):
     return bytes(out)
 
 
-def wrap(r, data, tmp_path, seed):
+def fasta_text(r):
+    """records wrapped at a width of their own, a few of them far longer than a round, descriptions or none"""
+    out = bytearray()
+    for i in range(r.randint(1, 1500)):
+        ln = r.choice([0, 1, 59, 60, 61]) if r.random() < 0.1 else r.randint(1, 2000)
+        if r.random() < 0.01:
+            ln = r.randint(100_000, 600_000)
+        width = r.choice([60, 70, 80, 1, 7, 120, 10 ** 9])
+        seq = (bytes(r.choice(b"ACGTN") for _ in range(min(ln, 211))) * (ln // 211 + 1))[:ln]
+        out += b">s%d" % i + (b" d%d %s" % (i, b"y" * r.randint(0, 30)) if r.random() < 0.6 else b"") + b"\n"
+        for o in range(0, ln, width):
+            out += seq[o:o + width] + b"\n"
+    return bytes(out)
+
+
+def wrap(r, data, tmp_path, seed, ext="fastq"):
     from zstd_util import compress, skippable
     kind = r.choice(["plain", "gz", "bgzf", "zst", "zst", "zst"])
     if kind == "plain":
-        p = tmp_path / f"s{seed}.fastq"
+        p = tmp_path / f"s{seed}.{ext}"
         p.write_bytes(data)
     elif kind == "gz":
         co = zlib.compressobj(r.randint(1, 9), zlib.DEFLATED, 31, 8, r.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED]))
-        p = tmp_path / f"s{seed}.fastq.gz"
+        p = tmp_path / f"s{seed}.{ext}.gz"
         p.write_bytes(co.compress(data) + co.flush())
     elif kind == "bgzf":
-        p = tmp_path / f"s{seed}.fastq.gz"
+        p = tmp_path / f"s{seed}.{ext}.gz"
         p.write_bytes(_bgzf(data, block=r.choice([997, 8191, 32768, 65280]), level=r.randint(1, 9)))
     else:
         level = r.choice([1, 2, 3, 3, 5, 9, 15, 19, -1, -5])
@@ -58,7 +73,7 @@ def wrap(r, data, tmp_path, seed):
             parts.append(compress(data[a:b], level, r.random() < 0.5, window_log=wl, content_size=r.random() < 0.7))
             if r.random() < 0.15:
                 parts.append(skippable(b"x" * r.randint(0, 40)))
-        p = tmp_path / f"s{seed}.fastq.zst"
+        p = tmp_path / f"s{seed}.{ext}.zst"
         p.write_bytes(b"".join(parts))
     return kind, p
 
@@ -86,3 +101,60 @@ def test_random_streams(gpu, oracle, tmp_path, monkeypatch, seed0):
         assert rd.count() == want[0], (seed, kind)
         rd.close()
         os.unlink(p)
+
+
+def _env(r, monkeypatch):
+    if r.random() < 0.35:
+        monkeypatch.setenv("EXG_DEVICE_MEM_CAP_MB", str(r.choice([16, 24, 64])))
+        monkeypatch.delenv("EXG_DEVICE_BATCH_BYTES", raising=False)
+    else:
+        monkeypatch.delenv("EXG_DEVICE_MEM_CAP_MB", raising=False)
+        monkeypatch.setenv("EXG_DEVICE_BATCH_BYTES", str(r.choice([128 << 10, 300_000, 1 << 20, 4 << 20, 0])))
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("seed0", range(0, N_SEEDS, 8))
+def test_random_fasta_streams(gpu, oracle, tmp_path, monkeypatch, seed0):
+    """FASTA: a record is as long as it is (batches are widened until they hold one), sequences are joined across their lines"""
+    for seed in range(seed0, min(seed0 + 8, N_SEEDS)):
+        r = random.Random(9000 + seed)
+        data = fasta_text(r)
+        want = _oracle_digest(oracle.fasta_parse(data), ["id", "description", "sequence"])
+        kind, p = wrap(r, data, tmp_path, seed, "fasta")
+        for mode in range(2):
+            _env(r, monkeypatch)
+            rd = _open(p, "fasta")
+            got = rd.digest()
+            rd.close()
+            assert got == want, (seed, kind, mode, len(data), dict((k, os.environ.get(k)) for k in ("EXG_DEVICE_MEM_CAP_MB", "EXG_DEVICE_BATCH_BYTES")))
+        os.unlink(p)
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("seed0", range(0, N_SEEDS, 8))
+def test_random_vcf_streams(gpu, tmp_path, monkeypatch, seed0):
+    """VCF (flat, typed and nested columns): a wrapped file gives the digest of the plain file, however it is cut into rounds
+    (the plain file against the oracle: tests/test_vcf_*.py, test_record_shapes_gpu.py)"""
+    from exon_duckdb_amd.testing import shapes
+    for seed in range(seed0, min(seed0 + 8, N_SEEDS)):
+        r = random.Random(11000 + seed)
+        data = shapes.vcf_lines(r.randint(1, 3000), r.choice([0, 0, 1, 3, 40, 120]), seed=seed, crlf_every=r.choice([0, 0, 7]))
+        plain = tmp_path / f"p{seed}.vcf"
+        plain.write_bytes(data)
+        monkeypatch.delenv("EXG_DEVICE_MEM_CAP_MB", raising=False)
+        monkeypatch.delenv("EXG_DEVICE_BATCH_BYTES", raising=False)
+        rd = _open(plain, "vcf")
+        want = rd.rows()          # (every column as Python values: the nested ones too, whatever the chunking)
+        rd.close()
+        kind, p = wrap(r, data, tmp_path, seed, "vcf")
+        for mode in range(2):
+            _env(r, monkeypatch)
+            rd = _open(p, "vcf")
+            got = rd.rows()
+            rd.close()
+            assert len(got) == len(want), (seed, kind, mode)
+            bad = next((i for i in range(len(want)) if repr(got[i]) != repr(want[i])), None)   # (repr: NaN == NaN)
+            assert bad is None, (seed, kind, mode, bad, got[bad], want[bad], dict((k, os.environ.get(k)) for k in ("EXG_DEVICE_MEM_CAP_MB", "EXG_DEVICE_BATCH_BYTES")))
+        os.unlink(p)
+        if plain.exists():
+            os.unlink(plain)
