@@ -50,7 +50,12 @@ public:
         Segment seg;
         std::vector<Part> parts;
     };
-    FrameHasher(int device, SegmentSink *sink, MemMeter *meter) : device_(device), sink_(sink), meter_(meter), thread_([this] { loop(); }) {}
+    FrameHasher(int device, SegmentSink *sink, MemMeter *meter)
+        : device_(device), sink_(sink), meter_(meter),
+          // segments that may wait behind the one being hashed: one (two or three measured nothing on a 4 GB checksummed frame —
+          // 250 / 264 against 247 / 284 ms, inside the boxes' noise — and each is a segment of device memory)
+          depth_(getenv("EXG_ZSTD_HASH_QUEUE") && !(meter && meter->cap) ? std::max(1, atoi(getenv("EXG_ZSTD_HASH_QUEUE"))) : 1),
+          thread_([this] { loop(); }) {}
     ~FrameHasher() {
         {
             std::lock_guard<std::mutex> g(mu_);
@@ -64,7 +69,7 @@ public:
     // false: nothing more is wanted — a checksum did not match (error()), or the consumer closed the stream (gone())
     bool submit(Job &&job) {
         std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&] { return queue_.size() < 1 || failed_ || gone_; });
+        cv_.wait(lk, [&] { return queue_.size() < depth_ || failed_ || gone_; });
         if (failed_ || gone_) {
             lk.unlock();
             sink_->give(job.seg.buf, job.seg.cap);
@@ -228,6 +233,7 @@ private:
     int device_;
     SegmentSink *sink_;
     MemMeter *meter_;
+    size_t depth_;
     exg::Xxh64 h_;
     std::mutex mu_;
     std::condition_variable cv_;
@@ -347,9 +353,13 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
     size_t d_comp_caps[3] = {0, 0, 0}, d_hist_cap = 4096;
     // where a round that begins with block b ends, and which file bytes it needs
     auto plan = [&](uint64_t from, uint64_t *to, uint64_t *lo, uint64_t *hi) {
-        // (a first round of a quarter of the size, so that the consumer begins earlier, measured nothing: 325 against 311 ms)
+        // The first round is a quarter of the size when rounds overlap: what stands behind the decoder — the scan, and the host's
+        // XXH64 of a frame with a Content_Checksum, which hashes slower than the device decodes — begins after ~25 ms instead of
+        // ~60.  (Measured "nothing" in round 3, 325 against 311 ms, when the decoder was what everything waited for.)
+        static const uint64_t first_div = getenv("EXG_ZSTD_FIRST_ROUND_DIV") ? std::max<uint64_t>(1, strtoull(getenv("EXG_ZSTD_FIRST_ROUND_DIV"), nullptr, 10)) : 4;
+        const uint64_t want_out = from == b_first && read_ahead_ ? std::max<uint64_t>(target_ / first_div, 16u << 20) : target_;
         uint64_t b1 = from, est = 0;
-        while (b1 < n_blocks && (b1 == from || est < target_)) {
+        while (b1 < n_blocks && (b1 == from || est < want_out)) {
             if (b1 > from && (b1 == b_mark[0] || b1 == b_mark[1])) break;
             const zst::Block &B = idx.blocks[b1];
             est += B.type == 2 ? zst::kBlockMax : B.src_size;  // raw / RLE: src_size is the regenerated size
