@@ -353,11 +353,12 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
     size_t d_comp_caps[3] = {0, 0, 0}, d_hist_cap = 4096;
     // where a round that begins with block b ends, and which file bytes it needs
     auto plan = [&](uint64_t from, uint64_t *to, uint64_t *lo, uint64_t *hi) {
-        // The first round is a quarter of the size when rounds overlap: what stands behind the decoder — the scan, and the host's
-        // XXH64 of a frame with a Content_Checksum, which hashes slower than the device decodes — begins after ~25 ms instead of
-        // ~60.  (Measured "nothing" in round 3, 325 against 311 ms, when the decoder was what everything waited for.)
-        static const uint64_t first_div = getenv("EXG_ZSTD_FIRST_ROUND_DIV") ? std::max<uint64_t>(1, strtoull(getenv("EXG_ZSTD_FIRST_ROUND_DIV"), nullptr, 10)) : 4;
-        const uint64_t want_out = from == b_first && read_ahead_ ? std::max<uint64_t>(target_ / first_div, 16u << 20) : target_;
+        // The first round is a quarter of the size (never more than a round, never below 16 MiB of one) when rounds overlap and
+        // the first frame carries a Content_Checksum: the host's XXH64, which hashes slower than the device decodes, begins after
+        // ~25 ms instead of ~60 (223-262 against 247-284 ms on a 4 GB frame; nothing without a checksum: 121-127 against 126 ms).
+        static const uint64_t first_div_env = getenv("EXG_ZSTD_FIRST_ROUND_DIV") ? std::max<uint64_t>(1, strtoull(getenv("EXG_ZSTD_FIRST_ROUND_DIV"), nullptr, 10)) : 0;
+        const uint64_t first_div = first_div_env ? first_div_env : (!idx.frames.empty() && idx.frames[idx.blocks[from].frame].has_checksum ? 4 : 1);
+        const uint64_t want_out = from == b_first && read_ahead_ ? std::min<uint64_t>(target_, std::max<uint64_t>(target_ / first_div, 16u << 20)) : target_;
         uint64_t b1 = from, est = 0;
         while (b1 < n_blocks && (b1 == from || est < want_out)) {
             if (b1 > from && (b1 == b_mark[0] || b1 == b_mark[1])) break;
