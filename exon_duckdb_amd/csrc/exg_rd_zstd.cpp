@@ -179,7 +179,8 @@ private:
             std::atomic<bool> helpers_ok{true};
             std::atomic<uint32_t> bad_frame{~0u};
             if (ok && whole.size() >= 2) {
-                const size_t nh = std::min<size_t>(kHelpers, whole.size());
+                static const size_t helpers_max = getenv("EXG_ZSTD_HASH_HELPERS") ? std::max(1, atoi(getenv("EXG_ZSTD_HASH_HELPERS"))) : kHelpers;
+                const size_t nh = std::min<size_t>(helpers_max, whole.size());
                 for (size_t t = 0; t < nh; t++)
                     helpers.emplace_back([&, this] {
                         (void)hipSetDevice(device_);

@@ -1178,7 +1178,7 @@ struct ResolveArgs {
 
 static constexpr uint32_t kGroupMax = 32;  // chunks per resolve launch
 
-__global__ __launch_bounds__(256) void k_zst_resolve(const ResolveArgs a) {
+__device__ __forceinline__ void resolve_group(const ResolveArgs &a, uint32_t block_x) {
     // the group's chunks: where they start in the output and in the symbol buffer, what lies in front of them as bytes
     __shared__ uint64_t s_out[kGroupMax], s_elem[kGroupMax], s_size[kGroupMax], s_bytes_below[kGroupMax], s_frame0[kGroupMax];
     const uint32_t n = a.n_sym_chunks;
@@ -1191,7 +1191,7 @@ __global__ __launch_bounds__(256) void k_zst_resolve(const ResolveArgs a) {
         s_frame0[threadIdx.x] = c.frame_out_off;
     }
     __syncthreads();
-    const uint64_t e = a.elem0 + (uint64_t)blockIdx.x * 1024 + (uint64_t)threadIdx.x * 4;
+    const uint64_t e = a.elem0 + (uint64_t)block_x * 1024 + (uint64_t)threadIdx.x * 4;
     if (e >= a.elem0 + a.n_elems) return;
     uint32_t k = 0;
     for (uint32_t j = 1; j < n; j++) k = s_elem[j] <= e ? j : k;
@@ -1233,6 +1233,17 @@ __global__ __launch_bounds__(256) void k_zst_resolve(const ResolveArgs a) {
         for (int j = 0; j < 3; j++)
             if ((uint32_t)j < nv) dst[j] = (uint8_t)x[j];
     }
+}
+
+__global__ __launch_bounds__(256) void k_zst_resolve(const ResolveArgs a) { resolve_group(a, blockIdx.x); }
+
+// Groups that do not depend on each other in ONE launch: references never leave their frame, so the k-th groups of all the
+// frames of a round resolve side by side (blockIdx.y: the group).  A round of one big frame is a chain of ~2 000 launches
+// whatever is done (14.7 ms of launch latency per GiB); a round of 8 MiB frames is sixteen.
+__global__ __launch_bounds__(256) void k_zst_resolve_many(const ResolveArgs *__restrict__ args) {
+    const ResolveArgs a = args[blockIdx.y];
+    if ((uint64_t)blockIdx.x * 1024 >= a.n_elems) return;  // (the grid is as wide as the batch's largest group)
+    resolve_group(a, blockIdx.x);
 }
 
 static double now_ms() {
@@ -1364,7 +1375,7 @@ struct DevTmp {
 struct RoundCtx {
     int dev;
     hipStream_t st;
-    DevTmp d_blocks, d_lit, d_ll, d_ml, d_off, d_meta, d_frames, d_chunks, d_status, d_out, d_sym, d_lookup;
+    DevTmp d_blocks, d_lit, d_ll, d_ml, d_off, d_meta, d_frames, d_chunks, d_status, d_out, d_sym, d_lookup, d_rargs;
     ScanState state;
     uint64_t H = 0, total = 0, target = 0;
     uint32_t nb = 0, nx = 0, nf = 0, nc = 0;
@@ -1387,14 +1398,15 @@ struct RoundCtx {
     uint8_t *out_bytes = nullptr;
     uint32_t *d_sym_list = nullptr;
     bool exec_enqueued = false;
+    char *h_rargs = nullptr;  // the resolve launches' arguments (pinned), when groups of several frames share launches
+    size_t h_rargs_cap = 0;
     RoundCtx(int d, hipStream_t s)
         : dev(d), st(s), d_blocks(d, s), d_lit(d, s), d_ll(d, s), d_ml(d, s), d_off(d, s), d_meta(d, s), d_frames(d, s), d_chunks(d, s), d_status(d, s),
-          d_out(d, s), d_sym(d, s), d_lookup(d, s) {}
+          d_out(d, s), d_sym(d, s), d_lookup(d, s), d_rargs(d, s) {}
     ~RoundCtx() {
-        if (h_status) {
-            (void)hipStreamSynchronize(st);
-            exg_rd::global_pool()->give(h_status, h_status_cap);
-        }
+        if (h_status || h_rargs) (void)hipStreamSynchronize(st);
+        if (h_status) exg_rd::global_pool()->give(h_status, h_status_cap);
+        if (h_rargs) exg_rd::global_pool()->give(h_rargs, h_rargs_cap);
     }
 };
 void decode_round_abandon(RoundCtx *c) { delete c; }
@@ -1658,22 +1670,67 @@ int decode_round_enqueue_resolve(Round &R, RoundCtx *ctx_p) {
                                    out_bytes, (uint32_t *)C.d_sym.p, (uint32_t *)C.d_status.p + Q.c0);
             first = false;
             static const uint64_t group_bytes = getenv("EXG_ZSTD_RESOLVE_BYTES") ? strtoull(getenv("EXG_ZSTD_RESOLVE_BYTES"), nullptr, 10) : (512ull << 10);
+            // groups of consecutive chunks of ONE frame (a reference never leaves its frame); batch j = the j-th group of every
+            // frame of the round: its groups are independent of each other, the batches run in order
+            std::vector<std::vector<ResolveArgs>> batches;
             for (uint32_t k0 = 0; k0 < Q.n_list;) {
-                uint32_t k1 = k0;
-                uint64_t bytes = 0;
-                while (k1 < Q.n_list && k1 - k0 < kGroupMax && (bytes < group_bytes || k1 == k0)) bytes += csize[sym_list[Q.list0 + k1]], k1++;
-                const Chunk &first_c = chunks[sym_list[Q.list0 + k0]], &last = chunks[sym_list[Q.list0 + k1 - 1]];
-                ResolveArgs ra;
-                ra.sym = (const uint32_t *)C.d_sym.p;
-                ra.chunks = (const Chunk *)C.d_chunks.p;
-                ra.sym_chunks = d_sym_list + Q.list0 + k0;
-                ra.n_sym_chunks = k1 - k0;
-                ra.out = out_bytes;
-                ra.final_below = first_c.out_off;
-                ra.elem0 = first_c.elem_off;
-                ra.n_elems = last.elem_off + ((last.size + 3) & ~3ull) - first_c.elem_off;
-                hipLaunchKernelGGL(k_zst_resolve, dim3((uint32_t)((ra.n_elems + 1023) / 1024)), dim3(256), 0, st, ra);
-                k0 = k1;
+                const uint64_t frame0 = chunks[sym_list[Q.list0 + k0]].frame_out_off;
+                for (uint32_t j = 0; k0 < Q.n_list && chunks[sym_list[Q.list0 + k0]].frame_out_off == frame0; j++) {
+                    uint32_t k1 = k0;
+                    uint64_t bytes = 0;
+                    while (k1 < Q.n_list && k1 - k0 < kGroupMax && (bytes < group_bytes || k1 == k0) && chunks[sym_list[Q.list0 + k1]].frame_out_off == frame0)
+                        bytes += csize[sym_list[Q.list0 + k1]], k1++;
+                    const Chunk &first_c = chunks[sym_list[Q.list0 + k0]], &last = chunks[sym_list[Q.list0 + k1 - 1]];
+                    ResolveArgs ra;
+                    ra.sym = (const uint32_t *)C.d_sym.p;
+                    ra.chunks = (const Chunk *)C.d_chunks.p;
+                    ra.sym_chunks = d_sym_list + Q.list0 + k0;
+                    ra.n_sym_chunks = k1 - k0;
+                    ra.out = out_bytes;
+                    ra.final_below = first_c.out_off;
+                    ra.elem0 = first_c.elem_off;
+                    ra.n_elems = last.elem_off + ((last.size + 3) & ~3ull) - first_c.elem_off;
+                    if (batches.size() <= j) batches.resize(j + 1);
+                    batches[j].push_back(ra);
+                    k0 = k1;
+                }
+            }
+            size_t n_shared = 0;  // arguments that travel through memory (batches of more than one group)
+            for (const auto &b : batches) n_shared += b.size() > 1 ? b.size() : 0;
+            const ResolveArgs *d_args = nullptr;
+            if (n_shared) {
+                if (C.h_rargs) {  // (a second symbol round: the first one's launches must have read theirs)
+                    EXG_HIP_CHECK(hipStreamSynchronize(st));
+                    exg_rd::global_pool()->give(C.h_rargs, C.h_rargs_cap);
+                    C.h_rargs = nullptr;
+                }
+                C.h_rargs_cap = n_shared * sizeof(ResolveArgs);
+                C.h_rargs = exg_rd::global_pool()->take(&C.h_rargs_cap);
+                if (!C.h_rargs) {
+                    set_error("zstd decode: out of pinned host memory");
+                    return EXG_E_NOMEM;
+                }
+                EXG_HIP_CHECK(C.d_rargs.alloc(n_shared * sizeof(ResolveArgs)));
+                size_t at = 0;
+                for (const auto &b : batches)
+                    if (b.size() > 1) memcpy(C.h_rargs + at * sizeof(ResolveArgs), b.data(), b.size() * sizeof(ResolveArgs)), at += b.size();
+                EXG_HIP_CHECK(hipMemcpyAsync(C.d_rargs.p, C.h_rargs, n_shared * sizeof(ResolveArgs), hipMemcpyHostToDevice, st));
+                d_args = (const ResolveArgs *)C.d_rargs.p;
+            }
+            size_t at = 0;
+            for (const auto &b : batches) {
+                if (b.size() == 1) {
+                    hipLaunchKernelGGL(k_zst_resolve, dim3((uint32_t)((b[0].n_elems + 1023) / 1024)), dim3(256), 0, st, b[0]);
+                    continue;
+                }
+                uint64_t widest = 0;
+                for (const ResolveArgs &ra : b) widest = std::max<uint64_t>(widest, ra.n_elems);
+                // (grid.y <= 65535: a round holds at most a few thousand frames' groups per batch; more are cut into several launches)
+                for (size_t g0 = 0; g0 < b.size(); g0 += 32768) {
+                    const size_t ng = std::min<size_t>(32768, b.size() - g0);
+                    hipLaunchKernelGGL(k_zst_resolve_many, dim3((uint32_t)((widest + 1023) / 1024), (uint32_t)ng), dim3(256), 0, st, d_args + at + g0);
+                }
+                at += b.size();
             }
         }
         hipLaunchKernelGGL(k_zst_xxh64, dim3(nf < 16384 ? nf : 16384), dim3(64), 0, st, (const uint8_t *)out_bytes, (const Frame *)C.d_frames.p, nf,
