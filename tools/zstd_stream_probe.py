@@ -11,7 +11,26 @@ from zstd_util import compress
 
 gb = float(os.environ.get("ZST_GB", "2"))
 n = int(gb * 1e9) // 332 * 332
-data = device.synth_fastq(n)[:n].cpu().numpy().tobytes()
+if os.environ.get("ZST_KIND") == "genome":
+    # reads sampled from a small genome (deep coverage: long matches far back, what a resequencing run looks like to an LZ coder)
+    # with qualities in runs — 332-byte records like exg_synth_fastq's, so that the row count is the same closed form
+    import numpy as np
+    rng = np.random.default_rng(3)
+    genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(float(os.environ.get("ZST_GENOME_MB", "2")) * 1e6))
+    n_rec = n // 332
+    rec = np.empty((n_rec, 332), dtype=np.uint8)
+    rec[:] = np.frombuffer(b"@" + b"G" * 26 + b"\n" + b"A" * 150 + b"\n+\n" + b"I" * 150 + b"\n", dtype=np.uint8)
+    ids = np.char.zfill(np.arange(n_rec).astype("U12"), 12)
+    rec[:, 1:13] = np.frombuffer("".join(ids).encode(), dtype=np.uint8).reshape(n_rec, 12)
+    rec[:, 13:27] = np.frombuffer(b" 1:N:0:ACGTACG", dtype=np.uint8)
+    pos = rng.integers(0, len(genome) - 150, n_rec)
+    rec[:, 28:178] = genome[pos[:, None] + np.arange(150)[None, :]]
+    q = np.repeat(rng.integers(35, 74, (n_rec, 15), dtype=np.uint8), 10, axis=1)
+    rec[:, 181:331] = q
+    data = rec.tobytes()
+    del rec, q, pos, ids
+else:
+    data = device.synth_fastq(n)[:n].cpu().numpy().tobytes()
 t0 = time.time()
 frame_mb = float(os.environ.get("ZST_FRAME_MB", "0"))   # (fractions: ZST_FRAME_MB=0.0625 = frames of 64 KiB)
 level, wlog = int(os.environ.get("ZST_LEVEL", "3")), int(os.environ.get("ZST_WLOG", "0"))
