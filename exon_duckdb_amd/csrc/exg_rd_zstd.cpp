@@ -352,6 +352,7 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
         }
     } pins[3];
     size_t d_comp_caps[3] = {0, 0, 0}, d_hist_cap = 4096;
+    uint64_t ramp_second = ~0ull;  // the block the second round begins with (plan)
     // where a round that begins with block b ends, and which file bytes it needs
     auto plan = [&](uint64_t from, uint64_t *to, uint64_t *lo, uint64_t *hi) {
         // The first round is a quarter of the size (never more than a round, never below 16 MiB of one) when rounds overlap and
@@ -359,7 +360,9 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
         // ~25 ms instead of ~60 (223-262 against 247-284 ms on a 4 GB frame; nothing without a checksum: 121-127 against 126 ms).
         static const uint64_t first_div_env = getenv("EXG_ZSTD_FIRST_ROUND_DIV") ? std::max<uint64_t>(1, strtoull(getenv("EXG_ZSTD_FIRST_ROUND_DIV"), nullptr, 10)) : 0;
         const uint64_t first_div = first_div_env ? first_div_env : (!idx.frames.empty() && idx.frames[idx.blocks[from].frame].has_checksum ? 4 : 1);
-        const uint64_t want_out = from == b_first && read_ahead_ ? std::min<uint64_t>(target_, std::max<uint64_t>(target_ / first_div, 16u << 20)) : target_;
+        // (and the second round half: a whole round behind the quarter left the hasher idle for ~14 ms of a 4 GB frame's time)
+        const uint64_t div = !read_ahead_ ? 1 : from == b_first ? first_div : from == ramp_second && first_div > 1 ? first_div / 2 : 1;
+        const uint64_t want_out = std::min<uint64_t>(target_, std::max<uint64_t>(target_ / std::max<uint64_t>(div, 1), 16u << 20));
         uint64_t b1 = from, est = 0;
         while (b1 < n_blocks && (b1 == from || est < want_out)) {
             if (b1 > from && (b1 == b_mark[0] || b1 == b_mark[1])) break;
@@ -368,6 +371,7 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
             b1++;
             if (b1 - from >= 0x7FFFFF00u) break;
         }
+        if (from == b_first) ramp_second = b1;
         *to = b1;
         *lo = idx.blocks[from].src_off & ~15ull;
         const zst::Block &BL = idx.blocks[b1 - 1];
