@@ -737,6 +737,12 @@ def main():
         else:
             dist.init_process_group(args.backend)
     lib = load_library()
+    # what the collective layer itself says it is (not what the command line asked for): the backend's name and the number
+    # of ranks in the process group that ran the all_gather / all_reduce of this line
+    coll = ({"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rccl": args.backend == "nccl",
+             "distinct_devices": not args.single_device} if world > 1 else {"backend": None, "world_size": 1})
+    if world > 1:
+        assert dist.get_world_size() == args.gpus
 
     from exon_duckdb_amd import sharding
 
@@ -854,6 +860,7 @@ def main():
             "value": total_records * L * args.steps / dt,
             "unit": "records/s",
             "n_gpus": world,
+            "collectives": coll,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,

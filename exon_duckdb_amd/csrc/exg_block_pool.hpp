@@ -7,7 +7,9 @@
 // exg_rd_fanout.hpp, or a table function whose scan threads claim shards) a block first used by a reader on socket 0 must
 // not be handed to a reader on socket 1: its DMA and its pread copies would cross the socket link for as long as the
 // block lives.  So the free list is searched only among the blocks of the taker's node, and the pool's cap follows the
-// number of devices in use (a reader holds two upload slots and the column blocks of the batches in flight: ~1.5 GiB).
+// number of devices IN USE — the distinct devices that were current on a thread that took a block, counted as they appear
+// (a reader holds two upload slots and the column blocks of the batches in flight: ~1.5 GiB); a process that reads on one
+// device of an 8-GPU node keeps 6 GiB, not 48.  A block whose node is unknown (sysfs says -1, or no hook) counts as node 0.
 //
 // No HIP in this header: allocation, release and "which node is this thread's device on" are hooks, so that the host-only
 // sanitizer driver (tests/host_asan_driver.cpp) runs the bookkeeping over malloc / free.
@@ -27,9 +29,9 @@ struct BlockPool {
         void *(*alloc)(size_t) = nullptr;   // pinned allocation near the calling thread's current device; NULL on failure
         void (*release)(void *) = nullptr;
         int (*current_node)() = nullptr;    // NUMA node of the calling thread's current device (>= 0; 0 when unknown)
-        int (*n_devices)() = nullptr;       // devices visible to the process
+        int (*current_device)() = nullptr;  // the calling thread's current device (>= 0; 0 when unknown)
     };
-    static constexpr size_t kPerDevice = 6ull << 30;  // pooled bytes kept per visible device (all nodes together: x n_devices)
+    static constexpr size_t kPerDevice = 6ull << 30;  // pooled bytes kept per device that has taken a block (all nodes together)
 
     explicit BlockPool(Hooks h, size_t cap_override = 0) : hooks(h), cap_override_(cap_override) {}
     BlockPool(const BlockPool &) = delete;
@@ -42,8 +44,10 @@ struct BlockPool {
     char *take(size_t *sz) {
         *sz = size_class(*sz);
         const int node = hooks.current_node ? std::max(0, hooks.current_node()) : 0;
+        const int dev = hooks.current_device ? std::min(63, std::max(0, hooks.current_device())) : 0;
         {
             std::lock_guard<std::mutex> g(mu);
+            devices_seen_ |= 1ull << dev;
             size_t best = free_blocks.size();
             for (size_t i = 0; i < free_blocks.size(); i++) {
                 const Free &f = free_blocks[i];
@@ -96,8 +100,11 @@ struct BlockPool {
     }
     size_t cap() const {  // (mu held, or a racy read for reporting)
         if (cap_override_) return cap_override_;
-        const int n = hooks.n_devices ? std::max(1, hooks.n_devices()) : 1;
-        return kPerDevice * (size_t)n;
+        return kPerDevice * (size_t)std::max(1, __builtin_popcountll(devices_seen_));
+    }
+    int devices_in_use() {
+        std::lock_guard<std::mutex> g(mu);
+        return __builtin_popcountll(devices_seen_);
     }
     // (reporting / tests)
     size_t pooled() {
@@ -128,6 +135,7 @@ private:
     std::unordered_map<char *, int> node_of;  // every live block made by this pool -> the node of its pages
     size_t pooled_bytes = 0;
     size_t cap_override_ = 0;
+    unsigned long long devices_seen_ = 0;  // bit d: a thread with device d current has taken a block
 };
 
 }  // namespace exg_rd

@@ -190,13 +190,14 @@ private:
                         hipEvent_t hev[2] = {nullptr, nullptr};
                         char *hpin[2] = {nullptr, nullptr};
                         size_t hcap[2] = {kPiece + 64, kPiece + 64};
+                        // (a helper that cannot get its stream, events or pinned blocks is no helper: it claims nothing, and what the
+                        // helpers leave is hashed by this stage's own thread below — only a copy that really fails fails the job)
                         bool up = stream_pool()->take(device_, &hst) == hipSuccess;
                         for (int i = 0; i < 2 && up; i++)
                             up = hipEventCreateWithFlags(&hev[i], hipEventDisableTiming) == hipSuccess && (hpin[i] = global_pool()->take(&hcap[i])) != nullptr;
                         exg::Xxh64 h;
                         for (size_t k; up && (k = next.fetch_add(1)) < whole.size();)
-                            if (!hash_part(job.parts[whole[k]], hst, hpin, hev, h, bad_frame)) up = false;
-                        if (!up) helpers_ok.store(false);
+                            if (!hash_part(job.parts[whole[k]], hst, hpin, hev, h, bad_frame)) up = false, helpers_ok.store(false);
                         if (hst && hipStreamSynchronize(hst) != hipSuccess) (void)hipGetLastError();
                         for (int i = 0; i < 2; i++) {
                             if (hpin[i]) global_pool()->give(hpin[i], hcap[i]);
@@ -209,6 +210,13 @@ private:
                 if (!helpers.empty() && job.parts[i].begins && job.parts[i].ends) continue;
                 ok = hash_part(job.parts[i], st, pin, ev, h_, bad_frame);
                 if (!ok) fail("copying a zstd frame back for its checksum failed");
+            }
+            if (!helpers.empty()) {  // the whole frames the helpers have not claimed (all of them when no helper came up)
+                exg::Xxh64 h;        // (h_ carries the frame that goes on into the next segment)
+                for (size_t k; ok && helpers_ok.load() && (k = next.fetch_add(1)) < whole.size();) {
+                    ok = hash_part(job.parts[whole[k]], st, pin, ev, h, bad_frame);
+                    if (!ok) fail("copying a zstd frame back for its checksum failed");
+                }
             }
             for (auto &t : helpers) t.join();
             if (ok && !helpers_ok.load()) {
@@ -383,11 +391,18 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
         int slot = 0;
         bool ok = false, hip_failed = false;
         hipEvent_t ev = nullptr;
+        hipStream_t io = nullptr;  // the stream the helper's H2D slices were enqueued on (pread_parallel only enqueues them)
+        // Whatever way run() is left — the consumer closed early (a LIMIT query), a cancelled sink, an error — a window may
+        // still be travelling: its pinned block and its device window are locals declared in front of this one, i.e. released
+        // to the process-wide pools AFTER this destructor.  The copies have to be over by then, or another reader of the same
+        // device takes a block that a DMA is still reading from / writing to (advisor, round 4).
         ~Ahead() {
             if (th.joinable()) th.join();
+            if (io) (void)hipStreamSynchronize(io);
             if (ev) (void)hipEventDestroy(ev);
         }
     } ahead;
+    ahead.io = st_io;
     if (read_ahead_ && hipEventCreateWithFlags(&ahead.ev, hipEventDisableTiming) != hipSuccess) read_ahead_ = false;
     auto ensure_window = [&](int slot, uint64_t comp_len) -> bool {
         if (kSide + comp_len + 64 > d_comp_caps[slot]) {

@@ -67,10 +67,10 @@ inline std::shared_ptr<BlockPool> global_pool() {
             if (hipGetDevice(&dev) != hipSuccess) return 0;
             return numa_node_of_device(dev);
         };
-        h.n_devices = [] {
-            int n = 0;
-            if (hipGetDeviceCount(&n) != hipSuccess) n = 1;
-            return n;
+        h.current_device = [] {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess) return 0;
+            return dev;
         };
         const char *e = getenv("EXG_PINNED_POOL_MB");
         return new std::shared_ptr<BlockPool>(std::make_shared<BlockPool>(h, e ? ((size_t)std::max(0, atoi(e)) << 20) : 0));

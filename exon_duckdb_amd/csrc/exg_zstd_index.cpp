@@ -25,17 +25,23 @@ static bool fail(Index &idx, const char *what, uint64_t at) {
     return false;
 }
 
-// S.get(off, len): the stream's bytes [off, off + len) (the caller has checked that they exist), valid until the next get
+// S.get(off, len): the stream's bytes [off, off + len) (the caller has checked that they exist), valid until the next get.
+// S.failed(): a get could not bring its bytes (a file that shrank behind its fstat, an I/O error): the walk STOPS there — what a
+// failed get returns are zeros, and a zero block header is a valid empty raw block that is not the last one: a walk that went on
+// would push one Block per three bytes of the remaining file, a failing pread each (advisor, round 4: hundreds of millions of
+// syscalls and tens of GB of host memory on a multi-GB file).  Nothing read behind the failure enters the index.
 template <class S>
-static bool build_index_from(S &src, uint64_t n, Index &idx) {
-    static const char *kSrcSize = "Src size is incorrect", *kCorrupt = "Data corruption detected";
+static bool build_index_walk(S &src, uint64_t n, Index &idx) {
+    static const char *kSrcSize = "Src size is incorrect", *kCorrupt = "Data corruption detected", *kIo = "short read while walking the zstd block headers";
     uint64_t pos = 0;
     while (pos < n) {
         if (n - pos < 4) return fail(idx, kSrcSize, pos);
         const uint32_t magic = rd32(src.get(pos, 4));
+        if (src.failed()) return fail(idx, kIo, pos);
         if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {  // skippable frame (3.1.2)
             if (n - pos < 8) return fail(idx, kSrcSize, pos);
             const uint64_t sz = rd32(src.get(pos + 4, 4));
+            if (src.failed()) return fail(idx, kIo, pos);
             if (n - pos - 8 < sz) return fail(idx, kSrcSize, pos);
             pos += 8 + sz;
             continue;
@@ -78,6 +84,7 @@ static bool build_index_from(S &src, uint64_t n, Index &idx) {
             fr.content_size = v;
             pos += fcs_bytes;
         }
+        if (src.failed()) return fail(idx, kIo, frame_at);
         if (single) fr.window = fr.content_size;
         if (fr.window > kWindowMax) return fail(idx, "Frame requires too much memory for decoding", frame_at);
         fr.first_block = (uint32_t)idx.blocks.size();
@@ -88,6 +95,7 @@ static bool build_index_from(S &src, uint64_t n, Index &idx) {
         for (;;) {
             if (n - pos < 3) return fail(idx, kSrcSize, pos);
             const uint32_t bh = rd24(src.get(pos, 3));
+            if (src.failed()) return fail(idx, kIo, pos);
             pos += 3;
             const int last = bh & 1, type = (bh >> 1) & 3;
             const uint32_t bsize = bh >> 3;
@@ -186,6 +194,7 @@ static bool build_index_from(S &src, uint64_t n, Index &idx) {
                 idx.n_seq += nseq;
                 pos += bsize;
             }
+            if (src.failed()) return fail(idx, kIo, b.src_off);  // (its literals / sequences header did not come: not a block of the index)
             idx.blocks.push_back(b);
             if (last) break;
         }
@@ -193,6 +202,7 @@ static bool build_index_from(S &src, uint64_t n, Index &idx) {
         if (fr.has_checksum) {
             if (n - pos < 4) return fail(idx, kSrcSize, pos);
             fr.checksum = rd32(src.get(pos, 4));
+            if (src.failed()) return fail(idx, kIo, pos);
             pos += 4;
         }
         idx.frames.push_back(fr);
@@ -201,10 +211,22 @@ static bool build_index_from(S &src, uint64_t n, Index &idx) {
     return true;
 }
 
+// (a get that failed hands out zeros until the walk's next failed() check: whatever the zeros made the walk say, the error is the read's)
+template <class S>
+static bool build_index_from(S &src, uint64_t n, Index &idx) {
+    const bool good = build_index_walk(src, n, idx);
+    if (src.failed()) {
+        idx.error = "short read while walking the zstd block headers";
+        return false;
+    }
+    return good;
+}
+
 namespace {
 struct MemSrc {
     const uint8_t *data;
     const uint8_t *get(uint64_t off, uint32_t) const { return data + off; }
+    bool failed() const { return false; }
 };
 // the same walk over a file: two small reads per block (its header with the literals header behind it, its sequences
 // header) and nothing mapped — a 2 GB mapping costs 20 ms of page faults on eight threads to walk and 49 ms to unmap
@@ -215,6 +237,7 @@ struct FdSrc {
     uint64_t at = ~0ull;
     uint32_t have = 0;
     bool io_error = false;
+    bool failed() const { return io_error; }
     const uint8_t *get(uint64_t off, uint32_t len) {
         if (at != ~0ull && off >= at && off + len <= at + have) return buf + (off - at);
         const uint32_t want = (uint32_t)std::min<uint64_t>(sizeof buf, n - off);
@@ -227,7 +250,7 @@ struct FdSrc {
             }
             got += (uint32_t)k;
         }
-        if (got < len) {  // (the file shrank, or an I/O error: zeros make the walk fail on its own checks or end early)
+        if (got < len) {  // (the file shrank, or an I/O error: the walk asks failed() behind every get and stops; zeros until then)
             io_error = true;
             memset(buf + got, 0, sizeof buf - got);
             got = len;
@@ -273,6 +296,7 @@ struct PrefetchedSrc {
     FdSrc fallback;
     const std::vector<Snip> *hdr, *seq;  // ascending offsets
     size_t ih = 0, is = 0;
+    bool failed() const { return fallback.io_error; }
     const uint8_t *get(uint64_t off, uint32_t len) {
         while (ih < hdr->size() && (*hdr)[ih].off + 16 <= off) ih++;
         if (ih < hdr->size() && (*hdr)[ih].off <= off && off + len <= (*hdr)[ih].off + 16) return (*hdr)[ih].b + (off - (*hdr)[ih].off);
@@ -371,12 +395,9 @@ bool build_index_fd(int fd, uint64_t n, Index &idx) {
     src.fallback.n = n;
     src.hdr = &hdr;
     src.seq = &seq;
-    const bool good = build_index_from(src, n, idx);
-    if (src.fallback.io_error) {
-        idx.error = "short read while walking the zstd block headers";
-        return false;
-    }
-    return good;
+    // (a failed read ends the walk where it happened — build_index_from — with the blocks in front of it in the index: the caller
+    // salvages them, the rows in front of the damage come first)
+    return build_index_from(src, n, idx);
 }
 
 bool salvage_index(Index &idx) {

@@ -351,3 +351,74 @@ def test_config2_full_size_properties(gpu):
         pref = (col[idx, 0] >> 32) & 0xFFFFFFFF
         got = sum(flat[332 * idx + off + j].to(torch.int64) << (8 * j) for j in range(4))
         assert bool((pref == got).all())
+
+
+def _newlines_in(lo, hi):
+    """'\\n' bytes of the synthetic FASTQ-150 file in [lo, hi): a record has them at offsets 27, 178, 180 and 331"""
+    def upto(x):   # newlines in [0, x)
+        q, r = divmod(x, 332)
+        return 4 * q + sum(1 for o in (27, 178, 180, 331) if o < r)
+    return upto(hi) - upto(lo)
+
+
+@pytest.mark.parametrize("rank", [3, 7])
+def test_config5_shard_full_size_properties(gpu, rank):
+    """BASELINE.json configs[4] as ONE of its eight GPUs sees it: shard `rank` of plan_shards(100 GB, 8) —
+    12.5 GB generated in HBM at its file offset, cut at 16-byte (NOT record) boundaries, a 1 KiB halo in front as `lead`,
+    no BOF (and no EOF for the middle shard 3; shard 7 is the file's last), the 4-line phase guessed from the shard's own
+    bytes by exg_fastq_guess_phase exactly as bench.py --gpus 8 does it.  Checked through the closed forms of
+    test_config2_full_size_properties: the shard owns the records whose last line ENDS in it, rows in file order."""
+    import ctypes as C
+
+    import torch
+    from exon_duckdb_amd import device, load_library, sharding
+
+    lib = load_library()
+    file_bytes = int(8 * 12.5e9) // 332 * 332
+    assert file_bytes // 332 == 301_204_819          # config 5: 100 GB of 332-byte records
+    sh = sharding.plan_shards(file_bytes, 8, halo=1024)[rank]
+    assert sh.halo == 1024 and not sh.is_first and sh.start % 332 != 0 and sh.is_last == (rank == 7)
+    n_bytes = sh.n_bytes
+    d_in = device.synth_fastq(n_bytes, file_offset=sh.load_offset)
+    first = sh.start // 332                           # the record that holds byte `start` ends at or behind it
+    n_rec = sh.end // 332 - first                     # ... and the one that straddles `end` is the next shard's
+    scan = device.FastqScan(n_bytes, capacity_records=n_rec + 16)
+    ph = torch.zeros(1, dtype=torch.int32, device="cuda")
+    device.check(lib.exg_fastq_guess_phase(C.c_void_p(d_in.data_ptr()), n_bytes, sh.halo, C.c_void_p(ph.data_ptr()), device.stream_ptr()))
+    guess = int(ph.item()) & 0xFFFFFFFF
+    assert guess < 4
+    prev_is_nl = bool(int(d_in[sh.halo - 1].item()) == 10)
+    fli = guess if prev_is_nl else (guess - 1) % 4
+    # the exact line index of the line that holds the shard's first byte, from the generator's geometry
+    assert fli == _newlines_in(0, sh.start) % 4
+    flags = abi.EXG_F_EOF if sh.is_last else 0
+    base = BASE + sh.load_offset
+    for algo in (abi.EXG_ALGO_FUSED, abi.EXG_ALGO_FUSED_FULL):
+        scan.launch(d_in, n_bytes=n_bytes, lead=sh.halo, first_line_index=fli, payload_base=base, flags=flags, algo=algo)
+        res = scan.fetch()
+        assert res.error_code == 0 and not (res.flags & (abi.EXG_RF_FALLBACK | abi.EXG_RF_HEAD_UNRESOLVED)), (res.error_code, res.flags)
+        assert res.n_records == n_rec, (res.n_records, n_rec)
+        assert res.n_lines == _newlines_in(sh.start, sh.end)
+        k = first + torch.arange(n_rec, device="cuda", dtype=torch.int64)
+        for col, (off, ln) in zip(scan.cols, [(1, 15), (17, 10), (28, 150), (181, 150)]):
+            c = col[:n_rec]
+            assert bool(((c[:, 0] & 0xFFFFFFFF) == ln).all())
+            if ln > 12:
+                assert bool((c[:, 1] == BASE + 332 * k + off).all())
+        first_digit = (k // 10 ** 11) % 10
+        want_prefix = 0x53 | (0x59 << 8) | (0x4E << 16) | ((0x30 + first_digit) << 24)
+        assert bool((((scan.cols[0][:n_rec, 0] >> 32) & 0xFFFFFFFF) == want_prefix).all())
+        want_desc = (0x30 + (k & 3)) | (0x3A << 8) | (0x4E << 16) | (0x3A << 24)
+        assert bool((((scan.cols[1][:n_rec, 0] >> 32) & 0xFFFFFFFF) == want_desc).all())
+        # the inlined description's remaining bytes: "0:ACGT" + two zero bytes (bytes 8..15 of the string_t)
+        assert bool((scan.cols[1][:n_rec, 1] == int.from_bytes(b"0:ACGT\0\0", "little")).all())
+        assert bool((scan.validity[: (n_rec + 63) // 64 - 1] == -1).all())
+        flat = d_in[:n_bytes].view(torch.uint8)
+        idx = torch.randint(0, n_rec, (1 << 20,), device="cuda", dtype=torch.int64)
+        for col, off in ((scan.cols[2], 28), (scan.cols[3], 181)):
+            pref = (col[idx, 0] >> 32) & 0xFFFFFFFF
+            got = sum(flat[332 * (first + idx) - sh.load_offset + off + j].to(torch.int64) << (8 * j) for j in range(4))
+            assert bool((pref == got).all())
+        del k, first_digit, want_prefix, want_desc, idx
+    # the eight shards' row counts add up to the file's
+    assert sum(s.end // 332 - (0 if s.is_first else s.start // 332) for s in sharding.plan_shards(file_bytes, 8, halo=1024)) == file_bytes // 332

@@ -321,6 +321,32 @@ def test_bench_launches_its_own_ranks(gpu):
     assert rs.get("verified") is True and len(rs["rows_per_shard"]) == 2 and "digest" in rs["verification"], rs
 
 
+def test_bench_eight_ranks_on_one_gpu(gpu):
+    """BASELINE config 5's process layout on a one-GPU box: `python3 bench.py --gpus 8` with no launcher starts EIGHT ranks (eight
+    processes' pinned / device pools and ports on one box), each scans its byte-range shard of the 8-shard file (middle shards:
+    halo, no BOF / EOF, guessed phase), the 8-way all_gather verifies the phases, the all_reduce gives COUNT(*), and the
+    reader-level leg has eight readers of ONE shared file whose digests must add up to the generator's.  gloo + --single-device:
+    the collectives' world size is printed in the line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--backend", "gloo", "--single-device", "--steps", "2",
+           "--warmup", "1", "--launches-per-step", "2", "--gb", "0.25", "--e2e-gb", "0.1"]
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=840)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["verified"] is True and j["scaling"] == "weak"
+    assert j["collectives"]["world_size"] == 8 and j["collectives"]["backend"] == "gloo"
+    assert j["config"]["file_bytes"] == int(8 * 0.25e9) // 332 * 332
+    rs = j["reader_sharded"]
+    assert rs.get("verified") is True and len(rs["rows_per_shard"]) == 8 and sum(rs["rows_per_shard"]) * 332 == rs["algorithmic_bytes"], rs
+
+
 def test_rccl_initialises_and_reduces_on_this_image(gpu):
     """bench.py's N > 1 collectives run over RCCL (torch's "nccl" backend).  A one-GPU box cannot run two ranks on it, but it
     can prove that the library loads, a communicator comes up and the three collectives the bench uses complete on the device."""

@@ -95,6 +95,47 @@ def test_close_in_the_middle_of_overlapped_zstd_rounds(gpu, fastq_mid, tmp_path,
         r.close()
 
 
+@pytest.mark.timeout(300)
+def test_early_close_of_a_zstd_reader_beside_another_reader_of_the_device(gpu, fastq_mid, tmp_path, monkeypatch):
+    """advisor, round 4: a multi-round .zst reader that is closed after its first batch may have a read-ahead window travelling
+    on its I/O stream; its pinned block and device window go back to the process-wide pools when the producer unwinds.  A second
+    reader of the same device takes blocks from those pools all the time: had a DMA still been reading / writing a returned
+    block, that reader's rows would be damaged.  Many early closes beside a reader that is digested again and again."""
+    import threading
+    from exon_duckdb_amd.reader import ShardReader
+    from exon_duckdb_amd.table_function import Chunk
+    import ctypes as C
+    data, want = fastq_mid
+    _files(tmp_path, data)
+    monkeypatch.delenv("EXG_DEVICE_MEM_CAP_MB", raising=False)
+    monkeypatch.setenv("EXG_DEVICE_BATCH_BYTES", str(2 << 20))
+    p = str(tmp_path / "c.fastq.zst")
+    bad, stop = [], threading.Event()
+
+    def other():
+        while not stop.is_set():
+            for name in ("c.fastq.zst", "a.fastq.gz"):
+                r = ShardReader(str(tmp_path / name), "fastq")
+                if r.digest() != want:
+                    bad.append(name)
+                r.close()
+
+    th = threading.Thread(target=other)
+    th.start()
+    try:
+        for it in range(40):
+            r = ShardReader(p, "fastq")
+            for _ in range(1 + it % 3):
+                ch = Chunk()
+                assert r._l.exg_next_chunk(r._r, C.byref(ch)) == 0 and ch.n_rows > 0
+                r._l.exg_release_chunk(r._r, C.byref(ch))
+            r.close()
+    finally:
+        stop.set()
+        th.join()
+    assert not bad, bad
+
+
 def _expect_error(path, fmt, min_rows_before, compression=None, **kw):
     """reads to the error: returns (rows delivered before it, message)"""
     import ctypes as C

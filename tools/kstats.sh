@@ -2,6 +2,8 @@
 # per-kernel time of a command over library builds inside ONE box: tools/kstats.sh <tag> "<command>" a.so b.so ...
 TAG=$1; CMD=$2; shift 2
 ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
+# the program itself must follow `--` (no env / bash -c / taskset / *.py run directly: _profcmd.sh says why); relative script paths are resolved against the repo root
+. "$ROOT/tools/_profcmd.sh"; profcmd_check "$CMD" || exit 2; CMD=$(profcmd_abs "$ROOT" "$CMD")
 for lib in "$@"; do
   cp exon_duckdb_amd/lib/$lib exon_duckdb_amd/lib/libexon_gpu.so
   d=$OUT/${TAG}_kt_${lib%.so}; rm -rf $d

@@ -4,6 +4,8 @@
 # Counter passes are separate rocprofv3 runs with --kernel-trace only (MI355X_MICROARCH.md: never with other trace domains).
 TAG=$1; KERNEL=$2; CMD=$3; shift 3
 ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
+# the program itself must follow `--` (no env / bash -c / taskset / *.py run directly: _profcmd.sh says why); relative script paths are resolved against the repo root
+. "$ROOT/tools/_profcmd.sh"; profcmd_check "$CMD" || exit 2; CMD=$(profcmd_abs "$ROOT" "$CMD")
 SETS=${PMC_SETS:-"SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY|SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY|SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH|SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM"}
 for lib in "$@"; do
   cp exon_duckdb_amd/lib/$lib exon_duckdb_amd/lib/libexon_gpu.so
