@@ -71,6 +71,64 @@ def cpu_baseline(seconds_target=12.0):
     }
 
 
+def measure_traffic_in_run(n_bytes_expected, timeout_s=240):
+    """roofline.traffic measured IN this run: the HBM bytes one launch of the headline kernel moves, from the FETCH_SIZE and
+    WRITE_SIZE counters — two `rocprofv3 --kernel-trace --pmc <counter>` passes (separate passes, no other trace domain:
+    MI355X_MICROARCH.md's HBM / rocprofv3 section) over a CHILD `python3 bench.py` with a few launches of the same 10 GB
+    workload, started before this process imports torch or touches the GPU.  FETCH_SIZE / WRITE_SIZE are reported in KiB; on
+    gfx950 FETCH_SIZE counts half the bytes of wide coalesced streaming reads (the guide's correction): doubled.
+    -> dict or None (no rocprofv3, a profiler already around this process, a pass that failed or ran out of time)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not prof or os.environ.get("EXG_BENCH_NO_TRAFFIC"):
+        return None
+    if any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None   # this process is being profiled itself
+    kernel = "k_fused<exg::FastqFormat, 0>"
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="exg_pmc_", dir="/tmp")
+    t0 = time.perf_counter()
+    try:
+        env = dict(os.environ, TMPDIR="/tmp", EXG_BENCH_NO_TRAFFIC="1")
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, c)
+            cmd = [prof, "--kernel-trace", "--pmc", c, "-d", d, "-o", "pmc", "--output-format", "csv", "--",
+                   "python3", os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--launches-per-step", "2", "--no-configs", "--no-cpu-baseline"]
+            left = timeout_s - (time.perf_counter() - t0)
+            if left < 30:
+                return None
+            res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=left)
+            if res.returncode != 0:
+                return None
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        if kernel in r["Kernel_Name"] and r["Counter_Name"] == c:
+                            vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return None
+            out[c] = (sum(vals) / len(vals) * 1024.0, len(vals))
+            # the child's line says which workload its launches ran on
+            for ln in res.stdout.splitlines():
+                if ln.startswith("{"):
+                    out["n_bytes"] = json.loads(ln)["config"]["bytes_per_gpu"]
+    except Exception:  # noqa: BLE001 (timeout, a box without counters, ...)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    if out.get("n_bytes") != n_bytes_expected:
+        return None
+    rd, wr = out["FETCH_SIZE"][0] * 2.0, out["WRITE_SIZE"][0]
+    return {"traffic": rd + wr, "read_bytes": rd, "write_bytes": wr, "dispatches": out["FETCH_SIZE"][1], "seconds": time.perf_counter() - t0,
+            "source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, two passes over a child `python3 bench.py "
+                      "--steps 1 --warmup 1 --launches-per-step 2 --no-configs` started before the timed run (KiB x 1024; FETCH_SIZE x 2: gfx950 correction); "
+                      f"average of {out['FETCH_SIZE'][1]} dispatches of {kernel}"}
+
+
 def verify_fastq(torch, scan, n_rec, base, first_record):
     """The columns the last launch left in HBM against the generator's closed forms, every row: record r of this buffer
     is global record k = first_record + r of the synthetic file; its four string_t hold the field lengths 15 / 10 / 150 /
@@ -554,6 +612,32 @@ def run_configs(torch, lib, args):
                                     "must equal the generator's",
                     "verified": bool(all(v["verified"] for v in res.values()))}
 
+        def arrow_leg(p_fq, want):
+            """The reference's OWN boundary (boundary A: exon/include/rust.hpp:41-46): new_reader(&stream, uri, 2048, NULL, "fastq",
+            NULL) -> an Arrow C stream whose record batches (Utf8 columns: int32 offsets + value bytes, built on the device and
+            copied back) a C loop pulls through get_next and releases — what the reference's unchanged glue (module.cpp:228-294)
+            would consume.  Timed without touching the values; an untimed pass folds every row into the generator's digest."""
+            def drain(with_digest):
+                rows, batches, dg = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+                err = C.create_string_buffer(512)
+                t0 = time.perf_counter()
+                rc = tl.exon_tf_drain_arrow_fastq(p_fq.encode(), None, None, with_digest, C.byref(rows), C.byref(batches), C.byref(dg), err, 512)
+                dt = time.perf_counter() - t0
+                assert rc == 0, err.value.decode("utf-8", "replace")
+                return int(rows.value), int(batches.value), int(dg.value), dt
+            drain(0)
+            rows, batches, _, dt = min((drain(0) for _ in range(3)), key=lambda x: x[3])
+            v_rows, _, got, _ = drain(1)
+            # Arrow copies the VALUES back (the chunk boundary's strings point into the file's mapping): offsets + values + validity
+            d2h = rows * (4 * 4 + 15 + 10 + 150 + 150) + 4 * 4 * batches
+            return {"workload": f"new_reader (the reference's FFI, Arrow C stream): {n_e2e / 1e9:.1f} GB FASTQ-150 file in the page cache -> record batches of "
+                                f"2048 rows on the host, all four Utf8 columns, PCIe inclusive",
+                    "algorithmic_bytes": n_e2e, "ms": dt * 1e3, "GB/s": n_e2e / dt / 1e9, "records_per_s": rows / dt, "record_batches": batches,
+                    "d2h_bytes": d2h, "frac": None,
+                    "verification": "an untimed pass folds every row of every record batch (int32 offsets, value bytes, the description's validity "
+                                    "bitmap) into a digest that must equal the generator's for these rows",
+                    "verified": bool(rows == v_rows == n_e2e // REC and got == want)}
+
         def files():
             # ---- end to end: FASTQ file in the page cache -> host DataChunks (PCIe inclusive) -------------------------------
             p_fq = os.path.join(tmp, "e2e.fastq")
@@ -576,6 +660,10 @@ def run_configs(torch, lib, args):
                 "verification": "an untimed pass folds every row of every chunk (each string_t dereferenced: length, prefix, pointer, payload "
                                 "bytes) into a digest that must equal the generator's for these rows",
                 "verified": bool(rows == n == v_rows == n_e2e // REC and chunks >= (rows + 2047) // 2048 and got == want and bad == 0)}
+            try:
+                out["end_to_end_arrow"] = arrow_leg(p_fq, want)
+            except Exception as e:  # noqa: BLE001
+                out["end_to_end_arrow"] = {"error": f"{type(e).__name__}: {e}"}
             try:
                 out["end_to_end_zstd"] = zstd_leg(p_fq, want)
             except Exception as e:  # noqa: BLE001
@@ -693,6 +781,7 @@ def main():
                     "scan alone (what a reader switches to on long / very short reads); 0 = fused + the gated general-path launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the configs / end_to_end legs")
+    ap.add_argument("--no-traffic", action="store_true", help="do not measure roofline.traffic in this run (two rocprofv3 --pmc passes over a child, ~40 s)")
     ap.add_argument("--vcf-gb", type=float, default=5.0)
     ap.add_argument("--e2e-gb", type=float, default=4.0)
     ap.add_argument("--gz-gb", type=float, default=10.0, help="config 4: compressed GB asked for (BASELINE: 10; bounded by the scratch space and --gz-build-s)")
@@ -715,6 +804,12 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}: start it without a launcher (it launches {args.gpus} ranks "
               f"itself) or with --nproc-per-node {args.gpus}", file=sys.stderr)
         raise SystemExit(2)
+
+    # roofline.traffic, measured by two counter passes over a child of this script BEFORE this process touches the GPU
+    # (N = 1 at the headline size only; ~40 s; --no-traffic skips it and the line falls back to the committed counters)
+    traffic_run = None
+    if world_env == 1 and not args.no_traffic and args.gb is None and args.algo == 2:
+        traffic_run = measure_traffic_in_run(int(10.0 * 1e9) // REC * REC)
 
     import torch
     import torch.distributed as dist
@@ -849,12 +944,16 @@ def main():
         read_only = (n_bytes - halo) / (ro_ms * 1e-3) / 1e9
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_fastq_fused.json")
-        if os.path.exists(pmc):
+        if traffic_run:
+            traffic, traffic_src = traffic_run["traffic"], traffic_run["source"]
+        elif os.path.exists(pmc):
             with open(pmc) as f:
                 j = json.load(f)
             # (counters were taken on the 10 GB launch of config 2: only that launch is priced with them)
             traffic = j.get("hbm_bytes_per_launch_10GB") if abs(n_bytes - 9999999692) < 1e8 else None
-            traffic_src = "profiles/pmc_fastq_fused.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, gfx950 corrections; not re-measured in this run)"
+            age_h = (time.time() - os.path.getmtime(pmc)) / 3600.0
+            traffic_src = (f"profiles/pmc_fastq_fused.json, tag {j.get('tag')}, file {age_h:.1f} h old (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                           "command, gfx950 corrections; NOT re-measured in this run: --no-traffic, no rocprofv3, or the in-run passes failed)")
         out = {
             "metric": "FASTQ records/sec into DataChunks",
             "value": total_records * L * args.steps / dt,
@@ -890,6 +989,9 @@ def main():
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                "traffic_read_bytes": traffic_run["read_bytes"] if traffic_run else None,
+                "traffic_write_bytes": traffic_run["write_bytes"] if traffic_run else None,
+                "traffic_passes_s": traffic_run["seconds"] if traffic_run else None,
                 "kernel": "exg_fastq_scan launch (k_fused<FastqFormat> dominant)",
                 "algorithmic_bytes_per_launch": n_bytes,
                 "avg_launch_ms": avg_ms,
@@ -909,6 +1011,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 cfg = {"end_to_end": {"error": f"{type(e).__name__}: {e}"}, "error": f"{type(e).__name__}: {e}"}
             out["end_to_end"] = cfg.pop("end_to_end", None)
+            out["end_to_end_arrow"] = cfg.pop("end_to_end_arrow", None)
             out["configs"] = cfg
             try:
                 out["record_shapes"] = run_record_shapes(torch, lib, args)

@@ -18,6 +18,7 @@
 #define DUCKDB_EXTENSION_MAIN
 #include "duckdb.hpp"
 #include "duckdb/common/types/vector_buffer.hpp"
+#include "duckdb/function/scalar_function.hpp"
 #include "duckdb/function/table_function.hpp"
 #include "duckdb/main/extension_util.hpp"
 #include "duckdb/parser/expression/constant_expression.hpp"
@@ -26,6 +27,7 @@
 #include "duckdb/planner/filter/conjunction_filter.hpp"
 #include "duckdb/planner/filter/constant_filter.hpp"
 #include "duckdb/planner/table_filter.hpp"
+#include "duckdb/storage/statistics/node_statistics.hpp"
 
 #include "exon_table_function.hpp"
 
@@ -184,11 +186,18 @@ static idx_t GetBatchIndex(ClientContext &, const FunctionData *, LocalTableFunc
 	return TF::BatchIndex(ls->Cast<TF::LocalState>());
 }
 
+// module.cpp:307 (there: ArrowTableFunction::ArrowScanCardinality = a NodeStatistics without an estimate)
+static unique_ptr<NodeStatistics> Cardinality(ClientContext &, const FunctionData *bind_data) {
+	const idx_t rows = TF::EstimatedCardinality(bind_data->Cast<TF::BindData>());
+	return rows ? make_uniq<NodeStatistics>(rows) : make_uniq<NodeStatistics>();
+}
+
 // module.cpp:296-318
 static void Register(const string &name, const string &file_type, DatabaseInstance &db) {
 	TableFunction scan(name, {LogicalType::VARCHAR}, Scan, FileTypeBind, InitGlobal, InitLocal);
 	scan.function_info = make_shared<WTArrowTableScanInfo>(file_type);
 	scan.named_parameters["compression"] = LogicalType::VARCHAR;
+	scan.cardinality = Cardinality;
 	scan.get_batch_index = GetBatchIndex;
 	scan.projection_pushdown = true;
 	scan.filter_pushdown = true; // like the reference (module.cpp:311); the predicate runs on the device
@@ -208,11 +217,49 @@ static unique_ptr<TableRef> ReplacementScan(ClientContext &, const string &table
 	return std::move(ref);
 }
 
+// fastq_functions/module.cpp:28-54: quality_score_string_to_list(VARCHAR) -> LIST(INTEGER), one value per byte, c - 33.
+// The reference goes through Value / SetValue per row; this writes the list entries and the child vector directly.  A NULL
+// string gives a NULL list (the reference's GetValue path has no defined answer for it: StringValue::Get of a NULL).
+static void QualityScoreStringToList(DataChunk &args, ExpressionState &, Vector &result) {
+	const idx_t count = args.size();
+	UnifiedVectorFormat in;
+	args.data[0].ToUnifiedFormat(count, in);
+	auto strings = reinterpret_cast<const string_t *>(in.data);
+	result.SetVectorType(VectorType::FLAT_VECTOR);
+	auto entries = FlatVector::GetData<list_entry_t>(result);
+	idx_t total = 0;
+	for (idx_t i = 0; i < count; i++) {
+		const idx_t k = in.sel->get_index(i);
+		total += in.validity.RowIsValid(k) ? strings[k].GetSize() : 0;
+	}
+	ListVector::Reserve(result, total);
+	auto values = FlatVector::GetData<int32_t>(ListVector::GetEntry(result));
+	idx_t at = 0;
+	for (idx_t i = 0; i < count; i++) {
+		const idx_t k = in.sel->get_index(i);
+		if (!in.validity.RowIsValid(k)) {
+			FlatVector::SetNull(result, i, true);
+			entries[i].offset = at;
+			entries[i].length = 0;
+			continue;
+		}
+		const idx_t n = strings[k].GetSize();
+		exon_scan::QualityScores(strings[k].GetData(), n, values + at);
+		entries[i].offset = at;
+		entries[i].length = n;
+		at += n;
+	}
+	ListVector::SetListSize(result, total);
+}
+
 // exon/src/exon_extension.cpp:25-96, restricted to the path
 static void LoadInternal(DatabaseInstance &db) {
 	for (const auto &reg : exon_scan::kRegistrations) {
 		Register(reg.name, reg.file_type, db);
 	}
+	// exon_extension.cpp:60 (FastqFunctions::GetQualityScoreStringToList)
+	ExtensionUtil::RegisterFunction(db, ScalarFunction("quality_score_string_to_list", {LogicalType::VARCHAR},
+	                                                   LogicalType::LIST(LogicalType::INTEGER), QualityScoreStringToList));
 	DBConfig::GetConfig(db).replacement_scans.emplace_back(ReplacementScan);
 }
 } // namespace exon

@@ -1,7 +1,7 @@
 """ctypes mirror of include/exon_gpu.h (keep in sync with the header; tests check sizes)."""
 import ctypes as C
 
-EXG_ABI_VERSION = 7
+EXG_ABI_VERSION = 8
 EXG_TYPE_VARCHAR, EXG_TYPE_BIGINT, EXG_TYPE_FLOAT, EXG_TYPE_INTEGER, EXG_TYPE_BOOLEAN, EXG_TYPE_LIST, EXG_TYPE_STRUCT = 1, 2, 3, 4, 5, 6, 7
 EXG_VECTOR_SIZE = 2048
 
@@ -171,7 +171,8 @@ SIGNATURES = {
 class ReaderStats(C.Structure):
     _fields_ = [("device_bytes_now", C.c_uint64), ("device_bytes_peak", C.c_uint64), ("device_mem_cap", C.c_uint64),
                 ("device_batch_bytes", C.c_uint64), ("device_batches", C.c_uint64), ("decoded_segments", C.c_uint64),
-                ("scan_algo", C.c_uint64), ("reserved", C.c_uint64 * 3)]
+                ("scan_algo", C.c_uint64), ("input_bytes", C.c_uint64), ("input_compression", C.c_uint64),
+                ("reserved", C.c_uint64 * 1)]
 
 # libexon_tf_test.so (csrc/testing/): test / bench scaffolding — synthetic inputs generated in HBM, consumers that drain a
 # reader's chunks (counting, or folding every row into a digest), host-only introspection, the host-pipeline probe
@@ -181,6 +182,8 @@ TEST_SIGNATURES = {
     "exg_synth_fasta": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]),
     "exon_tf_support_error": (C.c_char_p, []),
     "exon_tf_drain_chunks": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "exon_tf_drain_arrow_fastq": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                            C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]),
     "exon_tf_drain_digest": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                        C.POINTER(C.c_uint64)]),
     "exon_tf_drain_digest_from": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),

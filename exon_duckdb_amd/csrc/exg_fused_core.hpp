@@ -20,7 +20,8 @@
 //                                         on this single pass over the input
 //   F::kTabMap                            also keep a '\t' bitmap of every half (VCF)
 //   F::kHalves                            16 KiB halves per workgroup (bytes waiting in registers: 16 VGPRs each)
-//   F::kMinWavesPerSimd                   occupancy the register allocator must respect (7 = 7 workgroups/CU)
+//   F::kMinWavesPerSimd                   occupancy the register allocator must respect (FASTQ lean scan: 6 = six workgroups per CU at
+//                                         80 VGPRs and 24.7 KiB of LDS each; VCF: 5; the any-shape instances one less)
 #pragma once
 #include "exg_fastq_ws.hpp"
 

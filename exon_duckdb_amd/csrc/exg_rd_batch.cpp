@@ -22,6 +22,7 @@
 
 #include "exg_fastq_ws.hpp"
 #include "exg_filter.hpp"
+#include "exg_map_guard.hpp"
 #include "exg_rd_source.hpp"
 
 namespace exg_rd {
@@ -329,7 +330,15 @@ int open_next_file(exg_reader *r) {
     int fd = open(p.c_str(), O_RDONLY);
     if (fd < 0) return fail(r, EXG_E_IO, "cannot open '" + p + "': " + strerror(errno));
     struct stat st;
-    fstat(fd, &st);
+    if (fstat(fd, &st) != 0) {
+        const std::string why = strerror(errno);
+        close(fd);
+        return fail(r, EXG_E_IO, "cannot stat '" + p + "': " + why);
+    }
+    if (!S_ISREG(st.st_mode)) {
+        close(fd);
+        return fail(r, EXG_E_IO, "'" + p + "' is not a regular file");
+    }
     auto blk = std::make_shared<PinnedBlock>();
     blk->n = (size_t)st.st_size;
     double t0 = now_s();
@@ -345,6 +354,9 @@ int open_next_file(exg_reader *r) {
         }
         blk->p = m;
         blk->mapped = blk->n;
+        // (another process may truncate the file while its rows are out: zeros + EXG_E_IO at the next call, not a SIGBUS that
+        // ends the DuckDB process — exg_map_guard.hpp)
+        blk->guard = MapGuard::add(m, blk->n);
     } else {
         hipError_t he = hipHostMalloc(&blk->p, 64, hipHostMallocDefault);
         if (he != hipSuccess) {
@@ -538,10 +550,16 @@ int ensure_device(exg_reader *r, uint64_t need_bytes) {
 
 // Scan the next device batch of the current file.  On return r->batch holds its host vectors
 // (n_rows may be 0 when the file is exhausted).  count_only: no column leaves the device.
+int truncated_while_read(exg_reader *r) {
+    if (!r->file || r->file->guard < 0 || !MapGuard::hit(r->file->guard)) return EXG_OK;
+    return fail(r, EXG_E_IO, "'" + r->files[r->file_idx - 1] + "' was truncated while it was being read");
+}
+
 int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
     *n_records_out = 0;
     r->batch.reset();
     r->batch_row = 0;
+    if (int trc = truncated_while_read(r)) return trc;
     if (r->file_done) return EXG_OK;  // (opening the file found nothing of this shard's in it)
     uint64_t want = r->device_batch_bytes;
     double t_batch = now_s();

@@ -164,5 +164,7 @@ int n_string_cols(int format);
 // the next device batch with rows -> r->batch (false + *end: every file is exhausted); what exg_next_chunk and a fan-out
 // worker both do between two batches: pending parse errors, the end of a file, the next file
 int advance_batch(exg_reader *r, bool *end);
+// the mapping of the current file lost pages to a truncation (exg_map_guard.hpp): EXG_E_IO
+int truncated_while_read(exg_reader *r);
 
 }  // namespace exg_rd

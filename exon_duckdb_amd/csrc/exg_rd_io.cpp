@@ -16,6 +16,7 @@
 #include <thread>
 
 #include "exg_rd_fanout.hpp"
+#include "exg_map_guard.hpp"
 #include "exg_rd_source.hpp"
 
 namespace exg_rd {
@@ -37,8 +38,10 @@ const RoctxApi &roctx_api() {
 
 PinnedBlock::~PinnedBlock() {
     if (!p) return;
-    if (mapped)
+    if (mapped) {
+        MapGuard::remove(guard);
         munmap(p, mapped);
+    }
     else if (pooled)
         global_pool()->give((char *)p, cap);
     else

@@ -4,6 +4,7 @@
 // rust/src/arrow_reader.rs:38-166) and the per-batch pull in WTArrowTableFunction::Scan
 // (exon/src/exon/arrow_table_function/module.cpp:257-294).  A reader is used by one thread at a time, like the
 // reference's stream (MaxThreads() == 1 there); the work behind it is in exg_rd_*.cpp (see exg_rd_internal.hpp).
+#include <sys/stat.h>
 #include <string.h>
 
 #include <algorithm>
@@ -265,6 +266,7 @@ extern "C" int exg_next_chunk(exg_reader *r, exg_chunk *out) {
     MeterScope meter_scope(&r->meter);
     memset(out, 0, sizeof *out);
     for (;;) {
+        if (int trc = truncated_while_read(r)) return trc;
         if (r->batch && r->batch_row < r->batch->n_rows) {
             uint64_t row0 = r->batch_row;
             uint64_t n = std::min<uint64_t>(r->batch_rows, r->batch->n_rows - row0);
@@ -379,6 +381,11 @@ extern "C" int exg_reader_stats_of(exg_reader *r, exg_reader_stats *out) {
     out->device_batches = r->n_batches;
     out->decoded_segments = r->n_segments;
     out->scan_algo = r->fan ? 0 : r->fused_algo;
+    for (const std::string &f : r->files) {
+        struct stat sb;
+        if (stat(f.c_str(), &sb) == 0 && S_ISREG(sb.st_mode)) out->input_bytes += (uint64_t)sb.st_size;
+    }
+    out->input_compression = r->compression == exg_rd::kNone ? 0 : r->compression == exg_rd::kZstd ? 2 : 1;
     if (r->fan) {
         // the front of a fan-out holds next to nothing itself: its stripes' readers (their own meters, on the workers' threads) do
         const exg_rd::FanOut::Stats fs = r->fan->stats();

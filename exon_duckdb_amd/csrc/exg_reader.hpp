@@ -42,6 +42,7 @@ struct PinnedBlock {  // host memory: pinned (hipHostMalloc) or a read-only file
     size_t mapped = 0;  // != 0: p is an mmap of that many bytes
     bool pooled = false;  // p came from the BlockPool (block size `cap`) and goes back to it
     size_t cap = 0;
+    int guard = -1;  // a mapping: its slot in exg_map_guard.hpp (a file truncated while it is read is EXG_E_IO, not a SIGBUS)
     ~PinnedBlock();
 };
 

@@ -1,16 +1,19 @@
 // exg_zstd.hip — Zstandard (RFC 8878) frames decoded on the device (gfx950).  See exg_zstd.hpp for what it replaces and
 // why the stages are cut where they are.  Stages, all launched back to back on one stream:
 //
-//   k_zst_literals   one wavefront per compressed block: the literals section.  Raw / RLE literals are wave-wide copies;
-//                    Huffman literals: the tree description (direct 4-bit weights, or FSE-coded weights) becomes a
-//                    single-lookup table of 2^log entries in LDS, then lanes 0-3 decode the four streams (a block has four
-//                    independent backward bitstreams — that is all the parallelism the format offers inside a block; the
-//                    chip gets its occupancy from the number of blocks in flight).
-//   k_zst_sequences  one wavefront per compressed block: the three FSE tables (predefined / RLE / described / repeated
-//                    from an earlier block, whose description is simply parsed again) go to LDS; lane 0 walks the
-//                    backward bitstream and writes (literal length, match length, offset) per sequence.  Offsets that
-//                    are repeat codes cannot be resolved without the previous blocks' history — they are emitted
-//                    symbolically ("incoming slot j minus k"), and the block's effect on the history likewise.
+//   k_zst_literals   one wavefront per EIGHT compressed blocks (since round 4: a wavefront per block had one or four working
+//                    lanes per instruction on every SIMD — the stage was issue-bound across the chip): the literals
+//                    section.  Raw / RLE literals are wave-wide copies, block after block; Huffman literals: the tree
+//                    description (direct 4-bit weights, or FSE-coded weights) becomes a single-lookup table of 2^log
+//                    entries in LDS, built by the block's first lane; the block's four backward bitstreams are four lanes
+//                    (a block has four independent bitstreams — all the parallelism the format offers inside a block),
+//                    each reading its stream from a 128-byte LDS ring of its own.
+//   k_zst_sequences  one wavefront per EIGHT compressed blocks, a lane per block: the three FSE tables (predefined / RLE /
+//                    described / repeated from an earlier block, whose description is simply parsed again) go to LDS as
+//                    16-bit entries (2.5 KiB per block); the block's lane walks the backward bitstream — every field read
+//                    straight from the lane's LDS ring — and writes (literal length, match length, offset) per sequence.
+//                    Offsets that are repeat codes cannot be resolved without the previous blocks' history — they are
+//                    emitted symbolically ("incoming slot j minus k"), and the block's effect on the history likewise.
 //   k_zst_scan       one wavefront over all blocks in file order: output offsets (prefix sum) and the repeat-offset
 //                    history at every block's start (composition of the blocks' symbolic updates).
 //   k_zst_exec       one wavefront per chunk (a run of blocks of one frame): literal runs and LZ77 copies into a ring of

@@ -70,6 +70,8 @@ struct ExonTableFunction {
         std::string file_name;
         std::vector<std::string> all_names;
         std::vector<LogicalType> all_types;
+        uint64_t input_bytes = 0;        // size of the input files on disk (exg_reader_stats.input_bytes at bind)
+        uint64_t input_compression = 0;  // 0 text, 1 gzip, 2 zstd
     };
 
     struct GlobalState : public D::GlobalTableFunctionState {
@@ -128,6 +130,8 @@ struct ExonTableFunction {
                 names.emplace_back(sch.names[i]);
             }
         const std::string why = rc == EXG_OK ? "" : exg_reader_error(r);
+        exg_reader_stats st;
+        if (exg_reader_stats_of(r, &st) == EXG_OK) result->input_bytes = st.input_bytes, result->input_compression = st.input_compression;
         exg_close(r);
         if (rc != EXG_OK) throw std::runtime_error("Failed to get schema: " + why);  // module.cpp:112-119
         result->all_names = names;
@@ -253,6 +257,19 @@ struct ExonTableFunction {
         }
     }
 
+    // TableFunction::cardinality (registered at module.cpp:307: ArrowTableFunction::ArrowScanCardinality, which returns a
+    // NodeStatistics without an estimate — the reference cannot know: its input is an opaque Arrow stream).  The reader knows
+    // the input's size on disk, so the planner gets an estimate here: bytes (x the usual deflate / zstd ratio of sequence text)
+    // / the usual bytes per row of the format.  0 = unknown (no estimate is set, like the reference).  Only the join order
+    // and the sink's sizing look at it; no result depends on it.
+    static idx_t EstimatedCardinality(const BindData &d) {
+        if (!d.input_bytes) return 0;
+        const double text = (double)d.input_bytes * (d.input_compression ? 3.5 : 1.0);
+        const double per_row = d.file_type == "fastq" ? 300.0 : d.file_type == "vcf" ? 120.0 : 4096.0;
+        const double rows = text / per_row;
+        return rows < 1 ? (idx_t)1 : (idx_t)rows;
+    }
+
     // TableFunction::get_batch_index: the chunks of shard s come before those of shard s + 1, a shard's device batches in
     // their order; the chunks of one device batch share an index (they are one DuckDB batch).  Non-decreasing per scan
     // thread: a thread claims shards in increasing order.  64 shards x 2^24 stays below 1.1e9 (DuckDB's pipelines are 1e13 apart).
@@ -275,6 +292,14 @@ struct ExonTableFunction {
         return "";
     }
 };
+
+// quality_score_string_to_list (exon/src/exon/fastq_functions/module.cpp:28-54, registered at exon_extension.cpp:60): one INTEGER
+// per byte of the string, `c - 33` with `char` signed as on x86-64.  The per-row arithmetic of the SQL scalar the shim registers
+// (host loop: the function runs on whatever VARCHAR vector DuckDB hands it); exg_quality_score_list is the same op on a scan
+// column that is still in HBM.
+static inline void QualityScores(const char *s, size_t n, int32_t *out) {
+    for (size_t i = 0; i < n; i++) out[i] = (int32_t)(signed char)s[i] - 33;
+}
 
 // exon/src/exon_extension.cpp:47-58: the registrations of the path (+ the read_vcf alias the north star names)
 struct Registration {

@@ -288,6 +288,68 @@ extern "C" int exon_tf_drain_digest(exg_reader *r, int kind, uint32_t want_seq_l
     return exon_tf_drain_digest_from(r, kind, want_seq_len, 0, n_rows, n_chunks, digest, bad);
 }
 
+// ---- the reference's own boundary: new_reader -> Arrow C stream (exon/include/rust.hpp:41-46) ----------------------------------
+// Pulls every record batch of a FASTQ stream through the Arrow callbacks and releases it — what DuckDB's ArrowToDuckDB consumer
+// of the reference does per batch, minus the conversion.  with_digest: every row's four Utf8 values (int32 offsets + value bytes
+// + the description's validity bitmap) folded into the digest exon_tf_expect_fastq150 predicts (untimed verification pass).
+extern "C" int exon_tf_drain_arrow_fastq(const char *path, const char *compression, const char *filters, int with_digest, uint64_t *n_rows,
+                                         uint64_t *n_batches, uint64_t *digest, char *err, size_t err_cap) {
+    if (!path || !n_rows || !n_batches || !digest) return EXG_E_INVALID_ARG;
+    *n_rows = *n_batches = *digest = 0;
+    auto say = [&](const char *m) {
+        if (err && err_cap) snprintf(err, err_cap, "%s", m ? m : "");
+    };
+    ArrowArrayStream stream;
+    memset(&stream, 0, sizeof stream);
+    const ReaderResult rr = new_reader(&stream, path, EXG_VECTOR_SIZE, compression, "fastq", filters);
+    if (rr.error) {
+        say(rr.error);
+        return EXG_E_IO;
+    }
+    uint64_t k = 0, acc = 0;
+    int rc = EXG_OK;
+    for (;;) {
+        ArrowArray a;
+        memset(&a, 0, sizeof a);
+        if (stream.get_next(&stream, &a) != 0) {
+            say(stream.get_last_error ? stream.get_last_error(&stream) : "get_next failed");
+            rc = EXG_E_PARSE;
+            break;
+        }
+        if (!a.release) break;  // end of stream
+        if (with_digest && a.n_children >= 4) {
+            const uint8_t *vals[4];
+            const int32_t *offs[4];
+            const uint8_t *valid1 = nullptr;
+            int64_t o[4];
+            for (int c = 0; c < 4; c++) {
+                const ArrowArray *ch = a.children[c];
+                offs[c] = (const int32_t *)ch->buffers[1];
+                vals[c] = (const uint8_t *)ch->buffers[2];
+                o[c] = ch->offset;
+                if (c == 1) valid1 = ch->null_count != 0 ? (const uint8_t *)ch->buffers[0] : nullptr;
+            }
+            for (int64_t i = 0; i < a.length; i++) {
+                const uint8_t *f[4];
+                size_t n[4];
+                for (int c = 0; c < 4; c++) {
+                    const int32_t b = offs[c][o[c] + i], e = offs[c][o[c] + i + 1];
+                    f[c] = vals[c] + b, n[c] = (size_t)(e - b);
+                }
+                const bool dv = !valid1 || ((valid1[(o[1] + i) >> 3] >> ((o[1] + i) & 7)) & 1);
+                acc += fastq_row_digest(k + (uint64_t)i, f[0], n[0], f[1], n[1], dv, f[2], n[2], f[3], n[3]);
+            }
+        }
+        k += (uint64_t)a.length;
+        *n_batches += 1;
+        a.release(&a);
+    }
+    if (stream.release) stream.release(&stream);
+    *n_rows = k;
+    *digest = acc;
+    return rc;
+}
+
 // ---- host-only introspection (no device is touched): what the CPU tests check ---------------------------------------
 // The postfix program a `filters` text compiles to, e.g.  "name = 'a' | pos >= 5 | AND".  Columns are those of the
 // format's schema (VCF: the flat ones; nested columns are refused like in new_reader).  Returns 0, or -1 with the

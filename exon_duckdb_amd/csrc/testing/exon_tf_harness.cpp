@@ -205,6 +205,13 @@ extern "C" int exon_tf_bind(const char *fn_name, const char *path, const char *c
     return EXG_OK;
 }
 
+// TableFunction::cardinality (module.cpp:307): the estimate the glue hands the planner; 0 = none
+extern "C" uint64_t exon_tf_cardinality(exon_tf_handle *h) {
+    return (uint64_t)TF::EstimatedCardinality(static_cast<const TF::BindData &>(*h->bind_data));
+}
+// the arithmetic of the SQL scalar quality_score_string_to_list as the shim registers it (fastq_functions/module.cpp:28-54)
+extern "C" void exon_tf_quality_scores(const char *s, uint64_t n, int32_t *out) { exon_scan::QualityScores(s, (size_t)n, out); }
+
 extern "C" int exon_tf_schema(exon_tf_handle *h, exg_schema *out) {
     memset(out, 0, sizeof *out);
     out->n_columns = (int)h->names.size();

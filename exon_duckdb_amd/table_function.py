@@ -172,6 +172,10 @@ def _lib():
         l.exon_tf_scan.restype = C.c_int
         l.exon_tf_scan.argtypes = [C.c_void_p, C.c_int, C.POINTER(Chunk), C.POINTER(C.c_uint64)]
         l.exon_tf_close.argtypes = [C.c_void_p]
+        l.exon_tf_cardinality.restype = C.c_uint64
+        l.exon_tf_cardinality.argtypes = [C.c_void_p]
+        l.exon_tf_quality_scores.restype = None
+        l.exon_tf_quality_scores.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(C.c_int32)]
         l.exon_replacement_scan.restype = C.c_int
         l.exon_replacement_scan.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
         _tf = l
@@ -215,6 +219,8 @@ class Relation:
         self.names = [sch.names[i].decode() for i in range(sch.n_columns)]
         self.types = [sch.types[i] for i in range(sch.n_columns)]
         self.trees = [type_tree(sch.tree[i].contents) for i in range(sch.n_columns)]
+        #: TableFunction::cardinality (module.cpp:307): the row estimate handed to the planner, 0 = none
+        self.estimated_cardinality = int(self._l.exon_tf_cardinality(h))
         self._l.exon_tf_close(h)
 
     #: how many scan threads `_scan` runs: None = MaxThreads() (DuckDB's upper bound); DuckDB itself runs fewer when
@@ -344,3 +350,11 @@ class Connection:
 
 def connect():
     return Connection()
+
+
+def quality_score_string_to_list(s: bytes):
+    """the SQL scalar of exon/src/exon/fastq_functions/module.cpp:28-54 as the DuckDB shim registers it (host arithmetic of
+    duckdb_shim/exon_extension.cpp: QualityScoreStringToList) -> list of int"""
+    out = (C.c_int32 * max(1, len(s)))()
+    _lib().exon_tf_quality_scores(s, len(s), out)
+    return list(out[:len(s)])

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define EXG_ABI_VERSION 7
+#define EXG_ABI_VERSION 8
 
 /* DuckDB v0.8.1 STANDARD_VECTOR_SIZE; the reference asks the Rust side for
  * batches of exactly this many rows (module.cpp:83, :233). */
@@ -474,7 +474,10 @@ typedef struct exg_reader_stats {
     uint64_t scan_algo;          /* EXG_ALGO_* the next device batch starts with: EXG_ALGO_FUSED until a batch came back with
                                   * EXG_RF_REDO (long reads, reads below ~45 bp, multi-sample VCF lines, bytes >= 0x80), then
                                   * EXG_ALGO_FUSED_FULL for the rest of the input (a fan-out reader: 0) */
-    uint64_t reserved[3];
+    uint64_t input_bytes;        /* ABI 8: size of the reader's input files on disk (all files of a directory; a shard: the whole
+                                  * files), what TableFunction::cardinality estimates rows from (module.cpp:307) */
+    uint64_t input_compression;  /* ABI 8: 0 plain text, 1 gzip / BGZF, 2 zstd (input_bytes are compressed bytes then) */
+    uint64_t reserved[1];
 } exg_reader_stats;
 int exg_reader_stats_of(exg_reader *r, exg_reader_stats *out);
 /* Device buffers, pinned host blocks and HIP streams of closed readers are recycled process-wide (size classes, at most

@@ -9,6 +9,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <functional>
 #include <memory>
 #include <string>
 #include <unordered_map>
@@ -83,6 +84,8 @@ struct string_t {
 	uint32_t length;
 	char prefix[4];
 	char *ptr;
+	idx_t GetSize() const;
+	const char *GetData() const;
 };
 struct list_entry_t {
 	uint64_t offset;
@@ -117,18 +120,34 @@ public:
 };
 struct ValidityMask {
 	void Initialize(validity_t *validity);
+	bool RowIsValid(idx_t row_idx) const;
 };
+struct SelectionVector {
+	idx_t get_index(idx_t idx) const;
+};
+struct UnifiedVectorFormat {
+	const SelectionVector *sel;
+	data_ptr_t data;
+	ValidityMask validity;
+};
+enum class VectorType : uint8_t { FLAT_VECTOR, FSST_VECTOR, CONSTANT_VECTOR, DICTIONARY_VECTOR, SEQUENCE_VECTOR };
 class Vector {
 public:
 	void SetAuxiliary(buffer_ptr<VectorBuffer> new_buffer);
+	void SetVectorType(VectorType vector_type);
+	void ToUnifiedFormat(idx_t count, UnifiedVectorFormat &data);
 };
 struct FlatVector {
 	static ValidityMask &Validity(Vector &vector);
 	static void SetData(Vector &vector, data_ptr_t data);
+	template <class T>
+	static T *GetData(Vector &vector);
+	static void SetNull(Vector &vector, idx_t idx, bool is_null);
 };
 struct ListVector {
 	static Vector &GetEntry(Vector &vector);
 	static void SetListSize(Vector &vec, idx_t size);
+	static void Reserve(Vector &vec, idx_t required_capacity);
 };
 struct StructVector {
 	static vector<unique_ptr<Vector>> &GetEntries(Vector &vector);
@@ -253,6 +272,18 @@ typedef unique_ptr<GlobalTableFunctionState> (*table_function_init_global_t)(Cli
 typedef unique_ptr<LocalTableFunctionState> (*table_function_init_local_t)(ExecutionContext &context, TableFunctionInitInput &input,
                                                                            GlobalTableFunctionState *global_state);
 typedef void (*table_function_t)(ClientContext &context, TableFunctionInput &data, DataChunk &output);
+// ---- duckdb/storage/statistics/node_statistics.hpp
+class NodeStatistics {
+public:
+	NodeStatistics();
+	explicit NodeStatistics(idx_t estimated_cardinality);
+	NodeStatistics(idx_t estimated_cardinality, idx_t max_cardinality);
+	bool has_estimated_cardinality;
+	idx_t estimated_cardinality;
+	bool has_max_cardinality;
+	idx_t max_cardinality;
+};
+typedef unique_ptr<NodeStatistics> (*table_function_cardinality_t)(ClientContext &context, const FunctionData *bind_data);
 typedef idx_t (*table_function_get_batch_index_t)(ClientContext &context, const FunctionData *bind_data,
                                                   LocalTableFunctionState *local_state, GlobalTableFunctionState *global_state);
 class TableFunction {
@@ -260,13 +291,22 @@ public:
 	TableFunction(string name, vector<LogicalType> arguments, table_function_t function, table_function_bind_t bind = nullptr,
 	              table_function_init_global_t init_global = nullptr, table_function_init_local_t init_local = nullptr);
 	named_parameter_type_map_t named_parameters;
+	table_function_cardinality_t cardinality;
 	table_function_get_batch_index_t get_batch_index;
 	bool projection_pushdown;
 	bool filter_pushdown;
 	shared_ptr<TableFunctionInfo> function_info;
 };
+// ---- duckdb/function/scalar_function.hpp
+struct ExpressionState;
+typedef std::function<void(DataChunk &, ExpressionState &, Vector &)> scalar_function_t;
+class ScalarFunction {
+public:
+	ScalarFunction(string name, vector<LogicalType> arguments, LogicalType return_type, scalar_function_t function);
+};
 struct ExtensionUtil {
 	static void RegisterFunction(DatabaseInstance &db, TableFunction function);
+	static void RegisterFunction(DatabaseInstance &db, ScalarFunction function);
 };
 
 // ---- parser

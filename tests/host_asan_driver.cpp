@@ -20,6 +20,8 @@
 #include "exg_rd_internal.hpp"
 #include "exg_vcf_header.hpp"
 #include "exg_xxh64.hpp"
+#include <sys/mman.h>
+#include "exg_map_guard.hpp"
 #include "exg_zstd.hpp"
 
 namespace exg {
@@ -350,6 +352,45 @@ int main(int argc, char **argv) {
             if (pool.pooled() != (64u << 20) || s_live != 2) return 10;
         }
         if (s_live != 0) return 10;
+    }
+    // a mapping whose file is truncated under it (exg_map_guard.cpp): the read gives zeros and marks the slot, nothing dies; a
+    // mapping that is not registered is not touched (the guard hands the signal on)
+    {
+        char name[] = "/tmp/exg_asan_map_XXXXXX";
+        const int fd = mkstemp(name);
+        if (fd < 0) return 12;
+        const size_t page = (size_t)sysconf(_SC_PAGESIZE), n = 64 * page;
+        std::vector<char> fill(n, 'x');
+        if (write(fd, fill.data(), n) != (ssize_t)n) return 12;
+        char *m = (char *)mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) return 12;
+        const int slot = exg_rd::MapGuard::add(m, n);
+        if (slot < 0 || exg_rd::MapGuard::hit(slot)) return 12;
+        volatile char c = m[10 * page];
+        if (c != 'x' || exg_rd::MapGuard::hit(slot)) return 12;
+        if (ftruncate(fd, (off_t)(8 * page)) != 0) return 12;
+        c = m[3 * page];                       // still there
+        if (c != 'x' || exg_rd::MapGuard::hit(slot)) return 12;
+        c = m[40 * page + 17];                 // gone: SIGBUS -> a zero page, the slot is marked
+        if (c != 0 || !exg_rd::MapGuard::hit(slot) || exg_rd::MapGuard::patched() != 1) return 12;
+        c = m[40 * page + 99];                 // the patched page: no second fault
+        if (c != 0 || exg_rd::MapGuard::patched() != 1) return 12;
+        c = m[63 * page];
+        if (c != 0 || exg_rd::MapGuard::patched() != 2) return 12;
+        exg_rd::MapGuard::remove(slot);
+        if (exg_rd::MapGuard::hit(slot)) { /* (a freed slot reports what it last saw until it is reused: harmless) */ }
+        munmap(m, n);
+        // slots are reused, and a full table refuses (-1) instead of overwriting
+        std::vector<int> slots;
+        for (int i = 0; i < 300; i++) slots.push_back(exg_rd::MapGuard::add(fill.data(), 16));
+        int ok = 0;
+        for (int sl : slots) ok += sl >= 0;
+        if (ok != 256) return 12;
+        for (int sl : slots) exg_rd::MapGuard::remove(sl);
+        if (exg_rd::MapGuard::add(fill.data(), 16) < 0) return 12;
+        close(fd);
+        unlink(name);
+        runs++;
     }
     // the fan-out's run-ahead (exg_rd_fanout.cpp): a worker never holds more than `depth` batches the consumer has not taken,
     // however short its stripes are (bounded per stripe, 40 stripes of one batch each would all be produced at once)

@@ -278,3 +278,56 @@ def test_round_size_does_not_change_the_rows(gpu, fastq_mid, tmp_path, monkeypat
         gb.write_bytes(bytes(bad))
         rows, msg = _expect_error(gb, "fastq", min_rows_before=int(want[0] * 0.99))
         assert "checksum" in msg.lower(), msg
+
+
+@pytest.mark.timeout(300)
+def test_a_text_file_truncated_while_its_rows_are_out(gpu, fastq_mid, tmp_path, monkeypatch):
+    """A plain text file is mapped and the DataChunk strings point into the mapping (zero-copy payload).  Another process that
+    truncates the file while a query runs used to be a SIGBUS — the end of the DuckDB process — as soon as anybody touched a
+    string behind the new end; the reference's buffered reader returns an I/O error.  Now: the strings of the chunk that is
+    out read as zeros where the bytes are gone, and the reader's next call fails with EXG_E_IO (exg_map_guard.hpp)."""
+    import ctypes as C
+    import os
+    from exon_duckdb_amd import abi
+    from exon_duckdb_amd.reader import ShardReader
+    from exon_duckdb_amd.table_function import Chunk
+    data, _ = fastq_mid
+    p = tmp_path / "t.fastq"
+    p.write_bytes(data)
+    monkeypatch.setenv("EXG_DEVICE_BATCH_BYTES", str(8 << 20))
+    r = ShardReader(str(p), "fastq")
+    # walk to a chunk whose strings lie well inside the file
+    ch = None
+    for _ in range(30):
+        ch = Chunk()
+        assert r._l.exg_next_chunk(r._r, C.byref(ch)) == 0 and ch.n_rows > 0
+        last = ch
+        if _ < 29:
+            r._l.exg_release_chunk(r._r, C.byref(ch))
+    n = int(last.n_rows)
+    seq = C.cast(last.data[2], C.POINTER(C.c_uint8 * 16))
+    raw = bytes(seq[n - 1])
+    ln = int.from_bytes(raw[:4], "little")
+    ptr = int.from_bytes(raw[8:], "little")
+    assert ln == 150 and C.string_at(ptr, ln) in data            # the payload is the mapping's bytes
+    os.truncate(p, 4096)                                         # ... which are gone now
+    got = C.string_at(ptr, ln)                                   # a SIGBUS without the guard
+    assert got == b"\0" * ln
+    r._l.exg_release_chunk(r._r, C.byref(last))
+    rc, msg = 0, ""
+    for _ in range(100000):
+        ch = Chunk()
+        rc = r._l.exg_next_chunk(r._r, C.byref(ch))
+        if rc != 0:
+            msg = (r._l.exg_reader_error(r._r) or b"").decode()
+            break
+        if ch.n_rows == 0:
+            break
+        r._l.exg_release_chunk(r._r, C.byref(ch))
+    assert rc == abi.EXG_E_IO and ("truncated" in msg or "short read" in msg), (rc, msg)
+    r.close()
+    # the process lives, and the next reader of a whole file is unharmed
+    p.write_bytes(data)
+    r = ShardReader(str(p), "fastq")
+    assert r.count() == 200000
+    r.close()

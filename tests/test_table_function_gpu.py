@@ -504,3 +504,34 @@ def test_bgzf_of_many_windows_in_flight(gpu, tmp_path, monkeypatch):
     rows = rd.rows()
     rd.close()
     assert len(rows) == n_rec and rows[0][0] == b"SYN000000000000" and rows[-1][0] == b"SYN%012d" % (n_rec - 1)
+
+
+def test_cardinality_estimate(con, golden_dir, oracle, tmp_path):
+    """TableFunction::cardinality (module.cpp:307).  The reference registers ArrowScanCardinality, which has no estimate to give
+    (an opaque Arrow stream); this glue knows the input's size on disk and estimates rows from it — within a small factor of
+    the truth on the usual record shapes, 0 (no estimate, like the reference) only when the size is unknown."""
+    from exon_duckdb_amd.table_function import Relation
+    data = bytes(oracle.synth_fastq(332 * 50000))
+    p = tmp_path / "c.fastq"
+    p.write_bytes(data)
+    est = Relation("read_fastq", str(p)).estimated_cardinality
+    assert 50000 / 2 <= est <= 50000 * 2, est
+    import gzip
+    pz = tmp_path / "c.fastq.gz"
+    pz.write_bytes(gzip.compress(data, 6))
+    est = Relation("read_fastq", str(pz)).estimated_cardinality
+    assert 50000 / 3 <= est <= 50000 * 3, est
+    est = Relation("read_vcf_file_records", os.path.join(golden_dir, "vcf", "index.vcf")).estimated_cardinality
+    assert 621 / 3 <= est <= 621 * 3, est
+    assert Relation("read_fasta", os.path.join(golden_dir, "test.fasta")).estimated_cardinality >= 1
+
+
+def test_quality_score_string_to_list_scalar(gpu):
+    """quality_score_string_to_list as `LOAD exon` registers it in SQL (exon_extension.cpp:60, fastq_functions/module.cpp:28-54:
+    `c - 33` per byte with `char` signed): the shim's host arithmetic against the closed form, and against the device op on
+    a column in HBM (tests/test_quality_list_gpu.py checks that one against the oracle)."""
+    from exon_duckdb_amd.table_function import quality_score_string_to_list
+    assert quality_score_string_to_list(b"!I5@") == [0, 40, 20, 31]
+    assert quality_score_string_to_list(b"") == []
+    s = bytes(range(256))
+    assert quality_score_string_to_list(s) == [(c - 256 if c >= 128 else c) - 33 for c in s]
