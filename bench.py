@@ -29,6 +29,10 @@ import zlib
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# A reader keeps 6-8 HIP streams busy per device; HIP's default of 4 hardware queues makes them share (a batch's 0.1 ms scan then
+# sits behind the decoder lanes' kernels and the 5 ms host copies of decoded segments: DESIGN 5.3a).  libexon_gpu sets this default
+# itself when it is what brings HIP into the process; here torch initialises HIP first, so the script does (never overriding).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 REC = 332
@@ -165,6 +169,27 @@ def timed_launches(torch, fn, reps, warm=2):
     torch.cuda.synchronize()
     ms = sorted(a.elapsed_time(b) for a, b in ev)
     return sum(ms) / len(ms), ms[0]
+
+
+def link_rates(torch, n=1 << 30, reps=3):
+    """what the PCIe link of this box moves, measured in this run: one pinned 1 GiB buffer <-> HBM, each direction alone (best of
+    `reps`) -> (h2d GB/s, d2h GB/s).  The file-level legs are priced against these, not against a nominal figure."""
+    host = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+    dev = torch.empty(n, dtype=torch.uint8, device="cuda")
+    out = []
+    for dst, src in ((dev, host), (host, dev)):
+        best = None
+        for _ in range(reps + 1):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            dst.copy_(src, non_blocking=True)
+            b.record()
+            torch.cuda.synchronize()
+            ms = a.elapsed_time(b)
+            best = ms if best is None else min(best, ms)
+        out.append(n / (best * 1e-3) / 1e9)
+    del host, dev
+    return out[0], out[1]
 
 
 def open_reader(lib, path, fmt, shard=(0, 1), device_index=0, columns=0):
@@ -495,6 +520,11 @@ def run_configs(torch, lib, args):
         n_e2e, n_gz_in = int(n_e2e * scale) // REC * REC, int(n_gz_in * scale) // REC * REC
     from exon_duckdb_amd import load_test_library
     tl = load_test_library()
+    try:
+        link = link_rates(torch)
+    except Exception:  # noqa: BLE001
+        link = (float("nan"), float("nan"))
+    out["pcie_link"] = {"h2d_GB/s": link[0], "d2h_GB/s": link[1], "what": "one pinned 1 GiB buffer <-> HBM, each direction alone, best of 3, measured in this run"}
     def leg(fn, *keys):
         """a side leg of the bench line: what goes wrong in it is reported in its own object(s)"""
         try:
@@ -595,21 +625,30 @@ def run_configs(torch, lib, args):
             for key, path in (("with_content_checksum", p_zc), ("without_checksum", p_z)):
                 reader_count(lib, path, "fastq")  # warm: pools, page cache
                 n, dt = min((reader_count(lib, path, "fastq") for _ in range(3)), key=lambda x: x[1])
+                # what the metric names — records INTO DataChunks: all four columns pulled and released by the C drain loop; the
+                # decoded bytes (the strings' payload) and 64 B of string_t per record cross PCIe back to the host
+                a_rows, a_chunks, dt_a = min((reader_chunks(lib, path, "fastq") for _ in range(3)), key=lambda x: x[2])
                 v_rows, v_chunks, got, bad = reader_digest(lib, path, "fastq", 150)
+                d2h = n_in + 64 * a_rows + a_rows // 8
                 res[key] = {"ms": dt * 1e3, "GB/s": n_in / dt / 1e9, "GB/s_compressed": (n_comp - (4 if key == "without_checksum" else 0)) / dt / 1e9,
-                            "records_per_s": n / dt, "verified": bool(n == v_rows == n_in // REC and got == want and bad == 0)}
+                            "records_per_s": n / dt,
+                            "all_columns": {"ms": dt_a * 1e3, "GB/s": n_in / dt_a / 1e9, "records_per_s": a_rows / dt_a, "chunks": a_chunks, "d2h_bytes": d2h,
+                                            "d2h_GB/s": d2h / dt_a / 1e9, "frac_of_d2h_link": d2h / dt_a / 1e9 / link[1]},
+                            "verified": bool(n == v_rows == a_rows == n_in // REC and got == want and bad == 0)}
                 os.unlink(path)
             return {"workload": f"SELECT COUNT(*) FROM read_fastq('x.fastq.zst'): {n_comp / 1e9:.2f} GB = {n_in / 1e9:.2f} GB of FASTQ-150 as ONE zstd frame "
                                 f"(libzstd level 3), file in the page cache; entropy stages, execution and resolve on the device in rounds of ~1 GiB, "
                                 f"two rounds overlapped, beside the scan",
                     "compressed_bytes": n_comp, "algorithmic_bytes": n_comp + 2 * n_in, **res,
                     "GB/s": res["without_checksum"]["GB/s"], "ms": res["without_checksum"]["ms"], "frac": None,
+                    "all_columns_GB/s": res["without_checksum"]["all_columns"]["GB/s"], "all_columns_records_per_s": res["without_checksum"]["all_columns"]["records_per_s"],
+                    "link_GB/s": {"h2d": link[0], "d2h": link[1]},
                     "bound_with_checksum": "XXH64 of a single frame is one serial chain: one host core hashes it beside the decode (frames up "
                                            "to 64 MiB are hashed on the device) — that leg cannot be faster than host_xxh64_one_core_GB/s",
                     "host_xxh64_one_core_GB/s": xxh_rate,
                     "libzstd_one_core_GB/s": n_piece / t_lib / 1e9 if lib_ok else None, "input_build_s": t_build,
-                    "verification": "COUNT(*) timed; an untimed pass pulls all four columns as DataChunks and folds every row into a digest that "
-                                    "must equal the generator's",
+                    "verification": "COUNT(*) and the all-columns drain timed (best of 3 each); an untimed pass pulls all four columns as DataChunks and "
+                                    "folds every row into a digest that must equal the generator's",
                     "verified": bool(all(v["verified"] for v in res.values()))}
 
         def arrow_leg(p_fq, want):
@@ -680,6 +719,13 @@ def run_configs(torch, lib, args):
             t_build = time.perf_counter() - t0
             reader_count(lib, p_gz, "fastq")
             n, dt_g = min((reader_count(lib, p_gz, "fastq") for _ in range(3)), key=lambda x: x[1])
+            # ... and what the metric names, records INTO DataChunks (module.cpp:257-294 always materialises the columns): all four
+            # columns pulled and released by the C drain loop — the inflated bytes (the strings' payload) and 64 B of string_t per
+            # record cross PCIe back to the host, beside the compressed bytes going up
+            a_rows, a_chunks, dt_a = min((reader_chunks(lib, p_gz, "fastq") for _ in range(3)), key=lambda x: x[2])
+            d2h = n_gz_in + 64 * a_rows + a_rows // 8
+            # a projection: name only — the payload that crosses PCIe is the name lines' bytes, not the file's
+            p_rows, p_chunks, dt_p = min((reader_chunks(lib, p_gz, "fastq", columns=0b0001) for _ in range(3)), key=lambda x: x[2])
             want = int(tl.exon_tf_expect_fastq150(abi.EXG_SYNTH_FASTQ_SEED, 0, n_gz_rec, cores))
             t1 = time.perf_counter()
             v_rows, v_chunks, got, bad = reader_digest(lib, p_gz, "fastq", 150)
@@ -691,10 +737,16 @@ def run_configs(torch, lib, args):
                 "compressed_bytes": comp, "algorithmic_bytes": comp + 2 * n_gz_in, "ms": dt_g * 1e3, "GB/s": n_gz_in / dt_g / 1e9,
                 "GB/s_compressed": comp / dt_g / 1e9, "records_per_s": n / dt_g, "frac": (comp + 2 * n_gz_in) / dt_g / 1e9 / HBM_PEAK_GBPS,
                 "input_build_s": t_build, "input_deflate_pool_s": getattr(build_bgzf, "pool_s", None),
+                "all_columns": {"what": "read_fastq('x.fastq.gz') into DataChunks: all four columns through exg_next_chunk / exg_release_chunk (C drain loop), best of 3",
+                                "ms": dt_a * 1e3, "GB/s": n_gz_in / dt_a / 1e9, "records_per_s": a_rows / dt_a, "chunks": a_chunks,
+                                "d2h_bytes": d2h, "d2h_GB/s": d2h / dt_a / 1e9, "link_GB/s": {"h2d": link[0], "d2h": link[1]},
+                                "frac_of_d2h_link": d2h / dt_a / 1e9 / link[1], "upload_bound_ms": comp / link[0] / 1e6, "d2h_bound_ms": d2h / link[1] / 1e6},
+                "projected_name": {"columns": "name (exg_open_args.columns = 1)", "ms": dt_p * 1e3, "GB/s": n_gz_in / dt_p / 1e9, "records_per_s": p_rows / dt_p,
+                                   "chunks": p_chunks},
                 "all_columns_verify_s": dt_v,
-                "verification": "COUNT(*) timed; an untimed pass pulls all four columns as DataChunks and folds every row into a digest that "
-                                "must equal the generator's",
-                "verified": bool(n == v_rows == n_gz_rec and got == want and bad == 0)}
+                "verification": "COUNT(*) and the all-columns drain timed (best of 3 each); an untimed pass pulls all four columns as DataChunks and folds "
+                                "every row into a digest that must equal the generator's",
+                "verified": bool(n == v_rows == a_rows == p_rows == n_gz_rec and got == want and bad == 0)}
 
         def vcf_file():
             # ---- read_vcf end to end: VCF-8 file in the page cache -> host DataChunks, every column of the reference's schema

@@ -1,6 +1,7 @@
 // exg_api.hip — C-ABI entry points of the device level (include/exon_gpu.h, layer 1) and the
 // library plumbing (errors, device probe, result fetch).
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "exg_arrow.hpp"
@@ -20,6 +21,15 @@ void set_error(const char *fmt, ...) {
 }  // namespace exg
 
 using namespace exg;
+
+// A reader keeps six to eight HIP streams busy on its device (its scan stream, the upload stream, three decoder lanes, the
+// decoded segments' host copies, a checksum stage); HIP maps streams onto GPU_MAX_HW_QUEUES = 4 hardware queues by default and
+// streams that share one wait for each other's packets: measured on a BGZF FASTQ read into DataChunks, the 0.1 ms scan of a
+// batch sat 23-28 ms behind the decoder lanes' kernels and the 5 ms host copies (EXG_TRACE).  The runtime reads the
+// variable when it initialises, i.e. at the process's first HIP call: when this library is what brings HIP into the process
+// (`LOAD exon` in DuckDB) the constructor below is in time; a host that initialised HIP earlier (bench.py imports torch first)
+// sets it itself.  Never overrides a value that is set.
+__attribute__((constructor)) static void exg_hw_queues_default() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 extern "C" int exg_abi_version(void) { return EXG_ABI_VERSION; }
 

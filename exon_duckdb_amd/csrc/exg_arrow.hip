@@ -180,6 +180,49 @@ void utf8_copy_from_views(const View *d_views, uint64_t n, const uint64_t *d_gof
     launch_copy(ViewGet{d_views}, n, d_goff, d_values, d_big, big_cap, stream);
 }
 
+// ---- the payload of ONE projected column (a decoded input whose bytes live only in HBM) ----------------------------------------
+// A string_t of more than 12 bytes points into the input.  When a projection selects a few columns of a compressed input, what
+// crosses PCIe should be those columns' bytes, not the decoded file: the out-of-line strings of a column are closed up into a
+// dense buffer (same scan + copy as the Arrow values buffer; inlined strings count as empty) and the column's pointers are
+// rewritten to address that buffer's host copy.
+struct ColGetLong {
+    ColGet g;
+    __device__ __forceinline__ uint32_t len(uint64_t j) const {
+        const uint32_t l = g.len(j);
+        return l > EXG_INLINE_LENGTH ? l : 0u;
+    }
+    __device__ __forceinline__ const uint8_t *ptr(uint64_t j, uint32_t *len_out) const {
+        uint32_t l;
+        const uint8_t *p = g.ptr(j, &l);
+        *len_out = l > EXG_INLINE_LENGTH ? l : 0u;
+        return p;
+    }
+};
+void payload_goff_from_col(const StrCol &c, const uint32_t *d_row_map, uint64_t n, uint64_t *d_goff, uint64_t *d_tmp, hipStream_t stream) {
+    launch_xscan(LenF<ColGetLong>{ColGetLong{ColGet{c, d_row_map}}}, n, d_goff, d_tmp, stream);
+}
+void payload_copy_from_col(const StrCol &c, const uint32_t *d_row_map, uint64_t n, const uint64_t *d_goff, uint8_t *d_values, uint32_t *d_big,
+                           uint32_t big_cap, hipStream_t stream) {
+    launch_copy(ColGetLong{ColGet{c, d_row_map}}, n, d_goff, d_values, d_big, big_cap, stream);
+}
+__global__ __launch_bounds__(256) void k_repoint(const uint4 *__restrict__ in, const uint32_t *__restrict__ row_map, uint64_t n,
+                                                 const uint64_t *__restrict__ goff, uint64_t new_base, uint4 *out) {
+    for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (uint64_t)gridDim.x * 256) {
+        uint4 v = in[row_map ? (uint64_t)row_map[j] : j];
+        if (v.x > EXG_INLINE_LENGTH) {
+            const uint64_t p = new_base + goff[j];
+            v.z = (uint32_t)p, v.w = (uint32_t)(p >> 32);
+        }
+        out[j] = v;
+    }
+}
+void repoint_strings(const exg_string_t *d_in, const uint32_t *d_row_map, uint64_t n, const uint64_t *d_goff, uint64_t new_base,
+                     exg_string_t *d_out, hipStream_t stream) {
+    if (!n) return;
+    uint32_t grid = (uint32_t)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_repoint, dim3(grid), dim3(256), 0, stream, (const uint4 *)d_in, d_row_map, n, d_goff, new_base, (uint4 *)d_out);
+}
+
 // ---- quality_score_string_to_list -------------------------------------------------------------------------------
 // Same shape as k_utf8_copy (workgroup = 256 consecutive strings = one contiguous range of the child vector),
 // but every source byte widens to an int32, so a thread produces four values and stores them as one 16-byte

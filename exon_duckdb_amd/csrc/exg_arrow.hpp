@@ -40,6 +40,15 @@ void utf8_copy_from_col(const StrCol &c, const uint32_t *d_row_map, uint64_t n, 
                         uint8_t *d_values, uint32_t *d_big, uint32_t big_cap, hipStream_t stream);
 void utf8_copy_from_views(const View *d_views, uint64_t n, const uint64_t *d_goff, uint8_t *d_values, uint32_t *d_big,
                           uint32_t big_cap, hipStream_t stream);
+// The payload of ONE projected column of an input whose bytes live only in HBM (a decoded stream): goff = exclusive prefix of the
+// lengths of the column's OUT-OF-LINE strings (> 12 bytes; inlined ones count 0), values = those strings closed up, and
+// repoint_strings writes the column (gathered through d_row_map when given) with every out-of-line pointer = new_base + goff[j]
+// — only the selected columns' bytes cross PCIe (exg_rd_batch.cpp).  d_out may be d_in when there is no row map.
+void payload_goff_from_col(const StrCol &c, const uint32_t *d_row_map, uint64_t n, uint64_t *d_goff, uint64_t *d_tmp, hipStream_t stream);
+void payload_copy_from_col(const StrCol &c, const uint32_t *d_row_map, uint64_t n, const uint64_t *d_goff, uint8_t *d_values, uint32_t *d_big,
+                           uint32_t big_cap, hipStream_t stream);
+void repoint_strings(const exg_string_t *d_in, const uint32_t *d_row_map, uint64_t n, const uint64_t *d_goff, uint64_t new_base,
+                     exg_string_t *d_out, hipStream_t stream);
 // per record batch of chunk_rows rows: off32[c * (chunk_rows + 1) + i] = goff[c * chunk_rows + i] - goff[c * chunk_rows]
 // (i = 0..rows of the chunk), chunk_base[c] = goff[c * chunk_rows]
 void rebase_offsets(const uint64_t *d_goff, uint64_t n, uint64_t chunk_rows, int32_t *d_off32, uint64_t *d_chunk_base,

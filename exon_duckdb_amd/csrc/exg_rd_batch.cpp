@@ -592,7 +592,14 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             src_pos = r->file_pos - shard_halo;
             uint64_t avail = 0;
             std::string msg;
-            int arc = r->src->acquire(src_pos, want + shard_halo, &src_at, &avail, &src_eof, &msg);
+            // What is asked of the stream is "the rest of the segment that holds file_pos", not a batch's worth of bytes: a
+            // segment shorter than a device batch (the first windows of a file are small on purpose: latency) used to be MERGED
+            // with the one behind it — a device copy of both, a pinned block of an odd size for the merged batch's payload
+            // (hipHostMalloc: ~1 ms per 10 MiB) and no host mirror.  Only a batch that held no complete record asks for more.
+            const uint64_t ask = (want > r->device_batch_bytes || r->format == EXG_FMT_FASTA) ? want : std::min<uint64_t>(want, 1u << 20);
+            const double t_acq = now_s();
+            int arc = r->src->acquire(src_pos, ask + shard_halo, &src_at, &avail, &src_eof, &msg);
+            TRACE("acquire(decoded segment)", t_acq);
             if (arc) return fail(r, arc, msg + (msg.find(r->files[r->file_idx - 1]) == std::string::npos ? " in '" + r->files[r->file_idx - 1] + "'" : ""));
             r->n_segments = r->src->segments_consumed() + 1;
             if (avail <= shard_halo && src_eof) {  // nothing behind file_pos: the stream has ended
@@ -656,6 +663,9 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         uint64_t lead = 0;
         uint64_t batch_end = r->file_pos + n;  // file offset one past the bytes of this batch
         std::shared_ptr<PinnedBlock> gz_payload;  // gzip: this batch's inflated bytes on the host (string_t payload)
+        std::shared_ptr<HostMirror> gz_mirror;    // ... when the producer sent them ahead (exg_rd_source.hpp); then only
+        uint64_t gz_front = 0;                    // ... the first gz_front bytes of the batch (the carried tail) are copied here
+        bool compact = false;                     // ... or: only the selected columns' out-of-line strings travel (a side buffer)
         if (r->src) {
             lead = shard_halo + (src_pos & 15);
             d_input = src_at - (src_pos & 15);
@@ -671,15 +681,45 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
                 d_input = r->d_in;
                 lead = 0;
             }
-            if (!count_only && !r->arrow_emit) {
-                gz_payload = std::make_shared<PinnedBlock>();
-                size_t cap = n + 64;
-                gz_payload->p = global_pool()->take(&cap);
-                if (!gz_payload->p) return fail(r, EXG_E_HIP, "out of pinned host memory for the inflated bytes");
-                gz_payload->cap = cap;
-                gz_payload->pooled = true;
-                gz_payload->n = n;
-                h = (const uint8_t *)gz_payload->p;
+            // A projection that leaves payload-bearing columns out (SELECT name FROM read_fastq('x.fastq.gz'); chrom, pos, ref of a
+            // bgzip VCF): the decoded bytes stay in HBM, the out-of-line strings of the selected columns are closed up into a side
+            // buffer behind the scan and only that crosses PCIe (payload_*_from_col, repoint_strings).  Not when a nested VCF
+            // column is selected: its element views are cut out of the line's text by the emitter.
+            if (!count_only && !r->arrow_emit && r->format != EXG_FMT_FASTA) {
+                static const bool off = getenv("EXG_NO_PAYLOAD_COMPACT") != nullptr;
+                const uint64_t strs = r->format == EXG_FMT_VCF ? 0x1DDull : 0xFull, nested = r->format == EXG_FMT_VCF ? 0x1D4ull : 0ull;
+                const uint64_t sel = r->want_cols & strs;
+                compact = !off && sel != 0 && sel != strs && !(sel & nested);
+            }
+            if (compact) {
+                h = (const uint8_t *)(uintptr_t)0x100000000000ull + (r->file_pos - lead);  // (a base the side buffer's pointers replace)
+            } else if (!count_only && !r->arrow_emit) {
+                // The strings of this batch point into host memory that holds the decoded bytes.  From the first such batch on
+                // the producer sends every segment to the host as it hands it over (HostMirror: the copy runs while the segment
+                // waits in the queue and while this thread is busy with the batch in front): the batch then points into that
+                // block, and only the bytes in front of the segment's own — the tail carried over from the segment before —
+                // are copied here.  A segment without a mirror (pushed before the first call, a block of the consumer's own
+                // making, FASTA) is copied behind the scan as before.
+                const bool wants_bytes = r->format == EXG_FMT_VCF ? (r->want_cols & 0x1DDull) != 0 : (r->want_cols & ((1ull << n_string_cols(r->format)) - 1)) != 0;
+                const uint8_t *h_at = nullptr;
+                uint64_t m_from = 0;
+                static const bool no_mirror = getenv("EXG_NO_HOST_MIRROR") != nullptr;  // (A/B and tests: the copy behind the scan)
+                if (wants_bytes && r->format != EXG_FMT_FASTA && !no_mirror) r->src->want_host_mirror();
+                if (wants_bytes && r->format != EXG_FMT_FASTA && !no_mirror && r->src->host_view((const uint8_t *)d_input, &h_at, &m_from, &gz_mirror)) {
+                    gz_payload = gz_mirror->blk;
+                    h = h_at;
+                    gz_front = m_from > src_pos - (src_pos & 15) ? std::min<uint64_t>(n, m_from - (src_pos - (src_pos & 15))) : 0;
+                } else {
+                    gz_mirror.reset();
+                    gz_payload = std::make_shared<PinnedBlock>();
+                    size_t cap = n + 64;
+                    gz_payload->p = global_pool()->take(&cap);
+                    if (!gz_payload->p) return fail(r, EXG_E_HIP, "out of pinned host memory for the inflated bytes");
+                    gz_payload->cap = cap;
+                    gz_payload->pooled = true;
+                    gz_payload->n = n;
+                    h = (const uint8_t *)gz_payload->p;
+                }
             } else {
                 // COUNT(*) / the Arrow stream: no host copy; h is only the base the device subtracts again
                 h = (const uint8_t *)(uintptr_t)0x100000000000ull + (r->file_pos - lead);
@@ -1000,9 +1040,57 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             // the projection (exg_open_args.columns): every column was parsed and validated above, only the wanted ones travel.
             // A decoded input's bytes are what its strings point into: they travel when any string column does
             const bool any_strings = r->format == EXG_FMT_VCF ? (r->want_cols & 0x1DDull) != 0 : (r->want_cols & ((1ull << n_string_cols(r->format)) - 1)) != 0;
-            if (gz_payload && any_strings) RD_HIP(r, hipMemcpyAsync(gz_payload->p, d_input, n, hipMemcpyDeviceToHost, r->stream));
+            if (gz_payload && any_strings && !gz_mirror) RD_HIP(r, hipMemcpyAsync(gz_payload->p, d_input, n, hipMemcpyDeviceToHost, r->stream));
+            if (gz_mirror && gz_front) RD_HIP(r, hipMemcpyAsync(const_cast<uint8_t *>(h), d_input, gz_front, hipMemcpyDeviceToHost, r->stream));
             b->n_rows = k;
             const int ns = n_string_cols(r->format);
+            // compact: the selected string columns' out-of-line bytes, closed up per column into ONE side buffer
+            struct SideCol {
+                uint64_t *d_goff = nullptr;
+                uint64_t total = 0, off = 0;
+            } side[9];
+            struct SideScratch {  // pooled device scratch of this batch's side buffer
+                int dev;
+                hipStream_t st;
+                std::vector<std::pair<void *, size_t>> blocks;
+                void *take(size_t n) {
+                    void *p = dev_pool()->take(dev, n);
+                    if (p) blocks.emplace_back(p, n);
+                    return p;
+                }
+                ~SideScratch() {
+                    if (!blocks.empty()) (void)hipStreamSynchronize(st);  // (an early return: kernels may still read them)
+                    for (auto &bl : blocks) dev_pool()->give(dev, bl.first, bl.second);
+                }
+            } side_scratch{r->device, r->stream, {}};
+            uint8_t *h_side = nullptr, *d_side = nullptr;
+            if (compact) {
+                namespace ea = exg::arrow;
+                uint64_t *d_tmp = (uint64_t *)side_scratch.take((ea::scan_tmp_entries(k) + 2) * 8);
+                if (!d_tmp) return fail(r, EXG_E_HIP, "out of device memory");
+                for (int c = 0; c < ns; c++) {
+                    if (!r->want(c) || (r->format == EXG_FMT_VCF && c != 0 && c != 3)) continue;
+                    if (!(side[c].d_goff = (uint64_t *)side_scratch.take((k + 2) * 8))) return fail(r, EXG_E_HIP, "out of device memory");
+                    const ea::StrCol sc{(const exg_string_t *)r->d_cols[c], (const uint8_t *)d_input, (uint64_t)(uintptr_t)h};
+                    ea::payload_goff_from_col(sc, row_map, k, side[c].d_goff, d_tmp, r->stream);
+                    RD_HIP(r, hipMemcpyAsync(&side[c].total, side[c].d_goff + k, 8, hipMemcpyDeviceToHost, r->stream));
+                }
+                RD_HIP(r, hipStreamSynchronize(r->stream));
+                uint64_t side_total = 0;
+                for (int c = 0; c < ns; c++) side[c].off = side_total, side_total += (side[c].total + 15) & ~15ull;
+                if (side_total) {
+                    if (!(h_side = (uint8_t *)b->host.alloc(side_total + 64))) return fail(r, EXG_E_HIP, "out of pinned host memory");
+                    const uint32_t big_cap = (uint32_t)(side_total / 8192 + 1);
+                    uint32_t *d_big = (uint32_t *)side_scratch.take(4 * ((size_t)big_cap + 1));
+                    if (!(d_side = (uint8_t *)side_scratch.take(side_total + 64)) || !d_big) return fail(r, EXG_E_HIP, "out of device memory");
+                    for (int c = 0; c < ns; c++) {
+                        if (!side[c].d_goff || !side[c].total) continue;
+                        const ea::StrCol sc{(const exg_string_t *)r->d_cols[c], (const uint8_t *)d_input, (uint64_t)(uintptr_t)h};
+                        ea::payload_copy_from_col(sc, row_map, k, side[c].d_goff, d_side + side[c].off, d_big, big_cap, r->stream);
+                    }
+                    RD_HIP(r, hipMemcpyAsync(h_side, d_side, side_total, hipMemcpyDeviceToHost, r->stream));
+                }
+            }
             // schema order (exg_schema_of): VCF exposes parsed POS / QUAL in place of their raw text
             b->n_cols = ns;
             const size_t vw = (size_t)((k + 63) / 64) * 8;
@@ -1019,7 +1107,13 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
                 if (r->format == EXG_FMT_VCF && c == 5) src = r->d_qual, es = 4;
                 b->elem[c] = es;
                 if (!(b->cols[c] = b->host.alloc(k * es))) return fail(r, EXG_E_HIP, "out of pinned host memory");
-                if (row_map) {
+                if (compact && es == 16 && side[c].d_goff) {
+                    // (gathers through the row map itself; in place without one: the column is the scan's scratch from here on)
+                    void *dst = row_map ? r->d_gather : r->d_cols[c];
+                    exg::arrow::repoint_strings((const exg_string_t *)r->d_cols[c], row_map, k, side[c].d_goff, (uint64_t)(uintptr_t)(h_side + side[c].off),
+                                                (exg_string_t *)dst, r->stream);
+                    src = dst;
+                } else if (row_map) {
                     if (es == 16)
                         exg::arrow::gather_u128(src, row_map, k, r->d_gather, r->stream);
                     else if (es == 8)
@@ -1056,7 +1150,12 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             }
             if (r->format == EXG_FMT_FASTA && res.payload_bytes && r->want(2))
                 RD_HIP(r, hipMemcpyAsync(b->payload, r->d_payload, res.payload_bytes, hipMemcpyDeviceToHost, r->stream));
+            const double t_cols = now_s();
             RD_HIP(r, hipStreamSynchronize(r->stream));
+            TRACE("wait(columns -> host)", t_cols);
+            const double t_mir = now_s();
+            if (gz_mirror) RD_HIP(r, hipEventSynchronize(gz_mirror->ev));  // the segment's own bytes have arrived
+            if (gz_mirror) TRACE("wait(host mirror of the segment)", t_mir);
             r->host_hint = b->host.total + b->host.total / 8 + (1u << 20);
             b->seq = r->batch_seq++;
             r->batch = b;

@@ -21,17 +21,53 @@ void SegmentSink::set_mark(int id, uint64_t pos) {
     src->mark_set_[id] = true;
     src->cv_.notify_all();
 }
+// the segment's own bytes [start, hi) begin to travel to the host (best effort: without pinned memory, a stream or an event the
+// consumer copies them itself, as it does for every segment that has no mirror)
+static void start_mirror(DecodedSource *src, int device, hipStream_t *d2h, Segment &s) {
+    if (s.hi <= s.start || s.mirror) return;
+    if (!*d2h && stream_pool()->take(device, d2h) != hipSuccess) {
+        (void)hipGetLastError();
+        *d2h = nullptr;
+        return;
+    }
+    auto m = std::make_shared<HostMirror>();
+    m->blk = std::make_shared<PinnedBlock>();
+    size_t cap = (size_t)((int64_t)s.hi - s.org) + 64;
+    m->blk->p = global_pool()->take(&cap);
+    if (!m->blk->p) return;
+    m->blk->cap = cap;
+    m->blk->pooled = true;
+    m->blk->n = cap;
+    m->from = s.start;
+    m->hi = s.hi;
+    if (hipEventCreateWithFlags(&m->ev, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        m->ev = nullptr;
+        return;
+    }
+    char *dst = (char *)m->blk->p + ((int64_t)s.start - s.org);
+    if (hipMemcpyAsync(dst, s.at(s.start), s.hi - s.start, hipMemcpyDeviceToHost, *d2h) != hipSuccess || hipEventRecord(m->ev, *d2h) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(*d2h);
+        return;  // (m's destructor waits for whatever was enqueued)
+    }
+    s.mirror = std::move(m);
+}
+
 bool SegmentSink::push(Segment &&s) {
+    if (src->mirror_wanted_.load(std::memory_order_acquire)) start_mirror(src, src->device_, &src->d2h_stream_, s);
     std::unique_lock<std::mutex> lk(src->mu_);
     src->cv_.wait(lk, [&] { return src->queue_.size() < src->max_queued_ || src->closed_; });
     if (src->closed_) {
         lk.unlock();
+        s.mirror.reset();  // (waits for its copy: the device block goes back to the pool)
         give(s.buf, s.cap);
         s.buf = nullptr;
         return false;
     }
     src->queue_.push_back(s);
     s.buf = nullptr;
+    s.mirror.reset();
     src->cv_.notify_all();
     return true;
 }
@@ -75,10 +111,22 @@ DecodedSource::~DecodedSource() {
     if (have_cur_) free_segment(cur_);
     for (Segment &s : queue_) free_segment(s);
     queue_.clear();
+    if (d2h_stream_) stream_pool()->give(device_, d2h_stream_);
+}
+
+bool DecodedSource::host_view(const uint8_t *d_at, const uint8_t **h_at, uint64_t *valid_from, std::shared_ptr<HostMirror> *keep) const {
+    if (!have_cur_ || !cur_.mirror || cur_.mirror->hi != cur_.hi) return false;
+    const int64_t off = d_at - (const uint8_t *)cur_.buf;
+    if (off < 0 || (size_t)off >= cur_.mirror->blk->cap) return false;
+    *h_at = (const uint8_t *)cur_.mirror->blk->p + off;
+    *valid_from = cur_.mirror->from;
+    *keep = cur_.mirror;
+    return true;
 }
 
 void DecodedSource::free_segment(Segment &s) {
     if (!s.buf) return;
+    s.mirror.reset();  // (the last reference here: a batch that points into the block keeps the block itself, not the mirror)
     dev_pool()->give(device_, s.buf, s.cap);
     s.buf = nullptr;
 }
@@ -189,6 +237,7 @@ int DecodedSource::acquire(uint64_t pos, uint64_t want, const uint8_t **d_pos, u
                 if (he == hipSuccess) he = hipStreamSynchronize(stream_);
                 cur_.hi = nx.hi;
                 cur_.last = nx.last;
+                cur_.mirror.reset();  // (a block of the consumer's own: it copies what it needs itself)
                 free_segment(nx);
                 n_consumed_++;
                 if (he != hipSuccess) {
@@ -219,6 +268,7 @@ int DecodedSource::acquire(uint64_t pos, uint64_t want, const uint8_t **d_pos, u
                 if (he == hipSuccess) he = hipMemsetAsync(base + carry + body, 0, 64, stream_);
                 if (he == hipSuccess) he = hipStreamSynchronize(stream_);
                 free_segment(nx);
+                nx.mirror.reset();
                 nx.buf = nb;
                 nx.cap = ncap;
                 nx.org = norg;

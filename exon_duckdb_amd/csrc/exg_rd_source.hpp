@@ -22,6 +22,26 @@
 
 namespace exg_rd {
 
+// The decoded bytes of a segment on the HOST, on their way or there (round 5).  A consumer that hands out string columns needs
+// the decoded bytes in host memory (its string_t point into them): copied behind the scan of every batch, that copy — 268 MB
+// per 256 MiB segment, 5-6 ms of the link — was a step of the consumer's own, in series with its scan, its column copies and
+// the caller's walk over the chunks.  Now the copy is issued when the producer hands the segment over, on a stream of the
+// source's own: it runs while the segment waits in the queue and while the consumer is busy with the one in front, and the
+// D2H link is kept busy back to back.  Layout: host byte x of the stream lives at blk->p + (x - org), the device block's own
+// addressing; valid for [from, hi) once `ev` has completed (bytes in front of `from` — the tail the consumer carried over
+// from the segment before — are copied by the consumer).
+struct HostMirror {
+    std::shared_ptr<PinnedBlock> blk;
+    hipEvent_t ev = nullptr;
+    uint64_t from = 0, hi = 0;
+    ~HostMirror() {
+        if (ev) {
+            (void)hipEventSynchronize(ev);  // (the block goes back to the pinned pool: no copy may still write it)
+            (void)hipEventDestroy(ev);
+        }
+    }
+};
+
 // Decoded stream bytes [lo, hi) in a pooled device block: byte x lives at buf + (x - org).  org is a multiple of 16 (and may
 // be negative), so an address is congruent to its stream offset mod 16 — a batch that begins at stream offset p is entered
 // at the 16-byte boundary below it with lead = p & 15, like a batch in an upload slot.  [lo, start) are bytes of earlier
@@ -32,6 +52,7 @@ struct Segment {
     int64_t org = 0;
     uint64_t lo = 0, start = 0, hi = 0;
     bool last = false;  // the stream ends at hi
+    std::shared_ptr<HostMirror> mirror;  // the same bytes on their way to the host (SegmentSink::push, when the consumer wants them)
     const uint8_t *at(uint64_t x) const { return (const uint8_t *)buf + ((int64_t)x - org); }
     uint64_t room_in_front() const { return (uint64_t)((int64_t)lo - org); }
     uint64_t room_behind() const {  // bytes of the block behind hi, less the 64 zero bytes that follow the last byte
@@ -86,6 +107,13 @@ public:
     bool peek_mark(int id, uint64_t *pos);
     uint64_t reserve() const { return reserve_; }
     uint64_t segments_consumed() const { return n_consumed_; }
+    // The consumer hands out string columns of this stream: from now on the producer's segments travel to the host as soon as
+    // they are handed over (HostMirror).  Segments pushed before the call have none: the consumer copies those itself.
+    void want_host_mirror() { mirror_wanted_.store(true, std::memory_order_release); }
+    // the host copy of the segment the last acquire() answered from, if it has one: *h_at = the host address of device address
+    // d_at (same offset in the block), *valid_from = the stream offset from which the mirror holds (or will hold, once
+    // (*keep)->ev has completed) the bytes; what the consumer needs in front of it, it copies itself
+    bool host_view(const uint8_t *d_at, const uint8_t **h_at, uint64_t *valid_from, std::shared_ptr<HostMirror> *keep) const;
 
 private:
     friend struct SegmentSink;
@@ -112,6 +140,8 @@ private:
     uint64_t private_p0_ = ~0ull;  // where the tail began that last moved into a block of its own (acquire)
     bool error_deferred_ = false;  // the producer's error was met while bytes in front of it were still to be handed out
     uint64_t n_consumed_ = 0;
+    std::atomic<bool> mirror_wanted_{false};
+    hipStream_t d2h_stream_ = nullptr;  // the mirrors' copies (made by the first push that wants one; the producer's thread)
 };
 
 // exg_rd_gzip.cpp: file bytes [c_begin, c_end) of fd are gzip members (BGZF or not, any mixture); `target` = decoded bytes per
