@@ -194,6 +194,7 @@ TEST_SIGNATURES = {
     "exon_tf_expect_vcf_file": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "exon_tf_filter_explain": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
     "exon_tf_vcf_header_explain": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
+    "exon_tf_link_probe": (C.c_int, [C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
     "exon_tf_host_pipeline_probe": (C.c_double, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]),
     "exon_tf_host_zero_bounce_probe": (C.c_double, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_double)]),
 }

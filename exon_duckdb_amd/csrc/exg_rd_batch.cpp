@@ -600,6 +600,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             const double t_acq = now_s();
             int arc = r->src->acquire(src_pos, ask + shard_halo, &src_at, &avail, &src_eof, &msg);
             TRACE("acquire(decoded segment)", t_acq);
+            trace_at("C acquired", r->n_batches);
             if (arc) return fail(r, arc, msg + (msg.find(r->files[r->file_idx - 1]) == std::string::npos ? " in '" + r->files[r->file_idx - 1] + "'" : ""));
             r->n_segments = r->src->segments_consumed() + 1;
             if (avail <= shard_halo && src_eof) {  // nothing behind file_pos: the stream has ended
@@ -1156,6 +1157,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             const double t_mir = now_s();
             if (gz_mirror) RD_HIP(r, hipEventSynchronize(gz_mirror->ev));  // the segment's own bytes have arrived
             if (gz_mirror) TRACE("wait(host mirror of the segment)", t_mir);
+            trace_at("C batch-done", r->n_batches);
             r->host_hint = b->host.total + b->host.total / 8 + (1u << 20);
             b->seq = r->batch_seq++;
             r->batch = b;

@@ -237,6 +237,7 @@ int GzipProducer::crc_of(const void *d, uint64_t n, hipStream_t st, uint32_t *cr
 // ---- BGZF: windows of members, up to three in flight ----------------------------------------------------------------
 int GzipProducer::bgzf_issue(SegmentSink &sink, Lane &l, bool *not_bgzf, std::string *err) {
     TraceRange range("exg: bgzf window (pread + h2d + inflate + crc32 enqueue)");
+    trace_at("P issue-begin", n_members_);
     *not_bgzf = false;
     l.k = 0;
     marks(sink);
@@ -340,6 +341,7 @@ int GzipProducer::bgzf_issue(SegmentSink &sink, Lane &l, bool *not_bgzf, std::st
     c_pos_ = a0 + rel;
     d_pos_ += out;
     l.seg.last = c_pos_ >= c_end_;
+    trace_at(have ? "P issue-end(read ahead)" : "P issue-end(read now)", n_members_);
     return EXG_OK;
 }
 
@@ -431,7 +433,9 @@ int GzipProducer::bgzf_run(SegmentSink &sink, std::string *err) {
         if (inflight.empty()) break;
         Lane &l = *lanes_[inflight.front()];
         std::string e2;
+        trace_at("P finish-wait", l.first_member);
         const int frc = bgzf_finish(l, &e2);
+        trace_at("P finished", l.first_member);
         if (frc) {
             drain();
             *err = e2;
@@ -443,6 +447,7 @@ int GzipProducer::bgzf_run(SegmentSink &sink, std::string *err) {
             drain();
             return EXG_OK;  // the consumer is gone
         }
+        trace_at("P pushed", l.first_member);
         read_ahead();
         if (c_pos_ >= c_end_ && inflight.empty()) break;
     }

@@ -40,6 +40,15 @@ inline bool trace_on() {
         if (::exg_rd::trace_on()) fprintf(stderr, "[exg] %-22s %.1f ms\n", label, (::exg_rd::now_s() - (t0)) * 1e3); \
     } while (0)
 
+// EXG_TRACE=2: absolute timestamps (ms since the process's first such line) of the producer's and the consumer's steps, one
+// line each — what a pipeline's bubbles are read from
+inline void trace_at(const char *what, uint64_t idx) {
+    static const int lvl = getenv("EXG_TRACE") ? atoi(getenv("EXG_TRACE")) : 0;
+    if (lvl < 2) return;
+    static const double t0 = now_s();
+    fprintf(stderr, "[exg@] %9.2f %s %llu\n", (now_s() - t0) * 1e3, what, (unsigned long long)idx);
+}
+
 // roctx ranges around the reader's stages (upload, inflate / decode, scan, columns back) so that a rocprofiler timeline
 // (rocprofv3 --marker-trace) of a query is readable (the reference has no tracing of its own).  The marker
 // library is looked up at run time (librocprofiler-sdk-roctx.so, ROCm's): the product does not link against a profiler; without

@@ -181,7 +181,7 @@ exg_reader::~exg_reader() {
     for (int k = 0; k < 2; k++)
         if (up_done_of[k]) (void)hipEventDestroy(up_done_of[k]);
     exg_rd::stream_pool()->give(device, up_stream);
-    exg_rd::stream_pool()->give(device, stream);
+    exg_rd::stream_pool()->give(device, stream, /*high=*/getenv("EXG_NO_SCAN_PRIORITY") == nullptr);
 }
 
 namespace exg_rd {

@@ -85,7 +85,7 @@ extern "C" int exg_open(const exg_open_args *args, exg_reader **out) {
         return EXG_E_INVALID_ARG;
     }
     DeviceGuard guard(r->device);
-    hipError_t he = exg_rd::stream_pool()->take(r->device, &r->stream);
+    hipError_t he = exg_rd::stream_pool()->take(r->device, &r->stream, /*high=*/getenv("EXG_NO_SCAN_PRIORITY") == nullptr);
     if (he != hipSuccess) {
         exg::set_error("cannot initialise device %d: %s", r->device, hipGetErrorString(he));
         return EXG_E_HIP;

@@ -86,26 +86,38 @@ inline std::shared_ptr<BlockPool> global_pool() {
 // file needs two: they are recycled process-wide, per device; a stream goes back synchronised.
 struct StreamPool {
     std::mutex mu;
-    std::vector<std::pair<int, hipStream_t>> free_streams;
-    hipError_t take(int dev, hipStream_t *out) {
+    std::vector<std::pair<int, hipStream_t>> free_streams;  // first: device, or kHigh + device for a high-priority stream
+    static constexpr int kHigh = 1 << 16;
+    // high: the stream of a reader's SCAN.  A compressed input keeps the chip full of decoder wavefronts that live for
+    // milliseconds (a wavefront per gzip member); the scan of the batch in front of them is 0.1 ms of work that the consumer —
+    // and everything behind it: the column copies, the chunks — waits for: its workgroups go first when slots free up.
+    hipError_t take(int dev, hipStream_t *out, bool high = false) {
+        const int key = (high ? kHigh : 0) + dev;
         {
             std::lock_guard<std::mutex> g(mu);
             for (size_t i = 0; i < free_streams.size(); i++)
-                if (free_streams[i].first == dev) {
+                if (free_streams[i].first == key) {
                     *out = free_streams[i].second;
                     free_streams.erase(free_streams.begin() + (long)i);
                     return hipSuccess;
                 }
         }
         DeviceGuard g(dev);
+        if (high) {
+            int least = 0, greatest = 0;
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least &&
+                hipStreamCreateWithPriority(out, hipStreamNonBlocking, greatest) == hipSuccess)
+                return hipSuccess;
+            (void)hipGetLastError();
+        }
         return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
     }
-    void give(int dev, hipStream_t s) {
+    void give(int dev, hipStream_t s, bool high = false) {
         if (!s) return;
         (void)hipStreamSynchronize(s);
         std::lock_guard<std::mutex> g(mu);
         if (free_streams.size() < 32) {
-            free_streams.emplace_back(dev, s);
+            free_streams.emplace_back((high ? kHigh : 0) + dev, s);
             return;
         }
         (void)hipStreamDestroy(s);

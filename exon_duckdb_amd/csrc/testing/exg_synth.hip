@@ -290,3 +290,68 @@ extern "C" int exg_synth_fastq(void *d_out, uint64_t file_offset, uint64_t n_byt
     EXG_HIP_CHECK(hipGetLastError());
     return EXG_OK;
 }
+
+// ---- the host link, each way and both ways at once (bench.py `pcie_link`, tools/duplex_probe.py) -----------------------------
+// out[0] H2D by hipMemcpyAsync (SDMA) alone, out[1] D2H by hipMemcpyAsync alone, out[2] both at once (aggregate bytes / s),
+// out[3] D2H by a copy KERNEL alone (16 B per lane stores into the pinned block, which is mapped into the device's address space),
+// out[4] H2D by hipMemcpyAsync + D2H by the kernel at once (aggregate), out[5] two D2H hipMemcpyAsync at once (aggregate).
+namespace exg {
+typedef uint32_t copy_v4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_copy16(const copy_v4 *__restrict__ src, copy_v4 *__restrict__ dst, uint64_t n16) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(&src[i]), &dst[i]);
+}
+}  // namespace exg
+extern "C" int exon_tf_link_probe(int device, uint64_t bytes, int copy_blocks, double *out) {
+    if (!out || bytes < (1u << 20)) return EXG_E_INVALID_ARG;
+    if (hipSetDevice(device) != hipSuccess) return EXG_E_HIP;
+    void *h_up = nullptr, *h_dn = nullptr, *h_dn2 = nullptr, *d_up = nullptr, *d_dn = nullptr, *d_dn2 = nullptr;
+    hipStream_t s1 = nullptr, s2 = nullptr;
+    int rc = EXG_E_HIP;
+    auto now = [] {
+        struct timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return ts.tv_sec + ts.tv_nsec * 1e-9;
+    };
+    do {
+        if (hipHostMalloc(&h_up, bytes, hipHostMallocDefault) != hipSuccess || hipHostMalloc(&h_dn, bytes, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc(&h_dn2, bytes, hipHostMallocDefault) != hipSuccess)
+            break;
+        if (hipMalloc(&d_up, bytes) != hipSuccess || hipMalloc(&d_dn, bytes) != hipSuccess || hipMalloc(&d_dn2, bytes) != hipSuccess) break;
+        if (hipStreamCreateWithFlags(&s1, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) break;
+        memset(h_up, 1, bytes);
+        (void)hipMemset(d_dn, 2, bytes);
+        (void)hipMemset(d_dn2, 3, bytes);
+        const uint64_t n16 = bytes / 16;
+        const int grid = copy_blocks > 0 ? copy_blocks : 256;
+        auto up = [&] { (void)hipMemcpyAsync(d_up, h_up, bytes, hipMemcpyHostToDevice, s1); };
+        auto dn = [&] { (void)hipMemcpyAsync(h_dn, d_dn, bytes, hipMemcpyDeviceToHost, s2); };
+        auto dn2 = [&] { (void)hipMemcpyAsync(h_dn2, d_dn2, bytes, hipMemcpyDeviceToHost, s1); };
+        auto dnk = [&] { hipLaunchKernelGGL(exg::k_copy16, dim3(grid), dim3(256), 0, s2, (const exg::copy_v4 *)d_dn, (exg::copy_v4 *)h_dn, n16); };
+        auto best = [&](auto fn, double moved) {
+            double b = 1e30;
+            for (int r = 0; r < 4; r++) {
+                (void)hipDeviceSynchronize();
+                const double t0 = now();
+                fn();
+                (void)hipDeviceSynchronize();
+                b = std::min(b, now() - t0);
+            }
+            return moved / b;
+        };
+        out[0] = best([&] { up(); }, (double)bytes);
+        out[1] = best([&] { dn(); }, (double)bytes);
+        out[2] = best([&] { up(); dn(); }, 2.0 * bytes);
+        out[3] = best([&] { dnk(); }, (double)bytes);
+        out[4] = best([&] { up(); dnk(); }, 2.0 * bytes);
+        out[5] = best([&] { dn(); dn2(); }, 2.0 * bytes);
+        rc = hipGetLastError() == hipSuccess ? EXG_OK : EXG_E_HIP;
+    } while (0);
+    if (s1) (void)hipStreamDestroy(s1);
+    if (s2) (void)hipStreamDestroy(s2);
+    for (void *p : {d_up, d_dn, d_dn2})
+        if (p) (void)hipFree(p);
+    for (void *p : {h_up, h_dn, h_dn2})
+        if (p) (void)hipHostFree(p);
+    return rc;
+}
