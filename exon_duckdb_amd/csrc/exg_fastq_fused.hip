@@ -226,9 +226,10 @@ struct FastqFormat {
 #define EXG_FASTQ_NLCAP 512
 #endif
     static constexpr int kNlCap = EXG_FASTQ_NLCAP;  // 197 lines per half for 150 bp reads
-    static constexpr bool kTabMap = false;
+    static constexpr bool kTabMapLean = false, kTabMapFull = false;
     static constexpr bool kBarriers = true;   // (exg_fused_core.hpp opaque: its lean scan spills without them)
     static constexpr int kHalves = kFastqHalves;
+    static constexpr int kHalvesFull = kHalves;
     static constexpr int kMinWavesPerSimd = 6;  // 80 VGPRs, no scratch: 6 x 48 KiB in flight per CU
 #ifndef EXG_FASTQ_WAVES_FULL
 #define EXG_FASTQ_WAVES_FULL 5

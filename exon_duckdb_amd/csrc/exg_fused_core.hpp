@@ -18,7 +18,8 @@
 //   F::write_far(...)                     (inside emit_half) the ONE record per half that begins before the window: a FarRec
 //                                         for the k_*_far kernel behind this one (exg_fastq_ws.hpp) — any record length stays
 //                                         on this single pass over the input
-//   F::kTabMap                            also keep a '\t' bitmap of every half (VCF)
+//   F::kTabMapLean / kTabMapFull          also keep a '\t' bitmap of every half (VCF's lean scan: short lines, every byte lies within 64 bytes of a
+//                                         line start; not its any-shape scan: on wide lines only the first nine tabs of a line are ever looked at)
 //   F::kHalves                            16 KiB halves per workgroup (bytes waiting in registers: 16 VGPRs each)
 //   F::kMinWavesPerSimd                   occupancy the register allocator must respect (FASTQ lean scan: 6 = six workgroups per CU at
 //                                         80 VGPRs and 24.7 KiB of LDS each; VCF: 5; the any-shape instances one less)
@@ -53,6 +54,7 @@ static constexpr unsigned long long kVal = (1ull << 48) - 1;
 template <int NL, int H, bool TABS = false>
 struct FusedLdsT {
     static constexpr int kNlCap = NL;
+    static constexpr bool kHasTabs = TABS;
     // TABS (VCF): '\t' mask of every 16-byte chunk next to the '\n' one; a line's first eight tabs are then eight
     // bit pops out of one funnel-shifted 64-bit word instead of a SWAR search over the line's bytes.  Rows carry
     // 8 bytes of slack so that the word after a line's last one can always be read.
@@ -384,9 +386,11 @@ template <class F, int kMode>
 __global__ __launch_bounds__(kThreads, kMode == kLean ? F::kMinWavesPerSimd : kMode == kFullPrimary ? F::kMinWavesPerSimdFull : F::kMinWavesPerSimdRedo) void k_fused(
     typename F::Dev a, unsigned int *__restrict__ tileA, unsigned long long *__restrict__ tileP, unsigned long long *__restrict__ tile_qend,
     ScanWsHeader *hdr, uint32_t n_super) {
-    using FusedLds = FusedLdsT<F::kNlCap, F::kHalves, F::kTabMap>;
+    // (the any-shape scan that runs ALONE may cut its super-tiles differently from the lean scan and its redo run, which share
+    // tile_redo: every per-half / per-super-tile array of the workspace is sized by 16 KiB tiles)
+    constexpr int kHalves = kMode == kFullPrimary ? F::kHalvesFull : F::kHalves;
+    using FusedLds = FusedLdsT<F::kNlCap, kHalves, (kMode == kLean ? F::kTabMapLean : F::kTabMapFull)>;
     constexpr int kNlCap = F::kNlCap;
-    constexpr int kHalves = F::kHalves;
     constexpr int kSuper = kTile * kHalves;
     constexpr bool kFull = kMode != kLean;
     constexpr bool kB = F::kBarriers;
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(kThreads, kMode == kLean ? F::kMinWavesPerSimd : kM
         st = blockIdx.x;
     } else {
         if (blockIdx.x == 0) {  // the scanner: one wave, no tile
-            if (wave == 0 && !(dev_mode >= 1 && dev_mode <= 3)) scanner_wave<F::kHalves * kTile>(a.d_in, a.n_bytes, tileA, tileP, n_super, lane);
+            if (wave == 0 && !(dev_mode >= 1 && dev_mode <= 3)) scanner_wave<kHalves * kTile>(a.d_in, a.n_bytes, tileA, tileP, n_super, lane);
             return;
         }
         st = blockIdx.x - 1;
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(kThreads, kMode == kLean ? F::kMinWavesPerSimd : kM
             if (rem < 16) mj &= rem <= 0 ? 0u : ((1u << rem) - 1u);
         }
         s.bitmap[j / kRows][(j % kRows) * kThreads + tid] = (uint16_t)mj;
-        if constexpr (F::kTabMap) s.tabmap[j / kRows][(j % kRows) * kThreads + tid] = (uint16_t)match16(v[j], 0x09090909u);
+        if constexpr (FusedLds::kHasTabs) s.tabmap[j / kRows][(j % kRows) * kThreads + tid] = (uint16_t)match16(v[j], 0x09090909u);
         cnt += __popc(mj);
     }
     hi &= 0x80808080u;

@@ -16,6 +16,8 @@
 //     path of inputs with non-ASCII bytes.
 // Header lines (leading '#') are found by the host and passed as `lead`: lines that end before
 // `lead` are not rows.
+#include <stdlib.h>
+
 #include "exg_fused_core.hpp"
 #include "exg_lines.hpp"
 
@@ -84,11 +86,9 @@ __device__ __forceinline__ VcfRowInfo vcf_line(const Src &src, int s, int e, con
             }
         }
     }
-    // otherwise (line starting in the window, or long with few tabs in front; general path): 64 bytes at a time
+    // otherwise (no map: the any-shape scan; a line starting in the window, or long with few tabs in front; general path): 64 bytes at a time
     for (int base = s; !have_tabs && base < e && found < 8; base += 64) {
-        unsigned long long bits = 0;
-#pragma unroll
-        for (int q = 0; q < 16; q++) bits |= (unsigned long long)nib4(match4(src.u32(base + 4 * q), 0x09090909u)) << (4 * q);
+        unsigned long long bits = src.tabs64(base);
         int rem = e - base;
         if (rem < 64) bits &= (1ull << rem) - 1ull;
         while (bits && found < 8) {
@@ -132,14 +132,52 @@ __device__ __forceinline__ VcfRowInfo vcf_line(const Src &src, int s, int e, con
     }
     r.rest_valid = found == 8;
     if (store) {
+#ifdef EXG_DEV_PROBE
+        if (((a.flags >> 8) & 15u) != 13) {
+#endif
         if (a.d_pos) a.d_pos[out] = pos_v;
         if (a.d_qual) a.d_qual[out] = qual_v;
+#ifdef EXG_DEV_PROBE
+        }
+#endif
         int fs = s;
+#ifdef EXG_DEV_PROBE
+        const uint32_t dm = (a.flags >> 8) & 15u;  // ablations: 7 = stores of (length, 0, 0, 0) — no string construction; 8 = construction, one store
+        if (dm == 7 || dm == 8) {
+            uint4 acc = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (dm == 7) {
+                    if (a.d_fields[k]) st_stream16(reinterpret_cast<uint4 *>(a.d_fields[k]) + out, make_uint4((uint32_t)(t[k] - fs), 0, 0, 0));
+                } else {
+                    const uint4 q = src.str(fs, (uint32_t)(t[k] - fs));
+                    acc.x ^= q.x, acc.y ^= q.y, acc.z ^= q.z, acc.w ^= q.w;
+                }
+                fs = t[k] + 1;
+            }
+            if (dm == 8 && a.d_fields[0]) st_stream16(reinterpret_cast<uint4 *>(a.d_fields[0]) + out, acc);
+            return r;
+        }
+#endif
 #pragma unroll
         for (int k = 0; k < 8; k++) {
+#ifdef EXG_DEV_PROBE
+            if (dm == 10) {
+                fs = t[k] + 1;
+                continue;  // (ablation: only the remainder's string_t)
+            }
+            if (dm == 12) {
+                if (a.d_fields[k]) reinterpret_cast<uint4 *>(a.d_fields[k])[out] = src.str(fs, (uint32_t)(t[k] - fs));  // (plain stores)
+                fs = t[k] + 1;
+                continue;
+            }
+#endif
             if (a.d_fields[k]) st_stream16(reinterpret_cast<uint4 *>(a.d_fields[k]) + out, src.str(fs, (uint32_t)(t[k] - fs)));
             fs = t[k] + 1;
         }
+#ifdef EXG_DEV_PROBE
+        if (dm == 9) return r;  // (ablation: the eight fixed fields, not the FORMAT + samples remainder)
+#endif
         if (a.d_fields[8]) {
             uint4 z = {0, 0, 0, 0};
             st_stream16(reinterpret_cast<uint4 *>(a.d_fields[8]) + out, r.rest_valid ? src.str(fs, (uint32_t)(e - fs)) : z);
@@ -196,8 +234,20 @@ struct LdsSrc {
         const lds_v3u w = *reinterpret_cast<const lds_v3u *>(s.bytes + e);
         *w0 = w.x, *w1 = w.y, *w2 = w.z;
     }
-    // tab bits of the 64 bytes starting at extended offset e (only for lines that start inside the half)
+    // '\t' mask of the 64 bytes from extended offset e on, classified here: four 16-byte reads at any alignment
+    __device__ __forceinline__ unsigned long long tabs64(int e) const {
+        typedef uint32_t lds_v4u __attribute__((ext_vector_type(4), aligned(1)));
+        unsigned long long bits = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const lds_v4u w = *reinterpret_cast<const lds_v4u *>(s.bytes + e + 16 * q);
+            bits |= (unsigned long long)match16(make_uint4(w.x, w.y, w.z, w.w), 0x09090909u) << (16 * q);
+        }
+        return bits;
+    }
+    // tab bits of the 64 bytes starting at extended offset e out of the half's map (only for lines that start inside the half)
     __device__ __forceinline__ bool tab_bits(int e, unsigned long long *out) const {
+        if (!L::kHasTabs) return false;
         const int p = e - kWin;
         if (p < 0) return false;
         const unsigned long long *w = reinterpret_cast<const unsigned long long *>(tabs) + (p >> 6);
@@ -217,7 +267,16 @@ struct VcfFormat {
     using Dev = VcfDev;
     static constexpr int kNlCap = 1024;  // short data lines are common
     static constexpr int kHalves = kVcfHalves;
-    static constexpr bool kTabMap = true;
+#ifndef EXG_VCF_HALVES_FULL
+#define EXG_VCF_HALVES_FULL 2
+#endif
+    static constexpr int kHalvesFull = EXG_VCF_HALVES_FULL;  // the any-shape scan alone (EXG_ALGO_FUSED_FULL)
+    // The lean scan (short lines: 49 bytes in BASELINE's config 3) classifies '\t' with '\n' in its single pass over the registers:
+    // every byte lies within 64 bytes of a line start, so every mask is used.  The any-shape scan — what a reader runs on
+    // cohort VCFs, lines of 400 bytes to 10 kB whose first nine tabs are all anybody looks at — does not: a line's tabs come
+    // from its first 64-byte words in LDS, read when the line is cut (LdsSrc::tabs64): 99 % of the tab classification of such
+    // a file, the 2 KiB map per half and its stores are gone (round 5: 2.04 -> TB/s on 100-sample lines)
+    static constexpr bool kTabMapLean = true, kTabMapFull = false;
     static constexpr bool kBarriers = false;  // (exg_fused_core.hpp opaque: its lean scan ran 3 % slower with them)
 #ifndef EXG_VCF_WAVES
 #define EXG_VCF_WAVES 5
@@ -237,20 +296,30 @@ struct VcfFormat {
                                                      const TileCtx &c, unsigned long long halo_nl, uint32_t dev_mode,
                                                      uint32_t lane, uint32_t wave,
                                                      unsigned long long *__restrict__ tile_qend, uint64_t tile_index) {
-        if (threadIdx.x == 0 && (c.pass_base == 0 || c.n_lines)) {  // offset just past the last line that ends in this half (0: none)
+        // (-DEXG_VCF_ROTATE: which wave takes which 64 lines rotates with the half — thread = line, so a half of wide lines has
+        // ONE busy wave and a half of short ones 1.3 passes of 256; tried in case the busy waves of a CU's workgroups shared a SIMD)
+#ifdef EXG_VCF_ROTATE
+        const uint32_t rot_w = (uint32_t)tile_index & 3u;
+#else
+        const uint32_t rot_w = 0;  // (measured, A/B in one box: rotating is 2-4 % SLOWER on wide and on short lines alike — kept as a switch)
+#endif
+        const uint32_t t_rot = (threadIdx.x - rot_w * 64u) & (uint32_t)(kThreads - 1);  // this thread's line of a pass of 256
+        unsigned long long qend_word = 0;  // (thread t_rot == 0: what it stored into tile_qend)
+        if (t_rot == 0 && (c.pass_base == 0 || c.n_lines)) {  // offset just past the last line that ends in this half (0: none)
             long long e = 0;
             if (c.n_lines) {
                 e = (long long)c.tile_off + (int)s.nlist[4 + c.n_lines - 1] - kWin + 1;
                 if ((unsigned long long)e > a.n_bytes) e = (long long)a.n_bytes;
             }
             if (c.pass_base) e |= (long long)(tile_qend[tile_index] & kFarBit);  // (a later pass keeps the first pass's mark)
-            tile_qend[tile_index] = (unsigned long long)e;
+            qend_word = (unsigned long long)e;
+            tile_qend[tile_index] = qend_word;
         }
-        if (dev_mode >= 3) return;
+        if (dev_mode == 3 || dev_mode == 4) return;
         const bool no_store = (a.flags & EXG_F_NO_STORE) != 0;
-        const LdsSrc<L> src{s, a.payload_base + c.tile_off - kWin, s.tabmap[tile_index % kHalves]};
+        const LdsSrc<L> src{s, a.payload_base + c.tile_off - kWin, s.tabmap[L::kHasTabs ? c.half : 0]};
         for (uint32_t jb = 0; jb < c.n_lines; jb += kThreads) {
-            const uint32_t j = jb + threadIdx.x;
+            const uint32_t j = jb + t_rot;
             const long long out = (long long)(c.P + j) - (long long)halo_nl;
             bool act = j < c.n_lines;
             int e1 = 0;
@@ -266,7 +335,7 @@ struct VcfFormat {
             if (act) {
                 const uint32_t q0 = s.nlist[3 + j];  // newline before the line
                 if (q0 == kNoneE) {
-                    // the line begins in front of the LDS window (only the first line of a half's first pass can: thread 0)
+                    // the line begins in front of the LDS window (only the first line of a half's first pass can: the thread with t_rot == 0)
                     if constexpr (kMode == kLean) {
                         // lean scan: the any-shape run redoes this super-tile
                         tile_redo_of<false>(tile_qend, a.n_bytes)[(uint32_t)(tile_index / kVcfHalves)] = kRedoFar;
@@ -281,12 +350,16 @@ struct VcfFormat {
                         f.out = out;
                         far_rec_of<false>(tile_qend, a.n_bytes)[tile_index] = f;
                         hdr->any_far = 1u;
-                        tile_qend[tile_index] |= kFarBit;  // (this thread stored the word above)
+                        tile_qend[tile_index] = qend_word | kFarBit;  // (this thread stored the word above: no load — a load behind
+                                                                       // the store cost a memory round trip per half of a cohort VCF)
                     }
                 } else {
                     int s0 = (int)q0 + 1;
                     if (e1 > s0 && !(c.is_eof_tile && e1 == c.lim_e) && ldb(s, e1 - 1) == '\r') e1--;
-                    VcfRowInfo r = vcf_line(src, s0, e1, a, (unsigned long long)out, !no_store && dev_mode != 2);
+#ifdef EXG_DEV_PROBE
+                    if (dev_mode == 6) continue;  // (ablation: the loop, the list reads and the validity ballots only)
+#endif
+                    VcfRowInfo r = vcf_line(src, s0, e1, a, (unsigned long long)out, !no_store && dev_mode != 2 && dev_mode != 5);
                     if constexpr (kMode != kLean) {  // noodles builds str fields: the line must be UTF-8
                         if (!r.code && c.non_ascii && !utf8_valid_lds(s, s0, e1)) r.code = EXG_PE_INVALID_UTF8;
                     }
@@ -297,7 +370,7 @@ struct VcfFormat {
                 }
             }
             if (!no_store) {
-                long long out_base = (long long)(c.P + jb + wave * 64) - (long long)halo_nl;
+                long long out_base = (long long)(c.P + jb + ((wave - rot_w) & 3u) * 64) - (long long)halo_nl;
                 unsigned long long qb = __ballot(qv), rb = __ballot(rv);
                 store_validity64(a.d_qual_valid, qb, out_base, lane);
                 store_validity64(a.d_formats_valid, rb, out_base, lane);
@@ -328,6 +401,12 @@ struct GlobalSrc {
         return make_string_global(p, base + (uint64_t)(int64_t)i, len, payload_base);
     }
     __device__ __forceinline__ bool tab_bits(int, unsigned long long *) const { return false; }
+    __device__ __forceinline__ unsigned long long tabs64(int base) const {
+        unsigned long long bits = 0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) bits |= (unsigned long long)nib4(match4(u32(base + 4 * q), 0x09090909u)) << (4 * q);
+        return bits;
+    }
 };
 
 __global__ __launch_bounds__(256) void k_vcf_lines(VcfDev a, const uint64_t *__restrict__ nl_pos, ScanWsHeader *hdr,
@@ -384,11 +463,11 @@ __global__ __launch_bounds__(256) void k_vcf_lines(VcfDev a, const uint64_t *__r
 
 // The rows k_fused<VcfFormat> left out: one line per marked half (it begins in front of the half's window), read from global
 // memory like the general path reads its lines.  Runs behind k_fused on the stream.
+template <uint32_t kHalves>
 __global__ __launch_bounds__(256) void k_vcf_far(VcfDev a, const unsigned int *__restrict__ tileA, const int32_t *__restrict__ tileL,
                                                  const unsigned long long *__restrict__ tile_qend, const FarRec *__restrict__ far_rec,
                                                  ScanWsHeader *hdr, uint32_t n_halves) {
     if (!hdr->any_far) return;
-    constexpr uint32_t kHalves = VcfFormat::kHalves;
     constexpr uint64_t kSuper = (uint64_t)kHalves * kTile;
     const bool no_store = (a.flags & EXG_F_NO_STORE) != 0;
     for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n_halves; x += (uint64_t)gridDim.x * blockDim.x) {
@@ -537,8 +616,8 @@ static int run_vcf_general(const VcfDev &dev, uint8_t *ws, const FastqWsLayout &
 static int run_vcf_fused(const VcfDev &dev, uint8_t *ws, const FastqWsLayout &l, exg_scan_result *d_result,
                          hipStream_t stream, bool full) {
     ScanWsHeader *hdr = reinterpret_cast<ScanWsHeader *>(ws);
-    constexpr uint64_t kSuperBytes = (uint64_t)VcfFormat::kHalves * kTile;
-    constexpr uint32_t kHalvesHost = VcfFormat::kHalves;
+    const uint32_t kHalvesHost = full ? VcfFormat::kHalvesFull : VcfFormat::kHalves;
+    const uint64_t kSuperBytes = (uint64_t)kHalvesHost * kTile;
     uint64_t n_super64 = (dev.n_bytes + kSuperBytes - 1) / kSuperBytes;
     if (n_super64 == 0) n_super64 = 1;
     if (n_super64 > 0x7FFFFFF0ull) {
@@ -571,7 +650,10 @@ static int run_vcf_fused(const VcfDev &dev, uint8_t *ws, const FastqWsLayout &l,
     {   // the rows of lines that begin in front of their half's window (returns at once when there is none)
         const uint32_t n_halves = n_super * kHalvesHost;
         const uint32_t grid = (n_halves + 255) / 256 < 4096 ? (n_halves + 255) / 256 : 4096;
-        hipLaunchKernelGGL(k_vcf_far, dim3(grid), dim3(256), 0, stream, dev, tileA, tileL, tile_qend, far_rec, hdr, n_halves);
+        if (full)
+            hipLaunchKernelGGL(k_vcf_far<VcfFormat::kHalvesFull>, dim3(grid), dim3(256), 0, stream, dev, tileA, tileL, tile_qend, far_rec, hdr, n_halves);
+        else
+            hipLaunchKernelGGL(k_vcf_far<VcfFormat::kHalves>, dim3(grid), dim3(256), 0, stream, dev, tileA, tileL, tile_qend, far_rec, hdr, n_halves);
     }
     hipLaunchKernelGGL(k_vcf_finalize, dim3(1), dim3(256), 0, stream, dev, hdr, tile_qend, n_super * kHalvesHost,
                        (const uint64_t *)nullptr, 1, d_result, (const unsigned int *)nullptr);
@@ -605,6 +687,9 @@ extern "C" int exg_vcf_scan(const exg_vcf_scan_args *a) {
     dev.first_line_index = 0;
     dev.payload_base = a->payload_base;
     dev.flags = a->flags;
+#ifdef EXG_DEV_PROBE
+    if (const char *e = getenv("EXG_VCF_DEV_MODE")) dev.flags |= ((uint32_t)atoi(e) & 15u) << 8;  // development builds only: the core's ablations (no emission / no stores)
+#endif
     dev.pad = 0;
     for (int k = 0; k < 9; k++) dev.d_fields[k] = a->d_fields[k];
     dev.d_pos = a->d_pos;
