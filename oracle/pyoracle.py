@@ -428,3 +428,104 @@ def infer_compression(uri, compression=None):
 def replacement_scan(uri):
     r = lib().orc_replacement_scan(uri.encode())
     return r.decode() if r else None
+
+
+# ---- decoder-level rules (round 5): what a compressed input's ROWS are -----------------------------------------------------------
+# The reference hands compressed files to DataFusion 28's FileCompressionType::convert_stream -> async-compression 0.4.0 (flate2 /
+# zstd) and bgzip'ed VCFs to noodles-bgzf (rust/src/arrow_reader.rs:60-91); which of these rules those decoders follow at the pinned
+# versions is [RECALLED] or open (an async GzipDecoder without multiple_members may stop behind the FIRST member).
+# What this build does, stated here so that tools/falsify_kit.py can put it in front of a real exon build:
+#   gzip  every member of a concatenation is decoded, in order (BGZF is such a concatenation; its empty EOF member is optional);
+#         behind the last complete member only another member may follow: anything else is "invalid gzip header"; a member that
+#         ends early, or whose CRC-32 / ISIZE trailer does not match, is an error;
+#   zstd  every frame is decoded, skippable frames are skipped; bytes that begin no frame, a frame that ends early, a
+#         Content_Checksum that does not match are errors;
+#   an error is reported when the rows in front of it have been handed out (through SQL: the query fails).
+def decode_by_rule(data: bytes, compression: str):
+    """-> (decoded bytes in front of the first error, error text or None)"""
+    import zlib
+    data = bytes(data)
+    if compression == "gzip":
+        out, buf = bytearray(), data
+        if not buf:
+            return b"", None   # (an empty file has no member and no rows)
+        while buf:
+            if len(buf) < 18 or buf[0] != 0x1F or buf[1] != 0x8B or buf[2] != 8:
+                return bytes(out), "invalid gzip header"
+            d = zlib.decompressobj(31)
+            try:
+                out += d.decompress(buf)
+            except zlib.error as e:   # a bad block, a CRC-32 / ISIZE mismatch
+                return bytes(out), f"corrupt gzip stream ({e})"
+            if not d.eof:
+                return bytes(out), "truncated gzip member"
+            buf = d.unused_data
+        return bytes(out), None
+    if compression == "zstd":
+        import ctypes as CC
+        so = os.path.join(HERE, "libzstd_oracle.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-s", "-C", HERE, "libzstd_oracle.so"])
+        o = CC.CDLL(so)
+        o.zso_decompress.argtypes = [CC.c_char_p, CC.c_uint64, CC.c_void_p, CC.c_uint64, CC.POINTER(CC.c_uint64), CC.c_void_p, CC.c_uint64, CC.c_void_p]
+        cap = max(1 << 20, 64 * len(data))
+        while True:
+            buf = CC.create_string_buffer(cap + 64)
+            p = CC.c_uint64(0)
+            rc = o.zso_decompress(data, len(data), buf, cap, CC.byref(p), None, 0, None)
+            if rc == 0 or p.value < cap or cap >= (1 << 31):
+                break
+            cap *= 8   # (the output did not fit)
+        return buf.raw[:p.value], (None if rc == 0 else f"corrupt or truncated zstd stream (oracle code {rc})")
+    if compression in (None, "", "none", "uncompressed"):
+        return data, None
+    raise ValueError(compression)
+
+
+class CompressedResult:
+    """rows of a compressed input by the rules above: `table` = the parse of the bytes decoded in front of the first decoder
+    error (None when the stream could not even be opened), `error` = the decoder's or the parser's error text (None: none)"""
+
+    def __init__(self, table, typed_rows, error):
+        self.table, self.typed_rows, self.error = table, typed_rows, error
+
+
+def compressed_parse(fmt: str, data: bytes, compression: str, ext: str = None):
+    """what `read_<fmt>('file.<ext>' [, compression = ...])` returns for these file bytes.  `ext` only names the case's file
+    for the falsifiability kit (e.g. "fastq.gz"; None: <fmt> + the usual extension of the compression)"""
+    text, derr = decode_by_rule(data, compression)
+    if fmt == "fastq":
+        t = fastq_parse(text, want_string_t=False)
+    elif fmt == "fasta":
+        t = fasta_parse(text)
+    else:
+        t = vcf_parse(text, want_string_t=False)
+    typed, perr = None, None
+    if fmt == "vcf" and not t.error_code:
+        typed, bad = vcf_typed_rows(text)
+        if bad is not None:
+            perr = f"a value of row {bad} does not parse"
+    if t.error_code and derr is None:
+        perr = f"{t.error_message} (record {t.error_record})"
+    # a stream that ends in an error: the rows in front of it come first; the text cut at the error may itself end inside a
+    # record — that record's error is the decoder's, not a parse error
+    return CompressedResult(t, typed, derr or perr)
+
+
+# ---- schema rules: column names and DuckDB types of the three table functions ----------------------------------------------------
+# test_fastq_scan.test:35-41 / test_fasta_scan.test:35 / test_vcf_record_scan.test:10-19 pin the names they select and that `alt` is a
+# list, `qual` a float, `info` a struct; every other type here is [RECALLED] from exon 0.2.6's schema builders
+# (rust/src/arrow_reader.rs:116-153 is where the schema comes from) as DuckDB's Arrow import renders it.
+def schema_of(fmt: str, data: bytes = b""):
+    """-> [(column name, DuckDB type as DESCRIBE prints it)]; VCF: from the header lines of `data`"""
+    if fmt == "fastq":
+        return [(c, "VARCHAR") for c in ("name", "description", "sequence", "quality_scores")]
+    if fmt == "fasta":
+        return [(c, "VARCHAR") for c in ("id", "description", "sequence")]
+    info, fmts = vcf_header_keys(data)
+    ty = {"Integer": "INTEGER", "Float": "FLOAT", "Flag": "BOOLEAN", "String": "VARCHAR"}
+
+    def struct(keys):
+        return "STRUCT(" + ", ".join(f"{k} {ty[t]}{'[]' if is_list else ''}" for k, t, is_list in keys) + ")"
+    return [("chrom", "VARCHAR"), ("pos", "BIGINT"), ("id", "VARCHAR[]"), ("ref", "VARCHAR"), ("alt", "VARCHAR[]"), ("qual", "FLOAT"),
+            ("filter", "VARCHAR[]"), ("info", struct(info)), ("formats", struct(fmts) + "[]")]

@@ -154,11 +154,17 @@ def test_falsifiability_kit_writes_every_rule_case(tmp_path):
     kit = tmp_path / "kit"
     subprocess.check_call([sys.executable, os.path.join(root, "tools", "falsify_kit.py"), str(kit)])
     cases = json.load(open(kit / "cases.json"))
-    assert len(cases) >= 60 and {c["format"] for c in cases} == {"fastq", "fasta", "vcf"}
+    assert len(cases) >= 90 and {c["format"] for c in cases} == {"fastq", "fasta", "vcf"}
     assert all(os.path.exists(kit / c["file"]) for c in cases)
+    # round 5: decoder-level cases (the compressed file is the case) and schema cases (DESCRIBE) ride along
+    assert sum(1 for c in cases if c["file"].endswith((".gz", ".zst"))) >= 18 and sum(1 for c in cases if c.get("compression")) >= 2
+    assert sum(1 for c in cases if c.get("schema")) == 3 and "DESCRIBE SELECT * FROM read_vcf_file_records" in open(kit / "run.sh").read()
     os.makedirs(kit / "got")
     for c in cases:   # what a run.sh against a build that agrees with the oracle leaves behind
         e = json.load(open(kit / "expected" / (c["case"] + ".json")))
+        if c.get("schema"):
+            (kit / "got" / (c["case"] + ".json")).write_text(json.dumps([dict(r, null="YES", key=None, default=None, extra=None) for r in e["schema"]]))
+            continue
         if e["error"]:
             (kit / "got" / (c["case"] + ".err")).write_text("Error: ...")
         else:
@@ -170,3 +176,12 @@ def test_falsifiability_kit_writes_every_rule_case(tmp_path):
     (kit / "got" / (c["case"] + ".json")).write_text(json.dumps({"name": "id a", "description": "b  c", "sequence": "AC", "quality_scores": "!!"}) + "\n")
     res = subprocess.run([sys.executable, "compare.py"], cwd=kit, capture_output=True, text=True)
     assert res.returncode == 1 and "DIFFERENT test_fastq_split_at_first_space_only" in res.stdout
+    # ... and one whose `pos` is INTEGER, or that stops behind the first gzip member
+    c = next(c for c in cases if c.get("schema") and c["format"] == "vcf")
+    e = json.load(open(kit / "expected" / (c["case"] + ".json")))["schema"]
+    (kit / "got" / (c["case"] + ".json")).write_text(json.dumps([dict(r, column_type="INTEGER") if r["column_name"] == "pos" else r for r in e]))
+    c2 = next(c for c in cases if c["case"].startswith("gzip_every_member_of_a_concatenation_is_read_0"))
+    e2 = json.load(open(kit / "expected" / (c2["case"] + ".json")))["rows"]
+    (kit / "got" / (c2["case"] + ".json")).write_text("".join(json.dumps(r) + "\n" for r in e2[:2]))
+    res = subprocess.run([sys.executable, "compare.py"], cwd=kit, capture_output=True, text=True)
+    assert "pos: expected BIGINT, got INTEGER" in res.stdout and "DIFFERENT test_gzip_every_member_of_a_concatenation_is_read" in res.stdout

@@ -345,3 +345,134 @@ def test_quality_score_list_golden_record(oracle, golden_dir):
     q0 = b"!''*((((***+))%%%++)(%%%%).1***-+*''))**55CCF>>>>>>CCCCCCC65"   # test_fastq_scan.test:35-41
     assert entries[0].tolist() == [0, len(q0)]
     assert values[: len(q0)].tolist() == [c - 33 for c in q0]
+
+
+# ---- decoder-level rules (oracle/pyoracle.py decode_by_rule): what the ROWS of a compressed input are -------------------------------
+# [RECALLED / open]: the reference decodes through DataFusion 28 -> async-compression 0.4.0 (rust/src/arrow_reader.rs:60-91); whether
+# its GzipDecoder reads past the first member decides the first two rules.  tools/falsify_kit.py writes each
+# input as a file with these rows beside it.
+FQ_A = b"@a x\nAC\n+\n!!\n@b\nGT\n+\n##\n"
+FQ_B = b"@c y z\nTTT\n+\nIII\n"
+FA_A, FA_B = b">s1 d\nACGT\nAC\n", b">s2\nGG\n"
+
+
+def _bgzf(data, block, eof=True):
+    import struct
+    import zlib
+    out = []
+    for i in range(0, len(data), block):
+        chunk = data[i:i + block]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        d = co.compress(chunk) + co.flush()
+        out.append(b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(d) + 8 - 1)
+                   + d + struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+    return b"".join(out) + (bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000") if eof else b"")
+
+
+def _crows(r):
+    return rows(r.table)
+
+
+def test_gzip_every_member_of_a_concatenation_is_read(oracle):
+    import gzip
+    r = oracle.compressed_parse("fastq", gzip.compress(FQ_A, 6, mtime=0) + gzip.compress(FQ_B, 6, mtime=0), "gzip", "fastq.gz")
+    assert r.error is None and _crows(r) == [[b"a", b"x", b"AC", b"!!"], [b"b", None, b"GT", b"##"], [b"c", b"y z", b"TTT", b"III"]]
+    r = oracle.compressed_parse("fasta", gzip.compress(FA_A, 6, mtime=0) + gzip.compress(FA_B, 6, mtime=0), "gzip", "fasta.gz")
+    assert r.error is None and _crows(r) == [[b"s1", b"d", b"ACGTAC"], [b"s2", None, b"GG"]]
+
+
+def test_gzip_a_record_may_span_members(oracle):
+    import gzip
+    cut = FQ_A.index(b"@b") + 4   # inside record b
+    r = oracle.compressed_parse("fastq", gzip.compress(FQ_A[:cut], 6, mtime=0) + gzip.compress(FQ_A[cut:] + FQ_B, 6, mtime=0), "gzip", "fastq.gz")
+    assert r.error is None and len(_crows(r)) == 3
+
+
+def test_bgzf_is_read_member_by_member_with_or_without_its_eof_block(oracle):
+    for eof in (True, False):
+        r = oracle.compressed_parse("fastq", _bgzf(FQ_A + FQ_B, 11, eof), "gzip", "fastq.gz")
+        assert r.error is None and len(_crows(r)) == 3
+        r = oracle.compressed_parse("fasta", _bgzf(FA_A + FA_B, 7, eof), "gzip", "fasta.gz")
+        assert r.error is None and _crows(r) == [[b"s1", b"d", b"ACGTAC"], [b"s2", None, b"GG"]]
+
+
+def test_gzip_bytes_behind_the_last_member_are_an_error(oracle):
+    import gzip
+    for tail in (b"\n", b"\0" * 4, b"not gzip"):
+        r = oracle.compressed_parse("fastq", gzip.compress(FQ_A, 6, mtime=0) + tail, "gzip", "fastq.gz")
+        assert r.error == "invalid gzip header" and len(_crows(r)) == 2   # (the rows in front come first; through SQL the query fails)
+
+
+def test_gzip_truncated_member_and_wrong_trailer_are_errors(oracle):
+    import gzip
+    z = gzip.compress(FQ_A + FQ_B, 6, mtime=0)
+    assert oracle.compressed_parse("fastq", z[:-5], "gzip", "fastq.gz").error == "truncated gzip member"
+    bad = bytearray(z)
+    bad[-8] ^= 1   # CRC-32
+    assert "corrupt gzip stream" in oracle.compressed_parse("fastq", bytes(bad), "gzip", "fastq.gz").error
+    bad = bytearray(z)
+    bad[-4] ^= 1   # ISIZE
+    assert "corrupt gzip stream" in oracle.compressed_parse("fastq", bytes(bad), "gzip", "fastq.gz").error
+
+
+def test_gzip_option_on_plain_text_is_an_error(oracle):
+    # read_fastq('x.fastq', compression = 'gzip'): the option wins over the extension (rust/src/arrow_reader.rs:60-75)
+    r = oracle.compressed_parse("fastq", FQ_A, "gzip", "fastq")
+    assert r.error == "invalid gzip header" and _crows(r) == []
+
+
+def test_empty_gzip_file_and_empty_member(oracle):
+    import gzip
+    assert oracle.compressed_parse("fastq", b"", "gzip", "fastq.gz").error is None
+    r = oracle.compressed_parse("fastq", gzip.compress(b"", 6, mtime=0) + gzip.compress(FQ_B, 6, mtime=0) + gzip.compress(b"", 6, mtime=0), "gzip", "fastq.gz")
+    assert r.error is None and _crows(r) == [[b"c", b"y z", b"TTT", b"III"]]
+
+
+def test_zstd_concatenated_and_skippable_frames_are_read_through(oracle):
+    from zstd_util import compress, skippable
+    z = compress(FQ_A, 3, True) + skippable(b"index", 3) + compress(FQ_B, 19, False, content_size=False) + skippable(b"")
+    r = oracle.compressed_parse("fastq", z, "zstd", "fastq.zst")
+    assert r.error is None and len(_crows(r)) == 3
+    cut = 9
+    r = oracle.compressed_parse("fasta", compress((FA_A + FA_B)[:cut], 1) + compress((FA_A + FA_B)[cut:], 1), "zstd", "fasta.zst")
+    assert r.error is None and _crows(r) == [[b"s1", b"d", b"ACGTAC"], [b"s2", None, b"GG"]]
+
+
+def test_zstd_bytes_that_begin_no_frame_and_truncated_frames_are_errors(oracle):
+    from zstd_util import compress
+    z = compress(FQ_A + FQ_B, 3, True)
+    assert oracle.compressed_parse("fastq", z + b"tail", "zstd", "fastq.zst").error is not None
+    assert oracle.compressed_parse("fastq", z[:-2], "zstd", "fastq.zst").error is not None
+    assert oracle.compressed_parse("fastq", FQ_A, "zstd", "fastq").error is not None   # compression = 'zstd' on plain text
+
+
+def test_zstd_content_checksum_is_verified(oracle):
+    from zstd_util import compress
+    bad = bytearray(compress(FQ_A + FQ_B, 3, True))
+    bad[-1] ^= 0x40
+    assert oracle.compressed_parse("fastq", bytes(bad), "zstd", "fastq.zst").error is not None
+
+
+# ---- schema rules (oracle/pyoracle.py schema_of): names and DuckDB types — DESCRIBE SELECT * FROM read_*(...) ------------------------
+def test_schema_of_fastq_and_fasta_is_all_varchar(oracle):
+    assert oracle.schema_of("fastq", FQ_A) == [("name", "VARCHAR"), ("description", "VARCHAR"), ("sequence", "VARCHAR"), ("quality_scores", "VARCHAR")]
+    assert oracle.schema_of("fasta", FA_A) == [("id", "VARCHAR"), ("description", "VARCHAR"), ("sequence", "VARCHAR")]
+
+
+VCF_TYPES = (b"##fileformat=VCFv4.2\n##INFO=<ID=DP,Number=1,Type=Integer,Description=\"d\">\n##INFO=<ID=AF,Number=A,Type=Float,Description=\"a\">\n"
+             b"##INFO=<ID=DB,Number=0,Type=Flag,Description=\"f\">\n##INFO=<ID=ANN,Number=.,Type=String,Description=\"s\">\n"
+             b"##INFO=<ID=CH,Number=1,Type=Character,Description=\"c\">\n"
+             b"##FORMAT=<ID=GT,Number=1,Type=String,Description=\"g\">\n##FORMAT=<ID=AD,Number=R,Type=Integer,Description=\"r\">\n"
+             b"##FORMAT=<ID=GL,Number=G,Type=Float,Description=\"l\">\n"
+             b"#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\n1\t5\trs1;rs2\tA\tC,G\t3.5\tq10;s50\tDP=3;AF=0.5,0.25;DB;CH=x\tGT:AD\t0/1:3,4,5\n")
+
+
+def test_schema_of_vcf_follows_the_header(oracle):
+    assert oracle.schema_of("vcf", VCF_TYPES) == [
+        ("chrom", "VARCHAR"), ("pos", "BIGINT"), ("id", "VARCHAR[]"), ("ref", "VARCHAR"), ("alt", "VARCHAR[]"), ("qual", "FLOAT"), ("filter", "VARCHAR[]"),
+        ("info", "STRUCT(DP INTEGER, AF FLOAT[], DB BOOLEAN, ANN VARCHAR[], CH VARCHAR)"),
+        ("formats", "STRUCT(GT VARCHAR, AD INTEGER[], GL FLOAT[])[]")]
+    rows_, err = oracle.vcf_typed_rows(VCF_TYPES)
+    assert err is None and rows_[0]["id"] == ["rs1", "rs2"] and rows_[0]["alt"] == ["C", "G"] and rows_[0]["filter"] == ["q10", "s50"]
+    assert rows_[0]["info"] == {"DP": 3, "AF": [0.5, 0.25], "DB": True, "ANN": None, "CH": "x"}
+    assert rows_[0]["formats"] == [{"GT": "0/1", "AD": [3, 4, 5], "GL": None}]
