@@ -435,7 +435,8 @@ def replacement_scan(uri):
 # zstd) and bgzip'ed VCFs to noodles-bgzf (rust/src/arrow_reader.rs:60-91); which of these rules those decoders follow at the pinned
 # versions is [RECALLED] or open (an async GzipDecoder without multiple_members may stop behind the FIRST member).
 # What this build does, stated here so that tools/falsify_kit.py can put it in front of a real exon build:
-#   gzip  every member of a concatenation is decoded, in order (BGZF is such a concatenation; its empty EOF member is optional);
+#   gzip  every member of a concatenation is decoded, in order (BGZF is such a concatenation; its empty EOF member is optional;
+#         a file of zero bytes holds no member: an error);
 #         behind the last complete member only another member may follow: anything else is "invalid gzip header"; a member that
 #         ends early, or whose CRC-32 / ISIZE trailer does not match, is an error;
 #   zstd  every frame is decoded, skippable frames are skipped; bytes that begin no frame, a frame that ends early, a
@@ -448,7 +449,7 @@ def decode_by_rule(data: bytes, compression: str):
     if compression == "gzip":
         out, buf = bytearray(), data
         if not buf:
-            return b"", None   # (an empty file has no member and no rows)
+            return b"", "empty gzip file"   # (no member at all: what `gzip -t` calls an unexpected end of file)
         while buf:
             if len(buf) < 18 or buf[0] != 0x1F or buf[1] != 0x8B or buf[2] != 8:
                 return bytes(out), "invalid gzip header"

@@ -423,7 +423,7 @@ def test_gzip_option_on_plain_text_is_an_error(oracle):
 
 def test_empty_gzip_file_and_empty_member(oracle):
     import gzip
-    assert oracle.compressed_parse("fastq", b"", "gzip", "fastq.gz").error is None
+    assert oracle.compressed_parse("fastq", b"", "gzip", "fastq.gz").error == "empty gzip file"   # (zero bytes: no member at all)
     r = oracle.compressed_parse("fastq", gzip.compress(b"", 6, mtime=0) + gzip.compress(FQ_B, 6, mtime=0) + gzip.compress(b"", 6, mtime=0), "gzip", "fastq.gz")
     assert r.error is None and _crows(r) == [[b"c", b"y z", b"TTT", b"III"]]
 
