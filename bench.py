@@ -192,6 +192,9 @@ def link_rates(torch, n=1 << 30, reps=3):
     return out[0], out[1]
 
 
+CHUNKS_HINT = 1 << 63  # exg_open_args.columns bit 63 (EXG_COLUMNS_CHUNKS): chunks will be pulled — what the table function says at init_global
+
+
 def open_reader(lib, path, fmt, shard=(0, 1), device_index=0, columns=0):
     from exon_duckdb_amd import abi
     lib.exg_open.argtypes = [C.POINTER(abi.OpenArgs), C.POINTER(C.c_void_p)]
@@ -219,7 +222,7 @@ def reader_chunks(lib, path, fmt, shard=(0, 1), device_index=0, columns=0):
     """every DataChunk pulled and released by a C loop of the scaffolding library (no interpreter between the chunks)"""
     from exon_duckdb_amd import load_test_library
     tl = load_test_library()
-    r = open_reader(lib, path, fmt, shard, device_index, columns)
+    r = open_reader(lib, path, fmt, shard, device_index, columns | CHUNKS_HINT)
     rows, chunks = C.c_uint64(0), C.c_uint64(0)
     t0 = time.perf_counter()
     rc = tl.exon_tf_drain_chunks(r, C.byref(rows), C.byref(chunks))
@@ -235,7 +238,7 @@ def reader_digest(lib, path, fmt, want_seq_len=0, columns=0, shard=(0, 1), devic
     A shard's rows are rows [first_row, first_row + n) of the file: the shards' digests add up to the file's."""
     from exon_duckdb_amd import load_test_library
     tl = load_test_library()
-    r = open_reader(lib, path, fmt, shard, device_index, columns)
+    r = open_reader(lib, path, fmt, shard, device_index, columns | CHUNKS_HINT)
     rows, chunks, dg, bad = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
     rc = tl.exon_tf_drain_digest_from(r, 1 if fmt == "vcf" else 0, want_seq_len, first_row, C.byref(rows), C.byref(chunks), C.byref(dg), C.byref(bad))
     assert rc == 0, lib.exg_last_error_message()

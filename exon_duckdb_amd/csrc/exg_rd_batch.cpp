@@ -166,6 +166,23 @@ static int plan_bgzf_shard(exg_reader *r, const std::string &path, uint64_t n, u
     return EXG_OK;
 }
 
+// How the bytes a decoded input's strings point into reach the host when chunks are handed out (never for COUNT(*) or the Arrow
+// stream): kPayloadCompact — a projection that leaves payload-bearing columns out: the selected columns' out-of-line strings are
+// closed up into a side buffer behind the scan; kPayloadMirror — the decoded segments themselves, sent ahead by the producer
+// (HostMirror; a segment without one is copied behind its scan); kPayloadNone — no string column is selected, or FASTA (its
+// sequences are compacted anyway, its definition lines travel with the batch).
+enum PayloadRoute { kPayloadNone, kPayloadCompact, kPayloadMirror };
+static PayloadRoute payload_route(const exg_reader *r) {
+    if (r->format == EXG_FMT_FASTA) return kPayloadNone;
+    const uint64_t strs = r->format == EXG_FMT_VCF ? 0x1DDull : 0xFull, nested = r->format == EXG_FMT_VCF ? 0x1D4ull : 0ull;
+    const uint64_t sel = r->want_cols & strs;
+    if (!sel) return kPayloadNone;
+    static const bool no_compact = getenv("EXG_NO_PAYLOAD_COMPACT") != nullptr;
+    if (!no_compact && sel != strs && !(sel & nested)) return kPayloadCompact;
+    static const bool no_mirror = getenv("EXG_NO_HOST_MIRROR") != nullptr;  // (A/B and tests: the copy behind the scan)
+    return no_mirror ? kPayloadNone : kPayloadMirror;
+}
+
 static int open_source(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const std::string &path, uint64_t n) {
     const int fd = r->fd_keep->fd;
     const uint64_t reserve = source_reserve(r), target = r->device_batch_bytes;
@@ -175,7 +192,9 @@ static int open_source(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const s
     auto make = [&](uint64_t c_begin, uint64_t c_end, bool bgzf_only, const uint64_t *marks) {
         std::unique_ptr<SegmentProducer> prod = r->compression == kGzip ? make_gzip_producer(r, fd, c_begin, c_end, target, path, bgzf_only, reserve, marks)
                                                                         : make_zstd_producer(r, fd, n, c_begin, c_end, target, path, reserve, marks);
-        return std::unique_ptr<DecodedSource>(new DecodedSource(r->device, r->stream, std::move(prod), reserve, queued, &r->meter));
+        // (EXG_COLUMNS_CHUNKS: the caller said it will pull chunks — the segments travel to the host from the first one on)
+        const bool mirror0 = r->expect_chunks && !r->arrow_emit && payload_route(r) == kPayloadMirror;
+        return std::unique_ptr<DecodedSource>(new DecodedSource(r->device, r->stream, std::move(prod), reserve, queued, &r->meter, mirror0));
     };
     if (r->compression == kGzip && n == 0) return fail(r, EXG_E_PARSE, "empty gzip file '" + path + "'");
     r->fa_shard = false;
@@ -686,12 +705,8 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             // bgzip VCF): the decoded bytes stay in HBM, the out-of-line strings of the selected columns are closed up into a side
             // buffer behind the scan and only that crosses PCIe (payload_*_from_col, repoint_strings).  Not when a nested VCF
             // column is selected: its element views are cut out of the line's text by the emitter.
-            if (!count_only && !r->arrow_emit && r->format != EXG_FMT_FASTA) {
-                static const bool off = getenv("EXG_NO_PAYLOAD_COMPACT") != nullptr;
-                const uint64_t strs = r->format == EXG_FMT_VCF ? 0x1DDull : 0xFull, nested = r->format == EXG_FMT_VCF ? 0x1D4ull : 0ull;
-                const uint64_t sel = r->want_cols & strs;
-                compact = !off && sel != 0 && sel != strs && !(sel & nested);
-            }
+            const PayloadRoute route = (!count_only && !r->arrow_emit) ? payload_route(r) : kPayloadNone;
+            compact = route == kPayloadCompact;
             if (compact) {
                 h = (const uint8_t *)(uintptr_t)0x100000000000ull + (r->file_pos - lead);  // (a base the side buffer's pointers replace)
             } else if (!count_only && !r->arrow_emit) {
@@ -701,12 +716,10 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
                 // block, and only the bytes in front of the segment's own — the tail carried over from the segment before —
                 // are copied here.  A segment without a mirror (pushed before the first call, a block of the consumer's own
                 // making, FASTA) is copied behind the scan as before.
-                const bool wants_bytes = r->format == EXG_FMT_VCF ? (r->want_cols & 0x1DDull) != 0 : (r->want_cols & ((1ull << n_string_cols(r->format)) - 1)) != 0;
                 const uint8_t *h_at = nullptr;
                 uint64_t m_from = 0;
-                static const bool no_mirror = getenv("EXG_NO_HOST_MIRROR") != nullptr;  // (A/B and tests: the copy behind the scan)
-                if (wants_bytes && r->format != EXG_FMT_FASTA && !no_mirror) r->src->want_host_mirror();
-                if (wants_bytes && r->format != EXG_FMT_FASTA && !no_mirror && r->src->host_view((const uint8_t *)d_input, &h_at, &m_from, &gz_mirror)) {
+                if (route == kPayloadMirror) r->src->want_host_mirror();
+                if (route == kPayloadMirror && r->src->host_view((const uint8_t *)d_input, &h_at, &m_from, &gz_mirror)) {
                     gz_payload = gz_mirror->blk;
                     h = h_at;
                     gz_front = m_from > src_pos - (src_pos & 15) ? std::min<uint64_t>(n, m_from - (src_pos - (src_pos & 15))) : 0;

@@ -4,6 +4,8 @@
 // readers for compressed inputs (rust/src/arrow_reader.rs:60-91, 116-118).
 #include "exg_rd_source.hpp"
 
+#include <algorithm>
+
 namespace exg_rd {
 
 bool SegmentSink::cancelled() const {
@@ -23,7 +25,7 @@ void SegmentSink::set_mark(int id, uint64_t pos) {
 }
 // the segment's own bytes [start, hi) begin to travel to the host (best effort: without pinned memory, a stream or an event the
 // consumer copies them itself, as it does for every segment that has no mirror)
-static void start_mirror(DecodedSource *src, int device, hipStream_t *d2h, Segment &s) {
+static void start_mirror(DecodedSource *src, int device, hipStream_t *d2h, Segment &s, uint64_t piece_bytes = 0) {
     if (s.hi <= s.start || s.mirror) return;
     if (!*d2h && stream_pool()->take(device, d2h) != hipSuccess) {
         (void)hipGetLastError();
@@ -46,7 +48,20 @@ static void start_mirror(DecodedSource *src, int device, hipStream_t *d2h, Segme
         return;
     }
     char *dst = (char *)m->blk->p + ((int64_t)s.start - s.org);
-    if (hipMemcpyAsync(dst, s.at(s.start), s.hi - s.start, hipMemcpyDeviceToHost, *d2h) != hipSuccess || hipEventRecord(m->ev, *d2h) != hipSuccess) {
+    bool ok = true;
+    if (piece_bytes) {
+        m->piece_bytes = piece_bytes;
+        for (uint64_t o = 0; ok && o < s.hi - s.start; o += piece_bytes) {
+            const uint64_t len = std::min<uint64_t>(piece_bytes, s.hi - s.start - o);
+            hipEvent_t e = nullptr;
+            ok = hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+            if (ok) m->piece_ev.push_back(e);
+            ok = ok && hipMemcpyAsync(dst + o, s.at(s.start + o), len, hipMemcpyDeviceToHost, *d2h) == hipSuccess && hipEventRecord(e, *d2h) == hipSuccess;
+        }
+    } else {
+        ok = hipMemcpyAsync(dst, s.at(s.start), s.hi - s.start, hipMemcpyDeviceToHost, *d2h) == hipSuccess;
+    }
+    if (!ok || hipEventRecord(m->ev, *d2h) != hipSuccess) {
         (void)hipGetLastError();
         (void)hipStreamSynchronize(*d2h);
         return;  // (m's destructor waits for whatever was enqueued)
@@ -54,8 +69,19 @@ static void start_mirror(DecodedSource *src, int device, hipStream_t *d2h, Segme
     s.mirror = std::move(m);
 }
 
+bool SegmentSink::mirror_wanted() const { return src->mirror_wanted_.load(std::memory_order_acquire); }
+bool SegmentSink::mirror_now(Segment &s, uint64_t piece_bytes) {
+    if (!mirror_wanted()) return false;
+    std::lock_guard<std::mutex> g(src->mirror_mu_);  // (the d2h stream is made by whoever comes first: the producer's thread or a stage behind it)
+    start_mirror(src, src->device_, &src->d2h_stream_, s, piece_bytes);
+    return s.mirror != nullptr;
+}
+
 bool SegmentSink::push(Segment &&s) {
-    if (src->mirror_wanted_.load(std::memory_order_acquire)) start_mirror(src, src->device_, &src->d2h_stream_, s);
+    if (src->mirror_wanted_.load(std::memory_order_acquire)) {
+        std::lock_guard<std::mutex> g(src->mirror_mu_);
+        start_mirror(src, src->device_, &src->d2h_stream_, s);
+    }
     std::unique_lock<std::mutex> lk(src->mu_);
     src->cv_.wait(lk, [&] { return src->queue_.size() < src->max_queued_ || src->closed_; });
     if (src->closed_) {
@@ -73,9 +99,10 @@ bool SegmentSink::push(Segment &&s) {
 }
 
 DecodedSource::DecodedSource(int device, hipStream_t consumer_stream, std::unique_ptr<SegmentProducer> producer, uint64_t reserve, size_t max_queued,
-                             MemMeter *meter)
+                             MemMeter *meter, bool mirror_from_start)
     : device_(device), stream_(consumer_stream), producer_(std::move(producer)), reserve_((reserve + 15) & ~15ull),
       max_queued_(max_queued ? max_queued : 1), meter_(meter) {
+    mirror_wanted_.store(mirror_from_start, std::memory_order_release);  // (before the producer's thread exists)
     thread_ = std::thread([this] {
         (void)hipSetDevice(device_);
         pin_to_device_node(device_);

@@ -17,6 +17,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <vector>
 
 #include "exg_rd_internal.hpp"
 
@@ -34,11 +35,18 @@ struct HostMirror {
     std::shared_ptr<PinnedBlock> blk;
     hipEvent_t ev = nullptr;
     uint64_t from = 0, hi = 0;
+    // a mirror made in pieces (SegmentSink::mirror_now: the zstd checksum stage hashes the bytes as they arrive instead of
+    // bringing them back a second time): piece k = stream bytes [from + k * piece_bytes, ...) is there when piece_ev[k] has completed
+    std::vector<hipEvent_t> piece_ev;
+    uint64_t piece_bytes = 0;
+    const uint8_t *host_of(uint64_t x, int64_t org) const { return (const uint8_t *)blk->p + ((int64_t)x - org); }
     ~HostMirror() {
         if (ev) {
             (void)hipEventSynchronize(ev);  // (the block goes back to the pinned pool: no copy may still write it)
             (void)hipEventDestroy(ev);
         }
+        for (hipEvent_t e : piece_ev)
+            if (e) (void)hipEventDestroy(e);
     }
 };
 
@@ -76,6 +84,12 @@ struct SegmentSink {
     // the shard's own members / frames (what is in front is the halo), mark 1 = the first byte behind them (a FASTA shard
     // reads on to the next record start).  Set BEFORE the segment that begins there is pushed.
     void set_mark(int id, uint64_t pos);
+    // the consumer hands out string columns: segments travel to the host (DecodedSource::want_host_mirror)
+    bool mirror_wanted() const;
+    // starts the segment's host mirror NOW, in pieces of piece_bytes with an event each — for a stage in front of push() that
+    // wants the bytes on the host itself (the zstd checksum); push() then finds the mirror made.  false: no mirror (not wanted,
+    // or no pinned memory / stream / event: the caller brings its bytes back itself)
+    bool mirror_now(Segment &s, uint64_t piece_bytes);
 };
 
 struct SegmentProducer {
@@ -88,7 +102,7 @@ struct SegmentProducer {
 class DecodedSource {
 public:
     DecodedSource(int device, hipStream_t consumer_stream, std::unique_ptr<SegmentProducer> producer, uint64_t reserve, size_t max_queued,
-                  MemMeter *meter);
+                  MemMeter *meter, bool mirror_from_start = false);
     ~DecodedSource();
     DecodedSource(const DecodedSource &) = delete;
     DecodedSource &operator=(const DecodedSource &) = delete;
@@ -141,7 +155,8 @@ private:
     bool error_deferred_ = false;  // the producer's error was met while bytes in front of it were still to be handed out
     uint64_t n_consumed_ = 0;
     std::atomic<bool> mirror_wanted_{false};
-    hipStream_t d2h_stream_ = nullptr;  // the mirrors' copies (made by the first push that wants one; the producer's thread)
+    hipStream_t d2h_stream_ = nullptr;  // the mirrors' copies (made by the first push / mirror_now that wants one)
+    std::mutex mirror_mu_;
 };
 
 // exg_rd_gzip.cpp: file bytes [c_begin, c_end) of fd are gzip members (BGZF or not, any mixture); `target` = decoded bytes per

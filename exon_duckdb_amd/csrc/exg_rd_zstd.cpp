@@ -133,6 +133,26 @@ private:
         }
         return true;  // (a mismatch is not a failed copy: the segment still goes out — the error comes behind its rows)
     }
+    // the same part out of the segment's host mirror (the consumer wants the bytes on the host anyway: they are brought back ONCE,
+    // in pieces, and hashed as the pieces arrive — not copied for the hash and again for the strings)
+    bool hash_part_mirror(const Part &part, const Segment &seg, exg::Xxh64 &h_, std::atomic<uint32_t> &bad_frame) {
+        const HostMirror &m = *seg.mirror;
+        if (part.begins) h_ = exg::Xxh64();
+        const uint64_t x0 = m.from + (uint64_t)(part.d_src - seg.at(m.from));  // the part's first stream byte
+        for (uint64_t x = x0; x < x0 + part.len;) {
+            const uint64_t k = (x - m.from) / m.piece_bytes, piece_end = m.from + (k + 1) * m.piece_bytes;
+            const uint64_t upto = std::min<uint64_t>(piece_end, x0 + part.len);
+            if (k >= m.piece_ev.size() || hipEventSynchronize(m.piece_ev[k]) != hipSuccess) return false;
+            h_.update(m.host_of(x, seg.org), (size_t)(upto - x));
+            x = upto;
+        }
+        if (part.ends && (uint32_t)h_.digest() != part.expect) {
+            uint32_t seen = bad_frame.load();
+            while (part.frame < seen && !bad_frame.compare_exchange_weak(seen, part.frame)) {
+            }
+        }
+        return true;
+    }
     void loop() {
         (void)hipSetDevice(device_);
         pin_to_device_node(device_);
@@ -158,7 +178,10 @@ private:
                 cv_.notify_all();
             }
             bool ok = true;
-            if (!job.parts.empty() && !ready) {
+            // the consumer wants the decoded bytes on the host (string columns): the mirror is made here, in pieces, and the hash
+            // reads it — otherwise the bytes come back through this stage's own two buffers, as before
+            const bool from_mirror = !job.parts.empty() && sink_->mirror_now(job.seg, kPiece) && job.seg.mirror && job.seg.mirror->piece_bytes;
+            if (!job.parts.empty() && !ready && !from_mirror) {
                 ok = stream_pool()->take(device_, &st) == hipSuccess;
                 for (int i = 0; i < 2 && ok; i++) {
                     ok = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
@@ -192,10 +215,18 @@ private:
                         size_t hcap[2] = {kPiece + 64, kPiece + 64};
                         // (a helper that cannot get its stream, events or pinned blocks is no helper: it claims nothing, and what the
                         // helpers leave is hashed by this stage's own thread below — only a copy that really fails fails the job)
+                        exg::Xxh64 h;
+                        if (from_mirror) {  // (nothing to set up: the pieces arrive in the segment's mirror)
+                            for (size_t k; (k = next.fetch_add(1)) < whole.size();)
+                                if (!hash_part_mirror(job.parts[whole[k]], job.seg, h, bad_frame)) {
+                                    helpers_ok.store(false);
+                                    break;
+                                }
+                            return;
+                        }
                         bool up = stream_pool()->take(device_, &hst) == hipSuccess;
                         for (int i = 0; i < 2 && up; i++)
                             up = hipEventCreateWithFlags(&hev[i], hipEventDisableTiming) == hipSuccess && (hpin[i] = global_pool()->take(&hcap[i])) != nullptr;
-                        exg::Xxh64 h;
                         for (size_t k; up && (k = next.fetch_add(1)) < whole.size();)
                             if (!hash_part(job.parts[whole[k]], hst, hpin, hev, h, bad_frame)) up = false, helpers_ok.store(false);
                         if (hst && hipStreamSynchronize(hst) != hipSuccess) (void)hipGetLastError();
@@ -208,13 +239,13 @@ private:
             }
             for (size_t i = 0; i < job.parts.size() && ok; i++) {
                 if (!helpers.empty() && job.parts[i].begins && job.parts[i].ends) continue;
-                ok = hash_part(job.parts[i], st, pin, ev, h_, bad_frame);
+                ok = from_mirror ? hash_part_mirror(job.parts[i], job.seg, h_, bad_frame) : hash_part(job.parts[i], st, pin, ev, h_, bad_frame);
                 if (!ok) fail("copying a zstd frame back for its checksum failed");
             }
             if (!helpers.empty()) {  // the whole frames the helpers have not claimed (all of them when no helper came up)
                 exg::Xxh64 h;        // (h_ carries the frame that goes on into the next segment)
                 for (size_t k; ok && helpers_ok.load() && (k = next.fetch_add(1)) < whole.size();) {
-                    ok = hash_part(job.parts[whole[k]], st, pin, ev, h, bad_frame);
+                    ok = from_mirror ? hash_part_mirror(job.parts[whole[k]], job.seg, h, bad_frame) : hash_part(job.parts[whole[k]], st, pin, ev, h, bad_frame);
                     if (!ok) fail("copying a zstd frame back for its checksum failed");
                 }
             }

@@ -330,6 +330,7 @@ struct exg_reader {
     uint64_t device_batch_bytes = 256ull << 20;
     uint64_t want_cols = ~0ull;  // exg_open_args.columns: the columns whose vectors are copied back (all are parsed)
     bool want(int c) const { return (want_cols >> c) & 1ull; }
+    bool expect_chunks = false;  // EXG_COLUMNS_CHUNKS: chunks will be pulled (a decoded source mirrors its segments to the host from the first one on)
     int device = 0;
     std::string error;
     hipStream_t stream = nullptr;

@@ -182,8 +182,11 @@ struct ExonTableFunction {
         gs->count_only = true;
         for (idx_t c : column_ids) {
             gs->count_only = gs->count_only && c == D::RowId;
-            if (c != D::RowId && c < 64) gs->columns |= (uint64_t)1 << c;
+            if (c != D::RowId && c < 63) gs->columns |= (uint64_t)1 << c;
         }
+        // the scan is going to pull chunks (anything but COUNT(*)): a compressed input's decoded segments travel to the host from
+        // the first one on, beside the decoder (include/exon_gpu.h: EXG_COLUMNS_CHUNKS)
+        if (!gs->count_only) gs->columns |= EXG_COLUMNS_CHUNKS;
         if (filters) gs->filter_clause = FilterToString(*filters, column_ids, data.all_names);  // module.cpp:222-226
         exg_open_args a;
         memset(&a, 0, sizeof a);

@@ -392,8 +392,14 @@ typedef struct exg_open_args {
                               * the device — a malformed INFO value is an error whether the column is selected or not, like in
                               * the reference, which parses everything and projects afterwards — but only the wanted ones are
                               * copied back: exg_chunk.vectors[c] of the others is NULL.  read_vcf's nested columns are
-                              * two thirds of its bytes over PCIe. */
+                              * two thirds of its bytes over PCIe.
+                              * Bit 63 (EXG_COLUMNS_CHUNKS, ABI 8) is a hint, not a column: the caller is going to pull chunks
+                              * (exg_next_chunk), not exg_count_only — what a table function knows at init_global (column_ids
+                              * != {ROW_ID}).  A compressed input's decoded segments then travel to the host from the FIRST one
+                              * on, beside the decoder; without the hint that begins with the first exg_next_chunk call, and
+                              * the segments decoded before it (one or two, up to 1 GiB each for zstd) are copied behind their scan. */
 } exg_open_args;
+#define EXG_COLUMNS_CHUNKS (1ull << 63)
 
 #define EXG_TYPE_VARCHAR 1
 #define EXG_TYPE_BIGINT 2
