@@ -1108,6 +1108,20 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             // schema order (exg_schema_of): VCF exposes parsed POS / QUAL in place of their raw text
             b->n_cols = ns;
             const size_t vw = (size_t)((k + 63) / 64) * 8;
+            // read_vcf: behind the flat columns come the nested ones' kernels (nested_emit: dozens of small launches that build — or,
+            // for columns the projection leaves out, only validate — id / alt / filter / info / formats).  In one stream the
+            // 200 MB of flat vectors (3.7 ms of the link) stood in front of them; on a stream of their own the copies run beside
+            // them (chrom, pos, ref of a 2 GB file: 70.6 -> 49.4 ms = 42 GB/s, COUNT(*) 47 ms: A/B in one box, EXG_VCF_ONE_STREAM)
+            hipStream_t cs = r->stream;
+            if (r->format == EXG_FMT_VCF && !compact && !getenv("EXG_VCF_ONE_STREAM")) {
+                if (!r->col_stream) {
+                    RD_HIP(r, stream_pool()->take(r->device, &r->col_stream));
+                    RD_HIP(r, hipEventCreateWithFlags(&r->col_ev, hipEventDisableTiming));
+                }
+                RD_HIP(r, hipEventRecord(r->col_ev, r->stream));          // (the scan, the predicate's row map)
+                RD_HIP(r, hipStreamWaitEvent(r->col_stream, r->col_ev, 0));
+                cs = r->col_stream;
+            }
             const bool nested_vcf = r->format == EXG_FMT_VCF;  // id, alt, filter, info, formats: built by nested_emit below
             for (int c = 0; c < ns; c++) {
                 if ((nested_vcf && (c == 2 || c == 4 || c >= 6)) || !r->want(c)) {
@@ -1129,22 +1143,22 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
                     src = dst;
                 } else if (row_map) {
                     if (es == 16)
-                        exg::arrow::gather_u128(src, row_map, k, r->d_gather, r->stream);
+                        exg::arrow::gather_u128(src, row_map, k, r->d_gather, cs);
                     else if (es == 8)
-                        exg::arrow::gather_u64((const uint64_t *)src, row_map, k, (uint64_t *)r->d_gather, r->stream);
+                        exg::arrow::gather_u64((const uint64_t *)src, row_map, k, (uint64_t *)r->d_gather, cs);
                     else
-                        exg::arrow::gather_u32((const uint32_t *)src, row_map, k, (uint32_t *)r->d_gather, r->stream);
+                        exg::arrow::gather_u32((const uint32_t *)src, row_map, k, (uint32_t *)r->d_gather, cs);
                     src = r->d_gather;
                 }
-                RD_HIP(r, hipMemcpyAsync(b->cols[c], src, k * es, hipMemcpyDeviceToHost, r->stream));
+                RD_HIP(r, hipMemcpyAsync(b->cols[c], src, k * es, hipMemcpyDeviceToHost, compact && es == 16 && side[c].d_goff ? r->stream : cs));
             }
             auto copy_validity = [&](int col, const void *d) -> int {
                 if (!(b->validity[col] = b->host.alloc(vw))) return fail(r, EXG_E_HIP, "out of pinned host memory");
                 if (row_map) {
-                    exg::arrow::gather_bits((const uint64_t *)d, row_map, k, (uint64_t *)r->d_gather, r->stream);
+                    exg::arrow::gather_bits((const uint64_t *)d, row_map, k, (uint64_t *)r->d_gather, cs);
                     d = r->d_gather;
                 }
-                RD_HIP(r, hipMemcpyAsync(b->validity[col], d, vw, hipMemcpyDeviceToHost, r->stream));
+                RD_HIP(r, hipMemcpyAsync(b->validity[col], d, vw, hipMemcpyDeviceToHost, cs));
                 return EXG_OK;
             };
             if (r->format == EXG_FMT_VCF) {
@@ -1166,6 +1180,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
                 RD_HIP(r, hipMemcpyAsync(b->payload, r->d_payload, res.payload_bytes, hipMemcpyDeviceToHost, r->stream));
             const double t_cols = now_s();
             RD_HIP(r, hipStreamSynchronize(r->stream));
+            if (r->col_stream) RD_HIP(r, hipStreamSynchronize(r->col_stream));
             TRACE("wait(columns -> host)", t_cols);
             const double t_mir = now_s();
             if (gz_mirror) RD_HIP(r, hipEventSynchronize(gz_mirror->ev));  // the segment's own bytes have arrived

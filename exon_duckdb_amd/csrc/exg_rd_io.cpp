@@ -180,6 +180,8 @@ exg_reader::~exg_reader() {
     if (d_filter_consts) exg_rd::dev_pool()->give(device, d_filter_consts, filter_consts_bytes);
     for (int k = 0; k < 2; k++)
         if (up_done_of[k]) (void)hipEventDestroy(up_done_of[k]);
+    if (col_ev) (void)hipEventDestroy(col_ev);
+    exg_rd::stream_pool()->give(device, col_stream);
     exg_rd::stream_pool()->give(device, up_stream);
     exg_rd::stream_pool()->give(device, stream, /*high=*/getenv("EXG_NO_SCAN_PRIORITY") == nullptr);
 }

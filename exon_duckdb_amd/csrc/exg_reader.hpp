@@ -345,6 +345,9 @@ struct exg_reader {
     void *d_in = nullptr, *d_ws = nullptr, *d_res = nullptr;  // d_in = the slot the current batch sits in
     void *d_in_slot[2] = {nullptr, nullptr};
     hipStream_t up_stream = nullptr;
+    // read_vcf: the flat columns' copies back run on a stream of their own beside the nested columns' kernels (next_batch)
+    hipStream_t col_stream = nullptr;
+    hipEvent_t col_ev = nullptr;
     // per input slot: the thread of the upload that is filling it (pread + H2D enqueue), its result, the event behind its copies
     std::thread up_thread_of[2];
     int up_rc_of[2] = {0, 0};
