@@ -87,6 +87,27 @@ def test_two_rank_sharded_count(ragged):
     assert got[0][2] == 0 and got[1][2] > 0
 
 
+def test_eight_rank_sharded_count():
+    """BASELINE config 5's collective shape on CPU: EIGHT gloo ranks (one per GPU of the node), six of them middle shards — no
+    BOF, no EOF, a halo in front, a phase guessed from their own bytes — the 8-way all_gather of the newline counts verifies
+    every guess and the all_reduce gives COUNT(*)."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    n = 16000
+    procs = [ctx.Process(target=_worker, args=(r, 8, port, n, False, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(8))
+    assert sum(g[1] for g in got) == n and [g[0] for g in got] == list(range(8))
+    assert got[0][2] == 0 and all(a[2] < b[2] for a, b in zip(got[:-1], got[1:]))   # first line index of every shard: ascending
+
+
 def test_plan_shards_properties():
     sys.path.insert(0, ROOT)
     from exon_duckdb_amd import sharding
