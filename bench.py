@@ -14,7 +14,10 @@ Beside it (rank 0, N=1, skipped with --no-configs): `configs` — BASELINE confi
 through the reader: latency), configs[2] (8-column VCF scan, 5 GB generated in HBM by exg_synth_vcf) and configs[3]
 (read_fastq on BGZF: members deflated on the host cores, inflated + scanned on the device, COUNT(*) through the reader) —
 and `end_to_end` / `configs.end_to_end_vcf` (file in the page cache -> host DataChunks through exg_open / exg_next_chunk, PCIe inclusive;
-never `value`).  With N>1 the same file-level leg runs sharded (`reader_sharded`: every rank opens the same file with
+never `value`).  Round 5: config 4 and the zstd leg also time what the metric names on a compressed input — records INTO DataChunks
+(`all_columns`: the decoded bytes and the string_t cross PCIe back; `projected_name`: only one column's bytes do) — against the link's
+rates measured in the run (`configs.pcie_link`); `end_to_end_arrow` is the reference's own boundary (new_reader -> Arrow C stream);
+`roofline.traffic` comes from two rocprofv3 --pmc passes over a child of this script started before torch is imported (--no-traffic skips them).  With N>1 the same file-level leg runs sharded (`reader_sharded`: every rank opens the same file with
 shard_index = rank).  `cpu_baseline` times the oracle (CPU restatement) on the host cores.
 """
 import argparse
