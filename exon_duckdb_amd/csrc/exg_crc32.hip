@@ -146,6 +146,29 @@ extern "C" int exg_crc32_members(const void *d_out, const exg_inflate_member *d_
     EXG_HIP_CHECK(hipGetLastError());
     return EXG_OK;
 }
+// A decoder's small results (member statuses + checksums, ~100 KB a window) written to PINNED HOST memory by a kernel, not by a
+// copy: a hipMemcpyAsync device-to-host is a packet on an SDMA engine, and the engine this stream's copies go to may be the
+// one that is sending 280 MB segment mirrors to the host (exg_rd_source.hpp: HostMirror) — the 100 KB then waited behind one
+// or two of them, 10 ms a window on every third BGZF lane (round 5: config 4's all-columns drain at 0.60 s instead of 0.45 s).
+// The stores leave over PCIe as they are made; they are visible to the host when an event recorded behind the kernel has
+// completed (hipHostMalloc memory is coherent by default).  bytes: a multiple of 4; both pointers 4-byte aligned.
+namespace exg {
+__global__ void k_post_to_host(uint32_t *__restrict__ h_dst, const uint32_t *__restrict__ d_src, uint32_t n_words) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += gridDim.x * blockDim.x) h_dst[i] = d_src[i];
+}
+int post_to_host(void *h_dst, const void *d_src, uint64_t bytes, void *stream) {
+    if (!bytes) return EXG_OK;
+    if (!h_dst || !d_src || (bytes & 3) || (((uintptr_t)h_dst | (uintptr_t)d_src) & 3) || bytes > (1ull << 32)) {
+        set_error("post_to_host: null, unaligned or oversized argument");
+        return EXG_E_INVALID_ARG;
+    }
+    const uint32_t n_words = (uint32_t)(bytes / 4), blocks = (n_words + 255) / 256;
+    hipLaunchKernelGGL(k_post_to_host, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, (hipStream_t)stream, (uint32_t *)h_dst,
+                       (const uint32_t *)d_src, n_words);
+    EXG_HIP_CHECK(hipGetLastError());
+    return EXG_OK;
+}
+}  // namespace exg
 // Host: the checksum of A followed by B from crc(A), crc(B) and len(B) (zlib's crc32_combine)
 extern "C" uint32_t exg_crc32_combine(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) {
     return exg::crc_multmodp(exg::crc_x2nmodp(len_b, 3), crc_a) ^ crc_b;

@@ -320,8 +320,10 @@ int GzipProducer::bgzf_issue(SegmentSink &sink, Lane &l, bool *not_bgzf, std::st
         if (rc) *err = exg_last_error_message();
     }
     if (!rc && he == hipSuccess) he = hipMemsetAsync((char *)l.seg.buf + base + out, 0, 64, l.st);
-    if (!rc && he == hipSuccess)
-        he = hipMemcpyAsync(l.tab.p + k * sizeof(exg_inflate_member), d_s, k * (sizeof(exg_inflate_status) + 4), hipMemcpyDeviceToHost, l.st);
+    // (statuses + checksums come back by a kernel's stores, not by a copy: exg_crc32.hip: post_to_host — a copy would queue on
+    // an SDMA engine behind the segments' host mirrors)
+    if (!rc && he == hipSuccess && (rc = exg::post_to_host(l.tab.p + k * sizeof(exg_inflate_member), d_s, k * (sizeof(exg_inflate_status) + 4), l.st)))
+        *err = exg_last_error_message();
     if (!rc && he == hipSuccess) he = hipEventRecord(l.ev, l.st);
     if (rc || he != hipSuccess) {
         (void)hipStreamSynchronize(l.st);
@@ -536,7 +538,7 @@ int GzipProducer::small_member(SegmentSink &sink, uint64_t stream_off, std::stri
         if (!rc) rc = exg_crc32_members(seg.buf, &d->m, &d->s, 1, &d->crc, l.st);
         if (rc) *err = exg_last_error_message();
     }
-    if (!rc && he == hipSuccess) he = hipMemcpyAsync(&h->s, &d->s, sizeof h->s + 4, hipMemcpyDeviceToHost, l.st);
+    if (!rc && he == hipSuccess && (rc = exg::post_to_host(&h->s, &d->s, sizeof h->s + 4, l.st))) *err = exg_last_error_message();
     if (he == hipSuccess) he = hipStreamSynchronize(l.st);
     if (!rc && he != hipSuccess) {
         *err = std::string("inflate failed: ") + hipGetErrorString(he);
