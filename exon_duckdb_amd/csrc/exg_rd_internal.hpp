@@ -17,12 +17,6 @@
 
 #include "exg_reader.hpp"
 
-// exg_crc32.hip: bytes (a multiple of 4, both ends 4-byte aligned) of device memory written to pinned host memory by a kernel on
-// `stream` — a decoder's small results, which a copy would queue behind the big copies of its SDMA engine
-namespace exg {
-int post_to_host(void *h_dst, const void *d_src, uint64_t bytes, void *stream);
-}
-
 namespace exg_rd {
 
 #define RD_HIP(r, expr)                                                                            \

@@ -14,6 +14,12 @@
 #include "exg_block_pool.hpp"
 #include "exg_common.hpp"
 
+// exg_crc32.hip: bytes (a multiple of 4, both ends 4-byte aligned) of device memory written to pinned host memory by a kernel on
+// `stream` — a decoder's small results, which a copy would queue behind the big copies of its SDMA engine
+namespace exg {
+int post_to_host(void *h_dst, const void *d_src, uint64_t bytes, void *stream);
+}
+
 namespace exg_rd {
 class DecodedSource;
 class FanOut;

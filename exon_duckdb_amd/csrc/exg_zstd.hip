@@ -1486,9 +1486,30 @@ int decode_round_begin(Round &R, void *stream_v, RoundCtx **out_ctx) {
         } side_guard{dev, st2, ev0, ev1};
         hipLaunchKernelGGL(k_zst_scan, dim3(1), dim3(64), 0, st, (Block *)C.d_blocks.p, nx, nb, (ScanState *)C.d_meta.p);
         EXG_HIP_CHECK(hipGetLastError());
-        EXG_HIP_CHECK(hipMemcpyAsync(blocks.data(), C.d_blocks.p, (size_t)nb * sizeof(Block), hipMemcpyDeviceToHost, st));
-        EXG_HIP_CHECK(hipMemcpyAsync(&state, C.d_meta.p, sizeof state, hipMemcpyDeviceToHost, st));
-        EXG_HIP_CHECK(hipStreamSynchronize(st));
+        // the block table and the scan's state come back by a kernel's stores into pinned memory (exg_crc32.hip: post_to_host) — a
+        // copy is a packet on an SDMA engine, where it may queue behind a 1 GiB segment on its way to the host (HostMirror)
+        static_assert(sizeof(Block) % 4 == 0 && sizeof(ScanState) % 4 == 0, "posted word by word");
+        struct Back {
+            char *p = nullptr;
+            size_t cap = 0;
+            ~Back() {
+                if (p) exg_rd::global_pool()->give(p, cap);
+            }
+        } back;
+        const size_t blocks_bytes = ((size_t)nb * sizeof(Block) + 15) & ~(size_t)15;
+        back.cap = blocks_bytes + sizeof state + 64;
+        back.p = (char *)exg_rd::global_pool()->take(&back.cap);
+        if (!back.p) {
+            set_error("zstd decode: out of pinned host memory");
+            return EXG_E_NOMEM;
+        }
+        int prc = post_to_host(back.p, C.d_blocks.p, (size_t)nb * sizeof(Block), st);
+        if (!prc) prc = post_to_host(back.p + blocks_bytes, C.d_meta.p, sizeof state, st);
+        const hipError_t she = hipStreamSynchronize(st);  // (before `back` goes to the pool, whatever happened)
+        if (prc) return prc;
+        EXG_HIP_CHECK(she);
+        memcpy(blocks.data(), back.p, (size_t)nb * sizeof(Block));
+        memcpy(&state, back.p + blocks_bytes, sizeof state);
         for (uint32_t b = nx; b < nb; b++)
             if (blocks[b].status) {
                 set_error("%s (zstd block %llu at byte %llu)", status_text(blocks[b].status), (unsigned long long)(R.first_block_id + (b - nx)),
@@ -1739,7 +1760,10 @@ int decode_round_enqueue_resolve(Round &R, RoundCtx *ctx_p) {
         hipLaunchKernelGGL(k_zst_xxh64, dim3(nf < 16384 ? nf : 16384), dim3(64), 0, st, (const uint8_t *)out_bytes, (const Frame *)C.d_frames.p, nf,
                            R.verify_max, (uint32_t *)C.d_status.p + nc);
         EXG_HIP_CHECK(hipGetLastError());
-        EXG_HIP_CHECK(hipMemcpyAsync(C.h_status, C.d_status.p, status_bytes, hipMemcpyDeviceToHost, st));
+        {
+            const int prc = post_to_host(C.h_status, C.d_status.p, status_bytes, st);
+            if (prc) return prc;
+        }
     }
     ctx.release();
     return EXG_OK;

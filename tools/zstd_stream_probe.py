@@ -59,4 +59,12 @@ for batch in os.environ.get("ZST_BATCHES", "0,536870912,1073741824,4294967296").
         assert rows == n // 332
         best = dt if best is None or dt < best else best
     print(f"device_batch_bytes={int(batch) >> 20} MiB: {best*1e3:.1f} ms = {n/best/1e9:.1f} GB/s of FASTQ ({st['decoded_segments']} segments, peak {st['device_bytes_peak']>>20} MiB)", flush=True)
+if os.environ.get("ZST_CHUNKS"):
+    # every column as DataChunks (the C drain loop of bench.reader_chunks), best of three
+    import bench
+    from exon_duckdb_amd import load_library
+    lib = load_library()
+    rows, chunks, dt = min((bench.reader_chunks(lib, p, "fastq") for _ in range(3)), key=lambda x: x[2])
+    assert rows == n // 332
+    print(f"all columns as DataChunks: {dt*1e3:.1f} ms = {n/dt/1e9:.1f} GB/s of FASTQ ({chunks} chunks)", flush=True)
 os.unlink(p); os.rmdir(d)
