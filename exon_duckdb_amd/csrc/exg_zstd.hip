@@ -26,6 +26,7 @@
 #include <time.h>
 
 #include <algorithm>
+#include <cmath>
 
 #include "exg_common.hpp"
 #include "exg_reader.hpp"
@@ -1172,81 +1173,196 @@ __global__ __launch_bounds__(64) void k_zst_xxh64(const uint8_t *__restrict__ ou
 struct ResolveArgs {
     const uint32_t *sym;
     const Chunk *chunks;        // all chunks
-    const uint32_t *sym_chunks; // the round's symbolic chunks (indices into chunks), ascending elem_off
-    uint32_t n_sym_chunks;
+    const uint32_t *sym_chunks; // the round's symbolic chunks (indices into chunks), ascending elem_off: the group's first
+    uint32_t n_sym_chunks;      // chunks of the group this launch looks at
+    uint32_t n_ctx;             // k_zst_resolve_inner: the first n_ctx of them are only read, the rest is rewritten
     uint8_t *out;
-    uint64_t final_below;       // everything in front of the group's first chunk is final
-    uint64_t elem0, n_elems;    // the group's symbol slots [elem0, elem0 + n_elems) (chunks padded to 4)
+    uint64_t final_below;       // everything in front of the group's first chunk is final (or left for a later pass)
+    uint64_t elem0, n_elems;    // the symbol slots [elem0, elem0 + n_elems) this launch works on (chunks padded to 4)
 };
 
-static constexpr uint32_t kGroupMax = 32;  // chunks per resolve launch
+static constexpr uint32_t kGroupMax = 256;     // chunks per resolve launch
+static constexpr uint32_t kGroupMaxBytes = 32; // ... of round 4's groups by bytes (EXG_ZSTD_RESOLVE_INNER=0)
 
+static constexpr uint32_t kResolveRows = 8;  // rows of 1 024 symbols per workgroup
+static constexpr uint64_t kRowElems = 1024ull * kResolveRows;
+
+// the last j in [0, n) with v[j] <= x (v ascending, v[0] <= x)
+__device__ __forceinline__ uint32_t last_at_or_below(const uint64_t *v, uint32_t n, uint64_t x) {
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (v[mid] <= x) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// ROWS rows of 1 024 symbols per workgroup: the group's tables are loaded once for all of them, and all rows' symbols are asked
+// for before the first is looked at (a workgroup per row was bound by the rate at which workgroups start: 0.6-1 TB/s).
+// ROWS = 1 for round 4's small groups, whose launches are a chain of latencies.
+template <uint32_t ROWS>
 __device__ __forceinline__ void resolve_group(const ResolveArgs &a, uint32_t block_x) {
     // the group's chunks: where they start in the output and in the symbol buffer, what lies in front of them as bytes
-    __shared__ uint64_t s_out[kGroupMax], s_elem[kGroupMax], s_size[kGroupMax], s_bytes_below[kGroupMax], s_frame0[kGroupMax];
+    __shared__ uint64_t s_out[kGroupMax], s_elem[kGroupMax], s_size[kGroupMax];
+    __shared__ uint64_t s_below_frame[2];
     const uint32_t n = a.n_sym_chunks;
     if (threadIdx.x < n) {
         const Chunk &c = a.chunks[a.sym_chunks[threadIdx.x]];
         s_out[threadIdx.x] = c.out_off;
         s_elem[threadIdx.x] = c.elem_off;
         s_size[threadIdx.x] = c.size;
-        s_bytes_below[threadIdx.x] = c.byte_end > a.final_below ? c.byte_end : a.final_below;
-        s_frame0[threadIdx.x] = c.frame_out_off;
+        if (threadIdx.x == 0) {  // (a group lies in ONE frame: where its bytes end and where it begins are the group's)
+            s_below_frame[0] = c.byte_end > a.final_below ? c.byte_end : a.final_below;
+            s_below_frame[1] = c.frame_out_off;
+        }
     }
     __syncthreads();
-    const uint64_t e = a.elem0 + (uint64_t)block_x * 1024 + (uint64_t)threadIdx.x * 4;
-    if (e >= a.elem0 + a.n_elems) return;
-    uint32_t k = 0;
-    for (uint32_t j = 1; j < n; j++) k = s_elem[j] <= e ? j : k;
-    const uint64_t i = e - s_elem[k], size = s_size[k];
-    if (i >= size) return;  // padding between two chunks
-    const uint4 xv = *reinterpret_cast<const uint4 *>(a.sym + e);  // (elem_off is a multiple of 4)
-    uint32_t x[4] = {xv.x, xv.y, xv.z, xv.w}, at[4] = {k, k, k, k};
-    const uint32_t nv = size - i < 4 ? (uint32_t)(size - i) : 4u;
-    // the four chains advance together (their loads overlap; neighbours usually take the same hops)
-    for (;;) {
-        bool more = false;
+    const uint64_t below = s_below_frame[0], frame0 = s_below_frame[1];
+    uint4 rows[ROWS];  // (elem_off is a multiple of 4, the slots are padded to it)
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if ((uint32_t)j >= nv || !(x[j] & kSymRef)) continue;
-            const uint64_t cs = s_out[at[j]], d = x[j] & ~kSymRef;
-            if (d == 0 || d > cs - s_frame0[at[j]]) {  // (only after a failed decode: the chunk's status says so)
-                x[j] = 0;
-                continue;
-            }
-            const uint64_t q = cs - d;
-            if (q < s_bytes_below[at[j]]) {
-                x[j] = a.out[q];
-                continue;
-            }
-            uint32_t c = 0;  // q lies in an earlier chunk of the group: the last one that starts at or before it
-            for (uint32_t m = 1; m < at[j]; m++) c = s_out[m] <= q ? m : c;
-            x[j] = a.sym[s_elem[c] + (q - s_out[c])];
-            at[j] = c;
-            more = more || (x[j] & kSymRef);
-        }
-        if (!more) break;
+    for (uint32_t row = 0; row < ROWS; row++) {
+        const uint64_t e = a.elem0 + ((uint64_t)block_x * ROWS + row) * 1024 + (uint64_t)threadIdx.x * 4;
+        rows[row] = e < a.elem0 + a.n_elems ? *reinterpret_cast<const uint4 *>(a.sym + e) : make_uint4(0, 0, 0, 0);
     }
-    uint8_t *dst = a.out + s_out[k] + i;
-    if (nv == 4) {
-        const uint32_t w = (x[0] & 255u) | ((x[1] & 255u) << 8) | ((x[2] & 255u) << 16) | (x[3] << 24);
-        __builtin_memcpy(dst, &w, 4);
-    } else {
 #pragma unroll
-        for (int j = 0; j < 3; j++)
-            if ((uint32_t)j < nv) dst[j] = (uint8_t)x[j];
+    for (uint32_t row = 0; row < ROWS; row++) {
+        const uint64_t e = a.elem0 + ((uint64_t)block_x * ROWS + row) * 1024 + (uint64_t)threadIdx.x * 4;
+        if (e >= a.elem0 + a.n_elems) break;
+        const uint32_t k = last_at_or_below(s_elem, n, e);
+        const uint64_t i = e - s_elem[k], size = s_size[k];
+        if (i >= size) continue;  // padding between two chunks
+        const uint4 xv = rows[row];
+        uint32_t x[4] = {xv.x, xv.y, xv.z, xv.w}, at[4] = {k, k, k, k};
+        const uint32_t nv = size - i < 4 ? (uint32_t)(size - i) : 4u;
+        // the four chains advance together (their loads overlap; neighbours usually take the same hops).  Behind the inner
+        // launches a chain is ONE hop: no reference leads into the group itself.
+        while ((x[0] | x[1] | x[2] | x[3]) & kSymRef) {
+            bool more = false;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (!(x[j] & kSymRef)) continue;
+                if ((uint32_t)j >= nv) {
+                    x[j] = 0;
+                    continue;
+                }
+                const uint64_t cs = s_out[at[j]], d = x[j] & ~kSymRef;
+                if (d == 0 || d > cs - frame0) {  // (only after a failed decode: the chunk's status says so)
+                    x[j] = 0;
+                    continue;
+                }
+                const uint64_t q = cs - d;
+                if (q < below) {
+                    x[j] = a.out[q];
+                    continue;
+                }
+                // q lies in an earlier chunk of the group: the last one that starts at or before it
+                const uint32_t c = last_at_or_below(s_out, at[j], q);
+                x[j] = a.sym[s_elem[c] + (q - s_out[c])];
+                at[j] = c;
+                more = more || (x[j] & kSymRef);
+            }
+            if (!more) break;
+        }
+        uint8_t *dst = a.out + s_out[k] + i;
+        if (nv == 4) {
+            const uint32_t w = (x[0] & 255u) | ((x[1] & 255u) << 8) | ((x[2] & 255u) << 16) | (x[3] << 24);
+            __builtin_memcpy(dst, &w, 4);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                if ((uint32_t)j < nv) dst[j] = (uint8_t)x[j];
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void k_zst_resolve(const ResolveArgs a) { resolve_group(a, blockIdx.x); }
+template <uint32_t ROWS>
+__global__ __launch_bounds__(256) void k_zst_resolve(const ResolveArgs a) {
+    resolve_group<ROWS>(a, blockIdx.x);
+}
 
 // Groups that do not depend on each other in ONE launch: references never leave their frame, so the k-th groups of all the
-// frames of a round resolve side by side (blockIdx.y: the group).  A round of one big frame is a chain of ~2 000 launches
-// whatever is done (14.7 ms of launch latency per GiB); a round of 8 MiB frames is sixteen.
+// frames of a round resolve side by side (blockIdx.y: the group): a round of 8 MiB frames is a handful of launches.
+template <uint32_t ROWS>
 __global__ __launch_bounds__(256) void k_zst_resolve_many(const ResolveArgs *__restrict__ args) {
     const ResolveArgs a = args[blockIdx.y];
-    if ((uint64_t)blockIdx.x * 1024 >= a.n_elems) return;  // (the grid is as wide as the batch's largest group)
-    resolve_group(a, blockIdx.x);
+    if ((uint64_t)blockIdx.x * 1024 * ROWS >= a.n_elems) return;  // (the grid is as wide as the batch's largest group)
+    resolve_group<ROWS>(a, blockIdx.x);
+}
+
+// Round 5, the chain of launches of ONE big frame cut from ~2 000 to ~130 per GiB.  The in-order launches take GROUPS of G1 (x G2)
+// chunks (64 of 256 KiB = 16 MiB for a 1 GiB round: 64 launches), and BEFORE they run, G1 - 1 launches (and, with a second
+// level — built, measured slower, off by default — G2 - 1 more) take the groups' INTERNAL references out, every group of the
+// round at once (blockIdx.y):
+//   level 1, launches j = 1 .. G1-1: chunk j of every run of G1 chunks — a reference that lands in an earlier chunk of its
+//     own run reads that chunk's symbol, which launch < j has left as a byte or as a reference in front of the run, and becomes
+//     that byte or that reference re-based on its own chunk: ONE hop, because the chunk it reads has been through the same;
+//   level 2, launches v = 1 .. G2-1: run v of every group — what still refers into the group (in front of its own run) reads
+//     a symbol of an earlier run, which launch < v has left as a byte or as a reference in front of the GROUP: one hop again.
+// What refers in front of the pass's scope is left alone.  Afterwards no chain has a link inside a group, and an in-order
+// launch resolves a whole group with one hop per reference, into bytes that are final.  (The fully parallel levels of this
+// round's first attempt let every symbol FOLLOW its chain through the group: j hops in chunk j, 2x slower than the chain of
+// launches; here the order inside the groups is kept and all groups walk it together.)  In place: a launch writes only the
+// chunks it was given ([n_ctx, n_sym_chunks) of the scope) and reads only the ones in front of them.
+__global__ __launch_bounds__(256) void k_zst_resolve_inner(const ResolveArgs *__restrict__ args, uint32_t *__restrict__ sym_rw) {
+    const ResolveArgs a = args[blockIdx.y];
+    if ((uint64_t)blockIdx.x * kRowElems >= a.n_elems) return;
+    __shared__ uint64_t s_out[kGroupMax], s_elem[kGroupMax], s_size[kGroupMax];
+    __shared__ uint64_t s_below_frame[2];
+    const uint32_t n = a.n_sym_chunks, n_ctx = a.n_ctx;  // chunks [0, n_ctx): read; [n_ctx, n): rewritten
+    if (threadIdx.x < n) {
+        const Chunk &c = a.chunks[a.sym_chunks[threadIdx.x]];
+        s_out[threadIdx.x] = c.out_off;
+        s_elem[threadIdx.x] = c.elem_off;
+        s_size[threadIdx.x] = c.size;
+        if (threadIdx.x == 0) {
+            s_below_frame[0] = c.byte_end > a.final_below ? c.byte_end : a.final_below;
+            s_below_frame[1] = c.frame_out_off;
+        }
+    }
+    __syncthreads();
+    const uint64_t below = s_below_frame[0], frame0 = s_below_frame[1];
+    uint4 rows[kResolveRows];
+#pragma unroll
+    for (uint32_t row = 0; row < kResolveRows; row++) {
+        const uint64_t e = a.elem0 + ((uint64_t)blockIdx.x * kResolveRows + row) * 1024 + (uint64_t)threadIdx.x * 4;
+        rows[row] = e < a.elem0 + a.n_elems ? *reinterpret_cast<const uint4 *>(a.sym + e) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (uint32_t row = 0; row < kResolveRows; row++) {
+        const uint64_t e = a.elem0 + ((uint64_t)blockIdx.x * kResolveRows + row) * 1024 + (uint64_t)threadIdx.x * 4;
+        if (e >= a.elem0 + a.n_elems) break;
+        const uint4 xv = rows[row];
+        uint32_t x[4] = {xv.x, xv.y, xv.z, xv.w};
+        if (!((x[0] | x[1] | x[2] | x[3]) & kSymRef)) continue;
+        const uint32_t k = n_ctx + last_at_or_below(s_elem + n_ctx, n - n_ctx, e);
+        const uint64_t i = e - s_elem[k], size = s_size[k];
+        if (i >= size) continue;  // padding between two chunks
+        const uint32_t nv = size - i < 4 ? (uint32_t)(size - i) : 4u;
+        const uint64_t cs = s_out[k], reach = cs - frame0, ctx_end = s_out[n_ctx];
+        bool changed = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if ((uint32_t)j >= nv || !(x[j] & kSymRef)) continue;
+            const uint64_t d = x[j] & ~kSymRef;
+            if (d == 0 || d > reach) continue;  // (only after a failed decode: the in-order launch makes it a zero)
+            const uint64_t q = cs - d;
+            // in front of the scope (or in the frame's bytes): a later pass reads it; q >= ctx_end cannot be behind the passes in
+            // front of this one (it would lead into the chunks being rewritten) — left alone, the in-order launch follows it
+            if (q < below || q >= ctx_end) continue;
+            const uint32_t c = last_at_or_below(s_out, n_ctx, q);
+            const uint32_t y = a.sym[s_elem[c] + (q - s_out[c])];
+            if (y & kSymRef) {
+                const uint64_t d2 = y & ~kSymRef, co = s_out[c];
+                // (chunk c's reference leads in front of the scope; an invalid one — a failed decode — becomes a zero here as there)
+                x[j] = (d2 == 0 || d2 > co - frame0) ? 0u : (kSymRef | (uint32_t)(cs - (co - d2)));
+            } else {
+                x[j] = y;
+            }
+            changed = true;
+        }
+        if (changed) *reinterpret_cast<uint4 *>(sym_rw + e) = make_uint4(x[0], x[1], x[2], x[3]);
+    }
 }
 
 static double now_ms() {
@@ -1694,32 +1810,91 @@ int decode_round_enqueue_resolve(Round &R, RoundCtx *ctx_p) {
                                    out_bytes, (uint32_t *)C.d_sym.p, (uint32_t *)C.d_status.p + Q.c0);
             first = false;
             static const uint64_t group_bytes = getenv("EXG_ZSTD_RESOLVE_BYTES") ? strtoull(getenv("EXG_ZSTD_RESOLVE_BYTES"), nullptr, 10) : (512ull << 10);
-            // groups of consecutive chunks of ONE frame (a reference never leaves its frame); batch j = the j-th group of every
-            // frame of the round: its groups are independent of each other, the batches run in order
-            std::vector<std::vector<ResolveArgs>> batches;
+            // EXG_ZSTD_RESOLVE_INNER=0: round 4's groups of ~512 KiB whose internal chains every thread follows (A/B);
+            // EXG_ZSTD_GROUP_CHUNKS=G1[,G2]: chunks per run and runs per group instead of the choice below
+            static const bool inner_on = !getenv("EXG_ZSTD_RESOLVE_INNER") || atoi(getenv("EXG_ZSTD_RESOLVE_INNER")) != 0;
+            static const char *group_env = getenv("EXG_ZSTD_GROUP_CHUNKS");
+            uint32_t G1 = 0, G2 = 1;  // G1 = 0: groups by bytes, no inner launches
+            if (inner_on) {
+                uint32_t longest = 0;
+                for (uint32_t k0 = 0; k0 < Q.n_list;) {
+                    const uint64_t frame0 = chunks[sym_list[Q.list0 + k0]].frame_out_off;
+                    uint32_t k1 = k0;
+                    while (k1 < Q.n_list && chunks[sym_list[Q.list0 + k1]].frame_out_off == frame0) k1++;
+                    longest = std::max(longest, k1 - k0);
+                    k0 = k1;
+                }
+                // dependent launches of the longest frame: (G1 - 1) + (G2 - 1) + longest / (G1 G2).  ONE level of inner launches with
+                // G1 ~ sqrt(longest) (4 096 chunks: 63 + 64 launches); a second level (G1 = G2 = 16: 46 launches) reads every symbol
+                // once more and measured SLOWER on a 4 GB frame (113-122 ms against 102-108; the launches are no longer what the
+                // round waits for) — EXG_ZSTD_GROUP_CHUNKS=16,16 builds it
+                G1 = std::min<uint32_t>(kGroupMax, std::max<uint32_t>(2, (uint32_t)std::ceil(std::sqrt((double)longest))));
+                if (group_env) {
+                    G1 = (uint32_t)std::max(2, atoi(group_env));
+                    G2 = strchr(group_env, ',') ? (uint32_t)std::max(1, atoi(strchr(group_env, ',') + 1)) : 1;
+                    G1 = std::min(G1, kGroupMax);
+                    G2 = std::min(G2, kGroupMax / G1);
+                }
+            }
+            // groups of consecutive chunks of ONE frame (a reference never leaves its frame); batch u = the u-th group of every
+            // frame of the round: its groups are independent of each other, the batches run in order.  inner1[j - 1]: chunk j of
+            // every run that has one; inner2[v - 1]: run v of every group that has one (k_zst_resolve_inner)
+            std::vector<std::vector<ResolveArgs>> batches, inner1, inner2;
             for (uint32_t k0 = 0; k0 < Q.n_list;) {
                 const uint64_t frame0 = chunks[sym_list[Q.list0 + k0]].frame_out_off;
-                for (uint32_t j = 0; k0 < Q.n_list && chunks[sym_list[Q.list0 + k0]].frame_out_off == frame0; j++) {
+                for (uint32_t u = 0; k0 < Q.n_list && chunks[sym_list[Q.list0 + k0]].frame_out_off == frame0; u++) {
                     uint32_t k1 = k0;
                     uint64_t bytes = 0;
-                    while (k1 < Q.n_list && k1 - k0 < kGroupMax && (bytes < group_bytes || k1 == k0) && chunks[sym_list[Q.list0 + k1]].frame_out_off == frame0)
+                    while (k1 < Q.n_list && (G1 ? k1 - k0 < G1 * G2 : (k1 - k0 < kGroupMaxBytes && (bytes < group_bytes || k1 == k0))) &&
+                           chunks[sym_list[Q.list0 + k1]].frame_out_off == frame0)
                         bytes += csize[sym_list[Q.list0 + k1]], k1++;
-                    const Chunk &first_c = chunks[sym_list[Q.list0 + k0]], &last = chunks[sym_list[Q.list0 + k1 - 1]];
+                    auto slots_end = [&](uint32_t k) {  // the end of list entry k's symbol slots
+                        const Chunk &c = chunks[sym_list[Q.list0 + k]];
+                        return c.elem_off + ((c.size + 3) & ~3ull);
+                    };
+                    const Chunk &first_c = chunks[sym_list[Q.list0 + k0]];
                     ResolveArgs ra;
                     ra.sym = (const uint32_t *)C.d_sym.p;
                     ra.chunks = (const Chunk *)C.d_chunks.p;
                     ra.sym_chunks = d_sym_list + Q.list0 + k0;
                     ra.n_sym_chunks = k1 - k0;
+                    ra.n_ctx = 0;
                     ra.out = out_bytes;
                     ra.final_below = first_c.out_off;
                     ra.elem0 = first_c.elem_off;
-                    ra.n_elems = last.elem_off + ((last.size + 3) & ~3ull) - first_c.elem_off;
-                    if (batches.size() <= j) batches.resize(j + 1);
-                    batches[j].push_back(ra);
+                    ra.n_elems = slots_end(k1 - 1) - first_c.elem_off;
+                    if (batches.size() <= u) batches.resize(u + 1);
+                    batches[u].push_back(ra);
+                    for (uint32_t v = 0, r0 = k0; G1 && r0 < k1; v++, r0 += G1) {  // the group's runs
+                        const uint32_t r1 = std::min(k1, r0 + G1);
+                        const Chunk &run_c = chunks[sym_list[Q.list0 + r0]];
+                        for (uint32_t m = 1; m < r1 - r0; m++) {
+                            ResolveArgs ia = ra;
+                            ia.sym_chunks = d_sym_list + Q.list0 + r0;
+                            ia.n_sym_chunks = m + 1;
+                            ia.n_ctx = m;
+                            ia.final_below = run_c.out_off;
+                            ia.elem0 = chunks[sym_list[Q.list0 + r0 + m]].elem_off;
+                            ia.n_elems = slots_end(r0 + m) - ia.elem0;
+                            if (inner1.size() < m) inner1.resize(m);
+                            inner1[m - 1].push_back(ia);
+                        }
+                        if (v) {
+                            ResolveArgs ia = ra;
+                            ia.n_sym_chunks = r1 - k0;
+                            ia.n_ctx = r0 - k0;
+                            ia.elem0 = run_c.elem_off;
+                            ia.n_elems = slots_end(r1 - 1) - ia.elem0;
+                            if (inner2.size() < v) inner2.resize(v);
+                            inner2[v - 1].push_back(ia);
+                        }
+                    }
                     k0 = k1;
                 }
             }
-            size_t n_shared = 0;  // arguments that travel through memory (batches of more than one group)
+            size_t n_shared = 0;  // arguments that travel through memory (the inner launches'; batches of more than one group)
+            for (const auto &b : inner1) n_shared += b.size();
+            for (const auto &b : inner2) n_shared += b.size();
             for (const auto &b : batches) n_shared += b.size() > 1 ? b.size() : 0;
             const ResolveArgs *d_args = nullptr;
             if (n_shared) {
@@ -1736,23 +1911,41 @@ int decode_round_enqueue_resolve(Round &R, RoundCtx *ctx_p) {
                 }
                 EXG_HIP_CHECK(C.d_rargs.alloc(n_shared * sizeof(ResolveArgs)));
                 size_t at = 0;
+                for (const auto *set : {&inner1, &inner2})
+                    for (const auto &b : *set) memcpy(C.h_rargs + at * sizeof(ResolveArgs), b.data(), b.size() * sizeof(ResolveArgs)), at += b.size();
                 for (const auto &b : batches)
                     if (b.size() > 1) memcpy(C.h_rargs + at * sizeof(ResolveArgs), b.data(), b.size() * sizeof(ResolveArgs)), at += b.size();
                 EXG_HIP_CHECK(hipMemcpyAsync(C.d_rargs.p, C.h_rargs, n_shared * sizeof(ResolveArgs), hipMemcpyHostToDevice, st));
                 d_args = (const ResolveArgs *)C.d_rargs.p;
             }
             size_t at = 0;
+            // (grid.y <= 65535: more groups than that in one batch are cut into several launches)
+            for (const auto *set : {&inner1, &inner2})
+                for (const auto &b : *set) {
+                    uint64_t widest = 0;
+                    for (const ResolveArgs &ra : b) widest = std::max<uint64_t>(widest, ra.n_elems);
+                    for (size_t g0 = 0; g0 < b.size(); g0 += 32768) {
+                        const size_t ng = std::min<size_t>(32768, b.size() - g0);
+                        hipLaunchKernelGGL(k_zst_resolve_inner, dim3((uint32_t)((widest + kRowElems - 1) / kRowElems), (uint32_t)ng), dim3(256), 0, st,
+                                           d_args + at + g0, (uint32_t *)C.d_sym.p);
+                    }
+                    at += b.size();
+                }
             for (const auto &b : batches) {
                 if (b.size() == 1) {
-                    hipLaunchKernelGGL(k_zst_resolve, dim3((uint32_t)((b[0].n_elems + 1023) / 1024)), dim3(256), 0, st, b[0]);
+                    if (G1) hipLaunchKernelGGL(k_zst_resolve<kResolveRows>, dim3((uint32_t)((b[0].n_elems + kRowElems - 1) / kRowElems)), dim3(256), 0, st, b[0]);
+                    else hipLaunchKernelGGL(k_zst_resolve<1>, dim3((uint32_t)((b[0].n_elems + 1023) / 1024)), dim3(256), 0, st, b[0]);
                     continue;
                 }
                 uint64_t widest = 0;
                 for (const ResolveArgs &ra : b) widest = std::max<uint64_t>(widest, ra.n_elems);
-                // (grid.y <= 65535: a round holds at most a few thousand frames' groups per batch; more are cut into several launches)
                 for (size_t g0 = 0; g0 < b.size(); g0 += 32768) {
                     const size_t ng = std::min<size_t>(32768, b.size() - g0);
-                    hipLaunchKernelGGL(k_zst_resolve_many, dim3((uint32_t)((widest + 1023) / 1024), (uint32_t)ng), dim3(256), 0, st, d_args + at + g0);
+                    if (G1)
+                        hipLaunchKernelGGL(k_zst_resolve_many<kResolveRows>, dim3((uint32_t)((widest + kRowElems - 1) / kRowElems), (uint32_t)ng), dim3(256), 0, st,
+                                           d_args + at + g0);
+                    else
+                        hipLaunchKernelGGL(k_zst_resolve_many<1>, dim3((uint32_t)((widest + 1023) / 1024), (uint32_t)ng), dim3(256), 0, st, d_args + at + g0);
                 }
                 at += b.size();
             }
