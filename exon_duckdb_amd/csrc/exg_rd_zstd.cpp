@@ -398,7 +398,10 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
         // the first frame carries a Content_Checksum: the host's XXH64, which hashes slower than the device decodes, begins after
         // ~25 ms instead of ~60 (223-262 against 247-284 ms on a 4 GB frame; nothing without a checksum: 121-127 against 126 ms).
         static const uint64_t first_div_env = getenv("EXG_ZSTD_FIRST_ROUND_DIV") ? std::max<uint64_t>(1, strtoull(getenv("EXG_ZSTD_FIRST_ROUND_DIV"), nullptr, 10)) : 0;
-        const uint64_t first_div = first_div_env ? first_div_env : (!idx.frames.empty() && idx.frames[idx.blocks[from].frame].has_checksum ? 4 : 1);
+        // (... and when the consumer pulls string columns: until the first segment is out nothing crosses the link, and behind it the
+        // drain is the link's — a 4 GB frame into DataChunks 161-165 -> 153-155 ms)
+        const uint64_t first_div =
+            first_div_env ? first_div_env : ((!idx.frames.empty() && idx.frames[idx.blocks[from].frame].has_checksum) || sink.mirror_wanted() ? 4 : 1);
         // (and the second round half: a whole round behind the quarter left the hasher idle for ~14 ms of a 4 GB frame's time)
         const uint64_t div = !read_ahead_ ? 1 : from == b_first ? first_div : from == ramp_second && first_div > 1 ? first_div / 2 : 1;
         const uint64_t want_out = std::min<uint64_t>(target_, std::max<uint64_t>(target_ / std::max<uint64_t>(div, 1), 16u << 20));
