@@ -463,8 +463,17 @@ def run_record_shapes(torch, lib, args):
         ms_first, _ = timed_launches(torch, lambda: scan.launch(d_in, algo=abi.EXG_ALGO_FUSED, **kw), 3, warm=0)
         ms, ms_min = timed_launches(torch, lambda: scan.launch(d_in, algo=abi.EXG_ALGO_FUSED_FULL, **kw), 6, warm=1)
         res = scan.fetch()
+        # ... and with the rows left to a kernel of their own (EXG_ALGO_FUSED_INDEX: what the reader switches to on lines of >= 256 bytes);
+        # the rows checked below are this launch's
+        try:
+            ms_ix, ms_ix_min = timed_launches(torch, lambda: scan.launch(d_in, algo=abi.EXG_ALGO_FUSED_INDEX, **kw), 6, warm=1)
+            res_ix = scan.fetch()
+        except Exception:  # (a library build from before the selector existed: tools/ab_shapes.sh)
+            ms_ix = ms_ix_min = float("nan")
+            res_ix = res
         ok = res.error_code == 0 and r1.error_code == 0 and int(res.n_records) == n_lines * reps == int(r1.n_records)
-        ok = ok and not ((res.flags | r1.flags) & abi.EXG_RF_FALLBACK)
+        ok = ok and res_ix.error_code == 0 and int(res_ix.n_records) == n_lines * reps
+        ok = ok and not ((res.flags | r1.flags | res_ix.flags) & abi.EXG_RF_FALLBACK)
         if ok:
             pos = torch.from_numpy(e["pos"]).cuda()
             chrom = torch.from_numpy(e["chrom"]).cuda()
@@ -481,10 +490,19 @@ def run_record_shapes(torch, lib, args):
                 bits[-1] &= (1 << ((n_lines * reps) % 64)) - 1
             got = sum(int(((bits >> b) & 1).sum()) for b in range(64))
             ok = ok and got == nq
+        # what the reader runs from its third batch on: lines of >= 2 KiB go to EXG_ALGO_FUSED_INDEX (exg_rd_batch.cpp), shorter ones stay
+        use_ix = len(block) // n_lines >= 2048 and ms_ix == ms_ix
+        ms_full, ms_full_min = ms, ms_min
+        if use_ix:
+            ms, ms_min = ms_ix, ms_ix_min
         out[name] = {"workload": f"read_vcf, lines of {n_samples} samples ({len(block) // n_lines} B each): {n / 1e9:.2f} GB in HBM "
                                  f"({n_lines * reps} lines, a {len(block) / 1e6:.0f} MB block x {reps}), all columns + typed POS / QUAL",
                      "algorithmic_bytes": n, "ms": ms, "ms_min": ms_min, "GB/s": n / (ms * 1e-3) / 1e9, "frac": n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                     "lines_per_s": n_lines * reps / (ms * 1e-3), "algo": "EXG_ALGO_FUSED_FULL (the any-shape scan alone)",
+                     "lines_per_s": n_lines * reps / (ms * 1e-3),
+                     "algo": ("EXG_ALGO_FUSED_INDEX (the any-shape scan notes where the lines end, k_vcf_lines parses the rows behind it: the reader's "
+                              "choice for lines of >= 2 KiB)" if use_ix else "EXG_ALGO_FUSED_FULL (the any-shape scan alone)"),
+                     "full_ms": ms_full, "full_GB/s": n / (ms_full * 1e-3) / 1e9,
+                     "indexed_ms": ms_ix, "indexed_ms_min": ms_ix_min, "indexed_GB/s": n / (ms_ix * 1e-3) / 1e9,
                      "first_batch_ms": ms_first, "first_batch_GB/s": n / (ms_first * 1e-3) / 1e9,
                      "first_batch_algo": "EXG_ALGO_FUSED (lean scan + any-shape run over the super-tiles it marked)",
                      "lean_scan_marked_tiles": bool(r1.flags & abi.EXG_RF_REDO),

@@ -30,7 +30,7 @@ EXG_F_BOF, EXG_F_EOF, EXG_F_NO_STORE = 1, 2, 4
 EXG_RF_NON_ASCII, EXG_RF_HEAD_UNRESOLVED, EXG_RF_FALLBACK, EXG_RF_CAPACITY, EXG_RF_INDEX_OVERFLOW = 1, 2, 4, 8, 16
 EXG_RF_QUAL_RANGE = 32
 EXG_RF_REDO = 64
-EXG_ALGO_AUTO, EXG_ALGO_MULTIPASS, EXG_ALGO_FUSED, EXG_ALGO_FUSED_FULL = 0, 1, 2, 3
+EXG_ALGO_AUTO, EXG_ALGO_MULTIPASS, EXG_ALGO_FUSED, EXG_ALGO_FUSED_FULL, EXG_ALGO_FUSED_INDEX = 0, 1, 2, 3, 4
 
 EXG_SYNTH_FASTQ_SEED = 0xE0A5EED0001
 EXG_SYNTH_VCF_SEED = 0xE0A5EED0002

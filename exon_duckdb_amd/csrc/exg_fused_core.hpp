@@ -365,7 +365,9 @@ struct TileCtx {  // what emission needs besides the LDS contents (all workgroup
 // Any shape: the half's lines are emitted kNlCap at a time (the 4 newlines in front of a pass are the last 4 of the pass
 // before); the record that begins in front of the window — at most one per half — is written as a FarRec for k_*_far; the 4
 // newlines in front of a half are carried as CODES (FarRec::pos), not as window offsets.
-enum { kLean = 0, kFullPrimary = 1, kFullRedo = 2 };
+// (kFullIndex: kFullPrimary with the format's "index" emission — VcfFormat: the half notes where its lines end, a kernel behind
+// the scan parses the rows; an instantiation of its own so that the any-shape scan proper keeps its registers and schedule)
+enum { kLean = 0, kFullPrimary = 1, kFullRedo = 2, kFullIndex = 3 };
 static constexpr unsigned int kRedoFar = 1u, kRedoDense = 2u, kRedoLast4 = 4u, kRedoUtf8 = 8u;  // tile_redo[st]: why (diagnostics; any bit = redo)
 
 // tile_redo (u32 per super-tile) lies between tileP and tile_qend: tileA | tileP | tile_redo are zeroed by one memset
@@ -383,12 +385,12 @@ __device__ __forceinline__ FarRec *far_rec_of(unsigned long long *tile_qend, uin
 }
 
 template <class F, int kMode>
-__global__ __launch_bounds__(kThreads, kMode == kLean ? F::kMinWavesPerSimd : kMode == kFullPrimary ? F::kMinWavesPerSimdFull : F::kMinWavesPerSimdRedo) void k_fused(
+__global__ __launch_bounds__(kThreads, kMode == kLean ? F::kMinWavesPerSimd : (kMode == kFullPrimary || kMode == kFullIndex) ? F::kMinWavesPerSimdFull : F::kMinWavesPerSimdRedo) void k_fused(
     typename F::Dev a, unsigned int *__restrict__ tileA, unsigned long long *__restrict__ tileP, unsigned long long *__restrict__ tile_qend,
     ScanWsHeader *hdr, uint32_t n_super) {
     // (the any-shape scan that runs ALONE may cut its super-tiles differently from the lean scan and its redo run, which share
     // tile_redo: every per-half / per-super-tile array of the workspace is sized by 16 KiB tiles)
-    constexpr int kHalves = kMode == kFullPrimary ? F::kHalvesFull : F::kHalves;
+    constexpr int kHalves = (kMode == kFullPrimary || kMode == kFullIndex) ? F::kHalvesFull : F::kHalves;
     using FusedLds = FusedLdsT<F::kNlCap, kHalves, (kMode == kLean ? F::kTabMapLean : F::kTabMapFull)>;
     constexpr int kNlCap = F::kNlCap;
     constexpr int kSuper = kTile * kHalves;
@@ -682,7 +684,7 @@ __global__ __launch_bounds__(kThreads, kMode == kLean ? F::kMinWavesPerSimd : kM
                     s.carry32[tid] = code;
                     if (h + 1 == kHalves || lim_s <= (h + 1) * kTile) tile_last4_of<kB>(tile_qend, a.n_bytes)[(uint64_t)st * 4 + tid] = code;
                 }
-                F::template emit_half<kFullPrimary>(s, a, hdr, c, halo_nl, dev_mode, lane, wave, tile_qend, half_index);
+                F::template emit_half<(kMode == kFullIndex ? kFullIndex : kFullPrimary)>(s, a, hdr, c, halo_nl, dev_mode, lane, wave, tile_qend, half_index);
                 base += m;
                 if (base >= n_lines) break;
                 uint16_t keep = 0;

@@ -939,6 +939,15 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             const uint64_t tile_bytes = r->format == EXG_FMT_FASTQ ? 3u * 16384u : 2u * 16384u;
             if (res.redo_tiles * 8 > n / tile_bytes) r->fused_algo = EXG_ALGO_FUSED_FULL;
         }
+        if (r->format == EXG_FMT_VCF && res.n_lines) {
+            // the any-shape scan on WIDE lines (cohort VCFs) leaves the rows to a kernel of their own (EXG_ALGO_FUSED_INDEX: exg_vcf.hip):
+            // 1.12 ms per 4 GB + ~1 us per 1 000 rows against 1.73 ms with the rows inside the scan — better above ~1.7 kB a line;
+            // sticky both ways with a gap between the thresholds (EXG_NO_VCF_INDEX: never — A/B)
+            const bool no_index = getenv("EXG_NO_VCF_INDEX") != nullptr;  // (per batch: the tests switch it inside one process)
+            const uint64_t per_line = (n - lead) / res.n_lines;
+            if (r->fused_algo == EXG_ALGO_FUSED_FULL && per_line >= 2048 && !no_index) r->fused_algo = EXG_ALGO_FUSED_INDEX;
+            else if (r->fused_algo == EXG_ALGO_FUSED_INDEX && per_line < 1280) r->fused_algo = EXG_ALGO_FUSED_FULL;
+        }
         TRACE("wait(h2d) + scan", t_scan);
         if (r->shard_first && (res.flags & EXG_RF_HEAD_UNRESOLVED) && r->file_pos - shard_halo > r->data_base) {
             // The record that ends behind the cut begins in front of the halo (a long read, a very wide VCF line): it belongs

@@ -42,6 +42,10 @@ struct VcfDev {
     uint64_t capacity;
     SlowLiteral *d_slow;  // workspace list of the QUAL literals left to the exact parser
     uint64_t slow_cap;
+    // EXG_ALGO_FUSED_INDEX: the any-shape scan writes where line j of the buffer ends to d_nl_pos[j] instead of parsing it
+    // (nl_cap entries; NULL: it parses), k_vcf_lines parses behind it
+    uint64_t *d_nl_pos;
+    uint64_t nl_cap;
 };
 
 struct VcfRowInfo {
@@ -316,6 +320,22 @@ struct VcfFormat {
             tile_qend[tile_index] = qend_word;
         }
         if (dev_mode == 3 || dev_mode == 4) return;
+        if constexpr (kMode == kFullIndex) {
+            // EXG_ALGO_FUSED_INDEX (round 5).  A half of a cohort VCF holds 1-40 lines: thread = line leaves ONE wave running each
+            // line's ~1 500 dependent instructions while its sisters wait — the scan is bound by that latency per workgroup (2.2-2.3
+            // TB/s; without the rows 3.1-3.9).  Here the half only says where its lines end — an 8-byte store a line, halo lines
+            // included (the line behind them begins at theirs), and the line that began in front of the window is a line like any
+            // other: no FarRec — and k_vcf_lines parses all rows of the buffer behind the scan, a thread per line, every line's
+            // chain beside thousands of others.
+            for (uint32_t jb = 0; jb < c.n_lines; jb += kThreads) {
+                const uint32_t j = jb + t_rot;
+                if (j >= c.n_lines) break;
+                const unsigned long long row = c.P + j;
+                if (row < a.nl_cap) a.d_nl_pos[row] = (unsigned long long)((long long)c.tile_off + (int)s.nlist[4 + j] - kWin);
+                else hdr->overflow = 1u;  // (the result says EXG_RF_FALLBACK: the caller's general path takes the batch)
+            }
+            return;
+        }
         const bool no_store = (a.flags & EXG_F_NO_STORE) != 0;
         const LdsSrc<L> src{s, a.payload_base + c.tile_off - kWin, s.tabmap[L::kHasTabs ? c.half : 0]};
         for (uint32_t jb = 0; jb < c.n_lines; jb += kThreads) {
@@ -381,31 +401,76 @@ struct VcfFormat {
 
 // ---- general path: thread = line, bytes from global memory -----------------------------------------------
 struct GlobalSrc {
-    const uint8_t *p;  // d_in
+    const uint8_t *p;  // d_in (16-byte aligned)
     uint64_t base;     // offset added to the (int) positions
     uint64_t payload_base;
     uint64_t limit;  // n_bytes rounded up to 16: reads past it are not allowed
+    // Round 5: aligned dword / 16-byte loads + a byte shift instead of a load per byte (u32 was four byte loads with a bound check
+    // each, tabs64 sixty-four: the rows k_vcf_far and k_vcf_lines parse out of global memory cost ~2 us of dependent loads each —
+    // a cohort VCF has one such row per half).  An aligned block that begins below `limit` lies inside the buffer; the last
+    // bytes of the buffer take the former byte path.
     __device__ __forceinline__ uint32_t b(int i) const { return p[base + (uint64_t)(int64_t)i]; }
-    __device__ __forceinline__ uint32_t u32(int i) const {
-        uint64_t o = base + (uint64_t)(int64_t)i;
+    __device__ __forceinline__ uint32_t u32_slow(uint64_t o) const {
         uint32_t w = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++)
             if (o + k < limit) w |= (uint32_t)p[o + k] << (8 * k);
         return w;
     }
+    __device__ __forceinline__ uint32_t u32(int i) const {
+        const uint64_t o = base + (uint64_t)(int64_t)i, al = o & ~3ull;
+        if (al + 8 > limit) return u32_slow(o);
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(p + al);
+        return __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)(o & 3));
+    }
     __device__ __forceinline__ void u96(int i, uint32_t *w0, uint32_t *w1, uint32_t *w2) const {
-        *w0 = u32(i), *w1 = u32(i + 4), *w2 = u32(i + 8);
+        const uint64_t o = base + (uint64_t)(int64_t)i, al = o & ~3ull;
+        if (al + 16 > limit) {
+            *w0 = u32_slow(o), *w1 = u32_slow(o + 4), *w2 = u32_slow(o + 8);
+            return;
+        }
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(p + al);
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], sh = (uint32_t)(o & 3);
+        *w0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
+        *w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        *w2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
     }
     __device__ __forceinline__ uint4 str(int i, uint32_t len) const {
-        return make_string_global(p, base + (uint64_t)(int64_t)i, len, payload_base);
+        const uint64_t o = base + (uint64_t)(int64_t)i;
+        if (((o & ~3ull) + 16) > limit) return make_string_global(p, o, len, payload_base);
+        uint32_t w0, w1, w2;
+        u96(i, &w0, &w1, &w2);
+        uint4 r;
+        r.x = len;
+        if (len <= EXG_INLINE_LENGTH) {  // the bytes behind the field are not the string's: zeros
+            const uint32_t n0 = len < 4u ? len : 4u, n1 = len < 4u ? 0u : len - 4u < 4u ? len - 4u : 4u, n2 = len < 8u ? 0u : len - 8u;
+            r.y = n0 == 4 ? w0 : w0 & ((1u << (8 * n0)) - 1u);
+            r.z = n1 == 4 ? w1 : w1 & ((1u << (8 * n1)) - 1u);
+            r.w = n2 == 4 ? w2 : w2 & ((1u << (8 * n2)) - 1u);
+        } else {
+            const uint64_t ptr = payload_base + o;
+            r.y = w0;
+            r.z = (uint32_t)ptr;
+            r.w = (uint32_t)(ptr >> 32);
+        }
+        return r;
     }
     __device__ __forceinline__ bool tab_bits(int, unsigned long long *) const { return false; }
-    __device__ __forceinline__ unsigned long long tabs64(int base) const {
-        unsigned long long bits = 0;
+    __device__ __forceinline__ unsigned long long tabs64(int base_i) const {
+        const uint64_t o = base + (uint64_t)(int64_t)base_i, al = o & ~15ull;
+        if (al + 80 > limit) {
+            unsigned long long bits = 0;
 #pragma unroll
-        for (int q = 0; q < 16; q++) bits |= (unsigned long long)nib4(match4(u32(base + 4 * q), 0x09090909u)) << (4 * q);
-        return bits;
+            for (int q = 0; q < 16; q++) bits |= (unsigned long long)nib4(match4(u32_slow(o + 4 * q), 0x09090909u)) << (4 * q);
+            return bits;
+        }
+        const uint4 *q = reinterpret_cast<const uint4 *>(p + al);
+        const uint4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3], v4 = q[4];  // (five loads in flight)
+        const unsigned long long lo = (unsigned long long)match16(v0, 0x09090909u) | ((unsigned long long)match16(v1, 0x09090909u) << 16) |
+                                      ((unsigned long long)match16(v2, 0x09090909u) << 32) | ((unsigned long long)match16(v3, 0x09090909u) << 48);
+        const unsigned long long hi = match16(v4, 0x09090909u);
+        const uint32_t sh = (uint32_t)(o & 15);
+        return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
     }
 };
 
@@ -613,8 +678,13 @@ static int run_vcf_general(const VcfDev &dev, uint8_t *ws, const FastqWsLayout &
     return EXG_OK;
 }
 
-static int run_vcf_fused(const VcfDev &dev, uint8_t *ws, const FastqWsLayout &l, exg_scan_result *d_result,
-                         hipStream_t stream, bool full) {
+static int run_vcf_fused(const VcfDev &dev_in, uint8_t *ws, const FastqWsLayout &l, exg_scan_result *d_result,
+                         hipStream_t stream, bool full, bool index = false) {
+    VcfDev dev = dev_in;
+    if (index) {
+        dev.d_nl_pos = reinterpret_cast<uint64_t *>(ws + l.off_nl_pos);
+        dev.nl_cap = l.lines_cap;
+    }
     ScanWsHeader *hdr = reinterpret_cast<ScanWsHeader *>(ws);
     const uint32_t kHalvesHost = full ? VcfFormat::kHalvesFull : VcfFormat::kHalves;
     const uint64_t kSuperBytes = (uint64_t)kHalvesHost * kTile;
@@ -639,7 +709,9 @@ static int run_vcf_fused(const VcfDev &dev, uint8_t *ws, const FastqWsLayout &l,
         int rc = exg_count_newlines(dev.d_in, 0, dev.lead, (uint64_t *)&hdr->halo_nl, stream);
         if (rc) return rc;
     }
-    if (full) {
+    if (index) {
+        hipLaunchKernelGGL((k_fused<VcfFormat, kFullIndex>), dim3(n_super + 1), dim3(kThreads), 0, stream, dev, tileA, tileP, tile_qend, hdr, n_super);
+    } else if (full) {
         hipLaunchKernelGGL((k_fused<VcfFormat, kFullPrimary>), dim3(n_super + 1), dim3(kThreads), 0, stream, dev, tileA, tileP, tile_qend, hdr, n_super);
     } else {
         hipLaunchKernelGGL((k_fused<VcfFormat, kLean>), dim3(n_super + 1), dim3(kThreads), 0, stream, dev, tileA, tileP, tile_qend, hdr, n_super);
@@ -647,7 +719,14 @@ static int run_vcf_fused(const VcfDev &dev, uint8_t *ws, const FastqWsLayout &l,
         hipLaunchKernelGGL((k_fused<VcfFormat, kFullRedo>), dim3(n_super < 1024 ? n_super : 1024), dim3(kThreads), 0, stream, dev, tileA, tileP,
                            tile_qend, hdr, n_super);
     }
-    {   // the rows of lines that begin in front of their half's window (returns at once when there is none)
+    if (index) {
+        // the rows, a thread per line (the any-shape scan left hdr->total_lines, halo_nl and the non-ASCII flag like the line index does)
+        VcfDev rows = dev;
+        rows.d_nl_pos = nullptr;
+        const uint64_t est = dev.n_bytes / 256 + 256;
+        const uint32_t grid = (uint32_t)((est + 255) / 256 < 4096 ? (est + 255) / 256 : 4096);
+        hipLaunchKernelGGL(k_vcf_lines, dim3(grid), dim3(256), 0, stream, rows, (const uint64_t *)dev.d_nl_pos, hdr, (const unsigned int *)nullptr);
+    } else {   // the rows of lines that begin in front of their half's window (returns at once when there is none)
         const uint32_t n_halves = n_super * kHalvesHost;
         const uint32_t grid = (n_halves + 255) / 256 < 4096 ? (n_halves + 255) / 256 : 4096;
         if (full)
@@ -701,6 +780,8 @@ extern "C" int exg_vcf_scan(const exg_vcf_scan_args *a) {
     uint8_t *ws = (uint8_t *)a->d_workspace;
     dev.d_slow = reinterpret_cast<SlowLiteral *>(ws + l.off_slow);
     dev.slow_cap = l.slow_cap;
+    dev.d_nl_pos = nullptr;
+    dev.nl_cap = 0;
     if (a->capacity_records && !(a->flags & EXG_F_NO_STORE)) {
         size_t vb = (size_t)((a->capacity_records + 63) / 64) * 8;
         if (dev.d_qual_valid) EXG_HIP_CHECK(hipMemsetAsync(dev.d_qual_valid, 0, vb, stream));
@@ -713,6 +794,8 @@ extern "C" int exg_vcf_scan(const exg_vcf_scan_args *a) {
             return run_vcf_fused(dev, ws, l, a->d_result, stream, false);
         case EXG_ALGO_FUSED_FULL:
             return run_vcf_fused(dev, ws, l, a->d_result, stream, true);
+        case EXG_ALGO_FUSED_INDEX:
+            return run_vcf_fused(dev, ws, l, a->d_result, stream, true, true);
         case EXG_ALGO_AUTO: {
             int rc = run_vcf_fused(dev, ws, l, a->d_result, stream, false);
             if (rc) return rc;

@@ -127,6 +127,10 @@ typedef union exg_string_t {
 #define EXG_ALGO_FUSED 2     /* single pass: the lean scan, then the any-shape scan over the super-tiles the lean one marked */
 #define EXG_ALGO_FUSED_FULL 3 /* single pass: the any-shape scan alone (any record length / line density; 17 % below the lean scan
                                * on 150 bp reads: 2.65 against 2.27 ms per 10 GB) */
+#define EXG_ALGO_FUSED_INDEX 4 /* exg_vcf_scan only — wide lines (cohort VCFs: hundreds of bytes to 10 kB a line): the any-shape scan
+                               * only notes where every line ends (8 bytes a line, in the workspace), the rows are parsed by a
+                               * kernel of their own behind it, a thread per line.  Same rows, flags and errors as
+                               * EXG_ALGO_FUSED_FULL; slower than it on short lines */
 
 /* Written by the device (64 bytes, 8-byte aligned), copied back by exg_fetch_result. */
 typedef struct exg_scan_result {

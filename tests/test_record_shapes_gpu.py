@@ -314,7 +314,17 @@ def test_reader_short_reads_and_wide_vcf(gpu, oracle, tmp_path):
     want = list(zip(t.columns["chrom"].to_list(), [int(x) for x in t.extra["pos"]], t.columns["ref"].to_list(),
                     [float(q) if v else None for q, v in zip(t.extra["qual"], t.extra["qual_valid"])]))
     assert len(got) == 900 and got == want
-    assert st["scan_algo"] == abi.EXG_ALGO_FUSED_FULL
+    # lines of 10 kB: the any-shape scan, then (round 5) with the rows left to a kernel of their own
+    assert st["scan_algo"] == abi.EXG_ALGO_FUSED_INDEX
+    # ... the same rows without that switch, and all columns of lines of ~500 bytes (which stay with the any-shape scan)
+    import os
+    os.environ["EXG_NO_VCF_INDEX"] = "1"
+    try:
+        r = ShardReader(str(pv), "vcf", device_batch_bytes=1 << 20, columns=[0, 1, 3, 5])
+        assert r.rows() == want and r.stats()["scan_algo"] == abi.EXG_ALGO_FUSED_FULL
+        r.close()
+    finally:
+        del os.environ["EXG_NO_VCF_INDEX"]
 
 
 def test_reader_non_ascii_batches(gpu, oracle, tmp_path):

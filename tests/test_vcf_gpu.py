@@ -10,8 +10,10 @@ from exon_duckdb_amd import abi
 pytestmark = pytest.mark.gpu
 
 BASE = 0x7E0000000000
-ALGOS = [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS, abi.EXG_ALGO_AUTO, abi.EXG_ALGO_FUSED_FULL]
-FUSED = (abi.EXG_ALGO_FUSED, abi.EXG_ALGO_FUSED_FULL)   # the lean scan + the any-shape run over what it marked; the any-shape scan alone
+ALGOS = [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS, abi.EXG_ALGO_AUTO, abi.EXG_ALGO_FUSED_FULL, abi.EXG_ALGO_FUSED_INDEX]
+# the lean scan + the any-shape run over what it marked; the any-shape scan alone; the any-shape scan noting the line ends for a
+# kernel behind it that parses the rows (round 5: wide lines)
+FUSED = (abi.EXG_ALGO_FUSED, abi.EXG_ALGO_FUSED_FULL, abi.EXG_ALGO_FUSED_INDEX)
 HDR = b"##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n"
 
 
@@ -155,7 +157,28 @@ def test_long_lines_stay_on_the_single_pass(gpu, oracle, algo):
     assert res.n_records == 200 and not (res.flags & abi.EXG_RF_FALLBACK)
 
 
-@pytest.mark.parametrize("algo", [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS, abi.EXG_ALGO_FUSED_FULL])
+def test_indexed_scan_on_wide_lines_and_when_its_index_is_too_small(gpu, oracle):
+    """EXG_ALGO_FUSED_INDEX (round 5): the any-shape scan notes where every line ends (8 bytes a line in the workspace), k_vcf_lines
+    parses the rows behind it — lines of 10 kB that straddle halves and super-tiles, CRLF, a last line without a newline; and a
+    buffer with more lines than the workspace's index holds (one per 8 bytes of input: only empty lines get there) says
+    EXG_RF_FALLBACK like every fused launch that gives a batch up, it does not write past the index"""
+    rng = np.random.default_rng(11)
+    lines = []
+    for k in range(300):
+        ns = int(rng.integers(2000, 2600))
+        eol = b"\r\n" if k % 7 == 0 else b"\n"
+        lines.append(b"chr%d\t%d\trs%d\tA\tC,G\t%s\tPASS\tDP=%d;AF=0.5\tGT:DP" % (k % 22 + 1, 1000 + k, k, b"." if k % 5 == 0 else b"%d.25" % k, k)
+                     + b"\t0/1:12" * ns + eol)
+    data = HDR + b"".join(lines)
+    for d in (data, data[:-1]):
+        res = check(oracle, d, abi.EXG_ALGO_FUSED_INDEX)
+        assert res.n_records == 300 and not (res.flags & abi.EXG_RF_FALLBACK)
+    # (the index holds a line per 8 bytes of input, and never fewer than min(n, 1 Mi) lines: 12 MiB of empty lines overflow it)
+    res, _ = run_gpu(HDR + b"\n" * (12 << 20), abi.EXG_ALGO_FUSED_INDEX, capacity=1024)
+    assert res.flags & abi.EXG_RF_FALLBACK
+
+
+@pytest.mark.parametrize("algo", [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS, abi.EXG_ALGO_FUSED_FULL, abi.EXG_ALGO_FUSED_INDEX])
 def test_qual_parse_is_correctly_rounded(gpu, oracle, algo):
     rng = np.random.default_rng(11)
     quals = []
@@ -200,7 +223,7 @@ def test_long_and_extreme_qual_literals_are_exact(gpu, oracle):
         quals.append(repr(x).encode())
         quals.append(repr(float(np.float32(x))).encode())
     lines = [b"1\t5\t.\tA\tC\t" + q + b"\tPASS\t.\n" for q in quals]
-    for algo in (abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS):
+    for algo in (abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS, abi.EXG_ALGO_FUSED_INDEX):
         res = check(oracle, HDR + b"".join(lines), algo)
         assert res.error_code == 0 and res.n_records == len(quals)
 
@@ -216,7 +239,7 @@ def test_long_literals_astride_a_rounding_boundary_are_decided_exactly(gpu, orac
             "-0.000000000000000000000000000000000000000000000700649232162408535461864791644958065640130970938257885878534141944895541342930300743319094181060791015626",
             "340282356779733661637539395458142568447.9999999", "16777219.000000000000000000001", "8388609.4999999999999999999999", "0.1" + "0" * 30 + "1"]
     lits = [l.encode() for l in lits]
-    for algo in (abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS):
+    for algo in (abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS, abi.EXG_ALGO_FUSED_INDEX):
         data = HDR + b"".join(b"1\t%d\t.\tA\tC\t" % (5 + k) + q + b"\tPASS\t.\n" for k, q in enumerate(lits) if not q.startswith(b"-"))
         res = check(oracle, data, algo)
         assert res.error_code == 0 and res.n_records == len(lits) - 1 and not (res.flags & abi.EXG_RF_QUAL_RANGE)
@@ -228,7 +251,7 @@ def test_long_literals_astride_a_rounding_boundary_are_decided_exactly(gpu, orac
     # of input, at most 4096)
     many = [lits[k % 4] for k in range(700)]
     data = HDR + b"".join(b"1\t%d\t.\tA\tC\t" % (5 + k) + q + b"\tPASS\t.\n" for k, q in enumerate(many))
-    for algo in (abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS):
+    for algo in (abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS, abi.EXG_ALGO_FUSED_INDEX):
         res = check(oracle, data, algo)
         assert res.error_code == 0 and res.n_records == len(many) and not (res.flags & abi.EXG_RF_QUAL_RANGE)
     # more than the list can hold (4096 per launch): reported, never mis-rounded
@@ -250,7 +273,7 @@ def test_short_decimal_qual_and_pos_fast_paths_are_exact(gpu, oracle):
             b"9223372036854775807", b"000000000000000000012"]
     lines = [b"1\t5\t.\tA\tC\t" + q + b"\tPASS\t.\n" for q in quals]
     lines += [b"1\t" + p + b"\t.\tA\tC\t1.5\tPASS\t.\n" for p in poss]
-    for algo in (abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS):
+    for algo in (abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS, abi.EXG_ALGO_FUSED_INDEX):
         check(oracle, HDR + b"".join(lines), algo)
     for bad in (b"9223372036854775808", b"12a", b"+", b""):
         res = check(oracle, HDR + b"1\t" + bad + b"\t.\tA\tC\t1.5\tPASS\t.\n", abi.EXG_ALGO_AUTO)
@@ -300,7 +323,7 @@ def test_random_number_fields(gpu, oracle, seed):
     rows = [b"%d\t%s\t.\tA\tC\t%s\tPASS\tDP=%d\n" % (1 + i % 22, pos().encode(), qual().encode(), int(rng.integers(0, 1000)))
             for i in range(3000)]
     data = HDR + b"".join(rows)
-    for algo in (abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS):
+    for algo in (abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS, abi.EXG_ALGO_FUSED_INDEX):
         res = check(oracle, data, algo)
         assert res.error_code == 0 and res.n_records == len(rows)
     bad_lits = [b"12a4", b"1..2", b"--1", b"1e", b"e5", b"+", b"1 2", b"0x10", b"-5", b"-inf"]
@@ -311,12 +334,12 @@ def test_random_number_fields(gpu, oracle, seed):
         cols = rows[r].split(b"\t")
         cols[field] = bad
         broken = HDR + b"".join(rows[:r]) + b"\t".join(cols) + b"".join(rows[r + 1:])
-        for algo in (abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS):
+        for algo in (abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS, abi.EXG_ALGO_FUSED_INDEX):
             res = check(oracle, broken, algo)
             assert res.error_code != 0 and res.error_record == r, (bad, field)
 
 
-@pytest.mark.parametrize("algo", [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS, abi.EXG_ALGO_FUSED_FULL])
+@pytest.mark.parametrize("algo", [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS, abi.EXG_ALGO_FUSED_FULL, abi.EXG_ALGO_FUSED_INDEX])
 def test_projection_and_capacity(gpu, oracle, algo):
     from exon_duckdb_amd import device
 

@@ -10,6 +10,6 @@ for l in sys.stdin:
     k,v=l.split(' ',1)
     try: d=json.loads(v)
     except Exception: continue
-    print(k, d['GB/s'], d['first_batch_GB/s'], d['verified'], end=' | ')")"
+    print(k, d['GB/s'], d.get('indexed_GB/s'), d['first_batch_GB/s'], d['verified'], end=' | ')")"
   done
 done

@@ -8,4 +8,4 @@ from exon_duckdb_amd import load_library
 args = types.SimpleNamespace(shape_gb=float(sys.argv[1]) if len(sys.argv) > 1 else 2.0, shape_only=sys.argv[2] if len(sys.argv) > 2 else "")
 out = bench.run_record_shapes(torch, load_library(), args)
 for k, v in out.items():
-    print(k, json.dumps({a: (round(b, 3) if isinstance(b, float) else b) for a, b in v.items() if a not in ("workload", "algo", "first_batch_algo")}))
+    print(k, json.dumps({a: (round(b, 3) if isinstance(b, float) else b) for a, b in v.items() if a not in ("workload", "algo", "first_batch_algo", "indexed_algo")}))
