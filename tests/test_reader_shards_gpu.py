@@ -173,6 +173,43 @@ def test_vcf_line_longer_than_the_halo_across_a_cut(gpu, oracle, tmp_path):
         assert [r[:2] for r in got] == [r[:2] for r in want] and len(got) == 3001
 
 
+@pytest.mark.parametrize("n_shards", [1, 3, 7])
+def test_cohort_vcf_shards_under_the_indexed_scan(gpu, oracle, tmp_path, monkeypatch, n_shards):
+    """lines of 3 - 14 kB in batches of 1 MiB: behind its first batches a shard's reader leaves the rows to a kernel of their own
+    (EXG_ALGO_FUSED_INDEX, round 5) — halo lines in front of a shard's first own line, lines across batch ends, CRLF, '.' QUAL, a
+    last line without a newline; the shards' rows are the file's rows in order, with and without the switch"""
+    from exon_duckdb_amd import abi
+    from exon_duckdb_amd.reader import ShardReader
+    rng = np.random.default_rng(21)
+    hdr = b"##fileformat=VCFv4.2\n##contig=<ID=chr1>\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ts\n"
+    lines = []
+    for k in range(1500):
+        ns = int(rng.integers(600, 2800))
+        eol = b"\r\n" if k % 11 == 0 else b"\n"
+        lines.append(b"chr1\t%d\trs%d\t%s\tC\t%s\tPASS\tDP=%d;AF=0.25\tGT:DP" % (1000 + k, k, b"A" * (1 + k % 20), b"." if k % 4 == 0 else b"%d.5" % (k % 97), k)
+                     + b"\t0/1:7" * ns + eol)
+    data = hdr + b"".join(lines)
+    data = data[:-1]  # no last newline
+    p = tmp_path / "cohort.vcf"
+    p.write_bytes(data)
+    t = oracle.vcf_parse(data, want_string_t=False)
+    assert t.error_code == 0 and t.n_rows == 1500
+    want = list(zip(t.columns["chrom"].to_list(), [int(x) for x in t.extra["pos"]], t.columns["ref"].to_list(),
+                    [float(q) if v else None for q, v in zip(t.extra["qual"], t.extra["qual_valid"])]))
+    monkeypatch.setenv("EXG_SHARD_HALO", "4096")  # (smaller than a line: the shard looks further back and scans again)
+    for no_index in (False, True):
+        if no_index:
+            monkeypatch.setenv("EXG_NO_VCF_INDEX", "1")
+        got, algos = [], set()
+        for i in range(n_shards):
+            r = ShardReader(str(p), "vcf", shard_index=i, shard_count=n_shards, device_batch_bytes=1 << 20, columns=[0, 1, 3, 5])
+            got.extend(r.rows())
+            algos.add(r.stats()["scan_algo"])
+            r.close()
+        assert got == want
+        assert (abi.EXG_ALGO_FUSED_INDEX in algos) == (not no_index)
+
+
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("EXG_SHARD_FUZZ", "12"))))
 def test_random_shard_geometry(gpu, oracle, tmp_path, monkeypatch, seed):
     # random record counts, shard counts, halo sizes and device batch sizes; text and BGZF (random member sizes)
