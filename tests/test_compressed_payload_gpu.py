@@ -105,3 +105,35 @@ def test_projection_of_a_bgzip_vcf_with_long_ref_alleles(gpu, oracle, tmp_path, 
     # a nested column in the projection: the whole payload travels (the emitter's views are cut out of the line's text)
     full = _rows(p, "vcf", columns=[0, 3, 4])
     assert [(f[0], f[1]) for f in full] == [(w[0], w[2]) for w in want] and full[0][2] == [b"A"]
+
+
+@pytest.mark.parametrize("cols", [[0, 1, 3], None])
+def test_bgzip_cohort_vcf_under_the_indexed_scan(gpu, oracle, tmp_path, monkeypatch, cols):
+    """a bgzip VCF of 4 - 12 kB lines in 1 MiB device batches: the reader switches to EXG_ALGO_FUSED_INDEX (round 5: the rows in a
+    kernel of their own) on decoded segments too — with a projection (the side buffer of long REF alleles) and with all columns"""
+    import random
+    from exon_duckdb_amd import abi
+    from exon_duckdb_amd.reader import ShardReader
+    rng = random.Random(9)
+    hdr = (b"##fileformat=VCFv4.2\n##contig=<ID=chr2>\n##INFO=<ID=DP,Number=1,Type=Integer,Description=\"d\">\n"
+           b"##FORMAT=<ID=GT,Number=1,Type=String,Description=\"g\">\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ts1\n")
+    lines = []
+    for i in range(1200):
+        ref = bytes(rng.choice(b"ACGT") for _ in range(rng.choice([1, 1, 2, 13, 40])))
+        lines.append(b"chr2\t%d\t.\t%s\tT\t%d\tPASS\tDP=%d\tGT" % (500 + i, ref, i % 60, i % 31) + b"\t0|1" * rng.randrange(1000, 3000) + b"\n")
+    data = hdr + b"".join(lines)
+    p = tmp_path / "c.vcf.gz"
+    p.write_bytes(_bgzf(data, 60000))
+    plain = tmp_path / "c.vcf"
+    plain.write_bytes(data)
+    monkeypatch.setenv("EXG_DEVICE_BATCH_BYTES", str(1 << 20))
+    kw = {"columns": cols} if cols else {}
+    want = _rows(plain, "vcf", **kw)
+    assert len(want) == 1200
+    r = ShardReader(str(p), "vcf", **kw)
+    try:
+        got = r.rows()
+        algo = r.stats()["scan_algo"]
+    finally:
+        r.close()
+    assert got == want and algo == abi.EXG_ALGO_FUSED_INDEX
