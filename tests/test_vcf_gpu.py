@@ -178,6 +178,45 @@ def test_indexed_scan_on_wide_lines_and_when_its_index_is_too_small(gpu, oracle)
     assert res.flags & abi.EXG_RF_FALLBACK
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_random_line_widths_every_selector(gpu, oracle, seed):
+    """lines of 16 bytes .. 24 kB in random order (narrow runs between wide lines: dense halves, halves without a line end, lines
+    across super-tiles), random CRLF / '.' QUAL / long REF / non-ASCII INFO, every other seed with ONE broken line (too few fields,
+    a bad POS, a bad QUAL, invalid UTF-8) at a random row: rows, flags, the error's code, row and offset against the oracle under
+    all five selectors — the row kernel behind the indexed scan reads its lines from global memory with aligned loads, whatever
+    their alignment and however close to the buffer's end"""
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.integers(300, 900))
+    bad_at = int(rng.integers(0, n)) if seed % 2 else -1
+    lines = []
+    for k in range(n):
+        wide = rng.random() < 0.35
+        ns = int(rng.integers(300, 4000)) if wide else int(rng.integers(0, 4))
+        ref = b"ACGT"[k % 4:k % 4 + 1] * int(rng.choice([1, 1, 1, 2, 12, 13, 60]))
+        qual = b"." if rng.random() < 0.3 else (b"%d" % int(rng.integers(0, 10000)) if rng.random() < 0.5 else b"%.3f" % float(rng.random() * 99))
+        info = b"DP=%d" % k + (b";NOTE=caf\xc3\xa9" if rng.random() < 0.1 else b"") + (b";AF=" + b",".join(b"0.%d" % j for j in range(int(rng.integers(1, 40)))) if wide else b"")
+        f = [b"chr%d" % (k % 22 + 1), b"%d" % (1 + k * 7), b"rs%d" % k if k % 3 else b".", ref, b"T", qual, b"PASS", info]
+        if k == bad_at:
+            kind = seed % 8 // 2
+            if kind == 0:
+                f = f[:5]
+            elif kind == 1:
+                f[1] = b"12x4"
+            elif kind == 2:
+                f[5] = b"-3"
+            else:
+                f[7] = b"DP=1;X=\xff\xfe"
+        line = b"\t".join(f)
+        if ns:
+            line += b"\tGT:DP" + b"\t0/1:%d" % (k % 50) * ns
+        lines.append(line + (b"\r\n" if rng.random() < 0.1 else b"\n"))
+    data = HDR + b"".join(lines)
+    if seed % 3 == 0:
+        data = data[:-1]  # no last newline
+    for algo in ALGOS:
+        check(oracle, data, algo)
+
+
 @pytest.mark.parametrize("algo", [abi.EXG_ALGO_FUSED, abi.EXG_ALGO_MULTIPASS, abi.EXG_ALGO_FUSED_FULL, abi.EXG_ALGO_FUSED_INDEX])
 def test_qual_parse_is_correctly_rounded(gpu, oracle, algo):
     rng = np.random.default_rng(11)
