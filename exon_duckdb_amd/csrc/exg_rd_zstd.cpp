@@ -339,30 +339,17 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
     // the whole file: a page fault per 64 KiB — 80-100 ms per 2 GB on this thread, 20 ms with eight threads taking the faults
     // first — and 49 ms to unmap it again at the end, a quarter of what a 4 GB frame took end to end.)
     std::string damage;  // a malformed or truncated stream: the rows in front of the damage first, like a streaming decoder
-    if (!zst::build_index_fd(fd_, n_, idx)) {
-        damage = idx.error + " in '" + path_ + "'";
-        if (!zst::salvage_index(idx)) {
-            *err = damage;
-            return EXG_E_PARSE;
+    // Round 5: a whole big file begins its first round on a PREFIX of the index (the blocks of one round and two more: ~6 ms of a
+    // 4 GB frame's 23) while a helper walks the whole file; the whole index takes the prefix's place behind the first round's
+    // entropy stages (finish_index), before anything asks for a block behind the prefix.  EXG_ZSTD_NO_INDEX_OVERLAP: never (A/B).
+    struct Walker {
+        std::thread th;
+        zst::Index full;
+        bool ok = false, pending = false;
+        ~Walker() {
+            if (th.joinable()) th.join();
         }
-    }
-    if (getenv("EXG_TRACE")) fprintf(stderr, "[exg] zstd producer: index of %.1f MB (%zu blocks) %.1f ms\n", n_ / 1e6, idx.blocks.size(), (now_s() - t_idx0) * 1e3);
-    // the frames whose first byte lies in [c_begin, c_end) (a shard decodes its own frames and a halo of frames in front)
-    uint64_t b_first = idx.blocks.size(), n_blocks = 0, b_mark[2] = {~0ull, ~0ull};
-    bool marked[2] = {false, false};
-    for (const zst::Frame &F : idx.frames) {
-        if (F.src_off >= c_begin_ && F.src_off < c_end_) {
-            b_first = std::min<uint64_t>(b_first, F.first_block);
-            n_blocks = std::max<uint64_t>(n_blocks, (uint64_t)F.first_block + F.n_blocks);
-        }
-        for (int i = 0; i < 2; i++)
-            if (mark_at_[i] != ~0ull && F.src_off >= mark_at_[i] && b_mark[i] == ~0ull) b_mark[i] = F.first_block;
-    }
-    if (b_first > n_blocks) b_first = n_blocks;
-    auto marks = [&](uint64_t b_next, uint64_t pos) {  // b_next: the next block to be decoded, pos: where its bytes will lie
-        for (int i = 0; i < 2; i++)
-            if (!marked[i] && mark_at_[i] != ~0ull && (b_next >= b_mark[i] || b_next >= n_blocks)) sink.set_mark(i, pos), marked[i] = true;
-    };
+    } walker;
     // the round's compressed bytes: [the blocks whose tables are repeated (at most four) | the round's own, from a 16-byte boundary]
     static constexpr uint64_t kSideSlot = (zst::kBlockMax + 64 + 15) & ~15ull, kSide = 4 * kSideSlot;
     // (three windows of compressed bytes in turn: while round n is decoded out of one — and round n - 1 still executes out of
@@ -391,37 +378,10 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
         }
     } pins[3];
     size_t d_comp_caps[3] = {0, 0, 0}, d_hist_cap = 4096;
-    uint64_t ramp_second = ~0ull;  // the block the second round begins with (plan)
-    // where a round that begins with block b ends, and which file bytes it needs
-    auto plan = [&](uint64_t from, uint64_t *to, uint64_t *lo, uint64_t *hi) {
-        // The first round is a quarter of the size (never more than a round, never below 16 MiB of one) when rounds overlap and
-        // the first frame carries a Content_Checksum: the host's XXH64, which hashes slower than the device decodes, begins after
-        // ~25 ms instead of ~60 (223-262 against 247-284 ms on a 4 GB frame; nothing without a checksum: 121-127 against 126 ms).
-        static const uint64_t first_div_env = getenv("EXG_ZSTD_FIRST_ROUND_DIV") ? std::max<uint64_t>(1, strtoull(getenv("EXG_ZSTD_FIRST_ROUND_DIV"), nullptr, 10)) : 0;
-        // (... and when the consumer pulls string columns: until the first segment is out nothing crosses the link, and behind it the
-        // drain is the link's — a 4 GB frame into DataChunks 161-165 -> 153-155 ms)
-        const uint64_t first_div =
-            first_div_env ? first_div_env : ((!idx.frames.empty() && idx.frames[idx.blocks[from].frame].has_checksum) || sink.mirror_wanted() ? 4 : 1);
-        // (and the second round half: a whole round behind the quarter left the hasher idle for ~14 ms of a 4 GB frame's time)
-        const uint64_t div = !read_ahead_ ? 1 : from == b_first ? first_div : from == ramp_second && first_div > 1 ? first_div / 2 : 1;
-        const uint64_t want_out = std::min<uint64_t>(target_, std::max<uint64_t>(target_ / std::max<uint64_t>(div, 1), 16u << 20));
-        uint64_t b1 = from, est = 0;
-        while (b1 < n_blocks && (b1 == from || est < want_out)) {
-            if (b1 > from && (b1 == b_mark[0] || b1 == b_mark[1])) break;
-            const zst::Block &B = idx.blocks[b1];
-            est += B.type == 2 ? zst::kBlockMax : B.src_size;  // raw / RLE: src_size is the regenerated size
-            b1++;
-            if (b1 - from >= 0x7FFFFF00u) break;
-        }
-        if (from == b_first) ramp_second = b1;
-        *to = b1;
-        *lo = idx.blocks[from].src_off & ~15ull;
-        const zst::Block &BL = idx.blocks[b1 - 1];
-        *hi = std::min<uint64_t>(n_, BL.src_off + (BL.type == 1 ? 1 : BL.src_size));
-    };
     struct Ahead {  // the window a helper thread is filling (or has filled) for the round that begins with block `b0`
         std::thread th;
         uint64_t b0 = ~0ull;
+        uint64_t lo = 0, hi = 0;  // the file bytes it holds (a window planned without the whole index is a guess: the round checks)
         int slot = 0;
         bool ok = false, hip_failed = false;
         hipEvent_t ev = nullptr;
@@ -444,6 +404,138 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
             if (!d_comps[slot]->take(d_comp_caps[slot])) return false;
         }
         return pins[slot].ensure((size_t)(kSide + comp_len + 64));
+    };
+    // file bytes [lo, lo + len) -> window `slot` on the helper thread (pread + H2D on st_io), for the round that begins with block b0
+    auto launch_ahead = [&](uint64_t b0_of, uint64_t lo, uint64_t len, int slot) {
+        ahead.b0 = b0_of;
+        ahead.lo = lo, ahead.hi = lo + len;
+        ahead.slot = slot;
+        ahead.ok = ahead.hip_failed = false;
+        char *h_dst = pins[slot].p + kSide, *d_dst = (char *)d_comps[slot]->p + kSide;
+        ahead.th = std::thread([this, &ahead, lo, len, h_dst, d_dst, st_io] {
+            (void)hipSetDevice(device_);
+            bool hf = false;
+            bool ok = !len || pread_parallel(device_, fd_, lo, (size_t)len, h_dst, d_dst, st_io, &hf);
+            if (ok && hipMemsetAsync(d_dst + len, 0, 64, st_io) != hipSuccess) ok = false, hf = true;
+            if (ok && hipEventRecord(ahead.ev, st_io) != hipSuccess) ok = false, hf = true;
+            ahead.hip_failed = hf;
+            ahead.ok = ok;
+        });
+    };
+    static constexpr uint64_t kFirstRound = ~1ull;  // launch_ahead's b0 while the first block is not known yet
+    {
+        const bool no_index_overlap = getenv("EXG_ZSTD_NO_INDEX_OVERLAP") != nullptr;  // (read per stream: the tests set them inside one process)
+        const uint64_t overlap_min = getenv("EXG_ZSTD_INDEX_OVERLAP_MIN") ? strtoull(getenv("EXG_ZSTD_INDEX_OVERLAP_MIN"), nullptr, 10) : (256ull << 20);  // (tests: 0)
+        const bool whole_file = c_begin_ == 0 && c_end_ >= n_ && mark_at_[0] == ~0ull && mark_at_[1] == ~0ull;
+        bool have = false, ok = false;
+        if (whole_file && read_ahead_ && !no_index_overlap && n_ >= overlap_min) {
+            walker.th = std::thread([&walker, this] { walker.ok = zst::build_index_fd(fd_, n_, walker.full); });
+            // ... and the first round's compressed bytes begin to travel before any block is known: the file's first 0.75 x a round's
+            // output (a round of a stream that compresses 1.33-fold or better lies inside; the round checks, and reads again if not)
+            // (a first round that will be a quarter — plan(): the consumer pulls strings, or the first frame carries a checksum, which
+            // its descriptor byte says — wants a quarter of that: the round waits for the whole guess to land)
+            uint8_t head[5] = {0, 0, 0, 0, 0};
+            const bool head_ok = pread(fd_, head, 5, 0) == 5;
+            const bool first_has_checksum = head_ok && head[0] == 0x28 && head[1] == 0xB5 && head[2] == 0x2F && head[3] == 0xFD && ((head[4] >> 2) & 1);
+            const uint64_t div_env = getenv("EXG_ZSTD_FIRST_ROUND_DIV") ? std::max<uint64_t>(1, strtoull(getenv("EXG_ZSTD_FIRST_ROUND_DIV"), nullptr, 10)) : 0;
+            const uint64_t div = div_env ? div_env : (first_has_checksum || sink.mirror_wanted()) ? 4 : 1;
+            const uint64_t first_out = std::min<uint64_t>(target_, std::max<uint64_t>(target_ / div, 16u << 20));
+            const uint64_t guess = std::min<uint64_t>(n_, first_out / 2 + first_out / 4);
+            if (ensure_window(0, guess)) launch_ahead(kFirstRound, 0, guess, 0);
+            bool stopped = false;
+            if (zst::build_index_prefix_fd(fd_, n_, first_out + 2 * (uint64_t)zst::kBlockMax, idx, &stopped) && stopped) {
+                walker.pending = true;
+                have = ok = true;
+            } else {  // (the stream is shorter than a round, or its prefix is damaged: the whole walk says what it is)
+                walker.th.join();
+                idx = std::move(walker.full);
+                have = true;
+                ok = walker.ok;
+            }
+        }
+        if (!have) ok = zst::build_index_fd(fd_, n_, idx);
+        if (!ok) {
+            damage = idx.error + " in '" + path_ + "'";
+            if (!zst::salvage_index(idx)) {
+                *err = damage;
+                return EXG_E_PARSE;
+            }
+        }
+    }
+    if (getenv("EXG_TRACE"))
+        fprintf(stderr, "[exg] zstd producer: index of %.1f MB (%zu blocks%s) %.1f ms\n", n_ / 1e6, idx.blocks.size(), walker.pending ? ": a prefix, the rest on a helper" : "",
+                (now_s() - t_idx0) * 1e3);
+    // the frames whose first byte lies in [c_begin, c_end) (a shard decodes its own frames and a halo of frames in front)
+    uint64_t b_first = 0, n_blocks = 0, b_mark[2] = {~0ull, ~0ull};
+    bool marked[2] = {false, false};
+    auto scan_frames = [&] {
+        b_first = idx.blocks.size(), n_blocks = 0;
+        for (const zst::Frame &F : idx.frames) {
+            if (F.src_off >= c_begin_ && F.src_off < c_end_) {
+                b_first = std::min<uint64_t>(b_first, F.first_block);
+                n_blocks = std::max<uint64_t>(n_blocks, (uint64_t)F.first_block + F.n_blocks);
+            }
+            for (int i = 0; i < 2; i++)
+                if (mark_at_[i] != ~0ull && F.src_off >= mark_at_[i] && b_mark[i] == ~0ull) b_mark[i] = F.first_block;
+        }
+        if (b_first > n_blocks) b_first = n_blocks;
+    };
+    scan_frames();
+    if (ahead.b0 == kFirstRound) ahead.b0 = b_first;
+    // the whole index in the prefix's place (block and frame numbers are the same: both walks begin at byte 0)
+    auto finish_index = [&](uint64_t blocks_used) -> int {
+        if (!walker.pending) return EXG_OK;
+        walker.pending = false;
+        walker.th.join();
+        idx = std::move(walker.full);
+        if (!walker.ok) {
+            damage = idx.error + " in '" + path_ + "'";
+            if (!zst::salvage_index(idx)) {
+                *err = damage;
+                return EXG_E_PARSE;
+            }
+        }
+        if (idx.blocks.size() < blocks_used) {  // (the file changed between the two walks)
+            *err = damage.empty() ? "the zstd stream changed while it was read: '" + path_ + "'" : damage;
+            return EXG_E_PARSE;
+        }
+        scan_frames();
+        if (getenv("EXG_TRACE")) fprintf(stderr, "[exg] zstd producer: whole index (%zu blocks) there %.1f ms after the start\n", idx.blocks.size(), (now_s() - t_idx0) * 1e3);
+        return EXG_OK;
+    };
+    auto marks = [&](uint64_t b_next, uint64_t pos) {  // b_next: the next block to be decoded, pos: where its bytes will lie
+        for (int i = 0; i < 2; i++)
+            if (!marked[i] && mark_at_[i] != ~0ull && (b_next >= b_mark[i] || b_next >= n_blocks)) sink.set_mark(i, pos), marked[i] = true;
+    };
+    uint64_t ramp_second = ~0ull;  // the block the second round begins with (plan)
+    uint64_t first_div_used = 1;   // what the first round's size was divided by (plan)
+    // where a round that begins with block b ends, and which file bytes it needs
+    auto plan = [&](uint64_t from, uint64_t *to, uint64_t *lo, uint64_t *hi) {
+        // The first round is a quarter of the size (never more than a round, never below 16 MiB of one) when rounds overlap and
+        // the first frame carries a Content_Checksum: the host's XXH64, which hashes slower than the device decodes, begins after
+        // ~25 ms instead of ~60 (223-262 against 247-284 ms on a 4 GB frame; nothing without a checksum: 121-127 against 126 ms).
+        static const uint64_t first_div_env = getenv("EXG_ZSTD_FIRST_ROUND_DIV") ? std::max<uint64_t>(1, strtoull(getenv("EXG_ZSTD_FIRST_ROUND_DIV"), nullptr, 10)) : 0;
+        // (... and when the consumer pulls string columns: until the first segment is out nothing crosses the link, and behind it the
+        // drain is the link's — a 4 GB frame into DataChunks 161-165 -> 153-155 ms)
+        const uint64_t first_div =
+            first_div_env ? first_div_env : ((!idx.frames.empty() && idx.frames[idx.blocks[from].frame].has_checksum) || sink.mirror_wanted() ? 4 : 1);
+        // (and the second round half: a whole round behind the quarter left the hasher idle for ~14 ms of a 4 GB frame's time)
+        const uint64_t div = !read_ahead_ ? 1 : from == b_first ? first_div : from == ramp_second && first_div > 1 ? first_div / 2 : 1;
+        if (from == b_first) first_div_used = div;
+        const uint64_t want_out = std::min<uint64_t>(target_, std::max<uint64_t>(target_ / std::max<uint64_t>(div, 1), 16u << 20));
+        uint64_t b1 = from, est = 0;
+        while (b1 < n_blocks && (b1 == from || est < want_out)) {
+            if (b1 > from && (b1 == b_mark[0] || b1 == b_mark[1])) break;
+            const zst::Block &B = idx.blocks[b1];
+            est += B.type == 2 ? zst::kBlockMax : B.src_size;  // raw / RLE: src_size is the regenerated size
+            b1++;
+            if (b1 - from >= 0x7FFFFF00u) break;
+        }
+        if (from == b_first) ramp_second = b1;
+        *to = b1;
+        *lo = idx.blocks[from].src_off & ~15ull;
+        const zst::Block &BL = idx.blocks[b1 - 1];
+        *hi = std::min<uint64_t>(n_, BL.src_off + (BL.type == 1 ? 1 : BL.src_size));
     };
     int cur = 0;
     if (!d_hist.take(d_hist_cap)) {
@@ -610,7 +702,7 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
         const double t_join0 = now_s();
         if (ahead.th.joinable()) {
             ahead.th.join();
-            if (ahead.b0 == b0 && ahead.ok) {
+            if (ahead.b0 == b0 && ahead.ok && ahead.lo == c_lo && ahead.hi >= c_hi) {
                 cur = ahead.slot;
                 ZS_HIP(hipStreamWaitEvent(st_r, ahead.ev, 0));
                 have = true;
@@ -659,27 +751,26 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
         }
         // the round behind this one: its bytes begin to travel now, into the next window (three in turn: the round in flight reads
         // the one before this round's)
-        if (read_ahead_ && b1 < n_blocks) {
+        auto start_ahead = [&](bool guess) {
+            if (!(read_ahead_ && b1 < n_blocks)) return;
             uint64_t nb1 = 0, nlo = 0, nhi = 0;
-            plan(b1, &nb1, &nlo, &nhi);
-            const int other = (cur + 1) % 3;
-            if (ensure_window(other, nhi - nlo)) {
-                ahead.b0 = b1;
-                ahead.slot = other;
-                ahead.ok = ahead.hip_failed = false;
-                char *h_dst = pins[other].p + kSide, *d_dst = (char *)d_comps[other]->p + kSide;
-                const uint64_t len = nhi - nlo;
-                ahead.th = std::thread([this, &ahead, nlo, len, h_dst, d_dst, st_io] {
-                    (void)hipSetDevice(device_);
-                    bool hf = false;
-                    bool ok = !len || pread_parallel(device_, fd_, nlo, (size_t)len, h_dst, d_dst, st_io, &hf);
-                    if (ok && hipMemsetAsync(d_dst + len, 0, 64, st_io) != hipSuccess) ok = false, hf = true;
-                    if (ok && hipEventRecord(ahead.ev, st_io) != hipSuccess) ok = false, hf = true;
-                    ahead.hip_failed = hf;
-                    ahead.ok = ok;
-                });
+            if (guess) {
+                // the index is still a prefix: the round behind this one begins with block b1 (in the prefix) and, with as many
+                // blocks, is about as long as this one (twice, behind a quarter) — 5 % more of the file travel; a window that turns out short is read again
+                nlo = idx.blocks[b1].src_off & ~15ull;
+                // (behind a first round of a quarter comes one of a half)
+                const uint64_t like = first_div_used > 1 ? 2 * comp_len : comp_len;
+                nhi = std::min<uint64_t>(n_, nlo + like + like / 20 + (1u << 20));
+            } else {
+                plan(b1, &nb1, &nlo, &nhi);
             }
-        }
+            const int other = (cur + 1) % 3;
+            if (ensure_window(other, nhi - nlo)) launch_ahead(b1, nlo, nhi - nlo, other);
+        };
+        // (the first round of a file whose index is still a prefix: the round behind it is planned once the whole index is there,
+        // behind this round's entropy stages — its bytes begin to travel now all the same, as a guess)
+        const bool ahead_deferred = walker.pending;
+        start_ahead(ahead_deferred);
         if (!have) ZS_HIP(hipMemsetAsync((char *)d_comp.p + kSide + comp_len, 0, 64, st_r));
         auto remap = [&](uint32_t g) -> uint32_t {
             if (g == zst::kNone) return zst::kNone;
@@ -739,6 +830,13 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
             if (int rp = flush_prev()) return rp < 0 ? EXG_OK : rp;
             *err = msg;
             return rc;
+        }
+        if (ahead_deferred) {
+            if (int ri = finish_index(b1)) {
+                zst::decode_round_abandon(F.ctx);
+                F.ctx = nullptr;
+                return ri;
+            }
         }
         // ---- frames: sizes
         std::string size_error;

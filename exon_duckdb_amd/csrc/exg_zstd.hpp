@@ -112,6 +112,8 @@ struct Index {
 bool build_index(const uint8_t *data, uint64_t n, Index &idx);
 // the same over file bytes [0, n) of fd, with small reads (nothing is mapped)
 bool build_index_fd(int fd, uint64_t n, Index &idx);
+// the index of the stream's first blocks (until their estimated output reaches stop_est): exg_zstd_index.cpp
+bool build_index_prefix_fd(int fd, uint64_t n, uint64_t stop_est, Index &idx, bool *stopped);
 // After a failed walk: keep what lies in front of the damage — the complete frames and the complete blocks of the frame that
 // was open (as a frame without a checksum or a stated size) — so that a reader can hand out their rows before it reports
 // idx.error, like a streaming decoder does with a truncated file.  false: nothing usable lies in front of it.
