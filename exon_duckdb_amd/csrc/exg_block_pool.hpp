@@ -74,19 +74,33 @@ struct BlockPool {
         n_created++;
         return p;
     }
+    // A block that does not fit under the cap takes the place of the blocks that have lain free the LONGEST (round 5: the pool
+    // kept whatever came first — a process that had read other shapes of input before kept their blocks and paid a
+    // hipHostMalloc for every new size again and again: +11 ms per zstd frame in bench.py's full run).
     void give(char *p, size_t sz) {
+        std::vector<char *> gone;
+        bool keep = false;
         {
             std::lock_guard<std::mutex> g(mu);
             const auto it = node_of.find(p);
             const int node = it == node_of.end() ? 0 : it->second;
-            if (pooled_bytes + sz <= cap()) {
+            if (sz <= cap()) {
+                while (pooled_bytes + sz > cap() && !free_blocks.empty()) {  // (free_blocks: oldest first)
+                    const Free f = free_blocks.front();
+                    free_blocks.erase(free_blocks.begin());
+                    pooled_bytes -= f.sz;
+                    node_of.erase(f.p);
+                    gone.push_back(f.p);
+                }
                 free_blocks.push_back(Free{p, sz, node});
                 pooled_bytes += sz;
-                return;
+                keep = true;
+            } else if (it != node_of.end()) {
+                node_of.erase(it);
             }
-            if (it != node_of.end()) node_of.erase(it);
         }
-        hooks.release(p);
+        for (char *q : gone) hooks.release(q);
+        if (!keep) hooks.release(p);
     }
     void trim() {
         std::vector<Free> gone;

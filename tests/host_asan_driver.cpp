@@ -343,6 +343,28 @@ int main(int argc, char **argv) {
         }
         s_dev = 0;
         if (s_live != 0) return 10;           // the pool's destructor released what it still held; nothing twice (ASan), nothing lost
+        {   // a block that does not fit under the cap takes the place of the ones that have lain free the longest (round 5)
+            exg_rd::BlockPool pool(h, /*cap_override=*/(size_t)(160u << 20));
+            s_node = 0;
+            size_t s1 = 64u << 20, s2 = 64u << 20, s3 = 96u << 20;
+            char *a = pool.take(&s1), *b = pool.take(&s2), *c = pool.take(&s3);
+            pool.give(a, s1);
+            pool.give(b, s2);
+            if (pool.pooled() != (128u << 20)) return 11;
+            pool.give(c, s3);  // 128 + 96 > 160: `a` (the oldest) goes, b and c stay
+            if (pool.pooled() != (160u << 20) || pool.free_on_node(0) != 2) return 11;
+            size_t s4 = 96u << 20;
+            if (pool.take(&s4) != c) return 11;
+            size_t s5 = 64u << 20;
+            if (pool.take(&s5) != b) return 11;
+            pool.give(c, s4);
+            pool.give(b, s5);
+            size_t big = 192u << 20;  // larger than the whole cap: never pooled
+            char *d = pool.take(&big);
+            pool.give(d, big);
+            if (pool.pooled() != (160u << 20)) return 11;
+        }
+        if (s_live != 0) return 11;
         // a small cap: blocks beyond it are released at once
         {
             exg_rd::BlockPool pool(h, 64u << 20);
