@@ -114,6 +114,36 @@ int main(int argc, char **argv) {
                     if (!fi.blocks.empty() && memcmp(fi.blocks.data(), mi.blocks.data(), fi.blocks.size() * sizeof fi.blocks[0])) return 9;
                     if (!fi.frames.empty() && memcmp(fi.frames.data(), mi.frames.data(), fi.frames.size() * sizeof fi.frames[0])) return 9;
                 }
+                // the PREFIX walk a reader begins its first round on (round 5: build_index_prefix_fd) — whatever the stop estimate, what
+                // it returns is the whole walk's first blocks, field for field; it stops inside a frame (the frame it cuts is in the
+                // index with the blocks seen so far and its header's real fields) or not at all (then it IS the whole index)
+                if (runs % 8 == 2 && whole) {
+                    char name[] = "/tmp/exg_asan_zst_XXXXXX";
+                    const int fd = mkstemp(name);
+                    if (fd < 0) return 9;
+                    unlink(name);
+                    if (!d.empty() && write(fd, p, d.size()) != (ssize_t)d.size()) return 9;
+                    for (const uint64_t stop : {(uint64_t)1, (uint64_t)(128u << 10), (uint64_t)(1u << 20), (uint64_t)(64u << 20)}) {
+                        exg::zst::Index pi;
+                        bool stopped = false;
+                        if (!exg::zst::build_index_prefix_fd(fd, d.size(), stop, pi, &stopped)) return 12;
+                        if (pi.blocks.size() > idx.blocks.size() || pi.frames.size() > idx.frames.size()) return 12;
+                        if (!pi.blocks.empty() && memcmp(pi.blocks.data(), idx.blocks.data(), pi.blocks.size() * sizeof pi.blocks[0])) return 12;
+                        if (!stopped) {
+                            if (pi.blocks.size() != idx.blocks.size() || pi.frames.size() != idx.frames.size()) return 12;
+                            if (!pi.frames.empty() && memcmp(pi.frames.data(), idx.frames.data(), pi.frames.size() * sizeof pi.frames[0])) return 12;
+                        } else {
+                            if (pi.frames.empty() || pi.blocks.empty()) return 12;
+                            const auto &cut = pi.frames.back(), &full = idx.frames[pi.frames.size() - 1];
+                            if (cut.first_block != full.first_block || cut.src_off != full.src_off || cut.window != full.window ||
+                                cut.has_checksum != full.has_checksum || cut.content_size != full.content_size)
+                                return 12;
+                            if (cut.first_block + cut.n_blocks != pi.blocks.size() || cut.n_blocks >= full.n_blocks) return 12;  // open: blocks follow
+                            if (pi.frames.size() > 1 && memcmp(pi.frames.data(), idx.frames.data(), (pi.frames.size() - 1) * sizeof pi.frames[0])) return 12;
+                        }
+                    }
+                    close(fd);
+                }
                 // a file that SHRANK behind its fstat (or an I/O error in the middle): the walk is told a size the file no longer has.
                 // It stops at the first read that does not come — no block behind the failure enters the index (a zero block header
                 // is a valid empty raw block: a walk that went on would push one block per three missing bytes) — and what was
