@@ -490,8 +490,8 @@ def run_record_shapes(torch, lib, args):
                 bits[-1] &= (1 << ((n_lines * reps) % 64)) - 1
             got = sum(int(((bits >> b) & 1).sum()) for b in range(64))
             ok = ok and got == nq
-        # what the reader runs from its third batch on: lines of >= 1.5 KiB go to EXG_ALGO_FUSED_INDEX (exg_rd_batch.cpp), shorter ones stay
-        use_ix = len(block) // n_lines >= 1536 and ms_ix == ms_ix
+        # what the reader runs from its third batch on: lines of >= 640 B go to EXG_ALGO_FUSED_INDEX (exg_rd_batch.cpp), shorter ones stay
+        use_ix = len(block) // n_lines >= 640 and ms_ix == ms_ix
         ms_full, ms_full_min = ms, ms_min
         if use_ix:
             ms, ms_min = ms_ix, ms_ix_min
@@ -499,8 +499,8 @@ def run_record_shapes(torch, lib, args):
                                  f"({n_lines * reps} lines, a {len(block) / 1e6:.0f} MB block x {reps}), all columns + typed POS / QUAL",
                      "algorithmic_bytes": n, "ms": ms, "ms_min": ms_min, "GB/s": n / (ms * 1e-3) / 1e9, "frac": n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                      "lines_per_s": n_lines * reps / (ms * 1e-3),
-                     "algo": ("EXG_ALGO_FUSED_INDEX (the any-shape scan notes where the lines end, k_vcf_lines parses the rows behind it: the reader's "
-                              "choice for lines of >= 1.5 KiB)" if use_ix else "EXG_ALGO_FUSED_FULL (the any-shape scan alone)"),
+                     "algo": ("EXG_ALGO_FUSED_INDEX (the any-shape scan notes where the lines end, k_vcf_rows parses the rows behind it: the reader's "
+                              "choice for lines of >= 640 B)" if use_ix else "EXG_ALGO_FUSED_FULL (the any-shape scan alone)"),
                      "full_ms": ms_full, "full_GB/s": n / (ms_full * 1e-3) / 1e9,
                      "indexed_ms": ms_ix, "indexed_ms_min": ms_ix_min, "indexed_GB/s": n / (ms_ix * 1e-3) / 1e9,
                      "first_batch_ms": ms_first, "first_batch_GB/s": n / (ms_first * 1e-3) / 1e9,

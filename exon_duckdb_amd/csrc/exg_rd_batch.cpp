@@ -941,13 +941,13 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         }
         if (r->format == EXG_FMT_VCF && res.n_lines) {
             // the any-shape scan on WIDE lines (cohort VCFs) leaves the rows to a kernel of their own (EXG_ALGO_FUSED_INDEX: exg_vcf.hip):
-            // measured over line widths (tools/vcf_index_crossover.py): level at 1.3 kB a line, 2.60 against 2.16 TB/s at 1.7 kB, 3.75
-            // against 2.30 at 10 kB — the switch at an average of 1.5 KiB;
+            // measured over line widths (tools/vcf_index_crossover.py, TB/s indexed against rows inside): level at 483 B a line, 2.72
+            // against 2.21 at 882 B, 3.13 against 2.15 at 1.7 kB, 3.82 against 2.28 at 10 kB — the switch at an average of 640 B;
             // sticky both ways with a gap between the thresholds (EXG_NO_VCF_INDEX: never — A/B)
             const bool no_index = getenv("EXG_NO_VCF_INDEX") != nullptr;  // (per batch: the tests switch it inside one process)
             const uint64_t per_line = (n - lead) / res.n_lines;
-            if (r->fused_algo == EXG_ALGO_FUSED_FULL && per_line >= 1536 && !no_index) r->fused_algo = EXG_ALGO_FUSED_INDEX;
-            else if (r->fused_algo == EXG_ALGO_FUSED_INDEX && per_line < 1024) r->fused_algo = EXG_ALGO_FUSED_FULL;
+            if (r->fused_algo == EXG_ALGO_FUSED_FULL && per_line >= 640 && !no_index) r->fused_algo = EXG_ALGO_FUSED_INDEX;
+            else if (r->fused_algo == EXG_ALGO_FUSED_INDEX && per_line < 448) r->fused_algo = EXG_ALGO_FUSED_FULL;
         }
         TRACE("wait(h2d) + scan", t_scan);
         if (r->shard_first && (res.flags & EXG_RF_HEAD_UNRESOLVED) && r->file_pos - shard_halo > r->data_base) {

@@ -526,6 +526,147 @@ __global__ __launch_bounds__(256) void k_vcf_lines(VcfDev a, const uint64_t *__r
     }
 }
 
+// ---- EXG_ALGO_FUSED_INDEX: the rows behind the scan, a thread per line, the line's HEAD through LDS -------------------------
+// k_vcf_lines walks its line in global memory: every byte the number parsers and the tab search look at is a load of its own
+// (an L1 / L2 round trip each, one behind the other).  Here a thread first copies the first kStageBytes of its line — nine
+// 16-byte loads, all in flight at once — into a row of its own in LDS and parses from there; what lies behind the staged bytes
+// (the FORMAT-and-samples remainder needs only its first bytes; an INFO longer than the stage) is read from global memory as
+// before.  Rows are kStageStride dwords apart (odd: the lanes of a wavefront hit different banks at the same offset).
+static constexpr int kStageBytes = 128, kStageBlocks = kStageBytes / 16 + 1, kStageStride = kStageBlocks * 4 + 1;
+struct StagedSrc {
+    const uint32_t *w;  // this thread's row: byte 0 = the input byte at (line start & ~15)
+    uint32_t lead;      // line start & 15
+    uint32_t have;      // bytes of the line (from its start) that are staged
+    GlobalSrc g;
+    __device__ __forceinline__ uint32_t dw(uint32_t k) const { return w[k]; }
+    __device__ __forceinline__ uint32_t b(int i) const {
+        if ((uint32_t)i >= have) return g.b(i);
+        const uint32_t p = lead + (uint32_t)i;
+        return (w[p >> 2] >> (8 * (p & 3))) & 255u;
+    }
+    __device__ __forceinline__ uint32_t u32(int i) const {
+        if ((uint32_t)i + 4 > have || i < 0) return g.u32(i);
+        const uint32_t p = lead + (uint32_t)i, k = p >> 2;
+        return __builtin_amdgcn_alignbyte(w[k + 1], w[k], p & 3);
+    }
+    __device__ __forceinline__ void u96(int i, uint32_t *w0, uint32_t *w1, uint32_t *w2) const {
+        if ((uint32_t)i + 12 > have || i < 0) {
+            g.u96(i, w0, w1, w2);
+            return;
+        }
+        const uint32_t p = lead + (uint32_t)i, k = p >> 2, sh = p & 3;
+        const uint32_t d0 = w[k], d1 = w[k + 1], d2 = w[k + 2], d3 = w[k + 3];
+        *w0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
+        *w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        *w2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
+    }
+    __device__ __forceinline__ uint4 str(int i, uint32_t len) const {
+        if ((uint32_t)i + 12 > have || i < 0) return g.str(i, len);
+        uint32_t w0, w1, w2;
+        u96(i, &w0, &w1, &w2);
+        uint4 r;
+        r.x = len;
+        if (len <= EXG_INLINE_LENGTH) {
+            const uint32_t n0 = len < 4u ? len : 4u, n1 = len < 4u ? 0u : len - 4u < 4u ? len - 4u : 4u, n2 = len < 8u ? 0u : len - 8u;
+            r.y = n0 == 4 ? w0 : w0 & ((1u << (8 * n0)) - 1u);
+            r.z = n1 == 4 ? w1 : w1 & ((1u << (8 * n1)) - 1u);
+            r.w = n2 == 4 ? w2 : w2 & ((1u << (8 * n2)) - 1u);
+        } else {
+            const uint64_t ptr = g.payload_base + g.base + (uint64_t)(int64_t)i;
+            r.y = w0;
+            r.z = (uint32_t)ptr;
+            r.w = (uint32_t)(ptr >> 32);
+        }
+        return r;
+    }
+    __device__ __forceinline__ bool tab_bits(int, unsigned long long *) const { return false; }
+    __device__ __forceinline__ unsigned long long tabs64(int base_i) const {
+        if ((uint32_t)base_i + 68 > have || base_i < 0) return g.tabs64(base_i);
+        const uint32_t p = lead + (uint32_t)base_i, k = p >> 2, sh = p & 3;
+        unsigned long long lo = 0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) lo |= (unsigned long long)nib4(match4(w[k + q], 0x09090909u)) << (4 * q);
+        const unsigned long long hi = nib4(match4(w[k + 16], 0x09090909u));
+        return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+    }
+};
+
+__global__ __launch_bounds__(256) void k_vcf_rows(VcfDev a, const uint64_t *__restrict__ nl_pos, ScanWsHeader *hdr) {
+    __shared__ uint32_t stage[256 * kStageStride];
+    uint32_t *const row = stage + threadIdx.x * kStageStride;
+    const uint64_t T = hdr->total_lines < hdr->lines_cap ? hdr->total_lines : hdr->lines_cap;
+    const uint64_t halo = hdr->halo_nl;
+    const bool no_store = (a.flags & EXG_F_NO_STORE) != 0;
+    const uint64_t limit = (a.n_bytes + 15) & ~15ull;
+    const uint64_t n_iter = (T + 63) / 64;
+    const uint64_t wave_id = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t it = wave_id; it < n_iter; it += n_waves) {
+        const uint64_t j = it * 64 + lane_id();
+        bool act = j < T && j >= halo;
+        const uint64_t out = j - halo;
+        if (act && !no_store && out >= a.capacity) {
+            atomicOr(&hdr->flags, EXG_RF_CAPACITY);
+            act = false;
+        }
+        bool qv = false, rv = false;
+        if (act) {
+            uint64_t e1 = nl_pos[j];
+            bool resolved = j > 0 || (a.flags & EXG_F_BOF);
+            uint64_t s0 = j > 0 ? nl_pos[j - 1] + 1 : 0;
+            if (!resolved) {
+                atomicAdd(&hdr->n_unresolved, 1ull);
+                atomicOr(&hdr->flags, EXG_RF_HEAD_UNRESOLVED);
+            } else if (e1 - s0 > 0x7FFFFFF0ull) {
+                vcf_report(hdr, EXG_PE_FIELD_TOO_LONG, out, s0);
+            } else {
+                if (s0 > e1) s0 = e1;
+                // the line's head: the 16-byte blocks from the one that holds its first byte (a block that begins below `limit`
+                // lies inside the buffer), all loads first, then the row
+                const uint64_t al = s0 & ~15ull;
+                uint4 blk[kStageBlocks];
+                uint32_t n_blk = 0;
+#pragma unroll
+                for (int q = 0; q < kStageBlocks; q++) {
+                    const bool in = al + 16ull * q < limit;
+                    blk[q] = in ? *reinterpret_cast<const uint4 *>(a.d_in + al + 16ull * q) : make_uint4(0, 0, 0, 0);
+                    n_blk += in;
+                }
+#pragma unroll
+                for (int q = 0; q < kStageBlocks; q++) {
+                    row[4 * q + 0] = blk[q].x;
+                    row[4 * q + 1] = blk[q].y;
+                    row[4 * q + 2] = blk[q].z;
+                    row[4 * q + 3] = blk[q].w;
+                }
+                row[4 * kStageBlocks] = 0;
+                const bool virt = e1 >= a.n_bytes;
+                if (!virt && e1 > s0 && a.d_in[e1 - 1] == '\r') e1--;
+                StagedSrc src;
+                src.w = row;
+                src.lead = (uint32_t)(s0 & 15);
+                src.have = 16u * n_blk > src.lead ? 16u * n_blk - src.lead : 0u;
+                src.g = GlobalSrc{a.d_in, s0, a.payload_base, limit};
+                VcfRowInfo r = vcf_line(src, 0, (int)(e1 - s0), a, out, !no_store);
+                if (!r.code && (hdr->flags & EXG_RF_NON_ASCII)) {
+                    // noodles builds str fields: the line must be UTF-8
+                    if (!utf8_valid_global(a.d_in, s0, e1)) r.code = EXG_PE_INVALID_UTF8;
+                }
+                if (r.code) vcf_report(hdr, r.code, out, s0);
+                else if (r.slow_len) vcf_slow_qual(hdr, a, s0 + (uint64_t)r.slow_s, (uint32_t)r.slow_len, out, s0);
+                qv = r.qual_valid;
+                rv = r.rest_valid;
+            }
+        }
+        if (!no_store) {
+            long long out_base = (long long)(it * 64) - (long long)halo;
+            unsigned long long qb = __ballot(qv), rb = __ballot(rv);
+            store_validity64(a.d_qual_valid, qb, out_base, lane_id());
+            store_validity64(a.d_formats_valid, rb, out_base, lane_id());
+        }
+    }
+}
+
 // The rows k_fused<VcfFormat> left out: one line per marked half (it begins in front of the half's window), read from global
 // memory like the general path reads its lines.  Runs behind k_fused on the stream.
 template <uint32_t kHalves>
@@ -725,7 +866,7 @@ static int run_vcf_fused(const VcfDev &dev_in, uint8_t *ws, const FastqWsLayout 
         rows.d_nl_pos = nullptr;
         const uint64_t est = dev.n_bytes / 256 + 256;
         const uint32_t grid = (uint32_t)((est + 255) / 256 < 4096 ? (est + 255) / 256 : 4096);
-        hipLaunchKernelGGL(k_vcf_lines, dim3(grid), dim3(256), 0, stream, rows, (const uint64_t *)dev.d_nl_pos, hdr, (const unsigned int *)nullptr);
+        hipLaunchKernelGGL(k_vcf_rows, dim3(grid), dim3(256), 0, stream, rows, (const uint64_t *)dev.d_nl_pos, hdr);
     } else {   // the rows of lines that begin in front of their half's window (returns at once when there is none)
         const uint32_t n_halves = n_super * kHalvesHost;
         const uint32_t grid = (n_halves + 255) / 256 < 4096 ? (n_halves + 255) / 256 : 4096;
