@@ -26,9 +26,11 @@
 #include "exg_rd_fanout.hpp"
 #include "exg_rd_source.hpp"
 #include "exg_vcf_header.hpp"
+#include "exg_vcf_nested.hpp"
 
 using namespace exg_rd;
 namespace ea = exg::arrow;
+namespace vn = exg::vn;
 
 namespace {
 
@@ -39,13 +41,13 @@ struct Field {
     std::vector<Field> children;
 };
 
-static_assert(kKeyFlag == ea::kVtFlag && kKeyInt == ea::kVtInt && kKeyFloat == ea::kVtFloat && kKeyString == ea::kVtString,
+static_assert(kKeyFlag == vn::kFlag && kKeyInt == vn::kInt && kKeyFloat == vn::kFloat && kKeyString == vn::kString,
               "the header parser's value types are the emitter's");
 
 Field key_field(const KeyDef &k) {
     Field f;
     f.name = k.id;
-    const char *fmt = k.type == ea::kVtInt ? "i" : k.type == ea::kVtFloat ? "f" : k.type == ea::kVtFlag ? "b" : "u";
+    const char *fmt = k.type == vn::kInt ? "i" : k.type == vn::kFloat ? "f" : k.type == vn::kFlag ? "b" : "u";
     if (k.is_list) {
         f.format = "+l";
         Field item;
@@ -132,8 +134,13 @@ struct StreamState {
     ea::FilterProgram prog;
     std::string consts;
     void *d_consts = nullptr, *d_prog = nullptr;
-    void *d_info_names = nullptr, *d_format_names = nullptr;
-    ea::VtKeys info_vt, format_vt;
+    // the header's keys on the device (exg_vcf_nested.hpp): any number of them, looked up by a hash of their text
+    struct NestedKeys {
+        vn::KeyTab tab;
+        void *d_keys = nullptr, *d_slots = nullptr, *d_names = nullptr;
+        NestedKeys() { memset(&tab, 0, sizeof tab); }
+    } nk_info, nk_format;
+    size_t side_cap = 64u << 10;  // bytes of percent-decoded String values a batch may hold (grows when a batch needs more)
     DevArena arena;
     std::shared_ptr<ABatch> batch;
     uint64_t batch_row = 0;
@@ -156,7 +163,7 @@ struct StreamState {
         fan.reset();  // (the workers' streams end first)
         if (copy_ev) (void)hipEventDestroy(copy_ev);
         if (copy_stream) stream_pool()->give(copy_dev, copy_stream);
-        for (void *p : {d_consts, d_prog, d_info_names, d_format_names})
+        for (void *p : {d_consts, d_prog, nk_info.d_keys, nk_info.d_slots, nk_info.d_names, nk_format.d_keys, nk_format.d_slots, nk_format.d_names})
             if (p) (void)hipFree(p);
         arena.reset();
         if (owns_reader) delete r;
@@ -176,7 +183,6 @@ struct Emit {
     hipStream_t s;
     uint64_t n;                 // output rows
     const uint32_t *d_row_map;  // NULL: identity
-    unsigned long long *d_err;
     int rc = 0;
     bool copy = true;  // false: the column being built is not in the projection — built and validated on the device, not copied back
 
@@ -212,25 +218,6 @@ struct Emit {
         return (const uint8_t *)h;
     }
     static size_t bitmap_bytes(uint64_t m) { return (size_t)((m + 63) / 64) * 8; }
-
-    // String / Character values are percent-decoded (noodles-vcf 0.34): the views that hold a %XX escape are decoded
-    // into a side buffer on the device and point there afterwards.  *side_bytes == 0: no value held an escape.
-    void decode_percent(ea::View *d_views, uint64_t m, const ea::PercentRows &rows, uint32_t err_code, uint8_t **d_side, uint64_t *side_bytes) {
-        *d_side = nullptr;
-        *side_bytes = 0;
-        if (!m) return;
-        unsigned long long *d_cnt = (unsigned long long *)dalloc(16);
-        if (rc) return;
-        (void)hipMemsetAsync(d_cnt, 0, 16, s);
-        ea::percent_count(d_views, m, d_cnt, s);
-        const uint64_t total = fetch_u64((const uint64_t *)d_cnt);
-        if (!total || rc) return;
-        uint8_t *side = (uint8_t *)dalloc(total + 16);
-        if (rc) return;
-        ea::percent_decode(d_views, m, side, d_cnt + 1, rows, d_err, err_code, s);
-        *d_side = side;
-        *side_bytes = total;
-    }
 
     // validity of a row-space column whose source bitmap is indexed by scan rows
     const uint8_t *row_validity(const uint64_t *d_src) {
@@ -270,8 +257,8 @@ struct Emit {
         return col;
     }
 
-    // strings given as views; m elements; absolute int32 offsets
-    AColumn utf8_abs(const ea::View *d_views, uint64_t m, const uint8_t *h_validity) {
+    // a string_t array on the device (the children the nested kernels write) -> Utf8 with absolute int32 offsets
+    AColumn utf8_abs(const exg_string_t *d_col, const uint8_t *d_base, uint64_t payload_base, uint64_t m, const uint8_t *h_validity) {
         AColumn col;
         col.kind = AColumn::kUtf8Abs;
         col.length = (int64_t)m;
@@ -279,7 +266,8 @@ struct Emit {
         uint64_t *d_goff = (uint64_t *)dalloc((m + 1) * 8);
         uint64_t *d_tmp = (uint64_t *)dalloc(ea::scan_tmp_entries(m) * 8);
         if (rc) return col;
-        ea::utf8_goff_from_views(d_views, m, d_goff, d_tmp, s);
+        const ea::StrCol sc{d_col, d_base, payload_base};
+        ea::utf8_goff_from_col(sc, nullptr, m, d_goff, d_tmp, s);
         const uint64_t total = fetch_u64(d_goff + m);
         if (total >= (1ull << 31)) {
             if (!rc) rc = fail(r, EXG_E_CAPACITY, "a nested string column exceeds Arrow's int32 offsets in one device batch");
@@ -290,286 +278,291 @@ struct Emit {
         uint32_t *d_big = (uint32_t *)dalloc(4 * ((size_t)big_cap + 1));
         int32_t *d_off32 = (int32_t *)dalloc((m + 1) * 4);
         if (rc) return col;
-        ea::utf8_copy_from_views(d_views, m, d_goff, d_values, d_big, big_cap, s);
+        ea::utf8_copy_from_col(sc, nullptr, m, d_goff, d_values, d_big, big_cap, s);
         ea::narrow_offsets(d_goff, m, d_off32, s);
         col.offsets = to_host(d_off32, (m + 1) * 4);
         col.data = to_host(d_values, total);
         return col;
     }
-
-    // List<Utf8> out of a raw column split on `sep`
-    AColumn list_of_strings(const ea::StrCol &c, uint8_t sep) {
-        AColumn col;
-        col.kind = AColumn::kList;
-        col.length = (int64_t)n;
-        uint64_t *d_goff = (uint64_t *)dalloc((n + 1) * 8);
-        uint64_t *d_tmp = (uint64_t *)dalloc(ea::scan_tmp_entries(n) * 8);
-        if (rc) return col;
-        ea::list_counts(c, d_row_map, n, sep, d_goff, d_tmp, s);
-        const uint64_t total = fetch_u64(d_goff + n);
-        if (total >= (1ull << 31)) {
-            if (!rc) rc = fail(r, EXG_E_CAPACITY, "a list column exceeds Arrow's int32 offsets in one device batch");
-            return col;
-        }
-        ea::View *d_views = (ea::View *)dalloc(total * sizeof(ea::View));
-        int32_t *d_off32 = (int32_t *)dalloc((n + 1) * 4);
-        if (rc) return col;
-        ea::list_views(c, d_row_map, n, sep, d_goff, d_views, s);
-        ea::narrow_offsets(d_goff, n, d_off32, s);
-        col.offsets = to_host(d_off32, (n + 1) * 4);
-        col.children.push_back(utf8_abs(d_views, total, nullptr));
-        return col;
-    }
-
-    // the typed children of INFO (elements = output rows) or FORMAT (elements = samples)
-    std::vector<AColumn> cell_children(const std::vector<KeyDef> &keys, ea::CellSrc src, uint64_t m, uint32_t err_code) {
-        std::vector<AColumn> kids;
-        for (size_t k = 0; k < keys.size() && !rc; k++) {
-            src.key = (uint32_t)k;
-            const KeyDef &kd = keys[k];
-            AColumn col;
-            col.length = (int64_t)m;
-            uint64_t *d_valid = (uint64_t *)dalloc(bitmap_bytes(m));
-            if (rc) break;
-            if (!kd.is_list) {
-                if (kd.type == ea::kVtInt || kd.type == ea::kVtFloat) {
-                    void *d_vals = dalloc(m * 4);
-                    if (rc) break;
-                    if (kd.type == ea::kVtInt)
-                        ea::cells_to_i32(src, m, (int32_t *)d_vals, d_valid, d_err, err_code, s);
-                    else
-                        ea::cells_to_f32(src, m, (float *)d_vals, d_valid, d_err, err_code, s);
-                    col.kind = AColumn::kPrim;
-                    col.elem_size = 4;
-                    col.data = to_host(d_vals, m * 4);
-                    col.validity = to_host(d_valid, bitmap_bytes(m));
-                } else if (kd.type == ea::kVtFlag) {
-                    uint64_t *d_bits = (uint64_t *)dalloc(bitmap_bytes(m));
-                    if (rc) break;
-                    ea::cells_to_flag(src, m, d_bits, d_valid, s);
-                    col.kind = AColumn::kBool;
-                    col.data = to_host(d_bits, bitmap_bytes(m));
-                    col.validity = to_host(d_valid, bitmap_bytes(m));
-                } else {
-                    ea::View *d_views = (ea::View *)dalloc(m * sizeof(ea::View));
-                    if (rc) break;
-                    ea::cells_to_views(src, m, d_views, d_valid, s);
-                    uint8_t *d_side;
-                    uint64_t side_bytes;
-                    decode_percent(d_views, m, ea::PercentRows{nullptr, 0, src.d_elem_row}, err_code, &d_side, &side_bytes);
-                    col = utf8_abs(d_views, m, to_host(d_valid, bitmap_bytes(m)));
-                }
-            } else {
-                uint64_t *d_goff = (uint64_t *)dalloc((m + 1) * 8);
-                uint64_t *d_tmp = (uint64_t *)dalloc(ea::scan_tmp_entries(m) * 8);
-                if (rc) break;
-                ea::cells_list_counts(src, m, d_goff, d_tmp, d_valid, s);
-                const uint64_t total = fetch_u64(d_goff + m);
-                if (total >= (1ull << 31)) {
-                    rc = fail(r, EXG_E_CAPACITY, "a list column exceeds Arrow's int32 offsets in one device batch");
-                    break;
-                }
-                col.kind = AColumn::kList;
-                int32_t *d_off32 = (int32_t *)dalloc((m + 1) * 4);
-                uint32_t *d_cv = (uint32_t *)dalloc(bitmap_bytes(total));
-                if (rc) break;
-                ea::narrow_offsets(d_goff, m, d_off32, s);
-                (void)hipMemsetAsync(d_cv, 0, bitmap_bytes(total), s);
-                col.offsets = to_host(d_off32, (m + 1) * 4);
-                col.validity = to_host(d_valid, bitmap_bytes(m));
-                AColumn child;
-                child.length = (int64_t)total;
-                if (kd.type == ea::kVtInt || kd.type == ea::kVtFloat) {
-                    void *d_vals = dalloc(total * 4);
-                    if (rc) break;
-                    if (kd.type == ea::kVtInt)
-                        ea::cells_list_i32(src, m, d_goff, (int32_t *)d_vals, d_cv, d_err, err_code, s);
-                    else
-                        ea::cells_list_f32(src, m, d_goff, (float *)d_vals, d_cv, d_err, err_code, s);
-                    child.kind = AColumn::kPrim;
-                    child.elem_size = 4;
-                    child.data = to_host(d_vals, total * 4);
-                    child.validity = to_host(d_cv, bitmap_bytes(total));
-                } else {
-                    ea::View *d_views = (ea::View *)dalloc(total * sizeof(ea::View));
-                    if (rc) break;
-                    ea::cells_list_views(src, m, d_goff, d_views, d_cv, s);
-                    uint8_t *d_side;
-                    uint64_t side_bytes;
-                    decode_percent(d_views, total, ea::PercentRows{d_goff, m, src.d_elem_row}, err_code, &d_side, &side_bytes);
-                    child = utf8_abs(d_views, total, to_host(d_cv, bitmap_bytes(total)));
-                }
-                col.children.push_back(std::move(child));
-            }
-            kids.push_back(std::move(col));
-        }
-        return kids;
-    }
 };
 
-// ---- the same columns in DuckDB's vector layouts (chunk boundary) ----------------------------------------------------
-struct DuckEmit {
-    Emit &em;
-    uint64_t B, n_chunks;       // rows per DataChunk, chunks of this batch
-    const uint8_t *d_base;      // the scanned text on the device ...
-    uint64_t payload_base;      // ... and the host address its bytes have in the chunk's payload
-
-    // rows != NULL: String / Character values of INFO / FORMAT, percent-decoded first (the decoded bytes travel in a side
-    // block of the batch's pinned arena; everything else stays a zero-copy pointer into the chunk's payload)
-    NVec strings_from_views(ea::View *d_views, uint64_t m, const uint64_t *h_validity, const ea::PercentRows *rows = nullptr,
-                            uint32_t err_code = 0) {
-        NVec v;
-        v.type = EXG_TYPE_VARCHAR;
-        v.elem = 16;
-        v.length = m;
-        v.validity = h_validity;
-        uint8_t *d_side = nullptr;
-        uint64_t side_bytes = 0, side_host = 0;
-        if (rows) em.decode_percent(d_views, m, *rows, err_code, &d_side, &side_bytes);
-        if (side_bytes) side_host = (uint64_t)(uintptr_t)em.to_host(d_side, side_bytes);
-        exg_string_t *d = (exg_string_t *)em.dalloc(m * 16 + 16);
-        if (em.rc) return v;
-        ea::views_to_string_t(d_views, m, d_base, payload_base, d_side, side_bytes, side_host, d, em.s);
-        v.data = em.to_host(d, m * 16);
-        return v;
-    }
-    // the n_chunks + 1 places where the chunks' elements begin, on the host (valid after the final sync) and on the device
-    const uint64_t *bases_rows(const uint64_t *d_goff, uint64_t n, uint64_t **d_out) {
-        uint64_t *d = (uint64_t *)em.dalloc((n_chunks + 1) * 8);
-        if (em.rc) return nullptr;
-        ea::chunk_bases_rows(d_goff, n, B, n_chunks, d, em.s);
-        if (d_out) *d_out = d;
-        return (const uint64_t *)em.to_host(d, (n_chunks + 1) * 8);
-    }
-    // LIST(VARCHAR) out of a raw column split on `sep`
-    NVec list_of_strings(const ea::StrCol &c, uint8_t sep) {
-        NVec v;
-        v.type = EXG_TYPE_LIST;
-        v.elem = 16;
-        v.length = em.n;
-        const uint64_t n = em.n;
-        uint64_t *d_goff = (uint64_t *)em.dalloc((n + 1) * 8);
-        uint64_t *d_tmp = (uint64_t *)em.dalloc(ea::scan_tmp_entries(n) * 8);
-        if (em.rc) return v;
-        ea::list_counts(c, em.d_row_map, n, sep, d_goff, d_tmp, em.s);
-        const uint64_t total = em.fetch_u64(d_goff + n);
-        ea::View *d_views = (ea::View *)em.dalloc(total * sizeof(ea::View) + 16);
-        ea::ListEntry *d_entries = (ea::ListEntry *)em.dalloc(n * 16);
-        if (em.rc) return v;
-        ea::list_views(c, em.d_row_map, n, sep, d_goff, d_views, em.s);
-        ea::list_entries_rows(d_goff, n, B, d_entries, em.s);
-        v.data = em.to_host(d_entries, n * 16);
-        v.child_base = bases_rows(d_goff, n, nullptr);
-        v.children.push_back(strings_from_views(d_views, total, nullptr));  // (id / alt / filter are not percent-decoded)
-        return v;
-    }
-    // the typed children of INFO (elements = output rows) or FORMAT (elements = samples: d_elem_row / d_outer_goff /
-    // d_outer_bases describe the enclosing list)
-    std::vector<NVec> cell_children(const std::vector<KeyDef> &keys, ea::CellSrc src, uint64_t m, uint32_t err_code,
-                                    const uint32_t *d_elem_row, const uint64_t *d_outer_goff, const uint64_t *d_outer_bases) {
-        std::vector<NVec> kids;
-        for (size_t k = 0; k < keys.size() && !em.rc; k++) {
-            src.key = (uint32_t)k;
-            const KeyDef &kd = keys[k];
-            NVec col;
-            col.length = m;
-            uint64_t *d_valid = (uint64_t *)em.dalloc(Emit::bitmap_bytes(m));
-            if (em.rc) break;
-            if (!kd.is_list) {
-                if (kd.type == ea::kVtInt || kd.type == ea::kVtFloat) {
-                    void *d_vals = em.dalloc(m * 4);
-                    if (em.rc) break;
-                    if (kd.type == ea::kVtInt)
-                        ea::cells_to_i32(src, m, (int32_t *)d_vals, d_valid, em.d_err, err_code, em.s);
-                    else
-                        ea::cells_to_f32(src, m, (float *)d_vals, d_valid, em.d_err, err_code, em.s);
-                    col.type = kd.type == ea::kVtInt ? EXG_TYPE_INTEGER : EXG_TYPE_FLOAT;
-                    col.elem = 4;
-                    col.data = em.to_host(d_vals, m * 4);
-                    col.validity = (const uint64_t *)em.to_host(d_valid, Emit::bitmap_bytes(m));
-                } else if (kd.type == ea::kVtFlag) {
-                    uint64_t *d_bits = (uint64_t *)em.dalloc(Emit::bitmap_bytes(m));
-                    uint8_t *d_bytes = (uint8_t *)em.dalloc(m + 16);
-                    if (em.rc) break;
-                    ea::cells_to_flag(src, m, d_bits, d_valid, em.s);
-                    ea::bits_to_bytes(d_bits, m, d_bytes, em.s);
-                    col.type = EXG_TYPE_BOOLEAN;
-                    col.elem = 1;
-                    col.data = em.to_host(d_bytes, m);
-                    col.validity = (const uint64_t *)em.to_host(d_valid, Emit::bitmap_bytes(m));
-                } else {
-                    ea::View *d_views = (ea::View *)em.dalloc(m * sizeof(ea::View) + 16);
-                    if (em.rc) break;
-                    ea::cells_to_views(src, m, d_views, d_valid, em.s);
-                    const ea::PercentRows pr{nullptr, 0, src.d_elem_row};
-                    col = strings_from_views(d_views, m, (const uint64_t *)em.to_host(d_valid, Emit::bitmap_bytes(m)), &pr, err_code);
-                }
-            } else {
-                uint64_t *d_goff = (uint64_t *)em.dalloc((m + 1) * 8);
-                uint64_t *d_tmp = (uint64_t *)em.dalloc(ea::scan_tmp_entries(m) * 8);
-                if (em.rc) break;
-                ea::cells_list_counts(src, m, d_goff, d_tmp, d_valid, em.s);
-                const uint64_t total = em.fetch_u64(d_goff + m);
-                col.type = EXG_TYPE_LIST;
-                col.elem = 16;
-                ea::ListEntry *d_entries = (ea::ListEntry *)em.dalloc(m * 16 + 16);
-                uint32_t *d_cv = (uint32_t *)em.dalloc(Emit::bitmap_bytes(total));
-                uint64_t *d_cb = (uint64_t *)em.dalloc((n_chunks + 1) * 8);
-                if (em.rc) break;
-                if (d_elem_row) {
-                    ea::list_entries_elems(d_goff, m, d_elem_row, d_outer_goff, B, d_entries, em.s);
-                    ea::chunk_bases_pick(d_goff, d_outer_bases, n_chunks, d_cb, em.s);
-                } else {
-                    ea::list_entries_rows(d_goff, m, B, d_entries, em.s);
-                    ea::chunk_bases_rows(d_goff, m, B, n_chunks, d_cb, em.s);
-                }
-                (void)hipMemsetAsync(d_cv, 0, Emit::bitmap_bytes(total), em.s);
-                col.data = em.to_host(d_entries, m * 16);
-                col.validity = (const uint64_t *)em.to_host(d_valid, Emit::bitmap_bytes(m));
-                col.child_base = (const uint64_t *)em.to_host(d_cb, (n_chunks + 1) * 8);
-                NVec child;
-                child.length = total;
-                if (kd.type == ea::kVtInt || kd.type == ea::kVtFloat) {
-                    void *d_vals = em.dalloc(total * 4);
-                    if (em.rc) break;
-                    if (kd.type == ea::kVtInt)
-                        ea::cells_list_i32(src, m, d_goff, (int32_t *)d_vals, d_cv, em.d_err, err_code, em.s);
-                    else
-                        ea::cells_list_f32(src, m, d_goff, (float *)d_vals, d_cv, em.d_err, err_code, em.s);
-                    child.type = kd.type == ea::kVtInt ? EXG_TYPE_INTEGER : EXG_TYPE_FLOAT;
-                    child.elem = 4;
-                    child.data = em.to_host(d_vals, total * 4);
-                    child.validity = (const uint64_t *)em.to_host(d_cv, Emit::bitmap_bytes(total));
-                } else {
-                    ea::View *d_views = (ea::View *)em.dalloc(total * sizeof(ea::View) + 16);
-                    if (em.rc) break;
-                    ea::cells_list_views(src, m, d_goff, d_views, d_cv, em.s);
-                    const ea::PercentRows pr{d_goff, m, src.d_elem_row};
-                    child = strings_from_views(d_views, total, (const uint64_t *)em.to_host(d_cv, Emit::bitmap_bytes(total)), &pr, err_code);
-                }
-                col.children.push_back(std::move(child));
+// ---- the nested VCF columns of one device batch (exg_vcf_nested.hpp), for both boundaries ------------------------------------
+// Everything is made in DuckDB's layouts — list_entry_t + child vectors, string_t, a byte per BOOLEAN, validity bits — one
+// device region per top-level column (id, alt, filter, info, formats), mirrored to pinned memory by one copy when the chunk
+// boundary wants the column; the Arrow boundary converts what differs (int32 offsets, Utf8 values, Boolean bits) on the device.
+struct NKeyBuf {  // where the children of one key are in the region of its column
+    size_t vals = 0, valid = 0, entries = 0, bases = 0, child_vals = 0, child_valid = 0;
+    uint64_t total = 0;  // list keys: child elements of the batch
+};
+struct NGroup {
+    char *d = nullptr, *h = nullptr;
+    size_t bytes = 0;
+};
+struct NestedOut {
+    uint64_t n = 0, S = 0, n_chunks = 0;
+    NGroup g[5];  // id, alt, filter, info, formats
+    size_t l_entries[3] = {0, 0, 0}, l_bases[3] = {0, 0, 0}, l_elems[3] = {0, 0, 0};
+    uint64_t l_total[3] = {0, 0, 0};
+    size_t f_entries = 0, f_bases = 0;
+    std::vector<NKeyBuf> info, format;
+    const uint64_t *d_goff = nullptr;  // list columns over rows (vn::kCol*), n + 1 offsets each
+    const uint64_t *d_fgoff = nullptr;  // FORMAT list keys over samples, S + 1 offsets each
+    uint64_t err = ~0ull;
+    uint64_t side_payload_base = 0;
+};
+struct Layout {  // offsets inside a region: what must be zero first, then what the kernels write whole, then what starts as ones
+    struct It {
+        size_t *slot, bytes;
+    };
+    std::vector<It> cat[3];
+    size_t end[3] = {0, 0, 0};
+    void add(int c, size_t *slot, size_t bytes) { cat[c].push_back(It{slot, bytes}); }
+    size_t finish() {
+        size_t off = 0;
+        for (int c = 0; c < 3; c++) {
+            for (It &it : cat[c]) {
+                *it.slot = off;
+                off += (it.bytes + 63) & ~(size_t)63;
             }
-            kids.push_back(std::move(col));
+            end[c] = off;
         }
-        return kids;
+        return off;
     }
 };
+inline size_t key_elem_size(uint8_t type) { return type == vn::kString ? 16 : type == vn::kFlag ? 1 : 4; }
 
-int upload_keys(exg_reader *r, const std::vector<KeyDef> &keys, ea::VtKeys *vt, void **d_names) {
-    if (keys.size() > (size_t)ea::kMaxVtKeys)
-        return fail(r, EXG_E_UNSUPPORTED, "VCF header declares more than " + std::to_string(ea::kMaxVtKeys) + " INFO or FORMAT keys");
+int upload_keys(exg_reader *r, const std::vector<KeyDef> &defs, StreamState::NestedKeys *nk) {
+    std::vector<vn::Key> keys(defs.size());
     std::string names;
-    vt->n = (uint32_t)keys.size();
-    for (size_t k = 0; k < keys.size(); k++) {
-        vt->k[k].name_off = (uint32_t)names.size();
-        vt->k[k].name_len = (uint32_t)keys[k].id.size();
-        vt->k[k].type = keys[k].type;
-        vt->k[k].is_list = keys[k].is_list;
-        names += keys[k].id;
+    uint32_t n_lists = 0;
+    for (size_t k = 0; k < defs.size(); k++) {
+        if (defs[k].id.size() > 0xFFFFu) return fail(r, EXG_E_UNSUPPORTED, "a VCF header key of more than 65 535 bytes");
+        vn::Key &key = keys[k];
+        key.name_off = (uint32_t)names.size();
+        key.name_len = (uint16_t)defs[k].id.size();
+        key.type = defs[k].type;
+        key.is_list = defs[k].is_list ? 1 : 0;
+        uint32_t h = vn::kKeyHashSeed;
+        for (unsigned char c : defs[k].id) h = vn::key_hash_step(h, c);
+        key.hash = h;
+        key.list_idx = defs[k].is_list ? (int32_t)n_lists++ : -1;
+        names += defs[k].id;
     }
-    EM_HIP(hipMalloc(d_names, names.size() + 16));
-    if (!names.empty()) EM_HIP(hipMemcpy(*d_names, names.data(), names.size(), hipMemcpyHostToDevice));
-    vt->d_names = (const uint8_t *)*d_names;
+    size_t n_slots = 2;
+    while (n_slots < 2 * keys.size()) n_slots <<= 1;
+    std::vector<uint32_t> slots(n_slots, 0u);
+    for (size_t k = 0; k < keys.size(); k++) {  // (the header parser keeps the first definition of an ID: the names are distinct)
+        uint32_t sl = vn::key_slot(keys[k].hash, (uint32_t)n_slots - 1);
+        while (slots[sl]) sl = (sl + 1) & ((uint32_t)n_slots - 1);
+        slots[sl] = (uint32_t)k + 1;
+    }
+    EM_HIP(hipMalloc(&nk->d_keys, keys.size() * sizeof(vn::Key) + 16));
+    EM_HIP(hipMalloc(&nk->d_slots, n_slots * 4));
+    EM_HIP(hipMalloc(&nk->d_names, names.size() + 16));
+    if (!keys.empty()) EM_HIP(hipMemcpy(nk->d_keys, keys.data(), keys.size() * sizeof(vn::Key), hipMemcpyHostToDevice));
+    EM_HIP(hipMemcpy(nk->d_slots, slots.data(), n_slots * 4, hipMemcpyHostToDevice));
+    if (!names.empty()) EM_HIP(hipMemcpy(nk->d_names, names.data(), names.size(), hipMemcpyHostToDevice));
+    nk->tab.keys = (const vn::Key *)nk->d_keys;
+    nk->tab.slots = (const uint32_t *)nk->d_slots;
+    nk->tab.names = (const uint8_t *)nk->d_names;
+    nk->tab.n_keys = (uint32_t)keys.size();
+    nk->tab.slot_mask = (uint32_t)n_slots - 1;
+    nk->tab.names_bytes = (uint32_t)names.size();
+    nk->tab.n_lists = n_lists;
+    return EXG_OK;
+}
+
+// want[c]: the chunk boundary hands column c out (its region is mirrored to pinned memory); mirror == false: the Arrow boundary
+// (nothing is copied here).  em.n rows (through em.d_row_map), B rows per DataChunk.
+int build_nested(Emit &em, const ScanCtx &ctx, uint64_t B, const bool *want, bool mirror, NestedOut *o) {
+    exg_reader *r = em.r;
+    StreamState *st = em.st;
+    hipStream_t s = em.s;
+    const uint64_t n = em.n, nc = (n + B - 1) / B;
+    const std::vector<KeyDef> &ik = st->info_keys, &fk = st->format_keys;
+    const vn::KeyTab &it = st->nk_info.tab, &ft = st->nk_format.tab;
+    const uint32_t nil = it.n_lists, nfl = ft.n_lists;
+    const uint64_t C = (uint64_t)vn::kColInfo0 + nil;
+    const bool rows_info = vn::rows_take_info(it.n_keys);
+    o->n = n;
+    o->n_chunks = nc;
+    const uint8_t *d_base = (const uint8_t *)ctx.d_input;
+    const uint64_t pb = (uint64_t)(uintptr_t)ctx.h;
+    // rows a wavefront looks at per turn of the wave kernels: one for cohort lines, 64 where most lines are k_rows' own
+    const uint64_t avg = ctx.res.n_records ? ctx.res.consumed_bytes / ctx.res.n_records : 64;
+    const uint32_t rpg = avg >= 2048 ? 1u : avg >= 256 ? 8u : 64u;
+
+    vn::Batch b;
+    memset(&b, 0, sizeof b);
+    const int src_col[5] = {2, 4, 6, 7, 8};
+    for (int c = 0; c < 5; c++) b.col[c] = (const exg_string_t *)r->d_cols[src_col[c]];
+    b.rest_valid = (const uint64_t *)r->d_valid[1];
+    b.row_map = em.d_row_map;
+    b.d_base = d_base;
+    b.payload_base = pb;
+    b.n = n;
+    vn::Ctl *d_ctl = (vn::Ctl *)em.dalloc(sizeof(vn::Ctl));
+    uint32_t *d_cnt = (uint32_t *)em.dalloc(C * n * 4);
+    uint64_t *d_goff = (uint64_t *)em.dalloc(C * (n + 1) * 8);
+    uint64_t *d_tmp = (uint64_t *)em.dalloc(vn::scan_tmp_entries(C, n) * 8);
+    uint64_t *d_tot = (uint64_t *)em.dalloc((C + nfl + 1) * 8);
+    uint64_t *h_tot = (uint64_t *)em.halloc((C + nfl + 1) * 8 + 64);
+    const size_t seen_bytes = vn::info_wide_seen_bytes(it, n, rpg);
+    uint32_t *d_seen = seen_bytes ? (uint32_t *)em.dalloc(seen_bytes) : nullptr;
+    if (em.rc) return em.rc;
+    b.ctl = d_ctl;
+    b.cnt = d_cnt;
+    b.cnt_stride = n;
+    b.goff = d_goff;
+    b.goff_stride = n + 1;
+    EM_HIP(hipMemsetAsync(d_ctl, 0xFF, 8, s));
+    EM_HIP(hipMemsetAsync((char *)d_ctl + 8, 0, 16, s));
+    if (!rows_info && nil) EM_HIP(hipMemsetAsync(d_cnt + (uint64_t)vn::kColInfo0 * n, 0, (size_t)nil * n * 4, s));  // (k_info_wide writes the keys a row has)
+    // ---- stage 1: elements per row of every list column over rows
+    vn::rows_count(b, it, s);
+    vn::info_wide_count(b, it, rpg, d_seen, s);
+    vn::samples_count(b, rpg, s);
+    vn::scan_counts(d_cnt, n, C, n, d_goff, n + 1, d_tot, d_tmp, s);
+    EM_HIP(hipMemcpyAsync(h_tot, d_tot, C * 8, hipMemcpyDeviceToHost, s));
+    EM_HIP(hipStreamSynchronize(s));
+    const uint64_t S = h_tot[vn::kColSamples];
+    o->S = S;
+    o->d_goff = d_goff;
+    // ---- stage 2: elements per sample of the FORMAT keys that are lists
+    vn::Samples sm;
+    memset(&sm, 0, sizeof sm);
+    sm.S = S;
+    uint64_t *h_ftot = h_tot + C;
+    for (uint32_t k = 0; k < nfl; k++) h_ftot[k] = 0;
+    if (S && nfl) {
+        uint32_t *d_fcnt = (uint32_t *)em.dalloc((size_t)nfl * S * 4);
+        uint64_t *d_fgoff = (uint64_t *)em.dalloc((size_t)nfl * (S + 1) * 8);
+        uint64_t *d_tmp2 = (uint64_t *)em.dalloc(vn::scan_tmp_entries(nfl, S) * 8);
+        uint32_t *d_srow = (uint32_t *)em.dalloc(S * 4);
+        if (em.rc) return em.rc;
+        EM_HIP(hipMemsetAsync(d_fcnt, 0, (size_t)nfl * S * 4, s));
+        sm.cnt = d_fcnt;
+        sm.cnt_stride = S;
+        vn::samples_count_lists(b, sm, ft, rpg, s);
+        vn::scan_counts(d_fcnt, S, nfl, S, d_fgoff, S + 1, d_tot + C, d_tmp2, s);
+        EM_HIP(hipMemcpyAsync(h_ftot, d_tot + C, (size_t)nfl * 8, hipMemcpyDeviceToHost, s));
+        EM_HIP(hipStreamSynchronize(s));
+        sm.goff = d_fgoff;
+        sm.goff_stride = S + 1;
+        sm.srow = d_srow;
+        o->d_fgoff = d_fgoff;
+    }
+    // ---- stage 3: the children
+    Layout L[5];
+    for (int c = 0; c < 3; c++) {
+        o->l_total[c] = h_tot[c];
+        L[c].add(1, &o->l_entries[c], n * 16);
+        L[c].add(1, &o->l_bases[c], (nc + 1) * 8);
+        L[c].add(1, &o->l_elems[c], h_tot[c] * 16 + 16);
+    }
+    auto lay_keys = [&](Layout &lay, const std::vector<KeyDef> &defs, const vn::KeyTab &, std::vector<NKeyBuf> *bufs, uint64_t m, const uint64_t *totals,
+                        int scalar_cat) {
+        bufs->assign(defs.size(), NKeyBuf());
+        uint32_t li = 0;
+        for (size_t q = 0; q < defs.size(); q++) {
+            NKeyBuf &kb = (*bufs)[q];
+            const size_t es = key_elem_size(defs[q].type);
+            if (!defs[q].is_list) {
+                lay.add(scalar_cat, &kb.vals, m * es + 16);
+                lay.add(scalar_cat, &kb.valid, Emit::bitmap_bytes(m));
+            } else {
+                kb.total = totals[li++];
+                lay.add(1, &kb.entries, m * 16 + 16);
+                lay.add(0, &kb.bases, (nc + 1) * 8);  // (zero first: a batch without samples runs no entries kernel for the FORMAT keys)
+                lay.add(scalar_cat, &kb.valid, Emit::bitmap_bytes(m));
+                lay.add(1, &kb.child_vals, kb.total * es + 16);
+                lay.add(2, &kb.child_valid, Emit::bitmap_bytes(kb.total));
+            }
+        }
+    };
+    // (k_rows stores every row's values and validity words of a header it takes; the wave kernels store what a row / sample has)
+    lay_keys(L[3], ik, it, &o->info, n, h_tot + vn::kColInfo0, rows_info ? 1 : 0);
+    L[4].add(1, &o->f_entries, n * 16);
+    L[4].add(1, &o->f_bases, (nc + 1) * 8);
+    lay_keys(L[4], fk, ft, &o->format, S, h_ftot, 0);
+    for (int attempt = 0;; attempt++) {
+        // (a second turn: a batch with more percent-decoded bytes than the side buffer held — everything is made again)
+        for (int c = 0; c < 5; c++) {
+            NGroup &g = o->g[c];
+            g.bytes = L[c].finish();
+            g.d = (char *)em.dalloc(g.bytes + 64);
+            g.h = mirror && want[c] ? (char *)em.halloc(g.bytes + 64) : nullptr;
+            if (em.rc) return em.rc;
+            if (L[c].end[0]) EM_HIP(hipMemsetAsync(g.d, 0, L[c].end[0], s));
+            if (L[c].end[2] > L[c].end[1]) EM_HIP(hipMemsetAsync(g.d + L[c].end[1], 0xFF, L[c].end[2] - L[c].end[1], s));
+        }
+        const size_t side_cap = st->side_cap;
+        uint8_t *d_side = (uint8_t *)em.dalloc(side_cap + 16);
+        char *h_side = mirror ? (char *)em.halloc(side_cap + 16) : nullptr;
+        vn::KeyOut *h_ko = (vn::KeyOut *)em.halloc((ik.size() + fk.size() + 1) * sizeof(vn::KeyOut));
+        vn::KeyOut *d_ko = (vn::KeyOut *)em.dalloc((ik.size() + fk.size() + 1) * sizeof(vn::KeyOut));
+        const size_t n_jobs_max = 4 + nil + nfl;
+        vn::EntryJob *h_jobs = (vn::EntryJob *)em.halloc(n_jobs_max * sizeof(vn::EntryJob));
+        vn::EntryJob *d_jobs = (vn::EntryJob *)em.dalloc(n_jobs_max * sizeof(vn::EntryJob));
+        uint64_t *h_ctl = (uint64_t *)em.halloc(64);
+        if (em.rc) return em.rc;
+        auto fill_ko = [&](vn::KeyOut *ko, const std::vector<KeyDef> &defs, const std::vector<NKeyBuf> &bufs, char *base) {
+            for (size_t q = 0; q < defs.size(); q++) {
+                const NKeyBuf &kb = bufs[q];
+                ko[q].vals = defs[q].is_list ? nullptr : base + kb.vals;
+                ko[q].valid = (uint64_t *)(base + kb.valid);
+                ko[q].child_vals = defs[q].is_list ? base + kb.child_vals : nullptr;
+                ko[q].child_valid = defs[q].is_list ? (uint32_t *)(base + kb.child_valid) : nullptr;
+            }
+        };
+        fill_ko(h_ko, ik, o->info, o->g[3].d);
+        fill_ko(h_ko + ik.size(), fk, o->format, o->g[4].d);
+        EM_HIP(hipMemcpyAsync(d_ko, h_ko, (ik.size() + fk.size()) * sizeof(vn::KeyOut) + 1, hipMemcpyHostToDevice, s));
+        for (int c = 0; c < 3; c++) b.elems[c] = (exg_string_t *)(o->g[c].d + o->l_elems[c]);
+        b.d_side = d_side;
+        b.side_cap = side_cap;
+        // (Arrow: the decoded strings become Utf8 values through the text's own (device base, payload base) pair)
+        o->side_payload_base = b.side_payload_base = mirror ? (uint64_t)(uintptr_t)h_side : pb + (uint64_t)((const uint8_t *)d_side - d_base);
+        vn::rows_write(b, it, d_ko, s);
+        vn::info_wide_write(b, it, d_ko, rpg, d_seen, s);
+        vn::samples_write(b, sm, ft, d_ko + ik.size(), rpg, s);
+        vn::fix_slow_floats(d_ctl, s);
+        // DuckDB's list_entry_t of every list column + where every DataChunk's children begin
+        uint32_t nj = 0;
+        for (int c = 0; c < 3; c++) h_jobs[nj++] = vn::EntryJob{d_goff + (uint64_t)c * (n + 1), o->g[c].d + o->l_entries[c], (uint64_t *)(o->g[c].d + o->l_bases[c])};
+        h_jobs[nj++] = vn::EntryJob{d_goff + (uint64_t)vn::kColSamples * (n + 1), o->g[4].d + o->f_entries, (uint64_t *)(o->g[4].d + o->f_bases)};
+        for (size_t q = 0, li = 0; q < ik.size(); q++)
+            if (ik[q].is_list) {
+                h_jobs[nj++] = vn::EntryJob{d_goff + (vn::kColInfo0 + li) * (n + 1), o->g[3].d + o->info[q].entries, (uint64_t *)(o->g[3].d + o->info[q].bases)};
+                li++;
+            }
+        const uint32_t nj_rows = nj;
+        if (sm.goff)
+            for (size_t q = 0, li = 0; q < fk.size(); q++)
+                if (fk[q].is_list) {
+                    h_jobs[nj++] = vn::EntryJob{sm.goff + li * (S + 1), o->g[4].d + o->format[q].entries, (uint64_t *)(o->g[4].d + o->format[q].bases)};
+                    li++;
+                }
+        EM_HIP(hipMemcpyAsync(d_jobs, h_jobs, nj * sizeof(vn::EntryJob), hipMemcpyHostToDevice, s));
+        vn::entries_rows(d_jobs, nj_rows, n, B, nc, s);
+        if (nj > nj_rows) vn::entries_elems(d_jobs + nj_rows, nj - nj_rows, S, sm.srow, d_goff + (uint64_t)vn::kColSamples * (n + 1), n, B, nc, s);
+        EM_HIP(hipMemcpyAsync(h_ctl, d_ctl, 24, hipMemcpyDeviceToHost, s));
+        EM_HIP(hipStreamSynchronize(s));
+        const uint64_t side_used = h_ctl[2];
+        if ((h_ctl[1] >> 32) && attempt == 0) {  // side_overflow
+            st->side_cap = (size_t)(side_used + side_used / 4 + 4096);
+            EM_HIP(hipMemsetAsync(d_ctl, 0xFF, 8, s));
+            EM_HIP(hipMemsetAsync((char *)d_ctl + 8, 0, 16, s));
+            continue;
+        }
+        o->err = h_ctl[0];
+        if (mirror) {
+            for (int c = 0; c < 5; c++)
+                if (o->g[c].h && o->g[c].bytes) EM_HIP(hipMemcpyAsync(o->g[c].h, o->g[c].d, o->g[c].bytes, hipMemcpyDeviceToHost, st->copy_stream));
+            if (side_used) EM_HIP(hipMemcpyAsync(h_side, d_side, (size_t)std::min<uint64_t>(side_used, side_cap), hipMemcpyDeviceToHost, st->copy_stream));
+        }
+        break;
+    }
     return EXG_OK;
 }
 
@@ -626,10 +619,7 @@ int arrow_emit(exg_reader *r, const ScanCtx &ctx) {
         }
         return sc;
     };
-    em.d_err = (unsigned long long *)em.dalloc(sizeof(ea::ErrBlock));  // the error word + the list of literals for the exact float parser
-    if (em.rc) return em.rc;
-    EM_HIP(hipMemsetAsync(em.d_err, 0xFF, 8, r->stream));
-    EM_HIP(hipMemsetAsync(em.d_err + 1, 0, 8, r->stream));
+    uint64_t err = ~0ull;  // (row << 8) | code of the first typed VCF value that does not parse
 
     if (st->has_filter) {
         ea::FilterCols fc;
@@ -693,64 +683,118 @@ int arrow_emit(exg_reader *r, const ScanCtx &ctx) {
         };
         cols.push_back(em.utf8_top(str_col(0), nullptr));                              // chrom
         cols.push_back(prim(r->d_pos, 8, nullptr));                                     // pos
-        cols.push_back(em.list_of_strings(str_col(2), ';'));                            // id
-        cols.push_back(em.utf8_top(str_col(3), nullptr));                              // ref
-        cols.push_back(em.list_of_strings(str_col(4), ','));                            // alt
-        cols.push_back(prim(r->d_qual, 4, (const uint64_t *)r->d_valid[0]));            // qual
-        cols.push_back(em.list_of_strings(str_col(6), ';'));                            // filter
+        AColumn c_ref = em.utf8_top(str_col(3), nullptr);
+        AColumn c_qual = prim(r->d_qual, 4, (const uint64_t *)r->d_valid[0]);
         if (em.rc) return em.rc;
-        EM_TRACE("flat + lists");
-        {  // info
+        EM_TRACE("flat");
+        // id / alt / filter / info / formats: made on the device in DuckDB's layouts (exg_vcf_nested.hpp), converted here to Arrow's
+        // (absolute int32 list offsets, Utf8 values closed up, Boolean bits)
+        const bool want_all[5] = {true, true, true, true, true};
+        NestedOut no;
+        if (int nrc = build_nested(em, ctx, r->batch_rows, want_all, false, &no)) return nrc;
+        err = no.err;
+        EM_TRACE("nested kernels");
+        auto off32_of = [&](const uint64_t *d_goff, uint64_t m) -> const uint8_t * {
+            if (!d_goff || !m) {  // (no element at all: one zero offset per entry)
+                void *h = em.halloc((m + 1) * 4);
+                if (h) memset(h, 0, (m + 1) * 4);
+                return (const uint8_t *)h;
+            }
+            int32_t *d = (int32_t *)em.dalloc((m + 1) * 4);
+            if (em.rc) return nullptr;
+            ea::narrow_offsets(d_goff, m, d, r->stream);
+            return em.to_host(d, (m + 1) * 4);
+        };
+        auto strings = [&](const char *d, uint64_t m, const uint8_t *h_valid) { return em.utf8_abs((const exg_string_t *)d, d_base, pb, m, h_valid); };
+        auto too_long = [&](uint64_t total) {
+            if (total >= (1ull << 31) && !em.rc) em.rc = fail(r, EXG_E_CAPACITY, "a list column exceeds Arrow's int32 offsets in one device batch");
+            return em.rc != 0;
+        };
+        auto list_utf8 = [&](int c) {
+            AColumn col;
+            col.kind = AColumn::kList;
+            col.length = (int64_t)n;
+            if (too_long(no.l_total[c])) return col;
+            col.offsets = off32_of(no.d_goff + (uint64_t)c * (n + 1), n);
+            col.children.push_back(strings(no.g[c].d + no.l_elems[c], no.l_total[c], nullptr));
+            return col;
+        };
+        auto key_cols = [&](const std::vector<KeyDef> &defs, const std::vector<NKeyBuf> &bufs, const char *base, uint64_t m, const uint64_t *goffs) {
+            std::vector<AColumn> kids;
+            uint64_t li = 0;
+            for (size_t q = 0; q < defs.size() && !em.rc; q++) {
+                const NKeyBuf &kb = bufs[q];
+                const KeyDef &kd = defs[q];
+                AColumn col;
+                col.length = (int64_t)m;
+                const uint8_t *valid = em.to_host(base + kb.valid, Emit::bitmap_bytes(m));
+                if (!kd.is_list) {
+                    if (kd.type == vn::kInt || kd.type == vn::kFloat) {
+                        col.kind = AColumn::kPrim;
+                        col.elem_size = 4;
+                        col.data = em.to_host(base + kb.vals, m * 4);
+                        col.validity = valid;
+                    } else if (kd.type == vn::kFlag) {
+                        uint64_t *d_bits = (uint64_t *)em.dalloc(Emit::bitmap_bytes(m));
+                        if (em.rc) break;
+                        vn::bytes_to_bits((const uint8_t *)base + kb.vals, m, d_bits, r->stream);
+                        col.kind = AColumn::kBool;
+                        col.data = em.to_host(d_bits, Emit::bitmap_bytes(m));
+                        col.validity = valid;
+                    } else {
+                        col = strings(base + kb.vals, m, valid);
+                    }
+                } else {
+                    if (too_long(kb.total)) break;
+                    col.kind = AColumn::kList;
+                    col.offsets = off32_of(goffs ? goffs + li * (m + 1) : nullptr, m);
+                    col.validity = valid;
+                    const uint8_t *cv = em.to_host(base + kb.child_valid, Emit::bitmap_bytes(kb.total));
+                    AColumn child;
+                    child.length = (int64_t)kb.total;
+                    if (kd.type == vn::kInt || kd.type == vn::kFloat) {
+                        child.kind = AColumn::kPrim;
+                        child.elem_size = 4;
+                        child.data = em.to_host(base + kb.child_vals, kb.total * 4);
+                        child.validity = cv;
+                    } else {
+                        child = strings(base + kb.child_vals, kb.total, cv);
+                    }
+                    col.children.push_back(std::move(child));
+                    li++;
+                }
+                kids.push_back(std::move(col));
+            }
+            return kids;
+        };
+        cols.push_back(list_utf8(0));   // id
+        cols.push_back(std::move(c_ref));
+        cols.push_back(list_utf8(1));   // alt
+        cols.push_back(std::move(c_qual));
+        cols.push_back(list_utf8(2));   // filter
+        {
             AColumn info;
             info.kind = AColumn::kStruct;
             info.length = (int64_t)n;
-            const uint32_t K = st->info_vt.n;
-            if (K) {
-                ea::VtCell *d_cells = (ea::VtCell *)em.dalloc((size_t)n * K * sizeof(ea::VtCell));
-                if (em.rc) return em.rc;
-                ea::info_cells(str_col(7), em.d_row_map, n, st->info_vt, d_cells, r->stream);
-                ea::CellSrc src{d_cells, K, 0, str_col(7), em.d_row_map, nullptr, nullptr};
-                info.children = em.cell_children(st->info_keys, src, n, EXG_PE_VCF_INFO);
-            }
+            info.children = key_cols(st->info_keys, no.info, no.g[3].d, n, no.d_goff + (uint64_t)vn::kColInfo0 * (n + 1));
             cols.push_back(std::move(info));
         }
-        if (em.rc) return em.rc;
-        EM_TRACE("info");
-        {  // formats
+        {
             AColumn fl;
             fl.kind = AColumn::kList;
             fl.length = (int64_t)n;
-            uint64_t *d_goff = (uint64_t *)em.dalloc((n + 1) * 8);
-            uint64_t *d_tmp = (uint64_t *)em.dalloc(ea::scan_tmp_entries(n) * 8);
-            if (em.rc) return em.rc;
-            ea::sample_counts(str_col(8), (const uint64_t *)r->d_valid[1], em.d_row_map, n, d_goff, d_tmp, r->stream);
-            const uint64_t S = em.fetch_u64(d_goff + n);
-            if (S >= (1ull << 31)) return fail(r, EXG_E_CAPACITY, "formats exceeds Arrow's int32 offsets in one device batch");
-            int32_t *d_off32 = (int32_t *)em.dalloc((n + 1) * 4);
-            if (em.rc) return em.rc;
-            ea::narrow_offsets(d_goff, n, d_off32, r->stream);
-            fl.offsets = em.to_host(d_off32, (n + 1) * 4);
+            if (too_long(no.S)) return em.rc;
+            fl.offsets = off32_of(no.d_goff + (uint64_t)vn::kColSamples * (n + 1), n);
             AColumn item;
             item.kind = AColumn::kStruct;
-            item.length = (int64_t)S;
-            const uint32_t K = st->format_vt.n;
-            if (K) {
-                ea::VtCell *d_cells = (ea::VtCell *)em.dalloc((size_t)S * K * sizeof(ea::VtCell));
-                ea::View *d_fields = (ea::View *)em.dalloc((size_t)S * sizeof(ea::View));
-                uint32_t *d_srow = (uint32_t *)em.dalloc((size_t)S * 4);
-                if (em.rc) return em.rc;
-                ea::sample_cells(str_col(8), em.d_row_map, n, d_goff, st->format_vt, d_cells, d_fields, d_srow, r->stream);
-                ea::CellSrc src{d_cells, K, 0, ea::StrCol{nullptr, nullptr, 0}, nullptr, d_fields, d_srow};
-                item.children = em.cell_children(st->format_keys, src, S, EXG_PE_VCF_FORMAT);
-            }
+            item.length = (int64_t)no.S;
+            item.children = key_cols(st->format_keys, no.format, no.g[4].d, no.S, no.d_fgoff);
             fl.children.push_back(std::move(item));
             cols.push_back(std::move(fl));
         }
     }
     if (em.rc) return em.rc;
     EM_TRACE("formats / columns");
-    const uint64_t err = em.fetch_u64((const uint64_t *)em.d_err);
-    if (em.rc) return em.rc;
     EM_HIP(hipStreamSynchronize(r->stream));
     EM_HIP(hipStreamSynchronize(st->copy_stream));  // every buffer has landed
     uint64_t n_rows = n;
@@ -1036,7 +1080,7 @@ static exg_type list_of(StreamState *st, const char *name, const exg_type &item,
     return t;
 }
 static exg_type key_type(StreamState *st, const KeyDef &k) {
-    const int base = k.type == ea::kVtInt ? EXG_TYPE_INTEGER : k.type == ea::kVtFloat ? EXG_TYPE_FLOAT : k.type == ea::kVtFlag ? EXG_TYPE_BOOLEAN : EXG_TYPE_VARCHAR;
+    const int base = k.type == vn::kInt ? EXG_TYPE_INTEGER : k.type == vn::kFloat ? EXG_TYPE_FLOAT : k.type == vn::kFlag ? EXG_TYPE_BOOLEAN : EXG_TYPE_VARCHAR;
     if (!k.is_list) return leaf(base, k.id.c_str(), 1);
     return list_of(st, k.id.c_str(), leaf(base, "item", 1), 1);
 }
@@ -1061,9 +1105,7 @@ int nested_prepare(exg_reader *r) {
     st->owns_reader = false;
     parse_vcf_header((const char *)r->file->p, (size_t)r->vcf_header_bytes, &st->info_keys, &st->format_keys);
     int rc;
-    if ((rc = upload_keys(r, st->info_keys, &st->info_vt, &st->d_info_names)) ||
-        (rc = upload_keys(r, st->format_keys, &st->format_vt, &st->d_format_names)))
-        return rc;
+    if ((rc = upload_keys(r, st->info_keys, &st->nk_info)) || (rc = upload_keys(r, st->format_keys, &st->nk_format))) return rc;
     exg_type *t = st->type_roots;
     t[0] = leaf(EXG_TYPE_VARCHAR, "chrom", 0);
     t[1] = leaf(EXG_TYPE_BIGINT, "pos", 0);
@@ -1108,7 +1150,7 @@ int nested_emit(exg_reader *r, const ScanCtx &ctx, Batch *b, const uint32_t *d_r
         hipStream_t cs;
         ~CopyDrain() { (void)hipStreamSynchronize(cs); }
     } drain{st->copy_stream};
-    const uint64_t n = *n_rows, B = r->batch_rows;
+    const uint64_t n = *n_rows;
     Emit em;
     em.r = r;
     em.st = st;
@@ -1116,84 +1158,68 @@ int nested_emit(exg_reader *r, const ScanCtx &ctx, Batch *b, const uint32_t *d_r
     em.s = r->stream;
     em.n = n;
     em.d_row_map = d_row_map;
-    em.d_err = (unsigned long long *)em.dalloc(sizeof(ea::ErrBlock));  // the error word + the list of literals for the exact float parser
-    if (em.rc) return em.rc;
-    EM_HIP(hipMemsetAsync(em.d_err, 0xFF, 8, r->stream));
-    EM_HIP(hipMemsetAsync(em.d_err + 1, 0, 8, r->stream));
-    const uint8_t *d_base = (const uint8_t *)ctx.d_input;
-    const uint64_t pb = (uint64_t)(uintptr_t)ctx.h;
-    auto str_col = [&](int c) { return ea::StrCol{(const exg_string_t *)r->d_cols[c], d_base, pb}; };
-    DuckEmit de{em, B, (n + B - 1) / B, d_base, pb};
-    b->nested.assign(9, NVec());
     // (columns outside the projection are built like the others — a malformed value is an error whether or not its column is
-    // selected, like in the reference — but em.copy is off for them and their NVec is dropped at the end)
-    em.copy = r->want(2);
-    b->nested[2] = de.list_of_strings(str_col(2), ';');
-    em.copy = r->want(4);
-    b->nested[4] = de.list_of_strings(str_col(4), ',');
-    em.copy = r->want(6);
-    b->nested[6] = de.list_of_strings(str_col(6), ';');
-    if (em.rc) return em.rc;
-    em.copy = r->want(7);
-    {  // info
-        NVec info;
-        info.type = EXG_TYPE_STRUCT;
-        info.length = n;
-        const uint32_t K = st->info_vt.n;
-        if (K) {
-            ea::VtCell *d_cells = (ea::VtCell *)em.dalloc((size_t)n * K * sizeof(ea::VtCell));
-            if (em.rc) return em.rc;
-            ea::info_cells(str_col(7), d_row_map, n, st->info_vt, d_cells, r->stream);
-            ea::CellSrc src{d_cells, K, 0, str_col(7), d_row_map, nullptr, nullptr};
-            info.children = de.cell_children(st->info_keys, src, n, EXG_PE_VCF_INFO, nullptr, nullptr, nullptr);
+    // selected, like in the reference — but their regions stay on the device)
+    const int top[5] = {2, 4, 6, 7, 8};
+    bool want[5];
+    for (int c = 0; c < 5; c++) want[c] = r->want(top[c]);
+    NestedOut no;
+    if (int rc = build_nested(em, ctx, r->batch_rows, want, true, &no)) return rc;
+    EM_HIP(hipStreamSynchronize(st->copy_stream));
+    b->nested.assign(9, NVec());
+    auto leaf = [](int type, uint32_t elem, uint64_t length, const void *data, const void *validity) {
+        NVec v;
+        v.type = type;
+        v.elem = elem;
+        v.length = length;
+        v.data = data;
+        v.validity = (const uint64_t *)validity;
+        return v;
+    };
+    auto duck_type = [](uint8_t t) { return t == vn::kInt ? EXG_TYPE_INTEGER : t == vn::kFloat ? EXG_TYPE_FLOAT : t == vn::kFlag ? EXG_TYPE_BOOLEAN : EXG_TYPE_VARCHAR; };
+    auto key_vecs = [&](const std::vector<KeyDef> &defs, const std::vector<NKeyBuf> &bufs, const char *h, uint64_t m) {
+        std::vector<NVec> kids;
+        for (size_t q = 0; q < defs.size(); q++) {
+            const NKeyBuf &kb = bufs[q];
+            const uint32_t es = (uint32_t)key_elem_size(defs[q].type);
+            if (!defs[q].is_list) {
+                kids.push_back(leaf(duck_type(defs[q].type), es, m, h + kb.vals, h + kb.valid));
+            } else {
+                NVec v = leaf(EXG_TYPE_LIST, 16, m, h + kb.entries, h + kb.valid);
+                v.child_base = (const uint64_t *)(h + kb.bases);
+                v.children.push_back(leaf(duck_type(defs[q].type), es, kb.total, h + kb.child_vals, h + kb.child_valid));
+                kids.push_back(std::move(v));
+            }
         }
+        return kids;
+    };
+    for (int c = 0; c < 3; c++) {
+        if (!want[c]) continue;
+        const char *h = no.g[c].h;
+        NVec v = leaf(EXG_TYPE_LIST, 16, n, h + no.l_entries[c], nullptr);
+        v.child_base = (const uint64_t *)(h + no.l_bases[c]);
+        v.children.push_back(leaf(EXG_TYPE_VARCHAR, 16, no.l_total[c], h + no.l_elems[c], nullptr));  // (id / alt / filter are not percent-decoded)
+        b->nested[(size_t)top[c]] = std::move(v);
+    }
+    if (want[3]) {
+        NVec info = leaf(EXG_TYPE_STRUCT, 0, n, nullptr, nullptr);
+        info.children = key_vecs(st->info_keys, no.info, no.g[3].h, n);
         b->nested[7] = std::move(info);
     }
-    if (em.rc) return em.rc;
-    em.copy = r->want(8);
-    {  // formats
-        NVec fl;
-        fl.type = EXG_TYPE_LIST;
-        fl.elem = 16;
-        fl.length = n;
-        uint64_t *d_goff = (uint64_t *)em.dalloc((n + 1) * 8);
-        uint64_t *d_tmp = (uint64_t *)em.dalloc(ea::scan_tmp_entries(n) * 8);
-        ea::ListEntry *d_entries = (ea::ListEntry *)em.dalloc(n * 16 + 16);
-        if (em.rc) return em.rc;
-        ea::sample_counts(str_col(8), (const uint64_t *)r->d_valid[1], d_row_map, n, d_goff, d_tmp, r->stream);
-        const uint64_t S = em.fetch_u64(d_goff + n);
-        ea::list_entries_rows(d_goff, n, B, d_entries, r->stream);
-        fl.data = em.to_host(d_entries, n * 16);
-        uint64_t *d_sb = nullptr;
-        fl.child_base = de.bases_rows(d_goff, n, &d_sb);
-        NVec item;
-        item.type = EXG_TYPE_STRUCT;
-        item.length = S;
-        const uint32_t K = st->format_vt.n;
-        if (K && !em.rc) {
-            ea::VtCell *d_cells = (ea::VtCell *)em.dalloc((size_t)S * K * sizeof(ea::VtCell) + 16);
-            ea::View *d_fields = (ea::View *)em.dalloc((size_t)S * sizeof(ea::View) + 16);
-            uint32_t *d_srow = (uint32_t *)em.dalloc((size_t)S * 4 + 16);
-            if (em.rc) return em.rc;
-            ea::sample_cells(str_col(8), d_row_map, n, d_goff, st->format_vt, d_cells, d_fields, d_srow, r->stream);
-            ea::CellSrc src{d_cells, K, 0, ea::StrCol{nullptr, nullptr, 0}, nullptr, d_fields, d_srow};
-            item.children = de.cell_children(st->format_keys, src, S, EXG_PE_VCF_FORMAT, d_srow, d_goff, d_sb);
-        }
+    if (want[4]) {
+        const char *h = no.g[4].h;
+        NVec fl = leaf(EXG_TYPE_LIST, 16, n, h + no.f_entries, nullptr);
+        fl.child_base = (const uint64_t *)(h + no.f_bases);
+        NVec item = leaf(EXG_TYPE_STRUCT, 0, no.S, nullptr, nullptr);
+        item.children = key_vecs(st->format_keys, no.format, h, no.S);
         fl.children.push_back(std::move(item));
         b->nested[8] = std::move(fl);
     }
-    if (em.rc) return em.rc;
-    const uint64_t err = em.fetch_u64((const uint64_t *)em.d_err);
-    if (em.rc) return em.rc;
-    EM_HIP(hipStreamSynchronize(r->stream));
-    EM_HIP(hipStreamSynchronize(st->copy_stream));
-    for (int c : {2, 4, 6, 7, 8})
-        if (!r->want(c)) b->nested[(size_t)c] = NVec();  // (validated, not handed out)
-    if (err != ~0ull) {
+    if (no.err != ~0ull) {
         // a typed value did not parse: the rows in front of it are handed out, then the error (like the scan's own errors)
-        *n_rows = err >> 8;
+        *n_rows = no.err >> 8;
         if (!r->pending_error) {
-            r->pending_error = (uint32_t)(err & 0xFF);
+            r->pending_error = (uint32_t)(no.err & 0xFF);
             r->pending_error_offset = 0;
         }
     }
@@ -1257,8 +1283,7 @@ static int build_stream(const exg_open_args &oa, const char *filters, std::share
         formats.children.push_back(item);
         st->schema = {utf8("chrom", false), pos, list_utf8("id"), utf8("ref", false), list_utf8("alt"), qual,
                       list_utf8("filter"), info, formats};
-        if ((rc = upload_keys(r, st->info_keys, &st->info_vt, &st->d_info_names)) ||
-            (rc = upload_keys(r, st->format_keys, &st->format_vt, &st->d_format_names))) {
+        if ((rc = upload_keys(r, st->info_keys, &st->nk_info)) || (rc = upload_keys(r, st->format_keys, &st->nk_format))) {
             *err = "could not register table: " + r->error;
             return rc;
         }
