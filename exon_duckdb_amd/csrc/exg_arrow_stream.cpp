@@ -185,6 +185,7 @@ struct Emit {
     const uint32_t *d_row_map;  // NULL: identity
     int rc = 0;
     bool copy = true;  // false: the column being built is not in the projection — built and validated on the device, not copied back
+    hipStream_t d2h = nullptr;  // the stream build_nested's mirrors travel on (NULL: st->copy_stream)
 
     void *dalloc(size_t bytes) {
         void *p = st->arena.alloc(bytes);
@@ -392,6 +393,15 @@ int build_nested(Emit &em, const ScanCtx &ctx, uint64_t B, const bool *want, boo
     const uint64_t avg = ctx.res.n_records ? ctx.res.consumed_bytes / ctx.res.n_records : 64;
     const uint32_t rpg = avg >= 2048 ? 1u : avg >= 256 ? 8u : 64u;
 
+    const bool trace = getenv("EXG_TRACE") != nullptr;
+    struct timespec ts0;
+    clock_gettime(CLOCK_MONOTONIC, &ts0);
+    auto since = [&]() {
+        struct timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return (ts.tv_sec - ts0.tv_sec) * 1e3 + (ts.tv_nsec - ts0.tv_nsec) * 1e-6;
+    };
+    double t_stage1 = 0, t_stage2 = 0, t_stage3 = 0;
     vn::Batch b;
     memset(&b, 0, sizeof b);
     const int src_col[5] = {2, 4, 6, 7, 8};
@@ -428,6 +438,7 @@ int build_nested(Emit &em, const ScanCtx &ctx, uint64_t B, const bool *want, boo
     const uint64_t S = h_tot[vn::kColSamples];
     o->S = S;
     o->d_goff = d_goff;
+    t_stage1 = since();
     // ---- stage 2: elements per sample of the FORMAT keys that are lists
     vn::Samples sm;
     memset(&sm, 0, sizeof sm);
@@ -452,6 +463,7 @@ int build_nested(Emit &em, const ScanCtx &ctx, uint64_t B, const bool *want, boo
         sm.srow = d_srow;
         o->d_fgoff = d_fgoff;
     }
+    t_stage2 = since();
     // ---- stage 3: the children
     Layout L[5];
     for (int c = 0; c < 3; c++) {
@@ -556,10 +568,18 @@ int build_nested(Emit &em, const ScanCtx &ctx, uint64_t B, const bool *want, boo
             continue;
         }
         o->err = h_ctl[0];
+        t_stage3 = since();
+        trace_at("N nested kernels done", n);
+        if (trace) {
+            size_t bytes = 0;
+            for (int c = 0; c < 5; c++) bytes += o->g[c].h ? o->g[c].bytes : 0;
+            fprintf(stderr, "[exg]   nested: counts %.2f ms, sample lists %.2f ms, children %.2f ms (%llu rows, %llu samples, %.1f MiB to the host)\n", t_stage1,
+                    t_stage2 - t_stage1, t_stage3 - t_stage2, (unsigned long long)n, (unsigned long long)S, bytes / 1048576.0);
+        }
         if (mirror) {
             for (int c = 0; c < 5; c++)
-                if (o->g[c].h && o->g[c].bytes) EM_HIP(hipMemcpyAsync(o->g[c].h, o->g[c].d, o->g[c].bytes, hipMemcpyDeviceToHost, st->copy_stream));
-            if (side_used) EM_HIP(hipMemcpyAsync(h_side, d_side, (size_t)std::min<uint64_t>(side_used, side_cap), hipMemcpyDeviceToHost, st->copy_stream));
+                if (o->g[c].h && o->g[c].bytes) EM_HIP(hipMemcpyAsync(o->g[c].h, o->g[c].d, o->g[c].bytes, hipMemcpyDeviceToHost, em.d2h ? em.d2h : st->copy_stream));
+            if (side_used) EM_HIP(hipMemcpyAsync(h_side, d_side, (size_t)std::min<uint64_t>(side_used, side_cap), hipMemcpyDeviceToHost, em.d2h ? em.d2h : st->copy_stream));
         }
         break;
     }
@@ -1163,9 +1183,17 @@ int nested_emit(exg_reader *r, const ScanCtx &ctx, Batch *b, const uint32_t *d_r
     const int top[5] = {2, 4, 6, 7, 8};
     bool want[5];
     for (int c = 0; c < 5; c++) want[c] = r->want(top[c]);
+    // Every byte that goes back to the host travels on ONE stream — behind the flat columns' copies when next_batch gave them a
+    // stream of their own: a copy occupies an SDMA engine, a second stream of D2H copies takes a second engine, and that was the
+    // one the next batch's upload runs on (EXG_TRACE=2: the upload landed 2 ms after the columns had left, the link never duplex)
+    em.d2h = r->col_stream && !getenv("EXG_VCF_TWO_D2H") ? r->col_stream : st->copy_stream;
+    struct D2hDrain {
+        hipStream_t cs;
+        ~D2hDrain() { (void)hipStreamSynchronize(cs); }
+    } drain2{em.d2h};
     NestedOut no;
     if (int rc = build_nested(em, ctx, r->batch_rows, want, true, &no)) return rc;
-    EM_HIP(hipStreamSynchronize(st->copy_stream));
+    EM_HIP(hipStreamSynchronize(em.d2h));
     b->nested.assign(9, NVec());
     auto leaf = [](int type, uint32_t elem, uint64_t length, const void *data, const void *validity) {
         NVec v;

@@ -677,7 +677,9 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
                 if (len + 16 <= r->d_in_cap) start_upload(r, &r->pf2, start, len, r->pf.slot ^ 1);
             }
         }
+        trace_at("N batch begins", r->n_batches);
         if ((rc = r->join_prefetch())) return rc;  // the upload thread of the previous call (its error is this call's)
+        trace_at("N upload thread joined", r->n_batches);
         const uint8_t *h = (const uint8_t *)r->file->p + r->file_pos;
         const void *d_input = nullptr;
         uint64_t lead = 0;
@@ -950,6 +952,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             else if (r->fused_algo == EXG_ALGO_FUSED_INDEX && per_line < 448) r->fused_algo = EXG_ALGO_FUSED_FULL;
         }
         TRACE("wait(h2d) + scan", t_scan);
+        trace_at("N scan result", r->n_batches);
         if (r->shard_first && (res.flags & EXG_RF_HEAD_UNRESOLVED) && r->file_pos - shard_halo > r->data_base) {
             // The record that ends behind the cut begins in front of the halo (a long read, a very wide VCF line): it belongs
             // to this shard, so this shard looks further back — eight times as far, up to the first byte of the data — and
@@ -1181,7 +1184,11 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
                 ctx.res = res;
                 ctx.h_seq_payload = nullptr;
                 uint64_t deliver = k;
+                const double t_ne = now_s();
+                trace_at("N nested begins", r->n_batches);
                 if ((rc = nested_emit(r, ctx, b.get(), row_map, &deliver))) return rc;
+                trace_at("N nested landed", r->n_batches);
+                TRACE("nested columns (kernels + their way back)", t_ne);
                 b->n_rows = deliver;
             } else {
                 if (r->want(1) && (rc = copy_validity(1, r->d_valid[0]))) return rc;

@@ -367,8 +367,15 @@ void start_upload(exg_reader *r, exg_reader::Prefetch *which, uint64_t start, ui
     r->up_thread_of[slot] = std::thread([r, start, len, slot] {
         (void)hipSetDevice(r->device);
         pin_to_device_node(r->device);
+        trace_at("U upload begins, slot", (uint64_t)slot);
         int rc3 = upload_range(r, start, len, slot, r->up_stream);
         if (!rc3 && hipEventRecord(r->up_done_of[slot], r->up_stream) != hipSuccess) rc3 = EXG_E_HIP;
+        trace_at("U upload enqueued, slot", (uint64_t)slot);
+        static const bool lvl2 = getenv("EXG_TRACE") && atoi(getenv("EXG_TRACE")) >= 2;
+        if (lvl2 && !rc3) {  // (when the bytes have landed: a timeline's question)
+            (void)hipEventSynchronize(r->up_done_of[slot]);
+            trace_at("U upload landed, slot", (uint64_t)slot);
+        }
         r->up_rc_of[slot] = rc3;
     });
     which->valid = true;
