@@ -195,15 +195,15 @@ def link_rates(torch, n=1 << 30, reps=3):
     return out[0], out[1]
 
 
-CHUNKS_HINT = 1 << 63  # exg_open_args.columns bit 63 (EXG_COLUMNS_CHUNKS): chunks will be pulled — what the table function says at init_global
+CHUNKS_HINT = 1  # exg_open_args.flags = EXG_OPEN_CHUNKS: chunks will be pulled — what the table function says at init_global
 
 
-def open_reader(lib, path, fmt, shard=(0, 1), device_index=0, columns=0):
+def open_reader(lib, path, fmt, shard=(0, 1), device_index=0, columns=0, flags=0):
     from exon_duckdb_amd import abi
     lib.exg_open.argtypes = [C.POINTER(abi.OpenArgs), C.POINTER(C.c_void_p)]
     lib.exg_count_only.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.exg_close.argtypes = [C.c_void_p]
-    a = abi.OpenArgs(path.encode(), fmt.encode(), None, 2048, device_index, 0, None, shard[0], shard[1], columns)
+    a = abi.OpenArgs(path.encode(), fmt.encode(), None, 2048, device_index, 0, None, shard[0], shard[1], columns, flags)
     r = C.c_void_p()
     rc = lib.exg_open(C.byref(a), C.byref(r))
     assert rc == 0, lib.exg_last_error_message()
@@ -221,18 +221,48 @@ def reader_count(lib, path, fmt, shard=(0, 1), device_index=0):
     return int(n.value), dt
 
 
-def reader_chunks(lib, path, fmt, shard=(0, 1), device_index=0, columns=0):
-    """every DataChunk pulled and released by a C loop of the scaffolding library (no interpreter between the chunks)"""
-    from exon_duckdb_amd import load_test_library
+def reader_chunks(lib, path, fmt, shard=(0, 1), device_index=0, columns=0, stats=None):
+    """every DataChunk pulled and released by a C loop of the scaffolding library (no interpreter between the chunks);
+    stats: a dict that receives exg_reader_stats_of at the end of the stream (nested_ns, host_vector_bytes, ...)"""
+    from exon_duckdb_amd import abi, load_test_library
     tl = load_test_library()
-    r = open_reader(lib, path, fmt, shard, device_index, columns | CHUNKS_HINT)
+    r = open_reader(lib, path, fmt, shard, device_index, columns, CHUNKS_HINT)
     rows, chunks = C.c_uint64(0), C.c_uint64(0)
     t0 = time.perf_counter()
     rc = tl.exon_tf_drain_chunks(r, C.byref(rows), C.byref(chunks))
     dt = time.perf_counter() - t0
     assert rc == 0, lib.exg_last_error_message()
+    if stats is not None:
+        st = abi.ReaderStats()
+        lib.exg_reader_stats_of.argtypes = [C.c_void_p, C.POINTER(abi.ReaderStats)]
+        assert lib.exg_reader_stats_of(r, C.byref(st)) == 0
+        stats.update({f: int(getattr(st, f)) for f, _ in abi.ReaderStats._fields_ if f != "reserved"})
     lib.exg_close(r)
     return int(rows.value), int(chunks.value), dt
+
+
+def timed_reader_chunks(lib, path, fmt, reps=3, **kw):
+    """best of `reps` drains -> (rows, chunks, seconds, the stats of that drain)"""
+    best = None
+    for _ in range(reps):
+        st = {}
+        rows, chunks, dt = reader_chunks(lib, path, fmt, stats=st, **kw)
+        if best is None or dt < best[2]:
+            best = (rows, chunks, dt, st)
+    return best
+
+
+def reader_formats_digest(lib, path, key=0):
+    """read_vcf's formats column walked like an operator would (list entries, the struct's child `key` of every sample) ->
+    (rows, samples, digest); the expectation is exon_tf_expect_vcf_formats_file's independent split of the file"""
+    from exon_duckdb_amd import load_test_library
+    tl = load_test_library()
+    r = open_reader(lib, path, "vcf", columns=1 << 8, flags=CHUNKS_HINT)
+    rows, samples, dg = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    rc = tl.exon_tf_drain_formats_digest(r, key, C.byref(rows), C.byref(samples), C.byref(dg))
+    assert rc == 0, lib.exg_last_error_message()
+    lib.exg_close(r)
+    return int(rows.value), int(samples.value), int(dg.value)
 
 
 def reader_digest(lib, path, fmt, want_seq_len=0, columns=0, shard=(0, 1), device_index=0, first_row=0):
@@ -241,7 +271,7 @@ def reader_digest(lib, path, fmt, want_seq_len=0, columns=0, shard=(0, 1), devic
     A shard's rows are rows [first_row, first_row + n) of the file: the shards' digests add up to the file's."""
     from exon_duckdb_amd import load_test_library
     tl = load_test_library()
-    r = open_reader(lib, path, fmt, shard, device_index, columns | CHUNKS_HINT)
+    r = open_reader(lib, path, fmt, shard, device_index, columns, CHUNKS_HINT)
     rows, chunks, dg, bad = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
     rc = tl.exon_tf_drain_digest_from(r, 1 if fmt == "vcf" else 0, want_seq_len, first_row, C.byref(rows), C.byref(chunks), C.byref(dg), C.byref(bad))
     assert rc == 0, lib.exg_last_error_message()
@@ -549,8 +579,12 @@ def run_configs(torch, lib, args):
     except Exception:  # noqa: BLE001
         link = (float("nan"), float("nan"))
     out["pcie_link"] = {"h2d_GB/s": link[0], "d2h_GB/s": link[1], "what": "one pinned 1 GiB buffer <-> HBM, each direction alone, best of 3, measured in this run"}
+    only_legs = [x for x in getattr(args, "legs", "").split(",") if x]   # (tools: --legs end_to_end_vcf,end_to_end_vcf_cohort)
+
     def leg(fn, *keys):
         """a side leg of the bench line: what goes wrong in it is reported in its own object(s)"""
+        if only_legs and not any(k in only_legs for k in keys):
+            return
         try:
             fn()
         except Exception as e:  # noqa: BLE001
@@ -785,7 +819,7 @@ def run_configs(torch, lib, args):
             torch.cuda.empty_cache()
             reader_count(lib, p_vcf, "vcf")
             n, dt_c = min((reader_count(lib, p_vcf, "vcf") for _ in range(3)), key=lambda x: x[1])
-            rows, chunks, dt_r = min((reader_chunks(lib, p_vcf, "vcf") for _ in range(3)), key=lambda x: x[2])
+            rows, chunks, dt_r, st_r = timed_reader_chunks(lib, p_vcf, "vcf")
             # content: CHROM, the parsed POS and REF of every row, against an independent split of the file's lines
             e_rows, e_dg = C.c_uint64(0), C.c_uint64(0)
             assert tl.exon_tf_expect_vcf_file(p_vcf.encode(), C.byref(e_rows), C.byref(e_dg)) == 0
@@ -793,9 +827,20 @@ def run_configs(torch, lib, args):
             # the same scan with a projection pushed into the reader (exg_open_args.columns; DuckDB's projection_pushdown):
             # chrom, pos, ref — every column is still parsed and typed on the device, three of nine cross PCIe
             proj = 0b1011
-            p_rows, p_chunks, dt_p = min((reader_chunks(lib, p_vcf, "vcf", columns=proj) for _ in range(3)), key=lambda x: x[2])
+            p_rows, p_chunks, dt_p, st_p = timed_reader_chunks(lib, p_vcf, "vcf", columns=proj)
             pv_rows, _, p_got, _ = reader_digest(lib, p_vcf, "vcf", columns=proj)
+            nested_s = st_r["nested_ns"] * 1e-9
+            d2h = st_r["host_vector_bytes"]
             out["end_to_end_vcf"] = {
+                # the nested columns' chain on the device (exg_vcf_nested.hip: counting passes, prefix sums, children — wall time on
+                # the reader's thread up to the point where the vectors start for the host, launches and the two syncs included)
+                "nested": {"what": "id / alt / filter LIST(VARCHAR), info STRUCT, formats LIST(STRUCT) of every batch made on the device: counts, "
+                                   "prefix sums, children (reader-thread wall time, exg_reader_stats.nested_ns)",
+                           "ms": nested_s * 1e3, "device_ms_per_GB": nested_s * 1e3 / (n_vcf / 1e9), "GB/s": n_vcf / nested_s / 1e9 if nested_s else None,
+                           "frac": n_vcf / nested_s / 1e9 / HBM_PEAK_GBPS if nested_s else None,
+                           "ms_when_projected_away": st_p["nested_ns"] * 1e-6},
+                "d2h_bytes": d2h, "d2h_GB/s": d2h / dt_r / 1e9, "frac_of_d2h_link": d2h / dt_r / 1e9 / link[1], "d2h_bound_ms": d2h / link[1] / 1e6,
+                "link_GB/s": {"h2d": link[0], "d2h": link[1]},
                 "projected": {"columns": "chrom, pos, ref (exg_open_args.columns)", "ms": dt_p * 1e3, "GB/s": n_vcf / dt_p / 1e9,
                               "records_per_s": p_rows / dt_p, "verified": bool(p_rows == pv_rows == n_lines and p_got == int(e_dg.value))},
                 "workload": f"read_vcf, {n_vcf / 1e9:.2f} GB VCF-8 file in the page cache -> host DataChunks of all 8 columns (exg_open / exg_next_chunk), PCIe inclusive",
@@ -804,6 +849,51 @@ def run_configs(torch, lib, args):
                 "verification": "an untimed pass folds CHROM, the parsed POS and REF of every row into a digest that must equal the one of "
                                 "an independent line / tab split of the file",
                 "verified": bool(rows == n == n_lines == v_rows == int(e_rows.value) and chunks >= (rows + 2047) // 2048 and got == int(e_dg.value))}
+
+        def cohort_files():
+            # ---- read_vcf on COHORT lines with the reference's real schema (module.cpp:126-147: formats = LIST(STRUCT(<##FORMAT keys>))):
+            # 100 and 2 504 samples a line, header with typed INFO keys and FORMAT GT, file in the page cache -> host DataChunks.
+            # Every sample is a list element with a 16-byte string_t child: the vectors are 4x the text, the leg is the D2H link's
+            from exon_duckdb_amd.testing import shapes
+            res = {}
+            for n_samples, n_lines in ((100, 100000), (2504, 6000)):
+                _, block, _ = shapes.vcf_multisample_block(n_lines, n_samples, seed=n_samples)
+                hdr = shapes.vcf_cohort_header(n_samples)
+                reps = max(1, int(min(args.vcf_gb, 1.0) * 1e9) // len(block))
+                p_c = os.path.join(tmp, f"cohort{n_samples}.vcf")
+                with open(p_c, "wb") as f:
+                    f.write(hdr)
+                    for _ in range(reps):
+                        f.write(block)
+                n_c = len(hdr) + reps * len(block)
+                reader_count(lib, p_c, "vcf")
+                n, dt_c = min((reader_count(lib, p_c, "vcf") for _ in range(3)), key=lambda x: x[1])
+                rows, chunks, dt_a, st_a = timed_reader_chunks(lib, p_c, "vcf")
+                f_rows, _, dt_f, st_f = timed_reader_chunks(lib, p_c, "vcf", columns=1 << 8)
+                p_rows, _, dt_p, st_p = timed_reader_chunks(lib, p_c, "vcf", columns=0b1011)
+                e_rows, e_smp, e_dg = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+                assert tl.exon_tf_expect_vcf_formats_file(p_c.encode(), b"GT", C.byref(e_rows), C.byref(e_smp), C.byref(e_dg)) == 0
+                v_rows, v_smp, v_dg = reader_formats_digest(lib, p_c, key=0)
+                os.unlink(p_c)
+                nested_s = st_a["nested_ns"] * 1e-9
+
+                def leg_of(dt, st):
+                    d2h = st["host_vector_bytes"]
+                    return {"ms": dt * 1e3, "GB/s": n_c / dt / 1e9, "lines_per_s": n_lines * reps / dt, "samples_per_s": n_lines * reps * n_samples / dt,
+                            "d2h_bytes": d2h, "d2h_GB/s": d2h / dt / 1e9, "frac_of_d2h_link": d2h / dt / 1e9 / link[1], "d2h_bound_ms": d2h / link[1] / 1e6}
+                res[f"vcf_multisample_{n_samples}"] = {
+                    "workload": f"read_vcf, {n_c / 1e9:.2f} GB file of lines with {n_samples} samples ({len(block) // n_lines} B each; {n_lines * reps} lines, "
+                                f"{n_lines * reps * n_samples} samples; header: 6 typed INFO keys, FORMAT GT) in the page cache -> host DataChunks, PCIe inclusive",
+                    "algorithmic_bytes": n_c, "count_only_ms": dt_c * 1e3, "count_only_GB/s": n_c / dt_c / 1e9,
+                    "all_columns": leg_of(dt_a, st_a), "formats_only": leg_of(dt_f, st_f), "chrom_pos_ref": leg_of(dt_p, st_p),
+                    "nested": {"ms": nested_s * 1e3, "device_ms_per_GB": nested_s * 1e3 / (n_c / 1e9), "GB/s": n_c / nested_s / 1e9 if nested_s else None,
+                               "frac": n_c / nested_s / 1e9 / HBM_PEAK_GBPS if nested_s else None},
+                    "link_GB/s": {"h2d": link[0], "d2h": link[1]}, "chunks": chunks, "frac": None,
+                    "verification": "an untimed pass walks formats like an operator would (list entries, the struct's GT child of every sample) and folds every "
+                                    "sample's GT into a digest that must equal the one of an independent line / tab / colon split of the file",
+                    "verified": bool(rows == n == f_rows == p_rows == v_rows == int(e_rows.value) == n_lines * reps and v_smp == int(e_smp.value) == rows * n_samples
+                                     and v_dg == int(e_dg.value))}
+            out["end_to_end_vcf_cohort"] = res
 
         def long_reads_file():
             # ---- read_fastq end to end on LONG reads (HiFi-like 15 kb): the first device batch comes back marked by the lean scan
@@ -839,6 +929,7 @@ def run_configs(torch, lib, args):
             out["end_to_end"]["host_pipeline_scaling"] = out.pop("host_pipeline_scaling")
         leg(long_reads_file, "end_to_end_long_reads")
         leg(vcf_file, "end_to_end_vcf")
+        leg(cohort_files, "end_to_end_vcf_cohort")
     finally:
         for f in os.listdir(tmp):
             os.unlink(os.path.join(tmp, f))
@@ -857,6 +948,7 @@ def main():
                     "scan alone (what a reader switches to on long / very short reads); 0 = fused + the gated general-path launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the configs / end_to_end legs")
+    ap.add_argument("--legs", default="", help="only these configs legs (comma separated keys of the line's `configs` object; default: all)")
     ap.add_argument("--no-traffic", action="store_true", help="do not measure roofline.traffic in this run (two rocprofv3 --pmc passes over a child, ~40 s)")
     ap.add_argument("--vcf-gb", type=float, default=5.0)
     ap.add_argument("--e2e-gb", type=float, default=4.0)
@@ -1090,7 +1182,8 @@ def main():
             out["end_to_end_arrow"] = cfg.pop("end_to_end_arrow", None)
             out["configs"] = cfg
             try:
-                out["record_shapes"] = run_record_shapes(torch, lib, args)
+                if not args.legs or "record_shapes" in args.legs.split(","):
+                    out["record_shapes"] = run_record_shapes(torch, lib, args)
             except Exception as e:  # noqa: BLE001
                 out["record_shapes"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:

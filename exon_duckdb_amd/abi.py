@@ -1,9 +1,10 @@
 """ctypes mirror of include/exon_gpu.h (keep in sync with the header; tests check sizes)."""
 import ctypes as C
 
-EXG_ABI_VERSION = 8
+EXG_ABI_VERSION = 9
 EXG_TYPE_VARCHAR, EXG_TYPE_BIGINT, EXG_TYPE_FLOAT, EXG_TYPE_INTEGER, EXG_TYPE_BOOLEAN, EXG_TYPE_LIST, EXG_TYPE_STRUCT = 1, 2, 3, 4, 5, 6, 7
 EXG_VECTOR_SIZE = 2048
+EXG_OPEN_CHUNKS = 1   # exg_open_args.flags
 
 EXG_OK = 0
 EXG_E_INVALID_ARG, EXG_E_NO_DEVICE, EXG_E_HIP, EXG_E_IO = -1, -2, -3, -4
@@ -135,7 +136,7 @@ class QualityListArgs(C.Structure):
 class OpenArgs(C.Structure):
     _fields_ = [("path", C.c_char_p), ("file_format", C.c_char_p), ("compression", C.c_char_p), ("batch_rows", C.c_uint64),
                 ("device", C.c_int), ("device_batch_bytes", C.c_uint64), ("filters", C.c_char_p),
-                ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("columns", C.c_uint64)]
+                ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("columns", C.c_uint64), ("flags", C.c_uint64)]
 
 
 class InflateMember(C.Structure):
@@ -172,7 +173,7 @@ class ReaderStats(C.Structure):
     _fields_ = [("device_bytes_now", C.c_uint64), ("device_bytes_peak", C.c_uint64), ("device_mem_cap", C.c_uint64),
                 ("device_batch_bytes", C.c_uint64), ("device_batches", C.c_uint64), ("decoded_segments", C.c_uint64),
                 ("scan_algo", C.c_uint64), ("input_bytes", C.c_uint64), ("input_compression", C.c_uint64),
-                ("reserved", C.c_uint64 * 1)]
+                ("nested_ns", C.c_uint64), ("host_vector_bytes", C.c_uint64), ("reserved", C.c_uint64 * 3)]
 
 # libexon_tf_test.so (csrc/testing/): test / bench scaffolding — synthetic inputs generated in HBM, consumers that drain a
 # reader's chunks (counting, or folding every row into a digest), host-only introspection, the host-pipeline probe
@@ -182,6 +183,8 @@ TEST_SIGNATURES = {
     "exg_synth_fasta": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]),
     "exon_tf_support_error": (C.c_char_p, []),
     "exon_tf_drain_chunks": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "exon_tf_drain_formats_digest": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "exon_tf_expect_vcf_formats_file": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "exon_tf_drain_arrow_fastq": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                             C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]),
     "exon_tf_drain_digest": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),

@@ -570,6 +570,9 @@ int build_nested(Emit &em, const ScanCtx &ctx, uint64_t B, const bool *want, boo
         o->err = h_ctl[0];
         t_stage3 = since();
         trace_at("N nested kernels done", n);
+        r->nested_ns += (uint64_t)(t_stage3 * 1e6);
+        if (mirror)
+            for (int c = 0; c < 5; c++) r->host_vector_bytes += o->g[c].h ? o->g[c].bytes : 0;
         if (trace) {
             size_t bytes = 0;
             for (int c = 0; c < 5; c++) bytes += o->g[c].h ? o->g[c].bytes : 0;

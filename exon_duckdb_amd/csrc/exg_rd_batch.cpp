@@ -192,7 +192,7 @@ static int open_source(exg_reader *r, std::shared_ptr<PinnedBlock> &blk, const s
     auto make = [&](uint64_t c_begin, uint64_t c_end, bool bgzf_only, const uint64_t *marks) {
         std::unique_ptr<SegmentProducer> prod = r->compression == kGzip ? make_gzip_producer(r, fd, c_begin, c_end, target, path, bgzf_only, reserve, marks)
                                                                         : make_zstd_producer(r, fd, n, c_begin, c_end, target, path, reserve, marks);
-        // (EXG_COLUMNS_CHUNKS: the caller said it will pull chunks — the segments travel to the host from the first one on)
+        // (EXG_OPEN_CHUNKS: the caller said it will pull chunks — the segments travel to the host from the first one on)
         const bool mirror0 = r->expect_chunks && !r->arrow_emit && payload_route(r) == kPayloadMirror;
         return std::unique_ptr<DecodedSource>(new DecodedSource(r->device, r->stream, std::move(prod), reserve, queued, &r->meter, mirror0));
     };
@@ -1164,6 +1164,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
                     src = r->d_gather;
                 }
                 RD_HIP(r, hipMemcpyAsync(b->cols[c], src, k * es, hipMemcpyDeviceToHost, compact && es == 16 && side[c].d_goff ? r->stream : cs));
+                r->host_vector_bytes += k * es;
             }
             auto copy_validity = [&](int col, const void *d) -> int {
                 if (!(b->validity[col] = b->host.alloc(vw))) return fail(r, EXG_E_HIP, "out of pinned host memory");
@@ -1172,6 +1173,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
                     d = r->d_gather;
                 }
                 RD_HIP(r, hipMemcpyAsync(b->validity[col], d, vw, hipMemcpyDeviceToHost, cs));
+                r->host_vector_bytes += vw;
                 return EXG_OK;
             };
             if (r->format == EXG_FMT_VCF) {

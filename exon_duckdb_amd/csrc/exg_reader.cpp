@@ -66,8 +66,8 @@ extern "C" int exg_open(const exg_open_args *args, exg_reader **out) {
     r->halo_want = getenv("EXG_SHARD_HALO") ? std::max<uint64_t>(16, strtoull(getenv("EXG_SHARD_HALO"), nullptr, 10)) : kShardHalo;
     r->device = args->device;
     r->shard_count = args->shard_count ? args->shard_count : 1;
-    r->expect_chunks = (args->columns & EXG_COLUMNS_CHUNKS) != 0;
-    r->want_cols = (args->columns & ~EXG_COLUMNS_CHUNKS) ? (args->columns & ~EXG_COLUMNS_CHUNKS) : ~0ull;
+    r->expect_chunks = (args->flags & EXG_OPEN_CHUNKS) != 0;
+    r->want_cols = args->columns ? args->columns : ~0ull;
     r->shard_index = args->shard_index;
     if (r->shard_index >= r->shard_count) {
         exg::set_error("exg_open: shard_index %u is not below shard_count %u", r->shard_index, r->shard_count);
@@ -382,6 +382,8 @@ extern "C" int exg_reader_stats_of(exg_reader *r, exg_reader_stats *out) {
     out->device_batches = r->n_batches;
     out->decoded_segments = r->n_segments;
     out->scan_algo = r->fan ? 0 : r->fused_algo;
+    out->nested_ns = r->nested_ns.load();
+    out->host_vector_bytes = r->host_vector_bytes.load();
     for (const std::string &f : r->files) {
         struct stat sb;
         if (stat(f.c_str(), &sb) == 0 && S_ISREG(sb.st_mode)) out->input_bytes += (uint64_t)sb.st_size;

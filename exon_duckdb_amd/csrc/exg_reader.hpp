@@ -336,7 +336,7 @@ struct exg_reader {
     uint64_t device_batch_bytes = 256ull << 20;
     uint64_t want_cols = ~0ull;  // exg_open_args.columns: the columns whose vectors are copied back (all are parsed)
     bool want(int c) const { return (want_cols >> c) & 1ull; }
-    bool expect_chunks = false;  // EXG_COLUMNS_CHUNKS: chunks will be pulled (a decoded source mirrors its segments to the host from the first one on)
+    bool expect_chunks = false;  // EXG_OPEN_CHUNKS: chunks will be pulled (a decoded source mirrors its segments to the host from the first one on)
     int device = 0;
     std::string error;
     hipStream_t stream = nullptr;
@@ -432,6 +432,7 @@ struct exg_reader {
     uint64_t mem_cap = 0;        // EXG_DEVICE_MEM_CAP_MB: what the batch / segment sizes are derived from (0: defaults)
     std::atomic<uint64_t> n_segments{0};  // decoded segments consumed so far (read by exg_reader_stats_of from any thread)
     std::atomic<uint64_t> n_batches{0};   // device batches scanned so far
+    std::atomic<uint64_t> nested_ns{0}, host_vector_bytes{0};  // exg_reader_stats (ABI 9)
 
     // current batch
     std::shared_ptr<exg_rd::Batch> batch;

@@ -78,6 +78,7 @@ struct ExonTableFunction {
         std::vector<idx_t> column_ids;
         std::string filter_clause;
         uint64_t columns = 0;  // exg_open_args.columns: the projection as a mask (0 = all)
+        uint64_t open_flags = 0;  // exg_open_args.flags
         bool count_only = false;
         uint32_t n_shards = 1;
         int devices[64];
@@ -97,7 +98,7 @@ struct ExonTableFunction {
     };
     static constexpr unsigned kBatchBits = 24;  // device batches per shard: 2^24 x 256 MiB = 4 PiB
 
-    static exg_reader *OpenReader(const BindData &d, const std::string &filter_clause, uint64_t columns, uint32_t shard, uint32_t n_shards, int device) {
+    static exg_reader *OpenReader(const BindData &d, const std::string &filter_clause, uint64_t columns, uint64_t flags, uint32_t shard, uint32_t n_shards, int device) {
         exg_open_args a;
         memset(&a, 0, sizeof a);
         a.filters = filter_clause.empty() ? nullptr : filter_clause.c_str();                // module.cpp:239-243
@@ -109,6 +110,7 @@ struct ExonTableFunction {
         a.shard_count = n_shards;
         a.device = device;
         a.columns = columns;  // projection_pushdown (module.cpp:310): only these columns' vectors cross PCIe
+        a.flags = flags;
         exg_reader *r = nullptr;
         if (exg_open(&a, &r) != EXG_OK) throw std::runtime_error(exg_last_error_message());  // module.cpp:105-108
         return r;
@@ -121,7 +123,7 @@ struct ExonTableFunction {
         result->file_name = file_name;
         result->compression = compression.empty() ? "auto_detect" : compression;
         result->file_type = file_type;
-        exg_reader *r = OpenReader(*result, "", 0, 0, 1, 0);
+        exg_reader *r = OpenReader(*result, "", 0, 0, 0, 1, 0);
         exg_schema sch;
         const int rc = exg_schema_of(r, &sch);
         if (rc == EXG_OK)
@@ -185,8 +187,8 @@ struct ExonTableFunction {
             if (c != D::RowId && c < 63) gs->columns |= (uint64_t)1 << c;
         }
         // the scan is going to pull chunks (anything but COUNT(*)): a compressed input's decoded segments travel to the host from
-        // the first one on, beside the decoder (include/exon_gpu.h: EXG_COLUMNS_CHUNKS)
-        if (!gs->count_only) gs->columns |= EXG_COLUMNS_CHUNKS;
+        // the first one on, beside the decoder (include/exon_gpu.h: EXG_OPEN_CHUNKS)
+        if (!gs->count_only) gs->open_flags |= EXG_OPEN_CHUNKS;
         if (filters) gs->filter_clause = FilterToString(*filters, column_ids, data.all_names);  // module.cpp:222-226
         exg_open_args a;
         memset(&a, 0, sizeof a);
@@ -217,7 +219,7 @@ struct ExonTableFunction {
         ls.shard = shard;
         ls.batch_no = 0;
         ls.counted = false;
-        ls.reader = OpenReader(data, gs.filter_clause, gs.columns, shard, gs.n_shards, gs.devices[shard]);
+        ls.reader = OpenReader(data, gs.filter_clause, gs.columns, gs.open_flags, shard, gs.n_shards, gs.devices[shard]);
         return true;
     }
 

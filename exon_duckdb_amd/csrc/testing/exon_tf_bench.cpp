@@ -288,6 +288,110 @@ extern "C" int exon_tf_drain_digest(exg_reader *r, int kind, uint32_t want_seq_l
     return exon_tf_drain_digest_from(r, kind, want_seq_len, 0, n_rows, n_chunks, digest, bad);
 }
 
+// read_vcf's `formats` column — LIST(STRUCT(<##FORMAT keys>)) — walked like a DuckDB operator would: every row's list entry,
+// every sample's value of the struct's child `key` (a VARCHAR key: GT) folded into a digest; *samples = list elements in all.
+extern "C" int exon_tf_drain_formats_digest(exg_reader *r, int key, uint64_t *n_rows, uint64_t *n_samples, uint64_t *digest) {
+    if (!r || !n_rows || !n_samples || !digest) return EXG_E_INVALID_ARG;
+    *n_rows = *n_samples = *digest = 0;
+    uint64_t k = 0, acc = 0, ns = 0;
+    for (;;) {
+        exg_chunk c;
+        const int rc = exg_next_chunk(r, &c);
+        if (rc) return rc;
+        if (c.n_rows == 0) break;
+        const exg_vector *fl = c.vectors[8];
+        if (!fl || fl->n_children != 1 || fl->children[0].n_children <= key) {
+            exg_release_chunk(r, &c);
+            return EXG_E_INVALID_ARG;
+        }
+        const exg_list_entry_t *ent = (const exg_list_entry_t *)fl->data;
+        const exg_vector &item = fl->children[0];
+        const exg_vector &gt = item.children[key];
+        const exg_string_t *str = (const exg_string_t *)gt.data;
+        for (uint64_t i = 0; i < c.n_rows; i++) {
+            uint64_t h = mix64(k + i);
+            if (ent[i].offset + ent[i].length > item.length) h ^= 0xBAD0FF5E7ull;  // an entry outside the chunk's child vector
+            else
+                for (uint64_t e = ent[i].offset; e < ent[i].offset + ent[i].length; e++) h = fold_string_t(h, str[e], bit(gt.validity, e));
+            ns += ent[i].length;
+            acc += mix64(h);
+        }
+        k += c.n_rows;
+        exg_release_chunk(r, &c);
+    }
+    *n_rows = k;
+    *n_samples = ns;
+    *digest = acc;
+    return EXG_OK;
+}
+// ... and what that digest must be, by a split of the file of its own: lines at '\n', fields at '\t', the FORMAT field at ':' to find
+// where `key_name` stands, every sample at ':'; "." is NULL.
+extern "C" int exon_tf_expect_vcf_formats_file(const char *path, const char *key_name, uint64_t *rows, uint64_t *samples, uint64_t *digest) {
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return -1;
+    struct stat st;
+    fstat(fd, &st);
+    const size_t n = (size_t)st.st_size;
+    const uint8_t *d = n ? (const uint8_t *)mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
+    close(fd);
+    if (n && d == MAP_FAILED) return -1;
+    const size_t kn = strlen(key_name);
+    uint64_t k = 0, acc = 0, ns = 0;
+    for (size_t pos = 0; pos < n;) {
+        const uint8_t *nl = (const uint8_t *)memchr(d + pos, '\n', n - pos);
+        size_t end = nl ? (size_t)(nl - d) : n;
+        const size_t next = nl ? end + 1 : n;
+        if (end > pos && d[end - 1] == '\r') end--;
+        if (end > pos && d[pos] != '#') {
+            uint64_t h = mix64(k);
+            size_t q = pos;
+            int field = 0, key_pos = -1;
+            while (q <= end) {
+                const uint8_t *tab = (const uint8_t *)memchr(d + q, '\t', end - q);
+                const size_t fe = tab ? (size_t)(tab - d) : end;
+                if (field == 8) {  // FORMAT
+                    int p = 0;
+                    for (size_t a = q; a <= fe;) {
+                        const uint8_t *col = (const uint8_t *)memchr(d + a, ':', fe - a);
+                        const size_t ke = col ? (size_t)(col - d) : fe;
+                        if (key_pos < 0 && ke - a == kn && memcmp(d + a, key_name, kn) == 0) key_pos = p;
+                        p++;
+                        a = ke + 1;
+                    }
+                } else if (field > 8) {
+                    int p = 0;
+                    bool found = false;
+                    for (size_t a = q; a <= fe;) {
+                        const uint8_t *col = (const uint8_t *)memchr(d + a, ':', fe - a);
+                        const size_t ve = col ? (size_t)(col - d) : fe;
+                        if (p == key_pos) {
+                            const bool null = ve - a == 1 && d[a] == '.';
+                            h = null ? fold_bytes(h ^ 0xDEADull, nullptr, 0) : fold_bytes(h, d + a, ve - a);
+                            found = true;
+                            break;
+                        }
+                        p++;
+                        a = ve + 1;
+                    }
+                    if (!found) h = fold_bytes(h ^ 0xDEADull, nullptr, 0);
+                    ns++;
+                }
+                field++;
+                if (!tab) break;
+                q = fe + 1;
+            }
+            acc += mix64(h);
+            k++;
+        }
+        pos = next;
+    }
+    if (d) munmap((void *)d, n);
+    *rows = k;
+    *samples = ns;
+    *digest = acc;
+    return 0;
+}
+
 // ---- the reference's own boundary: new_reader -> Arrow C stream (exon/include/rust.hpp:41-46) ----------------------------------
 // Pulls every record batch of a FASTQ stream through the Arrow callbacks and releases it — what DuckDB's ArrowToDuckDB consumer
 // of the reference does per batch, minus the conversion.  with_digest: every row's four Utf8 values (int32 offsets + value bytes

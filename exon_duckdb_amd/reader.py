@@ -11,7 +11,7 @@ class ShardReader:
     def __init__(self, path, file_format, shard_index=0, shard_count=1, compression=None, device=0, device_batch_bytes=0,
                  filters=None, batch_rows=2048, columns=None, expect_chunks=False):
         """columns: indices (exg_schema_of order) of the columns to copy back; None = all (exg_open_args.columns);
-        expect_chunks: EXG_COLUMNS_CHUNKS — chunks will be pulled (a compressed input mirrors its decoded segments from the first on)"""
+        expect_chunks: exg_open_args.flags = EXG_OPEN_CHUNKS — chunks will be pulled (a compressed input mirrors its decoded segments from the first on)"""
         self._l = load_library()
         self._l.exg_open.argtypes = [C.POINTER(abi.OpenArgs), C.POINTER(C.c_void_p)]
         self._l.exg_next_chunk.argtypes = [C.c_void_p, C.POINTER(Chunk)]
@@ -23,7 +23,7 @@ class ShardReader:
         self._l.exg_close.argtypes = [C.c_void_p]
         a = abi.OpenArgs(path.encode(), file_format.encode(), compression.encode() if compression else None, batch_rows, device,
                          device_batch_bytes, filters.encode() if filters else None, shard_index, shard_count,
-                         (sum(1 << int(c) for c in columns) if columns is not None else 0) | ((1 << 63) if expect_chunks else 0))
+                         sum(1 << int(c) for c in columns) if columns is not None else 0, abi.EXG_OPEN_CHUNKS if expect_chunks else 0)
         self.columns = None if columns is None else sorted(int(c) for c in columns)
         self._r = C.c_void_p()
         rc = self._l.exg_open(C.byref(a), C.byref(self._r))

@@ -113,6 +113,18 @@ def fastq_long_block(lengths, seed=7):
     return b"".join(out), {c: (np.asarray(o, np.int64), np.asarray(n, np.int64)) for c, (o, n) in cols.items()}
 
 
+def vcf_cohort_header(n_samples):
+    """the header vcf_multisample_block's lines need for the reference's real schema: its INFO keys typed (AC / AF per-allele lists,
+    like 1000 Genomes declares them) and FORMAT GT, so that `info` is a STRUCT of six children and `formats` a LIST(STRUCT(GT VARCHAR))"""
+    smp = b"\t".join(b"S%05d" % i for i in range(n_samples))
+    return (b"##fileformat=VCFv4.2\n"
+            b'##INFO=<ID=AC,Number=A,Type=Integer,Description="Allele count">\n##INFO=<ID=AF,Number=A,Type=Float,Description="Allele frequency">\n'
+            b'##INFO=<ID=AN,Number=1,Type=Integer,Description="Alleles">\n##INFO=<ID=NS,Number=1,Type=Integer,Description="Samples">\n'
+            b'##INFO=<ID=DP,Number=1,Type=Integer,Description="Depth">\n##INFO=<ID=VT,Number=.,Type=String,Description="Variant type">\n'
+            b'##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">\n'
+            b"#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + smp + b"\n")
+
+
 def vcf_multisample_block(n_lines, n_samples, seed=7):
     """-> (header bytes, data-line bytes, expect): 1000-Genomes-like lines, GT per sample ("0|0\\t" ...), vectorised genotypes.
     expect: line starts, CHROM values, POS, QUAL validity, and where each line's FORMAT + samples remainder lies"""

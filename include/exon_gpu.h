@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define EXG_ABI_VERSION 8
+#define EXG_ABI_VERSION 9
 
 /* DuckDB v0.8.1 STANDARD_VECTOR_SIZE; the reference asks the Rust side for
  * batches of exactly this many rows (module.cpp:83, :233). */
@@ -396,14 +396,15 @@ typedef struct exg_open_args {
                               * the device — a malformed INFO value is an error whether the column is selected or not, like in
                               * the reference, which parses everything and projects afterwards — but only the wanted ones are
                               * copied back: exg_chunk.vectors[c] of the others is NULL.  read_vcf's nested columns are
-                              * two thirds of its bytes over PCIe.
-                              * Bit 63 (EXG_COLUMNS_CHUNKS, ABI 8) is a hint, not a column: the caller is going to pull chunks
-                              * (exg_next_chunk), not exg_count_only — what a table function knows at init_global (column_ids
-                              * != {ROW_ID}).  A compressed input's decoded segments then travel to the host from the FIRST one
-                              * on, beside the decoder; without the hint that begins with the first exg_next_chunk call, and
-                              * the segments decoded before it (one or two, up to 1 GiB each for zstd) are copied behind their scan. */
+                              * two thirds of its bytes over PCIe.  Every bit is a column: ~0 = all, like 0. */
+    uint64_t flags;          /* ABI 9 (a word of its own: ABI 8 kept this hint in bit 63 of `columns`, where columns = ~0 for "all"
+                              * set it by accident).  EXG_OPEN_CHUNKS: the caller is going to pull chunks (exg_next_chunk), not
+                              * exg_count_only — what a table function knows at init_global (column_ids != {ROW_ID}).  A compressed
+                              * input's decoded segments then travel to the host from the FIRST one on, beside the decoder; without
+                              * the hint that begins with the first exg_next_chunk call, and the segments decoded before it (one or
+                              * two, up to 1 GiB each for zstd) are copied behind their scan. */
 } exg_open_args;
-#define EXG_COLUMNS_CHUNKS (1ull << 63)
+#define EXG_OPEN_CHUNKS 1ull
 
 #define EXG_TYPE_VARCHAR 1
 #define EXG_TYPE_BIGINT 2
@@ -487,7 +488,12 @@ typedef struct exg_reader_stats {
     uint64_t input_bytes;        /* ABI 8: size of the reader's input files on disk (all files of a directory; a shard: the whole
                                   * files), what TableFunction::cardinality estimates rows from (module.cpp:307) */
     uint64_t input_compression;  /* ABI 8: 0 plain text, 1 gzip / BGZF, 2 zstd (input_bytes are compressed bytes then) */
-    uint64_t reserved[1];
+    uint64_t nested_ns;          /* ABI 9: read_vcf — wall time the reader's thread spent making the nested columns (id / alt / filter /
+                                  * info / formats) of its batches on the device, counting passes, prefix sums and children, up to the
+                                  * point where their vectors start for the host (exg_vcf_nested.hpp) */
+    uint64_t host_vector_bytes;  /* ABI 9: bytes of column vectors (flat and nested, validity included) sent to the host so far —
+                                  * what a scan INTO DataChunks pays on the D2H link next to a decoded input's own bytes */
+    uint64_t reserved[3];
 } exg_reader_stats;
 int exg_reader_stats_of(exg_reader *r, exg_reader_stats *out);
 /* Device buffers, pinned host blocks and HIP streams of closed readers are recycled process-wide (size classes, at most

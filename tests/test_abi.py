@@ -34,7 +34,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     missing = [f for f in declared_functions() if not hasattr(lib, f)]
     assert not missing, f"declared in include/exon_gpu.h but not exported: {missing}"
     from exon_duckdb_amd import abi
-    assert lib.exg_abi_version() == abi.EXG_ABI_VERSION == 8
+    assert lib.exg_abi_version() == abi.EXG_ABI_VERSION == 9
     lib.exg_parse_error_string.restype = C.c_char_p
     assert lib.exg_parse_error_string(1) == b"invalid name prefix"
 

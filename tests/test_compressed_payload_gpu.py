@@ -56,7 +56,7 @@ def test_all_columns_of_a_compressed_fastq_through_the_host_mirror(gpu, ragged, 
     got = _rows(p, "fastq")
     assert len(got) == len(want)
     assert got == want
-    # with the caller's word that chunks will be pulled (EXG_COLUMNS_CHUNKS: every segment has a mirror, the first one too)
+    # with the caller's word that chunks will be pulled (EXG_OPEN_CHUNKS: every segment has a mirror, the first one too)
     assert _rows(p, "fastq", expect_chunks=True) == want
     # ... and without the mirror (the copy behind the scan): the same rows
     monkeypatch.setenv("EXG_NO_HOST_MIRROR", "1")
