@@ -11,7 +11,7 @@
 namespace exg_rd {
 namespace {
 
-constexpr int kSlots = 256;  // mappings alive at once (a reader holds one per open text file + the chunks still out)
+constexpr int kSlots = 4096;  // mappings alive at once (a reader holds one per open text file + the chunks still out); full: add() = -1 and the reader refuses the file
 struct Slot {
     std::atomic<uintptr_t> base{0};  // 0 = free; 1 = being filled
     std::atomic<size_t> len{0};
@@ -38,11 +38,14 @@ void on_sigbus(int sig, siginfo_t *si, void *uctx) {
         return;  // the faulting access restarts
     }
     // not ours: whoever was there before
-    if (g_prev.sa_flags & SA_SIGINFO) {
-        if (g_prev.sa_sigaction) {
-            g_prev.sa_sigaction(sig, si, uctx);
-            return;
-        }
+    // (sa_handler and sa_sigaction share their storage: a disposition of SIG_IGN / SIG_DFL is one whatever SA_SIGINFO says)
+    if (g_prev.sa_handler == SIG_IGN) {
+        return;
+    } else if (g_prev.sa_handler == SIG_DFL || g_prev.sa_handler == nullptr) {
+        // (falls through to the default action below)
+    } else if (g_prev.sa_flags & SA_SIGINFO) {
+        g_prev.sa_sigaction(sig, si, uctx);
+        return;
     } else if (g_prev.sa_handler == SIG_IGN) {
         return;
     } else if (g_prev.sa_handler != SIG_DFL && g_prev.sa_handler != nullptr) {

@@ -21,7 +21,8 @@
 namespace exg_rd {
 
 struct MapGuard {
-    // registers [base, base + len) -> slot (>= 0), or -1 when the table is full (the mapping is then simply not guarded)
+    // registers [base, base + len) -> slot (>= 0), or -1 when the table (4096 mappings) is full: the caller refuses the file
+    // (EXG_E_NOMEM) rather than read it unguarded
     static int add(const void *base, size_t len);
     // forgets the slot (call BEFORE munmap)
     static void remove(int slot);

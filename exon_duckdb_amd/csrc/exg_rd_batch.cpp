@@ -376,6 +376,11 @@ int open_next_file(exg_reader *r) {
         // (another process may truncate the file while its rows are out: zeros + EXG_E_IO at the next call, not a SIGBUS that
         // ends the DuckDB process — exg_map_guard.hpp)
         blk->guard = MapGuard::add(m, blk->n);
+        if (blk->guard < 0) {  // (the table holds 4096 mappings: chunks of thousands of files are still out)
+            blk.reset();       // (unmaps)
+            close(fd);
+            return fail(r, EXG_E_NOMEM, "too many text files mapped at once (4096): release chunks or close readers before opening '" + p + "'");
+        }
     } else {
         hipError_t he = hipHostMalloc(&blk->p, 64, hipHostMallocDefault);
         if (he != hipSuccess) {
@@ -421,6 +426,8 @@ int open_next_file(exg_reader *r) {
     r->range_hi = r->src ? ~0ull : blk->n;  // (a decoded stream ends where its source says so)
     r->shard_first = false;
     r->data_base = r->file_pos;  // 0, or the end of the VCF header
+    static const bool no_ramp = getenv("EXG_NO_RAMP") != nullptr;
+    r->ramp_bytes = (!r->src && r->format != EXG_FMT_FASTA && !no_ramp && r->device_batch_bytes > kRampFirstBytes) ? kRampFirstBytes : 0;
     if (r->fa_shard) {
         // a shard of a compressed FASTA: the run of whole records from the first '>' line that begins in its own bytes to the
         // first that begins behind them (found while scanning: next_batch), like a text shard's run
@@ -589,6 +596,8 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             return EXG_OK;
         }
         uint64_t n = std::min<uint64_t>(want, remaining);
+        // (the head of a text file: a small batch first — exg_reader.hpp ramp_bytes; the uploads behind it are sized where they are issued)
+        if (r->ramp_bytes && !r->src && !r->pf.valid && want == r->device_batch_bytes) n = std::min<uint64_t>(n, r->next_ramp());
         bool range_end = n == remaining;                    // the batch reaches the end of this reader's bytes ...
         bool eof = range_end && r->range_eof;               // ... which is the end of the file unless a later shard follows
         // first batch of a shard that begins inside the file: up to 1 MiB in front of it travels along (`lead`), so that
@@ -673,7 +682,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             if (end1 < r->range_hi) {
                 const uint64_t slack = std::min<uint64_t>(kPrefetchSlack, (end1 - r->file_pos) / 2);
                 const uint64_t start = (end1 - slack) & ~15ull;
-                const uint64_t len = std::min<uint64_t>(r->range_hi - start, r->device_batch_bytes + slack);
+                const uint64_t len = std::min<uint64_t>(r->range_hi - start, r->next_ramp() + slack);
                 if (len + 16 <= r->d_in_cap) start_upload(r, &r->pf2, start, len, r->pf.slot ^ 1);
             }
         }
@@ -997,18 +1006,22 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             const bool can = !range_end && !res.error_code && !r->src && r->format != EXG_FMT_FASTA && want == r->device_batch_bytes && !no_prefetch;
             const uint64_t slack = std::min<uint64_t>(kPrefetchSlack, (batch_end - r->file_pos) / 2);
             const uint64_t start = (batch_end - slack) & ~15ull;
-            const uint64_t len = std::min<uint64_t>(r->range_hi - start, r->device_batch_bytes + slack);
             const int other = r->cur_slot ^ 1;
             if (r->pf2.valid) {
-                if (can && r->pf2.file_start == start && r->pf2.len == len && r->pf2.slot == other) {
+                // (its length was chosen where it was issued: a step of the ramp, or a full batch)
+                if (can && r->pf2.file_start == start && r->pf2.len > 0 && r->pf2.slot == other) {
                     r->pf = r->pf2;
                     r->pf2.valid = false;
                 } else {
                     r->drop_prefetch2();  // (the batch turned out otherwise: an error, a retry, the end of the range)
                 }
             }
-            if (can && !r->pf.valid && len + 16 <= r->d_in_cap && r->d_in_slot[other] && !r->up_thread_of[other].joinable())
-                start_upload(r, &r->pf, start, len, other);
+            if (can && !r->pf.valid && r->d_in_slot[other] && !r->up_thread_of[other].joinable()) {
+                const uint64_t ramp_before = r->ramp_bytes;
+                const uint64_t len = std::min<uint64_t>(r->range_hi - start, r->next_ramp() + slack);
+                if (len + 16 <= r->d_in_cap) start_upload(r, &r->pf, start, len, other);
+                else r->ramp_bytes = ramp_before;
+            }
         }
         TRACE("prefetch issue", t_pf);
         uint64_t k = res.n_records;

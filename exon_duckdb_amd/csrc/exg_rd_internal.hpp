@@ -106,6 +106,7 @@ static constexpr uint64_t kShardHalo = 1u << 20;
 // prefetch starts this many bytes before the end of the current batch; a batch whose unconsumed tail is
 // longer (one giant record) falls back to the synchronous upload.
 static constexpr uint64_t kPrefetchSlack = 1u << 20;
+static constexpr uint64_t kRampFirstBytes = 32u << 20;  // the first device batch of a text file (exg_reader.hpp: ramp_bytes)
 static constexpr size_t kUploadWindow = 256u << 20;
 
 // ---- exg_rd_io.cpp

@@ -169,6 +169,7 @@ int exg_reader::finish_source() {
 }
 exg_reader::exg_reader() {}
 exg_reader::~exg_reader() {
+    join_ahead();
     exg_rd::DeviceGuard guard(device);
     exg_rd::MeterScope meter_scope(&meter);
     fan.reset();  // (its workers close their readers)

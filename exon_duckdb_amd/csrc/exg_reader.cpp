@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "exg_filter.hpp"
+#include "exg_map_guard.hpp"
 #include "exg_rd_fanout.hpp"
 #include "exg_rd_source.hpp"
 
@@ -213,6 +214,7 @@ static void flat_schema(const exg_reader *r, exg_schema *out) {
 
 extern "C" int exg_schema_of(exg_reader *r, exg_schema *out) {
     if (!r || !out) return EXG_E_INVALID_ARG;
+    r->join_ahead();
     flat_schema(r, out);
     if (r->format == EXG_FMT_VCF) {
         DeviceGuard guard(r->device);
@@ -261,34 +263,51 @@ static void slice_vector(const NVec &v, uint64_t e0, uint64_t e1, uint64_t chunk
     out->children = kids;
 }
 
+// the batch behind `cur` on a thread of the reader's own (exg_reader.hpp: ahead)
+static void start_ahead(exg_reader *r) {
+    r->ahead_done = false;
+    r->ahead = std::thread([r] {
+        DeviceGuard guard(r->device);
+        MeterScope meter_scope(&r->meter);
+        r->ahead_end = false;
+        r->ahead_rc = advance_batch(r, &r->ahead_end);
+        r->ahead_done = true;
+    });
+}
+
 extern "C" int exg_next_chunk(exg_reader *r, exg_chunk *out) {
     if (!r || !out) return EXG_E_INVALID_ARG;
     DeviceGuard guard(r->device);
     MeterScope meter_scope(&r->meter);
     memset(out, 0, sizeof *out);
+    static const bool no_ahead = getenv("EXG_NO_RUN_AHEAD") != nullptr;
     for (;;) {
-        if (int trc = truncated_while_read(r)) return trc;
-        if (r->batch && r->batch_row < r->batch->n_rows) {
-            uint64_t row0 = r->batch_row;
-            uint64_t n = std::min<uint64_t>(r->batch_rows, r->batch->n_rows - row0);
+        if (r->cur && r->cur_row < r->cur->n_rows) {
+            // A text file that shrank under the query (exg_map_guard.hpp): asked of the mapping THIS batch's strings point into —
+            // the reader's current file may be another one by now, and a fan-out's front has none of its own
+            if (r->cur->file && r->cur->file->guard >= 0 && MapGuard::hit(r->cur->file->guard))
+                return fail(r, EXG_E_IO, "an input file was truncated while it was being read");
+            const Batch &bt = *r->cur;
+            uint64_t row0 = r->cur_row;
+            uint64_t n = std::min<uint64_t>(r->batch_rows, bt.n_rows - row0);
             out->n_rows = n;
-            out->n_columns = r->batch->n_cols;
+            out->n_columns = bt.n_cols;
             ChunkKeep *keep = new ChunkKeep();
-            keep->batch = r->batch;
+            keep->batch = r->cur;
             const uint64_t chunk = row0 / r->batch_rows;
-            for (int c = 0; c < r->batch->n_cols; c++) {
+            for (int c = 0; c < bt.n_cols; c++) {
                 exg_vector &v = keep->top[c];
-                if ((size_t)c < r->batch->nested.size() && r->batch->nested[c].type) {
-                    slice_vector(r->batch->nested[c], row0, row0 + n, chunk, keep, &v);
-                } else if (!r->batch->cols[c]) {  // not in the projection (exg_open_args.columns)
+                if ((size_t)c < bt.nested.size() && bt.nested[c].type) {
+                    slice_vector(bt.nested[c], row0, row0 + n, chunk, keep, &v);
+                } else if (!bt.cols[c]) {  // not in the projection (exg_open_args.columns)
                     out->data[c] = nullptr;
                     out->validity[c] = nullptr;
                     out->vectors[c] = nullptr;
                     continue;
                 } else {
                     memset(&v, 0, sizeof v);
-                    v.data = (char *)r->batch->cols[c] + row0 * r->batch->elem[c];
-                    v.validity = r->batch->validity[c] ? (uint64_t *)r->batch->validity[c] + row0 / 64 : nullptr;
+                    v.data = (char *)bt.cols[c] + row0 * bt.elem[c];
+                    v.validity = bt.validity[c] ? (uint64_t *)bt.validity[c] + row0 / 64 : nullptr;
                     v.length = n;
                 }
                 out->data[c] = v.data;
@@ -296,29 +315,41 @@ extern "C" int exg_next_chunk(exg_reader *r, exg_chunk *out) {
                 out->vectors[c] = &v;
             }
             out->keepalive = keep;
-            out->batch_no = r->batch->seq;
-            r->batch_row += n;
+            out->batch_no = bt.seq;
+            r->cur_row += n;
+            // the first chunk of a batch leaves: the batch behind it starts being made
+            if (row0 == 0 && !no_ahead && !r->fan && !r->ahead.joinable() && !r->ahead_done) start_ahead(r);
             return EXG_OK;
         }
+        r->cur.reset();
         if (r->fan) {
             // the batches of the stripes' readers, in file order
             FanItem item;
             std::string msg;
             const int rc = r->fan->next(&item, &msg);
             if (rc) return fail(r, rc, msg);
-            if (!item.batch) {
-                r->batch.reset();
-                return EXG_OK;  // n_rows == 0: end of stream
-            }
-            r->batch = std::static_pointer_cast<Batch>(item.batch);
-            r->batch->seq = r->batch_seq++;
-            r->batch_row = 0;
+            if (!item.batch) return EXG_OK;  // n_rows == 0: end of stream
+            r->cur = std::static_pointer_cast<Batch>(item.batch);
+            r->cur->seq = r->batch_seq++;
+            r->cur_row = 0;
             continue;
         }
         bool end = false;
-        const int rc = advance_batch(r, &end);
+        int rc;
+        r->join_ahead();
+        if (r->ahead_done) {
+            r->ahead_done = false;
+            rc = r->ahead_rc;
+            end = r->ahead_end;
+            if (rc) exg::set_error("%s", r->error.c_str());  // (the message was set on the other thread)
+        } else {
+            rc = advance_batch(r, &end);
+        }
         if (rc) return rc;
         if (end) return EXG_OK;  // n_rows == 0: end of stream
+        r->cur = std::move(r->batch);
+        r->batch.reset();
+        r->cur_row = 0;
     }
 }
 
@@ -333,6 +364,9 @@ extern "C" int exg_count_only(exg_reader *r, uint64_t *n_rows) {
     if (!r || !n_rows) return EXG_E_INVALID_ARG;
     DeviceGuard guard(r->device);
     MeterScope meter_scope(&r->meter);
+    r->join_ahead();  // (chunks were pulled before: the batch that was being made behind them is dropped with the rest of them)
+    r->ahead_done = false;
+    r->cur.reset();
     if (r->fan) {
         std::string msg;
         const int rc = r->fan->count(n_rows, &msg);

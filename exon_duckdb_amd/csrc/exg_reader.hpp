@@ -368,6 +368,17 @@ struct exg_reader {
     // own upload is known to cover it (the slot of the batch before is free by then), so that the link never waits for a scan
     Prefetch pf2;
     void drop_prefetch2();  // join + let it land + forget
+    // The first batches of a text file are small and double (round 6): 32 MiB, 64, 128, ... up to device_batch_bytes.  The first
+    // upload has nothing to hide behind — a full 256 MiB batch kept the scan, and the link back to the host, idle for ~6 ms at
+    // the head of every query; behind a 32 MiB batch the first DataChunk leaves after ~1.5 ms and every later upload travels
+    // beside the vectors of the batch in front.  0: not ramping (the batches are device_batch_bytes).
+    uint64_t ramp_bytes = 0;
+    uint64_t next_ramp() {  // the size of the next upload, and one step up the ramp
+        if (!ramp_bytes) return device_batch_bytes;
+        const uint64_t n = std::min<uint64_t>(ramp_bytes, device_batch_bytes);
+        ramp_bytes = n >= device_batch_bytes ? 0 : n * 2;
+        return n;
+    }
     int cur_slot = 0;
     size_t host_hint = 0;  // pinned bytes the previous batch's host vectors needed
     std::vector<std::pair<void **, size_t>> dev_allocs;  // pooled device buffers of this reader (slot, bytes)
@@ -449,6 +460,19 @@ struct exg_reader {
 
     void free_device();
     exg_reader();  // (out of line: `src` is a pointer to a type this header only declares)
+    // The chunk boundary runs one device batch AHEAD of its consumer (round 6): `cur` is the batch whose chunks are being handed
+    // out; when its first chunk leaves, a thread of the reader's own starts making the batch behind it (advance_batch -> `batch`) —
+    // upload wait, scan, nested columns, the vectors' way back — while the consumer (DuckDB's operators) works through cur's
+    // chunks.  cur is whole on the host by then and the device buffers are the next scan's.  One thread at a time; every other
+    // entry point joins it first (join_ahead).
+    std::shared_ptr<exg_rd::Batch> cur;
+    uint64_t cur_row = 0;
+    std::thread ahead;
+    int ahead_rc = 0;
+    bool ahead_end = false, ahead_done = false;
+    void join_ahead() {
+        if (ahead.joinable()) ahead.join();
+    }
     ~exg_reader();
 };
 

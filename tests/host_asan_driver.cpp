@@ -434,10 +434,10 @@ int main(int argc, char **argv) {
         munmap(m, n);
         // slots are reused, and a full table refuses (-1) instead of overwriting
         std::vector<int> slots;
-        for (int i = 0; i < 300; i++) slots.push_back(exg_rd::MapGuard::add(fill.data(), 16));
+        for (int i = 0; i < 4200; i++) slots.push_back(exg_rd::MapGuard::add(fill.data(), 16));
         int ok = 0;
         for (int sl : slots) ok += sl >= 0;
-        if (ok != 256) return 12;
+        if (ok != 4096) return 12;
         for (int sl : slots) exg_rd::MapGuard::remove(sl);
         if (exg_rd::MapGuard::add(fill.data(), 16) < 0) return 12;
         close(fd);
