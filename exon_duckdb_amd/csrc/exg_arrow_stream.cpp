@@ -141,6 +141,7 @@ struct StreamState {
         NestedKeys() { memset(&tab, 0, sizeof tab); }
     } nk_info, nk_format;
     size_t side_cap = 64u << 10;  // bytes of percent-decoded String values a batch may hold (grows when a batch needs more)
+    bool small_rows = false;      // k_rows' row size: the batch before had (nearly) no INFO field of 65 - 128 bytes (exg_vcf_nested.hip)
     DevArena arena;
     std::shared_ptr<ABatch> batch;
     uint64_t batch_row = 0;
@@ -429,12 +430,17 @@ int build_nested(Emit &em, const ScanCtx &ctx, uint64_t B, const bool *want, boo
     EM_HIP(hipMemsetAsync((char *)d_ctl + 8, 0, 16, s));
     if (!rows_info && nil) EM_HIP(hipMemsetAsync(d_cnt + (uint64_t)vn::kColInfo0 * n, 0, (size_t)nil * n * 4, s));  // (k_info_wide writes the keys a row has)
     // ---- stage 1: elements per row of every list column over rows
-    vn::rows_count(b, it, s);
-    vn::info_wide_count(b, it, rpg, d_seen, s);
+    b.mid_rows = (unsigned long long *)(d_tot + C + nfl);
+    EM_HIP(hipMemsetAsync(b.mid_rows, 0, 8, s));
+    vn::rows_count(b, it, st->small_rows, s);
+    vn::info_wide_count(b, it, rpg, d_seen, st->small_rows, s);
     vn::samples_count(b, rpg, s);
     vn::scan_counts(d_cnt, n, C, n, d_goff, n + 1, d_tot, d_tmp, s);
-    EM_HIP(hipMemcpyAsync(h_tot, d_tot, C * 8, hipMemcpyDeviceToHost, s));
+    EM_HIP(hipMemcpyAsync(h_tot, d_tot, (C + nfl + 1) * 8, hipMemcpyDeviceToHost, s));
     EM_HIP(hipStreamSynchronize(s));
+    // the writing pass's row size: small when at most one INFO field in 64 would be pushed to the wave kernel by it
+    const bool small_rows = rows_info && h_tot[C + nfl] * 64 <= n;
+    st->small_rows = small_rows;
     const uint64_t S = h_tot[vn::kColSamples];
     o->S = S;
     o->d_goff = d_goff;
@@ -535,8 +541,8 @@ int build_nested(Emit &em, const ScanCtx &ctx, uint64_t B, const bool *want, boo
         b.side_cap = side_cap;
         // (Arrow: the decoded strings become Utf8 values through the text's own (device base, payload base) pair)
         o->side_payload_base = b.side_payload_base = mirror ? (uint64_t)(uintptr_t)h_side : pb + (uint64_t)((const uint8_t *)d_side - d_base);
-        vn::rows_write(b, it, d_ko, s);
-        vn::info_wide_write(b, it, d_ko, rpg, d_seen, s);
+        vn::rows_write(b, it, d_ko, small_rows, s);
+        vn::info_wide_write(b, it, d_ko, rpg, d_seen, small_rows, s);
         vn::samples_write(b, sm, ft, d_ko + ik.size(), rpg, s);
         vn::fix_slow_floats(d_ctl, s);
         // DuckDB's list_entry_t of every list column + where every DataChunk's children begin

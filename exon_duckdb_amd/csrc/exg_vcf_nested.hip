@@ -243,12 +243,23 @@ __device__ __forceinline__ int lookup(const KeyTab &kt, uint32_t h, const Txt &t
 // ---- k_rows: thread = row -----------------------------------------------------------------------------------------------
 static constexpr int kKA = 32;            // INFO keys a header may declare for k_rows to take its INFO fields
 static constexpr int kRowThreads = 128;
-static constexpr int kRowStage = 128;     // bytes of a field staged per thread (9 aligned 16-byte blocks cover them at any alignment)
-static constexpr int kRowBlocks = 9;
-static constexpr int kRowStride = 41;     // dwords per thread: the blocks + slack for 12-byte reads at the field's end; odd: no bank conflicts
+// A thread stages its field in an LDS row of its own, and the rows are what bounds the kernel's occupancy (A/B in one box,
+// 5.3 M lines of 49 bytes: rows of 128 bytes + cells for 32 keys = 30 KB a block: children 0.83 ms; rows of 64 bytes + 8 keys =
+// 15 KB: 0.62 ms).  So the kernel comes in two row sizes and two key-table sizes; the host picks per batch — the small row when
+// (nearly) no INFO field of the batch is longer than 64 bytes (the counting pass counts those that are), the small table
+// when the header declares at most 8 keys.  Fields longer than the row are k_info_wide's either way.
+static constexpr int kStageSmall = 64, kStageLarge = 128, kKASmall = 8;
+template <int STAGE>
+struct RowGeo {
+    static constexpr int kStage = STAGE;          // bytes of a field staged per thread
+    static constexpr int kBlocks = STAGE / 16 + 1;  // aligned 16-byte blocks that cover them at any alignment
+    static constexpr int kStride = (kBlocks * 4 + 4) | 1;  // dwords per thread: the blocks + slack for 12-byte reads at the field's end; odd: no bank conflicts
+};
 static constexpr uint32_t kCellAbsent = 0xFFFFu, kCellBare = 0xFFFEu;
 
+template <class G>
 __device__ __forceinline__ Txt stage_row(uint32_t *row, const Fld &f) {
+    constexpr int kRowStage = G::kStage, kRowBlocks = G::kBlocks, kRowStride = G::kStride;
     const uint32_t lead = (uint32_t)(reinterpret_cast<uintptr_t>(f.g) & 15u);
     const uint8_t *al = f.g - lead;
     const uint32_t want = f.len < (uint32_t)kRowStage ? f.len : (uint32_t)kRowStage;
@@ -281,7 +292,7 @@ __device__ __forceinline__ Txt stage_row(uint32_t *row, const Fld &f) {
 __device__ __forceinline__ bool fld_missing(const Txt &t, uint32_t len) { return len == 0 || (len == 1 && t.b(0) == '.'); }
 
 // id / alt / filter of one row
-template <int MODE>
+template <int MODE, class G>
 __device__ __forceinline__ void row_list(uint32_t *row, const exg_string_t *slot, const Batch &a, uint32_t sep, uint32_t *cnt_out, uint4 *elems,
                                          uint64_t out) {
     if (MODE == kCount) {
@@ -295,7 +306,7 @@ __device__ __forceinline__ void row_list(uint32_t *row, const exg_string_t *slot
         }
     }
     const Fld f = field_of(slot, a.d_base, a.payload_base);
-    const Txt t = stage_row(row, f);
+    const Txt t = stage_row<G>(row, f);
     const bool none = fld_missing(t, f.len);
     if (MODE == kCount) {
         uint32_t c = none ? 0u : 1u;
@@ -312,19 +323,21 @@ __device__ __forceinline__ void row_list(uint32_t *row, const exg_string_t *slot
     }
 }
 
+template <int STAGE, int KA>
 struct RowsLds {
-    uint32_t stage[kRowThreads * kRowStride];
-    uint16_t cells[kKA * kRowThreads];
-    Key keys[kKA];
-    uint32_t slots[2 * kKA];
+    uint32_t stage[kRowThreads * RowGeo<STAGE>::kStride];
+    uint16_t cells[KA * kRowThreads];
+    Key keys[KA];
+    uint32_t slots[2 * KA];
     uint8_t names[512];
 };
 
-template <int MODE>
+template <int MODE, int STAGE, int KA>
 __global__ __launch_bounds__(kRowThreads) void k_rows(Batch a, KeyTab kt_in, const KeyOut *__restrict__ ko, int take_info) {
-    __shared__ RowsLds s;
+    using G = RowGeo<STAGE>;
+    __shared__ RowsLds<STAGE, KA> s;
     const uint32_t tid = threadIdx.x;
-    uint32_t *const row = s.stage + tid * kRowStride;
+    uint32_t *const row = s.stage + tid * G::kStride;
     // the key table in LDS (<= kKA keys): the walk looks a key up per entry
     KeyTab kt = kt_in;
     if (take_info) {
@@ -363,8 +376,14 @@ __global__ __launch_bounds__(kRowThreads) void k_rows(Batch a, KeyTab kt_in, con
                     out = a.goff[c * a.goff_stride + j];
                     if (a.goff[c * a.goff_stride + j + 1] == out) continue;
                 }
-                row_list<MODE>(row, a.col[c] + r, a, sep, a.cnt + c * a.cnt_stride + j, reinterpret_cast<uint4 *>(a.elems[c]), out);
+                row_list<MODE, G>(row, a.col[c] + r, a, sep, a.cnt + c * a.cnt_stride + j, reinterpret_cast<uint4 *>(a.elems[c]), out);
             }
+        }
+        if (MODE == kCount && a.mid_rows) {
+            // INFO fields too long for the small row but not for the large one: what the host picks the writing pass's row size by
+            const uint32_t il = act ? reinterpret_cast<const uint4 *>(a.col[3] + r)->x : 0u;
+            const unsigned long long mid = __ballot(il > (uint32_t)kStageSmall && il <= (uint32_t)kStageLarge);
+            if ((tid & 63u) == 0 && mid) atomicAdd(a.mid_rows, (unsigned long long)__popcll(mid));
         }
         if (!info_pass) continue;
         // INFO: the walk fills the row's cells (first occurrence of a key wins) ...
@@ -378,8 +397,8 @@ __global__ __launch_bounds__(kRowThreads) void k_rows(Batch a, KeyTab kt_in, con
         if (act) {
             const Fld f = field_of(a.col[3] + r, a.d_base, a.payload_base);
             hptr = f.hptr;
-            if (f.len <= (uint32_t)kRowStage) {  // (longer: k_info_wide's)
-                t = stage_row(row, f);
+            if (f.len <= (uint32_t)STAGE) {  // (longer: k_info_wide's)
+                t = stage_row<G>(row, f);
                 const int len = (int)f.len;
                 if (!fld_missing(t, f.len)) {
                     int p = 0;
@@ -587,7 +606,7 @@ static constexpr uint32_t kSeenWordsLds = 512;  // 16 384 keys per wave in LDS; 
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_info_wide(Batch a, KeyTab kt, const KeyOut *__restrict__ ko, uint32_t rpg, int all_rows,
-                                                   uint32_t *g_seen, uint32_t seen_words) {
+                                                   uint32_t *g_seen, uint32_t seen_words, uint32_t row_stage) {
     __shared__ WaveLds s_w[4];
     __shared__ uint32_t s_seen[4][kSeenWordsLds];
     const uint32_t wv = threadIdx.x >> 6, lane = lane_id();
@@ -613,7 +632,7 @@ __global__ __launch_bounds__(256) void k_info_wide(Batch a, KeyTab kt, const Key
         if (lane < rpg && jl < a.n) {
             const uint64_t r = a.row_map ? (uint64_t)a.row_map[jl] : jl;
             mine = field_of(a.col[3] + r, a.d_base, a.payload_base);
-            need = mine.len > 0 && !(mine.len == 1 && mine.g[0] == '.') && (all_rows || mine.len > (uint32_t)kRowStage);
+            need = mine.len > 0 && !(mine.len == 1 && mine.g[0] == '.') && (all_rows || mine.len > row_stage);
         }
         unsigned long long todo = __ballot(need);
         while (todo) {
@@ -947,17 +966,24 @@ inline uint32_t rows_grid(uint64_t n) {
 }  // namespace
 
 bool rows_take_info(uint32_t n_info_keys) { return n_info_keys <= (uint32_t)kKA; }
+uint32_t rows_stage_bytes(bool small_rows) { return small_rows ? kStageSmall : kStageLarge; }
 
 uint64_t scan_tmp_entries(uint64_t n_cols, uint64_t n) { return n_cols * ((n + kScanChunk - 1) / kScanChunk + 2); }
 
-void rows_count(const Batch &b, const KeyTab &info, hipStream_t s) {
+template <int MODE>
+static void launch_rows(const Batch &b, const KeyTab &info, const KeyOut *d_out, bool small_rows, hipStream_t s) {
     if (!b.n) return;
-    hipLaunchKernelGGL(k_rows<kCount>, dim3(rows_grid(b.n)), dim3(kRowThreads), 0, s, b, info, (const KeyOut *)nullptr,
-                       rows_take_info(info.n_keys) ? 1 : 0);
+    const int take = rows_take_info(info.n_keys) ? 1 : 0;
+    const bool small_tab = info.n_keys <= (uint32_t)kKASmall || !take;
+    const dim3 grid(rows_grid(b.n)), block(kRowThreads);
+    if (small_rows && small_tab) hipLaunchKernelGGL((k_rows<MODE, kStageSmall, kKASmall>), grid, block, 0, s, b, info, d_out, take);
+    else if (small_rows) hipLaunchKernelGGL((k_rows<MODE, kStageSmall, kKA>), grid, block, 0, s, b, info, d_out, take);
+    else if (small_tab) hipLaunchKernelGGL((k_rows<MODE, kStageLarge, kKASmall>), grid, block, 0, s, b, info, d_out, take);
+    else hipLaunchKernelGGL((k_rows<MODE, kStageLarge, kKA>), grid, block, 0, s, b, info, d_out, take);
 }
-void rows_write(const Batch &b, const KeyTab &info, const KeyOut *d_info_out, hipStream_t s) {
-    if (!b.n) return;
-    hipLaunchKernelGGL(k_rows<kWrite>, dim3(rows_grid(b.n)), dim3(kRowThreads), 0, s, b, info, d_info_out, rows_take_info(info.n_keys) ? 1 : 0);
+void rows_count(const Batch &b, const KeyTab &info, bool small_rows, hipStream_t s) { launch_rows<kCount>(b, info, nullptr, small_rows, s); }
+void rows_write(const Batch &b, const KeyTab &info, const KeyOut *d_info_out, bool small_rows, hipStream_t s) {
+    launch_rows<kWrite>(b, info, d_info_out, small_rows, s);
 }
 // wider headers than 16 384 keys: the seen bits of every wave of the launch live in global scratch
 static uint32_t seen_words_of(const KeyTab &info) { return (info.n_keys + 31) / 32; }
@@ -965,15 +991,16 @@ size_t info_wide_seen_bytes(const KeyTab &info, uint64_t n, uint32_t rpg) {
     const uint32_t words = seen_words_of(info);
     return words > kSeenWordsLds ? (size_t)wave_grid(n, rpg) * 4 * words * 4 : 0;
 }
-void info_wide_count(const Batch &b, const KeyTab &info, uint32_t rpg, uint32_t *d_seen, hipStream_t s) {
+void info_wide_count(const Batch &b, const KeyTab &info, uint32_t rpg, uint32_t *d_seen, bool small_rows, hipStream_t s) {
     if (!b.n || !info.n_keys || !info.n_lists) return;
     hipLaunchKernelGGL(k_info_wide<kCount>, dim3(wave_grid(b.n, rpg)), dim3(256), 0, s, b, info, (const KeyOut *)nullptr, rpg,
-                       rows_take_info(info.n_keys) ? 0 : 1, seen_words_of(info) > kSeenWordsLds ? d_seen : (uint32_t *)nullptr, seen_words_of(info));
+                       rows_take_info(info.n_keys) ? 0 : 1, seen_words_of(info) > kSeenWordsLds ? d_seen : (uint32_t *)nullptr, seen_words_of(info),
+                       rows_stage_bytes(small_rows));
 }
-void info_wide_write(const Batch &b, const KeyTab &info, const KeyOut *d_info_out, uint32_t rpg, uint32_t *d_seen, hipStream_t s) {
+void info_wide_write(const Batch &b, const KeyTab &info, const KeyOut *d_info_out, uint32_t rpg, uint32_t *d_seen, bool small_rows, hipStream_t s) {
     if (!b.n || !info.n_keys) return;
     hipLaunchKernelGGL(k_info_wide<kWrite>, dim3(wave_grid(b.n, rpg)), dim3(256), 0, s, b, info, d_info_out, rpg, rows_take_info(info.n_keys) ? 0 : 1,
-                       seen_words_of(info) > kSeenWordsLds ? d_seen : (uint32_t *)nullptr, seen_words_of(info));
+                       seen_words_of(info) > kSeenWordsLds ? d_seen : (uint32_t *)nullptr, seen_words_of(info), rows_stage_bytes(small_rows));
 }
 void samples_count(const Batch &b, uint32_t rpg, hipStream_t s) {
     if (!b.n) return;

@@ -90,6 +90,7 @@ struct Batch {
     const uint64_t *goff;  // goff[c * goff_stride + j], n + 1 entries per column (after the scan)
     uint64_t goff_stride;
     exg_string_t *elems[3];  // WRITE: the elements of id / alt / filter
+    unsigned long long *mid_rows;  // COUNT: += rows whose INFO field is longer than k_rows' small row (64 bytes) but not than its large one (NULL: not counted)
 };
 
 // FORMAT-level state of a batch (elements = samples)
@@ -106,10 +107,11 @@ uint64_t scan_tmp_entries(uint64_t n_cols, uint64_t n);
 
 // ---- stage 1: counts over rows ---------------------------------------------------------------------------------------
 // id / alt / filter (and the narrow INFO fields' list keys), the wide INFO fields' list keys, samples per row
-void rows_count(const Batch &b, const KeyTab &info, hipStream_t s);
+// small_rows: k_rows with the 64-byte row (the fields of 65 - 128 bytes are then k_info_wide's too); count and write may differ
+void rows_count(const Batch &b, const KeyTab &info, bool small_rows, hipStream_t s);
 // (d_seen: info_wide_seen_bytes() of scratch, NULL when that is 0)
 size_t info_wide_seen_bytes(const KeyTab &info, uint64_t n, uint32_t rows_per_group);
-void info_wide_count(const Batch &b, const KeyTab &info, uint32_t rows_per_group, uint32_t *d_seen, hipStream_t s);
+void info_wide_count(const Batch &b, const KeyTab &info, uint32_t rows_per_group, uint32_t *d_seen, bool small_rows, hipStream_t s);
 void samples_count(const Batch &b, uint32_t rows_per_group, hipStream_t s);
 // exclusive prefix sums of n_cols columns of counts (cnt[c * cnt_stride + i], i < n) -> goff[c * goff_stride + i] (n + 1 entries),
 // totals[c] = goff[c][n].  d_tmp: scan_tmp_entries(n_cols, n) u64
@@ -118,8 +120,8 @@ void scan_counts(const uint32_t *d_cnt, uint64_t cnt_stride, uint64_t n_cols, ui
 // ---- stage 2: counts over samples (FORMAT keys that are lists) -------------------------------------------------------------
 void samples_count_lists(const Batch &b, const Samples &sm, const KeyTab &format, uint32_t rows_per_group, hipStream_t s);
 // ---- stage 3: the children --------------------------------------------------------------------------------------------------
-void rows_write(const Batch &b, const KeyTab &info, const KeyOut *d_info_out, hipStream_t s);
-void info_wide_write(const Batch &b, const KeyTab &info, const KeyOut *d_info_out, uint32_t rows_per_group, uint32_t *d_seen, hipStream_t s);
+void rows_write(const Batch &b, const KeyTab &info, const KeyOut *d_info_out, bool small_rows, hipStream_t s);
+void info_wide_write(const Batch &b, const KeyTab &info, const KeyOut *d_info_out, uint32_t rows_per_group, uint32_t *d_seen, bool small_rows, hipStream_t s);
 void samples_write(const Batch &b, const Samples &sm, const KeyTab &format, const KeyOut *d_format_out, uint32_t rows_per_group, hipStream_t s);
 // the Float literals the kernels above left to the exact parser
 void fix_slow_floats(Ctl *ctl, hipStream_t s);

@@ -268,3 +268,24 @@ def test_value_error_in_a_wide_row_and_in_a_sample(gpu, oracle, tmp_path):
         with pytest.raises(ExgError):
             r.rows()
         r.close()
+
+
+@pytest.mark.parametrize("device_batch", [0, 64 << 10])
+def test_small_rows_with_a_few_longer_fields(gpu, oracle, tmp_path, device_batch):
+    # nearly every INFO field <= 64 bytes: k_rows runs with its 64-byte row (picked per batch from the counting pass's tally of the
+    # fields of 65 - 128 bytes) and the few longer fields — 65 to 128 bytes, and beyond — are the wave kernel's; lists on both sides
+    rng = random.Random(11)
+    hdr, info, fmt = make_header(8, 2, 1)
+    lines = []
+    for k in range(4000):
+        mid, long_ = k % 400 == 7, k % 1000 == 13
+        while True:
+            line = make_line(rng, k, info, fmt, 1, 8 if long_ else rng.choice([3, 4, 5, 6]) if mid else rng.choice([0, 1, 2, 3]), 2, long_strings=long_)
+            n_info = len(line.split(b"\t")[7])
+            if long_ or (mid and 64 < n_info <= 128) or (not mid and n_info <= 64):
+                break
+        lines.append(line)
+    data = hdr + b"\n".join(lines) + b"\n"
+    lens = [len(l.split(b"\t")[7]) for l in lines]
+    assert sum(64 < x <= 128 for x in lens) * 64 <= len(lines) and any(64 < x <= 128 for x in lens) and any(x > 128 for x in lens)
+    check(oracle, tmp_path, data, device_batch_bytes=device_batch)
