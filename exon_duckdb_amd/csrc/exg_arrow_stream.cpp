@@ -142,7 +142,10 @@ struct StreamState {
     } nk_info, nk_format;
     size_t side_cap = 64u << 10;  // bytes of percent-decoded String values a batch may hold (grows when a batch needs more)
     bool small_rows = false;      // k_rows' row size: the batch before had (nearly) no INFO field of 65 - 128 bytes (exg_vcf_nested.hip)
-    DevArena arena;
+    // two arenas, taken in turn: a batch's regions are still being copied back while the batch behind it is built (Batch::landed)
+    DevArena arena_a, arena_b;
+    DevArena *arena_p = &arena_a;
+    DevArena &arena() { return *arena_p; }
     std::shared_ptr<ABatch> batch;
     uint64_t batch_row = 0;
     // the device batch AFTER the one being handed out is produced on a thread of its own (scan, Arrow buffers, their way
@@ -166,7 +169,8 @@ struct StreamState {
         if (copy_stream) stream_pool()->give(copy_dev, copy_stream);
         for (void *p : {d_consts, d_prog, nk_info.d_keys, nk_info.d_slots, nk_info.d_names, nk_format.d_keys, nk_format.d_slots, nk_format.d_names})
             if (p) (void)hipFree(p);
-        arena.reset();
+        arena_a.reset();
+        arena_b.reset();
         if (owns_reader) delete r;
     }
 };
@@ -189,7 +193,7 @@ struct Emit {
     hipStream_t d2h = nullptr;  // the stream build_nested's mirrors travel on (NULL: st->copy_stream)
 
     void *dalloc(size_t bytes) {
-        void *p = st->arena.alloc(bytes);
+        void *p = st->arena().alloc(bytes);
         if (!p && !rc) rc = fail(r, EXG_E_HIP, "out of device memory in the Arrow emitter");
         return p;
     }
@@ -614,11 +618,11 @@ static double em_now() {
 int arrow_emit(exg_reader *r, const ScanCtx &ctx) {
     StreamState *st = (StreamState *)r->arrow_state.get();
     double em_t0 = em_now();
-    st->arena.reset();
+    st->arena().reset();
     // sized for the typical batch: offsets + values + views of every column; what a batch needs beyond that comes from the
     // pool and enlarges the arena of the next one
-    st->arena.min_extra = r->mem_cap ? (64u << 10) : (1u << 20);
-    st->arena.prepare(r->device, (size_t)std::min<uint64_t>(r->mem_cap ? r->d_in_cap * 6 + (1u << 20) : r->d_in_cap * 3 + (64u << 20), 6ull << 30));
+    st->arena().min_extra = r->mem_cap ? (64u << 10) : (1u << 20);
+    st->arena().prepare(r->device, (size_t)std::min<uint64_t>(r->mem_cap ? r->d_in_cap * 6 + (1u << 20) : r->d_in_cap * 3 + (64u << 20), 6ull << 30));
     EM_TRACE("arena");
     if (!st->copy_stream) {
         EM_HIP(stream_pool()->take(r->device, &st->copy_stream));
@@ -844,7 +848,7 @@ int arrow_emit(exg_reader *r, const ScanCtx &ctx) {
         }
     if (getenv("EXG_TRACE"))
         fprintf(stderr, "[exg] arrow emit: arena %zu of %zu MiB, %zu extra allocations (%zu MiB), %zu pinned blocks\n",
-                st->arena.used >> 20, st->arena.cap >> 20, st->arena.extra.size(), st->arena.extra_bytes >> 20,
+                st->arena().used >> 20, st->arena().cap >> 20, st->arena().extra.size(), st->arena().extra_bytes >> 20,
                 batch->host.blocks.size());
     EM_TRACE("drain");
     st->host_hint = batch->host.total + batch->host.total / 8 + (1u << 20);
@@ -1165,11 +1169,14 @@ int nested_emit(exg_reader *r, const ScanCtx &ctx, Batch *b, const uint32_t *d_r
     StreamState *st = (StreamState *)r->nested_state.get();
     if (!st) return fail(r, EXG_E_INVALID_ARG, "nested_emit without nested_prepare");
     if (getenv("EXG_TRACE"))
-        fprintf(stderr, "[exg] nested emit: the batch before used %zu KiB of a %zu KiB arena + %zu extra blocks (%zu KiB)\n", st->arena.used >> 10,
-                st->arena.cap >> 10, st->arena.extra.size(), st->arena.extra_bytes >> 10);
-    st->arena.reset();
-    st->arena.min_extra = r->mem_cap ? (64u << 10) : (1u << 20);
-    st->arena.prepare(r->device, (size_t)std::min<uint64_t>(r->mem_cap ? r->d_in_cap * 6 + (1u << 20) : r->d_in_cap * 3 + (64u << 20), 6ull << 30));
+        fprintf(stderr, "[exg] nested emit: the batch before used %zu KiB of a %zu KiB arena + %zu extra blocks (%zu KiB)\n", st->arena().used >> 10,
+                st->arena().cap >> 10, st->arena().extra.size(), st->arena().extra_bytes >> 10);
+    // (the other arena: the one of the batch before may still be read by its copies — whose end the consumer waits for before this
+    // function is entered a second time after it)
+    st->arena_p = st->arena_p == &st->arena_a ? &st->arena_b : &st->arena_a;
+    st->arena().reset();
+    st->arena().min_extra = r->mem_cap ? (64u << 10) : (1u << 20);
+    st->arena().prepare(r->device, (size_t)std::min<uint64_t>(r->mem_cap ? r->d_in_cap * 6 + (1u << 20) : r->d_in_cap * 3 + (64u << 20), 6ull << 30));
     if (!st->copy_stream) {
         EM_HIP(stream_pool()->take(r->device, &st->copy_stream));
         st->copy_dev = r->device;
@@ -1196,13 +1203,18 @@ int nested_emit(exg_reader *r, const ScanCtx &ctx, Batch *b, const uint32_t *d_r
     // stream of their own: a copy occupies an SDMA engine, a second stream of D2H copies takes a second engine, and that was the
     // one the next batch's upload runs on (EXG_TRACE=2: the upload landed 2 ms after the columns had left, the link never duplex)
     em.d2h = r->col_stream && !getenv("EXG_VCF_TWO_D2H") ? r->col_stream : st->copy_stream;
-    struct D2hDrain {
+    struct D2hDrain {  // (an error return: nothing may still be writing the batch's blocks)
         hipStream_t cs;
-        ~D2hDrain() { (void)hipStreamSynchronize(cs); }
+        ~D2hDrain() {
+            if (cs) (void)hipStreamSynchronize(cs);
+        }
     } drain2{em.d2h};
     NestedOut no;
     if (int rc = build_nested(em, ctx, r->batch_rows, want, true, &no)) return rc;
-    EM_HIP(hipStreamSynchronize(em.d2h));
+    if (r->lazy_landing && em.d2h == r->col_stream)
+        drain2.cs = nullptr;  // the caller records the batch's landing event behind these copies (Batch::landed)
+    else
+        EM_HIP(hipStreamSynchronize(em.d2h));
     b->nested.assign(9, NVec());
     auto leaf = [](int type, uint32_t elem, uint64_t length, const void *data, const void *validity) {
         NVec v;

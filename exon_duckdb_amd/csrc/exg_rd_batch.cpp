@@ -898,6 +898,10 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             a.workspace_bytes = r->ws_bytes;
             a.d_result = (exg_scan_result *)r->d_res;
             a.stream = r->stream;
+            if (r->flat_pending) {  // (the batch before: its flat columns' copies read what this scan writes)
+                RD_HIP(r, hipStreamWaitEvent(r->stream, r->flat_ev, 0));
+                r->flat_pending = false;
+            }
             rc = exg_vcf_scan(&a);
             fused_first = true;
             rescan_general = [a]() mutable {
@@ -1139,15 +1143,29 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             // 200 MB of flat vectors (3.7 ms of the link) stood in front of them; on a stream of their own the copies run beside
             // them (chrom, pos, ref of a 2 GB file: 70.6 -> 49.4 ms = 42 GB/s, COUNT(*) 47 ms: A/B in one box, EXG_VCF_ONE_STREAM)
             hipStream_t cs = r->stream;
+            // (whatever way this block is left once copies are on the columns' stream: they have landed — or the batch carries the
+            // event that says when — before its pinned blocks can go back to the pool)
+            struct ColDrain {
+                hipStream_t cs = nullptr;
+                ~ColDrain() {
+                    if (cs) (void)hipStreamSynchronize(cs);
+                }
+            } col_drain;
             if (r->format == EXG_FMT_VCF && !compact && !getenv("EXG_VCF_ONE_STREAM")) {
                 if (!r->col_stream) {
                     RD_HIP(r, stream_pool()->take(r->device, &r->col_stream));
                     RD_HIP(r, hipEventCreateWithFlags(&r->col_ev, hipEventDisableTiming));
+                    RD_HIP(r, hipEventCreateWithFlags(&r->flat_ev, hipEventDisableTiming));
                 }
                 RD_HIP(r, hipEventRecord(r->col_ev, r->stream));          // (the scan, the predicate's row map)
                 RD_HIP(r, hipStreamWaitEvent(r->col_stream, r->col_ev, 0));
                 cs = r->col_stream;
+                col_drain.cs = cs;
             }
+            // read_vcf hands its batch on while the vectors are still travelling (Batch::landed): the batch behind it — upload wait,
+            // scan, the nested columns' kernels — is made beside them, and the link back to the host does not idle between batches
+            static const bool eager_landing = getenv("EXG_VCF_EAGER_LANDING") != nullptr;
+            r->lazy_landing = cs == r->col_stream && cs != r->stream && !eager_landing;
             const bool nested_vcf = r->format == EXG_FMT_VCF;  // id, alt, filter, info, formats: built by nested_emit below
             for (int c = 0; c < ns; c++) {
                 if ((nested_vcf && (c == 2 || c == 4 || c >= 6)) || !r->want(c)) {
@@ -1191,6 +1209,10 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             };
             if (r->format == EXG_FMT_VCF) {
                 if (r->want(5) && (rc = copy_validity(5, r->d_valid[0]))) return rc;
+                if (r->lazy_landing) {
+                    RD_HIP(r, hipEventRecord(r->flat_ev, cs));  // (the scan's columns are free again behind this)
+                    r->flat_pending = true;
+                }
                 if (!r->nested_state && (rc = nested_prepare(r))) return rc;
                 ScanCtx ctx;
                 ctx.d_input = d_input;
@@ -1205,6 +1227,11 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
                 trace_at("N nested landed", r->n_batches);
                 TRACE("nested columns (kernels + their way back)", t_ne);
                 b->n_rows = deliver;
+                if (r->lazy_landing) {
+                    RD_HIP(r, hipEventCreateWithFlags(&b->landed, hipEventDisableTiming));
+                    RD_HIP(r, hipEventRecord(b->landed, cs));
+                    col_drain.cs = nullptr;
+                }
             } else {
                 if (r->want(1) && (rc = copy_validity(1, r->d_valid[0]))) return rc;
             }
@@ -1212,7 +1239,8 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
                 RD_HIP(r, hipMemcpyAsync(b->payload, r->d_payload, res.payload_bytes, hipMemcpyDeviceToHost, r->stream));
             const double t_cols = now_s();
             RD_HIP(r, hipStreamSynchronize(r->stream));
-            if (r->col_stream) RD_HIP(r, hipStreamSynchronize(r->col_stream));
+            if (r->col_stream && !b->landed) RD_HIP(r, hipStreamSynchronize(r->col_stream));
+            col_drain.cs = nullptr;
             TRACE("wait(columns -> host)", t_cols);
             const double t_mir = now_s();
             if (gz_mirror) RD_HIP(r, hipEventSynchronize(gz_mirror->ev));  // the segment's own bytes have arrived

@@ -146,6 +146,8 @@ void exg_reader::free_device() {
     (void)join_prefetch();
     drop_prefetch2();
     if (up_stream) (void)hipStreamSynchronize(up_stream);
+    if (col_stream) (void)hipStreamSynchronize(col_stream);  // (copies out of the columns that are about to be freed)
+    flat_pending = false;
     pf.valid = false;
     d_in = nullptr;
     for (auto &a : dev_allocs) {
@@ -182,6 +184,7 @@ exg_reader::~exg_reader() {
     for (int k = 0; k < 2; k++)
         if (up_done_of[k]) (void)hipEventDestroy(up_done_of[k]);
     if (col_ev) (void)hipEventDestroy(col_ev);
+    if (flat_ev) (void)hipEventDestroy(flat_ev);
     exg_rd::stream_pool()->give(device, col_stream);
     exg_rd::stream_pool()->give(device, up_stream);
     exg_rd::stream_pool()->give(device, stream, /*high=*/getenv("EXG_NO_SCAN_PRIORITY") == nullptr);

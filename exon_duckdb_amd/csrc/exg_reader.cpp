@@ -139,6 +139,10 @@ extern "C" int exg_open(const exg_open_args *args, exg_reader **out) {
                         return rc;
                     }
                     if (!end) {
+                        if (rd->batch->wait_landed()) {
+                            *err = "the batch's vectors did not arrive (hipEventSynchronize failed)";
+                            return EXG_E_HIP;
+                        }
                         item->rows = rd->batch->n_rows;
                         item->batch = rd->batch;  // the batch's host buffers outlive its reader
                         rd->batch.reset();
@@ -350,6 +354,11 @@ extern "C" int exg_next_chunk(exg_reader *r, exg_chunk *out) {
         r->cur = std::move(r->batch);
         r->batch.reset();
         r->cur_row = 0;
+        if (r->cur && r->cur->landed) {
+            // read_vcf: the batch's vectors are still on their way — the batch behind it starts being made right now, beside them
+            if (!no_ahead && r->cur->n_rows && !r->ahead.joinable() && !r->ahead_done) start_ahead(r);
+            if (r->cur->wait_landed()) return fail(r, EXG_E_HIP, "the batch's vectors did not arrive (hipEventSynchronize failed)");
+        }
     }
 }
 

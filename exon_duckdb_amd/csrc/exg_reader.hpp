@@ -304,6 +304,22 @@ struct Batch {  // host vectors of one device batch, shared by its chunks
     uint64_t n_rows = 0;
     uint64_t seq = 0;          // which device batch of its reader this is (exg_chunk.batch_no)
     std::vector<NVec> nested;  // per column; type == 0 for the flat ones
+    // read_vcf (round 6): the batch is handed to the reader while its vectors are still on their way — recorded behind the last
+    // copy; whoever hands out the batch's first chunk waits for it (wait_landed).  NULL: everything had landed when it was made.
+    hipEvent_t landed = nullptr;
+    int wait_landed() {
+        if (!landed) return 0;
+        const hipError_t e = hipEventSynchronize(landed);
+        (void)hipEventDestroy(landed);
+        landed = nullptr;
+        return e == hipSuccess ? 0 : -1;
+    }
+    ~Batch() {
+        if (landed) {
+            (void)hipEventSynchronize(landed);  // (the pinned blocks go back to the pool: nothing may still be writing them)
+            (void)hipEventDestroy(landed);
+        }
+    }
 };
 
 struct ChunkKeep {
@@ -354,6 +370,10 @@ struct exg_reader {
     // read_vcf: the flat columns' copies back run on a stream of their own beside the nested columns' kernels (next_batch)
     hipStream_t col_stream = nullptr;
     hipEvent_t col_ev = nullptr;
+    // read_vcf: the next scan may overwrite the columns only when the flat columns' copies of the batch before have left them
+    hipEvent_t flat_ev = nullptr;
+    bool flat_pending = false;
+    bool lazy_landing = false;  // this batch's vectors are not waited for inside next_batch (Batch::landed)
     // per input slot: the thread of the upload that is filling it (pread + H2D enqueue), its result, the event behind its copies
     std::thread up_thread_of[2];
     int up_rc_of[2] = {0, 0};
