@@ -454,13 +454,21 @@ def run_record_shapes(torch, lib, args):
         d[len(header):n] = torch.frombuffer(bytearray(block), dtype=torch.uint8).cuda().repeat(reps)
         return d, n, reps
 
+    lib.exg_scan_algo_hint.restype = C.c_int
+    lib.exg_scan_algo_hint.argtypes = [C.c_int, C.c_char_p, C.c_uint64]
+    algo_name = {abi.EXG_ALGO_FUSED: "EXG_ALGO_FUSED (the lean scan)", abi.EXG_ALGO_FUSED_FULL: "EXG_ALGO_FUSED_FULL (the any-shape scan)",
+                 abi.EXG_ALGO_FUSED_INDEX: "EXG_ALGO_FUSED_INDEX (the any-shape scan + k_vcf_rows)"}
+
     def fastq_leg(name, what, block, expect):
         rows_blk = len(expect["name"][0])
         d_in, n, reps = tiled(b"", block)
         scan = device.FastqScan(n, capacity_records=rows_blk * reps + 16)
         scan.launch(d_in, payload_base=BASE, algo=abi.EXG_ALGO_FUSED)
         r1 = scan.fetch()
-        ms_first, _ = timed_launches(torch, lambda: scan.launch(d_in, payload_base=BASE, algo=abi.EXG_ALGO_FUSED), 3, warm=0)
+        # what a reader launches FIRST on this input since round 6: chosen from the first MiB on the host (exg_scan_algo_hint)
+        hint = int(lib.exg_scan_algo_hint(abi.EXG_FMT_FASTQ, bytes(block[:1 << 20]), min(len(block), 1 << 20)))
+        ms_lean_redo, _ = timed_launches(torch, lambda: scan.launch(d_in, payload_base=BASE, algo=abi.EXG_ALGO_FUSED), 3, warm=0)
+        ms_first, _ = timed_launches(torch, lambda: scan.launch(d_in, payload_base=BASE, algo=hint), 3, warm=0)
         ms, ms_min = timed_launches(torch, lambda: scan.launch(d_in, payload_base=BASE, algo=abi.EXG_ALGO_FUSED_FULL), 6, warm=1)
         res = scan.fetch()
         ok = res.error_code == 0 and r1.error_code == 0 and int(res.n_records) == rows_blk * reps == int(r1.n_records)
@@ -478,7 +486,9 @@ def run_record_shapes(torch, lib, args):
                      "algorithmic_bytes": n, "ms": ms, "ms_min": ms_min, "GB/s": n / (ms * 1e-3) / 1e9, "frac": n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                      "records_per_s": rows_blk * reps / (ms * 1e-3), "algo": "EXG_ALGO_FUSED_FULL (the any-shape scan alone)",
                      "first_batch_ms": ms_first, "first_batch_GB/s": n / (ms_first * 1e-3) / 1e9,
-                     "first_batch_algo": "EXG_ALGO_FUSED (lean scan + any-shape run over the super-tiles it marked: EXG_RF_REDO)",
+                     "first_batch_algo": algo_name[hint] + ": exg_scan_algo_hint over the input's first MiB, what a reader launches first",
+                     "lean_plus_redo_ms": ms_lean_redo,
+                     "lean_plus_redo": "EXG_ALGO_FUSED on this shape (lean scan + any-shape run over the super-tiles it marked: what a reader's first batch cost before round 6)",
                      "fallback": bool((res.flags | r1.flags) & abi.EXG_RF_FALLBACK), "verified": bool(ok)}
         del scan, d_in
         torch.cuda.empty_cache()
@@ -490,7 +500,9 @@ def run_record_shapes(torch, lib, args):
         kw = dict(n_bytes=n, lead=len(hdr), payload_base=BASE)
         scan.launch(d_in, algo=abi.EXG_ALGO_FUSED, **kw)
         r1 = scan.fetch()
-        ms_first, _ = timed_launches(torch, lambda: scan.launch(d_in, algo=abi.EXG_ALGO_FUSED, **kw), 3, warm=0)
+        hint = int(lib.exg_scan_algo_hint(abi.EXG_FMT_VCF, bytes(block[:1 << 20]), min(len(block), 1 << 20)))
+        ms_lean_redo, _ = timed_launches(torch, lambda: scan.launch(d_in, algo=abi.EXG_ALGO_FUSED, **kw), 3, warm=0)
+        ms_first, _ = timed_launches(torch, lambda: scan.launch(d_in, algo=hint, **kw), 3, warm=0)
         ms, ms_min = timed_launches(torch, lambda: scan.launch(d_in, algo=abi.EXG_ALGO_FUSED_FULL, **kw), 6, warm=1)
         res = scan.fetch()
         # ... and with the rows left to a kernel of their own (EXG_ALGO_FUSED_INDEX: what the reader switches to on lines of >= 256 bytes);
@@ -534,7 +546,8 @@ def run_record_shapes(torch, lib, args):
                      "full_ms": ms_full, "full_GB/s": n / (ms_full * 1e-3) / 1e9,
                      "indexed_ms": ms_ix, "indexed_ms_min": ms_ix_min, "indexed_GB/s": n / (ms_ix * 1e-3) / 1e9,
                      "first_batch_ms": ms_first, "first_batch_GB/s": n / (ms_first * 1e-3) / 1e9,
-                     "first_batch_algo": "EXG_ALGO_FUSED (lean scan + any-shape run over the super-tiles it marked)",
+                     "first_batch_algo": algo_name[hint] + ": exg_scan_algo_hint over the input's first MiB, what a reader launches first",
+                     "lean_plus_redo_ms": ms_lean_redo,
                      "lean_scan_marked_tiles": bool(r1.flags & abi.EXG_RF_REDO),
                      "fallback": bool((res.flags | r1.flags) & abi.EXG_RF_FALLBACK), "verified": bool(ok)}
         del scan, d_in

@@ -150,6 +150,7 @@ class InflateStatus(C.Structure):
 # every symbol include/exon_gpu.h declares -> (restype, argtypes); None = not yet bound by name only
 SIGNATURES = {
     "exg_abi_version": (C.c_int, []),
+    "exg_scan_algo_hint": (C.c_int, [C.c_int, C.c_void_p, C.c_uint64]),
     "exg_device_count": (C.c_int, []),
     "exg_last_error_message": (C.c_char_p, []),
     "exg_parse_error_string": (C.c_char_p, [C.c_uint32]),

@@ -426,6 +426,10 @@ int open_next_file(exg_reader *r) {
     r->range_hi = r->src ? ~0ull : blk->n;  // (a decoded stream ends where its source says so)
     r->shard_first = false;
     r->data_base = r->file_pos;  // 0, or the end of the VCF header
+    // Which scan first: from the first MiB behind the header, which is mapped anyway (a decoded stream has no bytes on the host: its
+    // first batches' results decide, as before).  The batches' result flags correct the choice either way.
+    if (!r->src && blk->p && blk->n > r->file_pos && !getenv("EXG_NO_ALGO_HINT"))
+        r->fused_algo = (uint32_t)exg_scan_algo_hint(r->format, (const uint8_t *)blk->p + r->file_pos, blk->n - r->file_pos);
     static const bool no_ramp = getenv("EXG_NO_RAMP") != nullptr;
     r->ramp_bytes = (!r->src && r->format != EXG_FMT_FASTA && !no_ramp && r->device_batch_bytes > kRampFirstBytes) ? kRampFirstBytes : 0;
     if (r->fa_shard) {

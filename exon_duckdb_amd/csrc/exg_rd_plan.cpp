@@ -208,3 +208,35 @@ extern "C" ReplacementScanResult replacement_scan(const char *uri) {
     if (ext == "vcf") res.file_type = "VCF";
     return res;
 }
+
+// ---- which scan first (include/exon_gpu.h: exg_scan_algo_hint) ---------------------------------------------------------------------
+// What the lean scan cannot do in its single pass, and so marks for the any-shape run behind it (exg_fused_core.hpp): a record that
+// begins in front of its half's 1 KiB window or whose last four newlines do not fit in it (FASTQ: four lines; VCF: lines of a few
+// hundred bytes), a 16 KiB half with more lines than its list holds (FASTQ 512: lines of < 32 bytes on average; VCF 1024), bytes
+// >= 0x80 (UTF-8 validation).  A sample of the first MiB tells all of that apart.
+extern "C" int exg_scan_algo_hint(int format, const void *sample, uint64_t n_bytes) {
+    if (format != EXG_FMT_FASTQ && format != EXG_FMT_VCF) return EXG_ALGO_FUSED;  // (FASTA has one scan)
+    const uint8_t *p = (const uint8_t *)sample;
+    const uint64_t n = n_bytes < (1u << 20) ? n_bytes : (1u << 20);
+    if (!p || n < 4096) return EXG_ALGO_FUSED;  // (too little to tell: the batch's own result decides)
+    uint64_t lines = 0, hi = 0, last_nl = 0;
+    for (uint64_t i = 0; i + 8 <= n; i += 8) {
+        uint64_t w;
+        memcpy(&w, p + i, 8);
+        hi |= w & 0x8080808080808080ull;
+        const uint64_t x = w ^ 0x0A0A0A0A0A0A0A0Aull;
+        uint64_t m = ~(((x & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | x | 0x7F7F7F7F7F7F7F7Full);  // 0x80 in every byte equal to '\n' (exact)
+        while (m) {
+            lines++;
+            last_nl = i + ((uint64_t)__builtin_ctzll(m) >> 3);
+            m &= m - 1;
+        }
+    }
+    if (hi) return EXG_ALGO_FUSED_FULL;
+    if (lines < 4) return format == EXG_FMT_VCF ? EXG_ALGO_FUSED_INDEX : EXG_ALGO_FUSED_FULL;  // lines of hundreds of KiB
+    const uint64_t avg = (last_nl + 1) / lines;
+    if (format == EXG_FMT_FASTQ) return (avg * 4 >= 900 || avg < 34) ? EXG_ALGO_FUSED_FULL : EXG_ALGO_FUSED;
+    if (avg >= 640) return getenv("EXG_NO_VCF_INDEX") ? EXG_ALGO_FUSED_FULL : EXG_ALGO_FUSED_INDEX;
+    return (avg >= 200 || avg < 18) ? EXG_ALGO_FUSED_FULL : EXG_ALGO_FUSED;
+}
+

@@ -243,6 +243,13 @@ int exg_fasta_find_record(const void *d_bytes, uint64_t begin, uint64_t end, int
  * structure ('@' on line 0, '+' on line 2 for 8 consecutive records).  *d_phase (device u32)
  * receives 0..3, or 0xFFFFFFFF when no or several phases fit (caller falls back to counting). */
 int exg_fastq_guess_phase(const void *d_input, uint64_t n_bytes, uint64_t lead, uint32_t *d_phase, void *stream);
+/* ABI 9: which scan to launch FIRST on an input, from a sample of its bytes on the HOST (the reader looks at the first MiB behind the
+ * header it has mapped anyway; host only, no device is touched): EXG_ALGO_FUSED for ordinary shapes (150 bp reads, 50-byte VCF lines),
+ * EXG_ALGO_FUSED_FULL where the lean scan would mark most super-tiles (records of ~1 KiB and more, lines denser than its list holds,
+ * bytes >= 0x80), EXG_ALGO_FUSED_INDEX for VCF lines of >= 640 bytes.  Before round 6 a reader found this out from its first
+ * batches' results: lean + redo, then the any-shape scan, then (cohort VCFs) the indexed one; a file of one batch never got its scan.
+ * The result flags of every batch still correct the choice (exg_reader_stats.scan_algo). */
+int exg_scan_algo_hint(int format, const void *sample, uint64_t n_bytes);
 
 /* ---- quality_score_string_to_list on device-resident columns ----------------------------------------
  * Replaces the scalar function of exon/src/exon/fastq_functions/module.cpp:28-54 (one INTEGER per byte of the

@@ -185,3 +185,32 @@ def test_falsifiability_kit_writes_every_rule_case(tmp_path):
     (kit / "got" / (c2["case"] + ".json")).write_text("".join(json.dumps(r) + "\n" for r in e2[:2]))
     res = subprocess.run([sys.executable, "compare.py"], cwd=kit, capture_output=True, text=True)
     assert "pos: expected BIGINT, got INTEGER" in res.stdout and "DIFFERENT test_gzip_every_member_of_a_concatenation_is_read" in res.stdout
+
+
+def test_scan_algo_hint_from_a_host_sample():
+    """exg_scan_algo_hint (ABI 9): the scan a reader launches first, from the first MiB of the input on the host — no device touched.
+    The five shapes of bench.py's record_shapes + the ordinary ones (what the lean scan cannot do in one pass: exg_fused_core.hpp)"""
+    import ctypes as C
+    from exon_duckdb_amd import abi, load_library
+    from exon_duckdb_amd.testing import shapes
+    lib = load_library()
+    lib.exg_scan_algo_hint.restype = C.c_int
+    lib.exg_scan_algo_hint.argtypes = [C.c_int, C.c_char_p, C.c_uint64]
+
+    def hint(fmt, data):
+        data = bytes(data[:1 << 20])
+        return lib.exg_scan_algo_hint(fmt, data, len(data))
+
+    fq150 = shapes.fastq_records([150] * 3000, seed=1)
+    assert hint(abi.EXG_FMT_FASTQ, fq150) == abi.EXG_ALGO_FUSED
+    assert hint(abi.EXG_FMT_FASTQ, shapes.fastq_records([15000] * 40, seed=2)) == abi.EXG_ALGO_FUSED_FULL     # HiFi
+    assert hint(abi.EXG_FMT_FASTQ, shapes.fastq_records([36] * 20000, seed=3, desc_every=0)) == abi.EXG_ALGO_FUSED_FULL   # dense lines
+    assert hint(abi.EXG_FMT_FASTQ, shapes.fastq_records([250] * 3000, seed=4)) == abi.EXG_ALGO_FUSED
+    assert hint(abi.EXG_FMT_FASTQ, b"@r caf\xc3\xa9\n" + fq150) == abi.EXG_ALGO_FUSED_FULL                      # bytes >= 0x80
+    body = lambda v: v[v.index(b"#CHROM"):].split(b"\n", 1)[1]   # noqa: E731
+    assert hint(abi.EXG_FMT_VCF, body(shapes.vcf_lines(5000, 0, seed=5))) == abi.EXG_ALGO_FUSED
+    assert hint(abi.EXG_FMT_VCF, body(shapes.vcf_lines(2000, 100, seed=6))) == abi.EXG_ALGO_FUSED_FULL           # 483-byte lines
+    assert hint(abi.EXG_FMT_VCF, body(shapes.vcf_lines(200, 2504, seed=7))) == abi.EXG_ALGO_FUSED_INDEX         # 10 kB lines
+    assert hint(abi.EXG_FMT_VCF, b"1\t1\t.\tA\tC\t.\t.\t" + b"x" * (2 << 20)) == abi.EXG_ALGO_FUSED_INDEX     # one line of megabytes
+    assert hint(abi.EXG_FMT_FASTQ, b"@r\nAC\n+\nII\n") == abi.EXG_ALGO_FUSED                                   # too little to tell
+    assert hint(abi.EXG_FMT_FASTA, b">a\nACGT\n" * 10000) == abi.EXG_ALGO_FUSED

@@ -432,3 +432,26 @@ def test_vcf_shapes_fuzz(gpu, oracle, seed):
         for algo in FUSED_AND_PARTNER:
             res = check_vcf(oracle, data, algo)
             no_fallback(res)
+
+
+def test_the_scan_is_chosen_before_the_first_launch(gpu, oracle, tmp_path):
+    """round 6: a reader looks at the first MiB behind the header (exg_scan_algo_hint) — a cohort VCF of ONE device batch runs the
+    indexed scan, a long-read file the any-shape scan, from their first launch (before: lean + redo, then any-shape, then indexed:
+    a file of one batch never reached its scan)"""
+    from exon_duckdb_amd.reader import ShardReader
+    vcf = vcf_lines(300, 2504, seed=9)
+    pv = tmp_path / "cohort.vcf"
+    pv.write_bytes(vcf)
+    r = ShardReader(str(pv), "vcf", columns=[0, 1, 3, 5])
+    assert r.stats()["scan_algo"] == abi.EXG_ALGO_FUSED_INDEX and r.stats()["device_batches"] == 0   # (the header is read at open)
+    got = r.rows()
+    st = r.stats()
+    r.close()
+    t = oracle.vcf_parse(vcf, want_string_t=False)
+    assert len(got) == 300 and [g[1] for g in got] == [int(x) for x in t.extra["pos"]]
+    assert st["device_batches"] == 1 and st["scan_algo"] == abi.EXG_ALGO_FUSED_INDEX
+    data = fastq_records([20000] * 30, seed=10)
+    pf = tmp_path / "long1.fastq"
+    pf.write_bytes(bytes(data))
+    rows, st = _reader_rows(pf, "fastq")
+    assert rows == _fastq_rows(oracle, data) and st["device_batches"] == 1 and st["scan_algo"] == abi.EXG_ALGO_FUSED_FULL
