@@ -279,6 +279,33 @@ def reader_digest(lib, path, fmt, want_seq_len=0, columns=0, shard=(0, 1), devic
     return int(rows.value), int(chunks.value), int(dg.value), int(bad.value)
 
 
+def rank_placement(torch, rank, local_rank):
+    """this rank's device and host placement: PCI bus id, the NUMA node sysfs gives for it (where the library's pinned pool
+    places this device's blocks: exg_rd_io.cpp numa_node_of_device reads the same file), the CPUs the process may use"""
+    info = {"rank": rank, "local_rank": local_rank, "pid": os.getpid()}
+    try:
+        p = torch.cuda.get_device_properties(local_rank)
+        bdf = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0))
+        info.update({"device": p.name, "pci": bdf, "cus": getattr(p, "multi_processor_count", None), "hbm_GB": round(p.total_memory / 1e9, 1)})
+        try:
+            with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+                info["numa_node"] = int(f.read().strip())
+        except OSError:
+            info["numa_node"] = None
+        info["pinned_pool_node"] = max(0, info["numa_node"]) if info["numa_node"] is not None else 0
+    except Exception as e:  # noqa: BLE001
+        info["error"] = f"{type(e).__name__}: {e}"
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        info["cpus"] = f"{cpus[0]}-{cpus[-1]} ({len(cpus)})" if cpus else ""
+    except Exception:  # noqa: BLE001
+        pass
+    for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "GPU_MAX_HW_QUEUES"):
+        if os.environ.get(k) is not None:
+            info[k] = os.environ[k]
+    return info
+
+
 def effective_cores():
     """cores this process may really use: the affinity mask and the cgroup CPU quota, not the machine's core count"""
     n = os.cpu_count() or 1
@@ -1019,6 +1046,10 @@ def main():
              "distinct_devices": not args.single_device} if world > 1 else {"backend": None, "world_size": 1})
     if world > 1:
         assert dist.get_world_size() == args.gpus
+        # where every rank runs — so that the first run on eight devices can be read from its JSON: the device's PCI address and
+        # the NUMA node it hangs off (sysfs), the CPUs this process may run on, its per-launch time (filled in below)
+        coll["ranks"] = [None] * world
+        dist.all_gather_object(coll["ranks"], rank_placement(torch, rank, local_rank))
 
     from exon_duckdb_amd import sharding
 
@@ -1100,6 +1131,11 @@ def main():
     nrec = torch.tensor([n_rec_local], dtype=torch.int64, device=coll_dev)
     ver = torch.tensor([1 if verified else 0], dtype=torch.int64, device=coll_dev)
     if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"rank": rank, "timed_s": dt, "avg_launch_ms": avg_ms, "records": n_rec_local})
+        for pr in per_rank:
+            if coll.get("ranks") and coll["ranks"][pr["rank"]] is not None:
+                coll["ranks"][pr["rank"]].update({k: v for k, v in pr.items() if k != "rank"})
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(nrec)
         dist.all_reduce(ver, op=dist.ReduceOp.MIN)

@@ -40,6 +40,9 @@ def load_library(path=None):
     # would cost every user seconds and silently change which HIP runtime the product binds to; EXG_PRELOAD_TORCH=1 asks
     # for it (a process that will import torch later and cannot order its imports).
     import sys
+    # a reader keeps six to eight streams busy: more hardware queues than HIP's default of four (csrc/exg_api.hip; read by the
+    # runtime at its first HIP call — a process that initialised HIP before this import exports it itself, like bench.py)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if "torch" not in sys.modules and os.environ.get("EXG_PRELOAD_TORCH"):
         try:
             import torch  # noqa: F401

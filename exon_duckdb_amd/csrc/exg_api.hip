@@ -26,10 +26,11 @@ using namespace exg;
 // decoded segments' host copies, a checksum stage); HIP maps streams onto GPU_MAX_HW_QUEUES = 4 hardware queues by default and
 // streams that share one wait for each other's packets: measured on a BGZF FASTQ read into DataChunks, the 0.1 ms scan of a
 // batch sat 23-28 ms behind the decoder lanes' kernels and the 5 ms host copies (EXG_TRACE).  The runtime reads the
-// variable when it initialises, i.e. at the process's first HIP call: when this library is what brings HIP into the process
-// (`LOAD exon` in DuckDB) the constructor below is in time; a host that initialised HIP earlier (bench.py imports torch first)
-// sets it itself.  Never overrides a value that is set.
-__attribute__((constructor)) static void exg_hw_queues_default() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// variable at the process's first HIP call.  Until round 5 a constructor of this library called setenv() for it: in a DuckDB
+// process that is already multi-threaded when `LOAD exon` runs that is a data race with every getenv (glibc may move `environ`),
+// and it changed the queue mapping of every other HIP user of the process.  The library does not touch the environment any
+// more: whoever starts the process exports GPU_MAX_HW_QUEUES=8 (bench.py and the Python loader do, before HIP
+// is initialised).
 
 extern "C" int exg_abi_version(void) { return EXG_ABI_VERSION; }
 

@@ -164,7 +164,9 @@ int post_to_host(void *h_dst, const void *d_src, uint64_t bytes, void *stream) {
         set_error("post_to_host: null, unaligned or oversized argument");
         return EXG_E_INVALID_ARG;
     }
-    static const bool by_copy = getenv("EXG_POST_BY_COPY") != nullptr;  // (A/B: the copy this replaced)
+    // (A/B: the copy this replaced.  Also under HIP_HOST_COHERENT=0: pinned memory is then not coherent, and the kernel's stores
+    // are only guaranteed visible at an event with hipEventReleaseToSystem — which the callers' events are not)
+    static const bool by_copy = getenv("EXG_POST_BY_COPY") != nullptr || (getenv("HIP_HOST_COHERENT") && atoi(getenv("HIP_HOST_COHERENT")) == 0);
     if (by_copy) {
         EXG_HIP_CHECK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
         return EXG_OK;

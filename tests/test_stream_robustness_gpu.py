@@ -331,3 +331,21 @@ def test_a_text_file_truncated_while_its_rows_are_out(gpu, fastq_mid, tmp_path, 
     r = ShardReader(str(p), "fastq")
     assert r.count() == 200000
     r.close()
+
+
+def test_three_hundred_text_readers_open_at_once(gpu, oracle, tmp_path):
+    """every mapped text file is registered with the SIGBUS guard (exg_map_guard.hpp): until round 5 its table held 256 mappings and the
+    257th file was silently read unguarded — now it holds 4096 and a full table refuses the file (EXG_E_NOMEM)"""
+    from exon_duckdb_amd.reader import ShardReader
+    data = bytes(oracle.synth_fastq(332 * 50))
+    p = tmp_path / "small.fastq"
+    p.write_bytes(data)
+    readers = []
+    try:
+        for _ in range(300):
+            r = ShardReader(str(p), "fastq", device_batch_bytes=64 << 10)
+            assert r.count() == 50          # (the file is mapped when it is first read)
+            readers.append(r)
+    finally:
+        for r in readers:
+            r.close()
