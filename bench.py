@@ -775,6 +775,21 @@ def run_configs(torch, lib, args):
                                     "bitmap) into a digest that must equal the generator's for these rows",
                     "verified": bool(rows == v_rows == n_e2e // REC and got == want)}
 
+        def cold_file_leg(path, n_bytes):
+            # the same file with NONE of it in the page cache (written back, then dropped with posix_fadvise(DONTNEED): what an
+            # unprivileged process can do): COUNT(*) through the reader's buffered pread path — the storage's rate, not the link's
+            fd = os.open(path, os.O_RDONLY)
+            try:
+                os.fsync(fd)
+            except OSError:
+                pass
+            os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+            os.close(fd)
+            n, dt = reader_count(lib, path, "fastq")
+            return {"what": "COUNT(*) of the same file with its pages dropped from the page cache first (fsync + posix_fadvise DONTNEED; buffered pread, "
+                            "8 threads of 8 MiB slices): bound by the scratch file system, not by PCIe", "ms": dt * 1e3, "GB/s": n_bytes / dt / 1e9,
+                    "rows": n, "scratch_dir": os.path.dirname(path)}
+
         def files():
             # ---- end to end: FASTQ file in the page cache -> host DataChunks (PCIe inclusive) -------------------------------
             p_fq = os.path.join(tmp, "e2e.fastq")
@@ -796,7 +811,13 @@ def run_configs(torch, lib, args):
                 "count_only_ms": dt_c * 1e3, "count_only_GB/s": n_e2e / dt_c / 1e9, "frac": None,
                 "verification": "an untimed pass folds every row of every chunk (each string_t dereferenced: length, prefix, pointer, payload "
                                 "bytes) into a digest that must equal the generator's for these rows",
+                "frac_of_h2d_link": n_e2e / dt_r / 1e9 / link[0], "count_only_frac_of_h2d_link": n_e2e / dt_c / 1e9 / link[0],
+                "link_GB/s": {"h2d": link[0], "d2h": link[1]},
                 "verified": bool(rows == n == v_rows == n_e2e // REC and chunks >= (rows + 2047) // 2048 and got == want and bad == 0)}
+            try:
+                out["end_to_end"]["cold_file"] = cold_file_leg(p_fq, n_e2e)
+            except Exception as e:  # noqa: BLE001
+                out["end_to_end"]["cold_file"] = {"error": f"{type(e).__name__}: {e}"}
             try:
                 out["end_to_end_arrow"] = arrow_leg(p_fq, want)
             except Exception as e:  # noqa: BLE001

@@ -30,6 +30,16 @@ GZ_RECORDS=800000 GZ_ONLY_SINGLE=1 rocprofv3 --kernel-trace --stats -d $OUT/${TA
 # FASTA (1 GB), VCF (5 GB), BGZF inflate alone: per-kernel times
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_fasta -o kt --output-format csv -- python3 $ROOT/tools/bench_fasta.py > $OUT/${TAG}_kt_fasta.log 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_vcf -o kt --output-format csv -- python3 $ROOT/tools/bench_vcf.py > $OUT/${TAG}_kt_vcf.log 2>&1
+# the nested VCF columns through the reader (round 6: exg_vcf_nested.hip): VCF-8 (2.08 GB, one all-columns drain) and cohort lines of 100 / 2 504
+# samples with FORMAT GT (1 GB each, two drains); then the HBM counters of the VCF-8 drain, a pass each
+export ONE_PASS=1
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_vcf_nested -o kt --output-format csv -- python3 $ROOT/tools/vcf_nested_probe.py > $OUT/${TAG}_kt_vcf_nested.log 2>&1
+SAMPLES=100 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_vcf_cohort100 -o kt --output-format csv -- python3 $ROOT/tools/vcf_cohort_probe.py > $OUT/${TAG}_kt_vcf_cohort100.log 2>&1
+SAMPLES=2504 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_vcf_cohort2504 -o kt --output-format csv -- python3 $ROOT/tools/vcf_cohort_probe.py > $OUT/${TAG}_kt_vcf_cohort2504.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c -d $OUT/${TAG}_pmcn_$c -o pmc --output-format csv -- python3 $ROOT/tools/vcf_nested_probe.py > $OUT/${TAG}_pmcn_$c.log 2>&1
+done
+unset ONE_PASS
 INFLATE_K=32 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_inflate -o kt --output-format csv -- python3 $ROOT/tools/bench_inflate.py > $OUT/${TAG}_kt_inflate.log 2>&1
 cd $ROOT && bash tools/pmc_inflate.sh $TAG > $OUT/${TAG}_pmcinf.log 2>&1; cd /tmp
 find $OUT -name "*kernel_stats.csv" -newer $OUT/${TAG}_bench.json | head

@@ -51,10 +51,28 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         w.writerows(rows)
     vals = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == c]
     res[c] = sum(vals) / len(vals)
-for leg in ("configs", "zstd", "gzstream", "fasta", "vcf", "inflate", "shapes"):
+for leg in ("configs", "zstd", "gzstream", "fasta", "vcf", "inflate", "shapes", "vcf_nested", "vcf_cohort100", "vcf_cohort2504"):
     st = find(f"{tag}_kt_{leg}/**/*kernel_stats.csv")
     if st:
         shutil.copy(st, os.path.join(prof, f"{tag}_{leg}_kernel_stats.csv"))
+# the nested VCF kernels' HBM traffic (round 6): per dispatch of k_rows / k_info_wide / k_samples / the batched scans, both counters
+nested = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    p = find(f"{tag}_pmcn_{c}/**/*counter_collection.csv")
+    if not p:
+        continue
+    rows = [r for r in csv.DictReader(open(p)) if "exg::vn::" in r["Kernel_Name"] and r["Counter_Name"] == c]
+    if rows:
+        with open(os.path.join(prof, f"{tag}_pmc_{c.lower()}_vcf_nested.csv"), "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+            w.writeheader()
+            w.writerows(rows)
+    for r in rows:
+        k = r["Kernel_Name"].split("(")[0].split("::")[-1]
+        nested.setdefault(k, {}).setdefault(c, []).append(float(r["Counter_Value"]))
+if nested:
+    res["vcf_nested_traffic"] = {k: {c: {"dispatches": len(v), "avg_KiB": sum(v) / len(v), "avg_bytes": sum(v) / len(v) * 1024 * (2 if c == "FETCH_SIZE" else 1)}
+                                     for c, v in d.items()} for k, d in nested.items()}
 # SQ activity counters of k_inflate (tools/pmc_inflate.sh): averages per counter
 import collections
 acc = collections.defaultdict(list)
@@ -85,4 +103,9 @@ if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
     })
     old.pop("sq_counters_per_launch", None)
     json.dump(old, open(os.path.join(prof, "pmc_fastq_fused.json"), "w"), indent=1)
+if res.get("vcf_nested_traffic"):
+    json.dump({"tag": tag, "what": "HBM traffic per dispatch of the nested-VCF kernels over one all-columns drain of the 2.08 GB VCF-8 file (device batches of 256 MiB "
+                                   "= ~5.3 M lines; the first batches of a file are smaller: exg_reader.hpp ramp_bytes): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
+                                   "passes of their own, KiB x 1024, FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md)",
+               "kernels": res["vcf_nested_traffic"]}, open(os.path.join(prof, f"{tag}_vcf_nested_traffic.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
