@@ -28,15 +28,6 @@ struct ColGet {
         return c.d_base + (p - c.payload_base);
     }
 };
-struct ViewGet {
-    const View *v;
-    __device__ __forceinline__ uint32_t len(uint64_t j) const { return v[j].len; }
-    __device__ __forceinline__ const uint8_t *ptr(uint64_t j, uint32_t *len_out) const {
-        View w = v[j];
-        *len_out = w.len;
-        return w.p;
-    }
-};
 template <class G>
 struct LenF {
     G g;
@@ -46,9 +37,6 @@ struct LenF {
 void utf8_goff_from_col(const StrCol &c, const uint32_t *d_row_map, uint64_t n, uint64_t *d_goff, uint64_t *d_tmp,
                         hipStream_t stream) {
     launch_xscan(LenF<ColGet>{ColGet{c, d_row_map}}, n, d_goff, d_tmp, stream);
-}
-void utf8_goff_from_views(const View *d_views, uint64_t n, uint64_t *d_goff, uint64_t *d_tmp, hipStream_t stream) {
-    launch_xscan(LenF<ViewGet>{ViewGet{d_views}}, n, d_goff, d_tmp, stream);
 }
 
 // ---- values copy ----------------------------------------------------------------------------------------------
@@ -174,10 +162,6 @@ static void launch_copy(G g, uint64_t n, const uint64_t *d_goff, uint8_t *d_valu
 void utf8_copy_from_col(const StrCol &c, const uint32_t *d_row_map, uint64_t n, const uint64_t *d_goff, uint8_t *d_values,
                         uint32_t *d_big, uint32_t big_cap, hipStream_t stream) {
     launch_copy(ColGet{c, d_row_map}, n, d_goff, d_values, d_big, big_cap, stream);
-}
-void utf8_copy_from_views(const View *d_views, uint64_t n, const uint64_t *d_goff, uint8_t *d_values, uint32_t *d_big,
-                          uint32_t big_cap, hipStream_t stream) {
-    launch_copy(ViewGet{d_views}, n, d_goff, d_values, d_big, big_cap, stream);
 }
 
 // ---- the payload of ONE projected column (a decoded input whose bytes live only in HBM) ----------------------------------------
@@ -451,95 +435,5 @@ void gather_u32(const uint32_t *d_in, const uint32_t *d_row_map, uint64_t n_out,
 }
 
 // ---- DuckDB vector layouts of the nested columns -------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_views_to_string_t(const View *__restrict__ views, uint64_t m, const uint8_t *d_base,
-                                                           uint64_t payload_base, const uint8_t *d_side, uint64_t side_bytes,
-                                                           uint64_t side_payload_base, uint4 *out) {
-    for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < m; j += (uint64_t)gridDim.x * 256) {
-        const View v = views[j];
-        uint4 r = make_uint4(0, 0, 0, 0);
-        if (v.valid) {
-            r.x = v.len;
-            if (v.len <= EXG_INLINE_LENGTH) {
-                uint32_t w[3] = {0, 0, 0};
-                for (uint32_t i = 0; i < v.len; i++) w[i >> 2] |= (uint32_t)v.p[i] << (8 * (i & 3));
-                r.y = w[0], r.z = w[1], r.w = w[2];
-            } else {
-                r.y = (uint32_t)v.p[0] | ((uint32_t)v.p[1] << 8) | ((uint32_t)v.p[2] << 16) | ((uint32_t)v.p[3] << 24);
-                const bool in_side = d_side && v.p >= d_side && v.p < d_side + side_bytes;
-                const uint64_t p = in_side ? side_payload_base + (uint64_t)(v.p - d_side) : payload_base + (uint64_t)(v.p - d_base);
-                r.z = (uint32_t)p, r.w = (uint32_t)(p >> 32);
-            }
-        }
-        out[j] = r;
-    }
-}
-void views_to_string_t(const View *d_views, uint64_t m, const uint8_t *d_base, uint64_t payload_base, const uint8_t *d_side,
-                       uint64_t side_bytes, uint64_t side_payload_base, exg_string_t *d_out, hipStream_t stream) {
-    if (!m) return;
-    uint32_t grid = (uint32_t)((m + 255) / 256 < 8192 ? (m + 255) / 256 : 8192);
-    hipLaunchKernelGGL(k_views_to_string_t, dim3(grid), dim3(256), 0, stream, d_views, m, d_base, payload_base, d_side, side_bytes,
-                       side_payload_base, (uint4 *)d_out);
-}
-
-__global__ __launch_bounds__(256) void k_list_entries_rows(const uint64_t *__restrict__ goff, uint64_t n, uint64_t chunk_rows,
-                                                           ListEntry *entries) {
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
-        const uint64_t a = goff[i], base = goff[i - i % chunk_rows];
-        entries[i] = ListEntry{a - base, goff[i + 1] - a};
-    }
-}
-void list_entries_rows(const uint64_t *d_goff, uint64_t n, uint64_t chunk_rows, ListEntry *d_entries, hipStream_t stream) {
-    if (!n) return;
-    uint32_t grid = (uint32_t)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-    hipLaunchKernelGGL(k_list_entries_rows, dim3(grid), dim3(256), 0, stream, d_goff, n, chunk_rows, d_entries);
-}
-
-__global__ __launch_bounds__(256) void k_list_entries_elems(const uint64_t *__restrict__ goff, uint64_t m,
-                                                            const uint32_t *__restrict__ elem_row, const uint64_t *__restrict__ outer_goff,
-                                                            uint64_t chunk_rows, ListEntry *entries) {
-    for (uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x; s < m; s += (uint64_t)gridDim.x * 256) {
-        const uint64_t row = elem_row[s];
-        const uint64_t first_elem = outer_goff[row - row % chunk_rows];  // first outer element of the row's DataChunk
-        const uint64_t a = goff[s];
-        entries[s] = ListEntry{a - goff[first_elem], goff[s + 1] - a};
-    }
-}
-void list_entries_elems(const uint64_t *d_goff, uint64_t m, const uint32_t *d_elem_row, const uint64_t *d_outer_goff,
-                        uint64_t chunk_rows, ListEntry *d_entries, hipStream_t stream) {
-    if (!m) return;
-    uint32_t grid = (uint32_t)((m + 255) / 256 < 8192 ? (m + 255) / 256 : 8192);
-    hipLaunchKernelGGL(k_list_entries_elems, dim3(grid), dim3(256), 0, stream, d_goff, m, d_elem_row, d_outer_goff, chunk_rows, d_entries);
-}
-
-__global__ __launch_bounds__(256) void k_chunk_bases_rows(const uint64_t *__restrict__ goff, uint64_t n, uint64_t chunk_rows,
-                                                          uint64_t n_chunks, uint64_t *out) {
-    for (uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x; c <= n_chunks; c += (uint64_t)gridDim.x * 256) {
-        const uint64_t row = c * chunk_rows < n ? c * chunk_rows : n;
-        out[c] = goff[row];
-    }
-}
-void chunk_bases_rows(const uint64_t *d_goff, uint64_t n, uint64_t chunk_rows, uint64_t n_chunks, uint64_t *d_out, hipStream_t stream) {
-    uint32_t grid = (uint32_t)((n_chunks + 256) / 256 < 1024 ? (n_chunks + 256) / 256 : 1024);
-    hipLaunchKernelGGL(k_chunk_bases_rows, dim3(grid), dim3(256), 0, stream, d_goff, n, chunk_rows, n_chunks, d_out);
-}
-__global__ __launch_bounds__(256) void k_chunk_bases_pick(const uint64_t *__restrict__ goff, const uint64_t *__restrict__ idx, uint64_t n_chunks,
-                                                          uint64_t *out) {
-    for (uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x; c <= n_chunks; c += (uint64_t)gridDim.x * 256) out[c] = goff[idx[c]];
-}
-void chunk_bases_pick(const uint64_t *d_goff, const uint64_t *d_idx, uint64_t n_chunks, uint64_t *d_out, hipStream_t stream) {
-    uint32_t grid = (uint32_t)((n_chunks + 256) / 256 < 1024 ? (n_chunks + 256) / 256 : 1024);
-    hipLaunchKernelGGL(k_chunk_bases_pick, dim3(grid), dim3(256), 0, stream, d_goff, d_idx, n_chunks, d_out);
-}
-
-__global__ __launch_bounds__(256) void k_bits_to_bytes(const uint64_t *__restrict__ bits, uint64_t m, uint8_t *out) {
-    for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < m; j += (uint64_t)gridDim.x * 256)
-        out[j] = (uint8_t)((bits[j >> 6] >> (j & 63)) & 1);
-}
-void bits_to_bytes(const uint64_t *d_bits, uint64_t m, uint8_t *d_out, hipStream_t stream) {
-    if (!m) return;
-    uint32_t grid = (uint32_t)((m + 255) / 256 < 8192 ? (m + 255) / 256 : 8192);
-    hipLaunchKernelGGL(k_bits_to_bytes, dim3(grid), dim3(256), 0, stream, d_bits, m, d_out);
-}
-
 }  // namespace arrow
 }  // namespace exg

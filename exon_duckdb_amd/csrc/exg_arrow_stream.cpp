@@ -7,7 +7,7 @@
 //            filter List<Utf8>, info Struct<##INFO keys>, formats List<Struct<##FORMAT keys>>
 // so the unchanged C++ glue of the reference (WTArrowTableFunction::FileTypeBind / InitGlobal / Scan,
 // module.cpp:75-294) can sit on top of it.  Every Arrow buffer is produced on the device (exg_arrow.hip,
-// exg_vcf_typed.hip); this file parses the VCF header and the `filters` text, sizes the buffers, copies
+// exg_vcf_nested.hip); this file parses the VCF header and the `filters` text, sizes the buffers, copies
 // them back and wires the ArrowArray / ArrowSchema structs.
 #include <errno.h>
 #include <stdlib.h>

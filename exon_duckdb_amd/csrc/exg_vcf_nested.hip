@@ -1,4 +1,5 @@
-// exg_vcf_nested.hip — see exg_vcf_nested.hpp.  Semantics restated from exg_vcf_typed.hip (round 3), which restates
+// exg_vcf_nested.hip — see exg_vcf_nested.hpp.  Semantics restated (not the code; parity unpinned beyond
+// test_vcf_record_scan.test:10-19, which pins alt = [<*>], info.indel = NULL, info.dp = 1 for row 1 of vcf/index.vcf):
 // exon 0.2.6 datasources::vcf::{VCFSchemaBuilder, VCFArrayBuilder} over noodles-vcf 0.34.0 (rust/src/arrow_reader.rs:116-153):
 //   * ID split on ';', ALT on ',', FILTER on ';'; "." => empty list;
 //   * INFO "." => every child NULL; else ';'-separated key[=value]; an absent key => NULL, a value "." => NULL; Flag => true

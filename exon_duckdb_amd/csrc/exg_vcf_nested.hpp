@@ -1,6 +1,6 @@
 // exg_vcf_nested.hpp — the reference's nested VCF columns (id / alt / filter LIST(VARCHAR), info STRUCT of the
 // header's ##INFO keys, formats LIST(STRUCT of the ##FORMAT keys)) built on the device in DuckDB's vector layouts, from the
-// tokeniser's string_t columns (exg_vcf.hip).  Round 6 rebuild of exg_vcf_typed.hip's thread-per-row byte loops:
+// tokeniser's string_t columns (exg_vcf.hip).  Round 6 rebuild of round 3's thread-per-row byte loops (exg_vcf_typed.hip, gone):
 //
 //   * keys live in device memory (any number of them: no by-value table), looked up through an open-addressed hash of the
 //     key text built on the host at bind; there is no (row x key) cell table in HBM — values are parsed where they are
@@ -18,7 +18,7 @@
 //   * one batched prefix sum for all list columns of a stage, one read-back of their totals (two for FORMAT keys that
 //     are lists), one contiguous device region per top-level column mirrored by one D2H copy.
 //
-// Semantics: exg_vcf_typed.hip's header comment (exon 0.2.6 VCFArrayBuilder over noodles-vcf 0.34; pinned by
+// Semantics: the header comment of exg_vcf_nested.hip (exon 0.2.6 VCFArrayBuilder over noodles-vcf 0.34; pinned by
 // test_vcf_record_scan.test:10-19 and restated by oracle/pyoracle.py::vcf_typed_rows).
 #pragma once
 #include <hip/hip_runtime.h>
