@@ -299,6 +299,7 @@ struct Emit {
 struct NKeyBuf {  // where the children of one key are in the region of its column
     size_t vals = 0, valid = 0, entries = 0, bases = 0, child_vals = 0, child_valid = 0;
     uint64_t total = 0;  // list keys: child elements of the batch
+    bool zero = false;   // no element of the key is valid in this batch: its values / entries and validity did not travel (NVec::zero)
 };
 struct NGroup {
     char *d = nullptr, *h = nullptr;
@@ -315,6 +316,8 @@ struct NestedOut {
     const uint64_t *d_fgoff = nullptr;  // FORMAT list keys over samples, S + 1 offsets each
     uint64_t err = ~0ull;
     uint64_t side_payload_base = 0;
+    bool group_zero[5] = {false, false, false, false, false};  // id / alt / filter: no element at all; formats: no sample at all
+    const void *h_zero = nullptr;  // the batch's block of zeros (B x 16 bytes): what NVec::zero nodes point at
 };
 struct Layout {  // offsets inside a region: what must be zero first, then what the kernels write whole, then what starts as ones
     struct It {
@@ -323,6 +326,19 @@ struct Layout {  // offsets inside a region: what must be zero first, then what 
     std::vector<It> cat[3];
     size_t end[3] = {0, 0, 0};
     void add(int c, size_t *slot, size_t bytes) { cat[c].push_back(It{slot, bytes}); }
+    // the byte ranges of the region that travel: everything but the buffers whose slot is in `skip`, neighbours merged
+    template <class Skip>
+    std::vector<std::pair<size_t, size_t>> ranges(const Skip &skip) const {
+        std::vector<std::pair<size_t, size_t>> r;
+        for (int c = 0; c < 3; c++)
+            for (const It &it : cat[c]) {
+                if (skip(it.slot)) continue;
+                const size_t len = (it.bytes + 63) & ~(size_t)63;
+                if (!r.empty() && r.back().first + r.back().second == *it.slot) r.back().second += len;
+                else r.emplace_back(*it.slot, len);
+            }
+        return r;
+    }
     size_t finish() {
         size_t off = 0;
         for (int c = 0; c < 3; c++) {
@@ -527,7 +543,11 @@ int build_nested(Emit &em, const ScanCtx &ctx, uint64_t B, const bool *want, boo
         vn::EntryJob *h_jobs = (vn::EntryJob *)em.halloc(n_jobs_max * sizeof(vn::EntryJob));
         vn::EntryJob *d_jobs = (vn::EntryJob *)em.dalloc(n_jobs_max * sizeof(vn::EntryJob));
         uint64_t *h_ctl = (uint64_t *)em.halloc(64);
+        uint32_t *d_any = (uint32_t *)em.dalloc(ik.size() * 4 + 16);
+        uint32_t *h_any = (uint32_t *)em.halloc(ik.size() * 4 + 16);
         if (em.rc) return em.rc;
+        EM_HIP(hipMemsetAsync(d_any, 0, ik.size() * 4 + 16, s));
+        b.key_any = mirror ? d_any : nullptr;
         auto fill_ko = [&](vn::KeyOut *ko, const std::vector<KeyDef> &defs, const std::vector<NKeyBuf> &bufs, char *base) {
             for (size_t q = 0; q < defs.size(); q++) {
                 const NKeyBuf &kb = bufs[q];
@@ -569,6 +589,7 @@ int build_nested(Emit &em, const ScanCtx &ctx, uint64_t B, const bool *want, boo
         vn::entries_rows(d_jobs, nj_rows, n, B, nc, s);
         if (nj > nj_rows) vn::entries_elems(d_jobs + nj_rows, nj - nj_rows, S, sm.srow, d_goff + (uint64_t)vn::kColSamples * (n + 1), n, B, nc, s);
         EM_HIP(hipMemcpyAsync(h_ctl, d_ctl, 24, hipMemcpyDeviceToHost, s));
+        if (mirror && !ik.empty()) EM_HIP(hipMemcpyAsync(h_any, d_any, ik.size() * 4, hipMemcpyDeviceToHost, s));
         EM_HIP(hipStreamSynchronize(s));
         const uint64_t side_used = h_ctl[2];
         if ((h_ctl[1] >> 32) && attempt == 0) {  // side_overflow
@@ -581,8 +602,7 @@ int build_nested(Emit &em, const ScanCtx &ctx, uint64_t B, const bool *want, boo
         t_stage3 = since();
         trace_at("N nested kernels done", n);
         r->nested_ns += (uint64_t)(t_stage3 * 1e6);
-        if (mirror)
-            for (int c = 0; c < 5; c++) r->host_vector_bytes += o->g[c].h ? o->g[c].bytes : 0;
+
         if (trace) {
             size_t bytes = 0;
             for (int c = 0; c < 5; c++) bytes += o->g[c].h ? o->g[c].bytes : 0;
@@ -590,8 +610,35 @@ int build_nested(Emit &em, const ScanCtx &ctx, uint64_t B, const bool *want, boo
                     t_stage2 - t_stage1, t_stage3 - t_stage2, (unsigned long long)n, (unsigned long long)S, bytes / 1048576.0);
         }
         if (mirror) {
-            for (int c = 0; c < 5; c++)
-                if (o->g[c].h && o->g[c].bytes) EM_HIP(hipMemcpyAsync(o->g[c].h, o->g[c].d, o->g[c].bytes, hipMemcpyDeviceToHost, em.d2h ? em.d2h : st->copy_stream));
+            // What is all zeros stays at home (round 6): a list column without a single element in the batch (`formats` of a file without
+            // samples, `id` of a file of "."s), an INFO key that no row of the batch has — 16 bytes a row each that said nothing; their
+            // NVec nodes point every chunk at one block of zeros instead (VCF-8: 32 of a line's 171 bytes)
+            static const bool no_zero_skip = getenv("EXG_VCF_NO_ZERO_SKIP") != nullptr;
+            std::vector<const size_t *> skip;
+            if (!no_zero_skip) {
+                void *hz = em.halloc(B * 16 + 64);
+                if (em.rc) return em.rc;
+                memset(hz, 0, B * 16 + 64);
+                o->h_zero = hz;
+                for (int c = 0; c < 3; c++) o->group_zero[c] = o->l_total[c] == 0;
+                o->group_zero[4] = S == 0;
+                for (size_t q = 0; q < ik.size(); q++) {
+                    NKeyBuf &kb = o->info[q];
+                    kb.zero = ik[q].is_list ? kb.total == 0 : h_any[q] == 0;
+                    if (!kb.zero) continue;
+                    if (ik[q].is_list) skip.push_back(&kb.entries), skip.push_back(&kb.child_vals), skip.push_back(&kb.child_valid);
+                    else skip.push_back(&kb.vals);
+                    skip.push_back(&kb.valid);
+                }
+            }
+            const hipStream_t cs = em.d2h ? em.d2h : st->copy_stream;
+            for (int c = 0; c < 5; c++) {
+                if (!o->g[c].h || !o->g[c].bytes || o->group_zero[c]) continue;
+                for (const auto &rg : L[c].ranges([&](const size_t *slot) { return std::find(skip.begin(), skip.end(), slot) != skip.end(); })) {
+                    EM_HIP(hipMemcpyAsync(o->g[c].h + rg.first, o->g[c].d + rg.first, rg.second, hipMemcpyDeviceToHost, cs));
+                    r->host_vector_bytes += rg.second;
+                }
+            }
             if (side_used) EM_HIP(hipMemcpyAsync(h_side, d_side, (size_t)std::min<uint64_t>(side_used, side_cap), hipMemcpyDeviceToHost, em.d2h ? em.d2h : st->copy_stream));
         }
         break;
@@ -1226,17 +1273,31 @@ int nested_emit(exg_reader *r, const ScanCtx &ctx, Batch *b, const uint32_t *d_r
         return v;
     };
     auto duck_type = [](uint8_t t) { return t == vn::kInt ? EXG_TYPE_INTEGER : t == vn::kFloat ? EXG_TYPE_FLOAT : t == vn::kFlag ? EXG_TYPE_BOOLEAN : EXG_TYPE_VARCHAR; };
-    auto key_vecs = [&](const std::vector<KeyDef> &defs, const std::vector<NKeyBuf> &bufs, const char *h, uint64_t m) {
+    // (a node whose buffers stayed at home — NKeyBuf::zero, NestedOut::group_zero — points at the batch's block of zeros)
+    const char *hz = (const char *)no.h_zero;
+    // (all chunks' children begin at 0 when a list column has no element at all)
+    const uint64_t *zero_bases = nullptr;
+    if (hz && (no.group_zero[0] || no.group_zero[1] || no.group_zero[2] || no.group_zero[4])) {
+        void *zb = em.halloc((no.n_chunks + 1) * 8);
+        if (em.rc) return em.rc;
+        memset(zb, 0, (no.n_chunks + 1) * 8);
+        zero_bases = (const uint64_t *)zb;
+    }
+    auto key_vecs = [&](const std::vector<KeyDef> &defs, const std::vector<NKeyBuf> &bufs, const char *h, uint64_t m, bool all_zero) {
         std::vector<NVec> kids;
         for (size_t q = 0; q < defs.size(); q++) {
             const NKeyBuf &kb = bufs[q];
             const uint32_t es = (uint32_t)key_elem_size(defs[q].type);
+            const bool z = (kb.zero || all_zero) && hz;
             if (!defs[q].is_list) {
-                kids.push_back(leaf(duck_type(defs[q].type), es, m, h + kb.vals, h + kb.valid));
+                kids.push_back(leaf(duck_type(defs[q].type), es, m, z ? hz : h + kb.vals, z ? hz : h + kb.valid));
+                kids.back().zero = z;
             } else {
-                NVec v = leaf(EXG_TYPE_LIST, 16, m, h + kb.entries, h + kb.valid);
-                v.child_base = (const uint64_t *)(h + kb.bases);
-                v.children.push_back(leaf(duck_type(defs[q].type), es, kb.total, h + kb.child_vals, h + kb.child_valid));
+                NVec v = leaf(EXG_TYPE_LIST, 16, m, z ? hz : h + kb.entries, z ? hz : h + kb.valid);
+                v.zero = z;
+                v.child_base = all_zero ? zero_bases : (const uint64_t *)(h + kb.bases);
+                v.children.push_back(leaf(duck_type(defs[q].type), es, kb.total, z ? hz : h + kb.child_vals, z ? hz : h + kb.child_valid));
+                v.children.back().zero = z;
                 kids.push_back(std::move(v));
             }
         }
@@ -1245,22 +1306,27 @@ int nested_emit(exg_reader *r, const ScanCtx &ctx, Batch *b, const uint32_t *d_r
     for (int c = 0; c < 3; c++) {
         if (!want[c]) continue;
         const char *h = no.g[c].h;
-        NVec v = leaf(EXG_TYPE_LIST, 16, n, h + no.l_entries[c], nullptr);
-        v.child_base = (const uint64_t *)(h + no.l_bases[c]);
-        v.children.push_back(leaf(EXG_TYPE_VARCHAR, 16, no.l_total[c], h + no.l_elems[c], nullptr));  // (id / alt / filter are not percent-decoded)
+        const bool z = no.group_zero[c] && hz;
+        NVec v = leaf(EXG_TYPE_LIST, 16, n, z ? hz : h + no.l_entries[c], nullptr);
+        v.zero = z;
+        v.child_base = z ? zero_bases : (const uint64_t *)(h + no.l_bases[c]);
+        v.children.push_back(leaf(EXG_TYPE_VARCHAR, 16, no.l_total[c], z ? hz : h + no.l_elems[c], nullptr));  // (id / alt / filter are not percent-decoded)
+        v.children.back().zero = z;
         b->nested[(size_t)top[c]] = std::move(v);
     }
     if (want[3]) {
         NVec info = leaf(EXG_TYPE_STRUCT, 0, n, nullptr, nullptr);
-        info.children = key_vecs(st->info_keys, no.info, no.g[3].h, n);
+        info.children = key_vecs(st->info_keys, no.info, no.g[3].h, n, false);
         b->nested[7] = std::move(info);
     }
     if (want[4]) {
         const char *h = no.g[4].h;
-        NVec fl = leaf(EXG_TYPE_LIST, 16, n, h + no.f_entries, nullptr);
-        fl.child_base = (const uint64_t *)(h + no.f_bases);
+        const bool z = no.group_zero[4] && hz;  // (no line of the batch has a sample: every entry {0, 0}, every child empty)
+        NVec fl = leaf(EXG_TYPE_LIST, 16, n, z ? hz : h + no.f_entries, nullptr);
+        fl.zero = z;
+        fl.child_base = z ? zero_bases : (const uint64_t *)(h + no.f_bases);
         NVec item = leaf(EXG_TYPE_STRUCT, 0, no.S, nullptr, nullptr);
-        item.children = key_vecs(st->format_keys, no.format, h, no.S);
+        item.children = key_vecs(st->format_keys, no.format, h, no.S, z);
         fl.children.push_back(std::move(item));
         b->nested[8] = std::move(fl);
     }

@@ -237,9 +237,11 @@ extern "C" int exg_schema_of(exg_reader *r, exg_schema *out) {
 static void slice_vector(const NVec &v, uint64_t e0, uint64_t e1, uint64_t chunk, ChunkKeep *keep, exg_vector *out) {
     memset(out, 0, sizeof *out);
     out->length = e1 - e0;
-    out->data = v.data ? (void *)((const char *)v.data + e0 * v.elem) : nullptr;
+    out->data = v.data ? (void *)((const char *)v.data + (v.zero ? 0 : e0 * v.elem)) : nullptr;
     if (v.validity) {
-        if ((e0 & 63) == 0) {
+        if (v.zero) {
+            out->validity = (uint64_t *)v.validity;
+        } else if ((e0 & 63) == 0) {
             out->validity = (uint64_t *)v.validity + e0 / 64;
         } else {
             const uint64_t n = e1 - e0, words = (n + 63) / 64, sh = e0 & 63;

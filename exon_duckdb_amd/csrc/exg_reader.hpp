@@ -290,6 +290,9 @@ struct NVec {
     uint32_t elem = 0;                   // bytes per element
     uint64_t length = 0;
     const uint64_t *child_base = nullptr;  // LIST: where every chunk's elements begin in children[0]
+    // round 6: no element of this node is valid / non-empty in the whole batch — data and validity are ONE block of zeros that every
+    // chunk's slice points at (it never crossed PCIe): a LIST's entries are all {0, 0}, a scalar's values 0 and its bits NULL
+    bool zero = false;
     std::vector<NVec> children;
 };
 

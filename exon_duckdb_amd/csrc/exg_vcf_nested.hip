@@ -224,6 +224,11 @@ __device__ bool put_value(const Key &k, const KeyOut &o, const Txt &t, int vs, i
     return true;
 }
 
+// "this key has a valid element in the batch": a word per key, written by whoever finds one first (read first: one store per key, not per wave)
+__device__ __forceinline__ void note_any(uint32_t *key_any, uint32_t q) {
+    if (key_any && !__builtin_nontemporal_load(key_any + q)) key_any[q] = 1u;
+}
+
 // index of the key t[s, s + klen) with hash h, or -1
 __device__ __forceinline__ int lookup(const KeyTab &kt, uint32_t h, const Txt &t, int s, int klen) {
     uint32_t slot = key_slot(h, kt.slot_mask);
@@ -449,7 +454,10 @@ __global__ __launch_bounds__(kRowThreads) void k_rows(Batch a, KeyTab kt_in, con
             }
             const unsigned long long m = __ballot(valid);
             const uint64_t w0 = j0 + (tid & ~63u);
-            if ((tid & 63u) == 0 && w0 < a.n) o.valid[w0 >> 6] = m;
+            if ((tid & 63u) == 0 && w0 < a.n) {
+                o.valid[w0 >> 6] = m;
+                if (m) note_any(a.key_any, q);
+            }
         }
     }
 }
@@ -680,8 +688,10 @@ __global__ __launch_bounds__(256) void k_info_wide(Batch a, KeyTab kt, const Key
                         if (k.is_list) (void)put_value<kCount>(k, KeyOut{nullptr, nullptr, nullptr, nullptr}, t, eq + 1, e, eq >= 0, j, j, env, f.hptr);
                     } else {
                         const KeyOut o = ko[q];
-                        if (put_value<kWrite>(k, o, t, eq + 1, e, eq >= 0, j, j, env, f.hptr))
+                        if (put_value<kWrite>(k, o, t, eq + 1, e, eq >= 0, j, j, env, f.hptr)) {
                             atomicOr(reinterpret_cast<unsigned long long *>(o.valid) + (j >> 6), 1ull << (j & 63));
+                            note_any(a.key_any, (uint32_t)q);
+                        }
                     }
                 }
             });

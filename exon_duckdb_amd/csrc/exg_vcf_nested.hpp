@@ -90,6 +90,7 @@ struct Batch {
     const uint64_t *goff;  // goff[c * goff_stride + j], n + 1 entries per column (after the scan)
     uint64_t goff_stride;
     exg_string_t *elems[3];  // WRITE: the elements of id / alt / filter
+    uint32_t *key_any;  // WRITE: key_any[q] = 1 when INFO key q has a valid element in this batch (NULL: not wanted): a child without one does not travel
     unsigned long long *mid_rows;  // COUNT: += rows whose INFO field is longer than k_rows' small row (64 bytes) but not than its large one (NULL: not counted)
 };
 

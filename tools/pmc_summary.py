@@ -8,7 +8,7 @@ profiles/pmc_fastq_fused.json (read by bench.py for roofline.traffic).  rocprofv
 FETCH_SIZE/WRITE_SIZE in kilobytes (x1024 -> bytes); on gfx950 FETCH_SIZE under-reports wide
 streaming reads by 2x (MI355X_MICROARCH.md, HBM section), so reads are doubled.
 """
-import csv, glob, json, os, shutil, sys
+import csv, glob, json, os, re, shutil, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01_d"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -68,7 +68,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             w.writeheader()
             w.writerows(rows)
     for r in rows:
-        k = r["Kernel_Name"].split("(")[0].split("::")[-1]
+        mm = re.search(r"(k_[a-z0-9_]+(<[^>]*>)?)", r["Kernel_Name"])
+        k = mm.group(1) if mm else r["Kernel_Name"][:40]
         nested.setdefault(k, {}).setdefault(c, []).append(float(r["Counter_Value"]))
 if nested:
     res["vcf_nested_traffic"] = {k: {c: {"dispatches": len(v), "avg_KiB": sum(v) / len(v), "avg_bytes": sum(v) / len(v) * 1024 * (2 if c == "FETCH_SIZE" else 1)}
