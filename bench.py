@@ -892,7 +892,28 @@ def run_configs(torch, lib, args):
             pv_rows, _, p_got, _ = reader_digest(lib, p_vcf, "vcf", columns=proj)
             nested_s = st_r["nested_ns"] * 1e-9
             d2h = st_r["host_vector_bytes"]
+            # the reference's OWN boundary on the same file: new_reader -> Arrow C stream with the nested columns as Arrow arrays
+            # (List<Utf8>, Struct, List<Struct>: converted from the DuckDB layouts on the device), every record batch pulled and released in C
+            def arrow_drain(with_digest):
+                rows_a, nb, dg, el = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+                err = C.create_string_buffer(512)
+                t0 = time.perf_counter()
+                rc = tl.exon_tf_drain_arrow_vcf(p_vcf.encode(), None, None, with_digest, C.byref(rows_a), C.byref(nb), C.byref(dg), C.byref(el), err, 512)
+                dt = time.perf_counter() - t0
+                assert rc == 0, err.value
+                return int(rows_a.value), int(nb.value), int(dg.value), int(el.value), dt
+            try:
+                arrow_drain(0)
+                a_rows, a_batches, _, a_elems, dt_a = min((arrow_drain(0) for _ in range(3)), key=lambda x: x[4])
+                av_rows, _, a_dg, _, _ = arrow_drain(1)
+                arrow_vcf = {"what": "new_reader(file_format='vcf') -> Arrow C stream, the reference's schema with its nested arrays, every record batch pulled "
+                                     "and released by a C loop (PCIe inclusive; the nested columns are converted to Arrow's layouts on the device)",
+                             "ms": dt_a * 1e3, "GB/s": n_vcf / dt_a / 1e9, "records_per_s": a_rows / dt_a, "record_batches": a_batches, "list_elements": a_elems,
+                             "verified": bool(a_rows == av_rows == n_lines and a_dg == int(e_dg.value))}
+            except Exception as e:  # noqa: BLE001
+                arrow_vcf = {"error": f"{type(e).__name__}: {e}"}
             out["end_to_end_vcf"] = {
+                "arrow_boundary": arrow_vcf,
                 # the nested columns' chain on the device (exg_vcf_nested.hip: counting passes, prefix sums, children — wall time on
                 # the reader's thread up to the point where the vectors start for the host, launches and the two syncs included)
                 "nested": {"what": "id / alt / filter LIST(VARCHAR), info STRUCT, formats LIST(STRUCT) of every batch made on the device: counts, "

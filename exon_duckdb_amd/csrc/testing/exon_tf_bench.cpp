@@ -454,6 +454,66 @@ extern "C" int exon_tf_drain_arrow_fastq(const char *path, const char *compressi
     return rc;
 }
 
+// The same for read_vcf's stream (the reference's schema: chrom Utf8, pos Int64, id List<Utf8>, ref Utf8, alt List<Utf8>, qual Float32,
+// filter List<Utf8>, info Struct, formats List<Struct>): every record batch pulled through the Arrow callbacks and released.
+// with_digest: chrom, pos and ref of every row folded into the digest exon_tf_expect_vcf_file predicts; *list_elems = elements of
+// the id + alt + filter lists and samples of formats in all (their last offsets: what a consumer of the nested arrays walks).
+extern "C" int exon_tf_drain_arrow_vcf(const char *path, const char *compression, const char *filters, int with_digest, uint64_t *n_rows,
+                                       uint64_t *n_batches, uint64_t *digest, uint64_t *list_elems, char *err, size_t err_cap) {
+    if (!path || !n_rows || !n_batches || !digest || !list_elems) return EXG_E_INVALID_ARG;
+    *n_rows = *n_batches = *digest = *list_elems = 0;
+    auto say = [&](const char *m) {
+        if (err && err_cap) snprintf(err, err_cap, "%s", m ? m : "");
+    };
+    ArrowArrayStream stream;
+    memset(&stream, 0, sizeof stream);
+    const ReaderResult rr = new_reader(&stream, path, EXG_VECTOR_SIZE, compression, "vcf", filters);
+    if (rr.error) {
+        say(rr.error);
+        return EXG_E_IO;
+    }
+    uint64_t k = 0, acc = 0, elems = 0;
+    int rc = EXG_OK;
+    for (;;) {
+        ArrowArray a;
+        memset(&a, 0, sizeof a);
+        if (stream.get_next(&stream, &a) != 0) {
+            say(stream.get_last_error ? stream.get_last_error(&stream) : "get_next failed");
+            rc = EXG_E_PARSE;
+            break;
+        }
+        if (!a.release) break;  // end of stream
+        if (a.n_children >= 9) {
+            for (int c : {2, 4, 6, 8}) {  // List arrays: offsets[length] - offsets[0] elements
+                const ArrowArray *ch = a.children[c];
+                const int32_t *off = (const int32_t *)ch->buffers[1] + ch->offset;
+                elems += (uint64_t)(off[ch->length] - off[0]);
+            }
+            if (with_digest) {
+                const ArrowArray *chrom = a.children[0], *pos = a.children[1], *ref = a.children[3];
+                const int32_t *co = (const int32_t *)chrom->buffers[1] + chrom->offset, *ro = (const int32_t *)ref->buffers[1] + ref->offset;
+                const uint8_t *cv = (const uint8_t *)chrom->buffers[2], *rv = (const uint8_t *)ref->buffers[2];
+                const int64_t *pv = (const int64_t *)pos->buffers[1] + pos->offset;
+                for (int64_t i = 0; i < a.length; i++) {
+                    uint64_t h = mix64(k + (uint64_t)i);
+                    h = fold_bytes(h, cv + co[i], (size_t)(co[i + 1] - co[i]));
+                    h = fold_bytes(h, (const uint8_t *)&pv[i], 8);
+                    h = fold_bytes(h, rv + ro[i], (size_t)(ro[i + 1] - ro[i]));
+                    acc += mix64(h);
+                }
+            }
+        }
+        k += (uint64_t)a.length;
+        *n_batches += 1;
+        a.release(&a);
+    }
+    stream.release(&stream);
+    *n_rows = k;
+    *digest = acc;
+    *list_elems = elems;
+    return rc;
+}
+
 // ---- host-only introspection (no device is touched): what the CPU tests check ---------------------------------------
 // The postfix program a `filters` text compiles to, e.g.  "name = 'a' | pos >= 5 | AND".  Columns are those of the
 // format's schema (VCF: the flat ones; nested columns are refused like in new_reader).  Returns 0, or -1 with the
