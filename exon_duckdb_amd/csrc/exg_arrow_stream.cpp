@@ -1186,6 +1186,13 @@ int nested_prepare(exg_reader *r) {
     parse_vcf_header((const char *)r->file->p, (size_t)r->vcf_header_bytes, &st->info_keys, &st->format_keys);
     int rc;
     if ((rc = upload_keys(r, st->info_keys, &st->nk_info)) || (rc = upload_keys(r, st->format_keys, &st->nk_format))) return rc;
+    // A wide header makes wide rows of vectors whatever the lines hold — every key is a child with a value slot per row (per sample)
+    // and, on the device, a count and an offset per row for each list key: a 1 000-key header over 256 MiB of SHORT lines would ask
+    // for tens of GB of both.  The device batch shrinks with the number of keys (64 keys: as before).
+    {
+        const uint64_t keys = st->info_keys.size() + st->format_keys.size();
+        if (keys > 64) r->device_batch_bytes = std::max<uint64_t>(8ull << 20, (r->device_batch_bytes * 64 / keys) & ~0xFFFFFull);
+    }
     exg_type *t = st->type_roots;
     t[0] = leaf(EXG_TYPE_VARCHAR, "chrom", 0);
     t[1] = leaf(EXG_TYPE_BIGINT, "pos", 0);

@@ -289,3 +289,40 @@ def test_small_rows_with_a_few_longer_fields(gpu, oracle, tmp_path, device_batch
     lens = [len(l.split(b"\t")[7]) for l in lines]
     assert sum(64 < x <= 128 for x in lens) * 64 <= len(lines) and any(64 < x <= 128 for x in lens) and any(x > 128 for x in lens)
     check(oracle, tmp_path, data, device_batch_bytes=device_batch)
+
+
+def test_wide_header_over_many_short_lines(gpu, oracle, tmp_path):
+    # 1 000 declared keys, lines that carry two of them: the children are a value slot per key and row whatever the lines hold, so the
+    # device batch shrinks with the header (a 256 MiB batch of such lines would ask for tens of GB of vectors)
+    from exon_duckdb_amd.reader import ShardReader
+    hdr, info, fmt = make_header(1000, 0, 0)
+    ints = [i[0].encode() for i in info if i[1] == "Integer" and i[2] == "1"]
+    n = 120000
+    lines = [b"%d\t%d\t.\tA\tC\t.\t.\t%s=%d;%s=%d" % (k % 22 + 1, k + 1, ints[k % len(ints)], k, ints[(k + 7) % len(ints)], -k) for k in range(n)]
+    data = hdr + b"\n".join(lines) + b"\n"
+    p = tmp_path / "ws.vcf"
+    p.write_bytes(data)
+    r = ShardReader(str(p), "vcf")
+    assert r.stats()["device_batch_bytes"] <= (256 << 20) * 64 // 1000
+    rows = 0
+    import ctypes as C
+    from exon_duckdb_amd.table_function import Chunk, decode_vector
+    # (120 000 rows x 1 000 children in Python would take minutes: the first and the last chunk are decoded, the others counted)
+    first = last = None
+    while True:
+        ch = Chunk()
+        assert r._l.exg_next_chunk(r._r, C.byref(ch)) == 0
+        if ch.n_rows == 0:
+            break
+        if first is None or rows + int(ch.n_rows) == n:
+            info_col = decode_vector(ch.vectors[7].contents, r.trees[7])
+            if first is None:
+                first = info_col[0]
+            last = info_col[-1]
+        rows += int(ch.n_rows)
+        r._l.exg_release_chunk(r._r, C.byref(ch))
+    r.close()
+    assert rows == n
+    k = n - 1
+    assert first[ints[0].decode()] == 0 and first[ints[7 % len(ints)].decode()] == 0 and sum(v is not None for v in first.values()) <= 2
+    assert last[ints[k % len(ints)].decode()] == k and last[ints[(k + 7) % len(ints)].decode()] == -k
