@@ -701,6 +701,11 @@ __global__ __launch_bounds__(256) void k_info_wide(Batch a, KeyTab kt, const Key
 
 // ---- k_samples -------------------------------------------------------------------------------------------------------------
 static constexpr uint32_t kMaxPos = 1024;  // FORMAT positions of one line (a line with more is a record error)
+static constexpr uint32_t kFmtCache = 256;  // bytes of the line before's FORMAT string a wavefront keeps (with its positions: key_at)
+struct FmtCache {
+    uint32_t len, n_pos;
+    uint8_t bytes[kFmtCache];
+};
 
 // 64 consecutive validity bits from element `base` on (words shared with neighbours: OR)
 __device__ __forceinline__ void or_bits64(uint64_t *words, uint64_t base, unsigned long long m) {
@@ -715,9 +720,13 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_samples(Batch a, Samples sm, KeyTab kt, const KeyOut *__restrict__ ko, uint32_t rpg) {
     __shared__ WaveLds s_w[4];
     __shared__ int16_t s_key_at[4][kMaxPos];
+    __shared__ FmtCache s_fc[4];
     const uint32_t wv = threadIdx.x >> 6, lane = lane_id();
     WaveLds &w = s_w[wv];
     int16_t *key_at = s_key_at[wv];
+    FmtCache &fc = s_fc[wv];
+    if (lane == 0) fc.len = 0, fc.n_pos = 0;
+    wave_sync();
     const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + wv, n_waves = (uint64_t)gridDim.x * 4;
     Env env;
     env.ctl = a.ctl;
@@ -779,34 +788,95 @@ __global__ __launch_bounds__(256) void k_samples(Batch a, Samples sm, KeyTab kt,
                 continue;
             }
             const uint64_t S0 = a.goff[kColSamples * a.goff_stride + j];
-            // FORMAT: lane = key, by position; a key that stands twice keeps its first position
-            const int T0 = wave_first_sep(f, 0, (int)f.len, 0x09090909u);
-            const uint32_t n_pos = wave_items(w, f, 0, T0, ':', [&](const Txt &t, bool act, int s, int e, uint32_t ord) {
-                if (!act || ord >= kMaxPos) return;
-                uint32_t h = kKeyHashSeed;
-                for (int i = s; i < e; i++) h = key_hash_step(h, t.b(i));
-                key_at[ord] = (int16_t)(e > s ? lookup(kt, h, t, s, e - s) : -1);
-            });
-            if (n_pos > kMaxPos) {
-                if (lane == 0) report(env, j);
-                continue;
-            }
-            wave_sync();
-            for (uint32_t p = lane; p < n_pos; p += 64) {
-                const int q = key_at[p];
-                bool dup = false;
-                for (uint32_t p2 = 0; p2 < p && !dup && q >= 0; p2++) dup = key_at[p2] == q;
-                if (dup) key_at[p] = -1;  // (first occurrences are never rewritten: the search above always finds one)
-            }
-            wave_sync();
-            if (T0 >= (int)f.len) continue;
-            wave_items(w, f, T0 + 1, (int)f.len, '\t', [&](const Txt &t, bool act, int s, int e, uint32_t ord) {
-                const uint64_t idx = S0 + ord;
-                const uint64_t base_idx = S0 + (ord - lane_id());
-                if (MODE == kWrite && sm.srow && act) sm.srow[idx] = (uint32_t)j;
+            // ONE walk over the field's tab-separated items: item 0 is FORMAT (lane 0 of the first step), the samples follow.  FORMAT is
+            // resolved when the first step arrives — out of the staged bytes, lane = key start; the line before's FORMAT and its
+            // positions are kept per wavefront (a cohort file repeats one FORMAT string for millions of lines: the lookups were a third
+            // of a 100-sample line's time)
+            uint32_t n_pos = 0;
+            bool bad_line = false;
+            wave_items(w, f, 0, (int)f.len, '\t', [&](const Txt &t, bool act, int s, int e, uint32_t ord) {
+                const bool first_step = ord == lane_id();  // (item 0 is lane 0's)
+                if (first_step) {
+                    const int fs = __builtin_amdgcn_readlane(s, 0), fe = __builtin_amdgcn_readlane(e, 0), flen = fe - fs;
+                    bool hit = false;
+                    if (flen > 0 && flen <= (int)kFmtCache && fe <= t.hi && (uint32_t)flen == fc.len) {  // the same string as the line before?
+                        bool same = true;
+                        for (int i = (int)lane_id(); i < flen; i += 64) same = same && t.b(fs + i) == fc.bytes[i];
+                        hit = __ballot(!same) == 0ull;
+                    }
+                    if (hit) {
+                        n_pos = fc.n_pos;
+                    } else if (fe <= t.hi) {
+                        // lane = byte, 64 at a time: a key starts at the field's first byte and behind every ':'; its position is the
+                        // number of ':' in front of it; the lane walks its key (hash + lookup)
+                        uint32_t before = 0;
+                        bool prev_colon = true;
+                        for (int base = 0; base <= flen; base += 64) {  // (position flen too: a key may be the empty string behind a last ':')
+                            const int i = base + (int)lane_id();
+                            const bool colon = i < flen && t.b(fs + i) == ':';
+                            const unsigned long long cm = __ballot(colon);
+                            const bool start = i <= flen && (lane_id() ? ((cm >> (lane_id() - 1)) & 1ull) != 0 : prev_colon);
+                            const uint32_t pos = before + (uint32_t)__popcll(cm & ((1ull << lane_id()) - 1ull));
+                            if (start && pos < kMaxPos) {
+                                int ke = fs + i;
+                                uint32_t h = kKeyHashSeed;
+                                while (ke < fe && t.b(ke) != ':') h = key_hash_step(h, t.b(ke)), ke++;
+                                key_at[pos] = (int16_t)(ke > fs + i ? lookup(kt, h, t, fs + i, ke - (fs + i)) : -1);
+                            }
+                            before += (uint32_t)__popcll(cm);
+                            prev_colon = ((cm >> 63) & 1ull) != 0;
+                        }
+                        n_pos = before + 1;
+                    } else {
+                        // (a FORMAT field that does not fit a staged piece — more than ~1 100 bytes: one lane walks it)
+                        uint32_t np = 0;
+                        if (lane_id() == 0) {
+                            int ks = fs;
+                            for (;;) {
+                                int ke = ks;
+                                uint32_t h = kKeyHashSeed;
+                                while (ke < fe && t.b(ke) != ':') h = key_hash_step(h, t.b(ke)), ke++;
+                                if (np < kMaxPos) key_at[np] = (int16_t)(ke > ks ? lookup(kt, h, t, ks, ke - ks) : -1);
+                                np++;
+                                if (ke >= fe) break;
+                                ks = ke + 1;
+                            }
+                        }
+                        n_pos = (uint32_t)__builtin_amdgcn_readlane((int)np, 0);
+                    }
+                    if (!hit) {
+                        wave_sync();
+                        if (n_pos > kMaxPos) {
+                            bad_line = true;  // more FORMAT positions than a line may have: a record error, never a dropped value
+                            fc.len = 0;
+                            if (lane_id() == 0) report(env, j);
+                        } else {
+                            // a key that stands twice keeps its first position
+                            for (uint32_t p = lane_id(); p < n_pos; p += 64) {
+                                const int q = key_at[p];
+                                bool dup = false;
+                                for (uint32_t p2 = 0; p2 < p && !dup && q >= 0; p2++) dup = key_at[p2] == q;
+                                if (dup) key_at[p] = -1;  // (first occurrences are never rewritten: the search above always finds one)
+                            }
+                            // ... and the string is remembered for the next line
+                            fc.len = 0;
+                            if (flen > 0 && flen <= (int)kFmtCache && fe <= t.hi) {
+                                for (int i = (int)lane_id(); i < flen; i += 64) fc.bytes[i] = (uint8_t)t.b(fs + i);
+                                fc.len = (uint32_t)flen;
+                                fc.n_pos = n_pos;
+                            }
+                        }
+                        wave_sync();
+                    }
+                }
+                if (bad_line) return;
+                const bool smp = act && ord >= 1;  // (ord 0 is FORMAT itself)
+                const uint64_t idx = S0 + ord - 1;
+                const uint64_t base_idx = first_step ? S0 : S0 + (ord - lane_id()) - 1;
+                if (MODE == kWrite && sm.srow && smp) sm.srow[idx] = (uint32_t)j;
                 int cur = s;
                 for (uint32_t p = 0; p < n_pos; p++) {
-                    const bool has = act && cur <= e;
+                    const bool has = smp && cur <= e;
                     if (!__ballot(has)) break;
                     int ve = cur;
                     if (has)
@@ -819,7 +889,9 @@ __global__ __launch_bounds__(256) void k_samples(Batch a, Samples sm, KeyTab kt,
                         } else {
                             const KeyOut o = ko[q];
                             const bool valid = has && put_value<kWrite>(k, o, t, cur, ve, true, idx, j, env, f.hptr);
-                            or_bits64(o.valid, base_idx, __ballot(valid));
+                            unsigned long long vm = __ballot(valid);
+                            if (first_step) vm >>= 1;  // (lane 0 held FORMAT: sample 0 is lane 1's)
+                            or_bits64(o.valid, base_idx, vm);
                         }
                     }
                     cur = ve + 1;

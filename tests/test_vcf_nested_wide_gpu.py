@@ -326,3 +326,18 @@ def test_wide_header_over_many_short_lines(gpu, oracle, tmp_path):
     k = n - 1
     assert first[ints[0].decode()] == 0 and first[ints[7 % len(ints)].decode()] == 0 and sum(v is not None for v in first.values()) <= 2
     assert last[ints[k % len(ints)].decode()] == k and last[ints[(k + 7) % len(ints)].decode()] == -k
+
+
+def test_format_strings_change_from_line_to_line(gpu, oracle, tmp_path):
+    # the line before's FORMAT string is kept per wavefront: lines that repeat it, change it, end it with ':' (an empty last key),
+    # make it exactly 64 / 65 / 256 / 257 bytes, or longer than a staged piece
+    hdr, info, fmt = make_header(2, 90, 2)
+    f = [x[0].encode() for x in fmt]
+    def line(k, keys, vals=b"1"):
+        return b"1\t%d\t.\tA\tC\t.\t.\t.\t" % (k + 1) + b":".join(keys) + b"\t" + b":".join([vals] * max(1, len(keys))) + b"\t."
+    pad = lambda n: [b"Z" * n]   # noqa: E731  (an undeclared key of n bytes)
+    shapes_ = [f[:1], f[:1], f[:3], f[:3], f[:1], f[:2] + [b""], f[:2] + [b""], [b""], f[:1] * 3, f[2:5],
+               f[:1] + pad(62), f[:1] + pad(63), f[:1] + pad(254), f[:1] + pad(255), f[:80], f[:80], f[:1] + pad(1500), f[:1] + pad(1500), f[:1]]
+    lines = [line(k, shapes_[k % len(shapes_)]) for k in range(len(shapes_) * 40)]
+    data = hdr + b"\n".join(lines) + b"\n"
+    check(oracle, tmp_path, data)
