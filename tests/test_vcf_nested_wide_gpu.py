@@ -87,7 +87,7 @@ def make_line(rng, k, info, fmt, n_samples, n_entries, n_fmt_keys, long_strings=
             if r < 0.05:
                 samples.append(b".")
                 continue
-            nv = len(names) if r < 0.8 else rng.randrange(1, len(names) + 1)
+            nv = len(names) if r < 0.8 or not names else rng.randrange(1, len(names) + 1)
             vals = []
             for nm in names[:nv]:
                 d = [f for f in fmt if f[0].encode() == nm]
