@@ -341,3 +341,16 @@ def test_format_strings_change_from_line_to_line(gpu, oracle, tmp_path):
     lines = [line(k, shapes_[k % len(shapes_)]) for k in range(len(shapes_) * 40)]
     data = hdr + b"\n".join(lines) + b"\n"
     check(oracle, tmp_path, data)
+
+
+@pytest.mark.parametrize("first", range(0, 48, 8))
+def test_soak_seeds_against_the_oracle(gpu, oracle, tmp_path, first):
+    # tools/vcf_nested_soak.py's first seeds: random headers (0 - 600 INFO keys, 0 - 90 FORMAT keys, 0 - 300 samples), random lines,
+    # structural mutations inside the INFO / FORMAT / sample fields, random chunk and device batch sizes: the rows in front of the
+    # first value error and whether there is one must be the oracle's
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import vcf_nested_soak
+    for seed in range(first, first + 8):
+        assert vcf_nested_soak.run_seed(seed, str(tmp_path / "s.vcf")) is None

@@ -15,7 +15,6 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402,F401  (first: the HIP runtime the library binds to)
 from oracle import pyoracle  # noqa: E402
-from exon_duckdb_amd import ExgError  # noqa: E402
 from exon_duckdb_amd.reader import ShardReader  # noqa: E402
 from exon_duckdb_amd.table_function import Chunk, decode_vector  # noqa: E402
 from test_arrow_stream_gpu import same  # noqa: E402
@@ -73,54 +72,65 @@ def read_rows(path, **kw):
     return out, failed
 
 
+def make_input(seed):
+    """-> (file bytes, reader keywords, header shape) of a seed"""
+    rng = random.Random(seed)
+    n_info = rng.choice([0, 1, 3, 8, 9, 31, 32, 33, 60, 150, 600])
+    n_fmt = rng.choice([0, 1, 4, 12, 90])
+    n_smp = rng.choice([0, 0, 1, 3, 70, 300]) if n_fmt or rng.random() < 0.3 else 0
+    hdr, info, fmt = make_header(n_info, n_fmt, n_smp, seed=seed)
+    n_fk = rng.choice([1, 2, 6, 60])
+    n_lines = min(rng.choice([1, 7, 64, 65, 300, 1200]), max(5, 150000 // max(1, n_smp * min(n_fk, max(1, n_fmt)))))
+    lines, rate = [], rng.choice([0.0, 0.004, 0.02, 0.02, 0.1, 1.0])   # (a value error ends the scan: few mutated lines -> deep files)
+    for k in range(n_lines):
+        ln = make_line(rng, k, info, fmt, n_smp, rng.choice([0, 1, 2, 5, 20, 120]), n_fk if rng.random() < 0.8 else rng.choice([1, 2, 6, 60]), long_strings=rng.random() < 0.03)
+        lines.append(mutate_fields(ln, rng) if rng.random() < rate else ln)
+    data = hdr + b"\n".join(lines) + b"\n"
+    kw = dict(batch_rows=rng.choice([64, 2048]), device_batch_bytes=rng.choice([0, 0, 16 << 10, 200 << 10]))
+    return data, kw, (n_info, n_fmt, n_smp)
+
+
+def run_seed(seed, path, dry=False):
+    """None when the reader and the oracle agree on the seed's file, else what differs"""
+    data, kw, shape = make_input(seed)
+    want, err_row = pyoracle.vcf_typed_rows(data)
+    tok = pyoracle.vcf_parse(data, want_string_t=False)
+    with open(path, "wb") as f:
+        f.write(data)
+    if dry:   # the generator and the oracle alone (no GPU)
+        return None
+    got, failed = read_rows(path, **kw)
+    if len(got) == len(want) and all(same(g, e) for g, e in zip(got, want)) and failed == (err_row is not None or bool(tok.error_code)):
+        return None
+    bad = next((i for i, (g, e) in enumerate(zip(got, want)) if not same(g, e)), None)
+    msg = (f"seed {seed}: rows {len(got)} / {len(want)}, failed {failed} (oracle: error row {err_row}, tokeniser {tok.error_code}), "
+           f"first bad row {bad}, {kw}, keys {shape[0]}/{shape[1]}, samples {shape[2]}")
+    if bad is not None:
+        g, e = got[bad], want[bad]
+        msg += "\n    " + repr({k: (g[k], e[k]) for k in g if not same(g[k], e[k])})[:2000]
+    return msg
+
+
 def main():
     n_seeds, first = int(os.environ.get("SOAK_SEEDS", "100")), int(os.environ.get("SOAK_FIRST", "0"))
     budget = float(os.environ.get("SOAK_SECONDS", "1e9"))
     t0 = time.time()
     d = tempfile.mkdtemp(prefix="exg_vn_soak_")
+    p = os.path.join(d, "s.vcf")
     done = 0
     for seed in range(first, first + n_seeds):
         if time.time() - t0 > budget:
             break
-        rng = random.Random(seed)
-        n_info = rng.choice([0, 1, 3, 8, 9, 31, 32, 33, 60, 150, 600])
-        n_fmt = rng.choice([0, 1, 4, 12, 90])
-        n_smp = rng.choice([0, 0, 1, 3, 70, 300]) if n_fmt or rng.random() < 0.3 else 0
-        hdr, info, fmt = make_header(n_info, n_fmt, n_smp, seed=seed)
-        n_fk = rng.choice([1, 2, 6, 60])
-        n_lines = min(rng.choice([1, 7, 64, 65, 300, 1200]), max(5, 150000 // max(1, n_smp * min(n_fk, max(1, n_fmt)))))
-        lines, rate = [], rng.choice([0.0, 0.004, 0.02, 0.02, 0.1, 1.0])   # (a value error ends the scan: few mutated lines -> deep files)
-        for k in range(n_lines):
-            ln = make_line(rng, k, info, fmt, n_smp, rng.choice([0, 1, 2, 5, 20, 120]), n_fk if rng.random() < 0.8 else rng.choice([1, 2, 6, 60]), long_strings=rng.random() < 0.03)
-            lines.append(mutate_fields(ln, rng) if rng.random() < rate else ln)
-        data = hdr + b"\n".join(lines) + b"\n"
-        if any(c >= 0x80 for c in data):
-            data = bytes(c if c < 0x80 else 0x41 for c in data)
-        want, err_row = pyoracle.vcf_typed_rows(data)
-        tok = pyoracle.vcf_parse(data, want_string_t=False)
-        p = os.path.join(d, "s.vcf")
-        with open(p, "wb") as f:
-            f.write(data)
-        kw = dict(batch_rows=rng.choice([64, 2048]), device_batch_bytes=rng.choice([0, 0, 16 << 10, 200 << 10]))
-        if os.environ.get("SOAK_DRY"):   # the generator and the oracle alone (no GPU)
-            done += 1
-            continue
-        got, failed = read_rows(p, **kw)
-        ok = len(got) == len(want) and all(same(g, e) for g, e in zip(got, want)) and failed == (err_row is not None or bool(tok.error_code))
-        if not ok:
-            bad = next((i for i, (g, e) in enumerate(zip(got, want)) if not same(g, e)), None)
+        msg = run_seed(seed, p, dry=bool(os.environ.get("SOAK_DRY")))
+        if msg:
             keep = os.path.join(ROOT, "gpurun_out", f"vn_soak_seed{seed}.vcf")
             os.makedirs(os.path.dirname(keep), exist_ok=True)
-            with open(keep, "wb") as f:
-                f.write(data)
-            print(f"seed {seed}: MISMATCH rows {len(got)} / {len(want)}, failed {failed} (oracle: error row {err_row}, tokeniser {tok.error_code}), "
-                  f"first bad row {bad}, {kw}, keys {n_info}/{n_fmt}, samples {n_smp}; input kept as {keep}", flush=True)
-            if bad is not None:
-                g, e = got[bad], want[bad]
-                print("   ", {k: (g[k], e[k]) for k in g if not same(g[k], e[k])}, flush=True)
+            os.replace(p, keep)
+            print("MISMATCH " + msg + f"\n    input kept as {keep}", flush=True)
             sys.exit(1)
         done += 1
-    os.unlink(p)
+    if os.path.exists(p):
+        os.unlink(p)
     os.rmdir(d)
     print(f"vcf nested soak: seeds {first}..{first + done - 1} ({done}) agree with the oracle, {time.time() - t0:.0f} s", flush=True)
 
