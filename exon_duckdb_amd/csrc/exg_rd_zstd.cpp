@@ -323,6 +323,13 @@ int ZstdProducer::run(SegmentSink &sink, std::string *err) {
         double t0;
         ~RunTrace() { if (getenv("EXG_TRACE")) fprintf(stderr, "[exg] zstd producer: gone %.1f ms after it began\n", (now_s() - t0) * 1e3); }
     } run_trace{t_run0};
+    // Round 6: a consumer that pulls string columns gets rounds of 640 MiB instead of 1 GiB.  Behind the ramp the decode and the link
+    // run at about the same rate (a 1 GiB round every ~23 ms, its bytes + vectors 22 ms of link), so the drain ends when the link
+    // has caught up with everything the decoder had ready before it: smaller rounds start the link earlier and leave a smaller last
+    // segment (4 GB: 160 + 320 + 5 x 640 + 135 MiB).  A 4 GB frame into DataChunks, three boxes, A/B inside each: 1 GiB rounds 133-138
+    // ms, 768 MiB 126-133, 640 MiB 125-129, 512 MiB 141 (the decode itself slows down: COUNT(*) 99 ms against 91; 640 MiB: 93.5).
+    // COUNT(*) keeps its 1 GiB rounds
+    if (target_ == (1ull << 30) && sink.mirror_wanted() && !getenv("EXG_STREAM_ROUND_OUT")) target_ = 640ull << 20;
     hipStream_t st = nullptr;
     if (stream_pool()->take(device_, &st) != hipSuccess) {
         *err = "cannot create a stream for the zstd decoder";

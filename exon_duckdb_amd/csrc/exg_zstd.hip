@@ -1519,10 +1519,14 @@ struct RoundCtx {
     bool exec_enqueued = false;
     char *h_rargs = nullptr;  // the resolve launches' arguments (pinned), when groups of several frames share launches
     size_t h_rargs_cap = 0;
+    hipStream_t hp = nullptr;  // the resolve launches' own high-priority stream (between two events on st; decode_round_enqueue_resolve)
+    hipEvent_t hp_ev = nullptr;
     RoundCtx(int d, hipStream_t s)
         : dev(d), st(s), d_blocks(d, s), d_lit(d, s), d_ll(d, s), d_ml(d, s), d_off(d, s), d_meta(d, s), d_frames(d, s), d_chunks(d, s), d_status(d, s),
           d_out(d, s), d_sym(d, s), d_lookup(d, s), d_rargs(d, s) {}
     ~RoundCtx() {
+        if (hp) exg_rd::stream_pool()->give(dev, hp, /*high=*/true);  // (synchronises it)
+        if (hp_ev) (void)hipEventDestroy(hp_ev);
         if (h_status || h_rargs) (void)hipStreamSynchronize(st);
         if (h_status) exg_rd::global_pool()->give(h_status, h_status_cap);
         if (h_rargs) exg_rd::global_pool()->give(h_rargs, h_rargs_cap);
@@ -1788,6 +1792,27 @@ int decode_round_enqueue_resolve(Round &R, RoundCtx *ctx_p) {
     std::unique_ptr<RoundCtx> ctx(ctx_p);
     RoundCtx &C = *ctx;
     hipStream_t st = C.st;
+    // Round 6: the resolve launches — a chain of ~130 short dependent launches per round — go out on a HIGH-PRIORITY stream of their
+    // own, between two events on the round's stream: the round behind runs its entropy stages and its execution (a chip full of
+    // wavefronts that live for milliseconds) beside them, and every launch of the chain waited for slots among those.  A 4 GB frame
+    // into DataChunks 142-146 -> 133-137 ms (COUNT(*) unchanged: 91 ms).  EXG_ZSTD_RESOLVE_PRIORITY=0: on the round's stream (A/B)
+    static const bool resolve_priority = !getenv("EXG_ZSTD_RESOLVE_PRIORITY") || atoi(getenv("EXG_ZSTD_RESOLVE_PRIORITY")) != 0;
+    struct Rejoin {  // whatever this half enqueues on the high-priority stream, C.st goes on behind it
+        RoundCtx &C;
+        bool on = false;
+        ~Rejoin() {
+            if (on && (hipEventRecord(C.hp_ev, C.hp) != hipSuccess || hipStreamWaitEvent(C.st, C.hp_ev, 0) != hipSuccess)) (void)hipStreamSynchronize(C.hp);
+        }
+    } rejoin{C};
+    if (resolve_priority && C.nc) {
+        if (exg_rd::stream_pool()->take(C.dev, &C.hp, /*high=*/true) == hipSuccess && hipEventCreateWithFlags(&C.hp_ev, hipEventDisableTiming) == hipSuccess &&
+            hipEventRecord(C.hp_ev, C.st) == hipSuccess && hipStreamWaitEvent(C.hp, C.hp_ev, 0) == hipSuccess) {
+            st = C.hp;
+            rejoin.on = true;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     const uint8_t *d_comp = (const uint8_t *)R.d_comp;
     std::vector<Chunk> &chunks = C.chunks;
     const uint64_t H = C.H;
