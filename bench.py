@@ -273,7 +273,7 @@ def reader_digest(lib, path, fmt, want_seq_len=0, columns=0, shard=(0, 1), devic
     tl = load_test_library()
     r = open_reader(lib, path, fmt, shard, device_index, columns, CHUNKS_HINT)
     rows, chunks, dg, bad = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
-    rc = tl.exon_tf_drain_digest_from(r, 1 if fmt == "vcf" else 0, want_seq_len, first_row, C.byref(rows), C.byref(chunks), C.byref(dg), C.byref(bad))
+    rc = tl.exon_tf_drain_digest_from(r, {"vcf": 1, "fasta": 2}.get(fmt, 0), want_seq_len, first_row, C.byref(rows), C.byref(chunks), C.byref(dg), C.byref(bad))
     assert rc == 0, lib.exg_last_error_message()
     lib.exg_close(r)
     return int(rows.value), int(chunks.value), int(dg.value), int(bad.value)
@@ -1004,7 +1004,37 @@ def run_configs(torch, lib, args):
                                 "split of the file",
                 "verified": bool(rows == n == v_rows == int(e_rows.value) == 2000 * reps and got == int(e_dg.value))}
 
+        def fasta_file():
+            # ---- read_fasta end to end at size: 60-column wrapped records of 0.3 - 3 kB, every third one without a description;
+            # the sequences come back as the newline-free strings the device compacted (k_fa_fused), not as slices of the file
+            n_rec = max(1000, int(min(args.e2e_gb, 2.0) * 1e9 / 1712))
+            d_fa, n_fa = device.synth_fasta(n_rec)
+            p_fa = os.path.join(tmp, "e2e.fasta")
+            write_device_bytes(torch, d_fa, n_fa, p_fa)
+            del d_fa
+            torch.cuda.empty_cache()
+            reader_count(lib, p_fa, "fasta")
+            n, dt_c = min((reader_count(lib, p_fa, "fasta") for _ in range(3)), key=lambda x: x[1])
+            rows, chunks, dt_r, st = timed_reader_chunks(lib, p_fa, "fasta")
+            e_rows, e_dg = C.c_uint64(0), C.c_uint64(0)
+            tl.exon_tf_expect_fasta_file.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+            assert tl.exon_tf_expect_fasta_file(p_fa.encode(), C.byref(e_rows), C.byref(e_dg)) == 0
+            v_rows, _, got, _ = reader_digest(lib, p_fa, "fasta")
+            os.unlink(p_fa)
+            d2h = int(st.get("host_vector_bytes", 0))
+            out["end_to_end_fasta"] = {
+                "workload": f"read_fasta, {n_fa / 1e9:.2f} GB file of {n_rec} records (sequences of 241 - 3 000 bases in lines of 60) in the page cache -> host "
+                            f"DataChunks of id, description, sequence (the sequences joined on the device), PCIe inclusive both ways",
+                "algorithmic_bytes": n_fa, "ms": dt_r * 1e3, "GB/s": n_fa / dt_r / 1e9, "records_per_s": rows / dt_r, "chunks": chunks,
+                "count_only_ms": dt_c * 1e3, "count_only_GB/s": n_fa / dt_c / 1e9, "frac": None,
+                "d2h_bytes": d2h or None, "frac_of_h2d_link": n_fa / dt_r / 1e9 / link[0], "frac_of_d2h_link": (d2h / dt_r / 1e9 / link[1]) if d2h else None,
+                "link_GB/s": {"h2d": link[0], "d2h": link[1]},
+                "verification": "an untimed pass folds every row of every chunk (id, description or NULL, the joined sequence) into a digest that must "
+                                "equal the one of an independent split of the file at its '>' lines",
+                "verified": bool(rows == n == v_rows == int(e_rows.value) == n_rec and got == int(e_dg.value))}
+
         leg(config1, "config1_fasta_1MB_count")
+        leg(fasta_file, "end_to_end_fasta")
         leg(config3, "config3_vcf_8col")
         leg(files, "end_to_end", "config4_fastq_bgzf")
         if "host_pipeline_scaling" in out and "end_to_end" in out and "error" not in out["end_to_end"]:

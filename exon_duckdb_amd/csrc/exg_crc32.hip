@@ -8,6 +8,7 @@
 // (63 - i) L: every lane runs the table-driven byte recurrence over its slice from state 0 (the lane that holds the piece's
 // first byte from the running state), and six combine levels add the lanes up — a state followed by n bytes of anything is
 // that state times x^(8n) mod P, one carry-less multiply-reduce (32 shift-xor steps), the multiplier squared per level.
+#include <algorithm>
 #include <stdlib.h>
 
 #include "exg_common.hpp"
@@ -174,6 +175,32 @@ int post_to_host(void *h_dst, const void *d_src, uint64_t bytes, void *stream) {
     const uint32_t n_words = (uint32_t)(bytes / 4), blocks = (n_words + 255) / 256;
     hipLaunchKernelGGL(k_post_to_host, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, (hipStream_t)stream, (uint32_t *)h_dst,
                        (const uint32_t *)d_src, n_words);
+    EXG_HIP_CHECK(hipGetLastError());
+    return EXG_OK;
+}
+// Bulk bytes to pinned host memory by a kernel's 16-byte stores (no copy engine: what a concurrent upload's slices cannot be queued
+// behind).  Both pointers 16-byte aligned; `bytes` is rounded up to 16 (the caller's blocks have the room).  blocks: PCIe is the bound,
+// a few wavefronts per CU saturate it (exon_tf_link_probe: 55 GB/s against hipMemcpyAsync's 57)
+typedef uint32_t stream_v4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_stream_to_host(stream_v4 *__restrict__ h_dst, const stream_v4 *__restrict__ d_src, uint64_t n16) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(&d_src[i]), &h_dst[i]);
+}
+int stream_to_host(void *h_dst, const void *d_src, uint64_t bytes, void *stream) {
+    if (!bytes) return EXG_OK;
+    if (!h_dst || !d_src || (((uintptr_t)h_dst | (uintptr_t)d_src) & 15)) {
+        set_error("stream_to_host: null or unaligned argument");
+        return EXG_E_INVALID_ARG;
+    }
+    static const bool by_copy = getenv("EXG_POST_BY_COPY") != nullptr || (getenv("HIP_HOST_COHERENT") && atoi(getenv("HIP_HOST_COHERENT")) == 0);
+    if (by_copy) {
+        EXG_HIP_CHECK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+        return EXG_OK;
+    }
+    static const uint32_t blocks = getenv("EXG_STREAM_TO_HOST_BLOCKS") ? (uint32_t)std::max(1, atoi(getenv("EXG_STREAM_TO_HOST_BLOCKS"))) : 512u;
+    const uint64_t n16 = (bytes + 15) / 16;
+    hipLaunchKernelGGL(k_stream_to_host, dim3((uint32_t)std::min<uint64_t>(blocks, (n16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (stream_v4 *)h_dst,
+                       (const stream_v4 *)d_src, n16);
     EXG_HIP_CHECK(hipGetLastError());
     return EXG_OK;
 }

@@ -547,10 +547,11 @@ int ensure_device(exg_reader *r, uint64_t need_bytes) {
         const uint64_t lines = cap / 8 + 65536 + 8;
         r->ws_bytes = std::min<uint64_t>(r->ws_bytes, l.off_nl_pos + (lines + 2) * 8 * arrays);
     }
-    // two upload slots; FASTA batches are not prefetched: one; a decoded stream is scanned in its segments: none (FASTA:
-    // one, for the 16-byte aligned copy its scan wants)
+    // two upload slots (a FASTA under a memory cap: one, its batches are then not prefetched); a decoded stream is scanned in its
+    // segments: none (FASTA: one, for the 16-byte aligned copy its scan wants)
     int arc = 0;
-    const int n_slots = r->format == EXG_FMT_FASTA ? 1 : r->src ? 0 : 2;
+    static const bool no_fasta_prefetch = getenv("EXG_NO_FASTA_PREFETCH") != nullptr;
+    const int n_slots = r->format == EXG_FMT_FASTA ? (r->src || r->mem_cap || no_fasta_prefetch ? 1 : 2) : r->src ? 0 : 2;
     for (int k = 0; k < n_slots; k++)
         if ((arc = r->dev_alloc(&r->d_in_slot[k], cap + 64))) return arc;
     r->d_in = r->d_in_slot[0];
@@ -1011,9 +1012,14 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
         // While the columns travel back (and the consumer works through the chunks): the bytes the next batch will need
         // move into the other slot — unless they left at the top of this call already (pf2), which is the steady state
         {
-            const bool can = !range_end && !res.error_code && !r->src && r->format != EXG_FMT_FASTA && want == r->device_batch_bytes && !no_prefetch;
-            const uint64_t slack = std::min<uint64_t>(kPrefetchSlack, (batch_end - r->file_pos) / 2);
-            const uint64_t start = (batch_end - slack) & ~15ull;
+            // FASTA (round 6: its batches were uploaded, scanned and sent back one after the other — 22.7 GB/s end to end against
+            // FASTQ's 50): the scan wants its batch at a 16-byte boundary with nothing in front, and where the next batch begins —
+            // behind this one's last whole record — is known with the scan's result: its upload starts HERE, at exactly that file
+            // offset into the other slot's first byte (no slack, no lead), beside this batch's sequences on their way back
+            const bool fasta = r->format == EXG_FMT_FASTA;
+            const bool can = !range_end && !res.error_code && !r->src && want == r->device_batch_bytes && !no_prefetch && (!fasta || res.n_records);
+            const uint64_t slack = fasta ? 0 : std::min<uint64_t>(kPrefetchSlack, (batch_end - r->file_pos) / 2);
+            const uint64_t start = fasta ? r->file_pos + (res.consumed_bytes - lead) : (batch_end - slack) & ~15ull;
             const int other = r->cur_slot ^ 1;
             if (r->pf2.valid) {
                 // (its length was chosen where it was issued: a step of the ramp, or a full batch)
@@ -1155,7 +1161,10 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
                     if (cs) (void)hipStreamSynchronize(cs);
                 }
             } col_drain;
-            if (r->format == EXG_FMT_VCF && !compact && !getenv("EXG_VCF_ONE_STREAM")) {
+            // (FASTA, round 6: its joined sequences are as many bytes as the batch itself — on the scan's stream they shared a copy
+            // engine with the next batch's upload, which landed 5 ms behind them: 9.7 ms per 256 MiB batch where the two directions
+            // should overlap)
+            if ((r->format == EXG_FMT_VCF || r->format == EXG_FMT_FASTA) && !compact && !getenv("EXG_VCF_ONE_STREAM")) {
                 if (!r->col_stream) {
                     RD_HIP(r, stream_pool()->take(r->device, &r->col_stream));
                     RD_HIP(r, hipEventCreateWithFlags(&r->col_ev, hipEventDisableTiming));
@@ -1169,7 +1178,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             // read_vcf hands its batch on while the vectors are still travelling (Batch::landed): the batch behind it — upload wait,
             // scan, the nested columns' kernels — is made beside them, and the link back to the host does not idle between batches
             static const bool eager_landing = getenv("EXG_VCF_EAGER_LANDING") != nullptr;
-            r->lazy_landing = cs == r->col_stream && cs != r->stream && !eager_landing;
+            r->lazy_landing = r->format == EXG_FMT_VCF && cs == r->col_stream && cs != r->stream && !eager_landing;
             const bool nested_vcf = r->format == EXG_FMT_VCF;  // id, alt, filter, info, formats: built by nested_emit below
             for (int c = 0; c < ns; c++) {
                 if ((nested_vcf && (c == 2 || c == 4 || c >= 6)) || !r->want(c)) {
@@ -1239,8 +1248,17 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             } else {
                 if (r->want(1) && (rc = copy_validity(1, r->d_valid[0]))) return rc;
             }
-            if (r->format == EXG_FMT_FASTA && res.payload_bytes && r->want(2))
-                RD_HIP(r, hipMemcpyAsync(b->payload, r->d_payload, res.payload_bytes, hipMemcpyDeviceToHost, r->stream));
+            if (r->format == EXG_FMT_FASTA && res.payload_bytes && r->want(2)) {
+                // by a kernel's stores, not by a copy engine: the next batch's upload (slices that each take whichever engine is free
+                // when they are enqueued) ended up behind this copy on ITS engine every other batch and landed 5 ms late
+                static const bool by_engine = getenv("EXG_FASTA_D2H_ENGINE") != nullptr;  // (A/B)
+                if (by_engine || (((uintptr_t)b->payload | (uintptr_t)r->d_payload) & 15)) {
+                    RD_HIP(r, hipMemcpyAsync(b->payload, r->d_payload, res.payload_bytes, hipMemcpyDeviceToHost, cs));
+                } else if (int prc = exg::stream_to_host(b->payload, r->d_payload, res.payload_bytes, cs)) {
+                    return fail(r, prc, exg_last_error_message());
+                }
+                r->host_vector_bytes += res.payload_bytes;  // (the joined sequences: the strings' payload is made on the device)
+            }
             const double t_cols = now_s();
             RD_HIP(r, hipStreamSynchronize(r->stream));
             if (r->col_stream && !b->landed) RD_HIP(r, hipStreamSynchronize(r->col_stream));

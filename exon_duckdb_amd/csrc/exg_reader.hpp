@@ -18,6 +18,7 @@
 // `stream` — a decoder's small results, which a copy would queue behind the big copies of its SDMA engine
 namespace exg {
 int post_to_host(void *h_dst, const void *d_src, uint64_t bytes, void *stream);
+int stream_to_host(void *h_dst, const void *d_src, uint64_t bytes, void *stream);  // bulk bytes, 16-byte aligned, by a kernel's stores (exg_crc32.hip)
 }
 
 namespace exg_rd {

@@ -221,6 +221,62 @@ extern "C" int exon_tf_expect_fastq_file(const char *path, uint64_t *rows, uint6
     return rc;
 }
 
+// A well-formed FASTA file's records as the digest of exon_tf_drain_digest_from's kind 2, by a split of its own: a '>' line begins
+// a record, its id ends at the first blank, the description is what follows with the blanks around it dropped (NULL when nothing
+// does), the sequence is the lines up to the next '>' line joined without their ends — independent of the engine's tokeniser and of
+// the oracle.
+extern "C" int exon_tf_expect_fasta_file(const char *path, uint64_t *rows, uint64_t *digest) {
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return -1;
+    struct stat st;
+    fstat(fd, &st);
+    const size_t n = (size_t)st.st_size;
+    const uint8_t *d = n ? (const uint8_t *)mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
+    close(fd);
+    if (n && d == MAP_FAILED) return -1;
+    uint64_t k = 0, acc = 0, h = 0;
+    bool open_rec = false;
+    std::vector<uint8_t> seq;
+    auto flush = [&] {
+        if (!open_rec) return;
+        h = fold_bytes(h, seq.data(), seq.size());
+        acc += mix64(h);
+        k++;
+        open_rec = false;
+    };
+    int rc = 0;
+    for (size_t pos = 0; pos < n;) {
+        const uint8_t *nl = (const uint8_t *)memchr(d + pos, '\n', n - pos);
+        size_t end = nl ? (size_t)(nl - d) : n;
+        const size_t next = nl ? end + 1 : n;
+        if (end > pos && d[end - 1] == '\r') end--;
+        if (end > pos && d[pos] == '>') {
+            flush();
+            const uint8_t *id = d + pos + 1, *e = d + end, *q = id;
+            while (q < e && *q != ' ' && *q != '\t') q++;
+            const uint8_t *ds = q, *de = e;
+            while (ds < de && (*ds == ' ' || *ds == '\t')) ds++;
+            while (de > ds && (de[-1] == ' ' || de[-1] == '\t')) de--;
+            h = mix64(k);
+            h = fold_bytes(h, id, (size_t)(q - id));
+            h = de > ds ? fold_bytes(h, ds, (size_t)(de - ds)) : fold_bytes(h ^ 0xDEADull, nullptr, 0);
+            seq.clear();
+            open_rec = true;
+        } else if (open_rec) {
+            seq.insert(seq.end(), d + pos, d + end);
+        } else if (end > pos) {
+            rc = -2;  // bytes in front of the first '>'
+            break;
+        }
+        pos = next;
+    }
+    flush();
+    if (d) munmap((void *)d, n);
+    *rows = k;
+    *digest = acc;
+    return rc;
+}
+
 // ---- consumers of a reader's chunks ------------------------------------------------------------------------------------------
 // pull and release every remaining chunk — what a consumer that only walks the DataChunks does
 extern "C" int exon_tf_drain_chunks(exg_reader *r, uint64_t *n_rows, uint64_t *n_chunks) {
@@ -238,7 +294,7 @@ extern "C" int exon_tf_drain_chunks(exg_reader *r, uint64_t *n_rows, uint64_t *n
 }
 
 // the same, folding every row's content.  kind 0: four VARCHAR columns (FASTQ: name, description, sequence, quality_scores);
-// kind 1: VCF — chrom (column 0), pos (BIGINT, column 1), ref (column 3).  *bad: rows whose name / sequence / quality length is
+// kind 1: VCF — chrom (column 0), pos (BIGINT, column 1), ref (column 3); kind 2: FASTA — id, description, sequence.  *bad: rows whose name / sequence / quality length is
 // not the one given (0: not checked).
 // first_row: the index of the reader's first row in the whole file (a shard's rows are rows [first_row, first_row + n) of the
 // file: the digests of all shards then add up to the file's).
@@ -263,6 +319,15 @@ extern "C" int exon_tf_drain_digest_from(exg_reader *r, int kind, uint32_t want_
                 h = fold_string_t(h, qual[i], true);
                 acc += mix64(h);
                 if (want_seq_len && (seq[i].inlined.length != want_seq_len || qual[i].inlined.length != want_seq_len)) (*bad)++;
+            }
+        } else if (kind == 2) {
+            const exg_string_t *id = (const exg_string_t *)c.data[0], *desc = (const exg_string_t *)c.data[1], *seq = (const exg_string_t *)c.data[2];
+            for (uint64_t i = 0; i < c.n_rows; i++) {
+                uint64_t h = mix64(k + i);
+                h = fold_string_t(h, id[i], true);
+                h = fold_string_t(h, desc[i], bit(c.validity[1], i));
+                h = fold_string_t(h, seq[i], true);
+                acc += mix64(h);
             }
         } else {
             const exg_string_t *chrom = (const exg_string_t *)c.data[0], *ref = (const exg_string_t *)c.data[3];

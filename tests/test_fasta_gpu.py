@@ -357,3 +357,29 @@ def test_scanner_helping_path(gpu, oracle):
         "print('helping ok')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, EXG_FASTA_HELP_TICKS="0"))
     assert res.returncode == 0 and "helping ok" in res.stdout, res.stdout[-1000:] + res.stderr[-3000:]
+
+
+@pytest.mark.parametrize("batch", [64 << 10, 300 << 10])
+def test_reader_batches_uploaded_ahead(gpu, oracle, tmp_path, batch):
+    # round 6: a text FASTA's next batch is uploaded — from exactly where this batch's last whole record ends, into the other input
+    # slot — while this batch's joined sequences travel back (they leave by a kernel's stores, not by a copy engine): dozens of
+    # batches, a record longer than a batch in the middle (the batch widens; no upload ahead for it), every row the oracle's
+    from exon_duckdb_amd.reader import ShardReader
+    a, b = bytes(oracle.synth_fasta(900, seed=11)), bytes(oracle.synth_fasta(700, seed=12))
+    long_rec = b">long one\n" + b"\n".join(b"ACGTTGCA" * 8 for _ in range(12000)) + b"\n"   # 780 kB
+    data = a + long_rec + b
+    exp = oracle.fasta_parse(data)
+    assert exp.error_code == 0
+    want = list(zip(*(exp.columns[k].to_list() for k in ("id", "description", "sequence"))))
+    p = tmp_path / "ahead.fasta"
+    p.write_bytes(data)
+    r = ShardReader(str(p), "fasta", device_batch_bytes=batch)
+    got = r.rows()
+    st = r.stats()
+    r.close()
+    assert len(got) == len(want) == 1601
+    assert got == want
+    assert st["batches"] > 10
+    r = ShardReader(str(p), "fasta", device_batch_bytes=batch)
+    assert r.count() == 1601
+    r.close()
