@@ -379,7 +379,7 @@ def test_reader_batches_uploaded_ahead(gpu, oracle, tmp_path, batch):
     r.close()
     assert len(got) == len(want) == 1601
     assert got == want
-    assert st["batches"] > 10
+    assert st["device_batches"] > 10
     r = ShardReader(str(p), "fasta", device_batch_bytes=batch)
     assert r.count() == 1601
     r.close()
