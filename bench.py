@@ -912,8 +912,29 @@ def run_configs(torch, lib, args):
                              "verified": bool(a_rows == av_rows == n_lines and a_dg == int(e_dg.value))}
             except Exception as e:  # noqa: BLE001
                 arrow_vcf = {"error": f"{type(e).__name__}: {e}"}
+            # the same file bgzip'd (x.vcf.gz, BGZF members like `bgzip` writes: what VCFs are shipped as): inflated on the device, the
+            # nested columns made from the inflated text, which goes back to the host beside the vectors (the strings point into it)
+            try:
+                from exon_duckdb_amd.testing.bgzf import bgzip
+                p_gz = p_vcf + ".gz"
+                nz = bgzip(p_vcf, p_gz)
+                reader_count(lib, p_gz, "vcf")
+                g_n, g_dt_c = min((reader_count(lib, p_gz, "vcf") for _ in range(3)), key=lambda x: x[1])
+                g_rows, g_chunks, g_dt, g_st = timed_reader_chunks(lib, p_gz, "vcf")
+                gv_rows, _, g_got, _ = reader_digest(lib, p_gz, "vcf")
+                os.unlink(p_gz)
+                g_d2h = g_st["host_vector_bytes"] + n_vcf
+                bgzip_vcf = {"what": "the same file as BGZF (zlib level 1, 65 280-byte members): inflate + scan + nested columns on the device -> host DataChunks of "
+                                     "all columns; d2h_bytes = the vectors + the inflated text the strings point into",
+                             "compressed_bytes": nz, "ms": g_dt * 1e3, "GB/s": n_vcf / g_dt / 1e9, "records_per_s": g_rows / g_dt, "chunks": g_chunks,
+                             "count_only_ms": g_dt_c * 1e3, "count_only_GB/s": n_vcf / g_dt_c / 1e9,
+                             "d2h_bytes": g_d2h, "frac_of_d2h_link": g_d2h / g_dt / 1e9 / link[1],
+                             "verified": bool(g_rows == g_n == gv_rows == n_lines and g_got == int(e_dg.value))}
+            except Exception as e:  # noqa: BLE001
+                bgzip_vcf = {"error": f"{type(e).__name__}: {e}"}
             out["end_to_end_vcf"] = {
                 "arrow_boundary": arrow_vcf,
+                "bgzip": bgzip_vcf,
                 # the nested columns' chain on the device (exg_vcf_nested.hip: counting passes, prefix sums, children — wall time on
                 # the reader's thread up to the point where the vectors start for the host, launches and the two syncs included)
                 "nested": {"what": "id / alt / filter LIST(VARCHAR), info STRUCT, formats LIST(STRUCT) of every batch made on the device: counts, "
@@ -1020,6 +1041,23 @@ def run_configs(torch, lib, args):
             tl.exon_tf_expect_fasta_file.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
             assert tl.exon_tf_expect_fasta_file(p_fa.encode(), C.byref(e_rows), C.byref(e_dg)) == 0
             v_rows, _, got, _ = reader_digest(lib, p_fa, "fasta")
+            try:   # the same file bgzip'd (x.fasta.gz)
+                from exon_duckdb_amd.testing.bgzf import bgzip
+                p_gz = p_fa + ".gz"
+                nz = bgzip(p_fa, p_gz)
+                reader_count(lib, p_gz, "fasta")
+                g_n, g_dt_c = min((reader_count(lib, p_gz, "fasta") for _ in range(3)), key=lambda x: x[1])
+                g_rows, g_chunks, g_dt, g_st = timed_reader_chunks(lib, p_gz, "fasta")
+                gv_rows, _, g_got, _ = reader_digest(lib, p_gz, "fasta")
+                os.unlink(p_gz)
+                bgzip_fa = {"what": "the same file as BGZF (zlib level 1, 65 280-byte members): inflate + scan on the device -> host DataChunks; the joined "
+                                    "sequences and a side buffer of the definition lines' strings travel back, not the inflated text",
+                            "compressed_bytes": nz, "ms": g_dt * 1e3, "GB/s": n_fa / g_dt / 1e9, "records_per_s": g_rows / g_dt, "chunks": g_chunks,
+                            "count_only_ms": g_dt_c * 1e3, "count_only_GB/s": n_fa / g_dt_c / 1e9, "d2h_bytes": int(g_st.get("host_vector_bytes", 0)) or None,
+                            "frac_of_d2h_link": (g_st.get("host_vector_bytes", 0) / g_dt / 1e9 / link[1]) or None,
+                            "verified": bool(g_rows == g_n == gv_rows == n_rec and g_got == int(e_dg.value))}
+            except Exception as e:  # noqa: BLE001
+                bgzip_fa = {"error": f"{type(e).__name__}: {e}"}
             os.unlink(p_fa)
             d2h = int(st.get("host_vector_bytes", 0))
             out["end_to_end_fasta"] = {
@@ -1028,7 +1066,7 @@ def run_configs(torch, lib, args):
                 "algorithmic_bytes": n_fa, "ms": dt_r * 1e3, "GB/s": n_fa / dt_r / 1e9, "records_per_s": rows / dt_r, "chunks": chunks,
                 "count_only_ms": dt_c * 1e3, "count_only_GB/s": n_fa / dt_c / 1e9, "frac": None,
                 "d2h_bytes": d2h or None, "frac_of_h2d_link": n_fa / dt_r / 1e9 / link[0], "frac_of_d2h_link": (d2h / dt_r / 1e9 / link[1]) if d2h else None,
-                "link_GB/s": {"h2d": link[0], "d2h": link[1]},
+                "link_GB/s": {"h2d": link[0], "d2h": link[1]}, "bgzip": bgzip_fa,
                 "verification": "an untimed pass folds every row of every chunk (id, description or NULL, the joined sequence) into a digest that must "
                                 "equal the one of an independent split of the file at its '>' lines",
                 "verified": bool(rows == n == v_rows == int(e_rows.value) == n_rec and got == int(e_dg.value))}

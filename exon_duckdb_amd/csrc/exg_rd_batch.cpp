@@ -169,11 +169,16 @@ static int plan_bgzf_shard(exg_reader *r, const std::string &path, uint64_t n, u
 // How the bytes a decoded input's strings point into reach the host when chunks are handed out (never for COUNT(*) or the Arrow
 // stream): kPayloadCompact — a projection that leaves payload-bearing columns out: the selected columns' out-of-line strings are
 // closed up into a side buffer behind the scan; kPayloadMirror — the decoded segments themselves, sent ahead by the producer
-// (HostMirror; a segment without one is copied behind its scan); kPayloadNone — no string column is selected, or FASTA (its
-// sequences are compacted anyway, its definition lines travel with the batch).
+// (HostMirror; a segment without one is copied behind its scan); kPayloadNone — no string column is selected.  FASTA (round 6):
+// always the side buffer for id / description — its sequences are joined on the device and travel as that, so the decoded text is
+// needed for the definition lines' strings alone, 2 % of it (the whole text went along until then: a bgzip FASTA into DataChunks
+// sent every byte back twice, 92 ms for 1.96 GB).
 enum PayloadRoute { kPayloadNone, kPayloadCompact, kPayloadMirror };
 static PayloadRoute payload_route(const exg_reader *r) {
-    if (r->format == EXG_FMT_FASTA) return kPayloadNone;
+    if (r->format == EXG_FMT_FASTA) {
+        static const bool fasta_whole = getenv("EXG_FASTA_WHOLE_TEXT") != nullptr;  // (A/B: the decoded text behind the scan)
+        return (r->want_cols & 3ull) && !fasta_whole ? kPayloadCompact : kPayloadNone;
+    }
     const uint64_t strs = r->format == EXG_FMT_VCF ? 0x1DDull : 0xFull, nested = r->format == EXG_FMT_VCF ? 0x1D4ull : 0ull;
     const uint64_t sel = r->want_cols & strs;
     if (!sel) return kPayloadNone;
@@ -1123,7 +1128,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
                 uint64_t *d_tmp = (uint64_t *)side_scratch.take((ea::scan_tmp_entries(k) + 2) * 8);
                 if (!d_tmp) return fail(r, EXG_E_HIP, "out of device memory");
                 for (int c = 0; c < ns; c++) {
-                    if (!r->want(c) || (r->format == EXG_FMT_VCF && c != 0 && c != 3)) continue;
+                    if (!r->want(c) || (r->format == EXG_FMT_VCF && c != 0 && c != 3) || (r->format == EXG_FMT_FASTA && c == 2)) continue;
                     if (!(side[c].d_goff = (uint64_t *)side_scratch.take((k + 2) * 8))) return fail(r, EXG_E_HIP, "out of device memory");
                     const ea::StrCol sc{(const exg_string_t *)r->d_cols[c], (const uint8_t *)d_input, (uint64_t)(uintptr_t)h};
                     ea::payload_goff_from_col(sc, row_map, k, side[c].d_goff, d_tmp, r->stream);

@@ -32,6 +32,12 @@ else:
     d, n = device.synth_fasta(n_rec)
     bench.write_device_bytes(torch, d, n, p)
     del d
+if os.environ.get("BGZF"):   # the same file bgzip'd (x.fasta.gz): the decoded segments are scanned from an aligned device copy
+    from exon_duckdb_amd.testing.bgzf import bgzip
+    nz = bgzip(p, p + ".gz")
+    os.unlink(p)
+    p = p + ".gz"
+    print(f"bgzip: {n/1e9:.2f} GB in {nz/1e9:.2f} GB", flush=True)
 lib = load_library()
 bench.reader_count(lib, p, "fasta")
 t_c = min(bench.reader_count(lib, p, "fasta")[1] for _ in range(3))
