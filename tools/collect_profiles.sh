@@ -30,6 +30,8 @@ GZ_RECORDS=800000 GZ_ONLY_SINGLE=1 rocprofv3 --kernel-trace --stats -d $OUT/${TA
 # FASTA (1 GB), VCF (5 GB), BGZF inflate alone: per-kernel times
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_fasta -o kt --output-format csv -- python3 $ROOT/tools/bench_fasta.py > $OUT/${TAG}_kt_fasta.log 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_vcf -o kt --output-format csv -- python3 $ROOT/tools/bench_vcf.py > $OUT/${TAG}_kt_vcf.log 2>&1
+# read_fasta through the reader (round 6: uploads ahead, the joined sequences back by k_stream_to_host): a 2 GB file, COUNT(*) and all-columns drains
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_fasta_e2e -o kt --output-format csv -- python3 $ROOT/tools/fasta_e2e_probe.py > $OUT/${TAG}_kt_fasta_e2e.log 2>&1
 # the nested VCF columns through the reader (round 6: exg_vcf_nested.hip): VCF-8 (2.08 GB, one all-columns drain) and cohort lines of 100 / 2 504
 # samples with FORMAT GT (1 GB each, two drains); then the HBM counters of the VCF-8 drain, a pass each
 export ONE_PASS=1

@@ -43,4 +43,15 @@ bench.reader_count(lib, p, "fasta")
 t_c = min(bench.reader_count(lib, p, "fasta")[1] for _ in range(3))
 t_a = min(bench.reader_chunks(lib, p, "fasta")[2] for _ in range(3))
 print(f"read_fasta {n/1e9:.2f} GB, {n_rec} records: COUNT(*) {t_c*1e3:.1f} ms = {n/t_c/1e9:.1f} GB/s, all columns {t_a*1e3:.1f} ms = {n/t_a/1e9:.1f} GB/s", flush=True)
+if os.environ.get("ARROW"):   # the reference's own boundary: new_reader -> Arrow C stream, batches pulled by pyarrow
+    import time
+    from exon_duckdb_amd.arrow import new_reader
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        rows = sum(b.num_rows for b in new_reader(p, "fasta"))
+        dt = time.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+    assert rows == n_rec
+    print(f"new_reader(fasta) -> Arrow record batches (pyarrow loop): {best*1e3:.1f} ms = {n/best/1e9:.1f} GB/s", flush=True)
 os.unlink(p)

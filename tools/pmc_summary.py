@@ -51,7 +51,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         w.writerows(rows)
     vals = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == c]
     res[c] = sum(vals) / len(vals)
-for leg in ("configs", "zstd", "gzstream", "fasta", "vcf", "inflate", "shapes", "vcf_nested", "vcf_cohort100", "vcf_cohort2504"):
+for leg in ("configs", "zstd", "gzstream", "fasta", "fasta_e2e", "vcf", "inflate", "shapes", "vcf_nested", "vcf_cohort100", "vcf_cohort2504"):
     st = find(f"{tag}_kt_{leg}/**/*kernel_stats.csv")
     if st:
         shutil.copy(st, os.path.join(prof, f"{tag}_{leg}_kernel_stats.csv"))
