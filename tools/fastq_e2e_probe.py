@@ -1,0 +1,23 @@
+"""read_fastq end to end on the 4 GB FASTQ-150 file of bench.py's `end_to_end` leg (page cache -> host DataChunks): COUNT(*) and the
+all-columns drain, RUNS (7) times each, every time printed (the leg's run-to-run spread is the question); knobs from the
+environment: EXG_IO_THREADS, EXG_IO_SLICE_MB, EXG_NO_RAMP, EXG_NO_RUN_AHEAD.  Run on the GPU box."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import bench  # noqa: E402
+from exon_duckdb_amd import device, load_library  # noqa: E402
+
+n = int(float(os.environ.get("GB", "4")) * 1e9) // 332 * 332
+p = os.environ.get("FQ_FILE") or "/dev/shm/fq_probe.fastq"
+if not os.path.exists(p):
+    bench.write_device_bytes(torch, device.synth_fastq(n)[:n], n, p)
+lib = load_library()
+runs = int(os.environ.get("RUNS", "7"))
+bench.reader_count(lib, p, "fastq")
+tc = [bench.reader_count(lib, p, "fastq")[1] * 1e3 for _ in range(runs)]
+ta = [bench.reader_chunks(lib, p, "fastq")[2] * 1e3 for _ in range(runs)]
+print(f"{os.environ.get('LABEL', '')} COUNT(*) " + " ".join(f"{x:.1f}" for x in tc) + " | all columns " + " ".join(f"{x:.1f}" for x in ta) +
+      f" | best {min(ta):.1f} ms = {n / min(ta) / 1e6:.1f} GB/s, median {sorted(ta)[runs // 2]:.1f}", flush=True)
+if not os.environ.get("FQ_FILE"):
+    os.unlink(p)
