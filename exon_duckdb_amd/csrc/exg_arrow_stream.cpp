@@ -214,11 +214,23 @@ struct Emit {
     const uint8_t *to_host(const void *d, size_t bytes) {
         static const uint8_t nowhere[64] = {0};
         if (!copy) return nowhere;
-        void *h = halloc(bytes);
+        // (round 6) the big buffers leave by a kernel's 16-byte stores (exg::stream_to_host), not by a copy engine: a text file's
+        // next batch is uploaded beside them in slices that each take whichever engine is free — every other batch they queued
+        // behind these copies and the upload landed 5 ms late (FASTQ at this boundary: batches of 5.4 and 11 ms in turn).
+        // EXG_ARROW_D2H_ENGINE=1: hipMemcpyAsync as before (A/B)
+        static const bool by_engine = getenv("EXG_ARROW_D2H_ENGINE") != nullptr;
+        const bool by_kernel = !by_engine && bytes >= (64u << 10);
+        void *h = halloc(by_kernel ? (bytes + 15) & ~(size_t)15 : bytes);
         if (h && bytes) {
             hipError_t e = hipEventRecord(st->copy_ev, s);
             if (e == hipSuccess) e = hipStreamWaitEvent(st->copy_stream, st->copy_ev, 0);
-            if (e == hipSuccess) e = hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, st->copy_stream);
+            if (e == hipSuccess) {
+                if (by_kernel && !(((uintptr_t)h | (uintptr_t)d) & 15)) {
+                    if (exg::stream_to_host(h, d, bytes, st->copy_stream) != EXG_OK) e = hipErrorUnknown;
+                } else {
+                    e = hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, st->copy_stream);
+                }
+            }
             if (e != hipSuccess && !rc) rc = fail(r, EXG_E_HIP, "D2H copy failed in the Arrow emitter");
         }
         return (const uint8_t *)h;

@@ -179,8 +179,9 @@ int post_to_host(void *h_dst, const void *d_src, uint64_t bytes, void *stream) {
     return EXG_OK;
 }
 // Bulk bytes to pinned host memory by a kernel's 16-byte stores (no copy engine: what a concurrent upload's slices cannot be queued
-// behind).  Both pointers 16-byte aligned; `bytes` is rounded up to 16 (the caller's blocks have the room).  blocks: PCIe is the bound,
-// a few wavefronts per CU saturate it (exon_tf_link_probe: 55 GB/s against hipMemcpyAsync's 57)
+// behind).  Both pointers 16-byte aligned; `bytes` is rounded up to 16 (the caller's blocks have the room).  64 workgroups: PCIe is the
+// bound (50-55 GB/s against hipMemcpyAsync's 57 with 32 to 2 048 of them), and kernels that run beside the copy slow down less the fewer
+// wavefronts sit on stores the link has not taken yet (the Arrow emitter's column kernels: FASTQ at that boundary 110 -> 107 ms)
 typedef uint32_t stream_v4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_stream_to_host(stream_v4 *__restrict__ h_dst, const stream_v4 *__restrict__ d_src, uint64_t n16) {
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256)
@@ -197,7 +198,7 @@ int stream_to_host(void *h_dst, const void *d_src, uint64_t bytes, void *stream)
         EXG_HIP_CHECK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
         return EXG_OK;
     }
-    static const uint32_t blocks = getenv("EXG_STREAM_TO_HOST_BLOCKS") ? (uint32_t)std::max(1, atoi(getenv("EXG_STREAM_TO_HOST_BLOCKS"))) : 512u;
+    static const uint32_t blocks = getenv("EXG_STREAM_TO_HOST_BLOCKS") ? (uint32_t)std::max(1, atoi(getenv("EXG_STREAM_TO_HOST_BLOCKS"))) : 64u;
     const uint64_t n16 = (bytes + 15) / 16;
     hipLaunchKernelGGL(k_stream_to_host, dim3((uint32_t)std::min<uint64_t>(blocks, (n16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (stream_v4 *)h_dst,
                        (const stream_v4 *)d_src, n16);

@@ -19,5 +19,21 @@ tc = [bench.reader_count(lib, p, "fastq")[1] * 1e3 for _ in range(runs)]
 ta = [bench.reader_chunks(lib, p, "fastq")[2] * 1e3 for _ in range(runs)]
 print(f"{os.environ.get('LABEL', '')} COUNT(*) " + " ".join(f"{x:.1f}" for x in tc) + " | all columns " + " ".join(f"{x:.1f}" for x in ta) +
       f" | best {min(ta):.1f} ms = {n / min(ta) / 1e6:.1f} GB/s, median {sorted(ta)[runs // 2]:.1f}", flush=True)
+if os.environ.get("ARROW"):   # the reference's own boundary: new_reader -> Arrow C stream, record batches pulled and released by a C loop
+    import ctypes as C
+    from exon_duckdb_amd import load_test_library
+    tl = load_test_library()
+    def drain():
+        import time
+        rows, batches, dg = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        err = C.create_string_buffer(512)
+        t0 = time.perf_counter()
+        rc = tl.exon_tf_drain_arrow_fastq(p.encode(), None, None, 0, C.byref(rows), C.byref(batches), C.byref(dg), err, 512)
+        dt = time.perf_counter() - t0
+        assert rc == 0 and rows.value == n // 332, err.value
+        return dt * 1e3
+    drain()
+    tr = [drain() for _ in range(runs)]
+    print(f"{os.environ.get('LABEL', '')} new_reader -> Arrow record batches " + " ".join(f"{x:.1f}" for x in tr) + f" | best {min(tr):.1f} ms = {n / min(tr) / 1e6:.1f} GB/s", flush=True)
 if not os.environ.get("FQ_FILE"):
     os.unlink(p)
