@@ -198,20 +198,20 @@ def link_rates(torch, n=1 << 30, reps=3):
 CHUNKS_HINT = 1  # exg_open_args.flags = EXG_OPEN_CHUNKS: chunks will be pulled — what the table function says at init_global
 
 
-def open_reader(lib, path, fmt, shard=(0, 1), device_index=0, columns=0, flags=0):
+def open_reader(lib, path, fmt, shard=(0, 1), device_index=0, columns=0, flags=0, filters=None):
     from exon_duckdb_amd import abi
     lib.exg_open.argtypes = [C.POINTER(abi.OpenArgs), C.POINTER(C.c_void_p)]
     lib.exg_count_only.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.exg_close.argtypes = [C.c_void_p]
-    a = abi.OpenArgs(path.encode(), fmt.encode(), None, 2048, device_index, 0, None, shard[0], shard[1], columns, flags)
+    a = abi.OpenArgs(path.encode(), fmt.encode(), None, 2048, device_index, 0, filters.encode() if filters else None, shard[0], shard[1], columns, flags)
     r = C.c_void_p()
     rc = lib.exg_open(C.byref(a), C.byref(r))
     assert rc == 0, lib.exg_last_error_message()
     return r
 
 
-def reader_count(lib, path, fmt, shard=(0, 1), device_index=0):
-    r = open_reader(lib, path, fmt, shard, device_index)
+def reader_count(lib, path, fmt, shard=(0, 1), device_index=0, filters=None):
+    r = open_reader(lib, path, fmt, shard, device_index, filters=filters)
     n = C.c_uint64(0)
     t0 = time.perf_counter()
     rc = lib.exg_count_only(r, C.byref(n))
@@ -221,12 +221,12 @@ def reader_count(lib, path, fmt, shard=(0, 1), device_index=0):
     return int(n.value), dt
 
 
-def reader_chunks(lib, path, fmt, shard=(0, 1), device_index=0, columns=0, stats=None):
+def reader_chunks(lib, path, fmt, shard=(0, 1), device_index=0, columns=0, stats=None, filters=None):
     """every DataChunk pulled and released by a C loop of the scaffolding library (no interpreter between the chunks);
     stats: a dict that receives exg_reader_stats_of at the end of the stream (nested_ns, host_vector_bytes, ...)"""
     from exon_duckdb_amd import abi, load_test_library
     tl = load_test_library()
-    r = open_reader(lib, path, fmt, shard, device_index, columns, CHUNKS_HINT)
+    r = open_reader(lib, path, fmt, shard, device_index, columns, CHUNKS_HINT, filters)
     rows, chunks = C.c_uint64(0), C.c_uint64(0)
     t0 = time.perf_counter()
     rc = tl.exon_tf_drain_chunks(r, C.byref(rows), C.byref(chunks))

@@ -19,6 +19,13 @@ tc = [bench.reader_count(lib, p, "fastq")[1] * 1e3 for _ in range(runs)]
 ta = [bench.reader_chunks(lib, p, "fastq")[2] * 1e3 for _ in range(runs)]
 print(f"{os.environ.get('LABEL', '')} COUNT(*) " + " ".join(f"{x:.1f}" for x in tc) + " | all columns " + " ".join(f"{x:.1f}" for x in ta) +
       f" | best {min(ta):.1f} ms = {n / min(ta) / 1e6:.1f} GB/s, median {sorted(ta)[runs // 2]:.1f}", flush=True)
+if os.environ.get("FILTERS"):   # the `filters` predicate evaluated on the device (exg_open_args.filters: what filter pushdown hands down)
+    f = os.environ["FILTERS"]
+    rows_c, _ = bench.reader_count(lib, p, "fastq", filters=f)
+    tfc = [bench.reader_count(lib, p, "fastq", filters=f)[1] * 1e3 for _ in range(3)]
+    out = [bench.reader_chunks(lib, p, "fastq", filters=f) for _ in range(3)]
+    print(f"filters {f!r}: {rows_c} of {n // 332} rows; COUNT(*) " + " ".join(f"{x:.1f}" for x in tfc) + " ms | chunks " +
+          " ".join(f"{x[2] * 1e3:.1f}" for x in out) + f" ms ({out[0][0]} rows in {out[0][1]} chunks)", flush=True)
 if os.environ.get("ARROW"):   # the reference's own boundary: new_reader -> Arrow C stream, record batches pulled and released by a C loop
     import ctypes as C
     from exon_duckdb_amd import load_test_library
