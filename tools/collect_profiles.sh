@@ -10,7 +10,9 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd $ROOT
 # the bench line as the driver takes it (all configs, cpu baseline)
+T0=$(date +%s)
 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+echo "bench.py (default flags): $(( $(date +%s) - T0 )) s"
 cd /tmp
 # headline kernel: per-kernel times of the same command (without the side legs), then the HBM counters in passes of their own
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt -o kt --output-format csv -- python3 $ROOT/bench.py --no-configs --no-cpu-baseline > $OUT/${TAG}_kt.log 2>&1
