@@ -214,3 +214,54 @@ def test_scan_algo_hint_from_a_host_sample():
     assert hint(abi.EXG_FMT_VCF, b"1\t1\t.\tA\tC\t.\t.\t" + b"x" * (2 << 20)) == abi.EXG_ALGO_FUSED_INDEX     # one line of megabytes
     assert hint(abi.EXG_FMT_FASTQ, b"@r\nAC\n+\nII\n") == abi.EXG_ALGO_FUSED                                   # too little to tell
     assert hint(abi.EXG_FMT_FASTA, b">a\nACGT\n" * 10000) == abi.EXG_ALGO_FUSED
+
+
+def _mix64(x):
+    m = (1 << 64) - 1
+    x = (x + 0x9E3779B97F4A7C15) & m
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & m
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & m
+    return x ^ (x >> 31)
+
+
+def _fold_bytes(h, b):
+    m = (1 << 64) - 1
+    n = len(b)
+    h ^= (n * 0x9E3779B97F4A7C15) & m
+    o = 0
+    while n - o >= 8:
+        h = ((h ^ int.from_bytes(b[o:o + 8], "little")) * 0x100000001B3) & m
+        h ^= h >> 29
+        o += 8
+    w = int.from_bytes(b[o:], "little") if n > o else 0
+    h = ((h ^ w ^ (((n - o) << 56) & m)) * 0x100000001B3) & m
+    return h ^ (h >> 32)
+
+
+def test_the_bench_legs_fasta_expectation_is_the_oracles_rows(lib, tmp_path):
+    # bench.py's end_to_end_fasta leg checks the reader's rows against exon_tf_expect_fasta_file — a split of the file of its own.
+    # Here that split is held against the oracle: the digest it gives must be the fold of the oracle's rows (id, description or
+    # NULL, the joined sequence), on the reference's fixtures and on a generated file
+    import os
+    from oracle import pyoracle
+    lib.exon_tf_expect_fasta_file.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    files = [os.path.join(g, "test.fasta"), os.path.join(g, "test.mixed-desc.fasta")]
+    p = tmp_path / "synth.fasta"
+    p.write_bytes(bytes(pyoracle.synth_fasta(300, seed=9)).replace(b"\n", b"\r\n", 40))
+    files.append(str(p))
+    for f in files:
+        with open(f, "rb") as fh:
+            data = fh.read()
+        exp = pyoracle.fasta_parse(data)
+        assert exp.error_code == 0
+        acc = 0
+        cols = [exp.columns[k].to_list() for k in ("id", "description", "sequence")]
+        for k, (i, d, s) in enumerate(zip(*cols)):
+            h = _fold_bytes(_mix64(k), i)
+            h = _fold_bytes(h, d) if d is not None else _fold_bytes(h ^ 0xDEAD, b"")
+            h = _fold_bytes(h, s)
+            acc = (acc + _mix64(h)) & ((1 << 64) - 1)
+        rows, dg = C.c_uint64(0), C.c_uint64(0)
+        assert lib.exon_tf_expect_fasta_file(f.encode(), C.byref(rows), C.byref(dg)) == 0
+        assert rows.value == exp.n_rows and dg.value == acc, f
