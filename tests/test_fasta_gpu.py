@@ -383,3 +383,29 @@ def test_reader_batches_uploaded_ahead(gpu, oracle, tmp_path, batch):
     r = ShardReader(str(p), "fasta", device_batch_bytes=batch)
     assert r.count() == 1601
     r.close()
+
+
+def test_reader_batches_uploaded_ahead_across_files_and_shards(gpu, oracle, tmp_path):
+    # the upload ahead ends with a file (nothing of the next file is asked of this one's slots) and with a shard's run of records
+    from exon_duckdb_amd.reader import ShardReader
+    parts = [bytes(oracle.synth_fasta(400 + 150 * k, seed=20 + k)) for k in range(3)]
+    d = tmp_path / "dir"
+    d.mkdir()
+    for k, p in enumerate(parts):
+        (d / f"f{k}.fasta").write_bytes(p)
+    want = []
+    for p in parts:
+        exp = oracle.fasta_parse(p)
+        want += list(zip(*(exp.columns[c].to_list() for c in ("id", "description", "sequence"))))
+    r = ShardReader(str(d) + "/", "fasta", device_batch_bytes=96 << 10)
+    got = r.rows()
+    r.close()
+    assert got == want
+    whole = tmp_path / "whole.fasta"
+    whole.write_bytes(b"".join(parts))
+    rows = []
+    for s in range(5):
+        r = ShardReader(str(whole), "fasta", shard_index=s, shard_count=5, device_batch_bytes=64 << 10)
+        rows += r.rows()
+        r.close()
+    assert rows == want
