@@ -35,7 +35,19 @@ __device__ __forceinline__ uint32_t match4(uint32_t w, uint32_t pat4) {
     return ~(y | x | 0x7F7F7F7Fu);
 }
 
-// bits 7,15,23,31 -> 4-bit nibble (multiply gathers them at 28..31, no carries collide)
+// bits 7,15,23,31 -> 4-bit nibble.  Round 6: by V_DOT4_U32_U8 — the four bytes (0x80 or 0) times the weights 1, 2, 4, 8 is 128 x the
+// nibble: one full-rate instruction and a shift where the multiply that gathered them (m * 0x00204081 >> 28) was a quarter-rate
+// V_MUL_LO_U32; a chunk's 16-bit mask is four dots (the second of a pair adds into the first) instead of four multiplies, four
+// shifts and three ORs.  The FASTA scan is VALU-issue bound (profiles/r06_c_pmc_sq_k_fa_fused.csv) and builds three such masks a row.
+// -DEXG_NO_DOT4: the multiply form (A/B).
+#ifndef EXG_NO_DOT4
+__device__ __forceinline__ uint32_t nib4(uint32_t m) { return __builtin_amdgcn_udot4(m, 0x08040201u, 0u, false) >> 7; }
+__device__ __forceinline__ uint32_t match16(uint4 v, uint32_t pat4) {
+    const uint32_t lo = __builtin_amdgcn_udot4(match4(v.y, pat4), 0x80402010u, __builtin_amdgcn_udot4(match4(v.x, pat4), 0x08040201u, 0u, false), false);
+    const uint32_t hi = __builtin_amdgcn_udot4(match4(v.w, pat4), 0x80402010u, __builtin_amdgcn_udot4(match4(v.z, pat4), 0x08040201u, 0u, false), false);
+    return ((hi << 8) + lo) >> 7;  // (lo, hi: 128 x their byte of the mask)
+}
+#else
 __device__ __forceinline__ uint32_t nib4(uint32_t m) { return (m * 0x00204081u) >> 28; }
 
 // 16-bit match mask of one 16-byte chunk
@@ -43,6 +55,7 @@ __device__ __forceinline__ uint32_t match16(uint4 v, uint32_t pat4) {
     return nib4(match4(v.x, pat4)) | (nib4(match4(v.y, pat4)) << 4) | (nib4(match4(v.z, pat4)) << 8) |
            (nib4(match4(v.w, pat4)) << 12);
 }
+#endif
 
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 
