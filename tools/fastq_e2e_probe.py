@@ -12,6 +12,13 @@ n = int(float(os.environ.get("GB", "4")) * 1e9) // 332 * 332
 p = os.environ.get("FQ_FILE") or "/dev/shm/fq_probe.fastq"
 if not os.path.exists(p):
     bench.write_device_bytes(torch, device.synth_fastq(n)[:n], n, p)
+if os.environ.get("BGZF") and not p.endswith(".gz"):   # the same file bgzip'd (x.fastq.gz)
+    from exon_duckdb_amd.testing.bgzf import bgzip
+    if not os.path.exists(p + ".gz"):
+        bgzip(p, p + ".gz")
+    if not os.environ.get("FQ_FILE"):
+        os.unlink(p)
+    p = p + ".gz"
 lib = load_library()
 runs = int(os.environ.get("RUNS", "7"))
 bench.reader_count(lib, p, "fastq")
