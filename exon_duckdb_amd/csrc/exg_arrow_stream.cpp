@@ -219,7 +219,9 @@ struct Emit {
         // behind these copies and the upload landed 5 ms late (FASTQ at this boundary: batches of 5.4 and 11 ms in turn).
         // EXG_ARROW_D2H_ENGINE=1: hipMemcpyAsync as before (A/B)
         static const bool by_engine = getenv("EXG_ARROW_D2H_ENGINE") != nullptr;
-        const bool by_kernel = !by_engine && bytes >= (64u << 10);
+        // (only beside a text file's uploads: a decoded stream sends up a fraction of the bytes, on its producer's streams, and the
+        // engine's 57 GB/s beat the kernel's 50 there — bgzip FASTQ at this boundary 144 ms by kernel, 122 by engine)
+        const bool by_kernel = !by_engine && bytes >= (64u << 10) && !r->src;
         void *h = halloc(by_kernel ? (bytes + 15) & ~(size_t)15 : bytes);
         if (h && bytes) {
             hipError_t e = hipEventRecord(st->copy_ev, s);

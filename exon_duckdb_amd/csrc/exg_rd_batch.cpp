@@ -1257,7 +1257,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
                 // by a kernel's stores, not by a copy engine: the next batch's upload (slices that each take whichever engine is free
                 // when they are enqueued) ended up behind this copy on ITS engine every other batch and landed 5 ms late
                 static const bool by_engine = getenv("EXG_FASTA_D2H_ENGINE") != nullptr;  // (A/B)
-                if (by_engine || (((uintptr_t)b->payload | (uintptr_t)r->d_payload) & 15)) {
+                if (by_engine || r->src || (((uintptr_t)b->payload | (uintptr_t)r->d_payload) & 15)) {  // (a decoded stream: no upload beside it, the engine is faster)
                     RD_HIP(r, hipMemcpyAsync(b->payload, r->d_payload, res.payload_bytes, hipMemcpyDeviceToHost, cs));
                 } else if (int prc = exg::stream_to_host(b->payload, r->d_payload, res.payload_bytes, cs)) {
                     return fail(r, prc, exg_last_error_message());
