@@ -30,6 +30,22 @@ def main():
         print(f"{label}: {n / 1e9:.2f} GB of VCF-8" + (f" in {nz / 1e9:.2f} GB" if p == gz else "") +
               f": COUNT(*) {dt_c * 1e3:.1f} ms = {n / dt_c / 1e9:.1f} GB/s; all columns {dt_a * 1e3:.1f} ms = {n / dt_a / 1e9:.2f} GB/s; "
               f"chrom,pos,ref {dt_p * 1e3:.1f} ms = {n / dt_p / 1e9:.1f} GB/s", flush=True)
+    if os.environ.get("ARROW"):   # the reference's own boundary on both files: new_reader -> Arrow C stream (nested arrays), drained by a C loop
+        import ctypes as C
+        import time
+        from exon_duckdb_amd import load_test_library
+        tl = load_test_library()
+        for label, p in (("plain text", plain), ("bgzip", gz)):
+            best = None
+            for _ in range(4):
+                rows_a, nb, dg, el = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+                err = C.create_string_buffer(512)
+                t0 = time.perf_counter()
+                rc = tl.exon_tf_drain_arrow_vcf(p.encode(), None, None, 0, C.byref(rows_a), C.byref(nb), C.byref(dg), C.byref(el), err, 512)
+                dt = time.perf_counter() - t0
+                assert rc == 0 and rows_a.value == n_lines, err.value
+                best = dt if best is None or dt < best else best
+            print(f"{label}: new_reader -> Arrow record batches {best * 1e3:.1f} ms = {n / best / 1e9:.2f} GB/s", flush=True)
     os.unlink(plain)
     os.unlink(gz)
 
