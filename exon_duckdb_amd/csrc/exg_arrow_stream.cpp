@@ -82,6 +82,13 @@ struct DevArena {  // bump allocator, reset per batch; what does not fit comes f
         extra_bytes += sz;
         return p;
     }
+    bool owns(const void *p) const {  // (a block of this arena: what stays put until its reset)
+        const char *q = (const char *)p;
+        if (base && q >= base && q < base + cap) return true;
+        for (const auto &e : extra)
+            if (q >= (const char *)e.first && q < (const char *)e.first + e.second) return true;
+        return false;
+    }
     void reset() {
         need = used + extra_bytes;
         for (auto &e : extra) dev_pool()->give(dev, e.first, e.second);
@@ -124,6 +131,16 @@ struct ABatch {
     HostArena host;
     std::vector<AColumn> cols;
     uint64_t n_rows = 0;
+    // round 6: the batch is handed on while its buffers still travel (an event behind the last copy): whoever hands out its first
+    // record batch waits for it — after the batch BEHIND it has begun to be made, whose kernels then run beside these copies
+    hipEvent_t landed = nullptr;
+    void wait_landed() {
+        if (!landed) return;
+        (void)hipEventSynchronize(landed);
+        (void)hipEventDestroy(landed);
+        landed = nullptr;
+    }
+    ~ABatch() { wait_landed(); }  // (before `host` gives its pinned blocks back)
 };
 
 struct StreamState {
@@ -146,6 +163,8 @@ struct StreamState {
     DevArena arena_a, arena_b;
     DevArena *arena_p = &arena_a;
     DevArena &arena() { return *arena_p; }
+    hipEvent_t arena_done[2] = {nullptr, nullptr};  // (Arrow mode) behind the last copy out of arena_a / arena_b; arena_busy: recorded, not yet waited for
+    bool arena_busy[2] = {false, false};
     std::shared_ptr<ABatch> batch;
     uint64_t batch_row = 0;
     // the device batch AFTER the one being handed out is produced on a thread of its own (scan, Arrow buffers, their way
@@ -166,7 +185,9 @@ struct StreamState {
     ~StreamState() {
         fan.reset();  // (the workers' streams end first)
         if (copy_ev) (void)hipEventDestroy(copy_ev);
-        if (copy_stream) stream_pool()->give(copy_dev, copy_stream);
+        if (copy_stream) stream_pool()->give(copy_dev, copy_stream);  // (synchronises it: nothing reads the arenas any more)
+        for (hipEvent_t e : arena_done)
+            if (e) (void)hipEventDestroy(e);
         for (void *p : {d_consts, d_prog, nk_info.d_keys, nk_info.d_slots, nk_info.d_names, nk_format.d_keys, nk_format.d_slots, nk_format.d_names})
             if (p) (void)hipFree(p);
         arena_a.reset();
@@ -191,6 +212,7 @@ struct Emit {
     int rc = 0;
     bool copy = true;  // false: the column being built is not in the projection — built and validated on the device, not copied back
     hipStream_t d2h = nullptr;  // the stream build_nested's mirrors travel on (NULL: st->copy_stream)
+    bool lazy = false;  // arrow_emit: the copies are not waited for here (ABatch::landed) — a source outside the arena is staged in it first
 
     void *dalloc(size_t bytes) {
         void *p = st->arena().alloc(bytes);
@@ -223,6 +245,13 @@ struct Emit {
         // engine's 57 GB/s beat the kernel's 50 there — bgzip FASTQ at this boundary 144 ms by kernel, 122 by engine)
         const bool by_kernel = !by_engine && bytes >= (64u << 10) && !r->src;
         void *h = halloc(by_kernel ? (bytes + 15) & ~(size_t)15 : bytes);
+        if (h && bytes && lazy && !st->arena().owns(d)) {
+            // (the scan's own vectors — POS, QUAL, validity words —: the next batch's scan writes them while this copy may still read)
+            void *g = dalloc(bytes + 16);
+            if (!g) return (const uint8_t *)h;
+            if (hipMemcpyAsync(g, d, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess && !rc) rc = fail(r, EXG_E_HIP, "device copy failed in the Arrow emitter");
+            d = g;
+        }
         if (h && bytes) {
             hipError_t e = hipEventRecord(st->copy_ev, s);
             if (e == hipSuccess) e = hipStreamWaitEvent(st->copy_stream, st->copy_ev, 0);
@@ -679,6 +708,22 @@ static double em_now() {
 int arrow_emit(exg_reader *r, const ScanCtx &ctx) {
     StreamState *st = (StreamState *)r->arrow_state.get();
     double em_t0 = em_now();
+    // Round 6: the batch leaves this function while its buffers still cross PCIe (ABatch::landed), the batch behind it is scanned and
+    // emitted beside them out of the OTHER arena — an arena is reset only when the last copy out of it has landed (arena_done).  A
+    // text file: FASTQ at this boundary 111 -> 101 ms (A/B in one box).  NOT a decoded stream: its decoder's kernels run ahead on the
+    // producer's streams all the time, and the emitter's kernels beside the copies AND the decoder measured slower (bgzip VCF 72 -> 86 ms,
+    // bgzip FASTQ 118 -> 127).  Not under a memory cap (one arena).  EXG_ARROW_EAGER_LANDING=1: as before (A/B)
+    static const bool eager_landing = getenv("EXG_ARROW_EAGER_LANDING") != nullptr;
+    const bool lazy = !eager_landing && !r->mem_cap && !r->src;
+    int arena_idx = 0;
+    if (lazy) {
+        st->arena_p = st->arena_p == &st->arena_a ? &st->arena_b : &st->arena_a;
+        arena_idx = st->arena_p == &st->arena_a ? 0 : 1;
+        if (st->arena_busy[arena_idx]) {
+            EM_HIP(hipEventSynchronize(st->arena_done[arena_idx]));
+            st->arena_busy[arena_idx] = false;
+        }
+    }
     st->arena().reset();
     // sized for the typical batch: offsets + values + views of every column; what a batch needs beyond that comes from the
     // pool and enlarges the arena of the next one
@@ -693,10 +738,13 @@ int arrow_emit(exg_reader *r, const ScanCtx &ctx) {
     auto batch = std::make_shared<ABatch>();
     struct CopyDrain {  // whatever way this function is left, no copy may still be writing into the batch's blocks
         hipStream_t cs;
-        ~CopyDrain() { (void)hipStreamSynchronize(cs); }
+        ~CopyDrain() {
+            if (cs) (void)hipStreamSynchronize(cs);
+        }
     } drain{st->copy_stream};
     batch->host.reserve(st->host_hint);
     Emit em;
+    em.lazy = lazy;
     em.r = r;
     em.st = st;
     em.host = &batch->host;
@@ -890,7 +938,15 @@ int arrow_emit(exg_reader *r, const ScanCtx &ctx) {
     if (em.rc) return em.rc;
     EM_TRACE("formats / columns");
     EM_HIP(hipStreamSynchronize(r->stream));
-    EM_HIP(hipStreamSynchronize(st->copy_stream));  // every buffer has landed
+    if (lazy) {
+        if (!st->arena_done[arena_idx]) EM_HIP(hipEventCreateWithFlags(&st->arena_done[arena_idx], hipEventDisableTiming));
+        EM_HIP(hipEventCreateWithFlags(&batch->landed, hipEventDisableTiming));
+        EM_HIP(hipEventRecord(batch->landed, st->copy_stream));
+        EM_HIP(hipEventRecord(st->arena_done[arena_idx], st->copy_stream));
+        st->arena_busy[arena_idx] = true;
+    } else {
+        EM_HIP(hipStreamSynchronize(st->copy_stream));  // every buffer has landed
+    }
     uint64_t n_rows = n;
     if (err != ~0ull) {
         // a typed value did not parse: rows before it are delivered, then the error (like the scan's own errors)
@@ -916,6 +972,7 @@ int arrow_emit(exg_reader *r, const ScanCtx &ctx) {
     batch->n_rows = n_rows;
     st->produced = n_rows ? batch : nullptr;
     EM_TRACE("swap batch");
+    if (lazy) drain.cs = nullptr;  // (the batch carries its landing event; a batch that is dropped waits for it itself: ~ABatch)
     return EXG_OK;
 }
 
@@ -1079,6 +1136,7 @@ int stream_get_next(ArrowArrayStream *s, ArrowArray *out) {
         if (st->batch && st->batch_row < st->batch->n_rows) {
             // the first record batch of a device batch: the next device batch starts being made
             if (st->batch_row == 0 && !st->fan && !st->producer.joinable() && st->produced_state == 0) st->producer = std::thread(produce, st);
+            if (st->batch_row == 0) st->batch->wait_landed();  // (behind the start of the next batch: its kernels run beside these copies)
             const uint64_t row0 = st->batch_row, B = r->batch_rows;
             const uint64_t len = std::min<uint64_t>(B, st->batch->n_rows - row0);
             auto *p = new ArrayPriv();
