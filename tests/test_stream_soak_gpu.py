@@ -158,3 +158,30 @@ def test_random_vcf_streams(gpu, tmp_path, monkeypatch, seed0):
         os.unlink(p)
         if plain.exists():
             os.unlink(plain)
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("seed0", range(0, N_SEEDS, 8))
+def test_random_streams_at_the_arrow_boundary(gpu, oracle, tmp_path, monkeypatch, seed0):
+    # the reference's own boundary (new_reader -> Arrow C stream): a text file's batch is handed on while its buffers still travel
+    # (round 6: ABatch::landed, two arenas in turn) — small device batches, so that a file is dozens of them, in every wrapping,
+    # a slow consumer every now and then (the producer thread then runs a whole batch ahead); every value must be the oracle's
+    import time
+    from exon_duckdb_amd.arrow import new_reader
+    from test_arrow_stream_gpu import fasta_rows, fastq_rows
+    for seed in range(seed0, min(seed0 + 8, N_SEEDS)):
+        r = random.Random(9000 + seed)
+        fasta = r.random() < 0.4
+        data = fasta_text(r) if fasta else fastq_text(r)
+        want = fasta_rows(oracle, data) if fasta else fastq_rows(oracle, data)
+        kind, p = wrap(r, data, tmp_path, seed, ext="fasta" if fasta else "fastq")
+        monkeypatch.delenv("EXG_DEVICE_MEM_CAP_MB", raising=False)
+        monkeypatch.setenv("EXG_DEVICE_BATCH_BYTES", str(r.choice([64 << 10, 128 << 10, 300_000, 1 << 20, 0])))
+        slow = r.random() < 0.3
+        rows = []
+        for b in new_reader(str(p), "fasta" if fasta else "fastq", batch_size=r.choice([2048, 128, 64])):
+            rows.extend(b.to_pylist())
+            if slow and r.random() < 0.02:
+                time.sleep(0.002)
+        assert rows == want, (seed, kind, fasta, len(data), os.environ.get("EXG_DEVICE_BATCH_BYTES"))
+        os.unlink(p)
