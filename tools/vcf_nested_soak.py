@@ -2,7 +2,8 @@
 ##INFO keys — both sides of k_rows' 32-key limit —, 0 to 90 ##FORMAT keys), random lines from the generators of
 tests/test_vcf_nested_wide_gpu.py, then structural mutations INSIDE the INFO / FORMAT / sample fields (separators doubled, dropped,
 swapped, '.', '%41', empty values, digits turned into letters), random DataChunk sizes and device batch sizes.  Everything must agree:
-the rows in front of the first value error, and whether there is one.    SOAK_SEEDS=200 SOAK_FIRST=0 python tools/vcf_nested_soak.py"""
+the rows in front of the first value error, and whether there is one.    SOAK_SEEDS=200 SOAK_FIRST=0 python tools/vcf_nested_soak.py
+SOAK_ARROW=1: through new_reader's Arrow stream (the nested columns converted to Arrow's layouts on the device) instead of the chunk boundary."""
 import ctypes as C
 import os
 import random
@@ -72,6 +73,24 @@ def read_rows(path, **kw):
     return out, failed
 
 
+def read_rows_arrow(path, batch_rows=2048, device_batch_bytes=0):
+    """the same through the reference's own boundary (new_reader -> Arrow C stream, pyarrow) -> (rows as dicts, failed?)"""
+    from exon_duckdb_amd.arrow import new_reader
+    if device_batch_bytes:
+        os.environ["EXG_DEVICE_BATCH_BYTES"] = str(device_batch_bytes)
+    else:
+        os.environ.pop("EXG_DEVICE_BATCH_BYTES", None)
+    out, failed = [], False
+    try:
+        for b in new_reader(path, "vcf", batch_size=batch_rows):
+            out.extend(b.to_pylist())
+    except Exception:  # noqa: BLE001  (pyarrow raises what get_next returned)
+        failed = True
+    finally:
+        os.environ.pop("EXG_DEVICE_BATCH_BYTES", None)
+    return out, failed
+
+
 def make_input(seed):
     """-> (file bytes, reader keywords, header shape) of a seed"""
     rng = random.Random(seed)
@@ -99,7 +118,7 @@ def run_seed(seed, path, dry=False):
         f.write(data)
     if dry:   # the generator and the oracle alone (no GPU)
         return None
-    got, failed = read_rows(path, **kw)
+    got, failed = read_rows_arrow(path, **kw) if os.environ.get("SOAK_ARROW") else read_rows(path, **kw)
     if len(got) == len(want) and all(same(g, e) for g, e in zip(got, want)) and failed == (err_row is not None or bool(tok.error_code)):
         return None
     bad = next((i for i, (g, e) in enumerate(zip(got, want)) if not same(g, e)), None)
