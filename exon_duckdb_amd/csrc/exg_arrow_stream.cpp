@@ -185,7 +185,7 @@ struct StreamState {
     ~StreamState() {
         fan.reset();  // (the workers' streams end first)
         if (copy_ev) (void)hipEventDestroy(copy_ev);
-        if (copy_stream) stream_pool()->give(copy_dev, copy_stream);  // (synchronises it: nothing reads the arenas any more)
+        if (copy_stream) stream_pool()->give_d2h(copy_dev, copy_stream);  // (synchronises it: nothing reads the arenas any more)
         for (hipEvent_t e : arena_done)
             if (e) (void)hipEventDestroy(e);
         for (void *p : {d_consts, d_prog, nk_info.d_keys, nk_info.d_slots, nk_info.d_names, nk_format.d_keys, nk_format.d_slots, nk_format.d_names})
@@ -731,7 +731,7 @@ int arrow_emit(exg_reader *r, const ScanCtx &ctx) {
     st->arena().prepare(r->device, (size_t)std::min<uint64_t>(r->mem_cap ? r->d_in_cap * 6 + (1u << 20) : r->d_in_cap * 3 + (64u << 20), 6ull << 30));
     EM_TRACE("arena");
     if (!st->copy_stream) {
-        EM_HIP(stream_pool()->take(r->device, &st->copy_stream));
+        EM_HIP(stream_pool()->take_d2h(r->device, &st->copy_stream, /*calibrate=*/r->file && r->file->n >= (512ull << 20) && !r->mem_cap));
         st->copy_dev = r->device;
         EM_HIP(hipEventCreateWithFlags(&st->copy_ev, hipEventDisableTiming));
     }
@@ -1304,7 +1304,7 @@ int nested_emit(exg_reader *r, const ScanCtx &ctx, Batch *b, const uint32_t *d_r
     st->arena().min_extra = r->mem_cap ? (64u << 10) : (1u << 20);
     st->arena().prepare(r->device, (size_t)std::min<uint64_t>(r->mem_cap ? r->d_in_cap * 6 + (1u << 20) : r->d_in_cap * 3 + (64u << 20), 6ull << 30));
     if (!st->copy_stream) {
-        EM_HIP(stream_pool()->take(r->device, &st->copy_stream));
+        EM_HIP(stream_pool()->take_d2h(r->device, &st->copy_stream, /*calibrate=*/r->file && r->file->n >= (512ull << 20) && !r->mem_cap));
         st->copy_dev = r->device;
         EM_HIP(hipEventCreateWithFlags(&st->copy_ev, hipEventDisableTiming));
     }

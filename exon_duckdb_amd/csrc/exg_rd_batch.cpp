@@ -1171,7 +1171,7 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             // should overlap)
             if ((r->format == EXG_FMT_VCF || r->format == EXG_FMT_FASTA) && !compact && !getenv("EXG_VCF_ONE_STREAM")) {
                 if (!r->col_stream) {
-                    RD_HIP(r, stream_pool()->take(r->device, &r->col_stream));
+                    RD_HIP(r, stream_pool()->take_d2h(r->device, &r->col_stream, /*calibrate=*/r->file && r->file->n >= (512ull << 20) && !r->mem_cap));
                     RD_HIP(r, hipEventCreateWithFlags(&r->col_ev, hipEventDisableTiming));
                     RD_HIP(r, hipEventCreateWithFlags(&r->flat_ev, hipEventDisableTiming));
                 }

@@ -25,9 +25,10 @@ void SegmentSink::set_mark(int id, uint64_t pos) {
 }
 // the segment's own bytes [start, hi) begin to travel to the host (best effort: without pinned memory, a stream or an event the
 // consumer copies them itself, as it does for every segment that has no mirror)
-static void start_mirror(DecodedSource *src, int device, hipStream_t *d2h, Segment &s, uint64_t piece_bytes = 0) {
+static void start_mirror(DecodedSource *src, int device, hipStream_t *d2h, Segment &s, bool capped, uint64_t piece_bytes = 0) {
     if (s.hi <= s.start || s.mirror) return;
-    if (!*d2h && stream_pool()->take(device, d2h) != hipSuccess) {
+    // (calibrated for big inputs only — the first segments of one are >= 64 MiB — and not under a memory cap: the try-out holds 64 MiB)
+    if (!*d2h && stream_pool()->take_d2h(device, d2h, /*calibrate=*/s.hi - s.start >= (64ull << 20) && !capped) != hipSuccess) {
         (void)hipGetLastError();
         *d2h = nullptr;
         return;
@@ -73,14 +74,14 @@ bool SegmentSink::mirror_wanted() const { return src->mirror_wanted_.load(std::m
 bool SegmentSink::mirror_now(Segment &s, uint64_t piece_bytes) {
     if (!mirror_wanted()) return false;
     std::lock_guard<std::mutex> g(src->mirror_mu_);  // (the d2h stream is made by whoever comes first: the producer's thread or a stage behind it)
-    start_mirror(src, src->device_, &src->d2h_stream_, s, piece_bytes);
+    start_mirror(src, src->device_, &src->d2h_stream_, s, src->meter_ && src->meter_->cap, piece_bytes);
     return s.mirror != nullptr;
 }
 
 bool SegmentSink::push(Segment &&s) {
     if (src->mirror_wanted_.load(std::memory_order_acquire)) {
         std::lock_guard<std::mutex> g(src->mirror_mu_);
-        start_mirror(src, src->device_, &src->d2h_stream_, s);
+        start_mirror(src, src->device_, &src->d2h_stream_, s, src->meter_ && src->meter_->cap);
     }
     std::unique_lock<std::mutex> lk(src->mu_);
     src->cv_.wait(lk, [&] { return src->queue_.size() < src->max_queued_ || src->closed_; });
@@ -138,7 +139,7 @@ DecodedSource::~DecodedSource() {
     if (have_cur_) free_segment(cur_);
     for (Segment &s : queue_) free_segment(s);
     queue_.clear();
-    if (d2h_stream_) stream_pool()->give(device_, d2h_stream_);
+    if (d2h_stream_) stream_pool()->give_d2h(device_, d2h_stream_);
 }
 
 bool DecodedSource::host_view(const uint8_t *d_at, const uint8_t **h_at, uint64_t *valid_from, std::shared_ptr<HostMirror> *keep) const {

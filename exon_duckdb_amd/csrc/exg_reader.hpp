@@ -134,6 +134,24 @@ struct StreamPool {
         for (auto &e : free_streams) (void)hipStreamDestroy(e.second);
         free_streams.clear();
     }
+    // A stream for BIG device-to-host copies that run beside uploads (round 6: the columns' stream, the Arrow emitter's, a decoded
+    // stream's mirrors).  Which copy engine a stream's D2H copies run on is a property of the stream (tools/sdma_pairs_probe.py: with
+    // some streams as the D2H side ANY upload beside them queues on the same engine — 55 GB/s in sum instead of 96 — and it stays so
+    // for the life of the process: the run-to-run halves of the D2H-bound legs, 0.91 or 0.78 of the link).  `calibrate`: a new
+    // stream is tried out against an upload (32 MiB each way, ~3 ms) and a stream that shares the uploads' engine is set aside for
+    // other work; streams that passed are kept apart and reused (exg_rd_io.cpp).  EXG_NO_D2H_CALIBRATION: any stream (A/B).
+    static constexpr int kD2H = 1 << 17;
+    hipError_t take_d2h(int dev, hipStream_t *out, bool calibrate);
+    void give_d2h(int dev, hipStream_t s) {
+        if (!s) return;
+        (void)hipStreamSynchronize(s);
+        std::lock_guard<std::mutex> g(mu);
+        if (free_streams.size() < 32) {
+            free_streams.emplace_back(kD2H + dev, s);
+            return;
+        }
+        (void)hipStreamDestroy(s);
+    }
 };
 inline StreamPool *stream_pool() {
     static StreamPool *pool = new StreamPool();  // never destroyed, like the other pools
