@@ -1169,7 +1169,8 @@ int next_batch(exg_reader *r, bool count_only, uint64_t *n_records_out) {
             // (FASTA, round 6: its joined sequences are as many bytes as the batch itself — on the scan's stream they shared a copy
             // engine with the next batch's upload, which landed 5 ms behind them: 9.7 ms per 256 MiB batch where the two directions
             // should overlap)
-            if ((r->format == EXG_FMT_VCF || r->format == EXG_FMT_FASTA) && !compact && !getenv("EXG_VCF_ONE_STREAM")) {
+            static const bool fastq_cols_on_scan_stream = getenv("EXG_FASTQ_ONE_STREAM") != nullptr;  // (A/B)
+            if ((r->format == EXG_FMT_VCF || r->format == EXG_FMT_FASTA || (!r->src && !fastq_cols_on_scan_stream)) && !compact && !getenv("EXG_VCF_ONE_STREAM")) {
                 if (!r->col_stream) {
                     RD_HIP(r, stream_pool()->take_d2h(r->device, &r->col_stream, /*calibrate=*/r->file && r->file->n >= (512ull << 20) && !r->mem_cap));
                     RD_HIP(r, hipEventCreateWithFlags(&r->col_ev, hipEventDisableTiming));

@@ -105,35 +105,34 @@ int numa_node_of_device(int device) {
     return nodes[device];
 }
 
-// do a D2H copy on `c` and an upload (8 MiB slices on another stream) overlap?  32 MiB each way: ~0.7 ms when they do, ~1.2 ms when they
-// queue on one engine; the best of two timed rounds behind a warm-up (a stream's first copy sets its queue up)
+// do a D2H copy on `c` and an upload (4 MiB slices on another stream) overlap?  16 MiB each way out of ONE pinned and ONE device block:
+// ~0.35 ms when they do, ~0.6 ms when they queue on one engine; the best of three timed rounds behind a warm-up (a stream's first copy
+// sets its queue up).  With the blocks and the streams it makes, a try-out costs the process ~20 ms, once.
 static bool d2h_overlaps_uploads(int dev, hipStream_t c) {
-    constexpr size_t kBytes = 32u << 20, kSlice = 8u << 20;
+    constexpr size_t kHalf = 16u << 20, kSlice = 4u << 20;
     hipStream_t up = nullptr;
     if (stream_pool()->take(dev, &up) != hipSuccess) return true;
-    size_t ca = kBytes, cb = kBytes;
-    char *ha = global_pool()->take(&ca), *hb = global_pool()->take(&cb);
-    void *da = dev_pool()->take(dev, kBytes), *db = dev_pool()->take(dev, kBytes);
+    size_t cap = 2 * kHalf;
+    char *h = global_pool()->take(&cap);
+    char *d = (char *)dev_pool()->take(dev, 2 * kHalf);
     bool ok = true;
-    if (ha && hb && da && db) {
+    if (h && d) {
         double best = 1e9;
-        for (int round = 0; round < 3 && ok; round++) {
+        for (int round = 0; round < 4 && ok; round++) {
             (void)hipStreamSynchronize(up);
             (void)hipStreamSynchronize(c);
             const double t0 = now_s();
-            ok = hipMemcpyAsync(hb, db, kBytes, hipMemcpyDeviceToHost, c) == hipSuccess;
-            for (size_t o = 0; ok && o < kBytes; o += kSlice) ok = hipMemcpyAsync((char *)da + o, ha + o, kSlice, hipMemcpyHostToDevice, up) == hipSuccess;
+            ok = hipMemcpyAsync(h + kHalf, d + kHalf, kHalf, hipMemcpyDeviceToHost, c) == hipSuccess;
+            for (size_t o = 0; ok && o < kHalf; o += kSlice) ok = hipMemcpyAsync(d + o, h + o, kSlice, hipMemcpyHostToDevice, up) == hipSuccess;
             ok = ok && hipStreamSynchronize(up) == hipSuccess && hipStreamSynchronize(c) == hipSuccess;
             if (round) best = std::min(best, now_s() - t0);
         }
         if (!ok) (void)hipGetLastError();
-        if (getenv("EXG_TRACE")) fprintf(stderr, "[exg] D2H stream %p beside an upload: 2 x 32 MiB in %.2f ms (%s)\n", (void *)c, best * 1e3, best < 0.95e-3 ? "they overlap" : "one engine");
-        ok = !ok || best < 0.95e-3;  // (a failed probe decides nothing)
+        if (getenv("EXG_TRACE")) fprintf(stderr, "[exg] D2H stream %p beside an upload: 2 x 16 MiB in %.2f ms (%s)\n", (void *)c, best * 1e3, best < 0.47e-3 ? "they overlap" : "one engine");
+        ok = !ok || best < 0.47e-3;  // (a failed probe decides nothing)
     }
-    if (ha) global_pool()->give(ha, ca);
-    if (hb) global_pool()->give(hb, cb);
-    if (da) dev_pool()->give(dev, da, kBytes);
-    if (db) dev_pool()->give(dev, db, kBytes);
+    if (h) global_pool()->give(h, cap);
+    if (d) dev_pool()->give(dev, d, 2 * kHalf);
     stream_pool()->give(dev, up);
     return ok;
 }
@@ -152,6 +151,13 @@ hipError_t StreamPool::take_d2h(int dev, hipStream_t *out, bool calibrate) {
     }
     if (!calibrate) return take(dev, out);
     DeviceGuard g(dev);
+    const double t_cal = now_s();
+    struct CalTrace {
+        double t0;
+        ~CalTrace() {
+            if (getenv("EXG_TRACE")) fprintf(stderr, "[exg] D2H stream try-out: %.1f ms in all\n", (now_s() - t0) * 1e3);
+        }
+    } cal_trace{t_cal};
     hipStream_t cand = nullptr;
     for (int k = 0; k < 4; k++) {
         const hipError_t e = hipStreamCreateWithFlags(&cand, hipStreamNonBlocking);
