@@ -140,17 +140,43 @@ static bool d2h_overlaps_uploads(int dev, hipStream_t c) {
 hipError_t StreamPool::take_d2h(int dev, hipStream_t *out, bool calibrate) {
     static const bool no_calibration = getenv("EXG_NO_D2H_CALIBRATION") != nullptr;
     if (no_calibration) return take(dev, out);
-    {
-        std::lock_guard<std::mutex> g(mu);
-        for (size_t i = 0; i < free_streams.size(); i++)
-            if (free_streams[i].first == kD2H + dev) {  // (one that passed before)
-                *out = free_streams[i].second;
-                free_streams.erase(free_streams.begin() + (long)i);
-                return hipSuccess;
+    DeviceGuard g(dev);
+    auto passed_at = [&](hipStream_t st, double t) {  // (mu held)
+        for (auto &e : d2h_tried)
+            if (e.first == st) {
+                e.second = t;
+                return;
             }
+        d2h_tried.emplace_back(st, t);
+    };
+    for (;;) {
+        hipStream_t kept = nullptr;
+        double tried = 0;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t i = 0; i < free_streams.size(); i++)
+                if (free_streams[i].first == kD2H + dev) {  // (one that passed before)
+                    kept = free_streams[i].second;
+                    free_streams.erase(free_streams.begin() + (long)i);
+                    break;
+                }
+            for (const auto &e : d2h_tried)
+                if (e.first == kept) tried = e.second;
+        }
+        if (!kept) break;
+        // (which engine a stream's copies take is not promised to stay: in a long-lived process a kept stream is tried again — ~2 ms
+        // with warm pools — when a big input asks for it more than a second after it last passed)
+        if (!calibrate || now_s() - tried < 1.0 || d2h_overlaps_uploads(dev, kept)) {
+            if (calibrate && now_s() - tried >= 1.0) {
+                std::lock_guard<std::mutex> lk(mu);
+                passed_at(kept, now_s());
+            }
+            *out = kept;
+            return hipSuccess;
+        }
+        give(dev, kept);  // (no longer apart: fine for kernels and uploads)
     }
     if (!calibrate) return take(dev, out);
-    DeviceGuard g(dev);
     const double t_cal = now_s();
     struct CalTrace {
         double t0;
@@ -165,6 +191,10 @@ hipError_t StreamPool::take_d2h(int dev, hipStream_t *out, bool calibrate) {
         if (k == 3 || d2h_overlaps_uploads(dev, cand)) break;
         give(dev, cand);  // (fine for kernels and uploads)
         cand = nullptr;
+    }
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        passed_at(cand, now_s());
     }
     *out = cand;
     return hipSuccess;

@@ -141,6 +141,7 @@ struct StreamPool {
     // stream is tried out against an upload (32 MiB each way, ~3 ms) and a stream that shares the uploads' engine is set aside for
     // other work; streams that passed are kept apart and reused (exg_rd_io.cpp).  EXG_NO_D2H_CALIBRATION: any stream (A/B).
     static constexpr int kD2H = 1 << 17;
+    std::vector<std::pair<hipStream_t, double>> d2h_tried;  // when a kept stream last passed its try-out (a long-lived process: tried again when a second has passed)
     hipError_t take_d2h(int dev, hipStream_t *out, bool calibrate);
     void give_d2h(int dev, hipStream_t s) {
         if (!s) return;
