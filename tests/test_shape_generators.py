@@ -30,3 +30,27 @@ def test_vcf_blocks_say_what_the_oracle_parses(oracle):
         assert np.array_equal(t.columns["formats"].lengths(), e["formats"][1])
         assert np.array_equal(t.columns["chrom"].src_off, e["start"] + len(hdr))
         assert [int(x) for x in t.columns["chrom"].to_list()] == list(e["chrom"])
+
+
+def test_bgzf_writer_of_the_bench_legs(tmp_path):
+    # exon_duckdb_amd/testing/bgzf.py (bench.py's bgzip sub-legs, the probes): what it writes is what `bgzip` writes — gzip members of at
+    # most 65 280 bytes of content, each with the BC extra field that holds its own size, the empty EOF member last — and gzip reads it back
+    import gzip
+    import random
+    import struct
+    from exon_duckdb_amd.testing.bgzf import bgzip
+    rng = random.Random(4)
+    data = bytes(rng.choice(b"ACGT\n") for _ in range(65280 * 3 + 1234))
+    p = tmp_path / "x.txt"
+    p.write_bytes(data)
+    n = bgzip(str(p), str(p) + ".gz")
+    raw = (tmp_path / "x.txt.gz").read_bytes()
+    assert n == len(raw) and gzip.decompress(raw) == data
+    off, members = 0, []
+    while off < len(raw):
+        assert raw[off:off + 4] == b"\x1f\x8b\x08\x04" and raw[off + 12:off + 16] == b"BC\x02\x00"
+        bsize = struct.unpack_from("<H", raw, off + 16)[0] + 1
+        isize = struct.unpack_from("<I", raw, off + bsize - 4)[0]
+        members.append(isize)
+        off += bsize
+    assert off == len(raw) and members[-1] == 0 and members[:-1] == [65280, 65280, 65280, 1234]
